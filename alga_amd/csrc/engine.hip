@@ -1,0 +1,484 @@
+// alga_amd/csrc/engine.hip -- host side of the C ABI declared in include/alga_amd.h.
+//
+// Orchestrates the kernels of prefsuf_kernels.hip on one HIP stream.  Phases of a build:
+//   seed   : memset + k_seed_build
+//   probe  : k_probe_sources                      (dominant kernel; retried with a larger record
+//                                                  buffer if the first capacity guess overflows)
+//   group  : scan(in-degree) + k_scatter_by_target
+//   reduce : k_reduce_targets
+//   emit   : scan(out-degree) + k_scatter_by_source + k_sort_rows
+// There is no CPU fallback anywhere in this file: every failure is reported to the caller.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#include "../../include/alga_amd.h"
+#include "prefsuf_common.h"
+#include "prefsuf_kernels.h"
+
+using namespace alga;
+
+namespace {
+
+struct DevBuf {
+    void  *p = nullptr;
+    size_t cap = 0;
+};
+
+enum { EV_START = 0, EV_SEED, EV_PROBE, EV_GROUP, EV_REDUCE, EV_EMIT, EV_COUNT };
+
+} // namespace
+
+struct alga_engine {
+    int         device = -1;
+    hipStream_t own_stream = nullptr;
+    std::string err;
+    char        dev_name[256] = {0};
+    hipEvent_t  ev[EV_COUNT] = {};
+    // device buffers, grown on demand and kept between calls
+    DevBuf table, counters, indeg, rowptr, rec_dst, rec_src, rec_ol, seg_src, seg_ol, out_cnt, outdeg, out_rowptr, edges, scan_scratch;
+    DevBuf up_words, up_len, up_from, up_to;   // uploads of the host-buffer entry point
+    unsigned long long *h_counters = nullptr;  // pinned, CNT_TOTAL + 2 entries
+    uint64_t    rec_cap_hint = 0;
+    uint64_t    last_records = 0;
+    alga_prefsuf_stats stats;
+};
+
+namespace {
+
+int fail(alga_engine *e, int code, const char *what, hipError_t herr = hipSuccess) {
+    char buf[512];
+    if (herr != hipSuccess) snprintf(buf, sizeof(buf), "%s: %s", what, hipGetErrorString(herr));
+    else snprintf(buf, sizeof(buf), "%s", what);
+    e->err = buf;
+    return code;
+}
+
+#define HIP_TRY(e, call)                                                                     \
+    do {                                                                                     \
+        hipError_t _err = (call);                                                            \
+        if (_err != hipSuccess) return fail((e), _err == hipErrorOutOfMemory ? ALGA_ERR_OUT_OF_MEMORY : ALGA_ERR_HIP, #call, _err); \
+    } while (0)
+
+int ensure(alga_engine *e, DevBuf &b, size_t bytes) {
+    if (bytes == 0) bytes = 16;
+    if (b.cap >= bytes) return ALGA_OK;
+    if (b.p) { HIP_TRY(e, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
+    HIP_TRY(e, hipMalloc(&b.p, bytes));
+    b.cap = bytes;
+    return ALGA_OK;
+}
+
+void release(DevBuf &b) {
+    if (b.p) (void) hipFree(b.p);
+    b.p = nullptr; b.cap = 0;
+}
+
+int check_launch(alga_engine *e, const char *what) {
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return fail(e, ALGA_ERR_HIP, what, err);
+    return ALGA_OK;
+}
+
+struct Prepared {
+    NodesDev   nd;
+    PrefSufCfg cfg;
+    int        max_len = 0;
+    uint64_t   live = 0;
+};
+
+// Validates arguments, measures max read length / live nodes on the device and derives the
+// iteration bounds of GraphCreatorPrefSuf::startAlignmentGraphCreation (GraphCreatorPrefSuf.cpp:91-100).
+int prepare(alga_engine *e, const alga_nodes *nodes, const alga_prefsuf_params *p, hipStream_t s, Prepared &out) {
+    if (!nodes || !p) return fail(e, ALGA_ERR_INVALID_ARGUMENT, "nodes/params must not be NULL");
+    if (nodes->n < 0) return fail(e, ALGA_ERR_INVALID_ARGUMENT, "negative node count");
+    if (nodes->n > 0 && (!nodes->words || !nodes->len)) return fail(e, ALGA_ERR_INVALID_ARGUMENT, "words/len must not be NULL");
+    if (nodes->stride_words <= 0 && nodes->n > 0) return fail(e, ALGA_ERR_INVALID_ARGUMENT, "stride_words must be positive");
+    if (p->min_overlap < 1 || p->min_overlap > 501) return fail(e, ALGA_ERR_INVALID_ARGUMENT, "min_overlap must be in [1, 501]");
+    if (p->soes != 3) return fail(e, ALGA_ERR_INVALID_ARGUMENT, "soes must be 3 (the reference hard-codes SOES = 3)");
+    if (p->max_len_cap < 1 || p->max_len_cap > 500) return fail(e, ALGA_ERR_INVALID_ARGUMENT, "max_len_cap must be in [1, 500]");
+    if (p->rsoe_min_overlap < 0) return fail(e, ALGA_ERR_INVALID_ARGUMENT, "rsoe_min_overlap must be >= 0");
+    int rc;
+    if ((rc = ensure(e, e->counters, (CNT_TOTAL + 2) * sizeof(unsigned long long)))) return rc;
+    HIP_TRY(e, hipMemsetAsync(e->counters.p, 0, (CNT_TOTAL + 2) * sizeof(unsigned long long), s));
+    NodesDev nd;
+    nd.words = nodes->words; nd.len = nodes->len; nd.from = nodes->align_from; nd.to = nodes->align_to;
+    nd.n = nodes->n; nd.stride = nodes->stride_words;
+    unsigned long long *cnt = (unsigned long long *) e->counters.p;
+    int *d_maxlen = (int *) (cnt + CNT_TOTAL);
+    launch_node_stats(nd, cnt, d_maxlen, s);
+    if ((rc = check_launch(e, "k_node_stats"))) return rc;
+    HIP_TRY(e, hipMemcpyAsync(e->h_counters, e->counters.p, (CNT_TOTAL + 2) * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    HIP_TRY(e, hipStreamSynchronize(s));
+    out.nd = nd;
+    out.max_len = (int) (e->h_counters[CNT_TOTAL] & 0xFFFFFFFFull);
+    out.live = e->h_counters[CNT_LIVE_NODES];
+    if ((int64_t) blocks_of(out.max_len) > (int64_t) nodes->stride_words)
+        return fail(e, ALGA_ERR_INVALID_ARGUMENT, "stride_words is smaller than the longest read needs");
+    PrefSufCfg c;
+    c.Lmin = p->min_overlap;
+    c.rsoemo = p->rsoe_min_overlap;
+    c.Lcap = std::min(out.max_len, p->max_len_cap) + 1;              // last value of currentPrefSufLength
+    c.soes = p->soes;
+    c.seed_words = (2 * c.Lmin + 31) >> 5;
+    c.seed_last_mask = (2 * c.Lmin & 31) ? ((1u << (2 * c.Lmin & 31)) - 1u) : 0xFFFFFFFFu;
+    // The reversal at L == rsoemo (GraphCreatorPrefSuf.cpp:288) only happens if that iteration exists.
+    // If rsoemo lies beyond the last iteration every overlap stays "small", the graph is never
+    // reversed mid-way and the final reverseGraphInPlace (:107) hands back the REVERSED graph.
+    c.reversed = (c.rsoemo > c.Lcap) ? 1 : 0;
+    c.stats = p->collect_stats ? 1 : 0;
+    out.cfg = c;
+    return ALGA_OK;
+}
+
+uint32_t table_slots_for(uint64_t live) {
+    uint64_t want = std::max<uint64_t>(2 * live, 1024);
+    uint64_t s = 1024;
+    while (s < want) s <<= 1;
+    return (uint32_t) std::min<uint64_t>(s, 1ull << 31);
+}
+
+// seed + probe.  On return the record arrays hold *n_rec records; if `fused_indeg`, e->indeg holds the
+// in-degree of every target in [dst_begin, dst_end).
+int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t src_end, bool fused_indeg,
+                  int32_t dst_begin, int32_t dst_end, hipStream_t s, uint64_t *n_rec) {
+    int rc;
+    const NodesDev &nd = pp.nd;
+    const PrefSufCfg &cfg = pp.cfg;
+    unsigned long long *cnt = (unsigned long long *) e->counters.p;
+    *n_rec = 0;
+    HIP_TRY(e, hipEventRecord(e->ev[EV_START], s));
+    if (pp.live >= (1ull << 30)) return fail(e, ALGA_ERR_CAPACITY, "too many nodes for one seed table; shard the input");
+    const uint32_t slots = table_slots_for(pp.live);
+    const uint32_t mask = slots - 1;
+    if ((rc = ensure(e, e->table, (size_t) slots * sizeof(unsigned long long)))) return rc;
+    HIP_TRY(e, hipMemsetAsync(e->table.p, 0xFF, (size_t) slots * sizeof(unsigned long long), s));
+    launch_seed_build(nd, cfg, (unsigned long long *) e->table.p, mask, s);
+    if ((rc = check_launch(e, "k_seed_build"))) return rc;
+    HIP_TRY(e, hipEventRecord(e->ev[EV_SEED], s));
+    e->stats.table_slots = slots;
+
+    const uint64_t n_src = (uint64_t) std::max<int64_t>(0, (int64_t) src_end - src_begin);
+    uint64_t cap = std::max<uint64_t>(e->rec_cap_hint, 16 * n_src + 4096);
+    const int64_t n_owned = (int64_t) dst_end - dst_begin;
+    for (int attempt = 0; attempt < 4; attempt++) {
+        if (cap >= (1ull << 32) - 16) return fail(e, ALGA_ERR_CAPACITY, "more than 2^32 overlap records; shard the input");
+        if ((rc = ensure(e, e->rec_dst, cap * sizeof(uint32_t)))) return rc;
+        if ((rc = ensure(e, e->rec_src, cap * sizeof(uint32_t)))) return rc;
+        if ((rc = ensure(e, e->rec_ol, cap * sizeof(uint32_t)))) return rc;
+        if (fused_indeg) {
+            if ((rc = ensure(e, e->indeg, (size_t) (n_owned + 1) * sizeof(uint32_t)))) return rc;
+            HIP_TRY(e, hipMemsetAsync(e->indeg.p, 0, (size_t) (n_owned + 1) * sizeof(uint32_t), s));
+        }
+        HIP_TRY(e, hipMemsetAsync(cnt + CNT_RECORDS, 0, 4 * sizeof(unsigned long long), s)); // RECORDS, RAW, WINDOWS, SLOTS
+        launch_probe(nd, cfg, (const unsigned long long *) e->table.p, mask, src_begin, src_end, (uint32_t *) e->rec_dst.p,
+                     (uint32_t *) e->rec_src.p, (uint32_t *) e->rec_ol.p, cap, fused_indeg ? (uint32_t *) e->indeg.p : nullptr,
+                     dst_begin, dst_end, cnt, s);
+        if ((rc = check_launch(e, "k_probe_sources"))) return rc;
+        HIP_TRY(e, hipEventRecord(e->ev[EV_PROBE], s));
+        HIP_TRY(e, hipMemcpyAsync(e->h_counters, cnt, CNT_TOTAL * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        HIP_TRY(e, hipStreamSynchronize(s));
+        const uint64_t need = e->h_counters[CNT_RECORDS];
+        if (need <= cap) {
+            *n_rec = need;
+            e->rec_cap_hint = std::max<uint64_t>(e->rec_cap_hint, need + need / 16 + 4096);
+            e->last_records = need;
+            e->stats.records = need;
+            e->stats.raw_overlaps = e->h_counters[CNT_RAW];
+            e->stats.windows_probed = e->h_counters[CNT_WINDOWS];
+            e->stats.slots_scanned = e->h_counters[CNT_SLOTS];
+            return ALGA_OK;
+        }
+        cap = need + need / 16 + 4096; // the counter kept counting past the capacity: exact need is known
+    }
+    return fail(e, ALGA_ERR_HIP, "record buffer kept overflowing");
+}
+
+// group + reduce + emit for the targets in [dst_begin, dst_end)
+int reduce_impl(alga_engine *e, const Prepared &pp, const uint32_t *rec_dst, const uint32_t *rec_src, const uint32_t *rec_ol,
+                uint64_t n_rec, bool indeg_ready, int32_t dst_begin, int32_t dst_end, hipStream_t s, uint64_t *n_edges) {
+    int rc;
+    const NodesDev &nd = pp.nd;
+    const PrefSufCfg &cfg = pp.cfg;
+    unsigned long long *cnt = (unsigned long long *) e->counters.p;
+    const int32_t n_owned = dst_end - dst_begin;
+    *n_edges = 0;
+    if (n_rec >= (1ull << 32) - 16) return fail(e, ALGA_ERR_CAPACITY, "more than 2^32 overlap records; shard the input");
+    if ((rc = ensure(e, e->indeg, (size_t) (n_owned + 1) * sizeof(uint32_t)))) return rc;
+    if (!indeg_ready) {
+        HIP_TRY(e, hipMemsetAsync(e->indeg.p, 0, (size_t) (n_owned + 1) * sizeof(uint32_t), s));
+        launch_count_targets(rec_dst, n_rec, dst_begin, dst_end, (uint32_t *) e->indeg.p, s);
+        if ((rc = check_launch(e, "k_count_targets"))) return rc;
+    }
+    const size_t scratch = std::max(scan_scratch_bytes((uint64_t) n_owned), scan_scratch_bytes((uint64_t) nd.n));
+    if ((rc = ensure(e, e->scan_scratch, scratch))) return rc;
+    if ((rc = ensure(e, e->rowptr, (size_t) (n_owned + 1) * sizeof(uint32_t)))) return rc;
+    launch_exclusive_scan((const uint32_t *) e->indeg.p, (uint64_t) n_owned, (uint32_t *) e->rowptr.p, (uint64_t *) e->scan_scratch.p, s);
+    if ((rc = check_launch(e, "scan(indeg)"))) return rc;
+    if ((rc = ensure(e, e->seg_src, (size_t) (n_rec + 1) * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(e, e->seg_ol, (size_t) (n_rec + 1) * sizeof(uint32_t)))) return rc;
+    launch_scatter_by_target(rec_dst, rec_src, rec_ol, nullptr, n_rec, dst_begin, dst_end, (const uint32_t *) e->rowptr.p,
+                             (uint32_t *) e->indeg.p, (uint32_t *) e->seg_src.p, (uint32_t *) e->seg_ol.p, s);
+    if ((rc = check_launch(e, "k_scatter_by_target"))) return rc;
+    HIP_TRY(e, hipEventRecord(e->ev[EV_GROUP], s));
+
+    if ((rc = ensure(e, e->out_cnt, (size_t) (n_owned + 1) * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(e, e->outdeg, (size_t) (nd.n + 1) * sizeof(uint32_t)))) return rc;
+    HIP_TRY(e, hipMemsetAsync(e->outdeg.p, 0, (size_t) (nd.n + 1) * sizeof(uint32_t), s));
+    launch_reduce_targets(nd, cfg, dst_begin, n_owned, (const uint32_t *) e->rowptr.p, (uint32_t *) e->seg_src.p, (uint32_t *) e->seg_ol.p,
+                          (uint32_t *) e->out_cnt.p, (uint32_t *) e->outdeg.p, cnt, s);
+    if ((rc = check_launch(e, "k_reduce_targets"))) return rc;
+    HIP_TRY(e, hipEventRecord(e->ev[EV_REDUCE], s));
+
+    if ((rc = ensure(e, e->out_rowptr, (size_t) (nd.n + 1) * sizeof(uint32_t)))) return rc;
+    launch_exclusive_scan((const uint32_t *) e->outdeg.p, (uint64_t) nd.n, (uint32_t *) e->out_rowptr.p, (uint64_t *) e->scan_scratch.p, s);
+    if ((rc = check_launch(e, "scan(outdeg)"))) return rc;
+    uint64_t *d_total = (uint64_t *) e->scan_scratch.p + scan_total_index((uint64_t) nd.n);
+    HIP_TRY(e, hipMemcpyAsync(&e->h_counters[CNT_TOTAL], d_total, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(e, hipMemcpyAsync(e->h_counters, cnt, CNT_TOTAL * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    HIP_TRY(e, hipStreamSynchronize(s));
+    const uint64_t E = e->h_counters[CNT_TOTAL];
+    if (E >= (1ull << 32) - 16) return fail(e, ALGA_ERR_CAPACITY, "more than 2^32 edges; shard the input");
+    if ((rc = ensure(e, e->edges, (size_t) (E + 1) * sizeof(alga_edge_dev)))) return rc;
+    launch_scatter_by_source(cfg, dst_begin, n_owned, (const uint32_t *) e->rowptr.p, (const uint32_t *) e->seg_src.p,
+                             (const uint32_t *) e->seg_ol.p, (const uint32_t *) e->out_cnt.p, (const uint32_t *) e->out_rowptr.p,
+                             (uint32_t *) e->outdeg.p, (alga_edge_dev *) e->edges.p, s);
+    if ((rc = check_launch(e, "k_scatter_by_source"))) return rc;
+    launch_sort_rows(nd.n, (const uint32_t *) e->out_rowptr.p, (alga_edge_dev *) e->edges.p, s);
+    if ((rc = check_launch(e, "k_sort_rows"))) return rc;
+    HIP_TRY(e, hipEventRecord(e->ev[EV_EMIT], s));
+    HIP_TRY(e, hipStreamSynchronize(s));
+    *n_edges = E;
+    e->stats.edges = E;
+    e->stats.transitive_listed = e->h_counters[CNT_TR_LISTED];
+    e->stats.transitive_compares = e->h_counters[CNT_TR_COMPARES];
+    e->stats.transitive_removed = e->h_counters[CNT_TR_REMOVED];
+    e->stats.max_in_records = e->h_counters[CNT_MAX_IN];
+    return ALGA_OK;
+}
+
+float ev_ms(alga_engine *e, int a, int b) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, e->ev[a], e->ev[b]) != hipSuccess) return 0.f;
+    return ms;
+}
+
+} // namespace
+
+// ============================================================================================
+// C ABI
+// ============================================================================================
+extern "C" {
+
+int alga_abi_version(void) { return ALGA_AMD_ABI_VERSION; }
+
+int alga_engine_create(int hip_device, alga_engine **out) {
+    if (!out) return ALGA_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t err = hipGetDeviceCount(&ndev);
+    if (err != hipSuccess || ndev <= 0) return ALGA_ERR_NO_DEVICE;
+    if (hip_device < 0 || hip_device >= ndev) return ALGA_ERR_INVALID_ARGUMENT;
+    if (hipSetDevice(hip_device) != hipSuccess) return ALGA_ERR_NO_DEVICE;
+    alga_engine *e = new alga_engine();
+    e->device = hip_device;
+    memset(&e->stats, 0, sizeof(e->stats));
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, hip_device) == hipSuccess) snprintf(e->dev_name, sizeof(e->dev_name), "%s (%s)", prop.name, prop.gcnArchName);
+    if (hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking) != hipSuccess) { delete e; return ALGA_ERR_HIP; }
+    for (int i = 0; i < EV_COUNT; i++)
+        if (hipEventCreate(&e->ev[i]) != hipSuccess) { delete e; return ALGA_ERR_HIP; }
+    if (hipHostMalloc((void **) &e->h_counters, (CNT_TOTAL + 2) * sizeof(unsigned long long)) != hipSuccess) { delete e; return ALGA_ERR_OUT_OF_MEMORY; }
+    *out = e;
+    return ALGA_OK;
+}
+
+void alga_engine_destroy(alga_engine *e) {
+    if (!e) return;
+    (void) hipSetDevice(e->device);
+    if (e->own_stream) (void) hipStreamSynchronize(e->own_stream);
+    DevBuf *bufs[] = {&e->table, &e->counters, &e->indeg, &e->rowptr, &e->rec_dst, &e->rec_src, &e->rec_ol, &e->seg_src, &e->seg_ol,
+                      &e->out_cnt, &e->outdeg, &e->out_rowptr, &e->edges, &e->scan_scratch, &e->up_words, &e->up_len, &e->up_from, &e->up_to};
+    for (DevBuf *b : bufs) release(*b);
+    if (e->h_counters) (void) hipHostFree(e->h_counters);
+    for (int i = 0; i < EV_COUNT; i++) if (e->ev[i]) (void) hipEventDestroy(e->ev[i]);
+    if (e->own_stream) (void) hipStreamDestroy(e->own_stream);
+    delete e;
+}
+
+const char *alga_last_error(const alga_engine *e) { return e ? e->err.c_str() : "no engine"; }
+
+int alga_engine_device_name(const alga_engine *e, char *buf, size_t buflen) {
+    if (!e || !buf || buflen == 0) return ALGA_ERR_INVALID_ARGUMENT;
+    snprintf(buf, buflen, "%s", e->dev_name);
+    return ALGA_OK;
+}
+
+void alga_prefsuf_default_params(alga_prefsuf_params *p) {
+    if (!p) return;
+    memset(p, 0, sizeof(*p));
+    p->min_overlap = 0;          /* caller must set: src/main.cpp:100-110 derives it from the read length */
+    p->rsoe_min_overlap = 0;
+    p->soes = 3;                 /* include/GraphCreators/GraphCreatorPrefSuf.h:62 */
+    p->max_len_cap = 500;        /* src/GraphCreators/GraphCreatorPrefSuf.cpp:92 */
+    p->collect_stats = 0;
+}
+
+int alga_prefsuf_build_device(alga_engine *e, const alga_nodes *nodes, const alga_prefsuf_params *p, void *hip_stream,
+                              const alga_edge **d_edges, uint64_t *n_edges) {
+    if (!e) return ALGA_ERR_INVALID_ARGUMENT;
+    e->err.clear();
+    if (!d_edges || !n_edges) return fail(e, ALGA_ERR_INVALID_ARGUMENT, "output pointers must not be NULL");
+    *d_edges = nullptr; *n_edges = 0;
+    HIP_TRY(e, hipSetDevice(e->device));
+    hipStream_t s = hip_stream ? (hipStream_t) hip_stream : e->own_stream;
+    memset(&e->stats, 0, sizeof(e->stats));
+    Prepared pp;
+    int rc = prepare(e, nodes, p, s, pp);
+    if (rc) return rc;
+    e->stats.nodes_live = pp.live;
+    uint64_t n_rec = 0, E = 0;
+    if ((rc = discover_impl(e, pp, 0, nodes->n, true, 0, nodes->n, s, &n_rec))) return rc;
+    if ((rc = reduce_impl(e, pp, (const uint32_t *) e->rec_dst.p, (const uint32_t *) e->rec_src.p, (const uint32_t *) e->rec_ol.p, n_rec, true,
+                          0, nodes->n, s, &E))) return rc;
+    e->stats.ms_seed = ev_ms(e, EV_START, EV_SEED);
+    e->stats.ms_probe = ev_ms(e, EV_SEED, EV_PROBE);
+    e->stats.ms_group = ev_ms(e, EV_PROBE, EV_GROUP);
+    e->stats.ms_reduce = ev_ms(e, EV_GROUP, EV_REDUCE);
+    e->stats.ms_emit = ev_ms(e, EV_REDUCE, EV_EMIT);
+    e->stats.ms_total = ev_ms(e, EV_START, EV_EMIT);
+    *d_edges = (const alga_edge *) e->edges.p;
+    *n_edges = E;
+    return ALGA_OK;
+}
+
+int alga_prefsuf_build_host(alga_engine *e, const alga_nodes *nodes, const alga_prefsuf_params *p, alga_edge **edges, uint64_t *n_edges) {
+    if (!e) return ALGA_ERR_INVALID_ARGUMENT;
+    e->err.clear();
+    if (!edges || !n_edges) return fail(e, ALGA_ERR_INVALID_ARGUMENT, "output pointers must not be NULL");
+    *edges = nullptr; *n_edges = 0;
+    if (!nodes || !p) return fail(e, ALGA_ERR_INVALID_ARGUMENT, "nodes/params must not be NULL");
+    if (nodes->n < 0 || (nodes->n > 0 && (!nodes->words || !nodes->len || nodes->stride_words <= 0)))
+        return fail(e, ALGA_ERR_INVALID_ARGUMENT, "bad node set");
+    HIP_TRY(e, hipSetDevice(e->device));
+    hipStream_t s = e->own_stream;
+    int rc;
+    const size_t n = (size_t) nodes->n;
+    const size_t wbytes = n * (size_t) nodes->stride_words * sizeof(uint32_t);
+    if ((rc = ensure(e, e->up_words, wbytes))) return rc;
+    if ((rc = ensure(e, e->up_len, n * sizeof(int32_t)))) return rc;
+    alga_nodes dn = *nodes;
+    if (n) {
+        HIP_TRY(e, hipMemcpyAsync(e->up_words.p, nodes->words, wbytes, hipMemcpyHostToDevice, s));
+        HIP_TRY(e, hipMemcpyAsync(e->up_len.p, nodes->len, n * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    }
+    dn.words = (const uint32_t *) e->up_words.p;
+    dn.len = (const int32_t *) e->up_len.p;
+    if (nodes->align_from) {
+        if ((rc = ensure(e, e->up_from, n))) return rc;
+        if (n) HIP_TRY(e, hipMemcpyAsync(e->up_from.p, nodes->align_from, n, hipMemcpyHostToDevice, s));
+        dn.align_from = (const uint8_t *) e->up_from.p;
+    }
+    if (nodes->align_to) {
+        if ((rc = ensure(e, e->up_to, n))) return rc;
+        if (n) HIP_TRY(e, hipMemcpyAsync(e->up_to.p, nodes->align_to, n, hipMemcpyHostToDevice, s));
+        dn.align_to = (const uint8_t *) e->up_to.p;
+    }
+    const alga_edge *d_edges = nullptr;
+    uint64_t E = 0;
+    if ((rc = alga_prefsuf_build_device(e, &dn, p, (void *) s, &d_edges, &E))) return rc;
+    alga_edge *h = (alga_edge *) malloc((size_t) (E ? E : 1) * sizeof(alga_edge));
+    if (!h) return fail(e, ALGA_ERR_OUT_OF_MEMORY, "host edge buffer");
+    if (E) {
+        hipError_t err = hipMemcpy(h, d_edges, (size_t) E * sizeof(alga_edge), hipMemcpyDeviceToHost);
+        if (err != hipSuccess) { free(h); return fail(e, ALGA_ERR_HIP, "copy edges to host", err); }
+    }
+    *edges = h; *n_edges = E;
+    return ALGA_OK;
+}
+
+void alga_free_edges(alga_engine *e, alga_edge *edges) { (void) e; free(edges); }
+
+int alga_prefsuf_last_stats(const alga_engine *e, alga_prefsuf_stats *out) {
+    if (!e || !out) return ALGA_ERR_INVALID_ARGUMENT;
+    *out = e->stats;
+    return ALGA_OK;
+}
+
+int alga_prefsuf_discover_device(alga_engine *e, const alga_nodes *nodes, const alga_prefsuf_params *p, int32_t src_begin, int32_t src_end,
+                                 void *hip_stream, const uint32_t **d_dst, const uint32_t **d_src, const uint32_t **d_ol, uint64_t *n_records) {
+    if (!e) return ALGA_ERR_INVALID_ARGUMENT;
+    e->err.clear();
+    if (!d_dst || !d_src || !d_ol || !n_records) return fail(e, ALGA_ERR_INVALID_ARGUMENT, "output pointers must not be NULL");
+    HIP_TRY(e, hipSetDevice(e->device));
+    hipStream_t s = hip_stream ? (hipStream_t) hip_stream : e->own_stream;
+    memset(&e->stats, 0, sizeof(e->stats));
+    Prepared pp;
+    int rc = prepare(e, nodes, p, s, pp);
+    if (rc) return rc;
+    if (src_begin < 0 || src_end > nodes->n || src_begin > src_end) return fail(e, ALGA_ERR_INVALID_ARGUMENT, "bad source range");
+    e->stats.nodes_live = pp.live;
+    uint64_t n_rec = 0;
+    if ((rc = discover_impl(e, pp, src_begin, src_end, false, 0, 0, s, &n_rec))) return rc;
+    e->stats.ms_seed = ev_ms(e, EV_START, EV_SEED);
+    e->stats.ms_probe = ev_ms(e, EV_SEED, EV_PROBE);
+    e->stats.ms_total = ev_ms(e, EV_START, EV_PROBE);
+    *d_dst = (const uint32_t *) e->rec_dst.p; *d_src = (const uint32_t *) e->rec_src.p; *d_ol = (const uint32_t *) e->rec_ol.p;
+    *n_records = n_rec;
+    return ALGA_OK;
+}
+
+int alga_prefsuf_reduce_device(alga_engine *e, const alga_nodes *nodes, const alga_prefsuf_params *p, const uint32_t *d_dst,
+                               const uint32_t *d_src, const uint32_t *d_ol, uint64_t n_records, int32_t dst_begin, int32_t dst_end,
+                               void *hip_stream, const alga_edge **d_edges, uint64_t *n_edges) {
+    if (!e) return ALGA_ERR_INVALID_ARGUMENT;
+    e->err.clear();
+    if (!d_edges || !n_edges) return fail(e, ALGA_ERR_INVALID_ARGUMENT, "output pointers must not be NULL");
+    *d_edges = nullptr; *n_edges = 0;
+    if (n_records && (!d_dst || !d_src || !d_ol)) return fail(e, ALGA_ERR_INVALID_ARGUMENT, "record arrays must not be NULL");
+    HIP_TRY(e, hipSetDevice(e->device));
+    hipStream_t s = hip_stream ? (hipStream_t) hip_stream : e->own_stream;
+    Prepared pp;
+    int rc = prepare(e, nodes, p, s, pp);
+    if (rc) return rc;
+    if (dst_begin < 0 || dst_end > nodes->n || dst_begin > dst_end) return fail(e, ALGA_ERR_INVALID_ARGUMENT, "bad target range");
+    HIP_TRY(e, hipEventRecord(e->ev[EV_PROBE], s));
+    uint64_t E = 0;
+    if ((rc = reduce_impl(e, pp, d_dst, d_src, d_ol, n_records, false, dst_begin, dst_end, s, &E))) return rc;
+    e->stats.ms_group = ev_ms(e, EV_PROBE, EV_GROUP);
+    e->stats.ms_reduce = ev_ms(e, EV_GROUP, EV_REDUCE);
+    e->stats.ms_emit = ev_ms(e, EV_REDUCE, EV_EMIT);
+    *d_edges = (const alga_edge *) e->edges.p;
+    *n_edges = E;
+    return ALGA_OK;
+}
+
+int alga_write_graph(const char *path, int32_t n_nodes, const alga_edge *edges, uint64_t n_edges) {
+    if (!path || n_nodes < 0 || (n_edges && !edges)) return ALGA_ERR_INVALID_ARGUMENT;
+    FILE *f = fopen(path, "wb");
+    if (!f) return ALGA_ERR_IO;
+    std::string buf;
+    buf.reserve(1 << 20);
+    auto put = [&](int32_t v) { buf.append((const char *) &v, 4); };
+    uint32_t s = (uint32_t) n_nodes;
+    buf.append((const char *) &s, 4);
+    uint64_t k = 0;
+    bool ok = true;
+    for (int32_t i = 0; i < n_nodes && ok; i++) {
+        uint64_t end = k;
+        while (end < n_edges && edges[end].src == i) end++;
+        put(i); put((int32_t) (end - k));
+        for (; k < end; k++) { put(edges[k].dst); put(edges[k].offset); }
+        if (buf.size() >= (1 << 20)) { ok = fwrite(buf.data(), 1, buf.size(), f) == buf.size(); buf.clear(); }
+    }
+    if (ok && !buf.empty()) ok = fwrite(buf.data(), 1, buf.size(), f) == buf.size();
+    if (fclose(f) != 0) ok = false;
+    if (!ok || k != n_edges) return ALGA_ERR_IO; /* k != n_edges: edges were not sorted by src / out of range */
+    return ALGA_OK;
+}
+
+} // extern "C"

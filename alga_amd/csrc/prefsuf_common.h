@@ -1,0 +1,87 @@
+// alga_amd/csrc/prefsuf_common.h -- shared host/device definitions of the PrefSuf overlap engine.
+//
+// The engine computes the graph of the reference's GraphCreatorPrefSuf
+// (src/GraphCreators/GraphCreatorPrefSuf.cpp:73-488 + src/main.cpp:291) with a different
+// algorithm shape: one seed table over the min_overlap-long prefixes of all
+// targets, one probe per (source, overlap length) suffix window verified by an exact 2-bit
+// compare, the per-source small-overlap cap applied inside the probing wave, and a per-target
+// sequential replay of the reference's insertion order for the transitive reduction.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define ALGA_HD __host__ __device__
+#else
+#define ALGA_HD
+#endif
+
+namespace alga {
+
+// ---- overlap record: one verified suffix(B)==prefix(C) pair that survived the per-source cap ----
+//   ol = offset | (overlap_len << 12) | (small << 31)      offset <= 500, overlap_len <= 501
+constexpr uint32_t OL_OFF_MASK = 0xFFFu;
+constexpr int      OL_LEN_SHIFT = 12;
+constexpr uint32_t OL_LEN_MASK = 0xFFFu;
+constexpr uint32_t OL_SMALL = 0x80000000u;
+
+ALGA_HD inline uint32_t ol_pack(int off, int L, bool small) {
+    return (uint32_t) off | ((uint32_t) L << OL_LEN_SHIFT) | (small ? OL_SMALL : 0u);
+}
+ALGA_HD inline int  ol_off(uint32_t ol) { return (int) (ol & OL_OFF_MASK); }
+ALGA_HD inline int  ol_len(uint32_t ol) { return (int) ((ol >> OL_LEN_SHIFT) & OL_LEN_MASK); }
+ALGA_HD inline bool ol_small(uint32_t ol) { return (ol & OL_SMALL) != 0; }
+
+// ---- seed fingerprint of a 2*min_overlap-bit window, fed 32 bits at a time --------------------
+// Only a filter: every candidate is verified bit for bit afterwards, so the fingerprint never
+// decides an edge (the reference decides on two modular hashes, GraphCreatorPrefSuf.cpp:386-387).
+ALGA_HD inline uint64_t fp_init() { return 0x243F6A8885A308D3ull; }
+ALGA_HD inline uint64_t fp_step(uint64_t h, uint32_t w) {
+    h = (h ^ (uint64_t) w) * 0xff51afd7ed558ccdull;
+    return h ^ (h >> 32);
+}
+ALGA_HD inline uint64_t fp_final(uint64_t h) {
+    h *= 0xc4ceb9fe1a85ec53ull;
+    return h ^ (h >> 29);
+}
+
+constexpr uint64_t SEED_EMPTY = ~0ull; // seed-table slot: (tag32 << 32) | node id ; empty = all ones
+
+// number of uint32 blocks that hold `len_nt` nucleotides (Bitset::blocks(), Bitset.h:206)
+ALGA_HD inline int blocks_of(int len_nt) { return len_nt <= 0 ? 0 : ((2 * len_nt - 1) >> 5) + 1; }
+
+// device-side counters; index = enum below
+enum Counter {
+    CNT_RECORDS = 0,       // records appended by the probe kernel (may exceed capacity -> retry)
+    CNT_RAW,               // verified raw overlaps
+    CNT_WINDOWS,           // windows probed
+    CNT_SLOTS,             // seed-table slots read
+    CNT_TR_LISTED,         // bitsetChecksCount
+    CNT_TR_COMPARES,       // goodBitsetChecksCount
+    CNT_TR_REMOVED,        // bitsetCheckEdgesRemoved
+    CNT_EDGES,             // final edges
+    CNT_MAX_IN,            // max records per target
+    CNT_LIVE_NODES,
+    CNT_TOTAL = 16
+};
+
+struct NodesDev {
+    const uint32_t *words;
+    const int32_t  *len;
+    const uint8_t  *from; // may be null
+    const uint8_t  *to;   // may be null
+    int32_t n;
+    int32_t stride;       // uint32 per row
+};
+
+struct PrefSufCfg {
+    int32_t Lmin;        // MIN_OVERLAP_PREF_SUF
+    int32_t rsoemo;      // REMOVE_SMALL_OVERLAP_EDGES_MIN_OVERLAP
+    int32_t Lcap;        // last overlap length iterated: min(maxReadLength, cap) + 1
+    int32_t soes;        // 3
+    int32_t seed_words;  // ceil(2*Lmin/32)
+    uint32_t seed_last_mask;
+    int32_t reversed;    // reference quirk: rsoemo beyond the last iteration -> graph comes out reversed
+    int32_t stats;
+};
+
+} // namespace alga

@@ -1,0 +1,259 @@
+"""ctypes binding of libalga_amd.so (include/alga_amd.h) + the host-side mirror of the reference's
+GraphCreator interface for this path (include/GraphCreators/GraphCreator.h:12-62 of the reference).
+
+Nothing here computes an overlap: every build call goes through the C ABI into the HIP kernels and
+raises AlgaError when the library or the device is missing.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+EDGE_DTYPE = np.dtype([("src", np.int32), ("dst", np.int32), ("offset", np.int32)])
+
+
+class AlgaError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("alga_amd error %d: %s" % (code, msg))
+        self.code = code
+
+
+class _Nodes(C.Structure):
+    _fields_ = [("words", C.c_void_p), ("stride_words", C.c_int32), ("len", C.c_void_p), ("n", C.c_int32),
+                ("align_from", C.c_void_p), ("align_to", C.c_void_p)]
+
+
+class PrefSufParams(C.Structure):
+    """alga_prefsuf_params"""
+    _fields_ = [("min_overlap", C.c_int32), ("rsoe_min_overlap", C.c_int32), ("soes", C.c_int32),
+                ("max_len_cap", C.c_int32), ("collect_stats", C.c_int32), ("reserved", C.c_int32 * 3)]
+
+
+class PrefSufStats(C.Structure):
+    """alga_prefsuf_stats"""
+    _fields_ = [("raw_overlaps", C.c_uint64), ("transitive_listed", C.c_uint64), ("transitive_compares", C.c_uint64),
+                ("transitive_removed", C.c_uint64), ("windows_probed", C.c_uint64), ("slots_scanned", C.c_uint64),
+                ("records", C.c_uint64), ("edges", C.c_uint64), ("table_slots", C.c_uint64),
+                ("max_in_records", C.c_uint64), ("ms_total", C.c_double), ("ms_seed", C.c_double),
+                ("ms_probe", C.c_double), ("ms_group", C.c_double), ("ms_reduce", C.c_double), ("ms_emit", C.c_double),
+                ("nodes_live", C.c_uint64), ("reserved", C.c_uint64 * 3)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+
+
+EXPORTS = ["alga_abi_version", "alga_engine_create", "alga_engine_destroy", "alga_last_error",
+           "alga_engine_device_name", "alga_prefsuf_default_params", "alga_prefsuf_build_host", "alga_free_edges",
+           "alga_prefsuf_build_device", "alga_prefsuf_last_stats", "alga_prefsuf_discover_device",
+           "alga_prefsuf_reduce_device", "alga_write_graph"]
+
+
+def library_path():
+    return os.path.join(_HERE, "lib", "libalga_amd.so")
+
+
+def load_library():
+    """Load libalga_amd.so; raises AlgaError (never falls back to anything else) if it is missing."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise AlgaError(-2, "HIP extension %s is not built (run `python -c 'import __graft_entry__ as g; g.build()'`)" % path)
+    lib = C.CDLL(path)
+    lib.alga_abi_version.restype = C.c_int
+    lib.alga_engine_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    lib.alga_engine_destroy.argtypes = [C.c_void_p]
+    lib.alga_engine_destroy.restype = None
+    lib.alga_last_error.argtypes = [C.c_void_p]
+    lib.alga_last_error.restype = C.c_char_p
+    lib.alga_engine_device_name.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+    lib.alga_prefsuf_default_params.argtypes = [C.POINTER(PrefSufParams)]
+    lib.alga_prefsuf_default_params.restype = None
+    lib.alga_prefsuf_build_host.argtypes = [C.c_void_p, C.POINTER(_Nodes), C.POINTER(PrefSufParams),
+                                            C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    lib.alga_free_edges.argtypes = [C.c_void_p, C.c_void_p]
+    lib.alga_free_edges.restype = None
+    lib.alga_prefsuf_build_device.argtypes = [C.c_void_p, C.POINTER(_Nodes), C.POINTER(PrefSufParams), C.c_void_p,
+                                              C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    lib.alga_prefsuf_last_stats.argtypes = [C.c_void_p, C.POINTER(PrefSufStats)]
+    lib.alga_prefsuf_discover_device.argtypes = [C.c_void_p, C.POINTER(_Nodes), C.POINTER(PrefSufParams), C.c_int32,
+                                                 C.c_int32, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                                 C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    lib.alga_prefsuf_reduce_device.argtypes = [C.c_void_p, C.POINTER(_Nodes), C.POINTER(PrefSufParams), C.c_void_p,
+                                               C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_int32, C.c_void_p,
+                                               C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    lib.alga_write_graph.argtypes = [C.c_char_p, C.c_int32, C.c_void_p, C.c_uint64]
+    _LIB = lib
+    return lib
+
+
+def pack_reads(codes, lens=None, stride_words=None):
+    """codes[n, maxlen] uint8 in {0,1,2,3} (A C G T) -> words[n, stride] uint32 in the reference's layout
+    (nucleotide i in bits 2i,2i+1 of a little-endian bit string; src/DataStructures/Read.cpp:40-68)."""
+    codes = np.asarray(codes, dtype=np.uint8)
+    n, m = codes.shape
+    W = (2 * m + 31) // 32
+    if stride_words is None:
+        stride_words = W
+    if lens is not None:
+        codes = np.where(np.arange(m)[None, :] < np.asarray(lens)[:, None], codes, 0).astype(np.uint8)
+    pad = W * 16 - m
+    if pad:
+        codes = np.concatenate([codes, np.zeros((n, pad), np.uint8)], axis=1)
+    c = codes.reshape(n, W, 16).astype(np.uint32)
+    shifts = (2 * np.arange(16, dtype=np.uint32))[None, None, :]
+    words = np.bitwise_or.reduce(c << shifts, axis=2).astype(np.uint32)
+    if stride_words > W:
+        words = np.concatenate([words, np.zeros((n, stride_words - W), np.uint32)], axis=1)
+    return np.ascontiguousarray(words)
+
+
+def derive_params(avg_len, trim_left=3, trim_right=3, scale=0.55):
+    """(min_overlap, rsoe_min_overlap) as src/main.cpp:93-108 of the reference derives them
+    (mixed float/int arithmetic with truncation, reproduced literally in float32)."""
+    LEN = int(avg_len + trim_left + trim_right)
+    sc = np.float32(scale)
+    L = int(np.float32(LEN) * sc)
+    rsoemo = int(np.float32(LEN) * (sc + np.float32(1)) / np.float32(2))
+    return L, rsoemo
+
+
+class Engine:
+    """One engine handle == one HIP device.  Mirrors the reference's GraphCreator life cycle:
+    construct -> (setAlignFrom/To masks) -> build -> read the graph."""
+
+    def __init__(self, device=0):
+        self._lib = load_library()
+        h = C.c_void_p()
+        rc = self._lib.alga_engine_create(int(device), C.byref(h))
+        if rc:
+            raise AlgaError(rc, "alga_engine_create(device=%d) failed -- no usable HIP device" % device)
+        self._h = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.alga_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc:
+            raise AlgaError(rc, (self._lib.alga_last_error(self._h) or b"").decode())
+
+    def device_name(self):
+        buf = C.create_string_buffer(256)
+        self._lib.alga_engine_device_name(self._h, buf, 256)
+        return buf.value.decode()
+
+    @staticmethod
+    def params(min_overlap, rsoe_min_overlap, collect_stats=False):
+        p = PrefSufParams()
+        load_library().alga_prefsuf_default_params(C.byref(p))
+        p.min_overlap, p.rsoe_min_overlap, p.collect_stats = int(min_overlap), int(rsoe_min_overlap), int(bool(collect_stats))
+        return p
+
+    def last_stats(self):
+        st = PrefSufStats()
+        self._check(self._lib.alga_prefsuf_last_stats(self._h, C.byref(st)))
+        return st.as_dict()
+
+    # ---- host buffers in, edges out (the drop-in call) --------------------------------------
+    def prefsuf_host(self, words, lens, min_overlap, rsoe_min_overlap, align_from=None, align_to=None, collect_stats=False):
+        words = np.ascontiguousarray(words, dtype=np.uint32)
+        lens = np.ascontiguousarray(lens, dtype=np.int32)
+        n = int(lens.shape[0])
+        stride = int(words.shape[1]) if words.ndim == 2 else (words.size // max(n, 1))
+        keep = [words, lens]
+        nd = _Nodes(words.ctypes.data, stride, lens.ctypes.data, n, None, None)
+        if align_from is not None:
+            af = np.ascontiguousarray(align_from, dtype=np.uint8); keep.append(af); nd.align_from = af.ctypes.data
+        if align_to is not None:
+            at = np.ascontiguousarray(align_to, dtype=np.uint8); keep.append(at); nd.align_to = at.ctypes.data
+        p = self.params(min_overlap, rsoe_min_overlap, collect_stats)
+        out = C.c_void_p()
+        m = C.c_uint64()
+        self._check(self._lib.alga_prefsuf_build_host(self._h, C.byref(nd), C.byref(p), C.byref(out), C.byref(m)))
+        try:
+            e = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_int32)), shape=(max(m.value, 1) * 3,))[: m.value * 3]
+            return e.reshape(-1, 3).copy()
+        finally:
+            self._lib.alga_free_edges(self._h, out)
+
+    # ---- device-resident node set (torch tensors on this engine's device) --------------------
+    @staticmethod
+    def _nodes_from_torch(words, lens, align_from=None, align_to=None):
+        assert words.is_cuda and lens.is_cuda and words.is_contiguous() and lens.is_contiguous()
+        n = int(lens.shape[0])
+        stride = int(words.shape[1])
+        nd = _Nodes(words.data_ptr(), stride, lens.data_ptr(), n, None, None)
+        if align_from is not None:
+            nd.align_from = align_from.data_ptr()
+        if align_to is not None:
+            nd.align_to = align_to.data_ptr()
+        return nd
+
+    def prefsuf_device(self, words, lens, min_overlap, rsoe_min_overlap, align_from=None, align_to=None, stream=None,
+                       collect_stats=False):
+        """words: int32/uint32-viewed torch tensor [n, stride] on the device, lens: int32 [n].
+        Returns (device pointer of alga_edge[n_edges], n_edges); the memory belongs to the engine."""
+        nd = self._nodes_from_torch(words, lens, align_from, align_to)
+        p = self.params(min_overlap, rsoe_min_overlap, collect_stats)
+        out = C.c_void_p()
+        m = C.c_uint64()
+        self._check(self._lib.alga_prefsuf_build_device(self._h, C.byref(nd), C.byref(p), C.c_void_p(stream or 0),
+                                                        C.byref(out), C.byref(m)))
+        return out.value, int(m.value)
+
+    def discover_device(self, words, lens, min_overlap, rsoe_min_overlap, src_begin, src_end, align_from=None,
+                        align_to=None, stream=None, collect_stats=False):
+        nd = self._nodes_from_torch(words, lens, align_from, align_to)
+        p = self.params(min_overlap, rsoe_min_overlap, collect_stats)
+        d, s, o = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        m = C.c_uint64()
+        self._check(self._lib.alga_prefsuf_discover_device(self._h, C.byref(nd), C.byref(p), int(src_begin), int(src_end),
+                                                           C.c_void_p(stream or 0), C.byref(d), C.byref(s), C.byref(o),
+                                                           C.byref(m)))
+        return d.value, s.value, o.value, int(m.value)
+
+    def reduce_device(self, words, lens, min_overlap, rsoe_min_overlap, rec_dst, rec_src, rec_ol, n_records, dst_begin,
+                      dst_end, align_from=None, align_to=None, stream=None, collect_stats=False):
+        """rec_*: device pointers (ints) or torch int32 tensors."""
+        nd = self._nodes_from_torch(words, lens, align_from, align_to)
+        p = self.params(min_overlap, rsoe_min_overlap, collect_stats)
+
+        def ptr(x):
+            return C.c_void_p(x if isinstance(x, int) else x.data_ptr())
+        out = C.c_void_p()
+        m = C.c_uint64()
+        self._check(self._lib.alga_prefsuf_reduce_device(self._h, C.byref(nd), C.byref(p), ptr(rec_dst), ptr(rec_src),
+                                                         ptr(rec_ol), int(n_records), int(dst_begin), int(dst_end),
+                                                         C.c_void_p(stream or 0), C.byref(out), C.byref(m)))
+        return out.value, int(m.value)
+
+    def write_graph(self, path, n_nodes, edges):
+        edges = np.ascontiguousarray(edges, dtype=np.int32).reshape(-1, 3)
+        rc = self._lib.alga_write_graph(path.encode(), int(n_nodes), edges.ctypes.data, len(edges))
+        if rc:
+            raise AlgaError(rc, "alga_write_graph(%s) failed" % path)
+
+
+def device_edges_to_numpy(ptr, n_edges):
+    """Copy an engine-owned device edge list to host (uses torch only as a memcpy)."""
+    import torch
+    if n_edges == 0:
+        return np.zeros((0, 3), np.int32)
+    out = torch.empty((n_edges, 3), dtype=torch.int32, device="cpu").pin_memory()
+    rc = torch.cuda.cudart().cudaMemcpy(out.data_ptr(), ptr, n_edges * 12, 2)  # 2 = DeviceToHost
+    if int(rc) != 0:
+        raise AlgaError(-3, "cudaMemcpy D2H failed: %s" % rc)
+    return out.numpy().copy()

@@ -1,0 +1,149 @@
+/*
+ * include/alga_amd.h -- C ABI of the MI355X (gfx950) overlap-graph engine for the ALGA assembler.
+ *
+ * This is the drop-in boundary for ONE path of swacisko/ALGA: the overlap-graph construction that
+ * sits behind `class GraphCreator` (reference include/GraphCreators/GraphCreator.h:12-62) and is
+ * selected in src/main.cpp:246-250.  Plain pointers and sizes only; no C++/torch types.
+ * The reference-side binding (a GraphCreator subclass that marshals to these calls) is shown in
+ * INTEGRATION.md.  Paths below are relative to the reference root.
+ *
+ * Conventions
+ *   - every call returns 0 on success or a negative alga_status; alga_last_error() gives the text.
+ *     (the reference's convention is cerr + exit(1), e.g. src/DataStructures/Read.cpp:146-149; the
+ *     adapter maps a non-zero status to that.)
+ *   - the engine borrows caller memory and never frees it (GraphCreator::~GraphCreator only nulls
+ *     its pointers, src/GraphCreators/GraphCreator.cpp:15-18); buffers the engine returns are
+ *     released with alga_free_edges().
+ *   - calls block until the result is complete (the reference joins its worker threads before
+ *     returning, src/GraphCreators/GraphCreatorPrefSuf.cpp:147-161); one engine handle must not be
+ *     used from two threads at once, different handles are independent.
+ *   - there is NO CPU fallback: without a usable HIP device every compute call fails.
+ */
+#ifndef ALGA_AMD_H
+#define ALGA_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ALGA_AMD_ABI_VERSION 1
+
+typedef enum {
+    ALGA_OK = 0,
+    ALGA_ERR_INVALID_ARGUMENT = -1,
+    ALGA_ERR_NO_DEVICE = -2,        /* no HIP device / HIP runtime failure at start-up        */
+    ALGA_ERR_HIP = -3,              /* a HIP call or kernel failed                            */
+    ALGA_ERR_OUT_OF_MEMORY = -4,
+    ALGA_ERR_CAPACITY = -5,         /* an internal 32-bit index space would overflow; shard   */
+    ALGA_ERR_IO = -6
+} alga_status;
+
+typedef struct alga_engine alga_engine; /* opaque */
+
+/* Directed overlap edge src -> dst: "dst starts at position `offset` of src"
+ * == one (neighbor, offset) pair of Graph::V[src] (include/DataStructures/Graph.h:54,97). */
+typedef struct { int32_t src, dst, offset; } alga_edge;
+
+/* Node set = what GraphCreator's constructor receives as `vector<Read*>* reads`:
+ * 2-bit packed reads, nucleotide i in bits (2i, 2i+1) of a little-endian bit string held in
+ * uint32 blocks, A0 C1 G2 T3, unused tail bits zero (include/DataStructures/Bitset.h:41-50,
+ * src/DataStructures/Read.cpp:40-68).  len[i] == 0 means READS[i] == nullptr. */
+typedef struct {
+    const uint32_t *words;   /* n rows of `stride_words` uint32                                  */
+    int32_t         stride_words; /* >= ceil(2*max_len/32)                                       */
+    const int32_t  *len;     /* n lengths in nucleotides                                         */
+    int32_t         n;       /* number of nodes == Graph::size()                                 */
+    const uint8_t  *align_from; /* n bytes or NULL (= all 1): GraphCreator::alignFrom            */
+    const uint8_t  *align_to;   /* n bytes or NULL (= all 1): GraphCreator::alignTo              */
+} alga_nodes;
+
+/* Parameters GraphCreatorPrefSuf reads from Params:: globals. */
+typedef struct {
+    int32_t min_overlap;      /* Params::MIN_OVERLAP_PREF_SUF                                    */
+    int32_t rsoe_min_overlap; /* Params::REMOVE_SMALL_OVERLAP_EDGES_MIN_OVERLAP                   */
+    int32_t soes;             /* small-overlap edges kept per source; the reference hard-codes 3
+                                 (include/GraphCreators/GraphCreatorPrefSuf.h:62)                 */
+    int32_t max_len_cap;      /* 500 (src/GraphCreators/GraphCreatorPrefSuf.cpp:92)               */
+    int32_t collect_stats;    /* != 0: fill the work counters of alga_prefsuf_stats               */
+    int32_t reserved[3];
+} alga_prefsuf_params;
+
+/* Work counters; the first four mirror GATHER_STATISTICS of the reference
+ * (include/GraphCreators/GraphCreatorPrefSuf.h:112-118). */
+typedef struct {
+    uint64_t raw_overlaps;        /* goodPrefSufChecks: suffix==prefix pairs found               */
+    uint64_t transitive_listed;   /* bitsetChecksCount: in-list entries visited by big overlaps  */
+    uint64_t transitive_compares; /* goodBitsetChecksCount: 2-bit compares started               */
+    uint64_t transitive_removed;  /* bitsetCheckEdgesRemoved                                     */
+    uint64_t windows_probed;      /* (node, overlap length) seed-table probes                    */
+    uint64_t slots_scanned;       /* seed-table slots read while probing                         */
+    uint64_t records;             /* overlap records kept after the small-overlap cap            */
+    uint64_t edges;               /* edges in the result                                         */
+    uint64_t table_slots;         /* seed-table capacity                                         */
+    uint64_t max_in_records;      /* largest per-target record list                              */
+    double   ms_total;            /* device time of the last call, HIP events on the engine's stream */
+    double   ms_seed, ms_probe, ms_group, ms_reduce, ms_emit;
+    uint64_t nodes_live;          /* nodes with len>0                                            */
+    uint64_t reserved[3];
+} alga_prefsuf_stats;
+
+/* ---- lifetime --------------------------------------------------------------------------- */
+int         alga_abi_version(void);
+int         alga_engine_create(int hip_device, alga_engine **out);
+void        alga_engine_destroy(alga_engine *e);
+const char *alga_last_error(const alga_engine *e);      /* valid until the next call on `e`     */
+int         alga_engine_device_name(const alga_engine *e, char *buf, size_t buflen);
+
+void        alga_prefsuf_default_params(alga_prefsuf_params *p);
+
+/* ---- the drop-in: GraphCreatorPrefSuf ---------------------------------------------------- */
+/* Host buffers in, edges out.  Replaces, for the caller at src/main.cpp:246-291,
+ *   new GraphCreatorPrefSuf(READS, G, false); setAlignFrom/To(...); startAlignmentGraphCreation();
+ *   G->retainOnlySmallestOffset();
+ * The result is the graph the caller would hold at src/main.cpp:293: edges grouped by src,
+ * each adjacency list sorted by (dst, offset) (src/DataStructures/Graph.cpp:367-387).
+ * *edges is engine-owned host memory; release with alga_free_edges(). */
+int  alga_prefsuf_build_host(alga_engine *e, const alga_nodes *nodes, const alga_prefsuf_params *p,
+                             alga_edge **edges, uint64_t *n_edges);
+void alga_free_edges(alga_engine *e, alga_edge *edges);
+
+/* Same computation with the node set already resident in HBM (all pointers in `nodes` are device
+ * pointers on the engine's device).  Work is enqueued on `hip_stream` (a hipStream_t, NULL = the
+ * engine's own stream).  The edge list stays on the device:
+ *   *d_edges : device pointer to alga_edge[*n_edges], owned by the engine, valid until the next
+ *              build call on this engine or alga_engine_destroy(). */
+int  alga_prefsuf_build_device(alga_engine *e, const alga_nodes *nodes, const alga_prefsuf_params *p,
+                               void *hip_stream, const alga_edge **d_edges, uint64_t *n_edges);
+
+/* Counters and per-phase device times of the last build call on `e`. */
+int  alga_prefsuf_last_stats(const alga_engine *e, alga_prefsuf_stats *out);
+
+/* ---- sharded form (one process per GPU; the exchange between the two calls is the caller's) ----
+ * Phase 1, on every rank: discover the overlaps whose SOURCE node id is in [src_begin, src_end)
+ * against the full (replicated) node set, apply the per-source small-overlap cap, and return the
+ * overlap records as device arrays of *n_records entries:
+ *   d_dst[i], d_src[i] : node ids;  d_ol[i] : offset | (overlap_len << 12) | (small << 31)
+ * Phase 2, on the rank that owns the target ids: reduce records (any order, all records of an
+ * owned target present) to edges.  Records of targets outside [dst_begin, dst_end) are ignored. */
+int  alga_prefsuf_discover_device(alga_engine *e, const alga_nodes *nodes, const alga_prefsuf_params *p,
+                                  int32_t src_begin, int32_t src_end, void *hip_stream,
+                                  const uint32_t **d_dst, const uint32_t **d_src, const uint32_t **d_ol,
+                                  uint64_t *n_records);
+int  alga_prefsuf_reduce_device(alga_engine *e, const alga_nodes *nodes, const alga_prefsuf_params *p,
+                                const uint32_t *d_dst, const uint32_t *d_src, const uint32_t *d_ol,
+                                uint64_t n_records, int32_t dst_begin, int32_t dst_end, void *hip_stream,
+                                const alga_edge **d_edges, uint64_t *n_edges);
+
+/* ---- graph dump: the reference's own checkpoint format ------------------------------------ */
+/* Graph::serializeGraph (src/DataStructures/Graph.cpp:269-297): u32 n; n x {i32 id; i32 deg;
+ * deg x {i32 neighbour; i32 offset}}, native endian.  Stock ALGA loads it with
+ * --deserialize_graph=1 (src/main.cpp:242).  `edges` must be sorted by (src, dst, offset). */
+int  alga_write_graph(const char *path, int32_t n_nodes, const alga_edge *edges, uint64_t n_edges);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ALGA_AMD_H */

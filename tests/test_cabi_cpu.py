@@ -1,0 +1,101 @@
+"""CPU-side checks (no GPU): the C-ABI library loads and exports every symbol include/alga_amd.h declares,
+the host logic (packing, parameter derivation, graph writer) agrees with the oracle / golden fixtures, and
+the product fails loudly -- never falls back -- when no HIP device is present."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import alga_amd
+import oracle_lib as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "alga_amd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(alga_[a-z_]+)\s*\(", hdr)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = alga_amd.load_library()
+    syms = _declared_symbols()
+    assert len(syms) >= 12
+    for s in syms:
+        assert hasattr(lib, s), "libalga_amd.so does not export %s" % s
+    assert set(syms) == set(alga_amd.engine.EXPORTS)
+    assert lib.alga_abi_version() == 1
+
+
+def test_library_contains_gfx950_code_object():
+    data = open(alga_amd.library_path(), "rb").read()
+    assert b"gfx950" in data
+    for k in (b"k_probe_sources", b"k_seed_build", b"k_reduce_targets"):
+        assert k in data
+
+
+def test_no_cpu_fallback_without_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(alga_amd.AlgaError):
+        alga_amd.Engine(0)
+
+
+def test_product_does_not_import_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "alga_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp", ".hpp")) or f == "Makefile":
+                txt = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "liboracle" not in txt and "alga_oracle" not in txt and "oracle_" not in txt, f
+
+
+def test_pack_reads_matches_oracle_pack():
+    rng = np.random.default_rng(3)
+    L = O.lib()
+    for n in (1, 15, 16, 17, 94, 144, 250):
+        codes = rng.integers(0, 4, size=(4, n), dtype=np.uint8)
+        w = alga_amd.pack_reads(codes)
+        W = w.shape[1]
+        for i in range(4):
+            s = bytes(b"ACGT"[c] for c in codes[i])
+            ref = np.zeros(W, np.uint32)
+            L.oracle_pack(s, n, ref.ctypes.data, W)
+            assert (ref == w[i]).all()
+    codes = rng.integers(0, 4, size=(3, 40), dtype=np.uint8)
+    w = alga_amd.pack_reads(codes, lens=[40, 10, 0], stride_words=4)
+    assert w.shape == (3, 4) and (w[2] == 0).all() and (w[1, 1:] == 0).all()
+
+
+@pytest.mark.parametrize("name", O.FIXTURES[:5])
+def test_derive_params_matches_reference(golden_dir, name):
+    fx = O.Fixture(golden_dir, name)
+    try:
+        f1, f2 = fx.inputs()
+        # average length over the reads as the reference sees them after trimming: re-derive through the oracle
+        nd = O.ingest(f1, f2, remove_pref_reads=3)  # no prefix removal: every parsed read still present
+        lens = nd["len"]
+    finally:
+        fx.cleanup()
+    # the reference derives from the mean over non-null reads right after input (src/main.cpp:93);
+    # short-read masking (len==0) happens later, so recover the original mean from the fixture's numbers
+    assert (nd["min_overlap"], nd["rsoemo"]) == (fx.meta["min_overlap"], fx.meta["rsoemo"])
+    if (lens > 0).all():
+        assert alga_amd.derive_params(float(lens.mean())) == (fx.meta["min_overlap"], fx.meta["rsoemo"])
+
+
+def test_write_graph_is_reference_wire_format(tmp_path, golden_dir):
+    fx = O.Fixture(golden_dir, "f1_cfg1")
+    ref = fx.ref_graph()
+    n, edges = O.parse_graph(ref)
+    path = str(tmp_path / "g.graph")
+    lib = alga_amd.load_library()
+    e = np.ascontiguousarray(edges, dtype=np.int32)
+    assert lib.alga_write_graph(path.encode(), n, e.ctypes.data, len(e)) == 0
+    assert open(path, "rb").read() == ref
+    # unsorted / out-of-range input is rejected instead of writing a corrupt dump
+    bad = e[::-1].copy()
+    assert lib.alga_write_graph(path.encode(), n, bad.ctypes.data, len(bad)) != 0

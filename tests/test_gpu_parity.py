@@ -1,0 +1,156 @@
+"""GPU parity: the HIP engine (through the C ABI) against the CPU oracle and the reference dumps.
+
+Bar: bit-exact edge sets (integer work).  The exact path of the reference decides on two modular hashes
+(src/GraphCreators/GraphCreatorPrefSuf.cpp:386-387) where the engine compares 2-bit words exactly, so the
+two can differ only on a double hash collision (p ~ 1e-27 per pair).
+"""
+import numpy as np
+import pytest
+
+import alga_amd
+import gen_reads
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    e = alga_amd.Engine(0)
+    yield e
+    e.close()
+
+
+def _check(eng, words, lens, lo, rs, af=None, at=None, stats=True):
+    want, _, cnt = O.prefsuf(words, lens, lo, rs, af, at)
+    got = eng.prefsuf_host(words, lens, lo, rs, af, at, collect_stats=stats)
+    assert got.shape == want.shape, (got.shape, want.shape)
+    assert (got == want).all()
+    if stats:
+        st = eng.last_stats()
+        assert st["raw_overlaps"] == cnt["hash_equal"]
+        assert st["transitive_listed"] == cnt["transitive_checks"]
+        assert st["transitive_removed"] == cnt["transitive_removed"]
+        assert st["edges"] == len(want)
+    return got
+
+
+@pytest.mark.parametrize("name", O.FIXTURES)
+def test_golden_fixture_bit_exact(eng, golden_dir, name):
+    fx = O.Fixture(golden_dir, name)
+    try:
+        f1, f2 = fx.inputs()
+        lo, rs = fx.explicit_params()
+        nd = O.ingest(f1, f2, min_overlap=lo, rsoemo=rs)
+    finally:
+        fx.cleanup()
+    got = _check(eng, nd["words"], nd["len"], nd["min_overlap"], nd["rsoemo"])
+    assert O.graph_bytes(nd["n"], got) == fx.ref_graph()          # the reference's own dump, byte for byte
+
+
+def _nodes(n, length, G, seed, err=0.0, min_length=None, both_strands=True, stride=None):
+    codes, lens = gen_reads.sample_reads(n, length, G, seed, err, min_length)
+    if both_strands:  # node 2i = reverse complement, 2i+1 = forward, as the reference's input stage lays them out
+        rc = np.zeros_like(codes)
+        for i in range(n):
+            rc[i, : lens[i]] = 3 - codes[i, : lens[i]][::-1]
+        codes = np.stack([rc, codes], axis=1).reshape(2 * n, length)
+        lens = np.repeat(lens, 2)
+    return alga_amd.pack_reads(codes, lens, stride), lens.astype(np.int32)
+
+
+@pytest.mark.parametrize("n,length,G,seed,err,minlen,lo,rs", [
+    (3000, 100, 6000, 11, 0.0, None, 55, 77),
+    (3000, 150, 9000, 12, 0.01, None, 82, 116),
+    (2500, 150, 5000, 13, 0.0, 90, 70, 100),      # variable length, duplicates and prefix reads NOT removed
+    (2000, 64, 3000, 14, 0.0, None, 20, 40),      # W=4, short seed (40 bits)
+    (1500, 150, 3000, 15, 0.03, 120, 16, 60),     # one-word seed
+    (1200, 250, 6000, 16, 0.0, 200, 140, 190),    # W=16
+])
+def test_random_sets_bit_exact(eng, n, length, G, seed, err, minlen, lo, rs):
+    words, lens = _nodes(n, length, G, seed, err, minlen)
+    _check(eng, words, lens, lo, rs)
+
+
+def test_masks_and_removed_nodes(eng):
+    words, lens = _nodes(2500, 120, 5000, 21)
+    rng = np.random.default_rng(21)
+    af = (rng.random(len(lens)) < 0.7).astype(np.uint8)
+    at = (rng.random(len(lens)) < 0.7).astype(np.uint8)
+    dead = rng.random(len(lens)) < 0.1
+    lens = lens.copy(); lens[dead] = 0; words = words.copy(); words[dead] = 0
+    _check(eng, words, lens, 66, 90, af, at)
+
+
+def test_row_stride_padding(eng):
+    words, lens = _nodes(1500, 100, 3000, 22, stride=12)
+    assert words.shape[1] == 12
+    _check(eng, words, lens, 55, 77)
+
+
+def test_long_reads_cap_500(eng):
+    # reads longer than 500 nt: overlap lengths stop at 501 (GraphCreatorPrefSuf.cpp:92-100), several 64-window chunks
+    words, lens = _nodes(500, 640, 4000, 23, min_length=420)
+    _check(eng, words, lens, 300, 420)
+    _check(eng, words, lens, 120, 330)
+
+
+def test_rsoemo_outside_iteration_range(eng):
+    words, lens = _nodes(1500, 100, 3000, 24)
+    _check(eng, words, lens, 55, 40)       # rsoemo < min_overlap: no small phase at all
+    _check(eng, words, lens, 55, 55)       # reversal in the very first iteration
+    _check(eng, words, lens, 55, 101)      # rsoemo == last iteration (L = maxlen+1)
+    _check(eng, words, lens, 55, 150)      # never reversed mid-way: the reference hands back the reversed graph
+    _check(eng, words, lens, 55, 0)
+
+
+def test_degenerate_inputs(eng):
+    z = np.zeros((0, 4), np.uint32)
+    assert eng.prefsuf_host(z, np.zeros(0, np.int32), 55, 77).shape == (0, 3)
+    words, lens = _nodes(200, 60, 2000, 25)
+    assert eng.prefsuf_host(words, np.zeros_like(lens), 30, 40).shape == (0, 3)      # every node removed
+    _check(eng, words, lens, 61, 70)                                                   # min_overlap > every read
+    _check(eng, words, lens, 60, 60)                                                   # only full-length overlaps
+    # heavy repeats: 400 copies of 5 distinct reads (long seed-table chains, big in-lists, ties in the cap)
+    codes, l5 = gen_reads.sample_reads(5, 80, 120, 26)
+    codes = np.repeat(codes, 80, axis=0)
+    w = alga_amd.pack_reads(codes)
+    _check(eng, w, np.full(len(w), 80, np.int32), 40, 60)
+
+
+def test_invalid_arguments_are_errors(eng):
+    words, lens = _nodes(50, 60, 500, 27)
+    with pytest.raises(alga_amd.AlgaError):
+        eng.prefsuf_host(words, lens, 0, 10)
+    with pytest.raises(alga_amd.AlgaError):
+        eng.prefsuf_host(words[:, :2].copy(), lens, 30, 40)   # stride too small for the reads
+
+
+def test_device_resident_and_sharded_paths_agree(eng):
+    import torch
+    from alga_amd.engine import device_edges_to_numpy
+    words, lens = _nodes(4000, 150, 9000, 31, err=0.005)
+    want, _, _ = O.prefsuf(words, lens, 82, 116)
+    dw = torch.from_numpy(words.view(np.int32)).cuda()
+    dl = torch.from_numpy(lens).cuda()
+    ptr, m = eng.prefsuf_device(dw, dl, 82, 116)
+    got = device_edges_to_numpy(ptr, m)
+    assert (got == want).all()
+    # sharded: sources in 3 ranges, targets in 2 ranges, as the multi-GPU driver does it
+    n = len(lens)
+    recs = []
+    for a, b in ((0, n // 3), (n // 3, n // 2), (n // 2, n)):
+        d, s, o, k = eng.discover_device(dw, dl, 82, 116, a, b)
+        if k:
+            buf = torch.empty((3, k), dtype=torch.int32, device="cuda")
+            for j, p in enumerate((d, s, o)):
+                torch.cuda.cudart().cudaMemcpy(buf[j].data_ptr(), p, k * 4, 3)   # DeviceToDevice
+            recs.append(buf)
+    rec = torch.cat(recs, dim=1).contiguous()
+    parts = []
+    for a, b in ((0, n // 2 + 7), (n // 2 + 7, n)):
+        ptr, m = eng.reduce_device(dw, dl, 82, 116, rec[0], rec[1], rec[2], rec.shape[1], a, b)
+        parts.append(device_edges_to_numpy(ptr, m))
+    allp = np.concatenate(parts)
+    order = np.lexsort((allp[:, 2], allp[:, 1], allp[:, 0]))
+    assert (allp[order] == want).all()
