@@ -38,6 +38,7 @@ struct alga_engine {
     hipStream_t own_stream = nullptr;
     std::string err;
     char        dev_name[256] = {0};
+    int         n_cu = 256;
     hipEvent_t  ev[EV_COUNT] = {};
     // device buffers, grown on demand and kept between calls
     DevBuf table, counters, indeg, rowptr, rec_dst, rec_src, rec_ol, seg_src, seg_ol, out_cnt, outdeg, out_rowptr, edges, scan_scratch;
@@ -163,7 +164,8 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
     e->stats.table_slots = slots;
 
     const uint64_t n_src = (uint64_t) std::max<int64_t>(0, (int64_t) src_end - src_begin);
-    uint64_t cap = std::max<uint64_t>(e->rec_cap_hint, 16 * n_src + 4096);
+    const uint64_t slack = probe_record_slack(e->n_cu, n_src);            // invalid padding of the chunked record list
+    uint64_t cap = std::max<uint64_t>(e->rec_cap_hint, 16 * n_src + 4096) + slack;
     const int64_t n_owned = (int64_t) dst_end - dst_begin;
     for (int attempt = 0; attempt < 4; attempt++) {
         if (cap >= (1ull << 32) - 16) return fail(e, ALGA_ERR_CAPACITY, "more than 2^32 overlap records; shard the input");
@@ -174,10 +176,10 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
             if ((rc = ensure(e, e->indeg, (size_t) (n_owned + 1) * sizeof(uint32_t)))) return rc;
             HIP_TRY(e, hipMemsetAsync(e->indeg.p, 0, (size_t) (n_owned + 1) * sizeof(uint32_t), s));
         }
-        HIP_TRY(e, hipMemsetAsync(cnt + CNT_RECORDS, 0, 4 * sizeof(unsigned long long), s)); // RECORDS, RAW, WINDOWS, SLOTS
+        HIP_TRY(e, hipMemsetAsync(cnt, 0, CNT_TOTAL * sizeof(unsigned long long), s));
         launch_probe(nd, cfg, (const unsigned long long *) e->table.p, mask, src_begin, src_end, (uint32_t *) e->rec_dst.p,
                      (uint32_t *) e->rec_src.p, (uint32_t *) e->rec_ol.p, cap, fused_indeg ? (uint32_t *) e->indeg.p : nullptr,
-                     dst_begin, dst_end, cnt, s);
+                     dst_begin, dst_end, cnt, e->n_cu, s);
         if ((rc = check_launch(e, "k_probe_sources"))) return rc;
         HIP_TRY(e, hipEventRecord(e->ev[EV_PROBE], s));
         HIP_TRY(e, hipMemcpyAsync(e->h_counters, cnt, CNT_TOTAL * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
@@ -187,13 +189,13 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
             *n_rec = need;
             e->rec_cap_hint = std::max<uint64_t>(e->rec_cap_hint, need + need / 16 + 4096);
             e->last_records = need;
-            e->stats.records = need;
+            e->stats.records = e->h_counters[CNT_VALID_RECORDS];
             e->stats.raw_overlaps = e->h_counters[CNT_RAW];
             e->stats.windows_probed = e->h_counters[CNT_WINDOWS];
             e->stats.slots_scanned = e->h_counters[CNT_SLOTS];
             return ALGA_OK;
         }
-        cap = need + need / 16 + 4096; // the counter kept counting past the capacity: exact need is known
+        cap = need + need / 16 + 4096 + slack; // the cursor kept counting past the capacity: the need is known
     }
     return fail(e, ALGA_ERR_HIP, "record buffer kept overflowing");
 }
@@ -288,7 +290,10 @@ int alga_engine_create(int hip_device, alga_engine **out) {
     e->device = hip_device;
     memset(&e->stats, 0, sizeof(e->stats));
     hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, hip_device) == hipSuccess) snprintf(e->dev_name, sizeof(e->dev_name), "%s (%s)", prop.name, prop.gcnArchName);
+    if (hipGetDeviceProperties(&prop, hip_device) == hipSuccess) {
+        snprintf(e->dev_name, sizeof(e->dev_name), "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+        if (prop.multiProcessorCount > 0) e->n_cu = prop.multiProcessorCount;
+    }
     if (hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking) != hipSuccess) { delete e; return ALGA_ERR_HIP; }
     for (int i = 0; i < EV_COUNT; i++)
         if (hipEventCreate(&e->ev[i]) != hipSuccess) { delete e; return ALGA_ERR_HIP; }

@@ -44,6 +44,7 @@ ALGA_HD inline uint64_t fp_final(uint64_t h) {
     return h ^ (h >> 29);
 }
 
+constexpr uint32_t REC_INVALID = 0xFFFFFFFFu; // rec_dst marker: unused slot of a record chunk
 constexpr uint64_t SEED_EMPTY = ~0ull; // seed-table slot: (tag32 << 32) | node id ; empty = all ones
 
 // number of uint32 blocks that hold `len_nt` nucleotides (Bitset::blocks(), Bitset.h:206)
@@ -51,7 +52,7 @@ ALGA_HD inline int blocks_of(int len_nt) { return len_nt <= 0 ? 0 : ((2 * len_nt
 
 // device-side counters; index = enum below
 enum Counter {
-    CNT_RECORDS = 0,       // records appended by the probe kernel (may exceed capacity -> retry)
+    CNT_RECORDS = 0,       // record-list cursor (incl. invalid padding; may exceed capacity -> retry)
     CNT_RAW,               // verified raw overlaps
     CNT_WINDOWS,           // windows probed
     CNT_SLOTS,             // seed-table slots read
@@ -61,6 +62,7 @@ enum Counter {
     CNT_EDGES,             // final edges
     CNT_MAX_IN,            // max records per target
     CNT_LIVE_NODES,
+    CNT_VALID_RECORDS,     // records that carry an overlap
     CNT_TOTAL = 16
 };
 

@@ -13,7 +13,8 @@ void launch_node_stats(const NodesDev &nd, unsigned long long *counters, int *ma
 void launch_seed_build(const NodesDev &nd, const PrefSufCfg &cfg, unsigned long long *table, uint32_t mask, hipStream_t s);
 void launch_probe(const NodesDev &nd, const PrefSufCfg &cfg, const unsigned long long *table, uint32_t mask,
                   int32_t src_begin, int32_t src_end, uint32_t *rec_dst, uint32_t *rec_src, uint32_t *rec_ol, uint64_t rec_cap,
-                  uint32_t *indeg, int32_t dst_begin, int32_t dst_end, unsigned long long *counters, hipStream_t s);
+                  uint32_t *indeg, int32_t dst_begin, int32_t dst_end, unsigned long long *counters, int n_cu, hipStream_t s);
+uint64_t probe_record_slack(int n_cu, uint64_t n_src);
 void launch_count_targets(const uint32_t *rec_dst, uint64_t n_rec, int32_t dst_begin, int32_t dst_end, uint32_t *indeg, hipStream_t s);
 
 size_t   scan_scratch_bytes(uint64_t n);

@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 #include "prefsuf_common.h"
 #include "prefsuf_kernels.h"
+#include <algorithm>
 
 namespace alga {
 
@@ -117,10 +118,20 @@ __global__ void __launch_bounds__(256) k_seed_build(NodesDev nd, PrefSufCfg cfg,
 }
 
 // ------------------------------------------------------------------------------------------
-// k_probe_sources : one wavefront per source node B
+// k_probe_sources : persistent wavefronts, one source node B at a time per wavefront
+//
+//   * B's tail (<= 501 nt) is staged in the wave's LDS row; lane p owns suffix window p
+//   * records are collected in a per-wave LDS buffer and flushed with coalesced 64-lane stores
+//     into chunks of the global record list; a chunk is reserved with ONE global atomic
+//     (a returning atomic on one address sustains only ~88 ops/us chip-wide, so per-record or
+//     per-source reservations would cap the kernel at tens of milliseconds)
+//   * unused chunk tails are filled with REC_INVALID and skipped downstream
 // ------------------------------------------------------------------------------------------
-constexpr int PROBE_WAVES = 4;       // waves per workgroup
-constexpr int STAGE_WORDS = 36;      // (2*501+31)/32 + alignment slack + 1 zero word
+constexpr int PROBE_WAVES = 4;        // waves per workgroup
+constexpr int STAGE_WORDS = 36;       // (2*501+31)/32 + alignment slack + 1 zero word
+constexpr int WBUF = 256;             // per-wave LDS record buffer (records)
+constexpr int WFLUSH = 128;           // flush once this many are buffered
+constexpr int REC_CHUNK = 512;        // records reserved per global atomic
 
 __device__ __forceinline__ void top3_insert(uint64_t &a, uint64_t &b, uint64_t &c, uint64_t k) {
     if (k > a) { c = b; b = a; a = k; }
@@ -128,122 +139,177 @@ __device__ __forceinline__ void top3_insert(uint64_t &a, uint64_t &b, uint64_t &
     else if (k > c) { c = k; }
 }
 
+struct ProbeOut {
+    uint32_t *__restrict__ rec_dst, *__restrict__ rec_src, *__restrict__ rec_ol;
+    uint64_t rec_cap;
+    uint32_t *__restrict__ indeg;
+    int32_t dst_begin, dst_end;
+    unsigned long long *__restrict__ counters;
+};
+
+__device__ __forceinline__ void store_record(const ProbeOut &o, uint64_t idx, uint32_t C, uint32_t B, uint32_t ol) {
+    if (idx < o.rec_cap) { o.rec_dst[idx] = C; o.rec_src[idx] = B; o.rec_ol[idx] = ol; }
+    if (o.indeg && (int) C >= o.dst_begin && (int) C < o.dst_end) atomicAdd(&o.indeg[(int) C - o.dst_begin], 1u);
+}
+
+// Convergent: all 64 lanes.  Moves the wave's LDS buffer to the record list.
+__device__ __forceinline__ void flush_records(const ProbeOut &o, uint32_t *sC, uint32_t *sS, uint32_t *sO, uint32_t *sCnt,
+                                              uint64_t &chunk_base, int &chunk_fill) {
+    const int lane = lane_id();
+    int n = (int) __builtin_amdgcn_readfirstlane((int) *sCnt);
+    if (n > WBUF) n = WBUF;                      // the excess went out through the direct path
+    if (n == 0) return;
+    if (chunk_fill + n > REC_CHUNK) {
+        // close the current chunk: invalid markers in its tail
+        for (int i = chunk_fill + lane; i < REC_CHUNK; i += 64) {
+            const uint64_t idx = chunk_base + (uint64_t) i;
+            if (idx < o.rec_cap) o.rec_dst[idx] = REC_INVALID;
+        }
+        uint64_t base = 0;
+        if (lane == 0) base = atomicAdd(&o.counters[CNT_RECORDS], (unsigned long long) REC_CHUNK);
+        chunk_base = shfl_u64(base, 0);
+        chunk_fill = 0;
+    }
+    for (int i = lane; i < n; i += 64) store_record(o, chunk_base + (uint64_t) (chunk_fill + i), sC[i], sS[i], sO[i]);
+    chunk_fill += n;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (lane == 0) *sCnt = 0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
+
 template <bool STATS>
 __global__ void __launch_bounds__(PROBE_WAVES * 64)
 k_probe_sources(NodesDev nd, PrefSufCfg cfg, const unsigned long long *__restrict__ table, uint32_t mask,
-                int32_t src_begin, int32_t src_end,
-                uint32_t *__restrict__ rec_dst, uint32_t *__restrict__ rec_src, uint32_t *__restrict__ rec_ol,
-                uint64_t rec_cap, uint32_t *__restrict__ indeg, int32_t dst_begin, int32_t dst_end,
-                unsigned long long *__restrict__ counters) {
+                int32_t src_begin, int32_t src_end, ProbeOut o) {
     __shared__ uint32_t sB[PROBE_WAVES][STAGE_WORDS];
+    __shared__ uint32_t sRecC[PROBE_WAVES][WBUF];
+    __shared__ uint32_t sRecS[PROBE_WAVES][WBUF];
+    __shared__ uint32_t sRecO[PROBE_WAVES][WBUF];
+    __shared__ uint32_t sRecN[PROBE_WAVES];
     const int wave = (int) (threadIdx.x >> 6);
     const int lane = lane_id();
-    const int64_t Bl = (int64_t) src_begin + (int64_t) blockIdx.x * PROBE_WAVES + wave;
-    const int B = (int) Bl;
-    int lenB = 0;
-    bool active = false;
-    if (Bl < src_end) {
-        lenB = nd.len[B];
-        active = lenB >= cfg.Lmin && lenB > 0 && (!nd.from || nd.from[B]);
-    }
-    // stage the last Lspan nucleotides of B (all an overlap of length <= Lcap can touch)
-    const int Lspan = lenB < cfg.Lcap ? lenB : cfg.Lcap;
-    const int w0 = (2 * (lenB - Lspan)) >> 5;             // first staged word of the row
-    const int nwB = blocks_of(lenB) - w0;                  // staged words (<= 33)
-    if (active) {
-        const uint32_t *row = nd.words + (size_t) B * nd.stride;
-        if (lane < STAGE_WORDS) sB[wave][lane] = lane < nwB ? row[w0 + lane] : 0u;
-    }
-    __syncthreads();
-    if (!active) return;
+    uint32_t *sb = sB[wave];
+    uint32_t *sC = sRecC[wave], *sS = sRecS[wave], *sO = sRecO[wave], *sCnt = &sRecN[wave];
+    if (lane == 0) *sCnt = 0;
+    uint64_t chunk_base = 0;
+    int chunk_fill = REC_CHUNK;                            // "no chunk yet"
+    uint64_t st_raw = 0, st_slots = 0, st_win = 0, st_rec = 0;
+    const int64_t total_waves = (int64_t) gridDim.x * PROBE_WAVES;
 
-    const uint32_t *sb = sB[wave];
-    const int nwin = Lspan - cfg.Lmin + 1;                 // overlap lengths Lmin..Lspan
-    uint64_t k0 = 0, k1 = 0, k2 = 0;                       // per-lane top-3 small overlaps, key=(L<<32)|C
-    uint64_t st_raw = 0, st_slots = 0, st_win = 0;
+    for (int64_t Bl = (int64_t) src_begin + (int64_t) blockIdx.x * PROBE_WAVES + wave; Bl < src_end; Bl += total_waves) {
+        const int B = (int) Bl;
+        const int lenB = nd.len[B];
+        if (!(lenB >= cfg.Lmin && lenB > 0 && (!nd.from || nd.from[B]))) continue;      // wave-uniform
+        // stage the last Lspan nucleotides of B (all an overlap of length <= Lcap can touch)
+        const int Lspan = lenB < cfg.Lcap ? lenB : cfg.Lcap;
+        const int w0 = (2 * (lenB - Lspan)) >> 5;         // first staged word of the row
+        const int nwB = blocks_of(lenB) - w0;              // staged words (<= 33)
+        {
+            const uint32_t *row = nd.words + (size_t) B * nd.stride;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (lane < STAGE_WORDS) sb[lane] = lane < nwB ? row[w0 + lane] : 0u;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+        const int nwin = Lspan - cfg.Lmin + 1;             // overlap lengths Lmin..Lspan
+        uint64_t k0 = 0, k1 = 0, k2 = 0;                   // per-lane top-3 small overlaps, key=(L<<32)|C
 
-    for (int base = 0; base < nwin; base += 64) {
-        const int widx = base + lane;
-        if (widx < nwin) {
-            const int L = Lspan - widx;
-            const int off = lenB - L;                      // == offset of the edge B -> C
-            const int bit = 2 * off - 32 * w0;
-            const int q = bit >> 5, r = bit & 31;
-            uint64_t h = fp_init();
-            for (int k = 0; k < cfg.seed_words; k++) {
-                uint32_t w = funnel(sb[q + k], sb[q + k + 1], r);
-                if (k == cfg.seed_words - 1) w &= cfg.seed_last_mask;
-                h = fp_step(h, w);
-            }
-            h = fp_final(h);
-            const uint32_t tag = (uint32_t) (h >> 32);
-            uint32_t slot = (uint32_t) h & mask;
-            if (STATS) st_win++;
-            const int nwL = (2 * L + 31) >> 5;
-            const uint32_t lastmask = (2 * L & 31) ? ((1u << (2 * L & 31)) - 1u) : 0xFFFFFFFFu;
-            for (;;) {
-                const unsigned long long e = table[slot];
-                if (STATS) st_slots++;
-                if (e == SEED_EMPTY) break;
-                slot = (slot + 1) & mask;
-                if ((uint32_t) (e >> 32) != tag) continue;
-                const int C = (int) (uint32_t) e;
-                if (C == B) continue;                                      // GraphCreatorPrefSuf.cpp:386
-                if (nd.len[C] < L) continue;                               // prefix of length L must exist (:215)
-                // exact verification: B[off .. lenB) == C[0 .. L)
-                const uint32_t *rc = nd.words + (size_t) C * nd.stride;
-                bool ok = true;
-                for (int k = 0; k < nwL; k++) {
-                    uint32_t x = funnel(sb[q + k], sb[q + k + 1], r) ^ rc[k];
-                    if (k == nwL - 1) x &= lastmask;
-                    if (x) { ok = false; break; }
+        for (int base = 0; base < nwin; base += 64) {
+            const int widx = base + lane;
+            if (widx < nwin) {
+                const int L = Lspan - widx;
+                const int off = lenB - L;                  // == offset of the edge B -> C
+                const int bit = 2 * off - 32 * w0;
+                const int q = bit >> 5, r = bit & 31;
+                uint64_t h = fp_init();
+                for (int k = 0; k < cfg.seed_words; k++) {
+                    uint32_t w = funnel(sb[q + k], sb[q + k + 1], r);
+                    if (k == cfg.seed_words - 1) w &= cfg.seed_last_mask;
+                    h = fp_step(h, w);
                 }
-                if (!ok) continue;
-                if (STATS) st_raw++;
-                if (L < cfg.rsoemo) {
-                    top3_insert(k0, k1, k2, ((uint64_t) (uint32_t) L << 32) | (uint32_t) C);   // :397-401
-                } else {
-                    const uint64_t idx = wave_append(&counters[CNT_RECORDS]);
-                    if (idx < rec_cap) {
-                        rec_dst[idx] = (uint32_t) C; rec_src[idx] = (uint32_t) B; rec_ol[idx] = ol_pack(off, L, false);
+                h = fp_final(h);
+                const uint32_t tag = (uint32_t) (h >> 32);
+                uint32_t slot = (uint32_t) h & mask;
+                if (STATS) st_win++;
+                const int nwL = (2 * L + 31) >> 5;
+                const uint32_t lastmask = (2 * L & 31) ? ((1u << (2 * L & 31)) - 1u) : 0xFFFFFFFFu;
+                for (;;) {
+                    const unsigned long long e = table[slot];
+                    if (STATS) st_slots++;
+                    if (e == SEED_EMPTY) break;
+                    slot = (slot + 1) & mask;
+                    if ((uint32_t) (e >> 32) != tag) continue;
+                    const int C = (int) (uint32_t) e;
+                    if (C == B) continue;                                  // GraphCreatorPrefSuf.cpp:386
+                    if (nd.len[C] < L) continue;                           // a prefix of length L must exist (:215)
+                    // exact verification: B[off .. lenB) == C[0 .. L)
+                    const uint32_t *rc = nd.words + (size_t) C * nd.stride;
+                    bool ok = true;
+                    for (int k = 0; k < nwL; k++) {
+                        uint32_t x = funnel(sb[q + k], sb[q + k + 1], r) ^ rc[k];
+                        if (k == nwL - 1) x &= lastmask;
+                        if (x) { ok = false; break; }
                     }
-                    if (indeg && C >= dst_begin && C < dst_end) atomicAdd(&indeg[C - dst_begin], 1u);
+                    if (!ok) continue;
+                    if (STATS) st_raw++;
+                    if (L < cfg.rsoemo) {
+                        top3_insert(k0, k1, k2, ((uint64_t) (uint32_t) L << 32) | (uint32_t) C);   // :397-401
+                    } else {
+                        st_rec++;
+                        const uint32_t i = atomicAdd(sCnt, 1u);            // LDS atomic
+                        if (i < (uint32_t) WBUF) { sC[i] = (uint32_t) C; sS[i] = (uint32_t) B; sO[i] = ol_pack(off, L, false); }
+                        else {                                             // buffer full (heavy repeats): direct, slow path
+                            const uint64_t idx = atomicAdd(&o.counters[CNT_RECORDS], 1ull);
+                            store_record(o, idx, (uint32_t) C, (uint32_t) B, ol_pack(off, L, false));
+                        }
+                    }
                 }
             }
         }
-    }
-    // per-source small-overlap cap: the reference keeps the LAST `SOES`=3 pushes in (L asc, C asc)
-    // order (GraphCreatorPrefSuf.cpp:400-401) == the 3 largest (L, C) keys.
-    uint64_t win[3] = {0, 0, 0};
-    int nwon = 0;
+        // per-source small-overlap cap: the reference keeps the LAST `SOES`=3 pushes in (L asc, C asc)
+        // order (GraphCreatorPrefSuf.cpp:400-401) == the 3 largest (L, C) keys.
+        uint64_t win[3] = {0, 0, 0};
+        int nwon = 0;
 #pragma unroll
-    for (int rnd = 0; rnd < 3; rnd++) {
-        const uint64_t m = wave_max_u64(k0);
-        if (m == 0) break;
-        if (k0 == m) { k0 = k1; k1 = k2; k2 = 0; }
-        win[rnd] = m; nwon = rnd + 1;
-    }
-    if (nwon > 0) {
-        uint64_t base = 0;
-        if (lane == 0) base = atomicAdd(&counters[CNT_RECORDS], (unsigned long long) nwon);
-        base = shfl_u64(base, 0);
+        for (int rnd = 0; rnd < 3; rnd++) {
+            const uint64_t m = wave_max_u64(k0);
+            if (m == 0) break;
+            if (k0 == m) { k0 = k1; k1 = k2; k2 = 0; }
+            win[rnd] = m; nwon = rnd + 1;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        int nbuf = (int) __builtin_amdgcn_readfirstlane((int) *sCnt);
+        if (nbuf > WBUF) nbuf = WBUF;
+        if (nbuf + nwon > WBUF) {                           // make room (convergent)
+            flush_records(o, sC, sS, sO, sCnt, chunk_base, chunk_fill);
+            nbuf = 0;
+        }
         if (lane < nwon) {
             const uint64_t m = lane == 0 ? win[0] : (lane == 1 ? win[1] : win[2]);
             const int L = (int) (m >> 32);
-            const int C = (int) (uint32_t) m;
-            const uint64_t idx = base + (uint64_t) lane;
-            if (idx < rec_cap) {
-                rec_dst[idx] = (uint32_t) C; rec_src[idx] = (uint32_t) B; rec_ol[idx] = ol_pack(lenB - L, L, true);
-            }
-            if (indeg && C >= dst_begin && C < dst_end) atomicAdd(&indeg[C - dst_begin], 1u);
+            sC[nbuf + lane] = (uint32_t) m; sS[nbuf + lane] = (uint32_t) B; sO[nbuf + lane] = ol_pack(lenB - L, L, true);
+            st_rec++;
+        }
+        if (lane == 0) *sCnt = (uint32_t) (nbuf + nwon);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (nbuf + nwon >= WFLUSH) flush_records(o, sC, sS, sO, sCnt, chunk_base, chunk_fill);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    flush_records(o, sC, sS, sO, sCnt, chunk_base, chunk_fill);
+    // invalid markers in the unused tail of the wave's last chunk
+    if (chunk_fill < REC_CHUNK) {
+        for (int i = chunk_fill + lane; i < REC_CHUNK; i += 64) {
+            const uint64_t idx = chunk_base + (uint64_t) i;
+            if (idx < o.rec_cap) o.rec_dst[idx] = REC_INVALID;
         }
     }
+    st_rec = wave_sum_u64(st_rec);
+    if (lane == 0 && st_rec) atomicAdd(&o.counters[CNT_VALID_RECORDS], (unsigned long long) st_rec);
     if (STATS) {
         st_raw = wave_sum_u64(st_raw); st_slots = wave_sum_u64(st_slots); st_win = wave_sum_u64(st_win);
         if (lane == 0) {
-            atomicAdd(&counters[CNT_RAW], (unsigned long long) st_raw);
-            atomicAdd(&counters[CNT_SLOTS], (unsigned long long) st_slots);
-            atomicAdd(&counters[CNT_WINDOWS], (unsigned long long) st_win);
+            atomicAdd(&o.counters[CNT_RAW], (unsigned long long) st_raw);
+            atomicAdd(&o.counters[CNT_SLOTS], (unsigned long long) st_slots);
+            atomicAdd(&o.counters[CNT_WINDOWS], (unsigned long long) st_win);
         }
     }
 }
@@ -254,7 +320,9 @@ k_probe_sources(NodesDev nd, PrefSufCfg cfg, const unsigned long long *__restric
 __global__ void __launch_bounds__(256) k_count_targets(const uint32_t *__restrict__ rec_dst, uint64_t n_rec,
                                                         int32_t dst_begin, int32_t dst_end, uint32_t *__restrict__ indeg) {
     for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n_rec; i += (uint64_t) gridDim.x * blockDim.x) {
-        int C = (int) rec_dst[i];
+        const uint32_t c = rec_dst[i];
+        if (c == REC_INVALID) continue;
+        int C = (int) c;
         if (C >= dst_begin && C < dst_end) atomicAdd(&indeg[C - dst_begin], 1u);
     }
 }
@@ -349,7 +417,9 @@ __global__ void __launch_bounds__(256) k_scatter_by_target(const uint32_t *__res
     uint64_t n_rec = n_rec_ptr ? (uint64_t) *n_rec_ptr : n_rec_max;
     if (n_rec > n_rec_max) n_rec = n_rec_max;
     for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n_rec; i += (uint64_t) gridDim.x * blockDim.x) {
-        int C = (int) rec_dst[i];
+        const uint32_t c = rec_dst[i];
+        if (c == REC_INVALID) continue;
+        int C = (int) c;
         if (C < dst_begin || C >= dst_end) continue;
         C -= dst_begin;
         uint32_t pos = rowptr[C] + (atomicSub(&cursor[C], 1u) - 1u);
@@ -505,18 +575,24 @@ void launch_seed_build(const NodesDev &nd, const PrefSufCfg &cfg, unsigned long 
     hipLaunchKernelGGL(k_seed_build, dim3(grid_for((uint64_t) nd.n, 256)), dim3(256), 0, s, nd, cfg, table, mask);
 }
 
+static uint64_t probe_blocks(int n_cu, uint64_t n_src) {
+    // persistent grid: 8 workgroups of 4 waves per CU fill the 32 wave slots of a CU
+    return std::max<uint64_t>(1, std::min<uint64_t>((n_src + PROBE_WAVES - 1) / PROBE_WAVES, (uint64_t) std::max(1, n_cu) * 8));
+}
+
 void launch_probe(const NodesDev &nd, const PrefSufCfg &cfg, const unsigned long long *table, uint32_t mask,
                   int32_t src_begin, int32_t src_end, uint32_t *rec_dst, uint32_t *rec_src, uint32_t *rec_ol, uint64_t rec_cap,
-                  uint32_t *indeg, int32_t dst_begin, int32_t dst_end, unsigned long long *counters, hipStream_t s) {
+                  uint32_t *indeg, int32_t dst_begin, int32_t dst_end, unsigned long long *counters, int n_cu, hipStream_t s) {
     const int64_t ns = (int64_t) src_end - src_begin;
     if (ns <= 0) return;
-    dim3 grid(grid_for((uint64_t) ns, PROBE_WAVES)), block(PROBE_WAVES * 64);
-    if (cfg.stats)
-        hipLaunchKernelGGL(k_probe_sources<true>, grid, block, 0, s, nd, cfg, table, mask, src_begin, src_end, rec_dst, rec_src, rec_ol,
-                           rec_cap, indeg, dst_begin, dst_end, counters);
-    else
-        hipLaunchKernelGGL(k_probe_sources<false>, grid, block, 0, s, nd, cfg, table, mask, src_begin, src_end, rec_dst, rec_src, rec_ol,
-                           rec_cap, indeg, dst_begin, dst_end, counters);
+    dim3 grid((unsigned) probe_blocks(n_cu, (uint64_t) ns)), block(PROBE_WAVES * 64);
+    ProbeOut o{rec_dst, rec_src, rec_ol, rec_cap, indeg, dst_begin, dst_end, counters};
+    if (cfg.stats) hipLaunchKernelGGL(k_probe_sources<true>, grid, block, 0, s, nd, cfg, table, mask, src_begin, src_end, o);
+    else           hipLaunchKernelGGL(k_probe_sources<false>, grid, block, 0, s, nd, cfg, table, mask, src_begin, src_end, o);
+}
+
+uint64_t probe_record_slack(int n_cu, uint64_t n_src) {  // worst-case invalid padding of one launch
+    return probe_blocks(n_cu, n_src) * PROBE_WAVES * REC_CHUNK;
 }
 
 void launch_count_targets(const uint32_t *rec_dst, uint64_t n_rec, int32_t dst_begin, int32_t dst_end, uint32_t *indeg, hipStream_t s) {

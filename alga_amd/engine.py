@@ -61,6 +61,13 @@ def load_library():
     if _LIB is not None:
         return _LIB
     path = library_path()
+    # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64.so.7 / libhsa-runtime64.  If the
+    # system copy under /opt/rocm is initialised first, torch's copy later finds "No HIP GPUs".  Importing
+    # torch first makes the loader resolve this library's NEEDED libamdhip64.so.7 to the copy already mapped.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(path):
         raise AlgaError(-2, "HIP extension %s is not built (run `python -c 'import __graft_entry__ as g; g.build()'`)" % path)
     lib = C.CDLL(path)
@@ -247,13 +254,23 @@ class Engine:
             raise AlgaError(rc, "alga_write_graph(%s) failed" % path)
 
 
-def device_edges_to_numpy(ptr, n_edges):
-    """Copy an engine-owned device edge list to host (uses torch only as a memcpy)."""
+class _DevArray:
+    """Zero-copy view of engine-owned device memory for torch (via __cuda_array_interface__)."""
+
+    def __init__(self, ptr, shape, typestr="<i4"):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+def device_view(ptr, shape, device=None):
+    """torch int32 tensor aliasing `ptr` (no copy).  Valid until the engine reuses the buffer."""
     import torch
+    if int(np.prod(shape)) == 0:
+        return torch.empty(tuple(shape), dtype=torch.int32, device=device or "cuda")
+    return torch.as_tensor(_DevArray(ptr, shape), device=device or "cuda")
+
+
+def device_edges_to_numpy(ptr, n_edges):
+    """Copy an engine-owned device edge list to host (torch is only the memcpy)."""
     if n_edges == 0:
         return np.zeros((0, 3), np.int32)
-    out = torch.empty((n_edges, 3), dtype=torch.int32, device="cpu").pin_memory()
-    rc = torch.cuda.cudart().cudaMemcpy(out.data_ptr(), ptr, n_edges * 12, 2)  # 2 = DeviceToHost
-    if int(rc) != 0:
-        raise AlgaError(-3, "cudaMemcpy D2H failed: %s" % rc)
-    return out.numpy().copy()
+    return device_view(ptr, (n_edges, 3)).cpu().numpy().copy()

@@ -1,0 +1,109 @@
+"""Synthetic workloads for bench.py and the full-size tests (SURVEY.md section 8(d) generator).
+
+`make_nodes` reproduces, with numpy, what the reference's input stages hand to the graph creator for
+FIXED-LENGTH error-free or noisy reads without N: trim 3 nt per side (src/IO/InputReader.cpp:298-303),
+reverse-complement doubling with node 2i = revcomp / 2i+1 = forward (:78-80, :363-377), removal of duplicate
+reads together with their twins (src/IO/ReadPreprocess.cpp:13-77: of identical sequences the one with the
+largest id survives) and id compaction (src/main.cpp:150-232).  tests/test_workload_cpu.py checks it node for
+node against the oracle's literal ingest of the same reads written as FASTA.
+"""
+import os
+import sys
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(os.path.dirname(_HERE), "tools"))
+import gen_reads  # noqa: E402
+
+from .engine import pack_reads, derive_params  # noqa: E402
+
+CONFIGS = {
+    # name: (reads, read length, genome length, seed, substitution rate)      BASELINE.json configs[0..4]
+    "cfg1_10k_100bp": (10_000, 100, 20_000, 1, 0.0),
+    "cfg2_1M_150bp": (1_000_000, 150, 3_000_000, 3, 0.0),
+    "cfg3_5M_150bp": (5_000_000, 150, 4_600_000, 7, 0.0),
+    "cfg4_50M_150bp": (50_000_000, 150, 250_000_000, 11, 0.0),
+    "cfg5_10M_150bp_err2": (10_000_000, 150, 30_000_000, 13, 0.02),
+}
+
+
+def min_period_le(codes, thr=20):
+    """rows whose minimal period is <= thr (the reference drops them as STR reads, InputReader.cpp:341-354)."""
+    n, m = codes.shape
+    out = np.zeros(n, dtype=bool)
+    for p in range(1, thr + 1):
+        out |= (codes[:, p:] == codes[:, :-p]).all(axis=1)
+    return out
+
+
+def make_nodes(codes, trim=3, stride_words=None):
+    """codes[n, L] uint8 (A0 C1 G2 T3) as sampled -> (words[N, stride] u32, lens[N] i32, kept_read_ids)."""
+    n, L = codes.shape
+    if trim and L >= 2 * trim + 10:
+        codes = codes[:, trim: L - trim]
+    m = codes.shape[1]
+    keep = ~min_period_le(codes)
+    rc = (3 - codes)[:, ::-1]
+    fw = pack_reads(codes)
+    rv = pack_reads(rc)
+    # canonical key = lexicographically smaller of (forward, revcomp) words as bytes: reads with the same key
+    # are duplicates of each other on one strand or the other; the reference keeps the one with the largest id
+    W = fw.shape[1]
+    # compare as big-endian byte strings: any total order works as long as it is the same for both strands
+    lt = np.zeros(n, dtype=bool)
+    fbytes = fw.view(np.uint8).reshape(n, 4 * W)
+    rbytes = rv.view(np.uint8).reshape(n, 4 * W)
+    diff = fbytes != rbytes
+    first = diff.argmax(axis=1)
+    anyd = diff.any(axis=1)
+    idx = np.arange(n)
+    lt[anyd] = fbytes[idx[anyd], first[anyd]] < rbytes[idx[anyd], first[anyd]]
+    canon = np.where(lt[:, None], fw, rv)
+    palin = ~anyd                                   # read == its own reverse complement: the reference loses both nodes
+    cb = np.ascontiguousarray(canon).view(np.dtype((np.void, 4 * W))).ravel()
+    valid = np.flatnonzero(keep)                    # STR reads are nullptr before the sort and never take part
+    cbk = cb[valid]
+    o = np.argsort(cbk, kind="stable")
+    s = cbk[o]
+    last = np.ones(len(valid), dtype=bool)
+    last[:-1] = s[1:] != s[:-1]
+    survivors = np.zeros(n, dtype=bool)
+    survivors[valid[o[last]]] = True
+    survivors &= ~palin
+    ids = np.flatnonzero(survivors)
+    N = 2 * len(ids)
+    if stride_words is None:
+        stride_words = W
+    words = np.zeros((N, stride_words), dtype=np.uint32)
+    words[0::2, :W] = rv[ids]
+    words[1::2, :W] = fw[ids]
+    lens = np.full(N, m, dtype=np.int32)
+    return words, lens, ids
+
+
+def build(config, scale=1, stride_words=None):
+    """-> dict(words, lens, n_reads, read_len, min_overlap, rsoemo, name).  `scale` multiplies reads AND genome
+    (coverage fixed): the weak-scaling workload for `scale` GPUs."""
+    n, L, G, seed, err = CONFIGS[config]
+    n, G = n * scale, G * scale
+    codes, _ = gen_reads.sample_reads(n, L, G, seed, err)
+    words, lens, ids = make_nodes(codes, stride_words=stride_words)
+    lo, rs = derive_params(float(L - 6))
+    return dict(words=words, lens=lens, n_reads=n, read_len=L, genome=G, seed=seed, err=err, min_overlap=lo, rsoemo=rs,
+                name=config, codes=codes, kept=ids)
+
+
+def write_fasta_fast(path, codes):
+    """one record per read, fixed-width header, vectorised (150 MB/s-ish)."""
+    n, L = codes.shape
+    hdr = np.frombuffer((">r%09d\n" % 0).encode(), dtype=np.uint8)
+    H = len(hdr)
+    rec = np.empty((n, H + L + 1), dtype=np.uint8)
+    rec[:, :H] = hdr
+    digits = np.arange(n)[:, None] // (10 ** np.arange(8, -1, -1))[None, :] % 10
+    rec[:, 2:11] = (digits + 48).astype(np.uint8)
+    rec[:, H:H + L] = np.frombuffer(b"ACGT", dtype=np.uint8)[codes]
+    rec[:, H + L] = 10
+    with open(path, "wb") as f:
+        f.write(rec.tobytes())

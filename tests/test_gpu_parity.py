@@ -128,7 +128,7 @@ def test_invalid_arguments_are_errors(eng):
 
 def test_device_resident_and_sharded_paths_agree(eng):
     import torch
-    from alga_amd.engine import device_edges_to_numpy
+    from alga_amd.engine import device_edges_to_numpy, device_view
     words, lens = _nodes(4000, 150, 9000, 31, err=0.005)
     want, _, _ = O.prefsuf(words, lens, 82, 116)
     dw = torch.from_numpy(words.view(np.int32)).cuda()
@@ -142,10 +142,7 @@ def test_device_resident_and_sharded_paths_agree(eng):
     for a, b in ((0, n // 3), (n // 3, n // 2), (n // 2, n)):
         d, s, o, k = eng.discover_device(dw, dl, 82, 116, a, b)
         if k:
-            buf = torch.empty((3, k), dtype=torch.int32, device="cuda")
-            for j, p in enumerate((d, s, o)):
-                torch.cuda.cudart().cudaMemcpy(buf[j].data_ptr(), p, k * 4, 3)   # DeviceToDevice
-            recs.append(buf)
+            recs.append(torch.stack([device_view(p, (k,)) for p in (d, s, o)]).clone())   # incl. invalid padding
     rec = torch.cat(recs, dim=1).contiguous()
     parts = []
     for a, b in ((0, n // 2 + 7), (n // 2 + 7, n)):
