@@ -39,13 +39,15 @@ struct alga_engine {
     std::string err;
     char        dev_name[256] = {0};
     int         n_cu = 256;
+    int         seed_fill_x10 = 20;
+    int         use_filter = 1;               // L2-resident fingerprint bitmap in front of the seed table (ALGA_SEED_FILTER=0 disables)           // average seed-table bucket fill x10 (tunable: ALGA_SEED_FILL_X10)
     hipEvent_t  ev[EV_COUNT] = {};
     // device buffers, grown on demand and kept between calls
-    DevBuf table, counters, indeg, rowptr, rec_dst, rec_src, rec_ol, seg_src, seg_ol, out_cnt, outdeg, out_rowptr, edges, scan_scratch;
+    DevBuf table, filter, counters, rowptr, rec_dst, rec_val, keys, seg_key, seg_val, sort_temp, out_cnt, outdeg, out_rowptr, edges, scan_scratch;
+    DevBuf edge_keys, edge_keys2, edge_vals, edge_vals2, edges_sorted;
     DevBuf up_words, up_len, up_from, up_to;   // uploads of the host-buffer entry point
     unsigned long long *h_counters = nullptr;  // pinned, CNT_TOTAL + 2 entries
     uint64_t    rec_cap_hint = 0;
-    uint64_t    last_records = 0;
     alga_prefsuf_stats stats;
 };
 
@@ -136,50 +138,39 @@ int prepare(alga_engine *e, const alga_nodes *nodes, const alga_prefsuf_params *
     return ALGA_OK;
 }
 
-uint32_t table_slots_for(uint64_t live) {
-    uint64_t want = std::max<uint64_t>(2 * live, 1024);
-    uint64_t s = 1024;
-    while (s < want) s <<= 1;
-    return (uint32_t) std::min<uint64_t>(s, 1ull << 31);
-}
-
-// seed + probe.  On return the record arrays hold *n_rec records; if `fused_indeg`, e->indeg holds the
-// in-degree of every target in [dst_begin, dst_end).
-int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t src_end, bool fused_indeg,
-                  int32_t dst_begin, int32_t dst_end, hipStream_t s, uint64_t *n_rec) {
+// seed + probe.  On return e->rec_dst / e->rec_val hold *n_rec record slots (chunk padding included).
+int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t src_end, hipStream_t s, uint64_t *n_rec) {
     int rc;
     const NodesDev &nd = pp.nd;
     const PrefSufCfg &cfg = pp.cfg;
     unsigned long long *cnt = (unsigned long long *) e->counters.p;
     *n_rec = 0;
     HIP_TRY(e, hipEventRecord(e->ev[EV_START], s));
-    if (pp.live >= (1ull << 30)) return fail(e, ALGA_ERR_CAPACITY, "too many nodes for one seed table; shard the input");
-    const uint32_t slots = table_slots_for(pp.live);
-    const uint32_t mask = slots - 1;
-    if ((rc = ensure(e, e->table, (size_t) slots * sizeof(unsigned long long)))) return rc;
-    HIP_TRY(e, hipMemsetAsync(e->table.p, 0xFF, (size_t) slots * sizeof(unsigned long long), s));
-    launch_seed_build(nd, cfg, (unsigned long long *) e->table.p, mask, s);
+    if (pp.live >= (1ull << 31)) return fail(e, ALGA_ERR_CAPACITY, "too many nodes for one seed table; shard the input");
+    const uint32_t n_buckets = seed_buckets_for(pp.live, e->seed_fill_x10);
+    const size_t table_bytes = (size_t) n_buckets * SEED_BUCKET * sizeof(unsigned long long);
+    if ((rc = ensure(e, e->table, table_bytes))) return rc;
+    HIP_TRY(e, hipMemsetAsync(e->table.p, 0xFF, table_bytes, s));
+    uint32_t filter_bits = e->use_filter ? seed_filter_bits_for(pp.live) : 0;
+    if (filter_bits) {
+        if ((rc = ensure(e, e->filter, filter_bits / 8))) return rc;
+        HIP_TRY(e, hipMemsetAsync(e->filter.p, 0, filter_bits / 8, s));
+    }
+    launch_seed_build(nd, cfg, (unsigned long long *) e->table.p, n_buckets, (uint32_t *) e->filter.p, filter_bits, s);
     if ((rc = check_launch(e, "k_seed_build"))) return rc;
     HIP_TRY(e, hipEventRecord(e->ev[EV_SEED], s));
-    e->stats.table_slots = slots;
+    e->stats.table_slots = (uint64_t) n_buckets * SEED_BUCKET;
 
     const uint64_t n_src = (uint64_t) std::max<int64_t>(0, (int64_t) src_end - src_begin);
     const uint64_t slack = probe_record_slack(e->n_cu, n_src);            // invalid padding of the chunked record list
     uint64_t cap = std::max<uint64_t>(e->rec_cap_hint, 16 * n_src + 4096) + slack;
-    const int64_t n_owned = (int64_t) dst_end - dst_begin;
     for (int attempt = 0; attempt < 4; attempt++) {
         if (cap >= (1ull << 32) - 16) return fail(e, ALGA_ERR_CAPACITY, "more than 2^32 overlap records; shard the input");
         if ((rc = ensure(e, e->rec_dst, cap * sizeof(uint32_t)))) return rc;
-        if ((rc = ensure(e, e->rec_src, cap * sizeof(uint32_t)))) return rc;
-        if ((rc = ensure(e, e->rec_ol, cap * sizeof(uint32_t)))) return rc;
-        if (fused_indeg) {
-            if ((rc = ensure(e, e->indeg, (size_t) (n_owned + 1) * sizeof(uint32_t)))) return rc;
-            HIP_TRY(e, hipMemsetAsync(e->indeg.p, 0, (size_t) (n_owned + 1) * sizeof(uint32_t), s));
-        }
+        if ((rc = ensure(e, e->rec_val, cap * sizeof(unsigned long long)))) return rc;
         HIP_TRY(e, hipMemsetAsync(cnt, 0, CNT_TOTAL * sizeof(unsigned long long), s));
-        launch_probe(nd, cfg, (const unsigned long long *) e->table.p, mask, src_begin, src_end, (uint32_t *) e->rec_dst.p,
-                     (uint32_t *) e->rec_src.p, (uint32_t *) e->rec_ol.p, cap, fused_indeg ? (uint32_t *) e->indeg.p : nullptr,
-                     dst_begin, dst_end, cnt, e->n_cu, s);
+        launch_probe(nd, cfg, (const unsigned long long *) e->table.p, n_buckets, (const uint32_t *) e->filter.p, filter_bits, src_begin, src_end, (uint32_t *) e->rec_dst.p,
+                     (unsigned long long *) e->rec_val.p, cap, cnt, e->n_cu, s);
         if ((rc = check_launch(e, "k_probe_sources"))) return rc;
         HIP_TRY(e, hipEventRecord(e->ev[EV_PROBE], s));
         HIP_TRY(e, hipMemcpyAsync(e->h_counters, cnt, CNT_TOTAL * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
@@ -188,7 +179,6 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
         if (need <= cap) {
             *n_rec = need;
             e->rec_cap_hint = std::max<uint64_t>(e->rec_cap_hint, need + need / 16 + 4096);
-            e->last_records = need;
             e->stats.records = e->h_counters[CNT_VALID_RECORDS];
             e->stats.raw_overlaps = e->h_counters[CNT_RAW];
             e->stats.windows_probed = e->h_counters[CNT_WINDOWS];
@@ -200,9 +190,15 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
     return fail(e, ALGA_ERR_HIP, "record buffer kept overflowing");
 }
 
-// group + reduce + emit for the targets in [dst_begin, dst_end)
-int reduce_impl(alga_engine *e, const Prepared &pp, const uint32_t *rec_dst, const uint32_t *rec_src, const uint32_t *rec_ol,
-                uint64_t n_rec, bool indeg_ready, int32_t dst_begin, int32_t dst_end, hipStream_t s, uint64_t *n_edges) {
+int key_bits_for(int64_t n_owned) {   // valid keys are < n_owned; the invalid key (all ones) must sort behind them
+    int b = 1;
+    while (b < 31 && (1ll << b) < n_owned) b++;
+    return std::min(32, b + 1);
+}
+
+// group (sort by target) + reduce + emit for the targets in [dst_begin, dst_end)
+int reduce_impl(alga_engine *e, const Prepared &pp, const uint32_t *rec_dst, const unsigned long long *rec_val, uint64_t n_rec,
+                uint64_t n_valid_hint, int32_t dst_begin, int32_t dst_end, hipStream_t s, uint64_t *n_edges) {
     int rc;
     const NodesDev &nd = pp.nd;
     const PrefSufCfg &cfg = pp.cfg;
@@ -210,32 +206,32 @@ int reduce_impl(alga_engine *e, const Prepared &pp, const uint32_t *rec_dst, con
     const int32_t n_owned = dst_end - dst_begin;
     *n_edges = 0;
     if (n_rec >= (1ull << 32) - 16) return fail(e, ALGA_ERR_CAPACITY, "more than 2^32 overlap records; shard the input");
-    if ((rc = ensure(e, e->indeg, (size_t) (n_owned + 1) * sizeof(uint32_t)))) return rc;
-    if (!indeg_ready) {
-        HIP_TRY(e, hipMemsetAsync(e->indeg.p, 0, (size_t) (n_owned + 1) * sizeof(uint32_t), s));
-        launch_count_targets(rec_dst, n_rec, dst_begin, dst_end, (uint32_t *) e->indeg.p, s);
-        if ((rc = check_launch(e, "k_count_targets"))) return rc;
-    }
-    const size_t scratch = std::max(scan_scratch_bytes((uint64_t) n_owned), scan_scratch_bytes((uint64_t) nd.n));
-    if ((rc = ensure(e, e->scan_scratch, scratch))) return rc;
-    if ((rc = ensure(e, e->rowptr, (size_t) (n_owned + 1) * sizeof(uint32_t)))) return rc;
-    launch_exclusive_scan((const uint32_t *) e->indeg.p, (uint64_t) n_owned, (uint32_t *) e->rowptr.p, (uint64_t *) e->scan_scratch.p, s);
-    if ((rc = check_launch(e, "scan(indeg)"))) return rc;
-    if ((rc = ensure(e, e->seg_src, (size_t) (n_rec + 1) * sizeof(uint32_t)))) return rc;
-    if ((rc = ensure(e, e->seg_ol, (size_t) (n_rec + 1) * sizeof(uint32_t)))) return rc;
-    launch_scatter_by_target(rec_dst, rec_src, rec_ol, nullptr, n_rec, dst_begin, dst_end, (const uint32_t *) e->rowptr.p,
-                             (uint32_t *) e->indeg.p, (uint32_t *) e->seg_src.p, (uint32_t *) e->seg_ol.p, s);
-    if ((rc = check_launch(e, "k_scatter_by_target"))) return rc;
+    const int bits = key_bits_for(n_owned);
+    const size_t temp_bytes = sort_records_temp_bytes(n_rec, bits);
+    if ((rc = ensure(e, e->keys, (size_t) (n_rec + 1) * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(e, e->seg_key, (size_t) (n_rec + 1) * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(e, e->seg_val, (size_t) (n_rec + 1) * sizeof(unsigned long long)))) return rc;
+    if ((rc = ensure(e, e->sort_temp, temp_bytes))) return rc;
+    if ((rc = ensure(e, e->rowptr, (size_t) (n_owned + 2) * sizeof(uint32_t)))) return rc;
+    HIP_TRY(e, hipMemsetAsync(cnt + CNT_SORT_VALID, 0, sizeof(unsigned long long), s));
+    launch_make_keys(rec_dst, n_rec, dst_begin, dst_end, (uint32_t *) e->keys.p, cnt + CNT_SORT_VALID, s);
+    if ((rc = check_launch(e, "k_make_keys"))) return rc;
+    HIP_TRY(e, sort_records(e->sort_temp.p, temp_bytes, (const uint32_t *) e->keys.p, (uint32_t *) e->seg_key.p, rec_val,
+                            (unsigned long long *) e->seg_val.p, n_rec, bits, s));
+    launch_rowptr_from_sorted((const uint32_t *) e->seg_key.p, cnt + CNT_SORT_VALID, n_rec, n_owned, (uint32_t *) e->rowptr.p, s);
+    if ((rc = check_launch(e, "k_rowptr_from_sorted"))) return rc;
     HIP_TRY(e, hipEventRecord(e->ev[EV_GROUP], s));
 
     if ((rc = ensure(e, e->out_cnt, (size_t) (n_owned + 1) * sizeof(uint32_t)))) return rc;
     if ((rc = ensure(e, e->outdeg, (size_t) (nd.n + 1) * sizeof(uint32_t)))) return rc;
     HIP_TRY(e, hipMemsetAsync(e->outdeg.p, 0, (size_t) (nd.n + 1) * sizeof(uint32_t), s));
-    launch_reduce_targets(nd, cfg, dst_begin, n_owned, (const uint32_t *) e->rowptr.p, (uint32_t *) e->seg_src.p, (uint32_t *) e->seg_ol.p,
+    const int tpb = reduce_targets_per_block(n_valid_hint, (uint64_t) std::max(1, n_owned));
+    launch_reduce_targets(nd, cfg, dst_begin, n_owned, tpb, (const uint32_t *) e->rowptr.p, (unsigned long long *) e->seg_val.p,
                           (uint32_t *) e->out_cnt.p, (uint32_t *) e->outdeg.p, cnt, s);
     if ((rc = check_launch(e, "k_reduce_targets"))) return rc;
     HIP_TRY(e, hipEventRecord(e->ev[EV_REDUCE], s));
 
+    if ((rc = ensure(e, e->scan_scratch, scan_scratch_bytes((uint64_t) nd.n)))) return rc;
     if ((rc = ensure(e, e->out_rowptr, (size_t) (nd.n + 1) * sizeof(uint32_t)))) return rc;
     launch_exclusive_scan((const uint32_t *) e->outdeg.p, (uint64_t) nd.n, (uint32_t *) e->out_rowptr.p, (uint64_t *) e->scan_scratch.p, s);
     if ((rc = check_launch(e, "scan(outdeg)"))) return rc;
@@ -246,9 +242,9 @@ int reduce_impl(alga_engine *e, const Prepared &pp, const uint32_t *rec_dst, con
     const uint64_t E = e->h_counters[CNT_TOTAL];
     if (E >= (1ull << 32) - 16) return fail(e, ALGA_ERR_CAPACITY, "more than 2^32 edges; shard the input");
     if ((rc = ensure(e, e->edges, (size_t) (E + 1) * sizeof(alga_edge_dev)))) return rc;
-    launch_scatter_by_source(cfg, dst_begin, n_owned, (const uint32_t *) e->rowptr.p, (const uint32_t *) e->seg_src.p,
-                             (const uint32_t *) e->seg_ol.p, (const uint32_t *) e->out_cnt.p, (const uint32_t *) e->out_rowptr.p,
-                             (uint32_t *) e->outdeg.p, (alga_edge_dev *) e->edges.p, s);
+    launch_scatter_by_source(cfg, dst_begin, n_owned, (const uint32_t *) e->rowptr.p, (const unsigned long long *) e->seg_val.p,
+                             (const uint32_t *) e->out_cnt.p, (const uint32_t *) e->out_rowptr.p, (uint32_t *) e->outdeg.p,
+                             (alga_edge_dev *) e->edges.p, s);
     if ((rc = check_launch(e, "k_scatter_by_source"))) return rc;
     launch_sort_rows(nd.n, (const uint32_t *) e->out_rowptr.p, (alga_edge_dev *) e->edges.p, s);
     if ((rc = check_launch(e, "k_sort_rows"))) return rc;
@@ -288,6 +284,8 @@ int alga_engine_create(int hip_device, alga_engine **out) {
     if (hipSetDevice(hip_device) != hipSuccess) return ALGA_ERR_NO_DEVICE;
     alga_engine *e = new alga_engine();
     e->device = hip_device;
+    if (const char *v = getenv("ALGA_SEED_FILL_X10")) e->seed_fill_x10 = atoi(v);
+    if (const char *v = getenv("ALGA_SEED_FILTER")) e->use_filter = atoi(v);
     memset(&e->stats, 0, sizeof(e->stats));
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, hip_device) == hipSuccess) {
@@ -306,8 +304,9 @@ void alga_engine_destroy(alga_engine *e) {
     if (!e) return;
     (void) hipSetDevice(e->device);
     if (e->own_stream) (void) hipStreamSynchronize(e->own_stream);
-    DevBuf *bufs[] = {&e->table, &e->counters, &e->indeg, &e->rowptr, &e->rec_dst, &e->rec_src, &e->rec_ol, &e->seg_src, &e->seg_ol,
-                      &e->out_cnt, &e->outdeg, &e->out_rowptr, &e->edges, &e->scan_scratch, &e->up_words, &e->up_len, &e->up_from, &e->up_to};
+    DevBuf *bufs[] = {&e->table, &e->filter, &e->counters, &e->rowptr, &e->rec_dst, &e->rec_val, &e->keys, &e->seg_key, &e->seg_val, &e->sort_temp,
+                      &e->out_cnt, &e->outdeg, &e->out_rowptr, &e->edges, &e->scan_scratch, &e->up_words, &e->up_len, &e->up_from, &e->up_to,
+                      &e->edge_keys, &e->edge_keys2, &e->edge_vals, &e->edge_vals2, &e->edges_sorted};
     for (DevBuf *b : bufs) release(*b);
     if (e->h_counters) (void) hipHostFree(e->h_counters);
     for (int i = 0; i < EV_COUNT; i++) if (e->ev[i]) (void) hipEventDestroy(e->ev[i]);
@@ -347,8 +346,8 @@ int alga_prefsuf_build_device(alga_engine *e, const alga_nodes *nodes, const alg
     if (rc) return rc;
     e->stats.nodes_live = pp.live;
     uint64_t n_rec = 0, E = 0;
-    if ((rc = discover_impl(e, pp, 0, nodes->n, true, 0, nodes->n, s, &n_rec))) return rc;
-    if ((rc = reduce_impl(e, pp, (const uint32_t *) e->rec_dst.p, (const uint32_t *) e->rec_src.p, (const uint32_t *) e->rec_ol.p, n_rec, true,
+    if ((rc = discover_impl(e, pp, 0, nodes->n, s, &n_rec))) return rc;
+    if ((rc = reduce_impl(e, pp, (const uint32_t *) e->rec_dst.p, (const unsigned long long *) e->rec_val.p, n_rec, e->stats.records,
                           0, nodes->n, s, &E))) return rc;
     e->stats.ms_seed = ev_ms(e, EV_START, EV_SEED);
     e->stats.ms_probe = ev_ms(e, EV_SEED, EV_PROBE);
@@ -373,14 +372,25 @@ int alga_prefsuf_build_host(alga_engine *e, const alga_nodes *nodes, const alga_
     hipStream_t s = e->own_stream;
     int rc;
     const size_t n = (size_t) nodes->n;
-    const size_t wbytes = n * (size_t) nodes->stride_words * sizeof(uint32_t);
+    {   // the caller's rows must hold the caller's reads (checked here: the upload below changes the stride)
+        int32_t max_len = 0;
+        for (size_t i = 0; i < n; i++) max_len = std::max(max_len, nodes->len[i]);
+        if ((int64_t) blocks_of(max_len) > (int64_t) nodes->stride_words)
+            return fail(e, ALGA_ERR_INVALID_ARGUMENT, "stride_words is smaller than the longest read needs");
+    }
+    // rows are re-strided to a multiple of 4 words on the way up: 16-byte aligned rows take the wide-load kernels
+    const int stride_up = (nodes->stride_words + 3) & ~3;
+    const size_t wbytes = n * (size_t) stride_up * sizeof(uint32_t);
     if ((rc = ensure(e, e->up_words, wbytes))) return rc;
     if ((rc = ensure(e, e->up_len, n * sizeof(int32_t)))) return rc;
     alga_nodes dn = *nodes;
     if (n) {
-        HIP_TRY(e, hipMemcpyAsync(e->up_words.p, nodes->words, wbytes, hipMemcpyHostToDevice, s));
+        if (stride_up != nodes->stride_words) HIP_TRY(e, hipMemsetAsync(e->up_words.p, 0, wbytes, s));
+        HIP_TRY(e, hipMemcpy2DAsync(e->up_words.p, (size_t) stride_up * 4, nodes->words, (size_t) nodes->stride_words * 4,
+                                    (size_t) nodes->stride_words * 4, n, hipMemcpyHostToDevice, s));
         HIP_TRY(e, hipMemcpyAsync(e->up_len.p, nodes->len, n * sizeof(int32_t), hipMemcpyHostToDevice, s));
     }
+    dn.stride_words = stride_up;
     dn.words = (const uint32_t *) e->up_words.p;
     dn.len = (const int32_t *) e->up_len.p;
     if (nodes->align_from) {
@@ -415,10 +425,10 @@ int alga_prefsuf_last_stats(const alga_engine *e, alga_prefsuf_stats *out) {
 }
 
 int alga_prefsuf_discover_device(alga_engine *e, const alga_nodes *nodes, const alga_prefsuf_params *p, int32_t src_begin, int32_t src_end,
-                                 void *hip_stream, const uint32_t **d_dst, const uint32_t **d_src, const uint32_t **d_ol, uint64_t *n_records) {
+                                 void *hip_stream, const uint32_t **d_dst, const uint64_t **d_val, uint64_t *n_records) {
     if (!e) return ALGA_ERR_INVALID_ARGUMENT;
     e->err.clear();
-    if (!d_dst || !d_src || !d_ol || !n_records) return fail(e, ALGA_ERR_INVALID_ARGUMENT, "output pointers must not be NULL");
+    if (!d_dst || !d_val || !n_records) return fail(e, ALGA_ERR_INVALID_ARGUMENT, "output pointers must not be NULL");
     HIP_TRY(e, hipSetDevice(e->device));
     hipStream_t s = hip_stream ? (hipStream_t) hip_stream : e->own_stream;
     memset(&e->stats, 0, sizeof(e->stats));
@@ -428,23 +438,23 @@ int alga_prefsuf_discover_device(alga_engine *e, const alga_nodes *nodes, const 
     if (src_begin < 0 || src_end > nodes->n || src_begin > src_end) return fail(e, ALGA_ERR_INVALID_ARGUMENT, "bad source range");
     e->stats.nodes_live = pp.live;
     uint64_t n_rec = 0;
-    if ((rc = discover_impl(e, pp, src_begin, src_end, false, 0, 0, s, &n_rec))) return rc;
+    if ((rc = discover_impl(e, pp, src_begin, src_end, s, &n_rec))) return rc;
     e->stats.ms_seed = ev_ms(e, EV_START, EV_SEED);
     e->stats.ms_probe = ev_ms(e, EV_SEED, EV_PROBE);
     e->stats.ms_total = ev_ms(e, EV_START, EV_PROBE);
-    *d_dst = (const uint32_t *) e->rec_dst.p; *d_src = (const uint32_t *) e->rec_src.p; *d_ol = (const uint32_t *) e->rec_ol.p;
+    *d_dst = (const uint32_t *) e->rec_dst.p; *d_val = (const uint64_t *) e->rec_val.p;
     *n_records = n_rec;
     return ALGA_OK;
 }
 
 int alga_prefsuf_reduce_device(alga_engine *e, const alga_nodes *nodes, const alga_prefsuf_params *p, const uint32_t *d_dst,
-                               const uint32_t *d_src, const uint32_t *d_ol, uint64_t n_records, int32_t dst_begin, int32_t dst_end,
+                               const uint64_t *d_val, uint64_t n_records, int32_t dst_begin, int32_t dst_end,
                                void *hip_stream, const alga_edge **d_edges, uint64_t *n_edges) {
     if (!e) return ALGA_ERR_INVALID_ARGUMENT;
     e->err.clear();
     if (!d_edges || !n_edges) return fail(e, ALGA_ERR_INVALID_ARGUMENT, "output pointers must not be NULL");
     *d_edges = nullptr; *n_edges = 0;
-    if (n_records && (!d_dst || !d_src || !d_ol)) return fail(e, ALGA_ERR_INVALID_ARGUMENT, "record arrays must not be NULL");
+    if (n_records && (!d_dst || !d_val)) return fail(e, ALGA_ERR_INVALID_ARGUMENT, "record arrays must not be NULL");
     HIP_TRY(e, hipSetDevice(e->device));
     hipStream_t s = hip_stream ? (hipStream_t) hip_stream : e->own_stream;
     Prepared pp;
@@ -453,7 +463,7 @@ int alga_prefsuf_reduce_device(alga_engine *e, const alga_nodes *nodes, const al
     if (dst_begin < 0 || dst_end > nodes->n || dst_begin > dst_end) return fail(e, ALGA_ERR_INVALID_ARGUMENT, "bad target range");
     HIP_TRY(e, hipEventRecord(e->ev[EV_PROBE], s));
     uint64_t E = 0;
-    if ((rc = reduce_impl(e, pp, d_dst, d_src, d_ol, n_records, false, dst_begin, dst_end, s, &E))) return rc;
+    if ((rc = reduce_impl(e, pp, d_dst, (const unsigned long long *) d_val, n_records, n_records, dst_begin, dst_end, s, &E))) return rc;
     e->stats.ms_group = ev_ms(e, EV_PROBE, EV_GROUP);
     e->stats.ms_reduce = ev_ms(e, EV_GROUP, EV_REDUCE);
     e->stats.ms_emit = ev_ms(e, EV_REDUCE, EV_EMIT);

@@ -45,7 +45,8 @@ ALGA_HD inline uint64_t fp_final(uint64_t h) {
 }
 
 constexpr uint32_t REC_INVALID = 0xFFFFFFFFu; // rec_dst marker: unused slot of a record chunk
-constexpr uint64_t SEED_EMPTY = ~0ull; // seed-table slot: (tag32 << 32) | node id ; empty = all ones
+constexpr uint64_t SEED_EMPTY = ~0ull; // seed-table slot: ((tag23 << 9 | len9) << 32) | node id ; empty = all ones
+constexpr int SEED_BUCKET = 8;         // slots per bucket: 8 x 8 B = one 64-byte line per probe
 
 // number of uint32 blocks that hold `len_nt` nucleotides (Bitset::blocks(), Bitset.h:206)
 ALGA_HD inline int blocks_of(int len_nt) { return len_nt <= 0 ? 0 : ((2 * len_nt - 1) >> 5) + 1; }
@@ -63,6 +64,7 @@ enum Counter {
     CNT_MAX_IN,            // max records per target
     CNT_LIVE_NODES,
     CNT_VALID_RECORDS,     // records that carry an overlap
+    CNT_SORT_VALID,        // records whose target lies in the owned range (k_make_keys)
     CNT_TOTAL = 16
 };
 

@@ -5,21 +5,24 @@
 // Integer / byte work only: no MFMA.  Wavefront = 64 lanes throughout.
 //
 //   k_node_stats        max read length, live-node count
-//   k_seed_build        fingerprint of the min_overlap-long prefix of every target -> seed table
-//   k_probe_sources     one wavefront per source: the source's tail is staged in LDS, lane p
-//                       fingerprints suffix window p, probes the table, verifies candidates with
-//                       an exact 2-bit compare, keeps the per-source small-overlap top-3
-//                       (wave max-reductions) and appends records (wave-aggregated atomics)
-//   k_count_targets     in-degree histogram for records that came from another rank
-//   k_scan_*            exclusive scan (row pointers)
-//   k_scatter_by_target records -> per-target segments
-//   k_reduce_targets    per target: replay of the reference's insertion order
-//                       (small-overlap dedupe, transitive reduction with 2-bit compares)
+//   k_seed_build        fingerprint of the min_overlap-long prefix of every target -> bucketised seed
+//                       table (64-byte buckets of 8 entries: one cache line answers one probe)
+//   k_probe_sources     persistent wavefronts, one source at a time: the source's tail is staged in
+//                       LDS, lane p fingerprints suffix window p and reads ONE bucket; tag hits become
+//                       candidates in LDS; candidates are then verified one per lane with wide row
+//                       loads and an exact 2-bit compare; the per-source small-overlap top-3 is a wave
+//                       max-reduction; records leave through an LDS buffer in coalesced chunks
+//   k_make_keys         record -> sort key (target id local to the owned range, invalid last)
+//   (radix sort by key: sort_records.hip)
+//   k_rowptr_from_sorted   row pointers of the per-target segments
+//   k_reduce_targets    per target: replay of the reference's insertion order (small-overlap dedupe,
+//                       transitive reduction with 2-bit compares); fast path entirely in LDS
+//   k_scan_*            exclusive scan (out-degree -> row pointers)
 //   k_scatter_by_source / k_sort_rows   final adjacency lists sorted by (dst, offset)
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include "prefsuf_common.h"
 #include "prefsuf_kernels.h"
-#include <algorithm>
 
 namespace alga {
 
@@ -56,45 +59,85 @@ __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
     return v;
 }
 
-// Slot in an append-only list for every CURRENTLY ACTIVE lane: one atomic per wave-instruction.
-__device__ __forceinline__ uint64_t wave_append(unsigned long long *counter) {
-    const uint64_t active = __ballot(1);
-    const int leader = __ffsll((long long) active) - 1;
-    const int lane = lane_id();
-    uint64_t base = 0;
-    if (lane == leader) base = atomicAdd(counter, (unsigned long long) __popcll(active));
-    base = shfl_u64(base, leader);
-    return base + (uint64_t) __popcll(active & ((1ull << lane) - 1ull));
+// ---- DPP cross-lane steps (no LDS crossbar round trip, unlike ds_bpermute-based __shfl) ----------------------
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint64_t dpp_or_zero_u64(uint64_t v) {   // lanes without a valid source read 0
+    const uint32_t lo = (uint32_t) __builtin_amdgcn_update_dpp(0, (int) (uint32_t) v, CTRL, ROW_MASK, 0xF, false);
+    const uint32_t hi = (uint32_t) __builtin_amdgcn_update_dpp(0, (int) (uint32_t) (v >> 32), CTRL, ROW_MASK, 0xF, false);
+    return ((uint64_t) hi << 32) | lo;
 }
 
-// 32 bits of a staged bit string starting at word q, bit r (v_alignbit_b32)
-__device__ __forceinline__ uint32_t funnel(uint32_t lo, uint32_t hi, int r) {
-    return __funnelshift_r(lo, hi, r);
+// max over the 64 lanes, returned uniformly (scalar registers): row_shr 1,2,4,8 scan inside each 16-lane row,
+// row_bcast15 / row_bcast31 carry the row totals upward, lane 63 holds the result
+__device__ __forceinline__ uint64_t wave_max_u64_dpp(uint64_t v) {
+    uint64_t t;
+    t = dpp_or_zero_u64<0x111, 0xF>(v); v = t > v ? t : v;
+    t = dpp_or_zero_u64<0x112, 0xF>(v); v = t > v ? t : v;
+    t = dpp_or_zero_u64<0x114, 0xF>(v); v = t > v ? t : v;
+    t = dpp_or_zero_u64<0x118, 0xF>(v); v = t > v ? t : v;
+    t = dpp_or_zero_u64<0x142, 0xA>(v); v = t > v ? t : v;
+    t = dpp_or_zero_u64<0x143, 0xC>(v); v = t > v ? t : v;
+    const uint32_t lo = (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) v, 63);
+    const uint32_t hi = (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) (v >> 32), 63);
+    return ((uint64_t) hi << 32) | lo;
 }
+
+// OR over each group of four adjacent lanes (quad_perm [1,0,3,2] then [2,3,0,1])
+__device__ __forceinline__ uint32_t quad_or(uint32_t v) {
+    v |= (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0xB1, 0xF, 0xF, true);
+    v |= (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x4E, 0xF, 0xF, true);
+    return v;
+}
+
+// 32 bits of a bit string starting at bit r of lo (v_alignbit_b32)
+__device__ __forceinline__ uint32_t funnel(uint32_t lo, uint32_t hi, int r) { return __funnelshift_r(lo, hi, r); }
+
+__device__ __forceinline__ void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
 
 // ------------------------------------------------------------------------------------------
-// k_node_stats
+// k_node_stats : few workgroups, grid-stride (one contended atomic per wave would dominate)
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_node_stats(NodesDev nd, unsigned long long *counters, int *max_len) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    int l = 0;
-    if (i < nd.n) l = nd.len[i];
-    int m = l;
+    __shared__ int s_max[4];
+    __shared__ unsigned long long s_live[4];
+    int m = 0;
+    unsigned long long live = 0;
+    for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < nd.n; i += (int64_t) gridDim.x * blockDim.x) {
+        int l = nd.len[i];
+        m = l > m ? l : m;
+        live += l > 0;
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(m, o); m = t > m ? t : m; }
-    uint64_t live = __popcll(__ballot(l > 0));
-    if (lane_id() == 0) {
+    live = wave_sum_u64(live);
+    const int wave = (int) (threadIdx.x >> 6);
+    if (lane_id() == 0) { s_max[wave] = m; s_live[wave] = live; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; w++) { m = s_max[w] > m ? s_max[w] : m; live += s_live[w]; }
         if (m > 0) atomicMax(max_len, m);
-        if (live) atomicAdd(&counters[CNT_LIVE_NODES], (unsigned long long) live);
+        if (live) atomicAdd(&counters[CNT_LIVE_NODES], live);
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// k_seed_build : one thread per target node
+// seed table: buckets of 8 x u64, entry = (tag23 | len9) << 32 | node id, empty = all ones
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t seed_bucket(uint64_t h, uint32_t n_buckets) { return __umulhi((uint32_t) h, n_buckets); }
+__device__ __forceinline__ uint32_t seed_taglen(uint64_t h, int len) {
+    return ((uint32_t) (h >> 41) << 9) | (uint32_t) (len > 511 ? 511 : len);
+}
+
+// one thread per target node
 //   replaces updatePrefixHash + putKmersIntoBucketsJob (GraphCreatorPrefSuf.cpp:213-223,323-332)
 //   for the single length min_overlap; longer overlaps are found by extension, not by re-hashing.
-// ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_seed_build(NodesDev nd, PrefSufCfg cfg, unsigned long long *table, uint32_t mask) {
+// Prefilter: one bit per fingerprint in a bitmap small enough to live in every XCD's L2 (<= 4 MB).  ~72 % of the
+// suffix windows of BASELINE configs[1] match no target; their bucket read (a random 64-byte line from the
+// Infinity Cache / HBM, the dominant cost of the probe) is skipped when the bit is clear.
+__device__ __forceinline__ uint32_t seed_filter_index(uint64_t h, uint32_t filter_mask) { return (uint32_t) (h >> 32) & filter_mask; }
+
+__global__ void __launch_bounds__(256) k_seed_build(NodesDev nd, PrefSufCfg cfg, unsigned long long *table, uint32_t n_buckets,
+                                                     uint32_t *filter, uint32_t filter_mask) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nd.n) return;
     int len = nd.len[i];
@@ -108,195 +151,403 @@ __global__ void __launch_bounds__(256) k_seed_build(NodesDev nd, PrefSufCfg cfg,
         h = fp_step(h, w);
     }
     h = fp_final(h);
-    uint32_t slot = (uint32_t) h & mask;
-    const unsigned long long entry = (h & 0xFFFFFFFF00000000ull) | (uint32_t) i;
+    uint32_t b = seed_bucket(h, n_buckets);
+    if (filter) { const uint32_t fi = seed_filter_index(h, filter_mask); atomicOr(&filter[fi >> 5], 1u << (fi & 31)); }
+    const unsigned long long entry = ((unsigned long long) seed_taglen(h, len) << 32) | (uint32_t) i;
     for (;;) {
-        unsigned long long old = atomicCAS(&table[slot], (unsigned long long) SEED_EMPTY, entry);
-        if (old == SEED_EMPTY) break;
-        slot = (slot + 1) & mask;
+        unsigned long long *bp = table + (size_t) b * SEED_BUCKET;
+        for (int j = 0; j < SEED_BUCKET; j++) {
+            if (bp[j] != SEED_EMPTY) continue;                 // slots only ever go empty -> full
+            if (atomicCAS(&bp[j], (unsigned long long) SEED_EMPTY, entry) == SEED_EMPTY) return;
+        }
+        b = (b + 1 == n_buckets) ? 0u : b + 1;                 // bucket full: spill to the next one
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// k_probe_sources : persistent wavefronts, one source node B at a time per wavefront
-//
-//   * B's tail (<= 501 nt) is staged in the wave's LDS row; lane p owns suffix window p
-//   * records are collected in a per-wave LDS buffer and flushed with coalesced 64-lane stores
-//     into chunks of the global record list; a chunk is reserved with ONE global atomic
-//     (a returning atomic on one address sustains only ~88 ops/us chip-wide, so per-record or
-//     per-source reservations would cap the kernel at tens of milliseconds)
-//   * unused chunk tails are filled with REC_INVALID and skipped downstream
+// k_probe_sources
 // ------------------------------------------------------------------------------------------
 constexpr int PROBE_WAVES = 4;        // waves per workgroup
-constexpr int STAGE_WORDS = 36;       // (2*501+31)/32 + alignment slack + 1 zero word
+constexpr int STAGE_WORDS = 52;       // staged tail (<= 33 words) + slack for unconditional wide compares
+constexpr int CANDMAX = 128;          // per-wave candidate buffer
 constexpr int WBUF = 256;             // per-wave LDS record buffer (records)
 constexpr int WFLUSH = 128;           // flush once this many are buffered
 constexpr int REC_CHUNK = 512;        // records reserved per global atomic
 
+// keep a >= b >= c = the three largest keys seen (branch-free: the three keys must stay in registers)
 __device__ __forceinline__ void top3_insert(uint64_t &a, uint64_t &b, uint64_t &c, uint64_t k) {
-    if (k > a) { c = b; b = a; a = k; }
-    else if (k > b) { c = b; b = k; }
-    else if (k > c) { c = k; }
+    uint64_t t = k > a ? k : a; k = k > a ? a : k; a = t;
+    t = k > b ? k : b; k = k > b ? b : k; b = t;
+    c = k > c ? k : c;
 }
 
 struct ProbeOut {
-    uint32_t *__restrict__ rec_dst, *__restrict__ rec_src, *__restrict__ rec_ol;
+    uint32_t *__restrict__ rec_dst;
+    unsigned long long *__restrict__ rec_val;
     uint64_t rec_cap;
-    uint32_t *__restrict__ indeg;
-    int32_t dst_begin, dst_end;
     unsigned long long *__restrict__ counters;
 };
 
-__device__ __forceinline__ void store_record(const ProbeOut &o, uint64_t idx, uint32_t C, uint32_t B, uint32_t ol) {
-    if (idx < o.rec_cap) { o.rec_dst[idx] = C; o.rec_src[idx] = B; o.rec_ol[idx] = ol; }
-    if (o.indeg && (int) C >= o.dst_begin && (int) C < o.dst_end) atomicAdd(&o.indeg[(int) C - o.dst_begin], 1u);
+__device__ __forceinline__ void store_record(const ProbeOut &o, uint64_t idx, uint32_t C, unsigned long long val) {
+    if (idx < o.rec_cap) { o.rec_dst[idx] = C; o.rec_val[idx] = val; }
 }
 
-// Convergent: all 64 lanes.  Moves the wave's LDS buffer to the record list.
-__device__ __forceinline__ void flush_records(const ProbeOut &o, uint32_t *sC, uint32_t *sS, uint32_t *sO, uint32_t *sCnt,
-                                              uint64_t &chunk_base, int &chunk_fill) {
+struct WaveLds {           // per-wave LDS views
+    uint32_t *sb;          // staged tail of the source
+    uint32_t *candC; uint32_t *candW; uint32_t *candN;
+    uint32_t *recC; unsigned long long *recV; uint32_t *recN;
+};
+
+// Convergent: all 64 lanes.  Moves the wave's LDS record buffer to the global record list.
+//   A chunk of the list is reserved with ONE global atomic (a returning atomic on a single address
+//   sustains only ~88 ops/us chip-wide: per-record or per-source reservations cost tens of ms).
+__device__ __forceinline__ void flush_records(const ProbeOut &o, const WaveLds &w, uint64_t &chunk_base, int &chunk_fill) {
     const int lane = lane_id();
-    int n = (int) __builtin_amdgcn_readfirstlane((int) *sCnt);
+    wave_lds_fence();
+    int n = (int) __builtin_amdgcn_readfirstlane((int) *w.recN);
     if (n > WBUF) n = WBUF;                      // the excess went out through the direct path
     if (n == 0) return;
     if (chunk_fill + n > REC_CHUNK) {
-        // close the current chunk: invalid markers in its tail
-        for (int i = chunk_fill + lane; i < REC_CHUNK; i += 64) {
+        for (int i = chunk_fill + lane; i < REC_CHUNK; i += 64) {      // close the chunk: invalid markers in its tail
             const uint64_t idx = chunk_base + (uint64_t) i;
             if (idx < o.rec_cap) o.rec_dst[idx] = REC_INVALID;
         }
         uint64_t base = 0;
         if (lane == 0) base = atomicAdd(&o.counters[CNT_RECORDS], (unsigned long long) REC_CHUNK);
-        chunk_base = shfl_u64(base, 0);
+        chunk_base = ((uint64_t) (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) (base >> 32)) << 32) |
+                     (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) base);
         chunk_fill = 0;
     }
-    for (int i = lane; i < n; i += 64) store_record(o, chunk_base + (uint64_t) (chunk_fill + i), sC[i], sS[i], sO[i]);
+    for (int i = lane; i < n; i += 64) store_record(o, chunk_base + (uint64_t) (chunk_fill + i), w.recC[i], w.recV[i]);
     chunk_fill += n;
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    if (lane == 0) *sCnt = 0;
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    wave_lds_fence();
+    if (lane == 0) *w.recN = 0;
+    wave_lds_fence();
 }
 
-template <bool STATS>
-__global__ void __launch_bounds__(PROBE_WAVES * 64)
-k_probe_sources(NodesDev nd, PrefSufCfg cfg, const unsigned long long *__restrict__ table, uint32_t mask,
-                int32_t src_begin, int32_t src_end, ProbeOut o) {
+// NQ > 0: rows are 16-byte aligned, hold >= NQ uint4 and every compared prefix fits NQ uint4:
+//         straight-line wide loads, all issued before the first use.
+// NQ == 0: generic word loop (any stride / read length).
+template <int NQ>
+__device__ __forceinline__ bool verify_overlap(const NodesDev &nd, const uint32_t *sb, int C, int q, int r, int L) {
+    const int nwL = (2 * L + 31) >> 5;
+    const uint32_t lastmask = (2 * L & 31) ? ((1u << (2 * L & 31)) - 1u) : 0xFFFFFFFFu;
+    uint32_t diff = 0;
+    if constexpr (NQ > 0) {
+        const uint4 *rc4 = reinterpret_cast<const uint4 *>(nd.words + (size_t) C * nd.stride);
+        uint4 c[NQ];
+#pragma unroll
+        for (int k4 = 0; k4 < NQ; k4++) c[k4] = rc4[k4];
+#pragma unroll
+        for (int k4 = 0; k4 < NQ; k4++) {
+            const uint32_t cw[4] = {c[k4].x, c[k4].y, c[k4].z, c[k4].w};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int k = 4 * k4 + j;
+                const uint32_t m = k < nwL - 1 ? 0xFFFFFFFFu : (k == nwL - 1 ? lastmask : 0u);
+                diff |= (funnel(sb[q + k], sb[q + k + 1], r) ^ cw[j]) & m;
+            }
+        }
+    } else {
+        const uint32_t *rc = nd.words + (size_t) C * nd.stride;
+        for (int k = 0; k < nwL; k++) {
+            uint32_t x = funnel(sb[q + k], sb[q + k + 1], r) ^ rc[k];
+            if (k == nwL - 1) x &= lastmask;
+            diff |= x;
+        }
+    }
+    return diff == 0;
+}
+
+#ifndef PROBE_OCC
+#define PROBE_OCC 4                   // minimum waves per SIMD requested from the register allocator
+#endif
+template <bool STATS, int NQ>
+__global__ void __launch_bounds__(PROBE_WAVES * 64, PROBE_OCC)
+k_probe_sources(NodesDev nd, PrefSufCfg cfg, const unsigned long long *__restrict__ table, uint32_t n_buckets,
+                const uint32_t *__restrict__ filter, uint32_t filter_mask, int32_t src_begin, int32_t src_end, ProbeOut o) {
     __shared__ uint32_t sB[PROBE_WAVES][STAGE_WORDS];
+    __shared__ uint32_t sCandC[PROBE_WAVES][CANDMAX];
+    __shared__ uint32_t sCandW[PROBE_WAVES][CANDMAX];
     __shared__ uint32_t sRecC[PROBE_WAVES][WBUF];
-    __shared__ uint32_t sRecS[PROBE_WAVES][WBUF];
-    __shared__ uint32_t sRecO[PROBE_WAVES][WBUF];
-    __shared__ uint32_t sRecN[PROBE_WAVES];
+    __shared__ unsigned long long sRecV[PROBE_WAVES][WBUF];
+    __shared__ uint32_t sCnt[PROBE_WAVES][2];
     const int wave = (int) (threadIdx.x >> 6);
     const int lane = lane_id();
-    uint32_t *sb = sB[wave];
-    uint32_t *sC = sRecC[wave], *sS = sRecS[wave], *sO = sRecO[wave], *sCnt = &sRecN[wave];
-    if (lane == 0) *sCnt = 0;
+    WaveLds w{sB[wave], sCandC[wave], sCandW[wave], &sCnt[wave][0], sRecC[wave], sRecV[wave], &sCnt[wave][1]};
+    if (lane == 0) { *w.candN = 0; *w.recN = 0; }
     uint64_t chunk_base = 0;
     int chunk_fill = REC_CHUNK;                            // "no chunk yet"
     uint64_t st_raw = 0, st_slots = 0, st_win = 0, st_rec = 0;
     const int64_t total_waves = (int64_t) gridDim.x * PROBE_WAVES;
+    const uint32_t *sb = w.sb;
 
-    for (int64_t Bl = (int64_t) src_begin + (int64_t) blockIdx.x * PROBE_WAVES + wave; Bl < src_end; Bl += total_waves) {
+    // software pipeline over sources: length, mask and row word of the NEXT source are requested before the
+    // current one is probed, so their latency hides behind the bucket and candidate-row round trips
+    const int pre_words = nd.stride < STAGE_WORDS ? nd.stride : STAGE_WORDS;
+    int64_t Bl = (int64_t) src_begin + (int64_t) blockIdx.x * PROBE_WAVES + wave;
+    int n_len = 0; uint32_t n_word = 0; uint8_t n_from = 1;
+    if (Bl < src_end) {
+        n_len = nd.len[Bl];
+        n_word = lane < pre_words ? nd.words[(size_t) Bl * nd.stride + lane] : 0u;
+        if (nd.from) n_from = nd.from[Bl];
+    }
+    while (Bl < src_end) {
         const int B = (int) Bl;
-        const int lenB = nd.len[B];
-        if (!(lenB >= cfg.Lmin && lenB > 0 && (!nd.from || nd.from[B]))) continue;      // wave-uniform
+        const int lenB = n_len;
+        const uint32_t word0 = n_word;
+        const bool from_ok = n_from != 0;
+        Bl += total_waves;
+        if (Bl < src_end) {
+            n_len = nd.len[Bl];
+            n_word = lane < pre_words ? nd.words[(size_t) Bl * nd.stride + lane] : 0u;
+            if (nd.from) n_from = nd.from[Bl];
+        }
+        if (!(lenB >= cfg.Lmin && lenB > 0 && from_ok)) continue;                       // wave-uniform
         // stage the last Lspan nucleotides of B (all an overlap of length <= Lcap can touch)
         const int Lspan = lenB < cfg.Lcap ? lenB : cfg.Lcap;
-        const int w0 = (2 * (lenB - Lspan)) >> 5;         // first staged word of the row
+        const int w0 = (2 * (lenB - Lspan)) >> 5;         // first staged word of the row (0 unless the read is > 501 nt)
         const int nwB = blocks_of(lenB) - w0;              // staged words (<= 33)
         {
-            const uint32_t *row = nd.words + (size_t) B * nd.stride;
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            if (lane < STAGE_WORDS) sb[lane] = lane < nwB ? row[w0 + lane] : 0u;
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            wave_lds_fence();
+            uint32_t x = word0;
+            if (w0 != 0) x = (lane < nwB) ? nd.words[(size_t) B * nd.stride + w0 + lane] : 0u;   // long read: re-read the tail
+            if (lane < STAGE_WORDS) w.sb[lane] = lane < nwB ? x : 0u;
+            wave_lds_fence();
         }
         const int nwin = Lspan - cfg.Lmin + 1;             // overlap lengths Lmin..Lspan
         uint64_t k0 = 0, k1 = 0, k2 = 0;                   // per-lane top-3 small overlaps, key=(L<<32)|C
 
+        // A verified overlap (B -> C, length L): small ones compete for the per-source top 3, big ones are records.
+        auto classify = [&](int C, int L) {
+            if (STATS) st_raw++;
+            if (L < cfg.rsoemo) {
+                top3_insert(k0, k1, k2, ((uint64_t) (uint32_t) L << 32) | (uint32_t) C);       // GraphCreatorPrefSuf.cpp:397-401
+            } else {
+                st_rec++;
+                const unsigned long long val = ((unsigned long long) ol_pack(lenB - L, L, false) << 32) | (uint32_t) B;
+                const uint32_t i = atomicAdd(w.recN, 1u);              // LDS atomic
+                if (i < (uint32_t) WBUF) { w.recC[i] = (uint32_t) C; w.recV[i] = val; }
+                else store_record(o, atomicAdd(&o.counters[CNT_RECORDS], 1ull), (uint32_t) C, val);   // buffer full: direct, slow
+            }
+        };
+
         for (int base = 0; base < nwin; base += 64) {
+            // ---- phase 1a: one window per lane -> fingerprint -> (bucket, tag) ----------------------------------
             const int widx = base + lane;
-            if (widx < nwin) {
+            const bool wvalid = widx < nwin;
+            uint32_t my_b = 0, my_tag = 0xFFFFFFFFu;       // tag 0xFFFFFFFF (> 23 bits) never matches an entry
+            int my_q = 0, my_r = 0;
+            if (wvalid) {
                 const int L = Lspan - widx;
-                const int off = lenB - L;                  // == offset of the edge B -> C
-                const int bit = 2 * off - 32 * w0;
-                const int q = bit >> 5, r = bit & 31;
+                const int bit = 2 * (lenB - L) - 32 * w0;
+                my_q = bit >> 5; my_r = bit & 31;
                 uint64_t h = fp_init();
+#if defined(ABLATE) && ABLATE == 3
+                h = fp_step(h, (uint32_t) B * 64u + (uint32_t) widx + sb[my_q]);
+#else
                 for (int k = 0; k < cfg.seed_words; k++) {
-                    uint32_t w = funnel(sb[q + k], sb[q + k + 1], r);
-                    if (k == cfg.seed_words - 1) w &= cfg.seed_last_mask;
-                    h = fp_step(h, w);
+                    uint32_t x = funnel(sb[my_q + k], sb[my_q + k + 1], my_r);
+                    if (k == cfg.seed_words - 1) x &= cfg.seed_last_mask;
+                    h = fp_step(h, x);
                 }
+#endif
                 h = fp_final(h);
-                const uint32_t tag = (uint32_t) (h >> 32);
-                uint32_t slot = (uint32_t) h & mask;
+                my_tag = (uint32_t) (h >> 41);
+                my_b = seed_bucket(h, n_buckets);
+#if defined(ABLATE) && ABLATE == 4
+                my_b &= 1023u;                                 // timing only: every probe hits an L2-resident corner of the table
+#endif
                 if (STATS) st_win++;
-                const int nwL = (2 * L + 31) >> 5;
-                const uint32_t lastmask = (2 * L & 31) ? ((1u << (2 * L & 31)) - 1u) : 0xFFFFFFFFu;
+#if defined(ABLATE) && ABLATE == 5
+                if (false) {
+#else
+                if (filter) {
+#endif
+                    const uint32_t fi = seed_filter_index(h, filter_mask);
+                    if (!((filter[fi >> 5] >> (fi & 31)) & 1u)) my_tag = 0xFFFFFFFFu;      // no target has this fingerprint
+                }
+            }
+#if defined(ABLATE) && ABLATE == 1
+            asm volatile("" :: "v"(my_b), "v"(my_tag));
+            continue;
+#endif
+            // ---- phase 1b: FOUR lanes read one 64-byte bucket with ONE request (16 buckets per instruction) -----
+            // A lane-private 4 x 16 B read of a random line costs four requests per window in the vector memory
+            // path; reading a line with four adjacent lanes costs one.
+            const int sub = lane & 3;
+            bool my_spill = false;                         // my window's bucket was full: entries may have spilled on
+            uint32_t tw4[4];
+            uint4 e4[4];
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++) {               // all four requests are in flight before the first use
+                const int wl = 16 * rr + (lane >> 2);      // window (lane index) served by this lane group
+                const uint32_t bw = (uint32_t) __shfl((int) my_b, wl);
+                tw4[rr] = (uint32_t) __shfl((int) my_tag, wl);
+                e4[rr] = make_uint4(0xFFFFFFFFu, 0u, 0xFFFFFFFFu, 0u);
+                if (tw4[rr] != 0xFFFFFFFFu) e4[rr] = reinterpret_cast<const uint4 *>(table + (size_t) bw * SEED_BUCKET)[sub];
+            }
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++) {
+                const int wl = 16 * rr + (lane >> 2);
+                const uint32_t tw = tw4[rr];
+                const uint4 e = e4[rr];
+                if (STATS && tw != 0xFFFFFFFFu) st_slots += 2;
+                const int Lw = Lspan - (base + wl);
+                // candidate: same tag, long enough for a prefix of length L (:215), not B itself (:386)
+                if (e.x != 0xFFFFFFFFu && (e.y >> 9) == tw && (int) (e.y & 511u) >= Lw && (int) e.x != B) {
+                    const uint32_t ci = atomicAdd(w.candN, 1u);
+                    if (ci < (uint32_t) CANDMAX) { w.candC[ci] = e.x; w.candW[ci] = (uint32_t) (base + wl); }
+                }
+                if (e.z != 0xFFFFFFFFu && (e.w >> 9) == tw && (int) (e.w & 511u) >= Lw && (int) e.z != B) {
+                    const uint32_t ci = atomicAdd(w.candN, 1u);
+                    if (ci < (uint32_t) CANDMAX) { w.candC[ci] = e.z; w.candW[ci] = (uint32_t) (base + wl); }
+                }
+                const bool full = sub == 3 && e.z != 0xFFFFFFFFu;
+                const uint64_t fm = __ballot(full);        // bit 4j+3 <-> window 16*rr + j
+                if ((lane >> 4) == rr) my_spill = (fm >> (4 * (lane & 15) + 3)) & 1ull;
+            }
+            // ---- phase 1c (rare): windows whose bucket was full walk the following buckets on their own ----------
+            if (my_spill) {
+                const int L = Lspan - widx;
+                uint32_t b = (my_b + 1 == n_buckets) ? 0u : my_b + 1;
                 for (;;) {
-                    const unsigned long long e = table[slot];
-                    if (STATS) st_slots++;
-                    if (e == SEED_EMPTY) break;
-                    slot = (slot + 1) & mask;
-                    if ((uint32_t) (e >> 32) != tag) continue;
-                    const int C = (int) (uint32_t) e;
-                    if (C == B) continue;                                  // GraphCreatorPrefSuf.cpp:386
-                    if (nd.len[C] < L) continue;                           // a prefix of length L must exist (:215)
-                    // exact verification: B[off .. lenB) == C[0 .. L)
-                    const uint32_t *rc = nd.words + (size_t) C * nd.stride;
-                    bool ok = true;
-                    for (int k = 0; k < nwL; k++) {
-                        uint32_t x = funnel(sb[q + k], sb[q + k + 1], r) ^ rc[k];
-                        if (k == nwL - 1) x &= lastmask;
-                        if (x) { ok = false; break; }
+                    const uint4 *bp = reinterpret_cast<const uint4 *>(table + (size_t) b * SEED_BUCKET);
+                    const uint4 e0 = bp[0], e1 = bp[1], e2 = bp[2], e3 = bp[3];
+                    if (STATS) st_slots += 8;
+#define ALGA_SLOT(ID, TL)                                                                                           \
+                    if ((ID) != 0xFFFFFFFFu && ((TL) >> 9) == my_tag && (int) ((TL) & 511u) >= L && (int) (ID) != B) {   \
+                        const uint32_t ci = atomicAdd(w.candN, 1u);                                                       \
+                        if (ci < (uint32_t) CANDMAX) { w.candC[ci] = (ID); w.candW[ci] = (uint32_t) widx; }                \
                     }
-                    if (!ok) continue;
-                    if (STATS) st_raw++;
-                    if (L < cfg.rsoemo) {
-                        top3_insert(k0, k1, k2, ((uint64_t) (uint32_t) L << 32) | (uint32_t) C);   // :397-401
-                    } else {
-                        st_rec++;
-                        const uint32_t i = atomicAdd(sCnt, 1u);            // LDS atomic
-                        if (i < (uint32_t) WBUF) { sC[i] = (uint32_t) C; sS[i] = (uint32_t) B; sO[i] = ol_pack(off, L, false); }
-                        else {                                             // buffer full (heavy repeats): direct, slow path
-                            const uint64_t idx = atomicAdd(&o.counters[CNT_RECORDS], 1ull);
-                            store_record(o, idx, (uint32_t) C, (uint32_t) B, ol_pack(off, L, false));
+                    ALGA_SLOT(e0.x, e0.y) ALGA_SLOT(e0.z, e0.w) ALGA_SLOT(e1.x, e1.y) ALGA_SLOT(e1.z, e1.w)
+                    ALGA_SLOT(e2.x, e2.y) ALGA_SLOT(e2.z, e2.w) ALGA_SLOT(e3.x, e3.y) ALGA_SLOT(e3.z, e3.w)
+#undef ALGA_SLOT
+                    if (e3.z == 0xFFFFFFFFu) break;        // bucket not full: nothing spilled past it
+                    b = (b + 1 == n_buckets) ? 0u : b + 1;
+                }
+            }
+            // ---- phase 2: candidates -> exact 2-bit compare of C[0, L) with B[off, off+L) ----------------------------
+            wave_lds_fence();
+#if defined(ABLATE) && ABLATE == 2
+            if (lane == 0) *w.candN = 0;
+            wave_lds_fence();
+            continue;
+#endif
+            const int ncand_raw = (int) __builtin_amdgcn_readfirstlane((int) *w.candN);
+            if (ncand_raw > CANDMAX) {
+                // More tag hits than the buffer holds (heavy repeats): the buffered ones are dropped and the whole
+                // 64-window batch is verified the slow way, window by window, straight from the table.
+                if (wvalid) {
+                    const int L = Lspan - widx;
+                    uint32_t b = my_b;
+                    for (;;) {
+                        const unsigned long long *bp = table + (size_t) b * SEED_BUCKET;
+                        bool full = true;
+                        for (int j = 0; j < SEED_BUCKET; j++) {
+                            const unsigned long long en = bp[j];
+                            const uint32_t id = (uint32_t) en, tl = (uint32_t) (en >> 32);
+                            if (id == 0xFFFFFFFFu) { full = false; break; }
+                            if ((tl >> 9) == my_tag && (int) (tl & 511u) >= L && (int) id != B &&
+                                verify_overlap<0>(nd, sb, (int) id, my_q, my_r, L)) classify((int) id, L);
                         }
+                        if (!full) break;
+                        b = (b + 1 == n_buckets) ? 0u : b + 1;
+                    }
+                }
+            } else if (NQ > 0) {
+                // four lanes per candidate: lane `sub` loads 16 bytes of C's row (one request per row), compares its
+                // four words, the group ORs its differences
+                const int ncand = ncand_raw;
+                for (int c0 = 0; c0 < ncand; c0 += 32) {          // two groups of 16 candidates per trip: both loads in flight
+                    int Cc[2], Lc[2];
+                    uint4 cc[2];
+                    bool act[2];
+#pragma unroll
+                    for (int g = 0; g < 2; g++) {
+                        const int ci = c0 + 16 * g + (lane >> 2);
+                        act[g] = ci < ncand;
+                        Cc[g] = 0; Lc[g] = Lspan;
+                        cc[g] = make_uint4(0u, 0u, 0u, 0u);
+                        if (act[g]) {
+                            Cc[g] = (int) w.candC[ci];
+                            Lc[g] = Lspan - (int) w.candW[ci];
+                            if (sub < NQ) cc[g] = reinterpret_cast<const uint4 *>(nd.words + (size_t) Cc[g] * nd.stride)[sub];
+                        }
+                    }
+#pragma unroll
+                    for (int g = 0; g < 2; g++) {
+                        uint32_t diff = 0;
+                        if (act[g] && sub < NQ) {
+                            const int L = Lc[g];
+                            const int bit = 2 * (lenB - L) - 32 * w0;
+                            const int q = bit >> 5, r = bit & 31;
+                            const int nwL = (2 * L + 31) >> 5;
+                            const uint32_t lastmask = (2 * L & 31) ? ((1u << (2 * L & 31)) - 1u) : 0xFFFFFFFFu;
+                            const uint32_t cw[4] = {cc[g].x, cc[g].y, cc[g].z, cc[g].w};
+#pragma unroll
+                            for (int j = 0; j < 4; j++) {
+                                const int k = 4 * sub + j;
+                                const uint32_t m = k < nwL - 1 ? 0xFFFFFFFFu : (k == nwL - 1 ? lastmask : 0u);
+                                diff |= (funnel(sb[q + k], sb[q + k + 1], r) ^ cw[j]) & m;
+                            }
+                        }
+                        diff = quad_or(diff);
+                        if (act[g] && sub == 0 && diff == 0) classify(Cc[g], Lc[g]);
+                    }
+                }
+            } else {
+                const int ncand = ncand_raw;
+                for (int c0 = 0; c0 < ncand; c0 += 64) {
+                    const int ci = c0 + lane;
+                    if (ci < ncand) {
+                        const int C = (int) w.candC[ci];
+                        const int L = Lspan - (int) w.candW[ci];
+                        const int bit = 2 * (lenB - L) - 32 * w0;
+                        if (verify_overlap<0>(nd, sb, C, bit >> 5, bit & 31, L)) classify(C, L);
                     }
                 }
             }
+            wave_lds_fence();
+            if (lane == 0) *w.candN = 0;
+            wave_lds_fence();
         }
         // per-source small-overlap cap: the reference keeps the LAST `SOES`=3 pushes in (L asc, C asc)
         // order (GraphCreatorPrefSuf.cpp:400-401) == the 3 largest (L, C) keys.
-        uint64_t win[3] = {0, 0, 0};
+        uint64_t win0 = 0, win1 = 0, win2 = 0;
         int nwon = 0;
-#pragma unroll
-        for (int rnd = 0; rnd < 3; rnd++) {
-            const uint64_t m = wave_max_u64(k0);
-            if (m == 0) break;
-            if (k0 == m) { k0 = k1; k1 = k2; k2 = 0; }
-            win[rnd] = m; nwon = rnd + 1;
+        {
+            uint64_t m = wave_max_u64_dpp(k0);
+            if (m) {
+                if (k0 == m) { k0 = k1; k1 = k2; k2 = 0; }
+                win0 = m; nwon = 1;
+                m = wave_max_u64_dpp(k0);
+                if (m) {
+                    if (k0 == m) { k0 = k1; k1 = k2; k2 = 0; }
+                    win1 = m; nwon = 2;
+                    m = wave_max_u64_dpp(k0);
+                    if (m) { win2 = m; nwon = 3; }
+                }
+            }
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        int nbuf = (int) __builtin_amdgcn_readfirstlane((int) *sCnt);
+        wave_lds_fence();
+        int nbuf = (int) __builtin_amdgcn_readfirstlane((int) *w.recN);
         if (nbuf > WBUF) nbuf = WBUF;
-        if (nbuf + nwon > WBUF) {                           // make room (convergent)
-            flush_records(o, sC, sS, sO, sCnt, chunk_base, chunk_fill);
-            nbuf = 0;
-        }
+        if (nbuf + nwon > WBUF) { flush_records(o, w, chunk_base, chunk_fill); nbuf = 0; }
         if (lane < nwon) {
-            const uint64_t m = lane == 0 ? win[0] : (lane == 1 ? win[1] : win[2]);
+            const uint64_t m = lane == 0 ? win0 : (lane == 1 ? win1 : win2);
             const int L = (int) (m >> 32);
-            sC[nbuf + lane] = (uint32_t) m; sS[nbuf + lane] = (uint32_t) B; sO[nbuf + lane] = ol_pack(lenB - L, L, true);
+            w.recC[nbuf + lane] = (uint32_t) m;
+            w.recV[nbuf + lane] = ((unsigned long long) ol_pack(lenB - L, L, true) << 32) | (uint32_t) B;
             st_rec++;
         }
-        if (lane == 0) *sCnt = (uint32_t) (nbuf + nwon);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        if (nbuf + nwon >= WFLUSH) flush_records(o, sC, sS, sO, sCnt, chunk_base, chunk_fill);
+        wave_lds_fence();
+        if (lane == 0) *w.recN = (uint32_t) (nbuf + nwon);
+        wave_lds_fence();
+        if (nbuf + nwon >= WFLUSH) flush_records(o, w, chunk_base, chunk_fill);
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    flush_records(o, sC, sS, sO, sCnt, chunk_base, chunk_fill);
-    // invalid markers in the unused tail of the wave's last chunk
-    if (chunk_fill < REC_CHUNK) {
+    flush_records(o, w, chunk_base, chunk_fill);
+    if (chunk_fill < REC_CHUNK) {                          // invalid markers in the unused tail of the last chunk
         for (int i = chunk_fill + lane; i < REC_CHUNK; i += 64) {
             const uint64_t idx = chunk_base + (uint64_t) i;
             if (idx < o.rec_cap) o.rec_dst[idx] = REC_INVALID;
@@ -315,15 +566,33 @@ k_probe_sources(NodesDev nd, PrefSufCfg cfg, const unsigned long long *__restric
 }
 
 // ------------------------------------------------------------------------------------------
-// in-degree histogram for records produced elsewhere (sharded reduce)
+// k_make_keys : sort key of a record = target id relative to the owned range; everything else
+// (chunk padding, foreign targets) gets the all-ones key and sorts behind the valid records
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_count_targets(const uint32_t *__restrict__ rec_dst, uint64_t n_rec,
-                                                        int32_t dst_begin, int32_t dst_end, uint32_t *__restrict__ indeg) {
+__global__ void __launch_bounds__(256) k_make_keys(const uint32_t *__restrict__ rec_dst, uint64_t n_rec, int32_t dst_begin, int32_t dst_end,
+                                                    uint32_t *__restrict__ keys, unsigned long long *__restrict__ n_valid) {
+    __shared__ unsigned long long s_cnt[4];
+    unsigned long long cnt = 0;
     for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n_rec; i += (uint64_t) gridDim.x * blockDim.x) {
         const uint32_t c = rec_dst[i];
-        if (c == REC_INVALID) continue;
-        int C = (int) c;
-        if (C >= dst_begin && C < dst_end) atomicAdd(&indeg[C - dst_begin], 1u);
+        const bool ok = c != REC_INVALID && (int) c >= dst_begin && (int) c < dst_end;
+        keys[i] = ok ? c - (uint32_t) dst_begin : 0xFFFFFFFFu;
+        cnt += ok;
+    }
+    cnt = wave_sum_u64(cnt);
+    if (lane_id() == 0) s_cnt[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) { cnt = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3]; if (cnt) atomicAdd(n_valid, cnt); }
+}
+
+// rowptr[t] = first index i in the sorted keys with key[i] >= t, for t in [0, n_owned]
+__global__ void __launch_bounds__(256) k_rowptr_from_sorted(const uint32_t *__restrict__ keys, const unsigned long long *__restrict__ n_valid_ptr,
+                                                             int32_t n_owned, uint32_t *__restrict__ rowptr) {
+    const uint64_t nv = (uint64_t) *n_valid_ptr;
+    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i <= nv; i += (uint64_t) gridDim.x * blockDim.x) {
+        const int64_t lo = i == 0 ? 0 : (int64_t) keys[i - 1] + 1;
+        const int64_t hi = i == nv ? (int64_t) n_owned : (int64_t) keys[i];
+        for (int64_t t = lo; t <= hi; t++) rowptr[t] = (uint32_t) i;
     }
 }
 
@@ -407,111 +676,183 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_tiles(const uint32_t *__res
 }
 
 // ------------------------------------------------------------------------------------------
-// k_scatter_by_target : records -> segments; `cursor` starts as a copy of the in-degrees
-// ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_scatter_by_target(const uint32_t *__restrict__ rec_dst, const uint32_t *__restrict__ rec_src,
-                                                            const uint32_t *__restrict__ rec_ol, const unsigned long long *__restrict__ n_rec_ptr,
-                                                            uint64_t n_rec_max, int32_t dst_begin, int32_t dst_end,
-                                                            const uint32_t *__restrict__ rowptr, uint32_t *__restrict__ cursor,
-                                                            uint32_t *__restrict__ seg_src, uint32_t *__restrict__ seg_ol) {
-    uint64_t n_rec = n_rec_ptr ? (uint64_t) *n_rec_ptr : n_rec_max;
-    if (n_rec > n_rec_max) n_rec = n_rec_max;
-    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n_rec; i += (uint64_t) gridDim.x * blockDim.x) {
-        const uint32_t c = rec_dst[i];
-        if (c == REC_INVALID) continue;
-        int C = (int) c;
-        if (C < dst_begin || C >= dst_end) continue;
-        C -= dst_begin;
-        uint32_t pos = rowptr[C] + (atomicSub(&cursor[C], 1u) - 1u);
-        seg_src[pos] = rec_src[i];
-        seg_ol[pos] = rec_ol[i];
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// k_reduce_targets : one thread per target C, in-place in C's segment
+// k_reduce_targets : per-target replay of the reference's insertion order on the sorted segments
 //   processing order == the reference's with --threads=1: small overlaps first (they exist before
 //   the reversal at L == rsoemo, GraphCreatorPrefSuf.cpp:288-296), then big overlaps by
 //   (L ascending, source id ascending) (:94-100, :369).
+//   Survivors are written back, compacted, to the front of the target's segment.
+//
+//   Fast path (whole workgroup): the records of the workgroup's targets and the first 64 nt of each
+//   record's source read are staged in LDS with coalesced / independent loads; the sequential replay
+//   then touches LDS only.  A transitive check compares A[d, d+off) with B[0, off) where
+//   d + off = off_A: both operands lie inside the first off_A / off_B nucleotides of the SOURCE reads.
+//   Slow path: one thread per target on global memory (segments too long for LDS, offsets > 64 nt).
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint64_t seg_key(uint32_t src, uint32_t ol) {
-    return ((uint64_t) (ol_small(ol) ? 0u : 1u) << 63) | ((uint64_t) (uint32_t) ol_len(ol) << 32) | src;
+__device__ __forceinline__ uint64_t seg_key(unsigned long long val) {
+    const uint32_t ol = (uint32_t) (val >> 32);
+    return ((uint64_t) (ol_small(ol) ? 0u : 1u) << 63) | ((uint64_t) (uint32_t) ol_len(ol) << 32) | (uint32_t) val;
 }
 
 // A[d .. d+nnt) == B[0 .. nnt) on 2-bit packed rows; replaces the Bitset temp/shift/mismatchBounded
-// sequence of GraphCreatorPrefSuf.cpp:434-451 (Bitset.cpp:116-163,879-909)
-__device__ __forceinline__ bool eq_shifted(const uint32_t *__restrict__ rowA, const uint32_t *__restrict__ rowB,
-                                           int d, int nnt, int stride) {
+// sequence of GraphCreatorPrefSuf.cpp:434-451 (Bitset.cpp:116-163,879-909).  `wordsA` = readable words of A.
+__device__ __forceinline__ bool eq_shifted(const uint32_t *rowA, const uint32_t *rowB, int d, int nnt, int wordsA) {
     const int bit = 2 * d, q = bit >> 5, r = bit & 31;
     const int nbits = 2 * nnt;
     const int nw = (nbits + 31) >> 5;
+    uint32_t diff = 0;
     for (int k = 0; k < nw; k++) {
         const uint32_t lo = rowA[q + k];
-        const uint32_t hi = (r != 0 && q + k + 1 < stride) ? rowA[q + k + 1] : 0u;
+        const uint32_t hi = (r != 0 && q + k + 1 < wordsA) ? rowA[q + k + 1] : 0u;
         uint32_t x = funnel(lo, hi, r) ^ rowB[k];
         if (k == nw - 1 && (nbits & 31)) x &= (1u << (nbits & 31)) - 1u;
-        if (x) return false;
+        diff |= x;
     }
-    return true;
+    return diff == 0;
 }
 
+constexpr int RED_BLOCK = 256;
+constexpr int RED_CAP = 4096;        // records staged per workgroup
+constexpr int RED_HEAD_NT = 64;      // nucleotides of each source read staged (4 words)
+
 template <bool STATS>
-__global__ void __launch_bounds__(256)
-k_reduce_targets(NodesDev nd, PrefSufCfg cfg, int32_t dst_begin, int32_t n_owned, const uint32_t *__restrict__ rowptr,
-                 uint32_t *__restrict__ seg_src, uint32_t *__restrict__ seg_ol, uint32_t *__restrict__ out_cnt,
+__global__ void __launch_bounds__(RED_BLOCK)
+k_reduce_targets(NodesDev nd, PrefSufCfg cfg, int32_t dst_begin, int32_t n_owned, int32_t targets_per_block,
+                 const uint32_t *__restrict__ rowptr, unsigned long long *__restrict__ seg_val, uint32_t *__restrict__ out_cnt,
                  uint32_t *__restrict__ outdeg, unsigned long long *__restrict__ counters) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ unsigned long long sVal[RED_CAP];
+    __shared__ uint32_t sHead[RED_CAP * 4];
+    __shared__ uint16_t sIdx[RED_CAP];
+    __shared__ int sSlow;
+    const int t0 = blockIdx.x * targets_per_block;
+    const int t1 = min(t0 + targets_per_block, n_owned);
+    const uint32_t r0 = rowptr[t0], r1 = rowptr[t1];
+    const uint32_t cnt = r1 - r0;
+    if (threadIdx.x == 0) sSlow = (cnt > (uint32_t) RED_CAP) ? 1 : 0;
+    __syncthreads();
     uint64_t st_listed = 0, st_cmp = 0, st_rem = 0;
     uint32_t nlive = 0, k = 0;
-    if (t < n_owned) {
-        const uint32_t beg = rowptr[t];
-        k = rowptr[t + 1] - beg;
-        uint32_t *ss = seg_src + beg, *so = seg_ol + beg;
-        // insertion sort by processing order
-        for (uint32_t i = 1; i < k; i++) {
-            const uint32_t xs = ss[i], xo = so[i];
-            const uint64_t kx = seg_key(xs, xo);
-            uint32_t j = i;
-            while (j > 0 && seg_key(ss[j - 1], so[j - 1]) > kx) { ss[j] = ss[j - 1]; so[j] = so[j - 1]; j--; }
-            ss[j] = xs; so[j] = xo;
+    const int t = t0 + (int) threadIdx.x;
+    const bool has_target = (int) threadIdx.x < targets_per_block && t < t1;
+    bool fast = sSlow == 0;
+    if (fast) {
+        // stage the records and the first 64 nt of every record's source read
+        const bool vec = (nd.stride & 3) == 0;
+        int slow = 0;
+        for (uint32_t i = threadIdx.x; i < cnt; i += RED_BLOCK) {
+            const unsigned long long v = seg_val[r0 + i];
+            sVal[i] = v;
+            sIdx[i] = (uint16_t) i;
+            if (ol_off((uint32_t) (v >> 32)) > RED_HEAD_NT) slow = 1;
+            const uint32_t *row = nd.words + (size_t) (uint32_t) v * nd.stride;
+            uint4 h;
+            if (vec) h = *reinterpret_cast<const uint4 *>(row);
+            else { h.x = row[0]; h.y = nd.stride > 1 ? row[1] : 0u; h.z = nd.stride > 2 ? row[2] : 0u; h.w = nd.stride > 3 ? row[3] : 0u; }
+            sHead[4 * i + 0] = h.x; sHead[4 * i + 1] = h.y; sHead[4 * i + 2] = h.z; sHead[4 * i + 3] = h.w;
         }
-        for (uint32_t i = 0; i < k; i++) {
-            const uint32_t B = ss[i], ol = so[i];
-            const int off = ol_off(ol), L = ol_len(ol);
-            if (ol_small(ol)) {
-                // Graph::retainOnlySmallestOffset after the reversal (Graph.cpp:348-387): one entry per source
-                bool found = false;
-                for (uint32_t u = 0; u < nlive; u++) {
-                    if (ss[u] == B) { if (off < ol_off(so[u])) so[u] = ol; found = true; break; }
-                }
-                if (!found) { ss[nlive] = B; so[nlive] = ol; nlive++; }
-            } else {
-                if (STATS && off > 0) st_listed += nlive;
-                const uint32_t *rowB = nd.words + (size_t) B * nd.stride;
-                uint32_t w = 0;
-                for (uint32_t u = 0; u < nlive; u++) {
-                    const uint32_t A = ss[u], olA = so[u];
-                    bool remove = (A == B);                                   // toRemove[suffId], :461-462
-                    if (!remove && off > 0) {                                 // :406
-                        const int d = ol_off(olA) - off;                      // offsetDiff, :417
-                        if (d >= 0) {                                         // :420
-                            if (STATS) st_cmp++;
-                            // Read::getRightOffset(rA, rB, d) = |B| + d - |A| = L_B - L_A  (:429)
-                            if (L - ol_len(olA) >= 0) {
-                                const uint32_t *rowA = nd.words + (size_t) A * nd.stride;
-                                if (eq_shifted(rowA, rowB, d, off, nd.stride)) { remove = true; if (STATS) st_rem++; }
+        if (slow) sSlow = 1;
+        __syncthreads();
+        fast = sSlow == 0;
+    }
+    if (has_target) {
+        const uint32_t gbeg = rowptr[t];
+        k = rowptr[t + 1] - gbeg;
+        if (fast) {
+            uint16_t *ix = sIdx + (gbeg - r0);
+            for (uint32_t i = 1; i < k; i++) {                            // order the index list by processing order
+                const uint16_t x = ix[i];
+                const uint64_t kx = seg_key(sVal[x]);
+                uint32_t j = i;
+                while (j > 0 && seg_key(sVal[ix[j - 1]]) > kx) { ix[j] = ix[j - 1]; j--; }
+                ix[j] = x;
+            }
+            // the live list is the front of the index list: it never grows past the processed prefix
+            for (uint32_t i = 0; i < k; i++) {
+                const uint16_t xi = ix[i];
+                const unsigned long long vb = sVal[xi];
+                const uint32_t B = (uint32_t) vb, ol = (uint32_t) (vb >> 32);
+                const int off = ol_off(ol), L = ol_len(ol);
+                if (ol_small(ol)) {
+                    // Graph::retainOnlySmallestOffset after the reversal (Graph.cpp:348-387): one entry per source
+                    bool found = false;
+                    for (uint32_t u = 0; u < nlive; u++) {
+                        const unsigned long long va = sVal[ix[u]];
+                        if ((uint32_t) va == B) { if (off < ol_off((uint32_t) (va >> 32))) ix[u] = xi; found = true; break; }
+                    }
+                    if (!found) { ix[nlive] = xi; nlive++; }
+                } else {
+                    if (STATS && off > 0) st_listed += nlive;
+                    uint32_t w = 0;
+                    for (uint32_t u = 0; u < nlive; u++) {
+                        const uint16_t ya = ix[u];
+                        const unsigned long long va = sVal[ya];
+                        const uint32_t olA = (uint32_t) (va >> 32);
+                        bool remove = ((uint32_t) va == B);                       // toRemove[suffId], :461-462
+                        if (!remove && off > 0) {                                 // :406
+                            const int d = ol_off(olA) - off;                      // offsetDiff, :417
+                            if (d >= 0) {                                         // :420
+                                if (STATS) st_cmp++;
+                                // Read::getRightOffset(rA, rB, d) = |B| + d - |A| = L_B - L_A  (:429)
+                                if (L - ol_len(olA) >= 0 && eq_shifted(&sHead[4 * ya], &sHead[4 * xi], d, off, 4)) {
+                                    remove = true;
+                                    if (STATS) st_rem++;
+                                }
                             }
                         }
+                        if (!remove) { ix[w] = ya; w++; }
                     }
-                    if (!remove) { if (w != u) { ss[w] = A; so[w] = olA; } w++; }
+                    ix[w] = xi;                                                   // pushDirectedEdge(prefId, suffId, offset), :477
+                    nlive = w + 1;
                 }
-                ss[w] = B; so[w] = ol;                                        // pushDirectedEdge(prefId, suffId, offset), :477
-                nlive = w + 1;
+            }
+            for (uint32_t u = 0; u < nlive; u++) seg_val[gbeg + u] = sVal[ix[u]];
+        } else {
+            unsigned long long *sv = seg_val + gbeg;
+            for (uint32_t i = 1; i < k; i++) {
+                const unsigned long long x = sv[i];
+                const uint64_t kx = seg_key(x);
+                uint32_t j = i;
+                while (j > 0 && seg_key(sv[j - 1]) > kx) { sv[j] = sv[j - 1]; j--; }
+                sv[j] = x;
+            }
+            for (uint32_t i = 0; i < k; i++) {
+                const unsigned long long vb = sv[i];
+                const uint32_t B = (uint32_t) vb, ol = (uint32_t) (vb >> 32);
+                const int off = ol_off(ol), L = ol_len(ol);
+                if (ol_small(ol)) {
+                    bool found = false;
+                    for (uint32_t u = 0; u < nlive; u++) {
+                        const unsigned long long va = sv[u];
+                        if ((uint32_t) va == B) { if (off < ol_off((uint32_t) (va >> 32))) sv[u] = vb; found = true; break; }
+                    }
+                    if (!found) { sv[nlive] = vb; nlive++; }
+                } else {
+                    if (STATS && off > 0) st_listed += nlive;
+                    const uint32_t *rowB = nd.words + (size_t) B * nd.stride;
+                    uint32_t w = 0;
+                    for (uint32_t u = 0; u < nlive; u++) {
+                        const unsigned long long va = sv[u];
+                        const uint32_t A = (uint32_t) va, olA = (uint32_t) (va >> 32);
+                        bool remove = (A == B);
+                        if (!remove && off > 0) {
+                            const int d = ol_off(olA) - off;
+                            if (d >= 0) {
+                                if (STATS) st_cmp++;
+                                if (L - ol_len(olA) >= 0 && eq_shifted(nd.words + (size_t) A * nd.stride, rowB, d, off, nd.stride)) {
+                                    remove = true;
+                                    if (STATS) st_rem++;
+                                }
+                            }
+                        }
+                        if (!remove) { if (w != u) sv[w] = va; w++; }
+                    }
+                    sv[w] = vb;
+                    nlive = w + 1;
+                }
             }
         }
         out_cnt[t] = nlive;
         if (cfg.reversed) { if (nlive) outdeg[dst_begin + t] = nlive; }       // never-reversed quirk: rows are the targets
-        else for (uint32_t u = 0; u < nlive; u++) atomicAdd(&outdeg[ss[u]], 1u);
+        else for (uint32_t u = 0; u < nlive; u++) atomicAdd(&outdeg[(uint32_t) seg_val[gbeg + u]], 1u);
     }
     if (STATS) {
         st_listed = wave_sum_u64(st_listed); st_cmp = wave_sum_u64(st_cmp); st_rem = wave_sum_u64(st_rem);
@@ -530,15 +871,16 @@ k_reduce_targets(NodesDev nd, PrefSufCfg cfg, int32_t dst_begin, int32_t n_owned
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 k_scatter_by_source(PrefSufCfg cfg, int32_t dst_begin, int32_t n_owned, const uint32_t *__restrict__ rowptr,
-                    const uint32_t *__restrict__ seg_src, const uint32_t *__restrict__ seg_ol, const uint32_t *__restrict__ out_cnt,
+                    const unsigned long long *__restrict__ seg_val, const uint32_t *__restrict__ out_cnt,
                     const uint32_t *__restrict__ out_rowptr, uint32_t *__restrict__ out_cursor, alga_edge_dev *__restrict__ edges) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_owned) return;
     const uint32_t beg = rowptr[t], cnt = out_cnt[t];
     const int C = dst_begin + t;
     for (uint32_t u = 0; u < cnt; u++) {
-        const int A = (int) seg_src[beg + u];
-        const int off = ol_off(seg_ol[beg + u]);
+        const unsigned long long v = seg_val[beg + u];
+        const int A = (int) (uint32_t) v;
+        const int off = ol_off((uint32_t) (v >> 32));
         const int row = cfg.reversed ? C : A;
         const int col = cfg.reversed ? A : C;
         const uint32_t pos = out_rowptr[row] + (atomicSub(&out_cursor[row], 1u) - 1u);
@@ -567,12 +909,32 @@ static inline unsigned grid_for(uint64_t n, int block) { return (unsigned) ((n +
 
 void launch_node_stats(const NodesDev &nd, unsigned long long *counters, int *max_len, hipStream_t s) {
     if (nd.n <= 0) return;
-    hipLaunchKernelGGL(k_node_stats, dim3(grid_for((uint64_t) nd.n, 256)), dim3(256), 0, s, nd, counters, max_len);
+    unsigned g = std::min<unsigned>(grid_for((uint64_t) nd.n, 256), 1024u);
+    hipLaunchKernelGGL(k_node_stats, dim3(g), dim3(256), 0, s, nd, counters, max_len);
 }
 
-void launch_seed_build(const NodesDev &nd, const PrefSufCfg &cfg, unsigned long long *table, uint32_t mask, hipStream_t s) {
+uint32_t seed_buckets_for(uint64_t live, int fill_x10) {   // average entries per 8-entry bucket = fill_x10 / 10
+    if (fill_x10 < 5) fill_x10 = 5;
+    if (fill_x10 > 60) fill_x10 = 60;
+    uint64_t nb = (live * 10 + (uint64_t) fill_x10 - 1) / (uint64_t) fill_x10;
+    if (nb < 64) nb = 64;
+    return (uint32_t) std::min<uint64_t>(nb, 0x7FFFFFFFull);
+}
+
+// filter bits: 0 = no prefilter (it only pays while the bitmap fits an XCD's L2)
+uint32_t seed_filter_bits_for(uint64_t live) {
+    uint64_t want = live * 8;
+    if (want > (1ull << 25)) return 0;
+    uint64_t bits = 1ull << 16;
+    while (bits < want) bits <<= 1;
+    return (uint32_t) bits;
+}
+
+void launch_seed_build(const NodesDev &nd, const PrefSufCfg &cfg, unsigned long long *table, uint32_t n_buckets, uint32_t *filter,
+                       uint32_t filter_bits, hipStream_t s) {
     if (nd.n <= 0) return;
-    hipLaunchKernelGGL(k_seed_build, dim3(grid_for((uint64_t) nd.n, 256)), dim3(256), 0, s, nd, cfg, table, mask);
+    hipLaunchKernelGGL(k_seed_build, dim3(grid_for((uint64_t) nd.n, 256)), dim3(256), 0, s, nd, cfg, table, n_buckets,
+                       filter_bits ? filter : nullptr, filter_bits ? filter_bits - 1 : 0u);
 }
 
 static uint64_t probe_blocks(int n_cu, uint64_t n_src) {
@@ -580,25 +942,49 @@ static uint64_t probe_blocks(int n_cu, uint64_t n_src) {
     return std::max<uint64_t>(1, std::min<uint64_t>((n_src + PROBE_WAVES - 1) / PROBE_WAVES, (uint64_t) std::max(1, n_cu) * 8));
 }
 
-void launch_probe(const NodesDev &nd, const PrefSufCfg &cfg, const unsigned long long *table, uint32_t mask,
-                  int32_t src_begin, int32_t src_end, uint32_t *rec_dst, uint32_t *rec_src, uint32_t *rec_ol, uint64_t rec_cap,
-                  uint32_t *indeg, int32_t dst_begin, int32_t dst_end, unsigned long long *counters, int n_cu, hipStream_t s) {
-    const int64_t ns = (int64_t) src_end - src_begin;
-    if (ns <= 0) return;
-    dim3 grid((unsigned) probe_blocks(n_cu, (uint64_t) ns)), block(PROBE_WAVES * 64);
-    ProbeOut o{rec_dst, rec_src, rec_ol, rec_cap, indeg, dst_begin, dst_end, counters};
-    if (cfg.stats) hipLaunchKernelGGL(k_probe_sources<true>, grid, block, 0, s, nd, cfg, table, mask, src_begin, src_end, o);
-    else           hipLaunchKernelGGL(k_probe_sources<false>, grid, block, 0, s, nd, cfg, table, mask, src_begin, src_end, o);
-}
-
 uint64_t probe_record_slack(int n_cu, uint64_t n_src) {  // worst-case invalid padding of one launch
     return probe_blocks(n_cu, n_src) * PROBE_WAVES * REC_CHUNK;
 }
 
-void launch_count_targets(const uint32_t *rec_dst, uint64_t n_rec, int32_t dst_begin, int32_t dst_end, uint32_t *indeg, hipStream_t s) {
+struct ProbeTable { const unsigned long long *table; uint32_t n_buckets; const uint32_t *filter; uint32_t filter_mask; };
+
+template <int NQ>
+static void launch_probe_nq(const NodesDev &nd, const PrefSufCfg &cfg, const ProbeTable &t,
+                            int32_t src_begin, int32_t src_end, const ProbeOut &o, dim3 grid, dim3 block, hipStream_t s) {
+    if (cfg.stats) hipLaunchKernelGGL((k_probe_sources<true, NQ>), grid, block, 0, s, nd, cfg, t.table, t.n_buckets, t.filter, t.filter_mask, src_begin, src_end, o);
+    else           hipLaunchKernelGGL((k_probe_sources<false, NQ>), grid, block, 0, s, nd, cfg, t.table, t.n_buckets, t.filter, t.filter_mask, src_begin, src_end, o);
+}
+
+void launch_probe(const NodesDev &nd, const PrefSufCfg &cfg, const unsigned long long *table, uint32_t n_buckets,
+                  const uint32_t *filter, uint32_t filter_bits,
+                  int32_t src_begin, int32_t src_end, uint32_t *rec_dst, unsigned long long *rec_val, uint64_t rec_cap,
+                  unsigned long long *counters, int n_cu, hipStream_t s) {
+    const int64_t ns = (int64_t) src_end - src_begin;
+    if (ns <= 0) return;
+    dim3 grid((unsigned) probe_blocks(n_cu, (uint64_t) ns)), block(PROBE_WAVES * 64);
+    ProbeOut o{rec_dst, rec_val, rec_cap, counters};
+    ProbeTable t{table, n_buckets, filter_bits ? filter : nullptr, filter_bits ? filter_bits - 1 : 0u};
+    // widest prefix ever compared: Lcap nucleotides; wide path needs 16-byte aligned rows that hold it
+    const int need_q = (((2 * cfg.Lcap + 31) >> 5) + 3) >> 2;
+    const bool aligned = (nd.stride & 3) == 0 && ((uintptr_t) nd.words & 15u) == 0;
+    const int row_q = nd.stride >> 2;
+    if (aligned && need_q <= 2 && row_q >= 2)      launch_probe_nq<2>(nd, cfg, t, src_begin, src_end, o, grid, block, s);
+    else if (aligned && need_q <= 3 && row_q >= 3) launch_probe_nq<3>(nd, cfg, t, src_begin, src_end, o, grid, block, s);
+    else if (aligned && need_q <= 4 && row_q >= 4) launch_probe_nq<4>(nd, cfg, t, src_begin, src_end, o, grid, block, s);
+    else                                           launch_probe_nq<0>(nd, cfg, t, src_begin, src_end, o, grid, block, s);
+}
+
+void launch_make_keys(const uint32_t *rec_dst, uint64_t n_rec, int32_t dst_begin, int32_t dst_end, uint32_t *keys,
+                      unsigned long long *n_valid, hipStream_t s) {
     if (n_rec == 0) return;
-    unsigned g = grid_for(n_rec, 256); if (g > 8192) g = 8192;
-    hipLaunchKernelGGL(k_count_targets, dim3(g), dim3(256), 0, s, rec_dst, n_rec, dst_begin, dst_end, indeg);
+    unsigned g = std::min<unsigned>(grid_for(n_rec, 256 * 4), 4096u);
+    hipLaunchKernelGGL(k_make_keys, dim3(std::max(1u, g)), dim3(256), 0, s, rec_dst, n_rec, dst_begin, dst_end, keys, n_valid);
+}
+
+void launch_rowptr_from_sorted(const uint32_t *keys, const unsigned long long *n_valid_ptr, uint64_t n_rec_max, int32_t n_owned,
+                               uint32_t *rowptr, hipStream_t s) {
+    unsigned g = std::min<unsigned>(grid_for(n_rec_max + 1, 256), 8192u);
+    hipLaunchKernelGGL(k_rowptr_from_sorted, dim3(std::max(1u, g)), dim3(256), 0, s, keys, n_valid_ptr, n_owned, rowptr);
 }
 
 size_t scan_scratch_bytes(uint64_t n) {
@@ -617,31 +1003,30 @@ void launch_exclusive_scan(const uint32_t *in, uint64_t n, uint32_t *out, uint64
 
 uint64_t scan_total_index(uint64_t n) { return (n + SCAN_TILE - 1) / SCAN_TILE; }
 
-void launch_scatter_by_target(const uint32_t *rec_dst, const uint32_t *rec_src, const uint32_t *rec_ol,
-                              const unsigned long long *n_rec_ptr, uint64_t n_rec_max, int32_t dst_begin, int32_t dst_end,
-                              const uint32_t *rowptr, uint32_t *cursor, uint32_t *seg_src, uint32_t *seg_ol, hipStream_t s) {
-    if (n_rec_max == 0) return;
-    unsigned g = grid_for(n_rec_max, 256); if (g > 16384) g = 16384;
-    hipLaunchKernelGGL(k_scatter_by_target, dim3(g), dim3(256), 0, s, rec_dst, rec_src, rec_ol, n_rec_ptr, n_rec_max, dst_begin, dst_end,
-                       rowptr, cursor, seg_src, seg_ol);
+int reduce_targets_per_block(uint64_t n_records, uint64_t n_targets) {
+    // aim at ~60 % of the LDS record capacity so that ordinary fluctuations stay on the fast path
+    const double avg = n_targets ? (double) n_records / (double) n_targets : 0.0;
+    int tpb = avg > 0 ? (int) (0.6 * RED_CAP / avg) : RED_BLOCK;
+    return std::max(16, std::min(RED_BLOCK, tpb));
 }
 
-void launch_reduce_targets(const NodesDev &nd, const PrefSufCfg &cfg, int32_t dst_begin, int32_t n_owned, const uint32_t *rowptr,
-                           uint32_t *seg_src, uint32_t *seg_ol, uint32_t *out_cnt, uint32_t *outdeg, unsigned long long *counters, hipStream_t s) {
+void launch_reduce_targets(const NodesDev &nd, const PrefSufCfg &cfg, int32_t dst_begin, int32_t n_owned, int32_t targets_per_block,
+                           const uint32_t *rowptr, unsigned long long *seg_val, uint32_t *out_cnt, uint32_t *outdeg,
+                           unsigned long long *counters, hipStream_t s) {
     if (n_owned <= 0) return;
-    dim3 grid(grid_for((uint64_t) n_owned, 256)), block(256);
+    dim3 grid(grid_for((uint64_t) n_owned, targets_per_block)), block(RED_BLOCK);
     if (cfg.stats)
-        hipLaunchKernelGGL(k_reduce_targets<true>, grid, block, 0, s, nd, cfg, dst_begin, n_owned, rowptr, seg_src, seg_ol, out_cnt, outdeg, counters);
+        hipLaunchKernelGGL(k_reduce_targets<true>, grid, block, 0, s, nd, cfg, dst_begin, n_owned, targets_per_block, rowptr, seg_val, out_cnt, outdeg, counters);
     else
-        hipLaunchKernelGGL(k_reduce_targets<false>, grid, block, 0, s, nd, cfg, dst_begin, n_owned, rowptr, seg_src, seg_ol, out_cnt, outdeg, counters);
+        hipLaunchKernelGGL(k_reduce_targets<false>, grid, block, 0, s, nd, cfg, dst_begin, n_owned, targets_per_block, rowptr, seg_val, out_cnt, outdeg, counters);
 }
 
-void launch_scatter_by_source(const PrefSufCfg &cfg, int32_t dst_begin, int32_t n_owned, const uint32_t *rowptr, const uint32_t *seg_src,
-                              const uint32_t *seg_ol, const uint32_t *out_cnt, const uint32_t *out_rowptr, uint32_t *out_cursor,
+void launch_scatter_by_source(const PrefSufCfg &cfg, int32_t dst_begin, int32_t n_owned, const uint32_t *rowptr,
+                              const unsigned long long *seg_val, const uint32_t *out_cnt, const uint32_t *out_rowptr, uint32_t *out_cursor,
                               alga_edge_dev *edges, hipStream_t s) {
     if (n_owned <= 0) return;
-    hipLaunchKernelGGL(k_scatter_by_source, dim3(grid_for((uint64_t) n_owned, 256)), dim3(256), 0, s, cfg, dst_begin, n_owned, rowptr, seg_src,
-                       seg_ol, out_cnt, out_rowptr, out_cursor, edges);
+    hipLaunchKernelGGL(k_scatter_by_source, dim3(grid_for((uint64_t) n_owned, 256)), dim3(256), 0, s, cfg, dst_begin, n_owned, rowptr, seg_val,
+                       out_cnt, out_rowptr, out_cursor, edges);
 }
 
 void launch_sort_rows(int32_t n, const uint32_t *out_rowptr, alga_edge_dev *edges, hipStream_t s) {

@@ -89,9 +89,9 @@ def load_library():
     lib.alga_prefsuf_last_stats.argtypes = [C.c_void_p, C.POINTER(PrefSufStats)]
     lib.alga_prefsuf_discover_device.argtypes = [C.c_void_p, C.POINTER(_Nodes), C.POINTER(PrefSufParams), C.c_int32,
                                                  C.c_int32, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
-                                                 C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+                                                 C.POINTER(C.c_uint64)]
     lib.alga_prefsuf_reduce_device.argtypes = [C.c_void_p, C.POINTER(_Nodes), C.POINTER(PrefSufParams), C.c_void_p,
-                                               C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_int32, C.c_void_p,
+                                               C.c_void_p, C.c_uint64, C.c_int32, C.c_int32, C.c_void_p,
                                                C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
     lib.alga_write_graph.argtypes = [C.c_char_p, C.c_int32, C.c_void_p, C.c_uint64]
     _LIB = lib
@@ -223,18 +223,18 @@ class Engine:
 
     def discover_device(self, words, lens, min_overlap, rsoe_min_overlap, src_begin, src_end, align_from=None,
                         align_to=None, stream=None, collect_stats=False):
+        """-> (d_dst ptr [u32], d_val ptr [u64], n_record_slots); slots with dst == 0xFFFFFFFF are padding."""
         nd = self._nodes_from_torch(words, lens, align_from, align_to)
         p = self.params(min_overlap, rsoe_min_overlap, collect_stats)
-        d, s, o = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        d, v = C.c_void_p(), C.c_void_p()
         m = C.c_uint64()
         self._check(self._lib.alga_prefsuf_discover_device(self._h, C.byref(nd), C.byref(p), int(src_begin), int(src_end),
-                                                           C.c_void_p(stream or 0), C.byref(d), C.byref(s), C.byref(o),
-                                                           C.byref(m)))
-        return d.value, s.value, o.value, int(m.value)
+                                                           C.c_void_p(stream or 0), C.byref(d), C.byref(v), C.byref(m)))
+        return d.value, v.value, int(m.value)
 
-    def reduce_device(self, words, lens, min_overlap, rsoe_min_overlap, rec_dst, rec_src, rec_ol, n_records, dst_begin,
+    def reduce_device(self, words, lens, min_overlap, rsoe_min_overlap, rec_dst, rec_val, n_records, dst_begin,
                       dst_end, align_from=None, align_to=None, stream=None, collect_stats=False):
-        """rec_*: device pointers (ints) or torch int32 tensors."""
+        """rec_dst (int32) / rec_val (int64): device pointers (ints) or torch tensors."""
         nd = self._nodes_from_torch(words, lens, align_from, align_to)
         p = self.params(min_overlap, rsoe_min_overlap, collect_stats)
 
@@ -242,8 +242,8 @@ class Engine:
             return C.c_void_p(x if isinstance(x, int) else x.data_ptr())
         out = C.c_void_p()
         m = C.c_uint64()
-        self._check(self._lib.alga_prefsuf_reduce_device(self._h, C.byref(nd), C.byref(p), ptr(rec_dst), ptr(rec_src),
-                                                         ptr(rec_ol), int(n_records), int(dst_begin), int(dst_end),
+        self._check(self._lib.alga_prefsuf_reduce_device(self._h, C.byref(nd), C.byref(p), ptr(rec_dst), ptr(rec_val),
+                                                         int(n_records), int(dst_begin), int(dst_end),
                                                          C.c_void_p(stream or 0), C.byref(out), C.byref(m)))
         return out.value, int(m.value)
 
@@ -261,12 +261,13 @@ class _DevArray:
         self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2}
 
 
-def device_view(ptr, shape, device=None):
-    """torch int32 tensor aliasing `ptr` (no copy).  Valid until the engine reuses the buffer."""
+def device_view(ptr, shape, device=None, typestr="<i4"):
+    """torch tensor (int32, or int64 with typestr "<i8") aliasing `ptr` (no copy).  Valid until the engine reuses
+    the buffer."""
     import torch
     if int(np.prod(shape)) == 0:
-        return torch.empty(tuple(shape), dtype=torch.int32, device=device or "cuda")
-    return torch.as_tensor(_DevArray(ptr, shape), device=device or "cuda")
+        return torch.empty(tuple(shape), dtype=torch.int32 if typestr == "<i4" else torch.int64, device=device or "cuda")
+    return torch.as_tensor(_DevArray(ptr, shape, typestr), device=device or "cuda")
 
 
 def device_edges_to_numpy(ptr, n_edges):

@@ -39,28 +39,29 @@ class ShardedPrefSuf:
         dist, eng, r, nr = self.dist, self.eng, self.rank, self.world
         b = self.bounds
         dev = self.w.device
-        d, s, o, k = eng.discover_device(self.w, self.l, self.lo, self.rs, b[r], b[r + 1], collect_stats=collect_stats)
+        d, v, k = eng.discover_device(self.w, self.l, self.lo, self.rs, b[r], b[r + 1], collect_stats=collect_stats)
         st = eng.last_stats()
         t0 = time.perf_counter()
-        rec = torch.stack([device_view(d, (k,), dev), device_view(s, (k,), dev), device_view(o, (k,), dev)])  # [3, k]
-        # owner of a record = rank whose target range holds dst; invalid padding (dst = -1 as int32) is dropped
+        rdst, rval = device_view(d, (k,), dev), device_view(v, (k,), dev, "<i8")
+        # owner of a record = rank whose target range holds dst; chunk padding (dst = -1 as int32) is dropped
         bounds_t = torch.tensor(b[1:], dtype=torch.int32, device=dev)
-        valid = rec[0] >= 0
-        rec = rec[:, valid]
-        owner = torch.searchsorted(bounds_t, rec[0], right=True)
+        valid = rdst >= 0
+        rdst, rval = rdst[valid], rval[valid]
+        owner = torch.searchsorted(bounds_t, rdst, right=True)
         order = torch.argsort(owner, stable=True)
-        send = rec[:, order].contiguous()
+        send_d, send_v = rdst[order].contiguous(), rval[order].contiguous()
         sc = torch.bincount(owner, minlength=nr)[:nr]
         rcnt = torch.empty_like(sc)
         dist.all_to_all_single(rcnt, sc)
         sc_l, rc_l = [int(x) for x in sc.cpu()], [int(x) for x in rcnt.cpu()]
         tot = sum(rc_l)
-        recv = torch.empty((3, max(tot, 1)), dtype=torch.int32, device=dev)
-        for j in range(3):
-            dist.all_to_all_single(recv[j, :tot], send[j], output_split_sizes=rc_l, input_split_sizes=sc_l)
+        recv_d = torch.empty(max(tot, 1), dtype=torch.int32, device=dev)
+        recv_v = torch.empty(max(tot, 1), dtype=torch.int64, device=dev)
+        dist.all_to_all_single(recv_d[:tot], send_d, output_split_sizes=rc_l, input_split_sizes=sc_l)
+        dist.all_to_all_single(recv_v[:tot], send_v, output_split_sizes=rc_l, input_split_sizes=sc_l)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        ptr, m = eng.reduce_device(self.w, self.l, self.lo, self.rs, recv[0], recv[1], recv[2], tot, b[r], b[r + 1],
+        ptr, m = eng.reduce_device(self.w, self.l, self.lo, self.rs, recv_d, recv_v, tot, b[r], b[r + 1],
                                    collect_stats=collect_stats)
         st2 = eng.last_stats()
         t2 = time.perf_counter()

@@ -123,18 +123,19 @@ int  alga_prefsuf_last_stats(const alga_engine *e, alga_prefsuf_stats *out);
 
 /* ---- sharded form (one process per GPU; the exchange between the two calls is the caller's) ----
  * Phase 1, on every rank: discover the overlaps whose SOURCE node id is in [src_begin, src_end)
- * against the full (replicated) node set, apply the per-source small-overlap cap, and return the
- * overlap records as device arrays of *n_records entries:
- *   d_dst[i], d_src[i] : node ids;  d_ol[i] : offset | (overlap_len << 12) | (small << 31)
- * Phase 2, on the rank that owns the target ids: reduce records (any order, all records of an
- * owned target present) to edges.  Records of targets outside [dst_begin, dst_end) are ignored. */
+ * against the full (replicated) node set, apply the per-source small-overlap cap (it is per source,
+ * so it needs no exchange: GraphCreatorPrefSuf.cpp:397-401), and return the overlap records as two
+ * device arrays of *n_records slots (engine-owned, valid until the next call on `e`):
+ *   d_dst[i] : target node id, or 0xFFFFFFFF for an unused slot (skip it)
+ *   d_val[i] : (ol << 32) | source node id,  ol = offset | (overlap_len << 12) | (small << 31)
+ * Phase 2, on the rank that owns the target ids [dst_begin, dst_end): reduce records (any order,
+ * every record of an owned target present) to edges.  Slots with d_dst outside the range are ignored. */
 int  alga_prefsuf_discover_device(alga_engine *e, const alga_nodes *nodes, const alga_prefsuf_params *p,
                                   int32_t src_begin, int32_t src_end, void *hip_stream,
-                                  const uint32_t **d_dst, const uint32_t **d_src, const uint32_t **d_ol,
-                                  uint64_t *n_records);
+                                  const uint32_t **d_dst, const uint64_t **d_val, uint64_t *n_records);
 int  alga_prefsuf_reduce_device(alga_engine *e, const alga_nodes *nodes, const alga_prefsuf_params *p,
-                                const uint32_t *d_dst, const uint32_t *d_src, const uint32_t *d_ol,
-                                uint64_t n_records, int32_t dst_begin, int32_t dst_end, void *hip_stream,
+                                const uint32_t *d_dst, const uint64_t *d_val, uint64_t n_records,
+                                int32_t dst_begin, int32_t dst_end, void *hip_stream,
                                 const alga_edge **d_edges, uint64_t *n_edges);
 
 /* ---- graph dump: the reference's own checkpoint format ------------------------------------ */

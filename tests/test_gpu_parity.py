@@ -140,13 +140,14 @@ def test_device_resident_and_sharded_paths_agree(eng):
     n = len(lens)
     recs = []
     for a, b in ((0, n // 3), (n // 3, n // 2), (n // 2, n)):
-        d, s, o, k = eng.discover_device(dw, dl, 82, 116, a, b)
+        d, v, k = eng.discover_device(dw, dl, 82, 116, a, b)
         if k:
-            recs.append(torch.stack([device_view(p, (k,)) for p in (d, s, o)]).clone())   # incl. invalid padding
-    rec = torch.cat(recs, dim=1).contiguous()
+            recs.append((device_view(d, (k,)).clone(), device_view(v, (k,), typestr="<i8").clone()))   # incl. padding
+    rd = torch.cat([r[0] for r in recs]).contiguous()
+    rv = torch.cat([r[1] for r in recs]).contiguous()
     parts = []
     for a, b in ((0, n // 2 + 7), (n // 2 + 7, n)):
-        ptr, m = eng.reduce_device(dw, dl, 82, 116, rec[0], rec[1], rec[2], rec.shape[1], a, b)
+        ptr, m = eng.reduce_device(dw, dl, 82, 116, rd, rv, rd.shape[0], a, b)
         parts.append(device_edges_to_numpy(ptr, m))
     allp = np.concatenate(parts)
     order = np.lexsort((allp[:, 2], allp[:, 1], allp[:, 0]))
