@@ -43,7 +43,7 @@ struct alga_engine {
     int         use_filter = 1;               // L2-resident fingerprint bitmap in front of the seed table (ALGA_SEED_FILTER=0 disables)           // average seed-table bucket fill x10 (tunable: ALGA_SEED_FILL_X10)
     hipEvent_t  ev[EV_COUNT] = {};
     // device buffers, grown on demand and kept between calls
-    DevBuf table, filter, counters, rowptr, rec_dst, rec_val, keys, seg_key, seg_val, sort_temp, out_cnt, outdeg, out_rowptr, edges, scan_scratch;
+    DevBuf table, filter, counters, rowptr, rec_dst, rec_val, keys, seg_key, seg_val, heads, sort_temp, out_cnt, outdeg, out_rowptr, edges, scan_scratch;
     DevBuf edge_keys, edge_keys2, edge_vals, edge_vals2, edges_sorted;
     DevBuf up_words, up_len, up_from, up_to;   // uploads of the host-buffer entry point
     unsigned long long *h_counters = nullptr;  // pinned, CNT_TOTAL + 2 entries
@@ -212,6 +212,7 @@ int reduce_impl(alga_engine *e, const Prepared &pp, const uint32_t *rec_dst, con
     if ((rc = ensure(e, e->seg_key, (size_t) (n_rec + 1) * sizeof(uint32_t)))) return rc;
     if ((rc = ensure(e, e->seg_val, (size_t) (n_rec + 1) * sizeof(unsigned long long)))) return rc;
     if ((rc = ensure(e, e->sort_temp, temp_bytes))) return rc;
+    if ((rc = ensure(e, e->heads, (size_t) (n_rec + 1) * 16))) return rc;
     if ((rc = ensure(e, e->rowptr, (size_t) (n_owned + 2) * sizeof(uint32_t)))) return rc;
     HIP_TRY(e, hipMemsetAsync(cnt + CNT_SORT_VALID, 0, sizeof(unsigned long long), s));
     launch_make_keys(rec_dst, n_rec, dst_begin, dst_end, (uint32_t *) e->keys.p, cnt + CNT_SORT_VALID, s);
@@ -220,6 +221,8 @@ int reduce_impl(alga_engine *e, const Prepared &pp, const uint32_t *rec_dst, con
                             (unsigned long long *) e->seg_val.p, n_rec, bits, s));
     launch_rowptr_from_sorted((const uint32_t *) e->seg_key.p, cnt + CNT_SORT_VALID, n_rec, n_owned, (uint32_t *) e->rowptr.p, s);
     if ((rc = check_launch(e, "k_rowptr_from_sorted"))) return rc;
+    launch_gather_heads(nd, (const unsigned long long *) e->seg_val.p, cnt + CNT_SORT_VALID, n_rec, e->heads.p, s);
+    if ((rc = check_launch(e, "k_gather_heads"))) return rc;
     HIP_TRY(e, hipEventRecord(e->ev[EV_GROUP], s));
 
     if ((rc = ensure(e, e->out_cnt, (size_t) (n_owned + 1) * sizeof(uint32_t)))) return rc;
@@ -227,7 +230,7 @@ int reduce_impl(alga_engine *e, const Prepared &pp, const uint32_t *rec_dst, con
     HIP_TRY(e, hipMemsetAsync(e->outdeg.p, 0, (size_t) (nd.n + 1) * sizeof(uint32_t), s));
     const int tpb = reduce_targets_per_block(n_valid_hint, (uint64_t) std::max(1, n_owned));
     launch_reduce_targets(nd, cfg, dst_begin, n_owned, tpb, (const uint32_t *) e->rowptr.p, (unsigned long long *) e->seg_val.p,
-                          (uint32_t *) e->out_cnt.p, (uint32_t *) e->outdeg.p, cnt, s);
+                          e->heads.p, (uint32_t *) e->out_cnt.p, (uint32_t *) e->outdeg.p, cnt, s);
     if ((rc = check_launch(e, "k_reduce_targets"))) return rc;
     HIP_TRY(e, hipEventRecord(e->ev[EV_REDUCE], s));
 
@@ -304,7 +307,7 @@ void alga_engine_destroy(alga_engine *e) {
     if (!e) return;
     (void) hipSetDevice(e->device);
     if (e->own_stream) (void) hipStreamSynchronize(e->own_stream);
-    DevBuf *bufs[] = {&e->table, &e->filter, &e->counters, &e->rowptr, &e->rec_dst, &e->rec_val, &e->keys, &e->seg_key, &e->seg_val, &e->sort_temp,
+    DevBuf *bufs[] = {&e->table, &e->filter, &e->counters, &e->rowptr, &e->rec_dst, &e->rec_val, &e->keys, &e->seg_key, &e->seg_val, &e->heads, &e->sort_temp,
                       &e->out_cnt, &e->outdeg, &e->out_rowptr, &e->edges, &e->scan_scratch, &e->up_words, &e->up_len, &e->up_from, &e->up_to,
                       &e->edge_keys, &e->edge_keys2, &e->edge_vals, &e->edge_vals2, &e->edges_sorted};
     for (DevBuf *b : bufs) release(*b);

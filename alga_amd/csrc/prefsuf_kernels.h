@@ -35,8 +35,10 @@ uint64_t scan_total_index(uint64_t n); // scratch[scan_total_index(n)] holds the
 void launch_exclusive_scan(const uint32_t *in, uint64_t n, uint32_t *out, uint64_t *scratch, hipStream_t s);
 
 int  reduce_targets_per_block(uint64_t n_records, uint64_t n_targets);
+void launch_gather_heads(const NodesDev &nd, const unsigned long long *seg_val, const unsigned long long *n_valid_ptr, uint64_t n_rec_max,
+                         void *heads /* 16 B per record */, hipStream_t s);
 void launch_reduce_targets(const NodesDev &nd, const PrefSufCfg &cfg, int32_t dst_begin, int32_t n_owned, int32_t targets_per_block,
-                           const uint32_t *rowptr, unsigned long long *seg_val, uint32_t *out_cnt, uint32_t *outdeg,
+                           const uint32_t *rowptr, unsigned long long *seg_val, const void *heads, uint32_t *out_cnt, uint32_t *outdeg,
                            unsigned long long *counters, hipStream_t s);
 void launch_scatter_by_source(const PrefSufCfg &cfg, int32_t dst_begin, int32_t n_owned, const uint32_t *rowptr,
                               const unsigned long long *seg_val, const uint32_t *out_cnt, const uint32_t *out_rowptr, uint32_t *out_cursor,

@@ -172,7 +172,7 @@ constexpr int STAGE_WORDS = 52;       // staged tail (<= 33 words) + slack for u
 constexpr int CANDMAX = 128;          // per-wave candidate buffer
 constexpr int WBUF = 256;             // per-wave LDS record buffer (records)
 constexpr int WFLUSH = 128;           // flush once this many are buffered
-constexpr int REC_CHUNK = 512;        // records reserved per global atomic
+constexpr int REC_CHUNK = 1024;       // records reserved per global atomic
 
 // keep a >= b >= c = the three largest keys seen (branch-free: the three keys must stay in registers)
 __device__ __forceinline__ void top3_insert(uint64_t &a, uint64_t &b, uint64_t &c, uint64_t k) {
@@ -711,14 +711,29 @@ __device__ __forceinline__ bool eq_shifted(const uint32_t *rowA, const uint32_t 
 }
 
 constexpr int RED_BLOCK = 256;
-constexpr int RED_CAP = 4096;        // records staged per workgroup
+constexpr int RED_CAP = 2048;        // records staged per workgroup (52 KB of LDS: three workgroups per CU)
 constexpr int RED_HEAD_NT = 64;      // nucleotides of each source read staged (4 words)
+
+// heads[i] = first 16 bytes (64 nt) of the source read of sorted record i.  A separate, fully parallel gather:
+// inside the reduction the same loads would sit in a dependent chain at one workgroup per CU.
+__global__ void __launch_bounds__(256) k_gather_heads(NodesDev nd, const unsigned long long *__restrict__ seg_val,
+                                                       const unsigned long long *__restrict__ n_valid_ptr, uint4 *__restrict__ heads) {
+    const uint64_t nv = (uint64_t) *n_valid_ptr;
+    const bool vec = (nd.stride & 3) == 0 && ((uintptr_t) nd.words & 15u) == 0;
+    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (uint64_t) gridDim.x * blockDim.x) {
+        const uint32_t *row = nd.words + (size_t) (uint32_t) seg_val[i] * nd.stride;
+        uint4 h;
+        if (vec) h = *reinterpret_cast<const uint4 *>(row);
+        else { h.x = row[0]; h.y = nd.stride > 1 ? row[1] : 0u; h.z = nd.stride > 2 ? row[2] : 0u; h.w = nd.stride > 3 ? row[3] : 0u; }
+        heads[i] = h;
+    }
+}
 
 template <bool STATS>
 __global__ void __launch_bounds__(RED_BLOCK)
 k_reduce_targets(NodesDev nd, PrefSufCfg cfg, int32_t dst_begin, int32_t n_owned, int32_t targets_per_block,
-                 const uint32_t *__restrict__ rowptr, unsigned long long *__restrict__ seg_val, uint32_t *__restrict__ out_cnt,
-                 uint32_t *__restrict__ outdeg, unsigned long long *__restrict__ counters) {
+                 const uint32_t *__restrict__ rowptr, unsigned long long *__restrict__ seg_val, const uint4 *__restrict__ heads,
+                 uint32_t *__restrict__ out_cnt, uint32_t *__restrict__ outdeg, unsigned long long *__restrict__ counters) {
     __shared__ unsigned long long sVal[RED_CAP];
     __shared__ uint32_t sHead[RED_CAP * 4];
     __shared__ uint16_t sIdx[RED_CAP];
@@ -735,18 +750,14 @@ k_reduce_targets(NodesDev nd, PrefSufCfg cfg, int32_t dst_begin, int32_t n_owned
     const bool has_target = (int) threadIdx.x < targets_per_block && t < t1;
     bool fast = sSlow == 0;
     if (fast) {
-        // stage the records and the first 64 nt of every record's source read
-        const bool vec = (nd.stride & 3) == 0;
+        // stage the records and the first 64 nt of every record's source read (both streams are contiguous)
         int slow = 0;
         for (uint32_t i = threadIdx.x; i < cnt; i += RED_BLOCK) {
             const unsigned long long v = seg_val[r0 + i];
+            const uint4 h = heads[r0 + i];
             sVal[i] = v;
             sIdx[i] = (uint16_t) i;
             if (ol_off((uint32_t) (v >> 32)) > RED_HEAD_NT) slow = 1;
-            const uint32_t *row = nd.words + (size_t) (uint32_t) v * nd.stride;
-            uint4 h;
-            if (vec) h = *reinterpret_cast<const uint4 *>(row);
-            else { h.x = row[0]; h.y = nd.stride > 1 ? row[1] : 0u; h.z = nd.stride > 2 ? row[2] : 0u; h.w = nd.stride > 3 ? row[3] : 0u; }
             sHead[4 * i + 0] = h.x; sHead[4 * i + 1] = h.y; sHead[4 * i + 2] = h.z; sHead[4 * i + 3] = h.w;
         }
         if (slow) sSlow = 1;
@@ -1010,15 +1021,24 @@ int reduce_targets_per_block(uint64_t n_records, uint64_t n_targets) {
     return std::max(16, std::min(RED_BLOCK, tpb));
 }
 
+void launch_gather_heads(const NodesDev &nd, const unsigned long long *seg_val, const unsigned long long *n_valid_ptr, uint64_t n_rec_max,
+                         void *heads, hipStream_t s) {
+    if (n_rec_max == 0) return;
+    unsigned g = std::min<unsigned>(grid_for(n_rec_max, 256), 16384u);
+    hipLaunchKernelGGL(k_gather_heads, dim3(std::max(1u, g)), dim3(256), 0, s, nd, seg_val, n_valid_ptr, (uint4 *) heads);
+}
+
 void launch_reduce_targets(const NodesDev &nd, const PrefSufCfg &cfg, int32_t dst_begin, int32_t n_owned, int32_t targets_per_block,
-                           const uint32_t *rowptr, unsigned long long *seg_val, uint32_t *out_cnt, uint32_t *outdeg,
+                           const uint32_t *rowptr, unsigned long long *seg_val, const void *heads, uint32_t *out_cnt, uint32_t *outdeg,
                            unsigned long long *counters, hipStream_t s) {
     if (n_owned <= 0) return;
     dim3 grid(grid_for((uint64_t) n_owned, targets_per_block)), block(RED_BLOCK);
     if (cfg.stats)
-        hipLaunchKernelGGL(k_reduce_targets<true>, grid, block, 0, s, nd, cfg, dst_begin, n_owned, targets_per_block, rowptr, seg_val, out_cnt, outdeg, counters);
+        hipLaunchKernelGGL(k_reduce_targets<true>, grid, block, 0, s, nd, cfg, dst_begin, n_owned, targets_per_block, rowptr, seg_val,
+                           (const uint4 *) heads, out_cnt, outdeg, counters);
     else
-        hipLaunchKernelGGL(k_reduce_targets<false>, grid, block, 0, s, nd, cfg, dst_begin, n_owned, targets_per_block, rowptr, seg_val, out_cnt, outdeg, counters);
+        hipLaunchKernelGGL(k_reduce_targets<false>, grid, block, 0, s, nd, cfg, dst_begin, n_owned, targets_per_block, rowptr, seg_val,
+                           (const uint4 *) heads, out_cnt, outdeg, counters);
 }
 
 void launch_scatter_by_source(const PrefSufCfg &cfg, int32_t dst_begin, int32_t n_owned, const uint32_t *rowptr,
