@@ -45,10 +45,26 @@ class PrefSufStats(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
 
 
+class IngestParams(C.Structure):
+    """alga_ingest_params"""
+    _fields_ = [("trim_left", C.c_int32), ("trim_right", C.c_int32), ("remove_reads_with_n", C.c_int32), ("rna", C.c_int32),
+                ("scale", C.c_float), ("min_overlap", C.c_int32), ("rsoemo", C.c_int32), ("remove_pref_reads", C.c_int32),
+                ("threads", C.c_int32)]
+
+
+class NodeSet(C.Structure):
+    """alga_node_set"""
+    _fields_ = [("n", C.c_int32), ("stride_words", C.c_int32), ("words", C.POINTER(C.c_uint32)), ("len", C.POINTER(C.c_int32)),
+                ("pair_off", C.POINTER(C.c_uint8)), ("LEN", C.c_int32), ("min_overlap", C.c_int32), ("rsoemo", C.c_int32),
+                ("li_kmer_length", C.c_int32), ("records", C.c_int64), ("removed_n", C.c_int32), ("removed_str", C.c_int32),
+                ("removed_prefix", C.c_int32), ("removed_short", C.c_int32), ("avg_len", C.c_double)]
+
+
 EXPORTS = ["alga_abi_version", "alga_engine_create", "alga_engine_destroy", "alga_last_error",
            "alga_engine_device_name", "alga_prefsuf_default_params", "alga_prefsuf_build_host", "alga_free_edges",
            "alga_prefsuf_build_device", "alga_prefsuf_last_stats", "alga_prefsuf_discover_device",
-           "alga_prefsuf_reduce_device", "alga_write_graph"]
+           "alga_prefsuf_reduce_device", "alga_write_graph", "alga_ingest_default_params", "alga_ingest_files",
+           "alga_free_node_set"]
 
 
 def library_path():
@@ -94,8 +110,37 @@ def load_library():
                                                C.c_void_p, C.c_uint64, C.c_int32, C.c_int32, C.c_void_p,
                                                C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
     lib.alga_write_graph.argtypes = [C.c_char_p, C.c_int32, C.c_void_p, C.c_uint64]
+    lib.alga_ingest_default_params.argtypes = [C.POINTER(IngestParams)]
+    lib.alga_ingest_default_params.restype = None
+    lib.alga_ingest_files.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(IngestParams), C.POINTER(NodeSet), C.c_char_p, C.c_size_t]
+    lib.alga_free_node_set.argtypes = [C.POINTER(NodeSet)]
+    lib.alga_free_node_set.restype = None
     _LIB = lib
     return lib
+
+
+def ingest_files(file1, file2=None, threads=1, **kw):
+    """Host input stages (C++, alga_amd/host/ingest.cpp) through the C ABI -> dict with numpy copies."""
+    lib = load_library()
+    p = IngestParams()
+    lib.alga_ingest_default_params(C.byref(p))
+    p.threads = int(threads)
+    for k, v in kw.items():
+        setattr(p, k, v)
+    ns = NodeSet()
+    err = C.create_string_buffer(512)
+    rc = lib.alga_ingest_files(file1.encode(), (file2 or "").encode() or None, C.byref(p), C.byref(ns), err, 512)
+    if rc:
+        raise AlgaError(rc, err.value.decode())
+    n, st = ns.n, ns.stride_words
+    out = dict(n=n, stride=st,
+               words=np.ctypeslib.as_array(ns.words, shape=(max(n, 1) * st,))[: n * st].reshape(n, st).copy(),
+               len=np.ctypeslib.as_array(ns.len, shape=(max(n, 1),))[:n].copy(),
+               pair_off=np.ctypeslib.as_array(ns.pair_off, shape=(max(n, 1),))[:n].copy(),
+               LEN=ns.LEN, min_overlap=ns.min_overlap, rsoemo=ns.rsoemo, li_kmer_length=ns.li_kmer_length, records=ns.records,
+               removed_n=ns.removed_n, removed_str=ns.removed_str, removed_prefix=ns.removed_prefix, removed_short=ns.removed_short)
+    lib.alga_free_node_set(C.byref(ns))
+    return out
 
 
 def pack_reads(codes, lens=None, stride_words=None):

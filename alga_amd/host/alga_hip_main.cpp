@@ -1,0 +1,96 @@
+// alga_amd/host/alga_hip_main.cpp -- `alga_hip`: ALGA's command line in front of the MI355X overlap engine.
+//
+//   alga_hip --file1=reads.fasta [--file2=mates.fasta] --output=contigs.fasta [--threads=N] [--error_rate=R | --error-rate=R]
+//            [--serialize=1] [-l MINOVERLAP] [--rsoemo=N] [--scale=F] [--retl=N --retr=N] [--remove_reads_with_n=0|1] [--rna=0|1]
+//            [--device=K] [--alga=/path/to/stock/ALGA]
+//
+// It reads the input exactly like the reference (src/IO/InputReader.cpp, src/IO/ReadPreprocess.cpp, src/main.cpp:93-266),
+// builds the overlap graph on the GPU and writes `<TEST_NAME>_beforeSimplifier.graph` in the reference's own dump
+// format (src/DataStructures/Graph.cpp:269-297).  Stock ALGA started with the same arguments plus
+// --deserialize_graph=1 loads that file instead of running its GraphCreator (src/main.cpp:242) and carries on with
+// the unchanged simplifier / contig stages; `--alga=` does that hand-off in one go.
+// Both spellings of the error-rate option are accepted (the reference registers `error_rate` only, src/Params.cpp:226).
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "GraphCreatorHIP.hpp"
+#include "ingest.hpp"
+
+static bool opt(const char *arg, const char *name, std::string &val) {
+    size_t n = strlen(name);
+    if (strncmp(arg, name, n) == 0 && arg[n] == '=') { val = arg + n + 1; return true; }
+    return false;
+}
+
+int main(int argc, char **argv) {
+    using clk = std::chrono::steady_clock;
+    std::string file1, file2, output, alga_exe, v;
+    alga_host::IngestParams ip;
+    double error_rate = 0.0;
+    int device = 0, serialize = 1;
+    std::vector<std::string> passthrough;
+    for (int i = 1; i < argc; i++) {
+        const char *a = argv[i];
+        if (opt(a, "--file1", v)) file1 = v;
+        else if (opt(a, "--file2", v)) file2 = v;
+        else if (opt(a, "--output", v)) output = v;
+        else if (opt(a, "--threads", v)) ip.threads = std::max(1, atoi(v.c_str()));
+        else if (opt(a, "--error_rate", v) || opt(a, "--error-rate", v) || opt(a, "--er", v)) error_rate = atof(v.c_str());
+        else if (opt(a, "--serialize", v)) serialize = atoi(v.c_str());
+        else if (opt(a, "--rsoemo", v)) ip.rsoemo = atoi(v.c_str());
+        else if (opt(a, "--scale", v)) ip.scale = (float) atof(v.c_str());
+        else if (opt(a, "--retl", v) || opt(a, "--read_end_trim_left", v)) ip.trim_left = atoi(v.c_str());
+        else if (opt(a, "--retr", v) || opt(a, "--read_end_trim_right", v)) ip.trim_right = atoi(v.c_str());
+        else if (opt(a, "--remove_reads_with_n", v)) ip.remove_reads_with_n = atoi(v.c_str());
+        else if (opt(a, "--rna", v)) ip.rna = atoi(v.c_str());
+        else if (opt(a, "--device", v)) device = atoi(v.c_str());
+        else if (opt(a, "--alga", v)) alga_exe = v;
+        else if (!strcmp(a, "-l") && i + 1 < argc) ip.min_overlap = atoi(argv[++i]);
+        else { fprintf(stderr, "alga_hip: unrecognized option '%s'\n", a); return 2; }
+        if (strncmp(a, "--device", 8) && strncmp(a, "--alga", 6)) { passthrough.push_back(a); if (!strcmp(a, "-l")) passthrough.push_back(argv[i]); }
+    }
+    if (file1.empty()) { fprintf(stderr, "\nERROR - PLEASE PROVIDE THE INPUT FILE using --file1 option!\n"); return 1; }
+    if (output.empty()) { fprintf(stderr, "\nERROR - PLEASE PROVIDE THE OUTPUT FILE NAME!\n"); return 1; }
+    if (error_rate > 0.01) {
+        // src/Params.cpp:357-359: rates above 1 % switch on the approximate supplement (GraphCreatorLI); that path is
+        // not in this build yet -- refuse rather than silently return the error-free graph.
+        fprintf(stderr, "alga_hip: --error_rate > 0.01 needs the approximate supplement, which this build does not have\n");
+        return 3;
+    }
+    auto t0 = clk::now();
+    alga_host::NodeSet nodes;
+    std::string err = alga_host::ingest(file1, file2, ip, nodes);
+    if (!err.empty()) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
+    auto t1 = clk::now();
+    fprintf(stderr, "input read: %lld records -> %d nodes (removed: %d with N, %d STR, %d duplicate/prefix, %d too short)\n",
+            (long long) nodes.records, nodes.n, nodes.removed_n, nodes.removed_str, nodes.removed_prefix, nodes.removed_short);
+    fprintf(stderr, "MIN_OVERLAP_PREF_SUF: %d\nREMOVE_SMALL_OVERLAP_EDGES_MIN_OVERLAP: %d\n", nodes.min_overlap, nodes.rsoemo);
+    fprintf(stderr, "Creating GraphCreator\n");
+    alga_host::GraphCreatorPrefSufHIP creator(nodes.words.data(), nodes.stride, nodes.len.data(), nodes.n, nodes.min_overlap, nodes.rsoemo, device);
+    creator.startAlignmentGraphCreation();
+    auto t2 = clk::now();
+    alga_prefsuf_stats st = creator.stats();
+    fprintf(stderr, "Before first simplifier graph has %llu edges\n", (unsigned long long) creator.countEdges());
+    auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    fprintf(stderr, "ingest %.1f ms, overlap graph %.1f ms wall (device %.3f ms: seed %.3f probe %.3f group %.3f reduce %.3f emit %.3f)\n",
+            ms(t0, t1), ms(t1, t2), st.ms_total, st.ms_seed, st.ms_probe, st.ms_group, st.ms_reduce, st.ms_emit);
+    std::string graph = alga_host::test_name(file1, ip.scale, ip.remove_reads_with_n) + "_beforeSimplifier.graph";
+    if (serialize) {
+        int rc = alga_write_graph(graph.c_str(), nodes.n, creator.edges(), creator.countEdges());
+        if (rc != ALGA_OK) { fprintf(stderr, "cannot write %s\n", graph.c_str()); return 1; }
+        fprintf(stderr, "Graph serialized! -> %s\n", graph.c_str());
+    }
+    if (!alga_exe.empty()) {
+        std::string cmd = "'" + alga_exe + "'";
+        for (const std::string &a : passthrough) cmd += " '" + a + "'";
+        cmd += " --deserialize_graph=1";
+        fprintf(stderr, "handing over to the unchanged simplifier / contig stages: %s\n", cmd.c_str());
+        int rc = system(cmd.c_str());
+        return rc == 0 ? 0 : 1;
+    }
+    return 0;
+}

@@ -138,6 +138,39 @@ int  alga_prefsuf_reduce_device(alga_engine *e, const alga_nodes *nodes, const a
                                 int32_t dst_begin, int32_t dst_end, void *hip_stream,
                                 const alga_edge **d_edges, uint64_t *n_edges);
 
+/* ---- input stages (host, multithreaded C++; no GPU involved) ---------------------------------
+ * What the reference does between its command line and the GraphCreator constructor, in its
+ * --threads=1 order: record parsing, end trimming, N / STR filters, 2-bit packing, reverse-complement
+ * twins, pair interleave (src/IO/InputReader.cpp:44-139,272-391), parameter derivation
+ * (src/main.cpp:93-115), duplicate / prefix read removal (src/IO/ReadPreprocess.cpp:13-152), id
+ * compaction and removal of too-short reads (src/main.cpp:150-232,253-266). */
+typedef struct {
+    int32_t trim_left, trim_right;   /* Params::READ_END_TRIM_LEFT/RIGHT, default 3 / 3           */
+    int32_t remove_reads_with_n;     /* default 1                                                  */
+    int32_t rna;                     /* default 0                                                  */
+    float   scale;                   /* Params::SCALE, default 0.55                                */
+    int32_t min_overlap;             /* -l ; -1 = derive from the mean read length                 */
+    int32_t rsoemo;                  /* --rsoemo ; -1 = derive                                     */
+    int32_t remove_pref_reads;       /* 1 duplicates, 2 all prefix reads (default), 3 none         */
+    int32_t threads;
+} alga_ingest_params;
+
+typedef struct {
+    int32_t   n, stride_words;       /* stride_words is a multiple of 4 (16-byte aligned rows)     */
+    uint32_t *words;                 /* n * stride_words                                           */
+    int32_t  *len;                   /* 0 = removed node                                           */
+    uint8_t  *pair_off;              /* Global::pairedReadOffset                                   */
+    int32_t   LEN, min_overlap, rsoemo, li_kmer_length;
+    int64_t   records;
+    int32_t   removed_n, removed_str, removed_prefix, removed_short;
+    double    avg_len;
+} alga_node_set;
+
+void alga_ingest_default_params(alga_ingest_params *p);
+int  alga_ingest_files(const char *file1, const char *file2 /* may be NULL */, const alga_ingest_params *p,
+                       alga_node_set *out, char *errbuf, size_t errlen);
+void alga_free_node_set(alga_node_set *ns);
+
 /* ---- graph dump: the reference's own checkpoint format ------------------------------------ */
 /* Graph::serializeGraph (src/DataStructures/Graph.cpp:269-297): u32 n; n x {i32 id; i32 deg;
  * deg x {i32 neighbour; i32 offset}}, native endian.  Stock ALGA loads it with

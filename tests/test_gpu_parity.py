@@ -152,3 +152,53 @@ def test_device_resident_and_sharded_paths_agree(eng):
     allp = np.concatenate(parts)
     order = np.lexsort((allp[:, 2], allp[:, 1], allp[:, 0]))
     assert (allp[order] == want).all()
+
+
+def test_cli_front_end_writes_the_reference_dump(golden_dir, tmp_path):
+    """alga_hip (C++ host over the C ABI): FASTA in, `<TEST_NAME>_beforeSimplifier.graph` out, byte-identical to the
+    dump the reference wrote for the same input."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(alga_amd.library_path()), "..", "bin", "alga_hip")
+    for name in ("f1_cfg1", "f3_paired", "f5_messy"):
+        fx = O.Fixture(golden_dir, name)
+        try:
+            f1, f2 = fx.inputs()
+            cmd = [exe, "--file1=" + f1, "--threads=4", "--output=o.fasta"] + (["--file2=" + f2] if f2 else [])
+            r = subprocess.run(cmd, cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+            assert r.returncode == 0, r.stderr[-2000:]
+            stem = os.path.basename(f1).rsplit(".", 1)[0]
+            got = open(os.path.join(str(tmp_path), "ALGA_%s_scale55_noN_beforeSimplifier.graph" % stem), "rb").read()
+            assert got == fx.ref_graph()
+            assert ("Before first simplifier graph has %d edges" % fx.meta["edges_before_simplifier"]) in r.stderr
+        finally:
+            fx.cleanup()
+    r = subprocess.run([exe, "--file1=x.fasta", "--output=o.fasta", "--error-rate=0.02"], cwd=str(tmp_path), stderr=subprocess.PIPE)
+    assert r.returncode == 3          # approximate supplement not in this build: refused, not silently ignored
+
+
+def test_drop_in_produces_identical_contigs(golden_dir, tmp_path):
+    """File-level drop-in: alga_hip builds the graph, stock ALGA consumes it with
+    --deserialize_graph=1; the contigs must equal those of a plain ALGA run on the same input."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ref = os.path.join(root, "oracle", "_ref", "ALGA")
+    if not os.path.exists(ref):
+        pytest.skip("oracle/_ref/ALGA not built (needs /root/reference at build time)")
+    exe = os.path.join(root, "alga_amd", "bin", "alga_hip")
+    fx = O.Fixture(golden_dir, "f1_cfg1")
+    try:
+        f1, _ = fx.inputs()
+        a, b = tmp_path / "plain", tmp_path / "dropin"
+        a.mkdir(); b.mkdir()
+        r = subprocess.run([ref, "--file1=" + f1, "--threads=1", "--output=o.fasta"], cwd=str(a), stdout=subprocess.DEVNULL,
+                           stderr=subprocess.DEVNULL)
+        assert r.returncode == 0
+        r = subprocess.run([exe, "--file1=" + f1, "--threads=1", "--output=o.fasta", "--alga=" + ref], cwd=str(b),
+                           stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert open(str(a / "o.fasta")).read() == open(str(b / "o.fasta")).read()
+        assert os.path.getsize(str(a / "o.fasta")) > 1000
+    finally:
+        fx.cleanup()
