@@ -44,7 +44,7 @@ struct alga_engine {
     hipEvent_t  ev[EV_COUNT] = {};
     // device buffers, grown on demand and kept between calls
     DevBuf table, filter, counters, rowptr, rec_dst, rec_val, keys, seg_key, seg_val, heads, sort_temp, out_cnt, outdeg, out_rowptr, edges, scan_scratch;
-    DevBuf edge_keys, edge_keys2, edge_vals, edge_vals2, edges_sorted;
+    DevBuf edge_keys, edge_keys2, edge_vals, edge_vals2, edges_sorted, xs_dst, xs_val;
     DevBuf up_words, up_len, up_from, up_to;   // uploads of the host-buffer entry point
     unsigned long long *h_counters = nullptr;  // pinned, CNT_TOTAL + 2 entries
     uint64_t    rec_cap_hint = 0;
@@ -309,7 +309,7 @@ void alga_engine_destroy(alga_engine *e) {
     if (e->own_stream) (void) hipStreamSynchronize(e->own_stream);
     DevBuf *bufs[] = {&e->table, &e->filter, &e->counters, &e->rowptr, &e->rec_dst, &e->rec_val, &e->keys, &e->seg_key, &e->seg_val, &e->heads, &e->sort_temp,
                       &e->out_cnt, &e->outdeg, &e->out_rowptr, &e->edges, &e->scan_scratch, &e->up_words, &e->up_len, &e->up_from, &e->up_to,
-                      &e->edge_keys, &e->edge_keys2, &e->edge_vals, &e->edge_vals2, &e->edges_sorted};
+                      &e->edge_keys, &e->edge_keys2, &e->edge_vals, &e->edge_vals2, &e->edges_sorted, &e->xs_dst, &e->xs_val};
     for (DevBuf *b : bufs) release(*b);
     if (e->h_counters) (void) hipHostFree(e->h_counters);
     for (int i = 0; i < EV_COUNT; i++) if (e->ev[i]) (void) hipEventDestroy(e->ev[i]);
@@ -472,6 +472,69 @@ int alga_prefsuf_reduce_device(alga_engine *e, const alga_nodes *nodes, const al
     e->stats.ms_emit = ev_ms(e, EV_REDUCE, EV_EMIT);
     *d_edges = (const alga_edge *) e->edges.p;
     *n_edges = E;
+    return ALGA_OK;
+}
+
+int alga_sort_records_device(alga_engine *e, const uint32_t *d_dst, const uint64_t *d_val, uint64_t n_records, int32_t n_nodes,
+                             void *hip_stream, const uint32_t **d_dst_sorted, const uint64_t **d_val_sorted, uint64_t *n_valid) {
+    if (!e) return ALGA_ERR_INVALID_ARGUMENT;
+    e->err.clear();
+    if (!d_dst_sorted || !d_val_sorted || !n_valid) return fail(e, ALGA_ERR_INVALID_ARGUMENT, "output pointers must not be NULL");
+    *d_dst_sorted = nullptr; *d_val_sorted = nullptr; *n_valid = 0;
+    if (n_records && (!d_dst || !d_val)) return fail(e, ALGA_ERR_INVALID_ARGUMENT, "record arrays must not be NULL");
+    if (n_nodes < 0) return fail(e, ALGA_ERR_INVALID_ARGUMENT, "negative node count");
+    if (n_records >= (1ull << 32) - 16) return fail(e, ALGA_ERR_CAPACITY, "more than 2^32 overlap records; shard the input");
+    HIP_TRY(e, hipSetDevice(e->device));
+    hipStream_t s = hip_stream ? (hipStream_t) hip_stream : e->own_stream;
+    int rc;
+    const int bits = key_bits_for(n_nodes);
+    const size_t temp_bytes = sort_records_temp_bytes(n_records, bits);
+    if ((rc = ensure(e, e->counters, (CNT_TOTAL + 2) * sizeof(unsigned long long)))) return rc;
+    if ((rc = ensure(e, e->keys, (size_t) (n_records + 1) * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(e, e->xs_dst, (size_t) (n_records + 1) * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(e, e->xs_val, (size_t) (n_records + 1) * sizeof(unsigned long long)))) return rc;
+    if ((rc = ensure(e, e->sort_temp, temp_bytes))) return rc;
+    unsigned long long *cnt = (unsigned long long *) e->counters.p;
+    HIP_TRY(e, hipMemsetAsync(cnt + CNT_SORT_VALID, 0, sizeof(unsigned long long), s));
+    launch_make_keys(d_dst, n_records, 0, n_nodes, (uint32_t *) e->keys.p, cnt + CNT_SORT_VALID, s);
+    if ((rc = check_launch(e, "k_make_keys"))) return rc;
+    HIP_TRY(e, sort_records(e->sort_temp.p, temp_bytes, (const uint32_t *) e->keys.p, (uint32_t *) e->xs_dst.p, (const unsigned long long *) d_val,
+                            (unsigned long long *) e->xs_val.p, n_records, bits, s));
+    HIP_TRY(e, hipMemcpyAsync(&e->h_counters[CNT_SORT_VALID], cnt + CNT_SORT_VALID, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    HIP_TRY(e, hipStreamSynchronize(s));
+    *d_dst_sorted = (const uint32_t *) e->xs_dst.p; *d_val_sorted = (const uint64_t *) e->xs_val.p;
+    *n_valid = e->h_counters[CNT_SORT_VALID];
+    return ALGA_OK;
+}
+
+int alga_sort_edges_device(alga_engine *e, const alga_edge *d_edges, uint64_t n_edges, int32_t n_nodes, void *hip_stream,
+                           const alga_edge **d_sorted) {
+    if (!e) return ALGA_ERR_INVALID_ARGUMENT;
+    e->err.clear();
+    if (!d_sorted) return fail(e, ALGA_ERR_INVALID_ARGUMENT, "output pointer must not be NULL");
+    *d_sorted = nullptr;
+    if (n_edges && !d_edges) return fail(e, ALGA_ERR_INVALID_ARGUMENT, "edge array must not be NULL");
+    if (n_edges >= (1ull << 32) - 16) return fail(e, ALGA_ERR_CAPACITY, "more than 2^32 edges");
+    HIP_TRY(e, hipSetDevice(e->device));
+    hipStream_t s = hip_stream ? (hipStream_t) hip_stream : e->own_stream;
+    int rc;
+    const size_t temp_bytes = sort_edges_temp_bytes(n_edges);
+    if ((rc = ensure(e, e->edge_keys, (size_t) (n_edges + 1) * sizeof(unsigned long long)))) return rc;
+    if ((rc = ensure(e, e->edge_keys2, (size_t) (n_edges + 1) * sizeof(unsigned long long)))) return rc;
+    if ((rc = ensure(e, e->edge_vals, (size_t) (n_edges + 1) * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(e, e->edge_vals2, (size_t) (n_edges + 1) * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(e, e->edges_sorted, (size_t) (n_edges + 1) * sizeof(alga_edge_dev)))) return rc;
+    if ((rc = ensure(e, e->sort_temp, temp_bytes))) return rc;
+    launch_edges_to_keys((const alga_edge_dev *) d_edges, n_edges, (unsigned long long *) e->edge_keys.p, (uint32_t *) e->edge_vals.p, s);
+    if ((rc = check_launch(e, "k_edges_to_keys"))) return rc;
+    int src_bits = 1;
+    while (src_bits < 31 && (1ll << src_bits) < (long long) n_nodes) src_bits++;
+    HIP_TRY(e, sort_edges(e->sort_temp.p, temp_bytes, (const unsigned long long *) e->edge_keys.p, (unsigned long long *) e->edge_keys2.p,
+                          (const uint32_t *) e->edge_vals.p, (uint32_t *) e->edge_vals2.p, n_edges, src_bits, s));
+    launch_keys_to_edges((const unsigned long long *) e->edge_keys2.p, (const uint32_t *) e->edge_vals2.p, n_edges, (alga_edge_dev *) e->edges_sorted.p, s);
+    if ((rc = check_launch(e, "k_keys_to_edges"))) return rc;
+    HIP_TRY(e, hipStreamSynchronize(s));
+    *d_sorted = (const alga_edge *) e->edges_sorted.p;
     return ALGA_OK;
 }
 

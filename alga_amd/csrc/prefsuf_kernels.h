@@ -45,6 +45,8 @@ void launch_scatter_by_source(const PrefSufCfg &cfg, int32_t dst_begin, int32_t 
                               alga_edge_dev *edges, hipStream_t s);
 void launch_sort_rows(int32_t n, const uint32_t *out_rowptr, alga_edge_dev *edges, hipStream_t s);
 
+void launch_edges_to_keys(const alga_edge_dev *e, uint64_t n, unsigned long long *keys, uint32_t *vals, hipStream_t s);
+void launch_keys_to_edges(const unsigned long long *keys, const uint32_t *vals, uint64_t n, alga_edge_dev *e, hipStream_t s);
 size_t     sort_edges_temp_bytes(uint64_t n);
 hipError_t sort_edges(void *temp, size_t temp_bytes, const unsigned long long *keys_in, unsigned long long *keys_out, const uint32_t *vals_in,
                       uint32_t *vals_out, uint64_t n, int src_bits, hipStream_t s);

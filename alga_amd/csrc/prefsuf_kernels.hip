@@ -914,6 +914,24 @@ k_sort_rows(int32_t n, const uint32_t *__restrict__ out_rowptr, alga_edge_dev *_
 }
 
 // ------------------------------------------------------------------------------------------
+// ordering of a gathered edge list (multi-GPU): key = (src << 32) | dst, value = offset
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_edges_to_keys(const alga_edge_dev *__restrict__ e, uint64_t n, unsigned long long *__restrict__ keys,
+                                                        uint32_t *__restrict__ vals) {
+    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) {
+        keys[i] = ((unsigned long long) (uint32_t) e[i].src << 32) | (uint32_t) e[i].dst;
+        vals[i] = (uint32_t) e[i].offset;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_keys_to_edges(const unsigned long long *__restrict__ keys, const uint32_t *__restrict__ vals, uint64_t n,
+                                                        alga_edge_dev *__restrict__ e) {
+    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) {
+        e[i].src = (int32_t) (keys[i] >> 32); e[i].dst = (int32_t) (uint32_t) keys[i]; e[i].offset = (int32_t) vals[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // launch wrappers (host)
 // ------------------------------------------------------------------------------------------
 static inline unsigned grid_for(uint64_t n, int block) { return (unsigned) ((n + (uint64_t) block - 1) / (uint64_t) block); }
@@ -1047,6 +1065,16 @@ void launch_scatter_by_source(const PrefSufCfg &cfg, int32_t dst_begin, int32_t 
     if (n_owned <= 0) return;
     hipLaunchKernelGGL(k_scatter_by_source, dim3(grid_for((uint64_t) n_owned, 256)), dim3(256), 0, s, cfg, dst_begin, n_owned, rowptr, seg_val,
                        out_cnt, out_rowptr, out_cursor, edges);
+}
+
+void launch_edges_to_keys(const alga_edge_dev *e, uint64_t n, unsigned long long *keys, uint32_t *vals, hipStream_t s) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_edges_to_keys, dim3(std::min<unsigned>(grid_for(n, 256), 8192u)), dim3(256), 0, s, e, n, keys, vals);
+}
+
+void launch_keys_to_edges(const unsigned long long *keys, const uint32_t *vals, uint64_t n, alga_edge_dev *e, hipStream_t s) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_keys_to_edges, dim3(std::min<unsigned>(grid_for(n, 256), 8192u)), dim3(256), 0, s, keys, vals, n, e);
 }
 
 void launch_sort_rows(int32_t n, const uint32_t *out_rowptr, alga_edge_dev *edges, hipStream_t s) {

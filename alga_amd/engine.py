@@ -64,7 +64,7 @@ EXPORTS = ["alga_abi_version", "alga_engine_create", "alga_engine_destroy", "alg
            "alga_engine_device_name", "alga_prefsuf_default_params", "alga_prefsuf_build_host", "alga_free_edges",
            "alga_prefsuf_build_device", "alga_prefsuf_last_stats", "alga_prefsuf_discover_device",
            "alga_prefsuf_reduce_device", "alga_write_graph", "alga_ingest_default_params", "alga_ingest_files",
-           "alga_free_node_set"]
+           "alga_free_node_set", "alga_sort_records_device", "alga_sort_edges_device"]
 
 
 def library_path():
@@ -110,6 +110,9 @@ def load_library():
                                                C.c_void_p, C.c_uint64, C.c_int32, C.c_int32, C.c_void_p,
                                                C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
     lib.alga_write_graph.argtypes = [C.c_char_p, C.c_int32, C.c_void_p, C.c_uint64]
+    lib.alga_sort_records_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p,
+                                             C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    lib.alga_sort_edges_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]
     lib.alga_ingest_default_params.argtypes = [C.POINTER(IngestParams)]
     lib.alga_ingest_default_params.restype = None
     lib.alga_ingest_files.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(IngestParams), C.POINTER(NodeSet), C.c_char_p, C.c_size_t]
@@ -291,6 +294,23 @@ class Engine:
                                                          int(n_records), int(dst_begin), int(dst_end),
                                                          C.c_void_p(stream or 0), C.byref(out), C.byref(m)))
         return out.value, int(m.value)
+
+    def sort_records_device(self, rec_dst, rec_val, n_records, n_nodes, stream=None):
+        """-> (d_dst_sorted ptr, d_val_sorted ptr, n_valid): records ordered by target id, padding dropped."""
+        def ptr(x):
+            return C.c_void_p(x if isinstance(x, int) else x.data_ptr())
+        d, v = C.c_void_p(), C.c_void_p()
+        m = C.c_uint64()
+        self._check(self._lib.alga_sort_records_device(self._h, ptr(rec_dst), ptr(rec_val), int(n_records), int(n_nodes),
+                                                       C.c_void_p(stream or 0), C.byref(d), C.byref(v), C.byref(m)))
+        return d.value, v.value, int(m.value)
+
+    def sort_edges_device(self, edges, n_edges, n_nodes, stream=None):
+        """edges: device pointer or int32 tensor [n_edges, 3] -> device pointer of the list ordered by (src, dst)."""
+        p = C.c_void_p(edges if isinstance(edges, int) else edges.data_ptr())
+        out = C.c_void_p()
+        self._check(self._lib.alga_sort_edges_device(self._h, p, int(n_edges), int(n_nodes), C.c_void_p(stream or 0), C.byref(out)))
+        return out.value
 
     def write_graph(self, path, n_nodes, edges):
         edges = np.ascontiguousarray(edges, dtype=np.int32).reshape(-1, 3)

@@ -1,107 +1,137 @@
 """One process per GPU: sharding of the PrefSuf build across ranks (torch.distributed = RCCL on ROCm).
 
-Layout: the packed node set is replicated on every GPU (36 B/read; 3.6 GB at 100 M nodes, HBM is 288 GB).
+Layout: the packed node set is replicated on every GPU (36-48 B/read; 4.8 GB at 100 M nodes, HBM is 288 GB).
   1. discover  rank r probes the SOURCES of its contiguous id range against the full seed table and applies the
-               per-source small-overlap cap locally (the cap is per source, so it needs no exchange)
-  2. exchange  overlap records go to the rank that owns the TARGET id range          (all_to_all_single)
+               per-source small-overlap cap locally (the cap is per source, so it needs no exchange), then orders
+               its records by target id (device radix sort): the slice for every owner is contiguous
+  2. exchange  overlap records go to the rank that owns the TARGET id range          (all_to_all_single x2)
   3. reduce    per-target transitive reduction of the owned targets                   (local)
   4. gather    edge lists of all ranks                                                 (all_gather, padded)
-  5. order     every rank sorts the gathered edges by (src, dst, offset)              (local, HIP)
-so the result is byte-identical for every world size.  torch supplies buffers and collectives only; all
-compute steps are C-ABI calls into the HIP kernels.
+  5. order     every rank orders the gathered edges by (src, dst)                     (device radix sort)
+so the result is byte-identical for every world size.  torch supplies buffers and collectives only; every compute
+step is a C-ABI call into the HIP engine (`HipBackend`).  The same driver runs on CPU tensors over gloo with a
+stand-in backend in tests/test_multigpu_gloo.py.
 """
+import time
+
 import numpy as np
 
 
-class ShardedPrefSuf:
-    def __init__(self, engine, d_words, d_lens, min_overlap, rsoemo, rank=0, world=1, dist=None):
+def shard_bounds(n, world):
+    """Contiguous id ranges, a read and its reverse complement (ids 2i, 2i+1) kept together."""
+    b = [(n * r) // world for r in range(world + 1)]
+    return [x - (x & 1) for x in b[:-1]] + [n]
+
+
+class HipBackend:
+    """The engine behind the driver: device tensors in, device tensors (views of engine memory) out."""
+
+    def __init__(self, engine, d_words, d_lens, min_overlap, rsoemo):
         self.eng, self.w, self.l = engine, d_words, d_lens
         self.lo, self.rs = int(min_overlap), int(rsoemo)
-        self.rank, self.world, self.dist = rank, world, dist
         self.n = int(d_lens.shape[0])
-        b = [(self.n * r) // world for r in range(world + 1)]
-        b = [x - (x & 1) for x in b[:-1]] + [self.n]          # keep a read and its reverse complement together
-        self.bounds = b
-        self.last_edges = None                                 # (device pointer, count) of the last step
+        self.device = d_words.device
+        self.stats = {}
+
+    def build(self, collect_stats=False):
+        from .engine import device_view
+        ptr, m = self.eng.prefsuf_device(self.w, self.l, self.lo, self.rs, collect_stats=collect_stats)
+        self.stats = self.eng.last_stats()
+        return device_view(ptr, (m, 3), self.device)
+
+    def discover_sorted(self, src_begin, src_end, collect_stats=False):
+        from .engine import device_view
+        d, v, k = self.eng.discover_device(self.w, self.l, self.lo, self.rs, src_begin, src_end, collect_stats=collect_stats)
+        self.stats = self.eng.last_stats()
+        ds, vs, nv = self.eng.sort_records_device(d, v, k, self.n)
+        return device_view(ds, (nv,), self.device), device_view(vs, (nv,), self.device, "<i8")
+
+    def reduce(self, rec_dst, rec_val, dst_begin, dst_end, collect_stats=False):
+        from .engine import device_view
+        ptr, m = self.eng.reduce_device(self.w, self.l, self.lo, self.rs, rec_dst, rec_val, int(rec_dst.shape[0]), dst_begin, dst_end,
+                                        collect_stats=collect_stats)
+        st = self.eng.last_stats()
+        for k in ("ms_group", "ms_reduce", "ms_emit", "transitive_listed", "transitive_compares", "transitive_removed", "max_in_records"):
+            self.stats[k] = st[k]
+        return device_view(ptr, (m, 3), self.device)
+
+    def sort_edges(self, edges):
+        from .engine import device_view
+        m = int(edges.shape[0])
+        ptr = self.eng.sort_edges_device(edges, m, self.n)
+        return device_view(ptr, (m, 3), self.device)
+
+    def sync(self):
+        import torch
+        torch.cuda.synchronize()
+
+
+class ShardedPrefSuf:
+    def __init__(self, backend, rank=0, world=1, dist=None):
+        self.be, self.rank, self.world, self.dist = backend, rank, world, dist
+        self.n = backend.n
+        self.bounds = shard_bounds(self.n, world)
+        self.edges = None                       # tensor [m, 3] of the last step (complete graph, on every rank)
 
     def step(self, collect_stats=False):
         """-> (n_edges of the complete graph, stats dict of this rank)."""
         if self.world == 1:
-            ptr, m = self.eng.prefsuf_device(self.w, self.l, self.lo, self.rs, collect_stats=collect_stats)
-            self.last_edges = (ptr, m)
-            return m, self.eng.last_stats()
+            self.edges = self.be.build(collect_stats)
+            return int(self.edges.shape[0]), dict(self.be.stats)
         return self._step_sharded(collect_stats)
 
     def _step_sharded(self, collect_stats):
-        import time
         import torch
-        from .engine import device_view
-        dist, eng, r, nr = self.dist, self.eng, self.rank, self.world
-        b = self.bounds
-        dev = self.w.device
-        d, v, k = eng.discover_device(self.w, self.l, self.lo, self.rs, b[r], b[r + 1], collect_stats=collect_stats)
-        st = eng.last_stats()
+        dist, be, r, nr, b = self.dist, self.be, self.rank, self.world, self.bounds
+        dev = be.device
+        # 1. discover + order by target
+        rdst, rval = be.discover_sorted(b[r], b[r + 1], collect_stats)
+        st = dict(be.stats)
         t0 = time.perf_counter()
-        rdst, rval = device_view(d, (k,), dev), device_view(v, (k,), dev, "<i8")
-        # owner of a record = rank whose target range holds dst; chunk padding (dst = -1 as int32) is dropped
-        bounds_t = torch.tensor(b[1:], dtype=torch.int32, device=dev)
-        valid = rdst >= 0
-        rdst, rval = rdst[valid], rval[valid]
-        owner = torch.searchsorted(bounds_t, rdst, right=True)
-        order = torch.argsort(owner, stable=True)
-        send_d, send_v = rdst[order].contiguous(), rval[order].contiguous()
-        sc = torch.bincount(owner, minlength=nr)[:nr]
+        # 2. exchange: the records for owner q are the contiguous slice [cut[q], cut[q+1]) of the sorted arrays
+        cuts = torch.searchsorted(rdst, torch.tensor(b, dtype=rdst.dtype, device=dev))
+        sc = (cuts[1:] - cuts[:-1]).to(torch.int64)
         rcnt = torch.empty_like(sc)
         dist.all_to_all_single(rcnt, sc)
         sc_l, rc_l = [int(x) for x in sc.cpu()], [int(x) for x in rcnt.cpu()]
         tot = sum(rc_l)
-        recv_d = torch.empty(max(tot, 1), dtype=torch.int32, device=dev)
-        recv_v = torch.empty(max(tot, 1), dtype=torch.int64, device=dev)
-        dist.all_to_all_single(recv_d[:tot], send_d, output_split_sizes=rc_l, input_split_sizes=sc_l)
-        dist.all_to_all_single(recv_v[:tot], send_v, output_split_sizes=rc_l, input_split_sizes=sc_l)
-        torch.cuda.synchronize()
+        recv_d = torch.empty(tot, dtype=rdst.dtype, device=dev)
+        recv_v = torch.empty(tot, dtype=rval.dtype, device=dev)
+        dist.all_to_all_single(recv_d, rdst.contiguous(), output_split_sizes=rc_l, input_split_sizes=sc_l)
+        dist.all_to_all_single(recv_v, rval.contiguous(), output_split_sizes=rc_l, input_split_sizes=sc_l)
+        be.sync()
         t1 = time.perf_counter()
-        ptr, m = eng.reduce_device(self.w, self.l, self.lo, self.rs, recv_d, recv_v, tot, b[r], b[r + 1],
-                                   collect_stats=collect_stats)
-        st2 = eng.last_stats()
+        # 3. reduce the owned targets
+        mine = be.reduce(recv_d, recv_v, b[r], b[r + 1], collect_stats)
+        st.update({k: be.stats[k] for k in be.stats if k.startswith("ms_") or k.startswith("transitive") or k == "max_in_records"})
         t2 = time.perf_counter()
-        # gather the per-rank edge lists (padded to the longest), then order them by (src, dst, offset)
-        mine = torch.tensor([m], dtype=torch.int64, device=dev)
+        # 4. gather the per-rank edge lists (padded to the longest) ...
+        m = int(mine.shape[0])
         allm = torch.empty(nr, dtype=torch.int64, device=dev)
-        dist.all_gather_into_tensor(allm, mine)
+        dist.all_gather_into_tensor(allm, torch.tensor([m], dtype=torch.int64, device=dev))
         ms = [int(x) for x in allm.cpu()]
         mx = max(max(ms), 1)
         local = torch.zeros((mx, 3), dtype=torch.int32, device=dev)
         if m:
-            local[:m] = device_view(ptr, (m, 3), dev)
+            local[:m] = mine
         gathered = torch.empty((nr, mx, 3), dtype=torch.int32, device=dev)
         dist.all_gather_into_tensor(gathered.view(-1), local.view(-1))
-        packed = torch.cat([gathered[q, :ms[q]] for q in range(nr)], dim=0)
-        key = (packed[:, 0].to(torch.int64) << 32) | packed[:, 1].to(torch.int64)
-        self.edges_sorted = packed[torch.argsort(key)].contiguous()
-        torch.cuda.synchronize()
+        packed = torch.cat([gathered[q, :ms[q]] for q in range(nr)], dim=0).contiguous()
+        # 5. ... and order them
+        self.edges = be.sort_edges(packed)
+        be.sync()
         t3 = time.perf_counter()
-        m2 = int(self.edges_sorted.shape[0])
-        self.last_edges = None
-        for key_ in ("ms_group", "ms_reduce", "ms_emit", "transitive_listed", "transitive_compares", "transitive_removed",
-                     "max_in_records"):
-            st[key_] = st2[key_]
+        m2 = int(self.edges.shape[0])
         st["edges"] = m2
         st["ms_exchange"] = (t1 - t0) * 1e3 + (t3 - t2) * 1e3
         if collect_stats:   # whole-job counters for the roofline bookkeeping
-            keys = ["nodes_live", "windows_probed", "slots_scanned", "raw_overlaps", "records", "transitive_listed",
-                    "transitive_compares", "transitive_removed"]
-            t = torch.tensor([st[kk] for kk in keys], dtype=torch.int64, device=dev)
-            live = st["nodes_live"]
+            keys = ["windows_probed", "slots_scanned", "raw_overlaps", "records", "transitive_listed", "transitive_compares",
+                    "transitive_removed"]
+            t = torch.tensor([int(st.get(kk, 0)) for kk in keys], dtype=torch.int64, device=dev)
             dist.all_reduce(t)
             for kk, v in zip(keys, t.cpu().tolist()):
                 st[kk] = int(v)
-            st["nodes_live"] = live
         return m2, st
 
     def edges_numpy(self):
-        from .engine import device_edges_to_numpy
-        if self.last_edges is None:
-            return self.edges_sorted.cpu().numpy().copy()
-        ptr, m = self.last_edges
-        return device_edges_to_numpy(ptr, m)
+        return self.edges.cpu().numpy().astype(np.int32).copy()

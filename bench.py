@@ -128,7 +128,7 @@ def main():
     d_words = torch.from_numpy(words.view(np.int32)).cuda()
     d_lens = torch.from_numpy(lens).cuda()
     eng = alga_amd.Engine(local_rank)
-    runner = multigpu.ShardedPrefSuf(eng, d_words, d_lens, lo, rs, rank, world, dist)
+    runner = multigpu.ShardedPrefSuf(multigpu.HipBackend(eng, d_words, d_lens, lo, rs), rank, world, dist)
 
     def sync_all():
         if dist is not None:

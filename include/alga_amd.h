@@ -138,6 +138,17 @@ int  alga_prefsuf_reduce_device(alga_engine *e, const alga_nodes *nodes, const a
                                 int32_t dst_begin, int32_t dst_end, void *hip_stream,
                                 const alga_edge **d_edges, uint64_t *n_edges);
 
+/* Exchange helpers of the sharded form (device in, device out, engine-owned results):
+ *   alga_sort_records_device  orders record slots by target id and drops the padding: the first *n_valid
+ *                             entries of the outputs are the records, so the slice that belongs to the rank
+ *                             owning targets [a, b) is contiguous (lower_bound of a and b in d_dst_sorted).
+ *   alga_sort_edges_device    orders a gathered edge list by (src, dst): the byte order of the single-GPU result. */
+int  alga_sort_records_device(alga_engine *e, const uint32_t *d_dst, const uint64_t *d_val, uint64_t n_records,
+                              int32_t n_nodes, void *hip_stream, const uint32_t **d_dst_sorted,
+                              const uint64_t **d_val_sorted, uint64_t *n_valid);
+int  alga_sort_edges_device(alga_engine *e, const alga_edge *d_edges, uint64_t n_edges, int32_t n_nodes,
+                            void *hip_stream, const alga_edge **d_sorted);
+
 /* ---- input stages (host, multithreaded C++; no GPU involved) ---------------------------------
  * What the reference does between its command line and the GraphCreator constructor, in its
  * --threads=1 order: record parsing, end trimming, N / STR filters, 2-bit packing, reverse-complement

@@ -202,3 +202,32 @@ def test_drop_in_produces_identical_contigs(golden_dir, tmp_path):
         assert os.path.getsize(str(a / "o.fasta")) > 1000
     finally:
         fx.cleanup()
+
+
+def test_exchange_helpers_emulated_ranks(eng):
+    """The multi-GPU driver's compute steps (HipBackend: discover+order, reduce, edge ordering) with the collectives
+    emulated in one process for 3 'ranks': the result must be the single-GPU graph, byte for byte."""
+    import torch
+    from alga_amd.multigpu import HipBackend, shard_bounds
+    words, lens = _nodes(3000, 150, 7000, 41, err=0.004, stride=12)
+    want, _, _ = O.prefsuf(words, lens, 82, 116)
+    dw = torch.from_numpy(words.view(np.int32)).cuda()
+    dl = torch.from_numpy(lens).cuda()
+    be = HipBackend(eng, dw, dl, 82, 116)
+    nr = 3
+    b = shard_bounds(len(lens), nr)
+    sent = []
+    for r in range(nr):
+        d, v = be.discover_sorted(b[r], b[r + 1])
+        assert bool((d[1:] >= d[:-1]).all()) and int(d.min()) >= 0          # ordered by target, padding dropped
+        cuts = torch.searchsorted(d, torch.tensor(b, dtype=d.dtype, device=d.device)).tolist()
+        sent.append([(d[cuts[q]:cuts[q + 1]].clone(), v[cuts[q]:cuts[q + 1]].clone()) for q in range(nr)])
+    parts = []
+    for q in range(nr):
+        rd = torch.cat([sent[r][q][0] for r in range(nr)]).contiguous()
+        rv = torch.cat([sent[r][q][1] for r in range(nr)]).contiguous()
+        parts.append(be.reduce(rd, rv, b[q], b[q + 1]).clone())
+    allp = torch.cat(parts).contiguous()
+    got = be.sort_edges(allp).cpu().numpy()
+    assert got.shape == want.shape and (got == want).all()
+    assert (be.build().cpu().numpy() == want).all()
