@@ -154,17 +154,20 @@ def pack_reads(codes, lens=None, stride_words=None):
     W = (2 * m + 31) // 32
     if stride_words is None:
         stride_words = W
-    if lens is not None:
-        codes = np.where(np.arange(m)[None, :] < np.asarray(lens)[:, None], codes, 0).astype(np.uint8)
-    pad = W * 16 - m
-    if pad:
-        codes = np.concatenate([codes, np.zeros((n, pad), np.uint8)], axis=1)
-    c = codes.reshape(n, W, 16).astype(np.uint32)
+    out = np.zeros((n, stride_words), dtype=np.uint32)
     shifts = (2 * np.arange(16, dtype=np.uint32))[None, None, :]
-    words = np.bitwise_or.reduce(c << shifts, axis=2).astype(np.uint32)
-    if stride_words > W:
-        words = np.concatenate([words, np.zeros((n, stride_words - W), np.uint32)], axis=1)
-    return np.ascontiguousarray(words)
+    lens = None if lens is None else np.asarray(lens)
+    CH = 1 << 18                                                   # bounded temporaries (64 B of uint32 per nucleotide row chunk)
+    for s0 in range(0, n, CH):
+        c = codes[s0:s0 + CH]
+        if lens is not None:
+            c = np.where(np.arange(m)[None, :] < lens[s0:s0 + CH, None], c, 0).astype(np.uint8)
+        pad = W * 16 - m
+        if pad:
+            c = np.concatenate([c, np.zeros((c.shape[0], pad), np.uint8)], axis=1)
+        c = c.reshape(c.shape[0], W, 16).astype(np.uint32)
+        out[s0:s0 + CH, :W] = np.bitwise_or.reduce(c << shifts, axis=2)
+    return out
 
 
 def derive_params(avg_len, trim_left=3, trim_right=3, scale=0.55):

@@ -97,8 +97,9 @@ class ShardedPrefSuf:
         tot = sum(rc_l)
         recv_d = torch.empty(tot, dtype=rdst.dtype, device=dev)
         recv_v = torch.empty(tot, dtype=rval.dtype, device=dev)
-        dist.all_to_all_single(recv_d, rdst.contiguous(), output_split_sizes=rc_l, input_split_sizes=sc_l)
-        dist.all_to_all_single(recv_v, rval.contiguous(), output_split_sizes=rc_l, input_split_sizes=sc_l)
+        # send buffers are copied out of engine-owned memory into tensors the collective backend manages
+        dist.all_to_all_single(recv_d, rdst.clone(), output_split_sizes=rc_l, input_split_sizes=sc_l)
+        dist.all_to_all_single(recv_v, rval.clone(), output_split_sizes=rc_l, input_split_sizes=sc_l)
         be.sync()
         t1 = time.perf_counter()
         # 3. reduce the owned targets

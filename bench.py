@@ -120,13 +120,25 @@ def main():
         import torch.distributed as dist
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
-    # ---- workload (synthetic, same on every rank) -------------------------------------------------------
-    wl = workload.build(args.config, scale=world, stride_words=(args.stride or None))
-    words, lens = wl["words"], wl["lens"]
-    n_nodes, W = len(lens), (2 * int(lens.max()) + 31) // 32
-    lo, rs = wl["min_overlap"], wl["rsoemo"]
-    d_words = torch.from_numpy(words.view(np.int32)).cuda()
-    d_lens = torch.from_numpy(lens).cuda()
+    # ---- workload (synthetic; built once on rank 0, replicated to every GPU over RCCL) -------------------------
+    wl = None
+    meta = torch.zeros(4, dtype=torch.int64, device="cuda")
+    if rank == 0:
+        wl = workload.build(args.config, scale=world, stride_words=(args.stride or None))
+        meta = torch.tensor([len(wl["lens"]), wl["words"].shape[1], wl["min_overlap"], wl["rsoemo"]], dtype=torch.int64, device="cuda")
+    if dist is not None:
+        dist.broadcast(meta, src=0)
+    n_nodes, stride, lo, rs = [int(x) for x in meta.cpu()]
+    if rank == 0:
+        d_words = torch.from_numpy(wl["words"].view(np.int32)).cuda()
+        d_lens = torch.from_numpy(wl["lens"]).cuda()
+    else:
+        d_words = torch.empty((n_nodes, stride), dtype=torch.int32, device="cuda")
+        d_lens = torch.empty(n_nodes, dtype=torch.int32, device="cuda")
+    if dist is not None:
+        dist.broadcast(d_words, src=0)
+        dist.broadcast(d_lens, src=0)
+    W = (2 * int(d_lens.max().item()) + 31) // 32 if n_nodes else 0
     eng = alga_amd.Engine(local_rank)
     runner = multigpu.ShardedPrefSuf(multigpu.HipBackend(eng, d_words, d_lens, lo, rs), rank, world, dist)
 
@@ -138,6 +150,8 @@ def main():
     # one counted pass (work counters for the roofline's algorithmic bytes); not timed
     n_edges, st = runner.step(collect_stats=True)
     stats = dict(st)
+    if world > 1:
+        stats["nodes_live"] = n_nodes                 # whole-job counters (all_reduced); nodes are replicated
     for _ in range(max(0, args.warmup - 1)):
         runner.step()
     sync_all()
@@ -162,12 +176,13 @@ def main():
         bases = wl["n_reads"] * wl["read_len"]
         alg = algorithmic_bytes(stats, W)
         probe_avg_ms = float(np.mean(probe_ms))
-        achieved = alg["probe"] / (probe_avg_ms * 1e-3) / 1e9
+        alg_probe_launch = alg["probe"] / world           # one launch = one rank's share of the sources
+        achieved = alg_probe_launch / (probe_avg_ms * 1e-3) / 1e9
         traffic = None
         tf = os.path.join(ROOT, "profiles", "probe_hbm_bytes.json")   # from the rocprofv3 --pmc passes (see profiles/README.md)
         if os.path.exists(tf):
             try:
-                traffic = json.load(open(tf)).get(args.config, {}).get("hbm_bytes_per_launch")
+                traffic = json.load(open(tf)).get(args.config, {}).get("hbm_bytes_per_launch") if world == 1 else None
             except Exception:
                 traffic = None
         out = {
@@ -182,7 +197,7 @@ def main():
                        "nodes": n_nodes, "edges": int(n_edges), "parallelism": "1 GPU" if world == 1 else
                        "sources sharded over %d ranks, records all_to_all by target owner, edges all_gather" % world},
             "roofline": {"bound": "hbm", "kernel": "k_probe_sources", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes": alg["probe"],
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes": alg_probe_launch,
                          "kernel_ms": probe_avg_ms,
                          "per_unit": "per source node: 4W + 16 P + 4W * raw/node bytes (W=%d words, P=%.1f windows, raw/node=%.2f)" %
                                      (W, stats["windows_probed"] / max(1, stats["nodes_live"]), stats["raw_overlaps"] / max(1, stats["nodes_live"]))},
@@ -193,7 +208,7 @@ def main():
             "algorithmic_bytes_total": alg["total"],
             "device": eng.device_name(),
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:        # the CPU baseline is a rank-0, N=1 measurement
             try:
                 cores = len(os.sched_getaffinity(0))
             except AttributeError:
@@ -201,7 +216,7 @@ def main():
             cores = max(1, min(cores, 16))          # the GPU box gives one GPU's CPU share: 16 cores
             cb = cpu_baseline_reference(wl["codes"], cores, min(args.cpu_sample_reads, wl["n_reads"]))
             if cb is None:
-                cb = cpu_baseline_port(words, lens, lo, rs, min(n_nodes, 200_000))
+                cb = cpu_baseline_port(wl["words"], wl["lens"], lo, rs, min(n_nodes, 200_000))
             out["cpu_baseline"] = cb
             if cb.get("kind") == "reference" and world == 1 and args.cpu_sample_reads >= wl["n_reads"]:
                 out["cpu_baseline"]["edges_equal_gpu"] = bool(cb["edges"] == int(n_edges))
