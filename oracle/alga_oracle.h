@@ -81,6 +81,25 @@ int  oracle_prefsuf(const uint32_t *words, const int32_t *len, int32_t n, int32_
                     int32_t min_overlap, int32_t rsoemo, oracle_graph *out);
 void oracle_free_graph(oracle_graph *g);
 
+/* ---- approximate supplement (error_rate > 0.01): oracle/alga_oracle_pkb.cpp ---------------------------------- */
+typedef struct {
+    int32_t min_overlap_area;    /* Params::MIN_OVERLAP_AREA = int((1+SCALE)*avg/2)          (src/main.cpp:333) */
+    int32_t max_offset_pct;      /* Params::MAX_OFFSET_CONSIDERED_FOR_ALIGNMENT, % of |r1|   (src/main.cpp:335) */
+    int32_t min_identity_pct;    /* Params::MINIMAL_OVERLAP_FOR_LCS_LOW_ERROR = 99 - ERROR_RATE (:336)         */
+    int32_t same_ends;           /* Params::ALIGNMENT_CONTROLLER_SAME_ENDS_LENGTH = 3                          */
+    int32_t li_k, li_intervals;  /* 35, 6 (src/main.cpp:339-340)                                               */
+    int32_t rounds;              /* min(4, LI_PRIORITIES_TO_CONSIDER) = 4                                      */
+} oracle_pkb_params;
+
+void oracle_pkb_derive_params(double avg_len, float scale, int error_rate_percent, oracle_pkb_params *p);
+int  oracle_can_align(const uint32_t *words, const int32_t *len, int32_t W, int32_t r1, int32_t r2, int32_t offset,
+                      const oracle_pkb_params *p);
+int  oracle_li_kmers(const uint32_t *row, int32_t len, int32_t k, int32_t intervals, const int32_t *prio,
+                     uint64_t *hash_out, int32_t *ind_out);
+int  oracle_supplement(const uint32_t *words, const int32_t *len, int32_t n, int32_t W, const oracle_edge *edges_in, int64_t m_in,
+                       const oracle_pkb_params *p, int32_t kmer_length_bucket, oracle_edge **edges_out, int64_t *m_out,
+                       int64_t *can_align_calls);
+
 /* Graph::serializeGraph wire format (src/DataStructures/Graph.cpp:269-297). */
 int  oracle_write_graph(const char *path, int32_t n, const oracle_edge *edges, int64_t n_edges);
 

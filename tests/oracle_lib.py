@@ -167,3 +167,69 @@ class Fixture:
 
 
 FIXTURES = ["f1_cfg1", "f2_err2", "f3_paired", "f4_varlen", "f5_messy", "f6_l40"]
+
+
+# ---- approximate supplement (oracle/alga_oracle_pkb.cpp) -----------------------------------------------------------
+class PkbParams(C.Structure):
+    _fields_ = [("min_overlap_area", C.c_int32), ("max_offset_pct", C.c_int32), ("min_identity_pct", C.c_int32),
+                ("same_ends", C.c_int32), ("li_k", C.c_int32), ("li_intervals", C.c_int32), ("rounds", C.c_int32)]
+
+
+def pkb_params(avg_len, scale=0.55, error_rate_percent=2):
+    L = lib()
+    L.oracle_pkb_derive_params.argtypes = [C.c_double, C.c_float, C.c_int, C.POINTER(PkbParams)]
+    p = PkbParams()
+    L.oracle_pkb_derive_params(float(avg_len), float(scale), int(error_rate_percent), C.byref(p))
+    return p
+
+
+def can_align(words, lens, triples, p):
+    L = lib()
+    L.oracle_can_align.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(PkbParams)]
+    words = np.ascontiguousarray(words, dtype=np.uint32)
+    lens = np.ascontiguousarray(lens, dtype=np.int32)
+    W = words.shape[1]
+    out = np.zeros(len(triples), dtype=np.uint8)
+    for i, (a, b, o) in enumerate(np.asarray(triples).tolist()):
+        out[i] = L.oracle_can_align(words.ctypes.data, lens.ctypes.data, W, a, b, o, C.byref(p))
+    return out
+
+
+def li_kmers(row, length, k, intervals, prio):
+    L = lib()
+    L.oracle_li_kmers.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    row = np.ascontiguousarray(row, dtype=np.uint32)
+    pr = np.ascontiguousarray(prio, dtype=np.int32)
+    h = np.zeros(intervals, dtype=np.uint64)
+    ind = np.zeros(intervals, dtype=np.int32)
+    c = L.oracle_li_kmers(row.ctypes.data, int(length), k, intervals, pr.ctypes.data, h.ctypes.data, ind.ctypes.data)
+    return h[:c].copy(), ind[:c].copy()
+
+
+def supplement(words, lens, edges_in, p, kmer_length_bucket):
+    """-> (edges[m,3] sorted, number of canAlign calls)"""
+    L = lib()
+    L.oracle_supplement.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.POINTER(PkbParams),
+                                    C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    words = np.ascontiguousarray(words, dtype=np.uint32)
+    lens = np.ascontiguousarray(lens, dtype=np.int32)
+    e = np.ascontiguousarray(edges_in, dtype=np.int32).reshape(-1, 3)
+    out = C.c_void_p()
+    m = C.c_int64()
+    calls = C.c_int64()
+    rc = L.oracle_supplement(words.ctypes.data, lens.ctypes.data, len(lens), words.shape[1], e.ctypes.data, len(e), C.byref(p),
+                             int(kmer_length_bucket), C.byref(out), C.byref(m), C.byref(calls))
+    if rc:
+        raise RuntimeError("oracle_supplement failed")
+    res = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_int32)), shape=(max(m.value, 1) * 3,))[: m.value * 3].reshape(-1, 3).copy()
+    C.CDLL(None).free(out)
+    return res, int(calls.value)
+
+
+def load_nodes_bin(path_gz):
+    with gzip.open(path_gz, "rb") as f:
+        buf = f.read()
+    n, W = np.frombuffer(buf[:8], dtype=np.int32)
+    lens = np.frombuffer(buf[8: 8 + 4 * n], dtype=np.int32).copy()
+    words = np.frombuffer(buf[8 + 4 * n:], dtype=np.uint32).reshape(n, W).copy()
+    return words, lens
