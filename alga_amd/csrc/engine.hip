@@ -16,76 +16,11 @@
 #include <cstring>
 #include <string>
 
-#include "../../include/alga_amd.h"
-#include "prefsuf_common.h"
-#include "prefsuf_kernels.h"
+#include "engine_internal.h"
 
 using namespace alga;
 
 namespace {
-
-struct DevBuf {
-    void  *p = nullptr;
-    size_t cap = 0;
-};
-
-enum { EV_START = 0, EV_SEED, EV_PROBE, EV_GROUP, EV_REDUCE, EV_EMIT, EV_COUNT };
-
-} // namespace
-
-struct alga_engine {
-    int         device = -1;
-    hipStream_t own_stream = nullptr;
-    std::string err;
-    char        dev_name[256] = {0};
-    int         n_cu = 256;
-    int         seed_fill_x10 = 20;
-    int         use_filter = 1;               // L2-resident fingerprint bitmap in front of the seed table (ALGA_SEED_FILTER=0 disables)           // average seed-table bucket fill x10 (tunable: ALGA_SEED_FILL_X10)
-    hipEvent_t  ev[EV_COUNT] = {};
-    // device buffers, grown on demand and kept between calls
-    DevBuf table, filter, counters, rowptr, rec_dst, rec_val, keys, seg_key, seg_val, heads, sort_temp, out_cnt, outdeg, out_rowptr, edges, scan_scratch;
-    DevBuf edge_keys, edge_keys2, edge_vals, edge_vals2, edges_sorted, xs_dst, xs_val;
-    DevBuf up_words, up_len, up_from, up_to;   // uploads of the host-buffer entry point
-    unsigned long long *h_counters = nullptr;  // pinned, CNT_TOTAL + 2 entries
-    uint64_t    rec_cap_hint = 0;
-    alga_prefsuf_stats stats;
-};
-
-namespace {
-
-int fail(alga_engine *e, int code, const char *what, hipError_t herr = hipSuccess) {
-    char buf[512];
-    if (herr != hipSuccess) snprintf(buf, sizeof(buf), "%s: %s", what, hipGetErrorString(herr));
-    else snprintf(buf, sizeof(buf), "%s", what);
-    e->err = buf;
-    return code;
-}
-
-#define HIP_TRY(e, call)                                                                     \
-    do {                                                                                     \
-        hipError_t _err = (call);                                                            \
-        if (_err != hipSuccess) return fail((e), _err == hipErrorOutOfMemory ? ALGA_ERR_OUT_OF_MEMORY : ALGA_ERR_HIP, #call, _err); \
-    } while (0)
-
-int ensure(alga_engine *e, DevBuf &b, size_t bytes) {
-    if (bytes == 0) bytes = 16;
-    if (b.cap >= bytes) return ALGA_OK;
-    if (b.p) { HIP_TRY(e, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
-    HIP_TRY(e, hipMalloc(&b.p, bytes));
-    b.cap = bytes;
-    return ALGA_OK;
-}
-
-void release(DevBuf &b) {
-    if (b.p) (void) hipFree(b.p);
-    b.p = nullptr; b.cap = 0;
-}
-
-int check_launch(alga_engine *e, const char *what) {
-    hipError_t err = hipGetLastError();
-    if (err != hipSuccess) return fail(e, ALGA_ERR_HIP, what, err);
-    return ALGA_OK;
-}
 
 struct Prepared {
     NodesDev   nd;
@@ -97,16 +32,16 @@ struct Prepared {
 // Validates arguments, measures max read length / live nodes on the device and derives the
 // iteration bounds of GraphCreatorPrefSuf::startAlignmentGraphCreation (GraphCreatorPrefSuf.cpp:91-100).
 int prepare(alga_engine *e, const alga_nodes *nodes, const alga_prefsuf_params *p, hipStream_t s, Prepared &out) {
-    if (!nodes || !p) return fail(e, ALGA_ERR_INVALID_ARGUMENT, "nodes/params must not be NULL");
-    if (nodes->n < 0) return fail(e, ALGA_ERR_INVALID_ARGUMENT, "negative node count");
-    if (nodes->n > 0 && (!nodes->words || !nodes->len)) return fail(e, ALGA_ERR_INVALID_ARGUMENT, "words/len must not be NULL");
-    if (nodes->stride_words <= 0 && nodes->n > 0) return fail(e, ALGA_ERR_INVALID_ARGUMENT, "stride_words must be positive");
-    if (p->min_overlap < 1 || p->min_overlap > 501) return fail(e, ALGA_ERR_INVALID_ARGUMENT, "min_overlap must be in [1, 501]");
-    if (p->soes != 3) return fail(e, ALGA_ERR_INVALID_ARGUMENT, "soes must be 3 (the reference hard-codes SOES = 3)");
-    if (p->max_len_cap < 1 || p->max_len_cap > 500) return fail(e, ALGA_ERR_INVALID_ARGUMENT, "max_len_cap must be in [1, 500]");
-    if (p->rsoe_min_overlap < 0) return fail(e, ALGA_ERR_INVALID_ARGUMENT, "rsoe_min_overlap must be >= 0");
+    if (!nodes || !p) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "nodes/params must not be NULL");
+    if (nodes->n < 0) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "negative node count");
+    if (nodes->n > 0 && (!nodes->words || !nodes->len)) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "words/len must not be NULL");
+    if (nodes->stride_words <= 0 && nodes->n > 0) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "stride_words must be positive");
+    if (p->min_overlap < 1 || p->min_overlap > 501) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "min_overlap must be in [1, 501]");
+    if (p->soes != 3) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "soes must be 3 (the reference hard-codes SOES = 3)");
+    if (p->max_len_cap < 1 || p->max_len_cap > 500) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "max_len_cap must be in [1, 500]");
+    if (p->rsoe_min_overlap < 0) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "rsoe_min_overlap must be >= 0");
     int rc;
-    if ((rc = ensure(e, e->counters, (CNT_TOTAL + 2) * sizeof(unsigned long long)))) return rc;
+    if ((rc = alga_ensure(e, e->counters, (CNT_TOTAL + 2) * sizeof(unsigned long long)))) return rc;
     HIP_TRY(e, hipMemsetAsync(e->counters.p, 0, (CNT_TOTAL + 2) * sizeof(unsigned long long), s));
     NodesDev nd;
     nd.words = nodes->words; nd.len = nodes->len; nd.from = nodes->align_from; nd.to = nodes->align_to;
@@ -114,14 +49,14 @@ int prepare(alga_engine *e, const alga_nodes *nodes, const alga_prefsuf_params *
     unsigned long long *cnt = (unsigned long long *) e->counters.p;
     int *d_maxlen = (int *) (cnt + CNT_TOTAL);
     launch_node_stats(nd, cnt, d_maxlen, s);
-    if ((rc = check_launch(e, "k_node_stats"))) return rc;
+    if ((rc = alga_check_launch(e, "k_node_stats"))) return rc;
     HIP_TRY(e, hipMemcpyAsync(e->h_counters, e->counters.p, (CNT_TOTAL + 2) * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     HIP_TRY(e, hipStreamSynchronize(s));
     out.nd = nd;
     out.max_len = (int) (e->h_counters[CNT_TOTAL] & 0xFFFFFFFFull);
     out.live = e->h_counters[CNT_LIVE_NODES];
     if ((int64_t) blocks_of(out.max_len) > (int64_t) nodes->stride_words)
-        return fail(e, ALGA_ERR_INVALID_ARGUMENT, "stride_words is smaller than the longest read needs");
+        return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "stride_words is smaller than the longest read needs");
     PrefSufCfg c;
     c.Lmin = p->min_overlap;
     c.rsoemo = p->rsoe_min_overlap;
@@ -146,18 +81,18 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
     unsigned long long *cnt = (unsigned long long *) e->counters.p;
     *n_rec = 0;
     HIP_TRY(e, hipEventRecord(e->ev[EV_START], s));
-    if (pp.live >= (1ull << 31)) return fail(e, ALGA_ERR_CAPACITY, "too many nodes for one seed table; shard the input");
+    if (pp.live >= (1ull << 31)) return alga_fail(e, ALGA_ERR_CAPACITY, "too many nodes for one seed table; shard the input");
     const uint32_t n_buckets = seed_buckets_for(pp.live, e->seed_fill_x10);
     const size_t table_bytes = (size_t) n_buckets * SEED_BUCKET * sizeof(unsigned long long);
-    if ((rc = ensure(e, e->table, table_bytes))) return rc;
+    if ((rc = alga_ensure(e, e->table, table_bytes))) return rc;
     HIP_TRY(e, hipMemsetAsync(e->table.p, 0xFF, table_bytes, s));
     uint32_t filter_bits = e->use_filter ? seed_filter_bits_for(pp.live) : 0;
     if (filter_bits) {
-        if ((rc = ensure(e, e->filter, filter_bits / 8))) return rc;
+        if ((rc = alga_ensure(e, e->filter, filter_bits / 8))) return rc;
         HIP_TRY(e, hipMemsetAsync(e->filter.p, 0, filter_bits / 8, s));
     }
     launch_seed_build(nd, cfg, (unsigned long long *) e->table.p, n_buckets, (uint32_t *) e->filter.p, filter_bits, s);
-    if ((rc = check_launch(e, "k_seed_build"))) return rc;
+    if ((rc = alga_check_launch(e, "k_seed_build"))) return rc;
     HIP_TRY(e, hipEventRecord(e->ev[EV_SEED], s));
     e->stats.table_slots = (uint64_t) n_buckets * SEED_BUCKET;
 
@@ -165,13 +100,13 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
     const uint64_t slack = probe_record_slack(e->n_cu, n_src);            // invalid padding of the chunked record list
     uint64_t cap = std::max<uint64_t>(e->rec_cap_hint, 16 * n_src + 4096) + slack;
     for (int attempt = 0; attempt < 4; attempt++) {
-        if (cap >= (1ull << 32) - 16) return fail(e, ALGA_ERR_CAPACITY, "more than 2^32 overlap records; shard the input");
-        if ((rc = ensure(e, e->rec_dst, cap * sizeof(uint32_t)))) return rc;
-        if ((rc = ensure(e, e->rec_val, cap * sizeof(unsigned long long)))) return rc;
+        if (cap >= (1ull << 32) - 16) return alga_fail(e, ALGA_ERR_CAPACITY, "more than 2^32 overlap records; shard the input");
+        if ((rc = alga_ensure(e, e->rec_dst, cap * sizeof(uint32_t)))) return rc;
+        if ((rc = alga_ensure(e, e->rec_val, cap * sizeof(unsigned long long)))) return rc;
         HIP_TRY(e, hipMemsetAsync(cnt, 0, CNT_TOTAL * sizeof(unsigned long long), s));
         launch_probe(nd, cfg, (const unsigned long long *) e->table.p, n_buckets, (const uint32_t *) e->filter.p, filter_bits, src_begin, src_end, (uint32_t *) e->rec_dst.p,
                      (unsigned long long *) e->rec_val.p, cap, cnt, e->n_cu, s);
-        if ((rc = check_launch(e, "k_probe_sources"))) return rc;
+        if ((rc = alga_check_launch(e, "k_probe_sources"))) return rc;
         HIP_TRY(e, hipEventRecord(e->ev[EV_PROBE], s));
         HIP_TRY(e, hipMemcpyAsync(e->h_counters, cnt, CNT_TOTAL * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
         HIP_TRY(e, hipStreamSynchronize(s));
@@ -187,7 +122,7 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
         }
         cap = need + need / 16 + 4096 + slack; // the cursor kept counting past the capacity: the need is known
     }
-    return fail(e, ALGA_ERR_HIP, "record buffer kept overflowing");
+    return alga_fail(e, ALGA_ERR_HIP, "record buffer kept overflowing");
 }
 
 int key_bits_for(int64_t n_owned) {   // valid keys are < n_owned; the invalid key (all ones) must sort behind them
@@ -205,52 +140,52 @@ int reduce_impl(alga_engine *e, const Prepared &pp, const uint32_t *rec_dst, con
     unsigned long long *cnt = (unsigned long long *) e->counters.p;
     const int32_t n_owned = dst_end - dst_begin;
     *n_edges = 0;
-    if (n_rec >= (1ull << 32) - 16) return fail(e, ALGA_ERR_CAPACITY, "more than 2^32 overlap records; shard the input");
+    if (n_rec >= (1ull << 32) - 16) return alga_fail(e, ALGA_ERR_CAPACITY, "more than 2^32 overlap records; shard the input");
     const int bits = key_bits_for(n_owned);
     const size_t temp_bytes = sort_records_temp_bytes(n_rec, bits);
-    if ((rc = ensure(e, e->keys, (size_t) (n_rec + 1) * sizeof(uint32_t)))) return rc;
-    if ((rc = ensure(e, e->seg_key, (size_t) (n_rec + 1) * sizeof(uint32_t)))) return rc;
-    if ((rc = ensure(e, e->seg_val, (size_t) (n_rec + 1) * sizeof(unsigned long long)))) return rc;
-    if ((rc = ensure(e, e->sort_temp, temp_bytes))) return rc;
-    if ((rc = ensure(e, e->heads, (size_t) (n_rec + 1) * 16))) return rc;
-    if ((rc = ensure(e, e->rowptr, (size_t) (n_owned + 2) * sizeof(uint32_t)))) return rc;
+    if ((rc = alga_ensure(e, e->keys, (size_t) (n_rec + 1) * sizeof(uint32_t)))) return rc;
+    if ((rc = alga_ensure(e, e->seg_key, (size_t) (n_rec + 1) * sizeof(uint32_t)))) return rc;
+    if ((rc = alga_ensure(e, e->seg_val, (size_t) (n_rec + 1) * sizeof(unsigned long long)))) return rc;
+    if ((rc = alga_ensure(e, e->sort_temp, temp_bytes))) return rc;
+    if ((rc = alga_ensure(e, e->heads, (size_t) (n_rec + 1) * 16))) return rc;
+    if ((rc = alga_ensure(e, e->rowptr, (size_t) (n_owned + 2) * sizeof(uint32_t)))) return rc;
     HIP_TRY(e, hipMemsetAsync(cnt + CNT_SORT_VALID, 0, sizeof(unsigned long long), s));
     launch_make_keys(rec_dst, n_rec, dst_begin, dst_end, (uint32_t *) e->keys.p, cnt + CNT_SORT_VALID, s);
-    if ((rc = check_launch(e, "k_make_keys"))) return rc;
+    if ((rc = alga_check_launch(e, "k_make_keys"))) return rc;
     HIP_TRY(e, sort_records(e->sort_temp.p, temp_bytes, (const uint32_t *) e->keys.p, (uint32_t *) e->seg_key.p, rec_val,
                             (unsigned long long *) e->seg_val.p, n_rec, bits, s));
     launch_rowptr_from_sorted((const uint32_t *) e->seg_key.p, cnt + CNT_SORT_VALID, n_rec, n_owned, (uint32_t *) e->rowptr.p, s);
-    if ((rc = check_launch(e, "k_rowptr_from_sorted"))) return rc;
+    if ((rc = alga_check_launch(e, "k_rowptr_from_sorted"))) return rc;
     launch_gather_heads(nd, (const unsigned long long *) e->seg_val.p, cnt + CNT_SORT_VALID, n_rec, e->heads.p, s);
-    if ((rc = check_launch(e, "k_gather_heads"))) return rc;
+    if ((rc = alga_check_launch(e, "k_gather_heads"))) return rc;
     HIP_TRY(e, hipEventRecord(e->ev[EV_GROUP], s));
 
-    if ((rc = ensure(e, e->out_cnt, (size_t) (n_owned + 1) * sizeof(uint32_t)))) return rc;
-    if ((rc = ensure(e, e->outdeg, (size_t) (nd.n + 1) * sizeof(uint32_t)))) return rc;
+    if ((rc = alga_ensure(e, e->out_cnt, (size_t) (n_owned + 1) * sizeof(uint32_t)))) return rc;
+    if ((rc = alga_ensure(e, e->outdeg, (size_t) (nd.n + 1) * sizeof(uint32_t)))) return rc;
     HIP_TRY(e, hipMemsetAsync(e->outdeg.p, 0, (size_t) (nd.n + 1) * sizeof(uint32_t), s));
     const int tpb = reduce_targets_per_block(n_valid_hint, (uint64_t) std::max(1, n_owned));
     launch_reduce_targets(nd, cfg, dst_begin, n_owned, tpb, (const uint32_t *) e->rowptr.p, (unsigned long long *) e->seg_val.p,
                           e->heads.p, (uint32_t *) e->out_cnt.p, (uint32_t *) e->outdeg.p, cnt, s);
-    if ((rc = check_launch(e, "k_reduce_targets"))) return rc;
+    if ((rc = alga_check_launch(e, "k_reduce_targets"))) return rc;
     HIP_TRY(e, hipEventRecord(e->ev[EV_REDUCE], s));
 
-    if ((rc = ensure(e, e->scan_scratch, scan_scratch_bytes((uint64_t) nd.n)))) return rc;
-    if ((rc = ensure(e, e->out_rowptr, (size_t) (nd.n + 1) * sizeof(uint32_t)))) return rc;
+    if ((rc = alga_ensure(e, e->scan_scratch, scan_scratch_bytes((uint64_t) nd.n)))) return rc;
+    if ((rc = alga_ensure(e, e->out_rowptr, (size_t) (nd.n + 1) * sizeof(uint32_t)))) return rc;
     launch_exclusive_scan((const uint32_t *) e->outdeg.p, (uint64_t) nd.n, (uint32_t *) e->out_rowptr.p, (uint64_t *) e->scan_scratch.p, s);
-    if ((rc = check_launch(e, "scan(outdeg)"))) return rc;
+    if ((rc = alga_check_launch(e, "scan(outdeg)"))) return rc;
     uint64_t *d_total = (uint64_t *) e->scan_scratch.p + scan_total_index((uint64_t) nd.n);
     HIP_TRY(e, hipMemcpyAsync(&e->h_counters[CNT_TOTAL], d_total, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(e, hipMemcpyAsync(e->h_counters, cnt, CNT_TOTAL * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     HIP_TRY(e, hipStreamSynchronize(s));
     const uint64_t E = e->h_counters[CNT_TOTAL];
-    if (E >= (1ull << 32) - 16) return fail(e, ALGA_ERR_CAPACITY, "more than 2^32 edges; shard the input");
-    if ((rc = ensure(e, e->edges, (size_t) (E + 1) * sizeof(alga_edge_dev)))) return rc;
+    if (E >= (1ull << 32) - 16) return alga_fail(e, ALGA_ERR_CAPACITY, "more than 2^32 edges; shard the input");
+    if ((rc = alga_ensure(e, e->edges, (size_t) (E + 1) * sizeof(alga_edge_dev)))) return rc;
     launch_scatter_by_source(cfg, dst_begin, n_owned, (const uint32_t *) e->rowptr.p, (const unsigned long long *) e->seg_val.p,
                              (const uint32_t *) e->out_cnt.p, (const uint32_t *) e->out_rowptr.p, (uint32_t *) e->outdeg.p,
                              (alga_edge_dev *) e->edges.p, s);
-    if ((rc = check_launch(e, "k_scatter_by_source"))) return rc;
+    if ((rc = alga_check_launch(e, "k_scatter_by_source"))) return rc;
     launch_sort_rows(nd.n, (const uint32_t *) e->out_rowptr.p, (alga_edge_dev *) e->edges.p, s);
-    if ((rc = check_launch(e, "k_sort_rows"))) return rc;
+    if ((rc = alga_check_launch(e, "k_sort_rows"))) return rc;
     HIP_TRY(e, hipEventRecord(e->ev[EV_EMIT], s));
     HIP_TRY(e, hipStreamSynchronize(s));
     *n_edges = E;
@@ -309,8 +244,10 @@ void alga_engine_destroy(alga_engine *e) {
     if (e->own_stream) (void) hipStreamSynchronize(e->own_stream);
     DevBuf *bufs[] = {&e->table, &e->filter, &e->counters, &e->rowptr, &e->rec_dst, &e->rec_val, &e->keys, &e->seg_key, &e->seg_val, &e->heads, &e->sort_temp,
                       &e->out_cnt, &e->outdeg, &e->out_rowptr, &e->edges, &e->scan_scratch, &e->up_words, &e->up_len, &e->up_from, &e->up_to,
-                      &e->edge_keys, &e->edge_keys2, &e->edge_vals, &e->edge_vals2, &e->edges_sorted, &e->xs_dst, &e->xs_val};
-    for (DevBuf *b : bufs) release(*b);
+                      &e->edge_keys, &e->edge_keys2, &e->edge_vals, &e->edge_vals2, &e->edges_sorted, &e->xs_dst, &e->xs_val,
+                      &e->pk_keys, &e->pk_keys2, &e->pk_vals, &e->pk_vals2, &e->pk_marks, &e->pk_big, &e->pk_add, &e->pk_ekeys, &e->pk_ekeys2,
+                      &e->pk_flag, &e->pk_pos, &e->pk_edges[0], &e->pk_edges[1], &e->pk_rowptr, &e->pk_deg, &e->pk_mask, &e->pk_cnt, &e->pk_io, &e->pk_io2};
+    for (DevBuf *b : bufs) alga_release(*b);
     if (e->h_counters) (void) hipHostFree(e->h_counters);
     for (int i = 0; i < EV_COUNT; i++) if (e->ev[i]) (void) hipEventDestroy(e->ev[i]);
     if (e->own_stream) (void) hipStreamDestroy(e->own_stream);
@@ -339,7 +276,7 @@ int alga_prefsuf_build_device(alga_engine *e, const alga_nodes *nodes, const alg
                               const alga_edge **d_edges, uint64_t *n_edges) {
     if (!e) return ALGA_ERR_INVALID_ARGUMENT;
     e->err.clear();
-    if (!d_edges || !n_edges) return fail(e, ALGA_ERR_INVALID_ARGUMENT, "output pointers must not be NULL");
+    if (!d_edges || !n_edges) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "output pointers must not be NULL");
     *d_edges = nullptr; *n_edges = 0;
     HIP_TRY(e, hipSetDevice(e->device));
     hipStream_t s = hip_stream ? (hipStream_t) hip_stream : e->own_stream;
@@ -366,11 +303,11 @@ int alga_prefsuf_build_device(alga_engine *e, const alga_nodes *nodes, const alg
 int alga_prefsuf_build_host(alga_engine *e, const alga_nodes *nodes, const alga_prefsuf_params *p, alga_edge **edges, uint64_t *n_edges) {
     if (!e) return ALGA_ERR_INVALID_ARGUMENT;
     e->err.clear();
-    if (!edges || !n_edges) return fail(e, ALGA_ERR_INVALID_ARGUMENT, "output pointers must not be NULL");
+    if (!edges || !n_edges) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "output pointers must not be NULL");
     *edges = nullptr; *n_edges = 0;
-    if (!nodes || !p) return fail(e, ALGA_ERR_INVALID_ARGUMENT, "nodes/params must not be NULL");
+    if (!nodes || !p) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "nodes/params must not be NULL");
     if (nodes->n < 0 || (nodes->n > 0 && (!nodes->words || !nodes->len || nodes->stride_words <= 0)))
-        return fail(e, ALGA_ERR_INVALID_ARGUMENT, "bad node set");
+        return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "bad node set");
     HIP_TRY(e, hipSetDevice(e->device));
     hipStream_t s = e->own_stream;
     int rc;
@@ -379,13 +316,13 @@ int alga_prefsuf_build_host(alga_engine *e, const alga_nodes *nodes, const alga_
         int32_t max_len = 0;
         for (size_t i = 0; i < n; i++) max_len = std::max(max_len, nodes->len[i]);
         if ((int64_t) blocks_of(max_len) > (int64_t) nodes->stride_words)
-            return fail(e, ALGA_ERR_INVALID_ARGUMENT, "stride_words is smaller than the longest read needs");
+            return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "stride_words is smaller than the longest read needs");
     }
     // rows are re-strided to a multiple of 4 words on the way up: 16-byte aligned rows take the wide-load kernels
     const int stride_up = (nodes->stride_words + 3) & ~3;
     const size_t wbytes = n * (size_t) stride_up * sizeof(uint32_t);
-    if ((rc = ensure(e, e->up_words, wbytes))) return rc;
-    if ((rc = ensure(e, e->up_len, n * sizeof(int32_t)))) return rc;
+    if ((rc = alga_ensure(e, e->up_words, wbytes))) return rc;
+    if ((rc = alga_ensure(e, e->up_len, n * sizeof(int32_t)))) return rc;
     alga_nodes dn = *nodes;
     if (n) {
         if (stride_up != nodes->stride_words) HIP_TRY(e, hipMemsetAsync(e->up_words.p, 0, wbytes, s));
@@ -397,12 +334,12 @@ int alga_prefsuf_build_host(alga_engine *e, const alga_nodes *nodes, const alga_
     dn.words = (const uint32_t *) e->up_words.p;
     dn.len = (const int32_t *) e->up_len.p;
     if (nodes->align_from) {
-        if ((rc = ensure(e, e->up_from, n))) return rc;
+        if ((rc = alga_ensure(e, e->up_from, n))) return rc;
         if (n) HIP_TRY(e, hipMemcpyAsync(e->up_from.p, nodes->align_from, n, hipMemcpyHostToDevice, s));
         dn.align_from = (const uint8_t *) e->up_from.p;
     }
     if (nodes->align_to) {
-        if ((rc = ensure(e, e->up_to, n))) return rc;
+        if ((rc = alga_ensure(e, e->up_to, n))) return rc;
         if (n) HIP_TRY(e, hipMemcpyAsync(e->up_to.p, nodes->align_to, n, hipMemcpyHostToDevice, s));
         dn.align_to = (const uint8_t *) e->up_to.p;
     }
@@ -410,10 +347,10 @@ int alga_prefsuf_build_host(alga_engine *e, const alga_nodes *nodes, const alga_
     uint64_t E = 0;
     if ((rc = alga_prefsuf_build_device(e, &dn, p, (void *) s, &d_edges, &E))) return rc;
     alga_edge *h = (alga_edge *) malloc((size_t) (E ? E : 1) * sizeof(alga_edge));
-    if (!h) return fail(e, ALGA_ERR_OUT_OF_MEMORY, "host edge buffer");
+    if (!h) return alga_fail(e, ALGA_ERR_OUT_OF_MEMORY, "host edge buffer");
     if (E) {
         hipError_t err = hipMemcpy(h, d_edges, (size_t) E * sizeof(alga_edge), hipMemcpyDeviceToHost);
-        if (err != hipSuccess) { free(h); return fail(e, ALGA_ERR_HIP, "copy edges to host", err); }
+        if (err != hipSuccess) { free(h); return alga_fail(e, ALGA_ERR_HIP, "copy edges to host", err); }
     }
     *edges = h; *n_edges = E;
     return ALGA_OK;
@@ -431,14 +368,14 @@ int alga_prefsuf_discover_device(alga_engine *e, const alga_nodes *nodes, const 
                                  void *hip_stream, const uint32_t **d_dst, const uint64_t **d_val, uint64_t *n_records) {
     if (!e) return ALGA_ERR_INVALID_ARGUMENT;
     e->err.clear();
-    if (!d_dst || !d_val || !n_records) return fail(e, ALGA_ERR_INVALID_ARGUMENT, "output pointers must not be NULL");
+    if (!d_dst || !d_val || !n_records) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "output pointers must not be NULL");
     HIP_TRY(e, hipSetDevice(e->device));
     hipStream_t s = hip_stream ? (hipStream_t) hip_stream : e->own_stream;
     memset(&e->stats, 0, sizeof(e->stats));
     Prepared pp;
     int rc = prepare(e, nodes, p, s, pp);
     if (rc) return rc;
-    if (src_begin < 0 || src_end > nodes->n || src_begin > src_end) return fail(e, ALGA_ERR_INVALID_ARGUMENT, "bad source range");
+    if (src_begin < 0 || src_end > nodes->n || src_begin > src_end) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "bad source range");
     e->stats.nodes_live = pp.live;
     uint64_t n_rec = 0;
     if ((rc = discover_impl(e, pp, src_begin, src_end, s, &n_rec))) return rc;
@@ -455,15 +392,15 @@ int alga_prefsuf_reduce_device(alga_engine *e, const alga_nodes *nodes, const al
                                void *hip_stream, const alga_edge **d_edges, uint64_t *n_edges) {
     if (!e) return ALGA_ERR_INVALID_ARGUMENT;
     e->err.clear();
-    if (!d_edges || !n_edges) return fail(e, ALGA_ERR_INVALID_ARGUMENT, "output pointers must not be NULL");
+    if (!d_edges || !n_edges) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "output pointers must not be NULL");
     *d_edges = nullptr; *n_edges = 0;
-    if (n_records && (!d_dst || !d_val)) return fail(e, ALGA_ERR_INVALID_ARGUMENT, "record arrays must not be NULL");
+    if (n_records && (!d_dst || !d_val)) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "record arrays must not be NULL");
     HIP_TRY(e, hipSetDevice(e->device));
     hipStream_t s = hip_stream ? (hipStream_t) hip_stream : e->own_stream;
     Prepared pp;
     int rc = prepare(e, nodes, p, s, pp);
     if (rc) return rc;
-    if (dst_begin < 0 || dst_end > nodes->n || dst_begin > dst_end) return fail(e, ALGA_ERR_INVALID_ARGUMENT, "bad target range");
+    if (dst_begin < 0 || dst_end > nodes->n || dst_begin > dst_end) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "bad target range");
     HIP_TRY(e, hipEventRecord(e->ev[EV_PROBE], s));
     uint64_t E = 0;
     if ((rc = reduce_impl(e, pp, d_dst, (const unsigned long long *) d_val, n_records, n_records, dst_begin, dst_end, s, &E))) return rc;
@@ -479,25 +416,25 @@ int alga_sort_records_device(alga_engine *e, const uint32_t *d_dst, const uint64
                              void *hip_stream, const uint32_t **d_dst_sorted, const uint64_t **d_val_sorted, uint64_t *n_valid) {
     if (!e) return ALGA_ERR_INVALID_ARGUMENT;
     e->err.clear();
-    if (!d_dst_sorted || !d_val_sorted || !n_valid) return fail(e, ALGA_ERR_INVALID_ARGUMENT, "output pointers must not be NULL");
+    if (!d_dst_sorted || !d_val_sorted || !n_valid) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "output pointers must not be NULL");
     *d_dst_sorted = nullptr; *d_val_sorted = nullptr; *n_valid = 0;
-    if (n_records && (!d_dst || !d_val)) return fail(e, ALGA_ERR_INVALID_ARGUMENT, "record arrays must not be NULL");
-    if (n_nodes < 0) return fail(e, ALGA_ERR_INVALID_ARGUMENT, "negative node count");
-    if (n_records >= (1ull << 32) - 16) return fail(e, ALGA_ERR_CAPACITY, "more than 2^32 overlap records; shard the input");
+    if (n_records && (!d_dst || !d_val)) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "record arrays must not be NULL");
+    if (n_nodes < 0) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "negative node count");
+    if (n_records >= (1ull << 32) - 16) return alga_fail(e, ALGA_ERR_CAPACITY, "more than 2^32 overlap records; shard the input");
     HIP_TRY(e, hipSetDevice(e->device));
     hipStream_t s = hip_stream ? (hipStream_t) hip_stream : e->own_stream;
     int rc;
     const int bits = key_bits_for(n_nodes);
     const size_t temp_bytes = sort_records_temp_bytes(n_records, bits);
-    if ((rc = ensure(e, e->counters, (CNT_TOTAL + 2) * sizeof(unsigned long long)))) return rc;
-    if ((rc = ensure(e, e->keys, (size_t) (n_records + 1) * sizeof(uint32_t)))) return rc;
-    if ((rc = ensure(e, e->xs_dst, (size_t) (n_records + 1) * sizeof(uint32_t)))) return rc;
-    if ((rc = ensure(e, e->xs_val, (size_t) (n_records + 1) * sizeof(unsigned long long)))) return rc;
-    if ((rc = ensure(e, e->sort_temp, temp_bytes))) return rc;
+    if ((rc = alga_ensure(e, e->counters, (CNT_TOTAL + 2) * sizeof(unsigned long long)))) return rc;
+    if ((rc = alga_ensure(e, e->keys, (size_t) (n_records + 1) * sizeof(uint32_t)))) return rc;
+    if ((rc = alga_ensure(e, e->xs_dst, (size_t) (n_records + 1) * sizeof(uint32_t)))) return rc;
+    if ((rc = alga_ensure(e, e->xs_val, (size_t) (n_records + 1) * sizeof(unsigned long long)))) return rc;
+    if ((rc = alga_ensure(e, e->sort_temp, temp_bytes))) return rc;
     unsigned long long *cnt = (unsigned long long *) e->counters.p;
     HIP_TRY(e, hipMemsetAsync(cnt + CNT_SORT_VALID, 0, sizeof(unsigned long long), s));
     launch_make_keys(d_dst, n_records, 0, n_nodes, (uint32_t *) e->keys.p, cnt + CNT_SORT_VALID, s);
-    if ((rc = check_launch(e, "k_make_keys"))) return rc;
+    if ((rc = alga_check_launch(e, "k_make_keys"))) return rc;
     HIP_TRY(e, sort_records(e->sort_temp.p, temp_bytes, (const uint32_t *) e->keys.p, (uint32_t *) e->xs_dst.p, (const unsigned long long *) d_val,
                             (unsigned long long *) e->xs_val.p, n_records, bits, s));
     HIP_TRY(e, hipMemcpyAsync(&e->h_counters[CNT_SORT_VALID], cnt + CNT_SORT_VALID, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
@@ -511,28 +448,28 @@ int alga_sort_edges_device(alga_engine *e, const alga_edge *d_edges, uint64_t n_
                            const alga_edge **d_sorted) {
     if (!e) return ALGA_ERR_INVALID_ARGUMENT;
     e->err.clear();
-    if (!d_sorted) return fail(e, ALGA_ERR_INVALID_ARGUMENT, "output pointer must not be NULL");
+    if (!d_sorted) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "output pointer must not be NULL");
     *d_sorted = nullptr;
-    if (n_edges && !d_edges) return fail(e, ALGA_ERR_INVALID_ARGUMENT, "edge array must not be NULL");
-    if (n_edges >= (1ull << 32) - 16) return fail(e, ALGA_ERR_CAPACITY, "more than 2^32 edges");
+    if (n_edges && !d_edges) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "edge array must not be NULL");
+    if (n_edges >= (1ull << 32) - 16) return alga_fail(e, ALGA_ERR_CAPACITY, "more than 2^32 edges");
     HIP_TRY(e, hipSetDevice(e->device));
     hipStream_t s = hip_stream ? (hipStream_t) hip_stream : e->own_stream;
     int rc;
     const size_t temp_bytes = sort_edges_temp_bytes(n_edges);
-    if ((rc = ensure(e, e->edge_keys, (size_t) (n_edges + 1) * sizeof(unsigned long long)))) return rc;
-    if ((rc = ensure(e, e->edge_keys2, (size_t) (n_edges + 1) * sizeof(unsigned long long)))) return rc;
-    if ((rc = ensure(e, e->edge_vals, (size_t) (n_edges + 1) * sizeof(uint32_t)))) return rc;
-    if ((rc = ensure(e, e->edge_vals2, (size_t) (n_edges + 1) * sizeof(uint32_t)))) return rc;
-    if ((rc = ensure(e, e->edges_sorted, (size_t) (n_edges + 1) * sizeof(alga_edge_dev)))) return rc;
-    if ((rc = ensure(e, e->sort_temp, temp_bytes))) return rc;
+    if ((rc = alga_ensure(e, e->edge_keys, (size_t) (n_edges + 1) * sizeof(unsigned long long)))) return rc;
+    if ((rc = alga_ensure(e, e->edge_keys2, (size_t) (n_edges + 1) * sizeof(unsigned long long)))) return rc;
+    if ((rc = alga_ensure(e, e->edge_vals, (size_t) (n_edges + 1) * sizeof(uint32_t)))) return rc;
+    if ((rc = alga_ensure(e, e->edge_vals2, (size_t) (n_edges + 1) * sizeof(uint32_t)))) return rc;
+    if ((rc = alga_ensure(e, e->edges_sorted, (size_t) (n_edges + 1) * sizeof(alga_edge_dev)))) return rc;
+    if ((rc = alga_ensure(e, e->sort_temp, temp_bytes))) return rc;
     launch_edges_to_keys((const alga_edge_dev *) d_edges, n_edges, (unsigned long long *) e->edge_keys.p, (uint32_t *) e->edge_vals.p, s);
-    if ((rc = check_launch(e, "k_edges_to_keys"))) return rc;
+    if ((rc = alga_check_launch(e, "k_edges_to_keys"))) return rc;
     int src_bits = 1;
     while (src_bits < 31 && (1ll << src_bits) < (long long) n_nodes) src_bits++;
     HIP_TRY(e, sort_edges(e->sort_temp.p, temp_bytes, (const unsigned long long *) e->edge_keys.p, (unsigned long long *) e->edge_keys2.p,
                           (const uint32_t *) e->edge_vals.p, (uint32_t *) e->edge_vals2.p, n_edges, src_bits, s));
     launch_keys_to_edges((const unsigned long long *) e->edge_keys2.p, (const uint32_t *) e->edge_vals2.p, n_edges, (alga_edge_dev *) e->edges_sorted.p, s);
-    if ((rc = check_launch(e, "k_keys_to_edges"))) return rc;
+    if ((rc = alga_check_launch(e, "k_keys_to_edges"))) return rc;
     HIP_TRY(e, hipStreamSynchronize(s));
     *d_sorted = (const alga_edge *) e->edges_sorted.p;
     return ALGA_OK;

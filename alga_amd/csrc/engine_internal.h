@@ -1,0 +1,73 @@
+// alga_amd/csrc/engine_internal.h -- engine state and small helpers shared by engine.hip and engine_pkb.hip
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <string>
+
+#include "../../include/alga_amd.h"
+#include "prefsuf_common.h"
+#include "prefsuf_kernels.h"
+
+struct DevBuf {
+    void  *p = nullptr;
+    size_t cap = 0;
+};
+
+enum { EV_START = 0, EV_SEED, EV_PROBE, EV_GROUP, EV_REDUCE, EV_EMIT, EV_COUNT };
+
+struct alga_engine {
+    int         device = -1;
+    hipStream_t own_stream = nullptr;
+    std::string err;
+    char        dev_name[256] = {0};
+    int         n_cu = 256;
+    int         seed_fill_x10 = 20;           // average seed-table bucket fill x10 (tunable: ALGA_SEED_FILL_X10)
+    int         use_filter = 1;               // L2-resident fingerprint bitmap in front of the seed table (ALGA_SEED_FILTER=0 disables)
+    hipEvent_t  ev[EV_COUNT] = {};
+    // device buffers, grown on demand and kept between calls
+    DevBuf table, filter, counters, rowptr, rec_dst, rec_val, keys, seg_key, seg_val, heads, sort_temp, out_cnt, outdeg, out_rowptr, edges, scan_scratch;
+    DevBuf edge_keys, edge_keys2, edge_vals, edge_vals2, edges_sorted, xs_dst, xs_val;
+    DevBuf up_words, up_len, up_from, up_to;   // uploads of the host-buffer entry points
+    // approximate supplement (engine_pkb.hip)
+    DevBuf pk_keys, pk_keys2, pk_vals, pk_vals2, pk_marks, pk_big, pk_add, pk_ekeys, pk_ekeys2, pk_flag, pk_pos, pk_edges[2], pk_rowptr, pk_deg,
+           pk_mask, pk_cnt, pk_io, pk_io2;
+    unsigned long long *h_counters = nullptr;  // pinned, CNT_TOTAL + 2 entries
+    uint64_t    rec_cap_hint = 0;
+    alga_prefsuf_stats stats;
+    alga_pkb_stats pkb_stats;
+};
+
+inline int alga_fail(alga_engine *e, int code, const char *what, hipError_t herr = hipSuccess) {
+    char buf[512];
+    if (herr != hipSuccess) snprintf(buf, sizeof(buf), "%s: %s", what, hipGetErrorString(herr));
+    else snprintf(buf, sizeof(buf), "%s", what);
+    e->err = buf;
+    return code;
+}
+
+#define HIP_TRY(e, call)                                                                     \
+    do {                                                                                     \
+        hipError_t _err = (call);                                                            \
+        if (_err != hipSuccess) return alga_fail((e), _err == hipErrorOutOfMemory ? ALGA_ERR_OUT_OF_MEMORY : ALGA_ERR_HIP, #call, _err); \
+    } while (0)
+
+inline int alga_ensure(alga_engine *e, DevBuf &b, size_t bytes) {
+    if (bytes == 0) bytes = 16;
+    if (b.cap >= bytes) return ALGA_OK;
+    if (b.p) { HIP_TRY(e, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
+    HIP_TRY(e, hipMalloc(&b.p, bytes));
+    b.cap = bytes;
+    return ALGA_OK;
+}
+
+inline void alga_release(DevBuf &b) {
+    if (b.p) (void) hipFree(b.p);
+    b.p = nullptr; b.cap = 0;
+}
+
+inline int alga_check_launch(alga_engine *e, const char *what) {
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return alga_fail(e, ALGA_ERR_HIP, what, err);
+    return ALGA_OK;
+}

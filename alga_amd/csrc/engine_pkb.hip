@@ -1,0 +1,303 @@
+// alga_amd/csrc/engine_pkb.hip -- host side of the approximate supplement (C ABI: include/alga_amd.h, "approximate
+// supplement" section).  Orchestrates pkb_kernels.hip; no CPU fallback.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+
+#include "engine_internal.h"
+#include "pkb_kernels.h"
+
+using namespace alga;
+
+namespace {
+
+PkbCfg make_cfg(const alga_pkb_params *p) {
+    PkbCfg c;
+    c.min_overlap_area = p->min_overlap_area; c.max_offset_pct = p->max_offset_pct; c.min_identity_pct = p->min_identity_pct;
+    c.same_ends = p->same_ends; c.li_k = p->li_k; c.li_intervals = p->li_intervals; c.kmer_length_bucket = p->kmer_length_bucket;
+    return c;
+}
+
+int check_params(alga_engine *e, const alga_nodes *nodes, const alga_pkb_params *p) {
+    if (!nodes || !p) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "nodes/params must not be NULL");
+    if (nodes->n < 0 || (nodes->n > 0 && (!nodes->words || !nodes->len || nodes->stride_words <= 0)))
+        return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "bad node set");
+    if (p->li_k < 1 || p->li_k > 63) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "li_k must be in [1, 63]");
+    if (p->li_intervals < 1 || p->li_intervals > PKB_MAX_INTERVALS) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "li_intervals must be in [1, 16]");
+    if (p->same_ends < 0 || p->same_ends > 15) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "same_ends must be in [0, 15]");
+    if (p->rounds < 0 || p->rounds > 4) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "rounds must be in [0, 4]");
+    if (p->min_overlap_area < p->same_ends) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "min_overlap_area must be >= same_ends");
+    if (nodes->n >= (1 << 27)) return alga_fail(e, ALGA_ERR_CAPACITY, "more than 2^27 nodes in the supplement; shard the input");
+    return ALGA_OK;
+}
+
+// uploads a host node set into the engine's staging buffers (rows re-strided to a multiple of 4 words)
+int upload_nodes(alga_engine *e, const alga_nodes *nodes, hipStream_t s, alga_nodes *dn) {
+    int rc;
+    const size_t n = (size_t) nodes->n;
+    int32_t max_len = 0;
+    for (size_t i = 0; i < n; i++) max_len = std::max(max_len, nodes->len[i]);
+    if ((int64_t) blocks_of(max_len) > (int64_t) nodes->stride_words)
+        return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "stride_words is smaller than the longest read needs");
+    const int stride_up = (nodes->stride_words + 3) & ~3;
+    const size_t wbytes = n * (size_t) stride_up * sizeof(uint32_t);
+    if ((rc = alga_ensure(e, e->up_words, wbytes))) return rc;
+    if ((rc = alga_ensure(e, e->up_len, n * sizeof(int32_t)))) return rc;
+    *dn = *nodes;
+    if (n) {
+        if (stride_up != nodes->stride_words) HIP_TRY(e, hipMemsetAsync(e->up_words.p, 0, wbytes, s));
+        HIP_TRY(e, hipMemcpy2DAsync(e->up_words.p, (size_t) stride_up * 4, nodes->words, (size_t) nodes->stride_words * 4,
+                                    (size_t) nodes->stride_words * 4, n, hipMemcpyHostToDevice, s));
+        HIP_TRY(e, hipMemcpyAsync(e->up_len.p, nodes->len, n * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    }
+    dn->words = (const uint32_t *) e->up_words.p; dn->len = (const int32_t *) e->up_len.p; dn->stride_words = stride_up;
+    dn->align_from = nullptr; dn->align_to = nullptr;
+    return ALGA_OK;
+}
+
+NodesDev nodes_dev(const alga_nodes *dn) {
+    NodesDev nd;
+    nd.words = dn->words; nd.len = dn->len; nd.from = nullptr; nd.to = nullptr; nd.n = dn->n; nd.stride = dn->stride_words;
+    return nd;
+}
+
+// edges (any order, invalid entries have src < 0) -> unique (src, dst) with the smallest offset, sorted, + row pointers.
+// Graph::addDirectedEdge / retainOnlySmallestOffset (src/DataStructures/Graph.cpp:53-71,348-387) as one sort.
+int normalize_edges(alga_engine *e, int32_t n_nodes, const alga_edge_dev *in, uint64_t n_in, DevBuf &out, uint64_t *n_out, hipStream_t s) {
+    int rc;
+    if (n_in >= (1ull << 32) - 16) return alga_fail(e, ALGA_ERR_CAPACITY, "more than 2^32 edges");
+    const size_t temp = sort_u64_keys_temp_bytes(n_in);
+    if ((rc = alga_ensure(e, e->pk_ekeys, (n_in + 1) * sizeof(unsigned long long)))) return rc;
+    if ((rc = alga_ensure(e, e->pk_ekeys2, (n_in + 1) * sizeof(unsigned long long)))) return rc;
+    if ((rc = alga_ensure(e, e->pk_flag, (n_in + 2) * sizeof(uint32_t)))) return rc;
+    if ((rc = alga_ensure(e, e->pk_pos, (n_in + 2) * sizeof(uint32_t)))) return rc;
+    if ((rc = alga_ensure(e, e->sort_temp, temp))) return rc;
+    if ((rc = alga_ensure(e, e->scan_scratch, std::max(scan_scratch_bytes(n_in), scan_scratch_bytes((uint64_t) n_nodes))))) return rc;
+    if ((rc = alga_ensure(e, e->pk_deg, (size_t) (n_nodes + 1) * sizeof(uint32_t)))) return rc;
+    if ((rc = alga_ensure(e, e->pk_rowptr, (size_t) (n_nodes + 2) * sizeof(uint32_t)))) return rc;
+    launch_pkb_edge_keys(in, n_in, (unsigned long long *) e->pk_ekeys.p, s);
+    if ((rc = alga_check_launch(e, "k_pkb_edge_keys"))) return rc;
+    HIP_TRY(e, sort_u64_keys(e->sort_temp.p, temp, (const unsigned long long *) e->pk_ekeys.p, (unsigned long long *) e->pk_ekeys2.p, n_in, s));
+    launch_pkb_unique_flags((const unsigned long long *) e->pk_ekeys2.p, n_in, (uint32_t *) e->pk_flag.p, s);
+    if ((rc = alga_check_launch(e, "k_pkb_unique_flags"))) return rc;
+    launch_exclusive_scan((const uint32_t *) e->pk_flag.p, n_in, (uint32_t *) e->pk_pos.p, (uint64_t *) e->scan_scratch.p, s);
+    if ((rc = alga_check_launch(e, "scan(flags)"))) return rc;
+    uint64_t total = 0;
+    HIP_TRY(e, hipMemcpyAsync(&e->h_counters[CNT_TOTAL], (uint64_t *) e->scan_scratch.p + scan_total_index(n_in), sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(e, hipStreamSynchronize(s));
+    total = n_in ? e->h_counters[CNT_TOTAL] : 0;
+    if ((rc = alga_ensure(e, out, (total + 1) * sizeof(alga_edge_dev)))) return rc;
+    HIP_TRY(e, hipMemsetAsync(e->pk_deg.p, 0, (size_t) (n_nodes + 1) * sizeof(uint32_t), s));
+    launch_pkb_compact((const unsigned long long *) e->pk_ekeys2.p, (const uint32_t *) e->pk_flag.p, (const uint32_t *) e->pk_pos.p, n_in,
+                       (alga_edge_dev *) out.p, (uint32_t *) e->pk_deg.p, s);
+    if ((rc = alga_check_launch(e, "k_pkb_compact"))) return rc;
+    launch_exclusive_scan((const uint32_t *) e->pk_deg.p, (uint64_t) n_nodes, (uint32_t *) e->pk_rowptr.p, (uint64_t *) e->scan_scratch.p, s);
+    if ((rc = alga_check_launch(e, "scan(outdeg)"))) return rc;
+    *n_out = total;
+    return ALGA_OK;
+}
+
+int supplement_device_impl(alga_engine *e, const alga_nodes *dn, const alga_pkb_params *p, const alga_edge *d_edges_in, uint64_t m_in,
+                           hipStream_t s, const alga_edge **d_out, uint64_t *m_out) {
+    int rc;
+    const PkbCfg c = make_cfg(p);
+    const NodesDev nd = nodes_dev(dn);
+    const int32_t n = dn->n;
+    memset(&e->pkb_stats, 0, sizeof(e->pkb_stats));
+    hipEvent_t ev0 = e->ev[EV_START], ev1 = e->ev[EV_EMIT];
+    HIP_TRY(e, hipEventRecord(ev0, s));
+    if ((rc = alga_ensure(e, e->pk_cnt, 16 * sizeof(unsigned long long)))) return rc;
+    unsigned long long *cnt = (unsigned long long *) e->pk_cnt.p;
+    int cur = 0;
+    uint64_t E = 0;
+    if ((rc = normalize_edges(e, n, (const alga_edge_dev *) d_edges_in, m_in, e->pk_edges[cur], &E, s))) return rc;
+    // masks from the degrees of the incoming graph, once (src/main.cpp:308-322)
+    if ((rc = alga_ensure(e, e->pk_mask, (size_t) n + 16))) return rc;
+    if ((rc = alga_ensure(e, e->outdeg, (size_t) (n + 1) * sizeof(uint32_t)))) return rc;
+    launch_pkb_masks(n, (const uint32_t *) e->pk_rowptr.p, (const alga_edge_dev *) e->pk_edges[cur].p, E, (uint32_t *) e->outdeg.p, (uint8_t *) e->pk_mask.p, s);
+    if ((rc = alga_check_launch(e, "k_pkb_masks"))) return rc;
+    int32_t prio[4] = {0, 1, 2, 3};
+    const uint64_t max_kmers = (uint64_t) n * (uint64_t) c.li_intervals;
+    for (int round = 0; round < p->rounds; round++) {
+        if ((rc = alga_ensure(e, e->pk_keys, (max_kmers + 1) * sizeof(unsigned long long)))) return rc;
+        if ((rc = alga_ensure(e, e->pk_vals, (max_kmers + 1) * sizeof(unsigned long long)))) return rc;
+        HIP_TRY(e, hipMemsetAsync(cnt, 0, 16 * sizeof(unsigned long long), s));
+        launch_pkb_kmers(nd, c, prio, (const uint8_t *) e->pk_mask.p, (unsigned long long *) e->pk_keys.p, (unsigned long long *) e->pk_vals.p, cnt + 0, s);
+        if ((rc = alga_check_launch(e, "k_pkb_kmers"))) return rc;
+        HIP_TRY(e, hipMemcpyAsync(e->h_counters, cnt, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        HIP_TRY(e, hipStreamSynchronize(s));
+        const uint64_t nk = e->h_counters[0];
+        e->pkb_stats.kmers[round] = nk;
+        if (nk >= 2) {
+            const size_t temp = sort_u64_pairs_temp_bytes(nk, 60);
+            if ((rc = alga_ensure(e, e->pk_keys2, (nk + 1) * sizeof(unsigned long long)))) return rc;
+            if ((rc = alga_ensure(e, e->pk_vals2, (nk + 1) * sizeof(unsigned long long)))) return rc;
+            if ((rc = alga_ensure(e, e->sort_temp, temp))) return rc;
+            // node order inside equal hashes is fixed by the stable sort: entries were appended in unspecified block order,
+            // so the group kernel re-orders every group by (indInRead desc, length asc, id asc) itself
+            HIP_TRY(e, sort_u64_pairs(e->sort_temp.p, temp, (const unsigned long long *) e->pk_keys.p, (unsigned long long *) e->pk_keys2.p,
+                                      (const unsigned long long *) e->pk_vals.p, (unsigned long long *) e->pk_vals2.p, nk, 60, s));
+            launch_pkb_group_sizes((const unsigned long long *) e->pk_keys2.p, nk, cnt + 1, cnt + 2, s);
+            if ((rc = alga_check_launch(e, "k_pkb_group_sizes"))) return rc;
+            HIP_TRY(e, hipMemcpyAsync(e->h_counters, cnt, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+            HIP_TRY(e, hipStreamSynchronize(s));
+            const uint64_t big_words = e->h_counters[1];
+            e->pkb_stats.groups[round] = e->h_counters[2];
+            e->pkb_stats.max_group = std::max<uint64_t>(e->pkb_stats.max_group, e->h_counters[3]);
+            const uint64_t add_dense = 2 * nk;
+            uint64_t add_ovf_cap = std::max<uint64_t>(1024, nk / 4);
+            for (int attempt = 0; attempt < 3; attempt++) {
+                const uint64_t add_cap = add_dense + add_ovf_cap;
+                if ((rc = alga_ensure(e, e->pk_marks, (nk + 1) * sizeof(unsigned long long)))) return rc;
+                if ((rc = alga_ensure(e, e->pk_big, (big_words + 1) * sizeof(unsigned long long)))) return rc;
+                if ((rc = alga_ensure(e, e->pk_add, (E + add_cap + 1) * sizeof(alga_edge_dev)))) return rc;
+                // pk_add = [ current graph (E) | dense additions (2 nk) | overflow additions ]
+                HIP_TRY(e, hipMemcpyAsync(e->pk_add.p, e->pk_edges[cur].p, E * sizeof(alga_edge_dev), hipMemcpyDeviceToDevice, s));
+                alga_edge_dev *add = (alga_edge_dev *) e->pk_add.p + E;
+                HIP_TRY(e, hipMemsetAsync(add + add_dense, 0xFF, add_ovf_cap * sizeof(alga_edge_dev), s));      // src = -1: invalid
+                HIP_TRY(e, hipMemsetAsync(cnt + 4, 0, 4 * sizeof(unsigned long long), s));                    // big cursor, overflow, calls
+                launch_pkb_groups(nd, c, (const uint32_t *) e->pk_rowptr.p, (const alga_edge_dev *) e->pk_edges[cur].p,
+                                  (const unsigned long long *) e->pk_keys2.p, (unsigned long long *) e->pk_vals2.p, nk,
+                                  (unsigned long long *) e->pk_marks.p, (unsigned long long *) e->pk_big.p, cnt + 4, add, add_dense, add_cap,
+                                  cnt + 5, cnt + 6, s);
+                if ((rc = alga_check_launch(e, "k_pkb_groups"))) return rc;
+                HIP_TRY(e, hipMemcpyAsync(e->h_counters, cnt, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+                HIP_TRY(e, hipStreamSynchronize(s));
+                if (e->h_counters[5] <= add_ovf_cap) {
+                    e->pkb_stats.can_align_calls[round] = e->h_counters[6];
+                    const int nxt = cur ^ 1;
+                    uint64_t E2 = 0;
+                    if ((rc = normalize_edges(e, n, (const alga_edge_dev *) e->pk_add.p, E + add_cap, e->pk_edges[nxt], &E2, s))) return rc;
+                    cur = nxt; E = E2;
+                    break;
+                }
+                add_ovf_cap = e->h_counters[5] + 1024;
+                if (attempt == 2) return alga_fail(e, ALGA_ERR_HIP, "supplement: addition buffer kept overflowing");
+            }
+        }
+        e->pkb_stats.edges_after[round] = E;
+        std::rotate(prio, prio + 1, prio + 4);                               // GraphCreatorLI.cpp:26
+    }
+    HIP_TRY(e, hipEventRecord(ev1, s));
+    HIP_TRY(e, hipStreamSynchronize(s));
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) e->pkb_stats.ms_total = ms;
+    *d_out = (const alga_edge *) e->pk_edges[cur].p;
+    *m_out = E;
+    return ALGA_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+void alga_pkb_derive_params(double avg_len, float scale, double error_rate, int32_t kmer_length_bucket, alga_pkb_params *p) {
+    if (!p) return;
+    const int er = (int) (100 * error_rate);                                 // Params::ERROR_RATE = 100 * rate (src/Params.cpp:357)
+    p->min_overlap_area = (int32_t) ((1.f + scale) * avg_len / 2);           // src/main.cpp:333
+    p->max_offset_pct = (int32_t) ((1.f - scale) * avg_len / 2);             // :335
+    p->min_identity_pct = 99 - er;                                           // :336
+    p->same_ends = 3; p->li_k = 35; p->li_intervals = 6; p->rounds = 4;
+    p->kmer_length_bucket = kmer_length_bucket;
+}
+
+int alga_can_align_batch_host(alga_engine *e, const alga_nodes *nodes, const alga_pkb_params *p, const int32_t *triples, uint64_t n, uint8_t *out) {
+    if (!e) return ALGA_ERR_INVALID_ARGUMENT;
+    e->err.clear();
+    int rc = check_params(e, nodes, p);
+    if (rc) return rc;
+    if (n && (!triples || !out)) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "triples/out must not be NULL");
+    HIP_TRY(e, hipSetDevice(e->device));
+    hipStream_t s = e->own_stream;
+    alga_nodes dn;
+    if ((rc = upload_nodes(e, nodes, s, &dn))) return rc;
+    if ((rc = alga_ensure(e, e->pk_io, (n + 1) * 3 * sizeof(int32_t)))) return rc;
+    if ((rc = alga_ensure(e, e->pk_io2, n + 16))) return rc;
+    if (n) HIP_TRY(e, hipMemcpyAsync(e->pk_io.p, triples, n * 3 * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    launch_can_align_batch(nodes_dev(&dn), make_cfg(p), (const int32_t *) e->pk_io.p, n, (uint8_t *) e->pk_io2.p, s);
+    if ((rc = alga_check_launch(e, "k_can_align_batch"))) return rc;
+    if (n) HIP_TRY(e, hipMemcpyAsync(out, e->pk_io2.p, n, hipMemcpyDeviceToHost, s));
+    HIP_TRY(e, hipStreamSynchronize(s));
+    return ALGA_OK;
+}
+
+int alga_li_kmers_host(alga_engine *e, const alga_nodes *nodes, const alga_pkb_params *p, const int32_t prio[4], uint64_t *hash, int32_t *ind,
+                       int32_t *count) {
+    if (!e) return ALGA_ERR_INVALID_ARGUMENT;
+    e->err.clear();
+    int rc = check_params(e, nodes, p);
+    if (rc) return rc;
+    if (!prio || (nodes->n && (!hash || !ind || !count))) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "output pointers must not be NULL");
+    HIP_TRY(e, hipSetDevice(e->device));
+    hipStream_t s = e->own_stream;
+    alga_nodes dn;
+    if ((rc = upload_nodes(e, nodes, s, &dn))) return rc;
+    const size_t slots = (size_t) nodes->n * (size_t) p->li_intervals;
+    if ((rc = alga_ensure(e, e->pk_keys, (slots + 1) * sizeof(uint64_t)))) return rc;
+    if ((rc = alga_ensure(e, e->pk_io, (slots + 1) * sizeof(int32_t)))) return rc;
+    if ((rc = alga_ensure(e, e->pk_io2, ((size_t) nodes->n + 1) * sizeof(int32_t)))) return rc;
+    launch_li_kmers_slots(nodes_dev(&dn), make_cfg(p), prio, (uint64_t *) e->pk_keys.p, (int32_t *) e->pk_io.p, (int32_t *) e->pk_io2.p, s);
+    if ((rc = alga_check_launch(e, "k_li_kmers_slots"))) return rc;
+    if (nodes->n) {
+        HIP_TRY(e, hipMemcpyAsync(hash, e->pk_keys.p, slots * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+        HIP_TRY(e, hipMemcpyAsync(ind, e->pk_io.p, slots * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        HIP_TRY(e, hipMemcpyAsync(count, e->pk_io2.p, (size_t) nodes->n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    }
+    HIP_TRY(e, hipStreamSynchronize(s));
+    return ALGA_OK;
+}
+
+int alga_pkb_supplement_device(alga_engine *e, const alga_nodes *nodes, const alga_pkb_params *p, const alga_edge *d_edges_in, uint64_t n_edges_in,
+                               void *hip_stream, const alga_edge **d_edges_out, uint64_t *n_edges_out) {
+    if (!e) return ALGA_ERR_INVALID_ARGUMENT;
+    e->err.clear();
+    if (!d_edges_out || !n_edges_out) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "output pointers must not be NULL");
+    *d_edges_out = nullptr; *n_edges_out = 0;
+    int rc = check_params(e, nodes, p);
+    if (rc) return rc;
+    if (n_edges_in && !d_edges_in) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "edges_in must not be NULL");
+    HIP_TRY(e, hipSetDevice(e->device));
+    hipStream_t s = hip_stream ? (hipStream_t) hip_stream : e->own_stream;
+    return supplement_device_impl(e, nodes, p, d_edges_in, n_edges_in, s, d_edges_out, n_edges_out);
+}
+
+int alga_pkb_supplement_host(alga_engine *e, const alga_nodes *nodes, const alga_pkb_params *p, const alga_edge *edges_in, uint64_t n_edges_in,
+                             alga_edge **edges_out, uint64_t *n_edges_out) {
+    if (!e) return ALGA_ERR_INVALID_ARGUMENT;
+    e->err.clear();
+    if (!edges_out || !n_edges_out) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "output pointers must not be NULL");
+    *edges_out = nullptr; *n_edges_out = 0;
+    int rc = check_params(e, nodes, p);
+    if (rc) return rc;
+    if (n_edges_in && !edges_in) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "edges_in must not be NULL");
+    for (uint64_t i = 0; i < n_edges_in; i++)
+        if (edges_in[i].src < 0 || edges_in[i].src >= nodes->n || edges_in[i].dst < 0 || edges_in[i].dst >= nodes->n || edges_in[i].offset < 0 || edges_in[i].offset > 511)
+            return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "edge out of range");
+    HIP_TRY(e, hipSetDevice(e->device));
+    hipStream_t s = e->own_stream;
+    alga_nodes dn;
+    if ((rc = upload_nodes(e, nodes, s, &dn))) return rc;
+    if ((rc = alga_ensure(e, e->pk_io, (n_edges_in + 1) * sizeof(alga_edge)))) return rc;
+    if (n_edges_in) HIP_TRY(e, hipMemcpyAsync(e->pk_io.p, edges_in, n_edges_in * sizeof(alga_edge), hipMemcpyHostToDevice, s));
+    const alga_edge *d_out = nullptr;
+    uint64_t m = 0;
+    if ((rc = supplement_device_impl(e, &dn, p, (const alga_edge *) e->pk_io.p, n_edges_in, s, &d_out, &m))) return rc;
+    alga_edge *h = (alga_edge *) malloc((size_t) (m ? m : 1) * sizeof(alga_edge));
+    if (!h) return alga_fail(e, ALGA_ERR_OUT_OF_MEMORY, "host edge buffer");
+    if (m) {
+        hipError_t err = hipMemcpy(h, d_out, (size_t) m * sizeof(alga_edge), hipMemcpyDeviceToHost);
+        if (err != hipSuccess) { free(h); return alga_fail(e, ALGA_ERR_HIP, "copy edges to host", err); }
+    }
+    *edges_out = h; *n_edges_out = m;
+    return ALGA_OK;
+}
+
+int alga_pkb_last_stats(const alga_engine *e, alga_pkb_stats *out) {
+    if (!e || !out) return ALGA_ERR_INVALID_ARGUMENT;
+    *out = e->pkb_stats;
+    return ALGA_OK;
+}
+
+} // extern "C"

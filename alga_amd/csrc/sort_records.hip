@@ -10,6 +10,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include "prefsuf_kernels.h"
+#include "pkb_kernels.h"
 
 namespace alga {
 
@@ -39,6 +40,32 @@ hipError_t sort_edges(void *temp, size_t temp_bytes, const unsigned long long *k
                       uint32_t *vals_out, uint64_t n, int src_bits, hipStream_t s) {
     if (n == 0) return hipSuccess;
     return rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t) n, 0u, (unsigned) (32 + src_bits), s);
+}
+
+size_t sort_u64_pairs_temp_bytes(uint64_t n, int bits) {
+    size_t bytes = 0;
+    (void) rocprim::radix_sort_pairs(nullptr, bytes, (const unsigned long long *) nullptr, (unsigned long long *) nullptr,
+                                     (const unsigned long long *) nullptr, (unsigned long long *) nullptr, (size_t) n, 0u, (unsigned) bits,
+                                     (hipStream_t) 0);
+    return bytes;
+}
+
+hipError_t sort_u64_pairs(void *temp, size_t temp_bytes, const unsigned long long *keys_in, unsigned long long *keys_out,
+                          const unsigned long long *vals_in, unsigned long long *vals_out, uint64_t n, int bits, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    return rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t) n, 0u, (unsigned) bits, s);
+}
+
+size_t sort_u64_keys_temp_bytes(uint64_t n) {
+    size_t bytes = 0;
+    (void) rocprim::radix_sort_keys(nullptr, bytes, (const unsigned long long *) nullptr, (unsigned long long *) nullptr, (size_t) n, 0u, 64u,
+                                    (hipStream_t) 0);
+    return bytes;
+}
+
+hipError_t sort_u64_keys(void *temp, size_t temp_bytes, const unsigned long long *keys_in, unsigned long long *keys_out, uint64_t n, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    return rocprim::radix_sort_keys(temp, temp_bytes, keys_in, keys_out, (size_t) n, 0u, 64u, s);
 }
 
 } // namespace alga

@@ -60,11 +60,26 @@ class NodeSet(C.Structure):
                 ("removed_prefix", C.c_int32), ("removed_short", C.c_int32), ("avg_len", C.c_double)]
 
 
+class PkbParams(C.Structure):
+    """alga_pkb_params"""
+    _fields_ = [("min_overlap_area", C.c_int32), ("max_offset_pct", C.c_int32), ("min_identity_pct", C.c_int32),
+                ("same_ends", C.c_int32), ("li_k", C.c_int32), ("li_intervals", C.c_int32), ("rounds", C.c_int32),
+                ("kmer_length_bucket", C.c_int32)]
+
+
+class PkbStats(C.Structure):
+    """alga_pkb_stats"""
+    _fields_ = [("kmers", C.c_uint64 * 4), ("groups", C.c_uint64 * 4), ("can_align_calls", C.c_uint64 * 4),
+                ("edges_after", C.c_uint64 * 4), ("max_group", C.c_uint64), ("ms_total", C.c_double)]
+
+
 EXPORTS = ["alga_abi_version", "alga_engine_create", "alga_engine_destroy", "alga_last_error",
            "alga_engine_device_name", "alga_prefsuf_default_params", "alga_prefsuf_build_host", "alga_free_edges",
            "alga_prefsuf_build_device", "alga_prefsuf_last_stats", "alga_prefsuf_discover_device",
            "alga_prefsuf_reduce_device", "alga_write_graph", "alga_ingest_default_params", "alga_ingest_files",
-           "alga_free_node_set", "alga_sort_records_device", "alga_sort_edges_device"]
+           "alga_free_node_set", "alga_sort_records_device", "alga_sort_edges_device", "alga_pkb_derive_params",
+           "alga_can_align_batch_host", "alga_li_kmers_host", "alga_pkb_supplement_host", "alga_pkb_supplement_device",
+           "alga_pkb_last_stats"]
 
 
 def library_path():
@@ -113,6 +128,15 @@ def load_library():
     lib.alga_sort_records_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p,
                                              C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
     lib.alga_sort_edges_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]
+    lib.alga_pkb_derive_params.argtypes = [C.c_double, C.c_float, C.c_double, C.c_int32, C.POINTER(PkbParams)]
+    lib.alga_pkb_derive_params.restype = None
+    lib.alga_can_align_batch_host.argtypes = [C.c_void_p, C.POINTER(_Nodes), C.POINTER(PkbParams), C.c_void_p, C.c_uint64, C.c_void_p]
+    lib.alga_li_kmers_host.argtypes = [C.c_void_p, C.POINTER(_Nodes), C.POINTER(PkbParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.alga_pkb_supplement_host.argtypes = [C.c_void_p, C.POINTER(_Nodes), C.POINTER(PkbParams), C.c_void_p, C.c_uint64,
+                                             C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    lib.alga_pkb_supplement_device.argtypes = [C.c_void_p, C.POINTER(_Nodes), C.POINTER(PkbParams), C.c_void_p, C.c_uint64, C.c_void_p,
+                                               C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    lib.alga_pkb_last_stats.argtypes = [C.c_void_p, C.POINTER(PkbStats)]
     lib.alga_ingest_default_params.argtypes = [C.POINTER(IngestParams)]
     lib.alga_ingest_default_params.restype = None
     lib.alga_ingest_files.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(IngestParams), C.POINTER(NodeSet), C.c_char_p, C.c_size_t]
@@ -314,6 +338,56 @@ class Engine:
         out = C.c_void_p()
         self._check(self._lib.alga_sort_edges_device(self._h, p, int(n_edges), int(n_nodes), C.c_void_p(stream or 0), C.byref(out)))
         return out.value
+
+    # ---- approximate supplement ---------------------------------------------------------------
+    @staticmethod
+    def pkb_params(avg_len, error_rate, kmer_length_bucket, scale=0.55):
+        p = PkbParams()
+        load_library().alga_pkb_derive_params(float(avg_len), float(scale), float(error_rate), int(kmer_length_bucket), C.byref(p))
+        return p
+
+    @staticmethod
+    def _host_nodes(words, lens):
+        words = np.ascontiguousarray(words, dtype=np.uint32)
+        lens = np.ascontiguousarray(lens, dtype=np.int32)
+        n = int(lens.shape[0])
+        stride = int(words.shape[1]) if words.ndim == 2 else (words.size // max(n, 1))
+        return _Nodes(words.ctypes.data, stride, lens.ctypes.data, n, None, None), (words, lens)
+
+    def can_align_batch(self, words, lens, triples, p):
+        nd, keep = self._host_nodes(words, lens)
+        t = np.ascontiguousarray(triples, dtype=np.int32).reshape(-1, 3)
+        out = np.zeros(len(t), dtype=np.uint8)
+        self._check(self._lib.alga_can_align_batch_host(self._h, C.byref(nd), C.byref(p), t.ctypes.data, len(t), out.ctypes.data))
+        return out
+
+    def li_kmers(self, words, lens, p, prio):
+        nd, keep = self._host_nodes(words, lens)
+        n, I = nd.n, p.li_intervals
+        h = np.zeros((n, I), dtype=np.uint64)
+        ind = np.zeros((n, I), dtype=np.int32)
+        cnt = np.zeros(n, dtype=np.int32)
+        pr = np.ascontiguousarray(prio, dtype=np.int32)
+        self._check(self._lib.alga_li_kmers_host(self._h, C.byref(nd), C.byref(p), pr.ctypes.data, h.ctypes.data, ind.ctypes.data, cnt.ctypes.data))
+        return h, ind, cnt
+
+    def pkb_supplement_host(self, words, lens, edges_in, p):
+        nd, keep = self._host_nodes(words, lens)
+        e = np.ascontiguousarray(edges_in, dtype=np.int32).reshape(-1, 3)
+        out = C.c_void_p()
+        m = C.c_uint64()
+        self._check(self._lib.alga_pkb_supplement_host(self._h, C.byref(nd), C.byref(p), e.ctypes.data, len(e), C.byref(out), C.byref(m)))
+        try:
+            r = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_int32)), shape=(max(m.value, 1) * 3,))[: m.value * 3]
+            return r.reshape(-1, 3).copy()
+        finally:
+            self._lib.alga_free_edges(self._h, out)
+
+    def pkb_last_stats(self):
+        st = PkbStats()
+        self._check(self._lib.alga_pkb_last_stats(self._h, C.byref(st)))
+        return dict(kmers=list(st.kmers), groups=list(st.groups), can_align_calls=list(st.can_align_calls),
+                    edges_after=list(st.edges_after), max_group=st.max_group, ms_total=st.ms_total)
 
     def write_graph(self, path, n_nodes, edges):
         edges = np.ascontiguousarray(edges, dtype=np.int32).reshape(-1, 3)

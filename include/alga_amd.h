@@ -149,6 +149,56 @@ int  alga_sort_records_device(alga_engine *e, const uint32_t *d_dst, const uint6
 int  alga_sort_edges_device(alga_engine *e, const alga_edge *d_edges, uint64_t n_edges, int32_t n_nodes,
                             void *hip_stream, const alga_edge **d_sorted);
 
+/* ---- approximate supplement (error_rate > 0.01): GraphCreatorLI ---------------------------------
+ * Replaces, for the caller at src/main.cpp:300-347,
+ *   new GraphCreatorLI(READS, G); setAlignFrom/To from the degrees of G; startAlignmentGraphCreation();
+ *   G->retainOnlySmallestOffset();
+ * i.e. four rounds (rotated alphabet priorities, src/GraphCreators/GraphCreatorLI.cpp:18-28) of: LI minimizer
+ * k-mers of the tip nodes (src/DataStructures/Read.cpp:145-226), groups of equal k-mer
+ * (src/GraphCreators/GraphCreatorKmerBased.cpp:28-136), pairwise join with branch markers
+ * (src/GraphCreators/GraphCreatorPairwiseKmerBranch.cpp:16-97) and the mismatch-budget check
+ * AlignmentControllerHybrid::canAlign (src/AlignmentControllers/AlignmentControllerLowErrorRate.cpp:15-49).
+ * Order dependence: the reference walks the groups of a round one after the other (and races between its threads when
+ * --threads > 1) and leaves the order of equal k-mers to std::sort; the engine gives every group the graph as it was
+ * when the round started and orders equal k-mers by node id.  DESIGN.md states the measured difference. */
+typedef struct {
+    int32_t min_overlap_area;   /* Params::MIN_OVERLAP_AREA        = int((1 + SCALE) * avg_len / 2)   (src/main.cpp:333) */
+    int32_t max_offset_pct;     /* Params::MAX_OFFSET_CONSIDERED_FOR_ALIGNMENT = int((1 - SCALE) * avg_len / 2), %      */
+    int32_t min_identity_pct;   /* Params::MINIMAL_OVERLAP_FOR_LCS_LOW_ERROR = 99 - int(100 * error_rate)             */
+    int32_t same_ends;          /* Params::ALIGNMENT_CONTROLLER_SAME_ENDS_LENGTH, 3                                    */
+    int32_t li_k;               /* Params::LI_KMER_LENGTH, 35 (src/main.cpp:340)                                       */
+    int32_t li_intervals;       /* Params::LI_KMER_INTERVALS, 6 (src/main.cpp:339)                                     */
+    int32_t rounds;             /* min(4, Params::LI_PRIORITIES_TO_CONSIDER) = 4                                       */
+    int32_t kmer_length_bucket; /* Params::KMER_LENGTH_BUCKET = min(2L/3, 60): shorter reads give no k-mers            */
+} alga_pkb_params;
+
+typedef struct {
+    uint64_t kmers[4];          /* k-mers per round                                                                    */
+    uint64_t groups[4];         /* groups of >= 2 equal k-mers per round                                               */
+    uint64_t can_align_calls[4];
+    uint64_t edges_after[4];    /* edges in the graph after each round                                                 */
+    uint64_t max_group;
+    double   ms_total;
+} alga_pkb_stats;
+
+/* (1 + SCALE) / (1 - SCALE) arithmetic of src/main.cpp:332-336 in float, truncating; error_rate as on the command line */
+void alga_pkb_derive_params(double avg_len, float scale, double error_rate, int32_t kmer_length_bucket, alga_pkb_params *p);
+
+/* canAlign on n (r1, r2, offset) int32 triples -> n bytes (host buffers in and out) */
+int  alga_can_align_batch_host(alga_engine *e, const alga_nodes *nodes, const alga_pkb_params *p, const int32_t *triples,
+                               uint64_t n, uint8_t *out);
+/* LI k-mers of every node under the alphabet permutation prio[4]: hash[n*li_intervals], ind[n*li_intervals], count[n] */
+int  alga_li_kmers_host(alga_engine *e, const alga_nodes *nodes, const alga_pkb_params *p, const int32_t prio[4],
+                        uint64_t *hash, int32_t *ind, int32_t *count);
+/* The supplement: edges_in = the graph of the exact path (sorted by (src, dst), one edge per pair), result in the same
+ * form; host buffers (`nodes` as for alga_prefsuf_build_host).  Release *edges_out with alga_free_edges(). */
+int  alga_pkb_supplement_host(alga_engine *e, const alga_nodes *nodes, const alga_pkb_params *p, const alga_edge *edges_in,
+                              uint64_t n_edges_in, alga_edge **edges_out, uint64_t *n_edges_out);
+/* Same with node set and edge list resident in HBM; the result stays on the device (engine-owned). */
+int  alga_pkb_supplement_device(alga_engine *e, const alga_nodes *nodes, const alga_pkb_params *p, const alga_edge *d_edges_in,
+                                uint64_t n_edges_in, void *hip_stream, const alga_edge **d_edges_out, uint64_t *n_edges_out);
+int  alga_pkb_last_stats(const alga_engine *e, alga_pkb_stats *out);
+
 /* ---- input stages (host, multithreaded C++; no GPU involved) ---------------------------------
  * What the reference does between its command line and the GraphCreator constructor, in its
  * --threads=1 order: record parsing, end trimming, N / STR filters, 2-bit packing, reverse-complement

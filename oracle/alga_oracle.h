@@ -96,8 +96,10 @@ int  oracle_can_align(const uint32_t *words, const int32_t *len, int32_t W, int3
                       const oracle_pkb_params *p);
 int  oracle_li_kmers(const uint32_t *row, int32_t len, int32_t k, int32_t intervals, const int32_t *prio,
                      uint64_t *hash_out, int32_t *ind_out);
+#define ORACLE_PKB_TIES_BY_ID 1   /* equal k-mers ordered by read id instead of std::sort's tie order            */
+#define ORACLE_PKB_SNAPSHOT    2   /* groups of a round see the round-start graph: the GPU engine's semantics     */
 int  oracle_supplement(const uint32_t *words, const int32_t *len, int32_t n, int32_t W, const oracle_edge *edges_in, int64_t m_in,
-                       const oracle_pkb_params *p, int32_t kmer_length_bucket, oracle_edge **edges_out, int64_t *m_out,
+                       const oracle_pkb_params *p, int32_t kmer_length_bucket, int32_t flags, oracle_edge **edges_out, int64_t *m_out,
                        int64_t *can_align_calls);
 
 /* Graph::serializeGraph wire format (src/DataStructures/Graph.cpp:269-297). */

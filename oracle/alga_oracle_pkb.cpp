@@ -129,11 +129,12 @@ namespace {
 struct KmerRec { int32_t read; uint64_t hash; int32_t ind; int32_t rsize; };
 
 struct KmerLess {   /* Kmer::operator< (src/DataStructures/Kmer.cpp:58-64) */
+    bool by_id;     /* false: the reference's comparator (ties left to std::sort); true: ties broken by read id */
     bool operator()(const KmerRec &a, const KmerRec &b) const {
         if (a.hash != b.hash) return a.hash < b.hash;
         if (a.ind != b.ind) return a.ind > b.ind;
         if (a.rsize != b.rsize) return a.rsize < b.rsize;
-        return false;
+        return by_id ? a.read < b.read : false;
     }
 };
 
@@ -164,8 +165,15 @@ extern "C" {
  * (src/GraphCreators/GraphCreatorKmerBased.cpp:28-92) with GraphCreatorPairwiseKmerBranch::createAlignmentsForKmers
  * (src/GraphCreators/GraphCreatorPairwiseKmerBranch.cpp:16-97) on every group of equal k-mer hash. */
 int oracle_supplement(const uint32_t *words, const int32_t *len, int32_t n, int32_t W, const oracle_edge *edges_in, int64_t m_in,
-                      const oracle_pkb_params *p, int32_t kmer_length_bucket, oracle_edge **edges_out, int64_t *m_out,
+                      const oracle_pkb_params *p, int32_t kmer_length_bucket, int32_t flags, oracle_edge **edges_out, int64_t *m_out,
                       int64_t *can_align_calls) {
+    /* flags: 0 = the reference with --threads=1.
+     *        ORACLE_PKB_TIES_BY_ID  : equal k-mers (same hash, position, read length) ordered by read id instead of by
+     *                                 std::sort's unspecified tie order
+     *        ORACLE_PKB_SNAPSHOT    : every group of a round sees the graph as it was when the round started (plus what
+     *                                 the group itself added) -- the order-independent semantics of the GPU engine; the
+     *                                 reference processes groups one after the other (and races when --threads > 1) */
+    const bool by_id = (flags & ORACLE_PKB_TIES_BY_ID) != 0, snapshot = (flags & ORACLE_PKB_SNAPSHOT) != 0;
     std::vector<AdjList> V((size_t) n);
     for (int64_t i = 0; i < m_in; i++) V[(size_t) edges_in[i].src].push_back({edges_in[i].dst, edges_in[i].offset});
     /* src/main.cpp:308-322 */
@@ -196,17 +204,29 @@ int oracle_supplement(const uint32_t *words, const int32_t *len, int32_t n, int3
                 buckets[(size_t) ind].push_back({i, hb[(size_t) j], ib[(size_t) j], len[i]});
             }
         }
-        for (auto &b : buckets) if (!b.empty()) std::sort(b.begin(), b.end(), KmerLess());   /* sortBucketsJob :94-106 */
+        for (auto &b : buckets) if (!b.empty()) std::sort(b.begin(), b.end(), KmerLess{by_id});   /* sortBucketsJob :94-106 */
         std::vector<std::vector<char>> marks;
+        std::vector<AdjList> Vsnap;
+        std::vector<oracle_edge> added_round;
+        if (snapshot) Vsnap = V;
+        std::vector<std::pair<int, int>> added_local;             /* (id2, offset) additions of the current `i` inside a group */
+        std::vector<oracle_edge> added_group;
         for (auto &km : buckets) {                                            /* createAlignmentForKmersJobNewGC :108-136 (clone: masks all true) */
             size_t P = 0, Q = 0;
             while (P < km.size()) {
                 while (Q < km.size() && km[Q].hash == km[P].hash) Q++;
                 const int pp = (int) P, qq = (int) Q - 1, D = qq - pp + 1;
                 marks.assign((size_t) D, std::vector<char>((size_t) D, 0));   /* branchMarkers */
+                added_group.clear();
                 for (int i = qq - 1; i >= pp; i--) {                          /* PairwiseKmerBranch.cpp:34-94 */
                     const int id1 = km[(size_t) i].read, ind1 = km[(size_t) i].ind;
-                    for (auto &x : V[(size_t) id1]) neighbors[(size_t) x.first] = x.second;
+                    const AdjList &cur = snapshot ? Vsnap[(size_t) id1] : V[(size_t) id1];
+                    for (auto &x : cur) neighbors[(size_t) x.first] = x.second;
+                    added_local.clear();
+                    if (snapshot) for (auto &g : added_group) if (g.src == id1) {
+                        if (g.offset < neighbors[(size_t) g.dst]) neighbors[(size_t) g.dst] = g.offset;
+                        added_local.push_back({g.dst, 0});
+                    }
                     for (int j = i + 1; j <= qq; j++) {
                         const int id2 = km[(size_t) j].read;
                         if (id1 == id2) continue;
@@ -220,7 +240,8 @@ int oracle_supplement(const uint32_t *words, const int32_t *len, int32_t n, int3
                             if (neighbors[(size_t) id2] > offset) {
                                 calls++;
                                 if (oracle_can_align(words, len, W, id1, id2, offset, p)) {
-                                    add_directed_edge(V, id1, id2, offset);
+                                    if (snapshot) { added_round.push_back({id1, id2, offset}); added_group.push_back({id1, id2, offset}); added_local.push_back({id2, 0}); }
+                                    else add_directed_edge(V, id1, id2, offset);
                                     neighbors[(size_t) id2] = offset;
                                 }
                             }
@@ -230,11 +251,13 @@ int oracle_supplement(const uint32_t *words, const int32_t *len, int32_t n, int3
                             }
                         }
                     }
-                    for (auto &x : V[(size_t) id1]) neighbors[(size_t) x.first] = 1000000001;
+                    for (auto &x : cur) neighbors[(size_t) x.first] = 1000000001;
+                    for (auto &x : added_local) neighbors[(size_t) x.first] = 1000000001;
                 }
                 P = Q;
             }
         }
+        if (snapshot) for (auto &g : added_round) add_directed_edge(V, g.src, g.dst, g.offset);
         retain_only_smallest_offset(V);                                       /* KmerBased.cpp:87 */
         std::rotate(prio, prio + 1, prio + 4);                                /* GraphCreatorLI.cpp:26 */
     }

@@ -206,11 +206,11 @@ def li_kmers(row, length, k, intervals, prio):
     return h[:c].copy(), ind[:c].copy()
 
 
-def supplement(words, lens, edges_in, p, kmer_length_bucket):
-    """-> (edges[m,3] sorted, number of canAlign calls)"""
+def supplement(words, lens, edges_in, p, kmer_length_bucket, flags=0):
+    """-> (edges[m,3] sorted, number of canAlign calls); flags: 1 = ties by read id, 2 = round-snapshot semantics"""
     L = lib()
     L.oracle_supplement.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.POINTER(PkbParams),
-                                    C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+                                    C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     words = np.ascontiguousarray(words, dtype=np.uint32)
     lens = np.ascontiguousarray(lens, dtype=np.int32)
     e = np.ascontiguousarray(edges_in, dtype=np.int32).reshape(-1, 3)
@@ -218,7 +218,7 @@ def supplement(words, lens, edges_in, p, kmer_length_bucket):
     m = C.c_int64()
     calls = C.c_int64()
     rc = L.oracle_supplement(words.ctypes.data, lens.ctypes.data, len(lens), words.shape[1], e.ctypes.data, len(e), C.byref(p),
-                             int(kmer_length_bucket), C.byref(out), C.byref(m), C.byref(calls))
+                             int(kmer_length_bucket), int(flags), C.byref(out), C.byref(m), C.byref(calls))
     if rc:
         raise RuntimeError("oracle_supplement failed")
     res = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_int32)), shape=(max(m.value, 1) * 3,))[: m.value * 3].reshape(-1, 3).copy()

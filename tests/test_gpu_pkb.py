@@ -1,0 +1,124 @@
+"""GPU parity of the approximate supplement through the C ABI.
+
+canAlign and the LI k-mers are pure functions: bit-exact against vectors made by the reference's own code.
+The supplement as a whole is order dependent in the reference: the engine must equal the oracle run
+with the engine's order-independent semantics (ORACLE_PKB_TIES_BY_ID | ORACLE_PKB_SNAPSHOT) bit for bit, and on the
+golden fixture that also equals the reference's own post-supplement graph byte for byte."""
+import gzip
+import json
+import os
+
+import numpy as np
+import pytest
+
+import alga_amd
+import gen_reads
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    e = alga_amd.Engine(0)
+    yield e
+    e.close()
+
+
+def _f7(golden_dir):
+    meta = json.load(open(os.path.join(golden_dir, "f7_pkb.json")))
+    words, lens = O.load_nodes_bin(os.path.join(golden_dir, "f7_pkb.nodes.bin.gz"))
+    return meta, words, lens
+
+
+def test_can_align_batch_bit_exact(eng, golden_dir):
+    meta, words, lens = _f7(golden_dir)
+    z = np.load(os.path.join(golden_dir, "f7_pkb.canalign.npz"))
+    p = eng.pkb_params(meta["avg_len"], 0.02, meta["kmer_length_bucket"])
+    assert (p.min_overlap_area, p.max_offset_pct, p.min_identity_pct) == (meta["min_overlap_area"], meta["max_offset_pct"], meta["min_identity_pct"])
+    got = eng.can_align_batch(words, lens, z["triples"], p)
+    assert (got == z["verdict"]).all()
+    # other thresholds on the same triples, and unequal read lengths (reads cut at random): against the oracle
+    rng = np.random.default_rng(5)
+    l2 = lens.copy()
+    cut = rng.random(len(l2)) < 0.5
+    l2[cut] = np.maximum(60, l2[cut] - rng.integers(0, 60, int(cut.sum()))) * (lens[cut] > 0)
+    w2 = words.copy()
+    for i in np.flatnonzero(cut):                       # keep the tail bits zero
+        nb = 2 * int(l2[i])
+        w2[i, (nb + 31) // 32:] = 0
+        if nb % 32:
+            w2[i, nb // 32] &= (1 << (nb % 32)) - 1
+    tri = z["triples"]
+    for (ww, ll) in ((words, lens), (w2, l2)):
+        for moa, mo, mi in ((60, 40, 90), (100, 32, 97), (30, 70, 80), (111, 32, 99)):
+            p2 = eng.pkb_params(144.0, 0.02, 54)
+            p2.min_overlap_area, p2.max_offset_pct, p2.min_identity_pct = moa, mo, mi
+            op = O.pkb_params(144.0)
+            op.min_overlap_area, op.max_offset_pct, op.min_identity_pct = moa, mo, mi
+            want = O.can_align(ww, ll, tri, op)
+            got = eng.can_align_batch(ww, ll, tri, p2)
+            assert want.sum() > 20 and (got == want).all()
+
+
+def test_li_kmers_bit_exact(eng, golden_dir):
+    meta, words, lens = _f7(golden_dir)
+    p = eng.pkb_params(meta["avg_len"], 0.02, meta["kmer_length_bucket"])
+    n = meta["likmer_nodes"]
+    with gzip.open(os.path.join(golden_dir, "f7_pkb.likmers.bin.gz"), "rb") as f:
+        buf = f.read()
+    pos = 0
+    prio = [0, 1, 2, 3]
+    for rot in range(4):
+        h, ind, cnt = eng.li_kmers(words[:n], lens[:n], p, prio)
+        for i in range(n):
+            if lens[i] < meta["li_k"]:
+                assert cnt[i] == 0
+                continue
+            c = int(np.frombuffer(buf[pos:pos + 4], dtype=np.int32)[0]); pos += 4
+            rec = np.frombuffer(buf[pos:pos + 12 * c], dtype=np.dtype([("h", "<u8"), ("i", "<i4")])); pos += 12 * c
+            assert cnt[i] == c
+            assert h[i, :c].tolist() == rec["h"].tolist() and ind[i, :c].tolist() == rec["i"].tolist()
+        prio = prio[1:] + prio[:1]
+    assert pos == len(buf)
+    # other k / interval counts / lengths against the oracle
+    codes, l2 = gen_reads.sample_reads(300, 120, 900, 56, min_length=40)
+    w2 = alga_amd.pack_reads(codes, l2)
+    for k, iv in ((35, 6), (21, 3), (60, 4), (40, 1)):
+        p.li_k, p.li_intervals = k, iv
+        h, ind, cnt = eng.li_kmers(w2, l2, p, [2, 0, 3, 1])
+        for i in range(len(l2)):
+            wh, wi = O.li_kmers(w2[i], l2[i], k, iv, [2, 0, 3, 1])
+            assert cnt[i] == len(wh) and h[i, :cnt[i]].tolist() == wh.tolist() and ind[i, :cnt[i]].tolist() == wi.tolist()
+
+
+def test_supplement_equals_reference_on_golden_fixture(eng, golden_dir):
+    meta, words, lens = _f7(golden_dir)
+    with gzip.open(os.path.join(golden_dir, meta["pre_graph"]), "rb") as f:
+        n, pre = O.parse_graph(f.read())
+    p = eng.pkb_params(meta["avg_len"], 0.02, meta["kmer_length_bucket"])
+    got = eng.pkb_supplement_host(words, lens, pre, p)
+    st = eng.pkb_last_stats()
+    assert len(got) == meta["edges_after"] == st["edges_after"][3]
+    with gzip.open(os.path.join(golden_dir, "f7_pkb.supplement.graph.gz"), "rb") as f:
+        assert O.graph_bytes(n, got) == f.read()
+
+
+@pytest.mark.parametrize("n,G,seed,err", [(4000, 9000, 61, 0.02), (3000, 3000, 62, 0.03), (2500, 12000, 63, 0.015)])
+def test_supplement_equals_oracle_with_engine_semantics(eng, n, G, seed, err):
+    codes, lens = gen_reads.sample_reads(n, 150, G, seed, err)
+    rc = (3 - codes)[:, ::-1]
+    codes = np.stack([rc, codes], axis=1).reshape(-1, 150)[:, 3:147]
+    lens = np.full(len(codes), 144, dtype=np.int32)
+    words = alga_amd.pack_reads(codes, lens)
+    pre = eng.prefsuf_host(words, lens, 82, 116)
+    op = O.pkb_params(144.0, error_rate_percent=2)
+    p = eng.pkb_params(144.0, 0.02, 54)
+    want, _ = O.supplement(words, lens, pre, op, 54, flags=3)
+    ref_order, _ = O.supplement(words, lens, pre, op, 54, flags=0)
+    got = eng.pkb_supplement_host(words, lens, pre, p)
+    assert len(want) > len(pre)
+    assert got.shape == want.shape and (got == want).all()
+    # how far the order-independent semantics is from the reference's sequential order on this input (reported, bounded)
+    a, b = set(map(tuple, ref_order.tolist())), set(map(tuple, want.tolist()))
+    assert len(a ^ b) <= 0.005 * len(a)
