@@ -51,16 +51,13 @@ int main(int argc, char **argv) {
         else if (opt(a, "--alga", v)) alga_exe = v;
         else if (!strcmp(a, "-l") && i + 1 < argc) ip.min_overlap = atoi(argv[++i]);
         else { fprintf(stderr, "alga_hip: unrecognized option '%s'\n", a); return 2; }
-        if (strncmp(a, "--device", 8) && strncmp(a, "--alga", 6)) { passthrough.push_back(a); if (!strcmp(a, "-l")) passthrough.push_back(argv[i]); }
+        // the hand-off to stock ALGA drops the error-rate option: the supplement it switches on (src/Params.cpp:357-359) has
+        // already run here and nothing downstream reads the rate
+        const bool is_er = !strncmp(a, "--error_rate", 12) || !strncmp(a, "--error-rate", 12) || !strncmp(a, "--er=", 5);
+        if (strncmp(a, "--device", 8) && strncmp(a, "--alga", 6) && !is_er) { passthrough.push_back(a); if (!strcmp(a, "-l")) passthrough.push_back(argv[i]); }
     }
     if (file1.empty()) { fprintf(stderr, "\nERROR - PLEASE PROVIDE THE INPUT FILE using --file1 option!\n"); return 1; }
     if (output.empty()) { fprintf(stderr, "\nERROR - PLEASE PROVIDE THE OUTPUT FILE NAME!\n"); return 1; }
-    if (error_rate > 0.01) {
-        // src/Params.cpp:357-359: rates above 1 % switch on the approximate supplement (GraphCreatorLI); that path is
-        // not in this build yet -- refuse rather than silently return the error-free graph.
-        fprintf(stderr, "alga_hip: --error_rate > 0.01 needs the approximate supplement, which this build does not have\n");
-        return 3;
-    }
     auto t0 = clk::now();
     alga_host::NodeSet nodes;
     std::string err = alga_host::ingest(file1, file2, ip, nodes);
@@ -74,13 +71,30 @@ int main(int argc, char **argv) {
     creator.startAlignmentGraphCreation();
     auto t2 = clk::now();
     alga_prefsuf_stats st = creator.stats();
-    fprintf(stderr, "Before first simplifier graph has %llu edges\n", (unsigned long long) creator.countEdges());
+    const alga_edge *final_edges = creator.edges();
+    uint64_t n_final = creator.countEdges();
+    alga_edge *sup_edges = nullptr;
+    alga_engine *sup_engine = nullptr;
+    if (error_rate > 0.01) {                                                   // src/Params.cpp:358-359, src/main.cpp:300-355
+        fprintf(stderr, "Before supplement, G has %llu edges\n", (unsigned long long) n_final);
+        double sum = 0; long long cnt = 0;
+        for (int i = 0; i < nodes.n; i++) if (nodes.len[(size_t) i] > 0) { sum += nodes.len[(size_t) i]; cnt++; }
+        alga_pkb_params pp;
+        alga_pkb_derive_params(cnt ? sum / (double) cnt : 0.0, ip.scale, error_rate, nodes.li_kmer_length, &pp);
+        if (alga_engine_create(device, &sup_engine) != ALGA_OK) { fprintf(stderr, "alga_amd: no usable HIP device\n"); return 1; }
+        alga_nodes nd{nodes.words.data(), nodes.stride, nodes.len.data(), nodes.n, nullptr, nullptr};
+        int rc = alga_pkb_supplement_host(sup_engine, &nd, &pp, final_edges, n_final, &sup_edges, &n_final);
+        if (rc != ALGA_OK) { fprintf(stderr, "alga_amd: %s (status %d)\n", alga_last_error(sup_engine), rc); return 1; }
+        final_edges = sup_edges;
+        fprintf(stderr, "After supplement G has %llu edges\n", (unsigned long long) n_final);
+    }
+    fprintf(stderr, "Before first simplifier graph has %llu edges\n", (unsigned long long) n_final);
     auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     fprintf(stderr, "ingest %.1f ms, overlap graph %.1f ms wall (device %.3f ms: seed %.3f probe %.3f group %.3f reduce %.3f emit %.3f)\n",
             ms(t0, t1), ms(t1, t2), st.ms_total, st.ms_seed, st.ms_probe, st.ms_group, st.ms_reduce, st.ms_emit);
     std::string graph = alga_host::test_name(file1, ip.scale, ip.remove_reads_with_n) + "_beforeSimplifier.graph";
     if (serialize) {
-        int rc = alga_write_graph(graph.c_str(), nodes.n, creator.edges(), creator.countEdges());
+        int rc = alga_write_graph(graph.c_str(), nodes.n, final_edges, n_final);
         if (rc != ALGA_OK) { fprintf(stderr, "cannot write %s\n", graph.c_str()); return 1; }
         fprintf(stderr, "Graph serialized! -> %s\n", graph.c_str());
     }
@@ -92,5 +106,7 @@ int main(int argc, char **argv) {
         int rc = system(cmd.c_str());
         return rc == 0 ? 0 : 1;
     }
+    if (sup_edges) alga_free_edges(sup_engine, sup_edges);
+    if (sup_engine) alga_engine_destroy(sup_engine);
     return 0;
 }

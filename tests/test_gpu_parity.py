@@ -173,14 +173,13 @@ def test_cli_front_end_writes_the_reference_dump(golden_dir, tmp_path):
             assert ("Before first simplifier graph has %d edges" % fx.meta["edges_before_simplifier"]) in r.stderr
         finally:
             fx.cleanup()
-    r = subprocess.run([exe, "--file1=x.fasta", "--output=o.fasta", "--error-rate=0.02"], cwd=str(tmp_path), stderr=subprocess.PIPE)
-    assert r.returncode == 3          # approximate supplement not in this build: refused, not silently ignored
 
 
 def test_drop_in_produces_identical_contigs(golden_dir, tmp_path):
     """File-level drop-in: alga_hip builds the graph, stock ALGA consumes it with
     --deserialize_graph=1; the contigs must equal those of a plain ALGA run on the same input."""
     import os
+    import re
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     ref = os.path.join(root, "oracle", "_ref", "ALGA")
@@ -200,6 +199,23 @@ def test_drop_in_produces_identical_contigs(golden_dir, tmp_path):
         assert r.returncode == 0, r.stderr[-2000:]
         assert open(str(a / "o.fasta")).read() == open(str(b / "o.fasta")).read()
         assert os.path.getsize(str(a / "o.fasta")) > 1000
+    finally:
+        fx.cleanup()
+    # with sequencing errors and --error-rate=0.02 (both spellings): exact path + approximate supplement on the GPU
+    fx = O.Fixture(golden_dir, "f2_err2")
+    try:
+        f1, _ = fx.inputs()
+        a, b = tmp_path / "plain_err", tmp_path / "dropin_err"
+        a.mkdir(); b.mkdir()
+        r = subprocess.run([ref, "--file1=" + f1, "--threads=1", "--output=o.fasta", "--error_rate=0.02"], cwd=str(a),
+                           stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, errors="replace")
+        assert r.returncode == 0
+        want_edges = int(re.search(r"After supplement G has (\d+) edges", r.stderr).group(1))
+        r = subprocess.run([exe, "--file1=" + f1, "--threads=1", "--output=o.fasta", "--error-rate=0.02", "--alga=" + ref], cwd=str(b),
+                           stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, errors="replace")
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert ("After supplement G has %d edges" % want_edges) in r.stderr
+        assert open(str(a / "o.fasta")).read() == open(str(b / "o.fasta")).read()
     finally:
         fx.cleanup()
 
