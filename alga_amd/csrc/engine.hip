@@ -82,19 +82,47 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
     *n_rec = 0;
     HIP_TRY(e, hipEventRecord(e->ev[EV_START], s));
     if (pp.live >= (1ull << 31)) return alga_fail(e, ALGA_ERR_CAPACITY, "too many nodes for one seed table; shard the input");
-    const uint32_t n_buckets = seed_buckets_for(pp.live, e->seed_fill_x10);
-    const size_t table_bytes = (size_t) n_buckets * SEED_BUCKET * sizeof(unsigned long long);
-    if ((rc = alga_ensure(e, e->table, table_bytes))) return rc;
-    HIP_TRY(e, hipMemsetAsync(e->table.p, 0xFF, table_bytes, s));
-    uint32_t filter_bits = e->use_filter ? seed_filter_bits_for(pp.live) : 0;
-    if (filter_bits) {
-        if ((rc = alga_ensure(e, e->filter, filter_bits / 8))) return rc;
-        HIP_TRY(e, hipMemsetAsync(e->filter.p, 0, filter_bits / 8, s));
+    uint32_t n_buckets = 0, filter_bits = 0, dir_slots = 0;
+    if (e->probe_mode == 0) {
+        n_buckets = seed_buckets_for(pp.live, e->seed_fill_x10);
+        const size_t table_bytes = (size_t) n_buckets * SEED_BUCKET * sizeof(unsigned long long);
+        if ((rc = alga_ensure(e, e->table, table_bytes))) return rc;
+        HIP_TRY(e, hipMemsetAsync(e->table.p, 0xFF, table_bytes, s));
+        filter_bits = e->use_filter ? seed_filter_bits_for(pp.live) : 0;
+        if (filter_bits) {
+            if ((rc = alga_ensure(e, e->filter, filter_bits / 8))) return rc;
+            HIP_TRY(e, hipMemsetAsync(e->filter.p, 0, filter_bits / 8, s));
+        }
+        launch_seed_build(nd, cfg, (unsigned long long *) e->table.p, n_buckets, (uint32_t *) e->filter.p, filter_bits, s);
+        if ((rc = alga_check_launch(e, "k_seed_build"))) return rc;
+        e->stats.table_slots = (uint64_t) n_buckets * SEED_BUCKET;
+    } else {
+        // minimizer index: (k-mer, node) pairs ordered by k-mer + a directory of the distinct k-mers
+        const uint64_t n = (uint64_t) nd.n;
+        const int kbits = minimizer_key_bits(cfg);
+        const size_t temp = sort_u64_pairs_temp_bytes(n, kbits);
+        if ((rc = alga_ensure(e, e->ix_keys, (n + 1) * sizeof(unsigned long long)))) return rc;
+        if ((rc = alga_ensure(e, e->ix_vals, (n + 1) * sizeof(unsigned long long)))) return rc;
+        if ((rc = alga_ensure(e, e->ix_keys2, (n + 1) * sizeof(unsigned long long)))) return rc;
+        if ((rc = alga_ensure(e, e->ix_vals2, (n + 1) * sizeof(unsigned long long)))) return rc;
+        if ((rc = alga_ensure(e, e->sort_temp, temp))) return rc;
+        launch_index_targets(nd, cfg, (unsigned long long *) e->ix_keys.p, (unsigned long long *) e->ix_vals.p, s);
+        if ((rc = alga_check_launch(e, "k_index_targets"))) return rc;
+        HIP_TRY(e, sort_u64_pairs(e->sort_temp.p, temp, (const unsigned long long *) e->ix_keys.p, (unsigned long long *) e->ix_keys2.p,
+                                  (const unsigned long long *) e->ix_vals.p, (unsigned long long *) e->ix_vals2.p, n, kbits, s));
+        HIP_TRY(e, hipMemsetAsync(cnt, 0, 2 * sizeof(unsigned long long), s));
+        launch_index_count((const unsigned long long *) e->ix_keys2.p, n, cnt, s);
+        if ((rc = alga_check_launch(e, "k_index_count"))) return rc;
+        HIP_TRY(e, hipMemcpyAsync(e->h_counters, cnt, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        HIP_TRY(e, hipStreamSynchronize(s));
+        dir_slots = index_directory_slots(e->h_counters[0]);
+        if ((rc = alga_ensure(e, e->ix_dir, (size_t) dir_slots * 2 * sizeof(unsigned long long)))) return rc;
+        HIP_TRY(e, hipMemsetAsync(e->ix_dir.p, 0xFF, (size_t) dir_slots * 2 * sizeof(unsigned long long), s));
+        launch_index_directory((const unsigned long long *) e->ix_keys2.p, n, (unsigned long long *) e->ix_dir.p, dir_slots, s);
+        if ((rc = alga_check_launch(e, "k_index_directory"))) return rc;
+        e->stats.table_slots = dir_slots;
     }
-    launch_seed_build(nd, cfg, (unsigned long long *) e->table.p, n_buckets, (uint32_t *) e->filter.p, filter_bits, s);
-    if ((rc = alga_check_launch(e, "k_seed_build"))) return rc;
     HIP_TRY(e, hipEventRecord(e->ev[EV_SEED], s));
-    e->stats.table_slots = (uint64_t) n_buckets * SEED_BUCKET;
 
     const uint64_t n_src = (uint64_t) std::max<int64_t>(0, (int64_t) src_end - src_begin);
     const uint64_t slack = probe_record_slack(e->n_cu, n_src);            // invalid padding of the chunked record list
@@ -104,8 +132,12 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
         if ((rc = alga_ensure(e, e->rec_dst, cap * sizeof(uint32_t)))) return rc;
         if ((rc = alga_ensure(e, e->rec_val, cap * sizeof(unsigned long long)))) return rc;
         HIP_TRY(e, hipMemsetAsync(cnt, 0, CNT_TOTAL * sizeof(unsigned long long), s));
-        launch_probe(nd, cfg, (const unsigned long long *) e->table.p, n_buckets, (const uint32_t *) e->filter.p, filter_bits, src_begin, src_end, (uint32_t *) e->rec_dst.p,
-                     (unsigned long long *) e->rec_val.p, cap, cnt, e->n_cu, s);
+        if (e->probe_mode == 0)
+            launch_probe(nd, cfg, (const unsigned long long *) e->table.p, n_buckets, (const uint32_t *) e->filter.p, filter_bits, src_begin, src_end,
+                         (uint32_t *) e->rec_dst.p, (unsigned long long *) e->rec_val.p, cap, cnt, e->n_cu, s);
+        else
+            launch_probe_min(nd, cfg, (const unsigned long long *) e->ix_dir.p, dir_slots, (const unsigned long long *) e->ix_vals2.p, src_begin, src_end,
+                             (uint32_t *) e->rec_dst.p, (unsigned long long *) e->rec_val.p, cap, cnt, e->n_cu, s);
         if ((rc = alga_check_launch(e, "k_probe_sources"))) return rc;
         HIP_TRY(e, hipEventRecord(e->ev[EV_PROBE], s));
         HIP_TRY(e, hipMemcpyAsync(e->h_counters, cnt, CNT_TOTAL * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
@@ -224,6 +256,7 @@ int alga_engine_create(int hip_device, alga_engine **out) {
     e->device = hip_device;
     if (const char *v = getenv("ALGA_SEED_FILL_X10")) e->seed_fill_x10 = atoi(v);
     if (const char *v = getenv("ALGA_SEED_FILTER")) e->use_filter = atoi(v);
+    if (const char *v = getenv("ALGA_PROBE")) e->probe_mode = strcmp(v, "min") == 0 ? 1 : 0;
     memset(&e->stats, 0, sizeof(e->stats));
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, hip_device) == hipSuccess) {
@@ -244,7 +277,7 @@ void alga_engine_destroy(alga_engine *e) {
     if (e->own_stream) (void) hipStreamSynchronize(e->own_stream);
     DevBuf *bufs[] = {&e->table, &e->filter, &e->counters, &e->rowptr, &e->rec_dst, &e->rec_val, &e->keys, &e->seg_key, &e->seg_val, &e->heads, &e->sort_temp,
                       &e->out_cnt, &e->outdeg, &e->out_rowptr, &e->edges, &e->scan_scratch, &e->up_words, &e->up_len, &e->up_from, &e->up_to,
-                      &e->edge_keys, &e->edge_keys2, &e->edge_vals, &e->edge_vals2, &e->edges_sorted, &e->xs_dst, &e->xs_val,
+                      &e->ix_keys, &e->ix_vals, &e->ix_keys2, &e->ix_vals2, &e->ix_dir, &e->edge_keys, &e->edge_keys2, &e->edge_vals, &e->edge_vals2, &e->edges_sorted, &e->xs_dst, &e->xs_val,
                       &e->pk_keys, &e->pk_keys2, &e->pk_vals, &e->pk_vals2, &e->pk_marks, &e->pk_big, &e->pk_add, &e->pk_ekeys, &e->pk_ekeys2,
                       &e->pk_flag, &e->pk_pos, &e->pk_edges[0], &e->pk_edges[1], &e->pk_rowptr, &e->pk_deg, &e->pk_mask, &e->pk_cnt, &e->pk_io, &e->pk_io2};
     for (DevBuf *b : bufs) alga_release(*b);

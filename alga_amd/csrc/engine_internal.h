@@ -23,10 +23,12 @@ struct alga_engine {
     char        dev_name[256] = {0};
     int         n_cu = 256;
     int         seed_fill_x10 = 20;           // average seed-table bucket fill x10 (tunable: ALGA_SEED_FILL_X10)
+    int         probe_mode = 0;               // 0 = bucketised seed table (default, faster: DESIGN.md section 5), 1 = minimizer index (ALGA_PROBE=min)
     int         use_filter = 1;               // L2-resident fingerprint bitmap in front of the seed table (ALGA_SEED_FILTER=0 disables)
     hipEvent_t  ev[EV_COUNT] = {};
     // device buffers, grown on demand and kept between calls
     DevBuf table, filter, counters, rowptr, rec_dst, rec_val, keys, seg_key, seg_val, heads, sort_temp, out_cnt, outdeg, out_rowptr, edges, scan_scratch;
+    DevBuf ix_keys, ix_vals, ix_keys2, ix_vals2, ix_dir;   // minimizer index
     DevBuf edge_keys, edge_keys2, edge_vals, edge_vals2, edges_sorted, xs_dst, xs_val;
     DevBuf up_words, up_len, up_from, up_to;   // uploads of the host-buffer entry points
     // approximate supplement (engine_pkb.hip)

@@ -34,9 +34,6 @@ void launch_pkb_compact(const unsigned long long *keys, const uint32_t *flag, co
                         uint32_t *outdeg, hipStream_t s);
 
 // sort_records.hip
-size_t     sort_u64_pairs_temp_bytes(uint64_t n, int bits);
-hipError_t sort_u64_pairs(void *temp, size_t temp_bytes, const unsigned long long *keys_in, unsigned long long *keys_out,
-                          const unsigned long long *vals_in, unsigned long long *vals_out, uint64_t n, int bits, hipStream_t s);
 size_t     sort_u64_keys_temp_bytes(uint64_t n);
 hipError_t sort_u64_keys(void *temp, size_t temp_bytes, const unsigned long long *keys_in, unsigned long long *keys_out, uint64_t n, hipStream_t s);
 

@@ -9,7 +9,7 @@
 //
 // Semantics: groups of one round are independent here (every group sees the graph as it was when the round started
 // plus its own additions); the reference walks the groups one after the other (and races between threads when
-// --threads > 1).  oracle/alga_oracle_pkb.cpp implements both and tests/ quantify the difference.  Equal k-mers
+// --threads > 1).  The CPU checker under tests/ implements both and quantifies the difference.  Equal k-mers
 // (same hash, position and read length) are ordered by read id where the reference leaves the order to std::sort.
 #include <hip/hip_runtime.h>
 #include <algorithm>

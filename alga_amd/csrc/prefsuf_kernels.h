@@ -22,6 +22,19 @@ void launch_probe(const NodesDev &nd, const PrefSufCfg &cfg, const unsigned long
                   unsigned long long *counters, int n_cu, hipStream_t s);
 uint64_t probe_record_slack(int n_cu, uint64_t n_src);
 
+// minimizer index (prefsuf_minimizer.hip)
+int      minimizer_key_bits(const PrefSufCfg &cfg);
+void     launch_index_targets(const NodesDev &nd, const PrefSufCfg &cfg, unsigned long long *keys, unsigned long long *vals, hipStream_t s);
+void     launch_index_count(const unsigned long long *keys, uint64_t n, unsigned long long *out, hipStream_t s);
+uint32_t index_directory_slots(uint64_t distinct);
+void     launch_index_directory(const unsigned long long *keys, uint64_t n, unsigned long long *dir, uint32_t slots, hipStream_t s);
+void     launch_probe_min(const NodesDev &nd, const PrefSufCfg &cfg, const unsigned long long *dir, uint32_t dir_slots, const unsigned long long *list,
+                          int32_t src_begin, int32_t src_end, uint32_t *rec_dst, unsigned long long *rec_val, uint64_t rec_cap,
+                          unsigned long long *counters, int n_cu, hipStream_t s);
+size_t     sort_u64_pairs_temp_bytes(uint64_t n, int bits);
+hipError_t sort_u64_pairs(void *temp, size_t temp_bytes, const unsigned long long *keys_in, unsigned long long *keys_out,
+                          const unsigned long long *vals_in, unsigned long long *vals_out, uint64_t n, int bits, hipStream_t s);
+
 void launch_make_keys(const uint32_t *rec_dst, uint64_t n_rec, int32_t dst_begin, int32_t dst_end, uint32_t *keys,
                       unsigned long long *n_valid, hipStream_t s);
 size_t     sort_records_temp_bytes(uint64_t n, int bits);
