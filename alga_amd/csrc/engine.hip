@@ -7,6 +7,8 @@
 //   group  : scan(in-degree) + k_scatter_by_target
 //   reduce : k_reduce_targets
 //   emit   : scan(out-degree) + k_scatter_by_source + k_sort_rows
+// With the source-side reduction (alga_reduction) the probing wave emits final edges and
+// group/reduce disappear: seed, probe, emit (radix sort of the edges by (src, dst)).
 // There is no CPU fallback anywhere in this file: every failure is reported to the caller.
 #include <hip/hip_runtime.h>
 
@@ -27,6 +29,8 @@ struct Prepared {
     PrefSufCfg cfg;
     int        max_len = 0;
     uint64_t   live = 0;
+    bool       local_ok = false;     // the source-side reduction is exact for this input
+    int        reduction = ALGA_REDUCTION_AUTO;
 };
 
 // Validates arguments, measures max read length / live nodes on the device and derives the
@@ -70,11 +74,20 @@ int prepare(alga_engine *e, const alga_nodes *nodes, const alga_prefsuf_params *
     c.reversed = (c.rsoemo > c.Lcap) ? 1 : 0;
     c.stats = p->collect_stats ? 1 : 0;
     out.cfg = c;
+    if (p->reduction < ALGA_REDUCTION_AUTO || p->reduction > ALGA_REDUCTION_SOURCE_SIDE)
+        return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "reduction must be an alga_reduction value");
+    // preconditions of the source-side reduction (prefsuf_device.h: local_reduce; tests/source_side_rule.py)
+    out.local_ok = out.max_len <= p->max_len_cap && out.max_len - c.Lmin <= LOCAL_MAX_SPAN && c.Lmin <= c.rsoemo && c.rsoemo <= c.Lcap &&
+                   e->h_counters[CNT_MASK_ASYM] == 0 && e->probe_mode == 0;
+    out.reduction = p->reduction;
+    if (out.reduction == ALGA_REDUCTION_AUTO && e->force_reduction) out.reduction = e->force_reduction == 1 ? ALGA_REDUCTION_PER_TARGET : ALGA_REDUCTION_AUTO;
     return ALGA_OK;
 }
 
 // seed + probe.  On return e->rec_dst / e->rec_val hold *n_rec record slots (chunk padding included).
-int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t src_end, hipStream_t s, uint64_t *n_rec) {
+// local: source-side reduction inside the probe; the records are then final edges (*overflow: a source exceeded its capacity).
+int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t src_end, hipStream_t s, uint64_t *n_rec, bool local = false,
+                  bool *overflow = nullptr) {
     int rc;
     const NodesDev &nd = pp.nd;
     const PrefSufCfg &cfg = pp.cfg;
@@ -125,8 +138,9 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
     HIP_TRY(e, hipEventRecord(e->ev[EV_SEED], s));
 
     const uint64_t n_src = (uint64_t) std::max<int64_t>(0, (int64_t) src_end - src_begin);
-    const uint64_t slack = probe_record_slack(e->n_cu, n_src);            // invalid padding of the chunked record list
-    uint64_t cap = std::max<uint64_t>(e->rec_cap_hint, 16 * n_src + 4096) + slack;
+    const uint64_t slack = probe_record_slack(e->n_cu, n_src, local);     // invalid padding of the chunked record list
+    uint64_t &hint = local ? e->rec_cap_hint_local : e->rec_cap_hint;
+    uint64_t cap = std::max<uint64_t>(hint, (local ? 2 : 16) * n_src + 4096) + slack;
     for (int attempt = 0; attempt < 4; attempt++) {
         if (cap >= (1ull << 32) - 16) return alga_fail(e, ALGA_ERR_CAPACITY, "more than 2^32 overlap records; shard the input");
         if ((rc = alga_ensure(e, e->rec_dst, cap * sizeof(uint32_t)))) return rc;
@@ -134,7 +148,7 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
         HIP_TRY(e, hipMemsetAsync(cnt, 0, CNT_TOTAL * sizeof(unsigned long long), s));
         if (e->probe_mode == 0)
             launch_probe(nd, cfg, (const unsigned long long *) e->table.p, n_buckets, (const uint32_t *) e->filter.p, filter_bits, src_begin, src_end,
-                         (uint32_t *) e->rec_dst.p, (unsigned long long *) e->rec_val.p, cap, cnt, e->n_cu, s);
+                         (uint32_t *) e->rec_dst.p, (unsigned long long *) e->rec_val.p, cap, cnt, e->n_cu, local, s);
         else
             launch_probe_min(nd, cfg, (const unsigned long long *) e->ix_dir.p, dir_slots, (const unsigned long long *) e->ix_vals2.p, src_begin, src_end,
                              (uint32_t *) e->rec_dst.p, (unsigned long long *) e->rec_val.p, cap, cnt, e->n_cu, s);
@@ -145,7 +159,9 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
         const uint64_t need = e->h_counters[CNT_RECORDS];
         if (need <= cap) {
             *n_rec = need;
-            e->rec_cap_hint = std::max<uint64_t>(e->rec_cap_hint, need + need / 16 + 4096);
+            hint = std::max<uint64_t>(hint, need + need / 16 + 4096);
+            if (overflow) *overflow = e->h_counters[CNT_LOCAL_OVERFLOW] != 0;
+            if (local) { e->stats.transitive_compares = e->h_counters[CNT_TR_COMPARES]; e->stats.generic_sources = e->h_counters[CNT_LOCAL_GENERIC]; }
             e->stats.records = e->h_counters[CNT_VALID_RECORDS];
             e->stats.raw_overlaps = e->h_counters[CNT_RAW];
             e->stats.windows_probed = e->h_counters[CNT_WINDOWS];
@@ -229,6 +245,50 @@ int reduce_impl(alga_engine *e, const Prepared &pp, const uint32_t *rec_dst, con
     return ALGA_OK;
 }
 
+// source-side reduction: the record slots hold final edges -> sort by (src, dst), drop the padding
+int finalize_local(alga_engine *e, const Prepared &pp, uint64_t n_rec, hipStream_t s, uint64_t *n_edges) {
+    int rc;
+    const uint64_t E = e->stats.records;                                   // CNT_VALID_RECORDS of the probe
+    *n_edges = 0;
+    if (n_rec >= (1ull << 32) - 16) return alga_fail(e, ALGA_ERR_CAPACITY, "more than 2^32 edge slots; shard the input");
+    const size_t temp_bytes = sort_edges_temp_bytes(n_rec);
+    if ((rc = alga_ensure(e, e->edge_keys, (size_t) (n_rec + 1) * sizeof(unsigned long long)))) return rc;
+    if ((rc = alga_ensure(e, e->edge_keys2, (size_t) (n_rec + 1) * sizeof(unsigned long long)))) return rc;
+    if ((rc = alga_ensure(e, e->edge_vals, (size_t) (n_rec + 1) * sizeof(uint32_t)))) return rc;
+    if ((rc = alga_ensure(e, e->edge_vals2, (size_t) (n_rec + 1) * sizeof(uint32_t)))) return rc;
+    if ((rc = alga_ensure(e, e->edges, (size_t) (E + 1) * sizeof(alga_edge_dev)))) return rc;
+    if ((rc = alga_ensure(e, e->sort_temp, temp_bytes))) return rc;
+    HIP_TRY(e, hipEventRecord(e->ev[EV_GROUP], s));
+    HIP_TRY(e, hipEventRecord(e->ev[EV_REDUCE], s));
+    launch_records_to_edge_keys((const uint32_t *) e->rec_dst.p, (const unsigned long long *) e->rec_val.p, n_rec, (unsigned long long *) e->edge_keys.p,
+                                (uint32_t *) e->edge_vals.p, s);
+    if ((rc = alga_check_launch(e, "k_records_to_edge_keys"))) return rc;
+    int src_bits = 1;
+    while (src_bits < 31 && (1ll << src_bits) < (long long) pp.nd.n) src_bits++;
+    HIP_TRY(e, sort_edges(e->sort_temp.p, temp_bytes, (const unsigned long long *) e->edge_keys.p, (unsigned long long *) e->edge_keys2.p,
+                          (const uint32_t *) e->edge_vals.p, (uint32_t *) e->edge_vals2.p, n_rec, src_bits + 1, s));   // +1: padding (all ones) sorts last
+    launch_keys_to_edges((const unsigned long long *) e->edge_keys2.p, (const uint32_t *) e->edge_vals2.p, E, (alga_edge_dev *) e->edges.p, s);
+    if ((rc = alga_check_launch(e, "k_keys_to_edges"))) return rc;
+    HIP_TRY(e, hipEventRecord(e->ev[EV_EMIT], s));
+    HIP_TRY(e, hipStreamSynchronize(s));
+    *n_edges = E;
+    e->stats.edges = E;
+    return ALGA_OK;
+}
+
+// Source-side form for the sources [src_begin, src_end): ALGA_ERR_UNSUPPORTED when it is not exact for the input.
+int build_local(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t src_end, hipStream_t s, uint64_t *n_edges) {
+    if (!pp.local_ok) return alga_fail(e, ALGA_ERR_UNSUPPORTED, "source-side reduction is not exact for this input (read lengths / masks / rsoemo)");
+    uint64_t n_rec = 0;
+    bool overflow = false;
+    int rc = discover_impl(e, pp, src_begin, src_end, s, &n_rec, true, &overflow);
+    if (rc) return rc;
+    if (overflow) return alga_fail(e, ALGA_ERR_UNSUPPORTED, "a source node has more raw overlaps than the source-side reduction holds");
+    if ((rc = finalize_local(e, pp, n_rec, s, n_edges))) return rc;
+    e->stats.reduction_used = ALGA_REDUCTION_SOURCE_SIDE;
+    return ALGA_OK;
+}
+
 float ev_ms(alga_engine *e, int a, int b) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, e->ev[a], e->ev[b]) != hipSuccess) return 0.f;
@@ -257,6 +317,7 @@ int alga_engine_create(int hip_device, alga_engine **out) {
     if (const char *v = getenv("ALGA_SEED_FILL_X10")) e->seed_fill_x10 = atoi(v);
     if (const char *v = getenv("ALGA_SEED_FILTER")) e->use_filter = atoi(v);
     if (const char *v = getenv("ALGA_PROBE")) e->probe_mode = strcmp(v, "min") == 0 ? 1 : 0;
+    if (const char *v = getenv("ALGA_REDUCE")) e->force_reduction = strcmp(v, "target") == 0 ? 1 : 0;
     memset(&e->stats, 0, sizeof(e->stats));
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, hip_device) == hipSuccess) {
@@ -319,9 +380,19 @@ int alga_prefsuf_build_device(alga_engine *e, const alga_nodes *nodes, const alg
     if (rc) return rc;
     e->stats.nodes_live = pp.live;
     uint64_t n_rec = 0, E = 0;
-    if ((rc = discover_impl(e, pp, 0, nodes->n, s, &n_rec))) return rc;
-    if ((rc = reduce_impl(e, pp, (const uint32_t *) e->rec_dst.p, (const unsigned long long *) e->rec_val.p, n_rec, e->stats.records,
-                          0, nodes->n, s, &E))) return rc;
+    bool done = false;
+    if (pp.reduction == ALGA_REDUCTION_SOURCE_SIDE || (pp.reduction == ALGA_REDUCTION_AUTO && pp.local_ok)) {
+        rc = build_local(e, pp, 0, nodes->n, s, &E);
+        if (rc == ALGA_OK) done = true;
+        else if (rc != ALGA_ERR_UNSUPPORTED || pp.reduction == ALGA_REDUCTION_SOURCE_SIDE) return rc;
+        else { e->err.clear(); memset(&e->stats, 0, sizeof(e->stats)); e->stats.nodes_live = pp.live; }    // AUTO: capacity case, per-target pipeline
+    }
+    if (!done) {
+        if ((rc = discover_impl(e, pp, 0, nodes->n, s, &n_rec))) return rc;
+        if ((rc = reduce_impl(e, pp, (const uint32_t *) e->rec_dst.p, (const unsigned long long *) e->rec_val.p, n_rec, e->stats.records,
+                              0, nodes->n, s, &E))) return rc;
+        e->stats.reduction_used = ALGA_REDUCTION_PER_TARGET;
+    }
     e->stats.ms_seed = ev_ms(e, EV_START, EV_SEED);
     e->stats.ms_probe = ev_ms(e, EV_SEED, EV_PROBE);
     e->stats.ms_group = ev_ms(e, EV_PROBE, EV_GROUP);
@@ -417,6 +488,32 @@ int alga_prefsuf_discover_device(alga_engine *e, const alga_nodes *nodes, const 
     e->stats.ms_total = ev_ms(e, EV_START, EV_PROBE);
     *d_dst = (const uint32_t *) e->rec_dst.p; *d_val = (const uint64_t *) e->rec_val.p;
     *n_records = n_rec;
+    return ALGA_OK;
+}
+
+int alga_prefsuf_build_range_device(alga_engine *e, const alga_nodes *nodes, const alga_prefsuf_params *p, int32_t src_begin, int32_t src_end,
+                                    void *hip_stream, const alga_edge **d_edges, uint64_t *n_edges) {
+    if (!e) return ALGA_ERR_INVALID_ARGUMENT;
+    e->err.clear();
+    if (!d_edges || !n_edges) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "output pointers must not be NULL");
+    *d_edges = nullptr; *n_edges = 0;
+    HIP_TRY(e, hipSetDevice(e->device));
+    hipStream_t s = hip_stream ? (hipStream_t) hip_stream : e->own_stream;
+    memset(&e->stats, 0, sizeof(e->stats));
+    Prepared pp;
+    int rc = prepare(e, nodes, p, s, pp);
+    if (rc) return rc;
+    if (src_begin < 0 || src_end > nodes->n || src_begin > src_end) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "bad source range");
+    if (pp.reduction == ALGA_REDUCTION_PER_TARGET) return alga_fail(e, ALGA_ERR_UNSUPPORTED, "per-target reduction requested: use discover + exchange + reduce");
+    e->stats.nodes_live = pp.live;
+    uint64_t E = 0;
+    if ((rc = build_local(e, pp, src_begin, src_end, s, &E))) return rc;
+    e->stats.ms_seed = ev_ms(e, EV_START, EV_SEED);
+    e->stats.ms_probe = ev_ms(e, EV_SEED, EV_PROBE);
+    e->stats.ms_emit = ev_ms(e, EV_REDUCE, EV_EMIT);
+    e->stats.ms_total = ev_ms(e, EV_START, EV_EMIT);
+    *d_edges = (const alga_edge *) e->edges.p;
+    *n_edges = E;
     return ALGA_OK;
 }
 

@@ -35,7 +35,8 @@ struct alga_engine {
     DevBuf pk_keys, pk_keys2, pk_vals, pk_vals2, pk_marks, pk_big, pk_add, pk_ekeys, pk_ekeys2, pk_flag, pk_pos, pk_edges[2], pk_rowptr, pk_deg,
            pk_mask, pk_cnt, pk_io, pk_io2;
     unsigned long long *h_counters = nullptr;  // pinned, CNT_TOTAL + 2 entries
-    uint64_t    rec_cap_hint = 0;
+    uint64_t    rec_cap_hint = 0, rec_cap_hint_local = 0;
+    int         force_reduction = 0;          // ALGA_REDUCE=target|source overrides alga_prefsuf_params.reduction == AUTO (experiments)
     alga_prefsuf_stats stats;
     alga_pkb_stats pkb_stats;
 };

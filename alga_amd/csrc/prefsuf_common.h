@@ -46,6 +46,7 @@ ALGA_HD inline uint64_t fp_final(uint64_t h) {
 
 constexpr uint32_t REC_INVALID = 0xFFFFFFFFu; // rec_dst marker: unused slot of a record chunk
 constexpr uint64_t SEED_EMPTY = ~0ull; // seed-table slot: ((tag23 << 9 | len9) << 32) | node id ; empty = all ones
+constexpr int LOCAL_MAX_SPAN = 63;     // source-side reduction: max_len - Lmin; offsets and overhangs fit 64-bit masks / 128 bits
 constexpr int SEED_BUCKET = 8;         // slots per bucket: 8 x 8 B = one 64-byte line per probe
 
 // number of uint32 blocks that hold `len_nt` nucleotides (Bitset::blocks(), Bitset.h:206)
@@ -65,6 +66,9 @@ enum Counter {
     CNT_LIVE_NODES,
     CNT_VALID_RECORDS,     // records that carry an overlap
     CNT_SORT_VALID,        // records whose target lies in the owned range (k_make_keys)
+    CNT_MASK_ASYM,         // live nodes with alignFrom but not alignTo (source-side reduction needs none)
+    CNT_LOCAL_OVERFLOW,    // sources with more raw overlaps than the source-side reduction holds in LDS
+    CNT_LOCAL_GENERIC,     // sources that took the all-pairs path of the source-side reduction
     CNT_TOTAL = 16
 };
 

@@ -82,7 +82,9 @@ constexpr int STAGE_WORDS = 52;       // staged tail (<= 33 words) + slack for u
 constexpr int CANDMAX = 128;          // per-wave candidate buffer
 constexpr int WBUF = 256;             // per-wave LDS record buffer (records)
 constexpr int WFLUSH = 128;           // flush once this many are buffered
-constexpr int REC_CHUNK = 1024;       // records reserved per global atomic
+constexpr int REC_CHUNK = 1024;       // records reserved per global atomic (per-target pipeline: ~11 records per source)
+constexpr int REC_CHUNK_LOCAL = 128;  // same, source-side reduction (~1 record per source)
+constexpr int WFLUSH_LOCAL = 64;
 
 // keep a >= b >= c = the three largest keys seen (branch-free: the three keys must stay in registers)
 __device__ __forceinline__ void top3_insert(uint64_t &a, uint64_t &b, uint64_t &c, uint64_t k) {
@@ -90,6 +92,26 @@ __device__ __forceinline__ void top3_insert(uint64_t &a, uint64_t &b, uint64_t &
     t = k > b ? k : b; k = k > b ? b : k; b = t;
     c = k > c ? k : c;
 }
+
+// the three largest keys over the wave's per-lane (k0 >= k1 >= k2) triples, uniform; 0 = none.  Convergent.
+__device__ __forceinline__ void wave_top3(uint64_t k0, uint64_t k1, uint64_t k2, uint64_t &win0, uint64_t &win1, uint64_t &win2) {
+    win0 = win1 = win2 = 0;
+    uint64_t m = wave_max_u64_dpp(k0);
+    if (m) {
+        if (k0 == m) { k0 = k1; k1 = k2; k2 = 0; }
+        win0 = m;
+        m = wave_max_u64_dpp(k0);
+        if (m) {
+            if (k0 == m) { k0 = k1; k1 = k2; k2 = 0; }
+            win1 = m;
+            win2 = wave_max_u64_dpp(k0);
+        }
+    }
+}
+
+// value of the quad's lane 0 / of the next lane of the quad (lane 3 reads itself); all lanes of the quad must be active
+__device__ __forceinline__ int quad_bcast0(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x00, 0xF, 0xF, true); }
+__device__ __forceinline__ uint32_t quad_next(uint32_t v) { return (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0xF9, 0xF, 0xF, true); }
 
 struct ProbeOut {
     uint32_t *__restrict__ rec_dst;
@@ -109,30 +131,43 @@ struct WaveLds {           // per-wave LDS views
 };
 
 // Convergent: all 64 lanes.  Moves the wave's LDS record buffer to the global record list.
-//   A chunk of the list is reserved with ONE global atomic (a returning atomic on a single address
-//   sustains only ~88 ops/us chip-wide: per-record or per-source reservations cost tens of ms).
+//   Chunks of the list are reserved with ONE global atomic each (a returning atomic on a single address
+//   sustains only ~88 ops/us chip-wide: per-record or per-source reservations cost tens of ms).  A flush fills the
+//   open chunk to the brim before it reserves the next one, so only the last chunk of a wave carries padding.
+//   chunk_fill == CHUNK means "no chunk reserved yet".
+template <int CHUNK>
 __device__ __forceinline__ void flush_records(const ProbeOut &o, const WaveLds &w, uint64_t &chunk_base, int &chunk_fill) {
     const int lane = lane_id();
     wave_lds_fence();
     int n = (int) __builtin_amdgcn_readfirstlane((int) *w.recN);
     if (n > WBUF) n = WBUF;                      // the excess went out through the direct path
     if (n == 0) return;
-    if (chunk_fill + n > REC_CHUNK) {
-        for (int i = chunk_fill + lane; i < REC_CHUNK; i += 64) {      // close the chunk: invalid markers in its tail
-            const uint64_t idx = chunk_base + (uint64_t) i;
-            if (idx < o.rec_cap) o.rec_dst[idx] = REC_INVALID;
+    int done = 0;
+    while (done < n) {                           // wave-uniform
+        if (chunk_fill == CHUNK) {
+            uint64_t base = 0;
+            if (lane == 0) base = atomicAdd(&o.counters[CNT_RECORDS], (unsigned long long) CHUNK);
+            chunk_base = ((uint64_t) (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) (base >> 32)) << 32) |
+                         (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) base);
+            chunk_fill = 0;
         }
-        uint64_t base = 0;
-        if (lane == 0) base = atomicAdd(&o.counters[CNT_RECORDS], (unsigned long long) REC_CHUNK);
-        chunk_base = ((uint64_t) (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) (base >> 32)) << 32) |
-                     (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) base);
-        chunk_fill = 0;
+        const int take = (n - done) < (CHUNK - chunk_fill) ? (n - done) : (CHUNK - chunk_fill);
+        for (int i = lane; i < take; i += 64) store_record(o, chunk_base + (uint64_t) (chunk_fill + i), w.recC[done + i], w.recV[done + i]);
+        chunk_fill += take;
+        done += take;
     }
-    for (int i = lane; i < n; i += 64) store_record(o, chunk_base + (uint64_t) (chunk_fill + i), w.recC[i], w.recV[i]);
-    chunk_fill += n;
     wave_lds_fence();
     if (lane == 0) *w.recN = 0;
     wave_lds_fence();
+}
+
+// Convergent: invalid markers in the unused tail of the wave's last chunk (end of the kernel).
+template <int CHUNK>
+__device__ __forceinline__ void close_chunk(const ProbeOut &o, uint64_t chunk_base, int chunk_fill) {
+    for (int i = chunk_fill + lane_id(); i < CHUNK; i += 64) {
+        const uint64_t idx = chunk_base + (uint64_t) i;
+        if (idx < o.rec_cap) o.rec_dst[idx] = REC_INVALID;
+    }
 }
 
 // NQ > 0: rows are 16-byte aligned, hold >= NQ uint4 and every compared prefix fits NQ uint4:
@@ -169,5 +204,144 @@ __device__ __forceinline__ bool verify_overlap(const NodesDev &nd, const uint32_
     return diff == 0;
 }
 
+// ------------------------------------------------------------------------------------------
+// Source-side transitive reduction (executable statement: tests/source_side_rule.py)
+//
+// The reference decides per TARGET C which in-overlaps (A -> C) are implied by a big overlap (B -> C), replaying the
+// pushes in (L, source) order (GraphCreatorPrefSuf.cpp:397-483).  Every such via B is itself a raw out-overlap of A
+// (A[d_B..] == B[0..], |A| - d_B >= L_AC >= min_overlap), so the wave that has just verified ALL raw overlaps of A
+// holds everything needed: with overhang(X) = X[L_AX ..) -- what X adds to the right of A's end --
+//     via(B, C)  <=>  d_B < d_C, B != C, alignFrom[B], |B| - (d_C - d_B) >= max(rsoemo, Lmin),
+//                     overhang(B) is a prefix of overhang(C), and (rho_B > 0 or B > A)   [push order at equal L]
+// Items live in LDS: C, meta = d | len_C << 9 | alignFrom << 18, overhang (<= 63 nt: 128 bits, filled by the quad that verified
+// the overlap from the row words it already holds).
+// Fast path (error-free reads): one item per offset; each item is tested against its nearest predecessor only and
+// anything that does not resolve that way sends the whole source down the generic all-pairs path.
+// Host-checked preconditions (engine.hip local_ok): max_len - Lmin <= 63, max_len <= cap, alignFrom => alignTo,
+// Lmin <= rsoemo <= Lcap.
+// ------------------------------------------------------------------------------------------
+constexpr int ITEMMAX = 192;              // raw overlaps of one source held in LDS; more -> CNT_LOCAL_OVERFLOW, per-target pipeline
+constexpr uint32_t ITEM_FROM = 1u << 18;
+
+struct ItemLds { uint32_t *C; uint32_t *M; uint4 *O; uint8_t *T; uint32_t *N; };
+
+__device__ __forceinline__ uint64_t wave_or_u64_dpp(uint64_t v) {
+    v |= dpp_or_zero_u64<0x111, 0xF>(v);
+    v |= dpp_or_zero_u64<0x112, 0xF>(v);
+    v |= dpp_or_zero_u64<0x114, 0xF>(v);
+    v |= dpp_or_zero_u64<0x118, 0xF>(v);
+    v |= dpp_or_zero_u64<0x142, 0xA>(v);
+    v |= dpp_or_zero_u64<0x143, 0xC>(v);
+    const uint32_t lo = (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) v, 63);
+    const uint32_t hi = (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) (v >> 32), 63);
+    return ((uint64_t) hi << 32) | lo;
+}
+
+__device__ __forceinline__ uint32_t low_bits32(int bits) { return bits >= 32 ? 0xFFFFFFFFu : (bits <= 0 ? 0u : ((1u << bits) - 1u)); }
+
+// is item j (= B) a via that removes item i (= C) of source A ?
+__device__ __forceinline__ bool via_ok(int A, int lenA, int Lbig, uint32_t Cj, uint32_t mj, const uint4 &oj, uint32_t Ci, int di, int rho_i,
+                                       const uint4 &oi) {
+    const int dj = (int) (mj & 511u), lenj = (int) ((mj >> 9) & 511u);
+    const int rho_j = lenj - (lenA - dj);
+    const int Lv = lenj - (di - dj);                       // length of the overlap B -> C
+    const bool ok = (mj & ITEM_FROM) != 0 && Cj != Ci && dj < di && Lv >= Lbig && rho_j <= rho_i && (rho_j > 0 || (int) Cj > A);
+    const int nb = 2 * rho_j;
+    const uint32_t diff = ((oi.x ^ oj.x) & low_bits32(nb)) | ((oi.y ^ oj.y) & low_bits32(nb - 32)) | ((oi.z ^ oj.z) & low_bits32(nb - 64)) |
+                          ((oi.w ^ oj.w) & low_bits32(nb - 96));
+    return ok && diff == 0;
+}
+
+// overhang of item `slot` from X's row in global memory (cold paths of the probe; the wide verification fills it from registers).
+// Bits past the overhang's own length are never compared (via_ok masks with the via's length <= the candidate's), so
+// nothing here is masked.
+__device__ __forceinline__ void item_overhang_global(const NodesDev &nd, const ItemLds &it, int slot, int C, int L, int lenC) {
+    if (slot < 0 || slot >= ITEMMAX) return;
+    const uint32_t *row = nd.words + (size_t) C * nd.stride;
+    const int ws = (2 * L) >> 5, r = (2 * L) & 31, lastw = (2 * lenC - 1) >> 5;
+    uint32_t x[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) x[k] = (ws + k <= lastw) ? row[ws + k] : 0u;
+    it.O[slot] = make_uint4(funnel(x[0], x[1], r), funnel(x[1], x[2], r), funnel(x[2], x[3], r), funnel(x[3], x[4], r));
+}
+
+// Convergent.  n = items of source A in `it` (<= ITEMMAX), overhangs filled.
+template <bool STATS>
+__device__ __forceinline__ void local_reduce(const NodesDev &nd, const PrefSufCfg &cfg, const ItemLds &it, const WaveLds &w, const ProbeOut &o,
+                                             int A, int lenA, int n, uint64_t &st_rec, uint64_t &st_cmp, uint64_t &st_generic) {
+    const int lane = lane_id();
+    const int Lbig = cfg.rsoemo > cfg.Lmin ? cfg.rsoemo : cfg.Lmin;
+    auto push = [&](uint32_t C, int d) {
+        const int L = lenA - d;
+        const unsigned long long val = ((unsigned long long) ol_pack(d, L, L < cfg.rsoemo) << 32) | (uint32_t) A;
+        const uint32_t i = atomicAdd(w.recN, 1u);
+        if (i < (uint32_t) WBUF) { w.recC[i] = C; w.recV[i] = val; }
+        else store_record(o, atomicAdd(&o.counters[CNT_RECORDS], 1ull), C, val);
+        st_rec++;
+    };
+    wave_lds_fence();
+    bool generic = n > 64;
+    if (!generic) {
+        const bool act = lane < n;
+        uint32_t C = 0, m = 0;
+        uint4 ov = make_uint4(0u, 0u, 0u, 0u);
+        int d = 0;
+        if (act) { C = it.C[lane]; m = it.M[lane]; ov = it.O[lane]; d = (int) (m & 511u); }
+        const uint64_t occ = wave_or_u64_dpp(act ? (1ull << d) : 0ull);
+        generic = __popcll(occ) != n;                      // two items at one offset
+        if (!generic) {
+            const uint64_t below = occ & ((1ull << d) - 1ull);
+            const bool has_pred = act && below != 0;
+            if (act) it.T[d] = (uint8_t) lane;
+            wave_lds_fence();
+            bool fail = false;
+            if (has_pred) {
+                const int j = (int) it.T[63 - __clzll((long long) below)];
+                const uint32_t Cj = it.C[j], mj = it.M[j];
+                const uint4 oj = it.O[j];
+                const int rho = (int) ((m >> 9) & 511u) - (lenA - d);
+                if (STATS) st_cmp++;
+                fail = !via_ok(A, lenA, Lbig, Cj, mj, oj, C, d, rho, ov);
+            }
+            generic = __ballot(fail) != 0ull;
+            // The item without a predecessor has the longest overlap of the source: it is big, or it is the largest of the
+            // source's small overlaps and survives the cap of 3 (GraphCreatorPrefSuf.cpp:397-401) -- no top-3 needed here.
+            if (!generic && act && !has_pred) push(C, d);
+        }
+    }
+    if (generic) {
+        if (STATS && lane == 0) st_generic++;
+        uint64_t k0 = 0, k1 = 0, k2 = 0, win0, win1, win2;
+        for (int i = lane; i < n; i += 64) {
+            const int L = lenA - (int) (it.M[i] & 511u);
+            if (L < cfg.rsoemo) top3_insert(k0, k1, k2, ((uint64_t) (uint32_t) L << 32) | it.C[i]);
+        }
+        wave_top3(k0, k1, k2, win0, win1, win2);
+        auto is_kept = [&](uint32_t C, int d) {
+            const int L = lenA - d;
+            const uint64_t key = ((uint64_t) (uint32_t) L << 32) | C;
+            return L >= cfg.rsoemo || key == win0 || key == win1 || key == win2;
+        };
+        for (int base = 0; base < n; base += 64) {
+            const int i = base + lane;
+            const bool act = i < n;
+            uint32_t C = 0, m = 0;
+            uint4 ov = make_uint4(0u, 0u, 0u, 0u);
+            if (act) { C = it.C[i]; m = it.M[i]; ov = it.O[i]; }
+            const int d = (int) (m & 511u);
+            const int rho = (int) ((m >> 9) & 511u) - (lenA - d);
+            bool removed = !act || !is_kept(C, d);
+            for (int j = 0; j < n; j++) {
+                const uint32_t Cj = it.C[j], mj = it.M[j];
+                const uint4 oj = it.O[j];
+                const int dj = (int) (mj & 511u);
+                if (Cj == C) removed = removed || (dj < d && is_kept(Cj, dj));      // same target at a smaller offset: Graph.cpp:348-387, :461-462
+                else { if (STATS && act && dj < d) st_cmp++; removed = removed || via_ok(A, lenA, Lbig, Cj, mj, oj, C, d, rho, ov); }
+            }
+            if (!removed) push(C, d);
+        }
+    }
+    wave_lds_fence();
+}
 
 } // namespace alga

@@ -19,8 +19,11 @@ void launch_seed_build(const NodesDev &nd, const PrefSufCfg &cfg, unsigned long 
 // overlap record = rec_dst[i] (target id, REC_INVALID for chunk padding) + rec_val[i] ((ol << 32) | source id)
 void launch_probe(const NodesDev &nd, const PrefSufCfg &cfg, const unsigned long long *table, uint32_t n_buckets,
                   const uint32_t *filter, uint32_t filter_bits, int32_t src_begin, int32_t src_end, uint32_t *rec_dst, unsigned long long *rec_val, uint64_t rec_cap,
-                  unsigned long long *counters, int n_cu, hipStream_t s);
-uint64_t probe_record_slack(int n_cu, uint64_t n_src);
+                  unsigned long long *counters, int n_cu, bool local, hipStream_t s);
+uint64_t probe_record_slack(int n_cu, uint64_t n_src, bool local);
+// source-side reduction: records are final edges -> (src << 32 | dst, offset) sort keys, padding = all ones
+void launch_records_to_edge_keys(const uint32_t *rec_dst, const unsigned long long *rec_val, uint64_t n, unsigned long long *keys, uint32_t *vals,
+                                 hipStream_t s);
 
 // minimizer index (prefsuf_minimizer.hip)
 int      minimizer_key_bits(const PrefSufCfg &cfg);

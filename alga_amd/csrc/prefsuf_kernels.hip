@@ -34,17 +34,19 @@ __global__ void __launch_bounds__(256) k_node_stats(NodesDev nd, unsigned long l
     __shared__ int s_max[4];
     __shared__ unsigned long long s_live[4];
     int m = 0;
-    unsigned long long live = 0;
+    unsigned long long live = 0, asym = 0;
     for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < nd.n; i += (int64_t) gridDim.x * blockDim.x) {
         int l = nd.len[i];
         m = l > m ? l : m;
         live += l > 0;
+        if (nd.to && l > 0 && !nd.to[i] && (nd.from == nullptr || nd.from[i])) asym++;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(m, o); m = t > m ? t : m; }
     live = wave_sum_u64(live);
+    asym = wave_sum_u64(asym);
     const int wave = (int) (threadIdx.x >> 6);
-    if (lane_id() == 0) { s_max[wave] = m; s_live[wave] = live; }
+    if (lane_id() == 0) { s_max[wave] = m; s_live[wave] = live; if (asym) atomicAdd(&counters[CNT_MASK_ASYM], asym); }
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int w = 1; w < 4; w++) { m = s_max[w] > m ? s_max[w] : m; live += s_live[w]; }
@@ -100,7 +102,9 @@ __global__ void __launch_bounds__(256) k_seed_build(NodesDev nd, PrefSufCfg cfg,
 #ifndef PROBE_OCC
 #define PROBE_OCC 4                   // minimum waves per SIMD requested from the register allocator
 #endif
-template <bool STATS, int NQ>
+// LOCAL: the wave also performs the transitive reduction for its source (prefsuf_device.h: local_reduce) and the
+// records it emits are the final edges; otherwise the records are all capped raw overlaps, reduced per target later.
+template <bool STATS, int NQ, bool LOCAL>
 __global__ void __launch_bounds__(PROBE_WAVES * 64, PROBE_OCC)
 k_probe_sources(NodesDev nd, PrefSufCfg cfg, const unsigned long long *__restrict__ table, uint32_t n_buckets,
                 const uint32_t *__restrict__ filter, uint32_t filter_mask, int32_t src_begin, int32_t src_end, ProbeOut o) {
@@ -109,14 +113,20 @@ k_probe_sources(NodesDev nd, PrefSufCfg cfg, const unsigned long long *__restric
     __shared__ uint32_t sCandW[PROBE_WAVES][CANDMAX];
     __shared__ uint32_t sRecC[PROBE_WAVES][WBUF];
     __shared__ unsigned long long sRecV[PROBE_WAVES][WBUF];
-    __shared__ uint32_t sCnt[PROBE_WAVES][2];
+    __shared__ uint32_t sCnt[PROBE_WAVES][3];
+    __shared__ uint32_t sItemC[PROBE_WAVES][LOCAL ? ITEMMAX : 1];
+    __shared__ uint32_t sItemM[PROBE_WAVES][LOCAL ? ITEMMAX : 1];
+    __shared__ uint4 sItemO[PROBE_WAVES][LOCAL ? ITEMMAX : 1];
+    __shared__ uint8_t sItemT[PROBE_WAVES][64];
+    constexpr int CHUNK = LOCAL ? REC_CHUNK_LOCAL : REC_CHUNK;
     const int wave = (int) (threadIdx.x >> 6);
     const int lane = lane_id();
     WaveLds w{sB[wave], sCandC[wave], sCandW[wave], &sCnt[wave][0], sRecC[wave], sRecV[wave], &sCnt[wave][1]};
-    if (lane == 0) { *w.candN = 0; *w.recN = 0; }
+    ItemLds it{sItemC[wave], sItemM[wave], sItemO[wave], sItemT[wave], &sCnt[wave][2]};
+    if (lane == 0) { *w.candN = 0; *w.recN = 0; *it.N = 0; }
     uint64_t chunk_base = 0;
-    int chunk_fill = REC_CHUNK;                            // "no chunk yet"
-    uint64_t st_raw = 0, st_slots = 0, st_win = 0, st_rec = 0;
+    int chunk_fill = CHUNK;                                // "no chunk yet"
+    uint64_t st_raw = 0, st_slots = 0, st_win = 0, st_rec = 0, st_cmp = 0, st_generic = 0;
     const int64_t total_waves = (int64_t) gridDim.x * PROBE_WAVES;
     const uint32_t *sb = w.sb;
 
@@ -157,8 +167,15 @@ k_probe_sources(NodesDev nd, PrefSufCfg cfg, const unsigned long long *__restric
         uint64_t k0 = 0, k1 = 0, k2 = 0;                   // per-lane top-3 small overlaps, key=(L<<32)|C
 
         // A verified overlap (B -> C, length L): small ones compete for the per-source top 3, big ones are records.
-        auto classify = [&](int C, int L) {
+        auto classify = [&](int C, int L, int lenC) -> int {                  // LOCAL: the item slot (may be >= ITEMMAX: not stored)
             if (STATS) st_raw++;
+            if (LOCAL) {
+                uint32_t m = (uint32_t) (lenB - L) | ((uint32_t) lenC << 9);
+                if (nd.from == nullptr || nd.from[C]) m |= ITEM_FROM;
+                const uint32_t i = atomicAdd(it.N, 1u);                // LDS atomic
+                if (i < (uint32_t) ITEMMAX) { it.C[i] = (uint32_t) C; it.M[i] = m; }
+                return (int) i;
+            }
             if (L < cfg.rsoemo) {
                 top3_insert(k0, k1, k2, ((uint64_t) (uint32_t) L << 32) | (uint32_t) C);       // GraphCreatorPrefSuf.cpp:397-401
             } else {
@@ -168,6 +185,7 @@ k_probe_sources(NodesDev nd, PrefSufCfg cfg, const unsigned long long *__restric
                 if (i < (uint32_t) WBUF) { w.recC[i] = (uint32_t) C; w.recV[i] = val; }
                 else store_record(o, atomicAdd(&o.counters[CNT_RECORDS], 1ull), (uint32_t) C, val);   // buffer full: direct, slow
             }
+            return -1;
         };
 
         for (int base = 0; base < nwin; base += 64) {
@@ -235,11 +253,11 @@ k_probe_sources(NodesDev nd, PrefSufCfg cfg, const unsigned long long *__restric
                 // candidate: same tag, long enough for a prefix of length L (:215), not B itself (:386)
                 if (e.x != 0xFFFFFFFFu && (e.y >> 9) == tw && (int) (e.y & 511u) >= Lw && (int) e.x != B) {
                     const uint32_t ci = atomicAdd(w.candN, 1u);
-                    if (ci < (uint32_t) CANDMAX) { w.candC[ci] = e.x; w.candW[ci] = (uint32_t) (base + wl); }
+                    if (ci < (uint32_t) CANDMAX) { w.candC[ci] = e.x; w.candW[ci] = (uint32_t) (base + wl) | ((e.y & 511u) << 16); }
                 }
                 if (e.z != 0xFFFFFFFFu && (e.w >> 9) == tw && (int) (e.w & 511u) >= Lw && (int) e.z != B) {
                     const uint32_t ci = atomicAdd(w.candN, 1u);
-                    if (ci < (uint32_t) CANDMAX) { w.candC[ci] = e.z; w.candW[ci] = (uint32_t) (base + wl); }
+                    if (ci < (uint32_t) CANDMAX) { w.candC[ci] = e.z; w.candW[ci] = (uint32_t) (base + wl) | ((e.w & 511u) << 16); }
                 }
                 const bool full = sub == 3 && e.z != 0xFFFFFFFFu;
                 const uint64_t fm = __ballot(full);        // bit 4j+3 <-> window 16*rr + j
@@ -256,7 +274,7 @@ k_probe_sources(NodesDev nd, PrefSufCfg cfg, const unsigned long long *__restric
 #define ALGA_SLOT(ID, TL)                                                                                           \
                     if ((ID) != 0xFFFFFFFFu && ((TL) >> 9) == my_tag && (int) ((TL) & 511u) >= L && (int) (ID) != B) {   \
                         const uint32_t ci = atomicAdd(w.candN, 1u);                                                       \
-                        if (ci < (uint32_t) CANDMAX) { w.candC[ci] = (ID); w.candW[ci] = (uint32_t) widx; }                \
+                        if (ci < (uint32_t) CANDMAX) { w.candC[ci] = (ID); w.candW[ci] = (uint32_t) widx | (((TL) & 511u) << 16); } \
                     }
                     ALGA_SLOT(e0.x, e0.y) ALGA_SLOT(e0.z, e0.w) ALGA_SLOT(e1.x, e1.y) ALGA_SLOT(e1.z, e1.w)
                     ALGA_SLOT(e2.x, e2.y) ALGA_SLOT(e2.z, e2.w) ALGA_SLOT(e3.x, e3.y) ALGA_SLOT(e3.z, e3.w)
@@ -287,7 +305,10 @@ k_probe_sources(NodesDev nd, PrefSufCfg cfg, const unsigned long long *__restric
                             const uint32_t id = (uint32_t) en, tl = (uint32_t) (en >> 32);
                             if (id == 0xFFFFFFFFu) { full = false; break; }
                             if ((tl >> 9) == my_tag && (int) (tl & 511u) >= L && (int) id != B &&
-                                verify_overlap<0>(nd, sb, (int) id, my_q, my_r, L)) classify((int) id, L);
+                                verify_overlap<0>(nd, sb, (int) id, my_q, my_r, L)) {
+                                const int slot = classify((int) id, L, (int) (tl & 511u));
+                                if (LOCAL) item_overhang_global(nd, it, slot, (int) id, L, (int) (tl & 511u));
+                            }
                         }
                         if (!full) break;
                         b = (b + 1 == n_buckets) ? 0u : b + 1;
@@ -298,18 +319,20 @@ k_probe_sources(NodesDev nd, PrefSufCfg cfg, const unsigned long long *__restric
                 // four words, the group ORs its differences
                 const int ncand = ncand_raw;
                 for (int c0 = 0; c0 < ncand; c0 += 32) {          // two groups of 16 candidates per trip: both loads in flight
-                    int Cc[2], Lc[2];
+                    int Cc[2], Lc[2], Nc[2];
                     uint4 cc[2];
                     bool act[2];
 #pragma unroll
                     for (int g = 0; g < 2; g++) {
                         const int ci = c0 + 16 * g + (lane >> 2);
                         act[g] = ci < ncand;
-                        Cc[g] = 0; Lc[g] = Lspan;
+                        Cc[g] = 0; Lc[g] = Lspan; Nc[g] = 0;
                         cc[g] = make_uint4(0u, 0u, 0u, 0u);
                         if (act[g]) {
                             Cc[g] = (int) w.candC[ci];
-                            Lc[g] = Lspan - (int) w.candW[ci];
+                            const uint32_t cw = w.candW[ci];
+                            Lc[g] = Lspan - (int) (cw & 0xFFFFu);
+                            Nc[g] = (int) (cw >> 16);
                             if (sub < NQ) cc[g] = reinterpret_cast<const uint4 *>(nd.words + (size_t) Cc[g] * nd.stride)[sub];
                         }
                     }
@@ -331,7 +354,23 @@ k_probe_sources(NodesDev nd, PrefSufCfg cfg, const unsigned long long *__restric
                             }
                         }
                         diff = quad_or(diff);
-                        if (act[g] && sub == 0 && diff == 0) classify(Cc[g], Lc[g]);
+                        int slot = -1;
+                        if (act[g] && sub == 0 && diff == 0) slot = classify(Cc[g], Lc[g], Nc[g]);
+                        if (LOCAL) {
+                            // the quad holds C's row: word p of the overhang stream = bits [2L + 32(p - ws), ...) of the row
+                            slot = quad_bcast0(slot);
+                            const uint32_t nxt = sub == 3 ? 0u : quad_next(cc[g].x);
+                            if (slot >= 0 && slot < ITEMMAX) {
+                                const int ws = (2 * Lc[g]) >> 5, r = (2 * Lc[g]) & 31;
+                                uint32_t *ow = reinterpret_cast<uint32_t *>(&it.O[slot]);
+                                const uint32_t cw[5] = {cc[g].x, cc[g].y, cc[g].z, cc[g].w, nxt};
+#pragma unroll
+                                for (int j = 0; j < 4; j++) {
+                                    const int k = 4 * sub + j - ws;
+                                    if (k >= 0 && k < 4) ow[k] = funnel(cw[j], cw[j + 1], r);
+                                }
+                            }
+                        }
                     }
                 }
             } else {
@@ -340,9 +379,13 @@ k_probe_sources(NodesDev nd, PrefSufCfg cfg, const unsigned long long *__restric
                     const int ci = c0 + lane;
                     if (ci < ncand) {
                         const int C = (int) w.candC[ci];
-                        const int L = Lspan - (int) w.candW[ci];
+                        const uint32_t cw = w.candW[ci];
+                        const int L = Lspan - (int) (cw & 0xFFFFu);
                         const int bit = 2 * (lenB - L) - 32 * w0;
-                        if (verify_overlap<0>(nd, sb, C, bit >> 5, bit & 31, L)) classify(C, L);
+                        if (verify_overlap<0>(nd, sb, C, bit >> 5, bit & 31, L)) {
+                            const int slot = classify(C, L, (int) (cw >> 16));
+                            if (LOCAL) item_overhang_global(nd, it, slot, C, L, (int) (cw >> 16));
+                        }
                     }
                 }
             }
@@ -350,28 +393,29 @@ k_probe_sources(NodesDev nd, PrefSufCfg cfg, const unsigned long long *__restric
             if (lane == 0) *w.candN = 0;
             wave_lds_fence();
         }
+        if (LOCAL) {
+            wave_lds_fence();
+            const int n_items = (int) __builtin_amdgcn_readfirstlane((int) *it.N);
+            if (n_items > ITEMMAX) {                       // the engine repeats the build with the per-target pipeline
+                if (lane == 0) atomicAdd(&o.counters[CNT_LOCAL_OVERFLOW], 1ull);
+            } else if (n_items > 0) {
+                local_reduce<STATS>(nd, cfg, it, w, o, B, lenB, n_items, st_rec, st_cmp, st_generic);
+            }
+            if (lane == 0) *it.N = 0;
+            wave_lds_fence();
+            const int nb = (int) __builtin_amdgcn_readfirstlane((int) *w.recN);
+            if (nb >= WFLUSH_LOCAL) flush_records<CHUNK>(o, w, chunk_base, chunk_fill);
+            continue;
+        }
         // per-source small-overlap cap: the reference keeps the LAST `SOES`=3 pushes in (L asc, C asc)
         // order (GraphCreatorPrefSuf.cpp:400-401) == the 3 largest (L, C) keys.
-        uint64_t win0 = 0, win1 = 0, win2 = 0;
-        int nwon = 0;
-        {
-            uint64_t m = wave_max_u64_dpp(k0);
-            if (m) {
-                if (k0 == m) { k0 = k1; k1 = k2; k2 = 0; }
-                win0 = m; nwon = 1;
-                m = wave_max_u64_dpp(k0);
-                if (m) {
-                    if (k0 == m) { k0 = k1; k1 = k2; k2 = 0; }
-                    win1 = m; nwon = 2;
-                    m = wave_max_u64_dpp(k0);
-                    if (m) { win2 = m; nwon = 3; }
-                }
-            }
-        }
+        uint64_t win0, win1, win2;
+        wave_top3(k0, k1, k2, win0, win1, win2);
+        const int nwon = (win0 != 0) + (win1 != 0) + (win2 != 0);
         wave_lds_fence();
         int nbuf = (int) __builtin_amdgcn_readfirstlane((int) *w.recN);
         if (nbuf > WBUF) nbuf = WBUF;
-        if (nbuf + nwon > WBUF) { flush_records(o, w, chunk_base, chunk_fill); nbuf = 0; }
+        if (nbuf + nwon > WBUF) { flush_records<CHUNK>(o, w, chunk_base, chunk_fill); nbuf = 0; }
         if (lane < nwon) {
             const uint64_t m = lane == 0 ? win0 : (lane == 1 ? win1 : win2);
             const int L = (int) (m >> 32);
@@ -382,23 +426,23 @@ k_probe_sources(NodesDev nd, PrefSufCfg cfg, const unsigned long long *__restric
         wave_lds_fence();
         if (lane == 0) *w.recN = (uint32_t) (nbuf + nwon);
         wave_lds_fence();
-        if (nbuf + nwon >= WFLUSH) flush_records(o, w, chunk_base, chunk_fill);
+        if (nbuf + nwon >= WFLUSH) flush_records<CHUNK>(o, w, chunk_base, chunk_fill);
     }
-    flush_records(o, w, chunk_base, chunk_fill);
-    if (chunk_fill < REC_CHUNK) {                          // invalid markers in the unused tail of the last chunk
-        for (int i = chunk_fill + lane; i < REC_CHUNK; i += 64) {
-            const uint64_t idx = chunk_base + (uint64_t) i;
-            if (idx < o.rec_cap) o.rec_dst[idx] = REC_INVALID;
-        }
-    }
+    flush_records<CHUNK>(o, w, chunk_base, chunk_fill);
+    close_chunk<CHUNK>(o, chunk_base, chunk_fill);
     st_rec = wave_sum_u64(st_rec);
     if (lane == 0 && st_rec) atomicAdd(&o.counters[CNT_VALID_RECORDS], (unsigned long long) st_rec);
     if (STATS) {
         st_raw = wave_sum_u64(st_raw); st_slots = wave_sum_u64(st_slots); st_win = wave_sum_u64(st_win);
+        st_cmp = wave_sum_u64(st_cmp); st_generic = wave_sum_u64(st_generic);
         if (lane == 0) {
             atomicAdd(&o.counters[CNT_RAW], (unsigned long long) st_raw);
             atomicAdd(&o.counters[CNT_SLOTS], (unsigned long long) st_slots);
             atomicAdd(&o.counters[CNT_WINDOWS], (unsigned long long) st_win);
+            if (LOCAL) {
+                atomicAdd(&o.counters[CNT_TR_COMPARES], (unsigned long long) st_cmp);
+                atomicAdd(&o.counters[CNT_LOCAL_GENERIC], (unsigned long long) st_generic);
+            }
         }
     }
 }
@@ -769,6 +813,19 @@ __global__ void __launch_bounds__(256) k_keys_to_edges(const unsigned long long 
     }
 }
 
+// records of the source-side reduction are final edges: key = (src << 32) | dst, value = offset; chunk padding gets
+// the all-ones key and sorts behind every edge
+__global__ void __launch_bounds__(256) k_records_to_edge_keys(const uint32_t *__restrict__ rec_dst, const unsigned long long *__restrict__ rec_val,
+                                                               uint64_t n, unsigned long long *__restrict__ keys, uint32_t *__restrict__ vals) {
+    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) {
+        const uint32_t c = rec_dst[i];
+        const unsigned long long v = rec_val[i];
+        const bool ok = c != REC_INVALID;
+        keys[i] = ok ? (((unsigned long long) (uint32_t) v << 32) | c) : ~0ull;
+        vals[i] = ok ? (uint32_t) ol_off((uint32_t) (v >> 32)) : 0u;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // launch wrappers (host)
 // ------------------------------------------------------------------------------------------
@@ -809,23 +866,29 @@ static uint64_t probe_blocks(int n_cu, uint64_t n_src) {
     return std::max<uint64_t>(1, std::min<uint64_t>((n_src + PROBE_WAVES - 1) / PROBE_WAVES, (uint64_t) std::max(1, n_cu) * 8));
 }
 
-uint64_t probe_record_slack(int n_cu, uint64_t n_src) {  // worst-case invalid padding of one launch
-    return probe_blocks(n_cu, n_src) * PROBE_WAVES * REC_CHUNK;
+uint64_t probe_record_slack(int n_cu, uint64_t n_src, bool local) {  // worst-case invalid padding of one launch
+    return probe_blocks(n_cu, n_src) * PROBE_WAVES * (uint64_t) (local ? REC_CHUNK_LOCAL : REC_CHUNK);
 }
 
 struct ProbeTable { const unsigned long long *table; uint32_t n_buckets; const uint32_t *filter; uint32_t filter_mask; };
 
+template <int NQ, bool LOCAL>
+static void launch_probe_nql(const NodesDev &nd, const PrefSufCfg &cfg, const ProbeTable &t,
+                             int32_t src_begin, int32_t src_end, const ProbeOut &o, dim3 grid, dim3 block, hipStream_t s) {
+    if (cfg.stats) hipLaunchKernelGGL((k_probe_sources<true, NQ, LOCAL>), grid, block, 0, s, nd, cfg, t.table, t.n_buckets, t.filter, t.filter_mask, src_begin, src_end, o);
+    else           hipLaunchKernelGGL((k_probe_sources<false, NQ, LOCAL>), grid, block, 0, s, nd, cfg, t.table, t.n_buckets, t.filter, t.filter_mask, src_begin, src_end, o);
+}
 template <int NQ>
-static void launch_probe_nq(const NodesDev &nd, const PrefSufCfg &cfg, const ProbeTable &t,
+static void launch_probe_nq(const NodesDev &nd, const PrefSufCfg &cfg, const ProbeTable &t, bool local,
                             int32_t src_begin, int32_t src_end, const ProbeOut &o, dim3 grid, dim3 block, hipStream_t s) {
-    if (cfg.stats) hipLaunchKernelGGL((k_probe_sources<true, NQ>), grid, block, 0, s, nd, cfg, t.table, t.n_buckets, t.filter, t.filter_mask, src_begin, src_end, o);
-    else           hipLaunchKernelGGL((k_probe_sources<false, NQ>), grid, block, 0, s, nd, cfg, t.table, t.n_buckets, t.filter, t.filter_mask, src_begin, src_end, o);
+    if (local) launch_probe_nql<NQ, true>(nd, cfg, t, src_begin, src_end, o, grid, block, s);
+    else       launch_probe_nql<NQ, false>(nd, cfg, t, src_begin, src_end, o, grid, block, s);
 }
 
 void launch_probe(const NodesDev &nd, const PrefSufCfg &cfg, const unsigned long long *table, uint32_t n_buckets,
                   const uint32_t *filter, uint32_t filter_bits,
                   int32_t src_begin, int32_t src_end, uint32_t *rec_dst, unsigned long long *rec_val, uint64_t rec_cap,
-                  unsigned long long *counters, int n_cu, hipStream_t s) {
+                  unsigned long long *counters, int n_cu, bool local, hipStream_t s) {
     const int64_t ns = (int64_t) src_end - src_begin;
     if (ns <= 0) return;
     dim3 grid((unsigned) probe_blocks(n_cu, (uint64_t) ns)), block(PROBE_WAVES * 64);
@@ -835,10 +898,17 @@ void launch_probe(const NodesDev &nd, const PrefSufCfg &cfg, const unsigned long
     const int need_q = (((2 * cfg.Lcap + 31) >> 5) + 3) >> 2;
     const bool aligned = (nd.stride & 3) == 0 && ((uintptr_t) nd.words & 15u) == 0;
     const int row_q = nd.stride >> 2;
-    if (aligned && need_q <= 2 && row_q >= 2)      launch_probe_nq<2>(nd, cfg, t, src_begin, src_end, o, grid, block, s);
-    else if (aligned && need_q <= 3 && row_q >= 3) launch_probe_nq<3>(nd, cfg, t, src_begin, src_end, o, grid, block, s);
-    else if (aligned && need_q <= 4 && row_q >= 4) launch_probe_nq<4>(nd, cfg, t, src_begin, src_end, o, grid, block, s);
-    else                                           launch_probe_nq<0>(nd, cfg, t, src_begin, src_end, o, grid, block, s);
+    if (aligned && need_q <= 2 && row_q >= 2)      launch_probe_nq<2>(nd, cfg, t, local, src_begin, src_end, o, grid, block, s);
+    else if (aligned && need_q <= 3 && row_q >= 3) launch_probe_nq<3>(nd, cfg, t, local, src_begin, src_end, o, grid, block, s);
+    else if (aligned && need_q <= 4 && row_q >= 4) launch_probe_nq<4>(nd, cfg, t, local, src_begin, src_end, o, grid, block, s);
+    else                                           launch_probe_nq<0>(nd, cfg, t, local, src_begin, src_end, o, grid, block, s);
+}
+
+void launch_records_to_edge_keys(const uint32_t *rec_dst, const unsigned long long *rec_val, uint64_t n, unsigned long long *keys, uint32_t *vals,
+                                 hipStream_t s) {
+    if (n == 0) return;
+    unsigned g = std::min<unsigned>(grid_for(n, 256 * 4), 4096u);
+    hipLaunchKernelGGL(k_records_to_edge_keys, dim3(std::max(1u, g)), dim3(256), 0, s, rec_dst, rec_val, n, keys, vals);
 }
 
 void launch_make_keys(const uint32_t *rec_dst, uint64_t n_rec, int32_t dst_begin, int32_t dst_end, uint32_t *keys,

@@ -392,7 +392,7 @@ k_probe_min(NodesDev nd, PrefSufCfg cfg, MinCfg mc, MinIndex ix, int32_t src_beg
         wave_lds_fence();
         int nbuf = (int) __builtin_amdgcn_readfirstlane((int) *w.recN);
         if (nbuf > WBUF) nbuf = WBUF;
-        if (nbuf + nwon > WBUF) { flush_records(o, w, chunk_base, chunk_fill); nbuf = 0; }
+        if (nbuf + nwon > WBUF) { flush_records<REC_CHUNK>(o, w, chunk_base, chunk_fill); nbuf = 0; }
         if (lane < nwon) {
             const uint64_t m = lane == 0 ? win0 : (lane == 1 ? win1 : win2);
             const int L = (int) (m >> 32);
@@ -403,9 +403,9 @@ k_probe_min(NodesDev nd, PrefSufCfg cfg, MinCfg mc, MinIndex ix, int32_t src_beg
         wave_lds_fence();
         if (lane == 0) *w.recN = (uint32_t) (nbuf + nwon);
         wave_lds_fence();
-        if (nbuf + nwon >= WFLUSH) flush_records(o, w, chunk_base, chunk_fill);
+        if (nbuf + nwon >= WFLUSH) flush_records<REC_CHUNK>(o, w, chunk_base, chunk_fill);
     }
-    flush_records(o, w, chunk_base, chunk_fill);
+    flush_records<REC_CHUNK>(o, w, chunk_base, chunk_fill);
     if (chunk_fill < REC_CHUNK) {
         for (int i = chunk_fill + lane; i < REC_CHUNK; i += 64) {
             const uint64_t idx = chunk_base + (uint64_t) i;

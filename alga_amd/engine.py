@@ -29,7 +29,8 @@ class _Nodes(C.Structure):
 class PrefSufParams(C.Structure):
     """alga_prefsuf_params"""
     _fields_ = [("min_overlap", C.c_int32), ("rsoe_min_overlap", C.c_int32), ("soes", C.c_int32),
-                ("max_len_cap", C.c_int32), ("collect_stats", C.c_int32), ("reserved", C.c_int32 * 3)]
+                ("max_len_cap", C.c_int32), ("collect_stats", C.c_int32), ("reduction", C.c_int32),
+                ("reserved", C.c_int32 * 2)]
 
 
 class PrefSufStats(C.Structure):
@@ -39,7 +40,8 @@ class PrefSufStats(C.Structure):
                 ("records", C.c_uint64), ("edges", C.c_uint64), ("table_slots", C.c_uint64),
                 ("max_in_records", C.c_uint64), ("ms_total", C.c_double), ("ms_seed", C.c_double),
                 ("ms_probe", C.c_double), ("ms_group", C.c_double), ("ms_reduce", C.c_double), ("ms_emit", C.c_double),
-                ("nodes_live", C.c_uint64), ("reserved", C.c_uint64 * 3)]
+                ("nodes_live", C.c_uint64), ("reduction_used", C.c_uint64), ("generic_sources", C.c_uint64),
+                ("reserved", C.c_uint64 * 1)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
@@ -76,7 +78,7 @@ class PkbStats(C.Structure):
 EXPORTS = ["alga_abi_version", "alga_engine_create", "alga_engine_destroy", "alga_last_error",
            "alga_engine_device_name", "alga_prefsuf_default_params", "alga_prefsuf_build_host", "alga_free_edges",
            "alga_prefsuf_build_device", "alga_prefsuf_last_stats", "alga_prefsuf_discover_device",
-           "alga_prefsuf_reduce_device", "alga_write_graph", "alga_ingest_default_params", "alga_ingest_files",
+           "alga_prefsuf_reduce_device", "alga_prefsuf_build_range_device", "alga_write_graph", "alga_ingest_default_params", "alga_ingest_files",
            "alga_free_node_set", "alga_sort_records_device", "alga_sort_edges_device", "alga_pkb_derive_params",
            "alga_can_align_batch_host", "alga_li_kmers_host", "alga_pkb_supplement_host", "alga_pkb_supplement_device",
            "alga_pkb_last_stats"]
@@ -124,6 +126,8 @@ def load_library():
     lib.alga_prefsuf_reduce_device.argtypes = [C.c_void_p, C.POINTER(_Nodes), C.POINTER(PrefSufParams), C.c_void_p,
                                                C.c_void_p, C.c_uint64, C.c_int32, C.c_int32, C.c_void_p,
                                                C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    lib.alga_prefsuf_build_range_device.argtypes = [C.c_void_p, C.POINTER(_Nodes), C.POINTER(PrefSufParams), C.c_int32, C.c_int32,
+                                                    C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
     lib.alga_write_graph.argtypes = [C.c_char_p, C.c_int32, C.c_void_p, C.c_uint64]
     lib.alga_sort_records_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p,
                                              C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
@@ -204,6 +208,10 @@ def derive_params(avg_len, trim_left=3, trim_right=3, scale=0.55):
     return L, rsoemo
 
 
+REDUCTION = {"auto": 0, "per_target": 1, "source_side": 2}     # alga_reduction
+ERR_UNSUPPORTED = -7
+
+
 class Engine:
     """One engine handle == one HIP device.  Mirrors the reference's GraphCreator life cycle:
     construct -> (setAlignFrom/To masks) -> build -> read the graph."""
@@ -238,10 +246,11 @@ class Engine:
         return buf.value.decode()
 
     @staticmethod
-    def params(min_overlap, rsoe_min_overlap, collect_stats=False):
+    def params(min_overlap, rsoe_min_overlap, collect_stats=False, reduction="auto"):
         p = PrefSufParams()
         load_library().alga_prefsuf_default_params(C.byref(p))
         p.min_overlap, p.rsoe_min_overlap, p.collect_stats = int(min_overlap), int(rsoe_min_overlap), int(bool(collect_stats))
+        p.reduction = REDUCTION[reduction] if isinstance(reduction, str) else int(reduction)
         return p
 
     def last_stats(self):
@@ -250,7 +259,8 @@ class Engine:
         return st.as_dict()
 
     # ---- host buffers in, edges out (the drop-in call) --------------------------------------
-    def prefsuf_host(self, words, lens, min_overlap, rsoe_min_overlap, align_from=None, align_to=None, collect_stats=False):
+    def prefsuf_host(self, words, lens, min_overlap, rsoe_min_overlap, align_from=None, align_to=None, collect_stats=False,
+                     reduction="auto"):
         words = np.ascontiguousarray(words, dtype=np.uint32)
         lens = np.ascontiguousarray(lens, dtype=np.int32)
         n = int(lens.shape[0])
@@ -261,7 +271,7 @@ class Engine:
             af = np.ascontiguousarray(align_from, dtype=np.uint8); keep.append(af); nd.align_from = af.ctypes.data
         if align_to is not None:
             at = np.ascontiguousarray(align_to, dtype=np.uint8); keep.append(at); nd.align_to = at.ctypes.data
-        p = self.params(min_overlap, rsoe_min_overlap, collect_stats)
+        p = self.params(min_overlap, rsoe_min_overlap, collect_stats, reduction)
         out = C.c_void_p()
         m = C.c_uint64()
         self._check(self._lib.alga_prefsuf_build_host(self._h, C.byref(nd), C.byref(p), C.byref(out), C.byref(m)))
@@ -285,15 +295,30 @@ class Engine:
         return nd
 
     def prefsuf_device(self, words, lens, min_overlap, rsoe_min_overlap, align_from=None, align_to=None, stream=None,
-                       collect_stats=False):
+                       collect_stats=False, reduction="auto"):
         """words: int32/uint32-viewed torch tensor [n, stride] on the device, lens: int32 [n].
         Returns (device pointer of alga_edge[n_edges], n_edges); the memory belongs to the engine."""
         nd = self._nodes_from_torch(words, lens, align_from, align_to)
-        p = self.params(min_overlap, rsoe_min_overlap, collect_stats)
+        p = self.params(min_overlap, rsoe_min_overlap, collect_stats, reduction)
         out = C.c_void_p()
         m = C.c_uint64()
         self._check(self._lib.alga_prefsuf_build_device(self._h, C.byref(nd), C.byref(p), C.c_void_p(stream or 0),
                                                         C.byref(out), C.byref(m)))
+        return out.value, int(m.value)
+
+    def build_range_device(self, words, lens, min_overlap, rsoe_min_overlap, src_begin, src_end, align_from=None, align_to=None,
+                           stream=None, collect_stats=False):
+        """Final edges of the sources [src_begin, src_end) by the source-side reduction -> (ptr, n_edges), or None when
+        that form is not exact for the input (ALGA_ERR_UNSUPPORTED): the caller then takes discover/exchange/reduce."""
+        nd = self._nodes_from_torch(words, lens, align_from, align_to)
+        p = self.params(min_overlap, rsoe_min_overlap, collect_stats)
+        out = C.c_void_p()
+        m = C.c_uint64()
+        rc = self._lib.alga_prefsuf_build_range_device(self._h, C.byref(nd), C.byref(p), int(src_begin), int(src_end),
+                                                       C.c_void_p(stream or 0), C.byref(out), C.byref(m))
+        if rc == ERR_UNSUPPORTED:
+            return None
+        self._check(rc)
         return out.value, int(m.value)
 
     def discover_device(self, words, lens, min_overlap, rsoe_min_overlap, src_begin, src_end, align_from=None,

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ALGA_AMD_ABI_VERSION 1
+#define ALGA_AMD_ABI_VERSION 2
 
 typedef enum {
     ALGA_OK = 0,
@@ -38,8 +38,18 @@ typedef enum {
     ALGA_ERR_HIP = -3,              /* a HIP call or kernel failed                            */
     ALGA_ERR_OUT_OF_MEMORY = -4,
     ALGA_ERR_CAPACITY = -5,         /* an internal 32-bit index space would overflow; shard   */
-    ALGA_ERR_IO = -6
+    ALGA_ERR_IO = -6,
+    ALGA_ERR_UNSUPPORTED = -7       /* the requested reduction form is not exact for this input: use the other one */
 } alga_status;
+
+/* Where the transitive reduction of GraphCreatorPrefSuf.cpp:397-483 is evaluated (same result either way):
+ *   PER_TARGET  : the literal replay of the reference's push order per target node (any input);
+ *   SOURCE_SIDE : per source node inside the probing wave, from the source's own raw overlaps;
+ *                 exact when max_len <= max_len_cap, max_len - min_overlap <= 63, min_overlap <= rsoe_min_overlap <=
+ *                 min(max_len, max_len_cap) + 1 and no live node has alignFrom without alignTo -- everything ALGA's
+ *                 command line can produce for reads up to ~140 nt after trimming with the default scale.
+ *   AUTO        : SOURCE_SIDE when those conditions hold (checked on the device), else PER_TARGET. */
+typedef enum { ALGA_REDUCTION_AUTO = 0, ALGA_REDUCTION_PER_TARGET = 1, ALGA_REDUCTION_SOURCE_SIDE = 2 } alga_reduction;
 
 typedef struct alga_engine alga_engine; /* opaque */
 
@@ -68,7 +78,8 @@ typedef struct {
                                  (include/GraphCreators/GraphCreatorPrefSuf.h:62)                 */
     int32_t max_len_cap;      /* 500 (src/GraphCreators/GraphCreatorPrefSuf.cpp:92)               */
     int32_t collect_stats;    /* != 0: fill the work counters of alga_prefsuf_stats               */
-    int32_t reserved[3];
+    int32_t reduction;        /* alga_reduction; SOURCE_SIDE fails with ALGA_ERR_UNSUPPORTED when not exact */
+    int32_t reserved[2];
 } alga_prefsuf_params;
 
 /* Work counters; the first four mirror GATHER_STATISTICS of the reference
@@ -87,7 +98,9 @@ typedef struct {
     double   ms_total;            /* device time of the last call, HIP events on the engine's stream */
     double   ms_seed, ms_probe, ms_group, ms_reduce, ms_emit;
     uint64_t nodes_live;          /* nodes with len>0                                            */
-    uint64_t reserved[3];
+    uint64_t reduction_used;      /* alga_reduction of the last build (1 or 2)                   */
+    uint64_t generic_sources;     /* SOURCE_SIDE: sources that needed the all-pairs path (collect_stats) */
+    uint64_t reserved[1];
 } alga_prefsuf_stats;
 
 /* ---- lifetime --------------------------------------------------------------------------- */
@@ -137,6 +150,15 @@ int  alga_prefsuf_reduce_device(alga_engine *e, const alga_nodes *nodes, const a
                                 const uint32_t *d_dst, const uint64_t *d_val, uint64_t n_records,
                                 int32_t dst_begin, int32_t dst_end, void *hip_stream,
                                 const alga_edge **d_edges, uint64_t *n_edges);
+
+/* Sharded form without an exchange: the final edges whose SOURCE node id is in [src_begin, src_end), by the source-side
+ * reduction (every rank holds the full node set; a source's edges depend on nothing another rank computes).  Returns
+ * ALGA_ERR_UNSUPPORTED when that form is not exact for the input (see alga_reduction) -- every rank gets the same answer
+ * for the same node set, except for the capacity case (a source with more than 192 raw overlaps), so ranks agree on the
+ * fallback with one flag all-reduce.  *d_edges: engine-owned, sorted by (src, dst), valid until the next call on `e`. */
+int  alga_prefsuf_build_range_device(alga_engine *e, const alga_nodes *nodes, const alga_prefsuf_params *p,
+                                     int32_t src_begin, int32_t src_end, void *hip_stream,
+                                     const alga_edge **d_edges, uint64_t *n_edges);
 
 /* Exchange helpers of the sharded form (device in, device out, engine-owned results):
  *   alga_sort_records_device  orders record slots by target id and drops the padding: the first *n_valid

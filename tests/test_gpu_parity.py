@@ -10,6 +10,7 @@ import pytest
 import alga_amd
 import gen_reads
 import oracle_lib as O
+from source_side_rule import preconditions
 
 pytestmark = pytest.mark.gpu
 
@@ -21,17 +22,37 @@ def eng():
     e.close()
 
 
-def _check(eng, words, lens, lo, rs, af=None, at=None, stats=True):
+def _check(eng, words, lens, lo, rs, af=None, at=None, stats=True, source_side=None):
+    """Both forms of the transitive reduction against the oracle: the per-target replay always, the source-side form
+    whenever it claims to be exact for the input (source_side=False: expected to decline, e.g. capacity)."""
     want, _, cnt = O.prefsuf(words, lens, lo, rs, af, at)
-    got = eng.prefsuf_host(words, lens, lo, rs, af, at, collect_stats=stats)
+    got = eng.prefsuf_host(words, lens, lo, rs, af, at, collect_stats=stats, reduction="per_target")
     assert got.shape == want.shape, (got.shape, want.shape)
     assert (got == want).all()
+    st = eng.last_stats()
+    assert st["reduction_used"] == 1
     if stats:
-        st = eng.last_stats()
         assert st["raw_overlaps"] == cnt["hash_equal"]
         assert st["transitive_listed"] == cnt["transitive_checks"]
         assert st["transitive_removed"] == cnt["transitive_removed"]
         assert st["edges"] == len(want)
+    exact = preconditions(lens, lo, rs, af, at) and int(np.max(lens, initial=0)) - lo <= 63
+    if source_side is None:
+        source_side = exact
+    if source_side:
+        got2 = eng.prefsuf_host(words, lens, lo, rs, af, at, collect_stats=stats, reduction="source_side")
+        assert got2.shape == want.shape and (got2 == want).all()
+        st = eng.last_stats()
+        assert st["reduction_used"] == 2 and st["edges"] == len(want)
+        if stats:
+            assert st["raw_overlaps"] == cnt["hash_equal"]
+    else:
+        with pytest.raises(alga_amd.AlgaError) as ei:
+            eng.prefsuf_host(words, lens, lo, rs, af, at, reduction="source_side")
+        assert ei.value.code == -7
+    got3 = eng.prefsuf_host(words, lens, lo, rs, af, at)                      # automatic choice
+    assert got3.shape == want.shape and (got3 == want).all()
+    assert eng.last_stats()["reduction_used"] == (2 if source_side else 1)
     return got
 
 
@@ -66,6 +87,10 @@ def _nodes(n, length, G, seed, err=0.0, min_length=None, both_strands=True, stri
     (2000, 64, 3000, 14, 0.0, None, 20, 40),      # W=4, short seed (40 bits)
     (1500, 150, 3000, 15, 0.03, 120, 16, 60),     # one-word seed
     (1200, 250, 6000, 16, 0.0, 200, 140, 190),    # W=16
+    (3000, 150, 9000, 19, 0.01, None, 90, 120),   # 150 nt, span 60: source-side form with errors
+    (2500, 144, 5000, 20, 0.0, 100, 82, 116),     # variable length incl. contained / prefix reads, span 62
+    (700, 100, 6000, 17, 0.0, None, 55, 77),      # low coverage: gaps too long for any big via (all-pairs path)
+    (3000, 100, 5000, 18, 0.004, 80, 50, 70),     # errors + variable length: several items per offset
 ])
 def test_random_sets_bit_exact(eng, n, length, G, seed, err, minlen, lo, rs):
     words, lens = _nodes(n, length, G, seed, err, minlen)
@@ -80,6 +105,7 @@ def test_masks_and_removed_nodes(eng):
     dead = rng.random(len(lens)) < 0.1
     lens = lens.copy(); lens[dead] = 0; words = words.copy(); words[dead] = 0
     _check(eng, words, lens, 66, 90, af, at)
+    _check(eng, words, lens, 66, 90, af, np.maximum(af, at))     # alignFrom implies alignTo: the source-side form applies
 
 
 def test_row_stride_padding(eng):
@@ -113,9 +139,56 @@ def test_degenerate_inputs(eng):
     _check(eng, words, lens, 60, 60)                                                   # only full-length overlaps
     # heavy repeats: 400 copies of 5 distinct reads (long seed-table chains, big in-lists, ties in the cap)
     codes, l5 = gen_reads.sample_reads(5, 80, 120, 26)
-    codes = np.repeat(codes, 80, axis=0)
-    w = alga_amd.pack_reads(codes)
+    codes80 = np.repeat(codes, 80, axis=0)
+    w = alga_amd.pack_reads(codes80)
+    # more raw overlaps per source than the source-side reduction holds (192) -> it declines, AUTO falls back
+    _check(eng, w, np.full(len(w), 80, np.int32), 40, 60, source_side=False)
+    # 25 copies: 65..192 raw overlaps per source, the multi-round all-pairs path of the source-side form
+    w = alga_amd.pack_reads(np.repeat(codes, 25, axis=0))
     _check(eng, w, np.full(len(w), 80, np.int32), 40, 60)
+
+
+def _tandem_nodes(seed, n_reads, genome_len, length, period):
+    rng = np.random.default_rng(seed)
+    g = rng.integers(0, 4, genome_len, dtype=np.uint8)
+    for s0 in range(0, genome_len - 400, 1500):
+        for k in range(1, 300 // period):
+            g[s0 + k * period: s0 + (k + 1) * period] = g[s0: s0 + period]
+    starts = np.unique(rng.integers(0, genome_len - length, n_reads))
+    fw = np.stack([g[p: p + length] for p in starts])
+    fw = np.unique(fw, axis=0)
+    codes = np.stack([3 - fw[:, ::-1], fw], axis=1).reshape(-1, length)
+    return alga_amd.pack_reads(codes), np.full(len(codes), length, np.int32)
+
+
+@pytest.mark.parametrize("seed,n_reads,period", [(41, 700, 5), (42, 2500, 7), (43, 1200, 23)])
+def test_tandem_repeats_same_target_at_several_offsets(eng, seed, n_reads, period):
+    words, lens = _tandem_nodes(seed, n_reads, 6000, 60, period)
+    _check(eng, words, lens, 33, 46)
+    st_needed = eng.prefsuf_host(words, lens, 33, 46, collect_stats=True, reduction="source_side")
+    assert eng.last_stats()["generic_sources"] > 0           # the all-pairs path of the source-side form really ran
+
+
+def test_source_side_range_build_needs_no_exchange(eng):
+    import torch
+    from alga_amd.engine import device_edges_to_numpy
+    words, lens = _nodes(4000, 150, 9000, 32, err=0.002)
+    want, _, _ = O.prefsuf(words, lens, 90, 120)
+    dw = torch.from_numpy(words.view(np.int32)).cuda()
+    dl = torch.from_numpy(lens).cuda()
+    n = len(lens)
+    parts = []
+    for a, b in ((0, n // 3), (n // 3, n // 3), (n // 3, n // 2 + 1), (n // 2 + 1, n)):
+        r = eng.build_range_device(dw, dl, 90, 120, a, b)
+        assert r is not None
+        parts.append(device_edges_to_numpy(*r))
+        assert len(parts[-1]) == 0 or (parts[-1][:, 0].min() >= a and parts[-1][:, 0].max() < b)
+    assert (np.concatenate(parts) == want).all()              # ranges in order: already the single-GPU byte order
+    # an input the source-side form declines (reads longer than min_overlap + 63)
+    words, lens = _nodes(300, 250, 3000, 33)
+    dw = torch.from_numpy(words.view(np.int32)).cuda()
+    dl = torch.from_numpy(lens).cuda()
+    assert eng.build_range_device(dw, dl, 137, 190, 0, len(lens)) is None
 
 
 def test_invalid_arguments_are_errors(eng):
