@@ -66,8 +66,9 @@ int prepare(alga_engine *e, const alga_nodes *nodes, const alga_prefsuf_params *
     c.rsoemo = p->rsoe_min_overlap;
     c.Lcap = std::min(out.max_len, p->max_len_cap) + 1;              // last value of currentPrefSufLength
     c.soes = p->soes;
-    c.seed_words = (2 * c.Lmin + 31) >> 5;
-    c.seed_last_mask = (2 * c.Lmin & 31) ? ((1u << (2 * c.Lmin & 31)) - 1u) : 0xFFFFFFFFu;
+    const int seed_nt = std::min(c.Lmin, SEED_MAX_NT);             // candidates are verified over the whole overlap anyway
+    c.seed_words = (2 * seed_nt + 31) >> 5;
+    c.seed_last_mask = (2 * seed_nt & 31) ? ((1u << (2 * seed_nt & 31)) - 1u) : 0xFFFFFFFFu;
     // The reversal at L == rsoemo (GraphCreatorPrefSuf.cpp:288) only happens if that iteration exists.
     // If rsoemo lies beyond the last iteration every overlap stays "small", the graph is never
     // reversed mid-way and the final reverseGraphInPlace (:107) hands back the REVERSED graph.

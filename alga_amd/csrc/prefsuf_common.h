@@ -34,12 +34,16 @@ ALGA_HD inline bool ol_small(uint32_t ol) { return (ol & OL_SMALL) != 0; }
 // ---- seed fingerprint of a 2*min_overlap-bit window, fed 32 bits at a time --------------------
 // Only a filter: every candidate is verified bit for bit afterwards, so the fingerprint never
 // decides an edge (the reference decides on two modular hashes, GraphCreatorPrefSuf.cpp:386-387).
+// Step = multiply-with-carry on 32-bit halves: one v_mad_u64_u32 per word (a full 64-bit multiply is four quarter-rate
+// instructions on CDNA).  The seed covers the first min(min_overlap, SEED_MAX_NT) nucleotides of a window.
+constexpr int SEED_MAX_NT = 64;
+constexpr int SEED_MAX_WORDS = SEED_MAX_NT / 16;
 ALGA_HD inline uint64_t fp_init() { return 0x243F6A8885A308D3ull; }
 ALGA_HD inline uint64_t fp_step(uint64_t h, uint32_t w) {
-    h = (h ^ (uint64_t) w) * 0xff51afd7ed558ccdull;
-    return h ^ (h >> 32);
+    return (uint64_t) ((uint32_t) h ^ w) * 0x9E3779B1u + (h >> 32);
 }
 ALGA_HD inline uint64_t fp_final(uint64_t h) {
+    h ^= h >> 31;
     h *= 0xc4ceb9fe1a85ec53ull;
     return h ^ (h >> 29);
 }
@@ -86,7 +90,7 @@ struct PrefSufCfg {
     int32_t rsoemo;      // REMOVE_SMALL_OVERLAP_EDGES_MIN_OVERLAP
     int32_t Lcap;        // last overlap length iterated: min(maxReadLength, cap) + 1
     int32_t soes;        // 3
-    int32_t seed_words;  // ceil(2*Lmin/32)
+    int32_t seed_words;  // ceil(2*seed_nt/32), seed_nt = min(Lmin, SEED_MAX_NT)
     uint32_t seed_last_mask;
     int32_t reversed;    // reference quirk: rsoemo beyond the last iteration -> graph comes out reversed
     int32_t stats;

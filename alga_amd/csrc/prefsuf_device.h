@@ -85,6 +85,7 @@ constexpr int WFLUSH = 128;           // flush once this many are buffered
 constexpr int REC_CHUNK = 1024;       // records reserved per global atomic (per-target pipeline: ~11 records per source)
 constexpr int REC_CHUNK_LOCAL = 128;  // same, source-side reduction (~1 record per source)
 constexpr int WFLUSH_LOCAL = 64;
+constexpr int WBUF_LOCAL = 128;       // per-wave LDS record buffer of the source-side form
 
 // keep a >= b >= c = the three largest keys seen (branch-free: the three keys must stay in registers)
 __device__ __forceinline__ void top3_insert(uint64_t &a, uint64_t &b, uint64_t &c, uint64_t k) {
@@ -128,6 +129,7 @@ struct WaveLds {           // per-wave LDS views
     uint32_t *sb;          // staged tail of the source
     uint32_t *candC; uint32_t *candW; uint32_t *candN;
     uint32_t *recC; unsigned long long *recV; uint32_t *recN;
+    uint32_t *actB = nullptr; uint32_t *actT = nullptr;      // compacted windows that passed the filter: bucket, tag | lane << 23
 };
 
 // Convergent: all 64 lanes.  Moves the wave's LDS record buffer to the global record list.
@@ -135,12 +137,12 @@ struct WaveLds {           // per-wave LDS views
 //   sustains only ~88 ops/us chip-wide: per-record or per-source reservations cost tens of ms).  A flush fills the
 //   open chunk to the brim before it reserves the next one, so only the last chunk of a wave carries padding.
 //   chunk_fill == CHUNK means "no chunk reserved yet".
-template <int CHUNK>
+template <int CHUNK, int WB = WBUF>
 __device__ __forceinline__ void flush_records(const ProbeOut &o, const WaveLds &w, uint64_t &chunk_base, int &chunk_fill) {
     const int lane = lane_id();
     wave_lds_fence();
     int n = (int) __builtin_amdgcn_readfirstlane((int) *w.recN);
-    if (n > WBUF) n = WBUF;                      // the excess went out through the direct path
+    if (n > WB) n = WB;                          // the excess went out through the direct path
     if (n == 0) return;
     int done = 0;
     while (done < n) {                           // wave-uniform
@@ -220,7 +222,7 @@ __device__ __forceinline__ bool verify_overlap(const NodesDev &nd, const uint32_
 // Host-checked preconditions (engine.hip local_ok): max_len - Lmin <= 63, max_len <= cap, alignFrom => alignTo,
 // Lmin <= rsoemo <= Lcap.
 // ------------------------------------------------------------------------------------------
-constexpr int ITEMMAX = 192;              // raw overlaps of one source held in LDS; more -> CNT_LOCAL_OVERFLOW, per-target pipeline
+constexpr int ITEMMAX = 160;              // raw overlaps of one source held in LDS; more -> CNT_LOCAL_OVERFLOW, per-target pipeline
 constexpr uint32_t ITEM_FROM = 1u << 18;
 
 struct ItemLds { uint32_t *C; uint32_t *M; uint4 *O; uint8_t *T; uint32_t *N; };
@@ -266,7 +268,7 @@ __device__ __forceinline__ void item_overhang_global(const NodesDev &nd, const I
 }
 
 // Convergent.  n = items of source A in `it` (<= ITEMMAX), overhangs filled.
-template <bool STATS>
+template <bool STATS, int WB>
 __device__ __forceinline__ void local_reduce(const NodesDev &nd, const PrefSufCfg &cfg, const ItemLds &it, const WaveLds &w, const ProbeOut &o,
                                              int A, int lenA, int n, uint64_t &st_rec, uint64_t &st_cmp, uint64_t &st_generic) {
     const int lane = lane_id();
@@ -275,7 +277,7 @@ __device__ __forceinline__ void local_reduce(const NodesDev &nd, const PrefSufCf
         const int L = lenA - d;
         const unsigned long long val = ((unsigned long long) ol_pack(d, L, L < cfg.rsoemo) << 32) | (uint32_t) A;
         const uint32_t i = atomicAdd(w.recN, 1u);
-        if (i < (uint32_t) WBUF) { w.recC[i] = C; w.recV[i] = val; }
+        if (i < (uint32_t) WB) { w.recC[i] = C; w.recV[i] = val; }
         else store_record(o, atomicAdd(&o.counters[CNT_RECORDS], 1ull), C, val);
         st_rec++;
     };

@@ -111,17 +111,20 @@ k_probe_sources(NodesDev nd, PrefSufCfg cfg, const unsigned long long *__restric
     __shared__ uint32_t sB[PROBE_WAVES][STAGE_WORDS];
     __shared__ uint32_t sCandC[PROBE_WAVES][CANDMAX];
     __shared__ uint32_t sCandW[PROBE_WAVES][CANDMAX];
-    __shared__ uint32_t sRecC[PROBE_WAVES][WBUF];
-    __shared__ unsigned long long sRecV[PROBE_WAVES][WBUF];
+    constexpr int WB = LOCAL ? WBUF_LOCAL : WBUF;
+    __shared__ uint32_t sRecC[PROBE_WAVES][WB];
+    __shared__ unsigned long long sRecV[PROBE_WAVES][WB];
     __shared__ uint32_t sCnt[PROBE_WAVES][3];
     __shared__ uint32_t sItemC[PROBE_WAVES][LOCAL ? ITEMMAX : 1];
     __shared__ uint32_t sItemM[PROBE_WAVES][LOCAL ? ITEMMAX : 1];
     __shared__ uint4 sItemO[PROBE_WAVES][LOCAL ? ITEMMAX : 1];
     __shared__ uint8_t sItemT[PROBE_WAVES][64];
+    __shared__ uint32_t sActB[PROBE_WAVES][64];
+    __shared__ uint32_t sActT[PROBE_WAVES][64];
     constexpr int CHUNK = LOCAL ? REC_CHUNK_LOCAL : REC_CHUNK;
     const int wave = (int) (threadIdx.x >> 6);
     const int lane = lane_id();
-    WaveLds w{sB[wave], sCandC[wave], sCandW[wave], &sCnt[wave][0], sRecC[wave], sRecV[wave], &sCnt[wave][1]};
+    WaveLds w{sB[wave], sCandC[wave], sCandW[wave], &sCnt[wave][0], sRecC[wave], sRecV[wave], &sCnt[wave][1], sActB[wave], sActT[wave]};
     ItemLds it{sItemC[wave], sItemM[wave], sItemO[wave], sItemT[wave], &sCnt[wave][2]};
     if (lane == 0) { *w.candN = 0; *w.recN = 0; *it.N = 0; }
     uint64_t chunk_base = 0;
@@ -188,8 +191,9 @@ k_probe_sources(NodesDev nd, PrefSufCfg cfg, const unsigned long long *__restric
             return -1;
         };
 
+        int n_items = 0;                                   // LOCAL: verified overlaps of this source so far (uniform)
         for (int base = 0; base < nwin; base += 64) {
-            // ---- phase 1a: one window per lane -> fingerprint -> (bucket, tag) ----------------------------------
+            // ---- phase 1a: one window per lane -> fingerprint of its first seed_nt nucleotides -> (bucket, tag) ----
             const int widx = base + lane;
             const bool wvalid = widx < nwin;
             uint32_t my_b = 0, my_tag = 0xFFFFFFFFu;       // tag 0xFFFFFFFF (> 23 bits) never matches an entry
@@ -202,10 +206,16 @@ k_probe_sources(NodesDev nd, PrefSufCfg cfg, const unsigned long long *__restric
 #if defined(ABLATE) && ABLATE == 3
                 h = fp_step(h, (uint32_t) B * 64u + (uint32_t) widx + sb[my_q]);
 #else
-                for (int k = 0; k < cfg.seed_words; k++) {
-                    uint32_t x = funnel(sb[my_q + k], sb[my_q + k + 1], my_r);
-                    if (k == cfg.seed_words - 1) x &= cfg.seed_last_mask;
-                    h = fp_step(h, x);
+                uint32_t x[SEED_MAX_WORDS + 1];            // all reads in flight before the first use (the tail has slack words)
+#pragma unroll
+                for (int k = 0; k <= SEED_MAX_WORDS; k++) x[k] = sb[my_q + k];
+#pragma unroll
+                for (int k = 0; k < SEED_MAX_WORDS; k++) {
+                    if (k < cfg.seed_words) {              // uniform
+                        uint32_t v = funnel(x[k], x[k + 1], my_r);
+                        if (k == cfg.seed_words - 1) v &= cfg.seed_last_mask;
+                        h = fp_step(h, v);
+                    }
                 }
 #endif
                 h = fp_final(h);
@@ -228,96 +238,116 @@ k_probe_sources(NodesDev nd, PrefSufCfg cfg, const unsigned long long *__restric
             asm volatile("" :: "v"(my_b), "v"(my_tag));
             continue;
 #endif
-            // ---- phase 1b: FOUR lanes read one 64-byte bucket with ONE request (16 buckets per instruction) -----
-            // A lane-private 4 x 16 B read of a random line costs four requests per window in the vector memory
-            // path; reading a line with four adjacent lanes costs one.
+            // ---- phase 1b: the windows that passed the filter are compacted; FOUR lanes read one 64-byte bucket with ONE
+            // request (16 buckets per instruction).  A lane-private 4 x 16 B read of a random line costs four requests in
+            // the vector memory path.  Candidates are appended with ballot + prefix count (no LDS atomics).
             const int sub = lane & 3;
-            bool my_spill = false;                         // my window's bucket was full: entries may have spilled on
-            uint32_t tw4[4];
-            uint4 e4[4];
-#pragma unroll
-            for (int rr = 0; rr < 4; rr++) {               // all four requests are in flight before the first use
-                const int wl = 16 * rr + (lane >> 2);      // window (lane index) served by this lane group
-                const uint32_t bw = (uint32_t) __shfl((int) my_b, wl);
-                tw4[rr] = (uint32_t) __shfl((int) my_tag, wl);
-                e4[rr] = make_uint4(0xFFFFFFFFu, 0u, 0xFFFFFFFFu, 0u);
-                if (tw4[rr] != 0xFFFFFFFFu) e4[rr] = reinterpret_cast<const uint4 *>(table + (size_t) bw * SEED_BUCKET)[sub];
+            const uint64_t amask = __ballot(my_tag != 0xFFFFFFFFu);
+            const int nact = __popcll(amask);
+            if (my_tag != 0xFFFFFFFFu) {
+                const int rank = (int) __builtin_amdgcn_mbcnt_hi((uint32_t) (amask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) amask, 0u));
+                w.actB[rank] = my_b;
+                w.actT[rank] = my_tag | ((uint32_t) lane << 23);
             }
-#pragma unroll
-            for (int rr = 0; rr < 4; rr++) {
-                const int wl = 16 * rr + (lane >> 2);
-                const uint32_t tw = tw4[rr];
-                const uint4 e = e4[rr];
-                if (STATS && tw != 0xFFFFFFFFu) st_slots += 2;
+            wave_lds_fence();
+            int ncand = 0;                                 // uniform
+            bool overflow_spill = false;
+            auto append = [&](bool hit, uint32_t id, uint32_t tl, int wl) {      // convergent
+                const uint64_t m = __ballot(hit);
+                if (hit) {
+                    const int ci = ncand + (int) __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, 0u));
+                    if (ci < CANDMAX) { w.candC[ci] = id; w.candW[ci] = (uint32_t) (base + wl) | ((tl & 511u) << 16); }
+                }
+                ncand += __popcll(m);
+            };
+            for (int r0 = 0; r0 < nact; r0 += 16) {
+                const int qi = r0 + (lane >> 2);
+                const bool qv = qi < nact;
+                uint32_t bw = 0, tw = 0xFFFFFFFFu;
+                int wl = 0;
+                uint4 e = make_uint4(0xFFFFFFFFu, 0u, 0xFFFFFFFFu, 0u);
+                if (qv) {
+                    bw = w.actB[qi];
+                    const uint32_t t = w.actT[qi];
+                    tw = t & 0x7FFFFFu; wl = (int) (t >> 23);
+                    e = reinterpret_cast<const uint4 *>(table + (size_t) bw * SEED_BUCKET)[sub];
+                    if (STATS) st_slots += 2;
+                }
                 const int Lw = Lspan - (base + wl);
                 // candidate: same tag, long enough for a prefix of length L (:215), not B itself (:386)
-                if (e.x != 0xFFFFFFFFu && (e.y >> 9) == tw && (int) (e.y & 511u) >= Lw && (int) e.x != B) {
-                    const uint32_t ci = atomicAdd(w.candN, 1u);
-                    if (ci < (uint32_t) CANDMAX) { w.candC[ci] = e.x; w.candW[ci] = (uint32_t) (base + wl) | ((e.y & 511u) << 16); }
-                }
-                if (e.z != 0xFFFFFFFFu && (e.w >> 9) == tw && (int) (e.w & 511u) >= Lw && (int) e.z != B) {
-                    const uint32_t ci = atomicAdd(w.candN, 1u);
-                    if (ci < (uint32_t) CANDMAX) { w.candC[ci] = e.z; w.candW[ci] = (uint32_t) (base + wl) | ((e.w & 511u) << 16); }
-                }
-                const bool full = sub == 3 && e.z != 0xFFFFFFFFu;
-                const uint64_t fm = __ballot(full);        // bit 4j+3 <-> window 16*rr + j
-                if ((lane >> 4) == rr) my_spill = (fm >> (4 * (lane & 15) + 3)) & 1ull;
-            }
-            // ---- phase 1c (rare): windows whose bucket was full walk the following buckets on their own ----------
-            if (my_spill) {
-                const int L = Lspan - widx;
-                uint32_t b = (my_b + 1 == n_buckets) ? 0u : my_b + 1;
-                for (;;) {
-                    const uint4 *bp = reinterpret_cast<const uint4 *>(table + (size_t) b * SEED_BUCKET);
-                    const uint4 e0 = bp[0], e1 = bp[1], e2 = bp[2], e3 = bp[3];
-                    if (STATS) st_slots += 8;
-#define ALGA_SLOT(ID, TL)                                                                                           \
-                    if ((ID) != 0xFFFFFFFFu && ((TL) >> 9) == my_tag && (int) ((TL) & 511u) >= L && (int) (ID) != B) {   \
-                        const uint32_t ci = atomicAdd(w.candN, 1u);                                                       \
-                        if (ci < (uint32_t) CANDMAX) { w.candC[ci] = (ID); w.candW[ci] = (uint32_t) widx | (((TL) & 511u) << 16); } \
+                append(e.x != 0xFFFFFFFFu && (e.y >> 9) == tw && (int) (e.y & 511u) >= Lw && (int) e.x != B, e.x, e.y, wl);
+                append(e.z != 0xFFFFFFFFu && (e.w >> 9) == tw && (int) (e.w & 511u) >= Lw && (int) e.z != B, e.z, e.w, wl);
+                // ---- phase 1c (rare): a full bucket may have spilled entries into the following ones; the wave walks them
+                uint64_t fm = __ballot(qv && sub == 3 && e.z != 0xFFFFFFFFu);
+                while (fm) {                               // uniform
+                    const int fl = __builtin_ctzll(fm);
+                    fm &= fm - 1;
+                    uint32_t b = (uint32_t) __builtin_amdgcn_readlane((int) bw, fl);
+                    const uint32_t stag = (uint32_t) __builtin_amdgcn_readlane((int) tw, fl);
+                    const int swl = __builtin_amdgcn_readlane(wl, fl);
+                    const int sL = Lspan - (base + swl);
+                    for (;;) {
+                        b = (b + 1 == n_buckets) ? 0u : b + 1;
+                        uint4 f = make_uint4(0xFFFFFFFFu, 0u, 0xFFFFFFFFu, 0u);
+                        if (lane < 4) f = reinterpret_cast<const uint4 *>(table + (size_t) b * SEED_BUCKET)[lane];
+                        if (STATS && lane < 4) st_slots += 2;
+                        append(f.x != 0xFFFFFFFFu && (f.y >> 9) == stag && (int) (f.y & 511u) >= sL && (int) f.x != B, f.x, f.y, swl);
+                        append(f.z != 0xFFFFFFFFu && (f.w >> 9) == stag && (int) (f.w & 511u) >= sL && (int) f.z != B, f.z, f.w, swl);
+                        if ((uint32_t) __builtin_amdgcn_readlane((int) f.z, 3) == 0xFFFFFFFFu) break;     // bucket not full: nothing spilled past it
                     }
-                    ALGA_SLOT(e0.x, e0.y) ALGA_SLOT(e0.z, e0.w) ALGA_SLOT(e1.x, e1.y) ALGA_SLOT(e1.z, e1.w)
-                    ALGA_SLOT(e2.x, e2.y) ALGA_SLOT(e2.z, e2.w) ALGA_SLOT(e3.x, e3.y) ALGA_SLOT(e3.z, e3.w)
-#undef ALGA_SLOT
-                    if (e3.z == 0xFFFFFFFFu) break;        // bucket not full: nothing spilled past it
-                    b = (b + 1 == n_buckets) ? 0u : b + 1;
                 }
             }
+            (void) overflow_spill;
             // ---- phase 2: candidates -> exact 2-bit compare of C[0, L) with B[off, off+L) ----------------------------
             wave_lds_fence();
 #if defined(ABLATE) && ABLATE == 2
-            if (lane == 0) *w.candN = 0;
-            wave_lds_fence();
             continue;
 #endif
-            const int ncand_raw = (int) __builtin_amdgcn_readfirstlane((int) *w.candN);
-            if (ncand_raw > CANDMAX) {
-                // More tag hits than the buffer holds (heavy repeats): the buffered ones are dropped and the whole
-                // 64-window batch is verified the slow way, window by window, straight from the table.
-                if (wvalid) {
-                    const int L = Lspan - widx;
-                    uint32_t b = my_b;
-                    for (;;) {
-                        const unsigned long long *bp = table + (size_t) b * SEED_BUCKET;
-                        bool full = true;
-                        for (int j = 0; j < SEED_BUCKET; j++) {
-                            const unsigned long long en = bp[j];
-                            const uint32_t id = (uint32_t) en, tl = (uint32_t) (en >> 32);
-                            if (id == 0xFFFFFFFFu) { full = false; break; }
-                            if ((tl >> 9) == my_tag && (int) (tl & 511u) >= L && (int) id != B &&
-                                verify_overlap<0>(nd, sb, (int) id, my_q, my_r, L)) {
-                                const int slot = classify((int) id, L, (int) (tl & 511u));
-                                if (LOCAL) item_overhang_global(nd, it, slot, (int) id, L, (int) (tl & 511u));
+            if (ncand > CANDMAX || NQ == 0) {
+                // NQ == 0: rows are not 16-byte aligned / longer than the wide path takes.  ncand > CANDMAX: more tag hits
+                // than the buffer holds (heavy repeats): the buffered ones are dropped and the whole 64-window batch is
+                // verified the slow way, window by window, straight from the table.  Both use LDS-atomic bookkeeping.
+                if (LOCAL) { if (lane == 0) *it.N = (uint32_t) n_items; wave_lds_fence(); }
+                if (ncand > CANDMAX) {
+                    if (wvalid && my_tag != 0xFFFFFFFFu) {
+                        const int L = Lspan - widx;
+                        uint32_t b = my_b;
+                        for (;;) {
+                            const unsigned long long *bp = table + (size_t) b * SEED_BUCKET;
+                            bool full = true;
+                            for (int j = 0; j < SEED_BUCKET; j++) {
+                                const unsigned long long en = bp[j];
+                                const uint32_t id = (uint32_t) en, tl = (uint32_t) (en >> 32);
+                                if (id == 0xFFFFFFFFu) { full = false; break; }
+                                if ((tl >> 9) == my_tag && (int) (tl & 511u) >= L && (int) id != B &&
+                                    verify_overlap<0>(nd, sb, (int) id, my_q, my_r, L)) {
+                                    const int slot = classify((int) id, L, (int) (tl & 511u));
+                                    if (LOCAL) item_overhang_global(nd, it, slot, (int) id, L, (int) (tl & 511u));
+                                }
+                            }
+                            if (!full) break;
+                            b = (b + 1 == n_buckets) ? 0u : b + 1;
+                        }
+                    }
+                } else {
+                    for (int c0 = 0; c0 < ncand; c0 += 64) {
+                        const int ci = c0 + lane;
+                        if (ci < ncand) {
+                            const int C = (int) w.candC[ci];
+                            const uint32_t cw = w.candW[ci];
+                            const int L = Lspan - (int) (cw & 0xFFFFu);
+                            const int bit = 2 * (lenB - L) - 32 * w0;
+                            if (verify_overlap<0>(nd, sb, C, bit >> 5, bit & 31, L)) {
+                                const int slot = classify(C, L, (int) (cw >> 16));
+                                if (LOCAL) item_overhang_global(nd, it, slot, C, L, (int) (cw >> 16));
                             }
                         }
-                        if (!full) break;
-                        b = (b + 1 == n_buckets) ? 0u : b + 1;
                     }
                 }
-            } else if (NQ > 0) {
+                if (LOCAL) { wave_lds_fence(); n_items = (int) __builtin_amdgcn_readfirstlane((int) *it.N); }
+            } else {
                 // four lanes per candidate: lane `sub` loads 16 bytes of C's row (one request per row), compares its
                 // four words, the group ORs its differences
-                const int ncand = ncand_raw;
                 for (int c0 = 0; c0 < ncand; c0 += 32) {          // two groups of 16 candidates per trip: both loads in flight
                     int Cc[2], Lc[2], Nc[2];
                     uint4 cc[2];
@@ -346,18 +376,33 @@ k_probe_sources(NodesDev nd, PrefSufCfg cfg, const unsigned long long *__restric
                             const int nwL = (2 * L + 31) >> 5;
                             const uint32_t lastmask = (2 * L & 31) ? ((1u << (2 * L & 31)) - 1u) : 0xFFFFFFFFu;
                             const uint32_t cw[4] = {cc[g].x, cc[g].y, cc[g].z, cc[g].w};
+                            uint32_t y[5];
+#pragma unroll
+                            for (int j = 0; j < 5; j++) y[j] = sb[q + 4 * sub + j];
 #pragma unroll
                             for (int j = 0; j < 4; j++) {
                                 const int k = 4 * sub + j;
                                 const uint32_t m = k < nwL - 1 ? 0xFFFFFFFFu : (k == nwL - 1 ? lastmask : 0u);
-                                diff |= (funnel(sb[q + k], sb[q + k + 1], r) ^ cw[j]) & m;
+                                diff |= (funnel(y[j], y[j + 1], r) ^ cw[j]) & m;
                             }
                         }
                         diff = quad_or(diff);
-                        int slot = -1;
-                        if (act[g] && sub == 0 && diff == 0) slot = classify(Cc[g], Lc[g], Nc[g]);
+                        const bool pass = act[g] && sub == 0 && diff == 0;
                         if (LOCAL) {
-                            // the quad holds C's row: word p of the overhang stream = bits [2L + 32(p - ws), ...) of the row
+                            // item slots by ballot + prefix count; the quad that holds C's row fills the item's overhang:
+                            // word k of it = bits [2L + 32k, 2L + 32k + 32) of the row
+                            const uint64_t pm = __ballot(pass);
+                            int slot = -1;
+                            if (pass) {
+                                if (STATS) st_raw++;
+                                slot = n_items + (int) __builtin_amdgcn_mbcnt_hi((uint32_t) (pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) pm, 0u));
+                                if (slot < ITEMMAX) {
+                                    uint32_t m = (uint32_t) (lenB - Lc[g]) | ((uint32_t) Nc[g] << 9);
+                                    if (nd.from == nullptr || nd.from[Cc[g]]) m |= ITEM_FROM;
+                                    it.C[slot] = (uint32_t) Cc[g]; it.M[slot] = m;
+                                }
+                            }
+                            n_items += __popcll(pm);
                             slot = quad_bcast0(slot);
                             const uint32_t nxt = sub == 3 ? 0u : quad_next(cc[g].x);
                             if (slot >= 0 && slot < ITEMMAX) {
@@ -370,41 +415,20 @@ k_probe_sources(NodesDev nd, PrefSufCfg cfg, const unsigned long long *__restric
                                     if (k >= 0 && k < 4) ow[k] = funnel(cw[j], cw[j + 1], r);
                                 }
                             }
-                        }
-                    }
-                }
-            } else {
-                const int ncand = ncand_raw;
-                for (int c0 = 0; c0 < ncand; c0 += 64) {
-                    const int ci = c0 + lane;
-                    if (ci < ncand) {
-                        const int C = (int) w.candC[ci];
-                        const uint32_t cw = w.candW[ci];
-                        const int L = Lspan - (int) (cw & 0xFFFFu);
-                        const int bit = 2 * (lenB - L) - 32 * w0;
-                        if (verify_overlap<0>(nd, sb, C, bit >> 5, bit & 31, L)) {
-                            const int slot = classify(C, L, (int) (cw >> 16));
-                            if (LOCAL) item_overhang_global(nd, it, slot, C, L, (int) (cw >> 16));
-                        }
+                        } else if (pass) classify(Cc[g], Lc[g], Nc[g]);
                     }
                 }
             }
-            wave_lds_fence();
-            if (lane == 0) *w.candN = 0;
-            wave_lds_fence();
         }
         if (LOCAL) {
             wave_lds_fence();
-            const int n_items = (int) __builtin_amdgcn_readfirstlane((int) *it.N);
             if (n_items > ITEMMAX) {                       // the engine repeats the build with the per-target pipeline
                 if (lane == 0) atomicAdd(&o.counters[CNT_LOCAL_OVERFLOW], 1ull);
             } else if (n_items > 0) {
-                local_reduce<STATS>(nd, cfg, it, w, o, B, lenB, n_items, st_rec, st_cmp, st_generic);
+                local_reduce<STATS, WB>(nd, cfg, it, w, o, B, lenB, n_items, st_rec, st_cmp, st_generic);
             }
-            if (lane == 0) *it.N = 0;
-            wave_lds_fence();
             const int nb = (int) __builtin_amdgcn_readfirstlane((int) *w.recN);
-            if (nb >= WFLUSH_LOCAL) flush_records<CHUNK>(o, w, chunk_base, chunk_fill);
+            if (nb >= WFLUSH_LOCAL) flush_records<CHUNK, WB>(o, w, chunk_base, chunk_fill);
             continue;
         }
         // per-source small-overlap cap: the reference keeps the LAST `SOES`=3 pushes in (L asc, C asc)
@@ -428,7 +452,7 @@ k_probe_sources(NodesDev nd, PrefSufCfg cfg, const unsigned long long *__restric
         wave_lds_fence();
         if (nbuf + nwon >= WFLUSH) flush_records<CHUNK>(o, w, chunk_base, chunk_fill);
     }
-    flush_records<CHUNK>(o, w, chunk_base, chunk_fill);
+    flush_records<CHUNK, WB>(o, w, chunk_base, chunk_fill);
     close_chunk<CHUNK>(o, chunk_base, chunk_fill);
     st_rec = wave_sum_u64(st_rec);
     if (lane == 0 && st_rec) atomicAdd(&o.counters[CNT_VALID_RECORDS], (unsigned long long) st_rec);

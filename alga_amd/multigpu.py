@@ -1,6 +1,13 @@
 """One process per GPU: sharding of the PrefSuf build across ranks (torch.distributed = RCCL on ROCm).
 
 Layout: the packed node set is replicated on every GPU (36-48 B/read; 4.8 GB at 100 M nodes, HBM is 288 GB).
+
+Source-side form (alga_reduction; the normal case for short reads): rank r builds the FINAL edges of
+the sources in its contiguous id range -- nothing a rank computes depends on another rank -- and the only collectives are
+one flag all-reduce (does every rank's input allow the form?) and the all_gather of the edge lists, which arrive in
+(src, dst) order because the ranges are ascending.
+
+Per-target form (any input; taken by all ranks when one of them cannot use the source-side form):
   1. discover  rank r probes the SOURCES of its contiguous id range against the full seed table and applies the
                per-source small-overlap cap locally (the cap is per source, so it needs no exchange), then orders
                its records by target id (device radix sort): the slice for every owner is contiguous
@@ -38,6 +45,15 @@ class HipBackend:
         ptr, m = self.eng.prefsuf_device(self.w, self.l, self.lo, self.rs, collect_stats=collect_stats)
         self.stats = self.eng.last_stats()
         return device_view(ptr, (m, 3), self.device)
+
+    def build_range(self, src_begin, src_end, collect_stats=False):
+        """Final edges of the sources in the range (tensor [m, 3]) or None when the source-side form is not exact here."""
+        from .engine import device_view
+        r = self.eng.build_range_device(self.w, self.l, self.lo, self.rs, src_begin, src_end, collect_stats=collect_stats)
+        if r is None:
+            return None
+        self.stats = self.eng.last_stats()
+        return device_view(r[0], (r[1], 3), self.device)
 
     def discover_sorted(self, src_begin, src_end, collect_stats=False):
         from .engine import device_view
@@ -84,6 +100,18 @@ class ShardedPrefSuf:
         import torch
         dist, be, r, nr, b = self.dist, self.be, self.rank, self.world, self.bounds
         dev = be.device
+        # 0. source-side form: final edges of my sources; all ranks must agree to use it
+        mine = be.build_range(b[r], b[r + 1], collect_stats)
+        flag = torch.tensor([0 if mine is not None else 1], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if int(flag.item()) == 0:
+            st = dict(be.stats)
+            t2 = time.perf_counter()
+            self.edges = self._gather(mine, ordered=True)
+            be.sync()
+            st["edges"] = int(self.edges.shape[0])
+            st["ms_exchange"] = (time.perf_counter() - t2) * 1e3
+            return self._finish(st, collect_stats)
         # 1. discover + order by target
         rdst, rval = be.discover_sorted(b[r], b[r + 1], collect_stats)
         st = dict(be.stats)
@@ -106,7 +134,19 @@ class ShardedPrefSuf:
         mine = be.reduce(recv_d, recv_v, b[r], b[r + 1], collect_stats)
         st.update({k: be.stats[k] for k in be.stats if k.startswith("ms_") or k.startswith("transitive") or k == "max_in_records"})
         t2 = time.perf_counter()
-        # 4. gather the per-rank edge lists (padded to the longest) ...
+        # 4. gather the per-rank edge lists and 5. order them
+        self.edges = self._gather(mine, ordered=False)
+        be.sync()
+        t3 = time.perf_counter()
+        st["edges"] = int(self.edges.shape[0])
+        st["ms_exchange"] = (t1 - t0) * 1e3 + (t3 - t2) * 1e3
+        return self._finish(st, collect_stats)
+
+    def _gather(self, mine, ordered):
+        """all_gather of per-rank edge lists (padded to the longest); `ordered`: rank lists are consecutive (src, dst) runs."""
+        import torch
+        dist, be, nr = self.dist, self.be, self.world
+        dev = be.device
         m = int(mine.shape[0])
         allm = torch.empty(nr, dtype=torch.int64, device=dev)
         dist.all_gather_into_tensor(allm, torch.tensor([m], dtype=torch.int64, device=dev))
@@ -118,21 +158,18 @@ class ShardedPrefSuf:
         gathered = torch.empty((nr, mx, 3), dtype=torch.int32, device=dev)
         dist.all_gather_into_tensor(gathered.view(-1), local.view(-1))
         packed = torch.cat([gathered[q, :ms[q]] for q in range(nr)], dim=0).contiguous()
-        # 5. ... and order them
-        self.edges = be.sort_edges(packed)
-        be.sync()
-        t3 = time.perf_counter()
-        m2 = int(self.edges.shape[0])
-        st["edges"] = m2
-        st["ms_exchange"] = (t1 - t0) * 1e3 + (t3 - t2) * 1e3
+        return packed if ordered else be.sort_edges(packed)
+
+    def _finish(self, st, collect_stats):
+        import torch
         if collect_stats:   # whole-job counters for the roofline bookkeeping
             keys = ["windows_probed", "slots_scanned", "raw_overlaps", "records", "transitive_listed", "transitive_compares",
                     "transitive_removed"]
-            t = torch.tensor([int(st.get(kk, 0)) for kk in keys], dtype=torch.int64, device=dev)
-            dist.all_reduce(t)
+            t = torch.tensor([int(st.get(kk, 0)) for kk in keys], dtype=torch.int64, device=self.be.device)
+            self.dist.all_reduce(t)
             for kk, v in zip(keys, t.cpu().tolist()):
                 st[kk] = int(v)
-        return m2, st
+        return st["edges"], st
 
     def edges_numpy(self):
         return self.edges.cpu().numpy().astype(np.int32).copy()

@@ -97,7 +97,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="cfg2_1M_150bp")
-    ap.add_argument("--stride", type=int, default=0, help="row stride in uint32 words (0 = minimal)")
+    ap.add_argument("--stride", type=int, default=0, help="row stride in uint32 words (0 = the engine's HBM layout: rows padded to 16 bytes, as alga_prefsuf_build_host uploads them; -1 = minimal)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-reads", type=int, default=1_000_000)
     args = ap.parse_args()
@@ -124,7 +124,7 @@ def main():
     wl = None
     meta = torch.zeros(4, dtype=torch.int64, device="cuda")
     if rank == 0:
-        wl = workload.build(args.config, scale=world, stride_words=(args.stride or None))
+        wl = workload.build(args.config, scale=world, stride_words=(None if args.stride < 0 else (args.stride or "aligned")))
         meta = torch.tensor([len(wl["lens"]), wl["words"].shape[1], wl["min_overlap"], wl["rsoemo"]], dtype=torch.int64, device="cuda")
     if dist is not None:
         dist.broadcast(meta, src=0)

@@ -154,7 +154,7 @@ int  alga_prefsuf_reduce_device(alga_engine *e, const alga_nodes *nodes, const a
 /* Sharded form without an exchange: the final edges whose SOURCE node id is in [src_begin, src_end), by the source-side
  * reduction (every rank holds the full node set; a source's edges depend on nothing another rank computes).  Returns
  * ALGA_ERR_UNSUPPORTED when that form is not exact for the input (see alga_reduction) -- every rank gets the same answer
- * for the same node set, except for the capacity case (a source with more than 192 raw overlaps), so ranks agree on the
+ * for the same node set, except for the capacity case (a source with more raw overlaps than the engine holds in LDS, 160), so ranks agree on the
  * fallback with one flag all-reduce.  *d_edges: engine-owned, sorted by (src, dst), valid until the next call on `e`. */
 int  alga_prefsuf_build_range_device(alga_engine *e, const alga_nodes *nodes, const alga_prefsuf_params *p,
                                      int32_t src_begin, int32_t src_end, void *hip_stream,

@@ -141,9 +141,9 @@ def test_degenerate_inputs(eng):
     codes, l5 = gen_reads.sample_reads(5, 80, 120, 26)
     codes80 = np.repeat(codes, 80, axis=0)
     w = alga_amd.pack_reads(codes80)
-    # more raw overlaps per source than the source-side reduction holds (192) -> it declines, AUTO falls back
+    # more raw overlaps per source than the source-side reduction holds (160) -> it declines, AUTO falls back
     _check(eng, w, np.full(len(w), 80, np.int32), 40, 60, source_side=False)
-    # 25 copies: 65..192 raw overlaps per source, the multi-round all-pairs path of the source-side form
+    # 25 copies: 65..160 raw overlaps per source, the multi-round all-pairs path of the source-side form
     w = alga_amd.pack_reads(np.repeat(codes, 25, axis=0))
     _check(eng, w, np.full(len(w), 80, np.int32), 40, 60)
 

@@ -27,7 +27,8 @@ def _seqs(words, lens):
 class PyBackend:
     """Stand-in for alga_amd.multigpu.HipBackend on CPU tensors."""
 
-    def __init__(self, words, lens, lo, rs):
+    def __init__(self, words, lens, lo, rs, source_side=False, decline_rank=None, rank=0):
+        self.source_side, self.decline = source_side, decline_rank == rank
         self.seq = _seqs(words, lens)
         self.n = len(self.seq)
         self.lo, self.rs = lo, rs
@@ -56,6 +57,17 @@ class PyBackend:
             for L, C, off in sorted(small)[-3:]:
                 dst.append(C); val.append(((off | (L << 12) | OL_SMALL) << 32) | B)
         return np.array(dst, dtype=np.int64), np.array(val, dtype=np.uint64)
+
+    def build_range(self, a, b, collect_stats=False):
+        """Stand-in of alga_prefsuf_build_range_device: the executable statement of the source-side rule, one source range."""
+        if not self.source_side or self.decline:
+            return None
+        from source_side_rule import source_side_edges
+        code = {"A": 0, "C": 1, "G": 2, "T": 3}
+        seqs = [bytes(code[c] for c in s) for s in self.seq]
+        e = source_side_edges(seqs, self.lo, self.rs)
+        e = e[(e[:, 0] >= a) & (e[:, 0] < b)]
+        return torch.from_numpy(e.copy()).reshape(-1, 3)
 
     def discover_sorted(self, a, b, collect_stats=False):
         d, v = self._records(a, b)
@@ -109,14 +121,14 @@ class PyBackend:
         pass
 
 
-def _worker(rank, world, port, words, lens, lo, rs, out_dir):
+def _worker(rank, world, port, words, lens, lo, rs, out_dir, source_side=False, decline_rank=None):
     import torch.distributed as dist
     from alga_amd import multigpu
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        run = multigpu.ShardedPrefSuf(PyBackend(words, lens, lo, rs), rank, world, dist)
+        run = multigpu.ShardedPrefSuf(PyBackend(words, lens, lo, rs, source_side, decline_rank, rank), rank, world, dist)
         m, st = run.step(collect_stats=True)
         e = run.edges_numpy()
         assert m == len(e)
@@ -133,8 +145,10 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_driver_over_gloo_equals_oracle(tmp_path, world):
+@pytest.mark.parametrize("world,source_side,decline_rank", [(2, False, None), (3, False, None), (2, True, None), (3, True, None), (3, True, 1)])
+def test_sharded_driver_over_gloo_equals_oracle(tmp_path, world, source_side, decline_rank):
+    """Per-target form (record exchange), source-side form (no exchange), and one rank declining the source-side form
+    (capacity case): every rank must fall back together."""
     import gen_reads
     import oracle_lib as O
     import alga_amd
@@ -148,7 +162,7 @@ def test_sharded_driver_over_gloo_equals_oracle(tmp_path, world):
     assert len(want) > 50
     single = PyBackend(words, lens, lo, rs).build().numpy()          # the stand-in itself agrees with the oracle
     assert (single == want).all()
-    mp.spawn(_worker, args=(world, _free_port(), words, lens, lo, rs, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), words, lens, lo, rs, str(tmp_path), source_side, decline_rank), nprocs=world, join=True)
     for r in range(world):
         got = np.load(str(tmp_path / ("edges_%d.npy" % r)))
         assert got.shape == want.shape and (got == want).all()      # every rank holds the complete, ordered graph
