@@ -142,14 +142,20 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
     const uint64_t slack = probe_record_slack(e->n_cu, n_src, local);     // invalid padding of the chunked record list
     uint64_t &hint = local ? e->rec_cap_hint_local : e->rec_cap_hint;
     uint64_t cap = std::max<uint64_t>(hint, (local ? 2 : 16) * n_src + 4096) + slack;
+    if (local) {
+        if ((rc = alga_ensure(e, e->outdeg, (size_t) (n_src + 1) * sizeof(uint32_t)))) return rc;
+        if ((rc = alga_ensure(e, e->loc_first, (size_t) (n_src + 1) * sizeof(unsigned long long)))) return rc;
+    }
     for (int attempt = 0; attempt < 4; attempt++) {
         if (cap >= (1ull << 32) - 16) return alga_fail(e, ALGA_ERR_CAPACITY, "more than 2^32 overlap records; shard the input");
+        if (local) HIP_TRY(e, hipMemsetAsync(e->outdeg.p, 0, (size_t) (n_src + 1) * sizeof(uint32_t), s));
         if ((rc = alga_ensure(e, e->rec_dst, cap * sizeof(uint32_t)))) return rc;
         if ((rc = alga_ensure(e, e->rec_val, cap * sizeof(unsigned long long)))) return rc;
         HIP_TRY(e, hipMemsetAsync(cnt, 0, CNT_TOTAL * sizeof(unsigned long long), s));
         if (e->probe_mode == 0)
             launch_probe(nd, cfg, (const unsigned long long *) e->table.p, n_buckets, (const uint32_t *) e->filter.p, filter_bits, src_begin, src_end,
-                         (uint32_t *) e->rec_dst.p, (unsigned long long *) e->rec_val.p, cap, cnt, e->n_cu, local, s);
+                         (uint32_t *) e->rec_dst.p, (unsigned long long *) e->rec_val.p, cap, cnt, e->n_cu, local, (uint32_t *) e->outdeg.p,
+                         (unsigned long long *) e->loc_first.p, s);
         else
             launch_probe_min(nd, cfg, (const unsigned long long *) e->ix_dir.p, dir_slots, (const unsigned long long *) e->ix_vals2.p, src_begin, src_end,
                              (uint32_t *) e->rec_dst.p, (unsigned long long *) e->rec_val.p, cap, cnt, e->n_cu, s);
@@ -246,32 +252,31 @@ int reduce_impl(alga_engine *e, const Prepared &pp, const uint32_t *rec_dst, con
     return ALGA_OK;
 }
 
-// source-side reduction: the record slots hold final edges -> sort by (src, dst), drop the padding
-int finalize_local(alga_engine *e, const Prepared &pp, uint64_t n_rec, hipStream_t s, uint64_t *n_edges) {
+// source-side reduction: adjacency lists from the out-degrees, one-edge slots and record list the probe left behind
+int finalize_local(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t src_end, uint64_t n_rec, hipStream_t s, uint64_t *n_edges) {
     int rc;
-    const uint64_t E = e->stats.records;                                   // CNT_VALID_RECORDS of the probe
     *n_edges = 0;
-    if (n_rec >= (1ull << 32) - 16) return alga_fail(e, ALGA_ERR_CAPACITY, "more than 2^32 edge slots; shard the input");
-    const size_t temp_bytes = sort_edges_temp_bytes(n_rec);
-    if ((rc = alga_ensure(e, e->edge_keys, (size_t) (n_rec + 1) * sizeof(unsigned long long)))) return rc;
-    if ((rc = alga_ensure(e, e->edge_keys2, (size_t) (n_rec + 1) * sizeof(unsigned long long)))) return rc;
-    if ((rc = alga_ensure(e, e->edge_vals, (size_t) (n_rec + 1) * sizeof(uint32_t)))) return rc;
-    if ((rc = alga_ensure(e, e->edge_vals2, (size_t) (n_rec + 1) * sizeof(uint32_t)))) return rc;
-    if ((rc = alga_ensure(e, e->edges, (size_t) (E + 1) * sizeof(alga_edge_dev)))) return rc;
-    if ((rc = alga_ensure(e, e->sort_temp, temp_bytes))) return rc;
+    const uint64_t n_src = (uint64_t) std::max<int64_t>(0, (int64_t) src_end - src_begin);
+    if ((rc = alga_ensure(e, e->scan_scratch, scan_scratch_bytes(n_src)))) return rc;
+    if ((rc = alga_ensure(e, e->out_rowptr, (size_t) (n_src + 1) * sizeof(uint32_t)))) return rc;
+    if ((rc = alga_ensure(e, e->out_cnt, (size_t) (n_src + 1) * sizeof(uint32_t)))) return rc;
     HIP_TRY(e, hipEventRecord(e->ev[EV_GROUP], s));
     HIP_TRY(e, hipEventRecord(e->ev[EV_REDUCE], s));
-    launch_records_to_edge_keys((const uint32_t *) e->rec_dst.p, (const unsigned long long *) e->rec_val.p, n_rec, (unsigned long long *) e->edge_keys.p,
-                                (uint32_t *) e->edge_vals.p, s);
-    if ((rc = alga_check_launch(e, "k_records_to_edge_keys"))) return rc;
-    int src_bits = 1;
-    while (src_bits < 31 && (1ll << src_bits) < (long long) pp.nd.n) src_bits++;
-    HIP_TRY(e, sort_edges(e->sort_temp.p, temp_bytes, (const unsigned long long *) e->edge_keys.p, (unsigned long long *) e->edge_keys2.p,
-                          (const uint32_t *) e->edge_vals.p, (uint32_t *) e->edge_vals2.p, n_rec, src_bits + 1, s));   // +1: padding (all ones) sorts last
-    launch_keys_to_edges((const unsigned long long *) e->edge_keys2.p, (const uint32_t *) e->edge_vals2.p, E, (alga_edge_dev *) e->edges.p, s);
-    if ((rc = alga_check_launch(e, "k_keys_to_edges"))) return rc;
+    launch_exclusive_scan((const uint32_t *) e->outdeg.p, n_src, (uint32_t *) e->out_rowptr.p, (uint64_t *) e->scan_scratch.p, s);
+    if ((rc = alga_check_launch(e, "scan(outdeg)"))) return rc;
+    HIP_TRY(e, hipMemsetAsync(e->out_cnt.p, 0, (size_t) (n_src + 1) * sizeof(uint32_t), s));
+    const uint64_t E = e->stats.records;                                   // CNT_VALID_RECORDS of the probe == sum of the out-degrees
+    if (E >= (1ull << 32) - 16) return alga_fail(e, ALGA_ERR_CAPACITY, "more than 2^32 edges; shard the input");
+    if ((rc = alga_ensure(e, e->edges, (size_t) (E + 1) * sizeof(alga_edge_dev)))) return rc;
+    launch_local_emit(src_begin, (int32_t) n_src, (const uint32_t *) e->outdeg.p, (const unsigned long long *) e->loc_first.p,
+                      (const uint32_t *) e->rec_dst.p, (const unsigned long long *) e->rec_val.p, n_rec, (const uint32_t *) e->out_rowptr.p,
+                      (uint32_t *) e->out_cnt.p, (alga_edge_dev *) e->edges.p, s);
+    if ((rc = alga_check_launch(e, "k_local_emit"))) return rc;
     HIP_TRY(e, hipEventRecord(e->ev[EV_EMIT], s));
+    uint64_t *d_total = (uint64_t *) e->scan_scratch.p + scan_total_index(n_src);
+    HIP_TRY(e, hipMemcpyAsync(&e->h_counters[CNT_TOTAL], d_total, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(e, hipStreamSynchronize(s));
+    if (e->h_counters[CNT_TOTAL] != E) return alga_fail(e, ALGA_ERR_HIP, "source-side emit: out-degrees and edge count disagree");
     *n_edges = E;
     e->stats.edges = E;
     return ALGA_OK;
@@ -285,7 +290,7 @@ int build_local(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t s
     int rc = discover_impl(e, pp, src_begin, src_end, s, &n_rec, true, &overflow);
     if (rc) return rc;
     if (overflow) return alga_fail(e, ALGA_ERR_UNSUPPORTED, "a source node has more raw overlaps than the source-side reduction holds");
-    if ((rc = finalize_local(e, pp, n_rec, s, n_edges))) return rc;
+    if ((rc = finalize_local(e, pp, src_begin, src_end, n_rec, s, n_edges))) return rc;
     e->stats.reduction_used = ALGA_REDUCTION_SOURCE_SIDE;
     return ALGA_OK;
 }
@@ -339,7 +344,7 @@ void alga_engine_destroy(alga_engine *e) {
     if (e->own_stream) (void) hipStreamSynchronize(e->own_stream);
     DevBuf *bufs[] = {&e->table, &e->filter, &e->counters, &e->rowptr, &e->rec_dst, &e->rec_val, &e->keys, &e->seg_key, &e->seg_val, &e->heads, &e->sort_temp,
                       &e->out_cnt, &e->outdeg, &e->out_rowptr, &e->edges, &e->scan_scratch, &e->up_words, &e->up_len, &e->up_from, &e->up_to,
-                      &e->ix_keys, &e->ix_vals, &e->ix_keys2, &e->ix_vals2, &e->ix_dir, &e->edge_keys, &e->edge_keys2, &e->edge_vals, &e->edge_vals2, &e->edges_sorted, &e->xs_dst, &e->xs_val,
+                      &e->ix_keys, &e->ix_vals, &e->ix_keys2, &e->ix_vals2, &e->ix_dir, &e->loc_first, &e->edge_keys, &e->edge_keys2, &e->edge_vals, &e->edge_vals2, &e->edges_sorted, &e->xs_dst, &e->xs_val,
                       &e->pk_keys, &e->pk_keys2, &e->pk_vals, &e->pk_vals2, &e->pk_marks, &e->pk_big, &e->pk_add, &e->pk_ekeys, &e->pk_ekeys2,
                       &e->pk_flag, &e->pk_pos, &e->pk_edges[0], &e->pk_edges[1], &e->pk_rowptr, &e->pk_deg, &e->pk_mask, &e->pk_cnt, &e->pk_io, &e->pk_io2};
     for (DevBuf *b : bufs) alga_release(*b);

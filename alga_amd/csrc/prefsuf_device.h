@@ -119,7 +119,13 @@ struct ProbeOut {
     unsigned long long *__restrict__ rec_val;
     uint64_t rec_cap;
     unsigned long long *__restrict__ counters;
+    // source-side form: per source of [src_base, ...) its out-degree and, for the one-edge fast path, the edge itself
+    // ((dst << 32) | offset; LOCAL_FIRST_NONE = "the edges are in the record list")
+    uint32_t *__restrict__ deg = nullptr;
+    unsigned long long *__restrict__ first = nullptr;
+    int32_t src_base = 0;
 };
+constexpr unsigned long long LOCAL_FIRST_NONE = ~0ull;
 
 __device__ __forceinline__ void store_record(const ProbeOut &o, uint64_t idx, uint32_t C, unsigned long long val) {
     if (idx < o.rec_cap) { o.rec_dst[idx] = C; o.rec_val[idx] = val; }
@@ -308,7 +314,12 @@ __device__ __forceinline__ void local_reduce(const NodesDev &nd, const PrefSufCf
             generic = __ballot(fail) != 0ull;
             // The item without a predecessor has the longest overlap of the source: it is big, or it is the largest of the
             // source's small overlaps and survives the cap of 3 (GraphCreatorPrefSuf.cpp:397-401) -- no top-3 needed here.
-            if (!generic && act && !has_pred) push(C, d);
+            // One edge: it goes straight to the source's slot, no record list, no sort.
+            if (!generic && act && !has_pred) {
+                o.first[A - o.src_base] = ((unsigned long long) C << 32) | (uint32_t) d;
+                o.deg[A - o.src_base] = 1u;
+                st_rec++;
+            }
         }
     }
     if (generic) {
@@ -324,6 +335,7 @@ __device__ __forceinline__ void local_reduce(const NodesDev &nd, const PrefSufCf
             const uint64_t key = ((uint64_t) (uint32_t) L << 32) | C;
             return L >= cfg.rsoemo || key == win0 || key == win1 || key == win2;
         };
+        int n_out = 0;
         for (int base = 0; base < n; base += 64) {
             const int i = base + lane;
             const bool act = i < n;
@@ -341,7 +353,9 @@ __device__ __forceinline__ void local_reduce(const NodesDev &nd, const PrefSufCf
                 else { if (STATS && act && dj < d) st_cmp++; removed = removed || via_ok(A, lenA, Lbig, Cj, mj, oj, C, d, rho, ov); }
             }
             if (!removed) push(C, d);
+            n_out += __popcll(__ballot(!removed));
         }
+        if (lane == 0 && n_out) { o.deg[A - o.src_base] = (uint32_t) n_out; o.first[A - o.src_base] = LOCAL_FIRST_NONE; }
     }
     wave_lds_fence();
 }

@@ -837,16 +837,33 @@ __global__ void __launch_bounds__(256) k_keys_to_edges(const unsigned long long 
     }
 }
 
-// records of the source-side reduction are final edges: key = (src << 32) | dst, value = offset; chunk padding gets
-// the all-ones key and sorts behind every edge
-__global__ void __launch_bounds__(256) k_records_to_edge_keys(const uint32_t *__restrict__ rec_dst, const unsigned long long *__restrict__ rec_val,
-                                                               uint64_t n, unsigned long long *__restrict__ keys, uint32_t *__restrict__ vals) {
-    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) {
+// Source-side form, final adjacency lists of the sources [src_base, src_base + n_src): the row pointers are the scan of
+// the out-degrees the probe wrote; a one-edge source (the fast path) left its edge in first[], every other source's edges
+// are in the record list and take their slot with a cursor (rows with more than one edge are ordered by k_sort_rows).
+__global__ void __launch_bounds__(256) k_local_emit_first(int32_t src_base, int32_t n_src, const uint32_t *__restrict__ deg,
+                                                           const unsigned long long *__restrict__ first, const uint32_t *__restrict__ rowptr,
+                                                           alga_edge_dev *__restrict__ edges) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_src || deg[i] == 0) return;
+    const unsigned long long f = first[i];
+    if (f == LOCAL_FIRST_NONE) return;
+    alga_edge_dev e;
+    e.src = src_base + i; e.dst = (int32_t) (uint32_t) (f >> 32); e.offset = (int32_t) (uint32_t) f;
+    edges[rowptr[i]] = e;
+}
+
+__global__ void __launch_bounds__(256) k_local_emit_records(int32_t src_base, const uint32_t *__restrict__ rec_dst,
+                                                             const unsigned long long *__restrict__ rec_val, uint64_t n_rec,
+                                                             const uint32_t *__restrict__ rowptr, uint32_t *__restrict__ cursor,
+                                                             alga_edge_dev *__restrict__ edges) {
+    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n_rec; i += (uint64_t) gridDim.x * blockDim.x) {
         const uint32_t c = rec_dst[i];
+        if (c == REC_INVALID) continue;
         const unsigned long long v = rec_val[i];
-        const bool ok = c != REC_INVALID;
-        keys[i] = ok ? (((unsigned long long) (uint32_t) v << 32) | c) : ~0ull;
-        vals[i] = ok ? (uint32_t) ol_off((uint32_t) (v >> 32)) : 0u;
+        const int32_t src = (int32_t) (uint32_t) v;
+        alga_edge_dev e;
+        e.src = src; e.dst = (int32_t) c; e.offset = ol_off((uint32_t) (v >> 32));
+        edges[rowptr[src - src_base] + atomicAdd(&cursor[src - src_base], 1u)] = e;
     }
 }
 
@@ -912,11 +929,11 @@ static void launch_probe_nq(const NodesDev &nd, const PrefSufCfg &cfg, const Pro
 void launch_probe(const NodesDev &nd, const PrefSufCfg &cfg, const unsigned long long *table, uint32_t n_buckets,
                   const uint32_t *filter, uint32_t filter_bits,
                   int32_t src_begin, int32_t src_end, uint32_t *rec_dst, unsigned long long *rec_val, uint64_t rec_cap,
-                  unsigned long long *counters, int n_cu, bool local, hipStream_t s) {
+                  unsigned long long *counters, int n_cu, bool local, uint32_t *deg, unsigned long long *first, hipStream_t s) {
     const int64_t ns = (int64_t) src_end - src_begin;
     if (ns <= 0) return;
     dim3 grid((unsigned) probe_blocks(n_cu, (uint64_t) ns)), block(PROBE_WAVES * 64);
-    ProbeOut o{rec_dst, rec_val, rec_cap, counters};
+    ProbeOut o{rec_dst, rec_val, rec_cap, counters, deg, first, src_begin};
     ProbeTable t{table, n_buckets, filter_bits ? filter : nullptr, filter_bits ? filter_bits - 1 : 0u};
     // widest prefix ever compared: Lcap nucleotides; wide path needs 16-byte aligned rows that hold it
     const int need_q = (((2 * cfg.Lcap + 31) >> 5) + 3) >> 2;
@@ -928,11 +945,16 @@ void launch_probe(const NodesDev &nd, const PrefSufCfg &cfg, const unsigned long
     else                                           launch_probe_nq<0>(nd, cfg, t, local, src_begin, src_end, o, grid, block, s);
 }
 
-void launch_records_to_edge_keys(const uint32_t *rec_dst, const unsigned long long *rec_val, uint64_t n, unsigned long long *keys, uint32_t *vals,
-                                 hipStream_t s) {
-    if (n == 0) return;
-    unsigned g = std::min<unsigned>(grid_for(n, 256 * 4), 4096u);
-    hipLaunchKernelGGL(k_records_to_edge_keys, dim3(std::max(1u, g)), dim3(256), 0, s, rec_dst, rec_val, n, keys, vals);
+void launch_local_emit(int32_t src_base, int32_t n_src, const uint32_t *deg, const unsigned long long *first, const uint32_t *rec_dst,
+                       const unsigned long long *rec_val, uint64_t n_rec, const uint32_t *rowptr, uint32_t *cursor, alga_edge_dev *edges,
+                       hipStream_t s) {
+    if (n_src <= 0) return;
+    hipLaunchKernelGGL(k_local_emit_first, dim3(grid_for((uint64_t) n_src, 256)), dim3(256), 0, s, src_base, n_src, deg, first, rowptr, edges);
+    if (n_rec) {
+        unsigned g = std::min<unsigned>(grid_for(n_rec, 256), 4096u);
+        hipLaunchKernelGGL(k_local_emit_records, dim3(std::max(1u, g)), dim3(256), 0, s, src_base, rec_dst, rec_val, n_rec, rowptr, cursor, edges);
+    }
+    hipLaunchKernelGGL(k_sort_rows, dim3(grid_for((uint64_t) n_src, 256)), dim3(256), 0, s, n_src, rowptr, edges);
 }
 
 void launch_make_keys(const uint32_t *rec_dst, uint64_t n_rec, int32_t dst_begin, int32_t dst_end, uint32_t *keys,
