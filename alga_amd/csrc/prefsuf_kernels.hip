@@ -886,9 +886,12 @@ uint32_t seed_buckets_for(uint64_t live, int fill_x10) {   // average entries pe
     return (uint32_t) std::min<uint64_t>(nb, 0x7FFFFFFFull);
 }
 
-// filter bits: 0 = no prefilter (it only pays while the bitmap fits an XCD's L2)
+// Prefilter size in bits (a power of two), 0 = off.  The bitmap pays only while it stays resident in every XCD's 4 MB L2
+// next to the streaming traffic (measured: a 4 MB bitmap at 6.1 M nodes made the probe 13 % SLOWER than no filter, its
+// lookups then miss L2 as often as the bucket reads they are meant to save) and while most windows match nothing (at
+// 163x coverage 65 % of the windows are real hits anyway).
 uint32_t seed_filter_bits_for(uint64_t live) {
-    uint64_t want = live * 8;
+    const uint64_t want = live * 8;
     if (want > (1ull << 25)) return 0;
     uint64_t bits = 1ull << 16;
     while (bits < want) bits <<= 1;
