@@ -428,8 +428,8 @@ int alga_prefsuf_build_host(alga_engine *e, const alga_nodes *nodes, const alga_
         if ((int64_t) blocks_of(max_len) > (int64_t) nodes->stride_words)
             return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "stride_words is smaller than the longest read needs");
     }
-    // rows are re-strided to a multiple of 4 words on the way up: 16-byte aligned rows take the wide-load kernels
-    const int stride_up = (nodes->stride_words + 3) & ~3;
+    // rows are re-strided on the way up (hbm_row_stride): 16-byte aligned rows that never straddle a 64-byte line take the wide-load kernels
+    const int stride_up = alga::hbm_row_stride(nodes->stride_words);
     const size_t wbytes = n * (size_t) stride_up * sizeof(uint32_t);
     if ((rc = alga_ensure(e, e->up_words, wbytes))) return rc;
     if ((rc = alga_ensure(e, e->up_len, n * sizeof(int32_t)))) return rc;

@@ -41,7 +41,7 @@ int upload_nodes(alga_engine *e, const alga_nodes *nodes, hipStream_t s, alga_no
     for (size_t i = 0; i < n; i++) max_len = std::max(max_len, nodes->len[i]);
     if ((int64_t) blocks_of(max_len) > (int64_t) nodes->stride_words)
         return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "stride_words is smaller than the longest read needs");
-    const int stride_up = (nodes->stride_words + 3) & ~3;
+    const int stride_up = alga::hbm_row_stride(nodes->stride_words);
     const size_t wbytes = n * (size_t) stride_up * sizeof(uint32_t);
     if ((rc = alga_ensure(e, e->up_words, wbytes))) return rc;
     if ((rc = alga_ensure(e, e->up_len, n * sizeof(int32_t)))) return rc;

@@ -56,6 +56,10 @@ constexpr int SEED_BUCKET = 8;         // slots per bucket: 8 x 8 B = one 64-byt
 // number of uint32 blocks that hold `len_nt` nucleotides (Bitset::blocks(), Bitset.h:206)
 ALGA_HD inline int blocks_of(int len_nt) { return len_nt <= 0 ? 0 : ((2 * len_nt - 1) >> 5) + 1; }
 
+// Row stride (uint32 words) of the engine's own HBM layout for rows of `w` used words: 16-, 32- or 64-byte rows never
+// straddle a 64-byte line (a 48-byte row does, every other time); longer rows are whole lines.
+ALGA_HD inline int hbm_row_stride(int w) { return w <= 4 ? 4 : (w <= 8 ? 8 : ((w + 15) & ~15)); }
+
 // device-side counters; index = enum below
 enum Counter {
     CNT_RECORDS = 0,       // record-list cursor (incl. invalid padding; may exceed capacity -> retry)

@@ -75,8 +75,8 @@ def make_nodes(codes, trim=3, stride_words=None):
     N = 2 * len(ids)
     if stride_words is None:
         stride_words = W
-    elif stride_words == "aligned":                 # 16-byte rows: the layout the engine's wide-load kernels take
-        stride_words = (W + 3) & ~3
+    elif stride_words == "aligned":                 # the engine's own HBM layout (prefsuf_common.h: hbm_row_stride)
+        stride_words = 4 if W <= 4 else (8 if W <= 8 else (W + 15) & ~15)
     words = np.zeros((N, stride_words), dtype=np.uint32)
     words[0::2, :W] = rv[ids]
     words[1::2, :W] = fw[ids]
