@@ -102,7 +102,7 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
         const size_t table_bytes = (size_t) n_buckets * SEED_BUCKET * sizeof(unsigned long long);
         if ((rc = alga_ensure(e, e->table, table_bytes))) return rc;
         HIP_TRY(e, hipMemsetAsync(e->table.p, 0xFF, table_bytes, s));
-        filter_bits = e->use_filter ? seed_filter_bits_for(pp.live) : 0;
+        filter_bits = e->use_filter ? (e->filter_log2 ? (1u << e->filter_log2) : seed_filter_bits_for(pp.live)) : 0;
         if (filter_bits) {
             if ((rc = alga_ensure(e, e->filter, filter_bits / 8))) return rc;
             HIP_TRY(e, hipMemsetAsync(e->filter.p, 0, filter_bits / 8, s));
@@ -322,6 +322,7 @@ int alga_engine_create(int hip_device, alga_engine **out) {
     e->device = hip_device;
     if (const char *v = getenv("ALGA_SEED_FILL_X10")) e->seed_fill_x10 = atoi(v);
     if (const char *v = getenv("ALGA_SEED_FILTER")) e->use_filter = atoi(v);
+    if (const char *v = getenv("ALGA_SEED_FILTER_LOG2")) e->filter_log2 = std::min(30, std::max(16, atoi(v)));
     if (const char *v = getenv("ALGA_PROBE")) e->probe_mode = strcmp(v, "min") == 0 ? 1 : 0;
     if (const char *v = getenv("ALGA_REDUCE")) e->force_reduction = strcmp(v, "target") == 0 ? 1 : 0;
     memset(&e->stats, 0, sizeof(e->stats));

@@ -24,6 +24,7 @@ struct alga_engine {
     int         n_cu = 256;
     int         seed_fill_x10 = 20;           // average seed-table bucket fill x10 (tunable: ALGA_SEED_FILL_X10)
     int         probe_mode = 0;               // 0 = bucketised seed table (default, faster: DESIGN.md section 5), 1 = minimizer index (ALGA_PROBE=min)
+    int         filter_log2 = 0;              // experiments: ALGA_SEED_FILTER_LOG2 forces the prefilter size (0 = automatic)
     int         use_filter = 1;               // L2-resident fingerprint bitmap in front of the seed table (ALGA_SEED_FILTER=0 disables)
     hipEvent_t  ev[EV_COUNT] = {};
     // device buffers, grown on demand and kept between calls

@@ -83,11 +83,17 @@ class HipBackend:
 
 
 class ShardedPrefSuf:
-    def __init__(self, backend, rank=0, world=1, dist=None):
+    """replicate=False (default): the complete graph is assembled on rank 0 only -- the one process that runs the unchanged
+    simplifier / contig stages afterwards -- with direct sends over each peer's own xGMI link (`gather`); the other ranks keep
+    an empty tensor.  replicate=True: every rank gets it (`all_gather`, 8x the traffic at 8 GPUs)."""
+
+    def __init__(self, backend, rank=0, world=1, dist=None, replicate=False):
         self.be, self.rank, self.world, self.dist = backend, rank, world, dist
+        self.replicate = replicate
         self.n = backend.n
         self.bounds = shard_bounds(self.n, world)
-        self.edges = None                       # tensor [m, 3] of the last step (complete graph, on every rank)
+        self.edges = None                       # tensor [m, 3] of the last step: the complete graph (rank 0, or every rank if replicate)
+        self.total_edges = 0
 
     def step(self, collect_stats=False):
         """-> (n_edges of the complete graph, stats dict of this rank)."""
@@ -100,16 +106,19 @@ class ShardedPrefSuf:
         import torch
         dist, be, r, nr, b = self.dist, self.be, self.rank, self.world, self.bounds
         dev = be.device
-        # 0. source-side form: final edges of my sources; all ranks must agree to use it
+        # 0. source-side form: final edges of my sources; all ranks must agree to use it.  One small all_gather carries
+        #    the "declined" flag and the edge count of every rank.
         mine = be.build_range(b[r], b[r + 1], collect_stats)
-        flag = torch.tensor([0 if mine is not None else 1], dtype=torch.int32, device=dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-        if int(flag.item()) == 0:
+        meta = torch.tensor([0 if mine is not None else 1, 0 if mine is None else int(mine.shape[0])], dtype=torch.int64, device=dev)
+        allmeta = torch.empty(2 * nr, dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(allmeta, meta)
+        allmeta = allmeta.cpu().view(nr, 2)
+        if int(allmeta[:, 0].max()) == 0:
             st = dict(be.stats)
             t2 = time.perf_counter()
-            self.edges = self._gather(mine, ordered=True)
+            self.edges = self._gather(mine, ordered=True, counts=[int(x) for x in allmeta[:, 1]])
             be.sync()
-            st["edges"] = int(self.edges.shape[0])
+            st["edges"] = int(allmeta[:, 1].sum())
             st["ms_exchange"] = (time.perf_counter() - t2) * 1e3
             return self._finish(st, collect_stats)
         # 1. discover + order by target
@@ -138,26 +147,36 @@ class ShardedPrefSuf:
         self.edges = self._gather(mine, ordered=False)
         be.sync()
         t3 = time.perf_counter()
-        st["edges"] = int(self.edges.shape[0])
+        st["edges"] = self.total_edges
         st["ms_exchange"] = (t1 - t0) * 1e3 + (t3 - t2) * 1e3
         return self._finish(st, collect_stats)
 
-    def _gather(self, mine, ordered):
-        """all_gather of per-rank edge lists (padded to the longest); `ordered`: rank lists are consecutive (src, dst) runs."""
+    def _gather(self, mine, ordered, counts=None):
+        """Edge lists of all ranks (padded to the longest) -> the complete list on rank 0 (or on every rank);
+        `ordered`: the rank lists are consecutive (src, dst) runs, no sort needed."""
         import torch
         dist, be, nr = self.dist, self.be, self.world
         dev = be.device
         m = int(mine.shape[0])
-        allm = torch.empty(nr, dtype=torch.int64, device=dev)
-        dist.all_gather_into_tensor(allm, torch.tensor([m], dtype=torch.int64, device=dev))
-        ms = [int(x) for x in allm.cpu()]
-        mx = max(max(ms), 1)
+        if counts is None:
+            allm = torch.empty(nr, dtype=torch.int64, device=dev)
+            dist.all_gather_into_tensor(allm, torch.tensor([m], dtype=torch.int64, device=dev))
+            counts = [int(x) for x in allm.cpu()]
+        self.total_edges = sum(counts)
+        mx = max(max(counts), 1)
         local = torch.zeros((mx, 3), dtype=torch.int32, device=dev)
         if m:
             local[:m] = mine
-        gathered = torch.empty((nr, mx, 3), dtype=torch.int32, device=dev)
-        dist.all_gather_into_tensor(gathered.view(-1), local.view(-1))
-        packed = torch.cat([gathered[q, :ms[q]] for q in range(nr)], dim=0).contiguous()
+        if self.replicate:
+            gathered = torch.empty((nr, mx, 3), dtype=torch.int32, device=dev)
+            dist.all_gather_into_tensor(gathered.view(-1), local.view(-1))
+        else:
+            parts = [torch.empty((mx, 3), dtype=torch.int32, device=dev) for _ in range(nr)] if self.rank == 0 else None
+            dist.gather(local, parts, dst=0)
+            if self.rank != 0:
+                return torch.empty((0, 3), dtype=torch.int32, device=dev)
+            gathered = parts
+        packed = torch.cat([gathered[q][:counts[q]] for q in range(nr)], dim=0).contiguous()
         return packed if ordered else be.sort_edges(packed)
 
     def _finish(self, st, collect_stats):

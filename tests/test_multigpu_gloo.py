@@ -121,17 +121,18 @@ class PyBackend:
         pass
 
 
-def _worker(rank, world, port, words, lens, lo, rs, out_dir, source_side=False, decline_rank=None):
+def _worker(rank, world, port, words, lens, lo, rs, out_dir, source_side=False, decline_rank=None, replicate=False):
     import torch.distributed as dist
     from alga_amd import multigpu
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        run = multigpu.ShardedPrefSuf(PyBackend(words, lens, lo, rs, source_side, decline_rank, rank), rank, world, dist)
+        run = multigpu.ShardedPrefSuf(PyBackend(words, lens, lo, rs, source_side, decline_rank, rank), rank, world, dist, replicate=replicate)
         m, st = run.step(collect_stats=True)
         e = run.edges_numpy()
-        assert m == len(e)
+        assert m == len(e) or (rank != 0 and not replicate and len(e) == 0)
+        np.save(os.path.join(out_dir, "count_%d.npy" % rank), np.array([m]))
         np.save(os.path.join(out_dir, "edges_%d.npy" % rank), e)
     finally:
         dist.destroy_process_group()
@@ -145,8 +146,9 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world,source_side,decline_rank", [(2, False, None), (3, False, None), (2, True, None), (3, True, None), (3, True, 1)])
-def test_sharded_driver_over_gloo_equals_oracle(tmp_path, world, source_side, decline_rank):
+@pytest.mark.parametrize("world,source_side,decline_rank,replicate", [(2, False, None, True), (3, False, None, False), (2, True, None, False),
+                                                                      (3, True, None, True), (3, True, 1, False)])
+def test_sharded_driver_over_gloo_equals_oracle(tmp_path, world, source_side, decline_rank, replicate):
     """Per-target form (record exchange), source-side form (no exchange), and one rank declining the source-side form
     (capacity case): every rank must fall back together."""
     import gen_reads
@@ -162,10 +164,14 @@ def test_sharded_driver_over_gloo_equals_oracle(tmp_path, world, source_side, de
     assert len(want) > 50
     single = PyBackend(words, lens, lo, rs).build().numpy()          # the stand-in itself agrees with the oracle
     assert (single == want).all()
-    mp.spawn(_worker, args=(world, _free_port(), words, lens, lo, rs, str(tmp_path), source_side, decline_rank), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), words, lens, lo, rs, str(tmp_path), source_side, decline_rank, replicate), nprocs=world, join=True)
     for r in range(world):
         got = np.load(str(tmp_path / ("edges_%d.npy" % r)))
-        assert got.shape == want.shape and (got == want).all()      # every rank holds the complete, ordered graph
+        assert int(np.load(str(tmp_path / ("count_%d.npy" % r)))[0]) == len(want)      # every rank knows the size of the graph
+        if r == 0 or replicate:
+            assert got.shape == want.shape and (got == want).all()  # the complete, ordered graph (rank 0; every rank if replicated)
+        else:
+            assert len(got) == 0
 
 
 def test_shard_bounds_keep_twins_together():
