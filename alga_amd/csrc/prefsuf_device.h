@@ -302,23 +302,50 @@ __device__ __forceinline__ void local_reduce(const NodesDev &nd, const PrefSufCf
             const bool has_pred = act && below != 0;
             if (act) it.T[d] = (uint8_t) lane;
             wave_lds_fence();
-            bool fail = false;
+            bool fail = false, removed = false;
             if (has_pred) {
                 const int j = (int) it.T[63 - __clzll((long long) below)];
                 const uint32_t Cj = it.C[j], mj = it.M[j];
                 const uint4 oj = it.O[j];
                 const int rho = (int) ((m >> 9) & 511u) - (lenA - d);
                 if (STATS) st_cmp++;
-                fail = !via_ok(A, lenA, Lbig, Cj, mj, oj, C, d, rho, ov);
+                removed = via_ok(A, lenA, Lbig, Cj, mj, oj, C, d, rho, ov);
+                // Not removed by the nearest predecessor: if even the longest read placed there could not reach C with a big
+                // overlap, no earlier item can (they all start further left) and the item stands; anything else is undecided.
+                fail = !removed && (cfg.Lcap - 1) - (d - (int) (mj & 511u)) >= Lbig;
             }
             generic = __ballot(fail) != 0ull;
-            // The item without a predecessor has the longest overlap of the source: it is big, or it is the largest of the
-            // source's small overlaps and survives the cap of 3 (GraphCreatorPrefSuf.cpp:397-401) -- no top-3 needed here.
-            // One edge: it goes straight to the source's slot, no record list, no sort.
-            if (!generic && act && !has_pred) {
-                o.first[A - o.src_base] = ((unsigned long long) C << 32) | (uint32_t) d;
-                o.deg[A - o.src_base] = 1u;
-                st_rec++;
+            if (!generic) {
+                uint64_t surv = __ballot(act && !removed);
+                if ((surv & (surv - 1)) == 0ull) {
+                    // One item stands: the one without a predecessor.  It has the longest overlap of the source, so it is big or
+                    // the largest of the small ones and passes the cap of 3 (GraphCreatorPrefSuf.cpp:397-401).  One edge: it goes
+                    // straight to the source's slot, no record list, no sort.
+                    if ((surv >> lane) & 1ull) {
+                        o.first[A - o.src_base] = ((unsigned long long) C << 32) | (uint32_t) d;
+                        o.deg[A - o.src_base] = 1u;
+                        st_rec++;
+                    }
+                } else {
+                    // Several stand (gaps too long for a big via).  Per-source cap: with one item per offset the 3 largest small
+                    // (L, C) keys are the 3 small items with the smallest offsets.
+                    const int ds0 = lenA - cfg.rsoemo + 1;                           // first offset of a small overlap
+                    const uint64_t small_mask = ds0 <= 0 ? ~0ull : (ds0 >= 64 ? 0ull : ~((1ull << ds0) - 1ull));
+                    const bool kept = act && (d < ds0 || __popcll(occ & below & small_mask) < 3);
+                    surv &= __ballot(kept);
+                    // the same target at a smaller offset supersedes (Graph.cpp:348-387, GraphCreatorPrefSuf.cpp:461-462), whatever
+                    // became of that instance: test each survivor against all kept items
+                    uint64_t todo = surv;
+                    while (todo) {                                                   // uniform
+                        const int sl = __builtin_ctzll(todo);
+                        todo &= todo - 1;
+                        const uint32_t Cs = (uint32_t) __builtin_amdgcn_readlane((int) C, sl);
+                        const int ds = __builtin_amdgcn_readlane(d, sl);
+                        if (__ballot(kept && C == Cs && d < ds) != 0ull) surv &= ~(1ull << sl);
+                    }
+                    if ((surv >> lane) & 1ull) push(C, d);
+                    if (lane == 0) { o.deg[A - o.src_base] = (uint32_t) __popcll(surv); o.first[A - o.src_base] = LOCAL_FIRST_NONE; }
+                }
             }
         }
     }

@@ -130,6 +130,8 @@ k_probe_sources(NodesDev nd, PrefSufCfg cfg, const unsigned long long *__restric
     uint64_t chunk_base = 0;
     int chunk_fill = CHUNK;                                // "no chunk yet"
     uint64_t st_raw = 0, st_slots = 0, st_win = 0, st_rec = 0, st_cmp = 0, st_generic = 0;
+    int f_left = filter != nullptr ? 16 : -1;              // uniform: batches still sampled for the pass rate; < 0 = filter not used
+    int f_bal = 0;                                         // 2 * passed - tested over the sampled batches
     const int64_t total_waves = (int64_t) gridDim.x * PROBE_WAVES;
     const uint32_t *sb = w.sb;
 
@@ -228,7 +230,7 @@ k_probe_sources(NodesDev nd, PrefSufCfg cfg, const unsigned long long *__restric
 #if defined(ABLATE) && ABLATE == 5
                 if (false) {
 #else
-                if (filter) {
+                if (f_left >= 0) {
 #endif
                     const uint32_t fi = seed_filter_index(h, filter_mask);
                     if (!((filter[fi >> 5] >> (fi & 31)) & 1u)) my_tag = 0xFFFFFFFFu;      // no target has this fingerprint
@@ -244,6 +246,10 @@ k_probe_sources(NodesDev nd, PrefSufCfg cfg, const unsigned long long *__restric
             const int sub = lane & 3;
             const uint64_t amask = __ballot(my_tag != 0xFFFFFFFFu);
             const int nact = __popcll(amask);
+            if (f_left > 0) {                              // pass rate over the wave's first batches: above 50 % the lookups are wasted
+                f_bal += 2 * nact - ((nwin - base) < 64 ? (nwin - base) : 64);
+                if (--f_left == 0 && f_bal > 0) f_left = -1;
+            }
             if (my_tag != 0xFFFFFFFFu) {
                 const int rank = (int) __builtin_amdgcn_mbcnt_hi((uint32_t) (amask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) amask, 0u));
                 w.actB[rank] = my_b;
@@ -886,16 +892,21 @@ uint32_t seed_buckets_for(uint64_t live, int fill_x10) {   // average entries pe
     return (uint32_t) std::min<uint64_t>(nb, 0x7FFFFFFFull);
 }
 
-// Prefilter size in bits (a power of two), 0 = off.  The bitmap pays only while it stays resident in every XCD's 4 MB L2
-// next to the streaming traffic (measured: a 4 MB bitmap at 6.1 M nodes made the probe 13 % SLOWER than no filter, its
-// lookups then miss L2 as often as the bucket reads they are meant to save) and while most windows match nothing (at
-// 163x coverage 65 % of the windows are real hits anyway).
+// Prefilter size in bits (a power of two), 0 = off.  Measured on MI355X:
+//  * up to 4 M nodes a bitmap of 8 bits/node fits every XCD's 4 MB L2 next to the streaming traffic: -12 % probe time at
+//    1.7 M nodes;
+//  * 6 M .. 14 M nodes: an L2-sized bitmap rejects too little, a bigger one misses L2 as often as the bucket reads it saves,
+//    and its build (one more random atomic per node) costs what the probe gains: off;
+//  * from 16 M nodes table + rows outgrow the 256 MB Infinity Cache and every bucket read goes to HBM, while a bitmap of up to
+//    128 MB still lives in that cache: -16 % at 90 M nodes (30x coverage).  At high coverage most windows are real hits and
+//    the lookups are wasted: the probing waves measure their pass rate and stop consulting the filter above 50 %.
 uint32_t seed_filter_bits_for(uint64_t live) {
     const uint64_t want = live * 8;
-    if (want > (1ull << 25)) return 0;
     uint64_t bits = 1ull << 16;
     while (bits < want) bits <<= 1;
-    return (uint32_t) bits;
+    if (bits <= (1ull << 25)) return (uint32_t) bits;
+    if (live < (1ull << 24)) return 0;
+    return (uint32_t) std::min<uint64_t>(bits, 1ull << 30);
 }
 
 void launch_seed_build(const NodesDev &nd, const PrefSufCfg &cfg, unsigned long long *table, uint32_t n_buckets, uint32_t *filter,

@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Config-4-shaped run on ONE GPU (BASELINE.json configs[3]: 50 M x 150 bp over a 250 Mb genome, error-free): the node set
+is generated in chunks straight into the engine's HBM layout, duplicates removed by start position (a forward read and a
+reverse read of the same interval are the same sequence up to reverse complement: the reference's duplicate removal keeps
+one of them; on an iid genome nothing else is a duplicate) -- and the graph is built with BOTH forms of the transitive reduction,
+which must agree edge for edge (the size-independent parity check at a size no CPU oracle finishes).
+usage: tools/run_cfg4.py [n_reads=50000000] [genome=250000000] [steps=2] [forms=source_side,per_target]"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+import alga_amd  # noqa: E402
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 50_000_000
+    G = int(sys.argv[2]) if len(sys.argv) > 2 else 250_000_000
+    steps = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+    forms = sys.argv[4].split(",") if len(sys.argv) > 4 else ["source_side", "per_target"]
+    L, trim = 150, 3
+    m = L - 2 * trim
+    t0 = time.time()
+    rng = np.random.default_rng(11)
+    genome = rng.integers(0, 4, G, dtype=np.uint8)
+    starts = rng.integers(0, G - L + 1, n)
+    flip = rng.random(n) < 0.5
+    starts, first = np.unique(starts, return_index=True)   # one read per start position, either strand
+    flip = flip[first]
+    perm = rng.permutation(len(starts))                 # node ids carry no positional information, as in a real read file
+    starts, flip = starts[perm], flip[perm]
+    R = len(starts)
+    N = 2 * R
+    stride = 16
+    words = np.zeros((N, stride), dtype=np.uint32)
+    CH = 1 << 20
+    for s0 in range(0, R, CH):
+        st = starts[s0:s0 + CH]
+        codes = genome[st[:, None] + (trim + np.arange(m))[None, :]]
+        f = flip[s0:s0 + CH]
+        codes[f] = (3 - codes[f])[:, ::-1]
+        words[2 * s0 + 1: 2 * (s0 + len(st)) + 1: 2, :9] = alga_amd.pack_reads(codes)
+        words[2 * s0: 2 * (s0 + len(st)): 2, :9] = alga_amd.pack_reads((3 - codes)[:, ::-1])
+        if (s0 // CH) % 8 == 0:
+            print("packed %d / %d reads, %.0f s" % (s0 + len(st), R, time.time() - t0), flush=True)
+    lens = np.full(N, m, dtype=np.int32)
+    lo, rs = alga_amd.derive_params(float(m))
+    print("node set: %d nodes, %.1f GB, built in %.0f s; min_overlap %d rsoemo %d" % (N, words.nbytes / 1e9, time.time() - t0, lo, rs), flush=True)
+    eng = alga_amd.Engine(0)
+    dw = torch.from_numpy(words.view(np.int32)).cuda()
+    dl = torch.from_numpy(lens).cuda()
+    del words
+    out = dict(reads=n, unique_reads=R, nodes=N, genome=G, min_overlap=lo, rsoemo=rs)
+    from alga_amd.engine import device_view
+    keep = {}
+    for red in forms:
+        ms = []
+        for it in range(steps):
+            ptr, E = eng.prefsuf_device(dw, dl, lo, rs, collect_stats=(it == 0), reduction=red)
+            st = eng.last_stats()
+            if it == 0:
+                out[red + "_counters"] = {k: st[k] for k in ("raw_overlaps", "records", "edges", "generic_sources", "windows_probed")}
+            ms.append({k: round(st[k], 3) for k in ("ms_total", "ms_seed", "ms_probe", "ms_group", "ms_reduce", "ms_emit")})
+            print(red, it, E, ms[-1], flush=True)
+        out[red] = ms
+        keep[red] = device_view(ptr, (E, 3), dw.device).clone()
+    if len(forms) == 2:
+        out["forms_agree"] = bool(keep[forms[0]].shape == keep[forms[1]].shape and torch.equal(keep[forms[0]], keep[forms[1]]))
+    e = keep[forms[0]]
+    out["edges"] = int(e.shape[0])
+    out["edges_per_sec_" + forms[0]] = out["edges"] / (out[forms[0]][-1]["ms_total"] * 1e-3)
+    out["gbp_per_sec_" + forms[0]] = n * 150 / (out[forms[0]][-1]["ms_total"] * 1e-3) / 1e9
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
