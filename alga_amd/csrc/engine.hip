@@ -347,7 +347,7 @@ void alga_engine_destroy(alga_engine *e) {
                       &e->out_cnt, &e->outdeg, &e->out_rowptr, &e->edges, &e->scan_scratch, &e->up_words, &e->up_len, &e->up_from, &e->up_to,
                       &e->ix_keys, &e->ix_vals, &e->ix_keys2, &e->ix_vals2, &e->ix_dir, &e->loc_first, &e->edge_keys, &e->edge_keys2, &e->edge_vals, &e->edge_vals2, &e->edges_sorted, &e->xs_dst, &e->xs_val,
                       &e->pk_keys, &e->pk_keys2, &e->pk_vals, &e->pk_vals2, &e->pk_marks, &e->pk_big, &e->pk_add, &e->pk_ekeys, &e->pk_ekeys2,
-                      &e->pk_flag, &e->pk_pos, &e->pk_edges[0], &e->pk_edges[1], &e->pk_rowptr, &e->pk_deg, &e->pk_mask, &e->pk_cnt, &e->pk_io, &e->pk_io2};
+                      &e->pk_flag, &e->pk_pos, &e->pk_edges[0], &e->pk_edges[1], &e->pk_rowptr, &e->pk_deg, &e->pk_mask, &e->pk_cnt, &e->pk_io, &e->pk_io2, &e->pk_tips, &e->pk_heads};
     for (DevBuf *b : bufs) alga_release(*b);
     if (e->h_counters) (void) hipHostFree(e->h_counters);
     for (int i = 0; i < EV_COUNT; i++) if (e->ev[i]) (void) hipEventDestroy(e->ev[i]);

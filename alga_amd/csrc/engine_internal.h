@@ -35,7 +35,7 @@ struct alga_engine {
     DevBuf up_words, up_len, up_from, up_to;   // uploads of the host-buffer entry points
     // approximate supplement (engine_pkb.hip)
     DevBuf pk_keys, pk_keys2, pk_vals, pk_vals2, pk_marks, pk_big, pk_add, pk_ekeys, pk_ekeys2, pk_flag, pk_pos, pk_edges[2], pk_rowptr, pk_deg,
-           pk_mask, pk_cnt, pk_io, pk_io2;
+           pk_mask, pk_cnt, pk_io, pk_io2, pk_tips, pk_heads;
     unsigned long long *h_counters = nullptr;  // pinned, CNT_TOTAL + 2 entries
     uint64_t    rec_cap_hint = 0, rec_cap_hint_local = 0;
     int         force_reduction = 0;          // ALGA_REDUCE=target|source overrides alga_prefsuf_params.reduction == AUTO (experiments)

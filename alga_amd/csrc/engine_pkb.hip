@@ -118,13 +118,21 @@ int supplement_device_impl(alga_engine *e, const alga_nodes *dn, const alga_pkb_
     if ((rc = alga_ensure(e, e->outdeg, (size_t) (n + 1) * sizeof(uint32_t)))) return rc;
     launch_pkb_masks(n, (const uint32_t *) e->pk_rowptr.p, (const alga_edge_dev *) e->pk_edges[cur].p, E, (uint32_t *) e->outdeg.p, (uint8_t *) e->pk_mask.p, s);
     if ((rc = alga_check_launch(e, "k_pkb_masks"))) return rc;
+    // the nodes that take part, as a dense list (the masks are fixed for all rounds)
+    if ((rc = alga_ensure(e, e->pk_tips, (size_t) (n + 1) * sizeof(uint32_t)))) return rc;
+    HIP_TRY(e, hipMemsetAsync(cnt, 0, 16 * sizeof(unsigned long long), s));
+    launch_pkb_tips(nd, c, (const uint8_t *) e->pk_mask.p, (uint32_t *) e->pk_tips.p, cnt + 0, s);
+    if ((rc = alga_check_launch(e, "k_pkb_tips"))) return rc;
+    HIP_TRY(e, hipMemcpyAsync(e->h_counters, cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    HIP_TRY(e, hipStreamSynchronize(s));
+    const uint32_t n_tips = (uint32_t) e->h_counters[0];
     int32_t prio[4] = {0, 1, 2, 3};
-    const uint64_t max_kmers = (uint64_t) n * (uint64_t) c.li_intervals;
+    const uint64_t max_kmers = (uint64_t) n_tips * (uint64_t) c.li_intervals;
     for (int round = 0; round < p->rounds; round++) {
         if ((rc = alga_ensure(e, e->pk_keys, (max_kmers + 1) * sizeof(unsigned long long)))) return rc;
         if ((rc = alga_ensure(e, e->pk_vals, (max_kmers + 1) * sizeof(unsigned long long)))) return rc;
         HIP_TRY(e, hipMemsetAsync(cnt, 0, 16 * sizeof(unsigned long long), s));
-        launch_pkb_kmers(nd, c, prio, (const uint8_t *) e->pk_mask.p, (unsigned long long *) e->pk_keys.p, (unsigned long long *) e->pk_vals.p, cnt + 0, s);
+        launch_pkb_kmers(nd, c, prio, (const uint32_t *) e->pk_tips.p, n_tips, (unsigned long long *) e->pk_keys.p, (unsigned long long *) e->pk_vals.p, cnt + 0, s);
         if ((rc = alga_check_launch(e, "k_pkb_kmers"))) return rc;
         HIP_TRY(e, hipMemcpyAsync(e->h_counters, cnt, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
         HIP_TRY(e, hipStreamSynchronize(s));
@@ -139,8 +147,15 @@ int supplement_device_impl(alga_engine *e, const alga_nodes *dn, const alga_pkb_
             // so the group kernel re-orders every group by (indInRead desc, length asc, id asc) itself
             HIP_TRY(e, sort_u64_pairs(e->sort_temp.p, temp, (const unsigned long long *) e->pk_keys.p, (unsigned long long *) e->pk_keys2.p,
                                       (const unsigned long long *) e->pk_vals.p, (unsigned long long *) e->pk_vals2.p, nk, 60, s));
-            launch_pkb_group_sizes((const unsigned long long *) e->pk_keys2.p, nk, cnt + 1, cnt + 2, s);
+            if ((rc = alga_ensure(e, e->pk_flag, (nk + 2) * sizeof(uint32_t)))) return rc;
+            if ((rc = alga_ensure(e, e->pk_pos, (nk + 2) * sizeof(uint32_t)))) return rc;
+            if ((rc = alga_ensure(e, e->pk_heads, (nk + 2) * sizeof(uint32_t)))) return rc;
+            if ((rc = alga_ensure(e, e->scan_scratch, scan_scratch_bytes(nk)))) return rc;
+            launch_pkb_group_sizes((const unsigned long long *) e->pk_keys2.p, nk, cnt + 1, cnt + 2, (uint32_t *) e->pk_flag.p, s);
             if ((rc = alga_check_launch(e, "k_pkb_group_sizes"))) return rc;
+            launch_exclusive_scan((const uint32_t *) e->pk_flag.p, nk, (uint32_t *) e->pk_pos.p, (uint64_t *) e->scan_scratch.p, s);
+            launch_pkb_head_list((const uint32_t *) e->pk_flag.p, (const uint32_t *) e->pk_pos.p, nk, (uint32_t *) e->pk_heads.p, s);
+            if ((rc = alga_check_launch(e, "k_pkb_head_list"))) return rc;
             HIP_TRY(e, hipMemcpyAsync(e->h_counters, cnt, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
             HIP_TRY(e, hipStreamSynchronize(s));
             const uint64_t big_words = e->h_counters[1];
@@ -159,7 +174,8 @@ int supplement_device_impl(alga_engine *e, const alga_nodes *dn, const alga_pkb_
                 HIP_TRY(e, hipMemsetAsync(add + add_dense, 0xFF, add_ovf_cap * sizeof(alga_edge_dev), s));      // src = -1: invalid
                 HIP_TRY(e, hipMemsetAsync(cnt + 4, 0, 4 * sizeof(unsigned long long), s));                    // big cursor, overflow, calls
                 launch_pkb_groups(nd, c, (const uint32_t *) e->pk_rowptr.p, (const alga_edge_dev *) e->pk_edges[cur].p,
-                                  (const unsigned long long *) e->pk_keys2.p, (unsigned long long *) e->pk_vals2.p, nk,
+                                  (const unsigned long long *) e->pk_keys2.p, (const uint32_t *) e->pk_heads.p, (uint32_t) e->pkb_stats.groups[round],
+                                  (unsigned long long *) e->pk_vals2.p, nk,
                                   (unsigned long long *) e->pk_marks.p, (unsigned long long *) e->pk_big.p, cnt + 4, add, add_dense, add_cap,
                                   cnt + 5, cnt + 6, s);
                 if ((rc = alga_check_launch(e, "k_pkb_groups"))) return rc;

@@ -21,10 +21,13 @@ struct PkbCfg {
 void launch_can_align_batch(const NodesDev &nd, const PkbCfg &c, const int32_t *triples, uint64_t n, uint8_t *out, hipStream_t s);
 void launch_li_kmers_slots(const NodesDev &nd, const PkbCfg &c, const int32_t prio[4], uint64_t *hash, int32_t *ind, int32_t *count, hipStream_t s);
 void launch_pkb_masks(int32_t n, const uint32_t *rowptr, const alga_edge_dev *edges, uint64_t m, uint32_t *indeg, uint8_t *mask, hipStream_t s);
-void launch_pkb_kmers(const NodesDev &nd, const PkbCfg &c, const int32_t prio[4], const uint8_t *mask, unsigned long long *keys,
+void launch_pkb_tips(const NodesDev &nd, const PkbCfg &c, const uint8_t *mask, uint32_t *tips, unsigned long long *counter, hipStream_t s);
+void launch_pkb_kmers(const NodesDev &nd, const PkbCfg &c, const int32_t prio[4], const uint32_t *tips, uint32_t n_tips, unsigned long long *keys,
                       unsigned long long *vals, unsigned long long *counter, hipStream_t s);
-void launch_pkb_group_sizes(const unsigned long long *keys, uint64_t n, unsigned long long *big_words, unsigned long long *stats, hipStream_t s);
-void launch_pkb_groups(const NodesDev &nd, const PkbCfg &c, const uint32_t *rowptr, const alga_edge_dev *edges, const unsigned long long *keys,
+void launch_pkb_group_sizes(const unsigned long long *keys, uint64_t n, unsigned long long *big_words, unsigned long long *stats, uint32_t *head_flag,
+                            hipStream_t s);
+void launch_pkb_head_list(const uint32_t *head_flag, const uint32_t *pos, uint64_t n, uint32_t *heads, hipStream_t s);
+void launch_pkb_groups(const NodesDev &nd, const PkbCfg &c, const uint32_t *rowptr, const alga_edge_dev *edges, const unsigned long long *keys, const uint32_t *heads, uint32_t n_heads,
                        unsigned long long *vals, uint64_t n, unsigned long long *marks, unsigned long long *big_marks,
                        unsigned long long *big_cursor, alga_edge_dev *add_edges, uint64_t add_dense, uint64_t add_cap,
                        unsigned long long *add_overflow, unsigned long long *counters, hipStream_t s);

@@ -137,20 +137,40 @@ __global__ void __launch_bounds__(256) k_pkb_masks(int32_t n, const uint32_t *__
     mask[i] = (uint8_t) (((ind > 0 && outd == 0) ? 1 : 0) | ((ind == 0 && outd > 0) ? 2 : 0));
 }
 
+// nodes that take part in the supplement (the masks never change between the rounds): dense id list, so that the k-mer kernel
+// runs with full waves (the tips are ~1 node in 5)
+__global__ void __launch_bounds__(256) k_pkb_tips(NodesDev nd, PkbCfg c, const uint8_t *__restrict__ mask, uint32_t *__restrict__ tips,
+                                                   unsigned long long *__restrict__ counter) {
+    __shared__ uint32_t s_cnt, s_base;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    const bool take = i < nd.n && mask[i] != 0 && nd.len[i] >= c.li_k && nd.len[i] >= c.kmer_length_bucket;   // Read::getKmers: length > size() -> none
+    uint32_t my = 0;
+    if (take) my = atomicAdd(&s_cnt, 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) s_base = s_cnt ? (uint32_t) atomicAdd(counter, (unsigned long long) s_cnt) : 0u;
+    __syncthreads();
+    if (take) tips[s_base + my] = (uint32_t) i;
+}
+
 // k-mers of every node that takes part (GraphCreatorKmerBased::getKmersForBucketJob :202-259), appended to a dense list
 //   key = hash, val = node id | (indInRead << 32)
-__global__ void __launch_bounds__(256) k_pkb_kmers(NodesDev nd, PkbCfg c, int4 prio4, const uint8_t *__restrict__ mask,
+__global__ void __launch_bounds__(256) k_pkb_kmers(NodesDev nd, PkbCfg c, int4 prio4, const uint32_t *__restrict__ tips, uint32_t n_tips,
                                                     unsigned long long *__restrict__ keys, unsigned long long *__restrict__ vals,
                                                     unsigned long long *__restrict__ counter) {
     __shared__ uint32_t s_cnt, s_base_lo, s_base_hi;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const int prio[4] = {prio4.x, prio4.y, prio4.z, prio4.w};
     uint64_t h[PKB_MAX_INTERVALS]; int32_t p[PKB_MAX_INTERVALS];
     int cnt = 0;
     if (threadIdx.x == 0) s_cnt = 0;
     __syncthreads();
-    if (i < nd.n && mask[i] != 0 && nd.len[i] >= c.li_k && nd.len[i] >= c.kmer_length_bucket)   // Read::getKmers: length > size() -> none
+    uint32_t i = 0;
+    if (t < n_tips) {
+        i = tips[t];
         cnt = li_kmers(nd.words + (size_t) i * nd.stride, nd.len[i], c.li_k, c.li_intervals, prio, h, p);
+    }
     uint32_t my = 0;
     if (cnt) my = atomicAdd(&s_cnt, (uint32_t) cnt);
     __syncthreads();
@@ -162,7 +182,7 @@ __global__ void __launch_bounds__(256) k_pkb_kmers(NodesDev nd, PkbCfg c, int4 p
     const unsigned long long base = ((unsigned long long) s_base_hi << 32) | s_base_lo;
     for (int j = 0; j < cnt; j++) {
         keys[base + my + j] = h[j];
-        vals[base + my + j] = (unsigned long long) (uint32_t) i | ((unsigned long long) (uint32_t) p[j] << 32);
+        vals[base + my + j] = (unsigned long long) i | ((unsigned long long) (uint32_t) p[j] << 32);
     }
 }
 
@@ -196,30 +216,50 @@ __device__ __forceinline__ uint64_t pkb_order_key(const NodesDev &nd, unsigned l
 
 __global__ void __launch_bounds__(256) k_pkb_group_sizes(const unsigned long long *__restrict__ keys, uint64_t n,
                                                           unsigned long long *__restrict__ big_words /* total words for groups > 64 */,
-                                                          unsigned long long *__restrict__ stats /* [0] groups >= 2, [1] max D */) {
+                                                          unsigned long long *__restrict__ stats /* [0] groups >= 2, [1] max D */,
+                                                          uint32_t *__restrict__ head_flag /* 1 = entry heads a group of >= 2 */) {
+    // per-thread tallies, one atomic per wave at the end (a contended atomic per group cost 0.8 ms per round)
+    unsigned long long n2 = 0, mx = 0, big = 0;
     for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) {
-        if (i > 0 && keys[i] == keys[i - 1]) continue;
+        if (i > 0 && keys[i] == keys[i - 1]) { head_flag[i] = 0u; continue; }
         uint64_t e = i + 1;
         while (e < n && keys[e] == keys[i]) e++;
         const uint64_t D = e - i;
-        if (D >= 2) atomicAdd(&stats[0], 1ull);
-        atomicMax(&stats[1], (unsigned long long) D);
-        if (D > 64) atomicAdd(big_words, (unsigned long long) (D * ((D + 63) / 64)));
+        head_flag[i] = D >= 2 ? 1u : 0u;
+        n2 += D >= 2;
+        mx = D > mx ? D : mx;
+        if (D > 64) big += D * ((D + 63) / 64);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        n2 += __shfl_xor(n2, o);
+        big += __shfl_xor(big, o);
+        const unsigned long long t = __shfl_xor(mx, o);
+        mx = t > mx ? t : mx;
+    }
+    __shared__ unsigned long long s_n2[4], s_mx[4], s_big[4];
+    const int wv = (int) (threadIdx.x >> 6);
+    if ((threadIdx.x & 63u) == 0) { s_n2[wv] = n2; s_mx[wv] = mx; s_big[wv] = big; }
+    __syncthreads();
+    if (threadIdx.x == 0) {                      // same-address atomics retire at ~88 per microsecond chip-wide: one set per workgroup
+        for (int k = 1; k < 4; k++) { n2 += s_n2[k]; big += s_big[k]; mx = s_mx[k] > mx ? s_mx[k] : mx; }
+        if (n2) atomicAdd(&stats[0], n2);
+        if (mx) atomicMax(&stats[1], mx);
+        if (big) atomicAdd(big_words, big);
     }
 }
 
-__global__ void __launch_bounds__(64) k_pkb_groups(NodesDev nd, PkbCfg c, PkbGraph g, const unsigned long long *__restrict__ keys,
-                                                    unsigned long long *__restrict__ vals, uint64_t n, unsigned long long *__restrict__ marks,
-                                                    unsigned long long *__restrict__ big_marks, unsigned long long *__restrict__ big_cursor,
-                                                    alga_edge_dev *__restrict__ add_edges, uint64_t add_dense, uint64_t add_cap,
-                                                    unsigned long long *__restrict__ add_overflow, unsigned long long *__restrict__ counters) {
-    const uint64_t gs = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (gs >= n) return;
-    if (gs > 0 && keys[gs] == keys[gs - 1]) return;                          // not the first entry of its group
+// one group (the thread owns the entry that heads it); returns the number of canAlign calls
+__device__ __forceinline__ unsigned long long pkb_group(const NodesDev &nd, const PkbCfg &c, const PkbGraph &g, const unsigned long long *__restrict__ keys,
+                                                       unsigned long long *__restrict__ vals, uint64_t n, uint64_t gs, unsigned long long *__restrict__ marks,
+                                                       unsigned long long *__restrict__ big_marks, unsigned long long *__restrict__ big_cursor,
+                                                       alga_edge_dev *__restrict__ add_edges, uint64_t add_dense, uint64_t add_cap,
+                                                       unsigned long long *__restrict__ add_overflow) {
+    if (gs > 0 && keys[gs] == keys[gs - 1]) return 0;                        // not the first entry of its group
     uint64_t ge = gs + 1;
     while (ge < n && keys[ge] == keys[gs]) ge++;
     const int D = (int) (ge - gs);
-    if (D < 2) return;
+    if (D < 2) return 0;
     unsigned long long *v = vals + gs;
     for (int i = 1; i < D; i++) {                                            // order the group
         const unsigned long long x = v[i];
@@ -282,7 +322,29 @@ __global__ void __launch_bounds__(64) k_pkb_groups(NodesDev nd, PkbCfg c, PkbGra
     }
     // unused dense slots are marked invalid
     for (int t = n_add; t < 2 * D; t++) mine[t].src = -1;
-    if (calls) atomicAdd(&counters[0], calls);
+    return calls;
+}
+
+// dense list of the entries that head a group of >= 2 (flags from k_pkb_group_sizes, positions from their scan): the group kernel
+// then runs with one group per lane instead of one lane in six
+__global__ void __launch_bounds__(256) k_pkb_head_list(const uint32_t *__restrict__ head_flag, const uint32_t *__restrict__ pos, uint64_t n,
+                                                        uint32_t *__restrict__ heads) {
+    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x)
+        if (head_flag[i]) heads[pos[i]] = (uint32_t) i;
+}
+
+__global__ void __launch_bounds__(64) k_pkb_groups(NodesDev nd, PkbCfg c, PkbGraph g, const unsigned long long *__restrict__ keys,
+                                                    const uint32_t *__restrict__ heads, uint32_t n_heads,
+                                                    unsigned long long *__restrict__ vals, uint64_t n, unsigned long long *__restrict__ marks,
+                                                    unsigned long long *__restrict__ big_marks, unsigned long long *__restrict__ big_cursor,
+                                                    alga_edge_dev *__restrict__ add_edges, uint64_t add_dense, uint64_t add_cap,
+                                                    unsigned long long *__restrict__ add_overflow, unsigned long long *__restrict__ counters) {
+    unsigned long long calls = 0;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n_heads) calls = pkb_group(nd, c, g, keys, vals, n, (uint64_t) heads[t], marks, big_marks, big_cursor, add_edges, add_dense, add_cap, add_overflow);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) calls += __shfl_xor(calls, o);          // one counter update per wave
+    if ((threadIdx.x & 63u) == 0 && calls) atomicAdd(&counters[0], calls);
 }
 
 __global__ void __launch_bounds__(256) k_pkb_mark_unused(const unsigned long long *__restrict__ keys, uint64_t n, alga_edge_dev *__restrict__ add_edges) {
@@ -348,26 +410,39 @@ void launch_pkb_masks(int32_t n, const uint32_t *rowptr, const alga_edge_dev *ed
     hipLaunchKernelGGL(k_pkb_masks, dim3((n + 255) / 256), dim3(256), 0, s, n, rowptr, indeg, mask);
 }
 
-void launch_pkb_kmers(const NodesDev &nd, const PkbCfg &c, const int32_t prio[4], const uint8_t *mask, unsigned long long *keys,
-                      unsigned long long *vals, unsigned long long *counter, hipStream_t s) {
+void launch_pkb_tips(const NodesDev &nd, const PkbCfg &c, const uint8_t *mask, uint32_t *tips, unsigned long long *counter, hipStream_t s) {
     if (nd.n <= 0) return;
-    hipLaunchKernelGGL(k_pkb_kmers, dim3((nd.n + 255) / 256), dim3(256), 0, s, nd, c, make_int4(prio[0], prio[1], prio[2], prio[3]), mask, keys, vals, counter);
+    hipLaunchKernelGGL(k_pkb_tips, dim3((nd.n + 255) / 256), dim3(256), 0, s, nd, c, mask, tips, counter);
 }
 
-void launch_pkb_group_sizes(const unsigned long long *keys, uint64_t n, unsigned long long *big_words, unsigned long long *stats, hipStream_t s) {
+void launch_pkb_kmers(const NodesDev &nd, const PkbCfg &c, const int32_t prio[4], const uint32_t *tips, uint32_t n_tips, unsigned long long *keys,
+                      unsigned long long *vals, unsigned long long *counter, hipStream_t s) {
+    if (n_tips == 0) return;
+    hipLaunchKernelGGL(k_pkb_kmers, dim3((n_tips + 255) / 256), dim3(256), 0, s, nd, c, make_int4(prio[0], prio[1], prio[2], prio[3]), tips, n_tips, keys, vals,
+                       counter);
+}
+
+void launch_pkb_group_sizes(const unsigned long long *keys, uint64_t n, unsigned long long *big_words, unsigned long long *stats, uint32_t *head_flag,
+                            hipStream_t s) {
     if (n == 0) return;
-    hipLaunchKernelGGL(k_pkb_group_sizes, dim3(pkb_grid(n, 256, 16384)), dim3(256), 0, s, keys, n, big_words, stats);
+    hipLaunchKernelGGL(k_pkb_group_sizes, dim3(pkb_grid(n, 256 * 8, 1024)), dim3(256), 0, s, keys, n, big_words, stats, head_flag);
+}
+
+void launch_pkb_head_list(const uint32_t *head_flag, const uint32_t *pos, uint64_t n, uint32_t *heads, hipStream_t s) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_pkb_head_list, dim3(pkb_grid(n, 256, 8192)), dim3(256), 0, s, head_flag, pos, n, heads);
 }
 
 void launch_pkb_groups(const NodesDev &nd, const PkbCfg &c, const uint32_t *rowptr, const alga_edge_dev *edges, const unsigned long long *keys,
-                       unsigned long long *vals, uint64_t n, unsigned long long *marks, unsigned long long *big_marks,
+                       const uint32_t *heads, uint32_t n_heads, unsigned long long *vals, uint64_t n, unsigned long long *marks, unsigned long long *big_marks,
                        unsigned long long *big_cursor, alga_edge_dev *add_edges, uint64_t add_dense, uint64_t add_cap,
                        unsigned long long *add_overflow, unsigned long long *counters, hipStream_t s) {
     if (n == 0) return;
     PkbGraph g{rowptr, edges};
     hipLaunchKernelGGL(k_pkb_mark_unused, dim3(pkb_grid(n, 256, 16384)), dim3(256), 0, s, keys, n, add_edges);
-    hipLaunchKernelGGL(k_pkb_groups, dim3((unsigned) ((n + 63) / 64)), dim3(64), 0, s, nd, c, g, keys, vals, n, marks, big_marks, big_cursor,
-                       add_edges, add_dense, add_cap, add_overflow, counters);
+    if (n_heads)
+        hipLaunchKernelGGL(k_pkb_groups, dim3((n_heads + 63) / 64), dim3(64), 0, s, nd, c, g, keys, heads, n_heads, vals, n, marks, big_marks, big_cursor,
+                           add_edges, add_dense, add_cap, add_overflow, counters);
 }
 
 void launch_pkb_edge_keys(const alga_edge_dev *e, uint64_t n, unsigned long long *keys, hipStream_t s) {
