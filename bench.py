@@ -195,7 +195,8 @@ def main():
                                    (wl["name"], world, wl["n_reads"], wl["read_len"], wl["genome"], wl["seed"], wl["err"],
                                     n_nodes, lo, rs),
                        "nodes": n_nodes, "edges": int(n_edges), "parallelism": "1 GPU" if world == 1 else
-                       "sources sharded over %d ranks, records all_to_all by target owner, edges all_gather" % world},
+                       "sources sharded over %d ranks, each builds the final edges of its sources (no record exchange), "
+                       "edge lists gathered on rank 0 over RCCL" % world},
             "roofline": {"bound": "hbm", "kernel": "k_probe_sources", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes": alg_probe_launch,
                          "kernel_ms": probe_avg_ms,
