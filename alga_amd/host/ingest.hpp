@@ -38,7 +38,24 @@ struct NodeSet {
     double avg_len = 0;
 };
 
-// returns "" on success, else an error message (the reference would print it and exit(1))
+// Stage 1 result: every record's two nodes in the reference's node order, before the removals that depend on other reads.
+struct Parsed {
+    size_t R = 0;                            // reads (= records; both files)
+    bool   paired = false;
+    int    W = 0;                            // uint32 words per row
+    std::vector<uint32_t> rows;              // 2R rows: node 2k = reverse complement, 2k+1 = forward of read k
+    std::vector<int32_t>  len;               // 2R; -1 = removed (N / STR)
+    int64_t records = 0, live = 0;
+    int removed_n = 0, removed_str = 0;
+    int LEN = 0, min_overlap = 0, rsoemo = 0, li_kmer_length = 0;
+    double avg_len = 0;
+    uint32_t *row(size_t i) { return rows.data() + i * (size_t) W; }
+    const uint32_t *row(size_t i) const { return rows.data() + i * (size_t) W; }
+};
+
+// Each returns "" on success, else an error message (the reference would print it and exit(1)).
+std::string parse(const std::string &file1, const std::string &file2, const IngestParams &p, Parsed &out);
+std::string preprocess_host(Parsed &P, const IngestParams &p, NodeSet &out);      // consumes P.len
 std::string ingest(const std::string &file1, const std::string &file2, const IngestParams &p, NodeSet &out);
 
 // "ALGA_<basename of file1 without extension>_scale<100*scale>_<noN|randN>" (src/Params.cpp:343,554-557)

@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""End-to-end time of the drop-in CLI at BASELINE configs[1]: FASTA on disk -> alga_hip (ingest on the host cores, overlap graph
+on the GPU, .graph dump) next to the reference binary's own time to the same point.  usage: tools/cli_e2e.py [config] [threads]"""
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import gen_reads  # noqa: E402
+from alga_amd import workload  # noqa: E402
+
+cfg = sys.argv[1] if len(sys.argv) > 1 else "cfg2_1M_150bp"
+threads = sys.argv[2] if len(sys.argv) > 2 else "16"
+n, L, G, seed, err = workload.CONFIGS[cfg]
+codes, _ = gen_reads.sample_reads(n, L, G, seed, err)
+out = {"config": cfg, "threads": int(threads)}
+with tempfile.TemporaryDirectory() as wd:
+    workload.write_fasta_fast(os.path.join(wd, "s.fasta"), codes)
+    exe = os.path.join(ROOT, "alga_amd", "bin", "alga_hip")
+    for rep in range(2):                     # second run: file in the page cache, HIP runtime warm on disk
+        t = time.perf_counter()
+        r = subprocess.run([exe, "--file1=s.fasta", "--threads=" + threads, "--output=o.fasta"], cwd=wd, stdout=subprocess.DEVNULL,
+                           stderr=subprocess.PIPE, text=True)
+        out["alga_hip_wall_s_run%d" % rep] = time.perf_counter() - t
+        m = re.search(r"ingest ([\d.]+) ms, overlap graph ([\d.]+) ms wall \(device ([\d.]+) ms", r.stderr)
+        if m:
+            out["alga_hip_ingest_ms"], out["alga_hip_graph_wall_ms"], out["alga_hip_graph_device_ms"] = map(float, m.groups())
+        m = re.search(r"Before first simplifier graph has (\d+) edges", r.stderr)
+        out["alga_hip_edges"] = int(m.group(1)) if m else None
+    ref = os.path.join(ROOT, "oracle", "_ref", "ALGA")
+    if os.path.exists(ref):
+        t = time.perf_counter()
+        p = subprocess.Popen([ref, "--file1=s.fasta", "--threads=" + threads, "--output=r.fasta"], cwd=wd, stdout=subprocess.DEVNULL,
+                             stderr=subprocess.PIPE, text=True, errors="replace")
+        for line in p.stderr:
+            if "Creating GraphCreator" in line:
+                out["ref_to_graph_creator_s"] = time.perf_counter() - t
+            if "Before first simplifier" in line:
+                out["ref_to_graph_done_s"] = time.perf_counter() - t
+                m = re.search(r"(\d+) edges", line)
+                out["ref_edges"] = int(m.group(1)) if m else None
+                p.kill()
+                break
+        p.wait()
+print(json.dumps(out))
