@@ -347,7 +347,8 @@ void alga_engine_destroy(alga_engine *e) {
                       &e->out_cnt, &e->outdeg, &e->out_rowptr, &e->edges, &e->scan_scratch, &e->up_words, &e->up_len, &e->up_from, &e->up_to,
                       &e->ix_keys, &e->ix_vals, &e->ix_keys2, &e->ix_vals2, &e->ix_dir, &e->loc_first, &e->edge_keys, &e->edge_keys2, &e->edge_vals, &e->edge_vals2, &e->edges_sorted, &e->xs_dst, &e->xs_val,
                       &e->pk_keys, &e->pk_keys2, &e->pk_vals, &e->pk_vals2, &e->pk_marks, &e->pk_big, &e->pk_add, &e->pk_ekeys, &e->pk_ekeys2,
-                      &e->pk_flag, &e->pk_pos, &e->pk_edges[0], &e->pk_edges[1], &e->pk_rowptr, &e->pk_deg, &e->pk_mask, &e->pk_cnt, &e->pk_io, &e->pk_io2, &e->pk_tips, &e->pk_heads};
+                      &e->pk_flag, &e->pk_pos, &e->pk_edges[0], &e->pk_edges[1], &e->pk_rowptr, &e->pk_deg, &e->pk_mask, &e->pk_cnt, &e->pk_io, &e->pk_io2, &e->pk_tips, &e->pk_heads, &e->pp_rows, &e->pp_len, &e->pp_perm[0], &e->pp_perm[1], &e->pp_keys[0], &e->pp_keys[1], &e->pp_mark,
+                      &e->pp_keep, &e->pp_pos, &e->pp_out_rows, &e->pp_out_len, &e->pp_out_pair, &e->pp_tally};
     for (DevBuf *b : bufs) alga_release(*b);
     if (e->h_counters) (void) hipHostFree(e->h_counters);
     for (int i = 0; i < EV_COUNT; i++) if (e->ev[i]) (void) hipEventDestroy(e->ev[i]);
@@ -468,6 +469,16 @@ int alga_prefsuf_build_host(alga_engine *e, const alga_nodes *nodes, const alga_
 }
 
 void alga_free_edges(alga_engine *e, alga_edge *edges) { (void) e; free(edges); }
+
+int alga_copy_to_host(alga_engine *e, void *dst, const void *d_src, size_t bytes) {
+    if (!e) return ALGA_ERR_INVALID_ARGUMENT;
+    e->err.clear();
+    if (bytes == 0) return ALGA_OK;
+    if (!dst || !d_src) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "pointers must not be NULL");
+    HIP_TRY(e, hipSetDevice(e->device));
+    HIP_TRY(e, hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost));
+    return ALGA_OK;
+}
 
 int alga_prefsuf_last_stats(const alga_engine *e, alga_prefsuf_stats *out) {
     if (!e || !out) return ALGA_ERR_INVALID_ARGUMENT;

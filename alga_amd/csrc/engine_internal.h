@@ -36,6 +36,8 @@ struct alga_engine {
     // approximate supplement (engine_pkb.hip)
     DevBuf pk_keys, pk_keys2, pk_vals, pk_vals2, pk_marks, pk_big, pk_add, pk_ekeys, pk_ekeys2, pk_flag, pk_pos, pk_edges[2], pk_rowptr, pk_deg,
            pk_mask, pk_cnt, pk_io, pk_io2, pk_tips, pk_heads;
+    // duplicate / prefix-read removal (engine_ingest.hip)
+    DevBuf pp_rows, pp_len, pp_perm[2], pp_keys[2], pp_mark, pp_keep, pp_pos, pp_out_rows, pp_out_len, pp_out_pair, pp_tally;
     unsigned long long *h_counters = nullptr;  // pinned, CNT_TOTAL + 2 entries
     uint64_t    rec_cap_hint = 0, rec_cap_hint_local = 0;
     int         force_reduction = 0;          // ALGA_REDUCE=target|source overrides alga_prefsuf_params.reduction == AUTO (experiments)

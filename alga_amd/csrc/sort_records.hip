@@ -11,6 +11,7 @@
 
 #include "prefsuf_kernels.h"
 #include "pkb_kernels.h"
+#include "ingest_kernels.h"
 
 namespace alga {
 
@@ -66,6 +67,14 @@ size_t sort_u64_keys_temp_bytes(uint64_t n) {
 hipError_t sort_u64_keys(void *temp, size_t temp_bytes, const unsigned long long *keys_in, unsigned long long *keys_out, uint64_t n, hipStream_t s) {
     if (n == 0) return hipSuccess;
     return rocprim::radix_sort_keys(temp, temp_bytes, keys_in, keys_out, (size_t) n, 0u, 64u, s);
+}
+
+// stable sort of (u64 key, u32 value) on the low `bits` key bits: the LSD passes of ingest_kernels.hip
+size_t sort_u64_u32_temp_bytes(uint64_t n) { return sort_edges_temp_bytes(n); }
+hipError_t sort_u64_u32(void *temp, size_t temp_bytes, const unsigned long long *keys_in, unsigned long long *keys_out, const uint32_t *vals_in,
+                        uint32_t *vals_out, uint64_t n, int bits, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    return rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t) n, 0u, (unsigned) bits, s);
 }
 
 } // namespace alga

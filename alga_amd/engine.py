@@ -62,6 +62,26 @@ class NodeSet(C.Structure):
                 ("removed_prefix", C.c_int32), ("removed_short", C.c_int32), ("avg_len", C.c_double)]
 
 
+class ParsedReads(C.Structure):
+    """alga_parsed_reads"""
+    _fields_ = [("n_nodes", C.c_int64), ("stride_words", C.c_int32), ("rows", C.POINTER(C.c_uint32)), ("len", C.POINTER(C.c_int32)),
+                ("paired", C.c_int32), ("records", C.c_int64), ("removed_n", C.c_int32), ("removed_str", C.c_int32), ("LEN", C.c_int32),
+                ("min_overlap", C.c_int32), ("rsoemo", C.c_int32), ("li_kmer_length", C.c_int32), ("avg_len", C.c_double),
+                ("owner", C.c_void_p)]
+
+
+class PreprocessInput(C.Structure):
+    """alga_preprocess_input"""
+    _fields_ = [("rows", C.c_void_p), ("stride_words", C.c_int32), ("len", C.c_void_p), ("n_nodes", C.c_int64),
+                ("remove_pref_reads", C.c_int32), ("min_keep_len", C.c_int32)]
+
+
+class DeviceNodeSet(C.Structure):
+    """alga_device_node_set"""
+    _fields_ = [("d_words", C.c_void_p), ("d_len", C.c_void_p), ("d_pair_off", C.c_void_p), ("n", C.c_int32), ("stride_words", C.c_int32),
+                ("removed_prefix", C.c_int32), ("removed_short", C.c_int32), ("max_len", C.c_int32), ("ms_device", C.c_double)]
+
+
 class PkbParams(C.Structure):
     """alga_pkb_params"""
     _fields_ = [("min_overlap_area", C.c_int32), ("max_offset_pct", C.c_int32), ("min_identity_pct", C.c_int32),
@@ -81,7 +101,7 @@ EXPORTS = ["alga_abi_version", "alga_engine_create", "alga_engine_destroy", "alg
            "alga_prefsuf_reduce_device", "alga_prefsuf_build_range_device", "alga_write_graph", "alga_ingest_default_params", "alga_ingest_files",
            "alga_free_node_set", "alga_sort_records_device", "alga_sort_edges_device", "alga_pkb_derive_params",
            "alga_can_align_batch_host", "alga_li_kmers_host", "alga_pkb_supplement_host", "alga_pkb_supplement_device",
-           "alga_pkb_last_stats"]
+           "alga_pkb_last_stats", "alga_parse_files", "alga_free_parsed_reads", "alga_preprocess_nodes", "alga_copy_to_host"]
 
 
 def library_path():
@@ -146,6 +166,11 @@ def load_library():
     lib.alga_ingest_files.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(IngestParams), C.POINTER(NodeSet), C.c_char_p, C.c_size_t]
     lib.alga_free_node_set.argtypes = [C.POINTER(NodeSet)]
     lib.alga_free_node_set.restype = None
+    lib.alga_parse_files.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(IngestParams), C.POINTER(ParsedReads), C.c_char_p, C.c_size_t]
+    lib.alga_free_parsed_reads.argtypes = [C.POINTER(ParsedReads)]
+    lib.alga_free_parsed_reads.restype = None
+    lib.alga_preprocess_nodes.argtypes = [C.c_void_p, C.POINTER(PreprocessInput), C.POINTER(DeviceNodeSet)]
+    lib.alga_copy_to_host.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
     _LIB = lib
     return lib
 
@@ -171,6 +196,29 @@ def ingest_files(file1, file2=None, threads=1, **kw):
                LEN=ns.LEN, min_overlap=ns.min_overlap, rsoemo=ns.rsoemo, li_kmer_length=ns.li_kmer_length, records=ns.records,
                removed_n=ns.removed_n, removed_str=ns.removed_str, removed_prefix=ns.removed_prefix, removed_short=ns.removed_short)
     lib.alga_free_node_set(C.byref(ns))
+    return out
+
+
+def parse_files(file1, file2=None, threads=1, **kw):
+    """Stage 1 of the input (C++ host): every record's two nodes in node order, before duplicate / prefix removal.
+    -> dict(rows[2R, stride] u32, len[2R] i32 (-1 removed), params); numpy copies."""
+    lib = load_library()
+    p = IngestParams()
+    lib.alga_ingest_default_params(C.byref(p))
+    p.threads = int(threads)
+    for k, v in kw.items():
+        setattr(p, k, v)
+    pr = ParsedReads()
+    err = C.create_string_buffer(512)
+    rc = lib.alga_parse_files(file1.encode(), (file2 or "").encode() or None, C.byref(p), C.byref(pr), err, 512)
+    if rc:
+        raise AlgaError(rc, err.value.decode())
+    n, st = int(pr.n_nodes), int(pr.stride_words)
+    out = dict(n_nodes=n, stride=st, rows=np.ctypeslib.as_array(pr.rows, shape=(max(n, 1) * st,))[: n * st].reshape(n, st).copy(),
+               len=np.ctypeslib.as_array(pr.len, shape=(max(n, 1),))[:n].copy(), paired=bool(pr.paired), records=pr.records,
+               removed_n=pr.removed_n, removed_str=pr.removed_str, LEN=pr.LEN, min_overlap=pr.min_overlap, rsoemo=pr.rsoemo,
+               li_kmer_length=pr.li_kmer_length, avg_len=pr.avg_len, remove_pref_reads=int(p.remove_pref_reads))
+    lib.alga_free_parsed_reads(C.byref(pr))
     return out
 
 
@@ -257,6 +305,17 @@ class Engine:
         st = PrefSufStats()
         self._check(self._lib.alga_prefsuf_last_stats(self._h, C.byref(st)))
         return st.as_dict()
+
+    # ---- duplicate / prefix-read removal + id compaction on the GPU ---------------------------
+    def preprocess_nodes(self, rows, lens, remove_pref_reads=2, min_keep_len=0):
+        """rows[2R, stride] u32 / lens[2R] i32 (-1 = removed) on the host -> DeviceNodeSet (device pointers, engine-owned)."""
+        rows = np.ascontiguousarray(rows, dtype=np.uint32)
+        lens = np.ascontiguousarray(lens, dtype=np.int32)
+        n = int(lens.shape[0])
+        inp = PreprocessInput(rows.ctypes.data, int(rows.shape[1]) if rows.ndim == 2 else 1, lens.ctypes.data, n, int(remove_pref_reads), int(min_keep_len))
+        out = DeviceNodeSet()
+        self._check(self._lib.alga_preprocess_nodes(self._h, C.byref(inp), C.byref(out)))
+        return out
 
     # ---- host buffers in, edges out (the drop-in call) --------------------------------------
     def prefsuf_host(self, words, lens, min_overlap, rsoe_min_overlap, align_from=None, align_to=None, collect_stats=False,

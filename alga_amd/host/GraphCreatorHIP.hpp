@@ -24,7 +24,16 @@ public:
         int rc = alga_engine_create(hip_device, &engine_);
         if (rc != ALGA_OK) die("cannot create the HIP engine (no usable MI355X / HIP device)", rc);
     }
-    ~GraphCreatorPrefSufHIP() { clear(); if (engine_) alga_engine_destroy(engine_); }
+    // Node set already resident in HBM (e.g. left there by alga_preprocess_nodes on `engine`): the engine is borrowed too,
+    // alignFrom / alignTo stay all-true (src/main.cpp:253-278 clears them for removed reads only, which carry len 0 here).
+    GraphCreatorPrefSufHIP(alga_engine *engine, const uint32_t *d_words, int stride_words, const int32_t *d_len, int n, int min_overlap,
+                           int rsoe_min_overlap)
+        : words_(d_words), stride_(stride_words), len_(d_len), n_(n), device_resident_(true), owns_engine_(false), engine_(engine) {
+        alga_prefsuf_default_params(&params_);
+        params_.min_overlap = min_overlap;
+        params_.rsoe_min_overlap = rsoe_min_overlap;
+    }
+    ~GraphCreatorPrefSufHIP() { clear(); if (engine_ && owns_engine_) alga_engine_destroy(engine_); }
 
     void setAlignTo(int id, bool val) { alignTo[(size_t) id] = val; }
     void setAlignFrom(int id, bool val) { alignFrom[(size_t) id] = val; }
@@ -34,10 +43,17 @@ public:
     // == startAlignmentGraphCreation() followed by the caller's G->retainOnlySmallestOffset() (src/main.cpp:282-291)
     void startAlignmentGraphCreation() {
         clear();
+        if (device_resident_) {
+            alga_nodes nd{words_, stride_, len_, n_, nullptr, nullptr};
+            int rc = alga_prefsuf_build_device(engine_, &nd, &params_, nullptr, &d_edges_, &n_edges_);
+            if (rc != ALGA_OK) die(alga_last_error(engine_), rc);
+            return;
+        }
         alga_nodes nd{words_, stride_, len_, n_, alignFrom.data(), alignTo.data()};
         int rc = alga_prefsuf_build_host(engine_, &nd, &params_, &edges_, &n_edges_);
         if (rc != ALGA_OK) die(alga_last_error(engine_), rc);
     }
+    const alga_edge *deviceEdges() const { return d_edges_; }    // device-resident form: engine-owned, valid until the next build
 
     const alga_edge *edges() const { return edges_; }
     uint64_t countEdges() const { return n_edges_; }             // Graph::countEdges
@@ -51,6 +67,8 @@ private:
         std::exit(1);
     }
     const uint32_t *words_; int stride_; const int32_t *len_; int n_;
+    bool device_resident_ = false, owns_engine_ = true;
+    const alga_edge *d_edges_ = nullptr;
     std::vector<uint8_t> alignFrom, alignTo;
     alga_prefsuf_params params_;
     alga_engine *engine_ = nullptr;

@@ -59,42 +59,51 @@ int main(int argc, char **argv) {
     if (file1.empty()) { fprintf(stderr, "\nERROR - PLEASE PROVIDE THE INPUT FILE using --file1 option!\n"); return 1; }
     if (output.empty()) { fprintf(stderr, "\nERROR - PLEASE PROVIDE THE OUTPUT FILE NAME!\n"); return 1; }
     auto t0 = clk::now();
-    alga_host::NodeSet nodes;
-    std::string err = alga_host::ingest(file1, file2, ip, nodes);
+    // stage 1 on the host cores: records -> packed node rows (src/IO/InputReader.cpp)
+    alga_host::Parsed parsed;
+    std::string err = alga_host::parse(file1, file2, ip, parsed);
     if (!err.empty()) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
     auto t1 = clk::now();
+    // stage 2 on the GPU: duplicate / prefix-read removal, id compaction (src/IO/ReadPreprocess.cpp, src/main.cpp:150-266);
+    // the node set stays in HBM for the graph creator
+    alga_engine *engine = nullptr;
+    if (alga_engine_create(device, &engine) != ALGA_OK) { fprintf(stderr, "alga_amd: no usable HIP device\n"); return 1; }
+    alga_preprocess_input pin{parsed.rows.data(), parsed.W, parsed.len.data(), (int64_t) (2 * parsed.R), ip.remove_pref_reads, 3 + parsed.li_kmer_length};
+    alga_device_node_set nodes;
+    if (alga_preprocess_nodes(engine, &pin, &nodes) != ALGA_OK) { fprintf(stderr, "%s\n", alga_last_error(engine)); return 1; }
+    auto t1b = clk::now();
     fprintf(stderr, "input read: %lld records -> %d nodes (removed: %d with N, %d STR, %d duplicate/prefix, %d too short)\n",
-            (long long) nodes.records, nodes.n, nodes.removed_n, nodes.removed_str, nodes.removed_prefix, nodes.removed_short);
-    fprintf(stderr, "MIN_OVERLAP_PREF_SUF: %d\nREMOVE_SMALL_OVERLAP_EDGES_MIN_OVERLAP: %d\n", nodes.min_overlap, nodes.rsoemo);
+            (long long) parsed.records, nodes.n, parsed.removed_n, parsed.removed_str, nodes.removed_prefix, nodes.removed_short);
+    fprintf(stderr, "MIN_OVERLAP_PREF_SUF: %d\nREMOVE_SMALL_OVERLAP_EDGES_MIN_OVERLAP: %d\n", parsed.min_overlap, parsed.rsoemo);
     fprintf(stderr, "Creating GraphCreator\n");
-    alga_host::GraphCreatorPrefSufHIP creator(nodes.words.data(), nodes.stride, nodes.len.data(), nodes.n, nodes.min_overlap, nodes.rsoemo, device);
+    alga_host::GraphCreatorPrefSufHIP creator(engine, nodes.d_words, nodes.stride_words, nodes.d_len, nodes.n, parsed.min_overlap, parsed.rsoemo);
     creator.startAlignmentGraphCreation();
     auto t2 = clk::now();
     alga_prefsuf_stats st = creator.stats();
-    const alga_edge *final_edges = creator.edges();
+    const alga_edge *d_final = creator.deviceEdges();
     uint64_t n_final = creator.countEdges();
-    alga_edge *sup_edges = nullptr;
-    alga_engine *sup_engine = nullptr;
     if (error_rate > 0.01) {                                                   // src/Params.cpp:358-359, src/main.cpp:300-355
         fprintf(stderr, "Before supplement, G has %llu edges\n", (unsigned long long) n_final);
+        std::vector<int32_t> hl((size_t) nodes.n);
+        if (nodes.n && alga_copy_to_host(engine, hl.data(), nodes.d_len, hl.size() * sizeof(int32_t)) != ALGA_OK) { fprintf(stderr, "alga_amd: cannot read node lengths back\n"); return 1; }
         double sum = 0; long long cnt = 0;
-        for (int i = 0; i < nodes.n; i++) if (nodes.len[(size_t) i] > 0) { sum += nodes.len[(size_t) i]; cnt++; }
+        for (int32_t l : hl) if (l > 0) { sum += l; cnt++; }
         alga_pkb_params pp;
-        alga_pkb_derive_params(cnt ? sum / (double) cnt : 0.0, ip.scale, error_rate, nodes.li_kmer_length, &pp);
-        if (alga_engine_create(device, &sup_engine) != ALGA_OK) { fprintf(stderr, "alga_amd: no usable HIP device\n"); return 1; }
-        alga_nodes nd{nodes.words.data(), nodes.stride, nodes.len.data(), nodes.n, nullptr, nullptr};
-        int rc = alga_pkb_supplement_host(sup_engine, &nd, &pp, final_edges, n_final, &sup_edges, &n_final);
-        if (rc != ALGA_OK) { fprintf(stderr, "alga_amd: %s (status %d)\n", alga_last_error(sup_engine), rc); return 1; }
-        final_edges = sup_edges;
+        alga_pkb_derive_params(cnt ? sum / (double) cnt : 0.0, ip.scale, error_rate, parsed.li_kmer_length, &pp);
+        alga_nodes nd{nodes.d_words, nodes.stride_words, nodes.d_len, nodes.n, nullptr, nullptr};
+        int rc = alga_pkb_supplement_device(engine, &nd, &pp, d_final, n_final, nullptr, &d_final, &n_final);
+        if (rc != ALGA_OK) { fprintf(stderr, "alga_amd: %s (status %d)\n", alga_last_error(engine), rc); return 1; }
         fprintf(stderr, "After supplement G has %llu edges\n", (unsigned long long) n_final);
     }
+    std::vector<alga_edge> final_edges((size_t) n_final);
+    if (n_final && alga_copy_to_host(engine, final_edges.data(), d_final, final_edges.size() * sizeof(alga_edge)) != ALGA_OK) { fprintf(stderr, "alga_amd: cannot read the edges back\n"); return 1; }
     fprintf(stderr, "Before first simplifier graph has %llu edges\n", (unsigned long long) n_final);
     auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-    fprintf(stderr, "ingest %.1f ms, overlap graph %.1f ms wall (device %.3f ms: seed %.3f probe %.3f group %.3f reduce %.3f emit %.3f)\n",
-            ms(t0, t1), ms(t1, t2), st.ms_total, st.ms_seed, st.ms_probe, st.ms_group, st.ms_reduce, st.ms_emit);
+    fprintf(stderr, "parse %.1f ms (host), duplicate/prefix removal %.1f ms wall (device %.3f ms), overlap graph %.1f ms wall (device %.3f ms: seed %.3f probe %.3f group %.3f reduce %.3f emit %.3f)\n",
+            ms(t0, t1), ms(t1, t1b), nodes.ms_device, ms(t1b, t2), st.ms_total, st.ms_seed, st.ms_probe, st.ms_group, st.ms_reduce, st.ms_emit);
     std::string graph = alga_host::test_name(file1, ip.scale, ip.remove_reads_with_n) + "_beforeSimplifier.graph";
     if (serialize) {
-        int rc = alga_write_graph(graph.c_str(), nodes.n, final_edges, n_final);
+        int rc = alga_write_graph(graph.c_str(), nodes.n, final_edges.data(), n_final);
         if (rc != ALGA_OK) { fprintf(stderr, "cannot write %s\n", graph.c_str()); return 1; }
         fprintf(stderr, "Graph serialized! -> %s\n", graph.c_str());
     }
@@ -106,7 +115,6 @@ int main(int argc, char **argv) {
         int rc = system(cmd.c_str());
         return rc == 0 ? 0 : 1;
     }
-    if (sup_edges) alga_free_edges(sup_engine, sup_edges);
-    if (sup_engine) alga_engine_destroy(sup_engine);
+    alga_engine_destroy(engine);
     return 0;
 }

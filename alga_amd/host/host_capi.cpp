@@ -45,6 +45,37 @@ int alga_ingest_files(const char *file1, const char *file2, const alga_ingest_pa
     return ALGA_OK;
 }
 
+static alga_host::IngestParams to_host_params(const alga_ingest_params *p) {
+    alga_host::IngestParams ip;
+    ip.trim_left = p->trim_left; ip.trim_right = p->trim_right; ip.remove_reads_with_n = p->remove_reads_with_n; ip.rna = p->rna;
+    ip.scale = p->scale; ip.min_overlap = p->min_overlap; ip.rsoemo = p->rsoemo; ip.remove_pref_reads = p->remove_pref_reads;
+    ip.threads = p->threads < 1 ? 1 : p->threads;
+    return ip;
+}
+
+int alga_parse_files(const char *file1, const char *file2, const alga_ingest_params *p, alga_parsed_reads *out, char *errbuf, size_t errlen) {
+    if (!file1 || !p || !out) return ALGA_ERR_INVALID_ARGUMENT;
+    memset(out, 0, sizeof(*out));
+    alga_host::Parsed *P = new alga_host::Parsed();
+    std::string err = alga_host::parse(file1, file2 ? file2 : "", to_host_params(p), *P);
+    if (!err.empty()) {
+        if (errbuf && errlen) snprintf(errbuf, errlen, "%s", err.c_str());
+        delete P;
+        return ALGA_ERR_IO;
+    }
+    out->n_nodes = (int64_t) (2 * P->R); out->stride_words = P->W; out->rows = P->rows.data(); out->len = P->len.data();
+    out->paired = P->paired ? 1 : 0; out->records = P->records; out->removed_n = P->removed_n; out->removed_str = P->removed_str;
+    out->LEN = P->LEN; out->min_overlap = P->min_overlap; out->rsoemo = P->rsoemo; out->li_kmer_length = P->li_kmer_length;
+    out->avg_len = P->avg_len; out->owner = P;
+    return ALGA_OK;
+}
+
+void alga_free_parsed_reads(alga_parsed_reads *pr) {
+    if (!pr) return;
+    delete (alga_host::Parsed *) pr->owner;
+    memset(pr, 0, sizeof(*pr));
+}
+
 void alga_free_node_set(alga_node_set *ns) {
     if (!ns) return;
     free(ns->words); free(ns->len); free(ns->pair_off);

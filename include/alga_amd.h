@@ -131,6 +131,10 @@ void alga_free_edges(alga_engine *e, alga_edge *edges);
 int  alga_prefsuf_build_device(alga_engine *e, const alga_nodes *nodes, const alga_prefsuf_params *p,
                                void *hip_stream, const alga_edge **d_edges, uint64_t *n_edges);
 
+/* Copies `bytes` of engine-owned device memory (an edge list, a device node set) into host memory: for callers that
+ * are plain C/C++ without the HIP headers. */
+int  alga_copy_to_host(alga_engine *e, void *dst, const void *d_src, size_t bytes);
+
 /* Counters and per-phase device times of the last build call on `e`. */
 int  alga_prefsuf_last_stats(const alga_engine *e, alga_prefsuf_stats *out);
 
@@ -253,6 +257,51 @@ void alga_ingest_default_params(alga_ingest_params *p);
 int  alga_ingest_files(const char *file1, const char *file2 /* may be NULL */, const alga_ingest_params *p,
                        alga_node_set *out, char *errbuf, size_t errlen);
 void alga_free_node_set(alga_node_set *ns);
+
+/* Stage 1 alone: files -> every record's two nodes in the reference's node order, before the removals that depend on other
+ * reads (src/IO/InputReader.cpp:44-139,272-391, parameters of src/main.cpp:93-115).  Release with alga_free_parsed_reads. */
+typedef struct {
+    int64_t   n_nodes;               /* 2 x records                                                                     */
+    int32_t   stride_words;
+    uint32_t *rows;                  /* n_nodes x stride_words, node 2k = reverse complement, 2k+1 = forward of read k  */
+    int32_t  *len;                   /* -1 = removed (N / STR)                                                          */
+    int32_t   paired;
+    int64_t   records;
+    int32_t   removed_n, removed_str;
+    int32_t   LEN, min_overlap, rsoemo, li_kmer_length;
+    double    avg_len;
+    void     *owner;                 /* internal                                                                        */
+} alga_parsed_reads;
+
+int  alga_parse_files(const char *file1, const char *file2 /* may be NULL */, const alga_ingest_params *p,
+                      alga_parsed_reads *out, char *errbuf, size_t errlen);
+void alga_free_parsed_reads(alga_parsed_reads *pr);
+
+/* ---- duplicate / prefix-read removal and id compaction on the GPU ----------------------------
+ * The stage between the parser and the GraphCreator constructor (src/IO/ReadPreprocess.cpp:13-152, src/main.cpp:150-232,
+ * 253-266): every record's two nodes in the reference's node order come in from the host (as alga_amd/host/ingest.cpp
+ * `parse` leaves them; len -1 = removed by the N / STR filters), the surviving node set stays on the device, ready for
+ * alga_prefsuf_build_device.  Same result as the host statement of the stage behind alga_ingest_files. */
+typedef struct {
+    const uint32_t *rows;            /* host: n_nodes rows of stride_words uint32, zero padded, node 2k = reverse complement,
+                                        2k+1 = forward strand of read k                                               */
+    int32_t         stride_words;
+    const int32_t  *len;             /* host: n_nodes lengths, -1 = removed                                             */
+    int64_t         n_nodes;         /* even                                                                            */
+    int32_t         remove_pref_reads; /* 1 duplicates, 2 all prefix reads (the reference's default), 3 none           */
+    int32_t         min_keep_len;    /* nodes shorter than this are emptied (len 0): 3 + li_kmer_length                */
+} alga_preprocess_input;
+
+typedef struct {
+    const uint32_t *d_words;         /* device, engine-owned until the next alga_preprocess_nodes call on the engine   */
+    const int32_t  *d_len;
+    const uint8_t  *d_pair_off;      /* Global::pairedReadOffset                                                        */
+    int32_t         n, stride_words;
+    int32_t         removed_prefix, removed_short, max_len;
+    double          ms_device;       /* upload excluded: sort + mark + compaction                                       */
+} alga_device_node_set;
+
+int  alga_preprocess_nodes(alga_engine *e, const alga_preprocess_input *in, alga_device_node_set *out);
 
 /* ---- graph dump: the reference's own checkpoint format ------------------------------------ */
 /* Graph::serializeGraph (src/DataStructures/Graph.cpp:269-297): u32 n; n x {i32 id; i32 deg;

@@ -28,9 +28,10 @@ with tempfile.TemporaryDirectory() as wd:
         r = subprocess.run([exe, "--file1=s.fasta", "--threads=" + threads, "--output=o.fasta"], cwd=wd, stdout=subprocess.DEVNULL,
                            stderr=subprocess.PIPE, text=True)
         out["alga_hip_wall_s_run%d" % rep] = time.perf_counter() - t
-        m = re.search(r"ingest ([\d.]+) ms, overlap graph ([\d.]+) ms wall \(device ([\d.]+) ms", r.stderr)
+        m = re.search(r"parse ([\d.]+) ms \(host\), duplicate/prefix removal ([\d.]+) ms wall \(device ([\d.]+) ms\), overlap graph ([\d.]+) ms wall \(device ([\d.]+) ms", r.stderr)
         if m:
-            out["alga_hip_ingest_ms"], out["alga_hip_graph_wall_ms"], out["alga_hip_graph_device_ms"] = map(float, m.groups())
+            (out["alga_hip_parse_ms"], out["alga_hip_dedupe_wall_ms"], out["alga_hip_dedupe_device_ms"], out["alga_hip_graph_wall_ms"],
+             out["alga_hip_graph_device_ms"]) = map(float, m.groups())
         m = re.search(r"Before first simplifier graph has (\d+) edges", r.stderr)
         out["alga_hip_edges"] = int(m.group(1)) if m else None
     ref = os.path.join(ROOT, "oracle", "_ref", "ALGA")
