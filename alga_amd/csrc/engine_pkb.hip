@@ -77,8 +77,18 @@ int normalize_edges(alga_engine *e, int32_t n_nodes, const alga_edge_dev *in, ui
     if ((rc = alga_ensure(e, e->scan_scratch, std::max(scan_scratch_bytes(n_in), scan_scratch_bytes((uint64_t) n_nodes))))) return rc;
     if ((rc = alga_ensure(e, e->pk_deg, (size_t) (n_nodes + 1) * sizeof(uint32_t)))) return rc;
     if ((rc = alga_ensure(e, e->pk_rowptr, (size_t) (n_nodes + 2) * sizeof(uint32_t)))) return rc;
-    launch_pkb_edge_keys(in, n_in, (unsigned long long *) e->pk_ekeys.p, s);
-    if ((rc = alga_check_launch(e, "k_pkb_edge_keys"))) return rc;
+    // only the used entries are sorted (a round's addition slots are ~99 % unused)
+    launch_pkb_valid_flags(in, n_in, (uint32_t *) e->pk_flag.p, s);
+    if ((rc = alga_check_launch(e, "k_pkb_valid_flags"))) return rc;
+    launch_exclusive_scan((const uint32_t *) e->pk_flag.p, n_in, (uint32_t *) e->pk_pos.p, (uint64_t *) e->scan_scratch.p, s);
+    if ((rc = alga_check_launch(e, "scan(valid)"))) return rc;
+    launch_pkb_edge_keys_dense(in, (const uint32_t *) e->pk_flag.p, (const uint32_t *) e->pk_pos.p, n_in, (unsigned long long *) e->pk_ekeys.p, s);
+    if ((rc = alga_check_launch(e, "k_pkb_edge_keys_dense"))) return rc;
+    HIP_TRY(e, hipMemcpyAsync(&e->h_counters[CNT_TOTAL], (uint64_t *) e->scan_scratch.p + scan_total_index(n_in), sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(e, hipStreamSynchronize(s));
+    const uint64_t n_all = n_in;
+    n_in = n_all ? e->h_counters[CNT_TOTAL] : 0;                 // from here on: the used entries
+    (void) n_all;
     HIP_TRY(e, sort_u64_keys(e->sort_temp.p, temp, (const unsigned long long *) e->pk_ekeys.p, (unsigned long long *) e->pk_ekeys2.p, n_in, s));
     launch_pkb_unique_flags((const unsigned long long *) e->pk_ekeys2.p, n_in, (uint32_t *) e->pk_flag.p, s);
     if ((rc = alga_check_launch(e, "k_pkb_unique_flags"))) return rc;

@@ -368,6 +368,20 @@ __global__ void __launch_bounds__(256) k_pkb_edge_keys(const alga_edge_dev *__re
     }
 }
 
+// The addition slots of a round are mostly unused (src < 0): only the used entries are worth sorting.
+__global__ void __launch_bounds__(256) k_pkb_valid_flags(const alga_edge_dev *__restrict__ e, uint64_t n, uint32_t *__restrict__ flag) {
+    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) flag[i] = e[i].src >= 0 ? 1u : 0u;
+}
+
+__global__ void __launch_bounds__(256) k_pkb_edge_keys_dense(const alga_edge_dev *__restrict__ e, const uint32_t *__restrict__ flag,
+                                                              const uint32_t *__restrict__ pos, uint64_t n, unsigned long long *__restrict__ keys) {
+    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) {
+        if (!flag[i]) continue;
+        const alga_edge_dev x = e[i];
+        keys[pos[i]] = ((unsigned long long) (uint32_t) x.src << 36) | ((unsigned long long) (uint32_t) x.dst << 9) | (uint32_t) (x.offset & 511);
+    }
+}
+
 // after the sort: keep the first key of every (src, dst) run == the smallest offset (Graph::retainOnlySmallestOffset)
 __global__ void __launch_bounds__(256) k_pkb_unique_flags(const unsigned long long *__restrict__ keys, uint64_t n, uint32_t *__restrict__ flag) {
     for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) {
@@ -448,6 +462,16 @@ void launch_pkb_groups(const NodesDev &nd, const PkbCfg &c, const uint32_t *rowp
 void launch_pkb_edge_keys(const alga_edge_dev *e, uint64_t n, unsigned long long *keys, hipStream_t s) {
     if (n == 0) return;
     hipLaunchKernelGGL(k_pkb_edge_keys, dim3(pkb_grid(n, 256, 16384)), dim3(256), 0, s, e, n, keys);
+}
+
+void launch_pkb_valid_flags(const alga_edge_dev *e, uint64_t n, uint32_t *flag, hipStream_t s) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_pkb_valid_flags, dim3(pkb_grid(n, 256, 16384)), dim3(256), 0, s, e, n, flag);
+}
+
+void launch_pkb_edge_keys_dense(const alga_edge_dev *e, const uint32_t *flag, const uint32_t *pos, uint64_t n, unsigned long long *keys, hipStream_t s) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_pkb_edge_keys_dense, dim3(pkb_grid(n, 256, 16384)), dim3(256), 0, s, e, flag, pos, n, keys);
 }
 
 void launch_pkb_unique_flags(const unsigned long long *keys, uint64_t n, uint32_t *flag, hipStream_t s) {
