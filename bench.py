@@ -209,6 +209,15 @@ def main():
             "algorithmic_bytes_total": alg["total"],
             "device": eng.device_name(),
         }
+        if world == 1:
+            # the same graph through the host-buffer entry point (pageable host arrays in, host edge list out): never `value`
+            ts = []
+            for _ in range(3):
+                t = time.perf_counter()
+                he = eng.prefsuf_host(wl["words"], wl["lens"], lo, rs)
+                ts.append(time.perf_counter() - t)
+            out["pcie_inclusive"] = {"ms_per_graph": min(ts) * 1e3, "edges_per_sec": len(he) / min(ts),
+                                     "note": "alga_prefsuf_build_host: H2D of the packed reads + build + D2H of the edges, best of 3"}
         if not args.no_cpu_baseline and world == 1:        # the CPU baseline is a rank-0, N=1 measurement
             try:
                 cores = len(os.sched_getaffinity(0))
