@@ -4,6 +4,8 @@ Bar: bit-exact edge sets (integer work).  The exact path of the reference decide
 (src/GraphCreators/GraphCreatorPrefSuf.cpp:386-387) where the engine compares 2-bit words exactly, so the
 two can differ only on a double hash collision (p ~ 1e-27 per pair).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -13,6 +15,7 @@ import oracle_lib as O
 from source_side_rule import preconditions
 
 pytestmark = pytest.mark.gpu
+MIN_PROBE = os.environ.get("ALGA_PROBE") == "min"      # experimental probe: per-target form only
 
 
 @pytest.fixture(scope="module")
@@ -37,6 +40,8 @@ def _check(eng, words, lens, lo, rs, af=None, at=None, stats=True, source_side=N
         assert st["transitive_removed"] == cnt["transitive_removed"]
         assert st["edges"] == len(want)
     exact = preconditions(lens, lo, rs, af, at) and int(np.max(lens, initial=0)) - lo <= 63
+    if os.environ.get("ALGA_PROBE") == "min":       # the experimental minimizer probe only feeds the per-target form
+        exact = False
     if source_side is None:
         source_side = exact
     if source_side:
@@ -161,6 +166,7 @@ def _tandem_nodes(seed, n_reads, genome_len, length, period):
     return alga_amd.pack_reads(codes), np.full(len(codes), length, np.int32)
 
 
+@pytest.mark.skipif(MIN_PROBE, reason="source-side form needs the bucket probe")
 @pytest.mark.parametrize("seed,n_reads,period", [(41, 700, 5), (42, 2500, 7), (43, 1200, 23)])
 def test_tandem_repeats_same_target_at_several_offsets(eng, seed, n_reads, period):
     words, lens = _tandem_nodes(seed, n_reads, 6000, 60, period)
@@ -169,6 +175,7 @@ def test_tandem_repeats_same_target_at_several_offsets(eng, seed, n_reads, perio
     assert eng.last_stats()["generic_sources"] > 0           # the all-pairs path of the source-side form really ran
 
 
+@pytest.mark.skipif(MIN_PROBE, reason="source-side form needs the bucket probe")
 def test_source_side_range_build_needs_no_exchange(eng):
     import torch
     from alga_amd.engine import device_edges_to_numpy
