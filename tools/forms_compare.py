@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Both forms of the transitive reduction on one synthetic set: tools/forms_compare.py n_reads genome err [steps]"""
+import json
+import sys
+
+import numpy as np
+import torch
+
+import alga_amd
+import gen_reads
+from alga_amd import workload
+
+n, G, err = int(sys.argv[1]), int(sys.argv[2]), float(sys.argv[3])
+steps = int(sys.argv[4]) if len(sys.argv) > 4 else 3
+codes, _ = gen_reads.sample_reads(n, 150, G, 13, err)
+words, lens, ids = workload.make_nodes(codes, stride_words="aligned")
+lo, rs = alga_amd.derive_params(144.0)
+eng = alga_amd.Engine(0)
+dw = torch.from_numpy(words.view(np.int32)).cuda()
+dl = torch.from_numpy(lens).cuda()
+out = {"nodes": int(len(lens))}
+for red in ("source_side", "per_target"):
+    ms = []
+    for it in range(steps + 1):
+        ptr, m = eng.prefsuf_device(dw, dl, lo, rs, collect_stats=(it == 0), reduction=red)
+        st = eng.last_stats()
+        if it == 0:
+            out[red + "_counters"] = {k: st[k] for k in ("edges", "raw_overlaps", "records", "generic_sources")}
+        else:
+            ms.append(st["ms_total"])
+    out[red + "_ms"] = float(np.mean(ms))
+print(json.dumps(out))
