@@ -1,0 +1,82 @@
+"""A thread-based stand-in for torch.distributed (the handful of collectives alga_amd/multigpu.py uses), so that the real
+sharded driver + the real HIP backend can run as N 'ranks' inside ONE process on ONE GPU -- TEST INFRASTRUCTURE.
+Every rank is a thread holding a FakeDist(rank); collectives rendezvous on a shared barrier."""
+import threading
+
+
+class _World:
+    def __init__(self, n):
+        self.n = n
+        self.barrier = threading.Barrier(n)
+        self.slots = [None] * n
+
+
+class ReduceOp:
+    SUM, MAX = "sum", "max"
+
+
+class FakeDist:
+    ReduceOp = ReduceOp
+
+    def __init__(self, world, rank):
+        self.w, self.rank = world, rank
+
+    def _exchange(self, obj):
+        self.w.slots[self.rank] = obj
+        self.w.barrier.wait()
+        got = list(self.w.slots)
+        self.w.barrier.wait()
+        return got
+
+    def all_gather_into_tensor(self, out, inp):
+        import torch
+        parts = self._exchange(inp.detach().clone())
+        out.copy_(torch.cat([p.reshape(-1) for p in parts]).reshape(out.shape))
+
+    def gather(self, tensor, gather_list=None, dst=0):
+        parts = self._exchange(tensor.detach().clone())
+        if self.rank == dst:
+            for g, p in zip(gather_list, parts):
+                g.copy_(p)
+
+    def all_reduce(self, t, op=ReduceOp.SUM):
+        import torch
+        parts = self._exchange(t.detach().clone())
+        st = torch.stack(parts)
+        t.copy_(st.max(dim=0).values if op == ReduceOp.MAX else st.sum(dim=0))
+
+    def all_to_all_single(self, out, inp, output_split_sizes=None, input_split_sizes=None):
+        import torch
+        n = self.w.n
+        if input_split_sizes is None:
+            k = inp.shape[0] // n
+            input_split_sizes = [k] * n
+        offs = [0]
+        for s in input_split_sizes:
+            offs.append(offs[-1] + s)
+        mine = [inp[offs[q]:offs[q + 1]].detach().clone() for q in range(n)]
+        allp = self._exchange(mine)
+        recv = [allp[r][self.rank] for r in range(n)]
+        out.copy_(torch.cat(recv) if recv else out)
+
+
+def run_ranks(n, fn):
+    """fn(rank, dist) in n threads; returns the list of results, re-raises the first exception."""
+    world = _World(n)
+    res, err = [None] * n, []
+
+    def work(r):
+        try:
+            res[r] = fn(r, FakeDist(world, r))
+        except BaseException as e:      # noqa: BLE001 -- surfaced below; a dead rank would deadlock the others
+            err.append(e)
+            world.barrier.abort()
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(n)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    if err:
+        raise err[0]
+    return res

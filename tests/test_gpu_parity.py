@@ -327,3 +327,37 @@ def test_exchange_helpers_emulated_ranks(eng):
     got = be.sort_edges(allp).cpu().numpy()
     assert got.shape == want.shape and (got == want).all()
     assert (be.build().cpu().numpy() == want).all()
+
+
+@pytest.mark.skipif(MIN_PROBE, reason="source-side form needs the bucket probe")
+@pytest.mark.parametrize("lo,rs,replicate", [(90, 120, False), (90, 120, True), (82, 116, False)])
+def test_sharded_driver_with_hip_backend_three_ranks_one_gpu(lo, rs, replicate):
+    """alga_amd.multigpu.ShardedPrefSuf exactly as bench.py --gpus N drives it (real HipBackend, device tensors), the
+    collectives replaced by a thread rendezvous: 3 ranks, one engine each, on this one GPU.  (90, 120): source-side form,
+    no record exchange; (82, 116): reads of 150 nt are too long for it, every rank declines and all take the exchange."""
+    import torch
+    from alga_amd.multigpu import HipBackend, ShardedPrefSuf
+    from fake_dist import run_ranks
+    words, lens = _nodes(3000, 150, 7000, 51, err=0.002, stride=16)
+    want, _, _ = O.prefsuf(words, lens, lo, rs)
+    dw = torch.from_numpy(words.view(np.int32)).cuda()
+    dl = torch.from_numpy(lens).cuda()
+
+    def rank_main(rank, dist):
+        e = alga_amd.Engine(0)
+        try:
+            run = ShardedPrefSuf(HipBackend(e, dw, dl, lo, rs), rank, 3, dist, replicate=replicate)
+            m, st = run.step(collect_stats=True)
+            m2, _ = run.step()
+            assert m == m2 == len(want)
+            return run.edges_numpy(), st["raw_overlaps"]
+        finally:
+            e.close()
+    res = run_ranks(3, rank_main)
+    _, _, cnt = O.prefsuf(words, lens, lo, rs)
+    for r, (got, raw) in enumerate(res):
+        assert raw == cnt["hash_equal"]                              # whole-job counter, all-reduced
+        if r == 0 or replicate:
+            assert got.shape == want.shape and (got == want).all()
+        else:
+            assert len(got) == 0
