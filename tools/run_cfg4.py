@@ -4,7 +4,9 @@ is generated in chunks straight into the engine's HBM layout, duplicates removed
 reverse read of the same interval are the same sequence up to reverse complement: the reference's duplicate removal keeps
 one of them; on an iid genome nothing else is a duplicate) -- and the graph is built with BOTH forms of the transitive reduction,
 which must agree edge for edge (the size-independent parity check at a size no CPU oracle finishes).
-usage: tools/run_cfg4.py [n_reads=50000000] [genome=250000000] [steps=2] [forms=source_side,per_target]"""
+usage: tools/run_cfg4.py [n_reads=50000000] [genome=250000000] [steps=2] [forms=source_side,per_target] [ref_threads=0]
+With ref_threads > 0 the same reads are written as FASTA and the real reference (oracle/_ref/ALGA) builds its graph beside it:
+wall time of its creator region and its edge count."""
 import json
 import os
 import sys
@@ -24,6 +26,7 @@ def main():
     G = int(sys.argv[2]) if len(sys.argv) > 2 else 250_000_000
     steps = int(sys.argv[3]) if len(sys.argv) > 3 else 2
     forms = sys.argv[4].split(",") if len(sys.argv) > 4 else ["source_side", "per_target"]
+    ref_threads = int(sys.argv[5]) if len(sys.argv) > 5 else 0
     L, trim = 150, 3
     m = L - 2 * trim
     t0 = time.time()
@@ -76,7 +79,63 @@ def main():
     out["edges"] = int(e.shape[0])
     out["edges_per_sec_" + forms[0]] = out["edges"] / (out[forms[0]][-1]["ms_total"] * 1e-3)
     out["gbp_per_sec_" + forms[0]] = n * 150 / (out[forms[0]][-1]["ms_total"] * 1e-3) / 1e9
+    if ref_threads > 0:
+        out["reference"] = run_reference(genome, starts, flip, L, ref_threads)
+        out["reference"]["edges_equal_gpu"] = out["reference"].get("edges") == out["edges"]
     print(json.dumps(out))
+
+
+def run_reference(genome, starts, flip, L, threads):
+    import re
+    import subprocess
+    import tempfile
+    exe = os.path.join(ROOT, "oracle", "_ref", "ALGA")
+    if not os.path.exists(exe):
+        return {"error": "oracle/_ref/ALGA is not built"}
+    res = {"threads": threads}
+    with tempfile.TemporaryDirectory(dir=os.environ.get("ALGA_TMP", None)) as wd:
+        t0 = time.time()
+        lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+        path = os.path.join(wd, "s.fasta")
+        with open(path, "wb") as f:
+            CH = 1 << 20
+            for s0 in range(0, len(starts), CH):
+                st = starts[s0:s0 + CH]
+                codes = genome[st[:, None] + np.arange(L)[None, :]]
+                fl = flip[s0:s0 + CH]
+                codes[fl] = (3 - codes[fl])[:, ::-1]
+                n = len(st)
+                rec = np.empty((n, 12 + L + 1), dtype=np.uint8)          # ">" + 10 digits + "\n" + sequence + "\n"
+                rec[:, 0] = ord(">")
+                ids = np.arange(s0, s0 + n)
+                for k in range(10):
+                    rec[:, 10 - k] = ord("0") + (ids // 10 ** k) % 10
+                rec[:, 11] = ord("\n")
+                rec[:, 12:12 + L] = lut[codes]
+                rec[:, 12 + L] = ord("\n")
+                f.write(rec.tobytes())
+        res["fasta_write_s"] = time.time() - t0
+        print("FASTA written in %.0f s; starting the reference with %d threads" % (res["fasta_write_s"], threads), flush=True)
+        t = time.time()
+        p = subprocess.Popen([exe, "--file1=s.fasta", "--threads=%d" % threads, "--output=o.fasta"], cwd=wd, stdout=subprocess.DEVNULL,
+                             stderr=subprocess.PIPE, text=True, errors="replace")
+        last = time.time()
+        for line in p.stderr:
+            if "Creating GraphCreator" in line:
+                res["to_graph_creator_s"] = time.time() - t
+            if "After Iteration" in line and time.time() - last > 30:
+                print("reference:", line.strip()[:100], "at %.0f s" % (time.time() - t), flush=True)
+                last = time.time()
+            if "Before first simplifier" in line:
+                res["to_graph_done_s"] = time.time() - t
+                m = re.search(r"(\d+) edges", line)
+                res["edges"] = int(m.group(1)) if m else None
+                p.kill()
+                break
+        p.wait()
+        if "to_graph_done_s" in res and "to_graph_creator_s" in res:
+            res["graph_creator_s"] = res["to_graph_done_s"] - res["to_graph_creator_s"]
+    return res
 
 
 if __name__ == "__main__":
