@@ -4,7 +4,7 @@
 //   seed   : memset + k_seed_build
 //   probe  : k_probe_sources                      (dominant kernel; retried with a larger record
 //                                                  buffer if the first capacity guess overflows)
-//   group  : scan(in-degree) + k_scatter_by_target
+//   group  : k_make_keys + radix sort by target + k_rowptr_from_sorted + k_gather_heads
 //   reduce : k_reduce_targets
 //   emit   : scan(out-degree) + k_scatter_by_source + k_sort_rows
 // With the source-side reduction (alga_reduction) the probing wave emits final edges and

@@ -2,10 +2,11 @@
 //
 // The engine computes the graph of the reference's GraphCreatorPrefSuf
 // (src/GraphCreators/GraphCreatorPrefSuf.cpp:73-488 + src/main.cpp:291) with a different
-// algorithm shape: one seed table over the min_overlap-long prefixes of all
-// targets, one probe per (source, overlap length) suffix window verified by an exact 2-bit
-// compare, the per-source small-overlap cap applied inside the probing wave, and a per-target
-// sequential replay of the reference's insertion order for the transitive reduction.
+// algorithm shape: one seed table over a prefix of every target, one probe per
+// (source, overlap length) suffix window verified by an exact 2-bit compare, and the transitive
+// reduction either at the source, inside the probing wave (the default whenever it is exact:
+// prefsuf_device.h local_reduce), or as a per-target sequential replay of
+// the reference's insertion order (any input).
 #pragma once
 #include <stdint.h>
 

@@ -5,13 +5,18 @@
 // Integer / byte work only: no MFMA.  Wavefront = 64 lanes throughout.
 //
 //   k_node_stats        max read length, live-node count
-//   k_seed_build        fingerprint of the min_overlap-long prefix of every target -> bucketised seed
-//                       table (64-byte buckets of 8 entries: one cache line answers one probe)
+//   k_seed_build        fingerprint of the first min(min_overlap, 64) nucleotides of every target ->
+//                       bucketised seed table (64-byte buckets of 8 entries: one cache line answers one
+//                       probe) + L2-resident prefilter bitmap
 //   k_probe_sources     persistent wavefronts, one source at a time: the source's tail is staged in
-//                       LDS, lane p fingerprints suffix window p and reads ONE bucket; tag hits become
-//                       candidates in LDS; candidates are then verified one per lane with wide row
-//                       loads and an exact 2-bit compare; the per-source small-overlap top-3 is a wave
-//                       max-reduction; records leave through an LDS buffer in coalesced chunks
+//                       LDS, lane p fingerprints suffix window p; the windows that pass the prefilter are
+//                       compacted, four lanes read one bucket; tag hits become candidates in LDS, four
+//                       lanes verify one candidate with a wide row load and an exact 2-bit compare.
+//                       LOCAL = true : verified overlaps become items, the transitive reduction runs in
+//                                      the wave (prefsuf_device.h local_reduce), final edges leave
+//                       LOCAL = false: per-source small-overlap top-3 (wave max-reduction), all capped
+//                                      overlaps leave as records for the per-target pipeline below
+//   k_local_emit_*      source-side form: adjacency lists from out-degrees, one-edge slots, record list
 //   k_make_keys         record -> sort key (target id local to the owned range, invalid last)
 //   (radix sort by key: sort_records.hip)
 //   k_rowptr_from_sorted   row pointers of the per-target segments
@@ -257,7 +262,6 @@ k_probe_sources(NodesDev nd, PrefSufCfg cfg, const unsigned long long *__restric
             }
             wave_lds_fence();
             int ncand = 0;                                 // uniform
-            bool overflow_spill = false;
             auto append = [&](bool hit, uint32_t id, uint32_t tl, int wl) {      // convergent
                 const uint64_t m = __ballot(hit);
                 if (hit) {
@@ -303,7 +307,6 @@ k_probe_sources(NodesDev nd, PrefSufCfg cfg, const unsigned long long *__restric
                     }
                 }
             }
-            (void) overflow_spill;
             // ---- phase 2: candidates -> exact 2-bit compare of C[0, L) with B[off, off+L) ----------------------------
             wave_lds_fence();
 #if defined(ABLATE) && ABLATE == 2
