@@ -30,6 +30,7 @@ struct Prepared {
     int        max_len = 0;
     uint64_t   live = 0;
     bool       local_ok = false;     // the source-side reduction is exact for this input
+    int        local_sw = 1;         // ... with one or two 64-bit words per offset mask / uint4 per overhang
     int        reduction = ALGA_REDUCTION_AUTO;
 };
 
@@ -80,6 +81,7 @@ int prepare(alga_engine *e, const alga_nodes *nodes, const alga_prefsuf_params *
     // preconditions of the source-side reduction (prefsuf_device.h: local_reduce; tests/source_side_rule.py)
     out.local_ok = out.max_len <= p->max_len_cap && out.max_len - c.Lmin <= LOCAL_MAX_SPAN && c.Lmin <= c.rsoemo && c.rsoemo <= c.Lcap &&
                    e->h_counters[CNT_MASK_ASYM] == 0 && e->probe_mode == 0;
+    out.local_sw = out.max_len - c.Lmin <= 63 ? 1 : 2;
     out.reduction = p->reduction;
     if (out.reduction == ALGA_REDUCTION_AUTO && e->force_reduction) out.reduction = e->force_reduction == 1 ? ALGA_REDUCTION_PER_TARGET : ALGA_REDUCTION_AUTO;
     return ALGA_OK;
@@ -154,7 +156,7 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
         HIP_TRY(e, hipMemsetAsync(cnt, 0, CNT_TOTAL * sizeof(unsigned long long), s));
         if (e->probe_mode == 0)
             launch_probe(nd, cfg, (const unsigned long long *) e->table.p, n_buckets, (const uint32_t *) e->filter.p, filter_bits, src_begin, src_end,
-                         (uint32_t *) e->rec_dst.p, (unsigned long long *) e->rec_val.p, cap, cnt, e->n_cu, local, (uint32_t *) e->outdeg.p,
+                         (uint32_t *) e->rec_dst.p, (unsigned long long *) e->rec_val.p, cap, cnt, e->n_cu, local ? pp.local_sw : 0, (uint32_t *) e->outdeg.p,
                          (unsigned long long *) e->loc_first.p, s);
         else
             launch_probe_min(nd, cfg, (const unsigned long long *) e->ix_dir.p, dir_slots, (const unsigned long long *) e->ix_vals2.p, src_begin, src_end,

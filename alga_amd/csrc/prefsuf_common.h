@@ -51,7 +51,7 @@ ALGA_HD inline uint64_t fp_final(uint64_t h) {
 
 constexpr uint32_t REC_INVALID = 0xFFFFFFFFu; // rec_dst marker: unused slot of a record chunk
 constexpr uint64_t SEED_EMPTY = ~0ull; // seed-table slot: ((tag23 << 9 | len9) << 32) | node id ; empty = all ones
-constexpr int LOCAL_MAX_SPAN = 63;     // source-side reduction: max_len - Lmin; offsets and overhangs fit 64-bit masks / 128 bits
+constexpr int LOCAL_MAX_SPAN = 127;    // source-side reduction: max_len - Lmin; offsets and overhangs fit one (<= 63) or two 64-bit mask words
 constexpr int SEED_BUCKET = 8;         // slots per bucket: 8 x 8 B = one 64-byte line per probe
 
 // number of uint32 blocks that hold `len_nt` nucleotides (Bitset::blocks(), Bitset.h:206)

@@ -225,8 +225,8 @@ __device__ __forceinline__ bool verify_overlap(const NodesDev &nd, const uint32_
 // the overlap from the row words it already holds).
 // Fast path (error-free reads): one item per offset; each item is tested against its nearest predecessor only and
 // anything that does not resolve that way sends the whole source down the generic all-pairs path.
-// Host-checked preconditions (engine.hip local_ok): max_len - Lmin <= 63, max_len <= cap, alignFrom => alignTo,
-// Lmin <= rsoemo <= Lcap.
+// Host-checked preconditions (engine.hip local_ok): max_len - Lmin <= 63 (SW = 1) or <= 127 (SW = 2), max_len <= cap,
+// alignFrom => alignTo, Lmin <= rsoemo <= Lcap.
 // ------------------------------------------------------------------------------------------
 constexpr int ITEMMAX = 160;              // raw overlaps of one source held in LDS; more -> CNT_LOCAL_OVERFLOW, per-target pipeline
 constexpr uint32_t ITEM_FROM = 1u << 18;
@@ -247,34 +247,85 @@ __device__ __forceinline__ uint64_t wave_or_u64_dpp(uint64_t v) {
 
 __device__ __forceinline__ uint32_t low_bits32(int bits) { return bits >= 32 ? 0xFFFFFFFFu : (bits <= 0 ? 0u : ((1u << bits) - 1u)); }
 
+// SW = 64-bit words of an offset mask = uint4 words of an overhang: 1 covers max_len - Lmin <= 63 (100-150 bp reads with the
+// reference's default scale), 2 covers <= 127 (250 bp).
+template <int SW> struct Ovh { uint32_t w[4 * SW]; };
+
+template <int SW>
+__device__ __forceinline__ Ovh<SW> load_ovh(const uint4 *O, int idx) {
+    Ovh<SW> r;
+#pragma unroll
+    for (int q = 0; q < SW; q++) { const uint4 v = O[idx * SW + q]; r.w[4 * q] = v.x; r.w[4 * q + 1] = v.y; r.w[4 * q + 2] = v.z; r.w[4 * q + 3] = v.w; }
+    return r;
+}
+
 // is item j (= B) a via that removes item i (= C) of source A ?
-__device__ __forceinline__ bool via_ok(int A, int lenA, int Lbig, uint32_t Cj, uint32_t mj, const uint4 &oj, uint32_t Ci, int di, int rho_i,
-                                       const uint4 &oi) {
+template <int SW>
+__device__ __forceinline__ bool via_ok(int A, int lenA, int Lbig, uint32_t Cj, uint32_t mj, const Ovh<SW> &oj, uint32_t Ci, int di, int rho_i,
+                                       const Ovh<SW> &oi) {
     const int dj = (int) (mj & 511u), lenj = (int) ((mj >> 9) & 511u);
     const int rho_j = lenj - (lenA - dj);
     const int Lv = lenj - (di - dj);                       // length of the overlap B -> C
     const bool ok = (mj & ITEM_FROM) != 0 && Cj != Ci && dj < di && Lv >= Lbig && rho_j <= rho_i && (rho_j > 0 || (int) Cj > A);
     const int nb = 2 * rho_j;
-    const uint32_t diff = ((oi.x ^ oj.x) & low_bits32(nb)) | ((oi.y ^ oj.y) & low_bits32(nb - 32)) | ((oi.z ^ oj.z) & low_bits32(nb - 64)) |
-                          ((oi.w ^ oj.w) & low_bits32(nb - 96));
+    uint32_t diff = 0;
+#pragma unroll
+    for (int k = 0; k < 4 * SW; k++) diff |= (oi.w[k] ^ oj.w[k]) & low_bits32(nb - 32 * k);
     return ok && diff == 0;
 }
 
 // overhang of item `slot` from X's row in global memory (cold paths of the probe; the wide verification fills it from registers).
 // Bits past the overhang's own length are never compared (via_ok masks with the via's length <= the candidate's), so
 // nothing here is masked.
+template <int SW>
 __device__ __forceinline__ void item_overhang_global(const NodesDev &nd, const ItemLds &it, int slot, int C, int L, int lenC) {
     if (slot < 0 || slot >= ITEMMAX) return;
     const uint32_t *row = nd.words + (size_t) C * nd.stride;
     const int ws = (2 * L) >> 5, r = (2 * L) & 31, lastw = (2 * lenC - 1) >> 5;
-    uint32_t x[5];
+    uint32_t x[4 * SW + 1];
 #pragma unroll
-    for (int k = 0; k < 5; k++) x[k] = (ws + k <= lastw) ? row[ws + k] : 0u;
-    it.O[slot] = make_uint4(funnel(x[0], x[1], r), funnel(x[1], x[2], r), funnel(x[2], x[3], r), funnel(x[3], x[4], r));
+    for (int k = 0; k <= 4 * SW; k++) x[k] = (ws + k <= lastw) ? row[ws + k] : 0u;
+#pragma unroll
+    for (int q = 0; q < SW; q++)
+        it.O[slot * SW + q] = make_uint4(funnel(x[4 * q], x[4 * q + 1], r), funnel(x[4 * q + 1], x[4 * q + 2], r), funnel(x[4 * q + 2], x[4 * q + 3], r),
+                                         funnel(x[4 * q + 3], x[4 * q + 4], r));
+}
+
+// set of offsets (bit d), SW x 64 bits
+template <int SW> struct OffMask { uint64_t w[SW]; };
+template <int SW> __device__ __forceinline__ OffMask<SW> offmask_below(const OffMask<SW> &m, int d) {      // bits < d
+    OffMask<SW> r;
+#pragma unroll
+    for (int q = 0; q < SW; q++) {
+        const int lo = d - 64 * q;
+        r.w[q] = lo >= 64 ? m.w[q] : (lo <= 0 ? 0ull : (m.w[q] & ((1ull << lo) - 1ull)));
+    }
+    return r;
+}
+template <int SW> __device__ __forceinline__ OffMask<SW> offmask_from(const OffMask<SW> &m, int d) {       // bits >= d
+    OffMask<SW> r;
+#pragma unroll
+    for (int q = 0; q < SW; q++) {
+        const int lo = d - 64 * q;
+        r.w[q] = lo >= 64 ? 0ull : (lo <= 0 ? m.w[q] : (m.w[q] & ~((1ull << lo) - 1ull)));
+    }
+    return r;
+}
+template <int SW> __device__ __forceinline__ int offmask_count(const OffMask<SW> &m) {
+    int c = 0;
+#pragma unroll
+    for (int q = 0; q < SW; q++) c += __popcll(m.w[q]);
+    return c;
+}
+template <int SW> __device__ __forceinline__ int offmask_highest(const OffMask<SW> &m) {                   // -1 = empty
+    int r = -1;
+#pragma unroll
+    for (int q = 0; q < SW; q++) if (m.w[q]) r = 64 * q + 63 - __clzll((long long) m.w[q]);
+    return r;
 }
 
 // Convergent.  n = items of source A in `it` (<= ITEMMAX), overhangs filled.
-template <bool STATS, int WB>
+template <bool STATS, int WB, int SW>
 __device__ __forceinline__ void local_reduce(const NodesDev &nd, const PrefSufCfg &cfg, const ItemLds &it, const WaveLds &w, const ProbeOut &o,
                                              int A, int lenA, int n, uint64_t &st_rec, uint64_t &st_cmp, uint64_t &st_generic) {
     const int lane = lane_id();
@@ -292,24 +343,29 @@ __device__ __forceinline__ void local_reduce(const NodesDev &nd, const PrefSufCf
     if (!generic) {
         const bool act = lane < n;
         uint32_t C = 0, m = 0;
-        uint4 ov = make_uint4(0u, 0u, 0u, 0u);
+        Ovh<SW> ov;
+#pragma unroll
+        for (int k = 0; k < 4 * SW; k++) ov.w[k] = 0u;
         int d = 0;
-        if (act) { C = it.C[lane]; m = it.M[lane]; ov = it.O[lane]; d = (int) (m & 511u); }
-        const uint64_t occ = wave_or_u64_dpp(act ? (1ull << d) : 0ull);
-        generic = __popcll(occ) != n;                      // two items at one offset
+        if (act) { C = it.C[lane]; m = it.M[lane]; ov = load_ovh<SW>(it.O, lane); d = (int) (m & 511u); }
+        OffMask<SW> occ;
+#pragma unroll
+        for (int q = 0; q < SW; q++) occ.w[q] = wave_or_u64_dpp((act && (d >> 6) == q) ? (1ull << (d & 63)) : 0ull);
+        generic = offmask_count<SW>(occ) != n;             // two items at one offset
         if (!generic) {
-            const uint64_t below = occ & ((1ull << d) - 1ull);
-            const bool has_pred = act && below != 0;
+            const OffMask<SW> below = offmask_below<SW>(occ, d);
+            const int pd = act ? offmask_highest<SW>(below) : -1;
+            const bool has_pred = pd >= 0;
             if (act) it.T[d] = (uint8_t) lane;
             wave_lds_fence();
             bool fail = false, removed = false;
             if (has_pred) {
-                const int j = (int) it.T[63 - __clzll((long long) below)];
+                const int j = (int) it.T[pd];
                 const uint32_t Cj = it.C[j], mj = it.M[j];
-                const uint4 oj = it.O[j];
+                const Ovh<SW> oj = load_ovh<SW>(it.O, j);
                 const int rho = (int) ((m >> 9) & 511u) - (lenA - d);
                 if (STATS) st_cmp++;
-                removed = via_ok(A, lenA, Lbig, Cj, mj, oj, C, d, rho, ov);
+                removed = via_ok<SW>(A, lenA, Lbig, Cj, mj, oj, C, d, rho, ov);
                 // Not removed by the nearest predecessor: if even the longest read placed there could not reach C with a big
                 // overlap, no earlier item can (they all start further left) and the item stands; anything else is undecided.
                 fail = !removed && (cfg.Lcap - 1) - (d - (int) (mj & 511u)) >= Lbig;
@@ -330,8 +386,7 @@ __device__ __forceinline__ void local_reduce(const NodesDev &nd, const PrefSufCf
                     // Several stand (gaps too long for a big via).  Per-source cap: with one item per offset the 3 largest small
                     // (L, C) keys are the 3 small items with the smallest offsets.
                     const int ds0 = lenA - cfg.rsoemo + 1;                           // first offset of a small overlap
-                    const uint64_t small_mask = ds0 <= 0 ? ~0ull : (ds0 >= 64 ? 0ull : ~((1ull << ds0) - 1ull));
-                    const bool kept = act && (d < ds0 || __popcll(occ & below & small_mask) < 3);
+                    const bool kept = act && (d < ds0 || offmask_count<SW>(offmask_from<SW>(below, ds0)) < 3);
                     surv &= __ballot(kept);
                     // the same target at a smaller offset supersedes (Graph.cpp:348-387, GraphCreatorPrefSuf.cpp:461-462), whatever
                     // became of that instance: test each survivor against all kept items
@@ -367,17 +422,19 @@ __device__ __forceinline__ void local_reduce(const NodesDev &nd, const PrefSufCf
             const int i = base + lane;
             const bool act = i < n;
             uint32_t C = 0, m = 0;
-            uint4 ov = make_uint4(0u, 0u, 0u, 0u);
-            if (act) { C = it.C[i]; m = it.M[i]; ov = it.O[i]; }
+            Ovh<SW> ov;
+#pragma unroll
+            for (int k = 0; k < 4 * SW; k++) ov.w[k] = 0u;
+            if (act) { C = it.C[i]; m = it.M[i]; ov = load_ovh<SW>(it.O, i); }
             const int d = (int) (m & 511u);
             const int rho = (int) ((m >> 9) & 511u) - (lenA - d);
             bool removed = !act || !is_kept(C, d);
             for (int j = 0; j < n; j++) {
                 const uint32_t Cj = it.C[j], mj = it.M[j];
-                const uint4 oj = it.O[j];
+                const Ovh<SW> oj = load_ovh<SW>(it.O, j);
                 const int dj = (int) (mj & 511u);
                 if (Cj == C) removed = removed || (dj < d && is_kept(Cj, dj));      // same target at a smaller offset: Graph.cpp:348-387, :461-462
-                else { if (STATS && act && dj < d) st_cmp++; removed = removed || via_ok(A, lenA, Lbig, Cj, mj, oj, C, d, rho, ov); }
+                else { if (STATS && act && dj < d) st_cmp++; removed = removed || via_ok<SW>(A, lenA, Lbig, Cj, mj, oj, C, d, rho, ov); }
             }
             if (!removed) push(C, d);
             n_out += __popcll(__ballot(!removed));

@@ -19,7 +19,7 @@ void launch_seed_build(const NodesDev &nd, const PrefSufCfg &cfg, unsigned long 
 // overlap record = rec_dst[i] (target id, REC_INVALID for chunk padding) + rec_val[i] ((ol << 32) | source id)
 void launch_probe(const NodesDev &nd, const PrefSufCfg &cfg, const unsigned long long *table, uint32_t n_buckets,
                   const uint32_t *filter, uint32_t filter_bits, int32_t src_begin, int32_t src_end, uint32_t *rec_dst, unsigned long long *rec_val, uint64_t rec_cap,
-                  unsigned long long *counters, int n_cu, bool local, uint32_t *deg /* local: zeroed, n_src */, unsigned long long *first /* local: n_src */,
+                  unsigned long long *counters, int n_cu, int local /* 0, or the mask width 1 | 2 of the source-side form */, uint32_t *deg /* local: zeroed, n_src */, unsigned long long *first /* local: n_src */,
                   hipStream_t s);
 uint64_t probe_record_slack(int n_cu, uint64_t n_src, bool local);
 // source-side reduction: adjacency lists from the probe's out-degrees (rowptr = their scan), one-edge slots and record list

@@ -107,9 +107,10 @@ __global__ void __launch_bounds__(256) k_seed_build(NodesDev nd, PrefSufCfg cfg,
 #ifndef PROBE_OCC
 #define PROBE_OCC 4                   // minimum waves per SIMD requested from the register allocator
 #endif
-// LOCAL: the wave also performs the transitive reduction for its source (prefsuf_device.h: local_reduce) and the
-// records it emits are the final edges; otherwise the records are all capped raw overlaps, reduced per target later.
-template <bool STATS, int NQ, bool LOCAL>
+// LOCAL != 0: the wave also performs the transitive reduction for its source (prefsuf_device.h: local_reduce; LOCAL = width of
+// its offset masks / overhangs: 1 for max_len - Lmin <= 63, 2 for <= 127) and what it emits are the final edges; LOCAL == 0: the
+// records are all capped raw overlaps, reduced per target later.
+template <bool STATS, int NQ, int LOCAL>
 __global__ void __launch_bounds__(PROBE_WAVES * 64, PROBE_OCC)
 k_probe_sources(NodesDev nd, PrefSufCfg cfg, const unsigned long long *__restrict__ table, uint32_t n_buckets,
                 const uint32_t *__restrict__ filter, uint32_t filter_mask, int32_t src_begin, int32_t src_end, ProbeOut o) {
@@ -122,8 +123,8 @@ k_probe_sources(NodesDev nd, PrefSufCfg cfg, const unsigned long long *__restric
     __shared__ uint32_t sCnt[PROBE_WAVES][3];
     __shared__ uint32_t sItemC[PROBE_WAVES][LOCAL ? ITEMMAX : 1];
     __shared__ uint32_t sItemM[PROBE_WAVES][LOCAL ? ITEMMAX : 1];
-    __shared__ uint4 sItemO[PROBE_WAVES][LOCAL ? ITEMMAX : 1];
-    __shared__ uint8_t sItemT[PROBE_WAVES][64];
+    __shared__ uint4 sItemO[PROBE_WAVES][LOCAL ? ITEMMAX * LOCAL : 1];
+    __shared__ uint8_t sItemT[PROBE_WAVES][LOCAL > 1 ? 64 * LOCAL : 64];
     __shared__ uint32_t sActB[PROBE_WAVES][64];
     __shared__ uint32_t sActT[PROBE_WAVES][64];
     constexpr int CHUNK = LOCAL ? REC_CHUNK_LOCAL : REC_CHUNK;
@@ -331,7 +332,7 @@ k_probe_sources(NodesDev nd, PrefSufCfg cfg, const unsigned long long *__restric
                                 if ((tl >> 9) == my_tag && (int) (tl & 511u) >= L && (int) id != B &&
                                     verify_overlap<0>(nd, sb, (int) id, my_q, my_r, L)) {
                                     const int slot = classify((int) id, L, (int) (tl & 511u));
-                                    if (LOCAL) item_overhang_global(nd, it, slot, (int) id, L, (int) (tl & 511u));
+                                    if (LOCAL) item_overhang_global<(LOCAL ? LOCAL : 1)>(nd, it, slot, (int) id, L, (int) (tl & 511u));
                                 }
                             }
                             if (!full) break;
@@ -348,7 +349,7 @@ k_probe_sources(NodesDev nd, PrefSufCfg cfg, const unsigned long long *__restric
                             const int bit = 2 * (lenB - L) - 32 * w0;
                             if (verify_overlap<0>(nd, sb, C, bit >> 5, bit & 31, L)) {
                                 const int slot = classify(C, L, (int) (cw >> 16));
-                                if (LOCAL) item_overhang_global(nd, it, slot, C, L, (int) (cw >> 16));
+                                if (LOCAL) item_overhang_global<(LOCAL ? LOCAL : 1)>(nd, it, slot, C, L, (int) (cw >> 16));
                             }
                         }
                     }
@@ -413,15 +414,16 @@ k_probe_sources(NodesDev nd, PrefSufCfg cfg, const unsigned long long *__restric
                             }
                             n_items += __popcll(pm);
                             slot = quad_bcast0(slot);
-                            const uint32_t nxt = sub == 3 ? 0u : quad_next(cc[g].x);
+                            const uint32_t nq = quad_next(cc[g].x);         // every lane of the quad must execute the DPP read
+                            const uint32_t nxt = sub == 3 ? 0u : nq;
                             if (slot >= 0 && slot < ITEMMAX) {
                                 const int ws = (2 * Lc[g]) >> 5, r = (2 * Lc[g]) & 31;
-                                uint32_t *ow = reinterpret_cast<uint32_t *>(&it.O[slot]);
+                                uint32_t *ow = reinterpret_cast<uint32_t *>(&it.O[slot * (LOCAL ? LOCAL : 1)]);
                                 const uint32_t cw[5] = {cc[g].x, cc[g].y, cc[g].z, cc[g].w, nxt};
 #pragma unroll
                                 for (int j = 0; j < 4; j++) {
                                     const int k = 4 * sub + j - ws;
-                                    if (k >= 0 && k < 4) ow[k] = funnel(cw[j], cw[j + 1], r);
+                                    if (k >= 0 && k < 4 * LOCAL) ow[k] = funnel(cw[j], cw[j + 1], r);
                                 }
                             }
                         } else if (pass) classify(Cc[g], Lc[g], Nc[g]);
@@ -434,7 +436,7 @@ k_probe_sources(NodesDev nd, PrefSufCfg cfg, const unsigned long long *__restric
             if (n_items > ITEMMAX) {                       // the engine repeats the build with the per-target pipeline
                 if (lane == 0) atomicAdd(&o.counters[CNT_LOCAL_OVERFLOW], 1ull);
             } else if (n_items > 0) {
-                local_reduce<STATS, WB>(nd, cfg, it, w, o, B, lenB, n_items, st_rec, st_cmp, st_generic);
+                local_reduce<STATS, WB, (LOCAL ? LOCAL : 1)>(nd, cfg, it, w, o, B, lenB, n_items, st_rec, st_cmp, st_generic);
             }
             const int nb = (int) __builtin_amdgcn_readfirstlane((int) *w.recN);
             if (nb >= WFLUSH_LOCAL) flush_records<CHUNK, WB>(o, w, chunk_base, chunk_fill);
@@ -930,23 +932,24 @@ uint64_t probe_record_slack(int n_cu, uint64_t n_src, bool local) {  // worst-ca
 
 struct ProbeTable { const unsigned long long *table; uint32_t n_buckets; const uint32_t *filter; uint32_t filter_mask; };
 
-template <int NQ, bool LOCAL>
+template <int NQ, int LOCAL>
 static void launch_probe_nql(const NodesDev &nd, const PrefSufCfg &cfg, const ProbeTable &t,
                              int32_t src_begin, int32_t src_end, const ProbeOut &o, dim3 grid, dim3 block, hipStream_t s) {
     if (cfg.stats) hipLaunchKernelGGL((k_probe_sources<true, NQ, LOCAL>), grid, block, 0, s, nd, cfg, t.table, t.n_buckets, t.filter, t.filter_mask, src_begin, src_end, o);
     else           hipLaunchKernelGGL((k_probe_sources<false, NQ, LOCAL>), grid, block, 0, s, nd, cfg, t.table, t.n_buckets, t.filter, t.filter_mask, src_begin, src_end, o);
 }
 template <int NQ>
-static void launch_probe_nq(const NodesDev &nd, const PrefSufCfg &cfg, const ProbeTable &t, bool local,
+static void launch_probe_nq(const NodesDev &nd, const PrefSufCfg &cfg, const ProbeTable &t, int local,
                             int32_t src_begin, int32_t src_end, const ProbeOut &o, dim3 grid, dim3 block, hipStream_t s) {
-    if (local) launch_probe_nql<NQ, true>(nd, cfg, t, src_begin, src_end, o, grid, block, s);
-    else       launch_probe_nql<NQ, false>(nd, cfg, t, src_begin, src_end, o, grid, block, s);
+    if (local == 1)      launch_probe_nql<NQ, 1>(nd, cfg, t, src_begin, src_end, o, grid, block, s);
+    else if (local == 2) launch_probe_nql<NQ, 2>(nd, cfg, t, src_begin, src_end, o, grid, block, s);
+    else                 launch_probe_nql<NQ, 0>(nd, cfg, t, src_begin, src_end, o, grid, block, s);
 }
 
 void launch_probe(const NodesDev &nd, const PrefSufCfg &cfg, const unsigned long long *table, uint32_t n_buckets,
                   const uint32_t *filter, uint32_t filter_bits,
                   int32_t src_begin, int32_t src_end, uint32_t *rec_dst, unsigned long long *rec_val, uint64_t rec_cap,
-                  unsigned long long *counters, int n_cu, bool local, uint32_t *deg, unsigned long long *first, hipStream_t s) {
+                  unsigned long long *counters, int n_cu, int local, uint32_t *deg, unsigned long long *first, hipStream_t s) {
     const int64_t ns = (int64_t) src_end - src_begin;
     if (ns <= 0) return;
     dim3 grid((unsigned) probe_blocks(n_cu, (uint64_t) ns)), block(PROBE_WAVES * 64);

@@ -45,9 +45,9 @@ typedef enum {
 /* Where the transitive reduction of GraphCreatorPrefSuf.cpp:397-483 is evaluated (same result either way):
  *   PER_TARGET  : the literal replay of the reference's push order per target node (any input);
  *   SOURCE_SIDE : per source node inside the probing wave, from the source's own raw overlaps;
- *                 exact when max_len <= max_len_cap, max_len - min_overlap <= 63, min_overlap <= rsoe_min_overlap <=
+ *                 exact when max_len <= max_len_cap, max_len - min_overlap <= 127, min_overlap <= rsoe_min_overlap <=
  *                 min(max_len, max_len_cap) + 1 and no live node has alignFrom without alignTo -- everything ALGA's
- *                 command line can produce for reads up to ~140 nt after trimming with the default scale.
+ *                 command line can produce for reads up to ~280 nt after trimming with the default scale.
  *   AUTO        : SOURCE_SIDE when those conditions hold (checked on the device), else PER_TARGET. */
 typedef enum { ALGA_REDUCTION_AUTO = 0, ALGA_REDUCTION_PER_TARGET = 1, ALGA_REDUCTION_SOURCE_SIDE = 2 } alga_reduction;
 

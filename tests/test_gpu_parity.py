@@ -39,7 +39,7 @@ def _check(eng, words, lens, lo, rs, af=None, at=None, stats=True, source_side=N
         assert st["transitive_listed"] == cnt["transitive_checks"]
         assert st["transitive_removed"] == cnt["transitive_removed"]
         assert st["edges"] == len(want)
-    exact = preconditions(lens, lo, rs, af, at) and int(np.max(lens, initial=0)) - lo <= 63
+    exact = preconditions(lens, lo, rs, af, at) and int(np.max(lens, initial=0)) - lo <= 127
     if os.environ.get("ALGA_PROBE") == "min":       # the experimental minimizer probe only feeds the per-target form
         exact = False
     if source_side is None:
@@ -94,6 +94,9 @@ def _nodes(n, length, G, seed, err=0.0, min_length=None, both_strands=True, stri
     (1200, 250, 6000, 16, 0.0, 200, 140, 190),    # W=16
     (3000, 150, 9000, 19, 0.01, None, 90, 120),   # 150 nt, span 60: source-side form with errors
     (2500, 144, 5000, 20, 0.0, 100, 82, 116),     # variable length incl. contained / prefix reads, span 62
+    (2500, 250, 9000, 28, 0.0, None, 137, 190),   # 250 nt: two-word offset masks, 256-bit overhangs (span 113)
+    (2500, 250, 6000, 29, 0.003, 180, 125, 180),  # same with errors, variable length, span 125
+    (900, 250, 9000, 30, 0.0, None, 137, 190),    # low coverage at 250 nt: several survivors per source
     (700, 100, 6000, 17, 0.0, None, 55, 77),      # low coverage: gaps too long for any big via (all-pairs path)
     (3000, 100, 5000, 18, 0.004, 80, 50, 70),     # errors + variable length: several items per offset
 ])
@@ -191,11 +194,14 @@ def test_source_side_range_build_needs_no_exchange(eng):
         parts.append(device_edges_to_numpy(*r))
         assert len(parts[-1]) == 0 or (parts[-1][:, 0].min() >= a and parts[-1][:, 0].max() < b)
     assert (np.concatenate(parts) == want).all()              # ranges in order: already the single-GPU byte order
-    # an input the source-side form declines (reads longer than min_overlap + 63)
+    # an input the source-side form declines (reads longer than min_overlap + 127)
     words, lens = _nodes(300, 250, 3000, 33)
     dw = torch.from_numpy(words.view(np.int32)).cuda()
     dl = torch.from_numpy(lens).cuda()
-    assert eng.build_range_device(dw, dl, 137, 190, 0, len(lens)) is None
+    assert eng.build_range_device(dw, dl, 100, 190, 0, len(lens)) is None
+    r = eng.build_range_device(dw, dl, 137, 190, 0, len(lens))       # 250 nt, span 113: the two-word form of the source-side reduction
+    want250, _, _ = O.prefsuf(words, lens, 137, 190)
+    assert r is not None and (device_edges_to_numpy(*r) == want250).all()
 
 
 def test_invalid_arguments_are_errors(eng):

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Both forms of the transitive reduction on one synthetic set: tools/forms_compare.py n_reads genome err [steps]"""
+"""Both forms of the transitive reduction on one synthetic set: tools/forms_compare.py n_reads genome err [steps] [read_len=150]"""
 import json
 import sys
 
@@ -12,13 +12,14 @@ from alga_amd import workload
 
 n, G, err = int(sys.argv[1]), int(sys.argv[2]), float(sys.argv[3])
 steps = int(sys.argv[4]) if len(sys.argv) > 4 else 3
-codes, _ = gen_reads.sample_reads(n, 150, G, 13, err)
+RL = int(sys.argv[5]) if len(sys.argv) > 5 else 150
+codes, _ = gen_reads.sample_reads(n, RL, G, 13, err)
 words, lens, ids = workload.make_nodes(codes, stride_words="aligned")
-lo, rs = alga_amd.derive_params(144.0)
+lo, rs = alga_amd.derive_params(float(RL - 6))
 eng = alga_amd.Engine(0)
 dw = torch.from_numpy(words.view(np.int32)).cuda()
 dl = torch.from_numpy(lens).cuda()
-out = {"nodes": int(len(lens))}
+out = {"nodes": int(len(lens)), "read_len": RL, "min_overlap": lo, "rsoemo": rs}
 for red in ("source_side", "per_target"):
     ms = []
     for it in range(steps + 1):
