@@ -148,16 +148,19 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
         if ((rc = alga_ensure(e, e->outdeg, (size_t) (n_src + 1) * sizeof(uint32_t)))) return rc;
         if ((rc = alga_ensure(e, e->loc_first, (size_t) (n_src + 1) * sizeof(unsigned long long)))) return rc;
     }
+    const uint32_t big_list_cap = 1u << 16;
+    if (local && (rc = alga_ensure(e, e->loc_big_list, big_list_cap * sizeof(int32_t)))) return rc;
     for (int attempt = 0; attempt < 4; attempt++) {
         if (cap >= (1ull << 32) - 16) return alga_fail(e, ALGA_ERR_CAPACITY, "more than 2^32 overlap records; shard the input");
         if (local) HIP_TRY(e, hipMemsetAsync(e->outdeg.p, 0, (size_t) (n_src + 1) * sizeof(uint32_t), s));
         if ((rc = alga_ensure(e, e->rec_dst, cap * sizeof(uint32_t)))) return rc;
         if ((rc = alga_ensure(e, e->rec_val, cap * sizeof(unsigned long long)))) return rc;
         HIP_TRY(e, hipMemsetAsync(cnt, 0, CNT_TOTAL * sizeof(unsigned long long), s));
+        ProbeBig big{(int32_t *) e->loc_big_list.p, big_list_cap, 0u, nullptr, 0u};
         if (e->probe_mode == 0)
             launch_probe(nd, cfg, (const unsigned long long *) e->table.p, n_buckets, (const uint32_t *) e->filter.p, filter_bits, src_begin, src_end,
                          (uint32_t *) e->rec_dst.p, (unsigned long long *) e->rec_val.p, cap, cnt, e->n_cu, local ? pp.local_sw : 0, (uint32_t *) e->outdeg.p,
-                         (unsigned long long *) e->loc_first.p, s);
+                         (unsigned long long *) e->loc_first.p, local ? &big : nullptr, s);
         else
             launch_probe_min(nd, cfg, (const unsigned long long *) e->ix_dir.p, dir_slots, (const unsigned long long *) e->ix_vals2.p, src_begin, src_end,
                              (uint32_t *) e->rec_dst.p, (unsigned long long *) e->rec_val.p, cap, cnt, e->n_cu, s);
@@ -165,11 +168,33 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
         HIP_TRY(e, hipEventRecord(e->ev[EV_PROBE], s));
         HIP_TRY(e, hipMemcpyAsync(e->h_counters, cnt, CNT_TOTAL * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
         HIP_TRY(e, hipStreamSynchronize(s));
+        if (local && e->h_counters[CNT_LOCAL_OVERFLOW] != 0) {
+            // Some sources have more raw overlaps than a wave's LDS holds (repeat-rich input): the first pass listed them, a second
+            // pass probes exactly those with their items in a global slice per wave.  Too many of them, or too many overlaps for the
+            // largest slice the engine allocates: the caller takes the per-target pipeline.
+            const uint64_t n_big = e->h_counters[CNT_LOCAL_OVERFLOW], max_items = e->h_counters[CNT_LOCAL_MAXITEMS];
+            const uint64_t limit = e->big_limit >= 0 ? (uint64_t) e->big_limit : (uint64_t) local_big_limit();
+            if (n_big > big_list_cap || max_items > limit) { if (overflow) *overflow = true; *n_rec = 0; return ALGA_OK; }
+            big.count = (uint32_t) n_big;
+            big.item_cap = (uint32_t) ((max_items + 63) & ~63ull);
+            if ((rc = alga_ensure(e, e->loc_big_items, probe_big_bytes(e->n_cu, big.count, pp.local_sw, big.item_cap)))) return rc;
+            big.items = e->loc_big_items.p;
+            HIP_TRY(e, hipMemsetAsync(cnt + CNT_LOCAL_OVERFLOW, 0, sizeof(unsigned long long), s));
+            launch_probe(nd, cfg, (const unsigned long long *) e->table.p, n_buckets, (const uint32_t *) e->filter.p, filter_bits, src_begin, src_end,
+                         (uint32_t *) e->rec_dst.p, (unsigned long long *) e->rec_val.p, cap, cnt, e->n_cu, pp.local_sw, (uint32_t *) e->outdeg.p,
+                         (unsigned long long *) e->loc_first.p, &big, s);
+            if ((rc = alga_check_launch(e, "k_probe_sources (second pass)"))) return rc;
+            HIP_TRY(e, hipEventRecord(e->ev[EV_PROBE], s));
+            HIP_TRY(e, hipMemcpyAsync(e->h_counters, cnt, CNT_TOTAL * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+            HIP_TRY(e, hipStreamSynchronize(s));
+            if (e->h_counters[CNT_LOCAL_OVERFLOW] != 0) { if (overflow) *overflow = true; *n_rec = 0; return ALGA_OK; }
+            e->stats.big_sources = n_big;
+        }
         const uint64_t need = e->h_counters[CNT_RECORDS];
         if (need <= cap) {
             *n_rec = need;
             hint = std::max<uint64_t>(hint, need + need / 16 + 4096);
-            if (overflow) *overflow = e->h_counters[CNT_LOCAL_OVERFLOW] != 0;
+            if (overflow) *overflow = false;
             if (local) { e->stats.transitive_compares = e->h_counters[CNT_TR_COMPARES]; e->stats.generic_sources = e->h_counters[CNT_LOCAL_GENERIC]; }
             e->stats.records = e->h_counters[CNT_VALID_RECORDS];
             e->stats.raw_overlaps = e->h_counters[CNT_RAW];
@@ -327,6 +352,7 @@ int alga_engine_create(int hip_device, alga_engine **out) {
     if (const char *v = getenv("ALGA_SEED_FILTER_LOG2")) e->filter_log2 = std::min(30, std::max(16, atoi(v)));
     if (const char *v = getenv("ALGA_PROBE")) e->probe_mode = strcmp(v, "min") == 0 ? 1 : 0;
     if (const char *v = getenv("ALGA_REDUCE")) e->force_reduction = strcmp(v, "target") == 0 ? 1 : 0;
+    if (const char *v = getenv("ALGA_LOCAL_BIG_MAX")) e->big_limit = std::max(0, atoi(v));
     memset(&e->stats, 0, sizeof(e->stats));
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, hip_device) == hipSuccess) {
@@ -347,7 +373,7 @@ void alga_engine_destroy(alga_engine *e) {
     if (e->own_stream) (void) hipStreamSynchronize(e->own_stream);
     DevBuf *bufs[] = {&e->table, &e->filter, &e->counters, &e->rowptr, &e->rec_dst, &e->rec_val, &e->keys, &e->seg_key, &e->seg_val, &e->heads, &e->sort_temp,
                       &e->out_cnt, &e->outdeg, &e->out_rowptr, &e->edges, &e->scan_scratch, &e->up_words, &e->up_len, &e->up_from, &e->up_to,
-                      &e->ix_keys, &e->ix_vals, &e->ix_keys2, &e->ix_vals2, &e->ix_dir, &e->loc_first, &e->edge_keys, &e->edge_keys2, &e->edge_vals, &e->edge_vals2, &e->edges_sorted, &e->xs_dst, &e->xs_val,
+                      &e->ix_keys, &e->ix_vals, &e->ix_keys2, &e->ix_vals2, &e->ix_dir, &e->loc_first, &e->loc_big_list, &e->loc_big_items, &e->edge_keys, &e->edge_keys2, &e->edge_vals, &e->edge_vals2, &e->edges_sorted, &e->xs_dst, &e->xs_val,
                       &e->pk_keys, &e->pk_keys2, &e->pk_vals, &e->pk_vals2, &e->pk_marks, &e->pk_big, &e->pk_add, &e->pk_ekeys, &e->pk_ekeys2,
                       &e->pk_flag, &e->pk_pos, &e->pk_edges[0], &e->pk_edges[1], &e->pk_rowptr, &e->pk_deg, &e->pk_mask, &e->pk_cnt, &e->pk_io, &e->pk_io2, &e->pk_tips, &e->pk_heads, &e->pp_rows, &e->pp_len, &e->pp_perm[0], &e->pp_perm[1], &e->pp_keys[0], &e->pp_keys[1], &e->pp_mark,
                       &e->pp_keep, &e->pp_pos, &e->pp_out_rows, &e->pp_out_len, &e->pp_out_pair, &e->pp_tally};

@@ -30,7 +30,8 @@ struct alga_engine {
     // device buffers, grown on demand and kept between calls
     DevBuf table, filter, counters, rowptr, rec_dst, rec_val, keys, seg_key, seg_val, heads, sort_temp, out_cnt, outdeg, out_rowptr, edges, scan_scratch;
     DevBuf ix_keys, ix_vals, ix_keys2, ix_vals2, ix_dir;   // minimizer index
-    DevBuf loc_first;                                       // source-side form: one-edge slots
+    DevBuf loc_first, loc_big_list, loc_big_items;          // source-side form: one-edge slots; second pass over repeat-rich sources
+    int    big_limit = -1;                                  // largest per-wave item slice of that pass; -1 = built-in (ALGA_LOCAL_BIG_MAX overrides: tests)
     DevBuf edge_keys, edge_keys2, edge_vals, edge_vals2, edges_sorted, xs_dst, xs_val;
     DevBuf up_words, up_len, up_from, up_to;   // uploads of the host-buffer entry points
     // approximate supplement (engine_pkb.hip)

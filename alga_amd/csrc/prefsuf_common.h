@@ -76,8 +76,9 @@ enum Counter {
     CNT_VALID_RECORDS,     // records that carry an overlap
     CNT_SORT_VALID,        // records whose target lies in the owned range (k_make_keys)
     CNT_MASK_ASYM,         // live nodes with alignFrom but not alignTo (source-side reduction needs none)
-    CNT_LOCAL_OVERFLOW,    // sources with more raw overlaps than the source-side reduction holds in LDS
+    CNT_LOCAL_OVERFLOW,    // sources with more raw overlaps than the source-side reduction holds (LDS; in the second pass: its global slice)
     CNT_LOCAL_GENERIC,     // sources that took the all-pairs path of the source-side reduction
+    CNT_LOCAL_MAXITEMS,    // largest number of raw overlaps of one source seen by the source-side reduction
     CNT_TOTAL = 16
 };
 

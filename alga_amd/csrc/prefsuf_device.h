@@ -124,6 +124,14 @@ struct ProbeOut {
     uint32_t *__restrict__ deg = nullptr;
     unsigned long long *__restrict__ first = nullptr;
     int32_t src_base = 0;
+    // sources with more raw overlaps than a wave's LDS holds (repeats): the first pass lists them, a second pass (BIG
+    // instantiation of the kernel) walks the list with the items in a global slice per wave
+    int32_t *__restrict__ big_list = nullptr;
+    uint32_t big_list_cap = 0, big_count = 0;
+    uint32_t *__restrict__ bigC = nullptr;
+    uint32_t *__restrict__ bigM = nullptr;
+    uint4 *__restrict__ bigO = nullptr;
+    uint32_t big_cap = 0;                                    // items per wave slice
 };
 constexpr unsigned long long LOCAL_FIRST_NONE = ~0ull;
 
@@ -228,7 +236,8 @@ __device__ __forceinline__ bool verify_overlap(const NodesDev &nd, const uint32_
 // Host-checked preconditions (engine.hip local_ok): max_len - Lmin <= 63 (SW = 1) or <= 127 (SW = 2), max_len <= cap,
 // alignFrom => alignTo, Lmin <= rsoemo <= Lcap.
 // ------------------------------------------------------------------------------------------
-constexpr int ITEMMAX = 160;              // raw overlaps of one source held in LDS; more -> CNT_LOCAL_OVERFLOW, per-target pipeline
+constexpr int ITEMMAX = 160;              // raw overlaps of one source held in LDS; sources with more go to the second pass
+constexpr int ITEM_BIG_MAX = 4096;        // largest per-wave global item slice of the second pass; beyond it: per-target pipeline
 constexpr uint32_t ITEM_FROM = 1u << 18;
 
 struct ItemLds { uint32_t *C; uint32_t *M; uint4 *O; uint8_t *T; uint32_t *N; };
@@ -278,8 +287,8 @@ __device__ __forceinline__ bool via_ok(int A, int lenA, int Lbig, uint32_t Cj, u
 // Bits past the overhang's own length are never compared (via_ok masks with the via's length <= the candidate's), so
 // nothing here is masked.
 template <int SW>
-__device__ __forceinline__ void item_overhang_global(const NodesDev &nd, const ItemLds &it, int slot, int C, int L, int lenC) {
-    if (slot < 0 || slot >= ITEMMAX) return;
+__device__ __forceinline__ void item_overhang_global(const NodesDev &nd, const ItemLds &it, int item_cap, int slot, int C, int L, int lenC) {
+    if (slot < 0 || slot >= item_cap) return;
     const uint32_t *row = nd.words + (size_t) C * nd.stride;
     const int ws = (2 * L) >> 5, r = (2 * L) & 31, lastw = (2 * lenC - 1) >> 5;
     uint32_t x[4 * SW + 1];

@@ -16,11 +16,18 @@ uint32_t seed_filter_bits_for(uint64_t live_nodes);   // 0 = prefilter off
 void launch_seed_build(const NodesDev &nd, const PrefSufCfg &cfg, unsigned long long *table, uint32_t n_buckets, uint32_t *filter,
                        uint32_t filter_bits, hipStream_t s);
 
+// source-side form, sources with more raw overlaps than a wave's LDS holds: the first pass appends them to `list` (counter
+// CNT_LOCAL_OVERFLOW), the second pass (count > 0) probes exactly those with `item_cap` items per wave in `items`
+struct ProbeBig { int32_t *list; uint32_t list_cap; uint32_t count; void *items; uint32_t item_cap; };
+int    local_item_capacity();    // items of one source a wave holds in LDS
+int    local_big_limit();        // largest per-wave item slice the engine allocates for the second pass
+size_t probe_big_bytes(int n_cu, uint32_t count, int local, uint32_t item_cap);
+
 // overlap record = rec_dst[i] (target id, REC_INVALID for chunk padding) + rec_val[i] ((ol << 32) | source id)
 void launch_probe(const NodesDev &nd, const PrefSufCfg &cfg, const unsigned long long *table, uint32_t n_buckets,
                   const uint32_t *filter, uint32_t filter_bits, int32_t src_begin, int32_t src_end, uint32_t *rec_dst, unsigned long long *rec_val, uint64_t rec_cap,
                   unsigned long long *counters, int n_cu, int local /* 0, or the mask width 1 | 2 of the source-side form */, uint32_t *deg /* local: zeroed, n_src */, unsigned long long *first /* local: n_src */,
-                  hipStream_t s);
+                  const ProbeBig *big /* local: may be null */, hipStream_t s);
 uint64_t probe_record_slack(int n_cu, uint64_t n_src, bool local);
 // source-side reduction: adjacency lists from the probe's out-degrees (rowptr = their scan), one-edge slots and record list
 void launch_local_emit(int32_t src_base, int32_t n_src, const uint32_t *deg, const unsigned long long *first, const uint32_t *rec_dst,

@@ -110,7 +110,9 @@ __global__ void __launch_bounds__(256) k_seed_build(NodesDev nd, PrefSufCfg cfg,
 // LOCAL != 0: the wave also performs the transitive reduction for its source (prefsuf_device.h: local_reduce; LOCAL = width of
 // its offset masks / overhangs: 1 for max_len - Lmin <= 63, 2 for <= 127) and what it emits are the final edges; LOCAL == 0: the
 // records are all capped raw overlaps, reduced per target later.
-template <bool STATS, int NQ, int LOCAL>
+// BIG (LOCAL only): second pass over the sources the first pass listed because they have more raw overlaps than a wave's LDS holds
+// (repeats): same probe, the items live in a global slice per wave, every source takes the all-pairs evaluation.
+template <bool STATS, int NQ, int LOCAL, bool BIG = false>
 __global__ void __launch_bounds__(PROBE_WAVES * 64, PROBE_OCC)
 k_probe_sources(NodesDev nd, PrefSufCfg cfg, const unsigned long long *__restrict__ table, uint32_t n_buckets,
                 const uint32_t *__restrict__ filter, uint32_t filter_mask, int32_t src_begin, int32_t src_end, ProbeOut o) {
@@ -121,9 +123,9 @@ k_probe_sources(NodesDev nd, PrefSufCfg cfg, const unsigned long long *__restric
     __shared__ uint32_t sRecC[PROBE_WAVES][WB];
     __shared__ unsigned long long sRecV[PROBE_WAVES][WB];
     __shared__ uint32_t sCnt[PROBE_WAVES][3];
-    __shared__ uint32_t sItemC[PROBE_WAVES][LOCAL ? ITEMMAX : 1];
-    __shared__ uint32_t sItemM[PROBE_WAVES][LOCAL ? ITEMMAX : 1];
-    __shared__ uint4 sItemO[PROBE_WAVES][LOCAL ? ITEMMAX * LOCAL : 1];
+    __shared__ uint32_t sItemC[PROBE_WAVES][LOCAL && !BIG ? ITEMMAX : 1];
+    __shared__ uint32_t sItemM[PROBE_WAVES][LOCAL && !BIG ? ITEMMAX : 1];
+    __shared__ uint4 sItemO[PROBE_WAVES][LOCAL && !BIG ? ITEMMAX * LOCAL : 1];
     __shared__ uint8_t sItemT[PROBE_WAVES][LOCAL > 1 ? 64 * LOCAL : 64];
     __shared__ uint32_t sActB[PROBE_WAVES][64];
     __shared__ uint32_t sActT[PROBE_WAVES][64];
@@ -131,7 +133,10 @@ k_probe_sources(NodesDev nd, PrefSufCfg cfg, const unsigned long long *__restric
     const int wave = (int) (threadIdx.x >> 6);
     const int lane = lane_id();
     WaveLds w{sB[wave], sCandC[wave], sCandW[wave], &sCnt[wave][0], sRecC[wave], sRecV[wave], &sCnt[wave][1], sActB[wave], sActT[wave]};
-    ItemLds it{sItemC[wave], sItemM[wave], sItemO[wave], sItemT[wave], &sCnt[wave][2]};
+    const size_t wave_gid = (size_t) blockIdx.x * PROBE_WAVES + (size_t) wave;
+    ItemLds it{BIG ? o.bigC + wave_gid * o.big_cap : sItemC[wave], BIG ? o.bigM + wave_gid * o.big_cap : sItemM[wave],
+               BIG ? o.bigO + wave_gid * o.big_cap * (LOCAL ? LOCAL : 1) : sItemO[wave], sItemT[wave], &sCnt[wave][2]};
+    const int item_cap = BIG ? (int) o.big_cap : ITEMMAX;
     if (lane == 0) { *w.candN = 0; *w.recN = 0; *it.N = 0; }
     uint64_t chunk_base = 0;
     int chunk_fill = CHUNK;                                // "no chunk yet"
@@ -144,23 +149,27 @@ k_probe_sources(NodesDev nd, PrefSufCfg cfg, const unsigned long long *__restric
     // software pipeline over sources: length, mask and row word of the NEXT source are requested before the
     // current one is probed, so their latency hides behind the bucket and candidate-row round trips
     const int pre_words = nd.stride < STAGE_WORDS ? nd.stride : STAGE_WORDS;
-    int64_t Bl = (int64_t) src_begin + (int64_t) blockIdx.x * PROBE_WAVES + wave;
-    int n_len = 0; uint32_t n_word = 0; uint8_t n_from = 1;
-    if (Bl < src_end) {
-        n_len = nd.len[Bl];
-        n_word = lane < pre_words ? nd.words[(size_t) Bl * nd.stride + lane] : 0u;
-        if (nd.from) n_from = nd.from[Bl];
+    // BIG: the loop runs over the positions of the source list instead of over source ids
+    const int64_t it_end = BIG ? (int64_t) o.big_count : (int64_t) src_end;
+    int64_t Bl = (BIG ? 0 : (int64_t) src_begin) + (int64_t) blockIdx.x * PROBE_WAVES + wave;
+    int n_id = 0, n_len = 0; uint32_t n_word = 0; uint8_t n_from = 1;
+    if (Bl < it_end) {
+        n_id = BIG ? o.big_list[Bl] : (int) Bl;
+        n_len = nd.len[n_id];
+        n_word = lane < pre_words ? nd.words[(size_t) n_id * nd.stride + lane] : 0u;
+        if (nd.from) n_from = nd.from[n_id];
     }
-    while (Bl < src_end) {
-        const int B = (int) Bl;
+    while (Bl < it_end) {
+        const int B = n_id;
         const int lenB = n_len;
         const uint32_t word0 = n_word;
         const bool from_ok = n_from != 0;
         Bl += total_waves;
-        if (Bl < src_end) {
-            n_len = nd.len[Bl];
-            n_word = lane < pre_words ? nd.words[(size_t) Bl * nd.stride + lane] : 0u;
-            if (nd.from) n_from = nd.from[Bl];
+        if (Bl < it_end) {
+            n_id = BIG ? o.big_list[Bl] : (int) Bl;
+            n_len = nd.len[n_id];
+            n_word = lane < pre_words ? nd.words[(size_t) n_id * nd.stride + lane] : 0u;
+            if (nd.from) n_from = nd.from[n_id];
         }
         if (!(lenB >= cfg.Lmin && lenB > 0 && from_ok)) continue;                       // wave-uniform
         // stage the last Lspan nucleotides of B (all an overlap of length <= Lcap can touch)
@@ -184,7 +193,7 @@ k_probe_sources(NodesDev nd, PrefSufCfg cfg, const unsigned long long *__restric
                 uint32_t m = (uint32_t) (lenB - L) | ((uint32_t) lenC << 9);
                 if (nd.from == nullptr || nd.from[C]) m |= ITEM_FROM;
                 const uint32_t i = atomicAdd(it.N, 1u);                // LDS atomic
-                if (i < (uint32_t) ITEMMAX) { it.C[i] = (uint32_t) C; it.M[i] = m; }
+                if (i < (uint32_t) item_cap) { it.C[i] = (uint32_t) C; it.M[i] = m; }
                 return (int) i;
             }
             if (L < cfg.rsoemo) {
@@ -332,7 +341,7 @@ k_probe_sources(NodesDev nd, PrefSufCfg cfg, const unsigned long long *__restric
                                 if ((tl >> 9) == my_tag && (int) (tl & 511u) >= L && (int) id != B &&
                                     verify_overlap<0>(nd, sb, (int) id, my_q, my_r, L)) {
                                     const int slot = classify((int) id, L, (int) (tl & 511u));
-                                    if (LOCAL) item_overhang_global<(LOCAL ? LOCAL : 1)>(nd, it, slot, (int) id, L, (int) (tl & 511u));
+                                    if (LOCAL) item_overhang_global<(LOCAL ? LOCAL : 1)>(nd, it, item_cap, slot, (int) id, L, (int) (tl & 511u));
                                 }
                             }
                             if (!full) break;
@@ -349,7 +358,7 @@ k_probe_sources(NodesDev nd, PrefSufCfg cfg, const unsigned long long *__restric
                             const int bit = 2 * (lenB - L) - 32 * w0;
                             if (verify_overlap<0>(nd, sb, C, bit >> 5, bit & 31, L)) {
                                 const int slot = classify(C, L, (int) (cw >> 16));
-                                if (LOCAL) item_overhang_global<(LOCAL ? LOCAL : 1)>(nd, it, slot, C, L, (int) (cw >> 16));
+                                if (LOCAL) item_overhang_global<(LOCAL ? LOCAL : 1)>(nd, it, item_cap, slot, C, L, (int) (cw >> 16));
                             }
                         }
                     }
@@ -406,7 +415,7 @@ k_probe_sources(NodesDev nd, PrefSufCfg cfg, const unsigned long long *__restric
                             if (pass) {
                                 if (STATS) st_raw++;
                                 slot = n_items + (int) __builtin_amdgcn_mbcnt_hi((uint32_t) (pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) pm, 0u));
-                                if (slot < ITEMMAX) {
+                                if (slot < item_cap) {
                                     uint32_t m = (uint32_t) (lenB - Lc[g]) | ((uint32_t) Nc[g] << 9);
                                     if (nd.from == nullptr || nd.from[Cc[g]]) m |= ITEM_FROM;
                                     it.C[slot] = (uint32_t) Cc[g]; it.M[slot] = m;
@@ -416,7 +425,7 @@ k_probe_sources(NodesDev nd, PrefSufCfg cfg, const unsigned long long *__restric
                             slot = quad_bcast0(slot);
                             const uint32_t nq = quad_next(cc[g].x);         // every lane of the quad must execute the DPP read
                             const uint32_t nxt = sub == 3 ? 0u : nq;
-                            if (slot >= 0 && slot < ITEMMAX) {
+                            if (slot >= 0 && slot < item_cap) {
                                 const int ws = (2 * Lc[g]) >> 5, r = (2 * Lc[g]) & 31;
                                 uint32_t *ow = reinterpret_cast<uint32_t *>(&it.O[slot * (LOCAL ? LOCAL : 1)]);
                                 const uint32_t cw[5] = {cc[g].x, cc[g].y, cc[g].z, cc[g].w, nxt};
@@ -433,9 +442,17 @@ k_probe_sources(NodesDev nd, PrefSufCfg cfg, const unsigned long long *__restric
         }
         if (LOCAL) {
             wave_lds_fence();
-            if (n_items > ITEMMAX) {                       // the engine repeats the build with the per-target pipeline
-                if (lane == 0) atomicAdd(&o.counters[CNT_LOCAL_OVERFLOW], 1ull);
+            if (n_items > item_cap) {
+                // first pass: the source goes on the list of the second pass; second pass (or a full list): the engine falls
+                // back to the per-target pipeline
+                if (lane == 0) {
+                    const unsigned long long k = atomicAdd(&o.counters[CNT_LOCAL_OVERFLOW], 1ull);
+                    if (!BIG && k < (unsigned long long) o.big_list_cap) o.big_list[k] = B;
+                    atomicMax(&o.counters[CNT_LOCAL_MAXITEMS], (unsigned long long) n_items);
+                    if (STATS) { st_raw -= (uint64_t) n_items; st_win -= (uint64_t) nwin; }     // the second pass counts this source
+                }
             } else if (n_items > 0) {
+                if (BIG) __threadfence();                  // the items were written to global memory by other lanes of this wave
                 local_reduce<STATS, WB, (LOCAL ? LOCAL : 1)>(nd, cfg, it, w, o, B, lenB, n_items, st_rec, st_cmp, st_generic);
             }
             const int nb = (int) __builtin_amdgcn_readfirstlane((int) *w.recN);
@@ -926,6 +943,12 @@ static uint64_t probe_blocks(int n_cu, uint64_t n_src) {
     return std::max<uint64_t>(1, std::min<uint64_t>((n_src + PROBE_WAVES - 1) / PROBE_WAVES, (uint64_t) std::max(1, n_cu) * 8));
 }
 
+int local_item_capacity() { return ITEMMAX; }
+int local_big_limit() { return ITEM_BIG_MAX; }
+size_t probe_big_bytes(int n_cu, uint32_t count, int local, uint32_t item_cap) {
+    return probe_blocks(n_cu, (uint64_t) count) * PROBE_WAVES * (size_t) item_cap * (8 + 16 * (size_t) local) + 64;
+}
+
 uint64_t probe_record_slack(int n_cu, uint64_t n_src, bool local) {  // worst-case invalid padding of one launch
     return probe_blocks(n_cu, n_src) * PROBE_WAVES * (uint64_t) (local ? REC_CHUNK_LOCAL : REC_CHUNK);
 }
@@ -935,6 +958,12 @@ struct ProbeTable { const unsigned long long *table; uint32_t n_buckets; const u
 template <int NQ, int LOCAL>
 static void launch_probe_nql(const NodesDev &nd, const PrefSufCfg &cfg, const ProbeTable &t,
                              int32_t src_begin, int32_t src_end, const ProbeOut &o, dim3 grid, dim3 block, hipStream_t s) {
+    if constexpr (LOCAL != 0) {
+        if (o.big_count) {                                 // second pass over the listed sources (statistics always on: it is rare)
+            hipLaunchKernelGGL((k_probe_sources<true, NQ, LOCAL, true>), grid, block, 0, s, nd, cfg, t.table, t.n_buckets, t.filter, t.filter_mask, src_begin, src_end, o);
+            return;
+        }
+    }
     if (cfg.stats) hipLaunchKernelGGL((k_probe_sources<true, NQ, LOCAL>), grid, block, 0, s, nd, cfg, t.table, t.n_buckets, t.filter, t.filter_mask, src_begin, src_end, o);
     else           hipLaunchKernelGGL((k_probe_sources<false, NQ, LOCAL>), grid, block, 0, s, nd, cfg, t.table, t.n_buckets, t.filter, t.filter_mask, src_begin, src_end, o);
 }
@@ -949,11 +978,23 @@ static void launch_probe_nq(const NodesDev &nd, const PrefSufCfg &cfg, const Pro
 void launch_probe(const NodesDev &nd, const PrefSufCfg &cfg, const unsigned long long *table, uint32_t n_buckets,
                   const uint32_t *filter, uint32_t filter_bits,
                   int32_t src_begin, int32_t src_end, uint32_t *rec_dst, unsigned long long *rec_val, uint64_t rec_cap,
-                  unsigned long long *counters, int n_cu, int local, uint32_t *deg, unsigned long long *first, hipStream_t s) {
+                  unsigned long long *counters, int n_cu, int local, uint32_t *deg, unsigned long long *first, const ProbeBig *big, hipStream_t s) {
     const int64_t ns = (int64_t) src_end - src_begin;
     if (ns <= 0) return;
-    dim3 grid((unsigned) probe_blocks(n_cu, (uint64_t) ns)), block(PROBE_WAVES * 64);
+    const bool second = local && big && big->count > 0;    // second pass: the grid covers the listed sources
+    dim3 grid((unsigned) probe_blocks(n_cu, second ? (uint64_t) big->count : (uint64_t) ns)), block(PROBE_WAVES * 64);
     ProbeOut o{rec_dst, rec_val, rec_cap, counters, deg, first, src_begin};
+    if (local && big) {
+        o.big_list = big->list; o.big_list_cap = big->list_cap;
+        if (second) {                                      // items: [O: uint4 x local | C: u32 | M: u32] per item, `item_cap` items per wave
+            const size_t items = (size_t) grid.x * PROBE_WAVES * (size_t) big->item_cap;
+            o.big_count = big->count;
+            o.bigO = (uint4 *) big->items;
+            o.bigC = (uint32_t *) (o.bigO + items * (size_t) local);
+            o.bigM = o.bigC + items;
+            o.big_cap = big->item_cap;
+        }
+    }
     ProbeTable t{table, n_buckets, filter_bits ? filter : nullptr, filter_bits ? filter_bits - 1 : 0u};
     // widest prefix ever compared: Lcap nucleotides; wide path needs 16-byte aligned rows that hold it
     const int need_q = (((2 * cfg.Lcap + 31) >> 5) + 3) >> 2;

@@ -100,7 +100,7 @@ typedef struct {
     uint64_t nodes_live;          /* nodes with len>0                                            */
     uint64_t reduction_used;      /* alga_reduction of the last build (1 or 2)                   */
     uint64_t generic_sources;     /* SOURCE_SIDE: sources that needed the all-pairs path (collect_stats) */
-    uint64_t reserved[1];
+    uint64_t big_sources;         /* SOURCE_SIDE: sources with more raw overlaps than a wave's LDS holds (second pass) */
 } alga_prefsuf_stats;
 
 /* ---- lifetime --------------------------------------------------------------------------- */
@@ -158,7 +158,8 @@ int  alga_prefsuf_reduce_device(alga_engine *e, const alga_nodes *nodes, const a
 /* Sharded form without an exchange: the final edges whose SOURCE node id is in [src_begin, src_end), by the source-side
  * reduction (every rank holds the full node set; a source's edges depend on nothing another rank computes).  Returns
  * ALGA_ERR_UNSUPPORTED when that form is not exact for the input (see alga_reduction) -- every rank gets the same answer
- * for the same node set, except for the capacity case (a source with more raw overlaps than the engine holds in LDS, 160), so ranks agree on the
+ * for the same node set, except for the capacity case (more than 65 536 sources with over 160 raw overlaps each, or one with
+ * over 4 096: repeat-rich input), so ranks agree on the
  * fallback with one flag all-reduce.  *d_edges: engine-owned, sorted by (src, dst), valid until the next call on `e`. */
 int  alga_prefsuf_build_range_device(alga_engine *e, const alga_nodes *nodes, const alga_prefsuf_params *p,
                                      int32_t src_begin, int32_t src_end, void *hip_stream,

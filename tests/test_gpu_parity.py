@@ -149,11 +149,24 @@ def test_degenerate_inputs(eng):
     codes, l5 = gen_reads.sample_reads(5, 80, 120, 26)
     codes80 = np.repeat(codes, 80, axis=0)
     w = alga_amd.pack_reads(codes80)
-    # more raw overlaps per source than the source-side reduction holds (160) -> it declines, AUTO falls back
-    _check(eng, w, np.full(len(w), 80, np.int32), 40, 60, source_side=False)
-    # 25 copies: 65..160 raw overlaps per source, the multi-round all-pairs path of the source-side form
-    w = alga_amd.pack_reads(np.repeat(codes, 25, axis=0))
+    # more raw overlaps per source than a wave's LDS holds (160): those sources go through the second pass (items in global memory)
     _check(eng, w, np.full(len(w), 80, np.int32), 40, 60)
+    eng.prefsuf_host(w, np.full(len(w), 80, np.int32), 40, 60, reduction="source_side")
+    assert eng.last_stats()["big_sources"] > 0
+    # 25 copies: 65..160 raw overlaps per source, the multi-round all-pairs path of the source-side form in LDS
+    w25 = alga_amd.pack_reads(np.repeat(codes, 25, axis=0))
+    _check(eng, w25, np.full(len(w25), 80, np.int32), 40, 60)
+    # beyond the largest item slice the engine allocates for the second pass (4096 per wave; lowered here) the source-side form
+    # declines and AUTO falls back to the per-target pipeline
+    os.environ["ALGA_LOCAL_BIG_MAX"] = "200"
+    try:
+        small = alga_amd.Engine(0)
+    finally:
+        del os.environ["ALGA_LOCAL_BIG_MAX"]
+    try:
+        _check(small, w, np.full(len(w), 80, np.int32), 40, 60, source_side=False)
+    finally:
+        small.close()
 
 
 def _tandem_nodes(seed, n_reads, genome_len, length, period):
