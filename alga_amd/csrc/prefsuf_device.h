@@ -239,6 +239,8 @@ __device__ __forceinline__ bool verify_overlap(const NodesDev &nd, const uint32_
 constexpr int ITEMMAX = 160;              // raw overlaps of one source held in LDS; sources with more go to the second pass
 constexpr int ITEM_BIG_MAX = 4096;        // largest per-wave global item slice of the second pass; beyond it: per-target pipeline
 constexpr uint32_t ITEM_FROM = 1u << 18;
+constexpr uint32_t ITEM_KEPT = 1u << 19;      // all-pairs evaluation: survives the per-source cap / is a big overlap
+constexpr uint32_t ITEM_REMOVED = 1u << 20;   // all-pairs evaluation: implied by a via or superseded
 
 struct ItemLds { uint32_t *C; uint32_t *M; uint4 *O; uint8_t *T; uint32_t *N; };
 
@@ -414,6 +416,8 @@ __device__ __forceinline__ void local_reduce(const NodesDev &nd, const PrefSufCf
         }
     }
     if (generic) {
+        // All pairs.  Lanes hold the possible vias j (64 at a time, their overhang pre-masked and its mask in registers), the
+        // kept items i pass by one at a time (uniform LDS / global reads); a hit marks i removed in its meta word.
         if (STATS && lane == 0) st_generic++;
         uint64_t k0 = 0, k1 = 0, k2 = 0, win0, win1, win2;
         for (int i = lane; i < n; i += 64) {
@@ -421,32 +425,57 @@ __device__ __forceinline__ void local_reduce(const NodesDev &nd, const PrefSufCf
             if (L < cfg.rsoemo) top3_insert(k0, k1, k2, ((uint64_t) (uint32_t) L << 32) | it.C[i]);
         }
         wave_top3(k0, k1, k2, win0, win1, win2);
-        auto is_kept = [&](uint32_t C, int d) {
-            const int L = lenA - d;
+        for (int i = lane; i < n; i += 64) {               // kept: big, or among the source's three largest small (L, C)
+            const uint32_t C = it.C[i], m = it.M[i];
+            const int L = lenA - (int) (m & 511u);
             const uint64_t key = ((uint64_t) (uint32_t) L << 32) | C;
-            return L >= cfg.rsoemo || key == win0 || key == win1 || key == win2;
-        };
+            it.M[i] = (m & ~(ITEM_KEPT | ITEM_REMOVED)) | ((L >= cfg.rsoemo || key == win0 || key == win1 || key == win2) ? ITEM_KEPT : 0u);
+        }
+        __threadfence_block();
+        wave_lds_fence();
+        for (int jb = 0; jb < n; jb += 64) {
+            const int j = jb + lane;
+            const bool actj = j < n;
+            uint32_t Cj = 0, mj = 0;
+            Ovh<SW> oj, kj;
+#pragma unroll
+            for (int k = 0; k < 4 * SW; k++) { oj.w[k] = 0u; kj.w[k] = 0u; }
+            if (actj) { Cj = it.C[j]; mj = it.M[j]; oj = load_ovh<SW>(it.O, j); }
+            const int dj = (int) (mj & 511u), lenj = (int) ((mj >> 9) & 511u);
+            const int rho_j = lenj - (lenA - dj);
+            const int dend_j = dj + lenj - Lbig;           // B -> C is big  <=>  d_C <= d_B + |B| - Lbig
+            const bool ok_j = actj && (mj & ITEM_FROM) != 0 && (rho_j > 0 || (int) Cj > A);
+            const bool kept_j = actj && (mj & ITEM_KEPT) != 0;
+#pragma unroll
+            for (int k = 0; k < 4 * SW; k++) { kj.w[k] = low_bits32(2 * rho_j - 32 * k); oj.w[k] &= kj.w[k]; }
+            for (int i = 0; i < n; i++) {                  // uniform
+                const uint32_t mi = (uint32_t) __builtin_amdgcn_readfirstlane((int) it.M[i]);     // scalar: the skip is a uniform branch
+                if ((mi & (ITEM_KEPT | ITEM_REMOVED)) != ITEM_KEPT) continue;
+                const uint32_t Ci = (uint32_t) __builtin_amdgcn_readfirstlane((int) it.C[i]);
+                const Ovh<SW> oi = load_ovh<SW>(it.O, i);
+                const int di = (int) (mi & 511u);
+                const int rho_i = (int) ((mi >> 9) & 511u) - (lenA - di);
+                uint32_t diff = 0;
+#pragma unroll
+                for (int k = 0; k < 4 * SW; k++) diff |= (oi.w[k] & kj.w[k]) ^ oj.w[k];
+                const bool via = ok_j && Cj != Ci && dj < di && di <= dend_j && rho_j <= rho_i && diff == 0;
+                const bool sup = kept_j && Cj == Ci && dj < di;      // same target at a smaller offset: Graph.cpp:348-387, :461-462
+                if (STATS && actj && Cj != Ci && dj < di) st_cmp++;
+                if (__ballot(via || sup) != 0ull) { if (lane == 0) it.M[i] = mi | ITEM_REMOVED; }
+            }
+            __threadfence_block();
+            wave_lds_fence();
+        }
         int n_out = 0;
         for (int base = 0; base < n; base += 64) {
             const int i = base + lane;
-            const bool act = i < n;
-            uint32_t C = 0, m = 0;
-            Ovh<SW> ov;
-#pragma unroll
-            for (int k = 0; k < 4 * SW; k++) ov.w[k] = 0u;
-            if (act) { C = it.C[i]; m = it.M[i]; ov = load_ovh<SW>(it.O, i); }
-            const int d = (int) (m & 511u);
-            const int rho = (int) ((m >> 9) & 511u) - (lenA - d);
-            bool removed = !act || !is_kept(C, d);
-            for (int j = 0; j < n; j++) {
-                const uint32_t Cj = it.C[j], mj = it.M[j];
-                const Ovh<SW> oj = load_ovh<SW>(it.O, j);
-                const int dj = (int) (mj & 511u);
-                if (Cj == C) removed = removed || (dj < d && is_kept(Cj, dj));      // same target at a smaller offset: Graph.cpp:348-387, :461-462
-                else { if (STATS && act && dj < d) st_cmp++; removed = removed || via_ok<SW>(A, lenA, Lbig, Cj, mj, oj, C, d, rho, ov); }
+            bool out = false;
+            if (i < n) {
+                const uint32_t m = it.M[i];
+                out = (m & (ITEM_KEPT | ITEM_REMOVED)) == ITEM_KEPT;
+                if (out) push(it.C[i], (int) (m & 511u));
             }
-            if (!removed) push(C, d);
-            n_out += __popcll(__ballot(!removed));
+            n_out += __popcll(__ballot(out));
         }
         if (lane == 0 && n_out) { o.deg[A - o.src_base] = (uint32_t) n_out; o.first[A - o.src_base] = LOCAL_FIRST_NONE; }
     }
