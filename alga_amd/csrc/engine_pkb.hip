@@ -130,10 +130,15 @@ int supplement_device_impl(alga_engine *e, const alga_nodes *dn, const alga_pkb_
     if ((rc = alga_check_launch(e, "k_pkb_masks"))) return rc;
     // the nodes that take part, as a dense list (the masks are fixed for all rounds)
     if ((rc = alga_ensure(e, e->pk_tips, (size_t) (n + 1) * sizeof(uint32_t)))) return rc;
-    HIP_TRY(e, hipMemsetAsync(cnt, 0, 16 * sizeof(unsigned long long), s));
-    launch_pkb_tips(nd, c, (const uint8_t *) e->pk_mask.p, (uint32_t *) e->pk_tips.p, cnt + 0, s);
-    if ((rc = alga_check_launch(e, "k_pkb_tips"))) return rc;
-    HIP_TRY(e, hipMemcpyAsync(e->h_counters, cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    if ((rc = alga_ensure(e, e->pk_flag, (size_t) (n + 2) * sizeof(uint32_t)))) return rc;
+    if ((rc = alga_ensure(e, e->pk_pos, (size_t) (n + 2) * sizeof(uint32_t)))) return rc;
+    if ((rc = alga_ensure(e, e->scan_scratch, scan_scratch_bytes((uint64_t) n)))) return rc;
+    launch_pkb_tip_flags(nd, c, (const uint8_t *) e->pk_mask.p, (uint32_t *) e->pk_flag.p, s);
+    if ((rc = alga_check_launch(e, "k_pkb_tip_flags"))) return rc;
+    launch_exclusive_scan((const uint32_t *) e->pk_flag.p, (uint64_t) n, (uint32_t *) e->pk_pos.p, (uint64_t *) e->scan_scratch.p, s);
+    launch_pkb_tip_list(n, (const uint32_t *) e->pk_flag.p, (const uint32_t *) e->pk_pos.p, (uint32_t *) e->pk_tips.p, s);
+    if ((rc = alga_check_launch(e, "k_pkb_tip_list"))) return rc;
+    HIP_TRY(e, hipMemcpyAsync(e->h_counters, (uint64_t *) e->scan_scratch.p + scan_total_index((uint64_t) n), sizeof(uint64_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(e, hipStreamSynchronize(s));
     const uint32_t n_tips = (uint32_t) e->h_counters[0];
     int32_t prio[4] = {0, 1, 2, 3};

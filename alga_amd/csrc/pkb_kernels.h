@@ -21,7 +21,8 @@ struct PkbCfg {
 void launch_can_align_batch(const NodesDev &nd, const PkbCfg &c, const int32_t *triples, uint64_t n, uint8_t *out, hipStream_t s);
 void launch_li_kmers_slots(const NodesDev &nd, const PkbCfg &c, const int32_t prio[4], uint64_t *hash, int32_t *ind, int32_t *count, hipStream_t s);
 void launch_pkb_masks(int32_t n, const uint32_t *rowptr, const alga_edge_dev *edges, uint64_t m, uint32_t *indeg, uint8_t *mask, hipStream_t s);
-void launch_pkb_tips(const NodesDev &nd, const PkbCfg &c, const uint8_t *mask, uint32_t *tips, unsigned long long *counter, hipStream_t s);
+void launch_pkb_tip_flags(const NodesDev &nd, const PkbCfg &c, const uint8_t *mask, uint32_t *flag, hipStream_t s);
+void launch_pkb_tip_list(int32_t n, const uint32_t *flag, const uint32_t *pos, uint32_t *tips, hipStream_t s);
 void launch_pkb_kmers(const NodesDev &nd, const PkbCfg &c, const int32_t prio[4], const uint32_t *tips, uint32_t n_tips, unsigned long long *keys,
                       unsigned long long *vals, unsigned long long *counter, hipStream_t s);
 void launch_pkb_group_sizes(const unsigned long long *keys, uint64_t n, unsigned long long *big_words, unsigned long long *stats, uint32_t *head_flag,

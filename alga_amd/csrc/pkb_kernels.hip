@@ -138,20 +138,16 @@ __global__ void __launch_bounds__(256) k_pkb_masks(int32_t n, const uint32_t *__
 }
 
 // nodes that take part in the supplement (the masks never change between the rounds): dense id list, so that the k-mer kernel
-// runs with full waves (the tips are ~1 node in 5)
-__global__ void __launch_bounds__(256) k_pkb_tips(NodesDev nd, PkbCfg c, const uint8_t *__restrict__ mask, uint32_t *__restrict__ tips,
-                                                   unsigned long long *__restrict__ counter) {
-    __shared__ uint32_t s_cnt, s_base;
+// runs with full waves (the tips are ~1 node in 5).  Flags -> scan -> scatter: a block-aggregated append would still issue one
+// same-address atomic per workgroup (78 k of them at 20 M nodes: 0.9 ms).
+__global__ void __launch_bounds__(256) k_pkb_tip_flags(NodesDev nd, PkbCfg c, const uint8_t *__restrict__ mask, uint32_t *__restrict__ flag) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (threadIdx.x == 0) s_cnt = 0;
-    __syncthreads();
-    const bool take = i < nd.n && mask[i] != 0 && nd.len[i] >= c.li_k && nd.len[i] >= c.kmer_length_bucket;   // Read::getKmers: length > size() -> none
-    uint32_t my = 0;
-    if (take) my = atomicAdd(&s_cnt, 1u);
-    __syncthreads();
-    if (threadIdx.x == 0) s_base = s_cnt ? (uint32_t) atomicAdd(counter, (unsigned long long) s_cnt) : 0u;
-    __syncthreads();
-    if (take) tips[s_base + my] = (uint32_t) i;
+    if (i < nd.n) flag[i] = (mask[i] != 0 && nd.len[i] >= c.li_k && nd.len[i] >= c.kmer_length_bucket) ? 1u : 0u;   // Read::getKmers: length > size() -> none
+}
+
+__global__ void __launch_bounds__(256) k_pkb_tip_list(int32_t n, const uint32_t *__restrict__ flag, const uint32_t *__restrict__ pos, uint32_t *__restrict__ tips) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && flag[i]) tips[pos[i]] = (uint32_t) i;
 }
 
 // k-mers of every node that takes part (GraphCreatorKmerBased::getKmersForBucketJob :202-259), appended to a dense list
@@ -424,9 +420,14 @@ void launch_pkb_masks(int32_t n, const uint32_t *rowptr, const alga_edge_dev *ed
     hipLaunchKernelGGL(k_pkb_masks, dim3((n + 255) / 256), dim3(256), 0, s, n, rowptr, indeg, mask);
 }
 
-void launch_pkb_tips(const NodesDev &nd, const PkbCfg &c, const uint8_t *mask, uint32_t *tips, unsigned long long *counter, hipStream_t s) {
+void launch_pkb_tip_flags(const NodesDev &nd, const PkbCfg &c, const uint8_t *mask, uint32_t *flag, hipStream_t s) {
     if (nd.n <= 0) return;
-    hipLaunchKernelGGL(k_pkb_tips, dim3((nd.n + 255) / 256), dim3(256), 0, s, nd, c, mask, tips, counter);
+    hipLaunchKernelGGL(k_pkb_tip_flags, dim3((nd.n + 255) / 256), dim3(256), 0, s, nd, c, mask, flag);
+}
+
+void launch_pkb_tip_list(int32_t n, const uint32_t *flag, const uint32_t *pos, uint32_t *tips, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_pkb_tip_list, dim3((n + 255) / 256), dim3(256), 0, s, n, flag, pos, tips);
 }
 
 void launch_pkb_kmers(const NodesDev &nd, const PkbCfg &c, const int32_t prio[4], const uint32_t *tips, uint32_t n_tips, unsigned long long *keys,
