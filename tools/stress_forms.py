@@ -1,0 +1,109 @@
+#!/usr/bin/env python3
+"""Randomised cross-check on the GPU: the two forms of the transitive reduction (per-target replay, source-side) must give
+the same edges on every input the source-side form accepts.  Random read lengths (fixed / variable), coverage, substitution
+errors, tandem repeats, exact duplicates and prefix reads left in, masks, min_overlap / rsoemo choices.
+usage: tools/stress_forms.py [n_cases=100] [first_seed=1000]"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import alga_amd  # noqa: E402
+
+
+def make_case(seed):
+    rng = np.random.default_rng(seed)
+    maxlen = int(rng.choice([48, 64, 80, 100, 144, 150, 200, 250]))
+    varlen = rng.random() < 0.4
+    minlen = int(maxlen * rng.uniform(0.6, 0.95)) if varlen else maxlen
+    n_reads = int(rng.integers(300, 6000))
+    cov = float(rng.choice([3, 8, 20, 50, 120]))
+    G = max(maxlen * 3, int(n_reads * (maxlen + minlen) / 2 / cov))
+    err = float(rng.choice([0, 0, 0.001, 0.005, 0.02]))
+    g = rng.integers(0, 4, G, dtype=np.uint8)
+    if rng.random() < 0.4:                                  # tandem repeats / multi-copy repeats
+        period = int(rng.integers(3, 60))
+        for s0 in range(0, max(1, G - 400), int(rng.integers(500, 3000))):
+            unit = g[s0: s0 + period].copy()
+            for k in range(1, 300 // period):
+                if s0 + (k + 1) * period <= G:
+                    g[s0 + k * period: s0 + (k + 1) * period] = unit
+    if rng.random() < 0.3 and G > 2000:                     # a dispersed repeat with several copies
+        rep = g[100:100 + int(rng.integers(100, 400))].copy()
+        for _ in range(int(rng.integers(2, 12))):
+            p = int(rng.integers(0, G - len(rep)))
+            g[p: p + len(rep)] = rep
+    reads = []
+    for _ in range(n_reads):
+        L = int(rng.integers(minlen, maxlen + 1))
+        p = int(rng.integers(0, G - L + 1))
+        r = g[p: p + L].copy()
+        if err:
+            m = rng.random(L) < err
+            r[m] = (r[m] + rng.integers(1, 4, int(m.sum()))) & 3
+        if rng.random() < 0.5:
+            r = (3 - r)[::-1]
+        reads.append(r)
+    if rng.random() < 0.5:                                  # remove exact duplicates (as the reference's preprocessing would)
+        seen, uniq = set(), []
+        for r in reads:
+            k = min(r.tobytes(), (3 - r)[::-1].tobytes())
+            if k not in seen:
+                seen.add(k); uniq.append(r)
+        reads = uniq
+    n = len(reads)
+    codes = np.zeros((2 * n, maxlen), dtype=np.uint8)
+    lens = np.zeros(2 * n, dtype=np.int32)
+    for i, r in enumerate(reads):
+        codes[2 * i, : len(r)] = (3 - r)[::-1]
+        codes[2 * i + 1, : len(r)] = r
+        lens[2 * i] = lens[2 * i + 1] = len(r)
+    words = alga_amd.pack_reads(codes, lens)
+    lo = int(maxlen * rng.uniform(0.35, 0.7))
+    if maxlen - lo > 127:
+        lo = maxlen - int(rng.integers(20, 127))
+    rs = int(rng.integers(lo, maxlen + 2))
+    af = at = None
+    if rng.random() < 0.25:
+        dead = rng.random(2 * n) < 0.05
+        lens = np.where(dead, 0, lens).astype(np.int32)
+        words[dead] = 0
+    if rng.random() < 0.2:
+        af = (rng.random(2 * n) < 0.85).astype(np.uint8)
+        at = np.maximum(af, (rng.random(2 * n) < 0.5).astype(np.uint8))
+    desc = dict(seed=seed, maxlen=maxlen, minlen=minlen, reads=n, genome=G, err=err, lo=lo, rs=rs, masks=af is not None)
+    return words, lens, lo, rs, af, at, desc
+
+
+def main():
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    first = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+    eng = alga_amd.Engine(0)
+    used, declined, bad = 0, 0, 0
+    big = generic = 0
+    for seed in range(first, first + n_cases):
+        words, lens, lo, rs, af, at, desc = make_case(seed)
+        a = eng.prefsuf_host(words, lens, lo, rs, af, at, reduction="per_target")
+        try:
+            b = eng.prefsuf_host(words, lens, lo, rs, af, at, reduction="source_side", collect_stats=True)
+        except alga_amd.AlgaError as e:
+            if e.code != -7:
+                raise
+            declined += 1
+            continue
+        st = eng.last_stats()
+        used += 1
+        big += st["big_sources"] > 0
+        generic += st["generic_sources"] > 0
+        if a.shape != b.shape or not (a == b).all():
+            bad += 1
+            print("MISMATCH", desc, a.shape, b.shape, flush=True)
+    print("cases %d: source-side used %d (all-pairs branch in %d, second pass in %d), declined %d, mismatches %d" %
+          (n_cases, used, generic, big, declined, bad))
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
