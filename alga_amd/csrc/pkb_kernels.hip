@@ -356,14 +356,7 @@ __global__ void __launch_bounds__(256) k_pkb_mark_unused(const unsigned long lon
     }
 }
 
-// edges (old graph + additions) -> sort key (src << 36 | dst << 9 | offset) ; invalid (src < 0) -> all ones
-__global__ void __launch_bounds__(256) k_pkb_edge_keys(const alga_edge_dev *__restrict__ e, uint64_t n, unsigned long long *__restrict__ keys) {
-    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) {
-        const alga_edge_dev x = e[i];
-        keys[i] = x.src < 0 ? ~0ull : (((unsigned long long) (uint32_t) x.src << 36) | ((unsigned long long) (uint32_t) x.dst << 9) | (uint32_t) (x.offset & 511));
-    }
-}
-
+// edges (old graph + additions) -> sort key (src << 36 | dst << 9 | offset).
 // The addition slots of a round are mostly unused (src < 0): only the used entries are worth sorting.
 __global__ void __launch_bounds__(256) k_pkb_valid_flags(const alga_edge_dev *__restrict__ e, uint64_t n, uint32_t *__restrict__ flag) {
     for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) flag[i] = e[i].src >= 0 ? 1u : 0u;
@@ -458,11 +451,6 @@ void launch_pkb_groups(const NodesDev &nd, const PkbCfg &c, const uint32_t *rowp
     if (n_heads)
         hipLaunchKernelGGL(k_pkb_groups, dim3((n_heads + 63) / 64), dim3(64), 0, s, nd, c, g, keys, heads, n_heads, vals, n, marks, big_marks, big_cursor,
                            add_edges, add_dense, add_cap, add_overflow, counters);
-}
-
-void launch_pkb_edge_keys(const alga_edge_dev *e, uint64_t n, unsigned long long *keys, hipStream_t s) {
-    if (n == 0) return;
-    hipLaunchKernelGGL(k_pkb_edge_keys, dim3(pkb_grid(n, 256, 16384)), dim3(256), 0, s, e, n, keys);
 }
 
 void launch_pkb_valid_flags(const alga_edge_dev *e, uint64_t n, uint32_t *flag, hipStream_t s) {
