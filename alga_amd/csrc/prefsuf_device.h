@@ -69,6 +69,10 @@ __device__ __forceinline__ uint32_t quad_or(uint32_t v) {
     return v;
 }
 
+// value of the lane N positions up / down inside the 16-lane row (0 past the row's end); all lanes involved must be active
+template <int N> __device__ __forceinline__ int row_from_above(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x100 + N, 0xF, 0xF, true); }   // row_shl:N
+template <int N> __device__ __forceinline__ int row_from_below(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x110 + N, 0xF, 0xF, true); }   // row_shr:N
+
 // 32 bits of a bit string starting at bit r of lo (v_alignbit_b32)
 __device__ __forceinline__ uint32_t funnel(uint32_t lo, uint32_t hi, int r) { return __funnelshift_r(lo, hi, r); }
 

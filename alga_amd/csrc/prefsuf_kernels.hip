@@ -364,6 +364,81 @@ k_probe_sources(NodesDev nd, PrefSufCfg cfg, const unsigned long long *__restric
                     }
                 }
                 if (LOCAL) { wave_lds_fence(); n_items = (int) __builtin_amdgcn_readfirstlane((int) *it.N); }
+            } else if (NQ == 3) {
+                // rows of 48 used bytes: THREE lanes per candidate, five candidates per 16-lane row (lane 15 idles), 20 per
+                // group: 76 % of the sources of configs[1] fit one group (41 % with quads of which one lane loads nothing)
+                const int pos = lane & 15, grp = (pos * 11) >> 5, sub3 = pos - 3 * grp;        // pos / 3 for pos < 16
+                const bool lane_ok = pos < 15;
+                for (int c0 = 0; c0 < ncand; c0 += 40) {          // two groups per trip: both row loads in flight
+                    int Cc[2], Lc[2], Nc[2];
+                    uint4 cc[2];
+                    bool act[2];
+#pragma unroll
+                    for (int g = 0; g < 2; g++) {
+                        const int ci = c0 + 20 * g + 5 * (lane >> 4) + grp;
+                        act[g] = lane_ok && ci < ncand;
+                        Cc[g] = 0; Lc[g] = Lspan; Nc[g] = 0;
+                        cc[g] = make_uint4(0u, 0u, 0u, 0u);
+                        if (act[g]) {
+                            Cc[g] = (int) w.candC[ci];
+                            const uint32_t cw = w.candW[ci];
+                            Lc[g] = Lspan - (int) (cw & 0xFFFFu);
+                            Nc[g] = (int) (cw >> 16);
+                            cc[g] = reinterpret_cast<const uint4 *>(nd.words + (size_t) Cc[g] * nd.stride)[sub3];
+                        }
+                    }
+#pragma unroll
+                    for (int g = 0; g < 2; g++) {
+                        uint32_t diff = 0;
+                        if (act[g]) {
+                            const int L = Lc[g];
+                            const int bit = 2 * (lenB - L) - 32 * w0;
+                            const int q = bit >> 5, r = bit & 31;
+                            const int nwL = (2 * L + 31) >> 5;
+                            const uint32_t lastmask = (2 * L & 31) ? ((1u << (2 * L & 31)) - 1u) : 0xFFFFFFFFu;
+                            const uint32_t cw[4] = {cc[g].x, cc[g].y, cc[g].z, cc[g].w};
+                            uint32_t y[5];
+#pragma unroll
+                            for (int j = 0; j < 5; j++) y[j] = sb[q + 4 * sub3 + j];
+#pragma unroll
+                            for (int j = 0; j < 4; j++) {
+                                const int k = 4 * sub3 + j;
+                                const uint32_t m = k < nwL - 1 ? 0xFFFFFFFFu : (k == nwL - 1 ? lastmask : 0u);
+                                diff |= (funnel(y[j], y[j + 1], r) ^ cw[j]) & m;
+                            }
+                        }
+                        const uint32_t d1 = (uint32_t) row_from_above<1>((int) diff), d2 = (uint32_t) row_from_above<2>((int) diff);
+                        const bool pass = act[g] && sub3 == 0 && (diff | d1 | d2) == 0;       // the group's first lane decides
+                        if (LOCAL) {
+                            const uint64_t pm = __ballot(pass);
+                            int slot = -1;
+                            if (pass) {
+                                if (STATS) st_raw++;
+                                slot = n_items + (int) __builtin_amdgcn_mbcnt_hi((uint32_t) (pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) pm, 0u));
+                                if (slot < item_cap) {
+                                    uint32_t m = (uint32_t) (lenB - Lc[g]) | ((uint32_t) Nc[g] << 9);
+                                    if (nd.from == nullptr || nd.from[Cc[g]]) m |= ITEM_FROM;
+                                    it.C[slot] = (uint32_t) Cc[g]; it.M[slot] = m;
+                                }
+                            }
+                            n_items += __popcll(pm);
+                            const int s1 = row_from_below<1>(slot), s2 = row_from_below<2>(slot);   // the first lane's slot for the other two
+                            slot = sub3 == 0 ? slot : (sub3 == 1 ? s1 : s2);
+                            const uint32_t nq = (uint32_t) row_from_above<1>((int) cc[g].x);
+                            const uint32_t nxt = sub3 == 2 ? 0u : nq;
+                            if (lane_ok && slot >= 0 && slot < item_cap) {
+                                const int ws = (2 * Lc[g]) >> 5, r = (2 * Lc[g]) & 31;
+                                uint32_t *ow = reinterpret_cast<uint32_t *>(&it.O[slot * (LOCAL ? LOCAL : 1)]);
+                                const uint32_t cw[5] = {cc[g].x, cc[g].y, cc[g].z, cc[g].w, nxt};
+#pragma unroll
+                                for (int j = 0; j < 4; j++) {
+                                    const int k = 4 * sub3 + j - ws;
+                                    if (k >= 0 && k < 4 * LOCAL) ow[k] = funnel(cw[j], cw[j + 1], r);
+                                }
+                            }
+                        } else if (pass) classify(Cc[g], Lc[g], Nc[g]);
+                    }
+                }
             } else {
                 // four lanes per candidate: lane `sub` loads 16 bytes of C's row (one request per row), compares its
                 // four words, the group ORs its differences
