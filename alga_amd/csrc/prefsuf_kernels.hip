@@ -364,18 +364,21 @@ k_probe_sources(NodesDev nd, PrefSufCfg cfg, const unsigned long long *__restric
                     }
                 }
                 if (LOCAL) { wave_lds_fence(); n_items = (int) __builtin_amdgcn_readfirstlane((int) *it.N); }
-            } else if (NQ == 3) {
-                // rows of 48 used bytes: THREE lanes per candidate, five candidates per 16-lane row (lane 15 idles), 20 per
+            } else if (NQ == 3 || NQ == 2) {
+                // rows of 48 (32) used bytes: THREE (TWO) lanes per candidate, five (eight) candidates per 16-lane row, 20 (32) per
                 // group: 76 % of the sources of configs[1] fit one group (41 % with quads of which one lane loads nothing)
-                const int pos = lane & 15, grp = (pos * 11) >> 5, sub3 = pos - 3 * grp;        // pos / 3 for pos < 16
-                const bool lane_ok = pos < 15;
-                for (int c0 = 0; c0 < ncand; c0 += 40) {          // two groups per trip: both row loads in flight
+                constexpr int GPR = NQ == 3 ? 5 : 8;              // candidates per 16-lane row
+                const int pos = lane & 15;
+                const int grp = NQ == 3 ? (pos * 11) >> 5 : pos >> 1;                          // pos / NQ for pos < 16
+                const int sub3 = pos - NQ * grp;
+                const bool lane_ok = NQ == 2 || pos < 15;         // lane 15 of a row idles with three lanes per candidate
+                for (int c0 = 0; c0 < ncand; c0 += 8 * GPR) {     // two groups per trip: both row loads in flight
                     int Cc[2], Lc[2], Nc[2];
                     uint4 cc[2];
                     bool act[2];
 #pragma unroll
                     for (int g = 0; g < 2; g++) {
-                        const int ci = c0 + 20 * g + 5 * (lane >> 4) + grp;
+                        const int ci = c0 + 4 * GPR * g + GPR * (lane >> 4) + grp;
                         act[g] = lane_ok && ci < ncand;
                         Cc[g] = 0; Lc[g] = Lspan; Nc[g] = 0;
                         cc[g] = make_uint4(0u, 0u, 0u, 0u);
@@ -407,7 +410,8 @@ k_probe_sources(NodesDev nd, PrefSufCfg cfg, const unsigned long long *__restric
                                 diff |= (funnel(y[j], y[j + 1], r) ^ cw[j]) & m;
                             }
                         }
-                        const uint32_t d1 = (uint32_t) row_from_above<1>((int) diff), d2 = (uint32_t) row_from_above<2>((int) diff);
+                        const uint32_t d1 = (uint32_t) row_from_above<1>((int) diff);
+                        const uint32_t d2 = NQ == 3 ? (uint32_t) row_from_above<2>((int) diff) : 0u;
                         const bool pass = act[g] && sub3 == 0 && (diff | d1 | d2) == 0;       // the group's first lane decides
                         if (LOCAL) {
                             const uint64_t pm = __ballot(pass);
@@ -422,10 +426,11 @@ k_probe_sources(NodesDev nd, PrefSufCfg cfg, const unsigned long long *__restric
                                 }
                             }
                             n_items += __popcll(pm);
-                            const int s1 = row_from_below<1>(slot), s2 = row_from_below<2>(slot);   // the first lane's slot for the other two
+                            const int s1 = row_from_below<1>(slot);                                 // the first lane's slot for the others
+                            const int s2 = NQ == 3 ? row_from_below<2>(slot) : -1;
                             slot = sub3 == 0 ? slot : (sub3 == 1 ? s1 : s2);
                             const uint32_t nq = (uint32_t) row_from_above<1>((int) cc[g].x);
-                            const uint32_t nxt = sub3 == 2 ? 0u : nq;
+                            const uint32_t nxt = sub3 == NQ - 1 ? 0u : nq;
                             if (lane_ok && slot >= 0 && slot < item_cap) {
                                 const int ws = (2 * Lc[g]) >> 5, r = (2 * Lc[g]) & 31;
                                 uint32_t *ow = reinterpret_cast<uint32_t *>(&it.O[slot * (LOCAL ? LOCAL : 1)]);
