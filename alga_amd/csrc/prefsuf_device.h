@@ -437,21 +437,58 @@ __device__ __forceinline__ void local_reduce(const NodesDev &nd, const PrefSufCf
         }
         __threadfence_block();
         wave_lds_fence();
-        for (int jb = 0; jb < n; jb += 64) {
-            const int j = jb + lane;
-            const bool actj = j < n;
-            uint32_t Cj = 0, mj = 0;
-            Ovh<SW> oj, kj;
+        // per-lane data of a possible via j: pre-masked overhang, its mask, reach
+        auto via_fields = [&](int j, bool actj, uint32_t &Cj, Ovh<SW> &oj, Ovh<SW> &kj, int &dj, int &rho_j, int &dend_j, bool &ok_j, bool &kept_j) {
+            uint32_t mj = 0;
+            Cj = 0;
 #pragma unroll
             for (int k = 0; k < 4 * SW; k++) { oj.w[k] = 0u; kj.w[k] = 0u; }
             if (actj) { Cj = it.C[j]; mj = it.M[j]; oj = load_ovh<SW>(it.O, j); }
-            const int dj = (int) (mj & 511u), lenj = (int) ((mj >> 9) & 511u);
-            const int rho_j = lenj - (lenA - dj);
-            const int dend_j = dj + lenj - Lbig;           // B -> C is big  <=>  d_C <= d_B + |B| - Lbig
-            const bool ok_j = actj && (mj & ITEM_FROM) != 0 && (rho_j > 0 || (int) Cj > A);
-            const bool kept_j = actj && (mj & ITEM_KEPT) != 0;
+            dj = (int) (mj & 511u);
+            const int lenj = (int) ((mj >> 9) & 511u);
+            rho_j = lenj - (lenA - dj);
+            dend_j = dj + lenj - Lbig;                     // B -> C is big  <=>  d_C <= d_B + |B| - Lbig
+            ok_j = actj && (mj & ITEM_FROM) != 0 && (rho_j > 0 || (int) Cj > A);
+            kept_j = actj && (mj & ITEM_KEPT) != 0;
 #pragma unroll
             for (int k = 0; k < 4 * SW; k++) { kj.w[k] = low_bits32(2 * rho_j - 32 * k); oj.w[k] &= kj.w[k]; }
+        };
+        if (n <= 64) {
+            // Few items (the usual case with sequencing errors): the 64 lanes hold (item i, via j) PAIRS, 64 / npad items per step with
+            // npad = n rounded up to a power of two, and a hit sets the item's removed bit with an LDS atomic.
+            const int lg = n <= 2 ? 1 : 32 - __clz(n - 1);
+            const int npad = 1 << lg, per_step = 64 >> lg;
+            const int j = lane & (npad - 1), il = lane >> lg;
+            const bool actj = j < n;
+            uint32_t Cj; Ovh<SW> oj, kj; int dj, rho_j, dend_j; bool ok_j, kept_j;
+            via_fields(j, actj, Cj, oj, kj, dj, rho_j, dend_j, ok_j, kept_j);
+            for (int ib = 0; ib < n; ib += per_step) {
+                const int i = ib + il;
+                if (i < n && actj) {
+                    const uint32_t mi = it.M[i];
+                    if ((mi & ITEM_KEPT) != 0) {
+                        const uint32_t Ci = it.C[i];
+                        const Ovh<SW> oi = load_ovh<SW>(it.O, i);
+                        const int di = (int) (mi & 511u);
+                        const int rho_i = (int) ((mi >> 9) & 511u) - (lenA - di);
+                        uint32_t diff = 0;
+#pragma unroll
+                        for (int k = 0; k < 4 * SW; k++) diff |= (oi.w[k] & kj.w[k]) ^ oj.w[k];
+                        const bool via = ok_j && Cj != Ci && dj < di && di <= dend_j && rho_j <= rho_i && diff == 0;
+                        const bool sup = kept_j && Cj == Ci && dj < di;
+                        if (STATS && Cj != Ci && dj < di) st_cmp++;
+                        if (via || sup) atomicOr(&it.M[i], ITEM_REMOVED);
+                    }
+                }
+            }
+            __threadfence_block();
+            wave_lds_fence();
+        } else
+        for (int jb = 0; jb < n; jb += 64) {
+            const int j = jb + lane;
+            const bool actj = j < n;
+            uint32_t Cj; Ovh<SW> oj, kj; int dj, rho_j, dend_j; bool ok_j, kept_j;
+            via_fields(j, actj, Cj, oj, kj, dj, rho_j, dend_j, ok_j, kept_j);
             for (int i = 0; i < n; i++) {                  // uniform
                 const uint32_t mi = (uint32_t) __builtin_amdgcn_readfirstlane((int) it.M[i]);     // scalar: the skip is a uniform branch
                 if ((mi & (ITEM_KEPT | ITEM_REMOVED)) != ITEM_KEPT) continue;
