@@ -156,6 +156,12 @@ def test_degenerate_inputs(eng):
     # 25 copies: 65..160 raw overlaps per source, the multi-round all-pairs path of the source-side form in LDS
     w25 = alga_amd.pack_reads(np.repeat(codes, 25, axis=0))
     _check(eng, w25, np.full(len(w25), 80, np.int32), 40, 60)
+    # the same with 250 nt reads: second pass in the two-word form (offsets up to 113, 256-bit overhangs)
+    codes250, _ = gen_reads.sample_reads(6, 250, 420, 27)
+    w250 = alga_amd.pack_reads(np.repeat(codes250, 60, axis=0))
+    _check(eng, w250, np.full(len(w250), 250, np.int32), 137, 190)
+    eng.prefsuf_host(w250, np.full(len(w250), 250, np.int32), 137, 190, reduction="source_side")
+    assert eng.last_stats()["big_sources"] > 0
     # beyond the largest item slice the engine allocates for the second pass (4096 per wave; lowered here) the source-side form
     # declines and AUTO falls back to the per-target pipeline
     os.environ["ALGA_LOCAL_BIG_MAX"] = "200"
