@@ -62,6 +62,7 @@ int prepare(alga_engine *e, const alga_nodes *nodes, const alga_prefsuf_params *
     out.live = e->h_counters[CNT_LIVE_NODES];
     if ((int64_t) blocks_of(out.max_len) > (int64_t) nodes->stride_words)
         return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "stride_words is smaller than the longest read needs");
+    if (out.max_len > OL_MAX_NODE_LEN) return alga_fail(e, ALGA_ERR_CAPACITY, "a node is longer than 4 194 303 nt (overlap records keep the offset in 22 bits)");
     PrefSufCfg c;
     c.Lmin = p->min_overlap;
     c.rsoemo = p->rsoe_min_overlap;

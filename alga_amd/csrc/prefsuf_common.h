@@ -19,10 +19,12 @@
 namespace alga {
 
 // ---- overlap record: one verified suffix(B)==prefix(C) pair that survived the per-source cap ----
-//   ol = offset | (overlap_len << 12) | (small << 31)      offset <= 500, overlap_len <= 501
-constexpr uint32_t OL_OFF_MASK = 0xFFFu;
-constexpr int      OL_LEN_SHIFT = 12;
-constexpr uint32_t OL_LEN_MASK = 0xFFFu;
+//   ol = offset | (overlap_len << 22) | (small << 31)      overlap_len <= 501 (9 bits); offset = |source| - overlap_len: 22 bits,
+//   so nodes of up to OL_MAX_NODE_LEN nucleotides (the reference's second call runs on contigs, src/main.cpp:633-656)
+constexpr uint32_t OL_OFF_MASK = 0x3FFFFFu;
+constexpr int      OL_LEN_SHIFT = 22;
+constexpr uint32_t OL_LEN_MASK = 0x1FFu;
+constexpr int      OL_MAX_NODE_LEN = (1 << 22) - 1;
 constexpr uint32_t OL_SMALL = 0x80000000u;
 
 ALGA_HD inline uint32_t ol_pack(int off, int L, bool small) {

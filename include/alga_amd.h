@@ -144,7 +144,7 @@ int  alga_prefsuf_last_stats(const alga_engine *e, alga_prefsuf_stats *out);
  * so it needs no exchange: GraphCreatorPrefSuf.cpp:397-401), and return the overlap records as two
  * device arrays of *n_records slots (engine-owned, valid until the next call on `e`):
  *   d_dst[i] : target node id, or 0xFFFFFFFF for an unused slot (skip it)
- *   d_val[i] : (ol << 32) | source node id,  ol = offset | (overlap_len << 12) | (small << 31)
+ *   d_val[i] : (ol << 32) | source node id,  ol = offset | (overlap_len << 22) | (small << 31)
  * Phase 2, on the rank that owns the target ids [dst_begin, dst_end): reduce records (any order,
  * every record of an owned target present) to edges.  Slots with d_dst outside the range are ignored. */
 int  alga_prefsuf_discover_device(alga_engine *e, const alga_nodes *nodes, const alga_prefsuf_params *p,

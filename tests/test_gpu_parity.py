@@ -386,3 +386,26 @@ def test_sharded_driver_with_hip_backend_three_ranks_one_gpu(lo, rs, replicate):
             assert got.shape == want.shape and (got == want).all()
         else:
             assert len(got) == 0
+
+
+def test_contig_like_inputs_second_call_of_the_reference(eng):
+    """src/main.cpp:633-656 calls the same creator once more on the CONTIGS (kb-long "reads", min_overlap = rsoemo = 25, overlap
+    lengths capped at 501): not on the benchmark path, but the engine takes it (per-target form: the reads are far too long for
+    the source-side one)."""
+    rng = np.random.default_rng(61)
+    g = rng.integers(0, 4, 120000, dtype=np.uint8)
+    seqs, p = [], 0
+    while p < len(g) - 9000:                                   # contigs of 3-8 kb whose ends share 30-450 nt with the next one
+        L = int(rng.integers(3000, 8000))
+        seqs.append(g[p: p + L].copy())
+        p += L - int(rng.integers(30, 450))
+    maxlen = max(len(s) for s in seqs)
+    codes = np.zeros((2 * len(seqs), maxlen), dtype=np.uint8)
+    lens = np.zeros(2 * len(seqs), dtype=np.int32)
+    for i, s in enumerate(seqs):
+        codes[2 * i, : len(s)] = (3 - s)[::-1]
+        codes[2 * i + 1, : len(s)] = s
+        lens[2 * i] = lens[2 * i + 1] = len(s)
+    words = alga_amd.pack_reads(codes, lens)
+    got = _check(eng, words, lens, 25, 25)
+    assert len(got) >= len(seqs) - 1

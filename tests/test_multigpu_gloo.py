@@ -53,9 +53,9 @@ class PyBackend:
                     if L < self.rs:
                         small.append((L, C, off))
                     else:
-                        dst.append(C); val.append(((off | (L << 12)) << 32) | B)
+                        dst.append(C); val.append(((off | (L << 22)) << 32) | B)
             for L, C, off in sorted(small)[-3:]:
-                dst.append(C); val.append(((off | (L << 12) | OL_SMALL) << 32) | B)
+                dst.append(C); val.append(((off | (L << 22) | OL_SMALL) << 32) | B)
         return np.array(dst, dtype=np.int64), np.array(val, dtype=np.uint64)
 
     def build_range(self, a, b, collect_stats=False):
@@ -83,7 +83,7 @@ class PyBackend:
             for x in v[d == C]:
                 x = int(x)
                 ol, src = x >> 32, x & 0xFFFFFFFF
-                recs.append((0 if ol & OL_SMALL else 1, (ol >> 12) & 0xFFF, src, ol & 0xFFF))
+                recs.append((0 if ol & OL_SMALL else 1, (ol >> 22) & 0x1FF, src, ol & 0x3FFFFF))
             recs.sort()
             live = []                                     # (A, offA, L_A)
             for big, L, B, off in recs:
