@@ -82,10 +82,15 @@ int normalize_edges(alga_engine *e, int32_t n_nodes, const alga_edge_dev *in, ui
     if ((rc = alga_check_launch(e, "k_pkb_valid_flags"))) return rc;
     launch_exclusive_scan((const uint32_t *) e->pk_flag.p, n_in, (uint32_t *) e->pk_pos.p, (uint64_t *) e->scan_scratch.p, s);
     if ((rc = alga_check_launch(e, "scan(valid)"))) return rc;
-    launch_pkb_edge_keys_dense(in, (const uint32_t *) e->pk_flag.p, (const uint32_t *) e->pk_pos.p, n_in, (unsigned long long *) e->pk_ekeys.p, s);
+    if ((rc = alga_ensure(e, e->pk_cnt, 16 * sizeof(unsigned long long)))) return rc;
+    unsigned long long *bad = (unsigned long long *) e->pk_cnt.p + 15;
+    HIP_TRY(e, hipMemsetAsync(bad, 0, sizeof(unsigned long long), s));
+    launch_pkb_edge_keys_dense(in, (const uint32_t *) e->pk_flag.p, (const uint32_t *) e->pk_pos.p, n_in, (unsigned long long *) e->pk_ekeys.p, bad, s);
     if ((rc = alga_check_launch(e, "k_pkb_edge_keys_dense"))) return rc;
     HIP_TRY(e, hipMemcpyAsync(&e->h_counters[CNT_TOTAL], (uint64_t *) e->scan_scratch.p + scan_total_index(n_in), sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(e, hipMemcpyAsync(&e->h_counters[CNT_TOTAL + 1], bad, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     HIP_TRY(e, hipStreamSynchronize(s));
+    if (e->h_counters[CNT_TOTAL + 1]) return alga_fail(e, ALGA_ERR_CAPACITY, "the supplement keeps edge offsets in 9 bits: an edge has an offset above 511 (reads longer than 512 nt?)");
     const uint64_t n_all = n_in;
     n_in = n_all ? e->h_counters[CNT_TOTAL] : 0;                 // from here on: the used entries
     (void) n_all;

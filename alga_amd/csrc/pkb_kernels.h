@@ -33,7 +33,8 @@ void launch_pkb_groups(const NodesDev &nd, const PkbCfg &c, const uint32_t *rowp
                        unsigned long long *big_cursor, alga_edge_dev *add_edges, uint64_t add_dense, uint64_t add_cap,
                        unsigned long long *add_overflow, unsigned long long *counters, hipStream_t s);
 void launch_pkb_valid_flags(const alga_edge_dev *e, uint64_t n, uint32_t *flag, hipStream_t s);
-void launch_pkb_edge_keys_dense(const alga_edge_dev *e, const uint32_t *flag, const uint32_t *pos, uint64_t n, unsigned long long *keys, hipStream_t s);
+void launch_pkb_edge_keys_dense(const alga_edge_dev *e, const uint32_t *flag, const uint32_t *pos, uint64_t n, unsigned long long *keys,
+                                unsigned long long *bad, hipStream_t s);
 void launch_pkb_unique_flags(const unsigned long long *keys, uint64_t n, uint32_t *flag, hipStream_t s);
 void launch_pkb_compact(const unsigned long long *keys, const uint32_t *flag, const uint32_t *pos, uint64_t n, alga_edge_dev *out,
                         uint32_t *outdeg, hipStream_t s);

@@ -363,10 +363,12 @@ __global__ void __launch_bounds__(256) k_pkb_valid_flags(const alga_edge_dev *__
 }
 
 __global__ void __launch_bounds__(256) k_pkb_edge_keys_dense(const alga_edge_dev *__restrict__ e, const uint32_t *__restrict__ flag,
-                                                              const uint32_t *__restrict__ pos, uint64_t n, unsigned long long *__restrict__ keys) {
+                                                              const uint32_t *__restrict__ pos, uint64_t n, unsigned long long *__restrict__ keys,
+                                                              unsigned long long *__restrict__ bad /* edges whose offset does not fit the key */) {
     for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) {
         if (!flag[i]) continue;
         const alga_edge_dev x = e[i];
+        if ((uint32_t) x.offset > 511u) atomicAdd(bad, 1ull);                // never on reads the supplement is meant for (<= 500 nt)
         keys[pos[i]] = ((unsigned long long) (uint32_t) x.src << 36) | ((unsigned long long) (uint32_t) x.dst << 9) | (uint32_t) (x.offset & 511);
     }
 }
@@ -458,9 +460,10 @@ void launch_pkb_valid_flags(const alga_edge_dev *e, uint64_t n, uint32_t *flag, 
     hipLaunchKernelGGL(k_pkb_valid_flags, dim3(pkb_grid(n, 256, 16384)), dim3(256), 0, s, e, n, flag);
 }
 
-void launch_pkb_edge_keys_dense(const alga_edge_dev *e, const uint32_t *flag, const uint32_t *pos, uint64_t n, unsigned long long *keys, hipStream_t s) {
+void launch_pkb_edge_keys_dense(const alga_edge_dev *e, const uint32_t *flag, const uint32_t *pos, uint64_t n, unsigned long long *keys,
+                                unsigned long long *bad, hipStream_t s) {
     if (n == 0) return;
-    hipLaunchKernelGGL(k_pkb_edge_keys_dense, dim3(pkb_grid(n, 256, 16384)), dim3(256), 0, s, e, flag, pos, n, keys);
+    hipLaunchKernelGGL(k_pkb_edge_keys_dense, dim3(pkb_grid(n, 256, 16384)), dim3(256), 0, s, e, flag, pos, n, keys, bad);
 }
 
 void launch_pkb_unique_flags(const unsigned long long *keys, uint64_t n, uint32_t *flag, hipStream_t s) {

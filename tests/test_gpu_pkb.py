@@ -122,3 +122,16 @@ def test_supplement_equals_oracle_with_engine_semantics(eng, n, G, seed, err):
     # how far the order-independent semantics is from the reference's sequential order on this input (reported, bounded)
     a, b = set(map(tuple, ref_order.tolist())), set(map(tuple, want.tolist()))
     assert len(a ^ b) <= 0.005 * len(a)
+
+
+def test_supplement_rejects_offsets_it_cannot_represent(eng):
+    """the edge merge packs (src, dst, offset) into 64 bits with 9 bits of offset: an edge outside that range is an error, not a
+    silently different graph"""
+    words = np.zeros((4, 40), np.uint32)
+    lens = np.array([600, 600, 600, 600], np.int32)
+    p = eng.pkb_params(600.0, 0.02, 60)
+    with pytest.raises(alga_amd.AlgaError) as ei:
+        eng.pkb_supplement_host(words, lens, np.array([[0, 2, 530]], np.int32), p)
+    assert ei.value.code in (-1, -5)        # the host entry point validates its edge list, the device one counts misfits in the key kernel
+    out = eng.pkb_supplement_host(words, lens, np.array([[0, 2, 300]], np.int32), p)       # in range: accepted
+    assert len(out) >= 1
