@@ -24,6 +24,8 @@ using namespace alga;
 
 namespace {
 
+constexpr uint64_t CLUSTER_AUTO_MIN_NODES = 4ull << 20;   // AUTO: node sets below this stay on the seed-table probe
+
 struct Prepared {
     NodesDev   nd;
     PrefSufCfg cfg;
@@ -31,6 +33,7 @@ struct Prepared {
     uint64_t   live = 0;
     bool       local_ok = false;     // the source-side reduction is exact for this input
     int        local_sw = 1;         // ... with one or two 64-bit words per offset mask / uint4 per overhang
+    int        cluster_eq = 0;       // clustered minimizer probe: 16-byte pieces per entry (0 = that probe does not take this input)
     int        reduction = ALGA_REDUCTION_AUTO;
 };
 
@@ -81,10 +84,16 @@ int prepare(alga_engine *e, const alga_nodes *nodes, const alga_prefsuf_params *
         return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "reduction must be an alga_reduction value");
     // preconditions of the source-side reduction (prefsuf_device.h: local_reduce; tests/source_side_rule.py)
     out.local_ok = out.max_len <= p->max_len_cap && out.max_len - c.Lmin <= LOCAL_MAX_SPAN && c.Lmin <= c.rsoemo && c.rsoemo <= c.Lcap &&
-                   e->h_counters[CNT_MASK_ASYM] == 0 && e->probe_mode == 0;
+                   e->h_counters[CNT_MASK_ASYM] == 0;
     out.local_sw = out.max_len - c.Lmin <= 63 ? 1 : 2;
+    // Which probe feeds the source-side form.  The clustered minimizer join (prefsuf_cluster.hip) takes one-word offset masks and
+    // rows of up to 13 words; AUTO uses it once the node set has outgrown the on-die caches (the seed-table probe is faster while
+    // table + rows stay in the 256 MB Infinity Cache: measured cross-over in DESIGN.md section 5c).
+    out.cluster_eq = (out.local_ok && out.local_sw == 1) ? cluster_entry_quads(out.max_len) : 0;
+    if (e->opt_probe == ALGA_PROBE_TABLE) out.cluster_eq = 0;
+    if (e->opt_probe == ALGA_PROBE_AUTO && out.live < CLUSTER_AUTO_MIN_NODES) out.cluster_eq = 0;
     out.reduction = p->reduction;
-    if (out.reduction == ALGA_REDUCTION_AUTO && e->force_reduction) out.reduction = e->force_reduction == 1 ? ALGA_REDUCTION_PER_TARGET : ALGA_REDUCTION_AUTO;
+    if (out.reduction == ALGA_REDUCTION_AUTO && e->opt_force_per_target) out.reduction = ALGA_REDUCTION_PER_TARGET;
     return ALGA_OK;
 }
 
@@ -99,50 +108,49 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
     *n_rec = 0;
     HIP_TRY(e, hipEventRecord(e->ev[EV_START], s));
     if (pp.live >= (1ull << 31)) return alga_fail(e, ALGA_ERR_CAPACITY, "too many nodes for one seed table; shard the input");
-    uint32_t n_buckets = 0, filter_bits = 0, dir_slots = 0;
-    if (e->probe_mode == 0) {
+    const bool clustered = local && pp.cluster_eq != 0;
+    uint32_t n_buckets = 0, filter_bits = 0;
+    bool have_table = false;
+    auto build_table = [&]() -> int {                      // bucketised seed table + prefilter of prefsuf_kernels.hip
         n_buckets = seed_buckets_for(pp.live, e->seed_fill_x10);
         const size_t table_bytes = (size_t) n_buckets * SEED_BUCKET * sizeof(unsigned long long);
-        if ((rc = alga_ensure(e, e->table, table_bytes))) return rc;
+        int r;
+        if ((r = alga_ensure(e, e->table, table_bytes))) return r;
         HIP_TRY(e, hipMemsetAsync(e->table.p, 0xFF, table_bytes, s));
-        filter_bits = e->use_filter ? (e->filter_log2 ? (1u << e->filter_log2) : seed_filter_bits_for(pp.live)) : 0;
+        filter_bits = seed_filter_bits_for(pp.live);
         if (filter_bits) {
-            if ((rc = alga_ensure(e, e->filter, filter_bits / 8))) return rc;
+            if ((r = alga_ensure(e, e->filter, filter_bits / 8))) return r;
             HIP_TRY(e, hipMemsetAsync(e->filter.p, 0, filter_bits / 8, s));
         }
         launch_seed_build(nd, cfg, (unsigned long long *) e->table.p, n_buckets, (uint32_t *) e->filter.p, filter_bits, s);
-        if ((rc = alga_check_launch(e, "k_seed_build"))) return rc;
+        if ((r = alga_check_launch(e, "k_seed_build"))) return r;
         e->stats.table_slots = (uint64_t) n_buckets * SEED_BUCKET;
-    } else {
-        // minimizer index: (k-mer, node) pairs ordered by k-mer + a directory of the distinct k-mers
+        have_table = true;
+        return ALGA_OK;
+    };
+    ClusterCfg cc{};
+    if (clustered) {
+        // targets in minimizer-hash order: sort keys, entry array, bucket index
         const uint64_t n = (uint64_t) nd.n;
-        const int kbits = minimizer_key_bits(cfg);
-        const size_t temp = sort_u64_pairs_temp_bytes(n, kbits);
-        if ((rc = alga_ensure(e, e->ix_keys, (n + 1) * sizeof(unsigned long long)))) return rc;
-        if ((rc = alga_ensure(e, e->ix_vals, (n + 1) * sizeof(unsigned long long)))) return rc;
-        if ((rc = alga_ensure(e, e->ix_keys2, (n + 1) * sizeof(unsigned long long)))) return rc;
-        if ((rc = alga_ensure(e, e->ix_vals2, (n + 1) * sizeof(unsigned long long)))) return rc;
+        cc = cluster_cfg(cfg, pp.live, e->opt_cluster_bucket_bias);
+        const size_t temp = cluster_sort_temp_bytes(n);
+        for (int k = 0; k < 2; k++) {
+            if ((rc = alga_ensure(e, e->cl_keys[k], (n + 1) * sizeof(uint32_t)))) return rc;
+            if ((rc = alga_ensure(e, e->cl_vals[k], (n + 1) * sizeof(uint32_t)))) return rc;
+        }
+        if ((rc = alga_ensure(e, e->cl_meta, (n + 1) * sizeof(uint32_t)))) return rc;
+        if ((rc = alga_ensure(e, e->cl_store, (n + 2) * 16 * (size_t) pp.cluster_eq))) return rc;
+        if ((rc = alga_ensure(e, e->cl_idx, ((size_t) cc.n_buckets + 2) * sizeof(uint32_t)))) return rc;
         if ((rc = alga_ensure(e, e->sort_temp, temp))) return rc;
-        launch_index_targets(nd, cfg, (unsigned long long *) e->ix_keys.p, (unsigned long long *) e->ix_vals.p, s);
-        if ((rc = alga_check_launch(e, "k_index_targets"))) return rc;
-        HIP_TRY(e, sort_u64_pairs(e->sort_temp.p, temp, (const unsigned long long *) e->ix_keys.p, (unsigned long long *) e->ix_keys2.p,
-                                  (const unsigned long long *) e->ix_vals.p, (unsigned long long *) e->ix_vals2.p, n, kbits, s));
-        HIP_TRY(e, hipMemsetAsync(cnt, 0, 2 * sizeof(unsigned long long), s));
-        launch_index_count((const unsigned long long *) e->ix_keys2.p, n, cnt, s);
-        if ((rc = alga_check_launch(e, "k_index_count"))) return rc;
-        HIP_TRY(e, hipMemcpyAsync(e->h_counters, cnt, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-        HIP_TRY(e, hipStreamSynchronize(s));
-        dir_slots = index_directory_slots(e->h_counters[0]);
-        if ((rc = alga_ensure(e, e->ix_dir, (size_t) dir_slots * 2 * sizeof(unsigned long long)))) return rc;
-        HIP_TRY(e, hipMemsetAsync(e->ix_dir.p, 0xFF, (size_t) dir_slots * 2 * sizeof(unsigned long long), s));
-        launch_index_directory((const unsigned long long *) e->ix_keys2.p, n, (unsigned long long *) e->ix_dir.p, dir_slots, s);
-        if ((rc = alga_check_launch(e, "k_index_directory"))) return rc;
-        e->stats.table_slots = dir_slots;
-    }
+        HIP_TRY(e, launch_cluster_build(nd, cfg, cc, pp.cluster_eq, (uint32_t *) e->cl_keys[0].p, (uint32_t *) e->cl_vals[0].p, (uint32_t *) e->cl_keys[1].p,
+                                        (uint32_t *) e->cl_vals[1].p, (uint32_t *) e->cl_meta.p, e->sort_temp.p, temp, e->cl_store.p,
+                                        (uint32_t *) e->cl_idx.p, s));
+        e->stats.table_slots = cc.n_buckets;
+    } else if ((rc = build_table())) return rc;
     HIP_TRY(e, hipEventRecord(e->ev[EV_SEED], s));
 
     const uint64_t n_src = (uint64_t) std::max<int64_t>(0, (int64_t) src_end - src_begin);
-    const uint64_t slack = probe_record_slack(e->n_cu, n_src, local);     // invalid padding of the chunked record list
+    const uint64_t slack = std::max(probe_record_slack(e->n_cu, n_src, local), clustered ? cluster_record_slack(e->n_cu, n_src) : 0);   // invalid padding of the chunked record list
     uint64_t &hint = local ? e->rec_cap_hint_local : e->rec_cap_hint;
     uint64_t cap = std::max<uint64_t>(hint, (local ? 2 : 16) * n_src + 4096) + slack;
     if (local) {
@@ -158,13 +166,13 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
         if ((rc = alga_ensure(e, e->rec_val, cap * sizeof(unsigned long long)))) return rc;
         HIP_TRY(e, hipMemsetAsync(cnt, 0, CNT_TOTAL * sizeof(unsigned long long), s));
         ProbeBig big{(int32_t *) e->loc_big_list.p, big_list_cap, 0u, nullptr, 0u};
-        if (e->probe_mode == 0)
+        if (clustered)
+            launch_probe_clustered(nd, cfg, cc, pp.cluster_eq, e->cl_store.p, (const uint32_t *) e->cl_idx.p, src_begin, src_end, (uint32_t *) e->rec_dst.p,
+                                   (unsigned long long *) e->rec_val.p, cap, cnt, e->n_cu, (uint32_t *) e->outdeg.p, (unsigned long long *) e->loc_first.p, &big, s);
+        else
             launch_probe(nd, cfg, (const unsigned long long *) e->table.p, n_buckets, (const uint32_t *) e->filter.p, filter_bits, src_begin, src_end,
                          (uint32_t *) e->rec_dst.p, (unsigned long long *) e->rec_val.p, cap, cnt, e->n_cu, local ? pp.local_sw : 0, (uint32_t *) e->outdeg.p,
                          (unsigned long long *) e->loc_first.p, local ? &big : nullptr, s);
-        else
-            launch_probe_min(nd, cfg, (const unsigned long long *) e->ix_dir.p, dir_slots, (const unsigned long long *) e->ix_vals2.p, src_begin, src_end,
-                             (uint32_t *) e->rec_dst.p, (unsigned long long *) e->rec_val.p, cap, cnt, e->n_cu, s);
         if ((rc = alga_check_launch(e, "k_probe_sources"))) return rc;
         HIP_TRY(e, hipEventRecord(e->ev[EV_PROBE], s));
         HIP_TRY(e, hipMemcpyAsync(e->h_counters, cnt, CNT_TOTAL * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
@@ -180,6 +188,7 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
             big.item_cap = (uint32_t) ((max_items + 63) & ~63ull);
             if ((rc = alga_ensure(e, e->loc_big_items, probe_big_bytes(e->n_cu, big.count, pp.local_sw, big.item_cap)))) return rc;
             big.items = e->loc_big_items.p;
+            if (!have_table && (rc = build_table())) return rc;            // the second pass probes through the seed table
             HIP_TRY(e, hipMemsetAsync(cnt + CNT_LOCAL_OVERFLOW, 0, sizeof(unsigned long long), s));
             launch_probe(nd, cfg, (const unsigned long long *) e->table.p, n_buckets, (const uint32_t *) e->filter.p, filter_bits, src_begin, src_end,
                          (uint32_t *) e->rec_dst.p, (unsigned long long *) e->rec_val.p, cap, cnt, e->n_cu, pp.local_sw, (uint32_t *) e->outdeg.p,
@@ -201,6 +210,7 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
             e->stats.raw_overlaps = e->h_counters[CNT_RAW];
             e->stats.windows_probed = e->h_counters[CNT_WINDOWS];
             e->stats.slots_scanned = e->h_counters[CNT_SLOTS];
+            e->stats.probe_used = clustered ? ALGA_PROBE_CLUSTER : ALGA_PROBE_TABLE;
             return ALGA_OK;
         }
         cap = need + need / 16 + 4096 + slack; // the cursor kept counting past the capacity: the need is known
@@ -348,12 +358,6 @@ int alga_engine_create(int hip_device, alga_engine **out) {
     if (hipSetDevice(hip_device) != hipSuccess) return ALGA_ERR_NO_DEVICE;
     alga_engine *e = new alga_engine();
     e->device = hip_device;
-    if (const char *v = getenv("ALGA_SEED_FILL_X10")) e->seed_fill_x10 = atoi(v);
-    if (const char *v = getenv("ALGA_SEED_FILTER")) e->use_filter = atoi(v);
-    if (const char *v = getenv("ALGA_SEED_FILTER_LOG2")) e->filter_log2 = std::min(30, std::max(16, atoi(v)));
-    if (const char *v = getenv("ALGA_PROBE")) e->probe_mode = strcmp(v, "min") == 0 ? 1 : 0;
-    if (const char *v = getenv("ALGA_REDUCE")) e->force_reduction = strcmp(v, "target") == 0 ? 1 : 0;
-    if (const char *v = getenv("ALGA_LOCAL_BIG_MAX")) e->big_limit = std::max(0, atoi(v));
     memset(&e->stats, 0, sizeof(e->stats));
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, hip_device) == hipSuccess) {
@@ -374,7 +378,7 @@ void alga_engine_destroy(alga_engine *e) {
     if (e->own_stream) (void) hipStreamSynchronize(e->own_stream);
     DevBuf *bufs[] = {&e->table, &e->filter, &e->counters, &e->rowptr, &e->rec_dst, &e->rec_val, &e->keys, &e->seg_key, &e->seg_val, &e->heads, &e->sort_temp,
                       &e->out_cnt, &e->outdeg, &e->out_rowptr, &e->edges, &e->scan_scratch, &e->up_words, &e->up_len, &e->up_from, &e->up_to,
-                      &e->ix_keys, &e->ix_vals, &e->ix_keys2, &e->ix_vals2, &e->ix_dir, &e->loc_first, &e->loc_big_list, &e->loc_big_items, &e->edge_keys, &e->edge_keys2, &e->edge_vals, &e->edge_vals2, &e->edges_sorted, &e->xs_dst, &e->xs_val,
+                      &e->cl_keys[0], &e->cl_keys[1], &e->cl_vals[0], &e->cl_vals[1], &e->cl_meta, &e->cl_store, &e->cl_idx, &e->loc_first, &e->loc_big_list, &e->loc_big_items, &e->edge_keys, &e->edge_keys2, &e->edge_vals, &e->edge_vals2, &e->edges_sorted, &e->xs_dst, &e->xs_val,
                       &e->pk_keys, &e->pk_keys2, &e->pk_vals, &e->pk_vals2, &e->pk_marks, &e->pk_big, &e->pk_add, &e->pk_ekeys, &e->pk_ekeys2,
                       &e->pk_flag, &e->pk_pos, &e->pk_edges[0], &e->pk_edges[1], &e->pk_rowptr, &e->pk_deg, &e->pk_mask, &e->pk_cnt, &e->pk_io, &e->pk_io2, &e->pk_tips, &e->pk_heads, &e->pp_rows, &e->pp_len, &e->pp_perm[0], &e->pp_perm[1], &e->pp_keys[0], &e->pp_keys[1], &e->pp_mark,
                       &e->pp_keep, &e->pp_pos, &e->pp_out_rows, &e->pp_out_len, &e->pp_out_pair, &e->pp_tally};
@@ -390,6 +394,23 @@ const char *alga_last_error(const alga_engine *e) { return e ? e->err.c_str() : 
 int alga_engine_device_name(const alga_engine *e, char *buf, size_t buflen) {
     if (!e || !buf || buflen == 0) return ALGA_ERR_INVALID_ARGUMENT;
     snprintf(buf, buflen, "%s", e->dev_name);
+    return ALGA_OK;
+}
+
+int alga_engine_set_option(alga_engine *e, const char *name, int64_t value) {
+    if (!e || !name) return ALGA_ERR_INVALID_ARGUMENT;
+    e->err.clear();
+    if (!strcmp(name, "probe")) {
+        if (value < ALGA_PROBE_AUTO || value > ALGA_PROBE_CLUSTER) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "option probe: 0 auto, 1 table, 2 cluster");
+        e->opt_probe = (int) value;
+    } else if (!strcmp(name, "cluster_bucket_bias")) {
+        if (value < -8 || value > 8) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "option cluster_bucket_bias: -8 .. 8");
+        e->opt_cluster_bucket_bias = (int) value;
+    } else if (!strcmp(name, "local_big_max")) {
+        e->big_limit = value < 0 ? -1 : (int) std::min<int64_t>(value, 1 << 20);
+    } else if (!strcmp(name, "auto_reduction_per_target")) {
+        e->opt_force_per_target = value != 0;
+    } else return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "unknown option");
     return ALGA_OK;
 }
 

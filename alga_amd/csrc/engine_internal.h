@@ -22,16 +22,17 @@ struct alga_engine {
     std::string err;
     char        dev_name[256] = {0};
     int         n_cu = 256;
-    int         seed_fill_x10 = 20;           // average seed-table bucket fill x10 (tunable: ALGA_SEED_FILL_X10)
-    int         probe_mode = 0;               // 0 = bucketised seed table (default, faster: DESIGN.md section 5), 1 = minimizer index (ALGA_PROBE=min)
-    int         filter_log2 = 0;              // experiments: ALGA_SEED_FILTER_LOG2 forces the prefilter size (0 = automatic)
-    int         use_filter = 1;               // L2-resident fingerprint bitmap in front of the seed table (ALGA_SEED_FILTER=0 disables)
+    int         seed_fill_x10 = 20;           // average seed-table bucket fill x10
+    // alga_engine_set_option (include/alga_amd.h): every switch that changes how (never what) the engine computes
+    int         opt_probe = 0;                // ALGA_PROBE_AUTO / _TABLE / _CLUSTER
+    int         opt_cluster_bucket_bias = 0;  // log2 factor on the bucket count of the clustered probe's index
+    int         opt_force_per_target = 0;     // AUTO reduction resolves to PER_TARGET
     hipEvent_t  ev[EV_COUNT] = {};
     // device buffers, grown on demand and kept between calls
     DevBuf table, filter, counters, rowptr, rec_dst, rec_val, keys, seg_key, seg_val, heads, sort_temp, out_cnt, outdeg, out_rowptr, edges, scan_scratch;
-    DevBuf ix_keys, ix_vals, ix_keys2, ix_vals2, ix_dir;   // minimizer index
+    DevBuf cl_keys[2], cl_vals[2], cl_meta, cl_store, cl_idx;   // clustered minimizer join: sort buffers, entry array, bucket index
     DevBuf loc_first, loc_big_list, loc_big_items;          // source-side form: one-edge slots; second pass over repeat-rich sources
-    int    big_limit = -1;                                  // largest per-wave item slice of that pass; -1 = built-in (ALGA_LOCAL_BIG_MAX overrides: tests)
+    int    big_limit = -1;                                  // largest per-wave item slice of that pass; -1 = built-in (option "local_big_max": tests)
     DevBuf edge_keys, edge_keys2, edge_vals, edge_vals2, edges_sorted, xs_dst, xs_val;
     DevBuf up_words, up_len, up_from, up_to;   // uploads of the host-buffer entry points
     // approximate supplement (engine_pkb.hip)
@@ -41,7 +42,6 @@ struct alga_engine {
     DevBuf pp_rows, pp_len, pp_perm[2], pp_keys[2], pp_mark, pp_keep, pp_pos, pp_out_rows, pp_out_len, pp_out_pair, pp_tally;
     unsigned long long *h_counters = nullptr;  // pinned, CNT_TOTAL + 2 entries
     uint64_t    rec_cap_hint = 0, rec_cap_hint_local = 0;
-    int         force_reduction = 0;          // ALGA_REDUCE=target|source overrides alga_prefsuf_params.reduction == AUTO (experiments)
     alga_prefsuf_stats stats;
     alga_pkb_stats pkb_stats;
 };

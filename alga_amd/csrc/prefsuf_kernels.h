@@ -34,15 +34,22 @@ void launch_local_emit(int32_t src_base, int32_t n_src, const uint32_t *deg, con
                        const unsigned long long *rec_val, uint64_t n_rec, const uint32_t *rowptr, uint32_t *cursor /* zeroed, n_src */,
                        alga_edge_dev *edges, hipStream_t s);
 
-// minimizer index (prefsuf_minimizer.hip)
-int      minimizer_key_bits(const PrefSufCfg &cfg);
-void     launch_index_targets(const NodesDev &nd, const PrefSufCfg &cfg, unsigned long long *keys, unsigned long long *vals, hipStream_t s);
-void     launch_index_count(const unsigned long long *keys, uint64_t n, unsigned long long *out, hipStream_t s);
-uint32_t index_directory_slots(uint64_t distinct);
-void     launch_index_directory(const unsigned long long *keys, uint64_t n, unsigned long long *dir, uint32_t slots, hipStream_t s);
-void     launch_probe_min(const NodesDev &nd, const PrefSufCfg &cfg, const unsigned long long *dir, uint32_t dir_slots, const unsigned long long *list,
-                          int32_t src_begin, int32_t src_end, uint32_t *rec_dst, unsigned long long *rec_val, uint64_t rec_cap,
-                          unsigned long long *counters, int n_cu, hipStream_t s);
+// clustered minimizer join (prefsuf_cluster.hip): source-side form with one-word offset masks (max_len - Lmin <= 63)
+int        cluster_entry_quads(int max_len);              // 16-byte pieces per entry; 0 = rows too long for this probe
+ClusterCfg cluster_cfg(const PrefSufCfg &cfg, uint64_t live, int bucket_log2_bias);
+size_t     cluster_sort_temp_bytes(uint64_t n);
+// keys/vals/keys2/vals2/meta: n uint32 each; store: (n + 1) * 16 * eq bytes; idx: n_buckets + 2 uint32
+hipError_t launch_cluster_build(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterCfg &cc, int eq, uint32_t *keys, uint32_t *vals,
+                                uint32_t *keys2, uint32_t *vals2, uint32_t *meta, void *sort_temp, size_t sort_temp_bytes, void *store,
+                                uint32_t *idx, hipStream_t s);
+uint64_t   cluster_record_slack(int n_cu, uint64_t n_src);
+void       launch_probe_clustered(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterCfg &cc, int eq, const void *store, const uint32_t *idx,
+                                  int32_t src_begin, int32_t src_end, uint32_t *rec_dst, unsigned long long *rec_val, uint64_t rec_cap,
+                                  unsigned long long *counters, int n_cu, uint32_t *deg, unsigned long long *first, const ProbeBig *big, hipStream_t s);
+
+size_t     sort_u32_pairs_temp_bytes(uint64_t n);
+hipError_t sort_u32_pairs(void *temp, size_t temp_bytes, const uint32_t *keys_in, uint32_t *keys_out, const uint32_t *vals_in, uint32_t *vals_out,
+                          uint64_t n, hipStream_t s);
 size_t     sort_u64_pairs_temp_bytes(uint64_t n, int bits);
 hipError_t sort_u64_pairs(void *temp, size_t temp_bytes, const unsigned long long *keys_in, unsigned long long *keys_out,
                           const unsigned long long *vals_in, unsigned long long *vals_out, uint64_t n, int bits, hipStream_t s);

@@ -220,9 +220,6 @@ k_probe_sources(NodesDev nd, PrefSufCfg cfg, const unsigned long long *__restric
                 const int bit = 2 * (lenB - L) - 32 * w0;
                 my_q = bit >> 5; my_r = bit & 31;
                 uint64_t h = fp_init();
-#if defined(ABLATE) && ABLATE == 3
-                h = fp_step(h, (uint32_t) B * 64u + (uint32_t) widx + sb[my_q]);
-#else
                 uint32_t x[SEED_MAX_WORDS + 1];            // all reads in flight before the first use (the tail has slack words)
 #pragma unroll
                 for (int k = 0; k <= SEED_MAX_WORDS; k++) x[k] = sb[my_q + k];
@@ -234,27 +231,15 @@ k_probe_sources(NodesDev nd, PrefSufCfg cfg, const unsigned long long *__restric
                         h = fp_step(h, v);
                     }
                 }
-#endif
                 h = fp_final(h);
                 my_tag = (uint32_t) (h >> 41);
                 my_b = seed_bucket(h, n_buckets);
-#if defined(ABLATE) && ABLATE == 4
-                my_b &= 1023u;                                 // timing only: every probe hits an L2-resident corner of the table
-#endif
                 if (STATS) st_win++;
-#if defined(ABLATE) && ABLATE == 5
-                if (false) {
-#else
                 if (f_left >= 0) {
-#endif
                     const uint32_t fi = seed_filter_index(h, filter_mask);
                     if (!((filter[fi >> 5] >> (fi & 31)) & 1u)) my_tag = 0xFFFFFFFFu;      // no target has this fingerprint
                 }
             }
-#if defined(ABLATE) && ABLATE == 1
-            asm volatile("" :: "v"(my_b), "v"(my_tag));
-            continue;
-#endif
             // ---- phase 1b: the windows that passed the filter are compacted; FOUR lanes read one 64-byte bucket with ONE
             // request (16 buckets per instruction).  A lane-private 4 x 16 B read of a random line costs four requests in
             // the vector memory path.  Candidates are appended with ballot + prefix count (no LDS atomics).
@@ -319,9 +304,6 @@ k_probe_sources(NodesDev nd, PrefSufCfg cfg, const unsigned long long *__restric
             }
             // ---- phase 2: candidates -> exact 2-bit compare of C[0, L) with B[off, off+L) ----------------------------
             wave_lds_fence();
-#if defined(ABLATE) && ABLATE == 2
-            continue;
-#endif
             if (ncand > CANDMAX || NQ == 0) {
                 // NQ == 0: rows are not 16-byte aligned / longer than the wide path takes.  ncand > CANDMAX: more tag hits
                 // than the buffer holds (heavy repeats): the buffered ones are dropped and the whole 64-window batch is

@@ -57,6 +57,20 @@ hipError_t sort_u64_pairs(void *temp, size_t temp_bytes, const unsigned long lon
     return rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t) n, 0u, (unsigned) bits, s);
 }
 
+// stable sort of (u32 key, u32 value) on all 32 key bits: targets by minimizer hash (prefsuf_cluster.hip)
+size_t sort_u32_pairs_temp_bytes(uint64_t n) {
+    size_t bytes = 0;
+    (void) rocprim::radix_sort_pairs(nullptr, bytes, (const uint32_t *) nullptr, (uint32_t *) nullptr, (const uint32_t *) nullptr,
+                                     (uint32_t *) nullptr, (size_t) n, 0u, 32u, (hipStream_t) 0);
+    return bytes;
+}
+
+hipError_t sort_u32_pairs(void *temp, size_t temp_bytes, const uint32_t *keys_in, uint32_t *keys_out, const uint32_t *vals_in, uint32_t *vals_out,
+                          uint64_t n, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    return rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t) n, 0u, 32u, s);
+}
+
 size_t sort_u64_keys_temp_bytes(uint64_t n) {
     size_t bytes = 0;
     (void) rocprim::radix_sort_keys(nullptr, bytes, (const unsigned long long *) nullptr, (unsigned long long *) nullptr, (size_t) n, 0u, 64u,

@@ -41,7 +41,7 @@ class PrefSufStats(C.Structure):
                 ("max_in_records", C.c_uint64), ("ms_total", C.c_double), ("ms_seed", C.c_double),
                 ("ms_probe", C.c_double), ("ms_group", C.c_double), ("ms_reduce", C.c_double), ("ms_emit", C.c_double),
                 ("nodes_live", C.c_uint64), ("reduction_used", C.c_uint64), ("generic_sources", C.c_uint64),
-                ("big_sources", C.c_uint64)]
+                ("big_sources", C.c_uint64), ("probe_used", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
@@ -95,7 +95,9 @@ class PkbStats(C.Structure):
                 ("edges_after", C.c_uint64 * 4), ("max_group", C.c_uint64), ("ms_total", C.c_double)]
 
 
-EXPORTS = ["alga_abi_version", "alga_engine_create", "alga_engine_destroy", "alga_last_error",
+PROBE = {"auto": 0, "table": 1, "cluster": 2}                  # alga_probe
+
+EXPORTS = ["alga_abi_version", "alga_engine_set_option", "alga_engine_create", "alga_engine_destroy", "alga_last_error",
            "alga_engine_device_name", "alga_prefsuf_default_params", "alga_prefsuf_build_host", "alga_free_edges",
            "alga_prefsuf_build_device", "alga_prefsuf_last_stats", "alga_prefsuf_discover_device",
            "alga_prefsuf_reduce_device", "alga_prefsuf_build_range_device", "alga_write_graph", "alga_ingest_default_params", "alga_ingest_files",
@@ -131,6 +133,7 @@ def load_library():
     lib.alga_last_error.argtypes = [C.c_void_p]
     lib.alga_last_error.restype = C.c_char_p
     lib.alga_engine_device_name.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+    lib.alga_engine_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
     lib.alga_prefsuf_default_params.argtypes = [C.POINTER(PrefSufParams)]
     lib.alga_prefsuf_default_params.restype = None
     lib.alga_prefsuf_build_host.argtypes = [C.c_void_p, C.POINTER(_Nodes), C.POINTER(PrefSufParams),
@@ -287,6 +290,13 @@ class Engine:
     def _check(self, rc):
         if rc:
             raise AlgaError(rc, (self._lib.alga_last_error(self._h) or b"").decode())
+
+    def set_option(self, name, value):
+        """alga_engine_set_option: "probe" ("auto" | "table" | "cluster"), "cluster_bucket_bias", "local_big_max",
+        "auto_reduction_per_target"."""
+        if name == "probe" and isinstance(value, str):
+            value = PROBE[value]
+        self._check(self._lib.alga_engine_set_option(self._h, name.encode(), int(value)))
 
     def device_name(self):
         buf = C.create_string_buffer(256)

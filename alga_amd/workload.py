@@ -109,3 +109,66 @@ def write_fasta_fast(path, codes):
     rec[:, H + L] = 10
     with open(path, "wb") as f:
         f.write(rec.tobytes())
+
+
+def device_build(n_reads, read_len, genome_len, seed, device="cuda", trim=3, chunk=1 << 21, sample_reads=0):
+    """The SURVEY.md section 8(d) workload for error-free fixed-length reads, generated ON THE DEVICE (torch is only the array
+    library) straight into the engine's HBM row layout: iid genome, uniform starts, strand flips; one read per start
+    position (on an iid genome two reads are duplicates of each other -- on one strand or the other -- exactly when they
+    start at the same position, which is what the reference's duplicate removal keeps one of: src/IO/ReadPreprocess.cpp:13-77;
+    STR reads and reverse-complement palindromes have probability < 4^-20 per read and are ignored); node ids shuffled so that
+    they carry no positional information, node 2i = reverse complement, 2i+1 = forward (src/IO/InputReader.cpp:78-80).
+    -> dict(words int32[N, 16|stride] (device), lens int32[N] (device), n_reads, unique_reads, min_overlap, rsoemo,
+            sample_codes uint8[sample_reads, read_len] (host): the untrimmed reads of the first `sample_reads` node pairs,
+            for the CPU baseline's FASTA)."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(int(seed))
+    genome = torch.randint(0, 4, (genome_len,), dtype=torch.uint8, device=device, generator=g)
+    starts = torch.randint(0, genome_len - read_len + 1, (n_reads,), device=device, generator=g)
+    flip = torch.rand(n_reads, device=device, generator=g) < 0.5
+    starts, order = torch.sort(starts, stable=True)
+    first = torch.ones_like(starts, dtype=torch.bool)
+    first[1:] = starts[1:] != starts[:-1]
+    starts, flip = starts[first], flip[order][first]
+    del order, first
+    R = int(starts.shape[0])
+    perm = torch.randperm(R, device=device, generator=g)
+    starts, flip = starts[perm], flip[perm]
+    del perm
+    m = read_len - 2 * trim if read_len >= 2 * trim + 10 else read_len
+    t0 = trim if m != read_len else 0
+    W = (2 * m + 31) // 32
+    stride = 4 if W <= 4 else (8 if W <= 8 else (W + 15) & ~15)
+    words = torch.zeros((2 * R, stride), dtype=torch.int32, device=device)
+    pad = W * 16 - m
+    shifts = (2 * torch.arange(16, device=device, dtype=torch.int64))[None, None, :]
+
+    def pack(codes):
+        if pad:
+            codes = torch.cat([codes, torch.zeros((codes.shape[0], pad), dtype=codes.dtype, device=device)], dim=1)
+        x = (codes.view(-1, W, 16).to(torch.int64) << shifts).sum(dim=2)
+        return torch.where(x >= 2 ** 31, x - 2 ** 32, x).to(torch.int32)
+
+    ar = torch.arange(m, device=device)[None, :]
+    for s0 in range(0, R, chunk):
+        st = starts[s0:s0 + chunk]
+        codes = genome[(st[:, None] + t0 + ar)]
+        f = flip[s0:s0 + chunk][:, None]
+        rc = (3 - codes).flip(1)
+        fw = torch.where(f, rc, codes)
+        rv = torch.where(f, codes, rc)
+        words[2 * s0 + 1: 2 * (s0 + st.shape[0]) + 1: 2, :W] = pack(fw)
+        words[2 * s0: 2 * (s0 + st.shape[0]): 2, :W] = pack(rv)
+        del codes, rc, fw, rv
+    lens = torch.full((2 * R,), m, dtype=torch.int32, device=device)
+    lo, rs = derive_params(float(m))
+    out = dict(words=words, lens=lens, n_reads=n_reads, unique_reads=R, read_len=read_len, genome=genome_len, seed=seed,
+               min_overlap=lo, rsoemo=rs, sample_codes=None)
+    if sample_reads:
+        k = min(sample_reads, R)
+        st = starts[:k]
+        codes = genome[(st[:, None] + torch.arange(read_len, device=device)[None, :])]
+        codes = torch.where(flip[:k][:, None], (3 - codes).flip(1), codes)
+        out["sample_codes"] = codes.cpu().numpy()
+    return out

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ALGA_AMD_ABI_VERSION 2
+#define ALGA_AMD_ABI_VERSION 3
 
 typedef enum {
     ALGA_OK = 0,
@@ -50,6 +50,13 @@ typedef enum {
  *                 command line can produce for reads up to ~280 nt after trimming with the default scale.
  *   AUTO        : SOURCE_SIDE when those conditions hold (checked on the device), else PER_TARGET. */
 typedef enum { ALGA_REDUCTION_AUTO = 0, ALGA_REDUCTION_PER_TARGET = 1, ALGA_REDUCTION_SOURCE_SIDE = 2 } alga_reduction;
+
+/* Which probe finds the raw overlaps of the SOURCE_SIDE form (same result either way):
+ *   TABLE   : bucketised seed table, one probe per (source, overlap length) -- fastest while table + reads fit the on-die caches;
+ *   CLUSTER : clustered minimizer join -- targets sorted by the minimizer of their min_overlap-long prefix, ~3 contiguous
+ *             lookups per source; takes max_len - min_overlap <= 63 and reads of up to 208 nt, anything else uses TABLE;
+ *   AUTO    : CLUSTER for node sets past the on-die caches (>= 4 Mi live nodes), else TABLE. */
+typedef enum { ALGA_PROBE_AUTO = 0, ALGA_PROBE_TABLE = 1, ALGA_PROBE_CLUSTER = 2 } alga_probe;
 
 typedef struct alga_engine alga_engine; /* opaque */
 
@@ -101,6 +108,7 @@ typedef struct {
     uint64_t reduction_used;      /* alga_reduction of the last build (1 or 2)                   */
     uint64_t generic_sources;     /* SOURCE_SIDE: sources that needed the all-pairs path (collect_stats) */
     uint64_t big_sources;         /* SOURCE_SIDE: sources with more raw overlaps than a wave's LDS holds (second pass) */
+    uint64_t probe_used;          /* alga_probe of the last build (1 or 2)                       */
 } alga_prefsuf_stats;
 
 /* ---- lifetime --------------------------------------------------------------------------- */
@@ -109,6 +117,14 @@ int         alga_engine_create(int hip_device, alga_engine **out);
 void        alga_engine_destroy(alga_engine *e);
 const char *alga_last_error(const alga_engine *e);      /* valid until the next call on `e`     */
 int         alga_engine_device_name(const alga_engine *e, char *buf, size_t buflen);
+
+/* Engine switches.  None changes a result, only how it is computed; there are no environment variables.
+ *   "probe"                      alga_probe (default AUTO)
+ *   "cluster_bucket_bias"        -8..8: log2 factor on the bucket count of the CLUSTER probe's index (default 0: ~1 entry per bucket)
+ *   "local_big_max"              largest per-wave item slice of the SOURCE_SIDE second pass (default -1 = built-in 4096); beyond it
+ *                                the build takes PER_TARGET
+ *   "auto_reduction_per_target"  != 0: alga_prefsuf_params.reduction == AUTO resolves to PER_TARGET */
+int         alga_engine_set_option(alga_engine *e, const char *name, int64_t value);
 
 void        alga_prefsuf_default_params(alga_prefsuf_params *p);
 

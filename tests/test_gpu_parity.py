@@ -15,7 +15,6 @@ import oracle_lib as O
 from source_side_rule import preconditions
 
 pytestmark = pytest.mark.gpu
-MIN_PROBE = os.environ.get("ALGA_PROBE") == "min"      # experimental probe: per-target form only
 
 
 @pytest.fixture(scope="module")
@@ -40,17 +39,25 @@ def _check(eng, words, lens, lo, rs, af=None, at=None, stats=True, source_side=N
         assert st["transitive_removed"] == cnt["transitive_removed"]
         assert st["edges"] == len(want)
     exact = preconditions(lens, lo, rs, af, at) and int(np.max(lens, initial=0)) - lo <= 127
-    if os.environ.get("ALGA_PROBE") == "min":       # the experimental minimizer probe only feeds the per-target form
-        exact = False
     if source_side is None:
         source_side = exact
     if source_side:
-        got2 = eng.prefsuf_host(words, lens, lo, rs, af, at, collect_stats=stats, reduction="source_side")
-        assert got2.shape == want.shape and (got2 == want).all()
-        st = eng.last_stats()
-        assert st["reduction_used"] == 2 and st["edges"] == len(want)
-        if stats:
-            assert st["raw_overlaps"] == cnt["hash_equal"]
+        # the source-side form through BOTH probes: the bucketised seed table and the clustered minimizer join (which takes
+        # one-word offset masks and rows of up to 13 words, and hands anything else to the table probe)
+        maxlen = int(np.max(lens, initial=0))
+        clusterable = maxlen - lo <= 63 and (2 * maxlen + 31) // 32 <= 13
+        for probe in ("table", "cluster"):
+            eng.set_option("probe", probe)
+            try:
+                got2 = eng.prefsuf_host(words, lens, lo, rs, af, at, collect_stats=stats, reduction="source_side")
+            finally:
+                eng.set_option("probe", "auto")
+            assert got2.shape == want.shape and (got2 == want).all(), probe
+            st = eng.last_stats()
+            assert st["reduction_used"] == 2 and st["edges"] == len(want)
+            assert st["probe_used"] == (2 if probe == "cluster" and clusterable else 1)
+            if stats:
+                assert st["raw_overlaps"] == cnt["hash_equal"], probe
     else:
         with pytest.raises(alga_amd.AlgaError) as ei:
             eng.prefsuf_host(words, lens, lo, rs, af, at, reduction="source_side")
@@ -164,11 +171,8 @@ def test_degenerate_inputs(eng):
     assert eng.last_stats()["big_sources"] > 0
     # beyond the largest item slice the engine allocates for the second pass (4096 per wave; lowered here) the source-side form
     # declines and AUTO falls back to the per-target pipeline
-    os.environ["ALGA_LOCAL_BIG_MAX"] = "200"
-    try:
-        small = alga_amd.Engine(0)
-    finally:
-        del os.environ["ALGA_LOCAL_BIG_MAX"]
+    small = alga_amd.Engine(0)
+    small.set_option("local_big_max", 200)
     try:
         _check(small, w, np.full(len(w), 80, np.int32), 40, 60, source_side=False)
     finally:
@@ -188,7 +192,6 @@ def _tandem_nodes(seed, n_reads, genome_len, length, period):
     return alga_amd.pack_reads(codes), np.full(len(codes), length, np.int32)
 
 
-@pytest.mark.skipif(MIN_PROBE, reason="source-side form needs the bucket probe")
 @pytest.mark.parametrize("seed,n_reads,period", [(41, 700, 5), (42, 2500, 7), (43, 1200, 23)])
 def test_tandem_repeats_same_target_at_several_offsets(eng, seed, n_reads, period):
     words, lens = _tandem_nodes(seed, n_reads, 6000, 60, period)
@@ -197,7 +200,6 @@ def test_tandem_repeats_same_target_at_several_offsets(eng, seed, n_reads, perio
     assert eng.last_stats()["generic_sources"] > 0           # the all-pairs path of the source-side form really ran
 
 
-@pytest.mark.skipif(MIN_PROBE, reason="source-side form needs the bucket probe")
 def test_source_side_range_build_needs_no_exchange(eng):
     import torch
     from alga_amd.engine import device_edges_to_numpy
@@ -354,7 +356,6 @@ def test_exchange_helpers_emulated_ranks(eng):
     assert (be.build().cpu().numpy() == want).all()
 
 
-@pytest.mark.skipif(MIN_PROBE, reason="source-side form needs the bucket probe")
 @pytest.mark.parametrize("lo,rs,replicate", [(90, 120, False), (90, 120, True), (82, 116, False)])
 def test_sharded_driver_with_hip_backend_three_ranks_one_gpu(lo, rs, replicate):
     """alga_amd.multigpu.ShardedPrefSuf exactly as bench.py --gpus N drives it (real HipBackend, device tensors), the

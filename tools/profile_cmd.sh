@@ -1,0 +1,21 @@
+#!/bin/bash
+# Runs on the GPU box (via gpurun): rocprofv3 kernel-trace stats + separate PMC passes of one python tool of this repo.
+# usage: tools/profile_cmd.sh <tag> <passes: t=trace,s=sq,f=fetch,w=write,m=mem> <script> [args...]
+# Outputs under gpurun_out/prof_<tag>/ ; summarise with tools/summarize_prof.py and copy what is to be judged into profiles/.
+set -u
+TAG=$1; PASSES=$2; SCRIPT=$3; shift 3
+REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$REPO/gpurun_out/prof_$TAG
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+run() {  # name, rocprof args...
+  local name=$1; shift
+  rocprofv3 "$@" --output-format csv -d "$OUT/$name" -- python3 "$REPO/$SCRIPT" $ARGS > "$OUT/out_$name.log" 2> "$OUT/$name.err" || { tail -20 "$OUT/$name.err"; exit 1; }
+}
+ARGS="$*"
+case $PASSES in *t*) run trace --kernel-trace --stats ;; esac
+case $PASSES in *s*) run pmc_sq --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU ;; esac
+case $PASSES in *f*) run pmc_fetch --pmc FETCH_SIZE ;; esac
+case $PASSES in *w*) run pmc_write --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum ;; esac
+case $PASSES in *m*) run pmc_mem --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SMEM SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE ;; esac
+python3 "$REPO/tools/summarize_prof.py" "$OUT" > "$OUT/summary.txt"
