@@ -138,14 +138,18 @@ __global__ void __launch_bounds__(256) k_tgt_index(const uint32_t *__restrict__ 
 #endif
 __device__ __forceinline__ uint32_t bperm(uint32_t v, int src_lane) { return (uint32_t) __builtin_amdgcn_ds_bpermute(src_lane << 2, (int) v); }
 
-template <bool STATS, int EQ>
+// Two-stage software pipeline over the sources of a wave: while the entry loads of source i are in flight the wave stages
+// source i+1, computes its window minimizers (six dependent ds_bpermute steps) and issues its index loads; those land while
+// source i is verified and reduced.  State of a source between the stages: its staged row, per-window minimizer positions and
+// run list in LDS (two buffers), four uniform scalars.
+template <bool STATS, int EQ, int KF>
 __global__ void __launch_bounds__(PROBE_WAVES * 64, CL_OCC)
 k_probe_clustered(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__restrict__ store, const uint32_t *__restrict__ idx,
                   int32_t src_begin, int32_t src_end, ProbeOut o) {
     constexpr int WC = 4 * EQ - 3;                         // row words of an entry
-    __shared__ uint32_t sB[PROBE_WAVES][STAGE_WORDS];
-    __shared__ uint32_t sWm[PROBE_WAVES][64];              // minimizer position of window p
-    __shared__ uint4 sRun[PROBE_WAVES][64];                // distinct minimizers of the source: position, hash, first entry, entries
+    __shared__ uint32_t sB[PROBE_WAVES][2][STAGE_WORDS];
+    __shared__ uint32_t sWm[PROBE_WAVES][2][64];           // minimizer position of window p
+    __shared__ uint4 sRun[PROBE_WAVES][2][64];             // distinct minimizers of a source: position, cluster key, first entry, entries
     __shared__ uint32_t sRecC[PROBE_WAVES][WBUF_LOCAL];
     __shared__ unsigned long long sRecV[PROBE_WAVES][WBUF_LOCAL];
     __shared__ uint32_t sCnt[PROBE_WAVES][3];
@@ -153,50 +157,52 @@ k_probe_clustered(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__res
     __shared__ uint32_t sItemM[PROBE_WAVES][ITEMMAX];
     __shared__ uint4 sItemO[PROBE_WAVES][ITEMMAX];
     __shared__ uint8_t sItemT[PROBE_WAVES][64];
-    const int wave = (int) (threadIdx.x >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));      // scalar: the source stream below is wave-uniform
     const int lane = lane_id();
-    WaveLds w{sB[wave], nullptr, nullptr, &sCnt[wave][0], sRecC[wave], sRecV[wave], &sCnt[wave][1]};
+    WaveLds w{sB[wave][0], nullptr, nullptr, &sCnt[wave][0], sRecC[wave], sRecV[wave], &sCnt[wave][1]};
     ItemLds it{sItemC[wave], sItemM[wave], sItemO[wave], sItemT[wave], &sCnt[wave][2]};
     if (lane == 0) { *w.recN = 0; *it.N = 0; }
     uint64_t chunk_base = 0;
     int chunk_fill = REC_CHUNK_LOCAL;                      // "no chunk yet"
     uint64_t st_raw = 0, st_slots = 0, st_win = 0, st_rec = 0, st_cmp = 0, st_generic = 0;
-    const int64_t total_waves = (int64_t) gridDim.x * PROBE_WAVES;
-    const uint32_t *sb = w.sb;
-    uint32_t *wm_lds = sWm[wave];
-    uint4 *run_lds = sRun[wave];
+    const int total_waves = (int) gridDim.x * PROBE_WAVES;
     const int grp = lane >> 4, sl = lane & 15;
-    const int kfull = (2 * cfg.Lmin) >> 5;                 // row words every overlap covers entirely
+    const int kfull = KF ? KF : (2 * cfg.Lmin) >> 5;      // row words every overlap covers entirely
 
+    // ---- source stream (scalar bookkeeping): the row, length and mask of the source after the one being staged are always in
+    //      flight.  Node ids are < 2^31 (alga_nodes.n is an int32).
     const int pre_words = nd.stride < STAGE_WORDS ? nd.stride : STAGE_WORDS;
-    int64_t Bl = (int64_t) src_begin + (int64_t) blockIdx.x * PROBE_WAVES + wave;
-    int n_len = 0; uint32_t n_word = 0; uint8_t n_from = 1;
-    if (Bl < src_end) {
-        n_len = nd.len[Bl];
-        n_word = lane < pre_words ? nd.words[(size_t) Bl * nd.stride + lane] : 0u;
-        if (nd.from) n_from = nd.from[Bl];
-    }
-    while (Bl < src_end) {
-        const int B = (int) Bl;
-        const int lenB = n_len;
-        const uint32_t word0 = n_word;
-        const bool from_ok = n_from != 0;
-        Bl += total_waves;
-        if (Bl < src_end) {                                // software pipeline: the next source's row is on its way
+    int Bl = src_begin + (int) blockIdx.x * PROBE_WAVES + wave;
+    int n_len = 0; uint32_t n_word = 0; int n_from = 1;
+    auto fetch = [&]() {
+        if (Bl < src_end) {                                // uniform
             n_len = nd.len[Bl];
             n_word = lane < pre_words ? nd.words[(size_t) Bl * nd.stride + lane] : 0u;
             if (nd.from) n_from = nd.from[Bl];
         }
-        if (!(lenB >= cfg.Lmin && lenB > 0 && from_ok)) continue;                       // wave-uniform
+    };
+    fetch();
+    // next source that takes part (long enough, alignFrom): uniform
+    auto advance = [&](int &B, int &lenB, uint32_t &word0) -> bool {
+        while (Bl < src_end) {
+            B = Bl; lenB = __builtin_amdgcn_readfirstlane(n_len); word0 = n_word;
+            const bool from_ok = __builtin_amdgcn_readfirstlane(n_from) != 0;
+            Bl = total_waves <= src_end - Bl ? Bl + total_waves : src_end;      // no overflow near 2^31
+            fetch();
+            if (lenB >= cfg.Lmin && lenB > 0 && from_ok) return true;
+        }
+        return false;
+    };
+    // stage 1 of a source: row -> LDS, window minimizers, distinct runs, index loads issued (e0 / e1 are NOT waited for here)
+    auto minimizers = [&](int buf, int lenB, uint32_t word0, int &nrun, bool &start, int &rank, uint32_t &q_out, uint32_t &key_out,
+                          uint32_t &bucket) {
+        uint32_t *sb = sB[wave][buf];
         const int nwB = blocks_of(lenB);
         wave_lds_fence();
-        if (lane < STAGE_WORDS) w.sb[lane] = lane < nwB ? word0 : 0u;
+        if (lane < STAGE_WORDS) sb[lane] = lane < nwB ? word0 : 0u;
         wave_lds_fence();
         const int nwin = lenB - cfg.Lmin + 1;              // overlap lengths Lmin..lenB <-> offsets p = 0..nwin-1 (<= 64)
         const int nk = lenB - cc.kk + 1;                   // k-mers of the source (<= 127)
-        if (STATS && lane == 0) st_win += (uint64_t) nwin;
-
-        // ---- order keys of all k-mers (two per lane), sliding-window minimum over w of them by doubling ----
         uint32_t h0, h1, a0, a1;
         kmer_key(sb, lane, lane < nk, cc, h0, a0);
         kmer_key(sb, lane + 64, lane + 64 < nk, cc, h1, a1);
@@ -215,90 +221,150 @@ k_probe_clustered(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__res
             const uint32_t u = lane + cc.wrest >= 64 ? t1 : t0;
             wm = wm < u ? wm : u;
         }
-        // ---- distinct minimizers: a window starts a run when its minimizer differs from the previous window's ----
+        // distinct minimizers: a window starts a run when its minimizer differs from the previous window's
         const bool wv = lane < nwin;
         const uint32_t prev = bperm(wm, (lane + 63) & 63);
-        const bool start = wv && (lane == 0 || wm != prev);
+        start = wv && (lane == 0 || wm != prev);
         const uint64_t runmask = __ballot(start);
-        const int nrun = __popcll(runmask);
+        nrun = __popcll(runmask);
         const int q = (int) (wm & 255u);                   // k-mer position of window p's minimizer
         const uint32_t g0 = bperm(h0, q & 63), g1 = bperm(h1, q & 63);
-        wm_lds[lane] = wv ? (uint32_t) q : 0xFFFFu;
-        if (start) {
-            const uint32_t hq = cluster_key(q >= 64 ? g1 : g0);
-            const int r = (int) __builtin_amdgcn_mbcnt_hi((uint32_t) (runmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) runmask, 0u));
-            const uint32_t b = hq >> cc.idx_shift;
-            const uint32_t e0 = idx[b], e1 = idx[b + 1];
-            run_lds[r] = make_uint4((uint32_t) q, hq, e0, e1 - e0);
-        }
+        sWm[wave][buf][lane] = wv ? (uint32_t) q : 0xFFFFu;
+        q_out = (uint32_t) q;
+        rank = (int) __builtin_amdgcn_mbcnt_hi((uint32_t) (runmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) runmask, 0u));
+        key_out = cluster_key(q >= 64 ? g1 : g0);
+        bucket = start ? key_out >> cc.idx_shift : 0u;     // lanes that start no run read bucket 0 (one shared line)
+    };
+    // The index loads of stage 1 are issued by EVERY lane and outside any branch: a load under a branch leaves the number of
+    // loads in flight unknown to the compiler, which then drains ALL of them where the entries are first used -- and that
+    // serialises the two stages of the pipeline.
+    auto index_loads = [&](uint32_t bucket, uint32_t &e0, uint32_t &e1) { e0 = idx[bucket]; e1 = idx[bucket + 1]; };
+    auto finish_runs = [&](int buf, bool start, int rank, uint32_t q, uint32_t key, uint32_t e0, uint32_t e1) {
+        if (start) sRun[wave][buf][rank] = make_uint4(q, key, e0, e1 - e0);
         wave_lds_fence();
+    };
+    // runs rb .. rb+3 of a source: 16 lanes each; uniform maximum of their entry counts
+    auto load_runs = [&](int buf, int rb, int nrun, uint4 &rp, uint32_t &mc) {
+        const int r = rb + grp;
+        rp = make_uint4(0u, 0u, 0u, 0u);
+        if (r < nrun) rp = sRun[wave][buf][r];
+        mc = (uint32_t) __builtin_amdgcn_readlane((int) rp.w, 0);
+        const uint32_t c1 = (uint32_t) __builtin_amdgcn_readlane((int) rp.w, 16), c2 = (uint32_t) __builtin_amdgcn_readlane((int) rp.w, 32),
+                       c3 = (uint32_t) __builtin_amdgcn_readlane((int) rp.w, 48);
+        mc = mc > c1 ? mc : c1; mc = mc > c2 ? mc : c2; mc = mc > c3 ? mc : c3;
+    };
+    // one entry per lane: entry k0 + (lane & 15) of the lane group's run
+    auto load_entries = [&](const uint4 &rp, uint32_t k0, bool &ev, size_t &ei, uint32_t (&ew)[4 * EQ]) {
+        const uint32_t j = k0 + (uint32_t) sl;
+        ev = j < rp.w;
+        ei = ev ? (size_t) rp.z + j : (size_t) 0;           // lanes without an entry read entry 0 (unconditional loads: see minimizers)
+#pragma unroll
+        for (int c = 0; c < EQ; c++) { const uint4 v = store[ei * EQ + c]; ew[4 * c] = v.x; ew[4 * c + 1] = v.y; ew[4 * c + 2] = v.z; ew[4 * c + 3] = v.w; }
+    };
 
-        // ---- entries: 16 lanes per minimizer, four minimizers per batch, one entry per lane ----
+    int B = 0, lenB = 0, nrun = 0;
+    uint32_t word0 = 0;
+    bool have = advance(B, lenB, word0);
+    int buf = 0;
+    if (have) {
+        bool start; int rank; uint32_t q, key, bk, e0, e1;
+        minimizers(0, lenB, word0, nrun, start, rank, q, key, bk);
+        index_loads(bk, e0, e1);
+        finish_runs(0, start, rank, q, key, e0, e1);
+    }
+    while (have) {                                         // uniform
+        const uint32_t *sb = sB[wave][buf];
+        const uint32_t *wm_lds = sWm[wave][buf];
+        const int nwin = lenB - cfg.Lmin + 1;
+        if (STATS && lane == 0) st_win += (uint64_t) nwin;
+        // ---- (1) pull the next source off the stream BEFORE any entry load is issued: its loop must not sit between the
+        //          loads and their use (hipcc drains vmcnt at loop headers) ----
+        int nB = 0, nlenB = 0, nnrun = 0, nrank = 0;
+        uint32_t nword0 = 0, nq = 0, nkey = 0, nbk = 0, ne0, ne1;
+        bool nstart = false;
+        const bool have_next = advance(nB, nlenB, nword0);
+        // ---- (2) first batch of this source's entries: loads issued ----
+        int rb = 0;
+        uint32_t k0 = 0, mc;
+        uint4 rp;
+        load_runs(buf, rb, nrun, rp, mc);
+        bool ev; size_t ei; uint32_t ew[4 * EQ];
+        load_entries(rp, k0, ev, ei, ew);
+        // ---- (3) the next source: minimizers, index loads issued behind the entry loads ----
+        if (have_next) minimizers(buf ^ 1, nlenB, nword0, nnrun, nstart, nrank, nq, nkey, nbk);
+        index_loads(nbk, ne0, ne1);
+        // ---- (4) verify: one entry per lane, four runs per batch ----
         int n_items = 0;                                   // verified overlaps of this source so far (uniform)
-        for (int rb = 0; rb < nrun; rb += 4) {
-            const int r = rb + grp;
-            uint4 rp = make_uint4(0u, 0u, 0u, 0u);
-            if (r < nrun) rp = run_lds[r];
-            uint32_t mc = (uint32_t) __builtin_amdgcn_readlane((int) rp.w, 0);
-            { const uint32_t c1 = (uint32_t) __builtin_amdgcn_readlane((int) rp.w, 16), c2 = (uint32_t) __builtin_amdgcn_readlane((int) rp.w, 32),
-                             c3 = (uint32_t) __builtin_amdgcn_readlane((int) rp.w, 48);
-              mc = mc > c1 ? mc : c1; mc = mc > c2 ? mc : c2; mc = mc > c3 ? mc : c3; }
-            for (uint32_t k0 = 0; k0 < mc; k0 += 16) {     // uniform
-                const uint32_t j = k0 + (uint32_t) sl;
-                const bool ev = j < rp.w;
-                const size_t ei = (size_t) rp.z + j;
-                uint32_t ew[4 * EQ];
+        auto verify = [&]() {
+            if (STATS && ev) st_slots++;
+            const uint32_t id = ew[4 * EQ - 3], eh = ew[4 * EQ - 2], meta = ew[4 * EQ - 1];
+            const int lenC = (int) ((meta >> 8) & 0xFFFu);
+            int p = (int) rp.x - (int) (meta & 255u);      // the only offset at which C's prefix can sit in B
+            // same minimizer k-mer, an offset of B, not B itself (GraphCreatorPrefSuf.cpp:386)
+            bool ok = ev && eh == rp.y && p >= 0 && p < nwin && (int) id != B;
+            p = ok ? p : 0;
+            // window p has THIS minimizer; C is long enough for a prefix of length L = |B| - p (:215)
+            ok = ok && wm_lds[p] == rp.x && lenC >= lenB - p;
+            const int L = lenB - p, nb = 2 * L;
+            const int qw = (2 * p) >> 5, sh = (2 * p) & 31;
+            uint32_t y[WC + 1];
 #pragma unroll
-                for (int c = 0; c < 4 * EQ; c++) ew[c] = 0u;
-                if (ev) {
+            for (int k = 0; k <= WC; k++) y[k] = sb[qw + k];
+            uint32_t diff = 0;
 #pragma unroll
-                    for (int c = 0; c < EQ; c++) { const uint4 v = store[ei * EQ + c]; ew[4 * c] = v.x; ew[4 * c + 1] = v.y; ew[4 * c + 2] = v.z; ew[4 * c + 3] = v.w; }
-                    if (STATS) st_slots++;
-                }
-                const uint32_t id = ew[4 * EQ - 3], eh = ew[4 * EQ - 2], meta = ew[4 * EQ - 1];
-                const int lenC = (int) ((meta >> 8) & 0xFFFu);
-                int p = (int) rp.x - (int) (meta & 255u);  // the only offset at which C's prefix can sit in B
-                // same minimizer k-mer, an offset of B, not B itself (GraphCreatorPrefSuf.cpp:386)
-                bool ok = ev && eh == rp.y && p >= 0 && p < nwin && (int) id != B;
-                p = ok ? p : 0;
-                // window p has THIS minimizer; C is long enough for a prefix of length L = |B| - p (:215)
-                ok = ok && wm_lds[p] == rp.x && lenC >= lenB - p;
-                const int L = lenB - p, nb = 2 * L;
-                const int qw = (2 * p) >> 5, sh = (2 * p) & 31;
-                uint32_t y[WC + 1];
+            for (int k = 0; k < WC; k++) {                 // exact compare C[0, L) == B[p, p + L)
+                const uint32_t x = funnel(y[k], y[k + 1], sh) ^ ew[k];
+                if (k < kfull) diff |= x;                  // uniform (compile time with KF)
+                else diff |= x & low_bits32(nb - 32 * k);
+            }
+            const bool pass = ok && diff == 0;
+            const uint64_t pm = __ballot(pass);
+            if (pm != 0ull) {                              // uniform
+                if (pass) {
+                    if (STATS) st_raw++;
+                    const int slot = n_items + (int) __builtin_amdgcn_mbcnt_hi((uint32_t) (pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) pm, 0u));
+                    if (slot < ITEMMAX) {
+                        it.C[slot] = id;
+                        it.M[slot] = (uint32_t) p | ((uint32_t) lenC << 9) | ((meta & CL_META_FROM) ? ITEM_FROM : 0u);
+                        // overhang: what C adds to the right of B's end = C's row from bit 2L on; bits past C's own end are
+                        // never compared (prefsuf_device.h via_ok), so the entry's trailing words may stand in for zeros
+                        const int ws = nb >> 5, r2 = nb & 31;
+                        uint32_t x[5];
+                        if constexpr (KF > 0 && WC - KF <= 6) {
+                            // word ws + k of the entry for ws in [KF, WC]: a select over registers
+                            const int t = ws - KF;
 #pragma unroll
-                for (int k = 0; k <= WC; k++) y[k] = sb[qw + k];
-                uint32_t diff = 0;
+                            for (int k = 0; k < 5; k++) {
+                                uint32_t v = 0u;
 #pragma unroll
-                for (int k = 0; k < WC; k++) {             // exact compare C[0, L) == B[p, p + L)
-                    const uint32_t x = funnel(y[k], y[k + 1], sh) ^ ew[k];
-                    if (k < kfull) diff |= x;              // uniform
-                    else diff |= x & low_bits32(nb - 32 * k);
-                }
-                const bool pass = ok && diff == 0;
-                const uint64_t pm = __ballot(pass);
-                if (pm != 0ull) {                          // uniform
-                    if (pass) {
-                        if (STATS) st_raw++;
-                        const int slot = n_items + (int) __builtin_amdgcn_mbcnt_hi((uint32_t) (pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) pm, 0u));
-                        if (slot < ITEMMAX) {
-                            it.C[slot] = id;
-                            it.M[slot] = (uint32_t) p | ((uint32_t) lenC << 9) | ((meta & CL_META_FROM) ? ITEM_FROM : 0u);
-                            // overhang: what C adds to the right of B's end = C's row from bit 2L on (bits past C's own end
-                            // are never compared: prefsuf_device.h via_ok); re-read from the entry (an L1 hit)
-                            const uint32_t *er = reinterpret_cast<const uint32_t *>(store + ei * EQ);
-                            const int ws = nb >> 5, r2 = nb & 31;
-                            uint32_t x[5];
+                                for (int u = 0; u <= WC - KF; u++) { const int wi = KF + k + u; if (wi < 4 * EQ) v = t == u ? ew[wi] : v; }
+                                x[k] = v;
+                            }
+                        } else {
+                            const uint32_t *er = reinterpret_cast<const uint32_t *>(store + ei * EQ);      // re-read (an L1 hit)
 #pragma unroll
                             for (int k = 0; k < 5; k++) x[k] = er[ws + k];
-                            it.O[slot] = make_uint4(funnel(x[0], x[1], r2), funnel(x[1], x[2], r2), funnel(x[2], x[3], r2), funnel(x[3], x[4], r2));
                         }
+                        it.O[slot] = make_uint4(funnel(x[0], x[1], r2), funnel(x[1], x[2], r2), funnel(x[2], x[3], r2), funnel(x[3], x[4], r2));
                     }
-                    n_items += __popcll(pm);
                 }
+                n_items += __popcll(pm);
             }
+        };
+        verify();                                          // the first batch, peeled: its wait covers the entry loads only
+        for (;;) {                                         // further batches: more than 16 entries in a run, more than four runs
+            k0 += 16;
+            if (k0 >= mc) {                                // uniform
+                rb += 4;
+                if (rb >= nrun) break;
+                k0 = 0;
+                load_runs(buf, rb, nrun, rp, mc);
+            }
+            load_entries(rp, k0, ev, ei, ew);
+            verify();
         }
         wave_lds_fence();
+        // ---- (5) transitive reduction at the source, edges out ----
         if (n_items > ITEMMAX) {
             // the source goes on the list of the second pass (k_probe_sources, BIG instantiation); a full list: per-target pipeline
             if (lane == 0) {
@@ -312,6 +378,9 @@ k_probe_clustered(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__res
         }
         const int nb2 = (int) __builtin_amdgcn_readfirstlane((int) *w.recN);
         if (nb2 >= WFLUSH_LOCAL) flush_records<REC_CHUNK_LOCAL, WBUF_LOCAL>(o, w, chunk_base, chunk_fill);
+        // ---- (6) the next source's index loads have had the time of (4) and (5) to land ----
+        if (have_next) finish_runs(buf ^ 1, nstart, nrank, nq, nkey, ne0, ne1);
+        have = have_next; B = nB; lenB = nlenB; nrun = nnrun; buf ^= 1;
     }
     flush_records<REC_CHUNK_LOCAL, WBUF_LOCAL>(o, w, chunk_base, chunk_fill);
     close_chunk<REC_CHUNK_LOCAL>(o, chunk_base, chunk_fill);
@@ -391,9 +460,18 @@ void launch_probe_clustered(const NodesDev &nd, const PrefSufCfg &cfg, const Clu
     ProbeOut o{rec_dst, rec_val, rec_cap, counters, deg, first, src_begin};
     if (big) { o.big_list = big->list; o.big_list_cap = big->list_cap; }
     const uint4 *st = (const uint4 *) store;
-#define CL_LAUNCH(ST, E) hipLaunchKernelGGL((k_probe_clustered<ST, E>), grid, block, 0, s, nd, cfg, cc, st, idx, src_begin, src_end, o)
-    if (cfg.stats) { if (eq == 2) CL_LAUNCH(true, 2); else if (eq == 3) CL_LAUNCH(true, 3); else CL_LAUNCH(true, 4); }
-    else           { if (eq == 2) CL_LAUNCH(false, 2); else if (eq == 3) CL_LAUNCH(false, 3); else CL_LAUNCH(false, 4); }
+    // KF = (2 * Lmin) >> 5 as a compile-time constant for the shapes ALGA's defaults produce (150-bp reads: Lmin 82, rows of 9
+    // words; 100-bp reads: Lmin 55, rows of 6 words); 0 = any shape
+    const int kf = (2 * cfg.Lmin) >> 5;
+#define CL_LAUNCH(ST, E, K) hipLaunchKernelGGL((k_probe_clustered<ST, E, K>), grid, block, 0, s, nd, cfg, cc, st, idx, src_begin, src_end, o)
+#define CL_STATS(E, K) do { if (cfg.stats) CL_LAUNCH(true, E, K); else CL_LAUNCH(false, E, K); } while (0)
+    if (eq == 3 && kf == 5)      CL_STATS(3, 5);
+    else if (eq == 3 && kf == 3) CL_STATS(3, 3);
+    else if (eq == 2 && kf == 3) CL_STATS(2, 3);
+    else if (eq == 2)            CL_STATS(2, 0);
+    else if (eq == 3)            CL_STATS(3, 0);
+    else                         CL_STATS(4, 0);
+#undef CL_STATS
 #undef CL_LAUNCH
 }
 
