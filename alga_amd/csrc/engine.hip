@@ -34,6 +34,7 @@ struct Prepared {
     bool       local_ok = false;     // the source-side reduction is exact for this input
     int        local_sw = 1;         // ... with one or two 64-bit words per offset mask / uint4 per overhang
     int        cluster_eq = 0;       // clustered minimizer probe: 16-byte pieces per entry (0 = that probe does not take this input)
+    ClusterCfg cluster{};
     int        reduction = ALGA_REDUCTION_AUTO;
 };
 
@@ -89,9 +90,11 @@ int prepare(alga_engine *e, const alga_nodes *nodes, const alga_prefsuf_params *
     // Which probe feeds the source-side form.  The clustered minimizer join (prefsuf_cluster.hip) takes one-word offset masks and
     // rows of up to 13 words; AUTO uses it once the node set has outgrown the on-die caches (the seed-table probe is faster while
     // table + rows stay in the 256 MB Infinity Cache: measured cross-over in DESIGN.md section 5c).
-    out.cluster_eq = (out.local_ok && out.local_sw == 1) ? cluster_entry_quads(out.max_len) : 0;
-    if (e->opt_probe == ALGA_PROBE_TABLE) out.cluster_eq = 0;
-    if (e->opt_probe == ALGA_PROBE_AUTO && out.live < CLUSTER_AUTO_MIN_NODES) out.cluster_eq = 0;
+    out.cluster_eq = 0;
+    if (out.local_ok && out.local_sw == 1 && e->opt_probe != ALGA_PROBE_TABLE && !(e->opt_probe == ALGA_PROBE_AUTO && out.live < CLUSTER_AUTO_MIN_NODES)) {
+        int eq = 0;
+        if (cluster_plan(c, out.max_len, out.live, e->opt_cluster_bucket_bias, &out.cluster, &eq)) out.cluster_eq = eq;
+    }
     out.reduction = p->reduction;
     if (out.reduction == ALGA_REDUCTION_AUTO && e->opt_force_per_target) out.reduction = ALGA_REDUCTION_PER_TARGET;
     return ALGA_OK;
@@ -132,18 +135,20 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
     if (clustered) {
         // targets in minimizer-hash order: sort keys, entry array, bucket index
         const uint64_t n = (uint64_t) nd.n;
-        cc = cluster_cfg(cfg, pp.live, e->opt_cluster_bucket_bias);
+        cc = pp.cluster;
         const size_t temp = cluster_sort_temp_bytes(n);
         for (int k = 0; k < 2; k++) {
             if ((rc = alga_ensure(e, e->cl_keys[k], (n + 1) * sizeof(uint32_t)))) return rc;
             if ((rc = alga_ensure(e, e->cl_vals[k], (n + 1) * sizeof(uint32_t)))) return rc;
         }
         if ((rc = alga_ensure(e, e->cl_meta, (n + 1) * sizeof(uint32_t)))) return rc;
+        if ((rc = alga_ensure(e, e->cl_runs, (n + 1) * CL_RMAX * 8))) return rc;
+        if ((rc = alga_ensure(e, e->cl_nruns, n + 16))) return rc;
         if ((rc = alga_ensure(e, e->cl_store, (n + 2) * 16 * (size_t) pp.cluster_eq))) return rc;
         if ((rc = alga_ensure(e, e->cl_idx, ((size_t) cc.n_buckets + 2) * sizeof(uint32_t)))) return rc;
         if ((rc = alga_ensure(e, e->sort_temp, temp))) return rc;
         HIP_TRY(e, launch_cluster_build(nd, cfg, cc, pp.cluster_eq, (uint32_t *) e->cl_keys[0].p, (uint32_t *) e->cl_vals[0].p, (uint32_t *) e->cl_keys[1].p,
-                                        (uint32_t *) e->cl_vals[1].p, (uint32_t *) e->cl_meta.p, e->sort_temp.p, temp, e->cl_store.p,
+                                        (uint32_t *) e->cl_vals[1].p, (uint32_t *) e->cl_meta.p, e->cl_runs.p, (uint8_t *) e->cl_nruns.p, e->sort_temp.p, temp, e->cl_store.p,
                                         (uint32_t *) e->cl_idx.p, s));
         e->stats.table_slots = cc.n_buckets;
     } else if ((rc = build_table())) return rc;
@@ -157,7 +162,7 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
         if ((rc = alga_ensure(e, e->outdeg, (size_t) (n_src + 1) * sizeof(uint32_t)))) return rc;
         if ((rc = alga_ensure(e, e->loc_first, (size_t) (n_src + 1) * sizeof(unsigned long long)))) return rc;
     }
-    const uint32_t big_list_cap = 1u << 16;
+    const uint32_t big_list_cap = 1u << 20;
     if (local && (rc = alga_ensure(e, e->loc_big_list, big_list_cap * sizeof(int32_t)))) return rc;
     for (int attempt = 0; attempt < 4; attempt++) {
         if (cap >= (1ull << 32) - 16) return alga_fail(e, ALGA_ERR_CAPACITY, "more than 2^32 overlap records; shard the input");
@@ -167,7 +172,7 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
         HIP_TRY(e, hipMemsetAsync(cnt, 0, CNT_TOTAL * sizeof(unsigned long long), s));
         ProbeBig big{(int32_t *) e->loc_big_list.p, big_list_cap, 0u, nullptr, 0u};
         if (clustered)
-            launch_probe_clustered(nd, cfg, cc, pp.cluster_eq, e->cl_store.p, (const uint32_t *) e->cl_idx.p, src_begin, src_end, (uint32_t *) e->rec_dst.p,
+            launch_probe_clustered(nd, cfg, cc, pp.cluster_eq, e->cl_store.p, (const uint32_t *) e->cl_idx.p, e->cl_runs.p, (const uint8_t *) e->cl_nruns.p, src_begin, src_end, (uint32_t *) e->rec_dst.p,
                                    (unsigned long long *) e->rec_val.p, cap, cnt, e->n_cu, (uint32_t *) e->outdeg.p, (unsigned long long *) e->loc_first.p, &big, s);
         else
             launch_probe(nd, cfg, (const unsigned long long *) e->table.p, n_buckets, (const uint32_t *) e->filter.p, filter_bits, src_begin, src_end,
@@ -378,7 +383,7 @@ void alga_engine_destroy(alga_engine *e) {
     if (e->own_stream) (void) hipStreamSynchronize(e->own_stream);
     DevBuf *bufs[] = {&e->table, &e->filter, &e->counters, &e->rowptr, &e->rec_dst, &e->rec_val, &e->keys, &e->seg_key, &e->seg_val, &e->heads, &e->sort_temp,
                       &e->out_cnt, &e->outdeg, &e->out_rowptr, &e->edges, &e->scan_scratch, &e->up_words, &e->up_len, &e->up_from, &e->up_to,
-                      &e->cl_keys[0], &e->cl_keys[1], &e->cl_vals[0], &e->cl_vals[1], &e->cl_meta, &e->cl_store, &e->cl_idx, &e->loc_first, &e->loc_big_list, &e->loc_big_items, &e->edge_keys, &e->edge_keys2, &e->edge_vals, &e->edge_vals2, &e->edges_sorted, &e->xs_dst, &e->xs_val,
+                      &e->cl_keys[0], &e->cl_keys[1], &e->cl_vals[0], &e->cl_vals[1], &e->cl_meta, &e->cl_runs, &e->cl_nruns, &e->cl_store, &e->cl_idx, &e->loc_first, &e->loc_big_list, &e->loc_big_items, &e->edge_keys, &e->edge_keys2, &e->edge_vals, &e->edge_vals2, &e->edges_sorted, &e->xs_dst, &e->xs_val,
                       &e->pk_keys, &e->pk_keys2, &e->pk_vals, &e->pk_vals2, &e->pk_marks, &e->pk_big, &e->pk_add, &e->pk_ekeys, &e->pk_ekeys2,
                       &e->pk_flag, &e->pk_pos, &e->pk_edges[0], &e->pk_edges[1], &e->pk_rowptr, &e->pk_deg, &e->pk_mask, &e->pk_cnt, &e->pk_io, &e->pk_io2, &e->pk_tips, &e->pk_heads, &e->pp_rows, &e->pp_len, &e->pp_perm[0], &e->pp_perm[1], &e->pp_keys[0], &e->pp_keys[1], &e->pp_mark,
                       &e->pp_keep, &e->pp_pos, &e->pp_out_rows, &e->pp_out_len, &e->pp_out_pair, &e->pp_tally};

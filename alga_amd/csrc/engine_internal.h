@@ -30,7 +30,7 @@ struct alga_engine {
     hipEvent_t  ev[EV_COUNT] = {};
     // device buffers, grown on demand and kept between calls
     DevBuf table, filter, counters, rowptr, rec_dst, rec_val, keys, seg_key, seg_val, heads, sort_temp, out_cnt, outdeg, out_rowptr, edges, scan_scratch;
-    DevBuf cl_keys[2], cl_vals[2], cl_meta, cl_store, cl_idx;   // clustered minimizer join: sort buffers, entry array, bucket index
+    DevBuf cl_keys[2], cl_vals[2], cl_meta, cl_runs, cl_nruns, cl_store, cl_idx;   // clustered minimizer join: sort buffers, per-node minimizer runs, entry array, bucket index
     DevBuf loc_first, loc_big_list, loc_big_items;          // source-side form: one-edge slots; second pass over repeat-rich sources
     int    big_limit = -1;                                  // largest per-wave item slice of that pass; -1 = built-in (option "local_big_max": tests)
     DevBuf edge_keys, edge_keys2, edge_vals, edge_vals2, edges_sorted, xs_dst, xs_val;

@@ -60,17 +60,30 @@ __device__ __forceinline__ void kmer_key(const uint32_t *row, int i, bool valid,
 }
 
 // ------------------------------------------------------------------------------------------
-// build: keys, gather, index
+// build: minimizer runs of every node, keys, gather, index
 // ------------------------------------------------------------------------------------------
-constexpr int TK_ROWS = 256;         // targets per workgroup of k_tgt_keys
-constexpr int TK_WORDS = 16;         // row words staged per target (Lmin <= 208: the prefix window ends inside word 13)
+constexpr int TK_ROWS = 256;         // nodes per workgroup of k_node_runs
+constexpr int TK_WORDS = 16;         // row words staged per node (reads of up to 208 nt: 13 words + the k-mer reads' slack)
 constexpr int TK_STRIDE = TK_WORDS + 1;
+constexpr int NR_STACK = 16;         // prefix-minimum records kept per node (a random window has ~4.7; more: the node is flagged)
 
-// one thread per node: keys[i] = cluster key of the minimizer of C[0, Lmin) (all ones: not a target), vals[i] = i,
-// meta[i] = m_C | len << 8 | alignFrom << 20.  Rows are staged through LDS (coalesced 64-byte pieces in, conflict-free out).
-__global__ void __launch_bounds__(TK_ROWS) k_tgt_keys(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, uint32_t *__restrict__ keys,
-                                                       uint32_t *__restrict__ vals, uint32_t *__restrict__ meta) {
+// One THREAD per node (full lane use; the same sliding-window minimum inside the probing wave costs ~100 wave instructions per
+// source at a quarter of the lanes): the distinct minimizers of the suffix windows p = 0 .. len - Lmin of the node, as runs
+// {cluster key, k-mer position q, windows [p0, p1)}; run 0's minimizer is the minimizer of the node's min_overlap-long prefix,
+// i.e. the key the node is filed under as a TARGET.
+//   Window p covers k-mers [p, p + w).  Block 0 = k-mers [0, w), block 1 = [w, nk).  min(window p) = min(suffix minimum of
+//   block 0 from p, prefix minimum of block 1 up to p + w - 1).  Forward scan of block 1 pushes its prefix-minimum records on
+//   a per-thread stack; the backward sweep over block 0 keeps the running suffix minimum, pops the records that lie beyond the
+//   window and emits a run whenever the winner changes.  All loops have uniform trip counts; order keys include the position,
+//   so ties go to the left on both the source and the target side.
+// keys[i] = cluster key of run 0 (all ones: not a target), vals[i] = i, meta[i] = m_C | len << 8 | alignFrom << 20,
+// runs[i * CL_RMAX + k] = {key, q | p0 << 8 | p1 << 16}, nruns[i] = number of runs (0: not a source; CL_RUNS_FLAGGED: more than
+// CL_RMAX runs or records than the stack holds -- the probe hands such a source to the seed-table second pass).
+__global__ void __launch_bounds__(TK_ROWS) k_node_runs(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, uint32_t *__restrict__ keys,
+                                                        uint32_t *__restrict__ vals, uint32_t *__restrict__ meta, uint2 *__restrict__ runs,
+                                                        uint8_t *__restrict__ nruns) {
     __shared__ uint32_t s[TK_ROWS][TK_STRIDE];
+    __shared__ uint32_t stk[NR_STACK][TK_ROWS];            // transposed: conflict-free
     const int base = blockIdx.x * TK_ROWS;
     const int nrows = min(TK_ROWS, nd.n - base);
     {
@@ -80,21 +93,65 @@ __global__ void __launch_bounds__(TK_ROWS) k_tgt_keys(NodesDev nd, PrefSufCfg cf
     }
     __syncthreads();
     const int t = (int) threadIdx.x;
-    if (t >= nrows) return;
-    const int i = base + t;
-    const int len = nd.len[i];
-    uint32_t key = 0xFFFFFFFFu, m = 0u;
-    if (len >= cfg.Lmin && len > 0 && (!nd.to || nd.to[i])) {
-        uint32_t best = 0xFFFFFFFFu, besth = 0u;
-        for (int j = 0; j < cc.w; j++) {
-            uint32_t h, pk;
-            kmer_key(s[t], j, true, cc, h, pk);
-            if (pk < best) { best = pk; besth = h; }
-        }
-        key = cluster_key(besth);
-        m = (best & 255u) | ((uint32_t) len << 8) | ((!nd.from || nd.from[i]) ? CL_META_FROM : 0u);
+    const bool in = t < nrows;
+    const int i = base + (in ? t : 0);
+    const int len = in ? nd.len[i] : 0;
+    const bool act = in && len >= cfg.Lmin && len > 0;
+    const bool is_tgt = act && (!nd.to || nd.to[i]);
+    const bool is_src = act && (!nd.from || nd.from[i]);
+    const uint32_t *row = s[in ? t : 0];
+    const int w = cc.w;
+    const int nwin = len - cfg.Lmin + 1;                   // <= 64 (one-word form of the source-side reduction)
+    const int nk = len - cc.kk + 1;                        // = nwin - 1 + w
+    // ---- block 1, left to right: prefix-minimum records ----
+    uint32_t cur1 = 0xFFFFFFFFu;
+    int sp = 0;
+    for (int k = w; k < 2 * w - 1; k++) {                  // uniform (nk <= 2w - 1: cluster_plan keeps nwin <= w)
+        uint32_t h, pk;
+        kmer_key(row, k, true, cc, h, pk);
+        if (act && k < nk && pk < cur1) { cur1 = pk; if (sp < NR_STACK) stk[sp][t] = pk; sp++; }
     }
-    keys[i] = key; vals[i] = (uint32_t) i; meta[i] = m;
+    const bool stack_ovf = sp > NR_STACK;
+    if (stack_ovf) sp = NR_STACK;
+    uint32_t top = sp > 0 ? stk[sp - 1][t] : 0xFFFFFFFFu;
+    // ---- block 0, right to left: suffix minimum, winner per window, runs ----
+    uint32_t cur0 = 0xFFFFFFFFu, prev_win = 0xFFFFFFFFu;
+    int p_hi = 0, nr = 0;
+    auto emit = [&](uint32_t winpk, int p0, int p1) {
+        uint32_t h, pk;
+        const int q = (int) (winpk & 255u);
+        kmer_key(row, q, true, cc, h, pk);
+        const uint32_t key = cluster_key(h);
+        if (is_src && nr < CL_RMAX) runs[(size_t) i * CL_RMAX + nr] = make_uint2(key, (uint32_t) q | ((uint32_t) p0 << 8) | ((uint32_t) p1 << 16));
+        nr++;
+        return key;
+    };
+    for (int k = w - 1; k >= 0; k--) {                     // uniform
+        uint32_t h, pk;
+        kmer_key(row, k, true, cc, h, pk);
+        if (act) {
+            cur0 = pk < cur0 ? pk : cur0;
+            if (k < nwin) {
+                const int j = k + w - 1;                   // last k-mer of window k
+                if (sp > 0 && (int) (top & 255u) > j) { sp--; top = sp > 0 ? stk[sp - 1][t] : 0xFFFFFFFFu; }     // at most one record leaves per step
+                const uint32_t win = (sp > 0 && top < cur0) ? top : cur0;
+                if (k == nwin - 1) { prev_win = win; p_hi = k; }
+                else if (win != prev_win) { emit(prev_win, k + 1, p_hi + 1); prev_win = win; p_hi = k; }
+            }
+        }
+    }
+    uint32_t key = 0xFFFFFFFFu, m = 0u;
+    if (act) {
+        const uint32_t k0 = emit(prev_win, 0, p_hi + 1);   // the run of window 0: the prefix minimizer
+        if (is_tgt) {
+            key = k0;
+            m = (prev_win & 255u) | ((uint32_t) len << 8) | (is_src ? CL_META_FROM : 0u);
+        }
+    }
+    if (in) {
+        keys[i] = key; vals[i] = (uint32_t) i; meta[i] = m;
+        nruns[i] = (uint8_t) (!is_src ? 0 : ((nr > CL_RMAX || stack_ovf) ? CL_RUNS_FLAGGED : nr));
+    }
 }
 
 // entry j (hash order) = {row words 0 .. 4*EQ-4, node id, hash, meta}; one thread per 16-byte piece
@@ -134,22 +191,20 @@ __global__ void __launch_bounds__(256) k_tgt_index(const uint32_t *__restrict__ 
 // k_probe_clustered
 // ------------------------------------------------------------------------------------------
 #ifndef CL_OCC
-#define CL_OCC 4
+#define CL_OCC 6                      // workgroups per CU of the persistent grid: 24 waves per CU (VGPR <= 80, LDS <= 26 KB, SGPR <= 112)
 #endif
 __device__ __forceinline__ uint32_t bperm(uint32_t v, int src_lane) { return (uint32_t) __builtin_amdgcn_ds_bpermute(src_lane << 2, (int) v); }
 
-// Two-stage software pipeline over the sources of a wave: while the entry loads of source i are in flight the wave stages
-// source i+1, computes its window minimizers (six dependent ds_bpermute steps) and issues its index loads; those land while
-// source i is verified and reduced.  State of a source between the stages: its staged row, per-window minimizer positions and
-// run list in LDS (two buffers), four uniform scalars.
+// Two-stage software pipeline over the sources of a wave: while the entry loads of source i are in flight the wave stages the
+// row of source i+1 and issues the index loads of its runs; those land while source i is verified and reduced.  State of a
+// source between the stages: its staged row and its resolved run list in LDS (two buffers), a few uniform scalars.
 template <bool STATS, int EQ, int KF>
 __global__ void __launch_bounds__(PROBE_WAVES * 64, CL_OCC)
 k_probe_clustered(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__restrict__ store, const uint32_t *__restrict__ idx,
-                  int32_t src_begin, int32_t src_end, ProbeOut o) {
+                  const uint2 *__restrict__ runs, const uint8_t *__restrict__ nruns, int32_t src_begin, int32_t src_end, ProbeOut o) {
     constexpr int WC = 4 * EQ - 3;                         // row words of an entry
     __shared__ uint32_t sB[PROBE_WAVES][2][STAGE_WORDS];
-    __shared__ uint32_t sWm[PROBE_WAVES][2][64];           // minimizer position of window p
-    __shared__ uint4 sRun[PROBE_WAVES][2][64];             // distinct minimizers of a source: position, cluster key, first entry, entries
+    __shared__ uint4 sRun[PROBE_WAVES][2][CL_RMAX];        // runs of a source: q | p0 << 8 | p1 << 16, cluster key, first entry, entries
     __shared__ uint32_t sRecC[PROBE_WAVES][WBUF_LOCAL];
     __shared__ unsigned long long sRecV[PROBE_WAVES][WBUF_LOCAL];
     __shared__ uint32_t sCnt[PROBE_WAVES][3];
@@ -157,164 +212,136 @@ k_probe_clustered(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__res
     __shared__ uint32_t sItemM[PROBE_WAVES][ITEMMAX];
     __shared__ uint4 sItemO[PROBE_WAVES][ITEMMAX];
     __shared__ uint8_t sItemT[PROBE_WAVES][64];
+    __shared__ uint4 sMask[KF > 0 ? 129 : 1];              // sMask[t] = masks of four consecutive words whose first holds t valid bits
     const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));      // scalar: the source stream below is wave-uniform
     const int lane = lane_id();
     WaveLds w{sB[wave][0], nullptr, nullptr, &sCnt[wave][0], sRecC[wave], sRecV[wave], &sCnt[wave][1]};
     ItemLds it{sItemC[wave], sItemM[wave], sItemO[wave], sItemT[wave], &sCnt[wave][2]};
     if (lane == 0) { *w.recN = 0; *it.N = 0; }
+    if constexpr (KF > 0) {
+        for (int t = (int) threadIdx.x; t <= 128; t += PROBE_WAVES * 64)
+            sMask[t] = make_uint4(low_bits32(t), low_bits32(t - 32), low_bits32(t - 64), low_bits32(t - 96));
+        __syncthreads();
+    }
     uint64_t chunk_base = 0;
     int chunk_fill = REC_CHUNK_LOCAL;                      // "no chunk yet"
     uint64_t st_raw = 0, st_slots = 0, st_win = 0, st_rec = 0, st_cmp = 0, st_generic = 0;
     const int total_waves = (int) gridDim.x * PROBE_WAVES;
-    const int grp = lane >> 4, sl = lane & 15;
     const int kfull = KF ? KF : (2 * cfg.Lmin) >> 5;      // row words every overlap covers entirely
 
-    // ---- source stream (scalar bookkeeping): the row, length and mask of the source after the one being staged are always in
-    //      flight.  Node ids are < 2^31 (alga_nodes.n is an int32).
+    // ---- source stream (scalar bookkeeping): row, length, run descriptors of the source after the one being staged are always
+    //      in flight.  Node ids are < 2^31 (alga_nodes.n is an int32).
     const int pre_words = nd.stride < STAGE_WORDS ? nd.stride : STAGE_WORDS;
     int Bl = src_begin + (int) blockIdx.x * PROBE_WAVES + wave;
-    int n_len = 0; uint32_t n_word = 0; int n_from = 1;
+    int n_len = 0, n_nr = 0; uint32_t n_word = 0; uint2 n_run = make_uint2(0u, 0u);
     auto fetch = [&]() {
         if (Bl < src_end) {                                // uniform
             n_len = nd.len[Bl];
+            n_nr = nruns[Bl];
             n_word = lane < pre_words ? nd.words[(size_t) Bl * nd.stride + lane] : 0u;
-            if (nd.from) n_from = nd.from[Bl];
+            if (lane < CL_RMAX) n_run = runs[(size_t) Bl * CL_RMAX + lane];
         }
     };
     fetch();
-    // next source that takes part (long enough, alignFrom): uniform
-    auto advance = [&](int &B, int &lenB, uint32_t &word0) -> bool {
+    // next source that takes part (nruns != 0: long enough, alignFrom): uniform
+    auto advance = [&](int &B, int &lenB, int &nr, uint32_t &word0, uint2 &run) -> bool {
         while (Bl < src_end) {
-            B = Bl; lenB = __builtin_amdgcn_readfirstlane(n_len); word0 = n_word;
-            const bool from_ok = __builtin_amdgcn_readfirstlane(n_from) != 0;
+            B = Bl; lenB = __builtin_amdgcn_readfirstlane(n_len); nr = __builtin_amdgcn_readfirstlane(n_nr); word0 = n_word; run = n_run;
             Bl = total_waves <= src_end - Bl ? Bl + total_waves : src_end;      // no overflow near 2^31
             fetch();
-            if (lenB >= cfg.Lmin && lenB > 0 && from_ok) return true;
+            if (nr != 0) return true;
         }
         return false;
     };
-    // stage 1 of a source: row -> LDS, window minimizers, distinct runs, index loads issued (e0 / e1 are NOT waited for here)
-    auto minimizers = [&](int buf, int lenB, uint32_t word0, int &nrun, bool &start, int &rank, uint32_t &q_out, uint32_t &key_out,
-                          uint32_t &bucket) {
-        uint32_t *sb = sB[wave][buf];
+    // stage 1 of a source: row -> LDS; bucket of each run (lanes without a run read bucket 0: one shared line)
+    auto stage = [&](int buf, int lenB, int nr, uint32_t word0, const uint2 &run) -> uint32_t {
         const int nwB = blocks_of(lenB);
         wave_lds_fence();
-        if (lane < STAGE_WORDS) sb[lane] = lane < nwB ? word0 : 0u;
-        wave_lds_fence();
-        const int nwin = lenB - cfg.Lmin + 1;              // overlap lengths Lmin..lenB <-> offsets p = 0..nwin-1 (<= 64)
-        const int nk = lenB - cc.kk + 1;                   // k-mers of the source (<= 127)
-        uint32_t h0, h1, a0, a1;
-        kmer_key(sb, lane, lane < nk, cc, h0, a0);
-        kmer_key(sb, lane + 64, lane + 64 < nk, cc, h1, a1);
-        for (int j = 0, s = 1; j < cc.J; j++, s <<= 1) {   // a[i] = min key[i .. i + 2s - 1]
-            const int src = (lane + s) & 63;
-            const uint32_t t0 = bperm(a0, src), t1 = bperm(a1, src);
-            const bool wrap = lane + s >= 64;
-            const uint32_t u0 = wrap ? t1 : t0, u1 = wrap ? 0xFFFFFFFFu : t1;
-            a0 = a0 < u0 ? a0 : u0;
-            a1 = a1 < u1 ? a1 : u1;
-        }
-        uint32_t wm = a0;                                  // window p = lane: k-mers [p, p + w)
-        if (cc.wrest) {
-            const int src = (lane + cc.wrest) & 63;
-            const uint32_t t0 = bperm(a0, src), t1 = bperm(a1, src);
-            const uint32_t u = lane + cc.wrest >= 64 ? t1 : t0;
-            wm = wm < u ? wm : u;
-        }
-        // distinct minimizers: a window starts a run when its minimizer differs from the previous window's
-        const bool wv = lane < nwin;
-        const uint32_t prev = bperm(wm, (lane + 63) & 63);
-        start = wv && (lane == 0 || wm != prev);
-        const uint64_t runmask = __ballot(start);
-        nrun = __popcll(runmask);
-        const int q = (int) (wm & 255u);                   // k-mer position of window p's minimizer
-        const uint32_t g0 = bperm(h0, q & 63), g1 = bperm(h1, q & 63);
-        sWm[wave][buf][lane] = wv ? (uint32_t) q : 0xFFFFu;
-        q_out = (uint32_t) q;
-        rank = (int) __builtin_amdgcn_mbcnt_hi((uint32_t) (runmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) runmask, 0u));
-        key_out = cluster_key(q >= 64 ? g1 : g0);
-        bucket = start ? key_out >> cc.idx_shift : 0u;     // lanes that start no run read bucket 0 (one shared line)
+        if (lane < STAGE_WORDS) sB[wave][buf][lane] = lane < nwB ? word0 : 0u;
+        return lane < nr ? run.x >> cc.idx_shift : 0u;
     };
     // The index loads of stage 1 are issued by EVERY lane and outside any branch: a load under a branch leaves the number of
     // loads in flight unknown to the compiler, which then drains ALL of them where the entries are first used -- and that
     // serialises the two stages of the pipeline.
     auto index_loads = [&](uint32_t bucket, uint32_t &e0, uint32_t &e1) { e0 = idx[bucket]; e1 = idx[bucket + 1]; };
-    auto finish_runs = [&](int buf, bool start, int rank, uint32_t q, uint32_t key, uint32_t e0, uint32_t e1) {
-        if (start) sRun[wave][buf][rank] = make_uint4(q, key, e0, e1 - e0);
+    // resolved run list -> LDS; returns the largest entry count of the source's runs (uniform)
+    auto finish_runs = [&](int buf, int nr, const uint2 &run, uint32_t e0, uint32_t e1) -> uint32_t {
+        const uint32_t cnt = lane < nr ? e1 - e0 : 0u;
+        if (lane < CL_RMAX) sRun[wave][buf][lane] = make_uint4(run.y, run.x, e0, cnt);
+        uint32_t m = cnt, t;                               // max over lanes 0..7: row_shr 1, 2, 4 inside the first row
+        t = (uint32_t) __builtin_amdgcn_update_dpp(0, (int) m, 0x111, 0xF, 0xF, true); m = m > t ? m : t;
+        t = (uint32_t) __builtin_amdgcn_update_dpp(0, (int) m, 0x112, 0xF, 0xF, true); m = m > t ? m : t;
+        t = (uint32_t) __builtin_amdgcn_update_dpp(0, (int) m, 0x114, 0xF, 0xF, true); m = m > t ? m : t;
         wave_lds_fence();
+        return (uint32_t) __builtin_amdgcn_readlane((int) m, CL_RMAX - 1);
     };
-    // runs rb .. rb+3 of a source: 16 lanes each; uniform maximum of their entry counts
-    auto load_runs = [&](int buf, int rb, int nrun, uint4 &rp, uint32_t &mc) {
-        const int r = rb + grp;
-        rp = make_uint4(0u, 0u, 0u, 0u);
-        if (r < nrun) rp = sRun[wave][buf][r];
-        mc = (uint32_t) __builtin_amdgcn_readlane((int) rp.w, 0);
-        const uint32_t c1 = (uint32_t) __builtin_amdgcn_readlane((int) rp.w, 16), c2 = (uint32_t) __builtin_amdgcn_readlane((int) rp.w, 32),
-                       c3 = (uint32_t) __builtin_amdgcn_readlane((int) rp.w, 48);
-        mc = mc > c1 ? mc : c1; mc = mc > c2 ? mc : c2; mc = mc > c3 ? mc : c3;
-    };
-    // one entry per lane: entry k0 + (lane & 15) of the lane group's run
-    auto load_entries = [&](const uint4 &rp, uint32_t k0, bool &ev, size_t &ei, uint32_t (&ew)[4 * EQ]) {
-        const uint32_t j = k0 + (uint32_t) sl;
+    // Lane layout of a source: 2^gs lanes per run (16 with up to four runs, 8 with up to eight), one entry per lane.
+    auto load_runs = [&](int buf, int gs, uint4 &rp) { rp = sRun[wave][buf][(lane >> gs) & (CL_RMAX - 1)]; };
+    auto load_entries = [&](const uint4 &rp, uint32_t k0, int gs, bool &ev, size_t &ei, uint32_t (&ew)[4 * EQ]) {
+        const uint32_t j = k0 + ((uint32_t) lane & ((1u << gs) - 1u));
         ev = j < rp.w;
-        ei = ev ? (size_t) rp.z + j : (size_t) 0;           // lanes without an entry read entry 0 (unconditional loads: see minimizers)
+        ei = ev ? (size_t) rp.z + j : (size_t) 0;           // lanes without an entry read entry 0 (unconditional loads: see index_loads)
 #pragma unroll
         for (int c = 0; c < EQ; c++) { const uint4 v = store[ei * EQ + c]; ew[4 * c] = v.x; ew[4 * c + 1] = v.y; ew[4 * c + 2] = v.z; ew[4 * c + 3] = v.w; }
     };
 
-    int B = 0, lenB = 0, nrun = 0;
-    uint32_t word0 = 0;
-    bool have = advance(B, lenB, word0);
+    int B = 0, lenB = 0, nr = 0;
+    uint32_t word0 = 0, mc = 0;
+    uint2 run = make_uint2(0u, 0u);
+    bool have = advance(B, lenB, nr, word0, run);
     int buf = 0;
     if (have) {
-        bool start; int rank; uint32_t q, key, bk, e0, e1;
-        minimizers(0, lenB, word0, nrun, start, rank, q, key, bk);
+        uint32_t e0, e1;
+        const uint32_t bk = stage(0, lenB, nr == CL_RUNS_FLAGGED ? 0 : nr, word0, run);
         index_loads(bk, e0, e1);
-        finish_runs(0, start, rank, q, key, e0, e1);
+        mc = finish_runs(0, nr == CL_RUNS_FLAGGED ? 0 : nr, run, e0, e1);
     }
     while (have) {                                         // uniform
         const uint32_t *sb = sB[wave][buf];
-        const uint32_t *wm_lds = sWm[wave][buf];
         const int nwin = lenB - cfg.Lmin + 1;
-        if (STATS && lane == 0) st_win += (uint64_t) nwin;
         // ---- (1) pull the next source off the stream BEFORE any entry load is issued: its loop must not sit between the
         //          loads and their use (hipcc drains vmcnt at loop headers) ----
-        int nB = 0, nlenB = 0, nnrun = 0, nrank = 0;
-        uint32_t nword0 = 0, nq = 0, nkey = 0, nbk = 0, ne0, ne1;
-        bool nstart = false;
-        const bool have_next = advance(nB, nlenB, nword0);
+        int nB = 0, nlenB = 0, nnr = 0;
+        uint32_t nword0 = 0, nbk = 0, ne0, ne1;
+        uint2 nrun = make_uint2(0u, 0u);
+        const bool have_next = advance(nB, nlenB, nnr, nword0, nrun);
+        const int nnr_eff = nnr == CL_RUNS_FLAGGED ? 0 : nnr;
         // ---- (2) first batch of this source's entries: loads issued ----
-        int rb = 0;
-        uint32_t k0 = 0, mc;
+        const bool flagged = nr == CL_RUNS_FLAGGED;       // its run list is empty here: the slow path below finds its runs
+        int gs = (nr > 4 || flagged) ? 3 : 4;
+        uint32_t k0 = 0;
         uint4 rp;
-        load_runs(buf, rb, nrun, rp, mc);
+        load_runs(buf, gs, rp);
         bool ev; size_t ei; uint32_t ew[4 * EQ];
-        load_entries(rp, k0, ev, ei, ew);
-        // ---- (3) the next source: minimizers, index loads issued behind the entry loads ----
-        if (have_next) minimizers(buf ^ 1, nlenB, nword0, nnrun, nstart, nrank, nq, nkey, nbk);
+        load_entries(rp, k0, gs, ev, ei, ew);
+        // ---- (3) the next source: row staged, index loads issued behind the entry loads ----
+        if (have_next) nbk = stage(buf ^ 1, nlenB, nnr_eff, nword0, nrun);
         index_loads(nbk, ne0, ne1);
-        // ---- (4) verify: one entry per lane, four runs per batch ----
+        // ---- (4) verify: one entry per lane ----
         int n_items = 0;                                   // verified overlaps of this source so far (uniform)
         auto verify = [&]() {
             if (STATS && ev) st_slots++;
             const uint32_t id = ew[4 * EQ - 3], eh = ew[4 * EQ - 2], meta = ew[4 * EQ - 1];
             const int lenC = (int) ((meta >> 8) & 0xFFFu);
-            int p = (int) rp.x - (int) (meta & 255u);      // the only offset at which C's prefix can sit in B
-            // same minimizer k-mer, an offset of B, not B itself (GraphCreatorPrefSuf.cpp:386)
-            bool ok = ev && eh == rp.y && p >= 0 && p < nwin && (int) id != B;
+            int p = (int) (rp.x & 255u) - (int) (meta & 255u);         // the only offset at which C's prefix can sit in B
+            // same minimizer k-mer, a window of THIS run (its minimizer is the run's), not B itself (GraphCreatorPrefSuf.cpp:386),
+            // C long enough for a prefix of length L = |B| - p (:215)
+            const bool ok = ev && eh == rp.y && p >= (int) ((rp.x >> 8) & 255u) && p < (int) ((rp.x >> 16) & 255u) && (int) id != B &&
+                            lenC >= lenB - p;
             p = ok ? p : 0;
-            // window p has THIS minimizer; C is long enough for a prefix of length L = |B| - p (:215)
-            ok = ok && wm_lds[p] == rp.x && lenC >= lenB - p;
             const int L = lenB - p, nb = 2 * L;
             const int qw = (2 * p) >> 5, sh = (2 * p) & 31;
             uint32_t y[WC + 1];
 #pragma unroll
             for (int k = 0; k <= WC; k++) y[k] = sb[qw + k];
             uint32_t diff = 0;
+            uint32_t mk[4] = {0u, 0u, 0u, 0u};
+            if constexpr (KF > 0) { const uint4 m4 = sMask[min(nb - 32 * KF, 128)]; mk[0] = m4.x; mk[1] = m4.y; mk[2] = m4.z; mk[3] = m4.w; }
 #pragma unroll
             for (int k = 0; k < WC; k++) {                 // exact compare C[0, L) == B[p, p + L)
                 const uint32_t x = funnel(y[k], y[k + 1], sh) ^ ew[k];
                 if (k < kfull) diff |= x;                  // uniform (compile time with KF)
+                else if (KF > 0 && k < KF + 4) diff |= x & mk[(k - KF) & 3];
                 else diff |= x & low_bits32(nb - 32 * k);
             }
             const bool pass = ok && diff == 0;
@@ -352,21 +379,55 @@ k_probe_clustered(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__res
             }
         };
         verify();                                          // the first batch, peeled: its wait covers the entry loads only
-        for (;;) {                                         // further batches: more than 16 entries in a run, more than four runs
-            k0 += 16;
-            if (k0 >= mc) {                                // uniform
-                rb += 4;
-                if (rb >= nrun) break;
-                k0 = 0;
-                load_runs(buf, rb, nrun, rp, mc);
-            }
-            load_entries(rp, k0, ev, ei, ew);
+        for (;;) {                                         // further batches: a run with more entries than its lane group
+            k0 += 1u << gs;
+            if (k0 >= mc) break;                           // uniform
+            load_entries(rp, k0, gs, ev, ei, ew);
             verify();
+        }
+        if (flagged) {
+            // ---- slow path (one source in ~10^4): more runs than k_node_runs stores.  Window minimizers by brute force (lane p
+            // scans the w k-mers of window p), runs by ballot, eight runs at a time through the same run list and verify(). ----
+            uint32_t wm = 0xFFFFFFFFu;
+            for (int k = 0; k < cc.w; k++) {               // uniform
+                uint32_t h, pk;
+                kmer_key(sb, (lane < nwin ? lane : 0) + k, true, cc, h, pk);
+                wm = pk < wm ? pk : wm;
+            }
+            const bool wv = lane < nwin;
+            const uint32_t prev = bperm(wm, (lane + 63) & 63);
+            const bool start = wv && (lane == 0 || wm != prev);
+            const uint64_t runmask = __ballot(start);
+            const int nrun_all = __popcll(runmask);
+            const uint64_t higher = lane >= 63 ? 0ull : runmask & ~((2ull << lane) - 1ull);
+            const int p1 = higher ? __builtin_ctzll(higher) : nwin;
+            const int rank = (int) __builtin_amdgcn_mbcnt_hi((uint32_t) (runmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) runmask, 0u));
+            uint32_t key = 0u;
+            { uint32_t h, pk; kmer_key(sb, (int) (wm & 255u) < 128 ? (int) (wm & 255u) : 0, true, cc, h, pk); key = cluster_key(h); }
+            gs = 3;
+            for (int rb = 0; rb < nrun_all; rb += CL_RMAX) {   // uniform
+                wave_lds_fence();
+                if (lane < CL_RMAX) sRun[wave][buf][lane] = make_uint4(0u, 0u, 0u, 0u);
+                wave_lds_fence();
+                uint32_t cnt = 0u;
+                if (start && rank >= rb && rank < rb + CL_RMAX) {
+                    const uint32_t bk = key >> cc.idx_shift;
+                    const uint32_t e0 = idx[bk], e1 = idx[bk + 1];
+                    cnt = e1 - e0;
+                    sRun[wave][buf][rank - rb] = make_uint4((wm & 255u) | ((uint32_t) lane << 8) | ((uint32_t) p1 << 16), key, e0, cnt);
+                }
+                wave_lds_fence();
+                const uint32_t mcs = (uint32_t) wave_max_u64_dpp((uint64_t) cnt);
+                load_runs(buf, gs, rp);
+                for (k0 = 0; k0 < mcs; k0 += 1u << gs) { load_entries(rp, k0, gs, ev, ei, ew); verify(); }
+            }
         }
         wave_lds_fence();
         // ---- (5) transitive reduction at the source, edges out ----
+        if (STATS && lane == 0) st_win += (uint64_t) nwin;
         if (n_items > ITEMMAX) {
-            // the source goes on the list of the second pass (k_probe_sources, BIG instantiation); a full list: per-target pipeline
+            // more raw overlaps than the item buffer holds (repeats): second pass (k_probe_sources, BIG instantiation: items in
+            // global memory, probing through the seed table); a full list: per-target pipeline
             if (lane == 0) {
                 const unsigned long long k = atomicAdd(&o.counters[CNT_LOCAL_OVERFLOW], 1ull);
                 if (k < (unsigned long long) o.big_list_cap) o.big_list[k] = B;
@@ -379,8 +440,8 @@ k_probe_clustered(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__res
         const int nb2 = (int) __builtin_amdgcn_readfirstlane((int) *w.recN);
         if (nb2 >= WFLUSH_LOCAL) flush_records<REC_CHUNK_LOCAL, WBUF_LOCAL>(o, w, chunk_base, chunk_fill);
         // ---- (6) the next source's index loads have had the time of (4) and (5) to land ----
-        if (have_next) finish_runs(buf ^ 1, nstart, nrank, nq, nkey, ne0, ne1);
-        have = have_next; B = nB; lenB = nlenB; nrun = nnrun; buf ^= 1;
+        mc = finish_runs(buf ^ 1, nnr_eff, nrun, ne0, ne1);
+        have = have_next; B = nB; lenB = nlenB; nr = nnr; buf ^= 1;
     }
     flush_records<REC_CHUNK_LOCAL, WBUF_LOCAL>(o, w, chunk_base, chunk_fill);
     close_chunk<REC_CHUNK_LOCAL>(o, chunk_base, chunk_fill);
@@ -402,37 +463,40 @@ k_probe_clustered(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__res
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
-int cluster_entry_quads(int max_len) {                    // 16-byte pieces per entry: row words + 3; 0 = rows too long for this path
+// Does the clustered probe take this input?  Fills the k-mer / index geometry and the entry size (16-byte pieces: row words + 3).
+//   rows of up to 4 * CL_MAX_EQ - 3 words; at most 64 suffix windows (the one-word form of the source-side reduction);
+//   w = Lmin - k + 1 k-mers per window with nwin <= w <= 64 (k_node_runs splits a window over two blocks of w k-mers) and
+//   k >= CL_KMIN_HARD: k = max(Lmin - 63, min(Lmin, CL_KMIN)), lowered to 2 Lmin - max_len when the windows outnumber w.
+bool cluster_plan(const PrefSufCfg &cfg, int max_len, uint64_t live, int bucket_log2_bias, ClusterCfg *c, int *eq) {
     const int W = blocks_of(max_len);
-    const int eq = (W + 3 + 3) / 4;
-    return eq < 2 ? 2 : (eq <= CL_MAX_EQ ? eq : 0);
-}
-
-ClusterCfg cluster_cfg(const PrefSufCfg &cfg, uint64_t live, int bucket_log2_bias) {
-    ClusterCfg c;
-    c.kk = std::max(cfg.Lmin - 63, std::min(cfg.Lmin, CL_KMIN));
-    c.w = cfg.Lmin - c.kk + 1;
-    c.J = 0;
-    while ((2 << c.J) <= c.w) c.J++;
-    c.wrest = c.w - (1 << c.J);
-    c.lo_mask = c.kk >= 16 ? 0xFFFFFFFFu : ((1u << (2 * c.kk)) - 1u);
-    c.hi_mask = c.kk <= 16 ? 0u : (c.kk >= 32 ? 0xFFFFFFFFu : ((1u << (2 * c.kk - 32)) - 1u));
+    int e = (W + 3 + 3) / 4;
+    if (e < 2) e = 2;
+    const int nwin = max_len - cfg.Lmin + 1;
+    if (e > CL_MAX_EQ || nwin < 1 || nwin > 64) return false;
+    int kk = std::max(cfg.Lmin - 63, std::min(cfg.Lmin, CL_KMIN));
+    if (nwin > cfg.Lmin - kk + 1) kk = 2 * cfg.Lmin - max_len;
+    if (kk < CL_KMIN_HARD || kk > 32 || kk > cfg.Lmin) return false;
+    c->kk = kk;
+    c->w = cfg.Lmin - kk + 1;
+    c->lo_mask = kk >= 16 ? 0xFFFFFFFFu : ((1u << (2 * kk)) - 1u);
+    c->hi_mask = kk <= 16 ? 0u : (kk >= 32 ? 0xFFFFFFFFu : ((1u << (2 * kk - 32)) - 1u));
     int bits = 4;
     while (bits < 28 && (1ull << bits) < live) bits++;     // ~one entry per bucket: a lookup returns its cluster and little else
     bits = std::max(4, std::min(30, bits + bucket_log2_bias));
-    c.n_buckets = 1u << bits;
-    c.idx_shift = 32 - bits;
-    return c;
+    c->n_buckets = 1u << bits;
+    c->idx_shift = 32 - bits;
+    *eq = e;
+    return true;
 }
 
 size_t cluster_sort_temp_bytes(uint64_t n) { return sort_u32_pairs_temp_bytes(n); }
 
 hipError_t launch_cluster_build(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterCfg &cc, int eq, uint32_t *keys, uint32_t *vals,
-                                uint32_t *keys2, uint32_t *vals2, uint32_t *meta, void *sort_temp, size_t sort_temp_bytes, void *store,
-                                uint32_t *idx, hipStream_t s) {
+                                uint32_t *keys2, uint32_t *vals2, uint32_t *meta, void *runs, uint8_t *nruns, void *sort_temp, size_t sort_temp_bytes,
+                                void *store, uint32_t *idx, hipStream_t s) {
     if (nd.n <= 0) return hipSuccess;
     const uint64_t n = (uint64_t) nd.n;
-    hipLaunchKernelGGL(k_tgt_keys, dim3((unsigned) ((n + TK_ROWS - 1) / TK_ROWS)), dim3(TK_ROWS), 0, s, nd, cfg, cc, keys, vals, meta);
+    hipLaunchKernelGGL(k_node_runs, dim3((unsigned) ((n + TK_ROWS - 1) / TK_ROWS)), dim3(TK_ROWS), 0, s, nd, cfg, cc, keys, vals, meta, (uint2 *) runs, nruns);
     hipError_t err = sort_u32_pairs(sort_temp, sort_temp_bytes, keys, keys2, vals, vals2, n, s);
     if (err != hipSuccess) return err;
     const uint64_t pieces = n * (uint64_t) eq;
@@ -452,7 +516,7 @@ uint64_t cluster_probe_blocks(int n_cu, uint64_t n_src) {
 uint64_t cluster_record_slack(int n_cu, uint64_t n_src) { return cluster_probe_blocks(n_cu, n_src) * PROBE_WAVES * (uint64_t) REC_CHUNK_LOCAL; }
 
 void launch_probe_clustered(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterCfg &cc, int eq, const void *store, const uint32_t *idx,
-                            int32_t src_begin, int32_t src_end, uint32_t *rec_dst, unsigned long long *rec_val, uint64_t rec_cap,
+                            const void *runs, const uint8_t *nruns, int32_t src_begin, int32_t src_end, uint32_t *rec_dst, unsigned long long *rec_val, uint64_t rec_cap,
                             unsigned long long *counters, int n_cu, uint32_t *deg, unsigned long long *first, const ProbeBig *big, hipStream_t s) {
     const int64_t ns = (int64_t) src_end - src_begin;
     if (ns <= 0) return;
@@ -463,7 +527,7 @@ void launch_probe_clustered(const NodesDev &nd, const PrefSufCfg &cfg, const Clu
     // KF = (2 * Lmin) >> 5 as a compile-time constant for the shapes ALGA's defaults produce (150-bp reads: Lmin 82, rows of 9
     // words; 100-bp reads: Lmin 55, rows of 6 words); 0 = any shape
     const int kf = (2 * cfg.Lmin) >> 5;
-#define CL_LAUNCH(ST, E, K) hipLaunchKernelGGL((k_probe_clustered<ST, E, K>), grid, block, 0, s, nd, cfg, cc, st, idx, src_begin, src_end, o)
+#define CL_LAUNCH(ST, E, K) hipLaunchKernelGGL((k_probe_clustered<ST, E, K>), grid, block, 0, s, nd, cfg, cc, st, idx, (const uint2 *) runs, nruns, src_begin, src_end, o)
 #define CL_STATS(E, K) do { if (cfg.stats) CL_LAUNCH(true, E, K); else CL_LAUNCH(false, E, K); } while (0)
     if (eq == 3 && kf == 5)      CL_STATS(3, 5);
     else if (eq == 3 && kf == 3) CL_STATS(3, 3);

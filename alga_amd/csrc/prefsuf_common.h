@@ -94,14 +94,15 @@ struct NodesDev {
 };
 
 // clustered minimizer join (prefsuf_cluster.hip): targets filed under the minimizer of their min_overlap-long prefix
-constexpr int      CL_KMIN = 16;              // shortest minimizer k-mer; k = max(Lmin - 63, min(Lmin, CL_KMIN)), w = Lmin - k + 1 <= 64
+constexpr int      CL_KMIN = 16;              // preferred shortest minimizer k-mer; k = max(Lmin - 63, min(Lmin, CL_KMIN)), w = Lmin - k + 1 <= 64
+constexpr int      CL_KMIN_HARD = 8;          // below this the clustered probe declines (the seed-table probe takes the input)
+constexpr int      CL_RMAX = 8;               // minimizer runs stored per node (a 150-bp read has 2.9 on average)
+constexpr int      CL_RUNS_FLAGGED = 0xFF;    // nruns marker: more runs / records than k_node_runs stores
 constexpr int      CL_MAX_EQ = 4;             // 16-byte pieces per entry: rows of up to 4 * CL_MAX_EQ - 3 words (208 nt)
 constexpr uint32_t CL_META_FROM = 1u << 20;   // entry meta word: m_C | len << 8 | alignFrom << 20
 struct ClusterCfg {
     int32_t  kk;         // minimizer k-mer length
     int32_t  w;          // k-mers per window
-    int32_t  J;          // floor(log2(w)): doubling steps of the sliding-window minimum
-    int32_t  wrest;      // w - 2^J
     uint32_t lo_mask;    // k-mer bits in the first / second 32-bit word
     uint32_t hi_mask;
     int32_t  idx_shift;  // hash bucket = hash >> idx_shift

@@ -240,7 +240,7 @@ __device__ __forceinline__ bool verify_overlap(const NodesDev &nd, const uint32_
 // Host-checked preconditions (engine.hip local_ok): max_len - Lmin <= 63 (SW = 1) or <= 127 (SW = 2), max_len <= cap,
 // alignFrom => alignTo, Lmin <= rsoemo <= Lcap.
 // ------------------------------------------------------------------------------------------
-constexpr int ITEMMAX = 160;              // raw overlaps of one source held in LDS; sources with more go to the second pass
+constexpr int ITEMMAX = 128;              // raw overlaps of one source held in LDS; sources with more go to the second pass
 constexpr int ITEM_BIG_MAX = 4096;        // largest per-wave global item slice of the second pass; beyond it: per-target pipeline
 constexpr uint32_t ITEM_FROM = 1u << 18;
 constexpr uint32_t ITEM_KEPT = 1u << 19;      // all-pairs evaluation: survives the per-source cap / is a big overlap

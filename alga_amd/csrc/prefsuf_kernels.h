@@ -35,16 +35,15 @@ void launch_local_emit(int32_t src_base, int32_t n_src, const uint32_t *deg, con
                        alga_edge_dev *edges, hipStream_t s);
 
 // clustered minimizer join (prefsuf_cluster.hip): source-side form with one-word offset masks (max_len - Lmin <= 63)
-int        cluster_entry_quads(int max_len);              // 16-byte pieces per entry; 0 = rows too long for this probe
-ClusterCfg cluster_cfg(const PrefSufCfg &cfg, uint64_t live, int bucket_log2_bias);
+bool       cluster_plan(const PrefSufCfg &cfg, int max_len, uint64_t live, int bucket_log2_bias, ClusterCfg *c, int *eq);   // false: this probe does not take the input
 size_t     cluster_sort_temp_bytes(uint64_t n);
-// keys/vals/keys2/vals2/meta: n uint32 each; store: (n + 1) * 16 * eq bytes; idx: n_buckets + 2 uint32
+// keys/vals/keys2/vals2/meta: n uint32 each; runs: n * CL_RMAX * 8 bytes; nruns: n bytes; store: (n + 2) * 16 * eq bytes; idx: n_buckets + 2 uint32
 hipError_t launch_cluster_build(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterCfg &cc, int eq, uint32_t *keys, uint32_t *vals,
-                                uint32_t *keys2, uint32_t *vals2, uint32_t *meta, void *sort_temp, size_t sort_temp_bytes, void *store,
-                                uint32_t *idx, hipStream_t s);
+                                uint32_t *keys2, uint32_t *vals2, uint32_t *meta, void *runs, uint8_t *nruns, void *sort_temp, size_t sort_temp_bytes,
+                                void *store, uint32_t *idx, hipStream_t s);
 uint64_t   cluster_record_slack(int n_cu, uint64_t n_src);
 void       launch_probe_clustered(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterCfg &cc, int eq, const void *store, const uint32_t *idx,
-                                  int32_t src_begin, int32_t src_end, uint32_t *rec_dst, unsigned long long *rec_val, uint64_t rec_cap,
+                                  const void *runs, const uint8_t *nruns, int32_t src_begin, int32_t src_end, uint32_t *rec_dst, unsigned long long *rec_val, uint64_t rec_cap,
                                   unsigned long long *counters, int n_cu, uint32_t *deg, unsigned long long *first, const ProbeBig *big, hipStream_t s);
 
 size_t     sort_u32_pairs_temp_bytes(uint64_t n);

@@ -45,7 +45,10 @@ def _check(eng, words, lens, lo, rs, af=None, at=None, stats=True, source_side=N
         # the source-side form through BOTH probes: the bucketised seed table and the clustered minimizer join (which takes
         # one-word offset masks and rows of up to 13 words, and hands anything else to the table probe)
         maxlen = int(np.max(lens, initial=0))
-        clusterable = maxlen - lo <= 63 and (2 * maxlen + 31) // 32 <= 13
+        kk = max(lo - 63, min(lo, 16))                       # cluster_plan (alga_amd/csrc/prefsuf_cluster.hip)
+        if maxlen - lo + 1 > lo - kk + 1:
+            kk = 2 * lo - maxlen
+        clusterable = 1 <= maxlen - lo + 1 <= 64 and (2 * maxlen + 31) // 32 <= 13 and 8 <= kk <= min(32, lo)
         for probe in ("table", "cluster"):
             eng.set_option("probe", probe)
             try:
