@@ -31,7 +31,10 @@ def shard_bounds(n, world):
 
 
 class HipBackend:
-    """The engine behind the driver: device tensors in, device tensors (views of engine memory) out."""
+    """The engine behind the driver: device tensors in, device tensors (views of engine memory) out.
+    Every engine call is enqueued on torch's CURRENT stream of the device: collectives (RCCL) and torch ops that produce an
+    engine input, and engine kernels that consume it, are then ordered by the stream itself (the engine's own stream is a
+    non-blocking one that orders with nothing else)."""
 
     def __init__(self, engine, d_words, d_lens, min_overlap, rsoemo):
         self.eng, self.w, self.l = engine, d_words, d_lens
@@ -40,16 +43,20 @@ class HipBackend:
         self.device = d_words.device
         self.stats = {}
 
+    def _stream(self):
+        import torch
+        return torch.cuda.current_stream(self.device).cuda_stream
+
     def build(self, collect_stats=False):
         from .engine import device_view
-        ptr, m = self.eng.prefsuf_device(self.w, self.l, self.lo, self.rs, collect_stats=collect_stats)
+        ptr, m = self.eng.prefsuf_device(self.w, self.l, self.lo, self.rs, collect_stats=collect_stats, stream=self._stream())
         self.stats = self.eng.last_stats()
         return device_view(ptr, (m, 3), self.device)
 
     def build_range(self, src_begin, src_end, collect_stats=False):
         """Final edges of the sources in the range (tensor [m, 3]) or None when the source-side form is not exact here."""
         from .engine import device_view
-        r = self.eng.build_range_device(self.w, self.l, self.lo, self.rs, src_begin, src_end, collect_stats=collect_stats)
+        r = self.eng.build_range_device(self.w, self.l, self.lo, self.rs, src_begin, src_end, collect_stats=collect_stats, stream=self._stream())
         if r is None:
             return None
         self.stats = self.eng.last_stats()
@@ -57,15 +64,15 @@ class HipBackend:
 
     def discover_sorted(self, src_begin, src_end, collect_stats=False):
         from .engine import device_view
-        d, v, k = self.eng.discover_device(self.w, self.l, self.lo, self.rs, src_begin, src_end, collect_stats=collect_stats)
+        d, v, k = self.eng.discover_device(self.w, self.l, self.lo, self.rs, src_begin, src_end, collect_stats=collect_stats, stream=self._stream())
         self.stats = self.eng.last_stats()
-        ds, vs, nv = self.eng.sort_records_device(d, v, k, self.n)
+        ds, vs, nv = self.eng.sort_records_device(d, v, k, self.n, stream=self._stream())
         return device_view(ds, (nv,), self.device), device_view(vs, (nv,), self.device, "<i8")
 
     def reduce(self, rec_dst, rec_val, dst_begin, dst_end, collect_stats=False):
         from .engine import device_view
         ptr, m = self.eng.reduce_device(self.w, self.l, self.lo, self.rs, rec_dst, rec_val, int(rec_dst.shape[0]), dst_begin, dst_end,
-                                        collect_stats=collect_stats)
+                                        collect_stats=collect_stats, stream=self._stream())
         st = self.eng.last_stats()
         for k in ("ms_group", "ms_reduce", "ms_emit", "transitive_listed", "transitive_compares", "transitive_removed", "max_in_records"):
             self.stats[k] = st[k]
@@ -74,7 +81,7 @@ class HipBackend:
     def sort_edges(self, edges):
         from .engine import device_view
         m = int(edges.shape[0])
-        ptr = self.eng.sort_edges_device(edges, m, self.n)
+        ptr = self.eng.sort_edges_device(edges, m, self.n, stream=self._stream())
         return device_view(ptr, (m, 3), self.device)
 
     def sync(self):

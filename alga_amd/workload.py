@@ -119,8 +119,9 @@ def device_build(n_reads, read_len, genome_len, seed, device="cuda", trim=3, chu
     STR reads and reverse-complement palindromes have probability < 4^-20 per read and are ignored); node ids shuffled so that
     they carry no positional information, node 2i = reverse complement, 2i+1 = forward (src/IO/InputReader.cpp:78-80).
     -> dict(words int32[N, 16|stride] (device), lens int32[N] (device), n_reads, unique_reads, min_overlap, rsoemo,
-            sample_codes uint8[sample_reads, read_len] (host): the untrimmed reads of the first `sample_reads` node pairs,
-            for the CPU baseline's FASTA)."""
+            sample_codes uint8[~sample_reads, read_len] (host): a genomic window of the SAME read set for the CPU baseline's
+            FASTA -- every (untrimmed) read that starts in the first genome_len * sample_reads / n_reads positions, in node
+            order: same coverage, same overlap statistics per read as the whole set)."""
     import torch
     g = torch.Generator(device=device)
     g.manual_seed(int(seed))
@@ -166,9 +167,10 @@ def device_build(n_reads, read_len, genome_len, seed, device="cuda", trim=3, chu
     out = dict(words=words, lens=lens, n_reads=n_reads, unique_reads=R, read_len=read_len, genome=genome_len, seed=seed,
                min_overlap=lo, rsoemo=rs, sample_codes=None)
     if sample_reads:
-        k = min(sample_reads, R)
-        st = starts[:k]
+        window = int(genome_len * min(1.0, sample_reads / max(1, n_reads)))
+        sel = torch.nonzero(starts < window).flatten()
+        st = starts[sel]
         codes = genome[(st[:, None] + torch.arange(read_len, device=device)[None, :])]
-        codes = torch.where(flip[:k][:, None], (3 - codes).flip(1), codes)
+        codes = torch.where(flip[sel][:, None], (3 - codes).flip(1), codes)
         out["sample_codes"] = codes.cpu().numpy()
     return out

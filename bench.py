@@ -1,23 +1,29 @@
 #!/usr/bin/env python3
 """bench.py -- overlap-graph construction throughput of the HIP engine on MI355X.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2_1M_150bp] [--no-cpu-baseline]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg4_50M_150bp] [--no-cpu-baseline]
 
-A "step" is one complete pass of the hot path (GraphCreatorPrefSuf: seed table, probe, per-source cap,
-per-target transitive reduction, sorted adjacency) over one synthetic read set that is already resident in
-HBM when the timed region starts.  Prints ONE JSON line (rank 0):
+A "step" is one complete pass of the hot path (GraphCreatorPrefSuf + retainOnlySmallestOffset, reference
+src/main.cpp:244-296: index of the targets, probe of every source, transitive reduction, sorted adjacency lists) over one
+synthetic read set that is already resident in HBM when the timed region starts.  Prints ONE JSON line (rank 0):
   metric   overlap_edges_per_sec   (BASELINE.json: overlap edges/sec; Gbp/s of input reads is `gbp_per_sec`)
-  value    edges in the emitted graph x steps / wall time of the K steps (max over ranks), whole job
-  roofline dominant kernel (k_probe_sources) algorithmic bytes / its HIP-event duration vs the 8 TB/s HBM peak
-  cpu_baseline  the real reference binary (oracle/_ref/ALGA, kind "reference") or, if it is absent, the C
-                oracle (kind "port"), timed on this box's host cores on a bounded sample of the same workload.
+  value    edges in the emitted graph x steps / wall time of the K steps (max over ranks), whole job, inputs resident in HBM
+  roofline dominant kernel (the probe): SURVEY.md section 8(d) algorithmic bytes / its HIP-event duration vs the 8 TB/s HBM peak
+  cpu_baseline  the real reference binary (oracle/_ref/ALGA, kind "reference") -- or the C oracle (kind "port") where it is
+                absent -- timed on this box's host cores on a bounded sample of the same workload; the GPU graph of the same
+                sample is compared with the reference's --serialize=1 dump byte for byte.
+  pcie_inclusive  the same graph through the host-buffer entry point (packed host reads in, host edge list out): never `value`.
 
-N=1: BASELINE.json configs[1] (1 M x 150 bp, error-free, 50x coverage).  N>1 (one process per GPU under
-torch.distributed.run, RCCL): weak scaling -- N x 1 M reads over an N x 3 Mb genome; sources are sharded
-across ranks, overlap records are exchanged to the rank that owns the target (all_to_all), edges are
-all-gathered.
+Workload: BASELINE.json configs[3]'s read set, the one `metric` is quoted on -- 50 M x 150 bp error-free reads over a 250 Mb
+genome (SURVEY.md section 8(d) generator, seed 11), generated on the device; it fits one GPU (5.8 GB of rows).
+N > 1 (one process per GPU under torch.distributed.run, RCCL): STRONG scaling -- the same 50 M reads for every N; every rank
+holds the node set, builds the target index, probes 1/N of the sources (contiguous id range) and the edge lists are gathered
+on rank 0 over RCCL.  Other configs (`--config cfg2_1M_150bp` ...) are built on the host exactly as the reference's input
+stages would number the nodes.
 """
 import argparse
+import glob
+import hashlib
 import json
 import os
 import re
@@ -44,18 +50,17 @@ def algorithmic_bytes(st, W):
     return dict(probe=probe, reduce=reduce_, emit=emit, total=probe + reduce_ + emit)
 
 
-def cpu_baseline_reference(codes, threads, budget_reads):
-    """Run the real reference (oracle/_ref/ALGA) on a bounded sample; creator wall time is taken between its
-    stderr markers 'Creating GraphCreator' and 'Before first simplifier' (its own timers report CPU-seconds,
-    src/Utils/TimeMeasurer.cpp:26-39)."""
+def cpu_baseline_reference(codes, threads, eng):
+    """The real reference (oracle/_ref/ALGA) on `codes` (uint8 [k, L]): creator wall time between its stderr markers 'Creating
+    GraphCreator' and 'Before first simplifier' (its own timers report CPU-seconds, src/Utils/TimeMeasurer.cpp:26-39), its
+    --serialize=1 dump compared byte for byte with the graph the engine builds from the same reads."""
     exe = os.path.join(ROOT, "oracle", "_ref", "ALGA")
     if not os.path.exists(exe):
         return None
     from alga_amd import workload
-    sample = codes[:budget_reads]
     with tempfile.TemporaryDirectory() as wd:
-        workload.write_fasta_fast(os.path.join(wd, "s.fasta"), sample)
-        p = subprocess.Popen([exe, "--file1=s.fasta", "--threads=%d" % threads, "--output=o.fasta"], cwd=wd,
+        workload.write_fasta_fast(os.path.join(wd, "s.fasta"), codes)
+        p = subprocess.Popen([exe, "--file1=s.fasta", "--threads=%d" % threads, "--serialize=1", "--output=o.fasta"], cwd=wd,
                              stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, errors="replace", bufsize=1)
         t0 = t1 = None
         edges = None
@@ -69,13 +74,23 @@ def cpu_baseline_reference(codes, threads, budget_reads):
                 break
         p.kill()
         p.wait()
-    if t0 is None or t1 is None:
-        return None
+        if t0 is None or t1 is None:
+            return None
+        dumps = glob.glob(os.path.join(wd, "*_beforeSimplifier.graph"))
+        bytes_equal = None
+        if dumps:
+            # the engine on the same reads: node set numbered as the reference numbers it (alga_amd/workload.make_nodes)
+            words, lens, _ = workload.make_nodes(codes)
+            lo, rs = workload.derive_params(float(codes.shape[1] - 6))
+            ge = eng.prefsuf_host(words, lens, lo, rs)
+            mine = os.path.join(wd, "gpu.graph")
+            eng.write_graph(mine, len(lens), ge)
+            bytes_equal = open(mine, "rb").read() == open(dumps[0], "rb").read()
     dt = t1 - t0
     return dict(value=edges / dt, unit="edges/s", cores=threads, kind="reference",
-                sample="%d x %d bp reads of the same workload (first reads of the set), ALGA --threads=%d, creator region "
-                       "src/main.cpp:244-296, %.2f s wall, %d edges" % (len(sample), sample.shape[1], threads, dt, edges),
-                seconds=dt, edges=edges, gbp_per_sec=sample.size / dt / 1e9)
+                sample="%d x %d bp reads of the same workload (every read that starts in the first genome_len * sample / n_reads positions: same coverage), ALGA --threads=%d --serialize=1, "
+                       "creator region src/main.cpp:244-296, %.2f s wall, %d edges" % (len(codes), codes.shape[1], threads, dt, edges),
+                seconds=dt, edges=edges, gbp_per_sec=codes.size / dt / 1e9, graph_bytes_equal_gpu=bytes_equal)
 
 
 def cpu_baseline_port(words, lens, lo, rs, budget_nodes):
@@ -91,15 +106,29 @@ def cpu_baseline_port(words, lens, lo, rs, budget_nodes):
                 sample="first %d nodes of the workload, single-thread C oracle, %.2f s" % (len(l), dt), seconds=dt, edges=len(e))
 
 
+def profiled_traffic(config, lib_sha):
+    """HBM-side bytes per probe launch from the rocprofv3 --pmc passes (tools/pmc_to_traffic.py -> profiles/probe_hbm_bytes.json),
+    reported only when they were taken on THIS build of the library; otherwise null."""
+    tf = os.path.join(ROOT, "profiles", "probe_hbm_bytes.json")
+    try:
+        ent = json.load(open(tf)).get(config)
+    except Exception:
+        return None
+    if not ent or ent.get("lib_sha256") != lib_sha:
+        return None
+    return ent.get("hbm_bytes_per_launch")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="cfg2_1M_150bp")
-    ap.add_argument("--stride", type=int, default=0, help="row stride in uint32 words (0 = the engine's HBM layout: rows padded to 16 bytes, as alga_prefsuf_build_host uploads them; -1 = minimal)")
+    ap.add_argument("--config", default="cfg4_50M_150bp")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-reads", type=int, default=1_000_000)
+    ap.add_argument("--no-pcie", action="store_true")
+    ap.add_argument("--cpu-sample-reads", type=int, default=1_000_000, help="reads of the workload the CPU baseline runs on (~10 s of the reference at 16 threads)")
+    ap.add_argument("--probe", default="auto", choices=["auto", "table", "cluster"])
     args = ap.parse_args()
 
     import torch
@@ -120,26 +149,30 @@ def main():
         import torch.distributed as dist
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
-    # ---- workload (synthetic; built once on rank 0, replicated to every GPU over RCCL) -------------------------
-    wl = None
-    meta = torch.zeros(4, dtype=torch.int64, device="cuda")
-    if rank == 0:
-        wl = workload.build(args.config, scale=world, stride_words=(None if args.stride < 0 else (args.stride or "aligned")))
-        meta = torch.tensor([len(wl["lens"]), wl["words"].shape[1], wl["min_overlap"], wl["rsoemo"]], dtype=torch.int64, device="cuda")
-    if dist is not None:
-        dist.broadcast(meta, src=0)
-    n_nodes, stride, lo, rs = [int(x) for x in meta.cpu()]
-    if rank == 0:
+    # ---- workload (synthetic).  Every rank builds the same node set on its own GPU: the generator is seeded. ----------------
+    n_reads, read_len, G, seed, err = workload.CONFIGS[args.config]
+    sample_codes = None
+    host_words = host_lens = None
+    t_build = time.perf_counter()
+    if err == 0.0 and n_reads >= 4_000_000:
+        wl = workload.device_build(n_reads, read_len, G, seed, sample_reads=(args.cpu_sample_reads if rank == 0 else 0))
+        d_words, d_lens = wl["words"], wl["lens"]
+        sample_codes = wl["sample_codes"]
+        how = "generated on the device (alga_amd.workload.device_build)"
+    else:
+        wl = workload.build(args.config, stride_words="aligned")
+        host_words, host_lens = wl["words"], wl["lens"]
         d_words = torch.from_numpy(wl["words"].view(np.int32)).cuda()
         d_lens = torch.from_numpy(wl["lens"]).cuda()
-    else:
-        d_words = torch.empty((n_nodes, stride), dtype=torch.int32, device="cuda")
-        d_lens = torch.empty(n_nodes, dtype=torch.int32, device="cuda")
-    if dist is not None:
-        dist.broadcast(d_words, src=0)
-        dist.broadcast(d_lens, src=0)
+        sample_codes = wl["codes"][:args.cpu_sample_reads]
+        how = "built on the host as the reference's input stages number the nodes (alga_amd.workload.build)"
+    torch.cuda.synchronize()
+    t_build = time.perf_counter() - t_build
+    lo, rs = wl["min_overlap"], wl["rsoemo"]
+    n_nodes = int(d_lens.shape[0])
     W = (2 * int(d_lens.max().item()) + 31) // 32 if n_nodes else 0
     eng = alga_amd.Engine(local_rank)
+    eng.set_option("probe", args.probe)
     runner = multigpu.ShardedPrefSuf(multigpu.HipBackend(eng, d_words, d_lens, lo, rs), rank, world, dist)
 
     def sync_all():
@@ -173,63 +206,63 @@ def main():
     out = None
     if rank == 0:
         ms_step = dt / args.steps * 1e3
-        bases = wl["n_reads"] * wl["read_len"]
+        bases = n_reads * read_len
         alg = algorithmic_bytes(stats, W)
         probe_avg_ms = float(np.mean(probe_ms))
         alg_probe_launch = alg["probe"] / world           # one launch = one rank's share of the sources
         achieved = alg_probe_launch / (probe_avg_ms * 1e-3) / 1e9
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "probe_hbm_bytes.json")   # from the rocprofv3 --pmc passes (see profiles/README.md)
-        if os.path.exists(tf):
-            try:
-                traffic = json.load(open(tf)).get(args.config, {}).get("hbm_bytes_per_launch") if world == 1 else None
-            except Exception:
-                traffic = None
+        probe_kernel = "k_probe_clustered" if stats.get("probe_used") == 2 else "k_probe_sources"
+        lib_sha = hashlib.sha256(open(alga_amd.engine.library_path(), "rb").read()).hexdigest()[:16]
         out = {
             "metric": "overlap_edges_per_sec", "value": n_edges * args.steps / dt, "unit": "edges/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "gbp_per_sec": bases / (ms_step * 1e-3) / 1e9,
-            "config": {"workload": "%s x%d: %d x %d bp reads, genome %d, seed %d, err %.2f -> %d nodes (both strands, "
-                                   "duplicates removed), min_overlap %d, rsoemo %d" %
-                                   (wl["name"], world, wl["n_reads"], wl["read_len"], wl["genome"], wl["seed"], wl["err"],
-                                    n_nodes, lo, rs),
+            "config": {"workload": "%s: %d x %d bp reads, genome %d, seed %d, err %.2f -> %d nodes (both strands, duplicates removed), "
+                                   "min_overlap %d, rsoemo %d; %s in %.1f s" %
+                                   (args.config, n_reads, read_len, G, seed, err, n_nodes, lo, rs, how, t_build),
                        "nodes": n_nodes, "edges": int(n_edges), "parallelism": "1 GPU" if world == 1 else
-                       "sources sharded over %d ranks, each builds the final edges of its sources (no record exchange), "
-                       "edge lists gathered on rank 0 over RCCL" % world},
-            "roofline": {"bound": "hbm", "kernel": "k_probe_sources", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes": alg_probe_launch,
-                         "kernel_ms": probe_avg_ms,
+                       "strong scaling: the same read set for every N; node set and target index on every rank, sources sharded over %d ranks "
+                       "(contiguous id ranges), each rank builds the final edges of its sources, edge lists gathered on rank 0 over RCCL" % world},
+            "roofline": {"bound": "hbm", "kernel": probe_kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": profiled_traffic(args.config, lib_sha) if world == 1 else None,
+                         "traffic_source": "rocprofv3 --pmc passes of this command on this build (profiles/probe_hbm_bytes.json, lib %s); null = not profiled on this build" % lib_sha,
+                         "algorithmic_bytes": alg_probe_launch, "kernel_ms": probe_avg_ms,
                          "per_unit": "per source node: 4W + 16 P + 4W * raw/node bytes (W=%d words, P=%.1f windows, raw/node=%.2f)" %
                                      (W, stats["windows_probed"] / max(1, stats["nodes_live"]), stats["raw_overlaps"] / max(1, stats["nodes_live"]))},
             "phases_ms": {k: v / args.steps for k, v in phase.items()},
             "counters": {k: int(stats[k]) for k in ("nodes_live", "windows_probed", "slots_scanned", "raw_overlaps", "records",
                                                     "transitive_listed", "transitive_compares", "transitive_removed", "edges",
-                                                    "max_in_records", "table_slots")},
+                                                    "max_in_records", "table_slots", "probe_used", "reduction_used", "big_sources")},
             "algorithmic_bytes_total": alg["total"],
             "device": eng.device_name(),
         }
-        if world == 1:
-            # the same graph through the host-buffer entry point (pageable host arrays in, host edge list out): never `value`
+        if world == 1 and not args.no_pcie:
+            # the same graph through the host-buffer entry point (packed host reads in, host edge list out): never `value`
+            if host_words is None:
+                host_words = d_words.cpu().numpy().view(np.uint32)
+                host_lens = d_lens.cpu().numpy()
             ts = []
             for _ in range(3):
                 t = time.perf_counter()
-                he = eng.prefsuf_host(wl["words"], wl["lens"], lo, rs)
+                he = eng.prefsuf_host(host_words, host_lens, lo, rs)
                 ts.append(time.perf_counter() - t)
             out["pcie_inclusive"] = {"ms_per_graph": min(ts) * 1e3, "edges_per_sec": len(he) / min(ts),
+                                     "edges_equal_resident": bool(len(he) == int(n_edges)),
                                      "note": "alga_prefsuf_build_host: H2D of the packed reads + build + D2H of the edges, best of 3"}
+            del he
         if not args.no_cpu_baseline and world == 1:        # the CPU baseline is a rank-0, N=1 measurement
             try:
                 cores = len(os.sched_getaffinity(0))
             except AttributeError:
                 cores = os.cpu_count() or 1
             cores = max(1, min(cores, 16))          # the GPU box gives one GPU's CPU share: 16 cores
-            cb = cpu_baseline_reference(wl["codes"], cores, min(args.cpu_sample_reads, wl["n_reads"]))
+            cb = cpu_baseline_reference(sample_codes, cores, eng) if sample_codes is not None else None
             if cb is None:
-                cb = cpu_baseline_port(wl["words"], wl["lens"], lo, rs, min(n_nodes, 200_000))
+                hw = host_words if host_words is not None else d_words[:200_000].cpu().numpy().view(np.uint32)
+                hl = host_lens if host_lens is not None else d_lens[:200_000].cpu().numpy()
+                cb = cpu_baseline_port(hw, hl, lo, rs, min(n_nodes, 200_000))
             out["cpu_baseline"] = cb
-            if cb.get("kind") == "reference" and world == 1 and args.cpu_sample_reads >= wl["n_reads"]:
-                out["cpu_baseline"]["edges_equal_gpu"] = bool(cb["edges"] == int(n_edges))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -140,8 +140,10 @@ int  alga_prefsuf_build_host(alga_engine *e, const alga_nodes *nodes, const alga
 void alga_free_edges(alga_engine *e, alga_edge *edges);
 
 /* Same computation with the node set already resident in HBM (all pointers in `nodes` are device
- * pointers on the engine's device).  Work is enqueued on `hip_stream` (a hipStream_t, NULL = the
- * engine's own stream).  The edge list stays on the device:
+ * pointers on the engine's device).  Work is enqueued on `hip_stream` (a hipStream_t).  NULL = the engine's own stream, a
+ * NON-BLOCKING stream that orders with no other stream (not even the null stream): with NULL every input must be complete
+ * before the call (synchronise the producing stream first); to chain behind work of another stream pass that stream.
+ * The same holds for every call below that takes a `hip_stream`.  The edge list stays on the device:
  *   *d_edges : device pointer to alga_edge[*n_edges], owned by the engine, valid until the next
  *              build call on this engine or alga_engine_destroy(). */
 int  alga_prefsuf_build_device(alga_engine *e, const alga_nodes *nodes, const alga_prefsuf_params *p,
