@@ -535,6 +535,31 @@ int alga_copy_to_host(alga_engine *e, void *dst, const void *d_src, size_t bytes
     return ALGA_OK;
 }
 
+int alga_device_alloc(alga_engine *e, size_t bytes, void **d_out) {
+    if (!e || !d_out) return ALGA_ERR_INVALID_ARGUMENT;
+    e->err.clear();
+    *d_out = nullptr;
+    HIP_TRY(e, hipSetDevice(e->device));
+    HIP_TRY(e, hipMalloc(d_out, bytes ? bytes : 16));
+    return ALGA_OK;
+}
+
+void alga_device_free(alga_engine *e, void *d_ptr) {
+    if (!e || !d_ptr) return;
+    (void) hipSetDevice(e->device);
+    (void) hipFree(d_ptr);
+}
+
+int alga_copy_to_device(alga_engine *e, void *d_dst, const void *src, size_t bytes) {
+    if (!e) return ALGA_ERR_INVALID_ARGUMENT;
+    e->err.clear();
+    if (bytes == 0) return ALGA_OK;
+    if (!d_dst || !src) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "pointers must not be NULL");
+    HIP_TRY(e, hipSetDevice(e->device));
+    HIP_TRY(e, hipMemcpy(d_dst, src, bytes, hipMemcpyHostToDevice));
+    return ALGA_OK;
+}
+
 int alga_prefsuf_last_stats(const alga_engine *e, alga_prefsuf_stats *out) {
     if (!e || !out) return ALGA_ERR_INVALID_ARGUMENT;
     *out = e->stats;

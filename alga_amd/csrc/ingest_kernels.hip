@@ -81,8 +81,12 @@ __global__ void __launch_bounds__(256) k_pp_apply(int32_t *__restrict__ len, con
         if (mark && l0 >= 0 && mark[2 * r]) { l0 = -1; removed++; }
         if (mark && l1 >= 0 && mark[2 * r + 1]) { l1 = -1; removed++; }
         len[2 * r] = l0; len[2 * r + 1] = l1;
+        // The reference's compaction looks at the EVEN node of a pair only (src/main.cpp:165-171): present -> the odd one must be
+        // present too (it asserts); absent -> the pair is dropped, whatever the odd node is.  The second case is not an input
+        // error: a read that equals its own reverse complement loses its even node as the "duplicate" of the odd one
+        // (src/IO/ReadPreprocess.cpp:13-77) and the reference then drops the read.  Both are reproduced as they are.
         keep[r] = l0 >= 0 ? 1u : 0u;
-        if (l0 >= 0 && l1 < 0) bad++;                                    // the reference asserts here (src/main.cpp:171)
+        if (l0 >= 0 && l1 < 0) bad++;
         if (l0 >= 0 && (unsigned long long) l0 > mx) mx = (unsigned long long) l0;
         if (l0 >= 0 && l1 >= 0 && (unsigned long long) l1 > mx) mx = (unsigned long long) l1;
     }

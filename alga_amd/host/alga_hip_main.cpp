@@ -10,6 +10,10 @@
 // --deserialize_graph=1 loads that file instead of running its GraphCreator (src/main.cpp:242) and carries on with
 // the unchanged simplifier / contig stages; `--alga=` does that hand-off in one go.
 // Both spellings of the error-rate option are accepted (the reference registers `error_rate` only, src/Params.cpp:226).
+#include <spawn.h>
+#include <sys/wait.h>
+#include <unistd.h>
+
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -53,11 +57,20 @@ int main(int argc, char **argv) {
         else { fprintf(stderr, "alga_hip: unrecognized option '%s'\n", a); return 2; }
         // the hand-off to stock ALGA drops the error-rate option: the supplement it switches on (src/Params.cpp:357-359) has
         // already run here and nothing downstream reads the rate
+        // ... and --serialize / --deserialize_graph: the hand-off always goes through the dump this program writes
         const bool is_er = !strncmp(a, "--error_rate", 12) || !strncmp(a, "--error-rate", 12) || !strncmp(a, "--er=", 5);
-        if (strncmp(a, "--device", 8) && strncmp(a, "--alga", 6) && !is_er) { passthrough.push_back(a); if (!strcmp(a, "-l")) passthrough.push_back(argv[i]); }
+        const bool is_ser = !strncmp(a, "--serialize", 11) || !strncmp(a, "--deserialize_graph", 19);
+        if (strncmp(a, "--device", 8) && strncmp(a, "--alga", 6) && !is_er && !is_ser) { passthrough.push_back(a); if (!strcmp(a, "-l")) passthrough.push_back(argv[i]); }
     }
     if (file1.empty()) { fprintf(stderr, "\nERROR - PLEASE PROVIDE THE INPUT FILE using --file1 option!\n"); return 1; }
     if (output.empty()) { fprintf(stderr, "\nERROR - PLEASE PROVIDE THE OUTPUT FILE NAME!\n"); return 1; }
+    const std::string graph = alga_host::test_name(file1, ip.scale, ip.remove_reads_with_n) + "_beforeSimplifier.graph";
+    if (!alga_exe.empty()) {
+        // The hand-off is the dump: it is always written, and a file of that name left behind by an earlier run must not be
+        // what stock ALGA loads if this run fails half-way (src/main.cpp:241-242 falls back to its own CPU creator without one).
+        serialize = 1;
+        (void) unlink(graph.c_str());
+    }
     auto t0 = clk::now();
     // stage 1 on the host cores: records -> packed node rows (src/IO/InputReader.cpp)
     alga_host::Parsed parsed;
@@ -101,20 +114,29 @@ int main(int argc, char **argv) {
     auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     fprintf(stderr, "parse %.1f ms (host), duplicate/prefix removal %.1f ms wall (device %.3f ms), overlap graph %.1f ms wall (device %.3f ms: seed %.3f probe %.3f group %.3f reduce %.3f emit %.3f)\n",
             ms(t0, t1), ms(t1, t1b), nodes.ms_device, ms(t1b, t2), st.ms_total, st.ms_seed, st.ms_probe, st.ms_group, st.ms_reduce, st.ms_emit);
-    std::string graph = alga_host::test_name(file1, ip.scale, ip.remove_reads_with_n) + "_beforeSimplifier.graph";
     if (serialize) {
         int rc = alga_write_graph(graph.c_str(), nodes.n, final_edges.data(), n_final);
         if (rc != ALGA_OK) { fprintf(stderr, "cannot write %s\n", graph.c_str()); return 1; }
         fprintf(stderr, "Graph serialized! -> %s\n", graph.c_str());
     }
+    final_edges.clear(); final_edges.shrink_to_fit();
+    alga_engine_destroy(engine);                           // the engine and its HBM buffers do not outlive the graph
     if (!alga_exe.empty()) {
-        std::string cmd = "'" + alga_exe + "'";
-        for (const std::string &a : passthrough) cmd += " '" + a + "'";
-        cmd += " --deserialize_graph=1";
-        fprintf(stderr, "handing over to the unchanged simplifier / contig stages: %s\n", cmd.c_str());
-        int rc = system(cmd.c_str());
-        return rc == 0 ? 0 : 1;
+        // argv vector, no shell: nothing in a file name is interpreted
+        std::vector<std::string> args{alga_exe};
+        for (const std::string &a : passthrough) args.push_back(a);
+        args.push_back("--deserialize_graph=1");
+        std::vector<char *> av;
+        std::string shown;
+        for (std::string &a : args) { av.push_back(&a[0]); shown += (shown.empty() ? "" : " ") + a; }
+        av.push_back(nullptr);
+        fprintf(stderr, "handing over to the unchanged simplifier / contig stages: %s\n", shown.c_str());
+        pid_t pid = 0;
+        extern char **environ;
+        if (posix_spawn(&pid, alga_exe.c_str(), nullptr, nullptr, av.data(), environ) != 0) { fprintf(stderr, "alga_hip: cannot start %s\n", alga_exe.c_str()); return 1; }
+        int status = 0;
+        if (waitpid(pid, &status, 0) < 0) return 1;
+        return (WIFEXITED(status) && WEXITSTATUS(status) == 0) ? 0 : 1;
     }
-    alga_engine_destroy(engine);
     return 0;
 }

@@ -153,6 +153,11 @@ int  alga_prefsuf_build_device(alga_engine *e, const alga_nodes *nodes, const al
  * are plain C/C++ without the HIP headers. */
 int  alga_copy_to_host(alga_engine *e, void *dst, const void *d_src, size_t bytes);
 
+/* Plain device buffers for callers without the HIP headers (e.g. alignFrom / alignTo masks next to a device-resident node set). */
+int  alga_device_alloc(alga_engine *e, size_t bytes, void **d_out);
+void alga_device_free(alga_engine *e, void *d_ptr);
+int  alga_copy_to_device(alga_engine *e, void *d_dst, const void *src, size_t bytes);
+
 /* Counters and per-phase device times of the last build call on `e`. */
 int  alga_prefsuf_last_stats(const alga_engine *e, alga_prefsuf_stats *out);
 

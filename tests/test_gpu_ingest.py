@@ -100,3 +100,15 @@ def test_degenerate_inputs(eng):
         eng.preprocess_nodes(np.zeros((3, 4), np.uint32), np.zeros(3, np.int32))                           # odd node count
     with pytest.raises(alga_amd.AlgaError):
         eng.preprocess_nodes(np.zeros((2, 1), np.uint32), np.array([40, 40], np.int32))                    # rows too short for the lengths
+
+
+def test_read_without_its_twin(eng):
+    # the reference's compaction looks at the even node of a pair (src/main.cpp:165-171): present without the odd one -> it asserts;
+    # absent -> the pair is dropped silently (what happens to a read that equals its own reverse complement)
+    rows = np.zeros((4, 4), np.uint32)
+    rows[:, 0] = [0x1234567, 0x7654321, 0x2222222, 0x1111111]
+    with pytest.raises(alga_amd.AlgaError) as ei:
+        eng.preprocess_nodes(rows, np.array([40, -1, 40, 40], np.int32), remove_pref_reads=3)
+    assert ei.value.code == -1
+    ds = eng.preprocess_nodes(rows, np.array([-1, 40, 40, 40], np.int32), remove_pref_reads=3)
+    assert ds.n == 2
