@@ -388,6 +388,8 @@ void alga_engine_destroy(alga_engine *e) {
                       &e->pk_flag, &e->pk_pos, &e->pk_edges[0], &e->pk_edges[1], &e->pk_rowptr, &e->pk_deg, &e->pk_mask, &e->pk_cnt, &e->pk_io, &e->pk_io2, &e->pk_tips, &e->pk_heads, &e->pp_rows, &e->pp_len, &e->pp_perm[0], &e->pp_perm[1], &e->pp_keys[0], &e->pp_keys[1], &e->pp_mark,
                       &e->pp_keep, &e->pp_pos, &e->pp_out_rows, &e->pp_out_len, &e->pp_out_pair, &e->pp_tally};
     for (DevBuf *b : bufs) alga_release(*b);
+    alga_release(e->up_raw);
+    alga_staging_release(e);
     if (e->h_counters) (void) hipHostFree(e->h_counters);
     for (int i = 0; i < EV_COUNT; i++) if (e->ev[i]) (void) hipEventDestroy(e->ev[i]);
     if (e->own_stream) (void) hipStreamDestroy(e->own_stream);
@@ -485,45 +487,48 @@ int alga_prefsuf_build_host(alga_engine *e, const alga_nodes *nodes, const alga_
         if ((int64_t) blocks_of(max_len) > (int64_t) nodes->stride_words)
             return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "stride_words is smaller than the longest read needs");
     }
-    // rows are re-strided on the way up (hbm_row_stride): 16-byte aligned rows that never straddle a 64-byte line take the wide-load kernels
+    // Rows travel at the caller's stride through pinned staging buffers (staging.hip) and are re-strided on the DEVICE to the
+    // engine's layout (hbm_row_stride: 16-byte aligned rows that never straddle a 64-byte line take the wide-load kernels).
     const int stride_up = alga::hbm_row_stride(nodes->stride_words);
     const size_t wbytes = n * (size_t) stride_up * sizeof(uint32_t);
+    const size_t raw_bytes = n * (size_t) nodes->stride_words * sizeof(uint32_t);
     if ((rc = alga_ensure(e, e->up_words, wbytes))) return rc;
     if ((rc = alga_ensure(e, e->up_len, n * sizeof(int32_t)))) return rc;
     alga_nodes dn = *nodes;
     if (n) {
-        if (stride_up != nodes->stride_words) HIP_TRY(e, hipMemsetAsync(e->up_words.p, 0, wbytes, s));
-        HIP_TRY(e, hipMemcpy2DAsync(e->up_words.p, (size_t) stride_up * 4, nodes->words, (size_t) nodes->stride_words * 4,
-                                    (size_t) nodes->stride_words * 4, n, hipMemcpyHostToDevice, s));
-        HIP_TRY(e, hipMemcpyAsync(e->up_len.p, nodes->len, n * sizeof(int32_t), hipMemcpyHostToDevice, s));
+        HIP_TRY(e, hipStreamSynchronize(s));                       // nothing of an earlier call still reads the upload buffers
+        if (stride_up != nodes->stride_words) {
+            if ((rc = alga_ensure(e, e->up_raw, raw_bytes))) return rc;
+            if ((rc = alga_staged_h2d(e, e->up_raw.p, nodes->words, raw_bytes))) return rc;
+            launch_restride((const uint32_t *) e->up_raw.p, nodes->stride_words, (uint32_t *) e->up_words.p, stride_up, (uint64_t) n, s);
+            if ((rc = alga_check_launch(e, "k_restride"))) return rc;
+        } else if ((rc = alga_staged_h2d(e, e->up_words.p, nodes->words, raw_bytes))) return rc;
+        if ((rc = alga_staged_h2d(e, e->up_len.p, nodes->len, n * sizeof(int32_t)))) return rc;
     }
     dn.stride_words = stride_up;
     dn.words = (const uint32_t *) e->up_words.p;
     dn.len = (const int32_t *) e->up_len.p;
     if (nodes->align_from) {
         if ((rc = alga_ensure(e, e->up_from, n))) return rc;
-        if (n) HIP_TRY(e, hipMemcpyAsync(e->up_from.p, nodes->align_from, n, hipMemcpyHostToDevice, s));
+        if (n && (rc = alga_staged_h2d(e, e->up_from.p, nodes->align_from, n))) return rc;
         dn.align_from = (const uint8_t *) e->up_from.p;
     }
     if (nodes->align_to) {
         if ((rc = alga_ensure(e, e->up_to, n))) return rc;
-        if (n) HIP_TRY(e, hipMemcpyAsync(e->up_to.p, nodes->align_to, n, hipMemcpyHostToDevice, s));
+        if (n && (rc = alga_staged_h2d(e, e->up_to.p, nodes->align_to, n))) return rc;
         dn.align_to = (const uint8_t *) e->up_to.p;
     }
     const alga_edge *d_edges = nullptr;
     uint64_t E = 0;
     if ((rc = alga_prefsuf_build_device(e, &dn, p, (void *) s, &d_edges, &E))) return rc;
-    alga_edge *h = (alga_edge *) malloc((size_t) (E ? E : 1) * sizeof(alga_edge));
+    alga_edge *h = (alga_edge *) alga_host_list_take(e, (size_t) (E ? E : 1) * sizeof(alga_edge));
     if (!h) return alga_fail(e, ALGA_ERR_OUT_OF_MEMORY, "host edge buffer");
-    if (E) {
-        hipError_t err = hipMemcpy(h, d_edges, (size_t) E * sizeof(alga_edge), hipMemcpyDeviceToHost);
-        if (err != hipSuccess) { free(h); return alga_fail(e, ALGA_ERR_HIP, "copy edges to host", err); }
-    }
+    if (E && (rc = alga_staged_d2h(e, h, d_edges, (size_t) E * sizeof(alga_edge)))) { alga_host_list_give(e, h); return rc; }
     *edges = h; *n_edges = E;
     return ALGA_OK;
 }
 
-void alga_free_edges(alga_engine *e, alga_edge *edges) { (void) e; free(edges); }
+void alga_free_edges(alga_engine *e, alga_edge *edges) { alga_host_list_give(e, edges); }
 
 int alga_copy_to_host(alga_engine *e, void *dst, const void *d_src, size_t bytes) {
     if (!e) return ALGA_ERR_INVALID_ARGUMENT;

@@ -4,6 +4,7 @@
 
 #include <cstdio>
 #include <string>
+#include <unordered_map>
 
 #include "../../include/alga_amd.h"
 #include "prefsuf_common.h"
@@ -15,6 +16,7 @@ struct DevBuf {
 };
 
 enum { EV_START = 0, EV_SEED, EV_PROBE, EV_GROUP, EV_REDUCE, EV_EMIT, EV_COUNT };
+constexpr int ALGA_STAGE_THREADS = 8;      // worker threads (pinned buffer pairs, streams) of the staged host <-> HBM copies
 
 struct alga_engine {
     int         device = -1;
@@ -40,6 +42,17 @@ struct alga_engine {
            pk_mask, pk_cnt, pk_io, pk_io2, pk_tips, pk_heads;
     // duplicate / prefix-read removal (engine_ingest.hip)
     DevBuf pp_rows, pp_len, pp_perm[2], pp_keys[2], pp_mark, pp_keep, pp_pos, pp_out_rows, pp_out_len, pp_out_pair, pp_tally;
+    // staged host <-> HBM copies (staging.hip)
+    bool        stage_ready = false;
+    void       *stage_pin[ALGA_STAGE_THREADS][2] = {};
+    hipEvent_t  stage_ev[ALGA_STAGE_THREADS][2] = {};
+    hipStream_t stage_stream[ALGA_STAGE_THREADS] = {};
+    DevBuf      up_raw;                        // the caller's rows at the caller's stride, before the device re-stride
+    // host edge lists handed out by the *_host entry points: capacity of every live one; one released list is kept for the
+    // next call (its pages are already mapped: a fresh 1 GB malloc costs more in page faults than the copy into it)
+    std::unordered_map<void *, size_t> host_lists;
+    void       *host_spare = nullptr;
+    size_t      host_spare_cap = 0;
     unsigned long long *h_counters = nullptr;  // pinned, CNT_TOTAL + 2 entries
     uint64_t    rec_cap_hint = 0, rec_cap_hint_local = 0;
     alga_prefsuf_stats stats;
@@ -73,6 +86,12 @@ inline void alga_release(DevBuf &b) {
     if (b.p) (void) hipFree(b.p);
     b.p = nullptr; b.cap = 0;
 }
+
+int  alga_staged_h2d(alga_engine *e, void *d_dst, const void *h_src, size_t bytes);   // staging.hip: blocking
+int  alga_staged_d2h(alga_engine *e, void *h_dst, const void *d_src, size_t bytes);
+void alga_staging_release(alga_engine *e);
+void *alga_host_list_take(alga_engine *e, size_t bytes);
+void alga_host_list_give(alga_engine *e, void *p);
 
 inline int alga_check_launch(alga_engine *e, const char *what) {
     hipError_t err = hipGetLastError();

@@ -320,11 +320,11 @@ int alga_pkb_supplement_host(alga_engine *e, const alga_nodes *nodes, const alga
     const alga_edge *d_out = nullptr;
     uint64_t m = 0;
     if ((rc = supplement_device_impl(e, &dn, p, (const alga_edge *) e->pk_io.p, n_edges_in, s, &d_out, &m))) return rc;
-    alga_edge *h = (alga_edge *) malloc((size_t) (m ? m : 1) * sizeof(alga_edge));
+    alga_edge *h = (alga_edge *) alga_host_list_take(e, (size_t) (m ? m : 1) * sizeof(alga_edge));
     if (!h) return alga_fail(e, ALGA_ERR_OUT_OF_MEMORY, "host edge buffer");
     if (m) {
         hipError_t err = hipMemcpy(h, d_out, (size_t) m * sizeof(alga_edge), hipMemcpyDeviceToHost);
-        if (err != hipSuccess) { free(h); return alga_fail(e, ALGA_ERR_HIP, "copy edges to host", err); }
+        if (err != hipSuccess) { alga_host_list_give(e, h); return alga_fail(e, ALGA_ERR_HIP, "copy edges to host", err); }
     }
     *edges_out = h; *n_edges_out = m;
     return ALGA_OK;

@@ -9,6 +9,7 @@ namespace alga {
 
 struct alga_edge_dev { int32_t src, dst, offset; }; // layout == alga_edge of include/alga_amd.h
 
+void launch_restride(const uint32_t *in, int stride_in, uint32_t *out, int stride_out, uint64_t n, hipStream_t s);
 void launch_node_stats(const NodesDev &nd, unsigned long long *counters, int *max_len, hipStream_t s);
 
 uint32_t seed_buckets_for(uint64_t live_nodes, int fill_x10);

@@ -957,10 +957,25 @@ __global__ void __launch_bounds__(256) k_local_emit_records(int32_t src_base, co
     }
 }
 
+// rows at the caller's stride -> rows at the engine's HBM stride (zero padded); one thread per output word
+__global__ void __launch_bounds__(256) k_restride(const uint32_t *__restrict__ in, int stride_in, uint32_t *__restrict__ out, int stride_out, uint64_t n) {
+    const uint64_t total = n * (uint64_t) stride_out;
+    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t) gridDim.x * blockDim.x) {
+        const uint64_t r = i / (uint64_t) stride_out;
+        const int c = (int) (i - r * (uint64_t) stride_out);
+        out[i] = c < stride_in ? in[r * (uint64_t) stride_in + c] : 0u;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // launch wrappers (host)
 // ------------------------------------------------------------------------------------------
 static inline unsigned grid_for(uint64_t n, int block) { return (unsigned) ((n + (uint64_t) block - 1) / (uint64_t) block); }
+
+void launch_restride(const uint32_t *in, int stride_in, uint32_t *out, int stride_out, uint64_t n, hipStream_t s) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_restride, dim3((unsigned) std::min<uint64_t>((n * (uint64_t) stride_out + 255) / 256, 1u << 16)), dim3(256), 0, s, in, stride_in, out, stride_out, n);
+}
 
 void launch_node_stats(const NodesDev &nd, unsigned long long *counters, int *max_len, hipStream_t s) {
     if (nd.n <= 0) return;

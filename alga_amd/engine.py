@@ -350,6 +350,26 @@ class Engine:
         finally:
             self._lib.alga_free_edges(self._h, out)
 
+    def prefsuf_host_timed(self, words, lens, min_overlap, rsoe_min_overlap, repeat=3):
+        """Wall time of the C call alone (alga_prefsuf_build_host + alga_free_edges; no Python-side copy of the result):
+        -> (best seconds, n_edges)."""
+        import time
+        words = np.ascontiguousarray(words, dtype=np.uint32)
+        lens = np.ascontiguousarray(lens, dtype=np.int32)
+        n = int(lens.shape[0])
+        nd = _Nodes(words.ctypes.data, int(words.shape[1]), lens.ctypes.data, n, None, None)
+        p = self.params(min_overlap, rsoe_min_overlap)
+        best, m_out = None, 0
+        for _ in range(repeat):
+            out, m = C.c_void_p(), C.c_uint64()
+            t = time.perf_counter()
+            self._check(self._lib.alga_prefsuf_build_host(self._h, C.byref(nd), C.byref(p), C.byref(out), C.byref(m)))
+            dt = time.perf_counter() - t
+            self._lib.alga_free_edges(self._h, out)
+            best = dt if best is None else min(best, dt)
+            m_out = int(m.value)
+        return best, m_out
+
     # ---- device-resident node set (torch tensors on this engine's device) --------------------
     @staticmethod
     def _nodes_from_torch(words, lens, align_from=None, align_to=None):

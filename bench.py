@@ -242,15 +242,12 @@ def main():
             if host_words is None:
                 host_words = d_words.cpu().numpy().view(np.uint32)
                 host_lens = d_lens.cpu().numpy()
-            ts = []
-            for _ in range(3):
-                t = time.perf_counter()
-                he = eng.prefsuf_host(host_words, host_lens, lo, rs)
-                ts.append(time.perf_counter() - t)
-            out["pcie_inclusive"] = {"ms_per_graph": min(ts) * 1e3, "edges_per_sec": len(he) / min(ts),
-                                     "edges_equal_resident": bool(len(he) == int(n_edges)),
-                                     "note": "alga_prefsuf_build_host: H2D of the packed reads + build + D2H of the edges, best of 3"}
-            del he
+            best, m_host = eng.prefsuf_host_timed(host_words, host_lens, lo, rs, repeat=3)
+            out["pcie_inclusive"] = {"ms_per_graph": best * 1e3, "edges_per_sec": m_host / best,
+                                     "edges_equal_resident": bool(m_host == int(n_edges)),
+                                     "host_bytes_in": int(host_words.nbytes + host_lens.nbytes), "host_bytes_out": int(m_host) * 12,
+                                     "note": "alga_prefsuf_build_host from pageable host arrays: staged H2D of the packed reads (pinned buffers, "
+                                             "8 copy threads) + build + staged D2H of the edges; wall time of the C call, best of 3"}
         if not args.no_cpu_baseline and world == 1:        # the CPU baseline is a rank-0, N=1 measurement
             try:
                 cores = len(os.sched_getaffinity(0))
