@@ -389,6 +389,7 @@ void alga_engine_destroy(alga_engine *e) {
                       &e->pp_keep, &e->pp_pos, &e->pp_out_rows, &e->pp_out_len, &e->pp_out_pair, &e->pp_tally};
     for (DevBuf *b : bufs) alga_release(*b);
     alga_release(e->up_raw);
+    for (DevBuf *b : {&e->sp_rowptr, &e->sp_sorted, &e->sp_list, &e->sp_cnt, &e->sp_orow, &e->sp_out, &e->sp_in}) alga_release(*b);
     alga_staging_release(e);
     if (e->h_counters) (void) hipHostFree(e->h_counters);
     for (int i = 0; i < EV_COUNT; i++) if (e->ev[i]) (void) hipEventDestroy(e->ev[i]);

@@ -103,7 +103,7 @@ EXPORTS = ["alga_abi_version", "alga_engine_set_option", "alga_engine_create", "
            "alga_prefsuf_reduce_device", "alga_prefsuf_build_range_device", "alga_write_graph", "alga_ingest_default_params", "alga_ingest_files",
            "alga_free_node_set", "alga_sort_records_device", "alga_sort_edges_device", "alga_pkb_derive_params",
            "alga_can_align_batch_host", "alga_li_kmers_host", "alga_pkb_supplement_host", "alga_pkb_supplement_device",
-           "alga_pkb_last_stats", "alga_parse_files", "alga_free_parsed_reads", "alga_preprocess_nodes", "alga_copy_to_host", "alga_device_alloc", "alga_device_free", "alga_copy_to_device"]
+           "alga_pkb_last_stats", "alga_parse_files", "alga_free_parsed_reads", "alga_preprocess_nodes", "alga_copy_to_host", "alga_device_alloc", "alga_device_free", "alga_copy_to_device", "alga_cut_triangles_device", "alga_cut_triangles_host"]
 
 
 def library_path():
@@ -174,6 +174,9 @@ def load_library():
     lib.alga_free_parsed_reads.restype = None
     lib.alga_preprocess_nodes.argtypes = [C.c_void_p, C.POINTER(PreprocessInput), C.POINTER(DeviceNodeSet)]
     lib.alga_copy_to_host.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.alga_cut_triangles_host.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_uint64, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    lib.alga_cut_triangles_device.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p),
+                                              C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     _LIB = lib
     return lib
 
@@ -502,6 +505,26 @@ class Engine:
         self._check(self._lib.alga_pkb_last_stats(self._h, C.byref(st)))
         return dict(kmers=list(st.kmers), groups=list(st.groups), can_align_calls=list(st.can_align_calls),
                     edges_after=list(st.edges_after), max_group=st.max_group, ms_total=st.ms_total)
+
+    # ---- first simplifier step ----------------------------------------------------------------
+    def cut_triangles_host(self, n_nodes, edges, max_offset_parallel_paths):
+        """edges [m, 3] sorted by (src, dst) -> the graph after sortEdgesByIncreasingOffset + cutNonAndWeaklyMetricTriangles,
+        lists in the reference's order."""
+        e = np.ascontiguousarray(edges, dtype=np.int32).reshape(-1, 3)
+        out, m = C.c_void_p(), C.c_uint64()
+        self._check(self._lib.alga_cut_triangles_host(self._h, int(n_nodes), e.ctypes.data, len(e), int(max_offset_parallel_paths), C.byref(out), C.byref(m)))
+        try:
+            r = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_int32)), shape=(max(m.value, 1) * 3,))[: m.value * 3]
+            return r.reshape(-1, 3).copy()
+        finally:
+            self._lib.alga_free_edges(self._h, out)
+
+    def cut_triangles_device(self, n_nodes, d_edges_ptr, n_edges, max_offset_parallel_paths, stream=None):
+        """device edge list (pointer) -> (device pointer, n_edges_out, n_removed); engine-owned."""
+        out, m, rem = C.c_void_p(), C.c_uint64(), C.c_uint64()
+        self._check(self._lib.alga_cut_triangles_device(self._h, int(n_nodes), C.c_void_p(d_edges_ptr), int(n_edges), int(max_offset_parallel_paths),
+                                                        C.c_void_p(stream or 0), C.byref(out), C.byref(m), C.byref(rem)))
+        return out.value, int(m.value), int(rem.value)
 
     def write_graph(self, path, n_nodes, edges):
         edges = np.ascontiguousarray(edges, dtype=np.int32).reshape(-1, 3)

@@ -327,6 +327,20 @@ typedef struct {
 
 int  alga_preprocess_nodes(alga_engine *e, const alga_preprocess_input *in, alga_device_node_set *out);
 
+/* ---- first step of the graph simplifier ---------------------------------------------------------
+ * What the caller does first with the graph on the PrefSuf path (GraphSimplifier::simplifyGraphOld,
+ * src/GraphSimplifiers/GraphSimplifier.cpp:90-125): Graph::sortEdgesByIncreasingOffset (src/DataStructures/Graph.cpp:584-614) and
+ * GraphSimplifier::cutNonAndWeaklyMetricTriangles (src/GraphSimplifiers/GraphSimplifier.cpp:228-348): an edge i -> b of weight
+ * w <= max_offset_parallel_paths (Params::MAX_OFFSET_PARALLEL_PATHS = max(250, int(1.75 * LEN)), src/main.cpp:95) goes when the
+ * shortest two-edge path i -> a -> b weighs exactly w.  In: edges grouped by src, lists sorted by (dst, offset) -- what the
+ * builds above return.  Out: grouped by src, every list in the order the reference leaves it in (sorted by (offset, dst), then
+ * Graph::removeDirectedEdge's swap-with-last removals, src/DataStructures/Graph.cpp:96-119), so a Graph::V filled from it is the
+ * reference's graph after that step, entry for entry.  *d_edges_out: engine-owned, valid until the next call of this function. */
+int  alga_cut_triangles_device(alga_engine *e, int32_t n_nodes, const alga_edge *d_edges, uint64_t n_edges, int32_t max_offset_parallel_paths,
+                               void *hip_stream, const alga_edge **d_edges_out, uint64_t *n_edges_out, uint64_t *n_removed /* may be NULL */);
+int  alga_cut_triangles_host(alga_engine *e, int32_t n_nodes, const alga_edge *edges, uint64_t n_edges, int32_t max_offset_parallel_paths,
+                             alga_edge **edges_out, uint64_t *n_edges_out);     /* release with alga_free_edges() */
+
 /* ---- graph dump: the reference's own checkpoint format ------------------------------------ */
 /* Graph::serializeGraph (src/DataStructures/Graph.cpp:269-297): u32 n; n x {i32 id; i32 deg;
  * deg x {i32 neighbour; i32 offset}}, native endian.  Stock ALGA loads it with

@@ -674,6 +674,57 @@ void oracle_free_graph(oracle_graph *g) {
 
 /* Graph::serializeGraph, src/DataStructures/Graph.cpp:269-297:
  *   u32 n; n x { i32 id; i32 deg; deg x { i32 neighbour; i32 offset } }   (native endian) */
+/* ---- first simplifier step: edges sorted by increasing offset, non- and weakly-metric triangles cut -------------------- */
+static int cmp_off_dst(const void *a, const void *b) {          /* Graph.cpp:606-609 */
+    const oracle_edge *x = (const oracle_edge *) a, *y = (const oracle_edge *) b;
+    if (x->offset != y->offset) return x->offset < y->offset ? -1 : 1;
+    return x->dst < y->dst ? -1 : (x->dst > y->dst ? 1 : 0);
+}
+
+int oracle_cut_triangles(int32_t n, const oracle_edge *edges_in, int64_t m_in, int32_t mopp, oracle_edge **edges_out, int64_t *m_out) {
+    int64_t *row = (int64_t *) calloc((size_t) n + 2, sizeof(int64_t));
+    oracle_edge *e = (oracle_edge *) malloc((size_t) (m_in ? m_in : 1) * sizeof(oracle_edge));
+    oracle_edge *out = (oracle_edge *) malloc((size_t) (m_in ? m_in : 1) * sizeof(oracle_edge));
+    if (!row || !e || !out) { free(row); free(e); free(out); return -1; }
+    for (int64_t k = 0; k < m_in; k++) row[edges_in[k].src + 1]++;
+    for (int32_t i = 0; i < n; i++) row[i + 1] += row[i];
+    {   /* adjacency lists, then sortEdgesByIncreasingOffset */
+        int64_t *cur = (int64_t *) malloc((size_t) (n + 1) * sizeof(int64_t));
+        if (!cur) { free(row); free(e); free(out); return -1; }
+        memcpy(cur, row, (size_t) (n + 1) * sizeof(int64_t));
+        for (int64_t k = 0; k < m_in; k++) e[cur[edges_in[k].src]++] = edges_in[k];
+        free(cur);
+        for (int32_t i = 0; i < n; i++) qsort(e + row[i], (size_t) (row[i + 1] - row[i]), sizeof(oracle_edge), cmp_off_dst);
+    }
+    int64_t m = 0;
+    for (int32_t i = 0; i < n; i++) {
+        const int64_t b0 = row[i], deg = row[i + 1] - row[i];
+        oracle_edge *L = out + m;                                /* the list of i as the reference will leave it */
+        memcpy(L, e + b0, (size_t) deg * sizeof(oracle_edge));
+        int64_t size = deg;
+        for (int64_t k = 0; k < deg; k++) {                      /* GraphSimplifier.cpp:297-318, decisions on the unchanged graph */
+            const int32_t b = e[b0 + k].dst, w = e[b0 + k].offset;
+            if (w > mopp) continue;                              /* :301-303 */
+            int have = 0; int32_t best = 0;                      /* dst[b]: shortest two-edge path i -> a -> b (:283-295) */
+            for (int64_t k2 = 0; k2 < deg; k2++) {
+                const int32_t a = e[b0 + k2].dst, w1 = e[b0 + k2].offset;
+                for (int64_t j = row[a]; j < row[a + 1]; j++)
+                    if (e[j].dst == b) { const int32_t d = w1 + e[j].offset; if (!have || d < best) { best = d; have = 1; } }
+            }
+            if (have && best == w) {                             /* :310: equal distances only */
+                /* removeDirectedEdge(i, b), Graph.cpp:104-114: every entry with that neighbour, from the back, swapped with the last */
+                int64_t p = size - 1;
+                for (int64_t x = size - 1; x >= 0; x--)
+                    if (L[x].dst == b) { oracle_edge t = L[x]; L[x] = L[p]; L[p] = t; size--; p--; }
+            }
+        }
+        m += size;
+    }
+    free(row); free(e);
+    *edges_out = out; *m_out = m;
+    return 0;
+}
+
 int oracle_write_graph(const char *path, int32_t n, const oracle_edge *edges, int64_t n_edges) {
     FILE *f = fopen(path, "wb");
     if (!f) return -1;

@@ -102,6 +102,14 @@ int  oracle_supplement(const uint32_t *words, const int32_t *len, int32_t n, int
                        const oracle_pkb_params *p, int32_t kmer_length_bucket, int32_t flags, oracle_edge **edges_out, int64_t *m_out,
                        int64_t *can_align_calls);
 
+/* First step of the simplifier on the PrefSuf path (src/GraphSimplifiers/GraphSimplifier.cpp:90-125 simplifyGraphOld):
+ * Graph::sortEdgesByIncreasingOffset (src/DataStructures/Graph.cpp:584-614) and GraphSimplifier::cutNonAndWeaklyMetricTriangles
+ * (src/GraphSimplifiers/GraphSimplifier.cpp:228-348).  edges_in: any order, grouped or not; *edges_out: grouped by src, every
+ * adjacency list in the order the reference leaves it (sorted by (offset, dst), then Graph::removeDirectedEdge's swap-with-last
+ * removals in list order, src/DataStructures/Graph.cpp:96-119).  Pinned by tests/golden/ after-cut dumps made through oracle/ref_driver.cpp. */
+int  oracle_cut_triangles(int32_t n, const oracle_edge *edges_in, int64_t m_in, int32_t max_offset_parallel_paths,
+                          oracle_edge **edges_out, int64_t *m_out);
+
 /* Graph::serializeGraph wire format (src/DataStructures/Graph.cpp:269-297). */
 int  oracle_write_graph(const char *path, int32_t n, const oracle_edge *edges, int64_t n_edges);
 

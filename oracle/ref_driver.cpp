@@ -13,6 +13,11 @@
 //       Read::getKmers for every live node under the 4 rotations of Read::priorities (src/GraphCreators/GraphCreatorLI.cpp:18-28)
 //       -> per node and rotation: count, then (hash u64, indInRead i32) pairs, in the order the reference returns them.
 //
+//   ref_driver triangles <graph_in> <graph_out> <max_offset_parallel_paths>
+//       the first step of the simplifier on a graph dump (src/GraphSimplifiers/GraphSimplifier.cpp:90-125: the PrefSuf path of
+//       simplifyGraphOld): Graph::sortEdgesByIncreasingOffset, GraphSimplifier::cutNonAndWeaklyMetricTriangles; writes the
+//       resulting graph in the reference's dump format (in-list order as the reference leaves it).
+//
 // node file: i32 n, i32 W, i32 len[n], u32 words[n*W]   (reference bit layout; len 0 = nullptr)
 #include <cstdio>
 #include <cstdlib>
@@ -23,6 +28,7 @@
 
 #include <AlignmentControllers/AlignmentControllerHybrid.h>
 #include <GraphCreators/GraphCreatorLI.h>
+#include <GraphSimplifiers/GraphSimplifier.h>
 #include <Global.h>
 #include <Params.h>
 
@@ -88,6 +94,28 @@ int main(int argc, char **argv) {
         delete gc;
         fprintf(stdout, "edges_after %lld\n", (long long) G->countEdges());
         G->serializeGraph(argv[4]);
+        return 0;
+    }
+    if (mode == "triangles") {
+        if (argc != 5) die("triangles <graph_in> <graph_out> <max_offset_parallel_paths>");
+        FILE *f = fopen(argv[2], "rb");
+        if (!f) die("cannot open graph");
+        uint32_t n = 0;
+        if (fread(&n, 4, 1, f) != 1) die("short graph file");
+        fclose(f);
+        Global::READS.assign((size_t) n, nullptr);
+        Global::GRAPH = Graph((int) n);
+        Graph *G = &Global::GRAPH;
+        if (!G->deserializeGraph(argv[2])) die("cannot load graph");
+        Params::MAX_OFFSET_PARALLEL_PATHS = atoi(argv[4]);
+        const long long before = G->countEdges();
+        {
+            GraphSimplifier simplifier(Global::GRAPH, Global::READS);
+            G->sortEdgesByIncreasingOffset();
+            simplifier.cutNonAndWeaklyMetricTriangles();
+        }
+        fprintf(stdout, "edges_before %lld edges_after %lld\n", before, (long long) G->countEdges());
+        G->serializeGraph(argv[3]);
         return 0;
     }
     if (mode == "canalign") {

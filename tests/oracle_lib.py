@@ -91,6 +91,19 @@ def prefsuf(words, lens, min_overlap, rsoemo, align_from=None, align_to=None):
     return e, it, cnt
 
 
+def cut_triangles(n, edges, mopp):
+    """first simplifier step (oracle_cut_triangles) -> edges [m, 3] grouped by src, lists in the reference's order"""
+    L = lib()
+    L.oracle_cut_triangles.argtypes = [C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+    e = np.ascontiguousarray(edges, dtype=np.int32).reshape(-1, 3)
+    out, m = C.c_void_p(), C.c_int64()
+    rc = L.oracle_cut_triangles(int(n), e.ctypes.data, len(e), int(mopp), C.byref(out), C.byref(m))
+    assert rc == 0
+    res = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_int32)), shape=(max(m.value, 1) * 3,))[: m.value * 3].reshape(-1, 3).copy()
+    C.CDLL(None).free(out)
+    return res
+
+
 def graph_bytes(n, edges):
     """Graph::serializeGraph wire format (src/DataStructures/Graph.cpp:269-297) from sorted edge triples."""
     edges = np.asarray(edges, dtype=np.int32).reshape(-1, 3)
