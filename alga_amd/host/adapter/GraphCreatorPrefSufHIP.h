@@ -73,6 +73,31 @@ inline void fill_graph(Graph *G, const alga_edge *e, uint64_t m) {
     for (std::thread &x : th) x.join();
 }
 
+[[noreturn]] inline void die(alga_engine *e, const char *what, int rc);
+
+// The simplifier's first step on the GPU: replaces `G->sortEdgesByIncreasingOffset(); cutNonAndWeaklyMetricTriangles();` of
+// GraphSimplifier::simplifyGraphOld (src/GraphSimplifiers/GraphSimplifier.cpp:113-117) -- G comes back with every list in the
+// order those two calls leave it in.
+inline void first_simplifier_step(Graph *G, int hip_device = 0) {
+    const int n = G->size();
+    std::vector<alga_edge> in;
+    for (int a = 0; a < n; a++) {
+        VPII row = (*G)[a];
+        std::sort(row.begin(), row.end());                                  // (neighbour, offset): the order the engine's lists have
+        for (const PII &x : row) in.push_back(alga_edge{a, x.first, x.second});
+    }
+    alga_engine *e = nullptr;
+    int rc = alga_engine_create(hip_device, &e);
+    if (rc != ALGA_OK) die(nullptr, "no usable HIP device", rc);
+    alga_edge *out = nullptr;
+    uint64_t m = 0;
+    rc = alga_cut_triangles_host(e, n, in.data(), (uint64_t) in.size(), Params::MAX_OFFSET_PARALLEL_PATHS, &out, &m);
+    if (rc != ALGA_OK) die(e, "triangle cut", rc);
+    fill_graph(G, out, m);
+    alga_free_edges(e, out);
+    alga_engine_destroy(e);
+}
+
 [[noreturn]] inline void die(alga_engine *e, const char *what, int rc) {   // the reference's convention: cerr + exit(1)
     std::cerr << "alga_amd: " << what << ": " << (e ? alga_last_error(e) : "no engine") << " (status " << rc << ")" << std::endl;
     exit(1);

@@ -5,6 +5,10 @@
 // its headers at build time and calls its classes.
 //
 //   ref_adapter <hip|cpu> <nodes.bin> <graph_out> <min_overlap> <rsoemo> <li_kmer_length> [<error_rate_percent> <kmer_length_bucket> <graph_out2>]
+//   ref_adapter <hip|cpu> <nodes.bin> <graph_out> <min_overlap> <rsoemo> <li_kmer_length> <max_offset_parallel_paths>
+//       (8 arguments: the exact graph, then the simplifier's first step -- sortEdgesByIncreasingOffset + cutNonAndWeaklyMetricTriangles,
+//        src/GraphSimplifiers/GraphSimplifier.cpp:113-117 -- on the CPU or through alga_adapter::first_simplifier_step; <graph_out> is
+//        the graph after that step)
 //
 // The call sequence is the one of src/main.cpp:239-296 (exact graph) and, with the last three arguments, :300-347 (supplement):
 // Graph(READS.size()); new <creator>; masks for short / removed reads; startAlignmentGraphCreation(); delete;
@@ -20,6 +24,7 @@
 
 #include <GraphCreators/GraphCreatorLI.h>
 #include <GraphCreators/GraphCreatorPrefSuf.h>
+#include <GraphSimplifiers/GraphSimplifier.h>
 #include <Global.h>
 #include <Params.h>
 
@@ -47,7 +52,7 @@ static void load_nodes(const char *path) {
 }
 
 int main(int argc, char **argv) {
-    if (argc != 7 && argc != 10) die("usage: ref_adapter <hip|cpu> <nodes.bin> <graph_out> <min_overlap> <rsoemo> <li_kmer_length> [<error_rate_percent> <kmer_length_bucket> <graph_out2>]");
+    if (argc != 7 && argc != 8 && argc != 10) die("usage: ref_adapter <hip|cpu> <nodes.bin> <graph_out> <min_overlap> <rsoemo> <li_kmer_length> [<error_rate_percent> <kmer_length_bucket> <graph_out2>]");
     const bool hip = !strcmp(argv[1], "hip");
     Read::priorities = VI(4);
     std::iota(Read::priorities.begin(), Read::priorities.end(), 0);
@@ -77,8 +82,19 @@ int main(int argc, char **argv) {
     delete graphCreator;
     G->retainOnlySmallestOffset();
     fprintf(stdout, "edges %lld\n", (long long) G->countEdges());
+    if (argc == 8) {
+        // ---- the simplifier's first step (src/GraphSimplifiers/GraphSimplifier.cpp:113-117) ----
+        Params::MAX_OFFSET_PARALLEL_PATHS = atoi(argv[7]);
+        if (hip) alga_adapter::first_simplifier_step(G);
+        else {
+            GraphSimplifier simplifier(Global::GRAPH, Global::READS);
+            G->sortEdgesByIncreasingOffset();
+            simplifier.cutNonAndWeaklyMetricTriangles();
+        }
+        fprintf(stdout, "edges_after_cut %lld\n", (long long) G->countEdges());
+    }
     G->serializeGraph(argv[3]);
-    if (argc == 7) return 0;
+    if (argc <= 8) return 0;
 
     // ---- the supplement call site (src/main.cpp:300-347) ----
     Params::ERROR_RATE = atoi(argv[7]);

@@ -87,3 +87,17 @@ def test_supplement_adapter_gives_the_reference_post_supplement_graph(golden_dir
     assert "edges_after_supplement %d" % meta["edges_after"] in log
     with gzip.open(os.path.join(golden_dir, "f7_pkb.supplement.graph.gz"), "rb") as f:
         assert open(out2, "rb").read() == f.read()
+
+
+@needs_exe
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["f2_err2", "f4_varlen"])
+def test_first_simplifier_step_through_the_adapter(golden_dir, tmp_path, name):
+    import json
+    c = json.load(open(os.path.join(golden_dir, "n3_aftercut.json")))[name]
+    fx, nd, nodes = _fixture_nodes(golden_dir, name, tmp_path)
+    out = str(tmp_path / "hipcut.graph")
+    log = _run("hip", nodes, nd, out, (c["max_offset_parallel_paths"],))
+    assert "edges_after_cut %d" % c["edges_after"] in log
+    with gzip.open(os.path.join(golden_dir, name + ".aftercut.graph.gz"), "rb") as f:
+        assert open(out, "rb").read() == f.read()
