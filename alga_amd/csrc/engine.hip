@@ -389,6 +389,7 @@ void alga_engine_destroy(alga_engine *e) {
                       &e->pp_keep, &e->pp_pos, &e->pp_out_rows, &e->pp_out_len, &e->pp_out_pair, &e->pp_tally};
     for (DevBuf *b : bufs) alga_release(*b);
     alga_release(e->up_raw);
+    for (DevBuf *b : {&e->in_bytes[0], &e->in_bytes[1], &e->in_nl[0], &e->in_nl[1], &e->in_tiles, &e->in_tile_off}) alga_release(*b);
     for (DevBuf *b : {&e->sp_rowptr, &e->sp_sorted, &e->sp_list, &e->sp_cnt, &e->sp_orow, &e->sp_out, &e->sp_in}) alga_release(*b);
     alga_staging_release(e);
     if (e->h_counters) (void) hipHostFree(e->h_counters);

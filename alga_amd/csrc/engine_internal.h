@@ -53,6 +53,7 @@ struct alga_engine {
     std::unordered_map<void *, size_t> host_lists;
     void       *host_spare = nullptr;
     size_t      host_spare_cap = 0;
+    DevBuf      in_bytes[2], in_nl[2], in_tiles, in_tile_off;   // device ingest: file bytes, line ends, newline counts per tile
     DevBuf      sp_rowptr, sp_sorted, sp_list, sp_cnt, sp_orow, sp_out, sp_in;   // first simplifier step (engine_simplify.hip)
     unsigned long long *h_counters = nullptr;  // pinned, CNT_TOTAL + 2 entries
     uint64_t    rec_cap_hint = 0, rec_cap_hint_local = 0;

@@ -17,6 +17,8 @@ namespace {
 
 constexpr size_t STAGE_CHUNK = 8u << 20;        // bytes per pinned buffer
 constexpr size_t STAGE_DIRECT = 4u << 20;       // below this a plain copy is as fast
+constexpr size_t STAGE_COLD_MIN = 512u << 20;   // setting the staging up (128 MB of pinned memory, 8 streams) costs tens of ms: a first
+                                                // copy smaller than this goes the plain way (13 GB/s) and leaves it for later
 
 int ensure_staging(alga_engine *e) {
     if (e->stage_ready) return ALGA_OK;
@@ -65,7 +67,7 @@ void worker(alga_engine *e, int t, int T, char *dev, char *host, size_t bytes, b
 
 int staged_copy(alga_engine *e, void *dev, void *host, size_t bytes, bool to_device) {
     if (bytes == 0) return ALGA_OK;
-    if (bytes < STAGE_DIRECT) {
+    if (bytes < STAGE_DIRECT || (!e->stage_ready && bytes < STAGE_COLD_MIN)) {
         HIP_TRY(e, to_device ? hipMemcpy(dev, host, bytes, hipMemcpyHostToDevice) : hipMemcpy(host, dev, bytes, hipMemcpyDeviceToHost));
         return ALGA_OK;
     }

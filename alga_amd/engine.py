@@ -82,6 +82,13 @@ class DeviceNodeSet(C.Structure):
                 ("removed_prefix", C.c_int32), ("removed_short", C.c_int32), ("max_len", C.c_int32), ("ms_device", C.c_double)]
 
 
+class IngestInfo(C.Structure):
+    """alga_ingest_info"""
+    _fields_ = [("records", C.c_int64), ("removed_n", C.c_int32), ("removed_str", C.c_int32), ("LEN", C.c_int32), ("min_overlap", C.c_int32),
+                ("rsoemo", C.c_int32), ("li_kmer_length", C.c_int32), ("paired", C.c_int32), ("avg_len", C.c_double), ("ms_parse", C.c_double),
+                ("ms_preprocess", C.c_double), ("ms_upload", C.c_double)]
+
+
 class PkbParams(C.Structure):
     """alga_pkb_params"""
     _fields_ = [("min_overlap_area", C.c_int32), ("max_offset_pct", C.c_int32), ("min_identity_pct", C.c_int32),
@@ -103,7 +110,7 @@ EXPORTS = ["alga_abi_version", "alga_engine_set_option", "alga_engine_create", "
            "alga_prefsuf_reduce_device", "alga_prefsuf_build_range_device", "alga_write_graph", "alga_ingest_default_params", "alga_ingest_files",
            "alga_free_node_set", "alga_sort_records_device", "alga_sort_edges_device", "alga_pkb_derive_params",
            "alga_can_align_batch_host", "alga_li_kmers_host", "alga_pkb_supplement_host", "alga_pkb_supplement_device",
-           "alga_pkb_last_stats", "alga_parse_files", "alga_free_parsed_reads", "alga_preprocess_nodes", "alga_copy_to_host", "alga_device_alloc", "alga_device_free", "alga_copy_to_device", "alga_cut_triangles_device", "alga_cut_triangles_host"]
+           "alga_pkb_last_stats", "alga_parse_files", "alga_free_parsed_reads", "alga_preprocess_nodes", "alga_copy_to_host", "alga_device_alloc", "alga_device_free", "alga_copy_to_device", "alga_cut_triangles_device", "alga_cut_triangles_host", "alga_ingest_device"]
 
 
 def library_path():
@@ -174,6 +181,7 @@ def load_library():
     lib.alga_free_parsed_reads.restype = None
     lib.alga_preprocess_nodes.argtypes = [C.c_void_p, C.POINTER(PreprocessInput), C.POINTER(DeviceNodeSet)]
     lib.alga_copy_to_host.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.alga_ingest_device.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.POINTER(IngestParams), C.POINTER(DeviceNodeSet), C.POINTER(IngestInfo)]
     lib.alga_cut_triangles_host.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_uint64, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
     lib.alga_cut_triangles_device.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p),
                                               C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
@@ -329,6 +337,17 @@ class Engine:
         out = DeviceNodeSet()
         self._check(self._lib.alga_preprocess_nodes(self._h, C.byref(inp), C.byref(out)))
         return out
+
+    def ingest_device(self, file1, file2=None, **kw):
+        """The whole input stage on the GPU (alga_ingest_device): files -> (DeviceNodeSet, info dict); raises AlgaError -7 for the
+        inputs that stage does not take (file types other than .fasta / .fastq / .fq, remove_reads_with_n = 0)."""
+        p = IngestParams()
+        self._lib.alga_ingest_default_params(C.byref(p))
+        for k, v in kw.items():
+            setattr(p, k, v)
+        ds, info = DeviceNodeSet(), IngestInfo()
+        self._check(self._lib.alga_ingest_device(self._h, file1.encode(), (file2 or "").encode() or None, C.byref(p), C.byref(ds), C.byref(info)))
+        return ds, {k: getattr(info, k) for k, _ in IngestInfo._fields_}
 
     # ---- host buffers in, edges out (the drop-in call) --------------------------------------
     def prefsuf_host(self, words, lens, min_overlap, rsoe_min_overlap, align_from=None, align_to=None, collect_stats=False,

@@ -72,18 +72,34 @@ int main(int argc, char **argv) {
         (void) unlink(graph.c_str());
     }
     auto t0 = clk::now();
-    // stage 1 on the host cores: records -> packed node rows (src/IO/InputReader.cpp)
-    alga_host::Parsed parsed;
-    std::string err = alga_host::parse(file1, file2, ip, parsed);
-    if (!err.empty()) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
-    auto t1 = clk::now();
-    // stage 2 on the GPU: duplicate / prefix-read removal, id compaction (src/IO/ReadPreprocess.cpp, src/main.cpp:150-266);
-    // the node set stays in HBM for the graph creator
+    // Input stages (src/IO/InputReader.cpp, src/IO/ReadPreprocess.cpp, src/main.cpp:93-266) on the GPU: the host maps the files and
+    // moves their bytes, the node set stays in HBM for the graph creator.  Inputs that stage does not take (file types other than
+    // FASTA / FASTQ, random replacement of N) are parsed on the host cores and join the GPU at the duplicate / prefix removal.
     alga_engine *engine = nullptr;
     if (alga_engine_create(device, &engine) != ALGA_OK) { fprintf(stderr, "alga_amd: no usable HIP device\n"); return 1; }
-    alga_preprocess_input pin{parsed.rows.data(), parsed.W, parsed.len.data(), (int64_t) (2 * parsed.R), ip.remove_pref_reads, 3 + parsed.li_kmer_length};
+    const auto t_engine = clk::now();
     alga_device_node_set nodes;
-    if (alga_preprocess_nodes(engine, &pin, &nodes) != ALGA_OK) { fprintf(stderr, "%s\n", alga_last_error(engine)); return 1; }
+    alga_host::Parsed parsed;
+    alga_ingest_params cp;
+    alga_ingest_default_params(&cp);
+    cp.trim_left = ip.trim_left; cp.trim_right = ip.trim_right; cp.remove_reads_with_n = ip.remove_reads_with_n; cp.rna = ip.rna; cp.scale = ip.scale;
+    cp.min_overlap = ip.min_overlap; cp.rsoemo = ip.rsoemo; cp.remove_pref_reads = ip.remove_pref_reads; cp.threads = ip.threads;
+    alga_ingest_info info;
+    auto t1 = t_engine;
+    int irc = alga_ingest_device(engine, file1.c_str(), file2.empty() ? nullptr : file2.c_str(), &cp, &nodes, &info);
+    if (irc == ALGA_OK) {
+        fprintf(stderr, "device ingest: upload %.1f ms, lines + records %.1f ms, duplicate/prefix removal %.1f ms (wall)\n", info.ms_upload,
+                info.ms_parse - info.ms_upload, info.ms_preprocess);
+        parsed.records = info.records; parsed.removed_n = info.removed_n; parsed.removed_str = info.removed_str;
+        parsed.min_overlap = info.min_overlap; parsed.rsoemo = info.rsoemo; parsed.li_kmer_length = info.li_kmer_length;
+        t1 = t_engine + std::chrono::duration_cast<clk::duration>(std::chrono::duration<double, std::milli>(info.ms_parse));
+    } else if (irc == ALGA_ERR_UNSUPPORTED) {
+        std::string err = alga_host::parse(file1, file2, ip, parsed);
+        if (!err.empty()) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
+        t1 = clk::now();
+        alga_preprocess_input pin{parsed.rows.data(), parsed.W, parsed.len.data(), (int64_t) (2 * parsed.R), ip.remove_pref_reads, 3 + parsed.li_kmer_length};
+        if (alga_preprocess_nodes(engine, &pin, &nodes) != ALGA_OK) { fprintf(stderr, "%s\n", alga_last_error(engine)); return 1; }
+    } else { fprintf(stderr, "%s\n", alga_last_error(engine)); return 1; }
     auto t1b = clk::now();
     fprintf(stderr, "input read: %lld records -> %d nodes (removed: %d with N, %d STR, %d duplicate/prefix, %d too short)\n",
             (long long) parsed.records, nodes.n, parsed.removed_n, parsed.removed_str, nodes.removed_prefix, nodes.removed_short);
@@ -112,8 +128,8 @@ int main(int argc, char **argv) {
     if (n_final && alga_copy_to_host(engine, final_edges.data(), d_final, final_edges.size() * sizeof(alga_edge)) != ALGA_OK) { fprintf(stderr, "alga_amd: cannot read the edges back\n"); return 1; }
     fprintf(stderr, "Before first simplifier graph has %llu edges\n", (unsigned long long) n_final);
     auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-    fprintf(stderr, "parse %.1f ms (host), duplicate/prefix removal %.1f ms wall (device %.3f ms), overlap graph %.1f ms wall (device %.3f ms: seed %.3f probe %.3f group %.3f reduce %.3f emit %.3f)\n",
-            ms(t0, t1), ms(t1, t1b), nodes.ms_device, ms(t1b, t2), st.ms_total, st.ms_seed, st.ms_probe, st.ms_group, st.ms_reduce, st.ms_emit);
+    fprintf(stderr, "HIP start-up %.1f ms, parse %.1f ms, duplicate/prefix removal %.1f ms wall (device %.3f ms), overlap graph %.1f ms wall (device %.3f ms: seed %.3f probe %.3f group %.3f reduce %.3f emit %.3f)\n",
+            ms(t0, t_engine), ms(t_engine, t1), ms(t1, t1b), nodes.ms_device, ms(t1b, t2), st.ms_total, st.ms_seed, st.ms_probe, st.ms_group, st.ms_reduce, st.ms_emit);
     if (serialize) {
         int rc = alga_write_graph(graph.c_str(), nodes.n, final_edges.data(), n_final);
         if (rc != ALGA_OK) { fprintf(stderr, "cannot write %s\n", graph.c_str()); return 1; }

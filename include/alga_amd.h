@@ -327,6 +327,25 @@ typedef struct {
 
 int  alga_preprocess_nodes(alga_engine *e, const alga_preprocess_input *in, alga_device_node_set *out);
 
+/* ---- the whole input stage on the GPU -----------------------------------------------------------
+ * Files -> node set resident in HBM.  The host maps the files and moves their bytes; everything InputReader does per record
+ * (src/IO/InputReader.cpp:142-180,272-391: sequence line, blanks, end trimming, letter check, N / STR filters, 2-bit packing,
+ * reverse complement, [rc, r] node order, pair interleave) and the stage behind alga_preprocess_nodes run as HIP kernels.
+ * Takes .fasta (two lines per record) and .fastq / .fq (four) with remove_reads_with_n = 1, the reference's default; anything
+ * else answers ALGA_ERR_UNSUPPORTED (use alga_parse_files + alga_preprocess_nodes).  Same node set as alga_ingest_files. */
+typedef struct {
+    int64_t records;                 /* records read (both files)                                                       */
+    int32_t removed_n, removed_str;  /* nodes removed by the N / STR filters                                             */
+    int32_t LEN, min_overlap, rsoemo, li_kmer_length;   /* src/main.cpp:93-115                                          */
+    int32_t paired;
+    double  avg_len;
+    double  ms_parse, ms_preprocess; /* wall: map + upload + parse kernels; duplicate / prefix removal + compaction     */
+    double  ms_upload;               /* part of ms_parse: device buffer + file bytes to HBM                             */
+} alga_ingest_info;
+
+int  alga_ingest_device(alga_engine *e, const char *file1, const char *file2 /* may be NULL */, const alga_ingest_params *p,
+                        alga_device_node_set *out, alga_ingest_info *info);
+
 /* ---- first step of the graph simplifier ---------------------------------------------------------
  * What the caller does first with the graph on the PrefSuf path (GraphSimplifier::simplifyGraphOld,
  * src/GraphSimplifiers/GraphSimplifier.cpp:90-125): Graph::sortEdgesByIncreasingOffset (src/DataStructures/Graph.cpp:584-614) and

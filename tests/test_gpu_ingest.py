@@ -1,5 +1,6 @@
-"""GPU input stage N1 (duplicate / prefix-read removal + id compaction, alga_preprocess_nodes) against the oracle's literal
-ingest: the node set that reaches the graph creator must be identical -- rows, lengths, pairedReadOffset, counters."""
+"""GPU input stages against the oracle's literal ingest: the node set that reaches the graph creator must be identical -- rows,
+lengths, pairedReadOffset, counters -- both for N1 alone (duplicate / prefix-read removal + id compaction on host-parsed rows,
+alga_preprocess_nodes) and for the whole input stage on the GPU (N2 + N1: files in, alga_ingest_device)."""
 import os
 
 import numpy as np
@@ -29,6 +30,14 @@ def _device_nodes(eng, pr, mode=None):
     return ds, words, lens, pair
 
 
+def _read_back(ds):
+    n, st = ds.n, ds.stride_words
+    words = device_view(ds.d_words, (n, st)).cpu().numpy().view(np.uint32) if n else np.zeros((0, st), np.uint32)
+    lens = device_view(ds.d_len, (n,)).cpu().numpy() if n else np.zeros(0, np.int32)
+    pair = device_view(ds.d_pair_off, ((n + 3) // 4,)).cpu().numpy().view(np.uint8)[:n] if n else np.zeros(0, np.uint8)
+    return words, lens, pair
+
+
 def _same_nodes(want, words, lens, pair):
     assert want["n"] == len(lens)
     assert (want["len"] == lens).all()
@@ -51,6 +60,17 @@ def test_fixture_node_set_identical(eng, golden_dir, name):
     ds, words, lens, pair = _device_nodes(eng, pr)
     _same_nodes(want, words, lens, pair)
     assert ds.removed_prefix == want["removed_prefix"]
+    # the whole input stage on the GPU: files in, the same node set out
+    fx2 = O.Fixture(golden_dir, name)
+    try:
+        g1, g2 = fx2.inputs()
+        ds2, info = eng.ingest_device(g1, g2, min_overlap=lo, rsoemo=rs)
+    finally:
+        fx2.cleanup()
+    _same_nodes(want, *_read_back(ds2))
+    assert (info["min_overlap"], info["rsoemo"], info["li_kmer_length"], info["LEN"]) == (want["min_overlap"], want["rsoemo"], want["li_kmer_length"], want["LEN"])
+    assert (info["removed_n"], info["removed_str"], ds2.removed_prefix) == (want["removed_n"], want["removed_str"], want["removed_prefix"])
+    ds = ds2
     # and the graph built from the device-resident node set is the reference's graph
     import torch
     ptr, m = eng.prefsuf_device(device_view(ds.d_words, (ds.n, ds.stride_words)), device_view(ds.d_len, (ds.n,)), want["min_overlap"], want["rsoemo"])
@@ -87,6 +107,9 @@ def test_removal_modes_and_messy_reads(eng, tmp_path, mode):
     ds, words, lens, pair = _device_nodes(eng, pr)
     _same_nodes(want, words, lens, pair)
     assert ds.removed_prefix == want["removed_prefix"]
+    ds2, info = eng.ingest_device(path, None, remove_pref_reads=mode)                                      # files in: N2 + N1 on the GPU
+    _same_nodes(want, *_read_back(ds2))
+    assert (info["removed_n"], info["removed_str"]) == (want["removed_n"], want["removed_str"])
     host = alga_amd.ingest_files(path, None, threads=3, remove_pref_reads=mode)                            # the host statement of the stage agrees too
     assert host["n"] == ds.n and (host["len"] == lens).all() and host["removed_short"] == ds.removed_short
 
@@ -112,3 +135,57 @@ def test_read_without_its_twin(eng):
     assert ei.value.code == -1
     ds = eng.preprocess_nodes(rows, np.array([-1, 40, 40, 40], np.int32), remove_pref_reads=3)
     assert ds.n == 2
+
+
+def test_device_ingest_messy_files(eng, tmp_path):
+    """record shapes the reference's reader handles: blanks around the sequence, text after a blank, short reads that escape the
+    trimming, U with and without --rna, a last line without newline, input that ends at an empty sequence line, FASTQ; and the
+    inputs the device stage hands back (other file types, random N replacement) or rejects (a letter outside ACGTNU)."""
+    rng = np.random.default_rng(77)
+    g = rng.integers(0, 4, 4000, dtype=np.uint8)
+
+    def read(L):
+        p = int(rng.integers(0, len(g) - L))
+        return "".join("ACGT"[c] for c in g[p: p + L])
+    recs = [read(int(rng.integers(30, 120))) for _ in range(1500)]
+    recs[3] = "   " + recs[3]
+    recs[4] = recs[4] + " trailing words"
+    recs[5] = read(14)                                     # shorter than trim + 10: not trimmed, then STR (<= 20 nt)
+    recs[6] = read(25)
+    recs[7] = recs[7][:20] + "U" + recs[7][21:]
+    recs[8] = recs[8][:5] + "N" + recs[8][6:]
+    for ext, lpr in (("fasta", 2), ("fastq", 4)):
+        path = str(tmp_path / ("m." + ext))
+        with open(path, "w") as f:
+            for i, s in enumerate(recs):
+                if lpr == 2:
+                    f.write(">r%d\n%s" % (i, s))
+                else:
+                    f.write("@r%d\n%s\n+\n%s" % (i, s, "I" * len(s)))
+                f.write("\n" if i + 1 < len(recs) else "")                       # no newline after the last record
+        for kw in ({}, {"rna": 1}, {"trim_left": 0, "trim_right": 7}):
+            want = O.ingest(path, None, **kw)
+            ds, info = eng.ingest_device(path, None, **kw)
+            _same_nodes(want, *_read_back(ds))
+            assert info["records"] == len(recs)
+    # the input ends at the first empty sequence line
+    path = str(tmp_path / "cut.fasta")
+    with open(path, "w") as f:
+        for i, s in enumerate(recs[:100]):
+            f.write(">r%d\n%s\n" % (i, s if i != 60 else ""))
+    want = O.ingest(path, None)
+    ds, info = eng.ingest_device(path, None)
+    _same_nodes(want, *_read_back(ds))
+    assert info["records"] == 60
+    # handed back / rejected
+    other = str(tmp_path / "reads.txt")
+    open(other, "w").write("\n".join(recs[:10]) + "\n")
+    for bad_call in (lambda: eng.ingest_device(other, None), lambda: eng.ingest_device(path, None, remove_reads_with_n=0)):
+        with pytest.raises(alga_amd.AlgaError) as ei:
+            bad_call()
+        assert ei.value.code == -7
+    badf = str(tmp_path / "bad.fasta")
+    open(badf, "w").write(">a\n%s\n>b\n%sX%s\n" % (recs[0], recs[1][:30], recs[1][30:]))
+    with pytest.raises(alga_amd.AlgaError) as ei:
+        eng.ingest_device(badf, None)
+    assert ei.value.code == -6 and "s[i] = X" in str(ei.value)
