@@ -317,9 +317,15 @@ k_probe_clustered(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__res
         // ---- (3) the next source: row staged, index loads issued behind the entry loads ----
         if (have_next) nbk = stage(buf ^ 1, nlenB, nnr_eff, nword0, nrun);
         index_loads(nbk, ne0, ne1);
-        // ---- (4) verify: one entry per lane ----
+        // ---- (4) verify: one entry per lane.  A verified overlap is an ITEM of the source-side reduction: target, offset | length |
+        //      alignFrom, overhang.  With every entry of the source in this one batch (the rule) the items stay in the lanes'
+        //      registers for the fused reduction below; otherwise they are appended to the item buffer in LDS. ----
         int n_items = 0;                                   // verified overlaps of this source so far (uniform)
-        auto verify = [&]() {
+        bool v_pass = false;
+        uint32_t v_id = 0, v_m = 0;
+        uint4 v_o = make_uint4(0u, 0u, 0u, 0u);
+        uint64_t v_pm = 0;
+        auto verify = [&](bool to_lds) {
             if (STATS && ev) st_slots++;
             const uint32_t id = ew[4 * EQ - 3], eh = ew[4 * EQ - 2], meta = ew[4 * EQ - 1];
             const int lenC = (int) ((meta >> 8) & 0xFFFu);
@@ -346,44 +352,98 @@ k_probe_clustered(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__res
             }
             const bool pass = ok && diff == 0;
             const uint64_t pm = __ballot(pass);
+            v_pass = pass; v_pm = pm; v_id = id;
+            v_m = (uint32_t) p | ((uint32_t) lenC << 9) | ((meta & CL_META_FROM) ? ITEM_FROM : 0u);
             if (pm != 0ull) {                              // uniform
                 if (pass) {
                     if (STATS) st_raw++;
-                    const int slot = n_items + (int) __builtin_amdgcn_mbcnt_hi((uint32_t) (pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) pm, 0u));
-                    if (slot < ITEMMAX) {
-                        it.C[slot] = id;
-                        it.M[slot] = (uint32_t) p | ((uint32_t) lenC << 9) | ((meta & CL_META_FROM) ? ITEM_FROM : 0u);
-                        // overhang: what C adds to the right of B's end = C's row from bit 2L on; bits past C's own end are
-                        // never compared (prefsuf_device.h via_ok), so the entry's trailing words may stand in for zeros
-                        const int ws = nb >> 5, r2 = nb & 31;
-                        uint32_t x[5];
-                        if constexpr (KF > 0 && WC - KF <= 6) {
-                            // word ws + k of the entry for ws in [KF, WC]: a select over registers
-                            const int t = ws - KF;
+                    // overhang: what C adds to the right of B's end = C's row from bit 2L on; bits past C's own end are
+                    // never compared (prefsuf_device.h via_ok), so the entry's trailing words may stand in for zeros
+                    const int ws = nb >> 5, r2 = nb & 31;
+                    uint32_t x[5];
+                    if constexpr (KF > 0 && WC - KF <= 6) {
+                        // word ws + k of the entry for ws in [KF, WC]: a select over registers
+                        const int t = ws - KF;
 #pragma unroll
-                            for (int k = 0; k < 5; k++) {
-                                uint32_t v = 0u;
+                        for (int k = 0; k < 5; k++) {
+                            uint32_t v = 0u;
 #pragma unroll
-                                for (int u = 0; u <= WC - KF; u++) { const int wi = KF + k + u; if (wi < 4 * EQ) v = t == u ? ew[wi] : v; }
-                                x[k] = v;
-                            }
-                        } else {
-                            const uint32_t *er = reinterpret_cast<const uint32_t *>(store + ei * EQ);      // re-read (an L1 hit)
-#pragma unroll
-                            for (int k = 0; k < 5; k++) x[k] = er[ws + k];
+                            for (int u = 0; u <= WC - KF; u++) { const int wi = KF + k + u; if (wi < 4 * EQ) v = t == u ? ew[wi] : v; }
+                            x[k] = v;
                         }
-                        it.O[slot] = make_uint4(funnel(x[0], x[1], r2), funnel(x[1], x[2], r2), funnel(x[2], x[3], r2), funnel(x[3], x[4], r2));
+                    } else {
+                        const uint32_t *er = reinterpret_cast<const uint32_t *>(store + ei * EQ);      // re-read (an L1 hit)
+#pragma unroll
+                        for (int k = 0; k < 5; k++) x[k] = er[ws + k];
+                    }
+                    v_o = make_uint4(funnel(x[0], x[1], r2), funnel(x[1], x[2], r2), funnel(x[2], x[3], r2), funnel(x[3], x[4], r2));
+                    if (to_lds) {
+                        const int slot = n_items + (int) __builtin_amdgcn_mbcnt_hi((uint32_t) (pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) pm, 0u));
+                        if (slot < ITEMMAX) { it.C[slot] = id; it.M[slot] = v_m; it.O[slot] = v_o; }
                     }
                 }
-                n_items += __popcll(pm);
+                if (to_lds) n_items += __popcll(pm);
             }
         };
-        verify();                                          // the first batch, peeled: its wait covers the entry loads only
-        for (;;) {                                         // further batches: a run with more entries than its lane group
-            k0 += 1u << gs;
-            if (k0 >= mc) break;                           // uniform
-            load_entries(rp, k0, gs, ev, ei, ew);
-            verify();
+        // every entry of the source in this batch, run list complete: the items can stay in registers
+        const bool one_batch = !flagged && mc <= (1u << gs);
+        verify(!one_batch);                                // the first batch, peeled: its wait covers the entry loads only
+        bool reduced = false;
+        if (one_batch) {
+            n_items = __popcll(v_pm);
+            if (n_items > 0) {
+                // ---- fused source-side reduction (prefsuf_device.h local_reduce's fast path on lane-resident items): one item per
+                // offset, every item but the first implied by its nearest predecessor -> the first one is the source's only edge.
+                // Anything else (two items at one offset, a predecessor that implies nothing but could: sequencing errors, repeats,
+                // several survivors) spills the items to LDS and takes local_reduce. ----
+                const int Lbig = cfg.rsoemo > cfg.Lmin ? cfg.rsoemo : cfg.Lmin;
+                uint8_t *T = it.T;
+                T[lane] = 0xFFu;
+                wave_lds_fence();
+                const int d = (int) (v_m & 511u);
+                if (v_pass) T[d] = (uint8_t) lane;
+                wave_lds_fence();
+                const uint64_t occ = __ballot(T[lane] != 0xFFu);
+                if (__popcll(occ) == n_items) {            // uniform
+                    const uint64_t below = v_pass ? (occ & ((1ull << d) - 1ull)) : 0ull;
+                    const bool has_pred = below != 0ull;
+                    const int j = has_pred ? (int) T[63 - __clzll((long long) below)] : lane;
+                    const uint32_t Cj = bperm(v_id, j), mj = bperm(v_m, j);
+                    Ovh<1> oj, oi;
+                    oj.w[0] = bperm(v_o.x, j); oj.w[1] = bperm(v_o.y, j); oj.w[2] = bperm(v_o.z, j); oj.w[3] = bperm(v_o.w, j);
+                    oi.w[0] = v_o.x; oi.w[1] = v_o.y; oi.w[2] = v_o.z; oi.w[3] = v_o.w;
+                    const int rho = (int) ((v_m >> 9) & 511u) - (lenB - d);
+                    const bool removed = has_pred && via_ok<1>(B, lenB, Lbig, Cj, mj, oj, v_id, d, rho, oi);
+                    // not removed by the nearest predecessor although even the longest read placed there could reach C with a big
+                    // overlap: undecided here
+                    const bool fail = has_pred && !removed && (cfg.Lcap - 1) - (d - (int) (mj & 511u)) >= Lbig;
+                    if (__ballot(fail) == 0ull) {          // uniform
+                        const uint64_t surv = __ballot(v_pass && !removed);
+                        if (__popcll(surv) == 1) {
+                            if (v_pass && !removed) {
+                                o.first[B - o.src_base] = ((unsigned long long) v_id << 32) | (uint32_t) d;
+                                o.deg[B - o.src_base] = 1u;
+                                st_rec++;
+                            }
+                            if (STATS && has_pred) st_cmp++;
+                            reduced = true;
+                        }
+                    }
+                }
+                if (!reduced) {
+                    if (v_pass) {
+                        const int slot = (int) __builtin_amdgcn_mbcnt_hi((uint32_t) (v_pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) v_pm, 0u));
+                        it.C[slot] = v_id; it.M[slot] = v_m; it.O[slot] = v_o;
+                    }
+                }
+            }
+        } else {
+            for (;;) {                                     // further batches: a run with more entries than its lane group
+                k0 += 1u << gs;
+                if (k0 >= mc) break;                       // uniform
+                load_entries(rp, k0, gs, ev, ei, ew);
+                verify(true);
+            }
         }
         if (flagged) {
             // ---- slow path (one source in ~10^4): more runs than k_node_runs stores.  Window minimizers by brute force (lane p
@@ -419,7 +479,7 @@ k_probe_clustered(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__res
                 wave_lds_fence();
                 const uint32_t mcs = (uint32_t) wave_max_u64_dpp((uint64_t) cnt);
                 load_runs(buf, gs, rp);
-                for (k0 = 0; k0 < mcs; k0 += 1u << gs) { load_entries(rp, k0, gs, ev, ei, ew); verify(); }
+                for (k0 = 0; k0 < mcs; k0 += 1u << gs) { load_entries(rp, k0, gs, ev, ei, ew); verify(true); }
             }
         }
         wave_lds_fence();
@@ -434,7 +494,7 @@ k_probe_clustered(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__res
                 atomicMax(&o.counters[CNT_LOCAL_MAXITEMS], (unsigned long long) n_items);
                 if (STATS) { st_raw -= (uint64_t) n_items; st_win -= (uint64_t) nwin; }     // the second pass counts this source
             }
-        } else if (n_items > 0) {
+        } else if (n_items > 0 && !reduced) {
             local_reduce<STATS, WBUF_LOCAL, 1>(nd, cfg, it, w, o, B, lenB, n_items, st_rec, st_cmp, st_generic);
         }
         const int nb2 = (int) __builtin_amdgcn_readfirstlane((int) *w.recN);
