@@ -32,7 +32,7 @@ namespace alga {
 // order hash of a k-mer (lo: nucleotides 0..15, hi: 16..31, both masked to the k-mer's length): its top 24 bits rank the
 // k-mers of a window
 __device__ __forceinline__ uint32_t kmer_hash(uint32_t lo, uint32_t hi) {
-    uint32_t x = (lo ^ (hi * 0x85EBCA6Bu)) * 0x9E3779B1u;
+    uint32_t x = (lo ^ __funnelshift_l(hi, hi, 13) ^ (hi >> 7)) * 0x9E3779B1u;     // two multiplies: 32-bit integer multiplies are quarter rate
     x ^= x >> 16;
     x *= 0x2C1B3C6Du;
     return x;
@@ -65,7 +65,7 @@ __device__ __forceinline__ void kmer_key(const uint32_t *row, int i, bool valid,
 constexpr int TK_ROWS = 256;         // nodes per workgroup of k_node_runs
 constexpr int TK_WORDS = 16;         // row words staged per node (reads of up to 208 nt: 13 words + the k-mer reads' slack)
 constexpr int TK_STRIDE = TK_WORDS + 1;
-constexpr int NR_STACK = 16;         // prefix-minimum records kept per node (a random window has ~4.7; more: the node is flagged)
+constexpr int NR_STACK = 12;         // prefix-minimum records kept per node (a random window has ~4.7; more: the node is flagged)
 
 // One THREAD per node (full lane use; the same sliding-window minimum inside the probing wave costs ~100 wave instructions per
 // source at a quarter of the lanes): the distinct minimizers of the suffix windows p = 0 .. len - Lmin of the node, as runs
@@ -84,6 +84,7 @@ __global__ void __launch_bounds__(TK_ROWS) k_node_runs(NodesDev nd, PrefSufCfg c
                                                         uint8_t *__restrict__ nruns) {
     __shared__ uint32_t s[TK_ROWS][TK_STRIDE];
     __shared__ uint32_t stk[NR_STACK][TK_ROWS];            // transposed: conflict-free
+    __shared__ uint32_t rbuf[CL_RMAX][TK_ROWS];            // runs as they are found: q | p0 << 8 | p1 << 16
     const int base = blockIdx.x * TK_ROWS;
     const int nrows = min(TK_ROWS, nd.n - base);
     {
@@ -103,13 +104,26 @@ __global__ void __launch_bounds__(TK_ROWS) k_node_runs(NodesDev nd, PrefSufCfg c
     const int w = cc.w;
     const int nwin = len - cfg.Lmin + 1;                   // <= 64 (one-word form of the source-side reduction)
     const int nk = len - cc.kk + 1;                        // = nwin - 1 + w
+    // The k-mer of position k as a 64-bit register pair that slides by one nucleotide per step (two shifts and an insert) instead
+    // of three LDS reads and two funnel shifts per position: `nuc(i)` reads one staged word per 16 nucleotides.
+    auto nuc = [&](int i) -> uint32_t { return (row[i >> 4] >> ((i & 15) << 1)) & 3u; };
+    auto key_of = [&](uint32_t lo, uint32_t hi, int pos) -> uint32_t { return (kmer_hash(lo & cc.lo_mask, hi & cc.hi_mask) & 0xFFFFFF00u) | (uint32_t) pos; };
+    const int kk = cc.kk;
     // ---- block 1, left to right: prefix-minimum records ----
     uint32_t cur1 = 0xFFFFFFFFu;
     int sp = 0;
-    for (int k = w; k < 2 * w - 1; k++) {                  // uniform (nk <= 2w - 1: cluster_plan keeps nwin <= w)
-        uint32_t h, pk;
-        kmer_key(row, k, true, cc, h, pk);
-        if (act && k < nk && pk < cur1) { cur1 = pk; if (sp < NR_STACK) stk[sp][t] = pk; sp++; }
+    {
+        uint32_t lo, hi;
+        { const int bit = 2 * w, q = bit >> 5, r = bit & 31; const uint32_t x0 = row[q], x1 = row[q + 1], x2 = row[q + 2]; lo = funnel(x0, x1, r); hi = funnel(x1, x2, r); }
+        for (int k = w; k < 2 * w - 1; k++) {              // uniform (nk <= 2w - 1: cluster_plan keeps nwin <= w)
+            const uint32_t pk = key_of(lo, hi, k);
+            if (act && k < nk && pk < cur1) { cur1 = pk; if (sp < NR_STACK) stk[sp][t] = pk; sp++; }
+            // slide right: drop nucleotide k, the k-mer of k + 1 ends with nucleotide k + kk (bits past the k-mer are masked in key_of)
+            lo = (lo >> 2) | (hi << 30);
+            hi = hi >> 2;
+            const uint32_t c = nuc(k + kk);
+            if (kk <= 16) lo |= c << (2 * (kk - 1)); else hi |= c << (2 * (kk - 17));
+        }
     }
     const bool stack_ovf = sp > NR_STACK;
     if (stack_ovf) sp = NR_STACK;
@@ -117,36 +131,50 @@ __global__ void __launch_bounds__(TK_ROWS) k_node_runs(NodesDev nd, PrefSufCfg c
     // ---- block 0, right to left: suffix minimum, winner per window, runs ----
     uint32_t cur0 = 0xFFFFFFFFu, prev_win = 0xFFFFFFFFu;
     int p_hi = 0, nr = 0;
+    // A run is only NOTED inside the sweep (one LDS store): with 64 nodes per wave some lane ends a run at nearly every step, and
+    // whatever the branch holds is paid by the whole wave every time.  Cluster keys and the global stores follow after the sweep.
     auto emit = [&](uint32_t winpk, int p0, int p1) {
-        uint32_t h, pk;
-        const int q = (int) (winpk & 255u);
-        kmer_key(row, q, true, cc, h, pk);
-        const uint32_t key = cluster_key(h);
-        if (is_src && nr < CL_RMAX) runs[(size_t) i * CL_RMAX + nr] = make_uint2(key, (uint32_t) q | ((uint32_t) p0 << 8) | ((uint32_t) p1 << 16));
+        if (nr < CL_RMAX) rbuf[nr][t] = (winpk & 255u) | ((uint32_t) p0 << 8) | ((uint32_t) p1 << 16);
         nr++;
-        return key;
     };
-    for (int k = w - 1; k >= 0; k--) {                     // uniform
-        uint32_t h, pk;
-        kmer_key(row, k, true, cc, h, pk);
-        if (act) {
-            cur0 = pk < cur0 ? pk : cur0;
-            if (k < nwin) {
-                const int j = k + w - 1;                   // last k-mer of window k
-                if (sp > 0 && (int) (top & 255u) > j) { sp--; top = sp > 0 ? stk[sp - 1][t] : 0xFFFFFFFFu; }     // at most one record leaves per step
-                const uint32_t win = (sp > 0 && top < cur0) ? top : cur0;
-                if (k == nwin - 1) { prev_win = win; p_hi = k; }
-                else if (win != prev_win) { emit(prev_win, k + 1, p_hi + 1); prev_win = win; p_hi = k; }
+    {
+        uint32_t lo, hi;
+        { const int bit = 2 * (w - 1), q = bit >> 5, r = bit & 31; const uint32_t x0 = row[q], x1 = row[q + 1], x2 = row[q + 2]; lo = funnel(x0, x1, r); hi = funnel(x1, x2, r); }
+        for (int k = w - 1; k >= 0; k--) {                 // uniform
+            const uint32_t pk = key_of(lo, hi, k);
+            if (act) {
+                cur0 = pk < cur0 ? pk : cur0;
+                if (k < nwin) {
+                    const int j = k + w - 1;               // last k-mer of window k
+                    if (sp > 0 && (int) (top & 255u) > j) { sp--; top = sp > 0 ? stk[sp - 1][t] : 0xFFFFFFFFu; }     // at most one record leaves per step
+                    const uint32_t win = (sp > 0 && top < cur0) ? top : cur0;
+                    if (k == nwin - 1) { prev_win = win; p_hi = k; }
+                    else if (win != prev_win) { emit(prev_win, k + 1, p_hi + 1); prev_win = win; p_hi = k; }
+                }
+            }
+            // slide left: the k-mer of k - 1 starts with nucleotide k - 1 (what leaves the k-mer moves up and out; key_of masks)
+            if (k > 0) {
+                hi = (hi << 2) | (lo >> 30);
+                lo = (lo << 2) | nuc(k - 1);
             }
         }
     }
     uint32_t key = 0xFFFFFFFFu, m = 0u;
-    if (act) {
-        const uint32_t k0 = emit(prev_win, 0, p_hi + 1);   // the run of window 0: the prefix minimizer
-        if (is_tgt) {
-            key = k0;
-            m = (prev_win & 255u) | ((uint32_t) len << 8) | (is_src ? CL_META_FROM : 0u);
+    if (act) emit(prev_win, 0, p_hi + 1);                  // the run of window 0: the prefix minimizer
+    const int nr_stored = nr < CL_RMAX ? nr : CL_RMAX;
+    for (int r = 0; r < CL_RMAX; r++) {                    // uniform
+        if (act && r < nr_stored && is_src) {
+            const uint32_t d = rbuf[r][t];
+            uint32_t h, pk;
+            kmer_key(row, (int) (d & 255u), true, cc, h, pk);
+            runs[(size_t) i * CL_RMAX + r] = make_uint2(cluster_key(h), d);
         }
+    }
+    if (is_tgt) {
+        uint32_t h, pk;
+        kmer_key(row, (int) (prev_win & 255u), true, cc, h, pk);
+        key = cluster_key(h);
+        m = (prev_win & 255u) | ((uint32_t) len << 8) | (is_src ? CL_META_FROM : 0u);
     }
     if (in) {
         keys[i] = key; vals[i] = (uint32_t) i; meta[i] = m;
