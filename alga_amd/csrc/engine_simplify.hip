@@ -1,6 +1,8 @@
 // alga_amd/csrc/engine_simplify.hip -- C ABI of the first simplifier step (simplify_kernels.hip).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "engine_internal.h"
 #include "simplify_kernels.h"
 
@@ -82,6 +84,50 @@ int alga_cut_triangles_host(alga_engine *e, int32_t n_nodes, const alga_edge *ed
     if (!h) return alga_fail(e, ALGA_ERR_OUT_OF_MEMORY, "host edge buffer");
     if (m && (rc = alga_staged_d2h(e, h, d_out, (size_t) m * sizeof(alga_edge)))) { alga_host_list_give(e, h); return rc; }
     *edges_out = h; *n_edges_out = m;
+    return ALGA_OK;
+}
+
+int alga_contig_trim_host(alga_engine *e, const uint32_t *words, int32_t stride_words, const int32_t *len, int32_t n_contigs, int32_t threshold,
+                          int32_t *trim_left) {
+    if (!e) return ALGA_ERR_INVALID_ARGUMENT;
+    e->err.clear();
+    if (n_contigs < 0 || (n_contigs && (!words || !len || !trim_left || stride_words <= 0))) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "bad contig arrays");
+    if (threshold < 1 || threshold > 501) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "threshold must be in [1, 501]");
+    if (n_contigs == 0) return ALGA_OK;
+    if (n_contigs > 0x3FFFFFFF) return alga_fail(e, ALGA_ERR_CAPACITY, "too many contigs");
+    const size_t M = (size_t) n_contigs;
+    int32_t max_len = 0;
+    for (size_t i = 0; i < M; i++) { if (len[i] < 0) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "negative contig length"); max_len = std::max(max_len, len[i]); }
+    if ((int64_t) blocks_of(max_len) > (int64_t) stride_words) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "stride_words is smaller than the longest contig needs");
+    const size_t row_bytes = (size_t) stride_words * sizeof(uint32_t);
+    if (2 * M * row_bytes > (64ull << 30)) return alga_fail(e, ALGA_ERR_CAPACITY, "contig rows at one fixed stride would take more than 64 GB: trim on the host");
+    HIP_TRY(e, hipSetDevice(e->device));
+    hipStream_t s = e->own_stream;
+    int rc;
+    // nodes as src/main.cpp:636-645 numbers them: contigs 0 .. M-1, then their reverse complements M .. 2M-1
+    if ((rc = alga_ensure(e, e->up_words, 2 * M * row_bytes))) return rc;
+    if ((rc = alga_ensure(e, e->up_len, 2 * M * sizeof(int32_t)))) return rc;
+    if ((rc = alga_ensure(e, e->sp_cnt, (M + 2) * sizeof(int32_t)))) return rc;
+    HIP_TRY(e, hipStreamSynchronize(s));
+    if ((rc = alga_staged_h2d(e, e->up_words.p, words, M * row_bytes))) return rc;
+    if ((rc = alga_staged_h2d(e, e->up_len.p, len, M * sizeof(int32_t)))) return rc;
+    launch_revcomp_rows((uint32_t *) e->up_words.p, stride_words, (int32_t *) e->up_len.p, n_contigs, s);
+    if ((rc = alga_check_launch(e, "k_revcomp_rows"))) return rc;
+    alga_nodes nd{(const uint32_t *) e->up_words.p, stride_words, (const int32_t *) e->up_len.p, 2 * n_contigs, nullptr, nullptr};
+    alga_prefsuf_params p;
+    alga_prefsuf_default_params(&p);
+    p.min_overlap = threshold;                             // src/main.cpp:651-653
+    p.rsoe_min_overlap = threshold;
+    const alga_edge *d_edges = nullptr;
+    uint64_t m = 0;
+    if ((rc = alga_prefsuf_build_device(e, &nd, &p, (void *) s, &d_edges, &m))) return rc;
+    // the reference does not call retainOnlySmallestOffset after this creator run; the largest overlap into a contig is the
+    // smallest offset of its (source, contig) pair, which that call keeps: trimLeft is the same either way
+    HIP_TRY(e, hipMemsetAsync(e->sp_cnt.p, 0, (M + 2) * sizeof(int32_t), s));
+    launch_trim_left((const alga_edge_dev *) d_edges, m, (const int32_t *) e->up_len.p, n_contigs, (int32_t *) e->sp_cnt.p, s);
+    if ((rc = alga_check_launch(e, "k_trim_left"))) return rc;
+    HIP_TRY(e, hipMemcpyAsync(trim_left, e->sp_cnt.p, M * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(e, hipStreamSynchronize(s));
     return ALGA_OK;
 }
 

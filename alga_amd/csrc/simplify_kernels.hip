@@ -81,6 +81,47 @@ __global__ void __launch_bounds__(256) k_compact_rows(const alga_edge_dev *__res
     for (uint32_t k = 0; k < c; k++) out[d + k] = work[s + k];
 }
 
+// ---- contig trimming (src/main.cpp:633-725) --------------------------------------------------
+// rows[M + i] = reverse complement of rows[i] (MyUtils::getComplimentaryString(getReverse(.)), src/main.cpp:641-643): one thread per
+// output word; nucleotide j of the result is 3 - nucleotide (len - 1 - j) of the contig
+__global__ void __launch_bounds__(256) k_revcomp_rows(uint32_t *__restrict__ rows, int stride, int32_t *__restrict__ len, int32_t M) {
+    const uint64_t t = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t i = t / (uint64_t) stride;
+    const int wq = (int) (t - i * (uint64_t) stride);
+    if (i >= (uint64_t) M) return;
+    const int n = len[i];
+    const uint32_t *src = rows + i * (size_t) stride;
+    uint32_t v = 0;
+    for (int j = 0; j < 16; j++) {
+        const int pos = 16 * wq + j;
+        if (pos < n) {
+            const int q = n - 1 - pos;
+            v |= (3u - ((src[q >> 4] >> ((q & 15) << 1)) & 3u)) << (2 * j);
+        }
+    }
+    rows[((size_t) M + i) * (size_t) stride + wq] = v;
+    if (wq == 0) len[(size_t) M + i] = n;
+}
+
+// trimLeft[d] = longest overlap |i| - offset over the edges i -> d between two FORWARD contigs (src/main.cpp:683-697)
+__global__ void __launch_bounds__(256) k_trim_left(const alga_edge_dev *__restrict__ e, uint64_t m, const int32_t *__restrict__ len, int32_t M,
+                                                    int32_t *__restrict__ trim) {
+    for (uint64_t k = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; k < m; k += (uint64_t) gridDim.x * blockDim.x) {
+        const alga_edge_dev x = e[k];
+        if (x.src < M && x.dst < M) atomicMax(&trim[x.dst], len[x.src] - x.offset);
+    }
+}
+
+void launch_revcomp_rows(uint32_t *rows, int stride, int32_t *len, int32_t M, hipStream_t s) {
+    if (M <= 0) return;
+    const uint64_t t = (uint64_t) M * (uint64_t) stride;
+    hipLaunchKernelGGL(k_revcomp_rows, dim3((unsigned) ((t + 255) / 256)), dim3(256), 0, s, rows, stride, len, M);
+}
+void launch_trim_left(const alga_edge_dev *e, uint64_t m, const int32_t *len, int32_t M, int32_t *trim, hipStream_t s) {
+    if (m == 0) return;
+    hipLaunchKernelGGL(k_trim_left, dim3((unsigned) std::min<uint64_t>((m + 255) / 256, 4096)), dim3(256), 0, s, e, m, len, M, trim);
+}
+
 void launch_edge_rowptr(const alga_edge_dev *e, uint64_t m, int32_t n, uint32_t *rowptr, hipStream_t s) {
     hipLaunchKernelGGL(k_edge_rowptr, dim3((unsigned) std::min<uint64_t>((m + 256) / 256, 8192)), dim3(256), 0, s, e, m, n, rowptr);
 }

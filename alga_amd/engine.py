@@ -110,7 +110,7 @@ EXPORTS = ["alga_abi_version", "alga_engine_set_option", "alga_engine_create", "
            "alga_prefsuf_reduce_device", "alga_prefsuf_build_range_device", "alga_write_graph", "alga_ingest_default_params", "alga_ingest_files",
            "alga_free_node_set", "alga_sort_records_device", "alga_sort_edges_device", "alga_pkb_derive_params",
            "alga_can_align_batch_host", "alga_li_kmers_host", "alga_pkb_supplement_host", "alga_pkb_supplement_device",
-           "alga_pkb_last_stats", "alga_parse_files", "alga_free_parsed_reads", "alga_preprocess_nodes", "alga_copy_to_host", "alga_device_alloc", "alga_device_free", "alga_copy_to_device", "alga_cut_triangles_device", "alga_cut_triangles_host", "alga_ingest_device"]
+           "alga_pkb_last_stats", "alga_parse_files", "alga_free_parsed_reads", "alga_preprocess_nodes", "alga_copy_to_host", "alga_device_alloc", "alga_device_free", "alga_copy_to_device", "alga_cut_triangles_device", "alga_cut_triangles_host", "alga_ingest_device", "alga_contig_trim_host"]
 
 
 def library_path():
@@ -181,6 +181,7 @@ def load_library():
     lib.alga_free_parsed_reads.restype = None
     lib.alga_preprocess_nodes.argtypes = [C.c_void_p, C.POINTER(PreprocessInput), C.POINTER(DeviceNodeSet)]
     lib.alga_copy_to_host.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.alga_contig_trim_host.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
     lib.alga_ingest_device.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.POINTER(IngestParams), C.POINTER(DeviceNodeSet), C.POINTER(IngestInfo)]
     lib.alga_cut_triangles_host.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_uint64, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
     lib.alga_cut_triangles_device.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p),
@@ -544,6 +545,15 @@ class Engine:
         self._check(self._lib.alga_cut_triangles_device(self._h, int(n_nodes), C.c_void_p(d_edges_ptr), int(n_edges), int(max_offset_parallel_paths),
                                                         C.c_void_p(stream or 0), C.byref(out), C.byref(m), C.byref(rem)))
         return out.value, int(m.value), int(rem.value)
+
+    def contig_trim(self, words, lens, threshold=25):
+        """src/main.cpp:636-697 on the GPU: packed contigs -> trim_left[n_contigs] (int32)."""
+        words = np.ascontiguousarray(words, dtype=np.uint32)
+        lens = np.ascontiguousarray(lens, dtype=np.int32)
+        out = np.zeros(len(lens), dtype=np.int32)
+        self._check(self._lib.alga_contig_trim_host(self._h, words.ctypes.data, int(words.shape[1]) if words.ndim == 2 else 1, lens.ctypes.data, len(lens),
+                                                    int(threshold), out.ctypes.data))
+        return out
 
     def write_graph(self, path, n_nodes, edges):
         edges = np.ascontiguousarray(edges, dtype=np.int32).reshape(-1, 3)

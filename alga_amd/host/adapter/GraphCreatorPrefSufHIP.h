@@ -98,6 +98,20 @@ inline void first_simplifier_step(Graph *G, int hip_device = 0) {
     alga_engine_destroy(e);
 }
 
+// The contig-trimming block on the GPU: replaces src/main.cpp:636-697 (contigs + reverse complements through one more
+// GraphCreatorPrefSuf run at threshold 25, trimLeft from its edges); the caller keeps the string surgery of :700-712.
+inline std::vector<int> contig_trim_left(std::vector<Read *> &contigs, int threshold = 25, int hip_device = 0) {
+    NodeArrays nodes(contigs);
+    std::vector<int32_t> trim(contigs.size(), 0);
+    alga_engine *e = nullptr;
+    int rc = alga_engine_create(hip_device, &e);
+    if (rc != ALGA_OK) die(nullptr, "no usable HIP device", rc);
+    rc = alga_contig_trim_host(e, nodes.words.data(), nodes.stride, nodes.len.data(), (int32_t) contigs.size(), threshold, trim.data());
+    if (rc != ALGA_OK) die(e, "contig trimming", rc);
+    alga_engine_destroy(e);
+    return std::vector<int>(trim.begin(), trim.end());
+}
+
 [[noreturn]] inline void die(alga_engine *e, const char *what, int rc) {   // the reference's convention: cerr + exit(1)
     std::cerr << "alga_amd: " << what << ": " << (e ? alga_last_error(e) : "no engine") << " (status " << rc << ")" << std::endl;
     exit(1);

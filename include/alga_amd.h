@@ -360,6 +360,15 @@ int  alga_cut_triangles_device(alga_engine *e, int32_t n_nodes, const alga_edge 
 int  alga_cut_triangles_host(alga_engine *e, int32_t n_nodes, const alga_edge *edges, uint64_t n_edges, int32_t max_offset_parallel_paths,
                              alga_edge **edges_out, uint64_t *n_edges_out);     /* release with alga_free_edges() */
 
+/* ---- contig trimming: the second use of the PrefSuf creator ---------------------------------------
+ * src/main.cpp:633-725: the contigs and their reverse complements become the "reads" of one more GraphCreatorPrefSuf run with
+ * MIN_OVERLAP_PREF_SUF = REMOVE_SMALL_OVERLAP_EDGES_MIN_OVERLAP = 25 (overlap lengths stop at 501 as always); the longest
+ * overlap of an edge between two forward contigs that ends in contig d is cut off the left end of d (:683-712).  This call
+ * replaces :636-697: contigs in (2-bit rows as everywhere, any length up to 4 194 303 nt), trim_left[n_contigs] out; the string
+ * surgery of :700-712 stays with the caller.  `threshold` = 25 in the reference. */
+int  alga_contig_trim_host(alga_engine *e, const uint32_t *words, int32_t stride_words, const int32_t *len, int32_t n_contigs,
+                           int32_t threshold, int32_t *trim_left);
+
 /* ---- graph dump: the reference's own checkpoint format ------------------------------------ */
 /* Graph::serializeGraph (src/DataStructures/Graph.cpp:269-297): u32 n; n x {i32 id; i32 deg;
  * deg x {i32 neighbour; i32 offset}}, native endian.  Stock ALGA loads it with

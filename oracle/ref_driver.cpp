@@ -18,6 +18,12 @@
 //       simplifyGraphOld): Graph::sortEdgesByIncreasingOffset, GraphSimplifier::cutNonAndWeaklyMetricTriangles; writes the
 //       resulting graph in the reference's dump format (in-list order as the reference leaves it).
 //
+//   ref_driver trim <contigs.bin> <out.txt> <avg_read_length>
+//       the contig-trimming block of src/main.cpp:633-725 on the contigs of a node file: contigs + their reverse complements as
+//       "reads", the reference's GraphCreatorPrefSuf with MIN_OVERLAP_PREF_SUF = REMOVE_SMALL_OVERLAP_EDGES_MIN_OVERLAP = 25,
+//       trimLeft[d] = longest overlap of an edge between two forward contigs that ends in d, sequences cut accordingly.
+//       Writes one line per contig: trimLeft and the trimmed sequence.
+//
 // node file: i32 n, i32 W, i32 len[n], u32 words[n*W]   (reference bit layout; len 0 = nullptr)
 #include <cstdio>
 #include <cstdlib>
@@ -28,7 +34,9 @@
 
 #include <AlignmentControllers/AlignmentControllerHybrid.h>
 #include <GraphCreators/GraphCreatorLI.h>
+#include <GraphCreators/GraphCreatorPrefSuf.h>
 #include <GraphSimplifiers/GraphSimplifier.h>
+#include <Utils/MyUtils.h>
 #include <Global.h>
 #include <Params.h>
 
@@ -116,6 +124,42 @@ int main(int argc, char **argv) {
         }
         fprintf(stdout, "edges_before %lld edges_after %lld\n", before, (long long) G->countEdges());
         G->serializeGraph(argv[3]);
+        return 0;
+    }
+    if (mode == "trim") {
+        if (argc != 5) die("trim <contigs.bin> <out.txt> <avg_read_length>");
+        load_nodes(argv[2]);                               // the contigs, as Reads
+        std::vector<Read *> contigs = Global::READS;
+        // src/main.cpp:636-656
+        std::vector<Read *> newReads;
+        for (auto t : contigs) newReads.push_back(t);
+        int cnt = 0;
+        for (auto t : contigs) newReads.push_back(new Read(cnt++, MyUtils::getComplimentaryString(MyUtils::getReverse(t->getSequenceAsString()))));
+        cnt = 0;
+        for (auto t : newReads) t->setId(cnt++);
+        Graph *newGraph = new Graph((int) newReads.size());
+        GraphCreatorPrefSuf gcps(&newReads, newGraph);
+        const int THRESHOLD = 25;
+        Params::MIN_OVERLAP_PREF_SUF = THRESHOLD;
+        Params::REMOVE_SMALL_OVERLAP_EDGES_MIN_OVERLAP = THRESHOLD;
+        gcps.startAlignmentGraphCreation();
+        // :676-697
+        const int M = (int) newReads.size() / 2;
+        std::vector<int> trimLeft((size_t) M, 0), trimRight((size_t) M, 0);
+        for (int i = 0; i < (int) newReads.size(); i++)
+            for (PII neigh : (*newGraph)[i]) {
+                const int d = neigh.first, offset = neigh.second, overlap = newReads[i]->size() - offset;
+                if (i < M && d < M) trimLeft[d] = std::max(trimLeft[d], overlap);
+            }
+        FILE *o = fopen(argv[3], "w");
+        for (int i = 0; i < M; i++) {                      // :700-712
+            std::string sq = newReads[i]->getSequenceAsString();
+            if (trimLeft[i] + trimRight[i] + 10 < (int) sq.size()) sq = sq.substr(trimLeft[i], std::max(1, (int) sq.size() - trimLeft[i] - trimRight[i]));
+            else sq = "CCCC";
+            fprintf(o, "%d %s\n", trimLeft[i], sq.c_str());
+        }
+        fclose(o);
+        fprintf(stdout, "contigs %d edges %lld\n", M, (long long) newGraph->countEdges());
         return 0;
     }
     if (mode == "canalign") {

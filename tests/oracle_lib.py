@@ -91,6 +91,31 @@ def prefsuf(words, lens, min_overlap, rsoemo, align_from=None, align_to=None):
     return e, it, cnt
 
 
+def revcomp_rows(words, lens):
+    """2-bit rows of the reverse complements (MyUtils::getComplimentaryString(getReverse(.)))"""
+    out = np.zeros_like(words)
+    for i in range(len(lens)):
+        n = int(lens[i])
+        c = np.array([(int(words[i, k >> 4]) >> ((k & 15) << 1)) & 3 for k in range(n)], dtype=np.uint8)
+        rc = (3 - c)[::-1]
+        for k in range(n):
+            out[i, k >> 4] |= np.uint32(int(rc[k]) << ((k & 15) << 1))
+    return out
+
+
+def contig_trim(words, lens, threshold=25):
+    """src/main.cpp:636-697 with the oracle's creator: nodes = contigs then their reverse complements; trimLeft per contig"""
+    M = len(lens)
+    w2 = np.concatenate([words, revcomp_rows(words, lens)], axis=0)
+    l2 = np.concatenate([lens, lens]).astype(np.int32)
+    e, _, _ = prefsuf(w2, l2, threshold, threshold)
+    trim = np.zeros(M, dtype=np.int32)
+    for a, d, off in e:
+        if a < M and d < M:
+            trim[d] = max(trim[d], int(l2[a]) - int(off))
+    return trim
+
+
 def cut_triangles(n, edges, mopp):
     """first simplifier step (oracle_cut_triangles) -> edges [m, 3] grouped by src, lists in the reference's order"""
     L = lib()
