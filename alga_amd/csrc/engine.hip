@@ -171,9 +171,34 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
         if ((rc = alga_ensure(e, e->rec_val, cap * sizeof(unsigned long long)))) return rc;
         HIP_TRY(e, hipMemsetAsync(cnt, 0, CNT_TOTAL * sizeof(unsigned long long), s));
         ProbeBig big{(int32_t *) e->loc_big_list.p, big_list_cap, 0u, nullptr, 0u};
-        if (clustered)
-            launch_probe_clustered(nd, cfg, cc, pp.cluster_eq, e->cl_store.p, (const uint32_t *) e->cl_idx.p, e->cl_runs.p, (const uint8_t *) e->cl_nruns.p, src_begin, src_end, (uint32_t *) e->rec_dst.p,
-                                   (unsigned long long *) e->rec_val.p, cap, cnt, e->n_cu, (uint32_t *) e->outdeg.p, (unsigned long long *) e->loc_first.p, &big, s);
+        if (clustered) {
+            // Two kernels: the pair kernel (two sources per wave) finishes the regular sources and lists the others; the general
+            // kernel (one source per wave, any shape) takes the list.  Data on which most sources are irregular (sequencing errors:
+            // several items per offset) would pay the pair kernel for nothing: after a build that deferred more than half of its
+            // sources the engine goes straight to the general kernel.
+            const bool pairs = e->opt_cluster_pairs && e->cl_defer_ratio <= 0.5;
+            if (pairs) {
+                if ((rc = alga_ensure(e, e->cl_defer, (size_t) (n_src + 64) * sizeof(int32_t)))) return rc;
+                launch_probe_pairs(nd, cfg, cc, pp.cluster_eq, e->cl_store.p, (const uint32_t *) e->cl_idx.p, e->cl_runs.p, (const uint8_t *) e->cl_nruns.p,
+                                   src_begin, src_end, cnt, e->n_cu, (uint32_t *) e->outdeg.p, (unsigned long long *) e->loc_first.p, (int32_t *) e->cl_defer.p,
+                                   (uint32_t) n_src, s);
+                if ((rc = alga_check_launch(e, "k_probe_pairs"))) return rc;
+                HIP_TRY(e, hipMemcpyAsync(&e->h_counters[CNT_DEFERRED], cnt + CNT_DEFERRED, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+                HIP_TRY(e, hipStreamSynchronize(s));
+                const uint64_t n_def = e->h_counters[CNT_DEFERRED];
+                e->cl_defer_ratio = n_src ? (double) n_def / (double) n_src : 0.0;
+                e->stats.deferred_sources = n_def;
+                if (n_def)
+                    launch_probe_clustered(nd, cfg, cc, pp.cluster_eq, e->cl_store.p, (const uint32_t *) e->cl_idx.p, e->cl_runs.p, (const uint8_t *) e->cl_nruns.p, 0,
+                                           (int32_t) n_def, (const int32_t *) e->cl_defer.p, src_begin, (uint32_t *) e->rec_dst.p, (unsigned long long *) e->rec_val.p,
+                                           cap, cnt, e->n_cu, (uint32_t *) e->outdeg.p, (unsigned long long *) e->loc_first.p, &big, s);
+            } else {
+                e->stats.deferred_sources = n_src;
+                launch_probe_clustered(nd, cfg, cc, pp.cluster_eq, e->cl_store.p, (const uint32_t *) e->cl_idx.p, e->cl_runs.p, (const uint8_t *) e->cl_nruns.p, src_begin,
+                                       src_end, nullptr, src_begin, (uint32_t *) e->rec_dst.p, (unsigned long long *) e->rec_val.p, cap, cnt, e->n_cu,
+                                       (uint32_t *) e->outdeg.p, (unsigned long long *) e->loc_first.p, &big, s);
+            }
+        }
         else
             launch_probe(nd, cfg, (const unsigned long long *) e->table.p, n_buckets, (const uint32_t *) e->filter.p, filter_bits, src_begin, src_end,
                          (uint32_t *) e->rec_dst.p, (unsigned long long *) e->rec_val.p, cap, cnt, e->n_cu, local ? pp.local_sw : 0, (uint32_t *) e->outdeg.p,
@@ -383,7 +408,7 @@ void alga_engine_destroy(alga_engine *e) {
     if (e->own_stream) (void) hipStreamSynchronize(e->own_stream);
     DevBuf *bufs[] = {&e->table, &e->filter, &e->counters, &e->rowptr, &e->rec_dst, &e->rec_val, &e->keys, &e->seg_key, &e->seg_val, &e->heads, &e->sort_temp,
                       &e->out_cnt, &e->outdeg, &e->out_rowptr, &e->edges, &e->scan_scratch, &e->up_words, &e->up_len, &e->up_from, &e->up_to,
-                      &e->cl_keys[0], &e->cl_keys[1], &e->cl_vals[0], &e->cl_vals[1], &e->cl_meta, &e->cl_runs, &e->cl_nruns, &e->cl_store, &e->cl_idx, &e->loc_first, &e->loc_big_list, &e->loc_big_items, &e->edge_keys, &e->edge_keys2, &e->edge_vals, &e->edge_vals2, &e->edges_sorted, &e->xs_dst, &e->xs_val,
+                      &e->cl_keys[0], &e->cl_keys[1], &e->cl_vals[0], &e->cl_vals[1], &e->cl_defer, &e->cl_meta, &e->cl_runs, &e->cl_nruns, &e->cl_store, &e->cl_idx, &e->loc_first, &e->loc_big_list, &e->loc_big_items, &e->edge_keys, &e->edge_keys2, &e->edge_vals, &e->edge_vals2, &e->edges_sorted, &e->xs_dst, &e->xs_val,
                       &e->pk_keys, &e->pk_keys2, &e->pk_vals, &e->pk_vals2, &e->pk_marks, &e->pk_big, &e->pk_add, &e->pk_ekeys, &e->pk_ekeys2,
                       &e->pk_flag, &e->pk_pos, &e->pk_edges[0], &e->pk_edges[1], &e->pk_rowptr, &e->pk_deg, &e->pk_mask, &e->pk_cnt, &e->pk_io, &e->pk_io2, &e->pk_tips, &e->pk_heads, &e->pp_rows, &e->pp_len, &e->pp_perm[0], &e->pp_perm[1], &e->pp_keys[0], &e->pp_keys[1], &e->pp_mark,
                       &e->pp_keep, &e->pp_pos, &e->pp_out_rows, &e->pp_out_len, &e->pp_out_pair, &e->pp_tally};
@@ -415,6 +440,9 @@ int alga_engine_set_option(alga_engine *e, const char *name, int64_t value) {
     } else if (!strcmp(name, "cluster_bucket_bias")) {
         if (value < -8 || value > 8) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "option cluster_bucket_bias: -8 .. 8");
         e->opt_cluster_bucket_bias = (int) value;
+    } else if (!strcmp(name, "cluster_pairs")) {
+        e->opt_cluster_pairs = value != 0;
+        e->cl_defer_ratio = 0.0;
     } else if (!strcmp(name, "local_big_max")) {
         e->big_limit = value < 0 ? -1 : (int) std::min<int64_t>(value, 1 << 20);
     } else if (!strcmp(name, "auto_reduction_per_target")) {

@@ -32,6 +32,9 @@ struct alga_engine {
     hipEvent_t  ev[EV_COUNT] = {};
     // device buffers, grown on demand and kept between calls
     DevBuf table, filter, counters, rowptr, rec_dst, rec_val, keys, seg_key, seg_val, heads, sort_temp, out_cnt, outdeg, out_rowptr, edges, scan_scratch;
+    DevBuf cl_defer;                                        // sources the pair kernel hands to the general kernel
+    double cl_defer_ratio = 0.0;                            // ... their share in the last build: above one half the pair kernel is skipped
+    int    opt_cluster_pairs = 1;                           // option "cluster_pairs": 0 = general kernel only
     DevBuf cl_keys[2], cl_vals[2], cl_meta, cl_runs, cl_nruns, cl_store, cl_idx;   // clustered minimizer join: sort buffers, per-node minimizer runs, entry array, bucket index
     DevBuf loc_first, loc_big_list, loc_big_items;          // source-side form: one-edge slots; second pass over repeat-rich sources
     int    big_limit = -1;                                  // largest per-wave item slice of that pass; -1 = built-in (option "local_big_max": tests)

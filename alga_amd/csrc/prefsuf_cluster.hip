@@ -229,7 +229,8 @@ __device__ __forceinline__ uint32_t bperm(uint32_t v, int src_lane) { return (ui
 template <bool STATS, int EQ, int KF>
 __global__ void __launch_bounds__(PROBE_WAVES * 64, CL_OCC)
 k_probe_clustered(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__restrict__ store, const uint32_t *__restrict__ idx,
-                  const uint2 *__restrict__ runs, const uint8_t *__restrict__ nruns, int32_t src_begin, int32_t src_end, ProbeOut o) {
+                  const uint2 *__restrict__ runs, const uint8_t *__restrict__ nruns, int32_t src_begin, int32_t src_end, ProbeOut o,
+                  const int32_t *__restrict__ src_list /* null: the sources are the ids src_begin .. src_end - 1; else src_list[src_begin .. src_end - 1] */) {
     constexpr int WC = 4 * EQ - 3;                         // row words of an entry
     __shared__ uint32_t sB[PROBE_WAVES][2][STAGE_WORDS];
     __shared__ uint4 sRun[PROBE_WAVES][2][CL_RMAX];        // runs of a source: q | p0 << 8 | p1 << 16, cluster key, first entry, entries
@@ -261,20 +262,22 @@ k_probe_clustered(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__res
     //      in flight.  Node ids are < 2^31 (alga_nodes.n is an int32).
     const int pre_words = nd.stride < STAGE_WORDS ? nd.stride : STAGE_WORDS;
     int Bl = src_begin + (int) blockIdx.x * PROBE_WAVES + wave;
-    int n_len = 0, n_nr = 0; uint32_t n_word = 0; uint2 n_run = make_uint2(0u, 0u);
+    int n_id = 0, n_len = 0, n_nr = 0; uint32_t n_word = 0; uint2 n_run = make_uint2(0u, 0u);
     auto fetch = [&]() {
         if (Bl < src_end) {                                // uniform
-            n_len = nd.len[Bl];
-            n_nr = nruns[Bl];
-            n_word = lane < pre_words ? nd.words[(size_t) Bl * nd.stride + lane] : 0u;
-            if (lane < CL_RMAX) n_run = runs[(size_t) Bl * CL_RMAX + lane];
+            const int b = src_list ? __builtin_amdgcn_readfirstlane(src_list[Bl]) : Bl;
+            n_id = b;
+            n_len = nd.len[b];
+            n_nr = nruns[b];
+            n_word = lane < pre_words ? nd.words[(size_t) b * nd.stride + lane] : 0u;
+            if (lane < CL_RMAX) n_run = runs[(size_t) b * CL_RMAX + lane];
         }
     };
     fetch();
     // next source that takes part (nruns != 0: long enough, alignFrom): uniform
     auto advance = [&](int &B, int &lenB, int &nr, uint32_t &word0, uint2 &run) -> bool {
         while (Bl < src_end) {
-            B = Bl; lenB = __builtin_amdgcn_readfirstlane(n_len); nr = __builtin_amdgcn_readfirstlane(n_nr); word0 = n_word; run = n_run;
+            B = n_id; lenB = __builtin_amdgcn_readfirstlane(n_len); nr = __builtin_amdgcn_readfirstlane(n_nr); word0 = n_word; run = n_run;
             Bl = total_waves <= src_end - Bl ? Bl + total_waves : src_end;      // no overflow near 2^31
             fetch();
             if (nr != 0) return true;
@@ -549,6 +552,248 @@ k_probe_clustered(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__res
 }
 
 // ------------------------------------------------------------------------------------------
+// k_probe_pairs : TWO sources per wave, 32 lanes each
+// ------------------------------------------------------------------------------------------
+// A 150-bp source at 30x coverage has ~24 entries to verify and ~11 items to reduce: a wave per source leaves most lanes idle
+// in exactly the parts that cost the instructions.  Here a wave takes two sources (adjacent ids), one per half: the entries of
+// all runs of a source are packed densely onto the 32 lanes of its half, verified there, and reduced there by the fused
+// single-survivor rule (k_probe_clustered, step (4)).  Only REGULAR sources finish here -- at most 8 runs, at most 32 entries,
+// one item per offset, every item but one implied by its nearest predecessor, i.e. error-free data at moderate coverage --
+// and their single edge goes straight to first[] / deg[].  Any other source is appended to `defer_list` and taken by
+// k_probe_clustered (list mode) afterwards: nothing is decided twice, nothing is approximated.
+// Same two-stage software pipeline as k_probe_clustered; "uniform per source" values live in vector registers (one per half).
+#ifndef CLP_OCC
+#define CLP_OCC 8
+#endif
+template <bool STATS, int EQ, int KF>
+__global__ void __launch_bounds__(PROBE_WAVES * 64, CLP_OCC)
+k_probe_pairs(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__restrict__ store, const uint32_t *__restrict__ idx,
+              const uint2 *__restrict__ runs, const uint8_t *__restrict__ nruns, int32_t src_begin, int32_t src_end, ProbeOut o,
+              int32_t *__restrict__ defer_list, uint32_t defer_cap) {
+    constexpr int WC = 4 * EQ - 3;                         // row words of an entry
+    constexpr int PW = 32;                                 // staged words per source (rows of up to 13 words + the compare's slack)
+    __shared__ uint32_t sB[PROBE_WAVES][2][2][PW];
+    __shared__ uint4 sRun[PROBE_WAVES][2][2][CL_RMAX];     // per run: q | p0 << 8 | p1 << 16, cluster key, first entry - slots before the run
+    __shared__ unsigned long long sIncl[PROBE_WAVES][2][2];// per source: inclusive prefix of the runs' entry counts, 8 x u8 (saturating)
+    __shared__ uint8_t sT[PROBE_WAVES][2][64];             // per source: lane of the item at offset d
+    __shared__ int32_t sDefer[PROBE_WAVES][64];
+    __shared__ uint4 sMask[KF > 0 ? 129 : 1];
+    const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+    const int lane = lane_id();
+    const int h = lane >> 5, hl = lane & 31;
+    if constexpr (KF > 0) {
+        for (int t = (int) threadIdx.x; t <= 128; t += PROBE_WAVES * 64)
+            sMask[t] = make_uint4(low_bits32(t), low_bits32(t - 32), low_bits32(t - 64), low_bits32(t - 96));
+        __syncthreads();
+    }
+    uint64_t st_raw = 0, st_slots = 0, st_win = 0, st_rec = 0, st_cmp = 0;
+    int n_defer = 0;                                       // uniform: sources waiting in sDefer
+    const int step = (int) gridDim.x * PROBE_WAVES * 2;
+    const int kfull = KF ? KF : (2 * cfg.Lmin) >> 5;
+    const int Lbig = cfg.rsoemo > cfg.Lmin ? cfg.rsoemo : cfg.Lmin;
+    auto half_of = [&](uint64_t m) -> uint32_t { return h ? (uint32_t) (m >> 32) : (uint32_t) m; };
+    auto flush_defer = [&]() {                             // convergent
+        if (n_defer == 0) return;
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(&o.counters[CNT_DEFERRED], (unsigned long long) n_defer);
+        base = ((unsigned long long) (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) (base >> 32)) << 32) | (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) base);
+        if (lane < n_defer && base + (unsigned long long) lane < (unsigned long long) defer_cap) defer_list[base + (unsigned long long) lane] = sDefer[wave][lane];
+        wave_lds_fence();
+        n_defer = 0;
+    };
+
+    // ---- source stream: pairs of adjacent ids; the rows / lengths / run lists of the pair after the one being staged are in flight ----
+    const int pre_words = nd.stride < PW ? nd.stride : PW;
+    int Bl = src_begin + 2 * ((int) blockIdx.x * PROBE_WAVES + wave);
+    int n_len = 0, n_nr = 0; uint32_t n_word = 0; uint2 n_run = make_uint2(0u, 0u);
+    auto fetch = [&]() {
+        n_len = 0; n_nr = 0; n_word = 0u; n_run = make_uint2(0u, 0u);
+        const int b = Bl + h;
+        if (Bl < src_end && b < src_end) {
+            n_len = nd.len[b];
+            n_nr = nruns[b];
+            if (hl < pre_words) n_word = nd.words[(size_t) b * nd.stride + hl];
+            if (hl < CL_RMAX) n_run = runs[(size_t) b * CL_RMAX + hl];
+        }
+    };
+    fetch();
+    // stage 1 of a pair: rows -> LDS; bucket of each run (lanes without a run read bucket 0: one shared line)
+    auto stage = [&](int buf, int lenB, int nr_eff, uint32_t word0, const uint2 &run) -> uint32_t {
+        wave_lds_fence();
+        sB[wave][buf][h][hl] = hl < blocks_of(lenB) ? word0 : 0u;
+        return hl < nr_eff ? run.x >> cc.idx_shift : 0u;
+    };
+    auto index_loads = [&](uint32_t bucket, uint32_t &e0, uint32_t &e1) { e0 = idx[bucket]; e1 = idx[bucket + 1]; };   // every lane, no branch
+    // run list of a pair -> LDS; entries are numbered densely over the runs of a source: slot = entries of the runs before + j.
+    // Returns the number of entries of this lane's source (uniform per half).
+    auto finish_runs = [&](int buf, int nr_eff, const uint2 &run, uint32_t e0, uint32_t e1) -> int {
+        const uint32_t cnt = hl < nr_eff ? e1 - e0 : 0u;   // lanes hl >= 8 hold no run
+        uint32_t inc = cnt, t;                             // inclusive scan over the runs (lanes hl 0..7 of the half: inside one 16-lane row)
+        t = (uint32_t) __builtin_amdgcn_update_dpp(0, (int) inc, 0x111, 0xF, 0xF, true); inc += t;
+        t = (uint32_t) __builtin_amdgcn_update_dpp(0, (int) inc, 0x112, 0xF, 0xF, true); inc += t;
+        t = (uint32_t) __builtin_amdgcn_update_dpp(0, (int) inc, 0x114, 0xF, 0xF, true); inc += t;
+        if (hl < CL_RMAX) {
+            sRun[wave][buf][h][hl] = make_uint4(run.y, run.x, e0 - (inc - cnt), cnt);
+            reinterpret_cast<uint8_t *>(&sIncl[wave][buf][h])[hl] = (uint8_t) (inc > 255u ? 255u : inc);
+        }
+        const int T0 = __builtin_amdgcn_readlane((int) inc, CL_RMAX - 1), T1 = __builtin_amdgcn_readlane((int) inc, 32 + CL_RMAX - 1);
+        wave_lds_fence();
+        return h ? T1 : T0;
+    };
+
+    bool have = Bl < src_end;
+    int B = 0, lenB = 0, nr = 0, T = 0, buf = 0;
+    if (have) {
+        B = Bl + h; lenB = n_len; nr = n_nr;
+        const uint32_t word0 = n_word; const uint2 run = n_run;
+        Bl += step;
+        fetch();
+        const int nr_eff = nr == CL_RUNS_FLAGGED ? 0 : nr;
+        uint32_t e0, e1;
+        const uint32_t bk = stage(0, lenB, nr_eff, word0, run);
+        index_loads(bk, e0, e1);
+        T = finish_runs(0, nr_eff, run, e0, e1);
+    }
+    while (have) {                                         // uniform
+        const uint32_t *sb = sB[wave][buf][h];
+        const int nwin = lenB - cfg.Lmin + 1;
+        // ---- (1) the next pair comes off the stream before any entry load is issued ----
+        const bool have_next = Bl < src_end;
+        const int nB = Bl + h, nlenB = n_len, nnr = n_nr;
+        const uint32_t nword0 = n_word; const uint2 nrun = n_run;
+        if (have_next) { Bl += step; fetch(); }
+        const int nnr_eff = nnr == CL_RUNS_FLAGGED ? 0 : nnr;
+        // ---- (2) this pair's entries, densely packed per half: loads issued ----
+        const bool takes_part = nr != 0;                               // nruns == 0: not a source
+        const bool packable = takes_part && nr != CL_RUNS_FLAGGED && T <= 32;
+        const bool ev = packable && hl < T;
+        uint4 rp = make_uint4(0u, 0u, 0u, 0u);
+        {
+            // run of slot hl: the number of runs whose inclusive prefix is <= hl (binary search over 8 packed bytes)
+            const unsigned long long inc8 = sIncl[wave][buf][h];
+            const uint32_t lo = (uint32_t) inc8, hi = (uint32_t) (inc8 >> 32);
+            int r = (int) ((lo >> 24) & 255u) <= hl ? 4 : 0;
+            { const uint32_t wv = r ? hi : lo; r += (int) ((wv >> 8) & 255u) <= hl ? 2 : 0; }
+            { const uint32_t wv = r >= 4 ? hi : lo; r += (int) ((wv >> (8 * (r & 3))) & 255u) <= hl ? 1 : 0; }
+            if (ev) rp = sRun[wave][buf][h][r & (CL_RMAX - 1)];
+        }
+        const size_t ei = ev ? (size_t) (rp.z + (uint32_t) hl) : (size_t) 0;
+        uint32_t ew[4 * EQ];
+#pragma unroll
+        for (int c = 0; c < EQ; c++) { const uint4 v = store[ei * EQ + c]; ew[4 * c] = v.x; ew[4 * c + 1] = v.y; ew[4 * c + 2] = v.z; ew[4 * c + 3] = v.w; }
+        // ---- (3) the next pair: rows staged, index loads issued behind the entry loads ----
+        uint32_t nbk = 0, ne0, ne1;
+        if (have_next) nbk = stage(buf ^ 1, nlenB, nnr_eff, nword0, nrun);
+        index_loads(nbk, ne0, ne1);
+        // ---- (4) verify: one entry per lane ----
+        const uint32_t id = ew[4 * EQ - 3], eh = ew[4 * EQ - 2], meta = ew[4 * EQ - 1];
+        const int lenC = (int) ((meta >> 8) & 0xFFFu);
+        int p = (int) (rp.x & 255u) - (int) (meta & 255u);
+        const bool ok = ev && eh == rp.y && p >= (int) ((rp.x >> 8) & 255u) && p < (int) ((rp.x >> 16) & 255u) && (int) id != B && lenC >= lenB - p;
+        p = ok ? p : 0;
+        const int L = lenB - p, nb = 2 * L;
+        bool pass;
+        {
+            const int qw = (2 * p) >> 5, sh = (2 * p) & 31;
+            uint32_t y[WC + 1];
+#pragma unroll
+            for (int k = 0; k <= WC; k++) y[k] = sb[qw + k];
+            uint32_t diff = 0;
+            uint32_t mk[4] = {0u, 0u, 0u, 0u};
+            if constexpr (KF > 0) { const uint4 m4 = sMask[min(max(nb - 32 * KF, 0), 128)]; mk[0] = m4.x; mk[1] = m4.y; mk[2] = m4.z; mk[3] = m4.w; }
+#pragma unroll
+            for (int k = 0; k < WC; k++) {
+                const uint32_t x = funnel(y[k], y[k + 1], sh) ^ ew[k];
+                if (k < kfull) diff |= x;
+                else if (KF > 0 && k < KF + 4) diff |= x & mk[(k - KF) & 3];
+                else diff |= x & low_bits32(nb - 32 * k);
+            }
+            pass = ok && diff == 0;
+        }
+        const uint64_t pm = __ballot(pass);
+        const uint32_t v_m = (uint32_t) p | ((uint32_t) lenC << 9) | ((meta & CL_META_FROM) ? ITEM_FROM : 0u);
+        uint4 v_o = make_uint4(0u, 0u, 0u, 0u);
+        bool reduced = packable;                           // a packable source without a raw overlap has no edge: done
+        if (pm != 0ull) {                                  // uniform
+            if (pass) {                                    // overhang: C's row from bit 2L on (see k_probe_clustered)
+                const int ws = nb >> 5, r2 = nb & 31;
+                uint32_t x[5];
+                if constexpr (KF > 0 && WC - KF <= 6) {
+                    const int t = ws - KF;
+#pragma unroll
+                    for (int k = 0; k < 5; k++) {
+                        uint32_t v = 0u;
+#pragma unroll
+                        for (int u = 0; u <= WC - KF; u++) { const int wi = KF + k + u; if (wi < 4 * EQ) v = t == u ? ew[wi] : v; }
+                        x[k] = v;
+                    }
+                } else {
+                    const uint32_t *er = reinterpret_cast<const uint32_t *>(store + ei * EQ);
+#pragma unroll
+                    for (int k = 0; k < 5; k++) x[k] = er[ws + k];
+                }
+                v_o = make_uint4(funnel(x[0], x[1], r2), funnel(x[1], x[2], r2), funnel(x[2], x[3], r2), funnel(x[3], x[4], r2));
+            }
+            // ---- fused single-survivor reduction, both halves at once ----
+            uint8_t *Tb = sT[wave][h];
+            Tb[hl] = 0xFFu; Tb[hl + 32] = 0xFFu;
+            wave_lds_fence();
+            const int d = p;
+            if (pass) Tb[d] = (uint8_t) lane;
+            wave_lds_fence();
+            const uint64_t b1 = __ballot(Tb[hl] != 0xFFu), b2 = __ballot(Tb[hl + 32] != 0xFFu);
+            const uint64_t occ = (uint64_t) half_of(b1) | ((uint64_t) half_of(b2) << 32);
+            const int nit = __popc(half_of(pm));
+            const bool one_per_offset = __popcll(occ) == nit;
+            const uint64_t below = pass ? (occ & ((1ull << d) - 1ull)) : 0ull;
+            const bool has_pred = below != 0ull;
+            const int j = has_pred ? (int) Tb[63 - __clzll((long long) below)] : lane;
+            const uint32_t Cj = bperm(id, j), mj = bperm(v_m, j);
+            Ovh<1> oj, oi;
+            oj.w[0] = bperm(v_o.x, j); oj.w[1] = bperm(v_o.y, j); oj.w[2] = bperm(v_o.z, j); oj.w[3] = bperm(v_o.w, j);
+            oi.w[0] = v_o.x; oi.w[1] = v_o.y; oi.w[2] = v_o.z; oi.w[3] = v_o.w;
+            const int rho = lenC - (lenB - d);
+            const bool removed = has_pred && via_ok<1>(B, lenB, Lbig, Cj, mj, oj, id, d, rho, oi);
+            const bool fail = has_pred && !removed && (cfg.Lcap - 1) - (d - (int) (mj & 511u)) >= Lbig;
+            const bool any_fail = half_of(__ballot(fail)) != 0u;
+            const bool keep = pass && !removed;
+            const int n_surv = __popc(half_of(__ballot(keep)));
+            reduced = packable && (nit == 0 || (one_per_offset && !any_fail && n_surv == 1));
+            if (reduced && keep) {
+                o.first[B - o.src_base] = ((unsigned long long) id << 32) | (uint32_t) d;
+                o.deg[B - o.src_base] = 1u;
+                st_rec++;
+            }
+            if (STATS && reduced) { st_raw += pass; st_cmp += has_pred; }
+        }
+        if (STATS && reduced) { st_slots += ev; if (hl == 0) st_win += (uint64_t) nwin; }
+        // ---- sources that do not finish here: to the general kernel ----
+        const uint64_t dm = __ballot(takes_part && !reduced && hl == 0);
+        if (dm != 0ull) {                                  // uniform
+            if (takes_part && !reduced && hl == 0) sDefer[wave][n_defer + (h && (dm & 1ull) ? 1 : 0)] = B;
+            n_defer += __popcll(dm);
+            wave_lds_fence();
+            if (n_defer >= 62) flush_defer();
+        }
+        // ---- (5) the next pair's index loads have had the time of (4) to land ----
+        const int nT = finish_runs(buf ^ 1, nnr_eff, nrun, ne0, ne1);
+        have = have_next; B = nB; lenB = nlenB; nr = nnr; T = nT; buf ^= 1;
+    }
+    flush_defer();
+    st_rec = wave_sum_u64(st_rec);
+    if (lane == 0 && st_rec) atomicAdd(&o.counters[CNT_VALID_RECORDS], (unsigned long long) st_rec);
+    if (STATS) {
+        st_raw = wave_sum_u64(st_raw); st_slots = wave_sum_u64(st_slots); st_win = wave_sum_u64(st_win); st_cmp = wave_sum_u64(st_cmp);
+        if (lane == 0) {
+            atomicAdd(&o.counters[CNT_RAW], (unsigned long long) st_raw);
+            atomicAdd(&o.counters[CNT_SLOTS], (unsigned long long) st_slots);
+            atomicAdd(&o.counters[CNT_WINDOWS], (unsigned long long) st_win);
+            atomicAdd(&o.counters[CNT_TR_COMPARES], (unsigned long long) st_cmp);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
 // Does the clustered probe take this input?  Fills the k-mer / index geometry and the entry size (16-byte pieces: row words + 3).
@@ -603,19 +848,44 @@ uint64_t cluster_probe_blocks(int n_cu, uint64_t n_src) {
 
 uint64_t cluster_record_slack(int n_cu, uint64_t n_src) { return cluster_probe_blocks(n_cu, n_src) * PROBE_WAVES * (uint64_t) REC_CHUNK_LOCAL; }
 
+// the pair kernel over the sources src_begin .. src_end - 1: regular sources get their edge, the others go on defer_list
+void launch_probe_pairs(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterCfg &cc, int eq, const void *store, const uint32_t *idx,
+                        const void *runs, const uint8_t *nruns, int32_t src_begin, int32_t src_end, unsigned long long *counters, int n_cu, uint32_t *deg,
+                        unsigned long long *first, int32_t *defer_list, uint32_t defer_cap, hipStream_t s) {
+    const int64_t ns = (int64_t) src_end - src_begin;
+    if (ns <= 0) return;
+    const uint64_t pairs = ((uint64_t) ns + 1) / 2;
+    dim3 grid((unsigned) std::max<uint64_t>(1, std::min<uint64_t>((pairs + PROBE_WAVES - 1) / PROBE_WAVES, (uint64_t) std::max(1, n_cu) * CLP_OCC))), block(PROBE_WAVES * 64);
+    ProbeOut o{nullptr, nullptr, 0, counters, deg, first, src_begin};
+    const uint4 *st = (const uint4 *) store;
+    const int kf = (2 * cfg.Lmin) >> 5;
+#define CLP_LAUNCH(ST, E, K) hipLaunchKernelGGL((k_probe_pairs<ST, E, K>), grid, block, 0, s, nd, cfg, cc, st, idx, (const uint2 *) runs, nruns, src_begin, src_end, o, defer_list, defer_cap)
+#define CLP_STATS(E, K) do { if (cfg.stats) CLP_LAUNCH(true, E, K); else CLP_LAUNCH(false, E, K); } while (0)
+    if (eq == 3 && kf == 5)      CLP_STATS(3, 5);
+    else if (eq == 3 && kf == 3) CLP_STATS(3, 3);
+    else if (eq == 2 && kf == 3) CLP_STATS(2, 3);
+    else if (eq == 2)            CLP_STATS(2, 0);
+    else if (eq == 3)            CLP_STATS(3, 0);
+    else                         CLP_STATS(4, 0);
+#undef CLP_STATS
+#undef CLP_LAUNCH
+}
+
+// src_list == null: the sources are the ids src_begin .. src_end - 1; else the ids src_list[src_begin .. src_end - 1]
 void launch_probe_clustered(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterCfg &cc, int eq, const void *store, const uint32_t *idx,
-                            const void *runs, const uint8_t *nruns, int32_t src_begin, int32_t src_end, uint32_t *rec_dst, unsigned long long *rec_val, uint64_t rec_cap,
+                            const void *runs, const uint8_t *nruns, int32_t src_begin, int32_t src_end, const int32_t *src_list, int32_t src_base,
+                            uint32_t *rec_dst, unsigned long long *rec_val, uint64_t rec_cap,
                             unsigned long long *counters, int n_cu, uint32_t *deg, unsigned long long *first, const ProbeBig *big, hipStream_t s) {
     const int64_t ns = (int64_t) src_end - src_begin;
     if (ns <= 0) return;
     dim3 grid((unsigned) cluster_probe_blocks(n_cu, (uint64_t) ns)), block(PROBE_WAVES * 64);
-    ProbeOut o{rec_dst, rec_val, rec_cap, counters, deg, first, src_begin};
+    ProbeOut o{rec_dst, rec_val, rec_cap, counters, deg, first, src_base};
     if (big) { o.big_list = big->list; o.big_list_cap = big->list_cap; }
     const uint4 *st = (const uint4 *) store;
     // KF = (2 * Lmin) >> 5 as a compile-time constant for the shapes ALGA's defaults produce (150-bp reads: Lmin 82, rows of 9
     // words; 100-bp reads: Lmin 55, rows of 6 words); 0 = any shape
     const int kf = (2 * cfg.Lmin) >> 5;
-#define CL_LAUNCH(ST, E, K) hipLaunchKernelGGL((k_probe_clustered<ST, E, K>), grid, block, 0, s, nd, cfg, cc, st, idx, (const uint2 *) runs, nruns, src_begin, src_end, o)
+#define CL_LAUNCH(ST, E, K) hipLaunchKernelGGL((k_probe_clustered<ST, E, K>), grid, block, 0, s, nd, cfg, cc, st, idx, (const uint2 *) runs, nruns, src_begin, src_end, o, src_list)
 #define CL_STATS(E, K) do { if (cfg.stats) CL_LAUNCH(true, E, K); else CL_LAUNCH(false, E, K); } while (0)
     if (eq == 3 && kf == 5)      CL_STATS(3, 5);
     else if (eq == 3 && kf == 3) CL_STATS(3, 3);

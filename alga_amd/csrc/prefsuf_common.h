@@ -81,7 +81,8 @@ enum Counter {
     CNT_LOCAL_OVERFLOW,    // sources with more raw overlaps than the source-side reduction holds (LDS; in the second pass: its global slice)
     CNT_LOCAL_GENERIC,     // sources that took the all-pairs path of the source-side reduction
     CNT_LOCAL_MAXITEMS,    // largest number of raw overlaps of one source seen by the source-side reduction
-    CNT_TOTAL = 16
+    CNT_DEFERRED,          // clustered probe, pair kernel: sources handed to the general kernel
+    CNT_TOTAL = 24
 };
 
 struct NodesDev {

@@ -43,8 +43,11 @@ hipError_t launch_cluster_build(const NodesDev &nd, const PrefSufCfg &cfg, const
                                 uint32_t *keys2, uint32_t *vals2, uint32_t *meta, void *runs, uint8_t *nruns, void *sort_temp, size_t sort_temp_bytes,
                                 void *store, uint32_t *idx, hipStream_t s);
 uint64_t   cluster_record_slack(int n_cu, uint64_t n_src);
+void       launch_probe_pairs(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterCfg &cc, int eq, const void *store, const uint32_t *idx,
+                              const void *runs, const uint8_t *nruns, int32_t src_begin, int32_t src_end, unsigned long long *counters, int n_cu, uint32_t *deg,
+                              unsigned long long *first, int32_t *defer_list, uint32_t defer_cap, hipStream_t s);
 void       launch_probe_clustered(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterCfg &cc, int eq, const void *store, const uint32_t *idx,
-                                  const void *runs, const uint8_t *nruns, int32_t src_begin, int32_t src_end, uint32_t *rec_dst, unsigned long long *rec_val, uint64_t rec_cap,
+                                  const void *runs, const uint8_t *nruns, int32_t src_begin, int32_t src_end, const int32_t *src_list, int32_t src_base, uint32_t *rec_dst, unsigned long long *rec_val, uint64_t rec_cap,
                                   unsigned long long *counters, int n_cu, uint32_t *deg, unsigned long long *first, const ProbeBig *big, hipStream_t s);
 
 size_t     sort_u32_pairs_temp_bytes(uint64_t n);

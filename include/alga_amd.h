@@ -109,6 +109,7 @@ typedef struct {
     uint64_t generic_sources;     /* SOURCE_SIDE: sources that needed the all-pairs path (collect_stats) */
     uint64_t big_sources;         /* SOURCE_SIDE: sources with more raw overlaps than a wave's LDS holds (second pass) */
     uint64_t probe_used;          /* alga_probe of the last build (1 or 2)                       */
+    uint64_t deferred_sources;    /* CLUSTER probe: sources the pair kernel handed to the general kernel (all of them when it was skipped) */
 } alga_prefsuf_stats;
 
 /* ---- lifetime --------------------------------------------------------------------------- */
@@ -121,6 +122,8 @@ int         alga_engine_device_name(const alga_engine *e, char *buf, size_t bufl
 /* Engine switches.  None changes a result, only how it is computed; there are no environment variables.
  *   "probe"                      alga_probe (default AUTO)
  *   "cluster_bucket_bias"        -8..8: log2 factor on the bucket count of the CLUSTER probe's index (default 0: ~1 entry per bucket)
+ *   "cluster_pairs"              0: the CLUSTER probe runs its general kernel only (one source per wave); default 1: the pair
+ *                                kernel (two sources per wave) first, the general kernel on what it defers
  *   "local_big_max"              largest per-wave item slice of the SOURCE_SIDE second pass (default -1 = built-in 4096); beyond it
  *                                the build takes PER_TARGET
  *   "auto_reduction_per_target"  != 0: alga_prefsuf_params.reduction == AUTO resolves to PER_TARGET */

@@ -39,7 +39,7 @@ def main():
             st = eng.last_stats()
             if it == 0:
                 out[probe + "_counters"] = {k: st[k] for k in ("raw_overlaps", "records", "edges", "generic_sources", "windows_probed", "slots_scanned",
-                                                                "big_sources", "probe_used")}
+                                                                "big_sources", "probe_used", "deferred_sources")}
             ms.append({k: round(st[k], 3) for k in ("ms_total", "ms_seed", "ms_probe", "ms_emit")})
             print(probe, it, E, ms[-1], flush=True)
         out[probe] = ms
