@@ -24,8 +24,6 @@ using namespace alga;
 
 namespace {
 
-constexpr uint64_t CLUSTER_AUTO_MIN_NODES = 4ull << 20;   // AUTO: node sets below this stay on the seed-table probe
-
 struct Prepared {
     NodesDev   nd;
     PrefSufCfg cfg;
@@ -88,10 +86,10 @@ int prepare(alga_engine *e, const alga_nodes *nodes, const alga_prefsuf_params *
                    e->h_counters[CNT_MASK_ASYM] == 0;
     out.local_sw = out.max_len - c.Lmin <= 63 ? 1 : 2;
     // Which probe feeds the source-side form.  The clustered minimizer join (prefsuf_cluster.hip) takes one-word offset masks and
-    // rows of up to 13 words; AUTO uses it once the node set has outgrown the on-die caches (the seed-table probe is faster while
-    // table + rows stay in the 256 MB Infinity Cache: measured cross-over in DESIGN.md section 5c).
+    // rows of up to 13 words; AUTO uses it whenever it takes the input (measured faster than the seed-table probe from 1.7 M
+    // nodes, where everything is cache-resident, to 90 M: DESIGN.md section 5c).
     out.cluster_eq = 0;
-    if (out.local_ok && out.local_sw == 1 && e->opt_probe != ALGA_PROBE_TABLE && !(e->opt_probe == ALGA_PROBE_AUTO && out.live < CLUSTER_AUTO_MIN_NODES)) {
+    if (out.local_ok && out.local_sw == 1 && e->opt_probe != ALGA_PROBE_TABLE) {
         int eq = 0;
         if (cluster_plan(c, out.max_len, out.live, e->opt_cluster_bucket_bias, &out.cluster, &eq)) out.cluster_eq = eq;
     }

@@ -563,7 +563,7 @@ k_probe_clustered(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__res
 // k_probe_clustered (list mode) afterwards: nothing is decided twice, nothing is approximated.
 // Same two-stage software pipeline as k_probe_clustered; "uniform per source" values live in vector registers (one per half).
 #ifndef CLP_OCC
-#define CLP_OCC 8
+#define CLP_OCC 7                     // workgroups per CU: 28 waves per CU (72 VGPRs, no spills; 6, 7 and 8 measured within 2 %)
 #endif
 template <bool STATS, int EQ, int KF>
 __global__ void __launch_bounds__(PROBE_WAVES * 64, CLP_OCC)
