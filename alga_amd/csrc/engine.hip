@@ -110,6 +110,7 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
     HIP_TRY(e, hipEventRecord(e->ev[EV_START], s));
     if (pp.live >= (1ull << 31)) return alga_fail(e, ALGA_ERR_CAPACITY, "too many nodes for one seed table; shard the input");
     const bool clustered = local && pp.cluster_eq != 0;
+    e->pairs_timed = false;
     uint32_t n_buckets = 0, filter_bits = 0;
     bool have_table = false;
     auto build_table = [&]() -> int {                      // bucketised seed table + prefilter of prefsuf_kernels.hip
@@ -181,6 +182,8 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
                                    src_begin, src_end, cnt, e->n_cu, (uint32_t *) e->outdeg.p, (unsigned long long *) e->loc_first.p, (int32_t *) e->cl_defer.p,
                                    (uint32_t) n_src, s);
                 if ((rc = alga_check_launch(e, "k_probe_pairs"))) return rc;
+                HIP_TRY(e, hipEventRecord(e->ev[EV_PAIRS], s));
+                e->pairs_timed = true;
                 HIP_TRY(e, hipMemcpyAsync(&e->h_counters[CNT_DEFERRED], cnt + CNT_DEFERRED, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
                 HIP_TRY(e, hipStreamSynchronize(s));
                 const uint64_t n_def = e->h_counters[CNT_DEFERRED];
@@ -488,6 +491,7 @@ int alga_prefsuf_build_device(alga_engine *e, const alga_nodes *nodes, const alg
     }
     e->stats.ms_seed = ev_ms(e, EV_START, EV_SEED);
     e->stats.ms_probe = ev_ms(e, EV_SEED, EV_PROBE);
+    e->stats.ms_probe_pairs = e->pairs_timed ? ev_ms(e, EV_SEED, EV_PAIRS) : 0.0;
     e->stats.ms_group = ev_ms(e, EV_PROBE, EV_GROUP);
     e->stats.ms_reduce = ev_ms(e, EV_GROUP, EV_REDUCE);
     e->stats.ms_emit = ev_ms(e, EV_REDUCE, EV_EMIT);
@@ -641,6 +645,7 @@ int alga_prefsuf_build_range_device(alga_engine *e, const alga_nodes *nodes, con
     if ((rc = build_local(e, pp, src_begin, src_end, s, &E))) return rc;
     e->stats.ms_seed = ev_ms(e, EV_START, EV_SEED);
     e->stats.ms_probe = ev_ms(e, EV_SEED, EV_PROBE);
+    e->stats.ms_probe_pairs = e->pairs_timed ? ev_ms(e, EV_SEED, EV_PAIRS) : 0.0;
     e->stats.ms_emit = ev_ms(e, EV_REDUCE, EV_EMIT);
     e->stats.ms_total = ev_ms(e, EV_START, EV_EMIT);
     *d_edges = (const alga_edge *) e->edges.p;

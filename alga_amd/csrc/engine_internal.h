@@ -15,7 +15,7 @@ struct DevBuf {
     size_t cap = 0;
 };
 
-enum { EV_START = 0, EV_SEED, EV_PROBE, EV_GROUP, EV_REDUCE, EV_EMIT, EV_COUNT };
+enum { EV_START = 0, EV_SEED, EV_PROBE, EV_GROUP, EV_REDUCE, EV_EMIT, EV_PAIRS, EV_COUNT };
 constexpr int ALGA_STAGE_THREADS = 8;      // worker threads (pinned buffer pairs, streams) of the staged host <-> HBM copies
 
 struct alga_engine {
@@ -33,6 +33,7 @@ struct alga_engine {
     // device buffers, grown on demand and kept between calls
     DevBuf table, filter, counters, rowptr, rec_dst, rec_val, keys, seg_key, seg_val, heads, sort_temp, out_cnt, outdeg, out_rowptr, edges, scan_scratch;
     DevBuf cl_defer;                                        // sources the pair kernel hands to the general kernel
+    bool   pairs_timed = false;                             // EV_PAIRS was recorded in the last discovery
     double cl_defer_ratio = 0.0;                            // ... their share in the last build: above one half the pair kernel is skipped
     int    opt_cluster_pairs = 1;                           // option "cluster_pairs": 0 = general kernel only
     DevBuf cl_keys[2], cl_vals[2], cl_meta, cl_runs, cl_nruns, cl_store, cl_idx;   // clustered minimizer join: sort buffers, per-node minimizer runs, entry array, bucket index

@@ -106,9 +106,10 @@ def cpu_baseline_port(words, lens, lo, rs, budget_nodes):
                 sample="first %d nodes of the workload, single-thread C oracle, %.2f s" % (len(l), dt), seconds=dt, edges=len(e))
 
 
-def profiled_traffic(config, lib_sha):
-    """HBM-side bytes per probe launch from the rocprofv3 --pmc passes (tools/pmc_to_traffic.py -> profiles/probe_hbm_bytes.json),
-    reported only when they were taken on THIS build of the library; otherwise null."""
+def profiled_traffic(config, lib_sha, kernel=None):
+    """Memory-side bytes per launch (FETCH_SIZE + WRITE_SIZE as counted) of one probe kernel, or of the whole probe phase, from the
+    rocprofv3 --pmc passes (tools/pmc_to_traffic.py -> profiles/probe_hbm_bytes.json); reported only when they were taken on THIS
+    build of the library, otherwise null."""
     tf = os.path.join(ROOT, "profiles", "probe_hbm_bytes.json")
     try:
         ent = json.load(open(tf)).get(config)
@@ -116,7 +117,12 @@ def profiled_traffic(config, lib_sha):
         return None
     if not ent or ent.get("lib_sha256") != lib_sha:
         return None
-    return ent.get("hbm_bytes_per_launch")
+    if kernel is None:
+        return ent.get("hbm_bytes_per_launch")
+    try:
+        return int((ent["fetch_kib"][kernel] + ent["write_kib"][kernel]) * 1024)
+    except Exception:
+        return None
 
 
 def main():
@@ -188,12 +194,13 @@ def main():
     for _ in range(max(0, args.warmup - 1)):
         runner.step()
     sync_all()
-    probe_ms = []
+    probe_ms, pairs_ms = [], []
     phase = dict(seed=0.0, probe=0.0, group=0.0, reduce=0.0, emit=0.0, exchange=0.0)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         n_edges, s = runner.step()
         probe_ms.append(s["ms_probe"])
+        pairs_ms.append(s.get("ms_probe_pairs", 0.0))
         for k in phase:
             phase[k] += s.get("ms_" + k, 0.0)
     sync_all()
@@ -211,7 +218,21 @@ def main():
         probe_avg_ms = float(np.mean(probe_ms))
         alg_probe_launch = alg["probe"] / world           # one launch = one rank's share of the sources
         achieved = alg_probe_launch / (probe_avg_ms * 1e-3) / 1e9
-        probe_kernel = "k_probe_clustered" if stats.get("probe_used") == 2 else "k_probe_sources"
+        # The probe of the clustered path is TWO kernels: k_probe_pairs finishes the regular sources (and defers the others),
+        # k_probe_clustered takes the deferred ones.  `roofline` is the dominant one, k_probe_pairs, on the sources it FINISHES;
+        # `probe_phase` is both kernels over all sources (the HIP events around the two launches).
+        n_src = max(1, stats["nodes_live"])
+        deferred = int(stats.get("deferred_sources", 0))
+        pairs_avg_ms = float(np.mean(pairs_ms)) if pairs_ms else 0.0
+        two_kernels = stats.get("probe_used") == 2 and pairs_avg_ms > 0 and world == 1
+        if two_kernels:
+            probe_kernel = "k_probe_pairs"
+            kernel_ms = pairs_avg_ms
+            kernel_bytes = alg_probe_launch * (1.0 - deferred / n_src)
+        else:
+            probe_kernel = "k_probe_clustered" if stats.get("probe_used") == 2 else "k_probe_sources"
+            kernel_ms, kernel_bytes = probe_avg_ms, alg_probe_launch
+        achieved_kernel = kernel_bytes / (kernel_ms * 1e-3) / 1e9
         lib_sha = hashlib.sha256(open(alga_amd.engine.library_path(), "rb").read()).hexdigest()[:16]
         out = {
             "metric": "overlap_edges_per_sec", "value": n_edges * args.steps / dt, "unit": "edges/s",
@@ -224,16 +245,20 @@ def main():
                        "nodes": n_nodes, "edges": int(n_edges), "parallelism": "1 GPU" if world == 1 else
                        "strong scaling: the same read set for every N; node set and target index on every rank, sources sharded over %d ranks "
                        "(contiguous id ranges), each rank builds the final edges of its sources, edge lists gathered on rank 0 over RCCL" % world},
-            "roofline": {"bound": "hbm", "kernel": probe_kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": profiled_traffic(args.config, lib_sha) if world == 1 else None,
-                         "traffic_source": "rocprofv3 --pmc passes of this command on this build (profiles/probe_hbm_bytes.json, lib %s); null = not profiled on this build" % lib_sha,
-                         "algorithmic_bytes": alg_probe_launch, "kernel_ms": probe_avg_ms,
+            "roofline": {"bound": "hbm", "kernel": probe_kernel, "achieved": achieved_kernel, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved_kernel / HBM_PEAK_GBS, "traffic": profiled_traffic(args.config, lib_sha, probe_kernel) if world == 1 else None,
+                         "traffic_source": "rocprofv3 --pmc passes of this command on this build (profiles/probe_hbm_bytes.json, lib %s): FETCH_SIZE + WRITE_SIZE of that kernel as counted; null = not profiled on this build" % lib_sha,
+                         "algorithmic_bytes": kernel_bytes, "kernel_ms": kernel_ms,
+                         "units": "%d source nodes finished by this kernel per launch (of %d; %d deferred to k_probe_clustered)" % (n_src - deferred, n_src, deferred) if two_kernels else "%d source nodes per launch" % (n_src // world),
                          "per_unit": "per source node: 4W + 16 P + 4W * raw/node bytes (W=%d words, P=%.1f windows, raw/node=%.2f)" %
                                      (W, stats["windows_probed"] / max(1, stats["nodes_live"]), stats["raw_overlaps"] / max(1, stats["nodes_live"]))},
+            "probe_phase": {"kernels": ["k_probe_pairs", "k_probe_clustered"] if two_kernels else [probe_kernel], "ms": probe_avg_ms,
+                            "algorithmic_bytes": alg_probe_launch, "achieved": achieved, "frac": achieved / HBM_PEAK_GBS,
+                            "traffic": profiled_traffic(args.config, lib_sha) if world == 1 else None},
             "phases_ms": {k: v / args.steps for k, v in phase.items()},
             "counters": {k: int(stats[k]) for k in ("nodes_live", "windows_probed", "slots_scanned", "raw_overlaps", "records",
                                                     "transitive_listed", "transitive_compares", "transitive_removed", "edges",
-                                                    "max_in_records", "table_slots", "probe_used", "reduction_used", "big_sources")},
+                                                    "max_in_records", "table_slots", "probe_used", "reduction_used", "big_sources", "deferred_sources")},
             "algorithmic_bytes_total": alg["total"],
             "device": eng.device_name(),
         }

@@ -111,6 +111,7 @@ typedef struct {
     uint64_t big_sources;         /* SOURCE_SIDE: sources with more raw overlaps than a wave's LDS holds (second pass) */
     uint64_t probe_used;          /* alga_probe of the last build (1 or 2)                       */
     uint64_t deferred_sources;    /* CLUSTER probe: sources the pair kernel handed to the general kernel (all of them when it was skipped) */
+    double   ms_probe_pairs;      /* CLUSTER probe: the pair kernel's part of ms_probe (0: not run) */
 } alga_prefsuf_stats;
 
 /* ---- lifetime --------------------------------------------------------------------------- */
