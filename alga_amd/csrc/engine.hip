@@ -34,6 +34,7 @@ struct Prepared {
     int        cluster_eq = 0;       // clustered minimizer probe: 16-byte pieces per entry (0 = that probe does not take this input)
     ClusterCfg cluster{};
     int        reduction = ALGA_REDUCTION_AUTO;
+    bool       keys_shared = false;  // the per-node keys come from alga_prefsuf_keys_device + the caller's all-gather
 };
 
 // Validates arguments, measures max read length / live nodes on the device and derives the
@@ -93,9 +94,27 @@ int prepare(alga_engine *e, const alga_nodes *nodes, const alga_prefsuf_params *
         int eq = 0;
         if (cluster_plan(c, out.max_len, out.live, e->opt_cluster_bucket_bias, &out.cluster, &eq)) out.cluster_eq = eq;
     }
+    out.keys_shared = p->keys_shared != 0;
     out.reduction = p->reduction;
     if (out.reduction == ALGA_REDUCTION_AUTO && e->opt_force_per_target) out.reduction = ALGA_REDUCTION_PER_TARGET;
     return ALGA_OK;
+}
+
+// buffers of the clustered minimizer join for pp's node set
+int cluster_alloc(alga_engine *e, const Prepared &pp) {
+    int rc;
+    const uint64_t n = (uint64_t) pp.nd.n;
+    // keys[0] / meta: ALGA_KEY_ARRAY_SLACK entries of room past n, so that equal-sized all-gather slices may run past the last node
+    for (int k = 0; k < 2; k++) {
+        if ((rc = alga_ensure(e, e->cl_keys[k], (n + ALGA_KEY_ARRAY_SLACK + 1) * sizeof(uint32_t)))) return rc;
+        if ((rc = alga_ensure(e, e->cl_vals[k], (n + 1) * sizeof(uint32_t)))) return rc;
+    }
+    if ((rc = alga_ensure(e, e->cl_meta, (n + ALGA_KEY_ARRAY_SLACK + 1) * sizeof(uint32_t)))) return rc;
+    if ((rc = alga_ensure(e, e->cl_runs, (n + 1) * CL_RMAX * 8))) return rc;
+    if ((rc = alga_ensure(e, e->cl_nruns, n + 16))) return rc;
+    if ((rc = alga_ensure(e, e->cl_store, (n + 2) * 16 * (size_t) pp.cluster_eq))) return rc;
+    if ((rc = alga_ensure(e, e->cl_idx, ((size_t) pp.cluster.n_buckets + 2) * sizeof(uint32_t)))) return rc;
+    return alga_ensure(e, e->sort_temp, cluster_sort_temp_bytes(n));
 }
 
 // seed + probe.  On return e->rec_dst / e->rec_val hold *n_rec record slots (chunk padding included).
@@ -133,22 +152,22 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
     ClusterCfg cc{};
     if (clustered) {
         // targets in minimizer-hash order: sort keys, entry array, bucket index
-        const uint64_t n = (uint64_t) nd.n;
         cc = pp.cluster;
-        const size_t temp = cluster_sort_temp_bytes(n);
-        for (int k = 0; k < 2; k++) {
-            if ((rc = alga_ensure(e, e->cl_keys[k], (n + 1) * sizeof(uint32_t)))) return rc;
-            if ((rc = alga_ensure(e, e->cl_vals[k], (n + 1) * sizeof(uint32_t)))) return rc;
+        if ((rc = cluster_alloc(e, pp))) return rc;
+        if (pp.keys_shared) {
+            // keys / meta of every node are in place (this rank's share by alga_prefsuf_keys_device, the others' by the caller's
+            // all-gather); the runs of this rank's share are what the probe of [src_begin, src_end) reads
+            if (e->keyed_n != nd.n || e->keyed_words != (const void *) nd.words || src_begin < e->keyed_begin || src_end > e->keyed_end)
+                return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "keys_shared: alga_prefsuf_keys_device has not been called on this node set for a range that covers the sources");
+        } else {
+            launch_cluster_keys(nd, cfg, cc, 0, nd.n, (uint32_t *) e->cl_keys[0].p, (uint32_t *) e->cl_vals[0].p, (uint32_t *) e->cl_meta.p, e->cl_runs.p,
+                                (uint8_t *) e->cl_nruns.p, s);
+            if ((rc = alga_check_launch(e, "k_node_runs"))) return rc;
         }
-        if ((rc = alga_ensure(e, e->cl_meta, (n + 1) * sizeof(uint32_t)))) return rc;
-        if ((rc = alga_ensure(e, e->cl_runs, (n + 1) * CL_RMAX * 8))) return rc;
-        if ((rc = alga_ensure(e, e->cl_nruns, n + 16))) return rc;
-        if ((rc = alga_ensure(e, e->cl_store, (n + 2) * 16 * (size_t) pp.cluster_eq))) return rc;
-        if ((rc = alga_ensure(e, e->cl_idx, ((size_t) cc.n_buckets + 2) * sizeof(uint32_t)))) return rc;
-        if ((rc = alga_ensure(e, e->sort_temp, temp))) return rc;
-        HIP_TRY(e, launch_cluster_build(nd, cfg, cc, pp.cluster_eq, (uint32_t *) e->cl_keys[0].p, (uint32_t *) e->cl_vals[0].p, (uint32_t *) e->cl_keys[1].p,
-                                        (uint32_t *) e->cl_vals[1].p, (uint32_t *) e->cl_meta.p, e->cl_runs.p, (uint8_t *) e->cl_nruns.p, e->sort_temp.p, temp, e->cl_store.p,
-                                        (uint32_t *) e->cl_idx.p, s));
+        e->keyed_n = -1;                                   // the sort below may reuse the key buffers: one build per key pass
+        HIP_TRY(e, launch_cluster_store(nd, cc, pp.cluster_eq, (uint32_t *) e->cl_keys[0].p, (uint32_t *) e->cl_vals[0].p, (uint32_t *) e->cl_keys[1].p,
+                                        (uint32_t *) e->cl_vals[1].p, (const uint32_t *) e->cl_meta.p, e->sort_temp.p, cluster_sort_temp_bytes((uint64_t) nd.n),
+                                        e->cl_store.p, (uint32_t *) e->cl_idx.p, pp.keys_shared, s));
         e->stats.table_slots = cc.n_buckets;
     } else if ((rc = build_table())) return rc;
     HIP_TRY(e, hipEventRecord(e->ev[EV_SEED], s));
@@ -650,6 +669,32 @@ int alga_prefsuf_build_range_device(alga_engine *e, const alga_nodes *nodes, con
     e->stats.ms_total = ev_ms(e, EV_START, EV_EMIT);
     *d_edges = (const alga_edge *) e->edges.p;
     *n_edges = E;
+    return ALGA_OK;
+}
+
+int alga_prefsuf_keys_device(alga_engine *e, const alga_nodes *nodes, const alga_prefsuf_params *p, int32_t node_begin, int32_t node_end,
+                             void *hip_stream, alga_node_keys *out) {
+    if (!e) return ALGA_ERR_INVALID_ARGUMENT;
+    e->err.clear();
+    if (!out) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "output pointer must not be NULL");
+    memset(out, 0, sizeof(*out));
+    e->keyed_n = -1;
+    HIP_TRY(e, hipSetDevice(e->device));
+    hipStream_t s = hip_stream ? (hipStream_t) hip_stream : e->own_stream;
+    Prepared pp;
+    int rc = prepare(e, nodes, p, s, pp);
+    if (rc) return rc;
+    if (node_begin < 0 || node_end > nodes->n || node_begin > node_end) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "bad node range");
+    out->n = nodes->n;
+    if (pp.cluster_eq == 0 || pp.reduction == ALGA_REDUCTION_PER_TARGET || nodes->n == 0) return ALGA_OK;      // eligible = 0: nothing to share
+    if ((rc = cluster_alloc(e, pp))) return rc;
+    launch_cluster_keys(pp.nd, pp.cfg, pp.cluster, node_begin, node_end, (uint32_t *) e->cl_keys[0].p, (uint32_t *) e->cl_vals[0].p, (uint32_t *) e->cl_meta.p,
+                        e->cl_runs.p, (uint8_t *) e->cl_nruns.p, s);
+    if ((rc = alga_check_launch(e, "k_node_runs"))) return rc;
+    e->keyed_n = nodes->n; e->keyed_begin = node_begin; e->keyed_end = node_end; e->keyed_words = (const void *) nodes->words;
+    out->eligible = 1;
+    out->d_keys = (uint32_t *) e->cl_keys[0].p;
+    out->d_meta = (uint32_t *) e->cl_meta.p;
     return ALGA_OK;
 }
 

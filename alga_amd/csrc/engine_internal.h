@@ -33,6 +33,10 @@ struct alga_engine {
     // device buffers, grown on demand and kept between calls
     DevBuf table, filter, counters, rowptr, rec_dst, rec_val, keys, seg_key, seg_val, heads, sort_temp, out_cnt, outdeg, out_rowptr, edges, scan_scratch;
     DevBuf cl_defer;                                        // sources the pair kernel hands to the general kernel
+    // alga_prefsuf_keys_device: the node range whose keys / runs this engine computed last (n < 0: none), consumed by a build with
+    // params.keys_shared
+    int32_t keyed_n = -1, keyed_begin = 0, keyed_end = 0;
+    const void *keyed_words = nullptr;
     bool   pairs_timed = false;                             // EV_PAIRS was recorded in the last discovery
     double cl_defer_ratio = 0.0;                            // ... their share in the last build: above one half the pair kernel is skipped
     int    opt_cluster_pairs = 1;                           // option "cluster_pairs": 0 = general kernel only

@@ -79,14 +79,14 @@ constexpr int NR_STACK = 12;         // prefix-minimum records kept per node (a 
 // keys[i] = cluster key of run 0 (all ones: not a target), vals[i] = i, meta[i] = m_C | len << 8 | alignFrom << 20,
 // runs[i * CL_RMAX + k] = {key, q | p0 << 8 | p1 << 16}, nruns[i] = number of runs (0: not a source; CL_RUNS_FLAGGED: more than
 // CL_RMAX runs or records than the stack holds -- the probe hands such a source to the seed-table second pass).
-__global__ void __launch_bounds__(TK_ROWS) k_node_runs(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, uint32_t *__restrict__ keys,
-                                                        uint32_t *__restrict__ vals, uint32_t *__restrict__ meta, uint2 *__restrict__ runs,
-                                                        uint8_t *__restrict__ nruns) {
+__global__ void __launch_bounds__(TK_ROWS) k_node_runs(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, int node_begin, int node_end,
+                                                        uint32_t *__restrict__ keys, uint32_t *__restrict__ vals, uint32_t *__restrict__ meta,
+                                                        uint2 *__restrict__ runs, uint8_t *__restrict__ nruns) {
     __shared__ uint32_t s[TK_ROWS][TK_STRIDE];
     __shared__ uint32_t stk[NR_STACK][TK_ROWS];            // transposed: conflict-free
     __shared__ uint32_t rbuf[CL_RMAX][TK_ROWS];            // runs as they are found: q | p0 << 8 | p1 << 16
-    const int base = blockIdx.x * TK_ROWS;
-    const int nrows = min(TK_ROWS, nd.n - base);
+    const int base = node_begin + blockIdx.x * TK_ROWS;     // the nodes node_begin .. node_end - 1 (a rank's share, or all of them)
+    const int nrows = min(TK_ROWS, node_end - base);
     {
         const int c = (int) (threadIdx.x & 15u);
         for (int r = (int) (threadIdx.x >> 4); r < nrows; r += TK_ROWS / 16)
@@ -824,19 +824,33 @@ bool cluster_plan(const PrefSufCfg &cfg, int max_len, uint64_t live, int bucket_
 
 size_t cluster_sort_temp_bytes(uint64_t n) { return sort_u32_pairs_temp_bytes(n); }
 
-hipError_t launch_cluster_build(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterCfg &cc, int eq, uint32_t *keys, uint32_t *vals,
-                                uint32_t *keys2, uint32_t *vals2, uint32_t *meta, void *runs, uint8_t *nruns, void *sort_temp, size_t sort_temp_bytes,
-                                void *store, uint32_t *idx, hipStream_t s) {
+// minimizer keys, entry words and runs of the nodes node_begin .. node_end - 1 (per-node arrays, written at the node's own index)
+void launch_cluster_keys(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterCfg &cc, int32_t node_begin, int32_t node_end, uint32_t *keys, uint32_t *vals,
+                         uint32_t *meta, void *runs, uint8_t *nruns, hipStream_t s) {
+    if (node_end <= node_begin) return;
+    const uint64_t m = (uint64_t) (node_end - node_begin);
+    hipLaunchKernelGGL(k_node_runs, dim3((unsigned) ((m + TK_ROWS - 1) / TK_ROWS)), dim3(TK_ROWS), 0, s, nd, cfg, cc, (int) node_begin, (int) node_end, keys, vals, meta,
+                       (uint2 *) runs, nruns);
+}
+
+__global__ void __launch_bounds__(256) k_iota(uint32_t *__restrict__ v, uint32_t n) {
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) v[i] = i;
+}
+
+// keys / meta of all n nodes -> the entry array in key order and its bucket index.  fill_vals: the ids (sort payload) were not
+// written by this engine's key pass for every node (keys gathered from other ranks): write them here.
+hipError_t launch_cluster_store(const NodesDev &nd, const ClusterCfg &cc, int eq, uint32_t *keys, uint32_t *vals, uint32_t *keys2, uint32_t *vals2,
+                                const uint32_t *meta, void *sort_temp, size_t sort_temp_bytes, void *store, uint32_t *idx, bool fill_vals, hipStream_t s) {
     if (nd.n <= 0) return hipSuccess;
     const uint64_t n = (uint64_t) nd.n;
-    hipLaunchKernelGGL(k_node_runs, dim3((unsigned) ((n + TK_ROWS - 1) / TK_ROWS)), dim3(TK_ROWS), 0, s, nd, cfg, cc, keys, vals, meta, (uint2 *) runs, nruns);
+    if (fill_vals) hipLaunchKernelGGL(k_iota, dim3((unsigned) std::min<uint64_t>((n + 255) / 256, 8192)), dim3(256), 0, s, vals, (uint32_t) n);
     hipError_t err = sort_u32_pairs(sort_temp, sort_temp_bytes, keys, keys2, vals, vals2, n, s);
     if (err != hipSuccess) return err;
     const uint64_t pieces = n * (uint64_t) eq;
     const unsigned g = (unsigned) ((pieces + 255) / 256);
-    if (eq == 2)      hipLaunchKernelGGL(k_tgt_gather<2>, dim3(g), dim3(256), 0, s, nd, (const uint32_t *) keys2, (const uint32_t *) vals2, (const uint32_t *) meta, (uint4 *) store);
-    else if (eq == 3) hipLaunchKernelGGL(k_tgt_gather<3>, dim3(g), dim3(256), 0, s, nd, (const uint32_t *) keys2, (const uint32_t *) vals2, (const uint32_t *) meta, (uint4 *) store);
-    else              hipLaunchKernelGGL(k_tgt_gather<4>, dim3(g), dim3(256), 0, s, nd, (const uint32_t *) keys2, (const uint32_t *) vals2, (const uint32_t *) meta, (uint4 *) store);
+    if (eq == 2)      hipLaunchKernelGGL(k_tgt_gather<2>, dim3(g), dim3(256), 0, s, nd, (const uint32_t *) keys2, (const uint32_t *) vals2, meta, (uint4 *) store);
+    else if (eq == 3) hipLaunchKernelGGL(k_tgt_gather<3>, dim3(g), dim3(256), 0, s, nd, (const uint32_t *) keys2, (const uint32_t *) vals2, meta, (uint4 *) store);
+    else              hipLaunchKernelGGL(k_tgt_gather<4>, dim3(g), dim3(256), 0, s, nd, (const uint32_t *) keys2, (const uint32_t *) vals2, meta, (uint4 *) store);
     hipLaunchKernelGGL(k_tgt_index, dim3((unsigned) std::min<uint64_t>((n + 256) / 256, 16384)), dim3(256), 0, s, (const uint32_t *) keys2, n, cc.idx_shift,
                        cc.n_buckets, idx);
     return hipGetLastError();

@@ -39,9 +39,10 @@ void launch_local_emit(int32_t src_base, int32_t n_src, const uint32_t *deg, con
 bool       cluster_plan(const PrefSufCfg &cfg, int max_len, uint64_t live, int bucket_log2_bias, ClusterCfg *c, int *eq);   // false: this probe does not take the input
 size_t     cluster_sort_temp_bytes(uint64_t n);
 // keys/vals/keys2/vals2/meta: n uint32 each; runs: n * CL_RMAX * 8 bytes; nruns: n bytes; store: (n + 2) * 16 * eq bytes; idx: n_buckets + 2 uint32
-hipError_t launch_cluster_build(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterCfg &cc, int eq, uint32_t *keys, uint32_t *vals,
-                                uint32_t *keys2, uint32_t *vals2, uint32_t *meta, void *runs, uint8_t *nruns, void *sort_temp, size_t sort_temp_bytes,
-                                void *store, uint32_t *idx, hipStream_t s);
+void       launch_cluster_keys(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterCfg &cc, int32_t node_begin, int32_t node_end, uint32_t *keys,
+                               uint32_t *vals, uint32_t *meta, void *runs, uint8_t *nruns, hipStream_t s);
+hipError_t launch_cluster_store(const NodesDev &nd, const ClusterCfg &cc, int eq, uint32_t *keys, uint32_t *vals, uint32_t *keys2, uint32_t *vals2,
+                                const uint32_t *meta, void *sort_temp, size_t sort_temp_bytes, void *store, uint32_t *idx, bool fill_vals, hipStream_t s);
 uint64_t   cluster_record_slack(int n_cu, uint64_t n_src);
 void       launch_probe_pairs(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterCfg &cc, int eq, const void *store, const uint32_t *idx,
                               const void *runs, const uint8_t *nruns, int32_t src_begin, int32_t src_end, unsigned long long *counters, int n_cu, uint32_t *deg,

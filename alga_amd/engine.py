@@ -30,7 +30,7 @@ class PrefSufParams(C.Structure):
     """alga_prefsuf_params"""
     _fields_ = [("min_overlap", C.c_int32), ("rsoe_min_overlap", C.c_int32), ("soes", C.c_int32),
                 ("max_len_cap", C.c_int32), ("collect_stats", C.c_int32), ("reduction", C.c_int32),
-                ("reserved", C.c_int32 * 2)]
+                ("keys_shared", C.c_int32), ("reserved", C.c_int32 * 1)]
 
 
 class PrefSufStats(C.Structure):
@@ -104,10 +104,14 @@ class PkbStats(C.Structure):
 
 PROBE = {"auto": 0, "table": 1, "cluster": 2}                  # alga_probe
 
+class NodeKeys(C.Structure):
+    _fields_ = [("d_keys", C.c_void_p), ("d_meta", C.c_void_p), ("n", C.c_int32), ("eligible", C.c_int32)]
+
+
 EXPORTS = ["alga_abi_version", "alga_engine_set_option", "alga_engine_create", "alga_engine_destroy", "alga_last_error",
            "alga_engine_device_name", "alga_prefsuf_default_params", "alga_prefsuf_build_host", "alga_free_edges",
            "alga_prefsuf_build_device", "alga_prefsuf_last_stats", "alga_prefsuf_discover_device",
-           "alga_prefsuf_reduce_device", "alga_prefsuf_build_range_device", "alga_write_graph", "alga_ingest_default_params", "alga_ingest_files",
+           "alga_prefsuf_reduce_device", "alga_prefsuf_build_range_device", "alga_prefsuf_keys_device", "alga_write_graph", "alga_ingest_default_params", "alga_ingest_files",
            "alga_free_node_set", "alga_sort_records_device", "alga_sort_edges_device", "alga_pkb_derive_params",
            "alga_can_align_batch_host", "alga_li_kmers_host", "alga_pkb_supplement_host", "alga_pkb_supplement_device",
            "alga_pkb_last_stats", "alga_parse_files", "alga_free_parsed_reads", "alga_preprocess_nodes", "alga_copy_to_host", "alga_device_alloc", "alga_device_free", "alga_copy_to_device", "alga_cut_triangles_device", "alga_cut_triangles_host", "alga_ingest_device", "alga_contig_trim_host"]
@@ -418,12 +422,26 @@ class Engine:
                                                         C.byref(out), C.byref(m)))
         return out.value, int(m.value)
 
+    def keys_device(self, words, lens, min_overlap, rsoe_min_overlap, node_begin, node_end, align_from=None, align_to=None, stream=None):
+        """Minimizer keys + runs of the nodes [node_begin, node_end) -> (d_keys ptr, d_meta ptr) over all n nodes (this range
+        filled; the caller all-gathers the rest in place), or None when the clustered probe does not take the input."""
+        nd = self._nodes_from_torch(words, lens, align_from, align_to)
+        p = self.params(min_overlap, rsoe_min_overlap, False)
+        out = NodeKeys()
+        self._check(self._lib.alga_prefsuf_keys_device(self._h, C.byref(nd), C.byref(p), int(node_begin), int(node_end), C.c_void_p(stream or 0),
+                                                       C.byref(out)))
+        if not out.eligible:
+            return None
+        return out.d_keys, out.d_meta
+
     def build_range_device(self, words, lens, min_overlap, rsoe_min_overlap, src_begin, src_end, align_from=None, align_to=None,
-                           stream=None, collect_stats=False):
+                           stream=None, collect_stats=False, keys_shared=False):
         """Final edges of the sources [src_begin, src_end) by the source-side reduction -> (ptr, n_edges), or None when
-        that form is not exact for the input (ALGA_ERR_UNSUPPORTED): the caller then takes discover/exchange/reduce."""
+        that form is not exact for the input (ALGA_ERR_UNSUPPORTED): the caller then takes discover/exchange/reduce.
+        keys_shared: keys_device + the all-gather of its arrays came first (include/alga_amd.h)."""
         nd = self._nodes_from_torch(words, lens, align_from, align_to)
         p = self.params(min_overlap, rsoe_min_overlap, collect_stats)
+        p.keys_shared = 1 if keys_shared else 0
         out = C.c_void_p()
         m = C.c_uint64()
         rc = self._lib.alga_prefsuf_build_range_device(self._h, C.byref(nd), C.byref(p), int(src_begin), int(src_end),

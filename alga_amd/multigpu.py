@@ -3,9 +3,11 @@
 Layout: the packed node set is replicated on every GPU (36-48 B/read; 4.8 GB at 100 M nodes, HBM is 288 GB).
 
 Source-side form (alga_reduction; the normal case for short reads): rank r builds the FINAL edges of
-the sources in its contiguous id range -- nothing a rank computes depends on another rank -- and the only collectives are
-one flag all-reduce (does every rank's input allow the form?) and the all_gather of the edge lists, which arrive in
-(src, dst) order because the ranges are ascending.
+the sources in its contiguous id range.  The build step is sharded as well: rank r computes the minimizer keys (and the
+probe runs) of its own nodes, the per-node key arrays are all-gathered (8 bytes per node), and every rank sorts them into its
+own copy of the bucket-ordered entry array.  After that nothing a rank computes depends on another rank; the remaining
+collectives are one small all_gather (does every rank's input allow the form? edge counts) and the gather of the edge lists,
+which arrive in (src, dst) order because the ranges are ascending.
 
 Per-target form (any input; taken by all ranks when one of them cannot use the source-side form):
   1. discover  rank r probes the SOURCES of its contiguous id range against the full seed table and applies the
@@ -19,22 +21,34 @@ so the result is byte-identical for every world size.  torch supplies buffers an
 step is a C-ABI call into the HIP engine (`HipBackend`).  The same driver runs on CPU tensors over gloo with a
 stand-in backend in tests/test_multigpu_gloo.py.
 """
+import contextlib
 import time
 
 import numpy as np
 
 
+def shard_chunk(n, world):
+    """Ids per rank: equal, even (a read and its reverse complement, ids 2i and 2i+1, stay together)."""
+    return 2 * ((n + 2 * world - 1) // (2 * world))
+
+
 def shard_bounds(n, world):
-    """Contiguous id ranges, a read and its reverse complement (ids 2i, 2i+1) kept together."""
-    b = [(n * r) // world for r in range(world + 1)]
-    return [x - (x & 1) for x in b[:-1]] + [n]
+    """Contiguous id ranges of `shard_chunk` ids (the last non-empty one may be shorter): rank r owns [b[r], b[r+1]).
+    Equal chunks make the per-node arrays all-gatherable in place (slice r = [r * chunk, (r + 1) * chunk))."""
+    c = shard_chunk(n, world)
+    return [min(n, r * c) for r in range(world)] + [n]
+
+
+KEY_ARRAY_SLACK = 1024      # the engine's per-node key arrays have room for n + 1024 entries (include/alga_amd.h): world * chunk <= n + 2 * world
 
 
 class HipBackend:
     """The engine behind the driver: device tensors in, device tensors (views of engine memory) out.
-    Every engine call is enqueued on torch's CURRENT stream of the device: collectives (RCCL) and torch ops that produce an
-    engine input, and engine kernels that consume it, are then ordered by the stream itself (the engine's own stream is a
-    non-blocking one that orders with nothing else)."""
+    A step runs inside `stream_scope()`: one side stream of this backend is torch's CURRENT stream for its duration and the stream
+    of every engine call, so collectives (RCCL), torch ops that produce an engine input and engine kernels that consume it are
+    ordered by the stream itself.  (Not torch's default stream: its handle is 0, which the C ABI reads as "the engine's own
+    stream", a non-blocking one that orders with nothing else -- an engine call that does not end in a host sync, like
+    alga_prefsuf_keys_device, would then race with the torch ops around it.)"""
 
     def __init__(self, engine, d_words, d_lens, min_overlap, rsoemo):
         self.eng, self.w, self.l = engine, d_words, d_lens
@@ -42,10 +56,20 @@ class HipBackend:
         self.n = int(d_lens.shape[0])
         self.device = d_words.device
         self.stats = {}
+        import torch
+        self.stream = torch.cuda.Stream(device=self.device)
 
     def _stream(self):
+        return self.stream.cuda_stream
+
+    @contextlib.contextmanager
+    def stream_scope(self):
         import torch
-        return torch.cuda.current_stream(self.device).cuda_stream
+        outer = torch.cuda.current_stream(self.device)
+        self.stream.wait_stream(outer)                    # inputs made on the caller's stream
+        with torch.cuda.stream(self.stream):
+            yield
+        outer.wait_stream(self.stream)                    # results read on the caller's stream
 
     def build(self, collect_stats=False):
         from .engine import device_view
@@ -53,10 +77,21 @@ class HipBackend:
         self.stats = self.eng.last_stats()
         return device_view(ptr, (m, 3), self.device)
 
-    def build_range(self, src_begin, src_end, collect_stats=False):
+    def node_keys(self, node_begin, node_end, span):
+        """Minimizer keys of my node range -> the per-node arrays to all-gather (views of engine memory, `span` entries each, my
+        range filled), or None when the clustered probe does not take this input."""
+        from .engine import device_view
+        r = self.eng.keys_device(self.w, self.l, self.lo, self.rs, node_begin, node_end, stream=self._stream())
+        if r is None:
+            return None
+        assert span <= self.n + KEY_ARRAY_SLACK
+        return [device_view(p, (span,), self.device) for p in r]
+
+    def build_range(self, src_begin, src_end, collect_stats=False, keys_shared=False):
         """Final edges of the sources in the range (tensor [m, 3]) or None when the source-side form is not exact here."""
         from .engine import device_view
-        r = self.eng.build_range_device(self.w, self.l, self.lo, self.rs, src_begin, src_end, collect_stats=collect_stats, stream=self._stream())
+        r = self.eng.build_range_device(self.w, self.l, self.lo, self.rs, src_begin, src_end, collect_stats=collect_stats, stream=self._stream(),
+                                        keys_shared=keys_shared)
         if r is None:
             return None
         self.stats = self.eng.last_stats()
@@ -94,9 +129,10 @@ class ShardedPrefSuf:
     simplifier / contig stages afterwards -- with direct sends over each peer's own xGMI link (`gather`); the other ranks keep
     an empty tensor.  replicate=True: every rank gets it (`all_gather`, 8x the traffic at 8 GPUs)."""
 
-    def __init__(self, backend, rank=0, world=1, dist=None, replicate=False):
+    def __init__(self, backend, rank=0, world=1, dist=None, replicate=False, shard_keys=True):
         self.be, self.rank, self.world, self.dist = backend, rank, world, dist
         self.replicate = replicate
+        self.shard_keys = shard_keys           # False: every rank computes the keys of all nodes itself (no key all-gather)
         self.n = backend.n
         self.bounds = shard_bounds(self.n, world)
         self.edges = None                       # tensor [m, 3] of the last step: the complete graph (rank 0, or every rank if replicate)
@@ -104,10 +140,11 @@ class ShardedPrefSuf:
 
     def step(self, collect_stats=False):
         """-> (n_edges of the complete graph, stats dict of this rank)."""
-        if self.world == 1:
-            self.edges = self.be.build(collect_stats)
-            return int(self.edges.shape[0]), dict(self.be.stats)
-        return self._step_sharded(collect_stats)
+        with getattr(self.be, "stream_scope", contextlib.nullcontext)():
+            if self.world == 1:
+                self.edges = self.be.build(collect_stats)
+                return int(self.edges.shape[0]), dict(self.be.stats)
+            return self._step_sharded(collect_stats)
 
     def _step_sharded(self, collect_stats):
         import torch
@@ -115,13 +152,23 @@ class ShardedPrefSuf:
         dev = be.device
         # 0. source-side form: final edges of my sources; all ranks must agree to use it.  One small all_gather carries
         #    the "declined" flag and the edge count of every rank.
-        mine = be.build_range(b[r], b[r + 1], collect_stats)
+        #    The build step is sharded too: each rank computes the minimizer keys of its own nodes only, and the per-node key
+        #    arrays (8 bytes per node) are all-gathered in place before every rank sorts them into its copy of the entry array.
+        t_keys = time.perf_counter()
+        chunk = shard_chunk(self.n, nr)
+        karr = be.node_keys(b[r], b[r + 1], nr * chunk) if self.shard_keys else None
+        if karr is not None:
+            for t in karr:
+                dist.all_gather_into_tensor(t, t[r * chunk:(r + 1) * chunk].clone())
+        ms_keys = (time.perf_counter() - t_keys) * 1e3
+        mine = be.build_range(b[r], b[r + 1], collect_stats, keys_shared=karr is not None)
         meta = torch.tensor([0 if mine is not None else 1, 0 if mine is None else int(mine.shape[0])], dtype=torch.int64, device=dev)
         allmeta = torch.empty(2 * nr, dtype=torch.int64, device=dev)
         dist.all_gather_into_tensor(allmeta, meta)
         allmeta = allmeta.cpu().view(nr, 2)
         if int(allmeta[:, 0].max()) == 0:
             st = dict(be.stats)
+            st["ms_keys_shared"] = ms_keys if karr is not None else 0.0       # host clock: key pass of my nodes + all-gather (enqueue; the build waits for it on the stream)
             t2 = time.perf_counter()
             self.edges = self._gather(mine, ordered=True, counts=[int(x) for x in allmeta[:, 1]])
             be.sync()

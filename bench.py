@@ -244,7 +244,7 @@ def main():
                                    (args.config, n_reads, read_len, G, seed, err, n_nodes, lo, rs, how, t_build),
                        "nodes": n_nodes, "edges": int(n_edges), "parallelism": "1 GPU" if world == 1 else
                        "strong scaling: the same read set for every N; node set and target index on every rank, sources sharded over %d ranks "
-                       "(contiguous id ranges), each rank builds the final edges of its sources, edge lists gathered on rank 0 over RCCL" % world},
+                       "(contiguous id ranges): each rank computes the minimizer keys of its nodes, the key arrays (8 B/node) are all-gathered over RCCL, each rank sorts them into its copy of the bucket-ordered entry array and builds the final edges of its sources; edge lists gathered on rank 0 over RCCL" % world},
             "roofline": {"bound": "hbm", "kernel": probe_kernel, "achieved": achieved_kernel, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_kernel / HBM_PEAK_GBS, "traffic": profiled_traffic(args.config, lib_sha, probe_kernel) if world == 1 else None,
                          "traffic_source": "rocprofv3 --pmc passes of this command on this build (profiles/probe_hbm_bytes.json, lib %s): FETCH_SIZE + WRITE_SIZE of that kernel as counted; null = not profiled on this build" % lib_sha,

@@ -87,7 +87,9 @@ typedef struct {
     int32_t max_len_cap;      /* 500 (src/GraphCreators/GraphCreatorPrefSuf.cpp:92)               */
     int32_t collect_stats;    /* != 0: fill the work counters of alga_prefsuf_stats               */
     int32_t reduction;        /* alga_reduction; SOURCE_SIDE fails with ALGA_ERR_UNSUPPORTED when not exact */
-    int32_t reserved[2];
+    int32_t keys_shared;      /* != 0 (sharded form only): the per-node keys were made by alga_prefsuf_keys_device and
+                                 all-gathered by the caller; the build skips its own key pass                      */
+    int32_t reserved[1];
 } alga_prefsuf_params;
 
 /* Work counters; the first four mirror GATHER_STATISTICS of the reference
@@ -192,6 +194,22 @@ int  alga_prefsuf_reduce_device(alga_engine *e, const alga_nodes *nodes, const a
 int  alga_prefsuf_build_range_device(alga_engine *e, const alga_nodes *nodes, const alga_prefsuf_params *p,
                                      int32_t src_begin, int32_t src_end, void *hip_stream,
                                      const alga_edge **d_edges, uint64_t *n_edges);
+
+/* Sharding of the build step itself (CLUSTER probe).  Without it every rank computes the minimizer keys of ALL nodes before it
+ * probes its own sources -- the part of a build that does not shrink with the rank count.  With it, rank r
+ *   1. alga_prefsuf_keys_device(node range of r)   keys + runs of its own nodes (the nodes whose sources it will probe);
+ *   2. all-gathers, IN PLACE, the two per-node arrays the call returns (uint32 d_keys[n], d_meta[n]: rank q's slice is
+ *      [node_begin_q, node_end_q)) -- 8 bytes per node over RCCL;
+ *   3. alga_prefsuf_build_range_device(params.keys_shared = 1, src range inside its node range): sorts the gathered keys into
+ *      the bucket order, builds the entry array and probes.
+ * out->eligible == 0: the CLUSTER probe does not take this input (every rank gets the same answer for the same node set and
+ * options); skip steps 2-3's flag and call the build as before.  The arrays are engine-owned, valid until the next build, and
+ * have room for n + ALGA_KEY_ARRAY_SLACK entries, so that equal-sized slices (ceil(n / ranks), the last one running past n) can be
+ * gathered in place. */
+#define ALGA_KEY_ARRAY_SLACK 1024
+typedef struct { uint32_t *d_keys; uint32_t *d_meta; int32_t n; int32_t eligible; } alga_node_keys;
+int  alga_prefsuf_keys_device(alga_engine *e, const alga_nodes *nodes, const alga_prefsuf_params *p,
+                              int32_t node_begin, int32_t node_end, void *hip_stream, alga_node_keys *out);
 
 /* Exchange helpers of the sharded form (device in, device out, engine-owned results):
  *   alga_sort_records_device  orders record slots by target id and drops the padding: the first *n_valid

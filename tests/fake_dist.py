@@ -21,7 +21,16 @@ class FakeDist:
     def __init__(self, world, rank):
         self.w, self.rank = world, rank
 
+    @staticmethod
+    def _sync():
+        # every rank thread works on its own stream: what one thread enqueued must be complete before another thread's stream
+        # reads it (and a reader must be done before the writer's buffers go back to the allocator)
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.current_stream().synchronize()
+
     def _exchange(self, obj):
+        self._sync()
         self.w.slots[self.rank] = obj
         self.w.barrier.wait()
         got = list(self.w.slots)
@@ -32,18 +41,21 @@ class FakeDist:
         import torch
         parts = self._exchange(inp.detach().clone())
         out.copy_(torch.cat([p.reshape(-1) for p in parts]).reshape(out.shape))
+        self._sync()
 
     def gather(self, tensor, gather_list=None, dst=0):
         parts = self._exchange(tensor.detach().clone())
         if self.rank == dst:
             for g, p in zip(gather_list, parts):
                 g.copy_(p)
+        self._sync()
 
     def all_reduce(self, t, op=ReduceOp.SUM):
         import torch
         parts = self._exchange(t.detach().clone())
         st = torch.stack(parts)
         t.copy_(st.max(dim=0).values if op == ReduceOp.MAX else st.sum(dim=0))
+        self._sync()
 
     def all_to_all_single(self, out, inp, output_split_sizes=None, input_split_sizes=None):
         import torch
@@ -58,6 +70,7 @@ class FakeDist:
         allp = self._exchange(mine)
         recv = [allp[r][self.rank] for r in range(n)]
         out.copy_(torch.cat(recv) if recv else out)
+        self._sync()
 
 
 def run_ranks(n, fn):

@@ -340,23 +340,24 @@ def test_exchange_helpers_emulated_ranks(eng):
     dw = torch.from_numpy(words.view(np.int32)).cuda()
     dl = torch.from_numpy(lens).cuda()
     be = HipBackend(eng, dw, dl, 82, 116)
-    nr = 3
-    b = shard_bounds(len(lens), nr)
-    sent = []
-    for r in range(nr):
-        d, v = be.discover_sorted(b[r], b[r + 1])
-        assert bool((d[1:] >= d[:-1]).all()) and int(d.min()) >= 0          # ordered by target, padding dropped
-        cuts = torch.searchsorted(d, torch.tensor(b, dtype=d.dtype, device=d.device)).tolist()
-        sent.append([(d[cuts[q]:cuts[q + 1]].clone(), v[cuts[q]:cuts[q + 1]].clone()) for q in range(nr)])
-    parts = []
-    for q in range(nr):
-        rd = torch.cat([sent[r][q][0] for r in range(nr)]).contiguous()
-        rv = torch.cat([sent[r][q][1] for r in range(nr)]).contiguous()
-        parts.append(be.reduce(rd, rv, b[q], b[q + 1]).clone())
-    allp = torch.cat(parts).contiguous()
-    got = be.sort_edges(allp).cpu().numpy()
-    assert got.shape == want.shape and (got == want).all()
-    assert (be.build().cpu().numpy() == want).all()
+    with be.stream_scope():                                    # torch ops and engine calls on one stream, as in ShardedPrefSuf.step
+        nr = 3
+        b = shard_bounds(len(lens), nr)
+        sent = []
+        for r in range(nr):
+            d, v = be.discover_sorted(b[r], b[r + 1])
+            assert bool((d[1:] >= d[:-1]).all()) and int(d.min()) >= 0          # ordered by target, padding dropped
+            cuts = torch.searchsorted(d, torch.tensor(b, dtype=d.dtype, device=d.device)).tolist()
+            sent.append([(d[cuts[q]:cuts[q + 1]].clone(), v[cuts[q]:cuts[q + 1]].clone()) for q in range(nr)])
+        parts = []
+        for q in range(nr):
+            rd = torch.cat([sent[r][q][0] for r in range(nr)]).contiguous()
+            rv = torch.cat([sent[r][q][1] for r in range(nr)]).contiguous()
+            parts.append(be.reduce(rd, rv, b[q], b[q + 1]).clone())
+        allp = torch.cat(parts).contiguous()
+        got = be.sort_edges(allp).cpu().numpy()
+        assert got.shape == want.shape and (got == want).all()
+        assert (be.build().cpu().numpy() == want).all()
 
 
 @pytest.mark.parametrize("lo,rs,replicate", [(90, 120, False), (90, 120, True), (82, 116, False)])

@@ -58,8 +58,28 @@ class PyBackend:
                 dst.append(C); val.append(((off | (L << 22) | OL_SMALL) << 32) | B)
         return np.array(dst, dtype=np.int64), np.array(val, dtype=np.uint64)
 
-    def build_range(self, a, b, collect_stats=False):
+    @staticmethod
+    def _fake_keys(lo, hi):
+        i = np.arange(lo, hi, dtype=np.int64)
+        return ((i * 2654435761 + 12345) & 0x7FFFFFFF).astype(np.int32), ((i * 40503 + 7) & 0x7FFFFFFF).astype(np.int32)
+
+    def node_keys(self, a, b, span):
+        """Stand-in of alga_prefsuf_keys_device: per-node arrays of `span` entries with my range filled."""
+        if not self.source_side:
+            return None
+        self.karr = [torch.full((span,), -1, dtype=torch.int32), torch.full((span,), -1, dtype=torch.int32)]
+        k, m = self._fake_keys(a, b)
+        self.karr[0][a:b] = torch.from_numpy(k)
+        self.karr[1][a:b] = torch.from_numpy(m)
+        return self.karr
+
+    def build_range(self, a, b, collect_stats=False, keys_shared=False):
         """Stand-in of alga_prefsuf_build_range_device: the executable statement of the source-side rule, one source range."""
+        if keys_shared:                                   # the all-gather delivered every rank's slice
+            k, m = self._fake_keys(0, self.n)
+            assert (self.karr[0][:self.n].numpy() == k).all() and (self.karr[1][:self.n].numpy() == m).all()
+        else:
+            assert not self.source_side
         if not self.source_side or self.decline:
             return None
         from source_side_rule import source_side_edges
