@@ -63,56 +63,43 @@ NodesDev nodes_dev(const alga_nodes *dn) {
     return nd;
 }
 
-// edges (any order, invalid entries have src < 0) -> unique (src, dst) with the smallest offset, sorted, + row pointers.
-// Graph::addDirectedEdge / retainOnlySmallestOffset (src/DataStructures/Graph.cpp:53-71,348-387) as one sort.
-int normalize_edges(alga_engine *e, int32_t n_nodes, const alga_edge_dev *in, uint64_t n_in, DevBuf &out, uint64_t *n_out, hipStream_t s) {
+int node_bits(int32_t n) { int b = 1; while (b < 28 && (1ll << b) < (long long) n) b++; return b; }
+
+// The incoming edge list -> the supplement's graph form: sorted unique keys (pkb_kernels.hip) in `out` + row pointers.  The C ABI
+// promises a list sorted by (src, dst) with one edge per pair; that is checked on the device, and a list that is not is sorted and
+// reduced to the smallest offset per pair (Graph::addDirectedEdge / retainOnlySmallestOffset, src/DataStructures/Graph.cpp:53-71,348-387).
+int graph_from_edges(alga_engine *e, int32_t n_nodes, const alga_edge_dev *in, uint64_t n_in, DevBuf &out, uint64_t *n_out, hipStream_t s) {
     int rc;
     if (n_in >= (1ull << 32) - 16) return alga_fail(e, ALGA_ERR_CAPACITY, "more than 2^32 edges");
-    const size_t temp = sort_u64_keys_temp_bytes(n_in);
-    if ((rc = alga_ensure(e, e->pk_ekeys, (n_in + 1) * sizeof(unsigned long long)))) return rc;
-    if ((rc = alga_ensure(e, e->pk_ekeys2, (n_in + 1) * sizeof(unsigned long long)))) return rc;
-    if ((rc = alga_ensure(e, e->pk_flag, (n_in + 2) * sizeof(uint32_t)))) return rc;
-    if ((rc = alga_ensure(e, e->pk_pos, (n_in + 2) * sizeof(uint32_t)))) return rc;
-    if ((rc = alga_ensure(e, e->sort_temp, temp))) return rc;
-    if ((rc = alga_ensure(e, e->scan_scratch, std::max(scan_scratch_bytes(n_in), scan_scratch_bytes((uint64_t) n_nodes))))) return rc;
-    if ((rc = alga_ensure(e, e->pk_deg, (size_t) (n_nodes + 1) * sizeof(uint32_t)))) return rc;
+    if ((rc = alga_ensure(e, out, (n_in + 1) * sizeof(unsigned long long)))) return rc;
     if ((rc = alga_ensure(e, e->pk_rowptr, (size_t) (n_nodes + 2) * sizeof(uint32_t)))) return rc;
-    // only the used entries are sorted (a round's addition slots are ~99 % unused)
-    launch_pkb_valid_flags(in, n_in, (uint32_t *) e->pk_flag.p, s);
-    if ((rc = alga_check_launch(e, "k_pkb_valid_flags"))) return rc;
-    launch_exclusive_scan((const uint32_t *) e->pk_flag.p, n_in, (uint32_t *) e->pk_pos.p, (uint64_t *) e->scan_scratch.p, s);
-    if ((rc = alga_check_launch(e, "scan(valid)"))) return rc;
     if ((rc = alga_ensure(e, e->pk_cnt, 16 * sizeof(unsigned long long)))) return rc;
-    unsigned long long *bad = (unsigned long long *) e->pk_cnt.p + 15;
-    HIP_TRY(e, hipMemsetAsync(bad, 0, sizeof(unsigned long long), s));
-    launch_pkb_edge_keys_dense(in, (const uint32_t *) e->pk_flag.p, (const uint32_t *) e->pk_pos.p, n_in, (unsigned long long *) e->pk_ekeys.p, bad, s);
-    if ((rc = alga_check_launch(e, "k_pkb_edge_keys_dense"))) return rc;
-    HIP_TRY(e, hipMemcpyAsync(&e->h_counters[CNT_TOTAL], (uint64_t *) e->scan_scratch.p + scan_total_index(n_in), sizeof(uint64_t), hipMemcpyDeviceToHost, s));
-    HIP_TRY(e, hipMemcpyAsync(&e->h_counters[CNT_TOTAL + 1], bad, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    unsigned long long *cnt = (unsigned long long *) e->pk_cnt.p;
+    HIP_TRY(e, hipMemsetAsync(cnt + 13, 0, 3 * sizeof(unsigned long long), s));
+    launch_pkb_edge_keys(in, n_in, (unsigned long long *) out.p, cnt + 14, s);
+    if ((rc = alga_check_launch(e, "k_pkb_edge_keys"))) return rc;
+    HIP_TRY(e, hipMemcpyAsync(&e->h_counters[CNT_TOTAL], cnt + 14, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     HIP_TRY(e, hipStreamSynchronize(s));
-    if (e->h_counters[CNT_TOTAL + 1]) return alga_fail(e, ALGA_ERR_CAPACITY, "the supplement keeps edge offsets in 9 bits: an edge has an offset above 511 (reads longer than 512 nt?)");
-    const uint64_t n_all = n_in;
-    n_in = n_all ? e->h_counters[CNT_TOTAL] : 0;                 // from here on: the used entries
-    (void) n_all;
-    HIP_TRY(e, sort_u64_keys(e->sort_temp.p, temp, (const unsigned long long *) e->pk_ekeys.p, (unsigned long long *) e->pk_ekeys2.p, n_in, s));
-    launch_pkb_unique_flags((const unsigned long long *) e->pk_ekeys2.p, n_in, (uint32_t *) e->pk_flag.p, s);
-    if ((rc = alga_check_launch(e, "k_pkb_unique_flags"))) return rc;
-    launch_exclusive_scan((const uint32_t *) e->pk_flag.p, n_in, (uint32_t *) e->pk_pos.p, (uint64_t *) e->scan_scratch.p, s);
-    if ((rc = alga_check_launch(e, "scan(flags)"))) return rc;
-    uint64_t total = 0;
-    HIP_TRY(e, hipMemcpyAsync(&e->h_counters[CNT_TOTAL], (uint64_t *) e->scan_scratch.p + scan_total_index(n_in), sizeof(uint64_t), hipMemcpyDeviceToHost, s));
-    HIP_TRY(e, hipStreamSynchronize(s));
-    total = n_in ? e->h_counters[CNT_TOTAL] : 0;
-    if ((rc = alga_ensure(e, out, (total + 1) * sizeof(alga_edge_dev)))) return rc;
-    HIP_TRY(e, hipMemsetAsync(e->pk_deg.p, 0, (size_t) (n_nodes + 1) * sizeof(uint32_t), s));
-    launch_pkb_compact((const unsigned long long *) e->pk_ekeys2.p, (const uint32_t *) e->pk_flag.p, (const uint32_t *) e->pk_pos.p, n_in,
-                       (alga_edge_dev *) out.p, (uint32_t *) e->pk_deg.p, s);
-    if ((rc = alga_check_launch(e, "k_pkb_compact"))) return rc;
-    launch_exclusive_scan((const uint32_t *) e->pk_deg.p, (uint64_t) n_nodes, (uint32_t *) e->pk_rowptr.p, (uint64_t *) e->scan_scratch.p, s);
-    if ((rc = alga_check_launch(e, "scan(outdeg)"))) return rc;
-    *n_out = total;
+    if (e->h_counters[CNT_TOTAL]) return alga_fail(e, ALGA_ERR_CAPACITY, "the supplement keeps edge offsets in 9 bits: an edge has an offset above 511 (reads longer than 512 nt?)");
+    uint64_t E = n_in;
+    if (e->h_counters[CNT_TOTAL + 1]) {
+        const size_t temp = std::max(sort_u64_keys_temp_bytes(n_in), unique_edge_keys_temp_bytes(n_in));
+        if ((rc = alga_ensure(e, e->pk_merged, (n_in + 1) * sizeof(unsigned long long)))) return rc;
+        if ((rc = alga_ensure(e, e->sort_temp, temp))) return rc;
+        HIP_TRY(e, sort_u64_keys(e->sort_temp.p, temp, (const unsigned long long *) out.p, (unsigned long long *) e->pk_merged.p, n_in, s));
+        HIP_TRY(e, unique_edge_keys(e->sort_temp.p, temp, (const unsigned long long *) e->pk_merged.p, (unsigned long long *) out.p, cnt + 13, n_in, s));
+        HIP_TRY(e, hipMemcpyAsync(&e->h_counters[CNT_TOTAL], cnt + 13, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        HIP_TRY(e, hipStreamSynchronize(s));
+        E = e->h_counters[CNT_TOTAL];
+    }
+    launch_pkb_rowptr((const unsigned long long *) out.p, E, n_nodes, (uint32_t *) e->pk_rowptr.p, s);
+    if ((rc = alga_check_launch(e, "k_pkb_rowptr"))) return rc;
+    *n_out = E;
     return ALGA_OK;
 }
+
+// k-mer entries are radix-sorted on this many low bits of the hash; k_pkb_fix_runs repairs the runs where two hashes share them
+constexpr int PKB_SORT_BITS = 32;
 
 int supplement_device_impl(alga_engine *e, const alga_nodes *dn, const alga_pkb_params *p, const alga_edge *d_edges_in, uint64_t m_in,
                            hipStream_t s, const alga_edge **d_out, uint64_t *m_out) {
@@ -127,100 +114,135 @@ int supplement_device_impl(alga_engine *e, const alga_nodes *dn, const alga_pkb_
     unsigned long long *cnt = (unsigned long long *) e->pk_cnt.p;
     int cur = 0;
     uint64_t E = 0;
-    if ((rc = normalize_edges(e, n, (const alga_edge_dev *) d_edges_in, m_in, e->pk_edges[cur], &E, s))) return rc;
+    if ((rc = graph_from_edges(e, n, (const alga_edge_dev *) d_edges_in, m_in, e->pk_g[cur], &E, s))) return rc;
     // masks from the degrees of the incoming graph, once (src/main.cpp:308-322)
     if ((rc = alga_ensure(e, e->pk_mask, (size_t) n + 16))) return rc;
     if ((rc = alga_ensure(e, e->outdeg, (size_t) (n + 1) * sizeof(uint32_t)))) return rc;
-    launch_pkb_masks(n, (const uint32_t *) e->pk_rowptr.p, (const alga_edge_dev *) e->pk_edges[cur].p, E, (uint32_t *) e->outdeg.p, (uint8_t *) e->pk_mask.p, s);
+    launch_pkb_masks(n, (const uint32_t *) e->pk_rowptr.p, (const unsigned long long *) e->pk_g[cur].p, E, (uint32_t *) e->outdeg.p, (uint8_t *) e->pk_mask.p, s);
     if ((rc = alga_check_launch(e, "k_pkb_masks"))) return rc;
-    // the nodes that take part, as a dense list (the masks are fixed for all rounds)
+    // the nodes that take part, as a dense list (the masks are fixed for all rounds), and where their k-mers go
     if ((rc = alga_ensure(e, e->pk_tips, (size_t) (n + 1) * sizeof(uint32_t)))) return rc;
+    if ((rc = alga_ensure(e, e->pk_gsz, (size_t) (n + 1) * sizeof(uint32_t)))) return rc;       // here: k-mers per tip
+    if ((rc = alga_ensure(e, e->pk_koff, (size_t) (n + 2) * sizeof(uint32_t)))) return rc;
     if ((rc = alga_ensure(e, e->pk_flag, (size_t) (n + 2) * sizeof(uint32_t)))) return rc;
     if ((rc = alga_ensure(e, e->pk_pos, (size_t) (n + 2) * sizeof(uint32_t)))) return rc;
     if ((rc = alga_ensure(e, e->scan_scratch, scan_scratch_bytes((uint64_t) n)))) return rc;
+    HIP_TRY(e, hipMemsetAsync(cnt + 12, 0, sizeof(unsigned long long), s));
     launch_pkb_tip_flags(nd, c, (const uint8_t *) e->pk_mask.p, (uint32_t *) e->pk_flag.p, s);
     if ((rc = alga_check_launch(e, "k_pkb_tip_flags"))) return rc;
     launch_exclusive_scan((const uint32_t *) e->pk_flag.p, (uint64_t) n, (uint32_t *) e->pk_pos.p, (uint64_t *) e->scan_scratch.p, s);
-    launch_pkb_tip_list(n, (const uint32_t *) e->pk_flag.p, (const uint32_t *) e->pk_pos.p, (uint32_t *) e->pk_tips.p, s);
+    launch_pkb_tip_list(nd, c, (const uint32_t *) e->pk_flag.p, (const uint32_t *) e->pk_pos.p, (uint32_t *) e->pk_tips.p, (uint32_t *) e->pk_gsz.p, cnt + 12, s);
     if ((rc = alga_check_launch(e, "k_pkb_tip_list"))) return rc;
     HIP_TRY(e, hipMemcpyAsync(e->h_counters, (uint64_t *) e->scan_scratch.p + scan_total_index((uint64_t) n), sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(e, hipMemcpyAsync(e->h_counters + 1, cnt + 12, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(e, hipStreamSynchronize(s));
-    const uint32_t n_tips = (uint32_t) e->h_counters[0];
-    int32_t prio[4] = {0, 1, 2, 3};
-    const uint64_t max_kmers = (uint64_t) n_tips * (uint64_t) c.li_intervals;
-    for (int round = 0; round < p->rounds; round++) {
-        if ((rc = alga_ensure(e, e->pk_keys, (max_kmers + 1) * sizeof(unsigned long long)))) return rc;
-        if ((rc = alga_ensure(e, e->pk_vals, (max_kmers + 1) * sizeof(unsigned long long)))) return rc;
-        HIP_TRY(e, hipMemsetAsync(cnt, 0, 16 * sizeof(unsigned long long), s));
-        launch_pkb_kmers(nd, c, prio, (const uint32_t *) e->pk_tips.p, n_tips, (unsigned long long *) e->pk_keys.p, (unsigned long long *) e->pk_vals.p, cnt + 0, s);
-        if ((rc = alga_check_launch(e, "k_pkb_kmers"))) return rc;
-        HIP_TRY(e, hipMemcpyAsync(e->h_counters, cnt, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    const uint32_t n_tips = n > 0 ? (uint32_t) e->h_counters[0] : 0u;
+    if (e->h_counters[1] >= 4096) return alga_fail(e, ALGA_ERR_CAPACITY, "the supplement keeps read lengths in 12 bits: a participating read has 4096 nt or more");
+    uint64_t nk = 0;
+    if (n_tips) {
+        launch_exclusive_scan((const uint32_t *) e->pk_gsz.p, (uint64_t) n_tips, (uint32_t *) e->pk_koff.p, (uint64_t *) e->scan_scratch.p, s);
+        HIP_TRY(e, hipMemcpyAsync(e->h_counters, (uint64_t *) e->scan_scratch.p + scan_total_index((uint64_t) n_tips), sizeof(uint64_t), hipMemcpyDeviceToHost, s));
         HIP_TRY(e, hipStreamSynchronize(s));
-        const uint64_t nk = e->h_counters[0];
+        nk = e->h_counters[0];
+    }
+    if (nk >= (1ull << 31)) return alga_fail(e, ALGA_ERR_CAPACITY, "more than 2^31 k-mers in the supplement; shard the input");
+    int32_t prio[4] = {0, 1, 2, 3};
+    const int key_bits = 36 + node_bits(n);
+    for (int round = 0; round < p->rounds; round++) {
         e->pkb_stats.kmers[round] = nk;
         if (nk >= 2) {
-            const size_t temp = sort_u64_pairs_temp_bytes(nk, 60);
-            if ((rc = alga_ensure(e, e->pk_keys2, (nk + 1) * sizeof(unsigned long long)))) return rc;
-            if ((rc = alga_ensure(e, e->pk_vals2, (nk + 1) * sizeof(unsigned long long)))) return rc;
+            const size_t temp = std::max(sort_u64_pairs_temp_bytes(nk, PKB_SORT_BITS), sort_u32_pairs_temp_bytes(nk));
+            for (DevBuf *b : {&e->pk_keys, &e->pk_vals, &e->pk_keys2, &e->pk_vals2, &e->pk_marks})
+                if ((rc = alga_ensure(e, *b, (nk + 1) * sizeof(unsigned long long)))) return rc;
+            for (DevBuf *b : {&e->pk_flag, &e->pk_pos, &e->pk_heads, &e->pk_heads2, &e->pk_hsz, &e->pk_hsz2, &e->pk_gsz, &e->pk_nadd})
+                if ((rc = alga_ensure(e, *b, (nk + 2) * sizeof(uint32_t)))) return rc;
             if ((rc = alga_ensure(e, e->sort_temp, temp))) return rc;
-            // node order inside equal hashes is fixed by the stable sort: entries were appended in unspecified block order,
-            // so the group kernel re-orders every group by (indInRead desc, length asc, id asc) itself
-            HIP_TRY(e, sort_u64_pairs(e->sort_temp.p, temp, (const unsigned long long *) e->pk_keys.p, (unsigned long long *) e->pk_keys2.p,
-                                      (const unsigned long long *) e->pk_vals.p, (unsigned long long *) e->pk_vals2.p, nk, 60, s));
-            if ((rc = alga_ensure(e, e->pk_flag, (nk + 2) * sizeof(uint32_t)))) return rc;
-            if ((rc = alga_ensure(e, e->pk_pos, (nk + 2) * sizeof(uint32_t)))) return rc;
-            if ((rc = alga_ensure(e, e->pk_heads, (nk + 2) * sizeof(uint32_t)))) return rc;
             if ((rc = alga_ensure(e, e->scan_scratch, scan_scratch_bytes(nk)))) return rc;
-            launch_pkb_group_sizes((const unsigned long long *) e->pk_keys2.p, nk, cnt + 1, cnt + 2, (uint32_t *) e->pk_flag.p, s);
+            launch_pkb_kmers(nd, c, prio, (const uint32_t *) e->pk_tips.p, (const uint32_t *) e->pk_koff.p, n_tips, (unsigned long long *) e->pk_keys.p,
+                             (unsigned long long *) e->pk_vals.p, s);
+            if ((rc = alga_check_launch(e, "k_pkb_kmers"))) return rc;
+            // equal hashes become contiguous; inside a group the group kernel orders the entries itself
+            HIP_TRY(e, sort_u64_pairs(e->sort_temp.p, temp, (const unsigned long long *) e->pk_keys.p, (unsigned long long *) e->pk_keys2.p,
+                                      (const unsigned long long *) e->pk_vals.p, (unsigned long long *) e->pk_vals2.p, nk, PKB_SORT_BITS, s));
+            launch_pkb_fix_runs((unsigned long long *) e->pk_keys2.p, (unsigned long long *) e->pk_vals2.p, nk, PKB_SORT_BITS, s);
+            if ((rc = alga_check_launch(e, "k_pkb_fix_runs"))) return rc;
+            HIP_TRY(e, hipMemsetAsync(cnt, 0, 12 * sizeof(unsigned long long), s));
+            launch_pkb_group_sizes((const unsigned long long *) e->pk_keys2.p, nk, cnt + 1, cnt + 2, (uint32_t *) e->pk_flag.p, (uint32_t *) e->pk_gsz.p, s);
             if ((rc = alga_check_launch(e, "k_pkb_group_sizes"))) return rc;
             launch_exclusive_scan((const uint32_t *) e->pk_flag.p, nk, (uint32_t *) e->pk_pos.p, (uint64_t *) e->scan_scratch.p, s);
-            launch_pkb_head_list((const uint32_t *) e->pk_flag.p, (const uint32_t *) e->pk_pos.p, nk, (uint32_t *) e->pk_heads.p, s);
+            launch_pkb_head_list((const uint32_t *) e->pk_flag.p, (const uint32_t *) e->pk_pos.p, (const uint32_t *) e->pk_gsz.p, nk, (uint32_t *) e->pk_heads.p,
+                                 (uint32_t *) e->pk_hsz.p, s);
             if ((rc = alga_check_launch(e, "k_pkb_head_list"))) return rc;
             HIP_TRY(e, hipMemcpyAsync(e->h_counters, cnt, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
             HIP_TRY(e, hipStreamSynchronize(s));
             const uint64_t big_words = e->h_counters[1];
-            e->pkb_stats.groups[round] = e->h_counters[2];
+            const uint32_t n_heads = (uint32_t) e->h_counters[2];
+            e->pkb_stats.groups[round] = n_heads;
             e->pkb_stats.max_group = std::max<uint64_t>(e->pkb_stats.max_group, e->h_counters[3]);
-            const uint64_t add_dense = 2 * nk;
-            uint64_t add_ovf_cap = std::max<uint64_t>(1024, nk / 4);
-            for (int attempt = 0; attempt < 3; attempt++) {
-                const uint64_t add_cap = add_dense + add_ovf_cap;
-                if ((rc = alga_ensure(e, e->pk_marks, (nk + 1) * sizeof(unsigned long long)))) return rc;
-                if ((rc = alga_ensure(e, e->pk_big, (big_words + 1) * sizeof(unsigned long long)))) return rc;
-                if ((rc = alga_ensure(e, e->pk_add, (E + add_cap + 1) * sizeof(alga_edge_dev)))) return rc;
-                // pk_add = [ current graph (E) | dense additions (2 nk) | overflow additions ]
-                HIP_TRY(e, hipMemcpyAsync(e->pk_add.p, e->pk_edges[cur].p, E * sizeof(alga_edge_dev), hipMemcpyDeviceToDevice, s));
-                alga_edge_dev *add = (alga_edge_dev *) e->pk_add.p + E;
-                HIP_TRY(e, hipMemsetAsync(add + add_dense, 0xFF, add_ovf_cap * sizeof(alga_edge_dev), s));      // src = -1: invalid
-                HIP_TRY(e, hipMemsetAsync(cnt + 4, 0, 4 * sizeof(unsigned long long), s));                    // big cursor, overflow, calls
-                launch_pkb_groups(nd, c, (const uint32_t *) e->pk_rowptr.p, (const alga_edge_dev *) e->pk_edges[cur].p,
-                                  (const unsigned long long *) e->pk_keys2.p, (const uint32_t *) e->pk_heads.p, (uint32_t) e->pkb_stats.groups[round],
-                                  (unsigned long long *) e->pk_vals2.p, nk,
-                                  (unsigned long long *) e->pk_marks.p, (unsigned long long *) e->pk_big.p, cnt + 4, add, add_dense, add_cap,
-                                  cnt + 5, cnt + 6, s);
-                if ((rc = alga_check_launch(e, "k_pkb_groups"))) return rc;
-                HIP_TRY(e, hipMemcpyAsync(e->h_counters, cnt, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-                HIP_TRY(e, hipStreamSynchronize(s));
-                if (e->h_counters[5] <= add_ovf_cap) {
-                    e->pkb_stats.can_align_calls[round] = e->h_counters[6];
-                    const int nxt = cur ^ 1;
-                    uint64_t E2 = 0;
-                    if ((rc = normalize_edges(e, n, (const alga_edge_dev *) e->pk_add.p, E + add_cap, e->pk_edges[nxt], &E2, s))) return rc;
-                    cur = nxt; E = E2;
-                    break;
+            if (n_heads) {
+                // groups in order of their size: the lanes of a wave replay groups of the same size
+                HIP_TRY(e, sort_u32_pairs_bits(e->sort_temp.p, temp, (const uint32_t *) e->pk_hsz.p, (uint32_t *) e->pk_hsz2.p, (const uint32_t *) e->pk_heads.p,
+                                               (uint32_t *) e->pk_heads2.p, n_heads, 8, s));
+                const uint64_t add_dense = 2 * nk;
+                uint64_t add_ovf_cap = std::max<uint64_t>(1024, nk / 4);
+                uint64_t n_dense = 0, n_ovf = 0;
+                for (int attempt = 0; attempt < 3; attempt++) {
+                    const uint64_t add_cap = add_dense + add_ovf_cap;
+                    if ((rc = alga_ensure(e, e->pk_big, (big_words + 1) * sizeof(unsigned long long)))) return rc;
+                    if ((rc = alga_ensure(e, e->pk_add, (add_cap + 1) * sizeof(unsigned long long)))) return rc;
+                    HIP_TRY(e, hipMemsetAsync(cnt + 4, 0, 4 * sizeof(unsigned long long), s));                    // big cursor, overflow, calls
+                    launch_pkb_groups(nd, c, (const uint32_t *) e->pk_rowptr.p, (const unsigned long long *) e->pk_g[cur].p, (const unsigned long long *) e->pk_keys2.p,
+                                      (const uint32_t *) e->pk_heads2.p, (const uint32_t *) e->pk_hsz2.p, n_heads, (unsigned long long *) e->pk_vals2.p, nk,
+                                      (unsigned long long *) e->pk_marks.p, (unsigned long long *) e->pk_big.p, cnt + 4, (unsigned long long *) e->pk_add.p, add_dense,
+                                      add_cap, cnt + 5, cnt + 6, (uint32_t *) e->pk_nadd.p, s);
+                    if ((rc = alga_check_launch(e, "k_pkb_groups"))) return rc;
+                    launch_exclusive_scan((const uint32_t *) e->pk_nadd.p, (uint64_t) n_heads, (uint32_t *) e->pk_pos.p, (uint64_t *) e->scan_scratch.p, s);
+                    HIP_TRY(e, hipMemcpyAsync(e->h_counters, cnt, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+                    HIP_TRY(e, hipMemcpyAsync(e->h_counters + 8, (uint64_t *) e->scan_scratch.p + scan_total_index((uint64_t) n_heads), sizeof(uint64_t),
+                                              hipMemcpyDeviceToHost, s));
+                    HIP_TRY(e, hipStreamSynchronize(s));
+                    if (e->h_counters[5] <= add_ovf_cap) { n_dense = e->h_counters[8]; n_ovf = e->h_counters[5]; break; }
+                    if (attempt == 2) return alga_fail(e, ALGA_ERR_HIP, "supplement: addition buffer kept overflowing");
+                    add_ovf_cap = e->h_counters[5] + 1024;
                 }
-                add_ovf_cap = e->h_counters[5] + 1024;
-                if (attempt == 2) return alga_fail(e, ALGA_ERR_HIP, "supplement: addition buffer kept overflowing");
+                e->pkb_stats.can_align_calls[round] = e->h_counters[6];
+                const uint64_t A = n_dense + n_ovf;
+                if (A) {
+                    // addDirectedEdge + retainOnlySmallestOffset: the additions as sorted keys, merged into the graph, first key per (src, dst)
+                    const int nxt = cur ^ 1;
+                    const size_t t2 = std::max(std::max(sort_u64_keys_temp_bytes(A), merge_u64_temp_bytes(E, A)), unique_edge_keys_temp_bytes(E + A));
+                    if ((rc = alga_ensure(e, e->pk_addk, (A + 1) * sizeof(unsigned long long)))) return rc;
+                    if ((rc = alga_ensure(e, e->pk_addk2, (A + 1) * sizeof(unsigned long long)))) return rc;
+                    if ((rc = alga_ensure(e, e->pk_merged, (E + A + 1) * sizeof(unsigned long long)))) return rc;
+                    if ((rc = alga_ensure(e, e->pk_g[nxt], (E + A + 1) * sizeof(unsigned long long)))) return rc;
+                    if ((rc = alga_ensure(e, e->sort_temp, t2))) return rc;
+                    launch_pkb_gather_adds((const uint32_t *) e->pk_heads2.p, (const uint32_t *) e->pk_nadd.p, (const uint32_t *) e->pk_pos.p, n_heads,
+                                           (const unsigned long long *) e->pk_add.p, add_dense, n_dense, n_ovf, (unsigned long long *) e->pk_addk.p, s);
+                    if ((rc = alga_check_launch(e, "k_pkb_gather_adds"))) return rc;
+                    HIP_TRY(e, sort_u64_keys_bits(e->sort_temp.p, t2, (const unsigned long long *) e->pk_addk.p, (unsigned long long *) e->pk_addk2.p, A, key_bits, s));
+                    HIP_TRY(e, merge_u64(e->sort_temp.p, t2, (const unsigned long long *) e->pk_g[cur].p, E, (const unsigned long long *) e->pk_addk2.p, A,
+                                         (unsigned long long *) e->pk_merged.p, s));
+                    HIP_TRY(e, unique_edge_keys(e->sort_temp.p, t2, (const unsigned long long *) e->pk_merged.p, (unsigned long long *) e->pk_g[nxt].p, cnt + 13, E + A, s));
+                    HIP_TRY(e, hipMemcpyAsync(e->h_counters, cnt + 13, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+                    HIP_TRY(e, hipStreamSynchronize(s));
+                    E = e->h_counters[0];
+                    cur = nxt;
+                    launch_pkb_rowptr((const unsigned long long *) e->pk_g[cur].p, E, n, (uint32_t *) e->pk_rowptr.p, s);
+                    if ((rc = alga_check_launch(e, "k_pkb_rowptr"))) return rc;
+                }
             }
         }
         e->pkb_stats.edges_after[round] = E;
         std::rotate(prio, prio + 1, prio + 4);                               // GraphCreatorLI.cpp:26
     }
+    if ((rc = alga_ensure(e, e->pk_edges[0], (E + 1) * sizeof(alga_edge_dev)))) return rc;
+    launch_pkb_keys_to_edges((const unsigned long long *) e->pk_g[cur].p, E, (alga_edge_dev *) e->pk_edges[0].p, s);
+    if ((rc = alga_check_launch(e, "k_pkb_keys_to_edges"))) return rc;
     HIP_TRY(e, hipEventRecord(ev1, s));
     HIP_TRY(e, hipStreamSynchronize(s));
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) e->pkb_stats.ms_total = ms;
-    *d_out = (const alga_edge *) e->pk_edges[cur].p;
+    *d_out = (const alga_edge *) e->pk_edges[0].p;
     *m_out = E;
     return ALGA_OK;
 }

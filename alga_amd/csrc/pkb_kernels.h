@@ -20,27 +20,37 @@ struct PkbCfg {
 
 void launch_can_align_batch(const NodesDev &nd, const PkbCfg &c, const int32_t *triples, uint64_t n, uint8_t *out, hipStream_t s);
 void launch_li_kmers_slots(const NodesDev &nd, const PkbCfg &c, const int32_t prio[4], uint64_t *hash, int32_t *ind, int32_t *count, hipStream_t s);
-void launch_pkb_masks(int32_t n, const uint32_t *rowptr, const alga_edge_dev *edges, uint64_t m, uint32_t *indeg, uint8_t *mask, hipStream_t s);
+void launch_pkb_edge_keys(const alga_edge_dev *e, uint64_t n, unsigned long long *keys, unsigned long long *counts /* [0] bad offsets, [1] unsorted */, hipStream_t s);
+void launch_pkb_rowptr(const unsigned long long *keys, uint64_t E, int32_t n, uint32_t *rowptr, hipStream_t s);
+void launch_pkb_keys_to_edges(const unsigned long long *keys, uint64_t E, alga_edge_dev *out, hipStream_t s);
+void launch_pkb_masks(int32_t n, const uint32_t *rowptr, const unsigned long long *keys, uint64_t m, uint32_t *indeg, uint8_t *mask, hipStream_t s);
 void launch_pkb_tip_flags(const NodesDev &nd, const PkbCfg &c, const uint8_t *mask, uint32_t *flag, hipStream_t s);
-void launch_pkb_tip_list(int32_t n, const uint32_t *flag, const uint32_t *pos, uint32_t *tips, hipStream_t s);
-void launch_pkb_kmers(const NodesDev &nd, const PkbCfg &c, const int32_t prio[4], const uint32_t *tips, uint32_t n_tips, unsigned long long *keys,
-                      unsigned long long *vals, unsigned long long *counter, hipStream_t s);
+void launch_pkb_tip_list(const NodesDev &nd, const PkbCfg &c, const uint32_t *flag, const uint32_t *pos, uint32_t *tips, uint32_t *kcount,
+                         unsigned long long *max_len, hipStream_t s);
+void launch_pkb_kmers(const NodesDev &nd, const PkbCfg &c, const int32_t prio[4], const uint32_t *tips, const uint32_t *koff, uint32_t n_tips,
+                      unsigned long long *keys, unsigned long long *vals, hipStream_t s);
+void launch_pkb_fix_runs(unsigned long long *keys, unsigned long long *vals, uint64_t n, int bits, hipStream_t s);
 void launch_pkb_group_sizes(const unsigned long long *keys, uint64_t n, unsigned long long *big_words, unsigned long long *stats, uint32_t *head_flag,
-                            hipStream_t s);
-void launch_pkb_head_list(const uint32_t *head_flag, const uint32_t *pos, uint64_t n, uint32_t *heads, hipStream_t s);
-void launch_pkb_groups(const NodesDev &nd, const PkbCfg &c, const uint32_t *rowptr, const alga_edge_dev *edges, const unsigned long long *keys, const uint32_t *heads, uint32_t n_heads,
-                       unsigned long long *vals, uint64_t n, unsigned long long *marks, unsigned long long *big_marks,
-                       unsigned long long *big_cursor, alga_edge_dev *add_edges, uint64_t add_dense, uint64_t add_cap,
-                       unsigned long long *add_overflow, unsigned long long *counters, hipStream_t s);
-void launch_pkb_valid_flags(const alga_edge_dev *e, uint64_t n, uint32_t *flag, hipStream_t s);
-void launch_pkb_edge_keys_dense(const alga_edge_dev *e, const uint32_t *flag, const uint32_t *pos, uint64_t n, unsigned long long *keys,
-                                unsigned long long *bad, hipStream_t s);
-void launch_pkb_unique_flags(const unsigned long long *keys, uint64_t n, uint32_t *flag, hipStream_t s);
-void launch_pkb_compact(const unsigned long long *keys, const uint32_t *flag, const uint32_t *pos, uint64_t n, alga_edge_dev *out,
-                        uint32_t *outdeg, hipStream_t s);
+                            uint32_t *gsize, hipStream_t s);
+void launch_pkb_head_list(const uint32_t *head_flag, const uint32_t *pos, const uint32_t *gsize, uint64_t n, uint32_t *heads, uint32_t *hsize, hipStream_t s);
+void launch_pkb_groups(const NodesDev &nd, const PkbCfg &c, const uint32_t *rowptr, const unsigned long long *gkeys, const unsigned long long *keys,
+                       const uint32_t *heads, const uint32_t *hsize, uint32_t n_heads, unsigned long long *vals, uint64_t n, unsigned long long *marks,
+                       unsigned long long *big_marks, unsigned long long *big_cursor, unsigned long long *add_keys, uint64_t add_dense, uint64_t add_cap,
+                       unsigned long long *add_overflow, unsigned long long *counters, uint32_t *n_add, hipStream_t s);
+void launch_pkb_gather_adds(const uint32_t *heads, const uint32_t *n_add, const uint32_t *pos, uint32_t n_heads, const unsigned long long *add_keys,
+                            uint64_t add_dense, uint64_t n_dense_total, uint64_t n_ovf, unsigned long long *out, hipStream_t s);
 
 // sort_records.hip
 size_t     sort_u64_keys_temp_bytes(uint64_t n);
 hipError_t sort_u64_keys(void *temp, size_t temp_bytes, const unsigned long long *keys_in, unsigned long long *keys_out, uint64_t n, hipStream_t s);
+hipError_t sort_u64_keys_bits(void *temp, size_t temp_bytes, const unsigned long long *keys_in, unsigned long long *keys_out, uint64_t n, int bits, hipStream_t s);
+hipError_t sort_u32_pairs_bits(void *temp, size_t temp_bytes, const uint32_t *keys_in, uint32_t *keys_out, const uint32_t *vals_in, uint32_t *vals_out,
+                               uint64_t n, int bits, hipStream_t s);
+size_t     merge_u64_temp_bytes(uint64_t na, uint64_t nb);
+hipError_t merge_u64(void *temp, size_t temp_bytes, const unsigned long long *a, uint64_t na, const unsigned long long *b, uint64_t nb, unsigned long long *out,
+                     hipStream_t s);
+size_t     unique_edge_keys_temp_bytes(uint64_t n);
+hipError_t unique_edge_keys(void *temp, size_t temp_bytes, const unsigned long long *in, unsigned long long *out, unsigned long long *d_count, uint64_t n,
+                            hipStream_t s);
 
 } // namespace alga

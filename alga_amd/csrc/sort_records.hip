@@ -83,6 +83,49 @@ hipError_t sort_u64_keys(void *temp, size_t temp_bytes, const unsigned long long
     return rocprim::radix_sort_keys(temp, temp_bytes, keys_in, keys_out, (size_t) n, 0u, 64u, s);
 }
 
+// (u32 key, u32 value) on the low `bits` key bits: group heads by group size (pkb_kernels.hip)
+hipError_t sort_u32_pairs_bits(void *temp, size_t temp_bytes, const uint32_t *keys_in, uint32_t *keys_out, const uint32_t *vals_in, uint32_t *vals_out,
+                               uint64_t n, int bits, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    return rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t) n, 0u, (unsigned) bits, s);
+}
+
+hipError_t sort_u64_keys_bits(void *temp, size_t temp_bytes, const unsigned long long *keys_in, unsigned long long *keys_out, uint64_t n, int bits,
+                              hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    return rocprim::radix_sort_keys(temp, temp_bytes, keys_in, keys_out, (size_t) n, 0u, (unsigned) bits, s);
+}
+
+// the supplement's graph (sorted unique edge keys, pkb_kernels.hip): merge of two sorted key lists, and "first key of every
+// (src, dst) run" = equality on key >> 9
+struct EdgePairEq { __device__ bool operator()(unsigned long long a, unsigned long long b) const { return (a >> 9) == (b >> 9); } };
+
+size_t merge_u64_temp_bytes(uint64_t na, uint64_t nb) {
+    size_t bytes = 0;
+    (void) rocprim::merge(nullptr, bytes, (const unsigned long long *) nullptr, (const unsigned long long *) nullptr, (unsigned long long *) nullptr,
+                          (size_t) na, (size_t) nb, rocprim::less<unsigned long long>(), (hipStream_t) 0);
+    return bytes;
+}
+
+hipError_t merge_u64(void *temp, size_t temp_bytes, const unsigned long long *a, uint64_t na, const unsigned long long *b, uint64_t nb,
+                     unsigned long long *out, hipStream_t s) {
+    if (na + nb == 0) return hipSuccess;
+    return rocprim::merge(temp, temp_bytes, a, b, out, (size_t) na, (size_t) nb, rocprim::less<unsigned long long>(), s);
+}
+
+size_t unique_edge_keys_temp_bytes(uint64_t n) {
+    size_t bytes = 0;
+    (void) rocprim::unique(nullptr, bytes, (const unsigned long long *) nullptr, (unsigned long long *) nullptr, (unsigned long long *) nullptr, (size_t) n,
+                           EdgePairEq(), (hipStream_t) 0);
+    return bytes;
+}
+
+// *d_count (device) = number of keys kept
+hipError_t unique_edge_keys(void *temp, size_t temp_bytes, const unsigned long long *in, unsigned long long *out, unsigned long long *d_count, uint64_t n,
+                            hipStream_t s) {
+    return rocprim::unique(temp, temp_bytes, in, out, d_count, (size_t) n, EdgePairEq(), s);
+}
+
 // stable sort of (u64 key, u32 value) on the low `bits` key bits: the LSD passes of ingest_kernels.hip
 size_t sort_u64_u32_temp_bytes(uint64_t n) { return sort_edges_temp_bytes(n); }
 hipError_t sort_u64_u32(void *temp, size_t temp_bytes, const unsigned long long *keys_in, unsigned long long *keys_out, const uint32_t *vals_in,

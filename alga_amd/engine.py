@@ -538,6 +538,15 @@ class Engine:
         finally:
             self._lib.alga_free_edges(self._h, out)
 
+    def pkb_supplement_device(self, words, lens, d_edges, n_edges, p, stream=None):
+        """node set (torch device tensors) and edge list (device pointer, sorted by (src, dst)) in HBM -> (ptr, n_edges) engine-owned"""
+        nd = self._nodes_from_torch(words, lens, None, None)
+        out = C.c_void_p()
+        m = C.c_uint64()
+        self._check(self._lib.alga_pkb_supplement_device(self._h, C.byref(nd), C.byref(p), C.c_void_p(d_edges), C.c_uint64(int(n_edges)),
+                                                         C.c_void_p(stream or 0), C.byref(out), C.byref(m)))
+        return out.value, int(m.value)
+
     def pkb_last_stats(self):
         st = PkbStats()
         self._check(self._lib.alga_pkb_last_stats(self._h, C.byref(st)))

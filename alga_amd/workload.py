@@ -111,13 +111,35 @@ def write_fasta_fast(path, codes):
         f.write(rec.tobytes())
 
 
-def device_build(n_reads, read_len, genome_len, seed, device="cuda", trim=3, chunk=1 << 21, sample_reads=0):
+def _mix64(x):
+    """splitmix-style mixer on int64 tensors (wrapping arithmetic, logical shifts emulated)"""
+    x = x * -7046029254386353131                           # 0x9E3779B97F4A7C15
+    x = x ^ ((x >> 32) & 0xFFFFFFFF)
+    x = x * -4658895280553007687                           # 0xBF58476D1CE4E5B9
+    x = x ^ ((x >> 29) & 0x7FFFFFFFF)
+    return x
+
+
+def _with_errors(codes, read_idx, err, seed):
+    """substitution errors at rate `err` as a pure function of (seed, original read index, position): regenerable in any order"""
+    import torch
+    L = codes.shape[1]
+    x = _mix64((read_idx[:, None] * L + torch.arange(L, device=codes.device)[None, :]) ^ (int(seed) * 1000003))
+    u = ((x >> 11) & ((1 << 40) - 1)).to(torch.float64) / float(1 << 40)
+    delta = (1 + ((x >> 3) & 0xFFFF) % 3).to(torch.uint8)
+    return torch.where(u < err, (codes + delta) & 3, codes)
+
+
+def device_build(n_reads, read_len, genome_len, seed, device="cuda", trim=3, chunk=1 << 21, sample_reads=0, err=0.0):
     """The SURVEY.md section 8(d) workload for error-free fixed-length reads, generated ON THE DEVICE (torch is only the array
     library) straight into the engine's HBM row layout: iid genome, uniform starts, strand flips; one read per start
     position (on an iid genome two reads are duplicates of each other -- on one strand or the other -- exactly when they
     start at the same position, which is what the reference's duplicate removal keeps one of: src/IO/ReadPreprocess.cpp:13-77;
     STR reads and reverse-complement palindromes have probability < 4^-20 per read and are ignored); node ids shuffled so that
     they carry no positional information, node 2i = reverse complement, 2i+1 = forward (src/IO/InputReader.cpp:78-80).
+    err > 0: substitution errors at that rate per nucleotide (applied in genome orientation, before the strand flip); two reads
+    are then duplicates when they start at the same position AND carry the same errors (in the part that survives the end
+    trimming), so the set is made unique on (start, hash of that erroneous sequence) instead of on the start alone.
     -> dict(words int32[N, 16|stride] (device), lens int32[N] (device), n_reads, unique_reads, min_overlap, rsoemo,
             sample_codes uint8[~sample_reads, read_len] (host): a genomic window of the SAME read set for the CPU baseline's
             FASTA -- every (untrimmed) read that starts in the first genome_len * sample_reads / n_reads positions, in node
@@ -128,14 +150,38 @@ def device_build(n_reads, read_len, genome_len, seed, device="cuda", trim=3, chu
     genome = torch.randint(0, 4, (genome_len,), dtype=torch.uint8, device=device, generator=g)
     starts = torch.randint(0, genome_len - read_len + 1, (n_reads,), device=device, generator=g)
     flip = torch.rand(n_reads, device=device, generator=g) < 0.5
-    starts, order = torch.sort(starts, stable=True)
-    first = torch.ones_like(starts, dtype=torch.bool)
-    first[1:] = starts[1:] != starts[:-1]
-    starts, flip = starts[first], flip[order][first]
-    del order, first
+    ridx = None
+    if err > 0:
+        # the key of a read: start and a 64-bit hash of its erroneous sequence
+        trm = read_len - 2 * trim if read_len >= 2 * trim + 10 else read_len
+        tr0 = trim if trm != read_len else 0
+        ridx = torch.arange(n_reads, device=device)
+        hsh = torch.empty(n_reads, dtype=torch.int64, device=device)
+        wts = _mix64(torch.arange(read_len, device=device) + 12345)[None, :]
+        arL = torch.arange(read_len, device=device)[None, :]
+        for s0 in range(0, n_reads, chunk):
+            c = _with_errors(genome[starts[s0:s0 + chunk][:, None] + arL], ridx[s0:s0 + chunk], err, seed)
+            hsh[s0:s0 + chunk] = ((c.to(torch.int64) + 1) * wts)[:, tr0:tr0 + trm].sum(dim=1)   # of what is left after the end trimming
+            del c
+        o1 = torch.argsort(hsh, stable=True)
+        o2 = torch.argsort(starts[o1], stable=True)
+        order = o1[o2]
+        starts, hsh = starts[order], hsh[order]
+        first = torch.ones_like(starts, dtype=torch.bool)
+        first[1:] = (starts[1:] != starts[:-1]) | (hsh[1:] != hsh[:-1])
+        starts, flip, ridx = starts[first], flip[order][first], ridx[order][first]
+        del o1, o2, order, first, hsh
+    else:
+        starts, order = torch.sort(starts, stable=True)
+        first = torch.ones_like(starts, dtype=torch.bool)
+        first[1:] = starts[1:] != starts[:-1]
+        starts, flip = starts[first], flip[order][first]
+        del order, first
     R = int(starts.shape[0])
     perm = torch.randperm(R, device=device, generator=g)
     starts, flip = starts[perm], flip[perm]
+    if ridx is not None:
+        ridx = ridx[perm]
     del perm
     m = read_len - 2 * trim if read_len >= 2 * trim + 10 else read_len
     t0 = trim if m != read_len else 0
@@ -154,7 +200,12 @@ def device_build(n_reads, read_len, genome_len, seed, device="cuda", trim=3, chu
     ar = torch.arange(m, device=device)[None, :]
     for s0 in range(0, R, chunk):
         st = starts[s0:s0 + chunk]
-        codes = genome[(st[:, None] + t0 + ar)]
+        if err > 0:
+            full = _with_errors(genome[st[:, None] + torch.arange(read_len, device=device)[None, :]], ridx[s0:s0 + chunk], err, seed)
+            codes = full[:, t0:t0 + m]
+            del full
+        else:
+            codes = genome[(st[:, None] + t0 + ar)]
         f = flip[s0:s0 + chunk][:, None]
         rc = (3 - codes).flip(1)
         fw = torch.where(f, rc, codes)
@@ -171,6 +222,8 @@ def device_build(n_reads, read_len, genome_len, seed, device="cuda", trim=3, chu
         sel = torch.nonzero(starts < window).flatten()
         st = starts[sel]
         codes = genome[(st[:, None] + torch.arange(read_len, device=device)[None, :])]
+        if err > 0:
+            codes = _with_errors(codes, ridx[sel], err, seed)
         codes = torch.where(flip[sel][:, None], (3 - codes).flip(1), codes)
         out["sample_codes"] = codes.cpu().numpy()
     return out
