@@ -33,6 +33,7 @@ struct alga_engine {
     // device buffers, grown on demand and kept between calls
     DevBuf table, filter, counters, rowptr, rec_dst, rec_val, keys, seg_key, seg_val, heads, sort_temp, out_cnt, outdeg, out_rowptr, edges, scan_scratch;
     DevBuf cl_defer;                                        // sources the pair kernel hands to the general kernel
+    uint32_t h_first_hkey = 255;                            // supplement: sort key of the longest group of a round (255 - min(D, 255))
     // alga_prefsuf_keys_device: the node range whose keys / runs this engine computed last (n < 0: none), consumed by a build with
     // params.keys_shared
     int32_t keyed_n = -1, keyed_begin = 0, keyed_end = 0;
@@ -48,7 +49,7 @@ struct alga_engine {
     // approximate supplement (engine_pkb.hip)
     DevBuf pk_keys, pk_keys2, pk_vals, pk_vals2, pk_marks, pk_big, pk_add, pk_ekeys, pk_ekeys2, pk_flag, pk_pos, pk_edges[2], pk_rowptr, pk_deg,
            pk_mask, pk_cnt, pk_io, pk_io2, pk_tips, pk_heads, pk_g[2], pk_addk, pk_addk2, pk_merged, pk_hsz, pk_hsz2, pk_heads2, pk_nadd, pk_koff,
-           pk_gsz;
+           pk_gsz, pk_fixlist;
     // duplicate / prefix-read removal (engine_ingest.hip)
     DevBuf pp_rows, pp_len, pp_perm[2], pp_keys[2], pp_mark, pp_keep, pp_pos, pp_out_rows, pp_out_len, pp_out_pair, pp_tally;
     // staged host <-> HBM copies (staging.hip)

@@ -98,8 +98,7 @@ int graph_from_edges(alga_engine *e, int32_t n_nodes, const alga_edge_dev *in, u
     return ALGA_OK;
 }
 
-// k-mer entries are radix-sorted on this many low bits of the hash; k_pkb_fix_runs repairs the runs where two hashes share them
-constexpr int PKB_SORT_BITS = 32;
+constexpr uint32_t PKB_FIX_LIST_CAP = 1u << 20;     // places where two hashes share their sorted low bits (k_pkb_fix_flag)
 
 int supplement_device_impl(alga_engine *e, const alga_nodes *dn, const alga_pkb_params *p, const alga_edge *d_edges_in, uint64_t m_in,
                            hipStream_t s, const alga_edge **d_out, uint64_t *m_out) {
@@ -151,34 +150,46 @@ int supplement_device_impl(alga_engine *e, const alga_nodes *dn, const alga_pkb_
     for (int round = 0; round < p->rounds; round++) {
         e->pkb_stats.kmers[round] = nk;
         if (nk >= 2) {
-            const size_t temp = std::max(sort_u64_pairs_temp_bytes(nk, PKB_SORT_BITS), sort_u32_pairs_temp_bytes(nk));
+            // k-mer entries are radix-sorted on this many low bits of their key (= top bits of the mixed hash) (expected places to repair: nk^2 / 2^(bits + 1) <= 2^18)
+            const int sort_bits = nk <= (1ull << 25) ? 32 : (nk <= (1ull << 29) ? 40 : 48);
+            const size_t temp = std::max(sort_u64_pairs_temp_bytes(nk, sort_bits), sort_u32_pairs_temp_bytes(nk));
+            if ((rc = alga_ensure(e, e->pk_fixlist, (size_t) PKB_FIX_LIST_CAP * sizeof(uint32_t)))) return rc;
             for (DevBuf *b : {&e->pk_keys, &e->pk_vals, &e->pk_keys2, &e->pk_vals2, &e->pk_marks})
                 if ((rc = alga_ensure(e, *b, (nk + 1) * sizeof(unsigned long long)))) return rc;
             for (DevBuf *b : {&e->pk_flag, &e->pk_pos, &e->pk_heads, &e->pk_heads2, &e->pk_hsz, &e->pk_hsz2, &e->pk_gsz, &e->pk_nadd})
                 if ((rc = alga_ensure(e, *b, (nk + 2) * sizeof(uint32_t)))) return rc;
             if ((rc = alga_ensure(e, e->sort_temp, temp))) return rc;
             if ((rc = alga_ensure(e, e->scan_scratch, scan_scratch_bytes(nk)))) return rc;
-            launch_pkb_kmers(nd, c, prio, (const uint32_t *) e->pk_tips.p, (const uint32_t *) e->pk_koff.p, n_tips, (unsigned long long *) e->pk_keys.p,
+            launch_pkb_kmers(nd, c, prio, (const uint32_t *) e->pk_tips.p, (const uint32_t *) e->pk_koff.p, n_tips, sort_bits, (unsigned long long *) e->pk_keys.p,
                              (unsigned long long *) e->pk_vals.p, s);
             if ((rc = alga_check_launch(e, "k_pkb_kmers"))) return rc;
             // equal hashes become contiguous; inside a group the group kernel orders the entries itself
             HIP_TRY(e, sort_u64_pairs(e->sort_temp.p, temp, (const unsigned long long *) e->pk_keys.p, (unsigned long long *) e->pk_keys2.p,
-                                      (const unsigned long long *) e->pk_vals.p, (unsigned long long *) e->pk_vals2.p, nk, PKB_SORT_BITS, s));
-            launch_pkb_fix_runs((unsigned long long *) e->pk_keys2.p, (unsigned long long *) e->pk_vals2.p, nk, PKB_SORT_BITS, s);
-            if ((rc = alga_check_launch(e, "k_pkb_fix_runs"))) return rc;
-            HIP_TRY(e, hipMemsetAsync(cnt, 0, 12 * sizeof(unsigned long long), s));
-            launch_pkb_group_sizes((const unsigned long long *) e->pk_keys2.p, nk, cnt + 1, cnt + 2, (uint32_t *) e->pk_flag.p, (uint32_t *) e->pk_gsz.p, s);
-            if ((rc = alga_check_launch(e, "k_pkb_group_sizes"))) return rc;
-            launch_exclusive_scan((const uint32_t *) e->pk_flag.p, nk, (uint32_t *) e->pk_pos.p, (uint64_t *) e->scan_scratch.p, s);
-            launch_pkb_head_list((const uint32_t *) e->pk_flag.p, (const uint32_t *) e->pk_pos.p, (const uint32_t *) e->pk_gsz.p, nk, (uint32_t *) e->pk_heads.p,
-                                 (uint32_t *) e->pk_hsz.p, s);
-            if ((rc = alga_check_launch(e, "k_pkb_head_list"))) return rc;
-            HIP_TRY(e, hipMemcpyAsync(e->h_counters, cnt, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-            HIP_TRY(e, hipStreamSynchronize(s));
-            const uint64_t big_words = e->h_counters[1];
-            const uint32_t n_heads = (uint32_t) e->h_counters[2];
+                                      (const unsigned long long *) e->pk_vals.p, (unsigned long long *) e->pk_vals2.p, nk, sort_bits, s));
+            uint32_t n_heads = 0;
+            uint64_t big_words = 0;
+            for (int pass = 0; pass < 2; pass++) {
+                HIP_TRY(e, hipMemsetAsync(cnt, 0, 12 * sizeof(unsigned long long), s));
+                if (pass == 0) launch_pkb_fix_runs((unsigned long long *) e->pk_keys2.p, (unsigned long long *) e->pk_vals2.p, nk, sort_bits, (uint32_t *) e->pk_fixlist.p,
+                                                   PKB_FIX_LIST_CAP, cnt + 9, s);
+                else launch_pkb_fix_runs_loop((unsigned long long *) e->pk_keys2.p, (unsigned long long *) e->pk_vals2.p, nk, sort_bits, s);   // the list overflowed
+                if ((rc = alga_check_launch(e, "k_pkb_fix_runs"))) return rc;
+                launch_pkb_group_sizes((const unsigned long long *) e->pk_keys2.p, nk, cnt + 1, cnt + 3, (uint32_t *) e->pk_flag.p, (uint32_t *) e->pk_gsz.p, s);
+                if ((rc = alga_check_launch(e, "k_pkb_group_sizes"))) return rc;
+                launch_exclusive_scan((const uint32_t *) e->pk_flag.p, nk, (uint32_t *) e->pk_pos.p, (uint64_t *) e->scan_scratch.p, s);
+                launch_pkb_head_list((const uint32_t *) e->pk_flag.p, (const uint32_t *) e->pk_pos.p, (const uint32_t *) e->pk_gsz.p, nk, (uint32_t *) e->pk_heads.p,
+                                     (uint32_t *) e->pk_hsz.p, s);
+                if ((rc = alga_check_launch(e, "k_pkb_head_list"))) return rc;
+                HIP_TRY(e, hipMemcpyAsync(e->h_counters, cnt, 12 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+                HIP_TRY(e, hipMemcpyAsync(e->h_counters + 12, (uint64_t *) e->scan_scratch.p + scan_total_index(nk), sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+                HIP_TRY(e, hipStreamSynchronize(s));
+                if (pass == 0 && e->h_counters[9] > PKB_FIX_LIST_CAP) continue;
+                big_words = e->h_counters[1];
+                n_heads = (uint32_t) e->h_counters[12];
+                break;
+            }
             e->pkb_stats.groups[round] = n_heads;
-            e->pkb_stats.max_group = std::max<uint64_t>(e->pkb_stats.max_group, e->h_counters[3]);
+            e->pkb_stats.max_group = std::max<uint64_t>(e->pkb_stats.max_group, e->h_counters[3]);             // exact for groups of more than 64
             if (n_heads) {
                 // groups in order of their size: the lanes of a wave replay groups of the same size
                 HIP_TRY(e, sort_u32_pairs_bits(e->sort_temp.p, temp, (const uint32_t *) e->pk_hsz.p, (uint32_t *) e->pk_hsz2.p, (const uint32_t *) e->pk_heads.p,
@@ -194,18 +205,20 @@ int supplement_device_impl(alga_engine *e, const alga_nodes *dn, const alga_pkb_
                     launch_pkb_groups(nd, c, (const uint32_t *) e->pk_rowptr.p, (const unsigned long long *) e->pk_g[cur].p, (const unsigned long long *) e->pk_keys2.p,
                                       (const uint32_t *) e->pk_heads2.p, (const uint32_t *) e->pk_hsz2.p, n_heads, (unsigned long long *) e->pk_vals2.p, nk,
                                       (unsigned long long *) e->pk_marks.p, (unsigned long long *) e->pk_big.p, cnt + 4, (unsigned long long *) e->pk_add.p, add_dense,
-                                      add_cap, cnt + 5, cnt + 6, (uint32_t *) e->pk_nadd.p, s);
+                                      add_cap, cnt + 5, cnt + 6, (uint32_t *) e->pk_nadd.p, (uint32_t *) e->pk_gsz.p, e->n_cu, s);
                     if ((rc = alga_check_launch(e, "k_pkb_groups"))) return rc;
                     launch_exclusive_scan((const uint32_t *) e->pk_nadd.p, (uint64_t) n_heads, (uint32_t *) e->pk_pos.p, (uint64_t *) e->scan_scratch.p, s);
                     HIP_TRY(e, hipMemcpyAsync(e->h_counters, cnt, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
                     HIP_TRY(e, hipMemcpyAsync(e->h_counters + 8, (uint64_t *) e->scan_scratch.p + scan_total_index((uint64_t) n_heads), sizeof(uint64_t),
                                               hipMemcpyDeviceToHost, s));
+                    HIP_TRY(e, hipMemcpyAsync(&e->h_first_hkey, e->pk_hsz2.p, sizeof(uint32_t), hipMemcpyDeviceToHost, s));    // the longest group's sort key
                     HIP_TRY(e, hipStreamSynchronize(s));
                     if (e->h_counters[5] <= add_ovf_cap) { n_dense = e->h_counters[8]; n_ovf = e->h_counters[5]; break; }
                     if (attempt == 2) return alga_fail(e, ALGA_ERR_HIP, "supplement: addition buffer kept overflowing");
                     add_ovf_cap = e->h_counters[5] + 1024;
                 }
                 e->pkb_stats.can_align_calls[round] = e->h_counters[6];
+                e->pkb_stats.max_group = std::max<uint64_t>(e->pkb_stats.max_group, 255u - std::min<uint32_t>(255u, e->h_first_hkey));
                 const uint64_t A = n_dense + n_ovf;
                 if (A) {
                     // addDirectedEdge + retainOnlySmallestOffset: the additions as sorted keys, merged into the graph, first key per (src, dst)

@@ -27,16 +27,18 @@ void launch_pkb_masks(int32_t n, const uint32_t *rowptr, const unsigned long lon
 void launch_pkb_tip_flags(const NodesDev &nd, const PkbCfg &c, const uint8_t *mask, uint32_t *flag, hipStream_t s);
 void launch_pkb_tip_list(const NodesDev &nd, const PkbCfg &c, const uint32_t *flag, const uint32_t *pos, uint32_t *tips, uint32_t *kcount,
                          unsigned long long *max_len, hipStream_t s);
-void launch_pkb_kmers(const NodesDev &nd, const PkbCfg &c, const int32_t prio[4], const uint32_t *tips, const uint32_t *koff, uint32_t n_tips,
+void launch_pkb_kmers(const NodesDev &nd, const PkbCfg &c, const int32_t prio[4], const uint32_t *tips, const uint32_t *koff, uint32_t n_tips, int sort_bits,
                       unsigned long long *keys, unsigned long long *vals, hipStream_t s);
-void launch_pkb_fix_runs(unsigned long long *keys, unsigned long long *vals, uint64_t n, int bits, hipStream_t s);
-void launch_pkb_group_sizes(const unsigned long long *keys, uint64_t n, unsigned long long *big_words, unsigned long long *stats, uint32_t *head_flag,
+void launch_pkb_fix_runs(unsigned long long *keys, unsigned long long *vals, uint64_t n, int bits, uint32_t *list, uint32_t list_cap, unsigned long long *counter,
+                         hipStream_t s);
+void launch_pkb_fix_runs_loop(unsigned long long *keys, unsigned long long *vals, uint64_t n, int bits, hipStream_t s);
+void launch_pkb_group_sizes(const unsigned long long *keys, uint64_t n, unsigned long long *big_words, unsigned long long *max_d, uint32_t *head_flag,
                             uint32_t *gsize, hipStream_t s);
-void launch_pkb_head_list(const uint32_t *head_flag, const uint32_t *pos, const uint32_t *gsize, uint64_t n, uint32_t *heads, uint32_t *hsize, hipStream_t s);
+void launch_pkb_head_list(const uint32_t *head_flag, const uint32_t *pos, const uint32_t *gsize, uint64_t n, uint32_t *heads, uint32_t *hkey, hipStream_t s);
 void launch_pkb_groups(const NodesDev &nd, const PkbCfg &c, const uint32_t *rowptr, const unsigned long long *gkeys, const unsigned long long *keys,
-                       const uint32_t *heads, const uint32_t *hsize, uint32_t n_heads, unsigned long long *vals, uint64_t n, unsigned long long *marks,
+                       const uint32_t *heads, const uint32_t *hkey, uint32_t n_heads, unsigned long long *vals, uint64_t n, unsigned long long *marks,
                        unsigned long long *big_marks, unsigned long long *big_cursor, unsigned long long *add_keys, uint64_t add_dense, uint64_t add_cap,
-                       unsigned long long *add_overflow, unsigned long long *counters, uint32_t *n_add, hipStream_t s);
+                       unsigned long long *add_overflow, unsigned long long *counters, uint32_t *n_add, uint32_t *left, int n_cu, hipStream_t s);
 void launch_pkb_gather_adds(const uint32_t *heads, const uint32_t *n_add, const uint32_t *pos, uint32_t n_heads, const unsigned long long *add_keys,
                             uint64_t add_dense, uint64_t n_dense_total, uint64_t n_ovf, unsigned long long *out, hipStream_t s);
 

@@ -222,7 +222,15 @@ __global__ void __launch_bounds__(256) k_pkb_tip_list(NodesDev nd, PkbCfg c, con
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(len, o); len = t > len ? t : len; }
-    if ((threadIdx.x & 63u) == 0 && len > 0) atomicMax(max_len, (unsigned long long) len);
+    // same-address atomics retire at ~88 per microsecond chip-wide (one per wave here was 3.5 ms at 20 M nodes) and reads of one hot
+    // address are not much better: one guarded update per workgroup
+    __shared__ int s_len[4];
+    if ((threadIdx.x & 63u) == 0) s_len[threadIdx.x >> 6] = len;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 4; k++) len = s_len[k] > len ? s_len[k] : len;
+        if (len > 0 && (unsigned long long) len > __hip_atomic_load(max_len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(max_len, (unsigned long long) len);
+    }
 }
 
 // A k-mer entry: key = hash, val = (4095 - indInRead) << 40 | read length << 28 | node id.  Ascending val == the order of the
@@ -232,29 +240,105 @@ __device__ __forceinline__ int pkb_val_id(unsigned long long v) { return (int) (
 __device__ __forceinline__ int pkb_val_len(unsigned long long v) { return (int) ((v >> 28) & 0xFFFull); }
 __device__ __forceinline__ int pkb_val_ind(unsigned long long v) { return 4095 - (int) (v >> 40); }
 
-// k-mers of every node that takes part (GraphCreatorKmerBased::getKmersForBucketJob :202-259) at the tip's fixed offset
+// k-mers of every node that takes part (GraphCreatorKmerBased::getKmersForBucketJob :202-259) at the tip's fixed offset.
+// STAGED (rows of up to 16 words): the workgroup's rows go through LDS -- one thread walking its own row in global memory costs
+// a 64-line access per load instruction of the wave (116 of them per row: 0.7 of the kernel's 1.25 ms at 3.6 M tips).
+// The sort key of an entry is hash * PKB_KEY_MIX mod 2^64 (odd multiplier: a bijection, equal keys == equal hashes), rotated so
+// that the product's top `sort_bits` bits are the key's low bits: the entries are radix-sorted on those only.  The hash itself will
+// not do: it is the k-mer's base-4 value when that is
+// below 10^18 + 3 -- true of most minimizers -- so its low 32 bits are the last 16 nucleotides, shared by every k-mer that differs
+// from another by a sequencing error further left (1.4 M such neighbours among 21 M entries).
+constexpr unsigned long long PKB_KEY_MIX = 0x9E3779B97F4A7C15ull;
+constexpr int PKB_ROW_WORDS = 16;
+template <bool STAGED>
 __global__ void __launch_bounds__(256) k_pkb_kmers(NodesDev nd, PkbCfg c, int4 prio4, const uint32_t *__restrict__ tips, const uint32_t *__restrict__ koff,
-                                                    uint32_t n_tips, unsigned long long *__restrict__ keys, unsigned long long *__restrict__ vals) {
+                                                    uint32_t n_tips, int sort_bits /* 1 .. 63 */, unsigned long long *__restrict__ keys,
+                                                    unsigned long long *__restrict__ vals) {
     __shared__ uint64_t T[64];
+    __shared__ uint32_t srow[STAGED ? 256 : 1][PKB_ROW_WORDS + 1];
     mod_table_fill(T);
+    const uint32_t base_t = blockIdx.x * blockDim.x;
+    if (STAGED) {
+        const int cw = (int) (threadIdx.x & 15u);
+        for (int r = (int) (threadIdx.x >> 4); r < 256; r += 16) {
+            const uint32_t t = base_t + (uint32_t) r;
+            srow[r][cw] = (t < n_tips && cw < nd.stride) ? nd.words[(size_t) tips[t] * nd.stride + cw] : 0u;
+        }
+    }
     __syncthreads();
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t t = base_t + threadIdx.x;
     if (t >= n_tips) return;
     const int prio[4] = {prio4.x, prio4.y, prio4.z, prio4.w};
     uint64_t h[PKB_MAX_INTERVALS]; int32_t p[PKB_MAX_INTERVALS];
     const uint32_t i = tips[t];
     const int len = nd.len[i];
-    const int cnt = li_kmers(nd.words + (size_t) i * nd.stride, len, c.li_k, c.li_intervals, prio, h, p, T);
+    const uint32_t *row = STAGED ? srow[threadIdx.x] : nd.words + (size_t) i * nd.stride;
+    const int cnt = li_kmers(row, len, c.li_k, c.li_intervals, prio, h, p, T);
     const uint32_t base = koff[t];
     for (int j = 0; j < cnt; j++) {
-        keys[base + j] = h[j];
+        const unsigned long long m = h[j] * PKB_KEY_MIX;
+        keys[base + j] = (m << sort_bits) | (m >> (64 - sort_bits));            // the product's top bits, where the sort looks
         vals[base + j] = ((unsigned long long) (4095 - p[j]) << 40) | ((unsigned long long) (uint32_t) len << 28) | i;
     }
 }
 
-// The k-mer entries are radix-sorted on the LOW `bits` bits of the hash only (half the passes of a full 60-bit sort).  A run of equal
-// low bits nearly always is one group; where two hashes share their low bits (n^2 / 2^(bits+1) pairs) the run is ordered by the full
-// hash here, so that equal hashes are contiguous for everything downstream.
+// The k-mer entries are radix-sorted on the low `bits` bits of the key only (half the passes of a full sort).  A run of equal
+// low bits nearly always is one group; where two keys share them (n^2 / 2^(bits+1) pairs) the run is ordered by the full
+// key, so that equal hashes are contiguous for everything downstream.  k_pkb_fix_flag lists the places (one streaming pass, no
+// loops), k_pkb_fix_apply repairs the listed runs; a list that overflows is answered with the loop form k_pkb_fix_runs.
+__device__ __forceinline__ void pkb_sort_run(unsigned long long *keys, unsigned long long *vals, uint64_t r, uint64_t e) {
+    for (uint64_t a = r + 1; a < e; a++) {                                      // insertion sort of the run by the full hash
+        const unsigned long long k = keys[a], v = vals[a];
+        uint64_t b = a;
+        while (b > r && keys[b - 1] > k) { keys[b] = keys[b - 1]; vals[b] = vals[b - 1]; b--; }
+        keys[b] = k; vals[b] = v;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_pkb_fix_flag(const unsigned long long *__restrict__ keys, uint64_t n, int bits, uint32_t *__restrict__ list,
+                                                       uint32_t list_cap, unsigned long long *__restrict__ counter) {
+    const unsigned long long lm = bits >= 64 ? ~0ull : ((1ull << bits) - 1ull);
+    const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0 || i >= n) return;
+    const unsigned long long k = keys[i], kp = keys[i - 1];
+    if (k != kp && (k & lm) == (kp & lm)) {
+        const unsigned long long at = atomicAdd(counter, 1ull);
+        if (at < list_cap) list[at] = (uint32_t) i;
+    }
+}
+
+// which listed place repairs its run: the first one of the run (decided while nobody writes: bit 31 of the list entry)
+__global__ void __launch_bounds__(64) k_pkb_fix_owner(const unsigned long long *__restrict__ keys, int bits, uint32_t *__restrict__ list, uint32_t list_cap,
+                                                       const unsigned long long *__restrict__ counter) {
+    const unsigned long long lm = bits >= 64 ? ~0ull : ((1ull << bits) - 1ull);
+    const unsigned long long cnt = *counter;
+    if (cnt > list_cap) return;                                                 // the host runs k_pkb_fix_runs instead
+    const uint64_t t = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= cnt) return;
+    const uint64_t i = list[t];
+    const unsigned long long low = keys[i] & lm;
+    uint64_t r = i;
+    while (r > 0 && (keys[r - 1] & lm) == low) r--;                             // start of the run
+    bool first = true;
+    for (uint64_t j = r + 1; j < i; j++) if (keys[j] != keys[j - 1]) { first = false; break; }
+    if (first) list[t] = (uint32_t) i | 0x80000000u;
+}
+
+__global__ void __launch_bounds__(64) k_pkb_fix_apply(unsigned long long *__restrict__ keys, unsigned long long *__restrict__ vals, uint64_t n, int bits,
+                                                       const uint32_t *__restrict__ list, uint32_t list_cap, const unsigned long long *__restrict__ counter) {
+    const unsigned long long lm = bits >= 64 ? ~0ull : ((1ull << bits) - 1ull);
+    const unsigned long long cnt = *counter;
+    if (cnt > list_cap) return;
+    const uint64_t t = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= cnt || !(list[t] & 0x80000000u)) return;
+    const uint64_t i = list[t] & 0x7FFFFFFFu;
+    const unsigned long long low = keys[i] & lm;                                // runs are disjoint: nobody else touches this one
+    uint64_t r = i, e = i + 1;
+    while (r > 0 && (keys[r - 1] & lm) == low) r--;
+    while (e < n && (keys[e] & lm) == low) e++;
+    pkb_sort_run(keys, vals, r, e);
+}
+
 __global__ void __launch_bounds__(256) k_pkb_fix_runs(unsigned long long *__restrict__ keys, unsigned long long *__restrict__ vals, uint64_t n, int bits) {
     const unsigned long long lm = bits >= 64 ? ~0ull : ((1ull << bits) - 1ull);
     for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) {
@@ -263,28 +347,29 @@ __global__ void __launch_bounds__(256) k_pkb_fix_runs(unsigned long long *__rest
         uint64_t e = i + 1;
         bool mixed = false;
         while (e < n) { const unsigned long long k = keys[e]; if ((k & lm) != (k0 & lm)) break; mixed |= k != k0; e++; }
-        if (!mixed) continue;
-        for (uint64_t a = i + 1; a < e; a++) {                                  // insertion sort of the run by the full hash
-            const unsigned long long k = keys[a], v = vals[a];
-            uint64_t b = a;
-            while (b > i && keys[b - 1] > k) { keys[b] = keys[b - 1]; vals[b] = vals[b - 1]; b--; }
-            keys[b] = k; vals[b] = v;
-        }
+        if (mixed) pkb_sort_run(keys, vals, i, e);
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// k_pkb_groups: one thread per group of equal hash.
+// The pairwise join inside a group of equal hash.
 //   createAlignmentsForKmers (PairwiseKmerBranch.cpp:16-97): entries ordered by (indInRead desc, read length asc, id asc);
-//   i from the last-but-one down to the first is the "from" k-mer, j > i the "to" k-mers; offset = ind_i - ind_j.
-//   branchMarkers rows are 64-bit masks kept in marks[] (one word per entry); groups larger than 64 use rows of
-//   ceil(D/64) words carved from big_marks.
-//   The groups are handed out in order of their size (heads sorted by D): the lanes of a wave then run loops of the same length --
-//   in entry order nearly every wave held one group of 8+ entries and 60 of two, and waited for it.
-//   New edges are written as keys to add_keys at [2 * group_start ...) (capacity 2 * D per group, their count to n_add[t]); the
-//   rare overflow goes through an atomic cursor behind the dense part.
+//   i from the last-but-one down to the first is the "from" k-mer, j > i the "to" k-mers; offset = ind_i - ind_j; a pair is skipped
+//   when j is already reachable from i inside the group (branchMarkers: one bit row per entry), tested with canAlign when the
+//   graph has no edge of at most that offset yet.
+// Groups are handed out in DESCENDING size (heads sorted by 255 - min(D, 255)): the long groups start first and the lanes of a wave
+// replay groups of the same size.  Three kernels share the list:
+//   k_pkb_groups_serial  D > 64, or a read twice in the group, or rows too long to stage: one thread, everything in global memory
+//   k_pkb_groups_wave    8 <= D <= 64: one wave per group, lane j = entry j, rows staged in LDS once; for each i all j at once
+//                        (offset look-up + canAlign speculatively), then the reference's j loop replayed on ballot masks
+//   k_pkb_groups_small   2 <= D <= 7: one thread per group, entries and marker rows in LDS / a register, rows staged per pair
+// New edges are written as keys to add_keys at [2 * group_start ...) (capacity 2 * D per group, their count to n_add[t]); the
+// rare overflow goes through an atomic cursor behind the dense part.
 // ------------------------------------------------------------------------------------------
 struct PkbGraph { const uint32_t *rowptr; const unsigned long long *keys; };   // snapshot of the round's start
+constexpr int PKB_SMALL_MAX = 7;
+constexpr int PKB_WAVE_MAX = 64;
+constexpr int PKB_SNAP_KEYS = 6;
 
 __device__ __forceinline__ int snapshot_offset(const PkbGraph &g, int a, int b) {
     uint32_t lo = g.rowptr[a], hi = g.rowptr[a + 1];
@@ -298,56 +383,99 @@ __device__ __forceinline__ int snapshot_offset(const PkbGraph &g, int a, int b) 
     return PKB_INF;
 }
 
+// one row of a node into LDS: PKB_ROW_WORDS words + a zero word behind them
+__device__ __forceinline__ void pkb_stage_row(const NodesDev &nd, int id, uint32_t *dst) {
+    const uint32_t *src = nd.words + (size_t) id * nd.stride;
+    if ((nd.stride & 3) == 0) {
+#pragma unroll
+        for (int q = 0; q < PKB_ROW_WORDS / 4; q++) {
+            uint4 x = make_uint4(0u, 0u, 0u, 0u);
+            if (4 * q < nd.stride) x = *reinterpret_cast<const uint4 *>(src + 4 * q);
+            dst[4 * q] = x.x; dst[4 * q + 1] = x.y; dst[4 * q + 2] = x.z; dst[4 * q + 3] = x.w;
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < PKB_ROW_WORDS; q++) dst[q] = q < nd.stride ? src[q] : 0u;
+    }
+    dst[PKB_ROW_WORDS] = 0u;
+}
+
+// canAlign (see can_align above) on staged rows; l1, l2 <= 16 * PKB_ROW_WORDS.  Every block the loop reads lies inside both reads
+// (32 k < 2 ov <= 2 min(l1 - off, l2)), words past a read's end are zero or masked.
+__device__ __forceinline__ bool can_align_rows(const uint32_t *a, const uint32_t *b, int l1, int l2, int off, const PkbCfg &c) {
+    if (100 * off > c.max_offset_pct * l1) return false;
+    if (off < 0) return false;
+    const int ov = (l1 < l2 + off ? l1 : l2 + off) - off;
+    if (ov < c.min_overlap_area) return false;
+    if (l2 + off - l1 < 0) return false;
+    const int bit = 2 * off, q = bit >> 5, r = bit & 31;
+    const int nbits = 2 * ov;
+    const int t0 = 2 * (ov - c.same_ends);
+    int total = 0, head = 0, tail = 0;
+    const int nblk = (nbits + 31) >> 5;
+    for (int k = 0; k < nblk; k++) {
+        uint32_t x = pkb_funnel(a[q + k], a[q + k + 1], r) ^ b[k];
+        const int rem = nbits - 32 * k;
+        const uint32_t vmask = rem >= 32 ? 0xFFFFFFFFu : ((1u << rem) - 1u);
+        x &= vmask;
+        total += __popc(x);
+        if (k == 0) head = __popc(x & ((2u << (2 * c.same_ends)) - 1u));
+        const int lo_t = t0 - 32 * k;
+        if (lo_t < 32) tail += __popc(lo_t <= 0 ? x : (x & ~((1u << lo_t) - 1u)));
+    }
+    if (head != 0 || tail != 0) return false;
+    const int seq = (nbits - total) >> 1;
+    return 100 * seq >= c.min_identity_pct * ov;
+}
+
+// thread per entry: which entries head a group of >= 2 and how long it is.  The number of such groups is the total of the flag scan,
+// the largest size is the first key of the sorted head list; the only atomics are the rare ones (groups of more than 64: *max_d
+// is exact for those)
 __global__ void __launch_bounds__(256) k_pkb_group_sizes(const unsigned long long *__restrict__ keys, uint64_t n,
                                                           unsigned long long *__restrict__ big_words /* total words for groups > 64 */,
-                                                          unsigned long long *__restrict__ stats /* [0] groups >= 2, [1] max D */,
+                                                          unsigned long long *__restrict__ max_d,
                                                           uint32_t *__restrict__ head_flag /* 1 = entry heads a group of >= 2 */,
                                                           uint32_t *__restrict__ gsize /* at such an entry: min(D, 255) */) {
-    // per-thread tallies, one atomic per workgroup at the end (a contended atomic per group cost 0.8 ms per round)
-    unsigned long long n2 = 0, mx = 0, big = 0;
-    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) {
-        if (i > 0 && keys[i] == keys[i - 1]) { head_flag[i] = 0u; continue; }
-        uint64_t e = i + 1;
-        while (e < n && keys[e] == keys[i]) e++;
+    const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long k = keys[i];
+    uint32_t flag = 0;
+    if ((i == 0 || keys[i - 1] != k) && i + 1 < n && keys[i + 1] == k) {
+        uint64_t e = i + 2;
+        while (e < n && keys[e] == k) e++;
         const uint64_t D = e - i;
-        head_flag[i] = D >= 2 ? 1u : 0u;
+        flag = 1u;
         gsize[i] = (uint32_t) (D < 255 ? D : 255);
-        n2 += D >= 2;
-        mx = D > mx ? D : mx;
-        if (D > 64) big += D * ((D + 63) / 64);
+        if (D > 64) { atomicAdd(big_words, (unsigned long long) (D * ((D + 63) / 64))); atomicMax(max_d, (unsigned long long) D); }   // rare
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        n2 += __shfl_xor(n2, o);
-        big += __shfl_xor(big, o);
-        const unsigned long long t = __shfl_xor(mx, o);
-        mx = t > mx ? t : mx;
-    }
-    __shared__ unsigned long long s_n2[4], s_mx[4], s_big[4];
-    const int wv = (int) (threadIdx.x >> 6);
-    if ((threadIdx.x & 63u) == 0) { s_n2[wv] = n2; s_mx[wv] = mx; s_big[wv] = big; }
-    __syncthreads();
-    if (threadIdx.x == 0) {                      // same-address atomics retire at ~88 per microsecond chip-wide: one set per workgroup
-        for (int k = 1; k < 4; k++) { n2 += s_n2[k]; big += s_big[k]; mx = s_mx[k] > mx ? s_mx[k] : mx; }
-        if (n2) atomicAdd(&stats[0], n2);
-        if (mx) atomicMax(&stats[1], mx);
-        if (big) atomicAdd(big_words, big);
-    }
+    head_flag[i] = flag;
 }
 
-// dense list of the entries that head a group of >= 2 (flags from k_pkb_group_sizes, positions from their scan) + their sizes as sort keys
+// dense list of the entries that head a group of >= 2 (flags from k_pkb_group_sizes, positions from their scan) + sort keys that
+// put the longest groups first
 __global__ void __launch_bounds__(256) k_pkb_head_list(const uint32_t *__restrict__ head_flag, const uint32_t *__restrict__ pos, const uint32_t *__restrict__ gsize,
-                                                        uint64_t n, uint32_t *__restrict__ heads, uint32_t *__restrict__ hsize) {
+                                                        uint64_t n, uint32_t *__restrict__ heads, uint32_t *__restrict__ hkey) {
     for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x)
-        if (head_flag[i]) { heads[pos[i]] = (uint32_t) i; hsize[pos[i]] = gsize[i]; }
+        if (head_flag[i]) { heads[pos[i]] = (uint32_t) i; hkey[pos[i]] = 255u - gsize[i]; }
 }
 
-// one group; returns the number of canAlign calls, *n_added = additions kept in the dense slots
-__device__ __forceinline__ unsigned long long pkb_group(const NodesDev &nd, const PkbCfg &c, const PkbGraph &g, const unsigned long long *__restrict__ keys,
-                                                       unsigned long long *__restrict__ vals, uint64_t n, uint64_t gs, int D, unsigned long long *__restrict__ marks,
-                                                       unsigned long long *__restrict__ big_marks, unsigned long long *__restrict__ big_cursor,
-                                                       unsigned long long *__restrict__ add_keys, uint64_t add_dense, uint64_t add_cap,
-                                                       unsigned long long *__restrict__ add_overflow, uint32_t *n_added) {
+struct PkbAdd {                                                             // where a round's additions go
+    unsigned long long *keys; uint64_t dense, cap; unsigned long long *overflow;
+};
+
+__device__ __forceinline__ void pkb_add_edge(const PkbAdd &ad, unsigned long long *mine, int slot, int cap2d, unsigned long long ne) {
+    if (slot < cap2d) mine[slot] = ne;
+    else {
+        const unsigned long long k = atomicAdd(ad.overflow, 1ull);
+        if (ad.dense + k < ad.cap) ad.keys[ad.dense + k] = ne;
+    }
+}
+
+// one group, one thread, global memory only; returns the number of canAlign calls, *n_added = additions kept in the dense slots
+__device__ __forceinline__ unsigned long long pkb_group_serial(const NodesDev &nd, const PkbCfg &c, const PkbGraph &g, const unsigned long long *__restrict__ keys,
+                                                              unsigned long long *__restrict__ vals, uint64_t n, uint64_t gs, int D, unsigned long long *__restrict__ marks,
+                                                              unsigned long long *__restrict__ big_marks, unsigned long long *__restrict__ big_cursor,
+                                                              const PkbAdd &ad, uint32_t *n_added) {
     if (D >= 255) {                                                          // the size key saturates: count
         uint64_t ge = gs + 1;
         while (ge < n && keys[ge] == keys[gs]) ge++;
@@ -368,7 +496,7 @@ __device__ __forceinline__ unsigned long long pkb_group(const NodesDev &nd, cons
     if (D <= 64) rows = marks + gs;
     else rows = big_marks + atomicAdd(big_cursor, (unsigned long long) ((uint64_t) D * RW));
     for (int i = 0; i < D * RW; i++) rows[i] = 0ull;
-    unsigned long long *mine = add_keys + 2 * gs;                            // dense slots of this group: 2 * D
+    unsigned long long *mine = ad.keys + 2 * gs;                             // dense slots of this group: 2 * D
     int n_add = 0;
     unsigned long long calls = 0;
     for (int i = D - 2; i >= 0; i--) {
@@ -396,12 +524,7 @@ __device__ __forceinline__ unsigned long long pkb_group(const NodesDev &nd, cons
             if (cur > off) {
                 calls++;
                 if (can_align(nd, id1, id2, off, c)) {                       // :66
-                    const unsigned long long ne = pkb_edge_key(id1, id2, off);
-                    if (n_add < 2 * D) mine[n_add] = ne;
-                    else {
-                        const unsigned long long k = atomicAdd(add_overflow, 1ull);
-                        if (add_dense + k < add_cap) add_keys[add_dense + k] = ne;
-                    }
+                    pkb_add_edge(ad, mine, n_add, 2 * D, pkb_edge_key(id1, id2, off));
                     n_add++;
                     cur = off;
                 }
@@ -417,23 +540,183 @@ __device__ __forceinline__ unsigned long long pkb_group(const NodesDev &nd, cons
     return calls;
 }
 
-__global__ void __launch_bounds__(64) k_pkb_groups(NodesDev nd, PkbCfg c, PkbGraph g, const unsigned long long *__restrict__ keys,
-                                                    const uint32_t *__restrict__ heads, const uint32_t *__restrict__ hsize, uint32_t n_heads,
-                                                    unsigned long long *__restrict__ vals, uint64_t n, unsigned long long *__restrict__ marks,
-                                                    unsigned long long *__restrict__ big_marks, unsigned long long *__restrict__ big_cursor,
-                                                    unsigned long long *__restrict__ add_keys, uint64_t add_dense, uint64_t add_cap,
-                                                    unsigned long long *__restrict__ add_overflow, unsigned long long *__restrict__ counters,
-                                                    uint32_t *__restrict__ n_add) {
+// The groups the other two kernels leave: the front of the list (D > 64), any group whose flag[t] they set (a read twice in the
+// group), or all of them (`all`: rows too long to stage)
+__global__ void __launch_bounds__(64) k_pkb_groups_serial(NodesDev nd, PkbCfg c, PkbGraph g, const unsigned long long *__restrict__ keys,
+                                                           const uint32_t *__restrict__ heads, const uint32_t *__restrict__ hkey, uint32_t n_heads, int all,
+                                                           const uint32_t *__restrict__ left /* per group: 1 = left for this kernel */,
+                                                           unsigned long long *__restrict__ vals, uint64_t n, unsigned long long *__restrict__ marks,
+                                                           unsigned long long *__restrict__ big_marks, unsigned long long *__restrict__ big_cursor, PkbAdd ad,
+                                                           unsigned long long *__restrict__ counters, uint32_t *__restrict__ n_add) {
     unsigned long long calls = 0;
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t < n_heads) {
-        uint32_t na = 0;
-        calls = pkb_group(nd, c, g, keys, vals, n, (uint64_t) heads[t], (int) hsize[t], marks, big_marks, big_cursor, add_keys, add_dense, add_cap, add_overflow, &na);
-        n_add[t] = na;
+        const int D = 255 - (int) hkey[t];
+        if (all || D > PKB_WAVE_MAX || left[t]) {
+            uint32_t na = 0;
+            calls = pkb_group_serial(nd, c, g, keys, vals, n, (uint64_t) heads[t], D, marks, big_marks, big_cursor, ad, &na);
+            n_add[t] = na;
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) calls += __shfl_xor(calls, o);          // one counter update per wave
     if ((threadIdx.x & 63u) == 0 && calls) atomicAdd(&counters[0], calls);
+}
+
+// 8 <= D <= 64: one wave per group.  The list is in descending size: a wave stops at the first group that is too small.
+__global__ void __launch_bounds__(64) k_pkb_groups_wave(NodesDev nd, PkbCfg c, PkbGraph g, const uint32_t *__restrict__ heads, const uint32_t *__restrict__ hkey,
+                                                         uint32_t n_heads, const unsigned long long *__restrict__ vals, PkbAdd ad,
+                                                         unsigned long long *__restrict__ counters, uint32_t *__restrict__ n_add, uint32_t *__restrict__ left) {
+    __shared__ uint32_t srow[64][PKB_ROW_WORDS + 1];
+    __shared__ unsigned long long sv[64], srows[64];
+    __shared__ uint32_t sr0[64], sr1[64];                                    // snapshot row of entry i: [sr0, sr1) ...
+    __shared__ unsigned long long sk[64][PKB_SNAP_KEYS + 1];                 // ... and its first keys (all of them, usually)
+    const int lane = (int) threadIdx.x;
+    unsigned long long calls = 0;
+    for (uint32_t t = blockIdx.x; t < n_heads; t += gridDim.x) {
+        const int D = 255 - (int) hkey[t];
+        if (D <= PKB_SMALL_MAX) break;
+        if (D > PKB_WAVE_MAX) continue;                                      // k_pkb_groups_serial
+        const uint64_t gs = heads[t];
+        __syncthreads();                                                     // the previous group's LDS is no longer read
+        // order the group: ascending val (vals are distinct: a read yields one k-mer per start position)
+        const unsigned long long mv = lane < D ? vals[gs + lane] : ~0ull;
+        sv[lane] = mv;
+        __syncthreads();
+        int rank = 0;
+        for (int k = 0; k < D; k++) rank += sv[k] < mv;
+        __syncthreads();
+        if (lane < D) sv[rank] = mv;
+        srows[lane] = 0ull;
+        __syncthreads();
+        const unsigned long long vj = lane < D ? sv[lane] : 0ull;
+        const int idj = pkb_val_id(vj), indj = pkb_val_ind(vj), lenj = pkb_val_len(vj);
+        bool twice = false;
+        for (int k = 0; k < D; k++) twice |= (lane < D && k != lane && pkb_val_id(sv[k]) == idj);
+        if (__ballot(twice) != 0ull) {                                       // a read twice in the group: the serial kernel replays it
+            if (lane == 0) { left[t] = 1u; n_add[t] = 0u; }
+            continue;
+        }
+        if (lane < D) {
+            pkb_stage_row(nd, idj, srow[lane]);
+            const uint32_t r0 = g.rowptr[idj], r1 = g.rowptr[idj + 1];
+            sr0[lane] = r0; sr1[lane] = r1;
+#pragma unroll
+            for (int q = 0; q < PKB_SNAP_KEYS; q++) if (r0 + q < r1) sk[lane][q] = g.keys[r0 + q];
+        }
+        __syncthreads();
+        unsigned long long *mine = ad.keys + 2 * gs;
+        int n_added = 0;
+        for (int i = D - 2; i >= 0; i--) {
+            const unsigned long long vi = sv[i];
+            const int id1 = pkb_val_id(vi), ind1 = pkb_val_ind(vi), len1 = pkb_val_len(vi);
+            const int off = ind1 - indj;
+            bool elig = lane > i && lane < D && id1 != idj && off >= 0 && !(100 * off > c.max_offset_pct * len1);
+            if (elig) {
+                const int ov = (len1 < lenj + off ? len1 : lenj + off) - off;
+                elig = ov >= c.min_overlap_area && lenj + off - len1 >= 0;
+            }
+            int snap = PKB_INF;
+            if (elig) {
+                const uint32_t r0 = sr0[i], r1 = sr1[i];
+                if (r1 - r0 <= (uint32_t) PKB_SNAP_KEYS) {                       // the row is in LDS
+                    for (uint32_t q = 0; q < r1 - r0; q++) { const unsigned long long k = sk[i][q]; if (pkb_key_dst(k) == idj) snap = pkb_key_off(k); }
+                } else snap = snapshot_offset(g, id1, idj);
+            }
+            const bool call = elig && snap > off;
+            const bool ok = call && can_align_rows(srow[i], srow[lane], len1, lenj, off, c);
+            const unsigned long long Em = __ballot(elig), Sm = __ballot(snap != PKB_INF), Cm = __ballot(call), Am = __ballot(ok);
+            // the j loop of the reference on the masks (the same in every lane)
+            unsigned long long row = 0ull, addm = 0ull;
+            for (unsigned long long m = Em; m; m &= m - 1ull) {
+                const int j = __builtin_ctzll(m);
+                if ((row >> j) & 1ull) continue;                             // already reachable inside the group (:62)
+                bool reach = true;                                           // an edge of at most this offset exists
+                if ((Cm >> j) & 1ull) {
+                    calls++;
+                    if ((Am >> j) & 1ull) addm |= 1ull << j;
+                    else reach = (Sm >> j) & 1ull;
+                }
+                if (reach) row |= (1ull << j) | srows[j];
+            }
+            if ((addm >> lane) & 1ull)
+                pkb_add_edge(ad, mine, n_added + __popcll(addm & ((1ull << lane) - 1ull)), 2 * D, pkb_edge_key(id1, idj, off));
+            n_added += __popcll(addm);
+            __syncthreads();
+            if (lane == 0) srows[i] = row;
+            __syncthreads();
+        }
+        if (lane == 0) { n_add[t] = (uint32_t) (n_added < 2 * D ? n_added : 2 * D); left[t] = 0u; }
+    }
+    if (lane == 0 && calls) atomicAdd(&counters[0], calls);                  // every lane counted the same calls
+}
+
+// 2 <= D <= 7: one thread per group; the entries in LDS, the marker rows in one register (8 bits per row), rows staged per pair
+__global__ void __launch_bounds__(64) k_pkb_groups_small(NodesDev nd, PkbCfg c, PkbGraph g, const uint32_t *__restrict__ heads, const uint32_t *__restrict__ hkey,
+                                                          uint32_t n_heads, const unsigned long long *__restrict__ vals, PkbAdd ad,
+                                                          unsigned long long *__restrict__ counters, uint32_t *__restrict__ n_add, uint32_t *__restrict__ left) {
+    __shared__ uint32_t srow[64][2 * PKB_ROW_WORDS + 3];                     // a | 0 | b | 0 (+1: odd stride, conflict-free)
+    __shared__ unsigned long long sv[PKB_SMALL_MAX][64];
+    const int lane = (int) threadIdx.x;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long calls = 0;
+    const int D = t < n_heads ? 255 - (int) hkey[t] : 0;
+    if (D >= 2 && D <= PKB_SMALL_MAX) {
+        const uint64_t gs = heads[t];
+#pragma unroll
+        for (int k = 0; k < PKB_SMALL_MAX; k++) if (k < D) sv[k][lane] = vals[gs + k];
+        for (int i = 1; i < D; i++) {                                        // order the group: ascending val
+            const unsigned long long x = sv[i][lane];
+            int j = i;
+            while (j > 0 && sv[j - 1][lane] > x) { sv[j][lane] = sv[j - 1][lane]; j--; }
+            sv[j][lane] = x;
+        }
+        bool dup = false;
+        for (int i = 0; i < D; i++) for (int j = i + 1; j < D; j++) dup |= pkb_val_id(sv[i][lane]) == pkb_val_id(sv[j][lane]);
+        if (dup) { left[t] = 1u; n_add[t] = 0u; }
+        else {
+            uint32_t *ra = srow[lane], *rb = srow[lane] + PKB_ROW_WORDS + 1;
+            unsigned long long *mine = ad.keys + 2 * gs;
+            unsigned long long rows = 0ull;                                  // row i = bits 8 i .. 8 i + 7
+            int n_added = 0;
+            for (int i = D - 2; i >= 0; i--) {
+                const unsigned long long vi = sv[i][lane];
+                const int id1 = pkb_val_id(vi), ind1 = pkb_val_ind(vi), len1 = pkb_val_len(vi);
+                bool staged = false;
+                uint32_t row_i = 0u;
+                for (int j = i + 1; j < D; j++) {
+                    const unsigned long long vj = sv[j][lane];
+                    const int id2 = pkb_val_id(vj);
+                    const int off = ind1 - pkb_val_ind(vj);
+                    if (off < 0) continue;
+                    if (100 * off > c.max_offset_pct * len1) break;          // :55
+                    const int len2 = pkb_val_len(vj);
+                    const int ov = (len1 < len2 + off ? len1 : len2 + off) - off;
+                    if (ov < c.min_overlap_area) continue;
+                    if (len2 + off - len1 < 0) continue;
+                    if ((row_i >> j) & 1u) continue;                         // already reachable inside the group (:62)
+                    int cur = snapshot_offset(g, id1, id2);                  // neighbors[id2]
+                    if (cur > off) {
+                        calls++;
+                        if (!staged) { pkb_stage_row(nd, id1, ra); staged = true; }
+                        pkb_stage_row(nd, id2, rb);
+                        if (can_align_rows(ra, rb, len1, len2, off, c)) {    // :66
+                            pkb_add_edge(ad, mine, n_added, 2 * D, pkb_edge_key(id1, id2, off));
+                            n_added++;
+                            cur = off;
+                        }
+                    }
+                    if (cur != PKB_INF) row_i |= (1u << j) | (uint32_t) ((rows >> (8 * j)) & 0xFFull);      // :73-77
+                }
+                rows |= (unsigned long long) row_i << (8 * i);
+            }
+            n_add[t] = (uint32_t) (n_added < 2 * D ? n_added : 2 * D);
+            left[t] = 0u;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) calls += __shfl_xor(calls, o);          // one counter update per wave
+    if (lane == 0 && calls) atomicAdd(&counters[0], calls);
 }
 
 // the additions of a round as one dense key list: group t's n_add[t] dense slots at pos[t], the overflow entries behind them
@@ -496,36 +779,57 @@ void launch_pkb_tip_list(const NodesDev &nd, const PkbCfg &c, const uint32_t *fl
     hipLaunchKernelGGL(k_pkb_tip_list, dim3((nd.n + 255) / 256), dim3(256), 0, s, nd, c, flag, pos, tips, kcount, max_len);
 }
 
-void launch_pkb_kmers(const NodesDev &nd, const PkbCfg &c, const int32_t prio[4], const uint32_t *tips, const uint32_t *koff, uint32_t n_tips,
+void launch_pkb_kmers(const NodesDev &nd, const PkbCfg &c, const int32_t prio[4], const uint32_t *tips, const uint32_t *koff, uint32_t n_tips, int sort_bits,
                       unsigned long long *keys, unsigned long long *vals, hipStream_t s) {
     if (n_tips == 0) return;
-    hipLaunchKernelGGL(k_pkb_kmers, dim3((n_tips + 255) / 256), dim3(256), 0, s, nd, c, make_int4(prio[0], prio[1], prio[2], prio[3]), tips, koff, n_tips, keys, vals);
+    const int4 pr = make_int4(prio[0], prio[1], prio[2], prio[3]);
+    if (nd.stride <= PKB_ROW_WORDS) hipLaunchKernelGGL(k_pkb_kmers<true>, dim3((n_tips + 255) / 256), dim3(256), 0, s, nd, c, pr, tips, koff, n_tips, sort_bits, keys, vals);
+    else hipLaunchKernelGGL(k_pkb_kmers<false>, dim3((n_tips + 255) / 256), dim3(256), 0, s, nd, c, pr, tips, koff, n_tips, sort_bits, keys, vals);
 }
 
-void launch_pkb_fix_runs(unsigned long long *keys, unsigned long long *vals, uint64_t n, int bits, hipStream_t s) {
+// counter: zeroed by the caller; after the call *counter > list_cap means "run launch_pkb_fix_runs_loop"
+void launch_pkb_fix_runs(unsigned long long *keys, unsigned long long *vals, uint64_t n, int bits, uint32_t *list, uint32_t list_cap, unsigned long long *counter,
+                         hipStream_t s) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_pkb_fix_flag, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, s, (const unsigned long long *) keys, n, bits, list, list_cap, counter);
+    hipLaunchKernelGGL(k_pkb_fix_owner, dim3((list_cap + 63) / 64), dim3(64), 0, s, (const unsigned long long *) keys, bits, list, list_cap, (const unsigned long long *) counter);
+    hipLaunchKernelGGL(k_pkb_fix_apply, dim3((list_cap + 63) / 64), dim3(64), 0, s, keys, vals, n, bits, (const uint32_t *) list, list_cap, (const unsigned long long *) counter);
+}
+
+void launch_pkb_fix_runs_loop(unsigned long long *keys, unsigned long long *vals, uint64_t n, int bits, hipStream_t s) {
     if (n == 0) return;
     hipLaunchKernelGGL(k_pkb_fix_runs, dim3(pkb_grid(n, 256, 16384)), dim3(256), 0, s, keys, vals, n, bits);
 }
 
-void launch_pkb_group_sizes(const unsigned long long *keys, uint64_t n, unsigned long long *big_words, unsigned long long *stats, uint32_t *head_flag,
+void launch_pkb_group_sizes(const unsigned long long *keys, uint64_t n, unsigned long long *big_words, unsigned long long *max_d, uint32_t *head_flag,
                             uint32_t *gsize, hipStream_t s) {
     if (n == 0) return;
-    hipLaunchKernelGGL(k_pkb_group_sizes, dim3(pkb_grid(n, 256 * 8, 1024)), dim3(256), 0, s, keys, n, big_words, stats, head_flag, gsize);
+    hipLaunchKernelGGL(k_pkb_group_sizes, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, s, keys, n, big_words, max_d, head_flag, gsize);
 }
 
-void launch_pkb_head_list(const uint32_t *head_flag, const uint32_t *pos, const uint32_t *gsize, uint64_t n, uint32_t *heads, uint32_t *hsize, hipStream_t s) {
+void launch_pkb_head_list(const uint32_t *head_flag, const uint32_t *pos, const uint32_t *gsize, uint64_t n, uint32_t *heads, uint32_t *hkey, hipStream_t s) {
     if (n == 0) return;
-    hipLaunchKernelGGL(k_pkb_head_list, dim3(pkb_grid(n, 256, 8192)), dim3(256), 0, s, head_flag, pos, gsize, n, heads, hsize);
+    hipLaunchKernelGGL(k_pkb_head_list, dim3(pkb_grid(n, 256, 8192)), dim3(256), 0, s, head_flag, pos, gsize, n, heads, hkey);
 }
 
+// heads / hkey: the group list in descending size (hkey = 255 - min(D, 255), ascending)
 void launch_pkb_groups(const NodesDev &nd, const PkbCfg &c, const uint32_t *rowptr, const unsigned long long *gkeys, const unsigned long long *keys,
-                       const uint32_t *heads, const uint32_t *hsize, uint32_t n_heads, unsigned long long *vals, uint64_t n, unsigned long long *marks,
+                       const uint32_t *heads, const uint32_t *hkey, uint32_t n_heads, unsigned long long *vals, uint64_t n, unsigned long long *marks,
                        unsigned long long *big_marks, unsigned long long *big_cursor, unsigned long long *add_keys, uint64_t add_dense, uint64_t add_cap,
-                       unsigned long long *add_overflow, unsigned long long *counters, uint32_t *n_add, hipStream_t s) {
+                       unsigned long long *add_overflow, unsigned long long *counters, uint32_t *n_add, uint32_t *left, int n_cu, hipStream_t s) {
     if (n == 0 || n_heads == 0) return;
     PkbGraph g{rowptr, gkeys};
-    hipLaunchKernelGGL(k_pkb_groups, dim3((n_heads + 63) / 64), dim3(64), 0, s, nd, c, g, keys, heads, hsize, n_heads, vals, n, marks, big_marks, big_cursor,
-                       add_keys, add_dense, add_cap, add_overflow, counters, n_add);
+    PkbAdd ad{add_keys, add_dense, add_cap, add_overflow};
+    const unsigned blocks = (n_heads + 63) / 64;
+    const bool staged = nd.stride <= PKB_ROW_WORDS;
+    if (staged) {
+        (void) hipMemsetAsync(left, 0, (size_t) n_heads * sizeof(uint32_t), s);
+        hipLaunchKernelGGL(k_pkb_groups_wave, dim3(std::min<unsigned>(n_heads, (unsigned) std::max(1, n_cu) * 24u)), dim3(64), 0, s, nd, c, g, heads, hkey, n_heads,
+                           (const unsigned long long *) vals, ad, counters, n_add, left);
+        hipLaunchKernelGGL(k_pkb_groups_small, dim3(blocks), dim3(64), 0, s, nd, c, g, heads, hkey, n_heads, (const unsigned long long *) vals, ad, counters, n_add, left);
+    }
+    hipLaunchKernelGGL(k_pkb_groups_serial, dim3(blocks), dim3(64), 0, s, nd, c, g, keys, heads, hkey, n_heads, staged ? 0 : 1, (const uint32_t *) left, vals, n, marks,
+                       big_marks, big_cursor, ad, counters, n_add);
 }
 
 void launch_pkb_gather_adds(const uint32_t *heads, const uint32_t *n_add, const uint32_t *pos, uint32_t n_heads, const unsigned long long *add_keys,

@@ -124,6 +124,51 @@ def test_supplement_equals_oracle_with_engine_semantics(eng, n, G, seed, err):
     assert len(a ^ b) <= 0.005 * len(a)
 
 
+def _supplement_vs_oracle(eng, codes, stride_words=None):
+    rc = (3 - codes)[:, ::-1]
+    codes = np.stack([rc, codes], axis=1).reshape(-1, codes.shape[1])[:, 3:-3]
+    L = codes.shape[1]
+    lens = np.full(len(codes), L, dtype=np.int32)
+    words = alga_amd.pack_reads(codes, lens)
+    if stride_words:
+        words = np.concatenate([words, np.zeros((len(words), stride_words - words.shape[1]), np.uint32)], axis=1)
+    lo, rs = alga_amd.derive_params(float(L))
+    pre = eng.prefsuf_host(words, lens, lo, rs)
+    kb = min(2 * lo // 3, 60)
+    op = O.pkb_params(float(L), error_rate_percent=2)
+    p = eng.pkb_params(float(L), 0.02, kb)
+    want, _ = O.supplement(words, lens, pre, op, kb, flags=3)
+    got = eng.pkb_supplement_host(words, lens, pre, p)
+    assert len(want) > len(pre)
+    assert got.shape == want.shape and (got == want).all()
+    return eng.pkb_last_stats()
+
+
+def test_supplement_group_shapes(eng):
+    """the three group kernels: deep coverage (groups of 8-64 entries: one wave each; above 64: the serial kernel), a tandem-repeat
+    genome (a read twice in a group: handed to the serial kernel) and rows too long to stage in LDS (everything serial)"""
+    rng = np.random.default_rng(91)
+
+    def reads(genome, n, L, err):
+        st = rng.integers(0, len(genome) - L + 1, n)
+        c = genome[st[:, None] + np.arange(L)[None, :]].copy()
+        m = rng.random(c.shape) < err
+        c[m] = (c[m] + rng.integers(1, 4, int(m.sum()))) & 3
+        flip = rng.random(n) < 0.5
+        c[flip] = (3 - c[flip])[:, ::-1]
+        return c.astype(np.uint8)
+    g = rng.integers(0, 4, 1500, dtype=np.uint8)
+    st = _supplement_vs_oracle(eng, reads(g, 4000, 150, 0.02))                       # ~400x coverage
+    assert st["max_group"] > 64
+    unit = rng.integers(0, 4, 43, dtype=np.uint8)
+    g2 = np.concatenate([rng.integers(0, 4, 400, dtype=np.uint8), np.tile(unit, 12), rng.integers(0, 4, 400, dtype=np.uint8), np.tile(unit[::-1].copy(), 9),
+                         rng.integers(0, 4, 300, dtype=np.uint8)])
+    _supplement_vs_oracle(eng, reads(g2, 1500, 150, 0.02))
+    g3 = rng.integers(0, 4, 9000, dtype=np.uint8)
+    _supplement_vs_oracle(eng, reads(g3, 2500, 150, 0.02), stride_words=20)          # device rows of 32 words: not staged
+    _supplement_vs_oracle(eng, reads(g3, 1200, 300, 0.02))                            # 294-nt reads: 19 words
+
+
 def test_supplement_rejects_offsets_it_cannot_represent(eng):
     """the edge merge packs (src, dst, offset) into 64 bits with 9 bits of offset: an edge outside that range is an error, not a
     silently different graph"""
