@@ -108,16 +108,17 @@ __device__ __forceinline__ int li_kmers(const uint32_t *row, int len, int k, int
     const bool fast = T != nullptr && k <= 35;
     auto mh = [&](u128 v) { return fast ? mod_hash_u70(v, T) : mod_hash_u128(v); };
     if (k > len || intervals <= 0) return 0;
-    auto digit = [&](int pos) { return (u128) (uint32_t) prio[(row[pos >> 4] >> ((pos & 15) << 1)) & 3u]; };
+    const uint32_t pp = (uint32_t) prio[0] | ((uint32_t) prio[1] << 2) | ((uint32_t) prio[2] << 4) | ((uint32_t) prio[3] << 6);
+    auto digit = [&](int pos) { return (u128) ((pp >> (((row[pos >> 4] >> ((pos & 15) << 1)) & 3u) << 1)) & 3u); };
     u128 h = 0;
     for (int q = 0; q < k; q++) h = (h << 2) + digit(q);
     const u128 low_mask = (((u128) 1) << (2 * (k - 1))) - 1;                  // factor - 1, factor = 4^(k-1)
     const int il = (len - k + 1 + intervals - 1) / intervals;                 // ceil((size - length + 1) / intervals)
-    u128 best = h; int best_p = 0, cur = 0, cnt = 0;
+    u128 best = h; int best_p = 0, cnt = 0;
+    int next = il;                                                            // first start position of the next interval (p / il changes there)
     for (int p = 1; p + k <= len; p++) {
         h = ((h & low_mask) << 2) + digit(p + k - 1);                         // hash -= factor * first; hash <<= 2; hash += next
-        const int iv = p / il;
-        if (iv != cur) { hash_out[cnt] = mh(best); ind_out[cnt] = best_p; cnt++; cur = iv; best = h; best_p = p; }
+        if (p == next) { hash_out[cnt] = mh(best); ind_out[cnt] = best_p; cnt++; next += il; best = h; best_p = p; }
         else if (h < best) { best = h; best_p = p; }
     }
     hash_out[cnt] = mh(best); ind_out[cnt] = best_p; cnt++;
@@ -360,8 +361,8 @@ __global__ void __launch_bounds__(256) k_pkb_fix_runs(unsigned long long *__rest
 // Groups are handed out in DESCENDING size (heads sorted by 255 - min(D, 255)): the long groups start first and the lanes of a wave
 // replay groups of the same size.  Three kernels share the list:
 //   k_pkb_groups_serial  D > 64, or a read twice in the group, or rows too long to stage: one thread, everything in global memory
-//   k_pkb_groups_wave    8 <= D <= 64: one wave per group, lane j = entry j, rows staged in LDS once; for each i all j at once
-//                        (offset look-up + canAlign speculatively), then the reference's j loop replayed on ballot masks
+//   k_pkb_groups_wave    8 <= D <= 64: one wave per group, the group's rows staged in LDS once; all pairs at once (lane = pair:
+//                        offset look-up + canAlign speculatively), then the reference's i / j loops replayed on the ballot masks
 //   k_pkb_groups_small   2 <= D <= 7: one thread per group, entries and marker rows in LDS / a register, rows staged per pair
 // New edges are written as keys to add_keys at [2 * group_start ...) (capacity 2 * D per group, their count to n_add[t]); the
 // rare overflow goes through an atomic cursor behind the dense part.
@@ -370,6 +371,7 @@ struct PkbGraph { const uint32_t *rowptr; const unsigned long long *keys; };   /
 constexpr int PKB_SMALL_MAX = 7;
 constexpr int PKB_WAVE_MAX = 64;
 constexpr int PKB_SNAP_KEYS = 6;
+constexpr int PKB_SMALL_WG = 256;
 
 __device__ __forceinline__ int snapshot_offset(const PkbGraph &g, int a, int b) {
     uint32_t lo = g.rowptr[a], hi = g.rowptr[a + 1];
@@ -568,7 +570,7 @@ __global__ void __launch_bounds__(64) k_pkb_groups_wave(NodesDev nd, PkbCfg c, P
                                                          uint32_t n_heads, const unsigned long long *__restrict__ vals, PkbAdd ad,
                                                          unsigned long long *__restrict__ counters, uint32_t *__restrict__ n_add, uint32_t *__restrict__ left) {
     __shared__ uint32_t srow[64][PKB_ROW_WORDS + 1];
-    __shared__ unsigned long long sv[64], srows[64];
+    __shared__ unsigned long long sv[64];
     __shared__ uint32_t sr0[64], sr1[64];                                    // snapshot row of entry i: [sr0, sr1) ...
     __shared__ unsigned long long sk[64][PKB_SNAP_KEYS + 1];                 // ... and its first keys (all of them, usually)
     const int lane = (int) threadIdx.x;
@@ -587,7 +589,6 @@ __global__ void __launch_bounds__(64) k_pkb_groups_wave(NodesDev nd, PkbCfg c, P
         for (int k = 0; k < D; k++) rank += sv[k] < mv;
         __syncthreads();
         if (lane < D) sv[rank] = mv;
-        srows[lane] = 0ull;
         __syncthreads();
         const unsigned long long vj = lane < D ? sv[lane] : 0ull;
         const int idj = pkb_val_id(vj), indj = pkb_val_ind(vj), lenj = pkb_val_len(vj);
@@ -606,45 +607,70 @@ __global__ void __launch_bounds__(64) k_pkb_groups_wave(NodesDev nd, PkbCfg c, P
         }
         __syncthreads();
         unsigned long long *mine = ad.keys + 2 * gs;
-        int n_added = 0;
-        for (int i = D - 2; i >= 0; i--) {
-            const unsigned long long vi = sv[i];
+        // All pairs (i, j > i) at once, 64 per pass, lane = pair: eligibility, offset look-up and canAlign -- speculatively, the replay
+        // below decides which of them the reference would have reached.  Pair order: rows ascending, j ascending; lane r collects
+        // the bits of row r (bit j = pair (r, j)).
+        unsigned long long Em = 0ull, Sm = 0ull, Cm = 0ull, Am = 0ull;
+        const int P = D * (D - 1) / 2;
+        const int my_start = lane * (D - 1) - lane * (lane - 1) / 2, my_cnt = D - 1 - lane;
+        for (int base = 0; base < P; base += 64) {
+            const int p = base + lane;
+            int i = 0, rem = p < P ? p : 0;
+            while (rem >= D - 1 - i) { rem -= D - 1 - i; i++; }
+            const int j = i + 1 + rem;
+            const unsigned long long vi = sv[i], vj2 = sv[j];
             const int id1 = pkb_val_id(vi), ind1 = pkb_val_ind(vi), len1 = pkb_val_len(vi);
-            const int off = ind1 - indj;
-            bool elig = lane > i && lane < D && id1 != idj && off >= 0 && !(100 * off > c.max_offset_pct * len1);
+            const int id2 = pkb_val_id(vj2), len2 = pkb_val_len(vj2);
+            const int off = ind1 - pkb_val_ind(vj2);
+            bool elig = p < P && off >= 0 && !(100 * off > c.max_offset_pct * len1);     // the `break` of :55 is monotone in j: part of the mask
             if (elig) {
-                const int ov = (len1 < lenj + off ? len1 : lenj + off) - off;
-                elig = ov >= c.min_overlap_area && lenj + off - len1 >= 0;
+                const int ov = (len1 < len2 + off ? len1 : len2 + off) - off;
+                elig = ov >= c.min_overlap_area && len2 + off - len1 >= 0;
             }
             int snap = PKB_INF;
             if (elig) {
                 const uint32_t r0 = sr0[i], r1 = sr1[i];
                 if (r1 - r0 <= (uint32_t) PKB_SNAP_KEYS) {                       // the row is in LDS
-                    for (uint32_t q = 0; q < r1 - r0; q++) { const unsigned long long k = sk[i][q]; if (pkb_key_dst(k) == idj) snap = pkb_key_off(k); }
-                } else snap = snapshot_offset(g, id1, idj);
+                    for (uint32_t q = 0; q < r1 - r0; q++) { const unsigned long long k = sk[i][q]; if (pkb_key_dst(k) == id2) snap = pkb_key_off(k); }
+                } else snap = snapshot_offset(g, id1, id2);
             }
             const bool call = elig && snap > off;
-            const bool ok = call && can_align_rows(srow[i], srow[lane], len1, lenj, off, c);
-            const unsigned long long Em = __ballot(elig), Sm = __ballot(snap != PKB_INF), Cm = __ballot(call), Am = __ballot(ok);
-            // the j loop of the reference on the masks (the same in every lane)
+            const bool ok = call && can_align_rows(srow[i], srow[j], len1, len2, off, c);
+            const unsigned long long be = __ballot(elig), bs = __ballot(snap != PKB_INF), bc = __ballot(call), ba = __ballot(ok);
+            const int lo = my_start > base ? my_start : base, hi = (my_start + my_cnt) < (base + 64) ? (my_start + my_cnt) : (base + 64);
+            if (lane < D - 1 && lo < hi) {
+                const int w = hi - lo;
+                const unsigned long long m = w >= 64 ? ~0ull : ((1ull << w) - 1ull);
+                const int from = lo - base, to = lane + 1 + (lo - my_start);
+                Em |= ((be >> from) & m) << to; Sm |= ((bs >> from) & m) << to; Cm |= ((bc >> from) & m) << to; Am |= ((ba >> from) & m) << to;
+            }
+        }
+        // the i / j loops of the reference on the masks (scalar: the same in every lane); lane r keeps the marker row of entry r
+        auto lane64 = [&](unsigned long long x, int l) -> unsigned long long {
+            return ((unsigned long long) (uint32_t) __builtin_amdgcn_readlane((int) (x >> 32), l) << 32) | (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) x, l);
+        };
+        unsigned long long myrow = 0ull;
+        int n_added = 0;
+        for (int i = D - 2; i >= 0; i--) {
+            const unsigned long long e_i = lane64(Em, i), s_i = lane64(Sm, i), c_i = lane64(Cm, i), a_i = lane64(Am, i);
             unsigned long long row = 0ull, addm = 0ull;
-            for (unsigned long long m = Em; m; m &= m - 1ull) {
+            for (unsigned long long m = e_i; m; m &= m - 1ull) {
                 const int j = __builtin_ctzll(m);
                 if ((row >> j) & 1ull) continue;                             // already reachable inside the group (:62)
                 bool reach = true;                                           // an edge of at most this offset exists
-                if ((Cm >> j) & 1ull) {
+                if ((c_i >> j) & 1ull) {
                     calls++;
-                    if ((Am >> j) & 1ull) addm |= 1ull << j;
-                    else reach = (Sm >> j) & 1ull;
+                    if ((a_i >> j) & 1ull) addm |= 1ull << j;
+                    else reach = (s_i >> j) & 1ull;
                 }
-                if (reach) row |= (1ull << j) | srows[j];
+                if (reach) row |= (1ull << j) | lane64(myrow, j);
             }
-            if ((addm >> lane) & 1ull)
-                pkb_add_edge(ad, mine, n_added + __popcll(addm & ((1ull << lane) - 1ull)), 2 * D, pkb_edge_key(id1, idj, off));
+            if (lane == i) myrow = row;
+            if ((addm >> lane) & 1ull) {
+                const unsigned long long vi = sv[i];
+                pkb_add_edge(ad, mine, n_added + __popcll(addm & ((1ull << lane) - 1ull)), 2 * D, pkb_edge_key(pkb_val_id(vi), idj, pkb_val_ind(vi) - indj));
+            }
             n_added += __popcll(addm);
-            __syncthreads();
-            if (lane == 0) srows[i] = row;
-            __syncthreads();
         }
         if (lane == 0) { n_add[t] = (uint32_t) (n_added < 2 * D ? n_added : 2 * D); left[t] = 0u; }
     }
@@ -652,12 +678,12 @@ __global__ void __launch_bounds__(64) k_pkb_groups_wave(NodesDev nd, PkbCfg c, P
 }
 
 // 2 <= D <= 7: one thread per group; the entries in LDS, the marker rows in one register (8 bits per row), rows staged per pair
-__global__ void __launch_bounds__(64) k_pkb_groups_small(NodesDev nd, PkbCfg c, PkbGraph g, const uint32_t *__restrict__ heads, const uint32_t *__restrict__ hkey,
+__global__ void __launch_bounds__(PKB_SMALL_WG) k_pkb_groups_small(NodesDev nd, PkbCfg c, PkbGraph g, const uint32_t *__restrict__ heads, const uint32_t *__restrict__ hkey,
                                                           uint32_t n_heads, const unsigned long long *__restrict__ vals, PkbAdd ad,
                                                           unsigned long long *__restrict__ counters, uint32_t *__restrict__ n_add, uint32_t *__restrict__ left) {
-    __shared__ uint32_t srow[64][2 * PKB_ROW_WORDS + 3];                     // a | 0 | b | 0 (+1: odd stride, conflict-free)
-    __shared__ unsigned long long sv[PKB_SMALL_MAX][64];
-    const int lane = (int) threadIdx.x;
+    __shared__ uint32_t srow[PKB_SMALL_WG][2 * PKB_ROW_WORDS + 3];           // a | 0 | b | 0 (+1: odd stride, conflict-free)
+    __shared__ unsigned long long sv[PKB_SMALL_MAX][PKB_SMALL_WG];
+    const int lane = (int) threadIdx.x;                                      // slot in the workgroup's LDS arrays
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long calls = 0;
     const int D = t < n_heads ? 255 - (int) hkey[t] : 0;
@@ -716,7 +742,7 @@ __global__ void __launch_bounds__(64) k_pkb_groups_small(NodesDev nd, PkbCfg c, 
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) calls += __shfl_xor(calls, o);          // one counter update per wave
-    if (lane == 0 && calls) atomicAdd(&counters[0], calls);
+    if ((lane & 63) == 0 && calls) atomicAdd(&counters[0], calls);
 }
 
 // the additions of a round as one dense key list: group t's n_add[t] dense slots at pos[t], the overflow entries behind them
@@ -826,7 +852,7 @@ void launch_pkb_groups(const NodesDev &nd, const PkbCfg &c, const uint32_t *rowp
         (void) hipMemsetAsync(left, 0, (size_t) n_heads * sizeof(uint32_t), s);
         hipLaunchKernelGGL(k_pkb_groups_wave, dim3(std::min<unsigned>(n_heads, (unsigned) std::max(1, n_cu) * 24u)), dim3(64), 0, s, nd, c, g, heads, hkey, n_heads,
                            (const unsigned long long *) vals, ad, counters, n_add, left);
-        hipLaunchKernelGGL(k_pkb_groups_small, dim3(blocks), dim3(64), 0, s, nd, c, g, heads, hkey, n_heads, (const unsigned long long *) vals, ad, counters, n_add, left);
+        hipLaunchKernelGGL(k_pkb_groups_small, dim3((n_heads + PKB_SMALL_WG - 1) / PKB_SMALL_WG), dim3(PKB_SMALL_WG), 0, s, nd, c, g, heads, hkey, n_heads, (const unsigned long long *) vals, ad, counters, n_add, left);
     }
     hipLaunchKernelGGL(k_pkb_groups_serial, dim3(blocks), dim3(64), 0, s, nd, c, g, keys, heads, hkey, n_heads, staged ? 0 : 1, (const uint32_t *) left, vals, n, marks,
                        big_marks, big_cursor, ad, counters, n_add);
