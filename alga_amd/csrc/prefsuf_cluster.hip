@@ -13,14 +13,16 @@
 //     through one minimizer are CONTIGUOUS in HBM (one genomic locus: ~6 entries at 30x coverage), found through a
 //     direct-address index on the top bits of the hash;
 //   * a source has ~2 * 63 / (w + 1) + 1 = 3 distinct window minimizers instead of 63 windows to look up: three index
-//     reads and three contiguous runs of entries, ONE LANE PER ENTRY (up to 64 entries per round): hash / offset / length
-//     checks from the entry's own words, exact 2-bit compare of the entry's row against the source's staged tail,
-//     verified overlaps become the items of the source-side transitive reduction (prefsuf_device.h local_reduce).
+//     reads and three contiguous runs of entries, ONE LANE PER ENTRY: hash / offset / length checks from the entry's own
+//     words, exact 2-bit compare of the entry's row against the source's staged tail, verified overlaps become the items
+//     of the source-side transitive reduction (prefsuf_device.h local_reduce).
 //
-//   k_tgt_keys      prefix minimizer of every target -> sort key (hash), meta word
-//   (radix sort by hash: rocPRIM)
-//   k_tgt_gather    rows in hash order -> entry array;   k_tgt_index   first entry of every hash bucket
-//   k_probe_clustered   persistent wavefronts, one source at a time (sliding-window minimum by doubling over ds_bpermute)
+//   k_node_runs        one thread per node: the runs of equal window minimizer {cluster key, k-mer position, windows [p0, p1)}
+//                      of the node as a SOURCE, and the key / meta word it is filed under as a TARGET (run 0)
+//   (radix sort of (key, id): rocPRIM)
+//   k_tgt_gather       rows in key order -> entry array;   k_tgt_index   first entry of every key bucket
+//   k_probe_pairs      two sources per wave (32 lanes each): finishes the regular sources, lists the others
+//   k_probe_clustered  one source per wave, any shape: the listed sources (or all of them)
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include "prefsuf_common.h"
@@ -78,7 +80,7 @@ constexpr int NR_STACK = 12;         // prefix-minimum records kept per node (a 
 //   so ties go to the left on both the source and the target side.
 // keys[i] = cluster key of run 0 (all ones: not a target), vals[i] = i, meta[i] = m_C | len << 8 | alignFrom << 20,
 // runs[i * CL_RMAX + k] = {key, q | p0 << 8 | p1 << 16}, nruns[i] = number of runs (0: not a source; CL_RUNS_FLAGGED: more than
-// CL_RMAX runs or records than the stack holds -- the probe hands such a source to the seed-table second pass).
+// CL_RMAX runs or records than the stack holds -- k_probe_clustered finds such a source's window minimizers by brute force).
 __global__ void __launch_bounds__(TK_ROWS) k_node_runs(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, int node_begin, int node_end,
                                                         uint32_t *__restrict__ keys, uint32_t *__restrict__ vals, uint32_t *__restrict__ meta,
                                                         uint2 *__restrict__ runs, uint8_t *__restrict__ nruns) {

@@ -4,7 +4,7 @@
 // tree: replace `new GraphCreatorPrefSuf(READS, G, false)` at src/main.cpp:249 by `new GraphCreatorPrefSufHIP(READS, G)` and
 // link -lalga_amd.  It compiles against the REFERENCE's headers (Read, Bitset, Graph, Params) and against include/alga_amd.h;
 // oracle/Makefile builds it (target `adapter`) together with oracle/ref_adapter.cpp into oracle/_ref/ref_adapter, which
-// tests/test_gpu_adapter.py runs against the reference's own creator and the golden dumps.
+// tests/test_adapter.py runs against the reference's own creator and the golden dumps.
 //
 // Same life cycle as GraphCreatorPrefSuf: construct -> setAlignFrom/To -> startAlignmentGraphCreation() -> delete; the
 // caller's G->retainOnlySmallestOffset() (src/main.cpp:291) finds the lists already deduplicated and sorted.

@@ -13,7 +13,7 @@
 // The call sequence is the one of src/main.cpp:239-296 (exact graph) and, with the last three arguments, :300-347 (supplement):
 // Graph(READS.size()); new <creator>; masks for short / removed reads; startAlignmentGraphCreation(); delete;
 // retainOnlySmallestOffset(); serializeGraph().  `cpu` takes the reference's own GraphCreatorPrefSuf / GraphCreatorLI,
-// `hip` the adapters: the two dumps must be identical (tests/test_gpu_adapter.py).
+// `hip` the adapters: the two dumps must be identical (tests/test_adapter.py).
 // node file: i32 n, i32 W, i32 len[n], u32 words[n*W]   (reference bit layout; len 0 = nullptr)
 #include <cstdio>
 #include <cstdlib>
