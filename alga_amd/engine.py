@@ -121,6 +121,21 @@ def library_path():
     return os.path.join(_HERE, "lib", "libalga_amd.so")
 
 
+def source_fingerprint():
+    """sha256 (first 16 hex digits) over the kernel / engine sources the library is built from (alga_amd/csrc/*, include/alga_amd.h):
+    what profiles/ records next to a counter measurement, so that a number is only ever quoted for the code it was measured on.
+    (The hash of the binary itself changes with the build directory.)"""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(_HERE, "csrc")
+    files = sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".h", ".hpp", ".cpp")) or f == "Makefile")
+    files.append(os.path.join(os.path.dirname(_HERE), "include", "alga_amd.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def load_library():
     """Load libalga_amd.so; raises AlgaError (never falls back to anything else) if it is missing."""
     global _LIB

@@ -108,14 +108,14 @@ def cpu_baseline_port(words, lens, lo, rs, budget_nodes):
 
 def profiled_traffic(config, lib_sha, kernel=None):
     """Memory-side bytes per launch (FETCH_SIZE + WRITE_SIZE as counted) of one probe kernel, or of the whole probe phase, from the
-    rocprofv3 --pmc passes (tools/pmc_to_traffic.py -> profiles/probe_hbm_bytes.json); reported only when they were taken on THIS
-    build of the library, otherwise null."""
+    rocprofv3 --pmc passes (tools/pmc_to_traffic.py -> profiles/probe_hbm_bytes.json); reported only when they were taken on THESE
+    kernel sources (alga_amd.engine.source_fingerprint), otherwise null."""
     tf = os.path.join(ROOT, "profiles", "probe_hbm_bytes.json")
     try:
         ent = json.load(open(tf)).get(config)
     except Exception:
         return None
-    if not ent or ent.get("lib_sha256") != lib_sha:
+    if not ent or ent.get("src_sha256") != lib_sha:
         return None
     if kernel is None:
         return ent.get("hbm_bytes_per_launch")
@@ -233,7 +233,7 @@ def main():
             probe_kernel = "k_probe_clustered" if stats.get("probe_used") == 2 else "k_probe_sources"
             kernel_ms, kernel_bytes = probe_avg_ms, alg_probe_launch
         achieved_kernel = kernel_bytes / (kernel_ms * 1e-3) / 1e9
-        lib_sha = hashlib.sha256(open(alga_amd.engine.library_path(), "rb").read()).hexdigest()[:16]
+        lib_sha = alga_amd.engine.source_fingerprint()     # of the kernel sources: what the counter passes are keyed on
         out = {
             "metric": "overlap_edges_per_sec", "value": n_edges * args.steps / dt, "unit": "edges/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
@@ -247,7 +247,7 @@ def main():
                        "(contiguous id ranges): each rank computes the minimizer keys of its nodes, the key arrays (8 B/node) are all-gathered over RCCL, each rank sorts them into its copy of the bucket-ordered entry array and builds the final edges of its sources; edge lists gathered on rank 0 over RCCL" % world},
             "roofline": {"bound": "hbm", "kernel": probe_kernel, "achieved": achieved_kernel, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_kernel / HBM_PEAK_GBS, "traffic": profiled_traffic(args.config, lib_sha, probe_kernel) if world == 1 else None,
-                         "traffic_source": "rocprofv3 --pmc passes of this command on this build (profiles/probe_hbm_bytes.json, lib %s): FETCH_SIZE + WRITE_SIZE of that kernel as counted; null = not profiled on this build" % lib_sha,
+                         "traffic_source": "rocprofv3 --pmc passes of this command on this build (profiles/probe_hbm_bytes.json, kernel sources %s): FETCH_SIZE + WRITE_SIZE of that kernel as counted; null = not profiled on this build" % lib_sha,
                          "algorithmic_bytes": kernel_bytes, "kernel_ms": kernel_ms,
                          "units": "%d source nodes finished by this kernel per launch (of %d; %d deferred to k_probe_clustered)" % (n_src - deferred, n_src, deferred) if two_kernels else "%d source nodes per launch" % (n_src // world),
                          "per_unit": "per source node: 4W + 16 P + 4W * raw/node bytes (W=%d words, P=%.1f windows, raw/node=%.2f)" %

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Extract the probe phase's memory-side traffic from the rocprofv3 PMC passes of tools/profile_cmd.sh (passes f and w of bench.py)
-and store it where bench.py picks it up (profiles/probe_hbm_bytes.json -> roofline.traffic), tagged with the hash of the library
-it was measured on: bench.py reports it only for that very build.
+and store it where bench.py picks it up (profiles/probe_hbm_bytes.json -> roofline.traffic), tagged with the fingerprint of the
+kernel sources it was measured on (alga_amd.engine.source_fingerprint): bench.py reports it only for that very code.
 
   tools/pmc_to_traffic.py gpurun_out/prof_<tag> <config name>
 
@@ -21,6 +21,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 PROBE_KERNELS = ("k_probe_pairs", "k_probe_clustered", "k_probe_sources")
 
 
@@ -38,6 +39,7 @@ def per_launch(root, sub, counter):
 
 
 def main():
+    from alga_amd.engine import source_fingerprint
     root, config = sys.argv[1], sys.argv[2]
     fetch, write = per_launch(root, "pmc_fetch", "FETCH_SIZE"), per_launch(root, "pmc_write", "WRITE_SIZE")
     lib = os.path.join(ROOT, "alga_amd", "lib", "libalga_amd.so")
@@ -47,7 +49,7 @@ def main():
     data[config] = {"kernels": sorted(set(fetch) | set(write)), "fetch_kib": fetch, "write_kib": write,
                     "hbm_bytes_per_launch": int((f_kib + w_kib) * 1024),
                     "hbm_bytes_per_launch_if_fetch_doubled": int((2 * f_kib + w_kib) * 1024),
-                    "lib_sha256": hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16],
+                    "lib_sha256": hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16], "src_sha256": source_fingerprint(),
                     "source": os.path.basename(root.rstrip("/"))}
     json.dump(data, open(out_path, "w"), indent=1, sort_keys=True)
     print(json.dumps(data[config]))
