@@ -114,6 +114,7 @@ int cluster_alloc(alga_engine *e, const Prepared &pp) {
     if ((rc = alga_ensure(e, e->cl_nruns, n + 16))) return rc;
     if ((rc = alga_ensure(e, e->cl_store, (n + 2) * 16 * (size_t) pp.cluster_eq))) return rc;
     if ((rc = alga_ensure(e, e->cl_idx, ((size_t) pp.cluster.n_buckets + 2) * sizeof(uint32_t)))) return rc;
+    if ((rc = alga_ensure(e, e->cl_dir, ((size_t) pp.cluster.n_buckets + 2) * 16))) return rc;
     return alga_ensure(e, e->sort_temp, cluster_sort_temp_bytes(n));
 }
 
@@ -167,7 +168,7 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
         e->keyed_n = -1;                                   // the sort below may reuse the key buffers: one build per key pass
         HIP_TRY(e, launch_cluster_store(nd, cc, pp.cluster_eq, (uint32_t *) e->cl_keys[0].p, (uint32_t *) e->cl_vals[0].p, (uint32_t *) e->cl_keys[1].p,
                                         (uint32_t *) e->cl_vals[1].p, (const uint32_t *) e->cl_meta.p, e->sort_temp.p, cluster_sort_temp_bytes((uint64_t) nd.n),
-                                        e->cl_store.p, (uint32_t *) e->cl_idx.p, pp.keys_shared, s));
+                                        e->cl_store.p, (uint32_t *) e->cl_idx.p, e->cl_dir.p, pp.keys_shared, s));
         e->stats.table_slots = cc.n_buckets;
     } else if ((rc = build_table())) return rc;
     HIP_TRY(e, hipEventRecord(e->ev[EV_SEED], s));
@@ -197,7 +198,7 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
             const bool pairs = e->opt_cluster_pairs && e->cl_defer_ratio <= 0.5;
             if (pairs) {
                 if ((rc = alga_ensure(e, e->cl_defer, (size_t) (n_src + 64) * sizeof(int32_t)))) return rc;
-                launch_probe_pairs(nd, cfg, cc, pp.cluster_eq, e->cl_store.p, (const uint32_t *) e->cl_idx.p, e->cl_runs.p, (const uint8_t *) e->cl_nruns.p,
+                launch_probe_pairs(nd, cfg, cc, pp.cluster_eq, e->cl_store.p, e->cl_dir.p, e->cl_runs.p, (const uint8_t *) e->cl_nruns.p,
                                    src_begin, src_end, cnt, e->n_cu, (uint32_t *) e->outdeg.p, (unsigned long long *) e->loc_first.p, (int32_t *) e->cl_defer.p,
                                    (uint32_t) n_src, s);
                 if ((rc = alga_check_launch(e, "k_probe_pairs"))) return rc;
@@ -209,12 +210,12 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
                 e->cl_defer_ratio = n_src ? (double) n_def / (double) n_src : 0.0;
                 e->stats.deferred_sources = n_def;
                 if (n_def)
-                    launch_probe_clustered(nd, cfg, cc, pp.cluster_eq, e->cl_store.p, (const uint32_t *) e->cl_idx.p, e->cl_runs.p, (const uint8_t *) e->cl_nruns.p, 0,
+                    launch_probe_clustered(nd, cfg, cc, pp.cluster_eq, e->cl_store.p, e->cl_dir.p, e->cl_runs.p, (const uint8_t *) e->cl_nruns.p, 0,
                                            (int32_t) n_def, (const int32_t *) e->cl_defer.p, src_begin, (uint32_t *) e->rec_dst.p, (unsigned long long *) e->rec_val.p,
                                            cap, cnt, e->n_cu, (uint32_t *) e->outdeg.p, (unsigned long long *) e->loc_first.p, &big, s);
             } else {
                 e->stats.deferred_sources = n_src;
-                launch_probe_clustered(nd, cfg, cc, pp.cluster_eq, e->cl_store.p, (const uint32_t *) e->cl_idx.p, e->cl_runs.p, (const uint8_t *) e->cl_nruns.p, src_begin,
+                launch_probe_clustered(nd, cfg, cc, pp.cluster_eq, e->cl_store.p, e->cl_dir.p, e->cl_runs.p, (const uint8_t *) e->cl_nruns.p, src_begin,
                                        src_end, nullptr, src_begin, (uint32_t *) e->rec_dst.p, (unsigned long long *) e->rec_val.p, cap, cnt, e->n_cu,
                                        (uint32_t *) e->outdeg.p, (unsigned long long *) e->loc_first.p, &big, s);
             }

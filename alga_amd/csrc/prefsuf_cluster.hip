@@ -52,6 +52,37 @@ __device__ __forceinline__ uint32_t cluster_key(uint32_t h) {
     return k == 0xFFFFFFFFu ? 0xFFFFFFFEu : k;
 }
 
+// Sort key of a target: the cluster key with the CL_MBITS bits right below its bucket bits replaced by m_C, the position of the
+// minimizer in the target's prefix (field at bit fs = idx_shift - CL_MBITS).  Inside a bucket the entries are therefore ordered
+// by m_C first, and the directory (k_tgt_dir) knows where every eighth of that order starts: a source run that covers the
+// windows [p0, p1) with its minimizer at q can only match targets with q - p1 < m_C <= q - p0 and reads that slice of the bucket
+// alone -- the other entries of the cluster are the reads of the same locus that start too far left or right of the run's
+// windows (half of them at 30x coverage).  0xFFFFFFFF stays reserved for "not a target" (m_C 63 -> 62: same eighth; the m_C
+// that is used for the offset comes from the entry's meta word).
+__device__ __forceinline__ uint32_t tgt_sort_key(uint32_t ckey, uint32_t m_c, int fs) {
+    const uint32_t fm = ((1u << CL_MBITS) - 1u) << fs;
+    const uint32_t k = (ckey & ~fm) | ((m_c << fs) & fm);
+    return k == 0xFFFFFFFFu ? k ^ (1u << fs) : k;
+}
+__device__ __forceinline__ bool same_cluster(uint32_t entry_key, uint32_t ckey, int fs) {
+    return ((entry_key ^ ckey) & ~(((1u << CL_MBITS) - 1u) << fs)) == 0u;
+}
+
+// directory record of a bucket: {first entry, entries, first entry (relative, saturating bytes) with m_C >> 3 >= 0..3, >= 4..7}
+// -> the entries [e0, e0 + cnt) a run {q | p0 << 8 | p1 << 16} has to look at
+__device__ __forceinline__ void run_slice(const uint4 &rec, uint32_t run_y, uint32_t &e0, uint32_t &cnt) {
+    const int q = (int) (run_y & 255u), p0 = (int) ((run_y >> 8) & 255u), p1 = (int) ((run_y >> 16) & 255u);
+    int mlo = q - p1 + 1, mhi = q - p0;
+    mlo = mlo < 0 ? 0 : mlo; mhi = mhi > 63 ? 63 : mhi;
+    e0 = rec.x; cnt = rec.y;
+    if (mhi < mlo) { cnt = 0u; return; }
+    if (rec.y > 255u) return;                              // offsets saturate: the whole bucket
+    const int s0 = mlo >> 3, s1 = (mhi >> 3) + 1;
+    const uint32_t b0 = ((s0 < 4 ? rec.z : rec.w) >> (8 * (s0 & 3))) & 255u;
+    const uint32_t b1 = s1 >= 8 ? rec.y : (((s1 < 4 ? rec.z : rec.w) >> (8 * (s1 & 3))) & 255u);
+    e0 = rec.x + b0; cnt = b1 - b0;
+}
+
 // k-mer starting at nucleotide i of a 2-bit row (words readable up to index (2i >> 5) + 2): its hash and its packed
 // order key (24-bit order | position); the smallest key of a window is the window's minimizer
 __device__ __forceinline__ void kmer_key(const uint32_t *row, int i, bool valid, const ClusterCfg &cc, uint32_t &h, uint32_t &pk) {
@@ -175,7 +206,7 @@ __global__ void __launch_bounds__(TK_ROWS) k_node_runs(NodesDev nd, PrefSufCfg c
     if (is_tgt) {
         uint32_t h, pk;
         kmer_key(row, (int) (prev_win & 255u), true, cc, h, pk);
-        key = cluster_key(h);
+        key = tgt_sort_key(cluster_key(h), prev_win & 255u, cc.idx_shift - CL_MBITS);
         m = (prev_win & 255u) | ((uint32_t) len << 8) | (is_src ? CL_META_FROM : 0u);
     }
     if (in) {
@@ -217,6 +248,29 @@ __global__ void __launch_bounds__(256) k_tgt_index(const uint32_t *__restrict__ 
     }
 }
 
+// dir[b] = {idx[b], entries of bucket b, byte offsets of the eight m_C >> 3 classes inside it}: one thread per bucket
+__global__ void __launch_bounds__(256) k_tgt_dir(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ idx, uint32_t n_buckets, int shift,
+                                                  uint4 *__restrict__ dir) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b > n_buckets) return;
+    const uint32_t s0 = idx[b], s1 = b < n_buckets ? idx[b + 1] : idx[b];
+    const uint32_t c = s1 - s0;
+    uint32_t lo = 0u, hi = 0u;
+    if (c > 0u && c <= 255u) {
+        uint32_t first[9];                                 // first[s] = entries with class < s
+#pragma unroll
+        for (int k = 0; k < 9; k++) first[k] = 0u;
+        for (uint32_t j = s0; j < s1; j++) {
+            const uint32_t cls = (keys[j] >> (shift - 3)) & 7u;   // top three bits of the m_C field
+#pragma unroll
+            for (int k = 1; k < 9; k++) first[k] += cls < (uint32_t) k ? 1u : 0u;
+        }
+        lo = first[0] | (first[1] << 8) | (first[2] << 16) | (first[3] << 24);
+        hi = first[4] | (first[5] << 8) | (first[6] << 16) | (first[7] << 24);
+    }
+    dir[b] = make_uint4(s0, c, lo, hi);
+}
+
 // ------------------------------------------------------------------------------------------
 // k_probe_clustered
 // ------------------------------------------------------------------------------------------
@@ -230,7 +284,7 @@ __device__ __forceinline__ uint32_t bperm(uint32_t v, int src_lane) { return (ui
 // source between the stages: its staged row and its resolved run list in LDS (two buffers), a few uniform scalars.
 template <bool STATS, int EQ, int KF>
 __global__ void __launch_bounds__(PROBE_WAVES * 64, CL_OCC)
-k_probe_clustered(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__restrict__ store, const uint32_t *__restrict__ idx,
+k_probe_clustered(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__restrict__ store, const uint4 *__restrict__ dir,
                   const uint2 *__restrict__ runs, const uint8_t *__restrict__ nruns, int32_t src_begin, int32_t src_end, ProbeOut o,
                   const int32_t *__restrict__ src_list /* null: the sources are the ids src_begin .. src_end - 1; else src_list[src_begin .. src_end - 1] */) {
     constexpr int WC = 4 * EQ - 3;                         // row words of an entry
@@ -296,10 +350,12 @@ k_probe_clustered(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__res
     // The index loads of stage 1 are issued by EVERY lane and outside any branch: a load under a branch leaves the number of
     // loads in flight unknown to the compiler, which then drains ALL of them where the entries are first used -- and that
     // serialises the two stages of the pipeline.
-    auto index_loads = [&](uint32_t bucket, uint32_t &e0, uint32_t &e1) { e0 = idx[bucket]; e1 = idx[bucket + 1]; };
+    auto index_loads = [&](uint32_t bucket, uint4 &rec) { rec = dir[bucket]; };
     // resolved run list -> LDS; returns the largest entry count of the source's runs (uniform)
-    auto finish_runs = [&](int buf, int nr, const uint2 &run, uint32_t e0, uint32_t e1) -> uint32_t {
-        const uint32_t cnt = lane < nr ? e1 - e0 : 0u;
+    auto finish_runs = [&](int buf, int nr, const uint2 &run, const uint4 &rec) -> uint32_t {
+        uint32_t e0, cnt;
+        run_slice(rec, run.y, e0, cnt);
+        cnt = lane < nr ? cnt : 0u;
         if (lane < CL_RMAX) sRun[wave][buf][lane] = make_uint4(run.y, run.x, e0, cnt);
         uint32_t m = cnt, t;                               // max over lanes 0..7: row_shr 1, 2, 4 inside the first row
         t = (uint32_t) __builtin_amdgcn_update_dpp(0, (int) m, 0x111, 0xF, 0xF, true); m = m > t ? m : t;
@@ -324,10 +380,10 @@ k_probe_clustered(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__res
     bool have = advance(B, lenB, nr, word0, run);
     int buf = 0;
     if (have) {
-        uint32_t e0, e1;
+        uint4 rec0;
         const uint32_t bk = stage(0, lenB, nr == CL_RUNS_FLAGGED ? 0 : nr, word0, run);
-        index_loads(bk, e0, e1);
-        mc = finish_runs(0, nr == CL_RUNS_FLAGGED ? 0 : nr, run, e0, e1);
+        index_loads(bk, rec0);
+        mc = finish_runs(0, nr == CL_RUNS_FLAGGED ? 0 : nr, run, rec0);
     }
     while (have) {                                         // uniform
         const uint32_t *sb = sB[wave][buf];
@@ -335,7 +391,8 @@ k_probe_clustered(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__res
         // ---- (1) pull the next source off the stream BEFORE any entry load is issued: its loop must not sit between the
         //          loads and their use (hipcc drains vmcnt at loop headers) ----
         int nB = 0, nlenB = 0, nnr = 0;
-        uint32_t nword0 = 0, nbk = 0, ne0, ne1;
+        uint32_t nword0 = 0, nbk = 0;
+        uint4 nrec;
         uint2 nrun = make_uint2(0u, 0u);
         const bool have_next = advance(nB, nlenB, nnr, nword0, nrun);
         const int nnr_eff = nnr == CL_RUNS_FLAGGED ? 0 : nnr;
@@ -349,7 +406,7 @@ k_probe_clustered(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__res
         load_entries(rp, k0, gs, ev, ei, ew);
         // ---- (3) the next source: row staged, index loads issued behind the entry loads ----
         if (have_next) nbk = stage(buf ^ 1, nlenB, nnr_eff, nword0, nrun);
-        index_loads(nbk, ne0, ne1);
+        index_loads(nbk, nrec);
         // ---- (4) verify: one entry per lane.  A verified overlap is an ITEM of the source-side reduction: target, offset | length |
         //      alignFrom, overhang.  With every entry of the source in this one batch (the rule) the items stay in the lanes'
         //      registers for the fused reduction below; otherwise they are appended to the item buffer in LDS. ----
@@ -365,7 +422,7 @@ k_probe_clustered(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__res
             int p = (int) (rp.x & 255u) - (int) (meta & 255u);         // the only offset at which C's prefix can sit in B
             // same minimizer k-mer, a window of THIS run (its minimizer is the run's), not B itself (GraphCreatorPrefSuf.cpp:386),
             // C long enough for a prefix of length L = |B| - p (:215)
-            const bool ok = ev && eh == rp.y && p >= (int) ((rp.x >> 8) & 255u) && p < (int) ((rp.x >> 16) & 255u) && (int) id != B &&
+            const bool ok = ev && same_cluster(eh, rp.y, cc.idx_shift - CL_MBITS) && p >= (int) ((rp.x >> 8) & 255u) && p < (int) ((rp.x >> 16) & 255u) && (int) id != B &&
                             lenC >= lenB - p;
             p = ok ? p : 0;
             const int L = lenB - p, nb = 2 * L;
@@ -504,10 +561,11 @@ k_probe_clustered(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__res
                 wave_lds_fence();
                 uint32_t cnt = 0u;
                 if (start && rank >= rb && rank < rb + CL_RMAX) {
-                    const uint32_t bk = key >> cc.idx_shift;
-                    const uint32_t e0 = idx[bk], e1 = idx[bk + 1];
-                    cnt = e1 - e0;
-                    sRun[wave][buf][rank - rb] = make_uint4((wm & 255u) | ((uint32_t) lane << 8) | ((uint32_t) p1 << 16), key, e0, cnt);
+                    const uint4 rec = dir[key >> cc.idx_shift];
+                    const uint32_t ry = (wm & 255u) | ((uint32_t) lane << 8) | ((uint32_t) p1 << 16);
+                    uint32_t e0;
+                    run_slice(rec, ry, e0, cnt);
+                    sRun[wave][buf][rank - rb] = make_uint4(ry, key, e0, cnt);
                 }
                 wave_lds_fence();
                 const uint32_t mcs = (uint32_t) wave_max_u64_dpp((uint64_t) cnt);
@@ -533,7 +591,7 @@ k_probe_clustered(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__res
         const int nb2 = (int) __builtin_amdgcn_readfirstlane((int) *w.recN);
         if (nb2 >= WFLUSH_LOCAL) flush_records<REC_CHUNK_LOCAL, WBUF_LOCAL>(o, w, chunk_base, chunk_fill);
         // ---- (6) the next source's index loads have had the time of (4) and (5) to land ----
-        mc = finish_runs(buf ^ 1, nnr_eff, nrun, ne0, ne1);
+        mc = finish_runs(buf ^ 1, nnr_eff, nrun, nrec);
         have = have_next; B = nB; lenB = nlenB; nr = nnr; buf ^= 1;
     }
     flush_records<REC_CHUNK_LOCAL, WBUF_LOCAL>(o, w, chunk_base, chunk_fill);
@@ -569,7 +627,7 @@ k_probe_clustered(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__res
 #endif
 template <bool STATS, int EQ, int KF>
 __global__ void __launch_bounds__(PROBE_WAVES * 64, CLP_OCC)
-k_probe_pairs(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__restrict__ store, const uint32_t *__restrict__ idx,
+k_probe_pairs(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__restrict__ store, const uint4 *__restrict__ dir,
               const uint2 *__restrict__ runs, const uint8_t *__restrict__ nruns, int32_t src_begin, int32_t src_end, ProbeOut o,
               int32_t *__restrict__ defer_list, uint32_t defer_cap) {
     constexpr int WC = 4 * EQ - 3;                         // row words of an entry
@@ -625,11 +683,13 @@ k_probe_pairs(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__restric
         sB[wave][buf][h][hl] = hl < blocks_of(lenB) ? word0 : 0u;
         return hl < nr_eff ? run.x >> cc.idx_shift : 0u;
     };
-    auto index_loads = [&](uint32_t bucket, uint32_t &e0, uint32_t &e1) { e0 = idx[bucket]; e1 = idx[bucket + 1]; };   // every lane, no branch
+    auto index_loads = [&](uint32_t bucket, uint4 &rec) { rec = dir[bucket]; };   // every lane, no branch
     // run list of a pair -> LDS; entries are numbered densely over the runs of a source: slot = entries of the runs before + j.
     // Returns the number of entries of this lane's source (uniform per half).
-    auto finish_runs = [&](int buf, int nr_eff, const uint2 &run, uint32_t e0, uint32_t e1) -> int {
-        const uint32_t cnt = hl < nr_eff ? e1 - e0 : 0u;   // lanes hl >= 8 hold no run
+    auto finish_runs = [&](int buf, int nr_eff, const uint2 &run, const uint4 &rec) -> int {
+        uint32_t e0, cnt;
+        run_slice(rec, run.y, e0, cnt);
+        cnt = hl < nr_eff ? cnt : 0u;                      // lanes hl >= 8 hold no run
         uint32_t inc = cnt, t;                             // inclusive scan over the runs (lanes hl 0..7 of the half: inside one 16-lane row)
         t = (uint32_t) __builtin_amdgcn_update_dpp(0, (int) inc, 0x111, 0xF, 0xF, true); inc += t;
         t = (uint32_t) __builtin_amdgcn_update_dpp(0, (int) inc, 0x112, 0xF, 0xF, true); inc += t;
@@ -651,10 +711,10 @@ k_probe_pairs(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__restric
         Bl += step;
         fetch();
         const int nr_eff = nr == CL_RUNS_FLAGGED ? 0 : nr;
-        uint32_t e0, e1;
+        uint4 rec0;
         const uint32_t bk = stage(0, lenB, nr_eff, word0, run);
-        index_loads(bk, e0, e1);
-        T = finish_runs(0, nr_eff, run, e0, e1);
+        index_loads(bk, rec0);
+        T = finish_runs(0, nr_eff, run, rec0);
     }
     while (have) {                                         // uniform
         const uint32_t *sb = sB[wave][buf][h];
@@ -684,14 +744,15 @@ k_probe_pairs(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__restric
 #pragma unroll
         for (int c = 0; c < EQ; c++) { const uint4 v = store[ei * EQ + c]; ew[4 * c] = v.x; ew[4 * c + 1] = v.y; ew[4 * c + 2] = v.z; ew[4 * c + 3] = v.w; }
         // ---- (3) the next pair: rows staged, index loads issued behind the entry loads ----
-        uint32_t nbk = 0, ne0, ne1;
+        uint32_t nbk = 0;
+        uint4 nrec;
         if (have_next) nbk = stage(buf ^ 1, nlenB, nnr_eff, nword0, nrun);
-        index_loads(nbk, ne0, ne1);
+        index_loads(nbk, nrec);
         // ---- (4) verify: one entry per lane ----
         const uint32_t id = ew[4 * EQ - 3], eh = ew[4 * EQ - 2], meta = ew[4 * EQ - 1];
         const int lenC = (int) ((meta >> 8) & 0xFFFu);
         int p = (int) (rp.x & 255u) - (int) (meta & 255u);
-        const bool ok = ev && eh == rp.y && p >= (int) ((rp.x >> 8) & 255u) && p < (int) ((rp.x >> 16) & 255u) && (int) id != B && lenC >= lenB - p;
+        const bool ok = ev && same_cluster(eh, rp.y, cc.idx_shift - CL_MBITS) && p >= (int) ((rp.x >> 8) & 255u) && p < (int) ((rp.x >> 16) & 255u) && (int) id != B && lenC >= lenB - p;
         p = ok ? p : 0;
         const int L = lenB - p, nb = 2 * L;
         bool pass;
@@ -778,7 +839,7 @@ k_probe_pairs(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__restric
             if (n_defer >= 62) flush_defer();
         }
         // ---- (5) the next pair's index loads have had the time of (4) to land ----
-        const int nT = finish_runs(buf ^ 1, nnr_eff, nrun, ne0, ne1);
+        const int nT = finish_runs(buf ^ 1, nnr_eff, nrun, nrec);
         have = have_next; B = nB; lenB = nlenB; nr = nnr; T = nT; buf ^= 1;
     }
     flush_defer();
@@ -817,7 +878,7 @@ bool cluster_plan(const PrefSufCfg &cfg, int max_len, uint64_t live, int bucket_
     c->hi_mask = kk <= 16 ? 0u : (kk >= 32 ? 0xFFFFFFFFu : ((1u << (2 * kk - 32)) - 1u));
     int bits = 4;
     while (bits < 28 && (1ull << bits) < live) bits++;     // ~one entry per bucket: a lookup returns its cluster and little else
-    bits = std::max(4, std::min(30, bits + bucket_log2_bias));
+    bits = std::max(4, std::min(32 - CL_MBITS, bits + bucket_log2_bias));      // the low CL_MBITS key bits carry m_C, not the cluster
     c->n_buckets = 1u << bits;
     c->idx_shift = 32 - bits;
     *eq = e;
@@ -842,7 +903,8 @@ __global__ void __launch_bounds__(256) k_iota(uint32_t *__restrict__ v, uint32_t
 // keys / meta of all n nodes -> the entry array in key order and its bucket index.  fill_vals: the ids (sort payload) were not
 // written by this engine's key pass for every node (keys gathered from other ranks): write them here.
 hipError_t launch_cluster_store(const NodesDev &nd, const ClusterCfg &cc, int eq, uint32_t *keys, uint32_t *vals, uint32_t *keys2, uint32_t *vals2,
-                                const uint32_t *meta, void *sort_temp, size_t sort_temp_bytes, void *store, uint32_t *idx, bool fill_vals, hipStream_t s) {
+                                const uint32_t *meta, void *sort_temp, size_t sort_temp_bytes, void *store, uint32_t *idx, void *dir, bool fill_vals,
+                                hipStream_t s) {
     if (nd.n <= 0) return hipSuccess;
     const uint64_t n = (uint64_t) nd.n;
     if (fill_vals) hipLaunchKernelGGL(k_iota, dim3((unsigned) std::min<uint64_t>((n + 255) / 256, 8192)), dim3(256), 0, s, vals, (uint32_t) n);
@@ -855,6 +917,8 @@ hipError_t launch_cluster_store(const NodesDev &nd, const ClusterCfg &cc, int eq
     else              hipLaunchKernelGGL(k_tgt_gather<4>, dim3(g), dim3(256), 0, s, nd, (const uint32_t *) keys2, (const uint32_t *) vals2, meta, (uint4 *) store);
     hipLaunchKernelGGL(k_tgt_index, dim3((unsigned) std::min<uint64_t>((n + 256) / 256, 16384)), dim3(256), 0, s, (const uint32_t *) keys2, n, cc.idx_shift,
                        cc.n_buckets, idx);
+    hipLaunchKernelGGL(k_tgt_dir, dim3((cc.n_buckets + 1 + 255) / 256), dim3(256), 0, s, (const uint32_t *) keys2, (const uint32_t *) idx, cc.n_buckets, cc.idx_shift,
+                       (uint4 *) dir);
     return hipGetLastError();
 }
 
@@ -865,7 +929,7 @@ uint64_t cluster_probe_blocks(int n_cu, uint64_t n_src) {
 uint64_t cluster_record_slack(int n_cu, uint64_t n_src) { return cluster_probe_blocks(n_cu, n_src) * PROBE_WAVES * (uint64_t) REC_CHUNK_LOCAL; }
 
 // the pair kernel over the sources src_begin .. src_end - 1: regular sources get their edge, the others go on defer_list
-void launch_probe_pairs(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterCfg &cc, int eq, const void *store, const uint32_t *idx,
+void launch_probe_pairs(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterCfg &cc, int eq, const void *store, const void *dir,
                         const void *runs, const uint8_t *nruns, int32_t src_begin, int32_t src_end, unsigned long long *counters, int n_cu, uint32_t *deg,
                         unsigned long long *first, int32_t *defer_list, uint32_t defer_cap, hipStream_t s) {
     const int64_t ns = (int64_t) src_end - src_begin;
@@ -875,7 +939,7 @@ void launch_probe_pairs(const NodesDev &nd, const PrefSufCfg &cfg, const Cluster
     ProbeOut o{nullptr, nullptr, 0, counters, deg, first, src_begin};
     const uint4 *st = (const uint4 *) store;
     const int kf = (2 * cfg.Lmin) >> 5;
-#define CLP_LAUNCH(ST, E, K) hipLaunchKernelGGL((k_probe_pairs<ST, E, K>), grid, block, 0, s, nd, cfg, cc, st, idx, (const uint2 *) runs, nruns, src_begin, src_end, o, defer_list, defer_cap)
+#define CLP_LAUNCH(ST, E, K) hipLaunchKernelGGL((k_probe_pairs<ST, E, K>), grid, block, 0, s, nd, cfg, cc, st, (const uint4 *) dir, (const uint2 *) runs, nruns, src_begin, src_end, o, defer_list, defer_cap)
 #define CLP_STATS(E, K) do { if (cfg.stats) CLP_LAUNCH(true, E, K); else CLP_LAUNCH(false, E, K); } while (0)
     if (eq == 3 && kf == 5)      CLP_STATS(3, 5);
     else if (eq == 3 && kf == 3) CLP_STATS(3, 3);
@@ -888,7 +952,7 @@ void launch_probe_pairs(const NodesDev &nd, const PrefSufCfg &cfg, const Cluster
 }
 
 // src_list == null: the sources are the ids src_begin .. src_end - 1; else the ids src_list[src_begin .. src_end - 1]
-void launch_probe_clustered(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterCfg &cc, int eq, const void *store, const uint32_t *idx,
+void launch_probe_clustered(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterCfg &cc, int eq, const void *store, const void *dir,
                             const void *runs, const uint8_t *nruns, int32_t src_begin, int32_t src_end, const int32_t *src_list, int32_t src_base,
                             uint32_t *rec_dst, unsigned long long *rec_val, uint64_t rec_cap,
                             unsigned long long *counters, int n_cu, uint32_t *deg, unsigned long long *first, const ProbeBig *big, hipStream_t s) {
@@ -901,7 +965,7 @@ void launch_probe_clustered(const NodesDev &nd, const PrefSufCfg &cfg, const Clu
     // KF = (2 * Lmin) >> 5 as a compile-time constant for the shapes ALGA's defaults produce (150-bp reads: Lmin 82, rows of 9
     // words; 100-bp reads: Lmin 55, rows of 6 words); 0 = any shape
     const int kf = (2 * cfg.Lmin) >> 5;
-#define CL_LAUNCH(ST, E, K) hipLaunchKernelGGL((k_probe_clustered<ST, E, K>), grid, block, 0, s, nd, cfg, cc, st, idx, (const uint2 *) runs, nruns, src_begin, src_end, o, src_list)
+#define CL_LAUNCH(ST, E, K) hipLaunchKernelGGL((k_probe_clustered<ST, E, K>), grid, block, 0, s, nd, cfg, cc, st, (const uint4 *) dir, (const uint2 *) runs, nruns, src_begin, src_end, o, src_list)
 #define CL_STATS(E, K) do { if (cfg.stats) CL_LAUNCH(true, E, K); else CL_LAUNCH(false, E, K); } while (0)
     if (eq == 3 && kf == 5)      CL_STATS(3, 5);
     else if (eq == 3 && kf == 3) CL_STATS(3, 3);

@@ -97,6 +97,7 @@ struct NodesDev {
 // clustered minimizer join (prefsuf_cluster.hip): targets filed under the minimizer of their min_overlap-long prefix
 constexpr int      CL_KMIN = 16;              // preferred shortest minimizer k-mer; k = max(Lmin - 63, min(Lmin, CL_KMIN)), w = Lmin - k + 1 <= 64
 constexpr int      CL_KMIN_HARD = 8;          // below this the clustered probe declines (the seed-table probe takes the input)
+constexpr int      CL_MBITS = 6;              // low bits of a target's sort key: m_C, the minimizer's position in its prefix (w <= 64)
 constexpr int      CL_RMAX = 8;               // minimizer runs stored per node (a 150-bp read has 2.9 on average)
 constexpr int      CL_RUNS_FLAGGED = 0xFF;    // nruns marker: more runs / records than k_node_runs stores
 constexpr int      CL_MAX_EQ = 4;             // 16-byte pieces per entry: rows of up to 4 * CL_MAX_EQ - 3 words (208 nt)
