@@ -126,6 +126,7 @@ def profiled_traffic(config, lib_sha, kernel=None):
 
 
 def main():
+    t_process = time.perf_counter()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -289,6 +290,9 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
+        wall = time.perf_counter() - t_process
+        out["fits_in_driver_run"] = {"wall_s": round(wall, 1), "limit_s": 600, "fits": wall < 600,
+                                     "note": "whole bench.py process: workload generation, counted pass, warmup, timed steps, PCIe leg, CPU baseline"}
         print(json.dumps(out))
 
 
