@@ -591,7 +591,7 @@ __global__ void __launch_bounds__(64) k_pkb_groups_wave(NodesDev nd, PkbCfg c, P
         if (lane < D) sv[rank] = mv;
         __syncthreads();
         const unsigned long long vj = lane < D ? sv[lane] : 0ull;
-        const int idj = pkb_val_id(vj), indj = pkb_val_ind(vj), lenj = pkb_val_len(vj);
+        const int idj = pkb_val_id(vj), indj = pkb_val_ind(vj);
         bool twice = false;
         for (int k = 0; k < D; k++) twice |= (lane < D && k != lane && pkb_val_id(sv[k]) == idj);
         if (__ballot(twice) != 0ull) {                                       // a read twice in the group: the serial kernel replays it

@@ -360,6 +360,73 @@ def test_exchange_helpers_emulated_ranks(eng):
         assert (be.build().cpu().numpy() == want).all()
 
 
+@pytest.mark.parametrize("n,length,G,seed,err,minlen,lo,rs", [
+    (4000, 150, 6000, 71, 0.0, None, 90, 120),     # 100x coverage: clusters of 60+ entries
+    (3000, 144, 5000, 72, 0.004, 110, 82, 116),    # variable length + errors
+    (2500, 100, 1200, 73, 0.0, None, 55, 77),      # 200x coverage on a short genome: hundreds of entries per bucket
+])
+def test_cluster_directory_geometries(n, length, G, seed, err, minlen, lo, rs):
+    """the clustered probe with every shape of its bucket directory: few huge buckets (more than 255 entries: the directory's byte
+    offsets saturate and a run reads the whole bucket), one cluster per bucket, more buckets than the key has bits for (clamped);
+    with and without the pair kernel.  Always the same graph."""
+    words, lens = _nodes(n, length, G, seed, err, minlen)
+    want, _, _ = O.prefsuf(words, lens, lo, rs)
+    e = alga_amd.Engine(0)
+    try:
+        e.set_option("probe", "cluster")
+        for bias in (-8, -4, 0, 3, 8):
+            for pairs in (1, 0):
+                e.set_option("cluster_bucket_bias", bias)
+                e.set_option("cluster_pairs", pairs)
+                got = e.prefsuf_host(words, lens, lo, rs, reduction="source_side")
+                st = e.last_stats()
+                assert st["probe_used"] == 2, (bias, pairs)
+                assert got.shape == want.shape and (got == want).all(), (bias, pairs)
+    finally:
+        e.close()
+
+
+def test_shared_keys_protocol(eng):
+    """alga_prefsuf_keys_device + keys_shared: two 'ranks' on one engine pair -- each computes the keys of its own nodes, the slices are
+    exchanged by hand, each builds its source range: together the single-GPU graph.  Misuse (no key pass, a source range outside
+    the keyed node range, another node set) is an error, not a wrong graph; inputs the clustered probe declines report so."""
+    import torch
+    from alga_amd.engine import device_view
+    words, lens = _nodes(3000, 150, 8000, 83, err=0.002, stride=16)
+    want, _, _ = O.prefsuf(words, lens, 90, 120)
+    dw = torch.from_numpy(words.view(np.int32)).cuda()
+    dl = torch.from_numpy(lens).cuda()
+    n, h = len(lens), (len(lens) // 4) * 2
+    e2 = alga_amd.Engine(0)
+    try:
+        k1 = eng.keys_device(dw, dl, 90, 120, 0, h)
+        k2 = e2.keys_device(dw, dl, 90, 120, h, n)
+        assert k1 is not None and k2 is not None
+        v1 = [device_view(p, (n,)) for p in k1]
+        v2 = [device_view(p, (n,)) for p in k2]
+        torch.cuda.synchronize()
+        for a, b in zip(v1, v2):
+            a[h:] = b[h:]
+            b[:h] = a[:h]
+        torch.cuda.synchronize()
+        r1 = eng.build_range_device(dw, dl, 90, 120, 0, h, keys_shared=True)
+        r2 = e2.build_range_device(dw, dl, 90, 120, h, n, keys_shared=True)
+        got = np.concatenate([device_view(r1[0], (r1[1], 3)).cpu().numpy(), device_view(r2[0], (r2[1], 3)).cpu().numpy()])
+        assert got.shape == want.shape and (got == want).all()
+        with pytest.raises(alga_amd.AlgaError) as ei:                 # the keys were consumed by the build
+            eng.build_range_device(dw, dl, 90, 120, 0, h, keys_shared=True)
+        assert ei.value.code == -1
+        eng.keys_device(dw, dl, 90, 120, 0, h)
+        with pytest.raises(alga_amd.AlgaError) as ei:                 # sources outside the keyed node range
+            eng.build_range_device(dw, dl, 90, 120, 0, n, keys_shared=True)
+        assert ei.value.code == -1
+        # 250-nt reads: the clustered probe declines (two-word offset masks) -> nothing to share
+        w2, l2 = _nodes(600, 250, 4000, 84)
+        assert eng.keys_device(torch.from_numpy(w2.view(np.int32)).cuda(), torch.from_numpy(l2).cuda(), 137, 190, 0, len(l2)) is None
+    finally:
+        e2.close()
+
+
 @pytest.mark.parametrize("lo,rs,replicate", [(90, 120, False), (90, 120, True), (82, 116, False)])
 def test_sharded_driver_with_hip_backend_three_ranks_one_gpu(lo, rs, replicate):
     """alga_amd.multigpu.ShardedPrefSuf exactly as bench.py --gpus N drives it (real HipBackend, device tensors), the
