@@ -231,7 +231,14 @@ def main():
             kernel_ms = pairs_avg_ms
             kernel_bytes = alg_probe_launch * (1.0 - deferred / n_src)
         else:
-            probe_kernel = "k_probe_clustered" if stats.get("probe_used") == 2 else "k_probe_sources"
+            # one kernel did the probing (seed-table probe, or the general clustered kernel alone); with N > 1 the per-kernel split
+            # of the probe phase is not collected: the phase as a whole, this rank's share of the sources
+            if stats.get("probe_used") != 2:
+                probe_kernel = "k_probe_sources"
+            elif world > 1 or pairs_avg_ms > 0:
+                probe_kernel = "k_probe_pairs + k_probe_clustered (probe phase)"
+            else:
+                probe_kernel = "k_probe_clustered"
             kernel_ms, kernel_bytes = probe_avg_ms, alg_probe_launch
         achieved_kernel = kernel_bytes / (kernel_ms * 1e-3) / 1e9
         lib_sha = alga_amd.engine.source_fingerprint()     # of the kernel sources: what the counter passes are keyed on
