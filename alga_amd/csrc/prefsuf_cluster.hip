@@ -665,16 +665,25 @@ k_probe_pairs(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__restric
     // ---- source stream: pairs of adjacent ids; the rows / lengths / run lists of the pair after the one being staged are in flight ----
     const int pre_words = nd.stride < PW ? nd.stride : PW;
     int Bl = src_begin + 2 * ((int) blockIdx.x * PROBE_WAVES + wave);
+    // Every lane issues every load, unconditionally, at clamped addresses: a load under a branch makes hipcc wait for it right
+    // there (the merge of the loaded value with its default needs it), which stalled the wave for a memory round trip at the top of
+    // every iteration.  What a lane must not use is masked where the values are consumed, one iteration later (take()).
     int n_len = 0, n_nr = 0; uint32_t n_word = 0; uint2 n_run = make_uint2(0u, 0u);
+    bool n_valid = false;
+    const int last_src = src_end - 1, col = hl < pre_words ? hl : pre_words - 1;
     auto fetch = [&]() {
-        n_len = 0; n_nr = 0; n_word = 0u; n_run = make_uint2(0u, 0u);
         const int b = Bl + h;
-        if (Bl < src_end && b < src_end) {
-            n_len = nd.len[b];
-            n_nr = nruns[b];
-            if (hl < pre_words) n_word = nd.words[(size_t) b * nd.stride + hl];
-            if (hl < CL_RMAX) n_run = runs[(size_t) b * CL_RMAX + hl];
-        }
+        n_valid = b < src_end;                             // (Bl < src_end follows)
+        const int bs = b < last_src ? b : last_src;
+        n_len = nd.len[bs];
+        n_nr = nruns[bs];
+        n_word = nd.words[(size_t) bs * nd.stride + col];
+        n_run = runs[(size_t) bs * CL_RMAX + (hl & (CL_RMAX - 1))];
+    };
+    auto take = [&](int &len, int &nrn, uint32_t &word, uint2 &run) {   // the fetched pair, masked
+        len = n_valid ? n_len : 0; nrn = n_valid ? n_nr : 0;
+        word = (n_valid && hl < pre_words) ? n_word : 0u;
+        run = (n_valid && hl < CL_RMAX) ? n_run : make_uint2(0u, 0u);
     };
     fetch();
     // stage 1 of a pair: rows -> LDS; bucket of each run (lanes without a run read bucket 0: one shared line)
@@ -706,8 +715,9 @@ k_probe_pairs(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__restric
     bool have = Bl < src_end;
     int B = 0, lenB = 0, nr = 0, T = 0, buf = 0;
     if (have) {
-        B = Bl + h; lenB = n_len; nr = n_nr;
-        const uint32_t word0 = n_word; const uint2 run = n_run;
+        uint32_t word0; uint2 run;
+        B = Bl + h;
+        take(lenB, nr, word0, run);
         Bl += step;
         fetch();
         const int nr_eff = nr == CL_RUNS_FLAGGED ? 0 : nr;
@@ -721,9 +731,11 @@ k_probe_pairs(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__restric
         const int nwin = lenB - cfg.Lmin + 1;
         // ---- (1) the next pair comes off the stream before any entry load is issued ----
         const bool have_next = Bl < src_end;
-        const int nB = Bl + h, nlenB = n_len, nnr = n_nr;
-        const uint32_t nword0 = n_word; const uint2 nrun = n_run;
-        if (have_next) { Bl += step; fetch(); }
+        const int nB = Bl + h;
+        int nlenB, nnr; uint32_t nword0; uint2 nrun;
+        take(nlenB, nnr, nword0, nrun);
+        Bl = have_next ? Bl + step : Bl;
+        fetch();                                                       // past the end: clamped reads of the last source, never used
         const int nnr_eff = nnr == CL_RUNS_FLAGGED ? 0 : nnr;
         // ---- (2) this pair's entries, densely packed per half: loads issued ----
         const bool takes_part = nr != 0;                               // nruns == 0: not a source
