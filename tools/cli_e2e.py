@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """End-to-end time of the drop-in CLI at BASELINE configs[1]: FASTA on disk -> alga_hip (ingest on the host cores, overlap graph
-on the GPU, .graph dump) next to the reference binary's own time to the same point.  usage: tools/cli_e2e.py [config] [threads]"""
+on the GPU, .graph dump) next to the reference binary's own time to the same point.
+usage: tools/cli_e2e.py [config] [threads] [--paired] [--compare-dump]
+--paired: the reads go into two files (--file1 / --file2, record i of file f = read 2i + f: BASELINE configs[2]'s input form);
+--compare-dump: the reference runs with --serialize=1 and its *_beforeSimplifier.graph must equal alga_hip's byte for byte."""
 import json
 import os
 import re
@@ -15,17 +18,29 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 import gen_reads  # noqa: E402
 from alga_amd import workload  # noqa: E402
 
-cfg = sys.argv[1] if len(sys.argv) > 1 else "cfg2_1M_150bp"
-threads = sys.argv[2] if len(sys.argv) > 2 else "16"
+import glob  # noqa: E402
+import shutil  # noqa: E402
+
+argv = [a for a in sys.argv[1:] if not a.startswith("--")]
+paired, compare = "--paired" in sys.argv, "--compare-dump" in sys.argv
+cfg = argv[0] if len(argv) > 0 else "cfg2_1M_150bp"
+threads = argv[1] if len(argv) > 1 else "16"
 n, L, G, seed, err = workload.CONFIGS[cfg]
 codes, _ = gen_reads.sample_reads(n, L, G, seed, err)
-out = {"config": cfg, "threads": int(threads)}
+out = {"config": cfg, "threads": int(threads), "paired": paired}
 with tempfile.TemporaryDirectory() as wd:
-    workload.write_fasta_fast(os.path.join(wd, "s.fasta"), codes)
+    if paired:
+        k = len(codes) // 2
+        workload.write_fasta_fast(os.path.join(wd, "s.fasta"), codes[0:2 * k:2])
+        workload.write_fasta_fast(os.path.join(wd, "s2.fasta"), codes[1:2 * k:2])
+        files = ["--file1=s.fasta", "--file2=s2.fasta"]
+    else:
+        workload.write_fasta_fast(os.path.join(wd, "s.fasta"), codes)
+        files = ["--file1=s.fasta"]
     exe = os.path.join(ROOT, "alga_amd", "bin", "alga_hip")
     for rep in range(3):                     # second run: file in the page cache, HIP runtime warm on disk
         t = time.perf_counter()
-        r = subprocess.run([exe, "--file1=s.fasta", "--threads=" + threads, "--output=o.fasta"], cwd=wd, stdout=subprocess.DEVNULL,
+        r = subprocess.run([exe] + files + ["--threads=" + threads, "--output=o.fasta"], cwd=wd, stdout=subprocess.DEVNULL,
                            stderr=subprocess.PIPE, text=True)
         out["alga_hip_wall_s_run%d" % rep] = time.perf_counter() - t
         m = re.search(r"HIP start-up ([\d.]+) ms", r.stderr)
@@ -37,11 +52,14 @@ with tempfile.TemporaryDirectory() as wd:
              out["alga_hip_graph_device_ms"]) = map(float, m.groups())
         m = re.search(r"Before first simplifier graph has (\d+) edges", r.stderr)
         out["alga_hip_edges"] = int(m.group(1)) if m else None
+    mine = glob.glob(os.path.join(wd, "*_beforeSimplifier.graph"))
+    if compare and mine:
+        shutil.move(mine[0], os.path.join(wd, "gpu.graph"))
     ref = os.path.join(ROOT, "oracle", "_ref", "ALGA")
     if os.path.exists(ref):
         t = time.perf_counter()
-        p = subprocess.Popen([ref, "--file1=s.fasta", "--threads=" + threads, "--output=r.fasta"], cwd=wd, stdout=subprocess.DEVNULL,
-                             stderr=subprocess.PIPE, text=True, errors="replace")
+        p = subprocess.Popen([ref] + files + ["--threads=" + threads, "--output=r.fasta"] + (["--serialize=1"] if compare else []), cwd=wd,
+                             stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, errors="replace")
         for line in p.stderr:
             if "Creating GraphCreator" in line:
                 out["ref_to_graph_creator_s"] = time.perf_counter() - t
@@ -52,4 +70,8 @@ with tempfile.TemporaryDirectory() as wd:
                 p.kill()
                 break
         p.wait()
+        if compare:
+            theirs = glob.glob(os.path.join(wd, "*_beforeSimplifier.graph"))
+            out["dump_bytes"] = os.path.getsize(theirs[0]) if theirs else None
+            out["dump_equal_to_reference"] = bool(theirs) and open(theirs[0], "rb").read() == open(os.path.join(wd, "gpu.graph"), "rb").read()
 print(json.dumps(out))
