@@ -253,20 +253,26 @@ __global__ void __launch_bounds__(256) k_tgt_dir(const uint32_t *__restrict__ ke
                                                   uint4 *__restrict__ dir) {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b > n_buckets) return;
-    const uint32_t s0 = idx[b], s1 = b < n_buckets ? idx[b + 1] : idx[b];
+    const uint32_t s0 = idx[b], s1 = idx[b < n_buckets ? b + 1 : b];     // two independent loads
     const uint32_t c = s1 - s0;
     uint32_t lo = 0u, hi = 0u;
     if (c > 0u && c <= 255u) {
-        uint32_t first[9];                                 // first[s] = entries with class < s
+        // first[s] = entries with class < s, eight saturation-free byte counters in two words (c <= 255).  Four keys per round
+        // trip: the loop runs as long as the fullest bucket of the wave needs, and every iteration is a memory latency
+        for (uint32_t j = s0; j < s1; j += 4u) {
+            uint32_t k4[4];
 #pragma unroll
-        for (int k = 0; k < 9; k++) first[k] = 0u;
-        for (uint32_t j = s0; j < s1; j++) {
-            const uint32_t cls = (keys[j] >> (shift - 3)) & 7u;   // top three bits of the m_C field
+            for (int u = 0; u < 4; u++) k4[u] = keys[j + u < s1 ? j + u : s1 - 1u];
 #pragma unroll
-            for (int k = 1; k < 9; k++) first[k] += cls < (uint32_t) k ? 1u : 0u;
+            for (int u = 0; u < 4; u++) {
+                if (j + u < s1) {
+                    const uint32_t cls = (k4[u] >> (shift - 3)) & 7u;   // top three bits of the m_C field
+                    // classes 0..2 raise first[1..3] (bytes 1..3 of lo), classes 0..6 raise first[4..7] where cls < s
+                    lo += (cls < 1u ? 0x00000100u : 0u) + (cls < 2u ? 0x00010000u : 0u) + (cls < 3u ? 0x01000000u : 0u);
+                    hi += (cls < 4u ? 0x00000001u : 0u) + (cls < 5u ? 0x00000100u : 0u) + (cls < 6u ? 0x00010000u : 0u) + (cls < 7u ? 0x01000000u : 0u);
+                }
+            }
         }
-        lo = first[0] | (first[1] << 8) | (first[2] << 16) | (first[3] << 24);
-        hi = first[4] | (first[5] << 8) | (first[6] << 16) | (first[7] << 24);
     }
     dir[b] = make_uint4(s0, c, lo, hi);
 }
