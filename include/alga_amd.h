@@ -4,8 +4,8 @@
  * This is the drop-in boundary for ONE path of swacisko/ALGA: the overlap-graph construction that
  * sits behind `class GraphCreator` (reference include/GraphCreators/GraphCreator.h:12-62) and is
  * selected in src/main.cpp:246-250.  Plain pointers and sizes only; no C++/torch types.
- * The reference-side binding (a GraphCreator subclass that marshals to these calls) is shown in
- * INTEGRATION.md.  Paths below are relative to the reference root.
+ * The reference-side bindings (GraphCreator subclasses that marshal to these calls) are
+ * alga_amd/host/adapter/*.h, described in INTEGRATION.md.  Paths below are relative to the reference root.
  *
  * Conventions
  *   - every call returns 0 on success or a negative alga_status; alga_last_error() gives the text.
@@ -56,7 +56,7 @@ typedef enum { ALGA_REDUCTION_AUTO = 0, ALGA_REDUCTION_PER_TARGET = 1, ALGA_REDU
  *   CLUSTER : clustered minimizer join -- targets sorted by the minimizer of their min_overlap-long prefix, ~3 contiguous
  *             lookups per source; takes max_len - min_overlap <= 63 and reads of up to 208 nt (every 100-150 bp configuration
  *             of ALGA's defaults), anything else uses TABLE;
- *   AUTO    : CLUSTER whenever it takes the input (1.2x faster at 1.7 M nodes, 2.4x at 90 M), else TABLE. */
+ *   AUTO    : CLUSTER whenever it takes the input (1.8x faster at 1.7 M nodes, 2.9x at 90 M), else TABLE. */
 typedef enum { ALGA_PROBE_AUTO = 0, ALGA_PROBE_TABLE = 1, ALGA_PROBE_CLUSTER = 2 } alga_probe;
 
 typedef struct alga_engine alga_engine; /* opaque */
