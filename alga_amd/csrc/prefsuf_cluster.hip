@@ -34,10 +34,10 @@ namespace alga {
 // order hash of a k-mer (lo: nucleotides 0..15, hi: 16..31, both masked to the k-mer's length): its top 24 bits rank the
 // k-mers of a window
 __device__ __forceinline__ uint32_t kmer_hash(uint32_t lo, uint32_t hi) {
-    uint32_t x = (lo ^ __funnelshift_l(hi, hi, 13) ^ (hi >> 7)) * 0x9E3779B1u;     // two multiplies: 32-bit integer multiplies are quarter rate
-    x ^= x >> 16;
-    x *= 0x2C1B3C6Du;
-    return x;
+    // ONE multiply (32-bit integer multiplies run at quarter rate; 13.6 G k-mers are hashed per build at the north-star size).  A
+    // second mixing round made no measurable difference to the minimizers' statistics (runs per node, entries per source, sources
+    // the pair kernel finishes): what has to be well mixed is the CLUSTER key, and that gets its own mix, once per run.
+    return (lo ^ __funnelshift_l(hi, hi, 13) ^ (hi >> 7)) * 0x9E3779B1u;
 }
 
 // Cluster key of a minimizer = a second, bijective mix of its order hash.  The order hashes of MINIMIZERS are minima of w

@@ -5,7 +5,7 @@
  * sits behind `class GraphCreator` (reference include/GraphCreators/GraphCreator.h:12-62) and is
  * selected in src/main.cpp:246-250.  Plain pointers and sizes only; no C++/torch types.
  * The reference-side bindings (GraphCreator subclasses that marshal to these calls) are
- * alga_amd/host/adapter/*.h, described in INTEGRATION.md.  Paths below are relative to the reference root.
+ * the headers under alga_amd/host/adapter/, described in INTEGRATION.md.  Paths below are relative to the reference root.
  *
  * Conventions
  *   - every call returns 0 on success or a negative alga_status; alga_last_error() gives the text.
