@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Randomised cross-check on the GPU: the two forms of the transitive reduction (per-target replay, source-side) must give
-the same edges on every input the source-side form accepts.  Random read lengths (fixed / variable), coverage, substitution
+the same edges on every input the source-side form accepts -- the source-side form through the seed-table probe, through the
+clustered probe with its pair kernel, and through the clustered probe's general kernel alone.  Random read lengths (fixed / variable), coverage, substitution
 errors, tandem repeats, exact duplicates and prefix reads left in, masks, min_overlap / rsoemo choices.
 usage: tools/stress_forms.py [n_cases=100] [first_seed=1000]"""
 import os
@@ -82,26 +83,39 @@ def main():
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
     eng = alga_amd.Engine(0)
     used, declined, bad = 0, 0, 0
-    big = generic = 0
+    big = generic = clustered = 0
     for seed in range(first, first + n_cases):
         words, lens, lo, rs, af, at, desc = make_case(seed)
         a = eng.prefsuf_host(words, lens, lo, rs, af, at, reduction="per_target")
-        try:
-            b = eng.prefsuf_host(words, lens, lo, rs, af, at, reduction="source_side", collect_stats=True)
-        except alga_amd.AlgaError as e:
-            if e.code != -7:
-                raise
+        ok = True
+        for probe, pairs in (("table", 1), ("cluster", 1), ("cluster", 0)):
+            eng.set_option("probe", probe)
+            eng.set_option("cluster_pairs", pairs)
+            try:
+                b = eng.prefsuf_host(words, lens, lo, rs, af, at, reduction="source_side", collect_stats=True)
+            except alga_amd.AlgaError as e:
+                if e.code != -7:
+                    raise
+                ok = False
+                break
+            finally:
+                eng.set_option("probe", "auto")
+                eng.set_option("cluster_pairs", 1)
+            st = eng.last_stats()
+            if probe == "table":
+                big += st["big_sources"] > 0
+                generic += st["generic_sources"] > 0
+            elif pairs:
+                clustered += st["probe_used"] == 2
+            if a.shape != b.shape or not (a == b).all():
+                bad += 1
+                print("MISMATCH", probe, pairs, desc, a.shape, b.shape, flush=True)
+        if not ok:
             declined += 1
             continue
-        st = eng.last_stats()
         used += 1
-        big += st["big_sources"] > 0
-        generic += st["generic_sources"] > 0
-        if a.shape != b.shape or not (a == b).all():
-            bad += 1
-            print("MISMATCH", desc, a.shape, b.shape, flush=True)
-    print("cases %d: source-side used %d (all-pairs branch in %d, second pass in %d), declined %d, mismatches %d" %
-          (n_cases, used, generic, big, declined, bad))
+    print("cases %d: source-side used %d (all-pairs branch in %d, second pass in %d, clustered probe in %d), declined %d, mismatches %d" %
+          (n_cases, used, generic, big, clustered, declined, bad))
     sys.exit(1 if bad else 0)
 
 
