@@ -270,6 +270,16 @@ def main():
             "algorithmic_bytes_total": alg["total"],
             "device": eng.device_name(),
         }
+        if world > 1:
+            # strong-scaling efficiency T1 / (N * TN) against the one-GPU time of the same workload recorded under profiles/ (the driver
+            # computes its own from its back-to-back runs; this one is for a reader of a single line)
+            try:
+                ref = json.loads(open(os.path.join(ROOT, "profiles", "r02_d_cfg4_50M_bench.json")).read().strip().splitlines()[-1])
+                if ref["config"]["nodes"] == n_nodes and ref["config"]["edges"] == int(n_edges):
+                    out["strong_scaling"] = {"t1_ms": ref["ms_per_step"], "t1_source": "profiles/r02_d_cfg4_50M_bench.json", "tn_ms": ms_step,
+                                             "efficiency": ref["ms_per_step"] / (world * ms_step)}
+            except Exception:
+                pass
         if world == 1 and not args.no_pcie:
             # the same graph through the host-buffer entry point (packed host reads in, host edge list out): never `value`
             if host_words is None:
