@@ -15,6 +15,7 @@
 // retainOnlySmallestOffset(); serializeGraph().  `cpu` takes the reference's own GraphCreatorPrefSuf / GraphCreatorLI,
 // `hip` the adapters: the two dumps must be identical (tests/test_adapter.py).
 // node file: i32 n, i32 W, i32 len[n], u32 words[n*W]   (reference bit layout; len 0 = nullptr)
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -77,10 +78,13 @@ int main(int argc, char **argv) {
         if ((*READS)[i] != nullptr && !graphCreator->getAlignFrom(i) && !graphCreator->getAlignTo(i)) Global::removeRead(i);
     for (int i = 0; i < G->size(); i++)
         if ((*READS)[i] == nullptr) { graphCreator->setAlignFrom(i, false); graphCreator->setAlignTo(i, false); }
+    if (hip) Params::THREADS = std::max(1u, std::thread::hardware_concurrency());   // only the adapter's marshalling and Graph::V fill use it
+    const auto t_creator = std::chrono::steady_clock::now();
     graphCreator->startAlignmentGraphCreation();
     graphCreator->clear();
     delete graphCreator;
     G->retainOnlySmallestOffset();
+    fprintf(stdout, "creator_region_ms %.1f\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_creator).count());
     fprintf(stdout, "edges %lld\n", (long long) G->countEdges());
     if (argc == 8) {
         // ---- the simplifier's first step (src/GraphSimplifiers/GraphSimplifier.cpp:113-117) ----
