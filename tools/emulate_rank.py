@@ -1,36 +1,61 @@
 #!/usr/bin/env python3
-"""One rank's compute of the weak-scaling bench at world size N, on ONE GPU: the node set of N x configs[1] is resident,
-the rank builds the edges of its 1/N of the sources (alga_prefsuf_build_range_device).  No collectives.
-  tools/emulate_rank.py [N=8] [config=cfg2_1M_150bp] [steps=5]"""
+"""One rank's COMPUTE of the strong-scaling bench at world size N, on ONE GPU (no collectives): the north-star node set is
+resident; the keys of the other ranks' nodes are put in place once, outside the timing (what the key all-gather delivers); timed
+per step: alga_prefsuf_keys_device on the rank's own nodes + alga_prefsuf_build_range_device(keys_shared) on its sources.
+DESIGN.md section 7 uses the result as the measured part of T_N; the two collectives (0.7 GB of keys, the rank's share of 1.1 GB
+of edges) come on top.
+  tools/emulate_rank.py [N=8] [n_reads=50000000] [genome=250000000] [steps=5]"""
 import json
+import os
 import sys
 import time
 
-import numpy as np
-import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
 
-import alga_amd
-from alga_amd import multigpu, workload
+import alga_amd  # noqa: E402
+from alga_amd import multigpu, workload  # noqa: E402
+from alga_amd.engine import device_view  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-cfg = sys.argv[2] if len(sys.argv) > 2 else "cfg2_1M_150bp"
-steps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
-t0 = time.time()
-wl = workload.build(cfg, scale=N, stride_words="aligned")
-print("workload built in %.1f s: %d nodes" % (time.time() - t0, len(wl["lens"])), flush=True)
-eng = alga_amd.Engine(0)
-dw = torch.from_numpy(wl["words"].view(np.int32)).cuda()
-dl = torch.from_numpy(wl["lens"]).cuda()
-n = len(wl["lens"])
+n_reads = int(sys.argv[2]) if len(sys.argv) > 2 else 50_000_000
+G = int(sys.argv[3]) if len(sys.argv) > 3 else 250_000_000
+steps = int(sys.argv[4]) if len(sys.argv) > 4 else 5
+wl = workload.device_build(n_reads, 150, G, 11)
+torch.cuda.synchronize()                                           # the engine's stream does not order with torch's
+dw, dl, lo, rs = wl["words"], wl["lens"], wl["min_overlap"], wl["rsoemo"]
+n = int(dl.shape[0])
 b = multigpu.shard_bounds(n, N)
-out = {"world": N, "nodes": n}
+eng, other = alga_amd.Engine(0), alga_amd.Engine(0)
+ko = other.keys_device(dw, dl, lo, rs, 0, n)                       # every node's keys, once
+assert ko is not None
+torch.cuda.synchronize()                                           # alga_prefsuf_keys_device does not end in a host sync
+all_keys = [device_view(p, (n,)).clone() for p in ko]
+other.close()
+torch.cuda.synchronize()
+out = {"world": N, "reads": n_reads, "nodes": n}
 for r in sorted(set([0, N - 1])):
-    ms = []
+    rows = []
     for it in range(steps + 1):
-        res = eng.build_range_device(dw, dl, wl["min_overlap"], wl["rsoemo"], b[r], b[r + 1])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        k = eng.keys_device(dw, dl, lo, rs, b[r], b[r + 1])
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for mine, full in zip(k, all_keys):                          # stands in for the all-gather (not timed)
+            v = device_view(mine, (n,))
+            v[:b[r]] = full[:b[r]]
+            v[b[r + 1]:] = full[b[r + 1]:]
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        res = eng.build_range_device(dw, dl, lo, rs, b[r], b[r + 1], keys_shared=True)
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
         st = eng.last_stats()
         if it:
-            ms.append((st["ms_seed"], st["ms_probe"], st["ms_emit"], st["ms_total"]))
-    a = np.mean(ms, axis=0)
-    out["rank%d" % r] = {"sources": b[r + 1] - b[r], "edges": res[1], "ms_seed": a[0], "ms_probe": a[1], "ms_emit": a[2], "ms_total": a[3]}
+            rows.append(((t1 - t0) * 1e3, st["ms_seed"], st["ms_probe"], st["ms_emit"], (t1 - t0 + t3 - t2) * 1e3))
+    a = [sum(x) / len(x) for x in zip(*rows)]
+    out["rank%d" % r] = {"sources": b[r + 1] - b[r], "edges": res[1], "ms_keys_own_nodes_wall": a[0], "ms_store_build": a[1], "ms_probe": a[2],
+                         "ms_emit": a[3], "ms_compute_wall": a[4]}
 print(json.dumps(out))
