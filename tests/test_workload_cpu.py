@@ -36,3 +36,25 @@ def test_write_fasta_fast_format(tmp_path):
     p = str(tmp_path / "x.fasta")
     workload.write_fasta_fast(p, codes)
     assert open(p).read() == ">r000000000\nACGT\n>r000000001\nTTAA\n"
+
+
+@pytest.mark.parametrize("err,seed", [(0.0, 13), (0.02, 13), (0.02, 5)])
+def test_device_generator_is_the_reference_node_set(tmp_path, err, seed):
+    """alga_amd.workload.device_build (bench.py's generator; torch ops, here on the CPU device): the node set it packs must be, as a
+    multiset of rows, what the reference's input stages make of the same reads -- the sample it hands to the CPU baseline IS the
+    read set when the window covers the genome.  With errors two reads are duplicates when they start at the same position and
+    carry the same errors in the part that survives the end trimming."""
+    torch = pytest.importorskip("torch")
+    wl = workload.device_build(20000, 150, 60000, seed, device="cpu", err=err, sample_reads=20000, chunk=4096)
+    codes = wl["sample_codes"]
+    assert codes.shape == (wl["unique_reads"], 150)
+    path = str(tmp_path / "reads.fasta")
+    workload.write_fasta_fast(path, codes)
+    nd = O.ingest(path)
+    mine = np.ascontiguousarray(wl["words"].numpy().view(np.uint32))
+    assert mine.shape[0] == nd["n"] and (wl["lens"].numpy() == nd["len"][0]).all()
+    W = nd["words"].shape[1]
+    assert not mine[:, W:].any()
+    key = lambda a: np.sort(np.ascontiguousarray(a[:, :W]).view([("", np.uint32)] * W).ravel())      # noqa: E731
+    assert (key(mine) == key(nd["words"])).all()
+    assert (wl["min_overlap"], wl["rsoemo"]) == (nd["min_overlap"], nd["rsoemo"])
