@@ -196,8 +196,12 @@ void parallel_sort(It b, It e, Cmp cmp, int threads) {
     }
 }
 
-struct Lap {
-    bool on = getenv("ALGA_INGEST_TIMING") != nullptr;
+struct Lap {                                               // stage timings on stderr: compile with -DALGA_INGEST_TIMING
+#ifdef ALGA_INGEST_TIMING
+    bool on = true;
+#else
+    bool on = false;
+#endif
     std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
     void operator()(const char *what) {
         if (!on) return;
