@@ -131,6 +131,7 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
     if (pp.live >= (1ull << 31)) return alga_fail(e, ALGA_ERR_CAPACITY, "too many nodes for one seed table; shard the input");
     const bool clustered = local && pp.cluster_eq != 0;
     e->pairs_timed = false;
+    e->loc_second_used = false;
     uint32_t n_buckets = 0, filter_bits = 0;
     bool have_table = false;
     auto build_table = [&]() -> int {                      // bucketised seed table + prefilter of prefsuf_kernels.hip
@@ -198,9 +199,11 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
             const bool pairs = e->opt_cluster_pairs && e->cl_defer_ratio <= 0.5;
             if (pairs) {
                 if ((rc = alga_ensure(e, e->cl_defer, (size_t) (n_src + 64) * sizeof(int32_t)))) return rc;
+                if ((rc = alga_ensure(e, e->loc_second, (size_t) (n_src + 1) * sizeof(unsigned long long)))) return rc;
+                e->loc_second_used = true;
                 launch_probe_pairs(nd, cfg, cc, pp.cluster_eq, e->cl_store.p, e->cl_dir.p, e->cl_runs.p, (const uint8_t *) e->cl_nruns.p,
-                                   src_begin, src_end, cnt, e->n_cu, (uint32_t *) e->outdeg.p, (unsigned long long *) e->loc_first.p, (int32_t *) e->cl_defer.p,
-                                   (uint32_t) n_src, s);
+                                   src_begin, src_end, cnt, e->n_cu, (uint32_t *) e->outdeg.p, (unsigned long long *) e->loc_first.p,
+                                   (unsigned long long *) e->loc_second.p, (int32_t *) e->cl_defer.p, (uint32_t) n_src, s);
                 if ((rc = alga_check_launch(e, "k_probe_pairs"))) return rc;
                 HIP_TRY(e, hipEventRecord(e->ev[EV_PAIRS], s));
                 e->pairs_timed = true;
@@ -358,7 +361,7 @@ int finalize_local(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_
     if (E >= (1ull << 32) - 16) return alga_fail(e, ALGA_ERR_CAPACITY, "more than 2^32 edges; shard the input");
     if ((rc = alga_ensure(e, e->edges, (size_t) (E + 1) * sizeof(alga_edge_dev)))) return rc;
     launch_local_emit(src_begin, (int32_t) n_src, (const uint32_t *) e->outdeg.p, (const unsigned long long *) e->loc_first.p,
-                      (const uint32_t *) e->rec_dst.p, (const unsigned long long *) e->rec_val.p, n_rec, (const uint32_t *) e->out_rowptr.p,
+                      e->loc_second_used ? (const unsigned long long *) e->loc_second.p : nullptr, (const uint32_t *) e->rec_dst.p, (const unsigned long long *) e->rec_val.p, n_rec, (const uint32_t *) e->out_rowptr.p,
                       (uint32_t *) e->out_cnt.p, (alga_edge_dev *) e->edges.p, s);
     if ((rc = alga_check_launch(e, "k_local_emit"))) return rc;
     HIP_TRY(e, hipEventRecord(e->ev[EV_EMIT], s));

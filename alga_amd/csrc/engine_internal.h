@@ -42,6 +42,8 @@ struct alga_engine {
     double cl_defer_ratio = 0.0;                            // ... their share in the last build: above one half the pair kernel is skipped
     int    opt_cluster_pairs = 1;                           // option "cluster_pairs": 0 = general kernel only
     DevBuf cl_keys[2], cl_vals[2], cl_meta, cl_runs, cl_nruns, cl_store, cl_idx, cl_dir;   // clustered minimizer join: sort buffers, per-node minimizer runs, entry array, bucket index
+    DevBuf loc_second;                                      // ... the other edge of a two-edge source the pair kernel finished (clustered probe)
+    bool   loc_second_used = false;                         // the last discovery wrote loc_second
     DevBuf loc_first, loc_big_list, loc_big_items;          // source-side form: one-edge slots; second pass over repeat-rich sources
     int    big_limit = -1;                                  // largest per-wave item slice of that pass; -1 = built-in (option "local_big_max": tests)
     DevBuf edge_keys, edge_keys2, edge_vals, edge_vals2, edges_sorted, xs_dst, xs_val;

@@ -845,6 +845,33 @@ k_probe_pairs(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__restric
                 o.deg[B - o.src_base] = 1u;
                 st_rec++;
             }
+            // Two items stand (a coverage gap too long for any big via; 1.7 % of the sources at 30x): the rest of local_reduce's
+            // "several stand" branch for exactly two -- the per-source cap (with one item per offset the three largest small (L, C)
+            // are the three small items at the smallest offsets) and "the same target at a smaller offset supersedes" -- and the
+            // one or two edges go to the source's two slots.
+            const bool two = packable && one_per_offset && !any_fail && n_surv == 2 && o.second != nullptr;
+            if (__ballot(two) != 0ull) {                       // uniform
+                const uint32_t km = half_of(__ballot(keep));
+                const int la = (h << 5) + (km ? __builtin_ctz(km) : 0), lb = (h << 5) + (km ? 31 - __builtin_clz(km) : 0);
+                const int ds0 = lenB - cfg.rsoemo + 1;                          // first offset of a small overlap
+                const uint64_t lowm = ds0 <= 0 ? 0ull : (ds0 >= 64 ? ~0ull : ((1ull << ds0) - 1ull));
+                const bool my_kept = pass && (d < ds0 || __popcll(below & ~lowm) < 3);
+                const uint32_t Ca = bperm(id, la), Cb = bperm(id, lb);
+                const int da = (int) bperm((uint32_t) d, la), db = (int) bperm((uint32_t) d, lb);
+                const bool ka = bperm(my_kept ? 1u : 0u, la) != 0u, kb = bperm(my_kept ? 1u : 0u, lb) != 0u;
+                const bool fa = ka && half_of(__ballot(my_kept && id == Ca && d < da)) == 0u;
+                const bool fb = kb && half_of(__ballot(my_kept && id == Cb && d < db)) == 0u;
+                if (two) {
+                    const unsigned long long mine = ((unsigned long long) id << 32) | (uint32_t) d;
+                    if (lane == la && fa) { o.first[B - o.src_base] = mine; o.deg[B - o.src_base] = (fb ? 2u : 1u); st_rec++; }
+                    if (lane == lb && fb) {
+                        if (fa) o.second[B - o.src_base] = mine;
+                        else { o.first[B - o.src_base] = mine; o.deg[B - o.src_base] = 1u; }
+                        st_rec++;
+                    }
+                    reduced = true;
+                }
+            }
             if (STATS && reduced) { st_raw += pass; st_cmp += has_pred; }
         }
         if (STATS && reduced) { st_slots += ev; if (hl == 0) st_win += (uint64_t) nwin; }
@@ -949,12 +976,12 @@ uint64_t cluster_record_slack(int n_cu, uint64_t n_src) { return cluster_probe_b
 // the pair kernel over the sources src_begin .. src_end - 1: regular sources get their edge, the others go on defer_list
 void launch_probe_pairs(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterCfg &cc, int eq, const void *store, const void *dir,
                         const void *runs, const uint8_t *nruns, int32_t src_begin, int32_t src_end, unsigned long long *counters, int n_cu, uint32_t *deg,
-                        unsigned long long *first, int32_t *defer_list, uint32_t defer_cap, hipStream_t s) {
+                        unsigned long long *first, unsigned long long *second, int32_t *defer_list, uint32_t defer_cap, hipStream_t s) {
     const int64_t ns = (int64_t) src_end - src_begin;
     if (ns <= 0) return;
     const uint64_t pairs = ((uint64_t) ns + 1) / 2;
     dim3 grid((unsigned) std::max<uint64_t>(1, std::min<uint64_t>((pairs + PROBE_WAVES - 1) / PROBE_WAVES, (uint64_t) std::max(1, n_cu) * CLP_OCC))), block(PROBE_WAVES * 64);
-    ProbeOut o{nullptr, nullptr, 0, counters, deg, first, src_begin};
+    ProbeOut o{nullptr, nullptr, 0, counters, deg, first, src_begin, second};
     const uint4 *st = (const uint4 *) store;
     const int kf = (2 * cfg.Lmin) >> 5;
 #define CLP_LAUNCH(ST, E, K) hipLaunchKernelGGL((k_probe_pairs<ST, E, K>), grid, block, 0, s, nd, cfg, cc, st, (const uint4 *) dir, (const uint2 *) runs, nruns, src_begin, src_end, o, defer_list, defer_cap)

@@ -128,6 +128,7 @@ struct ProbeOut {
     uint32_t *__restrict__ deg = nullptr;
     unsigned long long *__restrict__ first = nullptr;
     int32_t src_base = 0;
+    unsigned long long *__restrict__ second = nullptr;     // pair kernel of the clustered probe: the other edge of a two-edge source
     // sources with more raw overlaps than a wave's LDS holds (repeats): the first pass lists them, a second pass (BIG
     // instantiation of the kernel) walks the list with the items in a global slice per wave
     int32_t *__restrict__ big_list = nullptr;

@@ -31,8 +31,8 @@ void launch_probe(const NodesDev &nd, const PrefSufCfg &cfg, const unsigned long
                   const ProbeBig *big /* local: may be null */, hipStream_t s);
 uint64_t probe_record_slack(int n_cu, uint64_t n_src, bool local);
 // source-side reduction: adjacency lists from the probe's out-degrees (rowptr = their scan), one-edge slots and record list
-void launch_local_emit(int32_t src_base, int32_t n_src, const uint32_t *deg, const unsigned long long *first, const uint32_t *rec_dst,
-                       const unsigned long long *rec_val, uint64_t n_rec, const uint32_t *rowptr, uint32_t *cursor /* zeroed, n_src */,
+void launch_local_emit(int32_t src_base, int32_t n_src, const uint32_t *deg, const unsigned long long *first, const unsigned long long *second,
+                       const uint32_t *rec_dst, const unsigned long long *rec_val, uint64_t n_rec, const uint32_t *rowptr, uint32_t *cursor,
                        alga_edge_dev *edges, hipStream_t s);
 
 // clustered minimizer join (prefsuf_cluster.hip): source-side form with one-word offset masks (max_len - Lmin <= 63)
@@ -47,7 +47,7 @@ hipError_t launch_cluster_store(const NodesDev &nd, const ClusterCfg &cc, int eq
 uint64_t   cluster_record_slack(int n_cu, uint64_t n_src);
 void       launch_probe_pairs(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterCfg &cc, int eq, const void *store, const void *dir,
                               const void *runs, const uint8_t *nruns, int32_t src_begin, int32_t src_end, unsigned long long *counters, int n_cu, uint32_t *deg,
-                              unsigned long long *first, int32_t *defer_list, uint32_t defer_cap, hipStream_t s);
+                              unsigned long long *first, unsigned long long *second, int32_t *defer_list, uint32_t defer_cap, hipStream_t s);
 void       launch_probe_clustered(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterCfg &cc, int eq, const void *store, const void *dir,
                                   const void *runs, const uint8_t *nruns, int32_t src_begin, int32_t src_end, const int32_t *src_list, int32_t src_base, uint32_t *rec_dst, unsigned long long *rec_val, uint64_t rec_cap,
                                   unsigned long long *counters, int n_cu, uint32_t *deg, unsigned long long *first, const ProbeBig *big, hipStream_t s);

@@ -930,16 +930,26 @@ __global__ void __launch_bounds__(256) k_keys_to_edges(const unsigned long long 
 // Source-side form, final adjacency lists of the sources [src_base, src_base + n_src): the row pointers are the scan of
 // the out-degrees the probe wrote; a one-edge source (the fast path) left its edge in first[], every other source's edges
 // are in the record list and take their slot with a cursor (rows with more than one edge are ordered by k_sort_rows).
+// `second` (may be null): a source with out-degree 2 whose first slot is set has its other edge there (the pair kernel of the
+// clustered probe finishes two-edge sources in slots too); k_sort_rows orders the two.
 __global__ void __launch_bounds__(256) k_local_emit_first(int32_t src_base, int32_t n_src, const uint32_t *__restrict__ deg,
-                                                           const unsigned long long *__restrict__ first, const uint32_t *__restrict__ rowptr,
-                                                           alga_edge_dev *__restrict__ edges) {
+                                                           const unsigned long long *__restrict__ first, const unsigned long long *__restrict__ second,
+                                                           const uint32_t *__restrict__ rowptr, alga_edge_dev *__restrict__ edges) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_src || deg[i] == 0) return;
+    if (i >= n_src) return;
+    const uint32_t dg = deg[i];
+    if (dg == 0) return;
     const unsigned long long f = first[i];
     if (f == LOCAL_FIRST_NONE) return;
     alga_edge_dev e;
     e.src = src_base + i; e.dst = (int32_t) (uint32_t) (f >> 32); e.offset = (int32_t) (uint32_t) f;
-    edges[rowptr[i]] = e;
+    const uint32_t at = rowptr[i];
+    edges[at] = e;
+    if (dg == 2u && second != nullptr) {
+        const unsigned long long g = second[i];
+        e.dst = (int32_t) (uint32_t) (g >> 32); e.offset = (int32_t) (uint32_t) g;
+        edges[at + 1] = e;
+    }
 }
 
 __global__ void __launch_bounds__(256) k_local_emit_records(int32_t src_base, const uint32_t *__restrict__ rec_dst,
@@ -1083,11 +1093,11 @@ void launch_probe(const NodesDev &nd, const PrefSufCfg &cfg, const unsigned long
     else                                           launch_probe_nq<0>(nd, cfg, t, local, src_begin, src_end, o, grid, block, s);
 }
 
-void launch_local_emit(int32_t src_base, int32_t n_src, const uint32_t *deg, const unsigned long long *first, const uint32_t *rec_dst,
-                       const unsigned long long *rec_val, uint64_t n_rec, const uint32_t *rowptr, uint32_t *cursor, alga_edge_dev *edges,
-                       hipStream_t s) {
+void launch_local_emit(int32_t src_base, int32_t n_src, const uint32_t *deg, const unsigned long long *first, const unsigned long long *second,
+                       const uint32_t *rec_dst, const unsigned long long *rec_val, uint64_t n_rec, const uint32_t *rowptr, uint32_t *cursor,
+                       alga_edge_dev *edges, hipStream_t s) {
     if (n_src <= 0) return;
-    hipLaunchKernelGGL(k_local_emit_first, dim3(grid_for((uint64_t) n_src, 256)), dim3(256), 0, s, src_base, n_src, deg, first, rowptr, edges);
+    hipLaunchKernelGGL(k_local_emit_first, dim3(grid_for((uint64_t) n_src, 256)), dim3(256), 0, s, src_base, n_src, deg, first, second, rowptr, edges);
     if (n_rec) {
         unsigned g = std::min<unsigned>(grid_for(n_rec, 256), 4096u);
         hipLaunchKernelGGL(k_local_emit_records, dim3(std::max(1u, g)), dim3(256), 0, s, src_base, rec_dst, rec_val, n_rec, rowptr, cursor, edges);
