@@ -34,7 +34,8 @@ struct Prepared {
     int        cluster_eq = 0;       // clustered minimizer probe: 16-byte pieces per entry (0 = that probe does not take this input)
     ClusterCfg cluster{};
     int        reduction = ALGA_REDUCTION_AUTO;
-    bool       keys_shared = false;  // the per-node keys come from alga_prefsuf_keys_device + the caller's all-gather
+    int        keys_shared = 0;      // 1: the per-node keys come from alga_prefsuf_keys_device + the caller's all-gather; 2: the whole
+                                     // entry array of the previous build of this node set is reused
 };
 
 // Validates arguments, measures max read length / live nodes on the device and derives the
@@ -56,13 +57,23 @@ int prepare(alga_engine *e, const alga_nodes *nodes, const alga_prefsuf_params *
     nd.n = nodes->n; nd.stride = nodes->stride_words;
     unsigned long long *cnt = (unsigned long long *) e->counters.p;
     int *d_maxlen = (int *) (cnt + CNT_TOTAL);
-    launch_node_stats(nd, cnt, d_maxlen, s);
-    if ((rc = alga_check_launch(e, "k_node_stats"))) return rc;
-    HIP_TRY(e, hipMemcpyAsync(e->h_counters, e->counters.p, (CNT_TOTAL + 2) * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-    HIP_TRY(e, hipStreamSynchronize(s));
+    unsigned long long mask_asym = 0;
+    if (p->keys_shared == 2 && e->store_n == nodes->n && e->store_words == (const void *) nodes->words && e->stat_len == (const void *) nodes->len &&
+        e->stat_from == (const void *) nodes->align_from && e->stat_to == (const void *) nodes->align_to) {
+        // a further piece of the build that measured this node set last (keys_shared = 2 promises nothing came in between)
+        out.max_len = e->stat_max_len; out.live = e->stat_live; mask_asym = e->stat_mask_asym;
+    } else {
+        launch_node_stats(nd, cnt, d_maxlen, s);
+        if ((rc = alga_check_launch(e, "k_node_stats"))) return rc;
+        HIP_TRY(e, hipMemcpyAsync(e->h_counters, e->counters.p, (CNT_TOTAL + 2) * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        HIP_TRY(e, hipStreamSynchronize(s));
+        out.max_len = (int) (e->h_counters[CNT_TOTAL] & 0xFFFFFFFFull);
+        out.live = e->h_counters[CNT_LIVE_NODES];
+        mask_asym = e->h_counters[CNT_MASK_ASYM];
+        e->stat_max_len = out.max_len; e->stat_live = out.live; e->stat_mask_asym = mask_asym;
+        e->stat_len = (const void *) nodes->len; e->stat_from = (const void *) nodes->align_from; e->stat_to = (const void *) nodes->align_to;
+    }
     out.nd = nd;
-    out.max_len = (int) (e->h_counters[CNT_TOTAL] & 0xFFFFFFFFull);
-    out.live = e->h_counters[CNT_LIVE_NODES];
     if ((int64_t) blocks_of(out.max_len) > (int64_t) nodes->stride_words)
         return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "stride_words is smaller than the longest read needs");
     if (out.max_len > OL_MAX_NODE_LEN) return alga_fail(e, ALGA_ERR_CAPACITY, "a node is longer than 4 194 303 nt (overlap records keep the offset in 22 bits)");
@@ -84,7 +95,7 @@ int prepare(alga_engine *e, const alga_nodes *nodes, const alga_prefsuf_params *
         return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "reduction must be an alga_reduction value");
     // preconditions of the source-side reduction (prefsuf_device.h: local_reduce; tests/source_side_rule.py)
     out.local_ok = out.max_len <= p->max_len_cap && out.max_len - c.Lmin <= LOCAL_MAX_SPAN && c.Lmin <= c.rsoemo && c.rsoemo <= c.Lcap &&
-                   e->h_counters[CNT_MASK_ASYM] == 0;
+                   mask_asym == 0;
     out.local_sw = out.max_len - c.Lmin <= 63 ? 1 : 2;
     // Which probe feeds the source-side form.  The clustered minimizer join (prefsuf_cluster.hip) takes one-word offset masks and
     // rows of up to 13 words; AUTO uses it whenever it takes the input (measured faster than the seed-table probe from 1.7 M
@@ -94,7 +105,8 @@ int prepare(alga_engine *e, const alga_nodes *nodes, const alga_prefsuf_params *
         int eq = 0;
         if (cluster_plan(c, out.max_len, out.live, e->opt_cluster_bucket_bias, &out.cluster, &eq)) out.cluster_eq = eq;
     }
-    out.keys_shared = p->keys_shared != 0;
+    if (p->keys_shared < 0 || p->keys_shared > 2) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "keys_shared must be 0, 1 or 2");
+    out.keys_shared = p->keys_shared;
     out.reduction = p->reduction;
     if (out.reduction == ALGA_REDUCTION_AUTO && e->opt_force_per_target) out.reduction = ALGA_REDUCTION_PER_TARGET;
     return ALGA_OK;
@@ -156,20 +168,33 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
         // targets in minimizer-hash order: sort keys, entry array, bucket index
         cc = pp.cluster;
         if ((rc = cluster_alloc(e, pp))) return rc;
-        if (pp.keys_shared) {
-            // keys / meta of every node are in place (this rank's share by alga_prefsuf_keys_device, the others' by the caller's
-            // all-gather); the runs of this rank's share are what the probe of [src_begin, src_end) reads
-            if (e->keyed_n != nd.n || e->keyed_words != (const void *) nd.words || src_begin < e->keyed_begin || src_end > e->keyed_end)
-                return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "keys_shared: alga_prefsuf_keys_device has not been called on this node set for a range that covers the sources");
+        if (pp.keys_shared == 2) {
+            // the entry array, index, directory and runs of the previous build are still what this node set needs (a rank that
+            // builds its source range in several pieces so that the gather of one piece overlaps the probe of the next)
+            if (e->store_n != nd.n || e->store_words != (const void *) nd.words || e->store_eq != pp.cluster_eq || e->store_buckets != cc.n_buckets ||
+                src_begin < e->store_run_begin || src_end > e->store_run_end)
+                return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "keys_shared = 2: no entry array of this node set that covers the sources is left from the previous build");
         } else {
-            launch_cluster_keys(nd, cfg, cc, 0, nd.n, (uint32_t *) e->cl_keys[0].p, (uint32_t *) e->cl_vals[0].p, (uint32_t *) e->cl_meta.p, e->cl_runs.p,
-                                (uint8_t *) e->cl_nruns.p, s);
-            if ((rc = alga_check_launch(e, "k_node_runs"))) return rc;
+            int32_t run_begin = 0, run_end = nd.n;
+            if (pp.keys_shared == 1) {
+                // keys / meta of every node are in place (this rank's share by alga_prefsuf_keys_device, the others' by the caller's
+                // all-gather); the runs of this rank's share are what the probe of [src_begin, src_end) reads
+                if (e->keyed_n != nd.n || e->keyed_words != (const void *) nd.words || src_begin < e->keyed_begin || src_end > e->keyed_end)
+                    return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "keys_shared: alga_prefsuf_keys_device has not been called on this node set for a range that covers the sources");
+                run_begin = e->keyed_begin; run_end = e->keyed_end;
+            } else {
+                launch_cluster_keys(nd, cfg, cc, 0, nd.n, (uint32_t *) e->cl_keys[0].p, (uint32_t *) e->cl_vals[0].p, (uint32_t *) e->cl_meta.p, e->cl_runs.p,
+                                    (uint8_t *) e->cl_nruns.p, s);
+                if ((rc = alga_check_launch(e, "k_node_runs"))) return rc;
+            }
+            e->keyed_n = -1;                               // the sort below may reuse the key buffers: one build per key pass
+            e->store_n = -1;
+            HIP_TRY(e, launch_cluster_store(nd, cc, pp.cluster_eq, (uint32_t *) e->cl_keys[0].p, (uint32_t *) e->cl_vals[0].p, (uint32_t *) e->cl_keys[1].p,
+                                            (uint32_t *) e->cl_vals[1].p, (const uint32_t *) e->cl_meta.p, e->sort_temp.p, cluster_sort_temp_bytes((uint64_t) nd.n),
+                                            e->cl_store.p, (uint32_t *) e->cl_idx.p, e->cl_dir.p, pp.keys_shared == 1, s));
+            e->store_n = nd.n; e->store_words = (const void *) nd.words; e->store_eq = pp.cluster_eq; e->store_buckets = cc.n_buckets;
+            e->store_run_begin = run_begin; e->store_run_end = run_end;
         }
-        e->keyed_n = -1;                                   // the sort below may reuse the key buffers: one build per key pass
-        HIP_TRY(e, launch_cluster_store(nd, cc, pp.cluster_eq, (uint32_t *) e->cl_keys[0].p, (uint32_t *) e->cl_vals[0].p, (uint32_t *) e->cl_keys[1].p,
-                                        (uint32_t *) e->cl_vals[1].p, (const uint32_t *) e->cl_meta.p, e->sort_temp.p, cluster_sort_temp_bytes((uint64_t) nd.n),
-                                        e->cl_store.p, (uint32_t *) e->cl_idx.p, e->cl_dir.p, pp.keys_shared, s));
         e->stats.table_slots = cc.n_buckets;
     } else if ((rc = build_table())) return rc;
     HIP_TRY(e, hipEventRecord(e->ev[EV_SEED], s));
@@ -683,6 +708,7 @@ int alga_prefsuf_keys_device(alga_engine *e, const alga_nodes *nodes, const alga
     if (!out) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "output pointer must not be NULL");
     memset(out, 0, sizeof(*out));
     e->keyed_n = -1;
+    e->store_n = -1;                                       // the key pass rewrites runs and keys
     HIP_TRY(e, hipSetDevice(e->device));
     hipStream_t s = hip_stream ? (hipStream_t) hip_stream : e->own_stream;
     Prepared pp;

@@ -38,6 +38,13 @@ struct alga_engine {
     // params.keys_shared
     int32_t keyed_n = -1, keyed_begin = 0, keyed_end = 0;
     const void *keyed_words = nullptr;
+    // the entry array / index / directory / runs left by the last clustered build (n < 0: none): reusable with params.keys_shared = 2
+    int32_t store_n = -1, store_run_begin = 0, store_run_end = 0, store_eq = 0;
+    uint32_t store_buckets = 0;
+    const void *store_words = nullptr;
+    // node statistics of the last prepare() (k_node_stats): reused by the further pieces of a build (params.keys_shared = 2)
+    int stat_max_len = 0; uint64_t stat_live = 0; unsigned long long stat_mask_asym = 0;
+    const void *stat_len = nullptr, *stat_from = nullptr, *stat_to = nullptr;
     bool   pairs_timed = false;                             // EV_PAIRS was recorded in the last discovery
     double cl_defer_ratio = 0.0;                            // ... their share in the last build: above one half the pair kernel is skipped
     int    opt_cluster_pairs = 1;                           // option "cluster_pairs": 0 = general kernel only

@@ -453,10 +453,11 @@ class Engine:
                            stream=None, collect_stats=False, keys_shared=False):
         """Final edges of the sources [src_begin, src_end) by the source-side reduction -> (ptr, n_edges), or None when
         that form is not exact for the input (ALGA_ERR_UNSUPPORTED): the caller then takes discover/exchange/reduce.
-        keys_shared: keys_device + the all-gather of its arrays came first (include/alga_amd.h)."""
+        keys_shared: 1/True = keys_device + the all-gather of its arrays came first; 2 = reuse the entry array of the previous build
+        of the same node set (include/alga_amd.h)."""
         nd = self._nodes_from_torch(words, lens, align_from, align_to)
         p = self.params(min_overlap, rsoe_min_overlap, collect_stats)
-        p.keys_shared = 1 if keys_shared else 0
+        p.keys_shared = int(keys_shared)
         out = C.c_void_p()
         m = C.c_uint64()
         rc = self._lib.alga_prefsuf_build_range_device(self._h, C.byref(nd), C.byref(p), int(src_begin), int(src_end),

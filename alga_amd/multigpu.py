@@ -87,7 +87,7 @@ class HipBackend:
         assert span <= self.n + KEY_ARRAY_SLACK
         return [device_view(p, (span,), self.device) for p in r]
 
-    def build_range(self, src_begin, src_end, collect_stats=False, keys_shared=False):
+    def build_range(self, src_begin, src_end, collect_stats=False, keys_shared=0):
         """Final edges of the sources in the range (tensor [m, 3]) or None when the source-side form is not exact here."""
         from .engine import device_view
         r = self.eng.build_range_device(self.w, self.l, self.lo, self.rs, src_begin, src_end, collect_stats=collect_stats, stream=self._stream(),
@@ -129,9 +129,13 @@ class ShardedPrefSuf:
     simplifier / contig stages afterwards -- with direct sends over each peer's own xGMI link (`gather`); the other ranks keep
     an empty tensor.  replicate=True: every rank gets it (`all_gather`, 8x the traffic at 8 GPUs)."""
 
-    def __init__(self, backend, rank=0, world=1, dist=None, replicate=False, shard_keys=True):
+    def __init__(self, backend, rank=0, world=1, dist=None, replicate=False, shard_keys=True, pieces=None):
         self.be, self.rank, self.world, self.dist = backend, rank, world, dist
         self.replicate = replicate
+        # source-side form: pieces of a rank's source range (the transfer of one overlaps the probe of the next).  A piece costs ~0.3 ms
+        # of its own (launches, host syncs, thinner kernels), the transfer it hides shrinks with the number of links in use: 4 pieces
+        # up to 4 ranks, 2 at 8, 1 beyond
+        self.pieces = max(1, int(pieces)) if pieces is not None else min(4, max(1, 16 // max(1, world)))
         self.shard_keys = shard_keys           # False: every rank computes the keys of all nodes itself (no key all-gather)
         self.n = backend.n
         self.bounds = shard_bounds(self.n, world)
@@ -167,20 +171,43 @@ class ShardedPrefSuf:
                 t.copy_(full)
                 del full
         ms_keys = (time.perf_counter() - t_keys) * 1e3
-        mine = be.build_range(b[r], b[r + 1], collect_stats, keys_shared=karr is not None)
-        meta = torch.tensor([0 if mine is not None else 1, 0 if mine is None else int(mine.shape[0])], dtype=torch.int64, device=dev)
-        allmeta = torch.empty(2 * nr, dtype=torch.int64, device=dev)
-        dist.all_gather_into_tensor(allmeta, meta)
-        allmeta = allmeta.cpu().view(nr, 2)
-        if int(allmeta[:, 0].max()) == 0:
-            st = dict(be.stats)
-            st["ms_keys_shared"] = ms_keys if karr is not None else 0.0       # host clock: key pass of my nodes + all-gather (enqueue; the build waits for it on the stream)
+        # The rank's source range in `pieces` consecutive pieces (the first one sorts the gathered keys into the entry array, the
+        # others reuse it): the edges of a piece travel to rank 0 while the next piece is probed.  Per piece one small all_gather
+        # carries every rank's "declined" flag and edge count.
+        pieces = self.pieces if karr is not None else 1
+        pb = [b[r] + 2 * (((b[r + 1] - b[r]) // 2 * k) // pieces) for k in range(pieces)] + [b[r + 1]]
+        st, pending, declined = None, [], False
+        t_wait = 0.0
+        for k in range(pieces):
+            mine = be.build_range(pb[k], pb[k + 1], collect_stats, keys_shared=(1 if karr is not None else 0) if k == 0 else 2)
+            meta = torch.tensor([0 if mine is not None else 1, 0 if mine is None else int(mine.shape[0])], dtype=torch.int64, device=dev)
+            allmeta = torch.empty(2 * nr, dtype=torch.int64, device=dev)
+            dist.all_gather_into_tensor(allmeta, meta)
+            allmeta = allmeta.cpu().view(nr, 2)
+            if int(allmeta[:, 0].max()) != 0:
+                declined = True
+                break
+            ps = dict(be.stats)
+            if st is None:
+                st = ps
+            else:
+                for kk, v in ps.items():
+                    if kk.startswith("ms_") or kk in ("windows_probed", "slots_scanned", "raw_overlaps", "records", "transitive_compares", "generic_sources",
+                                                       "big_sources", "deferred_sources", "edges"):
+                        st[kk] = st.get(kk, 0) + v
+            pending.append(self._gather_start(mine, [int(x) for x in allmeta[:, 1]]))
+        if not declined:
             t2 = time.perf_counter()
-            self.edges = self._gather(mine, ordered=True, counts=[int(x) for x in allmeta[:, 1]])
+            self.edges = self._gather_finish(pending)
             be.sync()
-            st["edges"] = int(allmeta[:, 1].sum())
-            st["ms_exchange"] = (time.perf_counter() - t2) * 1e3
+            st["ms_keys_shared"] = ms_keys if karr is not None else 0.0       # host clock: key pass of my nodes + all-gather (enqueue; the build waits for it on the stream)
+            st["edges"] = self.total_edges
+            st["ms_exchange"] = (time.perf_counter() - t2) * 1e3               # what was left of the gathers after the last piece's probe
             return self._finish(st, collect_stats)
+        for w in pending:                                                      # a rank declined (capacity case): all take the general form
+            if w[0] is not None:
+                w[0].wait()
+        del pending
         # 1. discover + order by target
         rdst, rval = be.discover_sorted(b[r], b[r + 1], collect_stats)
         st = dict(be.stats)
@@ -210,6 +237,36 @@ class ShardedPrefSuf:
         st["edges"] = self.total_edges
         st["ms_exchange"] = (t1 - t0) * 1e3 + (t3 - t2) * 1e3
         return self._finish(st, collect_stats)
+
+    def _gather_start(self, mine, counts):
+        """Start moving one piece of every rank's edge list to rank 0 (or to every rank): -> (work, receive buffers, counts)."""
+        import torch
+        dist, nr, dev = self.dist, self.world, self.be.device
+        m = int(mine.shape[0])
+        mx = max(max(counts), 1)
+        local = torch.zeros((mx, 3), dtype=torch.int32, device=dev)         # also the copy out of the engine's buffer, which the next piece reuses
+        if m:
+            local[:m] = mine
+        if self.replicate:
+            parts = torch.empty((nr, mx, 3), dtype=torch.int32, device=dev)
+            work = dist.all_gather_into_tensor(parts.view(-1), local.view(-1), async_op=True)
+        else:
+            parts = [torch.empty((mx, 3), dtype=torch.int32, device=dev) for _ in range(nr)] if self.rank == 0 else None
+            work = dist.gather(local, parts, dst=0, async_op=True)
+        return work, parts, counts, local
+
+    def _gather_finish(self, pending):
+        """Wait for the pieces; the complete list in (src, dst) order: rank by rank, piece by piece (ascending source ranges)."""
+        import torch
+        nr, dev = self.world, self.be.device
+        for w in pending:
+            if w[0] is not None:
+                w[0].wait()
+        self.total_edges = sum(sum(w[2]) for w in pending)
+        if not self.replicate and self.rank != 0:
+            return torch.empty((0, 3), dtype=torch.int32, device=dev)
+        chunks = [w[1][q][:w[2][q]] for q in range(nr) for w in pending]
+        return torch.cat(chunks, dim=0).contiguous()
 
     def _gather(self, mine, ordered, counts=None):
         """Edge lists of all ranks (padded to the longest) -> the complete list on rank 0 (or on every rank);

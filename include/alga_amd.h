@@ -87,8 +87,10 @@ typedef struct {
     int32_t max_len_cap;      /* 500 (src/GraphCreators/GraphCreatorPrefSuf.cpp:92)               */
     int32_t collect_stats;    /* != 0: fill the work counters of alga_prefsuf_stats               */
     int32_t reduction;        /* alga_reduction; SOURCE_SIDE fails with ALGA_ERR_UNSUPPORTED when not exact */
-    int32_t keys_shared;      /* != 0 (sharded form only): the per-node keys were made by alga_prefsuf_keys_device and
-                                 all-gathered by the caller; the build skips its own key pass                      */
+    int32_t keys_shared;      /* sharded form only.  1: the per-node keys were made by alga_prefsuf_keys_device and
+                                 all-gathered by the caller; the build skips its own key pass.  2: this build follows
+                                 another build of the SAME node set on this engine (nothing else in between) and reuses
+                                 its sorted entry array: only the probe of [src_begin, src_end) runs                 */
     int32_t reserved[1];
 } alga_prefsuf_params;
 
@@ -202,6 +204,8 @@ int  alga_prefsuf_build_range_device(alga_engine *e, const alga_nodes *nodes, co
  *      [node_begin_q, node_end_q)) -- 8 bytes per node over RCCL;
  *   3. alga_prefsuf_build_range_device(params.keys_shared = 1, src range inside its node range): sorts the gathered keys into
  *      the bucket order, builds the entry array and probes.
+ *   A rank may cut step 3 into pieces (first piece keys_shared = 1, the following ones keys_shared = 2 on consecutive source
+ *   sub-ranges) so that the transfer of one piece's edges overlaps the probe of the next.
  * out->eligible == 0: the CLUSTER probe does not take this input (every rank gets the same answer for the same node set and
  * options); skip steps 2-3's flag and call the build as before.  The arrays are engine-owned, valid until the next build, and
  * have room for n + ALGA_KEY_ARRAY_SLACK entries, so that equal-sized slices (ceil(n / ranks), the last one running past n) can be

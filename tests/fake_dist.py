@@ -37,18 +37,24 @@ class FakeDist:
         self.w.barrier.wait()
         return got
 
-    def all_gather_into_tensor(self, out, inp):
+    class _Done:
+        def wait(self):
+            return True
+
+    def all_gather_into_tensor(self, out, inp, async_op=False):
         import torch
         parts = self._exchange(inp.detach().clone())
         out.copy_(torch.cat([p.reshape(-1) for p in parts]).reshape(out.shape))
         self._sync()
+        return self._Done() if async_op else None
 
-    def gather(self, tensor, gather_list=None, dst=0):
+    def gather(self, tensor, gather_list=None, dst=0, async_op=False):
         parts = self._exchange(tensor.detach().clone())
         if self.rank == dst:
             for g, p in zip(gather_list, parts):
                 g.copy_(p)
         self._sync()
+        return self._Done() if async_op else None
 
     def all_reduce(self, t, op=ReduceOp.SUM):
         import torch

@@ -73,9 +73,12 @@ class PyBackend:
         self.karr[1][a:b] = torch.from_numpy(m)
         return self.karr
 
-    def build_range(self, a, b, collect_stats=False, keys_shared=False):
+    def build_range(self, a, b, collect_stats=False, keys_shared=0):
         """Stand-in of alga_prefsuf_build_range_device: the executable statement of the source-side rule, one source range."""
-        if keys_shared:                                   # the all-gather delivered every rank's slice
+        if keys_shared == 2:                              # a later piece of the rank's range: the first piece came first
+            assert self.first_piece_done
+        elif keys_shared:                                 # the all-gather delivered every rank's slice
+            self.first_piece_done = True
             k, m = self._fake_keys(0, self.n)
             assert (self.karr[0][:self.n].numpy() == k).all() and (self.karr[1][:self.n].numpy() == m).all()
         else:

@@ -4,7 +4,8 @@ resident; the keys of the other ranks' nodes are put in place once, outside the 
 per step: alga_prefsuf_keys_device on the rank's own nodes + alga_prefsuf_build_range_device(keys_shared) on its sources.
 DESIGN.md section 7 uses the result as the measured part of T_N; the two collectives (0.7 GB of keys, the rank's share of 1.1 GB
 of edges) come on top.
-  tools/emulate_rank.py [N=8] [n_reads=50000000] [genome=250000000] [steps=5]"""
+The source range is built in `pieces` pieces as alga_amd.multigpu does (first piece keys_shared = 1, the others reuse the entry array).
+  tools/emulate_rank.py [N=8] [n_reads=50000000] [genome=250000000] [steps=5] [pieces=4]"""
 import json
 import os
 import sys
@@ -22,6 +23,7 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 n_reads = int(sys.argv[2]) if len(sys.argv) > 2 else 50_000_000
 G = int(sys.argv[3]) if len(sys.argv) > 3 else 250_000_000
 steps = int(sys.argv[4]) if len(sys.argv) > 4 else 5
+pieces = int(sys.argv[5]) if len(sys.argv) > 5 else 4
 wl = workload.device_build(n_reads, 150, G, 11)
 torch.cuda.synchronize()                                           # the engine's stream does not order with torch's
 dw, dl, lo, rs = wl["words"], wl["lens"], wl["min_overlap"], wl["rsoemo"]
@@ -34,7 +36,7 @@ torch.cuda.synchronize()                                           # alga_prefsu
 all_keys = [device_view(p, (n,)).clone() for p in ko]
 other.close()
 torch.cuda.synchronize()
-out = {"world": N, "reads": n_reads, "nodes": n}
+out = {"world": N, "reads": n_reads, "nodes": n, "pieces": pieces}
 for r in sorted(set([0, N - 1])):
     rows = []
     for it in range(steps + 1):
@@ -49,10 +51,16 @@ for r in sorted(set([0, N - 1])):
             v[b[r + 1]:] = full[b[r + 1]:]
         torch.cuda.synchronize()
         t2 = time.perf_counter()
-        res = eng.build_range_device(dw, dl, lo, rs, b[r], b[r + 1], keys_shared=True)
+        pb = [b[r] + 2 * (((b[r + 1] - b[r]) // 2 * k) // pieces) for k in range(pieces)] + [b[r + 1]]
+        edges, seed, probe, emit = 0, 0.0, 0.0, 0.0
+        for k in range(pieces):
+            res = eng.build_range_device(dw, dl, lo, rs, pb[k], pb[k + 1], keys_shared=1 if k == 0 else 2)
+            st = eng.last_stats()
+            edges += res[1]; seed += st["ms_seed"]; probe += st["ms_probe"]; emit += st["ms_emit"]
         torch.cuda.synchronize()
         t3 = time.perf_counter()
-        st = eng.last_stats()
+        st = dict(ms_seed=seed, ms_probe=probe, ms_emit=emit)
+        res = (None, edges)
         if it:
             rows.append(((t1 - t0) * 1e3, st["ms_seed"], st["ms_probe"], st["ms_emit"], (t1 - t0 + t3 - t2) * 1e3))
     a = [sum(x) / len(x) for x in zip(*rows)]
