@@ -409,10 +409,25 @@ def test_shared_keys_protocol(eng):
             a[h:] = b[h:]
             b[:h] = a[:h]
         torch.cuda.synchronize()
-        r1 = eng.build_range_device(dw, dl, 90, 120, 0, h, keys_shared=True)
+        # rank 0 builds its range in two pieces (the second reuses the entry array: keys_shared = 2), rank 1 in one
+        q = (h // 4) * 2
+        r1a = eng.build_range_device(dw, dl, 90, 120, 0, q, keys_shared=1)
+        e1a = device_view(r1a[0], (r1a[1], 3)).cpu().numpy()              # the next build reuses the edge buffer
+        r1b = eng.build_range_device(dw, dl, 90, 120, q, h, keys_shared=2)
+        e1b = device_view(r1b[0], (r1b[1], 3)).cpu().numpy()
         r2 = e2.build_range_device(dw, dl, 90, 120, h, n, keys_shared=True)
-        got = np.concatenate([device_view(r1[0], (r1[1], 3)).cpu().numpy(), device_view(r2[0], (r2[1], 3)).cpu().numpy()])
+        got = np.concatenate([e1a, e1b, device_view(r2[0], (r2[1], 3)).cpu().numpy()])
         assert got.shape == want.shape and (got == want).all()
+        with pytest.raises(alga_amd.AlgaError) as ei:                 # a piece outside the range the entry array has runs for
+            eng.build_range_device(dw, dl, 90, 120, h, n, keys_shared=2)
+        assert ei.value.code == -1
+        fresh = alga_amd.Engine(0)
+        try:
+            with pytest.raises(alga_amd.AlgaError) as ei:             # no build came before
+                fresh.build_range_device(dw, dl, 90, 120, 0, q, keys_shared=2)
+            assert ei.value.code == -1
+        finally:
+            fresh.close()
         with pytest.raises(alga_amd.AlgaError) as ei:                 # the keys were consumed by the build
             eng.build_range_device(dw, dl, 90, 120, 0, h, keys_shared=True)
         assert ei.value.code == -1
