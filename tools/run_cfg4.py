@@ -6,7 +6,8 @@ one of them; on an iid genome nothing else is a duplicate) -- and the graph is b
 which must agree edge for edge (the size-independent parity check at a size no CPU oracle finishes).
 usage: tools/run_cfg4.py [n_reads=50000000] [genome=250000000] [steps=2] [forms=source_side,per_target] [ref_threads=0]
 With ref_threads > 0 the same reads are written as FASTA and the real reference (oracle/_ref/ALGA) builds its graph beside it:
-wall time of its creator region and its edge count."""
+wall time of its creator region, its edge count, and its `--serialize=1` dump compared byte for byte (size + sha256) with the engine's
+graph written by alga_write_graph."""
 import json
 import os
 import sys
@@ -80,12 +81,23 @@ def main():
     out["edges_per_sec_" + forms[0]] = out["edges"] / (out[forms[0]][-1]["ms_total"] * 1e-3)
     out["gbp_per_sec_" + forms[0]] = n * 150 / (out[forms[0]][-1]["ms_total"] * 1e-3) / 1e9
     if ref_threads > 0:
-        out["reference"] = run_reference(genome, starts, flip, L, ref_threads)
+        gpu_edges = e.cpu().numpy().astype(np.int32)
+        out["reference"] = run_reference(genome, starts, flip, L, ref_threads, eng, N, gpu_edges)
         out["reference"]["edges_equal_gpu"] = out["reference"].get("edges") == out["edges"]
     print(json.dumps(out))
 
 
-def run_reference(genome, starts, flip, L, threads):
+def file_sha256(path):
+    import hashlib
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 24), b""):
+            h.update(blk)
+    return h.hexdigest()
+
+
+def run_reference(genome, starts, flip, L, threads, eng, n_nodes, gpu_edges):
+    import glob
     import re
     import subprocess
     import tempfile
@@ -117,7 +129,7 @@ def run_reference(genome, starts, flip, L, threads):
         res["fasta_write_s"] = time.time() - t0
         print("FASTA written in %.0f s; starting the reference with %d threads" % (res["fasta_write_s"], threads), flush=True)
         t = time.time()
-        p = subprocess.Popen([exe, "--file1=s.fasta", "--threads=%d" % threads, "--output=o.fasta"], cwd=wd, stdout=subprocess.DEVNULL,
+        p = subprocess.Popen([exe, "--file1=s.fasta", "--threads=%d" % threads, "--output=o.fasta", "--serialize=1"], cwd=wd, stdout=subprocess.DEVNULL,
                              stderr=subprocess.PIPE, text=True, errors="replace")
         last = time.time()
         for line in p.stderr:
@@ -135,6 +147,15 @@ def run_reference(genome, starts, flip, L, threads):
         p.wait()
         if "to_graph_done_s" in res and "to_graph_creator_s" in res:
             res["graph_creator_s"] = res["to_graph_done_s"] - res["to_graph_creator_s"]
+        dumps = glob.glob(os.path.join(wd, "*_beforeSimplifier.graph"))
+        if dumps:
+            os.unlink(path)                                                  # room for the second dump
+            mine = os.path.join(wd, "gpu.graph")
+            eng.write_graph(mine, n_nodes, gpu_edges)
+            res["dump_bytes"], res["gpu_dump_bytes"] = os.path.getsize(dumps[0]), os.path.getsize(mine)
+            res["dump_sha256"], res["gpu_dump_sha256"] = file_sha256(dumps[0]), file_sha256(mine)
+            res["dump_byte_identical"] = res["dump_bytes"] == res["gpu_dump_bytes"] and res["dump_sha256"] == res["gpu_dump_sha256"]
+            print("dumps: reference %d bytes %s, engine %d bytes %s" % (res["dump_bytes"], res["dump_sha256"][:16], res["gpu_dump_bytes"], res["gpu_dump_sha256"][:16]), flush=True)
     return res
 
 
