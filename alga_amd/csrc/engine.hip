@@ -462,6 +462,7 @@ void alga_engine_destroy(alga_engine *e) {
                       &e->pk_flag, &e->pk_pos, &e->pk_edges[0], &e->pk_edges[1], &e->pk_rowptr, &e->pk_deg, &e->pk_mask, &e->pk_cnt, &e->pk_io, &e->pk_io2, &e->pk_tips, &e->pk_heads, &e->pp_rows, &e->pp_len, &e->pp_perm[0], &e->pp_perm[1], &e->pp_keys[0], &e->pp_keys[1], &e->pp_mark,
                       &e->pp_keep, &e->pp_pos, &e->pp_out_rows, &e->pp_out_len, &e->pp_out_pair, &e->pp_tally};
     for (DevBuf *b : bufs) alga_release(*b);
+    for (DevBuf *b : e->owned) alga_release(*b);           // everything alga_ensure ever allocated (covers the list above and what it misses)
     alga_release(e->up_raw);
     for (DevBuf *b : {&e->in_bytes[0], &e->in_bytes[1], &e->in_nl[0], &e->in_nl[1], &e->in_tiles, &e->in_tile_off}) alga_release(*b);
     for (DevBuf *b : {&e->sp_rowptr, &e->sp_sorted, &e->sp_list, &e->sp_cnt, &e->sp_orow, &e->sp_out, &e->sp_in}) alga_release(*b);

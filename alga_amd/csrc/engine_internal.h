@@ -3,7 +3,9 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <algorithm>
 #include <string>
+#include <vector>
 #include <unordered_map>
 
 #include "../../include/alga_amd.h"
@@ -19,6 +21,7 @@ enum { EV_START = 0, EV_SEED, EV_PROBE, EV_GROUP, EV_REDUCE, EV_EMIT, EV_PAIRS, 
 constexpr int ALGA_STAGE_THREADS = 8;      // worker threads (pinned buffer pairs, streams) of the staged host <-> HBM copies
 
 struct alga_engine {
+    std::vector<DevBuf *> owned;              // the members below that hold an allocation (alga_ensure)
     int         device = -1;
     hipStream_t own_stream = nullptr;
     std::string err;
@@ -94,10 +97,13 @@ inline int alga_fail(alga_engine *e, int code, const char *what, hipError_t herr
         if (_err != hipSuccess) return alga_fail((e), _err == hipErrorOutOfMemory ? ALGA_ERR_OUT_OF_MEMORY : ALGA_ERR_HIP, #call, _err); \
     } while (0)
 
+// Every device buffer of an engine is allocated here, and remembered: alga_engine_destroy releases what this function handed out
+// (a hand-written list of the members missed the buffers later rounds added).
 inline int alga_ensure(alga_engine *e, DevBuf &b, size_t bytes) {
     if (bytes == 0) bytes = 16;
     if (b.cap >= bytes) return ALGA_OK;
     if (b.p) { HIP_TRY(e, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
+    else if (std::find(e->owned.begin(), e->owned.end(), &b) == e->owned.end()) e->owned.push_back(&b);
     HIP_TRY(e, hipMalloc(&b.p, bytes));
     b.cap = bytes;
     return ALGA_OK;

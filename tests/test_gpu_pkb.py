@@ -180,3 +180,34 @@ def test_supplement_rejects_offsets_it_cannot_represent(eng):
     assert ei.value.code in (-1, -5)        # the host entry point validates its edge list, the device one counts misfits in the key kernel
     out = eng.pkb_supplement_host(words, lens, np.array([[0, 2, 300]], np.int32), p)       # in range: accepted
     assert len(out) >= 1
+
+
+def test_engine_destroy_releases_every_device_buffer():
+    """an engine that has run the clustered build, the supplement, the simplifier step and the sharded protocol gives all of its
+    device memory back when it is destroyed (every buffer goes through one allocator that remembers it)"""
+    import torch
+    codes, lens = gen_reads.sample_reads(3000, 150, 6000, 77, 0.02)
+    rc = (3 - codes)[:, ::-1]
+    codes = np.stack([rc, codes], axis=1).reshape(-1, 150)[:, 3:147]
+    lens = np.full(len(codes), 144, dtype=np.int32)
+    words = alga_amd.pack_reads(codes, lens, 16)
+    dw, dl = torch.from_numpy(words.view(np.int32)).cuda(), torch.from_numpy(lens).cuda()
+
+    def use_one():
+        e = alga_amd.Engine(0)
+        try:
+            pre = e.prefsuf_host(words, lens, 82, 116)
+            e.pkb_supplement_host(words, lens, pre, e.pkb_params(144.0, 0.02, 54))
+            e.cut_triangles_host(len(lens), pre, 250)
+            e.keys_device(dw, dl, 82, 116, 0, len(lens))
+            e.build_range_device(dw, dl, 82, 116, 0, len(lens), keys_shared=1)
+        finally:
+            e.close()
+    use_one()                                               # runtime-side pools and code objects settle in the first round
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(3):
+        use_one()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < (8 << 20), (free0, free1)
