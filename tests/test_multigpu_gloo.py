@@ -203,3 +203,16 @@ def test_shard_bounds_keep_twins_together():
         for w in (1, 2, 3, 4, 8):
             b = shard_bounds(n, w)
             assert b[0] == 0 and b[-1] == n and all(x <= y for x, y in zip(b, b[1:])) and all(x % 2 == 0 for x in b[:-1])
+
+
+def test_piece_bounds_cover_the_rank_range():
+    """the pieces a rank cuts its source range into (alga_amd/multigpu.py): consecutive, even-aligned, covering, for every world size"""
+    from alga_amd.multigpu import shard_bounds
+    for n in (10, 2000, 1700526, 90621096):
+        for w in (2, 3, 4, 8):
+            b = shard_bounds(n, w)
+            for r in range(w):
+                for pieces in (1, 2, 4):
+                    pb = [b[r] + 2 * (((b[r + 1] - b[r]) // 2 * k) // pieces) for k in range(pieces)] + [b[r + 1]]
+                    assert pb[0] == b[r] and pb[-1] == b[r + 1] and all(x <= y for x, y in zip(pb, pb[1:]))
+                    assert all((x - b[r]) % 2 == 0 for x in pb[:-1])
