@@ -116,7 +116,7 @@ __global__ void __launch_bounds__(TK_ROWS) k_node_runs(NodesDev nd, PrefSufCfg c
                                                         uint32_t *__restrict__ keys, uint32_t *__restrict__ vals, uint32_t *__restrict__ meta,
                                                         uint2 *__restrict__ runs, uint8_t *__restrict__ nruns) {
     __shared__ uint32_t s[TK_ROWS][TK_STRIDE];
-    __shared__ uint32_t stk[NR_STACK][TK_ROWS];            // transposed: conflict-free
+    __shared__ uint32_t stk[NR_STACK + 1][TK_ROWS];        // transposed: conflict-free; the last row takes the stores of lanes that do not push
     __shared__ uint32_t rbuf[CL_RMAX][TK_ROWS];            // runs as they are found: q | p0 << 8 | p1 << 16
     const int base = node_begin + blockIdx.x * TK_ROWS;     // the nodes node_begin .. node_end - 1 (a rank's share, or all of them)
     const int nrows = min(TK_ROWS, node_end - base);
@@ -150,7 +150,11 @@ __global__ void __launch_bounds__(TK_ROWS) k_node_runs(NodesDev nd, PrefSufCfg c
         { const int bit = 2 * w, q = bit >> 5, r = bit & 31; const uint32_t x0 = row[q], x1 = row[q + 1], x2 = row[q + 2]; lo = funnel(x0, x1, r); hi = funnel(x1, x2, r); }
         for (int k = w; k < 2 * w - 1; k++) {              // uniform (nk <= 2w - 1: cluster_plan keeps nwin <= w)
             const uint32_t pk = key_of(lo, hi, k);
-            if (act && k < nk && pk < cur1) { cur1 = pk; if (sp < NR_STACK) stk[sp][t] = pk; sp++; }
+            // no branch: a lane that does not push writes the spare row (the push is taken by some lane of the wave at most steps)
+            const bool push = act && k < nk && pk < cur1;
+            stk[(push && sp < NR_STACK) ? sp : NR_STACK][t] = pk;
+            cur1 = push ? pk : cur1;
+            sp += push ? 1 : 0;
             // slide right: drop nucleotide k, the k-mer of k + 1 ends with nucleotide k + kk (bits past the k-mer are masked in key_of)
             lo = (lo >> 2) | (hi << 30);
             hi = hi >> 2;
@@ -175,16 +179,18 @@ __global__ void __launch_bounds__(TK_ROWS) k_node_runs(NodesDev nd, PrefSufCfg c
         { const int bit = 2 * (w - 1), q = bit >> 5, r = bit & 31; const uint32_t x0 = row[q], x1 = row[q + 1], x2 = row[q + 2]; lo = funnel(x0, x1, r); hi = funnel(x1, x2, r); }
         for (int k = w - 1; k >= 0; k--) {                 // uniform
             const uint32_t pk = key_of(lo, hi, k);
-            if (act) {
-                cur0 = pk < cur0 ? pk : cur0;
-                if (k < nwin) {
-                    const int j = k + w - 1;               // last k-mer of window k
-                    if (sp > 0 && (int) (top & 255u) > j) { sp--; top = sp > 0 ? stk[sp - 1][t] : 0xFFFFFFFFu; }     // at most one record leaves per step
-                    const uint32_t win = (sp > 0 && top < cur0) ? top : cur0;
-                    if (k == nwin - 1) { prev_win = win; p_hi = k; }
-                    else if (win != prev_win) { emit(prev_win, k + 1, p_hi + 1); prev_win = win; p_hi = k; }
-                }
-            }
+            // two branches only (a record leaves the stack; a run ends), both rare: everything else is selects -- the nested ifs of
+            // the first version cost an exec-mask round trip each at every one of the 64 steps
+            cur0 = pk < cur0 ? pk : cur0;
+            const bool inwin = act && k < nwin;
+            const int j = k + w - 1;                       // last k-mer of window k
+            if (inwin && sp > 0 && (int) (top & 255u) > j) { sp--; top = sp > 0 ? stk[sp - 1][t] : 0xFFFFFFFFu; }     // at most one record leaves per step
+            const uint32_t win = top < cur0 ? top : cur0;  // top is all ones while the stack is empty
+            const bool first = k == nwin - 1;
+            const bool change = inwin && (first || win != prev_win);
+            if (change && !first) emit(prev_win, k + 1, p_hi + 1);
+            prev_win = change ? win : prev_win;
+            p_hi = change ? k : p_hi;
             // slide left: the k-mer of k - 1 starts with nucleotide k - 1 (what leaves the k-mer moves up and out; key_of masks)
             if (k > 0) {
                 hi = (hi << 2) | (lo >> 30);
