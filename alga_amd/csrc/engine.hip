@@ -28,6 +28,7 @@ struct Prepared {
     NodesDev   nd;
     PrefSufCfg cfg;
     int        max_len = 0;
+    int        uniform_len = 0;      // > 0: every live node has this length and there is no alignFrom mask
     uint64_t   live = 0;
     bool       local_ok = false;     // the source-side reduction is exact for this input
     int        local_sw = 1;         // ... with one or two 64-bit words per offset mask / uint4 per overhang
@@ -49,6 +50,7 @@ int prepare(alga_engine *e, const alga_nodes *nodes, const alga_prefsuf_params *
     if (p->soes != 3) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "soes must be 3 (the reference hard-codes SOES = 3)");
     if (p->max_len_cap < 1 || p->max_len_cap > 500) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "max_len_cap must be in [1, 500]");
     if (p->rsoe_min_overlap < 0) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "rsoe_min_overlap must be >= 0");
+    if (p->keys_shared < 0 || p->keys_shared > 2) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "keys_shared must be 0, 1 or 2");
     int rc;
     if ((rc = alga_ensure(e, e->counters, (CNT_TOTAL + 2) * sizeof(unsigned long long)))) return rc;
     HIP_TRY(e, hipMemsetAsync(e->counters.p, 0, (CNT_TOTAL + 2) * sizeof(unsigned long long), s));
@@ -58,22 +60,25 @@ int prepare(alga_engine *e, const alga_nodes *nodes, const alga_prefsuf_params *
     unsigned long long *cnt = (unsigned long long *) e->counters.p;
     int *d_maxlen = (int *) (cnt + CNT_TOTAL);
     unsigned long long mask_asym = 0;
+    int min_len = 0;
     if (p->keys_shared == 2 && e->store_n == nodes->n && e->store_words == (const void *) nodes->words && e->stat_len == (const void *) nodes->len &&
         e->stat_from == (const void *) nodes->align_from && e->stat_to == (const void *) nodes->align_to) {
         // a further piece of the build that measured this node set last (keys_shared = 2 promises nothing came in between)
-        out.max_len = e->stat_max_len; out.live = e->stat_live; mask_asym = e->stat_mask_asym;
+        out.max_len = e->stat_max_len; out.live = e->stat_live; mask_asym = e->stat_mask_asym; min_len = e->stat_min_len;
     } else {
         launch_node_stats(nd, cnt, d_maxlen, s);
         if ((rc = alga_check_launch(e, "k_node_stats"))) return rc;
         HIP_TRY(e, hipMemcpyAsync(e->h_counters, e->counters.p, (CNT_TOTAL + 2) * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
         HIP_TRY(e, hipStreamSynchronize(s));
         out.max_len = (int) (e->h_counters[CNT_TOTAL] & 0xFFFFFFFFull);
+        min_len = out.max_len > 0 ? 0x7FFFFFFF - (int) (e->h_counters[CNT_TOTAL] >> 32) : 0;
         out.live = e->h_counters[CNT_LIVE_NODES];
         mask_asym = e->h_counters[CNT_MASK_ASYM];
-        e->stat_max_len = out.max_len; e->stat_live = out.live; e->stat_mask_asym = mask_asym;
+        e->stat_max_len = out.max_len; e->stat_min_len = min_len; e->stat_live = out.live; e->stat_mask_asym = mask_asym;
         e->stat_len = (const void *) nodes->len; e->stat_from = (const void *) nodes->align_from; e->stat_to = (const void *) nodes->align_to;
     }
     out.nd = nd;
+    out.uniform_len = (out.max_len > 0 && min_len == out.max_len && !nodes->align_from) ? out.max_len : 0;
     if ((int64_t) blocks_of(out.max_len) > (int64_t) nodes->stride_words)
         return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "stride_words is smaller than the longest read needs");
     if (out.max_len > OL_MAX_NODE_LEN) return alga_fail(e, ALGA_ERR_CAPACITY, "a node is longer than 4 194 303 nt (overlap records keep the offset in 22 bits)");
@@ -105,7 +110,6 @@ int prepare(alga_engine *e, const alga_nodes *nodes, const alga_prefsuf_params *
         int eq = 0;
         if (cluster_plan(c, out.max_len, out.live, e->opt_cluster_bucket_bias, &out.cluster, &eq)) out.cluster_eq = eq;
     }
-    if (p->keys_shared < 0 || p->keys_shared > 2) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "keys_shared must be 0, 1 or 2");
     out.keys_shared = p->keys_shared;
     out.reduction = p->reduction;
     if (out.reduction == ALGA_REDUCTION_AUTO && e->opt_force_per_target) out.reduction = ALGA_REDUCTION_PER_TARGET;
@@ -125,7 +129,6 @@ int cluster_alloc(alga_engine *e, const Prepared &pp) {
     if ((rc = alga_ensure(e, e->cl_runs, (n + 1) * CL_RMAX * 8))) return rc;
     if ((rc = alga_ensure(e, e->cl_nruns, n + 16))) return rc;
     if ((rc = alga_ensure(e, e->cl_store, (n + 2) * 16 * (size_t) pp.cluster_eq))) return rc;
-    if ((rc = alga_ensure(e, e->cl_idx, ((size_t) pp.cluster.n_buckets + 2) * sizeof(uint32_t)))) return rc;
     if ((rc = alga_ensure(e, e->cl_dir, ((size_t) pp.cluster.n_buckets + 2) * 16))) return rc;
     return alga_ensure(e, e->sort_temp, cluster_sort_temp_bytes(n));
 }
@@ -190,8 +193,8 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
             e->keyed_n = -1;                               // the sort below may reuse the key buffers: one build per key pass
             e->store_n = -1;
             HIP_TRY(e, launch_cluster_store(nd, cc, pp.cluster_eq, (uint32_t *) e->cl_keys[0].p, (uint32_t *) e->cl_vals[0].p, (uint32_t *) e->cl_keys[1].p,
-                                            (uint32_t *) e->cl_vals[1].p, (const uint32_t *) e->cl_meta.p, e->sort_temp.p, cluster_sort_temp_bytes((uint64_t) nd.n),
-                                            e->cl_store.p, (uint32_t *) e->cl_idx.p, e->cl_dir.p, pp.keys_shared == 1, s));
+                                            (uint32_t *) e->cl_vals[1].p, (const uint32_t *) e->cl_meta.p, pp.uniform_len, e->sort_temp.p,
+                                            cluster_sort_temp_bytes((uint64_t) nd.n), e->cl_store.p, e->cl_dir.p, pp.keys_shared == 1, s));
             e->store_n = nd.n; e->store_words = (const void *) nd.words; e->store_eq = pp.cluster_eq; e->store_buckets = cc.n_buckets;
             e->store_run_begin = run_begin; e->store_run_end = run_end;
         }
@@ -457,7 +460,7 @@ void alga_engine_destroy(alga_engine *e) {
     if (e->own_stream) (void) hipStreamSynchronize(e->own_stream);
     DevBuf *bufs[] = {&e->table, &e->filter, &e->counters, &e->rowptr, &e->rec_dst, &e->rec_val, &e->keys, &e->seg_key, &e->seg_val, &e->heads, &e->sort_temp,
                       &e->out_cnt, &e->outdeg, &e->out_rowptr, &e->edges, &e->scan_scratch, &e->up_words, &e->up_len, &e->up_from, &e->up_to,
-                      &e->cl_keys[0], &e->cl_keys[1], &e->cl_vals[0], &e->cl_vals[1], &e->cl_defer, &e->cl_meta, &e->cl_runs, &e->cl_nruns, &e->cl_store, &e->cl_idx, &e->loc_first, &e->loc_big_list, &e->loc_big_items, &e->edge_keys, &e->edge_keys2, &e->edge_vals, &e->edge_vals2, &e->edges_sorted, &e->xs_dst, &e->xs_val,
+                      &e->cl_keys[0], &e->cl_keys[1], &e->cl_vals[0], &e->cl_vals[1], &e->cl_defer, &e->cl_meta, &e->cl_runs, &e->cl_nruns, &e->cl_store, &e->loc_first, &e->loc_big_list, &e->loc_big_items, &e->edge_keys, &e->edge_keys2, &e->edge_vals, &e->edge_vals2, &e->edges_sorted, &e->xs_dst, &e->xs_val,
                       &e->pk_keys, &e->pk_keys2, &e->pk_vals, &e->pk_vals2, &e->pk_marks, &e->pk_big, &e->pk_add, &e->pk_ekeys, &e->pk_ekeys2,
                       &e->pk_flag, &e->pk_pos, &e->pk_edges[0], &e->pk_edges[1], &e->pk_rowptr, &e->pk_deg, &e->pk_mask, &e->pk_cnt, &e->pk_io, &e->pk_io2, &e->pk_tips, &e->pk_heads, &e->pp_rows, &e->pp_len, &e->pp_perm[0], &e->pp_perm[1], &e->pp_keys[0], &e->pp_keys[1], &e->pp_mark,
                       &e->pp_keep, &e->pp_pos, &e->pp_out_rows, &e->pp_out_len, &e->pp_out_pair, &e->pp_tally};

@@ -46,12 +46,12 @@ struct alga_engine {
     uint32_t store_buckets = 0;
     const void *store_words = nullptr;
     // node statistics of the last prepare() (k_node_stats): reused by the further pieces of a build (params.keys_shared = 2)
-    int stat_max_len = 0; uint64_t stat_live = 0; unsigned long long stat_mask_asym = 0;
+    int stat_max_len = 0, stat_min_len = 0; uint64_t stat_live = 0; unsigned long long stat_mask_asym = 0;
     const void *stat_len = nullptr, *stat_from = nullptr, *stat_to = nullptr;
     bool   pairs_timed = false;                             // EV_PAIRS was recorded in the last discovery
     double cl_defer_ratio = 0.0;                            // ... their share in the last build: above one half the pair kernel is skipped
     int    opt_cluster_pairs = 1;                           // option "cluster_pairs": 0 = general kernel only
-    DevBuf cl_keys[2], cl_vals[2], cl_meta, cl_runs, cl_nruns, cl_store, cl_idx, cl_dir;   // clustered minimizer join: sort buffers, per-node minimizer runs, entry array, bucket index
+    DevBuf cl_keys[2], cl_vals[2], cl_meta, cl_runs, cl_nruns, cl_store, cl_dir;   // clustered minimizer join: sort buffers, per-node minimizer runs, entry array, bucket directory
     DevBuf loc_second;                                      // ... the other edge of a two-edge source the pair kernel finished (clustered probe)
     bool   loc_second_used = false;                         // the last discovery wrote loc_second
     DevBuf loc_first, loc_big_list, loc_big_items;          // source-side form: one-edge slots; second pass over repeat-rich sources

@@ -20,7 +20,7 @@
 //   k_node_runs        one thread per node: the runs of equal window minimizer {cluster key, k-mer position, windows [p0, p1)}
 //                      of the node as a SOURCE, and the key / meta word it is filed under as a TARGET (run 0)
 //   (radix sort of (key, id): rocPRIM)
-//   k_tgt_gather       rows in key order -> entry array;   k_tgt_index   first entry of every key bucket
+//   k_tgt_gather       rows in key order -> entry array;   k_tgt_dir     directory record of every key bucket
 //   k_probe_pairs      two sources per wave (32 lanes each): finishes the regular sources, lists the others
 //   k_probe_clustered  one source per wave, any shape: the listed sources (or all of them)
 #include <hip/hip_runtime.h>
@@ -31,25 +31,54 @@
 
 namespace alga {
 
-// order hash of a k-mer (lo: nucleotides 0..15, hi: 16..31, both masked to the k-mer's length): its top 24 bits rank the
-// k-mers of a window
+// order hash of a k-mer (lo: nucleotides 0..15, hi: 16..31, both masked to the k-mer's length)
 __device__ __forceinline__ uint32_t kmer_hash(uint32_t lo, uint32_t hi) {
-    // ONE multiply (32-bit integer multiplies run at quarter rate; 13.6 G k-mers are hashed per build at the north-star size).  A
-    // second mixing round made no measurable difference to the minimizers' statistics (runs per node, entries per source, sources
-    // the pair kernel finishes): what has to be well mixed is the CLUSTER key, and that gets its own mix, once per run.
+    // ONE multiply (32-bit integer multiplies run at quarter rate).  A second mixing round made no measurable difference to the
+    // minimizers' statistics (runs per node, entries per source, sources the pair kernel finishes): what has to be well mixed is
+    // the CLUSTER key, and that gets its own mix, once per run.
     return (lo ^ __funnelshift_l(hi, hi, 13) ^ (hi >> 7)) * 0x9E3779B1u;
+}
+
+// ORDER of the k-mers of a window: the smallest order key is the window's minimizer.
+//   bit 31      content class: 0 for a k-mer that starts with A followed by C or G (one k-mer in eight), 1 for any other
+//   bits 30..8  23 bits of the order hash
+//   bits 7..0   position in the read (ties to the left; equal windows of a source and a target agree on it)
+// The class bit is what makes k_node_runs cheap: a window of w = 64 k-mers holds a class-0 k-mer with probability 1 - (7/8)^64,
+// so the minimizer of (nearly) every window is a class-0 k-mer, and those are found with a few word-parallel bit operations on
+// the 2-bit rows -- the order hash is evaluated for one k-mer position in eight instead of all of them (13.6 G hashes and
+// 11.4 ms per build at the north-star size in round 2).  It stays a function of the window's content alone, which is all the
+// join needs: a source window and the equal target prefix choose the same k-mer.  Windows without a class-0 k-mer take the
+// minimum over their class-1 k-mers (brute force: the prefix window inside k_node_runs, a source's other windows in
+// k_probe_clustered's slow path).
+// nucleotide codes: A = 0, C = 1, G = 2, T = 3 (include/Params.h:275-279); nucleotide j of a k-mer = bits (2j, 2j + 1) of lo
+__device__ __forceinline__ bool kmer_class0(uint32_t lo) { return (lo & 3u) == 0u && ((((lo >> 2) ^ (lo >> 3)) & 1u) != 0u); }
+__device__ __forceinline__ uint32_t order_key0(uint32_t h, int pos) { return ((h >> 1) & 0x7FFFFF00u) | (uint32_t) pos; }      // of a class-0 k-mer
+__device__ __forceinline__ uint32_t order_key(uint32_t h, uint32_t lo, int pos) { return order_key0(h, pos) | (kmer_class0(lo) ? 0u : 0x80000000u); }
+// class-0 positions among the 16 nucleotides of `cur` (bit 2j: nucleotide j); nxt = the following row word
+__device__ __forceinline__ uint32_t class0_mask16(uint32_t cur, uint32_t nxt) {
+    const uint32_t nx = __funnelshift_r(cur, nxt, 2);      // nucleotide j + 1 at bits (2j, 2j + 1)
+    return ~(cur | (cur >> 1)) & (nx ^ (nx >> 1)) & 0x55555555u;
+}
+// bits 0, 2, 4, ... 30 of x (the others are zero) -> bits 0 .. 15
+__device__ __forceinline__ uint32_t compress_even(uint32_t x) {
+    x = (x | (x >> 1)) & 0x33333333u;
+    x = (x | (x >> 2)) & 0x0F0F0F0Fu;
+    x = (x | (x >> 4)) & 0x00FF00FFu;
+    return (x | (x >> 8)) & 0x0000FFFFu;
 }
 
 // Cluster key of a minimizer = a second, bijective mix of its order hash.  The order hashes of MINIMIZERS are minima of w
 // uniform values -- concentrated near zero -- so bucketing the entry array by their own top bits would put most clusters in
-// 1/w of the buckets; the mix spreads them evenly.  0xFFFFFFFF is reserved for "not a target".
-__device__ __forceinline__ uint32_t cluster_key(uint32_t h) {
-    uint32_t k = h * 0x9E3779B1u;
+// 1/w of the buckets; the mix spreads them evenly.  The bits outside the m_C field (tgt_sort_key below) are never all ones: the
+// sort key of a target then never is 0xFFFFFFFF ("not a target") whatever its m_C, and m_C can be read back from it.
+__device__ __forceinline__ uint32_t cluster_key(uint32_t h, int fs) {
+    uint32_t k = h * 0x9E3779B1u;                          // (one multiply instead of three: +2 % entries scanned, +28 % deferred sources)
     k ^= k >> 15;
     k *= 0x85EBCA77u;
     k ^= k >> 13;
     k *= 0xC2B2AE3Du;
-    return k == 0xFFFFFFFFu ? 0xFFFFFFFEu : k;
+    const uint32_t fm = ((1u << CL_MBITS) - 1u) << fs;
+    return (k | fm) == 0xFFFFFFFFu ? k ^ 0x80000000u : k;
 }
 
 // Sort key of a target: the cluster key with the CL_MBITS bits right below its bucket bits replaced by m_C, the position of the
@@ -57,12 +86,10 @@ __device__ __forceinline__ uint32_t cluster_key(uint32_t h) {
 // by m_C first, and the directory (k_tgt_dir) knows where every eighth of that order starts: a source run that covers the
 // windows [p0, p1) with its minimizer at q can only match targets with q - p1 < m_C <= q - p0 and reads that slice of the bucket
 // alone -- the other entries of the cluster are the reads of the same locus that start too far left or right of the run's
-// windows (half of them at 30x coverage).  0xFFFFFFFF stays reserved for "not a target" (m_C 63 -> 62: same eighth; the m_C
-// that is used for the offset comes from the entry's meta word).
+// windows (half of them at 30x coverage).  0xFFFFFFFF stays reserved for "not a target".
 __device__ __forceinline__ uint32_t tgt_sort_key(uint32_t ckey, uint32_t m_c, int fs) {
     const uint32_t fm = ((1u << CL_MBITS) - 1u) << fs;
-    const uint32_t k = (ckey & ~fm) | ((m_c << fs) & fm);
-    return k == 0xFFFFFFFFu ? k ^ (1u << fs) : k;
+    return (ckey & ~fm) | ((m_c << fs) & fm);               // never all ones: cluster_key
 }
 __device__ __forceinline__ bool same_cluster(uint32_t entry_key, uint32_t ckey, int fs) {
     return ((entry_key ^ ckey) & ~(((1u << CL_MBITS) - 1u) << fs)) == 0u;
@@ -84,46 +111,57 @@ __device__ __forceinline__ void run_slice(const uint4 &rec, uint32_t run_y, uint
 }
 
 // k-mer starting at nucleotide i of a 2-bit row (words readable up to index (2i >> 5) + 2): its hash and its packed
-// order key (24-bit order | position); the smallest key of a window is the window's minimizer
+// order key (class | 23-bit order | position); the smallest key of a window is the window's minimizer
 __device__ __forceinline__ void kmer_key(const uint32_t *row, int i, bool valid, const ClusterCfg &cc, uint32_t &h, uint32_t &pk) {
     const int bit = 2 * i, q = bit >> 5, r = bit & 31;
     const uint32_t x0 = row[q], x1 = row[q + 1], x2 = row[q + 2];
-    h = kmer_hash(funnel(x0, x1, r) & cc.lo_mask, funnel(x1, x2, r) & cc.hi_mask);
-    pk = valid ? ((h & 0xFFFFFF00u) | (uint32_t) i) : 0xFFFFFFFFu;
+    const uint32_t lo = funnel(x0, x1, r) & cc.lo_mask;
+    h = kmer_hash(lo, funnel(x1, x2, r) & cc.hi_mask);
+    pk = valid ? order_key(h, lo, i) : 0xFFFFFFFFu;
 }
 
 // ------------------------------------------------------------------------------------------
 // build: minimizer runs of every node, keys, gather, index
 // ------------------------------------------------------------------------------------------
-constexpr int TK_ROWS = 256;         // nodes per workgroup of k_node_runs
-constexpr int TK_WORDS = 16;         // row words staged per node (reads of up to 208 nt: 13 words + the k-mer reads' slack)
-constexpr int TK_STRIDE = TK_WORDS + 1;
-constexpr int NR_STACK = 12;         // prefix-minimum records kept per node (a random window has ~4.7; more: the node is flagged)
+constexpr int TK_ROWS = 128;         // nodes per workgroup of k_node_runs
+constexpr int NR_STACK = 8;          // minimum records kept per node and block (a random block has ~2.7; more: the node is flagged)
 
-// One THREAD per node (full lane use; the same sliding-window minimum inside the probing wave costs ~100 wave instructions per
-// source at a quarter of the lanes): the distinct minimizers of the suffix windows p = 0 .. len - Lmin of the node, as runs
-// {cluster key, k-mer position q, windows [p0, p1)}; run 0's minimizer is the minimizer of the node's min_overlap-long prefix,
-// i.e. the key the node is filed under as a TARGET.
-//   Window p covers k-mers [p, p + w).  Block 0 = k-mers [0, w), block 1 = [w, nk).  min(window p) = min(suffix minimum of
-//   block 0 from p, prefix minimum of block 1 up to p + w - 1).  Forward scan of block 1 pushes its prefix-minimum records on
-//   a per-thread stack; the backward sweep over block 0 keeps the running suffix minimum, pops the records that lie beyond the
-//   window and emits a run whenever the winner changes.  All loops have uniform trip counts; order keys include the position,
-//   so ties go to the left on both the source and the target side.
-// keys[i] = cluster key of run 0 (all ones: not a target), vals[i] = i, meta[i] = m_C | len << 8 | alignFrom << 20,
-// runs[i * CL_RMAX + k] = {key, q | p0 << 8 | p1 << 16}, nruns[i] = number of runs (0: not a source; CL_RUNS_FLAGGED: more than
-// CL_RMAX runs or records than the stack holds -- k_probe_clustered finds such a source's window minimizers by brute force).
+// One THREAD per node: the distinct minimizers of the suffix windows p = 0 .. len - Lmin of the node, as runs
+// {cluster key, k-mer position q, windows [p0, p1)}; the minimizer of window 0 (the node's min_overlap-long prefix) is the key the
+// node is filed under as a TARGET.
+//   Window p covers the k-mers [p, p + w), nk = nwin - 1 + w <= 2w - 1 <= 127 k-mers in all.  Only the class-0 k-mers (order_key:
+//   one position in eight) can be minimizers of a window that holds one; their positions are a 128-bit mask, built from the staged
+//   row with word-parallel bit operations.  Block 0 = k-mers [0, w), block 1 = [w, nk):
+//     min(window p) = min(suffix minimum of block 0 from p, prefix minimum of block 1 up to p + w - 1).
+//   (1) block 1, class-0 positions left to right: the prefix-minimum RECORDS (a k-mer smaller than all before it) go on a
+//       per-thread stack; (2) block 0, right to left: its suffix-minimum records on a second stack; the order hash is evaluated
+//       in these two loops only, once per class-0 k-mer; (3) the sweep over the windows from the last to the first is a merge of
+//       the two record lists -- a block-0 record at position c joins the windows p <= c, a block-1 record at c drops out of the
+//       windows p <= c - w -- ~5 events per node, a run noted whenever the winner changes.
+//   Ties go to the left on both the source and the target side (the position is part of the order key).
+// keys[i] = sort key of the node as a target (all ones: not a target), vals[i] = i, meta[i] = m_C | len << 8 | alignFrom << 20,
+// runs[i * CL_RMAX + k] = {cluster key, q | p0 << 8 | p1 << 16}, nruns[i] = number of runs (0: not a source; CL_RUNS_FLAGGED: a
+// window without a class-0 k-mer, more than CL_RMAX runs or more records than a stack holds -- k_probe_clustered finds such a
+// source's window minimizers by brute force over all k-mers, 1 source in ~10^3).
+// TKW = row words staged per node: the row (<= TKW - 2 words) + the two words a k-mer read may run past it; odd: conflict-free.
+template <int TKW>
 __global__ void __launch_bounds__(TK_ROWS) k_node_runs(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, int node_begin, int node_end,
                                                         uint32_t *__restrict__ keys, uint32_t *__restrict__ vals, uint32_t *__restrict__ meta,
                                                         uint2 *__restrict__ runs, uint8_t *__restrict__ nruns) {
-    __shared__ uint32_t s[TK_ROWS][TK_STRIDE];
-    __shared__ uint32_t stk[NR_STACK + 1][TK_ROWS];        // transposed: conflict-free; the last row takes the stores of lanes that do not push
-    __shared__ uint32_t rbuf[CL_RMAX][TK_ROWS];            // runs as they are found: q | p0 << 8 | p1 << 16
+    __shared__ uint32_t s[TK_ROWS][TKW];
+    // records, transposed (conflict-free): rows 0 .. NR_STACK - 1 block 1, NR_STACK the spare row that takes the stores of lanes
+    // that do not push, NR_STACK + 1 .. 2 NR_STACK block 0, 2 NR_STACK + 1 its spare row
+    __shared__ uint32_t stk[2 * (NR_STACK + 1)][TK_ROWS];
+    __shared__ uint16_t rbuf[CL_RMAX + 1][TK_ROWS];        // runs as they are found: q | p0 << 8 (p1 = p0 of the run found before); last row: spare
+    constexpr int S0 = NR_STACK + 1;                       // first row of block 0's records
     const int base = node_begin + blockIdx.x * TK_ROWS;     // the nodes node_begin .. node_end - 1 (a rank's share, or all of them)
     const int nrows = min(TK_ROWS, node_end - base);
     {
         const int c = (int) (threadIdx.x & 15u);
-        for (int r = (int) (threadIdx.x >> 4); r < nrows; r += TK_ROWS / 16)
-            s[r][c] = c < nd.stride ? nd.words[(size_t) (base + r) * nd.stride + c] : 0u;
+        if (c < TKW)
+            for (int r = (int) (threadIdx.x >> 4); r < nrows; r += TK_ROWS / 16)
+                s[r][c] = c < nd.stride ? nd.words[(size_t) (base + r) * nd.stride + c] : 0u;
+        if (TKW > 16) for (int r = (int) threadIdx.x; r < nrows; r += TK_ROWS) s[r][16] = 0u;
     }
     __syncthreads();
     const int t = (int) threadIdx.x;
@@ -136,95 +174,135 @@ __global__ void __launch_bounds__(TK_ROWS) k_node_runs(NodesDev nd, PrefSufCfg c
     const uint32_t *row = s[in ? t : 0];
     const int w = cc.w;
     const int nwin = len - cfg.Lmin + 1;                   // <= 64 (one-word form of the source-side reduction)
-    const int nk = len - cc.kk + 1;                        // = nwin - 1 + w
-    // The k-mer of position k as a 64-bit register pair that slides by one nucleotide per step (two shifts and an insert) instead
-    // of three LDS reads and two funnel shifts per position: `nuc(i)` reads one staged word per 16 nucleotides.
-    auto nuc = [&](int i) -> uint32_t { return (row[i >> 4] >> ((i & 15) << 1)) & 3u; };
-    auto key_of = [&](uint32_t lo, uint32_t hi, int pos) -> uint32_t { return (kmer_hash(lo & cc.lo_mask, hi & cc.hi_mask) & 0xFFFFFF00u) | (uint32_t) pos; };
-    const int kk = cc.kk;
-    // ---- block 1, left to right: prefix-minimum records ----
-    uint32_t cur1 = 0xFFFFFFFFu;
-    int sp = 0;
+    const int nk = act ? len - cc.kk + 1 : 0;              // = nwin - 1 + w <= 127
+    // ---- class-0 k-mer positions: bit p of the 128-bit mask (static row indices: registers, no scratch) ----
+    uint64_t m_lo, m_hi;
     {
-        uint32_t lo, hi;
-        { const int bit = 2 * w, q = bit >> 5, r = bit & 31; const uint32_t x0 = row[q], x1 = row[q + 1], x2 = row[q + 2]; lo = funnel(x0, x1, r); hi = funnel(x1, x2, r); }
-        for (int k = w; k < 2 * w - 1; k++) {              // uniform (nk <= 2w - 1: cluster_plan keeps nwin <= w)
-            const uint32_t pk = key_of(lo, hi, k);
-            // no branch: a lane that does not push writes the spare row (the push is taken by some lane of the wave at most steps)
-            const bool push = act && k < nk && pk < cur1;
-            stk[(push && sp < NR_STACK) ? sp : NR_STACK][t] = pk;
-            cur1 = push ? pk : cur1;
-            sp += push ? 1 : 0;
-            // slide right: drop nucleotide k, the k-mer of k + 1 ends with nucleotide k + kk (bits past the k-mer are masked in key_of)
-            lo = (lo >> 2) | (hi << 30);
-            hi = hi >> 2;
-            const uint32_t c = nuc(k + kk);
-            if (kk <= 16) lo |= c << (2 * (kk - 1)); else hi |= c << (2 * (kk - 17));
+        uint32_t dm[4];
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            const uint32_t x0 = row[2 * d], x1 = row[2 * d + 1], x2 = row[2 * d + 2];
+            dm[d] = compress_even(class0_mask16(x0, x1)) | (compress_even(class0_mask16(x1, x2)) << 16);
+        }
+        m_lo = (uint64_t) dm[0] | ((uint64_t) dm[1] << 32);
+        m_hi = (uint64_t) dm[2] | ((uint64_t) dm[3] << 32);
+        m_lo &= nk >= 64 ? ~0ull : ((1ull << nk) - 1ull);              // positions below nk only (0 for a node that takes no part)
+        m_hi &= nk <= 64 ? 0ull : ((1ull << (nk - 64)) - 1ull);
+    }
+    uint64_t b0 = w >= 64 ? m_lo : (m_lo & ((1ull << w) - 1ull));
+    uint64_t b1 = w >= 64 ? m_hi : ((m_lo >> w) | (m_hi << (64 - w)));    // uniform branch; bit e = k-mer w + e
+    auto key_at = [&](int pos) -> uint32_t {               // order key of the class-0 k-mer at `pos`
+        const int bit = 2 * pos, q = bit >> 5, r = bit & 31;
+        const uint32_t x0 = row[q], x1 = row[q + 1], x2 = row[q + 2];
+        return order_key0(kmer_hash(funnel(x0, x1, r) & cc.lo_mask, funnel(x1, x2, r) & cc.hi_mask), pos);
+    };
+    // ---- (1) block 1, left to right: prefix-minimum records ----
+    uint32_t cur1 = 0xFFFFFFFFu;
+    int sp1 = 0;
+    while (b1 != 0ull) {
+        const int e = __builtin_ctzll(b1);
+        b1 &= b1 - 1ull;
+        const uint32_t pk = key_at(w + e);
+        // no branch: a lane that does not push writes the spare row
+        const bool push = pk < cur1;
+        stk[(push && sp1 < NR_STACK) ? sp1 : NR_STACK][t] = pk;
+        cur1 = push ? pk : cur1;
+        sp1 += push ? 1 : 0;
+    }
+    // ---- (2) block 0, right to left: suffix-minimum records ----
+    uint32_t cur0 = 0xFFFFFFFFu;
+    int sp0 = 0;
+    while (b0 != 0ull) {
+        const int e = 63 - __builtin_clzll(b0);
+        b0 ^= 1ull << e;
+        const uint32_t pk = key_at(e);
+        const bool push = pk < cur0;
+        stk[S0 + ((push && sp0 < NR_STACK) ? sp0 : NR_STACK)][t] = pk;
+        cur0 = push ? pk : cur0;
+        sp0 += push ? 1 : 0;
+    }
+    const bool stack_ovf = sp1 > NR_STACK || sp0 > NR_STACK;
+    sp1 = sp1 > NR_STACK ? NR_STACK : sp1;
+    sp0 = sp0 > NR_STACK ? NR_STACK : sp0;
+    // ---- (3) the windows, last to first: merge of the two record lists ----
+    int nr = 0;
+    bool uncovered = false;                                // some window holds no class-0 k-mer
+    {
+        uint32_t top = sp1 > 0 ? stk[sp1 - 1][t] : 0xFFFFFFFFu;       // smallest record of block 1: in every window until it drops out
+        uint32_t nxt0 = stk[S0][t];                                   // next record of block 0 (if i0 < sp0)
+        uint32_t c0 = 0xFFFFFFFFu, win = top;
+        int i0 = 0, p_hi = nwin - 1;
+        int e0 = sp0 > 0 ? (int) (nxt0 & 255u) : -1;                  // the next block-0 record joins the windows p <= e0
+        int e1 = sp1 > 0 ? (int) (top & 255u) - w : -1;               // block 1's smallest record is in no window p <= e1
+        while ((e0 > e1 ? e0 : e1) >= 0) {
+            const int pe = e0 > e1 ? e0 : e1;
+            const bool take0 = e0 >= e1;
+            // ONE stack read serves either move: the record after the block-0 record that joins, or the one below block 1's top
+            const int row_i = take0 ? S0 + i0 + 1 : (sp1 >= 2 ? sp1 - 2 : NR_STACK);
+            const uint32_t v = stk[row_i][t];
+            i0 += take0 ? 1 : 0;
+            sp1 -= take0 ? 0 : 1;
+            c0 = take0 ? nxt0 : c0;
+            nxt0 = take0 ? v : nxt0;
+            top = take0 ? top : (sp1 >= 1 ? v : 0xFFFFFFFFu);
+            e0 = take0 ? (i0 < sp0 ? (int) (v & 255u) : -1) : e0;
+            e1 = take0 ? e1 : (sp1 >= 1 ? (int) (v & 255u) - w : -1);
+            const uint32_t wn = c0 < top ? c0 : top;
+            const int pc = pe < p_hi ? pe : p_hi;
+            const bool em = wn != win && pc < p_hi;         // the windows (pc, p_hi] had `win`
+            rbuf[(em && nr < CL_RMAX) ? nr : CL_RMAX][t] = (uint16_t) ((win & 255u) | ((uint32_t) (pc + 1) << 8));
+            uncovered = uncovered || (em && win == 0xFFFFFFFFu);
+            nr += em ? 1 : 0;
+            p_hi = em ? pc : p_hi;
+            win = wn;
+        }
+        if (act) {                                         // the run of window 0
+            if (nr < CL_RMAX) rbuf[nr][t] = (uint16_t) (win & 255u);
+            uncovered = uncovered || win == 0xFFFFFFFFu;
+            nr++;
         }
     }
-    const bool stack_ovf = sp > NR_STACK;
-    if (stack_ovf) sp = NR_STACK;
-    uint32_t top = sp > 0 ? stk[sp - 1][t] : 0xFFFFFFFFu;
-    // ---- block 0, right to left: suffix minimum, winner per window, runs ----
-    uint32_t cur0 = 0xFFFFFFFFu, prev_win = 0xFFFFFFFFu;
-    int p_hi = 0, nr = 0;
-    // A run is only NOTED inside the sweep (one LDS store): with 64 nodes per wave some lane ends a run at nearly every step, and
-    // whatever the branch holds is paid by the whole wave every time.  Cluster keys and the global stores follow after the sweep.
-    auto emit = [&](uint32_t winpk, int p0, int p1) {
-        if (nr < CL_RMAX) rbuf[nr][t] = (winpk & 255u) | ((uint32_t) p0 << 8) | ((uint32_t) p1 << 16);
-        nr++;
-    };
+    const int fs = cc.idx_shift - CL_MBITS;
+    const int nr_stored = nr < CL_RMAX ? nr : CL_RMAX;
     {
-        uint32_t lo, hi;
-        { const int bit = 2 * (w - 1), q = bit >> 5, r = bit & 31; const uint32_t x0 = row[q], x1 = row[q + 1], x2 = row[q + 2]; lo = funnel(x0, x1, r); hi = funnel(x1, x2, r); }
-        for (int k = w - 1; k >= 0; k--) {                 // uniform
-            const uint32_t pk = key_of(lo, hi, k);
-            // two branches only (a record leaves the stack; a run ends), both rare: everything else is selects -- the nested ifs of
-            // the first version cost an exec-mask round trip each at every one of the 64 steps
-            cur0 = pk < cur0 ? pk : cur0;
-            const bool inwin = act && k < nwin;
-            const int j = k + w - 1;                       // last k-mer of window k
-            if (inwin && sp > 0 && (int) (top & 255u) > j) { sp--; top = sp > 0 ? stk[sp - 1][t] : 0xFFFFFFFFu; }     // at most one record leaves per step
-            const uint32_t win = top < cur0 ? top : cur0;  // top is all ones while the stack is empty
-            const bool first = k == nwin - 1;
-            const bool change = inwin && (first || win != prev_win);
-            if (change && !first) emit(prev_win, k + 1, p_hi + 1);
-            prev_win = change ? win : prev_win;
-            p_hi = change ? k : p_hi;
-            // slide left: the k-mer of k - 1 starts with nucleotide k - 1 (what leaves the k-mer moves up and out; key_of masks)
-            if (k > 0) {
-                hi = (hi << 2) | (lo >> 30);
-                lo = (lo << 2) | nuc(k - 1);
+        int p1 = nwin;
+        for (int r = 0; r < CL_RMAX; r++) {                // (skipped by the waves none of whose nodes has that many runs)
+            if (r < nr_stored && is_src) {
+                const uint32_t d = rbuf[r][t];
+                const int q = (int) (d & 255u);
+                uint32_t h, pk;
+                kmer_key(row, q < 128 ? q : 0, true, cc, h, pk);
+                runs[(size_t) i * CL_RMAX + r] = make_uint2(cluster_key(h, fs), d | ((uint32_t) p1 << 16));
+                p1 = (int) (d >> 8);
             }
         }
     }
+    // ---- the node as a target: the minimizer of window 0 = the minimum of block 0 (cur0: every class-0 k-mer of the block has
+    //      been seen, whatever the stacks hold) ----
     uint32_t key = 0xFFFFFFFFu, m = 0u;
-    if (act) emit(prev_win, 0, p_hi + 1);                  // the run of window 0: the prefix minimizer
-    const int nr_stored = nr < CL_RMAX ? nr : CL_RMAX;
-    for (int r = 0; r < CL_RMAX; r++) {                    // uniform
-        if (act && r < nr_stored && is_src) {
-            const uint32_t d = rbuf[r][t];
-            uint32_t h, pk;
-            kmer_key(row, (int) (d & 255u), true, cc, h, pk);
-            runs[(size_t) i * CL_RMAX + r] = make_uint2(cluster_key(h), d);
-        }
-    }
     if (is_tgt) {
+        uint32_t pmin = cur0;
+        if (pmin == 0xFFFFFFFFu) {                         // no class-0 k-mer in the prefix window (2 nodes in 10^4): all of its k-mers
+            for (int k = 0; k < w; k++) { uint32_t h, pk; kmer_key(row, k, true, cc, h, pk); pmin = pk < pmin ? pk : pmin; }
+        }
         uint32_t h, pk;
-        kmer_key(row, (int) (prev_win & 255u), true, cc, h, pk);
-        key = tgt_sort_key(cluster_key(h), prev_win & 255u, cc.idx_shift - CL_MBITS);
-        m = (prev_win & 255u) | ((uint32_t) len << 8) | (is_src ? CL_META_FROM : 0u);
+        kmer_key(row, (int) (pmin & 255u), true, cc, h, pk);
+        key = tgt_sort_key(cluster_key(h, fs), pmin & 255u, fs);
+        m = (pmin & 255u) | ((uint32_t) len << 8) | (is_src ? CL_META_FROM : 0u);
     }
     if (in) {
         keys[i] = key; vals[i] = (uint32_t) i; meta[i] = m;
-        nruns[i] = (uint8_t) (!is_src ? 0 : ((nr > CL_RMAX || stack_ovf) ? CL_RUNS_FLAGGED : nr));
+        nruns[i] = (uint8_t) (!is_src ? 0 : ((nr > CL_RMAX || stack_ovf || uncovered) ? CL_RUNS_FLAGGED : nr));
     }
 }
 
-// entry j (hash order) = {row words 0 .. 4*EQ-4, node id, hash, meta}; one thread per 16-byte piece
-template <int EQ>
+// entry j (key order) = {row words 0 .. 4*EQ-4, node id, sort key, meta}; one thread per 16-byte piece.
+// UNIFORM (every live node has the same length and there is no alignFrom mask -- every BASELINE configuration): the meta word
+// follows from the sort key (its m_C field) and the common length, and the one random 4-byte read per entry of meta[] goes away
+// (4.6 -> 3.0 ms at 90.6 M nodes).
+template <int EQ, bool UNIFORM>
 __global__ void __launch_bounds__(256) k_tgt_gather(NodesDev nd, const uint32_t *__restrict__ keys, const uint32_t *__restrict__ vals,
-                                                     const uint32_t *__restrict__ meta, uint4 *__restrict__ store) {
+                                                     const uint32_t *__restrict__ meta, uint32_t uniform_meta, int fs, uint4 *__restrict__ store) {
     const uint64_t t = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t j = t / EQ;
     const int c = (int) (t % EQ);
@@ -239,48 +317,66 @@ __global__ void __launch_bounds__(256) k_tgt_gather(NodesDev nd, const uint32_t 
         v.x = 4 * c + 0 < nd.stride ? row[4 * c + 0] : 0u; v.y = 4 * c + 1 < nd.stride ? row[4 * c + 1] : 0u;
         v.z = 4 * c + 2 < nd.stride ? row[4 * c + 2] : 0u; v.w = 4 * c + 3 < nd.stride ? row[4 * c + 3] : 0u;
     }
-    if (c == EQ - 1) { v.y = id; v.z = key; v.w = meta[id]; }
+    if (c == EQ - 1) { v.y = id; v.z = key; v.w = UNIFORM ? (uniform_meta | ((key >> fs) & ((1u << CL_MBITS) - 1u))) : meta[id]; }
     store[j * EQ + c] = v;
 }
 
-// idx[b] = first entry whose hash bucket is >= b, for b in [0, n_buckets]; non-targets (all-ones keys) count as bucket n_buckets
-__global__ void __launch_bounds__(256) k_tgt_index(const uint32_t *__restrict__ keys, uint64_t n, int shift, uint32_t n_buckets,
-                                                    uint32_t *__restrict__ idx) {
-    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += (uint64_t) gridDim.x * blockDim.x) {
-        auto bucket = [&](uint64_t k) -> int64_t { const uint32_t x = keys[k]; return x == 0xFFFFFFFFu ? (int64_t) n_buckets : (int64_t) (x >> shift); };
-        const int64_t lo = i == 0 ? 0 : bucket(i - 1) + 1;
-        const int64_t hi = i == n ? (int64_t) n_buckets : bucket(i);
-        for (int64_t b = lo; b <= hi && b <= (int64_t) n_buckets; b++) idx[b] = (uint32_t) i;
-    }
-}
-
-// dir[b] = {idx[b], entries of bucket b, byte offsets of the eight m_C >> 3 classes inside it}: one thread per bucket
-__global__ void __launch_bounds__(256) k_tgt_dir(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ idx, uint32_t n_buckets, int shift,
-                                                  uint4 *__restrict__ dir) {
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b > n_buckets) return;
-    const uint32_t s0 = idx[b], s1 = idx[b < n_buckets ? b + 1 : b];     // two independent loads
-    const uint32_t c = s1 - s0;
-    uint32_t lo = 0u, hi = 0u;
-    if (c > 0u && c <= 255u) {
-        // first[s] = entries with class < s, eight saturation-free byte counters in two words (c <= 255).  Four keys per round
-        // trip: the loop runs as long as the fullest bucket of the wave needs, and every iteration is a memory latency
-        for (uint32_t j = s0; j < s1; j += 4u) {
-            uint32_t k4[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) k4[u] = keys[j + u < s1 ? j + u : s1 - 1u];
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                if (j + u < s1) {
-                    const uint32_t cls = (k4[u] >> (shift - 3)) & 7u;   // top three bits of the m_C field
-                    // classes 0..2 raise first[1..3] (bytes 1..3 of lo), classes 0..6 raise first[4..7] where cls < s
+// dir[b] = {first entry of bucket b (of the next non-empty one if b is empty), entries of bucket b, byte offsets of the eight
+// m_C >> 3 classes inside it}, for b in [0, n_buckets]; non-targets (all-ones keys) count as bucket n_buckets.  One thread per
+// entry of the sorted key array plus one past its end: the thread of the FIRST entry of a bucket makes the record of that
+// bucket and of the empty buckets before it.  One streaming pass over the keys, a tile of them (and what follows it) staged in
+// LDS so that a bucket is walked at LDS latency (round 2: an index array first, then a second pass through global memory per
+// bucket).  Measured and rejected: folding this pass into k_tgt_gather (the walk serialises behind that kernel's random row
+// reads: 6.5 against 3.0 + 1.2 ms); collecting the records of a tile in LDS and writing them out as whole lines (1.4 against 1.2 ms).
+constexpr int TD_TILE = 256, TD_HALO = 96;                 // entries per tile; entries staged past it
+__global__ void __launch_bounds__(TD_TILE) k_tgt_dir(const uint32_t *__restrict__ keys, uint64_t n, int shift, uint32_t n_buckets, uint4 *__restrict__ dir) {
+    __shared__ uint32_t sb[TD_TILE + TD_HALO + 1];         // (bucket << 3 | m_C class) of the entries base - 1 .. base + TD_TILE + TD_HALO - 1
+    const uint64_t base = (uint64_t) blockIdx.x * TD_TILE;
+    const uint32_t nb3 = n_buckets << 3;
+    auto tagged = [&](uint64_t k) -> uint32_t { if (k >= n) return nb3; const uint32_t x = keys[k]; return x == 0xFFFFFFFFu ? nb3 : x >> (shift - 3); };
+    for (int k = (int) threadIdx.x; k <= TD_TILE + TD_HALO; k += TD_TILE)
+        sb[k] = (base == 0 && k == 0) ? 0xFFFFFFFFu : tagged(base + (uint64_t) k - 1u);     // "entry -1": a bucket no entry has
+    __syncthreads();
+    const int t = (int) threadIdx.x;
+    const uint64_t j = base + (uint64_t) t;
+    auto put = [&](int64_t b, const uint4 &rec) { dir[b] = rec; };
+    if (j <= n) {
+        const uint32_t b = sb[t + 1] >> 3, bprev = sb[t] >> 3;
+        if (b != bprev) {
+            for (int64_t e = j == 0 ? 0 : (int64_t) bprev + 1; e < (int64_t) b; e++) put(e, make_uint4((uint32_t) j, 0u, 0u, 0u));
+            if (b == n_buckets) put(b, make_uint4((uint32_t) j, 0u, 0u, 0u));
+            else {
+                // first[s] = entries with class < s, eight saturation-free byte counters in two words (meaningful for c <= 255 only)
+                uint32_t lo = 0u, hi = 0u;
+                auto tally = [&](uint32_t cls) {
                     lo += (cls < 1u ? 0x00000100u : 0u) + (cls < 2u ? 0x00010000u : 0u) + (cls < 3u ? 0x01000000u : 0u);
                     hi += (cls < 4u ? 0x00000001u : 0u) + (cls < 5u ? 0x00000100u : 0u) + (cls < 6u ? 0x00010000u : 0u) + (cls < 7u ? 0x01000000u : 0u);
+                };
+                int u = 0;
+                const int lim = TD_TILE + TD_HALO - t;     // entries of this bucket that can lie in the staged tile
+                for (; u < lim; u++) {
+                    const uint32_t x = sb[t + 1 + u];
+                    if ((x >> 3) != b) break;
+                    tally(x & 7u);
                 }
+                uint64_t k = j + (uint64_t) u;
+                if (u == lim && (tagged(k) >> 3) == b) {   // the bucket runs past the tile (repeats): on through global memory
+                    for (; k < j + 256u; k++) {            // the class offsets matter up to 255 entries only
+                        const uint32_t x = tagged(k);
+                        if ((x >> 3) != b) break;
+                        tally(x & 7u);
+                    }
+                    if (k >= j + 256u && (tagged(k) >> 3) == b) {      // more than 256 entries: the end by bisection
+                        uint64_t a = k, z = n;             // bucket(a) == b, bucket(z) > b (z == n: past the end)
+                        while (z - a > 1) { const uint64_t mid = a + (z - a) / 2; if ((tagged(mid) >> 3) == b) a = mid; else z = mid; }
+                        k = z;
+                    }
+                }
+                const uint32_t c = (uint32_t) (k - j);
+                put(b, make_uint4((uint32_t) j, c, c <= 255u ? lo : 0u, c <= 255u ? hi : 0u));
             }
         }
     }
-    dir[b] = make_uint4(s0, c, lo, hi);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -565,7 +661,7 @@ k_probe_clustered(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__res
             const int p1 = higher ? __builtin_ctzll(higher) : nwin;
             const int rank = (int) __builtin_amdgcn_mbcnt_hi((uint32_t) (runmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) runmask, 0u));
             uint32_t key = 0u;
-            { uint32_t h, pk; kmer_key(sb, (int) (wm & 255u) < 128 ? (int) (wm & 255u) : 0, true, cc, h, pk); key = cluster_key(h); }
+            { uint32_t h, pk; kmer_key(sb, (int) (wm & 255u) < 128 ? (int) (wm & 255u) : 0, true, cc, h, pk); key = cluster_key(h, cc.idx_shift - CL_MBITS); }
             gs = 3;
             for (int rb = 0; rb < nrun_all; rb += CL_RMAX) {   // uniform
                 wave_lds_fence();
@@ -943,18 +1039,23 @@ void launch_cluster_keys(const NodesDev &nd, const PrefSufCfg &cfg, const Cluste
                          uint32_t *meta, void *runs, uint8_t *nruns, hipStream_t s) {
     if (node_end <= node_begin) return;
     const uint64_t m = (uint64_t) (node_end - node_begin);
-    hipLaunchKernelGGL(k_node_runs, dim3((unsigned) ((m + TK_ROWS - 1) / TK_ROWS)), dim3(TK_ROWS), 0, s, nd, cfg, cc, (int) node_begin, (int) node_end, keys, vals, meta,
-                       (uint2 *) runs, nruns);
+    const dim3 grid((unsigned) ((m + TK_ROWS - 1) / TK_ROWS)), block(TK_ROWS);
+    // rows of up to 9 words (every 100 - 150 bp configuration) stage 11 words per node, longer ones (<= 13 words) 17
+    if (blocks_of(cfg.Lcap - 1) <= 9)
+        hipLaunchKernelGGL(k_node_runs<11>, grid, block, 0, s, nd, cfg, cc, (int) node_begin, (int) node_end, keys, vals, meta, (uint2 *) runs, nruns);
+    else
+        hipLaunchKernelGGL(k_node_runs<17>, grid, block, 0, s, nd, cfg, cc, (int) node_begin, (int) node_end, keys, vals, meta, (uint2 *) runs, nruns);
 }
 
 __global__ void __launch_bounds__(256) k_iota(uint32_t *__restrict__ v, uint32_t n) {
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) v[i] = i;
 }
 
-// keys / meta of all n nodes -> the entry array in key order and its bucket index.  fill_vals: the ids (sort payload) were not
-// written by this engine's key pass for every node (keys gathered from other ranks): write them here.
+// keys / meta of all n nodes -> the entry array in key order and its bucket directory.  fill_vals: the ids (sort payload) were not
+// written by this engine's key pass for every node (keys gathered from other ranks): write them here.  uniform_len > 0: every
+// live node has that length and there is no alignFrom mask (k_tgt_gather<., true>: meta[] is not read).
 hipError_t launch_cluster_store(const NodesDev &nd, const ClusterCfg &cc, int eq, uint32_t *keys, uint32_t *vals, uint32_t *keys2, uint32_t *vals2,
-                                const uint32_t *meta, void *sort_temp, size_t sort_temp_bytes, void *store, uint32_t *idx, void *dir, bool fill_vals,
+                                const uint32_t *meta, int uniform_len, void *sort_temp, size_t sort_temp_bytes, void *store, void *dir, bool fill_vals,
                                 hipStream_t s) {
     if (nd.n <= 0) return hipSuccess;
     const uint64_t n = (uint64_t) nd.n;
@@ -963,13 +1064,16 @@ hipError_t launch_cluster_store(const NodesDev &nd, const ClusterCfg &cc, int eq
     if (err != hipSuccess) return err;
     const uint64_t pieces = n * (uint64_t) eq;
     const unsigned g = (unsigned) ((pieces + 255) / 256);
-    if (eq == 2)      hipLaunchKernelGGL(k_tgt_gather<2>, dim3(g), dim3(256), 0, s, nd, (const uint32_t *) keys2, (const uint32_t *) vals2, meta, (uint4 *) store);
-    else if (eq == 3) hipLaunchKernelGGL(k_tgt_gather<3>, dim3(g), dim3(256), 0, s, nd, (const uint32_t *) keys2, (const uint32_t *) vals2, meta, (uint4 *) store);
-    else              hipLaunchKernelGGL(k_tgt_gather<4>, dim3(g), dim3(256), 0, s, nd, (const uint32_t *) keys2, (const uint32_t *) vals2, meta, (uint4 *) store);
-    hipLaunchKernelGGL(k_tgt_index, dim3((unsigned) std::min<uint64_t>((n + 256) / 256, 16384)), dim3(256), 0, s, (const uint32_t *) keys2, n, cc.idx_shift,
-                       cc.n_buckets, idx);
-    hipLaunchKernelGGL(k_tgt_dir, dim3((cc.n_buckets + 1 + 255) / 256), dim3(256), 0, s, (const uint32_t *) keys2, (const uint32_t *) idx, cc.n_buckets, cc.idx_shift,
-                       (uint4 *) dir);
+    const int fs = cc.idx_shift - CL_MBITS;
+    const uint32_t um = uniform_len > 0 ? (((uint32_t) uniform_len << 8) | CL_META_FROM) : 0u;
+#define TG_LAUNCH(E, U) hipLaunchKernelGGL((k_tgt_gather<E, U>), dim3(g), dim3(256), 0, s, nd, (const uint32_t *) keys2, (const uint32_t *) vals2, meta, um, fs, (uint4 *) store)
+#define TG_EQ(E) do { if (uniform_len > 0) TG_LAUNCH(E, true); else TG_LAUNCH(E, false); } while (0)
+    if (eq == 2)      TG_EQ(2);
+    else if (eq == 3) TG_EQ(3);
+    else              TG_EQ(4);
+#undef TG_EQ
+#undef TG_LAUNCH
+    hipLaunchKernelGGL(k_tgt_dir, dim3((unsigned) ((n + 1 + TD_TILE - 1) / TD_TILE)), dim3(TD_TILE), 0, s, (const uint32_t *) keys2, n, cc.idx_shift, cc.n_buckets, (uint4 *) dir);
     return hipGetLastError();
 }
 

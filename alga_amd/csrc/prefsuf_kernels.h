@@ -10,7 +10,7 @@ namespace alga {
 struct alga_edge_dev { int32_t src, dst, offset; }; // layout == alga_edge of include/alga_amd.h
 
 void launch_restride(const uint32_t *in, int stride_in, uint32_t *out, int stride_out, uint64_t n, hipStream_t s);
-void launch_node_stats(const NodesDev &nd, unsigned long long *counters, int *max_len, hipStream_t s);
+void launch_node_stats(const NodesDev &nd, unsigned long long *counters, int *max_len /* [0] = max length, [1] = INT32_MAX - min length of the live nodes */, hipStream_t s);
 
 uint32_t seed_buckets_for(uint64_t live_nodes, int fill_x10);
 uint32_t seed_filter_bits_for(uint64_t live_nodes);   // 0 = prefilter off
@@ -38,12 +38,12 @@ void launch_local_emit(int32_t src_base, int32_t n_src, const uint32_t *deg, con
 // clustered minimizer join (prefsuf_cluster.hip): source-side form with one-word offset masks (max_len - Lmin <= 63)
 bool       cluster_plan(const PrefSufCfg &cfg, int max_len, uint64_t live, int bucket_log2_bias, ClusterCfg *c, int *eq);   // false: this probe does not take the input
 size_t     cluster_sort_temp_bytes(uint64_t n);
-// keys/vals/keys2/vals2/meta: n uint32 each; runs: n * CL_RMAX * 8 bytes; nruns: n bytes; store: (n + 2) * 16 * eq bytes; idx: n_buckets + 2 uint32; dir: (n_buckets + 2) * 16 bytes
+// keys/vals/keys2/vals2/meta: n uint32 each; runs: n * CL_RMAX * 8 bytes; nruns: n bytes; store: (n + 2) * 16 * eq bytes; dir: (n_buckets + 2) * 16 bytes
 void       launch_cluster_keys(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterCfg &cc, int32_t node_begin, int32_t node_end, uint32_t *keys,
                                uint32_t *vals, uint32_t *meta, void *runs, uint8_t *nruns, hipStream_t s);
 hipError_t launch_cluster_store(const NodesDev &nd, const ClusterCfg &cc, int eq, uint32_t *keys, uint32_t *vals, uint32_t *keys2, uint32_t *vals2,
-                                const uint32_t *meta, void *sort_temp, size_t sort_temp_bytes, void *store, uint32_t *idx, void *dir, bool fill_vals,
-                                hipStream_t s);
+                                const uint32_t *meta, int uniform_len /* > 0: all live nodes have this length, no alignFrom mask */, void *sort_temp,
+                                size_t sort_temp_bytes, void *store, void *dir, bool fill_vals, hipStream_t s);
 uint64_t   cluster_record_slack(int n_cu, uint64_t n_src);
 void       launch_probe_pairs(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterCfg &cc, int eq, const void *store, const void *dir,
                               const void *runs, const uint8_t *nruns, int32_t src_begin, int32_t src_end, unsigned long long *counters, int n_cu, uint32_t *deg,

@@ -36,26 +36,27 @@ namespace alga {
 // k_node_stats : few workgroups, grid-stride (one contended atomic per wave would dominate)
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_node_stats(NodesDev nd, unsigned long long *counters, int *max_len) {
-    __shared__ int s_max[4];
+    __shared__ int s_max[4], s_min[4];
     __shared__ unsigned long long s_live[4];
-    int m = 0;
+    int m = 0, mn = 0x7FFFFFFF;
     unsigned long long live = 0, asym = 0;
     for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < nd.n; i += (int64_t) gridDim.x * blockDim.x) {
         int l = nd.len[i];
         m = l > m ? l : m;
+        mn = (l > 0 && l < mn) ? l : mn;
         live += l > 0;
         if (nd.to && l > 0 && !nd.to[i] && (nd.from == nullptr || nd.from[i])) asym++;
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(m, o); m = t > m ? t : m; }
+    for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(m, o); m = t > m ? t : m; t = __shfl_xor(mn, o); mn = t < mn ? t : mn; }
     live = wave_sum_u64(live);
     asym = wave_sum_u64(asym);
     const int wave = (int) (threadIdx.x >> 6);
-    if (lane_id() == 0) { s_max[wave] = m; s_live[wave] = live; if (asym) atomicAdd(&counters[CNT_MASK_ASYM], asym); }
+    if (lane_id() == 0) { s_max[wave] = m; s_min[wave] = mn; s_live[wave] = live; if (asym) atomicAdd(&counters[CNT_MASK_ASYM], asym); }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int w = 1; w < 4; w++) { m = s_max[w] > m ? s_max[w] : m; live += s_live[w]; }
-        if (m > 0) atomicMax(max_len, m);
+        for (int w = 1; w < 4; w++) { m = s_max[w] > m ? s_max[w] : m; mn = s_min[w] < mn ? s_min[w] : mn; live += s_live[w]; }
+        if (m > 0) { atomicMax(max_len, m); atomicMax(max_len + 1, 0x7FFFFFFF - mn); }
         if (live) atomicAdd(&counters[CNT_LIVE_NODES], live);
     }
 }
