@@ -220,35 +220,38 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
         HIP_TRY(e, hipMemsetAsync(cnt, 0, CNT_TOTAL * sizeof(unsigned long long), s));
         ProbeBig big{(int32_t *) e->loc_big_list.p, big_list_cap, 0u, nullptr, 0u};
         if (clustered) {
-            // Two kernels: the pair kernel (two sources per wave) finishes the regular sources and lists the others; the general
-            // kernel (one source per wave, any shape) takes the list.  Data on which most sources are irregular (sequencing errors:
-            // several items per offset) would pay the pair kernel for nothing: after a build that deferred more than half of its
-            // sources the engine goes straight to the general kernel.
-            const bool pairs = e->opt_cluster_pairs && e->cl_defer_ratio <= 0.5;
-            if (pairs) {
+            // Two kernels: the quad kernel (four sources per wave, entries packed densely; option cluster_pairs = 1: round 2's pair
+            // kernel, two sources per wave) finishes the regular sources and lists the others; the general kernel (one source per
+            // wave, any shape) takes the list.  No host round trip in between: the general kernel runs as a persistent grid over a
+            // list whose length it reads from the device counter the first kernel left.  Data on which most sources are irregular
+            // (sequencing errors: several items per offset): the waves of the first kernel notice it on their own first sources
+            // and hand the rest of their share on unseen -- a decision taken from THIS build's data, not from an earlier build.
+            if (e->opt_cluster_pairs) {
                 if ((rc = alga_ensure(e, e->cl_defer, (size_t) (n_src + 64) * sizeof(int32_t)))) return rc;
                 if ((rc = alga_ensure(e, e->loc_second, (size_t) (n_src + 1) * sizeof(unsigned long long)))) return rc;
                 e->loc_second_used = true;
-                launch_probe_pairs(nd, cfg, cc, pp.cluster_eq, e->cl_store.p, e->cl_dir.p, e->cl_runs.p, (const uint8_t *) e->cl_nruns.p,
-                                   src_begin, src_end, cnt, e->n_cu, (uint32_t *) e->outdeg.p, (unsigned long long *) e->loc_first.p,
-                                   (unsigned long long *) e->loc_second.p, (int32_t *) e->cl_defer.p, (uint32_t) n_src, s);
-                if ((rc = alga_check_launch(e, "k_probe_pairs"))) return rc;
+                if (e->opt_cluster_pairs == 1)
+                    launch_probe_pairs(nd, cfg, cc, pp.cluster_eq, e->cl_store.p, e->cl_dir.p, e->cl_runs.p, (const uint8_t *) e->cl_nruns.p,
+                                       src_begin, src_end, cnt, e->n_cu, (uint32_t *) e->outdeg.p, (unsigned long long *) e->loc_first.p,
+                                       (unsigned long long *) e->loc_second.p, (int32_t *) e->cl_defer.p, (uint32_t) n_src, s);
+                else {
+                    // all sources: in the order of the entry array (consecutive sources share a locus: option cluster_order); a range of
+                    // ids (a rank's share, a piece): in id order
+                    const bool by_key = e->opt_cluster_order != 0 && src_begin == 0 && src_end == nd.n;
+                    launch_probe_quads(nd, cfg, cc, pp.cluster_eq, e->cl_store.p, e->cl_dir.p, e->cl_runs.p, (const uint8_t *) e->cl_nruns.p,
+                                       src_begin, src_end, by_key, cnt, e->n_cu, (uint32_t *) e->outdeg.p, (unsigned long long *) e->loc_first.p,
+                                       (unsigned long long *) e->loc_second.p, (int32_t *) e->cl_defer.p, (uint32_t) n_src, s);
+                }
+                if ((rc = alga_check_launch(e, "k_probe_quads / k_probe_pairs"))) return rc;
                 HIP_TRY(e, hipEventRecord(e->ev[EV_PAIRS], s));
                 e->pairs_timed = true;
-                HIP_TRY(e, hipMemcpyAsync(&e->h_counters[CNT_DEFERRED], cnt + CNT_DEFERRED, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-                HIP_TRY(e, hipStreamSynchronize(s));
-                const uint64_t n_def = e->h_counters[CNT_DEFERRED];
-                e->cl_defer_ratio = n_src ? (double) n_def / (double) n_src : 0.0;
-                e->stats.deferred_sources = n_def;
-                if (n_def)
-                    launch_probe_clustered(nd, cfg, cc, pp.cluster_eq, e->cl_store.p, e->cl_dir.p, e->cl_runs.p, (const uint8_t *) e->cl_nruns.p, 0,
-                                           (int32_t) n_def, (const int32_t *) e->cl_defer.p, src_begin, (uint32_t *) e->rec_dst.p, (unsigned long long *) e->rec_val.p,
-                                           cap, cnt, e->n_cu, (uint32_t *) e->outdeg.p, (unsigned long long *) e->loc_first.p, &big, s);
+                launch_probe_clustered(nd, cfg, cc, pp.cluster_eq, e->cl_store.p, e->cl_dir.p, e->cl_runs.p, (const uint8_t *) e->cl_nruns.p, 0,
+                                       (int32_t) n_src, (const int32_t *) e->cl_defer.p, src_begin, (uint32_t *) e->rec_dst.p, (unsigned long long *) e->rec_val.p,
+                                       cap, cnt, e->n_cu, (uint32_t *) e->outdeg.p, (unsigned long long *) e->loc_first.p, &big, cnt + CNT_DEFERRED, s);
             } else {
-                e->stats.deferred_sources = n_src;
                 launch_probe_clustered(nd, cfg, cc, pp.cluster_eq, e->cl_store.p, e->cl_dir.p, e->cl_runs.p, (const uint8_t *) e->cl_nruns.p, src_begin,
                                        src_end, nullptr, src_begin, (uint32_t *) e->rec_dst.p, (unsigned long long *) e->rec_val.p, cap, cnt, e->n_cu,
-                                       (uint32_t *) e->outdeg.p, (unsigned long long *) e->loc_first.p, &big, s);
+                                       (uint32_t *) e->outdeg.p, (unsigned long long *) e->loc_first.p, &big, nullptr, s);
             }
         }
         else
@@ -293,6 +296,7 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
             e->stats.windows_probed = e->h_counters[CNT_WINDOWS];
             e->stats.slots_scanned = e->h_counters[CNT_SLOTS];
             e->stats.probe_used = clustered ? ALGA_PROBE_CLUSTER : ALGA_PROBE_TABLE;
+            if (clustered) e->stats.deferred_sources = e->opt_cluster_pairs ? e->h_counters[CNT_DEFERRED] : n_src;
             return ALGA_OK;
         }
         cap = need + need / 16 + 4096 + slack; // the cursor kept counting past the capacity: the need is known
@@ -494,8 +498,10 @@ int alga_engine_set_option(alga_engine *e, const char *name, int64_t value) {
         if (value < -8 || value > 8) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "option cluster_bucket_bias: -8 .. 8");
         e->opt_cluster_bucket_bias = (int) value;
     } else if (!strcmp(name, "cluster_pairs")) {
-        e->opt_cluster_pairs = value != 0;
-        e->cl_defer_ratio = 0.0;
+        if (value < 0 || value > 2) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "option cluster_pairs: 0 general kernel only, 1 pair kernel first, 2 quad kernel first");
+        e->opt_cluster_pairs = (int) value;
+    } else if (!strcmp(name, "cluster_order")) {
+        e->opt_cluster_order = value != 0;
     } else if (!strcmp(name, "local_big_max")) {
         e->big_limit = value < 0 ? -1 : (int) std::min<int64_t>(value, 1 << 20);
     } else if (!strcmp(name, "auto_reduction_per_target")) {

@@ -49,8 +49,8 @@ struct alga_engine {
     int stat_max_len = 0, stat_min_len = 0; uint64_t stat_live = 0; unsigned long long stat_mask_asym = 0;
     const void *stat_len = nullptr, *stat_from = nullptr, *stat_to = nullptr;
     bool   pairs_timed = false;                             // EV_PAIRS was recorded in the last discovery
-    double cl_defer_ratio = 0.0;                            // ... their share in the last build: above one half the pair kernel is skipped
-    int    opt_cluster_pairs = 1;                           // option "cluster_pairs": 0 = general kernel only
+    int    opt_cluster_order = 1;                           // option "cluster_order": the quad kernel walks all sources in entry-array (key) order (0: id order)
+    int    opt_cluster_pairs = 2;                           // option "cluster_pairs": 0 = general kernel only, 1 = pair kernel first, 2 = quad kernel first
     DevBuf cl_keys[2], cl_vals[2], cl_meta, cl_runs, cl_nruns, cl_store, cl_dir;   // clustered minimizer join: sort buffers, per-node minimizer runs, entry array, bucket directory
     DevBuf loc_second;                                      // ... the other edge of a two-edge source the pair kernel finished (clustered probe)
     bool   loc_second_used = false;                         // the last discovery wrote loc_second

@@ -128,8 +128,11 @@ int         alga_engine_device_name(const alga_engine *e, char *buf, size_t bufl
 /* Engine switches.  None changes a result, only how it is computed; there are no environment variables.
  *   "probe"                      alga_probe (default AUTO)
  *   "cluster_bucket_bias"        -8..8: log2 factor on the bucket count of the CLUSTER probe's index (default 0: ~1 entry per bucket)
- *   "cluster_pairs"              0: the CLUSTER probe runs its general kernel only (one source per wave); default 1: the pair
- *                                kernel (two sources per wave) first, the general kernel on what it defers
+ *   "cluster_pairs"              0: the CLUSTER probe runs its general kernel only (one source per wave); 1: the pair kernel (two
+ *                                sources per wave) first, the general kernel on what it defers; default 2: the quad kernel (four
+ *                                sources per wave, their entries packed densely onto the lanes) first
+ *   "cluster_order"              default 1: the quad kernel takes the sources in the order of the entry array (sources of one locus together:
+ *                                shared look-ups, cache hits); 0: in id order (what a range of ids always gets)
  *   "local_big_max"              largest per-wave item slice of the SOURCE_SIDE second pass (default -1 = built-in 4096); beyond it
  *                                the build takes PER_TARGET
  *   "auto_reduction_per_target"  != 0: alga_prefsuf_params.reduction == AUTO resolves to PER_TARGET */

@@ -49,13 +49,19 @@ def _check(eng, words, lens, lo, rs, af=None, at=None, stats=True, source_side=N
         if maxlen - lo + 1 > lo - kk + 1:
             kk = 2 * lo - maxlen
         clusterable = 1 <= maxlen - lo + 1 <= 64 and (2 * maxlen + 31) // 32 <= 13 and 8 <= kk <= min(32, lo)
-        for probe in ("table", "cluster"):
+        # the clustered probe with its quad kernel first (the default; sources in key order and in id order) and with round 2's
+        # pair kernel first
+        for probe, first_kernel, order in (("table", 2, 1), ("cluster", 2, 1), ("cluster", 2, 0), ("cluster", 1, 1)):
             eng.set_option("probe", probe)
+            eng.set_option("cluster_pairs", first_kernel)
+            eng.set_option("cluster_order", order)
             try:
                 got2 = eng.prefsuf_host(words, lens, lo, rs, af, at, collect_stats=stats, reduction="source_side")
             finally:
                 eng.set_option("probe", "auto")
-            assert got2.shape == want.shape and (got2 == want).all(), probe
+                eng.set_option("cluster_pairs", 2)
+                eng.set_option("cluster_order", 1)
+            assert got2.shape == want.shape and (got2 == want).all(), (probe, first_kernel, order)
             st = eng.last_stats()
             assert st["reduction_used"] == 2 and st["edges"] == len(want)
             assert st["probe_used"] == (2 if probe == "cluster" and clusterable else 1)
@@ -368,16 +374,17 @@ def test_exchange_helpers_emulated_ranks(eng):
 def test_cluster_directory_geometries(n, length, G, seed, err, minlen, lo, rs):
     """the clustered probe with every shape of its bucket directory: few huge buckets (more than 255 entries: the directory's byte
     offsets saturate and a run reads the whole bucket), one cluster per bucket, more buckets than the key has bits for (clamped);
-    with and without the pair kernel.  Always the same graph."""
+    with the quad kernel, the pair kernel or the general kernel alone.  Always the same graph."""
     words, lens = _nodes(n, length, G, seed, err, minlen)
     want, _, _ = O.prefsuf(words, lens, lo, rs)
     e = alga_amd.Engine(0)
     try:
         e.set_option("probe", "cluster")
         for bias in (-8, -4, 0, 3, 8):
-            for pairs in (1, 0):
+            for pairs in (2, 3, 1, 0):                    # 3: the quad kernel over the sources in id order
                 e.set_option("cluster_bucket_bias", bias)
-                e.set_option("cluster_pairs", pairs)
+                e.set_option("cluster_pairs", min(pairs, 2))
+                e.set_option("cluster_order", 0 if pairs == 3 else 1)
                 got = e.prefsuf_host(words, lens, lo, rs, reduction="source_side")
                 st = e.last_stats()
                 assert st["probe_used"] == 2, (bias, pairs)

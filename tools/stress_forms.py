@@ -88,7 +88,7 @@ def main():
         words, lens, lo, rs, af, at, desc = make_case(seed)
         a = eng.prefsuf_host(words, lens, lo, rs, af, at, reduction="per_target")
         ok = True
-        for probe, pairs in (("table", 1), ("cluster", 1), ("cluster", 0)):
+        for probe, pairs in (("table", 2), ("cluster", 2), ("cluster", 1), ("cluster", 0)):
             eng.set_option("probe", probe)
             eng.set_option("cluster_pairs", pairs)
             try:
@@ -100,7 +100,7 @@ def main():
                 break
             finally:
                 eng.set_option("probe", "auto")
-                eng.set_option("cluster_pairs", 1)
+                eng.set_option("cluster_pairs", 2)
             st = eng.last_stats()
             if probe == "table":
                 big += st["big_sources"] > 0
