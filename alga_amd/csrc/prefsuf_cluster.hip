@@ -1032,7 +1032,7 @@ k_probe_pairs(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__restric
 // for k_probe_clustered.  A wave that has had to defer more than half of its first sources (reads with sequencing errors) stops
 // verifying and lists the rest of its share: the decision is taken from THIS build's data, inside the kernel.
 #ifndef CLQ_OCC
-#define CLQ_OCC 6
+#define CLQ_OCC 5                      // workgroups per CU: 20 waves per CU (84 VGPRs; at 6 the kernel spills into scratch inside the loop)
 #endif
 struct QuadPlan {                     // of one quad, wave-uniform (scalar registers)
     int t[4];                         // entries of source g (0: not packed)
@@ -1245,7 +1245,9 @@ k_probe_quads(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__restric
         const uint32_t id = ew[4 * EQ - 3], eh = ew[4 * EQ - 2], meta = ew[4 * EQ - 1];
         const int lenC = (int) ((meta >> 8) & 0xFFFu);
         int p = (int) (rp.x & 255u) - (int) (meta & 255u);
-        const bool ok = ev && same_cluster(eh, rp.y, cc.idx_shift - CL_MBITS) && p >= (int) ((rp.x >> 8) & 255u) && p < (int) ((rp.x >> 16) & 255u) && (int) id != Bs && lenC >= lenBs - p;
+        // (bitwise &: one straight line of compares instead of a chain of exec-mask branches)
+        const bool ok = ev & same_cluster(eh, rp.y, cc.idx_shift - CL_MBITS) & (p >= (int) ((rp.x >> 8) & 255u)) & (p < (int) ((rp.x >> 16) & 255u)) & ((int) id != Bs) &
+                        (lenC >= lenBs - p);
         p = ok ? p : 0;
         const int L = lenBs - p, nb = 2 * L;
         bool pass;
@@ -1298,7 +1300,7 @@ k_probe_quads(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__restric
             uint8_t *Tb = sT[wave][s];
             if (pass) { atomicOr(occp, 1ull << d); Tb[d] = (uint8_t) lane; }
             wave_lds_fence();
-            const uint64_t occ = *(volatile unsigned long long *) occp;
+            const uint64_t occ = *occp;                    // (plain LDS reads: a volatile access becomes a flat load and drains vmcnt)
             const bool clash = pass && Tb[d] != (uint8_t) lane;        // another item of this source sits at the same offset
             const uint64_t below = pass ? (occ & ((1ull << d) - 1ull)) : 0ull;
             has_pred = below != 0ull;
@@ -1308,14 +1310,23 @@ k_probe_quads(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__restric
             oj.w[0] = bperm(v_o.x, j); oj.w[1] = bperm(v_o.y, j); oj.w[2] = bperm(v_o.z, j); oj.w[3] = bperm(v_o.w, j);
             oi.w[0] = v_o.x; oi.w[1] = v_o.y; oi.w[2] = v_o.z; oi.w[3] = v_o.w;
             const int rho = lenC - (lenBs - d);
-            const bool removed = has_pred && via_ok<1>(Bs, lenBs, Lbig, Cj, mj, oj, id, d, rho, oi);
+            bool removed;
+            if constexpr (KF > 0) {
+                // via_ok<1> (prefsuf_device.h) with the four word masks of the overhang compare from the table in LDS
+                const int dj = (int) (mj & 511u), lenj = (int) ((mj >> 9) & 511u);
+                const int rho_j = lenj - (lenBs - dj), Lv = lenj - (d - dj);
+                const bool vok = ((mj & ITEM_FROM) != 0u) & (Cj != id) & (dj < d) & (Lv >= Lbig) & (rho_j <= rho) & ((rho_j > 0) | ((int) Cj > Bs));
+                const uint4 m4 = sMask[min(max(2 * rho_j, 0), 128)];
+                const uint32_t df = ((oi.w[0] ^ oj.w[0]) & m4.x) | ((oi.w[1] ^ oj.w[1]) & m4.y) | ((oi.w[2] ^ oj.w[2]) & m4.z) | ((oi.w[3] ^ oj.w[3]) & m4.w);
+                removed = has_pred & vok & (df == 0u);
+            } else removed = has_pred && via_ok<1>(Bs, lenBs, Lbig, Cj, mj, oj, id, d, rho, oi);
             // not removed by the nearest predecessor although even the longest read placed there could reach C with a big overlap: undecided here
             const bool fail = has_pred && !removed && (cfg.Lcap - 1) - (d - (int) (mj & 511u)) >= Lbig;
             const bool keep = pass && !removed;
             if (clash || fail) atomicOr(stp, 1u);
             if (keep) atomicAdd(stp, 0x100u);
             wave_lds_fence();
-            stv = *(volatile uint32_t *) stp;
+            stv = *stp;
             if (keep && stv == 0x100u) {                   // the only item that stands: the source's edge
                 o.first[Bs - o.src_base] = ((unsigned long long) id << 32) | (uint32_t) d;
                 o.deg[Bs - o.src_base] = 1u;
@@ -1359,7 +1370,7 @@ k_probe_quads(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__restric
         {
             const int my_rnd = g == 0 ? P.rnd[0] : (g == 1 ? P.rnd[1] : (g == 2 ? P.rnd[2] : P.rnd[3]));
             if (gl == 0 && my_rnd == r) {
-                const uint32_t sv = *(volatile uint32_t *) &sStat[wave][buf][g];
+                const uint32_t sv = sStat[wave][buf][g];
                 red = ((P.pk >> g) & 1u) != 0u && (sv & 255u) == 0u && (sv >> 8) <= 2u;
                 if (STATS && red) st_win += (uint64_t) (lenB - cfg.Lmin + 1);
             }
