@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <new>
 #include <string>
 
 #include "engine_internal.h"
@@ -146,6 +147,7 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
     if (pp.live >= (1ull << 31)) return alga_fail(e, ALGA_ERR_CAPACITY, "too many nodes for one seed table; shard the input");
     const bool clustered = local && pp.cluster_eq != 0;
     e->pairs_timed = false;
+    e->store_timed = false;
     e->loc_second_used = false;
     uint32_t n_buckets = 0, filter_bits = 0;
     bool have_table = false;
@@ -190,11 +192,14 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
                                     (uint8_t *) e->cl_nruns.p, s);
                 if ((rc = alga_check_launch(e, "k_node_runs"))) return rc;
             }
+            HIP_TRY(e, hipEventRecord(e->ev[EV_KEYS], s));
             e->keyed_n = -1;                               // the sort below may reuse the key buffers: one build per key pass
             e->store_n = -1;
             HIP_TRY(e, launch_cluster_store(nd, cc, pp.cluster_eq, (uint32_t *) e->cl_keys[0].p, (uint32_t *) e->cl_vals[0].p, (uint32_t *) e->cl_keys[1].p,
                                             (uint32_t *) e->cl_vals[1].p, (const uint32_t *) e->cl_meta.p, pp.uniform_len, e->sort_temp.p,
-                                            cluster_sort_temp_bytes((uint64_t) nd.n), e->cl_store.p, e->cl_dir.p, pp.keys_shared == 1, s));
+                                            cluster_sort_temp_bytes((uint64_t) nd.n), e->cl_store.p, e->cl_dir.p, pp.keys_shared == 1, e->ev[EV_SORT],
+                                            e->ev[EV_GATHER], s));
+            e->store_timed = nd.n > 0;
             e->store_n = nd.n; e->store_words = (const void *) nd.words; e->store_eq = pp.cluster_eq; e->store_buckets = cc.n_buckets;
             e->store_run_begin = run_begin; e->store_run_end = run_end;
         }
@@ -425,6 +430,15 @@ float ev_ms(alga_engine *e, int a, int b) {
     return ms;
 }
 
+// the parts of the index build of the clustered probe (what ms_seed is made of)
+void store_phase_stats(alga_engine *e) {
+    if (!e->store_timed) return;
+    e->stats.ms_keys = ev_ms(e, EV_START, EV_KEYS);
+    e->stats.ms_sort = ev_ms(e, EV_KEYS, EV_SORT);
+    e->stats.ms_gather = ev_ms(e, EV_SORT, EV_GATHER);
+    e->stats.ms_dir = ev_ms(e, EV_GATHER, EV_SEED);
+}
+
 } // namespace
 
 // ============================================================================================
@@ -434,6 +448,22 @@ extern "C" {
 
 int alga_abi_version(void) { return ALGA_AMD_ABI_VERSION; }
 
+// the caller's current HIP device stays what it was across create / destroy (the engine sets its own device in every call that
+// needs it; a host program with several GPUs must not find its device switched by a library call)
+struct DeviceGuard {
+    int prev = -1;
+    DeviceGuard() { if (hipGetDevice(&prev) != hipSuccess) prev = -1; }
+    ~DeviceGuard() { if (prev >= 0) (void) hipSetDevice(prev); }
+};
+
+static void engine_free_handles(alga_engine *e) {
+    if (e->h_counters) (void) hipHostFree(e->h_counters);
+    for (int i = 0; i < EV_COUNT; i++) if (e->ev[i]) (void) hipEventDestroy(e->ev[i]);
+    if (e->own_stream) (void) hipStreamDestroy(e->own_stream);
+    e->h_counters = nullptr; e->own_stream = nullptr;
+    for (int i = 0; i < EV_COUNT; i++) e->ev[i] = nullptr;
+}
+
 int alga_engine_create(int hip_device, alga_engine **out) {
     if (!out) return ALGA_ERR_INVALID_ARGUMENT;
     *out = nullptr;
@@ -441,8 +471,10 @@ int alga_engine_create(int hip_device, alga_engine **out) {
     hipError_t err = hipGetDeviceCount(&ndev);
     if (err != hipSuccess || ndev <= 0) return ALGA_ERR_NO_DEVICE;
     if (hip_device < 0 || hip_device >= ndev) return ALGA_ERR_INVALID_ARGUMENT;
+    DeviceGuard guard;
     if (hipSetDevice(hip_device) != hipSuccess) return ALGA_ERR_NO_DEVICE;
-    alga_engine *e = new alga_engine();
+    alga_engine *e = new (std::nothrow) alga_engine();
+    if (!e) return ALGA_ERR_OUT_OF_MEMORY;
     e->device = hip_device;
     memset(&e->stats, 0, sizeof(e->stats));
     hipDeviceProp_t prop;
@@ -450,33 +482,29 @@ int alga_engine_create(int hip_device, alga_engine **out) {
         snprintf(e->dev_name, sizeof(e->dev_name), "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
         if (prop.multiProcessorCount > 0) e->n_cu = prop.multiProcessorCount;
     }
-    if (hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking) != hipSuccess) { delete e; return ALGA_ERR_HIP; }
-    for (int i = 0; i < EV_COUNT; i++)
-        if (hipEventCreate(&e->ev[i]) != hipSuccess) { delete e; return ALGA_ERR_HIP; }
-    if (hipHostMalloc((void **) &e->h_counters, (CNT_TOTAL + 2) * sizeof(unsigned long long)) != hipSuccess) { delete e; return ALGA_ERR_OUT_OF_MEMORY; }
+    int rc = ALGA_OK;
+    if (hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking) != hipSuccess) { e->own_stream = nullptr; rc = ALGA_ERR_HIP; }
+    for (int i = 0; i < EV_COUNT && rc == ALGA_OK; i++)
+        if (hipEventCreate(&e->ev[i]) != hipSuccess) { e->ev[i] = nullptr; rc = ALGA_ERR_HIP; }
+    if (rc == ALGA_OK && hipHostMalloc((void **) &e->h_counters, (CNT_TOTAL + 2) * sizeof(unsigned long long)) != hipSuccess) { e->h_counters = nullptr; rc = ALGA_ERR_OUT_OF_MEMORY; }
+    if (rc != ALGA_OK) { engine_free_handles(e); delete e; return rc; }     // nothing the failed attempt created is left behind
     *out = e;
     return ALGA_OK;
 }
 
 void alga_engine_destroy(alga_engine *e) {
     if (!e) return;
+    DeviceGuard guard;
     (void) hipSetDevice(e->device);
     if (e->own_stream) (void) hipStreamSynchronize(e->own_stream);
-    DevBuf *bufs[] = {&e->table, &e->filter, &e->counters, &e->rowptr, &e->rec_dst, &e->rec_val, &e->keys, &e->seg_key, &e->seg_val, &e->heads, &e->sort_temp,
-                      &e->out_cnt, &e->outdeg, &e->out_rowptr, &e->edges, &e->scan_scratch, &e->up_words, &e->up_len, &e->up_from, &e->up_to,
-                      &e->cl_keys[0], &e->cl_keys[1], &e->cl_vals[0], &e->cl_vals[1], &e->cl_defer, &e->cl_meta, &e->cl_runs, &e->cl_nruns, &e->cl_store, &e->loc_first, &e->loc_big_list, &e->loc_big_items, &e->edge_keys, &e->edge_keys2, &e->edge_vals, &e->edge_vals2, &e->edges_sorted, &e->xs_dst, &e->xs_val,
-                      &e->pk_keys, &e->pk_keys2, &e->pk_vals, &e->pk_vals2, &e->pk_marks, &e->pk_big, &e->pk_add, &e->pk_ekeys, &e->pk_ekeys2,
-                      &e->pk_flag, &e->pk_pos, &e->pk_edges[0], &e->pk_edges[1], &e->pk_rowptr, &e->pk_deg, &e->pk_mask, &e->pk_cnt, &e->pk_io, &e->pk_io2, &e->pk_tips, &e->pk_heads, &e->pp_rows, &e->pp_len, &e->pp_perm[0], &e->pp_perm[1], &e->pp_keys[0], &e->pp_keys[1], &e->pp_mark,
-                      &e->pp_keep, &e->pp_pos, &e->pp_out_rows, &e->pp_out_len, &e->pp_out_pair, &e->pp_tally};
-    for (DevBuf *b : bufs) alga_release(*b);
-    for (DevBuf *b : e->owned) alga_release(*b);           // everything alga_ensure ever allocated (covers the list above and what it misses)
+    for (DevBuf *b : e->owned) alga_release(*b);           // everything alga_ensure ever allocated
     alga_release(e->up_raw);
     for (DevBuf *b : {&e->in_bytes[0], &e->in_bytes[1], &e->in_nl[0], &e->in_nl[1], &e->in_tiles, &e->in_tile_off}) alga_release(*b);
     for (DevBuf *b : {&e->sp_rowptr, &e->sp_sorted, &e->sp_list, &e->sp_cnt, &e->sp_orow, &e->sp_out, &e->sp_in}) alga_release(*b);
     alga_staging_release(e);
-    if (e->h_counters) (void) hipHostFree(e->h_counters);
-    for (int i = 0; i < EV_COUNT; i++) if (e->ev[i]) (void) hipEventDestroy(e->ev[i]);
-    if (e->own_stream) (void) hipStreamDestroy(e->own_stream);
+    for (auto &kv : e->host_lists) free(kv.first);         // host edge lists the caller never gave back (alga_free_edges after this is an error: alga_amd.h)
+    e->host_lists.clear();
+    engine_free_handles(e);
     delete e;
 }
 
@@ -507,6 +535,51 @@ int alga_engine_set_option(alga_engine *e, const char *name, int64_t value) {
     } else if (!strcmp(name, "auto_reduction_per_target")) {
         e->opt_force_per_target = value != 0;
     } else return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "unknown option");
+    return ALGA_OK;
+}
+
+int alga_engine_reserve(alga_engine *e, int32_t n_nodes, int32_t max_len, int32_t min_overlap, uint64_t n_edges_hint) {
+    if (!e) return ALGA_ERR_INVALID_ARGUMENT;
+    e->err.clear();
+    if (n_nodes < 0 || max_len < 1 || min_overlap < 1) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "alga_engine_reserve: n_nodes >= 0, max_len >= 1, min_overlap >= 1");
+    DeviceGuard guard;
+    HIP_TRY(e, hipSetDevice(e->device));
+    int rc;
+    const uint64_t n = (uint64_t) n_nodes;
+    const uint64_t E = n_edges_hint ? n_edges_hint : n + n / 16 + 4096;
+    if ((rc = alga_ensure(e, e->counters, (CNT_TOTAL + 2) * sizeof(unsigned long long)))) return rc;
+    // what prepare() would derive for this shape: the same sizing functions as the build itself
+    Prepared pp;
+    pp.nd.n = n_nodes; pp.max_len = max_len; pp.live = n;
+    pp.cfg.Lmin = min_overlap; pp.cfg.Lcap = std::min(max_len, 500) + 1; pp.cfg.rsoemo = min_overlap; pp.cfg.soes = 3;
+    int eq = 0;
+    const bool local = max_len <= 500 && max_len - min_overlap <= LOCAL_MAX_SPAN;
+    const bool clustered = local && max_len - min_overlap <= 63 && e->opt_probe != ALGA_PROBE_TABLE &&
+                           cluster_plan(pp.cfg, max_len, n, e->opt_cluster_bucket_bias, &pp.cluster, &eq);
+    if (clustered) {
+        pp.cluster_eq = eq;
+        if ((rc = cluster_alloc(e, pp))) return rc;
+        if ((rc = alga_ensure(e, e->cl_defer, (size_t) (n + 64) * sizeof(int32_t)))) return rc;
+        if ((rc = alga_ensure(e, e->loc_second, (size_t) (n + 1) * sizeof(unsigned long long)))) return rc;
+    } else {
+        const uint32_t nb = seed_buckets_for(n, e->seed_fill_x10);
+        if ((rc = alga_ensure(e, e->table, (size_t) nb * SEED_BUCKET * sizeof(unsigned long long)))) return rc;
+        const uint32_t fb = seed_filter_bits_for(n);
+        if (fb && (rc = alga_ensure(e, e->filter, fb / 8))) return rc;
+    }
+    if (local) {
+        const uint64_t slack = std::max(probe_record_slack(e->n_cu, n, true), clustered ? cluster_record_slack(e->n_cu, n) : 0);
+        const uint64_t cap = std::max<uint64_t>(e->rec_cap_hint_local, 2 * n + 4096) + slack;
+        if ((rc = alga_ensure(e, e->outdeg, (size_t) (n + 1) * sizeof(uint32_t)))) return rc;
+        if ((rc = alga_ensure(e, e->loc_first, (size_t) (n + 1) * sizeof(unsigned long long)))) return rc;
+        if ((rc = alga_ensure(e, e->loc_big_list, (1u << 20) * sizeof(int32_t)))) return rc;
+        if ((rc = alga_ensure(e, e->rec_dst, cap * sizeof(uint32_t)))) return rc;
+        if ((rc = alga_ensure(e, e->rec_val, cap * sizeof(unsigned long long)))) return rc;
+        if ((rc = alga_ensure(e, e->scan_scratch, scan_scratch_bytes(n)))) return rc;
+        if ((rc = alga_ensure(e, e->out_rowptr, (size_t) (n + 1) * sizeof(uint32_t)))) return rc;
+        if ((rc = alga_ensure(e, e->out_cnt, (size_t) (n + 1) * sizeof(uint32_t)))) return rc;
+    }
+    if ((rc = alga_ensure(e, e->edges, (size_t) (E + 1) * sizeof(alga_edge_dev)))) return rc;
     return ALGA_OK;
 }
 
@@ -550,6 +623,7 @@ int alga_prefsuf_build_device(alga_engine *e, const alga_nodes *nodes, const alg
     e->stats.ms_seed = ev_ms(e, EV_START, EV_SEED);
     e->stats.ms_probe = ev_ms(e, EV_SEED, EV_PROBE);
     e->stats.ms_probe_pairs = e->pairs_timed ? ev_ms(e, EV_SEED, EV_PAIRS) : 0.0;
+    store_phase_stats(e);
     e->stats.ms_group = ev_ms(e, EV_PROBE, EV_GROUP);
     e->stats.ms_reduce = ev_ms(e, EV_GROUP, EV_REDUCE);
     e->stats.ms_emit = ev_ms(e, EV_REDUCE, EV_EMIT);
@@ -582,6 +656,7 @@ int alga_prefsuf_build_host(alga_engine *e, const alga_nodes *nodes, const alga_
     const int stride_up = alga::hbm_row_stride(nodes->stride_words);
     const size_t wbytes = n * (size_t) stride_up * sizeof(uint32_t);
     const size_t raw_bytes = n * (size_t) nodes->stride_words * sizeof(uint32_t);
+    alga_forget_node_set(e);
     if ((rc = alga_ensure(e, e->up_words, wbytes))) return rc;
     if ((rc = alga_ensure(e, e->up_len, n * sizeof(int32_t)))) return rc;
     alga_nodes dn = *nodes;
@@ -704,6 +779,7 @@ int alga_prefsuf_build_range_device(alga_engine *e, const alga_nodes *nodes, con
     e->stats.ms_seed = ev_ms(e, EV_START, EV_SEED);
     e->stats.ms_probe = ev_ms(e, EV_SEED, EV_PROBE);
     e->stats.ms_probe_pairs = e->pairs_timed ? ev_ms(e, EV_SEED, EV_PAIRS) : 0.0;
+    store_phase_stats(e);
     e->stats.ms_emit = ev_ms(e, EV_REDUCE, EV_EMIT);
     e->stats.ms_total = ev_ms(e, EV_START, EV_EMIT);
     *d_edges = (const alga_edge *) e->edges.p;

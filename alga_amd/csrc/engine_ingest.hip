@@ -68,6 +68,7 @@ int preprocess_impl(alga_engine *e, const uint32_t *rows, int stride, int32_t *l
     launch_exclusive_scan((const uint32_t *) e->pp_keep.p, R, (uint32_t *) e->pp_pos.p, (uint64_t *) e->scan_scratch.p, s);
     if ((rc = alga_check_launch(e, "scan(keep)"))) return rc;
     // the output is sized for every read surviving: no round trip for the count before the copy
+    alga_forget_node_set(e);
     if ((rc = alga_ensure(e, e->pp_out_rows, (n + 2) * (size_t) stride_out * sizeof(uint32_t)))) return rc;
     if ((rc = alga_ensure(e, e->pp_out_len, (n + 2) * sizeof(int32_t)))) return rc;
     if ((rc = alga_ensure(e, e->pp_out_pair, n + 16))) return rc;

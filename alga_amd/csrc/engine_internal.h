@@ -17,7 +17,7 @@ struct DevBuf {
     size_t cap = 0;
 };
 
-enum { EV_START = 0, EV_SEED, EV_PROBE, EV_GROUP, EV_REDUCE, EV_EMIT, EV_PAIRS, EV_COUNT };
+enum { EV_START = 0, EV_SEED, EV_PROBE, EV_GROUP, EV_REDUCE, EV_EMIT, EV_PAIRS, EV_KEYS, EV_SORT, EV_GATHER, EV_COUNT };
 constexpr int ALGA_STAGE_THREADS = 8;      // worker threads (pinned buffer pairs, streams) of the staged host <-> HBM copies
 
 struct alga_engine {
@@ -49,6 +49,7 @@ struct alga_engine {
     int stat_max_len = 0, stat_min_len = 0; uint64_t stat_live = 0; unsigned long long stat_mask_asym = 0;
     const void *stat_len = nullptr, *stat_from = nullptr, *stat_to = nullptr;
     bool   pairs_timed = false;                             // EV_PAIRS was recorded in the last discovery
+    bool   store_timed = false;                             // EV_KEYS / EV_SORT / EV_GATHER were recorded in the last discovery
     int    opt_cluster_order = 1;                           // option "cluster_order": the quad kernel walks all sources in entry-array (key) order (0: id order)
     int    opt_cluster_pairs = 2;                           // option "cluster_pairs": 0 = general kernel only, 1 = pair kernel first, 2 = quad kernel first
     DevBuf cl_keys[2], cl_vals[2], cl_meta, cl_runs, cl_nruns, cl_store, cl_dir;   // clustered minimizer join: sort buffers, per-node minimizer runs, entry array, bucket directory
@@ -107,6 +108,14 @@ inline int alga_ensure(alga_engine *e, DevBuf &b, size_t bytes) {
     HIP_TRY(e, hipMalloc(&b.p, bytes));
     b.cap = bytes;
     return ALGA_OK;
+}
+
+// Engine-owned node storage (uploads, the output of the device input stage) is about to be rewritten: nothing derived from the
+// node set that lived there -- key pass, entry array, node statistics -- may be reused by a later build (they are matched on
+// addresses and sizes, which a rewrite does not change).
+inline void alga_forget_node_set(alga_engine *e) {
+    e->keyed_n = -1; e->store_n = -1;
+    e->stat_len = nullptr; e->stat_from = nullptr; e->stat_to = nullptr;
 }
 
 inline void alga_release(DevBuf &b) {

@@ -43,6 +43,7 @@ int upload_nodes(alga_engine *e, const alga_nodes *nodes, hipStream_t s, alga_no
         return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "stride_words is smaller than the longest read needs");
     const int stride_up = alga::hbm_row_stride(nodes->stride_words);
     const size_t wbytes = n * (size_t) stride_up * sizeof(uint32_t);
+    alga_forget_node_set(e);
     if ((rc = alga_ensure(e, e->up_words, wbytes))) return rc;
     if ((rc = alga_ensure(e, e->up_len, n * sizeof(int32_t)))) return rc;
     *dn = *nodes;

@@ -105,6 +105,7 @@ int alga_contig_trim_host(alga_engine *e, const uint32_t *words, int32_t stride_
     hipStream_t s = e->own_stream;
     int rc;
     // nodes as src/main.cpp:636-645 numbers them: contigs 0 .. M-1, then their reverse complements M .. 2M-1
+    alga_forget_node_set(e);
     if ((rc = alga_ensure(e, e->up_words, 2 * M * row_bytes))) return rc;
     if ((rc = alga_ensure(e, e->up_len, 2 * M * sizeof(int32_t)))) return rc;
     if ((rc = alga_ensure(e, e->sp_cnt, (M + 2) * sizeof(int32_t)))) return rc;

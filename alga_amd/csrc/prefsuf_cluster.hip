@@ -1474,12 +1474,13 @@ __global__ void __launch_bounds__(256) k_iota(uint32_t *__restrict__ v, uint32_t
 // live node has that length and there is no alignFrom mask (k_tgt_gather<., true>: meta[] is not read).
 hipError_t launch_cluster_store(const NodesDev &nd, const ClusterCfg &cc, int eq, uint32_t *keys, uint32_t *vals, uint32_t *keys2, uint32_t *vals2,
                                 const uint32_t *meta, int uniform_len, void *sort_temp, size_t sort_temp_bytes, void *store, void *dir, bool fill_vals,
-                                hipStream_t s) {
+                                hipEvent_t ev_sorted, hipEvent_t ev_gathered, hipStream_t s) {
     if (nd.n <= 0) return hipSuccess;
     const uint64_t n = (uint64_t) nd.n;
     if (fill_vals) hipLaunchKernelGGL(k_iota, dim3((unsigned) std::min<uint64_t>((n + 255) / 256, 8192)), dim3(256), 0, s, vals, (uint32_t) n);
     hipError_t err = sort_u32_pairs(sort_temp, sort_temp_bytes, keys, keys2, vals, vals2, n, s);
     if (err != hipSuccess) return err;
+    if (ev_sorted) (void) hipEventRecord(ev_sorted, s);
     const uint64_t pieces = n * (uint64_t) eq;
     const unsigned g = (unsigned) ((pieces + 255) / 256);
     const int fs = cc.idx_shift - CL_MBITS;
@@ -1491,6 +1492,7 @@ hipError_t launch_cluster_store(const NodesDev &nd, const ClusterCfg &cc, int eq
     else              TG_EQ(4);
 #undef TG_EQ
 #undef TG_LAUNCH
+    if (ev_gathered) (void) hipEventRecord(ev_gathered, s);
     hipLaunchKernelGGL(k_tgt_dir, dim3((unsigned) ((n + 1 + TD_TILE - 1) / TD_TILE)), dim3(TD_TILE), 0, s, (const uint32_t *) keys2, n, cc.idx_shift, cc.n_buckets, (uint4 *) dir);
     return hipGetLastError();
 }

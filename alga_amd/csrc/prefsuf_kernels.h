@@ -43,7 +43,8 @@ void       launch_cluster_keys(const NodesDev &nd, const PrefSufCfg &cfg, const 
                                uint32_t *vals, uint32_t *meta, void *runs, uint8_t *nruns, hipStream_t s);
 hipError_t launch_cluster_store(const NodesDev &nd, const ClusterCfg &cc, int eq, uint32_t *keys, uint32_t *vals, uint32_t *keys2, uint32_t *vals2,
                                 const uint32_t *meta, int uniform_len /* > 0: all live nodes have this length, no alignFrom mask */, void *sort_temp,
-                                size_t sort_temp_bytes, void *store, void *dir, bool fill_vals, hipStream_t s);
+                                size_t sort_temp_bytes, void *store, void *dir, bool fill_vals, hipEvent_t ev_sorted /* may be null */,
+                                hipEvent_t ev_gathered /* may be null */, hipStream_t s);
 uint64_t   cluster_record_slack(int n_cu, uint64_t n_src);
 void       launch_probe_pairs(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterCfg &cc, int eq, const void *store, const void *dir,
                               const void *runs, const uint8_t *nruns, int32_t src_begin, int32_t src_end, unsigned long long *counters, int n_cu, uint32_t *deg,

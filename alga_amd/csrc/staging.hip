@@ -76,8 +76,17 @@ int staged_copy(alga_engine *e, void *dev, void *host, size_t bytes, bool to_dev
     const int T = (int) std::min<size_t>(ALGA_STAGE_THREADS, (bytes + STAGE_CHUNK - 1) / STAGE_CHUNK);
     hipError_t errs[ALGA_STAGE_THREADS];
     std::vector<std::thread> th;
-    for (int t = 0; t < T; t++) { errs[t] = hipSuccess; th.emplace_back(worker, e, t, T, (char *) dev, (char *) host, bytes, to_device, &errs[t]); }
+    // a std::thread that cannot be started throws: nothing may cross the C ABI, so the copy then goes the plain way
+    bool started = true;
+    try {
+        th.reserve((size_t) T);
+        for (int t = 0; t < T; t++) { errs[t] = hipSuccess; th.emplace_back(worker, e, t, T, (char *) dev, (char *) host, bytes, to_device, &errs[t]); }
+    } catch (...) { started = false; }
     for (std::thread &x : th) x.join();
+    if (!started) {
+        HIP_TRY(e, to_device ? hipMemcpy(dev, host, bytes, hipMemcpyHostToDevice) : hipMemcpy(host, dev, bytes, hipMemcpyDeviceToHost));
+        return ALGA_OK;
+    }
     for (int t = 0; t < T; t++) if (errs[t] != hipSuccess) return alga_fail(e, ALGA_ERR_HIP, "staged host/device copy", errs[t]);
     return ALGA_OK;
 }

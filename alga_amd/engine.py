@@ -41,7 +41,8 @@ class PrefSufStats(C.Structure):
                 ("max_in_records", C.c_uint64), ("ms_total", C.c_double), ("ms_seed", C.c_double),
                 ("ms_probe", C.c_double), ("ms_group", C.c_double), ("ms_reduce", C.c_double), ("ms_emit", C.c_double),
                 ("nodes_live", C.c_uint64), ("reduction_used", C.c_uint64), ("generic_sources", C.c_uint64),
-                ("big_sources", C.c_uint64), ("probe_used", C.c_uint64), ("deferred_sources", C.c_uint64), ("ms_probe_pairs", C.c_double)]
+                ("big_sources", C.c_uint64), ("probe_used", C.c_uint64), ("deferred_sources", C.c_uint64), ("ms_probe_pairs", C.c_double),
+                ("ms_keys", C.c_double), ("ms_sort", C.c_double), ("ms_gather", C.c_double), ("ms_dir", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
@@ -114,7 +115,7 @@ EXPORTS = ["alga_abi_version", "alga_engine_set_option", "alga_engine_create", "
            "alga_prefsuf_reduce_device", "alga_prefsuf_build_range_device", "alga_prefsuf_keys_device", "alga_write_graph", "alga_ingest_default_params", "alga_ingest_files",
            "alga_free_node_set", "alga_sort_records_device", "alga_sort_edges_device", "alga_pkb_derive_params",
            "alga_can_align_batch_host", "alga_li_kmers_host", "alga_pkb_supplement_host", "alga_pkb_supplement_device",
-           "alga_pkb_last_stats", "alga_parse_files", "alga_free_parsed_reads", "alga_preprocess_nodes", "alga_copy_to_host", "alga_device_alloc", "alga_device_free", "alga_copy_to_device", "alga_cut_triangles_device", "alga_cut_triangles_host", "alga_ingest_device", "alga_contig_trim_host"]
+           "alga_pkb_last_stats", "alga_parse_files", "alga_free_parsed_reads", "alga_preprocess_nodes", "alga_copy_to_host", "alga_device_alloc", "alga_device_free", "alga_copy_to_device", "alga_cut_triangles_device", "alga_cut_triangles_host", "alga_ingest_device", "alga_contig_trim_host", "alga_engine_reserve"]
 
 
 def library_path():
@@ -160,6 +161,7 @@ def load_library():
     lib.alga_last_error.restype = C.c_char_p
     lib.alga_engine_device_name.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
     lib.alga_engine_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+    lib.alga_engine_reserve.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_uint64]
     lib.alga_prefsuf_default_params.argtypes = [C.POINTER(PrefSufParams)]
     lib.alga_prefsuf_default_params.restype = None
     lib.alga_prefsuf_build_host.argtypes = [C.c_void_p, C.POINTER(_Nodes), C.POINTER(PrefSufParams),
@@ -323,11 +325,15 @@ class Engine:
             raise AlgaError(rc, (self._lib.alga_last_error(self._h) or b"").decode())
 
     def set_option(self, name, value):
-        """alga_engine_set_option: "probe" ("auto" | "table" | "cluster"), "cluster_bucket_bias", "local_big_max",
-        "auto_reduction_per_target"."""
+        """alga_engine_set_option: "probe" ("auto" | "table" | "cluster"), "cluster_bucket_bias", "cluster_pairs", "cluster_order",
+        "local_big_max", "auto_reduction_per_target"."""
         if name == "probe" and isinstance(value, str):
             value = PROBE[value]
         self._check(self._lib.alga_engine_set_option(self._h, name.encode(), int(value)))
+
+    def reserve(self, n_nodes, max_len, min_overlap, n_edges_hint=0):
+        """alga_engine_reserve: every device buffer of a build for this shape, ahead of the build."""
+        self._check(self._lib.alga_engine_reserve(self._h, int(n_nodes), int(max_len), int(min_overlap), int(n_edges_hint)))
 
     def device_name(self):
         buf = C.create_string_buffer(256)

@@ -129,14 +129,18 @@ class ShardedPrefSuf:
     simplifier / contig stages afterwards -- with direct sends over each peer's own xGMI link (`gather`); the other ranks keep
     an empty tensor.  replicate=True: every rank gets it (`all_gather`, 8x the traffic at 8 GPUs)."""
 
-    def __init__(self, backend, rank=0, world=1, dist=None, replicate=False, shard_keys=True, pieces=None):
+    def __init__(self, backend, rank=0, world=1, dist=None, replicate=False, shard_keys=False, pieces=1):
         self.be, self.rank, self.world, self.dist = backend, rank, world, dist
         self.replicate = replicate
-        # source-side form: pieces of a rank's source range (the transfer of one overlaps the probe of the next).  A piece costs ~0.3 ms
-        # of its own (launches, host syncs, thinner kernels), the transfer it hides shrinks with the number of links in use: 4 pieces
-        # up to 4 ranks, 2 at 8, 1 beyond
+        # Defaults = the form with the fewest moving parts (one piece, every rank computes all keys itself, no key all-gather): no
+        # collective of this driver has run over RCCL on hardware yet, and the sharded key pass with several outstanding gathers is
+        # exactly what a stand-in transport cannot validate (ADVICE round 2).  Opt in once tools/multigpu_check.py has passed on an
+        # N-GPU node:
+        #   pieces     pieces of a rank's source range (the transfer of one overlaps the probe of the next).  A piece costs ~0.3 ms of
+        #              its own (launches, host syncs, thinner kernels): 4 pieces up to 4 ranks, 2 at 8 were the measured optimum
+        #   shard_keys every rank computes the minimizer keys of its own nodes only, the key arrays are all-gathered
         self.pieces = max(1, int(pieces)) if pieces is not None else min(4, max(1, 16 // max(1, world)))
-        self.shard_keys = shard_keys           # False: every rank computes the keys of all nodes itself (no key all-gather)
+        self.shard_keys = shard_keys
         self.n = backend.n
         self.bounds = shard_bounds(self.n, world)
         self.edges = None                       # tensor [m, 3] of the last step: the complete graph (rank 0, or every rank if replicate)
@@ -164,12 +168,20 @@ class ShardedPrefSuf:
         if karr is not None:
             import torch
             for t in karr:
-                # both ends of the collective are tensors of torch's own allocator (the engine's arrays are foreign memory to
-                # it); the gathered array then goes back into the engine's with one device copy (0.36 GB at 90 M nodes)
-                full = torch.empty(nr * chunk, dtype=t.dtype, device=dev)
+                # In place: rank r's slice already sits at its position of the engine's (slack-padded) array, the other slices arrive
+                # next to it -- no staging tensors, no copy back.  A backend that refuses aliased buffers (gloo) gets one staging
+                # tensor, kept between steps.
+                if not getattr(self, "_keys_in_place_refused", False):
+                    try:
+                        dist.all_gather_into_tensor(t[:nr * chunk], t[r * chunk:(r + 1) * chunk])
+                        continue
+                    except (RuntimeError, ValueError, TypeError):
+                        self._keys_in_place_refused = True
+                full = getattr(self, "_keys_full", None)
+                if full is None or full.shape[0] != nr * chunk or full.dtype != t.dtype or full.device != t.device:
+                    full = self._keys_full = torch.empty(nr * chunk, dtype=t.dtype, device=dev)
                 dist.all_gather_into_tensor(full, t[r * chunk:(r + 1) * chunk].clone())
                 t.copy_(full)
-                del full
         ms_keys = (time.perf_counter() - t_keys) * 1e3
         # The rank's source range in `pieces` consecutive pieces (the first one sorts the gathered keys into the entry array, the
         # others reuse it): the edges of a piece travel to rank 0 while the next piece is probed.  Per piece one small all_gather
@@ -204,9 +216,8 @@ class ShardedPrefSuf:
             st["edges"] = self.total_edges
             st["ms_exchange"] = (time.perf_counter() - t2) * 1e3               # what was left of the gathers after the last piece's probe
             return self._finish(st, collect_stats)
-        for w in pending:                                                      # a rank declined (capacity case): all take the general form
-            if w[0] is not None:
-                w[0].wait()
+        if pending:                                                            # a rank declined (capacity case): all take the general form;
+            self._gather_finish(pending)                                       # what is already on its way is received and dropped
         del pending
         # 1. discover + order by target
         rdst, rval = be.discover_sorted(b[r], b[r + 1], collect_stats)
@@ -239,34 +250,56 @@ class ShardedPrefSuf:
         return self._finish(st, collect_stats)
 
     def _gather_start(self, mine, counts):
-        """Start moving one piece of every rank's edge list to rank 0 (or to every rank): -> (work, receive buffers, counts)."""
+        """Start moving one piece of every rank's edge list to rank 0 (or to every rank): -> (works, buffer, counts, send buffer).
+        Rank 0 receives every rank's piece with its exact length: point-to-point transfers (one per peer, each over that peer's own
+        xGMI link) that `_gather_finish` lands at their offsets of ONE preallocated list -- no padding to the longest piece and no
+        concatenation afterwards (round 2 copied the 1.1 GB list once more on rank 0)."""
         import torch
         dist, nr, dev = self.dist, self.world, self.be.device
         m = int(mine.shape[0])
-        mx = max(max(counts), 1)
-        local = torch.zeros((mx, 3), dtype=torch.int32, device=dev)         # also the copy out of the engine's buffer, which the next piece reuses
-        if m:
-            local[:m] = mine
         if self.replicate:
+            mx = max(max(counts), 1)
+            local = torch.zeros((mx, 3), dtype=torch.int32, device=dev)     # also the copy out of the engine's buffer, which the next piece reuses
+            if m:
+                local[:m] = mine
             parts = torch.empty((nr, mx, 3), dtype=torch.int32, device=dev)
             work = dist.all_gather_into_tensor(parts.view(-1), local.view(-1), async_op=True)
-        else:
-            parts = [torch.empty((mx, 3), dtype=torch.int32, device=dev) for _ in range(nr)] if self.rank == 0 else None
-            work = dist.gather(local, parts, dst=0, async_op=True)
-        return work, parts, counts, local
+            return [work], parts, counts, local
+        local = mine.clone() if m else torch.empty((0, 3), dtype=torch.int32, device=dev)     # the engine's edge buffer is reused by the next piece
+        if self.rank != 0:
+            return ([dist.isend(local.view(-1), dst=0)] if m else []), None, counts, local
+        return [], None, counts, local                     # rank 0 posts its receives in _gather_finish, straight into the final list
 
     def _gather_finish(self, pending):
         """Wait for the pieces; the complete list in (src, dst) order: rank by rank, piece by piece (ascending source ranges)."""
         import torch
-        nr, dev = self.world, self.be.device
-        for w in pending:
-            if w[0] is not None:
-                w[0].wait()
+        dist, nr, dev = self.dist, self.world, self.be.device
         self.total_edges = sum(sum(w[2]) for w in pending)
-        if not self.replicate and self.rank != 0:
+        if self.replicate:
+            for w in pending:
+                for x in w[0]:
+                    x.wait()
+            return torch.cat([w[1][q][:w[2][q]] for q in range(nr) for w in pending], dim=0).contiguous()
+        if self.rank != 0:
+            for w in pending:
+                for x in w[0]:
+                    x.wait()
             return torch.empty((0, 3), dtype=torch.int32, device=dev)
-        chunks = [w[1][q][:w[2][q]] for q in range(nr) for w in pending]
-        return torch.cat(chunks, dim=0).contiguous()
+        out = torch.empty((self.total_edges, 3), dtype=torch.int32, device=dev)
+        works, off = [], 0
+        for q in range(nr):                                 # final order: rank by rank, inside a rank piece by piece
+            for w in pending:
+                c = w[2][q]
+                if c:
+                    dst = out[off:off + c]
+                    if q == 0:
+                        dst.copy_(w[3])
+                    else:
+                        works.append(dist.irecv(dst.view(-1), src=q))
+                off += c
+        for x in works:
+            x.wait()
+        return out
 
     def _gather(self, mine, ordered, counts=None):
         """Edge lists of all ranks (padded to the longest) -> the complete list on rank 0 (or on every rank);

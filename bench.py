@@ -50,7 +50,7 @@ def algorithmic_bytes(st, W):
     return dict(probe=probe, reduce=reduce_, emit=emit, total=probe + reduce_ + emit)
 
 
-def cpu_baseline_reference(codes, threads, eng):
+def cpu_baseline_reference(codes, threads, eng, err=0.0):
     """The real reference (oracle/_ref/ALGA) on `codes` (uint8 [k, L]): creator wall time between its stderr markers 'Creating
     GraphCreator' and 'Before first simplifier' (its own timers report CPU-seconds, src/Utils/TimeMeasurer.cpp:26-39), its
     --serialize=1 dump compared byte for byte with the graph the engine builds from the same reads."""
@@ -60,7 +60,8 @@ def cpu_baseline_reference(codes, threads, eng):
     from alga_amd import workload
     with tempfile.TemporaryDirectory() as wd:
         workload.write_fasta_fast(os.path.join(wd, "s.fasta"), codes)
-        p = subprocess.Popen([exe, "--file1=s.fasta", "--threads=%d" % threads, "--serialize=1", "--output=o.fasta"], cwd=wd,
+        extra = ["--error_rate=%g" % err] if err > 0 else []     # > 0.01: the reference adds its approximate supplement (src/main.cpp:300-355)
+        p = subprocess.Popen([exe, "--file1=s.fasta", "--threads=%d" % threads, "--serialize=1", "--output=o.fasta"] + extra, cwd=wd,
                              stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, errors="replace", bufsize=1)
         t0 = t1 = None
         edges = None
@@ -85,11 +86,12 @@ def cpu_baseline_reference(codes, threads, eng):
             ge = eng.prefsuf_host(words, lens, lo, rs)
             mine = os.path.join(wd, "gpu.graph")
             eng.write_graph(mine, len(lens), ge)
-            bytes_equal = open(mine, "rb").read() == open(dumps[0], "rb").read()
+            bytes_equal = open(mine, "rb").read() == open(dumps[0], "rb").read()      # (the dump is the EXACT path's graph, before any supplement)
     dt = t1 - t0
     return dict(value=edges / dt, unit="edges/s", cores=threads, kind="reference",
-                sample="%d x %d bp reads of the same workload (every read that starts in the first genome_len * sample / n_reads positions: same coverage), ALGA --threads=%d --serialize=1, "
-                       "creator region src/main.cpp:244-296, %.2f s wall, %d edges" % (len(codes), codes.shape[1], threads, dt, edges),
+                sample="%d x %d bp reads of the same workload (every read that starts in the first genome_len * sample / n_reads positions: same coverage), ALGA --threads=%d --serialize=1%s, "
+                       "creator region src/main.cpp:244-%d, %.2f s wall, %d edges" % (len(codes), codes.shape[1], threads, " --error_rate=%g" % err if err > 0 else "",
+                                                                                     355 if err > 0 else 296, dt, edges),
                 seconds=dt, edges=edges, gbp_per_sec=codes.size / dt / 1e9, graph_bytes_equal_gpu=bytes_equal)
 
 
@@ -106,23 +108,22 @@ def cpu_baseline_port(words, lens, lo, rs, budget_nodes):
                 sample="first %d nodes of the workload, single-thread C oracle, %.2f s" % (len(l), dt), seconds=dt, edges=len(e))
 
 
-def profiled_traffic(config, lib_sha, kernel=None):
-    """Memory-side bytes per launch (FETCH_SIZE + WRITE_SIZE as counted) of one probe kernel, or of the whole probe phase, from the
-    rocprofv3 --pmc passes (tools/pmc_to_traffic.py -> profiles/probe_hbm_bytes.json); reported only when they were taken on THESE
-    kernel sources (alga_amd.engine.source_fingerprint), otherwise null."""
-    tf = os.path.join(ROOT, "profiles", "probe_hbm_bytes.json")
+def profiled_traffic(config, src_sha):
+    """{kernel name: HBM bytes per dispatch} from the rocprofv3 --pmc passes of this command (tools/profile_cmd.sh passes r, x ->
+    tools/pmc_to_traffic.py -> profiles/hbm_traffic.json: 128 B per read request, 32 / 64 B per write request), only when they
+    were taken on THESE kernel sources (alga_amd.engine.source_fingerprint); else {}."""
     try:
-        ent = json.load(open(tf)).get(config)
+        ent = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json"))).get(config)
     except Exception:
-        return None
-    if not ent or ent.get("src_sha256") != lib_sha:
-        return None
-    if kernel is None:
-        return ent.get("hbm_bytes_per_launch")
-    try:
-        return int((ent["fetch_kib"][kernel] + ent["write_kib"][kernel]) * 1024)
-    except Exception:
-        return None
+        return {}
+    if not ent or ent.get("src_sha256") != src_sha:
+        return {}
+    return {k: v["read_bytes"] + v["write_bytes"] for k, v in ent["per_dispatch"].items()}
+
+
+def traffic_of(traffic, prefix):
+    v = [b for k, b in traffic.items() if k.startswith(prefix)]
+    return int(sum(v)) if v else None
 
 
 def main():
@@ -134,6 +135,7 @@ def main():
     ap.add_argument("--config", default="cfg4_50M_150bp")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true")
+    ap.add_argument("--no-first-call", action="store_true")
     ap.add_argument("--cpu-sample-reads", type=int, default=1_000_000, help="reads of the workload the CPU baseline runs on (~10 s of the reference at 16 threads)")
     ap.add_argument("--probe", default="auto", choices=["auto", "table", "cluster"])
     args = ap.parse_args()
@@ -161,8 +163,8 @@ def main():
     sample_codes = None
     host_words = host_lens = None
     t_build = time.perf_counter()
-    if err == 0.0 and n_reads >= 4_000_000:
-        wl = workload.device_build(n_reads, read_len, G, seed, sample_reads=(args.cpu_sample_reads if rank == 0 else 0))
+    if n_reads >= 4_000_000:
+        wl = workload.device_build(n_reads, read_len, G, seed, err=err, sample_reads=(args.cpu_sample_reads if rank == 0 else 0))
         d_words, d_lens = wl["words"], wl["lens"]
         sample_codes = wl["sample_codes"]
         how = "generated on the device (alga_amd.workload.device_build)"
@@ -177,9 +179,40 @@ def main():
     t_build = time.perf_counter() - t_build
     lo, rs = wl["min_overlap"], wl["rsoemo"]
     n_nodes = int(d_lens.shape[0])
-    W = (2 * int(d_lens.max().item()) + 31) // 32 if n_nodes else 0
+    max_len = int(d_lens.max().item()) if n_nodes else 0
+    W = (2 * max_len + 31) // 32
+    # error_rate > 0.01: the scored path is the exact graph PLUS the approximate supplement (src/main.cpp:244-355); one GPU
+    supplement = err > 0.01 and world == 1
+    pkb = alga_amd.Engine.pkb_params(float(d_lens[d_lens > 0].float().mean().item()), err, min(2 * lo // 3, 60)) if supplement else None
+
+    # ---- the FIRST call of a process (what an assembler pays: it builds its graph once) --------------------------------------
+    first = None
     eng = alga_amd.Engine(local_rank)
     eng.set_option("probe", args.probe)
+    if world == 1 and not args.no_first_call:
+        # (a) the first engine of this process: alga_engine_reserve (an assembler calls it while it still parses / uploads), then the build
+        t0 = time.perf_counter()
+        eng.reserve(n_nodes, max_len, lo)
+        torch.cuda.synchronize()
+        t_res = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        eng.prefsuf_device(d_words, d_lens, lo, rs)
+        torch.cuda.synchronize()
+        t_first = time.perf_counter() - t0
+        first = {"reserve_ms": t_res * 1e3, "first_call_ms": t_first * 1e3, "first_call_device_ms": eng.last_stats()["ms_total"]}
+        # (b) a second fresh engine WITHOUT the reserve call: every device buffer is allocated inside the build (each hipMalloc waits for
+        #     the stream, so the kernels around it no longer overlap their launches)
+        cold = alga_amd.Engine(local_rank)
+        cold.set_option("probe", args.probe)
+        t0 = time.perf_counter()
+        cold.prefsuf_device(d_words, d_lens, lo, rs)
+        torch.cuda.synchronize()
+        first["unprepared_first_call_ms"] = (time.perf_counter() - t0) * 1e3
+        first["unprepared_first_call_device_ms"] = cold.last_stats()["ms_total"]
+        cold.close()
+        del cold
+        first["note"] = ("wall time of alga_prefsuf_build_device on a fresh engine, kernel code objects loaded on first launch included; reserve = "
+                         "alga_engine_reserve: all device buffers sized from the node count ahead of the build; unprepared = another fresh engine without it")
     runner = multigpu.ShardedPrefSuf(multigpu.HipBackend(eng, d_words, d_lens, lo, rs), rank, world, dist)
 
     def sync_all():
@@ -187,21 +220,30 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def step(collect_stats=False):
+        """one pass of the hot path over the resident read set -> (edges of the graph handed to the simplifier, stats)"""
+        m, st = runner.step(collect_stats=collect_stats)
+        if supplement:
+            _, m = eng.pkb_supplement_device(d_words, d_lens, runner.edges.data_ptr(), m, pkb)
+            ps = eng.pkb_last_stats()
+            st = dict(st)
+            st["ms_supplement"] = ps["ms_total"]
+            st["pkb"] = ps
+        return m, st
+
     # one counted pass (work counters for the roofline's algorithmic bytes); not timed
-    n_edges, st = runner.step(collect_stats=True)
+    n_edges, st = step(collect_stats=True)
     stats = dict(st)
     if world > 1:
         stats["nodes_live"] = n_nodes                 # whole-job counters (all_reduced); nodes are replicated
     for _ in range(max(0, args.warmup - 1)):
-        runner.step()
+        step()
     sync_all()
-    probe_ms, pairs_ms = [], []
-    phase = dict(seed=0.0, probe=0.0, group=0.0, reduce=0.0, emit=0.0, exchange=0.0)
+    keys_ms = ("seed", "probe", "group", "reduce", "emit", "exchange", "probe_pairs", "keys", "sort", "gather", "dir", "supplement")
+    phase = {k: 0.0 for k in keys_ms}
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        n_edges, s = runner.step()
-        probe_ms.append(s["ms_probe"])
-        pairs_ms.append(s.get("ms_probe_pairs", 0.0))
+        n_edges, s = step()
         for k in phase:
             phase[k] += s.get("ms_" + k, 0.0)
     sync_all()
@@ -214,73 +256,115 @@ def main():
     out = None
     if rank == 0:
         ms_step = dt / args.steps * 1e3
+        ms = {k: v / args.steps for k, v in phase.items()}
         bases = n_reads * read_len
         alg = algorithmic_bytes(stats, W)
-        probe_avg_ms = float(np.mean(probe_ms))
         alg_probe_launch = alg["probe"] / world           # one launch = one rank's share of the sources
-        achieved = alg_probe_launch / (probe_avg_ms * 1e-3) / 1e9
-        # The probe of the clustered path is TWO kernels: k_probe_pairs finishes the regular sources (and defers the others),
-        # k_probe_clustered takes the deferred ones.  `roofline` is the dominant one, k_probe_pairs, on the sources it FINISHES;
+        achieved = alg_probe_launch / (ms["probe"] * 1e-3) / 1e9
+        # The probe of the clustered path is TWO kernels: k_probe_quads (four sources per wave) finishes the regular sources and
+        # defers the others, k_probe_clustered takes the deferred ones.  `roofline` is the dominant one on the sources it FINISHES;
         # `probe_phase` is both kernels over all sources (the HIP events around the two launches).
         n_src = max(1, stats["nodes_live"])
         deferred = int(stats.get("deferred_sources", 0))
-        pairs_avg_ms = float(np.mean(pairs_ms)) if pairs_ms else 0.0
-        two_kernels = stats.get("probe_used") == 2 and pairs_avg_ms > 0 and world == 1
-        if two_kernels:
-            probe_kernel = "k_probe_pairs"
-            kernel_ms = pairs_avg_ms
+        two_kernels = stats.get("probe_used") == 2 and ms["probe_pairs"] > 0 and world == 1
+        first_dominates = two_kernels and 2 * ms["probe_pairs"] >= ms["probe"]
+        if first_dominates:
+            probe_kernel, kernel_ms = "k_probe_quads", ms["probe_pairs"]
             kernel_bytes = alg_probe_launch * (1.0 - deferred / n_src)
         else:
-            # one kernel did the probing (seed-table probe, or the general clustered kernel alone); with N > 1 the per-kernel split
-            # of the probe phase is not collected: the phase as a whole, this rank's share of the sources
-            if stats.get("probe_used") != 2:
-                probe_kernel = "k_probe_sources"
-            elif world > 1 or pairs_avg_ms > 0:
-                probe_kernel = "k_probe_pairs + k_probe_clustered (probe phase)"
-            else:
-                probe_kernel = "k_probe_clustered"
-            kernel_ms, kernel_bytes = probe_avg_ms, alg_probe_launch
+            # one kernel did (nearly all of) the probing -- seed-table probe; the general clustered kernel on reads with sequencing
+            # errors, where the quad kernel's waves hand their share on; N > 1, where the split is not collected: the phase as a whole
+            probe_kernel = "k_probe_sources" if stats.get("probe_used") != 2 else ("k_probe_quads + k_probe_clustered (probe phase)")
+            kernel_ms, kernel_bytes = ms["probe"], alg_probe_launch
         achieved_kernel = kernel_bytes / (kernel_ms * 1e-3) / 1e9
-        lib_sha = alga_amd.engine.source_fingerprint()     # of the kernel sources: what the counter passes are keyed on
+        src_sha = alga_amd.engine.source_fingerprint()     # of the kernel sources: what the counter passes are keyed on
+        traffic = profiled_traffic(args.config, src_sha) if world == 1 else {}
+        tr_kernel = traffic_of(traffic, "k_probe_quads") if first_dominates else (
+            (traffic_of(traffic, "k_probe_quads") or 0) + (traffic_of(traffic, "k_probe_clustered") or 0) or traffic_of(traffic, "k_probe_sources"))
         out = {
             "metric": "overlap_edges_per_sec", "value": n_edges * args.steps / dt, "unit": "edges/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "gbp_per_sec": bases / (ms_step * 1e-3) / 1e9,
             "config": {"workload": "%s: %d x %d bp reads, genome %d, seed %d, err %.2f -> %d nodes (both strands, duplicates removed), "
-                                   "min_overlap %d, rsoemo %d; %s in %.1f s" %
-                                   (args.config, n_reads, read_len, G, seed, err, n_nodes, lo, rs, how, t_build),
+                                   "min_overlap %d, rsoemo %d; %s in %.1f s%s" %
+                                   (args.config, n_reads, read_len, G, seed, err, n_nodes, lo, rs, how, t_build,
+                                    "; a step = exact overlap graph + approximate supplement (error_rate %.2f)" % err if supplement else ""),
                        "nodes": n_nodes, "edges": int(n_edges), "parallelism": "1 GPU" if world == 1 else
                        "strong scaling: the same read set for every N; node set and target index on every rank, sources sharded over %d ranks "
-                       "(contiguous id ranges): each rank computes the minimizer keys of its nodes, the key arrays (8 B/node) are all-gathered over RCCL, each rank sorts them into its copy of the bucket-ordered entry array and builds the final edges of its sources; edge lists gathered on rank 0 over RCCL" % world},
+                       "(contiguous id ranges); edge lists gathered on rank 0 over RCCL" % world},
             "roofline": {"bound": "hbm", "kernel": probe_kernel, "achieved": achieved_kernel, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved_kernel / HBM_PEAK_GBS, "traffic": profiled_traffic(args.config, lib_sha, probe_kernel) if world == 1 else None,
-                         "traffic_source": "rocprofv3 --pmc passes of this command on this build (profiles/probe_hbm_bytes.json, kernel sources %s): FETCH_SIZE + WRITE_SIZE of that kernel as counted; null = not profiled on this build" % lib_sha,
+                         "frac": achieved_kernel / HBM_PEAK_GBS, "traffic": tr_kernel,
+                         "traffic_over_algorithmic": (tr_kernel / kernel_bytes) if tr_kernel else None,
+                         "achieved_hbm": (tr_kernel / (kernel_ms * 1e-3) / 1e9) if tr_kernel else None,
+                         "traffic_source": "rocprofv3 --pmc passes of this command on this build (tools/profile_cmd.sh r, x -> profiles/hbm_traffic.json, kernel sources %s): "
+                                           "128 B per memory-side read request (gfx950 issues no other size), 32 / 64 B per write request; null = not profiled on this build; "
+                                           "achieved_hbm = that traffic / kernel_ms: the HBM rate the kernel really sustains" % src_sha,
                          "algorithmic_bytes": kernel_bytes, "kernel_ms": kernel_ms,
-                         "units": "%d source nodes finished by this kernel per launch (of %d; %d deferred to k_probe_clustered)" % (n_src - deferred, n_src, deferred) if two_kernels else "%d source nodes per launch" % (n_src // world),
+                         "units": "%d source nodes finished by this kernel per launch (of %d; %d deferred to k_probe_clustered)" % (n_src - deferred, n_src, deferred) if first_dominates else "%d source nodes per launch" % (n_src // world),
                          "per_unit": "per source node: 4W + 16 P + 4W * raw/node bytes (W=%d words, P=%.1f windows, raw/node=%.2f)" %
                                      (W, stats["windows_probed"] / max(1, stats["nodes_live"]), stats["raw_overlaps"] / max(1, stats["nodes_live"]))},
-            "probe_phase": {"kernels": ["k_probe_pairs", "k_probe_clustered"] if two_kernels else [probe_kernel], "ms": probe_avg_ms,
-                            "algorithmic_bytes": alg_probe_launch, "achieved": achieved, "frac": achieved / HBM_PEAK_GBS,
-                            "traffic": profiled_traffic(args.config, lib_sha) if world == 1 else None},
-            "phases_ms": {k: v / args.steps for k, v in phase.items()},
+            "probe_phase": {"kernels": ["k_probe_quads", "k_probe_clustered"] if two_kernels else [probe_kernel], "ms": ms["probe"],
+                            "algorithmic_bytes": alg_probe_launch, "achieved": achieved, "frac": achieved / HBM_PEAK_GBS},
+            "phases_ms": {k: ms[k] for k in ("seed", "probe", "group", "reduce", "emit", "exchange")},
             "counters": {k: int(stats[k]) for k in ("nodes_live", "windows_probed", "slots_scanned", "raw_overlaps", "records",
                                                     "transitive_listed", "transitive_compares", "transitive_removed", "edges",
                                                     "max_in_records", "table_slots", "probe_used", "reduction_used", "big_sources", "deferred_sources")},
             "algorithmic_bytes_total": alg["total"],
             "device": eng.device_name(),
         }
+        if stats.get("probe_used") == 2 and world == 1 and ms["keys"] > 0:
+            # every kernel of a step that takes 2 % of it or more: live HIP-event time (alga_prefsuf_stats), the bytes the kernel has to
+            # move by its own definition (DESIGN.md section 5 lists the formulas), the counter traffic where profiled on this build
+            n, E = n_nodes, int(stats["edges"])
+            eq = (W + 3 + 3) // 4
+            runs_per_node = 1.0 + 2.0 * (stats["windows_probed"] / n_src - 1.0) / (min(64, lo - max(lo - 63, min(lo, 16)) + 1) + 1.0)
+            nb = int(stats["table_slots"])
+            rk = [("k_node_runs", ms["keys"], n * (4 * W + 4) + n * (13 + 8 * runs_per_node), "VALU-bound: ~1650 vector instructions per node"),
+                  ("rocprim radix sort of (key, id) (onesweep, 4 passes)", ms["sort"], 4 * n + 4 * 2 * 8 * n, None),
+                  ("k_tgt_gather", ms["gather"], n * (4 * W + 8 + 16 * eq), "one isolated 64-byte row per entry: 128 bytes fetched for it"),
+                  ("k_tgt_dir", ms["dir"], 4 * n + 16 * (nb + 1), None),
+                  (probe_kernel if first_dominates else "k_probe_quads", ms["probe_pairs"], alg_probe_launch * (1.0 - deferred / n_src), None),
+                  ("k_probe_clustered", ms["probe"] - ms["probe_pairs"], alg_probe_launch * (deferred / n_src), None),
+                  ("scan + k_local_emit_* + k_sort_rows", ms["emit"], n * 16 + E * 12 * 2, None)]
+            prefix = {"rocprim": "void rocprim", "scan": "k_scan"}
+            out["roofline_kernels"] = []
+            for name, kms, ab, note in rk:
+                if kms < 0.02 * ms_step:
+                    continue
+                tr = traffic_of(traffic, prefix.get(name.split()[0], name.split()[0])) if name.split()[0] not in ("scan",) else (
+                    sum(filter(None, (traffic_of(traffic, q) for q in ("k_scan", "k_local_emit", "k_sort_rows")))) or None)
+                ent = {"kernel": name, "ms": kms, "share_of_step": kms / ms_step, "algorithmic_bytes": int(ab), "achieved": ab / (kms * 1e-3) / 1e9,
+                       "frac": ab / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": tr, "achieved_hbm": (tr / (kms * 1e-3) / 1e9) if tr else None}
+                if note:
+                    ent["note"] = note
+                out["roofline_kernels"].append(ent)
+            out["index_build_ms"] = {k: ms[k] for k in ("keys", "sort", "gather", "dir")}
+        if supplement:
+            ps = stats["pkb"]
+            ab = sum(ps["kmers"]) * 24 + sum(ps["can_align_calls"]) * 8 * W + sum(ps["edges_after"]) * 8
+            out["supplement"] = {"ms": ms["supplement"], "exact_path_ms": ms_step - ms["supplement"], "kmers": ps["kmers"], "can_align_calls": ps["can_align_calls"],
+                                 "edges_after_round": ps["edges_after"], "edges_exact": int(stats["edges"]),
+                                 "algorithmic_bytes": int(ab), "achieved": ab / (ms["supplement"] * 1e-3) / 1e9, "frac": ab / (ms["supplement"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                 "per_unit": "SURVEY.md section 8(d) for cfg 5: 24 B per LI k-mer + 8W B per canAlign call (+ 8 B per edge key of the graph merged per round); "
+                                             "sort / merge / unique are rocPRIM, the group joins are k_pkb_groups_* (DESIGN.md section 9)"}
+        if first is not None:
+            first["warm_ms"] = ms_step - (ms["supplement"] if supplement else 0.0)
+            first["first_over_warm"] = first["first_call_ms"] / first["warm_ms"]
+            out["first_call"] = first
         if world > 1:
-            # strong-scaling efficiency T1 / (N * TN) against the one-GPU time of the same workload recorded under profiles/ (the driver
-            # computes its own from its back-to-back runs; this one is for a reader of a single line)
+            # strong-scaling efficiency T1 / (N * TN) against the one-GPU time of the same workload AND the same kernel sources
+            # recorded under profiles/ (the driver computes its own from its back-to-back runs; this one is for a reader of a single line)
             try:
-                ref = json.loads(open(os.path.join(ROOT, "profiles", "r02_d_cfg4_50M_bench.json")).read().strip().splitlines()[-1])
-                if ref["config"]["nodes"] == n_nodes and ref["config"]["edges"] == int(n_edges):
-                    out["strong_scaling"] = {"t1_ms": ref["ms_per_step"], "t1_source": "profiles/r02_d_cfg4_50M_bench.json", "tn_ms": ms_step,
+                ref = json.loads(open(os.path.join(ROOT, "profiles", "r03_cfg4_50M_bench.json")).read().strip().splitlines()[-1])
+                if ref["config"]["nodes"] == n_nodes and ref["config"]["edges"] == int(n_edges) and ref.get("src_sha256") == src_sha:
+                    out["strong_scaling"] = {"t1_ms": ref["ms_per_step"], "t1_source": "profiles/r03_cfg4_50M_bench.json", "tn_ms": ms_step,
                                              "efficiency": ref["ms_per_step"] / (world * ms_step)}
             except Exception:
                 pass
-        if world == 1 and not args.no_pcie:
+            out["multi_gpu_validation"] = "the N-rank path has not run over RCCL on hardware (no multi-GPU node available to the builder): N-rank graph == one-GPU graph is checked over gloo and as N ranks on one GPU only"
+        out["src_sha256"] = src_sha
+        if world == 1 and not args.no_pcie and not supplement:
             # the same graph through the host-buffer entry point (packed host reads in, host edge list out): never `value`
             if host_words is None:
                 host_words = d_words.cpu().numpy().view(np.uint32)
@@ -297,7 +381,10 @@ def main():
             except AttributeError:
                 cores = os.cpu_count() or 1
             cores = max(1, min(cores, 16))          # the GPU box gives one GPU's CPU share: 16 cores
-            cb = cpu_baseline_reference(sample_codes, cores, eng) if sample_codes is not None else None
+            cb = cpu_baseline_reference(sample_codes, cores, eng, err) if sample_codes is not None else None
+            if cb is not None and err > 0:
+                cb["note"] = ("reads with errors: the reference's own --threads > 1 result differs by a few edges from run to run (its creator races on ties, "
+                              "SURVEY.md section 0.6), so graph_bytes_equal_gpu is informative only here; the exact path equals the --threads=1 dump (tests/test_gpu_fullsize.py)")
             if cb is None:
                 hw = host_words if host_words is not None else d_words[:200_000].cpu().numpy().view(np.uint32)
                 hl = host_lens if host_lens is not None else d_lens[:200_000].cpu().numpy()
@@ -309,7 +396,7 @@ def main():
     if rank == 0:
         wall = time.perf_counter() - t_process
         out["fits_in_driver_run"] = {"wall_s": round(wall, 1), "limit_s": 600, "fits": wall < 600,
-                                     "note": "whole bench.py process: workload generation, counted pass, warmup, timed steps, PCIe leg, CPU baseline"}
+                                     "note": "whole bench.py process: workload generation, first-call legs, counted pass, warmup, timed steps, PCIe leg, CPU baseline"}
         print(json.dumps(out))
 
 

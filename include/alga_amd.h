@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ALGA_AMD_ABI_VERSION 3
+#define ALGA_AMD_ABI_VERSION 4
 
 typedef enum {
     ALGA_OK = 0,
@@ -115,7 +115,9 @@ typedef struct {
     uint64_t big_sources;         /* SOURCE_SIDE: sources with more raw overlaps than a wave's LDS holds (second pass) */
     uint64_t probe_used;          /* alga_probe of the last build (1 or 2)                       */
     uint64_t deferred_sources;    /* CLUSTER probe: sources the pair kernel handed to the general kernel (all of them when it was skipped) */
-    double   ms_probe_pairs;      /* CLUSTER probe: the pair kernel's part of ms_probe (0: not run) */
+    double   ms_probe_pairs;      /* CLUSTER probe: the first kernel's (quad / pair kernel) part of ms_probe (0: not run) */
+    double   ms_keys, ms_sort, ms_gather, ms_dir; /* CLUSTER probe: the parts of ms_seed -- k_node_runs, radix sort of (key, id),
+                                     k_tgt_gather, k_tgt_dir (0 for a build that reused them: keys_shared)         */
 } alga_prefsuf_stats;
 
 /* ---- lifetime --------------------------------------------------------------------------- */
@@ -146,10 +148,19 @@ void        alga_prefsuf_default_params(alga_prefsuf_params *p);
  *   G->retainOnlySmallestOffset();
  * The result is the graph the caller would hold at src/main.cpp:293: edges grouped by src,
  * each adjacency list sorted by (dst, offset) (src/DataStructures/Graph.cpp:367-387).
- * *edges is engine-owned host memory; release with alga_free_edges(). */
+ * *edges is engine-owned host memory; release with alga_free_edges() on the SAME engine and BEFORE alga_engine_destroy():
+ * the engine keeps track of the lists it handed out (one released list is kept as a spare for the next call), destroy frees
+ * whatever is still outstanding, and a list must not be touched afterwards. */
 int  alga_prefsuf_build_host(alga_engine *e, const alga_nodes *nodes, const alga_prefsuf_params *p,
                              alga_edge **edges, uint64_t *n_edges);
 void alga_free_edges(alga_engine *e, alga_edge *edges);
+
+/* Allocates, ahead of time, every device buffer a build of the exact path needs for a node set of `n_nodes` rows of up to
+ * `max_len` nucleotides (and, n_edges_hint > 0, for that many edges; 0 = one per node): an assembler builds its graph ONCE, and
+ * without this the first build pays ~30 device allocations of up to 6 GB in the middle of its kernels (76 ms instead of 54 at
+ * 90 M nodes in round 2).  Safe to call from a second host thread while the caller is still parsing or uploading the reads --
+ * but not concurrently with another call on the same engine.  Later builds allocate only what turns out larger. */
+int  alga_engine_reserve(alga_engine *e, int32_t n_nodes, int32_t max_len, int32_t min_overlap, uint64_t n_edges_hint);
 
 /* Same computation with the node set already resident in HBM (all pointers in `nodes` are device
  * pointers on the engine's device).  Work is enqueued on `hip_stream` (a hipStream_t).  NULL = the engine's own stream, a

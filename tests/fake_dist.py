@@ -1,7 +1,9 @@
 """A thread-based stand-in for torch.distributed (the handful of collectives alga_amd/multigpu.py uses), so that the real
 sharded driver + the real HIP backend can run as N 'ranks' inside ONE process on ONE GPU -- TEST INFRASTRUCTURE.
 Every rank is a thread holding a FakeDist(rank); collectives rendezvous on a shared barrier."""
+import queue
 import threading
+from collections import defaultdict
 
 
 class _World:
@@ -9,6 +11,7 @@ class _World:
         self.n = n
         self.barrier = threading.Barrier(n)
         self.slots = [None] * n
+        self.mail = defaultdict(queue.Queue)        # (src, dst) -> tensors in send order (point-to-point transfers)
 
 
 class ReduceOp:
@@ -55,6 +58,24 @@ class FakeDist:
                 g.copy_(p)
         self._sync()
         return self._Done() if async_op else None
+
+    def isend(self, tensor, dst):
+        self._sync()
+        self.w.mail[(self.rank, dst)].put(tensor.detach().clone())
+        return self._Done()
+
+    class _Recv:
+        def __init__(self, outer, tensor, src):
+            self.o, self.t, self.src = outer, tensor, src
+
+        def wait(self):
+            got = self.o.w.mail[(self.src, self.o.rank)].get(timeout=300)
+            self.t.copy_(got.reshape(self.t.shape))
+            self.o._sync()
+            return True
+
+    def irecv(self, tensor, src):
+        return self._Recv(self, tensor, src)
 
     def all_reduce(self, t, op=ReduceOp.SUM):
         import torch

@@ -465,21 +465,64 @@ def test_sharded_driver_with_hip_backend_three_ranks_one_gpu(lo, rs, replicate):
     def rank_main(rank, dist):
         e = alga_amd.Engine(0)
         try:
-            run = ShardedPrefSuf(HipBackend(e, dw, dl, lo, rs), rank, 3, dist, replicate=replicate)
-            m, st = run.step(collect_stats=True)
-            m2, _ = run.step()
-            assert m == m2 == len(want)
-            return run.edges_numpy(), st["raw_overlaps"]
+            out = []
+            for kw in (dict(), dict(shard_keys=True, pieces=None)):        # the driver's defaults; sharded key pass + pieces (opt-in)
+                run = ShardedPrefSuf(HipBackend(e, dw, dl, lo, rs), rank, 3, dist, replicate=replicate, **kw)
+                m, st = run.step(collect_stats=True)
+                m2, _ = run.step()
+                assert m == m2 == len(want)
+                out.append((run.edges_numpy(), st["raw_overlaps"]))
+            return out
         finally:
             e.close()
     res = run_ranks(3, rank_main)
     _, _, cnt = O.prefsuf(words, lens, lo, rs)
-    for r, (got, raw) in enumerate(res):
-        assert raw == cnt["hash_equal"]                              # whole-job counter, all-reduced
-        if r == 0 or replicate:
-            assert got.shape == want.shape and (got == want).all()
-        else:
-            assert len(got) == 0
+    for r, outs in enumerate(res):
+        for got, raw in outs:
+            assert raw == cnt["hash_equal"]                          # whole-job counter, all-reduced
+            if r == 0 or replicate:
+                assert got.shape == want.shape and (got == want).all()
+            else:
+                assert len(got) == 0
+
+
+def test_sharded_driver_three_ranks_one_gpu_at_a_payload_that_can_race():
+    """The same driver at 1 M reads (1.7 M nodes): key arrays of 7 MB, edge pieces of several MB per rank, four pieces per rank with
+    their transfers outstanding while the next piece is probed -- the size at which the stream-ordering bug of round 2's rehearsal
+    showed (wrong edge counts at 2 and 4 ranks; HipBackend.stream_scope is the fix this test guards).  Reference = the one-GPU
+    graph of the same engine (itself byte-equal to the reference binary at this size: tests/test_gpu_fullsize.py)."""
+    import torch
+    from alga_amd import workload
+    from alga_amd.multigpu import HipBackend, ShardedPrefSuf
+    from fake_dist import run_ranks
+    wl = workload.build("cfg2_1M_150bp", stride_words="aligned")
+    lo, rs = wl["min_overlap"], wl["rsoemo"]
+    dw = torch.from_numpy(wl["words"].view(np.int32)).cuda()
+    dl = torch.from_numpy(wl["lens"]).cuda()
+    e0 = alga_amd.Engine(0)
+    try:
+        ptr, m = e0.prefsuf_device(dw, dl, lo, rs)
+        want = alga_amd.engine.device_view(ptr, (m, 3), dw.device).cpu().numpy().astype(np.int32).copy()
+    finally:
+        e0.close()
+    assert len(want) > 1_000_000
+
+    def rank_main(rank, dist):
+        e = alga_amd.Engine(0)
+        try:
+            got = []
+            for kw in (dict(shard_keys=True, pieces=4), dict()):
+                run = ShardedPrefSuf(HipBackend(e, dw, dl, lo, rs), rank, 3, dist, **kw)
+                for _ in range(2):
+                    m_r, _ = run.step()
+                    assert m_r == len(want)
+                got.append(run.edges_numpy())
+            return got
+        finally:
+            e.close()
+    res = run_ranks(3, rank_main)
+    for got in res[0]:
+        assert got.shape == want.shape and (got == want).all()
 
 
 def test_contig_like_inputs_second_call_of_the_reference(eng):

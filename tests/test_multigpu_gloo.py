@@ -81,8 +81,7 @@ class PyBackend:
             self.first_piece_done = True
             k, m = self._fake_keys(0, self.n)
             assert (self.karr[0][:self.n].numpy() == k).all() and (self.karr[1][:self.n].numpy() == m).all()
-        else:
-            assert not self.source_side
+        # keys_shared == 0: the rank computes all keys itself (the driver's default until the sharded key pass has run over RCCL)
         if not self.source_side or self.decline:
             return None
         from source_side_rule import source_side_edges
@@ -144,14 +143,16 @@ class PyBackend:
         pass
 
 
-def _worker(rank, world, port, words, lens, lo, rs, out_dir, source_side=False, decline_rank=None, replicate=False):
+def _worker(rank, world, port, words, lens, lo, rs, out_dir, source_side=False, decline_rank=None, replicate=False, opt_in=True):
     import torch.distributed as dist
     from alga_amd import multigpu
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        run = multigpu.ShardedPrefSuf(PyBackend(words, lens, lo, rs, source_side, decline_rank, rank), rank, world, dist, replicate=replicate)
+        # opt_in: the sharded key pass + key all-gather and several pieces per rank; else the driver's defaults (one piece, own keys)
+        kw = dict(shard_keys=True, pieces=None) if opt_in else {}
+        run = multigpu.ShardedPrefSuf(PyBackend(words, lens, lo, rs, source_side, decline_rank, rank), rank, world, dist, replicate=replicate, **kw)
         m, st = run.step(collect_stats=True)
         e = run.edges_numpy()
         assert m == len(e) or (rank != 0 and not replicate and len(e) == 0)
@@ -169,11 +170,14 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world,source_side,decline_rank,replicate", [(2, False, None, True), (3, False, None, False), (2, True, None, False),
-                                                                      (3, True, None, True), (3, True, 1, False)])
-def test_sharded_driver_over_gloo_equals_oracle(tmp_path, world, source_side, decline_rank, replicate):
+@pytest.mark.parametrize("world,source_side,decline_rank,replicate,opt_in", [
+    (2, False, None, True, True), (3, False, None, False, True), (2, True, None, False, True), (3, True, None, True, True), (3, True, 1, False, True),
+    (2, True, None, False, False), (3, True, None, False, False), (3, True, 2, False, False)])
+def test_sharded_driver_over_gloo_equals_oracle(tmp_path, world, source_side, decline_rank, replicate, opt_in):
     """Per-target form (record exchange), source-side form (no exchange), and one rank declining the source-side form
-    (capacity case): every rank must fall back together."""
+    (capacity case): every rank must fall back together.  opt_in: sharded key pass + key all-gather + several pieces per rank;
+    else the driver's defaults (one piece, every rank its own keys).  The edge lists reach rank 0 as exact-length point-to-point
+    transfers landed at their offsets of one list."""
     import gen_reads
     import oracle_lib as O
     import alga_amd
@@ -187,7 +191,7 @@ def test_sharded_driver_over_gloo_equals_oracle(tmp_path, world, source_side, de
     assert len(want) > 50
     single = PyBackend(words, lens, lo, rs).build().numpy()          # the stand-in itself agrees with the oracle
     assert (single == want).all()
-    mp.spawn(_worker, args=(world, _free_port(), words, lens, lo, rs, str(tmp_path), source_side, decline_rank, replicate), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), words, lens, lo, rs, str(tmp_path), source_side, decline_rank, replicate, opt_in), nprocs=world, join=True)
     for r in range(world):
         got = np.load(str(tmp_path / ("edges_%d.npy" % r)))
         assert int(np.load(str(tmp_path / ("count_%d.npy" % r)))[0]) == len(want)      # every rank knows the size of the graph

@@ -1,58 +1,66 @@
 #!/usr/bin/env python3
-"""Extract the probe phase's memory-side traffic from the rocprofv3 PMC passes of tools/profile_cmd.sh (passes f and w of bench.py)
-and store it where bench.py picks it up (profiles/probe_hbm_bytes.json -> roofline.traffic), tagged with the fingerprint of the
-kernel sources it was measured on (alga_amd.engine.source_fingerprint): bench.py reports it only for that very code.
+"""Memory-side traffic of every engine kernel from the rocprofv3 PMC passes `r` and `x` of tools/profile_cmd.sh, stored where
+bench.py picks it up (profiles/hbm_traffic.json -> roofline.traffic, roofline_kernels[].traffic), tagged with the fingerprint
+of the kernel sources it was measured on (alga_amd.engine.source_fingerprint): bench.py quotes it only for that very code.
 
   tools/pmc_to_traffic.py gpurun_out/prof_<tag> <config name>
 
-FETCH_SIZE / WRITE_SIZE are KiB per dispatch (MI355X_MICROARCH.md, section HBM).  Calibration on this build, same run, kernels of
-known byte count: k_node_runs streams every node row once (coalesced dword loads, 64 B per row + the lengths) and FETCH_SIZE shows
-HALF of those bytes -- the guide's gfx950 correction (x2) applies to coalesced streams; k_tgt_gather reads one random 64-byte line per
-node (+ one random 4-byte meta word = one more line) and FETCH_SIZE shows them in FULL -- no correction for isolated 64-byte lines.
-The probe kernels read a mix (a 64-byte row, a 64-byte run list, random index lines: isolated lines; the entries of a cluster:
-runs of adjacent lines), so both figures are stored: `hbm_bytes_per_launch` = FETCH + WRITE as counted, and the upper bound with
-FETCH doubled.
+gfx950 counts the L2's memory-side requests BY SIZE (`rocprofv3 -L`: TCC_EA0_RDREQ_32B / _64B / _128B, TCC_EA0_WRREQ / _64B):
+    bytes read    = 32 * RDREQ_32B + 64 * RDREQ_64B + 128 * RDREQ_128B
+    bytes written = 64 * WRREQ_64B + 32 * (WRREQ - WRREQ_64B)
+Measured on this engine (profiles/r03_*): EVERY read request is a 128-byte one (RDREQ_128B == RDREQ, none of 32 or 64 bytes), for
+streaming and for isolated accesses alike.  Calibration on kernels of known byte count, same run: k_node_runs streams every node
+row (64 B) and length once: 6.16 GB expected, 128 * RDREQ = 6.16 GB; k_tgt_gather reads one isolated 64-byte row per node and
+fetches 128 bytes for it (12.6 GB for 5.8 GB of rows + 0.7 GB of keys).  FETCH_SIZE, which ROCm 7.2 derives with the gfx94x
+formula (64 bytes per request), therefore reports HALF of the bytes read for every access pattern: the guide's "x2" holds
+everywhere, and the round-2 bracket of this repository (78 .. 153 GB for the probe phase) resolves to its upper end.
 """
 import csv
 import glob
-import hashlib
 import json
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-PROBE_KERNELS = ("k_probe_pairs", "k_probe_clustered", "k_probe_sources")
 
 
-def per_launch(root, sub, counter):
-    """sum over the probe kernels of (mean per dispatch), non-statistics instantiations only"""
+def short(name):
+    name = name.split("(")[0]
+    for p in ("void alga::", "alga::"):
+        if name.startswith(p):
+            name = name[len(p):]
+    return name
+
+
+def means(root, sub):
     acc = {}
     for f in glob.glob(os.path.join(root, sub, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            name = r["Kernel_Name"]
-            k = next((p for p in PROBE_KERNELS if p in name), None)
-            if k is None or r["Counter_Name"] != counter or "<true" in name or "(bool)1" in name:
-                continue
-            acc.setdefault(k, []).append(float(r["Counter_Value"]))
-    return {k: sum(v) / len(v) for k, v in acc.items()}
+            acc.setdefault(short(r["Kernel_Name"]), {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    return {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in acc.items()}
 
 
 def main():
     from alga_amd.engine import source_fingerprint
     root, config = sys.argv[1], sys.argv[2]
-    fetch, write = per_launch(root, "pmc_fetch", "FETCH_SIZE"), per_launch(root, "pmc_write", "WRITE_SIZE")
-    lib = os.path.join(ROOT, "alga_amd", "lib", "libalga_amd.so")
-    out_path = os.path.join(ROOT, "profiles", "probe_hbm_bytes.json")
+    rd, wr = means(root, "pmc_rdreq"), means(root, "pmc_wrreq")
+    kernels = {}
+    for k in sorted(set(rd) | set(wr)):
+        if not (k.startswith("k_") or "rocprim" in k) or "<true" in k:          # engine kernels and the library sort; not the statistics builds
+            continue
+        r, w = rd.get(k, {}), wr.get(k, {})
+        n128, n64, n32 = r.get("TCC_EA0_RDREQ_128B_sum", 0.0), r.get("TCC_EA0_RDREQ_64B_sum", 0.0), r.get("TCC_EA0_RDREQ_32B_sum", 0.0)
+        other = r.get("TCC_EA0_RDREQ_sum", 0.0) - n128 - n64 - n32                # requests of no listed size (none seen): priced at 64 bytes
+        w64 = w.get("TCC_EA0_WRREQ_64B_sum", 0.0)
+        kernels[k[:70]] = {"read_bytes": int(128 * n128 + 64 * n64 + 32 * n32 + 64 * max(0.0, other)),
+                           "write_bytes": int(64 * w64 + 32 * max(0.0, w.get("TCC_EA0_WRREQ_sum", 0.0) - w64)),
+                           "read_requests": {"128B": int(n128), "64B": int(n64), "32B": int(n32)}}
+    out_path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     data = json.load(open(out_path)) if os.path.exists(out_path) else {}
-    f_kib, w_kib = sum(fetch.values()), sum(write.values())
-    data[config] = {"kernels": sorted(set(fetch) | set(write)), "fetch_kib": fetch, "write_kib": write,
-                    "hbm_bytes_per_launch": int((f_kib + w_kib) * 1024),
-                    "hbm_bytes_per_launch_if_fetch_doubled": int((2 * f_kib + w_kib) * 1024),
-                    "lib_sha256": hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16], "src_sha256": source_fingerprint(),
-                    "source": os.path.basename(root.rstrip("/"))}
+    data[config] = {"src_sha256": source_fingerprint(), "source": os.path.basename(root.rstrip("/")), "per_dispatch": kernels}
     json.dump(data, open(out_path, "w"), indent=1, sort_keys=True)
-    print(json.dumps(data[config]))
+    print(json.dumps({k: v["read_bytes"] + v["write_bytes"] for k, v in kernels.items()}))
 
 
 if __name__ == "__main__":
