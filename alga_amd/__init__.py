@@ -5,5 +5,5 @@ the hand-written HIP kernels under alga_amd/csrc/.  This Python package is a thi
 the tests, bench.py and the multi-GPU driver; torch supplies device memory, streams and
 torch.distributed only.  There is no CPU fallback: importing works anywhere, computing needs the GPU.
 """
-from .engine import (Engine, AlgaError, PrefSufParams, load_library, library_path, pack_reads, derive_params, ingest_files, parse_files,  # noqa: F401
+from .engine import (Engine, MultiEngine, AlgaError, PrefSufParams, load_library, library_path, pack_reads, derive_params, ingest_files, parse_files,  # noqa: F401
                      EDGE_DTYPE)

@@ -633,12 +633,12 @@ int alga_prefsuf_build_device(alga_engine *e, const alga_nodes *nodes, const alg
     return ALGA_OK;
 }
 
-int alga_prefsuf_build_host(alga_engine *e, const alga_nodes *nodes, const alga_prefsuf_params *p, alga_edge **edges, uint64_t *n_edges) {
+// Host node set -> the engine's own upload buffers, in the engine's row layout (hbm_row_stride: 16-byte aligned rows that never
+// straddle a 64-byte line take the wide-load kernels); *dev describes the resident copy (masks included when given).
+int alga_upload_nodes(alga_engine *e, const alga_nodes *nodes, alga_nodes *dev) {
     if (!e) return ALGA_ERR_INVALID_ARGUMENT;
     e->err.clear();
-    if (!edges || !n_edges) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "output pointers must not be NULL");
-    *edges = nullptr; *n_edges = 0;
-    if (!nodes || !p) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "nodes/params must not be NULL");
+    if (!nodes || !dev) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "nodes / output must not be NULL");
     if (nodes->n < 0 || (nodes->n > 0 && (!nodes->words || !nodes->len || nodes->stride_words <= 0)))
         return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "bad node set");
     HIP_TRY(e, hipSetDevice(e->device));
@@ -651,8 +651,7 @@ int alga_prefsuf_build_host(alga_engine *e, const alga_nodes *nodes, const alga_
         if ((int64_t) blocks_of(max_len) > (int64_t) nodes->stride_words)
             return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "stride_words is smaller than the longest read needs");
     }
-    // Rows travel at the caller's stride through pinned staging buffers (staging.hip) and are re-strided on the DEVICE to the
-    // engine's layout (hbm_row_stride: 16-byte aligned rows that never straddle a 64-byte line take the wide-load kernels).
+    // Rows travel at the caller's stride through pinned staging buffers (staging.hip) and are re-strided on the DEVICE.
     const int stride_up = alga::hbm_row_stride(nodes->stride_words);
     const size_t wbytes = n * (size_t) stride_up * sizeof(uint32_t);
     const size_t raw_bytes = n * (size_t) nodes->stride_words * sizeof(uint32_t);
@@ -667,6 +666,7 @@ int alga_prefsuf_build_host(alga_engine *e, const alga_nodes *nodes, const alga_
             if ((rc = alga_staged_h2d(e, e->up_raw.p, nodes->words, raw_bytes))) return rc;
             launch_restride((const uint32_t *) e->up_raw.p, nodes->stride_words, (uint32_t *) e->up_words.p, stride_up, (uint64_t) n, s);
             if ((rc = alga_check_launch(e, "k_restride"))) return rc;
+            HIP_TRY(e, hipStreamSynchronize(s));
         } else if ((rc = alga_staged_h2d(e, e->up_words.p, nodes->words, raw_bytes))) return rc;
         if ((rc = alga_staged_h2d(e, e->up_len.p, nodes->len, n * sizeof(int32_t)))) return rc;
     }
@@ -683,13 +683,38 @@ int alga_prefsuf_build_host(alga_engine *e, const alga_nodes *nodes, const alga_
         if (n && (rc = alga_staged_h2d(e, e->up_to.p, nodes->align_to, n))) return rc;
         dn.align_to = (const uint8_t *) e->up_to.p;
     }
+    *dev = dn;
+    return ALGA_OK;
+}
+
+int alga_download_edges(alga_engine *e, const alga_edge *d_edges, uint64_t n_edges, alga_edge **edges) {
+    if (!e) return ALGA_ERR_INVALID_ARGUMENT;
+    e->err.clear();
+    if (!edges || (n_edges && !d_edges)) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "pointers must not be NULL");
+    *edges = nullptr;
+    HIP_TRY(e, hipSetDevice(e->device));
+    alga_edge *h = (alga_edge *) alga_host_list_take(e, (size_t) (n_edges ? n_edges : 1) * sizeof(alga_edge));
+    if (!h) return alga_fail(e, ALGA_ERR_OUT_OF_MEMORY, "host edge buffer");
+    int rc;
+    if (n_edges && (rc = alga_staged_d2h(e, h, d_edges, (size_t) n_edges * sizeof(alga_edge)))) { alga_host_list_give(e, h); return rc; }
+    *edges = h;
+    return ALGA_OK;
+}
+
+int alga_prefsuf_build_host(alga_engine *e, const alga_nodes *nodes, const alga_prefsuf_params *p, alga_edge **edges, uint64_t *n_edges) {
+    if (!e) return ALGA_ERR_INVALID_ARGUMENT;
+    e->err.clear();
+    if (!edges || !n_edges) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "output pointers must not be NULL");
+    *edges = nullptr; *n_edges = 0;
+    if (!nodes || !p) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "nodes/params must not be NULL");
+    alga_nodes dn;
+    int rc = alga_upload_nodes(e, nodes, &dn);
+    if (rc) return rc;
     const alga_edge *d_edges = nullptr;
     uint64_t E = 0;
-    if ((rc = alga_prefsuf_build_device(e, &dn, p, (void *) s, &d_edges, &E))) return rc;
-    alga_edge *h = (alga_edge *) alga_host_list_take(e, (size_t) (E ? E : 1) * sizeof(alga_edge));
-    if (!h) return alga_fail(e, ALGA_ERR_OUT_OF_MEMORY, "host edge buffer");
-    if (E && (rc = alga_staged_d2h(e, h, d_edges, (size_t) E * sizeof(alga_edge)))) { alga_host_list_give(e, h); return rc; }
-    *edges = h; *n_edges = E;
+    if ((rc = alga_prefsuf_build_device(e, &dn, p, (void *) e->own_stream, &d_edges, &E))) return rc;
+    if ((rc = alga_download_edges(e, d_edges, E, edges))) return rc;
+    *n_edges = E;
     return ALGA_OK;
 }
 
@@ -809,6 +834,7 @@ int alga_prefsuf_keys_device(alga_engine *e, const alga_nodes *nodes, const alga
     if ((rc = alga_check_launch(e, "k_node_runs"))) return rc;
     e->keyed_n = nodes->n; e->keyed_begin = node_begin; e->keyed_end = node_end; e->keyed_words = (const void *) nodes->words;
     out->eligible = 1;
+    out->meta_needed = pp.uniform_len > 0 ? 0 : 1;
     out->d_keys = (uint32_t *) e->cl_keys[0].p;
     out->d_meta = (uint32_t *) e->cl_meta.p;
     return ALGA_OK;

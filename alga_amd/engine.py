@@ -105,8 +105,18 @@ class PkbStats(C.Structure):
 
 PROBE = {"auto": 0, "table": 1, "cluster": 2}                  # alga_probe
 
+class MultiStats(C.Structure):
+    """alga_multi_stats"""
+    _fields_ = [("n_ranks", C.c_int32), ("transport", C.c_int32), ("fell_back_to_one_gpu", C.c_int32), ("reserved", C.c_int32), ("edges", C.c_uint64),
+                ("ms_upload", C.c_double), ("ms_download", C.c_double), ("ms_keys", C.c_double), ("ms_share", C.c_double), ("ms_build", C.c_double),
+                ("ms_gather", C.c_double), ("ms_total", C.c_double)]
+
+
+TRANSPORT = {"auto": 0, "rccl": 1, "copy": 2}                  # alga_transport
+
+
 class NodeKeys(C.Structure):
-    _fields_ = [("d_keys", C.c_void_p), ("d_meta", C.c_void_p), ("n", C.c_int32), ("eligible", C.c_int32)]
+    _fields_ = [("d_keys", C.c_void_p), ("d_meta", C.c_void_p), ("n", C.c_int32), ("eligible", C.c_int32), ("meta_needed", C.c_int32), ("reserved", C.c_int32)]
 
 
 EXPORTS = ["alga_abi_version", "alga_engine_set_option", "alga_engine_create", "alga_engine_destroy", "alga_last_error",
@@ -115,7 +125,9 @@ EXPORTS = ["alga_abi_version", "alga_engine_set_option", "alga_engine_create", "
            "alga_prefsuf_reduce_device", "alga_prefsuf_build_range_device", "alga_prefsuf_keys_device", "alga_write_graph", "alga_ingest_default_params", "alga_ingest_files",
            "alga_free_node_set", "alga_sort_records_device", "alga_sort_edges_device", "alga_pkb_derive_params",
            "alga_can_align_batch_host", "alga_li_kmers_host", "alga_pkb_supplement_host", "alga_pkb_supplement_device",
-           "alga_pkb_last_stats", "alga_parse_files", "alga_free_parsed_reads", "alga_preprocess_nodes", "alga_copy_to_host", "alga_device_alloc", "alga_device_free", "alga_copy_to_device", "alga_cut_triangles_device", "alga_cut_triangles_host", "alga_ingest_device", "alga_contig_trim_host", "alga_engine_reserve"]
+           "alga_pkb_last_stats", "alga_parse_files", "alga_free_parsed_reads", "alga_preprocess_nodes", "alga_copy_to_host", "alga_device_alloc", "alga_device_free", "alga_copy_to_device", "alga_cut_triangles_device", "alga_cut_triangles_host", "alga_ingest_device", "alga_contig_trim_host", "alga_engine_reserve", "alga_upload_nodes", "alga_download_edges",
+           "alga_multi_create", "alga_multi_destroy", "alga_multi_last_error", "alga_multi_engine", "alga_multi_prefsuf_build_host", "alga_multi_prefsuf_build_device",
+           "alga_multi_free_edges", "alga_multi_last_stats"]
 
 
 def library_path():
@@ -609,6 +621,81 @@ class Engine:
         rc = self._lib.alga_write_graph(path.encode(), int(n_nodes), edges.ctypes.data, len(edges))
         if rc:
             raise AlgaError(rc, "alga_write_graph(%s) failed" % path)
+
+
+class MultiEngine:
+    """alga_multi_*: the N GPUs of one node behind one handle -- one process, one host thread and one engine per rank
+    (alga_amd/csrc/engine_multi.hip).  devices may name the same GPU several times with transport="copy" (how a one-GPU box tests it)."""
+
+    def __init__(self, devices, transport="auto"):
+        self._lib = load_library()
+        self._lib.alga_multi_create.argtypes = [C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
+        self._lib.alga_multi_destroy.argtypes = [C.c_void_p]
+        self._lib.alga_multi_destroy.restype = None
+        self._lib.alga_multi_last_error.argtypes = [C.c_void_p]
+        self._lib.alga_multi_last_error.restype = C.c_char_p
+        self._lib.alga_multi_prefsuf_build_host.argtypes = [C.c_void_p, C.POINTER(_Nodes), C.POINTER(PrefSufParams), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+        self._lib.alga_multi_prefsuf_build_device.argtypes = [C.c_void_p, C.POINTER(_Nodes), C.POINTER(PrefSufParams), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+        self._lib.alga_multi_free_edges.argtypes = [C.c_void_p, C.c_void_p]
+        self._lib.alga_multi_free_edges.restype = None
+        self._lib.alga_multi_last_stats.argtypes = [C.c_void_p, C.POINTER(MultiStats), C.c_void_p]
+        devs = (C.c_int32 * len(devices))(*[int(d) for d in devices])
+        h = C.c_void_p()
+        rc = self._lib.alga_multi_create(devs, len(devices), TRANSPORT[transport] if isinstance(transport, str) else int(transport), C.byref(h))
+        if rc:
+            raise AlgaError(rc, "alga_multi_create(devices=%s, transport=%s) failed" % (list(devices), transport))
+        self._h, self.n = h, len(devices)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.alga_multi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc:
+            raise AlgaError(rc, (self._lib.alga_multi_last_error(self._h) or b"").decode())
+
+    def prefsuf_host(self, words, lens, min_overlap, rsoe_min_overlap, align_from=None, align_to=None, collect_stats=False, reduction="auto"):
+        words = np.ascontiguousarray(words, dtype=np.uint32)
+        lens = np.ascontiguousarray(lens, dtype=np.int32)
+        n = int(lens.shape[0])
+        stride = int(words.shape[1]) if words.ndim == 2 else (words.size // max(n, 1))
+        keep = [words, lens]
+        nd = _Nodes(words.ctypes.data, stride, lens.ctypes.data, n, None, None)
+        if align_from is not None:
+            af = np.ascontiguousarray(align_from, dtype=np.uint8); keep.append(af); nd.align_from = af.ctypes.data
+        if align_to is not None:
+            at = np.ascontiguousarray(align_to, dtype=np.uint8); keep.append(at); nd.align_to = at.ctypes.data
+        p = Engine.params(min_overlap, rsoe_min_overlap, collect_stats, reduction)
+        out, m = C.c_void_p(), C.c_uint64()
+        self._check(self._lib.alga_multi_prefsuf_build_host(self._h, C.byref(nd), C.byref(p), C.byref(out), C.byref(m)))
+        try:
+            e = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_int32)), shape=(max(m.value, 1) * 3,))[: m.value * 3]
+            return e.reshape(-1, 3).copy()
+        finally:
+            self._lib.alga_multi_free_edges(self._h, out)
+
+    def prefsuf_device(self, per_rank, min_overlap, rsoe_min_overlap):
+        """per_rank: [(words, lens)] torch tensors on each rank's device (the same node set) -> (device pointer on rank 0's GPU, n_edges)."""
+        arr = (_Nodes * self.n)(*[Engine._nodes_from_torch(w, l) for w, l in per_rank])
+        p = Engine.params(min_overlap, rsoe_min_overlap)
+        out, m = C.c_void_p(), C.c_uint64()
+        self._check(self._lib.alga_multi_prefsuf_build_device(self._h, arr, C.byref(p), C.byref(out), C.byref(m)))
+        return out.value, int(m.value)
+
+    def last_stats(self):
+        st = MultiStats()
+        per = (PrefSufStats * self.n)()
+        self._check(self._lib.alga_multi_last_stats(self._h, C.byref(st), C.cast(per, C.c_void_p)))
+        d = {k: getattr(st, k) for k, _ in st._fields_ if k != "reserved"}
+        d["ranks"] = [x.as_dict() for x in per]
+        return d
 
 
 class _DevArray:

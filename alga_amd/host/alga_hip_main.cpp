@@ -2,7 +2,12 @@
 //
 //   alga_hip --file1=reads.fasta [--file2=mates.fasta] --output=contigs.fasta [--threads=N] [--error_rate=R | --error-rate=R]
 //            [--serialize=1] [-l MINOVERLAP] [--rsoemo=N] [--scale=F] [--retl=N --retr=N] [--remove_reads_with_n=0|1] [--rna=0|1]
-//            [--device=K] [--alga=/path/to/stock/ALGA]
+//            [--device=K] [--gpus=N | --gpu-list=0,1,2,...] [--alga=/path/to/stock/ALGA]
+//
+// --gpus=N: the overlap graph on the GPUs K .. K+N-1 of this node (alga_multi_*, include/alga_amd.h: one host thread and one engine
+// per GPU, keys and edge lists exchanged over RCCL / xGMI) -- the counterpart of the reference's --threads for this stage
+// (src/Params.cpp:237-294).  Every GPU runs the input stage on the files itself (each over its own PCIe link), so no node set
+// crosses xGMI.  --gpu-list names the devices explicitly; a device named more than once selects the copy transport (testing).
 //
 // It reads the input exactly like the reference (src/IO/InputReader.cpp, src/IO/ReadPreprocess.cpp, src/main.cpp:93-266),
 // builds the overlap graph on the GPU and writes `<TEST_NAME>_beforeSimplifier.graph` in the reference's own dump
@@ -15,6 +20,7 @@
 #include <unistd.h>
 
 #include <chrono>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -35,7 +41,8 @@ int main(int argc, char **argv) {
     std::string file1, file2, output, alga_exe, v;
     alga_host::IngestParams ip;
     double error_rate = 0.0;
-    int device = 0, serialize = 1;
+    int device = 0, serialize = 1, gpus = 1;
+    std::vector<int32_t> gpu_list;
     std::vector<std::string> passthrough;
     for (int i = 1; i < argc; i++) {
         const char *a = argv[i];
@@ -52,6 +59,8 @@ int main(int argc, char **argv) {
         else if (opt(a, "--remove_reads_with_n", v)) ip.remove_reads_with_n = atoi(v.c_str());
         else if (opt(a, "--rna", v)) ip.rna = atoi(v.c_str());
         else if (opt(a, "--device", v)) device = atoi(v.c_str());
+        else if (opt(a, "--gpus", v)) gpus = std::max(1, atoi(v.c_str()));
+        else if (opt(a, "--gpu-list", v)) { gpu_list.clear(); for (size_t k = 0; k < v.size();) { gpu_list.push_back(atoi(v.c_str() + k)); size_t c = v.find(',', k); if (c == std::string::npos) break; k = c + 1; } }
         else if (opt(a, "--alga", v)) alga_exe = v;
         else if (!strcmp(a, "-l") && i + 1 < argc) ip.min_overlap = atoi(argv[++i]);
         else { fprintf(stderr, "alga_hip: unrecognized option '%s'\n", a); return 2; }
@@ -60,7 +69,7 @@ int main(int argc, char **argv) {
         // ... and --serialize / --deserialize_graph: the hand-off always goes through the dump this program writes
         const bool is_er = !strncmp(a, "--error_rate", 12) || !strncmp(a, "--error-rate", 12) || !strncmp(a, "--er=", 5);
         const bool is_ser = !strncmp(a, "--serialize", 11) || !strncmp(a, "--deserialize_graph", 19);
-        if (strncmp(a, "--device", 8) && strncmp(a, "--alga", 6) && !is_er && !is_ser) { passthrough.push_back(a); if (!strcmp(a, "-l")) passthrough.push_back(argv[i]); }
+        if (strncmp(a, "--device", 8) && strncmp(a, "--alga", 6) && strncmp(a, "--gpus", 6) && strncmp(a, "--gpu-list", 10) && !is_er && !is_ser) { passthrough.push_back(a); if (!strcmp(a, "-l")) passthrough.push_back(argv[i]); }
     }
     if (file1.empty()) { fprintf(stderr, "\nERROR - PLEASE PROVIDE THE INPUT FILE using --file1 option!\n"); return 1; }
     if (output.empty()) { fprintf(stderr, "\nERROR - PLEASE PROVIDE THE OUTPUT FILE NAME!\n"); return 1; }
@@ -75,8 +84,18 @@ int main(int argc, char **argv) {
     // Input stages (src/IO/InputReader.cpp, src/IO/ReadPreprocess.cpp, src/main.cpp:93-266) on the GPU: the host maps the files and
     // moves their bytes, the node set stays in HBM for the graph creator.  Inputs that stage does not take (file types other than
     // FASTA / FASTQ, random replacement of N) are parsed on the host cores and join the GPU at the duplicate / prefix removal.
+    if (gpu_list.empty()) for (int k = 0; k < gpus; k++) gpu_list.push_back(device + k);
+    const int n_ranks = (int) gpu_list.size();
+    alga_multi *multi = nullptr;
     alga_engine *engine = nullptr;
-    if (alga_engine_create(device, &engine) != ALGA_OK) { fprintf(stderr, "alga_amd: no usable HIP device\n"); return 1; }
+    if (n_ranks > 1) {
+        bool distinct = true;
+        for (int a = 0; a < n_ranks; a++) for (int b = 0; b < a; b++) distinct = distinct && gpu_list[(size_t) a] != gpu_list[(size_t) b];
+        int rc = alga_multi_create(gpu_list.data(), n_ranks, distinct ? ALGA_TRANSPORT_AUTO : ALGA_TRANSPORT_COPY, &multi);
+        if (rc == ALGA_ERR_UNSUPPORTED) rc = alga_multi_create(gpu_list.data(), n_ranks, ALGA_TRANSPORT_COPY, &multi);     // no RCCL on this box
+        if (rc != ALGA_OK) { fprintf(stderr, "alga_amd: cannot open %d HIP devices (status %d)\n", n_ranks, rc); return 1; }
+        engine = alga_multi_engine(multi, 0);
+    } else if (alga_engine_create(gpu_list[0], &engine) != ALGA_OK) { fprintf(stderr, "alga_amd: no usable HIP device\n"); return 1; }
     const auto t_engine = clk::now();
     alga_device_node_set nodes;
     alga_host::Parsed parsed;
@@ -86,31 +105,71 @@ int main(int argc, char **argv) {
     cp.min_overlap = ip.min_overlap; cp.rsoemo = ip.rsoemo; cp.remove_pref_reads = ip.remove_pref_reads; cp.threads = ip.threads;
     alga_ingest_info info;
     auto t1 = t_engine;
-    int irc = alga_ingest_device(engine, file1.c_str(), file2.empty() ? nullptr : file2.c_str(), &cp, &nodes, &info);
+    // the input stage on every GPU of the run, side by side (rank 0's on this thread): the node set never crosses xGMI
+    std::vector<alga_device_node_set> rank_nodes((size_t) n_ranks);
+    std::vector<alga_ingest_info> rank_info((size_t) n_ranks);
+    std::vector<int> rank_rc((size_t) n_ranks, ALGA_OK);
+    {
+        std::vector<std::thread> th;
+        auto ingest = [&](int r) {
+            alga_engine *er = multi ? alga_multi_engine(multi, r) : engine;
+            rank_rc[(size_t) r] = alga_ingest_device(er, file1.c_str(), file2.empty() ? nullptr : file2.c_str(), &cp, &rank_nodes[(size_t) r], &rank_info[(size_t) r]);
+        };
+        for (int r = 1; r < n_ranks; r++) th.emplace_back(ingest, r);
+        ingest(0);
+        for (std::thread &x : th) x.join();
+    }
+    int irc = ALGA_OK;
+    for (int r = 0; r < n_ranks; r++) if (rank_rc[(size_t) r] != ALGA_OK) { irc = rank_rc[(size_t) r]; if (irc != ALGA_ERR_UNSUPPORTED) { fprintf(stderr, "%s\n", alga_last_error(multi ? alga_multi_engine(multi, r) : engine)); return 1; } }
+    nodes = rank_nodes[0]; info = rank_info[0];
     if (irc == ALGA_OK) {
         fprintf(stderr, "device ingest: upload %.1f ms, lines + records %.1f ms, duplicate/prefix removal %.1f ms (wall)\n", info.ms_upload,
                 info.ms_parse - info.ms_upload, info.ms_preprocess);
         parsed.records = info.records; parsed.removed_n = info.removed_n; parsed.removed_str = info.removed_str;
         parsed.min_overlap = info.min_overlap; parsed.rsoemo = info.rsoemo; parsed.li_kmer_length = info.li_kmer_length;
         t1 = t_engine + std::chrono::duration_cast<clk::duration>(std::chrono::duration<double, std::milli>(info.ms_parse));
-    } else if (irc == ALGA_ERR_UNSUPPORTED) {
+    } else {                                               // ALGA_ERR_UNSUPPORTED: the host parser, then the duplicate / prefix removal on every GPU
         std::string err = alga_host::parse(file1, file2, ip, parsed);
         if (!err.empty()) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
         t1 = clk::now();
         alga_preprocess_input pin{parsed.rows.data(), parsed.W, parsed.len.data(), (int64_t) (2 * parsed.R), ip.remove_pref_reads, 3 + parsed.li_kmer_length};
-        if (alga_preprocess_nodes(engine, &pin, &nodes) != ALGA_OK) { fprintf(stderr, "%s\n", alga_last_error(engine)); return 1; }
-    } else { fprintf(stderr, "%s\n", alga_last_error(engine)); return 1; }
+        for (int r = 0; r < n_ranks; r++) {
+            alga_engine *er = multi ? alga_multi_engine(multi, r) : engine;
+            if (alga_preprocess_nodes(er, &pin, &rank_nodes[(size_t) r]) != ALGA_OK) { fprintf(stderr, "%s\n", alga_last_error(er)); return 1; }
+        }
+        nodes = rank_nodes[0];
+    }
     auto t1b = clk::now();
     fprintf(stderr, "input read: %lld records -> %d nodes (removed: %d with N, %d STR, %d duplicate/prefix, %d too short)\n",
             (long long) parsed.records, nodes.n, parsed.removed_n, parsed.removed_str, nodes.removed_prefix, nodes.removed_short);
     fprintf(stderr, "MIN_OVERLAP_PREF_SUF: %d\nREMOVE_SMALL_OVERLAP_EDGES_MIN_OVERLAP: %d\n", parsed.min_overlap, parsed.rsoemo);
     fprintf(stderr, "Creating GraphCreator\n");
+    alga_prefsuf_stats st;
+    const alga_edge *d_final = nullptr;
+    uint64_t n_final = 0;
     alga_host::GraphCreatorPrefSufHIP creator(engine, nodes.d_words, nodes.stride_words, nodes.d_len, nodes.n, parsed.min_overlap, parsed.rsoemo);
-    creator.startAlignmentGraphCreation();
+    if (multi) {
+        std::vector<alga_nodes> per_rank;
+        for (int r = 0; r < n_ranks; r++) per_rank.push_back(alga_nodes{rank_nodes[(size_t) r].d_words, rank_nodes[(size_t) r].stride_words, rank_nodes[(size_t) r].d_len, rank_nodes[(size_t) r].n, nullptr, nullptr});
+        alga_prefsuf_params pp;
+        alga_prefsuf_default_params(&pp);
+        pp.min_overlap = parsed.min_overlap; pp.rsoe_min_overlap = parsed.rsoemo;
+        int rc = alga_multi_prefsuf_build_device(multi, per_rank.data(), &pp, &d_final, &n_final);
+        if (rc != ALGA_OK) { fprintf(stderr, "alga_amd: %s (status %d)\n", alga_multi_last_error(multi), rc); return 1; }
+        alga_multi_stats ms;
+        std::vector<alga_prefsuf_stats> rs((size_t) n_ranks);
+        alga_multi_last_stats(multi, &ms, rs.data());
+        st = rs[0];
+        fprintf(stderr, "%d GPUs (%s): keys %.1f ms, key all-gather %.1f ms, build %.1f ms, edge gather %.1f ms (rank 0's host clock)%s\n", n_ranks,
+                ms.transport == ALGA_TRANSPORT_RCCL ? "RCCL" : "peer copies", ms.ms_keys, ms.ms_share, ms.ms_build, ms.ms_gather,
+                ms.fell_back_to_one_gpu ? "; the source-side form does not take this input: rank 0 built the graph alone" : "");
+    } else {
+        creator.startAlignmentGraphCreation();
+        st = creator.stats();
+        d_final = creator.deviceEdges();
+        n_final = creator.countEdges();
+    }
     auto t2 = clk::now();
-    alga_prefsuf_stats st = creator.stats();
-    const alga_edge *d_final = creator.deviceEdges();
-    uint64_t n_final = creator.countEdges();
     if (error_rate > 0.01) {                                                   // src/Params.cpp:358-359, src/main.cpp:300-355
         fprintf(stderr, "Before supplement, G has %llu edges\n", (unsigned long long) n_final);
         std::vector<int32_t> hl((size_t) nodes.n);
@@ -136,7 +195,8 @@ int main(int argc, char **argv) {
         fprintf(stderr, "Graph serialized! -> %s\n", graph.c_str());
     }
     final_edges.clear(); final_edges.shrink_to_fit();
-    alga_engine_destroy(engine);                           // the engine and its HBM buffers do not outlive the graph
+    creator.clear();
+    if (multi) alga_multi_destroy(multi); else alga_engine_destroy(engine);     // the engines and their HBM buffers do not outlive the graph
     if (!alga_exe.empty()) {
         // argv vector, no shell: nothing in a file name is interpreted
         std::vector<std::string> args{alga_exe};

@@ -162,6 +162,12 @@ void alga_free_edges(alga_engine *e, alga_edge *edges);
  * but not concurrently with another call on the same engine.  Later builds allocate only what turns out larger. */
 int  alga_engine_reserve(alga_engine *e, int32_t n_nodes, int32_t max_len, int32_t min_overlap, uint64_t n_edges_hint);
 
+/* The two halves of alga_prefsuf_build_host for callers that keep the node set resident across several stages (exact graph ->
+ * supplement -> ... on ONE upload): host node set -> the engine's upload buffers in the engine's row layout, `*dev` describes the
+ * resident copy (valid until the next upload on this engine); device edge list -> engine-owned host list (alga_free_edges). */
+int  alga_upload_nodes(alga_engine *e, const alga_nodes *nodes, alga_nodes *dev);
+int  alga_download_edges(alga_engine *e, const alga_edge *d_edges, uint64_t n_edges, alga_edge **edges);
+
 /* Same computation with the node set already resident in HBM (all pointers in `nodes` are device
  * pointers on the engine's device).  Work is enqueued on `hip_stream` (a hipStream_t).  NULL = the engine's own stream, a
  * NON-BLOCKING stream that orders with no other stream (not even the null stream): with NULL every input must be complete
@@ -225,9 +231,45 @@ int  alga_prefsuf_build_range_device(alga_engine *e, const alga_nodes *nodes, co
  * have room for n + ALGA_KEY_ARRAY_SLACK entries, so that equal-sized slices (ceil(n / ranks), the last one running past n) can be
  * gathered in place. */
 #define ALGA_KEY_ARRAY_SLACK 1024
-typedef struct { uint32_t *d_keys; uint32_t *d_meta; int32_t n; int32_t eligible; } alga_node_keys;
+typedef struct { uint32_t *d_keys; uint32_t *d_meta; int32_t n; int32_t eligible;
+                 int32_t meta_needed; /* 0: every live node has the same length and there is no alignFrom mask -- the build does not read d_meta, it need not be shared */
+                 int32_t reserved; } alga_node_keys;
 int  alga_prefsuf_keys_device(alga_engine *e, const alga_nodes *nodes, const alga_prefsuf_params *p,
                               int32_t node_begin, int32_t node_end, void *hip_stream, alga_node_keys *out);
+
+/* ---- the N GPUs of one node behind one handle (alga_amd/csrc/engine_multi.hip) ------------------------------------
+ * The reference's parallelism is --threads (src/Params.cpp:237-294; worker threads inside GraphCreatorPrefSuf,
+ * src/GraphCreators/GraphCreatorPrefSuf.cpp:150-161); the counterpart: ONE process, one host thread and one engine per GPU.  Rank r
+ * computes the minimizer keys of its node range, the key arrays are all-gathered in place (RCCL over xGMI), every rank builds the final
+ * edges of its own sources (steps 1-3 above) and the lists are gathered on rank 0's GPU with their exact lengths (grouped
+ * ncclSend / ncclRecv) -- the concatenation is the single-GPU byte order.  A rank declining the source-side form makes rank 0 build
+ * the whole graph alone: the result never depends on the number of ranks.
+ * transport: RCCL (dlopen of librccl.so.1; one GPU per rank) or COPY (hipMemcpyPeerAsync + host barriers; also takes several ranks on
+ * ONE device, which is how the driver is tested on a one-GPU box); AUTO = RCCL when every rank has its own GPU and there is more
+ * than one, else COPY.  Not yet run on more than one GPU. */
+typedef struct alga_multi alga_multi; /* opaque */
+typedef enum { ALGA_TRANSPORT_AUTO = 0, ALGA_TRANSPORT_RCCL = 1, ALGA_TRANSPORT_COPY = 2 } alga_transport;
+typedef struct {
+    int32_t  n_ranks, transport;          /* alga_transport actually used                                        */
+    int32_t  fell_back_to_one_gpu;        /* a rank declined the source-side form: rank 0 built the whole graph  */
+    int32_t  reserved;
+    uint64_t edges;
+    double   ms_upload, ms_download;      /* host entry point only: node set to every GPU (side by side), edges from rank 0 */
+    double   ms_keys, ms_share, ms_build, ms_gather, ms_total;   /* rank 0's host clock: key pass of its nodes, key all-gather, build of its
+                                             sources (waits for the slowest rank at its end), gather of the edge lists, all of it */
+} alga_multi_stats;
+int         alga_multi_create(const int32_t *hip_devices, int32_t n_ranks, int32_t transport, alga_multi **out);
+void        alga_multi_destroy(alga_multi *m);
+const char *alga_multi_last_error(const alga_multi *m);
+alga_engine *alga_multi_engine(alga_multi *m, int32_t rank);   /* rank's engine: input stage (alga_ingest_device) before, further stages (supplement ...) after, on rank 0's */
+/* nodes_per_rank[r]: the node set resident on rank r's GPU (the same nodes on every rank).  *d_edges: the complete graph on rank 0's
+ * GPU, owned by the handle, valid until its next build. */
+int         alga_multi_prefsuf_build_device(alga_multi *m, const alga_nodes *nodes_per_rank, const alga_prefsuf_params *p,
+                                            const alga_edge **d_edges, uint64_t *n_edges);
+/* Host buffers in, edges out -- alga_prefsuf_build_host on N GPUs; release *edges with alga_multi_free_edges before alga_multi_destroy. */
+int         alga_multi_prefsuf_build_host(alga_multi *m, const alga_nodes *nodes, const alga_prefsuf_params *p, alga_edge **edges, uint64_t *n_edges);
+void        alga_multi_free_edges(alga_multi *m, alga_edge *edges);
+int         alga_multi_last_stats(const alga_multi *m, alga_multi_stats *out, alga_prefsuf_stats *per_rank /* n_ranks entries, or NULL */);
 
 /* Exchange helpers of the sharded form (device in, device out, engine-owned results):
  *   alga_sort_records_device  orders record slots by target id and drops the padding: the first *n_valid

@@ -45,6 +45,15 @@ def test_no_cpu_fallback_without_device():
         alga_amd.Engine(0)
 
 
+def test_no_multi_gpu_handle_without_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    for transport in ("auto", "copy", "rccl"):
+        with pytest.raises(alga_amd.AlgaError):
+            alga_amd.MultiEngine([0, 0], transport=transport)
+
+
 def test_product_does_not_import_oracle():
     for dirpath, _, files in os.walk(os.path.join(ROOT, "alga_amd")):
         for f in files:

@@ -1,0 +1,107 @@
+"""alga_multi_* (alga_amd/csrc/engine_multi.hip): the C++ N-GPU driver behind the C ABI -- one process, one host thread and one engine
+per rank.  On a one-GPU box the ranks share the GPU and the COPY transport stands in for RCCL (the same driver code, the
+collectives as peer copies + host barriers); RCCL itself is exercised as far as one GPU allows: loaded, a one-rank communicator
+made, its in-place all-gather called.  The N-rank graph must be the one-GPU graph byte for byte."""
+import numpy as np
+import pytest
+
+import alga_amd
+import oracle_lib as O
+from test_gpu_parity import _nodes
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("ranks", [2, 3, 5])
+@pytest.mark.parametrize("n,length,G,seed,err,minlen,lo,rs", [
+    (3000, 100, 6000, 81, 0.0, None, 55, 77),          # uniform length: only the key array is shared
+    (3000, 144, 5000, 82, 0.004, 110, 82, 116),        # variable length + errors: the meta array travels too, some sources go the general way
+])
+def test_multi_copy_transport_equals_oracle(ranks, n, length, G, seed, err, minlen, lo, rs):
+    words, lens = _nodes(n, length, G, seed, err, minlen)
+    want, _, _ = O.prefsuf(words, lens, lo, rs)
+    m = alga_amd.MultiEngine([0] * ranks, transport="copy")
+    try:
+        for _ in range(2):                               # warm buffers the second time
+            got = m.prefsuf_host(words, lens, lo, rs)
+            assert got.shape == want.shape and (got == want).all()
+        st = m.last_stats()
+        assert st["n_ranks"] == ranks and st["transport"] == 2 and st["fell_back_to_one_gpu"] == 0 and st["edges"] == len(want)
+        assert all(r["probe_used"] == 2 and r["reduction_used"] == 2 for r in st["ranks"])
+        assert sum(r["edges"] for r in st["ranks"]) == len(want)
+    finally:
+        m.close()
+
+
+def test_multi_falls_back_when_a_rank_declines():
+    """250-nt reads at the default scale still take the source-side form (two-word masks, seed-table probe: no keys to share); reads
+    beyond 288 nt do not -- every rank declines and rank 0 builds the whole graph the general way.  Same graph as one engine."""
+    for length, lo, rs, fell in ((250, 140, 190, 0), (400, 60, 90, 1)):
+        words, lens = _nodes(1500, length, 9000, 83, 0.0, None)
+        want, _, _ = O.prefsuf(words, lens, lo, rs)
+        m = alga_amd.MultiEngine([0, 0, 0], transport="copy")
+        try:
+            got = m.prefsuf_host(words, lens, lo, rs)
+            assert got.shape == want.shape and (got == want).all()
+            assert m.last_stats()["fell_back_to_one_gpu"] == fell
+        finally:
+            m.close()
+
+
+def test_multi_masks_and_empty_input():
+    words, lens = _nodes(2000, 100, 4000, 84, 0.0, None)
+    rng = np.random.default_rng(84)
+    at = (rng.random(len(lens)) > 0.1).astype(np.uint8)
+    af = (at & (rng.random(len(lens)) > 0.1)).astype(np.uint8)          # alignFrom => alignTo (the source-side form's precondition)
+    want, _, _ = O.prefsuf(words, lens, 55, 77, af, at)
+    m = alga_amd.MultiEngine([0, 0], transport="copy")
+    try:
+        got = m.prefsuf_host(words, lens, 55, 77, af, at)
+        assert got.shape == want.shape and (got == want).all()
+        empty = m.prefsuf_host(np.zeros((0, 8), np.uint32), np.zeros(0, np.int32), 55, 77)
+        assert empty.shape == (0, 3)
+    finally:
+        m.close()
+
+
+def test_multi_rccl_one_rank():
+    """RCCL as far as one GPU goes: librccl loaded, ncclCommInitAll for one device, the in-place ncclAllGather of the key arrays."""
+    words, lens = _nodes(3000, 100, 6000, 85, 0.0, None)
+    want, _, _ = O.prefsuf(words, lens, 55, 77)
+    try:
+        m = alga_amd.MultiEngine([0], transport="rccl")
+    except alga_amd.AlgaError as e:
+        if e.code == -7:
+            pytest.skip("librccl.so.1 is not loadable on this box")
+        raise
+    try:
+        got = m.prefsuf_host(words, lens, 55, 77)
+        assert got.shape == want.shape and (got == want).all()
+        assert m.last_stats()["transport"] == 1
+    finally:
+        m.close()
+    with pytest.raises(alga_amd.AlgaError):                # RCCL wants one GPU per rank
+        alga_amd.MultiEngine([0, 0], transport="rccl")
+
+
+def test_multi_device_entry_point_at_1m_reads():
+    """the device-resident entry point with three ranks on one GPU at 1 M reads (1.7 M nodes): == the one-engine graph"""
+    import torch
+    from alga_amd import workload
+    wl = workload.build("cfg2_1M_150bp", stride_words="aligned")
+    lo, rs = wl["min_overlap"], wl["rsoemo"]
+    dw = torch.from_numpy(wl["words"].view(np.int32)).cuda()
+    dl = torch.from_numpy(wl["lens"]).cuda()
+    e0 = alga_amd.Engine(0)
+    try:
+        ptr, k = e0.prefsuf_device(dw, dl, lo, rs)
+        want = alga_amd.engine.device_view(ptr, (k, 3), dw.device).cpu().numpy().astype(np.int32).copy()
+    finally:
+        e0.close()
+    m = alga_amd.MultiEngine([0, 0, 0], transport="copy")
+    try:
+        ptr, k = m.prefsuf_device([(dw, dl)] * 3, lo, rs)
+        got = alga_amd.engine.device_view(ptr, (k, 3), dw.device).cpu().numpy().astype(np.int32)
+        assert got.shape == want.shape and (got == want).all()
+    finally:
+        m.close()

@@ -280,13 +280,19 @@ def test_cli_front_end_writes_the_reference_dump(golden_dir, tmp_path):
         fx = O.Fixture(golden_dir, name)
         try:
             f1, f2 = fx.inputs()
-            cmd = [exe, "--file1=" + f1, "--threads=4", "--output=o.fasta"] + (["--file2=" + f2] if f2 else [])
-            r = subprocess.run(cmd, cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
-            assert r.returncode == 0, r.stderr[-2000:]
-            stem = os.path.basename(f1).rsplit(".", 1)[0]
-            got = open(os.path.join(str(tmp_path), "ALGA_%s_scale55_noN_beforeSimplifier.graph" % stem), "rb").read()
-            assert got == fx.ref_graph()
-            assert ("Before first simplifier graph has %d edges" % fx.meta["edges_before_simplifier"]) in r.stderr
+            # one GPU; and `--gpu-list=0,0,0`: the N-GPU path of the command line (alga_multi_*: three ranks, here on the one GPU
+            # of the box with the copy transport), every rank running the input stage itself
+            for extra in ([], ["--gpu-list=0,0,0"]):
+                cmd = [exe, "--file1=" + f1, "--threads=4", "--output=o.fasta"] + (["--file2=" + f2] if f2 else []) + extra
+                r = subprocess.run(cmd, cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+                assert r.returncode == 0, r.stderr[-2000:]
+                stem = os.path.basename(f1).rsplit(".", 1)[0]
+                dump = os.path.join(str(tmp_path), "ALGA_%s_scale55_noN_beforeSimplifier.graph" % stem)
+                got = open(dump, "rb").read()
+                os.unlink(dump)
+                assert got == fx.ref_graph(), extra
+                assert ("Before first simplifier graph has %d edges" % fx.meta["edges_before_simplifier"]) in r.stderr
+                assert not extra or "3 GPUs (peer copies)" in r.stderr
         finally:
             fx.cleanup()
 
