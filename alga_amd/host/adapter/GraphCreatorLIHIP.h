@@ -15,16 +15,15 @@ public:
 
     void startAlignmentGraphCreation() override {
         const int n = G->size();
-        alga_adapter::NodeArrays nodes(*reads);
+        alga_adapter::Session &ses = alga_adapter::Session::get(device);
+        alga_engine *e = ses.engine();
+        alga_nodes nd = ses.nodes_of(*reads);                                   // resident since the exact graph was built: no second upload
         std::vector<alga_edge> in;                                             // the exact graph, lists sorted by (dst, offset)
         for (int a = 0; a < n; a++) {
             VPII row = (*G)[a];
             std::sort(row.begin(), row.end());
             for (const PII &x : row) in.push_back(alga_edge{a, x.first, x.second});
         }
-        alga_engine *e = nullptr;
-        int rc = alga_engine_create(device, &e);
-        if (rc != ALGA_OK) alga_adapter::die(nullptr, "no usable HIP device", rc);
         // The engine derives the tip masks from the degrees of the incoming graph itself (src/main.cpp:308-322) and takes the
         // parameters the caller has just stored in Params (src/main.cpp:332-340).
         alga_pkb_params p;
@@ -36,14 +35,16 @@ public:
         p.li_intervals = Params::LI_KMER_INTERVALS;
         p.rounds = 4;
         p.kmer_length_bucket = Params::KMER_LENGTH_BUCKET;
-        alga_nodes nd = {nodes.words.data(), nodes.stride, nodes.len.data(), n, nullptr, nullptr};
+        const alga_edge *d_in = (const alga_edge *) ses.to_device(2, in.data(), in.size() * sizeof(alga_edge));
+        const alga_edge *d_out = nullptr;
         alga_edge *out = nullptr;
         uint64_t m = 0;
-        rc = alga_pkb_supplement_host(e, &nd, &p, in.data(), (uint64_t) in.size(), &out, &m);
+        int rc = alga_pkb_supplement_device(e, &nd, &p, d_in, (uint64_t) in.size(), nullptr, &d_out, &m);
         if (rc != ALGA_OK) alga_adapter::die(e, "approximate supplement", rc);
+        rc = alga_download_edges(e, d_out, m, &out);
+        if (rc != ALGA_OK) alga_adapter::die(e, "approximate supplement (edges to the host)", rc);
         alga_adapter::fill_graph(G, out, m);
         alga_free_edges(e, out);
-        alga_engine_destroy(e);
     }
 
 private:

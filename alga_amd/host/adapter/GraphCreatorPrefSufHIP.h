@@ -75,6 +75,88 @@ inline void fill_graph(Graph *G, const alga_edge *e, uint64_t m) {
 
 [[noreturn]] inline void die(alga_engine *e, const char *what, int rc);
 
+// ONE engine and ONE resident node set per process.  The stages of an ALGA run that go through this library -- exact graph
+// (src/main.cpp:246-291), approximate supplement (:300-347), first simplifier step, contig trimming (:633-725) -- share them: the node
+// set crosses PCIe once (6 GB at 90 M nodes) and the engine's device buffers are allocated once, instead of once per stage.
+// The resident copy is matched on the vector's identity, its size and a sampled fingerprint of the reads (4096 evenly spaced reads:
+// length and first block); a caller that edits reads in place between two stages calls Session::get(dev).forget().
+class Session {
+public:
+    static Session &get(int hip_device) {
+        static Session s;
+        if (s.e_ == nullptr || s.device_ != hip_device) {
+            s.close();
+            int rc = alga_engine_create(hip_device, &s.e_);
+            if (rc != ALGA_OK) die(nullptr, "no usable HIP device", rc);
+            s.device_ = hip_device;
+        }
+        return s;
+    }
+    alga_engine *engine() { return e_; }
+    void forget() { resident_ = false; }
+    // the node set of `reads`, resident in HBM (uploaded now unless it already is)
+    alga_nodes nodes_of(std::vector<Read *> &reads) {
+        const uint64_t fp = fingerprint(reads);
+        if (!(resident_ && reads_id_ == (const void *) &reads && n_ == reads.size() && fp_ == fp)) {
+            NodeArrays host(reads);
+            alga_nodes hn = {host.words.data(), host.stride, host.len.data(), (int32_t) reads.size(), nullptr, nullptr};
+            // every device buffer of the builds to come, while nothing else is in flight (alga_engine_reserve, include/alga_amd.h)
+            int max_len = 0;
+            for (int32_t l : host.len) max_len = std::max(max_len, (int) l);
+            if (max_len > 0) (void) alga_engine_reserve(e_, hn.n, max_len, std::max(1, Params::MIN_OVERLAP_PREF_SUF), 0);
+            int rc = alga_upload_nodes(e_, &hn, &dev_);
+            if (rc != ALGA_OK) die(e_, "upload of the reads", rc);
+            resident_ = true; reads_id_ = (const void *) &reads; n_ = reads.size(); fp_ = fp;
+        }
+        alga_nodes nd = dev_;
+        nd.align_from = nullptr; nd.align_to = nullptr;
+        return nd;
+    }
+    // n bytes -> a session-owned device buffer (slot 0 / 1: the two masks; slot 2: an edge list)
+    const void *to_device(int slot, const void *host, size_t bytes) {
+        if (cap_[slot] < bytes) {
+            if (buf_[slot]) alga_device_free(e_, buf_[slot]);
+            buf_[slot] = nullptr; cap_[slot] = 0;
+            int rc = alga_device_alloc(e_, bytes, &buf_[slot]);
+            if (rc != ALGA_OK) die(e_, "device buffer", rc);
+            cap_[slot] = bytes;
+        }
+        if (bytes) { int rc = alga_copy_to_device(e_, buf_[slot], host, bytes); if (rc != ALGA_OK) die(e_, "copy to the device", rc); }
+        return buf_[slot];
+    }
+    // (no destructor work: at static-destruction time the HIP runtime may already be gone; a caller that wants the HBM back before the
+    // process ends calls shutdown())
+    static void shutdown(int hip_device) { get(hip_device).close(); }
+
+private:
+    Session() = default;
+    void close() {
+        if (!e_) return;
+        for (int k = 0; k < 3; k++) { if (buf_[k]) alga_device_free(e_, buf_[k]); buf_[k] = nullptr; cap_[k] = 0; }
+        alga_engine_destroy(e_);
+        e_ = nullptr; resident_ = false;
+    }
+    static uint64_t fingerprint(std::vector<Read *> &reads) {
+        uint64_t h = 0x9E3779B97F4A7C15ull ^ (uint64_t) reads.size();
+        const size_t n = reads.size(), step = std::max<size_t>(1, n / 4096);
+        for (size_t i = 0; i < n; i += step) {
+            Read *r = reads[i];
+            uint64_t x = r == nullptr ? ~0ull : (((uint64_t) r->size() << 32) | (r->size() > 0 ? r->getSequence().getBlock(0) : 0u));
+            h = (h ^ x) * 0x100000001B3ull;
+        }
+        return h;
+    }
+    alga_engine *e_ = nullptr;
+    int device_ = -1;
+    bool resident_ = false;
+    const void *reads_id_ = nullptr;
+    size_t n_ = 0;
+    uint64_t fp_ = 0;
+    alga_nodes dev_{};
+    void *buf_[3] = {nullptr, nullptr, nullptr};
+    size_t cap_[3] = {0, 0, 0};
+};
+
 // The simplifier's first step on the GPU: replaces `G->sortEdgesByIncreasingOffset(); cutNonAndWeaklyMetricTriangles();` of
 // GraphSimplifier::simplifyGraphOld (src/GraphSimplifiers/GraphSimplifier.cpp:113-117) -- G comes back with every list in the
 // order those two calls leave it in.
@@ -86,16 +168,13 @@ inline void first_simplifier_step(Graph *G, int hip_device = 0) {
         std::sort(row.begin(), row.end());                                  // (neighbour, offset): the order the engine's lists have
         for (const PII &x : row) in.push_back(alga_edge{a, x.first, x.second});
     }
-    alga_engine *e = nullptr;
-    int rc = alga_engine_create(hip_device, &e);
-    if (rc != ALGA_OK) die(nullptr, "no usable HIP device", rc);
+    alga_engine *e = Session::get(hip_device).engine();
     alga_edge *out = nullptr;
     uint64_t m = 0;
-    rc = alga_cut_triangles_host(e, n, in.data(), (uint64_t) in.size(), Params::MAX_OFFSET_PARALLEL_PATHS, &out, &m);
+    int rc = alga_cut_triangles_host(e, n, in.data(), (uint64_t) in.size(), Params::MAX_OFFSET_PARALLEL_PATHS, &out, &m);
     if (rc != ALGA_OK) die(e, "triangle cut", rc);
     fill_graph(G, out, m);
     alga_free_edges(e, out);
-    alga_engine_destroy(e);
 }
 
 // The contig-trimming block on the GPU: replaces src/main.cpp:636-697 (contigs + reverse complements through one more
@@ -103,12 +182,11 @@ inline void first_simplifier_step(Graph *G, int hip_device = 0) {
 inline std::vector<int> contig_trim_left(std::vector<Read *> &contigs, int threshold = 25, int hip_device = 0) {
     NodeArrays nodes(contigs);
     std::vector<int32_t> trim(contigs.size(), 0);
-    alga_engine *e = nullptr;
-    int rc = alga_engine_create(hip_device, &e);
-    if (rc != ALGA_OK) die(nullptr, "no usable HIP device", rc);
-    rc = alga_contig_trim_host(e, nodes.words.data(), nodes.stride, nodes.len.data(), (int32_t) contigs.size(), threshold, trim.data());
+    Session &ses = Session::get(hip_device);
+    alga_engine *e = ses.engine();
+    ses.forget();                                          // the contigs take the engine's upload buffers: the reads are no longer resident
+    int rc = alga_contig_trim_host(e, nodes.words.data(), nodes.stride, nodes.len.data(), (int32_t) contigs.size(), threshold, trim.data());
     if (rc != ALGA_OK) die(e, "contig trimming", rc);
-    alga_engine_destroy(e);
     return std::vector<int>(trim.begin(), trim.end());
 }
 
@@ -125,25 +203,30 @@ public:
 
     void startAlignmentGraphCreation() override {
         const int n = G->size();
-        alga_adapter::NodeArrays nodes(*reads);
+        alga_adapter::Session &ses = alga_adapter::Session::get(device);
+        alga_engine *e = ses.engine();
+        alga_nodes nd = ses.nodes_of(*reads);                                   // uploaded once per process, shared with the later stages
         std::vector<uint8_t> from((size_t) n), to((size_t) n);
-        for (int i = 0; i < n; i++) { from[(size_t) i] = alignFrom[i]; to[(size_t) i] = alignTo[i]; }
-        alga_engine *e = nullptr;
-        int rc = alga_engine_create(device, &e);
-        if (rc != ALGA_OK) alga_adapter::die(nullptr, "no usable HIP device", rc);
+        bool masked = false;
+        for (int i = 0; i < n; i++) { from[(size_t) i] = alignFrom[i]; to[(size_t) i] = alignTo[i]; masked = masked || !alignFrom[i] || !alignTo[i]; }
+        if (masked) {                                                           // (all-true masks need not travel: NULL means all 1)
+            nd.align_from = (const uint8_t *) ses.to_device(0, from.data(), from.size());
+            nd.align_to = (const uint8_t *) ses.to_device(1, to.data(), to.size());
+        }
         alga_prefsuf_params p;
         alga_prefsuf_default_params(&p);
         p.min_overlap = Params::MIN_OVERLAP_PREF_SUF;                           // read at GraphCreatorPrefSuf.cpp:76,167
         p.rsoe_min_overlap = Params::REMOVE_SMALL_OVERLAP_EDGES_MIN_OVERLAP;    // :288,397
         // p.reduction stays ALGA_REDUCTION_AUTO: same graph either way, the engine picks the faster exact form
-        alga_nodes nd = {nodes.words.data(), nodes.stride, nodes.len.data(), n, from.data(), to.data()};
+        const alga_edge *d_edges = nullptr;
         alga_edge *edges = nullptr;
         uint64_t m = 0;
-        rc = alga_prefsuf_build_host(e, &nd, &p, &edges, &m);
+        int rc = alga_prefsuf_build_device(e, &nd, &p, nullptr, &d_edges, &m);
         if (rc != ALGA_OK) alga_adapter::die(e, "overlap graph", rc);
+        rc = alga_download_edges(e, d_edges, m, &edges);
+        if (rc != ALGA_OK) alga_adapter::die(e, "overlap graph (edges to the host)", rc);
         alga_adapter::fill_graph(G, edges, m);
         alga_free_edges(e, edges);
-        alga_engine_destroy(e);
     }
 
 private:
