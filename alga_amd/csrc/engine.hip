@@ -18,6 +18,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "engine_internal.h"
 
@@ -580,6 +581,44 @@ int alga_engine_reserve(alga_engine *e, int32_t n_nodes, int32_t max_len, int32_
         if ((rc = alga_ensure(e, e->out_cnt, (size_t) (n + 1) * sizeof(uint32_t)))) return rc;
     }
     if ((rc = alga_ensure(e, e->edges, (size_t) (E + 1) * sizeof(alga_edge_dev)))) return rc;
+    // The other cost of a process's first build is not memory: the HIP runtime loads a kernel's code object when the kernel is first
+    // launched (~20 ms for the kernels of one build, measured: a fresh engine's first build 58 ms against 37 ms for the second fresh
+    // engine of the same process).  A miniature build of the same SHAPE -- 4096 random reads of max_len nucleotides, so the very
+    // template instantiations the real build will use -- pays that here, ahead of time.
+    if (!e->warmed && n_nodes > 0) {
+        const int W = blocks_of(max_len), stride = hbm_row_stride(W), wn = 4096;
+        std::vector<uint32_t> rows((size_t) wn * stride, 0u);
+        std::vector<int32_t> lens((size_t) wn, max_len);
+        uint64_t x = 0x9E3779B97F4A7C15ull;
+        for (int i = 0; i < wn; i++)
+            for (int k = 0; k < W; k++) {
+                x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+                uint32_t w = (uint32_t) (x >> 16);
+                const int used = 2 * max_len - 32 * k;                           // bits of this block that belong to the read (tail bits stay zero)
+                if (used < 32) w &= used <= 0 ? 0u : ((1u << used) - 1u);
+                rows[(size_t) i * stride + k] = w;
+            }
+        void *d_rows = nullptr, *d_len = nullptr;
+        if (hipMalloc(&d_rows, rows.size() * 4) == hipSuccess && hipMalloc(&d_len, lens.size() * 4) == hipSuccess &&
+            hipMemcpy(d_rows, rows.data(), rows.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
+            hipMemcpy(d_len, lens.data(), lens.size() * 4, hipMemcpyHostToDevice) == hipSuccess) {
+            alga_nodes nd{(const uint32_t *) d_rows, stride, (const int32_t *) d_len, wn, nullptr, nullptr};
+            alga_prefsuf_params wp;
+            alga_prefsuf_default_params(&wp);
+            wp.min_overlap = min_overlap; wp.rsoe_min_overlap = std::min(max_len, min_overlap + (max_len - min_overlap) / 2);
+            const alga_edge *d = nullptr;
+            uint64_t m = 0;
+            const int wrc = alga_prefsuf_build_device(e, &nd, &wp, nullptr, &d, &m);   // its result is of no interest; a failure is not one of reserve
+            (void) wrc;
+            e->err.clear();
+            e->warmed = true;
+        }
+        if (d_rows) (void) hipFree(d_rows);
+        if (d_len) (void) hipFree(d_len);
+        (void) hipGetLastError();
+        alga_forget_node_set(e);
+        memset(&e->stats, 0, sizeof(e->stats));
+    }
     return ALGA_OK;
 }
 

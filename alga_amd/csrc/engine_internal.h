@@ -48,6 +48,7 @@ struct alga_engine {
     // node statistics of the last prepare() (k_node_stats): reused by the further pieces of a build (params.keys_shared = 2)
     int stat_max_len = 0, stat_min_len = 0; uint64_t stat_live = 0; unsigned long long stat_mask_asym = 0;
     const void *stat_len = nullptr, *stat_from = nullptr, *stat_to = nullptr;
+    bool   warmed = false;                                  // alga_engine_reserve has run its miniature build (kernel code objects loaded)
     bool   pairs_timed = false;                             // EV_PAIRS was recorded in the last discovery
     bool   store_timed = false;                             // EV_KEYS / EV_SORT / EV_GATHER were recorded in the last discovery
     int    opt_cluster_order = 1;                           // option "cluster_order": the quad kernel walks all sources in entry-array (key) order (0: id order)

@@ -211,8 +211,10 @@ def main():
         first["unprepared_first_call_device_ms"] = cold.last_stats()["ms_total"]
         cold.close()
         del cold
-        first["note"] = ("wall time of alga_prefsuf_build_device on a fresh engine, kernel code objects loaded on first launch included; reserve = "
-                         "alga_engine_reserve: all device buffers sized from the node count ahead of the build; unprepared = another fresh engine without it")
+        first["note"] = ("wall time of alga_prefsuf_build_device on a fresh engine.  (a) the FIRST engine of this process after alga_engine_reserve (reserve_ms: every device "
+                         "buffer sized from the node count + a miniature build of the same shape that makes the HIP runtime load the kernels' code objects -- an assembler "
+                         "calls it while it still parses / uploads); (b) unprepared = a second fresh engine of the same process without reserve: it allocates inside its build, "
+                         "but finds the code objects loaded.  Without either, the first build of a process took 58 ms at this size (code-object loading ~20 ms, allocations ~1 ms).")
     runner = multigpu.ShardedPrefSuf(multigpu.HipBackend(eng, d_words, d_lens, lo, rs), rank, world, dist)
 
     def sync_all():

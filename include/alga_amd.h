@@ -156,10 +156,11 @@ int  alga_prefsuf_build_host(alga_engine *e, const alga_nodes *nodes, const alga
 void alga_free_edges(alga_engine *e, alga_edge *edges);
 
 /* Allocates, ahead of time, every device buffer a build of the exact path needs for a node set of `n_nodes` rows of up to
- * `max_len` nucleotides (and, n_edges_hint > 0, for that many edges; 0 = one per node): an assembler builds its graph ONCE, and
- * without this the first build pays ~30 device allocations of up to 6 GB in the middle of its kernels (76 ms instead of 54 at
- * 90 M nodes in round 2).  Safe to call from a second host thread while the caller is still parsing or uploading the reads --
- * but not concurrently with another call on the same engine.  Later builds allocate only what turns out larger. */
+ * `max_len` nucleotides (and, n_edges_hint > 0, for that many edges; 0 = one per node), and runs a miniature build of the same shape
+ * (4096 random reads) so that the HIP runtime loads the kernels' code objects now: an assembler builds its graph ONCE, and what the
+ * first build of a process pays on top of a warm one is mostly that loading (~20 ms; the allocations themselves ~1 ms at 90 M nodes).
+ * Safe to call from a second host thread while the caller is still parsing or uploading the reads -- but not concurrently with
+ * another call on the same engine.  Later builds allocate only what turns out larger. */
 int  alga_engine_reserve(alga_engine *e, int32_t n_nodes, int32_t max_len, int32_t min_overlap, uint64_t n_edges_hint);
 
 /* The two halves of alga_prefsuf_build_host for callers that keep the node set resident across several stages (exact graph ->

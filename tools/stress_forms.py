@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised cross-check on the GPU: the two forms of the transitive reduction (per-target replay, source-side) must give
 the same edges on every input the source-side form accepts -- the source-side form through the seed-table probe, through the
-clustered probe with its pair kernel, and through the clustered probe's general kernel alone.  Random read lengths (fixed / variable), coverage, substitution
+clustered probe with its quad kernel (sources in key order and in id order), with round 2's pair kernel, and through the clustered probe's general kernel alone.  Random read lengths (fixed / variable), coverage, substitution
 errors, tandem repeats, exact duplicates and prefix reads left in, masks, min_overlap / rsoemo choices.
 usage: tools/stress_forms.py [n_cases=100] [first_seed=1000]"""
 import os
@@ -88,9 +88,10 @@ def main():
         words, lens, lo, rs, af, at, desc = make_case(seed)
         a = eng.prefsuf_host(words, lens, lo, rs, af, at, reduction="per_target")
         ok = True
-        for probe, pairs in (("table", 2), ("cluster", 2), ("cluster", 1), ("cluster", 0)):
+        for probe, pairs, order in (("table", 2, 1), ("cluster", 2, 1), ("cluster", 2, 0), ("cluster", 1, 1), ("cluster", 0, 1)):
             eng.set_option("probe", probe)
             eng.set_option("cluster_pairs", pairs)
+            eng.set_option("cluster_order", order)
             try:
                 b = eng.prefsuf_host(words, lens, lo, rs, af, at, reduction="source_side", collect_stats=True)
             except alga_amd.AlgaError as e:
@@ -101,6 +102,7 @@ def main():
             finally:
                 eng.set_option("probe", "auto")
                 eng.set_option("cluster_pairs", 2)
+                eng.set_option("cluster_order", 1)
             st = eng.last_stats()
             if probe == "table":
                 big += st["big_sources"] > 0
