@@ -301,6 +301,7 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
             e->stats.raw_overlaps = e->h_counters[CNT_RAW];
             e->stats.windows_probed = e->h_counters[CNT_WINDOWS];
             e->stats.slots_scanned = e->h_counters[CNT_SLOTS];
+            e->stats.probe_rounds = e->h_counters[CNT_ROUNDS];
             e->stats.probe_used = clustered ? ALGA_PROBE_CLUSTER : ALGA_PROBE_TABLE;
             if (clustered) e->stats.deferred_sources = e->opt_cluster_pairs ? e->h_counters[CNT_DEFERRED] : n_src;
             return ALGA_OK;

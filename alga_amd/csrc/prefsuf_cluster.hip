@@ -1067,7 +1067,7 @@ k_probe_quads(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__restric
         __syncthreads();
     }
     wave_lds_fence();
-    uint64_t st_raw = 0, st_slots = 0, st_win = 0, st_rec = 0, st_cmp = 0;
+    uint64_t st_raw = 0, st_slots = 0, st_win = 0, st_rec = 0, st_cmp = 0, st_rounds = 0;
     int n_defer = 0;                                       // uniform: sources waiting in sDefer
     int n_seen = 0, n_deferred = 0;                        // uniform: sources of this wave that took part / that it deferred
     const int step = (int) gridDim.x * PROBE_WAVES * 4;
@@ -1363,6 +1363,7 @@ k_probe_quads(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__restric
             }
         }
         if (STATS) {
+            st_rounds++;
             const bool fin = ev && (stv & 255u) == 0u && (stv >> 8) <= 2u;      // this lane's source finishes here
             st_slots += fin; st_raw += fin && pass; st_cmp += fin && has_pred;
         }
@@ -1417,6 +1418,7 @@ k_probe_quads(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__restric
             atomicAdd(&o.counters[CNT_SLOTS], (unsigned long long) st_slots);
             atomicAdd(&o.counters[CNT_WINDOWS], (unsigned long long) st_win);
             atomicAdd(&o.counters[CNT_TR_COMPARES], (unsigned long long) st_cmp);
+            atomicAdd(&o.counters[CNT_ROUNDS], (unsigned long long) st_rounds);
         }
     }
 }

@@ -82,6 +82,7 @@ enum Counter {
     CNT_LOCAL_GENERIC,     // sources that took the all-pairs path of the source-side reduction
     CNT_LOCAL_MAXITEMS,    // largest number of raw overlaps of one source seen by the source-side reduction
     CNT_DEFERRED,          // clustered probe, pair kernel: sources handed to the general kernel
+    CNT_ROUNDS,            // clustered probe, quad kernel: rounds (wave iterations), statistics builds only
     CNT_TOTAL = 24
 };
 

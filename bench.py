@@ -311,7 +311,7 @@ def main():
             "phases_ms": {k: ms[k] for k in ("seed", "probe", "group", "reduce", "emit", "exchange")},
             "counters": {k: int(stats[k]) for k in ("nodes_live", "windows_probed", "slots_scanned", "raw_overlaps", "records",
                                                     "transitive_listed", "transitive_compares", "transitive_removed", "edges",
-                                                    "max_in_records", "table_slots", "probe_used", "reduction_used", "big_sources", "deferred_sources")},
+                                                    "max_in_records", "table_slots", "probe_used", "reduction_used", "big_sources", "deferred_sources", "probe_rounds")},
             "algorithmic_bytes_total": alg["total"],
             "device": eng.device_name(),
         }
@@ -329,13 +329,17 @@ def main():
                   (probe_kernel if first_dominates else "k_probe_quads", ms["probe_pairs"], alg_probe_launch * (1.0 - deferred / n_src), None),
                   ("k_probe_clustered", ms["probe"] - ms["probe_pairs"], alg_probe_launch * (deferred / n_src), None),
                   ("scan + k_local_emit_* + k_sort_rows", ms["emit"], n * 16 + E * 12 * 2, None)]
-            prefix = {"rocprim": "void rocprim", "scan": "k_scan"}
             out["roofline_kernels"] = []
             for name, kms, ab, note in rk:
                 if kms < 0.02 * ms_step:
                     continue
-                tr = traffic_of(traffic, prefix.get(name.split()[0], name.split()[0])) if name.split()[0] not in ("scan",) else (
-                    sum(filter(None, (traffic_of(traffic, q) for q in ("k_scan", "k_local_emit", "k_sort_rows")))) or None)
+                head = name.split()[0]
+                if head == "rocprim":
+                    tr = None                              # several dispatches of different kernels per sort: the per-dispatch means of profiles/hbm_traffic.json do not add up to one sort
+                elif head == "scan":
+                    tr = sum(filter(None, (traffic_of(traffic, q) for q in ("k_scan", "k_local_emit", "k_sort_rows")))) or None
+                else:
+                    tr = traffic_of(traffic, head)
                 ent = {"kernel": name, "ms": kms, "share_of_step": kms / ms_step, "algorithmic_bytes": int(ab), "achieved": ab / (kms * 1e-3) / 1e9,
                        "frac": ab / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": tr, "achieved_hbm": (tr / (kms * 1e-3) / 1e9) if tr else None}
                 if note:

@@ -118,6 +118,7 @@ typedef struct {
     double   ms_probe_pairs;      /* CLUSTER probe: the first kernel's (quad / pair kernel) part of ms_probe (0: not run) */
     double   ms_keys, ms_sort, ms_gather, ms_dir; /* CLUSTER probe: the parts of ms_seed -- k_node_runs, radix sort of (key, id),
                                      k_tgt_gather, k_tgt_dir (0 for a build that reused them: keys_shared)         */
+    uint64_t probe_rounds;        /* CLUSTER probe, quad kernel: wave iterations (collect_stats); 4 * rounds / sources = lanes' worth of sources per round */
 } alga_prefsuf_stats;
 
 /* ---- lifetime --------------------------------------------------------------------------- */
