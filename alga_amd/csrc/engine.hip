@@ -245,7 +245,7 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
                     // ids (a rank's share, a piece): in id order
                     const bool by_key = e->opt_cluster_order != 0 && src_begin == 0 && src_end == nd.n;
                     launch_probe_quads(nd, cfg, cc, pp.cluster_eq, e->cl_store.p, e->cl_dir.p, e->cl_runs.p, (const uint8_t *) e->cl_nruns.p,
-                                       src_begin, src_end, by_key, cnt, e->n_cu, (uint32_t *) e->outdeg.p, (unsigned long long *) e->loc_first.p,
+                                       src_begin, src_end, by_key, e->opt_cluster_pairs >= 3, cnt, e->n_cu, (uint32_t *) e->outdeg.p, (unsigned long long *) e->loc_first.p,
                                        (unsigned long long *) e->loc_second.p, (int32_t *) e->cl_defer.p, (uint32_t) n_src, s);
                 }
                 if ((rc = alga_check_launch(e, "k_probe_quads / k_probe_pairs"))) return rc;
@@ -528,7 +528,7 @@ int alga_engine_set_option(alga_engine *e, const char *name, int64_t value) {
         if (value < -8 || value > 8) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "option cluster_bucket_bias: -8 .. 8");
         e->opt_cluster_bucket_bias = (int) value;
     } else if (!strcmp(name, "cluster_pairs")) {
-        if (value < 0 || value > 2) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "option cluster_pairs: 0 general kernel only, 1 pair kernel first, 2 quad kernel first");
+        if (value < 0 || value > 3) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "option cluster_pairs: 0 general kernel only, 1 pair kernel first, 2 quad kernel first, 3 quad kernel with a sliding window first");
         e->opt_cluster_pairs = (int) value;
     } else if (!strcmp(name, "cluster_order")) {
         e->opt_cluster_order = value != 0;

@@ -1424,6 +1424,432 @@ k_probe_quads(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__restric
 }
 
 // ------------------------------------------------------------------------------------------
+// k_probe_stream : the quad kernel with a SLIDING WINDOW over the source stream
+// ------------------------------------------------------------------------------------------
+// k_probe_quads packs the four sources of ONE quad onto the 64 lanes: at 30x their entries add up to 63 on average, so four in ten
+// quads need a second round and an average round holds 2.8 sources on 45 lanes.  Here the window is TWO quads (eight consecutive
+// sources, both staged, their run lists resolved) and a round takes sources from the cursor on for as long as they fit the 64
+// lanes -- across the quad boundary -- so the lanes fill up whatever the quad's sum is.  When the cursor has passed the older
+// quad it retires (its unfinished sources go on the defer list), the younger one takes its place and the quad staged during
+// this round becomes the younger one: three LDS buffers in rotation, at most one rotation per round (a round never takes the
+// last source of the younger quad, so the quad that follows is always ready when it is needed).
+// Everything per lane -- entry slot, verify, fused reduction through the per-source LDS words -- is k_probe_quads'.
+template <bool STATS, int EQ, int KF, bool BYKEY>
+__global__ void __launch_bounds__(PROBE_WAVES * 64, CLQ_OCC)
+k_probe_stream(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__restrict__ store, const uint4 *__restrict__ dir,
+               const uint2 *__restrict__ runs, const uint8_t *__restrict__ nruns, int32_t src_begin, int32_t src_end, ProbeOut o,
+               int32_t *__restrict__ defer_list, uint32_t defer_cap) {
+    constexpr int WC = 4 * EQ - 3;                         // row words of an entry
+    constexpr int QW = 24;                                 // staged words per source: the row (<= 13) + the compare's slack, words 16.. stay zero
+    constexpr int NS = 12;                                 // source slots: three quads
+    __shared__ uint32_t sB[PROBE_WAVES][NS][QW];
+    __shared__ uint4 sRun[PROBE_WAVES][NS][CL_RMAX];       // per run: q | p0 << 8 | p1 << 16, cluster key, first entry - slots before the run, entries
+    __shared__ unsigned long long sIncl[PROBE_WAVES][NS];  // per source: inclusive prefix of the runs' entry counts, 8 x u8 (saturating)
+    __shared__ uint2 sSrc[PROBE_WAVES][NS];                // per source: id, length
+    __shared__ unsigned long long sOcc[PROBE_WAVES][NS];   // per source: offsets that hold an item
+    __shared__ uint32_t sStat[PROBE_WAVES][NS];            // per source: bit 0 = irregular, bits 8.. = items that stand
+    __shared__ uint8_t sT[PROBE_WAVES][8][64];             // per source of the window: lane of the item at offset d
+    __shared__ int32_t sDefer[PROBE_WAVES][72];
+    __shared__ uint4 sMask[KF > 0 ? 129 : 1];
+    const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+    const int lane = lane_id();
+    const int g = lane >> 4, gl = lane & 15;
+    for (int k = lane; k < NS * 8; k += 64) sB[wave][k >> 3][16 + (k & 7)] = 0u;       // the slack words, once
+    if constexpr (KF > 0) {
+        for (int t = (int) threadIdx.x; t <= 128; t += PROBE_WAVES * 64)
+            sMask[t] = make_uint4(low_bits32(t), low_bits32(t - 32), low_bits32(t - 64), low_bits32(t - 96));
+        __syncthreads();
+    }
+    wave_lds_fence();
+    uint64_t st_raw = 0, st_slots = 0, st_win = 0, st_rec = 0, st_cmp = 0, st_rounds = 0;
+    int n_defer = 0;                                       // uniform: sources waiting in sDefer
+    int n_seen = 0, n_deferred = 0;                        // uniform: sources of this wave that took part / that it deferred
+    const int step = (int) gridDim.x * PROBE_WAVES * 4;
+    const int kfull = KF ? KF : (2 * cfg.Lmin) >> 5;
+    const int Lbig = cfg.rsoemo > cfg.Lmin ? cfg.rsoemo : cfg.Lmin;
+    auto flush_defer = [&]() {                             // convergent
+        if (n_defer == 0) return;
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(&o.counters[CNT_DEFERRED], (unsigned long long) n_defer);
+        base = ((unsigned long long) (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) (base >> 32)) << 32) | (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) base);
+        for (int k = lane; k < n_defer; k += 64)
+            if (base + (unsigned long long) k < (unsigned long long) defer_cap) defer_list[base + (unsigned long long) k] = sDefer[wave][k];
+        wave_lds_fence();
+        n_defer = 0;
+    };
+    auto defer_rows = [&](bool dfr, int id) {              // convergent: the leaders with `dfr` put their source on the list
+        const uint64_t dm = __ballot(dfr);
+        if (dm != 0ull) {                                  // uniform
+            if (dfr) sDefer[wave][n_defer + (int) __builtin_amdgcn_mbcnt_hi((uint32_t) (dm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) dm, 0u))] = id;
+            n_defer += __popcll(dm);
+            n_deferred += __popcll(dm);
+            wave_lds_fence();
+            if (n_defer >= 60) flush_defer();
+        }
+    };
+
+    // ---- source stream (k_probe_quads): quads of consecutive sources, one per 16-lane row; stage A = identity, length and row word of
+    //      the quad after the one stage B holds; stage B = the quad that is staged next, with its run list ----
+    const int pre_words = BYKEY ? (4 * EQ - 3) : (nd.stride < 16 ? nd.stride : 16);
+    const int last_src = src_end - 1, col = gl < pre_words ? gl : pre_words - 1;
+    const uint32_t *run_w = reinterpret_cast<const uint32_t *>(runs);
+    int posA = src_begin + 4 * ((int) blockIdx.x * PROBE_WAVES + wave), posB = posA;
+    bool a_valid = false, b_valid = false;
+    int a_id = 0, a_len = 0, b_id = 0, b_len = 0;
+    uint32_t a_word = 0, b_word = 0, b_nrw = 0;
+    uint2 b_run = make_uint2(0u, 0u);
+    auto fetchA = [&]() {
+        const int j = posA + g;
+        a_valid = j < src_end;
+        const int js = j < last_src ? j : last_src;
+        if constexpr (BYKEY) {
+            const uint32_t *ent = reinterpret_cast<const uint32_t *>(store) + (size_t) js * (4 * EQ);
+            a_word = ent[col];
+            a_id = (int) ent[4 * EQ - 3];
+            a_len = (int) ((ent[4 * EQ - 1] >> 8) & 0xFFFu);
+        } else {
+            a_id = js;
+            a_len = nd.len[js];
+            a_word = nd.words[(size_t) js * nd.stride + col];
+        }
+    };
+    auto fetchB = [&]() {                                  // (b_id is a valid node id even where b_valid is false: clamped positions)
+        b_run = runs[(size_t) b_id * CL_RMAX + (gl & (CL_RMAX - 1))];
+        b_nrw = run_w[(size_t) b_id * (2 * CL_RMAX) + 1];  // run 0, second word: nruns in its top byte
+    };
+    auto take = [&](int &id, int &len, int &nrn, uint32_t &word, uint2 &run) {   // the quad of stage B, masked
+        id = b_id;
+        len = b_valid ? b_len : 0; nrn = b_valid ? (int) (b_nrw >> 24) : 0;
+        word = (b_valid && gl < pre_words) ? b_word : 0u;
+        run = (b_valid && gl < CL_RMAX) ? b_run : make_uint2(0u, 0u);
+    };
+    auto advance = [&](bool adv) {                         // adv (uniform): stage B takes the quad of stage A, stage A moves on
+        b_valid = adv ? a_valid : b_valid; b_id = adv ? a_id : b_id; b_len = adv ? a_len : b_len; b_word = adv ? a_word : b_word;
+        posB = adv ? posA : posB;
+        posA = adv ? (step <= src_end - posA ? posA + step : src_end) : posA;
+        fetchB();
+        fetchA();
+    };
+    fetchA();
+    // stage 1 of a quad into the buffer `qb` (slots 4 qb .. 4 qb + 3): rows -> LDS; bucket of each run
+    auto stage = [&](int qb, int id, int lenB, int nr_eff, uint32_t word0, const uint2 &run) -> uint32_t {
+        wave_lds_fence();
+        sB[wave][4 * qb + g][gl] = gl < blocks_of(lenB) ? word0 : 0u;
+        if (gl == 0) sSrc[wave][4 * qb + g] = make_uint2((uint32_t) id, (uint32_t) lenB);
+        return gl < nr_eff ? run.x >> cc.idx_shift : 0u;
+    };
+    auto index_loads = [&](uint32_t bucket, uint4 &rec) { rec = dir[bucket]; };   // every lane, no branch
+    auto finish_runs = [&](int qb, int nr_eff, const uint2 &run, const uint4 &rec) -> uint32_t {
+        uint32_t e0, cnt;
+        run_slice(rec, run.y, e0, cnt);
+        cnt = gl < nr_eff ? cnt : 0u;                      // lanes gl >= 8 hold no run
+        uint32_t inc = cnt, t;                             // inclusive scan over the runs (lanes 0..7 of the row)
+        t = (uint32_t) __builtin_amdgcn_update_dpp(0, (int) inc, 0x111, 0xF, 0xF, true); inc += t;
+        t = (uint32_t) __builtin_amdgcn_update_dpp(0, (int) inc, 0x112, 0xF, 0xF, true); inc += t;
+        t = (uint32_t) __builtin_amdgcn_update_dpp(0, (int) inc, 0x114, 0xF, 0xF, true); inc += t;
+        if (gl < CL_RMAX) {
+            sRun[wave][4 * qb + g][gl] = make_uint4(run.y, run.x, e0 - (inc - cnt), cnt);
+            reinterpret_cast<uint8_t *>(&sIncl[wave][4 * qb + g])[gl] = (uint8_t) (inc > 255u ? 255u : inc);
+        }
+        if (gl == 0) { sOcc[wave][4 * qb + g] = 0ull; sStat[wave][4 * qb + g] = 0u; }
+        wave_lds_fence();
+        return inc;
+    };
+    // entries (one byte each, <= 64) / packed / takes-part of the four sources of a quad: wave-uniform, kept in few scalar registers
+    // (the window's bookkeeping must not spill: every scalar beyond ~100 costs a v_readlane per use inside the loop)
+    auto quad_plan = [&](uint32_t inc, int nrv, uint32_t &t4w, uint32_t &fl /* pk | tp << 4 */) {
+        t4w = 0u; fl = 0u;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int T = __builtin_amdgcn_readlane((int) inc, q * 16 + CL_RMAX - 1), nrq = __builtin_amdgcn_readlane(nrv, q * 16);
+            const bool p = nrq != 0 && nrq != CL_RUNS_FLAGGED && T <= 64;
+            t4w |= (p ? (uint32_t) T : 0u) << (8 * q);
+            fl |= (p ? 1u << q : 0u) | (nrq != 0 ? 16u << q : 0u);
+        }
+    };
+
+    // ---- the window: quad 0 (buffer b0, the older one, consumed from `cur` on), quad 1 (buffer b1), quad 2 being staged into b2 ----
+    uint64_t tw = 0ull;                                    // entries of the window's eight sources, one byte each
+    uint32_t fl0 = 0u, fl1 = 0u;                           // quad 0 / quad 1: bit g = source g is packed, bit 4 + g = it takes part
+    int b0 = 0, b1 = 1, b2 = 2, cur = 0;
+    uint32_t red = 0u;                                     // leader lanes: bit 0 / 1 = the row's source of quad 0 / quad 1 is finished
+    int pos0 = posA;                                       // stream position of quad 0
+    bool have0 = posA < src_end;
+    if (have0) {
+        int id, len, nrv; uint32_t word0; uint2 run; uint4 rec;
+        advance(true);                                     // stage B = the first quad
+        take(id, len, nrv, word0, run);
+        pos0 = posB;
+        advance(true);
+        {
+            const int ne = nrv == CL_RUNS_FLAGGED ? 0 : nrv;
+            const uint32_t bk = stage(0, id, len, ne, word0, run);
+            index_loads(bk, rec);
+            const uint32_t inc = finish_runs(0, ne, run, rec);
+            uint32_t t4w;
+            quad_plan(inc, nrv, t4w, fl0);
+            tw = (uint64_t) t4w;
+        }
+        const bool have1 = posB < src_end;                 // the second quad (possibly past the end: then it is empty)
+        take(id, len, nrv, word0, run);
+        advance(have1);
+        {
+            const int ne = nrv == CL_RUNS_FLAGGED ? 0 : nrv;
+            const uint32_t bk = stage(1, id, len, ne, word0, run);
+            index_loads(bk, rec);
+            const uint32_t inc = finish_runs(1, ne, run, rec);
+            uint32_t t4w;
+            quad_plan(inc, nrv, t4w, fl1);
+            tw |= (uint64_t) t4w << 32;
+        }
+    }
+    bool bail = false;
+    while (have0 && !bail) {                               // uniform; one ROUND per iteration
+        // ---- (0) what this round takes: up to five sources of the window from `cur` on, for as long as they fit the 64 lanes; never
+        //      the window's last source (the quad after quad 1 is only ready at the end of this round).  Scalar packing and the
+        //      lanes' look-up of their source in one pass. ----
+        const uint64_t tsh = tw >> (8 * cur);
+        int fill_r = 0, cntg = 0, a = 0, taken = 0;
+        {
+            bool open = true;
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                const int tk = (int) ((tsh >> (8 * k)) & 255ull);
+                const bool in = open && fill_r + tk <= 64 && (k < 4 || cur < 3);
+                open = in;
+                const int lo = in ? fill_r : 64;           // first lane of the source in this round
+                const bool c = lane >= lo;
+                cntg += c ? 1 : 0;
+                a = c ? lo : a;
+                fill_r += in ? tk : 0;
+                taken += in ? 1 : 0;
+            }
+        }
+        const int e = cur + taken;
+        const bool rot = e >= 4;                           // quad 0 retires at the end of this round
+        // ---- (1) the quad that is staged next comes off the stream before any entry load is issued ----
+        const bool have2 = posB < src_end;
+        int nB, nlenB, nnr; uint32_t nword0; uint2 nrun;
+        take(nB, nlenB, nnr, nword0, nrun);
+        advance(rot && have2);                                         // past the end: clamped reads of the last source, never used
+        const int nnr_eff = nnr == CL_RUNS_FLAGGED ? 0 : nnr;
+        // ---- (2) lanes -> sources of this round, entries: loads issued ----
+        const bool ev = lane < fill_r;
+        const int s8 = ev ? cur + cntg - 1 : cur;          // window source of this lane (0 .. 6)
+        const int slot = 4 * (s8 < 4 ? b0 : b1) + (s8 & 3);
+        const int hl = ev ? lane - a : 0;                  // slot of this lane in its source
+        const uint2 srec = sSrc[wave][slot];
+        const int Bs = (int) srec.x, lenBs = (int) srec.y;
+        const uint32_t *sb = sB[wave][slot];
+        uint4 rp = make_uint4(0u, 0u, 0u, 0u);
+        {
+            // run of slot hl: the number of runs whose inclusive prefix is <= hl (binary search over 8 packed bytes)
+            const unsigned long long inc8 = sIncl[wave][slot];
+            const uint32_t lo = (uint32_t) inc8, hi = (uint32_t) (inc8 >> 32);
+            int ri = (int) ((lo >> 24) & 255u) <= hl ? 4 : 0;
+            { const uint32_t wv = ri ? hi : lo; ri += (int) ((wv >> 8) & 255u) <= hl ? 2 : 0; }
+            { const uint32_t wv = ri >= 4 ? hi : lo; ri += (int) ((wv >> (8 * (ri & 3))) & 255u) <= hl ? 1 : 0; }
+            if (ev) rp = sRun[wave][slot][ri & (CL_RMAX - 1)];
+        }
+        const size_t ei = ev ? (size_t) (rp.z + (uint32_t) hl) : (size_t) 0;
+        uint32_t ew[4 * EQ];
+#pragma unroll
+        for (int c = 0; c < EQ; c++) { const uint4 v = store[ei * EQ + c]; ew[4 * c] = v.x; ew[4 * c + 1] = v.y; ew[4 * c + 2] = v.z; ew[4 * c + 3] = v.w; }
+        // ---- (3) the quad after quad 1: rows staged into the free buffer, index loads issued behind the entry loads ----
+        uint32_t nbk = 0;
+        uint4 nrec;
+        if (have2) nbk = stage(b2, nB, nlenB, nnr_eff, nword0, nrun);
+        index_loads(nbk, nrec);
+        // ---- (4) verify: one entry per lane ----
+        const uint32_t id = ew[4 * EQ - 3], eh = ew[4 * EQ - 2], meta = ew[4 * EQ - 1];
+        const int lenC = (int) ((meta >> 8) & 0xFFFu);
+        int p = (int) (rp.x & 255u) - (int) (meta & 255u);
+        // (bitwise &: one straight line of compares instead of a chain of exec-mask branches)
+        const bool ok = ev & same_cluster(eh, rp.y, cc.idx_shift - CL_MBITS) & (p >= (int) ((rp.x >> 8) & 255u)) & (p < (int) ((rp.x >> 16) & 255u)) & ((int) id != Bs) &
+                        (lenC >= lenBs - p);
+        p = ok ? p : 0;
+        const int L = lenBs - p, nb = 2 * L;
+        bool pass;
+        {
+            const int qw = (2 * p) >> 5, sh = (2 * p) & 31;
+            uint32_t y[WC + 1];
+#pragma unroll
+            for (int k = 0; k <= WC; k++) y[k] = sb[qw + k];
+            uint32_t diff = 0;
+            uint32_t mk[4] = {0u, 0u, 0u, 0u};
+            if constexpr (KF > 0) { const uint4 m4 = sMask[min(max(nb - 32 * KF, 0), 128)]; mk[0] = m4.x; mk[1] = m4.y; mk[2] = m4.z; mk[3] = m4.w; }
+#pragma unroll
+            for (int k = 0; k < WC; k++) {
+                const uint32_t x = funnel(y[k], y[k + 1], sh) ^ ew[k];
+                if (k < kfull) diff |= x;
+                else if (KF > 0 && k < KF + 4) diff |= x & mk[(k - KF) & 3];
+                else diff |= x & low_bits32(nb - 32 * k);
+            }
+            pass = ok && diff == 0;
+        }
+        const uint64_t pm = __ballot(pass);
+        const int d = p;
+        const uint32_t v_m = (uint32_t) p | ((uint32_t) lenC << 9) | ((meta & CL_META_FROM) ? ITEM_FROM : 0u);
+        uint32_t stv = 0u;                                 // status word of this lane's source after the reduction
+        bool has_pred = false;
+        if (pm != 0ull) {                                  // uniform
+            uint4 v_o = make_uint4(0u, 0u, 0u, 0u);
+            if (pass) {                                    // overhang: C's row from bit 2L on (see k_probe_clustered)
+                const int ws = nb >> 5, r2 = nb & 31;
+                uint32_t x[5];
+                if constexpr (KF > 0 && WC - KF <= 6) {
+                    const int t = ws - KF;
+#pragma unroll
+                    for (int k = 0; k < 5; k++) {
+                        uint32_t v = 0u;
+#pragma unroll
+                        for (int u = 0; u <= WC - KF; u++) { const int wi = KF + k + u; if (wi < 4 * EQ) v = t == u ? ew[wi] : v; }
+                        x[k] = v;
+                    }
+                } else {
+                    const uint32_t *er = reinterpret_cast<const uint32_t *>(store + ei * EQ);
+#pragma unroll
+                    for (int k = 0; k < 5; k++) x[k] = er[ws + k];
+                }
+                v_o = make_uint4(funnel(x[0], x[1], r2), funnel(x[1], x[2], r2), funnel(x[2], x[3], r2), funnel(x[3], x[4], r2));
+            }
+            // ---- fused single-survivor reduction, every source of the round at once ----
+            unsigned long long *occp = &sOcc[wave][slot];
+            uint32_t *stp = &sStat[wave][slot];
+            uint8_t *Tb = sT[wave][s8];
+            if (pass) { atomicOr(occp, 1ull << d); Tb[d] = (uint8_t) lane; }
+            wave_lds_fence();
+            const uint64_t occ = *occp;                    // (plain LDS reads: a volatile access becomes a flat load and drains vmcnt)
+            const bool clash = pass && Tb[d] != (uint8_t) lane;        // another item of this source sits at the same offset
+            const uint64_t below = pass ? (occ & ((1ull << d) - 1ull)) : 0ull;
+            has_pred = below != 0ull;
+            const int j = has_pred ? (int) Tb[63 - __clzll((long long) below)] : lane;
+            const uint32_t Cj = bperm(id, j), mj = bperm(v_m, j);
+            Ovh<1> oj, oi;
+            oj.w[0] = bperm(v_o.x, j); oj.w[1] = bperm(v_o.y, j); oj.w[2] = bperm(v_o.z, j); oj.w[3] = bperm(v_o.w, j);
+            oi.w[0] = v_o.x; oi.w[1] = v_o.y; oi.w[2] = v_o.z; oi.w[3] = v_o.w;
+            const int rho = lenC - (lenBs - d);
+            bool removed;
+            if constexpr (KF > 0) {
+                // via_ok<1> (prefsuf_device.h) with the four word masks of the overhang compare from the table in LDS
+                const int dj = (int) (mj & 511u), lenj = (int) ((mj >> 9) & 511u);
+                const int rho_j = lenj - (lenBs - dj), Lv = lenj - (d - dj);
+                const bool vok = ((mj & ITEM_FROM) != 0u) & (Cj != id) & (dj < d) & (Lv >= Lbig) & (rho_j <= rho) & ((rho_j > 0) | ((int) Cj > Bs));
+                const uint4 m4 = sMask[min(max(2 * rho_j, 0), 128)];
+                const uint32_t df = ((oi.w[0] ^ oj.w[0]) & m4.x) | ((oi.w[1] ^ oj.w[1]) & m4.y) | ((oi.w[2] ^ oj.w[2]) & m4.z) | ((oi.w[3] ^ oj.w[3]) & m4.w);
+                removed = has_pred & vok & (df == 0u);
+            } else removed = has_pred && via_ok<1>(Bs, lenBs, Lbig, Cj, mj, oj, id, d, rho, oi);
+            // not removed by the nearest predecessor although even the longest read placed there could reach C with a big overlap: undecided here
+            const bool fail = has_pred && !removed && (cfg.Lcap - 1) - (d - (int) (mj & 511u)) >= Lbig;
+            const bool keep = pass && !removed;
+            if (clash || fail) atomicOr(stp, 1u);
+            if (keep) atomicAdd(stp, 0x100u);
+            wave_lds_fence();
+            stv = *stp;
+            if (keep && stv == 0x100u) {                   // the only item that stands: the source's edge
+                o.first[Bs - o.src_base] = ((unsigned long long) id << 32) | (uint32_t) d;
+                o.deg[Bs - o.src_base] = 1u;
+                st_rec++;
+            }
+            // Two items stand (a coverage gap too long for any big via; 1.7 % of the sources at 30x): the rest of local_reduce's
+            // "several stand" branch for exactly two -- the per-source cap (with one item per offset the three largest small (L, C)
+            // are the three small items at the smallest offsets) and "the same target at a smaller offset supersedes" -- and the
+            // one or two edges go to the source's two slots.
+            const bool two = keep && stv == 0x200u;
+            if (__ballot(two) != 0ull) {                   // uniform
+                uint64_t segm = 0ull;                      // the lanes of this lane's source
+#pragma unroll
+                for (int q = 0; q < 8; q++) { const uint64_t mq = __ballot(ev && s8 == q); segm = s8 == q ? mq : segm; }
+                const uint64_t km = __ballot(keep) & segm;
+                const int la = km ? __builtin_ctzll(km) : 0, lb = km ? 63 - __builtin_clzll(km) : 0;
+                const int ds0 = lenBs - cfg.rsoemo + 1;                         // first offset of a small overlap
+                const uint64_t lowm = ds0 <= 0 ? 0ull : (ds0 >= 64 ? ~0ull : ((1ull << ds0) - 1ull));
+                const bool my_kept = pass && (d < ds0 || __popcll(below & ~lowm) < 3);
+                const uint32_t Ca = bperm(id, la), Cb = bperm(id, lb);
+                const int da = (int) bperm((uint32_t) d, la), db = (int) bperm((uint32_t) d, lb);
+                const bool ka = bperm(my_kept ? 1u : 0u, la) != 0u, kb = bperm(my_kept ? 1u : 0u, lb) != 0u;
+                const bool fa = ka && (__ballot(my_kept && id == Ca && d < da) & segm) == 0ull;
+                const bool fb = kb && (__ballot(my_kept && id == Cb && d < db) & segm) == 0ull;
+                if (two) {
+                    const unsigned long long mine = ((unsigned long long) id << 32) | (uint32_t) d;
+                    if (lane == la && fa) { o.first[Bs - o.src_base] = mine; o.deg[Bs - o.src_base] = (fb ? 2u : 1u); st_rec++; }
+                    if (lane == lb && fb) {
+                        if (fa) o.second[Bs - o.src_base] = mine;
+                        else { o.first[Bs - o.src_base] = mine; o.deg[Bs - o.src_base] = 1u; }
+                        st_rec++;
+                    }
+                }
+            }
+        }
+        if (STATS) {
+            st_rounds++;
+            const bool fin = ev && (stv & 255u) == 0u && (stv >> 8) <= 2u;      // this lane's source finishes here
+            st_slots += fin; st_raw += fin && pass; st_cmp += fin && has_pred;
+        }
+        // ---- (5) the leader of a row: are its sources of quad 0 / quad 1 finished?  (status word of the round that packed them) ----
+        if (gl == 0) {
+            if (g >= cur && g < e) {
+                const uint32_t sv = sStat[wave][4 * b0 + g];
+                const bool ok = ((fl0 >> g) & 1u) != 0u && (sv & 255u) == 0u && (sv >> 8) <= 2u;
+                red = ok ? red | 1u : red & ~1u;
+                if (STATS && ok) st_win += (uint64_t) ((int) sSrc[wave][4 * b0 + g].y - cfg.Lmin + 1);
+            }
+            if (4 + g >= cur && 4 + g < e) {
+                const uint32_t sv = sStat[wave][4 * b1 + g];
+                const bool ok = ((fl1 >> g) & 1u) != 0u && (sv & 255u) == 0u && (sv >> 8) <= 2u;
+                red = ok ? red | 2u : red & ~2u;
+                if (STATS && ok) st_win += (uint64_t) ((int) sSrc[wave][4 * b1 + g].y - cfg.Lmin + 1);
+            }
+        }
+        // ---- (6) the staged quad's index loads have had the time of (4) to land ----
+        const uint32_t ninc = finish_runs(b2, nnr_eff, nrun, nrec);
+        cur = e;
+        if (rot) {                                         // uniform: quad 0 is done
+            // its sources that did not finish here: to the general kernel
+            n_seen += __popc(fl0 >> 4);
+            defer_rows(gl == 0 && ((fl0 >> (4 + g)) & 1u) != 0u && (red & 1u) == 0u, (int) sSrc[wave][4 * b0 + g].x);
+            // the window moves on by one quad
+            uint32_t t4w, fl2;
+            quad_plan(ninc, nnr, t4w, fl2);
+            tw = (tw >> 32) | ((uint64_t) t4w << 32);
+            fl0 = fl1; fl1 = fl2;
+            red >>= 1;
+            const int bt = b0; b0 = b1; b1 = b2; b2 = bt;
+            pos0 = step <= src_end - pos0 ? pos0 + step : src_end;
+            have0 = pos0 < src_end;
+            cur -= 4;
+            bail = n_seen >= 192 && 2 * n_deferred > n_seen;
+        }
+    }
+    if (bail && have0) {
+        // most of this wave's sources are irregular: what quad 0 has already had packed is settled like a retirement, the rest of the
+        // wave's share goes to the general kernel unseen
+        defer_rows(gl == 0 && g < cur && ((fl0 >> (4 + g)) & 1u) != 0u && (red & 1u) == 0u, (int) sSrc[wave][4 * b0 + g].x);
+        bool first = true;
+        for (int q = pos0; q < src_end; q = step <= src_end - q ? q + step : src_end) {     // uniform
+            const int j = q + g < src_end ? q + g : last_src;
+            const int b = BYKEY ? (int) reinterpret_cast<const uint32_t *>(store)[(size_t) j * (4 * EQ) + 4 * EQ - 3] : j;
+            const bool dfr = gl == 0 && q + g < src_end && !(first && g < cur) && (run_w[(size_t) b * (2 * CL_RMAX) + 1] >> 24) != 0u;
+            defer_rows(dfr, b);
+            first = false;
+        }
+    }
+    flush_defer();
+    st_rec = wave_sum_u64(st_rec);
+    if (lane == 0 && st_rec) atomicAdd(&o.counters[CNT_VALID_RECORDS], (unsigned long long) st_rec);
+    if (STATS) {
+        st_raw = wave_sum_u64(st_raw); st_slots = wave_sum_u64(st_slots); st_win = wave_sum_u64(st_win); st_cmp = wave_sum_u64(st_cmp);
+        if (lane == 0) {
+            atomicAdd(&o.counters[CNT_RAW], (unsigned long long) st_raw);
+            atomicAdd(&o.counters[CNT_SLOTS], (unsigned long long) st_slots);
+            atomicAdd(&o.counters[CNT_WINDOWS], (unsigned long long) st_win);
+            atomicAdd(&o.counters[CNT_TR_COMPARES], (unsigned long long) st_cmp);
+            atomicAdd(&o.counters[CNT_ROUNDS], (unsigned long long) st_rounds);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
 // Does the clustered probe take this input?  Fills the k-mer / index geometry and the entry size (16-byte pieces: row words + 3).
@@ -1529,9 +1955,10 @@ void launch_probe_pairs(const NodesDev &nd, const PrefSufCfg &cfg, const Cluster
 }
 
 // the quad kernel (four sources per wave, entries packed densely) over the sources src_begin .. src_end - 1; by_key: over the
-// sources whose entries are at the positions src_begin .. src_end - 1 of the entry array (which holds an entry for every node)
+// sources whose entries are at the positions src_begin .. src_end - 1 of the entry array (which holds an entry for every node);
+// window: k_probe_stream (rounds packed from a sliding window of two quads) instead of k_probe_quads (one quad per round)
 void launch_probe_quads(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterCfg &cc, int eq, const void *store, const void *dir,
-                        const void *runs, const uint8_t *nruns, int32_t src_begin, int32_t src_end, bool by_key, unsigned long long *counters, int n_cu,
+                        const void *runs, const uint8_t *nruns, int32_t src_begin, int32_t src_end, bool by_key, bool window, unsigned long long *counters, int n_cu,
                         uint32_t *deg, unsigned long long *first, unsigned long long *second, int32_t *defer_list, uint32_t defer_cap, hipStream_t s) {
     const int64_t ns = (int64_t) src_end - src_begin;
     if (ns <= 0) return;
@@ -1540,7 +1967,8 @@ void launch_probe_quads(const NodesDev &nd, const PrefSufCfg &cfg, const Cluster
     ProbeOut o{nullptr, nullptr, 0, counters, deg, first, by_key ? 0 : src_begin, second};
     const uint4 *st = (const uint4 *) store;
     const int kf = (2 * cfg.Lmin) >> 5;
-#define CLQ_LAUNCH(ST, E, K, BK) hipLaunchKernelGGL((k_probe_quads<ST, E, K, BK>), grid, block, 0, s, nd, cfg, cc, st, (const uint4 *) dir, (const uint2 *) runs, nruns, src_begin, src_end, o, defer_list, defer_cap)
+#define CLQ_ARGS grid, block, 0, s, nd, cfg, cc, st, (const uint4 *) dir, (const uint2 *) runs, nruns, src_begin, src_end, o, defer_list, defer_cap
+#define CLQ_LAUNCH(ST, E, K, BK) do { if (window) hipLaunchKernelGGL((k_probe_stream<ST, E, K, BK>), CLQ_ARGS); else hipLaunchKernelGGL((k_probe_quads<ST, E, K, BK>), CLQ_ARGS); } while (0)
 #define CLQ_ORDER(ST, E, K) do { if (by_key) CLQ_LAUNCH(ST, E, K, true); else CLQ_LAUNCH(ST, E, K, false); } while (0)
 #define CLQ_STATS(E, K) do { if (cfg.stats) CLQ_ORDER(true, E, K); else CLQ_ORDER(false, E, K); } while (0)
     if (eq == 3 && kf == 5)      CLQ_STATS(3, 5);
@@ -1552,6 +1980,7 @@ void launch_probe_quads(const NodesDev &nd, const PrefSufCfg &cfg, const Cluster
 #undef CLQ_STATS
 #undef CLQ_ORDER
 #undef CLQ_LAUNCH
+#undef CLQ_ARGS
 }
 
 // src_list == null: the sources are the ids src_begin .. src_end - 1; else the ids src_list[src_begin .. src_end - 1]

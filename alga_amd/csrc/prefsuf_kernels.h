@@ -54,7 +54,7 @@ void       launch_probe_clustered(const NodesDev &nd, const PrefSufCfg &cfg, con
                                   unsigned long long *counters, int n_cu, uint32_t *deg, unsigned long long *first, const ProbeBig *big,
                                   const unsigned long long *list_count /* device, may be null: list mode ends at min(src_end, *list_count) */, hipStream_t s);
 void       launch_probe_quads(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterCfg &cc, int eq, const void *store, const void *dir,
-                              const void *runs, const uint8_t *nruns, int32_t src_begin, int32_t src_end, bool by_key /* the range is one of entry-array positions */,
+                              const void *runs, const uint8_t *nruns, int32_t src_begin, int32_t src_end, bool by_key /* the range is one of entry-array positions */, bool window /* k_probe_stream */,
                               unsigned long long *counters, int n_cu, uint32_t *deg, unsigned long long *first, unsigned long long *second, int32_t *defer_list,
                               uint32_t defer_cap, hipStream_t s);
 

@@ -49,9 +49,9 @@ def _check(eng, words, lens, lo, rs, af=None, at=None, stats=True, source_side=N
         if maxlen - lo + 1 > lo - kk + 1:
             kk = 2 * lo - maxlen
         clusterable = 1 <= maxlen - lo + 1 <= 64 and (2 * maxlen + 31) // 32 <= 13 and 8 <= kk <= min(32, lo)
-        # the clustered probe with its quad kernel first (the default; sources in key order and in id order) and with round 2's
-        # pair kernel first
-        for probe, first_kernel, order in (("table", 2, 1), ("cluster", 2, 1), ("cluster", 2, 0), ("cluster", 1, 1)):
+        # the clustered probe with its quad kernel first -- sliding window (3, the default) and one quad per round (2), sources in key
+        # order and in id order -- and with round 2's pair kernel first
+        for probe, first_kernel, order in (("table", 3, 1), ("cluster", 3, 1), ("cluster", 3, 0), ("cluster", 2, 1), ("cluster", 2, 0), ("cluster", 1, 1)):
             eng.set_option("probe", probe)
             eng.set_option("cluster_pairs", first_kernel)
             eng.set_option("cluster_order", order)
@@ -59,7 +59,7 @@ def _check(eng, words, lens, lo, rs, af=None, at=None, stats=True, source_side=N
                 got2 = eng.prefsuf_host(words, lens, lo, rs, af, at, collect_stats=stats, reduction="source_side")
             finally:
                 eng.set_option("probe", "auto")
-                eng.set_option("cluster_pairs", 2)
+                eng.set_option("cluster_pairs", 3)
                 eng.set_option("cluster_order", 1)
             assert got2.shape == want.shape and (got2 == want).all(), (probe, first_kernel, order)
             st = eng.last_stats()
@@ -387,14 +387,14 @@ def test_cluster_directory_geometries(n, length, G, seed, err, minlen, lo, rs):
     try:
         e.set_option("probe", "cluster")
         for bias in (-8, -4, 0, 3, 8):
-            for pairs in (2, 3, 1, 0):                    # 3: the quad kernel over the sources in id order
+            for pairs, order in ((3, 1), (3, 0), (2, 1), (2, 0), (1, 1), (0, 1)):      # first kernel; sources in key / id order
                 e.set_option("cluster_bucket_bias", bias)
-                e.set_option("cluster_pairs", min(pairs, 2))
-                e.set_option("cluster_order", 0 if pairs == 3 else 1)
+                e.set_option("cluster_pairs", pairs)
+                e.set_option("cluster_order", order)
                 got = e.prefsuf_host(words, lens, lo, rs, reduction="source_side")
                 st = e.last_stats()
-                assert st["probe_used"] == 2, (bias, pairs)
-                assert got.shape == want.shape and (got == want).all(), (bias, pairs)
+                assert st["probe_used"] == 2, (bias, pairs, order)
+                assert got.shape == want.shape and (got == want).all(), (bias, pairs, order)
     finally:
         e.close()
 

@@ -88,7 +88,7 @@ def main():
         words, lens, lo, rs, af, at, desc = make_case(seed)
         a = eng.prefsuf_host(words, lens, lo, rs, af, at, reduction="per_target")
         ok = True
-        for probe, pairs, order in (("table", 2, 1), ("cluster", 2, 1), ("cluster", 2, 0), ("cluster", 1, 1), ("cluster", 0, 1)):
+        for probe, pairs, order in (("table", 3, 1), ("cluster", 3, 1), ("cluster", 3, 0), ("cluster", 2, 1), ("cluster", 2, 0), ("cluster", 1, 1), ("cluster", 0, 1)):
             eng.set_option("probe", probe)
             eng.set_option("cluster_pairs", pairs)
             eng.set_option("cluster_order", order)
@@ -101,7 +101,7 @@ def main():
                 break
             finally:
                 eng.set_option("probe", "auto")
-                eng.set_option("cluster_pairs", 2)
+                eng.set_option("cluster_pairs", 3)
                 eng.set_option("cluster_order", 1)
             st = eng.last_stats()
             if probe == "table":
