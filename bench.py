@@ -263,7 +263,7 @@ def main():
         alg = algorithmic_bytes(stats, W)
         alg_probe_launch = alg["probe"] / world           # one launch = one rank's share of the sources
         achieved = alg_probe_launch / (ms["probe"] * 1e-3) / 1e9
-        # The probe of the clustered path is TWO kernels: k_probe_quads (four sources per wave) finishes the regular sources and
+        # The probe of the clustered path is TWO kernels: k_probe_stream (four-source rows, rounds packed from a sliding window of two quads) finishes the regular sources and
         # defers the others, k_probe_clustered takes the deferred ones.  `roofline` is the dominant one on the sources it FINISHES;
         # `probe_phase` is both kernels over all sources (the HIP events around the two launches).
         n_src = max(1, stats["nodes_live"])
@@ -271,18 +271,18 @@ def main():
         two_kernels = stats.get("probe_used") == 2 and ms["probe_pairs"] > 0 and world == 1
         first_dominates = two_kernels and 2 * ms["probe_pairs"] >= ms["probe"]
         if first_dominates:
-            probe_kernel, kernel_ms = "k_probe_quads", ms["probe_pairs"]
+            probe_kernel, kernel_ms = "k_probe_stream", ms["probe_pairs"]
             kernel_bytes = alg_probe_launch * (1.0 - deferred / n_src)
         else:
             # one kernel did (nearly all of) the probing -- seed-table probe; the general clustered kernel on reads with sequencing
             # errors, where the quad kernel's waves hand their share on; N > 1, where the split is not collected: the phase as a whole
-            probe_kernel = "k_probe_sources" if stats.get("probe_used") != 2 else ("k_probe_quads + k_probe_clustered (probe phase)")
+            probe_kernel = "k_probe_sources" if stats.get("probe_used") != 2 else ("k_probe_stream + k_probe_clustered (probe phase)")
             kernel_ms, kernel_bytes = ms["probe"], alg_probe_launch
         achieved_kernel = kernel_bytes / (kernel_ms * 1e-3) / 1e9
         src_sha = alga_amd.engine.source_fingerprint()     # of the kernel sources: what the counter passes are keyed on
         traffic = profiled_traffic(args.config, src_sha) if world == 1 else {}
-        tr_kernel = traffic_of(traffic, "k_probe_quads") if first_dominates else (
-            (traffic_of(traffic, "k_probe_quads") or 0) + (traffic_of(traffic, "k_probe_clustered") or 0) or traffic_of(traffic, "k_probe_sources"))
+        tr_kernel = traffic_of(traffic, "k_probe_stream") if first_dominates else (
+            (traffic_of(traffic, "k_probe_stream") or 0) + (traffic_of(traffic, "k_probe_clustered") or 0) or traffic_of(traffic, "k_probe_sources"))
         out = {
             "metric": "overlap_edges_per_sec", "value": n_edges * args.steps / dt, "unit": "edges/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
@@ -306,7 +306,7 @@ def main():
                          "units": "%d source nodes finished by this kernel per launch (of %d; %d deferred to k_probe_clustered)" % (n_src - deferred, n_src, deferred) if first_dominates else "%d source nodes per launch" % (n_src // world),
                          "per_unit": "per source node: 4W + 16 P + 4W * raw/node bytes (W=%d words, P=%.1f windows, raw/node=%.2f)" %
                                      (W, stats["windows_probed"] / max(1, stats["nodes_live"]), stats["raw_overlaps"] / max(1, stats["nodes_live"]))},
-            "probe_phase": {"kernels": ["k_probe_quads", "k_probe_clustered"] if two_kernels else [probe_kernel], "ms": ms["probe"],
+            "probe_phase": {"kernels": ["k_probe_stream", "k_probe_clustered"] if two_kernels else [probe_kernel], "ms": ms["probe"],
                             "algorithmic_bytes": alg_probe_launch, "achieved": achieved, "frac": achieved / HBM_PEAK_GBS},
             "phases_ms": {k: ms[k] for k in ("seed", "probe", "group", "reduce", "emit", "exchange")},
             "counters": {k: int(stats[k]) for k in ("nodes_live", "windows_probed", "slots_scanned", "raw_overlaps", "records",
@@ -326,7 +326,7 @@ def main():
                   ("rocprim radix sort of (key, id) (onesweep, 4 passes)", ms["sort"], 4 * n + 4 * 2 * 8 * n, None),
                   ("k_tgt_gather", ms["gather"], n * (4 * W + 8 + 16 * eq), "one isolated 64-byte row per entry: 128 bytes fetched for it"),
                   ("k_tgt_dir", ms["dir"], 4 * n + 16 * (nb + 1), None),
-                  (probe_kernel if first_dominates else "k_probe_quads", ms["probe_pairs"], alg_probe_launch * (1.0 - deferred / n_src), None),
+                  (probe_kernel if first_dominates else "k_probe_stream", ms["probe_pairs"], alg_probe_launch * (1.0 - deferred / n_src), None),
                   ("k_probe_clustered", ms["probe"] - ms["probe_pairs"], alg_probe_launch * (deferred / n_src), None),
                   ("scan + k_local_emit_* + k_sort_rows", ms["emit"], n * 16 + E * 12 * 2, None)]
             out["roofline_kernels"] = []
