@@ -207,7 +207,7 @@ class ShardedPrefSuf:
                     if kk.startswith("ms_") or kk in ("windows_probed", "slots_scanned", "raw_overlaps", "records", "transitive_compares", "generic_sources",
                                                        "big_sources", "deferred_sources", "edges"):
                         st[kk] = st.get(kk, 0) + v
-            pending.append(self._gather_start(mine, [int(x) for x in allmeta[:, 1]]))
+            pending.append(self._gather_start(mine, [int(x) for x in allmeta[:, 1]], single=(pieces == 1)))
         if not declined:
             t2 = time.perf_counter()
             self.edges = self._gather_finish(pending)
@@ -249,11 +249,15 @@ class ShardedPrefSuf:
         st["ms_exchange"] = (t1 - t0) * 1e3 + (t3 - t2) * 1e3
         return self._finish(st, collect_stats)
 
-    def _gather_start(self, mine, counts):
-        """Start moving one piece of every rank's edge list to rank 0 (or to every rank): -> (works, buffer, counts, send buffer).
-        Rank 0 receives every rank's piece with its exact length: point-to-point transfers (one per peer, each over that peer's own
-        xGMI link) that `_gather_finish` lands at their offsets of ONE preallocated list -- no padding to the longest piece and no
-        concatenation afterwards (round 2 copied the 1.1 GB list once more on rank 0)."""
+    def _gather_start(self, mine, counts, single=False):
+        """Start moving one piece of every rank's edge list to rank 0 (or to every rank): -> (works, buffers, counts, send buffer).
+        Rank 0 receives every rank's piece with its exact length as point-to-point transfers (one per peer, each over that peer's own
+        xGMI link), POSTED HERE -- at the program point where the peers post their sends: a send that finds no receive blocks what
+        the sender's communicator is asked to do next (the small all_gather of the following piece), so the receives must not wait
+        for `_gather_finish`.  single (the rank builds its range in one piece: the driver's default): the counts of this piece are
+        the final layout, and the receives land at their offsets of ONE preallocated list -- no padding to the longest piece, no
+        concatenation afterwards (round 2 copied the 1.1 GB list once more on rank 0).  Several pieces: one exact-length buffer per
+        (peer, piece), concatenated at the end (the final offsets are unknown until the last piece is built)."""
         import torch
         dist, nr, dev = self.dist, self.world, self.be.device
         m = int(mine.shape[0])
@@ -265,41 +269,47 @@ class ShardedPrefSuf:
             parts = torch.empty((nr, mx, 3), dtype=torch.int32, device=dev)
             work = dist.all_gather_into_tensor(parts.view(-1), local.view(-1), async_op=True)
             return [work], parts, counts, local
-        local = mine.clone() if m else torch.empty((0, 3), dtype=torch.int32, device=dev)     # the engine's edge buffer is reused by the next piece
+        # one batch per rank and piece (ncclGroupStart / End under torch's NCCL backend): rank 0's receives run side by side, one per link
         if self.rank != 0:
-            return ([dist.isend(local.view(-1), dst=0)] if m else []), None, counts, local
-        return [], None, counts, local                     # rank 0 posts its receives in _gather_finish, straight into the final list
+            local = mine.clone() if m else torch.empty((0, 3), dtype=torch.int32, device=dev)   # the engine's edge buffer is reused by the next piece
+            return (list(dist.batch_isend_irecv([dist.P2POp(dist.isend, local.view(-1), 0)])) if m else []), None, counts, local
+        ops = []
+        if single:
+            out = torch.empty((sum(counts), 3), dtype=torch.int32, device=dev)
+            off = 0
+            parts = []
+            for q in range(nr):
+                dst = out[off:off + counts[q]]
+                if q == 0:
+                    dst.copy_(mine)
+                elif counts[q]:
+                    ops.append(dist.P2POp(dist.irecv, dst.view(-1), q))
+                parts.append(dst)
+                off += counts[q]
+            return (list(dist.batch_isend_irecv(ops)) if ops else []), parts, counts, out
+        parts = [mine.clone() if m else torch.empty((0, 3), dtype=torch.int32, device=dev)]
+        for q in range(1, nr):
+            buf = torch.empty((counts[q], 3), dtype=torch.int32, device=dev)
+            if counts[q]:
+                ops.append(dist.P2POp(dist.irecv, buf.view(-1), q))
+            parts.append(buf)
+        return (list(dist.batch_isend_irecv(ops)) if ops else []), parts, counts, None
 
     def _gather_finish(self, pending):
         """Wait for the pieces; the complete list in (src, dst) order: rank by rank, piece by piece (ascending source ranges)."""
         import torch
-        dist, nr, dev = self.dist, self.world, self.be.device
+        nr, dev = self.world, self.be.device
+        for w in pending:
+            for x in w[0]:
+                x.wait()
         self.total_edges = sum(sum(w[2]) for w in pending)
         if self.replicate:
-            for w in pending:
-                for x in w[0]:
-                    x.wait()
             return torch.cat([w[1][q][:w[2][q]] for q in range(nr) for w in pending], dim=0).contiguous()
         if self.rank != 0:
-            for w in pending:
-                for x in w[0]:
-                    x.wait()
             return torch.empty((0, 3), dtype=torch.int32, device=dev)
-        out = torch.empty((self.total_edges, 3), dtype=torch.int32, device=dev)
-        works, off = [], 0
-        for q in range(nr):                                 # final order: rank by rank, inside a rank piece by piece
-            for w in pending:
-                c = w[2][q]
-                if c:
-                    dst = out[off:off + c]
-                    if q == 0:
-                        dst.copy_(w[3])
-                    else:
-                        works.append(dist.irecv(dst.view(-1), src=q))
-                off += c
-        for x in works:
-            x.wait()
-        return out
+        if len(pending) == 1 and pending[0][3] is not None:
+            return pending[0][3]                            # received in place
+        return torch.cat([w[1][q] for q in range(nr) for w in pending], dim=0).contiguous()
 
     def _gather(self, mine, ordered, counts=None):
         """Edge lists of all ranks (padded to the longest) -> the complete list on rank 0 (or on every rank);

@@ -130,7 +130,7 @@ def main():
     t_process = time.perf_counter()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="cfg4_50M_150bp")
     ap.add_argument("--no-cpu-baseline", action="store_true")

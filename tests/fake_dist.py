@@ -77,6 +77,14 @@ class FakeDist:
     def irecv(self, tensor, src):
         return self._Recv(self, tensor, src)
 
+    class P2POp:
+        def __init__(self, op, tensor, peer):
+            self.op, self.tensor, self.peer = op, tensor, peer
+
+    @staticmethod
+    def batch_isend_irecv(ops):
+        return [o.op(o.tensor, o.peer) for o in ops]
+
     def all_reduce(self, t, op=ReduceOp.SUM):
         import torch
         parts = self._exchange(t.detach().clone())
