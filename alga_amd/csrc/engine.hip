@@ -226,29 +226,23 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
         HIP_TRY(e, hipMemsetAsync(cnt, 0, CNT_TOTAL * sizeof(unsigned long long), s));
         ProbeBig big{(int32_t *) e->loc_big_list.p, big_list_cap, 0u, nullptr, 0u};
         if (clustered) {
-            // Two kernels: the quad kernel (four sources per wave, entries packed densely; option cluster_pairs = 1: round 2's pair
-            // kernel, two sources per wave) finishes the regular sources and lists the others; the general kernel (one source per
-            // wave, any shape) takes the list.  No host round trip in between: the general kernel runs as a persistent grid over a
-            // list whose length it reads from the device counter the first kernel left.  Data on which most sources are irregular
-            // (sequencing errors: several items per offset): the waves of the first kernel notice it on their own first sources
-            // and hand the rest of their share on unseen -- a decision taken from THIS build's data, not from an earlier build.
+            // Two kernels: k_probe_stream (the entries of consecutive sources packed densely onto the lanes) finishes the regular sources
+            // and lists the others; the general kernel (one source per wave, any shape) takes the list.  No host round trip in between:
+            // the general kernel runs as a persistent grid over a list whose length it reads from the device counter the first
+            // kernel left.  Data on which most sources are irregular (sequencing errors: several items per offset): the waves of the
+            // first kernel notice it on their own first sources and hand the rest of their share on unseen -- a decision taken from
+            // THIS build's data, not from an earlier build.
             if (e->opt_cluster_pairs) {
                 if ((rc = alga_ensure(e, e->cl_defer, (size_t) (n_src + 64) * sizeof(int32_t)))) return rc;
                 if ((rc = alga_ensure(e, e->loc_second, (size_t) (n_src + 1) * sizeof(unsigned long long)))) return rc;
                 e->loc_second_used = true;
-                if (e->opt_cluster_pairs == 1)
-                    launch_probe_pairs(nd, cfg, cc, pp.cluster_eq, e->cl_store.p, e->cl_dir.p, e->cl_runs.p, (const uint8_t *) e->cl_nruns.p,
-                                       src_begin, src_end, cnt, e->n_cu, (uint32_t *) e->outdeg.p, (unsigned long long *) e->loc_first.p,
-                                       (unsigned long long *) e->loc_second.p, (int32_t *) e->cl_defer.p, (uint32_t) n_src, s);
-                else {
-                    // all sources: in the order of the entry array (consecutive sources share a locus: option cluster_order); a range of
-                    // ids (a rank's share, a piece): in id order
-                    const bool by_key = e->opt_cluster_order != 0 && src_begin == 0 && src_end == nd.n;
-                    launch_probe_quads(nd, cfg, cc, pp.cluster_eq, e->cl_store.p, e->cl_dir.p, e->cl_runs.p, (const uint8_t *) e->cl_nruns.p,
-                                       src_begin, src_end, by_key, e->opt_cluster_pairs >= 3, cnt, e->n_cu, (uint32_t *) e->outdeg.p, (unsigned long long *) e->loc_first.p,
-                                       (unsigned long long *) e->loc_second.p, (int32_t *) e->cl_defer.p, (uint32_t) n_src, s);
-                }
-                if ((rc = alga_check_launch(e, "k_probe_quads / k_probe_pairs"))) return rc;
+                // all sources: in the order of the entry array (consecutive sources share a locus: option cluster_order); a range of
+                // ids (a rank's share, a piece): in id order
+                const bool by_key = e->opt_cluster_order != 0 && src_begin == 0 && src_end == nd.n;
+                launch_probe_stream(nd, cfg, cc, pp.cluster_eq, e->cl_store.p, e->cl_dir.p, e->cl_runs.p, (const uint8_t *) e->cl_nruns.p,
+                                    src_begin, src_end, by_key, cnt, e->n_cu, (uint32_t *) e->outdeg.p, (unsigned long long *) e->loc_first.p,
+                                    (unsigned long long *) e->loc_second.p, (int32_t *) e->cl_defer.p, (uint32_t) n_src, s);
+                if ((rc = alga_check_launch(e, "k_probe_stream"))) return rc;
                 HIP_TRY(e, hipEventRecord(e->ev[EV_PAIRS], s));
                 e->pairs_timed = true;
                 launch_probe_clustered(nd, cfg, cc, pp.cluster_eq, e->cl_store.p, e->cl_dir.p, e->cl_runs.p, (const uint8_t *) e->cl_nruns.p, 0,
@@ -528,8 +522,7 @@ int alga_engine_set_option(alga_engine *e, const char *name, int64_t value) {
         if (value < -8 || value > 8) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "option cluster_bucket_bias: -8 .. 8");
         e->opt_cluster_bucket_bias = (int) value;
     } else if (!strcmp(name, "cluster_pairs")) {
-        if (value < 0 || value > 3) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "option cluster_pairs: 0 general kernel only, 1 pair kernel first, 2 quad kernel first, 3 quad kernel with a sliding window first");
-        e->opt_cluster_pairs = (int) value;
+        e->opt_cluster_pairs = value != 0;
     } else if (!strcmp(name, "cluster_order")) {
         e->opt_cluster_order = value != 0;
     } else if (!strcmp(name, "local_big_max")) {

@@ -51,8 +51,8 @@ struct alga_engine {
     bool   warmed = false;                                  // alga_engine_reserve has run its miniature build (kernel code objects loaded)
     bool   pairs_timed = false;                             // EV_PAIRS was recorded in the last discovery
     bool   store_timed = false;                             // EV_KEYS / EV_SORT / EV_GATHER were recorded in the last discovery
-    int    opt_cluster_order = 1;                           // option "cluster_order": the quad kernel walks all sources in entry-array (key) order (0: id order)
-    int    opt_cluster_pairs = 3;                           // option "cluster_pairs": 0 = general kernel only, 1 = pair kernel first, 2 = quad kernel first, 3 = quad kernel with a sliding window first
+    int    opt_cluster_order = 1;                           // option "cluster_order": k_probe_stream walks all sources in entry-array (key) order (0: id order)
+    int    opt_cluster_pairs = 1;                           // option "cluster_pairs": 0 = general kernel only, 1 = k_probe_stream first
     DevBuf cl_keys[2], cl_vals[2], cl_meta, cl_runs, cl_nruns, cl_store, cl_dir;   // clustered minimizer join: sort buffers, per-node minimizer runs, entry array, bucket directory
     DevBuf loc_second;                                      // ... the other edge of a two-edge source the pair kernel finished (clustered probe)
     bool   loc_second_used = false;                         // the last discovery wrote loc_second

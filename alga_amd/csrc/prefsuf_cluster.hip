@@ -21,7 +21,7 @@
 //                      of the node as a SOURCE, and the key / meta word it is filed under as a TARGET (run 0)
 //   (radix sort of (key, id): rocPRIM)
 //   k_tgt_gather       rows in key order -> entry array;   k_tgt_dir     directory record of every key bucket
-//   k_probe_pairs      two sources per wave (32 lanes each): finishes the regular sources, lists the others
+//   k_probe_stream     entries of consecutive sources packed densely onto the lanes: finishes the regular sources, lists the others
 //   k_probe_clustered  one source per wave, any shape: the listed sources (or all of them)
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -733,707 +733,35 @@ k_probe_clustered(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__res
 }
 
 // ------------------------------------------------------------------------------------------
-// k_probe_pairs : TWO sources per wave, 32 lanes each
+// k_probe_stream : the entries of consecutive sources packed densely onto the 64 lanes
 // ------------------------------------------------------------------------------------------
-// A 150-bp source at 30x coverage has ~24 entries to verify and ~11 items to reduce: a wave per source leaves most lanes idle
-// in exactly the parts that cost the instructions.  Here a wave takes two sources (adjacent ids), one per half: the entries of
-// all runs of a source are packed densely onto the 32 lanes of its half, verified there, and reduced there by the fused
-// single-survivor rule (k_probe_clustered, step (4)).  Only REGULAR sources finish here -- at most 8 runs, at most 32 entries,
-// one item per offset, every item but one implied by its nearest predecessor, i.e. error-free data at moderate coverage --
-// and their single edge goes straight to first[] / deg[].  Any other source is appended to `defer_list` and taken by
-// k_probe_clustered (list mode) afterwards: nothing is decided twice, nothing is approximated.
-// Same two-stage software pipeline as k_probe_clustered; "uniform per source" values live in vector registers (one per half).
-#ifndef CLP_OCC
-#define CLP_OCC 7                     // workgroups per CU: 28 waves per CU (72 VGPRs, no spills; 6, 7 and 8 measured within 2 %)
-#endif
-template <bool STATS, int EQ, int KF>
-__global__ void __launch_bounds__(PROBE_WAVES * 64, CLP_OCC)
-k_probe_pairs(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__restrict__ store, const uint4 *__restrict__ dir,
-              const uint2 *__restrict__ runs, const uint8_t *__restrict__ nruns, int32_t src_begin, int32_t src_end, ProbeOut o,
-              int32_t *__restrict__ defer_list, uint32_t defer_cap) {
-    constexpr int WC = 4 * EQ - 3;                         // row words of an entry
-    constexpr int PW = 32;                                 // staged words per source (rows of up to 13 words + the compare's slack)
-    __shared__ uint32_t sB[PROBE_WAVES][2][2][PW];
-    __shared__ uint4 sRun[PROBE_WAVES][2][2][CL_RMAX];     // per run: q | p0 << 8 | p1 << 16, cluster key, first entry - slots before the run
-    __shared__ unsigned long long sIncl[PROBE_WAVES][2][2];// per source: inclusive prefix of the runs' entry counts, 8 x u8 (saturating)
-    __shared__ uint8_t sT[PROBE_WAVES][2][64];             // per source: lane of the item at offset d
-    __shared__ int32_t sDefer[PROBE_WAVES][64];
-    __shared__ uint4 sMask[KF > 0 ? 129 : 1];
-    const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
-    const int lane = lane_id();
-    const int h = lane >> 5, hl = lane & 31;
-    if constexpr (KF > 0) {
-        for (int t = (int) threadIdx.x; t <= 128; t += PROBE_WAVES * 64)
-            sMask[t] = make_uint4(low_bits32(t), low_bits32(t - 32), low_bits32(t - 64), low_bits32(t - 96));
-        __syncthreads();
-    }
-    uint64_t st_raw = 0, st_slots = 0, st_win = 0, st_rec = 0, st_cmp = 0;
-    int n_defer = 0;                                       // uniform: sources waiting in sDefer
-    const int step = (int) gridDim.x * PROBE_WAVES * 2;
-    const int kfull = KF ? KF : (2 * cfg.Lmin) >> 5;
-    const int Lbig = cfg.rsoemo > cfg.Lmin ? cfg.rsoemo : cfg.Lmin;
-    auto half_of = [&](uint64_t m) -> uint32_t { return h ? (uint32_t) (m >> 32) : (uint32_t) m; };
-    auto flush_defer = [&]() {                             // convergent
-        if (n_defer == 0) return;
-        unsigned long long base = 0;
-        if (lane == 0) base = atomicAdd(&o.counters[CNT_DEFERRED], (unsigned long long) n_defer);
-        base = ((unsigned long long) (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) (base >> 32)) << 32) | (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) base);
-        if (lane < n_defer && base + (unsigned long long) lane < (unsigned long long) defer_cap) defer_list[base + (unsigned long long) lane] = sDefer[wave][lane];
-        wave_lds_fence();
-        n_defer = 0;
-    };
-
-    // ---- source stream: pairs of adjacent ids; the rows / lengths / run lists of the pair after the one being staged are in flight ----
-    const int pre_words = nd.stride < PW ? nd.stride : PW;
-    int Bl = src_begin + 2 * ((int) blockIdx.x * PROBE_WAVES + wave);
-    // Every lane issues every load, unconditionally, at clamped addresses: a load under a branch makes hipcc wait for it right
-    // there (the merge of the loaded value with its default needs it), which stalled the wave for a memory round trip at the top of
-    // every iteration.  What a lane must not use is masked where the values are consumed, one iteration later (take()).
-    int n_len = 0, n_nr = 0; uint32_t n_word = 0; uint2 n_run = make_uint2(0u, 0u);
-    bool n_valid = false;
-    const int last_src = src_end - 1, col = hl < pre_words ? hl : pre_words - 1;
-    auto fetch = [&]() {
-        const int b = Bl + h;
-        n_valid = b < src_end;                             // (Bl < src_end follows)
-        const int bs = b < last_src ? b : last_src;
-        n_len = nd.len[bs];
-        n_nr = nruns[bs];
-        n_word = nd.words[(size_t) bs * nd.stride + col];
-        n_run = runs[(size_t) bs * CL_RMAX + (hl & (CL_RMAX - 1))];
-    };
-    auto take = [&](int &len, int &nrn, uint32_t &word, uint2 &run) {   // the fetched pair, masked
-        len = n_valid ? n_len : 0; nrn = n_valid ? n_nr : 0;
-        word = (n_valid && hl < pre_words) ? n_word : 0u;
-        run = (n_valid && hl < CL_RMAX) ? n_run : make_uint2(0u, 0u);
-    };
-    fetch();
-    // stage 1 of a pair: rows -> LDS; bucket of each run (lanes without a run read bucket 0: one shared line)
-    auto stage = [&](int buf, int lenB, int nr_eff, uint32_t word0, const uint2 &run) -> uint32_t {
-        wave_lds_fence();
-        sB[wave][buf][h][hl] = hl < blocks_of(lenB) ? word0 : 0u;
-        return hl < nr_eff ? run.x >> cc.idx_shift : 0u;
-    };
-    auto index_loads = [&](uint32_t bucket, uint4 &rec) { rec = dir[bucket]; };   // every lane, no branch
-    // run list of a pair -> LDS; entries are numbered densely over the runs of a source: slot = entries of the runs before + j.
-    // Returns the number of entries of this lane's source (uniform per half).
-    auto finish_runs = [&](int buf, int nr_eff, const uint2 &run, const uint4 &rec) -> int {
-        uint32_t e0, cnt;
-        run_slice(rec, run.y, e0, cnt);
-        cnt = hl < nr_eff ? cnt : 0u;                      // lanes hl >= 8 hold no run
-        uint32_t inc = cnt, t;                             // inclusive scan over the runs (lanes hl 0..7 of the half: inside one 16-lane row)
-        t = (uint32_t) __builtin_amdgcn_update_dpp(0, (int) inc, 0x111, 0xF, 0xF, true); inc += t;
-        t = (uint32_t) __builtin_amdgcn_update_dpp(0, (int) inc, 0x112, 0xF, 0xF, true); inc += t;
-        t = (uint32_t) __builtin_amdgcn_update_dpp(0, (int) inc, 0x114, 0xF, 0xF, true); inc += t;
-        if (hl < CL_RMAX) {
-            sRun[wave][buf][h][hl] = make_uint4(run.y, run.x, e0 - (inc - cnt), cnt);
-            reinterpret_cast<uint8_t *>(&sIncl[wave][buf][h])[hl] = (uint8_t) (inc > 255u ? 255u : inc);
-        }
-        const int T0 = __builtin_amdgcn_readlane((int) inc, CL_RMAX - 1), T1 = __builtin_amdgcn_readlane((int) inc, 32 + CL_RMAX - 1);
-        wave_lds_fence();
-        return h ? T1 : T0;
-    };
-
-    bool have = Bl < src_end;
-    int B = 0, lenB = 0, nr = 0, T = 0, buf = 0;
-    if (have) {
-        uint32_t word0; uint2 run;
-        B = Bl + h;
-        take(lenB, nr, word0, run);
-        Bl += step;
-        fetch();
-        const int nr_eff = nr == CL_RUNS_FLAGGED ? 0 : nr;
-        uint4 rec0;
-        const uint32_t bk = stage(0, lenB, nr_eff, word0, run);
-        index_loads(bk, rec0);
-        T = finish_runs(0, nr_eff, run, rec0);
-    }
-    while (have) {                                         // uniform
-        const uint32_t *sb = sB[wave][buf][h];
-        const int nwin = lenB - cfg.Lmin + 1;
-        // ---- (1) the next pair comes off the stream before any entry load is issued ----
-        const bool have_next = Bl < src_end;
-        const int nB = Bl + h;
-        int nlenB, nnr; uint32_t nword0; uint2 nrun;
-        take(nlenB, nnr, nword0, nrun);
-        Bl = have_next ? Bl + step : Bl;
-        fetch();                                                       // past the end: clamped reads of the last source, never used
-        const int nnr_eff = nnr == CL_RUNS_FLAGGED ? 0 : nnr;
-        // ---- (2) this pair's entries, densely packed per half: loads issued ----
-        const bool takes_part = nr != 0;                               // nruns == 0: not a source
-        const bool packable = takes_part && nr != CL_RUNS_FLAGGED && T <= 32;
-        const bool ev = packable && hl < T;
-        uint4 rp = make_uint4(0u, 0u, 0u, 0u);
-        {
-            // run of slot hl: the number of runs whose inclusive prefix is <= hl (binary search over 8 packed bytes)
-            const unsigned long long inc8 = sIncl[wave][buf][h];
-            const uint32_t lo = (uint32_t) inc8, hi = (uint32_t) (inc8 >> 32);
-            int r = (int) ((lo >> 24) & 255u) <= hl ? 4 : 0;
-            { const uint32_t wv = r ? hi : lo; r += (int) ((wv >> 8) & 255u) <= hl ? 2 : 0; }
-            { const uint32_t wv = r >= 4 ? hi : lo; r += (int) ((wv >> (8 * (r & 3))) & 255u) <= hl ? 1 : 0; }
-            if (ev) rp = sRun[wave][buf][h][r & (CL_RMAX - 1)];
-        }
-        const size_t ei = ev ? (size_t) (rp.z + (uint32_t) hl) : (size_t) 0;
-        uint32_t ew[4 * EQ];
-#pragma unroll
-        for (int c = 0; c < EQ; c++) { const uint4 v = store[ei * EQ + c]; ew[4 * c] = v.x; ew[4 * c + 1] = v.y; ew[4 * c + 2] = v.z; ew[4 * c + 3] = v.w; }
-        // ---- (3) the next pair: rows staged, index loads issued behind the entry loads ----
-        uint32_t nbk = 0;
-        uint4 nrec;
-        if (have_next) nbk = stage(buf ^ 1, nlenB, nnr_eff, nword0, nrun);
-        index_loads(nbk, nrec);
-        // ---- (4) verify: one entry per lane ----
-        const uint32_t id = ew[4 * EQ - 3], eh = ew[4 * EQ - 2], meta = ew[4 * EQ - 1];
-        const int lenC = (int) ((meta >> 8) & 0xFFFu);
-        int p = (int) (rp.x & 255u) - (int) (meta & 255u);
-        const bool ok = ev && same_cluster(eh, rp.y, cc.idx_shift - CL_MBITS) && p >= (int) ((rp.x >> 8) & 255u) && p < (int) ((rp.x >> 16) & 255u) && (int) id != B && lenC >= lenB - p;
-        p = ok ? p : 0;
-        const int L = lenB - p, nb = 2 * L;
-        bool pass;
-        {
-            const int qw = (2 * p) >> 5, sh = (2 * p) & 31;
-            uint32_t y[WC + 1];
-#pragma unroll
-            for (int k = 0; k <= WC; k++) y[k] = sb[qw + k];
-            uint32_t diff = 0;
-            uint32_t mk[4] = {0u, 0u, 0u, 0u};
-            if constexpr (KF > 0) { const uint4 m4 = sMask[min(max(nb - 32 * KF, 0), 128)]; mk[0] = m4.x; mk[1] = m4.y; mk[2] = m4.z; mk[3] = m4.w; }
-#pragma unroll
-            for (int k = 0; k < WC; k++) {
-                const uint32_t x = funnel(y[k], y[k + 1], sh) ^ ew[k];
-                if (k < kfull) diff |= x;
-                else if (KF > 0 && k < KF + 4) diff |= x & mk[(k - KF) & 3];
-                else diff |= x & low_bits32(nb - 32 * k);
-            }
-            pass = ok && diff == 0;
-        }
-        const uint64_t pm = __ballot(pass);
-        const uint32_t v_m = (uint32_t) p | ((uint32_t) lenC << 9) | ((meta & CL_META_FROM) ? ITEM_FROM : 0u);
-        uint4 v_o = make_uint4(0u, 0u, 0u, 0u);
-        bool reduced = packable;                           // a packable source without a raw overlap has no edge: done
-        if (pm != 0ull) {                                  // uniform
-            if (pass) {                                    // overhang: C's row from bit 2L on (see k_probe_clustered)
-                const int ws = nb >> 5, r2 = nb & 31;
-                uint32_t x[5];
-                if constexpr (KF > 0 && WC - KF <= 6) {
-                    const int t = ws - KF;
-#pragma unroll
-                    for (int k = 0; k < 5; k++) {
-                        uint32_t v = 0u;
-#pragma unroll
-                        for (int u = 0; u <= WC - KF; u++) { const int wi = KF + k + u; if (wi < 4 * EQ) v = t == u ? ew[wi] : v; }
-                        x[k] = v;
-                    }
-                } else {
-                    const uint32_t *er = reinterpret_cast<const uint32_t *>(store + ei * EQ);
-#pragma unroll
-                    for (int k = 0; k < 5; k++) x[k] = er[ws + k];
-                }
-                v_o = make_uint4(funnel(x[0], x[1], r2), funnel(x[1], x[2], r2), funnel(x[2], x[3], r2), funnel(x[3], x[4], r2));
-            }
-            // ---- fused single-survivor reduction, both halves at once ----
-            uint8_t *Tb = sT[wave][h];
-            Tb[hl] = 0xFFu; Tb[hl + 32] = 0xFFu;
-            wave_lds_fence();
-            const int d = p;
-            if (pass) Tb[d] = (uint8_t) lane;
-            wave_lds_fence();
-            const uint64_t b1 = __ballot(Tb[hl] != 0xFFu), b2 = __ballot(Tb[hl + 32] != 0xFFu);
-            const uint64_t occ = (uint64_t) half_of(b1) | ((uint64_t) half_of(b2) << 32);
-            const int nit = __popc(half_of(pm));
-            const bool one_per_offset = __popcll(occ) == nit;
-            const uint64_t below = pass ? (occ & ((1ull << d) - 1ull)) : 0ull;
-            const bool has_pred = below != 0ull;
-            const int j = has_pred ? (int) Tb[63 - __clzll((long long) below)] : lane;
-            const uint32_t Cj = bperm(id, j), mj = bperm(v_m, j);
-            Ovh<1> oj, oi;
-            oj.w[0] = bperm(v_o.x, j); oj.w[1] = bperm(v_o.y, j); oj.w[2] = bperm(v_o.z, j); oj.w[3] = bperm(v_o.w, j);
-            oi.w[0] = v_o.x; oi.w[1] = v_o.y; oi.w[2] = v_o.z; oi.w[3] = v_o.w;
-            const int rho = lenC - (lenB - d);
-            const bool removed = has_pred && via_ok<1>(B, lenB, Lbig, Cj, mj, oj, id, d, rho, oi);
-            const bool fail = has_pred && !removed && (cfg.Lcap - 1) - (d - (int) (mj & 511u)) >= Lbig;
-            const bool any_fail = half_of(__ballot(fail)) != 0u;
-            const bool keep = pass && !removed;
-            const int n_surv = __popc(half_of(__ballot(keep)));
-            reduced = packable && (nit == 0 || (one_per_offset && !any_fail && n_surv == 1));
-            if (reduced && keep) {
-                o.first[B - o.src_base] = ((unsigned long long) id << 32) | (uint32_t) d;
-                o.deg[B - o.src_base] = 1u;
-                st_rec++;
-            }
-            // Two items stand (a coverage gap too long for any big via; 1.7 % of the sources at 30x): the rest of local_reduce's
-            // "several stand" branch for exactly two -- the per-source cap (with one item per offset the three largest small (L, C)
-            // are the three small items at the smallest offsets) and "the same target at a smaller offset supersedes" -- and the
-            // one or two edges go to the source's two slots.
-            const bool two = packable && one_per_offset && !any_fail && n_surv == 2 && o.second != nullptr;
-            if (__ballot(two) != 0ull) {                       // uniform
-                const uint32_t km = half_of(__ballot(keep));
-                const int la = (h << 5) + (km ? __builtin_ctz(km) : 0), lb = (h << 5) + (km ? 31 - __builtin_clz(km) : 0);
-                const int ds0 = lenB - cfg.rsoemo + 1;                          // first offset of a small overlap
-                const uint64_t lowm = ds0 <= 0 ? 0ull : (ds0 >= 64 ? ~0ull : ((1ull << ds0) - 1ull));
-                const bool my_kept = pass && (d < ds0 || __popcll(below & ~lowm) < 3);
-                const uint32_t Ca = bperm(id, la), Cb = bperm(id, lb);
-                const int da = (int) bperm((uint32_t) d, la), db = (int) bperm((uint32_t) d, lb);
-                const bool ka = bperm(my_kept ? 1u : 0u, la) != 0u, kb = bperm(my_kept ? 1u : 0u, lb) != 0u;
-                const bool fa = ka && half_of(__ballot(my_kept && id == Ca && d < da)) == 0u;
-                const bool fb = kb && half_of(__ballot(my_kept && id == Cb && d < db)) == 0u;
-                if (two) {
-                    const unsigned long long mine = ((unsigned long long) id << 32) | (uint32_t) d;
-                    if (lane == la && fa) { o.first[B - o.src_base] = mine; o.deg[B - o.src_base] = (fb ? 2u : 1u); st_rec++; }
-                    if (lane == lb && fb) {
-                        if (fa) o.second[B - o.src_base] = mine;
-                        else { o.first[B - o.src_base] = mine; o.deg[B - o.src_base] = 1u; }
-                        st_rec++;
-                    }
-                    reduced = true;
-                }
-            }
-            if (STATS && reduced) { st_raw += pass; st_cmp += has_pred; }
-        }
-        if (STATS && reduced) { st_slots += ev; if (hl == 0) st_win += (uint64_t) nwin; }
-        // ---- sources that do not finish here: to the general kernel ----
-        const uint64_t dm = __ballot(takes_part && !reduced && hl == 0);
-        if (dm != 0ull) {                                  // uniform
-            if (takes_part && !reduced && hl == 0) sDefer[wave][n_defer + (h && (dm & 1ull) ? 1 : 0)] = B;
-            n_defer += __popcll(dm);
-            wave_lds_fence();
-            if (n_defer >= 62) flush_defer();
-        }
-        // ---- (5) the next pair's index loads have had the time of (4) to land ----
-        const int nT = finish_runs(buf ^ 1, nnr_eff, nrun, nrec);
-        have = have_next; B = nB; lenB = nlenB; nr = nnr; T = nT; buf ^= 1;
-    }
-    flush_defer();
-    st_rec = wave_sum_u64(st_rec);
-    if (lane == 0 && st_rec) atomicAdd(&o.counters[CNT_VALID_RECORDS], (unsigned long long) st_rec);
-    if (STATS) {
-        st_raw = wave_sum_u64(st_raw); st_slots = wave_sum_u64(st_slots); st_win = wave_sum_u64(st_win); st_cmp = wave_sum_u64(st_cmp);
-        if (lane == 0) {
-            atomicAdd(&o.counters[CNT_RAW], (unsigned long long) st_raw);
-            atomicAdd(&o.counters[CNT_SLOTS], (unsigned long long) st_slots);
-            atomicAdd(&o.counters[CNT_WINDOWS], (unsigned long long) st_win);
-            atomicAdd(&o.counters[CNT_TR_COMPARES], (unsigned long long) st_cmp);
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// k_probe_quads : FOUR sources per wave, their entries packed densely onto the 64 lanes
-// ------------------------------------------------------------------------------------------
-// k_probe_pairs gives every source 32 lanes and a 150-bp source at 30x has ~16 entries: half of the lanes are idle through the
-// verify and the reduction, which is where the instructions go (the kernel is VALU-bound).  Here a wave takes four adjacent
-// sources at a time: rows, run lists and directory look-ups are handled by the four 16-lane rows (one source each, DPP scans stay
-// inside a row), and then the ENTRIES of the four sources are laid out back to back on the 64 lanes -- source g occupies the
-// lanes [start_g, start_g + T_g).  Sources that do not fit the 64 lanes together wait for a further ROUND of the same quad
-// (every iteration of the main loop is one round: the prefetch of the next quad is simply issued again, at the same addresses).
-// What is per source in the reduction -- offsets taken, two items at one offset, an undecided implication, the number of
-// survivors -- is aggregated through a few LDS atomics on a per-source word instead of ballots over fixed half-waves, so a
-// source may sit on any run of lanes.  Same rule as k_probe_pairs: only REGULAR sources finish here (at most 8 runs, at most 64
-// entries, one item per offset, every item but one or two implied by its nearest predecessor); the others go on `defer_list`
-// for k_probe_clustered.  A wave that has had to defer more than half of its first sources (reads with sequencing errors) stops
-// verifying and lists the rest of its share: the decision is taken from THIS build's data, inside the kernel.
+// One source per wave (k_probe_clustered) leaves most lanes idle: a 150-bp source at 30x has ~16 entries to verify and ~11 items to
+// reduce, and that is where the instructions go (the kernel is instruction-bound).  Round 2's pair kernel gave every source 32
+// lanes (half of them idle); this kernel packs.
+//   * The sources come four at a time (a QUAD): rows, run lists and directory look-ups are handled by the four 16-lane rows, one
+//     source each (the DPP scans over the <= 8 runs stay inside a row).
+//   * The ENTRIES of several sources are then laid out back to back on the 64 lanes -- source j occupies the lanes
+//     [start_j, start_j + T_j) -- from a SLIDING WINDOW of two quads: eight consecutive sources, both quads staged, their run lists
+//     resolved.  A round (= one iteration of the main loop) takes up to five sources from the cursor on for as long as they fit
+//     the 64 lanes, across the quad boundary.  When the cursor has passed the older quad it retires (its unfinished sources go on
+//     the defer list), the younger one takes its place and the quad staged during this round becomes the younger one: three LDS
+//     buffers in rotation, at most one rotation per round (a round never takes the window's last source, so the quad that follows
+//     is always ready when it is needed).  What is not consumed is fetched and staged again at the same addresses in the next
+//     round: no load ever sits under a branch.  Measured at 30x: 3.45 sources and 55 of the 64 lanes per round (one quad per
+//     round, the first version: 2.83 sources, 45 lanes).
+//   * What is per source in the reduction -- offsets taken, two items at one offset, an undecided implication, the number of items
+//     that stand -- is aggregated through a few LDS atomics on a per-source word instead of ballots over fixed parts of the wave,
+//     so a source may sit on any run of lanes.
+//   * Only REGULAR sources finish here (at most 8 runs, at most 64 entries, one item per offset, every item but one or two implied
+//     by its nearest predecessor -- error-free data at moderate coverage): their one or two edges go straight to first[] /
+//     second[] / deg[].  Any other source is appended to `defer_list` and taken by k_probe_clustered (list mode) afterwards:
+//     nothing is decided twice, nothing is approximated.  A wave that has had to defer more than half of its first sources (reads
+//     with sequencing errors) stops verifying and lists the rest of its share: the decision is taken from THIS build's data.
+//   * The window's bookkeeping lives in few scalar registers (entry counts as packed bytes, flags as bit fields): scalars beyond
+//     ~100 are spilled into VGPR lanes and cost a v_readlane per use inside the loop.
 #ifndef CLQ_OCC
 #define CLQ_OCC 5                      // workgroups per CU: 20 waves per CU (84 VGPRs; at 6 the kernel spills into scratch inside the loop)
 #endif
-struct QuadPlan {                     // of one quad, wave-uniform (scalar registers)
-    int t[4];                         // entries of source g (0: not packed)
-    int start[4], rnd[4];             // first lane and round of source g
-    int nrounds;
-    uint32_t pk, tp;                  // bit g: source g is packed / takes part at all
-};
-
-template <bool STATS, int EQ, int KF, bool BYKEY>
-__global__ void __launch_bounds__(PROBE_WAVES * 64, CLQ_OCC)
-k_probe_quads(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__restrict__ store, const uint4 *__restrict__ dir,
-              const uint2 *__restrict__ runs, const uint8_t *__restrict__ nruns, int32_t src_begin, int32_t src_end, ProbeOut o,
-              int32_t *__restrict__ defer_list, uint32_t defer_cap) {
-    constexpr int WC = 4 * EQ - 3;                         // row words of an entry
-    constexpr int QW = 24;                                 // staged words per source: the row (<= 13) + the compare's slack, words 16.. stay zero
-    __shared__ uint32_t sB[PROBE_WAVES][2][4][QW];
-    __shared__ uint4 sRun[PROBE_WAVES][2][4][CL_RMAX];     // per run: q | p0 << 8 | p1 << 16, cluster key, first entry - slots before the run, entries
-    __shared__ unsigned long long sIncl[PROBE_WAVES][2][4];// per source: inclusive prefix of the runs' entry counts, 8 x u8 (saturating)
-    __shared__ uint2 sSrc[PROBE_WAVES][2][4];              // per source: id, length
-    __shared__ unsigned long long sOcc[PROBE_WAVES][2][4]; // per source: offsets that hold an item
-    __shared__ uint32_t sStat[PROBE_WAVES][2][4];          // per source: bit 0 = irregular, bits 8.. = items that stand
-    __shared__ uint8_t sT[PROBE_WAVES][4][64];             // per source: lane of the item at offset d
-    __shared__ int32_t sDefer[PROBE_WAVES][72];
-    __shared__ uint4 sMask[KF > 0 ? 129 : 1];
-    const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
-    const int lane = lane_id();
-    const int g = lane >> 4, gl = lane & 15;
-    sB[wave][lane >> 5][(lane >> 3) & 3][16 + (lane & 7)] = 0u;       // the slack words, once
-    if constexpr (KF > 0) {
-        for (int t = (int) threadIdx.x; t <= 128; t += PROBE_WAVES * 64)
-            sMask[t] = make_uint4(low_bits32(t), low_bits32(t - 32), low_bits32(t - 64), low_bits32(t - 96));
-        __syncthreads();
-    }
-    wave_lds_fence();
-    uint64_t st_raw = 0, st_slots = 0, st_win = 0, st_rec = 0, st_cmp = 0, st_rounds = 0;
-    int n_defer = 0;                                       // uniform: sources waiting in sDefer
-    int n_seen = 0, n_deferred = 0;                        // uniform: sources of this wave that took part / that it deferred
-    const int step = (int) gridDim.x * PROBE_WAVES * 4;
-    const int kfull = KF ? KF : (2 * cfg.Lmin) >> 5;
-    const int Lbig = cfg.rsoemo > cfg.Lmin ? cfg.rsoemo : cfg.Lmin;
-    auto flush_defer = [&]() {                             // convergent
-        if (n_defer == 0) return;
-        unsigned long long base = 0;
-        if (lane == 0) base = atomicAdd(&o.counters[CNT_DEFERRED], (unsigned long long) n_defer);
-        base = ((unsigned long long) (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) (base >> 32)) << 32) | (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) base);
-        for (int k = lane; k < n_defer; k += 64)
-            if (base + (unsigned long long) k < (unsigned long long) defer_cap) defer_list[base + (unsigned long long) k] = sDefer[wave][k];
-        wave_lds_fence();
-        n_defer = 0;
-    };
-
-    // ---- source stream: quads of consecutive sources, one per 16-lane row, two quads ahead of the one being worked on:
-    //      stage A (registers a_*) = identity, length and row word of the quad after next; stage B (b_*) = the next quad, its A data
-    //      one iteration old plus its run list, which is loaded by id.  Every lane issues every load, unconditionally, at clamped
-    //      addresses (see k_probe_pairs).
-    //      BYKEY = false: the sources are the ids src_begin .. src_end - 1, rows and lengths from the node set.
-    //      BYKEY = true : the sources are taken in the order of the ENTRY ARRAY (positions src_begin .. src_end - 1 of it): id, length
-    //      and row come from the source's own entry (48 sequential bytes).  Consecutive sources then share their prefix minimizer
-    //      -- the same genomic locus -- so the four sources of a quad, and the waves of a workgroup, look up the same directory
-    //      records and the same entries: one fetch serves several lanes and the rest hits the caches, where the id order touched
-    //      ~1.1 KB of HBM per source in isolated lines.
-    const int pre_words = BYKEY ? (4 * EQ - 3) : (nd.stride < 16 ? nd.stride : 16);
-    const int last_src = src_end - 1, col = gl < pre_words ? gl : pre_words - 1;
-    const uint32_t *run_w = reinterpret_cast<const uint32_t *>(runs);
-    int posA = src_begin + 4 * ((int) blockIdx.x * PROBE_WAVES + wave), posB = posA;
-    bool a_valid = false, b_valid = false;
-    int a_id = 0, a_len = 0, b_id = 0, b_len = 0;
-    uint32_t a_word = 0, b_word = 0, b_nrw = 0;
-    uint2 b_run = make_uint2(0u, 0u);
-    auto fetchA = [&]() {
-        const int j = posA + g;
-        a_valid = j < src_end;
-        const int js = j < last_src ? j : last_src;
-        if constexpr (BYKEY) {
-            const uint32_t *ent = reinterpret_cast<const uint32_t *>(store) + (size_t) js * (4 * EQ);
-            a_word = ent[col];
-            a_id = (int) ent[4 * EQ - 3];
-            a_len = (int) ((ent[4 * EQ - 1] >> 8) & 0xFFFu);
-        } else {
-            a_id = js;
-            a_len = nd.len[js];
-            a_word = nd.words[(size_t) js * nd.stride + col];
-        }
-    };
-    auto fetchB = [&]() {                                  // (b_id is a valid node id even where b_valid is false: clamped positions)
-        b_run = runs[(size_t) b_id * CL_RMAX + (gl & (CL_RMAX - 1))];
-        b_nrw = run_w[(size_t) b_id * (2 * CL_RMAX) + 1];  // run 0, second word: nruns in its top byte
-    };
-    auto take = [&](int &id, int &len, int &nrn, uint32_t &word, uint2 &run) {   // the next quad (stage B), masked
-        id = b_id;
-        len = b_valid ? b_len : 0; nrn = b_valid ? (int) (b_nrw >> 24) : 0;
-        word = (b_valid && gl < pre_words) ? b_word : 0u;
-        run = (b_valid && gl < CL_RMAX) ? b_run : make_uint2(0u, 0u);
-    };
-    auto advance = [&](bool adv) {                         // adv (uniform): stage B takes the quad of stage A, stage A moves on
-        b_valid = adv ? a_valid : b_valid; b_id = adv ? a_id : b_id; b_len = adv ? a_len : b_len; b_word = adv ? a_word : b_word;
-        posB = adv ? posA : posB;
-        posA = adv ? (step <= src_end - posA ? posA + step : src_end) : posA;
-        fetchB();
-        fetchA();
-    };
-    fetchA();
-    // stage 1 of a quad: rows -> LDS; bucket of each run (lanes without a run read bucket 0: one shared line)
-    auto stage = [&](int buf, int id, int lenB, int nr_eff, uint32_t word0, const uint2 &run) -> uint32_t {
-        wave_lds_fence();
-        sB[wave][buf][g][gl] = gl < blocks_of(lenB) ? word0 : 0u;
-        if (gl == 0) sSrc[wave][buf][g] = make_uint2((uint32_t) id, (uint32_t) lenB);
-        return gl < nr_eff ? run.x >> cc.idx_shift : 0u;
-    };
-    auto index_loads = [&](uint32_t bucket, uint4 &rec) { rec = dir[bucket]; };   // every lane, no branch
-    // run list of a quad -> LDS; entries are numbered densely over the runs of a source: slot = entries of the runs before + j.
-    // Returns the inclusive prefix of the entry counts (lane 7 of a row: the entries of its source).
-    auto finish_runs = [&](int buf, int nr_eff, const uint2 &run, const uint4 &rec) -> uint32_t {
-        uint32_t e0, cnt;
-        run_slice(rec, run.y, e0, cnt);
-        cnt = gl < nr_eff ? cnt : 0u;                      // lanes gl >= 8 hold no run
-        uint32_t inc = cnt, t;                             // inclusive scan over the runs (lanes 0..7 of the row)
-        t = (uint32_t) __builtin_amdgcn_update_dpp(0, (int) inc, 0x111, 0xF, 0xF, true); inc += t;
-        t = (uint32_t) __builtin_amdgcn_update_dpp(0, (int) inc, 0x112, 0xF, 0xF, true); inc += t;
-        t = (uint32_t) __builtin_amdgcn_update_dpp(0, (int) inc, 0x114, 0xF, 0xF, true); inc += t;
-        if (gl < CL_RMAX) {
-            sRun[wave][buf][g][gl] = make_uint4(run.y, run.x, e0 - (inc - cnt), cnt);
-            reinterpret_cast<uint8_t *>(&sIncl[wave][buf][g])[gl] = (uint8_t) (inc > 255u ? 255u : inc);
-        }
-        if (gl == 0) { sOcc[wave][buf][g] = 0ull; sStat[wave][buf][g] = 0u; }
-        wave_lds_fence();
-        return inc;
-    };
-    // which source goes where: greedy, in id order, a new round whenever the next source does not fit the 64 lanes
-    auto make_plan = [&](uint32_t inc, int nrv, QuadPlan &P) {
-        P.pk = 0u; P.tp = 0u;
-        int rnd = 0, fill = 0;
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int T = __builtin_amdgcn_readlane((int) inc, q * 16 + CL_RMAX - 1), nrq = __builtin_amdgcn_readlane(nrv, q * 16);
-            const bool pk = nrq != 0 && nrq != CL_RUNS_FLAGGED && T <= 64;
-            P.t[q] = pk ? T : 0;
-            P.pk |= pk ? 1u << q : 0u; P.tp |= nrq != 0 ? 1u << q : 0u;
-            if (fill + P.t[q] > 64) { rnd++; fill = 0; }
-            P.start[q] = fill; P.rnd[q] = rnd;
-            fill += P.t[q];
-        }
-        P.nrounds = rnd + 1;
-    };
-
-    bool have = posA < src_end;
-    QuadPlan P{};
-    int B = 0, lenB = 0, nr = 0, buf = 0, r = 0, cur_base = posA;
-    bool red = false;                                      // leader lanes: this row's source is finished
-    if (have) {
-        uint32_t word0; uint2 run;
-        advance(true);                                     // stage B = the first quad, its runs in flight; stage A = the second
-        take(B, lenB, nr, word0, run);
-        advance(true);
-        const int nr_eff = nr == CL_RUNS_FLAGGED ? 0 : nr;
-        uint4 rec0;
-        const uint32_t bk = stage(0, B, lenB, nr_eff, word0, run);
-        index_loads(bk, rec0);
-        const uint32_t inc = finish_runs(0, nr_eff, run, rec0);
-        make_plan(inc, nr, P);
-    }
-    bool bail = false;
-    while (have && !bail) {                                // uniform; one ROUND of the current quad per iteration
-        const bool last = r + 1 >= P.nrounds;              // uniform
-        // ---- (1) the next quad comes off the stream before any entry load is issued (again in every round of this quad) ----
-        const bool have_next = posB < src_end;
-        const int next_base = posB;
-        int nB, nlenB, nnr; uint32_t nword0; uint2 nrun;
-        take(nB, nlenB, nnr, nword0, nrun);
-        advance(last && have_next);                                    // past the end: clamped reads of the last source, never used
-        const int nnr_eff = nnr == CL_RUNS_FLAGGED ? 0 : nnr;
-        // ---- (2) lanes -> sources of this round, entries: loads issued ----
-        int cntg = 0, a = 0, fill_r = 0, ga = 4;
-#pragma unroll
-        for (int q = 3; q >= 0; q--) { if (P.rnd[q] == r) ga = q; }    // scalar
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int lo = P.rnd[q] == r ? P.start[q] : 64;           // scalar
-            fill_r += P.rnd[q] == r ? P.t[q] : 0;
-            const bool c = lane >= lo;
-            cntg += c ? 1 : 0;
-            a = c ? lo : a;
-        }
-        const bool ev = lane < fill_r;
-        const int s = ev ? ga + cntg - 1 : 0;              // 0 .. 3
-        const int hl = ev ? lane - a : 0;                  // slot of this lane in its source
-        const uint2 srec = sSrc[wave][buf][s];
-        const int Bs = (int) srec.x, lenBs = (int) srec.y;
-        const uint32_t *sb = sB[wave][buf][s];
-        uint4 rp = make_uint4(0u, 0u, 0u, 0u);
-        {
-            // run of slot hl: the number of runs whose inclusive prefix is <= hl (binary search over 8 packed bytes)
-            const unsigned long long inc8 = sIncl[wave][buf][s];
-            const uint32_t lo = (uint32_t) inc8, hi = (uint32_t) (inc8 >> 32);
-            int ri = (int) ((lo >> 24) & 255u) <= hl ? 4 : 0;
-            { const uint32_t wv = ri ? hi : lo; ri += (int) ((wv >> 8) & 255u) <= hl ? 2 : 0; }
-            { const uint32_t wv = ri >= 4 ? hi : lo; ri += (int) ((wv >> (8 * (ri & 3))) & 255u) <= hl ? 1 : 0; }
-            if (ev) rp = sRun[wave][buf][s][ri & (CL_RMAX - 1)];
-        }
-        const size_t ei = ev ? (size_t) (rp.z + (uint32_t) hl) : (size_t) 0;
-        uint32_t ew[4 * EQ];
-#pragma unroll
-        for (int c = 0; c < EQ; c++) { const uint4 v = store[ei * EQ + c]; ew[4 * c] = v.x; ew[4 * c + 1] = v.y; ew[4 * c + 2] = v.z; ew[4 * c + 3] = v.w; }
-        // ---- (3) the next quad: rows staged, index loads issued behind the entry loads ----
-        uint32_t nbk = 0;
-        uint4 nrec;
-        if (have_next) nbk = stage(buf ^ 1, nB, nlenB, nnr_eff, nword0, nrun);
-        index_loads(nbk, nrec);
-        // ---- (4) verify: one entry per lane ----
-        const uint32_t id = ew[4 * EQ - 3], eh = ew[4 * EQ - 2], meta = ew[4 * EQ - 1];
-        const int lenC = (int) ((meta >> 8) & 0xFFFu);
-        int p = (int) (rp.x & 255u) - (int) (meta & 255u);
-        // (bitwise &: one straight line of compares instead of a chain of exec-mask branches)
-        const bool ok = ev & same_cluster(eh, rp.y, cc.idx_shift - CL_MBITS) & (p >= (int) ((rp.x >> 8) & 255u)) & (p < (int) ((rp.x >> 16) & 255u)) & ((int) id != Bs) &
-                        (lenC >= lenBs - p);
-        p = ok ? p : 0;
-        const int L = lenBs - p, nb = 2 * L;
-        bool pass;
-        {
-            const int qw = (2 * p) >> 5, sh = (2 * p) & 31;
-            uint32_t y[WC + 1];
-#pragma unroll
-            for (int k = 0; k <= WC; k++) y[k] = sb[qw + k];
-            uint32_t diff = 0;
-            uint32_t mk[4] = {0u, 0u, 0u, 0u};
-            if constexpr (KF > 0) { const uint4 m4 = sMask[min(max(nb - 32 * KF, 0), 128)]; mk[0] = m4.x; mk[1] = m4.y; mk[2] = m4.z; mk[3] = m4.w; }
-#pragma unroll
-            for (int k = 0; k < WC; k++) {
-                const uint32_t x = funnel(y[k], y[k + 1], sh) ^ ew[k];
-                if (k < kfull) diff |= x;
-                else if (KF > 0 && k < KF + 4) diff |= x & mk[(k - KF) & 3];
-                else diff |= x & low_bits32(nb - 32 * k);
-            }
-            pass = ok && diff == 0;
-        }
-        const uint64_t pm = __ballot(pass);
-        const int d = p;
-        const uint32_t v_m = (uint32_t) p | ((uint32_t) lenC << 9) | ((meta & CL_META_FROM) ? ITEM_FROM : 0u);
-        uint32_t stv = 0u;                                 // status word of this lane's source after the reduction
-        bool has_pred = false;
-        if (pm != 0ull) {                                  // uniform
-            uint4 v_o = make_uint4(0u, 0u, 0u, 0u);
-            if (pass) {                                    // overhang: C's row from bit 2L on (see k_probe_clustered)
-                const int ws = nb >> 5, r2 = nb & 31;
-                uint32_t x[5];
-                if constexpr (KF > 0 && WC - KF <= 6) {
-                    const int t = ws - KF;
-#pragma unroll
-                    for (int k = 0; k < 5; k++) {
-                        uint32_t v = 0u;
-#pragma unroll
-                        for (int u = 0; u <= WC - KF; u++) { const int wi = KF + k + u; if (wi < 4 * EQ) v = t == u ? ew[wi] : v; }
-                        x[k] = v;
-                    }
-                } else {
-                    const uint32_t *er = reinterpret_cast<const uint32_t *>(store + ei * EQ);
-#pragma unroll
-                    for (int k = 0; k < 5; k++) x[k] = er[ws + k];
-                }
-                v_o = make_uint4(funnel(x[0], x[1], r2), funnel(x[1], x[2], r2), funnel(x[2], x[3], r2), funnel(x[3], x[4], r2));
-            }
-            // ---- fused single-survivor reduction, every source of the round at once ----
-            unsigned long long *occp = &sOcc[wave][buf][s];
-            uint32_t *stp = &sStat[wave][buf][s];
-            uint8_t *Tb = sT[wave][s];
-            if (pass) { atomicOr(occp, 1ull << d); Tb[d] = (uint8_t) lane; }
-            wave_lds_fence();
-            const uint64_t occ = *occp;                    // (plain LDS reads: a volatile access becomes a flat load and drains vmcnt)
-            const bool clash = pass && Tb[d] != (uint8_t) lane;        // another item of this source sits at the same offset
-            const uint64_t below = pass ? (occ & ((1ull << d) - 1ull)) : 0ull;
-            has_pred = below != 0ull;
-            const int j = has_pred ? (int) Tb[63 - __clzll((long long) below)] : lane;
-            const uint32_t Cj = bperm(id, j), mj = bperm(v_m, j);
-            Ovh<1> oj, oi;
-            oj.w[0] = bperm(v_o.x, j); oj.w[1] = bperm(v_o.y, j); oj.w[2] = bperm(v_o.z, j); oj.w[3] = bperm(v_o.w, j);
-            oi.w[0] = v_o.x; oi.w[1] = v_o.y; oi.w[2] = v_o.z; oi.w[3] = v_o.w;
-            const int rho = lenC - (lenBs - d);
-            bool removed;
-            if constexpr (KF > 0) {
-                // via_ok<1> (prefsuf_device.h) with the four word masks of the overhang compare from the table in LDS
-                const int dj = (int) (mj & 511u), lenj = (int) ((mj >> 9) & 511u);
-                const int rho_j = lenj - (lenBs - dj), Lv = lenj - (d - dj);
-                const bool vok = ((mj & ITEM_FROM) != 0u) & (Cj != id) & (dj < d) & (Lv >= Lbig) & (rho_j <= rho) & ((rho_j > 0) | ((int) Cj > Bs));
-                const uint4 m4 = sMask[min(max(2 * rho_j, 0), 128)];
-                const uint32_t df = ((oi.w[0] ^ oj.w[0]) & m4.x) | ((oi.w[1] ^ oj.w[1]) & m4.y) | ((oi.w[2] ^ oj.w[2]) & m4.z) | ((oi.w[3] ^ oj.w[3]) & m4.w);
-                removed = has_pred & vok & (df == 0u);
-            } else removed = has_pred && via_ok<1>(Bs, lenBs, Lbig, Cj, mj, oj, id, d, rho, oi);
-            // not removed by the nearest predecessor although even the longest read placed there could reach C with a big overlap: undecided here
-            const bool fail = has_pred && !removed && (cfg.Lcap - 1) - (d - (int) (mj & 511u)) >= Lbig;
-            const bool keep = pass && !removed;
-            if (clash || fail) atomicOr(stp, 1u);
-            if (keep) atomicAdd(stp, 0x100u);
-            wave_lds_fence();
-            stv = *stp;
-            if (keep && stv == 0x100u) {                   // the only item that stands: the source's edge
-                o.first[Bs - o.src_base] = ((unsigned long long) id << 32) | (uint32_t) d;
-                o.deg[Bs - o.src_base] = 1u;
-                st_rec++;
-            }
-            // Two items stand (a coverage gap too long for any big via; 1.7 % of the sources at 30x): the rest of local_reduce's
-            // "several stand" branch for exactly two -- the per-source cap (with one item per offset the three largest small (L, C)
-            // are the three small items at the smallest offsets) and "the same target at a smaller offset supersedes" -- and the
-            // one or two edges go to the source's two slots.
-            const bool two = keep && stv == 0x200u;
-            if (__ballot(two) != 0ull) {                   // uniform
-                uint64_t segm = 0ull;                      // the lanes of this lane's source
-#pragma unroll
-                for (int q = 0; q < 4; q++) { const uint64_t mq = __ballot(ev && s == q); segm = s == q ? mq : segm; }
-                const uint64_t km = __ballot(keep) & segm;
-                const int la = km ? __builtin_ctzll(km) : 0, lb = km ? 63 - __builtin_clzll(km) : 0;
-                const int ds0 = lenBs - cfg.rsoemo + 1;                         // first offset of a small overlap
-                const uint64_t lowm = ds0 <= 0 ? 0ull : (ds0 >= 64 ? ~0ull : ((1ull << ds0) - 1ull));
-                const bool my_kept = pass && (d < ds0 || __popcll(below & ~lowm) < 3);
-                const uint32_t Ca = bperm(id, la), Cb = bperm(id, lb);
-                const int da = (int) bperm((uint32_t) d, la), db = (int) bperm((uint32_t) d, lb);
-                const bool ka = bperm(my_kept ? 1u : 0u, la) != 0u, kb = bperm(my_kept ? 1u : 0u, lb) != 0u;
-                const bool fa = ka && (__ballot(my_kept && id == Ca && d < da) & segm) == 0ull;
-                const bool fb = kb && (__ballot(my_kept && id == Cb && d < db) & segm) == 0ull;
-                if (two) {
-                    const unsigned long long mine = ((unsigned long long) id << 32) | (uint32_t) d;
-                    if (lane == la && fa) { o.first[Bs - o.src_base] = mine; o.deg[Bs - o.src_base] = (fb ? 2u : 1u); st_rec++; }
-                    if (lane == lb && fb) {
-                        if (fa) o.second[Bs - o.src_base] = mine;
-                        else { o.first[Bs - o.src_base] = mine; o.deg[Bs - o.src_base] = 1u; }
-                        st_rec++;
-                    }
-                }
-            }
-        }
-        if (STATS) {
-            st_rounds++;
-            const bool fin = ev && (stv & 255u) == 0u && (stv >> 8) <= 2u;      // this lane's source finishes here
-            st_slots += fin; st_raw += fin && pass; st_cmp += fin && has_pred;
-        }
-        // ---- (5) the leader of a row: is its source finished?  (status word of the round the source was packed in) ----
-        {
-            const int my_rnd = g == 0 ? P.rnd[0] : (g == 1 ? P.rnd[1] : (g == 2 ? P.rnd[2] : P.rnd[3]));
-            if (gl == 0 && my_rnd == r) {
-                const uint32_t sv = sStat[wave][buf][g];
-                red = ((P.pk >> g) & 1u) != 0u && (sv & 255u) == 0u && (sv >> 8) <= 2u;
-                if (STATS && red) st_win += (uint64_t) (lenB - cfg.Lmin + 1);
-            }
-        }
-        // ---- (6) the next quad's index loads have had the time of (4) to land ----
-        const uint32_t ninc = finish_runs(buf ^ 1, nnr_eff, nrun, nrec);
-        if (last) {                                        // uniform: this quad is done
-            // sources that do not finish here: to the general kernel
-            const bool dfr = gl == 0 && ((P.tp >> g) & 1u) != 0u && !red;
-            const uint64_t dm = __ballot(dfr);
-            n_seen += __popc(P.tp);
-            if (dm != 0ull) {                              // uniform
-                if (dfr) sDefer[wave][n_defer + (int) __builtin_amdgcn_mbcnt_hi((uint32_t) (dm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) dm, 0u))] = B;
-                n_defer += __popcll(dm);
-                n_deferred += __popcll(dm);
-                wave_lds_fence();
-                if (n_defer >= 60) flush_defer();
-            }
-            have = have_next; B = nB; lenB = nlenB; nr = nnr; buf ^= 1; r = 0; red = false; cur_base = next_base;
-            make_plan(ninc, nr, P);
-            bail = n_seen >= 192 && 2 * n_deferred > n_seen;
-        } else r++;
-    }
-    if (bail) {
-        // most of this wave's sources are irregular: the rest of its share goes to the general kernel unseen
-        for (int q = cur_base; have && q < src_end; q = step <= src_end - q ? q + step : src_end) {     // uniform
-            const int j = q + g < src_end ? q + g : last_src;
-            const int b = BYKEY ? (int) reinterpret_cast<const uint32_t *>(store)[(size_t) j * (4 * EQ) + 4 * EQ - 3] : j;
-            const bool dfr = gl == 0 && q + g < src_end && (run_w[(size_t) b * (2 * CL_RMAX) + 1] >> 24) != 0u;
-            const uint64_t dm = __ballot(dfr);
-            if (dfr) sDefer[wave][n_defer + (int) __builtin_amdgcn_mbcnt_hi((uint32_t) (dm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) dm, 0u))] = b;
-            n_defer += __popcll(dm);
-            wave_lds_fence();
-            if (n_defer >= 60) flush_defer();
-        }
-    }
-    flush_defer();
-    st_rec = wave_sum_u64(st_rec);
-    if (lane == 0 && st_rec) atomicAdd(&o.counters[CNT_VALID_RECORDS], (unsigned long long) st_rec);
-    if (STATS) {
-        st_raw = wave_sum_u64(st_raw); st_slots = wave_sum_u64(st_slots); st_win = wave_sum_u64(st_win); st_cmp = wave_sum_u64(st_cmp);
-        if (lane == 0) {
-            atomicAdd(&o.counters[CNT_RAW], (unsigned long long) st_raw);
-            atomicAdd(&o.counters[CNT_SLOTS], (unsigned long long) st_slots);
-            atomicAdd(&o.counters[CNT_WINDOWS], (unsigned long long) st_win);
-            atomicAdd(&o.counters[CNT_TR_COMPARES], (unsigned long long) st_cmp);
-            atomicAdd(&o.counters[CNT_ROUNDS], (unsigned long long) st_rounds);
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// k_probe_stream : the quad kernel with a SLIDING WINDOW over the source stream
-// ------------------------------------------------------------------------------------------
-// k_probe_quads packs the four sources of ONE quad onto the 64 lanes: at 30x their entries add up to 63 on average, so four in ten
-// quads need a second round and an average round holds 2.8 sources on 45 lanes.  Here the window is TWO quads (eight consecutive
-// sources, both staged, their run lists resolved) and a round takes sources from the cursor on for as long as they fit the 64
-// lanes -- across the quad boundary -- so the lanes fill up whatever the quad's sum is.  When the cursor has passed the older
-// quad it retires (its unfinished sources go on the defer list), the younger one takes its place and the quad staged during
-// this round becomes the younger one: three LDS buffers in rotation, at most one rotation per round (a round never takes the
-// last source of the younger quad, so the quad that follows is always ready when it is needed).
-// Everything per lane -- entry slot, verify, fused reduction through the per-source LDS words -- is k_probe_quads'.
 template <bool STATS, int EQ, int KF, bool BYKEY>
 __global__ void __launch_bounds__(PROBE_WAVES * 64, CLQ_OCC)
 k_probe_stream(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__restrict__ store, const uint4 *__restrict__ dir,
@@ -1488,8 +816,16 @@ k_probe_stream(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__restri
         }
     };
 
-    // ---- source stream (k_probe_quads): quads of consecutive sources, one per 16-lane row; stage A = identity, length and row word of
-    //      the quad after the one stage B holds; stage B = the quad that is staged next, with its run list ----
+    // ---- source stream: quads of consecutive sources, one per 16-lane row; stage A (registers a_*) = identity, length and row word of
+    //      the quad after the one stage B holds; stage B (b_*) = the quad that is staged next: its A data one iteration old plus its
+    //      run list, which is loaded by id.  Every lane issues every load, unconditionally, at clamped addresses: a load under a
+    //      branch makes hipcc wait for it right there.
+    //      BYKEY = false: the sources are the ids src_begin .. src_end - 1, rows and lengths from the node set.
+    //      BYKEY = true : the sources are taken in the order of the ENTRY ARRAY (positions src_begin .. src_end - 1 of it): id, length
+    //      and row come from the source's own entry (48 sequential bytes).  Consecutive sources then share their prefix minimizer
+    //      -- the same genomic locus -- so the sources of a round, and the waves of a workgroup, look up the same directory records
+    //      and the same entries: one fetch serves several lanes and the rest hits the caches, where the id order touched ~1.1 KB
+    //      of HBM per source in isolated lines (150 GB per launch at the north-star size against 64 GB). ----
     const int pre_words = BYKEY ? (4 * EQ - 3) : (nd.stride < 16 ? nd.stride : 16);
     const int last_src = src_end - 1, col = gl < pre_words ? gl : pre_words - 1;
     const uint32_t *run_w = reinterpret_cast<const uint32_t *>(runs);
@@ -1931,35 +1267,11 @@ uint64_t cluster_probe_blocks(int n_cu, uint64_t n_src) {
 
 uint64_t cluster_record_slack(int n_cu, uint64_t n_src) { return cluster_probe_blocks(n_cu, n_src) * PROBE_WAVES * (uint64_t) REC_CHUNK_LOCAL; }
 
-// the pair kernel over the sources src_begin .. src_end - 1: regular sources get their edge, the others go on defer_list
-void launch_probe_pairs(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterCfg &cc, int eq, const void *store, const void *dir,
-                        const void *runs, const uint8_t *nruns, int32_t src_begin, int32_t src_end, unsigned long long *counters, int n_cu, uint32_t *deg,
-                        unsigned long long *first, unsigned long long *second, int32_t *defer_list, uint32_t defer_cap, hipStream_t s) {
-    const int64_t ns = (int64_t) src_end - src_begin;
-    if (ns <= 0) return;
-    const uint64_t pairs = ((uint64_t) ns + 1) / 2;
-    dim3 grid((unsigned) std::max<uint64_t>(1, std::min<uint64_t>((pairs + PROBE_WAVES - 1) / PROBE_WAVES, (uint64_t) std::max(1, n_cu) * CLP_OCC))), block(PROBE_WAVES * 64);
-    ProbeOut o{nullptr, nullptr, 0, counters, deg, first, src_begin, second};
-    const uint4 *st = (const uint4 *) store;
-    const int kf = (2 * cfg.Lmin) >> 5;
-#define CLP_LAUNCH(ST, E, K) hipLaunchKernelGGL((k_probe_pairs<ST, E, K>), grid, block, 0, s, nd, cfg, cc, st, (const uint4 *) dir, (const uint2 *) runs, nruns, src_begin, src_end, o, defer_list, defer_cap)
-#define CLP_STATS(E, K) do { if (cfg.stats) CLP_LAUNCH(true, E, K); else CLP_LAUNCH(false, E, K); } while (0)
-    if (eq == 3 && kf == 5)      CLP_STATS(3, 5);
-    else if (eq == 3 && kf == 3) CLP_STATS(3, 3);
-    else if (eq == 2 && kf == 3) CLP_STATS(2, 3);
-    else if (eq == 2)            CLP_STATS(2, 0);
-    else if (eq == 3)            CLP_STATS(3, 0);
-    else                         CLP_STATS(4, 0);
-#undef CLP_STATS
-#undef CLP_LAUNCH
-}
-
-// the quad kernel (four sources per wave, entries packed densely) over the sources src_begin .. src_end - 1; by_key: over the
-// sources whose entries are at the positions src_begin .. src_end - 1 of the entry array (which holds an entry for every node);
-// window: k_probe_stream (rounds packed from a sliding window of two quads) instead of k_probe_quads (one quad per round)
-void launch_probe_quads(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterCfg &cc, int eq, const void *store, const void *dir,
-                        const void *runs, const uint8_t *nruns, int32_t src_begin, int32_t src_end, bool by_key, bool window, unsigned long long *counters, int n_cu,
-                        uint32_t *deg, unsigned long long *first, unsigned long long *second, int32_t *defer_list, uint32_t defer_cap, hipStream_t s) {
+// k_probe_stream over the sources src_begin .. src_end - 1: regular sources get their edges, the others go on defer_list.  by_key: the
+// range is one of positions of the entry array (which holds an entry for every node), the sources are taken in that order
+void launch_probe_stream(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterCfg &cc, int eq, const void *store, const void *dir,
+                         const void *runs, const uint8_t *nruns, int32_t src_begin, int32_t src_end, bool by_key, unsigned long long *counters, int n_cu,
+                         uint32_t *deg, unsigned long long *first, unsigned long long *second, int32_t *defer_list, uint32_t defer_cap, hipStream_t s) {
     const int64_t ns = (int64_t) src_end - src_begin;
     if (ns <= 0) return;
     const uint64_t quads = ((uint64_t) ns + 3) / 4;
@@ -1967,8 +1279,7 @@ void launch_probe_quads(const NodesDev &nd, const PrefSufCfg &cfg, const Cluster
     ProbeOut o{nullptr, nullptr, 0, counters, deg, first, by_key ? 0 : src_begin, second};
     const uint4 *st = (const uint4 *) store;
     const int kf = (2 * cfg.Lmin) >> 5;
-#define CLQ_ARGS grid, block, 0, s, nd, cfg, cc, st, (const uint4 *) dir, (const uint2 *) runs, nruns, src_begin, src_end, o, defer_list, defer_cap
-#define CLQ_LAUNCH(ST, E, K, BK) do { if (window) hipLaunchKernelGGL((k_probe_stream<ST, E, K, BK>), CLQ_ARGS); else hipLaunchKernelGGL((k_probe_quads<ST, E, K, BK>), CLQ_ARGS); } while (0)
+#define CLQ_LAUNCH(ST, E, K, BK) hipLaunchKernelGGL((k_probe_stream<ST, E, K, BK>), grid, block, 0, s, nd, cfg, cc, st, (const uint4 *) dir, (const uint2 *) runs, nruns, src_begin, src_end, o, defer_list, defer_cap)
 #define CLQ_ORDER(ST, E, K) do { if (by_key) CLQ_LAUNCH(ST, E, K, true); else CLQ_LAUNCH(ST, E, K, false); } while (0)
 #define CLQ_STATS(E, K) do { if (cfg.stats) CLQ_ORDER(true, E, K); else CLQ_ORDER(false, E, K); } while (0)
     if (eq == 3 && kf == 5)      CLQ_STATS(3, 5);
@@ -1980,7 +1291,6 @@ void launch_probe_quads(const NodesDev &nd, const PrefSufCfg &cfg, const Cluster
 #undef CLQ_STATS
 #undef CLQ_ORDER
 #undef CLQ_LAUNCH
-#undef CLQ_ARGS
 }
 
 // src_list == null: the sources are the ids src_begin .. src_end - 1; else the ids src_list[src_begin .. src_end - 1]

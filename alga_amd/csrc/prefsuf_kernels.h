@@ -46,17 +46,14 @@ hipError_t launch_cluster_store(const NodesDev &nd, const ClusterCfg &cc, int eq
                                 size_t sort_temp_bytes, void *store, void *dir, bool fill_vals, hipEvent_t ev_sorted /* may be null */,
                                 hipEvent_t ev_gathered /* may be null */, hipStream_t s);
 uint64_t   cluster_record_slack(int n_cu, uint64_t n_src);
-void       launch_probe_pairs(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterCfg &cc, int eq, const void *store, const void *dir,
-                              const void *runs, const uint8_t *nruns, int32_t src_begin, int32_t src_end, unsigned long long *counters, int n_cu, uint32_t *deg,
-                              unsigned long long *first, unsigned long long *second, int32_t *defer_list, uint32_t defer_cap, hipStream_t s);
 void       launch_probe_clustered(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterCfg &cc, int eq, const void *store, const void *dir,
                                   const void *runs, const uint8_t *nruns, int32_t src_begin, int32_t src_end, const int32_t *src_list, int32_t src_base, uint32_t *rec_dst, unsigned long long *rec_val, uint64_t rec_cap,
                                   unsigned long long *counters, int n_cu, uint32_t *deg, unsigned long long *first, const ProbeBig *big,
                                   const unsigned long long *list_count /* device, may be null: list mode ends at min(src_end, *list_count) */, hipStream_t s);
-void       launch_probe_quads(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterCfg &cc, int eq, const void *store, const void *dir,
-                              const void *runs, const uint8_t *nruns, int32_t src_begin, int32_t src_end, bool by_key /* the range is one of entry-array positions */, bool window /* k_probe_stream */,
-                              unsigned long long *counters, int n_cu, uint32_t *deg, unsigned long long *first, unsigned long long *second, int32_t *defer_list,
-                              uint32_t defer_cap, hipStream_t s);
+void       launch_probe_stream(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterCfg &cc, int eq, const void *store, const void *dir,
+                               const void *runs, const uint8_t *nruns, int32_t src_begin, int32_t src_end, bool by_key /* the range is one of entry-array positions */,
+                               unsigned long long *counters, int n_cu, uint32_t *deg, unsigned long long *first, unsigned long long *second, int32_t *defer_list,
+                               uint32_t defer_cap, hipStream_t s);
 
 size_t     sort_u32_pairs_temp_bytes(uint64_t n);
 hipError_t sort_u32_pairs(void *temp, size_t temp_bytes, const uint32_t *keys_in, uint32_t *keys_out, const uint32_t *vals_in, uint32_t *vals_out,

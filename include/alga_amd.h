@@ -114,11 +114,11 @@ typedef struct {
     uint64_t generic_sources;     /* SOURCE_SIDE: sources that needed the all-pairs path (collect_stats) */
     uint64_t big_sources;         /* SOURCE_SIDE: sources with more raw overlaps than a wave's LDS holds (second pass) */
     uint64_t probe_used;          /* alga_probe of the last build (1 or 2)                       */
-    uint64_t deferred_sources;    /* CLUSTER probe: sources the pair kernel handed to the general kernel (all of them when it was skipped) */
-    double   ms_probe_pairs;      /* CLUSTER probe: the first kernel's (quad / pair kernel) part of ms_probe (0: not run) */
+    uint64_t deferred_sources;    /* CLUSTER probe: sources the first kernel handed to the general kernel (all of them when it was skipped) */
+    double   ms_probe_pairs;      /* CLUSTER probe: the first kernel's (k_probe_stream) part of ms_probe (0: not run) */
     double   ms_keys, ms_sort, ms_gather, ms_dir; /* CLUSTER probe: the parts of ms_seed -- k_node_runs, radix sort of (key, id),
                                      k_tgt_gather, k_tgt_dir (0 for a build that reused them: keys_shared)         */
-    uint64_t probe_rounds;        /* CLUSTER probe, quad kernel: wave iterations (collect_stats); 4 * rounds / sources = lanes' worth of sources per round */
+    uint64_t probe_rounds;        /* CLUSTER probe, k_probe_stream: rounds = wave iterations (collect_stats); sources / rounds = sources packed per round */
 } alga_prefsuf_stats;
 
 /* ---- lifetime --------------------------------------------------------------------------- */
@@ -131,10 +131,9 @@ int         alga_engine_device_name(const alga_engine *e, char *buf, size_t bufl
 /* Engine switches.  None changes a result, only how it is computed; there are no environment variables.
  *   "probe"                      alga_probe (default AUTO)
  *   "cluster_bucket_bias"        -8..8: log2 factor on the bucket count of the CLUSTER probe's index (default 0: ~1 entry per bucket)
- *   "cluster_pairs"              0: the CLUSTER probe runs its general kernel only (one source per wave); 1: the pair kernel (two
- *                                sources per wave) first, the general kernel on what it defers; default 2: the quad kernel (four
- *                                sources per wave, their entries packed densely onto the lanes) first
- *   "cluster_order"              default 1: the quad kernel takes the sources in the order of the entry array (sources of one locus together:
+ *   "cluster_pairs"              0: the CLUSTER probe runs its general kernel only (one source per wave); default 1: k_probe_stream first
+ *                                (the entries of consecutive sources packed densely onto the lanes), the general kernel on what it defers
+ *   "cluster_order"              default 1: k_probe_stream takes the sources in the order of the entry array (sources of one locus together:
  *                                shared look-ups, cache hits); 0: in id order (what a range of ids always gets)
  *   "local_big_max"              largest per-wave item slice of the SOURCE_SIDE second pass (default -1 = built-in 4096); beyond it
  *                                the build takes PER_TARGET

@@ -53,7 +53,9 @@ def test_makefile_builds_the_adapter_where_the_reference_is_present():
     assert os.path.exists(EXE)
     syms = subprocess.run(["nm", "-C", EXE], capture_output=True, text=True).stdout
     assert "GraphCreatorPrefSufHIP::startAlignmentGraphCreation" in syms and "GraphCreatorLIHIP::startAlignmentGraphCreation" in syms
-    assert "alga_prefsuf_build_host" in syms and "alga_pkb_supplement_host" in syms      # bound through the C ABI
+    # bound through the C ABI: one upload per process (alga_adapter::Session), the stages on the resident node set
+    for sym in ("alga_upload_nodes", "alga_prefsuf_build_device", "alga_pkb_supplement_device", "alga_download_edges", "alga_engine_reserve"):
+        assert sym in syms, sym
 
 
 @needs_exe

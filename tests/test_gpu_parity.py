@@ -49,9 +49,8 @@ def _check(eng, words, lens, lo, rs, af=None, at=None, stats=True, source_side=N
         if maxlen - lo + 1 > lo - kk + 1:
             kk = 2 * lo - maxlen
         clusterable = 1 <= maxlen - lo + 1 <= 64 and (2 * maxlen + 31) // 32 <= 13 and 8 <= kk <= min(32, lo)
-        # the clustered probe with its quad kernel first -- sliding window (3, the default) and one quad per round (2), sources in key
-        # order and in id order -- and with round 2's pair kernel first
-        for probe, first_kernel, order in (("table", 3, 1), ("cluster", 3, 1), ("cluster", 3, 0), ("cluster", 2, 1), ("cluster", 2, 0), ("cluster", 1, 1)):
+        # the clustered probe with k_probe_stream first (the default), sources in key order and in id order, and its general kernel alone
+        for probe, first_kernel, order in (("table", 1, 1), ("cluster", 1, 1), ("cluster", 1, 0), ("cluster", 0, 1)):
             eng.set_option("probe", probe)
             eng.set_option("cluster_pairs", first_kernel)
             eng.set_option("cluster_order", order)
@@ -59,7 +58,7 @@ def _check(eng, words, lens, lo, rs, af=None, at=None, stats=True, source_side=N
                 got2 = eng.prefsuf_host(words, lens, lo, rs, af, at, collect_stats=stats, reduction="source_side")
             finally:
                 eng.set_option("probe", "auto")
-                eng.set_option("cluster_pairs", 3)
+                eng.set_option("cluster_pairs", 1)
                 eng.set_option("cluster_order", 1)
             assert got2.shape == want.shape and (got2 == want).all(), (probe, first_kernel, order)
             st = eng.last_stats()
@@ -380,14 +379,14 @@ def test_exchange_helpers_emulated_ranks(eng):
 def test_cluster_directory_geometries(n, length, G, seed, err, minlen, lo, rs):
     """the clustered probe with every shape of its bucket directory: few huge buckets (more than 255 entries: the directory's byte
     offsets saturate and a run reads the whole bucket), one cluster per bucket, more buckets than the key has bits for (clamped);
-    with the quad kernel, the pair kernel or the general kernel alone.  Always the same graph."""
+    with k_probe_stream first or the general kernel alone.  Always the same graph."""
     words, lens = _nodes(n, length, G, seed, err, minlen)
     want, _, _ = O.prefsuf(words, lens, lo, rs)
     e = alga_amd.Engine(0)
     try:
         e.set_option("probe", "cluster")
         for bias in (-8, -4, 0, 3, 8):
-            for pairs, order in ((3, 1), (3, 0), (2, 1), (2, 0), (1, 1), (0, 1)):      # first kernel; sources in key / id order
+            for pairs, order in ((1, 1), (1, 0), (0, 1)):      # k_probe_stream first (sources in key / id order); the general kernel alone
                 e.set_option("cluster_bucket_bias", bias)
                 e.set_option("cluster_pairs", pairs)
                 e.set_option("cluster_order", order)
