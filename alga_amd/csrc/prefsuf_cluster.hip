@@ -69,21 +69,21 @@ __device__ __forceinline__ uint32_t compress_even(uint32_t x) {
 
 // Cluster key of a minimizer = a second, bijective mix of its order hash.  The order hashes of MINIMIZERS are minima of w
 // uniform values -- concentrated near zero -- so bucketing the entry array by their own top bits would put most clusters in
-// 1/w of the buckets; the mix spreads them evenly.  The bits outside the m_C field (tgt_sort_key below) are never all ones: the
-// sort key of a target then never is 0xFFFFFFFF ("not a target") whatever its m_C, and m_C can be read back from it.
+// 1/w of the buckets; the mix spreads them evenly.  The BUCKET bits (above the m_C field, tgt_sort_key below) are never all ones:
+// the sort key of a target then never is 0xFFFFFFFF ("not a target") whatever its m_C, m_C can be read back from it, and a sort
+// on the bucket bits alone already puts every target before every non-target (the last bucket stays empty).
 __device__ __forceinline__ uint32_t cluster_key(uint32_t h, int fs) {
     uint32_t k = h * 0x9E3779B1u;                          // (one multiply instead of three: +2 % entries scanned, +28 % deferred sources)
     k ^= k >> 15;
     k *= 0x85EBCA77u;
     k ^= k >> 13;
     k *= 0xC2B2AE3Du;
-    const uint32_t fm = ((1u << CL_MBITS) - 1u) << fs;
-    return (k | fm) == 0xFFFFFFFFu ? k ^ 0x80000000u : k;
+    return (k >> (fs + CL_MBITS)) == (0xFFFFFFFFu >> (fs + CL_MBITS)) ? k ^ 0x80000000u : k;
 }
 
 // Sort key of a target: the cluster key with the CL_MBITS bits right below its bucket bits replaced by m_C, the position of the
 // minimizer in the target's prefix (field at bit fs = idx_shift - CL_MBITS).  Inside a bucket the entries are therefore ordered
-// by m_C first, and the directory (k_tgt_dir) knows where every eighth of that order starts: a source run that covers the
+// by m_C >> 3 first (the sort stops there: launch_cluster_store), and the directory (k_tgt_dir) knows where every eighth of that order starts: a source run that covers the
 // windows [p0, p1) with its minimizer at q can only match targets with q - p1 < m_C <= q - p0 and reads that slice of the bucket
 // alone -- the other entries of the cluster are the reads of the same locus that start too far left or right of the run's
 // windows (half of them at 30x coverage).  0xFFFFFFFF stays reserved for "not a target".
@@ -1242,7 +1242,10 @@ hipError_t launch_cluster_store(const NodesDev &nd, const ClusterCfg &cc, int eq
     if (nd.n <= 0) return hipSuccess;
     const uint64_t n = (uint64_t) nd.n;
     if (fill_vals) hipLaunchKernelGGL(k_iota, dim3((unsigned) std::min<uint64_t>((n + 255) / 256, 8192)), dim3(256), 0, s, vals, (uint32_t) n);
-    hipError_t err = sort_u32_pairs(sort_temp, sort_temp_bytes, keys, keys2, vals, vals2, n, s);
+    // The order the directory and the probe need: bucket, then m_C >> 3 (the directory's eight classes).  The key bits below that --
+    // the low three of m_C, the cluster bits under the field -- are compared entry by entry by the probe, never searched: they stay
+    // unsorted (29 significant bits at the north-star size: three radix passes instead of four).
+    hipError_t err = sort_u32_pairs(sort_temp, sort_temp_bytes, keys, keys2, vals, vals2, n, cc.idx_shift - 3, s);
     if (err != hipSuccess) return err;
     if (ev_sorted) (void) hipEventRecord(ev_sorted, s);
     const uint64_t pieces = n * (uint64_t) eq;

@@ -57,7 +57,7 @@ void       launch_probe_stream(const NodesDev &nd, const PrefSufCfg &cfg, const 
 
 size_t     sort_u32_pairs_temp_bytes(uint64_t n);
 hipError_t sort_u32_pairs(void *temp, size_t temp_bytes, const uint32_t *keys_in, uint32_t *keys_out, const uint32_t *vals_in, uint32_t *vals_out,
-                          uint64_t n, hipStream_t s);
+                          uint64_t n, int begin_bit /* the bits below it are not looked at */, hipStream_t s);
 size_t     sort_u64_pairs_temp_bytes(uint64_t n, int bits);
 hipError_t sort_u64_pairs(void *temp, size_t temp_bytes, const unsigned long long *keys_in, unsigned long long *keys_out,
                           const unsigned long long *vals_in, unsigned long long *vals_out, uint64_t n, int bits, hipStream_t s);

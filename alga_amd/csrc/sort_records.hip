@@ -57,18 +57,37 @@ hipError_t sort_u64_pairs(void *temp, size_t temp_bytes, const unsigned long lon
     return rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t) n, 0u, (unsigned) bits, s);
 }
 
-// stable sort of (u32 key, u32 value) on all 32 key bits: targets by minimizer hash (prefsuf_cluster.hip)
+// stable sort of (u32 key, u32 value) on the key bits [begin_bit, 32): targets by minimizer key (prefsuf_cluster.hip).  rocPRIM's
+// onesweep sort moves every pair once per pass; its gfx950 default takes 8 bits per pass (1024 threads x 16 items, match ranking).
+// 25 .. 30 significant bits -- the north-star index build sorts 29 -- go in THREE passes of 10 bits instead of four of 8: a 10-bit pass
+// costs 0.75 ms at 90.6 M pairs against 0.66 ms (tools/micro/sort_bits.hip: 2.26 against 2.65 ms), 9 bits per pass cost the same as
+// 8, 11 bits (512 x 16: the counters of 1024 threads no longer fit the LDS) twice as much.
+using Sort10 = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                          rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 16>, rocprim::kernel_config<1024, 16>, 10,
+                                                                              rocprim::block_radix_rank_algorithm::match>>;
+static bool sort_u32_three_wide_passes(int begin_bit) { const int bits = 32 - begin_bit; return bits > 24 && bits <= 30; }
+
 size_t sort_u32_pairs_temp_bytes(uint64_t n) {
-    size_t bytes = 0;
-    (void) rocprim::radix_sort_pairs(nullptr, bytes, (const uint32_t *) nullptr, (uint32_t *) nullptr, (const uint32_t *) nullptr,
+    size_t a = 0, b = 0;
+    (void) rocprim::radix_sort_pairs(nullptr, a, (const uint32_t *) nullptr, (uint32_t *) nullptr, (const uint32_t *) nullptr,
                                      (uint32_t *) nullptr, (size_t) n, 0u, 32u, (hipStream_t) 0);
-    return bytes;
+    (void) rocprim::radix_sort_pairs<Sort10>(nullptr, b, (const uint32_t *) nullptr, (uint32_t *) nullptr, (const uint32_t *) nullptr,
+                                             (uint32_t *) nullptr, (size_t) n, 2u, 32u, (hipStream_t) 0);
+    return a > b ? a : b;
 }
 
 hipError_t sort_u32_pairs(void *temp, size_t temp_bytes, const uint32_t *keys_in, uint32_t *keys_out, const uint32_t *vals_in, uint32_t *vals_out,
-                          uint64_t n, hipStream_t s) {
+                          uint64_t n, int begin_bit, hipStream_t s) {
     if (n == 0) return hipSuccess;
-    return rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t) n, 0u, 32u, s);
+    if (begin_bit < 0 || begin_bit > 31) return hipErrorInvalidValue;
+    // Below rocPRIM's merge-sort limit (2^20 pairs by default) a sort on the bits [b, 32) of a 32-bit key goes through
+    // radix_merge_compare, whose mask is built as (T(1) << 32) - 1 -- undefined, in practice 0: the comparison then looks at the bits
+    // BELOW b only (rocPRIM 4.2.0, device/detail/device_radix_sort.hpp:685).  Small inputs are sorted on all 32 bits; the skipped
+    // bits only ever matter for the pass count of the onesweep sort of large ones.
+    if (n < (1ull << 22)) begin_bit = 0;
+    if (sort_u32_three_wide_passes(begin_bit))
+        return rocprim::radix_sort_pairs<Sort10>(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t) n, (unsigned) begin_bit, 32u, s);
+    return rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t) n, (unsigned) begin_bit, 32u, s);
 }
 
 size_t sort_u64_keys_temp_bytes(uint64_t n) {

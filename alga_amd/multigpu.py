@@ -352,3 +352,58 @@ class ShardedPrefSuf:
 
     def edges_numpy(self):
         return self.edges.cpu().numpy().astype(np.int32).copy()
+
+
+def graph_digest(runner):
+    """One step -> (edges, [count, position-weighted checksum] of the complete graph on rank 0, as every rank sees them).
+    int64 wrap-around arithmetic: depends on the order of the list, not only on its content."""
+    import torch
+    m, _ = runner.step()
+    e, dev = runner.edges, runner.be.device
+    d = torch.zeros(2, dtype=torch.int64, device=dev)
+    k = int(e.shape[0])
+    if runner.rank == 0 and k:
+        e64 = e.to(torch.int64)
+        w = torch.arange(1, k + 1, dtype=torch.int64, device=e.device) | 1
+        d[0] = k
+        d[1] = (((e64[:, 0] * 1000003 + e64[:, 1]) * 10007 + e64[:, 2]) * w).sum()
+        del e64, w
+    if runner.world > 1:
+        alld = torch.empty(2 * runner.world, dtype=torch.int64, device=dev)
+        runner.dist.all_gather_into_tensor(alld, d)
+        d = alld[:2]
+    return int(m), [int(x) for x in d.cpu()]
+
+
+def validated_runner(backend, rank, world, dist, plain=None, **fast_kw):
+    """The driver to time at N > 1 -> (runner, {"form", "validated"}).  ShardedPrefSuf's defaults are its plainest form (every rank
+    computes all keys, one piece per rank).  The faster one -- keys of the own nodes only + in-place key all-gather, the source range in
+    pieces whose edge transfers overlap the next piece's probe -- is returned only after it has reproduced, in THIS process group and
+    over its real transport, the plain form's complete graph on rank 0 byte for byte (count + position-weighted checksum); on any
+    difference, or when a rank's collective raises, all ranks stay with the plain form.  Two steps (one per form) are spent on it."""
+    import torch
+    plain = plain if plain is not None else ShardedPrefSuf(backend, rank, world, dist)
+    form = {"form": "plain (all keys on every rank, one piece per rank)", "validated": None}
+    if world <= 1:
+        return plain, form
+    kw = dict(shard_keys=True, pieces=None)
+    kw.update(fast_kw)
+    ok, why, fast, m_plain = 0, "", None, 0
+    try:
+        m_plain, d_plain = graph_digest(plain)
+        fast = ShardedPrefSuf(backend, rank, world, dist, **kw)
+        m_fast, d_fast = graph_digest(fast)
+        ok = int(m_plain == m_fast and d_plain == d_fast and d_plain[0] == m_plain)
+        if not ok:
+            why = "graphs differ: plain %s / %d edges, sharded %s / %d edges" % (d_plain, m_plain, d_fast, m_fast)
+    except (RuntimeError, ValueError, TypeError, AssertionError) as e:            # a refused collective: stay with the plain form
+        why = "%s: %s" % (type(e).__name__, e)
+    t = torch.tensor([ok], dtype=torch.int64, device=backend.device)
+    dist.all_reduce(t)
+    if int(t.item()) == world:
+        form = {"form": "keys of own nodes + in-place key all-gather, %d pieces per rank (edge transfers overlap the next piece's probe)" % fast.pieces,
+                "validated": "complete graph on rank 0 byte-identical (count + position-weighted checksum) to the plain form's in this run: %d edges" % m_plain}
+        return fast, form
+    form["validated"] = "sharded form NOT taken: " + (why or "another rank failed its check")
+    return plain, form
+

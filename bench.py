@@ -138,6 +138,7 @@ def main():
     ap.add_argument("--no-first-call", action="store_true")
     ap.add_argument("--cpu-sample-reads", type=int, default=1_000_000, help="reads of the workload the CPU baseline runs on (~10 s of the reference at 16 threads)")
     ap.add_argument("--probe", default="auto", choices=["auto", "table", "cluster"])
+    ap.add_argument("--multi-plain", action="store_true", help="N > 1: time the driver's plainest form (no sharded key pass, no pieces)")
     args = ap.parse_args()
 
     import torch
@@ -156,7 +157,9 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        import datetime
+        # a collective that never completes aborts the job after 5 minutes instead of holding the node
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=300))
 
     # ---- workload (synthetic).  Every rank builds the same node set on its own GPU: the generator is seeded. ----------------
     n_reads, read_len, G, seed, err = workload.CONFIGS[args.config]
@@ -215,12 +218,23 @@ def main():
                          "buffer sized from the node count + a miniature build of the same shape that makes the HIP runtime load the kernels' code objects -- an assembler "
                          "calls it while it still parses / uploads); (b) unprepared = a second fresh engine of the same process without reserve: it allocates inside its build, "
                          "but finds the code objects loaded.  Without either, the first build of a process took 58 ms at this size (code-object loading ~20 ms, allocations ~1 ms).")
-    runner = multigpu.ShardedPrefSuf(multigpu.HipBackend(eng, d_words, d_lens, lo, rs), rank, world, dist)
+    backend = multigpu.HipBackend(eng, d_words, d_lens, lo, rs)
+    runner = multigpu.ShardedPrefSuf(backend, rank, world, dist)
 
     def sync_all():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
+
+    # N > 1: the driver's defaults are its plainest form (every rank computes all keys, one piece per rank: ADVICE of round 2).  The
+    # faster one -- keys of the own nodes only + in-place key all-gather, the source range in pieces whose edge transfers overlap the
+    # next piece's probe -- is taken for the timed steps only after it has reproduced, in THIS run and over the real transport, the
+    # plain form's complete graph on rank 0 byte for byte (count + position-weighted checksum); otherwise the plain form is timed.
+    multi_form = None
+    if world > 1 and not args.multi_plain:
+        runner, multi_form = multigpu.validated_runner(backend, rank, world, dist, plain=runner)
+    elif world > 1:
+        multi_form = {"form": "plain (all keys on every rank, one piece per rank)", "validated": "--multi-plain"}
 
     def step(collect_stats=False):
         """one pass of the hot path over the resident read set -> (edges of the graph handed to the simplifier, stats)"""
@@ -368,6 +382,7 @@ def main():
                                              "efficiency": ref["ms_per_step"] / (world * ms_step)}
             except Exception:
                 pass
+            out["multi_gpu_form"] = multi_form
             out["multi_gpu_validation"] = "the N-rank path has not run over RCCL on hardware (no multi-GPU node available to the builder): N-rank graph == one-GPU graph is checked over gloo and as N ranks on one GPU only"
         out["src_sha256"] = src_sha
         if world == 1 and not args.no_pcie and not supplement:

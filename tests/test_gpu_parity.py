@@ -530,6 +530,38 @@ def test_sharded_driver_three_ranks_one_gpu_at_a_payload_that_can_race():
         assert got.shape == want.shape and (got == want).all()
 
 
+def test_validated_runner_three_ranks_one_gpu():
+    """What bench.py --gpus N times (alga_amd.multigpu.validated_runner): the sharded key pass + pieces after their graph equalled
+    the plain form's, on the real HipBackend at 1 M reads, three ranks on this GPU."""
+    import torch
+    from alga_amd import workload
+    from alga_amd.multigpu import HipBackend, validated_runner
+    from fake_dist import run_ranks
+    wl = workload.build("cfg2_1M_150bp", stride_words="aligned")
+    lo, rs = wl["min_overlap"], wl["rsoemo"]
+    dw = torch.from_numpy(wl["words"].view(np.int32)).cuda()
+    dl = torch.from_numpy(wl["lens"]).cuda()
+    e0 = alga_amd.Engine(0)
+    try:
+        ptr, m = e0.prefsuf_device(dw, dl, lo, rs)
+        want = alga_amd.engine.device_view(ptr, (m, 3), dw.device).cpu().numpy().astype(np.int32).copy()
+    finally:
+        e0.close()
+
+    def rank_main(rank, dist):
+        e = alga_amd.Engine(0)
+        try:
+            run, form = validated_runner(HipBackend(e, dw, dl, lo, rs), rank, 3, dist)
+            assert form["form"].startswith("keys of own nodes") and run.pieces == 4 and run.shard_keys, form
+            m_r, _ = run.step()
+            assert m_r == len(want)
+            return run.edges_numpy()
+        finally:
+            e.close()
+    res = run_ranks(3, rank_main)
+    assert res[0].shape == want.shape and (res[0] == want).all()
+
+
 def test_contig_like_inputs_second_call_of_the_reference(eng):
     """src/main.cpp:633-656 calls the same creator once more on the CONTIGS (kb-long "reads", min_overlap = rsoemo = 25, overlap
     lengths capped at 501): not on the benchmark path, but the engine takes it (per-target form: the reads are far too long for

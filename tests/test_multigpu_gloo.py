@@ -201,6 +201,56 @@ def test_sharded_driver_over_gloo_equals_oracle(tmp_path, world, source_side, de
             assert len(got) == 0
 
 
+def _worker_validated(rank, world, port, words, lens, lo, rs, out_dir, corrupt):
+    import torch.distributed as dist
+    from alga_amd import multigpu
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        be = PyBackend(words, lens, lo, rs, True, None, rank)
+        if corrupt and rank == 1:
+            inner = be.build_range
+
+            def bad(a, b, collect_stats=False, keys_shared=0):      # the sharded form (keys_shared != 0) of one rank loses an edge
+                e = inner(a, b, collect_stats, keys_shared=keys_shared)
+                return e[1:] if keys_shared and len(e) else e
+            be.build_range = bad
+        run, form = multigpu.validated_runner(be, rank, world, dist)
+        m, _ = run.step()
+        with open(os.path.join(out_dir, "form_%d.txt" % rank), "w") as f:
+            f.write("%d|%d|%s|%s" % (m, run.pieces, form["form"], form["validated"]))
+        np.save(os.path.join(out_dir, "edges_%d.npy" % rank), run.edges_numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("corrupt", [False, True])
+def test_validated_runner_takes_the_sharded_form_only_when_it_reproduces_the_plain_one(tmp_path, corrupt):
+    """bench.py --gpus N: the sharded key pass + pieces are timed only after their graph equalled the plain form's in the same
+    process group (alga_amd.multigpu.validated_runner); a rank whose sharded form differs makes ALL ranks stay plain."""
+    import gen_reads
+    import oracle_lib as O
+    import alga_amd
+    codes, lens = gen_reads.sample_reads(150, 60, 400, 78)
+    rc = (3 - codes)[:, ::-1]
+    codes = np.stack([rc, codes], axis=1).reshape(-1, 60)
+    lens = np.repeat(lens, 2).astype(np.int32)
+    words = alga_amd.pack_reads(codes, lens)
+    lo, rs = 25, 40
+    want, _, _ = O.prefsuf(words, lens, lo, rs)
+    mp.spawn(_worker_validated, args=(2, _free_port(), words, lens, lo, rs, str(tmp_path), corrupt), nprocs=2, join=True)
+    for r in range(2):
+        m, pieces, form, validated = open(str(tmp_path / ("form_%d.txt" % r))).read().split("|", 3)
+        assert int(m) == len(want)
+        if corrupt:
+            assert form.startswith("plain") and "NOT taken" in validated and int(pieces) == 1
+        else:
+            assert form.startswith("keys of own nodes") and "byte-identical" in validated and int(pieces) > 1
+    got = np.load(str(tmp_path / "edges_0.npy"))
+    assert got.shape == want.shape and (got == want).all()
+
+
 def test_shard_bounds_keep_twins_together():
     from alga_amd.multigpu import shard_bounds
     for n in (0, 2, 10, 1700526, 99999998):
