@@ -329,14 +329,16 @@ __global__ void __launch_bounds__(256) k_tgt_gather(NodesDev nd, const uint32_t 
     store[j * EQ + c] = v;
 }
 
-// dir[b] = {first entry of bucket b (of the next non-empty one if b is empty), entries of bucket b, byte offsets of the eight
-// m_C >> 3 classes inside it}, for b in [0, n_buckets]; non-targets (all-ones keys) count as bucket n_buckets.  One thread per
-// entry of the sorted key array plus one past its end: the thread of the FIRST entry of a bucket makes the record of that
-// bucket and of the empty buckets before it.  One streaming pass over the keys, a tile of them (and what follows it) staged in
+// dir[b] = {first entry of bucket b, entries of bucket b, byte offsets of the eight m_C >> 3 classes inside it} for the NON-EMPTY
+// buckets b in [0, n_buckets]; non-targets (all-ones keys) count as bucket n_buckets.  The directory is zero-filled before this
+// kernel (launch_cluster_store): an all-zero record reads as "no entries" (run_slice), and nine of ten buckets are empty at one
+// bucket per node -- their records used to be written one by one from here (1.07 GB of 16-byte stores: 1.1 ms against 0.2 ms of fill
+// + 0.2 ms for the non-empty ones).  One thread per entry of the sorted key array plus one past its end: the thread of the FIRST
+// entry of a bucket makes its record.  One streaming pass over the keys, a tile of them (and what follows it) staged in
 // LDS so that a bucket is walked at LDS latency (round 2: an index array first, then a second pass through global memory per
 // bucket).  Measured and rejected: folding this pass into k_tgt_gather (the walk serialises behind that kernel's random row
 // reads: 6.5 against 3.0 + 1.2 ms); collecting the records of a tile in LDS and writing them out as whole lines (1.4 against 1.2 ms).
-constexpr int TD_TILE = 256, TD_HALO = 96;                 // entries per tile; entries staged past it
+constexpr int TD_TILE = 256, TD_HALO = 96;                 // entries per tile (512 and 1024 measure the same); entries staged past it
 __global__ void __launch_bounds__(TD_TILE) k_tgt_dir(const uint32_t *__restrict__ keys, uint64_t n, int shift, uint32_t n_buckets, uint4 *__restrict__ dir) {
     __shared__ uint32_t sb[TD_TILE + TD_HALO + 1];         // (bucket << 3 | m_C class) of the entries base - 1 .. base + TD_TILE + TD_HALO - 1
     const uint64_t base = (uint64_t) blockIdx.x * TD_TILE;
@@ -345,44 +347,77 @@ __global__ void __launch_bounds__(TD_TILE) k_tgt_dir(const uint32_t *__restrict_
     for (int k = (int) threadIdx.x; k <= TD_TILE + TD_HALO; k += TD_TILE)
         sb[k] = (base == 0 && k == 0) ? 0xFFFFFFFFu : tagged(base + (uint64_t) k - 1u);     // "entry -1": a bucket no entry has
     __syncthreads();
-    const int t = (int) threadIdx.x;
+    const int t = (int) threadIdx.x, lane = lane_id();
     const uint64_t j = base + (uint64_t) t;
     auto put = [&](int64_t b, const uint4 &rec) { dir[b] = rec; };
-    if (j <= n) {
-        const uint32_t b = sb[t + 1] >> 3, bprev = sb[t] >> 3;
-        if (b != bprev) {
-            for (int64_t e = j == 0 ? 0 : (int64_t) bprev + 1; e < (int64_t) b; e++) put(e, make_uint4((uint32_t) j, 0u, 0u, 0u));
-            if (b == n_buckets) put(b, make_uint4((uint32_t) j, 0u, 0u, 0u));
-            else {
-                // first[s] = entries with class < s, eight saturation-free byte counters in two words (meaningful for c <= 255 only)
-                uint32_t lo = 0u, hi = 0u;
-                auto tally = [&](uint32_t cls) {
-                    lo += (cls < 1u ? 0x00000100u : 0u) + (cls < 2u ? 0x00010000u : 0u) + (cls < 3u ? 0x01000000u : 0u);
-                    hi += (cls < 4u ? 0x00000001u : 0u) + (cls < 5u ? 0x00000100u : 0u) + (cls < 6u ? 0x00010000u : 0u) + (cls < 7u ? 0x01000000u : 0u);
-                };
-                int u = 0;
-                const int lim = TD_TILE + TD_HALO - t;     // entries of this bucket that can lie in the staged tile
-                for (; u < lim; u++) {
-                    const uint32_t x = sb[t + 1 + u];
-                    if ((x >> 3) != b) break;
-                    tally(x & 7u);
-                }
-                uint64_t k = j + (uint64_t) u;
-                if (u == lim && (tagged(k) >> 3) == b) {   // the bucket runs past the tile (repeats): on through global memory
-                    for (; k < j + 256u; k++) {            // the class offsets matter up to 255 entries only
-                        const uint32_t x = tagged(k);
-                        if ((x >> 3) != b) break;
-                        tally(x & 7u);
-                    }
-                    if (k >= j + 256u && (tagged(k) >> 3) == b) {      // more than 256 entries: the end by bisection
-                        uint64_t a = k, z = n;             // bucket(a) == b, bucket(z) > b (z == n: past the end)
-                        while (z - a > 1) { const uint64_t mid = a + (z - a) / 2; if ((tagged(mid) >> 3) == b) a = mid; else z = mid; }
-                        k = z;
-                    }
-                }
-                const uint32_t c = (uint32_t) (k - j);
-                put(b, make_uint4((uint32_t) j, c, c <= 255u ? lo : 0u, c <= 255u ? hi : 0u));
+    // first[s] = entries of the bucket with class < s, s = 1 .. 7: seven byte counters in one 64-bit word (byte s; meaningful for
+    // buckets of <= 255 entries only).  An entry of class c counts for every s > c: one shifted constant.
+    auto tally = [](unsigned long long acc, uint32_t cls) { return acc + (0x0101010101010100ull << (8u * cls)); };
+    const uint32_t b = sb[t + 1] >> 3;
+    const bool start = j <= n && b != (sb[t] >> 3);
+    if (start && b == n_buckets) put(b, make_uint4((uint32_t) j, 0u, 0u, 0u));
+    const bool real = start && b != n_buckets;
+    // A wave's time is its longest lane's: with one lane per bucket walking its entries, the 3 - 5 buckets that start in a wave's 64
+    // entries (13 entries each at 30x coverage, hundreds in repeats) kept the other 60 lanes waiting -- 1.06 ms, VALU-bound.  Now a
+    // lane walks its own bucket only if that ends within TD_SHORT entries; the longer ones are taken one after the other by the whole
+    // wave, 64 entries per step, the class counts from ballots.
+    constexpr int TD_SHORT = 4;
+    const bool is_short = real && (sb[t + 1 + TD_SHORT] >> 3) != b;       // (t + 1 + TD_SHORT <= TD_TILE + TD_HALO)
+    if (is_short) {
+        unsigned long long acc = 0ull;
+        int u = 0;
+#pragma unroll
+        for (; u < TD_SHORT; u++) {
+            const uint32_t x = sb[t + 1 + u];
+            if ((x >> 3) != b) break;
+            acc = tally(acc, x & 7u);
+        }
+        put(b, make_uint4((uint32_t) j, (uint32_t) u, (uint32_t) acc, (uint32_t) (acc >> 32)));
+    }
+    unsigned long long longs = __ballot(real && !is_short);
+    while (longs != 0ull) {                                // uniform
+        const int l0 = __builtin_ctzll(longs);
+        longs &= longs - 1ull;
+        const int t0 = (t & ~63) + l0;                     // the starting thread's index in the workgroup
+        const uint32_t bb = (uint32_t) __builtin_amdgcn_readlane((int) b, l0);
+        uint32_t cnt = 0u, lo = 0u, hi = 0u;
+        bool past = false;                                 // the bucket runs past the staged entries
+        for (int u = 0;; u += 64) {
+            const int idx = t0 + 1 + u + lane;
+            const bool staged = idx <= TD_TILE + TD_HALO;
+            const uint32_t x = staged ? sb[idx] : 0xFFFFFFFFu;
+            const bool inb = staged && (x >> 3) == bb;
+            const uint32_t cls = inb ? (x & 7u) : 8u;
+            const unsigned long long m = __ballot(inb);
+            cnt += (uint32_t) __popcll(m);
+            lo += ((uint32_t) __popcll(__ballot(cls < 1u)) << 8) + ((uint32_t) __popcll(__ballot(cls < 2u)) << 16) + ((uint32_t) __popcll(__ballot(cls < 3u)) << 24);
+            hi += (uint32_t) __popcll(__ballot(cls < 4u)) + ((uint32_t) __popcll(__ballot(cls < 5u)) << 8) + ((uint32_t) __popcll(__ballot(cls < 6u)) << 16) +
+                  ((uint32_t) __popcll(__ballot(cls < 7u)) << 24);
+            if (m != ~0ull) {                              // the bucket ended inside this step -- or the staged entries did
+                const int last = t0 + 1 + u + (int) __popcll(m);           // first index not taken
+                past = last > TD_TILE + TD_HALO;
+                break;
             }
+            if (cnt >= 256u) { past = true; break; }       // the class offsets are moot from here on: only the end is needed
+        }
+        if (lane == l0) {
+            uint64_t k = j + (uint64_t) cnt;
+            if (past || cnt >= 256u) {                     // repeats: on through global memory, the end by bisection beyond 256 entries
+                unsigned long long acc = ((unsigned long long) hi << 32) | lo;
+                for (; k < j + 256u; k++) {
+                    const uint32_t x = tagged(k);
+                    if ((x >> 3) != b) break;
+                    acc = tally(acc, x & 7u);
+                }
+                lo = (uint32_t) acc; hi = (uint32_t) (acc >> 32);
+                if (k >= j + 256u && (tagged(k) >> 3) == b) {
+                    uint64_t a = k, z = n;                 // bucket(a) == b, bucket(z) > b (z == n: past the end)
+                    while (z - a > 1) { const uint64_t mid = a + (z - a) / 2; if ((tagged(mid) >> 3) == b) a = mid; else z = mid; }
+                    k = z;
+                }
+            }
+            const uint32_t c = (uint32_t) (k - j);
+            put(b, make_uint4((uint32_t) j, c, c <= 255u ? lo : 0u, c <= 255u ? hi : 0u));
         }
     }
 }
@@ -1260,6 +1295,10 @@ hipError_t launch_cluster_store(const NodesDev &nd, const ClusterCfg &cc, int eq
 #undef TG_EQ
 #undef TG_LAUNCH
     if (ev_gathered) (void) hipEventRecord(ev_gathered, s);
+    // (measured and rejected: zero-filling the directory as a side job of the VALU-bound k_node_runs -- that kernel got slower by what
+    // the fill costs on its own, 0.24 ms)
+    err = hipMemsetAsync(dir, 0, ((size_t) cc.n_buckets + 2) * 16, s);
+    if (err != hipSuccess) return err;
     hipLaunchKernelGGL(k_tgt_dir, dim3((unsigned) ((n + 1 + TD_TILE - 1) / TD_TILE)), dim3(TD_TILE), 0, s, (const uint32_t *) keys2, n, cc.idx_shift, cc.n_buckets, (uint4 *) dir);
     return hipGetLastError();
 }

@@ -597,7 +597,7 @@ __global__ void __launch_bounds__(256) k_rowptr_from_sorted(const uint32_t *__re
 // exclusive scan of uint32 (n up to 2^31): reduce tiles, scan tile sums, scan tiles
 // ------------------------------------------------------------------------------------------
 constexpr int SCAN_BLOCK = 256;
-constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_ITEMS = 16;                             // per thread: four 16-byte loads / stores of consecutive values
 constexpr int SCAN_TILE = SCAN_BLOCK * SCAN_ITEMS;
 
 __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *total, uint32_t *lds /*>= 8 words*/) {
@@ -619,10 +619,15 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_tile_sums(const uint32_t *_
     __shared__ uint32_t lds[8];
     const uint64_t base = (uint64_t) blockIdx.x * SCAN_TILE;
     uint32_t s = 0;
+    if (base + SCAN_TILE <= n && (reinterpret_cast<uintptr_t>(in) & 15u) == 0) {
+        const uint4 *in4 = reinterpret_cast<const uint4 *>(in + base);
 #pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; k++) {
-        uint64_t i = base + (uint64_t) k * SCAN_BLOCK + threadIdx.x;
-        if (i < n) s += in[i];
+        for (int k = 0; k < SCAN_ITEMS / 4; k++) { const uint4 v = in4[k * SCAN_BLOCK + threadIdx.x]; s += v.x + v.y + v.z + v.w; }
+    } else {
+        for (int k = 0; k < SCAN_ITEMS; k++) {
+            uint64_t i = base + (uint64_t) k * SCAN_BLOCK + threadIdx.x;
+            if (i < n) s += in[i];
+        }
     }
     uint32_t tot;
     block_exclusive_scan(s, &tot, lds);
@@ -656,19 +661,57 @@ __global__ void __launch_bounds__(1024) k_scan_spine(uint64_t *tile_sums, uint32
     if (threadIdx.x == 0) tile_sums[n_tiles] = carry;
 }
 
-// out[i] = exclusive prefix (uint32; the host checks the 64-bit total fits); out[n] = total
+// out[i] = exclusive prefix (uint32; the host checks the 64-bit total fits); out[n] = total.  Full tiles: a wave owns 1024
+// consecutive values and moves them as four fully coalesced 1 KB loads / stores (lane l holds the values 256 k + 4 l .. + 3 of the
+// wave's region, k = 0 .. 3); four wave scans of the lanes' sums, the waves' totals through LDS.  (One value per load instruction and
+// SCAN_ITEMS consecutive values per thread left a wave's 64 loads 32 bytes apart: 0.30 ms for 90.6 M values, against 0.09 ms for the
+// reduction pass over the same input.)
 __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_tiles(const uint32_t *__restrict__ in, uint64_t n,
                                                             const uint64_t *__restrict__ tile_sums, uint32_t *__restrict__ out) {
     __shared__ uint32_t lds[8];
-    const uint64_t base = (uint64_t) blockIdx.x * SCAN_TILE + (uint64_t) threadIdx.x * SCAN_ITEMS;
-    uint32_t v[SCAN_ITEMS];
-    uint32_t s = 0;
+    const bool full = (uint64_t) (blockIdx.x + 1) * SCAN_TILE <= n && (reinterpret_cast<uintptr_t>(in) & 15u) == 0 && (reinterpret_cast<uintptr_t>(out) & 15u) == 0;
+    if (full) {
+        constexpr int G = SCAN_ITEMS / 4;                  // 16-byte groups per lane
+        const int lane = lane_id(), wave = (int) (threadIdx.x >> 6);
+        const uint64_t wbase = (uint64_t) blockIdx.x * SCAN_TILE + (uint64_t) wave * (64 * SCAN_ITEMS);
+        const uint4 *in4 = reinterpret_cast<const uint4 *>(in + wbase);
+        uint4 q[G];
+        uint32_t ex[G];
 #pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; k++) { uint64_t i = base + k; v[k] = i < n ? in[i] : 0u; s += v[k]; }
-    uint32_t tot;
-    uint32_t ex = block_exclusive_scan(s, &tot, lds) + (uint32_t) tile_sums[blockIdx.x];
+        for (int k = 0; k < G; k++) q[k] = in4[k * 64 + lane];
+        uint32_t run = 0;                                  // values of the wave before group k
 #pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; k++) { uint64_t i = base + k; if (i < n) out[i] = ex; ex += v[k]; }
+        for (int k = 0; k < G; k++) {
+            const uint32_t sk = q[k].x + q[k].y + q[k].z + q[k].w;
+            uint32_t inc = sk;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t) __shfl_up((int) inc, o); if (lane >= o) inc += t; }
+            ex[k] = run + inc - sk;
+            run += (uint32_t) __shfl((int) inc, 63);
+        }
+        if (lane == 0) lds[wave] = run;
+        __syncthreads();
+        uint32_t woff = (uint32_t) tile_sums[blockIdx.x];
+        for (int w = 0; w < wave; w++) woff += lds[w];
+        uint4 *out4 = reinterpret_cast<uint4 *>(out + wbase);
+#pragma unroll
+        for (int k = 0; k < G; k++) {
+            uint32_t e = woff + ex[k];
+            uint4 r;
+            r.x = e; e += q[k].x; r.y = e; e += q[k].y; r.z = e; e += q[k].z; r.w = e;
+            out4[k * 64 + lane] = r;
+        }
+    } else {
+        const uint64_t base = (uint64_t) blockIdx.x * SCAN_TILE + (uint64_t) threadIdx.x * SCAN_ITEMS;
+        uint32_t v[SCAN_ITEMS];
+        uint32_t s = 0;
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS; k++) { uint64_t i = base + k; v[k] = i < n ? in[i] : 0u; s += v[k]; }
+        uint32_t tot;
+        uint32_t ex = block_exclusive_scan(s, &tot, lds) + (uint32_t) tile_sums[blockIdx.x];
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS; k++) { uint64_t i = base + k; if (i < n) out[i] = ex; ex += v[k]; }
+    }
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) out[n] = (uint32_t) tile_sums[gridDim.x];
 }
 
