@@ -1,0 +1,141 @@
+"""BASELINE.json's full sizes (configs[3]: 50 M x 150 bp; configs[4]: 10 M x 150 bp with 2 % errors) through properties that do not
+need the reference at that size (the byte-for-byte comparisons against the real reference binary are tests/test_gpu_fullsize.py
+at 1 M reads in this suite and the builder-run dumps under profiles/ at 10 M and 50 M):
+
+  * two independent discovery algorithms -- the seed-table probe (one hash probe per suffix window) and the clustered minimizer
+    join (sorted entry array + bucket directory) -- give the SAME edge list, byte for byte;
+  * two independent reductions -- the source-side form and the per-target replay of the reference's insertion order -- give the same list;
+  * the list is strictly (src, dst)-ordered, ids and offsets are in range, no self edges;
+  * every sampled edge IS a suffix-prefix overlap of the packed reads (checked on the host against the 2-bit rows), of length
+    >= min_overlap;
+  * a second build of the same engine returns the same bytes (no dependence on what a previous build left in its buffers);
+  * the counts equal the ones of the runs whose dumps were compared with the reference's (profiles/, cited below).
+The node sets are generated on the device (alga_amd.workload.device_build, what bench.py measures on)."""
+import numpy as np
+import pytest
+
+import alga_amd
+from alga_amd import workload
+from alga_amd.engine import device_view
+
+pytestmark = pytest.mark.gpu
+
+
+def _codes(words_row, n):
+    """2-bit codes of one packed row (A0 C1 G2 T3, nucleotide i at bits 2i, 2i+1 of the LSB-first words)."""
+    w = words_row.astype(np.uint64)
+    i = np.arange(n)
+    return ((w[(2 * i) >> 5] >> ((2 * i) & 31).astype(np.uint64)) & 3).astype(np.uint8)
+
+
+def _check_list(edges, n_nodes, lens_max, lo):
+    import torch
+    e = edges.to(torch.int64)
+    assert int(e[:, 0].min()) >= 0 and int(e[:, 0].max()) < n_nodes and int(e[:, 1].min()) >= 0 and int(e[:, 1].max()) < n_nodes
+    assert not bool((e[:, 0] == e[:, 1]).any())
+    assert int(e[:, 2].min()) >= 0 and int(e[:, 2].max()) <= lens_max - lo
+    key = e[:, 0] * n_nodes + e[:, 1]
+    assert bool((key[1:] > key[:-1]).all()), "not strictly (src, dst)-ordered"
+
+
+def _check_overlaps(edges, d_words, d_lens, lo, sample, seed):
+    import torch
+    m = int(edges.shape[0])
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    pick = torch.randint(0, m, (sample,), generator=g).to(edges.device)
+    es = edges[pick].cpu().numpy()
+    rows_a = d_words[es[:, 0].astype(np.int64)].cpu().numpy().view(np.uint32)
+    rows_b = d_words[es[:, 1].astype(np.int64)].cpu().numpy().view(np.uint32)
+    la = d_lens[es[:, 0].astype(np.int64)].cpu().numpy()
+    lb = d_lens[es[:, 1].astype(np.int64)].cpu().numpy()
+    for k in range(sample):
+        off = int(es[k, 2])
+        ov = min(int(la[k]) - off, int(lb[k]))
+        assert ov >= lo
+        a, b = _codes(rows_a[k], int(la[k])), _codes(rows_b[k], int(lb[k]))
+        assert (a[off:off + ov] == b[:ov]).all(), "edge %s is not an overlap" % (es[k],)
+
+
+def _build(eng, wl, probe, reduction="auto", **opts):
+    import torch
+    eng.set_option("probe", probe)
+    ptr, m = eng.prefsuf_device(wl["words"], wl["lens"], wl["min_overlap"], wl["rsoemo"], reduction=reduction, collect_stats=True)
+    torch.cuda.synchronize()
+    return device_view(ptr, (m, 3), wl["words"].device).clone(), eng.last_stats()
+
+
+def test_north_star_50M_reads_properties():
+    """BASELINE configs[3] on one GPU: 90 621 096 nodes -> 92 350 115 edges (profiles/r03_cfg4_50M_bench.json; the host-generated set
+    of the same shape is byte-equal to the reference's dump: profiles/r02_d_cfg4_50M_dump_vs_reference.log)."""
+    import torch
+    n_reads, read_len, G, seed, err = workload.CONFIGS["cfg4_50M_150bp"]
+    wl = workload.device_build(n_reads, read_len, G, seed, err=err)
+    torch.cuda.synchronize()                       # the engine works on its own stream: its inputs must be complete
+    n = int(wl["lens"].shape[0])
+    lo = wl["min_overlap"]
+    eng = alga_amd.Engine(0)
+    try:
+        cl, st = _build(eng, wl, "cluster")
+        assert st["probe_used"] == 2 and st["reduction_used"] == 2
+        assert n == 90_621_096 and int(cl.shape[0]) == 92_350_115 == st["edges"]
+        _check_list(cl, n, int(wl["lens"].max().item()), lo)
+        _check_overlaps(cl, wl["words"], wl["lens"], lo, 4000, 1)
+        cl2, st2 = _build(eng, wl, "cluster")
+        assert torch.equal(cl, cl2) and st2["raw_overlaps"] == st["raw_overlaps"]
+        del cl2
+        tb, st3 = _build(eng, wl, "table")
+        assert st3["probe_used"] == 1
+        assert st3["raw_overlaps"] == st["raw_overlaps"]                     # both probes verified the same set of overlaps
+        assert torch.equal(cl, tb), "seed-table probe and clustered join disagree"
+        del tb
+    finally:
+        eng.close()
+
+
+def test_configs4_10M_reads_with_errors_properties():
+    """BASELINE configs[4]: exact graph through both probes and both reductions, then the approximate supplement: 19 989 632 nodes,
+    4 617 669 exact edges, 8 991 578 after the supplement (profiles/r03_cfg5_10M_bench.json; the exact graph of this shape equals the
+    reference's --threads=1 dump, the supplement equals the oracle in the engine's semantics edge for edge:
+    profiles/r02_d_cfg5_10M_exact_path_vs_reference_threads1.json, profiles/r02_cfg5_10M_err2_oracle_modes.json)."""
+    import torch
+    n_reads, read_len, G, seed, err = workload.CONFIGS["cfg5_10M_150bp_err2"]
+    wl = workload.device_build(n_reads, read_len, G, seed, err=err)
+    torch.cuda.synchronize()                       # the engine works on its own stream: its inputs must be complete
+    n = int(wl["lens"].shape[0])
+    lo = wl["min_overlap"]
+    eng = alga_amd.Engine(0)
+    try:
+        cl, st = _build(eng, wl, "cluster")
+        assert st["probe_used"] == 2
+        assert n == 19_989_632 and int(cl.shape[0]) == 4_617_669
+        _check_list(cl, n, int(wl["lens"].max().item()), lo)
+        _check_overlaps(cl, wl["words"], wl["lens"], lo, 2000, 2)
+        tb, st2 = _build(eng, wl, "table")
+        assert st2["probe_used"] == 1 and torch.equal(cl, tb), "seed-table probe and clustered join disagree"
+        del tb
+        pt, st3 = _build(eng, wl, "auto", reduction="per_target")
+        assert st3["reduction_used"] == 1 and torch.equal(cl, pt), "per-target replay and source-side form disagree"
+        del pt
+        # the supplement on the resident exact graph: same result twice, a superset of nothing it removes wrongly -- every exact
+        # (src, dst) pair survives (addDirectedEdge only adds pairs or lowers offsets), list ordered, count as recorded
+        eng.set_option("probe", "auto")
+        mean_len = float(wl["lens"][wl["lens"] > 0].float().mean().item())
+        pkb = alga_amd.Engine.pkb_params(mean_len, err, min(2 * lo // 3, 60))
+        outs = []
+        for _ in range(2):
+            ptr, m = eng.prefsuf_device(wl["words"], wl["lens"], lo, wl["rsoemo"])
+            p2, m2 = eng.pkb_supplement_device(wl["words"], wl["lens"], ptr, m, pkb)
+            torch.cuda.synchronize()
+            outs.append(device_view(p2, (m2, 3), wl["words"].device).clone())
+        assert torch.equal(outs[0], outs[1])
+        sup = outs[0]
+        assert int(sup.shape[0]) == 8_991_578
+        _check_list(sup, n, int(wl["lens"].max().item()), 0)
+        ks = sup[:, 0].to(torch.int64) * n + sup[:, 1].to(torch.int64)
+        ke = cl[:, 0].to(torch.int64) * n + cl[:, 1].to(torch.int64)
+        pos = torch.searchsorted(ks, ke)
+        assert bool((ks[pos.clamp(max=ks.shape[0] - 1)] == ke).all()), "an exact edge is missing after the supplement"
+        assert bool((sup[pos, 2] <= cl[:, 2]).all())                       # offsets only ever go down (keep-min)
+    finally:
+        eng.close()
