@@ -25,6 +25,9 @@ CONFIGS = {
     "cfg3_5M_150bp": (5_000_000, 150, 4_600_000, 7, 0.0),
     "cfg4_50M_150bp": (50_000_000, 150, 250_000_000, 11, 0.0),
     "cfg5_10M_150bp_err2": (10_000_000, 150, 30_000_000, 13, 0.02),
+    # beyond BASELINE: the north-star shape at 2x and 4x the reads (same 30x coverage) -- how far one GPU's 288 GB goes
+    "x2_100M_150bp": (100_000_000, 150, 500_000_000, 17, 0.0),
+    "x4_200M_150bp": (200_000_000, 150, 1_000_000_000, 19, 0.0),
 }
 
 

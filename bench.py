@@ -126,8 +126,7 @@ def traffic_of(traffic, prefix):
     return int(sum(v)) if v else None
 
 
-def main():
-    t_process = time.perf_counter()
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
@@ -139,13 +138,13 @@ def main():
     ap.add_argument("--cpu-sample-reads", type=int, default=1_000_000, help="reads of the workload the CPU baseline runs on (~10 s of the reference at 16 threads)")
     ap.add_argument("--probe", default="auto", choices=["auto", "table", "cluster"])
     ap.add_argument("--multi-plain", action="store_true", help="N > 1: time the driver's plainest form (no sharded key pass, no pieces)")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
+
+def main():
+    t_process = time.perf_counter()
+    args = parse_args()
     import torch
-    import alga_amd
-    from alga_amd import workload
-    from alga_amd import multigpu
-
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -160,6 +159,24 @@ def main():
         import datetime
         # a collective that never completes aborts the job after 5 minutes instead of holding the node
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=300))
+    out = run(args, rank, world, local_rank, dist, t_process)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        wall = time.perf_counter() - t_process
+        out["fits_in_driver_run"] = {"wall_s": round(wall, 1), "limit_s": 600, "fits": wall < 600,
+                                     "note": "whole bench.py process: workload generation, first-call legs, counted pass, warmup, timed steps, PCIe leg, CPU baseline"}
+        print(json.dumps(out))
+
+
+def run(args, rank, world, local_rank, dist, t_process=None):
+    """The measurement of one rank -> the JSON object (rank 0) or None.  `dist`: torch.distributed with the process group up (N > 1), or
+    a stand-in with the same calls (tests/test_gpu_parity.py rehearses this function as N thread-ranks on one GPU)."""
+    import torch
+    import alga_amd
+    from alga_amd import workload
+    from alga_amd import multigpu
 
     # ---- workload (synthetic).  Every rank builds the same node set on its own GPU: the generator is seeded. ----------------
     n_reads, read_len, G, seed, err = workload.CONFIGS[args.config]
@@ -414,14 +431,7 @@ def main():
                 hl = host_lens if host_lens is not None else d_lens[:200_000].cpu().numpy()
                 cb = cpu_baseline_port(hw, hl, lo, rs, min(n_nodes, 200_000))
             out["cpu_baseline"] = cb
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
-    if rank == 0:
-        wall = time.perf_counter() - t_process
-        out["fits_in_driver_run"] = {"wall_s": round(wall, 1), "limit_s": 600, "fits": wall < 600,
-                                     "note": "whole bench.py process: workload generation, first-call legs, counted pass, warmup, timed steps, PCIe leg, CPU baseline"}
-        print(json.dumps(out))
+    return out
 
 
 if __name__ == "__main__":

@@ -85,6 +85,9 @@ class FakeDist:
     def batch_isend_irecv(ops):
         return [o.op(o.tensor, o.peer) for o in ops]
 
+    def barrier(self):
+        self._exchange(None)
+
     def all_reduce(self, t, op=ReduceOp.SUM):
         import torch
         parts = self._exchange(t.detach().clone())

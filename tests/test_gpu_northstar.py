@@ -65,11 +65,13 @@ def _build(eng, wl, probe, reduction="auto", **opts):
     return device_view(ptr, (m, 3), wl["words"].device).clone(), eng.last_stats()
 
 
-def test_north_star_50M_reads_properties():
+@pytest.mark.parametrize("config,nodes,edges", [("cfg4_50M_150bp", 90_621_096, 92_350_115), ("x2_100M_150bp", 181_269_292, 184_711_310)])
+def test_north_star_50M_reads_properties(config, nodes, edges):
     """BASELINE configs[3] on one GPU: 90 621 096 nodes -> 92 350 115 edges (profiles/r03_cfg4_50M_bench.json; the host-generated set
-    of the same shape is byte-equal to the reference's dump: profiles/r02_d_cfg4_50M_dump_vs_reference.log)."""
+    of the same shape is byte-equal to the reference's dump: profiles/r02_d_cfg4_50M_dump_vs_reference.log) -- and the same shape at
+    twice the reads (181 M nodes: the bucket directory at its 2^26 limit, two entries per bucket)."""
     import torch
-    n_reads, read_len, G, seed, err = workload.CONFIGS["cfg4_50M_150bp"]
+    n_reads, read_len, G, seed, err = workload.CONFIGS[config]
     wl = workload.device_build(n_reads, read_len, G, seed, err=err)
     torch.cuda.synchronize()                       # the engine works on its own stream: its inputs must be complete
     n = int(wl["lens"].shape[0])
@@ -78,7 +80,7 @@ def test_north_star_50M_reads_properties():
     try:
         cl, st = _build(eng, wl, "cluster")
         assert st["probe_used"] == 2 and st["reduction_used"] == 2
-        assert n == 90_621_096 and int(cl.shape[0]) == 92_350_115 == st["edges"]
+        assert n == nodes and int(cl.shape[0]) == edges == st["edges"]
         _check_list(cl, n, int(wl["lens"].max().item()), lo)
         _check_overlaps(cl, wl["words"], wl["lens"], lo, 4000, 1)
         cl2, st2 = _build(eng, wl, "cluster")

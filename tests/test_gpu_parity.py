@@ -562,6 +562,27 @@ def test_validated_runner_three_ranks_one_gpu():
     assert res[0].shape == want.shape and (res[0] == want).all()
 
 
+def test_bench_run_as_two_thread_ranks_equals_one_gpu():
+    """bench.py's measurement body (bench.run: what `bench.py --gpus N` executes per rank after the process group is up) as two
+    thread-ranks on this GPU, the collectives replaced by the thread rendezvous: the N > 1 branch of the script -- runner validation,
+    counted pass, timing, max over ranks, the JSON line -- runs in the suite, and its graph has the one-GPU edge count."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from fake_dist import run_ranks
+    common = ["--steps", "2", "--warmup", "1", "--config", "cfg3_5M_150bp", "--no-cpu-baseline", "--no-pcie", "--no-first-call"]
+    one = bench.run(bench.parse_args(["--gpus", "1"] + common), 0, 1, 0, None)
+    args2 = bench.parse_args(["--gpus", "2"] + common)
+    res = run_ranks(2, lambda rank, dist: bench.run(args2, rank, 2, 0, dist))
+    assert res[1] is None
+    two = res[0]
+    assert two["n_gpus"] == 2 and two["config"]["edges"] == one["config"]["edges"] > 5_000_000 and two["config"]["nodes"] == one["config"]["nodes"]
+    assert two["multi_gpu_form"]["form"].startswith("keys of own nodes") and "byte-identical" in two["multi_gpu_form"]["validated"]
+    assert two["value"] > 0 and two["roofline"]["frac"] > 0 and two["scaling"] == "strong"
+    plain = run_ranks(2, lambda rank, dist: bench.run(bench.parse_args(["--gpus", "2", "--multi-plain"] + common), rank, 2, 0, dist))[0]
+    assert plain["config"]["edges"] == one["config"]["edges"] and plain["multi_gpu_form"]["form"].startswith("plain")
+
+
 def test_contig_like_inputs_second_call_of_the_reference(eng):
     """src/main.cpp:633-656 calls the same creator once more on the CONTIGS (kb-long "reads", min_overlap = rsoemo = 25, overlap
     lengths capped at 501): not on the benchmark path, but the engine takes it (per-target form: the reads are far too long for
