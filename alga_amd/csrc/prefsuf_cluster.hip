@@ -795,7 +795,7 @@ k_probe_clustered(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__res
 //   * The window's bookkeeping lives in few scalar registers (entry counts as packed bytes, flags as bit fields): scalars beyond
 //     ~100 are spilled into VGPR lanes and cost a v_readlane per use inside the loop.
 #ifndef CLQ_OCC
-#define CLQ_OCC 5                      // workgroups per CU: 20 waves per CU (84 VGPRs; at 6 the kernel spills into scratch inside the loop)
+#define CLQ_OCC 6                      // workgroups per CU: 24 waves per CU (80 VGPRs, 26.6 KB LDS; no scratch)
 #endif
 template <bool STATS, int EQ, int KF, bool BYKEY>
 __global__ void __launch_bounds__(PROBE_WAVES * 64, CLQ_OCC)
@@ -814,10 +814,16 @@ k_probe_stream(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__restri
     __shared__ uint8_t sT[PROBE_WAVES][8][64];             // per source of the window: lane of the item at offset d
     __shared__ int32_t sDefer[PROBE_WAVES][72];
     __shared__ uint4 sMask[KF > 0 ? 129 : 1];
+    // per lane: the entry words KF .. 4 EQ - 1 and zeros up to word WC + 4, from which the overhang of a passing item is read at a
+    // dynamic word offset (a register array can only be indexed through a chain of selects: 25 v_cndmask per round)
+    constexpr int OVW = KF > 0 ? WC - KF + 5 : 1;          // words per lane (odd for every instantiated shape: conflict-free stride)
+    constexpr int OVE = KF > 0 ? 4 * EQ - KF : 0;          // of which the entry supplies the first OVE
+    __shared__ uint32_t sOv[PROBE_WAVES][KF > 0 ? 64 : 1][OVW];
     const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
     const int lane = lane_id();
     const int g = lane >> 4, gl = lane & 15;
     for (int k = lane; k < NS * 8; k += 64) sB[wave][k >> 3][16 + (k & 7)] = 0u;       // the slack words, once
+    if constexpr (KF > 0) { for (int k = OVE; k < OVW; k++) sOv[wave][lane][k] = 0u; }
     if constexpr (KF > 0) {
         for (int t = (int) threadIdx.x; t <= 128; t += PROBE_WAVES * 64)
             sMask[t] = make_uint4(low_bits32(t), low_bits32(t - 32), low_bits32(t - 64), low_bits32(t - 96));
@@ -1068,15 +1074,13 @@ k_probe_stream(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__restri
             if (pass) {                                    // overhang: C's row from bit 2L on (see k_probe_clustered)
                 const int ws = nb >> 5, r2 = nb & 31;
                 uint32_t x[5];
-                if constexpr (KF > 0 && WC - KF <= 6) {
-                    const int t = ws - KF;
+                if constexpr (KF > 0) {
+                    uint32_t *ov = sOv[wave][lane];        // (this lane's own words: LDS operations of a wave complete in order)
 #pragma unroll
-                    for (int k = 0; k < 5; k++) {
-                        uint32_t v = 0u;
+                    for (int k = 0; k < OVE; k++) ov[k] = ew[KF + k];
+                    const int t = min(max(ws - KF, 0), WC - KF);
 #pragma unroll
-                        for (int u = 0; u <= WC - KF; u++) { const int wi = KF + k + u; if (wi < 4 * EQ) v = t == u ? ew[wi] : v; }
-                        x[k] = v;
-                    }
+                    for (int k = 0; k < 5; k++) x[k] = ov[t + k];
                 } else {
                     const uint32_t *er = reinterpret_cast<const uint32_t *>(store + ei * EQ);
 #pragma unroll
