@@ -371,7 +371,6 @@ struct PkbGraph { const uint32_t *rowptr; const unsigned long long *keys; };   /
 constexpr int PKB_SMALL_MAX = 7;
 constexpr int PKB_WAVE_MAX = 64;
 constexpr int PKB_SNAP_KEYS = 6;
-constexpr int PKB_SMALL_WG = 256;
 
 __device__ __forceinline__ int snapshot_offset(const PkbGraph &g, int a, int b) {
     uint32_t lo = g.rowptr[a], hi = g.rowptr[a + 1];
@@ -677,16 +676,24 @@ __global__ void __launch_bounds__(64) k_pkb_groups_wave(NodesDev nd, PkbCfg c, P
     if (lane == 0 && calls) atomicAdd(&counters[0], calls);                  // every lane counted the same calls
 }
 
-// 2 <= D <= 7: one thread per group; the entries in LDS, the marker rows in one register (8 bits per row), rows staged per pair
+
+// 2 <= D <= 7: one THREAD per group; the entries in LDS, the marker rows in one register (8 bits per row), rows staged per pair.
+// Persistent grid (a thread walks the list with the grid's stride): the call counter is updated once per wave of the GRID, not of
+// the list -- with one launch wave per 64 groups the 55 k same-address atomics were a third of the kernel's time (0.89 -> 0.6 ms per
+// round at 10 M reads).  Measured and rejected (round 3): eight LANES per group -- the pairs (i, j > i) of a row side by side,
+// speculatively, then the replay on 8 x 8 bit masks as k_pkb_groups_wave does it, a group's chain of dependent accesses two long
+// whatever its size -- 1.8 ms against 0.6: most groups have two or three members, seven of eight lanes idle, and the kernel turns
+// VALU-bound; no split point between the two shapes (thread per group up to D = 1 .. 7, lanes above) beat the thread per group alone.
+constexpr int PKB_SMALL_WG = 256;
 __global__ void __launch_bounds__(PKB_SMALL_WG) k_pkb_groups_small(NodesDev nd, PkbCfg c, PkbGraph g, const uint32_t *__restrict__ heads, const uint32_t *__restrict__ hkey,
                                                           uint32_t n_heads, const unsigned long long *__restrict__ vals, PkbAdd ad,
                                                           unsigned long long *__restrict__ counters, uint32_t *__restrict__ n_add, uint32_t *__restrict__ left) {
     __shared__ uint32_t srow[PKB_SMALL_WG][2 * PKB_ROW_WORDS + 3];           // a | 0 | b | 0 (+1: odd stride, conflict-free)
     __shared__ unsigned long long sv[PKB_SMALL_MAX][PKB_SMALL_WG];
     const int lane = (int) threadIdx.x;                                      // slot in the workgroup's LDS arrays
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long calls = 0;
-    const int D = t < n_heads ? 255 - (int) hkey[t] : 0;
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n_heads; t += gridDim.x * blockDim.x) {
+    const int D = 255 - (int) hkey[t];
     if (D >= 2 && D <= PKB_SMALL_MAX) {
         const uint64_t gs = heads[t];
 #pragma unroll
@@ -740,10 +747,12 @@ __global__ void __launch_bounds__(PKB_SMALL_WG) k_pkb_groups_small(NodesDev nd, 
             left[t] = 0u;
         }
     }
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) calls += __shfl_xor(calls, o);          // one counter update per wave
     if ((lane & 63) == 0 && calls) atomicAdd(&counters[0], calls);
 }
+
 
 // the additions of a round as one dense key list: group t's n_add[t] dense slots at pos[t], the overflow entries behind them
 __global__ void __launch_bounds__(256) k_pkb_gather_adds(const uint32_t *__restrict__ heads, const uint32_t *__restrict__ n_add, const uint32_t *__restrict__ pos,
@@ -852,7 +861,8 @@ void launch_pkb_groups(const NodesDev &nd, const PkbCfg &c, const uint32_t *rowp
         (void) hipMemsetAsync(left, 0, (size_t) n_heads * sizeof(uint32_t), s);
         hipLaunchKernelGGL(k_pkb_groups_wave, dim3(std::min<unsigned>(n_heads, (unsigned) std::max(1, n_cu) * 24u)), dim3(64), 0, s, nd, c, g, heads, hkey, n_heads,
                            (const unsigned long long *) vals, ad, counters, n_add, left);
-        hipLaunchKernelGGL(k_pkb_groups_small, dim3((n_heads + PKB_SMALL_WG - 1) / PKB_SMALL_WG), dim3(PKB_SMALL_WG), 0, s, nd, c, g, heads, hkey, n_heads, (const unsigned long long *) vals, ad, counters, n_add, left);
+        hipLaunchKernelGGL(k_pkb_groups_small, dim3(std::min<unsigned>((n_heads + PKB_SMALL_WG - 1) / PKB_SMALL_WG, (unsigned) std::max(1, n_cu) * 3u)), dim3(PKB_SMALL_WG), 0, s, nd, c, g,
+                           heads, hkey, n_heads, (const unsigned long long *) vals, ad, counters, n_add, left);
     }
     hipLaunchKernelGGL(k_pkb_groups_serial, dim3(blocks), dim3(64), 0, s, nd, c, g, keys, heads, hkey, n_heads, staged ? 0 : 1, (const uint32_t *) left, vals, n, marks,
                        big_marks, big_cursor, ad, counters, n_add);

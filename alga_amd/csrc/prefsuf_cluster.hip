@@ -794,11 +794,16 @@ k_probe_clustered(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__res
 //     with sequencing errors) stops verifying and lists the rest of its share: the decision is taken from THIS build's data.
 //   * The window's bookkeeping lives in few scalar registers (entry counts as packed bytes, flags as bit fields): scalars beyond
 //     ~100 are spilled into VGPR lanes and cost a v_readlane per use inside the loop.
-#ifndef CLQ_OCC
-#define CLQ_OCC 6                      // workgroups per CU: 24 waves per CU (80 VGPRs, 26.6 KB LDS; no scratch)
+// Workgroups per CU.  Six (24 waves per CU) where the shape fits 80 VGPRs and a sixth of the LDS without scratch -- every 150-bp
+// configuration: (EQ, KF) = (3, 5); the kernel is bound by VALU issue with ~75 % of the slots used, a sixth wave per SIMD fills some
+// of the rest: 20.3 -> 19.8 ms -- five for the shapes that would spill ((3, 3): 100-bp reads; EQ = 4: rows of 10 - 13 words), and, by
+// the same measurement, for the id-order traversal, which waits for HBM, not for issue slots (CLQ_OCC_IDORDER).
+#ifndef CLQ_OCC_IDORDER
+#define CLQ_OCC_IDORDER 5
 #endif
+constexpr int clq_occ(int eq, int kf, bool bykey) { return (eq == 4 || (eq == 3 && kf == 3)) ? 5 : (bykey ? 6 : CLQ_OCC_IDORDER); }
 template <bool STATS, int EQ, int KF, bool BYKEY>
-__global__ void __launch_bounds__(PROBE_WAVES * 64, CLQ_OCC)
+__global__ void __launch_bounds__(PROBE_WAVES * 64, clq_occ(EQ, KF, BYKEY))
 k_probe_stream(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__restrict__ store, const uint4 *__restrict__ dir,
                const uint2 *__restrict__ runs, const uint8_t *__restrict__ nruns, int32_t src_begin, int32_t src_end, ProbeOut o,
                int32_t *__restrict__ defer_list, uint32_t defer_cap) {
@@ -1321,10 +1326,12 @@ void launch_probe_stream(const NodesDev &nd, const PrefSufCfg &cfg, const Cluste
     const int64_t ns = (int64_t) src_end - src_begin;
     if (ns <= 0) return;
     const uint64_t quads = ((uint64_t) ns + 3) / 4;
-    dim3 grid((unsigned) std::max<uint64_t>(1, std::min<uint64_t>((quads + PROBE_WAVES - 1) / PROBE_WAVES, (uint64_t) std::max(1, n_cu) * CLQ_OCC))), block(PROBE_WAVES * 64);
+    const int kf = (2 * cfg.Lmin) >> 5;
+    const int kfs = (eq == 3 && (kf == 5 || kf == 3)) || (eq == 2 && kf == 3) ? kf : 0;       // the instantiated shape
+    dim3 grid((unsigned) std::max<uint64_t>(1, std::min<uint64_t>((quads + PROBE_WAVES - 1) / PROBE_WAVES, (uint64_t) std::max(1, n_cu) * clq_occ(eq <= 3 ? eq : 4, kfs, by_key)))),
+         block(PROBE_WAVES * 64);
     ProbeOut o{nullptr, nullptr, 0, counters, deg, first, by_key ? 0 : src_begin, second};
     const uint4 *st = (const uint4 *) store;
-    const int kf = (2 * cfg.Lmin) >> 5;
 #define CLQ_LAUNCH(ST, E, K, BK) hipLaunchKernelGGL((k_probe_stream<ST, E, K, BK>), grid, block, 0, s, nd, cfg, cc, st, (const uint4 *) dir, (const uint2 *) runs, nruns, src_begin, src_end, o, defer_list, defer_cap)
 #define CLQ_ORDER(ST, E, K) do { if (by_key) CLQ_LAUNCH(ST, E, K, true); else CLQ_LAUNCH(ST, E, K, false); } while (0)
 #define CLQ_STATS(E, K) do { if (cfg.stats) CLQ_ORDER(true, E, K); else CLQ_ORDER(false, E, K); } while (0)

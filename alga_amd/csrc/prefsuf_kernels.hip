@@ -40,13 +40,21 @@ __global__ void __launch_bounds__(256) k_node_stats(NodesDev nd, unsigned long l
     __shared__ unsigned long long s_live[4];
     int m = 0, mn = 0x7FFFFFFF;
     unsigned long long live = 0, asym = 0;
-    for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < nd.n; i += (int64_t) gridDim.x * blockDim.x) {
-        int l = nd.len[i];
+    auto one = [&](int l, int64_t i) {
         m = l > m ? l : m;
         mn = (l > 0 && l < mn) ? l : mn;
         live += l > 0;
         if (nd.to && l > 0 && !nd.to[i] && (nd.from == nullptr || nd.from[i])) asym++;
+    };
+    const int64_t gid = (int64_t) blockIdx.x * blockDim.x + threadIdx.x, gsz = (int64_t) gridDim.x * blockDim.x;
+    int64_t done = 0;                                      // lengths taken four at a time (16-byte loads) where the array allows it
+    if ((reinterpret_cast<uintptr_t>(nd.len) & 15u) == 0) {
+        const int64_t nq = (int64_t) nd.n >> 2;
+        const int4 *len4 = reinterpret_cast<const int4 *>(nd.len);
+        for (int64_t q = gid; q < nq; q += gsz) { const int4 l = len4[q]; one(l.x, 4 * q); one(l.y, 4 * q + 1); one(l.z, 4 * q + 2); one(l.w, 4 * q + 3); }
+        done = 4 * nq;
     }
+    for (int64_t i = done + gid; i < nd.n; i += gsz) one(nd.len[i], i);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(m, o); m = t > m ? t : m; t = __shfl_xor(mn, o); mn = t < mn ? t : mn; }
     live = wave_sum_u64(live);
