@@ -95,6 +95,28 @@ def test_north_star_50M_reads_properties(config, nodes, edges):
         eng.close()
 
 
+@pytest.mark.parametrize("n_reads", [2_250_000, 2_400_000])
+def test_both_sides_of_the_partial_sort_threshold(n_reads):
+    """The index build sorts only the key bits the directory needs (bucket and m_C >> 3) once there are 2^22 nodes or more, all 32 bits
+    below that (rocPRIM's merge-sort path compares the wrong bits for a sort on [b, 32): alga_amd/csrc/sort_records.hip).  Node sets just
+    under and just over the threshold, the clustered join against the seed-table probe."""
+    import torch
+    wl = workload.device_build(n_reads, 150, 5 * n_reads, 23)
+    torch.cuda.synchronize()
+    n = int(wl["lens"].shape[0])
+    assert (n < (1 << 22)) == (n_reads == 2_250_000) and abs(n - (1 << 22)) < 300_000
+    eng = alga_amd.Engine(0)
+    try:
+        cl, st = _build(eng, wl, "cluster")
+        assert st["probe_used"] == 2
+        _check_list(cl, n, int(wl["lens"].max().item()), wl["min_overlap"])
+        tb, st2 = _build(eng, wl, "table")
+        assert st2["probe_used"] == 1 and st2["raw_overlaps"] == st["raw_overlaps"]
+        assert torch.equal(cl, tb)
+    finally:
+        eng.close()
+
+
 def test_configs4_10M_reads_with_errors_properties():
     """BASELINE configs[4]: exact graph through both probes and both reductions, then the approximate supplement: 19 989 632 nodes,
     4 617 669 exact edges, 8 991 578 after the supplement (profiles/r03_cfg5_10M_bench.json; the exact graph of this shape equals the
