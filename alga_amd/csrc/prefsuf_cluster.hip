@@ -338,6 +338,7 @@ __global__ void __launch_bounds__(256) k_tgt_gather(NodesDev nd, const uint32_t 
 // LDS so that a bucket is walked at LDS latency (round 2: an index array first, then a second pass through global memory per
 // bucket).  Measured and rejected: folding this pass into k_tgt_gather (the walk serialises behind that kernel's random row
 // reads: 6.5 against 3.0 + 1.2 ms); collecting the records of a tile in LDS and writing them out as whole lines (1.4 against 1.2 ms).
+__device__ __forceinline__ uint32_t bperm(uint32_t v, int src_lane) { return (uint32_t) __builtin_amdgcn_ds_bpermute(src_lane << 2, (int) v); }
 constexpr int TD_TILE = 256, TD_HALO = 96;                 // entries per tile (512 and 1024 measure the same); entries staged past it
 __global__ void __launch_bounds__(TD_TILE) k_tgt_dir(const uint32_t *__restrict__ keys, uint64_t n, int shift, uint32_t n_buckets, uint4 *__restrict__ dir) {
     __shared__ uint32_t sb[TD_TILE + TD_HALO + 1];         // (bucket << 3 | m_C class) of the entries base - 1 .. base + TD_TILE + TD_HALO - 1
@@ -359,8 +360,8 @@ __global__ void __launch_bounds__(TD_TILE) k_tgt_dir(const uint32_t *__restrict_
     const bool real = start && b != n_buckets;
     // A wave's time is its longest lane's: with one lane per bucket walking its entries, the 3 - 5 buckets that start in a wave's 64
     // entries (13 entries each at 30x coverage, hundreds in repeats) kept the other 60 lanes waiting -- 1.06 ms, VALU-bound.  Now a
-    // lane walks its own bucket only if that ends within TD_SHORT entries; the longer ones are taken one after the other by the whole
-    // wave, 64 entries per step, the class counts from ballots.
+    // lane walks its own bucket only if that ends within TD_SHORT entries; the longer ones are taken by 16-lane rows, four buckets side
+    // by side (one after the other by the whole wave, the class counts from seven ballots per step: 0.82 ms).
     constexpr int TD_SHORT = 4;
     const bool is_short = real && (sb[t + 1 + TD_SHORT] >> 3) != b;       // (t + 1 + TD_SHORT <= TD_TILE + TD_HALO)
     if (is_short) {
@@ -374,50 +375,59 @@ __global__ void __launch_bounds__(TD_TILE) k_tgt_dir(const uint32_t *__restrict_
         }
         put(b, make_uint4((uint32_t) j, (uint32_t) u, (uint32_t) acc, (uint32_t) (acc >> 32)));
     }
+    // the longer buckets, FOUR at a time, each by one 16-lane row of the wave: 16 entries per step, the eight byte counters of the
+    // step summed over the row by a DPP scan (byte 0 counts the entries themselves; no byte overflows below 240 entries)
     unsigned long long longs = __ballot(real && !is_short);
-    while (longs != 0ull) {                                // uniform
-        const int l0 = __builtin_ctzll(longs);
-        longs &= longs - 1ull;
-        const int t0 = (t & ~63) + l0;                     // the starting thread's index in the workgroup
-        const uint32_t bb = (uint32_t) __builtin_amdgcn_readlane((int) b, l0);
-        uint32_t cnt = 0u, lo = 0u, hi = 0u;
-        bool past = false;                                 // the bucket runs past the staged entries
-        for (int u = 0;; u += 64) {
-            const int idx = t0 + 1 + u + lane;
+    const int g = lane >> 4, gl = lane & 15;
+    while (longs != 0ull) {                                // uniform: up to four bucket starts per pass
+        int lsel = 64;                                     // the start lane this row takes (64: none)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int l = longs ? __builtin_ctzll(longs) : 64;
+            longs = longs ? (longs & (longs - 1ull)) : 0ull;
+            lsel = g == q ? l : lsel;
+        }
+        const bool has = lsel < 64;
+        const int t0 = (t & ~63) + (has ? lsel : 0);       // the starting thread's index in the workgroup
+        const uint32_t bb = bperm(b, has ? lsel : 0);
+        unsigned long long acc = 0ull;                     // byte 0: entries, bytes 1 .. 7: first[s]
+        bool open = has, past = false;
+        for (int u = 0;; u += 16) {
+            const int idx = t0 + 1 + u + gl;
             const bool staged = idx <= TD_TILE + TD_HALO;
             const uint32_t x = staged ? sb[idx] : 0xFFFFFFFFu;
-            const bool inb = staged && (x >> 3) == bb;
-            const uint32_t cls = inb ? (x & 7u) : 8u;
-            const unsigned long long m = __ballot(inb);
-            cnt += (uint32_t) __popcll(m);
-            lo += ((uint32_t) __popcll(__ballot(cls < 1u)) << 8) + ((uint32_t) __popcll(__ballot(cls < 2u)) << 16) + ((uint32_t) __popcll(__ballot(cls < 3u)) << 24);
-            hi += (uint32_t) __popcll(__ballot(cls < 4u)) + ((uint32_t) __popcll(__ballot(cls < 5u)) << 8) + ((uint32_t) __popcll(__ballot(cls < 6u)) << 16) +
-                  ((uint32_t) __popcll(__ballot(cls < 7u)) << 24);
-            if (m != ~0ull) {                              // the bucket ended inside this step -- or the staged entries did
-                const int last = t0 + 1 + u + (int) __popcll(m);           // first index not taken
-                past = last > TD_TILE + TD_HALO;
-                break;
-            }
-            if (cnt >= 256u) { past = true; break; }       // the class offsets are moot from here on: only the end is needed
+            const bool inb = open && staged && (x >> 3) == bb;
+            const unsigned long long c = inb ? ((0x0101010101010100ull << (8u * (x & 7u))) | 1ull) : 0ull;
+            uint32_t lo = (uint32_t) c, hi = (uint32_t) (c >> 32);
+            lo += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) lo, 0x111, 0xF, 0xF, true); hi += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) hi, 0x111, 0xF, 0xF, true);
+            lo += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) lo, 0x112, 0xF, 0xF, true); hi += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) hi, 0x112, 0xF, 0xF, true);
+            lo += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) lo, 0x114, 0xF, 0xF, true); hi += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) hi, 0x114, 0xF, 0xF, true);
+            lo += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) lo, 0x118, 0xF, 0xF, true); hi += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) hi, 0x118, 0xF, 0xF, true);
+            lo = bperm(lo, lane | 15); hi = bperm(hi, lane | 15);          // the row's total, in every lane of the row
+            acc += ((unsigned long long) hi << 32) | lo;
+            const uint32_t took = lo & 255u, cnt = (uint32_t) acc & 255u;
+            if (open && took < 16u) { open = false; past = t0 + 1 + u + (int) took > TD_TILE + TD_HALO; }     // ended in this step -- or the staged entries did
+            else if (open && cnt >= 240u) { open = false; past = true; }                                    // the byte counters stop here: on serially
+            if (__ballot(open) == 0ull) break;             // uniform
         }
-        if (lane == l0) {
-            uint64_t k = j + (uint64_t) cnt;
-            if (past || cnt >= 256u) {                     // repeats: on through global memory, the end by bisection beyond 256 entries
-                unsigned long long acc = ((unsigned long long) hi << 32) | lo;
-                for (; k < j + 256u; k++) {
+        if (has && gl == 0) {
+            const uint64_t j0 = base + (uint64_t) t0;
+            uint64_t k = j0 + (uint64_t) ((uint32_t) acc & 255u);
+            acc &= ~255ull;
+            if (past) {                                    // repeats: on through global memory, the end by bisection beyond 256 entries
+                for (; k < j0 + 256u; k++) {
                     const uint32_t x = tagged(k);
-                    if ((x >> 3) != b) break;
+                    if ((x >> 3) != bb) break;
                     acc = tally(acc, x & 7u);
                 }
-                lo = (uint32_t) acc; hi = (uint32_t) (acc >> 32);
-                if (k >= j + 256u && (tagged(k) >> 3) == b) {
-                    uint64_t a = k, z = n;                 // bucket(a) == b, bucket(z) > b (z == n: past the end)
-                    while (z - a > 1) { const uint64_t mid = a + (z - a) / 2; if ((tagged(mid) >> 3) == b) a = mid; else z = mid; }
+                if (k >= j0 + 256u && (tagged(k) >> 3) == bb) {
+                    uint64_t a = k, z = n;                 // bucket(a) == bb, bucket(z) > bb (z == n: past the end)
+                    while (z - a > 1) { const uint64_t mid = a + (z - a) / 2; if ((tagged(mid) >> 3) == bb) a = mid; else z = mid; }
                     k = z;
                 }
             }
-            const uint32_t c = (uint32_t) (k - j);
-            put(b, make_uint4((uint32_t) j, c, c <= 255u ? lo : 0u, c <= 255u ? hi : 0u));
+            const uint32_t c = (uint32_t) (k - j0);
+            put(bb, make_uint4((uint32_t) j0, c, c <= 255u ? (uint32_t) acc : 0u, c <= 255u ? (uint32_t) (acc >> 32) : 0u));
         }
     }
 }
@@ -428,7 +438,6 @@ __global__ void __launch_bounds__(TD_TILE) k_tgt_dir(const uint32_t *__restrict_
 #ifndef CL_OCC
 #define CL_OCC 6                      // workgroups per CU of the persistent grid: 24 waves per CU (VGPR <= 80, LDS <= 26 KB, SGPR <= 112)
 #endif
-__device__ __forceinline__ uint32_t bperm(uint32_t v, int src_lane) { return (uint32_t) __builtin_amdgcn_ds_bpermute(src_lane << 2, (int) v); }
 
 // Two-stage software pipeline over the sources of a wave: while the entry loads of source i are in flight the wave stages the
 // row of source i+1 and issues the index loads of its runs; those land while source i is verified and reduced.  State of a
