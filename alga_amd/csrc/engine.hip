@@ -225,6 +225,7 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
         if ((rc = alga_ensure(e, e->rec_val, cap * sizeof(unsigned long long)))) return rc;
         HIP_TRY(e, hipMemsetAsync(cnt, 0, CNT_TOTAL * sizeof(unsigned long long), s));
         ProbeBig big{(int32_t *) e->loc_big_list.p, big_list_cap, 0u, nullptr, 0u};
+        e->defer_list_valid = clustered && e->opt_cluster_pairs;           // k_probe_stream first: every source with records is on cl_defer (finalize_local)
         if (clustered) {
             // Two kernels: k_probe_stream (the entries of consecutive sources packed densely onto the lanes) finishes the regular sources
             // and lists the others; the general kernel (one source per wave, any shape) takes the list.  No host round trip in between:
@@ -389,13 +390,13 @@ int finalize_local(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_
     HIP_TRY(e, hipEventRecord(e->ev[EV_REDUCE], s));
     launch_exclusive_scan((const uint32_t *) e->outdeg.p, n_src, (uint32_t *) e->out_rowptr.p, (uint64_t *) e->scan_scratch.p, s);
     if ((rc = alga_check_launch(e, "scan(outdeg)"))) return rc;
-    HIP_TRY(e, hipMemsetAsync(e->out_cnt.p, 0, (size_t) (n_src + 1) * sizeof(uint32_t), s));
-    const uint64_t E = e->stats.records;                                   // CNT_VALID_RECORDS of the probe == sum of the out-degrees
+    const uint64_t E = e->stats.records;                                   // CNT_VALID_RECORDS of the probe == sum of the out-degrees (launch_local_emit zeroes the cursors it needs)
     if (E >= (1ull << 32) - 16) return alga_fail(e, ALGA_ERR_CAPACITY, "more than 2^32 edges; shard the input");
     if ((rc = alga_ensure(e, e->edges, (size_t) (E + 1) * sizeof(alga_edge_dev)))) return rc;
     launch_local_emit(src_begin, (int32_t) n_src, (const uint32_t *) e->outdeg.p, (const unsigned long long *) e->loc_first.p,
                       e->loc_second_used ? (const unsigned long long *) e->loc_second.p : nullptr, (const uint32_t *) e->rec_dst.p, (const unsigned long long *) e->rec_val.p, n_rec, (const uint32_t *) e->out_rowptr.p,
-                      (uint32_t *) e->out_cnt.p, (alga_edge_dev *) e->edges.p, s);
+                      (uint32_t *) e->out_cnt.p, (alga_edge_dev *) e->edges.p,
+                      e->defer_list_valid ? (const int32_t *) e->cl_defer.p : nullptr, (const unsigned long long *) e->counters.p + CNT_DEFERRED, (uint32_t) n_src, s);
     if ((rc = alga_check_launch(e, "k_local_emit"))) return rc;
     HIP_TRY(e, hipEventRecord(e->ev[EV_EMIT], s));
     uint64_t *d_total = (uint64_t *) e->scan_scratch.p + scan_total_index(n_src);

@@ -40,6 +40,7 @@ struct alga_engine {
     // alga_prefsuf_keys_device: the node range whose keys / runs this engine computed last (n < 0: none), consumed by a build with
     // params.keys_shared
     int32_t keyed_n = -1, keyed_begin = 0, keyed_end = 0;
+    bool defer_list_valid = false;     // the last discover ran k_probe_stream first: cl_defer / counters[CNT_DEFERRED] list every source whose row came from records
     const void *keyed_words = nullptr;
     // the entry array / index / directory / runs left by the last clustered build (n < 0: none): reusable with params.keys_shared = 2
     int32_t store_n = -1, store_run_begin = 0, store_run_end = 0, store_eq = 0;

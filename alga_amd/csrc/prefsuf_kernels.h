@@ -31,9 +31,11 @@ void launch_probe(const NodesDev &nd, const PrefSufCfg &cfg, const unsigned long
                   const ProbeBig *big /* local: may be null */, hipStream_t s);
 uint64_t probe_record_slack(int n_cu, uint64_t n_src, bool local);
 // source-side reduction: adjacency lists from the probe's out-degrees (rowptr = their scan), one-edge slots and record list
+// record_sources (device, may be null: every row is sorted): the ids of the only sources whose rows were filled from records, their number at
+// *record_sources_count (device), at most record_sources_cap
 void launch_local_emit(int32_t src_base, int32_t n_src, const uint32_t *deg, const unsigned long long *first, const unsigned long long *second,
                        const uint32_t *rec_dst, const unsigned long long *rec_val, uint64_t n_rec, const uint32_t *rowptr, uint32_t *cursor,
-                       alga_edge_dev *edges, hipStream_t s);
+                       alga_edge_dev *edges, const int32_t *record_sources, const unsigned long long *record_sources_count, uint32_t record_sources_cap, hipStream_t s);
 
 // clustered minimizer join (prefsuf_cluster.hip): source-side form with one-word offset masks (max_len - Lmin <= 63)
 bool       cluster_plan(const PrefSufCfg &cfg, int max_len, uint64_t live, int bucket_log2_bias, ClusterCfg *c, int *eq);   // false: this probe does not take the input
