@@ -354,12 +354,13 @@ def run(args, rank, world, local_rank, dist, t_process=None):
             runs_per_node = 1.0 + 2.0 * (stats["windows_probed"] / n_src - 1.0) / (min(64, lo - max(lo - 63, min(lo, 16)) + 1) + 1.0)
             nb = int(stats["table_slots"])
             rk = [("k_node_runs", ms["keys"], n * (4 * W + 4) + n * (13 + 8 * runs_per_node), "VALU-bound: ~1650 vector instructions per node"),
-                  ("rocprim radix sort of (key, id) (onesweep, 4 passes)", ms["sort"], 4 * n + 4 * 2 * 8 * n, None),
+                  ("rocprim radix sort of (key, id) (onesweep; >= 2^22 nodes: the 29 key bits the directory needs in 3 passes of 10, else 32 bits in 4 passes of 8)",
+                   ms["sort"], 4 * n + (3 if n >= (1 << 22) else 4) * 2 * 8 * n, "library code; bytes = histogram read + passes x (read + write) of 8-byte pairs"),
                   ("k_tgt_gather", ms["gather"], n * (4 * W + 8 + 16 * eq), "one isolated 64-byte row per entry: 128 bytes fetched for it"),
-                  ("k_tgt_dir", ms["dir"], 4 * n + 16 * (nb + 1), None),
+                  ("k_tgt_dir", ms["dir"], 4 * n + 16 * (nb + 1), "includes the zero fill of the directory (16 B per bucket) in front of the kernel"),
                   (probe_kernel if first_dominates else "k_probe_stream", ms["probe_pairs"], alg_probe_launch * (1.0 - deferred / n_src), None),
                   ("k_probe_clustered", ms["probe"] - ms["probe_pairs"], alg_probe_launch * (deferred / n_src), None),
-                  ("scan + k_local_emit_* + k_sort_rows", ms["emit"], n * 16 + E * 12 * 2, None)]
+                  ("scan + k_local_emit_* + k_sort_rows_list", ms["emit"], n * 16 + E * 12, None)]
             out["roofline_kernels"] = []
             for name, kms, ab, note in rk:
                 if kms < 0.02 * ms_step:
