@@ -186,7 +186,7 @@ class ShardedPrefSuf:
         # The rank's source range in `pieces` consecutive pieces (the first one sorts the gathered keys into the entry array, the
         # others reuse it): the edges of a piece travel to rank 0 while the next piece is probed.  Per piece one small all_gather
         # carries every rank's "declined" flag and edge count.
-        pieces = self.pieces if karr is not None else 1
+        pieces = self.pieces                     # (without the sharded key pass the first piece computes every node's keys itself: keys_shared 0, then 2)
         pb = [b[r] + 2 * (((b[r + 1] - b[r]) // 2 * k) // pieces) for k in range(pieces)] + [b[r + 1]]
         st, pending, declined = None, [], False
         t_wait = 0.0
@@ -386,7 +386,10 @@ def validated_runner(backend, rank, world, dist, plain=None, **fast_kw):
     form = {"form": "plain (all keys on every rank, one piece per rank)", "validated": None}
     if world <= 1:
         return plain, form
-    kw = dict(shard_keys=True, pieces=None)
+    # two ranks: every rank computes all keys itself (5.4 ms at the north-star size) -- cheaper than the keys of half the nodes plus the
+    # all-gather of the other half over the one link between two GPUs (2.7 + 3.6 ms), and one collective less; from three ranks on the
+    # sharded key pass wins (1.5 + 1.8 ms at four)
+    kw = dict(shard_keys=world > 2, pieces=None)
     kw.update(fast_kw)
     ok, why, fast, m_plain = 0, "", None, 0
     try:
@@ -401,7 +404,8 @@ def validated_runner(backend, rank, world, dist, plain=None, **fast_kw):
     t = torch.tensor([ok], dtype=torch.int64, device=backend.device)
     dist.all_reduce(t)
     if int(t.item()) == world:
-        form = {"form": "keys of own nodes + in-place key all-gather, %d pieces per rank (edge transfers overlap the next piece's probe)" % fast.pieces,
+        form = {"form": "%s, %d pieces per rank (edge transfers overlap the next piece's probe)" %
+                        ("keys of own nodes + in-place key all-gather" if fast.shard_keys else "all keys on every rank", fast.pieces),
                 "validated": "complete graph on rank 0 byte-identical (count + position-weighted checksum) to the plain form's in this run: %d edges" % m_plain}
         return fast, form
     form["validated"] = "sharded form NOT taken: " + (why or "another rank failed its check")

@@ -577,7 +577,7 @@ def test_bench_run_as_two_thread_ranks_equals_one_gpu():
     assert res[1] is None
     two = res[0]
     assert two["n_gpus"] == 2 and two["config"]["edges"] == one["config"]["edges"] > 5_000_000 and two["config"]["nodes"] == one["config"]["nodes"]
-    assert two["multi_gpu_form"]["form"].startswith("keys of own nodes") and "byte-identical" in two["multi_gpu_form"]["validated"]
+    assert two["multi_gpu_form"]["form"].startswith("all keys on every rank, 4 pieces") and "byte-identical" in two["multi_gpu_form"]["validated"]   # (two ranks: no key all-gather)
     assert two["value"] > 0 and two["roofline"]["frac"] > 0 and two["scaling"] == "strong"
     plain = run_ranks(2, lambda rank, dist: bench.run(bench.parse_args(["--gpus", "2", "--multi-plain"] + common), rank, 2, 0, dist))[0]
     assert plain["config"]["edges"] == one["config"]["edges"] and plain["multi_gpu_form"]["form"].startswith("plain")

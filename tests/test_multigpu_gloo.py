@@ -81,7 +81,8 @@ class PyBackend:
             self.first_piece_done = True
             k, m = self._fake_keys(0, self.n)
             assert (self.karr[0][:self.n].numpy() == k).all() and (self.karr[1][:self.n].numpy() == m).all()
-        # keys_shared == 0: the rank computes all keys itself (the driver's default until the sharded key pass has run over RCCL)
+        else:                                             # keys_shared == 0: the rank computes all keys itself (the plain form; the first piece of a two-rank run)
+            self.first_piece_done = True
         if not self.source_side or self.decline:
             return None
         from source_side_rule import source_side_edges
@@ -246,7 +247,7 @@ def test_validated_runner_takes_the_sharded_form_only_when_it_reproduces_the_pla
         if corrupt:
             assert form.startswith("plain") and "NOT taken" in validated and int(pieces) == 1
         else:
-            assert form.startswith("keys of own nodes") and "byte-identical" in validated and int(pieces) > 1
+            assert form.startswith("all keys on every rank") and "byte-identical" in validated and int(pieces) > 1      # (two ranks: pieces without the key all-gather)
     got = np.load(str(tmp_path / "edges_0.npy"))
     assert got.shape == want.shape and (got == want).all()
 
