@@ -39,6 +39,27 @@ def shard_bounds(n, world):
     return [min(n, r * c) for r in range(world)] + [n]
 
 
+PIECE_RATIO = 0.75      # a piece is this fraction of the one before it (piece_bounds)
+
+
+def piece_bounds(lo, hi, pieces, ratio=PIECE_RATIO):
+    """A rank's source range [lo, hi) in `pieces` consecutive pieces, even-aligned (a read and its reverse complement stay together), each
+    `ratio` times the one before: the edges of a piece travel while the next piece is probed, so what the last piece ships is not hidden --
+    shrinking pieces leave a short tail, and a piece's transfer (link time ~0.73 of its probe time at two ranks, ~0.79 at four and eight:
+    DESIGN.md section 7) still ends before the next, smaller piece's probe does."""
+    pairs = (hi - lo) // 2
+    w = [ratio ** k for k in range(pieces)]
+    tot = sum(w)
+    cuts, acc = [lo], 0.0
+    for k in range(pieces - 1):
+        acc += w[k]
+        cuts.append(lo + 2 * min(pairs, int(round(pairs * acc / tot))))
+    cuts.append(hi)
+    for k in range(1, len(cuts)):
+        cuts[k] = max(cuts[k], cuts[k - 1])
+    return cuts
+
+
 KEY_ARRAY_SLACK = 1024      # the engine's per-node key arrays have room for n + 1024 entries (include/alga_amd.h): world * chunk <= n + 2 * world
 
 
@@ -187,7 +208,7 @@ class ShardedPrefSuf:
         # others reuse it): the edges of a piece travel to rank 0 while the next piece is probed.  Per piece one small all_gather
         # carries every rank's "declined" flag and edge count.
         pieces = self.pieces                     # (without the sharded key pass the first piece computes every node's keys itself: keys_shared 0, then 2)
-        pb = [b[r] + 2 * (((b[r + 1] - b[r]) // 2 * k) // pieces) for k in range(pieces)] + [b[r + 1]]
+        pb = piece_bounds(b[r], b[r + 1], pieces)
         st, pending, declined = None, [], False
         t_wait = 0.0
         for k in range(pieces):

@@ -262,12 +262,15 @@ def test_shard_bounds_keep_twins_together():
 
 def test_piece_bounds_cover_the_rank_range():
     """the pieces a rank cuts its source range into (alga_amd/multigpu.py): consecutive, even-aligned, covering, for every world size"""
-    from alga_amd.multigpu import shard_bounds
+    from alga_amd.multigpu import shard_bounds, piece_bounds
     for n in (10, 2000, 1700526, 90621096):
         for w in (2, 3, 4, 8):
             b = shard_bounds(n, w)
             for r in range(w):
                 for pieces in (1, 2, 4):
-                    pb = [b[r] + 2 * (((b[r + 1] - b[r]) // 2 * k) // pieces) for k in range(pieces)] + [b[r + 1]]
-                    assert pb[0] == b[r] and pb[-1] == b[r + 1] and all(x <= y for x, y in zip(pb, pb[1:]))
+                    pb = piece_bounds(b[r], b[r + 1], pieces)
+                    assert len(pb) == pieces + 1 and pb[0] == b[r] and pb[-1] == b[r + 1] and all(x <= y for x, y in zip(pb, pb[1:]))
                     assert all((x - b[r]) % 2 == 0 for x in pb[:-1])
+                    if b[r + 1] - b[r] > 1000 and pieces > 1:          # each piece about three quarters of the one before it
+                        sz = [y - x for x, y in zip(pb, pb[1:])]
+                        assert all(0.70 < q / p < 0.80 for p, q in zip(sz, sz[1:]))

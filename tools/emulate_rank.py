@@ -51,7 +51,7 @@ for r in sorted(set([0, N - 1])):
             v[b[r + 1]:] = full[b[r + 1]:]
         torch.cuda.synchronize()
         t2 = time.perf_counter()
-        pb = [b[r] + 2 * (((b[r + 1] - b[r]) // 2 * k) // pieces) for k in range(pieces)] + [b[r + 1]]
+        pb = multigpu.piece_bounds(b[r], b[r + 1], pieces)
         edges, seed, probe, emit = 0, 0.0, 0.0, 0.0
         for k in range(pieces):
             res = eng.build_range_device(dw, dl, lo, rs, pb[k], pb[k + 1], keys_shared=1 if k == 0 else 2)
