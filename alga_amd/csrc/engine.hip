@@ -199,7 +199,7 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
             HIP_TRY(e, launch_cluster_store(nd, cc, pp.cluster_eq, (uint32_t *) e->cl_keys[0].p, (uint32_t *) e->cl_vals[0].p, (uint32_t *) e->cl_keys[1].p,
                                             (uint32_t *) e->cl_vals[1].p, (const uint32_t *) e->cl_meta.p, pp.uniform_len, e->sort_temp.p,
                                             cluster_sort_temp_bytes((uint64_t) nd.n), e->cl_store.p, e->cl_dir.p, pp.keys_shared == 1, e->ev[EV_SORT],
-                                            e->ev[EV_GATHER], s));
+                                            e->ev[EV_GATHER], cnt + CNT_TOTAL + 1, e->opt_test_unsorted_index != 0, s));
             e->store_timed = nd.n > 0;
             e->store_n = nd.n; e->store_words = (const void *) nd.words; e->store_eq = pp.cluster_eq; e->store_buckets = cc.n_buckets;
             e->store_run_begin = run_begin; e->store_run_end = run_end;
@@ -261,8 +261,14 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
                          (unsigned long long *) e->loc_first.p, local ? &big : nullptr, s);
         if ((rc = alga_check_launch(e, "k_probe_sources"))) return rc;
         HIP_TRY(e, hipEventRecord(e->ev[EV_PROBE], s));
-        HIP_TRY(e, hipMemcpyAsync(e->h_counters, cnt, CNT_TOTAL * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        HIP_TRY(e, hipMemcpyAsync(e->h_counters, cnt, (CNT_TOTAL + 2) * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
         HIP_TRY(e, hipStreamSynchronize(s));
+        if (clustered && e->h_counters[CNT_TOTAL + 1] != 0) {
+            // k_tgt_dir found the sorted key array out of order (a sort that did not sort): the directory describes nothing.  The probe
+            // clamps its entry reads, so nothing faulted; nothing it produced is used either.
+            e->store_n = -1; e->keyed_n = -1;
+            return alga_fail(e, ALGA_ERR_HIP, "clustered index: the sorted key array is not in order (entry directory invalid)");
+        }
         if (local && e->h_counters[CNT_LOCAL_OVERFLOW] != 0) {
             // Some sources have more raw overlaps than a wave's LDS holds (repeat-rich input): the first pass listed them, a second
             // pass probes exactly those with their items in a global slice per wave.  Too many of them, or too many overlaps for the
@@ -528,6 +534,8 @@ int alga_engine_set_option(alga_engine *e, const char *name, int64_t value) {
         e->opt_cluster_order = value != 0;
     } else if (!strcmp(name, "local_big_max")) {
         e->big_limit = value < 0 ? -1 : (int) std::min<int64_t>(value, 1 << 20);
+    } else if (!strcmp(name, "test_unsorted_index")) {
+        e->opt_test_unsorted_index = value != 0;           // tests only: the clustered index is built over UNSORTED keys; the build must fail, not fault
     } else if (!strcmp(name, "auto_reduction_per_target")) {
         e->opt_force_per_target = value != 0;
     } else return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "unknown option");

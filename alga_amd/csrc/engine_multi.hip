@@ -68,15 +68,24 @@ struct Rccl {
     }
 };
 
-// all ranks arrive, all leave; reusable
+// What every rank must see alike after a rendezvous: did any rank fail, did any rank decline the source-side form.  The LAST arriver of
+// a barrier takes the snapshot under the barrier's mutex and every rank leaves with that one copy: a rank that runs ahead and fails (or
+// resets its slot) in the next phase can no longer make two ranks read different answers and take different branches -- which would
+// leave them in barriers of different phases for ever.
+struct Agreed { bool failed = false, declined = false; };
+
+// all ranks arrive, all leave; reusable.  n is fixed before the first rank thread runs (run_build's start gate).
 struct Barrier {
     std::mutex mu; std::condition_variable cv; int n = 1, waiting = 0; unsigned long phase = 0;
-    void wait() {
+    Agreed snap;
+    template <class F> Agreed wait(F &&take_snapshot) {
         std::unique_lock<std::mutex> lk(mu);
         const unsigned long ph = phase;
-        if (++waiting == n) { waiting = 0; phase++; cv.notify_all(); }
+        if (++waiting == n) { waiting = 0; snap = take_snapshot(); phase++; cv.notify_all(); }
         else cv.wait(lk, [&] { return phase != ph; });
+        return snap;                                       // read under the mutex: the next phase's snapshot needs all n ranks back in wait()
     }
+    void wait() { (void) wait([this] { return snap; }); }
 };
 
 inline double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -99,6 +108,7 @@ struct alga_multi {
     std::vector<alga_node_keys> keys;
     std::vector<const alga_edge *> d_edges;
     std::vector<uint64_t> counts;
+    std::vector<char> declined;                            // rank r's build answered ALGA_ERR_UNSUPPORTED; written by r before the barrier, read by the barrier's snapshot only
     std::vector<alga_prefsuf_stats> stats;
     DevBuf gathered;                                       // rank 0's device: the complete edge list
     alga_multi_stats mstats{};
@@ -111,6 +121,15 @@ int mfail(alga_multi *m, int code, const std::string &what) { m->err = what; ret
 // ids per rank: equal, even (a read and its reverse complement, ids 2i and 2i + 1, stay together); alga_amd/multigpu.py: shard_chunk
 int64_t shard_chunk(int64_t n, int ranks) { return 2 * ((n + 2 * (int64_t) ranks - 1) / (2 * (int64_t) ranks)); }
 
+// the snapshot the last arriver of a barrier takes (under the barrier's mutex; every rank has written its slots before arriving)
+Agreed snapshot(const alga_multi *m) {
+    Agreed a;
+    for (int x : m->rc) a.failed = a.failed || x != ALGA_OK;
+    for (char d : m->declined) a.declined = a.declined || d != 0;
+    return a;
+}
+Agreed rendezvous(alga_multi *m) { return m->bar.wait([m] { return snapshot(m); }); }
+
 // The collectives of the driver behind one small interface (m->transport): everything else of a rank's work is transport-agnostic.
 //   all_gather_u32: every rank's slice [r * chunk, (r + 1) * chunk) of its own array `mine` -> the same slice of every rank's array
 //   gather_edges  : rank q's list (counts[q] edges at d_edges[q]) -> rank 0's `out` at offset off[q]
@@ -121,14 +140,14 @@ struct Collectives {
     int hip(hipError_t e, const char *what) { return e == hipSuccess ? ALGA_OK : fail(ALGA_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e)); }
     int nccl(int e, const char *what) { return e == 0 ? ALGA_OK : fail(ALGA_ERR_HIP, std::string(what) + ": " + m->rccl.GetErrorString(e)); }
 
-    int all_gather_u32(uint32_t *mine, uint32_t *const *all /* all[q] = rank q's array */, size_t chunk) {
+    // (the collectives end in a rendezvous and hand back its snapshot: what every rank agrees on at that point)
+    Agreed all_gather_u32(uint32_t *mine, uint32_t *const *all /* all[q] = rank q's array */, size_t chunk) {
         hipStream_t s = m->stream[(size_t) r];
         int rc = ALGA_OK;
         if (m->transport == ALGA_TRANSPORT_RCCL) {
             rc = nccl(m->rccl.AllGather(mine + (size_t) r * chunk, mine, chunk, NCCL_UINT32, m->comm[(size_t) r], s), "ncclAllGather(keys)");
             if (rc == ALGA_OK) rc = hip(hipStreamSynchronize(s), "all-gather of the keys");
-            m->bar.wait();
-            return rc;
+            return rendezvous(m);
         }
         rc = hip(hipStreamSynchronize(s), "key pass");     // my slice is complete before a peer reads it
         m->bar.wait();
@@ -138,26 +157,26 @@ struct Collectives {
                      "peer copy of a key slice");
         }
         if (rc == ALGA_OK) rc = hip(hipStreamSynchronize(s), "peer copies of the key slices");
-        m->bar.wait();                                     // nobody's build (which sorts the key array in place) starts while a peer still reads it
-        return rc;
+        return rendezvous(m);                              // nobody's build (which sorts the key array in place) starts while a peer still reads it
     }
 
-    int gather_edges(alga_edge *out /* rank 0 */, const std::vector<uint64_t> &off) {
+    Agreed gather_edges(alga_edge *out /* rank 0 */, const std::vector<uint64_t> &off) {
         hipStream_t s = m->stream[(size_t) r];
         int rc = ALGA_OK;
         if (m->transport == ALGA_TRANSPORT_RCCL) {
+            // every rank's transfers inside one group (rank 0: its receives; a peer: its one send), so that no call blocks on its partner
+            rc = nccl(m->rccl.GroupStart(), "ncclGroupStart");
             if (r == 0) {
-                if (m->counts[0]) rc = hip(hipMemcpyAsync(out, m->d_edges[0], m->counts[0] * sizeof(alga_edge), hipMemcpyDeviceToDevice, s), "own edges");
-                if (rc == ALGA_OK) rc = nccl(m->rccl.GroupStart(), "ncclGroupStart");
                 for (int q = 1; q < m->n && rc == ALGA_OK; q++)
                     if (m->counts[(size_t) q]) rc = nccl(m->rccl.Recv(out + off[(size_t) q], m->counts[(size_t) q] * 3, NCCL_INT32, q, m->comm[0], s), "ncclRecv(edges)");
-                if (rc == ALGA_OK) rc = nccl(m->rccl.GroupEnd(), "ncclGroupEnd");
             } else if (m->counts[(size_t) r]) {
                 rc = nccl(m->rccl.Send(m->d_edges[(size_t) r], m->counts[(size_t) r] * 3, NCCL_INT32, 0, m->comm[(size_t) r], s), "ncclSend(edges)");
             }
+            { const int rc2 = nccl(m->rccl.GroupEnd(), "ncclGroupEnd"); if (rc == ALGA_OK) rc = rc2; }
+            if (r == 0 && rc == ALGA_OK && m->counts[0])
+                rc = hip(hipMemcpyAsync(out, m->d_edges[0], m->counts[0] * sizeof(alga_edge), hipMemcpyDeviceToDevice, s), "own edges");
             if (rc == ALGA_OK) rc = hip(hipStreamSynchronize(s), "gather of the edge lists");
-            m->bar.wait();
-            return rc;
+            return rendezvous(m);
         }
         if (r == 0) {                                      // every build has ended in a host sync and the barrier before this call: rank 0 pulls
             for (int q = 0; q < m->n && rc == ALGA_OK; q++)
@@ -166,14 +185,12 @@ struct Collectives {
                              "peer copy of an edge list");
             if (rc == ALGA_OK) rc = hip(hipStreamSynchronize(s), "peer copies of the edge lists");
         }
-        m->bar.wait();                                     // the peers keep their lists until rank 0 has them
-        return rc;
+        return rendezvous(m);                              // the peers keep their lists until rank 0 has them
     }
 };
 
-bool any_failed(const alga_multi *m) { for (int x : m->rc) if (x != ALGA_OK) return true; return false; }
-
-// one rank's part of a build; nodes_r: the node set on THIS rank's device
+// one rank's part of a build; nodes_r: the node set on THIS rank's device.  Every branch that contains a rendezvous is taken on an
+// `Agreed` snapshot (the same copy on every rank), never on a flag another rank may be rewriting.
 void rank_main(alga_multi *m, int r, const alga_nodes *nodes_r, const alga_prefsuf_params *p, std::vector<uint64_t> *off, double *t_phase /* 5 */) {
     Collectives co{m, r};
     alga_engine *e = m->eng[(size_t) r];
@@ -188,45 +205,39 @@ void rank_main(alga_multi *m, int r, const alga_nodes *nodes_r, const alga_prefs
     int rc = alga_prefsuf_keys_device(e, nodes_r, p, b0, b1, (void *) s, &k);
     if (rc != ALGA_OK) co.fail(rc, alga_last_error(e));
     m->keys[(size_t) r] = k;
-    m->bar.wait();
-    bool ok = !any_failed(m);
-    bool shared = ok && (int64_t) N * chunk <= n + ALGA_KEY_ARRAY_SLACK;
-    for (int q = 0; q < N && shared; q++) shared = m->keys[(size_t) q].eligible != 0;
+    Agreed ag = rendezvous(m);
+    bool shared = !ag.failed && (int64_t) N * chunk <= n + ALGA_KEY_ARRAY_SLACK;
+    for (int q = 0; q < N && shared; q++) shared = m->keys[(size_t) q].eligible != 0;      // (written before the rendezvous, not touched again in this build)
     double t1 = now_ms();
     // ---- 3. share ----
     if (shared) {
         std::vector<uint32_t *> all((size_t) N);
         for (int q = 0; q < N; q++) all[(size_t) q] = m->keys[(size_t) q].d_keys;
-        co.all_gather_u32(k.d_keys, all.data(), (size_t) chunk);
+        ag = co.all_gather_u32(k.d_keys, all.data(), (size_t) chunk);
         bool meta = false;
         for (int q = 0; q < N; q++) meta = meta || m->keys[(size_t) q].meta_needed != 0;
-        if (meta) {
+        if (meta) {                                        // (taken by all ranks or none; a rank that failed above still joins the rendezvous inside)
             for (int q = 0; q < N; q++) all[(size_t) q] = m->keys[(size_t) q].d_meta;
-            co.all_gather_u32(k.d_meta, all.data(), (size_t) chunk);
+            ag = co.all_gather_u32(k.d_meta, all.data(), (size_t) chunk);
         }
-        ok = !any_failed(m);
     }
     double t2 = now_ms();
     // ---- 4. build: the final edges of my sources ----
-    bool declined = false;
-    if (ok) {
+    if (!ag.failed) {
         alga_prefsuf_params p2 = *p;
         p2.keys_shared = shared ? 1 : 0;
         const alga_edge *d = nullptr;
         uint64_t cnt = 0;
         rc = alga_prefsuf_build_range_device(e, nodes_r, &p2, b0, b1, (void *) s, &d, &cnt);
-        if (rc == ALGA_ERR_UNSUPPORTED) declined = true;
+        if (rc == ALGA_ERR_UNSUPPORTED) { m->declined[(size_t) r] = 1; cnt = 0; d = nullptr; }
         else if (rc != ALGA_OK) co.fail(rc, alga_last_error(e));
-        m->d_edges[(size_t) r] = d; m->counts[(size_t) r] = declined ? ~0ull : cnt;
+        m->d_edges[(size_t) r] = d; m->counts[(size_t) r] = cnt;
         (void) alga_prefsuf_last_stats(e, &m->stats[(size_t) r]);
     }
-    m->bar.wait();
-    ok = !any_failed(m);
-    bool any_declined = false;
-    for (int q = 0; q < N; q++) any_declined = any_declined || m->counts[(size_t) q] == ~0ull;
+    ag = rendezvous(m);
     double t3 = now_ms();
     // ---- 5. gather (or, a rank having declined the source-side form: rank 0 builds the whole graph, the general way) ----
-    if (ok && any_declined) {
+    if (!ag.failed && ag.declined) {
         if (r == 0) {
             const alga_edge *d = nullptr;
             uint64_t cnt = 0;
@@ -237,9 +248,9 @@ void rank_main(alga_multi *m, int r, const alga_nodes *nodes_r, const alga_prefs
             m->d_edges[0] = d; m->counts[0] = cnt;
             (void) alga_prefsuf_last_stats(e, &m->stats[0]);
             m->mstats.fell_back_to_one_gpu = 1;
-        } else m->counts[(size_t) r] = 0;
-        m->bar.wait();
-    } else if (ok) {
+        }
+        (void) rendezvous(m);                              // (counts[r != 0] are not read after a fallback: run_build takes rank 0's list alone)
+    } else if (!ag.failed) {
         if (r == 0) {
             uint64_t total = 0;
             for (int q = 0; q < N; q++) { (*off)[(size_t) q] = total; total += m->counts[(size_t) q]; }
@@ -256,8 +267,8 @@ void rank_main(alga_multi *m, int r, const alga_nodes *nodes_r, const alga_prefs
                 if (he != hipSuccess) co.fail(ALGA_ERR_OUT_OF_MEMORY, "edge list of the whole graph on rank 0");
             }
         }
-        m->bar.wait();
-        if (!any_failed(m) && N > 1) co.gather_edges((alga_edge *) m->gathered.p, *off);
+        ag = rendezvous(m);
+        if (!ag.failed && N > 1) (void) co.gather_edges((alga_edge *) m->gathered.p, *off);
     }
     double t4 = now_ms();
     if (r == 0) { t_phase[0] = t1 - t0; t_phase[1] = t2 - t1; t_phase[2] = t3 - t2; t_phase[3] = t4 - t3; t_phase[4] = t4 - t0; }
@@ -269,22 +280,29 @@ int run_build(alga_multi *m, const alga_nodes *per_rank, const alga_prefsuf_para
         if (per_rank[r].n != per_rank[0].n || per_rank[r].stride_words != per_rank[0].stride_words) return mfail(m, ALGA_ERR_INVALID_ARGUMENT, "the ranks hold different node sets");
     m->rc.assign((size_t) N, ALGA_OK); m->rank_err.assign((size_t) N, "");
     m->keys.assign((size_t) N, alga_node_keys{}); m->d_edges.assign((size_t) N, nullptr); m->counts.assign((size_t) N, 0);
+    m->declined.assign((size_t) N, 0);
     m->stats.assign((size_t) N, alga_prefsuf_stats{});
     memset(&m->mstats, 0, sizeof(m->mstats));
     std::vector<uint64_t> off((size_t) N + 1, 0);
     double t_phase[5] = {0, 0, 0, 0, 0};
+    // Start gate: no rank thread touches the barrier before ALL of them exist.  A thread that cannot be started (std::system_error)
+    // is noticed while the others still wait at the gate, and they leave without ever entering a rendezvous -- the barrier's count is
+    // never rewritten under a waiting thread.
+    struct Gate { std::mutex mu; std::condition_variable cv; int state = 0; /* 0 wait, 1 go, 2 abort */ } gate;
+    auto gated = [&](int r) {
+        { std::unique_lock<std::mutex> lk(gate.mu); gate.cv.wait(lk, [&] { return gate.state != 0; }); if (gate.state == 2) return; }
+        rank_main(m, r, &per_rank[r], p, &off, t_phase);
+    };
     std::vector<std::thread> th;
+    bool started = true;
     try {
-        for (int r = 1; r < N; r++) th.emplace_back(rank_main, m, r, &per_rank[r], p, &off, t_phase);
-    } catch (...) {
-        // a rank without its thread would leave the others at the first barrier for ever: nothing can be salvaged but the process
-        // state is intact -- run what was started to its end is impossible, so fail before rank 0 joins in
-        m->bar.n = (int) th.size() + 1;                    // the started threads + this one still rendezvous among themselves
-        m->rc[0] = ALGA_ERR_OUT_OF_MEMORY; m->rank_err[0] = "cannot start a host thread per GPU";
-    }
-    rank_main(m, 0, &per_rank[0], p, &off, t_phase);
+        for (int r = 1; r < N; r++) th.emplace_back(gated, r);
+    } catch (...) { started = false; }
+    { std::lock_guard<std::mutex> lk(gate.mu); gate.state = started ? 1 : 2; }
+    gate.cv.notify_all();
+    if (started) rank_main(m, 0, &per_rank[0], p, &off, t_phase);
     for (std::thread &x : th) x.join();
-    m->bar.n = N;
+    if (!started) return mfail(m, ALGA_ERR_OUT_OF_MEMORY, "cannot start a host thread per GPU");
     for (int r = 0; r < N; r++)
         if (m->rc[(size_t) r] != ALGA_OK) return mfail(m, m->rc[(size_t) r], "rank " + std::to_string(r) + ": " + m->rank_err[(size_t) r]);
     const bool one = N == 1 || m->mstats.fell_back_to_one_gpu;

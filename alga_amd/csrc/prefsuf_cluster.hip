@@ -340,7 +340,8 @@ __global__ void __launch_bounds__(256) k_tgt_gather(NodesDev nd, const uint32_t 
 // reads: 6.5 against 3.0 + 1.2 ms); collecting the records of a tile in LDS and writing them out as whole lines (1.4 against 1.2 ms).
 __device__ __forceinline__ uint32_t bperm(uint32_t v, int src_lane) { return (uint32_t) __builtin_amdgcn_ds_bpermute(src_lane << 2, (int) v); }
 constexpr int TD_TILE = 256, TD_HALO = 96;                 // entries per tile (512 and 1024 measure the same); entries staged past it
-__global__ void __launch_bounds__(TD_TILE) k_tgt_dir(const uint32_t *__restrict__ keys, uint64_t n, int shift, uint32_t n_buckets, uint4 *__restrict__ dir) {
+__global__ void __launch_bounds__(TD_TILE) k_tgt_dir(const uint32_t *__restrict__ keys, uint64_t n, int shift, uint32_t n_buckets, uint4 *__restrict__ dir,
+                                                     unsigned long long *__restrict__ bad /* set when the keys are not in (bucket, m_C class) order: the build fails with ALGA_ERR_HIP */) {
     __shared__ uint32_t sb[TD_TILE + TD_HALO + 1];         // (bucket << 3 | m_C class) of the entries base - 1 .. base + TD_TILE + TD_HALO - 1
     const uint64_t base = (uint64_t) blockIdx.x * TD_TILE;
     const uint32_t nb3 = n_buckets << 3;
@@ -354,6 +355,9 @@ __global__ void __launch_bounds__(TD_TILE) k_tgt_dir(const uint32_t *__restrict_
     // first[s] = entries of the bucket with class < s, s = 1 .. 7: seven byte counters in one 64-bit word (byte s; meaningful for
     // buckets of <= 255 entries only).  An entry of class c counts for every s > c: one shifted constant.
     auto tally = [](unsigned long long acc, uint32_t cls) { return acc + (0x0101010101010100ull << (8u * cls)); };
+    // fail closed: a directory over keys that are not in order would send the probe to entries that are not there (the probe clamps its
+    // reads, so nothing faults; the build reports the flag)
+    if (j >= 1 && j < n && sb[t + 1] < sb[t]) atomicOr(bad, 1ull);
     const uint32_t b = sb[t + 1] >> 3;
     const bool start = j <= n && b != (sb[t] >> 3);
     if (start && b == n_buckets) put(b, make_uint4((uint32_t) j, 0u, 0u, 0u));
@@ -534,7 +538,7 @@ k_probe_clustered(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__res
     auto load_entries = [&](const uint4 &rp, uint32_t k0, int gs, bool &ev, size_t &ei, uint32_t (&ew)[4 * EQ]) {
         const uint32_t j = k0 + ((uint32_t) lane & ((1u << gs) - 1u));
         ev = j < rp.w;
-        ei = ev ? (size_t) rp.z + j : (size_t) 0;           // lanes without an entry read entry 0 (unconditional loads: see index_loads)
+        ei = ev ? (size_t) min(rp.z + j, (uint32_t) nd.n - 1u) : (size_t) 0;   // lanes without an entry read entry 0 (unconditional loads: see index_loads); clamped: a corrupt directory must not fault
 #pragma unroll
         for (int c = 0; c < EQ; c++) { const uint4 v = store[ei * EQ + c]; ew[4 * c] = v.x; ew[4 * c + 1] = v.y; ew[4 * c + 2] = v.z; ew[4 * c + 3] = v.w; }
     };
@@ -896,7 +900,7 @@ k_probe_stream(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__restri
         if constexpr (BYKEY) {
             const uint32_t *ent = reinterpret_cast<const uint32_t *>(store) + (size_t) js * (4 * EQ);
             a_word = ent[col];
-            a_id = (int) ent[4 * EQ - 3];
+            a_id = (int) min(ent[4 * EQ - 3], (uint32_t) nd.n - 1u);      // (clamped: the run list is fetched by this id)
             a_len = (int) ((ent[4 * EQ - 1] >> 8) & 0xFFFu);
         } else {
             a_id = js;
@@ -1042,7 +1046,7 @@ k_probe_stream(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__restri
             { const uint32_t wv = ri >= 4 ? hi : lo; ri += (int) ((wv >> (8 * (ri & 3))) & 255u) <= hl ? 1 : 0; }
             if (ev) rp = sRun[wave][slot][ri & (CL_RMAX - 1)];
         }
-        const size_t ei = ev ? (size_t) (rp.z + (uint32_t) hl) : (size_t) 0;
+        const size_t ei = ev ? (size_t) min(rp.z + (uint32_t) hl, (uint32_t) nd.n - 1u) : (size_t) 0;      // clamped: a corrupt directory must not fault
         uint32_t ew[4 * EQ];
 #pragma unroll
         for (int c = 0; c < EQ; c++) { const uint4 v = store[ei * EQ + c]; ew[4 * c] = v.x; ew[4 * c + 1] = v.y; ew[4 * c + 2] = v.z; ew[4 * c + 3] = v.w; }
@@ -1291,14 +1295,18 @@ __global__ void __launch_bounds__(256) k_iota(uint32_t *__restrict__ v, uint32_t
 // live node has that length and there is no alignFrom mask (k_tgt_gather<., true>: meta[] is not read).
 hipError_t launch_cluster_store(const NodesDev &nd, const ClusterCfg &cc, int eq, uint32_t *keys, uint32_t *vals, uint32_t *keys2, uint32_t *vals2,
                                 const uint32_t *meta, int uniform_len, void *sort_temp, size_t sort_temp_bytes, void *store, void *dir, bool fill_vals,
-                                hipEvent_t ev_sorted, hipEvent_t ev_gathered, hipStream_t s) {
+                                hipEvent_t ev_sorted, hipEvent_t ev_gathered, unsigned long long *bad_flag, bool test_skip_sort, hipStream_t s) {
     if (nd.n <= 0) return hipSuccess;
     const uint64_t n = (uint64_t) nd.n;
     if (fill_vals) hipLaunchKernelGGL(k_iota, dim3((unsigned) std::min<uint64_t>((n + 255) / 256, 8192)), dim3(256), 0, s, vals, (uint32_t) n);
     // The order the directory and the probe need: bucket, then m_C >> 3 (the directory's eight classes).  The key bits below that --
     // the low three of m_C, the cluster bits under the field -- are compared entry by entry by the probe, never searched: they stay
     // unsorted (29 significant bits at the north-star size: three radix passes instead of four).
-    hipError_t err = sort_u32_pairs(sort_temp, sort_temp_bytes, keys, keys2, vals, vals2, n, cc.idx_shift - 3, s);
+    hipError_t err = hipSuccess;
+    if (test_skip_sort) {                                  // tests only (option "test_unsorted_index"): the keys go on as they are, the directory pass must notice
+        err = hipMemcpyAsync(keys2, keys, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s);
+        if (err == hipSuccess) err = hipMemcpyAsync(vals2, vals, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s);
+    } else err = sort_u32_pairs(sort_temp, sort_temp_bytes, keys, keys2, vals, vals2, n, cc.idx_shift - 3, s);
     if (err != hipSuccess) return err;
     if (ev_sorted) (void) hipEventRecord(ev_sorted, s);
     const uint64_t pieces = n * (uint64_t) eq;
@@ -1317,7 +1325,7 @@ hipError_t launch_cluster_store(const NodesDev &nd, const ClusterCfg &cc, int eq
     // the fill costs on its own, 0.24 ms)
     err = hipMemsetAsync(dir, 0, ((size_t) cc.n_buckets + 2) * 16, s);
     if (err != hipSuccess) return err;
-    hipLaunchKernelGGL(k_tgt_dir, dim3((unsigned) ((n + 1 + TD_TILE - 1) / TD_TILE)), dim3(TD_TILE), 0, s, (const uint32_t *) keys2, n, cc.idx_shift, cc.n_buckets, (uint4 *) dir);
+    hipLaunchKernelGGL(k_tgt_dir, dim3((unsigned) ((n + 1 + TD_TILE - 1) / TD_TILE)), dim3(TD_TILE), 0, s, (const uint32_t *) keys2, n, cc.idx_shift, cc.n_buckets, (uint4 *) dir, bad_flag);
     return hipGetLastError();
 }
 

@@ -46,7 +46,8 @@ void       launch_cluster_keys(const NodesDev &nd, const PrefSufCfg &cfg, const 
 hipError_t launch_cluster_store(const NodesDev &nd, const ClusterCfg &cc, int eq, uint32_t *keys, uint32_t *vals, uint32_t *keys2, uint32_t *vals2,
                                 const uint32_t *meta, int uniform_len /* > 0: all live nodes have this length, no alignFrom mask */, void *sort_temp,
                                 size_t sort_temp_bytes, void *store, void *dir, bool fill_vals, hipEvent_t ev_sorted /* may be null */,
-                                hipEvent_t ev_gathered /* may be null */, hipStream_t s);
+                                hipEvent_t ev_gathered /* may be null */, unsigned long long *bad_flag /* device: set when the sorted keys are not in order */,
+                                bool test_skip_sort /* tests: build the index over UNSORTED keys */, hipStream_t s);
 uint64_t   cluster_record_slack(int n_cu, uint64_t n_src);
 void       launch_probe_clustered(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterCfg &cc, int eq, const void *store, const void *dir,
                                   const void *runs, const uint8_t *nruns, int32_t src_begin, int32_t src_end, const int32_t *src_list, int32_t src_base, uint32_t *rec_dst, unsigned long long *rec_val, uint64_t rec_cap,

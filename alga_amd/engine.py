@@ -661,6 +661,18 @@ class MultiEngine:
         if rc:
             raise AlgaError(rc, (self._lib.alga_multi_last_error(self._h) or b"").decode())
 
+    def set_rank_option(self, rank, name, value):
+        """alga_engine_set_option on ONE rank's engine (alga_multi_engine): tests make a single rank decline this way."""
+        self._lib.alga_multi_engine.argtypes = [C.c_void_p, C.c_int32]
+        self._lib.alga_multi_engine.restype = C.c_void_p
+        self._lib.alga_engine_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+        eh = self._lib.alga_multi_engine(self._h, int(rank))
+        if not eh:
+            raise AlgaError(-1, "no such rank")
+        rc = self._lib.alga_engine_set_option(C.c_void_p(eh), name.encode(), int(value))
+        if rc:
+            raise AlgaError(rc, "alga_engine_set_option(%s) on rank %d" % (name, rank))
+
     def prefsuf_host(self, words, lens, min_overlap, rsoe_min_overlap, align_from=None, align_to=None, collect_stats=False, reduction="auto"):
         words = np.ascontiguousarray(words, dtype=np.uint32)
         lens = np.ascontiguousarray(lens, dtype=np.int32)

@@ -137,7 +137,9 @@ int         alga_engine_device_name(const alga_engine *e, char *buf, size_t bufl
  *                                shared look-ups, cache hits); 0: in id order (what a range of ids always gets)
  *   "local_big_max"              largest per-wave item slice of the SOURCE_SIDE second pass (default -1 = built-in 4096); beyond it
  *                                the build takes PER_TARGET
- *   "auto_reduction_per_target"  != 0: alga_prefsuf_params.reduction == AUTO resolves to PER_TARGET */
+ *   "auto_reduction_per_target"  != 0: alga_prefsuf_params.reduction == AUTO resolves to PER_TARGET
+ *   "test_unsorted_index"        tests only.  != 0: the CLUSTER probe's entry directory is built over UNSORTED keys; the directory pass
+ *                                flags it, the probe's reads are clamped to the entry array, and the build returns ALGA_ERR_HIP (no GPU fault) */
 int         alga_engine_set_option(alga_engine *e, const char *name, int64_t value);
 
 void        alga_prefsuf_default_params(alga_prefsuf_params *p);

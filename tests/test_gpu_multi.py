@@ -48,6 +48,28 @@ def test_multi_falls_back_when_a_rank_declines():
             m.close()
 
 
+@pytest.mark.parametrize("who", [0, 1, 2])
+def test_multi_exactly_one_rank_declines(who):
+    """The capacity case: ONE rank's build answers UNSUPPORTED (its per-wave item slice lowered; every source of this repeat-rich
+    input has more raw overlaps than a wave's LDS holds), the other two succeed.  All three must agree on the fallback from one
+    snapshot taken at the rendezvous (a rank re-reading a peer's flags after the barrier could see them already reset, take the
+    gather branch and wait there for ever): rank 0 builds the whole graph, same edges as the oracle."""
+    import gen_reads
+    codes, _ = gen_reads.sample_reads(5, 80, 120, 26)
+    w = alga_amd.pack_reads(np.repeat(codes, 80, axis=0))
+    lens = np.full(len(w), 80, np.int32)
+    want, _, _ = O.prefsuf(w, lens, 40, 60)
+    m = alga_amd.MultiEngine([0, 0, 0], transport="copy")
+    try:
+        m.set_rank_option(who, "local_big_max", 200)
+        for _ in range(2):
+            got = m.prefsuf_host(w, lens, 40, 60)
+            assert got.shape == want.shape and (got == want).all()
+            assert m.last_stats()["fell_back_to_one_gpu"] == 1
+    finally:
+        m.close()
+
+
 def test_multi_masks_and_empty_input():
     words, lens = _nodes(2000, 100, 4000, 84, 0.0, None)
     rng = np.random.default_rng(84)

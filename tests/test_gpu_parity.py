@@ -233,6 +233,29 @@ def test_source_side_range_build_needs_no_exchange(eng):
     assert r is not None and (device_edges_to_numpy(*r) == want250).all()
 
 
+@pytest.mark.parametrize("pairs", [1, 0])
+def test_corrupt_index_fails_closed(pairs):
+    """A clustered index built over UNSORTED keys (test-only option: the sort is skipped, as if a library sort had compared the wrong
+    bits -- round 3's GPU fault): the directory pass flags the key order, both probe kernels clamp their entry reads, and the build
+    answers ALGA_ERR_HIP instead of faulting the GPU.  The same engine then builds the right graph."""
+    words, lens = _nodes(20000, 100, 40000, 91)
+    want, _, _ = O.prefsuf(words, lens, 55, 77)
+    e = alga_amd.Engine(0)
+    try:
+        e.set_option("probe", "cluster")
+        e.set_option("cluster_pairs", pairs)
+        e.set_option("test_unsorted_index", 1)
+        with pytest.raises(alga_amd.AlgaError) as ei:
+            e.prefsuf_host(words, lens, 55, 77, reduction="source_side")
+        assert ei.value.code == -3 and "not in order" in str(ei.value)
+        e.set_option("test_unsorted_index", 0)
+        got = e.prefsuf_host(words, lens, 55, 77, reduction="source_side")
+        assert got.shape == want.shape and (got == want).all()
+        assert e.last_stats()["probe_used"] == 2
+    finally:
+        e.close()
+
+
 def test_invalid_arguments_are_errors(eng):
     words, lens = _nodes(50, 60, 500, 27)
     with pytest.raises(alga_amd.AlgaError):

@@ -4,7 +4,10 @@ is generated in chunks straight into the engine's HBM layout, duplicates removed
 reverse read of the same interval are the same sequence up to reverse complement: the reference's duplicate removal keeps
 one of them; on an iid genome nothing else is a duplicate) -- and the graph is built with BOTH forms of the transitive reduction,
 which must agree edge for edge (the size-independent parity check at a size no CPU oracle finishes).
-usage: tools/run_cfg4.py [n_reads=50000000] [genome=250000000] [steps=2] [forms=source_side,per_target] [ref_threads=0]
+usage: tools/run_cfg4.py [n_reads=50000000] [genome=250000000] [steps=2] [forms=source_side,per_target] [ref_threads=0] [ref_sha256=]
+ref_sha256 (with ref_threads = 0): the sha256 of the reference's dump for this seeded read set as recorded by an earlier full run
+(error-free data: the reference's graph does not depend on its thread count); only the engine's dump is made and compared with it.
+The output carries alga_amd.engine.source_fingerprint(): the kernel sources the result was computed with.
 With ref_threads > 0 the same reads are written as FASTA and the real reference (oracle/_ref/ALGA) builds its graph beside it:
 wall time of its creator region, its edge count, and its `--serialize=1` dump compared byte for byte (size + sha256) with the engine's
 graph written by alga_write_graph."""
@@ -28,6 +31,7 @@ def main():
     steps = int(sys.argv[3]) if len(sys.argv) > 3 else 2
     forms = sys.argv[4].split(",") if len(sys.argv) > 4 else ["source_side", "per_target"]
     ref_threads = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+    ref_sha = sys.argv[6] if len(sys.argv) > 6 else ""
     L, trim = 150, 3
     m = L - 2 * trim
     t0 = time.time()
@@ -60,7 +64,7 @@ def main():
     dw = torch.from_numpy(words.view(np.int32)).cuda()
     dl = torch.from_numpy(lens).cuda()
     del words
-    out = dict(reads=n, unique_reads=R, nodes=N, genome=G, min_overlap=lo, rsoemo=rs)
+    out = dict(reads=n, unique_reads=R, nodes=N, genome=G, min_overlap=lo, rsoemo=rs, src_sha256=alga_amd.engine.source_fingerprint())
     from alga_amd.engine import device_view
     keep = {}
     for red in forms:
@@ -84,6 +88,15 @@ def main():
         gpu_edges = e.cpu().numpy().astype(np.int32)
         out["reference"] = run_reference(genome, starts, flip, L, ref_threads, eng, N, gpu_edges)
         out["reference"]["edges_equal_gpu"] = out["reference"].get("edges") == out["edges"]
+    elif ref_sha:
+        import tempfile
+        gpu_edges = e.cpu().numpy().astype(np.int32)
+        with tempfile.TemporaryDirectory(dir=os.environ.get("ALGA_TMP", None)) as wd:
+            mine = os.path.join(wd, "gpu.graph")
+            eng.write_graph(mine, N, gpu_edges)
+            out["gpu_dump_bytes"], out["gpu_dump_sha256"] = os.path.getsize(mine), file_sha256(mine)
+        out["reference_dump_sha256_recorded"] = ref_sha
+        out["dump_byte_identical_to_recorded_reference"] = out["gpu_dump_sha256"] == ref_sha
     print(json.dumps(out))
 
 
