@@ -133,7 +133,7 @@ def _with_errors(codes, read_idx, err, seed):
     return torch.where(u < err, (codes + delta) & 3, codes)
 
 
-def device_build(n_reads, read_len, genome_len, seed, device="cuda", trim=3, chunk=1 << 21, sample_reads=0, err=0.0):
+def device_build(n_reads, read_len, genome_len, seed, device="cuda", trim=3, chunk=1 << 21, sample_reads=0, err=0.0, return_genome=False):
     """The SURVEY.md section 8(d) workload for error-free fixed-length reads, generated ON THE DEVICE (torch is only the array
     library) straight into the engine's HBM row layout: iid genome, uniform starts, strand flips; one read per start
     position (on an iid genome two reads are duplicates of each other -- on one strand or the other -- exactly when they
@@ -229,4 +229,6 @@ def device_build(n_reads, read_len, genome_len, seed, device="cuda", trim=3, chu
             codes = _with_errors(codes, ridx[sel], err, seed)
         codes = torch.where(flip[sel][:, None], (3 - codes).flip(1), codes)
         out["sample_codes"] = codes.cpu().numpy()
+    if return_genome:
+        out["genome_codes"] = genome.cpu().numpy()          # the truth the contigs are scored against (tools/genome_score.py)
     return out

@@ -10,7 +10,10 @@ DOWNSTREAM is measured here on the same reads:
   ref #2 : the same command again -- with T > 1 the reference races on ties: the distance between two of
            its own runs is the noise floor the engine's distance has to be read against
 and reported as contig statistics (count, total bp, N50, longest) plus the share of contig bp that sits in contigs found
-IDENTICALLY (up to strand) by both sides of a pair.
+IDENTICALLY (up to strand) by both sides of a pair -- and, the referee that knows the truth, against the GENOME the reads were drawn
+from (tools/genome_score.py): every contig of either side is placed on the synthetic genome or its reverse complement over its full
+length with <= 2 % mismatches; reported per side: aligned / misjoined (chimeric) / unplaced contigs, genome fraction, duplicated bp,
+N50 of the aligned contigs.  A false join raises N50; it also shows up here as a misjoined contig.
 
 usage: tools/score_supplement.py [n_reads=1000000] [genome=3*n] [threads=16] [--seed S]
 Runs on the GPU box (oracle/_ref/ALGA and alga_amd/bin/alga_hip travel with the repository snapshot)."""
@@ -82,11 +85,12 @@ def score(n, G, T=16, seed=13, rate=0.02, ref_runs=2):
     names = ["engine"] + ["ref%d" % (k + 1) for k in range(ref_runs)]
     with tempfile.TemporaryDirectory(dir=os.environ.get("TMPDIR", "/tmp")) as wd:
         if n >= 4_000_000:
-            wl = workload.device_build(n, 150, G, seed, err=rate, sample_reads=n)
-            codes = wl["sample_codes"]
+            wl = workload.device_build(n, 150, G, seed, err=rate, sample_reads=n, return_genome=True)
+            codes, genome = wl["sample_codes"], wl["genome_codes"]
             del wl
         else:
             codes, _ = gen_reads.sample_reads(n, 150, G, seed, rate)
+            genome = gen_reads.make_genome(G, np.random.default_rng(seed))      # the generator's first draw (gen_reads.sample_reads)
         fasta = os.path.join(wd, "s.fasta")
         workload.write_fasta_fast(fasta, codes)
         out["reads_written"] = int(len(codes))
@@ -106,6 +110,9 @@ def score(n, G, T=16, seed=13, rate=0.02, ref_runs=2):
         C = {k: read_contigs(os.path.join(dirs[k], "c.fasta")) for k in dirs}
     for k, v in C.items():
         out[k] = stats(v)
+    import genome_score
+    idx = genome_score.GenomeIndex(genome)
+    out["genome"] = {k: genome_score.genome_report(v, idx) for k, v in C.items()}
     rel = lambda a, b: abs(a - b) / max(1, b)      # noqa: E731
     out["bp_in_identical_contigs"] = {"engine_in_ref1": shared(C["engine"], C["ref1"]), "ref1_in_engine": shared(C["ref1"], C["engine"])}
     out["relative_difference"] = {"engine_vs_ref1": {m: rel(out["engine"][m], out["ref1"][m]) for m in ("contigs", "total_bp", "n50")}}
