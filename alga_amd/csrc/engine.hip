@@ -26,20 +26,7 @@ using namespace alga;
 
 namespace {
 
-struct Prepared {
-    NodesDev   nd;
-    PrefSufCfg cfg;
-    int        max_len = 0;
-    int        uniform_len = 0;      // > 0: every live node has this length and there is no alignFrom mask
-    uint64_t   live = 0;
-    bool       local_ok = false;     // the source-side reduction is exact for this input
-    int        local_sw = 1;         // ... with one or two 64-bit words per offset mask / uint4 per overhang
-    int        cluster_eq = 0;       // clustered minimizer probe: 16-byte pieces per entry (0 = that probe does not take this input)
-    ClusterCfg cluster{};
-    int        reduction = ALGA_REDUCTION_AUTO;
-    int        keys_shared = 0;      // 1: the per-node keys come from alga_prefsuf_keys_device + the caller's all-gather; 2: the whole
-                                     // entry array of the previous build of this node set is reused
-};
+using Prepared = AlgaPrepared;
 
 // Validates arguments, measures max read length / live nodes on the device and derives the
 // iteration bounds of GraphCreatorPrefSuf::startAlignmentGraphCreation (GraphCreatorPrefSuf.cpp:91-100).
@@ -443,6 +430,10 @@ void store_phase_stats(alga_engine *e) {
 }
 
 } // namespace
+
+// for engine_shard.hip (the bucket-sharded N-GPU build shares the argument checks, the node statistics and the key buffers)
+int alga_prepare(alga_engine *e, const alga_nodes *nodes, const alga_prefsuf_params *p, hipStream_t s, AlgaPrepared &out) { return prepare(e, nodes, p, s, out); }
+int alga_cluster_alloc(alga_engine *e, const AlgaPrepared &pp) { return cluster_alloc(e, pp); }
 
 // ============================================================================================
 // C ABI

@@ -81,11 +81,46 @@ struct alga_engine {
     size_t      host_spare_cap = 0;
     DevBuf      in_bytes[2], in_nl[2], in_tiles, in_tile_off;   // device ingest: file bytes, line ends, newline counts per tile
     DevBuf      sp_rowptr, sp_sorted, sp_list, sp_cnt, sp_orow, sp_out, sp_in;   // first simplifier step (engine_simplify.hip)
+    // seed-bucket-sharded N-GPU build (engine_shard.hip): state between its phases (the exchanges in between are the caller's)
+    DevBuf      sh_keys[2], sh_vals[2], sh_store, sh_dir, sh_desc_out, sh_dkey[2], sh_dval[2], sh_small_top, sh_pending, sh_bitmap, sh_small_out,
+                sh_ssrc[2], sh_skey[2], sh_edges_out, sh_deg, sh_rowptr, sh_cursor, sh_edges, sh_flagged, sh_cnt;
+    struct {
+        int      phase = 0;                    // 0 none, 1 indexed, 2 joined, 3 small keys listed, 4 resolved
+        int      rank = 0, n_ranks = 1, eq = 0, uniform_len = 0;
+        int32_t  n = 0;
+        const void *words = nullptr;
+        alga::PrefSufCfg cfg{};
+        alga::ClusterCfg cc{};
+        uint32_t bucket_base = 0, bpr = 0;
+        uint64_t n_targets = 0, n_desc = 0, n_rec = 0;
+        uint32_t *d_keys_sorted = nullptr;     // descriptors of the last join, sorted by bucket
+        unsigned long long *d_vals_sorted = nullptr;
+    } sh;
+    alga_shard_stats shard_stats{};
     unsigned long long *h_counters = nullptr;  // pinned, CNT_TOTAL + 2 entries
     uint64_t    rec_cap_hint = 0, rec_cap_hint_local = 0;
     alga_prefsuf_stats stats;
     alga_pkb_stats pkb_stats;
 };
+
+// what prepare() (engine.hip) derives from a build's arguments and the node statistics
+struct AlgaPrepared {
+    alga::NodesDev   nd;
+    alga::PrefSufCfg cfg;
+    int        max_len = 0;
+    int        uniform_len = 0;      // > 0: every live node has this length and there is no alignFrom mask
+    uint64_t   live = 0;
+    bool       local_ok = false;     // the source-side reduction is exact for this input
+    int        local_sw = 1;         // ... with one or two 64-bit words per offset mask / uint4 per overhang
+    int        cluster_eq = 0;       // clustered minimizer probe: 16-byte pieces per entry (0 = that probe does not take this input)
+    alga::ClusterCfg cluster{};
+    int        reduction = ALGA_REDUCTION_AUTO;
+    int        keys_shared = 0;      // 1: the per-node keys come from alga_prefsuf_keys_device + the caller's all-gather; 2: the whole
+                                     // entry array of the previous build of this node set is reused
+};
+
+int alga_prepare(alga_engine *e, const alga_nodes *nodes, const alga_prefsuf_params *p, hipStream_t s, AlgaPrepared &out);
+int alga_cluster_alloc(alga_engine *e, const AlgaPrepared &pp);
 
 inline int alga_fail(alga_engine *e, int code, const char *what, hipError_t herr = hipSuccess) {
     char buf[512];

@@ -72,7 +72,7 @@ struct Rccl {
 // a barrier takes the snapshot under the barrier's mutex and every rank leaves with that one copy: a rank that runs ahead and fails (or
 // resets its slot) in the next phase can no longer make two ranks read different answers and take different branches -- which would
 // leave them in barriers of different phases for ever.
-struct Agreed { bool failed = false, declined = false; };
+struct Agreed { bool failed = false, declined = false, shard_declined = false; };
 
 // all ranks arrive, all leave; reusable.  n is fixed before the first rank thread runs (run_build's start gate).
 struct Barrier {
@@ -109,6 +109,12 @@ struct alga_multi {
     std::vector<const alga_edge *> d_edges;
     std::vector<uint64_t> counts;
     std::vector<char> declined;                            // rank r's build answered ALGA_ERR_UNSUPPORTED; written by r before the barrier, read by the barrier's snapshot only
+    std::vector<char> shard_declined;                      // the same for a phase of the bucket-sharded form (all ranks then continue in the replicated form)
+    int form = ALGA_MULTI_FORM_AUTO;
+    // variable-length exchanges of the bucket-sharded form: what rank r offers (device pointer, per-destination counts and offsets in units), N x N
+    std::vector<const void *> x_send;
+    std::vector<uint64_t> x_cnt, x_off;
+    std::vector<DevBuf> rx_desc, rx_pending, rx_small, rx_edges;   // per rank, on the rank's device: the receive buffers
     std::vector<alga_prefsuf_stats> stats;
     DevBuf gathered;                                       // rank 0's device: the complete edge list
     alga_multi_stats mstats{};
@@ -126,6 +132,7 @@ Agreed snapshot(const alga_multi *m) {
     Agreed a;
     for (int x : m->rc) a.failed = a.failed || x != ALGA_OK;
     for (char d : m->declined) a.declined = a.declined || d != 0;
+    for (char d : m->shard_declined) a.shard_declined = a.shard_declined || d != 0;
     return a;
 }
 Agreed rendezvous(alga_multi *m) { return m->bar.wait([m] { return snapshot(m); }); }
@@ -160,6 +167,66 @@ struct Collectives {
         return rendezvous(m);                              // nobody's build (which sorts the key array in place) starts while a peer still reads it
     }
 
+    // Variable-length exchange in units of `unit` bytes (a multiple of 4): rank r offers cnt[q] units at send + off[q] * unit to every rank
+    // q; afterwards recv holds, rank by rank, what the ranks offered to r (*recv_total units).  An all-gather is the same thing with
+    // one segment offered to everybody.  Ends in a rendezvous: the senders keep their buffers until everybody has what it wanted.
+    Agreed exchange_v(const void *send, const uint64_t *cnt, const uint64_t *off, size_t unit, DevBuf &recv, uint64_t *recv_total, uint64_t *sent_bytes) {
+        const int N = m->n;
+        hipStream_t s = m->stream[(size_t) r];
+        m->x_send[(size_t) r] = send;
+        for (int q = 0; q < N; q++) { m->x_cnt[(size_t) r * N + q] = cnt[q]; m->x_off[(size_t) r * N + q] = off[q]; }
+        int rc = hip(hipStreamSynchronize(s), "exchange: my segments");      // complete before a peer reads them
+        Agreed ag = rendezvous(m);
+        uint64_t total = 0, out_bytes = 0;
+        for (int q = 0; q < N; q++) { total += m->x_cnt[(size_t) q * N + r]; if (q != r) out_bytes += cnt[q] * unit; }
+        *recv_total = total;
+        if (sent_bytes) *sent_bytes = out_bytes;
+        if (rc == ALGA_OK && !ag.failed && recv.cap < (total + 1) * unit) {
+            if (recv.p) (void) hipFree(recv.p);
+            recv.p = nullptr; recv.cap = 0;
+            if (hipMalloc(&recv.p, (total + 1) * unit + (total + 1) * unit / 8) != hipSuccess) { recv.p = nullptr; rc = fail(ALGA_ERR_OUT_OF_MEMORY, "receive buffer of an exchange"); }
+            else recv.cap = (total + 1) * unit + (total + 1) * unit / 8;
+        }
+        if (m->transport == ALGA_TRANSPORT_RCCL) {
+            // a rank that could not allocate still takes part (with nothing to receive into it fails the build at the rendezvous below; its
+            // peers' sends to it complete into a scratch of the same size class only if it posts receives -- so it posts none and the
+            // group is skipped by ALL ranks): agree first
+            ag = rendezvous(m);
+            if (!ag.failed) {
+                rc = nccl(m->rccl.GroupStart(), "ncclGroupStart");
+                uint64_t at = 0;
+                for (int q = 0; q < N && rc == ALGA_OK; q++) {
+                    const uint64_t cq = m->x_cnt[(size_t) q * N + r];
+                    if (q == r) {
+                        if (cq) rc = hip(hipMemcpyAsync((char *) recv.p + at * unit, (const char *) send + off[r] * unit, cq * unit, hipMemcpyDeviceToDevice, s), "exchange: own segment");
+                    } else {
+                        if (cq) rc = nccl(m->rccl.Recv((char *) recv.p + at * unit, cq * unit / 4, NCCL_UINT32, q, m->comm[(size_t) r], s), "ncclRecv(exchange)");
+                        if (rc == ALGA_OK && cnt[q]) rc = nccl(m->rccl.Send((const char *) send + off[q] * unit, cnt[q] * unit / 4, NCCL_UINT32, q, m->comm[(size_t) r], s), "ncclSend(exchange)");
+                    }
+                    at += cq;
+                }
+                { const int rc2 = nccl(m->rccl.GroupEnd(), "ncclGroupEnd"); if (rc == ALGA_OK) rc = rc2; }
+                if (rc == ALGA_OK) rc = hip(hipStreamSynchronize(s), "exchange");
+            }
+            return rendezvous(m);
+        }
+        if (rc == ALGA_OK && !ag.failed) {                   // pull: every rank copies what the others offered to it
+            uint64_t at = 0;
+            for (int q = 0; q < N && rc == ALGA_OK; q++) {
+                const uint64_t cq = m->x_cnt[(size_t) q * N + r];
+                if (cq) rc = hip(hipMemcpyPeerAsync((char *) recv.p + at * unit, m->dev[(size_t) r], (const char *) m->x_send[(size_t) q] + m->x_off[(size_t) q * N + r] * unit,
+                                                    m->dev[(size_t) q], cq * unit, s), "peer copy of an exchange segment");
+                at += cq;
+            }
+            if (rc == ALGA_OK) rc = hip(hipStreamSynchronize(s), "peer copies of an exchange");
+        }
+        return rendezvous(m);
+    }
+    Agreed all_gather_v(const void *send, uint64_t count, size_t unit, DevBuf &recv, uint64_t *recv_total, uint64_t *sent_bytes) {
+        std::vector<uint64_t> cnt((size_t) m->n, count), off((size_t) m->n, 0);
+        return exchange_v(send, cnt.data(), off.data(), unit, recv, recv_total, sent_bytes);
+    }
+
     Agreed gather_edges(alga_edge *out /* rank 0 */, const std::vector<uint64_t> &off) {
         hipStream_t s = m->stream[(size_t) r];
         int rc = ALGA_OK;
@@ -189,9 +256,72 @@ struct Collectives {
     }
 };
 
+// The build step of the bucket-sharded form (alga_shard_*, include/alga_amd.h) for rank r, keys already all-gathered: on success the
+// rank's (src, dst)-ordered edge list of its own source range is in d_edges[r] / counts[r], exactly what the replicated build leaves.
+// A phase that answers ALGA_ERR_UNSUPPORTED on ANY rank ends the attempt for all of them (snapshot.shard_declined): the caller goes
+// on in the replicated form with the keys still in place.
+Agreed shard_build(alga_multi *m, int r, Collectives &co, const alga_nodes *nodes_r, const alga_prefsuf_params *p, int32_t b0, int32_t b1, double *t_shard /* 5 */) {
+    alga_engine *e = m->eng[(size_t) r];
+    hipStream_t s = m->stream[(size_t) r];
+    const int N = m->n;
+    std::vector<uint64_t> cnt((size_t) N, 0), off((size_t) N, 0);
+    auto note = [&](int rc) { if (rc == ALGA_ERR_UNSUPPORTED) m->shard_declined[(size_t) r] = 1; else if (rc != ALGA_OK) co.fail(rc, alga_last_error(e)); };
+    double t0 = now_ms(), tx = 0;
+    // ---- my slice of the index; my sources' run descriptors by owner ----
+    const uint32_t *d_desc = nullptr;
+    note(alga_shard_index_device(e, nodes_r, p, r, N, (void *) s, &d_desc, cnt.data(), off.data()));
+    Agreed ag = rendezvous(m);
+    double t1 = now_ms();
+    if (ag.failed || ag.shard_declined) return ag;
+    uint64_t n_desc = 0, xb = 0;
+    ag = co.exchange_v(d_desc, cnt.data(), off.data(), 12, m->rx_desc[(size_t) r], &n_desc, &xb);
+    if (r == 0) m->mstats.xbytes_descriptors = xb;
+    double t2 = now_ms(); tx += t2 - t1;
+    if (ag.failed) return ag;
+    // ---- join in my buckets ----
+    const uint32_t *d_pend = nullptr;
+    uint64_t n_pend = 0;
+    note(alga_shard_join_device(e, nodes_r, (const uint32_t *) m->rx_desc[(size_t) r].p, n_desc, (void *) s, &d_pend, &n_pend));
+    ag = rendezvous(m);
+    double t3 = now_ms();
+    if (ag.failed || ag.shard_declined) return ag;
+    // ---- the per-source cap on the pending small survivors ----
+    uint64_t n_pend_all = 0, n_small = 0, n_small_all = 0;
+    ag = co.all_gather_v(d_pend, n_pend, 4, m->rx_pending[(size_t) r], &n_pend_all, &xb);
+    if (r == 0) m->mstats.xbytes_pending = xb;
+    if (ag.failed) return ag;
+    const uint32_t *d_small = nullptr;
+    note(alga_shard_small_keys_device(e, (const uint32_t *) m->rx_pending[(size_t) r].p, n_pend_all, (void *) s, &d_small, &n_small));
+    ag = co.all_gather_v(d_small, n_small, 12, m->rx_small[(size_t) r], &n_small_all, &xb);
+    if (r == 0) m->mstats.xbytes_small_keys = xb;
+    if (ag.failed) return ag;
+    const alga_edge *d_out = nullptr;
+    note(alga_shard_resolve_device(e, (const uint32_t *) m->rx_small[(size_t) r].p, n_small_all, (void *) s, &d_out, cnt.data(), off.data()));
+    ag = rendezvous(m);
+    double t4 = now_ms();
+    if (ag.failed) return ag;
+    // ---- edges to the owner of the source id, adjacency lists there ----
+    uint64_t n_in = 0;
+    ag = co.exchange_v(d_out, cnt.data(), off.data(), sizeof(alga_edge), m->rx_edges[(size_t) r], &n_in, &xb);
+    if (r == 0) m->mstats.xbytes_edges = xb;
+    double t5 = now_ms(); tx += t5 - t4;
+    if (ag.failed) return ag;
+    const alga_edge *d = nullptr;
+    uint64_t k = 0;
+    note(alga_shard_place_device(e, (const alga_edge *) m->rx_edges[(size_t) r].p, n_in, b0, b1, (void *) s, &d, &k));
+    m->d_edges[(size_t) r] = d; m->counts[(size_t) r] = k;
+    memset(&m->stats[(size_t) r], 0, sizeof(alga_prefsuf_stats));
+    m->stats[(size_t) r].edges = k; m->stats[(size_t) r].probe_used = ALGA_PROBE_CLUSTER; m->stats[(size_t) r].reduction_used = ALGA_REDUCTION_PER_TARGET;
+    ag = rendezvous(m);
+    double t6 = now_ms();
+    if (r == 0) { t_shard[0] = t1 - t0; t_shard[1] = tx; t_shard[2] = t3 - t2; t_shard[3] = t4 - t3; t_shard[4] = t6 - t5; }
+    return ag;
+}
+
 // one rank's part of a build; nodes_r: the node set on THIS rank's device.  Every branch that contains a rendezvous is taken on an
 // `Agreed` snapshot (the same copy on every rank), never on a flag another rank may be rewriting.
-void rank_main(alga_multi *m, int r, const alga_nodes *nodes_r, const alga_prefsuf_params *p, std::vector<uint64_t> *off, double *t_phase /* 5 */) {
+void rank_main(alga_multi *m, int r, const alga_nodes *nodes_r, const alga_prefsuf_params *p, std::vector<uint64_t> *off, double *t_phase /* 5 */,
+               alga_edge **host_edges /* null: the complete list is gathered on rank 0's GPU; else: every rank downloads its own range over its own PCIe link into ONE host list */) {
     Collectives co{m, r};
     alga_engine *e = m->eng[(size_t) r];
     hipStream_t s = m->stream[(size_t) r];
@@ -223,7 +353,20 @@ void rank_main(alga_multi *m, int r, const alga_nodes *nodes_r, const alga_prefs
     }
     double t2 = now_ms();
     // ---- 4. build: the final edges of my sources ----
-    if (!ag.failed) {
+    const bool try_sharded = shared && N > 1 && (m->form == ALGA_MULTI_FORM_BUCKET_SHARDED || (m->form == ALGA_MULTI_FORM_AUTO && N >= 3));
+    bool have = false;
+    if (!ag.failed && try_sharded) {
+        double t_shard[5] = {0, 0, 0, 0, 0};
+        ag = shard_build(m, r, co, nodes_r, p, b0, b1, t_shard);
+        have = !ag.failed && !ag.shard_declined;
+        if (r == 0 && have) {
+            m->mstats.form = ALGA_MULTI_FORM_BUCKET_SHARDED;
+            m->mstats.ms_shard_index = t_shard[0]; m->mstats.ms_shard_exchange = t_shard[1]; m->mstats.ms_shard_join = t_shard[2]; m->mstats.ms_shard_cap = t_shard[3];
+            m->mstats.ms_shard_place = t_shard[4];
+        }
+    }
+    if (!ag.failed && !have) {
+        if (r == 0) m->mstats.form = ALGA_MULTI_FORM_REPLICATED;
         alga_prefsuf_params p2 = *p;
         p2.keys_shared = shared ? 1 : 0;
         const alga_edge *d = nullptr;
@@ -236,6 +379,7 @@ void rank_main(alga_multi *m, int r, const alga_nodes *nodes_r, const alga_prefs
     }
     ag = rendezvous(m);
     double t3 = now_ms();
+    if (r == 0 && shared) m->mstats.xbytes_keys = (uint64_t) (N - 1) * (uint64_t) chunk * 4u;
     // ---- 5. gather (or, a rank having declined the source-side form: rank 0 builds the whole graph, the general way) ----
     if (!ag.failed && ag.declined) {
         if (r == 0) {
@@ -248,6 +392,10 @@ void rank_main(alga_multi *m, int r, const alga_nodes *nodes_r, const alga_prefs
             m->d_edges[0] = d; m->counts[0] = cnt;
             (void) alga_prefsuf_last_stats(e, &m->stats[0]);
             m->mstats.fell_back_to_one_gpu = 1;
+            if (host_edges && rc == ALGA_OK) {
+                rc = alga_download_edges(e, d, cnt, host_edges);
+                if (rc != ALGA_OK) co.fail(rc, alga_last_error(e));
+            }
         }
         (void) rendezvous(m);                              // (counts[r != 0] are not read after a fallback: run_build takes rank 0's list alone)
     } else if (!ag.failed) {
@@ -256,7 +404,10 @@ void rank_main(alga_multi *m, int r, const alga_nodes *nodes_r, const alga_prefs
             for (int q = 0; q < N; q++) { (*off)[(size_t) q] = total; total += m->counts[(size_t) q]; }
             (*off)[(size_t) N] = total;
             if (total >= (1ull << 32) - 16) co.fail(ALGA_ERR_CAPACITY, "more than 2^32 edges");
-            else if (N > 1) {
+            else if (host_edges) {
+                *host_edges = (alga_edge *) alga_host_list_take(m->eng[0], (size_t) (total ? total : 1) * sizeof(alga_edge));
+                if (!*host_edges) co.fail(ALGA_ERR_OUT_OF_MEMORY, "host edge list of the whole graph");
+            } else if (N > 1) {
                 hipError_t he = hipSuccess;
                 if (m->gathered.cap < (total + 1) * sizeof(alga_edge)) {
                     if (m->gathered.p) (void) hipFree(m->gathered.p);
@@ -268,19 +419,29 @@ void rank_main(alga_multi *m, int r, const alga_nodes *nodes_r, const alga_prefs
             }
         }
         ag = rendezvous(m);
-        if (!ag.failed && N > 1) (void) co.gather_edges((alga_edge *) m->gathered.p, *off);
+        if (!ag.failed && host_edges) {
+            // the consumer is the HOST: every GPU has its own PCIe link, no list crosses xGMI first (ranges ascending, lists (src, dst)-ordered:
+            // the host list is the single-GPU byte order)
+            if (m->counts[(size_t) r]) {
+                rc = alga_staged_d2h(e, *host_edges + (*off)[(size_t) r], m->d_edges[(size_t) r], (size_t) m->counts[(size_t) r] * sizeof(alga_edge));
+                if (rc != ALGA_OK) co.fail(rc, alga_last_error(e));
+            }
+            (void) rendezvous(m);
+        } else if (!ag.failed && N > 1) (void) co.gather_edges((alga_edge *) m->gathered.p, *off);
+        if (r == 0) m->mstats.xbytes_gather = 0;           // rank 0 only receives
     }
     double t4 = now_ms();
     if (r == 0) { t_phase[0] = t1 - t0; t_phase[1] = t2 - t1; t_phase[2] = t3 - t2; t_phase[3] = t4 - t3; t_phase[4] = t4 - t0; }
 }
 
-int run_build(alga_multi *m, const alga_nodes *per_rank, const alga_prefsuf_params *p, const alga_edge **d_edges, uint64_t *n_edges) {
+int run_build(alga_multi *m, const alga_nodes *per_rank, const alga_prefsuf_params *p, const alga_edge **d_edges, uint64_t *n_edges, alga_edge **host_edges = nullptr) {
     const int N = m->n;
     for (int r = 1; r < N; r++)
         if (per_rank[r].n != per_rank[0].n || per_rank[r].stride_words != per_rank[0].stride_words) return mfail(m, ALGA_ERR_INVALID_ARGUMENT, "the ranks hold different node sets");
     m->rc.assign((size_t) N, ALGA_OK); m->rank_err.assign((size_t) N, "");
     m->keys.assign((size_t) N, alga_node_keys{}); m->d_edges.assign((size_t) N, nullptr); m->counts.assign((size_t) N, 0);
-    m->declined.assign((size_t) N, 0);
+    m->declined.assign((size_t) N, 0); m->shard_declined.assign((size_t) N, 0);
+    m->x_send.assign((size_t) N, nullptr); m->x_cnt.assign((size_t) N * N, 0); m->x_off.assign((size_t) N * N, 0);
     m->stats.assign((size_t) N, alga_prefsuf_stats{});
     memset(&m->mstats, 0, sizeof(m->mstats));
     std::vector<uint64_t> off((size_t) N + 1, 0);
@@ -291,7 +452,7 @@ int run_build(alga_multi *m, const alga_nodes *per_rank, const alga_prefsuf_para
     struct Gate { std::mutex mu; std::condition_variable cv; int state = 0; /* 0 wait, 1 go, 2 abort */ } gate;
     auto gated = [&](int r) {
         { std::unique_lock<std::mutex> lk(gate.mu); gate.cv.wait(lk, [&] { return gate.state != 0; }); if (gate.state == 2) return; }
-        rank_main(m, r, &per_rank[r], p, &off, t_phase);
+        rank_main(m, r, &per_rank[r], p, &off, t_phase, host_edges);
     };
     std::vector<std::thread> th;
     bool started = true;
@@ -300,11 +461,15 @@ int run_build(alga_multi *m, const alga_nodes *per_rank, const alga_prefsuf_para
     } catch (...) { started = false; }
     { std::lock_guard<std::mutex> lk(gate.mu); gate.state = started ? 1 : 2; }
     gate.cv.notify_all();
-    if (started) rank_main(m, 0, &per_rank[0], p, &off, t_phase);
+    if (host_edges) *host_edges = nullptr;
+    if (started) rank_main(m, 0, &per_rank[0], p, &off, t_phase, host_edges);
     for (std::thread &x : th) x.join();
     if (!started) return mfail(m, ALGA_ERR_OUT_OF_MEMORY, "cannot start a host thread per GPU");
     for (int r = 0; r < N; r++)
-        if (m->rc[(size_t) r] != ALGA_OK) return mfail(m, m->rc[(size_t) r], "rank " + std::to_string(r) + ": " + m->rank_err[(size_t) r]);
+        if (m->rc[(size_t) r] != ALGA_OK) {
+            if (host_edges && *host_edges) { alga_free_edges(m->eng[0], *host_edges); *host_edges = nullptr; }
+            return mfail(m, m->rc[(size_t) r], "rank " + std::to_string(r) + ": " + m->rank_err[(size_t) r]);
+        }
     const bool one = N == 1 || m->mstats.fell_back_to_one_gpu;
     *d_edges = one ? m->d_edges[0] : (const alga_edge *) m->gathered.p;
     *n_edges = one ? m->counts[0] : off[(size_t) N];
@@ -326,6 +491,8 @@ int alga_multi_create(const int32_t *hip_devices, int32_t n_ranks, int32_t trans
     alga_multi *m = new (std::nothrow) alga_multi();
     if (!m) return ALGA_ERR_OUT_OF_MEMORY;
     m->n = n_ranks; m->bar.n = n_ranks;
+    m->rx_desc.assign((size_t) n_ranks, DevBuf{}); m->rx_pending.assign((size_t) n_ranks, DevBuf{}); m->rx_small.assign((size_t) n_ranks, DevBuf{});
+    m->rx_edges.assign((size_t) n_ranks, DevBuf{});
     bool distinct = true;
     for (int r = 0; r < n_ranks; r++) for (int q = 0; q < r; q++) distinct = distinct && hip_devices[r] != hip_devices[q];
     if (transport == ALGA_TRANSPORT_AUTO) transport = (distinct && n_ranks > 1) ? ALGA_TRANSPORT_RCCL : ALGA_TRANSPORT_COPY;
@@ -371,11 +538,24 @@ void alga_multi_destroy(alga_multi *m) {
     if (hipGetDevice(&prev) != hipSuccess) prev = -1;
     for (nccl_comm_t c : m->comm) if (c && m->rccl.CommDestroy) (void) m->rccl.CommDestroy(c);
     if (!m->dev.empty() && m->gathered.p) { (void) hipSetDevice(m->dev[0]); (void) hipFree(m->gathered.p); }
+    for (size_t r = 0; r < m->dev.size(); r++)
+        for (std::vector<DevBuf> *v : {&m->rx_desc, &m->rx_pending, &m->rx_small, &m->rx_edges})
+            if (r < v->size() && (*v)[r].p) { (void) hipSetDevice(m->dev[r]); (void) hipFree((*v)[r].p); (*v)[r].p = nullptr; }
     for (size_t r = 0; r < m->stream.size(); r++) { (void) hipSetDevice(m->dev[r]); (void) hipStreamSynchronize(m->stream[r]); (void) hipStreamDestroy(m->stream[r]); }
     for (alga_engine *e : m->eng) alga_engine_destroy(e);
     if (m->rccl.lib) (void) dlclose(m->rccl.lib);
     if (prev >= 0) (void) hipSetDevice(prev);
     delete m;
+}
+
+int alga_multi_set_option(alga_multi *m, const char *name, int64_t value) {
+    if (!m || !name) return ALGA_ERR_INVALID_ARGUMENT;
+    if (!strcmp(name, "form")) {
+        if (value < ALGA_MULTI_FORM_AUTO || value > ALGA_MULTI_FORM_BUCKET_SHARDED) return mfail(m, ALGA_ERR_INVALID_ARGUMENT, "option form: 0 auto, 1 replicated, 2 bucket-sharded");
+        m->form = (int) value;
+        return ALGA_OK;
+    }
+    return mfail(m, ALGA_ERR_INVALID_ARGUMENT, "unknown option");
 }
 
 const char *alga_multi_last_error(const alga_multi *m) { return m ? m->err.c_str() : "no multi-GPU handle"; }
@@ -419,14 +599,16 @@ int alga_multi_prefsuf_build_host(alga_multi *m, const alga_nodes *nodes, const 
     const double t1 = now_ms();
     const alga_edge *d = nullptr;
     uint64_t E = 0;
-    if (rc == ALGA_OK) rc = run_build(m, dev.data(), p, &d, &E);
-    const double t2 = now_ms();
+    alga_edge *h = nullptr;
+    if (rc == ALGA_OK) rc = run_build(m, dev.data(), p, &d, &E, &h);     // every rank brings its own range down: ms_gather is the download here
     if (rc == ALGA_OK) {
-        rc = alga_download_edges(m->eng[0], d, E, edges);
-        if (rc != ALGA_OK) mfail(m, rc, alga_last_error(m->eng[0]));
-        else *n_edges = E;
+        if (N == 1 && !h) {                                 // (one rank: run_build leaves the list on the device)
+            rc = alga_download_edges(m->eng[0], d, E, &h);
+            if (rc != ALGA_OK) mfail(m, rc, alga_last_error(m->eng[0]));
+        }
+        if (rc == ALGA_OK) { *edges = h; *n_edges = E; }
     }
-    m->mstats.ms_upload = t1 - t0; m->mstats.ms_download = now_ms() - t2;
+    m->mstats.ms_upload = t1 - t0; m->mstats.ms_download = m->mstats.ms_gather;
     if (prev >= 0) (void) hipSetDevice(prev);
     return rc;
 }

@@ -28,97 +28,9 @@
 #include "prefsuf_common.h"
 #include "prefsuf_kernels.h"
 #include "prefsuf_device.h"
+#include "prefsuf_cluster_device.h"
 
 namespace alga {
-
-// order hash of a k-mer (lo: nucleotides 0..15, hi: 16..31, both masked to the k-mer's length)
-__device__ __forceinline__ uint32_t kmer_hash(uint32_t lo, uint32_t hi) {
-    // ONE multiply (32-bit integer multiplies run at quarter rate).  A second mixing round made no measurable difference to the
-    // minimizers' statistics (runs per node, entries per source, sources the pair kernel finishes): what has to be well mixed is
-    // the CLUSTER key, and that gets its own mix, once per run.
-    return (lo ^ __funnelshift_l(hi, hi, 13) ^ (hi >> 7)) * 0x9E3779B1u;
-}
-
-// ORDER of the k-mers of a window: the smallest order key is the window's minimizer.
-//   bit 31      content class: 0 for a k-mer that starts with A followed by C or G (one k-mer in eight), 1 for any other
-//   bits 30..8  23 bits of the order hash
-//   bits 7..0   position in the read (ties to the left; equal windows of a source and a target agree on it)
-// The class bit is what makes k_node_runs cheap: a window of w = 64 k-mers holds a class-0 k-mer with probability 1 - (7/8)^64,
-// so the minimizer of (nearly) every window is a class-0 k-mer, and those are found with a few word-parallel bit operations on
-// the 2-bit rows -- the order hash is evaluated for one k-mer position in eight instead of all of them (13.6 G hashes and
-// 11.4 ms per build at the north-star size in round 2).  It stays a function of the window's content alone, which is all the
-// join needs: a source window and the equal target prefix choose the same k-mer.  Windows without a class-0 k-mer take the
-// minimum over their class-1 k-mers (brute force: the prefix window inside k_node_runs, a source's other windows in
-// k_probe_clustered's slow path).
-// nucleotide codes: A = 0, C = 1, G = 2, T = 3 (include/Params.h:275-279); nucleotide j of a k-mer = bits (2j, 2j + 1) of lo
-__device__ __forceinline__ bool kmer_class0(uint32_t lo) { return (lo & 3u) == 0u && ((((lo >> 2) ^ (lo >> 3)) & 1u) != 0u); }
-__device__ __forceinline__ uint32_t order_key0(uint32_t h, int pos) { return ((h >> 1) & 0x7FFFFF00u) | (uint32_t) pos; }      // of a class-0 k-mer
-__device__ __forceinline__ uint32_t order_key(uint32_t h, uint32_t lo, int pos) { return order_key0(h, pos) | (kmer_class0(lo) ? 0u : 0x80000000u); }
-// class-0 positions among the 16 nucleotides of `cur` (bit 2j: nucleotide j); nxt = the following row word
-__device__ __forceinline__ uint32_t class0_mask16(uint32_t cur, uint32_t nxt) {
-    const uint32_t nx = __funnelshift_r(cur, nxt, 2);      // nucleotide j + 1 at bits (2j, 2j + 1)
-    return ~(cur | (cur >> 1)) & (nx ^ (nx >> 1)) & 0x55555555u;
-}
-// bits 0, 2, 4, ... 30 of x (the others are zero) -> bits 0 .. 15
-__device__ __forceinline__ uint32_t compress_even(uint32_t x) {
-    x = (x | (x >> 1)) & 0x33333333u;
-    x = (x | (x >> 2)) & 0x0F0F0F0Fu;
-    x = (x | (x >> 4)) & 0x00FF00FFu;
-    return (x | (x >> 8)) & 0x0000FFFFu;
-}
-
-// Cluster key of a minimizer = a second, bijective mix of its order hash.  The order hashes of MINIMIZERS are minima of w
-// uniform values -- concentrated near zero -- so bucketing the entry array by their own top bits would put most clusters in
-// 1/w of the buckets; the mix spreads them evenly.  The BUCKET bits (above the m_C field, tgt_sort_key below) are never all ones:
-// the sort key of a target then never is 0xFFFFFFFF ("not a target") whatever its m_C, m_C can be read back from it, and a sort
-// on the bucket bits alone already puts every target before every non-target (the last bucket stays empty).
-__device__ __forceinline__ uint32_t cluster_key(uint32_t h, int fs) {
-    uint32_t k = h * 0x9E3779B1u;                          // (one multiply instead of three: +2 % entries scanned, +28 % deferred sources)
-    k ^= k >> 15;
-    k *= 0x85EBCA77u;
-    k ^= k >> 13;
-    k *= 0xC2B2AE3Du;
-    return (k >> (fs + CL_MBITS)) == (0xFFFFFFFFu >> (fs + CL_MBITS)) ? k ^ 0x80000000u : k;
-}
-
-// Sort key of a target: the cluster key with the CL_MBITS bits right below its bucket bits replaced by m_C, the position of the
-// minimizer in the target's prefix (field at bit fs = idx_shift - CL_MBITS).  Inside a bucket the entries are therefore ordered
-// by m_C >> 3 first (the sort stops there: launch_cluster_store), and the directory (k_tgt_dir) knows where every eighth of that order starts: a source run that covers the
-// windows [p0, p1) with its minimizer at q can only match targets with q - p1 < m_C <= q - p0 and reads that slice of the bucket
-// alone -- the other entries of the cluster are the reads of the same locus that start too far left or right of the run's
-// windows (half of them at 30x coverage).  0xFFFFFFFF stays reserved for "not a target".
-__device__ __forceinline__ uint32_t tgt_sort_key(uint32_t ckey, uint32_t m_c, int fs) {
-    const uint32_t fm = ((1u << CL_MBITS) - 1u) << fs;
-    return (ckey & ~fm) | ((m_c << fs) & fm);               // never all ones: cluster_key
-}
-__device__ __forceinline__ bool same_cluster(uint32_t entry_key, uint32_t ckey, int fs) {
-    return ((entry_key ^ ckey) & ~(((1u << CL_MBITS) - 1u) << fs)) == 0u;
-}
-
-// directory record of a bucket: {first entry, entries, first entry (relative, saturating bytes) with m_C >> 3 >= 0..3, >= 4..7}
-// -> the entries [e0, e0 + cnt) a run {q | p0 << 8 | p1 << 16} has to look at
-__device__ __forceinline__ void run_slice(const uint4 &rec, uint32_t run_y, uint32_t &e0, uint32_t &cnt) {
-    const int q = (int) (run_y & 255u), p0 = (int) ((run_y >> 8) & 255u), p1 = (int) ((run_y >> 16) & 255u);
-    int mlo = q - p1 + 1, mhi = q - p0;
-    mlo = mlo < 0 ? 0 : mlo; mhi = mhi > 63 ? 63 : mhi;
-    e0 = rec.x; cnt = rec.y;
-    if (mhi < mlo) { cnt = 0u; return; }
-    if (rec.y > 255u) return;                              // offsets saturate: the whole bucket
-    const int s0 = mlo >> 3, s1 = (mhi >> 3) + 1;
-    const uint32_t b0 = ((s0 < 4 ? rec.z : rec.w) >> (8 * (s0 & 3))) & 255u;
-    const uint32_t b1 = s1 >= 8 ? rec.y : (((s1 < 4 ? rec.z : rec.w) >> (8 * (s1 & 3))) & 255u);
-    e0 = rec.x + b0; cnt = b1 - b0;
-}
-
-// k-mer starting at nucleotide i of a 2-bit row (words readable up to index (2i >> 5) + 2): its hash and its packed
-// order key (class | 23-bit order | position); the smallest key of a window is the window's minimizer
-__device__ __forceinline__ void kmer_key(const uint32_t *row, int i, bool valid, const ClusterCfg &cc, uint32_t &h, uint32_t &pk) {
-    const int bit = 2 * i, q = bit >> 5, r = bit & 31;
-    const uint32_t x0 = row[q], x1 = row[q + 1], x2 = row[q + 2];
-    const uint32_t lo = funnel(x0, x1, r) & cc.lo_mask;
-    h = kmer_hash(lo, funnel(x1, x2, r) & cc.hi_mask);
-    pk = valid ? order_key(h, lo, i) : 0xFFFFFFFFu;
-}
 
 // ------------------------------------------------------------------------------------------
 // build: minimizer runs of every node, keys, gather, index
@@ -305,12 +217,13 @@ __global__ void __launch_bounds__(TK_ROWS) k_node_runs(NodesDev nd, PrefSufCfg c
 // follows from the sort key (its m_C field) and the common length, and the one random 4-byte read per entry of meta[] goes away
 // (4.6 -> 3.0 ms at 90.6 M nodes).
 template <int EQ, bool UNIFORM>
-__global__ void __launch_bounds__(256) k_tgt_gather(NodesDev nd, const uint32_t *__restrict__ keys, const uint32_t *__restrict__ vals,
+__global__ void __launch_bounds__(256) k_tgt_gather(NodesDev nd, uint64_t count /* sorted (key, id) pairs: all nodes, or the targets of a rank's bucket range */,
+                                                     const uint32_t *__restrict__ keys, const uint32_t *__restrict__ vals,
                                                      const uint32_t *__restrict__ meta, uint32_t uniform_meta, int fs, uint4 *__restrict__ store) {
     const uint64_t t = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t j = t / EQ;
     const int c = (int) (t % EQ);
-    if (j >= (uint64_t) nd.n) return;
+    if (j >= count) return;
     const uint32_t key = keys[j];                          // all ones: not a target -- behind the last bucket, never looked up; its entry
     const uint32_t id = vals[j];                           // serves the quad kernel, which walks the SOURCES in this order
     const uint32_t *row = nd.words + (size_t) id * nd.stride;
@@ -338,14 +251,14 @@ __global__ void __launch_bounds__(256) k_tgt_gather(NodesDev nd, const uint32_t 
 // LDS so that a bucket is walked at LDS latency (round 2: an index array first, then a second pass through global memory per
 // bucket).  Measured and rejected: folding this pass into k_tgt_gather (the walk serialises behind that kernel's random row
 // reads: 6.5 against 3.0 + 1.2 ms); collecting the records of a tile in LDS and writing them out as whole lines (1.4 against 1.2 ms).
-__device__ __forceinline__ uint32_t bperm(uint32_t v, int src_lane) { return (uint32_t) __builtin_amdgcn_ds_bpermute(src_lane << 2, (int) v); }
 constexpr int TD_TILE = 256, TD_HALO = 96;                 // entries per tile (512 and 1024 measure the same); entries staged past it
-__global__ void __launch_bounds__(TD_TILE) k_tgt_dir(const uint32_t *__restrict__ keys, uint64_t n, int shift, uint32_t n_buckets, uint4 *__restrict__ dir,
+__global__ void __launch_bounds__(TD_TILE) k_tgt_dir(const uint32_t *__restrict__ keys, uint64_t n, int shift, uint32_t n_buckets /* of this directory */,
+                                                     uint32_t bucket_base /* first bucket of this directory: 0, or the start of a rank's bucket range (every key lies in it) */, uint4 *__restrict__ dir,
                                                      unsigned long long *__restrict__ bad /* set when the keys are not in (bucket, m_C class) order: the build fails with ALGA_ERR_HIP */) {
     __shared__ uint32_t sb[TD_TILE + TD_HALO + 1];         // (bucket << 3 | m_C class) of the entries base - 1 .. base + TD_TILE + TD_HALO - 1
     const uint64_t base = (uint64_t) blockIdx.x * TD_TILE;
     const uint32_t nb3 = n_buckets << 3;
-    auto tagged = [&](uint64_t k) -> uint32_t { if (k >= n) return nb3; const uint32_t x = keys[k]; return x == 0xFFFFFFFFu ? nb3 : x >> (shift - 3); };
+    auto tagged = [&](uint64_t k) -> uint32_t { if (k >= n) return nb3; const uint32_t x = keys[k]; return x == 0xFFFFFFFFu ? nb3 : (x >> (shift - 3)) - (bucket_base << 3); };
     for (int k = (int) threadIdx.x; k <= TD_TILE + TD_HALO; k += TD_TILE)
         sb[k] = (base == 0 && k == 0) ? 0xFFFFFFFFu : tagged(base + (uint64_t) k - 1u);     // "entry -1": a bucket no entry has
     __syncthreads();
@@ -1313,7 +1226,7 @@ hipError_t launch_cluster_store(const NodesDev &nd, const ClusterCfg &cc, int eq
     const unsigned g = (unsigned) ((pieces + 255) / 256);
     const int fs = cc.idx_shift - CL_MBITS;
     const uint32_t um = uniform_len > 0 ? (((uint32_t) uniform_len << 8) | CL_META_FROM) : 0u;
-#define TG_LAUNCH(E, U) hipLaunchKernelGGL((k_tgt_gather<E, U>), dim3(g), dim3(256), 0, s, nd, (const uint32_t *) keys2, (const uint32_t *) vals2, meta, um, fs, (uint4 *) store)
+#define TG_LAUNCH(E, U) hipLaunchKernelGGL((k_tgt_gather<E, U>), dim3(g), dim3(256), 0, s, nd, n, (const uint32_t *) keys2, (const uint32_t *) vals2, meta, um, fs, (uint4 *) store)
 #define TG_EQ(E) do { if (uniform_len > 0) TG_LAUNCH(E, true); else TG_LAUNCH(E, false); } while (0)
     if (eq == 2)      TG_EQ(2);
     else if (eq == 3) TG_EQ(3);
@@ -1325,7 +1238,33 @@ hipError_t launch_cluster_store(const NodesDev &nd, const ClusterCfg &cc, int eq
     // the fill costs on its own, 0.24 ms)
     err = hipMemsetAsync(dir, 0, ((size_t) cc.n_buckets + 2) * 16, s);
     if (err != hipSuccess) return err;
-    hipLaunchKernelGGL(k_tgt_dir, dim3((unsigned) ((n + 1 + TD_TILE - 1) / TD_TILE)), dim3(TD_TILE), 0, s, (const uint32_t *) keys2, n, cc.idx_shift, cc.n_buckets, (uint4 *) dir, bad_flag);
+    hipLaunchKernelGGL(k_tgt_dir, dim3((unsigned) ((n + 1 + TD_TILE - 1) / TD_TILE)), dim3(TD_TILE), 0, s, (const uint32_t *) keys2, n, cc.idx_shift, cc.n_buckets, 0u, (uint4 *) dir, bad_flag);
+    return hipGetLastError();
+}
+
+// The same for the targets of ONE RANK'S BUCKET RANGE (the seed-bucket-sharded N-GPU build, prefsuf_shard.hip): m (key, id) pairs whose
+// bucket lies in [bucket_base, bucket_base + n_buckets_local) -> their entries in bucket order and a directory of that range alone
+// (record b - bucket_base), ordered like the full build's (bucket, then m_C >> 3).
+hipError_t launch_cluster_store_slice(const NodesDev &nd, const ClusterCfg &cc, int eq, uint64_t m, uint32_t bucket_base, uint32_t n_buckets_local, uint32_t *keys,
+                                      uint32_t *vals, uint32_t *keys2, uint32_t *vals2, const uint32_t *meta, int uniform_len, void *sort_temp, size_t sort_temp_bytes,
+                                      void *store, void *dir, unsigned long long *bad_flag, hipStream_t s) {
+    hipError_t err = hipMemsetAsync(dir, 0, ((size_t) n_buckets_local + 2) * 16, s);
+    if (err != hipSuccess || m == 0) return err;
+    err = sort_u32_pairs(sort_temp, sort_temp_bytes, keys, keys2, vals, vals2, m, cc.idx_shift - 3, s);
+    if (err != hipSuccess) return err;
+    const uint64_t n = m, pieces = m * (uint64_t) eq;
+    const unsigned g = (unsigned) ((pieces + 255) / 256);
+    const int fs = cc.idx_shift - CL_MBITS;
+    const uint32_t um = uniform_len > 0 ? (((uint32_t) uniform_len << 8) | CL_META_FROM) : 0u;
+#define TG_LAUNCH(E, U) hipLaunchKernelGGL((k_tgt_gather<E, U>), dim3(g), dim3(256), 0, s, nd, n, (const uint32_t *) keys2, (const uint32_t *) vals2, meta, um, fs, (uint4 *) store)
+#define TG_EQ(E) do { if (uniform_len > 0) TG_LAUNCH(E, true); else TG_LAUNCH(E, false); } while (0)
+    if (eq == 2)      TG_EQ(2);
+    else if (eq == 3) TG_EQ(3);
+    else              TG_EQ(4);
+#undef TG_EQ
+#undef TG_LAUNCH
+    hipLaunchKernelGGL(k_tgt_dir, dim3((unsigned) ((n + 1 + TD_TILE - 1) / TD_TILE)), dim3(TD_TILE), 0, s, (const uint32_t *) keys2, n, cc.idx_shift, n_buckets_local, bucket_base,
+                       (uint4 *) dir, bad_flag);
     return hipGetLastError();
 }
 

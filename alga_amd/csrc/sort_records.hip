@@ -12,6 +12,7 @@
 #include "prefsuf_kernels.h"
 #include "pkb_kernels.h"
 #include "ingest_kernels.h"
+#include "prefsuf_shard.h"
 
 namespace alga {
 
@@ -88,6 +89,16 @@ hipError_t sort_u32_pairs(void *temp, size_t temp_bytes, const uint32_t *keys_in
     if (sort_u32_three_wide_passes(begin_bit))
         return rocprim::radix_sort_pairs<Sort10>(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t) n, (unsigned) begin_bit, 32u, s);
     return rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t) n, (unsigned) begin_bit, 32u, s);
+}
+
+// run descriptors of the bucket-sharded N-GPU build (prefsuf_shard.hip): (u32 cluster key, u64 {source id, q | p0 | p1}) by bucket =
+// the key bits [begin_bit, end_bit) (the bits above are the same for every bucket of one rank's range)
+size_t sort_desc_temp_bytes(uint64_t n) { return sort_records_temp_bytes(n, 32); }
+hipError_t sort_desc(void *temp, size_t temp_bytes, const uint32_t *keys_in, uint32_t *keys_out, const unsigned long long *vals_in, unsigned long long *vals_out, uint64_t n,
+                     int begin_bit, int end_bit, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    if (n < (1ull << 22) || begin_bit < 0 || end_bit > 32 || end_bit <= begin_bit) { begin_bit = 0; end_bit = 32; }      // (small inputs: see sort_u32_pairs)
+    return rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t) n, (unsigned) begin_bit, (unsigned) end_bit, s);
 }
 
 size_t sort_u64_keys_temp_bytes(uint64_t n) {

@@ -107,9 +107,26 @@ PROBE = {"auto": 0, "table": 1, "cluster": 2}                  # alga_probe
 
 class MultiStats(C.Structure):
     """alga_multi_stats"""
-    _fields_ = [("n_ranks", C.c_int32), ("transport", C.c_int32), ("fell_back_to_one_gpu", C.c_int32), ("reserved", C.c_int32), ("edges", C.c_uint64),
+    _fields_ = [("n_ranks", C.c_int32), ("transport", C.c_int32), ("fell_back_to_one_gpu", C.c_int32), ("form", C.c_int32), ("edges", C.c_uint64),
                 ("ms_upload", C.c_double), ("ms_download", C.c_double), ("ms_keys", C.c_double), ("ms_share", C.c_double), ("ms_build", C.c_double),
-                ("ms_gather", C.c_double), ("ms_total", C.c_double)]
+                ("ms_gather", C.c_double), ("ms_total", C.c_double),
+                ("xbytes_keys", C.c_uint64), ("xbytes_descriptors", C.c_uint64), ("xbytes_pending", C.c_uint64), ("xbytes_small_keys", C.c_uint64),
+                ("xbytes_edges", C.c_uint64), ("xbytes_gather", C.c_uint64),
+                ("ms_shard_index", C.c_double), ("ms_shard_exchange", C.c_double), ("ms_shard_join", C.c_double), ("ms_shard_cap", C.c_double),
+                ("ms_shard_place", C.c_double)]
+
+
+class ShardStats(C.Structure):
+    """alga_shard_stats"""
+    _fields_ = [(k, C.c_uint64) for k in ("targets_owned", "descriptors_out", "descriptors_in", "flagged_sources", "records", "pending", "pending_sources",
+                                          "small_keys_out", "small_keys_in", "dropped", "edges_out", "edges_in", "edges")] + \
+               [(k, C.c_double) for k in ("ms_index", "ms_export", "ms_sort", "ms_join", "ms_cap", "ms_edges_out", "ms_place")]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+MULTI_FORM = {"auto": 0, "replicated": 1, "bucket_sharded": 2}   # alga_multi_form
 
 
 TRANSPORT = {"auto": 0, "rccl": 1, "copy": 2}                  # alga_transport
@@ -127,7 +144,9 @@ EXPORTS = ["alga_abi_version", "alga_engine_set_option", "alga_engine_create", "
            "alga_can_align_batch_host", "alga_li_kmers_host", "alga_pkb_supplement_host", "alga_pkb_supplement_device",
            "alga_pkb_last_stats", "alga_parse_files", "alga_free_parsed_reads", "alga_preprocess_nodes", "alga_copy_to_host", "alga_device_alloc", "alga_device_free", "alga_copy_to_device", "alga_cut_triangles_device", "alga_cut_triangles_host", "alga_ingest_device", "alga_contig_trim_host", "alga_engine_reserve", "alga_upload_nodes", "alga_download_edges",
            "alga_multi_create", "alga_multi_destroy", "alga_multi_last_error", "alga_multi_engine", "alga_multi_prefsuf_build_host", "alga_multi_prefsuf_build_device",
-           "alga_multi_free_edges", "alga_multi_last_stats"]
+           "alga_multi_free_edges", "alga_multi_last_stats", "alga_multi_set_option",
+           "alga_shard_index_device", "alga_shard_join_device", "alga_shard_small_keys_device", "alga_shard_resolve_device", "alga_shard_place_device",
+           "alga_shard_last_stats"]
 
 
 def library_path():
@@ -191,6 +210,12 @@ def load_library():
                                                C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
     lib.alga_prefsuf_build_range_device.argtypes = [C.c_void_p, C.POINTER(_Nodes), C.POINTER(PrefSufParams), C.c_int32, C.c_int32,
                                                     C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    lib.alga_shard_index_device.argtypes = [C.c_void_p, C.POINTER(_Nodes), C.POINTER(PrefSufParams), C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p),
+                                            C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    lib.alga_shard_join_device.argtypes = [C.c_void_p, C.POINTER(_Nodes), C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    lib.alga_shard_small_keys_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    lib.alga_shard_resolve_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    lib.alga_shard_place_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
     lib.alga_write_graph.argtypes = [C.c_char_p, C.c_int32, C.c_void_p, C.c_uint64]
     lib.alga_sort_records_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p,
                                              C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
@@ -485,6 +510,53 @@ class Engine:
         self._check(rc)
         return out.value, int(m.value)
 
+    # ---- the bucket-sharded N-GPU form, phase by phase (include/alga_amd.h: alga_shard_*); None = ALGA_ERR_UNSUPPORTED ----
+    def shard_index_device(self, words, lens, min_overlap, rsoe_min_overlap, rank, n_ranks, align_from=None, align_to=None, stream=None):
+        """-> (d_desc ptr [3 x u32 per descriptor], counts[n_ranks], offsets[n_ranks]) after keys_device + the key all-gather."""
+        nd = self._nodes_from_torch(words, lens, align_from, align_to)
+        p = self.params(min_overlap, rsoe_min_overlap, False)
+        out = C.c_void_p()
+        cnt, off = (C.c_uint64 * n_ranks)(), (C.c_uint64 * n_ranks)()
+        rc = self._lib.alga_shard_index_device(self._h, C.byref(nd), C.byref(p), int(rank), int(n_ranks), C.c_void_p(stream or 0), C.byref(out), cnt, off)
+        if rc == ERR_UNSUPPORTED:
+            return None
+        self._check(rc)
+        return out.value, [int(x) for x in cnt], [int(x) for x in off]
+
+    def shard_join_device(self, words, lens, desc_in, n_desc, align_from=None, align_to=None, stream=None):
+        """desc_in: device tensor / pointer of n_desc received descriptors -> (d_pending_src ptr [u32], n_pending) or None."""
+        nd = self._nodes_from_torch(words, lens, align_from, align_to)
+        out, m = C.c_void_p(), C.c_uint64()
+        rc = self._lib.alga_shard_join_device(self._h, C.byref(nd), C.c_void_p(_ptr(desc_in)), C.c_uint64(int(n_desc)), C.c_void_p(stream or 0), C.byref(out), C.byref(m))
+        if rc == ERR_UNSUPPORTED:
+            return None
+        self._check(rc)
+        return out.value, int(m.value)
+
+    def shard_small_keys_device(self, pending_all, n_all, stream=None):
+        out, m = C.c_void_p(), C.c_uint64()
+        self._check(self._lib.alga_shard_small_keys_device(self._h, C.c_void_p(_ptr(pending_all)), C.c_uint64(int(n_all)), C.c_void_p(stream or 0), C.byref(out), C.byref(m)))
+        return out.value, int(m.value)
+
+    def shard_resolve_device(self, small_all, n_small_all, n_ranks, stream=None):
+        """-> (d_edges ptr, counts[n_ranks], offsets[n_ranks]): final edges grouped by the rank that owns the source id"""
+        out = C.c_void_p()
+        cnt, off = (C.c_uint64 * n_ranks)(), (C.c_uint64 * n_ranks)()
+        self._check(self._lib.alga_shard_resolve_device(self._h, C.c_void_p(_ptr(small_all)), C.c_uint64(int(n_small_all)), C.c_void_p(stream or 0), C.byref(out), cnt, off))
+        return out.value, [int(x) for x in cnt], [int(x) for x in off]
+
+    def shard_place_device(self, edges_in, n_in, src_begin, src_end, stream=None):
+        out, m = C.c_void_p(), C.c_uint64()
+        self._check(self._lib.alga_shard_place_device(self._h, C.c_void_p(_ptr(edges_in)), C.c_uint64(int(n_in)), int(src_begin), int(src_end), C.c_void_p(stream or 0),
+                                                      C.byref(out), C.byref(m)))
+        return out.value, int(m.value)
+
+    def shard_stats(self):
+        st = ShardStats()
+        self._lib.alga_shard_last_stats.argtypes = [C.c_void_p, C.POINTER(ShardStats)]
+        self._lib.alga_shard_last_stats(self._h, C.byref(st))
+        return st.as_dict()
+
     def discover_device(self, words, lens, min_overlap, rsoe_min_overlap, src_begin, src_end, align_from=None,
                         align_to=None, stream=None, collect_stats=False):
         """-> (d_dst ptr [u32], d_val ptr [u64], n_record_slots); slots with dst == 0xFFFFFFFF are padding."""
@@ -661,6 +733,22 @@ class MultiEngine:
         if rc:
             raise AlgaError(rc, (self._lib.alga_multi_last_error(self._h) or b"").decode())
 
+    def set_option(self, name, value):
+        """alga_multi_set_option: "form" ("auto" | "replicated" | "bucket_sharded")."""
+        if name == "form" and isinstance(value, str):
+            value = MULTI_FORM[value]
+        self._lib.alga_multi_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+        self._check(self._lib.alga_multi_set_option(self._h, name.encode(), int(value)))
+
+    def rank_shard_stats(self, rank):
+        """alga_shard_last_stats of one rank's engine (the bucket-sharded form's counters and device times)."""
+        self._lib.alga_multi_engine.argtypes = [C.c_void_p, C.c_int32]
+        self._lib.alga_multi_engine.restype = C.c_void_p
+        self._lib.alga_shard_last_stats.argtypes = [C.c_void_p, C.POINTER(ShardStats)]
+        st = ShardStats()
+        self._lib.alga_shard_last_stats(C.c_void_p(self._lib.alga_multi_engine(self._h, int(rank))), C.byref(st))
+        return st.as_dict()
+
     def set_rank_option(self, rank, name, value):
         """alga_engine_set_option on ONE rank's engine (alga_multi_engine): tests make a single rank decline this way."""
         self._lib.alga_multi_engine.argtypes = [C.c_void_p, C.c_int32]
@@ -705,9 +793,18 @@ class MultiEngine:
         st = MultiStats()
         per = (PrefSufStats * self.n)()
         self._check(self._lib.alga_multi_last_stats(self._h, C.byref(st), C.cast(per, C.c_void_p)))
-        d = {k: getattr(st, k) for k, _ in st._fields_ if k != "reserved"}
+        d = {k: getattr(st, k) for k, _ in st._fields_}
         d["ranks"] = [x.as_dict() for x in per]
         return d
+
+
+def _ptr(x):
+    """device pointer of a torch tensor (or an int that already is one; None / empty -> 0)"""
+    if x is None:
+        return 0
+    if isinstance(x, int):
+        return x
+    return x.data_ptr() if x.numel() else 0
 
 
 class _DevArray:

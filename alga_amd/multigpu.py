@@ -118,6 +118,42 @@ class HipBackend:
         self.stats = self.eng.last_stats()
         return device_view(r[0], (r[1], 3), self.device)
 
+    # ---- the bucket-sharded form, phase by phase (include/alga_amd.h: alga_shard_*): tensors are views of engine memory ----
+    def shard_index(self, rank, world):
+        """-> (descriptors [cap, 3] int32, counts, offsets) or None (the form does not take this input)"""
+        from .engine import device_view
+        r = self.eng.shard_index_device(self.w, self.l, self.lo, self.rs, rank, world, stream=self._stream())
+        if r is None:
+            return None
+        ptr, cnt, off = r
+        cap = max(o + c for o, c in zip(off, cnt))
+        return device_view(ptr, (cap, 3), self.device), cnt, off
+
+    def shard_join(self, desc_in):
+        """received descriptors [m, 3] -> the sources of my pending edges (int32 tensor) or None (declined)"""
+        from .engine import device_view
+        r = self.eng.shard_join_device(self.w, self.l, desc_in, int(desc_in.shape[0]), stream=self._stream())
+        if r is None:
+            return None
+        return device_view(r[0], (r[1],), self.device)
+
+    def shard_small_keys(self, pending_all):
+        from .engine import device_view
+        ptr, k = self.eng.shard_small_keys_device(pending_all, int(pending_all.shape[0]), stream=self._stream())
+        return device_view(ptr, (k, 3), self.device)
+
+    def shard_resolve(self, small_all, world):
+        from .engine import device_view
+        ptr, cnt, off = self.eng.shard_resolve_device(small_all, int(small_all.shape[0]), world, stream=self._stream())
+        return device_view(ptr, (sum(cnt), 3), self.device), cnt, off
+
+    def shard_place(self, edges_in, src_begin, src_end):
+        from .engine import device_view
+        ptr, k = self.eng.shard_place_device(edges_in, int(edges_in.shape[0]), src_begin, src_end, stream=self._stream())
+        self.stats = dict(self.eng.shard_stats())
+        self.stats["edges"] = k
+        return device_view(ptr, (k, 3), self.device)
+
     def discover_sorted(self, src_begin, src_end, collect_stats=False):
         from .engine import device_view
         d, v, k = self.eng.discover_device(self.w, self.l, self.lo, self.rs, src_begin, src_end, collect_stats=collect_stats, stream=self._stream())
@@ -150,7 +186,7 @@ class ShardedPrefSuf:
     simplifier / contig stages afterwards -- with direct sends over each peer's own xGMI link (`gather`); the other ranks keep
     an empty tensor.  replicate=True: every rank gets it (`all_gather`, 8x the traffic at 8 GPUs)."""
 
-    def __init__(self, backend, rank=0, world=1, dist=None, replicate=False, shard_keys=False, pieces=1):
+    def __init__(self, backend, rank=0, world=1, dist=None, replicate=False, shard_keys=False, pieces=1, bucket_sharded=False):
         self.be, self.rank, self.world, self.dist = backend, rank, world, dist
         self.replicate = replicate
         # Defaults = the form with the fewest moving parts (one piece, every rank computes all keys itself, no key all-gather): no
@@ -161,7 +197,13 @@ class ShardedPrefSuf:
         #              its own (launches, host syncs, thinner kernels): 4 pieces up to 4 ranks, 2 at 8 were the measured optimum
         #   shard_keys every rank computes the minimizer keys of its own nodes only, the key arrays are all-gathered
         self.pieces = max(1, int(pieces)) if pieces is not None else min(4, max(1, 16 // max(1, world)))
-        self.shard_keys = shard_keys
+        self.shard_keys = shard_keys or bucket_sharded
+        # bucket_sharded: the INDEX is sharded by seed bucket (alga_shard_*): every rank builds 1 / world of the entry
+        # array, run descriptors travel to the bucket's owner, the reduction is decided per target there, edges return to the source's
+        # owner.  A build the form declines (any rank) continues in the replicated form with the gathered keys.
+        self.bucket_sharded = bucket_sharded
+        self.form_used = None
+        self.exchange_bytes = {}
         self.n = backend.n
         self.bounds = shard_bounds(self.n, world)
         self.edges = None                       # tensor [m, 3] of the last step: the complete graph (rank 0, or every rank if replicate)
@@ -204,6 +246,11 @@ class ShardedPrefSuf:
                 dist.all_gather_into_tensor(full, t[r * chunk:(r + 1) * chunk].clone())
                 t.copy_(full)
         ms_keys = (time.perf_counter() - t_keys) * 1e3
+        if self.bucket_sharded and karr is not None:
+            done = self._step_bucket_sharded(ms_keys, collect_stats)
+            if done is not None:
+                return done
+        self.form_used = "replicated"
         # The rank's source range in `pieces` consecutive pieces (the first one sorts the gathered keys into the entry array, the
         # others reuse it): the edges of a piece travel to rank 0 while the next piece is probed.  Per piece one small all_gather
         # carries every rank's "declined" flag and edge count.
@@ -268,6 +315,82 @@ class ShardedPrefSuf:
         t3 = time.perf_counter()
         st["edges"] = self.total_edges
         st["ms_exchange"] = (t1 - t0) * 1e3 + (t3 - t2) * 1e3
+        return self._finish(st, collect_stats)
+
+    # ---- the variable-length exchanges of the bucket-sharded form ----
+    def _agree(self, flag):
+        """does ANY rank raise `flag`?  (one small all_reduce: every rank takes the same branch)"""
+        import torch
+        t = torch.tensor([1 if flag else 0], dtype=torch.int64, device=self.be.device)
+        self.dist.all_reduce(t)
+        return int(t.item()) != 0
+
+    def _all_to_all_rows(self, rows, cnt, off, name):
+        """rows [cap, 3] int32 with the segment for rank q at rows[off[q] : off[q] + cnt[q]] -> what the ranks sent to me, rank by rank"""
+        import torch
+        dist, dev = self.dist, self.be.device
+        send = torch.cat([rows[off[q]:off[q] + cnt[q]] for q in range(self.world)], dim=0).contiguous() if sum(cnt) else torch.empty((0, 3), dtype=torch.int32, device=dev)
+        sc = torch.tensor(cnt, dtype=torch.int64, device=dev)
+        rc = torch.empty_like(sc)
+        dist.all_to_all_single(rc, sc)
+        rc_l = [int(x) for x in rc.cpu()]
+        recv = torch.empty((sum(rc_l), 3), dtype=torch.int32, device=dev)
+        dist.all_to_all_single(recv.view(-1), send.view(-1), output_split_sizes=[3 * x for x in rc_l], input_split_sizes=[3 * x for x in cnt])
+        self.exchange_bytes[name] = 12 * (sum(cnt) - cnt[self.rank])
+        return recv
+
+    def _all_gather_rows(self, mine, width, name):
+        """mine: [k] or [k, width] int32 of any length per rank -> the concatenation over the ranks"""
+        import torch
+        dist, dev, nr = self.dist, self.be.device, self.world
+        k = int(mine.shape[0])
+        allk = torch.empty(nr, dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(allk, torch.tensor([k], dtype=torch.int64, device=dev))
+        ks = [int(x) for x in allk.cpu()]
+        mx = max(max(ks), 1)
+        local = torch.zeros((mx, width), dtype=torch.int32, device=dev)
+        if k:
+            local[:k] = mine.reshape(k, width)
+        parts = torch.empty((nr, mx, width), dtype=torch.int32, device=dev)
+        dist.all_gather_into_tensor(parts.view(-1), local.view(-1))
+        self.exchange_bytes[name] = 4 * width * k * (nr - 1)
+        out = torch.cat([parts[q, :ks[q]] for q in range(nr)], dim=0).contiguous()
+        return out if width > 1 else out.view(-1)
+
+    def _step_bucket_sharded(self, ms_keys, collect_stats):
+        """The build with the index sharded by seed bucket, keys already all-gathered; -> (edges, stats), or None when a rank's engine
+        declined a phase (all ranks then continue in the replicated form)."""
+        import torch
+        be, r, nr, b = self.be, self.rank, self.world, self.bounds
+        t0 = time.perf_counter()
+        idx = be.shard_index(r, nr)
+        if self._agree(idx is None):
+            return None
+        desc, cnt, off = idx
+        recv = self._all_to_all_rows(desc, cnt, off, "descriptors")
+        pend = be.shard_join(recv)
+        if self._agree(pend is None):
+            return None
+        pend_all = self._all_gather_rows(pend, 1, "pending")
+        small = be.shard_small_keys(pend_all)
+        small_all = self._all_gather_rows(small, 3, "small_keys")
+        eout, ecnt, eoff = be.shard_resolve(small_all, nr)
+        ein = self._all_to_all_rows(eout, ecnt, eoff, "edges")
+        mine = be.shard_place(ein, b[r], b[r + 1])
+        st = dict(be.stats)
+        st["ms_shard_wall"] = (time.perf_counter() - t0) * 1e3
+        # edge lists of the ascending source ranges -> rank 0
+        meta = torch.tensor([int(mine.shape[0])], dtype=torch.int64, device=be.device)
+        allmeta = torch.empty(nr, dtype=torch.int64, device=be.device)
+        self.dist.all_gather_into_tensor(allmeta, meta)
+        t2 = time.perf_counter()
+        self.edges = self._gather_finish([self._gather_start(mine, [int(x) for x in allmeta.cpu()], single=True)])
+        be.sync()
+        st["ms_keys_shared"] = ms_keys
+        st["edges"] = self.total_edges
+        st["ms_exchange"] = (time.perf_counter() - t2) * 1e3
+        st["exchange_bytes"] = dict(self.exchange_bytes)
+        self.form_used = "bucket_sharded"
         return self._finish(st, collect_stats)
 
     def _gather_start(self, mine, counts, single=False):

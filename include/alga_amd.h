@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ALGA_AMD_ABI_VERSION 4
+#define ALGA_AMD_ABI_VERSION 5
 
 typedef enum {
     ALGA_OK = 0,
@@ -240,6 +240,47 @@ typedef struct { uint32_t *d_keys; uint32_t *d_meta; int32_t n; int32_t eligible
 int  alga_prefsuf_keys_device(alga_engine *e, const alga_nodes *nodes, const alga_prefsuf_params *p,
                               int32_t node_begin, int32_t node_end, void *hip_stream, alga_node_keys *out);
 
+/* ---- sharded form with the INDEX sharded by seed bucket (alga_amd/csrc/prefsuf_shard.hip, engine_shard.hip) --------------------
+ * The reference's one bucket table per overlap length (src/GraphCreators/GraphCreatorPrefSuf.cpp:247-280,317-332: every thread reads every
+ * bucket) divided over N ranks: rank g owns the targets whose minimizer bucket lies in its 1 / N of the bucket space, builds THEIR
+ * entries and directory only, receives the run descriptors (12 bytes: cluster key, source id, minimizer position and window range)
+ * of every rank's sources that fall into its buckets, and decides the transitive reduction per TARGET from the target's complete
+ * candidate list (tests/bucket_side_rule.py: the reference's per-target rule, GraphCreatorPrefSuf.cpp:403-483).  The per-source cap
+ * of three small overlaps (:397-401) is the one decision that needs a source's other overlaps: surviving small overlaps are PENDING
+ * until the top-3 small keys of their sources have been collected from the bucket owners.  Per build, on every rank r of N:
+ *   1. alga_prefsuf_keys_device(own node range [b_r, b_r+1))          keys + runs of the rank's nodes
+ *   2. all-gather, in place, of the key array (and meta if meta_needed) -- as for the replicated form above
+ *   3. alga_shard_index_device       my slice of the entry array + directory; the descriptors of MY sources, grouped by owner rank
+ *   4. all-to-all of the descriptors (12-byte records; counts / offsets per destination from step 3)
+ *   5. alga_shard_join_device        verification + per-target reduction in my buckets; the sources of my pending edges
+ *   6. all-gather of the pending source ids (u32, variable length)
+ *   7. alga_shard_small_keys_device  {source, L, C} (3 x u32) of the small overlaps my descriptors of those sources saw (top 3 per run)
+ *   8. all-gather of those lists
+ *   9. alga_shard_resolve_device     pending edges that fail their source's cap are dropped; final edges grouped by the rank that owns
+ *                                    the SOURCE id (ranges of alga_amd/multigpu.py: shard_chunk -- the same as for the key all-gather)
+ *  10. all-to-all of the edges (12-byte alga_edge)
+ *  11. alga_shard_place_device       adjacency lists of my source range, (src, dst)-ordered: ready for the gather to rank 0
+ * A call answers ALGA_ERR_UNSUPPORTED when the form does not take the input (what the clustered probe declines; a bucket with more than
+ * 4096 descriptors): all ranks then take the replicated form.  Every result is engine-owned and valid until the next shard call. */
+typedef struct {
+    uint64_t targets_owned, descriptors_out, descriptors_in, flagged_sources;   /* index phase / join phase                          */
+    uint64_t records, pending, pending_sources, small_keys_out, small_keys_in, dropped;
+    uint64_t edges_out, edges_in, edges;
+    double   ms_index, ms_export, ms_sort, ms_join, ms_cap, ms_edges_out, ms_place;   /* device time of each phase (HIP events)  */
+} alga_shard_stats;
+/* desc_counts[q] descriptors for rank q start at descriptor desc_offsets[q] of *d_desc (3 x uint32 each) */
+int  alga_shard_index_device(alga_engine *e, const alga_nodes *nodes, const alga_prefsuf_params *p, int32_t rank, int32_t n_ranks, void *hip_stream,
+                             const uint32_t **d_desc, uint64_t *desc_counts /* n_ranks */, uint64_t *desc_offsets /* n_ranks */);
+int  alga_shard_join_device(alga_engine *e, const alga_nodes *nodes, const uint32_t *d_desc_in, uint64_t n_desc, void *hip_stream,
+                            const uint32_t **d_pending_src, uint64_t *n_pending_src);
+int  alga_shard_small_keys_device(alga_engine *e, const uint32_t *d_pending_src_all, uint64_t n_all, void *hip_stream,
+                                  const uint32_t **d_small /* 3 x uint32: source, L, C */, uint64_t *n_small);
+int  alga_shard_resolve_device(alga_engine *e, const uint32_t *d_small_all, uint64_t n_small_all, void *hip_stream,
+                               const alga_edge **d_edges_out, uint64_t *edge_counts /* n_ranks */, uint64_t *edge_offsets /* n_ranks */);
+int  alga_shard_place_device(alga_engine *e, const alga_edge *d_edges_in, uint64_t n_in, int32_t src_begin, int32_t src_end, void *hip_stream,
+                             const alga_edge **d_edges, uint64_t *n_edges);
+int  alga_shard_last_stats(const alga_engine *e, alga_shard_stats *out);
+
 /* ---- the N GPUs of one node behind one handle (alga_amd/csrc/engine_multi.hip) ------------------------------------
  * The reference's parallelism is --threads (src/Params.cpp:237-294; worker threads inside GraphCreatorPrefSuf,
  * src/GraphCreators/GraphCreatorPrefSuf.cpp:150-161); the counterpart: ONE process, one host thread and one engine per GPU.  Rank r
@@ -252,15 +293,28 @@ int  alga_prefsuf_keys_device(alga_engine *e, const alga_nodes *nodes, const alg
  * than one, else COPY.  Not yet run on more than one GPU. */
 typedef struct alga_multi alga_multi; /* opaque */
 typedef enum { ALGA_TRANSPORT_AUTO = 0, ALGA_TRANSPORT_RCCL = 1, ALGA_TRANSPORT_COPY = 2 } alga_transport;
+/* How the N ranks divide a build (alga_multi_set_option "form"; same graph either way):
+ *   REPLICATED      every rank builds the whole bucket-ordered entry array from the all-gathered keys and probes its own source ids
+ *                   (round 3: nothing but keys and edges travels, but the index build does not shrink with N);
+ *   BUCKET_SHARDED  the index itself is sharded by seed bucket (alga_shard_* above): 1 / N of the entry array per rank, run descriptors
+ *                   travel to the bucket's owner, the reduction is decided per target there, edges return to the source's owner;
+ *   AUTO            BUCKET_SHARDED from three ranks on (at two, half an index costs less than the extra exchanges), REPLICATED below;
+ *                   a build the sharded form declines (ALGA_ERR_UNSUPPORTED on any rank) continues in the replicated form. */
+typedef enum { ALGA_MULTI_FORM_AUTO = 0, ALGA_MULTI_FORM_REPLICATED = 1, ALGA_MULTI_FORM_BUCKET_SHARDED = 2 } alga_multi_form;
 typedef struct {
     int32_t  n_ranks, transport;          /* alga_transport actually used                                        */
     int32_t  fell_back_to_one_gpu;        /* a rank declined the source-side form: rank 0 built the whole graph  */
-    int32_t  reserved;
+    int32_t  form;                        /* alga_multi_form the last build ended in (1 or 2)                     */
     uint64_t edges;
-    double   ms_upload, ms_download;      /* host entry point only: node set to every GPU (side by side), edges from rank 0 */
+    double   ms_upload, ms_download;      /* host entry point only: node set to every GPU (side by side), edges from the GPUs */
     double   ms_keys, ms_share, ms_build, ms_gather, ms_total;   /* rank 0's host clock: key pass of its nodes, key all-gather, build of its
                                              sources (waits for the slowest rank at its end), gather of the edge lists, all of it */
+    /* what rank 0 SENT to other ranks in each exchange of the last build, bytes (the all-gathers: its own slice times N - 1) */
+    uint64_t xbytes_keys, xbytes_descriptors, xbytes_pending, xbytes_small_keys, xbytes_edges, xbytes_gather;
+    double   ms_shard_index, ms_shard_exchange, ms_shard_join, ms_shard_cap, ms_shard_place;   /* BUCKET_SHARDED, rank 0's host clock per phase */
 } alga_multi_stats;
+/* "form": alga_multi_form */
+int         alga_multi_set_option(alga_multi *m, const char *name, int64_t value);
 int         alga_multi_create(const int32_t *hip_devices, int32_t n_ranks, int32_t transport, alga_multi **out);
 void        alga_multi_destroy(alga_multi *m);
 const char *alga_multi_last_error(const alga_multi *m);

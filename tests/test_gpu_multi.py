@@ -33,6 +33,79 @@ def test_multi_copy_transport_equals_oracle(ranks, n, length, G, seed, err, minl
         m.close()
 
 
+@pytest.mark.parametrize("ranks", [2, 3, 5])
+@pytest.mark.parametrize("n,length,G,seed,err,minlen,lo,rs", [
+    (3000, 100, 6000, 81, 0.0, None, 55, 77),          # uniform length, error-free
+    (3000, 144, 5000, 82, 0.004, 110, 82, 116),        # variable length + errors: irregular targets, pending small overlaps, the meta array travels
+    (4000, 100, 2500, 86, 0.01, None, 55, 77),         # 160x coverage with errors: buckets of more than 64 descriptors (the chunked path of the join)
+    (1500, 100, 30000, 87, 0.0, None, 55, 77),         # 5x coverage: most survivors are SMALL overlaps -- the per-source cap decides (pending edges, top-3 exchange)
+])
+def test_multi_bucket_sharded_form_equals_oracle(ranks, n, length, G, seed, err, minlen, lo, rs):
+    """The index sharded by seed bucket (alga_shard_*: every rank 1 / N of the entry array, run descriptors to the bucket's owner, the
+    reduction per target there, the per-source cap through the pending / small-key exchange, edges back to the source's owner): the
+    same bytes as the oracle for 2, 3 and 5 ranks."""
+    words, lens = _nodes(n, length, G, seed, err, minlen)
+    want, _, _ = O.prefsuf(words, lens, lo, rs)
+    m = alga_amd.MultiEngine([0] * ranks, transport="copy")
+    try:
+        m.set_option("form", "bucket_sharded")
+        for _ in range(2):
+            got = m.prefsuf_host(words, lens, lo, rs)
+            assert got.shape == want.shape and (got == want).all()
+        st = m.last_stats()
+        assert st["form"] == 2 and st["fell_back_to_one_gpu"] == 0 and st["edges"] == len(want)
+        sh = [m.rank_shard_stats(r) for r in range(ranks)]
+        assert sum(x["edges"] for x in sh) == len(want)
+        assert sum(x["targets_owned"] for x in sh) > 0 and sum(x["descriptors_out"] for x in sh) == sum(x["descriptors_in"] for x in sh)
+        assert sum(x["edges_out"] for x in sh) == len(want)
+    finally:
+        m.close()
+
+
+def test_multi_bucket_sharded_masks_tandem_repeats_and_declines():
+    import gen_reads
+    from test_gpu_parity import _tandem_nodes
+    rng = np.random.default_rng(88)
+    m = alga_amd.MultiEngine([0, 0, 0], transport="copy")
+    try:
+        m.set_option("form", "bucket_sharded")
+        # masks (alignFrom => alignTo) and removed nodes
+        words, lens = _nodes(2500, 100, 5000, 88, 0.0, None)
+        lens = lens.copy()
+        lens[rng.random(len(lens)) < 0.05] = 0
+        at = (rng.random(len(lens)) > 0.1).astype(np.uint8)
+        af = (at & (rng.random(len(lens)) > 0.1)).astype(np.uint8)
+        want, _, _ = O.prefsuf(words, lens, 55, 77, af, at)
+        got = m.prefsuf_host(words, lens, 55, 77, af, at)
+        assert got.shape == want.shape and (got == want).all() and m.last_stats()["form"] == 2
+        # tandem repeats: the same target at several offsets of a source (two descriptors of one source in a bucket: supersede)
+        words, lens = _tandem_nodes(89, 1500, 6000, 100, 7)
+        want, _, _ = O.prefsuf(words, lens, 55, 77)
+        got = m.prefsuf_host(words, lens, 55, 77)
+        assert got.shape == want.shape and (got == want).all()
+        # un-deduplicated input: 1000 copies of five overlapping reads -- buckets with more descriptors than the join takes (4096): the
+        # join declines, all ranks continue in the replicated form (whose own capacity case ends on rank 0); == one engine
+        codes, _ = gen_reads.sample_reads(5, 100, 130, 26)
+        w = alga_amd.pack_reads(np.tile(codes, (1000, 1)))
+        l100 = np.full(len(w), 100, np.int32)
+        one = alga_amd.Engine(0)
+        try:
+            want = one.prefsuf_host(w, l100, 55, 77)
+        finally:
+            one.close()
+        got = m.prefsuf_host(w, l100, 55, 77)
+        assert got.shape == want.shape and (got == want).all()
+        assert m.last_stats()["form"] == 1
+        # what the clustered probe does not take (250-nt reads): the sharded form is not even tried
+        words, lens = _nodes(1200, 250, 8000, 90, 0.0, None)
+        want, _, _ = O.prefsuf(words, lens, 140, 190)
+        got = m.prefsuf_host(words, lens, 140, 190)
+        assert got.shape == want.shape and (got == want).all() and m.last_stats()["form"] == 1
+        assert m.prefsuf_host(np.zeros((0, 8), np.uint32), np.zeros(0, np.int32), 55, 77).shape == (0, 3)
+    finally:
+        m.close()
+
+
 def test_multi_falls_back_when_a_rank_declines():
     """250-nt reads at the default scale still take the source-side form (two-word masks, seed-table probe: no keys to share); reads
     beyond 288 nt do not -- every rank declines and rank 0 builds the whole graph the general way.  Same graph as one engine."""
@@ -56,7 +129,7 @@ def test_multi_exactly_one_rank_declines(who):
     gather branch and wait there for ever): rank 0 builds the whole graph, same edges as the oracle."""
     import gen_reads
     codes, _ = gen_reads.sample_reads(5, 80, 120, 26)
-    w = alga_amd.pack_reads(np.repeat(codes, 80, axis=0))
+    w = alga_amd.pack_reads(np.tile(codes, (80, 1)))     # copies interleaved: every rank's id range holds every one of the five reads
     lens = np.full(len(w), 80, np.int32)
     want, _, _ = O.prefsuf(w, lens, 40, 60)
     m = alga_amd.MultiEngine([0, 0, 0], transport="copy")

@@ -27,8 +27,9 @@ def _seqs(words, lens):
 class PyBackend:
     """Stand-in for alga_amd.multigpu.HipBackend on CPU tensors."""
 
-    def __init__(self, words, lens, lo, rs, source_side=False, decline_rank=None, rank=0):
+    def __init__(self, words, lens, lo, rs, source_side=False, decline_rank=None, rank=0, decline_phase=None):
         self.source_side, self.decline = source_side, decline_rank == rank
+        self.decline_phase = decline_phase                  # "index" / "join": the declining rank declines that phase of the bucket-sharded form (and not the replicated build)
         self.seq = _seqs(words, lens)
         self.n = len(self.seq)
         self.lo, self.rs = lo, rs
@@ -68,6 +69,7 @@ class PyBackend:
         if not self.source_side:
             return None
         self.karr = [torch.full((span,), -1, dtype=torch.int32), torch.full((span,), -1, dtype=torch.int32)]
+        self.kr = (a, b)
         k, m = self._fake_keys(a, b)
         self.karr[0][a:b] = torch.from_numpy(k)
         self.karr[1][a:b] = torch.from_numpy(m)
@@ -83,7 +85,7 @@ class PyBackend:
             assert (self.karr[0][:self.n].numpy() == k).all() and (self.karr[1][:self.n].numpy() == m).all()
         else:                                             # keys_shared == 0: the rank computes all keys itself (the plain form; the first piece of a two-rank run)
             self.first_piece_done = True
-        if not self.source_side or self.decline:
+        if not self.source_side or (self.decline and self.decline_phase is None):
             return None
         from source_side_rule import source_side_edges
         code = {"A": 0, "C": 1, "G": 2, "T": 3}
@@ -91,6 +93,87 @@ class PyBackend:
         e = source_side_edges(seqs, self.lo, self.rs)
         e = e[(e[:, 0] >= a) & (e[:, 0] < b)]
         return torch.from_numpy(e.copy()).reshape(-1, 3)
+
+    # ---- stand-ins of the bucket-sharded form's phases (alga_shard_*): the "bucket" of a target is a hash of its id, the
+    #      per-target decision is tests/bucket_side_rule.py -- what is under test is the driver's five exchanges ----
+    def _owner(self, c, world):
+        return ((c * 2654435761) >> 7) % world
+
+    def _seqs_bytes(self):
+        code = {"A": 0, "C": 1, "G": 2, "T": 3}
+        return [bytes(code[ch] for ch in s) for s in self.seq]
+
+    def shard_index(self, rank, world):
+        if self.decline_phase == "index" and self.decline:
+            return None
+        import bucket_side_rule as B
+        self.world, self.rank_ = world, rank
+        self.sb = self._seqs_bytes()
+        self.cands = B.raw_overlaps(self.sb, self.lo)
+        a, b = self.kr                                      # my node range (node_keys): a descriptor per (source, owner it reaches)
+        rows, cnt = [[] for _ in range(world)], []
+        reach = {}
+        for c, lst in self.cands.items():
+            for (src, d, L) in lst:
+                if a <= src < b:
+                    reach.setdefault(src, set()).add(self._owner(c, world))
+        for src, owners in sorted(reach.items()):
+            for q in owners:
+                rows[q].append((q, src, 0))
+        flat, off, cnt = [], [], []
+        for q in range(world):
+            off.append(len(flat) + 3 * q)                   # segments with slack between them, as the engine's have
+            flat += [(-1, -1, -1)] * 3 + rows[q] if q else rows[q]
+            cnt.append(len(rows[q]))
+        off = [3 * q + sum(cnt[:q]) for q in range(world)]
+        t = torch.tensor(flat, dtype=torch.int32).reshape(-1, 3)
+        return t, cnt, off
+
+    def shard_join(self, desc_in):
+        if self.decline_phase == "join" and self.decline:
+            return None
+        import bucket_side_rule as B
+        srcs = set(int(x) for x in desc_in[:, 1])
+        assert all(int(x) == self.rank_ for x in desc_in[:, 0])              # only what falls into my buckets came
+        self.final, self.pending = [], []
+        for c, lst in self.cands.items():
+            if self._owner(c, self.world) != self.rank_:
+                continue
+            assert all(a in srcs for (a, d, L) in lst)                         # every source that reaches my target sent its descriptor
+            for (a, d, L) in B.target_survivors(self.sb, c, lst, self.lo, self.rs):
+                (self.pending if L < self.rs else self.final).append((a, c, d, L))
+        return torch.tensor([a for (a, c, d, L) in self.pending], dtype=torch.int32)
+
+    def shard_small_keys(self, pending_all):
+        want = set(int(x) for x in pending_all)
+        rows = []
+        for c, lst in self.cands.items():
+            if self._owner(c, self.world) == self.rank_:
+                rows += [(a, L, c) for (a, d, L) in lst if L < self.rs and a in want]
+        return torch.tensor(rows, dtype=torch.int32).reshape(-1, 3)
+
+    def shard_resolve(self, small_all, world):
+        keys = {}
+        for a, L, c in small_all.tolist():
+            keys.setdefault(a, []).append((L, c))
+        out = list(self.final)
+        for (a, c, d, L) in self.pending:
+            if sum(1 for k in keys[a] if k > (L, c)) < 3:
+                out.append((a, c, d, L))
+        from alga_amd.multigpu import shard_chunk
+        ch = shard_chunk(self.n, world)
+        rows = [[] for _ in range(world)]
+        for (a, c, d, L) in out:
+            rows[min(world - 1, a // ch)].append((a, c, d))
+        cnt = [len(x) for x in rows]
+        off = [sum(cnt[:q]) for q in range(world)]
+        return torch.tensor([x for r in rows for x in r], dtype=torch.int32).reshape(-1, 3), cnt, off
+
+    def shard_place(self, edges_in, a, b):
+        e = edges_in.numpy().reshape(-1, 3)
+        assert ((e[:, 0] >= a) & (e[:, 0] < b)).all()
+        self.stats = {"edges": len(e)}
+        return self.sort_edges(torch.from_numpy(e.copy())) if len(e) else torch.empty((0, 3), dtype=torch.int32)
 
     def discover_sorted(self, a, b, collect_stats=False):
         d, v = self._records(a, b)
@@ -161,6 +244,50 @@ def _worker(rank, world, port, words, lens, lo, rs, out_dir, source_side=False, 
         np.save(os.path.join(out_dir, "edges_%d.npy" % rank), e)
     finally:
         dist.destroy_process_group()
+
+
+def _worker_bucket(rank, world, port, words, lens, lo, rs, out_dir, decline_rank, decline_phase):
+    import torch.distributed as dist
+    from alga_amd import multigpu
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        be = PyBackend(words, lens, lo, rs, True, decline_rank, rank, decline_phase)
+        run = multigpu.ShardedPrefSuf(be, rank, world, dist, bucket_sharded=True)
+        for _ in range(2):
+            m, st = run.step()
+        np.save(os.path.join(out_dir, "count_%d.npy" % rank), np.array([m]))
+        np.save(os.path.join(out_dir, "edges_%d.npy" % rank), run.edges_numpy())
+        with open(os.path.join(out_dir, "form_%d.txt" % rank), "w") as f:
+            f.write(run.form_used)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,decline_rank,decline_phase", [(2, None, None), (3, None, None), (3, 1, "index"), (3, 2, "join")])
+def test_bucket_sharded_driver_over_gloo_equals_oracle(tmp_path, world, decline_rank, decline_phase):
+    """The five exchanges of the bucket-sharded form (descriptor all-to-all, pending-source and small-key all-gathers of any length
+    per rank -- also zero --, edge all-to-all, gather to rank 0) over gloo, with a stand-in engine that decides per target by
+    tests/bucket_side_rule.py and applies the per-source cap from the gathered small keys; one rank declining a phase makes ALL
+    ranks continue in the replicated form.  Low coverage on purpose: most survivors are small overlaps, the cap really decides."""
+    import gen_reads
+    import oracle_lib as O
+    import alga_amd
+    codes, lens = gen_reads.sample_reads(150, 60, 900, 79)
+    rc = (3 - codes)[:, ::-1]
+    codes = np.stack([rc, codes], axis=1).reshape(-1, 60)
+    lens = np.repeat(lens, 2).astype(np.int32)
+    words = alga_amd.pack_reads(codes, lens)
+    lo, rs = 25, 45
+    want, _, _ = O.prefsuf(words, lens, lo, rs)
+    assert len(want) > 50
+    mp.spawn(_worker_bucket, args=(world, _free_port(), words, lens, lo, rs, str(tmp_path), decline_rank, decline_phase), nprocs=world, join=True)
+    for r in range(world):
+        assert int(np.load(str(tmp_path / ("count_%d.npy" % r)))[0]) == len(want)
+        assert open(str(tmp_path / ("form_%d.txt" % r))).read() == ("replicated" if decline_rank is not None else "bucket_sharded")
+    got = np.load(str(tmp_path / "edges_0.npy"))
+    assert got.shape == want.shape and (got == want).all()
 
 
 def _free_port():

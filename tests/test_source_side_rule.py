@@ -6,6 +6,7 @@ import pytest
 
 import oracle_lib as O
 from source_side_rule import decode_rows, preconditions, source_side_edges
+from bucket_side_rule import bucket_side_edges
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -15,6 +16,9 @@ def _check(words, lens, lo, rs, af=None, at=None):
     want, _, _ = O.prefsuf(words, lens, lo, rs, af, at)
     got = source_side_edges(decode_rows(words, lens), lo, rs, af, at)
     assert got.shape == want.shape and np.array_equal(got, want), (got.shape, want.shape)
+    # the same decision taken from the TARGET's candidate list (the seed-bucket-sharded N-GPU build: tests/bucket_side_rule.py)
+    got2 = bucket_side_edges(decode_rows(words, lens), lo, rs, af, at)
+    assert got2.shape == want.shape and np.array_equal(got2, want), (got2.shape, want.shape)
     return len(want)
 
 
