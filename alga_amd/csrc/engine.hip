@@ -525,6 +525,8 @@ int alga_engine_set_option(alga_engine *e, const char *name, int64_t value) {
         e->opt_cluster_order = value != 0;
     } else if (!strcmp(name, "local_big_max")) {
         e->big_limit = value < 0 ? -1 : (int) std::min<int64_t>(value, 1 << 20);
+    } else if (!strcmp(name, "shard_bucket_max")) {
+        e->opt_shard_dmax = (int) std::max<int64_t>(1, std::min<int64_t>(value, 4096));
     } else if (!strcmp(name, "test_unsorted_index")) {
         e->opt_test_unsorted_index = value != 0;           // tests only: the clustered index is built over UNSORTED keys; the build must fail, not fault
     } else if (!strcmp(name, "auto_reduction_per_target")) {

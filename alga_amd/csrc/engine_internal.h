@@ -32,6 +32,7 @@ struct alga_engine {
     int         opt_probe = 0;                // ALGA_PROBE_AUTO / _TABLE / _CLUSTER
     int         opt_cluster_bucket_bias = 0;  // log2 factor on the bucket count of the clustered probe's index
     int         opt_force_per_target = 0;     // AUTO reduction resolves to PER_TARGET
+    int         opt_shard_dmax = 4096;        // bucket-sharded join: descriptors of one bucket it takes (option "shard_bucket_max"; tests lower it to see the decline)
     int         opt_test_unsorted_index = 0;  // tests only: skip the sort of the clustered index (the directory pass must flag it, the build must fail)
     hipEvent_t  ev[EV_COUNT] = {};
     // device buffers, grown on demand and kept between calls

@@ -174,7 +174,7 @@ int alga_shard_join_device(alga_engine *e, const alga_nodes *nodes, const uint32
         HIP_TRY(e, hipMemsetAsync(cnt, 0, CNT_TOTAL * sizeof(unsigned long long), s));
         HIP_TRY(e, hipMemsetAsync(scnt, 0, 8 * sizeof(unsigned long long), s));
         launch_shard_join(nd, e->sh.cfg, e->sh.cc, e->sh.eq, e->sh.uniform_len, e->sh_store.p, e->sh_dir.p, e->sh.bucket_base, e->sh.d_keys_sorted, e->sh.d_vals_sorted, n_desc,
-                          (uint32_t *) e->rec_dst.p, (unsigned long long *) e->rec_val.p, cap, cnt, (unsigned long long *) e->sh_small_top.p, scnt + 3, e->n_cu, s);
+                          (uint32_t *) e->rec_dst.p, (unsigned long long *) e->rec_val.p, cap, cnt, (unsigned long long *) e->sh_small_top.p, scnt + 3, e->opt_shard_dmax, e->n_cu, s);
         if ((rc = alga_check_launch(e, "k_shard_join"))) return rc;
         HIP_TRY(e, hipMemcpyAsync(e->h_counters, cnt, CNT_TOTAL * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
         HIP_TRY(e, hipMemcpyAsync(e->h_counters + CNT_TOTAL, scnt + 3, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));

@@ -26,7 +26,8 @@ hipError_t sort_desc(void *temp, size_t temp_bytes, const uint32_t *keys_in, uin
 uint64_t shard_join_record_slack(int n_cu);
 void launch_shard_join(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterCfg &cc, int eq, int uniform_len, const void *store, const void *dir, uint32_t bucket_base,
                        const uint32_t *dkey, const unsigned long long *dval, uint64_t n_desc, uint32_t *rec_dst, unsigned long long *rec_val, uint64_t rec_cap,
-                       unsigned long long *counters, unsigned long long *small_top, unsigned long long *declined, int n_cu, hipStream_t s);
+                       unsigned long long *counters, unsigned long long *small_top, unsigned long long *declined, int dmax /* descriptors of one bucket the join takes (<= 4096) */,
+                       int n_cu, hipStream_t s);
 void launch_shard_pending_src(const uint32_t *rec_dst, const unsigned long long *rec_val, uint64_t n_rec, uint32_t *list, uint32_t cap, unsigned long long *count, hipStream_t s);
 void launch_shard_bitmap_set(const uint32_t *ids, uint64_t n, uint32_t n_nodes, uint32_t *bitmap, hipStream_t s);
 void launch_shard_small_emit(const unsigned long long *dval, const unsigned long long *small_top, uint64_t n_desc, const uint32_t *bitmap, uint32_t *out, uint32_t cap,

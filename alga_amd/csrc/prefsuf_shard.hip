@@ -223,7 +223,7 @@ template <int EQ>
 __global__ void __launch_bounds__(SJ_WAVES * 64)
 k_shard_join(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, int ulen, const uint4 *__restrict__ store, const uint4 *__restrict__ dir, uint32_t bucket_base,
              const uint32_t *__restrict__ dkey, const unsigned long long *__restrict__ dval, uint64_t n_desc, ProbeOut o,
-             unsigned long long *__restrict__ small_top, unsigned long long *__restrict__ declined) {
+             unsigned long long *__restrict__ small_top, unsigned long long *__restrict__ declined, int dmax /* <= SJ_DMAX */) {
     constexpr int WC = 4 * EQ - 3;
     __shared__ uint32_t sA[SJ_WAVES][64][SJ_QW];
     __shared__ uint32_t sEM[SJ_WAVES][64], sEI[SJ_WAVES][64];
@@ -307,7 +307,7 @@ k_shard_join(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, int ulen, const uint4 *
     auto group = [&](uint64_t gs, int D, uint32_t b) {
         const uint4 rec = dir[b - bucket_base];
         const uint32_t e0 = rec.x, ecnt = rec.y;
-        if (D > SJ_DMAX) { if (lane == 0) atomicOr(declined, 1ull); return; }
+        if (D > dmax) { if (lane == 0) atomicOr(declined, 1ull); return; }
         if (D <= 64 && ecnt <= 64u) {
             // ---------------- the usual bucket: one chunk, candidate masks in registers ----------------
             load_chunk(gs, D);
@@ -438,7 +438,7 @@ k_shard_join(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, int ulen, const uint4 *
                 // to the end of the tile ... and on, while the bucket goes on
                 const uint64_t tile_end = (tile * 64 + 64 < n_desc) ? tile * 64 + 64 : n_desc;
                 D = (int) (tile_end - gs);
-                for (uint64_t j = tile_end; j < n_desc && D <= SJ_DMAX; j += 64) {
+                for (uint64_t j = tile_end; j < n_desc && D <= dmax; j += 64) {
                     const bool same = j + lane < n_desc && (dkey[j + lane] >> shift) == b;
                     const uint64_t m = __ballot(same);
                     const int run = m == ~0ull ? 64 : __builtin_ctzll(~m);
@@ -667,12 +667,12 @@ uint64_t shard_join_record_slack(int n_cu) { return (uint64_t) std::max(1, n_cu)
 
 void launch_shard_join(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterCfg &cc, int eq, int uniform_len, const void *store, const void *dir, uint32_t bucket_base,
                        const uint32_t *dkey, const unsigned long long *dval, uint64_t n_desc, uint32_t *rec_dst, unsigned long long *rec_val, uint64_t rec_cap,
-                       unsigned long long *counters, unsigned long long *small_top, unsigned long long *declined, int n_cu, hipStream_t s) {
+                       unsigned long long *counters, unsigned long long *small_top, unsigned long long *declined, int dmax, int n_cu, hipStream_t s) {
     if (n_desc == 0) return;
     const uint64_t tiles = (n_desc + 63) / 64;
     dim3 grid((unsigned) std::max<uint64_t>(1, std::min<uint64_t>((tiles + SJ_WAVES - 1) / SJ_WAVES, (uint64_t) std::max(1, n_cu) * 6))), block(SJ_WAVES * 64);
     ProbeOut o{rec_dst, rec_val, rec_cap, counters};
-#define SJ_LAUNCH(E) hipLaunchKernelGGL((k_shard_join<E>), grid, block, 0, s, nd, cfg, cc, uniform_len, (const uint4 *) store, (const uint4 *) dir, bucket_base, dkey, dval, n_desc, o, small_top, declined)
+#define SJ_LAUNCH(E) hipLaunchKernelGGL((k_shard_join<E>), grid, block, 0, s, nd, cfg, cc, uniform_len, (const uint4 *) store, (const uint4 *) dir, bucket_base, dkey, dval, n_desc, o, small_top, declined, std::max(1, std::min(dmax, SJ_DMAX)))
     if (eq == 2)      SJ_LAUNCH(2);
     else if (eq == 3) SJ_LAUNCH(3);
     else              SJ_LAUNCH(4);

@@ -138,6 +138,8 @@ int         alga_engine_device_name(const alga_engine *e, char *buf, size_t bufl
  *   "local_big_max"              largest per-wave item slice of the SOURCE_SIDE second pass (default -1 = built-in 4096); beyond it
  *                                the build takes PER_TARGET
  *   "auto_reduction_per_target"  != 0: alga_prefsuf_params.reduction == AUTO resolves to PER_TARGET
+ *   "shard_bucket_max"           1..4096 (default 4096): run descriptors of ONE bucket the bucket-sharded join (alga_shard_join_device) takes; a
+ *                                bucket with more makes the call answer ALGA_ERR_UNSUPPORTED (tests lower it to exercise that)
  *   "test_unsorted_index"        tests only.  != 0: the CLUSTER probe's entry directory is built over UNSORTED keys; the directory pass
  *                                flags it, the probe's reads are clamped to the entry array, and the build returns ALGA_ERR_HIP (no GPU fault) */
 int         alga_engine_set_option(alga_engine *e, const char *name, int64_t value);

@@ -22,11 +22,12 @@ def test_multi_copy_transport_equals_oracle(ranks, n, length, G, seed, err, minl
     want, _, _ = O.prefsuf(words, lens, lo, rs)
     m = alga_amd.MultiEngine([0] * ranks, transport="copy")
     try:
+        m.set_option("form", "replicated")               # round 3's form: every rank the whole index, its own source ids
         for _ in range(2):                               # warm buffers the second time
             got = m.prefsuf_host(words, lens, lo, rs)
             assert got.shape == want.shape and (got == want).all()
         st = m.last_stats()
-        assert st["n_ranks"] == ranks and st["transport"] == 2 and st["fell_back_to_one_gpu"] == 0 and st["edges"] == len(want)
+        assert st["n_ranks"] == ranks and st["transport"] == 2 and st["fell_back_to_one_gpu"] == 0 and st["edges"] == len(want) and st["form"] == 1
         assert all(r["probe_used"] == 2 and r["reduction_used"] == 2 for r in st["ranks"])
         assert sum(r["edges"] for r in st["ranks"]) == len(want)
     finally:
@@ -83,19 +84,17 @@ def test_multi_bucket_sharded_masks_tandem_repeats_and_declines():
         want, _, _ = O.prefsuf(words, lens, 55, 77)
         got = m.prefsuf_host(words, lens, 55, 77)
         assert got.shape == want.shape and (got == want).all()
-        # un-deduplicated input: 1000 copies of five overlapping reads -- buckets with more descriptors than the join takes (4096): the
-        # join declines, all ranks continue in the replicated form (whose own capacity case ends on rank 0); == one engine
-        codes, _ = gen_reads.sample_reads(5, 100, 130, 26)
-        w = alga_amd.pack_reads(np.tile(codes, (1000, 1)))
-        l100 = np.full(len(w), 100, np.int32)
-        one = alga_amd.Engine(0)
-        try:
-            want = one.prefsuf_host(w, l100, 55, 77)
-        finally:
-            one.close()
-        got = m.prefsuf_host(w, l100, 55, 77)
+        # a bucket with more descriptors than ONE rank's join takes (its limit lowered to 48; 160x coverage): that rank declines the phase,
+        # all ranks continue in the replicated form with the keys already gathered
+        words, lens = _nodes(4000, 100, 2500, 86, 0.01, None)
+        want, _, _ = O.prefsuf(words, lens, 55, 77)
+        m.set_rank_option(1, "shard_bucket_max", 48)
+        got = m.prefsuf_host(words, lens, 55, 77)
         assert got.shape == want.shape and (got == want).all()
         assert m.last_stats()["form"] == 1
+        m.set_rank_option(1, "shard_bucket_max", 4096)
+        got = m.prefsuf_host(words, lens, 55, 77)
+        assert got.shape == want.shape and (got == want).all() and m.last_stats()["form"] == 2
         # what the clustered probe does not take (250-nt reads): the sharded form is not even tried
         words, lens = _nodes(1200, 250, 8000, 90, 0.0, None)
         want, _, _ = O.prefsuf(words, lens, 140, 190)
