@@ -84,7 +84,7 @@ struct alga_engine {
     DevBuf      sp_rowptr, sp_sorted, sp_list, sp_cnt, sp_orow, sp_out, sp_in;   // first simplifier step (engine_simplify.hip)
     // seed-bucket-sharded N-GPU build (engine_shard.hip): state between its phases (the exchanges in between are the caller's)
     DevBuf      sh_keys[2], sh_vals[2], sh_store, sh_dir, sh_desc_out, sh_dkey[2], sh_dval[2], sh_small_top, sh_pending, sh_bitmap, sh_small_out,
-                sh_ssrc[2], sh_skey[2], sh_edges_out, sh_deg, sh_rowptr, sh_cursor, sh_edges, sh_flagged, sh_cnt;
+                sh_ssrc[2], sh_skey[2], sh_edges_out, sh_deg, sh_rowptr, sh_cursor, sh_edges, sh_flagged, sh_cnt, sh_gflag, sh_gpos, sh_gstart;
     struct {
         int      phase = 0;                    // 0 none, 1 indexed, 2 joined, 3 small keys listed, 4 resolved
         int      rank = 0, n_ranks = 1, eq = 0, uniform_len = 0;

@@ -353,7 +353,9 @@ void rank_main(alga_multi *m, int r, const alga_nodes *nodes_r, const alga_prefs
     }
     double t2 = now_ms();
     // ---- 4. build: the final edges of my sources ----
-    const bool try_sharded = shared && N > 1 && (m->form == ALGA_MULTI_FORM_BUCKET_SHARDED || (m->form == ALGA_MULTI_FORM_AUTO && N >= 3));
+    // (AUTO = REPLICATED: by the one-GPU emulation of both forms at the north-star size the sharded one costs a rank MORE device time than
+    // the replicated one up to eight ranks -- tools/emulate_shard.py against tools/emulate_rank.py, DESIGN.md section 7 -- so it is opt-in)
+    const bool try_sharded = shared && N > 1 && m->form == ALGA_MULTI_FORM_BUCKET_SHARDED;
     bool have = false;
     if (!ag.failed && try_sharded) {
         double t_shard[5] = {0, 0, 0, 0, 0};

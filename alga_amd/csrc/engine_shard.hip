@@ -155,10 +155,27 @@ int alga_shard_join_device(alga_engine *e, const alga_nodes *nodes, const uint32
     }
     if ((rc = alga_ensure(e, e->sort_temp, sort_desc_temp_bytes(n_desc)))) return rc;
     if ((rc = alga_ensure(e, e->sh_small_top, (n_desc + 1) * 3 * sizeof(unsigned long long)))) return rc;
-    launch_shard_desc_split(d_desc_in, n_desc, (uint32_t *) e->sh_dkey[0].p, (unsigned long long *) e->sh_dval[0].p, s);
+    const int shift = e->sh.cc.idx_shift;
+    int range_bits = 1;                                    // bits of a bucket index relative to my range
+    while (range_bits < 32 - shift && (1ull << range_bits) < (uint64_t) e->sh.bpr) range_bits++;
+    launch_shard_desc_split(d_desc_in, n_desc, e->sh.bucket_base << shift, (uint32_t *) e->sh_dkey[0].p, (unsigned long long *) e->sh_dval[0].p, s);
     if ((rc = alga_check_launch(e, "k_shard_desc_split"))) return rc;
     HIP_TRY(e, sort_desc(e->sort_temp.p, sort_desc_temp_bytes(n_desc), (const uint32_t *) e->sh_dkey[0].p, (uint32_t *) e->sh_dkey[1].p, (const unsigned long long *) e->sh_dval[0].p,
-                         (unsigned long long *) e->sh_dval[1].p, n_desc, e->sh.cc.idx_shift, 32, s));
+                         (unsigned long long *) e->sh_dval[1].p, n_desc, shift, std::min(32, shift + range_bits), s));
+    // the groups (one per bucket) of the sorted array
+    if ((rc = alga_ensure(e, e->sh_gflag, (n_desc + 2) * sizeof(uint32_t)))) return rc;
+    if ((rc = alga_ensure(e, e->sh_gpos, (n_desc + 2) * sizeof(uint32_t)))) return rc;
+    if ((rc = alga_ensure(e, e->sh_gstart, (n_desc + 2) * sizeof(uint32_t)))) return rc;
+    if ((rc = alga_ensure(e, e->scan_scratch, scan_scratch_bytes(n_desc + 1)))) return rc;
+    launch_shard_groups((const uint32_t *) e->sh_dkey[1].p, n_desc, e->sh.cc.idx_shift, (uint32_t *) e->sh_gflag.p, (uint32_t *) e->sh_gpos.p, (uint32_t *) e->sh_gstart.p,
+                        (uint64_t *) e->scan_scratch.p, s);
+    if ((rc = alga_check_launch(e, "k_shard_groups"))) return rc;
+    uint32_t n_groups = 0;
+    if (n_desc) {
+        HIP_TRY(e, hipMemcpyAsync(e->h_counters, (const uint32_t *) e->sh_gpos.p + n_desc, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        HIP_TRY(e, hipStreamSynchronize(s));
+        n_groups = *(const uint32_t *) e->h_counters;
+    }
     e->shard_stats.ms_sort = t_sort.stop();
     e->sh.d_keys_sorted = (uint32_t *) e->sh_dkey[1].p; e->sh.d_vals_sorted = (unsigned long long *) e->sh_dval[1].p;
     // ---- join: records = surviving overlaps (small ones pending their source's cap) ----
@@ -174,7 +191,7 @@ int alga_shard_join_device(alga_engine *e, const alga_nodes *nodes, const uint32
         HIP_TRY(e, hipMemsetAsync(cnt, 0, CNT_TOTAL * sizeof(unsigned long long), s));
         HIP_TRY(e, hipMemsetAsync(scnt, 0, 8 * sizeof(unsigned long long), s));
         launch_shard_join(nd, e->sh.cfg, e->sh.cc, e->sh.eq, e->sh.uniform_len, e->sh_store.p, e->sh_dir.p, e->sh.bucket_base, e->sh.d_keys_sorted, e->sh.d_vals_sorted, n_desc,
-                          (uint32_t *) e->rec_dst.p, (unsigned long long *) e->rec_val.p, cap, cnt, (unsigned long long *) e->sh_small_top.p, scnt + 3, e->opt_shard_dmax, e->n_cu, s);
+                          (const uint32_t *) e->sh_gstart.p, n_groups, (uint32_t *) e->rec_dst.p, (unsigned long long *) e->rec_val.p, cap, cnt, (unsigned long long *) e->sh_small_top.p, scnt + 3, e->opt_shard_dmax, e->n_cu, s);
         if ((rc = alga_check_launch(e, "k_shard_join"))) return rc;
         HIP_TRY(e, hipMemcpyAsync(e->h_counters, cnt, CNT_TOTAL * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
         HIP_TRY(e, hipMemcpyAsync(e->h_counters + CNT_TOTAL, scnt + 3, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
@@ -270,8 +287,10 @@ int alga_shard_resolve_device(alga_engine *e, const uint32_t *d_small_all, uint6
         if ((rc = alga_ensure(e, e->sort_temp, sort_records_temp_bytes(n_small_all, 32)))) return rc;
         launch_shard_small_split(d_small_all, n_small_all, (uint32_t *) e->sh_ssrc[0].p, (unsigned long long *) e->sh_skey[0].p, s);
         if ((rc = alga_check_launch(e, "k_shard_small_split"))) return rc;
+        int src_bits = 1;
+        while (src_bits < 32 && (1ll << src_bits) < (long long) e->sh.n) src_bits++;
         HIP_TRY(e, sort_records(e->sort_temp.p, sort_records_temp_bytes(n_small_all, 32), (const uint32_t *) e->sh_ssrc[0].p, (uint32_t *) e->sh_ssrc[1].p,
-                                (const unsigned long long *) e->sh_skey[0].p, (unsigned long long *) e->sh_skey[1].p, n_small_all, 32, s));
+                                (const unsigned long long *) e->sh_skey[0].p, (unsigned long long *) e->sh_skey[1].p, n_small_all, src_bits, s));
         launch_shard_resolve((uint32_t *) e->rec_dst.p, (const unsigned long long *) e->rec_val.p, e->sh.n_rec, (const uint32_t *) e->sh_ssrc[1].p,
                              (const unsigned long long *) e->sh_skey[1].p, n_small_all, scnt + 6, s);
         if ((rc = alga_check_launch(e, "k_shard_resolve"))) return rc;

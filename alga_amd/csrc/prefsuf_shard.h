@@ -19,15 +19,16 @@ void launch_shard_export(bool count, const void *runs, int32_t node_begin, int32
                          uint32_t *out, hipStream_t s);
 void launch_shard_export_flagged(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterCfg &cc, const int32_t *flagged_list, uint32_t n_flagged, uint32_t bpr, uint32_t n_ranks,
                                  const unsigned long long *seg_off, unsigned long long *cursor, uint32_t *out, hipStream_t s);
-void launch_shard_desc_split(const uint32_t *in, uint64_t n, uint32_t *dkey, unsigned long long *dval, hipStream_t s);
+void launch_shard_desc_split(const uint32_t *in, uint64_t n, uint32_t key_base /* first key of the rank's bucket range */, uint32_t *dkey, unsigned long long *dval, hipStream_t s);
 size_t     sort_desc_temp_bytes(uint64_t n);
 hipError_t sort_desc(void *temp, size_t temp_bytes, const uint32_t *keys_in, uint32_t *keys_out, const unsigned long long *vals_in, unsigned long long *vals_out, uint64_t n,
                      int begin_bit, int end_bit, hipStream_t s);
 uint64_t shard_join_record_slack(int n_cu);
+void launch_shard_groups(const uint32_t *dkey, uint64_t n_desc, int shift, uint32_t *flag, uint32_t *pos, uint32_t *gstart, uint64_t *scan_scratch, hipStream_t s);
 void launch_shard_join(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterCfg &cc, int eq, int uniform_len, const void *store, const void *dir, uint32_t bucket_base,
-                       const uint32_t *dkey, const unsigned long long *dval, uint64_t n_desc, uint32_t *rec_dst, unsigned long long *rec_val, uint64_t rec_cap,
-                       unsigned long long *counters, unsigned long long *small_top, unsigned long long *declined, int dmax /* descriptors of one bucket the join takes (<= 4096) */,
-                       int n_cu, hipStream_t s);
+                       const uint32_t *dkey, const unsigned long long *dval, uint64_t n_desc, const uint32_t *gstart, uint32_t n_groups, uint32_t *rec_dst,
+                       unsigned long long *rec_val, uint64_t rec_cap, unsigned long long *counters, unsigned long long *small_top, unsigned long long *declined,
+                       int dmax /* descriptors of one bucket the join takes (<= 4096) */, int n_cu, hipStream_t s);
 void launch_shard_pending_src(const uint32_t *rec_dst, const unsigned long long *rec_val, uint64_t n_rec, uint32_t *list, uint32_t cap, unsigned long long *count, hipStream_t s);
 void launch_shard_bitmap_set(const uint32_t *ids, uint64_t n, uint32_t n_nodes, uint32_t *bitmap, hipStream_t s);
 void launch_shard_small_emit(const unsigned long long *dval, const unsigned long long *small_top, uint64_t n_desc, const uint32_t *bitmap, uint32_t *out, uint32_t cap,

@@ -59,6 +59,18 @@ __device__ __forceinline__ uint32_t wave_min_u32_dpp(uint32_t v) {
     return (uint32_t) __builtin_amdgcn_readlane((int) v, 63);
 }
 
+// max over the 64 lanes, uniform
+__device__ __forceinline__ uint32_t wave_max_u32_dpp_or0(uint32_t v) {
+    uint32_t t;
+    t = (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x111, 0xF, 0xF, false); v = t > v ? t : v;
+    t = (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x112, 0xF, 0xF, false); v = t > v ? t : v;
+    t = (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x114, 0xF, 0xF, false); v = t > v ? t : v;
+    t = (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x118, 0xF, 0xF, false); v = t > v ? t : v;
+    t = (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x142, 0xA, 0xF, false); v = t > v ? t : v;
+    t = (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x143, 0xC, 0xF, false); v = t > v ? t : v;
+    return (uint32_t) __builtin_amdgcn_readlane((int) v, 63);
+}
+
 // ------------------------------------------------------------------------------------------
 // k_shard_select : (key, id) of the targets whose bucket lies in [b_lo, b_hi)
 // ------------------------------------------------------------------------------------------
@@ -196,40 +208,65 @@ __global__ void __launch_bounds__(256) k_shard_export_flagged(NodesDev nd, PrefS
 }
 
 // received descriptors {key, src, y} -> sort key + payload
-__global__ void __launch_bounds__(256) k_shard_desc_split(const uint32_t *__restrict__ in, uint64_t n, uint32_t *__restrict__ dkey, unsigned long long *__restrict__ dval) {
+// (the key RELATIVE to the first key of the rank's bucket range: its bits above the range's width are zero and need not be sorted)
+__global__ void __launch_bounds__(256) k_shard_desc_split(const uint32_t *__restrict__ in, uint64_t n, uint32_t key_base, uint32_t *__restrict__ dkey, unsigned long long *__restrict__ dval) {
     for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) {
-        dkey[i] = in[3 * i];
+        dkey[i] = in[3 * i] - key_base;
         dval[i] = (unsigned long long) in[3 * i + 1] | ((unsigned long long) in[3 * i + 2] << 32);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_shard_groups : the descriptor groups (one per bucket) of the bucket-sorted descriptor array
+// ------------------------------------------------------------------------------------------
+// flag[i] = 1 where descriptor i opens a group; the exclusive scan of the flags numbers the groups; gstart[g] = first descriptor of
+// group g, gstart[n_groups] = n_desc.  (A list, because the join packs WHOLE groups onto a wave's lanes.)
+__global__ void __launch_bounds__(256) k_shard_group_flags(const uint32_t *__restrict__ dkey, uint64_t n, int shift, uint32_t *__restrict__ flag) {
+    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x)
+        flag[i] = (i == 0 || (dkey[i] >> shift) != (dkey[i - 1] >> shift)) ? 1u : 0u;
+}
+__global__ void __launch_bounds__(256) k_shard_group_starts(const uint32_t *__restrict__ flag, const uint32_t *__restrict__ pos, uint64_t n, uint32_t *__restrict__ gstart) {
+    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += (uint64_t) gridDim.x * blockDim.x) {
+        if (i == n) gstart[pos[n]] = (uint32_t) n;          // pos[n] = number of groups (launch_exclusive_scan writes the total there)
+        else if (flag[i]) gstart[pos[i]] = (uint32_t) i;
     }
 }
 
 // ------------------------------------------------------------------------------------------
 // k_shard_join
 // ------------------------------------------------------------------------------------------
-// Descriptors sorted by bucket; a wave takes the tiles of 64 consecutive descriptors of its grid stride and every GROUP (the
-// descriptors of one bucket) that STARTS in its tile -- no group list, no atomics to build one.  Lanes = descriptors (source runs):
-//   pass 1  the bucket's entries one after the other (uniform loads): lane l verifies its source against the entry at the one offset
-//           their minimizers allow (p = q - m_C, inside the run's windows), exact 2-bit compare from the source's row staged in LDS
-//           -> bit c of the lane's candidate mask; the top-3 small (L, C) keys of the run go to small_top[] (the cap's raw material);
-//   pass 2  per entry (= per TARGET) with candidates: the vias B in the order of their offsets, smallest first; B removes candidate
-//           A when B -> C is big, B sits at offset delta = p_A - p_B >= 0 of A reaching at least to A's end but not past C's, and
-//           A[delta:] == B[:|A| - delta] (2-bit compare of the two staged rows); a second descriptor of the SAME source at a smaller
-//           offset supersedes.  On error-free data the first B removes every other candidate and the loop ends after one step.
+// Descriptors sorted by bucket, groups listed (gstart).  A wave takes chunks of SJ_GCH consecutive groups and packs WHOLE groups
+// onto its 64 lanes for as long as they fit (a 150-bp bucket at 30x holds ~20 descriptors: three groups a pass) -- lanes =
+// descriptors (source runs), every lane with its own bucket's entry range:
+//   pass 1  entry c of the lane's own bucket, c = 0 .. the longest bucket of the pass (lanes of one group read the same entry: one
+//           fetch): the lane verifies its source against the entry at the one offset their minimizers allow (p = q - m_C, inside the
+//           run's windows), exact 2-bit compare from the source's row staged in LDS -> bit c of the lane's candidate mask; the top-3
+//           small (L, C) keys of the run go to small_top[] (the cap's raw material);
+//   pass 2  entry c again (= one TARGET per group): the vias B of a group in the order of their offsets, smallest first (a
+//           segmented minimum through one LDS word per group); B removes candidate A when B -> C is big, B sits at offset
+//           delta = p_A - p_B >= 0 of A, reaches at least to A's end but not past C's, and A[delta, p_A) == B[0, p_B) -- beyond that
+//           both already equal C (the reference's compare, GraphCreatorPrefSuf.cpp:434-451: p_B <= 63 nucleotides, four words); a second
+//           descriptor of the SAME source at a smaller offset supersedes.  On error-free data the first B removes every other
+//           candidate and the loop ends after one step.
 //   Survivors leave as records {target, offset | L | small, source} through the chunked record list of the probes
 //   (prefsuf_device.h flush_records); `small` marks the ones that still have to pass their source's cap.
-// Buckets with more than 64 descriptors or entries take the same steps chunk by chunk with the candidate masks in LDS and the vias'
-// rows from global memory (repeats, buckets shared by several loci at 400x coverage): slow and rare.
-template <int EQ>
+// A group with more than 64 descriptors or entries takes the same steps alone, chunk by chunk, with the candidate masks of one
+// target in LDS and the vias' rows from global memory (repeats, 400x coverage): slow and rare.
+constexpr int SJ_GCH = 32;           // groups per chunk of a wave's share
+constexpr int SJ_WB = 128;           // per-wave LDS record buffer
+constexpr int SJ_ES = 96;            // entries of one pass whose id / meta stay in LDS for pass 2
+template <int EQ, int KF>
 __global__ void __launch_bounds__(SJ_WAVES * 64)
 k_shard_join(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, int ulen, const uint4 *__restrict__ store, const uint4 *__restrict__ dir, uint32_t bucket_base,
-             const uint32_t *__restrict__ dkey, const unsigned long long *__restrict__ dval, uint64_t n_desc, ProbeOut o,
-             unsigned long long *__restrict__ small_top, unsigned long long *__restrict__ declined, int dmax /* <= SJ_DMAX */) {
+             const uint32_t *__restrict__ dkey, const unsigned long long *__restrict__ dval, uint64_t n_desc, const uint32_t *__restrict__ gstart, uint32_t n_groups,
+             ProbeOut o, unsigned long long *__restrict__ small_top, unsigned long long *__restrict__ declined, int dmax /* <= SJ_DMAX */) {
     constexpr int WC = 4 * EQ - 3;
     __shared__ uint32_t sA[SJ_WAVES][64][SJ_QW];
-    __shared__ uint32_t sEM[SJ_WAVES][64], sEI[SJ_WAVES][64];
+    __shared__ uint32_t sSrc[SJ_WAVES][64], sLen[SJ_WAVES][64], sMin[SJ_WAVES][64];
+    __shared__ uint32_t sEI[SJ_WAVES][SJ_ES], sEM[SJ_WAVES][SJ_ES];     // id / meta of the pass's entries, group by group
     __shared__ unsigned long long sVM[SJ_WAVES][SJ_DMAX / 64];
-    __shared__ uint32_t sRecC[SJ_WAVES][WBUF];
-    __shared__ unsigned long long sRecV[SJ_WAVES][WBUF];
+    __shared__ uint32_t sRecC[SJ_WAVES][SJ_WB];
+    __shared__ unsigned long long sRecV[SJ_WAVES][SJ_WB];
     __shared__ uint32_t sCnt[SJ_WAVES][2];
     const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
     const int lane = lane_id();
@@ -241,17 +278,18 @@ k_shard_join(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, int ulen, const uint4 *
     uint64_t st_rec = 0;
     const int fs = cc.idx_shift - CL_MBITS, shift = cc.idx_shift;
     const int Lbig = cfg.rsoemo > cfg.Lmin ? cfg.rsoemo : cfg.Lmin;
+    const int kfull = KF ? KF : (2 * cfg.Lmin) >> 5;       // row words every overlap covers entirely
     uint32_t *sb = sA[wave][lane];
 
-    // per-lane state of the descriptor chunk in the lanes
+    // per-lane state of the descriptors in the lanes
     bool act = false;
     uint32_t key = 0, src = 0;
     int q = 0, p0 = 0, p1 = 0, lenA = 0;
-    auto load_chunk = [&](uint64_t first, int count) {     // descriptors first .. first + count - 1 -> lanes 0 .. count - 1, rows staged
+    auto load_descs = [&](uint64_t first, int count) {     // descriptors first .. first + count - 1 -> lanes 0 .. count - 1, rows staged
         act = lane < count;
         const uint64_t idx = act ? first + (uint64_t) lane : first;
         const unsigned long long v = dval[idx];
-        key = dkey[idx];
+        key = dkey[idx] + (bucket_base << shift);           // (stored relative to the rank's first key)
         src = (uint32_t) v;
         const uint32_t y = (uint32_t) (v >> 32);
         q = (int) (y & 255u); p0 = (int) ((y >> 8) & 255u); p1 = (int) ((y >> 16) & 255u);
@@ -259,197 +297,247 @@ k_shard_join(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, int ulen, const uint4 *
         const int nw = blocks_of(lenA);
         const uint32_t *row = nd.words + (size_t) src * nd.stride;
         wave_lds_fence();
+        if ((nd.stride & 3) == 0) {                        // the engine's own layout: 16-byte pieces
+            const uint4 *r4 = reinterpret_cast<const uint4 *>(row);
 #pragma unroll
-        for (int k = 0; k < SJ_QW; k++) sb[k] = (k < nw && k < nd.stride) ? row[k] : 0u;
+            for (int k4 = 0; k4 < EQ; k4++) {
+                const uint4 x = 4 * k4 < nd.stride ? r4[k4] : make_uint4(0u, 0u, 0u, 0u);
+                if (4 * k4 + 0 < SJ_QW) sb[4 * k4 + 0] = 4 * k4 + 0 < nw ? x.x : 0u;
+                if (4 * k4 + 1 < SJ_QW) sb[4 * k4 + 1] = 4 * k4 + 1 < nw ? x.y : 0u;
+                if (4 * k4 + 2 < SJ_QW) sb[4 * k4 + 2] = 4 * k4 + 2 < nw ? x.z : 0u;
+                if (4 * k4 + 3 < SJ_QW) sb[4 * k4 + 3] = 4 * k4 + 3 < nw ? x.w : 0u;
+            }
+#pragma unroll
+            for (int k = 4 * EQ; k < SJ_QW; k++) sb[k] = 0u;
+        } else {
+#pragma unroll
+            for (int k = 0; k < SJ_QW; k++) sb[k] = (k < nw && k < nd.stride) ? row[k] : 0u;
+        }
+        sSrc[wave][lane] = src; sLen[wave][lane] = (uint32_t) lenA;
         wave_lds_fence();
     };
-    // entry `ei` of the rank's entry array, uniform
-    auto load_entry = [&](uint32_t ei, uint32_t (&ew)[4 * EQ]) {
-        const uint4 *ent = store + (size_t) ei * EQ;
-#pragma unroll
-        for (int c = 0; c < EQ; c++) { const uint4 v = ent[c]; ew[4 * c] = v.x; ew[4 * c + 1] = v.y; ew[4 * c + 2] = v.z; ew[4 * c + 3] = v.w; }
-    };
     // does this lane's run overlap the entry?  p = the one offset their minimizers allow
-    auto verify = [&](const uint32_t (&ew)[4 * EQ], int &p) -> bool {
+    auto verify = [&](bool has, const uint32_t (&ew)[4 * EQ], int &p) -> bool {
         const uint32_t id = ew[4 * EQ - 3], ekey = ew[4 * EQ - 2], meta = ew[4 * EQ - 1];
         const int lenC = (int) ((meta >> 8) & 0xFFFu);
         p = q - (int) (meta & 255u);
-        const bool ok = act & same_cluster(ekey, key, fs) & (p >= p0) & (p < p1) & (id != src) & (lenC >= lenA - p);
+        const bool ok = has & same_cluster(ekey, key, fs) & (p >= p0) & (p < p1) & (id != src) & (lenC >= lenA - p);
         p = ok ? p : 0;
         const int nb = 2 * (lenA - p), qw = (2 * p) >> 5, sh = (2 * p) & 31;
         uint32_t diff = 0;
 #pragma unroll
-        for (int k = 0; k < WC; k++) diff |= (funnel(sb[qw + k], sb[qw + k + 1], sh) ^ ew[k]) & low_bits32(nb - 32 * k);
+        for (int k = 0; k < WC; k++) {
+            const uint32_t x = funnel(sb[qw + k], sb[qw + k + 1], sh) ^ ew[k];
+            if (k < kfull) diff |= x;                      // (compile time with KF)
+            else diff |= x & low_bits32(nb - 32 * k);
+        }
         return ok && diff == 0;
     };
-    // does via B (uniform: id, length, offset into C, row words) remove this lane's candidate (offset p into C, rho_c past A's end)?
-    auto via = [&](uint32_t srcB, int lenB, int pB, const uint32_t (&rowB)[WC], int p, int rho_c) -> bool {
+    // does via B (id, length, offset pB into C, its first four row words) remove this lane's candidate (offset p into C, rho_c past A's end)?
+    auto via = [&](uint32_t srcB, int lenB, int pB, uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3, int p, int rho_c) -> bool {
         const int delta = p - pB;
         const bool same = srcB == src;
         const int rho_b = lenB - (lenA - delta);
         const bool vok = (!same) & (pB > 0) & (delta >= 0) & (lenB - pB >= Lbig) & (rho_b >= 0) & (rho_b <= rho_c) & ((rho_b > 0) | (srcB > src));
         const int dd = delta < 0 ? 0 : delta;
-        const int nb = 2 * (lenA - dd), qw = (2 * dd) >> 5, sh = (2 * dd) & 31;
-        uint32_t diff = 0;
-#pragma unroll
-        for (int k = 0; k < WC; k++) diff |= (funnel(sb[qw + k], sb[qw + k + 1], sh) ^ rowB[k]) & low_bits32(nb - 32 * k);
+        const int nb = 2 * pB, qw = (2 * dd) >> 5, sh = (2 * dd) & 31;       // A[delta, delta + pB) against B[0, pB): pB <= 63
+        const uint32_t diff = ((funnel(sb[qw], sb[qw + 1], sh) ^ b0) & low_bits32(nb)) | ((funnel(sb[qw + 1], sb[qw + 2], sh) ^ b1) & low_bits32(nb - 32)) |
+                              ((funnel(sb[qw + 2], sb[qw + 3], sh) ^ b2) & low_bits32(nb - 64)) | ((funnel(sb[qw + 3], sb[qw + 4], sh) ^ b3) & low_bits32(nb - 96));
         return (vok && diff == 0) || (same && pB < p);
     };
     auto push = [&](uint32_t C, int p) {
         const int L = lenA - p;
         const unsigned long long val = ((unsigned long long) ol_pack(p, L, L < cfg.rsoemo) << 32) | src;
         const uint32_t i = atomicAdd(w.recN, 1u);
-        if (i < (uint32_t) WBUF) { w.recC[i] = C; w.recV[i] = val; }
+        if (i < (uint32_t) SJ_WB) { w.recC[i] = C; w.recV[i] = val; }
         else store_record(o, atomicAdd(&o.counters[CNT_RECORDS], 1ull), C, val);
         st_rec++;
     };
+    auto maybe_flush = [&]() {
+        wave_lds_fence();
+        const int nb2 = (int) __builtin_amdgcn_readfirstlane((int) *w.recN);
+        if (nb2 >= SJ_WB / 2) flush_records<REC_CHUNK, SJ_WB>(o, w, chunk_base, chunk_fill);
+    };
 
-    auto group = [&](uint64_t gs, int D, uint32_t b) {
-        const uint4 rec = dir[b - bucket_base];
-        const uint32_t e0 = rec.x, ecnt = rec.y;
+    // ---------------- one big bucket alone: chunks of 64 descriptors, candidate masks of one target in LDS, via rows from global memory ----------------
+    auto big_group = [&](uint64_t gs, int D) {
         if (D > dmax) { if (lane == 0) atomicOr(declined, 1ull); return; }
-        if (D <= 64 && ecnt <= 64u) {
-            // ---------------- the usual bucket: one chunk, candidate masks in registers ----------------
-            load_chunk(gs, D);
-            uint64_t vmask = 0, k0 = 0, k1 = 0, k2 = 0;
-            for (uint32_t c = 0; c < ecnt; c++) {          // uniform
-                uint32_t ew[4 * EQ];
-                load_entry(e0 + c, ew);
-                int p;
-                const bool V = verify(ew, p);
-                if (lane == 0) { sEM[wave][c] = ew[4 * EQ - 1]; sEI[wave][c] = ew[4 * EQ - 3]; }
-                vmask |= V ? 1ull << c : 0ull;
-                const int L = lenA - p;
-                if (V && L < cfg.rsoemo) top3_insert(k0, k1, k2, ((uint64_t) (uint32_t) L << 32) | ew[4 * EQ - 3]);
+        const uint32_t b = (uint32_t) __builtin_amdgcn_readfirstlane((int) (dkey[gs] >> shift));       // relative to the rank's first bucket
+        const uint4 rec = dir[b];
+        const uint32_t e0 = rec.x, ecnt = rec.y;
+        const int nch = (D + 63) >> 6;
+        for (int cc2 = 0; cc2 < nch; cc2++) {
+            const int cnt = D - 64 * cc2 < 64 ? D - 64 * cc2 : 64;
+            if (lane < cnt) { const uint64_t i = gs + 64u * (uint64_t) cc2 + lane; small_top[3 * i] = 0ull; small_top[3 * i + 1] = 0ull; small_top[3 * i + 2] = 0ull; }
+        }
+        for (uint32_t c = 0; c < ecnt; c++) {              // uniform
+            uint32_t ew[4 * EQ];
+            {
+                const uint4 *ent = store + (size_t) (e0 + c) * EQ;
+#pragma unroll
+                for (int k4 = 0; k4 < EQ; k4++) { const uint4 v = ent[k4]; ew[4 * k4] = v.x; ew[4 * k4 + 1] = v.y; ew[4 * k4 + 2] = v.z; ew[4 * k4 + 3] = v.w; }
             }
-            if (act) { small_top[3 * (gs + lane)] = k0; small_top[3 * (gs + lane) + 1] = k1; small_top[3 * (gs + lane) + 2] = k2; }
+            const uint32_t meta = ew[4 * EQ - 1], idC = ew[4 * EQ - 3];
+            const int lenC = (int) ((meta >> 8) & 0xFFFu);
+            uint64_t any = 0ull;
+            for (int cc2 = 0; cc2 < nch; cc2++) {
+                const int cnt = D - 64 * cc2 < 64 ? D - 64 * cc2 : 64;
+                load_descs(gs + 64u * (uint64_t) cc2, cnt);
+                int p;
+                const bool V = verify(act, ew, p);
+                const uint64_t m = __ballot(V);
+                if (lane == 0) sVM[wave][cc2] = m;
+                any |= m;
+                const int L = lenA - p;
+                if (V && L < cfg.rsoemo) {
+                    const uint64_t i = gs + 64u * (uint64_t) cc2 + lane;
+                    uint64_t a = small_top[3 * i], b2 = small_top[3 * i + 1], c2 = small_top[3 * i + 2];
+                    top3_insert(a, b2, c2, ((uint64_t) (uint32_t) L << 32) | idC);
+                    small_top[3 * i] = a; small_top[3 * i + 1] = b2; small_top[3 * i + 2] = c2;
+                }
+            }
             wave_lds_fence();
-            const uint64_t anyv = wave_or_u64_dpp(vmask);
-            for (uint64_t todo = anyv; todo != 0ull; todo &= todo - 1ull) {      // uniform: the targets with candidates
-                const int c = __builtin_ctzll(todo);
-                const uint32_t meta = sEM[wave][c], idC = sEI[wave][c];
-                const int lenC = (int) ((meta >> 8) & 0xFFFu);
-                const bool V = ((vmask >> c) & 1ull) != 0ull;
+            if (any == 0ull) continue;
+            for (int cc2 = 0; cc2 < nch; cc2++) {          // candidate chunk
+                const uint64_t cm = sVM[wave][cc2];
+                if (cm == 0ull) continue;
+                const int cnt = D - 64 * cc2 < 64 ? D - 64 * cc2 : 64;
+                if (nch > 1) load_descs(gs + 64u * (uint64_t) cc2, cnt);
+                const bool V = ((cm >> lane) & 1ull) != 0ull;
                 const int p = q - (int) (meta & 255u);
                 const int rho_c = lenC - (lenA - p);
                 bool removed = false;
-                uint64_t used = 0ull;
-                for (;;) {                                 // uniform
-                    const bool avail = V && ((used >> lane) & 1ull) == 0ull;
-                    const uint32_t m = wave_min_u32_dpp(avail ? (((uint32_t) p << 6) | (uint32_t) lane) : 0xFFFFFFFFu);
-                    if (m == 0xFFFFFFFFu) break;
-                    const int Bl = (int) (m & 63u), pB = (int) (m >> 6);
-                    used |= 1ull << Bl;
-                    const bool test = V && !removed && lane != Bl && p >= pB;
-                    if (__ballot(test) == 0ull) break;     // nobody is left whom this or any later via (they all sit further right) could remove
-                    const uint32_t srcB = (uint32_t) __builtin_amdgcn_readlane((int) src, Bl);
-                    const int lenB = __builtin_amdgcn_readlane(lenA, Bl);
-                    uint32_t rowB[WC];
+                for (int bb = 0; bb < nch; bb++) {
+                    for (uint64_t bm = sVM[wave][bb]; bm != 0ull; bm &= bm - 1ull) {     // uniform: every via, in index order
+                        const int bl = __builtin_ctzll(bm);
+                        const bool test = V && !removed && !(bb == cc2 && bl == lane);
+                        if (__ballot(test) == 0ull) continue;
+                        const uint64_t bi = gs + 64u * (uint64_t) bb + (uint64_t) bl;
+                        const unsigned long long vB = dval[bi];
+                        const uint32_t srcB = (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) vB);
+                        const int pB = (int) ((uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) (vB >> 32)) & 255u) - (int) (meta & 255u);
+                        const int lenB = ulen > 0 ? ulen : __builtin_amdgcn_readfirstlane(nd.len[srcB]);
+                        const int nwB = blocks_of(lenB);
+                        const uint32_t *rb = nd.words + (size_t) srcB * nd.stride;
+                        uint32_t rB[4];
 #pragma unroll
-                    for (int k = 0; k < WC; k++) rowB[k] = sA[wave][Bl][k];
-                    removed = removed || (test && via(srcB, lenB, pB, rowB, p, rho_c));
+                        for (int k = 0; k < 4; k++) rB[k] = (k < nwB && k < nd.stride) ? rb[k] : 0u;
+                        removed = removed || (test && p >= pB && via(srcB, lenB, pB, rB[0], rB[1], rB[2], rB[3], p, rho_c));
+                    }
+                }
+                if (V && !removed) push(idC, p);
+                maybe_flush();
+            }
+        }
+    };
+
+    const uint32_t total_waves = gridDim.x * SJ_WAVES;
+    for (uint32_t g0 = ((uint32_t) blockIdx.x * SJ_WAVES + (uint32_t) wave) * SJ_GCH; g0 < n_groups; g0 += total_waves * SJ_GCH) {
+        const uint32_t gend = g0 + SJ_GCH < n_groups ? g0 + SJ_GCH : n_groups;
+        uint32_t ga = g0;
+        while (ga < gend) {                                // uniform: one pass per iteration
+            // whole groups from ga on for as long as they fit the 64 lanes
+            const uint32_t s0 = gstart[ga];
+            const uint32_t gi = ga + 1u + (uint32_t) lane;
+            const uint32_t ge = gstart[gi <= gend ? gi : gend];
+            const uint64_t fits = __ballot(gi <= gend && ge - s0 <= 64u);
+            const int ng = fits == ~0ull ? 64 : __builtin_ctzll(~fits);
+            if (ng == 0) {                                 // the group at ga alone exceeds a pass
+                big_group((uint64_t) s0, (int) min(gstart[ga + 1u] - s0, (uint32_t) SJ_DMAX + 1u));
+                ga++;
+                continue;
+            }
+            const int cnt = (int) ((uint32_t) __builtin_amdgcn_readlane((int) ge, ng - 1) - s0);
+            ga += (uint32_t) ng;
+            load_descs((uint64_t) s0, cnt);
+            // ---- the lanes' groups: bucket, entry range, first lane ----
+            const uint32_t b = act ? key >> shift : 0xFFFFFFFFu;
+            const uint32_t bprev = bperm(b, (lane + 63) & 63);
+            const uint64_t starts = __ballot(act && (lane == 0 || b != bprev));
+            const int gfirst = 63 - __builtin_clzll((long long) ((starts & (lane >= 63 ? ~0ull : ((2ull << lane) - 1ull))) | 1ull));
+            const uint4 rec = dir[act ? b - bucket_base : 0u];       // (key is absolute again: load_descs)
+            uint32_t e0 = rec.x, ecnt = act ? rec.y : 0u;
+            // a bucket with more than 64 entries (several loci in one bucket at extreme coverage): that group alone, afterwards
+            const uint64_t wide = __ballot(act && ecnt > 64u);
+            if (wide != 0ull) ecnt = ecnt > 64u ? 0u : ecnt;
+            const uint32_t max_e = wave_max_u32_dpp_or0(ecnt);
+            // slots of the pass's entries in LDS (id, meta: what pass 2 needs of an entry): group by group, SJ_ES in all (beyond: re-read)
+            int ebase;
+            {
+                uint32_t inc = (act && lane == gfirst) ? ecnt : 0u, t;      // inclusive scan over the lanes
+                t = (uint32_t) __builtin_amdgcn_update_dpp(0, (int) inc, 0x111, 0xF, 0xF, false); inc += t;
+                t = (uint32_t) __builtin_amdgcn_update_dpp(0, (int) inc, 0x112, 0xF, 0xF, false); inc += t;
+                t = (uint32_t) __builtin_amdgcn_update_dpp(0, (int) inc, 0x114, 0xF, 0xF, false); inc += t;
+                t = (uint32_t) __builtin_amdgcn_update_dpp(0, (int) inc, 0x118, 0xF, 0xF, false); inc += t;
+                t = (uint32_t) __builtin_amdgcn_update_dpp(0, (int) inc, 0x142, 0xA, 0xF, false); inc += t;
+                t = (uint32_t) __builtin_amdgcn_update_dpp(0, (int) inc, 0x143, 0xC, 0xF, false); inc += t;
+                ebase = (int) (bperm(inc, gfirst) - ecnt);                    // entries of the groups before this lane's
+            }
+            // ---- pass 1: the entry loads of step c + 1 are in flight while step c is verified ----
+            uint64_t vmask = 0, k0 = 0, k1 = 0, k2 = 0;
+            uint32_t en[4 * EQ];
+            auto load_entry = [&](uint32_t c, uint32_t (&ew)[4 * EQ]) {
+                const uint4 *ent = store + (size_t) (c < ecnt ? e0 + c : e0) * EQ;
+#pragma unroll
+                for (int k4 = 0; k4 < EQ; k4++) { const uint4 v = ent[k4]; ew[4 * k4] = v.x; ew[4 * k4 + 1] = v.y; ew[4 * k4 + 2] = v.z; ew[4 * k4 + 3] = v.w; }
+            };
+            load_entry(0u, en);
+            for (uint32_t c = 0; c < max_e; c++) {         // uniform
+                uint32_t ew[4 * EQ];
+#pragma unroll
+                for (int k = 0; k < 4 * EQ; k++) ew[k] = en[k];
+                load_entry(c + 1u, en);                    // (past the bucket's end: its first entry again, never used)
+                const bool has = c < ecnt;
+                int p;
+                const bool V = verify(has, ew, p);
+                vmask |= V ? 1ull << c : 0ull;
+                const int L = lenA - p;
+                if (V && L < cfg.rsoemo) top3_insert(k0, k1, k2, ((uint64_t) (uint32_t) L << 32) | ew[4 * EQ - 3]);
+                if (has && lane == gfirst && ebase + (int) c < SJ_ES) { sEI[wave][ebase + (int) c] = ew[4 * EQ - 3]; sEM[wave][ebase + (int) c] = ew[4 * EQ - 1]; }
+            }
+            if (act && ((wide >> gfirst) & 1ull) == 0ull) { small_top[3 * ((uint64_t) s0 + lane)] = k0; small_top[3 * ((uint64_t) s0 + lane) + 1] = k1; small_top[3 * ((uint64_t) s0 + lane) + 2] = k2; }
+            wave_lds_fence();
+            // ---- pass 2: per target, the vias of each group by ascending offset ----
+            for (uint32_t c = 0; c < max_e; c++) {         // uniform
+                const bool V = ((vmask >> c) & 1ull) != 0ull;
+                if (__ballot(V) == 0ull) continue;
+                uint32_t idC, meta;
+                const int es = ebase + (int) c;
+                if (__ballot(V && es >= SJ_ES) == 0ull) { const int e2 = (es >= 0 && es < SJ_ES) ? es : 0; idC = sEI[wave][e2]; meta = sEM[wave][e2]; }
+                else { const uint4 tail = store[(size_t) (c < ecnt ? e0 + c : e0) * EQ + (EQ - 1)]; idC = tail.y; meta = tail.w; }
+                const int lenC = (int) ((meta >> 8) & 0xFFFu);
+                const int p = q - (int) (meta & 255u);
+                const int rho_c = lenC - (lenA - p);
+                bool removed = false, used = false;
+                for (;;) {                                 // uniform
+                    wave_lds_fence();
+                    if (lane == gfirst) sMin[wave][lane] = 0xFFFFFFFFu;
+                    wave_lds_fence();
+                    if (V && !used) atomicMin(&sMin[wave][gfirst], ((uint32_t) p << 6) | (uint32_t) lane);
+                    wave_lds_fence();
+                    const uint32_t m = sMin[wave][gfirst];
+                    const bool hasB = act && m != 0xFFFFFFFFu;
+                    const int Bl = (int) (m & 63u), pB = (int) (m >> 6);
+                    used = used || (hasB && lane == Bl);
+                    const bool test = hasB && V && !removed && lane != Bl && p >= pB;
+                    if (__ballot(test) == 0ull) break;     // in no group is anybody left whom this or a later via (they all sit further right) could remove
+                    const uint32_t srcB = sSrc[wave][Bl];
+                    const int lenB = (int) sLen[wave][Bl];
+                    const uint32_t *rB = sA[wave][Bl];
+                    removed = removed || (test && via(srcB, lenB, pB, rB[0], rB[1], rB[2], rB[3], p, rho_c));
                 }
                 if (V && !removed) push(idC, p);
             }
-        } else {
-            // ---------------- big bucket: chunks of 64 descriptors, candidate masks of one target in LDS, via rows from global memory ----------------
-            const int nch = (D + 63) >> 6;
-            for (int cc2 = 0; cc2 < nch; cc2++) {
-                const int cnt = D - 64 * cc2 < 64 ? D - 64 * cc2 : 64;
-                if (lane < cnt) { const uint64_t i = gs + 64u * (uint64_t) cc2 + lane; small_top[3 * i] = 0ull; small_top[3 * i + 1] = 0ull; small_top[3 * i + 2] = 0ull; }
+            maybe_flush();
+            for (uint64_t wg = wide & starts; wg != 0ull; wg &= wg - 1ull) {      // uniform: the wide buckets of this pass, one by one
+                const int fl = __builtin_ctzll(wg);
+                const uint64_t after = fl >= 63 ? 0ull : starts & ~((2ull << fl) - 1ull);
+                const int nl = after ? __builtin_ctzll(after) : cnt;
+                big_group((uint64_t) s0 + (uint64_t) fl, nl - fl);
             }
-            for (uint32_t c = 0; c < ecnt; c++) {          // uniform
-                uint32_t ew[4 * EQ];
-                load_entry(e0 + c, ew);
-                const uint32_t meta = ew[4 * EQ - 1], idC = ew[4 * EQ - 3];
-                const int lenC = (int) ((meta >> 8) & 0xFFFu);
-                uint64_t any = 0ull;
-                for (int cc2 = 0; cc2 < nch; cc2++) {
-                    const int cnt = D - 64 * cc2 < 64 ? D - 64 * cc2 : 64;
-                    load_chunk(gs + 64u * (uint64_t) cc2, cnt);
-                    int p;
-                    const bool V = verify(ew, p);
-                    const uint64_t m = __ballot(V);
-                    if (lane == 0) sVM[wave][cc2] = m;
-                    any |= m;
-                    const int L = lenA - p;
-                    if (V && L < cfg.rsoemo) {
-                        const uint64_t i = gs + 64u * (uint64_t) cc2 + lane;
-                        uint64_t a = small_top[3 * i], b2 = small_top[3 * i + 1], c2 = small_top[3 * i + 2];
-                        top3_insert(a, b2, c2, ((uint64_t) (uint32_t) L << 32) | idC);
-                        small_top[3 * i] = a; small_top[3 * i + 1] = b2; small_top[3 * i + 2] = c2;
-                    }
-                }
-                wave_lds_fence();
-                if (any == 0ull) continue;
-                for (int cc2 = 0; cc2 < nch; cc2++) {      // candidate chunk
-                    const uint64_t cm = sVM[wave][cc2];
-                    if (cm == 0ull) continue;
-                    const int cnt = D - 64 * cc2 < 64 ? D - 64 * cc2 : 64;
-                    if (nch > 1 || cc2 != nch - 1) load_chunk(gs + 64u * (uint64_t) cc2, cnt);
-                    const bool V = ((cm >> lane) & 1ull) != 0ull;
-                    const int p = q - (int) (meta & 255u);
-                    const int rho_c = lenC - (lenA - p);
-                    bool removed = false;
-                    for (int bb = 0; bb < nch; bb++) {
-                        for (uint64_t bm = sVM[wave][bb]; bm != 0ull; bm &= bm - 1ull) {     // uniform: every via, in index order
-                            const int bl = __builtin_ctzll(bm);
-                            const bool test = V && !removed && !(bb == cc2 && bl == lane);
-                            if (__ballot(test) == 0ull) continue;
-                            const uint64_t bi = gs + 64u * (uint64_t) bb + (uint64_t) bl;
-                            const unsigned long long vB = dval[bi];
-                            const uint32_t srcB = (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) vB);
-                            const int pB = (int) ((uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) (vB >> 32)) & 255u) - (int) (meta & 255u);
-                            const int lenB = ulen > 0 ? ulen : __builtin_amdgcn_readfirstlane(nd.len[srcB]);
-                            const int nwB = blocks_of(lenB);
-                            const uint32_t *rb = nd.words + (size_t) srcB * nd.stride;
-                            uint32_t rowB[WC];
-#pragma unroll
-                            for (int k = 0; k < WC; k++) rowB[k] = (k < nwB && k < nd.stride) ? rb[k] : 0u;
-                            removed = removed || (test && p >= pB && via(srcB, lenB, pB, rowB, p, rho_c));
-                        }
-                    }
-                    if (V && !removed) push(idC, p);
-                    const int nb2 = (int) __builtin_amdgcn_readfirstlane((int) *w.recN);
-                    if (nb2 >= WFLUSH) flush_records<REC_CHUNK, WBUF>(o, w, chunk_base, chunk_fill);
-                }
-            }
-        }
-        wave_lds_fence();
-        const int nb2 = (int) __builtin_amdgcn_readfirstlane((int) *w.recN);
-        if (nb2 >= WFLUSH) flush_records<REC_CHUNK, WBUF>(o, w, chunk_base, chunk_fill);
-    };
-
-    const uint64_t n_tiles = (n_desc + 63) >> 6;
-    for (uint64_t tile = (uint64_t) blockIdx.x * SJ_WAVES + (uint64_t) wave; tile < n_tiles; tile += (uint64_t) gridDim.x * SJ_WAVES) {
-        const uint64_t i = tile * 64 + (uint64_t) lane;
-        const bool in = i < n_desc;
-        const uint32_t bcur = in ? dkey[i] >> shift : 0xFFFFFFFFu;
-        const uint32_t bprev = (in && i > 0) ? dkey[i - 1] >> shift : 0xFFFFFFFEu;
-        uint64_t starts = __ballot(in && bcur != bprev);
-        while (starts != 0ull) {                           // uniform: the groups that start in this tile
-            const int sl = __builtin_ctzll(starts);
-            starts &= starts - 1ull;
-            const uint32_t b = (uint32_t) __builtin_amdgcn_readlane((int) bcur, sl);
-            const uint64_t gs = tile * 64 + (uint64_t) sl;
-            int D;
-            if (starts != 0ull) D = __builtin_ctzll(starts) - sl;
-            else {
-                // to the end of the tile ... and on, while the bucket goes on
-                const uint64_t tile_end = (tile * 64 + 64 < n_desc) ? tile * 64 + 64 : n_desc;
-                D = (int) (tile_end - gs);
-                for (uint64_t j = tile_end; j < n_desc && D <= dmax; j += 64) {
-                    const bool same = j + lane < n_desc && (dkey[j + lane] >> shift) == b;
-                    const uint64_t m = __ballot(same);
-                    const int run = m == ~0ull ? 64 : __builtin_ctzll(~m);
-                    D += run;
-                    if (run < 64) break;
-                }
-            }
-            group(gs, D, b);
         }
     }
-    flush_records<REC_CHUNK, WBUF>(o, w, chunk_base, chunk_fill);
+    flush_records<REC_CHUNK, SJ_WB>(o, w, chunk_base, chunk_fill);
     close_chunk<REC_CHUNK>(o, chunk_base, chunk_fill);
     st_rec = wave_sum_u64(st_rec);
     if (lane == 0 && st_rec) atomicAdd(&o.counters[CNT_VALID_RECORDS], (unsigned long long) st_rec);
@@ -658,24 +746,37 @@ void launch_shard_export_flagged(const NodesDev &nd, const PrefSufCfg &cfg, cons
     hipLaunchKernelGGL(k_shard_export_flagged, dim3((n_flagged + 3) / 4), dim3(256), 0, s, nd, cfg, cc, flagged_list, n_flagged, bpr, n_ranks, seg_off, cursor, out);
 }
 
-void launch_shard_desc_split(const uint32_t *in, uint64_t n, uint32_t *dkey, unsigned long long *dval, hipStream_t s) {
+void launch_shard_desc_split(const uint32_t *in, uint64_t n, uint32_t key_base, uint32_t *dkey, unsigned long long *dval, hipStream_t s) {
     if (n == 0) return;
-    hipLaunchKernelGGL(k_shard_desc_split, dim3(grid_stride_blocks(n, 256)), dim3(256), 0, s, in, n, dkey, dval);
+    hipLaunchKernelGGL(k_shard_desc_split, dim3(grid_stride_blocks(n, 256)), dim3(256), 0, s, in, n, key_base, dkey, dval);
 }
 
-uint64_t shard_join_record_slack(int n_cu) { return (uint64_t) std::max(1, n_cu) * 6 * SJ_WAVES * (uint64_t) REC_CHUNK; }
+uint64_t shard_join_record_slack(int n_cu) { return (uint64_t) std::max(1, n_cu) * 8 * SJ_WAVES * (uint64_t) REC_CHUNK; }
+
+// flag / pos / gstart: n_desc + 2 uint32 each; scan_scratch: scan_scratch_bytes(n_desc + 1).  *n_groups_dev = pos[n_desc] afterwards.
+void launch_shard_groups(const uint32_t *dkey, uint64_t n_desc, int shift, uint32_t *flag, uint32_t *pos, uint32_t *gstart, uint64_t *scan_scratch, hipStream_t s) {
+    if (n_desc == 0) return;
+    hipLaunchKernelGGL(k_shard_group_flags, dim3(grid_stride_blocks(n_desc, 256)), dim3(256), 0, s, dkey, n_desc, shift, flag);
+    launch_exclusive_scan(flag, n_desc, pos, scan_scratch, s);
+    hipLaunchKernelGGL(k_shard_group_starts, dim3(grid_stride_blocks(n_desc + 1, 256)), dim3(256), 0, s, (const uint32_t *) flag, (const uint32_t *) pos, n_desc, gstart);
+}
 
 void launch_shard_join(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterCfg &cc, int eq, int uniform_len, const void *store, const void *dir, uint32_t bucket_base,
-                       const uint32_t *dkey, const unsigned long long *dval, uint64_t n_desc, uint32_t *rec_dst, unsigned long long *rec_val, uint64_t rec_cap,
-                       unsigned long long *counters, unsigned long long *small_top, unsigned long long *declined, int dmax, int n_cu, hipStream_t s) {
-    if (n_desc == 0) return;
-    const uint64_t tiles = (n_desc + 63) / 64;
-    dim3 grid((unsigned) std::max<uint64_t>(1, std::min<uint64_t>((tiles + SJ_WAVES - 1) / SJ_WAVES, (uint64_t) std::max(1, n_cu) * 6))), block(SJ_WAVES * 64);
+                       const uint32_t *dkey, const unsigned long long *dval, uint64_t n_desc, const uint32_t *gstart, uint32_t n_groups, uint32_t *rec_dst,
+                       unsigned long long *rec_val, uint64_t rec_cap, unsigned long long *counters, unsigned long long *small_top, unsigned long long *declined, int dmax, int n_cu,
+                       hipStream_t s) {
+    if (n_desc == 0 || n_groups == 0) return;
+    const uint64_t chunks = ((uint64_t) n_groups + SJ_GCH - 1) / SJ_GCH;
+    dim3 grid((unsigned) std::max<uint64_t>(1, std::min<uint64_t>((chunks + SJ_WAVES - 1) / SJ_WAVES, (uint64_t) std::max(1, n_cu) * 8))), block(SJ_WAVES * 64);
     ProbeOut o{rec_dst, rec_val, rec_cap, counters};
-#define SJ_LAUNCH(E) hipLaunchKernelGGL((k_shard_join<E>), grid, block, 0, s, nd, cfg, cc, uniform_len, (const uint4 *) store, (const uint4 *) dir, bucket_base, dkey, dval, n_desc, o, small_top, declined, std::max(1, std::min(dmax, SJ_DMAX)))
-    if (eq == 2)      SJ_LAUNCH(2);
-    else if (eq == 3) SJ_LAUNCH(3);
-    else              SJ_LAUNCH(4);
+    const int kf = (2 * cfg.Lmin) >> 5;
+#define SJ_LAUNCH(E, K) hipLaunchKernelGGL((k_shard_join<E, K>), grid, block, 0, s, nd, cfg, cc, uniform_len, (const uint4 *) store, (const uint4 *) dir, bucket_base, dkey, dval, n_desc, gstart, n_groups, o, small_top, declined, std::max(1, std::min(dmax, SJ_DMAX)))
+    if (eq == 3 && kf == 5)      SJ_LAUNCH(3, 5);
+    else if (eq == 3 && kf == 3) SJ_LAUNCH(3, 3);
+    else if (eq == 2 && kf == 3) SJ_LAUNCH(2, 3);
+    else if (eq == 2)            SJ_LAUNCH(2, 0);
+    else if (eq == 3)            SJ_LAUNCH(3, 0);
+    else                         SJ_LAUNCH(4, 0);
 #undef SJ_LAUNCH
 }
 

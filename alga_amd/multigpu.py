@@ -548,8 +548,11 @@ def validated_runner(backend, rank, world, dist, plain=None, **fast_kw):
     t = torch.tensor([ok], dtype=torch.int64, device=backend.device)
     dist.all_reduce(t)
     if int(t.item()) == world:
-        form = {"form": "%s, %d pieces per rank (edge transfers overlap the next piece's probe)" %
-                        ("keys of own nodes + in-place key all-gather" if fast.shard_keys else "all keys on every rank", fast.pieces),
+        what = "keys of own nodes + in-place key all-gather" if fast.shard_keys else "all keys on every rank"
+        if getattr(fast, "bucket_sharded", False):
+            what = "index sharded by seed bucket (%s)" % ("alga_shard_*: descriptors to the bucket's owner, per-target reduction there" if fast.form_used == "bucket_sharded"
+                                                          else "DECLINED by the engine: replicated form with the gathered keys")
+        form = {"form": "%s, %d pieces per rank (edge transfers overlap the next piece's probe)" % (what, fast.pieces),
                 "validated": "complete graph on rank 0 byte-identical (count + position-weighted checksum) to the plain form's in this run: %d edges" % m_plain}
         return fast, form
     form["validated"] = "sharded form NOT taken: " + (why or "another rank failed its check")

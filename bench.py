@@ -138,6 +138,9 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-sample-reads", type=int, default=1_000_000, help="reads of the workload the CPU baseline runs on (~10 s of the reference at 16 threads)")
     ap.add_argument("--probe", default="auto", choices=["auto", "table", "cluster"])
     ap.add_argument("--multi-plain", action="store_true", help="N > 1: time the driver's plainest form (no sharded key pass, no pieces)")
+    ap.add_argument("--multi-form", default="replicated", choices=["replicated", "bucket_sharded"],
+                    help="N > 1: replicated = every rank the whole index, its own source ids (default: the faster one by the one-GPU emulation, DESIGN.md section 7); "
+                         "bucket_sharded = the index sharded by seed bucket (alga_shard_*); either is timed only after it reproduced the plain form's graph in this run")
     return ap.parse_args(argv)
 
 
@@ -249,7 +252,8 @@ def run(args, rank, world, local_rank, dist, t_process=None):
     # plain form's complete graph on rank 0 byte for byte (count + position-weighted checksum); otherwise the plain form is timed.
     multi_form = None
     if world > 1 and not args.multi_plain:
-        runner, multi_form = multigpu.validated_runner(backend, rank, world, dist, plain=runner)
+        fast_kw = dict(bucket_sharded=True, pieces=1) if args.multi_form == "bucket_sharded" else {}
+        runner, multi_form = multigpu.validated_runner(backend, rank, world, dist, plain=runner, **fast_kw)
     elif world > 1:
         multi_form = {"form": "plain (all keys on every rank, one piece per rank)", "validated": "--multi-plain"}
 

@@ -300,8 +300,9 @@ typedef enum { ALGA_TRANSPORT_AUTO = 0, ALGA_TRANSPORT_RCCL = 1, ALGA_TRANSPORT_
  *                   (round 3: nothing but keys and edges travels, but the index build does not shrink with N);
  *   BUCKET_SHARDED  the index itself is sharded by seed bucket (alga_shard_* above): 1 / N of the entry array per rank, run descriptors
  *                   travel to the bucket's owner, the reduction is decided per target there, edges return to the source's owner;
- *   AUTO            BUCKET_SHARDED from three ranks on (at two, half an index costs less than the extra exchanges), REPLICATED below;
- *                   a build the sharded form declines (ALGA_ERR_UNSUPPORTED on any rank) continues in the replicated form. */
+ *   AUTO            = REPLICATED: measured per rank on one GPU at the north-star size (tools/emulate_shard.py, tools/emulate_rank.py), the
+ *                   sharded form costs a rank more device time than the replicated one up to eight ranks.
+ *   A build the sharded form declines (ALGA_ERR_UNSUPPORTED on any rank) continues in the replicated form. */
 typedef enum { ALGA_MULTI_FORM_AUTO = 0, ALGA_MULTI_FORM_REPLICATED = 1, ALGA_MULTI_FORM_BUCKET_SHARDED = 2 } alga_multi_form;
 typedef struct {
     int32_t  n_ranks, transport;          /* alga_transport actually used                                        */

@@ -60,8 +60,9 @@ class FakeDist:
         return self._Done() if async_op else None
 
     def isend(self, tensor, dst):
-        self._sync()
-        self.w.mail[(self.rank, dst)].put(tensor.detach().clone())
+        c = tensor.detach().clone()                          # the copy is enqueued on the sender's stream ...
+        self._sync()                                         # ... and complete before the receiver (another thread, another stream) may read it
+        self.w.mail[(self.rank, dst)].put(c)
         return self._Done()
 
     class _Recv:

@@ -514,6 +514,38 @@ def test_sharded_driver_with_hip_backend_three_ranks_one_gpu(lo, rs, replicate):
                 assert len(got) == 0
 
 
+@pytest.mark.parametrize("ranks,n,length,G,seed,err,lo,rs", [(3, 3000, 100, 6000, 52, 0.0, 55, 77), (2, 2500, 150, 6000, 53, 0.004, 82, 116), (3, 1500, 100, 30000, 54, 0.0, 55, 77)])
+def test_python_driver_bucket_sharded_form_thread_ranks_one_gpu(ranks, n, length, G, seed, err, lo, rs):
+    """alga_amd.multigpu.ShardedPrefSuf(bucket_sharded=True) as bench.py --gpus N --multi-form bucket_sharded drives it (real HipBackend,
+    device tensors; the collectives a thread rendezvous): the index sharded by seed bucket, five exchanges, == the oracle; the last case
+    at 5x coverage, where the per-source cap decides most edges (pending edges, small-key exchange)."""
+    import torch
+    from alga_amd.multigpu import HipBackend, ShardedPrefSuf
+    from fake_dist import run_ranks
+    words, lens = _nodes(n, length, G, seed, err=err, stride=16)
+    want, _, _ = O.prefsuf(words, lens, lo, rs)
+    dw = torch.from_numpy(words.view(np.int32)).cuda()
+    dl = torch.from_numpy(lens).cuda()
+
+    def rank_main(rank, dist):
+        e = alga_amd.Engine(0)
+        try:
+            run = ShardedPrefSuf(HipBackend(e, dw, dl, lo, rs), rank, ranks, dist, bucket_sharded=True)
+            m, st = run.step()
+            m2, _ = run.step()
+            torch.cuda.synchronize()
+            return m, m2, run.form_used, run.edges_numpy(), dict(run.exchange_bytes)
+        finally:
+            e.close()
+
+    res = run_ranks(ranks, rank_main)
+    for r, (m, m2, form, edges, xb) in enumerate(res):
+        assert m == len(want) and m2 == len(want) and form == "bucket_sharded"
+        assert set(xb) == {"descriptors", "pending", "small_keys", "edges"}
+        if r == 0:
+            assert edges.shape == want.shape and (edges == want).all()
+
+
 def test_sharded_driver_three_ranks_one_gpu_at_a_payload_that_can_race():
     """The same driver at 1 M reads (1.7 M nodes): key arrays of 7 MB, edge pieces of several MB per rank, four pieces per rank with
     their transfers outstanding while the next piece is probed -- the size at which the stream-ordering bug of round 2's rehearsal

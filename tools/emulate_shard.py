@@ -1,0 +1,135 @@
+#!/usr/bin/env python3
+"""The bucket-sharded N-GPU build (alga_shard_*) emulated on ONE GPU: N engines, one per rank, driven phase by phase in
+one thread -- rank after rank, so that every phase's device time is that rank's alone -- with the five exchanges done by slicing and
+concatenating the ranks' buffers (exactly the bytes RCCL would move, counted per rank).  The complete graph must equal the one-GPU
+graph edge for edge.  What comes out is what DESIGN.md section 7 prices: per-rank COMPUTE (device time of every phase, from the
+engine's own HIP events) and the VOLUME every exchange sends out of a rank; the link time itself cannot be measured on one GPU.
+  tools/emulate_shard.py [N=8] [n_reads=50000000] [genome=250000000] [steps=3] [err=0]"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+import alga_amd  # noqa: E402
+from alga_amd import multigpu, workload  # noqa: E402
+from alga_amd.engine import device_view  # noqa: E402
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+n_reads = int(sys.argv[2]) if len(sys.argv) > 2 else 50_000_000
+G = int(sys.argv[3]) if len(sys.argv) > 3 else 250_000_000
+steps = int(sys.argv[4]) if len(sys.argv) > 4 else 3
+err = float(sys.argv[5]) if len(sys.argv) > 5 else 0.0
+wl = workload.device_build(n_reads, 150, G, 11, err=err)
+torch.cuda.synchronize()
+dw, dl, lo, rs = wl["words"], wl["lens"], wl["min_overlap"], wl["rsoemo"]
+n = int(dl.shape[0])
+b = multigpu.shard_bounds(n, N)
+chunk = multigpu.shard_chunk(n, N)
+dev = dw.device
+out = {"world": N, "reads": n_reads, "nodes": n, "src_sha256": alga_amd.engine.source_fingerprint()}
+
+one = alga_amd.Engine(0)
+ptr, k1 = one.prefsuf_device(dw, dl, lo, rs)
+want = device_view(ptr, (k1, 3), dev).clone()
+out["one_gpu_ms"] = one.last_stats()["ms_total"]
+one.close()
+torch.cuda.synchronize()
+
+eng = [alga_amd.Engine(0) for _ in range(N)]
+
+
+def timed(fn):
+    """host wall clock between two device-wide syncs (the engine works on its own stream: torch events would not see it)"""
+    import time
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    r = fn()
+    torch.cuda.synchronize()
+    return r, (time.perf_counter() - t) * 1e3
+
+
+rows = []
+for it in range(steps + 1):
+    per = [dict() for _ in range(N)]
+    # ---- keys of the own nodes (stream 0 = the engine's own stream; every call below sits between two device-wide syncs) ----
+    st = 0
+    karr = []
+    for q in range(N):
+        (kq, per[q]["ms_keys"]) = timed(lambda q=q: eng[q].keys_device(dw, dl, lo, rs, b[q], b[q + 1], stream=st))
+        assert kq is not None
+        karr.append([device_view(p, (N * chunk,), dev) for p in kq])
+    # exchange 1: all-gather of the key array (4 B / node), in place
+    for q in range(N):
+        for p in range(N):
+            if p != q:
+                karr[q][0][b[p]:b[p + 1]] = karr[p][0][b[p]:b[p + 1]]
+    xb = {"keys": 4 * (b[1] - b[0]) * (N - 1)}
+    # ---- my slice of the index, my sources' descriptors by owner ----
+    idx = []
+    for q in range(N):
+        r, ms = timed(lambda q=q: eng[q].shard_index_device(dw, dl, lo, rs, q, N, stream=st))
+        assert r is not None
+        ptr, cnt, off = r
+        cap = max(o + c for o, c in zip(off, cnt))
+        idx.append((device_view(ptr, (cap, 3), dev), cnt, off))
+        per[q]["ms_index_export_wall"] = ms
+        s = eng[q].shard_stats()
+        per[q].update(ms_index=s["ms_index"], ms_export=s["ms_export"], targets_owned=s["targets_owned"], descriptors_out=s["descriptors_out"],
+                      flagged_sources=s["flagged_sources"])
+    # exchange 2: descriptors to the bucket's owner
+    recv = [torch.cat([idx[p][0][idx[p][2][q]:idx[p][2][q] + idx[p][1][q]] for p in range(N)], dim=0).contiguous() for q in range(N)]
+    xb["descriptors"] = 12 * (sum(idx[0][1]) - idx[0][1][0])
+    # ---- join ----
+    pend = []
+    for q in range(N):
+        r, ms = timed(lambda q=q: eng[q].shard_join_device(dw, dl, recv[q], int(recv[q].shape[0]), stream=st))
+        assert r is not None, "rank %d declined the join" % q
+        pend.append(device_view(r[0], (r[1],), dev).clone())
+        s = eng[q].shard_stats()
+        per[q].update(ms_sort=s["ms_sort"], ms_join=s["ms_join"], ms_join_wall=ms, descriptors_in=s["descriptors_in"], records=s["records"], pending=s["pending"])
+    pend_all = torch.cat(pend).contiguous()
+    xb["pending"] = 4 * int(pend[0].shape[0]) * (N - 1)
+    small = []
+    for q in range(N):
+        r, ms = timed(lambda q=q: eng[q].shard_small_keys_device(pend_all, int(pend_all.shape[0]), stream=st))
+        small.append(device_view(r[0], (r[1], 3), dev).clone())
+        per[q]["ms_small_keys_wall"] = ms
+    small_all = torch.cat(small, dim=0).contiguous()
+    xb["small_keys"] = 12 * int(small[0].shape[0]) * (N - 1)
+    eout = []
+    for q in range(N):
+        r, ms = timed(lambda q=q: eng[q].shard_resolve_device(small_all, int(small_all.shape[0]), N, stream=st))
+        eout.append((device_view(r[0], (sum(r[1]), 3), dev), r[1], r[2]))
+        s = eng[q].shard_stats()
+        per[q].update(ms_cap=s["ms_cap"], ms_edges_out=s["ms_edges_out"], ms_resolve_wall=ms, dropped=s["dropped"], edges_out=s["edges_out"])
+    xb["edges"] = 12 * (sum(eout[0][1]) - eout[0][1][0])
+    ein = [torch.cat([eout[p][0][eout[p][2][q]:eout[p][2][q] + eout[p][1][q]] for p in range(N)], dim=0).contiguous() for q in range(N)]
+    parts = []
+    for q in range(N):
+        r, ms = timed(lambda q=q: eng[q].shard_place_device(ein[q], int(ein[q].shape[0]), b[q], b[q + 1], stream=st))
+        parts.append(device_view(r[0], (r[1], 3), dev).clone())
+        per[q].update(ms_place=eng[q].shard_stats()["ms_place"], ms_place_wall=ms, edges=r[1])
+    xb["gather_to_rank0"] = 12 * int(parts[1].shape[0]) if N > 1 else 0
+    got = torch.cat(parts, dim=0)
+    assert got.shape == want.shape and bool(torch.equal(got, want)), "the sharded graph differs from the one-GPU graph"
+    if it:
+        rows.append((per, xb))
+    del recv, ein, parts, got, pend_all, small_all
+
+# averages over the timed steps, rank 0 and the last rank + the maximum over ranks of the per-rank compute
+keys = ["ms_keys", "ms_index", "ms_export", "ms_sort", "ms_join", "ms_cap", "ms_edges_out", "ms_place"]
+avg = [{k: sum(r[0][q][k] for r in rows) / len(rows) for k in keys} for q in range(N)]
+for q in range(N):
+    avg[q]["ms_compute"] = sum(avg[q][k] for k in keys)
+    for k in ("targets_owned", "descriptors_out", "descriptors_in", "flagged_sources", "records", "pending", "dropped", "edges_out", "edges"):
+        avg[q][k] = rows[-1][0][q][k]
+out["graph_equals_one_gpu"] = True
+out["edges"] = int(want.shape[0])
+out["rank0"], out["rank%d" % (N - 1)] = avg[0], avg[N - 1]
+out["ms_compute_max_over_ranks"] = max(a["ms_compute"] for a in avg)
+out["ms_compute_mean_over_ranks"] = sum(a["ms_compute"] for a in avg) / N
+out["exchange_bytes_out_of_rank0"] = rows[-1][1]
+print(json.dumps(out))
