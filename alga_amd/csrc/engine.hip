@@ -18,6 +18,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "engine_internal.h"
@@ -680,9 +681,21 @@ int alga_upload_nodes(alga_engine *e, const alga_nodes *nodes, alga_nodes *dev) 
     hipStream_t s = e->own_stream;
     int rc;
     const size_t n = (size_t) nodes->n;
-    {   // the caller's rows must hold the caller's reads (checked here: the upload below changes the stride)
+    {   // the caller's rows must hold the caller's reads (checked here: the upload below changes the stride).  90 M lengths are 0.36 GB:
+        // one core needs ~30 ms for the maximum, eight need four
         int32_t max_len = 0;
-        for (size_t i = 0; i < n; i++) max_len = std::max(max_len, nodes->len[i]);
+        const int T = n >= (1u << 22) ? 8 : 1;
+        if (T == 1) { for (size_t i = 0; i < n; i++) max_len = std::max(max_len, nodes->len[i]); }
+        else {
+            int32_t part[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            std::vector<std::thread> th;
+            auto job = [&](int t) { int32_t m = 0; for (size_t i = n * (size_t) t / T, z = n * (size_t) (t + 1) / T; i < z; i++) m = std::max(m, nodes->len[i]); part[t] = m; };
+            try { for (int t = 1; t < T; t++) th.emplace_back(job, t); } catch (...) { }
+            job(0);
+            for (size_t t = th.size() + 1; t < (size_t) T; t++) job((int) t);       // (threads that could not be started: their share here)
+            for (std::thread &x : th) x.join();
+            for (int t = 0; t < T; t++) max_len = std::max(max_len, part[t]);
+        }
         if ((int64_t) blocks_of(max_len) > (int64_t) nodes->stride_words)
             return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "stride_words is smaller than the longest read needs");
     }

@@ -480,7 +480,7 @@ class Engine:
                                                         C.byref(out), C.byref(m)))
         return out.value, int(m.value)
 
-    def keys_device(self, words, lens, min_overlap, rsoe_min_overlap, node_begin, node_end, align_from=None, align_to=None, stream=None):
+    def keys_device(self, words, lens, min_overlap, rsoe_min_overlap, node_begin, node_end, align_from=None, align_to=None, stream=None, want_meta_flag=False):
         """Minimizer keys + runs of the nodes [node_begin, node_end) -> (d_keys ptr, d_meta ptr) over all n nodes (this range
         filled; the caller all-gathers the rest in place), or None when the clustered probe does not take the input."""
         nd = self._nodes_from_torch(words, lens, align_from, align_to)
@@ -490,6 +490,8 @@ class Engine:
                                                        C.byref(out)))
         if not out.eligible:
             return None
+        if want_meta_flag:
+            return out.d_keys, out.d_meta, bool(out.meta_needed)
         return out.d_keys, out.d_meta
 
     def build_range_device(self, words, lens, min_overlap, rsoe_min_overlap, src_begin, src_end, align_from=None, align_to=None,

@@ -31,7 +31,9 @@ struct NodeArrays {
         const size_t n = reads.size();
         int max_len = 0;
         for (Read *r : reads) if (r != nullptr) max_len = std::max(max_len, r->size());
-        stride = std::max(4, (((2 * max_len + 31) / 32) + 3) & ~3);          // 16-byte aligned rows
+        // rows as tight as the Bitset itself (9 words for a 150-bp read): what crosses PCIe is this array, and the engine re-strides it to
+        // its own HBM layout on the device (alga_upload_nodes); 16-byte aligned rows (12 words) cost a third more upload for nothing
+        stride = std::max(1, (2 * max_len + 31) / 32);
         words.assign(n * (size_t) stride, 0u);
         len.assign(n, 0);
         const int T = std::max(1, Params::THREADS);

@@ -102,11 +102,14 @@ class HipBackend:
         """Minimizer keys of my node range -> the per-node arrays to all-gather (views of engine memory, `span` entries each, my
         range filled), or None when the clustered probe does not take this input."""
         from .engine import device_view
-        r = self.eng.keys_device(self.w, self.l, self.lo, self.rs, node_begin, node_end, stream=self._stream())
+        r = self.eng.keys_device(self.w, self.l, self.lo, self.rs, node_begin, node_end, stream=self._stream(), want_meta_flag=True)
         if r is None:
             return None
         assert span <= self.n + KEY_ARRAY_SLACK
-        return [device_view(p, (span,), self.device) for p in r]
+        d_keys, d_meta, meta_needed = r
+        # the meta array travels only when the build reads it (reads of different lengths, or an alignFrom mask): the same answer on every
+        # rank for the same node set -- half the key traffic for every BASELINE configuration (ADVICE round 3)
+        return [device_view(p, (span,), self.device) for p in ((d_keys, d_meta) if meta_needed else (d_keys,))]
 
     def build_range(self, src_begin, src_end, collect_stats=False, keys_shared=0):
         """Final edges of the sources in the range (tensor [m, 3]) or None when the source-side form is not exact here."""
@@ -230,16 +233,15 @@ class ShardedPrefSuf:
         karr = be.node_keys(b[r], b[r + 1], nr * chunk) if self.shard_keys else None
         if karr is not None:
             import torch
+            # In place: rank r's slice already sits at its position of the engine's (slack-padded) array, the other slices arrive next to
+            # it -- no staging tensors, no copy back.  Whether the backend takes aliased buffers is decided from the backend's NAME, the
+            # same on every rank -- never from an exception one rank might be alone in raising while its peers are already inside the
+            # collective: gloo gets one staging tensor, kept between steps.
+            in_place = getattr(dist, "get_backend", lambda: "nccl")() != "gloo"
             for t in karr:
-                # In place: rank r's slice already sits at its position of the engine's (slack-padded) array, the other slices arrive
-                # next to it -- no staging tensors, no copy back.  A backend that refuses aliased buffers (gloo) gets one staging
-                # tensor, kept between steps.
-                if not getattr(self, "_keys_in_place_refused", False):
-                    try:
-                        dist.all_gather_into_tensor(t[:nr * chunk], t[r * chunk:(r + 1) * chunk])
-                        continue
-                    except (RuntimeError, ValueError, TypeError):
-                        self._keys_in_place_refused = True
+                if in_place:
+                    dist.all_gather_into_tensor(t[:nr * chunk], t[r * chunk:(r + 1) * chunk])
+                    continue
                 full = getattr(self, "_keys_full", None)
                 if full is None or full.shape[0] != nr * chunk or full.dtype != t.dtype or full.device != t.device:
                     full = self._keys_full = torch.empty(nr * chunk, dtype=t.dtype, device=dev)
@@ -535,16 +537,14 @@ def validated_runner(backend, rank, world, dist, plain=None, **fast_kw):
     # sharded key pass wins (1.5 + 1.8 ms at four)
     kw = dict(shard_keys=world > 2, pieces=None)
     kw.update(fast_kw)
-    ok, why, fast, m_plain = 0, "", None, 0
-    try:
-        m_plain, d_plain = graph_digest(plain)
-        fast = ShardedPrefSuf(backend, rank, world, dist, **kw)
-        m_fast, d_fast = graph_digest(fast)
-        ok = int(m_plain == m_fast and d_plain == d_fast and d_plain[0] == m_plain)
-        if not ok:
-            why = "graphs differ: plain %s / %d edges, sharded %s / %d edges" % (d_plain, m_plain, d_fast, m_fast)
-    except (RuntimeError, ValueError, TypeError, AssertionError) as e:            # a refused collective: stay with the plain form
-        why = "%s: %s" % (type(e).__name__, e)
+    # No exception handling around the collectives: a rank that raised alone inside a step would leave its peers in a collective it
+    # never joins -- an error there ends the job (the process group's timeout sees to the peers).  Plain or fast is
+    # decided from the all-reduced comparison of the two digests alone.
+    fast = ShardedPrefSuf(backend, rank, world, dist, **kw)
+    m_plain, d_plain = graph_digest(plain)
+    m_fast, d_fast = graph_digest(fast)
+    ok = int(m_plain == m_fast and d_plain == d_fast and d_plain[0] == m_plain)
+    why = "" if ok else "graphs differ: plain %s / %d edges, sharded %s / %d edges" % (d_plain, m_plain, d_fast, m_fast)
     t = torch.tensor([ok], dtype=torch.int64, device=backend.device)
     dist.all_reduce(t)
     if int(t.item()) == world:

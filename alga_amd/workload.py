@@ -114,6 +114,31 @@ def write_fasta_fast(path, codes):
         f.write(rec.tobytes())
 
 
+def write_fasta_chunked(path, n, L, G, seed, chunk=1 << 20):
+    """n error-free reads of L nt over an iid genome of G nt straight to a FASTA file, a chunk of reads at a time (the 50 M-read
+    north-star file is 8 GB: never held in memory).  Same distribution as gen_reads.sample_reads, not the same draws."""
+    rng = np.random.default_rng(seed)
+    genome = rng.integers(0, 4, G, dtype=np.uint8)
+    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+    ar = np.arange(L)[None, :]
+    with open(path, "wb") as f:
+        for s0 in range(0, n, chunk):
+            m = min(chunk, n - s0)
+            st = rng.integers(0, G - L + 1, m)
+            codes = genome[st[:, None] + ar]
+            fl = rng.random(m) < 0.5
+            codes[fl] = (3 - codes[fl])[:, ::-1]
+            rec = np.empty((m, 12 + L + 1), dtype=np.uint8)          # ">" + 10 digits + "\n" + sequence + "\n"
+            rec[:, 0] = ord(">")
+            ids = np.arange(s0, s0 + m)
+            for k in range(10):
+                rec[:, 10 - k] = ord("0") + (ids // 10 ** k) % 10
+            rec[:, 11] = ord("\n")
+            rec[:, 12:12 + L] = lut[codes]
+            rec[:, 12 + L] = ord("\n")
+            f.write(rec.tobytes())
+
+
 def _mix64(x):
     """splitmix-style mixer on int64 tensors (wrapping arithmetic, logical shifts emulated)"""
     x = x * -7046029254386353131                           # 0x9E3779B97F4A7C15

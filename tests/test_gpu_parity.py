@@ -514,15 +514,16 @@ def test_sharded_driver_with_hip_backend_three_ranks_one_gpu(lo, rs, replicate):
                 assert len(got) == 0
 
 
-@pytest.mark.parametrize("ranks,n,length,G,seed,err,lo,rs", [(3, 3000, 100, 6000, 52, 0.0, 55, 77), (2, 2500, 150, 6000, 53, 0.004, 82, 116), (3, 1500, 100, 30000, 54, 0.0, 55, 77)])
-def test_python_driver_bucket_sharded_form_thread_ranks_one_gpu(ranks, n, length, G, seed, err, lo, rs):
+@pytest.mark.parametrize("ranks,n,length,G,seed,err,minlen,lo,rs", [(3, 3000, 100, 6000, 52, 0.0, None, 55, 77), (2, 2500, 144, 6000, 53, 0.004, 110, 82, 116),
+                                                                      (3, 1500, 100, 30000, 54, 0.0, None, 55, 77)])
+def test_python_driver_bucket_sharded_form_thread_ranks_one_gpu(ranks, n, length, G, seed, err, minlen, lo, rs):
     """alga_amd.multigpu.ShardedPrefSuf(bucket_sharded=True) as bench.py --gpus N --multi-form bucket_sharded drives it (real HipBackend,
     device tensors; the collectives a thread rendezvous): the index sharded by seed bucket, five exchanges, == the oracle; the last case
     at 5x coverage, where the per-source cap decides most edges (pending edges, small-key exchange)."""
     import torch
     from alga_amd.multigpu import HipBackend, ShardedPrefSuf
     from fake_dist import run_ranks
-    words, lens = _nodes(n, length, G, seed, err=err, stride=16)
+    words, lens = _nodes(n, length, G, seed, err, minlen, stride=16)      # (the second case: variable lengths + errors, the meta array travels too)
     want, _, _ = O.prefsuf(words, lens, lo, rs)
     dw = torch.from_numpy(words.view(np.int32)).cuda()
     dl = torch.from_numpy(lens).cuda()
