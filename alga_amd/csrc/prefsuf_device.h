@@ -384,7 +384,8 @@ __device__ __forceinline__ void local_reduce(const NodesDev &nd, const PrefSufCf
                 removed = via_ok<SW>(A, lenA, Lbig, Cj, mj, oj, C, d, rho, ov);
                 // Not removed by the nearest predecessor: if even the longest read placed there could not reach C with a big
                 // overlap, no earlier item can (they all start further left) and the item stands; anything else is undecided.
-                fail = !removed && (cfg.Lcap - 1) - (d - (int) (mj & 511u)) >= Lbig;
+                // (a lone predecessor that is no via settles it: nobody else sits before this item)
+                fail = !removed && offmask_count<SW>(below) >= 2 && (cfg.Lcap - 1) - (d - (int) (mj & 511u)) >= Lbig;
             }
             generic = __ballot(fail) != 0ull;
             if (!generic) {
