@@ -184,6 +184,7 @@ int alga_shard_join_device(alga_engine *e, const alga_nodes *nodes, const uint32
     uint64_t cap = std::max<uint64_t>(e->rec_cap_hint, 2 * e->sh.n_targets + n_desc / 4 + 4096) + slack;
     uint64_t n_rec = 0;
     bool done = false;
+    unsigned long long join_passes[2] = {0, 0};
     for (int attempt = 0; attempt < 4 && !done; attempt++) {
         if (cap >= (1ull << 32) - 16) return alga_fail(e, ALGA_ERR_CAPACITY, "more than 2^32 overlap records; shard the input");
         if ((rc = alga_ensure(e, e->rec_dst, cap * sizeof(uint32_t)))) return rc;
@@ -195,6 +196,7 @@ int alga_shard_join_device(alga_engine *e, const alga_nodes *nodes, const uint32
         if ((rc = alga_check_launch(e, "k_shard_join"))) return rc;
         HIP_TRY(e, hipMemcpyAsync(e->h_counters, cnt, CNT_TOTAL * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
         HIP_TRY(e, hipMemcpyAsync(e->h_counters + CNT_TOTAL, scnt + 3, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        HIP_TRY(e, hipMemcpyAsync(join_passes, scnt + 4, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
         HIP_TRY(e, hipStreamSynchronize(s));
         if (e->h_counters[CNT_TOTAL] != 0) return alga_fail(e, ALGA_ERR_UNSUPPORTED, "a bucket holds more run descriptors than the bucket-sharded join takes (repeat-rich input)");
         const uint64_t need = e->h_counters[CNT_RECORDS];
@@ -204,6 +206,7 @@ int alga_shard_join_device(alga_engine *e, const alga_nodes *nodes, const uint32
     if (!done) return alga_fail(e, ALGA_ERR_HIP, "record buffer kept overflowing");
     e->shard_stats.ms_join = t_join.stop();
     e->shard_stats.records = e->h_counters[CNT_VALID_RECORDS];
+    e->shard_stats.join_passes = join_passes[0]; e->shard_stats.join_passes_serial = join_passes[1];
     e->shard_stats.descriptors_in = n_desc;
     // ---- the sources of the pending (small) survivors ----
     const uint32_t pend_cap = (uint32_t) std::min<uint64_t>(e->shard_stats.records + 1, (1ull << 32) - 16);

@@ -264,6 +264,7 @@ k_shard_join(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, int ulen, const uint4 *
     __shared__ uint32_t sA[SJ_WAVES][64][SJ_QW];
     __shared__ uint32_t sSrc[SJ_WAVES][64], sLen[SJ_WAVES][64], sMin[SJ_WAVES][64];
     __shared__ uint32_t sEI[SJ_WAVES][SJ_ES], sEM[SJ_WAVES][SJ_ES];     // id / meta of the pass's entries, group by group
+    __shared__ uint32_t sTab[SJ_WAVES][SJ_ES];                          // ... and the first candidate (offset << 6 | lane) of each
     __shared__ unsigned long long sVM[SJ_WAVES][SJ_DMAX / 64];
     __shared__ uint32_t sRecC[SJ_WAVES][SJ_WB];
     __shared__ unsigned long long sRecV[SJ_WAVES][SJ_WB];
@@ -276,6 +277,7 @@ k_shard_join(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, int ulen, const uint4 *
     uint64_t chunk_base = 0;
     int chunk_fill = REC_CHUNK;
     uint64_t st_rec = 0;
+    uint32_t st_pass = 0, st_serial = 0;                   // uniform: passes of this wave, passes decided target by target
     const int fs = cc.idx_shift - CL_MBITS, shift = cc.idx_shift;
     const int Lbig = cfg.rsoemo > cfg.Lmin ? cfg.rsoemo : cfg.Lmin;
     const int kfull = KF ? KF : (2 * cfg.Lmin) >> 5;       // row words every overlap covers entirely
@@ -497,8 +499,49 @@ k_shard_join(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, int ulen, const uint4 *
             }
             if (act && ((wide >> gfirst) & 1ull) == 0ull) { small_top[3 * ((uint64_t) s0 + lane)] = k0; small_top[3 * ((uint64_t) s0 + lane) + 1] = k1; small_top[3 * ((uint64_t) s0 + lane) + 2] = k2; }
             wave_lds_fence();
-            // ---- pass 2: per target, the vias of each group by ascending offset ----
-            for (uint32_t c = 0; c < max_e; c++) {         // uniform
+            // ---- pass 2, all targets at once: every candidate against the FIRST via of its target (the candidate with the smallest offset: a
+            //      segmented minimum through one LDS word per target).  On error-free data that via removes every other candidate and itself
+            //      stands: one step per overlap a lane holds (~4) instead of two per entry of the longest bucket (~11).  Anything else -- a
+            //      candidate the first via does not remove (another one still might), two candidates at one offset, entries beyond the LDS
+            //      slots -- and the pass is decided target by target below instead; nothing has been pushed by then. ----
+            bool serial = __ballot(act && vmask != 0ull && ebase + 64 - (int) __builtin_clzll(vmask | 1ull) > SJ_ES) != 0ull;
+            if (!serial) {
+                const int total_e = (int) bperm((uint32_t) (ebase + (int) ecnt), 63 - (int) __builtin_clzll((long long) (starts | 1ull)));   // slots used: base + count of the last group
+                wave_lds_fence();
+                for (int k = lane; k < total_e && k < SJ_ES; k += 64) sTab[wave][k] = 0xFFFFFFFFu;
+                wave_lds_fence();
+                for (uint64_t m = vmask; m != 0ull; m &= m - 1ull) {           // per lane: its own overlaps
+                    const int es = ebase + (int) __builtin_ctzll(m);
+                    atomicMin(&sTab[wave][es], ((uint32_t) (q - (int) (sEM[wave][es] & 255u)) << 6) | (uint32_t) lane);
+                }
+                wave_lds_fence();
+                bool undecided = false;
+                uint64_t mine = 0ull;                                           // the targets whose first candidate this lane is
+                for (uint64_t m = vmask; m != 0ull; m &= m - 1ull) {
+                    const int c = (int) __builtin_ctzll(m), es = ebase + c;
+                    const uint32_t meta = sEM[wave][es], t = sTab[wave][es];
+                    const int p = q - (int) (meta & 255u), Bl = (int) (t & 63u), pB = (int) (t >> 6);
+                    if (Bl == lane) { mine |= 1ull << c; continue; }
+                    const int rho_c = (int) ((meta >> 8) & 0xFFFu) - (lenA - p);
+                    const uint32_t *rB = sA[wave][Bl];
+                    const bool removed = via(sSrc[wave][Bl], (int) sLen[wave][Bl], pB, rB[0], rB[1], rB[2], rB[3], p, rho_c);
+                    // Not removed by the first via.  Reads of ONE length: when even the first via's overlap with the target is small, every later
+                    // candidate's is smaller still -- there is no via at all and every candidate of the target stands (a coverage gap: the
+                    // pending small survivors).  Otherwise another via may still remove it: undecided.
+                    const bool none_big = ulen > 0 && ulen - pB < Lbig;
+                    if (!removed && none_big && p != pB) mine |= 1ull << c;
+                    undecided = undecided || (!removed && !none_big) || p == pB;
+                }
+                serial = __ballot(undecided) != 0ull;
+                st_pass++; st_serial += serial ? 1u : 0u;
+                if (!serial)
+                    for (uint64_t m = mine; m != 0ull; m &= m - 1ull) {
+                        const int es = ebase + (int) __builtin_ctzll(m);
+                        push(sEI[wave][es], q - (int) (sEM[wave][es] & 255u));
+                    }
+            }
+            // ---- pass 2, target by target: the vias of each group by ascending offset, until nobody is left whom a later one could remove ----
+            for (uint32_t c = 0; serial && c < max_e; c++) {         // uniform
                 const bool V = ((vmask >> c) & 1ull) != 0ull;
                 if (__ballot(V) == 0ull) continue;
                 uint32_t idC, meta;
@@ -541,6 +584,7 @@ k_shard_join(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, int ulen, const uint4 *
     close_chunk<REC_CHUNK>(o, chunk_base, chunk_fill);
     st_rec = wave_sum_u64(st_rec);
     if (lane == 0 && st_rec) atomicAdd(&o.counters[CNT_VALID_RECORDS], (unsigned long long) st_rec);
+    if (lane == 0 && st_pass) { atomicAdd(&declined[1], (unsigned long long) st_pass); atomicAdd(&declined[2], (unsigned long long) st_serial); }
 }
 
 // ------------------------------------------------------------------------------------------

@@ -119,7 +119,7 @@ class MultiStats(C.Structure):
 class ShardStats(C.Structure):
     """alga_shard_stats"""
     _fields_ = [(k, C.c_uint64) for k in ("targets_owned", "descriptors_out", "descriptors_in", "flagged_sources", "records", "pending", "pending_sources",
-                                          "small_keys_out", "small_keys_in", "dropped", "edges_out", "edges_in", "edges")] + \
+                                          "small_keys_out", "small_keys_in", "dropped", "edges_out", "edges_in", "edges", "join_passes", "join_passes_serial")] + \
                [(k, C.c_double) for k in ("ms_index", "ms_export", "ms_sort", "ms_join", "ms_cap", "ms_edges_out", "ms_place")]
 
     def as_dict(self):

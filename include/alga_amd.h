@@ -268,6 +268,7 @@ typedef struct {
     uint64_t targets_owned, descriptors_out, descriptors_in, flagged_sources;   /* index phase / join phase                          */
     uint64_t records, pending, pending_sources, small_keys_out, small_keys_in, dropped;
     uint64_t edges_out, edges_in, edges;
+    uint64_t join_passes, join_passes_serial;   /* wave passes of k_shard_join (whole buckets packed onto 64 lanes); those decided target by target */
     double   ms_index, ms_export, ms_sort, ms_join, ms_cap, ms_edges_out, ms_place;   /* device time of each phase (HIP events)  */
 } alga_shard_stats;
 /* desc_counts[q] descriptors for rank q start at descriptor desc_offsets[q] of *d_desc (3 x uint32 each) */

@@ -89,7 +89,8 @@ for it in range(steps + 1):
         assert r is not None, "rank %d declined the join" % q
         pend.append(device_view(r[0], (r[1],), dev).clone())
         s = eng[q].shard_stats()
-        per[q].update(ms_sort=s["ms_sort"], ms_join=s["ms_join"], ms_join_wall=ms, descriptors_in=s["descriptors_in"], records=s["records"], pending=s["pending"])
+        per[q].update(ms_sort=s["ms_sort"], ms_join=s["ms_join"], ms_join_wall=ms, descriptors_in=s["descriptors_in"], records=s["records"], pending=s["pending"],
+                      join_passes=s["join_passes"], join_passes_serial=s["join_passes_serial"])
     pend_all = torch.cat(pend).contiguous()
     xb["pending"] = 4 * int(pend[0].shape[0]) * (N - 1)
     small = []
@@ -124,7 +125,7 @@ keys = ["ms_keys", "ms_index", "ms_export", "ms_sort", "ms_join", "ms_cap", "ms_
 avg = [{k: sum(r[0][q][k] for r in rows) / len(rows) for k in keys} for q in range(N)]
 for q in range(N):
     avg[q]["ms_compute"] = sum(avg[q][k] for k in keys)
-    for k in ("targets_owned", "descriptors_out", "descriptors_in", "flagged_sources", "records", "pending", "dropped", "edges_out", "edges"):
+    for k in ("targets_owned", "descriptors_out", "descriptors_in", "flagged_sources", "records", "pending", "dropped", "edges_out", "edges", "join_passes", "join_passes_serial"):
         avg[q][k] = rows[-1][0][q][k]
 out["graph_equals_one_gpu"] = True
 out["edges"] = int(want.shape[0])
