@@ -96,7 +96,11 @@ int prepare(alga_engine *e, const alga_nodes *nodes, const alga_prefsuf_params *
     // rows of up to 13 words; AUTO uses it whenever it takes the input (measured faster than the seed-table probe from 1.7 M
     // nodes, where everything is cache-resident, to 90 M: DESIGN.md section 5c).
     out.cluster_eq = 0;
-    if (out.local_ok && out.local_sw == 1 && e->opt_probe != ALGA_PROBE_TABLE) {
+    // (wide inputs -- more than 64 suffix windows or rows of more than 13 words: 250-bp reads -- go through the clustered probe's general
+    // kernel alone; while table and rows fit the caches the seed-table probe is faster there: 3.4 against 3.8 ms at 1.8 M nodes, 19.8 against
+    // 15.7 ms at 7.2 M (tools/forms_compare.py ... 250): AUTO takes the clustered probe for them from 4 M live nodes on)
+    const bool wide = out.local_sw == 2 || blocks_of(out.max_len) > 13;
+    if (out.local_ok && e->opt_probe != ALGA_PROBE_TABLE && !(wide && e->opt_probe == ALGA_PROBE_AUTO && out.live < (4ull << 20))) {
         int eq = 0;
         if (cluster_plan(c, out.max_len, out.live, e->opt_cluster_bucket_bias, &out.cluster, &eq)) out.cluster_eq = eq;
     }
@@ -213,7 +217,7 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
         if ((rc = alga_ensure(e, e->rec_val, cap * sizeof(unsigned long long)))) return rc;
         HIP_TRY(e, hipMemsetAsync(cnt, 0, CNT_TOTAL * sizeof(unsigned long long), s));
         ProbeBig big{(int32_t *) e->loc_big_list.p, big_list_cap, 0u, nullptr, 0u};
-        e->defer_list_valid = clustered && e->opt_cluster_pairs;           // k_probe_stream first: every source with records is on cl_defer (finalize_local)
+        e->defer_list_valid = clustered && e->opt_cluster_pairs && pp.local_sw == 1 && pp.cluster_eq <= 4;           // k_probe_stream first: every source with records is on cl_defer (finalize_local)
         if (clustered) {
             // Two kernels: k_probe_stream (the entries of consecutive sources packed densely onto the lanes) finishes the regular sources
             // and lists the others; the general kernel (one source per wave, any shape) takes the list.  No host round trip in between:
@@ -221,7 +225,7 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
             // kernel left.  Data on which most sources are irregular (sequencing errors: several items per offset): the waves of the
             // first kernel notice it on their own first sources and hand the rest of their share on unseen -- a decision taken from
             // THIS build's data, not from an earlier build.
-            if (e->opt_cluster_pairs) {
+            if (e->opt_cluster_pairs && pp.local_sw == 1 && pp.cluster_eq <= 4) {      // (k_probe_stream: one-word offset masks, rows of up to 13 words)
                 if ((rc = alga_ensure(e, e->cl_defer, (size_t) (n_src + 64) * sizeof(int32_t)))) return rc;
                 if ((rc = alga_ensure(e, e->loc_second, (size_t) (n_src + 1) * sizeof(unsigned long long)))) return rc;
                 e->loc_second_used = true;
@@ -236,11 +240,11 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
                 e->pairs_timed = true;
                 launch_probe_clustered(nd, cfg, cc, pp.cluster_eq, e->cl_store.p, e->cl_dir.p, e->cl_runs.p, (const uint8_t *) e->cl_nruns.p, 0,
                                        (int32_t) n_src, (const int32_t *) e->cl_defer.p, src_begin, (uint32_t *) e->rec_dst.p, (unsigned long long *) e->rec_val.p,
-                                       cap, cnt, e->n_cu, (uint32_t *) e->outdeg.p, (unsigned long long *) e->loc_first.p, &big, cnt + CNT_DEFERRED, s);
+                                       cap, cnt, e->n_cu, (uint32_t *) e->outdeg.p, (unsigned long long *) e->loc_first.p, &big, cnt + CNT_DEFERRED, 1, s);
             } else {
                 launch_probe_clustered(nd, cfg, cc, pp.cluster_eq, e->cl_store.p, e->cl_dir.p, e->cl_runs.p, (const uint8_t *) e->cl_nruns.p, src_begin,
                                        src_end, nullptr, src_begin, (uint32_t *) e->rec_dst.p, (unsigned long long *) e->rec_val.p, cap, cnt, e->n_cu,
-                                       (uint32_t *) e->outdeg.p, (unsigned long long *) e->loc_first.p, &big, nullptr, s);
+                                       (uint32_t *) e->outdeg.p, (unsigned long long *) e->loc_first.p, &big, nullptr, pp.local_sw, s);
             }
         }
         else
@@ -292,7 +296,7 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
             e->stats.slots_scanned = e->h_counters[CNT_SLOTS];
             e->stats.probe_rounds = e->h_counters[CNT_ROUNDS];
             e->stats.probe_used = clustered ? ALGA_PROBE_CLUSTER : ALGA_PROBE_TABLE;
-            if (clustered) e->stats.deferred_sources = e->opt_cluster_pairs ? e->h_counters[CNT_DEFERRED] : n_src;
+            if (clustered) e->stats.deferred_sources = e->defer_list_valid ? e->h_counters[CNT_DEFERRED] : n_src;
             return ALGA_OK;
         }
         cap = need + need / 16 + 4096 + slack; // the cursor kept counting past the capacity: the need is known
@@ -552,13 +556,15 @@ int alga_engine_reserve(alga_engine *e, int32_t n_nodes, int32_t max_len, int32_
     pp.cfg.Lmin = min_overlap; pp.cfg.Lcap = std::min(max_len, 500) + 1; pp.cfg.rsoemo = min_overlap; pp.cfg.soes = 3;
     int eq = 0;
     const bool local = max_len <= 500 && max_len - min_overlap <= LOCAL_MAX_SPAN;
-    const bool clustered = local && max_len - min_overlap <= 63 && e->opt_probe != ALGA_PROBE_TABLE &&
+    const bool clustered = local && e->opt_probe != ALGA_PROBE_TABLE &&
                            cluster_plan(pp.cfg, max_len, n, e->opt_cluster_bucket_bias, &pp.cluster, &eq);
     if (clustered) {
         pp.cluster_eq = eq;
         if ((rc = cluster_alloc(e, pp))) return rc;
-        if ((rc = alga_ensure(e, e->cl_defer, (size_t) (n + 64) * sizeof(int32_t)))) return rc;
-        if ((rc = alga_ensure(e, e->loc_second, (size_t) (n + 1) * sizeof(unsigned long long)))) return rc;
+        if (max_len - min_overlap <= 63 && eq <= 4) {
+            if ((rc = alga_ensure(e, e->cl_defer, (size_t) (n + 64) * sizeof(int32_t)))) return rc;
+            if ((rc = alga_ensure(e, e->loc_second, (size_t) (n + 1) * sizeof(unsigned long long)))) return rc;
+        }
     } else {
         const uint32_t nb = seed_buckets_for(n, e->seed_fill_x10);
         if ((rc = alga_ensure(e, e->table, (size_t) nb * SEED_BUCKET * sizeof(unsigned long long)))) return rc;

@@ -64,8 +64,8 @@ int alga_shard_index_device(alga_engine *e, const alga_nodes *nodes, const alga_
         if (rc) return rc;
         e->keyed_n = kn;
     }
-    if (!pp.local_ok || pp.cluster_eq == 0 || pp.reduction == ALGA_REDUCTION_PER_TARGET)
-        return alga_fail(e, ALGA_ERR_UNSUPPORTED, "the bucket-sharded form takes what the clustered probe takes (reads up to 208 nt, max_len - min_overlap <= 63, source-side preconditions)");
+    if (!pp.local_ok || pp.cluster_eq == 0 || pp.cluster_eq > 4 || pp.local_sw != 1 || pp.reduction == ALGA_REDUCTION_PER_TARGET)
+        return alga_fail(e, ALGA_ERR_UNSUPPORTED, "the bucket-sharded form takes reads of up to 208 nt with max_len - min_overlap <= 63 (one-word offset masks) and the source-side preconditions");
     memset(&e->shard_stats, 0, sizeof(e->shard_stats));
     const ClusterCfg cc = pp.cluster;
     const uint32_t n = (uint32_t) nodes->n;

@@ -56,7 +56,11 @@ constexpr int NR_STACK = 8;          // minimum records kept per node and block 
 // window without a class-0 k-mer, more than CL_RMAX runs or more records than a stack holds -- k_probe_clustered finds such a
 // source's window minimizers by brute force over all k-mers, 1 source in ~10^3).
 // TKW = row words staged per node: the row (<= TKW - 2 words) + the two words a k-mer read may run past it; odd: conflict-free.
-template <int TKW>
+// WIDE: nodes with up to 128 suffix windows (reads of up to ~270 nt at the reference's default scale: the two-word form of the source-side
+// reduction).  The window minimum by two blocks needs nwin <= w <= 64, so the windows are taken in two halves of up to 64 -- [64, nwin) on
+// the k-mers from position 64 on, then [0, 64) -- each by the very same three steps on the row shifted by 64 nucleotides (four words), and
+// the runs of both halves are listed one after the other (a minimizer that spans the seam makes two runs: one more look-up, same overlaps).
+template <int TKW, bool WIDE>
 __global__ void __launch_bounds__(TK_ROWS) k_node_runs(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, int node_begin, int node_end,
                                                         uint32_t *__restrict__ keys, uint32_t *__restrict__ vals, uint32_t *__restrict__ meta,
                                                         uint2 *__restrict__ runs, uint8_t *__restrict__ nruns) {
@@ -68,13 +72,9 @@ __global__ void __launch_bounds__(TK_ROWS) k_node_runs(NodesDev nd, PrefSufCfg c
     constexpr int S0 = NR_STACK + 1;                       // first row of block 0's records
     const int base = node_begin + blockIdx.x * TK_ROWS;     // the nodes node_begin .. node_end - 1 (a rank's share, or all of them)
     const int nrows = min(TK_ROWS, node_end - base);
-    {
-        const int c = (int) (threadIdx.x & 15u);
-        if (c < TKW)
-            for (int r = (int) (threadIdx.x >> 4); r < nrows; r += TK_ROWS / 16)
-                s[r][c] = c < nd.stride ? nd.words[(size_t) (base + r) * nd.stride + c] : 0u;
-        if (TKW > 16) for (int r = (int) threadIdx.x; r < nrows; r += TK_ROWS) s[r][16] = 0u;
-    }
+    for (int c = (int) (threadIdx.x & 15u); c < TKW; c += 16)
+        for (int r = (int) (threadIdx.x >> 4); r < nrows; r += TK_ROWS / 16)
+            s[r][c] = c < nd.stride ? nd.words[(size_t) (base + r) * nd.stride + c] : 0u;
     __syncthreads();
     const int t = (int) threadIdx.x;
     const bool in = t < nrows;
@@ -85,93 +85,101 @@ __global__ void __launch_bounds__(TK_ROWS) k_node_runs(NodesDev nd, PrefSufCfg c
     const bool is_src = act && (!nd.from || nd.from[i]);
     const uint32_t *row = s[in ? t : 0];
     const int w = cc.w;
-    const int nwin = len - cfg.Lmin + 1;                   // <= 64 (one-word form of the source-side reduction)
-    const int nk = act ? len - cc.kk + 1 : 0;              // = nwin - 1 + w <= 127
-    // ---- class-0 k-mer positions: bit p of the 128-bit mask (static row indices: registers, no scratch) ----
-    uint64_t m_lo, m_hi;
-    {
-        uint32_t dm[4];
-#pragma unroll
-        for (int d = 0; d < 4; d++) {
-            const uint32_t x0 = row[2 * d], x1 = row[2 * d + 1], x2 = row[2 * d + 2];
-            dm[d] = compress_even(class0_mask16(x0, x1)) | (compress_even(class0_mask16(x1, x2)) << 16);
-        }
-        m_lo = (uint64_t) dm[0] | ((uint64_t) dm[1] << 32);
-        m_hi = (uint64_t) dm[2] | ((uint64_t) dm[3] << 32);
-        m_lo &= nk >= 64 ? ~0ull : ((1ull << nk) - 1ull);              // positions below nk only (0 for a node that takes no part)
-        m_hi &= nk <= 64 ? 0ull : ((1ull << (nk - 64)) - 1ull);
-    }
-    uint64_t b0 = w >= 64 ? m_lo : (m_lo & ((1ull << w) - 1ull));
-    uint64_t b1 = w >= 64 ? m_hi : ((m_lo >> w) | (m_hi << (64 - w)));    // uniform branch; bit e = k-mer w + e
-    auto key_at = [&](int pos) -> uint32_t {               // order key of the class-0 k-mer at `pos`
-        const int bit = 2 * pos, q = bit >> 5, r = bit & 31;
-        const uint32_t x0 = row[q], x1 = row[q + 1], x2 = row[q + 2];
-        return order_key0(kmer_hash(funnel(x0, x1, r) & cc.lo_mask, funnel(x1, x2, r) & cc.hi_mask), pos);
-    };
-    // ---- (1) block 1, left to right: prefix-minimum records ----
-    uint32_t cur1 = 0xFFFFFFFFu;
-    int sp1 = 0;
-    while (b1 != 0ull) {
-        const int e = __builtin_ctzll(b1);
-        b1 &= b1 - 1ull;
-        const uint32_t pk = key_at(w + e);
-        // no branch: a lane that does not push writes the spare row
-        const bool push = pk < cur1;
-        stk[(push && sp1 < NR_STACK) ? sp1 : NR_STACK][t] = pk;
-        cur1 = push ? pk : cur1;
-        sp1 += push ? 1 : 0;
-    }
-    // ---- (2) block 0, right to left: suffix-minimum records ----
-    uint32_t cur0 = 0xFFFFFFFFu;
-    int sp0 = 0;
-    while (b0 != 0ull) {
-        const int e = 63 - __builtin_clzll(b0);
-        b0 ^= 1ull << e;
-        const uint32_t pk = key_at(e);
-        const bool push = pk < cur0;
-        stk[S0 + ((push && sp0 < NR_STACK) ? sp0 : NR_STACK)][t] = pk;
-        cur0 = push ? pk : cur0;
-        sp0 += push ? 1 : 0;
-    }
-    const bool stack_ovf = sp1 > NR_STACK || sp0 > NR_STACK;
-    sp1 = sp1 > NR_STACK ? NR_STACK : sp1;
-    sp0 = sp0 > NR_STACK ? NR_STACK : sp0;
-    // ---- (3) the windows, last to first: merge of the two record lists ----
+    const int nwin = len - cfg.Lmin + 1;                   // <= 64 (one-word form of the source-side reduction); <= 128 with WIDE
     int nr = 0;
     bool uncovered = false;                                // some window holds no class-0 k-mer
-    {
-        uint32_t top = sp1 > 0 ? stk[sp1 - 1][t] : 0xFFFFFFFFu;       // smallest record of block 1: in every window until it drops out
-        uint32_t nxt0 = stk[S0][t];                                   // next record of block 0 (if i0 < sp0)
-        uint32_t c0 = 0xFFFFFFFFu, win = top;
-        int i0 = 0, p_hi = nwin - 1;
-        int e0 = sp0 > 0 ? (int) (nxt0 & 255u) : -1;                  // the next block-0 record joins the windows p <= e0
-        int e1 = sp1 > 0 ? (int) (top & 255u) - w : -1;               // block 1's smallest record is in no window p <= e1
-        while ((e0 > e1 ? e0 : e1) >= 0) {
-            const int pe = e0 > e1 ? e0 : e1;
-            const bool take0 = e0 >= e1;
-            // ONE stack read serves either move: the record after the block-0 record that joins, or the one below block 1's top
-            const int row_i = take0 ? S0 + i0 + 1 : (sp1 >= 2 ? sp1 - 2 : NR_STACK);
-            const uint32_t v = stk[row_i][t];
-            i0 += take0 ? 1 : 0;
-            sp1 -= take0 ? 0 : 1;
-            c0 = take0 ? nxt0 : c0;
-            nxt0 = take0 ? v : nxt0;
-            top = take0 ? top : (sp1 >= 1 ? v : 0xFFFFFFFFu);
-            e0 = take0 ? (i0 < sp0 ? (int) (v & 255u) : -1) : e0;
-            e1 = take0 ? e1 : (sp1 >= 1 ? (int) (v & 255u) - w : -1);
-            const uint32_t wn = c0 < top ? c0 : top;
-            const int pc = pe < p_hi ? pe : p_hi;
-            const bool em = wn != win && pc < p_hi;         // the windows (pc, p_hi] had `win`
-            rbuf[(em && nr < CL_RMAX) ? nr : CL_RMAX][t] = (uint16_t) ((win & 255u) | ((uint32_t) (pc + 1) << 8));
-            uncovered = uncovered || (em && win == 0xFFFFFFFFu);
-            nr += em ? 1 : 0;
-            p_hi = em ? pc : p_hi;
-            win = wn;
+    bool stack_ovf = false;
+    uint32_t cur0 = 0xFFFFFFFFu;                           // minimum of block 0 of the FIRST half: the node's key as a target
+    for (int hb = (WIDE && nwin > 64) ? 64 : 0; hb >= 0; hb -= 64) {       // first window of the half (one pass with hb = 0 unless WIDE)
+        const uint32_t *rowh = row + (hb >> 4);
+        const int nwh = !WIDE ? nwin : (hb ? nwin - 64 : (nwin < 64 ? nwin : 64));
+        const int nk = act ? nwh - 1 + w : 0;              // k-mer positions of the half (relative to hb): <= 127
+        // ---- class-0 k-mer positions: bit p of the 128-bit mask (static row indices: registers, no scratch) ----
+        uint64_t m_lo, m_hi;
+        {
+            uint32_t dm[4];
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+                const uint32_t x0 = rowh[2 * d], x1 = rowh[2 * d + 1], x2 = rowh[2 * d + 2];
+                dm[d] = compress_even(class0_mask16(x0, x1)) | (compress_even(class0_mask16(x1, x2)) << 16);
+            }
+            m_lo = (uint64_t) dm[0] | ((uint64_t) dm[1] << 32);
+            m_hi = (uint64_t) dm[2] | ((uint64_t) dm[3] << 32);
+            m_lo &= nk >= 64 ? ~0ull : (nk <= 0 ? 0ull : ((1ull << nk) - 1ull));       // positions below nk only (0 for a node that takes no part)
+            m_hi &= nk <= 64 ? 0ull : ((1ull << (nk - 64)) - 1ull);
         }
-        if (act) {                                         // the run of window 0
-            if (nr < CL_RMAX) rbuf[nr][t] = (uint16_t) (win & 255u);
-            uncovered = uncovered || win == 0xFFFFFFFFu;
-            nr++;
+        uint64_t b0 = w >= 64 ? m_lo : (m_lo & ((1ull << w) - 1ull));
+        uint64_t b1 = w >= 64 ? m_hi : ((m_lo >> w) | (m_hi << (64 - w)));    // uniform branch; bit e = k-mer w + e
+        auto key_at = [&](int pos) -> uint32_t {           // order key of the class-0 k-mer at `pos` (relative to the half)
+            const int bit = 2 * pos, q = bit >> 5, r = bit & 31;
+            const uint32_t x0 = rowh[q], x1 = rowh[q + 1], x2 = rowh[q + 2];
+            return order_key0(kmer_hash(funnel(x0, x1, r) & cc.lo_mask, funnel(x1, x2, r) & cc.hi_mask), pos);
+        };
+        // ---- (1) block 1, left to right: prefix-minimum records ----
+        uint32_t cur1 = 0xFFFFFFFFu;
+        int sp1 = 0;
+        while (b1 != 0ull) {
+            const int e = __builtin_ctzll(b1);
+            b1 &= b1 - 1ull;
+            const uint32_t pk = key_at(w + e);
+            // no branch: a lane that does not push writes the spare row
+            const bool push = pk < cur1;
+            stk[(push && sp1 < NR_STACK) ? sp1 : NR_STACK][t] = pk;
+            cur1 = push ? pk : cur1;
+            sp1 += push ? 1 : 0;
+        }
+        // ---- (2) block 0, right to left: suffix-minimum records ----
+        uint32_t cur0h = 0xFFFFFFFFu;
+        int sp0 = 0;
+        while (b0 != 0ull) {
+            const int e = 63 - __builtin_clzll(b0);
+            b0 ^= 1ull << e;
+            const uint32_t pk = key_at(e);
+            const bool push = pk < cur0h;
+            stk[S0 + ((push && sp0 < NR_STACK) ? sp0 : NR_STACK)][t] = pk;
+            cur0h = push ? pk : cur0h;
+            sp0 += push ? 1 : 0;
+        }
+        if (hb == 0) cur0 = cur0h;
+        stack_ovf = stack_ovf || sp1 > NR_STACK || sp0 > NR_STACK;
+        sp1 = sp1 > NR_STACK ? NR_STACK : sp1;
+        sp0 = sp0 > NR_STACK ? NR_STACK : sp0;
+        // ---- (3) the windows of the half, last to first: merge of the two record lists ----
+        {
+            const uint32_t hq = (uint32_t) hb | ((uint32_t) hb << 8);     // what makes q and p0 of a run absolute
+            uint32_t top = sp1 > 0 ? stk[sp1 - 1][t] : 0xFFFFFFFFu;       // smallest record of block 1: in every window until it drops out
+            uint32_t nxt0 = stk[S0][t];                                   // next record of block 0 (if i0 < sp0)
+            uint32_t c0 = 0xFFFFFFFFu, win = top;
+            int i0 = 0, p_hi = nwh - 1;
+            int e0 = sp0 > 0 ? (int) (nxt0 & 255u) : -1;                  // the next block-0 record joins the windows p <= e0
+            int e1 = sp1 > 0 ? (int) (top & 255u) - w : -1;               // block 1's smallest record is in no window p <= e1
+            while ((e0 > e1 ? e0 : e1) >= 0) {
+                const int pe = e0 > e1 ? e0 : e1;
+                const bool take0 = e0 >= e1;
+                // ONE stack read serves either move: the record after the block-0 record that joins, or the one below block 1's top
+                const int row_i = take0 ? S0 + i0 + 1 : (sp1 >= 2 ? sp1 - 2 : NR_STACK);
+                const uint32_t v = stk[row_i][t];
+                i0 += take0 ? 1 : 0;
+                sp1 -= take0 ? 0 : 1;
+                c0 = take0 ? nxt0 : c0;
+                nxt0 = take0 ? v : nxt0;
+                top = take0 ? top : (sp1 >= 1 ? v : 0xFFFFFFFFu);
+                e0 = take0 ? (i0 < sp0 ? (int) (v & 255u) : -1) : e0;
+                e1 = take0 ? e1 : (sp1 >= 1 ? (int) (v & 255u) - w : -1);
+                const uint32_t wn = c0 < top ? c0 : top;
+                const int pc = pe < p_hi ? pe : p_hi;
+                const bool em = wn != win && pc < p_hi;         // the windows (pc, p_hi] had `win`
+                rbuf[(em && nr < CL_RMAX) ? nr : CL_RMAX][t] = (uint16_t) (((win & 255u) | ((uint32_t) (pc + 1) << 8)) + hq);
+                uncovered = uncovered || (em && win == 0xFFFFFFFFu);
+                nr += em ? 1 : 0;
+                p_hi = em ? pc : p_hi;
+                win = wn;
+            }
+            if (act) {                                         // the run of the half's first window
+                if (nr < CL_RMAX) rbuf[nr][t] = (uint16_t) ((win & 255u) + hq);
+                uncovered = uncovered || win == 0xFFFFFFFFu;
+                nr++;
+            }
         }
     }
     const int fs = cc.idx_shift - CL_MBITS;
@@ -185,7 +193,7 @@ __global__ void __launch_bounds__(TK_ROWS) k_node_runs(NodesDev nd, PrefSufCfg c
                 const uint32_t d = rbuf[r][t];
                 const int q = (int) (d & 255u);
                 uint32_t h, pk;
-                kmer_key(row, q < 128 ? q : 0, true, cc, h, pk);
+                kmer_key(row, q < (WIDE ? 192 : 128) ? q : 0, true, cc, h, pk);
                 runs[(size_t) i * CL_RMAX + r] = make_uint2(cluster_key(h, fs), d | ((uint32_t) p1 << 16) | (r == 0 ? nr_code << 24 : 0u));
                 p1 = (int) (d >> 8);
             }
@@ -359,8 +367,11 @@ __global__ void __launch_bounds__(TD_TILE) k_tgt_dir(const uint32_t *__restrict_
 // Two-stage software pipeline over the sources of a wave: while the entry loads of source i are in flight the wave stages the
 // row of source i+1 and issues the index loads of its runs; those land while source i is verified and reduced.  State of a
 // source between the stages: its staged row and its resolved run list in LDS (two buffers), a few uniform scalars.
-template <bool STATS, int EQ, int KF>
-__global__ void __launch_bounds__(PROBE_WAVES * 64, CL_OCC)
+// SW = 64-bit words of an offset mask / uint4 words of an overhang in the source-side reduction (prefsuf_device.h): 1 for sources of up to
+// 64 suffix windows, 2 for up to 128 (round 4: 250-bp reads; the items then always go through LDS and local_reduce<., ., 2>, their
+// overhangs are read from the target's row, and a flagged source's windows are taken 64 at a time).
+template <bool STATS, int EQ, int KF, int SW = 1>
+__global__ void __launch_bounds__(PROBE_WAVES * 64, SW == 1 && EQ <= 4 ? CL_OCC : 4)
 k_probe_clustered(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__restrict__ store, const uint4 *__restrict__ dir,
                   const uint2 *__restrict__ runs, const uint8_t *__restrict__ nruns, int32_t src_begin, int32_t src_end, ProbeOut o,
                   const int32_t *__restrict__ src_list /* null: the sources are the ids src_begin .. src_end - 1; else src_list[src_begin .. src_end - 1] */,
@@ -377,8 +388,8 @@ k_probe_clustered(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__res
     __shared__ uint32_t sCnt[PROBE_WAVES][3];
     __shared__ uint32_t sItemC[PROBE_WAVES][ITEMMAX];
     __shared__ uint32_t sItemM[PROBE_WAVES][ITEMMAX];
-    __shared__ uint4 sItemO[PROBE_WAVES][ITEMMAX];
-    __shared__ uint8_t sItemT[PROBE_WAVES][64];
+    __shared__ uint4 sItemO[PROBE_WAVES][ITEMMAX * SW];
+    __shared__ uint8_t sItemT[PROBE_WAVES][64 * SW];
     __shared__ uint4 sMask[KF > 0 ? 129 : 1];              // sMask[t] = masks of four consecutive words whose first holds t valid bits
     const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));      // scalar: the source stream below is wave-uniform
     const int lane = lane_id();
@@ -551,14 +562,18 @@ k_probe_clustered(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__res
                     v_o = make_uint4(funnel(x[0], x[1], r2), funnel(x[1], x[2], r2), funnel(x[2], x[3], r2), funnel(x[3], x[4], r2));
                     if (to_lds) {
                         const int slot = n_items + (int) __builtin_amdgcn_mbcnt_hi((uint32_t) (pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) pm, 0u));
-                        if (slot < ITEMMAX) { it.C[slot] = id; it.M[slot] = v_m; it.O[slot] = v_o; }
+                        if (slot < ITEMMAX) {
+                            it.C[slot] = id; it.M[slot] = v_m;
+                            if constexpr (SW == 1) it.O[slot] = v_o;
+                            else item_overhang_global<SW>(nd, it, ITEMMAX, slot, (int) id, L, lenC);      // up to 127 nt: from C's own row
+                        }
                     }
                 }
                 if (to_lds) n_items += __popcll(pm);
             }
         };
         // every entry of the source in this batch, run list complete: the items can stay in registers
-        const bool one_batch = !flagged && mc <= (1u << gs);
+        const bool one_batch = SW == 1 && !flagged && mc <= (1u << gs);
         verify(!one_batch);                                // the first batch, peeled: its wait covers the entry loads only
         bool reduced = false;
         if (one_batch) {
@@ -621,39 +636,43 @@ k_probe_clustered(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__res
         if (flagged) {
             // ---- slow path (one source in ~10^4): more runs than k_node_runs stores.  Window minimizers by brute force (lane p
             // scans the w k-mers of window p), runs by ballot, eight runs at a time through the same run list and verify(). ----
-            uint32_t wm = 0xFFFFFFFFu;
-            for (int k = 0; k < cc.w; k++) {               // uniform
-                uint32_t h, pk;
-                kmer_key(sb, (lane < nwin ? lane : 0) + k, true, cc, h, pk);
-                wm = pk < wm ? pk : wm;
-            }
-            const bool wv = lane < nwin;
-            const uint32_t prev = bperm(wm, (lane + 63) & 63);
-            const bool start = wv && (lane == 0 || wm != prev);
-            const uint64_t runmask = __ballot(start);
-            const int nrun_all = __popcll(runmask);
-            const uint64_t higher = lane >= 63 ? 0ull : runmask & ~((2ull << lane) - 1ull);
-            const int p1 = higher ? __builtin_ctzll(higher) : nwin;
-            const int rank = (int) __builtin_amdgcn_mbcnt_hi((uint32_t) (runmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) runmask, 0u));
-            uint32_t key = 0u;
-            { uint32_t h, pk; kmer_key(sb, (int) (wm & 255u) < 128 ? (int) (wm & 255u) : 0, true, cc, h, pk); key = cluster_key(h, cc.idx_shift - CL_MBITS); }
             gs = 3;
-            for (int rb = 0; rb < nrun_all; rb += CL_RMAX) {   // uniform
-                wave_lds_fence();
-                if (lane < CL_RMAX) sRun[wave][buf][lane] = make_uint4(0u, 0u, 0u, 0u);
-                wave_lds_fence();
-                uint32_t cnt = 0u;
-                if (start && rank >= rb && rank < rb + CL_RMAX) {
-                    const uint4 rec = dir[key >> cc.idx_shift];
-                    const uint32_t ry = (wm & 255u) | ((uint32_t) lane << 8) | ((uint32_t) p1 << 16);
-                    uint32_t e0;
-                    run_slice(rec, ry, e0, cnt);
-                    sRun[wave][buf][rank - rb] = make_uint4(ry, key, e0, cnt);
+            for (int wb = 0; wb < nwin; wb += 64) {        // uniform: the windows 64 at a time (one pass unless SW == 2)
+                const int wl = wb + lane;                  // this lane's window
+                const bool wv = wl < nwin;
+                uint32_t wm = 0xFFFFFFFFu;
+                for (int k = 0; k < cc.w; k++) {           // uniform
+                    uint32_t h, pk;
+                    kmer_key(sb, (wv ? wl : 0) + k, true, cc, h, pk);
+                    wm = pk < wm ? pk : wm;
                 }
-                wave_lds_fence();
-                const uint32_t mcs = (uint32_t) wave_max_u64_dpp((uint64_t) cnt);
-                load_runs(buf, gs, rp);
-                for (k0 = 0; k0 < mcs; k0 += 1u << gs) { load_entries(rp, k0, gs, ev, ei, ew); verify(true); }
+                const uint32_t prev = bperm(wm, (lane + 63) & 63);
+                const bool start = wv && (lane == 0 || wm != prev);         // (a minimizer that spans two passes makes two runs: one more look-up)
+                const uint64_t runmask = __ballot(start);
+                const int nrun_all = __popcll(runmask);
+                const uint64_t higher = lane >= 63 ? 0ull : runmask & ~((2ull << lane) - 1ull);
+                const int wend = nwin - wb < 64 ? nwin - wb : 64;           // windows of this pass
+                const int p1 = wb + (higher ? __builtin_ctzll(higher) : wend);
+                const int rank = (int) __builtin_amdgcn_mbcnt_hi((uint32_t) (runmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) runmask, 0u));
+                uint32_t key = 0u;
+                { uint32_t h, pk; kmer_key(sb, (int) (wm & 255u) < 192 ? (int) (wm & 255u) : 0, true, cc, h, pk); key = cluster_key(h, cc.idx_shift - CL_MBITS); }
+                for (int rb = 0; rb < nrun_all; rb += CL_RMAX) {   // uniform
+                    wave_lds_fence();
+                    if (lane < CL_RMAX) sRun[wave][buf][lane] = make_uint4(0u, 0u, 0u, 0u);
+                    wave_lds_fence();
+                    uint32_t cnt = 0u;
+                    if (start && rank >= rb && rank < rb + CL_RMAX) {
+                        const uint4 rec = dir[key >> cc.idx_shift];
+                        const uint32_t ry = (wm & 255u) | ((uint32_t) wl << 8) | ((uint32_t) p1 << 16);
+                        uint32_t e0;
+                        run_slice(rec, ry, e0, cnt);
+                        sRun[wave][buf][rank - rb] = make_uint4(ry, key, e0, cnt);
+                    }
+                    wave_lds_fence();
+                    const uint32_t mcs = (uint32_t) wave_max_u64_dpp((uint64_t) cnt);
+                    load_runs(buf, gs, rp);
+                    for (k0 = 0; k0 < mcs; k0 += 1u << gs) { load_entries(rp, k0, gs, ev, ei, ew); verify(true); }
+                }
             }
         }
         wave_lds_fence();
@@ -669,7 +688,7 @@ k_probe_clustered(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__res
                 if (STATS) { st_raw -= (uint64_t) n_items; st_win -= (uint64_t) nwin; }     // the second pass counts this source
             }
         } else if (n_items > 0 && !reduced) {
-            local_reduce<STATS, WBUF_LOCAL, 1>(nd, cfg, it, w, o, B, lenB, n_items, st_rec, st_cmp, st_generic);
+            local_reduce<STATS, WBUF_LOCAL, SW>(nd, cfg, it, w, o, B, lenB, n_items, st_rec, st_cmp, st_generic);
         }
         const int nb2 = (int) __builtin_amdgcn_readfirstlane((int) *w.recN);
         if (nb2 >= WFLUSH_LOCAL) flush_records<REC_CHUNK_LOCAL, WBUF_LOCAL>(o, w, chunk_base, chunk_fill);
@@ -1170,12 +1189,18 @@ bool cluster_plan(const PrefSufCfg &cfg, int max_len, uint64_t live, int bucket_
     int e = (W + 3 + 3) / 4;
     if (e < 2) e = 2;
     const int nwin = max_len - cfg.Lmin + 1;
-    if (e > CL_MAX_EQ || nwin < 1 || nwin > 64) return false;
-    int kk = std::max(cfg.Lmin - 63, std::min(cfg.Lmin, CL_KMIN));
-    if (nwin > cfg.Lmin - kk + 1) kk = 2 * cfg.Lmin - max_len;
+    // up to 128 suffix windows: 64 take the one-word form of the source-side reduction (and k_probe_stream), 65 .. 128 the two-word form
+    // (k_node_runs<., true>: the windows in two halves; k_probe_clustered<., ., ., 2>)
+    if (e > CL_MAX_EQ || nwin < 1 || nwin > 128) return false;
+    // The minimizer of a window is chosen among its first w = min(Lmin - k + 1, 64) k-mers (they all lie inside the window, so the choice
+    // is a function of the window's content: a source window and the equal target prefix agree on it -- that is all the join needs).
+    // k <= 32 (two hash words); the window minimum by two blocks needs the windows of one half (<= 64) not to outnumber w.
+    int kk = std::min(32, std::max(cfg.Lmin - 63, std::min(cfg.Lmin, CL_KMIN)));
+    const int nw_half = std::min(nwin, 64);
+    if (nw_half > std::min(cfg.Lmin - kk + 1, 64)) kk = cfg.Lmin - nw_half + 1;
     if (kk < CL_KMIN_HARD || kk > 32 || kk > cfg.Lmin) return false;
     c->kk = kk;
-    c->w = cfg.Lmin - kk + 1;
+    c->w = std::min(cfg.Lmin - kk + 1, 64);
     c->lo_mask = kk >= 16 ? 0xFFFFFFFFu : ((1u << (2 * kk)) - 1u);
     c->hi_mask = kk <= 16 ? 0u : (kk >= 32 ? 0xFFFFFFFFu : ((1u << (2 * kk - 32)) - 1u));
     int bits = 4;
@@ -1196,10 +1221,13 @@ void launch_cluster_keys(const NodesDev &nd, const PrefSufCfg &cfg, const Cluste
     const uint64_t m = (uint64_t) (node_end - node_begin);
     const dim3 grid((unsigned) ((m + TK_ROWS - 1) / TK_ROWS)), block(TK_ROWS);
     // rows of up to 9 words (every 100 - 150 bp configuration) stage 11 words per node, longer ones (<= 13 words) 17
-    if (blocks_of(cfg.Lcap - 1) <= 9)
-        hipLaunchKernelGGL(k_node_runs<11>, grid, block, 0, s, nd, cfg, cc, (int) node_begin, (int) node_end, keys, vals, meta, (uint2 *) runs, nruns);
+    // ... and rows of up to 17 words or nodes with more than 64 suffix windows (250-bp reads) the two-halves form with 21
+    if (blocks_of(cfg.Lcap - 1) > 13 || (cfg.Lcap - 1) - cfg.Lmin + 1 > 64)
+        hipLaunchKernelGGL((k_node_runs<21, true>), grid, block, 0, s, nd, cfg, cc, (int) node_begin, (int) node_end, keys, vals, meta, (uint2 *) runs, nruns);
+    else if (blocks_of(cfg.Lcap - 1) <= 9)
+        hipLaunchKernelGGL((k_node_runs<11, false>), grid, block, 0, s, nd, cfg, cc, (int) node_begin, (int) node_end, keys, vals, meta, (uint2 *) runs, nruns);
     else
-        hipLaunchKernelGGL(k_node_runs<17>, grid, block, 0, s, nd, cfg, cc, (int) node_begin, (int) node_end, keys, vals, meta, (uint2 *) runs, nruns);
+        hipLaunchKernelGGL((k_node_runs<17, false>), grid, block, 0, s, nd, cfg, cc, (int) node_begin, (int) node_end, keys, vals, meta, (uint2 *) runs, nruns);
 }
 
 __global__ void __launch_bounds__(256) k_iota(uint32_t *__restrict__ v, uint32_t n) {
@@ -1233,7 +1261,8 @@ hipError_t launch_cluster_store(const NodesDev &nd, const ClusterCfg &cc, int eq
 #define TG_EQ(E) do { if (uniform_len > 0) TG_LAUNCH(E, true); else TG_LAUNCH(E, false); } while (0)
     if (eq == 2)      TG_EQ(2);
     else if (eq == 3) TG_EQ(3);
-    else              TG_EQ(4);
+    else if (eq == 4) TG_EQ(4);
+    else              TG_EQ(5);
 #undef TG_EQ
 #undef TG_LAUNCH
     if (ev_gathered) (void) hipEventRecord(ev_gathered, s);
@@ -1263,7 +1292,8 @@ hipError_t launch_cluster_store_slice(const NodesDev &nd, const ClusterCfg &cc, 
 #define TG_EQ(E) do { if (uniform_len > 0) TG_LAUNCH(E, true); else TG_LAUNCH(E, false); } while (0)
     if (eq == 2)      TG_EQ(2);
     else if (eq == 3) TG_EQ(3);
-    else              TG_EQ(4);
+    else if (eq == 4) TG_EQ(4);
+    else              TG_EQ(5);
 #undef TG_EQ
 #undef TG_LAUNCH
     hipLaunchKernelGGL(k_tgt_dir, dim3((unsigned) ((n + 1 + TD_TILE - 1) / TD_TILE)), dim3(TD_TILE), 0, s, (const uint32_t *) keys2, n, cc.idx_shift, n_buckets_local, bucket_base,
@@ -1310,7 +1340,7 @@ void launch_probe_clustered(const NodesDev &nd, const PrefSufCfg &cfg, const Clu
                             const void *runs, const uint8_t *nruns, int32_t src_begin, int32_t src_end, const int32_t *src_list, int32_t src_base,
                             uint32_t *rec_dst, unsigned long long *rec_val, uint64_t rec_cap,
                             unsigned long long *counters, int n_cu, uint32_t *deg, unsigned long long *first, const ProbeBig *big,
-                            const unsigned long long *list_count, hipStream_t s) {
+                            const unsigned long long *list_count, int sw /* 1 | 2: words per offset mask of the source-side form */, hipStream_t s) {
     const int64_t ns = (int64_t) src_end - src_begin;
     if (ns <= 0) return;
     dim3 grid((unsigned) cluster_probe_blocks(n_cu, (uint64_t) ns)), block(PROBE_WAVES * 64);
@@ -1322,12 +1352,23 @@ void launch_probe_clustered(const NodesDev &nd, const PrefSufCfg &cfg, const Clu
     const int kf = (2 * cfg.Lmin) >> 5;
 #define CL_LAUNCH(ST, E, K) hipLaunchKernelGGL((k_probe_clustered<ST, E, K>), grid, block, 0, s, nd, cfg, cc, st, (const uint4 *) dir, (const uint2 *) runs, nruns, src_begin, src_end, o, src_list, list_count)
 #define CL_STATS(E, K) do { if (cfg.stats) CL_LAUNCH(true, E, K); else CL_LAUNCH(false, E, K); } while (0)
-    if (eq == 3 && kf == 5)      CL_STATS(3, 5);
+#define CL_LAUNCH2(ST, E) hipLaunchKernelGGL((k_probe_clustered<ST, E, 0, 2>), grid, block, 0, s, nd, cfg, cc, st, (const uint4 *) dir, (const uint2 *) runs, nruns, src_begin, src_end, o, src_list, list_count)
+#define CL_STATS2(E) do { if (cfg.stats) CL_LAUNCH2(true, E); else CL_LAUNCH2(false, E); } while (0)
+    if (sw == 2) {                                         // more than 64 suffix windows (250-bp reads): the two-word form, any row length
+        if (eq == 2)      CL_STATS2(2);
+        else if (eq == 3) CL_STATS2(3);
+        else if (eq == 4) CL_STATS2(4);
+        else              CL_STATS2(5);
+    }
+    else if (eq == 3 && kf == 5) CL_STATS(3, 5);
     else if (eq == 3 && kf == 3) CL_STATS(3, 3);
     else if (eq == 2 && kf == 3) CL_STATS(2, 3);
     else if (eq == 2)            CL_STATS(2, 0);
     else if (eq == 3)            CL_STATS(3, 0);
-    else                         CL_STATS(4, 0);
+    else if (eq == 4)            CL_STATS(4, 0);
+    else                         CL_STATS(5, 0);
+#undef CL_STATS2
+#undef CL_LAUNCH2
 #undef CL_STATS
 #undef CL_LAUNCH
 }

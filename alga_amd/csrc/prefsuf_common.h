@@ -101,7 +101,7 @@ constexpr int      CL_KMIN_HARD = 8;          // below this the clustered probe 
 constexpr int      CL_MBITS = 6;              // low bits of a target's sort key: m_C, the minimizer's position in its prefix (w <= 64)
 constexpr int      CL_RMAX = 8;               // minimizer runs stored per node (a 150-bp read has 2.9 on average)
 constexpr int      CL_RUNS_FLAGGED = 0xFF;    // nruns marker: more runs / records than k_node_runs stores
-constexpr int      CL_MAX_EQ = 4;             // 16-byte pieces per entry: rows of up to 4 * CL_MAX_EQ - 3 words (208 nt)
+constexpr int      CL_MAX_EQ = 5;             // 16-byte pieces per entry: rows of up to 4 * CL_MAX_EQ - 3 words (272 nt)
 constexpr uint32_t CL_META_FROM = 1u << 20;   // entry meta word: m_C | len << 8 | alignFrom << 20
 struct ClusterCfg {
     int32_t  kk;         // minimizer k-mer length

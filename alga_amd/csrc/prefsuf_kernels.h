@@ -52,7 +52,8 @@ uint64_t   cluster_record_slack(int n_cu, uint64_t n_src);
 void       launch_probe_clustered(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterCfg &cc, int eq, const void *store, const void *dir,
                                   const void *runs, const uint8_t *nruns, int32_t src_begin, int32_t src_end, const int32_t *src_list, int32_t src_base, uint32_t *rec_dst, unsigned long long *rec_val, uint64_t rec_cap,
                                   unsigned long long *counters, int n_cu, uint32_t *deg, unsigned long long *first, const ProbeBig *big,
-                                  const unsigned long long *list_count /* device, may be null: list mode ends at min(src_end, *list_count) */, hipStream_t s);
+                                  const unsigned long long *list_count /* device, may be null: list mode ends at min(src_end, *list_count) */,
+                                  int sw /* 1 | 2: 64-bit words per offset mask (sources of up to 64 | 128 suffix windows) */, hipStream_t s);
 void       launch_probe_stream(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterCfg &cc, int eq, const void *store, const void *dir,
                                const void *runs, const uint8_t *nruns, int32_t src_begin, int32_t src_end, bool by_key /* the range is one of entry-array positions */,
                                unsigned long long *counters, int n_cu, uint32_t *deg, unsigned long long *first, unsigned long long *second, int32_t *defer_list,

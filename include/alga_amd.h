@@ -54,9 +54,11 @@ typedef enum { ALGA_REDUCTION_AUTO = 0, ALGA_REDUCTION_PER_TARGET = 1, ALGA_REDU
 /* Which probe finds the raw overlaps of the SOURCE_SIDE form (same result either way):
  *   TABLE   : bucketised seed table, one probe per (source, overlap length) -- takes any input;
  *   CLUSTER : clustered minimizer join -- targets sorted by the minimizer of their min_overlap-long prefix, ~3 contiguous
- *             lookups per source; takes max_len - min_overlap <= 63 and reads of up to 208 nt (every 100-150 bp configuration
- *             of ALGA's defaults), anything else uses TABLE;
- *   AUTO    : CLUSTER whenever it takes the input (1.8x faster at 1.7 M nodes, 2.9x at 90 M), else TABLE. */
+ *             lookups per source; takes max_len - min_overlap <= 127 and reads of up to 272 nt (round 4: 250-bp reads too, in the
+ *             two-word form of the source-side reduction through its general kernel; up to 63 / 208 nt through k_probe_stream),
+ *             anything else uses TABLE;
+ *   AUTO    : CLUSTER whenever it takes the input (1.8x faster at 1.7 M nodes, 2.9x at 90 M) -- for the wide shapes (span > 63 or
+ *             reads > 208 nt) from 4 M live nodes on (below, table and rows are cache-resident and TABLE is faster) --, else TABLE. */
 typedef enum { ALGA_PROBE_AUTO = 0, ALGA_PROBE_TABLE = 1, ALGA_PROBE_CLUSTER = 2 } alga_probe;
 
 typedef struct alga_engine alga_engine; /* opaque */

@@ -95,7 +95,7 @@ def test_multi_bucket_sharded_masks_tandem_repeats_and_declines():
         m.set_rank_option(1, "shard_bucket_max", 4096)
         got = m.prefsuf_host(words, lens, 55, 77)
         assert got.shape == want.shape and (got == want).all() and m.last_stats()["form"] == 2
-        # what the clustered probe does not take (250-nt reads): the sharded form is not even tried
+        # 250-nt reads: the clustered probe takes them (two-word form), the bucket-sharded join (one-word offsets) does not: declined at its first phase
         words, lens = _nodes(1200, 250, 8000, 90, 0.0, None)
         want, _, _ = O.prefsuf(words, lens, 140, 190)
         got = m.prefsuf_host(words, lens, 140, 190)
@@ -106,8 +106,8 @@ def test_multi_bucket_sharded_masks_tandem_repeats_and_declines():
 
 
 def test_multi_falls_back_when_a_rank_declines():
-    """250-nt reads at the default scale still take the source-side form (two-word masks, seed-table probe: no keys to share); reads
-    beyond 288 nt do not -- every rank declines and rank 0 builds the whole graph the general way.  Same graph as one engine."""
+    """250-nt reads at the default scale take the source-side form (two-word masks; since round 4 through the clustered probe, keys
+    shared); reads beyond 288 nt do not -- every rank declines and rank 0 builds the whole graph the general way.  Same graph as one engine."""
     for length, lo, rs, fell in ((250, 140, 190, 0), (400, 60, 90, 1)):
         words, lens = _nodes(1500, length, 9000, 83, 0.0, None)
         want, _, _ = O.prefsuf(words, lens, lo, rs)

@@ -42,13 +42,14 @@ def _check(eng, words, lens, lo, rs, af=None, at=None, stats=True, source_side=N
     if source_side is None:
         source_side = exact
     if source_side:
-        # the source-side form through BOTH probes: the bucketised seed table and the clustered minimizer join (which takes
-        # one-word offset masks and rows of up to 13 words, and hands anything else to the table probe)
+        # the source-side form through BOTH probes: the bucketised seed table and the clustered minimizer join (round 4: up to 128 suffix
+        # windows -- 250-bp reads, the two-word form -- and rows of up to 17 words; anything else goes to the table probe)
         maxlen = int(np.max(lens, initial=0))
-        kk = max(lo - 63, min(lo, 16))                       # cluster_plan (alga_amd/csrc/prefsuf_cluster.hip)
-        if maxlen - lo + 1 > lo - kk + 1:
-            kk = 2 * lo - maxlen
-        clusterable = 1 <= maxlen - lo + 1 <= 64 and (2 * maxlen + 31) // 32 <= 13 and 8 <= kk <= min(32, lo)
+        nwin = maxlen - lo + 1
+        kk = min(32, max(lo - 63, min(lo, 16)))              # cluster_plan (alga_amd/csrc/prefsuf_cluster.hip)
+        if min(nwin, 64) > min(lo - kk + 1, 64):
+            kk = lo - min(nwin, 64) + 1
+        clusterable = 1 <= nwin <= 128 and (2 * maxlen + 31) // 32 <= 17 and 8 <= kk <= min(32, lo)
         # the clustered probe with k_probe_stream first (the default), sources in key order and in id order, and its general kernel alone
         for probe, first_kernel, order in (("table", 1, 1), ("cluster", 1, 1), ("cluster", 1, 0), ("cluster", 0, 1)):
             eng.set_option("probe", probe)
@@ -470,9 +471,12 @@ def test_shared_keys_protocol(eng):
         with pytest.raises(alga_amd.AlgaError) as ei:                 # sources outside the keyed node range
             eng.build_range_device(dw, dl, 90, 120, 0, n, keys_shared=True)
         assert ei.value.code == -1
-        # 250-nt reads: the clustered probe declines (two-word offset masks) -> nothing to share
+        # 250-nt reads take the clustered probe too (round 4: two-word offset masks, 80-byte entries): there are keys to share;
+        # reads beyond 272 nt (rows of more than 17 words) do not
         w2, l2 = _nodes(600, 250, 4000, 84)
-        assert eng.keys_device(torch.from_numpy(w2.view(np.int32)).cuda(), torch.from_numpy(l2).cuda(), 137, 190, 0, len(l2)) is None
+        assert eng.keys_device(torch.from_numpy(w2.view(np.int32)).cuda(), torch.from_numpy(l2).cuda(), 137, 190, 0, len(l2)) is not None
+        w3, l3 = _nodes(300, 280, 4000, 85)
+        assert eng.keys_device(torch.from_numpy(w3.view(np.int32)).cuda(), torch.from_numpy(l3).cuda(), 160, 200, 0, len(l3)) is None
     finally:
         e2.close()
 
