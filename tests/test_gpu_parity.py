@@ -473,10 +473,17 @@ def test_shared_keys_protocol(eng):
         assert ei.value.code == -1
         # 250-nt reads take the clustered probe too (round 4: two-word offset masks, 80-byte entries): there are keys to share;
         # reads beyond 272 nt (rows of more than 17 words) do not
+        # (at this size AUTO keeps the seed-table probe for them -- cache-resident, faster --: nothing to share; asked for, the clustered probe shares)
         w2, l2 = _nodes(600, 250, 4000, 84)
-        assert eng.keys_device(torch.from_numpy(w2.view(np.int32)).cuda(), torch.from_numpy(l2).cuda(), 137, 190, 0, len(l2)) is not None
-        w3, l3 = _nodes(300, 280, 4000, 85)
-        assert eng.keys_device(torch.from_numpy(w3.view(np.int32)).cuda(), torch.from_numpy(l3).cuda(), 160, 200, 0, len(l3)) is None
+        d2, dl2 = torch.from_numpy(w2.view(np.int32)).cuda(), torch.from_numpy(l2).cuda()
+        assert eng.keys_device(d2, dl2, 137, 190, 0, len(l2)) is None
+        eng.set_option("probe", "cluster")
+        try:
+            assert eng.keys_device(d2, dl2, 137, 190, 0, len(l2)) is not None
+            w3, l3 = _nodes(300, 280, 4000, 85)
+            assert eng.keys_device(torch.from_numpy(w3.view(np.int32)).cuda(), torch.from_numpy(l3).cuda(), 160, 200, 0, len(l3)) is None
+        finally:
+            eng.set_option("probe", "auto")
     finally:
         e2.close()
 
