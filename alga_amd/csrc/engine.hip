@@ -677,7 +677,13 @@ int alga_prefsuf_build_device(alga_engine *e, const alga_nodes *nodes, const alg
 
 // Host node set -> the engine's own upload buffers, in the engine's row layout (hbm_row_stride: 16-byte aligned rows that never
 // straddle a 64-byte line take the wide-load kernels); *dev describes the resident copy (masks included when given).
-int alga_upload_nodes(alga_engine *e, const alga_nodes *nodes, alga_nodes *dev) {
+static int upload_nodes_impl(alga_engine *e, const alga_nodes *nodes, alga_nodes *dev, bool twin_rows);
+
+int alga_upload_nodes(alga_engine *e, const alga_nodes *nodes, alga_nodes *dev) { return upload_nodes_impl(e, nodes, dev, false); }
+int alga_upload_twin_nodes(alga_engine *e, const alga_nodes *nodes, alga_nodes *dev) { return upload_nodes_impl(e, nodes, dev, true); }
+
+// twin_rows: nodes->words holds the rows of the ODD nodes only (row k = node 2k + 1); len / masks have all n entries
+static int upload_nodes_impl(alga_engine *e, const alga_nodes *nodes, alga_nodes *dev, bool twin_rows) {
     if (!e) return ALGA_ERR_INVALID_ARGUMENT;
     e->err.clear();
     if (!nodes || !dev) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "nodes / output must not be NULL");
@@ -705,16 +711,32 @@ int alga_upload_nodes(alga_engine *e, const alga_nodes *nodes, alga_nodes *dev) 
         if ((int64_t) blocks_of(max_len) > (int64_t) nodes->stride_words)
             return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "stride_words is smaller than the longest read needs");
     }
+    if (twin_rows) {
+        // node 2k is rebuilt from node 2k + 1: it must be removed (0) or as long as its twin
+        if (n & 1) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "twin_rows: the node count must be even");
+        for (size_t k = 0; k + 1 < n; k += 2)
+            if (nodes->len[k] != 0 && nodes->len[k] != nodes->len[k + 1])
+                return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "twin_rows: node 2k is neither removed nor as long as node 2k + 1");
+    }
     // Rows travel at the caller's stride through pinned staging buffers (staging.hip) and are re-strided on the DEVICE.
     const int stride_up = alga::hbm_row_stride(nodes->stride_words);
     const size_t wbytes = n * (size_t) stride_up * sizeof(uint32_t);
-    const size_t raw_bytes = n * (size_t) nodes->stride_words * sizeof(uint32_t);
+    const size_t raw_bytes = (twin_rows ? n / 2 : n) * (size_t) nodes->stride_words * sizeof(uint32_t);
     alga_forget_node_set(e);
     if ((rc = alga_ensure(e, e->up_words, wbytes))) return rc;
     if ((rc = alga_ensure(e, e->up_len, n * sizeof(int32_t)))) return rc;
     alga_nodes dn = *nodes;
     if (n) {
         HIP_TRY(e, hipStreamSynchronize(s));                       // nothing of an earlier call still reads the upload buffers
+        if (twin_rows) {
+            // half of the rows cross PCIe; the lengths first (the expansion reads them)
+            if ((rc = alga_ensure(e, e->up_raw, raw_bytes))) return rc;
+            if ((rc = alga_staged_h2d(e, e->up_len.p, nodes->len, n * sizeof(int32_t)))) return rc;
+            if ((rc = alga_staged_h2d(e, e->up_raw.p, nodes->words, raw_bytes))) return rc;
+            launch_expand_twins((const uint32_t *) e->up_raw.p, nodes->stride_words, (const int32_t *) e->up_len.p, (uint32_t *) e->up_words.p, stride_up, (uint64_t) (n / 2), s);
+            if ((rc = alga_check_launch(e, "k_expand_twins"))) return rc;
+            HIP_TRY(e, hipStreamSynchronize(s));
+        } else
         if (stride_up != nodes->stride_words) {
             if ((rc = alga_ensure(e, e->up_raw, raw_bytes))) return rc;
             if ((rc = alga_staged_h2d(e, e->up_raw.p, nodes->words, raw_bytes))) return rc;
@@ -722,7 +744,7 @@ int alga_upload_nodes(alga_engine *e, const alga_nodes *nodes, alga_nodes *dev) 
             if ((rc = alga_check_launch(e, "k_restride"))) return rc;
             HIP_TRY(e, hipStreamSynchronize(s));
         } else if ((rc = alga_staged_h2d(e, e->up_words.p, nodes->words, raw_bytes))) return rc;
-        if ((rc = alga_staged_h2d(e, e->up_len.p, nodes->len, n * sizeof(int32_t)))) return rc;
+        if (!twin_rows && (rc = alga_staged_h2d(e, e->up_len.p, nodes->len, n * sizeof(int32_t)))) return rc;
     }
     dn.stride_words = stride_up;
     dn.words = (const uint32_t *) e->up_words.p;
@@ -762,7 +784,7 @@ int alga_prefsuf_build_host(alga_engine *e, const alga_nodes *nodes, const alga_
     *edges = nullptr; *n_edges = 0;
     if (!nodes || !p) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "nodes/params must not be NULL");
     alga_nodes dn;
-    int rc = alga_upload_nodes(e, nodes, &dn);
+    int rc = upload_nodes_impl(e, nodes, &dn, p->twin_rows != 0);
     if (rc) return rc;
     const alga_edge *d_edges = nullptr;
     uint64_t E = 0;

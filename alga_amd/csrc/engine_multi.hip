@@ -590,7 +590,7 @@ int alga_multi_prefsuf_build_host(alga_multi *m, const alga_nodes *nodes, const 
     const double t0 = now_ms();
     {
         std::vector<std::thread> th;
-        auto up = [&](int r) { urc[(size_t) r] = alga_upload_nodes(m->eng[(size_t) r], nodes, &dev[(size_t) r]); };
+        auto up = [&](int r) { urc[(size_t) r] = p->twin_rows ? alga_upload_twin_nodes(m->eng[(size_t) r], nodes, &dev[(size_t) r]) : alga_upload_nodes(m->eng[(size_t) r], nodes, &dev[(size_t) r]); };
         try { for (int r = 1; r < N; r++) th.emplace_back(up, r); } catch (...) { for (int r = (int) th.size() + 1; r < N; r++) urc[(size_t) r] = ALGA_ERR_OUT_OF_MEMORY; }
         up(0);
         for (std::thread &x : th) x.join();

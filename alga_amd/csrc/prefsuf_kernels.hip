@@ -1058,10 +1058,48 @@ __global__ void __launch_bounds__(256) k_restride(const uint32_t *__restrict__ i
     }
 }
 
+// The node set of ALGA comes in TWIN PAIRS: node 2k is the reverse complement of node 2k + 1 (src/IO/InputReader.cpp:78-80,363-377; the
+// duplicate removal deletes twins together, src/main.cpp:150-232).  A caller that says so (alga_prefsuf_params.twin_rows) sends the rows of the
+// odd nodes only -- half of the PCIe upload -- and the even rows are made here: row 2k + 1 = in[k] (re-strided), row 2k = its reverse
+// complement over len[2k] nucleotides (0: removed node, an all-zero row).  One thread per output word: nucleotide-reversed, complemented
+// input words taken from the end, shifted down by the padding of the last word.
+__device__ __forceinline__ uint32_t nuc_revcomp32(uint32_t x) {      // 16 nucleotides reversed and complemented (A0 C1 G2 T3: 3 - c = ~c)
+    x = __brev(x);
+    x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
+    return ~x;
+}
+__global__ void __launch_bounds__(256) k_expand_twins(const uint32_t *__restrict__ in, int stride_in, const int32_t *__restrict__ len, uint32_t *__restrict__ out, int stride_out,
+                                                       uint64_t n_pairs) {
+    const uint64_t total = n_pairs * (uint64_t) stride_out;
+    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t) gridDim.x * blockDim.x) {
+        const uint64_t k = i / (uint64_t) stride_out;
+        const int c = (int) (i - k * (uint64_t) stride_out);
+        const uint32_t *row = in + k * (uint64_t) stride_in;
+        out[(2 * k + 1) * (uint64_t) stride_out + c] = c < stride_in ? row[c] : 0u;
+        const int n = len[2 * k];
+        uint32_t v = 0u;
+        if (n > 0) {
+            const int wn = (2 * n + 31) >> 5, pad = 32 * wn - 2 * n;              // words of the read; unused bits of its last word
+            if (c < wn) {
+                const uint32_t f0 = (wn - 1 - c) < stride_in ? nuc_revcomp32(row[wn - 1 - c]) : 0u;
+                const uint32_t f1 = (c + 1 < wn && (wn - 2 - c) < stride_in) ? nuc_revcomp32(row[wn - 2 - c]) : 0u;
+                v = pad ? ((f0 >> pad) | (f1 << (32 - pad))) : f0;
+            }
+        }
+        out[(2 * k) * (uint64_t) stride_out + c] = v;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // launch wrappers (host)
 // ------------------------------------------------------------------------------------------
 static inline unsigned grid_for(uint64_t n, int block) { return (unsigned) ((n + (uint64_t) block - 1) / (uint64_t) block); }
+
+void launch_expand_twins(const uint32_t *in, int stride_in, const int32_t *len, uint32_t *out, int stride_out, uint64_t n_pairs, hipStream_t s) {
+    if (n_pairs == 0) return;
+    hipLaunchKernelGGL(k_expand_twins, dim3((unsigned) std::min<uint64_t>((n_pairs * (uint64_t) stride_out + 255) / 256, 1u << 16)), dim3(256), 0, s, in, stride_in, len, out,
+                       stride_out, n_pairs);
+}
 
 void launch_restride(const uint32_t *in, int stride_in, uint32_t *out, int stride_out, uint64_t n, hipStream_t s) {
     if (n == 0) return;

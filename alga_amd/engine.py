@@ -30,7 +30,7 @@ class PrefSufParams(C.Structure):
     """alga_prefsuf_params"""
     _fields_ = [("min_overlap", C.c_int32), ("rsoe_min_overlap", C.c_int32), ("soes", C.c_int32),
                 ("max_len_cap", C.c_int32), ("collect_stats", C.c_int32), ("reduction", C.c_int32),
-                ("keys_shared", C.c_int32), ("reserved", C.c_int32 * 1)]
+                ("keys_shared", C.c_int32), ("twin_rows", C.c_int32)]
 
 
 class PrefSufStats(C.Structure):
@@ -144,7 +144,7 @@ EXPORTS = ["alga_abi_version", "alga_engine_set_option", "alga_engine_create", "
            "alga_can_align_batch_host", "alga_li_kmers_host", "alga_pkb_supplement_host", "alga_pkb_supplement_device",
            "alga_pkb_last_stats", "alga_parse_files", "alga_free_parsed_reads", "alga_preprocess_nodes", "alga_copy_to_host", "alga_device_alloc", "alga_device_free", "alga_copy_to_device", "alga_cut_triangles_device", "alga_cut_triangles_host", "alga_ingest_device", "alga_contig_trim_host", "alga_engine_reserve", "alga_upload_nodes", "alga_download_edges",
            "alga_multi_create", "alga_multi_destroy", "alga_multi_last_error", "alga_multi_engine", "alga_multi_prefsuf_build_host", "alga_multi_prefsuf_build_device",
-           "alga_multi_free_edges", "alga_multi_last_stats", "alga_multi_set_option",
+           "alga_multi_free_edges", "alga_multi_last_stats", "alga_multi_set_option", "alga_upload_twin_nodes",
            "alga_shard_index_device", "alga_shard_join_device", "alga_shard_small_keys_device", "alga_shard_resolve_device", "alga_shard_place_device",
            "alga_shard_last_stats"]
 
@@ -414,11 +414,12 @@ class Engine:
 
     # ---- host buffers in, edges out (the drop-in call) --------------------------------------
     def prefsuf_host(self, words, lens, min_overlap, rsoe_min_overlap, align_from=None, align_to=None, collect_stats=False,
-                     reduction="auto"):
+                     reduction="auto", twin_rows=False):
+        """twin_rows: `words` holds the rows of the ODD nodes alone (n / 2 rows; alga_prefsuf_params.twin_rows)."""
         words = np.ascontiguousarray(words, dtype=np.uint32)
         lens = np.ascontiguousarray(lens, dtype=np.int32)
         n = int(lens.shape[0])
-        stride = int(words.shape[1]) if words.ndim == 2 else (words.size // max(n, 1))
+        stride = int(words.shape[1]) if words.ndim == 2 else (words.size // max(n // 2 if twin_rows else n, 1))
         keep = [words, lens]
         nd = _Nodes(words.ctypes.data, stride, lens.ctypes.data, n, None, None)
         if align_from is not None:
@@ -426,6 +427,7 @@ class Engine:
         if align_to is not None:
             at = np.ascontiguousarray(align_to, dtype=np.uint8); keep.append(at); nd.align_to = at.ctypes.data
         p = self.params(min_overlap, rsoe_min_overlap, collect_stats, reduction)
+        p.twin_rows = 1 if twin_rows else 0
         out = C.c_void_p()
         m = C.c_uint64()
         self._check(self._lib.alga_prefsuf_build_host(self._h, C.byref(nd), C.byref(p), C.byref(out), C.byref(m)))
@@ -435,15 +437,16 @@ class Engine:
         finally:
             self._lib.alga_free_edges(self._h, out)
 
-    def prefsuf_host_timed(self, words, lens, min_overlap, rsoe_min_overlap, repeat=3):
+    def prefsuf_host_timed(self, words, lens, min_overlap, rsoe_min_overlap, repeat=3, twin_rows=False):
         """Wall time of the C call alone (alga_prefsuf_build_host + alga_free_edges; no Python-side copy of the result):
-        -> (best seconds, n_edges)."""
+        -> (best seconds, n_edges).  twin_rows: `words` holds the rows of the odd nodes alone (alga_prefsuf_params.twin_rows)."""
         import time
         words = np.ascontiguousarray(words, dtype=np.uint32)
         lens = np.ascontiguousarray(lens, dtype=np.int32)
         n = int(lens.shape[0])
         nd = _Nodes(words.ctypes.data, int(words.shape[1]), lens.ctypes.data, n, None, None)
         p = self.params(min_overlap, rsoe_min_overlap)
+        p.twin_rows = 1 if twin_rows else 0
         best, m_out = None, 0
         for _ in range(repeat):
             out, m = C.c_void_p(), C.c_uint64()

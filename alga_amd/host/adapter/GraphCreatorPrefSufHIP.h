@@ -22,19 +22,43 @@
 
 namespace alga_adapter {
 
-// vector<Read*> -> the engine's node arrays: 2-bit rows as the Bitset holds them (Bitset.h:41-50,175), 0 = READS[i] == nullptr
+// vector<Read*> -> the engine's node arrays: 2-bit rows as the Bitset holds them (Bitset.h:41-50,175), 0 = READS[i] == nullptr.
+// twins: ALGA's read set comes in pairs -- READS[2k] is the reverse complement of READS[2k + 1] (src/IO/InputReader.cpp:78-80,363-377; the
+// duplicate removal deletes twins together, src/main.cpp:150-232).  Where that holds (every even read absent or as long as its odd twin, and
+// up to 256 evenly spaced pairs checked nucleotide by nucleotide) only the ODD reads' rows are packed and uploaded -- half of the PCIe
+// traffic -- and the engine rebuilds the even rows on the device (alga_upload_twin_nodes).  Any other vector (the contigs of the trimming
+// stage: contigs first, reverse complements behind) fails the check and travels whole.
 struct NodeArrays {
     std::vector<uint32_t> words;
     std::vector<int32_t> len;
-    int stride = 4;
-    explicit NodeArrays(std::vector<Read *> &reads) {
+    int stride = 1;
+    bool twins = false;
+    static bool is_twin_layout(std::vector<Read *> &reads) {
+        const size_t n = reads.size();
+        if (n == 0 || (n & 1)) return false;
+        for (size_t k = 0; k + 1 < n; k += 2) {
+            if (reads[k] == nullptr) continue;
+            if (reads[k + 1] == nullptr || reads[k]->size() != reads[k + 1]->size()) return false;
+        }
+        const size_t pairs = n / 2, step = std::max<size_t>(1, pairs / 256);
+        for (size_t k = 0; k < pairs; k += step) {
+            Read *a = reads[2 * k], *b = reads[2 * k + 1];
+            if (a == nullptr || b == nullptr) continue;
+            const int m = a->size();
+            for (int i = 0; i < m; i++) if ((*a)[i] != 3 - (*b)[m - 1 - i]) return false;
+        }
+        return true;
+    }
+    explicit NodeArrays(std::vector<Read *> &reads, bool allow_twins = true) {
         const size_t n = reads.size();
         int max_len = 0;
         for (Read *r : reads) if (r != nullptr) max_len = std::max(max_len, r->size());
         // rows as tight as the Bitset itself (9 words for a 150-bp read): what crosses PCIe is this array, and the engine re-strides it to
         // its own HBM layout on the device (alga_upload_nodes); 16-byte aligned rows (12 words) cost a third more upload for nothing
         stride = std::max(1, (2 * max_len + 31) / 32);
-        words.assign(n * (size_t) stride, 0u);
+        twins = allow_twins && is_twin_layout(reads);
+        const size_t rows = twins ? n / 2 : n;
+        words.assign(rows * (size_t) stride, 0u);
         len.assign(n, 0);
         const int T = std::max(1, Params::THREADS);
         std::vector<std::thread> th;
@@ -44,9 +68,11 @@ struct NodeArrays {
                     Read *r = reads[i];
                     if (r == nullptr) continue;
                     len[i] = r->size();
+                    if (twins && (i & 1) == 0) continue;         // an even read: rebuilt on the device from its odd twin
                     Bitset &b = r->getSequence();
                     const int nb = (int) b.countBlocks();
-                    for (int k = 0; k < nb; k++) words[i * (size_t) stride + k] = b.getBlock(k);
+                    uint32_t *row = words.data() + (twins ? i / 2 : i) * (size_t) stride;
+                    for (int k = 0; k < nb; k++) row[k] = b.getBlock(k);
                 }
             });
         for (std::thread &x : th) x.join();
@@ -106,7 +132,7 @@ public:
             int max_len = 0;
             for (int32_t l : host.len) max_len = std::max(max_len, (int) l);
             if (max_len > 0) (void) alga_engine_reserve(e_, hn.n, max_len, std::max(1, Params::MIN_OVERLAP_PREF_SUF), 0);
-            int rc = alga_upload_nodes(e_, &hn, &dev_);
+            int rc = host.twins ? alga_upload_twin_nodes(e_, &hn, &dev_) : alga_upload_nodes(e_, &hn, &dev_);
             if (rc != ALGA_OK) die(e_, "upload of the reads", rc);
             resident_ = true; reads_id_ = (const void *) &reads; n_ = reads.size(); fp_ = fp;
         }
@@ -182,7 +208,7 @@ inline void first_simplifier_step(Graph *G, int hip_device = 0) {
 // The contig-trimming block on the GPU: replaces src/main.cpp:636-697 (contigs + reverse complements through one more
 // GraphCreatorPrefSuf run at threshold 25, trimLeft from its edges); the caller keeps the string surgery of :700-712.
 inline std::vector<int> contig_trim_left(std::vector<Read *> &contigs, int threshold = 25, int hip_device = 0) {
-    NodeArrays nodes(contigs);
+    NodeArrays nodes(contigs, false);
     std::vector<int32_t> trim(contigs.size(), 0);
     Session &ses = Session::get(hip_device);
     alga_engine *e = ses.engine();

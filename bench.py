@@ -418,11 +418,18 @@ def run(args, rank, world, local_rank, dist, t_process=None):
                 stride_host = max(1, W)
                 host_words = np.ascontiguousarray(d_words[:, :stride_host].cpu().numpy().view(np.uint32))
                 host_lens = d_lens.cpu().numpy()
-            best, m_host = eng.prefsuf_host_timed(host_words, host_lens, lo, rs, repeat=3)
+            # ALGA's node set comes in twin pairs (node 2k = reverse complement of node 2k + 1): the adapter sends the rows of the odd nodes
+            # alone and the engine rebuilds the even ones on the device (alga_prefsuf_params.twin_rows) -- what is timed here
+            twin_words = np.ascontiguousarray(host_words[1::2])
+            best, m_host = eng.prefsuf_host_timed(twin_words, host_lens, lo, rs, repeat=3, twin_rows=True)
+            full_best, m_full = eng.prefsuf_host_timed(host_words, host_lens, lo, rs, repeat=2)
             out["pcie_inclusive"] = {"ms_per_graph": best * 1e3, "edges_per_sec": m_host / best,
                                      "edges_equal_resident": bool(m_host == int(n_edges)),
-                                     "host_bytes_in": int(host_words.nbytes + host_lens.nbytes), "host_bytes_out": int(m_host) * 12,
-                                     "note": "alga_prefsuf_build_host from pageable host arrays (rows at the adapter's stride: the Bitset's own blocks, 9 words per 150-bp read): "
+                                     "host_bytes_in": int(twin_words.nbytes + host_lens.nbytes), "host_bytes_out": int(m_host) * 12,
+                                     "all_rows_uploaded": {"ms_per_graph": full_best * 1e3, "host_bytes_in": int(host_words.nbytes + host_lens.nbytes),
+                                                           "edges_equal": bool(m_full == m_host)},
+                                     "note": "alga_prefsuf_build_host from pageable host arrays as the adapter lays them out (the Bitset's own blocks, 9 words per 150-bp read; rows of the ODD nodes only, the "
+                                             "reverse-complement twins rebuilt on the device: twin_rows; all_rows_uploaded = the same without that): "
                                              "staged H2D of the packed reads (pinned buffers, 8 copy threads) + re-stride + build + staged D2H of the edges; wall time of the C call, best of 3"}
             # SURVEY.md section 8(d)'s headline is END TO END from packed host reads; `value` (the contract's number) is the HBM-resident rate
             out["value_end_to_end"] = m_host / best

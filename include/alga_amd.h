@@ -93,7 +93,11 @@ typedef struct {
                                  all-gathered by the caller; the build skips its own key pass.  2: this build follows
                                  another build of the SAME node set on this engine (nothing else in between) and reuses
                                  its sorted entry array: only the probe of [src_begin, src_end) runs                 */
-    int32_t reserved[1];
+    int32_t twin_rows;        /* host entry points only.  1: nodes->words holds the rows of the ODD nodes alone (row k = node 2k + 1,
+                                 n / 2 rows): node 2k is the reverse complement of node 2k + 1 -- ALGA's layout (src/IO/InputReader.cpp:
+                                 78-80,363-377; the duplicate removal deletes twins together, src/main.cpp:150-232) -- and its row is
+                                 rebuilt on the device from len[2k] (0 = removed, else == len[2k + 1]); half of the PCIe upload.  len and
+                                 the masks keep all n entries                                                                           */
 } alga_prefsuf_params;
 
 /* Work counters; the first four mirror GATHER_STATISTICS of the reference
@@ -173,6 +177,8 @@ int  alga_engine_reserve(alga_engine *e, int32_t n_nodes, int32_t max_len, int32
  * supplement -> ... on ONE upload): host node set -> the engine's upload buffers in the engine's row layout, `*dev` describes the
  * resident copy (valid until the next upload on this engine); device edge list -> engine-owned host list (alga_free_edges). */
 int  alga_upload_nodes(alga_engine *e, const alga_nodes *nodes, alga_nodes *dev);
+/* the same for a node set in ALGA's twin layout, given by the rows of its ODD nodes alone (alga_prefsuf_params.twin_rows): half the upload */
+int  alga_upload_twin_nodes(alga_engine *e, const alga_nodes *nodes /* words: n / 2 rows */, alga_nodes *dev);
 int  alga_download_edges(alga_engine *e, const alga_edge *d_edges, uint64_t n_edges, alga_edge **edges);
 
 /* Same computation with the node set already resident in HBM (all pointers in `nodes` are device

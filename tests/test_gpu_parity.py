@@ -257,6 +257,30 @@ def test_corrupt_index_fails_closed(pairs):
         e.close()
 
 
+@pytest.mark.parametrize("n,length,G,seed,err,minlen,lo,rs", [(3000, 100, 6000, 92, 0.0, None, 55, 77), (2500, 144, 5000, 93, 0.004, 100, 82, 116),
+                                                             (1200, 250, 9000, 94, 0.0, 180, 125, 180)])
+def test_twin_rows_upload_equals_full_upload(eng, n, length, G, seed, err, minlen, lo, rs):
+    """ALGA's node set in twin layout (node 2k = reverse complement of node 2k + 1), given by the rows of its ODD nodes alone
+    (alga_prefsuf_params.twin_rows): the even rows are rebuilt on the device (k_expand_twins) -- same graph as the full upload, also with
+    variable lengths, removed nodes (even alone, or both), rows of 16 words; a pair of different lengths is refused."""
+    words, lens = _nodes(n, length, G, seed, err, minlen)
+    lens = lens.copy()
+    rng = np.random.default_rng(seed)
+    gone = rng.random(len(lens) // 2) < 0.05
+    lens[0::2][gone] = 0                                             # the even node alone removed ...
+    lens[1::2][gone & (rng.random(len(gone)) < 0.5)] = 0             # ... or the pair
+    want, _, _ = O.prefsuf(words, lens, lo, rs)
+    for red in ("auto", "per_target"):
+        got = eng.prefsuf_host(np.ascontiguousarray(words[1::2]), lens, lo, rs, reduction=red, twin_rows=True)
+        assert got.shape == want.shape and (got == want).all(), red
+    bad = lens.copy()
+    k = int(np.flatnonzero(bad[0::2] > 0)[0])
+    bad[2 * k + 1] -= 1
+    with pytest.raises(alga_amd.AlgaError) as ei:
+        eng.prefsuf_host(np.ascontiguousarray(words[1::2]), bad, lo, rs, twin_rows=True)
+    assert ei.value.code == -1
+
+
 def test_invalid_arguments_are_errors(eng):
     words, lens = _nodes(50, 60, 500, 27)
     with pytest.raises(alga_amd.AlgaError):
