@@ -6,7 +6,7 @@
 #           index sharded by seed bucket (tools/emulate_shard.py: all ranks, graph == one-GPU graph, exchange volumes); the C++ driver, both
 #           forms, as 2 ranks at the north-star size against one engine
 #   part C: full-size parity on THIS tree against the recorded reference dumps (sha256): 50 M reads error-free, 10 M reads with 2 % errors
-# usage: tools/final_measure_r04.sh A|B|C
+# usage: tools/final_measure_r04.sh A1|A2|B|C      (A1: suite + configs[3]; A2: configs[4], configs[1], configs[2])
 set -u
 PART=${1:-A}
 REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
@@ -14,11 +14,16 @@ OUT=$REPO/gpurun_out/r04_final
 mkdir -p $OUT
 cd $REPO
 export TMPDIR=/tmp
-if [ "$PART" = A ]; then
-  timeout -k 10 1000 python -m pytest tests -x -q -m gpu > $OUT/pytest_gpu.log 2>&1; rc=$?
-  tail -3 $OUT/pytest_gpu.log
-  [ $rc -ne 0 ] && exit $rc
-  for CFG in cfg4_50M_150bp cfg5_10M_150bp_err2; do
+if [ "$PART" = A1 ] || [ "$PART" = A2 ]; then
+  if [ "$PART" = A1 ]; then
+    timeout -k 10 1000 python -m pytest tests -x -q -m gpu > $OUT/pytest_gpu.log 2>&1; rc=$?
+    tail -3 $OUT/pytest_gpu.log
+    [ $rc -ne 0 ] && exit $rc
+    CFGS="cfg4_50M_150bp"
+  else
+    CFGS="cfg5_10M_150bp_err2"
+  fi
+  for CFG in $CFGS; do
     timeout -k 10 900 bash tools/profile_cmd.sh r04_final_$CFG trx bench.py --config $CFG --steps 5 --warmup 2 --no-cpu-baseline --no-pcie --no-first-call || exit 1
     python tools/pmc_to_traffic.py gpurun_out/prof_r04_final_$CFG $CFG > $OUT/traffic_$CFG.json || exit 1
     cp gpurun_out/prof_r04_final_$CFG/summary.txt $OUT/rocprof_$CFG.txt
@@ -26,6 +31,7 @@ if [ "$PART" = A ]; then
     echo "$CFG: $(python3 -c "import json,sys; d=json.loads(open('$OUT/bench_$CFG.json').read().strip().splitlines()[-1]); print(d['ms_per_step'], d['value'], d['roofline']['frac'], d['roofline']['traffic'], d.get('ms_end_to_end'))")"
   done
   cp profiles/hbm_traffic.json $OUT/hbm_traffic.json
+  [ "$PART" = A1 ] && exit 0
   for CFG in cfg2_1M_150bp cfg3_5M_150bp; do
     timeout -k 10 600 python bench.py --config $CFG > $OUT/bench_$CFG.json 2> $OUT/bench_$CFG.err || { tail -20 $OUT/bench_$CFG.err; exit 1; }
     echo "$CFG: $(python3 -c "import json,sys; d=json.loads(open('$OUT/bench_$CFG.json').read().strip().splitlines()[-1]); print(d['ms_per_step'], d['value'])")"
