@@ -141,6 +141,10 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
     const bool clustered = local && pp.cluster_eq != 0;
     e->pairs_timed = false;
     e->store_timed = false;
+    e->pile_timed = false;
+    // the probe through piles: all sources in entry order, reads of one length without masks (prefsuf_pile.hip: pile_plan)
+    const bool pile = clustered && e->opt_pile != 0 && e->opt_cluster_pairs != 0 && e->opt_cluster_order != 0 && pp.local_sw == 1 && pp.keys_shared == 0 &&
+                      src_begin == 0 && src_end == pp.nd.n && pile_plan(cfg, pp.cluster, pp.cluster_eq, pp.uniform_len, pp.nd.from != nullptr || pp.nd.to != nullptr);
     e->loc_second_used = false;
     uint32_t n_buckets = 0, filter_bits = 0;
     bool have_table = false;
@@ -192,6 +196,19 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
                                             (uint32_t *) e->cl_vals[1].p, (const uint32_t *) e->cl_meta.p, pp.uniform_len, e->sort_temp.p,
                                             cluster_sort_temp_bytes((uint64_t) nd.n), e->cl_store.p, e->cl_dir.p, pp.keys_shared == 1, e->ev[EV_SORT],
                                             e->ev[EV_GATHER], cnt + CNT_TOTAL + 1, e->opt_test_unsorted_index != 0, s));
+            HIP_TRY(e, hipEventRecord(e->ev[EV_DIR], s));
+            e->pile_n = -1;
+            if (pile) {
+                // piles of the entry array: belongs to the index (a function of the targets alone), read by k_pile_probe
+                if ((rc = alga_ensure(e, e->cl_pile_rec, pile_record_bytes((uint64_t) nd.n)))) return rc;
+                if ((rc = alga_ensure(e, e->cl_pile_sub, (size_t) nd.n + 64))) return rc;
+                if ((rc = alga_ensure(e, e->cl_pile_cnt, 2 * sizeof(unsigned long long)))) return rc;
+                launch_pile_build(cc, pp.uniform_len, e->cl_store.p, (uint64_t) nd.n, e->cl_dir.p, e->cl_pile_rec.p, (uint8_t *) e->cl_pile_sub.p,
+                                  (unsigned long long *) e->cl_pile_cnt.p, s);
+                if ((rc = alga_check_launch(e, "k_pile_build"))) return rc;
+                e->pile_n = nd.n; e->pile_words = (const void *) nd.words;
+                e->pile_timed = nd.n > 0;
+            }
             e->store_timed = nd.n > 0;
             e->store_n = nd.n; e->store_words = (const void *) nd.words; e->store_eq = pp.cluster_eq; e->store_buckets = cc.n_buckets;
             e->store_run_begin = run_begin; e->store_run_end = run_end;
@@ -232,15 +249,26 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
                 // all sources: in the order of the entry array (consecutive sources share a locus: option cluster_order); a range of
                 // ids (a rank's share, a piece): in id order
                 const bool by_key = e->opt_cluster_order != 0 && src_begin == 0 && src_end == nd.n;
+                const bool piled = pile && e->pile_n == nd.n && e->pile_words == (const void *) nd.words;
+                if (piled) {
+                    HIP_TRY(e, hipMemsetAsync(e->loc_first.p, 0xFF, (size_t) (n_src + 1) * sizeof(unsigned long long), s));     // "no edge": k_pile_deg
+                    // k_pile_probe first; it and k_probe_stream read the same two counters k_pile_build left and exactly one of them works
+                    launch_pile_probe(cfg, cc, pp.uniform_len, e->cl_store.p, (uint64_t) nd.n, nd.n, e->cl_dir.p, e->cl_pile_rec.p, (const uint8_t *) e->cl_pile_sub.p,
+                                      e->cl_runs.p, cnt, (uint32_t *) e->outdeg.p, (unsigned long long *) e->loc_first.p, (unsigned long long *) e->loc_second.p,
+                                      (int32_t *) e->cl_defer.p, (uint32_t) n_src, (const unsigned long long *) e->cl_pile_cnt.p, e->n_cu, s);
+                    if ((rc = alga_check_launch(e, "k_pile_probe"))) return rc;
+                }
                 launch_probe_stream(nd, cfg, cc, pp.cluster_eq, e->cl_store.p, e->cl_dir.p, e->cl_runs.p, (const uint8_t *) e->cl_nruns.p,
                                     src_begin, src_end, by_key, cnt, e->n_cu, (uint32_t *) e->outdeg.p, (unsigned long long *) e->loc_first.p,
-                                    (unsigned long long *) e->loc_second.p, (int32_t *) e->cl_defer.p, (uint32_t) n_src, s);
+                                    (unsigned long long *) e->loc_second.p, (int32_t *) e->cl_defer.p, (uint32_t) n_src,
+                                    piled ? (const unsigned long long *) e->cl_pile_cnt.p : nullptr, s);
                 if ((rc = alga_check_launch(e, "k_probe_stream"))) return rc;
                 HIP_TRY(e, hipEventRecord(e->ev[EV_PAIRS], s));
                 e->pairs_timed = true;
                 launch_probe_clustered(nd, cfg, cc, pp.cluster_eq, e->cl_store.p, e->cl_dir.p, e->cl_runs.p, (const uint8_t *) e->cl_nruns.p, 0,
                                        (int32_t) n_src, (const int32_t *) e->cl_defer.p, src_begin, (uint32_t *) e->rec_dst.p, (unsigned long long *) e->rec_val.p,
                                        cap, cnt, e->n_cu, (uint32_t *) e->outdeg.p, (unsigned long long *) e->loc_first.p, &big, cnt + CNT_DEFERRED, 1, s);
+                if (piled) launch_pile_deg((int32_t) n_src, (unsigned long long *) e->loc_first.p, (uint32_t *) e->outdeg.p, s);
             } else {
                 launch_probe_clustered(nd, cfg, cc, pp.cluster_eq, e->cl_store.p, e->cl_dir.p, e->cl_runs.p, (const uint8_t *) e->cl_nruns.p, src_begin,
                                        src_end, nullptr, src_begin, (uint32_t *) e->rec_dst.p, (unsigned long long *) e->rec_val.p, cap, cnt, e->n_cu,
@@ -295,6 +323,7 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
             e->stats.windows_probed = e->h_counters[CNT_WINDOWS];
             e->stats.slots_scanned = e->h_counters[CNT_SLOTS];
             e->stats.probe_rounds = e->h_counters[CNT_ROUNDS];
+            e->stats.pile_buckets = e->h_counters[CNT_PILE_BUCKETS]; e->stats.pile_irregular = e->h_counters[CNT_PILE_IRREGULAR];
             e->stats.probe_used = clustered ? ALGA_PROBE_CLUSTER : ALGA_PROBE_TABLE;
             if (clustered) e->stats.deferred_sources = e->defer_list_valid ? e->h_counters[CNT_DEFERRED] : n_src;
             return ALGA_OK;
@@ -431,7 +460,8 @@ void store_phase_stats(alga_engine *e) {
     e->stats.ms_keys = ev_ms(e, EV_START, EV_KEYS);
     e->stats.ms_sort = ev_ms(e, EV_KEYS, EV_SORT);
     e->stats.ms_gather = ev_ms(e, EV_SORT, EV_GATHER);
-    e->stats.ms_dir = ev_ms(e, EV_GATHER, EV_SEED);
+    e->stats.ms_dir = ev_ms(e, EV_GATHER, EV_DIR);
+    e->stats.ms_pile = e->pile_timed ? ev_ms(e, EV_DIR, EV_SEED) : 0.0;
 }
 
 } // namespace
@@ -526,6 +556,8 @@ int alga_engine_set_option(alga_engine *e, const char *name, int64_t value) {
         e->opt_cluster_bucket_bias = (int) value;
     } else if (!strcmp(name, "cluster_pairs")) {
         e->opt_cluster_pairs = value != 0;
+    } else if (!strcmp(name, "pile")) {
+        e->opt_pile = value != 0;
     } else if (!strcmp(name, "cluster_order")) {
         e->opt_cluster_order = value != 0;
     } else if (!strcmp(name, "local_big_max")) {

@@ -17,7 +17,7 @@ struct DevBuf {
     size_t cap = 0;
 };
 
-enum { EV_START = 0, EV_SEED, EV_PROBE, EV_GROUP, EV_REDUCE, EV_EMIT, EV_PAIRS, EV_KEYS, EV_SORT, EV_GATHER, EV_COUNT };
+enum { EV_START = 0, EV_SEED, EV_PROBE, EV_GROUP, EV_REDUCE, EV_EMIT, EV_PAIRS, EV_KEYS, EV_SORT, EV_GATHER, EV_DIR, EV_COUNT };
 constexpr int ALGA_STAGE_THREADS = 8;      // worker threads (pinned buffer pairs, streams) of the staged host <-> HBM copies
 
 struct alga_engine {
@@ -54,6 +54,10 @@ struct alga_engine {
     bool   warmed = false;                                  // alga_engine_reserve has run its miniature build (kernel code objects loaded)
     bool   pairs_timed = false;                             // EV_PAIRS was recorded in the last discovery
     bool   store_timed = false;                             // EV_KEYS / EV_SORT / EV_GATHER were recorded in the last discovery
+    int    opt_pile = 1;                                    // option "pile": the probe through piles (prefsuf_pile.hip) where the input allows it
+    bool   pile_timed = false;                              // EV_DIR was recorded in the last discovery (k_pile_build ran behind it)
+    DevBuf cl_pile_rec, cl_pile_sub, cl_pile_cnt;           // pile records (64 B per entry slot), group of every entry, {buckets, irregular buckets}
+    int32_t pile_n = -1; const void *pile_words = nullptr;  // the node set the pile records describe (n < 0: none)
     int    opt_cluster_order = 1;                           // option "cluster_order": k_probe_stream walks all sources in entry-array (key) order (0: id order)
     int    opt_cluster_pairs = 1;                           // option "cluster_pairs": 0 = general kernel only, 1 = k_probe_stream first
     DevBuf cl_keys[2], cl_vals[2], cl_meta, cl_runs, cl_nruns, cl_store, cl_dir;   // clustered minimizer join: sort buffers, per-node minimizer runs, entry array, bucket directory

@@ -752,7 +752,10 @@ template <bool STATS, int EQ, int KF, bool BYKEY>
 __global__ void __launch_bounds__(PROBE_WAVES * 64, clq_occ(EQ, KF, BYKEY))
 k_probe_stream(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__restrict__ store, const uint4 *__restrict__ dir,
                const uint2 *__restrict__ runs, const uint8_t *__restrict__ nruns, int32_t src_begin, int32_t src_end, ProbeOut o,
-               int32_t *__restrict__ defer_list, uint32_t defer_cap) {
+               int32_t *__restrict__ defer_list, uint32_t defer_cap, const unsigned long long *__restrict__ pile_cnt) {
+    // the pile kernel (prefsuf_pile.hip) was launched in front of this one and takes the build unless most buckets are irregular: the
+    // same test on the same two counters, so exactly one of the two kernels does the work -- decided on the device, from this build's data
+    if (pile_cnt != nullptr && pile_cnt[1] * 8ull <= pile_cnt[0]) return;
     constexpr int WC = 4 * EQ - 3;                         // row words of an entry
     constexpr int QW = 24;                                 // staged words per source: the row (<= 13) + the compare's slack, words 16.. stay zero
     constexpr int NS = 12;                                 // source slots: three quads
@@ -1311,7 +1314,8 @@ uint64_t cluster_record_slack(int n_cu, uint64_t n_src) { return cluster_probe_b
 // range is one of positions of the entry array (which holds an entry for every node), the sources are taken in that order
 void launch_probe_stream(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterCfg &cc, int eq, const void *store, const void *dir,
                          const void *runs, const uint8_t *nruns, int32_t src_begin, int32_t src_end, bool by_key, unsigned long long *counters, int n_cu,
-                         uint32_t *deg, unsigned long long *first, unsigned long long *second, int32_t *defer_list, uint32_t defer_cap, hipStream_t s) {
+                         uint32_t *deg, unsigned long long *first, unsigned long long *second, int32_t *defer_list, uint32_t defer_cap,
+                         const unsigned long long *pile_cnt, hipStream_t s) {
     const int64_t ns = (int64_t) src_end - src_begin;
     if (ns <= 0) return;
     const uint64_t quads = ((uint64_t) ns + 3) / 4;
@@ -1321,7 +1325,7 @@ void launch_probe_stream(const NodesDev &nd, const PrefSufCfg &cfg, const Cluste
          block(PROBE_WAVES * 64);
     ProbeOut o{nullptr, nullptr, 0, counters, deg, first, by_key ? 0 : src_begin, second};
     const uint4 *st = (const uint4 *) store;
-#define CLQ_LAUNCH(ST, E, K, BK) hipLaunchKernelGGL((k_probe_stream<ST, E, K, BK>), grid, block, 0, s, nd, cfg, cc, st, (const uint4 *) dir, (const uint2 *) runs, nruns, src_begin, src_end, o, defer_list, defer_cap)
+#define CLQ_LAUNCH(ST, E, K, BK) hipLaunchKernelGGL((k_probe_stream<ST, E, K, BK>), grid, block, 0, s, nd, cfg, cc, st, (const uint4 *) dir, (const uint2 *) runs, nruns, src_begin, src_end, o, defer_list, defer_cap, pile_cnt)
 #define CLQ_ORDER(ST, E, K) do { if (by_key) CLQ_LAUNCH(ST, E, K, true); else CLQ_LAUNCH(ST, E, K, false); } while (0)
 #define CLQ_STATS(E, K) do { if (cfg.stats) CLQ_ORDER(true, E, K); else CLQ_ORDER(false, E, K); } while (0)
     if (eq == 3 && kf == 5)      CLQ_STATS(3, 5);

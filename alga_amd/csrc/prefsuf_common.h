@@ -83,6 +83,8 @@ enum Counter {
     CNT_LOCAL_MAXITEMS,    // largest number of raw overlaps of one source seen by the source-side reduction
     CNT_DEFERRED,          // clustered probe, pair kernel: sources handed to the general kernel
     CNT_ROUNDS,            // clustered probe, quad kernel: rounds (wave iterations), statistics builds only
+    CNT_PILE_BUCKETS,      // pile path: non-empty buckets of the entry array / those it does not take (copied from k_pile_build's counters by k_pile_probe)
+    CNT_PILE_IRREGULAR,
     CNT_TOTAL = 24
 };
 

@@ -59,7 +59,17 @@ void       launch_probe_clustered(const NodesDev &nd, const PrefSufCfg &cfg, con
 void       launch_probe_stream(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterCfg &cc, int eq, const void *store, const void *dir,
                                const void *runs, const uint8_t *nruns, int32_t src_begin, int32_t src_end, bool by_key /* the range is one of entry-array positions */,
                                unsigned long long *counters, int n_cu, uint32_t *deg, unsigned long long *first, unsigned long long *second, int32_t *defer_list,
-                               uint32_t defer_cap, hipStream_t s);
+                               uint32_t defer_cap, const unsigned long long *pile_cnt /* null, or the pile kernel's two counters: leave at once where that kernel works */,
+                               hipStream_t s);
+// the probe through piles (prefsuf_pile.hip)
+void       launch_pile_deg(int32_t n, unsigned long long *first, uint32_t *deg, hipStream_t s);
+bool       pile_plan(const PrefSufCfg &cfg, const ClusterCfg &cc, int eq, int uniform_len, bool masks);
+size_t     pile_record_bytes(uint64_t n);
+void       launch_pile_build(const ClusterCfg &cc, int uniform_len, const void *store, uint64_t n_entries, const void *dir, void *rec, uint8_t *sub,
+                             unsigned long long *pile_cnt /* [0] buckets, [1] irregular buckets */, hipStream_t s);
+void       launch_pile_probe(const PrefSufCfg &cfg, const ClusterCfg &cc, int uniform_len, const void *store, uint64_t n_entries, int n_nodes, const void *dir,
+                             const void *rec, const uint8_t *sub, const void *runs, unsigned long long *counters, uint32_t *deg, unsigned long long *first,
+                             unsigned long long *second, int32_t *defer_list, uint32_t defer_cap, const unsigned long long *pile_cnt, int n_cu, hipStream_t s);
 
 size_t     sort_u32_pairs_temp_bytes(uint64_t n);
 hipError_t sort_u32_pairs(void *temp, size_t temp_bytes, const uint32_t *keys_in, uint32_t *keys_out, const uint32_t *vals_in, uint32_t *vals_out,

@@ -1,0 +1,433 @@
+// alga_amd/csrc/prefsuf_pile.hip -- the probe of the clustered minimizer join through PILES (gfx950).
+//
+// k_probe_stream (prefsuf_cluster.hip) verifies every (source, entry) pair with a 2-bit compare of the whole overlap and every item
+// against its predecessor's overhang: ~16 row compares and ~11 overhang compares per 150-bp source at 30x, one lane each.  On
+// error-free reads nearly all of them say what one compare per READ already says.  The targets filed under one minimizer k-mer (one
+// bucket of the entry array, or one of the few k-mers that share it) all contain that k-mer, so they lie on ONE coordinate axis --
+// the k-mer at [0, k), target C on [-m_C, -m_C + |C|) -- and if each of them equals one CONSENSUS string S on its whole extent (a
+// PILE), then
+//   * a source B that holds the k-mer at q lies at [-q, -q + |B|) of the same axis, and  B[p..] == C[..|B| - p]  at p = q - m_C  holds
+//     for exactly the targets that start right of the LAST position where B differs from S: one compare of B against S per
+//     (source, minimizer run) decides every entry of the pile at once, and the set of offsets that hold an item is the pile's set
+//     of m_C, mirrored and shifted by q;
+//   * two targets of one pile agree wherever both are defined: the overhang compare of the source-side reduction (the via B -> C,
+//     src/GraphCreators/GraphCreatorPrefSuf.cpp:434-451) is implied inside a pile, and between the piles of two runs of a source it is
+//     ONE compare of the two consensus strings past the source's end.
+// With reads of one length and no alignFrom / alignTo mask (every BASELINE configuration) the reduction of a regular source is then a
+// function of its 64-bit offset set alone (prefsuf_device.h local_reduce, fast path, with lenC == lenB everywhere): an item is removed
+// iff another item sits at most G = len - max(rsoemo, Lmin) offsets before it, one or two items stand, the cap of three small overlaps
+// is a population count.  Only the one or two targets that stand are looked up by id.
+//
+//   k_pile_build   one lane per ENTRY of the entry array: per bucket the groups of equal minimizer k-mer (<= PILE_MAXSUB), per group the
+//                  consensus (leftmost-starting | rightmost-ending member), every member verified against it, the mirrored m_C set;
+//                  a 64-byte record per group at the slot of its first member, a byte per entry (its group).  A bucket where any of
+//                  it fails (a member that differs from the consensus, two members at one m_C, more groups or entries than fit) is
+//                  flagged: its sources go to the general kernel.
+//   k_pile_probe   one lane per SOURCE (in the order of the entry array): its runs from the last window to the first, per run the
+//                  bucket's records; regular sources get their edges, the others go on the defer list of k_probe_clustered.
+// Nothing is approximated: every decision either follows from verified equalities or is handed to the pairwise kernels.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include "prefsuf_common.h"
+#include "prefsuf_kernels.h"
+#include "prefsuf_device.h"
+#include "prefsuf_cluster_device.h"
+
+namespace alga {
+
+constexpr int PB_TILE = 512, PB_HALO = 64, PB_THREADS = PB_TILE + PB_HALO;      // buckets that START in the tile; the halo holds their tails
+constexpr int PILE_SW = 13;                    // consensus words: coordinates -64 .. 143 (m_C <= 63, rows of up to 9 words)
+constexpr int PILE_MAXSUB = 4;                 // k-mer groups of one bucket (two k-mers share one of 2^26 buckets for ~20 % of the buckets at the north-star size)
+constexpr int PILE_EQ = 3;                     // entry size this path takes: rows of up to 9 words (reads of 100 - 150 bp)
+// record (16 words) of a group, at the entry slot of its first member (the LEADER):
+//   w[0 .. 12]  consensus, word k = coordinates -64 + 16 k ..
+//   w[13]       bit 0: the BUCKET is irregular (record of the bucket's first entry only); bits 8..14: slots to the next leader of
+//               the bucket (0: none); bits 16..21: the leader's index in the bucket
+//   w[14], w[15] bit (63 - m) set: a member with m_C == m
+
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(PB_THREADS, 3) k_pile_build(const uint4 *__restrict__ store, uint64_t n_entries, const uint4 *__restrict__ dir, int idx_shift, int kk, int U,
+                                                           uint4 *__restrict__ rec, uint8_t *__restrict__ sub, unsigned long long *__restrict__ pile_cnt) {
+    __shared__ uint32_t sRow[PB_THREADS][PILE_SW];         // the entry's row on the pile's axis, masked to its extent (odd stride: conflict-free)
+    __shared__ unsigned long long sKm[PB_THREADS];         // minimizer k-mer of the entry
+    __shared__ unsigned long long sLead[PB_THREADS];       // per bucket (at its first entry): bit i = entry i leads a group
+    __shared__ unsigned long long sRm[PB_THREADS];         // per leader: mirrored m_C set
+    __shared__ uint32_t sMin[PB_THREADS], sMax[PB_THREADS];    // per leader: m_C << 16 | thread of the member with the smallest / largest m_C
+    __shared__ uint32_t sBad[PB_THREADS];                  // per bucket
+    __shared__ uint32_t sCount[2];
+    const int t = (int) threadIdx.x;
+    const uint64_t base = (uint64_t) blockIdx.x * PB_TILE;
+    const uint64_t j = base + (uint64_t) t;
+    const bool have = j < n_entries;
+    const uint64_t jc = have ? j : (n_entries ? n_entries - 1 : 0);
+    uint32_t row[9];
+    uint32_t key, meta;
+    {
+        const uint4 v0 = store[jc * PILE_EQ], v1 = store[jc * PILE_EQ + 1], v2 = store[jc * PILE_EQ + 2];
+        row[0] = v0.x; row[1] = v0.y; row[2] = v0.z; row[3] = v0.w; row[4] = v1.x; row[5] = v1.y; row[6] = v1.z; row[7] = v1.w; row[8] = v2.x;
+        key = v2.z; meta = v2.w;
+    }
+    const bool tgt = have && key != 0xFFFFFFFFu;
+    uint4 drec = make_uint4(0u, 0u, 0u, 0u);
+    if (tgt) drec = dir[key >> idx_shift];
+    const uint64_t e0 = drec.x;
+    const uint32_t cnt = drec.y;
+    const bool owned = tgt && e0 >= base && e0 < base + PB_TILE && e0 <= j && j - e0 < (uint64_t) cnt;
+    const int s = owned ? (int) (e0 - base) : 0;           // thread of the bucket's first entry
+    const int i = owned ? (int) (j - e0) : 0;              // index of this entry in its bucket
+    const bool part = owned && cnt <= 64u;
+    sLead[t] = 0ull; sRm[t] = 0ull; sMin[t] = 0xFFFFFFFFu; sMax[t] = 0u; sBad[t] = 0u;
+    if (t < 2) sCount[t] = 0u;
+    __syncthreads();
+    // the row on the pile's axis: consensus index x (coordinate x - 64) = nucleotide x - 64 + m of the row = bit 2 x + 2 m of the row padded
+    // with four zero words in front.  The word offset (2 m) >> 5 is one of 0 .. 3: two selects per word, static register indices.
+    const int m = (int) (meta & 63u);
+    uint32_t A[PILE_SW];
+    {
+        const int w0 = (2 * m) >> 5, sh = (2 * m) & 31;
+        const int lo = 2 * (64 - m), hi = lo + 2 * U;      // bits of the axis this entry covers
+        uint32_t Rp[18];
+#pragma unroll
+        for (int k = 0; k < 18; k++) Rp[k] = (k >= 4 && k < 13) ? row[k - 4] : 0u;
+        uint32_t y[PILE_SW + 1];
+#pragma unroll
+        for (int k = 0; k <= PILE_SW; k++) {
+            const uint32_t e = (w0 & 1) ? Rp[k + 1] : Rp[k], f = (w0 & 1) ? Rp[k + 3] : Rp[k + 2];
+            y[k] = (w0 & 2) ? f : e;
+        }
+#pragma unroll
+        for (int k = 0; k < PILE_SW; k++) A[k] = funnel(y[k], y[k + 1], sh) & low_bits32(hi - 32 * k) & ~low_bits32(lo - 32 * k);
+    }
+    const unsigned long long kmask = kk >= 32 ? ~0ull : ((1ull << (2 * kk)) - 1ull);
+    const unsigned long long kmer = (((unsigned long long) A[5] << 32) | A[4]) & kmask;       // coordinates 0 .. k - 1
+    sKm[t] = kmer;
+#pragma unroll
+    for (int k = 0; k < PILE_SW; k++) sRow[t][k] = A[k];
+    __syncthreads();
+    int L = t;                                             // leader: the first entry of the bucket with this k-mer
+    if (part) {
+        for (int u = 0; u < i; u++) if (sKm[s + u] == kmer) { L = s + u; break; }
+        if (L == t) atomicOr(&sLead[s], 1ull << i);
+        atomicMin(&sMin[L], ((uint32_t) m << 16) | (uint32_t) t);
+        atomicMax(&sMax[L], ((uint32_t) m << 16) | (uint32_t) t);
+        const unsigned long long bit = 1ull << (63 - m);
+        if (atomicOr(&sRm[L], bit) & bit) atomicOr(&sBad[s], 1u);          // two members start at the same coordinate
+    }
+    __syncthreads();
+    uint32_t S[PILE_SW];
+#pragma unroll
+    for (int k = 0; k < PILE_SW; k++) S[k] = 0u;
+    if (part) {
+        const int t0 = (int) (sMax[L] & 0xFFFFu), t1 = (int) (sMin[L] & 0xFFFFu);      // leftmost start; rightmost end (one length)
+        const int lo = 2 * (64 - m), hi = lo + 2 * U;
+        uint32_t diff = 0u;
+#pragma unroll
+        for (int k = 0; k < PILE_SW; k++) {
+            S[k] = sRow[t0][k] | sRow[t1][k];
+            diff |= (A[k] ^ S[k]) & low_bits32(hi - 32 * k) & ~low_bits32(lo - 32 * k);
+        }
+        if (diff != 0u) atomicOr(&sBad[s], 1u);
+    }
+    __syncthreads();
+    if (owned) {
+        if (!part) {
+            if (i == 0) { rec[j * 4 + 3] = make_uint4(0u, 1u, 0u, 0u); atomicAdd(&sCount[0], 1u); atomicAdd(&sCount[1], 1u); }
+        } else {
+            sub[j] = (uint8_t) (L - s);
+            const unsigned long long lm = sLead[s];
+            const bool irregular = sBad[s] != 0u || __popcll(lm) > PILE_MAXSUB;
+            if (L == t) {
+                const unsigned long long above = i >= 63 ? 0ull : (lm >> (i + 1));
+                const uint32_t nxt = above ? (uint32_t) __builtin_ctzll(above) + 1u : 0u;
+                const uint32_t head = ((i == 0 && irregular) ? 1u : 0u) | (nxt << 8) | ((uint32_t) i << 16);
+                const unsigned long long rm = sRm[t];
+                rec[j * 4 + 0] = make_uint4(S[0], S[1], S[2], S[3]);
+                rec[j * 4 + 1] = make_uint4(S[4], S[5], S[6], S[7]);
+                rec[j * 4 + 2] = make_uint4(S[8], S[9], S[10], S[11]);
+                rec[j * 4 + 3] = make_uint4(S[12], head, (uint32_t) rm, (uint32_t) (rm >> 32));
+            }
+            if (i == 0) { atomicAdd(&sCount[0], 1u); if (irregular) atomicAdd(&sCount[1], 1u); }
+        }
+    }
+    __syncthreads();
+    // (one workgroup in sixteen reports: the two counters only say whether most buckets are irregular, and 177 k same-address atomics are a millisecond)
+    if (t < 2 && sCount[t] && (blockIdx.x & 15u) == 0u) atomicAdd(&pile_cnt[t], (unsigned long long) sCount[t]);
+}
+
+// ------------------------------------------------------------------------------------------
+// OR of x << 1 .. x << g
+__device__ __forceinline__ unsigned long long smear_up(unsigned long long x, int g /* uniform, 0 .. 63 */) {
+    unsigned long long acc = 0ull, pw = x;                 // pw = OR of x << 0 .. x << (2^b - 1)
+    int done = 0;
+#pragma unroll
+    for (int b = 0; b < 6; b++) {
+        if ((g >> b) & 1) { acc |= pw << (done + 1); done += 1 << b; }       // uniform; done + 1 <= 63
+        pw |= pw << (1 << b);
+    }
+    return acc;
+}
+
+constexpr int PP_WAVES = 4;
+#ifndef PP_OCC
+#define PP_OCC 4
+#endif
+// One lane per source.  What bounds this kernel is the CHAIN of dependent memory reads of a lane (own entry -> run list -> directory ->
+// record -> ... -> the targets that stand), not arithmetic: the directory records of all eight run slots are read at once, the first
+// record of the next run is on its way while the current one is compared, the run loop is unrolled over the eight slots (static
+// registers, a wave skips the slots none of its lanes uses), and five workgroups share a CU.
+__global__ void __launch_bounds__(PP_WAVES * 64, PP_OCC) k_pile_probe(PrefSufCfg cfg, ClusterCfg cc, int U, const uint4 *__restrict__ store, uint64_t n_entries, int n_nodes,
+                                                                 const uint4 *__restrict__ dir, const uint4 *__restrict__ rec, const uint8_t *__restrict__ sub,
+                                                                 const uint2 *__restrict__ runs, ProbeOut o, int32_t *__restrict__ defer_list, uint32_t defer_cap,
+                                                                 const unsigned long long *__restrict__ pile_cnt) {
+    __shared__ uint32_t sS[PP_WAVES][64][23];              // per lane: words 0..3 zero, 4..16 the consensus of the record at hand, 17..22 zero
+    __shared__ int32_t sDefer[PP_WAVES][128];              // sources of this wave that wait for the defer list
+    if (blockIdx.x == 0 && threadIdx.x == 0) { o.counters[CNT_PILE_BUCKETS] = pile_cnt[0]; o.counters[CNT_PILE_IRREGULAR] = pile_cnt[1]; }
+    // a build whose buckets are mostly irregular (reads with sequencing errors) is k_probe_stream's: this kernel leaves at once
+    if (pile_cnt[1] * 8ull > pile_cnt[0]) return;
+    const int wave = (int) (threadIdx.x >> 6), lane = lane_id();
+    uint32_t *ss = sS[wave][lane];
+#pragma unroll
+    for (int k = 0; k < 4; k++) ss[k] = 0u;
+#pragma unroll
+    for (int k = 17; k < 23; k++) ss[k] = 0u;
+    // A persistent grid: one global atomic per WAVE for the edge count and one per ~64 deferred sources -- as one workgroup per 256 sources
+    // the kernel made 1.4 M same-address atomics per build, which serialise in the L2 at ~90 per microsecond (6 ms of its 19).
+    uint64_t st_rec = 0;
+    int n_defer = 0;                                       // uniform
+    auto flush_defer = [&]() {                             // convergent
+        if (n_defer == 0) return;
+        unsigned long long basep = 0;
+        if (lane == 0) basep = atomicAdd(&o.counters[CNT_DEFERRED], (unsigned long long) n_defer);
+        basep = ((unsigned long long) (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) (basep >> 32)) << 32) | (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) basep);
+        for (int k = lane; k < n_defer; k += 64)
+            if (basep + (unsigned long long) k < (unsigned long long) defer_cap) defer_list[basep + (unsigned long long) k] = sDefer[wave][k];
+        wave_lds_fence();
+        n_defer = 0;
+    };
+    const uint64_t n_tiles = (n_entries + PP_WAVES * 64 - 1) / (PP_WAVES * 64);
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {      // uniform
+    const uint64_t j = tile * (PP_WAVES * 64) + threadIdx.x;
+    const bool have = j < n_entries;
+    const uint64_t jc = have ? j : n_entries - 1;
+    const uint64_t last = n_entries - 1;
+    uint32_t B[9];
+    int Bs;
+    {
+        const uint4 v0 = store[jc * PILE_EQ], v1 = store[jc * PILE_EQ + 1], v2 = store[jc * PILE_EQ + 2];
+        B[0] = v0.x; B[1] = v0.y; B[2] = v0.z; B[3] = v0.w; B[4] = v1.x; B[5] = v1.y; B[6] = v1.z; B[7] = v1.w; B[8] = v2.x;
+        Bs = (int) min(v2.y, (uint32_t) n_nodes - 1u);
+    }
+    uint32_t rk[CL_RMAX], ry[CL_RMAX];
+    {
+        const uint4 *rp = reinterpret_cast<const uint4 *>(runs + (size_t) Bs * CL_RMAX);
+#pragma unroll
+        for (int c = 0; c < CL_RMAX / 2; c++) { const uint4 v = rp[c]; rk[2 * c] = v.x; ry[2 * c] = v.y; rk[2 * c + 1] = v.z; ry[2 * c + 1] = v.w; }
+    }
+    const int nr_code = have ? (int) (ry[0] >> 24) : 0;
+    bool dfr = nr_code == CL_RUNS_FLAGGED;                 // runs k_node_runs could not list: the general kernel finds them by brute force
+    const bool active = nr_code != 0 && !dfr;
+    const int nr = active ? (nr_code < CL_RMAX ? nr_code : CL_RMAX) : 0;
+    // directory records of all run slots, at once (an unused slot reads the record behind the last bucket)
+    uint32_t dx[CL_RMAX], dnz = 0u;                        // first entry of the run's bucket; bit a: the bucket has entries
+#pragma unroll
+    for (int a = 0; a < CL_RMAX; a++) {
+        const uint4 d = dir[a < nr ? min(rk[a] >> cc.idx_shift, cc.n_buckets) : cc.n_buckets];
+        dx[a] = d.x;
+        dnz |= (a < nr && d.y != 0u) ? 1u << a : 0u;
+    }
+    // the same minimizer twice in one source (a tandem repeat): a target could be an item at two offsets
+#pragma unroll
+    for (int a = 0; a < CL_RMAX; a++)
+#pragma unroll
+        for (int b = a + 1; b < CL_RMAX; b++) dfr = dfr || (b < nr && rk[a] == rk[b]);
+    const int Lbig = cfg.rsoemo > cfg.Lmin ? cfg.rsoemo : cfg.Lmin;
+    const int G = min(max(U - Lbig, 0), 63);               // an item is removed iff another sits 1 .. G offsets before it
+    unsigned long long occ = 0ull;
+    int nkept = 0;
+    uint2 c1 = make_uint2(0u, 0u), c2 = c1;                // the items that stand: {bucket, d | m << 8 | leader << 16}
+    uint32_t Ep[4] = {0u, 0u, 0u, 0u};                     // consensus past the source's end, of the run that gave the last item
+    // one record against the source: the items it gives, the ones of them that stand
+    auto take_record = [&](const uint4 &R0, const uint4 &R1, const uint4 &R2, const uint4 &R3, uint32_t bucket, uint32_t y, bool first, bool on) {
+        const uint32_t head = R3.y;
+        if (on && first && (head & 1u)) dfr = true;
+        on = on && !dfr;
+        const int q = (int) (y & 255u), p0 = (int) ((y >> 8) & 255u), p1 = (int) ((y >> 16) & 255u);
+        ss[4] = R0.x; ss[5] = R0.y; ss[6] = R0.z; ss[7] = R0.w; ss[8] = R1.x; ss[9] = R1.y; ss[10] = R1.z; ss[11] = R1.w;
+        ss[12] = R2.x; ss[13] = R2.y; ss[14] = R2.z; ss[15] = R2.w; ss[16] = R3.x;
+        // position t of the source = consensus index 64 - q + t = bit 2 (128 - q + t) of the padded consensus
+        const int ob = 2 * (128 - min(q, 127)), w0 = ob >> 5, sh = ob & 31;
+        uint32_t x[10];
+#pragma unroll
+        for (int k = 0; k < 10; k++) x[k] = ss[w0 + k];
+        int mism = -1;                                     // last position where the source differs from the consensus
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            const uint32_t dd = (funnel(x[k], x[k + 1], sh) ^ B[k]) & low_bits32(2 * U - 32 * k);
+            mism = dd ? 16 * k + ((31 - __clz((int) dd)) >> 1) : mism;
+        }
+        const unsigned long long rm = ((unsigned long long) R3.w << 32) | R3.z;
+        unsigned long long oc = q <= 63 ? (rm >> (63 - q)) : (q - 63 >= 64 ? 0ull : (rm << (q - 63)));            // offset d = q - m
+        oc &= (p1 >= 64 ? ~0ull : ((1ull << p1) - 1ull)) & ~((1ull << (p0 & 63)) - 1ull) & ~1ull;                 // the run's windows; offset 0 is the source itself
+        if (mism >= 0) oc &= mism >= 63 ? 0ull : ~((2ull << mism) - 1ull);
+        oc = on ? oc : 0ull;
+        if (oc != 0ull) {
+            uint32_t E[4];                                 // the consensus from the source's end on: 64 positions
+            {
+                const int oe = ob + 2 * U, we = oe >> 5, she = oe & 31;
+                uint32_t xe[5];
+#pragma unroll
+                for (int k = 0; k < 5; k++) xe[k] = ss[we + k];
+#pragma unroll
+                for (int k = 0; k < 4; k++) E[k] = funnel(xe[k], xe[k + 1], she);
+            }
+            if (occ != 0ull) {                             // the nearest item before this run's first: do the two consensus strings agree where it overhangs?
+                const int dj = 63 - __clzll((long long) occ);
+                uint32_t df = 0u;
+#pragma unroll
+                for (int k = 0; k < 4; k++) df |= (E[k] ^ Ep[k]) & low_bits32(2 * dj - 32 * k);
+                if (df != 0u) dfr = true;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) Ep[k] = E[k];
+            const unsigned long long all = occ | oc;
+            unsigned long long kr = all & ~smear_up(all, G) & oc;          // this record's items that stand (what follows only adds higher offsets)
+            while (kr != 0ull) {
+                const int d = __builtin_ctzll(kr);
+                kr &= kr - 1ull;
+                const uint2 c = make_uint2(bucket, (uint32_t) d | ((uint32_t) (q - d) << 8) | (((head >> 16) & 63u) << 16));
+                nkept++;
+                if (nkept == 1) c1 = c; else if (nkept == 2) c2 = c; else dfr = true;
+            }
+            occ = all;
+        }
+        return on ? (head >> 8) & 127u : 0u;               // slots to the bucket's next record (0: none)
+    };
+    auto rec_slot = [&](uint32_t first_entry) -> uint64_t { return min((uint64_t) first_entry, last); };    // (clamped: a corrupt directory must not fault)
+    // runs from the one of window 0 upwards (slot 0 holds the last windows); the first record of slot a - 1 is read while slot a is compared
+    uint4 N0, N1, N2, N3;
+    {
+        const uint64_t sl = rec_slot(dx[CL_RMAX - 1]);
+        N0 = rec[sl * 4]; N1 = rec[sl * 4 + 1]; N2 = rec[sl * 4 + 2]; N3 = rec[sl * 4 + 3];
+    }
+#pragma unroll
+    for (int a = CL_RMAX - 1; a >= 0; a--) {
+        const uint4 R0 = N0, R1 = N1, R2 = N2, R3 = N3;
+        if (a > 0) {
+            const uint64_t sl = rec_slot(dx[a - 1]);
+            N0 = rec[sl * 4]; N1 = rec[sl * 4 + 1]; N2 = rec[sl * 4 + 2]; N3 = rec[sl * 4 + 3];
+        }
+        const bool on = ((dnz >> a) & 1u) != 0u && !dfr;
+        if (__ballot(on) == 0ull) continue;                // uniform
+        const uint32_t bucket = min(rk[a] >> cc.idx_shift, cc.n_buckets);
+        uint32_t nxt = take_record(R0, R1, R2, R3, bucket, ry[a], true, on);
+        uint64_t slot = rec_slot(dx[a]);
+        for (int it = 1; it < PILE_MAXSUB && __ballot(nxt != 0u) != 0ull; it++) {       // the other k-mers that share the bucket
+            const bool more = nxt != 0u;
+            slot = min(slot + nxt, last);
+            const uint4 Q0 = rec[slot * 4], Q1 = rec[slot * 4 + 1], Q2 = rec[slot * 4 + 2], Q3 = rec[slot * 4 + 3];
+            nxt = take_record(Q0, Q1, Q2, Q3, bucket, ry[a], false, more);
+        }
+    }
+    // ---- the one or two items that stand: their targets by id ----
+    auto lookup = [&](const uint2 &c) -> uint32_t {
+        const uint4 d = dir[c.x];                          // the member with m_C == mm among the entries of its m_C >> 3 class
+        const int mm = (int) ((c.y >> 8) & 255u), lead = (int) ((c.y >> 16) & 63u);
+        const int cl = mm >> 3;
+        const uint32_t b0 = ((cl < 4 ? d.z : d.w) >> (8 * (cl & 3))) & 255u;
+        const uint32_t b1 = cl >= 7 ? d.y : ((((cl + 1) < 4 ? d.z : d.w) >> (8 * ((cl + 1) & 3))) & 255u);
+        uint32_t id = 0xFFFFFFFFu;
+        for (uint32_t e = b0; e < b1 && e < 64u; e++) {
+            const uint64_t ei = min((uint64_t) d.x + e, last);
+            const uint4 tail = store[ei * PILE_EQ + 2];
+            if ((int) (tail.w & 63u) == mm && (int) sub[ei] == lead) id = tail.y;
+        }
+        return id;
+    };
+    if (active && !dfr && nkept > 0) {
+        const uint32_t id1 = lookup(c1);
+        const int d1 = (int) (c1.y & 255u);
+        uint32_t id2 = 0u;
+        int d2 = 0;
+        bool two = false;
+        if (nkept == 2) {
+            id2 = lookup(c2);
+            d2 = (int) (c2.y & 255u);
+            // the cap of three small overlaps per source: the second item stands if it is big or fewer than three small items lie before it
+            const int ds0 = U - cfg.rsoemo + 1;
+            const unsigned long long lowm = ds0 <= 0 ? 0ull : (ds0 >= 64 ? ~0ull : ((1ull << ds0) - 1ull));
+            two = d2 < ds0 || __popcll(occ & ((1ull << d2) - 1ull) & ~lowm) < 3;
+        }
+        if (id1 == 0xFFFFFFFFu || (nkept == 2 && id2 == 0xFFFFFFFFu)) dfr = true;       // (cannot happen: the set said a member sits there)
+        else {
+            // ONE scattered store per source: the out-degree rides in bit 8 of the slot and k_pile_deg, a streaming pass, moves it to deg[]
+            // (a second scattered 4-byte store per source cost this kernel 6 ms of its 19 at the north-star size)
+            o.first[Bs - o.src_base] = ((unsigned long long) id1 << 32) | (uint32_t) d1 | (two ? 0x100u : 0u);
+            if (two) o.second[Bs - o.src_base] = ((unsigned long long) id2 << 32) | (uint32_t) d2;
+            st_rec += two ? 2 : 1;
+        }
+    }
+    // ---- the others: to the general kernel ----
+    dfr = dfr && nr_code != 0;
+    const uint64_t dm = __ballot(dfr);
+    if (dm != 0ull) {                                      // uniform
+        if (dfr) sDefer[wave][n_defer + (int) __builtin_amdgcn_mbcnt_hi((uint32_t) (dm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) dm, 0u))] = Bs;
+        n_defer += __popcll(dm);
+        wave_lds_fence();
+        if (n_defer >= 64) flush_defer();
+    }
+    }                                                      // tiles
+    flush_defer();
+    st_rec = wave_sum_u64(st_rec);
+    if (lane == 0 && st_rec) atomicAdd(&o.counters[CNT_VALID_RECORDS], (unsigned long long) st_rec);
+}
+
+// out-degrees of the sources k_pile_probe finished (it left them in bit 8 of the source's slot; the slots were filled with ones before)
+__global__ void __launch_bounds__(256) k_pile_deg(int32_t n, unsigned long long *__restrict__ first, uint32_t *__restrict__ deg) {
+    const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long f = first[i];
+    if (f == LOCAL_FIRST_NONE || deg[i] != 0u) return;     // no edge, or a source the pairwise kernels finished (deg and slot are theirs)
+    deg[i] = 1u + (uint32_t) ((f >> 8) & 1ull);
+    if (f & 0x100ull) first[i] = f & ~0x100ull;
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+// Does the pile path take this input?  Entries of three 16-byte pieces (rows of up to 9 words: reads of up to 144 nt after ALGA's
+// trimming), ONE read length and no alignFrom / alignTo mask (the reduction is then a function of the offset set), one-word offset sets.
+// A build that collects the work counters (cfg.stats) takes the pairwise kernels: the counters are defined by what those do.
+bool pile_plan(const PrefSufCfg &cfg, const ClusterCfg &cc, int eq, int uniform_len, bool masks) {
+    if (eq != PILE_EQ || uniform_len <= 0 || masks || cfg.stats) return false;
+    if (uniform_len > 144 || blocks_of(uniform_len) > 9) return false;
+    if (uniform_len - cfg.Lmin + 1 > 64 || cc.w > 64 || cc.kk > 32 || cc.kk < 1) return false;
+    return true;
+}
+size_t pile_record_bytes(uint64_t n) { return (size_t) (n + 2) * 64; }
+
+void launch_pile_build(const ClusterCfg &cc, int uniform_len, const void *store, uint64_t n_entries, const void *dir, void *rec, uint8_t *sub,
+                       unsigned long long *pile_cnt, hipStream_t s) {
+    (void) hipMemsetAsync(pile_cnt, 0, 2 * sizeof(unsigned long long), s);
+    if (n_entries == 0) return;
+    const dim3 grid((unsigned) ((n_entries + PB_TILE - 1) / PB_TILE)), block(PB_THREADS);
+    hipLaunchKernelGGL(k_pile_build, grid, block, 0, s, (const uint4 *) store, n_entries, (const uint4 *) dir, cc.idx_shift, cc.kk, uniform_len, (uint4 *) rec, sub, pile_cnt);
+}
+
+void launch_pile_probe(const PrefSufCfg &cfg, const ClusterCfg &cc, int uniform_len, const void *store, uint64_t n_entries, int n_nodes, const void *dir, const void *rec,
+                       const uint8_t *sub, const void *runs, unsigned long long *counters, uint32_t *deg, unsigned long long *first, unsigned long long *second,
+                       int32_t *defer_list, uint32_t defer_cap, const unsigned long long *pile_cnt, int n_cu, hipStream_t s) {
+    if (n_entries == 0) return;
+    ProbeOut o{};
+    o.counters = counters; o.deg = deg; o.first = first; o.second = second; o.src_base = 0;
+    const uint64_t tiles = (n_entries + PP_WAVES * 64 - 1) / (PP_WAVES * 64);
+    const dim3 grid((unsigned) std::max<uint64_t>(1, std::min<uint64_t>(tiles, (uint64_t) std::max(1, n_cu) * PP_OCC))), block(PP_WAVES * 64);
+    hipLaunchKernelGGL(k_pile_probe, grid, block, 0, s, cfg, cc, uniform_len, (const uint4 *) store, n_entries, n_nodes, (const uint4 *) dir, (const uint4 *) rec, sub,
+                       (const uint2 *) runs, o, defer_list, defer_cap, pile_cnt);
+}
+
+void launch_pile_deg(int32_t n, unsigned long long *first, uint32_t *deg, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_pile_deg, dim3((unsigned) (((int64_t) n + 255) / 256)), dim3(256), 0, s, n, first, deg);
+}
+
+} // namespace alga

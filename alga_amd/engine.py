@@ -42,7 +42,8 @@ class PrefSufStats(C.Structure):
                 ("ms_probe", C.c_double), ("ms_group", C.c_double), ("ms_reduce", C.c_double), ("ms_emit", C.c_double),
                 ("nodes_live", C.c_uint64), ("reduction_used", C.c_uint64), ("generic_sources", C.c_uint64),
                 ("big_sources", C.c_uint64), ("probe_used", C.c_uint64), ("deferred_sources", C.c_uint64), ("ms_probe_pairs", C.c_double),
-                ("ms_keys", C.c_double), ("ms_sort", C.c_double), ("ms_gather", C.c_double), ("ms_dir", C.c_double), ("probe_rounds", C.c_uint64)]
+                ("ms_keys", C.c_double), ("ms_sort", C.c_double), ("ms_gather", C.c_double), ("ms_dir", C.c_double), ("probe_rounds", C.c_uint64), ("ms_pile", C.c_double),
+                ("pile_buckets", C.c_uint64), ("pile_irregular", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ALGA_AMD_ABI_VERSION 5
+#define ALGA_AMD_ABI_VERSION 6
 
 typedef enum {
     ALGA_OK = 0,
@@ -125,6 +125,9 @@ typedef struct {
     double   ms_keys, ms_sort, ms_gather, ms_dir; /* CLUSTER probe: the parts of ms_seed -- k_node_runs, radix sort of (key, id),
                                      k_tgt_gather, k_tgt_dir (0 for a build that reused them: keys_shared)         */
     uint64_t probe_rounds;        /* CLUSTER probe, k_probe_stream: rounds = wave iterations (collect_stats); sources / rounds = sources packed per round */
+    double   ms_pile;             /* CLUSTER probe, option pile: k_pile_build (consensus records of the entry array), part of ms_seed; 0: not run  */
+    uint64_t pile_buckets, pile_irregular;   /* ... non-empty buckets of the entry array / those the pile path does not take (their sources go to the
+                                     general kernel); more than 1 in 8 irregular: k_probe_stream took the build instead of k_pile_probe          */
 } alga_prefsuf_stats;
 
 /* ---- lifetime --------------------------------------------------------------------------- */
@@ -139,6 +142,8 @@ int         alga_engine_device_name(const alga_engine *e, char *buf, size_t bufl
  *   "cluster_bucket_bias"        -8..8: log2 factor on the bucket count of the CLUSTER probe's index (default 0: ~1 entry per bucket)
  *   "cluster_pairs"              0: the CLUSTER probe runs its general kernel only (one source per wave); default 1: k_probe_stream first
  *                                (the entries of consecutive sources packed densely onto the lanes), the general kernel on what it defers
+ *   "pile"                       default 1: reads of one length without masks take the probe through PILES (alga_amd/csrc/prefsuf_pile.hip): one compare
+ *                                of a source against the consensus of a minimizer's targets instead of one per target; 0: always the pairwise kernels
  *   "cluster_order"              default 1: k_probe_stream takes the sources in the order of the entry array (sources of one locus together:
  *                                shared look-ups, cache hits); 0: in id order (what a range of ids always gets)
  *   "local_big_max"              largest per-wave item slice of the SOURCE_SIDE second pass (default -1 = built-in 4096); beyond it

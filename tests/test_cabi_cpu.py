@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), "libalga_amd.so does not export %s" % s
     assert set(syms) == set(alga_amd.engine.EXPORTS)
-    assert lib.alga_abi_version() == 5
+    assert lib.alga_abi_version() == 6
 
 
 def test_library_contains_gfx950_code_object():
