@@ -755,7 +755,7 @@ k_probe_stream(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__restri
                int32_t *__restrict__ defer_list, uint32_t defer_cap, const unsigned long long *__restrict__ pile_cnt) {
     // the pile kernel (prefsuf_pile.hip) was launched in front of this one and takes the build unless most buckets are irregular: the
     // same test on the same two counters, so exactly one of the two kernels does the work -- decided on the device, from this build's data
-    if (pile_cnt != nullptr && pile_cnt[1] * 8ull <= pile_cnt[0]) return;
+    if (pile_cnt != nullptr && pile_cnt[1] * PILE_IRREGULAR_ONE_IN <= pile_cnt[0]) return;
     constexpr int WC = 4 * EQ - 3;                         // row words of an entry
     constexpr int QW = 24;                                 // staged words per source: the row (<= 13) + the compare's slack, words 16.. stay zero
     constexpr int NS = 12;                                 // source slots: three quads

@@ -37,23 +37,36 @@ namespace alga {
 
 constexpr int PB_TILE = 512, PB_HALO = 64, PB_THREADS = PB_TILE + PB_HALO;      // buckets that START in the tile; the halo holds their tails
 constexpr int PILE_SW = 13;                    // consensus words: coordinates -64 .. 143 (m_C <= 63, rows of up to 9 words)
-constexpr int PILE_MAXSUB = 4;                 // k-mer groups of one bucket (two k-mers share one of 2^26 buckets for ~20 % of the buckets at the north-star size)
+constexpr int PILE_MAXSUB = 4;                 // k-mer groups of one bucket (two k-mers share one of 2^26 buckets for ~9 % of the non-empty buckets at the north-star size)
 constexpr int PILE_EQ = 3;                     // entry size this path takes: rows of up to 9 words (reads of 100 - 150 bp)
-// record (16 words) of a group, at the entry slot of its first member (the LEADER):
-//   w[0 .. 12]  consensus, word k = coordinates -64 + 16 k ..
-//   w[13]       bit 0: the BUCKET is irregular (record of the bucket's first entry only); bits 8..14: slots to the next leader of
-//               the bucket (0: none); bits 16..21: the leader's index in the bucket
+// record (16 words) of the k-th group of a bucket (k in the order of the groups' first members), at entry slot first + k:
+//   w[0 .. 12]  consensus, word k = coordinates -64 + 16 k ..;  w[13] unused
 //   w[14], w[15] bit (63 - m) set: a member with m_C == m
+// and the bucket's DIRECTORY record says which group a source's run wants without a second read: k_pile_build rewrites its entry count
+// (dir.y; <= 64 for every bucket this path takes) as
+//   bits 0..6 entries | bits 7..11, 12..16, 17..21, 22..26 tag of group 0 .. 3 | bits 27..28 groups - 1 | bit 30 irregular | bit 31 set
+// tag = low five bits of the k-mer's cluster key, i.e. of the word a run carries (they lie below the bucket bits).  A bucket of more
+// than 64 entries keeps its plain count: bit 31 clear and not empty = not for this path.  run_slice (prefsuf_cluster_device.h) decodes.
 
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(PB_THREADS, 3) k_pile_build(const uint4 *__restrict__ store, uint64_t n_entries, const uint4 *__restrict__ dir, int idx_shift, int kk, int U,
+// Is this a build for the pile path?  pile_cnt = {buckets, irregular buckets} of a SAMPLE of the entry array (its first 1 / 32, in hash order: loci
+// from all over the genome): more than one bucket in PILE_IRREGULAR_ONE_IN irregular -- reads with sequencing errors -- and the sources that
+// would have to go to the general kernel (every source with a run in such a bucket, ~1.2 ms per million) cost more than the pile path saves
+// (~0.09 ms per million sources): k_pile_build, k_pile_probe and k_probe_stream all read the same two counters, decided on the device.
+__device__ __forceinline__ bool pile_declines(const unsigned long long *pile_cnt) { return pile_cnt[1] * PILE_IRREGULAR_ONE_IN > pile_cnt[0]; }
+
+template <bool SAMPLE>
+__global__ void __launch_bounds__(PB_THREADS, 3) k_pile_build(const uint4 *__restrict__ store, uint64_t n_entries, uint4 *__restrict__ dir, ClusterCfg cc, int U,
                                                            uint4 *__restrict__ rec, uint8_t *__restrict__ sub, unsigned long long *__restrict__ pile_cnt) {
+    if (!SAMPLE && pile_declines(pile_cnt)) return;
+    const int idx_shift = cc.idx_shift, kk = cc.kk;
     __shared__ uint32_t sRow[PB_THREADS][PILE_SW];         // the entry's row on the pile's axis, masked to its extent (odd stride: conflict-free)
     __shared__ unsigned long long sKm[PB_THREADS];         // minimizer k-mer of the entry
     __shared__ unsigned long long sLead[PB_THREADS];       // per bucket (at its first entry): bit i = entry i leads a group
     __shared__ unsigned long long sRm[PB_THREADS];         // per leader: mirrored m_C set
     __shared__ uint32_t sMin[PB_THREADS], sMax[PB_THREADS];    // per leader: m_C << 16 | thread of the member with the smallest / largest m_C
     __shared__ uint32_t sBad[PB_THREADS];                  // per bucket
+    __shared__ uint8_t sTag[PB_THREADS];                   // per leader
     __shared__ uint32_t sCount[2];
     const int t = (int) threadIdx.x;
     const uint64_t base = (uint64_t) blockIdx.x * PB_TILE;
@@ -71,7 +84,7 @@ __global__ void __launch_bounds__(PB_THREADS, 3) k_pile_build(const uint4 *__res
     uint4 drec = make_uint4(0u, 0u, 0u, 0u);
     if (tgt) drec = dir[key >> idx_shift];
     const uint64_t e0 = drec.x;
-    const uint32_t cnt = drec.y;
+    const uint32_t cnt = dir_count(drec.y);
     const bool owned = tgt && e0 >= base && e0 < base + PB_TILE && e0 <= j && j - e0 < (uint64_t) cnt;
     const int s = owned ? (int) (e0 - base) : 0;           // thread of the bucket's first entry
     const int i = owned ? (int) (j - e0) : 0;              // index of this entry in its bucket
@@ -88,13 +101,17 @@ __global__ void __launch_bounds__(PB_THREADS, 3) k_pile_build(const uint4 *__res
         const int lo = 2 * (64 - m), hi = lo + 2 * U;      // bits of the axis this entry covers
         uint32_t Rp[18];
 #pragma unroll
-        for (int k = 0; k < 18; k++) Rp[k] = (k >= 4 && k < 13) ? row[k - 4] : 0u;
-        uint32_t y[PILE_SW + 1];
+        for (int k = 0; k < 18; k++) Rp[k] = 0u;
 #pragma unroll
-        for (int k = 0; k <= PILE_SW; k++) {
-            const uint32_t e = (w0 & 1) ? Rp[k + 1] : Rp[k], f = (w0 & 1) ? Rp[k + 3] : Rp[k + 2];
-            y[k] = (w0 & 2) ? f : e;
-        }
+        for (int k = 0; k < 9; k++) Rp[4 + k] = row[k];
+        // (bit masks the compiler cannot see through: written as selects, hipcc turns the two stages into ONE dynamically indexed array in scratch)
+        uint32_t m1 = 0u - (uint32_t) (w0 & 1), m2 = 0u - (uint32_t) ((w0 >> 1) & 1);
+        asm volatile("" : "+v"(m1), "+v"(m2));
+        uint32_t y1[PILE_SW + 3], y[PILE_SW + 1];
+#pragma unroll
+        for (int k = 0; k < PILE_SW + 3; k++) y1[k] = (Rp[k + 1] & m1) | (Rp[k] & ~m1);
+#pragma unroll
+        for (int k = 0; k <= PILE_SW; k++) y[k] = (y1[k + 2] & m2) | (y1[k] & ~m2);
 #pragma unroll
         for (int k = 0; k < PILE_SW; k++) A[k] = funnel(y[k], y[k + 1], sh) & low_bits32(hi - 32 * k) & ~low_bits32(lo - 32 * k);
     }
@@ -107,7 +124,10 @@ __global__ void __launch_bounds__(PB_THREADS, 3) k_pile_build(const uint4 *__res
     int L = t;                                             // leader: the first entry of the bucket with this k-mer
     if (part) {
         for (int u = 0; u < i; u++) if (sKm[s + u] == kmer) { L = s + u; break; }
-        if (L == t) atomicOr(&sLead[s], 1ull << i);
+        if (L == t) {
+            atomicOr(&sLead[s], 1ull << i);
+            sTag[t] = (uint8_t) (cluster_key(kmer_hash((uint32_t) kmer & cc.lo_mask, (uint32_t) (kmer >> 32) & cc.hi_mask), idx_shift - CL_MBITS) & 31u);
+        }
         atomicMin(&sMin[L], ((uint32_t) m << 16) | (uint32_t) t);
         atomicMax(&sMax[L], ((uint32_t) m << 16) | (uint32_t) t);
         const unsigned long long bit = 1ull << (63 - m);
@@ -131,27 +151,40 @@ __global__ void __launch_bounds__(PB_THREADS, 3) k_pile_build(const uint4 *__res
     __syncthreads();
     if (owned) {
         if (!part) {
-            if (i == 0) { rec[j * 4 + 3] = make_uint4(0u, 1u, 0u, 0u); atomicAdd(&sCount[0], 1u); atomicAdd(&sCount[1], 1u); }
+            if (i == 0) { atomicAdd(&sCount[0], 1u); atomicAdd(&sCount[1], 1u); }      // (its plain count stays in the directory: not for this path)
         } else {
-            sub[j] = (uint8_t) (L - s);
             const unsigned long long lm = sLead[s];
-            const bool irregular = sBad[s] != 0u || __popcll(lm) > PILE_MAXSUB;
-            if (L == t) {
-                const unsigned long long above = i >= 63 ? 0ull : (lm >> (i + 1));
-                const uint32_t nxt = above ? (uint32_t) __builtin_ctzll(above) + 1u : 0u;
-                const uint32_t head = ((i == 0 && irregular) ? 1u : 0u) | (nxt << 8) | ((uint32_t) i << 16);
+            const int nsub = __popcll(lm);
+            const int iL = L - s;                          // index of my group's first member in the bucket
+            const int k = __popcll(lm & ((1ull << iL) - 1ull));                        // my group's number
+            if (!SAMPLE) sub[j] = (uint8_t) k;
+            if (!SAMPLE && L == t && k < PILE_MAXSUB) {
                 const unsigned long long rm = sRm[t];
-                rec[j * 4 + 0] = make_uint4(S[0], S[1], S[2], S[3]);
-                rec[j * 4 + 1] = make_uint4(S[4], S[5], S[6], S[7]);
-                rec[j * 4 + 2] = make_uint4(S[8], S[9], S[10], S[11]);
-                rec[j * 4 + 3] = make_uint4(S[12], head, (uint32_t) rm, (uint32_t) (rm >> 32));
+                const uint64_t slot = e0 + (uint64_t) k;
+                rec[slot * 4 + 0] = make_uint4(S[0], S[1], S[2], S[3]);
+                rec[slot * 4 + 1] = make_uint4(S[4], S[5], S[6], S[7]);
+                rec[slot * 4 + 2] = make_uint4(S[8], S[9], S[10], S[11]);
+                rec[slot * 4 + 3] = make_uint4(S[12], 0u, (uint32_t) rm, (uint32_t) (rm >> 32));
             }
-            if (i == 0) { atomicAdd(&sCount[0], 1u); if (irregular) atomicAdd(&sCount[1], 1u); }
+            if (i == 0) {
+                // the bucket's directory record: which group a run wants (tags of the first three groups' leaders)
+                uint32_t tg[PILE_MAXSUB] = {0u, 0u, 0u, 0u};
+                unsigned long long rest = lm;
+#pragma unroll
+                for (int g = 0; g < PILE_MAXSUB; g++) {
+                    if (rest) { tg[g] = sTag[s + __builtin_ctzll(rest)]; rest &= rest - 1ull; }
+                }
+                const bool irregular = sBad[s] != 0u || nsub > PILE_MAXSUB;
+                const uint32_t ns1 = (uint32_t) (nsub < PILE_MAXSUB ? nsub : PILE_MAXSUB) - 1u;
+                if (!SAMPLE) reinterpret_cast<uint32_t *>(dir + (key >> idx_shift))[1] =
+                    cnt | (tg[0] << 7) | (tg[1] << 12) | (tg[2] << 17) | (tg[3] << 22) | (ns1 << 27) | (irregular ? 1u << 30 : 0u) | 0x80000000u;
+                atomicAdd(&sCount[0], 1u);
+                if (irregular) atomicAdd(&sCount[1], 1u);
+            }
         }
     }
     __syncthreads();
-    // (one workgroup in sixteen reports: the two counters only say whether most buckets are irregular, and 177 k same-address atomics are a millisecond)
-    if (t < 2 && sCount[t] && (blockIdx.x & 15u) == 0u) atomicAdd(&pile_cnt[t], (unsigned long long) sCount[t]);
+    if (SAMPLE && t < 2 && sCount[t]) atomicAdd(&pile_cnt[t], (unsigned long long) sCount[t]);      // (the sample is a few thousand workgroups)
 }
 
 // ------------------------------------------------------------------------------------------
@@ -183,7 +216,7 @@ __global__ void __launch_bounds__(PP_WAVES * 64, PP_OCC) k_pile_probe(PrefSufCfg
     __shared__ int32_t sDefer[PP_WAVES][128];              // sources of this wave that wait for the defer list
     if (blockIdx.x == 0 && threadIdx.x == 0) { o.counters[CNT_PILE_BUCKETS] = pile_cnt[0]; o.counters[CNT_PILE_IRREGULAR] = pile_cnt[1]; }
     // a build whose buckets are mostly irregular (reads with sequencing errors) is k_probe_stream's: this kernel leaves at once
-    if (pile_cnt[1] * 8ull > pile_cnt[0]) return;
+    if (pile_declines(pile_cnt)) return;
     const int wave = (int) (threadIdx.x >> 6), lane = lane_id();
     uint32_t *ss = sS[wave][lane];
 #pragma unroll
@@ -227,13 +260,26 @@ __global__ void __launch_bounds__(PP_WAVES * 64, PP_OCC) k_pile_probe(PrefSufCfg
     bool dfr = nr_code == CL_RUNS_FLAGGED;                 // runs k_node_runs could not list: the general kernel finds them by brute force
     const bool active = nr_code != 0 && !dfr;
     const int nr = active ? (nr_code < CL_RMAX ? nr_code : CL_RMAX) : 0;
-    // directory records of all run slots, at once (an unused slot reads the record behind the last bucket)
-    uint32_t dx[CL_RMAX], dnz = 0u;                        // first entry of the run's bucket; bit a: the bucket has entries
+    // directory records of all run slots, at once (an unused slot reads the record behind the last bucket).  Which k-mer group of the
+    // bucket a run wants is read off the directory record: the groups whose tag equals the low six bits of the run's cluster key -- one,
+    // except where two k-mers of a bucket share all 32 bits of their hash (3 % of the buckets at the north-star size: 19-mers do not fit
+    // 32 bits); the first of them is taken in the main loop, the others in a short loop behind it (the order of the records is free:
+    // what a source keeps is decided from the complete offset set).
+    uint32_t dx[CL_RMAX], dnz = 0u, more = 0u;             // first entry of the run's bucket | first group << 30; bit a: there is one; 4 bits per slot: further groups
 #pragma unroll
     for (int a = 0; a < CL_RMAX; a++) {
         const uint4 d = dir[a < nr ? min(rk[a] >> cc.idx_shift, cc.n_buckets) : cc.n_buckets];
-        dx[a] = d.x;
-        dnz |= (a < nr && d.y != 0u) ? 1u << a : 0u;
+        const uint32_t y = d.y, tag = rk[a] & 31u;
+        // (bit 31 clear and entries: a bucket k_pile_build left alone -- more than 64 entries; bit 30: one it found irregular)
+        dfr = dfr || (a < nr && y != 0u && ((y >> 31) == 0u || ((y >> 30) & 1u) != 0u));
+        const uint32_t ns = ((y >> 27) & 3u) + 1u;
+        uint32_t mt = (((y >> 7) & 31u) == tag ? 1u : 0u) | ((ns >= 2u && ((y >> 12) & 31u) == tag) ? 2u : 0u) | ((ns >= 3u && ((y >> 17) & 31u) == tag) ? 4u : 0u) |
+                      ((ns >= 4u && ((y >> 22) & 31u) == tag) ? 8u : 0u);
+        mt = (a < nr && (y >> 31) != 0u) ? mt : 0u;
+        const uint32_t g0 = mt ? (uint32_t) __builtin_ctz(mt) : 0u;
+        dx[a] = (d.x & 0x3FFFFFFFu) | (g0 << 30);
+        dnz |= mt ? 1u << a : 0u;
+        more |= (mt & (mt - 1u)) << (4 * a);
     }
     // the same minimizer twice in one source (a tandem repeat): a target could be an item at two offsets
 #pragma unroll
@@ -242,15 +288,13 @@ __global__ void __launch_bounds__(PP_WAVES * 64, PP_OCC) k_pile_probe(PrefSufCfg
         for (int b = a + 1; b < CL_RMAX; b++) dfr = dfr || (b < nr && rk[a] == rk[b]);
     const int Lbig = cfg.rsoemo > cfg.Lmin ? cfg.rsoemo : cfg.Lmin;
     const int G = min(max(U - Lbig, 0), 63);               // an item is removed iff another sits 1 .. G offsets before it
-    unsigned long long occ = 0ull;
-    int nkept = 0;
-    uint2 c1 = make_uint2(0u, 0u), c2 = c1;                // the items that stand: {bucket, d | m << 8 | leader << 16}
-    uint32_t Ep[4] = {0u, 0u, 0u, 0u};                     // consensus past the source's end, of the run that gave the last item
-    // one record against the source: the items it gives, the ones of them that stand
-    auto take_record = [&](const uint4 &R0, const uint4 &R1, const uint4 &R2, const uint4 &R3, uint32_t bucket, uint32_t y, bool first, bool on) {
-        const uint32_t head = R3.y;
-        if (on && first && (head & 1u)) dfr = true;
-        on = on && !dfr;
+    unsigned long long occ = 0ull;                         // offsets that hold an item
+    uint32_t grp = 0u;                                     // 2 bits per slot: the group that gave the slot's items
+    uint32_t Ea[4] = {0u, 0u, 0u, 0u};                     // consensus past the source's end: the longest one seen, valid for `ea_len` positions
+    int ea_len = 0;
+    // one record against the source: the items it gives.  The consensus strings of two runs must agree past the source's end wherever both
+    // are defined -- that is what makes "the overhangs of two items agree" (the via compare of the reduction) hold across runs.
+    auto take_record = [&](const uint4 &R0, const uint4 &R1, const uint4 &R2, const uint4 &R3, int slot_a, uint32_t group, uint32_t y, bool on) {
         const int q = (int) (y & 255u), p0 = (int) ((y >> 8) & 255u), p1 = (int) ((y >> 16) & 255u);
         ss[4] = R0.x; ss[5] = R0.y; ss[6] = R0.z; ss[7] = R0.w; ss[8] = R1.x; ss[9] = R1.y; ss[10] = R1.z; ss[11] = R1.w;
         ss[12] = R2.x; ss[13] = R2.y; ss[14] = R2.z; ss[15] = R2.w; ss[16] = R3.x;
@@ -259,19 +303,22 @@ __global__ void __launch_bounds__(PP_WAVES * 64, PP_OCC) k_pile_probe(PrefSufCfg
         uint32_t x[10];
 #pragma unroll
         for (int k = 0; k < 10; k++) x[k] = ss[w0 + k];
-        int mism = -1;                                     // last position where the source differs from the consensus
+        uint32_t dv = 0u;                                  // last word in which the source differs from the consensus, and which
+        int dk = 0;
 #pragma unroll
         for (int k = 0; k < 9; k++) {
             const uint32_t dd = (funnel(x[k], x[k + 1], sh) ^ B[k]) & low_bits32(2 * U - 32 * k);
-            mism = dd ? 16 * k + ((31 - __clz((int) dd)) >> 1) : mism;
+            dk = dd ? k : dk;
+            dv = dd ? dd : dv;
         }
+        const int mism = dv ? 16 * dk + ((31 - __clz((int) dv)) >> 1) : -1;
         const unsigned long long rm = ((unsigned long long) R3.w << 32) | R3.z;
         unsigned long long oc = q <= 63 ? (rm >> (63 - q)) : (q - 63 >= 64 ? 0ull : (rm << (q - 63)));            // offset d = q - m
         oc &= (p1 >= 64 ? ~0ull : ((1ull << p1) - 1ull)) & ~((1ull << (p0 & 63)) - 1ull) & ~1ull;                 // the run's windows; offset 0 is the source itself
         if (mism >= 0) oc &= mism >= 63 ? 0ull : ~((2ull << mism) - 1ull);
-        oc = on ? oc : 0ull;
+        oc = (on && !dfr) ? oc : 0ull;
         if (oc != 0ull) {
-            uint32_t E[4];                                 // the consensus from the source's end on: 64 positions
+            uint32_t E[4];                                 // the consensus from the source's end on: 64 positions, defined up to the group's rightmost member
             {
                 const int oe = ob + 2 * U, we = oe >> 5, she = oe & 31;
                 uint32_t xe[5];
@@ -280,78 +327,90 @@ __global__ void __launch_bounds__(PP_WAVES * 64, PP_OCC) k_pile_probe(PrefSufCfg
 #pragma unroll
                 for (int k = 0; k < 4; k++) E[k] = funnel(xe[k], xe[k + 1], she);
             }
-            if (occ != 0ull) {                             // the nearest item before this run's first: do the two consensus strings agree where it overhangs?
-                const int dj = 63 - __clzll((long long) occ);
+            const int len = min(64, max(0, q - __clzll((long long) rm)));       // (smallest m_C of the group = clz of its mirrored set)
+            if (occ != 0ull) {
+                const int nb = 2 * min(len, ea_len);
                 uint32_t df = 0u;
 #pragma unroll
-                for (int k = 0; k < 4; k++) df |= (E[k] ^ Ep[k]) & low_bits32(2 * dj - 32 * k);
+                for (int k = 0; k < 4; k++) df |= (E[k] ^ Ea[k]) & low_bits32(nb - 32 * k);
                 if (df != 0u) dfr = true;
             }
+            if (occ == 0ull || len > ea_len) {
 #pragma unroll
-            for (int k = 0; k < 4; k++) Ep[k] = E[k];
-            const unsigned long long all = occ | oc;
-            unsigned long long kr = all & ~smear_up(all, G) & oc;          // this record's items that stand (what follows only adds higher offsets)
-            while (kr != 0ull) {
-                const int d = __builtin_ctzll(kr);
-                kr &= kr - 1ull;
-                const uint2 c = make_uint2(bucket, (uint32_t) d | ((uint32_t) (q - d) << 8) | (((head >> 16) & 63u) << 16));
-                nkept++;
-                if (nkept == 1) c1 = c; else if (nkept == 2) c2 = c; else dfr = true;
+                for (int k = 0; k < 4; k++) Ea[k] = E[k];
+                ea_len = len;
             }
-            occ = all;
+            occ |= oc;
+            grp = (grp & ~(3u << (2 * slot_a))) | (group << (2 * slot_a));
         }
-        return on ? (head >> 8) & 127u : 0u;               // slots to the bucket's next record (0: none)
     };
-    auto rec_slot = [&](uint32_t first_entry) -> uint64_t { return min((uint64_t) first_entry, last); };    // (clamped: a corrupt directory must not fault)
-    // runs from the one of window 0 upwards (slot 0 holds the last windows); the first record of slot a - 1 is read while slot a is compared
+    auto rec_slot = [&](uint32_t dxa, uint32_t group) -> uint64_t { return min((uint64_t) (dxa & 0x3FFFFFFFu) + group, last); };       // (clamped: a corrupt directory must not fault)
+    // the first record of slot a - 1 is read while slot a is compared
     uint4 N0, N1, N2, N3;
     {
-        const uint64_t sl = rec_slot(dx[CL_RMAX - 1]);
+        const uint64_t sl = rec_slot(dx[CL_RMAX - 1], dx[CL_RMAX - 1] >> 30);
         N0 = rec[sl * 4]; N1 = rec[sl * 4 + 1]; N2 = rec[sl * 4 + 2]; N3 = rec[sl * 4 + 3];
     }
 #pragma unroll
     for (int a = CL_RMAX - 1; a >= 0; a--) {
         const uint4 R0 = N0, R1 = N1, R2 = N2, R3 = N3;
         if (a > 0) {
-            const uint64_t sl = rec_slot(dx[a - 1]);
+            const uint64_t sl = rec_slot(dx[a - 1], dx[a - 1] >> 30);
             N0 = rec[sl * 4]; N1 = rec[sl * 4 + 1]; N2 = rec[sl * 4 + 2]; N3 = rec[sl * 4 + 3];
         }
         const bool on = ((dnz >> a) & 1u) != 0u && !dfr;
         if (__ballot(on) == 0ull) continue;                // uniform
-        const uint32_t bucket = min(rk[a] >> cc.idx_shift, cc.n_buckets);
-        uint32_t nxt = take_record(R0, R1, R2, R3, bucket, ry[a], true, on);
-        uint64_t slot = rec_slot(dx[a]);
-        for (int it = 1; it < PILE_MAXSUB && __ballot(nxt != 0u) != 0ull; it++) {       // the other k-mers that share the bucket
-            const bool more = nxt != 0u;
-            slot = min(slot + nxt, last);
-            const uint4 Q0 = rec[slot * 4], Q1 = rec[slot * 4 + 1], Q2 = rec[slot * 4 + 2], Q3 = rec[slot * 4 + 3];
-            nxt = take_record(Q0, Q1, Q2, Q3, bucket, ry[a], false, more);
-        }
+        take_record(R0, R1, R2, R3, a, dx[a] >> 30, ry[a], on);
     }
-    // ---- the one or two items that stand: their targets by id ----
-    auto lookup = [&](const uint2 &c) -> uint32_t {
-        const uint4 d = dir[c.x];                          // the member with m_C == mm among the entries of its m_C >> 3 class
-        const int mm = (int) ((c.y >> 8) & 255u), lead = (int) ((c.y >> 16) & 63u);
-        const int cl = mm >> 3;
-        const uint32_t b0 = ((cl < 4 ? d.z : d.w) >> (8 * (cl & 3))) & 255u;
-        const uint32_t b1 = cl >= 7 ? d.y : ((((cl + 1) < 4 ? d.z : d.w) >> (8 * ((cl + 1) & 3))) & 255u);
+    // the further groups that share a run's tag (hash collisions between k-mers): at most one of a slot's groups holds the source's k-mer
+    more = dfr ? 0u : more;
+    while (__ballot(more != 0u) != 0ull) {                 // uniform
+        const bool on = more != 0u;
+        const int bit = on ? __builtin_ctz(more) : 0;
+        more &= more - 1u;
+        const int a = bit >> 2;
+        const uint32_t g = (uint32_t) (bit & 3);
+        uint32_t ya = ry[0], xa = dx[0];
+#pragma unroll
+        for (int k = 1; k < CL_RMAX; k++) { ya = a == k ? ry[k] : ya; xa = a == k ? dx[k] : xa; }
+        const uint64_t sl = rec_slot(xa, g);
+        const uint4 Q0 = rec[sl * 4], Q1 = rec[sl * 4 + 1], Q2 = rec[sl * 4 + 2], Q3 = rec[sl * 4 + 3];
+        take_record(Q0, Q1, Q2, Q3, a, g, ya, on);
+    }
+    // ---- what the source keeps, from the complete offset set; the one or two targets by id ----
+    const unsigned long long kept = occ & ~smear_up(occ, G);
+    const int nkept = __popcll(kept);
+    if (nkept > 2) dfr = true;
+    auto lookup = [&](int d) -> uint32_t {
+        // the run whose windows hold offset d, its bucket, the group that gave the items; the member with m_C == q - d among the entries of its m_C >> 3 class
+        uint32_t ya = 0u, ka = 0u, ga = 0u;
+#pragma unroll
+        for (int k = 0; k < CL_RMAX; k++) {
+            const bool in = k < nr && d >= (int) ((ry[k] >> 8) & 255u) && d < (int) ((ry[k] >> 16) & 255u);
+            ya = in ? ry[k] : ya; ka = in ? rk[k] : ka; ga = in ? (grp >> (2 * k)) & 3u : ga;
+        }
+        const uint4 dd = dir[min(ka >> cc.idx_shift, cc.n_buckets)];
+        const int mm = (int) (ya & 255u) - d;
+        const int cl = (mm >> 3) & 7;
+        const uint32_t b0 = ((cl < 4 ? dd.z : dd.w) >> (8 * (cl & 3))) & 255u;
+        const uint32_t b1 = cl >= 7 ? dir_count(dd.y) : ((((cl + 1) < 4 ? dd.z : dd.w) >> (8 * ((cl + 1) & 3))) & 255u);
         uint32_t id = 0xFFFFFFFFu;
         for (uint32_t e = b0; e < b1 && e < 64u; e++) {
-            const uint64_t ei = min((uint64_t) d.x + e, last);
+            const uint64_t ei = min((uint64_t) dd.x + e, last);
             const uint4 tail = store[ei * PILE_EQ + 2];
-            if ((int) (tail.w & 63u) == mm && (int) sub[ei] == lead) id = tail.y;
+            if ((int) (tail.w & 63u) == mm && (uint32_t) sub[ei] == ga) id = tail.y;
         }
         return id;
     };
     if (active && !dfr && nkept > 0) {
-        const uint32_t id1 = lookup(c1);
-        const int d1 = (int) (c1.y & 255u);
+        const int d1 = __builtin_ctzll(kept);
+        const uint32_t id1 = lookup(d1);
         uint32_t id2 = 0u;
         int d2 = 0;
         bool two = false;
         if (nkept == 2) {
-            id2 = lookup(c2);
-            d2 = (int) (c2.y & 255u);
+            d2 = 63 - __clzll((long long) kept);
+            id2 = lookup(d2);
             // the cap of three small overlaps per source: the second item stands if it is big or fewer than three small items lie before it
             const int ds0 = U - cfg.rsoemo + 1;
             const unsigned long long lowm = ds0 <= 0 ? 0ull : (ds0 >= 64 ? ~0ull : ((1ull << ds0) - 1ull));
@@ -360,7 +419,7 @@ __global__ void __launch_bounds__(PP_WAVES * 64, PP_OCC) k_pile_probe(PrefSufCfg
         if (id1 == 0xFFFFFFFFu || (nkept == 2 && id2 == 0xFFFFFFFFu)) dfr = true;       // (cannot happen: the set said a member sits there)
         else {
             // ONE scattered store per source: the out-degree rides in bit 8 of the slot and k_pile_deg, a streaming pass, moves it to deg[]
-            // (a second scattered 4-byte store per source cost this kernel 6 ms of its 19 at the north-star size)
+            // (a second scattered 4-byte store per source costs this kernel 2.8 ms at the north-star size, the streaming pass 0.3)
             o.first[Bs - o.src_base] = ((unsigned long long) id1 << 32) | (uint32_t) d1 | (two ? 0x100u : 0u);
             if (two) o.second[Bs - o.src_base] = ((unsigned long long) id2 << 32) | (uint32_t) d2;
             st_rec += two ? 2 : 1;
@@ -405,12 +464,14 @@ bool pile_plan(const PrefSufCfg &cfg, const ClusterCfg &cc, int eq, int uniform_
 }
 size_t pile_record_bytes(uint64_t n) { return (size_t) (n + 2) * 64; }
 
-void launch_pile_build(const ClusterCfg &cc, int uniform_len, const void *store, uint64_t n_entries, const void *dir, void *rec, uint8_t *sub,
+void launch_pile_build(const ClusterCfg &cc, int uniform_len, const void *store, uint64_t n_entries, void *dir, void *rec, uint8_t *sub,
                        unsigned long long *pile_cnt, hipStream_t s) {
     (void) hipMemsetAsync(pile_cnt, 0, 2 * sizeof(unsigned long long), s);
     if (n_entries == 0) return;
-    const dim3 grid((unsigned) ((n_entries + PB_TILE - 1) / PB_TILE)), block(PB_THREADS);
-    hipLaunchKernelGGL(k_pile_build, grid, block, 0, s, (const uint4 *) store, n_entries, (const uint4 *) dir, cc.idx_shift, cc.kk, uniform_len, (uint4 *) rec, sub, pile_cnt);
+    const uint64_t tiles = (n_entries + PB_TILE - 1) / PB_TILE;
+    const dim3 grid((unsigned) tiles), sample((unsigned) std::max<uint64_t>(1, std::min<uint64_t>(tiles, std::max<uint64_t>(64, tiles / 32)))), block(PB_THREADS);
+    hipLaunchKernelGGL((k_pile_build<true>), sample, block, 0, s, (const uint4 *) store, n_entries, (uint4 *) dir, cc, uniform_len, (uint4 *) rec, sub, pile_cnt);
+    hipLaunchKernelGGL((k_pile_build<false>), grid, block, 0, s, (const uint4 *) store, n_entries, (uint4 *) dir, cc, uniform_len, (uint4 *) rec, sub, pile_cnt);
 }
 
 void launch_pile_probe(const PrefSufCfg &cfg, const ClusterCfg &cc, int uniform_len, const void *store, uint64_t n_entries, int n_nodes, const void *dir, const void *rec,

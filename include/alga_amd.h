@@ -126,8 +126,9 @@ typedef struct {
                                      k_tgt_gather, k_tgt_dir (0 for a build that reused them: keys_shared)         */
     uint64_t probe_rounds;        /* CLUSTER probe, k_probe_stream: rounds = wave iterations (collect_stats); sources / rounds = sources packed per round */
     double   ms_pile;             /* CLUSTER probe, option pile: k_pile_build (consensus records of the entry array), part of ms_seed; 0: not run  */
-    uint64_t pile_buckets, pile_irregular;   /* ... non-empty buckets of the entry array / those the pile path does not take (their sources go to the
-                                     general kernel); more than 1 in 8 irregular: k_probe_stream took the build instead of k_pile_probe          */
+    uint64_t pile_buckets, pile_irregular;   /* ... non-empty buckets in a SAMPLE of the entry array (its first 1/32) / those of them the pile path does
+                                     not take (a source with a run in such a bucket goes to the general kernel); more than 1 in 40 irregular
+                                     (reads with sequencing errors): the pairwise kernel k_probe_stream took the build instead of k_pile_probe   */
 } alga_prefsuf_stats;
 
 /* ---- lifetime --------------------------------------------------------------------------- */
