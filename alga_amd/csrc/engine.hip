@@ -251,7 +251,6 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
                 const bool by_key = e->opt_cluster_order != 0 && src_begin == 0 && src_end == nd.n;
                 const bool piled = pile && e->pile_n == nd.n && e->pile_words == (const void *) nd.words;
                 if (piled) {
-                    HIP_TRY(e, hipMemsetAsync(e->loc_first.p, 0xFF, (size_t) (n_src + 1) * sizeof(unsigned long long), s));     // "no edge": k_pile_deg
                     // k_pile_probe first; it and k_probe_stream read the same two counters k_pile_build left and exactly one of them works
                     launch_pile_probe(cfg, cc, pp.uniform_len, e->cl_store.p, (uint64_t) nd.n, nd.n, e->cl_dir.p, e->cl_pile_rec.p, (const uint8_t *) e->cl_pile_sub.p,
                                       e->cl_runs.p, cnt, (uint32_t *) e->outdeg.p, (unsigned long long *) e->loc_first.p, (unsigned long long *) e->loc_second.p,
@@ -268,7 +267,7 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
                 launch_probe_clustered(nd, cfg, cc, pp.cluster_eq, e->cl_store.p, e->cl_dir.p, e->cl_runs.p, (const uint8_t *) e->cl_nruns.p, 0,
                                        (int32_t) n_src, (const int32_t *) e->cl_defer.p, src_begin, (uint32_t *) e->rec_dst.p, (unsigned long long *) e->rec_val.p,
                                        cap, cnt, e->n_cu, (uint32_t *) e->outdeg.p, (unsigned long long *) e->loc_first.p, &big, cnt + CNT_DEFERRED, 1, s);
-                if (piled) launch_pile_deg((int32_t) n_src, (unsigned long long *) e->loc_first.p, (uint32_t *) e->outdeg.p, s);
+                if (piled) launch_pile_deg((int32_t) n_src, (unsigned long long *) e->loc_first.p, (uint32_t *) e->outdeg.p, (const unsigned long long *) e->cl_pile_cnt.p, s);
             } else {
                 launch_probe_clustered(nd, cfg, cc, pp.cluster_eq, e->cl_store.p, e->cl_dir.p, e->cl_runs.p, (const uint8_t *) e->cl_nruns.p, src_begin,
                                        src_end, nullptr, src_begin, (uint32_t *) e->rec_dst.p, (unsigned long long *) e->rec_val.p, cap, cnt, e->n_cu,

@@ -62,7 +62,7 @@ void       launch_probe_stream(const NodesDev &nd, const PrefSufCfg &cfg, const 
                                uint32_t defer_cap, const unsigned long long *pile_cnt /* null, or the pile kernel's two counters: leave at once where that kernel works */,
                                hipStream_t s);
 // the probe through piles (prefsuf_pile.hip)
-void       launch_pile_deg(int32_t n, unsigned long long *first, uint32_t *deg, hipStream_t s);
+void       launch_pile_deg(int32_t n, unsigned long long *first, uint32_t *deg, const unsigned long long *pile_cnt, hipStream_t s);
 bool       pile_plan(const PrefSufCfg &cfg, const ClusterCfg &cc, int eq, int uniform_len, bool masks);
 size_t     pile_record_bytes(uint64_t n);
 void       launch_pile_build(const ClusterCfg &cc, int uniform_len, const void *store, uint64_t n_entries, void *dir /* entry counts rewritten: dir_count */, void *rec, uint8_t *sub,

@@ -402,6 +402,9 @@ __global__ void __launch_bounds__(PP_WAVES * 64, PP_OCC) k_pile_probe(PrefSufCfg
         }
         return id;
     };
+    // every source position writes its slot exactly once (no fill in front of this kernel): the edge(s), or "none" -- also for a source that
+    // goes to the general kernel, which overwrites it if the source has edges
+    unsigned long long slot_val = LOCAL_FIRST_NONE;
     if (active && !dfr && nkept > 0) {
         const int d1 = __builtin_ctzll(kept);
         const uint32_t id1 = lookup(d1);
@@ -420,11 +423,12 @@ __global__ void __launch_bounds__(PP_WAVES * 64, PP_OCC) k_pile_probe(PrefSufCfg
         else {
             // ONE scattered store per source: the out-degree rides in bit 8 of the slot and k_pile_deg, a streaming pass, moves it to deg[]
             // (a second scattered 4-byte store per source costs this kernel 2.8 ms at the north-star size, the streaming pass 0.3)
-            o.first[Bs - o.src_base] = ((unsigned long long) id1 << 32) | (uint32_t) d1 | (two ? 0x100u : 0u);
+            slot_val = ((unsigned long long) id1 << 32) | (uint32_t) d1 | (two ? 0x100u : 0u);
             if (two) o.second[Bs - o.src_base] = ((unsigned long long) id2 << 32) | (uint32_t) d2;
             st_rec += two ? 2 : 1;
         }
     }
+    if (have) o.first[Bs - o.src_base] = slot_val;
     // ---- the others: to the general kernel ----
     dfr = dfr && nr_code != 0;
     const uint64_t dm = __ballot(dfr);
@@ -440,8 +444,10 @@ __global__ void __launch_bounds__(PP_WAVES * 64, PP_OCC) k_pile_probe(PrefSufCfg
     if (lane == 0 && st_rec) atomicAdd(&o.counters[CNT_VALID_RECORDS], (unsigned long long) st_rec);
 }
 
-// out-degrees of the sources k_pile_probe finished (it left them in bit 8 of the source's slot; the slots were filled with ones before)
-__global__ void __launch_bounds__(256) k_pile_deg(int32_t n, unsigned long long *__restrict__ first, uint32_t *__restrict__ deg) {
+// out-degrees of the sources k_pile_probe finished (it left them in bit 8 of the source's slot, and "none" in every other slot); nothing
+// to do where that kernel declined the build (the slots are then what the pairwise kernels made of them)
+__global__ void __launch_bounds__(256) k_pile_deg(int32_t n, unsigned long long *__restrict__ first, uint32_t *__restrict__ deg, const unsigned long long *__restrict__ pile_cnt) {
+    if (pile_declines(pile_cnt)) return;
     const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const unsigned long long f = first[i];
@@ -486,9 +492,9 @@ void launch_pile_probe(const PrefSufCfg &cfg, const ClusterCfg &cc, int uniform_
                        (const uint2 *) runs, o, defer_list, defer_cap, pile_cnt);
 }
 
-void launch_pile_deg(int32_t n, unsigned long long *first, uint32_t *deg, hipStream_t s) {
+void launch_pile_deg(int32_t n, unsigned long long *first, uint32_t *deg, const unsigned long long *pile_cnt, hipStream_t s) {
     if (n <= 0) return;
-    hipLaunchKernelGGL(k_pile_deg, dim3((unsigned) (((int64_t) n + 255) / 256)), dim3(256), 0, s, n, first, deg);
+    hipLaunchKernelGGL(k_pile_deg, dim3((unsigned) (((int64_t) n + 255) / 256)), dim3(256), 0, s, n, first, deg, pile_cnt);
 }
 
 } // namespace alga

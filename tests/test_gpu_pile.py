@@ -1,0 +1,145 @@
+"""GPU parity of the probe through PILES (alga_amd/csrc/prefsuf_pile.hip; engine option "pile", default on).
+
+The pile path replaces the pairwise verification of the clustered probe (src/GraphCreators/GraphCreatorPrefSuf.cpp:238-395 and the via
+compare :434-451) by one compare of a source against the consensus of a minimizer's targets.  It may only ever change HOW a graph is
+computed: every case here is built three ways -- pile path, pairwise kernels, CPU oracle -- and the three edge lists must be identical.
+The cases are chosen to hit what the pile path hands on instead of deciding: duplicate reads (two members at one coordinate), repeats
+(one k-mer, two loci: members that differ from the consensus), tandem repeats (one minimizer twice in a source), coverage gaps (two
+items stand), reads with errors (the build is left to the pairwise kernels), and inputs it does not take at all (several lengths,
+masks)."""
+import numpy as np
+import pytest
+
+import alga_amd
+import gen_reads
+import oracle_lib as O
+from alga_amd import workload
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    e = alga_amd.Engine(0)
+    yield e
+    e.close()
+
+
+def _three_ways(eng, words, lens, lo, rs, af=None, at=None):
+    want, _, _ = O.prefsuf(words, lens, lo, rs, af, at)
+    out = {}
+    for pile in (1, 0):
+        eng.set_option("pile", pile)
+        try:
+            got = eng.prefsuf_host(words, lens, lo, rs, af, at, reduction="source_side")
+        finally:
+            eng.set_option("pile", 1)
+        st = eng.last_stats()
+        assert got.shape == want.shape and (got == want).all(), ("pile", pile, got.shape, want.shape)
+        assert st["edges"] == len(want)
+        out[pile] = st
+    assert out[0]["pile_buckets"] == 0 and out[0]["ms_pile"] == 0.0
+    return out[1], len(want)
+
+
+def _nodes(n, length, G, seed, err=0.0, genome=None):
+    if genome is None:
+        codes, _ = gen_reads.sample_reads(n, length, G, seed, err)
+    else:
+        rng = np.random.default_rng(seed)
+        starts = rng.integers(0, len(genome) - length + 1, size=n)
+        codes = np.stack([genome[s:s + length] for s in starts]).astype(np.uint8)
+        flip = rng.random(n) < 0.5
+        codes[flip] = (3 - codes[flip])[:, ::-1]
+    words, lens, _ = workload.make_nodes(codes)
+    return words, lens
+
+
+@pytest.mark.parametrize("length,coverage", [(150, 30), (150, 8), (100, 40), (126, 25), (150, 120)])
+def test_pile_path_equals_pairwise_and_oracle(eng, length, coverage):
+    G = 60_000
+    words, lens = _nodes(G * coverage // length, length, G, 5 + length + coverage)
+    lo, rs = alga_amd.derive_params(float(length - 6))
+    st, E = _three_ways(eng, words, lens, lo, rs)
+    assert st["probe_used"] == 2 and st["pile_buckets"] > 0, st              # the pile path ran ...
+    assert st["pile_irregular"] * 40 <= st["pile_buckets"]                   # ... and kept the build
+    live = int((lens > 0).sum())
+    assert st["deferred_sources"] <= live // 10, (st["deferred_sources"], live)   # nearly every source finished there
+    assert E > 0
+
+
+@pytest.mark.parametrize("rs", [82, 116, 140, 144, 145])
+def test_pile_path_all_reduction_gaps(eng, rs):
+    """G = len - max(rsoemo, Lmin): from the whole window range (rsoemo = min_overlap) down to 0 (rsoemo past the read length: no overlap is
+    big, every item stands and every source with more than two is handed on); the source-side form takes min_overlap <= rsoemo <= len + 1."""
+    words, lens = _nodes(9000, 150, 40_000, 77)
+    lo, _ = alga_amd.derive_params(144.0)
+    assert lo == 82
+    _three_ways(eng, words, lens, lo, rs)
+
+
+def test_pile_path_with_duplicate_reads(eng):
+    """The same read several times (no duplicate removal in front of the build): two members of a pile at one coordinate."""
+    codes, _ = gen_reads.sample_reads(6000, 150, 30_000, 3)
+    codes = np.concatenate([codes, codes[:1500], codes[100:400]])
+    fw = alga_amd.pack_reads(np.ascontiguousarray(codes[:, 3:147]))
+    rv = alga_amd.pack_reads(np.ascontiguousarray((3 - codes[:, 3:147])[:, ::-1]))
+    words = np.empty((2 * len(codes), fw.shape[1]), dtype=np.uint32)
+    words[0::2], words[1::2] = fw, rv
+    lens = np.full(2 * len(codes), 144, dtype=np.int32)
+    lo, rs = alga_amd.derive_params(144.0)
+    st, _ = _three_ways(eng, words, lens, lo, rs)
+    assert st["pile_buckets"] > 0
+
+
+def test_pile_path_on_repeats_and_tandems(eng):
+    """A genome made of a few units repeated with point differences, plus a short-period stretch: one minimizer at several loci
+    (members that differ from the consensus), one minimizer twice inside a read."""
+    rng = np.random.default_rng(11)
+    unit = rng.integers(0, 4, size=700).astype(np.uint8)
+    parts = []
+    for k in range(12):
+        u = unit.copy()
+        pos = rng.integers(0, len(u), size=3)
+        u[pos] = (u[pos] + 1 + rng.integers(0, 3, size=3)) % 4
+        parts.append(u)
+        parts.append(rng.integers(0, 4, size=300).astype(np.uint8))
+    motif = rng.integers(0, 4, size=37).astype(np.uint8)
+    parts.append(np.tile(motif, 30))
+    genome = np.concatenate(parts)
+    words, lens = _nodes(9000, 150, None, 19, genome=genome)
+    lo, rs = alga_amd.derive_params(144.0)
+    st, _ = _three_ways(eng, words, lens, lo, rs)
+    assert st["pile_buckets"] > 0
+
+
+def test_reads_with_errors_leave_the_build_to_the_pairwise_kernels(eng):
+    words, lens = _nodes(12_000, 150, 40_000, 23, err=0.02)
+    lo, rs = alga_amd.derive_params(144.0)
+    st, _ = _three_ways(eng, words, lens, lo, rs)
+    assert st["pile_buckets"] > 0 and st["pile_irregular"] * 40 > st["pile_buckets"], st      # sampled, found irregular, declined on the device
+
+
+def test_inputs_the_pile_path_does_not_take(eng):
+    """Several read lengths, or an alignFrom / alignTo mask: the reduction is no function of the offset set alone."""
+    codes, lens_nt = gen_reads.sample_reads(5000, 144, 30_000, 31, 0.0, min_length=130)
+    rc = np.zeros_like(codes)
+    for i, l in enumerate(lens_nt):
+        rc[i, :l] = (3 - codes[i, :l])[::-1]
+    both = np.empty((2 * len(codes), codes.shape[1]), dtype=np.uint8)
+    both[0::2], both[1::2] = codes, rc
+    vlens = np.repeat(lens_nt, 2).astype(np.int32)
+    vwords = alga_amd.pack_reads(both, vlens)
+    lo, rs = alga_amd.derive_params(144.0)
+    want, _, _ = O.prefsuf(vwords, vlens, lo, rs)
+    got = eng.prefsuf_host(vwords, vlens, lo, rs)
+    assert got.shape == want.shape and (got == want).all()
+    assert eng.last_stats()["pile_buckets"] == 0
+    words, lens = _nodes(5000, 150, 30_000, 37)
+    lo, rs = alga_amd.derive_params(144.0)
+    rng = np.random.default_rng(2)
+    at = (rng.random(len(lens)) < 0.7).astype(np.uint8)
+    want, _, _ = O.prefsuf(words, lens, lo, rs, None, at)
+    got = eng.prefsuf_host(words, lens, lo, rs, None, at)
+    assert got.shape == want.shape and (got == want).all()
+    assert eng.last_stats()["pile_buckets"] == 0
