@@ -596,6 +596,12 @@ int alga_engine_reserve(alga_engine *e, int32_t n_nodes, int32_t max_len, int32_
             if ((rc = alga_ensure(e, e->cl_defer, (size_t) (n + 64) * sizeof(int32_t)))) return rc;
             if ((rc = alga_ensure(e, e->loc_second, (size_t) (n + 1) * sizeof(unsigned long long)))) return rc;
         }
+        // the pile path, should the reads turn out to have one length and no masks (what reserve assumes: it is told one length)
+        if (e->opt_pile != 0 && e->opt_cluster_pairs != 0 && e->opt_cluster_order != 0 && max_len - min_overlap <= 63 && pile_plan(pp.cfg, pp.cluster, eq, max_len, false)) {
+            if ((rc = alga_ensure(e, e->cl_pile_rec, pile_record_bytes(n)))) return rc;
+            if ((rc = alga_ensure(e, e->cl_pile_sub, (size_t) n + 64))) return rc;
+            if ((rc = alga_ensure(e, e->cl_pile_cnt, 2 * sizeof(unsigned long long)))) return rc;
+        }
     } else {
         const uint32_t nb = seed_buckets_for(n, e->seed_fill_x10);
         if ((rc = alga_ensure(e, e->table, (size_t) nb * SEED_BUCKET * sizeof(unsigned long long)))) return rc;

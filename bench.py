@@ -276,7 +276,7 @@ def run(args, rank, world, local_rank, dist, t_process=None):
     for _ in range(max(0, args.warmup - 1)):
         step()
     sync_all()
-    keys_ms = ("seed", "probe", "group", "reduce", "emit", "exchange", "probe_pairs", "keys", "sort", "gather", "dir", "supplement")
+    keys_ms = ("seed", "probe", "group", "reduce", "emit", "exchange", "probe_pairs", "keys", "sort", "gather", "dir", "pile", "supplement")
     phase = {k: 0.0 for k in keys_ms}
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -302,11 +302,16 @@ def run(args, rank, world, local_rank, dist, t_process=None):
         # defers the others, k_probe_clustered takes the deferred ones.  `roofline` is the dominant one on the sources it FINISHES;
         # `probe_phase` is both kernels over all sources (the HIP events around the two launches).
         n_src = max(1, stats["nodes_live"])
-        deferred = int(stats.get("deferred_sources", 0))
+        # The counted pass above ran the PAIRWISE kernels (a build that collects the work counters does: they are defined by what those
+        # do); the timed steps take the probe through piles where the input allows it (prefsuf_pile.hip): k_pile_probe instead of
+        # k_probe_stream, and its own number of sources handed to the general kernel.
+        piled = world == 1 and s.get("pile_buckets", 0) > 0 and s.get("pile_irregular", 0) * 40 <= s.get("pile_buckets", 0) and ms["pile"] > 0
+        first_name = "k_pile_probe" if piled else "k_probe_stream"
+        deferred = int((s if piled else stats).get("deferred_sources", 0))
         two_kernels = stats.get("probe_used") == 2 and ms["probe_pairs"] > 0 and world == 1
         first_dominates = two_kernels and 2 * ms["probe_pairs"] >= ms["probe"]
         if first_dominates:
-            probe_kernel, kernel_ms = "k_probe_stream", ms["probe_pairs"]
+            probe_kernel, kernel_ms = first_name, ms["probe_pairs"]
             kernel_bytes = alg_probe_launch * (1.0 - deferred / n_src)
         else:
             # one kernel did (nearly all of) the probing -- seed-table probe; the general clustered kernel on reads with sequencing
@@ -316,7 +321,7 @@ def run(args, rank, world, local_rank, dist, t_process=None):
         achieved_kernel = kernel_bytes / (kernel_ms * 1e-3) / 1e9
         src_sha = alga_amd.engine.source_fingerprint()     # of the kernel sources: what the counter passes are keyed on
         traffic = profiled_traffic(args.config, src_sha) if world == 1 else {}
-        tr_kernel = traffic_of(traffic, "k_probe_stream") if first_dominates else (
+        tr_kernel = traffic_of(traffic, first_name) if first_dominates else (
             (traffic_of(traffic, "k_probe_stream") or 0) + (traffic_of(traffic, "k_probe_clustered") or 0) or traffic_of(traffic, "k_probe_sources"))
         out = {
             "metric": "overlap_edges_per_sec", "value": n_edges * args.steps / dt, "unit": "edges/s",
@@ -341,7 +346,7 @@ def run(args, rank, world, local_rank, dist, t_process=None):
                          "units": "%d source nodes finished by this kernel per launch (of %d; %d deferred to k_probe_clustered)" % (n_src - deferred, n_src, deferred) if first_dominates else "%d source nodes per launch" % (n_src // world),
                          "per_unit": "per source node: 4W + 16 P + 4W * raw/node bytes (W=%d words, P=%.1f windows, raw/node=%.2f)" %
                                      (W, stats["windows_probed"] / max(1, stats["nodes_live"]), stats["raw_overlaps"] / max(1, stats["nodes_live"]))},
-            "probe_phase": {"kernels": ["k_probe_stream", "k_probe_clustered"] if two_kernels else [probe_kernel], "ms": ms["probe"],
+            "probe_phase": {"kernels": [first_name, "k_probe_clustered"] + (["k_pile_deg"] if piled else []) if two_kernels else [probe_kernel], "ms": ms["probe"],
                             "algorithmic_bytes": alg_probe_launch, "achieved": achieved, "frac": achieved / HBM_PEAK_GBS},
             "phases_ms": {k: ms[k] for k in ("seed", "probe", "group", "reduce", "emit", "exchange")},
             "counters": {k: int(stats[k]) for k in ("nodes_live", "windows_probed", "slots_scanned", "raw_overlaps", "records",
@@ -362,8 +367,12 @@ def run(args, rank, world, local_rank, dist, t_process=None):
                    ms["sort"], 4 * n + (3 if n >= (1 << 22) else 4) * 2 * 8 * n, "library code; bytes = histogram read + passes x (read + write) of 8-byte pairs"),
                   ("k_tgt_gather", ms["gather"], n * (4 * W + 8 + 16 * eq), "one isolated 64-byte row per entry: 128 bytes fetched for it"),
                   ("k_tgt_dir", ms["dir"], 4 * n + 16 * (nb + 1), "includes the zero fill of the directory (16 B per bucket) in front of the kernel"),
-                  (probe_kernel if first_dominates else "k_probe_stream", ms["probe_pairs"], alg_probe_launch * (1.0 - deferred / n_src), None),
-                  ("k_probe_clustered", ms["probe"] - ms["probe_pairs"], alg_probe_launch * (deferred / n_src), None),
+                  ("k_pile_build", ms["pile"], n * (16 * eq + 16 + 1) + 64 * (n / 6.0),
+                   "pile records of the entry array: entries read once, a directory record per entry, 64 B written per k-mer group (~6 entries), a byte per entry; part of the index build"),
+                  (probe_kernel if first_dominates else first_name, ms["probe_pairs"], alg_probe_launch * (1.0 - deferred / n_src),
+                   "bytes by SURVEY's pairwise definition; the pile path itself has to move ~%d B per source (own entry, run list, directory + pile record per run, one 8-byte slot): %.1f GB" %
+                   (16 * eq + 64 + int(runs_per_node * 80) + 8, n_src * (16 * eq + 64 + runs_per_node * 80 + 8) / 1e9) if piled else None),
+                  ("k_probe_clustered" + (" + k_pile_deg" if piled else ""), ms["probe"] - ms["probe_pairs"], alg_probe_launch * (deferred / n_src), None),
                   ("scan + k_local_emit_* + k_sort_rows_list", ms["emit"], n * 16 + E * 12, None)]
             out["roofline_kernels"] = []
             for name, kms, ab, note in rk:
@@ -381,7 +390,15 @@ def run(args, rank, world, local_rank, dist, t_process=None):
                 if note:
                     ent["note"] = note
                 out["roofline_kernels"].append(ent)
-            out["index_build_ms"] = {k: ms[k] for k in ("keys", "sort", "gather", "dir")}
+            out["index_build_ms"] = {k: ms[k] for k in ("keys", "sort", "gather", "dir", "pile")}
+            if piled:
+                own = n_src * (16 * eq + 64 + runs_per_node * 80 + 8)
+                out["roofline"]["pile_path"] = {
+                    "note": "the timed steps probe through PILES (alga_amd/csrc/prefsuf_pile.hip): one compare of a source against the consensus of a minimizer's targets instead of one "
+                            "per target -- `achieved` / `frac` above keep SURVEY section 8(d)'s per-source bytes of the pairwise algorithm (what the contract defines; a frac above 1 "
+                            "says the kernel does not move those bytes), own_* price the kernel against the bytes ITS formulation has to move",
+                    "own_algorithmic_bytes": int(own), "own_achieved": own / (kernel_ms * 1e-3) / 1e9, "own_frac": own / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "sampled_buckets": int(s.get("pile_buckets", 0)), "sampled_irregular_buckets": int(s.get("pile_irregular", 0))}
         if supplement:
             ps = stats["pkb"]
             ab = sum(ps["kmers"]) * 24 + sum(ps["can_align_calls"]) * 8 * W + sum(ps["edges_after"]) * 8
