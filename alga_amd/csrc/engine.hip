@@ -127,6 +127,24 @@ int cluster_alloc(alga_engine *e, const Prepared &pp) {
     return alga_ensure(e, e->sort_temp, cluster_sort_temp_bytes(n));
 }
 
+// buffers of the pile path (prefsuf_pile.hip).  The bucket table is never cleared between builds -- a record is valid when it carries the
+// epoch of the build at hand -- so it is zeroed here when it is (re)allocated, and the epoch starts over.
+int pile_alloc(alga_engine *e, uint64_t n, uint32_t n_buckets, hipStream_t s) {
+    int rc;
+    if ((rc = alga_ensure(e, e->cl_pile_rec, pile_record_bytes(n)))) return rc;
+    if ((rc = alga_ensure(e, e->cl_pile_sub, (size_t) n + 64))) return rc;
+    if ((rc = alga_ensure(e, e->cl_pile_cnt, 2 * sizeof(unsigned long long)))) return rc;
+    const void *before = e->cl_pile_tab.p;
+    const size_t cap_before = e->cl_pile_tab.cap;
+    if ((rc = alga_ensure(e, e->cl_pile_tab, pile_table_bytes(n_buckets)))) return rc;
+    if (e->cl_pile_tab.p != before || e->cl_pile_tab.cap != cap_before) {
+        HIP_TRY(e, hipMemsetAsync(e->cl_pile_tab.p, 0, e->cl_pile_tab.cap, s));
+        HIP_TRY(e, hipStreamSynchronize(s));               // (once per allocation; the next build may come on another stream)
+        e->pile_epoch = 0;
+    }
+    return ALGA_OK;
+}
+
 // seed + probe.  On return e->rec_dst / e->rec_val hold *n_rec record slots (chunk padding included).
 // local: source-side reduction inside the probe; the records are then final edges (*overflow: a source exceeded its capacity).
 int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t src_end, hipStream_t s, uint64_t *n_rec, bool local = false,
@@ -200,10 +218,13 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
             e->pile_n = -1;
             if (pile) {
                 // piles of the entry array: belongs to the index (a function of the targets alone), read by k_pile_probe
-                if ((rc = alga_ensure(e, e->cl_pile_rec, pile_record_bytes((uint64_t) nd.n)))) return rc;
-                if ((rc = alga_ensure(e, e->cl_pile_sub, (size_t) nd.n + 64))) return rc;
-                if ((rc = alga_ensure(e, e->cl_pile_cnt, 2 * sizeof(unsigned long long)))) return rc;
-                launch_pile_build(cc, pp.uniform_len, e->cl_store.p, (uint64_t) nd.n, e->cl_dir.p, e->cl_pile_rec.p, (uint8_t *) e->cl_pile_sub.p,
+                if ((rc = pile_alloc(e, (uint64_t) nd.n, cc.n_buckets, s))) return rc;
+                if (e->pile_epoch == 0xFFFFFFFFu) {        // the epoch wraps: every record of the table becomes "empty" again
+                    HIP_TRY(e, hipMemsetAsync(e->cl_pile_tab.p, 0, e->cl_pile_tab.cap, s));
+                    e->pile_epoch = 0;
+                }
+                e->pile_epoch++;
+                launch_pile_build(cc, pp.uniform_len, e->cl_store.p, (uint64_t) nd.n, e->cl_dir.p, e->cl_pile_rec.p, e->cl_pile_tab.p, e->pile_epoch, (uint8_t *) e->cl_pile_sub.p,
                                   (unsigned long long *) e->cl_pile_cnt.p, s);
                 if ((rc = alga_check_launch(e, "k_pile_build"))) return rc;
                 e->pile_n = nd.n; e->pile_words = (const void *) nd.words;
@@ -252,7 +273,7 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
                 const bool piled = pile && e->pile_n == nd.n && e->pile_words == (const void *) nd.words;
                 if (piled) {
                     // k_pile_probe first; it and k_probe_stream read the same two counters k_pile_build left and exactly one of them works
-                    launch_pile_probe(cfg, cc, pp.uniform_len, e->cl_store.p, (uint64_t) nd.n, nd.n, e->cl_dir.p, e->cl_pile_rec.p, (const uint8_t *) e->cl_pile_sub.p,
+                    launch_pile_probe(cfg, cc, pp.uniform_len, e->cl_store.p, (uint64_t) nd.n, nd.n, e->cl_pile_tab.p, e->pile_epoch, e->cl_pile_rec.p, (const uint8_t *) e->cl_pile_sub.p,
                                       e->cl_runs.p, cnt, (uint32_t *) e->outdeg.p, (unsigned long long *) e->loc_first.p, (unsigned long long *) e->loc_second.p,
                                       (int32_t *) e->cl_defer.p, (uint32_t) n_src, (const unsigned long long *) e->cl_pile_cnt.p, e->n_cu, s);
                     if ((rc = alga_check_launch(e, "k_pile_probe"))) return rc;
@@ -598,9 +619,7 @@ int alga_engine_reserve(alga_engine *e, int32_t n_nodes, int32_t max_len, int32_
         }
         // the pile path, should the reads turn out to have one length and no masks (what reserve assumes: it is told one length)
         if (e->opt_pile != 0 && e->opt_cluster_pairs != 0 && e->opt_cluster_order != 0 && max_len - min_overlap <= 63 && pile_plan(pp.cfg, pp.cluster, eq, max_len, false)) {
-            if ((rc = alga_ensure(e, e->cl_pile_rec, pile_record_bytes(n)))) return rc;
-            if ((rc = alga_ensure(e, e->cl_pile_sub, (size_t) n + 64))) return rc;
-            if ((rc = alga_ensure(e, e->cl_pile_cnt, 2 * sizeof(unsigned long long)))) return rc;
+            if ((rc = pile_alloc(e, n, pp.cluster.n_buckets, e->own_stream))) return rc;
         }
     } else {
         const uint32_t nb = seed_buckets_for(n, e->seed_fill_x10);

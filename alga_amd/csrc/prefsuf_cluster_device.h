@@ -76,20 +76,16 @@ __device__ __forceinline__ bool same_cluster(uint32_t entry_key, uint32_t ckey, 
 // -> the entries [e0, e0 + cnt) a run {q | p0 << 8 | p1 << 16} has to look at
 // k_pile_build / k_pile_probe / k_probe_stream: more than one bucket in this many irregular and the pairwise kernels take the build (prefsuf_pile.hip)
 constexpr unsigned long long PILE_IRREGULAR_ONE_IN = 40ull;
-// entries of a bucket from its directory record's second word: the plain count, or -- bit 31 set -- the count (<= 64) in the low seven
-// bits with the k-mer groups of the pile path above it (k_pile_build, prefsuf_pile.hip)
-__device__ __forceinline__ uint32_t dir_count(uint32_t y) { return (y >> 31) ? (y & 127u) : y; }
 __device__ __forceinline__ void run_slice(const uint4 &rec, uint32_t run_y, uint32_t &e0, uint32_t &cnt) {
     const int q = (int) (run_y & 255u), p0 = (int) ((run_y >> 8) & 255u), p1 = (int) ((run_y >> 16) & 255u);
     int mlo = q - p1 + 1, mhi = q - p0;
     mlo = mlo < 0 ? 0 : mlo; mhi = mhi > 63 ? 63 : mhi;
-    const uint32_t n = dir_count(rec.y);
-    e0 = rec.x; cnt = n;
+    e0 = rec.x; cnt = rec.y;
     if (mhi < mlo) { cnt = 0u; return; }
-    if (n > 255u) return;                                  // offsets saturate: the whole bucket
+    if (rec.y > 255u) return;                              // offsets saturate: the whole bucket
     const int s0 = mlo >> 3, s1 = (mhi >> 3) + 1;
     const uint32_t b0 = ((s0 < 4 ? rec.z : rec.w) >> (8 * (s0 & 3))) & 255u;
-    const uint32_t b1 = s1 >= 8 ? n : (((s1 < 4 ? rec.z : rec.w) >> (8 * (s1 & 3))) & 255u);
+    const uint32_t b1 = s1 >= 8 ? rec.y : (((s1 < 4 ? rec.z : rec.w) >> (8 * (s1 & 3))) & 255u);
     e0 = rec.x + b0; cnt = b1 - b0;
 }
 

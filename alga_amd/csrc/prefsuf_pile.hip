@@ -39,14 +39,15 @@ constexpr int PB_TILE = 512, PB_HALO = 64, PB_THREADS = PB_TILE + PB_HALO;      
 constexpr int PILE_SW = 13;                    // consensus words: coordinates -64 .. 143 (m_C <= 63, rows of up to 9 words)
 constexpr int PILE_MAXSUB = 4;                 // k-mer groups of one bucket (two k-mers share one of 2^26 buckets for ~9 % of the non-empty buckets at the north-star size)
 constexpr int PILE_EQ = 3;                     // entry size this path takes: rows of up to 9 words (reads of 100 - 150 bp)
-// record (16 words) of the k-th group of a bucket (k in the order of the groups' first members), at entry slot first + k:
-//   w[0 .. 12]  consensus, word k = coordinates -64 + 16 k ..;  w[13] unused
-//   w[14], w[15] bit (63 - m) set: a member with m_C == m
-// and the bucket's DIRECTORY record says which group a source's run wants without a second read: k_pile_build rewrites its entry count
-// (dir.y; <= 64 for every bucket this path takes) as
-//   bits 0..6 entries | bits 7..11, 12..16, 17..21, 22..26 tag of group 0 .. 3 | bits 27..28 groups - 1 | bit 30 irregular | bit 31 set
-// tag = low five bits of the k-mer's cluster key, i.e. of the word a run carries (they lie below the bucket bits).  A bucket of more
-// than 64 entries keeps its plain count: bit 31 clear and not empty = not for this path.  run_slice (prefsuf_cluster_device.h) decodes.
+// What a source reads per run is ONE 128-byte line: the bucket's record in a table indexed by the bucket itself (`tab`, 32 words per bucket)
+//   w[0 .. 12]  consensus of the bucket's FIRST k-mer group, word k = coordinates -64 + 16 k ..
+//   w[13], w[14] bit (63 - m) set: a member of that group with m_C == m
+//   w[15]       epoch of the build that wrote the record (the table is never cleared: a record of another epoch is an empty bucket)
+//   w[16]       entries (bits 0..6; 127: more than 64) | tag of group 0 .. 3 (bits 7..11, 12..16, 17..21, 22..26) | groups - 1 (bits 27..28) | irregular (bit 30)
+//   w[17]       first entry of the bucket;  w[18], w[19] the directory's class offsets (k_tgt_dir) -- what the look-up of a target needs
+// tag = low five bits of the k-mer's cluster key, i.e. of the word a run carries (they lie below the bucket bits): which group a run wants
+// without a second read.  The further groups of a bucket (another k-mer in the same bucket: 9 % of the non-empty buckets at the north-star
+// size) have 16-word records {consensus, -, set} in `rec` at entry slot first + k, k in the order of the groups' first members.
 
 // ------------------------------------------------------------------------------------------
 // Is this a build for the pile path?  pile_cnt = {buckets, irregular buckets} of a SAMPLE of the entry array (its first 1 / 32, in hash order: loci
@@ -56,8 +57,9 @@ constexpr int PILE_EQ = 3;                     // entry size this path takes: ro
 __device__ __forceinline__ bool pile_declines(const unsigned long long *pile_cnt) { return pile_cnt[1] * PILE_IRREGULAR_ONE_IN > pile_cnt[0]; }
 
 template <bool SAMPLE>
-__global__ void __launch_bounds__(PB_THREADS, 3) k_pile_build(const uint4 *__restrict__ store, uint64_t n_entries, uint4 *__restrict__ dir, ClusterCfg cc, int U,
-                                                           uint4 *__restrict__ rec, uint8_t *__restrict__ sub, unsigned long long *__restrict__ pile_cnt) {
+__global__ void __launch_bounds__(PB_THREADS, 3) k_pile_build(const uint4 *__restrict__ store, uint64_t n_entries, const uint4 *__restrict__ dir, ClusterCfg cc, int U,
+                                                           uint4 *__restrict__ rec, uint4 *__restrict__ tab, uint32_t epoch, uint8_t *__restrict__ sub,
+                                                           unsigned long long *__restrict__ pile_cnt) {
     if (!SAMPLE && pile_declines(pile_cnt)) return;
     const int idx_shift = cc.idx_shift, kk = cc.kk;
     __shared__ uint32_t sRow[PB_THREADS][PILE_SW];         // the entry's row on the pile's axis, masked to its extent (odd stride: conflict-free)
@@ -84,7 +86,7 @@ __global__ void __launch_bounds__(PB_THREADS, 3) k_pile_build(const uint4 *__res
     uint4 drec = make_uint4(0u, 0u, 0u, 0u);
     if (tgt) drec = dir[key >> idx_shift];
     const uint64_t e0 = drec.x;
-    const uint32_t cnt = dir_count(drec.y);
+    const uint32_t cnt = drec.y;
     const bool owned = tgt && e0 >= base && e0 < base + PB_TILE && e0 <= j && j - e0 < (uint64_t) cnt;
     const int s = owned ? (int) (e0 - base) : 0;           // thread of the bucket's first entry
     const int i = owned ? (int) (j - e0) : 0;              // index of this entry in its bucket
@@ -150,15 +152,19 @@ __global__ void __launch_bounds__(PB_THREADS, 3) k_pile_build(const uint4 *__res
     }
     __syncthreads();
     if (owned) {
+        uint4 *line = tab + (size_t) (key >> idx_shift) * 8;                        // the bucket's 128-byte record
         if (!part) {
-            if (i == 0) { atomicAdd(&sCount[0], 1u); atomicAdd(&sCount[1], 1u); }      // (its plain count stays in the directory: not for this path)
+            if (i == 0) {                                  // more than 64 entries: not for this path
+                if (!SAMPLE) { line[3] = make_uint4(0u, 0u, 0u, epoch); line[4] = make_uint4(127u | (1u << 30), drec.x, drec.z, drec.w); }
+                atomicAdd(&sCount[0], 1u); atomicAdd(&sCount[1], 1u);
+            }
         } else {
             const unsigned long long lm = sLead[s];
             const int nsub = __popcll(lm);
             const int iL = L - s;                          // index of my group's first member in the bucket
             const int k = __popcll(lm & ((1ull << iL) - 1ull));                        // my group's number
             if (!SAMPLE) sub[j] = (uint8_t) k;
-            if (!SAMPLE && L == t && k < PILE_MAXSUB) {
+            if (!SAMPLE && L == t && k >= 1 && k < PILE_MAXSUB) {
                 const unsigned long long rm = sRm[t];
                 const uint64_t slot = e0 + (uint64_t) k;
                 rec[slot * 4 + 0] = make_uint4(S[0], S[1], S[2], S[3]);
@@ -167,7 +173,7 @@ __global__ void __launch_bounds__(PB_THREADS, 3) k_pile_build(const uint4 *__res
                 rec[slot * 4 + 3] = make_uint4(S[12], 0u, (uint32_t) rm, (uint32_t) (rm >> 32));
             }
             if (i == 0) {
-                // the bucket's directory record: which group a run wants (tags of the first three groups' leaders)
+                // the bucket's first entry leads group 0: its consensus, its set, and which group a run wants (tags of the groups' leaders)
                 uint32_t tg[PILE_MAXSUB] = {0u, 0u, 0u, 0u};
                 unsigned long long rest = lm;
 #pragma unroll
@@ -176,8 +182,14 @@ __global__ void __launch_bounds__(PB_THREADS, 3) k_pile_build(const uint4 *__res
                 }
                 const bool irregular = sBad[s] != 0u || nsub > PILE_MAXSUB;
                 const uint32_t ns1 = (uint32_t) (nsub < PILE_MAXSUB ? nsub : PILE_MAXSUB) - 1u;
-                if (!SAMPLE) reinterpret_cast<uint32_t *>(dir + (key >> idx_shift))[1] =
-                    cnt | (tg[0] << 7) | (tg[1] << 12) | (tg[2] << 17) | (tg[3] << 22) | (ns1 << 27) | (irregular ? 1u << 30 : 0u) | 0x80000000u;
+                if (!SAMPLE) {
+                    const unsigned long long rm = sRm[t];
+                    line[0] = make_uint4(S[0], S[1], S[2], S[3]);
+                    line[1] = make_uint4(S[4], S[5], S[6], S[7]);
+                    line[2] = make_uint4(S[8], S[9], S[10], S[11]);
+                    line[3] = make_uint4(S[12], (uint32_t) rm, (uint32_t) (rm >> 32), epoch);
+                    line[4] = make_uint4(cnt | (tg[0] << 7) | (tg[1] << 12) | (tg[2] << 17) | (tg[3] << 22) | (ns1 << 27) | (irregular ? 1u << 30 : 0u), drec.x, drec.z, drec.w);
+                }
                 atomicAdd(&sCount[0], 1u);
                 if (irregular) atomicAdd(&sCount[1], 1u);
             }
@@ -209,7 +221,7 @@ constexpr int PP_WAVES = 4;
 // record of the next run is on its way while the current one is compared, the run loop is unrolled over the eight slots (static
 // registers, a wave skips the slots none of its lanes uses), and five workgroups share a CU.
 __global__ void __launch_bounds__(PP_WAVES * 64, PP_OCC) k_pile_probe(PrefSufCfg cfg, ClusterCfg cc, int U, const uint4 *__restrict__ store, uint64_t n_entries, int n_nodes,
-                                                                 const uint4 *__restrict__ dir, const uint4 *__restrict__ rec, const uint8_t *__restrict__ sub,
+                                                                 const uint4 *__restrict__ tab, uint32_t epoch, const uint4 *__restrict__ rec, const uint8_t *__restrict__ sub,
                                                                  const uint2 *__restrict__ runs, ProbeOut o, int32_t *__restrict__ defer_list, uint32_t defer_cap,
                                                                  const unsigned long long *__restrict__ pile_cnt) {
     __shared__ uint32_t sS[PP_WAVES][64][23];              // per lane: words 0..3 zero, 4..16 the consensus of the record at hand, 17..22 zero
@@ -260,27 +272,6 @@ __global__ void __launch_bounds__(PP_WAVES * 64, PP_OCC) k_pile_probe(PrefSufCfg
     bool dfr = nr_code == CL_RUNS_FLAGGED;                 // runs k_node_runs could not list: the general kernel finds them by brute force
     const bool active = nr_code != 0 && !dfr;
     const int nr = active ? (nr_code < CL_RMAX ? nr_code : CL_RMAX) : 0;
-    // directory records of all run slots, at once (an unused slot reads the record behind the last bucket).  Which k-mer group of the
-    // bucket a run wants is read off the directory record: the groups whose tag equals the low six bits of the run's cluster key -- one,
-    // except where two k-mers of a bucket share all 32 bits of their hash (3 % of the buckets at the north-star size: 19-mers do not fit
-    // 32 bits); the first of them is taken in the main loop, the others in a short loop behind it (the order of the records is free:
-    // what a source keeps is decided from the complete offset set).
-    uint32_t dx[CL_RMAX], dnz = 0u, more = 0u;             // first entry of the run's bucket | first group << 30; bit a: there is one; 4 bits per slot: further groups
-#pragma unroll
-    for (int a = 0; a < CL_RMAX; a++) {
-        const uint4 d = dir[a < nr ? min(rk[a] >> cc.idx_shift, cc.n_buckets) : cc.n_buckets];
-        const uint32_t y = d.y, tag = rk[a] & 31u;
-        // (bit 31 clear and entries: a bucket k_pile_build left alone -- more than 64 entries; bit 30: one it found irregular)
-        dfr = dfr || (a < nr && y != 0u && ((y >> 31) == 0u || ((y >> 30) & 1u) != 0u));
-        const uint32_t ns = ((y >> 27) & 3u) + 1u;
-        uint32_t mt = (((y >> 7) & 31u) == tag ? 1u : 0u) | ((ns >= 2u && ((y >> 12) & 31u) == tag) ? 2u : 0u) | ((ns >= 3u && ((y >> 17) & 31u) == tag) ? 4u : 0u) |
-                      ((ns >= 4u && ((y >> 22) & 31u) == tag) ? 8u : 0u);
-        mt = (a < nr && (y >> 31) != 0u) ? mt : 0u;
-        const uint32_t g0 = mt ? (uint32_t) __builtin_ctz(mt) : 0u;
-        dx[a] = (d.x & 0x3FFFFFFFu) | (g0 << 30);
-        dnz |= mt ? 1u << a : 0u;
-        more |= (mt & (mt - 1u)) << (4 * a);
-    }
     // the same minimizer twice in one source (a tandem repeat): a target could be an item at two offsets
 #pragma unroll
     for (int a = 0; a < CL_RMAX; a++)
@@ -294,10 +285,10 @@ __global__ void __launch_bounds__(PP_WAVES * 64, PP_OCC) k_pile_probe(PrefSufCfg
     int ea_len = 0;
     // one record against the source: the items it gives.  The consensus strings of two runs must agree past the source's end wherever both
     // are defined -- that is what makes "the overhangs of two items agree" (the via compare of the reduction) hold across runs.
-    auto take_record = [&](const uint4 &R0, const uint4 &R1, const uint4 &R2, const uint4 &R3, int slot_a, uint32_t group, uint32_t y, bool on) {
+    auto take_record = [&](const uint4 &R0, const uint4 &R1, const uint4 &R2, uint32_t s12, unsigned long long rm, int slot_a, uint32_t group, uint32_t y, bool on) {
         const int q = (int) (y & 255u), p0 = (int) ((y >> 8) & 255u), p1 = (int) ((y >> 16) & 255u);
         ss[4] = R0.x; ss[5] = R0.y; ss[6] = R0.z; ss[7] = R0.w; ss[8] = R1.x; ss[9] = R1.y; ss[10] = R1.z; ss[11] = R1.w;
-        ss[12] = R2.x; ss[13] = R2.y; ss[14] = R2.z; ss[15] = R2.w; ss[16] = R3.x;
+        ss[12] = R2.x; ss[13] = R2.y; ss[14] = R2.z; ss[15] = R2.w; ss[16] = s12;
         // position t of the source = consensus index 64 - q + t = bit 2 (128 - q + t) of the padded consensus
         const int ob = 2 * (128 - min(q, 127)), w0 = ob >> 5, sh = ob & 31;
         uint32_t x[10];
@@ -312,7 +303,6 @@ __global__ void __launch_bounds__(PP_WAVES * 64, PP_OCC) k_pile_probe(PrefSufCfg
             dv = dd ? dd : dv;
         }
         const int mism = dv ? 16 * dk + ((31 - __clz((int) dv)) >> 1) : -1;
-        const unsigned long long rm = ((unsigned long long) R3.w << 32) | R3.z;
         unsigned long long oc = q <= 63 ? (rm >> (63 - q)) : (q - 63 >= 64 ? 0ull : (rm << (q - 63)));            // offset d = q - m
         oc &= (p1 >= 64 ? ~0ull : ((1ull << p1) - 1ull)) & ~((1ull << (p0 & 63)) - 1ull) & ~1ull;                 // the run's windows; offset 0 is the source itself
         if (mism >= 0) oc &= mism >= 63 ? 0ull : ~((2ull << mism) - 1ull);
@@ -344,25 +334,41 @@ __global__ void __launch_bounds__(PP_WAVES * 64, PP_OCC) k_pile_probe(PrefSufCfg
             grp = (grp & ~(3u << (2 * slot_a))) | (group << (2 * slot_a));
         }
     };
-    auto rec_slot = [&](uint32_t dxa, uint32_t group) -> uint64_t { return min((uint64_t) (dxa & 0x3FFFFFFFu) + group, last); };       // (clamped: a corrupt directory must not fault)
-    // the first record of slot a - 1 is read while slot a is compared
-    uint4 N0, N1, N2, N3;
+    // Runs from slot 7 down; the record of slot a - 1 is on its way while slot a is compared.  Which k-mer group of the bucket a run wants is
+    // read off the record: the groups whose tag equals the low five bits of the run's cluster key -- one, except where two k-mers of a
+    // bucket share all 32 bits of their hash (3 % of the buckets at the north-star size: 19-mers do not fit 32 bits).  Group 0 is in the
+    // record itself; the others are taken in a short loop behind this one (the order of the records is free: what a source keeps is
+    // decided from the complete offset set).
+    auto bucket_of = [&](int a) -> uint32_t { return a < nr ? min(rk[a] >> cc.idx_shift, cc.n_buckets) : cc.n_buckets; };
+    uint32_t more = 0u;                                    // 4 bits per slot: further groups to take
+    uint32_t e0s[CL_RMAX];                                 // first entry of the slot's bucket
+    uint4 N0, N1, N2, N3, N4;
     {
-        const uint64_t sl = rec_slot(dx[CL_RMAX - 1], dx[CL_RMAX - 1] >> 30);
-        N0 = rec[sl * 4]; N1 = rec[sl * 4 + 1]; N2 = rec[sl * 4 + 2]; N3 = rec[sl * 4 + 3];
+        const uint4 *ln = tab + (size_t) bucket_of(CL_RMAX - 1) * 8;
+        N0 = ln[0]; N1 = ln[1]; N2 = ln[2]; N3 = ln[3]; N4 = ln[4];
     }
 #pragma unroll
     for (int a = CL_RMAX - 1; a >= 0; a--) {
-        const uint4 R0 = N0, R1 = N1, R2 = N2, R3 = N3;
+        const uint4 R0 = N0, R1 = N1, R2 = N2, R3 = N3, R4 = N4;
         if (a > 0) {
-            const uint64_t sl = rec_slot(dx[a - 1], dx[a - 1] >> 30);
-            N0 = rec[sl * 4]; N1 = rec[sl * 4 + 1]; N2 = rec[sl * 4 + 2]; N3 = rec[sl * 4 + 3];
+            const uint4 *ln = tab + (size_t) bucket_of(a - 1) * 8;
+            N0 = ln[0]; N1 = ln[1]; N2 = ln[2]; N3 = ln[3]; N4 = ln[4];
         }
-        const bool on = ((dnz >> a) & 1u) != 0u && !dfr;
+        const bool live = a < nr && R3.w == epoch;         // a record of another epoch: no entry in this bucket
+        const uint32_t y = R4.x, tag = rk[a] & 31u;
+        dfr = dfr || (live && ((y >> 30) & 1u) != 0u);     // a bucket k_pile_build found irregular (or of more than 64 entries)
+        const uint32_t ns = ((y >> 27) & 3u) + 1u;
+        uint32_t mt = (((y >> 7) & 31u) == tag ? 1u : 0u) | ((ns >= 2u && ((y >> 12) & 31u) == tag) ? 2u : 0u) | ((ns >= 3u && ((y >> 17) & 31u) == tag) ? 4u : 0u) |
+                      ((ns >= 4u && ((y >> 22) & 31u) == tag) ? 8u : 0u);
+        mt = (live && !dfr) ? mt : 0u;
+        e0s[a] = R4.y;
+        more |= (mt & ~1u) << (4 * a);
+        const bool on = (mt & 1u) != 0u;
         if (__ballot(on) == 0ull) continue;                // uniform
-        take_record(R0, R1, R2, R3, a, dx[a] >> 30, ry[a], on);
+        take_record(R0, R1, R2, R3.x, ((unsigned long long) R3.z << 32) | R3.y, a, 0u, ry[a], on);
     }
-    // the further groups that share a run's tag (hash collisions between k-mers): at most one of a slot's groups holds the source's k-mer
+    // the further groups that share a run's tag (another k-mer of the bucket with the same tag, or the run's own k-mer when it is not the
+    // bucket's first): at most one of a slot's groups holds the source's k-mer
     more = dfr ? 0u : more;
     while (__ballot(more != 0u) != 0ull) {                 // uniform
         const bool on = more != 0u;
@@ -370,12 +376,12 @@ __global__ void __launch_bounds__(PP_WAVES * 64, PP_OCC) k_pile_probe(PrefSufCfg
         more &= more - 1u;
         const int a = bit >> 2;
         const uint32_t g = (uint32_t) (bit & 3);
-        uint32_t ya = ry[0], xa = dx[0];
+        uint32_t ya = ry[0], xa = e0s[0];
 #pragma unroll
-        for (int k = 1; k < CL_RMAX; k++) { ya = a == k ? ry[k] : ya; xa = a == k ? dx[k] : xa; }
-        const uint64_t sl = rec_slot(xa, g);
+        for (int k = 1; k < CL_RMAX; k++) { ya = a == k ? ry[k] : ya; xa = a == k ? e0s[k] : xa; }
+        const uint64_t sl = min((uint64_t) xa + g, last);  // (clamped: a corrupt record must not fault)
         const uint4 Q0 = rec[sl * 4], Q1 = rec[sl * 4 + 1], Q2 = rec[sl * 4 + 2], Q3 = rec[sl * 4 + 3];
-        take_record(Q0, Q1, Q2, Q3, a, g, ya, on);
+        take_record(Q0, Q1, Q2, Q3.x, ((unsigned long long) Q3.w << 32) | Q3.z, a, g, ya, on);
     }
     // ---- what the source keeps, from the complete offset set; the one or two targets by id ----
     const unsigned long long kept = occ & ~smear_up(occ, G);
@@ -389,14 +395,14 @@ __global__ void __launch_bounds__(PP_WAVES * 64, PP_OCC) k_pile_probe(PrefSufCfg
             const bool in = k < nr && d >= (int) ((ry[k] >> 8) & 255u) && d < (int) ((ry[k] >> 16) & 255u);
             ya = in ? ry[k] : ya; ka = in ? rk[k] : ka; ga = in ? (grp >> (2 * k)) & 3u : ga;
         }
-        const uint4 dd = dir[min(ka >> cc.idx_shift, cc.n_buckets)];
+        const uint4 dd = tab[(size_t) min(ka >> cc.idx_shift, cc.n_buckets) * 8 + 4];       // {entries | ..., first entry, class offsets}
         const int mm = (int) (ya & 255u) - d;
         const int cl = (mm >> 3) & 7;
         const uint32_t b0 = ((cl < 4 ? dd.z : dd.w) >> (8 * (cl & 3))) & 255u;
-        const uint32_t b1 = cl >= 7 ? dir_count(dd.y) : ((((cl + 1) < 4 ? dd.z : dd.w) >> (8 * ((cl + 1) & 3))) & 255u);
+        const uint32_t b1 = cl >= 7 ? (dd.x & 127u) : ((((cl + 1) < 4 ? dd.z : dd.w) >> (8 * ((cl + 1) & 3))) & 255u);
         uint32_t id = 0xFFFFFFFFu;
         for (uint32_t e = b0; e < b1 && e < 64u; e++) {
-            const uint64_t ei = min((uint64_t) dd.x + e, last);
+            const uint64_t ei = min((uint64_t) dd.y + e, last);
             const uint4 tail = store[ei * PILE_EQ + 2];
             if ((int) (tail.w & 63u) == mm && (uint32_t) sub[ei] == ga) id = tail.y;
         }
@@ -470,17 +476,19 @@ bool pile_plan(const PrefSufCfg &cfg, const ClusterCfg &cc, int eq, int uniform_
 }
 size_t pile_record_bytes(uint64_t n) { return (size_t) (n + 2) * 64; }
 
-void launch_pile_build(const ClusterCfg &cc, int uniform_len, const void *store, uint64_t n_entries, void *dir, void *rec, uint8_t *sub,
+size_t pile_table_bytes(uint32_t n_buckets) { return ((size_t) n_buckets + 2) * 128; }
+
+void launch_pile_build(const ClusterCfg &cc, int uniform_len, const void *store, uint64_t n_entries, const void *dir, void *rec, void *tab, uint32_t epoch, uint8_t *sub,
                        unsigned long long *pile_cnt, hipStream_t s) {
     (void) hipMemsetAsync(pile_cnt, 0, 2 * sizeof(unsigned long long), s);
     if (n_entries == 0) return;
     const uint64_t tiles = (n_entries + PB_TILE - 1) / PB_TILE;
     const dim3 grid((unsigned) tiles), sample((unsigned) std::max<uint64_t>(1, std::min<uint64_t>(tiles, std::max<uint64_t>(64, tiles / 32)))), block(PB_THREADS);
-    hipLaunchKernelGGL((k_pile_build<true>), sample, block, 0, s, (const uint4 *) store, n_entries, (uint4 *) dir, cc, uniform_len, (uint4 *) rec, sub, pile_cnt);
-    hipLaunchKernelGGL((k_pile_build<false>), grid, block, 0, s, (const uint4 *) store, n_entries, (uint4 *) dir, cc, uniform_len, (uint4 *) rec, sub, pile_cnt);
+    hipLaunchKernelGGL((k_pile_build<true>), sample, block, 0, s, (const uint4 *) store, n_entries, (const uint4 *) dir, cc, uniform_len, (uint4 *) rec, (uint4 *) tab, epoch, sub, pile_cnt);
+    hipLaunchKernelGGL((k_pile_build<false>), grid, block, 0, s, (const uint4 *) store, n_entries, (const uint4 *) dir, cc, uniform_len, (uint4 *) rec, (uint4 *) tab, epoch, sub, pile_cnt);
 }
 
-void launch_pile_probe(const PrefSufCfg &cfg, const ClusterCfg &cc, int uniform_len, const void *store, uint64_t n_entries, int n_nodes, const void *dir, const void *rec,
+void launch_pile_probe(const PrefSufCfg &cfg, const ClusterCfg &cc, int uniform_len, const void *store, uint64_t n_entries, int n_nodes, const void *tab, uint32_t epoch, const void *rec,
                        const uint8_t *sub, const void *runs, unsigned long long *counters, uint32_t *deg, unsigned long long *first, unsigned long long *second,
                        int32_t *defer_list, uint32_t defer_cap, const unsigned long long *pile_cnt, int n_cu, hipStream_t s) {
     if (n_entries == 0) return;
@@ -488,7 +496,7 @@ void launch_pile_probe(const PrefSufCfg &cfg, const ClusterCfg &cc, int uniform_
     o.counters = counters; o.deg = deg; o.first = first; o.second = second; o.src_base = 0;
     const uint64_t tiles = (n_entries + PP_WAVES * 64 - 1) / (PP_WAVES * 64);
     const dim3 grid((unsigned) std::max<uint64_t>(1, std::min<uint64_t>(tiles, (uint64_t) std::max(1, n_cu) * PP_OCC))), block(PP_WAVES * 64);
-    hipLaunchKernelGGL(k_pile_probe, grid, block, 0, s, cfg, cc, uniform_len, (const uint4 *) store, n_entries, n_nodes, (const uint4 *) dir, (const uint4 *) rec, sub,
+    hipLaunchKernelGGL(k_pile_probe, grid, block, 0, s, cfg, cc, uniform_len, (const uint4 *) store, n_entries, n_nodes, (const uint4 *) tab, epoch, (const uint4 *) rec, sub,
                        (const uint2 *) runs, o, defer_list, defer_cap, pile_cnt);
 }
 
