@@ -50,7 +50,7 @@ elif [ "$PART" = B ]; then
     cut -c1-1200 $OUT/multi_cxx_2ranks_50M_$FORM.json
   done
 else
-  timeout -k 10 600 python tools/run_cfg4.py 50000000 250000000 1 source_side 0 a21745295ac286551ab5ce9fd8a1b9b2107f53cab6c329ed32e819deb3aed925 > $OUT/cfg4_50M_dump_vs_recorded_reference.log 2>&1 || { tail -5 $OUT/cfg4_50M_dump_vs_recorded_reference.log; exit 1; }
+  timeout -k 10 600 python tools/run_cfg4.py 50000000 250000000 2 source_side 0 a21745295ac286551ab5ce9fd8a1b9b2107f53cab6c329ed32e819deb3aed925 > $OUT/cfg4_50M_dump_vs_recorded_reference.log 2>&1 || { tail -5 $OUT/cfg4_50M_dump_vs_recorded_reference.log; exit 1; }
   tail -1 $OUT/cfg4_50M_dump_vs_recorded_reference.log | cut -c1-900
   timeout -k 10 600 python tools/cfg5_exact_dump_hash.py > $OUT/cfg5_10M_exact_path_vs_recorded_reference.json 2> $OUT/cfg5_hash.err || { tail -5 $OUT/cfg5_hash.err; exit 1; }
   cat $OUT/cfg5_10M_exact_path_vs_recorded_reference.json

@@ -77,6 +77,8 @@ def main():
             ms.append({k: round(st[k], 3) for k in ("ms_total", "ms_seed", "ms_probe", "ms_group", "ms_reduce", "ms_emit")})
             print(red, it, E, ms[-1], flush=True)
         out[red] = ms
+        # the build whose edges are kept (and dumped): the last one -- with steps >= 2 one WITHOUT the work counters, i.e. through the pile path where it applies
+        out[red + "_last_build"] = {k: st[k] for k in ("probe_used", "deferred_sources", "pile_buckets", "pile_irregular", "ms_pile")}
         keep[red] = device_view(ptr, (E, 3), dw.device).clone()
     if len(forms) == 2:
         out["forms_agree"] = bool(keep[forms[0]].shape == keep[forms[1]].shape and torch.equal(keep[forms[0]], keep[forms[1]]))
