@@ -219,7 +219,7 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
             if (pile) {
                 // piles of the entry array: belongs to the index (a function of the targets alone), read by k_pile_probe
                 if ((rc = pile_alloc(e, (uint64_t) nd.n, cc.n_buckets, s))) return rc;
-                if (e->pile_epoch == 0xFFFFFFFFu) {        // the epoch wraps: every record of the table becomes "empty" again
+                if (e->pile_epoch >= 511u) {               // the epoch (9 bits of a record) wraps: every record of the table becomes "empty" again
                     HIP_TRY(e, hipMemsetAsync(e->cl_pile_tab.p, 0, e->cl_pile_tab.cap, s));
                     e->pile_epoch = 0;
                 }

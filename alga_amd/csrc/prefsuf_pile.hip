@@ -42,9 +42,10 @@ constexpr int PILE_EQ = 3;                     // entry size this path takes: ro
 // What a source reads per run is ONE 128-byte line: the bucket's record in a table indexed by the bucket itself (`tab`, 32 words per bucket)
 //   w[0 .. 12]  consensus of the bucket's FIRST k-mer group, word k = coordinates -64 + 16 k ..
 //   w[13], w[14] bit (63 - m) set: a member of that group with m_C == m
-//   w[15]       epoch of the build that wrote the record (the table is never cleared: a record of another epoch is an empty bucket)
-//   w[16]       entries (bits 0..6; 127: more than 64) | tag of group 0 .. 3 (bits 7..11, 12..16, 17..21, 22..26) | groups - 1 (bits 27..28) | irregular (bit 30)
-//   w[17]       first entry of the bucket;  w[18], w[19] the directory's class offsets (k_tgt_dir) -- what the look-up of a target needs
+//   w[15]       tag of group 0 .. 3 (bits 0..4, 5..9, 10..14, 15..19) | groups - 1 (bits 20..21) | irregular (bit 22) | epoch of the build that wrote
+//               the record (bits 23..31, never 0: the table is not cleared between builds, a record of another epoch is an empty bucket)
+//   -- the first 64 bytes are all the run loop reads (the kernel is bound by the number of 64-byte requests that miss its L1) --
+//   w[16]       entries (127: more than 64);  w[17] first entry of the bucket;  w[18], w[19] the directory's class offsets (k_tgt_dir): the look-up of a target
 // tag = low five bits of the k-mer's cluster key, i.e. of the word a run carries (they lie below the bucket bits): which group a run wants
 // without a second read.  The further groups of a bucket (another k-mer in the same bucket: 9 % of the non-empty buckets at the north-star
 // size) have 16-word records {consensus, -, set} in `rec` at entry slot first + k, k in the order of the groups' first members.
@@ -155,7 +156,7 @@ __global__ void __launch_bounds__(PB_THREADS, 3) k_pile_build(const uint4 *__res
         uint4 *line = tab + (size_t) (key >> idx_shift) * 8;                        // the bucket's 128-byte record
         if (!part) {
             if (i == 0) {                                  // more than 64 entries: not for this path
-                if (!SAMPLE) { line[3] = make_uint4(0u, 0u, 0u, epoch); line[4] = make_uint4(127u | (1u << 30), drec.x, drec.z, drec.w); }
+                if (!SAMPLE) { line[3] = make_uint4(0u, 0u, 0u, (1u << 22) | (epoch << 23)); line[4] = make_uint4(127u, drec.x, drec.z, drec.w); }
                 atomicAdd(&sCount[0], 1u); atomicAdd(&sCount[1], 1u);
             }
         } else {
@@ -187,8 +188,8 @@ __global__ void __launch_bounds__(PB_THREADS, 3) k_pile_build(const uint4 *__res
                     line[0] = make_uint4(S[0], S[1], S[2], S[3]);
                     line[1] = make_uint4(S[4], S[5], S[6], S[7]);
                     line[2] = make_uint4(S[8], S[9], S[10], S[11]);
-                    line[3] = make_uint4(S[12], (uint32_t) rm, (uint32_t) (rm >> 32), epoch);
-                    line[4] = make_uint4(cnt | (tg[0] << 7) | (tg[1] << 12) | (tg[2] << 17) | (tg[3] << 22) | (ns1 << 27) | (irregular ? 1u << 30 : 0u), drec.x, drec.z, drec.w);
+                    line[3] = make_uint4(S[12], (uint32_t) rm, (uint32_t) (rm >> 32), tg[0] | (tg[1] << 5) | (tg[2] << 10) | (tg[3] << 15) | (ns1 << 20) | (irregular ? 1u << 22 : 0u) | (epoch << 23));
+                    line[4] = make_uint4(cnt, drec.x, drec.z, drec.w);
                 }
                 atomicAdd(&sCount[0], 1u);
                 if (irregular) atomicAdd(&sCount[1], 1u);
@@ -212,7 +213,10 @@ __device__ __forceinline__ unsigned long long smear_up(unsigned long long x, int
     return acc;
 }
 
-constexpr int PP_WAVES = 4;
+#ifndef PP_WAVES_N
+#define PP_WAVES_N 4
+#endif
+constexpr int PP_WAVES = PP_WAVES_N;
 #ifndef PP_OCC
 #define PP_OCC 4
 #endif
@@ -250,24 +254,37 @@ __global__ void __launch_bounds__(PP_WAVES * 64, PP_OCC) k_pile_probe(PrefSufCfg
         n_defer = 0;
     };
     const uint64_t n_tiles = (n_entries + PP_WAVES * 64 - 1) / (PP_WAVES * 64);
+    const uint64_t last = n_entries - 1;
+    // The first two links of a lane's chain -- own entry -> run list by id -- are taken a tile ahead: the id of the next tile's source is read while
+    // this tile's records are compared, its run list while this tile's targets are looked up; at the top of a tile only the row itself is
+    // still to come, and that read runs beside the first bucket line's.
+    auto entry_id = [&](uint64_t t) -> int {               // id of this lane's source in tile t (clamped: the last entry)
+        const uint64_t j = t * (PP_WAVES * 64) + threadIdx.x;
+        return (int) min(reinterpret_cast<const uint32_t *>(store)[(j < n_entries ? j : last) * (4 * PILE_EQ) + 4 * PILE_EQ - 3], (uint32_t) n_nodes - 1u);
+    };
+    int next_id = blockIdx.x < n_tiles ? entry_id(blockIdx.x) : 0;
+    uint4 Qr[CL_RMAX / 2];
+    {
+        const uint4 *rp = reinterpret_cast<const uint4 *>(runs + (size_t) next_id * CL_RMAX);
+#pragma unroll
+        for (int c = 0; c < CL_RMAX / 2; c++) Qr[c] = rp[c];
+    }
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {      // uniform
     const uint64_t j = tile * (PP_WAVES * 64) + threadIdx.x;
     const bool have = j < n_entries;
-    const uint64_t jc = have ? j : n_entries - 1;
-    const uint64_t last = n_entries - 1;
-    uint32_t B[9];
-    int Bs;
-    {
-        const uint4 v0 = store[jc * PILE_EQ], v1 = store[jc * PILE_EQ + 1], v2 = store[jc * PILE_EQ + 2];
-        B[0] = v0.x; B[1] = v0.y; B[2] = v0.z; B[3] = v0.w; B[4] = v1.x; B[5] = v1.y; B[6] = v1.z; B[7] = v1.w; B[8] = v2.x;
-        Bs = (int) min(v2.y, (uint32_t) n_nodes - 1u);
-    }
+    const uint64_t jc = have ? j : last;
+    const int Bs = next_id;
     uint32_t rk[CL_RMAX], ry[CL_RMAX];
-    {
-        const uint4 *rp = reinterpret_cast<const uint4 *>(runs + (size_t) Bs * CL_RMAX);
 #pragma unroll
-        for (int c = 0; c < CL_RMAX / 2; c++) { const uint4 v = rp[c]; rk[2 * c] = v.x; ry[2 * c] = v.y; rk[2 * c + 1] = v.z; ry[2 * c + 1] = v.w; }
+    for (int c = 0; c < CL_RMAX / 2; c++) { rk[2 * c] = Qr[c].x; ry[2 * c] = Qr[c].y; rk[2 * c + 1] = Qr[c].z; ry[2 * c + 1] = Qr[c].w; }
+    uint32_t B[9];
+    {
+        const uint4 v0 = store[jc * PILE_EQ], v1 = store[jc * PILE_EQ + 1];
+        B[0] = v0.x; B[1] = v0.y; B[2] = v0.z; B[3] = v0.w; B[4] = v1.x; B[5] = v1.y; B[6] = v1.z; B[7] = v1.w;
+        B[8] = reinterpret_cast<const uint32_t *>(store)[jc * (4 * PILE_EQ) + 8];
     }
+    const uint64_t tile_next = tile + gridDim.x < n_tiles ? tile + gridDim.x : tile;
+    next_id = entry_id(tile_next);
     const int nr_code = have ? (int) (ry[0] >> 24) : 0;
     bool dfr = nr_code == CL_RUNS_FLAGGED;                 // runs k_node_runs could not list: the general kernel finds them by brute force
     const bool active = nr_code != 0 && !dfr;
@@ -341,31 +358,34 @@ __global__ void __launch_bounds__(PP_WAVES * 64, PP_OCC) k_pile_probe(PrefSufCfg
     // decided from the complete offset set).
     auto bucket_of = [&](int a) -> uint32_t { return a < nr ? min(rk[a] >> cc.idx_shift, cc.n_buckets) : cc.n_buckets; };
     uint32_t more = 0u;                                    // 4 bits per slot: further groups to take
-    uint32_t e0s[CL_RMAX];                                 // first entry of the slot's bucket
-    uint4 N0, N1, N2, N3, N4;
+    uint4 N0, N1, N2, N3;
     {
         const uint4 *ln = tab + (size_t) bucket_of(CL_RMAX - 1) * 8;
-        N0 = ln[0]; N1 = ln[1]; N2 = ln[2]; N3 = ln[3]; N4 = ln[4];
+        N0 = ln[0]; N1 = ln[1]; N2 = ln[2]; N3 = ln[3];
     }
 #pragma unroll
     for (int a = CL_RMAX - 1; a >= 0; a--) {
-        const uint4 R0 = N0, R1 = N1, R2 = N2, R3 = N3, R4 = N4;
+        const uint4 R0 = N0, R1 = N1, R2 = N2, R3 = N3;
         if (a > 0) {
             const uint4 *ln = tab + (size_t) bucket_of(a - 1) * 8;
-            N0 = ln[0]; N1 = ln[1]; N2 = ln[2]; N3 = ln[3]; N4 = ln[4];
+            N0 = ln[0]; N1 = ln[1]; N2 = ln[2]; N3 = ln[3];
         }
-        const bool live = a < nr && R3.w == epoch;         // a record of another epoch: no entry in this bucket
-        const uint32_t y = R4.x, tag = rk[a] & 31u;
-        dfr = dfr || (live && ((y >> 30) & 1u) != 0u);     // a bucket k_pile_build found irregular (or of more than 64 entries)
-        const uint32_t ns = ((y >> 27) & 3u) + 1u;
-        uint32_t mt = (((y >> 7) & 31u) == tag ? 1u : 0u) | ((ns >= 2u && ((y >> 12) & 31u) == tag) ? 2u : 0u) | ((ns >= 3u && ((y >> 17) & 31u) == tag) ? 4u : 0u) |
-                      ((ns >= 4u && ((y >> 22) & 31u) == tag) ? 8u : 0u);
+        const uint32_t y = R3.w, tag = rk[a] & 31u;
+        const bool live = a < nr && (y >> 23) == epoch;    // a record of another epoch: no entry in this bucket
+        dfr = dfr || (live && ((y >> 22) & 1u) != 0u);     // a bucket k_pile_build found irregular (or of more than 64 entries)
+        const uint32_t ns = ((y >> 20) & 3u) + 1u;
+        uint32_t mt = ((y & 31u) == tag ? 1u : 0u) | ((ns >= 2u && ((y >> 5) & 31u) == tag) ? 2u : 0u) | ((ns >= 3u && ((y >> 10) & 31u) == tag) ? 4u : 0u) |
+                      ((ns >= 4u && ((y >> 15) & 31u) == tag) ? 8u : 0u);
         mt = (live && !dfr) ? mt : 0u;
-        e0s[a] = R4.y;
         more |= (mt & ~1u) << (4 * a);
         const bool on = (mt & 1u) != 0u;
         if (__ballot(on) == 0ull) continue;                // uniform
         take_record(R0, R1, R2, R3.x, ((unsigned long long) R3.z << 32) | R3.y, a, 0u, ry[a], on);
+    }
+    {                                                      // the next tile's run lists: on their way while this tile's targets are looked up
+        const uint4 *rp = reinterpret_cast<const uint4 *>(runs + (size_t) next_id * CL_RMAX);
+#pragma unroll
+        for (int c = 0; c < CL_RMAX / 2; c++) Qr[c] = rp[c];
     }
     // the further groups that share a run's tag (another k-mer of the bucket with the same tag, or the run's own k-mer when it is not the
     // bucket's first): at most one of a slot's groups holds the source's k-mer
@@ -376,9 +396,10 @@ __global__ void __launch_bounds__(PP_WAVES * 64, PP_OCC) k_pile_probe(PrefSufCfg
         more &= more - 1u;
         const int a = bit >> 2;
         const uint32_t g = (uint32_t) (bit & 3);
-        uint32_t ya = ry[0], xa = e0s[0];
+        uint32_t ya = ry[0], ka = rk[0];
 #pragma unroll
-        for (int k = 1; k < CL_RMAX; k++) { ya = a == k ? ry[k] : ya; xa = a == k ? e0s[k] : xa; }
+        for (int k = 1; k < CL_RMAX; k++) { ya = a == k ? ry[k] : ya; ka = a == k ? rk[k] : ka; }
+        const uint32_t xa = reinterpret_cast<const uint32_t *>(tab)[(size_t) min(ka >> cc.idx_shift, cc.n_buckets) * 32 + 17];      // first entry of the bucket
         const uint64_t sl = min((uint64_t) xa + g, last);  // (clamped: a corrupt record must not fault)
         const uint4 Q0 = rec[sl * 4], Q1 = rec[sl * 4 + 1], Q2 = rec[sl * 4 + 2], Q3 = rec[sl * 4 + 3];
         take_record(Q0, Q1, Q2, Q3.x, ((unsigned long long) Q3.w << 32) | Q3.z, a, g, ya, on);
@@ -495,7 +516,7 @@ void launch_pile_probe(const PrefSufCfg &cfg, const ClusterCfg &cc, int uniform_
     ProbeOut o{};
     o.counters = counters; o.deg = deg; o.first = first; o.second = second; o.src_base = 0;
     const uint64_t tiles = (n_entries + PP_WAVES * 64 - 1) / (PP_WAVES * 64);
-    const dim3 grid((unsigned) std::max<uint64_t>(1, std::min<uint64_t>(tiles, (uint64_t) std::max(1, n_cu) * PP_OCC))), block(PP_WAVES * 64);
+    const dim3 grid((unsigned) std::max<uint64_t>(1, std::min<uint64_t>(tiles, (uint64_t) std::max(1, n_cu) * (PP_OCC * 4 / PP_WAVES)))), block(PP_WAVES * 64);      // PP_OCC waves per SIMD, four SIMDs per CU
     hipLaunchKernelGGL(k_pile_probe, grid, block, 0, s, cfg, cc, uniform_len, (const uint4 *) store, n_entries, n_nodes, (const uint4 *) tab, epoch, (const uint4 *) rec, sub,
                        (const uint2 *) runs, o, defer_list, defer_cap, pile_cnt);
 }
