@@ -225,7 +225,7 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
                 }
                 e->pile_epoch++;
                 launch_pile_build(cc, pp.uniform_len, e->cl_store.p, (uint64_t) nd.n, e->cl_dir.p, e->cl_pile_rec.p, e->cl_pile_tab.p, e->pile_epoch, (uint8_t *) e->cl_pile_sub.p,
-                                  (unsigned long long *) e->cl_pile_cnt.p, s);
+                                  (unsigned long long *) e->cl_pile_cnt.p, e->opt_pile == 2, s);
                 if ((rc = alga_check_launch(e, "k_pile_build"))) return rc;
                 e->pile_n = nd.n; e->pile_words = (const void *) nd.words;
                 e->pile_timed = nd.n > 0;
@@ -577,7 +577,7 @@ int alga_engine_set_option(alga_engine *e, const char *name, int64_t value) {
     } else if (!strcmp(name, "cluster_pairs")) {
         e->opt_cluster_pairs = value != 0;
     } else if (!strcmp(name, "pile")) {
-        e->opt_pile = value != 0;
+        e->opt_pile = value == 2 ? 2 : (value != 0);       // (2, tests only: no sample -- the pile kernels take every build they can, however many buckets are irregular)
     } else if (!strcmp(name, "cluster_order")) {
         e->opt_cluster_order = value != 0;
     } else if (!strcmp(name, "local_big_max")) {

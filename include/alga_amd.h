@@ -144,7 +144,8 @@ int         alga_engine_device_name(const alga_engine *e, char *buf, size_t bufl
  *   "cluster_pairs"              0: the CLUSTER probe runs its general kernel only (one source per wave); default 1: k_probe_stream first
  *                                (the entries of consecutive sources packed densely onto the lanes), the general kernel on what it defers
  *   "pile"                       default 1: reads of one length without masks take the probe through PILES (alga_amd/csrc/prefsuf_pile.hip): one compare
- *                                of a source against the consensus of a minimizer's targets instead of one per target; 0: always the pairwise kernels
+ *                                of a source against the consensus of a minimizer's targets instead of one per target; 0: always the pairwise kernels;
+ *                                2 (tests only): without the sample that leaves reads with errors to the pairwise kernels
  *   "cluster_order"              default 1: k_probe_stream takes the sources in the order of the entry array (sources of one locus together:
  *                                shared look-ups, cache hits); 0: in id order (what a range of ids always gets)
  *   "local_big_max"              largest per-wave item slice of the SOURCE_SIDE second pass (default -1 = built-in 4096); beyond it

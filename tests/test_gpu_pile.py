@@ -28,7 +28,7 @@ def eng():
 def _three_ways(eng, words, lens, lo, rs, af=None, at=None):
     want, _, _ = O.prefsuf(words, lens, lo, rs, af, at)
     out = {}
-    for pile in (1, 0):
+    for pile in (1, 2, 0):                                     # 2 (tests only): without the sample -- the pile kernels take the build however irregular its buckets are
         eng.set_option("pile", pile)
         try:
             got = eng.prefsuf_host(words, lens, lo, rs, af, at, reduction="source_side")
@@ -39,6 +39,7 @@ def _three_ways(eng, words, lens, lo, rs, af=None, at=None):
         assert st["edges"] == len(want)
         out[pile] = st
     assert out[0]["pile_buckets"] == 0 and out[0]["ms_pile"] == 0.0
+    assert (out[2]["ms_pile"] > 0) == (out[1]["ms_pile"] > 0)       # forced or not, the same inputs are the pile path's
     return out[1], len(want)
 
 
@@ -143,3 +144,21 @@ def test_inputs_the_pile_path_does_not_take(eng):
     got = eng.prefsuf_host(words, lens, lo, rs, None, at)
     assert got.shape == want.shape and (got == want).all()
     assert eng.last_stats()["pile_buckets"] == 0
+
+
+def test_bucket_table_is_valid_by_epoch(eng):
+    """The bucket table of the pile path is never cleared between builds: a record counts only when it carries the epoch of the build at hand.
+    One engine builds two different read sets of different sizes alternately -- every record the other set left behind is stale -- and far
+    more often than the nine bits of the epoch hold, so that the table is cleared and the epoch starts over at least once."""
+    sets = []
+    for n, G, seed in ((1500, 8000, 101), (2600, 11_000, 102)):
+        words, lens = _nodes(n, 150, G, seed)
+        lo, rs = alga_amd.derive_params(144.0)
+        want, _, _ = O.prefsuf(words, lens, lo, rs)
+        sets.append((words, lens, lo, rs, want))
+    for it in range(540):
+        words, lens, lo, rs, want = sets[it & 1]
+        got = eng.prefsuf_host(words, lens, lo, rs)
+        assert got.shape == want.shape and (got == want).all(), it
+        if it < 2:
+            assert eng.last_stats()["pile_buckets"] > 0

@@ -2,8 +2,9 @@
 """Randomised cross-check on the GPU: the two forms of the transitive reduction (per-target replay, source-side) must give
 the same edges on every input the source-side form accepts -- the source-side form through the seed-table probe, through the
 clustered probe with k_probe_stream first (sources in key order and in id order), and through the clustered probe's general kernel alone.  Random read lengths (fixed / variable), coverage, substitution
-errors, tandem repeats, exact duplicates and prefix reads left in, masks, min_overlap / rsoemo choices.
-usage: tools/stress_forms.py [n_cases=100] [first_seed=1000]"""
+errors, tandem repeats, exact duplicates and prefix reads left in, masks, min_overlap / rsoemo choices; and, round 4, the probe through piles (a build without
+work counters) wherever the input allows it.
+usage: tools/stress_forms.py [--pile] [n_cases=100] [first_seed=1000]"""
 import os
 import sys
 
@@ -14,15 +15,22 @@ sys.path.insert(0, ROOT)
 import alga_amd  # noqa: E402
 
 
+PILE_DOMAIN = False          # --pile: only cases the pile path takes (one read length <= 144, no masks, at most 64 suffix windows, few or no errors)
+
+
 def make_case(seed):
     rng = np.random.default_rng(seed)
     maxlen = int(rng.choice([48, 64, 80, 100, 144, 150, 200, 250]))
-    varlen = rng.random() < 0.4
+    if PILE_DOMAIN:
+        maxlen = int(rng.choice([64, 80, 94, 100, 128, 144]))
+    varlen = rng.random() < 0.4 and not PILE_DOMAIN
     minlen = int(maxlen * rng.uniform(0.6, 0.95)) if varlen else maxlen
     n_reads = int(rng.integers(300, 6000))
     cov = float(rng.choice([3, 8, 20, 50, 120]))
     G = max(maxlen * 3, int(n_reads * (maxlen + minlen) / 2 / cov))
     err = float(rng.choice([0, 0, 0.001, 0.005, 0.02]))
+    if PILE_DOMAIN:
+        err = float(rng.choice([0, 0, 0, 0.0005, 0.002]))
     g = rng.integers(0, 4, G, dtype=np.uint8)
     if rng.random() < 0.4:                                  # tandem repeats / multi-copy repeats
         period = int(rng.integers(3, 60))
@@ -65,13 +73,15 @@ def make_case(seed):
     lo = int(maxlen * rng.uniform(0.35, 0.7))
     if maxlen - lo > 127:
         lo = maxlen - int(rng.integers(20, 127))
+    if PILE_DOMAIN:
+        lo = maxlen - int(rng.integers(8, 64))
     rs = int(rng.integers(lo, maxlen + 2))
     af = at = None
-    if rng.random() < 0.25:
+    if rng.random() < 0.25 and not PILE_DOMAIN:
         dead = rng.random(2 * n) < 0.05
         lens = np.where(dead, 0, lens).astype(np.int32)
         words[dead] = 0
-    if rng.random() < 0.2:
+    if rng.random() < 0.2 and not PILE_DOMAIN:
         af = (rng.random(2 * n) < 0.85).astype(np.uint8)
         at = np.maximum(af, (rng.random(2 * n) < 0.5).astype(np.uint8))
     desc = dict(seed=seed, maxlen=maxlen, minlen=minlen, reads=n, genome=G, err=err, lo=lo, rs=rs, masks=af is not None)
@@ -79,11 +89,15 @@ def make_case(seed):
 
 
 def main():
+    global PILE_DOMAIN
+    if "--pile" in sys.argv:
+        PILE_DOMAIN = True
+        sys.argv.remove("--pile")
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
     eng = alga_amd.Engine(0)
     used, declined, bad = 0, 0, 0
-    big = generic = clustered = 0
+    big = generic = clustered = piled = pile_kept = pile_forced = 0
     for seed in range(first, first + n_cases):
         words, lens, lo, rs, af, at, desc = make_case(seed)
         a = eng.prefsuf_host(words, lens, lo, rs, af, at, reduction="per_target")
@@ -116,8 +130,26 @@ def main():
             declined += 1
             continue
         used += 1
-    print("cases %d: source-side used %d (all-pairs branch in %d, second pass in %d, clustered probe in %d), declined %d, mismatches %d" %
-          (n_cases, used, generic, big, clustered, declined, bad))
+        # the probe through piles (prefsuf_pile.hip): a build WITHOUT work counters through the clustered probe -- reads of one length without masks take it
+        for mode in (1, 2):                                # 2: without the sample that declines irregular data -- every irregular bucket's sources are handed on one by one
+            eng.set_option("probe", "cluster")
+            eng.set_option("pile", mode)
+            try:
+                c = eng.prefsuf_host(words, lens, lo, rs, af, at, reduction="source_side")
+            finally:
+                eng.set_option("probe", "auto")
+                eng.set_option("pile", 1)
+            st = eng.last_stats()
+            if mode == 1 and st["pile_buckets"] > 0:
+                piled += 1
+                pile_kept += st["pile_irregular"] * 40 <= st["pile_buckets"]
+            if mode == 2:
+                pile_forced += st["ms_pile"] > 0
+            if a.shape != c.shape or not (a == c).all():
+                bad += 1
+                print("MISMATCH pile", mode, desc, a.shape, c.shape, flush=True)
+    print("cases %d: source-side used %d (all-pairs branch in %d, second pass in %d, clustered probe in %d; pile path sampled in %d, kept the build in %d, forced through it in %d), declined %d, mismatches %d" %
+          (n_cases, used, generic, big, clustered, piled, pile_kept, pile_forced, declined, bad))
     sys.exit(1 if bad else 0)
 
 
