@@ -20,11 +20,13 @@
 //
 //   k_pile_build   one lane per ENTRY of the entry array: per bucket the groups of equal minimizer k-mer (<= PILE_MAXSUB), per group the
 //                  consensus (leftmost-starting | rightmost-ending member), every member verified against it, the mirrored m_C set;
-//                  a 64-byte record per group at the slot of its first member, a byte per entry (its group).  A bucket where any of
-//                  it fails (a member that differs from the consensus, two members at one m_C, more groups or entries than fit) is
-//                  flagged: its sources go to the general kernel.
-//   k_pile_probe   one lane per SOURCE (in the order of the entry array): its runs from the last window to the first, per run the
-//                  bucket's records; regular sources get their edges, the others go on the defer list of k_probe_clustered.
+//                  the record of the bucket's first group in a table indexed by the bucket, the further groups' at their entry slots, a byte
+//                  per entry (its group).  A bucket where any of it fails (a member that differs from the consensus, two members at one
+//                  m_C, more groups or entries than fit) is flagged: its sources go to the general kernel.  As <SAMPLE> on the first 1/32
+//                  of the entry array it only counts such buckets: the three kernels leave a build of reads with errors to k_probe_stream.
+//   k_pile_probe   one lane per SOURCE (in the order of the entry array): per run ONE 64-byte read of the bucket's record; regular sources
+//                  get their edges, the others go on the defer list of k_probe_clustered.
+//   k_pile_deg     a streaming pass that moves the out-degree k_pile_probe left in the source's slot to deg[].
 // Nothing is approximated: every decision either follows from verified equalities or is handed to the pairwise kernels.
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -220,10 +222,10 @@ constexpr int PP_WAVES = PP_WAVES_N;
 #ifndef PP_OCC
 #define PP_OCC 4
 #endif
-// One lane per source.  What bounds this kernel is the CHAIN of dependent memory reads of a lane (own entry -> run list -> directory ->
-// record -> ... -> the targets that stand), not arithmetic: the directory records of all eight run slots are read at once, the first
-// record of the next run is on its way while the current one is compared, the run loop is unrolled over the eight slots (static
-// registers, a wave skips the slots none of its lanes uses), and five workgroups share a CU.
+// One lane per source.  What bounds this kernel is the CHAIN of dependent memory reads of a lane (own entry -> run list by id -> bucket record
+// -> ... -> the targets that stand) and the number of 64-byte requests that miss its L1, not arithmetic and not bytes: id and run list are read
+// a tile ahead, the record of the next run is on its way while the current one is compared, the run loop is unrolled over the eight slots
+// (static registers, a wave skips the slots none of its lanes uses), four waves per SIMD (five spill: 11.7 against 10.8 ms).
 __global__ void __launch_bounds__(PP_WAVES * 64, PP_OCC) k_pile_probe(PrefSufCfg cfg, ClusterCfg cc, int U, const uint4 *__restrict__ store, uint64_t n_entries, int n_nodes,
                                                                  const uint4 *__restrict__ tab, uint32_t epoch, const uint4 *__restrict__ rec, const uint8_t *__restrict__ sub,
                                                                  const uint2 *__restrict__ runs, ProbeOut o, int32_t *__restrict__ defer_list, uint32_t defer_cap,
@@ -258,6 +260,8 @@ __global__ void __launch_bounds__(PP_WAVES * 64, PP_OCC) k_pile_probe(PrefSufCfg
     // The first two links of a lane's chain -- own entry -> run list by id -- are taken a tile ahead: the id of the next tile's source is read while
     // this tile's records are compared, its run list while this tile's targets are looked up; at the top of a tile only the row itself is
     // still to come, and that read runs beside the first bucket line's.
+    // (the id comes from the entry itself, not from the sorted id array next to it: the early touch brings the entry's line into the memory-side
+    // cache a tile before its row is read -- 4 GB more counter traffic, 3 % less time)
     auto entry_id = [&](uint64_t t) -> int {               // id of this lane's source in tile t (clamped: the last entry)
         const uint64_t j = t * (PP_WAVES * 64) + threadIdx.x;
         return (int) min(reinterpret_cast<const uint32_t *>(store)[(j < n_entries ? j : last) * (4 * PILE_EQ) + 4 * PILE_EQ - 3], (uint32_t) n_nodes - 1u);
