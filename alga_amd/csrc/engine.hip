@@ -133,6 +133,7 @@ int pile_alloc(alga_engine *e, uint64_t n, uint32_t n_buckets, hipStream_t s) {
     int rc;
     if ((rc = alga_ensure(e, e->cl_pile_rec, pile_record_bytes(n)))) return rc;
     if ((rc = alga_ensure(e, e->cl_pile_sub, (size_t) n + 64))) return rc;
+    if ((rc = alga_ensure(e, e->cl_pile_succ, ((size_t) n + 64) * 8))) return rc;
     if ((rc = alga_ensure(e, e->cl_pile_cnt, 2 * sizeof(unsigned long long)))) return rc;
     const void *before = e->cl_pile_tab.p;
     const size_t cap_before = e->cl_pile_tab.cap;
@@ -225,7 +226,7 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
                 }
                 e->pile_epoch++;
                 launch_pile_build(cc, pp.uniform_len, e->cl_store.p, (uint64_t) nd.n, e->cl_dir.p, e->cl_pile_rec.p, e->cl_pile_tab.p, e->pile_epoch, (uint8_t *) e->cl_pile_sub.p,
-                                  (unsigned long long *) e->cl_pile_cnt.p, e->opt_pile == 2, s);
+                                  e->cl_pile_succ.p, (unsigned long long *) e->cl_pile_cnt.p, e->opt_pile == 2, s);
                 if ((rc = alga_check_launch(e, "k_pile_build"))) return rc;
                 e->pile_n = nd.n; e->pile_words = (const void *) nd.words;
                 e->pile_timed = nd.n > 0;
@@ -273,7 +274,7 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
                 const bool piled = pile && e->pile_n == nd.n && e->pile_words == (const void *) nd.words;
                 if (piled) {
                     // k_pile_probe first; it and k_probe_stream read the same two counters k_pile_build left and exactly one of them works
-                    launch_pile_probe(cfg, cc, pp.uniform_len, e->cl_store.p, (uint64_t) nd.n, nd.n, e->cl_pile_tab.p, e->pile_epoch, e->cl_pile_rec.p, (const uint8_t *) e->cl_pile_sub.p,
+                    launch_pile_probe(cfg, cc, pp.uniform_len, e->cl_store.p, (uint64_t) nd.n, nd.n, e->cl_pile_tab.p, e->pile_epoch, e->cl_pile_rec.p, (const uint8_t *) e->cl_pile_sub.p, e->cl_pile_succ.p,
                                       e->cl_runs.p, cnt, (uint32_t *) e->outdeg.p, (unsigned long long *) e->loc_first.p, (unsigned long long *) e->loc_second.p,
                                       (int32_t *) e->cl_defer.p, (uint32_t) n_src, (const unsigned long long *) e->cl_pile_cnt.p, e->n_cu, s);
                     if ((rc = alga_check_launch(e, "k_pile_probe"))) return rc;

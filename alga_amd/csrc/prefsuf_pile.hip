@@ -62,7 +62,7 @@ __device__ __forceinline__ bool pile_declines(const unsigned long long *pile_cnt
 template <bool SAMPLE>
 __global__ void __launch_bounds__(PB_THREADS, 3) k_pile_build(const uint4 *__restrict__ store, uint64_t n_entries, const uint4 *__restrict__ dir, ClusterCfg cc, int U,
                                                            uint4 *__restrict__ rec, uint4 *__restrict__ tab, uint32_t epoch, uint8_t *__restrict__ sub,
-                                                           unsigned long long *__restrict__ pile_cnt) {
+                                                           uint2 *__restrict__ succ, unsigned long long *__restrict__ pile_cnt) {
     if (!SAMPLE && pile_declines(pile_cnt)) return;
     const int idx_shift = cc.idx_shift, kk = cc.kk;
     __shared__ uint32_t sRow[PB_THREADS][PILE_SW];         // the entry's row on the pile's axis, masked to its extent (odd stride: conflict-free)
@@ -79,11 +79,11 @@ __global__ void __launch_bounds__(PB_THREADS, 3) k_pile_build(const uint4 *__res
     const bool have = j < n_entries;
     const uint64_t jc = have ? j : (n_entries ? n_entries - 1 : 0);
     uint32_t row[9];
-    uint32_t key, meta;
+    uint32_t key, meta, node_id;
     {
         const uint4 v0 = store[jc * PILE_EQ], v1 = store[jc * PILE_EQ + 1], v2 = store[jc * PILE_EQ + 2];
         row[0] = v0.x; row[1] = v0.y; row[2] = v0.z; row[3] = v0.w; row[4] = v1.x; row[5] = v1.y; row[6] = v1.z; row[7] = v1.w; row[8] = v2.x;
-        key = v2.z; meta = v2.w;
+        node_id = v2.y; key = v2.z; meta = v2.w;
     }
     const bool tgt = have && key != 0xFFFFFFFFu;
     uint4 drec = make_uint4(0u, 0u, 0u, 0u);
@@ -139,6 +139,26 @@ __global__ void __launch_bounds__(PB_THREADS, 3) k_pile_build(const uint4 *__res
         if (atomicOr(&sRm[L], bit) & bit) atomicOr(&sBad[s], 1u);          // two members start at the same coordinate
     }
     __syncthreads();
+    // The members of a group in the order of their m_C, densely inside the bucket's own stretch of a table (the k-mers have done their job:
+    // their words hold it): slot = bucket start + members of the groups before mine + members of my group with a smaller m_C.  The member
+    // that starts next to a member's right is then the one slot below it -- no search.
+    uint32_t *sSlot = reinterpret_cast<uint32_t *>(sKm);
+    int my_slot = -1, my_rank = 0;
+    if (part) {
+        const unsigned long long lm = sLead[s];
+        const int kgrp = __popcll(lm & ((1ull << (L - s)) - 1ull));
+        if (kgrp < PILE_MAXSUB) {
+            int before = 0;
+            unsigned long long rest = lm;
+#pragma unroll
+            for (int g = 0; g < PILE_MAXSUB - 1; g++) {
+                if (g < kgrp) { before += __popcll(sRm[s + __builtin_ctzll(rest)]); rest &= rest - 1ull; }
+            }
+            my_rank = m == 0 ? 0 : __popcll(sRm[L] >> (64 - m));                     // members of my group that start right of me
+            my_slot = s + before + my_rank;
+            if (my_slot < s + (int) cnt) sSlot[my_slot] = node_id; else my_slot = -1;   // (beyond the stretch: two members at one m_C -- an irregular bucket)
+        }
+    }
     uint32_t S[PILE_SW];
 #pragma unroll
     for (int k = 0; k < PILE_SW; k++) S[k] = 0u;
@@ -166,7 +186,15 @@ __global__ void __launch_bounds__(PB_THREADS, 3) k_pile_build(const uint4 *__res
             const int nsub = __popcll(lm);
             const int iL = L - s;                          // index of my group's first member in the bucket
             const int k = __popcll(lm & ((1ull << iL) - 1ull));                        // my group's number
-            if (!SAMPLE) sub[j] = (uint8_t) k;
+            if (!SAMPLE) {
+                sub[j] = (uint8_t) k;
+                // the member of my group that starts next to my right (the largest m_C below mine): what a source of this pile keeps when that
+                // member lies within its home run's windows -- k_pile_probe then needs no look-up at all
+                const unsigned long long right = m == 0 ? 0ull : (sRm[L] >> (64 - m));    // bit b: a member with m_C == m - 1 - b
+                uint2 sc = make_uint2(0xFFFFFFFFu, 0u);
+                if (right != 0ull && my_slot > s && my_rank >= 1) sc = make_uint2(sSlot[my_slot - 1], 1u + (uint32_t) __builtin_ctzll(right));
+                succ[j] = sc;
+            }
             if (!SAMPLE && L == t && k >= 1 && k < PILE_MAXSUB) {
                 const unsigned long long rm = sRm[t];
                 const uint64_t slot = e0 + (uint64_t) k;
@@ -198,6 +226,8 @@ __global__ void __launch_bounds__(PB_THREADS, 3) k_pile_build(const uint4 *__res
             }
         }
     }
+    // entries of no regular bucket (non-targets, buckets of more than 64 entries): no successor; written by the thread of the tile proper
+    if (!SAMPLE && have && t < PB_TILE && !(tgt && cnt <= 64u)) succ[j] = make_uint2(0xFFFFFFFFu, 0u);
     __syncthreads();
     if (SAMPLE && t < 2 && sCount[t]) atomicAdd(&pile_cnt[t], (unsigned long long) sCount[t]);      // (the sample is a few thousand workgroups)
 }
@@ -228,7 +258,7 @@ constexpr int PP_WAVES = PP_WAVES_N;
 // (static registers, a wave skips the slots none of its lanes uses), four waves per SIMD (five spill: 11.7 against 10.8 ms).
 __global__ void __launch_bounds__(PP_WAVES * 64, PP_OCC) k_pile_probe(PrefSufCfg cfg, ClusterCfg cc, int U, const uint4 *__restrict__ store, uint64_t n_entries, int n_nodes,
                                                                  const uint4 *__restrict__ tab, uint32_t epoch, const uint4 *__restrict__ rec, const uint8_t *__restrict__ sub,
-                                                                 const uint2 *__restrict__ runs, ProbeOut o, int32_t *__restrict__ defer_list, uint32_t defer_cap,
+                                                                 const uint2 *__restrict__ succ, const uint2 *__restrict__ runs, ProbeOut o, int32_t *__restrict__ defer_list, uint32_t defer_cap,
                                                                  const unsigned long long *__restrict__ pile_cnt) {
     __shared__ uint32_t sS[PP_WAVES][64][23];              // per lane: words 0..3 zero, 4..16 the consensus of the record at hand, 17..22 zero
     __shared__ int32_t sDefer[PP_WAVES][128];              // sources of this wave that wait for the defer list
@@ -260,8 +290,9 @@ __global__ void __launch_bounds__(PP_WAVES * 64, PP_OCC) k_pile_probe(PrefSufCfg
     // The first two links of a lane's chain -- own entry -> run list by id -- are taken a tile ahead: the id of the next tile's source is read while
     // this tile's records are compared, its run list while this tile's targets are looked up; at the top of a tile only the row itself is
     // still to come, and that read runs beside the first bucket line's.
-    // (the id comes from the entry itself, not from the sorted id array next to it: the early touch brings the entry's line into the memory-side
-    // cache a tile before its row is read -- 4 GB more counter traffic, 3 % less time)
+    // (The id comes from the entry itself: the early touch brings the entry's line into the memory-side cache a tile before its row is read.
+    // Measured against it: the id from the sorted id array next to the entries -- 4 GB less counter traffic, 3 % more time -- and the whole
+    // entry read a tile ahead into registers -- one visit per line, 4 % more time.)
     auto entry_id = [&](uint64_t t) -> int {               // id of this lane's source in tile t (clamped: the last entry)
         const uint64_t j = t * (PP_WAVES * 64) + threadIdx.x;
         return (int) min(reinterpret_cast<const uint32_t *>(store)[(j < n_entries ? j : last) * (4 * PILE_EQ) + 4 * PILE_EQ - 3], (uint32_t) n_nodes - 1u);
@@ -287,6 +318,7 @@ __global__ void __launch_bounds__(PP_WAVES * 64, PP_OCC) k_pile_probe(PrefSufCfg
         B[0] = v0.x; B[1] = v0.y; B[2] = v0.z; B[3] = v0.w; B[4] = v1.x; B[5] = v1.y; B[6] = v1.z; B[7] = v1.w;
         B[8] = reinterpret_cast<const uint32_t *>(store)[jc * (4 * PILE_EQ) + 8];
     }
+    const uint2 my_succ = succ[jc];                        // {id, offset} of the member of my own pile that starts next to my right (k_pile_build)
     const uint64_t tile_next = tile + gridDim.x < n_tiles ? tile + gridDim.x : tile;
     next_id = entry_id(tile_next);
     const int nr_code = have ? (int) (ry[0] >> 24) : 0;
@@ -438,7 +470,13 @@ __global__ void __launch_bounds__(PP_WAVES * 64, PP_OCC) k_pile_probe(PrefSufCfg
     unsigned long long slot_val = LOCAL_FIRST_NONE;
     if (active && !dfr && nkept > 0) {
         const int d1 = __builtin_ctzll(kept);
-        const uint32_t id1 = lookup(d1);
+        // the first item lies within the windows of the home run (the run of window 0: the source's own pile) for nine sources in ten: it is the
+        // member k_pile_build noted for this entry, no look-up (a bucket line's second half, an entry tail and a group byte: three more L1 misses)
+        int p1_home = 0;
+#pragma unroll
+        for (int k = 0; k < CL_RMAX; k++) p1_home = (k < nr && ((ry[k] >> 8) & 255u) == 0u) ? (int) ((ry[k] >> 16) & 255u) : p1_home;
+        const bool by_succ = d1 < p1_home && (int) my_succ.y == d1 && my_succ.x != 0xFFFFFFFFu;
+        const uint32_t id1 = by_succ ? my_succ.x : lookup(d1);
         uint32_t id2 = 0u;
         int d2 = 0;
         bool two = false;
@@ -504,18 +542,18 @@ size_t pile_record_bytes(uint64_t n) { return (size_t) (n + 2) * 64; }
 size_t pile_table_bytes(uint32_t n_buckets) { return ((size_t) n_buckets + 2) * 128; }
 
 void launch_pile_build(const ClusterCfg &cc, int uniform_len, const void *store, uint64_t n_entries, const void *dir, void *rec, void *tab, uint32_t epoch, uint8_t *sub,
-                       unsigned long long *pile_cnt, bool no_sample, hipStream_t s) {
+                       void *succ, unsigned long long *pile_cnt, bool no_sample, hipStream_t s) {
     (void) hipMemsetAsync(pile_cnt, 0, 2 * sizeof(unsigned long long), s);
     if (n_entries == 0) return;
     const uint64_t tiles = (n_entries + PB_TILE - 1) / PB_TILE;
     const dim3 grid((unsigned) tiles), sample((unsigned) std::max<uint64_t>(1, std::min<uint64_t>(tiles, std::max<uint64_t>(64, tiles / 32)))), block(PB_THREADS);
     // (no_sample -- tests only: the two counters stay zero and the pile kernels take the build whatever its buckets look like)
-    if (!no_sample) hipLaunchKernelGGL((k_pile_build<true>), sample, block, 0, s, (const uint4 *) store, n_entries, (const uint4 *) dir, cc, uniform_len, (uint4 *) rec, (uint4 *) tab, epoch, sub, pile_cnt);
-    hipLaunchKernelGGL((k_pile_build<false>), grid, block, 0, s, (const uint4 *) store, n_entries, (const uint4 *) dir, cc, uniform_len, (uint4 *) rec, (uint4 *) tab, epoch, sub, pile_cnt);
+    if (!no_sample) hipLaunchKernelGGL((k_pile_build<true>), sample, block, 0, s, (const uint4 *) store, n_entries, (const uint4 *) dir, cc, uniform_len, (uint4 *) rec, (uint4 *) tab, epoch, sub, (uint2 *) succ, pile_cnt);
+    hipLaunchKernelGGL((k_pile_build<false>), grid, block, 0, s, (const uint4 *) store, n_entries, (const uint4 *) dir, cc, uniform_len, (uint4 *) rec, (uint4 *) tab, epoch, sub, (uint2 *) succ, pile_cnt);
 }
 
 void launch_pile_probe(const PrefSufCfg &cfg, const ClusterCfg &cc, int uniform_len, const void *store, uint64_t n_entries, int n_nodes, const void *tab, uint32_t epoch, const void *rec,
-                       const uint8_t *sub, const void *runs, unsigned long long *counters, uint32_t *deg, unsigned long long *first, unsigned long long *second,
+                       const uint8_t *sub, const void *succ, const void *runs, unsigned long long *counters, uint32_t *deg, unsigned long long *first, unsigned long long *second,
                        int32_t *defer_list, uint32_t defer_cap, const unsigned long long *pile_cnt, int n_cu, hipStream_t s) {
     if (n_entries == 0) return;
     ProbeOut o{};
@@ -523,7 +561,7 @@ void launch_pile_probe(const PrefSufCfg &cfg, const ClusterCfg &cc, int uniform_
     const uint64_t tiles = (n_entries + PP_WAVES * 64 - 1) / (PP_WAVES * 64);
     const dim3 grid((unsigned) std::max<uint64_t>(1, std::min<uint64_t>(tiles, (uint64_t) std::max(1, n_cu) * (PP_OCC * 4 / PP_WAVES)))), block(PP_WAVES * 64);      // PP_OCC waves per SIMD, four SIMDs per CU
     hipLaunchKernelGGL(k_pile_probe, grid, block, 0, s, cfg, cc, uniform_len, (const uint4 *) store, n_entries, n_nodes, (const uint4 *) tab, epoch, (const uint4 *) rec, sub,
-                       (const uint2 *) runs, o, defer_list, defer_cap, pile_cnt);
+                       (const uint2 *) succ, (const uint2 *) runs, o, defer_list, defer_cap, pile_cnt);
 }
 
 void launch_pile_deg(int32_t n, unsigned long long *first, uint32_t *deg, const unsigned long long *pile_cnt, hipStream_t s) {
