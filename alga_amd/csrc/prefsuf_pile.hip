@@ -62,7 +62,7 @@ __device__ __forceinline__ bool pile_declines(const unsigned long long *pile_cnt
 template <bool SAMPLE>
 __global__ void __launch_bounds__(PB_THREADS, 3) k_pile_build(const uint4 *__restrict__ store, uint64_t n_entries, const uint4 *__restrict__ dir, ClusterCfg cc, int U,
                                                            uint4 *__restrict__ rec, uint4 *__restrict__ tab, uint32_t epoch, uint8_t *__restrict__ sub,
-                                                           uint2 *__restrict__ succ, unsigned long long *__restrict__ pile_cnt) {
+                                                           uint4 *__restrict__ side, unsigned long long *__restrict__ pile_cnt) {
     if (!SAMPLE && pile_declines(pile_cnt)) return;
     const int idx_shift = cc.idx_shift, kk = cc.kk;
     __shared__ uint32_t sRow[PB_THREADS][PILE_SW];         // the entry's row on the pile's axis, masked to its extent (odd stride: conflict-free)
@@ -191,9 +191,12 @@ __global__ void __launch_bounds__(PB_THREADS, 3) k_pile_build(const uint4 *__res
                 // the member of my group that starts next to my right (the largest m_C below mine): what a source of this pile keeps when that
                 // member lies within its home run's windows -- k_pile_probe then needs no look-up at all
                 const unsigned long long right = m == 0 ? 0ull : (sRm[L] >> (64 - m));    // bit b: a member with m_C == m - 1 - b
-                uint2 sc = make_uint2(0xFFFFFFFFu, 0u);
-                if (right != 0ull && my_slot > s && my_rank >= 1) sc = make_uint2(sSlot[my_slot - 1], 1u + (uint32_t) __builtin_ctzll(right));
-                succ[j] = sc;
+                uint32_t succ_id = 0xFFFFFFFFu, delta = 0u;
+                if (right != 0ull && my_slot > s && my_rank >= 1) { succ_id = sSlot[my_slot - 1]; delta = 1u + (uint32_t) __builtin_ctzll(right); }
+                // ... and what k_pile_probe reads of the entry AS A SOURCE: a member of a regular bucket's first group equals that group's consensus on
+                // its whole extent (verified above), so the probe takes its row from the bucket's record, which it reads anyway, not from the entry
+                const bool first_group = k == 0 && sBad[s] == 0u && nsub <= PILE_MAXSUB;
+                side[j] = make_uint4(node_id, succ_id, delta | ((uint32_t) m << 8) | ((uint32_t) k << 16) | (first_group ? 0x80000000u : 0u), 0u);
             }
             if (!SAMPLE && L == t && k >= 1 && k < PILE_MAXSUB) {
                 const unsigned long long rm = sRm[t];
@@ -226,8 +229,8 @@ __global__ void __launch_bounds__(PB_THREADS, 3) k_pile_build(const uint4 *__res
             }
         }
     }
-    // entries of no regular bucket (non-targets, buckets of more than 64 entries): no successor; written by the thread of the tile proper
-    if (!SAMPLE && have && t < PB_TILE && !(tgt && cnt <= 64u)) succ[j] = make_uint2(0xFFFFFFFFu, 0u);
+    // entries of no regular bucket (non-targets, buckets of more than 64 entries): written by the thread of the tile proper
+    if (!SAMPLE && have && t < PB_TILE && !(tgt && cnt <= 64u)) side[j] = make_uint4(node_id, 0xFFFFFFFFu, 0u, 0u);
     __syncthreads();
     if (SAMPLE && t < 2 && sCount[t]) atomicAdd(&pile_cnt[t], (unsigned long long) sCount[t]);      // (the sample is a few thousand workgroups)
 }
@@ -258,7 +261,7 @@ constexpr int PP_WAVES = PP_WAVES_N;
 // (static registers, a wave skips the slots none of its lanes uses), four waves per SIMD (five spill: 11.7 against 10.8 ms).
 __global__ void __launch_bounds__(PP_WAVES * 64, PP_OCC) k_pile_probe(PrefSufCfg cfg, ClusterCfg cc, int U, const uint4 *__restrict__ store, uint64_t n_entries, int n_nodes,
                                                                  const uint4 *__restrict__ tab, uint32_t epoch, const uint4 *__restrict__ rec, const uint8_t *__restrict__ sub,
-                                                                 const uint2 *__restrict__ succ, const uint2 *__restrict__ runs, ProbeOut o, int32_t *__restrict__ defer_list, uint32_t defer_cap,
+                                                                 const uint4 *__restrict__ side, const uint2 *__restrict__ runs, ProbeOut o, int32_t *__restrict__ defer_list, uint32_t defer_cap,
                                                                  const unsigned long long *__restrict__ pile_cnt) {
     __shared__ uint32_t sS[PP_WAVES][64][23];              // per lane: words 0..3 zero, 4..16 the consensus of the record at hand, 17..22 zero
     __shared__ int32_t sDefer[PP_WAVES][128];              // sources of this wave that wait for the defer list
@@ -287,20 +290,21 @@ __global__ void __launch_bounds__(PP_WAVES * 64, PP_OCC) k_pile_probe(PrefSufCfg
     };
     const uint64_t n_tiles = (n_entries + PP_WAVES * 64 - 1) / (PP_WAVES * 64);
     const uint64_t last = n_entries - 1;
-    // The first two links of a lane's chain -- own entry -> run list by id -- are taken a tile ahead: the id of the next tile's source is read while
-    // this tile's records are compared, its run list while this tile's targets are looked up; at the top of a tile only the row itself is
-    // still to come, and that read runs beside the first bucket line's.
-    // (The id comes from the entry itself: the early touch brings the entry's line into the memory-side cache a tile before its row is read.
-    // Measured against it: the id from the sorted id array next to the entries -- 4 GB less counter traffic, 3 % more time -- and the whole
-    // entry read a tile ahead into registers -- one visit per line, 4 % more time.)
-    auto entry_id = [&](uint64_t t) -> int {               // id of this lane's source in tile t (clamped: the last entry)
+    // What a lane reads of its source is a 16-byte SIDE record (k_pile_build: id, the right neighbour in its pile, its place in the pile), a
+    // tile ahead, and the run list by that id while this tile's targets are looked up.  The source's ROW is not read at all where the source is
+    // a member of its home bucket's first group (94 % of them): it equals that group's consensus on its whole extent -- k_pile_build verified
+    // it -- and the consensus arrives with the home run's record anyway.  (The entry's line visited twice, a tile apart, was 1.5 of the kernel's
+    // ~4.6 L1 misses per source; the other sources read their row from the entry array.)
+    auto side_of = [&](uint64_t t) -> uint4 {              // side record of this lane's source in tile t (clamped: the last entry)
         const uint64_t j = t * (PP_WAVES * 64) + threadIdx.x;
-        return (int) min(reinterpret_cast<const uint32_t *>(store)[(j < n_entries ? j : last) * (4 * PILE_EQ) + 4 * PILE_EQ - 3], (uint32_t) n_nodes - 1u);
+        uint4 v = side[j < n_entries ? j : last];
+        v.x = min(v.x, (uint32_t) n_nodes - 1u);
+        return v;
     };
-    int next_id = blockIdx.x < n_tiles ? entry_id(blockIdx.x) : 0;
+    uint4 next_side = side_of(blockIdx.x < n_tiles ? blockIdx.x : 0);
     uint4 Qr[CL_RMAX / 2];
     {
-        const uint4 *rp = reinterpret_cast<const uint4 *>(runs + (size_t) next_id * CL_RMAX);
+        const uint4 *rp = reinterpret_cast<const uint4 *>(runs + (size_t) next_side.x * CL_RMAX);
 #pragma unroll
         for (int c = 0; c < CL_RMAX / 2; c++) Qr[c] = rp[c];
     }
@@ -308,19 +312,19 @@ __global__ void __launch_bounds__(PP_WAVES * 64, PP_OCC) k_pile_probe(PrefSufCfg
     const uint64_t j = tile * (PP_WAVES * 64) + threadIdx.x;
     const bool have = j < n_entries;
     const uint64_t jc = have ? j : last;
-    const int Bs = next_id;
+    const uint4 my = next_side;                            // {id, right neighbour's id, its offset | m_C << 8 | group << 16 | first-group member << 31, -}
+    const int Bs = (int) my.x;
+    const bool row_from_pile = (my.z >> 31) != 0u;         // my row = my home bucket's first consensus on [64 - m_C, 64 - m_C + len)
     uint32_t rk[CL_RMAX], ry[CL_RMAX];
 #pragma unroll
     for (int c = 0; c < CL_RMAX / 2; c++) { rk[2 * c] = Qr[c].x; ry[2 * c] = Qr[c].y; rk[2 * c + 1] = Qr[c].z; ry[2 * c + 1] = Qr[c].w; }
-    uint32_t B[9];
-    {
+    uint32_t B[9] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    if (!row_from_pile) {
         const uint4 v0 = store[jc * PILE_EQ], v1 = store[jc * PILE_EQ + 1];
         B[0] = v0.x; B[1] = v0.y; B[2] = v0.z; B[3] = v0.w; B[4] = v1.x; B[5] = v1.y; B[6] = v1.z; B[7] = v1.w;
         B[8] = reinterpret_cast<const uint32_t *>(store)[jc * (4 * PILE_EQ) + 8];
     }
-    const uint2 my_succ = succ[jc];                        // {id, offset} of the member of my own pile that starts next to my right (k_pile_build)
-    const uint64_t tile_next = tile + gridDim.x < n_tiles ? tile + gridDim.x : tile;
-    next_id = entry_id(tile_next);
+    next_side = side_of(tile + gridDim.x < n_tiles ? tile + gridDim.x : tile);
     const int nr_code = have ? (int) (ry[0] >> 24) : 0;
     bool dfr = nr_code == CL_RUNS_FLAGGED;                 // runs k_node_runs could not list: the general kernel finds them by brute force
     const bool active = nr_code != 0 && !dfr;
@@ -338,7 +342,7 @@ __global__ void __launch_bounds__(PP_WAVES * 64, PP_OCC) k_pile_probe(PrefSufCfg
     int ea_len = 0;
     // one record against the source: the items it gives.  The consensus strings of two runs must agree past the source's end wherever both
     // are defined -- that is what makes "the overhangs of two items agree" (the via compare of the reduction) hold across runs.
-    auto take_record = [&](const uint4 &R0, const uint4 &R1, const uint4 &R2, uint32_t s12, unsigned long long rm, int slot_a, uint32_t group, uint32_t y, bool on) {
+    auto take_record = [&](const uint4 &R0, const uint4 &R1, const uint4 &R2, uint32_t s12, unsigned long long rm, int slot_a, uint32_t group, uint32_t y, bool on, bool home) {
         const int q = (int) (y & 255u), p0 = (int) ((y >> 8) & 255u), p1 = (int) ((y >> 16) & 255u);
         ss[4] = R0.x; ss[5] = R0.y; ss[6] = R0.z; ss[7] = R0.w; ss[8] = R1.x; ss[9] = R1.y; ss[10] = R1.z; ss[11] = R1.w;
         ss[12] = R2.x; ss[13] = R2.y; ss[14] = R2.z; ss[15] = R2.w; ss[16] = s12;
@@ -351,7 +355,9 @@ __global__ void __launch_bounds__(PP_WAVES * 64, PP_OCC) k_pile_probe(PrefSufCfg
         int dk = 0;
 #pragma unroll
         for (int k = 0; k < 9; k++) {
-            const uint32_t dd = (funnel(x[k], x[k + 1], sh) ^ B[k]) & low_bits32(2 * U - 32 * k);
+            const uint32_t sw = funnel(x[k], x[k + 1], sh) & low_bits32(2 * U - 32 * k);
+            B[k] = home ? sw : B[k];                       // the home run of a first-group member: this IS the source's row (and the first record a lane sees)
+            const uint32_t dd = (sw ^ B[k]) & low_bits32(2 * U - 32 * k);
             dk = dd ? k : dk;
             dv = dd ? dd : dv;
         }
@@ -394,6 +400,7 @@ __global__ void __launch_bounds__(PP_WAVES * 64, PP_OCC) k_pile_probe(PrefSufCfg
     // decided from the complete offset set).
     auto bucket_of = [&](int a) -> uint32_t { return a < nr ? min(rk[a] >> cc.idx_shift, cc.n_buckets) : cc.n_buckets; };
     uint32_t more = 0u;                                    // 4 bits per slot: further groups to take
+    bool got_row = !row_from_pile;                         // the source's row is in B
     uint4 N0, N1, N2, N3;
     {
         const uint4 *ln = tab + (size_t) bucket_of(CL_RMAX - 1) * 8;
@@ -416,13 +423,16 @@ __global__ void __launch_bounds__(PP_WAVES * 64, PP_OCC) k_pile_probe(PrefSufCfg
         more |= (mt & ~1u) << (4 * a);
         const bool on = (mt & 1u) != 0u;
         if (__ballot(on) == 0ull) continue;                // uniform
-        take_record(R0, R1, R2, R3.x, ((unsigned long long) R3.z << 32) | R3.y, a, 0u, ry[a], on);
+        const bool home = on && row_from_pile && a == nr - 1;
+        got_row = got_row || home;
+        take_record(R0, R1, R2, R3.x, ((unsigned long long) R3.z << 32) | R3.y, a, 0u, ry[a], on, home);
     }
     {                                                      // the next tile's run lists: on their way while this tile's targets are looked up
-        const uint4 *rp = reinterpret_cast<const uint4 *>(runs + (size_t) next_id * CL_RMAX);
+        const uint4 *rp = reinterpret_cast<const uint4 *>(runs + (size_t) next_side.x * CL_RMAX);
 #pragma unroll
         for (int c = 0; c < CL_RMAX / 2; c++) Qr[c] = rp[c];
     }
+    dfr = dfr || (active && !got_row);                     // (cannot happen: a first-group member's home run wants its bucket's first group)
     // the further groups that share a run's tag (another k-mer of the bucket with the same tag, or the run's own k-mer when it is not the
     // bucket's first): at most one of a slot's groups holds the source's k-mer
     more = dfr ? 0u : more;
@@ -438,7 +448,7 @@ __global__ void __launch_bounds__(PP_WAVES * 64, PP_OCC) k_pile_probe(PrefSufCfg
         const uint32_t xa = reinterpret_cast<const uint32_t *>(tab)[(size_t) min(ka >> cc.idx_shift, cc.n_buckets) * 32 + 17];      // first entry of the bucket
         const uint64_t sl = min((uint64_t) xa + g, last);  // (clamped: a corrupt record must not fault)
         const uint4 Q0 = rec[sl * 4], Q1 = rec[sl * 4 + 1], Q2 = rec[sl * 4 + 2], Q3 = rec[sl * 4 + 3];
-        take_record(Q0, Q1, Q2, Q3.x, ((unsigned long long) Q3.w << 32) | Q3.z, a, g, ya, on);
+        take_record(Q0, Q1, Q2, Q3.x, ((unsigned long long) Q3.w << 32) | Q3.z, a, g, ya, on, false);
     }
     // ---- what the source keeps, from the complete offset set; the one or two targets by id ----
     const unsigned long long kept = occ & ~smear_up(occ, G);
@@ -475,8 +485,8 @@ __global__ void __launch_bounds__(PP_WAVES * 64, PP_OCC) k_pile_probe(PrefSufCfg
         int p1_home = 0;
 #pragma unroll
         for (int k = 0; k < CL_RMAX; k++) p1_home = (k < nr && ((ry[k] >> 8) & 255u) == 0u) ? (int) ((ry[k] >> 16) & 255u) : p1_home;
-        const bool by_succ = d1 < p1_home && (int) my_succ.y == d1 && my_succ.x != 0xFFFFFFFFu;
-        const uint32_t id1 = by_succ ? my_succ.x : lookup(d1);
+        const bool by_succ = d1 < p1_home && (int) (my.z & 255u) == d1 && my.y != 0xFFFFFFFFu;
+        const uint32_t id1 = by_succ ? my.y : lookup(d1);
         uint32_t id2 = 0u;
         int d2 = 0;
         bool two = false;
@@ -542,18 +552,18 @@ size_t pile_record_bytes(uint64_t n) { return (size_t) (n + 2) * 64; }
 size_t pile_table_bytes(uint32_t n_buckets) { return ((size_t) n_buckets + 2) * 128; }
 
 void launch_pile_build(const ClusterCfg &cc, int uniform_len, const void *store, uint64_t n_entries, const void *dir, void *rec, void *tab, uint32_t epoch, uint8_t *sub,
-                       void *succ, unsigned long long *pile_cnt, bool no_sample, hipStream_t s) {
+                       void *side, unsigned long long *pile_cnt, bool no_sample, hipStream_t s) {
     (void) hipMemsetAsync(pile_cnt, 0, 2 * sizeof(unsigned long long), s);
     if (n_entries == 0) return;
     const uint64_t tiles = (n_entries + PB_TILE - 1) / PB_TILE;
     const dim3 grid((unsigned) tiles), sample((unsigned) std::max<uint64_t>(1, std::min<uint64_t>(tiles, std::max<uint64_t>(64, tiles / 32)))), block(PB_THREADS);
     // (no_sample -- tests only: the two counters stay zero and the pile kernels take the build whatever its buckets look like)
-    if (!no_sample) hipLaunchKernelGGL((k_pile_build<true>), sample, block, 0, s, (const uint4 *) store, n_entries, (const uint4 *) dir, cc, uniform_len, (uint4 *) rec, (uint4 *) tab, epoch, sub, (uint2 *) succ, pile_cnt);
-    hipLaunchKernelGGL((k_pile_build<false>), grid, block, 0, s, (const uint4 *) store, n_entries, (const uint4 *) dir, cc, uniform_len, (uint4 *) rec, (uint4 *) tab, epoch, sub, (uint2 *) succ, pile_cnt);
+    if (!no_sample) hipLaunchKernelGGL((k_pile_build<true>), sample, block, 0, s, (const uint4 *) store, n_entries, (const uint4 *) dir, cc, uniform_len, (uint4 *) rec, (uint4 *) tab, epoch, sub, (uint4 *) side, pile_cnt);
+    hipLaunchKernelGGL((k_pile_build<false>), grid, block, 0, s, (const uint4 *) store, n_entries, (const uint4 *) dir, cc, uniform_len, (uint4 *) rec, (uint4 *) tab, epoch, sub, (uint4 *) side, pile_cnt);
 }
 
 void launch_pile_probe(const PrefSufCfg &cfg, const ClusterCfg &cc, int uniform_len, const void *store, uint64_t n_entries, int n_nodes, const void *tab, uint32_t epoch, const void *rec,
-                       const uint8_t *sub, const void *succ, const void *runs, unsigned long long *counters, uint32_t *deg, unsigned long long *first, unsigned long long *second,
+                       const uint8_t *sub, const void *side, const void *runs, unsigned long long *counters, uint32_t *deg, unsigned long long *first, unsigned long long *second,
                        int32_t *defer_list, uint32_t defer_cap, const unsigned long long *pile_cnt, int n_cu, hipStream_t s) {
     if (n_entries == 0) return;
     ProbeOut o{};
@@ -561,7 +571,7 @@ void launch_pile_probe(const PrefSufCfg &cfg, const ClusterCfg &cc, int uniform_
     const uint64_t tiles = (n_entries + PP_WAVES * 64 - 1) / (PP_WAVES * 64);
     const dim3 grid((unsigned) std::max<uint64_t>(1, std::min<uint64_t>(tiles, (uint64_t) std::max(1, n_cu) * (PP_OCC * 4 / PP_WAVES)))), block(PP_WAVES * 64);      // PP_OCC waves per SIMD, four SIMDs per CU
     hipLaunchKernelGGL(k_pile_probe, grid, block, 0, s, cfg, cc, uniform_len, (const uint4 *) store, n_entries, n_nodes, (const uint4 *) tab, epoch, (const uint4 *) rec, sub,
-                       (const uint2 *) succ, (const uint2 *) runs, o, defer_list, defer_cap, pile_cnt);
+                       (const uint4 *) side, (const uint2 *) runs, o, defer_list, defer_cap, pile_cnt);
 }
 
 void launch_pile_deg(int32_t n, unsigned long long *first, uint32_t *deg, const unsigned long long *pile_cnt, hipStream_t s) {
