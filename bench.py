@@ -370,8 +370,8 @@ def run(args, rank, world, local_rank, dist, t_process=None):
                   ("k_pile_build", ms["pile"], n * (16 * eq + 16 + 1) + 64 * (n / 6.0),
                    "pile records of the entry array: entries read once, a directory record per entry, 64 B written per k-mer group (~6 entries), a byte per entry; part of the index build"),
                   (probe_kernel if first_dominates else first_name, ms["probe_pairs"], alg_probe_launch * (1.0 - deferred / n_src),
-                   "bytes by SURVEY's pairwise definition; the pile path itself has to move ~%d B per source (own entry, run list, directory + pile record per run, one 8-byte slot): %.1f GB" %
-                   (16 * eq + 64 + int(runs_per_node * 80) + 8, n_src * (16 * eq + 64 + runs_per_node * 80 + 8) / 1e9) if piled else None),
+                   "bytes by SURVEY's pairwise definition; the pile path itself has to move ~%d B per source (16-byte side record, 64-byte run list, the first 64 bytes of a bucket record per run, one 8-byte slot): %.1f GB" %
+                   (16 + 64 + int(runs_per_node * 64) + 8, n_src * (16 + 64 + runs_per_node * 64 + 8) / 1e9) if piled else None),
                   ("k_probe_clustered" + (" + k_pile_deg" if piled else ""), ms["probe"] - ms["probe_pairs"], alg_probe_launch * (deferred / n_src), None),
                   ("scan + k_local_emit_* + k_sort_rows_list", ms["emit"], n * 16 + E * 12, None)]
             out["roofline_kernels"] = []
@@ -392,7 +392,7 @@ def run(args, rank, world, local_rank, dist, t_process=None):
                 out["roofline_kernels"].append(ent)
             out["index_build_ms"] = {k: ms[k] for k in ("keys", "sort", "gather", "dir", "pile")}
             if piled:
-                own = n_src * (16 * eq + 64 + runs_per_node * 80 + 8)
+                own = n_src * (16 + 64 + runs_per_node * 64 + 8)       # side record, run list, 64 bytes of a bucket record per run, the slot
                 out["roofline"]["pile_path"] = {
                     "note": "the timed steps probe through PILES (alga_amd/csrc/prefsuf_pile.hip): one compare of a source against the consensus of a minimizer's targets instead of one "
                             "per target -- `achieved` / `frac` above keep SURVEY section 8(d)'s per-source bytes of the pairwise algorithm (what the contract defines; a frac above 1 "

@@ -35,7 +35,10 @@ def short(name):
 
 def means(root, sub):
     acc = {}
-    for f in glob.glob(os.path.join(root, sub, "**", "*counter_collection.csv"), recursive=True):
+    # (one pass = one rocprofv3 process = one file; gpurun merges every call's files into the same local directory, so only the NEWEST
+    # file of a pass directory belongs to the build at hand -- averaging over older ones mixed kernels of different builds)
+    files = sorted(glob.glob(os.path.join(root, sub, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)
+    for f in files[-1:]:
         for r in csv.DictReader(open(f)):
             acc.setdefault(short(r["Kernel_Name"]), {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
     return {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in acc.items()}
