@@ -226,7 +226,7 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
                 }
                 e->pile_epoch++;
                 launch_pile_build(cc, pp.uniform_len, e->cl_store.p, (uint64_t) nd.n, e->cl_dir.p, e->cl_pile_rec.p, e->cl_pile_tab.p, e->pile_epoch, (uint8_t *) e->cl_pile_sub.p,
-                                  e->cl_pile_succ.p, (unsigned long long *) e->cl_pile_cnt.p, e->opt_pile == 2, s);
+                                  e->cl_pile_succ.p, e->cl_runs.p, nd.n, pp.uniform_len - cfg.Lmin + 1, (unsigned long long *) e->cl_pile_cnt.p, e->opt_pile == 2, s);
                 if ((rc = alga_check_launch(e, "k_pile_build"))) return rc;
                 e->pile_n = nd.n; e->pile_words = (const void *) nd.words;
                 e->pile_timed = nd.n > 0;

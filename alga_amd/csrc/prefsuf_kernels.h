@@ -67,7 +67,7 @@ bool       pile_plan(const PrefSufCfg &cfg, const ClusterCfg &cc, int eq, int un
 size_t     pile_record_bytes(uint64_t n);
 size_t     pile_table_bytes(uint32_t n_buckets);
 void       launch_pile_build(const ClusterCfg &cc, int uniform_len, const void *store, uint64_t n_entries, const void *dir, void *rec, void *tab /* 128 B per bucket, never cleared */,
-                             uint32_t epoch /* of this build: what makes a record of `tab` valid */, uint8_t *sub, void *side /* 16 B per entry */,
+                             uint32_t epoch /* of this build: what makes a record of `tab` valid */, uint8_t *sub, void *side /* 16 B per entry */, const void *runs, int n_nodes, int nwin /* suffix windows of a read */,
                              unsigned long long *pile_cnt /* [0] buckets, [1] irregular buckets */, bool no_sample, hipStream_t s);
 void       launch_pile_probe(const PrefSufCfg &cfg, const ClusterCfg &cc, int uniform_len, const void *store, uint64_t n_entries, int n_nodes, const void *tab, uint32_t epoch,
                              const void *rec, const uint8_t *sub, const void *side, const void *runs, unsigned long long *counters, uint32_t *deg, unsigned long long *first,

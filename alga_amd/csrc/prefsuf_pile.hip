@@ -196,7 +196,8 @@ __global__ void __launch_bounds__(PB_THREADS, 3) k_pile_build(const uint4 *__res
                 // ... and what k_pile_probe reads of the entry AS A SOURCE: a member of a regular bucket's first group equals that group's consensus on
                 // its whole extent (verified above), so the probe takes its row from the bucket's record, which it reads anyway, not from the entry
                 const bool first_group = k == 0 && sBad[s] == 0u && nsub <= PILE_MAXSUB;
-                side[j] = make_uint4(node_id, succ_id, delta | ((uint32_t) m << 8) | ((uint32_t) k << 16) | (first_group ? 0x80000000u : 0u), 0u);
+                const bool leftmost = first_group && t == (int) (sMax[s] & 0xFFFFu);          // T0: k_pile_runs makes the pile's run list from its lane
+                side[j] = make_uint4(node_id, succ_id, delta | ((uint32_t) m << 8) | ((uint32_t) k << 16) | (leftmost ? 0x40000000u : 0u) | (first_group ? 0x80000000u : 0u), key >> idx_shift);
             }
             if (!SAMPLE && L == t && k >= 1 && k < PILE_MAXSUB) {
                 const unsigned long long rm = sRm[t];
@@ -222,10 +223,15 @@ __global__ void __launch_bounds__(PB_THREADS, 3) k_pile_build(const uint4 *__res
                     line[1] = make_uint4(S[4], S[5], S[6], S[7]);
                     line[2] = make_uint4(S[8], S[9], S[10], S[11]);
                     line[3] = make_uint4(S[12], (uint32_t) rm, (uint32_t) (rm >> 32), tg[0] | (tg[1] << 5) | (tg[2] << 10) | (tg[3] << 15) | (ns1 << 20) | (irregular ? 1u << 22 : 0u) | (epoch << 23));
-                    line[4] = make_uint4(cnt, drec.x, drec.z, drec.w);
                 }
                 atomicAdd(&sCount[0], 1u);
                 if (irregular) atomicAdd(&sCount[1], 1u);
+            }
+            if (!SAMPLE && L == s && t == (int) (sMax[s] & 0xFFFFu)) {
+                // T0 of the first group (the member that starts leftmost): the second half of the bucket's record -- no run list yet (k_pile_runs), and
+                // who T1 is (the member that starts rightmost: the lowest slot of the group's dense stretch): its id and its m_C
+                line[4] = make_uint4(cnt, drec.x, drec.z, drec.w);
+                line[5] = make_uint4(sSlot[s], sMin[s] >> 16, 0u, 0u);
             }
         }
     }
@@ -233,6 +239,65 @@ __global__ void __launch_bounds__(PB_THREADS, 3) k_pile_build(const uint4 *__res
     if (!SAMPLE && have && t < PB_TILE && !(tgt && cnt <= 64u)) side[j] = make_uint4(node_id, 0xFFFFFFFFu, 0u, 0u);
     __syncthreads();
     if (SAMPLE && t < 2 && sCount[t]) atomicAdd(&pile_cnt[t], (unsigned long long) sCount[t]);      // (the sample is a few thousand workgroups)
+}
+
+// ------------------------------------------------------------------------------------------
+// The RUN LIST of a pile (the first group of a regular bucket).  The windows of the pile's members overlap, and a window's minimizer is a matter
+// of its content: the member that starts leftmost (T0) and the one that starts rightmost (T1) between them hold every window of every member,
+// so their two run lists, joined where T0's windows end, are the run list of the whole pile on the pile's axis -- and a member's own run list is
+// that list clipped to its windows.  k_pile_probe reads it from the bucket's record (one read shared by the pile's members, who sit side by side
+// in the entry order) instead of every source's own list by id: a random read per source, 3 of that kernel's 10 ms; here it is two random reads
+// per PILE.  One lane per entry; the lanes of the T0s work (k_pile_build flagged them and left T1's id in the record).
+__global__ void __launch_bounds__(256) k_pile_runs(const uint4 *__restrict__ side, uint64_t n_entries, uint32_t n_buckets, uint4 *__restrict__ tab, const uint2 *__restrict__ runs,
+                                                   int n_nodes, int nwin, const unsigned long long *__restrict__ pile_cnt) {
+    if (pile_declines(pile_cnt)) return;
+    const uint64_t j = (uint64_t) blockIdx.x * 256 + threadIdx.x;
+    if (j >= n_entries) return;
+    const uint4 sd = side[j];
+    if (((sd.z >> 30) & 1u) == 0u) return;                 // not the leftmost member of a pile
+    uint4 *line = tab + (size_t) min(sd.w, n_buckets) * 8;
+    const uint4 l4 = line[4], l5 = line[5];
+    const uint4 *r0 = reinterpret_cast<const uint4 *>(runs + (size_t) min(sd.x, (uint32_t) n_nodes - 1u) * CL_RMAX);
+    const uint4 *r1 = reinterpret_cast<const uint4 *>(runs + (size_t) min(l5.x, (uint32_t) n_nodes - 1u) * CL_RMAX);
+    const uint4 a0 = r0[0], a1 = r0[1], a2 = r0[2], a3 = r0[3], b0 = r1[0], b1 = r1[1], b2 = r1[2];
+    // windows ascending, on the pile's axis (coordinate + 64 in a byte): T0's runs from its first window to its last (its run 0 holds the last ones),
+    // then what T1's first six runs hold beyond T0's last window; at most six runs, else the members read their own lists
+    const int s0 = -(int) ((sd.z >> 8) & 63u), s1 = -(int) (l5.y & 63u), seam = s0 + nwin;
+    const uint32_t k0[CL_RMAX] = {a0.x, a0.z, a1.x, a1.z, a2.x, a2.z, a3.x, a3.z}, y0[CL_RMAX] = {a0.y, a0.w, a1.y, a1.w, a2.y, a2.w, a3.y, a3.w};
+    const uint32_t k1[6] = {b0.x, b0.z, b1.x, b1.z, b2.x, b2.z}, y1[6] = {b0.y, b0.w, b1.y, b1.w, b2.y, b2.w};
+    const int nr0 = (int) (y0[0] >> 24), nr1 = (int) (y1[0] >> 24);
+    bool ok = nr0 >= 1 && nr0 <= CL_RMAX && nr1 >= 1 && nr1 <= 6 && s1 <= seam;
+    uint2 *out = reinterpret_cast<uint2 *>(line + 5);
+    int n = 0;
+    uint32_t last_key = 0u, last_pos = 0xFFFFFFFFu, last_c0 = 0u;
+#pragma unroll
+    for (int r = CL_RMAX - 1; r >= 0; r--) {
+        if (ok && r < nr0) {
+            const uint32_t kpos = (uint32_t) (s0 + (int) (y0[r] & 255u) + 64), c0 = (uint32_t) (s0 + (int) ((y0[r] >> 8) & 255u) + 64), c1 = (uint32_t) (s0 + (int) ((y0[r] >> 16) & 255u) + 64);
+            if (n < 6) out[n] = make_uint2(k0[r], kpos | (c0 << 8) | (c1 << 16));
+            last_key = k0[r]; last_pos = kpos; last_c0 = c0;
+            n++;
+        }
+    }
+#pragma unroll
+    for (int r = 5; r >= 0; r--) {
+        if (ok && r < nr1) {
+            const int c1i = s1 + (int) ((y1[r] >> 16) & 255u);
+            if (c1i > seam) {
+                const int c0i = max(s1 + (int) ((y1[r] >> 8) & 255u), seam);
+                const uint32_t kpos = (uint32_t) (s1 + (int) (y1[r] & 255u) + 64), c1 = (uint32_t) (c1i + 64);
+                if (n >= 1 && k1[r] == last_key && kpos == last_pos) {             // the same minimizer on both sides of the seam: one run
+                    if (n <= 6) out[n - 1] = make_uint2(last_key, last_pos | (last_c0 << 8) | (c1 << 16));
+                } else {
+                    if (n < 6) out[n] = make_uint2(k1[r], kpos | ((uint32_t) (c0i + 64) << 8) | (c1 << 16));
+                    last_key = k1[r]; last_pos = kpos; last_c0 = (uint32_t) (c0i + 64);
+                    n++;
+                }
+            }
+        }
+    }
+    ok = ok && n >= 1 && n <= 6;
+    reinterpret_cast<uint32_t *>(line + 4)[0] = (l4.x & 255u) | (ok ? (uint32_t) n << 8 : 0u);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -301,10 +366,16 @@ __global__ void __launch_bounds__(PP_WAVES * 64, PP_OCC) k_pile_probe(PrefSufCfg
         v.x = min(v.x, (uint32_t) n_nodes - 1u);
         return v;
     };
+    // Where a lane's run list comes from: the second half of its home bucket's record (the PILE's run list, k_pile_build: one 64-byte read
+    // shared by the pile's members, who sit side by side) for a member of the bucket's first group; its own list by id (a random read) otherwise.
+    auto run_list_of = [&](const uint4 &sd) -> const uint4 * {
+        return (sd.z >> 31) ? tab + (size_t) min(sd.w, cc.n_buckets) * 8 + 4 : reinterpret_cast<const uint4 *>(runs + (size_t) sd.x * CL_RMAX);
+    };
+    const int nwin = U - cfg.Lmin + 1;
     uint4 next_side = side_of(blockIdx.x < n_tiles ? blockIdx.x : 0);
     uint4 Qr[CL_RMAX / 2];
     {
-        const uint4 *rp = reinterpret_cast<const uint4 *>(runs + (size_t) next_side.x * CL_RMAX);
+        const uint4 *rp = run_list_of(next_side);
 #pragma unroll
         for (int c = 0; c < CL_RMAX / 2; c++) Qr[c] = rp[c];
     }
@@ -314,10 +385,47 @@ __global__ void __launch_bounds__(PP_WAVES * 64, PP_OCC) k_pile_probe(PrefSufCfg
     const uint64_t jc = have ? j : last;
     const uint4 my = next_side;                            // {id, right neighbour's id, its offset | m_C << 8 | group << 16 | first-group member << 31, -}
     const int Bs = (int) my.x;
-    const bool row_from_pile = (my.z >> 31) != 0u;         // my row = my home bucket's first consensus on [64 - m_C, 64 - m_C + len)
-    uint32_t rk[CL_RMAX], ry[CL_RMAX];
+    const bool first_group = (my.z >> 31) != 0u;
+    const uint32_t npr = first_group ? (Qr[0].x >> 8) & 15u : 0u;         // runs of my pile's list (0: it has none -- more than six, or a member's own list is flagged)
+    if (first_group && npr == 0u) {                        // (rare: my own list after all, late)
+        const uint4 *rp = reinterpret_cast<const uint4 *>(runs + (size_t) Bs * CL_RMAX);
 #pragma unroll
-    for (int c = 0; c < CL_RMAX / 2; c++) { rk[2 * c] = Qr[c].x; ry[2 * c] = Qr[c].y; rk[2 * c + 1] = Qr[c].z; ry[2 * c + 1] = Qr[c].w; }
+        for (int c = 0; c < CL_RMAX / 2; c++) Qr[c] = rp[c];
+    }
+    // my row = my home bucket's first consensus on [64 - m_C, 64 - m_C + len): with the pile's run list the home run is the first slot, so the
+    // row is there before any other run is compared
+    const bool row_from_pile = npr != 0u;
+    uint32_t rk[CL_RMAX], ry[CL_RMAX];
+    uint32_t vmask = 0u;                                   // bit a: slot a holds a run of this source
+    {
+        // (a) my own list: slot a = run a, the last windows first
+        uint32_t ok[CL_RMAX], oy[CL_RMAX];
+#pragma unroll
+        for (int c = 0; c < CL_RMAX / 2; c++) { ok[2 * c] = Qr[c].x; oy[2 * c] = Qr[c].y; ok[2 * c + 1] = Qr[c].z; oy[2 * c + 1] = Qr[c].w; }
+        // (b) the pile's list, windows ascending on the pile's axis (coordinate + 64): clipped to my windows [-m_C, -m_C + nwin)
+        const uint32_t pk[6] = {Qr[1].x, Qr[1].z, Qr[2].x, Qr[2].z, Qr[3].x, Qr[3].z}, pp[6] = {Qr[1].y, Qr[1].w, Qr[2].y, Qr[2].w, Qr[3].y, Qr[3].w};
+        const int sB = 64 - (int) ((my.z >> 8) & 63u);     // my first window, + 64
+#pragma unroll
+        for (int a = 0; a < CL_RMAX; a++) {
+            uint32_t k = ok[a], y = oy[a] & 0x00FFFFFFu;
+            bool v = false;
+            if (a < 6) {
+                const int kpos = (int) (pp[a] & 255u), c0 = (int) ((pp[a] >> 8) & 255u), c1 = (int) ((pp[a] >> 16) & 255u);
+                const int p0 = max(c0, sB) - sB, p1 = min(c1, sB + nwin) - sB;
+                const bool pv = row_from_pile && (uint32_t) a < npr && p0 < p1 && kpos >= sB;
+                k = row_from_pile ? pk[a] : k;
+                y = row_from_pile ? (uint32_t) (kpos - sB) | ((uint32_t) max(p0, 0) << 8) | ((uint32_t) max(p1, 0) << 16) : y;
+                v = pv;
+            }
+            rk[a] = k; ry[a] = y;
+            vmask |= v ? 1u << a : 0u;
+        }
+        if (!row_from_pile) {
+            const int code = have ? (int) (oy[0] >> 24) : 0;
+            vmask = (code == 0 || code == CL_RUNS_FLAGGED) ? 0u : (code >= CL_RMAX ? 0xFFu : ((1u << code) - 1u));
+            ry[0] |= (uint32_t) code << 24;
+        }
+    }
     uint32_t B[9] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
     if (!row_from_pile) {
         const uint4 v0 = store[jc * PILE_EQ], v1 = store[jc * PILE_EQ + 1];
@@ -325,15 +433,15 @@ __global__ void __launch_bounds__(PP_WAVES * 64, PP_OCC) k_pile_probe(PrefSufCfg
         B[8] = reinterpret_cast<const uint32_t *>(store)[jc * (4 * PILE_EQ) + 8];
     }
     next_side = side_of(tile + gridDim.x < n_tiles ? tile + gridDim.x : tile);
-    const int nr_code = have ? (int) (ry[0] >> 24) : 0;
+    const int nr_code = !have ? 0 : (row_from_pile ? 1 : (int) (ry[0] >> 24));       // (a pile's member is a source: one length, no masks)
     bool dfr = nr_code == CL_RUNS_FLAGGED;                 // runs k_node_runs could not list: the general kernel finds them by brute force
     const bool active = nr_code != 0 && !dfr;
-    const int nr = active ? (nr_code < CL_RMAX ? nr_code : CL_RMAX) : 0;
+    vmask = active ? vmask : 0u;
     // the same minimizer twice in one source (a tandem repeat): a target could be an item at two offsets
 #pragma unroll
     for (int a = 0; a < CL_RMAX; a++)
 #pragma unroll
-        for (int b = a + 1; b < CL_RMAX; b++) dfr = dfr || (b < nr && rk[a] == rk[b]);
+        for (int b = a + 1; b < CL_RMAX; b++) dfr = dfr || (((vmask >> a) & (vmask >> b) & 1u) != 0u && rk[a] == rk[b]);
     const int Lbig = cfg.rsoemo > cfg.Lmin ? cfg.rsoemo : cfg.Lmin;
     const int G = min(max(U - Lbig, 0), 63);               // an item is removed iff another sits 1 .. G offsets before it
     unsigned long long occ = 0ull;                         // offsets that hold an item
@@ -398,23 +506,23 @@ __global__ void __launch_bounds__(PP_WAVES * 64, PP_OCC) k_pile_probe(PrefSufCfg
     // bucket share all 32 bits of their hash (3 % of the buckets at the north-star size: 19-mers do not fit 32 bits).  Group 0 is in the
     // record itself; the others are taken in a short loop behind this one (the order of the records is free: what a source keeps is
     // decided from the complete offset set).
-    auto bucket_of = [&](int a) -> uint32_t { return a < nr ? min(rk[a] >> cc.idx_shift, cc.n_buckets) : cc.n_buckets; };
+    auto bucket_of = [&](int a) -> uint32_t { return ((vmask >> a) & 1u) ? min(rk[a] >> cc.idx_shift, cc.n_buckets) : cc.n_buckets; };
     uint32_t more = 0u;                                    // 4 bits per slot: further groups to take
     bool got_row = !row_from_pile;                         // the source's row is in B
     uint4 N0, N1, N2, N3;
     {
-        const uint4 *ln = tab + (size_t) bucket_of(CL_RMAX - 1) * 8;
+        const uint4 *ln = tab + (size_t) bucket_of(0) * 8;
         N0 = ln[0]; N1 = ln[1]; N2 = ln[2]; N3 = ln[3];
     }
 #pragma unroll
-    for (int a = CL_RMAX - 1; a >= 0; a--) {
+    for (int a = 0; a < CL_RMAX; a++) {                    // (slot 0 first: the home run of a lane that takes its row from the pile)
         const uint4 R0 = N0, R1 = N1, R2 = N2, R3 = N3;
-        if (a > 0) {
-            const uint4 *ln = tab + (size_t) bucket_of(a - 1) * 8;
+        if (a + 1 < CL_RMAX) {
+            const uint4 *ln = tab + (size_t) bucket_of(a + 1) * 8;
             N0 = ln[0]; N1 = ln[1]; N2 = ln[2]; N3 = ln[3];
         }
         const uint32_t y = R3.w, tag = rk[a] & 31u;
-        const bool live = a < nr && (y >> 23) == epoch;    // a record of another epoch: no entry in this bucket
+        const bool live = ((vmask >> a) & 1u) != 0u && (y >> 23) == epoch;    // a record of another epoch: no entry in this bucket
         dfr = dfr || (live && ((y >> 22) & 1u) != 0u);     // a bucket k_pile_build found irregular (or of more than 64 entries)
         const uint32_t ns = ((y >> 20) & 3u) + 1u;
         uint32_t mt = ((y & 31u) == tag ? 1u : 0u) | ((ns >= 2u && ((y >> 5) & 31u) == tag) ? 2u : 0u) | ((ns >= 3u && ((y >> 10) & 31u) == tag) ? 4u : 0u) |
@@ -423,12 +531,12 @@ __global__ void __launch_bounds__(PP_WAVES * 64, PP_OCC) k_pile_probe(PrefSufCfg
         more |= (mt & ~1u) << (4 * a);
         const bool on = (mt & 1u) != 0u;
         if (__ballot(on) == 0ull) continue;                // uniform
-        const bool home = on && row_from_pile && a == nr - 1;
+        const bool home = on && row_from_pile && !got_row && ((ry[a] >> 8) & 255u) == 0u;      // the run of window 0
         got_row = got_row || home;
         take_record(R0, R1, R2, R3.x, ((unsigned long long) R3.z << 32) | R3.y, a, 0u, ry[a], on, home);
     }
     {                                                      // the next tile's run lists: on their way while this tile's targets are looked up
-        const uint4 *rp = reinterpret_cast<const uint4 *>(runs + (size_t) next_side.x * CL_RMAX);
+        const uint4 *rp = run_list_of(next_side);
 #pragma unroll
         for (int c = 0; c < CL_RMAX / 2; c++) Qr[c] = rp[c];
     }
@@ -459,7 +567,7 @@ __global__ void __launch_bounds__(PP_WAVES * 64, PP_OCC) k_pile_probe(PrefSufCfg
         uint32_t ya = 0u, ka = 0u, ga = 0u;
 #pragma unroll
         for (int k = 0; k < CL_RMAX; k++) {
-            const bool in = k < nr && d >= (int) ((ry[k] >> 8) & 255u) && d < (int) ((ry[k] >> 16) & 255u);
+            const bool in = ((vmask >> k) & 1u) != 0u && d >= (int) ((ry[k] >> 8) & 255u) && d < (int) ((ry[k] >> 16) & 255u);
             ya = in ? ry[k] : ya; ka = in ? rk[k] : ka; ga = in ? (grp >> (2 * k)) & 3u : ga;
         }
         const uint4 dd = tab[(size_t) min(ka >> cc.idx_shift, cc.n_buckets) * 8 + 4];       // {entries | ..., first entry, class offsets}
@@ -484,7 +592,7 @@ __global__ void __launch_bounds__(PP_WAVES * 64, PP_OCC) k_pile_probe(PrefSufCfg
         // member k_pile_build noted for this entry, no look-up (a bucket line's second half, an entry tail and a group byte: three more L1 misses)
         int p1_home = 0;
 #pragma unroll
-        for (int k = 0; k < CL_RMAX; k++) p1_home = (k < nr && ((ry[k] >> 8) & 255u) == 0u) ? (int) ((ry[k] >> 16) & 255u) : p1_home;
+        for (int k = 0; k < CL_RMAX; k++) p1_home = (((vmask >> k) & 1u) != 0u && ((ry[k] >> 8) & 255u) == 0u) ? (int) ((ry[k] >> 16) & 255u) : p1_home;
         const bool by_succ = d1 < p1_home && (int) (my.z & 255u) == d1 && my.y != 0xFFFFFFFFu;
         const uint32_t id1 = by_succ ? my.y : lookup(d1);
         uint32_t id2 = 0u;
@@ -552,7 +660,7 @@ size_t pile_record_bytes(uint64_t n) { return (size_t) (n + 2) * 64; }
 size_t pile_table_bytes(uint32_t n_buckets) { return ((size_t) n_buckets + 2) * 128; }
 
 void launch_pile_build(const ClusterCfg &cc, int uniform_len, const void *store, uint64_t n_entries, const void *dir, void *rec, void *tab, uint32_t epoch, uint8_t *sub,
-                       void *side, unsigned long long *pile_cnt, bool no_sample, hipStream_t s) {
+                       void *side, const void *runs, int n_nodes, int nwin, unsigned long long *pile_cnt, bool no_sample, hipStream_t s) {
     (void) hipMemsetAsync(pile_cnt, 0, 2 * sizeof(unsigned long long), s);
     if (n_entries == 0) return;
     const uint64_t tiles = (n_entries + PB_TILE - 1) / PB_TILE;
@@ -560,6 +668,7 @@ void launch_pile_build(const ClusterCfg &cc, int uniform_len, const void *store,
     // (no_sample -- tests only: the two counters stay zero and the pile kernels take the build whatever its buckets look like)
     if (!no_sample) hipLaunchKernelGGL((k_pile_build<true>), sample, block, 0, s, (const uint4 *) store, n_entries, (const uint4 *) dir, cc, uniform_len, (uint4 *) rec, (uint4 *) tab, epoch, sub, (uint4 *) side, pile_cnt);
     hipLaunchKernelGGL((k_pile_build<false>), grid, block, 0, s, (const uint4 *) store, n_entries, (const uint4 *) dir, cc, uniform_len, (uint4 *) rec, (uint4 *) tab, epoch, sub, (uint4 *) side, pile_cnt);
+    hipLaunchKernelGGL(k_pile_runs, dim3((unsigned) ((n_entries + 255) / 256)), dim3(256), 0, s, (const uint4 *) side, n_entries, cc.n_buckets, (uint4 *) tab, (const uint2 *) runs, n_nodes, nwin, pile_cnt);
 }
 
 void launch_pile_probe(const PrefSufCfg &cfg, const ClusterCfg &cc, int uniform_len, const void *store, uint64_t n_entries, int n_nodes, const void *tab, uint32_t epoch, const void *rec,
