@@ -367,8 +367,9 @@ def run(args, rank, world, local_rank, dist, t_process=None):
                    ms["sort"], 4 * n + (3 if n >= (1 << 22) else 4) * 2 * 8 * n, "library code; bytes = histogram read + passes x (read + write) of 8-byte pairs"),
                   ("k_tgt_gather", ms["gather"], n * (4 * W + 8 + 16 * eq), "one isolated 64-byte row per entry: 128 bytes fetched for it"),
                   ("k_tgt_dir", ms["dir"], 4 * n + 16 * (nb + 1), "includes the zero fill of the directory (16 B per bucket) in front of the kernel"),
-                  ("k_pile_build", ms["pile"], n * (16 * eq + 16 + 1) + 64 * (n / 6.0),
-                   "pile records of the entry array: entries read once, a directory record per entry, 64 B written per k-mer group (~6 entries), a byte per entry; part of the index build"),
+                  ("k_pile_build + k_pile_runs", ms["pile"], n * (16 * eq + 16 + 1 + 16) + 64 * (n / 6.0) + n * 16 + (n / 6.0) * (128 + 48),
+                   "pile records of the entry array: entries read once, a directory record per entry, 64 B written per k-mer group (~6 entries), a byte and a 16-byte side record per entry; "
+                   "then the run list of each pile: side records read, two 64-byte run lists in and 48 bytes out per group; part of the index build"),
                   (probe_kernel if first_dominates else first_name, ms["probe_pairs"], alg_probe_launch * (1.0 - deferred / n_src),
                    "bytes by SURVEY's pairwise definition; the pile path itself has to move ~%d B per source (16-byte side record, 64-byte run list, the first 64 bytes of a bucket record per run, one 8-byte slot): %.1f GB" %
                    (16 + 64 + int(runs_per_node * 64) + 8, n_src * (16 + 64 + runs_per_node * 64 + 8) / 1e9) if piled else None),
@@ -384,7 +385,7 @@ def run(args, rank, world, local_rank, dist, t_process=None):
                 elif head == "scan":
                     tr = sum(filter(None, (traffic_of(traffic, q) for q in ("k_scan", "k_local_emit", "k_sort_rows")))) or None
                 else:
-                    tr = traffic_of(traffic, head)
+                    tr = sum(filter(None, (traffic_of(traffic, q.split()[0]) for q in name.split(" + ")))) or None
                 ent = {"kernel": name, "ms": kms, "share_of_step": kms / ms_step, "algorithmic_bytes": int(ab), "achieved": ab / (kms * 1e-3) / 1e9,
                        "frac": ab / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": tr, "achieved_hbm": (tr / (kms * 1e-3) / 1e9) if tr else None}
                 if note:
