@@ -21,11 +21,14 @@
 //   k_pile_build   one lane per ENTRY of the entry array: per bucket the groups of equal minimizer k-mer (<= PILE_MAXSUB), per group the
 //                  consensus (leftmost-starting | rightmost-ending member), every member verified against it, the mirrored m_C set;
 //                  the record of the bucket's first group in a table indexed by the bucket, the further groups' at their entry slots, a byte
-//                  per entry (its group).  A bucket where any of it fails (a member that differs from the consensus, two members at one
-//                  m_C, more groups or entries than fit) is flagged: its sources go to the general kernel.  As <SAMPLE> on the first 1/32
-//                  of the entry array it only counts such buckets: the three kernels leave a build of reads with errors to k_probe_stream.
-//   k_pile_probe   one lane per SOURCE (in the order of the entry array): per run ONE 64-byte read of the bucket's record; regular sources
-//                  get their edges, the others go on the defer list of k_probe_clustered.
+//                  per entry (its group) and a 16-byte SIDE record (what k_pile_probe reads of the entry as a source).  A bucket where any
+//                  of it fails (a member that differs from the consensus, two members at one m_C, more groups or entries than fit) is
+//                  flagged: its sources go to the general kernel.  As <SAMPLE> on the first 1/32 of the entry array it only counts such
+//                  buckets: the pile kernels leave a build of reads with errors to k_probe_stream.
+//   k_pile_runs    one lane per entry, the lane of a pile's leftmost member works: the RUN LIST of the pile (the minimizer runs of all its
+//                  members' windows on the pile's axis), into the second half of the bucket's record.
+//   k_pile_probe   one lane per SOURCE (in the order of the entry array): per run the first 64 bytes of the bucket's record, loaded once
+//                  per distinct bucket of a wave; regular sources get their edges, the others go on the defer list of k_probe_clustered.
 //   k_pile_deg     a streaming pass that moves the out-degree k_pile_probe left in the source's slot to deg[].
 // Nothing is approximated: every decision either follows from verified equalities or is handed to the pairwise kernels.
 #include <hip/hip_runtime.h>
@@ -39,7 +42,7 @@ namespace alga {
 
 constexpr int PB_TILE = 512, PB_HALO = 64, PB_THREADS = PB_TILE + PB_HALO;      // buckets that START in the tile; the halo holds their tails
 constexpr int PILE_SW = 13;                    // consensus words: coordinates -64 .. 143 (m_C <= 63, rows of up to 9 words)
-constexpr int PILE_MAXSUB = 4;                 // k-mer groups of one bucket (two k-mers share one of 2^26 buckets for ~9 % of the non-empty buckets at the north-star size)
+constexpr int PILE_MAXSUB = 4;                 // k-mer groups of one bucket (two k-mers share one of 2^26 buckets for ~12 % of the non-empty buckets at the north-star size)
 constexpr int PILE_EQ = 3;                     // entry size this path takes: rows of up to 9 words (reads of 100 - 150 bp)
 // What a source reads per run is ONE 128-byte line: the bucket's record in a table indexed by the bucket itself (`tab`, 32 words per bucket)
 //   w[0 .. 12]  consensus of the bucket's FIRST k-mer group, word k = coordinates -64 + 16 k ..
@@ -47,9 +50,12 @@ constexpr int PILE_EQ = 3;                     // entry size this path takes: ro
 //   w[15]       tag of group 0 .. 3 (bits 0..4, 5..9, 10..14, 15..19) | groups - 1 (bits 20..21) | irregular (bit 22) | epoch of the build that wrote
 //               the record (bits 23..31, never 0: the table is not cleared between builds, a record of another epoch is an empty bucket)
 //   -- the first 64 bytes are all the run loop reads (the kernel is bound by the number of 64-byte requests that miss its L1) --
-//   w[16]       entries (127: more than 64);  w[17] first entry of the bucket;  w[18], w[19] the directory's class offsets (k_tgt_dir): the look-up of a target
+//   w[16]       entries (127: more than 64) | runs of the pile's run list << 8 (0: none -- its members read their own lists);  w[17] first entry of
+//               the bucket;  w[18], w[19] the directory's class offsets (k_tgt_dir): the look-up of a target
+//   w[20 .. 31] the pile's run list (k_pile_runs): up to six runs {cluster key, (k-mer position + 64) | (first window + 64) << 8 | (end + 64) << 16},
+//               windows ascending on the pile's axis
 // tag = low five bits of the k-mer's cluster key, i.e. of the word a run carries (they lie below the bucket bits): which group a run wants
-// without a second read.  The further groups of a bucket (another k-mer in the same bucket: 9 % of the non-empty buckets at the north-star
+// without a second read.  The further groups of a bucket (another k-mer in the same bucket: 12 % of the non-empty buckets at the north-star
 // size) have 16-word records {consensus, -, set} in `rec` at entry slot first + k, k in the order of the groups' first members.
 
 // ------------------------------------------------------------------------------------------
@@ -317,28 +323,31 @@ __device__ __forceinline__ unsigned long long smear_up(unsigned long long x, int
 #define PP_WAVES_N 4
 #endif
 constexpr int PP_WAVES = PP_WAVES_N;
+constexpr int PP_LSTRIDE = 20;
 #ifndef PP_OCC
 #define PP_OCC 4
 #endif
-// One lane per source.  What bounds this kernel is the CHAIN of dependent memory reads of a lane (own entry -> run list by id -> bucket record
-// -> ... -> the targets that stand) and the number of 64-byte requests that miss its L1, not arithmetic and not bytes: id and run list are read
-// a tile ahead, the record of the next run is on its way while the current one is compared, the run loop is unrolled over the eight slots
-// (static registers, a wave skips the slots none of its lanes uses), four waves per SIMD (five spill: 11.7 against 10.8 ms).
+// One lane per source.  What bounds this kernel is neither arithmetic (its vector ALUs are busy ~55 % of the time) nor bytes (2.7 TB/s) but
+// the waves' waiting for memory -- the chain side record -> run list -> bucket records -> the targets that stand -- at four waves per SIMD
+// (five spill: 9.9 against 7.9 ms): side record and run list are read a tile ahead, the records of the next run are on their way while
+// the current one is compared (of the next two: no faster), the run loop is unrolled over the eight slots (static registers; a wave skips the slots none of its lanes uses).
 __global__ void __launch_bounds__(PP_WAVES * 64, PP_OCC) k_pile_probe(PrefSufCfg cfg, ClusterCfg cc, int U, const uint4 *__restrict__ store, uint64_t n_entries, int n_nodes,
                                                                  const uint4 *__restrict__ tab, uint32_t epoch, const uint4 *__restrict__ rec, const uint8_t *__restrict__ sub,
                                                                  const uint4 *__restrict__ side, const uint2 *__restrict__ runs, ProbeOut o, int32_t *__restrict__ defer_list, uint32_t defer_cap,
                                                                  const unsigned long long *__restrict__ pile_cnt) {
-    __shared__ uint32_t sS[PP_WAVES][64][23];              // per lane: words 0..3 zero, 4..16 the consensus of the record at hand, 17..22 zero
+    // the records of the slot at hand, ONE copy per distinct bucket of the wave (the members of a pile sit side by side and want the same
+    // records): PP_LSTRIDE words per record (16 used; 20: the lanes of sixteen records read conflict-free), four words of slack in front and
+    // twelve behind -- a compare reads up to four words before and six behind a record, and what it finds there is masked
+    __shared__ __attribute__((aligned(16))) uint32_t sL[PP_WAVES][4 + 64 * PP_LSTRIDE + 12];
+    __shared__ uint32_t sBk[PP_WAVES][64];                 // the distinct buckets of the slot whose records are on their way, in lane order
     __shared__ int32_t sDefer[PP_WAVES][128];              // sources of this wave that wait for the defer list
     if (blockIdx.x == 0 && threadIdx.x == 0) { o.counters[CNT_PILE_BUCKETS] = pile_cnt[0]; o.counters[CNT_PILE_IRREGULAR] = pile_cnt[1]; }
     // a build whose buckets are mostly irregular (reads with sequencing errors) is k_probe_stream's: this kernel leaves at once
     if (pile_declines(pile_cnt)) return;
     const int wave = (int) (threadIdx.x >> 6), lane = lane_id();
-    uint32_t *ss = sS[wave][lane];
-#pragma unroll
-    for (int k = 0; k < 4; k++) ss[k] = 0u;
-#pragma unroll
-    for (int k = 17; k < 23; k++) ss[k] = 0u;
+    uint32_t *sl = sL[wave] + 4;                           // word 0 of record 0
+    for (int k = lane; k < 4 + 64 * PP_LSTRIDE + 12; k += 64) sL[wave][k] = 0u;
+    wave_lds_fence();
     // A persistent grid: one global atomic per WAVE for the edge count and one per ~64 deferred sources -- as one workgroup per 256 sources
     // the kernel made 1.4 M same-address atomics per build, which serialise in the L2 at ~90 per microsecond (6 ms of its 19).
     uint64_t st_rec = 0;
@@ -437,11 +446,20 @@ __global__ void __launch_bounds__(PP_WAVES * 64, PP_OCC) k_pile_probe(PrefSufCfg
     bool dfr = nr_code == CL_RUNS_FLAGGED;                 // runs k_node_runs could not list: the general kernel finds them by brute force
     const bool active = nr_code != 0 && !dfr;
     vmask = active ? vmask : 0u;
+    uint32_t um = 0u;                                      // uniform: slots in which any lane of the wave has a run
+#pragma unroll
+    for (int a = 0; a < CL_RMAX; a++) um |= __ballot(((vmask >> a) & 1u) != 0u) != 0ull ? 1u << a : 0u;
     // the same minimizer twice in one source (a tandem repeat): a target could be an item at two offsets
 #pragma unroll
-    for (int a = 0; a < CL_RMAX; a++)
+    for (int a = 0; a < 6; a++)
 #pragma unroll
-        for (int b = a + 1; b < CL_RMAX; b++) dfr = dfr || (((vmask >> a) & (vmask >> b) & 1u) != 0u && rk[a] == rk[b]);
+        for (int b = a + 1; b < 6; b++) dfr = dfr || (((vmask >> a) & (vmask >> b) & 1u) != 0u && rk[a] == rk[b]);
+    if (um >> 6) {                                         // uniform: a lane with seven or eight runs of its own
+#pragma unroll
+        for (int a = 0; a < CL_RMAX; a++)
+#pragma unroll
+            for (int b = (a + 1 > 6 ? a + 1 : 6); b < CL_RMAX; b++) dfr = dfr || (((vmask >> a) & (vmask >> b) & 1u) != 0u && rk[a] == rk[b]);
+    }
     const int Lbig = cfg.rsoemo > cfg.Lmin ? cfg.rsoemo : cfg.Lmin;
     const int G = min(max(U - Lbig, 0), 63);               // an item is removed iff another sits 1 .. G offsets before it
     unsigned long long occ = 0ull;                         // offsets that hold an item
@@ -450,11 +468,13 @@ __global__ void __launch_bounds__(PP_WAVES * 64, PP_OCC) k_pile_probe(PrefSufCfg
     int ea_len = 0;
     // one record against the source: the items it gives.  The consensus strings of two runs must agree past the source's end wherever both
     // are defined -- that is what makes "the overhangs of two items agree" (the via compare of the reduction) hold across runs.
-    auto take_record = [&](const uint4 &R0, const uint4 &R1, const uint4 &R2, uint32_t s12, unsigned long long rm, int slot_a, uint32_t group, uint32_t y, bool on, bool home) {
+    // `lb`: where the record's word 0 is (in sl).  Consensus word k = coordinates -64 + 16 k ..; the words the compare touches outside 0 .. 12
+    // (a source that reaches left of coordinate -64, or the words behind the consensus) belong to positions no item of the record can use:
+    // a mismatch there lies left of every offset the record's set holds, and the consensus past the source's end is masked to its length.
+    auto take_record = [&](int lb, unsigned long long rm, int slot_a, uint32_t group, uint32_t y, bool on, bool home) {
         const int q = (int) (y & 255u), p0 = (int) ((y >> 8) & 255u), p1 = (int) ((y >> 16) & 255u);
-        ss[4] = R0.x; ss[5] = R0.y; ss[6] = R0.z; ss[7] = R0.w; ss[8] = R1.x; ss[9] = R1.y; ss[10] = R1.z; ss[11] = R1.w;
-        ss[12] = R2.x; ss[13] = R2.y; ss[14] = R2.z; ss[15] = R2.w; ss[16] = s12;
-        // position t of the source = consensus index 64 - q + t = bit 2 (128 - q + t) of the padded consensus
+        const uint32_t *ss = sl + lb - 4;                  // (index 4 = word 0 of the record)
+        // position t of the source = consensus index 64 - q + t = bit 2 (128 - q + t) of the consensus padded with four words in front
         const int ob = 2 * (128 - min(q, 127)), w0 = ob >> 5, sh = ob & 31;
         uint32_t x[10];
 #pragma unroll
@@ -501,7 +521,7 @@ __global__ void __launch_bounds__(PP_WAVES * 64, PP_OCC) k_pile_probe(PrefSufCfg
             grp = (grp & ~(3u << (2 * slot_a))) | (group << (2 * slot_a));
         }
     };
-    // Runs from slot 7 down; the record of slot a - 1 is on its way while slot a is compared.  Which k-mer group of the bucket a run wants is
+    // Runs from slot 0 up.  Which k-mer group of the bucket a run wants is
     // read off the record: the groups whose tag equals the low five bits of the run's cluster key -- one, except where two k-mers of a
     // bucket share all 32 bits of their hash (3 % of the buckets at the north-star size: 19-mers do not fit 32 bits).  Group 0 is in the
     // record itself; the others are taken in a short loop behind this one (the order of the records is free: what a source keeps is
@@ -509,18 +529,45 @@ __global__ void __launch_bounds__(PP_WAVES * 64, PP_OCC) k_pile_probe(PrefSufCfg
     auto bucket_of = [&](int a) -> uint32_t { return ((vmask >> a) & 1u) ? min(rk[a] >> cc.idx_shift, cc.n_buckets) : cc.n_buckets; };
     uint32_t more = 0u;                                    // 4 bits per slot: further groups to take
     bool got_row = !row_from_pile;                         // the source's row is in B
-    uint4 N0, N1, N2, N3;
-    {
-        const uint4 *ln = tab + (size_t) bucket_of(0) * 8;
-        N0 = ln[0]; N1 = ln[1]; N2 = ln[2]; N3 = ln[3];
-    }
+    // The records of a slot, loaded ONCE per distinct bucket of the wave: lanes in entry order -> equal buckets in adjacent lanes -> the first
+    // lane of each stretch leads; the leaders' buckets go through sBk, then four lanes load the 64 bytes of one record (sixteen records per
+    // load instruction) and park them in LDS, where every lane of the stretch reads them.  (As four 16-byte loads per LANE the same ~15
+    // distinct lines per slot were looked up 4 x 64 times in the L1, the kernel's address path was busy half of the time, and each lane
+    // staged its own copy through LDS: 7.9 -> 7.7 ms on one box.)  The loads of slot a + 1 are in flight while slot a is compared.
+    uint4 V0 = make_uint4(0u, 0u, 0u, 0u), V1 = V0;        // the records on their way: sixteen per register
+    int li_next = 0, nl_next = 0, li = 0;
+    const int l0 = lane >> 2, c4 = lane & 3;
+    uint32_t *bk = sBk[wave];
+    auto issue = [&](int a) {                              // convergent
+        const uint32_t b = bucket_of(a);
+        const uint32_t bp = (uint32_t) __builtin_amdgcn_update_dpp((int) ~b, (int) b, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+        const bool lead = b != bp;                         // (lane 0 reads ~b)
+        const uint64_t lm = __ballot(lead);
+        li_next = (int) __builtin_amdgcn_mbcnt_hi((uint32_t) (lm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) lm, 0u)) + (lead ? 1 : 0) - 1;
+        nl_next = __popcll(lm);                            // uniform, >= 1
+        if (lead) bk[li_next] = b;
+        wave_lds_fence();
+        V0 = tab[(size_t) bk[min(l0, nl_next - 1)] * 8 + c4];
+        if (nl_next > 16) V1 = tab[(size_t) bk[min(16 + l0, nl_next - 1)] * 8 + c4];
+    };
+    auto commit = [&]() {                                  // convergent: the records `issue` asked for, into LDS
+        li = li_next;
+        *reinterpret_cast<uint4 *>(sl + l0 * PP_LSTRIDE + 4 * c4) = V0;
+        if (nl_next > 16) *reinterpret_cast<uint4 *>(sl + (16 + l0) * PP_LSTRIDE + 4 * c4) = V1;
+        for (int r = 32; r < nl_next; r += 16) {           // (more than 32 distinct buckets in a wave: rare, not overlapped)
+            const uint4 v = tab[(size_t) bk[min(r + l0, nl_next - 1)] * 8 + c4];
+            *reinterpret_cast<uint4 *>(sl + (r + l0) * PP_LSTRIDE + 4 * c4) = v;
+        }
+        wave_lds_fence();
+    };
+    if (um & 1u) issue(0);
 #pragma unroll
     for (int a = 0; a < CL_RMAX; a++) {                    // (slot 0 first: the home run of a lane that takes its row from the pile)
-        const uint4 R0 = N0, R1 = N1, R2 = N2, R3 = N3;
-        if (a + 1 < CL_RMAX) {
-            const uint4 *ln = tab + (size_t) bucket_of(a + 1) * 8;
-            N0 = ln[0]; N1 = ln[1]; N2 = ln[2]; N3 = ln[3];
-        }
+        const bool use = ((um >> a) & 1u) != 0u;           // uniform: a lane of the wave has a run in this slot
+        if (use) commit();
+        if (a + 1 < CL_RMAX && ((um >> (a + 1)) & 1u)) issue(a + 1);
+        if (!use) continue;
+        const uint4 R3 = *reinterpret_cast<const uint4 *>(sl + li * PP_LSTRIDE + 12);      // {consensus word 12, set, set, tags | flags | epoch}
         const uint32_t y = R3.w, tag = rk[a] & 31u;
         const bool live = ((vmask >> a) & 1u) != 0u && (y >> 23) == epoch;    // a record of another epoch: no entry in this bucket
         dfr = dfr || (live && ((y >> 22) & 1u) != 0u);     // a bucket k_pile_build found irregular (or of more than 64 entries)
@@ -533,7 +580,7 @@ __global__ void __launch_bounds__(PP_WAVES * 64, PP_OCC) k_pile_probe(PrefSufCfg
         if (__ballot(on) == 0ull) continue;                // uniform
         const bool home = on && row_from_pile && !got_row && ((ry[a] >> 8) & 255u) == 0u;      // the run of window 0
         got_row = got_row || home;
-        take_record(R0, R1, R2, R3.x, ((unsigned long long) R3.z << 32) | R3.y, a, 0u, ry[a], on, home);
+        take_record(li * PP_LSTRIDE, ((unsigned long long) R3.z << 32) | R3.y, a, 0u, ry[a], on, home);
     }
     {                                                      // the next tile's run lists: on their way while this tile's targets are looked up
         const uint4 *rp = run_list_of(next_side);
@@ -554,9 +601,13 @@ __global__ void __launch_bounds__(PP_WAVES * 64, PP_OCC) k_pile_probe(PrefSufCfg
 #pragma unroll
         for (int k = 1; k < CL_RMAX; k++) { ya = a == k ? ry[k] : ya; ka = a == k ? rk[k] : ka; }
         const uint32_t xa = reinterpret_cast<const uint32_t *>(tab)[(size_t) min(ka >> cc.idx_shift, cc.n_buckets) * 32 + 17];      // first entry of the bucket
-        const uint64_t sl = min((uint64_t) xa + g, last);  // (clamped: a corrupt record must not fault)
-        const uint4 Q0 = rec[sl * 4], Q1 = rec[sl * 4 + 1], Q2 = rec[sl * 4 + 2], Q3 = rec[sl * 4 + 3];
-        take_record(Q0, Q1, Q2, Q3.x, ((unsigned long long) Q3.w << 32) | Q3.z, a, g, ya, on, false);
+        const uint64_t se = min((uint64_t) xa + g, last);  // (clamped: a corrupt record must not fault)
+        const uint4 Q0 = rec[se * 4], Q1 = rec[se * 4 + 1], Q2 = rec[se * 4 + 2], Q3 = rec[se * 4 + 3];
+        uint4 *mine = reinterpret_cast<uint4 *>(sl + lane * PP_LSTRIDE);              // (the slot loop is done with the records in LDS)
+        mine[0] = Q0; mine[1] = Q1; mine[2] = Q2; mine[3] = Q3;
+        wave_lds_fence();
+        take_record(lane * PP_LSTRIDE, ((unsigned long long) Q3.w << 32) | Q3.z, a, g, ya, on, false);
+        wave_lds_fence();
     }
     // ---- what the source keeps, from the complete offset set; the one or two targets by id ----
     const unsigned long long kept = occ & ~smear_up(occ, G);
@@ -594,6 +645,17 @@ __global__ void __launch_bounds__(PP_WAVES * 64, PP_OCC) k_pile_probe(PrefSufCfg
 #pragma unroll
         for (int k = 0; k < CL_RMAX; k++) p1_home = (((vmask >> k) & 1u) != 0u && ((ry[k] >> 8) & 255u) == 0u) ? (int) ((ry[k] >> 16) & 255u) : p1_home;
         const bool by_succ = d1 < p1_home && (int) (my.z & 255u) == d1 && my.y != 0xFFFFFFFFu;
+#ifdef PP_LK
+        const int d2 = nkept == 2 ? 63 - __clzll((long long) kept) : -1;
+        const int dA = by_succ ? d2 : d1, dB = by_succ ? -1 : d2;
+        uint32_t idA = 0xFFFFFFFFu, idB = 0xFFFFFFFFu;
+        if (dA >= 0) idA = lookup(dA);
+        if (dB >= 0) idB = lookup(dB);
+        const uint32_t id1 = by_succ ? my.y : idA;
+        const uint32_t id2 = by_succ ? idA : idB;
+        bool two = false;
+        if (nkept == 2) {
+#else
         const uint32_t id1 = by_succ ? my.y : lookup(d1);
         uint32_t id2 = 0u;
         int d2 = 0;
@@ -601,6 +663,7 @@ __global__ void __launch_bounds__(PP_WAVES * 64, PP_OCC) k_pile_probe(PrefSufCfg
         if (nkept == 2) {
             d2 = 63 - __clzll((long long) kept);
             id2 = lookup(d2);
+#endif
             // the cap of three small overlaps per source: the second item stands if it is big or fewer than three small items lie before it
             const int ds0 = U - cfg.rsoemo + 1;
             const unsigned long long lowm = ds0 <= 0 ? 0ull : (ds0 >= 64 ? ~0ull : ((1ull << ds0) - 1ull));
