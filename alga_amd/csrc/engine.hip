@@ -132,7 +132,6 @@ int cluster_alloc(alga_engine *e, const Prepared &pp) {
 int pile_alloc(alga_engine *e, uint64_t n, uint32_t n_buckets, hipStream_t s) {
     int rc;
     if ((rc = alga_ensure(e, e->cl_pile_rec, pile_record_bytes(n)))) return rc;
-    if ((rc = alga_ensure(e, e->cl_pile_sub, (size_t) n + 64))) return rc;
     if ((rc = alga_ensure(e, e->cl_pile_succ, ((size_t) n + 64) * 16))) return rc;
     if ((rc = alga_ensure(e, e->cl_pile_cnt, 2 * sizeof(unsigned long long)))) return rc;
     const void *before = e->cl_pile_tab.p;
@@ -211,28 +210,37 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
             HIP_TRY(e, hipEventRecord(e->ev[EV_KEYS], s));
             e->keyed_n = -1;                               // the sort below may reuse the key buffers: one build per key pass
             e->store_n = -1;
-            HIP_TRY(e, launch_cluster_store(nd, cc, pp.cluster_eq, (uint32_t *) e->cl_keys[0].p, (uint32_t *) e->cl_vals[0].p, (uint32_t *) e->cl_keys[1].p,
-                                            (uint32_t *) e->cl_vals[1].p, (const uint32_t *) e->cl_meta.p, pp.uniform_len, e->sort_temp.p,
-                                            cluster_sort_temp_bytes((uint64_t) nd.n), e->cl_store.p, e->cl_dir.p, pp.keys_shared == 1, e->ev[EV_SORT],
-                                            e->ev[EV_GATHER], cnt + CNT_TOTAL + 1, e->opt_test_unsorted_index != 0, s));
+            HIP_TRY(e, launch_cluster_store(nd, cc, (uint32_t *) e->cl_keys[0].p, (uint32_t *) e->cl_vals[0].p, (uint32_t *) e->cl_keys[1].p,
+                                            (uint32_t *) e->cl_vals[1].p, e->sort_temp.p, cluster_sort_temp_bytes((uint64_t) nd.n), e->cl_dir.p, pp.keys_shared == 1,
+                                            e->ev[EV_SORT], cnt + CNT_TOTAL + 1, e->opt_test_unsorted_index != 0, s));
             HIP_TRY(e, hipEventRecord(e->ev[EV_DIR], s));
             e->pile_n = -1;
             if (pile) {
-                // piles of the entry array: belongs to the index (a function of the targets alone), read by k_pile_probe
+                // piles of the key order: belong to the index (a function of the targets alone), read by k_pile_probe.  The sample first: a
+                // build the pile path keeps has no use for the entry array, and k_tgt_gather reads the sample's two counters like the probes do
                 if ((rc = pile_alloc(e, (uint64_t) nd.n, cc.n_buckets, s))) return rc;
+                launch_pile_sample(nd, cc, pp.uniform_len, (const uint32_t *) e->cl_keys[1].p, (const uint32_t *) e->cl_vals[1].p, e->cl_dir.p,
+                                   (unsigned long long *) e->cl_pile_cnt.p, e->opt_pile == 2, s);
+                if ((rc = alga_check_launch(e, "k_pile_build<sample>"))) return rc;
+            }
+            HIP_TRY(e, launch_cluster_gather(nd, cc, pp.cluster_eq, (const uint32_t *) e->cl_keys[1].p, (const uint32_t *) e->cl_vals[1].p, (const uint32_t *) e->cl_meta.p,
+                                             pp.uniform_len, e->cl_store.p, (pile && e->opt_pile_skip_gather) ? (const unsigned long long *) e->cl_pile_cnt.p : nullptr, s));
+            HIP_TRY(e, hipEventRecord(e->ev[EV_GATHER], s));
+            if (pile) {
                 if (e->pile_epoch >= 511u) {               // the epoch (9 bits of a record) wraps: every record of the table becomes "empty" again
                     HIP_TRY(e, hipMemsetAsync(e->cl_pile_tab.p, 0, e->cl_pile_tab.cap, s));
                     e->pile_epoch = 0;
                 }
                 e->pile_epoch++;
-                launch_pile_build(cc, pp.uniform_len, e->cl_store.p, (uint64_t) nd.n, e->cl_dir.p, e->cl_pile_rec.p, e->cl_pile_tab.p, e->pile_epoch, (uint8_t *) e->cl_pile_sub.p,
-                                  e->cl_pile_succ.p, e->cl_runs.p, nd.n, pp.uniform_len - cfg.Lmin + 1, (unsigned long long *) e->cl_pile_cnt.p, e->opt_pile == 2, s);
+                launch_pile_build(nd, cc, pp.uniform_len, (const uint32_t *) e->cl_keys[1].p, (const uint32_t *) e->cl_vals[1].p, e->cl_dir.p, e->cl_pile_rec.p, e->cl_pile_tab.p,
+                                  e->pile_epoch, e->cl_pile_succ.p, e->cl_runs.p, pp.uniform_len - cfg.Lmin + 1, (const unsigned long long *) e->cl_pile_cnt.p, s);
                 if ((rc = alga_check_launch(e, "k_pile_build"))) return rc;
                 e->pile_n = nd.n; e->pile_words = (const void *) nd.words;
                 e->pile_timed = nd.n > 0;
             }
             e->store_timed = nd.n > 0;
-            e->store_n = nd.n; e->store_words = (const void *) nd.words; e->store_eq = pp.cluster_eq; e->store_buckets = cc.n_buckets;
+            e->store_n = pile ? -1 : nd.n;                   // (a build the pile path may have kept -- decided on the device -- leaves no entry array for keys_shared = 2)
+            e->store_words = (const void *) nd.words; e->store_eq = pp.cluster_eq; e->store_buckets = cc.n_buckets;
             e->store_run_begin = run_begin; e->store_run_end = run_end;
         }
         e->stats.table_slots = cc.n_buckets;
@@ -274,7 +282,7 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
                 const bool piled = pile && e->pile_n == nd.n && e->pile_words == (const void *) nd.words;
                 if (piled) {
                     // k_pile_probe first; it and k_probe_stream read the same two counters k_pile_build left and exactly one of them works
-                    launch_pile_probe(cfg, cc, pp.uniform_len, e->cl_store.p, (uint64_t) nd.n, nd.n, e->cl_pile_tab.p, e->pile_epoch, e->cl_pile_rec.p, (const uint8_t *) e->cl_pile_sub.p, e->cl_pile_succ.p,
+                    launch_pile_probe(nd, cfg, cc, pp.uniform_len, e->cl_pile_tab.p, e->pile_epoch, e->cl_pile_rec.p, e->cl_pile_succ.p,
                                       e->cl_runs.p, cnt, (uint32_t *) e->outdeg.p, (unsigned long long *) e->loc_first.p, (unsigned long long *) e->loc_second.p,
                                       (int32_t *) e->cl_defer.p, (uint32_t) n_src, (const unsigned long long *) e->cl_pile_cnt.p, e->n_cu, s);
                     if ((rc = alga_check_launch(e, "k_pile_probe"))) return rc;
@@ -288,7 +296,9 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
                 e->pairs_timed = true;
                 launch_probe_clustered(nd, cfg, cc, pp.cluster_eq, e->cl_store.p, e->cl_dir.p, e->cl_runs.p, (const uint8_t *) e->cl_nruns.p, 0,
                                        (int32_t) n_src, (const int32_t *) e->cl_defer.p, src_begin, (uint32_t *) e->rec_dst.p, (unsigned long long *) e->rec_val.p,
-                                       cap, cnt, e->n_cu, (uint32_t *) e->outdeg.p, (unsigned long long *) e->loc_first.p, &big, cnt + CNT_DEFERRED, 1, s);
+                                       cap, cnt, e->n_cu, (uint32_t *) e->outdeg.p, (unsigned long long *) e->loc_first.p, &big, cnt + CNT_DEFERRED, 1, s,
+                                       (const uint32_t *) e->cl_keys[1].p, (const uint32_t *) e->cl_vals[1].p, pp.uniform_len,
+                                       (piled && e->opt_pile_skip_gather) ? (const unsigned long long *) e->cl_pile_cnt.p : nullptr);
                 if (piled) launch_pile_deg((int32_t) n_src, (unsigned long long *) e->loc_first.p, (uint32_t *) e->outdeg.p, (const unsigned long long *) e->cl_pile_cnt.p, s);
             } else {
                 launch_probe_clustered(nd, cfg, cc, pp.cluster_eq, e->cl_store.p, e->cl_dir.p, e->cl_runs.p, (const uint8_t *) e->cl_nruns.p, src_begin,
@@ -480,9 +490,9 @@ void store_phase_stats(alga_engine *e) {
     if (!e->store_timed) return;
     e->stats.ms_keys = ev_ms(e, EV_START, EV_KEYS);
     e->stats.ms_sort = ev_ms(e, EV_KEYS, EV_SORT);
-    e->stats.ms_gather = ev_ms(e, EV_SORT, EV_GATHER);
-    e->stats.ms_dir = ev_ms(e, EV_GATHER, EV_DIR);
-    e->stats.ms_pile = e->pile_timed ? ev_ms(e, EV_DIR, EV_SEED) : 0.0;
+    e->stats.ms_dir = ev_ms(e, EV_SORT, EV_DIR);
+    e->stats.ms_gather = ev_ms(e, EV_DIR, EV_GATHER);      // (with the pile path's sample in front of k_tgt_gather: all there is of this phase when that path keeps the build)
+    e->stats.ms_pile = e->pile_timed ? ev_ms(e, EV_GATHER, EV_SEED) : 0.0;
 }
 
 } // namespace
@@ -579,6 +589,8 @@ int alga_engine_set_option(alga_engine *e, const char *name, int64_t value) {
         e->opt_cluster_pairs = value != 0;
     } else if (!strcmp(name, "pile")) {
         e->opt_pile = value == 2 ? 2 : (value != 0);       // (2, tests only: no sample -- the pile kernels take every build they can, however many buckets are irregular)
+    } else if (!strcmp(name, "pile_skip_gather")) {
+        e->opt_pile_skip_gather = value != 0;
     } else if (!strcmp(name, "cluster_order")) {
         e->opt_cluster_order = value != 0;
     } else if (!strcmp(name, "local_big_max")) {

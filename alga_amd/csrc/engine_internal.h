@@ -54,10 +54,11 @@ struct alga_engine {
     bool   warmed = false;                                  // alga_engine_reserve has run its miniature build (kernel code objects loaded)
     bool   pairs_timed = false;                             // EV_PAIRS was recorded in the last discovery
     bool   store_timed = false;                             // EV_KEYS / EV_SORT / EV_GATHER were recorded in the last discovery
+    int    opt_pile_skip_gather = 1;                        // option "pile_skip_gather": no entry array for a build the pile path keeps
     int    opt_pile = 1;                                    // option "pile": the probe through piles (prefsuf_pile.hip) where the input allows it
     bool   pile_timed = false;                              // EV_DIR was recorded in the last discovery (k_pile_build ran behind it)
     DevBuf cl_pile_succ;                                    // per entry (16 B): its id, the member of its own pile that starts next to its right, its place in the pile (k_pile_probe reads this, not the entry)
-    DevBuf cl_pile_rec, cl_pile_sub, cl_pile_cnt, cl_pile_tab;   // records of further k-mer groups (64 B per entry slot), group of every entry, {buckets, irregular buckets} of the sample, bucket records (128 B per bucket)
+    DevBuf cl_pile_rec, cl_pile_cnt, cl_pile_tab;   // records of further k-mer groups (64 B per entry slot), group of every entry, {buckets, irregular buckets} of the sample, bucket records (128 B per bucket)
     uint32_t pile_epoch = 0;                                // of the last k_pile_build: what makes a record of cl_pile_tab valid (the table is cleared when it is allocated, and when this wraps)
     int32_t pile_n = -1; const void *pile_words = nullptr;  // the node set the pile records describe (n < 0: none)
     int    opt_cluster_order = 1;                           // option "cluster_order": k_probe_stream walks all sources in entry-array (key) order (0: id order)

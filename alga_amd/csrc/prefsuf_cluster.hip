@@ -227,11 +227,12 @@ __global__ void __launch_bounds__(TK_ROWS) k_node_runs(NodesDev nd, PrefSufCfg c
 template <int EQ, bool UNIFORM>
 __global__ void __launch_bounds__(256) k_tgt_gather(NodesDev nd, uint64_t count /* sorted (key, id) pairs: all nodes, or the targets of a rank's bucket range */,
                                                      const uint32_t *__restrict__ keys, const uint32_t *__restrict__ vals,
-                                                     const uint32_t *__restrict__ meta, uint32_t uniform_meta, int fs, uint4 *__restrict__ store) {
-    const uint64_t t = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+                                                     const uint32_t *__restrict__ meta, uint32_t uniform_meta, int fs, uint4 *__restrict__ store,
+                                                     const unsigned long long *__restrict__ pile_cnt /* null, or the pile path's sample: a build it keeps has no use for the entry array */) {
+    if (pile_cnt && pile_cnt[1] * PILE_IRREGULAR_ONE_IN <= pile_cnt[0]) return;
+    for (uint64_t t = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; t < count * EQ; t += (uint64_t) gridDim.x * blockDim.x) {      // (a bounded grid: a million workgroups that only look at pile_cnt cost 0.3 ms)
     const uint64_t j = t / EQ;
     const int c = (int) (t % EQ);
-    if (j >= count) return;
     const uint32_t key = keys[j];                          // all ones: not a target -- behind the last bucket, never looked up; its entry
     const uint32_t id = vals[j];                           // serves the quad kernel, which walks the SOURCES in this order
     const uint32_t *row = nd.words + (size_t) id * nd.stride;
@@ -248,6 +249,7 @@ __global__ void __launch_bounds__(256) k_tgt_gather(NodesDev nd, uint64_t count 
         else v.w = (uint32_t) nd.len[id] == (uniform_meta >> 8 & 0xFFFu) ? uniform_meta : 0u;     // a removed node, or a source that is no target (alignTo)
     }
     store[j * EQ + c] = v;
+    }
 }
 
 // dir[b] = {first entry of bucket b, entries of bucket b, byte offsets of the eight m_C >> 3 classes inside it} for the NON-EMPTY
@@ -370,13 +372,26 @@ __global__ void __launch_bounds__(TD_TILE) k_tgt_dir(const uint32_t *__restrict_
 // SW = 64-bit words of an offset mask / uint4 words of an overhang in the source-side reduction (prefsuf_device.h): 1 for sources of up to
 // 64 suffix windows, 2 for up to 128 (round 4: 250-bp reads; the items then always go through LDS and local_reduce<., ., 2>, their
 // overhangs are read from the target's row, and a flagged source's windows are taken 64 at a time).
-template <bool STATS, int EQ, int KF, int SW = 1>
+// BYID: there is no entry array -- a build the pile path (prefsuf_pile.hip) keeps does not make one; entry j of the key order is node sids[j] with
+// sort key skeys[j], its row is read from the node array, its meta word follows from the key (one read length, no masks).  Whether the build
+// has an entry array is decided on the device (pile_cnt: the pile path's sample): both forms are launched, the one that does not apply leaves.
+struct ByIdEntries {
+    const uint32_t *skeys, *sids;                          // the sorted (key, id) pairs
+    uint32_t uniform_meta;                                 // len << 8 | CL_META_FROM
+    const unsigned long long *pile_cnt;                    // null: the build has an entry array, no question
+};
+template <bool STATS, int EQ, int KF, int SW = 1, bool BYID = false>
 __global__ void __launch_bounds__(PROBE_WAVES * 64, SW == 1 && EQ <= 4 ? CL_OCC : 4)
 k_probe_clustered(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__restrict__ store, const uint4 *__restrict__ dir,
                   const uint2 *__restrict__ runs, const uint8_t *__restrict__ nruns, int32_t src_begin, int32_t src_end, ProbeOut o,
                   const int32_t *__restrict__ src_list /* null: the sources are the ids src_begin .. src_end - 1; else src_list[src_begin .. src_end - 1] */,
-                  const unsigned long long *__restrict__ list_count /* list mode, may be null: the list ends at min(src_end, *list_count) -- what the kernel before this one appended, no host round trip */) {
+                  const unsigned long long *__restrict__ list_count /* list mode, may be null: the list ends at min(src_end, *list_count) -- what the kernel before this one appended, no host round trip */,
+                  ByIdEntries by) {
     constexpr int WC = 4 * EQ - 3;                         // row words of an entry
+    if (by.pile_cnt) {
+        const bool kept = by.pile_cnt[1] * PILE_IRREGULAR_ONE_IN <= by.pile_cnt[0];
+        if (kept != BYID) return;
+    }
     if (list_count) {
         const unsigned long long c = *list_count;
         if (c < (unsigned long long) src_end) src_end = (int32_t) c;
@@ -463,6 +478,15 @@ k_probe_clustered(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__res
         const uint32_t j = k0 + ((uint32_t) lane & ((1u << gs) - 1u));
         ev = j < rp.w;
         ei = ev ? (size_t) min(rp.z + j, (uint32_t) nd.n - 1u) : (size_t) 0;   // lanes without an entry read entry 0 (unconditional loads: see index_loads); clamped: a corrupt directory must not fault
+        if (BYID) {
+            const uint32_t key = by.skeys[ei], id = min(by.sids[ei], (uint32_t) nd.n - 1u);
+            const uint32_t *row = nd.words + (size_t) id * nd.stride;
+#pragma unroll
+            for (int k = 0; k < WC; k++) ew[k] = k < nd.stride ? row[k] : 0u;
+            ew[4 * EQ - 3] = id; ew[4 * EQ - 2] = key;
+            ew[4 * EQ - 1] = key != 0xFFFFFFFFu ? (by.uniform_meta | ((key >> (cc.idx_shift - CL_MBITS)) & ((1u << CL_MBITS) - 1u))) : 0u;
+            return;
+        }
 #pragma unroll
         for (int c = 0; c < EQ; c++) { const uint4 v = store[ei * EQ + c]; ew[4 * c] = v.x; ew[4 * c + 1] = v.y; ew[4 * c + 2] = v.z; ew[4 * c + 3] = v.w; }
     };
@@ -554,6 +578,10 @@ k_probe_clustered(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__res
                             for (int u = 0; u <= WC - KF; u++) { const int wi = KF + k + u; if (wi < 4 * EQ) v = t == u ? ew[wi] : v; }
                             x[k] = v;
                         }
+                    } else if constexpr (BYID) {
+                        const uint32_t *er = nd.words + (size_t) id * nd.stride;                       // C's own row (no entry array)
+#pragma unroll
+                        for (int k = 0; k < 5; k++) x[k] = ws + k < nd.stride ? er[ws + k] : 0u;
                     } else {
                         const uint32_t *er = reinterpret_cast<const uint32_t *>(store + ei * EQ);      // re-read (an L1 hit)
 #pragma unroll
@@ -1240,9 +1268,9 @@ __global__ void __launch_bounds__(256) k_iota(uint32_t *__restrict__ v, uint32_t
 // keys / meta of all n nodes -> the entry array in key order and its bucket directory.  fill_vals: the ids (sort payload) were not
 // written by this engine's key pass for every node (keys gathered from other ranks): write them here.  uniform_len > 0: every
 // live node has that length and there is no alignFrom mask (k_tgt_gather<., true>: meta[] is not read).
-hipError_t launch_cluster_store(const NodesDev &nd, const ClusterCfg &cc, int eq, uint32_t *keys, uint32_t *vals, uint32_t *keys2, uint32_t *vals2,
-                                const uint32_t *meta, int uniform_len, void *sort_temp, size_t sort_temp_bytes, void *store, void *dir, bool fill_vals,
-                                hipEvent_t ev_sorted, hipEvent_t ev_gathered, unsigned long long *bad_flag, bool test_skip_sort, hipStream_t s) {
+hipError_t launch_cluster_store(const NodesDev &nd, const ClusterCfg &cc, uint32_t *keys, uint32_t *vals, uint32_t *keys2, uint32_t *vals2,
+                                void *sort_temp, size_t sort_temp_bytes, void *dir, bool fill_vals,
+                                hipEvent_t ev_sorted, unsigned long long *bad_flag, bool test_skip_sort, hipStream_t s) {
     if (nd.n <= 0) return hipSuccess;
     const uint64_t n = (uint64_t) nd.n;
     if (fill_vals) hipLaunchKernelGGL(k_iota, dim3((unsigned) std::min<uint64_t>((n + 255) / 256, 8192)), dim3(256), 0, s, vals, (uint32_t) n);
@@ -1256,11 +1284,26 @@ hipError_t launch_cluster_store(const NodesDev &nd, const ClusterCfg &cc, int eq
     } else err = sort_u32_pairs(sort_temp, sort_temp_bytes, keys, keys2, vals, vals2, n, cc.idx_shift - 3, s);
     if (err != hipSuccess) return err;
     if (ev_sorted) (void) hipEventRecord(ev_sorted, s);
+    // (measured and rejected: zero-filling the directory as a side job of the VALU-bound k_node_runs -- that kernel got slower by what
+    // the fill costs on its own, 0.24 ms)
+    err = hipMemsetAsync(dir, 0, ((size_t) cc.n_buckets + 2) * 16, s);
+    if (err != hipSuccess) return err;
+    hipLaunchKernelGGL(k_tgt_dir, dim3((unsigned) ((n + 1 + TD_TILE - 1) / TD_TILE)), dim3(TD_TILE), 0, s, (const uint32_t *) keys2, n, cc.idx_shift, cc.n_buckets, 0u, (uint4 *) dir, bad_flag);
+    return hipGetLastError();
+}
+
+// ... and the entry array itself: the rows in key order (what the pairwise probes walk).  uniform_len > 0: every live node has that length and
+// there is no alignFrom mask (k_tgt_gather<., true>: meta[] is not read).  pile_cnt: the counters of the pile path's sample (prefsuf_pile.hip) --
+// the kernel leaves at once for a build that path keeps.
+hipError_t launch_cluster_gather(const NodesDev &nd, const ClusterCfg &cc, int eq, const uint32_t *keys2, const uint32_t *vals2, const uint32_t *meta, int uniform_len,
+                                 void *store, const unsigned long long *pile_cnt, hipStream_t s) {
+    if (nd.n <= 0) return hipSuccess;
+    const uint64_t n = (uint64_t) nd.n;
     const uint64_t pieces = n * (uint64_t) eq;
-    const unsigned g = (unsigned) ((pieces + 255) / 256);
+    const unsigned g = (unsigned) std::min<uint64_t>((pieces + 255) / 256, 1u << 16);
     const int fs = cc.idx_shift - CL_MBITS;
     const uint32_t um = uniform_len > 0 ? (((uint32_t) uniform_len << 8) | CL_META_FROM) : 0u;
-#define TG_LAUNCH(E, U) hipLaunchKernelGGL((k_tgt_gather<E, U>), dim3(g), dim3(256), 0, s, nd, n, (const uint32_t *) keys2, (const uint32_t *) vals2, meta, um, fs, (uint4 *) store)
+#define TG_LAUNCH(E, U) hipLaunchKernelGGL((k_tgt_gather<E, U>), dim3(g), dim3(256), 0, s, nd, n, keys2, vals2, meta, um, fs, (uint4 *) store, pile_cnt)
 #define TG_EQ(E) do { if (uniform_len > 0) TG_LAUNCH(E, true); else TG_LAUNCH(E, false); } while (0)
     if (eq == 2)      TG_EQ(2);
     else if (eq == 3) TG_EQ(3);
@@ -1268,12 +1311,6 @@ hipError_t launch_cluster_store(const NodesDev &nd, const ClusterCfg &cc, int eq
     else              TG_EQ(5);
 #undef TG_EQ
 #undef TG_LAUNCH
-    if (ev_gathered) (void) hipEventRecord(ev_gathered, s);
-    // (measured and rejected: zero-filling the directory as a side job of the VALU-bound k_node_runs -- that kernel got slower by what
-    // the fill costs on its own, 0.24 ms)
-    err = hipMemsetAsync(dir, 0, ((size_t) cc.n_buckets + 2) * 16, s);
-    if (err != hipSuccess) return err;
-    hipLaunchKernelGGL(k_tgt_dir, dim3((unsigned) ((n + 1 + TD_TILE - 1) / TD_TILE)), dim3(TD_TILE), 0, s, (const uint32_t *) keys2, n, cc.idx_shift, cc.n_buckets, 0u, (uint4 *) dir, bad_flag);
     return hipGetLastError();
 }
 
@@ -1291,7 +1328,7 @@ hipError_t launch_cluster_store_slice(const NodesDev &nd, const ClusterCfg &cc, 
     const unsigned g = (unsigned) ((pieces + 255) / 256);
     const int fs = cc.idx_shift - CL_MBITS;
     const uint32_t um = uniform_len > 0 ? (((uint32_t) uniform_len << 8) | CL_META_FROM) : 0u;
-#define TG_LAUNCH(E, U) hipLaunchKernelGGL((k_tgt_gather<E, U>), dim3(g), dim3(256), 0, s, nd, n, (const uint32_t *) keys2, (const uint32_t *) vals2, meta, um, fs, (uint4 *) store)
+#define TG_LAUNCH(E, U) hipLaunchKernelGGL((k_tgt_gather<E, U>), dim3(g), dim3(256), 0, s, nd, n, (const uint32_t *) keys2, (const uint32_t *) vals2, meta, um, fs, (uint4 *) store, (const unsigned long long *) nullptr)
 #define TG_EQ(E) do { if (uniform_len > 0) TG_LAUNCH(E, true); else TG_LAUNCH(E, false); } while (0)
     if (eq == 2)      TG_EQ(2);
     else if (eq == 3) TG_EQ(3);
@@ -1344,19 +1381,24 @@ void launch_probe_clustered(const NodesDev &nd, const PrefSufCfg &cfg, const Clu
                             const void *runs, const uint8_t *nruns, int32_t src_begin, int32_t src_end, const int32_t *src_list, int32_t src_base,
                             uint32_t *rec_dst, unsigned long long *rec_val, uint64_t rec_cap,
                             unsigned long long *counters, int n_cu, uint32_t *deg, unsigned long long *first, const ProbeBig *big,
-                            const unsigned long long *list_count, int sw /* 1 | 2: words per offset mask of the source-side form */, hipStream_t s) {
+                            const unsigned long long *list_count, int sw /* 1 | 2: words per offset mask of the source-side form */, hipStream_t s,
+                            const uint32_t *skeys, const uint32_t *sids, int uniform_len, const unsigned long long *pile_cnt) {
     const int64_t ns = (int64_t) src_end - src_begin;
     if (ns <= 0) return;
     dim3 grid((unsigned) cluster_probe_blocks(n_cu, (uint64_t) ns)), block(PROBE_WAVES * 64);
     ProbeOut o{rec_dst, rec_val, rec_cap, counters, deg, first, src_base};
     if (big) { o.big_list = big->list; o.big_list_cap = big->list_cap; }
     const uint4 *st = (const uint4 *) store;
+    // pile_cnt: the build may have no entry array (decided on the device): the form that reads the rows by id is launched beside the usual one
+    const bool maybe_by_id = pile_cnt && skeys && sids && uniform_len > 0 && eq == 3 && sw == 1 && !cfg.stats;
+    const ByIdEntries by{skeys, sids, uniform_len > 0 ? (((uint32_t) uniform_len << 8) | CL_META_FROM) : 0u, maybe_by_id ? pile_cnt : nullptr};
     // KF = (2 * Lmin) >> 5 as a compile-time constant for the shapes ALGA's defaults produce (150-bp reads: Lmin 82, rows of 9
     // words; 100-bp reads: Lmin 55, rows of 6 words); 0 = any shape
     const int kf = (2 * cfg.Lmin) >> 5;
-#define CL_LAUNCH(ST, E, K) hipLaunchKernelGGL((k_probe_clustered<ST, E, K>), grid, block, 0, s, nd, cfg, cc, st, (const uint4 *) dir, (const uint2 *) runs, nruns, src_begin, src_end, o, src_list, list_count)
+#define CL_LAUNCH(ST, E, K) hipLaunchKernelGGL((k_probe_clustered<ST, E, K>), grid, block, 0, s, nd, cfg, cc, st, (const uint4 *) dir, (const uint2 *) runs, nruns, src_begin, src_end, o, src_list, list_count, by)
+#define CL_BYID(K) hipLaunchKernelGGL((k_probe_clustered<false, 3, K, 1, true>), grid, block, 0, s, nd, cfg, cc, st, (const uint4 *) dir, (const uint2 *) runs, nruns, src_begin, src_end, o, src_list, list_count, by)
 #define CL_STATS(E, K) do { if (cfg.stats) CL_LAUNCH(true, E, K); else CL_LAUNCH(false, E, K); } while (0)
-#define CL_LAUNCH2(ST, E) hipLaunchKernelGGL((k_probe_clustered<ST, E, 0, 2>), grid, block, 0, s, nd, cfg, cc, st, (const uint4 *) dir, (const uint2 *) runs, nruns, src_begin, src_end, o, src_list, list_count)
+#define CL_LAUNCH2(ST, E) hipLaunchKernelGGL((k_probe_clustered<ST, E, 0, 2>), grid, block, 0, s, nd, cfg, cc, st, (const uint4 *) dir, (const uint2 *) runs, nruns, src_begin, src_end, o, src_list, list_count, by)
 #define CL_STATS2(E) do { if (cfg.stats) CL_LAUNCH2(true, E); else CL_LAUNCH2(false, E); } while (0)
     if (sw == 2) {                                         // more than 64 suffix windows (250-bp reads): the two-word form, any row length
         if (eq == 2)      CL_STATS2(2);
@@ -1364,17 +1406,18 @@ void launch_probe_clustered(const NodesDev &nd, const PrefSufCfg &cfg, const Clu
         else if (eq == 4) CL_STATS2(4);
         else              CL_STATS2(5);
     }
-    else if (eq == 3 && kf == 5) CL_STATS(3, 5);
-    else if (eq == 3 && kf == 3) CL_STATS(3, 3);
+    else if (eq == 3 && kf == 5) { CL_STATS(3, 5); if (maybe_by_id) CL_BYID(5); }
+    else if (eq == 3 && kf == 3) { CL_STATS(3, 3); if (maybe_by_id) CL_BYID(3); }
     else if (eq == 2 && kf == 3) CL_STATS(2, 3);
     else if (eq == 2)            CL_STATS(2, 0);
-    else if (eq == 3)            CL_STATS(3, 0);
+    else if (eq == 3)            { CL_STATS(3, 0); if (maybe_by_id) CL_BYID(0); }
     else if (eq == 4)            CL_STATS(4, 0);
     else                         CL_STATS(5, 0);
 #undef CL_STATS2
 #undef CL_LAUNCH2
 #undef CL_STATS
 #undef CL_LAUNCH
+#undef CL_BYID
 }
 
 } // namespace alga

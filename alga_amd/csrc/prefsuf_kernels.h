@@ -45,17 +45,21 @@ size_t     cluster_sort_temp_bytes(uint64_t n);
 // keys/vals/keys2/vals2/meta: n uint32 each; runs: n * CL_RMAX * 8 bytes; nruns: n bytes; store: (n + 2) * 16 * eq bytes; dir: (n_buckets + 2) * 16 bytes
 void       launch_cluster_keys(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterCfg &cc, int32_t node_begin, int32_t node_end, uint32_t *keys,
                                uint32_t *vals, uint32_t *meta, void *runs, uint8_t *nruns, hipStream_t s);
-hipError_t launch_cluster_store(const NodesDev &nd, const ClusterCfg &cc, int eq, uint32_t *keys, uint32_t *vals, uint32_t *keys2, uint32_t *vals2,
-                                const uint32_t *meta, int uniform_len /* > 0: all live nodes have this length, no alignFrom mask */, void *sort_temp,
-                                size_t sort_temp_bytes, void *store, void *dir, bool fill_vals, hipEvent_t ev_sorted /* may be null */,
-                                hipEvent_t ev_gathered /* may be null */, unsigned long long *bad_flag /* device: set when the sorted keys are not in order */,
-                                bool test_skip_sort /* tests: build the index over UNSORTED keys */, hipStream_t s);
+hipError_t launch_cluster_store(const NodesDev &nd, const ClusterCfg &cc, uint32_t *keys, uint32_t *vals, uint32_t *keys2 /* out: sorted */, uint32_t *vals2, void *sort_temp,
+                                size_t sort_temp_bytes, void *dir, bool fill_vals, hipEvent_t ev_sorted /* may be null */,
+                                unsigned long long *bad_flag /* device: set when the sorted keys are not in order */,
+                                bool test_skip_sort /* tests: build the index over UNSORTED keys */, hipStream_t s);      // sort + directory
+hipError_t launch_cluster_gather(const NodesDev &nd, const ClusterCfg &cc, int eq, const uint32_t *keys2, const uint32_t *vals2, const uint32_t *meta,
+                                 int uniform_len /* > 0: all live nodes have this length, no alignFrom mask */, void *store,
+                                 const unsigned long long *pile_cnt /* null, or the pile path's sample counters: no entry array for a build it keeps */, hipStream_t s);
 uint64_t   cluster_record_slack(int n_cu, uint64_t n_src);
 void       launch_probe_clustered(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterCfg &cc, int eq, const void *store, const void *dir,
                                   const void *runs, const uint8_t *nruns, int32_t src_begin, int32_t src_end, const int32_t *src_list, int32_t src_base, uint32_t *rec_dst, unsigned long long *rec_val, uint64_t rec_cap,
                                   unsigned long long *counters, int n_cu, uint32_t *deg, unsigned long long *first, const ProbeBig *big,
                                   const unsigned long long *list_count /* device, may be null: list mode ends at min(src_end, *list_count) */,
-                                  int sw /* 1 | 2: 64-bit words per offset mask (sources of up to 64 | 128 suffix windows) */, hipStream_t s);
+                                  int sw /* 1 | 2: 64-bit words per offset mask (sources of up to 64 | 128 suffix windows) */, hipStream_t s,
+                                  const uint32_t *skeys = nullptr, const uint32_t *sids = nullptr, int uniform_len = 0,
+                                  const unsigned long long *pile_cnt = nullptr /* the pile path's sample: the build may have no entry array -- then the sorted (key, id) pairs stand in for it */);
 void       launch_probe_stream(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterCfg &cc, int eq, const void *store, const void *dir,
                                const void *runs, const uint8_t *nruns, int32_t src_begin, int32_t src_end, bool by_key /* the range is one of entry-array positions */,
                                unsigned long long *counters, int n_cu, uint32_t *deg, unsigned long long *first, unsigned long long *second, int32_t *defer_list,
@@ -66,12 +70,14 @@ void       launch_pile_deg(int32_t n, unsigned long long *first, uint32_t *deg, 
 bool       pile_plan(const PrefSufCfg &cfg, const ClusterCfg &cc, int eq, int uniform_len, bool masks);
 size_t     pile_record_bytes(uint64_t n);
 size_t     pile_table_bytes(uint32_t n_buckets);
-void       launch_pile_build(const ClusterCfg &cc, int uniform_len, const void *store, uint64_t n_entries, const void *dir, void *rec, void *tab /* 128 B per bucket, never cleared */,
-                             uint32_t epoch /* of this build: what makes a record of `tab` valid */, uint8_t *sub, void *side /* 16 B per entry */, const void *runs, int n_nodes, int nwin /* suffix windows of a read */,
-                             unsigned long long *pile_cnt /* [0] buckets, [1] irregular buckets */, bool no_sample, hipStream_t s);
-void       launch_pile_probe(const PrefSufCfg &cfg, const ClusterCfg &cc, int uniform_len, const void *store, uint64_t n_entries, int n_nodes, const void *tab, uint32_t epoch,
-                             const void *rec, const uint8_t *sub, const void *side, const void *runs, unsigned long long *counters, uint32_t *deg, unsigned long long *first,
-                             unsigned long long *second, int32_t *defer_list, uint32_t defer_cap, const unsigned long long *pile_cnt, int n_cu, hipStream_t s);
+void       launch_pile_sample(const NodesDev &nd, const ClusterCfg &cc, int uniform_len, const uint32_t *skeys /* sorted keys */, const uint32_t *sids /* their node ids */, const void *dir,
+                              unsigned long long *pile_cnt /* [0] buckets, [1] irregular buckets of the sample */, bool no_sample, hipStream_t s);
+void       launch_pile_build(const NodesDev &nd, const ClusterCfg &cc, int uniform_len, const uint32_t *skeys, const uint32_t *sids, const void *dir, void *rec,
+                             void *tab /* 128 B per bucket, never cleared */, uint32_t epoch /* of this build: what makes a record of `tab` valid */, void *side /* 16 B per entry */,
+                             const void *runs, int nwin /* suffix windows of a read */, const unsigned long long *pile_cnt, hipStream_t s);
+void       launch_pile_probe(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterCfg &cc, int uniform_len, const void *tab, uint32_t epoch, const void *rec, const void *side,
+                             const void *runs, unsigned long long *counters, uint32_t *deg, unsigned long long *first, unsigned long long *second, int32_t *defer_list,
+                             uint32_t defer_cap, const unsigned long long *pile_cnt, int n_cu, hipStream_t s);
 
 size_t     sort_u32_pairs_temp_bytes(uint64_t n);
 hipError_t sort_u32_pairs(void *temp, size_t temp_bytes, const uint32_t *keys_in, uint32_t *keys_out, const uint32_t *vals_in, uint32_t *vals_out,

@@ -65,9 +65,22 @@ constexpr int PILE_EQ = 3;                     // entry size this path takes: ro
 // (~0.09 ms per million sources): k_pile_build, k_pile_probe and k_probe_stream all read the same two counters, decided on the device.
 __device__ __forceinline__ bool pile_declines(const unsigned long long *pile_cnt) { return pile_cnt[1] * PILE_IRREGULAR_ONE_IN > pile_cnt[0]; }
 
+// the row of node `id`, up to nine words (the pile path takes rows of that size only), straight from the node array
+__device__ __forceinline__ void load_row9(const NodesDev &nd, uint32_t id, uint32_t (&row)[9]) {
+    const uint32_t *rp = nd.words + (size_t) id * nd.stride;
+    if ((nd.stride & 3) == 0 && nd.stride >= 12 && ((uintptr_t) nd.words & 15u) == 0) {
+        const uint4 v0 = reinterpret_cast<const uint4 *>(rp)[0], v1 = reinterpret_cast<const uint4 *>(rp)[1];
+        row[0] = v0.x; row[1] = v0.y; row[2] = v0.z; row[3] = v0.w; row[4] = v1.x; row[5] = v1.y; row[6] = v1.z; row[7] = v1.w;
+        row[8] = rp[8];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 9; k++) row[k] = k < nd.stride ? rp[k] : 0u;
+    }
+}
+
 template <bool SAMPLE>
-__global__ void __launch_bounds__(PB_THREADS, 3) k_pile_build(const uint4 *__restrict__ store, uint64_t n_entries, const uint4 *__restrict__ dir, ClusterCfg cc, int U,
-                                                           uint4 *__restrict__ rec, uint4 *__restrict__ tab, uint32_t epoch, uint8_t *__restrict__ sub,
+__global__ void __launch_bounds__(PB_THREADS, 3) k_pile_build(NodesDev nd, const uint32_t *__restrict__ skeys, const uint32_t *__restrict__ sids, uint64_t n_entries, const uint4 *__restrict__ dir, ClusterCfg cc, int U,
+                                                           uint4 *__restrict__ rec, uint4 *__restrict__ tab, uint32_t epoch,
                                                            uint4 *__restrict__ side, unsigned long long *__restrict__ pile_cnt) {
     if (!SAMPLE && pile_declines(pile_cnt)) return;
     const int idx_shift = cc.idx_shift, kk = cc.kk;
@@ -84,13 +97,10 @@ __global__ void __launch_bounds__(PB_THREADS, 3) k_pile_build(const uint4 *__res
     const uint64_t j = base + (uint64_t) t;
     const bool have = j < n_entries;
     const uint64_t jc = have ? j : (n_entries ? n_entries - 1 : 0);
-    uint32_t row[9];
-    uint32_t key, meta, node_id;
-    {
-        const uint4 v0 = store[jc * PILE_EQ], v1 = store[jc * PILE_EQ + 1], v2 = store[jc * PILE_EQ + 2];
-        row[0] = v0.x; row[1] = v0.y; row[2] = v0.z; row[3] = v0.w; row[4] = v1.x; row[5] = v1.y; row[6] = v1.z; row[7] = v1.w; row[8] = v2.x;
-        node_id = v2.y; key = v2.z; meta = v2.w;
-    }
+    // entry j of the key order = node sids[j] with sort key skeys[j]; its row comes straight from the node array (the entry array of the
+    // pairwise kernels -- the same rows copied into key order -- is not built for a build the pile path keeps: k_tgt_gather)
+    const uint32_t key = skeys[jc], node_id = min(sids[jc], (uint32_t) nd.n - 1u);
+    const uint32_t meta = key >> (cc.idx_shift - CL_MBITS);       // low bits: m_C (a target's sort key holds it under the bucket)
     const bool tgt = have && key != 0xFFFFFFFFu;
     uint4 drec = make_uint4(0u, 0u, 0u, 0u);
     if (tgt) drec = dir[key >> idx_shift];
@@ -100,6 +110,10 @@ __global__ void __launch_bounds__(PB_THREADS, 3) k_pile_build(const uint4 *__res
     const int s = owned ? (int) (e0 - base) : 0;           // thread of the bucket's first entry
     const int i = owned ? (int) (j - e0) : 0;              // index of this entry in its bucket
     const bool part = owned && cnt <= 64u;
+    // (only the thread that WORKS on an entry reads its row: the entries of a bucket that began in the tile before are that tile's halo, and a
+    // halo thread whose bucket begins behind the tile has nothing to do -- one random row read per entry, none for the overlap of the tiles)
+    uint32_t row[9] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    if (part) load_row9(nd, node_id, row);
     sLead[t] = 0ull; sRm[t] = 0ull; sMin[t] = 0xFFFFFFFFu; sMax[t] = 0u; sBad[t] = 0u;
     if (t < 2) sCount[t] = 0u;
     __syncthreads();
@@ -193,7 +207,6 @@ __global__ void __launch_bounds__(PB_THREADS, 3) k_pile_build(const uint4 *__res
             const int iL = L - s;                          // index of my group's first member in the bucket
             const int k = __popcll(lm & ((1ull << iL) - 1ull));                        // my group's number
             if (!SAMPLE) {
-                sub[j] = (uint8_t) k;
                 // the member of my group that starts next to my right (the largest m_C below mine): what a source of this pile keeps when that
                 // member lies within its home run's windows -- k_pile_probe then needs no look-up at all
                 const unsigned long long right = m == 0 ? 0ull : (sRm[L] >> (64 - m));    // bit b: a member with m_C == m - 1 - b
@@ -331,8 +344,8 @@ constexpr int PP_LSTRIDE = 20;
 // the waves' waiting for memory -- the chain side record -> run list -> bucket records -> the targets that stand -- at four waves per SIMD
 // (five spill: 9.9 against 7.9 ms): side record and run list are read a tile ahead, the records of the next run are on their way while
 // the current one is compared (of the next two: no faster), the run loop is unrolled over the eight slots (static registers; a wave skips the slots none of its lanes uses).
-__global__ void __launch_bounds__(PP_WAVES * 64, PP_OCC) k_pile_probe(PrefSufCfg cfg, ClusterCfg cc, int U, const uint4 *__restrict__ store, uint64_t n_entries, int n_nodes,
-                                                                 const uint4 *__restrict__ tab, uint32_t epoch, const uint4 *__restrict__ rec, const uint8_t *__restrict__ sub,
+__global__ void __launch_bounds__(PP_WAVES * 64, PP_OCC) k_pile_probe(PrefSufCfg cfg, ClusterCfg cc, int U, NodesDev nd, uint64_t n_entries, int n_nodes,
+                                                                 const uint4 *__restrict__ tab, uint32_t epoch, const uint4 *__restrict__ rec,
                                                                  const uint4 *__restrict__ side, const uint2 *__restrict__ runs, ProbeOut o, int32_t *__restrict__ defer_list, uint32_t defer_cap,
                                                                  const unsigned long long *__restrict__ pile_cnt) {
     // the records of the slot at hand, ONE copy per distinct bucket of the wave (the members of a pile sit side by side and want the same
@@ -391,7 +404,6 @@ __global__ void __launch_bounds__(PP_WAVES * 64, PP_OCC) k_pile_probe(PrefSufCfg
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {      // uniform
     const uint64_t j = tile * (PP_WAVES * 64) + threadIdx.x;
     const bool have = j < n_entries;
-    const uint64_t jc = have ? j : last;
     const uint4 my = next_side;                            // {id, right neighbour's id, its offset | m_C << 8 | group << 16 | first-group member << 31, -}
     const int Bs = (int) my.x;
     const bool first_group = (my.z >> 31) != 0u;
@@ -436,11 +448,7 @@ __global__ void __launch_bounds__(PP_WAVES * 64, PP_OCC) k_pile_probe(PrefSufCfg
         }
     }
     uint32_t B[9] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
-    if (!row_from_pile) {
-        const uint4 v0 = store[jc * PILE_EQ], v1 = store[jc * PILE_EQ + 1];
-        B[0] = v0.x; B[1] = v0.y; B[2] = v0.z; B[3] = v0.w; B[4] = v1.x; B[5] = v1.y; B[6] = v1.z; B[7] = v1.w;
-        B[8] = reinterpret_cast<const uint32_t *>(store)[jc * (4 * PILE_EQ) + 8];
-    }
+    if (!row_from_pile) load_row9(nd, (uint32_t) Bs, B);      // (one source in sixteen: its row by id)
     next_side = side_of(tile + gridDim.x < n_tiles ? tile + gridDim.x : tile);
     const int nr_code = !have ? 0 : (row_from_pile ? 1 : (int) (ry[0] >> 24));       // (a pile's member is a source: one length, no masks)
     bool dfr = nr_code == CL_RUNS_FLAGGED;                 // runs k_node_runs could not list: the general kernel finds them by brute force
@@ -627,10 +635,10 @@ __global__ void __launch_bounds__(PP_WAVES * 64, PP_OCC) k_pile_probe(PrefSufCfg
         const uint32_t b0 = ((cl < 4 ? dd.z : dd.w) >> (8 * (cl & 3))) & 255u;
         const uint32_t b1 = cl >= 7 ? (dd.x & 127u) : ((((cl + 1) < 4 ? dd.z : dd.w) >> (8 * ((cl + 1) & 3))) & 255u);
         uint32_t id = 0xFFFFFFFFu;
-        for (uint32_t e = b0; e < b1 && e < 64u; e++) {
+        for (uint32_t e = b0; e < b1 && e < 64u; e++) {         // (the entries' side records: id, m_C, group)
             const uint64_t ei = min((uint64_t) dd.y + e, last);
-            const uint4 tail = store[ei * PILE_EQ + 2];
-            if ((int) (tail.w & 63u) == mm && (uint32_t) sub[ei] == ga) id = tail.y;
+            const uint4 sd = side[ei];
+            if ((int) ((sd.z >> 8) & 63u) == mm && ((sd.z >> 16) & 3u) == ga) id = sd.x;
         }
         return id;
     };
@@ -722,27 +730,38 @@ size_t pile_record_bytes(uint64_t n) { return (size_t) (n + 2) * 64; }
 
 size_t pile_table_bytes(uint32_t n_buckets) { return ((size_t) n_buckets + 2) * 128; }
 
-void launch_pile_build(const ClusterCfg &cc, int uniform_len, const void *store, uint64_t n_entries, const void *dir, void *rec, void *tab, uint32_t epoch, uint8_t *sub,
-                       void *side, const void *runs, int n_nodes, int nwin, unsigned long long *pile_cnt, bool no_sample, hipStream_t s) {
+// The SAMPLE (k_pile_build<true> on the first 1/32 of the key order) comes before k_tgt_gather: a build the pile path keeps needs no entry
+// array -- its kernels take the rows by id -- and that kernel, like the pairwise probes, reads the two counters and leaves at once.
+void launch_pile_sample(const NodesDev &nd, const ClusterCfg &cc, int uniform_len, const uint32_t *skeys, const uint32_t *sids, const void *dir, unsigned long long *pile_cnt,
+                        bool no_sample, hipStream_t s) {
     (void) hipMemsetAsync(pile_cnt, 0, 2 * sizeof(unsigned long long), s);
-    if (n_entries == 0) return;
+    const uint64_t n_entries = nd.n > 0 ? (uint64_t) nd.n : 0;
+    if (n_entries == 0 || no_sample) return;               // (no_sample -- tests only: the two counters stay zero and the pile kernels take the build whatever its buckets look like)
     const uint64_t tiles = (n_entries + PB_TILE - 1) / PB_TILE;
-    const dim3 grid((unsigned) tiles), sample((unsigned) std::max<uint64_t>(1, std::min<uint64_t>(tiles, std::max<uint64_t>(64, tiles / 32)))), block(PB_THREADS);
-    // (no_sample -- tests only: the two counters stay zero and the pile kernels take the build whatever its buckets look like)
-    if (!no_sample) hipLaunchKernelGGL((k_pile_build<true>), sample, block, 0, s, (const uint4 *) store, n_entries, (const uint4 *) dir, cc, uniform_len, (uint4 *) rec, (uint4 *) tab, epoch, sub, (uint4 *) side, pile_cnt);
-    hipLaunchKernelGGL((k_pile_build<false>), grid, block, 0, s, (const uint4 *) store, n_entries, (const uint4 *) dir, cc, uniform_len, (uint4 *) rec, (uint4 *) tab, epoch, sub, (uint4 *) side, pile_cnt);
-    hipLaunchKernelGGL(k_pile_runs, dim3((unsigned) ((n_entries + 255) / 256)), dim3(256), 0, s, (const uint4 *) side, n_entries, cc.n_buckets, (uint4 *) tab, (const uint2 *) runs, n_nodes, nwin, pile_cnt);
+    const dim3 sample((unsigned) std::max<uint64_t>(1, std::min<uint64_t>(tiles, std::max<uint64_t>(64, tiles / 32)))), block(PB_THREADS);
+    hipLaunchKernelGGL((k_pile_build<true>), sample, block, 0, s, nd, skeys, sids, n_entries, (const uint4 *) dir, cc, uniform_len, (uint4 *) nullptr, (uint4 *) nullptr, 0u, (uint4 *) nullptr, pile_cnt);
 }
 
-void launch_pile_probe(const PrefSufCfg &cfg, const ClusterCfg &cc, int uniform_len, const void *store, uint64_t n_entries, int n_nodes, const void *tab, uint32_t epoch, const void *rec,
-                       const uint8_t *sub, const void *side, const void *runs, unsigned long long *counters, uint32_t *deg, unsigned long long *first, unsigned long long *second,
+void launch_pile_build(const NodesDev &nd, const ClusterCfg &cc, int uniform_len, const uint32_t *skeys, const uint32_t *sids, const void *dir, void *rec, void *tab, uint32_t epoch,
+                       void *side, const void *runs, int nwin, const unsigned long long *pile_cnt, hipStream_t s) {
+    const uint64_t n_entries = nd.n > 0 ? (uint64_t) nd.n : 0;
+    if (n_entries == 0) return;
+    const uint64_t tiles = (n_entries + PB_TILE - 1) / PB_TILE;
+    hipLaunchKernelGGL((k_pile_build<false>), dim3((unsigned) tiles), dim3(PB_THREADS), 0, s, nd, skeys, sids, n_entries, (const uint4 *) dir, cc, uniform_len, (uint4 *) rec, (uint4 *) tab, epoch,
+                       (uint4 *) side, const_cast<unsigned long long *>(pile_cnt));
+    hipLaunchKernelGGL(k_pile_runs, dim3((unsigned) ((n_entries + 255) / 256)), dim3(256), 0, s, (const uint4 *) side, n_entries, cc.n_buckets, (uint4 *) tab, (const uint2 *) runs, nd.n, nwin, pile_cnt);
+}
+
+void launch_pile_probe(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterCfg &cc, int uniform_len, const void *tab, uint32_t epoch, const void *rec,
+                       const void *side, const void *runs, unsigned long long *counters, uint32_t *deg, unsigned long long *first, unsigned long long *second,
                        int32_t *defer_list, uint32_t defer_cap, const unsigned long long *pile_cnt, int n_cu, hipStream_t s) {
+    const uint64_t n_entries = nd.n > 0 ? (uint64_t) nd.n : 0;
     if (n_entries == 0) return;
     ProbeOut o{};
     o.counters = counters; o.deg = deg; o.first = first; o.second = second; o.src_base = 0;
     const uint64_t tiles = (n_entries + PP_WAVES * 64 - 1) / (PP_WAVES * 64);
     const dim3 grid((unsigned) std::max<uint64_t>(1, std::min<uint64_t>(tiles, (uint64_t) std::max(1, n_cu) * (PP_OCC * 4 / PP_WAVES)))), block(PP_WAVES * 64);      // PP_OCC waves per SIMD, four SIMDs per CU
-    hipLaunchKernelGGL(k_pile_probe, grid, block, 0, s, cfg, cc, uniform_len, (const uint4 *) store, n_entries, n_nodes, (const uint4 *) tab, epoch, (const uint4 *) rec, sub,
+    hipLaunchKernelGGL(k_pile_probe, grid, block, 0, s, cfg, cc, uniform_len, nd, n_entries, nd.n, (const uint4 *) tab, epoch, (const uint4 *) rec,
                        (const uint4 *) side, (const uint2 *) runs, o, defer_list, defer_cap, pile_cnt);
 }
 

@@ -365,10 +365,11 @@ def run(args, rank, world, local_rank, dist, t_process=None):
             rk = [("k_node_runs", ms["keys"], n * (4 * W + 4) + n * (13 + 8 * runs_per_node), "VALU-bound: ~1650 vector instructions per node"),
                   ("rocprim radix sort of (key, id) (onesweep; >= 2^22 nodes: the 29 key bits the directory needs in 3 passes of 10, else 32 bits in 4 passes of 8)",
                    ms["sort"], 4 * n + (3 if n >= (1 << 22) else 4) * 2 * 8 * n, "library code; bytes = histogram read + passes x (read + write) of 8-byte pairs"),
-                  ("k_tgt_gather", ms["gather"], n * (4 * W + 8 + 16 * eq), "one isolated 64-byte row per entry: 128 bytes fetched for it"),
+                  ("k_tgt_gather", ms["gather"], n * (4 * W + 8 + 16 * eq), "one isolated 64-byte row per entry: 128 bytes fetched for it (not run for a build the pile path keeps)"),
                   ("k_tgt_dir", ms["dir"], 4 * n + 16 * (nb + 1), "includes the zero fill of the directory (16 B per bucket) in front of the kernel"),
-                  ("k_pile_build + k_pile_runs", ms["pile"], n * (16 * eq + 16 + 1 + 16) + 64 * (n / 6.0) + n * 16 + (n / 6.0) * (128 + 48),
-                   "pile records of the entry array: entries read once, a directory record per entry, 64 B written per k-mer group (~6 entries), a byte and a 16-byte side record per entry; "
+                  ("k_pile_build + k_pile_runs", ms["pile"], n * (4 * W + 8 + 16 + 16) + 64 * (n / 6.0) + n * 16 + (n / 6.0) * (128 + 48),
+                   "pile records of the key order: every node's row read once BY ID (no entry array is built for a build the pile path keeps: one isolated row per entry, "
+                   "128 bytes fetched for it), its sorted (key, id) pair and a directory record, 64 B written per k-mer group (~6 entries) and a 16-byte side record per entry; "
                    "then the run list of each pile: side records read, two 64-byte run lists in and 48 bytes out per group; part of the index build"),
                   (probe_kernel if first_dominates else first_name, ms["probe_pairs"], alg_probe_launch * (1.0 - deferred / n_src),
                    "bytes by SURVEY's pairwise definition; the pile path itself has to move ~%d B per source (16-byte side record, 64-byte run list, the first 64 bytes of a bucket record per run, one 8-byte slot): %.1f GB" %

@@ -146,6 +146,8 @@ int         alga_engine_device_name(const alga_engine *e, char *buf, size_t bufl
  *   "pile"                       default 1: reads of one length without masks take the probe through PILES (alga_amd/csrc/prefsuf_pile.hip): one compare
  *                                of a source against the consensus of a minimizer's targets instead of one per target; 0: always the pairwise kernels;
  *                                2 (tests only): without the sample that leaves reads with errors to the pairwise kernels
+ *   "pile_skip_gather"           default 1: a build the pile path keeps has no entry array (the rows in key order, 48 bytes per node: its kernels
+ *                                read the rows by id, and the copy alone costs 3 ms per 90 M nodes); 0: the entry array is always built
  *   "cluster_order"              default 1: k_probe_stream takes the sources in the order of the entry array (sources of one locus together:
  *                                shared look-ups, cache hits); 0: in id order (what a range of ids always gets)
  *   "local_big_max"              largest per-wave item slice of the SOURCE_SIDE second pass (default -1 = built-in 4096); beyond it

@@ -146,6 +146,32 @@ def test_inputs_the_pile_path_does_not_take(eng):
     assert eng.last_stats()["pile_buckets"] == 0
 
 
+def test_no_entry_array_is_left_over(eng):
+    """A build the pile path keeps makes no entry array (its kernels and the general kernel read the rows by id): whatever an EARLIER build
+    left in that buffer must not be read.  First a pairwise build of other reads (which fills the entry array), then reads of a length whose
+    shape takes the generic instantiation of the general kernel (120 nt: no compile-time word count), through the pile path -- with and
+    without the entry array -- against the oracle."""
+    words, lens = _nodes(9000, 150, 40_000, 301)
+    lo, rs = alga_amd.derive_params(144.0)
+    eng.set_option("pile", 0)
+    try:
+        eng.prefsuf_host(words, lens, lo, rs)
+    finally:
+        eng.set_option("pile", 1)
+    words, lens = _nodes(12_000, 126, 60_000, 302)
+    lo, rs = alga_amd.derive_params(120.0)
+    want, _, _ = O.prefsuf(words, lens, lo, rs)
+    for skip in (1, 0):
+        eng.set_option("pile_skip_gather", skip)
+        try:
+            got = eng.prefsuf_host(words, lens, lo, rs)
+        finally:
+            eng.set_option("pile_skip_gather", 1)
+        st = eng.last_stats()
+        assert got.shape == want.shape and (got == want).all(), ("pile_skip_gather", skip, got.shape, want.shape)
+        assert st["pile_buckets"] > 0 and st["deferred_sources"] > 0          # the general kernel had sources to finish
+
+
 def test_bucket_table_is_valid_by_epoch(eng):
     """The bucket table of the pile path is never cleared between builds: a record counts only when it carries the epoch of the build at hand.
     One engine builds two different read sets of different sizes alternately -- every record the other set left behind is stale -- and far
