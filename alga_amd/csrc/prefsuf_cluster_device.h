@@ -4,6 +4,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "prefsuf_common.h"
+#include "../../include/alga_amd.h"
 #include "prefsuf_device.h"
 
 namespace alga {
@@ -75,7 +76,7 @@ __device__ __forceinline__ bool same_cluster(uint32_t entry_key, uint32_t ckey, 
 // directory record of a bucket: {first entry, entries, first entry (relative, saturating bytes) with m_C >> 3 >= 0..3, >= 4..7}
 // -> the entries [e0, e0 + cnt) a run {q | p0 << 8 | p1 << 16} has to look at
 // k_pile_build / k_pile_probe / k_probe_stream: more than one bucket in this many irregular and the pairwise kernels take the build (prefsuf_pile.hip)
-constexpr unsigned long long PILE_IRREGULAR_ONE_IN = 40ull;
+constexpr unsigned long long PILE_IRREGULAR_ONE_IN = ALGA_PILE_IRREGULAR_ONE_IN;      // include/alga_amd.h
 __device__ __forceinline__ void run_slice(const uint4 &rec, uint32_t run_y, uint32_t &e0, uint32_t &cnt) {
     const int q = (int) (run_y & 255u), p0 = (int) ((run_y >> 8) & 255u), p1 = (int) ((run_y >> 16) & 255u);
     int mlo = q - p1 + 1, mhi = q - p0;

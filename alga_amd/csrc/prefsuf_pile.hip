@@ -60,9 +60,11 @@ constexpr int PILE_EQ = 3;                     // entry size this path takes: ro
 
 // ------------------------------------------------------------------------------------------
 // Is this a build for the pile path?  pile_cnt = {buckets, irregular buckets} of a SAMPLE of the entry array (its first 1 / 32, in hash order: loci
-// from all over the genome): more than one bucket in PILE_IRREGULAR_ONE_IN irregular -- reads with sequencing errors -- and the sources that
-// would have to go to the general kernel (every source with a run in such a bucket, ~1.2 ms per million) cost more than the pile path saves
-// (~0.09 ms per million sources): k_pile_build, k_pile_probe and k_probe_stream all read the same two counters, decided on the device.
+// from all over the genome): more than one bucket in PILE_IRREGULAR_ONE_IN (250) irregular -- reads with sequencing errors (one in four), or a
+// genome so large that a 19-mer often sits at two loci (error-free reads of 1 Gb: 1.5 %) -- and the sources that would have to go to the general
+// kernel (every source with a run in such a bucket: eight times the buckets' share, 2 - 3.5 ms per million) cost more than the pile path saves
+// (~0.2 ms per million sources; measured: 363 M nodes of a 1 Gb genome took 252 ms this way against 160 ms through the pairwise kernels, 181 M
+// nodes of 500 Mb -- 0.27 % irregular -- 57 against 69).  Every kernel concerned reads the same two counters: decided on the device.
 __device__ __forceinline__ bool pile_declines(const unsigned long long *pile_cnt) { return pile_cnt[1] * PILE_IRREGULAR_ONE_IN > pile_cnt[0]; }
 
 // the row of node `id`, up to nine words (the pile path takes rows of that size only), straight from the node array

@@ -105,6 +105,7 @@ class PkbStats(C.Structure):
 
 
 PROBE = {"auto": 0, "table": 1, "cluster": 2}                  # alga_probe
+PILE_IRREGULAR_ONE_IN = 250                                    # ALGA_PILE_IRREGULAR_ONE_IN (include/alga_amd.h): the pile path keeps a build iff pile_irregular * this <= pile_buckets
 
 class MultiStats(C.Structure):
     """alga_multi_stats"""

@@ -63,7 +63,7 @@ def test_pile_path_equals_pairwise_and_oracle(eng, length, coverage):
     lo, rs = alga_amd.derive_params(float(length - 6))
     st, E = _three_ways(eng, words, lens, lo, rs)
     assert st["probe_used"] == 2 and st["pile_buckets"] > 0, st              # the pile path ran ...
-    assert st["pile_irregular"] * 40 <= st["pile_buckets"]                   # ... and kept the build
+    assert st["pile_irregular"] * alga_amd.engine.PILE_IRREGULAR_ONE_IN <= st["pile_buckets"]                   # ... and kept the build
     live = int((lens > 0).sum())
     assert st["deferred_sources"] <= live // 10, (st["deferred_sources"], live)   # nearly every source finished there
     assert E > 0
@@ -118,7 +118,7 @@ def test_reads_with_errors_leave_the_build_to_the_pairwise_kernels(eng):
     words, lens = _nodes(12_000, 150, 40_000, 23, err=0.02)
     lo, rs = alga_amd.derive_params(144.0)
     st, _ = _three_ways(eng, words, lens, lo, rs)
-    assert st["pile_buckets"] > 0 and st["pile_irregular"] * 40 > st["pile_buckets"], st      # sampled, found irregular, declined on the device
+    assert st["pile_buckets"] > 0 and st["pile_irregular"] * alga_amd.engine.PILE_IRREGULAR_ONE_IN > st["pile_buckets"], st      # sampled, found irregular, declined on the device
 
 
 def test_inputs_the_pile_path_does_not_take(eng):

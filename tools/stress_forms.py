@@ -142,7 +142,7 @@ def main():
             st = eng.last_stats()
             if mode == 1 and st["pile_buckets"] > 0:
                 piled += 1
-                pile_kept += st["pile_irregular"] * 40 <= st["pile_buckets"]
+                pile_kept += st["pile_irregular"] * alga_amd.engine.PILE_IRREGULAR_ONE_IN <= st["pile_buckets"]
             if mode == 2:
                 pile_forced += st["ms_pile"] > 0
             if a.shape != c.shape or not (a == c).all():
