@@ -6,7 +6,7 @@ computed: every case here is built three ways -- pile path, pairwise kernels, CP
 The cases are chosen to hit what the pile path hands on instead of deciding: duplicate reads (two members at one coordinate), repeats
 (one k-mer, two loci: members that differ from the consensus), tandem repeats (one minimizer twice in a source), coverage gaps (two
 items stand), reads with errors (the build is left to the pairwise kernels), and inputs it does not take at all (several lengths,
-masks)."""
+masks); and what the last step of round 4 added: no entry array for a build the pile path keeps (rows by id, any row stride, nothing stale read)."""
 import numpy as np
 import pytest
 
@@ -170,6 +170,28 @@ def test_no_entry_array_is_left_over(eng):
         st = eng.last_stats()
         assert got.shape == want.shape and (got == want).all(), ("pile_skip_gather", skip, got.shape, want.shape)
         assert st["pile_buckets"] > 0 and st["deferred_sources"] > 0          # the general kernel had sources to finish
+
+
+@pytest.mark.parametrize("stride", [9, 10, 12, 13, 16])
+def test_rows_by_id_with_any_row_stride(eng, stride):
+    """The pile kernels and the general kernel behind them read the rows straight from the caller's node array: tight rows (9 words per 144-nt node, the
+    Bitset's own layout), strides that are no multiple of four words (scalar loads) and padded ones (16-byte loads) must give the same graph."""
+    import torch
+    from alga_amd.engine import device_view
+    words, lens = _nodes(9000, 150, 40_000, 401)
+    lo, rs = alga_amd.derive_params(144.0)
+    want, _, _ = O.prefsuf(words, lens, lo, rs)
+    W = 9
+    wide = np.zeros((len(lens), stride), dtype=np.uint32)
+    wide[:, :W] = words[:, :W]
+    wide[:, W:] = 0xDEADBEEF                                                 # what lies between the rows is never looked at
+    dw = torch.from_numpy(wide.view(np.int32)).cuda()
+    dl = torch.from_numpy(lens.astype(np.int32)).cuda()
+    ptr, m = eng.prefsuf_device(dw, dl, lo, rs, reduction="source_side")
+    st = eng.last_stats()
+    got = device_view(ptr, (m, 3), dw.device).cpu().numpy()
+    assert got.shape == want.shape and (got == want).all(), (stride, got.shape, want.shape)
+    assert st["pile_buckets"] > 0 and st["ms_pile"] > 0
 
 
 def test_bucket_table_is_valid_by_epoch(eng):
