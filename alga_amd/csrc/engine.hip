@@ -133,7 +133,7 @@ int pile_alloc(alga_engine *e, uint64_t n, uint32_t n_buckets, hipStream_t s) {
     int rc;
     if ((rc = alga_ensure(e, e->cl_pile_rec, pile_record_bytes(n)))) return rc;
     if ((rc = alga_ensure(e, e->cl_pile_succ, ((size_t) n + 64) * 16))) return rc;
-    if ((rc = alga_ensure(e, e->cl_pile_cnt, 2 * sizeof(unsigned long long)))) return rc;
+    if ((rc = alga_ensure(e, e->cl_pile_cnt, 3 * sizeof(unsigned long long)))) return rc;
     const void *before = e->cl_pile_tab.p;
     const size_t cap_before = e->cl_pile_tab.cap;
     if ((rc = alga_ensure(e, e->cl_pile_tab, pile_table_bytes(n_buckets)))) return rc;

@@ -71,7 +71,7 @@ bool       pile_plan(const PrefSufCfg &cfg, const ClusterCfg &cc, int eq, int un
 size_t     pile_record_bytes(uint64_t n);
 size_t     pile_table_bytes(uint32_t n_buckets);
 void       launch_pile_sample(const NodesDev &nd, const ClusterCfg &cc, int uniform_len, const uint32_t *skeys /* sorted keys */, const uint32_t *sids /* their node ids */, const void *dir,
-                              unsigned long long *pile_cnt /* [0] buckets, [1] irregular buckets of the sample */, bool no_sample, hipStream_t s);
+                              unsigned long long *pile_cnt /* of the sample: [0] buckets (raised to entries / 8), [1] irregular buckets, [2] entries */, bool no_sample, hipStream_t s);
 void       launch_pile_build(const NodesDev &nd, const ClusterCfg &cc, int uniform_len, const uint32_t *skeys, const uint32_t *sids, const void *dir, void *rec,
                              void *tab /* 128 B per bucket, never cleared */, uint32_t epoch /* of this build: what makes a record of `tab` valid */, void *side /* 16 B per entry */,
                              const void *runs, int nwin /* suffix windows of a read */, const unsigned long long *pile_cnt, hipStream_t s);

@@ -93,7 +93,7 @@ __global__ void __launch_bounds__(PB_THREADS, 3) k_pile_build(NodesDev nd, const
     __shared__ uint32_t sMin[PB_THREADS], sMax[PB_THREADS];    // per leader: m_C << 16 | thread of the member with the smallest / largest m_C
     __shared__ uint32_t sBad[PB_THREADS];                  // per bucket
     __shared__ uint8_t sTag[PB_THREADS];                   // per leader
-    __shared__ uint32_t sCount[2];
+    __shared__ uint32_t sCount[3];                         // buckets, irregular buckets, entries of buckets that begin in the tile (sample only)
     const int t = (int) threadIdx.x;
     const uint64_t base = (uint64_t) blockIdx.x * PB_TILE;
     const uint64_t j = base + (uint64_t) t;
@@ -117,7 +117,7 @@ __global__ void __launch_bounds__(PB_THREADS, 3) k_pile_build(NodesDev nd, const
     uint32_t row[9] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
     if (part) load_row9(nd, node_id, row);
     sLead[t] = 0ull; sRm[t] = 0ull; sMin[t] = 0xFFFFFFFFu; sMax[t] = 0u; sBad[t] = 0u;
-    if (t < 2) sCount[t] = 0u;
+    if (t < 3) sCount[t] = 0u;
     __syncthreads();
     // the row on the pile's axis: consensus index x (coordinate x - 64) = nucleotide x - 64 + m of the row = bit 2 x + 2 m of the row padded
     // with four zero words in front.  The word offset (2 m) >> 5 is one of 0 .. 3: two selects per word, static register indices.
@@ -258,8 +258,9 @@ __global__ void __launch_bounds__(PB_THREADS, 3) k_pile_build(NodesDev nd, const
     }
     // entries of no regular bucket (non-targets, buckets of more than 64 entries): written by the thread of the tile proper
     if (!SAMPLE && have && t < PB_TILE && !(tgt && cnt <= 64u)) side[j] = make_uint4(node_id, 0xFFFFFFFFu, 0u, 0u);
+    if (SAMPLE && owned) atomicAdd(&sCount[2], 1u);
     __syncthreads();
-    if (SAMPLE && t < 2 && sCount[t]) atomicAdd(&pile_cnt[t], (unsigned long long) sCount[t]);      // (the sample is a few thousand workgroups)
+    if (SAMPLE && t < 3 && sCount[t]) atomicAdd(&pile_cnt[t], (unsigned long long) sCount[t]);      // (the sample is a few thousand workgroups)
 }
 
 // ------------------------------------------------------------------------------------------
@@ -732,16 +733,25 @@ size_t pile_record_bytes(uint64_t n) { return (size_t) (n + 2) * 64; }
 
 size_t pile_table_bytes(uint32_t n_buckets) { return ((size_t) n_buckets + 2) * 128; }
 
+// What a bucket of the sample stands for grows with the coverage: the pairwise kernels pay per ENTRY of a bucket, the pile path per bucket.  The
+// sample's bucket count is therefore raised to an eighth of its entries where that is more (at 30x a bucket holds ~7.6 entries: unchanged; at
+// 160x the threshold of irregular buckets is three times as generous) -- every kernel that reads the two counters then needs no third one.
+__global__ void k_pile_sample_close(unsigned long long *__restrict__ pile_cnt) {
+    const unsigned long long by_entries = pile_cnt[2] / 8ull;
+    if (by_entries > pile_cnt[0]) pile_cnt[0] = by_entries;
+}
+
 // The SAMPLE (k_pile_build<true> on the first 1/32 of the key order) comes before k_tgt_gather: a build the pile path keeps needs no entry
 // array -- its kernels take the rows by id -- and that kernel, like the pairwise probes, reads the two counters and leaves at once.
 void launch_pile_sample(const NodesDev &nd, const ClusterCfg &cc, int uniform_len, const uint32_t *skeys, const uint32_t *sids, const void *dir, unsigned long long *pile_cnt,
                         bool no_sample, hipStream_t s) {
-    (void) hipMemsetAsync(pile_cnt, 0, 2 * sizeof(unsigned long long), s);
+    (void) hipMemsetAsync(pile_cnt, 0, 3 * sizeof(unsigned long long), s);
     const uint64_t n_entries = nd.n > 0 ? (uint64_t) nd.n : 0;
     if (n_entries == 0 || no_sample) return;               // (no_sample -- tests only: the two counters stay zero and the pile kernels take the build whatever its buckets look like)
     const uint64_t tiles = (n_entries + PB_TILE - 1) / PB_TILE;
     const dim3 sample((unsigned) std::max<uint64_t>(1, std::min<uint64_t>(tiles, std::max<uint64_t>(64, tiles / 32)))), block(PB_THREADS);
     hipLaunchKernelGGL((k_pile_build<true>), sample, block, 0, s, nd, skeys, sids, n_entries, (const uint4 *) dir, cc, uniform_len, (uint4 *) nullptr, (uint4 *) nullptr, 0u, (uint4 *) nullptr, pile_cnt);
+    hipLaunchKernelGGL(k_pile_sample_close, dim3(1), dim3(1), 0, s, pile_cnt);
 }
 
 void launch_pile_build(const NodesDev &nd, const ClusterCfg &cc, int uniform_len, const uint32_t *skeys, const uint32_t *sids, const void *dir, void *rec, void *tab, uint32_t epoch,

@@ -126,11 +126,13 @@ typedef struct {
                                      k_tgt_gather, k_tgt_dir (0 for a build that reused them: keys_shared)         */
     uint64_t probe_rounds;        /* CLUSTER probe, k_probe_stream: rounds = wave iterations (collect_stats); sources / rounds = sources packed per round */
     double   ms_pile;             /* CLUSTER probe, option pile: k_pile_build (consensus records of the entry array), part of ms_seed; 0: not run  */
-    uint64_t pile_buckets, pile_irregular;   /* ... non-empty buckets in a SAMPLE of the entry array (its first 1/32) / those of them the pile path does
+    uint64_t pile_buckets, pile_irregular;   /* ... non-empty buckets in a SAMPLE of the key order (its first 1/32; an eighth of the sample's entries where that
+                                     is more: a bucket of a high-coverage read set stands for more pairwise work saved) / those of them the pile path does
                                      not take (a source with a run in such a bucket goes to the general kernel); more than 1 in
                                      ALGA_PILE_IRREGULAR_ONE_IN irregular: the pairwise kernel k_probe_stream took the build instead of k_pile_probe */
 } alga_prefsuf_stats;
-/* The pile path keeps a build iff  pile_irregular * ALGA_PILE_IRREGULAR_ONE_IN <= pile_buckets  (decided on the device).  Every source with a run in an
+/* The pile path keeps a build iff  pile_irregular * ALGA_PILE_IRREGULAR_ONE_IN <= pile_buckets  (decided on the device; pile_buckets as reported: raised to
+ * an eighth of the sample's entries at high coverage).  Every source with a run in an
  * irregular bucket goes to the general kernel -- eight times the buckets' share of the sources, at ~20 times the cost per source: above ~0.5 % of
  * irregular buckets the pairwise kernels are faster (reads with sequencing errors: 25 %; error-free reads of a genome of 1 Gb: 1.5 %, 250 Mb: 0.07 %). */
 #define ALGA_PILE_IRREGULAR_ONE_IN 250
