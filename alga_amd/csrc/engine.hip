@@ -161,7 +161,7 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
     e->store_timed = false;
     e->pile_timed = false;
     // the probe through piles: all sources in entry order, reads of one length without masks (prefsuf_pile.hip: pile_plan)
-    const bool pile = clustered && e->opt_pile != 0 && e->opt_cluster_pairs != 0 && e->opt_cluster_order != 0 && pp.local_sw == 1 && pp.keys_shared == 0 &&
+    bool pile = clustered && e->opt_pile != 0 && e->opt_cluster_pairs != 0 && e->opt_cluster_order != 0 && pp.local_sw == 1 && pp.keys_shared == 0 &&
                       src_begin == 0 && src_end == pp.nd.n && pile_plan(cfg, pp.cluster, pp.cluster_eq, pp.uniform_len, pp.nd.from != nullptr || pp.nd.to != nullptr);
     e->loc_second_used = false;
     uint32_t n_buckets = 0, filter_bits = 0;
@@ -218,7 +218,19 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
             if (pile) {
                 // piles of the key order: belong to the index (a function of the targets alone), read by k_pile_probe.  The sample first: a
                 // build the pile path keeps has no use for the entry array, and k_tgt_gather reads the sample's two counters like the probes do
-                if ((rc = pile_alloc(e, (uint64_t) nd.n, cc.n_buckets, s))) return rc;
+                rc = e->opt_test_pile_oom ? alga_fail(e, ALGA_ERR_OUT_OF_MEMORY, "pile_alloc (option test_pile_oom)") : pile_alloc(e, (uint64_t) nd.n, cc.n_buckets, s);
+                if (rc == ALGA_ERR_OUT_OF_MEMORY) {
+                    // the pile path needs ~180 B per node on top of the pairwise kernels' buffers (bucket table, group records, side records): an input
+                    // that fitted without it must not fail because of it.  Give back what was allocated of it and take the pairwise kernels.
+                    (void) hipGetLastError();
+                    alga_release(e->cl_pile_tab); alga_release(e->cl_pile_rec); alga_release(e->cl_pile_succ);
+                    e->pile_epoch = 0; e->pile_n = -1;
+                    e->err.clear();
+                    pile = false;
+                    rc = ALGA_OK;
+                } else if (rc) return rc;
+            }
+            if (pile) {
                 launch_pile_sample(nd, cc, pp.uniform_len, (const uint32_t *) e->cl_keys[1].p, (const uint32_t *) e->cl_vals[1].p, e->cl_dir.p,
                                    (unsigned long long *) e->cl_pile_cnt.p, e->opt_pile == 2, s);
                 if ((rc = alga_check_launch(e, "k_pile_build<sample>"))) return rc;
@@ -355,6 +367,12 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
             e->stats.slots_scanned = e->h_counters[CNT_SLOTS];
             e->stats.probe_rounds = e->h_counters[CNT_ROUNDS];
             e->stats.pile_buckets = e->h_counters[CNT_PILE_BUCKETS]; e->stats.pile_irregular = e->h_counters[CNT_PILE_IRREGULAR];
+            if (pile && pp.keys_shared != 2 && e->pile_n == nd.n) {
+                // the sample's verdict is on the host now: a build the pile path DECLINED (or one with pile_skip_gather off) did build the entry
+                // array, and a later keys_shared = 2 build of this node set may use it
+                const bool kept = e->opt_pile == 2 || e->stats.pile_irregular * (uint64_t) ALGA_PILE_IRREGULAR_ONE_IN <= e->stats.pile_buckets;
+                if (!kept || !e->opt_pile_skip_gather) e->store_n = nd.n;
+            }
             e->stats.probe_used = clustered ? ALGA_PROBE_CLUSTER : ALGA_PROBE_TABLE;
             if (clustered) e->stats.deferred_sources = e->defer_list_valid ? e->h_counters[CNT_DEFERRED] : n_src;
             return ALGA_OK;
@@ -597,6 +615,8 @@ int alga_engine_set_option(alga_engine *e, const char *name, int64_t value) {
         e->big_limit = value < 0 ? -1 : (int) std::min<int64_t>(value, 1 << 20);
     } else if (!strcmp(name, "shard_bucket_max")) {
         e->opt_shard_dmax = (int) std::max<int64_t>(1, std::min<int64_t>(value, 4096));
+    } else if (!strcmp(name, "test_pile_oom")) {
+        e->opt_test_pile_oom = value != 0;                 // tests only: the pile path's allocation answers out of memory; the build must continue on the pairwise kernels
     } else if (!strcmp(name, "test_unsorted_index")) {
         e->opt_test_unsorted_index = value != 0;           // tests only: the clustered index is built over UNSORTED keys; the build must fail, not fault
     } else if (!strcmp(name, "auto_reduction_per_target")) {

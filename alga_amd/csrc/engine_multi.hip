@@ -47,6 +47,7 @@ struct Rccl {
     void *lib = nullptr;
     int (*CommInitAll)(nccl_comm_t *, int, const int *) = nullptr;
     int (*CommDestroy)(nccl_comm_t) = nullptr;
+    int (*CommAbort)(nccl_comm_t) = nullptr;               // optional: absent in a build without it, the driver then cannot unblock peers after a failed post
     const char *(*GetErrorString)(int) = nullptr;
     int (*AllGather)(const void *, void *, size_t, int, nccl_comm_t, hipStream_t) = nullptr;
     int (*Send)(const void *, size_t, int, int, nccl_comm_t, hipStream_t) = nullptr;
@@ -64,6 +65,7 @@ struct Rccl {
         RCCL_SYM(AllGather, "ncclAllGather"); RCCL_SYM(Send, "ncclSend"); RCCL_SYM(Recv, "ncclRecv");
         RCCL_SYM(GroupStart, "ncclGroupStart"); RCCL_SYM(GroupEnd, "ncclGroupEnd");
 #undef RCCL_SYM
+        *(void **) (&CommAbort) = dlsym(lib, "ncclCommAbort");
         return true;
     }
 };
@@ -100,6 +102,8 @@ struct alga_multi {
     std::vector<hipStream_t> stream;
     Rccl rccl;
     std::vector<nccl_comm_t> comm;
+    std::mutex comm_mu;
+    bool comm_broken = false;                              // a post inside an RCCL group failed and the communicators were aborted: every later RCCL collective of this handle fails fast
     std::string err;
     Barrier bar;
     // per call, shared between the rank threads
@@ -146,14 +150,29 @@ struct Collectives {
     int fail(int code, const std::string &w) { m->rc[(size_t) r] = code; m->rank_err[(size_t) r] = w; return code; }
     int hip(hipError_t e, const char *what) { return e == hipSuccess ? ALGA_OK : fail(ALGA_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e)); }
     int nccl(int e, const char *what) { return e == 0 ? ALGA_OK : fail(ALGA_ERR_HIP, std::string(what) + ": " + m->rccl.GetErrorString(e)); }
+    // A post inside an RCCL group failed on this rank: the peers' matching sends and receives will never complete, and their stream syncs
+    // would wait for ever in front of the closing rendezvous.  All communicators live in this process (ncclCommInitAll), so
+    // the failing rank aborts every one of them -- ncclCommAbort may be called while operations are in flight, that is what it is for --
+    // the peers' syncs return, the rendezvous agrees on `failed`, and the handle refuses further RCCL collectives (create a new one).
+    void abort_comms() {
+        std::lock_guard<std::mutex> lk(m->comm_mu);
+        if (m->comm_broken) return;
+        m->comm_broken = true;
+        if (m->rccl.CommAbort)
+            for (nccl_comm_t &c : m->comm) if (c) { (void) m->rccl.CommAbort(c); c = nullptr; }
+    }
+    bool broken() { std::lock_guard<std::mutex> lk(m->comm_mu); return m->comm_broken; }
+    int refuse() { return fail(ALGA_ERR_HIP, "RCCL communicators of this handle were aborted after a failed exchange: destroy it and create a new one"); }
 
     // (the collectives end in a rendezvous and hand back its snapshot: what every rank agrees on at that point)
     Agreed all_gather_u32(uint32_t *mine, uint32_t *const *all /* all[q] = rank q's array */, size_t chunk) {
         hipStream_t s = m->stream[(size_t) r];
         int rc = ALGA_OK;
         if (m->transport == ALGA_TRANSPORT_RCCL) {
+            if (broken()) { refuse(); return rendezvous(m); }
             rc = nccl(m->rccl.AllGather(mine + (size_t) r * chunk, mine, chunk, NCCL_UINT32, m->comm[(size_t) r], s), "ncclAllGather(keys)");
-            if (rc == ALGA_OK) rc = hip(hipStreamSynchronize(s), "all-gather of the keys");
+            if (rc != ALGA_OK) abort_comms();              // (a peer already inside the collective would wait for this rank for ever)
+            else rc = hip(hipStreamSynchronize(s), "all-gather of the keys");
             return rendezvous(m);
         }
         rc = hip(hipStreamSynchronize(s), "key pass");     // my slice is complete before a peer reads it
@@ -191,6 +210,7 @@ struct Collectives {
             // a rank that could not allocate still takes part (with nothing to receive into it fails the build at the rendezvous below; its
             // peers' sends to it complete into a scratch of the same size class only if it posts receives -- so it posts none and the
             // group is skipped by ALL ranks): agree first
+            if (broken()) refuse();
             ag = rendezvous(m);
             if (!ag.failed) {
                 rc = nccl(m->rccl.GroupStart(), "ncclGroupStart");
@@ -206,7 +226,8 @@ struct Collectives {
                     at += cq;
                 }
                 { const int rc2 = nccl(m->rccl.GroupEnd(), "ncclGroupEnd"); if (rc == ALGA_OK) rc = rc2; }
-                if (rc == ALGA_OK) rc = hip(hipStreamSynchronize(s), "exchange");
+                if (rc != ALGA_OK) abort_comms();          // my posts are incomplete: the peers' matching halves must not wait for them
+                else rc = hip(hipStreamSynchronize(s), "exchange");
             }
             return rendezvous(m);
         }
@@ -232,6 +253,7 @@ struct Collectives {
         int rc = ALGA_OK;
         if (m->transport == ALGA_TRANSPORT_RCCL) {
             // every rank's transfers inside one group (rank 0: its receives; a peer: its one send), so that no call blocks on its partner
+            if (broken()) { refuse(); return rendezvous(m); }
             rc = nccl(m->rccl.GroupStart(), "ncclGroupStart");
             if (r == 0) {
                 for (int q = 1; q < m->n && rc == ALGA_OK; q++)
@@ -240,6 +262,7 @@ struct Collectives {
                 rc = nccl(m->rccl.Send(m->d_edges[(size_t) r], m->counts[(size_t) r] * 3, NCCL_INT32, 0, m->comm[(size_t) r], s), "ncclSend(edges)");
             }
             { const int rc2 = nccl(m->rccl.GroupEnd(), "ncclGroupEnd"); if (rc == ALGA_OK) rc = rc2; }
+            if (rc != ALGA_OK) abort_comms();
             if (r == 0 && rc == ALGA_OK && m->counts[0])
                 rc = hip(hipMemcpyAsync(out, m->d_edges[0], m->counts[0] * sizeof(alga_edge), hipMemcpyDeviceToDevice, s), "own edges");
             if (rc == ALGA_OK) rc = hip(hipStreamSynchronize(s), "gather of the edge lists");

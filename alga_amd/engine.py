@@ -439,9 +439,10 @@ class Engine:
         finally:
             self._lib.alga_free_edges(self._h, out)
 
-    def prefsuf_host_timed(self, words, lens, min_overlap, rsoe_min_overlap, repeat=3, twin_rows=False):
+    def prefsuf_host_timed(self, words, lens, min_overlap, rsoe_min_overlap, repeat=3, twin_rows=False, digest=False):
         """Wall time of the C call alone (alga_prefsuf_build_host + alga_free_edges; no Python-side copy of the result):
-        -> (best seconds, n_edges).  twin_rows: `words` holds the rows of the odd nodes alone (alga_prefsuf_params.twin_rows)."""
+        -> (best seconds, n_edges, digest).  twin_rows: `words` holds the rows of the odd nodes alone (alga_prefsuf_params.twin_rows).
+        digest: [count, position-weighted checksum] of the last repeat's host list (host_edges_digest; outside the timing), else None."""
         import time
         words = np.ascontiguousarray(words, dtype=np.uint32)
         lens = np.ascontiguousarray(lens, dtype=np.int32)
@@ -449,16 +450,18 @@ class Engine:
         nd = _Nodes(words.ctypes.data, int(words.shape[1]), lens.ctypes.data, n, None, None)
         p = self.params(min_overlap, rsoe_min_overlap)
         p.twin_rows = 1 if twin_rows else 0
-        best, m_out = None, 0
-        for _ in range(repeat):
+        best, m_out, dg = None, 0, None
+        for it in range(repeat):
             out, m = C.c_void_p(), C.c_uint64()
             t = time.perf_counter()
             self._check(self._lib.alga_prefsuf_build_host(self._h, C.byref(nd), C.byref(p), C.byref(out), C.byref(m)))
             dt = time.perf_counter() - t
+            if digest and it == repeat - 1:
+                dg = host_edges_digest(np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_int32)), shape=(int(m.value), 3))) if m.value else [0, 0]
             self._lib.alga_free_edges(self._h, out)
             best = dt if best is None else min(best, dt)
             m_out = int(m.value)
-        return best, m_out
+        return best, m_out, dg
 
     # ---- device-resident node set (torch tensors on this engine's device) --------------------
     @staticmethod
@@ -828,6 +831,19 @@ def device_view(ptr, shape, device=None, typestr="<i4"):
     if int(np.prod(shape)) == 0:
         return torch.empty(tuple(shape), dtype=torch.int32 if typestr == "<i4" else torch.int64, device=device or "cuda")
     return torch.as_tensor(_DevArray(ptr, shape, typestr), device=device or "cuda")
+
+
+def host_edges_digest(e):
+    """alga_amd.multigpu.edges_digest for a HOST edge list (numpy int32 [m, 3]): the same wrap-around int64 arithmetic -> [count, checksum]"""
+    k = int(e.shape[0])
+    acc = np.uint64(0)
+    with np.errstate(over="ignore"):
+        for s0 in range(0, k, 1 << 24):
+            c = e[s0:s0 + (1 << 24)].astype(np.int64)
+            w = np.arange(s0 + 1, s0 + c.shape[0] + 1, dtype=np.int64) | 1
+            v = ((c[:, 0] * 1000003 + c[:, 1]) * 10007 + c[:, 2]) * w
+            acc = acc + v.view(np.uint64).sum(dtype=np.uint64)
+    return [k, int(np.array([acc], dtype=np.uint64).view(np.int64)[0])]
 
 
 def device_edges_to_numpy(ptr, n_edges):

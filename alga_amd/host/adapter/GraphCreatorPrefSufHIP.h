@@ -12,6 +12,7 @@
 #define ALGA_AMD_GRAPHCREATORPREFSUFHIP_H
 
 #include <algorithm>
+#include <atomic>
 #include <thread>
 #include <vector>
 
@@ -24,58 +25,87 @@ namespace alga_adapter {
 
 // vector<Read*> -> the engine's node arrays: 2-bit rows as the Bitset holds them (Bitset.h:41-50,175), 0 = READS[i] == nullptr.
 // twins: ALGA's read set comes in pairs -- READS[2k] is the reverse complement of READS[2k + 1] (src/IO/InputReader.cpp:78-80,363-377; the
-// duplicate removal deletes twins together, src/main.cpp:150-232).  Where that holds (every even read absent or as long as its odd twin, and
-// up to 256 evenly spaced pairs checked nucleotide by nucleotide) only the ODD reads' rows are packed and uploaded -- half of the PCIe
-// traffic -- and the engine rebuilds the even rows on the device (alga_upload_twin_nodes).  Any other vector (the contigs of the trimming
-// stage: contigs first, reverse complements behind) fails the check and travels whole.
+// duplicate removal deletes twins together, src/main.cpp:150-232).  Where that holds only the ODD reads' rows are packed and uploaded --
+// half of the PCIe traffic -- and the engine rebuilds the even rows on the device (alga_upload_twin_nodes).  It is CHECKED, not assumed: the
+// lengths of every pair first (cheap: any other vector, e.g. the contigs of the trimming stage -- contigs first, reverse complements
+// behind -- fails here), then, inside the packing loop, EVERY even read's blocks against the reverse complement of its odd twin's
+// (word-parallel; the blocks of the even read are read instead of being packed, so the check costs what packing it would have).  One pair
+// that is not an exact reverse complement and the whole set is packed again and travels whole.
 struct NodeArrays {
     std::vector<uint32_t> words;
     std::vector<int32_t> len;
     int stride = 1;
     bool twins = false;
-    static bool is_twin_layout(std::vector<Read *> &reads) {
+    static bool twin_lengths(std::vector<Read *> &reads) {
         const size_t n = reads.size();
         if (n == 0 || (n & 1)) return false;
         for (size_t k = 0; k + 1 < n; k += 2) {
             if (reads[k] == nullptr) continue;
             if (reads[k + 1] == nullptr || reads[k]->size() != reads[k + 1]->size()) return false;
         }
-        const size_t pairs = n / 2, step = std::max<size_t>(1, pairs / 256);
-        for (size_t k = 0; k < pairs; k += step) {
-            Read *a = reads[2 * k], *b = reads[2 * k + 1];
-            if (a == nullptr || b == nullptr) continue;
-            const int m = a->size();
-            for (int i = 0; i < m; i++) if ((*a)[i] != 3 - (*b)[m - 1 - i]) return false;
+        return true;
+    }
+    static inline uint32_t rev_groups(uint32_t x) {              // the sixteen 2-bit groups of a block in reverse order
+        x = ((x >> 2) & 0x33333333u) | ((x & 0x33333333u) << 2);
+        x = ((x >> 4) & 0x0F0F0F0Fu) | ((x & 0x0F0F0F0Fu) << 4);
+        return __builtin_bswap32(x);
+    }
+    // blocks of `even` == reverse complement of the m nucleotides in `odd` (nb blocks, tail bits zero as the Bitset keeps them)
+    static bool is_revcomp(Bitset &even, const uint32_t *odd, int m, int nb) {
+        const int pad = nb * 32 - 2 * m;                         // bits of the last block the read does not use
+        for (int k = 0; k < nb; k++) {
+            const uint32_t lo = rev_groups(~odd[nb - 1 - k]);
+            const uint32_t hi = k + 1 < nb ? rev_groups(~odd[nb - 2 - k]) : 0u;
+            uint32_t w = pad ? (lo >> pad) | (hi << (32 - pad)) : lo;
+            if (k == nb - 1 && pad) w &= 0xFFFFFFFFu >> pad;
+            if (w != (uint32_t) even.getBlock(k)) return false;
         }
         return true;
     }
     explicit NodeArrays(std::vector<Read *> &reads, bool allow_twins = true) {
-        const size_t n = reads.size();
         int max_len = 0;
         for (Read *r : reads) if (r != nullptr) max_len = std::max(max_len, r->size());
         // rows as tight as the Bitset itself (9 words for a 150-bp read): what crosses PCIe is this array, and the engine re-strides it to
         // its own HBM layout on the device (alga_upload_nodes); 16-byte aligned rows (12 words) cost a third more upload for nothing
         stride = std::max(1, (2 * max_len + 31) / 32);
-        twins = allow_twins && is_twin_layout(reads);
+        twins = allow_twins && twin_lengths(reads);
+        if (!pack(reads) && twins) {                             // a pair that is no reverse-complement pair: every row travels
+            twins = false;
+            pack(reads);
+        }
+    }
+
+private:
+    bool pack(std::vector<Read *> &reads) {
+        const size_t n = reads.size();
         const size_t rows = twins ? n / 2 : n;
         words.assign(rows * (size_t) stride, 0u);
         len.assign(n, 0);
         const int T = std::max(1, Params::THREADS);
+        std::atomic<bool> ok{true};
         std::vector<std::thread> th;
         for (int t = 0; t < T; t++)
             th.emplace_back([&, t]() {
-                for (size_t i = n * t / T; i < n * (t + 1) / T; i++) {
+                // whole pairs per thread (the odd row is packed before its even twin is compared with it)
+                const size_t p0 = (n / 2) * t / T, p1 = (n / 2) * (t + 1) / T;
+                const size_t i0 = twins ? 2 * p0 : n * t / T, i1 = twins ? 2 * p1 : n * (t + 1) / T;
+                for (size_t j = i0; j < i1 && ok.load(std::memory_order_relaxed); j++) {
+                    const size_t i = twins ? (j ^ 1) : j;        // twins: odd read first, then its even twin
                     Read *r = reads[i];
                     if (r == nullptr) continue;
                     len[i] = r->size();
-                    if (twins && (i & 1) == 0) continue;         // an even read: rebuilt on the device from its odd twin
                     Bitset &b = r->getSequence();
                     const int nb = (int) b.countBlocks();
+                    if (twins && (i & 1) == 0) {                 // an even read: rebuilt on the device from its odd twin -- which it must equal reversed and complemented
+                        if (!is_revcomp(b, words.data() + (i / 2) * (size_t) stride, r->size(), nb)) ok.store(false, std::memory_order_relaxed);
+                        continue;
+                    }
                     uint32_t *row = words.data() + (twins ? i / 2 : i) * (size_t) stride;
                     for (int k = 0; k < nb; k++) row[k] = b.getBlock(k);
                 }
             });
         for (std::thread &x : th) x.join();
+        return ok.load();
     }
 };
 

@@ -500,20 +500,31 @@ class ShardedPrefSuf:
         return self.edges.cpu().numpy().astype(np.int32).copy()
 
 
+def edges_digest(e, chunk=1 << 25):
+    """[count, position-weighted checksum] of an edge list [m, 3] (device tensor) as a device int64[2].  int64 wrap-around arithmetic:
+    depends on the ORDER of the list, not only on its content -- two lists with equal digests are the same bytes but for a 2^-64 accident.
+    In chunks, so that a 92 M-edge list costs 1 GB of temporaries, not 4."""
+    import torch
+    d = torch.zeros(2, dtype=torch.int64, device=e.device)
+    k = int(e.shape[0])
+    d[0] = k
+    for s0 in range(0, k, chunk):
+        e64 = e[s0:s0 + chunk].to(torch.int64)
+        w = torch.arange(s0 + 1, s0 + int(e64.shape[0]) + 1, dtype=torch.int64, device=e.device) | 1
+        d[1] += (((e64[:, 0] * 1000003 + e64[:, 1]) * 10007 + e64[:, 2]) * w).sum()
+        del e64, w
+    return d
+
+
 def graph_digest(runner):
-    """One step -> (edges, [count, position-weighted checksum] of the complete graph on rank 0, as every rank sees them).
-    int64 wrap-around arithmetic: depends on the order of the list, not only on its content."""
+    """One step -> (edges, [count, position-weighted checksum] of the complete graph on rank 0, as every rank sees them)."""
     import torch
     m, _ = runner.step()
     e, dev = runner.edges, runner.be.device
     d = torch.zeros(2, dtype=torch.int64, device=dev)
     k = int(e.shape[0])
     if runner.rank == 0 and k:
-        e64 = e.to(torch.int64)
-        w = torch.arange(1, k + 1, dtype=torch.int64, device=e.device) | 1
-        d[0] = k
-        d[1] = (((e64[:, 0] * 1000003 + e64[:, 1]) * 10007 + e64[:, 2]) * w).sum()
-        del e64, w
+        d = edges_digest(e).to(dev)
     if runner.world > 1:
         alld = torch.empty(2 * runner.world, dtype=torch.int64, device=dev)
         runner.dist.all_gather_into_tensor(alld, d)

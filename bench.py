@@ -109,16 +109,16 @@ def cpu_baseline_port(words, lens, lo, rs, budget_nodes):
 
 
 def profiled_traffic(config, src_sha):
-    """{kernel name: HBM bytes per dispatch} from the rocprofv3 --pmc passes of this command (tools/profile_cmd.sh passes r, x ->
-    tools/pmc_to_traffic.py -> profiles/hbm_traffic.json: 128 B per read request, 32 / 64 B per write request), only when they
-    were taken on THESE kernel sources (alga_amd.engine.source_fingerprint); else {}."""
+    """({kernel name: HBM bytes per dispatch}, HBM bytes per STEP over all kernels) from the rocprofv3 --pmc passes of `bench.py --traffic-pass`
+    (tools/profile_cmd.sh passes r, x -> tools/pmc_to_traffic.py -> profiles/hbm_traffic.json: 128 B per read request, 32 / 64 B per write
+    request), only when they were taken on THESE kernel sources (alga_amd.engine.source_fingerprint); else ({}, None)."""
     try:
         ent = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json"))).get(config)
     except Exception:
-        return {}
+        return {}, None
     if not ent or ent.get("src_sha256") != src_sha:
-        return {}
-    return {k: v["read_bytes"] + v["write_bytes"] for k, v in ent["per_dispatch"].items()}
+        return {}, None
+    return {k: v["read_bytes"] + v["write_bytes"] for k, v in ent["per_dispatch"].items()}, ent.get("per_step_bytes")
 
 
 def traffic_of(traffic, prefix):
@@ -135,6 +135,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true")
     ap.add_argument("--no-first-call", action="store_true")
+    ap.add_argument("--traffic-pass", action="store_true",
+                    help="for the rocprofv3 --pmc passes (tools/profile_cmd.sh): only W + K steps of the TIMED form -- no first-call legs, no counted pass, no "
+                         "PCIe leg, no CPU baseline -- so that every dispatch the counters see belongs to a step as it is timed (tools/pmc_to_traffic.py ... --builds W+K)")
     ap.add_argument("--cpu-sample-reads", type=int, default=1_000_000, help="reads of the workload the CPU baseline runs on (~10 s of the reference at 16 threads)")
     ap.add_argument("--probe", default="auto", choices=["auto", "table", "cluster"])
     ap.add_argument("--multi-plain", action="store_true", help="N > 1: time the driver's plainest form (no sharded key pass, no pieces)")
@@ -171,6 +174,8 @@ def main():
         out["fits_in_driver_run"] = {"wall_s": round(wall, 1), "limit_s": 600, "fits": wall < 600,
                                      "note": "whole bench.py process: workload generation, first-call legs, counted pass, warmup, timed steps, PCIe leg, CPU baseline"}
         print(json.dumps(out))
+        if out.get("timed_edges_digest_equal_pairwise") is False:
+            raise SystemExit("bench.py: the edge list of the last timed step differs from the counted (pairwise) pass: %s" % (out["timed_edges_digest"],))
 
 
 def run(args, rank, world, local_rank, dist, t_process=None):
@@ -212,7 +217,7 @@ def run(args, rank, world, local_rank, dist, t_process=None):
     first = None
     eng = alga_amd.Engine(local_rank)
     eng.set_option("probe", args.probe)
-    if world == 1 and not args.no_first_call:
+    if world == 1 and not args.no_first_call and not args.traffic_pass:
         # (a) the first engine of this process: alga_engine_reserve (an assembler calls it while it still parses / uploads), then the build
         t0 = time.perf_counter()
         eng.reserve(n_nodes, max_len, lo)
@@ -257,20 +262,41 @@ def run(args, rank, world, local_rank, dist, t_process=None):
     elif world > 1:
         multi_form = {"form": "plain (all keys on every rank, one piece per rank)", "validated": "--multi-plain"}
 
+    final = {}
+
     def step(collect_stats=False):
         """one pass of the hot path over the resident read set -> (edges of the graph handed to the simplifier, stats)"""
         m, st = runner.step(collect_stats=collect_stats)
+        final["edges"] = runner.edges
         if supplement:
-            _, m = eng.pkb_supplement_device(d_words, d_lens, runner.edges.data_ptr(), m, pkb)
+            p2, m = eng.pkb_supplement_device(d_words, d_lens, runner.edges.data_ptr(), m, pkb)
+            final["edges"] = alga_amd.engine.device_view(p2, (m, 3), d_words.device)
             ps = eng.pkb_last_stats()
             st = dict(st)
             st["ms_supplement"] = ps["ms_total"]
             st["pkb"] = ps
         return m, st
 
-    # one counted pass (work counters for the roofline's algorithmic bytes); not timed
+    def digest():
+        """[count, position-weighted checksum] of the list the last step left (rank 0 holds the complete graph)"""
+        e = final.get("edges")
+        if e is None or rank != 0:
+            return None
+        torch.cuda.synchronize()
+        return [int(x) for x in multigpu.edges_digest(e).cpu()]
+
+    if args.traffic_pass:
+        for _ in range(args.warmup + args.steps):
+            n_edges, s = step()
+        sync_all()
+        return {"traffic_pass": True, "builds": args.warmup + args.steps, "edges": int(n_edges), "config": {"workload": args.config},
+                "pile_buckets": int(s.get("pile_buckets", 0)), "pile_irregular": int(s.get("pile_irregular", 0)), "src_sha256": alga_amd.engine.source_fingerprint()} if rank == 0 else None
+
+    # one counted pass (work counters for the roofline's algorithmic bytes); not timed.  A build that collects the work counters runs
+    # the PAIRWISE kernels (the counters are defined by what those do) -- its edge list is the independent one the timed list is compared with
     n_edges, st = step(collect_stats=True)
     stats = dict(st)
+    digest_counted = digest()
     if world > 1:
         stats["nodes_live"] = n_nodes                 # whole-job counters (all_reduced); nodes are replicated
     for _ in range(max(0, args.warmup - 1)):
@@ -285,6 +311,7 @@ def run(args, rank, world, local_rank, dist, t_process=None):
             phase[k] += s.get("ms_" + k, 0.0)
     sync_all()
     dt = time.perf_counter() - t0
+    digest_timed = digest()                   # of the LAST timed step's list, after the clock has stopped
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -318,11 +345,40 @@ def run(args, rank, world, local_rank, dist, t_process=None):
             # errors, where the quad kernel's waves hand their share on; N > 1, where the split is not collected: the phase as a whole
             probe_kernel = "k_probe_sources" if stats.get("probe_used") != 2 else ("k_probe_stream + k_probe_clustered (probe phase)")
             kernel_ms, kernel_bytes = ms["probe"], alg_probe_launch
-        achieved_kernel = kernel_bytes / (kernel_ms * 1e-3) / 1e9
         src_sha = alga_amd.engine.source_fingerprint()     # of the kernel sources: what the counter passes are keyed on
-        traffic = profiled_traffic(args.config, src_sha) if world == 1 else {}
+        traffic, traffic_step = profiled_traffic(args.config, src_sha) if world == 1 else ({}, None)
         tr_kernel = traffic_of(traffic, first_name) if first_dominates else (
             (traffic_of(traffic, "k_probe_stream") or 0) + (traffic_of(traffic, "k_probe_clustered") or 0) or traffic_of(traffic, "k_probe_sources"))
+        # The kernel's OWN byte model: what its formulation has to move per source.  Pile path: a 16-byte side record, a 64-byte run list, the
+        # first 64 bytes of a bucket record per run, one 8-byte slot.  Pairwise clustered kernels: the source's entry and run list, a 16-byte
+        # directory record per run, every entry scanned.  Seed-table probe: SURVEY section 8(d)'s figure is its own model (one 16-byte probe per
+        # window, one row per candidate).
+        eq = (W + 3 + 3) // 4
+        runs_per_node = 1.0 + 2.0 * (stats["windows_probed"] / n_src - 1.0) / (min(64, lo - max(lo - 63, min(lo, 16)) + 1) + 1.0)
+        if piled:
+            own_bytes = (n_src - deferred) * (16 + 64 + runs_per_node * 64 + 8)
+            own_def = "per source: 16 B side record + 64 B run list + 64 B of a bucket record per run (%.2f runs) + 8 B slot" % runs_per_node
+        elif stats.get("probe_used") == 2:
+            own_bytes = (kernel_bytes / max(1.0, alg_probe_launch)) * (n_src * (16 * eq + 64 + runs_per_node * 16) + stats["slots_scanned"] * 16 * eq)
+            own_def = "per source: its %d B entry + 64 B run list + 16 B directory record per run (%.2f runs) + %d B per entry scanned (%.1f per source)" % (
+                16 * eq, runs_per_node, 16 * eq, stats["slots_scanned"] / n_src)
+        else:
+            own_bytes, own_def = kernel_bytes, "SURVEY section 8(d): 4W + 16 per window + 4W per verified candidate"
+        # PRIMARY figure = what the kernel physically sustains: HBM bytes from the memory-request counters / its launch duration / peak when a
+        # counter pass of THESE kernel sources exists, else its own byte model.  SURVEY section 8(d)'s pairwise bytes / duration stays next to
+        # it as frac_pairwise_equivalent: for a kernel that no longer moves those bytes (the pile path) it exceeds 1 and is a statement about
+        # the algorithm, not about HBM.
+        phys_bytes, basis = (tr_kernel, "counters") if tr_kernel else (own_bytes, "own_byte_model")
+        achieved_kernel = phys_bytes / (kernel_ms * 1e-3) / 1e9
+        pairwise_equiv = kernel_bytes / (kernel_ms * 1e-3) / 1e9
+        # step level: the bytes a build cannot avoid (every row and length read once, every edge written once) against what all kernels of a
+        # step move together (counter traffic summed over a step's dispatches)
+        compulsory = n_nodes * (4 * W + 4) + int(n_edges) * 12
+        roofline_step = {"compulsory_bytes": int(compulsory), "compulsory_def": "n_nodes * (4W + 4) + edges * 12: rows and lengths read once, edges written once",
+                         "ms_per_step": ms_step, "frac_compulsory": compulsory / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "traffic_bytes": traffic_step, "frac_traffic": (traffic_step / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic_step else None,
+                         "traffic_amplification": (traffic_step / compulsory) if traffic_step else None,
+                         "traffic_source": "sum over every dispatch of a timed-form step (bench.py --traffic-pass under rocprofv3 --pmc; null = not profiled on these kernel sources)"}
         out = {
             "metric": "overlap_edges_per_sec", "value": n_edges * args.steps / dt, "unit": "edges/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
@@ -335,17 +391,24 @@ def run(args, rank, world, local_rank, dist, t_process=None):
                        "nodes": n_nodes, "edges": int(n_edges), "parallelism": "1 GPU" if world == 1 else
                        "strong scaling: the same read set for every N; node set and target index on every rank, sources sharded over %d ranks "
                        "(contiguous id ranges); edge lists gathered on rank 0 over RCCL" % world},
+            "timed_edges_digest_equal_pairwise": bool(digest_timed is not None and digest_timed == digest_counted),
+            "timed_edges_digest": {"timed_last_step": digest_timed, "counted_pairwise_pass": digest_counted,
+                                   "note": "[count, position-weighted int64 checksum] of the edge list the LAST timed step left against the list of the counted pass, "
+                                           "which ran other kernels (a build that collects work counters takes the pairwise probe); the run fails when they differ"},
             "roofline": {"bound": "hbm", "kernel": probe_kernel, "achieved": achieved_kernel, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved_kernel / HBM_PEAK_GBS, "traffic": tr_kernel,
-                         "traffic_over_algorithmic": (tr_kernel / kernel_bytes) if tr_kernel else None,
-                         "achieved_hbm": (tr_kernel / (kernel_ms * 1e-3) / 1e9) if tr_kernel else None,
-                         "traffic_source": "rocprofv3 --pmc passes of this command on this build (tools/profile_cmd.sh r, x -> profiles/hbm_traffic.json, kernel sources %s): "
-                                           "128 B per memory-side read request (gfx950 issues no other size), 32 / 64 B per write request; null = not profiled on this build; "
-                                           "achieved_hbm = that traffic / kernel_ms: the HBM rate the kernel really sustains" % src_sha,
+                         "frac": achieved_kernel / HBM_PEAK_GBS, "basis": basis, "traffic": tr_kernel,
+                         "own_byte_model": {"bytes": int(own_bytes), "def": own_def, "frac": own_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                         "frac_pairwise_equivalent": pairwise_equiv / HBM_PEAK_GBS,
+                         "pairwise_equivalent_note": "SURVEY.md section 8(d)'s algorithmic bytes of the reference's pairwise algorithm (4W + 16 P + 4W raw per source) / this kernel's duration / peak: "
+                                                     "above 1 when the kernel decides the same overlaps without moving those bytes (pile path) -- not a roofline fraction",
+                         "traffic_source": "rocprofv3 --pmc passes of bench.py --traffic-pass on this build (tools/profile_cmd.sh r, x -> profiles/hbm_traffic.json, kernel sources %s): "
+                                           "128 B per memory-side read request (gfx950 issues no other size), 32 / 64 B per write request; null = not profiled on this build "
+                                           "(frac then rests on the kernel's own byte model)" % src_sha,
                          "algorithmic_bytes": kernel_bytes, "kernel_ms": kernel_ms,
                          "units": "%d source nodes finished by this kernel per launch (of %d; %d deferred to k_probe_clustered)" % (n_src - deferred, n_src, deferred) if first_dominates else "%d source nodes per launch" % (n_src // world),
                          "per_unit": "per source node: 4W + 16 P + 4W * raw/node bytes (W=%d words, P=%.1f windows, raw/node=%.2f)" %
                                      (W, stats["windows_probed"] / max(1, stats["nodes_live"]), stats["raw_overlaps"] / max(1, stats["nodes_live"]))},
+            "roofline_step": roofline_step,
             "probe_phase": {"kernels": [first_name, "k_probe_clustered"] + (["k_pile_deg"] if piled else []) if two_kernels else [probe_kernel], "ms": ms["probe"],
                             "algorithmic_bytes": alg_probe_launch, "achieved": achieved, "frac": achieved / HBM_PEAK_GBS},
             "phases_ms": {k: ms[k] for k in ("seed", "probe", "group", "reduce", "emit", "exchange")},
@@ -371,10 +434,9 @@ def run(args, rank, world, local_rank, dist, t_process=None):
                    "pile records of the key order: every node's row read once BY ID (no entry array is built for a build the pile path keeps: one isolated row per entry, "
                    "128 bytes fetched for it), its sorted (key, id) pair and a directory record, 64 B written per k-mer group (~6 entries) and a 16-byte side record per entry; "
                    "then the run list of each pile: side records read, two 64-byte run lists in and 48 bytes out per group; part of the index build"),
-                  (probe_kernel if first_dominates else first_name, ms["probe_pairs"], alg_probe_launch * (1.0 - deferred / n_src),
-                   "bytes by SURVEY's pairwise definition; the pile path itself has to move ~%d B per source (16-byte side record, 64-byte run list, the first 64 bytes of a bucket record per run, one 8-byte slot): %.1f GB" %
-                   (16 + 64 + int(runs_per_node * 64) + 8, n_src * (16 + 64 + runs_per_node * 64 + 8) / 1e9) if piled else None),
-                  ("k_probe_clustered" + (" + k_pile_deg" if piled else ""), ms["probe"] - ms["probe_pairs"], alg_probe_launch * (deferred / n_src), None),
+                  (probe_kernel if first_dominates else first_name, ms["probe_pairs"], own_bytes, own_def),
+                  ("k_probe_clustered" + (" + k_pile_deg" if piled else ""), ms["probe"] - ms["probe_pairs"], alg_probe_launch * (deferred / n_src) + (16 * n if piled else 0),
+                   "the sources handed on, priced by SURVEY section 8(d)'s per-source bytes (this kernel does verify pairwise)" + ("; + the streaming pass that moves the out-degrees (16 B per node)" if piled else "")),
                   ("scan + k_local_emit_* + k_sort_rows_list", ms["emit"], n * 16 + E * 12, None)]
             out["roofline_kernels"] = []
             for name, kms, ab, note in rk:
@@ -387,20 +449,18 @@ def run(args, rank, world, local_rank, dist, t_process=None):
                     tr = sum(filter(None, (traffic_of(traffic, q) for q in ("k_scan", "k_local_emit", "k_sort_rows")))) or None
                 else:
                     tr = sum(filter(None, (traffic_of(traffic, q.split()[0]) for q in name.split(" + ")))) or None
-                ent = {"kernel": name, "ms": kms, "share_of_step": kms / ms_step, "algorithmic_bytes": int(ab), "achieved": ab / (kms * 1e-3) / 1e9,
-                       "frac": ab / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": tr, "achieved_hbm": (tr / (kms * 1e-3) / 1e9) if tr else None}
+                phys = tr if tr else ab                        # counters where profiled on these sources, else the kernel's own byte model
+                ent = {"kernel": name, "ms": kms, "share_of_step": kms / ms_step, "own_model_bytes": int(ab), "frac_own_model": ab / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                       "traffic": tr, "achieved": phys / (kms * 1e-3) / 1e9, "frac": phys / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "basis": "counters" if tr else "own_byte_model",
+                       "traffic_over_own_model": (tr / ab) if tr else None}
                 if note:
                     ent["note"] = note
                 out["roofline_kernels"].append(ent)
             out["index_build_ms"] = {k: ms[k] for k in ("keys", "sort", "gather", "dir", "pile")}
             if piled:
-                own = n_src * (16 + 64 + runs_per_node * 64 + 8)       # side record, run list, 64 bytes of a bucket record per run, the slot
                 out["roofline"]["pile_path"] = {
-                    "note": "the timed steps probe through PILES (alga_amd/csrc/prefsuf_pile.hip): one compare of a source against the consensus of a minimizer's targets instead of one "
-                            "per target -- `achieved` / `frac` above keep SURVEY section 8(d)'s per-source bytes of the pairwise algorithm (what the contract defines; a frac above 1 "
-                            "says the kernel does not move those bytes), own_* price the kernel against the bytes ITS formulation has to move",
-                    "own_algorithmic_bytes": int(own), "own_achieved": own / (kernel_ms * 1e-3) / 1e9, "own_frac": own / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                    "sampled_buckets": int(s.get("pile_buckets", 0)), "sampled_irregular_buckets": int(s.get("pile_irregular", 0))}
+                    "note": "the timed steps probe through PILES (alga_amd/csrc/prefsuf_pile.hip): one compare of a source against the consensus of a minimizer's targets instead of one per target",
+                    "sampled_buckets": int(s.get("pile_buckets", 0)), "sampled_irregular_buckets": int(s.get("pile_irregular", 0)), "deferred_sources": deferred}
         if supplement:
             ps = stats["pkb"]
             ab = sum(ps["kmers"]) * 24 + sum(ps["can_align_calls"]) * 8 * W + sum(ps["edges_after"]) * 8
@@ -414,18 +474,8 @@ def run(args, rank, world, local_rank, dist, t_process=None):
             first["first_over_warm"] = first["first_call_ms"] / first["warm_ms"]
             out["first_call"] = first
         if world > 1:
-            # strong-scaling efficiency T1 / (N * TN) against the one-GPU time of the same workload AND the same kernel sources
-            # recorded under profiles/ (the driver computes its own from its back-to-back runs; this one is for a reader of a single line)
-            try:
-                ref = json.loads(open(os.path.join(ROOT, "profiles", "r04_cfg4_50M_bench.json")).read().strip().splitlines()[-1])
-                if ref["config"]["nodes"] == n_nodes and ref["config"]["edges"] == int(n_edges) and ref.get("src_sha256") == src_sha:
-                    out["strong_scaling"] = {"t1_ms": ref["ms_per_step"], "t1_source": "profiles/r04_cfg4_50M_bench.json", "tn_ms": ms_step,
-                                             "efficiency": ref["ms_per_step"] / (world * ms_step)}
-            except Exception:
-                pass
             if err > 0.01:
                 out["supplement"] = "skipped (N > 1): the timed step is the exact overlap graph only -- not comparable with the N = 1 line of this config, which includes the approximate supplement"
-                out.pop("strong_scaling", None)
             out["multi_gpu_form"] = multi_form
             out["multi_gpu_validation"] = "the N-rank path has not run over RCCL on hardware (no multi-GPU node available to the builder): N-rank graph == one-GPU graph is checked over gloo and as N ranks on one GPU only"
         out["src_sha256"] = src_sha
@@ -440,10 +490,11 @@ def run(args, rank, world, local_rank, dist, t_process=None):
             # ALGA's node set comes in twin pairs (node 2k = reverse complement of node 2k + 1): the adapter sends the rows of the odd nodes
             # alone and the engine rebuilds the even ones on the device (alga_prefsuf_params.twin_rows) -- what is timed here
             twin_words = np.ascontiguousarray(host_words[1::2])
-            best, m_host = eng.prefsuf_host_timed(twin_words, host_lens, lo, rs, repeat=3, twin_rows=True)
-            full_best, m_full = eng.prefsuf_host_timed(host_words, host_lens, lo, rs, repeat=2)
+            best, m_host, dg_host = eng.prefsuf_host_timed(twin_words, host_lens, lo, rs, repeat=3, twin_rows=True, digest=True)
+            full_best, m_full, _ = eng.prefsuf_host_timed(host_words, host_lens, lo, rs, repeat=2)
             out["pcie_inclusive"] = {"ms_per_graph": best * 1e3, "edges_per_sec": m_host / best,
                                      "edges_equal_resident": bool(m_host == int(n_edges)),
+                                     "edges_digest_equal_resident": bool(digest_timed is not None and dg_host == digest_timed),
                                      "host_bytes_in": int(twin_words.nbytes + host_lens.nbytes), "host_bytes_out": int(m_host) * 12,
                                      "all_rows_uploaded": {"ms_per_graph": full_best * 1e3, "host_bytes_in": int(host_words.nbytes + host_lens.nbytes),
                                                            "edges_equal": bool(m_full == m_host)},

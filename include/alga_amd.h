@@ -92,7 +92,10 @@ typedef struct {
     int32_t keys_shared;      /* sharded form only.  1: the per-node keys were made by alga_prefsuf_keys_device and
                                  all-gathered by the caller; the build skips its own key pass.  2: this build follows
                                  another build of the SAME node set on this engine (nothing else in between) and reuses
-                                 its sorted entry array: only the probe of [src_begin, src_end) runs                 */
+                                 its sorted entry array: only the probe of [src_begin, src_end) runs.  A previous build that
+                                 the pile path KEPT (reads of one length, no masks, all sources, the sample found the buckets
+                                 regular: option "pile") has no entry array: keys_shared = 2 after it is refused with
+                                 ALGA_ERR_INVALID_ARGUMENT; after one the pile path declined it works as before        */
     int32_t twin_rows;        /* host entry points only.  1: nodes->words holds the rows of the ODD nodes alone (row k = node 2k + 1,
                                  n / 2 rows): node 2k is the reverse complement of node 2k + 1 -- ALGA's layout (src/IO/InputReader.cpp:
                                  78-80,363-377; the duplicate removal deletes twins together, src/main.cpp:150-232) -- and its row is
@@ -161,6 +164,8 @@ int         alga_engine_device_name(const alga_engine *e, char *buf, size_t bufl
  *   "auto_reduction_per_target"  != 0: alga_prefsuf_params.reduction == AUTO resolves to PER_TARGET
  *   "shard_bucket_max"           1..4096 (default 4096): run descriptors of ONE bucket the bucket-sharded join (alga_shard_join_device) takes; a
  *                                bucket with more makes the call answer ALGA_ERR_UNSUPPORTED (tests lower it to exercise that)
+ *   "test_pile_oom"              tests only.  != 0: the allocation of the pile path's own buffers (~180 B per node) answers ALGA_ERR_OUT_OF_MEMORY: the build
+ *                                must give them back and finish on the pairwise kernels (what a real out-of-memory there does)
  *   "test_unsorted_index"        tests only.  != 0: the CLUSTER probe's entry directory is built over UNSORTED keys; the directory pass
  *                                flags it, the probe's reads are clamped to the entry array, and the build returns ALGA_ERR_HIP (no GPU fault) */
 int         alga_engine_set_option(alga_engine *e, const char *name, int64_t value);
@@ -316,7 +321,10 @@ int  alga_shard_last_stats(const alga_engine *e, alga_shard_stats *out);
  * the whole graph alone: the result never depends on the number of ranks.
  * transport: RCCL (dlopen of librccl.so.1; one GPU per rank) or COPY (hipMemcpyPeerAsync + host barriers; also takes several ranks on
  * ONE device, which is how the driver is tested on a one-GPU box); AUTO = RCCL when every rank has its own GPU and there is more
- * than one, else COPY.  Not yet run on more than one GPU. */
+ * than one, else COPY.  Not yet run on more than one GPU: in particular the variable-length exchanges of the
+ * BUCKET_SHARDED form have only ever run over COPY and gloo, never over RCCL.  A post inside an RCCL group that fails on one rank aborts
+ * every communicator of the handle (ncclCommAbort: the peers' matching halves would otherwise wait for ever), the build returns an
+ * error on all ranks, and the handle refuses further RCCL collectives: destroy it and create a new one. */
 typedef struct alga_multi alga_multi; /* opaque */
 typedef enum { ALGA_TRANSPORT_AUTO = 0, ALGA_TRANSPORT_RCCL = 1, ALGA_TRANSPORT_COPY = 2 } alga_transport;
 /* How the N ranks divide a build (alga_multi_set_option "form"; same graph either way):

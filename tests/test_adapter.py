@@ -103,3 +103,23 @@ def test_first_simplifier_step_through_the_adapter(golden_dir, tmp_path, name):
     assert "edges_after_cut %d" % c["edges_after"] in log
     with gzip.open(os.path.join(golden_dir, name + ".aftercut.graph.gz"), "rb") as f:
         assert open(out, "rb").read() == f.read()
+
+
+@needs_exe
+@pytest.mark.gpu
+def test_one_pair_that_is_no_reverse_complement_pair_travels_whole(golden_dir, tmp_path):
+    """ALGA's reads come as reverse-complement pairs and the adapter uploads the odd rows only (alga_adapter::NodeArrays) -- after checking
+    EVERY pair, not a sample: a vector whose lengths pair up but where ONE even read is some other sequence must give the
+    graph the reference's creator gives for that very vector (cpu mode of the same driver), i.e. the even read as it is, not a rebuilt twin."""
+    fx, nd, _ = _fixture_nodes(golden_dir, "f1_cfg1", tmp_path)
+    words, lens = nd["words"].copy(), nd["len"].copy()
+    pairs = len(lens) // 2
+    k = next(q for q in range(7, pairs) if q % max(1, pairs // 256) != 0 and lens[2 * q] > 0 and lens[2 * q + 2] == lens[2 * q])
+    words[2 * k] = words[2 * k + 2]                      # node 2k: now a copy of node 2k + 2 instead of the reverse complement of node 2k + 1
+    nodes = str(tmp_path / "edited.nodes.bin")
+    _write_nodes(nodes, words, lens)
+    out_cpu, out_hip = str(tmp_path / "cpu.graph"), str(tmp_path / "hip.graph")
+    _run("cpu", nodes, nd, out_cpu)
+    _run("hip", nodes, nd, out_hip)
+    assert open(out_hip, "rb").read() == open(out_cpu, "rb").read()
+    assert open(out_cpu, "rb").read() != fx.ref_graph()          # (the edit did change the graph: the case tests something)

@@ -57,12 +57,17 @@ def _check_overlaps(edges, d_words, d_lens, lo, sample, seed):
         assert (a[off:off + ov] == b[:ov]).all(), "edge %s is not an overlap" % (es[k],)
 
 
-def _build(eng, wl, probe, reduction="auto", **opts):
+def _build(eng, wl, probe, reduction="auto", collect_stats=True, **opts):
     import torch
     eng.set_option("probe", probe)
-    ptr, m = eng.prefsuf_device(wl["words"], wl["lens"], wl["min_overlap"], wl["rsoemo"], reduction=reduction, collect_stats=True)
+    ptr, m = eng.prefsuf_device(wl["words"], wl["lens"], wl["min_overlap"], wl["rsoemo"], reduction=reduction, collect_stats=collect_stats)
     torch.cuda.synchronize()
     return device_view(ptr, (m, 3), wl["words"].device).clone(), eng.last_stats()
+
+
+def _pile_kept(st):
+    """the pile path sampled the key order and KEPT the build (prefsuf_pile.hip: k_pile_sample_close)"""
+    return st["pile_buckets"] > 0 and st["pile_irregular"] * alga_amd.engine.PILE_IRREGULAR_ONE_IN <= st["pile_buckets"] and st["ms_pile"] > 0
 
 
 @pytest.mark.parametrize("config,nodes,edges", [("cfg4_50M_150bp", 90_621_096, 92_350_115), ("x2_100M_150bp", 181_269_292, 184_711_310)])
@@ -91,6 +96,47 @@ def test_north_star_50M_reads_properties(config, nodes, edges):
         assert st3["raw_overlaps"] == st["raw_overlaps"]                     # both probes verified the same set of overlaps
         assert torch.equal(cl, tb), "seed-table probe and clustered join disagree"
         del tb
+        # WHAT bench.py TIMES: a build without the work counters takes the probe through PILES (k_pile_build / k_pile_runs /
+        # k_pile_probe; a build that collects the counters runs the pairwise kernels, which is what the three lists above came
+        # from).  Same bytes, at the size where the 2^26-bucket directory, two k-mers per bucket, 5-bit tag collisions and the
+        # ~0.5 % of sources handed to the general kernel all occur.  Semantics held: GraphCreatorPrefSuf.cpp:369-483.
+        assert st["pile_buckets"] == 0 and st["ms_pile"] == 0.0 and st3["pile_buckets"] == 0     # (the counted builds did not pile)
+        for rep in range(2):                                                              # twice: epoch-tagged bucket table reused
+            pl, stp = _build(eng, wl, "auto", collect_stats=False)
+            assert stp["probe_used"] == 2 and stp["reduction_used"] == 2
+            assert _pile_kept(stp), stp
+            assert 0 < stp["deferred_sources"] < n // 20                                   # the general kernel finished what the piles handed on (0.54 % at 50 M reads, 2.1 % at 100 M)
+            assert int(pl.shape[0]) == edges
+            assert torch.equal(cl, pl), "pile path and pairwise kernels disagree at %s (build %d)" % (config, rep)
+            del pl
+    finally:
+        eng.close()
+
+
+def test_pile_path_declines_at_4x_and_equals_pairwise():
+    """Four times the north-star read set (200 M reads of a 1 Gb genome, 363 M nodes): a 19-mer sits at a second locus often enough
+    that the sample finds more than 1 irregular bucket in 250 and the pile kernels leave the build to the pairwise ones -- decided on
+    the device.  The list must be the one a build with the pile path switched off gives, and a valid overlap list."""
+    import torch
+    n_reads, read_len, G, seed, err = workload.CONFIGS["x4_200M_150bp"]
+    wl = workload.device_build(n_reads, read_len, G, seed, err=err)
+    torch.cuda.synchronize()
+    n = int(wl["lens"].shape[0])
+    lo = wl["min_overlap"]
+    eng = alga_amd.Engine(0)
+    try:
+        a, sta = _build(eng, wl, "auto", collect_stats=False)
+        assert sta["probe_used"] == 2 and sta["pile_buckets"] > 0
+        kept = _pile_kept(sta)
+        _check_list(a, n, int(wl["lens"].max().item()), lo)
+        _check_overlaps(a, wl["words"], wl["lens"], lo, 2000, 3)
+        eng.set_option("pile", 0)
+        b, stb = _build(eng, wl, "auto", collect_stats=False)
+        eng.set_option("pile", 1)
+        assert stb["pile_buckets"] == 0
+        assert torch.equal(a, b), "4x set: build with the pile path %s differs from the pairwise build" % ("kept" if kept else "declined")
+        if not kept:
+            assert sta["pile_irregular"] * alga_amd.engine.PILE_IRREGULAR_ONE_IN > sta["pile_buckets"]
     finally:
         eng.close()
 

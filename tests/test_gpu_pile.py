@@ -210,3 +210,53 @@ def test_bucket_table_is_valid_by_epoch(eng):
         assert got.shape == want.shape and (got == want).all(), it
         if it < 2:
             assert eng.last_stats()["pile_buckets"] > 0
+
+
+def test_out_of_memory_in_the_pile_buffers_falls_back_to_the_pairwise_kernels(eng):
+    """The pile path needs ~180 B per node of its own (bucket table, group records, side records).  An input that fits without them must not
+    fail because of them: when their allocation answers out of memory the build gives them back and finishes on the
+    pairwise kernels -- same graph, no error left behind -- and the next build, with memory again, takes the pile path as before."""
+    words, lens = _nodes(9000, 150, 40_000, 501)
+    lo, rs = alga_amd.derive_params(144.0)
+    want, _, _ = O.prefsuf(words, lens, lo, rs)
+    eng.set_option("test_pile_oom", 1)
+    try:
+        got = eng.prefsuf_host(words, lens, lo, rs)
+    finally:
+        eng.set_option("test_pile_oom", 0)
+    st = eng.last_stats()
+    assert got.shape == want.shape and (got == want).all()
+    assert st["probe_used"] == 2 and st["pile_buckets"] == 0 and st["ms_pile"] == 0.0      # the pairwise kernels took it
+    got = eng.prefsuf_host(words, lens, lo, rs)
+    st = eng.last_stats()
+    assert got.shape == want.shape and (got == want).all()
+    assert st["pile_buckets"] > 0 and st["ms_pile"] > 0
+
+
+def test_a_further_piece_after_a_build_the_pile_path_declined(eng):
+    """params.keys_shared = 2 (a further piece of the same node set reuses the entry array of the build before it): refused after a build the
+    pile path KEPT (there is no entry array), but a build it DECLINED -- reads with errors: decided on the device -- did make one and must
+    serve the next piece as it did before the pile path existed."""
+    import torch
+    from alga_amd.engine import device_view
+    lo, rs = alga_amd.derive_params(144.0)
+    for err, kept in ((0.02, False), (0.0, True)):
+        words, lens = _nodes(12_000, 150, 40_000, 23, err=err)
+        want, _, _ = O.prefsuf(words, lens, lo, rs)
+        dw = torch.from_numpy(words.view(np.int32)).cuda()
+        dl = torch.from_numpy(lens.astype(np.int32)).cuda()
+        n = len(lens)
+        ptr, m = eng.build_range_device(dw, dl, lo, rs, 0, n)
+        st = eng.last_stats()
+        assert (st["pile_irregular"] * alga_amd.engine.PILE_IRREGULAR_ONE_IN <= st["pile_buckets"]) == kept and st["pile_buckets"] > 0
+        full = device_view(ptr, (m, 3), dw.device).cpu().numpy()
+        assert full.shape == want.shape and (full == want).all()
+        half = (n // 4) * 2
+        if kept:
+            with pytest.raises(alga_amd.AlgaError):
+                eng.build_range_device(dw, dl, lo, rs, 0, half, keys_shared=2)
+        else:
+            ptr, m = eng.build_range_device(dw, dl, lo, rs, 0, half, keys_shared=2)
+            got = device_view(ptr, (m, 3), dw.device).cpu().numpy()
+            sel = want[want[:, 0] < half]
+            assert got.shape == sel.shape and (got == sel).all()

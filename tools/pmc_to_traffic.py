@@ -33,37 +33,59 @@ def short(name):
     return name
 
 
-def means(root, sub):
-    acc = {}
+def collect(root, sub):
+    """{kernel: {counter: [values in dispatch order]}} of the newest file of a pass directory, from the engine's FIRST dispatch on:
+    everything before it is the workload generator (torch kernels, and torch's own rocPRIM sorts, which carry the same names as the
+    library sorts the supplement still uses)."""
     # (one pass = one rocprofv3 process = one file; gpurun merges every call's files into the same local directory, so only the NEWEST
     # file of a pass directory belongs to the build at hand -- averaging over older ones mixed kernels of different builds)
     files = sorted(glob.glob(os.path.join(root, sub, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)
+    rows = []
     for f in files[-1:]:
-        for r in csv.DictReader(open(f)):
-            acc.setdefault(short(r["Kernel_Name"]), {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
-    return {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in acc.items()}
+        rows = [(int(r["Dispatch_Id"]), short(r["Kernel_Name"]), r["Counter_Name"], float(r["Counter_Value"])) for r in csv.DictReader(open(f))]
+    first = min([d for d, k, _, _ in rows if k.startswith("k_")], default=0)
+    acc = {}
+    for d, k, c, v in sorted(rows):
+        if d >= first:
+            acc.setdefault(k, {}).setdefault(c, []).append(v)
+    return acc
 
 
 def main():
     from alga_amd.engine import source_fingerprint
-    root, config = sys.argv[1], sys.argv[2]
-    rd, wr = means(root, "pmc_rdreq"), means(root, "pmc_wrreq")
+    argv = [a for a in sys.argv[1:] if not a.startswith("--builds")]
+    builds = [int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--builds=")]
+    root, config = argv[0], argv[1]
+    rd, wr = collect(root, "pmc_rdreq"), collect(root, "pmc_wrreq")
     kernels = {}
+    total = 0.0
     for k in sorted(set(rd) | set(wr)):
-        if not (k.startswith("k_") or "rocprim" in k) or "<true" in k:          # engine kernels and the library sort; not the statistics builds
+        if not (k.startswith("k_") or "rocprim" in k):                           # engine kernels and the library sorts
             continue
         r, w = rd.get(k, {}), wr.get(k, {})
-        n128, n64, n32 = r.get("TCC_EA0_RDREQ_128B_sum", 0.0), r.get("TCC_EA0_RDREQ_64B_sum", 0.0), r.get("TCC_EA0_RDREQ_32B_sum", 0.0)
-        other = r.get("TCC_EA0_RDREQ_sum", 0.0) - n128 - n64 - n32                # requests of no listed size (none seen): priced at 64 bytes
-        w64 = w.get("TCC_EA0_WRREQ_64B_sum", 0.0)
-        kernels[k[:70]] = {"read_bytes": int(128 * n128 + 64 * n64 + 32 * n32 + 64 * max(0.0, other)),
-                           "write_bytes": int(64 * w64 + 32 * max(0.0, w.get("TCC_EA0_WRREQ_sum", 0.0) - w64)),
-                           "read_requests": {"128B": int(n128), "64B": int(n64), "32B": int(n32)}}
+        tot = lambda d, c: float(sum(d.get(c, [])))
+        calls = max([len(v) for v in list(r.values()) + list(w.values())] or [1])
+        n128, n64, n32 = tot(r, "TCC_EA0_RDREQ_128B_sum"), tot(r, "TCC_EA0_RDREQ_64B_sum"), tot(r, "TCC_EA0_RDREQ_32B_sum")
+        other = tot(r, "TCC_EA0_RDREQ_sum") - n128 - n64 - n32                    # requests of no listed size (none seen): priced at 64 bytes
+        w64 = tot(w, "TCC_EA0_WRREQ_64B_sum")
+        rb = 128 * n128 + 64 * n64 + 32 * n32 + 64 * max(0.0, other)
+        wb = 64 * w64 + 32 * max(0.0, tot(w, "TCC_EA0_WRREQ_sum") - w64)
+        total += rb + wb
+        if "<true" in k and k.startswith("k_probe"):                             # the statistics builds of the probes (bench.py's counted pass): not a timed kernel
+            continue
+        kernels[k[:70]] = {"read_bytes": int(rb / calls), "write_bytes": int(wb / calls), "dispatches": calls,
+                           "read_requests": {"128B": int(n128 / calls), "64B": int(n64 / calls), "32B": int(n32 / calls)}}
     out_path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     data = json.load(open(out_path)) if os.path.exists(out_path) else {}
-    data[config] = {"src_sha256": source_fingerprint(), "source": os.path.basename(root.rstrip("/")), "per_dispatch": kernels}
+    ent = {"src_sha256": source_fingerprint(), "source": os.path.basename(root.rstrip("/")), "per_dispatch": kernels}
+    if builds:
+        # the profiled command was `bench.py --traffic-pass`: W + K builds of the timed form and nothing else of the engine -- the sum over every
+        # dispatch / builds = the HBM bytes of ONE step (bench.py: roofline_step.traffic_bytes)
+        ent["builds"] = builds[0]
+        ent["per_step_bytes"] = int(total / builds[0])
+    data[config] = ent
     json.dump(data, open(out_path, "w"), indent=1, sort_keys=True)
-    print(json.dumps({k: v["read_bytes"] + v["write_bytes"] for k, v in kernels.items()}))
+    print(json.dumps({"per_step_bytes": ent.get("per_step_bytes"), **{k: v["read_bytes"] + v["write_bytes"] for k, v in kernels.items()}}))
 
 
 if __name__ == "__main__":
