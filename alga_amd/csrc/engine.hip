@@ -212,7 +212,7 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
             e->store_n = -1;
             HIP_TRY(e, launch_cluster_store(nd, cc, (uint32_t *) e->cl_keys[0].p, (uint32_t *) e->cl_vals[0].p, (uint32_t *) e->cl_keys[1].p,
                                             (uint32_t *) e->cl_vals[1].p, e->sort_temp.p, cluster_sort_temp_bytes((uint64_t) nd.n), e->cl_dir.p, pp.keys_shared == 1,
-                                            e->ev[EV_SORT], cnt + CNT_TOTAL + 1, e->opt_test_unsorted_index != 0, s));
+                                            e->ev[EV_SORT], cnt + CNT_TOTAL + 1, e->opt_test_unsorted_index != 0, s, e->opt_own_sort != 0));
             HIP_TRY(e, hipEventRecord(e->ev[EV_DIR], s));
             e->pile_n = -1;
             if (pile) {
@@ -615,6 +615,10 @@ int alga_engine_set_option(alga_engine *e, const char *name, int64_t value) {
         e->big_limit = value < 0 ? -1 : (int) std::min<int64_t>(value, 1 << 20);
     } else if (!strcmp(name, "shard_bucket_max")) {
         e->opt_shard_dmax = (int) std::max<int64_t>(1, std::min<int64_t>(value, 4096));
+    } else if (!strcmp(name, "rsort_variant")) {
+        rsort_set_variant((int) value);                    // tuning only (process-wide): tile shape of radix_sort.hip
+    } else if (!strcmp(name, "own_sort")) {
+        e->opt_own_sort = value != 0;
     } else if (!strcmp(name, "test_pile_oom")) {
         e->opt_test_pile_oom = value != 0;                 // tests only: the pile path's allocation answers out of memory; the build must continue on the pairwise kernels
     } else if (!strcmp(name, "test_unsorted_index")) {
@@ -1090,6 +1094,39 @@ int alga_sort_edges_device(alga_engine *e, const alga_edge *d_edges, uint64_t n_
     if ((rc = alga_check_launch(e, "k_keys_to_edges"))) return rc;
     HIP_TRY(e, hipStreamSynchronize(s));
     *d_sorted = (const alga_edge *) e->edges_sorted.p;
+    return ALGA_OK;
+}
+
+// the (u32 key, u32 value) sort of the index build on its own (tests / tools): stable on the key bits [begin_bit, 32)
+int alga_sort_u32_pairs_device(alga_engine *e, const uint32_t *d_keys, const uint32_t *d_vals, uint64_t n, int32_t begin_bit, int32_t own, int32_t repeat,
+                               void *hip_stream, const uint32_t **d_keys_sorted, const uint32_t **d_vals_sorted, double *ms_best) {
+    if (!e) return ALGA_ERR_INVALID_ARGUMENT;
+    e->err.clear();
+    if (!d_keys_sorted || !d_vals_sorted) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "output pointers must not be NULL");
+    *d_keys_sorted = nullptr; *d_vals_sorted = nullptr;
+    if (n && (!d_keys || !d_vals)) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "key / value arrays must not be NULL");
+    if (begin_bit < 0 || begin_bit > 31) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "begin_bit must be in [0, 31]");
+    if (n >= (1ull << 32) - (1u << 16)) return alga_fail(e, ALGA_ERR_CAPACITY, "more than 2^32 pairs");
+    DeviceGuard guard;
+    HIP_TRY(e, hipSetDevice(e->device));
+    hipStream_t s = hip_stream ? (hipStream_t) hip_stream : e->own_stream;
+    int rc;
+    const size_t temp_bytes = sort_u32_pairs_temp_bytes(n);
+    if ((rc = alga_ensure(e, e->cl_keys[1], (size_t) (n + ALGA_KEY_ARRAY_SLACK + 1) * sizeof(uint32_t)))) return rc;
+    if ((rc = alga_ensure(e, e->cl_vals[1], (size_t) (n + 1) * sizeof(uint32_t)))) return rc;
+    if ((rc = alga_ensure(e, e->sort_temp, temp_bytes))) return rc;
+    e->store_n = -1; e->keyed_n = -1; e->pile_n = -1;      // (the sort buffers of a clustered build are rewritten)
+    double best = 0.0;
+    for (int it = 0; it < std::max(1, repeat); it++) {
+        HIP_TRY(e, hipEventRecord(e->ev[EV_START], s));
+        HIP_TRY(e, sort_u32_pairs(e->sort_temp.p, temp_bytes, d_keys, (uint32_t *) e->cl_keys[1].p, d_vals, (uint32_t *) e->cl_vals[1].p, n, begin_bit, s, own != 0));
+        HIP_TRY(e, hipEventRecord(e->ev[EV_SORT], s));
+        HIP_TRY(e, hipStreamSynchronize(s));
+        const double ms = ev_ms(e, EV_START, EV_SORT);
+        best = it == 0 ? ms : std::min(best, ms);
+    }
+    if (ms_best) *ms_best = best;
+    *d_keys_sorted = (const uint32_t *) e->cl_keys[1].p; *d_vals_sorted = (const uint32_t *) e->cl_vals[1].p;
     return ALGA_OK;
 }
 

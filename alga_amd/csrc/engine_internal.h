@@ -56,6 +56,7 @@ struct alga_engine {
     bool   store_timed = false;                             // EV_KEYS / EV_SORT / EV_GATHER were recorded in the last discovery
     int    opt_pile_skip_gather = 1;                        // option "pile_skip_gather": no entry array for a build the pile path keeps
     int    opt_pile = 1;                                    // option "pile": the probe through piles (prefsuf_pile.hip) where the input allows it
+    int    opt_own_sort = 1;                                // option "own_sort": the (key, id) sort of the index build is the engine's own radix sort (radix_sort.hip); 0: rocPRIM's
     int    opt_test_pile_oom = 0;                           // tests only: the pile path's allocation reports out of memory (the build must continue on the pairwise kernels)
     bool   pile_timed = false;                              // EV_DIR was recorded in the last discovery (k_pile_build ran behind it)
     DevBuf cl_pile_succ;                                    // per entry (16 B): its id, the member of its own pile that starts next to its right, its place in the pile (k_pile_probe reads this, not the entry)

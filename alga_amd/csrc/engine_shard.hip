@@ -106,7 +106,7 @@ int alga_shard_index_device(alga_engine *e, const alga_nodes *nodes, const alga_
     if ((rc = alga_ensure(e, e->sort_temp, std::max(cluster_sort_temp_bytes(m), sort_desc_temp_bytes(1))))) return rc;
     HIP_TRY(e, launch_cluster_store_slice(pp.nd, cc, pp.cluster_eq, m, b_lo, n_b_local, (uint32_t *) e->sh_keys[0].p, (uint32_t *) e->sh_vals[0].p, (uint32_t *) e->sh_keys[1].p,
                                           (uint32_t *) e->sh_vals[1].p, (const uint32_t *) e->cl_meta.p, pp.uniform_len, e->sort_temp.p, cluster_sort_temp_bytes(m),
-                                          e->sh_store.p, e->sh_dir.p, cnt + 2, s));
+                                          e->sh_store.p, e->sh_dir.p, cnt + 2, s, e->opt_own_sort != 0));
     e->shard_stats.ms_index = t_index.stop();
     PhaseTimer t_export(s);
     launch_shard_export(false, e->cl_runs.p, kb, ke, cc.idx_shift, bpr, (uint32_t) n_ranks, nullptr, nullptr, nullptr, 0u, cnt + 192, cnt + 128, (uint32_t *) e->sh_desc_out.p, s);

@@ -60,36 +60,16 @@ constexpr int NR_STACK = 8;          // minimum records kept per node and block 
 // reduction).  The window minimum by two blocks needs nwin <= w <= 64, so the windows are taken in two halves of up to 64 -- [64, nwin) on
 // the k-mers from position 64 on, then [0, 64) -- each by the very same three steps on the row shifted by 64 nucleotides (four words), and
 // the runs of both halves are listed one after the other (a minimizer that spans the seam makes two runs: one more look-up, same overlaps).
-template <int TKW, bool WIDE>
-__global__ void __launch_bounds__(TK_ROWS) k_node_runs(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, int node_begin, int node_end,
-                                                        uint32_t *__restrict__ keys, uint32_t *__restrict__ vals, uint32_t *__restrict__ meta,
-                                                        uint2 *__restrict__ runs, uint8_t *__restrict__ nruns) {
-    __shared__ uint32_t s[TK_ROWS][TKW];
-    // records, transposed (conflict-free): rows 0 .. NR_STACK - 1 block 1, NR_STACK the spare row that takes the stores of lanes
-    // that do not push, NR_STACK + 1 .. 2 NR_STACK block 0, 2 NR_STACK + 1 its spare row
-    __shared__ uint32_t stk[2 * (NR_STACK + 1)][TK_ROWS];
-    __shared__ uint16_t rbuf[CL_RMAX + 1][TK_ROWS];        // runs as they are found: q | p0 << 8 (p1 = p0 of the run found before); last row: spare
+// The window minimizers of ONE row (thread t of the workgroup; the row staged in LDS, `act`: the row takes part): steps (1) - (3) above.
+// Leaves the runs in rbuf[0 .. min(nr, CL_RMAX))[t] as q | p0 << 8 (p1 = p0 of the run before; the last windows first), the minimum of
+// block 0 of the first half (the row's minimizer as a TARGET) in cur0.  Shared by k_node_runs (a node's row) and k_pile_runs_consensus
+// (prefsuf_pile.hip: the consensus of a pile on the pile's extent -- the windows of all its members at once).
+template <bool WIDE>
+__device__ __forceinline__ void node_runs_core(const uint32_t *row, int nwin, bool act, const ClusterCfg &cc, uint32_t (*stk)[TK_ROWS], uint16_t (*rbuf)[TK_ROWS], int t,
+                                               int &nr, bool &uncovered, bool &stack_ovf, uint32_t &cur0) {
     constexpr int S0 = NR_STACK + 1;                       // first row of block 0's records
-    const int base = node_begin + blockIdx.x * TK_ROWS;     // the nodes node_begin .. node_end - 1 (a rank's share, or all of them)
-    const int nrows = min(TK_ROWS, node_end - base);
-    for (int c = (int) (threadIdx.x & 15u); c < TKW; c += 16)
-        for (int r = (int) (threadIdx.x >> 4); r < nrows; r += TK_ROWS / 16)
-            s[r][c] = c < nd.stride ? nd.words[(size_t) (base + r) * nd.stride + c] : 0u;
-    __syncthreads();
-    const int t = (int) threadIdx.x;
-    const bool in = t < nrows;
-    const int i = base + (in ? t : 0);
-    const int len = in ? nd.len[i] : 0;
-    const bool act = in && len >= cfg.Lmin && len > 0;
-    const bool is_tgt = act && (!nd.to || nd.to[i]);
-    const bool is_src = act && (!nd.from || nd.from[i]);
-    const uint32_t *row = s[in ? t : 0];
     const int w = cc.w;
-    const int nwin = len - cfg.Lmin + 1;                   // <= 64 (one-word form of the source-side reduction); <= 128 with WIDE
-    int nr = 0;
-    bool uncovered = false;                                // some window holds no class-0 k-mer
-    bool stack_ovf = false;
-    uint32_t cur0 = 0xFFFFFFFFu;                           // minimum of block 0 of the FIRST half: the node's key as a target
+    nr = 0; uncovered = false; stack_ovf = false; cur0 = 0xFFFFFFFFu;
     for (int hb = (WIDE && nwin > 64) ? 64 : 0; hb >= 0; hb -= 64) {       // first window of the half (one pass with hb = 0 unless WIDE)
         const uint32_t *rowh = row + (hb >> 4);
         const int nwh = !WIDE ? nwin : (hb ? nwin - 64 : (nwin < 64 ? nwin : 64));
@@ -182,11 +162,56 @@ __global__ void __launch_bounds__(TK_ROWS) k_node_runs(NodesDev nd, PrefSufCfg c
             }
         }
     }
+}
+
+// TARGETS ONLY (what_runs = false below): the key pass of a build whose sources get their run lists elsewhere (the pile path: a pile's run
+// list comes from its consensus, prefsuf_pile.hip) needs the minimum of block 0 alone -- no stacks, no window sweep.
+template <int TKW, bool WIDE, bool RUNS>
+__global__ void __launch_bounds__(TK_ROWS) k_node_runs(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, int node_begin, int node_end,
+                                                        uint32_t *__restrict__ keys, uint32_t *__restrict__ vals, uint32_t *__restrict__ meta,
+                                                        uint2 *__restrict__ runs, uint8_t *__restrict__ nruns, const int32_t *__restrict__ id_list, const unsigned long long *__restrict__ id_count) {
+    __shared__ uint32_t s[TK_ROWS][TKW];
+    // records, transposed (conflict-free): rows 0 .. NR_STACK - 1 block 1, NR_STACK the spare row that takes the stores of lanes
+    // that do not push, NR_STACK + 1 .. 2 NR_STACK block 0, 2 NR_STACK + 1 its spare row
+    __shared__ uint32_t stk[RUNS ? 2 * (NR_STACK + 1) : 1][TK_ROWS];
+    __shared__ uint16_t rbuf[RUNS ? CL_RMAX + 1 : 1][TK_ROWS];        // runs as they are found: q | p0 << 8 (p1 = p0 of the run found before); last row: spare
+    // the nodes node_begin .. node_end - 1 (a rank's share, or all of them), or -- id_list -- the nodes a list names (RUNS only: their run
+    // lists and nothing else; the list's length is read from the device)
+    const int list_n = id_list ? (int) min((unsigned long long) (node_end - node_begin), *id_count) : 0;
+    __shared__ int sid[TK_ROWS];
+    // (a list is walked with the grid's stride -- its length is only known on the device, the grid is sized for the chip, not for the cap)
+    for (int blk = (int) blockIdx.x; id_list ? blk * TK_ROWS < list_n : blk == (int) blockIdx.x; blk += (int) gridDim.x) {
+    const int base = node_begin + blk * TK_ROWS;
+    const int nrows = id_list ? min(TK_ROWS, list_n - blk * TK_ROWS) : min(TK_ROWS, node_end - base);
+    if (id_list) {
+        __syncthreads();                                   // (the rows of the chunk before are done with)
+        if ((int) threadIdx.x < nrows) sid[threadIdx.x] = min(max(id_list[blk * TK_ROWS + (int) threadIdx.x], 0), nd.n - 1);
+        __syncthreads();
+    }
+    for (int c = (int) (threadIdx.x & 15u); c < TKW; c += 16)
+        for (int r = (int) (threadIdx.x >> 4); r < nrows; r += TK_ROWS / 16)
+            s[r][c] = c < nd.stride ? nd.words[(size_t) (id_list ? sid[r] : base + r) * nd.stride + c] : 0u;
+    __syncthreads();
+    const int t = (int) threadIdx.x;
+    const bool in = t < nrows;
+    const int i = id_list ? sid[in ? t : 0] : base + (in ? t : 0);
+    const int len = in ? nd.len[i] : 0;
+    const bool act = in && len >= cfg.Lmin && len > 0;
+    const bool is_tgt = act && (!nd.to || nd.to[i]);
+    const bool is_src = act && (!nd.from || nd.from[i]);
+    const uint32_t *row = s[in ? t : 0];
+    const int w = cc.w;
+    const int nwin = len - cfg.Lmin + 1;                   // <= 64 (one-word form of the source-side reduction); <= 128 with WIDE
     const int fs = cc.idx_shift - CL_MBITS;
-    const int nr_stored = nr < CL_RMAX ? nr : CL_RMAX;
-    // what nruns[i] says, also in the top byte of run 0's second word (the quad kernel reads the run list and nothing else)
-    const uint32_t nr_code = !is_src ? 0u : ((nr > CL_RMAX || stack_ovf || uncovered) ? (uint32_t) CL_RUNS_FLAGGED : (uint32_t) nr);
-    {
+    int nr = 0;
+    bool uncovered = false;                                // some window holds no class-0 k-mer
+    bool stack_ovf = false;
+    uint32_t cur0 = 0xFFFFFFFFu;                           // minimum of block 0 of the FIRST half: the node's key as a target
+    if (RUNS) {
+        node_runs_core<WIDE>(row, nwin, act, cc, stk, rbuf, t, nr, uncovered, stack_ovf, cur0);
+        const int nr_stored = nr < CL_RMAX ? nr : CL_RMAX;
+        // what nruns[i] says, also in the top byte of run 0's second word (the quad kernel reads the run list and nothing else)
+        const uint32_t nr_code = !is_src ? 0u : ((nr > CL_RMAX || stack_ovf || uncovered) ? (uint32_t) CL_RUNS_FLAGGED : (uint32_t) nr);
         int p1 = nwin;
         for (int r = 0; r < CL_RMAX; r++) {                // (skipped by the waves none of whose nodes has that many runs)
             if (r < nr_stored && is_src) {
@@ -199,6 +224,28 @@ __global__ void __launch_bounds__(TK_ROWS) k_node_runs(NodesDev nd, PrefSufCfg c
             }
         }
         if (in && !is_src) runs[(size_t) i * CL_RMAX] = make_uint2(0u, 0u);
+        if (in) nruns[i] = (uint8_t) nr_code;
+        if (id_list) continue;                             // (the listed nodes' keys are in place)
+    } else {
+        // the minimum of block 0 (k-mers [0, w)) over its class-0 positions
+        const int nk = act ? min(nwin, WIDE ? 64 : nwin) - 1 + w : 0;
+        uint64_t b0;
+        {
+            const uint32_t x0 = row[0], x1 = row[1], x2 = row[2], x3 = row[3], x4 = row[4];
+            const uint32_t d0 = compress_even(class0_mask16(x0, x1)) | (compress_even(class0_mask16(x1, x2)) << 16);
+            const uint32_t d1 = compress_even(class0_mask16(x2, x3)) | (compress_even(class0_mask16(x3, x4)) << 16);
+            b0 = (uint64_t) d0 | ((uint64_t) d1 << 32);
+            b0 &= nk >= 64 ? ~0ull : (nk <= 0 ? 0ull : ((1ull << nk) - 1ull));
+            b0 &= w >= 64 ? ~0ull : ((1ull << w) - 1ull);
+        }
+        while (b0 != 0ull) {
+            const int e = __builtin_ctzll(b0);
+            b0 &= b0 - 1ull;
+            const int bit = 2 * e, q = bit >> 5, r = bit & 31;
+            const uint32_t x0 = row[q], x1 = row[q + 1], x2 = row[q + 2];
+            const uint32_t pk = order_key0(kmer_hash(funnel(x0, x1, r) & cc.lo_mask, funnel(x1, x2, r) & cc.hi_mask), e);
+            cur0 = pk < cur0 ? pk : cur0;
+        }
     }
     // ---- the node as a target: the minimizer of window 0 = the minimum of block 0 (cur0: every class-0 k-mer of the block has
     //      been seen, whatever the stacks hold) ----
@@ -213,9 +260,7 @@ __global__ void __launch_bounds__(TK_ROWS) k_node_runs(NodesDev nd, PrefSufCfg c
         key = tgt_sort_key(cluster_key(h, fs), pmin & 255u, fs);
         m = (pmin & 255u) | ((uint32_t) len << 8) | (is_src ? CL_META_FROM : 0u);
     }
-    if (in) {
-        keys[i] = key; vals[i] = (uint32_t) i; meta[i] = m;
-        nruns[i] = (uint8_t) nr_code;
+    if (in) { keys[i] = key; vals[i] = (uint32_t) i; meta[i] = m; }
     }
 }
 
@@ -1245,20 +1290,35 @@ bool cluster_plan(const PrefSufCfg &cfg, int max_len, uint64_t live, int bucket_
 
 size_t cluster_sort_temp_bytes(uint64_t n) { return sort_u32_pairs_temp_bytes(n); }
 
-// minimizer keys, entry words and runs of the nodes node_begin .. node_end - 1 (per-node arrays, written at the node's own index)
+// minimizer keys, entry words and runs of the nodes node_begin .. node_end - 1 (per-node arrays, written at the node's own index).
+// with_runs = false: the keys (and meta words) alone -- the key pass of a build whose run lists are made elsewhere (prefsuf_pile.hip).
 void launch_cluster_keys(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterCfg &cc, int32_t node_begin, int32_t node_end, uint32_t *keys, uint32_t *vals,
-                         uint32_t *meta, void *runs, uint8_t *nruns, hipStream_t s) {
+                         uint32_t *meta, void *runs, uint8_t *nruns, hipStream_t s, bool with_runs) {
     if (node_end <= node_begin) return;
     const uint64_t m = (uint64_t) (node_end - node_begin);
     const dim3 grid((unsigned) ((m + TK_ROWS - 1) / TK_ROWS)), block(TK_ROWS);
+    const int32_t *nol = nullptr; const unsigned long long *noc = nullptr;
     // rows of up to 9 words (every 100 - 150 bp configuration) stage 11 words per node, longer ones (<= 13 words) 17
     // ... and rows of up to 17 words or nodes with more than 64 suffix windows (250-bp reads) the two-halves form with 21
-    if (blocks_of(cfg.Lcap - 1) > 13 || (cfg.Lcap - 1) - cfg.Lmin + 1 > 64)
-        hipLaunchKernelGGL((k_node_runs<21, true>), grid, block, 0, s, nd, cfg, cc, (int) node_begin, (int) node_end, keys, vals, meta, (uint2 *) runs, nruns);
-    else if (blocks_of(cfg.Lcap - 1) <= 9)
-        hipLaunchKernelGGL((k_node_runs<11, false>), grid, block, 0, s, nd, cfg, cc, (int) node_begin, (int) node_end, keys, vals, meta, (uint2 *) runs, nruns);
-    else
-        hipLaunchKernelGGL((k_node_runs<17, false>), grid, block, 0, s, nd, cfg, cc, (int) node_begin, (int) node_end, keys, vals, meta, (uint2 *) runs, nruns);
+#define NR_LAUNCH(TKW, WIDE) do { if (with_runs) hipLaunchKernelGGL((k_node_runs<TKW, WIDE, true>), grid, block, 0, s, nd, cfg, cc, (int) node_begin, (int) node_end, keys, vals, meta, (uint2 *) runs, nruns, nol, noc); \
+                                  else hipLaunchKernelGGL((k_node_runs<TKW, WIDE, false>), grid, block, 0, s, nd, cfg, cc, (int) node_begin, (int) node_end, keys, vals, meta, (uint2 *) runs, nruns, nol, noc); } while (0)
+    if (blocks_of(cfg.Lcap - 1) > 13 || (cfg.Lcap - 1) - cfg.Lmin + 1 > 64) NR_LAUNCH(21, true);
+    else if (blocks_of(cfg.Lcap - 1) <= 9) NR_LAUNCH(11, false);
+    else NR_LAUNCH(17, false);
+#undef NR_LAUNCH
+}
+
+// the run lists (and nothing else) of the nodes a device-side list names: ids[0 .. min(*count, cap))
+void launch_cluster_runs_list(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterCfg &cc, const int32_t *ids, const unsigned long long *count, uint32_t cap, uint32_t grid_blocks,
+                              void *runs, uint8_t *nruns, hipStream_t s) {
+    if (cap == 0 || nd.n <= 0) return;
+    const dim3 grid(std::max<uint32_t>(1u, std::min<uint32_t>(grid_blocks, (cap + TK_ROWS - 1) / TK_ROWS))), block(TK_ROWS);
+    uint32_t *nok = nullptr;
+#define NR_LAUNCH(TKW, WIDE) hipLaunchKernelGGL((k_node_runs<TKW, WIDE, true>), grid, block, 0, s, nd, cfg, cc, 0, (int) cap, nok, nok, nok, (uint2 *) runs, nruns, ids, count)
+    if (blocks_of(cfg.Lcap - 1) > 13 || (cfg.Lcap - 1) - cfg.Lmin + 1 > 64) NR_LAUNCH(21, true);
+    else if (blocks_of(cfg.Lcap - 1) <= 9) NR_LAUNCH(11, false);
+    else NR_LAUNCH(17, false);
+#undef NR_LAUNCH
 }
 
 __global__ void __launch_bounds__(256) k_iota(uint32_t *__restrict__ v, uint32_t n) {
@@ -1270,7 +1330,7 @@ __global__ void __launch_bounds__(256) k_iota(uint32_t *__restrict__ v, uint32_t
 // live node has that length and there is no alignFrom mask (k_tgt_gather<., true>: meta[] is not read).
 hipError_t launch_cluster_store(const NodesDev &nd, const ClusterCfg &cc, uint32_t *keys, uint32_t *vals, uint32_t *keys2, uint32_t *vals2,
                                 void *sort_temp, size_t sort_temp_bytes, void *dir, bool fill_vals,
-                                hipEvent_t ev_sorted, unsigned long long *bad_flag, bool test_skip_sort, hipStream_t s) {
+                                hipEvent_t ev_sorted, unsigned long long *bad_flag, bool test_skip_sort, hipStream_t s, bool own_sort) {
     if (nd.n <= 0) return hipSuccess;
     const uint64_t n = (uint64_t) nd.n;
     if (fill_vals) hipLaunchKernelGGL(k_iota, dim3((unsigned) std::min<uint64_t>((n + 255) / 256, 8192)), dim3(256), 0, s, vals, (uint32_t) n);
@@ -1281,7 +1341,7 @@ hipError_t launch_cluster_store(const NodesDev &nd, const ClusterCfg &cc, uint32
     if (test_skip_sort) {                                  // tests only (option "test_unsorted_index"): the keys go on as they are, the directory pass must notice
         err = hipMemcpyAsync(keys2, keys, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s);
         if (err == hipSuccess) err = hipMemcpyAsync(vals2, vals, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s);
-    } else err = sort_u32_pairs(sort_temp, sort_temp_bytes, keys, keys2, vals, vals2, n, cc.idx_shift - 3, s);
+    } else err = sort_u32_pairs(sort_temp, sort_temp_bytes, keys, keys2, vals, vals2, n, cc.idx_shift - 3, s, own_sort);
     if (err != hipSuccess) return err;
     if (ev_sorted) (void) hipEventRecord(ev_sorted, s);
     // (measured and rejected: zero-filling the directory as a side job of the VALU-bound k_node_runs -- that kernel got slower by what
@@ -1319,10 +1379,10 @@ hipError_t launch_cluster_gather(const NodesDev &nd, const ClusterCfg &cc, int e
 // (record b - bucket_base), ordered like the full build's (bucket, then m_C >> 3).
 hipError_t launch_cluster_store_slice(const NodesDev &nd, const ClusterCfg &cc, int eq, uint64_t m, uint32_t bucket_base, uint32_t n_buckets_local, uint32_t *keys,
                                       uint32_t *vals, uint32_t *keys2, uint32_t *vals2, const uint32_t *meta, int uniform_len, void *sort_temp, size_t sort_temp_bytes,
-                                      void *store, void *dir, unsigned long long *bad_flag, hipStream_t s) {
+                                      void *store, void *dir, unsigned long long *bad_flag, hipStream_t s, bool own_sort) {
     hipError_t err = hipMemsetAsync(dir, 0, ((size_t) n_buckets_local + 2) * 16, s);
     if (err != hipSuccess || m == 0) return err;
-    err = sort_u32_pairs(sort_temp, sort_temp_bytes, keys, keys2, vals, vals2, m, cc.idx_shift - 3, s);
+    err = sort_u32_pairs(sort_temp, sort_temp_bytes, keys, keys2, vals, vals2, m, cc.idx_shift - 3, s, own_sort);
     if (err != hipSuccess) return err;
     const uint64_t n = m, pieces = m * (uint64_t) eq;
     const unsigned g = (unsigned) ((pieces + 255) / 256);

@@ -44,11 +44,13 @@ bool       cluster_plan(const PrefSufCfg &cfg, int max_len, uint64_t live, int b
 size_t     cluster_sort_temp_bytes(uint64_t n);
 // keys/vals/keys2/vals2/meta: n uint32 each; runs: n * CL_RMAX * 8 bytes; nruns: n bytes; store: (n + 2) * 16 * eq bytes; dir: (n_buckets + 2) * 16 bytes
 void       launch_cluster_keys(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterCfg &cc, int32_t node_begin, int32_t node_end, uint32_t *keys,
-                               uint32_t *vals, uint32_t *meta, void *runs, uint8_t *nruns, hipStream_t s);
+                               uint32_t *vals, uint32_t *meta, void *runs, uint8_t *nruns, hipStream_t s, bool with_runs = true /* false: keys and meta words alone */);
+void       launch_cluster_runs_list(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterCfg &cc, const int32_t *ids, const unsigned long long *count, uint32_t cap,
+                                    uint32_t grid_blocks, void *runs, uint8_t *nruns, hipStream_t s);      // run lists of the listed nodes (list length read on the device)
 hipError_t launch_cluster_store(const NodesDev &nd, const ClusterCfg &cc, uint32_t *keys, uint32_t *vals, uint32_t *keys2 /* out: sorted */, uint32_t *vals2, void *sort_temp,
                                 size_t sort_temp_bytes, void *dir, bool fill_vals, hipEvent_t ev_sorted /* may be null */,
                                 unsigned long long *bad_flag /* device: set when the sorted keys are not in order */,
-                                bool test_skip_sort /* tests: build the index over UNSORTED keys */, hipStream_t s);      // sort + directory
+                                bool test_skip_sort /* tests: build the index over UNSORTED keys */, hipStream_t s, bool own_sort = true);      // sort + directory
 hipError_t launch_cluster_gather(const NodesDev &nd, const ClusterCfg &cc, int eq, const uint32_t *keys2, const uint32_t *vals2, const uint32_t *meta,
                                  int uniform_len /* > 0: all live nodes have this length, no alignFrom mask */, void *store,
                                  const unsigned long long *pile_cnt /* null, or the pile path's sample counters: no entry array for a build it keeps */, hipStream_t s);
@@ -79,9 +81,14 @@ void       launch_pile_probe(const NodesDev &nd, const PrefSufCfg &cfg, const Cl
                              const void *runs, unsigned long long *counters, uint32_t *deg, unsigned long long *first, unsigned long long *second, int32_t *defer_list,
                              uint32_t defer_cap, const unsigned long long *pile_cnt, int n_cu, hipStream_t s);
 
+// radix_sort.hip: the engine's own stable LSD radix sort of (u32 key, u32 value) pairs on the key bits [begin_bit, 32)
+size_t     rsort_u32_pairs_temp_bytes(uint64_t n);
+void       rsort_set_variant(int v);                       // tuning only
+hipError_t rsort_u32_pairs(void *temp, size_t temp_bytes, const uint32_t *keys_in, uint32_t *keys_out, const uint32_t *vals_in, uint32_t *vals_out, uint64_t n,
+                           int begin_bit, hipStream_t s);
 size_t     sort_u32_pairs_temp_bytes(uint64_t n);
 hipError_t sort_u32_pairs(void *temp, size_t temp_bytes, const uint32_t *keys_in, uint32_t *keys_out, const uint32_t *vals_in, uint32_t *vals_out,
-                          uint64_t n, int begin_bit /* the bits below it are not looked at */, hipStream_t s);
+                          uint64_t n, int begin_bit /* the bits below it are not looked at */, hipStream_t s, bool own_sort = true /* radix_sort.hip; false: rocPRIM */);
 size_t     sort_u64_pairs_temp_bytes(uint64_t n, int bits);
 hipError_t sort_u64_pairs(void *temp, size_t temp_bytes, const unsigned long long *keys_in, unsigned long long *keys_out,
                           const unsigned long long *vals_in, unsigned long long *vals_out, uint64_t n, int bits, hipStream_t s);

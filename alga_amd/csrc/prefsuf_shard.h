@@ -13,7 +13,7 @@ inline uint32_t shard_buckets_per_rank(uint32_t n_buckets, int n_ranks) { return
 void launch_shard_select(const uint32_t *keys, uint32_t n, int shift, uint32_t b_lo, uint32_t b_hi, uint32_t *okeys, uint32_t *ovals, unsigned long long *cursor, hipStream_t s);
 hipError_t launch_cluster_store_slice(const NodesDev &nd, const ClusterCfg &cc, int eq, uint64_t m, uint32_t bucket_base, uint32_t n_buckets_local, uint32_t *keys,
                                       uint32_t *vals, uint32_t *keys2, uint32_t *vals2, const uint32_t *meta, int uniform_len, void *sort_temp, size_t sort_temp_bytes,
-                                      void *store, void *dir, unsigned long long *bad_flag, hipStream_t s);
+                                      void *store, void *dir, unsigned long long *bad_flag, hipStream_t s, bool own_sort = true);
 void launch_shard_export(bool count, const void *runs, int32_t node_begin, int32_t node_end, int shift, uint32_t bpr, uint32_t n_ranks, unsigned long long *counts,
                          int32_t *flagged_list, unsigned long long *flagged_count, uint32_t flagged_cap, const unsigned long long *seg_off, unsigned long long *cursor,
                          uint32_t *out, hipStream_t s);

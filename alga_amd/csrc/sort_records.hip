@@ -5,6 +5,7 @@
 // the same records with streaming passes instead.  The sort itself is the vendor primitive
 // (rocPRIM, header-only, part of ROCm) -- a plain library sort, like a plain library GEMM; the
 // kernels that carry the algorithm of the reference are in prefsuf_kernels.hip.
+#include <algorithm>
 #include <cstring>
 #include <hip/hip_runtime.h>
 #include <rocprim/rocprim.hpp>
@@ -74,13 +75,16 @@ size_t sort_u32_pairs_temp_bytes(uint64_t n) {
                                      (uint32_t *) nullptr, (size_t) n, 0u, 32u, (hipStream_t) 0);
     (void) rocprim::radix_sort_pairs<Sort10>(nullptr, b, (const uint32_t *) nullptr, (uint32_t *) nullptr, (const uint32_t *) nullptr,
                                              (uint32_t *) nullptr, (size_t) n, 2u, 32u, (hipStream_t) 0);
-    return a > b ? a : b;
+    const size_t own = rsort_u32_pairs_temp_bytes(n);
+    return std::max(own, a > b ? a : b);
 }
 
 hipError_t sort_u32_pairs(void *temp, size_t temp_bytes, const uint32_t *keys_in, uint32_t *keys_out, const uint32_t *vals_in, uint32_t *vals_out,
-                          uint64_t n, int begin_bit, hipStream_t s) {
+                          uint64_t n, int begin_bit, hipStream_t s, bool own_sort) {
     if (n == 0) return hipSuccess;
     if (begin_bit < 0 || begin_bit > 31) return hipErrorInvalidValue;
+    // round 5: the engine's own radix sort (radix_sort.hip) unless the caller asks for the library's (engine option "own_sort" = 0: A/B and tests)
+    if (own_sort) return rsort_u32_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, n, begin_bit, s);
     // Below rocPRIM's merge-sort limit (2^20 pairs by default) a sort on the bits [b, 32) of a 32-bit key goes through
     // radix_merge_compare, whose mask is built as (T(1) << 32) - 1 -- undefined, in practice 0: the comparison then looks at the bits
     // BELOW b only (rocPRIM 4.2.0, device/detail/device_radix_sort.hpp:685).  Small inputs are sorted on all 32 bits; the skipped

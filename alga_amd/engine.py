@@ -148,7 +148,7 @@ EXPORTS = ["alga_abi_version", "alga_engine_set_option", "alga_engine_create", "
            "alga_multi_create", "alga_multi_destroy", "alga_multi_last_error", "alga_multi_engine", "alga_multi_prefsuf_build_host", "alga_multi_prefsuf_build_device",
            "alga_multi_free_edges", "alga_multi_last_stats", "alga_multi_set_option", "alga_upload_twin_nodes",
            "alga_shard_index_device", "alga_shard_join_device", "alga_shard_small_keys_device", "alga_shard_resolve_device", "alga_shard_place_device",
-           "alga_shard_last_stats"]
+           "alga_shard_last_stats", "alga_sort_u32_pairs_device"]
 
 
 def library_path():
@@ -222,6 +222,8 @@ def load_library():
     lib.alga_sort_records_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p,
                                              C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
     lib.alga_sort_edges_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]
+    lib.alga_sort_u32_pairs_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
+                                               C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_double)]
     lib.alga_pkb_derive_params.argtypes = [C.c_double, C.c_float, C.c_double, C.c_int32, C.POINTER(PkbParams)]
     lib.alga_pkb_derive_params.restype = None
     lib.alga_can_align_batch_host.argtypes = [C.c_void_p, C.POINTER(_Nodes), C.POINTER(PkbParams), C.c_void_p, C.c_uint64, C.c_void_p]
@@ -602,6 +604,15 @@ class Engine:
         self._check(self._lib.alga_sort_records_device(self._h, ptr(rec_dst), ptr(rec_val), int(n_records), int(n_nodes),
                                                        C.c_void_p(stream or 0), C.byref(d), C.byref(v), C.byref(m)))
         return d.value, v.value, int(m.value)
+
+    def sort_u32_pairs_device(self, keys, vals, begin_bit=0, own=True, repeat=1, stream=None):
+        """alga_sort_u32_pairs_device: (key, value) int32 / uint32 tensors on this device, stable on the key bits [begin_bit, 32) ->
+        (keys ptr, vals ptr, best ms).  own: the engine's radix sort (radix_sort.hip), else rocPRIM's."""
+        n = int(keys.shape[0])
+        ko, vo, ms = C.c_void_p(), C.c_void_p(), C.c_double()
+        self._check(self._lib.alga_sort_u32_pairs_device(self._h, keys.data_ptr() if n else None, vals.data_ptr() if n else None, n, int(begin_bit), int(bool(own)),
+                                                         int(repeat), C.c_void_p(stream or 0), C.byref(ko), C.byref(vo), C.byref(ms)))
+        return ko.value, vo.value, ms.value
 
     def sort_edges_device(self, edges, n_edges, n_nodes, stream=None):
         """edges: device pointer or int32 tensor [n_edges, 3] -> device pointer of the list ordered by (src, dst)."""

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ALGA_AMD_ABI_VERSION 6
+#define ALGA_AMD_ABI_VERSION 7
 
 typedef enum {
     ALGA_OK = 0,
@@ -164,6 +164,8 @@ int         alga_engine_device_name(const alga_engine *e, char *buf, size_t bufl
  *   "auto_reduction_per_target"  != 0: alga_prefsuf_params.reduction == AUTO resolves to PER_TARGET
  *   "shard_bucket_max"           1..4096 (default 4096): run descriptors of ONE bucket the bucket-sharded join (alga_shard_join_device) takes; a
  *                                bucket with more makes the call answer ALGA_ERR_UNSUPPORTED (tests lower it to exercise that)
+ *   "own_sort"                   default 1: the (key, id) sort of the index build is the engine's own radix sort (alga_amd/csrc/radix_sort.hip: stable LSD,
+ *                                wave-match ranking, XCD-contiguous tiles); 0: rocPRIM's onesweep sort (what rounds 2-4 used; kept for A/B and tests)
  *   "test_pile_oom"              tests only.  != 0: the allocation of the pile path's own buffers (~180 B per node) answers ALGA_ERR_OUT_OF_MEMORY: the build
  *                                must give them back and finish on the pairwise kernels (what a real out-of-memory there does)
  *   "test_unsorted_index"        tests only.  != 0: the CLUSTER probe's entry directory is built over UNSORTED keys; the directory pass
@@ -371,6 +373,12 @@ int         alga_multi_last_stats(const alga_multi *m, alga_multi_stats *out, al
 int  alga_sort_records_device(alga_engine *e, const uint32_t *d_dst, const uint64_t *d_val, uint64_t n_records,
                               int32_t n_nodes, void *hip_stream, const uint32_t **d_dst_sorted,
                               const uint64_t **d_val_sorted, uint64_t *n_valid);
+/* The (u32 key, u32 value) sort of the index build on its own (tests and tools): stable on the key bits [begin_bit, 32).  own != 0: the
+ * engine's radix sort (alga_amd/csrc/radix_sort.hip), 0: rocPRIM's.  For n < 2^22 the library path sorts on all 32 bits (its merge-sort path
+ * compares the wrong bits for a partial key); the engine's own sort looks at [begin_bit, 32) whatever n is.  The sorted arrays are engine-owned
+ * (valid until the next call on e); *ms_best = the fastest of `repeat` runs by HIP events. */
+int  alga_sort_u32_pairs_device(alga_engine *e, const uint32_t *d_keys, const uint32_t *d_vals, uint64_t n, int32_t begin_bit, int32_t own, int32_t repeat,
+                                void *hip_stream, const uint32_t **d_keys_sorted, const uint32_t **d_vals_sorted, double *ms_best);
 int  alga_sort_edges_device(alga_engine *e, const alga_edge *d_edges, uint64_t n_edges, int32_t n_nodes,
                             void *hip_stream, const alga_edge **d_sorted);
 

@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared_symbols():
     hdr = open(os.path.join(ROOT, "include", "alga_amd.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    return sorted(set(re.findall(r"\b(alga_[a-z_]+)\s*\(", hdr)))
+    return sorted(set(re.findall(r"\b(alga_[a-z0-9_]+)\s*\(", hdr)))
 
 
 def test_library_exports_every_declared_symbol():
@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), "libalga_amd.so does not export %s" % s
     assert set(syms) == set(alga_amd.engine.EXPORTS)
-    assert lib.alga_abi_version() == 6
+    assert lib.alga_abi_version() == 7
     hdr = open(os.path.join(ROOT, "include", "alga_amd.h")).read()
     assert int(re.search(r"#define\s+ALGA_PILE_IRREGULAR_ONE_IN\s+(\d+)", hdr).group(1)) == alga_amd.engine.PILE_IRREGULAR_ONE_IN
 
