@@ -133,7 +133,9 @@ int pile_alloc(alga_engine *e, uint64_t n, uint32_t n_buckets, hipStream_t s) {
     int rc;
     if ((rc = alga_ensure(e, e->cl_pile_rec, pile_record_bytes(n)))) return rc;
     if ((rc = alga_ensure(e, e->cl_pile_succ, ((size_t) n + 64) * 16))) return rc;
-    if ((rc = alga_ensure(e, e->cl_pile_cnt, 3 * sizeof(unsigned long long)))) return rc;
+    if ((rc = alga_ensure(e, e->cl_pile_cnt, PILE_CNT_WORDS * sizeof(unsigned long long)))) return rc;
+    if ((rc = alga_ensure(e, e->cl_pile_own, pile_own_mask_bytes(n)))) return rc;
+    if ((rc = alga_ensure(e, e->cl_defer, (size_t) (n + 64) * sizeof(int32_t)))) return rc;      // (the list of own-list ids first, the probe's defer list later)
     const void *before = e->cl_pile_tab.p;
     const size_t cap_before = e->cl_pile_tab.cap;
     if ((rc = alga_ensure(e, e->cl_pile_tab, pile_table_bytes(n_buckets)))) return rc;
@@ -164,6 +166,7 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
     bool pile = clustered && e->opt_pile != 0 && e->opt_cluster_pairs != 0 && e->opt_cluster_order != 0 && pp.local_sw == 1 && pp.keys_shared == 0 &&
                       src_begin == 0 && src_end == pp.nd.n && pile_plan(cfg, pp.cluster, pp.cluster_eq, pp.uniform_len, pp.nd.from != nullptr || pp.nd.to != nullptr);
     e->loc_second_used = false;
+    bool keys_only = false;                                // the key pass made no run lists (see there)
     uint32_t n_buckets = 0, filter_bits = 0;
     bool have_table = false;
     auto build_table = [&]() -> int {                      // bucketised seed table + prefilter of prefsuf_kernels.hip
@@ -203,8 +206,13 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
                     return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "keys_shared: alga_prefsuf_keys_device has not been called on this node set for a range that covers the sources");
                 run_begin = e->keyed_begin; run_end = e->keyed_end;
             } else {
+                // A build the pile path keeps takes its run lists from the piles' consensus (k_pile_runs_consensus): the key pass then computes the
+                // TARGET keys alone, and own lists only where one is read (entries outside a first group, sources handed to the general
+                // kernel).  Whether the path keeps the build is decided on the device, after the sort: where the build before this one was declined
+                // (reads with errors) the full pass runs up front as before; else it follows behind the sample, for a declined build only.
+                keys_only = pile && e->opt_pile_runs != 0 && !e->expect_pairwise && !e->opt_pile_check;
                 launch_cluster_keys(nd, cfg, cc, 0, nd.n, (uint32_t *) e->cl_keys[0].p, (uint32_t *) e->cl_vals[0].p, (uint32_t *) e->cl_meta.p, e->cl_runs.p,
-                                    (uint8_t *) e->cl_nruns.p, s);
+                                    (uint8_t *) e->cl_nruns.p, s, !keys_only);
                 if ((rc = alga_check_launch(e, "k_node_runs"))) return rc;
             }
             HIP_TRY(e, hipEventRecord(e->ev[EV_KEYS], s));
@@ -223,11 +231,17 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
                     // the pile path needs ~180 B per node on top of the pairwise kernels' buffers (bucket table, group records, side records): an input
                     // that fitted without it must not fail because of it.  Give back what was allocated of it and take the pairwise kernels.
                     (void) hipGetLastError();
-                    alga_release(e->cl_pile_tab); alga_release(e->cl_pile_rec); alga_release(e->cl_pile_succ);
+                    alga_release(e->cl_pile_tab); alga_release(e->cl_pile_rec); alga_release(e->cl_pile_succ); alga_release(e->cl_pile_own);
                     e->pile_epoch = 0; e->pile_n = -1;
                     e->err.clear();
                     pile = false;
                     rc = ALGA_OK;
+                    if (keys_only) {                       // the pairwise kernels read every node's run list
+                        launch_cluster_keys(nd, cfg, cc, 0, nd.n, (uint32_t *) e->cl_keys[0].p, (uint32_t *) e->cl_vals[0].p, (uint32_t *) e->cl_meta.p, e->cl_runs.p,
+                                            (uint8_t *) e->cl_nruns.p, s, true);
+                        if ((rc = alga_check_launch(e, "k_node_runs"))) return rc;
+                        keys_only = false;
+                    }
                 } else if (rc) return rc;
             }
             if (pile) {
@@ -244,9 +258,25 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
                     e->pile_epoch = 0;
                 }
                 e->pile_epoch++;
-                launch_pile_build(nd, cc, pp.uniform_len, (const uint32_t *) e->cl_keys[1].p, (const uint32_t *) e->cl_vals[1].p, e->cl_dir.p, e->cl_pile_rec.p, e->cl_pile_tab.p,
-                                  e->pile_epoch, e->cl_pile_succ.p, e->cl_runs.p, pp.uniform_len - cfg.Lmin + 1, (const unsigned long long *) e->cl_pile_cnt.p, s);
+                const bool from_consensus = e->opt_pile_runs != 0;
+                launch_pile_build(nd, cfg, cc, pp.uniform_len, (const uint32_t *) e->cl_keys[1].p, (const uint32_t *) e->cl_vals[1].p, e->cl_dir.p, e->cl_pile_rec.p, e->cl_pile_tab.p,
+                                  e->pile_epoch, e->cl_pile_succ.p, e->cl_runs.p, pp.uniform_len - cfg.Lmin + 1, (const unsigned long long *) e->cl_pile_cnt.p,
+                                  from_consensus ? (uint32_t *) e->cl_pile_own.p : nullptr, s);
                 if ((rc = alga_check_launch(e, "k_pile_build"))) return rc;
+                if (keys_only) {
+                    // own run lists of the entries outside a first group (6 % at the north-star size) ...
+                    launch_pile_own_ids((const uint32_t *) e->cl_pile_own.p, (const uint32_t *) e->cl_vals[1].p, (uint64_t) nd.n, (int32_t *) e->cl_defer.p, (uint32_t) nd.n,
+                                        (unsigned long long *) e->cl_pile_cnt.p, s);
+                    launch_cluster_runs_list(nd, cfg, cc, (const int32_t *) e->cl_defer.p, (const unsigned long long *) e->cl_pile_cnt.p + 3, (uint32_t) nd.n, (uint32_t) e->n_cu * 16u,
+                                             e->cl_runs.p, (uint8_t *) e->cl_nruns.p, s);
+                    // ... and every node's, after all, for a build the sample hands to the pairwise kernels
+                    launch_cluster_keys(nd, cfg, cc, 0, nd.n, (uint32_t *) e->cl_keys[0].p, (uint32_t *) e->cl_vals[0].p, (uint32_t *) e->cl_meta.p, e->cl_runs.p,
+                                        (uint8_t *) e->cl_nruns.p, s, true, (const unsigned long long *) e->cl_pile_cnt.p);
+                    if ((rc = alga_check_launch(e, "k_node_runs (own lists)"))) return rc;
+                }
+                if (e->opt_pile_check && from_consensus)
+                    launch_pile_check(e->cl_pile_succ.p, (uint64_t) nd.n, cc.n_buckets, e->cl_pile_tab.p, e->pile_epoch, e->cl_runs.p, nd.n, pp.uniform_len - cfg.Lmin + 1,
+                                      (unsigned long long *) e->cl_pile_cnt.p, s);
                 e->pile_n = nd.n; e->pile_words = (const void *) nd.words;
                 e->pile_timed = nd.n > 0;
             }
@@ -298,6 +328,11 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
                                       e->cl_runs.p, cnt, (uint32_t *) e->outdeg.p, (unsigned long long *) e->loc_first.p, (unsigned long long *) e->loc_second.p,
                                       (int32_t *) e->cl_defer.p, (uint32_t) n_src, (const unsigned long long *) e->cl_pile_cnt.p, e->n_cu, s);
                     if ((rc = alga_check_launch(e, "k_pile_probe"))) return rc;
+                    // the sources it handed on have no run list of their own yet (the general kernel reads it): a list-driven key pass over the
+                    // defer list, whose length the device knows
+                    if (keys_only)
+                        launch_cluster_runs_list(nd, cfg, cc, (const int32_t *) e->cl_defer.p, cnt + CNT_DEFERRED, (uint32_t) std::min<uint64_t>(n_src + 64, 0xFFFFFFFFull),
+                                                 (uint32_t) e->n_cu * 16u, e->cl_runs.p, (uint8_t *) e->cl_nruns.p, s);
                 }
                 launch_probe_stream(nd, cfg, cc, pp.cluster_eq, e->cl_store.p, e->cl_dir.p, e->cl_runs.p, (const uint8_t *) e->cl_nruns.p,
                                     src_begin, src_end, by_key, cnt, e->n_cu, (uint32_t *) e->outdeg.p, (unsigned long long *) e->loc_first.p,
@@ -367,12 +402,22 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
             e->stats.slots_scanned = e->h_counters[CNT_SLOTS];
             e->stats.probe_rounds = e->h_counters[CNT_ROUNDS];
             e->stats.pile_buckets = e->h_counters[CNT_PILE_BUCKETS]; e->stats.pile_irregular = e->h_counters[CNT_PILE_IRREGULAR];
+            e->stats.pile_own_lists = e->h_counters[CNT_PILE_OWN];
             if (pile && pp.keys_shared != 2 && e->pile_n == nd.n) {
                 // the sample's verdict is on the host now: a build the pile path DECLINED (or one with pile_skip_gather off) did build the entry
                 // array, and a later keys_shared = 2 build of this node set may use it
                 const bool kept = e->opt_pile == 2 || e->stats.pile_irregular * (uint64_t) ALGA_PILE_IRREGULAR_ONE_IN <= e->stats.pile_buckets;
                 if (!kept || !e->opt_pile_skip_gather) e->store_n = nd.n;
+                e->expect_pairwise = !kept;               // (how the NEXT build's key pass is laid out -- never what it computes)
+                e->stats.pile_list_checked = 0; e->stats.pile_list_mismatch = 0;
+                if (e->opt_pile_check) {
+                    unsigned long long chk[2] = {0ull, 0ull};
+                    HIP_TRY(e, hipMemcpyAsync(chk, (const unsigned long long *) e->cl_pile_cnt.p + 4, sizeof(chk), hipMemcpyDeviceToHost, s));
+                    HIP_TRY(e, hipStreamSynchronize(s));
+                    e->stats.pile_list_checked = chk[0]; e->stats.pile_list_mismatch = chk[1];
+                }
             }
+            if (!pile) e->expect_pairwise = false;
             e->stats.probe_used = clustered ? ALGA_PROBE_CLUSTER : ALGA_PROBE_TABLE;
             if (clustered) e->stats.deferred_sources = e->defer_list_valid ? e->h_counters[CNT_DEFERRED] : n_src;
             return ALGA_OK;
@@ -607,6 +652,10 @@ int alga_engine_set_option(alga_engine *e, const char *name, int64_t value) {
         e->opt_cluster_pairs = value != 0;
     } else if (!strcmp(name, "pile")) {
         e->opt_pile = value == 2 ? 2 : (value != 0);       // (2, tests only: no sample -- the pile kernels take every build they can, however many buckets are irregular)
+    } else if (!strcmp(name, "pile_runs")) {
+        e->opt_pile_runs = value != 0;
+    } else if (!strcmp(name, "pile_check")) {
+        e->opt_pile_check = value != 0;
     } else if (!strcmp(name, "pile_skip_gather")) {
         e->opt_pile_skip_gather = value != 0;
     } else if (!strcmp(name, "cluster_order")) {

@@ -56,6 +56,10 @@ struct alga_engine {
     bool   store_timed = false;                             // EV_KEYS / EV_SORT / EV_GATHER were recorded in the last discovery
     int    opt_pile_skip_gather = 1;                        // option "pile_skip_gather": no entry array for a build the pile path keeps
     int    opt_pile = 1;                                    // option "pile": the probe through piles (prefsuf_pile.hip) where the input allows it
+    int    opt_pile_runs = 1;                               // option "pile_runs": 1 = a pile's run list from its consensus (k_pile_runs_consensus; the key pass of a kept build makes target keys only), 0 = from its outer members' own lists (round 4)
+    int    opt_pile_check = 0;                              // option "pile_check" (tests): every node gets its own run list and every first-group member's is compared with its pile's clipped list (stats.pile_list_*)
+    bool   expect_pairwise = false;                         // the pile path declined the build before this one: the next key pass makes every run list up front
+    DevBuf cl_pile_own;                                     // bit j: entry j of the key order reads a run list of its own
     int    opt_own_sort = 1;                                // option "own_sort": the (key, id) sort of the index build is the engine's own radix sort (radix_sort.hip); 0: rocPRIM's
     int    opt_test_pile_oom = 0;                           // tests only: the pile path's allocation reports out of memory (the build must continue on the pairwise kernels)
     bool   pile_timed = false;                              // EV_DIR was recorded in the last discovery (k_pile_build ran behind it)

@@ -35,8 +35,7 @@ namespace alga {
 // ------------------------------------------------------------------------------------------
 // build: minimizer runs of every node, keys, gather, index
 // ------------------------------------------------------------------------------------------
-constexpr int TK_ROWS = 128;         // nodes per workgroup of k_node_runs
-constexpr int NR_STACK = 8;          // minimum records kept per node and block (a random block has ~2.7; more: the node is flagged)
+// (TK_ROWS, NR_STACK and node_runs_core: prefsuf_cluster_device.h -- shared with prefsuf_pile.hip)
 
 // One THREAD per node: the distinct minimizers of the suffix windows p = 0 .. len - Lmin of the node, as runs
 // {cluster key, k-mer position q, windows [p0, p1)}; the minimizer of window 0 (the node's min_overlap-long prefix) is the key the
@@ -60,116 +59,14 @@ constexpr int NR_STACK = 8;          // minimum records kept per node and block 
 // reduction).  The window minimum by two blocks needs nwin <= w <= 64, so the windows are taken in two halves of up to 64 -- [64, nwin) on
 // the k-mers from position 64 on, then [0, 64) -- each by the very same three steps on the row shifted by 64 nucleotides (four words), and
 // the runs of both halves are listed one after the other (a minimizer that spans the seam makes two runs: one more look-up, same overlaps).
-// The window minimizers of ONE row (thread t of the workgroup; the row staged in LDS, `act`: the row takes part): steps (1) - (3) above.
-// Leaves the runs in rbuf[0 .. min(nr, CL_RMAX))[t] as q | p0 << 8 (p1 = p0 of the run before; the last windows first), the minimum of
-// block 0 of the first half (the row's minimizer as a TARGET) in cur0.  Shared by k_node_runs (a node's row) and k_pile_runs_consensus
-// (prefsuf_pile.hip: the consensus of a pile on the pile's extent -- the windows of all its members at once).
-template <bool WIDE>
-__device__ __forceinline__ void node_runs_core(const uint32_t *row, int nwin, bool act, const ClusterCfg &cc, uint32_t (*stk)[TK_ROWS], uint16_t (*rbuf)[TK_ROWS], int t,
-                                               int &nr, bool &uncovered, bool &stack_ovf, uint32_t &cur0) {
-    constexpr int S0 = NR_STACK + 1;                       // first row of block 0's records
-    const int w = cc.w;
-    nr = 0; uncovered = false; stack_ovf = false; cur0 = 0xFFFFFFFFu;
-    for (int hb = (WIDE && nwin > 64) ? 64 : 0; hb >= 0; hb -= 64) {       // first window of the half (one pass with hb = 0 unless WIDE)
-        const uint32_t *rowh = row + (hb >> 4);
-        const int nwh = !WIDE ? nwin : (hb ? nwin - 64 : (nwin < 64 ? nwin : 64));
-        const int nk = act ? nwh - 1 + w : 0;              // k-mer positions of the half (relative to hb): <= 127
-        // ---- class-0 k-mer positions: bit p of the 128-bit mask (static row indices: registers, no scratch) ----
-        uint64_t m_lo, m_hi;
-        {
-            uint32_t dm[4];
-#pragma unroll
-            for (int d = 0; d < 4; d++) {
-                const uint32_t x0 = rowh[2 * d], x1 = rowh[2 * d + 1], x2 = rowh[2 * d + 2];
-                dm[d] = compress_even(class0_mask16(x0, x1)) | (compress_even(class0_mask16(x1, x2)) << 16);
-            }
-            m_lo = (uint64_t) dm[0] | ((uint64_t) dm[1] << 32);
-            m_hi = (uint64_t) dm[2] | ((uint64_t) dm[3] << 32);
-            m_lo &= nk >= 64 ? ~0ull : (nk <= 0 ? 0ull : ((1ull << nk) - 1ull));       // positions below nk only (0 for a node that takes no part)
-            m_hi &= nk <= 64 ? 0ull : ((1ull << (nk - 64)) - 1ull);
-        }
-        uint64_t b0 = w >= 64 ? m_lo : (m_lo & ((1ull << w) - 1ull));
-        uint64_t b1 = w >= 64 ? m_hi : ((m_lo >> w) | (m_hi << (64 - w)));    // uniform branch; bit e = k-mer w + e
-        auto key_at = [&](int pos) -> uint32_t {           // order key of the class-0 k-mer at `pos` (relative to the half)
-            const int bit = 2 * pos, q = bit >> 5, r = bit & 31;
-            const uint32_t x0 = rowh[q], x1 = rowh[q + 1], x2 = rowh[q + 2];
-            return order_key0(kmer_hash(funnel(x0, x1, r) & cc.lo_mask, funnel(x1, x2, r) & cc.hi_mask), pos);
-        };
-        // ---- (1) block 1, left to right: prefix-minimum records ----
-        uint32_t cur1 = 0xFFFFFFFFu;
-        int sp1 = 0;
-        while (b1 != 0ull) {
-            const int e = __builtin_ctzll(b1);
-            b1 &= b1 - 1ull;
-            const uint32_t pk = key_at(w + e);
-            // no branch: a lane that does not push writes the spare row
-            const bool push = pk < cur1;
-            stk[(push && sp1 < NR_STACK) ? sp1 : NR_STACK][t] = pk;
-            cur1 = push ? pk : cur1;
-            sp1 += push ? 1 : 0;
-        }
-        // ---- (2) block 0, right to left: suffix-minimum records ----
-        uint32_t cur0h = 0xFFFFFFFFu;
-        int sp0 = 0;
-        while (b0 != 0ull) {
-            const int e = 63 - __builtin_clzll(b0);
-            b0 ^= 1ull << e;
-            const uint32_t pk = key_at(e);
-            const bool push = pk < cur0h;
-            stk[S0 + ((push && sp0 < NR_STACK) ? sp0 : NR_STACK)][t] = pk;
-            cur0h = push ? pk : cur0h;
-            sp0 += push ? 1 : 0;
-        }
-        if (hb == 0) cur0 = cur0h;
-        stack_ovf = stack_ovf || sp1 > NR_STACK || sp0 > NR_STACK;
-        sp1 = sp1 > NR_STACK ? NR_STACK : sp1;
-        sp0 = sp0 > NR_STACK ? NR_STACK : sp0;
-        // ---- (3) the windows of the half, last to first: merge of the two record lists ----
-        {
-            const uint32_t hq = (uint32_t) hb | ((uint32_t) hb << 8);     // what makes q and p0 of a run absolute
-            uint32_t top = sp1 > 0 ? stk[sp1 - 1][t] : 0xFFFFFFFFu;       // smallest record of block 1: in every window until it drops out
-            uint32_t nxt0 = stk[S0][t];                                   // next record of block 0 (if i0 < sp0)
-            uint32_t c0 = 0xFFFFFFFFu, win = top;
-            int i0 = 0, p_hi = nwh - 1;
-            int e0 = sp0 > 0 ? (int) (nxt0 & 255u) : -1;                  // the next block-0 record joins the windows p <= e0
-            int e1 = sp1 > 0 ? (int) (top & 255u) - w : -1;               // block 1's smallest record is in no window p <= e1
-            while ((e0 > e1 ? e0 : e1) >= 0) {
-                const int pe = e0 > e1 ? e0 : e1;
-                const bool take0 = e0 >= e1;
-                // ONE stack read serves either move: the record after the block-0 record that joins, or the one below block 1's top
-                const int row_i = take0 ? S0 + i0 + 1 : (sp1 >= 2 ? sp1 - 2 : NR_STACK);
-                const uint32_t v = stk[row_i][t];
-                i0 += take0 ? 1 : 0;
-                sp1 -= take0 ? 0 : 1;
-                c0 = take0 ? nxt0 : c0;
-                nxt0 = take0 ? v : nxt0;
-                top = take0 ? top : (sp1 >= 1 ? v : 0xFFFFFFFFu);
-                e0 = take0 ? (i0 < sp0 ? (int) (v & 255u) : -1) : e0;
-                e1 = take0 ? e1 : (sp1 >= 1 ? (int) (v & 255u) - w : -1);
-                const uint32_t wn = c0 < top ? c0 : top;
-                const int pc = pe < p_hi ? pe : p_hi;
-                const bool em = wn != win && pc < p_hi;         // the windows (pc, p_hi] had `win`
-                rbuf[(em && nr < CL_RMAX) ? nr : CL_RMAX][t] = (uint16_t) (((win & 255u) | ((uint32_t) (pc + 1) << 8)) + hq);
-                uncovered = uncovered || (em && win == 0xFFFFFFFFu);
-                nr += em ? 1 : 0;
-                p_hi = em ? pc : p_hi;
-                win = wn;
-            }
-            if (act) {                                         // the run of the half's first window
-                if (nr < CL_RMAX) rbuf[nr][t] = (uint16_t) ((win & 255u) + hq);
-                uncovered = uncovered || win == 0xFFFFFFFFu;
-                nr++;
-            }
-        }
-    }
-}
-
 // TARGETS ONLY (what_runs = false below): the key pass of a build whose sources get their run lists elsewhere (the pile path: a pile's run
 // list comes from its consensus, prefsuf_pile.hip) needs the minimum of block 0 alone -- no stacks, no window sweep.
 template <int TKW, bool WIDE, bool RUNS>
 __global__ void __launch_bounds__(TK_ROWS) k_node_runs(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, int node_begin, int node_end,
                                                         uint32_t *__restrict__ keys, uint32_t *__restrict__ vals, uint32_t *__restrict__ meta,
-                                                        uint2 *__restrict__ runs, uint8_t *__restrict__ nruns, const int32_t *__restrict__ id_list, const unsigned long long *__restrict__ id_count) {
+                                                        uint2 *__restrict__ runs, uint8_t *__restrict__ nruns, const int32_t *__restrict__ id_list, const unsigned long long *__restrict__ id_count,
+                                                        const unsigned long long *__restrict__ only_if_declined /* null, or the pile path's sample: the kernel leaves for a build that path keeps */) {
+    if (only_if_declined && only_if_declined[1] * PILE_IRREGULAR_ONE_IN <= only_if_declined[0]) return;
     __shared__ uint32_t s[TK_ROWS][TKW];
     // records, transposed (conflict-free): rows 0 .. NR_STACK - 1 block 1, NR_STACK the spare row that takes the stores of lanes
     // that do not push, NR_STACK + 1 .. 2 NR_STACK block 0, 2 NR_STACK + 1 its spare row
@@ -179,12 +76,13 @@ __global__ void __launch_bounds__(TK_ROWS) k_node_runs(NodesDev nd, PrefSufCfg c
     // lists and nothing else; the list's length is read from the device)
     const int list_n = id_list ? (int) min((unsigned long long) (node_end - node_begin), *id_count) : 0;
     __shared__ int sid[TK_ROWS];
-    // (a list is walked with the grid's stride -- its length is only known on the device, the grid is sized for the chip, not for the cap)
-    for (int blk = (int) blockIdx.x; id_list ? blk * TK_ROWS < list_n : blk == (int) blockIdx.x; blk += (int) gridDim.x) {
+    // (a list is walked with the grid's stride -- its length is only known on the device, the grid is sized for the chip, not for the cap; so is
+    //  the node range of a launch that may leave at once: 700 000 workgroups that only look at two counters cost 0.15 ms)
+    for (int blk = (int) blockIdx.x; id_list ? blk * TK_ROWS < list_n : node_begin + blk * TK_ROWS < node_end; blk += (int) gridDim.x) {
     const int base = node_begin + blk * TK_ROWS;
     const int nrows = id_list ? min(TK_ROWS, list_n - blk * TK_ROWS) : min(TK_ROWS, node_end - base);
+    if (blk != (int) blockIdx.x) __syncthreads();          // (the rows of the chunk before are done with)
     if (id_list) {
-        __syncthreads();                                   // (the rows of the chunk before are done with)
         if ((int) threadIdx.x < nrows) sid[threadIdx.x] = min(max(id_list[blk * TK_ROWS + (int) threadIdx.x], 0), nd.n - 1);
         __syncthreads();
     }
@@ -1293,15 +1191,16 @@ size_t cluster_sort_temp_bytes(uint64_t n) { return sort_u32_pairs_temp_bytes(n)
 // minimizer keys, entry words and runs of the nodes node_begin .. node_end - 1 (per-node arrays, written at the node's own index).
 // with_runs = false: the keys (and meta words) alone -- the key pass of a build whose run lists are made elsewhere (prefsuf_pile.hip).
 void launch_cluster_keys(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterCfg &cc, int32_t node_begin, int32_t node_end, uint32_t *keys, uint32_t *vals,
-                         uint32_t *meta, void *runs, uint8_t *nruns, hipStream_t s, bool with_runs) {
+                         uint32_t *meta, void *runs, uint8_t *nruns, hipStream_t s, bool with_runs, const unsigned long long *only_if_declined) {
     if (node_end <= node_begin) return;
     const uint64_t m = (uint64_t) (node_end - node_begin);
-    const dim3 grid((unsigned) ((m + TK_ROWS - 1) / TK_ROWS)), block(TK_ROWS);
+    const unsigned long long *gate = only_if_declined;
+    const dim3 grid((unsigned) (gate ? std::min<uint64_t>((m + TK_ROWS - 1) / TK_ROWS, 8192) : (m + TK_ROWS - 1) / TK_ROWS)), block(TK_ROWS);
     const int32_t *nol = nullptr; const unsigned long long *noc = nullptr;
     // rows of up to 9 words (every 100 - 150 bp configuration) stage 11 words per node, longer ones (<= 13 words) 17
     // ... and rows of up to 17 words or nodes with more than 64 suffix windows (250-bp reads) the two-halves form with 21
-#define NR_LAUNCH(TKW, WIDE) do { if (with_runs) hipLaunchKernelGGL((k_node_runs<TKW, WIDE, true>), grid, block, 0, s, nd, cfg, cc, (int) node_begin, (int) node_end, keys, vals, meta, (uint2 *) runs, nruns, nol, noc); \
-                                  else hipLaunchKernelGGL((k_node_runs<TKW, WIDE, false>), grid, block, 0, s, nd, cfg, cc, (int) node_begin, (int) node_end, keys, vals, meta, (uint2 *) runs, nruns, nol, noc); } while (0)
+#define NR_LAUNCH(TKW, WIDE) do { if (with_runs) hipLaunchKernelGGL((k_node_runs<TKW, WIDE, true>), grid, block, 0, s, nd, cfg, cc, (int) node_begin, (int) node_end, keys, vals, meta, (uint2 *) runs, nruns, nol, noc, gate); \
+                                  else hipLaunchKernelGGL((k_node_runs<TKW, WIDE, false>), grid, block, 0, s, nd, cfg, cc, (int) node_begin, (int) node_end, keys, vals, meta, (uint2 *) runs, nruns, nol, noc, gate); } while (0)
     if (blocks_of(cfg.Lcap - 1) > 13 || (cfg.Lcap - 1) - cfg.Lmin + 1 > 64) NR_LAUNCH(21, true);
     else if (blocks_of(cfg.Lcap - 1) <= 9) NR_LAUNCH(11, false);
     else NR_LAUNCH(17, false);
@@ -1314,7 +1213,7 @@ void launch_cluster_runs_list(const NodesDev &nd, const PrefSufCfg &cfg, const C
     if (cap == 0 || nd.n <= 0) return;
     const dim3 grid(std::max<uint32_t>(1u, std::min<uint32_t>(grid_blocks, (cap + TK_ROWS - 1) / TK_ROWS))), block(TK_ROWS);
     uint32_t *nok = nullptr;
-#define NR_LAUNCH(TKW, WIDE) hipLaunchKernelGGL((k_node_runs<TKW, WIDE, true>), grid, block, 0, s, nd, cfg, cc, 0, (int) cap, nok, nok, nok, (uint2 *) runs, nruns, ids, count)
+#define NR_LAUNCH(TKW, WIDE) hipLaunchKernelGGL((k_node_runs<TKW, WIDE, true>), grid, block, 0, s, nd, cfg, cc, 0, (int) cap, nok, nok, nok, (uint2 *) runs, nruns, ids, count, (const unsigned long long *) nullptr)
     if (blocks_of(cfg.Lcap - 1) > 13 || (cfg.Lcap - 1) - cfg.Lmin + 1 > 64) NR_LAUNCH(21, true);
     else if (blocks_of(cfg.Lcap - 1) <= 9) NR_LAUNCH(11, false);
     else NR_LAUNCH(17, false);

@@ -100,6 +100,117 @@ __device__ __forceinline__ void kmer_key(const uint32_t *row, int i, bool valid,
     pk = valid ? order_key(h, lo, i) : 0xFFFFFFFFu;
 }
 
+constexpr int TK_ROWS = 128;         // rows per workgroup of k_node_runs / k_pile_runs_consensus
+constexpr int NR_STACK = 8;          // minimum records kept per row and block (a random block has ~2.7; more: the row is flagged)
+
+// The window minimizers of ONE row (thread t of the workgroup; the row staged in LDS, `act`: the row takes part): steps (1) - (3) above.
+// Leaves the runs in rbuf[0 .. min(nr, CL_RMAX))[t] as q | p0 << 8 (p1 = p0 of the run before; the last windows first), the minimum of
+// block 0 of the first half (the row's minimizer as a TARGET) in cur0.  Shared by k_node_runs (a node's row) and k_pile_runs_consensus
+// (prefsuf_pile.hip: the consensus of a pile on the pile's extent -- the windows of all its members at once).
+// WIDE: more windows than one sweep takes (the two-block minimum needs no more windows than w): the windows go in PIECES of `step` (a multiple
+// of 16 nucleotides = a whole row word, <= min(w, 64): 64 for the wide nodes cluster_plan admits), the last piece first, each by the same three
+// steps on the row shifted by the piece's first window; the runs of the pieces are listed one after the other (a minimizer that spans a seam makes
+// two runs: one more look-up for a node, merged again for a pile).
+template <bool WIDE>
+__device__ __forceinline__ void node_runs_core(const uint32_t *row, int nwin, bool act, const ClusterCfg &cc, uint32_t (*stk)[TK_ROWS], uint16_t (*rbuf)[TK_ROWS], int t,
+                                               int &nr, bool &uncovered, bool &stack_ovf, uint32_t &cur0, int step = 64) {
+    constexpr int S0 = NR_STACK + 1;                       // first row of block 0's records
+    const int w = cc.w;
+    nr = 0; uncovered = false; stack_ovf = false; cur0 = 0xFFFFFFFFu;
+    for (int hb = (WIDE && nwin > step) ? ((nwin - 1) / step) * step : 0; hb >= 0; hb -= step) {       // first window of the piece (one pass with hb = 0 unless WIDE)
+        const uint32_t *rowh = row + (hb >> 4);
+        const int nwh = !WIDE ? nwin : (nwin - hb < step ? nwin - hb : step);
+        const int nk = act ? nwh - 1 + w : 0;              // k-mer positions of the half (relative to hb): <= 127
+        // ---- class-0 k-mer positions: bit p of the 128-bit mask (static row indices: registers, no scratch) ----
+        uint64_t m_lo, m_hi;
+        {
+            uint32_t dm[4];
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+                const uint32_t x0 = rowh[2 * d], x1 = rowh[2 * d + 1], x2 = rowh[2 * d + 2];
+                dm[d] = compress_even(class0_mask16(x0, x1)) | (compress_even(class0_mask16(x1, x2)) << 16);
+            }
+            m_lo = (uint64_t) dm[0] | ((uint64_t) dm[1] << 32);
+            m_hi = (uint64_t) dm[2] | ((uint64_t) dm[3] << 32);
+            m_lo &= nk >= 64 ? ~0ull : (nk <= 0 ? 0ull : ((1ull << nk) - 1ull));       // positions below nk only (0 for a node that takes no part)
+            m_hi &= nk <= 64 ? 0ull : ((1ull << (nk - 64)) - 1ull);
+        }
+        uint64_t b0 = w >= 64 ? m_lo : (m_lo & ((1ull << w) - 1ull));
+        uint64_t b1 = w >= 64 ? m_hi : ((m_lo >> w) | (m_hi << (64 - w)));    // uniform branch; bit e = k-mer w + e
+        auto key_at = [&](int pos) -> uint32_t {           // order key of the class-0 k-mer at `pos` (relative to the half)
+            const int bit = 2 * pos, q = bit >> 5, r = bit & 31;
+            const uint32_t x0 = rowh[q], x1 = rowh[q + 1], x2 = rowh[q + 2];
+            return order_key0(kmer_hash(funnel(x0, x1, r) & cc.lo_mask, funnel(x1, x2, r) & cc.hi_mask), pos);
+        };
+        // ---- (1) block 1, left to right: prefix-minimum records ----
+        uint32_t cur1 = 0xFFFFFFFFu;
+        int sp1 = 0;
+        while (b1 != 0ull) {
+            const int e = __builtin_ctzll(b1);
+            b1 &= b1 - 1ull;
+            const uint32_t pk = key_at(w + e);
+            // no branch: a lane that does not push writes the spare row
+            const bool push = pk < cur1;
+            stk[(push && sp1 < NR_STACK) ? sp1 : NR_STACK][t] = pk;
+            cur1 = push ? pk : cur1;
+            sp1 += push ? 1 : 0;
+        }
+        // ---- (2) block 0, right to left: suffix-minimum records ----
+        uint32_t cur0h = 0xFFFFFFFFu;
+        int sp0 = 0;
+        while (b0 != 0ull) {
+            const int e = 63 - __builtin_clzll(b0);
+            b0 ^= 1ull << e;
+            const uint32_t pk = key_at(e);
+            const bool push = pk < cur0h;
+            stk[S0 + ((push && sp0 < NR_STACK) ? sp0 : NR_STACK)][t] = pk;
+            cur0h = push ? pk : cur0h;
+            sp0 += push ? 1 : 0;
+        }
+        if (hb == 0) cur0 = cur0h;
+        stack_ovf = stack_ovf || sp1 > NR_STACK || sp0 > NR_STACK;
+        sp1 = sp1 > NR_STACK ? NR_STACK : sp1;
+        sp0 = sp0 > NR_STACK ? NR_STACK : sp0;
+        // ---- (3) the windows of the half, last to first: merge of the two record lists ----
+        {
+            const uint32_t hq = (uint32_t) hb | ((uint32_t) hb << 8);     // what makes q and p0 of a run absolute
+            uint32_t top = sp1 > 0 ? stk[sp1 - 1][t] : 0xFFFFFFFFu;       // smallest record of block 1: in every window until it drops out
+            uint32_t nxt0 = stk[S0][t];                                   // next record of block 0 (if i0 < sp0)
+            uint32_t c0 = 0xFFFFFFFFu, win = top;
+            int i0 = 0, p_hi = nwh - 1;
+            int e0 = sp0 > 0 ? (int) (nxt0 & 255u) : -1;                  // the next block-0 record joins the windows p <= e0
+            int e1 = sp1 > 0 ? (int) (top & 255u) - w : -1;               // block 1's smallest record is in no window p <= e1
+            while ((e0 > e1 ? e0 : e1) >= 0) {
+                const int pe = e0 > e1 ? e0 : e1;
+                const bool take0 = e0 >= e1;
+                // ONE stack read serves either move: the record after the block-0 record that joins, or the one below block 1's top
+                const int row_i = take0 ? S0 + i0 + 1 : (sp1 >= 2 ? sp1 - 2 : NR_STACK);
+                const uint32_t v = stk[row_i][t];
+                i0 += take0 ? 1 : 0;
+                sp1 -= take0 ? 0 : 1;
+                c0 = take0 ? nxt0 : c0;
+                nxt0 = take0 ? v : nxt0;
+                top = take0 ? top : (sp1 >= 1 ? v : 0xFFFFFFFFu);
+                e0 = take0 ? (i0 < sp0 ? (int) (v & 255u) : -1) : e0;
+                e1 = take0 ? e1 : (sp1 >= 1 ? (int) (v & 255u) - w : -1);
+                const uint32_t wn = c0 < top ? c0 : top;
+                const int pc = pe < p_hi ? pe : p_hi;
+                const bool em = wn != win && pc < p_hi;         // the windows (pc, p_hi] had `win`
+                rbuf[(em && nr < CL_RMAX) ? nr : CL_RMAX][t] = (uint16_t) (((win & 255u) | ((uint32_t) (pc + 1) << 8)) + hq);
+                uncovered = uncovered || (em && win == 0xFFFFFFFFu);
+                nr += em ? 1 : 0;
+                p_hi = em ? pc : p_hi;
+                win = wn;
+            }
+            if (act) {                                         // the run of the half's first window
+                if (nr < CL_RMAX) rbuf[nr][t] = (uint16_t) ((win & 255u) + hq);
+                uncovered = uncovered || win == 0xFFFFFFFFu;
+                nr++;
+            }
+        }
+    }
+}
+
 __device__ __forceinline__ uint32_t bperm(uint32_t v, int src_lane) { return (uint32_t) __builtin_amdgcn_ds_bpermute(src_lane << 2, (int) v); }
 
 } // namespace alga

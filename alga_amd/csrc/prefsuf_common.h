@@ -85,6 +85,7 @@ enum Counter {
     CNT_ROUNDS,            // clustered probe, quad kernel: rounds (wave iterations), statistics builds only
     CNT_PILE_BUCKETS,      // pile path: non-empty buckets of the entry array / those it does not take (copied from k_pile_build's counters by k_pile_probe)
     CNT_PILE_IRREGULAR,
+    CNT_PILE_OWN,          // pile path: entries that read a run list of their own (the list-driven key pass behind k_pile_runs_consensus)
     CNT_TOTAL = 24
 };
 

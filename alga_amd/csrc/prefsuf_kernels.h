@@ -44,7 +44,8 @@ bool       cluster_plan(const PrefSufCfg &cfg, int max_len, uint64_t live, int b
 size_t     cluster_sort_temp_bytes(uint64_t n);
 // keys/vals/keys2/vals2/meta: n uint32 each; runs: n * CL_RMAX * 8 bytes; nruns: n bytes; store: (n + 2) * 16 * eq bytes; dir: (n_buckets + 2) * 16 bytes
 void       launch_cluster_keys(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterCfg &cc, int32_t node_begin, int32_t node_end, uint32_t *keys,
-                               uint32_t *vals, uint32_t *meta, void *runs, uint8_t *nruns, hipStream_t s, bool with_runs = true /* false: keys and meta words alone */);
+                               uint32_t *vals, uint32_t *meta, void *runs, uint8_t *nruns, hipStream_t s, bool with_runs = true /* false: keys and meta words alone */,
+                               const unsigned long long *only_if_declined = nullptr /* the pile path's sample counters: the kernel leaves for a build that path keeps */);
 void       launch_cluster_runs_list(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterCfg &cc, const int32_t *ids, const unsigned long long *count, uint32_t cap,
                                     uint32_t grid_blocks, void *runs, uint8_t *nruns, hipStream_t s);      // run lists of the listed nodes (list length read on the device)
 hipError_t launch_cluster_store(const NodesDev &nd, const ClusterCfg &cc, uint32_t *keys, uint32_t *vals, uint32_t *keys2 /* out: sorted */, uint32_t *vals2, void *sort_temp,
@@ -74,9 +75,14 @@ size_t     pile_record_bytes(uint64_t n);
 size_t     pile_table_bytes(uint32_t n_buckets);
 void       launch_pile_sample(const NodesDev &nd, const ClusterCfg &cc, int uniform_len, const uint32_t *skeys /* sorted keys */, const uint32_t *sids /* their node ids */, const void *dir,
                               unsigned long long *pile_cnt /* of the sample: [0] buckets (raised to entries / 8), [1] irregular buckets, [2] entries */, bool no_sample, hipStream_t s);
-void       launch_pile_build(const NodesDev &nd, const ClusterCfg &cc, int uniform_len, const uint32_t *skeys, const uint32_t *sids, const void *dir, void *rec,
-                             void *tab /* 128 B per bucket, never cleared */, uint32_t epoch /* of this build: what makes a record of `tab` valid */, void *side /* 16 B per entry */,
-                             const void *runs, int nwin /* suffix windows of a read */, const unsigned long long *pile_cnt, hipStream_t s);
+constexpr int PILE_CNT_WORDS = 6;      // {sampled buckets, irregular ones, sampled entries, own-list ids, members checked, members whose lists differ}
+size_t     pile_own_mask_bytes(uint64_t n);
+void       launch_pile_build(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterCfg &cc, int uniform_len, const uint32_t *skeys, const uint32_t *sids, const void *dir, void *rec,
+                             void *tab, uint32_t epoch, void *side, const void *runs, int nwin, const unsigned long long *pile_cnt,
+                             uint32_t *own_mask /* null: the piles' run lists from their outer members' own lists (round 4) */, hipStream_t s);
+void       launch_pile_own_ids(const uint32_t *own_mask, const uint32_t *sids, uint64_t n_entries, int32_t *list, uint32_t cap, unsigned long long *pile_cnt, hipStream_t s);
+void       launch_pile_check(const void *side, uint64_t n_entries, uint32_t n_buckets, const void *tab, uint32_t epoch, const void *runs, int n_nodes, int nwin,
+                             unsigned long long *pile_cnt, hipStream_t s);
 void       launch_pile_probe(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterCfg &cc, int uniform_len, const void *tab, uint32_t epoch, const void *rec, const void *side,
                              const void *runs, unsigned long long *counters, uint32_t *deg, unsigned long long *first, unsigned long long *second, int32_t *defer_list,
                              uint32_t defer_cap, const unsigned long long *pile_cnt, int n_cu, hipStream_t s);

@@ -50,10 +50,11 @@ constexpr int PILE_EQ = 3;                     // entry size this path takes: ro
 //   w[15]       tag of group 0 .. 3 (bits 0..4, 5..9, 10..14, 15..19) | groups - 1 (bits 20..21) | irregular (bit 22) | epoch of the build that wrote
 //               the record (bits 23..31, never 0: the table is not cleared between builds, a record of another epoch is an empty bucket)
 //   -- the first 64 bytes are all the run loop reads (the kernel is bound by the number of 64-byte requests that miss its L1) --
-//   w[16]       entries (127: more than 64) | runs of the pile's run list << 8 (0: none -- its members read their own lists);  w[17] first entry of
-//               the bucket;  w[18], w[19] the directory's class offsets (k_tgt_dir): the look-up of a target
-//   w[20 .. 31] the pile's run list (k_pile_runs): up to six runs {cluster key, (k-mer position + 64) | (first window + 64) << 8 | (end + 64) << 16},
-//               windows ascending on the pile's axis
+//   w[16]       entries (127: more than 64) | runs of the pile's run list << 8 (0: none -- its members read their own lists) | end of the last run's
+//               windows (+ 64) << 16;  w[17] first entry of the bucket;  w[18], w[19] the directory's class offsets (k_tgt_dir): the look-up of a target
+//   w[20 .. 31] the pile's run list (k_pile_runs_consensus): up to EIGHT runs, windows ascending and contiguous on the pile's axis: w[20 .. 27] their
+//               cluster keys, w[28 .. 31] per run (k-mer position + 64) | (first window + 64) << 8 in 16 bits (a run ends where the next begins).
+//               A pile's extent holds ~5.4 minimizers at 30x (one per 32 positions of ~174): with six slots one pile in four had no list
 // tag = low five bits of the k-mer's cluster key, i.e. of the word a run carries (they lie below the bucket bits): which group a run wants
 // without a second read.  The further groups of a bucket (another k-mer in the same bucket: 12 % of the non-empty buckets at the north-star
 // size) have 16-word records {consensus, -, set} in `rec` at entry slot first + k, k in the order of the groups' first members.
@@ -83,7 +84,7 @@ __device__ __forceinline__ void load_row9(const NodesDev &nd, uint32_t id, uint3
 template <bool SAMPLE>
 __global__ void __launch_bounds__(PB_THREADS, 3) k_pile_build(NodesDev nd, const uint32_t *__restrict__ skeys, const uint32_t *__restrict__ sids, uint64_t n_entries, const uint4 *__restrict__ dir, ClusterCfg cc, int U,
                                                            uint4 *__restrict__ rec, uint4 *__restrict__ tab, uint32_t epoch,
-                                                           uint4 *__restrict__ side, unsigned long long *__restrict__ pile_cnt) {
+                                                           uint4 *__restrict__ side, unsigned long long *__restrict__ pile_cnt, uint32_t *__restrict__ own_mask) {
     if (!SAMPLE && pile_declines(pile_cnt)) return;
     const int idx_shift = cc.idx_shift, kk = cc.kk;
     __shared__ uint32_t sRow[PB_THREADS][PILE_SW];         // the entry's row on the pile's axis, masked to its extent (odd stride: conflict-free)
@@ -219,6 +220,8 @@ __global__ void __launch_bounds__(PB_THREADS, 3) k_pile_build(NodesDev nd, const
                 const bool first_group = k == 0 && sBad[s] == 0u && nsub <= PILE_MAXSUB;
                 const bool leftmost = first_group && t == (int) (sMax[s] & 0xFFFFu);          // T0: k_pile_runs makes the pile's run list from its lane
                 side[j] = make_uint4(node_id, succ_id, delta | ((uint32_t) m << 8) | ((uint32_t) k << 16) | (leftmost ? 0x40000000u : 0u) | (first_group ? 0x80000000u : 0u), key >> idx_shift);
+                // an entry outside a first group reads its OWN run list as a source (k_pile_probe): bit j of the mask the list-driven key pass works from
+                if (!first_group && own_mask) atomicOr(&own_mask[j >> 5], 1u << (j & 31u));
             }
             if (!SAMPLE && L == t && k >= 1 && k < PILE_MAXSUB) {
                 const unsigned long long rm = sRm[t];
@@ -257,7 +260,10 @@ __global__ void __launch_bounds__(PB_THREADS, 3) k_pile_build(NodesDev nd, const
         }
     }
     // entries of no regular bucket (non-targets, buckets of more than 64 entries): written by the thread of the tile proper
-    if (!SAMPLE && have && t < PB_TILE && !(tgt && cnt <= 64u)) side[j] = make_uint4(node_id, 0xFFFFFFFFu, 0u, 0u);
+    if (!SAMPLE && have && t < PB_TILE && !(tgt && cnt <= 64u)) {
+        side[j] = make_uint4(node_id, 0xFFFFFFFFu, 0u, 0u);
+        if (own_mask) atomicOr(&own_mask[j >> 5], 1u << (j & 31u));
+    }
     if (SAMPLE && owned) atomicAdd(&sCount[2], 1u);
     __syncthreads();
     if (SAMPLE && t < 3 && sCount[t]) atomicAdd(&pile_cnt[t], (unsigned long long) sCount[t]);      // (the sample is a few thousand workgroups)
@@ -270,6 +276,18 @@ __global__ void __launch_bounds__(PB_THREADS, 3) k_pile_build(NodesDev nd, const
 // that list clipped to its windows.  k_pile_probe reads it from the bucket's record (one read shared by the pile's members, who sit side by side
 // in the entry order) instead of every source's own list by id: a random read per source, 3 of that kernel's 10 ms; here it is two random reads
 // per PILE.  One lane per entry; the lanes of the T0s work (k_pile_build flagged them and left T1's id in the record).
+constexpr int PILE_RUNS = 8;                               // runs a pile's list holds
+// the list into the second half of the bucket's record (n in 1 .. PILE_RUNS; kc[a] = kpos | c0 << 8), or "none"
+__device__ __forceinline__ void pile_list_store(uint4 *line, uint32_t entries, bool ok, int n, const uint32_t (&key)[PILE_RUNS], const uint32_t (&kc)[PILE_RUNS], uint32_t c1_last) {
+    uint32_t *lw = reinterpret_cast<uint32_t *>(line);
+    if (ok) {
+        line[5] = make_uint4(key[0], key[1], key[2], key[3]);
+        line[6] = make_uint4(key[4], key[5], key[6], key[7]);
+        line[7] = make_uint4(kc[0] | (kc[1] << 16), kc[2] | (kc[3] << 16), kc[4] | (kc[5] << 16), kc[6] | (kc[7] << 16));
+        lw[16] = (entries & 255u) | ((uint32_t) n << 8) | ((c1_last & 255u) << 16);
+    } else lw[16] = entries & 255u;
+}
+
 __global__ void __launch_bounds__(256) k_pile_runs(const uint4 *__restrict__ side, uint64_t n_entries, uint32_t n_buckets, uint4 *__restrict__ tab, const uint2 *__restrict__ runs,
                                                    int n_nodes, int nwin, const unsigned long long *__restrict__ pile_cnt) {
     if (pile_declines(pile_cnt)) return;
@@ -289,15 +307,18 @@ __global__ void __launch_bounds__(256) k_pile_runs(const uint4 *__restrict__ sid
     const uint32_t k1[6] = {b0.x, b0.z, b1.x, b1.z, b2.x, b2.z}, y1[6] = {b0.y, b0.w, b1.y, b1.w, b2.y, b2.w};
     const int nr0 = (int) (y0[0] >> 24), nr1 = (int) (y1[0] >> 24);
     bool ok = nr0 >= 1 && nr0 <= CL_RMAX && nr1 >= 1 && nr1 <= 6 && s1 <= seam;
-    uint2 *out = reinterpret_cast<uint2 *>(line + 5);
+    uint32_t ok_[PILE_RUNS], kc_[PILE_RUNS];
+#pragma unroll
+    for (int k = 0; k < PILE_RUNS; k++) { ok_[k] = 0u; kc_[k] = 0u; }
     int n = 0;
-    uint32_t last_key = 0u, last_pos = 0xFFFFFFFFu, last_c0 = 0u;
+    uint32_t last_key = 0u, last_pos = 0xFFFFFFFFu, c1_last = 0u;
 #pragma unroll
     for (int r = CL_RMAX - 1; r >= 0; r--) {
         if (ok && r < nr0) {
             const uint32_t kpos = (uint32_t) (s0 + (int) (y0[r] & 255u) + 64), c0 = (uint32_t) (s0 + (int) ((y0[r] >> 8) & 255u) + 64), c1 = (uint32_t) (s0 + (int) ((y0[r] >> 16) & 255u) + 64);
-            if (n < 6) out[n] = make_uint2(k0[r], kpos | (c0 << 8) | (c1 << 16));
-            last_key = k0[r]; last_pos = kpos; last_c0 = c0;
+#pragma unroll
+            for (int k = 0; k < PILE_RUNS; k++) if (k == n) { ok_[k] = k0[r]; kc_[k] = kpos | (c0 << 8); }
+            last_key = k0[r]; last_pos = kpos; c1_last = c1;
             n++;
         }
     }
@@ -308,18 +329,207 @@ __global__ void __launch_bounds__(256) k_pile_runs(const uint4 *__restrict__ sid
             if (c1i > seam) {
                 const int c0i = max(s1 + (int) ((y1[r] >> 8) & 255u), seam);
                 const uint32_t kpos = (uint32_t) (s1 + (int) (y1[r] & 255u) + 64), c1 = (uint32_t) (c1i + 64);
-                if (n >= 1 && k1[r] == last_key && kpos == last_pos) {             // the same minimizer on both sides of the seam: one run
-                    if (n <= 6) out[n - 1] = make_uint2(last_key, last_pos | (last_c0 << 8) | (c1 << 16));
-                } else {
-                    if (n < 6) out[n] = make_uint2(k1[r], kpos | ((uint32_t) (c0i + 64) << 8) | (c1 << 16));
-                    last_key = k1[r]; last_pos = kpos; last_c0 = (uint32_t) (c0i + 64);
+                if (n >= 1 && k1[r] == last_key && kpos == last_pos) c1_last = c1;             // the same minimizer on both sides of the seam: one run
+                else {
+#pragma unroll
+                    for (int k = 0; k < PILE_RUNS; k++) if (k == n) { ok_[k] = k1[r]; kc_[k] = kpos | ((uint32_t) (c0i + 64) << 8); }
+                    last_key = k1[r]; last_pos = kpos; c1_last = c1;
                     n++;
                 }
             }
         }
     }
-    ok = ok && n >= 1 && n <= 6;
-    reinterpret_cast<uint32_t *>(line + 4)[0] = (l4.x & 255u) | (ok ? (uint32_t) n << 8 : 0u);
+    ok = ok && n >= 1 && n <= PILE_RUNS;
+    pile_list_store(line, l4.x, ok, n, ok_, kc_, c1_last);
+}
+
+// ------------------------------------------------------------------------------------------
+// The run list of a pile FROM ITS CONSENSUS (round 5).  A window's minimizer is a function of the window's content, and the windows of all
+// members of a pile are windows of its consensus: the pile's extent [-m_max, -m_min + U) is treated as ONE long row and goes through the very
+// code that lists a node's runs (node_runs_core, two halves of up to 64 windows: a pile spans up to 126) -- once per PILE instead of once per
+// member (six at 30x), and no member of a first group needs a run list of its own any more: the key pass of a build the pile path keeps
+// computes the TARGET keys alone (k_node_runs<., ., false>), and own lists only for the entries outside a first group (own_mask) and for
+// the sources k_pile_probe hands to the general kernel.  A member's own list is the pile's list clipped to its windows, bit for bit
+// (tests/test_gpu_pile.py: test_consensus_run_lists_equal_the_members_own; engine option "pile_check").
+// A block takes a tile of entries, lists the leftmost members (T0, flagged by k_pile_build) in LDS and gives every thread one pile.
+// A pile whose list cannot be made (a window without a class-0 k-mer, more than eight runs, more records than a stack holds) stays without one:
+// its members probe with their own lists (own_mask), and a member whose own list is flagged as well goes to the general kernel.
+constexpr int PR_TILE = 3072;                              // entries per block of k_pile_runs_consensus (~500 piles at 30x: four rounds of 128)
+constexpr int PR_TKW = 21;
+__global__ void __launch_bounds__(TK_ROWS) k_pile_runs_consensus(const uint4 *__restrict__ side, uint64_t n_entries, uint32_t n_buckets, uint4 *__restrict__ tab, ClusterCfg cc, int U, int Lmin,
+                                                                 const unsigned long long *__restrict__ pile_cnt, uint32_t *__restrict__ own_mask) {
+    if (pile_declines(pile_cnt)) return;
+    __shared__ uint32_t s[TK_ROWS][PR_TKW];
+    __shared__ uint32_t stk[2 * (NR_STACK + 1)][TK_ROWS];
+    __shared__ uint16_t rbuf[CL_RMAX + 1][TK_ROWS];
+    __shared__ uint32_t sList[PR_TILE];                    // buckets of the tile's piles
+    __shared__ uint32_t sN;
+    const int t = (int) threadIdx.x;
+    if (t == 0) sN = 0u;
+    __syncthreads();
+    const uint64_t base = (uint64_t) blockIdx.x * PR_TILE;
+#pragma unroll
+    for (int q = 0; q < PR_TILE / TK_ROWS; q++) {
+        const uint64_t j = base + (uint64_t) q * TK_ROWS + (uint64_t) t;
+        if (j < n_entries) {
+            const uint4 sd = side[j];
+            if ((sd.z >> 30) & 1u) sList[atomicAdd(&sN, 1u)] = min(sd.w, n_buckets);      // (the order of the piles in the list is free: each writes its own record)
+        }
+    }
+    __syncthreads();
+    const int np = (int) sN;
+    const int fs = cc.idx_shift - CL_MBITS;
+    const int step = max(16, min(64, cc.w) & ~15);         // windows per piece of the sweep: no more than w, whole row words (w >= 16 for every shape pile_plan takes)
+    for (int c0 = 0; c0 < np; c0 += TK_ROWS) {             // uniform
+        const bool in = c0 + t < np;
+        uint4 *line = tab + (size_t) sList[in ? c0 + t : 0] * 8;
+        uint32_t S[PILE_SW + 1];
+        unsigned long long rm = 0ull;
+        {
+            const uint4 l0 = line[0], l1 = line[1], l2 = line[2], l3 = line[3];
+            S[0] = l0.x; S[1] = l0.y; S[2] = l0.z; S[3] = l0.w; S[4] = l1.x; S[5] = l1.y; S[6] = l1.z; S[7] = l1.w;
+            S[8] = l2.x; S[9] = l2.y; S[10] = l2.z; S[11] = l2.w; S[12] = l3.x; S[13] = 0u;
+            rm = in ? (((unsigned long long) l3.z << 32) | l3.y) : 0ull;
+        }
+        const bool act = in && rm != 0ull;
+        const int m_min = act ? __clzll((long long) rm) : 0, m_max = act ? 63 - __builtin_ctzll(rm) : 0;
+        const int len_v = U + m_max - m_min;               // the pile's extent: [-m_max, -m_min + U)
+        const int nwin = len_v - Lmin + 1;                 // <= 126
+        // the extent as a row of its own: consensus index 64 - m_max onwards (the consensus is zero outside the extent, like the tail of a row)
+        {
+            const int ob = 2 * (64 - m_max), w0 = ob >> 5, sh = ob & 31;          // w0 in 0 .. 4 (4: every member starts at the k-mer)
+            uint32_t m1 = 0u - (uint32_t) (w0 & 1), m2 = 0u - (uint32_t) ((w0 >> 1) & 1), m4 = 0u - (uint32_t) ((w0 >> 2) & 1);
+            asm volatile("" : "+v"(m1), "+v"(m2), "+v"(m4));          // (opaque masks: written as selects the stages become a dynamically indexed array in scratch)
+            uint32_t y1[PILE_SW + 1], y2[PILE_SW + 1], y[PILE_SW + 1];
+#pragma unroll
+            for (int k = 0; k <= PILE_SW; k++) y1[k] = ((k + 1 <= PILE_SW ? S[k + 1] : 0u) & m1) | (S[k] & ~m1);
+#pragma unroll
+            for (int k = 0; k <= PILE_SW; k++) y2[k] = ((k + 2 <= PILE_SW ? y1[k + 2] : 0u) & m2) | (y1[k] & ~m2);
+#pragma unroll
+            for (int k = 0; k <= PILE_SW; k++) y[k] = ((k + 4 <= PILE_SW ? y2[k + 4] : 0u) & m4) | (y2[k] & ~m4);
+#pragma unroll
+            for (int k = 0; k < PR_TKW; k++) s[t][k] = k < PILE_SW ? funnel(y[k], y[k + 1], sh) : 0u;
+        }
+        // (each thread reads the row it wrote: no barrier)
+        int nr = 0;
+        bool uncovered = false, stack_ovf = false;
+        uint32_t cur0 = 0u;
+        node_runs_core<true>(s[t], nwin, act, cc, stk, rbuf, t, nr, uncovered, stack_ovf, cur0, step);
+        bool ok = act && nr >= 1 && nr <= CL_RMAX && !uncovered && !stack_ovf;
+        // runs as they were found: the last windows first, q | p0 << 8 in the extent's own coordinates, p1 = p0 of the run before.  The record
+        // wants them ascending on the pile's axis (coordinate + 64 in a byte); the two halves of the window range meet at window 64: a minimizer
+        // on both sides of that seam is ONE run (k_pile_probe takes "the same minimizer twice" for a tandem repeat)
+        uint32_t key_[PILE_RUNS], kc_[PILE_RUNS];
+#pragma unroll
+        for (int k = 0; k < PILE_RUNS; k++) { key_[k] = 0u; kc_[k] = 0u; }
+        int n = 0;
+        uint32_t last_q = 0xFFFFFFFFu;
+        const int nrs = nr < CL_RMAX ? nr : CL_RMAX;
+        for (int r = CL_RMAX - 1; r >= 0; r--) {
+            if (ok && r < nrs) {
+                const uint32_t d = rbuf[r][t];
+                const int q = (int) (d & 255u), p0 = (int) (d >> 8);
+                if ((uint32_t) q != last_q) {              // (the same k-mer as the run before: the seam of two pieces -- one run)
+                    uint32_t h, pk;
+                    kmer_key(s[t], q < 192 ? q : 0, true, cc, h, pk);
+                    const uint32_t kv = cluster_key(h, fs), cv = (uint32_t) (q - m_max + 64) | ((uint32_t) (p0 - m_max + 64) << 8);
+#pragma unroll
+                    for (int k = 0; k < PILE_RUNS; k++) if (k == n) { key_[k] = kv; kc_[k] = cv; }
+                    n++;
+                    last_q = (uint32_t) q;
+                }
+            }
+        }
+        ok = ok && n >= 1 && n <= PILE_RUNS;
+        if (in) {
+            uint32_t *lw = reinterpret_cast<uint32_t *>(line);
+            pile_list_store(line, lw[16], ok, n, key_, kc_, (uint32_t) (nwin - m_max + 64));
+            if (!ok) {
+                // no list (3 piles in 1000: a window without a class-0 k-mer somewhere on the extent, mostly): the members probe with their OWN
+                // lists, as the entries outside a first group do -- noted in own_mask for the list-driven key pass that follows.  (Marking the
+                // bucket irregular instead sent every source with a run in it to the general kernel: 1.7 M more sources at the north-star size.)
+                lw[16] = lw[16] & 255u;
+                const uint32_t cntb = min(lw[16] & 255u, 64u), e0b = lw[17];
+                for (uint32_t i2 = 0; i2 < cntb; i2++) {
+                    const uint64_t j2 = (uint64_t) e0b + i2;
+                    if (j2 < n_entries && (side[j2].z >> 31)) atomicOr(&own_mask[j2 >> 5], 1u << (j2 & 31u));
+                }
+            }
+        }
+    }
+}
+
+// own_mask (bit j: entry j of the key order reads its own run list) -> the ids of those entries, densely (the order is free).  A block takes
+// 32 768 entries: one global atomic per block.
+__global__ void __launch_bounds__(256) k_pile_own_ids(const uint32_t *__restrict__ own_mask, const uint32_t *__restrict__ sids, uint64_t n_entries, int32_t *__restrict__ out, uint32_t cap,
+                                                      unsigned long long *__restrict__ count, const unsigned long long *__restrict__ pile_cnt) {
+    if (pile_declines(pile_cnt)) return;
+    __shared__ uint32_t sTot, sBase;
+    const uint64_t words = (n_entries + 31) / 32;
+    const uint64_t w0 = (uint64_t) blockIdx.x * 1024 + threadIdx.x;
+    uint32_t mw[4];
+    uint32_t mine = 0u;
+#pragma unroll
+    for (int q = 0; q < 4; q++) { const uint64_t w = w0 + (uint64_t) q * 256; mw[q] = w < words ? own_mask[w] : 0u; mine += (uint32_t) __popc(mw[q]); }
+    if (threadIdx.x == 0) sTot = 0u;
+    __syncthreads();
+    const uint32_t at = atomicAdd(&sTot, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) sBase = (uint32_t) atomicAdd(count, (unsigned long long) sTot);
+    __syncthreads();
+    uint32_t o = sBase + at;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const uint64_t w = w0 + (uint64_t) q * 256;
+        uint32_t m = mw[q];
+        while (m) {
+            const int b = __builtin_ctz(m);
+            m &= m - 1u;
+            const uint64_t j = w * 32 + (uint64_t) b;
+            if (j < n_entries && o < cap) out[o] = (int32_t) sids[j];
+            o++;
+        }
+    }
+}
+
+// test harness (engine option "pile_check"; every node has its own run list): a first-group member's own list against its pile's list clipped
+// to its windows -- count of the members for which the two differ
+__global__ void __launch_bounds__(256) k_pile_list_check(const uint4 *__restrict__ side, uint64_t n_entries, uint32_t n_buckets, const uint4 *__restrict__ tab, uint32_t epoch,
+                                                         const uint2 *__restrict__ runs, int n_nodes, int nwin, unsigned long long *__restrict__ out /* [0] members checked, [1] mismatches */,
+                                                         const unsigned long long *__restrict__ pile_cnt) {
+    if (pile_declines(pile_cnt)) return;
+    const uint64_t j = (uint64_t) blockIdx.x * 256 + threadIdx.x;
+    if (j >= n_entries) return;
+    const uint4 sd = side[j];
+    if ((sd.z >> 31) == 0u) return;
+    const uint4 *line = tab + (size_t) min(sd.w, n_buckets) * 8;
+    const uint4 l3 = line[3], l4 = line[4];
+    if ((l3.w >> 23) != epoch || ((l3.w >> 22) & 1u)) return;                    // an irregular bucket (or one without a list): nothing to compare
+    const int npr = (int) ((l4.x >> 8) & 15u);
+    if (npr == 0) return;
+    const uint32_t *lw = reinterpret_cast<const uint32_t *>(line);
+    const uint2 *own = runs + (size_t) min(sd.x, (uint32_t) n_nodes - 1u) * CL_RMAX;
+    const int code = (int) (own[0].y >> 24);
+    if (code == 0 || code == CL_RUNS_FLAGGED) return;      // (a flagged member: its list says nothing)
+    const int nown = code < CL_RMAX ? code : CL_RMAX;
+    const int sB = 64 - (int) ((sd.z >> 8) & 63u);
+    bool bad = false;
+    int r = nown - 1;                                      // own runs: the last windows first -> walk them backwards
+    for (int a = 0; a < npr && a < PILE_RUNS; a++) {
+        const uint32_t vx = lw[20 + a], pq = (lw[28 + (a >> 1)] >> (16 * (a & 1))) & 0xFFFFu;
+        const uint32_t pqn = a + 1 < npr ? (lw[28 + ((a + 1) >> 1)] >> (16 * ((a + 1) & 1))) & 0xFFFFu : 0u;
+        const int kpos = (int) (pq & 255u), c0 = (int) (pq >> 8), c1 = a + 1 < npr ? (int) (pqn >> 8) : (int) ((l4.x >> 16) & 255u);
+        const int p0 = max(c0, sB) - sB, p1 = min(c1, sB + nwin) - sB;
+        if (p0 >= p1) continue;
+        if (r < 0) { bad = true; break; }
+        const uint2 o = own[r];
+        const int oq = (int) (o.y & 255u), op0 = (int) ((o.y >> 8) & 255u), op1 = (int) ((o.y >> 16) & 255u);
+        bad = bad || o.x != vx || oq != kpos - sB || op0 != p0 || op1 != p1;
+        r--;
+    }
+    bad = bad || r >= 0;
+    atomicAdd(&out[0], 1ull);
+    if (bad) atomicAdd(&out[1], 1ull);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -357,7 +567,7 @@ __global__ void __launch_bounds__(PP_WAVES * 64, PP_OCC) k_pile_probe(PrefSufCfg
     __shared__ __attribute__((aligned(16))) uint32_t sL[PP_WAVES][4 + 64 * PP_LSTRIDE + 12];
     __shared__ uint32_t sBk[PP_WAVES][64];                 // the distinct buckets of the slot whose records are on their way, in lane order
     __shared__ int32_t sDefer[PP_WAVES][128];              // sources of this wave that wait for the defer list
-    if (blockIdx.x == 0 && threadIdx.x == 0) { o.counters[CNT_PILE_BUCKETS] = pile_cnt[0]; o.counters[CNT_PILE_IRREGULAR] = pile_cnt[1]; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { o.counters[CNT_PILE_BUCKETS] = pile_cnt[0]; o.counters[CNT_PILE_IRREGULAR] = pile_cnt[1]; o.counters[CNT_PILE_OWN] = pile_cnt[3]; }
     // a build whose buckets are mostly irregular (reads with sequencing errors) is k_probe_stream's: this kernel leaves at once
     if (pile_declines(pile_cnt)) return;
     const int wave = (int) (threadIdx.x >> 6), lane = lane_id();
@@ -411,7 +621,7 @@ __global__ void __launch_bounds__(PP_WAVES * 64, PP_OCC) k_pile_probe(PrefSufCfg
     const int Bs = (int) my.x;
     const bool first_group = (my.z >> 31) != 0u;
     const uint32_t npr = first_group ? (Qr[0].x >> 8) & 15u : 0u;         // runs of my pile's list (0: it has none -- more than six, or a member's own list is flagged)
-    if (first_group && npr == 0u) {                        // (rare: my own list after all, late)
+    if (first_group && npr == 0u) {                        // (rare: a pile without a list -- its members probe with their own, k_pile_runs_consensus saw to them)
         const uint4 *rp = reinterpret_cast<const uint4 *>(runs + (size_t) Bs * CL_RMAX);
 #pragma unroll
         for (int c = 0; c < CL_RMAX / 2; c++) Qr[c] = rp[c];
@@ -427,14 +637,16 @@ __global__ void __launch_bounds__(PP_WAVES * 64, PP_OCC) k_pile_probe(PrefSufCfg
 #pragma unroll
         for (int c = 0; c < CL_RMAX / 2; c++) { ok[2 * c] = Qr[c].x; oy[2 * c] = Qr[c].y; ok[2 * c + 1] = Qr[c].z; oy[2 * c + 1] = Qr[c].w; }
         // (b) the pile's list, windows ascending on the pile's axis (coordinate + 64): clipped to my windows [-m_C, -m_C + nwin)
-        const uint32_t pk[6] = {Qr[1].x, Qr[1].z, Qr[2].x, Qr[2].z, Qr[3].x, Qr[3].z}, pp[6] = {Qr[1].y, Qr[1].w, Qr[2].y, Qr[2].w, Qr[3].y, Qr[3].w};
+        const uint32_t pk[PILE_RUNS] = {Qr[1].x, Qr[1].y, Qr[1].z, Qr[1].w, Qr[2].x, Qr[2].y, Qr[2].z, Qr[2].w};
+        const uint32_t pq[PILE_RUNS] = {Qr[3].x & 0xFFFFu, Qr[3].x >> 16, Qr[3].y & 0xFFFFu, Qr[3].y >> 16, Qr[3].z & 0xFFFFu, Qr[3].z >> 16, Qr[3].w & 0xFFFFu, Qr[3].w >> 16};
+        const int c1_last = (int) ((Qr[0].x >> 16) & 255u);
         const int sB = 64 - (int) ((my.z >> 8) & 63u);     // my first window, + 64
 #pragma unroll
         for (int a = 0; a < CL_RMAX; a++) {
             uint32_t k = ok[a], y = oy[a] & 0x00FFFFFFu;
             bool v = false;
-            if (a < 6) {
-                const int kpos = (int) (pp[a] & 255u), c0 = (int) ((pp[a] >> 8) & 255u), c1 = (int) ((pp[a] >> 16) & 255u);
+            {
+                const int kpos = (int) (pq[a] & 255u), c0 = (int) (pq[a] >> 8), c1 = ((uint32_t) a + 1u < npr && a + 1 < PILE_RUNS) ? (int) (pq[a + 1 < PILE_RUNS ? a + 1 : a] >> 8) : c1_last;
                 const int p0 = max(c0, sB) - sB, p1 = min(c1, sB + nwin) - sB;
                 const bool pv = row_from_pile && (uint32_t) a < npr && p0 < p1 && kpos >= sB;
                 k = row_from_pile ? pk[a] : k;
@@ -726,7 +938,7 @@ __global__ void __launch_bounds__(256) k_pile_deg(int32_t n, unsigned long long 
 bool pile_plan(const PrefSufCfg &cfg, const ClusterCfg &cc, int eq, int uniform_len, bool masks) {
     if (eq != PILE_EQ || uniform_len <= 0 || masks || cfg.stats) return false;
     if (uniform_len > 144 || blocks_of(uniform_len) > 9) return false;
-    if (uniform_len - cfg.Lmin + 1 > 64 || cc.w > 64 || cc.kk > 32 || cc.kk < 1) return false;
+    if (uniform_len - cfg.Lmin + 1 > 64 || cc.w > 64 || cc.w < 16 || cc.kk > 32 || cc.kk < 1) return false;      // (w >= 16: k_pile_runs_consensus sweeps a pile's windows in pieces of whole row words)
     return true;
 }
 size_t pile_record_bytes(uint64_t n) { return (size_t) (n + 2) * 64; }
@@ -745,23 +957,49 @@ __global__ void k_pile_sample_close(unsigned long long *__restrict__ pile_cnt) {
 // array -- its kernels take the rows by id -- and that kernel, like the pairwise probes, reads the two counters and leaves at once.
 void launch_pile_sample(const NodesDev &nd, const ClusterCfg &cc, int uniform_len, const uint32_t *skeys, const uint32_t *sids, const void *dir, unsigned long long *pile_cnt,
                         bool no_sample, hipStream_t s) {
-    (void) hipMemsetAsync(pile_cnt, 0, 3 * sizeof(unsigned long long), s);
+    (void) hipMemsetAsync(pile_cnt, 0, PILE_CNT_WORDS * sizeof(unsigned long long), s);
     const uint64_t n_entries = nd.n > 0 ? (uint64_t) nd.n : 0;
     if (n_entries == 0 || no_sample) return;               // (no_sample -- tests only: the two counters stay zero and the pile kernels take the build whatever its buckets look like)
     const uint64_t tiles = (n_entries + PB_TILE - 1) / PB_TILE;
     const dim3 sample((unsigned) std::max<uint64_t>(1, std::min<uint64_t>(tiles, std::max<uint64_t>(64, tiles / 32)))), block(PB_THREADS);
-    hipLaunchKernelGGL((k_pile_build<true>), sample, block, 0, s, nd, skeys, sids, n_entries, (const uint4 *) dir, cc, uniform_len, (uint4 *) nullptr, (uint4 *) nullptr, 0u, (uint4 *) nullptr, pile_cnt);
+    hipLaunchKernelGGL((k_pile_build<true>), sample, block, 0, s, nd, skeys, sids, n_entries, (const uint4 *) dir, cc, uniform_len, (uint4 *) nullptr, (uint4 *) nullptr, 0u, (uint4 *) nullptr, pile_cnt,
+                       (uint32_t *) nullptr);
     hipLaunchKernelGGL(k_pile_sample_close, dim3(1), dim3(1), 0, s, pile_cnt);
 }
 
-void launch_pile_build(const NodesDev &nd, const ClusterCfg &cc, int uniform_len, const uint32_t *skeys, const uint32_t *sids, const void *dir, void *rec, void *tab, uint32_t epoch,
-                       void *side, const void *runs, int nwin, const unsigned long long *pile_cnt, hipStream_t s) {
+// own_mask != null: the run lists come from the consensus (k_pile_runs_consensus) and the entries that read a list of their own are noted
+// in own_mask (zeroed here); null: round 4's form -- the pile's list joined from the own lists of its two outer members (k_pile_runs: every node
+// must have its run list then)
+void launch_pile_build(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterCfg &cc, int uniform_len, const uint32_t *skeys, const uint32_t *sids, const void *dir, void *rec, void *tab,
+                       uint32_t epoch, void *side, const void *runs, int nwin, const unsigned long long *pile_cnt, uint32_t *own_mask, hipStream_t s) {
     const uint64_t n_entries = nd.n > 0 ? (uint64_t) nd.n : 0;
     if (n_entries == 0) return;
     const uint64_t tiles = (n_entries + PB_TILE - 1) / PB_TILE;
+    if (own_mask) (void) hipMemsetAsync(own_mask, 0, pile_own_mask_bytes(n_entries), s);
     hipLaunchKernelGGL((k_pile_build<false>), dim3((unsigned) tiles), dim3(PB_THREADS), 0, s, nd, skeys, sids, n_entries, (const uint4 *) dir, cc, uniform_len, (uint4 *) rec, (uint4 *) tab, epoch,
-                       (uint4 *) side, const_cast<unsigned long long *>(pile_cnt));
-    hipLaunchKernelGGL(k_pile_runs, dim3((unsigned) ((n_entries + 255) / 256)), dim3(256), 0, s, (const uint4 *) side, n_entries, cc.n_buckets, (uint4 *) tab, (const uint2 *) runs, nd.n, nwin, pile_cnt);
+                       (uint4 *) side, const_cast<unsigned long long *>(pile_cnt), own_mask);
+    if (own_mask)
+        hipLaunchKernelGGL(k_pile_runs_consensus, dim3((unsigned) ((n_entries + PR_TILE - 1) / PR_TILE)), dim3(TK_ROWS), 0, s, (const uint4 *) side, n_entries, cc.n_buckets, (uint4 *) tab, cc,
+                           uniform_len, cfg.Lmin, pile_cnt, own_mask);
+    else
+        hipLaunchKernelGGL(k_pile_runs, dim3((unsigned) ((n_entries + 255) / 256)), dim3(256), 0, s, (const uint4 *) side, n_entries, cc.n_buckets, (uint4 *) tab, (const uint2 *) runs, nd.n, nwin, pile_cnt);
+}
+
+size_t pile_own_mask_bytes(uint64_t n) { return (size_t) ((n + 31) / 32 + 1024) * 4; }
+
+// the ids of the entries own_mask names -> list (dense; *count = how many: pile_cnt + 3, zeroed by launch_pile_sample)
+void launch_pile_own_ids(const uint32_t *own_mask, const uint32_t *sids, uint64_t n_entries, int32_t *list, uint32_t cap, unsigned long long *pile_cnt, hipStream_t s) {
+    if (n_entries == 0) return;
+    const uint64_t words = (n_entries + 31) / 32;
+    hipLaunchKernelGGL(k_pile_own_ids, dim3((unsigned) ((words + 1023) / 1024)), dim3(256), 0, s, own_mask, sids, n_entries, list, cap, pile_cnt + 3, (const unsigned long long *) pile_cnt);
+}
+
+// test harness: members checked / members whose own list differs from their pile's clipped list -> pile_cnt[4], pile_cnt[5]
+void launch_pile_check(const void *side, uint64_t n_entries, uint32_t n_buckets, const void *tab, uint32_t epoch, const void *runs, int n_nodes, int nwin, unsigned long long *pile_cnt,
+                       hipStream_t s) {
+    if (n_entries == 0) return;
+    hipLaunchKernelGGL(k_pile_list_check, dim3((unsigned) ((n_entries + 255) / 256)), dim3(256), 0, s, (const uint4 *) side, n_entries, n_buckets, (const uint4 *) tab, epoch, (const uint2 *) runs,
+                       n_nodes, nwin, pile_cnt + 4, (const unsigned long long *) pile_cnt);
 }
 
 void launch_pile_probe(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterCfg &cc, int uniform_len, const void *tab, uint32_t epoch, const void *rec,

@@ -43,7 +43,8 @@ class PrefSufStats(C.Structure):
                 ("nodes_live", C.c_uint64), ("reduction_used", C.c_uint64), ("generic_sources", C.c_uint64),
                 ("big_sources", C.c_uint64), ("probe_used", C.c_uint64), ("deferred_sources", C.c_uint64), ("ms_probe_pairs", C.c_double),
                 ("ms_keys", C.c_double), ("ms_sort", C.c_double), ("ms_gather", C.c_double), ("ms_dir", C.c_double), ("probe_rounds", C.c_uint64), ("ms_pile", C.c_double),
-                ("pile_buckets", C.c_uint64), ("pile_irregular", C.c_uint64)]
+                ("pile_buckets", C.c_uint64), ("pile_irregular", C.c_uint64), ("pile_list_checked", C.c_uint64), ("pile_list_mismatch", C.c_uint64),
+                ("pile_own_lists", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}

@@ -133,6 +133,10 @@ typedef struct {
                                      is more: a bucket of a high-coverage read set stands for more pairwise work saved) / those of them the pile path does
                                      not take (a source with a run in such a bucket goes to the general kernel); more than 1 in
                                      ALGA_PILE_IRREGULAR_ONE_IN irregular: the pairwise kernel k_probe_stream took the build instead of k_pile_probe */
+    uint64_t pile_list_checked, pile_list_mismatch;   /* option "pile_check" (tests): first-group members whose own run list was compared with their pile's
+                                     consensus-derived list clipped to their windows / those for which the two differ (must be 0) */
+    uint64_t pile_own_lists;      /* pile path (option pile_runs): entries of the key order that read a run list of their OWN -- outside a first group, or members of a
+                                     pile whose consensus gave no list -- and got it from the list-driven key pass (0: every node's list was made up front) */
 } alga_prefsuf_stats;
 /* The pile path keeps a build iff  pile_irregular * ALGA_PILE_IRREGULAR_ONE_IN <= pile_buckets  (decided on the device; pile_buckets as reported: raised to
  * an eighth of the sample's entries at high coverage).  Every source with a run in an
@@ -155,6 +159,12 @@ int         alga_engine_device_name(const alga_engine *e, char *buf, size_t bufl
  *   "pile"                       default 1: reads of one length without masks take the probe through PILES (alga_amd/csrc/prefsuf_pile.hip): one compare
  *                                of a source against the consensus of a minimizer's targets instead of one per target; 0: always the pairwise kernels;
  *                                2 (tests only): without the sample that leaves reads with errors to the pairwise kernels
+ *   "pile_runs"                  default 1: the run list of a pile (what its members probe with) is computed from the pile's CONSENSUS, once per pile
+ *                                (k_pile_runs_consensus), and the key pass of a build the pile path keeps makes the target keys alone -- own run lists
+ *                                only for the entries outside a first group and the sources handed to the general kernel; 0: round 4's form (every
+ *                                node its own list, a pile's list joined from its two outer members')
+ *   "pile_check"                 tests only.  != 0: every node gets its own run list as well and every first-group member's is compared with its pile's list
+ *                                clipped to the member's windows (alga_prefsuf_stats.pile_list_checked / pile_list_mismatch)
  *   "pile_skip_gather"           default 1: a build the pile path keeps has no entry array (the rows in key order, 48 bytes per node: its kernels
  *                                read the rows by id, and the copy alone costs 3 ms per 90 M nodes); 0: the entry array is always built
  *   "cluster_order"              default 1: k_probe_stream takes the sources in the order of the entry array (sources of one locus together:

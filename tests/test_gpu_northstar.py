@@ -109,6 +109,16 @@ def test_north_star_50M_reads_properties(config, nodes, edges):
             assert int(pl.shape[0]) == edges
             assert torch.equal(cl, pl), "pile path and pairwise kernels disagree at %s (build %d)" % (config, rep)
             del pl
+        # the parity harness of the consensus-derived run lists at this size: every first-group member's own list (k_node_runs) against its
+        # pile's list clipped to the member's windows -- not one may differ (tests/test_gpu_pile.py: the same on the small inputs)
+        eng.set_option("pile_check", 1)
+        try:
+            pl, stp = _build(eng, wl, "auto", collect_stats=False)
+        finally:
+            eng.set_option("pile_check", 0)
+        assert _pile_kept(stp) and torch.equal(cl, pl)
+        assert stp["pile_list_checked"] > n // 2 and stp["pile_list_mismatch"] == 0, stp
+        del pl
     finally:
         eng.close()
 

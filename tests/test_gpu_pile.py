@@ -28,15 +28,29 @@ def eng():
 def _three_ways(eng, words, lens, lo, rs, af=None, at=None):
     want, _, _ = O.prefsuf(words, lens, lo, rs, af, at)
     out = {}
-    for pile in (1, 2, 0):                                     # 2 (tests only): without the sample -- the pile kernels take the build however irregular its buckets are
+    # pile 2 (tests only): without the sample -- the pile kernels take the build however irregular its buckets are.  pile_runs 0: round 4's form (every
+    # node its own run list, a pile's list joined from its outer members'); 1: the list from the pile's consensus, target keys only in the key pass.
+    # pile_check: every node's own list as well, and every first-group member's compared with its pile's list clipped to its windows.
+    for pile, pile_runs, check in ((1, 1, 0), (2, 1, 0), (1, 0, 0), (2, 1, 1), (0, 1, 0)):
         eng.set_option("pile", pile)
+        eng.set_option("pile_runs", pile_runs)
+        eng.set_option("pile_check", check)
         try:
             got = eng.prefsuf_host(words, lens, lo, rs, af, at, reduction="source_side")
         finally:
             eng.set_option("pile", 1)
+            eng.set_option("pile_runs", 1)
+            eng.set_option("pile_check", 0)
         st = eng.last_stats()
-        assert got.shape == want.shape and (got == want).all(), ("pile", pile, got.shape, want.shape)
+        assert got.shape == want.shape and (got == want).all(), ("pile", pile, "pile_runs", pile_runs, got.shape, want.shape)
         assert st["edges"] == len(want)
+        if check:
+            assert st["pile_list_mismatch"] == 0, st
+            assert (st["pile_list_checked"] > 0) == (st["ms_pile"] > 0)
+            continue
+        if pile_runs == 0:
+            assert (st["ms_pile"] > 0) == (out[1]["ms_pile"] > 0)
+            continue
         out[pile] = st
     assert out[0]["pile_buckets"] == 0 and out[0]["ms_pile"] == 0.0
     assert (out[2]["ms_pile"] > 0) == (out[1]["ms_pile"] > 0)       # forced or not, the same inputs are the pile path's
@@ -260,3 +274,47 @@ def test_a_further_piece_after_a_build_the_pile_path_declined(eng):
             got = device_view(ptr, (m, 3), dw.device).cpu().numpy()
             sel = want[want[:, 0] < half]
             assert got.shape == sel.shape and (got == sel).all()
+
+
+@pytest.mark.parametrize("length,coverage,G", [(150, 30, 400_000), (150, 8, 300_000), (100, 40, 200_000), (150, 120, 60_000), (132, 25, 200_000)])
+def test_consensus_run_lists_equal_the_members_own(eng, length, coverage, G):
+    """The parity harness of the consensus-derived run lists (k_pile_runs_consensus): with option pile_check every node gets its own run list
+    (k_node_runs, as in round 4) AND the piles get theirs from the consensus; a kernel then clips the pile's list to the windows of each
+    first-group member and compares it with the member's own, run for run (cluster key, k-mer position, window range).  Not one may differ:
+    a pile list that differs from a member's own would make the probe look in the wrong buckets and lose overlaps silently."""
+    words, lens = _nodes(G * coverage // length, length, G, 900 + length + coverage)
+    lo, rs = alga_amd.derive_params(float(length - 6))
+    want, _, _ = O.prefsuf(words, lens, lo, rs)
+    eng.set_option("pile_check", 1)
+    try:
+        got = eng.prefsuf_host(words, lens, lo, rs)
+    finally:
+        eng.set_option("pile_check", 0)
+    st = eng.last_stats()
+    assert got.shape == want.shape and (got == want).all()
+    live = int((lens > 0).sum())
+    assert st["pile_list_checked"] > live // 2, (st["pile_list_checked"], live)      # most nodes are members of a first group with a list
+    assert st["pile_list_mismatch"] == 0, st
+    # and the build as it is timed (target keys only in the key pass): same graph, nearly every source finished by the pile kernels
+    got = eng.prefsuf_host(words, lens, lo, rs)
+    st = eng.last_stats()
+    assert got.shape == want.shape and (got == want).all()
+    assert st["pile_buckets"] > 0 and st["deferred_sources"] <= live // 10
+
+
+def test_declined_then_kept_then_declined(eng):
+    """Where the run lists come from is laid out from the verdict of the build BEFORE (a declined build makes every node's list up front, a kept
+    one only where a list is read; the first build of either kind makes them behind the sample): reads with errors, clean reads and reads with
+    errors again through one engine -- every transition -- against the oracle."""
+    lo, rs = alga_amd.derive_params(144.0)
+    sets = []
+    for err, seed in ((0.02, 61), (0.0, 62), (0.02, 63), (0.02, 64), (0.0, 65), (0.0, 66)):
+        words, lens = _nodes(10_000, 150, 40_000, seed, err=err)
+        want, _, _ = O.prefsuf(words, lens, lo, rs)
+        sets.append((err, words, lens, want))
+    for err, words, lens, want in sets:
+        got = eng.prefsuf_host(words, lens, lo, rs)
+        st = eng.last_stats()
+        assert got.shape == want.shape and (got == want).all(), err
+        kept = st["pile_irregular"] * alga_amd.engine.PILE_IRREGULAR_ONE_IN <= st["pile_buckets"]
+        assert st["pile_buckets"] > 0 and kept == (err == 0.0)
