@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -542,6 +543,8 @@ int build_local(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t s
     return ALGA_OK;
 }
 
+double now_ms_host() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 float ev_ms(alga_engine *e, int a, int b) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, e->ev[a], e->ev[b]) != hipSuccess) return 0.f;
@@ -835,31 +838,66 @@ static int upload_nodes_impl(alga_engine *e, const alga_nodes *nodes, alga_nodes
     hipStream_t s = e->own_stream;
     int rc;
     const size_t n = (size_t) nodes->n;
-    {   // the caller's rows must hold the caller's reads (checked here: the upload below changes the stride).  90 M lengths are 0.36 GB:
-        // one core needs ~30 ms for the maximum, eight need four
-        int32_t max_len = 0;
+    // ONE parallel pass over the lengths (0.36 GB at 90 M nodes: a single core needs 30 ms for it, eight need four): the longest read -- the
+    // caller's rows must hold the caller's reads, the upload below changes the stride -- and, for twin rows, that node 2k is removed (0) or
+    // as long as node 2k + 1, from which it is rebuilt.  For large node sets it runs BESIDE the upload of the rows (which does not depend on
+    // it; a node set it refuses has then travelled for nothing).
+    const double t_check0 = now_ms_host();
+    int32_t max_len = 0;
+    if (twin_rows && (n & 1)) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "twin_rows: the node count must be even");
+    const char *check_msg = nullptr;                       // (written by the checking thread, read after its join)
+    double check_ms = 0.0;
+    auto check = [&]() {
         const int T = n >= (1u << 22) ? 8 : 1;
-        if (T == 1) { for (size_t i = 0; i < n; i++) max_len = std::max(max_len, nodes->len[i]); }
-        else {
-            int32_t part[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            std::vector<std::thread> th;
-            auto job = [&](int t) { int32_t m = 0; for (size_t i = n * (size_t) t / T, z = n * (size_t) (t + 1) / T; i < z; i++) m = std::max(m, nodes->len[i]); part[t] = m; };
-            try { for (int t = 1; t < T; t++) th.emplace_back(job, t); } catch (...) { }
-            job(0);
-            for (size_t t = th.size() + 1; t < (size_t) T; t++) job((int) t);       // (threads that could not be started: their share here)
-            for (std::thread &x : th) x.join();
-            for (int t = 0; t < T; t++) max_len = std::max(max_len, part[t]);
-        }
-        if ((int64_t) blocks_of(max_len) > (int64_t) nodes->stride_words)
-            return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "stride_words is smaller than the longest read needs");
-    }
-    if (twin_rows) {
-        // node 2k is rebuilt from node 2k + 1: it must be removed (0) or as long as its twin
-        if (n & 1) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "twin_rows: the node count must be even");
-        for (size_t k = 0; k + 1 < n; k += 2)
-            if (nodes->len[k] != 0 && nodes->len[k] != nodes->len[k + 1])
-                return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "twin_rows: node 2k is neither removed nor as long as node 2k + 1");
-    }
+        int32_t part[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        char bad[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        auto job = [&](int t) {
+            int32_t m = 0; char b = 0;
+            size_t i0 = n * (size_t) t / T, i1 = n * (size_t) (t + 1) / T;
+            i0 &= ~(size_t) 1; if (t + 1 < T) i1 &= ~(size_t) 1;              // whole pairs
+            if (twin_rows) { for (size_t i = i0; i + 1 < i1 + 1 && i + 1 < n; i += 2) { const int32_t a = nodes->len[i], c = nodes->len[i + 1]; m = std::max(m, std::max(a, c)); b |= (a != 0 && a != c); } }
+            else for (size_t i = i0; i < i1; i++) m = std::max(m, nodes->len[i]);
+            part[t] = m; bad[t] = b;
+        };
+        std::vector<std::thread> th;
+        try { for (int t = 1; t < T; t++) th.emplace_back(job, t); } catch (...) { }
+        job(0);
+        for (size_t t = th.size() + 1; t < (size_t) T; t++) job((int) t);       // (threads that could not be started: their share here)
+        for (std::thread &x : th) x.join();
+        bool any_bad = false;
+        int32_t mx = 0;
+        for (int t = 0; t < T; t++) { mx = std::max(mx, part[t]); any_bad = any_bad || bad[t]; }
+        max_len = mx;
+        if ((int64_t) blocks_of(mx) > (int64_t) nodes->stride_words) check_msg = "stride_words is smaller than the longest read needs";
+        else if (any_bad) check_msg = "twin_rows: node 2k is neither removed nor as long as node 2k + 1";
+        check_ms = now_ms_host() - t_check0;
+    };
+    struct Joiner { std::thread t; ~Joiner() { if (t.joinable()) t.join(); } } chk;
+    bool async_check = n >= (1u << 22);
+    if (async_check) { try { chk.t = std::thread(check); } catch (...) { async_check = false; } }
+    if (!async_check) { check(); if (check_msg) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, check_msg); }
+    const double t_up0 = now_ms_host();
+    // the lengths cross PCIe as narrow as they are: a byte per node where no read is longer than 255 nt (every short-read set: 0.09 GB instead
+    // of 0.36 GB at 90 M nodes), two up to 65 535; narrowed by the staging threads on their way into the pinned buffers, widened on the device
+    auto upload_len = [&]() -> int {
+        int r;
+        const int len_bytes = max_len <= 255 ? 1 : (max_len <= 65535 ? 2 : 4);
+        if (len_bytes == 4 || n < (1u << 20)) return alga_staged_h2d(e, e->up_len.p, nodes->len, n * sizeof(int32_t));
+        if ((r = alga_ensure(e, e->up_len_narrow, n * (size_t) len_bytes + 16))) return r;
+        const int32_t *src = nodes->len;
+        const AlgaStageFill fill = [src, len_bytes](void *dst, size_t off, size_t bytes) {
+            if (len_bytes == 1) { uint8_t *d = (uint8_t *) dst; const int32_t *p = src + off; for (size_t i = 0; i < bytes; i++) d[i] = (uint8_t) p[i]; }
+            else { uint16_t *d = (uint16_t *) dst; const int32_t *p = src + off / 2; for (size_t i = 0; i < bytes / 2; i++) d[i] = (uint16_t) p[i]; }
+        };
+        if ((r = alga_staged_h2d_fill(e, e->up_len_narrow.p, n * (size_t) len_bytes, fill))) return r;
+        launch_widen_len(e->up_len_narrow.p, len_bytes, (int32_t *) e->up_len.p, (uint64_t) n, s);
+        return alga_check_launch(e, "k_widen_len");
+    };
+    // what the rows' upload waits for: the check (when it runs beside it) -- before anything reads max_len
+    auto join_check = [&]() -> int {
+        if (chk.t.joinable()) chk.t.join();
+        return check_msg ? alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, check_msg) : ALGA_OK;
+    };
     // Rows travel at the caller's stride through pinned staging buffers (staging.hip) and are re-strided on the DEVICE.
     const int stride_up = alga::hbm_row_stride(nodes->stride_words);
     const size_t wbytes = n * (size_t) stride_up * sizeof(uint32_t);
@@ -871,10 +909,11 @@ static int upload_nodes_impl(alga_engine *e, const alga_nodes *nodes, alga_nodes
     if (n) {
         HIP_TRY(e, hipStreamSynchronize(s));                       // nothing of an earlier call still reads the upload buffers
         if (twin_rows) {
-            // half of the rows cross PCIe; the lengths first (the expansion reads them)
+            // half of the rows cross PCIe; then the lengths (the expansion reads them)
             if ((rc = alga_ensure(e, e->up_raw, raw_bytes))) return rc;
-            if ((rc = alga_staged_h2d(e, e->up_len.p, nodes->len, n * sizeof(int32_t)))) return rc;
             if ((rc = alga_staged_h2d(e, e->up_raw.p, nodes->words, raw_bytes))) return rc;
+            if ((rc = join_check())) return rc;
+            if ((rc = upload_len())) return rc;
             launch_expand_twins((const uint32_t *) e->up_raw.p, nodes->stride_words, (const int32_t *) e->up_len.p, (uint32_t *) e->up_words.p, stride_up, (uint64_t) (n / 2), s);
             if ((rc = alga_check_launch(e, "k_expand_twins"))) return rc;
             HIP_TRY(e, hipStreamSynchronize(s));
@@ -886,8 +925,11 @@ static int upload_nodes_impl(alga_engine *e, const alga_nodes *nodes, alga_nodes
             if ((rc = alga_check_launch(e, "k_restride"))) return rc;
             HIP_TRY(e, hipStreamSynchronize(s));
         } else if ((rc = alga_staged_h2d(e, e->up_words.p, nodes->words, raw_bytes))) return rc;
-        if (!twin_rows && (rc = alga_staged_h2d(e, e->up_len.p, nodes->len, n * sizeof(int32_t)))) return rc;
+        if ((rc = join_check())) return rc;
+        if (!twin_rows) { if ((rc = upload_len())) return rc; HIP_TRY(e, hipStreamSynchronize(s)); }
     }
+    if ((rc = join_check())) return rc;
+    e->stats_host[0] = check_ms;
     dn.stride_words = stride_up;
     dn.words = (const uint32_t *) e->up_words.p;
     dn.len = (const int32_t *) e->up_len.p;
@@ -902,6 +944,7 @@ static int upload_nodes_impl(alga_engine *e, const alga_nodes *nodes, alga_nodes
         dn.align_to = (const uint8_t *) e->up_to.p;
     }
     *dev = dn;
+    e->stats_host[1] = now_ms_host() - t_up0;
     return ALGA_OK;
 }
 
@@ -930,10 +973,91 @@ int alga_prefsuf_build_host(alga_engine *e, const alga_nodes *nodes, const alga_
     if (rc) return rc;
     const alga_edge *d_edges = nullptr;
     uint64_t E = 0;
+    const double t0 = now_ms_host();
     if ((rc = alga_prefsuf_build_device(e, &dn, p, (void *) e->own_stream, &d_edges, &E))) return rc;
+    const double t1 = now_ms_host();
     if ((rc = alga_download_edges(e, d_edges, E, edges))) return rc;
     *n_edges = E;
+    e->stats.host_ms_check = e->stats_host[0]; e->stats.host_ms_upload = e->stats_host[1]; e->stats.host_ms_build = t1 - t0; e->stats.host_ms_download = now_ms_host() - t1;
     return ALGA_OK;
+}
+
+// An edge list on the device (grouped by src: a build's result, or the supplement's) -> host, in COMPACT form: a byte per node (out-degree), per
+// edge its neighbour (4 bytes) and its offset (1 byte), lists in node order -- 5.1 bytes per edge on the way down instead of 12 (0.56 GB instead
+// of 1.1 GB at the north-star size: the host entry point is PCIe-bound).  ALGA_ERR_UNSUPPORTED where a degree or an offset does not fit a byte.
+int alga_download_edges_compact(alga_engine *e, int32_t n_nodes, const alga_edge *d_edges, uint64_t E, alga_compact_edges *out) {
+    if (!e) return ALGA_ERR_INVALID_ARGUMENT;
+    e->err.clear();
+    if (!out) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "output must not be NULL");
+    memset(out, 0, sizeof(*out));
+    if (n_nodes < 0 || (E && !d_edges)) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "bad edge list");
+    HIP_TRY(e, hipSetDevice(e->device));
+    hipStream_t s = e->own_stream;
+    int rc;
+    const size_t n = (size_t) n_nodes;
+    if ((rc = alga_ensure(e, e->counters, (CNT_TOTAL + 2) * sizeof(unsigned long long)))) return rc;
+    if ((rc = alga_ensure(e, e->cp_deg, n + 16))) return rc;
+    if ((rc = alga_ensure(e, e->cp_dst, (size_t) (E + 4) * sizeof(uint32_t)))) return rc;
+    if ((rc = alga_ensure(e, e->cp_off, (size_t) E + 16))) return rc;
+    unsigned long long *bad = (unsigned long long *) e->counters.p + CNT_TOTAL + 1;
+    HIP_TRY(e, hipMemsetAsync(bad, 0, sizeof(unsigned long long), s));
+    launch_compact_edges((const alga_edge_dev *) d_edges, n_nodes, E, (uint8_t *) e->cp_deg.p, (uint32_t *) e->cp_dst.p, (uint8_t *) e->cp_off.p, bad, s);
+    if ((rc = alga_check_launch(e, "k_compact_edges"))) return rc;
+    HIP_TRY(e, hipMemcpyAsync(&e->h_counters[CNT_TOTAL + 1], bad, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    HIP_TRY(e, hipStreamSynchronize(s));
+    if (e->h_counters[CNT_TOTAL + 1] != 0) return alga_fail(e, ALGA_ERR_UNSUPPORTED, "compact edges: an out-degree or an offset does not fit a byte; take the edge triples");
+    // one host block: [dst: 4 E][off: E][deg: n], each part 64-byte aligned
+    const size_t o_off = (((size_t) E * 4) + 63) & ~(size_t) 63, o_deg = (o_off + (size_t) E + 63) & ~(size_t) 63, total = o_deg + n + 64;
+    char *h = (char *) alga_host_list_take(e, total);
+    if (!h) return alga_fail(e, ALGA_ERR_OUT_OF_MEMORY, "host edge buffer");
+    if ((E && ((rc = alga_staged_d2h(e, h, e->cp_dst.p, (size_t) E * 4)) || (rc = alga_staged_d2h(e, h + o_off, e->cp_off.p, (size_t) E)))) ||
+        (n && (rc = alga_staged_d2h(e, h + o_deg, e->cp_deg.p, n)))) { alga_host_list_give(e, h); return rc; }
+    out->n_nodes = n_nodes; out->n_edges = E;
+    out->dst = (const uint32_t *) h; out->offset = (const uint8_t *) (h + o_off); out->degree = (const uint8_t *) (h + o_deg);
+    return ALGA_OK;
+}
+
+// The build of alga_prefsuf_build_host with the graph handed back in that form.
+int alga_prefsuf_build_host_compact(alga_engine *e, const alga_nodes *nodes, const alga_prefsuf_params *p, alga_compact_edges *out) {
+    if (!e) return ALGA_ERR_INVALID_ARGUMENT;
+    e->err.clear();
+    if (!out) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "output must not be NULL");
+    memset(out, 0, sizeof(*out));
+    if (!nodes || !p) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "nodes/params must not be NULL");
+    alga_nodes dn;
+    int rc = upload_nodes_impl(e, nodes, &dn, p->twin_rows != 0);
+    if (rc) return rc;
+    const alga_edge *d_edges = nullptr;
+    uint64_t E = 0;
+    const double t0 = now_ms_host();
+    if ((rc = alga_prefsuf_build_device(e, &dn, p, (void *) e->own_stream, &d_edges, &E))) return rc;
+    const double t1 = now_ms_host();
+    if ((rc = alga_download_edges_compact(e, nodes->n, d_edges, E, out))) return rc;
+    e->stats.host_ms_check = e->stats_host[0]; e->stats.host_ms_upload = e->stats_host[1]; e->stats.host_ms_build = t1 - t0; e->stats.host_ms_download = now_ms_host() - t1;
+    return ALGA_OK;
+}
+
+void alga_free_compact_edges(alga_engine *e, alga_compact_edges *c) {
+    if (!c) return;
+    alga_host_list_give(e, const_cast<uint32_t *>(c->dst));
+    memset(c, 0, sizeof(*c));
+}
+
+// Host memory the DMA engines read and write directly (pinned): node arrays allocated here go up without the copy through the engine's staging
+// buffers, and nothing else about them differs from malloc'ed memory.  (Allocation itself is slow -- the pages are mapped and locked: seconds
+// per ten GB -- an assembler asks once, while it still parses.)
+void *alga_host_alloc(alga_engine *e, size_t bytes) {
+    if (!e) return nullptr;
+    e->err.clear();
+    DeviceGuard guard;
+    if (hipSetDevice(e->device) != hipSuccess) return nullptr;
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 16) != hipSuccess) { (void) hipGetLastError(); alga_fail(e, ALGA_ERR_OUT_OF_MEMORY, "alga_host_alloc"); return nullptr; }
+    return p;
+}
+void alga_host_free(alga_engine *e, void *p) {
+    (void) e;
+    if (p) (void) hipHostFree(p);
 }
 
 void alga_free_edges(alga_engine *e, alga_edge *edges) { alga_host_list_give(e, edges); }

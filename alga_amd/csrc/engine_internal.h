@@ -76,6 +76,8 @@ struct alga_engine {
     int    big_limit = -1;                                  // largest per-wave item slice of that pass; -1 = built-in (option "local_big_max": tests)
     DevBuf edge_keys, edge_keys2, edge_vals, edge_vals2, edges_sorted, xs_dst, xs_val;
     DevBuf up_words, up_len, up_from, up_to;   // uploads of the host-buffer entry points
+    DevBuf up_len_narrow;                      // ... the lengths as they cross PCIe (one or two bytes per node), widened on the device
+    DevBuf cp_deg, cp_dst, cp_off;             // compact edge list (alga_prefsuf_build_host_compact): degree bytes, neighbours, offset bytes
     // approximate supplement (engine_pkb.hip)
     DevBuf pk_keys, pk_keys2, pk_vals, pk_vals2, pk_marks, pk_big, pk_add, pk_ekeys, pk_ekeys2, pk_flag, pk_pos, pk_edges[2], pk_rowptr, pk_deg,
            pk_mask, pk_cnt, pk_io, pk_io2, pk_tips, pk_heads, pk_g[2], pk_addk, pk_addk2, pk_merged, pk_hsz, pk_hsz2, pk_heads2, pk_nadd, pk_koff,
@@ -114,6 +116,7 @@ struct alga_engine {
     unsigned long long *h_counters = nullptr;  // pinned, CNT_TOTAL + 2 entries
     uint64_t    rec_cap_hint = 0, rec_cap_hint_local = 0;
     alga_prefsuf_stats stats;
+    double      stats_host[2] = {0.0, 0.0};   // upload_nodes_impl: wall ms of its checks / of the upload (the host entry points copy them into stats)
     alga_pkb_stats pkb_stats;
 };
 
@@ -175,7 +178,10 @@ inline void alga_release(DevBuf &b) {
     b.p = nullptr; b.cap = 0;
 }
 
+#include <functional>
+typedef std::function<void(void * /* pinned chunk */, size_t /* byte offset of the chunk */, size_t /* bytes */)> AlgaStageFill;
 int  alga_staged_h2d(alga_engine *e, void *d_dst, const void *h_src, size_t bytes);   // staging.hip: blocking
+int  alga_staged_h2d_fill(alga_engine *e, void *d_dst, size_t bytes, const AlgaStageFill &fill);
 int  alga_staged_d2h(alga_engine *e, void *h_dst, const void *d_src, size_t bytes);
 void alga_staging_release(alga_engine *e);
 void *alga_host_list_take(alga_engine *e, size_t bytes);

@@ -10,6 +10,8 @@ namespace alga {
 struct alga_edge_dev { int32_t src, dst, offset; }; // layout == alga_edge of include/alga_amd.h
 
 void launch_restride(const uint32_t *in, int stride_in, uint32_t *out, int stride_out, uint64_t n, hipStream_t s);
+void launch_widen_len(const void *in, int elem_bytes /* 1 or 2 */, int32_t *out, uint64_t n, hipStream_t s);
+void launch_compact_edges(const alga_edge_dev *edges, int32_t n, uint64_t n_edges, uint8_t *deg, uint32_t *dst, uint8_t *off, unsigned long long *bad, hipStream_t s);
 // in: rows of the odd nodes (n_pairs rows); out: 2 n_pairs rows, the even ones = reverse complements over len[2k] nucleotides
 void launch_expand_twins(const uint32_t *in, int stride_in, const int32_t *len /* device, 2 n_pairs */, uint32_t *out, int stride_out, uint64_t n_pairs, hipStream_t s);
 void launch_node_stats(const NodesDev &nd, unsigned long long *counters, int *max_len /* [0] = max length, [1] = INT32_MAX - min length of the live nodes */, hipStream_t s);

@@ -34,7 +34,7 @@ int ensure_staging(alga_engine *e) {
 }
 
 // worker t moves chunks t, t + T, t + 2T, ... ; `to_device`: host -> pinned -> device, else device -> pinned -> host
-void worker(alga_engine *e, int t, int T, char *dev, char *host, size_t bytes, bool to_device, hipError_t *err) {
+void worker(alga_engine *e, int t, int T, char *dev, char *host, size_t bytes, bool to_device, hipError_t *err, const AlgaStageFill *fill) {
     (void) hipSetDevice(e->device);
     hipStream_t s = e->stage_stream[t];
     const size_t n_chunks = (bytes + STAGE_CHUNK - 1) / STAGE_CHUNK;
@@ -53,7 +53,7 @@ void worker(alga_engine *e, int t, int T, char *dev, char *host, size_t bytes, b
         drain(b);                                 // buffer b is free again (its previous DMA is done)
         hipError_t r;
         if (to_device) {
-            memcpy(e->stage_pin[t][b], host + off, len);
+            if (fill) (*fill)(e->stage_pin[t][b], off, len); else memcpy(e->stage_pin[t][b], host + off, len);
             r = hipMemcpyAsync(dev + off, e->stage_pin[t][b], len, hipMemcpyHostToDevice, s);
         } else {
             r = hipMemcpyAsync(e->stage_pin[t][b], dev + off, len, hipMemcpyDeviceToHost, s);
@@ -65,9 +65,21 @@ void worker(alga_engine *e, int t, int T, char *dev, char *host, size_t bytes, b
     drain(0); drain(1);
 }
 
-int staged_copy(alga_engine *e, void *dev, void *host, size_t bytes, bool to_device) {
+// is `p` memory the runtime can DMA from / to directly (hipHostMalloc / hipHostRegister: alga_host_alloc)?
+bool is_pinned(const void *p) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void) hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeHost;
+}
+
+int staged_copy(alga_engine *e, void *dev, void *host, size_t bytes, bool to_device, const AlgaStageFill *fill = nullptr) {
     if (bytes == 0) return ALGA_OK;
-    if (bytes < STAGE_DIRECT || (!e->stage_ready && bytes < STAGE_COLD_MIN)) {
+    if (!fill && bytes >= STAGE_DIRECT && is_pinned(host)) {
+        // the caller's buffer is pinned (alga_host_alloc): the DMA engine takes it as it is -- no copy through staging buffers, no worker threads
+        HIP_TRY(e, to_device ? hipMemcpy(dev, host, bytes, hipMemcpyHostToDevice) : hipMemcpy(host, dev, bytes, hipMemcpyDeviceToHost));
+        return ALGA_OK;
+    }
+    if (!fill && (bytes < STAGE_DIRECT || (!e->stage_ready && bytes < STAGE_COLD_MIN))) {
         HIP_TRY(e, to_device ? hipMemcpy(dev, host, bytes, hipMemcpyHostToDevice) : hipMemcpy(host, dev, bytes, hipMemcpyDeviceToHost));
         return ALGA_OK;
     }
@@ -80,10 +92,11 @@ int staged_copy(alga_engine *e, void *dev, void *host, size_t bytes, bool to_dev
     bool started = true;
     try {
         th.reserve((size_t) T);
-        for (int t = 0; t < T; t++) { errs[t] = hipSuccess; th.emplace_back(worker, e, t, T, (char *) dev, (char *) host, bytes, to_device, &errs[t]); }
+        for (int t = 0; t < T; t++) { errs[t] = hipSuccess; th.emplace_back(worker, e, t, T, (char *) dev, (char *) host, bytes, to_device, &errs[t], fill); }
     } catch (...) { started = false; }
     for (std::thread &x : th) x.join();
     if (!started) {
+        if (fill) return alga_fail(e, ALGA_ERR_HIP, "staged copy: worker threads could not be started");
         HIP_TRY(e, to_device ? hipMemcpy(dev, host, bytes, hipMemcpyHostToDevice) : hipMemcpy(host, dev, bytes, hipMemcpyDeviceToHost));
         return ALGA_OK;
     }
@@ -96,6 +109,8 @@ int staged_copy(alga_engine *e, void *dev, void *host, size_t bytes, bool to_dev
 // both block until the bytes are where they belong; the device side must not be in use by work still in flight
 int alga_staged_h2d(alga_engine *e, void *d_dst, const void *h_src, size_t bytes) { return staged_copy(e, d_dst, const_cast<void *>(h_src), bytes, true); }
 int alga_staged_d2h(alga_engine *e, void *h_dst, const void *d_src, size_t bytes) { return staged_copy(e, const_cast<void *>(d_src), h_dst, bytes, false); }
+// host -> device where the bytes are MADE chunk by chunk (fill(pinned chunk, byte offset, bytes): e.g. lengths narrowed to a byte on their way)
+int alga_staged_h2d_fill(alga_engine *e, void *d_dst, size_t bytes, const AlgaStageFill &fill) { return staged_copy(e, d_dst, nullptr, bytes, true, &fill); }
 
 // host edge list of at least `bytes`: the spare one if it is large enough, else a new allocation
 void *alga_host_list_take(alga_engine *e, size_t bytes) {

@@ -33,6 +33,11 @@ class PrefSufParams(C.Structure):
                 ("keys_shared", C.c_int32), ("twin_rows", C.c_int32)]
 
 
+class CompactEdges(C.Structure):
+    """alga_compact_edges"""
+    _fields_ = [("n_nodes", C.c_int32), ("n_edges", C.c_uint64), ("degree", C.c_void_p), ("dst", C.c_void_p), ("offset", C.c_void_p)]
+
+
 class PrefSufStats(C.Structure):
     """alga_prefsuf_stats"""
     _fields_ = [("raw_overlaps", C.c_uint64), ("transitive_listed", C.c_uint64), ("transitive_compares", C.c_uint64),
@@ -44,7 +49,8 @@ class PrefSufStats(C.Structure):
                 ("big_sources", C.c_uint64), ("probe_used", C.c_uint64), ("deferred_sources", C.c_uint64), ("ms_probe_pairs", C.c_double),
                 ("ms_keys", C.c_double), ("ms_sort", C.c_double), ("ms_gather", C.c_double), ("ms_dir", C.c_double), ("probe_rounds", C.c_uint64), ("ms_pile", C.c_double),
                 ("pile_buckets", C.c_uint64), ("pile_irregular", C.c_uint64), ("pile_list_checked", C.c_uint64), ("pile_list_mismatch", C.c_uint64),
-                ("pile_own_lists", C.c_uint64)]
+                ("pile_own_lists", C.c_uint64), ("host_ms_check", C.c_double), ("host_ms_upload", C.c_double), ("host_ms_build", C.c_double),
+                ("host_ms_download", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
@@ -149,7 +155,7 @@ EXPORTS = ["alga_abi_version", "alga_engine_set_option", "alga_engine_create", "
            "alga_multi_create", "alga_multi_destroy", "alga_multi_last_error", "alga_multi_engine", "alga_multi_prefsuf_build_host", "alga_multi_prefsuf_build_device",
            "alga_multi_free_edges", "alga_multi_last_stats", "alga_multi_set_option", "alga_upload_twin_nodes",
            "alga_shard_index_device", "alga_shard_join_device", "alga_shard_small_keys_device", "alga_shard_resolve_device", "alga_shard_place_device",
-           "alga_shard_last_stats", "alga_sort_u32_pairs_device"]
+           "alga_shard_last_stats", "alga_sort_u32_pairs_device", "alga_prefsuf_build_host_compact", "alga_download_edges_compact", "alga_free_compact_edges", "alga_host_alloc", "alga_host_free"]
 
 
 def library_path():
@@ -202,6 +208,13 @@ def load_library():
                                             C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
     lib.alga_free_edges.argtypes = [C.c_void_p, C.c_void_p]
     lib.alga_free_edges.restype = None
+    lib.alga_prefsuf_build_host_compact.argtypes = [C.c_void_p, C.POINTER(_Nodes), C.POINTER(PrefSufParams), C.POINTER(CompactEdges)]
+    lib.alga_free_compact_edges.argtypes = [C.c_void_p, C.POINTER(CompactEdges)]
+    lib.alga_free_compact_edges.restype = None
+    lib.alga_host_alloc.argtypes = [C.c_void_p, C.c_size_t]
+    lib.alga_host_alloc.restype = C.c_void_p
+    lib.alga_host_free.argtypes = [C.c_void_p, C.c_void_p]
+    lib.alga_host_free.restype = None
     lib.alga_prefsuf_build_device.argtypes = [C.c_void_p, C.POINTER(_Nodes), C.POINTER(PrefSufParams), C.c_void_p,
                                               C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
     lib.alga_prefsuf_last_stats.argtypes = [C.c_void_p, C.POINTER(PrefSufStats)]
@@ -441,6 +454,48 @@ class Engine:
             return e.reshape(-1, 3).copy()
         finally:
             self._lib.alga_free_edges(self._h, out)
+
+    def host_array(self, shape, dtype):
+        """numpy array over pinned host memory (alga_host_alloc); released when the array's base object goes (alga_host_free)"""
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = self._lib.alga_host_alloc(self._h, n)
+        if not p:
+            raise AlgaError(-1, (self._lib.alga_last_error(self._h) or b"").decode())
+        lib, h = self._lib, self._h
+
+        class _Owner:
+            def __del__(self_inner):
+                lib.alga_host_free(h, p)
+        buf = (C.c_char * n).from_address(p)
+        buf._owner = _Owner()
+        return np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+    def prefsuf_host_compact(self, words, lens, min_overlap, rsoe_min_overlap, twin_rows=False, repeat=1, as_triples=True):
+        """alga_prefsuf_build_host_compact -> (edges int32[m, 3] rebuilt from the compact form (or None), best seconds of the C call alone)"""
+        import time
+        words = np.ascontiguousarray(words, dtype=np.uint32)
+        lens = np.ascontiguousarray(lens, dtype=np.int32)
+        n = int(lens.shape[0])
+        nd = _Nodes(words.ctypes.data, int(words.shape[1]), lens.ctypes.data, n, None, None)
+        p = self.params(min_overlap, rsoe_min_overlap)
+        p.twin_rows = 1 if twin_rows else 0
+        best, edges = None, None
+        for it in range(repeat):
+            out = CompactEdges()
+            t = time.perf_counter()
+            self._check(self._lib.alga_prefsuf_build_host_compact(self._h, C.byref(nd), C.byref(p), C.byref(out)))
+            dt = time.perf_counter() - t
+            best = dt if best is None else min(best, dt)
+            if it == repeat - 1 and as_triples:
+                m = int(out.n_edges)
+                deg = np.ctypeslib.as_array(C.cast(out.degree, C.POINTER(C.c_uint8)), shape=(n,)) if n else np.zeros(0, np.uint8)
+                edges = np.empty((m, 3), dtype=np.int32)
+                if m:
+                    edges[:, 0] = np.repeat(np.arange(n, dtype=np.int32), deg)
+                    edges[:, 1] = np.ctypeslib.as_array(C.cast(out.dst, C.POINTER(C.c_uint32)), shape=(m,)).view(np.int32)
+                    edges[:, 2] = np.ctypeslib.as_array(C.cast(out.offset, C.POINTER(C.c_uint8)), shape=(m,))
+            self._lib.alga_free_compact_edges(self._h, C.byref(out))
+        return edges, best
 
     def prefsuf_host_timed(self, words, lens, min_overlap, rsoe_min_overlap, repeat=3, twin_rows=False, digest=False):
         """Wall time of the C call alone (alga_prefsuf_build_host + alga_free_edges; no Python-side copy of the result):

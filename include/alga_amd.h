@@ -137,6 +137,8 @@ typedef struct {
                                      consensus-derived list clipped to their windows / those for which the two differ (must be 0) */
     uint64_t pile_own_lists;      /* pile path (option pile_runs): entries of the key order that read a run list of their OWN -- outside a first group, or members of a
                                      pile whose consensus gave no list -- and got it from the list-driven key pass (0: every node's list was made up front) */
+    double   host_ms_check, host_ms_upload, host_ms_build, host_ms_download;   /* host entry points (alga_prefsuf_build_host*): wall time of the argument / length
+                                     checks, of the upload (staging, re-stride / twin expansion included), of the build, of the download of the edges */
 } alga_prefsuf_stats;
 /* The pile path keeps a build iff  pile_irregular * ALGA_PILE_IRREGULAR_ONE_IN <= pile_buckets  (decided on the device; pile_buckets as reported: raised to
  * an eighth of the sample's entries at high coverage).  Every source with a run in an
@@ -196,6 +198,29 @@ void        alga_prefsuf_default_params(alga_prefsuf_params *p);
 int  alga_prefsuf_build_host(alga_engine *e, const alga_nodes *nodes, const alga_prefsuf_params *p,
                              alga_edge **edges, uint64_t *n_edges);
 void alga_free_edges(alga_engine *e, alga_edge *edges);
+
+/* The same build with the graph handed back in COMPACT form -- what crosses PCIe on the way down is 5.1 bytes per edge instead of 12 (the host
+ * entry point is PCIe-bound: 0.56 GB instead of 1.1 GB at the north-star size).  Lists in node order: node i owns the next degree[i] entries of
+ * dst[] / offset[] (each list sorted by (dst, offset), as in alga_edge form: src/DataStructures/Graph.cpp:367-387).  ALGA_ERR_UNSUPPORTED where an
+ * out-degree or an offset does not fit a byte (reads longer than min_overlap + 255): take alga_prefsuf_build_host.  One host block, released by
+ * alga_free_compact_edges; alga_adapter::fill_graph_compact turns it into Graph::V. */
+typedef struct {
+    int32_t         n_nodes;
+    uint64_t        n_edges;
+    const uint8_t  *degree;   /* n_nodes */
+    const uint32_t *dst;      /* n_edges */
+    const uint8_t  *offset;   /* n_edges */
+} alga_compact_edges;
+int         alga_prefsuf_build_host_compact(alga_engine *e, const alga_nodes *nodes, const alga_prefsuf_params *p, alga_compact_edges *out);
+/* ... and any edge list on the device (a build's result, the supplement's) brought down in that form: what alga_download_edges is to alga_edge triples */
+int         alga_download_edges_compact(alga_engine *e, int32_t n_nodes, const alga_edge *d_edges, uint64_t n_edges, alga_compact_edges *out);
+void        alga_free_compact_edges(alga_engine *e, alga_compact_edges *c);
+
+/* Pinned host memory (hipHostMalloc): node arrays allocated here are read by the DMA engines as they are -- alga_prefsuf_build_host* and
+ * alga_upload_*nodes then skip the copy through the engine's staging buffers (the pointer is recognised, nothing else changes).  Allocation is slow
+ * (pages are mapped and locked): ask once, while the reads are still being parsed.  NULL on failure (alga_last_error). */
+void       *alga_host_alloc(alga_engine *e, size_t bytes);
+void        alga_host_free(alga_engine *e, void *p);
 
 /* Allocates, ahead of time, every device buffer a build of the exact path needs for a node set of `n_nodes` rows of up to
  * `max_len` nucleotides (and, n_edges_hint > 0, for that many edges; 0 = one per node), and runs a miniature build of the same shape

@@ -23,6 +23,6 @@ print("ms_per_step", d['ms_per_step'], "value", d['value'], "digest_equal", d.ge
 print("roofline", {k: d['roofline'].get(k) for k in ('kernel','frac','basis','kernel_ms','frac_pairwise_equivalent')})
 print("roofline_step", d.get('roofline_step'))
 print("index_build_ms", d.get('index_build_ms'), "phases", d.get('phases_ms'))
-print("e2e", d.get('ms_end_to_end'), d.get('pcie_inclusive',{}).get('edges_digest_equal_resident'))
+pi=d.get("pcie_inclusive",{}); print("e2e", d.get("ms_end_to_end"), d.get("end_to_end_form"), "triples", pi.get("ms_per_graph"), pi.get("phases_ms"), "compact", pi.get("compact_edges",{}).get("ms_per_graph"), pi.get("compact_edges",{}).get("phases_ms"), "pinned", pi.get("compact_edges",{}).get("pinned_node_arrays"))
 PY
 fi
