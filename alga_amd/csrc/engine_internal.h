@@ -11,6 +11,7 @@
 #include "../../include/alga_amd.h"
 #include "prefsuf_common.h"
 #include "prefsuf_kernels.h"
+#include "pkb_kernels.h"
 
 struct DevBuf {
     void  *p = nullptr;
@@ -113,6 +114,16 @@ struct alga_engine {
         unsigned long long *d_vals_sorted = nullptr;
     } sh;
     alga_shard_stats shard_stats{};
+    // the approximate supplement between its phases (engine_pkb.hip: begin / round / merge / end)
+    struct {
+        int      phase = 0;                    // 0 none, 1 between rounds, 2 a round's additions are out, their merge pending
+        int      rounds = 0, round = 0, rank = 0, n_ranks = 1, cur = 0, key_bits = 0;
+        int32_t  prio[4] = {0, 1, 2, 3};
+        uint64_t E = 0, nk = 0;
+        uint32_t n_tips = 0;
+        alga_nodes dn{};
+        alga::PkbCfg cfg{};
+    } pkb;
     unsigned long long *h_counters = nullptr;  // pinned, CNT_TOTAL + 2 entries
     uint64_t    rec_cap_hint = 0, rec_cap_hint_local = 0;
     alga_prefsuf_stats stats;

@@ -503,6 +503,73 @@ int run_build(alga_multi *m, const alga_nodes *per_rank, const alga_prefsuf_para
     return ALGA_OK;
 }
 
+// fn(rank) on one host thread per rank, behind a start gate (no rank touches the barrier before all of them exist); false: a thread could not be started
+template <class F>
+bool run_rank_threads(alga_multi *m, F &&fn) {
+    const int N = m->n;
+    struct Gate { std::mutex mu; std::condition_variable cv; int state = 0; } gate;
+    auto gated = [&](int r) {
+        { std::unique_lock<std::mutex> lk(gate.mu); gate.cv.wait(lk, [&] { return gate.state != 0; }); if (gate.state == 2) return; }
+        fn(r);
+    };
+    std::vector<std::thread> th;
+    bool started = true;
+    try { for (int r = 1; r < N; r++) th.emplace_back(gated, r); } catch (...) { started = false; }
+    { std::lock_guard<std::mutex> lk(gate.mu); gate.state = started ? 1 : 2; }
+    gate.cv.notify_all();
+    if (started) fn(0);
+    for (std::thread &x : th) x.join();
+    return started;
+}
+
+// The approximate supplement on the N ranks of the handle (alga_pkb_shard_*): the exact graph -- complete on rank 0 -- goes to every rank (an
+// all-gather in which rank 0 offers the whole list and the others nothing), then per round every rank joins the k-mer groups it owns, the
+// additions of all ranks are all-gathered and merged by everybody.  All ranks end with the same graph; rank 0's is handed back.
+int run_supplement(alga_multi *m, const alga_nodes *per_rank, const alga_pkb_params *p, const alga_edge *d_edges0, uint64_t n_edges0, const alga_edge **d_out, uint64_t *n_out) {
+    const int N = m->n;
+    m->rc.assign((size_t) N, ALGA_OK);
+    m->rank_err.assign((size_t) N, std::string());
+    m->declined.assign((size_t) N, 0);
+    m->shard_declined.assign((size_t) N, 0);
+    m->x_send.assign((size_t) N, nullptr);
+    m->x_cnt.assign((size_t) N * N, 0); m->x_off.assign((size_t) N * N, 0);
+    std::vector<const alga_edge *> outs((size_t) N, nullptr);
+    std::vector<uint64_t> outn((size_t) N, 0);
+    auto body = [&](int r) {
+        Collectives co{m, r};
+        alga_engine *e = m->eng[(size_t) r];
+        hipStream_t s = m->stream[(size_t) r];
+        (void) hipSetDevice(m->dev[(size_t) r]);
+        auto note = [&](int rc) { if (rc != ALGA_OK) co.fail(rc, alga_last_error(e)); };
+        uint64_t n_all = 0, xb = 0;
+        // the exact graph to everybody (rx_edges[r]: the receive buffer of the edge exchange of the build, free by now)
+        Agreed ag = co.all_gather_v(r == 0 ? (const void *) d_edges0 : nullptr, r == 0 ? n_edges0 : 0, sizeof(alga_edge), m->rx_edges[(size_t) r], &n_all, &xb);
+        if (ag.failed) return;
+        note(alga_pkb_shard_begin(e, &per_rank[r], p, (const alga_edge *) m->rx_edges[(size_t) r].p, n_all, r, N, (void *) s));
+        ag = rendezvous(m);
+        if (ag.failed) return;
+        for (int round = 0; round < p->rounds; round++) {
+            const uint64_t *d_add = nullptr;
+            uint64_t a = 0, a_all = 0;
+            note(alga_pkb_shard_round(e, (void *) s, &d_add, &a));
+            ag = co.all_gather_v(d_add, a, sizeof(uint64_t), m->rx_small[(size_t) r], &a_all, &xb);
+            if (ag.failed) return;
+            note(alga_pkb_shard_merge(e, (const uint64_t *) m->rx_small[(size_t) r].p, a_all, (void *) s));
+            ag = rendezvous(m);
+            if (ag.failed) return;
+        }
+        note(alga_pkb_shard_end(e, (void *) s, &outs[(size_t) r], &outn[(size_t) r]));
+        (void) rendezvous(m);
+    };
+    if (!run_rank_threads(m, body)) return mfail(m, ALGA_ERR_OUT_OF_MEMORY, "cannot start a host thread per GPU");
+    for (int r = 0; r < N; r++)
+        if (m->rc[(size_t) r] != ALGA_OK) return mfail(m, m->rc[(size_t) r], "rank " + std::to_string(r) + ": " + m->rank_err[(size_t) r]);
+    for (int r = 1; r < N; r++)
+        if (outn[(size_t) r] != outn[0]) return mfail(m, ALGA_ERR_HIP, "supplement: the ranks ended with different graphs");
+    *d_out = outs[0]; *n_out = outn[0];
+    return ALGA_OK;
+}
+
 } // namespace
 
 extern "C" {
@@ -634,6 +701,19 @@ int alga_multi_prefsuf_build_host(alga_multi *m, const alga_nodes *nodes, const 
         if (rc == ALGA_OK) { *edges = h; *n_edges = E; }
     }
     m->mstats.ms_upload = t1 - t0; m->mstats.ms_download = m->mstats.ms_gather;
+    if (prev >= 0) (void) hipSetDevice(prev);
+    return rc;
+}
+
+int alga_multi_pkb_supplement_device(alga_multi *m, const alga_nodes *nodes_per_rank, const alga_pkb_params *p, const alga_edge *d_edges_rank0, uint64_t n_edges,
+                                     const alga_edge **d_edges_out, uint64_t *n_edges_out) {
+    if (!m) return ALGA_ERR_INVALID_ARGUMENT;
+    m->err.clear();
+    if (!nodes_per_rank || !p || !d_edges_out || !n_edges_out || (n_edges && !d_edges_rank0)) return mfail(m, ALGA_ERR_INVALID_ARGUMENT, "arguments must not be NULL");
+    *d_edges_out = nullptr; *n_edges_out = 0;
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    const int rc = run_supplement(m, nodes_per_rank, p, d_edges_rank0, n_edges, d_edges_out, n_edges_out);
     if (prev >= 0) (void) hipSetDevice(prev);
     return rc;
 }

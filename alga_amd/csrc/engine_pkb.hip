@@ -101,24 +101,29 @@ int graph_from_edges(alga_engine *e, int32_t n_nodes, const alga_edge_dev *in, u
 
 constexpr uint32_t PKB_FIX_LIST_CAP = 1u << 20;     // places where two hashes share their sorted low bits (k_pkb_fix_flag)
 
-int supplement_device_impl(alga_engine *e, const alga_nodes *dn, const alga_pkb_params *p, const alga_edge *d_edges_in, uint64_t m_in,
-                           hipStream_t s, const alga_edge **d_out, uint64_t *m_out) {
+// The supplement in PHASES (state in e->pkb between them): begin -- graph form, masks, the tips and where their k-mers go; per round: this
+// rank's additions (the pairwise join of the k-mer groups it owns: rank = mix(k-mer key) mod n_ranks; one rank: all of them), then the merge of
+// the additions of ALL ranks into the graph; end -- the graph as an edge list.  One GPU runs them back to back (supplement_device_impl); N ranks
+// exchange the additions between `round` and `merge` (alga_pkb_shard_*, include/alga_amd.h).  The engine's semantics make that exact: every
+// group of a round sees the graph as it was when the round started, and the merge orders by key -- the result does not depend on N.
+int pkb_begin(alga_engine *e, const alga_nodes *dn, const alga_pkb_params *p, const alga_edge *d_edges_in, uint64_t m_in, int rank, int n_ranks, hipStream_t s) {
     int rc;
-    const PkbCfg c = make_cfg(p);
+    auto &st = e->pkb;
+    st.phase = 0;
+    st.cfg = make_cfg(p); st.dn = *dn; st.rounds = p->rounds; st.rank = rank; st.n_ranks = n_ranks; st.round = 0;
     const NodesDev nd = nodes_dev(dn);
     const int32_t n = dn->n;
+    const PkbCfg &c = st.cfg;
     memset(&e->pkb_stats, 0, sizeof(e->pkb_stats));
-    hipEvent_t ev0 = e->ev[EV_START], ev1 = e->ev[EV_EMIT];
-    HIP_TRY(e, hipEventRecord(ev0, s));
+    HIP_TRY(e, hipEventRecord(e->ev[EV_START], s));
     if ((rc = alga_ensure(e, e->pk_cnt, 16 * sizeof(unsigned long long)))) return rc;
     unsigned long long *cnt = (unsigned long long *) e->pk_cnt.p;
-    int cur = 0;
-    uint64_t E = 0;
-    if ((rc = graph_from_edges(e, n, (const alga_edge_dev *) d_edges_in, m_in, e->pk_g[cur], &E, s))) return rc;
+    st.cur = 0; st.E = 0;
+    if ((rc = graph_from_edges(e, n, (const alga_edge_dev *) d_edges_in, m_in, e->pk_g[st.cur], &st.E, s))) return rc;
     // masks from the degrees of the incoming graph, once (src/main.cpp:308-322)
     if ((rc = alga_ensure(e, e->pk_mask, (size_t) n + 16))) return rc;
     if ((rc = alga_ensure(e, e->outdeg, (size_t) (n + 1) * sizeof(uint32_t)))) return rc;
-    launch_pkb_masks(n, (const uint32_t *) e->pk_rowptr.p, (const unsigned long long *) e->pk_g[cur].p, E, (uint32_t *) e->outdeg.p, (uint8_t *) e->pk_mask.p, s);
+    launch_pkb_masks(n, (const uint32_t *) e->pk_rowptr.p, (const unsigned long long *) e->pk_g[st.cur].p, st.E, (uint32_t *) e->outdeg.p, (uint8_t *) e->pk_mask.p, s);
     if ((rc = alga_check_launch(e, "k_pkb_masks"))) return rc;
     // the nodes that take part, as a dense list (the masks are fixed for all rounds), and where their k-mers go
     if ((rc = alga_ensure(e, e->pk_tips, (size_t) (n + 1) * sizeof(uint32_t)))) return rc;
@@ -136,129 +141,178 @@ int supplement_device_impl(alga_engine *e, const alga_nodes *dn, const alga_pkb_
     HIP_TRY(e, hipMemcpyAsync(e->h_counters, (uint64_t *) e->scan_scratch.p + scan_total_index((uint64_t) n), sizeof(uint64_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(e, hipMemcpyAsync(e->h_counters + 1, cnt + 12, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(e, hipStreamSynchronize(s));
-    const uint32_t n_tips = n > 0 ? (uint32_t) e->h_counters[0] : 0u;
+    st.n_tips = n > 0 ? (uint32_t) e->h_counters[0] : 0u;
     if (e->h_counters[1] >= 4096) return alga_fail(e, ALGA_ERR_CAPACITY, "the supplement keeps read lengths in 12 bits: a participating read has 4096 nt or more");
-    uint64_t nk = 0;
-    if (n_tips) {
-        launch_exclusive_scan((const uint32_t *) e->pk_gsz.p, (uint64_t) n_tips, (uint32_t *) e->pk_koff.p, (uint64_t *) e->scan_scratch.p, s);
-        HIP_TRY(e, hipMemcpyAsync(e->h_counters, (uint64_t *) e->scan_scratch.p + scan_total_index((uint64_t) n_tips), sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    st.nk = 0;
+    if (st.n_tips) {
+        launch_exclusive_scan((const uint32_t *) e->pk_gsz.p, (uint64_t) st.n_tips, (uint32_t *) e->pk_koff.p, (uint64_t *) e->scan_scratch.p, s);
+        HIP_TRY(e, hipMemcpyAsync(e->h_counters, (uint64_t *) e->scan_scratch.p + scan_total_index((uint64_t) st.n_tips), sizeof(uint64_t), hipMemcpyDeviceToHost, s));
         HIP_TRY(e, hipStreamSynchronize(s));
-        nk = e->h_counters[0];
+        st.nk = e->h_counters[0];
     }
-    if (nk >= (1ull << 31)) return alga_fail(e, ALGA_ERR_CAPACITY, "more than 2^31 k-mers in the supplement; shard the input");
-    int32_t prio[4] = {0, 1, 2, 3};
-    const int key_bits = 36 + node_bits(n);
-    for (int round = 0; round < p->rounds; round++) {
-        e->pkb_stats.kmers[round] = nk;
-        if (nk >= 2) {
-            // k-mer entries are radix-sorted on this many low bits of their key (= top bits of the mixed hash) (expected places to repair: nk^2 / 2^(bits + 1) <= 2^18)
-            const int sort_bits = nk <= (1ull << 25) ? 32 : (nk <= (1ull << 29) ? 40 : 48);
-            const size_t temp = std::max(sort_u64_pairs_temp_bytes(nk, sort_bits), sort_u32_pairs_temp_bytes(nk));
-            if ((rc = alga_ensure(e, e->pk_fixlist, (size_t) PKB_FIX_LIST_CAP * sizeof(uint32_t)))) return rc;
-            for (DevBuf *b : {&e->pk_keys, &e->pk_vals, &e->pk_keys2, &e->pk_vals2, &e->pk_marks})
-                if ((rc = alga_ensure(e, *b, (nk + 1) * sizeof(unsigned long long)))) return rc;
-            for (DevBuf *b : {&e->pk_flag, &e->pk_pos, &e->pk_heads, &e->pk_heads2, &e->pk_hsz, &e->pk_hsz2, &e->pk_gsz, &e->pk_nadd})
-                if ((rc = alga_ensure(e, *b, (nk + 2) * sizeof(uint32_t)))) return rc;
-            if ((rc = alga_ensure(e, e->sort_temp, temp))) return rc;
-            if ((rc = alga_ensure(e, e->scan_scratch, scan_scratch_bytes(nk)))) return rc;
-            launch_pkb_kmers(nd, c, prio, (const uint32_t *) e->pk_tips.p, (const uint32_t *) e->pk_koff.p, n_tips, sort_bits, (unsigned long long *) e->pk_keys.p,
-                             (unsigned long long *) e->pk_vals.p, s);
-            if ((rc = alga_check_launch(e, "k_pkb_kmers"))) return rc;
-            // equal hashes become contiguous; inside a group the group kernel orders the entries itself
-            HIP_TRY(e, sort_u64_pairs(e->sort_temp.p, temp, (const unsigned long long *) e->pk_keys.p, (unsigned long long *) e->pk_keys2.p,
-                                      (const unsigned long long *) e->pk_vals.p, (unsigned long long *) e->pk_vals2.p, nk, sort_bits, s));
-            uint32_t n_heads = 0;
-            uint64_t big_words = 0;
-            for (int pass = 0; pass < 2; pass++) {
-                HIP_TRY(e, hipMemsetAsync(cnt, 0, 12 * sizeof(unsigned long long), s));
-                if (pass == 0) launch_pkb_fix_runs((unsigned long long *) e->pk_keys2.p, (unsigned long long *) e->pk_vals2.p, nk, sort_bits, (uint32_t *) e->pk_fixlist.p,
-                                                   PKB_FIX_LIST_CAP, cnt + 9, s);
-                else launch_pkb_fix_runs_loop((unsigned long long *) e->pk_keys2.p, (unsigned long long *) e->pk_vals2.p, nk, sort_bits, s);   // the list overflowed
-                if ((rc = alga_check_launch(e, "k_pkb_fix_runs"))) return rc;
-                launch_pkb_group_sizes((const unsigned long long *) e->pk_keys2.p, nk, cnt + 1, cnt + 3, (uint32_t *) e->pk_flag.p, (uint32_t *) e->pk_gsz.p, s);
-                if ((rc = alga_check_launch(e, "k_pkb_group_sizes"))) return rc;
-                launch_exclusive_scan((const uint32_t *) e->pk_flag.p, nk, (uint32_t *) e->pk_pos.p, (uint64_t *) e->scan_scratch.p, s);
-                launch_pkb_head_list((const uint32_t *) e->pk_flag.p, (const uint32_t *) e->pk_pos.p, (const uint32_t *) e->pk_gsz.p, nk, (uint32_t *) e->pk_heads.p,
-                                     (uint32_t *) e->pk_hsz.p, s);
-                if ((rc = alga_check_launch(e, "k_pkb_head_list"))) return rc;
-                HIP_TRY(e, hipMemcpyAsync(e->h_counters, cnt, 12 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-                HIP_TRY(e, hipMemcpyAsync(e->h_counters + 12, (uint64_t *) e->scan_scratch.p + scan_total_index(nk), sizeof(uint64_t), hipMemcpyDeviceToHost, s));
-                HIP_TRY(e, hipStreamSynchronize(s));
-                if (pass == 0 && e->h_counters[9] > PKB_FIX_LIST_CAP) continue;
-                big_words = e->h_counters[1];
-                n_heads = (uint32_t) e->h_counters[12];
-                break;
-            }
-            e->pkb_stats.groups[round] = n_heads;
-            e->pkb_stats.max_group = std::max<uint64_t>(e->pkb_stats.max_group, e->h_counters[3]);             // exact for groups of more than 64
-            if (n_heads) {
-                // groups in order of their size: the lanes of a wave replay groups of the same size
-                HIP_TRY(e, sort_u32_pairs_bits(e->sort_temp.p, temp, (const uint32_t *) e->pk_hsz.p, (uint32_t *) e->pk_hsz2.p, (const uint32_t *) e->pk_heads.p,
-                                               (uint32_t *) e->pk_heads2.p, n_heads, 8, s));
-                const uint64_t add_dense = 2 * nk;
-                uint64_t add_ovf_cap = std::max<uint64_t>(1024, nk / 4);
-                uint64_t n_dense = 0, n_ovf = 0;
-                for (int attempt = 0; attempt < 3; attempt++) {
-                    const uint64_t add_cap = add_dense + add_ovf_cap;
-                    if ((rc = alga_ensure(e, e->pk_big, (big_words + 1) * sizeof(unsigned long long)))) return rc;
-                    if ((rc = alga_ensure(e, e->pk_add, (add_cap + 1) * sizeof(unsigned long long)))) return rc;
-                    HIP_TRY(e, hipMemsetAsync(cnt + 4, 0, 4 * sizeof(unsigned long long), s));                    // big cursor, overflow, calls
-                    launch_pkb_groups(nd, c, (const uint32_t *) e->pk_rowptr.p, (const unsigned long long *) e->pk_g[cur].p, (const unsigned long long *) e->pk_keys2.p,
-                                      (const uint32_t *) e->pk_heads2.p, (const uint32_t *) e->pk_hsz2.p, n_heads, (unsigned long long *) e->pk_vals2.p, nk,
-                                      (unsigned long long *) e->pk_marks.p, (unsigned long long *) e->pk_big.p, cnt + 4, (unsigned long long *) e->pk_add.p, add_dense,
-                                      add_cap, cnt + 5, cnt + 6, (uint32_t *) e->pk_nadd.p, (uint32_t *) e->pk_gsz.p, e->n_cu, s);
-                    if ((rc = alga_check_launch(e, "k_pkb_groups"))) return rc;
-                    launch_exclusive_scan((const uint32_t *) e->pk_nadd.p, (uint64_t) n_heads, (uint32_t *) e->pk_pos.p, (uint64_t *) e->scan_scratch.p, s);
-                    HIP_TRY(e, hipMemcpyAsync(e->h_counters, cnt, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-                    HIP_TRY(e, hipMemcpyAsync(e->h_counters + 8, (uint64_t *) e->scan_scratch.p + scan_total_index((uint64_t) n_heads), sizeof(uint64_t),
-                                              hipMemcpyDeviceToHost, s));
-                    HIP_TRY(e, hipMemcpyAsync(&e->h_first_hkey, e->pk_hsz2.p, sizeof(uint32_t), hipMemcpyDeviceToHost, s));    // the longest group's sort key
-                    HIP_TRY(e, hipStreamSynchronize(s));
-                    if (e->h_counters[5] <= add_ovf_cap) { n_dense = e->h_counters[8]; n_ovf = e->h_counters[5]; break; }
-                    if (attempt == 2) return alga_fail(e, ALGA_ERR_HIP, "supplement: addition buffer kept overflowing");
-                    add_ovf_cap = e->h_counters[5] + 1024;
-                }
-                e->pkb_stats.can_align_calls[round] = e->h_counters[6];
-                e->pkb_stats.max_group = std::max<uint64_t>(e->pkb_stats.max_group, 255u - std::min<uint32_t>(255u, e->h_first_hkey));
-                const uint64_t A = n_dense + n_ovf;
-                if (A) {
-                    // addDirectedEdge + retainOnlySmallestOffset: the additions as sorted keys, merged into the graph, first key per (src, dst)
-                    const int nxt = cur ^ 1;
-                    const size_t t2 = std::max(std::max(sort_u64_keys_temp_bytes(A), merge_u64_temp_bytes(E, A)), unique_edge_keys_temp_bytes(E + A));
-                    if ((rc = alga_ensure(e, e->pk_addk, (A + 1) * sizeof(unsigned long long)))) return rc;
-                    if ((rc = alga_ensure(e, e->pk_addk2, (A + 1) * sizeof(unsigned long long)))) return rc;
-                    if ((rc = alga_ensure(e, e->pk_merged, (E + A + 1) * sizeof(unsigned long long)))) return rc;
-                    if ((rc = alga_ensure(e, e->pk_g[nxt], (E + A + 1) * sizeof(unsigned long long)))) return rc;
-                    if ((rc = alga_ensure(e, e->sort_temp, t2))) return rc;
-                    launch_pkb_gather_adds((const uint32_t *) e->pk_heads2.p, (const uint32_t *) e->pk_nadd.p, (const uint32_t *) e->pk_pos.p, n_heads,
-                                           (const unsigned long long *) e->pk_add.p, add_dense, n_dense, n_ovf, (unsigned long long *) e->pk_addk.p, s);
-                    if ((rc = alga_check_launch(e, "k_pkb_gather_adds"))) return rc;
-                    HIP_TRY(e, sort_u64_keys_bits(e->sort_temp.p, t2, (const unsigned long long *) e->pk_addk.p, (unsigned long long *) e->pk_addk2.p, A, key_bits, s));
-                    HIP_TRY(e, merge_u64(e->sort_temp.p, t2, (const unsigned long long *) e->pk_g[cur].p, E, (const unsigned long long *) e->pk_addk2.p, A,
-                                         (unsigned long long *) e->pk_merged.p, s));
-                    HIP_TRY(e, unique_edge_keys(e->sort_temp.p, t2, (const unsigned long long *) e->pk_merged.p, (unsigned long long *) e->pk_g[nxt].p, cnt + 13, E + A, s));
-                    HIP_TRY(e, hipMemcpyAsync(e->h_counters, cnt + 13, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-                    HIP_TRY(e, hipStreamSynchronize(s));
-                    E = e->h_counters[0];
-                    cur = nxt;
-                    launch_pkb_rowptr((const unsigned long long *) e->pk_g[cur].p, E, n, (uint32_t *) e->pk_rowptr.p, s);
-                    if ((rc = alga_check_launch(e, "k_pkb_rowptr"))) return rc;
-                }
-            }
-        }
-        e->pkb_stats.edges_after[round] = E;
-        std::rotate(prio, prio + 1, prio + 4);                               // GraphCreatorLI.cpp:26
+    if (st.nk >= (1ull << 31)) return alga_fail(e, ALGA_ERR_CAPACITY, "more than 2^31 k-mers in the supplement; shard the input");
+    st.prio[0] = 0; st.prio[1] = 1; st.prio[2] = 2; st.prio[3] = 3;
+    st.key_bits = 36 + node_bits(n);
+    st.phase = 1;
+    return ALGA_OK;
+}
+
+// the additions of this rank's groups in the round at hand: *d_add (device, unsorted edge keys), *n_add
+int pkb_round(alga_engine *e, hipStream_t s, const unsigned long long **d_add, uint64_t *n_add) {
+    int rc;
+    auto &st = e->pkb;
+    *d_add = nullptr; *n_add = 0;
+    if (st.phase != 1 || st.round >= st.rounds) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "supplement round: begin (and the merge of the round before) come first");
+    const NodesDev nd = nodes_dev(&st.dn);
+    const PkbCfg &c = st.cfg;
+    unsigned long long *cnt = (unsigned long long *) e->pk_cnt.p;
+    const uint64_t nk = st.nk;
+    const int round = st.round, cur = st.cur;
+    const uint32_t n_tips = st.n_tips;
+    e->pkb_stats.kmers[round] = nk;
+    st.phase = 2;
+    if (nk < 2) return ALGA_OK;
+    // k-mer entries are radix-sorted on this many low bits of their key (= top bits of the mixed hash) (expected places to repair: nk^2 / 2^(bits + 1) <= 2^18)
+    const int sort_bits = nk <= (1ull << 25) ? 32 : (nk <= (1ull << 29) ? 40 : 48);
+    const size_t temp = std::max(sort_u64_pairs_temp_bytes(nk, sort_bits), sort_u32_pairs_temp_bytes(nk));
+    if ((rc = alga_ensure(e, e->pk_fixlist, (size_t) PKB_FIX_LIST_CAP * sizeof(uint32_t)))) return rc;
+    for (DevBuf *b : {&e->pk_keys, &e->pk_vals, &e->pk_keys2, &e->pk_vals2, &e->pk_marks})
+        if ((rc = alga_ensure(e, *b, (nk + 1) * sizeof(unsigned long long)))) return rc;
+    for (DevBuf *b : {&e->pk_flag, &e->pk_pos, &e->pk_heads, &e->pk_heads2, &e->pk_hsz, &e->pk_hsz2, &e->pk_gsz, &e->pk_nadd})
+        if ((rc = alga_ensure(e, *b, (nk + 2) * sizeof(uint32_t)))) return rc;
+    if ((rc = alga_ensure(e, e->sort_temp, temp))) return rc;
+    if ((rc = alga_ensure(e, e->scan_scratch, scan_scratch_bytes(nk)))) return rc;
+    launch_pkb_kmers(nd, c, st.prio, (const uint32_t *) e->pk_tips.p, (const uint32_t *) e->pk_koff.p, n_tips, sort_bits, (unsigned long long *) e->pk_keys.p,
+                     (unsigned long long *) e->pk_vals.p, s);
+    if ((rc = alga_check_launch(e, "k_pkb_kmers"))) return rc;
+    // equal hashes become contiguous; inside a group the group kernel orders the entries itself
+    HIP_TRY(e, sort_u64_pairs(e->sort_temp.p, temp, (const unsigned long long *) e->pk_keys.p, (unsigned long long *) e->pk_keys2.p,
+                              (const unsigned long long *) e->pk_vals.p, (unsigned long long *) e->pk_vals2.p, nk, sort_bits, s));
+    uint32_t n_heads = 0;
+    uint64_t big_words = 0;
+    for (int pass = 0; pass < 2; pass++) {
+        HIP_TRY(e, hipMemsetAsync(cnt, 0, 12 * sizeof(unsigned long long), s));
+        if (pass == 0) launch_pkb_fix_runs((unsigned long long *) e->pk_keys2.p, (unsigned long long *) e->pk_vals2.p, nk, sort_bits, (uint32_t *) e->pk_fixlist.p,
+                                           PKB_FIX_LIST_CAP, cnt + 9, s);
+        else launch_pkb_fix_runs_loop((unsigned long long *) e->pk_keys2.p, (unsigned long long *) e->pk_vals2.p, nk, sort_bits, s);   // the list overflowed
+        if ((rc = alga_check_launch(e, "k_pkb_fix_runs"))) return rc;
+        launch_pkb_group_sizes((const unsigned long long *) e->pk_keys2.p, nk, cnt + 1, cnt + 3, (uint32_t *) e->pk_flag.p, (uint32_t *) e->pk_gsz.p, st.rank, st.n_ranks, s);
+        if ((rc = alga_check_launch(e, "k_pkb_group_sizes"))) return rc;
+        launch_exclusive_scan((const uint32_t *) e->pk_flag.p, nk, (uint32_t *) e->pk_pos.p, (uint64_t *) e->scan_scratch.p, s);
+        launch_pkb_head_list((const uint32_t *) e->pk_flag.p, (const uint32_t *) e->pk_pos.p, (const uint32_t *) e->pk_gsz.p, nk, (uint32_t *) e->pk_heads.p,
+                             (uint32_t *) e->pk_hsz.p, s);
+        if ((rc = alga_check_launch(e, "k_pkb_head_list"))) return rc;
+        HIP_TRY(e, hipMemcpyAsync(e->h_counters, cnt, 12 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        HIP_TRY(e, hipMemcpyAsync(e->h_counters + 12, (uint64_t *) e->scan_scratch.p + scan_total_index(nk), sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+        HIP_TRY(e, hipStreamSynchronize(s));
+        if (pass == 0 && e->h_counters[9] > PKB_FIX_LIST_CAP) continue;
+        big_words = e->h_counters[1];
+        n_heads = (uint32_t) e->h_counters[12];
+        break;
     }
-    if ((rc = alga_ensure(e, e->pk_edges[0], (E + 1) * sizeof(alga_edge_dev)))) return rc;
-    launch_pkb_keys_to_edges((const unsigned long long *) e->pk_g[cur].p, E, (alga_edge_dev *) e->pk_edges[0].p, s);
+    e->pkb_stats.groups[round] = n_heads;
+    e->pkb_stats.max_group = std::max<uint64_t>(e->pkb_stats.max_group, e->h_counters[3]);             // exact for groups of more than 64
+    if (!n_heads) return ALGA_OK;
+    // groups in order of their size: the lanes of a wave replay groups of the same size
+    HIP_TRY(e, sort_u32_pairs_bits(e->sort_temp.p, temp, (const uint32_t *) e->pk_hsz.p, (uint32_t *) e->pk_hsz2.p, (const uint32_t *) e->pk_heads.p,
+                                   (uint32_t *) e->pk_heads2.p, n_heads, 8, s));
+    const uint64_t add_dense = 2 * nk;
+    uint64_t add_ovf_cap = std::max<uint64_t>(1024, nk / 4);
+    uint64_t n_dense = 0, n_ovf = 0;
+    for (int attempt = 0; attempt < 3; attempt++) {
+        const uint64_t add_cap = add_dense + add_ovf_cap;
+        if ((rc = alga_ensure(e, e->pk_big, (big_words + 1) * sizeof(unsigned long long)))) return rc;
+        if ((rc = alga_ensure(e, e->pk_add, (add_cap + 1) * sizeof(unsigned long long)))) return rc;
+        HIP_TRY(e, hipMemsetAsync(cnt + 4, 0, 4 * sizeof(unsigned long long), s));                    // big cursor, overflow, calls
+        launch_pkb_groups(nd, c, (const uint32_t *) e->pk_rowptr.p, (const unsigned long long *) e->pk_g[cur].p, (const unsigned long long *) e->pk_keys2.p,
+                          (const uint32_t *) e->pk_heads2.p, (const uint32_t *) e->pk_hsz2.p, n_heads, (unsigned long long *) e->pk_vals2.p, nk,
+                          (unsigned long long *) e->pk_marks.p, (unsigned long long *) e->pk_big.p, cnt + 4, (unsigned long long *) e->pk_add.p, add_dense,
+                          add_cap, cnt + 5, cnt + 6, (uint32_t *) e->pk_nadd.p, (uint32_t *) e->pk_gsz.p, e->n_cu, s);
+        if ((rc = alga_check_launch(e, "k_pkb_groups"))) return rc;
+        launch_exclusive_scan((const uint32_t *) e->pk_nadd.p, (uint64_t) n_heads, (uint32_t *) e->pk_pos.p, (uint64_t *) e->scan_scratch.p, s);
+        HIP_TRY(e, hipMemcpyAsync(e->h_counters, cnt, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        HIP_TRY(e, hipMemcpyAsync(e->h_counters + 8, (uint64_t *) e->scan_scratch.p + scan_total_index((uint64_t) n_heads), sizeof(uint64_t),
+                                  hipMemcpyDeviceToHost, s));
+        HIP_TRY(e, hipMemcpyAsync(&e->h_first_hkey, e->pk_hsz2.p, sizeof(uint32_t), hipMemcpyDeviceToHost, s));    // the longest group's sort key
+        HIP_TRY(e, hipStreamSynchronize(s));
+        if (e->h_counters[5] <= add_ovf_cap) { n_dense = e->h_counters[8]; n_ovf = e->h_counters[5]; break; }
+        if (attempt == 2) return alga_fail(e, ALGA_ERR_HIP, "supplement: addition buffer kept overflowing");
+        add_ovf_cap = e->h_counters[5] + 1024;
+    }
+    e->pkb_stats.can_align_calls[round] = e->h_counters[6];
+    e->pkb_stats.max_group = std::max<uint64_t>(e->pkb_stats.max_group, 255u - std::min<uint32_t>(255u, e->h_first_hkey));
+    const uint64_t A = n_dense + n_ovf;
+    if (A) {
+        if ((rc = alga_ensure(e, e->pk_addk, (A + 1) * sizeof(unsigned long long)))) return rc;
+        launch_pkb_gather_adds((const uint32_t *) e->pk_heads2.p, (const uint32_t *) e->pk_nadd.p, (const uint32_t *) e->pk_pos.p, n_heads,
+                               (const unsigned long long *) e->pk_add.p, add_dense, n_dense, n_ovf, (unsigned long long *) e->pk_addk.p, s);
+        if ((rc = alga_check_launch(e, "k_pkb_gather_adds"))) return rc;
+        *d_add = (const unsigned long long *) e->pk_addk.p; *n_add = A;
+    }
+    return ALGA_OK;
+}
+
+// addDirectedEdge + retainOnlySmallestOffset for the additions of ALL ranks (A keys on this device, any order): sorted, merged into the graph,
+// the first key per (src, dst) kept; closes the round
+int pkb_merge(alga_engine *e, const unsigned long long *d_all, uint64_t A, hipStream_t s) {
+    int rc;
+    auto &st = e->pkb;
+    if (st.phase != 2) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "supplement merge: the round's own additions come first");
+    unsigned long long *cnt = (unsigned long long *) e->pk_cnt.p;
+    if (A) {
+        const uint64_t E = st.E;
+        const int cur = st.cur, nxt = cur ^ 1;
+        const size_t t2 = std::max(std::max(sort_u64_keys_temp_bytes(A), merge_u64_temp_bytes(E, A)), unique_edge_keys_temp_bytes(E + A));
+        if ((rc = alga_ensure(e, e->pk_addk2, (A + 1) * sizeof(unsigned long long)))) return rc;
+        if ((rc = alga_ensure(e, e->pk_merged, (E + A + 1) * sizeof(unsigned long long)))) return rc;
+        if ((rc = alga_ensure(e, e->pk_g[nxt], (E + A + 1) * sizeof(unsigned long long)))) return rc;
+        if ((rc = alga_ensure(e, e->sort_temp, t2))) return rc;
+        HIP_TRY(e, sort_u64_keys_bits(e->sort_temp.p, t2, d_all, (unsigned long long *) e->pk_addk2.p, A, st.key_bits, s));
+        HIP_TRY(e, merge_u64(e->sort_temp.p, t2, (const unsigned long long *) e->pk_g[cur].p, E, (const unsigned long long *) e->pk_addk2.p, A,
+                             (unsigned long long *) e->pk_merged.p, s));
+        HIP_TRY(e, unique_edge_keys(e->sort_temp.p, t2, (const unsigned long long *) e->pk_merged.p, (unsigned long long *) e->pk_g[nxt].p, cnt + 13, E + A, s));
+        HIP_TRY(e, hipMemcpyAsync(e->h_counters, cnt + 13, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        HIP_TRY(e, hipStreamSynchronize(s));
+        st.E = e->h_counters[0];
+        st.cur = nxt;
+        launch_pkb_rowptr((const unsigned long long *) e->pk_g[st.cur].p, st.E, st.dn.n, (uint32_t *) e->pk_rowptr.p, s);
+        if ((rc = alga_check_launch(e, "k_pkb_rowptr"))) return rc;
+    }
+    e->pkb_stats.edges_after[st.round] = st.E;
+    std::rotate(st.prio, st.prio + 1, st.prio + 4);                          // GraphCreatorLI.cpp:26
+    st.round++;
+    st.phase = 1;
+    return ALGA_OK;
+}
+
+int pkb_end(alga_engine *e, hipStream_t s, const alga_edge **d_out, uint64_t *m_out) {
+    int rc;
+    auto &st = e->pkb;
+    if (st.phase != 1) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "supplement end: a round is open");
+    if ((rc = alga_ensure(e, e->pk_edges[0], (st.E + 1) * sizeof(alga_edge_dev)))) return rc;
+    launch_pkb_keys_to_edges((const unsigned long long *) e->pk_g[st.cur].p, st.E, (alga_edge_dev *) e->pk_edges[0].p, s);
     if ((rc = alga_check_launch(e, "k_pkb_keys_to_edges"))) return rc;
-    HIP_TRY(e, hipEventRecord(ev1, s));
+    HIP_TRY(e, hipEventRecord(e->ev[EV_EMIT], s));
     HIP_TRY(e, hipStreamSynchronize(s));
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) e->pkb_stats.ms_total = ms;
+    if (hipEventElapsedTime(&ms, e->ev[EV_START], e->ev[EV_EMIT]) == hipSuccess) e->pkb_stats.ms_total = ms;
     *d_out = (const alga_edge *) e->pk_edges[0].p;
-    *m_out = E;
+    *m_out = st.E;
+    st.phase = 0;
     return ALGA_OK;
+}
+
+int supplement_device_impl(alga_engine *e, const alga_nodes *dn, const alga_pkb_params *p, const alga_edge *d_edges_in, uint64_t m_in,
+                           hipStream_t s, const alga_edge **d_out, uint64_t *m_out) {
+    int rc = pkb_begin(e, dn, p, d_edges_in, m_in, 0, 1, s);
+    if (rc) return rc;
+    for (int round = 0; round < p->rounds; round++) {
+        const unsigned long long *d_add = nullptr;
+        uint64_t A = 0;
+        if ((rc = pkb_round(e, s, &d_add, &A))) return rc;
+        if ((rc = pkb_merge(e, d_add, A, s))) return rc;
+    }
+    return pkb_end(e, s, d_out, m_out);
 }
 
 } // namespace
@@ -364,6 +418,49 @@ int alga_pkb_supplement_host(alga_engine *e, const alga_nodes *nodes, const alga
     }
     *edges_out = h; *n_edges_out = m;
     return ALGA_OK;
+}
+
+// ---- the supplement on N ranks: the same phases, the exchange of a round's additions in the caller's hands (include/alga_amd.h) ----
+int alga_pkb_shard_begin(alga_engine *e, const alga_nodes *nodes, const alga_pkb_params *p, const alga_edge *d_edges_in, uint64_t n_edges_in, int32_t rank, int32_t n_ranks,
+                         void *hip_stream) {
+    if (!e) return ALGA_ERR_INVALID_ARGUMENT;
+    e->err.clear();
+    int rc = check_params(e, nodes, p);
+    if (rc) return rc;
+    if (n_edges_in && !d_edges_in) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "edges_in must not be NULL");
+    if (n_ranks < 1 || rank < 0 || rank >= n_ranks) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "bad rank / n_ranks");
+    HIP_TRY(e, hipSetDevice(e->device));
+    return pkb_begin(e, nodes, p, d_edges_in, n_edges_in, rank, n_ranks, hip_stream ? (hipStream_t) hip_stream : e->own_stream);
+}
+
+int alga_pkb_shard_round(alga_engine *e, void *hip_stream, const uint64_t **d_additions, uint64_t *n_additions) {
+    if (!e) return ALGA_ERR_INVALID_ARGUMENT;
+    e->err.clear();
+    if (!d_additions || !n_additions) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "output pointers must not be NULL");
+    HIP_TRY(e, hipSetDevice(e->device));
+    const unsigned long long *d = nullptr;
+    uint64_t a = 0;
+    const int rc = pkb_round(e, hip_stream ? (hipStream_t) hip_stream : e->own_stream, &d, &a);
+    *d_additions = (const uint64_t *) d; *n_additions = a;
+    return rc;
+}
+
+int alga_pkb_shard_merge(alga_engine *e, const uint64_t *d_all_additions, uint64_t n_all, void *hip_stream) {
+    if (!e) return ALGA_ERR_INVALID_ARGUMENT;
+    e->err.clear();
+    if (n_all && !d_all_additions) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "additions must not be NULL");
+    if (n_all >= (1ull << 32) - 16) return alga_fail(e, ALGA_ERR_CAPACITY, "more than 2^32 additions");
+    HIP_TRY(e, hipSetDevice(e->device));
+    return pkb_merge(e, (const unsigned long long *) d_all_additions, n_all, hip_stream ? (hipStream_t) hip_stream : e->own_stream);
+}
+
+int alga_pkb_shard_end(alga_engine *e, void *hip_stream, const alga_edge **d_edges_out, uint64_t *n_edges_out) {
+    if (!e) return ALGA_ERR_INVALID_ARGUMENT;
+    e->err.clear();
+    if (!d_edges_out || !n_edges_out) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "output pointers must not be NULL");
+    *d_edges_out = nullptr; *n_edges_out = 0;
+    HIP_TRY(e, hipSetDevice(e->device));
+    return pkb_end(e, hip_stream ? (hipStream_t) hip_stream : e->own_stream, d_edges_out, n_edges_out);
 }
 
 int alga_pkb_last_stats(const alga_engine *e, alga_pkb_stats *out) {

@@ -436,12 +436,14 @@ __global__ void __launch_bounds__(256) k_pkb_group_sizes(const unsigned long lon
                                                           unsigned long long *__restrict__ big_words /* total words for groups > 64 */,
                                                           unsigned long long *__restrict__ max_d,
                                                           uint32_t *__restrict__ head_flag /* 1 = entry heads a group of >= 2 */,
-                                                          uint32_t *__restrict__ gsize /* at such an entry: min(D, 255) */) {
+                                                          uint32_t *__restrict__ gsize /* at such an entry: min(D, 255) */,
+                                                          uint32_t rank, uint32_t n_ranks /* N ranks: a group belongs to rank mix(k-mer key) mod N */) {
     const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const unsigned long long k = keys[i];
     uint32_t flag = 0;
-    if ((i == 0 || keys[i - 1] != k) && i + 1 < n && keys[i + 1] == k) {
+    const bool mine = n_ranks <= 1u || (uint32_t) (((k ^ (k >> 29)) * 0x9E3779B97F4A7C15ull) >> 40) % n_ranks == rank;
+    if (mine && (i == 0 || keys[i - 1] != k) && i + 1 < n && keys[i + 1] == k) {
         uint64_t e = i + 2;
         while (e < n && keys[e] == k) e++;
         const uint64_t D = e - i;
@@ -837,9 +839,9 @@ void launch_pkb_fix_runs_loop(unsigned long long *keys, unsigned long long *vals
 }
 
 void launch_pkb_group_sizes(const unsigned long long *keys, uint64_t n, unsigned long long *big_words, unsigned long long *max_d, uint32_t *head_flag,
-                            uint32_t *gsize, hipStream_t s) {
+                            uint32_t *gsize, int rank, int n_ranks, hipStream_t s) {
     if (n == 0) return;
-    hipLaunchKernelGGL(k_pkb_group_sizes, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, s, keys, n, big_words, max_d, head_flag, gsize);
+    hipLaunchKernelGGL(k_pkb_group_sizes, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, s, keys, n, big_words, max_d, head_flag, gsize, (uint32_t) rank, (uint32_t) n_ranks);
 }
 
 void launch_pkb_head_list(const uint32_t *head_flag, const uint32_t *pos, const uint32_t *gsize, uint64_t n, uint32_t *heads, uint32_t *hkey, hipStream_t s) {

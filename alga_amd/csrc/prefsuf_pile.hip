@@ -669,6 +669,22 @@ __global__ void __launch_bounds__(PP_WAVES * 64, PP_OCC) k_pile_probe(PrefSufCfg
     bool dfr = nr_code == CL_RUNS_FLAGGED;                 // runs k_node_runs could not list: the general kernel finds them by brute force
     const bool active = nr_code != 0 && !dfr;
     vmask = active ? vmask : 0u;
+#ifndef PP_NO_COMPACT
+    // A member's runs are a stretch of its pile's eight slots (the pile's list clipped to the member's windows); the slot loop below runs over the
+    // UNION of the wave's slots -- ten piles, each with its own stretch: nearly all eight.  Shifted down to slot 0 the loop ends with the longest
+    // list of the wave instead (three stages of selects: by four, two, one slot).
+    {
+        const int sh = vmask ? __builtin_ctz(vmask) : 0;
+        const bool s4 = (sh & 4) != 0, s2 = (sh & 2) != 0, s1 = (sh & 1) != 0;
+#pragma unroll
+        for (int a = 0; a < CL_RMAX; a++) { rk[a] = s4 ? (a + 4 < CL_RMAX ? rk[a + 4] : 0u) : rk[a]; ry[a] = s4 ? (a + 4 < CL_RMAX ? ry[a + 4] : 0u) : ry[a]; }
+#pragma unroll
+        for (int a = 0; a < CL_RMAX; a++) { rk[a] = s2 ? (a + 2 < CL_RMAX ? rk[a + 2] : 0u) : rk[a]; ry[a] = s2 ? (a + 2 < CL_RMAX ? ry[a + 2] : 0u) : ry[a]; }
+#pragma unroll
+        for (int a = 0; a < CL_RMAX; a++) { rk[a] = s1 ? (a + 1 < CL_RMAX ? rk[a + 1] : 0u) : rk[a]; ry[a] = s1 ? (a + 1 < CL_RMAX ? ry[a + 1] : 0u) : ry[a]; }
+        vmask >>= sh;
+    }
+#endif
     uint32_t um = 0u;                                      // uniform: slots in which any lane of the wave has a run
 #pragma unroll
     for (int a = 0; a < CL_RMAX; a++) um |= __ballot(((vmask >> a) & 1u) != 0u) != 0ull ? 1u << a : 0u;

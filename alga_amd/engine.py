@@ -155,7 +155,8 @@ EXPORTS = ["alga_abi_version", "alga_engine_set_option", "alga_engine_create", "
            "alga_multi_create", "alga_multi_destroy", "alga_multi_last_error", "alga_multi_engine", "alga_multi_prefsuf_build_host", "alga_multi_prefsuf_build_device",
            "alga_multi_free_edges", "alga_multi_last_stats", "alga_multi_set_option", "alga_upload_twin_nodes",
            "alga_shard_index_device", "alga_shard_join_device", "alga_shard_small_keys_device", "alga_shard_resolve_device", "alga_shard_place_device",
-           "alga_shard_last_stats", "alga_sort_u32_pairs_device", "alga_prefsuf_build_host_compact", "alga_download_edges_compact", "alga_free_compact_edges", "alga_host_alloc", "alga_host_free"]
+           "alga_shard_last_stats", "alga_sort_u32_pairs_device", "alga_multi_pkb_supplement_device", "alga_pkb_shard_begin", "alga_pkb_shard_round", "alga_pkb_shard_merge", "alga_pkb_shard_end",
+           "alga_prefsuf_build_host_compact", "alga_download_edges_compact", "alga_free_compact_edges", "alga_host_alloc", "alga_host_free"]
 
 
 def library_path():
@@ -238,6 +239,10 @@ def load_library():
     lib.alga_sort_edges_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]
     lib.alga_sort_u32_pairs_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                                C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_double)]
+    lib.alga_pkb_shard_begin.argtypes = [C.c_void_p, C.POINTER(_Nodes), C.POINTER(PkbParams), C.c_void_p, C.c_uint64, C.c_int32, C.c_int32, C.c_void_p]
+    lib.alga_pkb_shard_round.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    lib.alga_pkb_shard_merge.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+    lib.alga_pkb_shard_end.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
     lib.alga_pkb_derive_params.argtypes = [C.c_double, C.c_float, C.c_double, C.c_int32, C.POINTER(PkbParams)]
     lib.alga_pkb_derive_params.restype = None
     lib.alga_can_align_batch_host.argtypes = [C.c_void_p, C.POINTER(_Nodes), C.POINTER(PkbParams), C.c_void_p, C.c_uint64, C.c_void_p]
@@ -730,6 +735,25 @@ class Engine:
                                                          C.c_void_p(stream or 0), C.byref(out), C.byref(m)))
         return out.value, int(m.value)
 
+    # ---- the supplement on N ranks: begin -> { round -> [all-gather of the additions] -> merge } x rounds -> end (include/alga_amd.h) ----
+    def pkb_shard_begin(self, words, lens, d_edges, n_edges, p, rank, n_ranks, stream=None):
+        nd = self._nodes_from_torch(words, lens)
+        self._check(self._lib.alga_pkb_shard_begin(self._h, C.byref(nd), C.byref(p), C.c_void_p(d_edges), int(n_edges), int(rank), int(n_ranks), C.c_void_p(stream or 0)))
+
+    def pkb_shard_round(self, stream=None):
+        """-> (device pointer of this rank's additions (uint64 keys), how many)"""
+        out, m = C.c_void_p(), C.c_uint64()
+        self._check(self._lib.alga_pkb_shard_round(self._h, C.c_void_p(stream or 0), C.byref(out), C.byref(m)))
+        return out.value, int(m.value)
+
+    def pkb_shard_merge(self, d_all, n_all, stream=None):
+        self._check(self._lib.alga_pkb_shard_merge(self._h, C.c_void_p(d_all), int(n_all), C.c_void_p(stream or 0)))
+
+    def pkb_shard_end(self, stream=None):
+        out, m = C.c_void_p(), C.c_uint64()
+        self._check(self._lib.alga_pkb_shard_end(self._h, C.c_void_p(stream or 0), C.byref(out), C.byref(m)))
+        return out.value, int(m.value)
+
     def pkb_last_stats(self):
         st = PkbStats()
         self._check(self._lib.alga_pkb_last_stats(self._h, C.byref(st)))
@@ -864,6 +888,15 @@ class MultiEngine:
         p = Engine.params(min_overlap, rsoe_min_overlap)
         out, m = C.c_void_p(), C.c_uint64()
         self._check(self._lib.alga_multi_prefsuf_build_device(self._h, arr, C.byref(p), C.byref(out), C.byref(m)))
+        return out.value, int(m.value)
+
+    def pkb_supplement_device(self, per_rank, d_edges_rank0, n_edges, p):
+        """alga_multi_pkb_supplement_device: the approximate supplement on the handle's ranks; the exact graph on rank 0's GPU (what prefsuf_device
+        returned) -> (device pointer on rank 0's GPU, n_edges)."""
+        self._lib.alga_multi_pkb_supplement_device.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(PkbParams), C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+        arr = (_Nodes * self.n)(*[Engine._nodes_from_torch(w, l) for w, l in per_rank])
+        out, m = C.c_void_p(), C.c_uint64()
+        self._check(self._lib.alga_multi_pkb_supplement_device(self._h, arr, C.byref(p), C.c_void_p(d_edges_rank0), int(n_edges), C.byref(out), C.byref(m)))
         return out.value, int(m.value)
 
     def last_stats(self):

@@ -179,8 +179,17 @@ int main(int argc, char **argv) {
         alga_pkb_params pp;
         alga_pkb_derive_params(cnt ? sum / (double) cnt : 0.0, ip.scale, error_rate, parsed.li_kmer_length, &pp);
         alga_nodes nd{nodes.d_words, nodes.stride_words, nodes.d_len, nodes.n, nullptr, nullptr};
-        int rc = alga_pkb_supplement_device(engine, &nd, &pp, d_final, n_final, nullptr, &d_final, &n_final);
-        if (rc != ALGA_OK) { fprintf(stderr, "alga_amd: %s (status %d)\n", alga_last_error(engine), rc); return 1; }
+        int rc;
+        if (multi) {
+            // the k-mer groups dealt out over the GPUs by hash; every rank ends with the same graph, rank 0's comes back
+            std::vector<alga_nodes> per_rank;
+            for (int r = 0; r < n_ranks; r++) per_rank.push_back(alga_nodes{rank_nodes[(size_t) r].d_words, rank_nodes[(size_t) r].stride_words, rank_nodes[(size_t) r].d_len, rank_nodes[(size_t) r].n, nullptr, nullptr});
+            rc = alga_multi_pkb_supplement_device(multi, per_rank.data(), &pp, d_final, n_final, &d_final, &n_final);
+            if (rc != ALGA_OK) { fprintf(stderr, "alga_amd: %s (status %d)\n", alga_multi_last_error(multi), rc); return 1; }
+        } else {
+            rc = alga_pkb_supplement_device(engine, &nd, &pp, d_final, n_final, nullptr, &d_final, &n_final);
+            if (rc != ALGA_OK) { fprintf(stderr, "alga_amd: %s (status %d)\n", alga_last_error(engine), rc); return 1; }
+        }
         fprintf(stderr, "After supplement G has %llu edges\n", (unsigned long long) n_final);
     }
     std::vector<alga_edge> final_edges((size_t) n_final);

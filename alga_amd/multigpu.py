@@ -179,6 +179,28 @@ class HipBackend:
         ptr = self.eng.sort_edges_device(edges, m, self.n, stream=self._stream())
         return device_view(ptr, (m, 3), self.device)
 
+    # ---- the supplement on N ranks (ShardedSupplement); self.pkb = the alga_pkb_params (Engine.pkb_params), set by the caller ----
+    pkb = None
+
+    def pkb_begin(self, edges, rank, world):
+        self._pkb_edges = edges.contiguous()                # (stays alive until the supplement has read it)
+        self.eng.pkb_shard_begin(self.w, self.l, self._pkb_edges.data_ptr() if int(edges.shape[0]) else None, int(edges.shape[0]), self.pkb, rank, world, stream=self._stream())
+
+    def pkb_round(self):
+        import torch
+        from .engine import device_view
+        ptr, k = self.eng.pkb_shard_round(stream=self._stream())
+        return device_view(ptr, (k,), self.device, typestr="<i8").clone() if k else torch.empty(0, dtype=torch.int64, device=self.device)
+
+    def pkb_merge(self, allk):
+        self._pkb_all = allk.contiguous()
+        self.eng.pkb_shard_merge(self._pkb_all.data_ptr() if int(allk.shape[0]) else None, int(allk.shape[0]), stream=self._stream())
+
+    def pkb_end(self):
+        from .engine import device_view
+        ptr, m = self.eng.pkb_shard_end(stream=self._stream())
+        return device_view(ptr, (m, 3), self.device)
+
     def sync(self):
         import torch
         torch.cuda.synchronize()
@@ -498,6 +520,58 @@ class ShardedPrefSuf:
 
     def edges_numpy(self):
         return self.edges.cpu().numpy().astype(np.int32).copy()
+
+
+class ShardedSupplement:
+    """The approximate supplement on N ranks (alga_pkb_shard_*, include/alga_amd.h; SURVEY.md section 8(e): the k-mer groups are dealt out by
+    hash).  Every rank holds the node set and -- `run` broadcasts it from rank 0 -- the complete exact graph; per round a rank joins its own
+    groups, the additions of all ranks are all-gathered (variable length: sizes first, then one padded all_gather) and every rank merges them
+    all.  The graphs stay identical on all ranks and identical to the one-GPU supplement's.
+    backend: pkb_begin(edges [m, 3] int32, rank, world), pkb_round() -> int64[k] addition keys, pkb_merge(int64[K]), pkb_end() -> edges [m', 3]
+    (HipBackend below; tests/test_multigpu_gloo.py drives this class over gloo with a stand-in)."""
+
+    def __init__(self, backend, rank, world, dist, rounds=4):
+        self.be, self.rank, self.world, self.dist, self.rounds = backend, rank, world, dist, rounds
+        self.exchange_bytes = []
+
+    def _bcast_edges(self, edges):
+        """the exact graph, complete on rank 0 (the gather of the build), to every rank"""
+        import torch
+        dev = self.be.device
+        k = torch.tensor([int(edges.shape[0]) if self.rank == 0 else 0], dtype=torch.int64, device=dev)
+        self.dist.broadcast(k, src=0)
+        m = int(k.item())
+        buf = edges.contiguous() if self.rank == 0 else torch.empty((m, 3), dtype=torch.int32, device=dev)
+        if m:
+            self.dist.broadcast(buf.view(-1), src=0)
+        return buf
+
+    def _all_gather_keys(self, mine):
+        import torch
+        dist, dev, nr = self.dist, self.be.device, self.world
+        k = int(mine.shape[0])
+        allk = torch.empty(nr, dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(allk, torch.tensor([k], dtype=torch.int64, device=dev))
+        ks = [int(x) for x in allk.cpu()]
+        mx = max(max(ks), 1)
+        local = torch.zeros(mx, dtype=torch.int64, device=dev)
+        if k:
+            local[:k] = mine
+        parts = torch.empty((nr, mx), dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(parts.view(-1), local)
+        self.exchange_bytes.append(8 * k * (nr - 1))
+        return torch.cat([parts[q, :ks[q]] for q in range(nr)], dim=0).contiguous()
+
+    def run(self, edges):
+        """edges: the exact graph [m, 3] int32 on rank 0 (anything on the others) -> the post-supplement graph, on EVERY rank"""
+        if self.world > 1:
+            edges = self._bcast_edges(edges)
+        self.be.pkb_begin(edges, self.rank, self.world)
+        for _ in range(self.rounds):
+            mine = self.be.pkb_round()
+            allk = self._all_gather_keys(mine) if self.world > 1 else mine
+            self.be.pkb_merge(allk)
+        return self.be.pkb_end()
 
 
 def edges_digest(e, chunk=1 << 25):

@@ -210,7 +210,8 @@ def run(args, rank, world, local_rank, dist, t_process=None):
     max_len = int(d_lens.max().item()) if n_nodes else 0
     W = (2 * max_len + 31) // 32
     # error_rate > 0.01: the scored path is the exact graph PLUS the approximate supplement (src/main.cpp:244-355); one GPU
-    supplement = err > 0.01 and world == 1
+    # (N > 1: the k-mer groups of the supplement are dealt out over the ranks by hash, alga_amd.multigpu.ShardedSupplement / alga_pkb_shard_*)
+    supplement = err > 0.01
     pkb = alga_amd.Engine.pkb_params(float(d_lens[d_lens > 0].float().mean().item()), err, min(2 * lo // 3, 60)) if supplement else None
 
     # ---- the FIRST call of a process (what an assembler pays: it builds its graph once) --------------------------------------
@@ -245,6 +246,8 @@ def run(args, rank, world, local_rank, dist, t_process=None):
                          "but finds the code objects loaded.  Without either, the first build of a process took 58 ms at this size (code-object loading ~20 ms, allocations ~1 ms).")
     backend = multigpu.HipBackend(eng, d_words, d_lens, lo, rs)
     runner = multigpu.ShardedPrefSuf(backend, rank, world, dist)
+    backend.pkb = pkb
+    sharded_sup = multigpu.ShardedSupplement(backend, rank, world, dist) if (supplement and world > 1) else None
 
     def sync_all():
         if dist is not None:
@@ -268,9 +271,14 @@ def run(args, rank, world, local_rank, dist, t_process=None):
         """one pass of the hot path over the resident read set -> (edges of the graph handed to the simplifier, stats)"""
         m, st = runner.step(collect_stats=collect_stats)
         final["edges"] = runner.edges
-        if supplement:
+        if supplement and world > 1:
+            with backend.stream_scope():
+                final["edges"] = sharded_sup.run(runner.edges)
+                m = int(final["edges"].shape[0])
+        elif supplement:
             p2, m = eng.pkb_supplement_device(d_words, d_lens, runner.edges.data_ptr(), m, pkb)
             final["edges"] = alga_amd.engine.device_view(p2, (m, 3), d_words.device)
+        if supplement:
             ps = eng.pkb_last_stats()
             st = dict(st)
             st["ms_supplement"] = ps["ms_total"]
@@ -475,7 +483,7 @@ def run(args, rank, world, local_rank, dist, t_process=None):
             out["first_call"] = first
         if world > 1:
             if err > 0.01:
-                out["supplement"] = "skipped (N > 1): the timed step is the exact overlap graph only -- not comparable with the N = 1 line of this config, which includes the approximate supplement"
+                out["supplement"]["n_gpu_form"] = "k-mer groups dealt out over the ranks by hash (alga_pkb_shard_*): the exact graph broadcast from rank 0, each round's additions all-gathered, every rank merges them all; counters are rank 0's"
             out["multi_gpu_form"] = multi_form
             out["multi_gpu_validation"] = "the N-rank path has not run over RCCL on hardware (no multi-GPU node available to the builder): N-rank graph == one-GPU graph is checked over gloo and as N ranks on one GPU only"
         out["src_sha256"] = src_sha

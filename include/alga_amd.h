@@ -467,6 +467,26 @@ int  alga_pkb_supplement_device(alga_engine *e, const alga_nodes *nodes, const a
                                 uint64_t n_edges_in, void *hip_stream, const alga_edge **d_edges_out, uint64_t *n_edges_out);
 int  alga_pkb_last_stats(const alga_engine *e, alga_pkb_stats *out);
 
+/* The supplement on N ranks (one engine per GPU; SURVEY.md section 8(e): groups are keyed by k-mer hash, the reference spreads its k-mer buckets
+ * over worker threads, src/GraphCreators/GraphCreatorKmerBased.cpp:108-136).  Every rank holds the node set and the COMPLETE exact graph; a group of
+ * equal k-mers belongs to rank mix(k-mer key) mod n_ranks.  Per round (params->rounds of them) each rank joins its own groups against the graph as
+ * it stood when the round began -> its additions (edge keys src << 36 | dst << 9 | offset, unsorted, engine-owned until the merge); the CALLER
+ * brings the additions of all ranks together on every rank (an all-gather of variable length: RCCL, torch.distributed, peer copies) and every rank
+ * merges them ALL: the graphs stay identical, and identical to the one-GPU supplement's -- every group of a round sees the round's start graph and
+ * the merge orders by key, so nothing depends on how the groups were dealt out (tests/test_gpu_pkb.py: 2, 3 and 5 ranks on one GPU).
+ *   begin -> { round -> [exchange] -> merge } x rounds -> end.   alga_pkb_supplement_device is exactly this with one rank.
+ * k-mers and their sort are computed by every rank (the pairwise join and canAlign are what is shared out). */
+int  alga_pkb_shard_begin(alga_engine *e, const alga_nodes *nodes, const alga_pkb_params *p, const alga_edge *d_edges_in, uint64_t n_edges_in, int32_t rank,
+                          int32_t n_ranks, void *hip_stream);
+int  alga_pkb_shard_round(alga_engine *e, void *hip_stream, const uint64_t **d_additions, uint64_t *n_additions);
+int  alga_pkb_shard_merge(alga_engine *e, const uint64_t *d_all_additions, uint64_t n_all, void *hip_stream);
+int  alga_pkb_shard_end(alga_engine *e, void *hip_stream, const alga_edge **d_edges_out, uint64_t *n_edges_out);
+/* The approximate supplement (alga_pkb_shard_*) on the handle's N ranks: d_edges_rank0 = the exact graph on rank 0's GPU (what
+ * alga_multi_prefsuf_build_device returned); it is sent to every rank, each round's additions are all-gathered over the handle's transport, and
+ * rank 0's copy of the result -- identical on all ranks, and to the one-GPU supplement's -- is handed back (engine-owned, rank 0's GPU). */
+int         alga_multi_pkb_supplement_device(alga_multi *m, const alga_nodes *nodes_per_rank, const alga_pkb_params *p, const alga_edge *d_edges_rank0,
+                                             uint64_t n_edges, const alga_edge **d_edges_out, uint64_t *n_edges_out);
+
 /* ---- input stages (host, multithreaded C++; no GPU involved) ---------------------------------
  * What the reference does between its command line and the GraphCreator constructor, in its
  * --threads=1 order: record parsing, end trimming, N / STR filters, 2-bit packing, reverse-complement

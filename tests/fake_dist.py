@@ -89,6 +89,12 @@ class FakeDist:
     def barrier(self):
         self._exchange(None)
 
+    def broadcast(self, tensor, src=0):
+        parts = self._exchange(tensor.detach().clone() if self.rank == src else None)
+        if self.rank != src:
+            tensor.copy_(parts[src].reshape(tensor.shape))
+        self._sync()
+
     def all_reduce(self, t, op=ReduceOp.SUM):
         import torch
         parts = self._exchange(t.detach().clone())

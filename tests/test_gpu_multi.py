@@ -199,3 +199,41 @@ def test_multi_device_entry_point_at_1m_reads():
         assert got.shape == want.shape and (got == want).all()
     finally:
         m.close()
+
+
+@pytest.mark.parametrize("ranks", [2, 3])
+def test_multi_supplement_equals_one_gpu(ranks):
+    """configs[4]'s scored path on N ranks through the C++ driver: exact graph (alga_multi_prefsuf_build_device), then the approximate supplement with
+    its k-mer groups dealt out by hash (alga_multi_pkb_supplement_device: the exact graph to every rank, a round's additions all-gathered over the
+    handle's transport) -- the post-supplement graph of one engine, edge for edge."""
+    import torch
+    import gen_reads
+    from alga_amd.engine import device_view
+    codes, _ = gen_reads.sample_reads(5000, 150, 12000, 91, 0.02)
+    rc = (3 - codes)[:, ::-1]
+    codes = np.stack([rc, codes], axis=1).reshape(-1, 150)[:, 3:147]
+    lens = np.full(len(codes), 144, dtype=np.int32)
+    words = alga_amd.pack_reads(codes, lens)
+    wide = np.zeros((len(lens), 16), dtype=np.uint32)
+    wide[:, :words.shape[1]] = words
+    e1 = alga_amd.Engine(0)
+    try:
+        pre = e1.prefsuf_host(words, lens, 82, 116)
+        p = e1.pkb_params(144.0, 0.02, 54)
+        want = e1.pkb_supplement_host(words, lens, pre, p)
+    finally:
+        e1.close()
+    assert len(want) > len(pre)
+    dw = torch.from_numpy(wide.view(np.int32)).cuda()
+    dl = torch.from_numpy(lens).cuda()
+    torch.cuda.synchronize()
+    m = alga_amd.MultiEngine([0] * ranks, transport="copy")
+    try:
+        for _ in range(2):
+            ptr, k = m.prefsuf_device([(dw, dl)] * ranks, 82, 116)
+            assert k == len(pre)
+            p2, k2 = m.pkb_supplement_device([(dw, dl)] * ranks, ptr, k, p)
+            got = device_view(p2, (k2, 3), dw.device).cpu().numpy()
+            assert got.shape == want.shape and (got == want).all()
+    finally:
+        m.close()

@@ -211,3 +211,57 @@ def test_engine_destroy_releases_every_device_buffer():
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info()
     assert free0 - free1 < (8 << 20), (free0, free1)
+
+
+@pytest.mark.parametrize("ranks,n,G,seed,err", [(2, 4000, 9000, 71, 0.02), (3, 3000, 3000, 72, 0.03), (5, 6000, 20000, 73, 0.02)])
+def test_supplement_on_n_ranks_equals_one_gpu(eng, ranks, n, G, seed, err):
+    """The supplement with its k-mer groups dealt out over N ranks by hash (alga_pkb_shard_*; the reference spreads its
+    k-mer buckets over worker threads, src/GraphCreators/GraphCreatorKmerBased.cpp:108-136): alga_amd.multigpu.ShardedSupplement as bench.py
+    --gpus N drives it -- real engines, one per rank, on this one GPU, the collectives a thread rendezvous.  Every rank must end with the graph
+    the one-GPU supplement gives, which equals the oracle in the engine's semantics."""
+    import torch
+    from alga_amd.engine import device_view
+    from alga_amd.multigpu import HipBackend, ShardedSupplement
+    from fake_dist import run_ranks
+    codes, lens = gen_reads.sample_reads(n, 150, G, seed, err)
+    rc = (3 - codes)[:, ::-1]
+    codes = np.stack([rc, codes], axis=1).reshape(-1, 150)[:, 3:147]
+    lens = np.full(len(codes), 144, dtype=np.int32)
+    words = alga_amd.pack_reads(codes, lens)
+    pre = eng.prefsuf_host(words, lens, 82, 116)
+    p = eng.pkb_params(144.0, 0.02, 54)
+    want = eng.pkb_supplement_host(words, lens, pre, p)
+    op = O.pkb_params(144.0, error_rate_percent=2)
+    orc, _ = O.supplement(words, lens, pre, op, 54, flags=3)
+    assert want.shape == orc.shape and (want == orc).all() and len(want) > len(pre)
+    stride = 16
+    wide = np.zeros((len(lens), stride), dtype=np.uint32)
+    wide[:, :words.shape[1]] = words
+    dw = torch.from_numpy(wide.view(np.int32)).cuda()
+    dl = torch.from_numpy(lens).cuda()
+    d_pre = torch.from_numpy(np.ascontiguousarray(pre, dtype=np.int32)).cuda()
+    torch.cuda.synchronize()
+
+    def rank_main(rank, dist):
+        e = alga_amd.Engine(0)
+        try:
+            be = HipBackend(e, dw, dl, 82, 116)
+            be.pkb = p
+            sup = ShardedSupplement(be, rank, ranks, dist)
+            with be.stream_scope():
+                out = sup.run(d_pre if rank == 0 else torch.empty((0, 3), dtype=torch.int32, device=dw.device))
+                got = out.clone()
+            torch.cuda.synchronize()
+            st = e.pkb_last_stats()
+            return got.cpu().numpy(), st["groups"], sup.exchange_bytes
+        finally:
+            e.close()
+    res = run_ranks(ranks, rank_main)
+    tot_groups = [sum(r[1][k] for r in res) for k in range(4)]
+    for r, (got, groups, xb) in enumerate(res):
+        assert got.shape == want.shape and (got == want).all(), r
+        assert len(xb) == 4
+    # the groups were dealt out: every rank joined some of them, together all of them (the one-GPU count)
+    eng.pkb_supplement_host(words, lens, pre, p)
+    assert tot_groups == list(eng.pkb_last_stats()["groups"])
+    assert all(sum(r[1]) > 0 for r in res)

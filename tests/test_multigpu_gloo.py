@@ -401,3 +401,82 @@ def test_piece_bounds_cover_the_rank_range():
                     if b[r + 1] - b[r] > 1000 and pieces > 1:          # each piece about three quarters of the one before it
                         sz = [y - x for x, y in zip(pb, pb[1:])]
                         assert all(0.70 < q / p < 0.80 for p, q in zip(sz, sz[1:]))
+
+
+class PySupplementBackend:
+    """Stand-in for the supplement phases of alga_amd.multigpu.HipBackend (alga_pkb_shard_*) on CPU tensors: a toy 'group join' whose groups are
+    dealt out by hash -- a candidate edge (a, b, off) of round r belongs to rank mix(a * 131 + b) mod world -- with the engine's semantics (every
+    addition is judged against the graph as it stood when the round began; the merge keeps the smallest offset per pair)."""
+
+    def __init__(self, n_nodes, rounds_of_candidates):
+        self.n, self.cands = n_nodes, rounds_of_candidates
+        self.device = torch.device("cpu")
+
+    def pkb_begin(self, edges, rank, world):
+        self.rank, self.world, self.round = rank, world, 0
+        e = edges.numpy().astype(np.int64)
+        self.g = {(int(a), int(b)): int(o) for a, b, o in e}
+
+    def pkb_round(self):
+        out = []
+        for a, b, off in self.cands[self.round]:
+            if ((a * 131 + b) * 2654435761 >> 7) % self.world != self.rank:
+                continue
+            cur = self.g.get((a, b))
+            if cur is None or cur > off:                      # addDirectedEdge keeps the minimum (src/DataStructures/Graph.cpp:53-71)
+                out.append((a << 36) | (b << 9) | off)
+        return torch.tensor(out, dtype=torch.int64)
+
+    def pkb_merge(self, allk):
+        for k in allk.tolist():
+            a, b, off = k >> 36, (k >> 9) & ((1 << 27) - 1), k & 511
+            if self.g.get((a, b), 1 << 30) > off:
+                self.g[(a, b)] = off
+        self.round += 1
+
+    def pkb_end(self):
+        e = sorted((a, b, o) for (a, b), o in self.g.items())
+        return torch.tensor(e, dtype=torch.int32).reshape(-1, 3)
+
+
+def _supp_inputs():
+    rng = np.random.default_rng(77)
+    n = 400
+    pre = sorted({(int(a), int(b)): int(o) for a, b, o in zip(rng.integers(0, n, 900), rng.integers(0, n, 900), rng.integers(1, 60, 900))}.items())
+    pre = np.array([(a, b, o) for (a, b), o in pre], dtype=np.int32)
+    rounds = [[(int(a), int(b), int(o)) for a, b, o in zip(rng.integers(0, n, 700), rng.integers(0, n, 700), rng.integers(0, 50, 700))] for _ in range(4)]
+    return n, pre, rounds
+
+
+def _worker_supplement(rank, world, port, out_dir):
+    import torch.distributed as dist
+    from alga_amd import multigpu
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n, pre, rounds = _supp_inputs()
+        sup = multigpu.ShardedSupplement(PySupplementBackend(n, rounds), rank, world, dist)
+        # the exact graph is complete on rank 0 only (the gather of the build); the driver broadcasts it
+        out = sup.run(torch.from_numpy(pre) if rank == 0 else torch.empty((0, 3), dtype=torch.int32))
+        np.save(os.path.join(out_dir, "supp_%d.npy" % rank), out.numpy())
+        assert len(sup.exchange_bytes) == 4
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_supplement_driver_over_gloo(tmp_path, world):
+    """alga_amd.multigpu.ShardedSupplement (what bench.py --gpus N runs on configs[4]): broadcast of the exact graph, four rounds of {own
+    additions, variable-length all-gather, merge of all} over gloo -- every rank must end with the graph one process gives."""
+    n, pre, rounds = _supp_inputs()
+    one = PySupplementBackend(n, rounds)
+    one.pkb_begin(torch.from_numpy(pre), 0, 1)
+    for _ in range(4):
+        one.pkb_merge(one.pkb_round())
+    want = one.pkb_end().numpy()
+    assert len(want) > len(pre)
+    mp.spawn(_worker_supplement, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        got = np.load(os.path.join(str(tmp_path), "supp_%d.npy" % r))
+        assert got.shape == want.shape and (got == want).all(), r
