@@ -822,13 +822,21 @@ int alga_prefsuf_build_device(alga_engine *e, const alga_nodes *nodes, const alg
 
 // Host node set -> the engine's own upload buffers, in the engine's row layout (hbm_row_stride: 16-byte aligned rows that never
 // straddle a 64-byte line take the wide-load kernels); *dev describes the resident copy (masks included when given).
-static int upload_nodes_impl(alga_engine *e, const alga_nodes *nodes, alga_nodes *dev, bool twin_rows);
+// mode 0: all of it.  The N-GPU host entry point (engine_multi.hip) cuts it in two so that the rows cross PCIe ONCE per node, not once per GPU:
+// mode 1 -- checks, lengths, and the rows [row_begin, row_end) of the caller's row array alone, into the raw buffer at their own place (room for
+// raw_rows_cap rows: the other ranks' slices arrive there by all-gather; *d_raw = the buffer); mode 2 -- what follows once the raw buffer is
+// complete: twin expansion / re-stride into the engine's layout, the masks.
+static int upload_nodes_impl(alga_engine *e, const alga_nodes *nodes, alga_nodes *dev, bool twin_rows, int mode = 0, uint64_t row_begin = 0, uint64_t row_end = 0,
+                             uint64_t raw_rows_cap = 0, uint32_t **d_raw = nullptr);
 
 int alga_upload_nodes(alga_engine *e, const alga_nodes *nodes, alga_nodes *dev) { return upload_nodes_impl(e, nodes, dev, false); }
 int alga_upload_twin_nodes(alga_engine *e, const alga_nodes *nodes, alga_nodes *dev) { return upload_nodes_impl(e, nodes, dev, true); }
+int alga_upload_nodes_phase(alga_engine *e, const alga_nodes *nodes, bool twin_rows, int mode, uint64_t row_begin, uint64_t row_end, uint64_t raw_rows_cap, alga_nodes *dev,
+                            uint32_t **d_raw) { return upload_nodes_impl(e, nodes, dev, twin_rows, mode, row_begin, row_end, raw_rows_cap, d_raw); }
 
 // twin_rows: nodes->words holds the rows of the ODD nodes only (row k = node 2k + 1); len / masks have all n entries
-static int upload_nodes_impl(alga_engine *e, const alga_nodes *nodes, alga_nodes *dev, bool twin_rows) {
+static int upload_nodes_impl(alga_engine *e, const alga_nodes *nodes, alga_nodes *dev, bool twin_rows, int mode, uint64_t row_begin, uint64_t row_end, uint64_t raw_rows_cap,
+                             uint32_t **d_raw) {
     if (!e) return ALGA_ERR_INVALID_ARGUMENT;
     e->err.clear();
     if (!nodes || !dev) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "nodes / output must not be NULL");
@@ -873,9 +881,10 @@ static int upload_nodes_impl(alga_engine *e, const alga_nodes *nodes, alga_nodes
         check_ms = now_ms_host() - t_check0;
     };
     struct Joiner { std::thread t; ~Joiner() { if (t.joinable()) t.join(); } } chk;
-    bool async_check = n >= (1u << 22);
+    bool async_check = n >= (1u << 22) && mode != 2;
+    if (mode == 2) async_check = false;
     if (async_check) { try { chk.t = std::thread(check); } catch (...) { async_check = false; } }
-    if (!async_check) { check(); if (check_msg) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, check_msg); }
+    if (!async_check && mode != 2) { check(); if (check_msg) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, check_msg); }
     const double t_up0 = now_ms_host();
     // the lengths cross PCIe as narrow as they are: a byte per node where no read is longer than 255 nt (every short-read set: 0.09 GB instead
     // of 0.36 GB at 90 M nodes), two up to 65 535; narrowed by the staging threads on their way into the pinned buffers, widened on the device
@@ -902,31 +911,34 @@ static int upload_nodes_impl(alga_engine *e, const alga_nodes *nodes, alga_nodes
     const int stride_up = alga::hbm_row_stride(nodes->stride_words);
     const size_t wbytes = n * (size_t) stride_up * sizeof(uint32_t);
     const size_t raw_bytes = (twin_rows ? n / 2 : n) * (size_t) nodes->stride_words * sizeof(uint32_t);
-    alga_forget_node_set(e);
+    if (mode != 2) alga_forget_node_set(e);
     if ((rc = alga_ensure(e, e->up_words, wbytes))) return rc;
     if ((rc = alga_ensure(e, e->up_len, n * sizeof(int32_t)))) return rc;
     alga_nodes dn = *nodes;
-    if (n) {
+    const size_t rows_total = twin_rows ? n / 2 : n, row_bytes = (size_t) nodes->stride_words * sizeof(uint32_t);
+    const bool via_raw = twin_rows || stride_up != nodes->stride_words || mode != 0;
+    if (n && mode != 2) {
         HIP_TRY(e, hipStreamSynchronize(s));                       // nothing of an earlier call still reads the upload buffers
-        if (twin_rows) {
-            // half of the rows cross PCIe; then the lengths (the expansion reads them)
-            if ((rc = alga_ensure(e, e->up_raw, raw_bytes))) return rc;
-            if ((rc = alga_staged_h2d(e, e->up_raw.p, nodes->words, raw_bytes))) return rc;
-            if ((rc = join_check())) return rc;
-            if ((rc = upload_len())) return rc;
-            launch_expand_twins((const uint32_t *) e->up_raw.p, nodes->stride_words, (const int32_t *) e->up_len.p, (uint32_t *) e->up_words.p, stride_up, (uint64_t) (n / 2), s);
-            if ((rc = alga_check_launch(e, "k_expand_twins"))) return rc;
-            HIP_TRY(e, hipStreamSynchronize(s));
-        } else
-        if (stride_up != nodes->stride_words) {
-            if ((rc = alga_ensure(e, e->up_raw, raw_bytes))) return rc;
-            if ((rc = alga_staged_h2d(e, e->up_raw.p, nodes->words, raw_bytes))) return rc;
-            launch_restride((const uint32_t *) e->up_raw.p, nodes->stride_words, (uint32_t *) e->up_words.p, stride_up, (uint64_t) n, s);
-            if ((rc = alga_check_launch(e, "k_restride"))) return rc;
-            HIP_TRY(e, hipStreamSynchronize(s));
+        if (via_raw) {
+            if ((rc = alga_ensure(e, e->up_raw, std::max(raw_bytes, (size_t) raw_rows_cap * row_bytes) + 64))) return rc;
+            const size_t r0 = mode == 1 ? (size_t) std::min<uint64_t>(row_begin, rows_total) : 0, r1 = mode == 1 ? (size_t) std::min<uint64_t>(row_end, rows_total) : rows_total;
+            if (r1 > r0 && (rc = alga_staged_h2d(e, (char *) e->up_raw.p + r0 * row_bytes, (const char *) nodes->words + r0 * row_bytes, (r1 - r0) * row_bytes))) return rc;
         } else if ((rc = alga_staged_h2d(e, e->up_words.p, nodes->words, raw_bytes))) return rc;
         if ((rc = join_check())) return rc;
-        if (!twin_rows) { if ((rc = upload_len())) return rc; HIP_TRY(e, hipStreamSynchronize(s)); }
+        if ((rc = upload_len())) return rc;                         // (the twin expansion reads the lengths)
+        HIP_TRY(e, hipStreamSynchronize(s));
+    }
+    if (d_raw) *d_raw = (uint32_t *) e->up_raw.p;
+    if (mode == 1) { e->stats_host[0] = check_ms; e->stats_host[1] = now_ms_host() - t_up0; return ALGA_OK; }
+    if (n && via_raw) {
+        if (twin_rows) {
+            launch_expand_twins((const uint32_t *) e->up_raw.p, nodes->stride_words, (const int32_t *) e->up_len.p, (uint32_t *) e->up_words.p, stride_up, (uint64_t) (n / 2), s);
+            if ((rc = alga_check_launch(e, "k_expand_twins"))) return rc;
+        } else {
+            launch_restride((const uint32_t *) e->up_raw.p, nodes->stride_words, (uint32_t *) e->up_words.p, stride_up, (uint64_t) n, s);
+            if ((rc = alga_check_launch(e, "k_restride"))) return rc;
+        }
+        HIP_TRY(e, hipStreamSynchronize(s));
     }
     if ((rc = join_check())) return rc;
     e->stats_host[0] = check_ms;
@@ -944,7 +956,7 @@ static int upload_nodes_impl(alga_engine *e, const alga_nodes *nodes, alga_nodes
         dn.align_to = (const uint8_t *) e->up_to.p;
     }
     *dev = dn;
-    e->stats_host[1] = now_ms_host() - t_up0;
+    e->stats_host[1] = (mode == 2 ? e->stats_host[1] : 0.0) + now_ms_host() - t_up0;
     return ALGA_OK;
 }
 

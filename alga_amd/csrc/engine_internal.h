@@ -147,6 +147,10 @@ struct AlgaPrepared {
                                      // entry array of the previous build of this node set is reused
 };
 
+// the upload of a host node set in two phases (engine.hip: upload_nodes_impl; mode 1 = my slice of the rows + all lengths, 2 = finish once the raw
+// buffer is complete): what alga_multi_prefsuf_build_host shards over the ranks
+extern "C" int alga_upload_nodes_phase(alga_engine *e, const alga_nodes *nodes, bool twin_rows, int mode, uint64_t row_begin, uint64_t row_end, uint64_t raw_rows_cap, alga_nodes *dev,
+                            uint32_t **d_raw);
 int alga_prepare(alga_engine *e, const alga_nodes *nodes, const alga_prefsuf_params *p, hipStream_t s, AlgaPrepared &out);
 int alga_cluster_alloc(alga_engine *e, const AlgaPrepared &pp);
 

@@ -122,6 +122,7 @@ struct alga_multi {
     std::vector<alga_prefsuf_stats> stats;
     DevBuf gathered;                                       // rank 0's device: the complete edge list
     alga_multi_stats mstats{};
+    uint64_t mstats_upload_bytes_per_rank = 0;             // host entry point: bytes of rows one rank brought up over its own PCIe link
 };
 
 namespace {
@@ -673,21 +674,46 @@ int alga_multi_prefsuf_build_host(alga_multi *m, const alga_nodes *nodes, const 
     *edges = nullptr; *n_edges = 0;
     int prev = -1;
     if (hipGetDevice(&prev) != hipSuccess) prev = -1;
-    // 1. the node set on every GPU: one upload per rank, each over its own PCIe link, side by side
+    // 1. the node set on every GPU.  The rows cross PCIe ONCE: rank r brings up its 1 / N of the caller's row array over its own link (all ranks
+    //    side by side), the slices are all-gathered between the GPUs (xGMI: RCCL, or peer copies), and every rank turns the complete raw buffer
+    //    into the engine's layout itself (twin expansion / re-stride).  The lengths (a byte per node on the wire) go to every rank directly.
+    //    (Round 4 uploaded the whole node set on every rank: N times the PCIe traffic for the same result.)
     const int N = m->n;
     std::vector<alga_nodes> dev((size_t) N);
-    std::vector<int> urc((size_t) N, ALGA_OK);
     const double t0 = now_ms();
-    {
-        std::vector<std::thread> th;
-        auto up = [&](int r) { urc[(size_t) r] = p->twin_rows ? alga_upload_twin_nodes(m->eng[(size_t) r], nodes, &dev[(size_t) r]) : alga_upload_nodes(m->eng[(size_t) r], nodes, &dev[(size_t) r]); };
-        try { for (int r = 1; r < N; r++) th.emplace_back(up, r); } catch (...) { for (int r = (int) th.size() + 1; r < N; r++) urc[(size_t) r] = ALGA_ERR_OUT_OF_MEMORY; }
-        up(0);
-        for (std::thread &x : th) x.join();
-    }
     int rc = ALGA_OK;
-    for (int r = 0; r < N && rc == ALGA_OK; r++)
-        if (urc[(size_t) r] != ALGA_OK) rc = mfail(m, urc[(size_t) r], "rank " + std::to_string(r) + ": upload: " + alga_last_error(m->eng[(size_t) r]));
+    {
+        const bool twin = p->twin_rows != 0;
+        const uint64_t rows = twin ? (uint64_t) nodes->n / 2 : (uint64_t) (nodes->n > 0 ? nodes->n : 0);
+        const size_t row_words = nodes->stride_words > 0 ? (size_t) nodes->stride_words : 1;
+        // equal slices of whole rows, padded so that the slice length in words is the same for every rank (the all-gather's unit)
+        const uint64_t chunk_rows = (rows + (uint64_t) N - 1) / (uint64_t) N;
+        m->rc.assign((size_t) N, ALGA_OK);
+        m->rank_err.assign((size_t) N, std::string());
+        m->declined.assign((size_t) N, 0);
+        m->shard_declined.assign((size_t) N, 0);
+        std::vector<uint32_t *> raw((size_t) N, nullptr);
+        auto up = [&](int r) {
+            Collectives co{m, r};
+            alga_engine *e = m->eng[(size_t) r];
+            (void) hipSetDevice(m->dev[(size_t) r]);
+            const int urc = N == 1 ? (twin ? alga_upload_twin_nodes(e, nodes, &dev[(size_t) r]) : alga_upload_nodes(e, nodes, &dev[(size_t) r]))
+                                   : alga_upload_nodes_phase(e, nodes, twin, 1, (uint64_t) r * chunk_rows, (uint64_t) (r + 1) * chunk_rows, chunk_rows * (uint64_t) N, &dev[(size_t) r], &raw[(size_t) r]);
+            if (urc != ALGA_OK) co.fail(urc, std::string("upload: ") + alga_last_error(e));
+            if (N == 1) return;
+            Agreed ag = rendezvous(m);                     // every rank's raw buffer exists (or somebody failed)
+            if (ag.failed) return;
+            ag = co.all_gather_u32(raw[(size_t) r], raw.data(), (size_t) chunk_rows * row_words);
+            if (ag.failed) return;
+            const int frc = alga_upload_nodes_phase(e, nodes, twin, 2, 0, 0, 0, &dev[(size_t) r], nullptr);
+            if (frc != ALGA_OK) co.fail(frc, std::string("upload (finish): ") + alga_last_error(e));
+            (void) rendezvous(m);
+        };
+        if (!run_rank_threads(m, up)) rc = mfail(m, ALGA_ERR_OUT_OF_MEMORY, "cannot start a host thread per GPU");
+        for (int r = 0; r < N && rc == ALGA_OK; r++)
+            if (m->rc[(size_t) r] != ALGA_OK) rc = mfail(m, m->rc[(size_t) r], "rank " + std::to_string(r) + ": " + m->rank_err[(size_t) r]);
+        m->mstats_upload_bytes_per_rank = (uint64_t) chunk_rows * row_words * 4;
+    }
     const double t1 = now_ms();
     const alga_edge *d = nullptr;
     uint64_t E = 0;

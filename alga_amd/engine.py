@@ -862,11 +862,12 @@ class MultiEngine:
         if rc:
             raise AlgaError(rc, "alga_engine_set_option(%s) on rank %d" % (name, rank))
 
-    def prefsuf_host(self, words, lens, min_overlap, rsoe_min_overlap, align_from=None, align_to=None, collect_stats=False, reduction="auto"):
+    def prefsuf_host(self, words, lens, min_overlap, rsoe_min_overlap, align_from=None, align_to=None, collect_stats=False, reduction="auto", twin_rows=False):
+        """twin_rows: `words` holds the rows of the odd nodes alone (alga_prefsuf_params.twin_rows)"""
         words = np.ascontiguousarray(words, dtype=np.uint32)
         lens = np.ascontiguousarray(lens, dtype=np.int32)
         n = int(lens.shape[0])
-        stride = int(words.shape[1]) if words.ndim == 2 else (words.size // max(n, 1))
+        stride = int(words.shape[1]) if words.ndim == 2 else (words.size // max(n // 2 if twin_rows else n, 1))
         keep = [words, lens]
         nd = _Nodes(words.ctypes.data, stride, lens.ctypes.data, n, None, None)
         if align_from is not None:
@@ -874,6 +875,7 @@ class MultiEngine:
         if align_to is not None:
             at = np.ascontiguousarray(align_to, dtype=np.uint8); keep.append(at); nd.align_to = at.ctypes.data
         p = Engine.params(min_overlap, rsoe_min_overlap, collect_stats, reduction)
+        p.twin_rows = 1 if twin_rows else 0
         out, m = C.c_void_p(), C.c_uint64()
         self._check(self._lib.alga_multi_prefsuf_build_host(self._h, C.byref(nd), C.byref(p), C.byref(out), C.byref(m)))
         try:

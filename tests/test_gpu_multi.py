@@ -237,3 +237,33 @@ def test_multi_supplement_equals_one_gpu(ranks):
             assert got.shape == want.shape and (got == want).all()
     finally:
         m.close()
+
+
+@pytest.mark.parametrize("ranks", [2, 3, 5])
+def test_multi_host_entry_uploads_a_slice_per_rank(ranks):
+    """alga_multi_prefsuf_build_host brings the rows over PCIe ONCE: every rank its 1 / N of the caller's row array, the slices all-gathered
+    between the GPUs, the engine's layout made on each rank (twin expansion / re-stride).  Odd row counts (the last slice is short), rows at
+    the Bitset's tight stride (9 words: re-strided on the device), twin rows (the odd nodes' rows alone), masks -- against the oracle."""
+    words, lens = _nodes(3001, 144, 6000, 95, 0.0, None)
+    tight = np.ascontiguousarray(words[:, :9])
+    want, _, _ = O.prefsuf(words, lens, 82, 116)
+    m = alga_amd.MultiEngine([0] * ranks, transport="copy")
+    try:
+        for _ in range(2):
+            got = m.prefsuf_host(tight, lens, 82, 116)
+            assert got.shape == want.shape and (got == want).all()
+        got = m.prefsuf_host(np.ascontiguousarray(tight[1::2]), lens, 82, 116, twin_rows=True)
+        assert got.shape == want.shape and (got == want).all()
+        rng = np.random.default_rng(4)
+        at = (rng.random(len(lens)) < 0.8).astype(np.uint8)
+        want_m, _, _ = O.prefsuf(words, lens, 82, 116, None, at)
+        got = m.prefsuf_host(words, lens, 82, 116, None, at)
+        assert got.shape == want_m.shape and (got == want_m).all()
+        # a bad pair is refused on every rank, and the handle works afterwards
+        l2 = lens.copy(); l2[10] = l2[10] - 1
+        with pytest.raises(alga_amd.AlgaError):
+            m.prefsuf_host(np.ascontiguousarray(tight[1::2]), l2, 82, 116, twin_rows=True)
+        got = m.prefsuf_host(tight, lens, 82, 116)
+        assert got.shape == want.shape and (got == want).all()
+    finally:
+        m.close()
