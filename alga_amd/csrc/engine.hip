@@ -133,6 +133,7 @@ int cluster_alloc(alga_engine *e, const Prepared &pp) {
 int pile_alloc(alga_engine *e, uint64_t n, uint32_t n_buckets, hipStream_t s) {
     int rc;
     if ((rc = alga_ensure(e, e->cl_pile_rec, pile_record_bytes(n)))) return rc;
+    if ((rc = alga_ensure(e, e->cl_pile_rec2, pile_record_bytes(n)))) return rc;
     if ((rc = alga_ensure(e, e->cl_pile_succ, ((size_t) n + 64) * 16))) return rc;
     if ((rc = alga_ensure(e, e->cl_pile_cnt, PILE_CNT_WORDS * sizeof(unsigned long long)))) return rc;
     if ((rc = alga_ensure(e, e->cl_pile_own, pile_own_mask_bytes(n)))) return rc;
@@ -232,7 +233,7 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
                     // the pile path needs ~180 B per node on top of the pairwise kernels' buffers (bucket table, group records, side records): an input
                     // that fitted without it must not fail because of it.  Give back what was allocated of it and take the pairwise kernels.
                     (void) hipGetLastError();
-                    alga_release(e->cl_pile_tab); alga_release(e->cl_pile_rec); alga_release(e->cl_pile_succ); alga_release(e->cl_pile_own);
+                    alga_release(e->cl_pile_tab); alga_release(e->cl_pile_rec); alga_release(e->cl_pile_rec2); alga_release(e->cl_pile_succ); alga_release(e->cl_pile_own);
                     e->pile_epoch = 0; e->pile_n = -1;
                     e->err.clear();
                     pile = false;
@@ -260,7 +261,7 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
                 }
                 e->pile_epoch++;
                 const bool from_consensus = e->opt_pile_runs != 0;
-                launch_pile_build(nd, cfg, cc, pp.uniform_len, (const uint32_t *) e->cl_keys[1].p, (const uint32_t *) e->cl_vals[1].p, e->cl_dir.p, e->cl_pile_rec.p, e->cl_pile_tab.p,
+                launch_pile_build(nd, cfg, cc, pp.uniform_len, (const uint32_t *) e->cl_keys[1].p, (const uint32_t *) e->cl_vals[1].p, e->cl_dir.p, e->cl_pile_rec.p, e->cl_pile_rec2.p, e->cl_pile_tab.p,
                                   e->pile_epoch, e->cl_pile_succ.p, e->cl_runs.p, pp.uniform_len - cfg.Lmin + 1, (const unsigned long long *) e->cl_pile_cnt.p,
                                   from_consensus ? (uint32_t *) e->cl_pile_own.p : nullptr, s);
                 if ((rc = alga_check_launch(e, "k_pile_build"))) return rc;
@@ -276,7 +277,7 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
                     if ((rc = alga_check_launch(e, "k_node_runs (own lists)"))) return rc;
                 }
                 if (e->opt_pile_check && from_consensus)
-                    launch_pile_check(e->cl_pile_succ.p, (uint64_t) nd.n, cc.n_buckets, e->cl_pile_tab.p, e->pile_epoch, e->cl_runs.p, nd.n, pp.uniform_len - cfg.Lmin + 1,
+                    launch_pile_check(e->cl_pile_succ.p, (uint64_t) nd.n, cc.n_buckets, e->cl_pile_tab.p, e->cl_pile_rec2.p, e->pile_epoch, e->cl_runs.p, nd.n, pp.uniform_len - cfg.Lmin + 1,
                                       (unsigned long long *) e->cl_pile_cnt.p, s);
                 e->pile_n = nd.n; e->pile_words = (const void *) nd.words;
                 e->pile_timed = nd.n > 0;
@@ -325,7 +326,7 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
                 const bool piled = pile && e->pile_n == nd.n && e->pile_words == (const void *) nd.words;
                 if (piled) {
                     // k_pile_probe first; it and k_probe_stream read the same two counters k_pile_build left and exactly one of them works
-                    launch_pile_probe(nd, cfg, cc, pp.uniform_len, e->cl_pile_tab.p, e->pile_epoch, e->cl_pile_rec.p, e->cl_pile_succ.p,
+                    launch_pile_probe(nd, cfg, cc, pp.uniform_len, e->cl_pile_tab.p, e->pile_epoch, e->cl_pile_rec.p, e->cl_pile_rec2.p, e->cl_pile_succ.p,
                                       e->cl_runs.p, cnt, (uint32_t *) e->outdeg.p, (unsigned long long *) e->loc_first.p, (unsigned long long *) e->loc_second.p,
                                       (int32_t *) e->cl_defer.p, (uint32_t) n_src, (const unsigned long long *) e->cl_pile_cnt.p, e->n_cu, s);
                     if ((rc = alga_check_launch(e, "k_pile_probe"))) return rc;

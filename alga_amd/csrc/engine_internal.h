@@ -65,6 +65,7 @@ struct alga_engine {
     int    opt_test_pile_oom = 0;                           // tests only: the pile path's allocation reports out of memory (the build must continue on the pairwise kernels)
     bool   pile_timed = false;                              // EV_DIR was recorded in the last discovery (k_pile_build ran behind it)
     DevBuf cl_pile_succ;                                    // per entry (16 B): its id, the member of its own pile that starts next to its right, its place in the pile (k_pile_probe reads this, not the entry)
+    DevBuf cl_pile_rec2;                                    // run lists of the further k-mer groups of a bucket (64 B at the group's slot, laid out like the second half of a bucket's line)
     DevBuf cl_pile_rec, cl_pile_cnt, cl_pile_tab;   // records of further k-mer groups (64 B per entry slot), group of every entry, {buckets, irregular buckets} of the sample, bucket records (128 B per bucket)
     uint32_t pile_epoch = 0;                                // of the last k_pile_build: what makes a record of cl_pile_tab valid (the table is cleared when it is allocated, and when this wraps)
     int32_t pile_n = -1; const void *pile_words = nullptr;  // the node set the pile records describe (n < 0: none)

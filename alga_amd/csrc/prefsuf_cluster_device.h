@@ -111,7 +111,8 @@ constexpr int NR_STACK = 8;          // minimum records kept per row and block (
 // of 16 nucleotides = a whole row word, <= min(w, 64): 64 for the wide nodes cluster_plan admits), the last piece first, each by the same three
 // steps on the row shifted by the piece's first window; the runs of the pieces are listed one after the other (a minimizer that spans a seam makes
 // two runs: one more look-up for a node, merged again for a pile).
-template <bool WIDE>
+// RCAP: runs the list holds (rbuf has RCAP + 1 rows; CL_RMAX for a node's list, more for a pile's extent, whose pieces each add a run at their seam)
+template <bool WIDE, int RCAP = CL_RMAX>
 __device__ __forceinline__ void node_runs_core(const uint32_t *row, int nwin, bool act, const ClusterCfg &cc, uint32_t (*stk)[TK_ROWS], uint16_t (*rbuf)[TK_ROWS], int t,
                                                int &nr, bool &uncovered, bool &stack_ovf, uint32_t &cur0, int step = 64) {
     constexpr int S0 = NR_STACK + 1;                       // first row of block 0's records
@@ -196,14 +197,14 @@ __device__ __forceinline__ void node_runs_core(const uint32_t *row, int nwin, bo
                 const uint32_t wn = c0 < top ? c0 : top;
                 const int pc = pe < p_hi ? pe : p_hi;
                 const bool em = wn != win && pc < p_hi;         // the windows (pc, p_hi] had `win`
-                rbuf[(em && nr < CL_RMAX) ? nr : CL_RMAX][t] = (uint16_t) (((win & 255u) | ((uint32_t) (pc + 1) << 8)) + hq);
+                rbuf[(em && nr < RCAP) ? nr : RCAP][t] = (uint16_t) (((win & 255u) | ((uint32_t) (pc + 1) << 8)) + hq);
                 uncovered = uncovered || (em && win == 0xFFFFFFFFu);
                 nr += em ? 1 : 0;
                 p_hi = em ? pc : p_hi;
                 win = wn;
             }
             if (act) {                                         // the run of the half's first window
-                if (nr < CL_RMAX) rbuf[nr][t] = (uint16_t) ((win & 255u) + hq);
+                if (nr < RCAP) rbuf[nr][t] = (uint16_t) ((win & 255u) + hq);
                 uncovered = uncovered || win == 0xFFFFFFFFu;
                 nr++;
             }

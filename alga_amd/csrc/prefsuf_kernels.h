@@ -80,12 +80,12 @@ void       launch_pile_sample(const NodesDev &nd, const ClusterCfg &cc, int unif
 constexpr int PILE_CNT_WORDS = 6;      // {sampled buckets, irregular ones, sampled entries, own-list ids, members checked, members whose lists differ}
 size_t     pile_own_mask_bytes(uint64_t n);
 void       launch_pile_build(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterCfg &cc, int uniform_len, const uint32_t *skeys, const uint32_t *sids, const void *dir, void *rec,
-                             void *tab, uint32_t epoch, void *side, const void *runs, int nwin, const unsigned long long *pile_cnt,
+                             void *rec2 /* run lists of the further groups, at the groups' slots */, void *tab, uint32_t epoch, void *side, const void *runs, int nwin, const unsigned long long *pile_cnt,
                              uint32_t *own_mask /* null: the piles' run lists from their outer members' own lists (round 4) */, hipStream_t s);
 void       launch_pile_own_ids(const uint32_t *own_mask, const uint32_t *sids, uint64_t n_entries, int32_t *list, uint32_t cap, unsigned long long *pile_cnt, hipStream_t s);
-void       launch_pile_check(const void *side, uint64_t n_entries, uint32_t n_buckets, const void *tab, uint32_t epoch, const void *runs, int n_nodes, int nwin,
+void       launch_pile_check(const void *side, uint64_t n_entries, uint32_t n_buckets, const void *tab, const void *rec2, uint32_t epoch, const void *runs, int n_nodes, int nwin,
                              unsigned long long *pile_cnt, hipStream_t s);
-void       launch_pile_probe(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterCfg &cc, int uniform_len, const void *tab, uint32_t epoch, const void *rec, const void *side,
+void       launch_pile_probe(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterCfg &cc, int uniform_len, const void *tab, uint32_t epoch, const void *rec, const void *rec2, const void *side,
                              const void *runs, unsigned long long *counters, uint32_t *deg, unsigned long long *first, unsigned long long *second, int32_t *defer_list,
                              uint32_t defer_cap, const unsigned long long *pile_cnt, int n_cu, hipStream_t s);
 

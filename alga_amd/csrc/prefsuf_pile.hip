@@ -217,10 +217,14 @@ __global__ void __launch_bounds__(PB_THREADS, 3) k_pile_build(NodesDev nd, const
                 if (right != 0ull && my_slot > s && my_rank >= 1) { succ_id = sSlot[my_slot - 1]; delta = 1u + (uint32_t) __builtin_ctzll(right); }
                 // ... and what k_pile_probe reads of the entry AS A SOURCE: a member of a regular bucket's first group equals that group's consensus on
                 // its whole extent (verified above), so the probe takes its row from the bucket's record, which it reads anyway, not from the entry
-                const bool first_group = k == 0 && sBad[s] == 0u && nsub <= PILE_MAXSUB;
-                const bool leftmost = first_group && t == (int) (sMax[s] & 0xFFFFu);          // T0: k_pile_runs makes the pile's run list from its lane
-                side[j] = make_uint4(node_id, succ_id, delta | ((uint32_t) m << 8) | ((uint32_t) k << 16) | (leftmost ? 0x40000000u : 0u) | (first_group ? 0x80000000u : 0u), key >> idx_shift);
-                // an entry outside a first group reads its OWN run list as a source (k_pile_probe): bit j of the mask the list-driven key pass works from
+                // (round 5, own_mask != null: the members of EVERY group of a regular bucket -- a further group's consensus sits in `rec` at slot first + k,
+                //  its run list in `rec2` at the same slot (k_pile_runs_consensus); round 4's form knows the first group only)
+                const bool first_group = (k == 0 || own_mask != nullptr) && k < PILE_MAXSUB && sBad[s] == 0u && nsub <= PILE_MAXSUB;
+                const bool leftmost = first_group && t == (int) (sMax[L] & 0xFFFFu);          // T0 of its group: the lane the group's run list is made from
+                // the last word: the bucket (a first group's record is the bucket's line of `tab`), or the slot of a further group's records
+                side[j] = make_uint4(node_id, succ_id, delta | ((uint32_t) m << 8) | ((uint32_t) k << 16) | (leftmost ? 0x40000000u : 0u) | (first_group ? 0x80000000u : 0u),
+                                     k == 0 ? key >> idx_shift : (uint32_t) (e0 + (uint64_t) k));
+                // an entry of no pile reads its OWN run list as a source (k_pile_probe): bit j of the mask the list-driven key pass works from
                 if (!first_group && own_mask) atomicOr(&own_mask[j >> 5], 1u << (j & 31u));
             }
             if (!SAMPLE && L == t && k >= 1 && k < PILE_MAXSUB) {
@@ -356,12 +360,14 @@ __global__ void __launch_bounds__(256) k_pile_runs(const uint4 *__restrict__ sid
 // its members probe with their own lists (own_mask), and a member whose own list is flagged as well goes to the general kernel.
 constexpr int PR_TILE = 3072;                              // entries per block of k_pile_runs_consensus (~500 piles at 30x: four rounds of 128)
 constexpr int PR_TKW = 21;
-__global__ void __launch_bounds__(TK_ROWS) k_pile_runs_consensus(const uint4 *__restrict__ side, uint64_t n_entries, uint32_t n_buckets, uint4 *__restrict__ tab, ClusterCfg cc, int U, int Lmin,
+constexpr int PR_RCAP = 14;                                // raw runs of a pile's extent (the eight a list holds after the seams are merged + a run per seam)
+__global__ void __launch_bounds__(TK_ROWS) k_pile_runs_consensus(const uint4 *__restrict__ side, uint64_t n_entries, uint32_t n_buckets, uint4 *__restrict__ tab, const uint4 *__restrict__ rec,
+                                                                 uint4 *__restrict__ rec2, ClusterCfg cc, int U, int Lmin,
                                                                  const unsigned long long *__restrict__ pile_cnt, uint32_t *__restrict__ own_mask) {
     if (pile_declines(pile_cnt)) return;
     __shared__ uint32_t s[TK_ROWS][PR_TKW];
     __shared__ uint32_t stk[2 * (NR_STACK + 1)][TK_ROWS];
-    __shared__ uint16_t rbuf[CL_RMAX + 1][TK_ROWS];
+    __shared__ uint16_t rbuf[PR_RCAP + 1][TK_ROWS];
     __shared__ uint32_t sList[PR_TILE];                    // buckets of the tile's piles
     __shared__ uint32_t sN;
     const int t = (int) threadIdx.x;
@@ -373,7 +379,8 @@ __global__ void __launch_bounds__(TK_ROWS) k_pile_runs_consensus(const uint4 *__
         const uint64_t j = base + (uint64_t) q * TK_ROWS + (uint64_t) t;
         if (j < n_entries) {
             const uint4 sd = side[j];
-            if ((sd.z >> 30) & 1u) sList[atomicAdd(&sN, 1u)] = min(sd.w, n_buckets);      // (the order of the piles in the list is free: each writes its own record)
+            // (the order of the piles in the list is free: each writes its own record).  A first group: its bucket; a further group: its slot | bit 31
+            if ((sd.z >> 30) & 1u) sList[atomicAdd(&sN, 1u)] = ((sd.z >> 16) & 3u) == 0u ? min(sd.w, n_buckets) : (uint32_t) min((uint64_t) sd.w, n_entries) | 0x80000000u;
         }
     }
     __syncthreads();
@@ -382,14 +389,18 @@ __global__ void __launch_bounds__(TK_ROWS) k_pile_runs_consensus(const uint4 *__
     const int step = max(16, min(64, cc.w) & ~15);         // windows per piece of the sweep: no more than w, whole row words (w >= 16 for every shape pile_plan takes)
     for (int c0 = 0; c0 < np; c0 += TK_ROWS) {             // uniform
         const bool in = c0 + t < np;
-        uint4 *line = tab + (size_t) sList[in ? c0 + t : 0] * 8;
+        const uint32_t who = sList[in ? c0 + t : 0];
+        const bool further = (who >> 31) != 0u;            // a further group of its bucket: consensus in rec, list into rec2
+        const uint32_t slot = who & 0x7FFFFFFFu;
+        uint4 *line = tab + (size_t) (further ? 0u : who) * 8;
+        const uint4 *src = further ? rec + (size_t) slot * 4 : (const uint4 *) line;
         uint32_t S[PILE_SW + 1];
         unsigned long long rm = 0ull;
         {
-            const uint4 l0 = line[0], l1 = line[1], l2 = line[2], l3 = line[3];
+            const uint4 l0 = src[0], l1 = src[1], l2 = src[2], l3 = src[3];
             S[0] = l0.x; S[1] = l0.y; S[2] = l0.z; S[3] = l0.w; S[4] = l1.x; S[5] = l1.y; S[6] = l1.z; S[7] = l1.w;
             S[8] = l2.x; S[9] = l2.y; S[10] = l2.z; S[11] = l2.w; S[12] = l3.x; S[13] = 0u;
-            rm = in ? (((unsigned long long) l3.z << 32) | l3.y) : 0ull;
+            rm = !in ? 0ull : (further ? (((unsigned long long) l3.w << 32) | l3.z) : (((unsigned long long) l3.z << 32) | l3.y));
         }
         const bool act = in && rm != 0ull;
         const int m_min = act ? __clzll((long long) rm) : 0, m_max = act ? 63 - __builtin_ctzll(rm) : 0;
@@ -414,8 +425,8 @@ __global__ void __launch_bounds__(TK_ROWS) k_pile_runs_consensus(const uint4 *__
         int nr = 0;
         bool uncovered = false, stack_ovf = false;
         uint32_t cur0 = 0u;
-        node_runs_core<true>(s[t], nwin, act, cc, stk, rbuf, t, nr, uncovered, stack_ovf, cur0, step);
-        bool ok = act && nr >= 1 && nr <= CL_RMAX && !uncovered && !stack_ovf;
+        node_runs_core<true, PR_RCAP>(s[t], nwin, act, cc, stk, rbuf, t, nr, uncovered, stack_ovf, cur0, step);
+        bool ok = act && nr >= 1 && nr <= PR_RCAP && !uncovered && !stack_ovf;
         // runs as they were found: the last windows first, q | p0 << 8 in the extent's own coordinates, p1 = p0 of the run before.  The record
         // wants them ascending on the pile's axis (coordinate + 64 in a byte); the two halves of the window range meet at window 64: a minimizer
         // on both sides of that seam is ONE run (k_pile_probe takes "the same minimizer twice" for a tandem repeat)
@@ -424,8 +435,8 @@ __global__ void __launch_bounds__(TK_ROWS) k_pile_runs_consensus(const uint4 *__
         for (int k = 0; k < PILE_RUNS; k++) { key_[k] = 0u; kc_[k] = 0u; }
         int n = 0;
         uint32_t last_q = 0xFFFFFFFFu;
-        const int nrs = nr < CL_RMAX ? nr : CL_RMAX;
-        for (int r = CL_RMAX - 1; r >= 0; r--) {
+        const int nrs = nr < PR_RCAP ? nr : PR_RCAP;
+        for (int r = PR_RCAP - 1; r >= 0; r--) {
             if (ok && r < nrs) {
                 const uint32_t d = rbuf[r][t];
                 const int q = (int) (d & 255u), p0 = (int) (d >> 8);
@@ -441,7 +452,20 @@ __global__ void __launch_bounds__(TK_ROWS) k_pile_runs_consensus(const uint4 *__
             }
         }
         ok = ok && n >= 1 && n <= PILE_RUNS;
-        if (in) {
+        if (in && further) {
+            // a further group: its list in rec2 at the group's slot, laid out like the second half of a bucket's line (word 0 = runs << 8 | end << 16)
+            uint4 *l2 = rec2 + (size_t) slot * 4 - 4;      // (pile_list_store writes line[4 .. 7])
+            pile_list_store(l2, 0u, ok, n, key_, kc_, (uint32_t) (nwin - m_max + 64));
+            if (!ok) {
+                // its members probe with their own lists: the entries of the bucket (it starts k slots back) that carry this group's slot
+                // (the bucket begins k <= 3 slots before the group's slot)
+                const uint64_t jb = slot >= 3u ? (uint64_t) slot - 3u : 0ull;
+                for (uint64_t j2 = jb; j2 < jb + 64u + 3u && j2 < n_entries; j2++) {
+                    const uint4 s2 = side[j2];
+                    if ((s2.z >> 31) && ((s2.z >> 16) & 3u) != 0u && s2.w == slot) atomicOr(&own_mask[j2 >> 5], 1u << (j2 & 31u));
+                }
+            }
+        } else if (in) {
             uint32_t *lw = reinterpret_cast<uint32_t *>(line);
             pile_list_store(line, lw[16], ok, n, key_, kc_, (uint32_t) (nwin - m_max + 64));
             if (!ok) {
@@ -452,7 +476,7 @@ __global__ void __launch_bounds__(TK_ROWS) k_pile_runs_consensus(const uint4 *__
                 const uint32_t cntb = min(lw[16] & 255u, 64u), e0b = lw[17];
                 for (uint32_t i2 = 0; i2 < cntb; i2++) {
                     const uint64_t j2 = (uint64_t) e0b + i2;
-                    if (j2 < n_entries && (side[j2].z >> 31)) atomicOr(&own_mask[j2 >> 5], 1u << (j2 & 31u));
+                    if (j2 < n_entries) { const uint4 s2 = side[j2]; if ((s2.z >> 31) && ((s2.z >> 16) & 3u) == 0u) atomicOr(&own_mask[j2 >> 5], 1u << (j2 & 31u)); }
                 }
             }
         }
@@ -494,17 +518,18 @@ __global__ void __launch_bounds__(256) k_pile_own_ids(const uint32_t *__restrict
 
 // test harness (engine option "pile_check"; every node has its own run list): a first-group member's own list against its pile's list clipped
 // to its windows -- count of the members for which the two differ
-__global__ void __launch_bounds__(256) k_pile_list_check(const uint4 *__restrict__ side, uint64_t n_entries, uint32_t n_buckets, const uint4 *__restrict__ tab, uint32_t epoch,
-                                                         const uint2 *__restrict__ runs, int n_nodes, int nwin, unsigned long long *__restrict__ out /* [0] members checked, [1] mismatches */,
+__global__ void __launch_bounds__(256) k_pile_list_check(const uint4 *__restrict__ side, uint64_t n_entries, uint32_t n_buckets, const uint4 *__restrict__ tab, const uint4 *__restrict__ rec2,
+                                                         uint32_t epoch, const uint2 *__restrict__ runs, int n_nodes, int nwin, unsigned long long *__restrict__ out /* [0] members checked, [1] mismatches */,
                                                          const unsigned long long *__restrict__ pile_cnt) {
     if (pile_declines(pile_cnt)) return;
     const uint64_t j = (uint64_t) blockIdx.x * 256 + threadIdx.x;
     if (j >= n_entries) return;
     const uint4 sd = side[j];
     if ((sd.z >> 31) == 0u) return;
-    const uint4 *line = tab + (size_t) min(sd.w, n_buckets) * 8;
-    const uint4 l3 = line[3], l4 = line[4];
-    if ((l3.w >> 23) != epoch || ((l3.w >> 22) & 1u)) return;                    // an irregular bucket (or one without a list): nothing to compare
+    const bool further = ((sd.z >> 16) & 3u) != 0u;        // (its list: rec2 at the group's slot, laid out like words 16 .. 31 of a bucket's line)
+    const uint4 *line = further ? rec2 + (size_t) min((uint64_t) sd.w, n_entries - 1) * 4 - 4 : tab + (size_t) min(sd.w, n_buckets) * 8;
+    const uint4 l4 = line[4];
+    if (!further) { const uint4 l3 = line[3]; if ((l3.w >> 23) != epoch || ((l3.w >> 22) & 1u)) return; }      // an irregular bucket: nothing to compare
     const int npr = (int) ((l4.x >> 8) & 15u);
     if (npr == 0) return;
     const uint32_t *lw = reinterpret_cast<const uint32_t *>(line);
@@ -558,7 +583,7 @@ constexpr int PP_LSTRIDE = 20;
 // (five spill: 9.9 against 7.9 ms): side record and run list are read a tile ahead, the records of the next run are on their way while
 // the current one is compared (of the next two: no faster), the run loop is unrolled over the eight slots (static registers; a wave skips the slots none of its lanes uses).
 __global__ void __launch_bounds__(PP_WAVES * 64, PP_OCC) k_pile_probe(PrefSufCfg cfg, ClusterCfg cc, int U, NodesDev nd, uint64_t n_entries, int n_nodes,
-                                                                 const uint4 *__restrict__ tab, uint32_t epoch, const uint4 *__restrict__ rec,
+                                                                 const uint4 *__restrict__ tab, uint32_t epoch, const uint4 *__restrict__ rec, const uint4 *__restrict__ rec2,
                                                                  const uint4 *__restrict__ side, const uint2 *__restrict__ runs, ProbeOut o, int32_t *__restrict__ defer_list, uint32_t defer_cap,
                                                                  const unsigned long long *__restrict__ pile_cnt) {
     // the records of the slot at hand, ONE copy per distinct bucket of the wave (the members of a pile sit side by side and want the same
@@ -603,8 +628,10 @@ __global__ void __launch_bounds__(PP_WAVES * 64, PP_OCC) k_pile_probe(PrefSufCfg
     };
     // Where a lane's run list comes from: the second half of its home bucket's record (the PILE's run list, k_pile_build: one 64-byte read
     // shared by the pile's members, who sit side by side) for a member of the bucket's first group; its own list by id (a random read) otherwise.
+    // (a member of a further group of its bucket: the group's list in rec2 at the group's slot, laid out like the second half of a bucket's line)
     auto run_list_of = [&](const uint4 &sd) -> const uint4 * {
-        return (sd.z >> 31) ? tab + (size_t) min(sd.w, cc.n_buckets) * 8 + 4 : reinterpret_cast<const uint4 *>(runs + (size_t) sd.x * CL_RMAX);
+        if ((sd.z >> 31) == 0u) return reinterpret_cast<const uint4 *>(runs + (size_t) sd.x * CL_RMAX);
+        return ((sd.z >> 16) & 3u) == 0u ? tab + (size_t) min(sd.w, cc.n_buckets) * 8 + 4 : rec2 + (size_t) min((uint64_t) sd.w, last) * 4;
     };
     const int nwin = U - cfg.Lmin + 1;
     uint4 next_side = side_of(blockIdx.x < n_tiles ? blockIdx.x : 0);
@@ -800,6 +827,31 @@ __global__ void __launch_bounds__(PP_WAVES * 64, PP_OCC) k_pile_probe(PrefSufCfg
         wave_lds_fence();
     };
     if (um & 1u) issue(0);
+    // A member of a FURTHER group of its bucket (another k-mer in the same bucket: one entry in ten): its row is its group's consensus on its own
+    // extent as well -- read from the group's record (rec, shared by the group's members: no read by id), through this lane's LDS stretch,
+    // which the slot loop has not touched yet (the records of slot 0 are still in registers)
+    {
+        const bool fur = row_from_pile && ((my.z >> 16) & 3u) != 0u;
+        if (__ballot(fur) != 0ull) {                       // uniform
+            const uint64_t se = min((uint64_t) my.w, last);
+            uint4 Q0 = make_uint4(0u, 0u, 0u, 0u), Q1 = Q0, Q2 = Q0, Q3 = Q0;
+            if (fur) { Q0 = rec[se * 4]; Q1 = rec[se * 4 + 1]; Q2 = rec[se * 4 + 2]; Q3 = rec[se * 4 + 3]; }
+            uint4 *mine = reinterpret_cast<uint4 *>(sl + lane * PP_LSTRIDE);
+            mine[0] = Q0; mine[1] = Q1; mine[2] = Q2; mine[3] = make_uint4(Q3.x, 0u, 0u, 0u);
+            wave_lds_fence();
+            // my row = the consensus from index 64 - m_C on (bit 2 (128 - m_C) of the record padded with four words in front)
+            const int mC = (int) ((my.z >> 8) & 63u);
+            const uint32_t *ss = sl + lane * PP_LSTRIDE - 4;
+            const int ob = 2 * (128 - mC), w0 = ob >> 5, sh = ob & 31;
+            uint32_t x[10];
+#pragma unroll
+            for (int k = 0; k < 10; k++) x[k] = ss[w0 + k];
+#pragma unroll
+            for (int k = 0; k < 9; k++) { const uint32_t sw = funnel(x[k], x[k + 1], sh) & low_bits32(2 * U - 32 * k); B[k] = fur ? sw : B[k]; }
+            got_row = got_row || fur;
+            wave_lds_fence();
+        }
+    }
 #pragma unroll
     for (int a = 0; a < CL_RMAX; a++) {                    // (slot 0 first: the home run of a lane that takes its row from the pile)
         const bool use = ((um >> a) & 1u) != 0u;           // uniform: a lane of the wave has a run in this slot
@@ -986,8 +1038,8 @@ void launch_pile_sample(const NodesDev &nd, const ClusterCfg &cc, int uniform_le
 // own_mask != null: the run lists come from the consensus (k_pile_runs_consensus) and the entries that read a list of their own are noted
 // in own_mask (zeroed here); null: round 4's form -- the pile's list joined from the own lists of its two outer members (k_pile_runs: every node
 // must have its run list then)
-void launch_pile_build(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterCfg &cc, int uniform_len, const uint32_t *skeys, const uint32_t *sids, const void *dir, void *rec, void *tab,
-                       uint32_t epoch, void *side, const void *runs, int nwin, const unsigned long long *pile_cnt, uint32_t *own_mask, hipStream_t s) {
+void launch_pile_build(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterCfg &cc, int uniform_len, const uint32_t *skeys, const uint32_t *sids, const void *dir, void *rec, void *rec2,
+                       void *tab, uint32_t epoch, void *side, const void *runs, int nwin, const unsigned long long *pile_cnt, uint32_t *own_mask, hipStream_t s) {
     const uint64_t n_entries = nd.n > 0 ? (uint64_t) nd.n : 0;
     if (n_entries == 0) return;
     const uint64_t tiles = (n_entries + PB_TILE - 1) / PB_TILE;
@@ -995,8 +1047,8 @@ void launch_pile_build(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterC
     hipLaunchKernelGGL((k_pile_build<false>), dim3((unsigned) tiles), dim3(PB_THREADS), 0, s, nd, skeys, sids, n_entries, (const uint4 *) dir, cc, uniform_len, (uint4 *) rec, (uint4 *) tab, epoch,
                        (uint4 *) side, const_cast<unsigned long long *>(pile_cnt), own_mask);
     if (own_mask)
-        hipLaunchKernelGGL(k_pile_runs_consensus, dim3((unsigned) ((n_entries + PR_TILE - 1) / PR_TILE)), dim3(TK_ROWS), 0, s, (const uint4 *) side, n_entries, cc.n_buckets, (uint4 *) tab, cc,
-                           uniform_len, cfg.Lmin, pile_cnt, own_mask);
+        hipLaunchKernelGGL(k_pile_runs_consensus, dim3((unsigned) ((n_entries + PR_TILE - 1) / PR_TILE)), dim3(TK_ROWS), 0, s, (const uint4 *) side, n_entries, cc.n_buckets, (uint4 *) tab,
+                           (const uint4 *) rec, (uint4 *) rec2, cc, uniform_len, cfg.Lmin, pile_cnt, own_mask);
     else
         hipLaunchKernelGGL(k_pile_runs, dim3((unsigned) ((n_entries + 255) / 256)), dim3(256), 0, s, (const uint4 *) side, n_entries, cc.n_buckets, (uint4 *) tab, (const uint2 *) runs, nd.n, nwin, pile_cnt);
 }
@@ -1011,14 +1063,15 @@ void launch_pile_own_ids(const uint32_t *own_mask, const uint32_t *sids, uint64_
 }
 
 // test harness: members checked / members whose own list differs from their pile's clipped list -> pile_cnt[4], pile_cnt[5]
-void launch_pile_check(const void *side, uint64_t n_entries, uint32_t n_buckets, const void *tab, uint32_t epoch, const void *runs, int n_nodes, int nwin, unsigned long long *pile_cnt,
-                       hipStream_t s) {
+void launch_pile_check(const void *side, uint64_t n_entries, uint32_t n_buckets, const void *tab, const void *rec2, uint32_t epoch, const void *runs, int n_nodes, int nwin,
+                       unsigned long long *pile_cnt, hipStream_t s) {
     if (n_entries == 0) return;
-    hipLaunchKernelGGL(k_pile_list_check, dim3((unsigned) ((n_entries + 255) / 256)), dim3(256), 0, s, (const uint4 *) side, n_entries, n_buckets, (const uint4 *) tab, epoch, (const uint2 *) runs,
+    hipLaunchKernelGGL(k_pile_list_check, dim3((unsigned) ((n_entries + 255) / 256)), dim3(256), 0, s, (const uint4 *) side, n_entries, n_buckets, (const uint4 *) tab, (const uint4 *) rec2, epoch,
+                       (const uint2 *) runs,
                        n_nodes, nwin, pile_cnt + 4, (const unsigned long long *) pile_cnt);
 }
 
-void launch_pile_probe(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterCfg &cc, int uniform_len, const void *tab, uint32_t epoch, const void *rec,
+void launch_pile_probe(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterCfg &cc, int uniform_len, const void *tab, uint32_t epoch, const void *rec, const void *rec2,
                        const void *side, const void *runs, unsigned long long *counters, uint32_t *deg, unsigned long long *first, unsigned long long *second,
                        int32_t *defer_list, uint32_t defer_cap, const unsigned long long *pile_cnt, int n_cu, hipStream_t s) {
     const uint64_t n_entries = nd.n > 0 ? (uint64_t) nd.n : 0;
@@ -1027,7 +1080,7 @@ void launch_pile_probe(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterC
     o.counters = counters; o.deg = deg; o.first = first; o.second = second; o.src_base = 0;
     const uint64_t tiles = (n_entries + PP_WAVES * 64 - 1) / (PP_WAVES * 64);
     const dim3 grid((unsigned) std::max<uint64_t>(1, std::min<uint64_t>(tiles, (uint64_t) std::max(1, n_cu) * (PP_OCC * 4 / PP_WAVES)))), block(PP_WAVES * 64);      // PP_OCC waves per SIMD, four SIMDs per CU
-    hipLaunchKernelGGL(k_pile_probe, grid, block, 0, s, cfg, cc, uniform_len, nd, n_entries, nd.n, (const uint4 *) tab, epoch, (const uint4 *) rec,
+    hipLaunchKernelGGL(k_pile_probe, grid, block, 0, s, cfg, cc, uniform_len, nd, n_entries, nd.n, (const uint4 *) tab, epoch, (const uint4 *) rec, (const uint4 *) rec2,
                        (const uint4 *) side, (const uint2 *) runs, o, defer_list, defer_cap, pile_cnt);
 }
 
