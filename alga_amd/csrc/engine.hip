@@ -169,6 +169,7 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
                       src_begin == 0 && src_end == pp.nd.n && pile_plan(cfg, pp.cluster, pp.cluster_eq, pp.uniform_len, pp.nd.from != nullptr || pp.nd.to != nullptr);
     e->loc_second_used = false;
     bool keys_only = false;                                // the key pass made no run lists (see there)
+    const bool need_vals = !e->opt_own_sort || e->opt_test_unsorted_index;
     uint32_t n_buckets = 0, filter_bits = 0;
     bool have_table = false;
     auto build_table = [&]() -> int {                      // bucketised seed table + prefilter of prefsuf_kernels.hip
@@ -213,7 +214,8 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
                 // kernel).  Whether the path keeps the build is decided on the device, after the sort: where the build before this one was declined
                 // (reads with errors) the full pass runs up front as before; else it follows behind the sample, for a declined build only.
                 keys_only = pile && e->opt_pile_runs != 0 && !e->expect_pairwise && !e->opt_pile_check;
-                launch_cluster_keys(nd, cfg, cc, 0, nd.n, (uint32_t *) e->cl_keys[0].p, (uint32_t *) e->cl_vals[0].p, (uint32_t *) e->cl_meta.p, e->cl_runs.p,
+                // (the sort payload -- the node ids -- is made up by the engine's own sort in its first pass: nobody writes or reads that array)
+                launch_cluster_keys(nd, cfg, cc, 0, nd.n, (uint32_t *) e->cl_keys[0].p, need_vals ? (uint32_t *) e->cl_vals[0].p : nullptr, (uint32_t *) e->cl_meta.p, e->cl_runs.p,
                                     (uint8_t *) e->cl_nruns.p, s, !keys_only);
                 if ((rc = alga_check_launch(e, "k_node_runs"))) return rc;
             }
@@ -221,7 +223,7 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
             e->keyed_n = -1;                               // the sort below may reuse the key buffers: one build per key pass
             e->store_n = -1;
             HIP_TRY(e, launch_cluster_store(nd, cc, (uint32_t *) e->cl_keys[0].p, (uint32_t *) e->cl_vals[0].p, (uint32_t *) e->cl_keys[1].p,
-                                            (uint32_t *) e->cl_vals[1].p, e->sort_temp.p, cluster_sort_temp_bytes((uint64_t) nd.n), e->cl_dir.p, pp.keys_shared == 1,
+                                            (uint32_t *) e->cl_vals[1].p, e->sort_temp.p, cluster_sort_temp_bytes((uint64_t) nd.n), e->cl_dir.p, pp.keys_shared == 1 || !need_vals,
                                             e->ev[EV_SORT], cnt + CNT_TOTAL + 1, e->opt_test_unsorted_index != 0, s, e->opt_own_sort != 0));
             HIP_TRY(e, hipEventRecord(e->ev[EV_DIR], s));
             e->pile_n = -1;

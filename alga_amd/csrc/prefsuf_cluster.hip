@@ -158,7 +158,7 @@ __global__ void __launch_bounds__(TK_ROWS) k_node_runs(NodesDev nd, PrefSufCfg c
         key = tgt_sort_key(cluster_key(h, fs), pmin & 255u, fs);
         m = (pmin & 255u) | ((uint32_t) len << 8) | (is_src ? CL_META_FROM : 0u);
     }
-    if (in) { keys[i] = key; vals[i] = (uint32_t) i; meta[i] = m; }
+    if (in) { keys[i] = key; if (vals) vals[i] = (uint32_t) i; meta[i] = m; }
     }
 }
 
@@ -1232,7 +1232,8 @@ hipError_t launch_cluster_store(const NodesDev &nd, const ClusterCfg &cc, uint32
                                 hipEvent_t ev_sorted, unsigned long long *bad_flag, bool test_skip_sort, hipStream_t s, bool own_sort) {
     if (nd.n <= 0) return hipSuccess;
     const uint64_t n = (uint64_t) nd.n;
-    if (fill_vals) hipLaunchKernelGGL(k_iota, dim3((unsigned) std::min<uint64_t>((n + 255) / 256, 8192)), dim3(256), 0, s, vals, (uint32_t) n);
+    // (the sort payload is the node id = the position: the engine's own sort makes it up in its first pass; the library's wants the array)
+    if (fill_vals && (!own_sort || test_skip_sort)) hipLaunchKernelGGL(k_iota, dim3((unsigned) std::min<uint64_t>((n + 255) / 256, 8192)), dim3(256), 0, s, vals, (uint32_t) n);
     // The order the directory and the probe need: bucket, then m_C >> 3 (the directory's eight classes).  The key bits below that --
     // the low three of m_C, the cluster bits under the field -- are compared entry by entry by the probe, never searched: they stay
     // unsorted (29 significant bits at the north-star size: three radix passes instead of four).
@@ -1240,7 +1241,7 @@ hipError_t launch_cluster_store(const NodesDev &nd, const ClusterCfg &cc, uint32
     if (test_skip_sort) {                                  // tests only (option "test_unsorted_index"): the keys go on as they are, the directory pass must notice
         err = hipMemcpyAsync(keys2, keys, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s);
         if (err == hipSuccess) err = hipMemcpyAsync(vals2, vals, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s);
-    } else err = sort_u32_pairs(sort_temp, sort_temp_bytes, keys, keys2, vals, vals2, n, cc.idx_shift - 3, s, own_sort);
+    } else err = sort_u32_pairs(sort_temp, sort_temp_bytes, keys, keys2, own_sort ? (const uint32_t *) nullptr : vals, vals2, n, cc.idx_shift - 3, s, own_sort);
     if (err != hipSuccess) return err;
     if (ev_sorted) (void) hipEventRecord(ev_sorted, s);
     // (measured and rejected: zero-filling the directory as a side job of the VALU-bound k_node_runs -- that kernel got slower by what

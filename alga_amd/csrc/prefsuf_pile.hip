@@ -288,7 +288,14 @@ __device__ __forceinline__ void pile_list_store(uint4 *line, uint32_t entries, b
         line[5] = make_uint4(key[0], key[1], key[2], key[3]);
         line[6] = make_uint4(key[4], key[5], key[6], key[7]);
         line[7] = make_uint4(kc[0] | (kc[1] << 16), kc[2] | (kc[3] << 16), kc[4] | (kc[5] << 16), kc[6] | (kc[7] << 16));
-        lw[16] = (entries & 255u) | ((uint32_t) n << 8) | ((c1_last & 255u) << 16);
+        // the same cluster key twice in the list (one k-mer at two places of the extent: a tandem repeat -- a target could be an item at two offsets;
+        // or two k-mers that share all 32 bits): noted once per PILE, bit 31, instead of compared pair by pair by every member
+        bool dup = false;
+#pragma unroll
+        for (int a = 0; a < PILE_RUNS; a++)
+#pragma unroll
+            for (int b = a + 1; b < PILE_RUNS; b++) dup = dup || (b < n && key[a] == key[b]);
+        lw[16] = (entries & 255u) | ((uint32_t) n << 8) | ((c1_last & 255u) << 16) | (dup ? 0x80000000u : 0u);
     } else lw[16] = entries & 255u;
 }
 
@@ -715,16 +722,14 @@ __global__ void __launch_bounds__(PP_WAVES * 64, PP_OCC) k_pile_probe(PrefSufCfg
     uint32_t um = 0u;                                      // uniform: slots in which any lane of the wave has a run
 #pragma unroll
     for (int a = 0; a < CL_RMAX; a++) um |= __ballot(((vmask >> a) & 1u) != 0u) != 0ull ? 1u << a : 0u;
-    // the same minimizer twice in one source (a tandem repeat): a target could be an item at two offsets
-#pragma unroll
-    for (int a = 0; a < 6; a++)
-#pragma unroll
-        for (int b = a + 1; b < 6; b++) dfr = dfr || (((vmask >> a) & (vmask >> b) & 1u) != 0u && rk[a] == rk[b]);
-    if (um >> 6) {                                         // uniform: a lane with seven or eight runs of its own
+    // the same minimizer twice in one source (a tandem repeat): a target could be an item at two offsets.  A pile's list carries the answer
+    // (pile_list_store, bit 31 of its first word); the lanes that probe with a list of their own (one entry in 400) compare pair by pair
+    dfr = dfr || (row_from_pile && (Qr[0].x >> 31) != 0u);
+    if (__ballot(active && !row_from_pile) != 0ull) {      // uniform
 #pragma unroll
         for (int a = 0; a < CL_RMAX; a++)
 #pragma unroll
-            for (int b = (a + 1 > 6 ? a + 1 : 6); b < CL_RMAX; b++) dfr = dfr || (((vmask >> a) & (vmask >> b) & 1u) != 0u && rk[a] == rk[b]);
+            for (int b = a + 1; b < CL_RMAX; b++) dfr = dfr || (((vmask >> a) & (vmask >> b) & 1u) != 0u && rk[a] == rk[b]);
     }
     const int Lbig = cfg.rsoemo > cfg.Lmin ? cfg.rsoemo : cfg.Lmin;
     const int G = min(max(U - Lbig, 0), 63);               // an item is removed iff another sits 1 .. G offsets before it
