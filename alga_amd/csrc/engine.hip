@@ -615,7 +615,7 @@ int alga_engine_create(int hip_device, alga_engine **out) {
     if (hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking) != hipSuccess) { e->own_stream = nullptr; rc = ALGA_ERR_HIP; }
     for (int i = 0; i < EV_COUNT && rc == ALGA_OK; i++)
         if (hipEventCreate(&e->ev[i]) != hipSuccess) { e->ev[i] = nullptr; rc = ALGA_ERR_HIP; }
-    if (rc == ALGA_OK && hipHostMalloc((void **) &e->h_counters, (CNT_TOTAL + 2) * sizeof(unsigned long long)) != hipSuccess) { e->h_counters = nullptr; rc = ALGA_ERR_OUT_OF_MEMORY; }
+    if (rc == ALGA_OK && hipHostMalloc((void **) &e->h_counters, (CNT_TOTAL + 2 + alga_engine::H_EXTRA) * sizeof(unsigned long long)) != hipSuccess) { e->h_counters = nullptr; rc = ALGA_ERR_OUT_OF_MEMORY; }
     if (rc != ALGA_OK) { engine_free_handles(e); delete e; return rc; }     // nothing the failed attempt created is left behind
     *out = e;
     return ALGA_OK;
@@ -672,6 +672,8 @@ int alga_engine_set_option(alga_engine *e, const char *name, int64_t value) {
         e->opt_shard_dmax = (int) std::max<int64_t>(1, std::min<int64_t>(value, 4096));
     } else if (!strcmp(name, "rsort_variant")) {
         rsort_set_variant((int) value);                    // tuning only (process-wide): tile shape of radix_sort.hip
+    } else if (!strcmp(name, "pkb_legacy")) {
+        e->opt_pkb_legacy = (int) value;
     } else if (!strcmp(name, "own_sort")) {
         e->opt_own_sort = value != 0;
     } else if (!strcmp(name, "test_pile_oom")) {

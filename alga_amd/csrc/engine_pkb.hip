@@ -216,6 +216,9 @@ int pkb_round(alga_engine *e, hipStream_t s, const unsigned long long **d_add, u
     // groups in order of their size: the lanes of a wave replay groups of the same size
     HIP_TRY(e, sort_u32_pairs_bits(e->sort_temp.p, temp, (const uint32_t *) e->pk_hsz.p, (uint32_t *) e->pk_hsz2.p, (const uint32_t *) e->pk_heads.p,
                                    (uint32_t *) e->pk_heads2.p, n_heads, 8, s));
+    if ((rc = alga_ensure(e, e->pk_bounds, 260 * sizeof(uint32_t)))) return rc;
+    launch_pkb_class_bounds((const uint32_t *) e->pk_hsz2.p, n_heads, (uint32_t *) e->pk_bounds.p, s);
+    if ((rc = alga_check_launch(e, "k_pkb_class_bounds"))) return rc;
     const uint64_t add_dense = 2 * nk;
     uint64_t add_ovf_cap = std::max<uint64_t>(1024, nk / 4);
     uint64_t n_dense = 0, n_ovf = 0;
@@ -225,21 +228,28 @@ int pkb_round(alga_engine *e, hipStream_t s, const unsigned long long **d_add, u
         if ((rc = alga_ensure(e, e->pk_add, (add_cap + 1) * sizeof(unsigned long long)))) return rc;
         HIP_TRY(e, hipMemsetAsync(cnt + 4, 0, 4 * sizeof(unsigned long long), s));                    // big cursor, overflow, calls
         launch_pkb_groups(nd, c, (const uint32_t *) e->pk_rowptr.p, (const unsigned long long *) e->pk_g[cur].p, (const unsigned long long *) e->pk_keys2.p,
-                          (const uint32_t *) e->pk_heads2.p, (const uint32_t *) e->pk_hsz2.p, n_heads, (unsigned long long *) e->pk_vals2.p, nk,
+                          (const uint32_t *) e->pk_heads2.p, (const uint32_t *) e->pk_hsz2.p, (const uint32_t *) e->pk_bounds.p, n_heads, (unsigned long long *) e->pk_vals2.p, nk,
                           (unsigned long long *) e->pk_marks.p, (unsigned long long *) e->pk_big.p, cnt + 4, (unsigned long long *) e->pk_add.p, add_dense,
-                          add_cap, cnt + 5, cnt + 6, (uint32_t *) e->pk_nadd.p, (uint32_t *) e->pk_gsz.p, e->n_cu, s);
+                          add_cap, cnt + 5, cnt + 6, (uint32_t *) e->pk_nadd.p, (uint32_t *) e->pk_gsz.p, e->n_cu, e->opt_pkb_legacy, s);
         if ((rc = alga_check_launch(e, "k_pkb_groups"))) return rc;
         launch_exclusive_scan((const uint32_t *) e->pk_nadd.p, (uint64_t) n_heads, (uint32_t *) e->pk_pos.p, (uint64_t *) e->scan_scratch.p, s);
         HIP_TRY(e, hipMemcpyAsync(e->h_counters, cnt, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
         HIP_TRY(e, hipMemcpyAsync(e->h_counters + 8, (uint64_t *) e->scan_scratch.p + scan_total_index((uint64_t) n_heads), sizeof(uint64_t),
                                   hipMemcpyDeviceToHost, s));
         HIP_TRY(e, hipMemcpyAsync(&e->h_first_hkey, e->pk_hsz2.p, sizeof(uint32_t), hipMemcpyDeviceToHost, s));    // the longest group's sort key
+        HIP_TRY(e, hipMemcpyAsync(e->h_counters + CNT_TOTAL + 2, e->pk_bounds.p, 257 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         HIP_TRY(e, hipStreamSynchronize(s));
         if (e->h_counters[5] <= add_ovf_cap) { n_dense = e->h_counters[8]; n_ovf = e->h_counters[5]; break; }
         if (attempt == 2) return alga_fail(e, ALGA_ERR_HIP, "supplement: addition buffer kept overflowing");
         add_ovf_cap = e->h_counters[5] + 1024;
     }
     e->pkb_stats.can_align_calls[round] = e->h_counters[6];
+    {
+        const uint32_t *hb = (const uint32_t *) (e->h_counters + CNT_TOTAL + 2);                         // groups of exactly D members: [hb[255 - D], hb[256 - D])
+        auto upto = [&](int d_lo, int d_hi) { return (uint64_t) (hb[256 - d_lo] - hb[255 - d_hi]); };        // sizes d_lo .. d_hi
+        uint64_t *h = e->pkb_stats.group_hist[round];
+        h[0] = upto(2, 2); h[1] = upto(3, 3); h[2] = upto(4, 4); h[3] = upto(5, 7); h[4] = upto(8, 15); h[5] = upto(16, 31); h[6] = upto(32, 64); h[7] = upto(65, 255);
+    }
     e->pkb_stats.max_group = std::max<uint64_t>(e->pkb_stats.max_group, 255u - std::min<uint32_t>(255u, e->h_first_hkey));
     const uint64_t A = n_dense + n_ovf;
     if (A) {

@@ -462,6 +462,16 @@ __global__ void __launch_bounds__(256) k_pkb_head_list(const uint32_t *__restric
         if (head_flag[i]) { heads[pos[i]] = (uint32_t) i; hkey[pos[i]] = 255u - gsize[i]; }
 }
 
+// first list position of every size key in the sorted head list: bound[k] = first t with hkey[t] >= k (k = 0 .. 256; bound[256] = n_heads).
+// Groups of exactly D members are [bound[255 - D], bound[256 - D]): the group kernels take their ranges from here, the host the histogram.
+__global__ void __launch_bounds__(256) k_pkb_class_bounds(const uint32_t *__restrict__ hkey, uint32_t n_heads, uint32_t *__restrict__ bound) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t > n_heads) return;
+    const int k0 = t == 0 ? 0 : (int) hkey[t - 1] + 1;
+    const int k1 = t == n_heads ? 256 : (int) hkey[t];
+    for (int k = k0; k <= k1; k++) bound[k] = t;
+}
+
 struct PkbAdd {                                                             // where a round's additions go
     unsigned long long *keys; uint64_t dense, cap; unsigned long long *overflow;
 };
@@ -568,7 +578,8 @@ __global__ void __launch_bounds__(64) k_pkb_groups_serial(NodesDev nd, PkbCfg c,
 
 // 8 <= D <= 64: one wave per group.  The list is in descending size: a wave stops at the first group that is too small.
 __global__ void __launch_bounds__(64) k_pkb_groups_wave(NodesDev nd, PkbCfg c, PkbGraph g, const uint32_t *__restrict__ heads, const uint32_t *__restrict__ hkey,
-                                                         uint32_t n_heads, const unsigned long long *__restrict__ vals, PkbAdd ad,
+                                                         const uint32_t *__restrict__ bound, int d_lo /* sizes d_lo .. PKB_WAVE_MAX */,
+                                                         const unsigned long long *__restrict__ vals, PkbAdd ad,
                                                          unsigned long long *__restrict__ counters, uint32_t *__restrict__ n_add, uint32_t *__restrict__ left) {
     __shared__ uint32_t srow[64][PKB_ROW_WORDS + 1];
     __shared__ unsigned long long sv[64];
@@ -576,10 +587,9 @@ __global__ void __launch_bounds__(64) k_pkb_groups_wave(NodesDev nd, PkbCfg c, P
     __shared__ unsigned long long sk[64][PKB_SNAP_KEYS + 1];                 // ... and its first keys (all of them, usually)
     const int lane = (int) threadIdx.x;
     unsigned long long calls = 0;
-    for (uint32_t t = blockIdx.x; t < n_heads; t += gridDim.x) {
+    const uint32_t t_lo = bound[255 - PKB_WAVE_MAX], t_hi = bound[256 - d_lo];
+    for (uint32_t t = t_lo + blockIdx.x; t < t_hi; t += gridDim.x) {
         const int D = 255 - (int) hkey[t];
-        if (D <= PKB_SMALL_MAX) break;
-        if (D > PKB_WAVE_MAX) continue;                                      // k_pkb_groups_serial
         const uint64_t gs = heads[t];
         __syncthreads();                                                     // the previous group's LDS is no longer read
         // order the group: ascending val (vals are distinct: a read yields one k-mer per start position)
@@ -679,6 +689,127 @@ __global__ void __launch_bounds__(64) k_pkb_groups_wave(NodesDev nd, PkbCfg c, P
 }
 
 
+// 8 <= D <= 16: FOUR groups per wave, sixteen lanes each (round 5).  At 10 M reads with 2 % errors all but 400 of a round's 297 k groups above seven
+// members have at most fifteen: a wave per group left three quarters of its lanes idle through a chain of four dependent memory round trips
+// (list entry -> k-mer entries -> rows and snapshot rows -> snapshot keys), 13 us per group and wave.  Same plan as k_pkb_groups_wave -- every pair
+// speculatively, then the reference's i / j loops on bit masks -- in 16-bit masks: a pass takes row i and row D - 2 - i of each group together
+// (D - 1 - i and i + 1 pairs: D lanes), the replay runs once per wave with every quarter on its own masks (cross-lane reads stay inside a quarter).
+constexpr int PKB_QUARTER_MAX = 16;
+__global__ void __launch_bounds__(64) k_pkb_groups_quarter(NodesDev nd, PkbCfg c, PkbGraph g, const uint32_t *__restrict__ heads, const uint32_t *__restrict__ hkey,
+                                                            const uint32_t *__restrict__ bound, const unsigned long long *__restrict__ vals, PkbAdd ad,
+                                                            unsigned long long *__restrict__ counters, uint32_t *__restrict__ n_add, uint32_t *__restrict__ left) {
+    __shared__ uint32_t srow[64][PKB_ROW_WORDS + 1];
+    __shared__ unsigned long long sv[64];
+    __shared__ uint32_t sr0[64], sr1[64];
+    __shared__ unsigned long long sk[64][PKB_SNAP_KEYS + 1];
+    const int lane = (int) threadIdx.x, sub = lane & 15, qb = lane & 48;     // qb: the quarter's first lane == its bit position in a ballot
+    const uint32_t t_lo = bound[255 - PKB_QUARTER_MAX], t_hi = bound[256 - (PKB_SMALL_MAX + 1)];
+    unsigned long long calls = 0;                                            // the quarter's calls, the same in its sixteen lanes
+    for (uint32_t t4 = t_lo + blockIdx.x * 4u; t4 < t_hi; t4 += gridDim.x * 4u) {
+        const uint32_t t = t4 + (uint32_t) (lane >> 4);
+        const bool valid = t < t_hi;
+        const int D = valid ? 255 - (int) hkey[t] : 0;
+        const uint64_t gs = valid ? heads[t] : 0;
+        __syncthreads();                                                     // the previous groups' LDS is no longer read
+        const unsigned long long mv = sub < D ? vals[gs + sub] : ~0ull;
+        sv[lane] = mv;
+        __syncthreads();
+        int rank = 0;
+#pragma unroll
+        for (int k = 0; k < PKB_QUARTER_MAX; k++) rank += sv[qb + k] < mv;   // (vals are distinct; the lanes past D hold ~0 and rank behind them)
+        __syncthreads();
+        if (sub < D) sv[qb + rank] = mv;
+        __syncthreads();
+        const unsigned long long vj = sub < D ? sv[lane] : 0ull;
+        const int idj = pkb_val_id(vj), indj = pkb_val_ind(vj);
+        bool twice = false;
+        for (int k = 0; k < PKB_QUARTER_MAX; k++) twice |= (sub < D && k < D && k != sub && pkb_val_id(sv[qb + k]) == idj);
+        const bool dup = ((__ballot(twice) >> qb) & 0xFFFFull) != 0ull;
+        if (dup && sub == 0) { left[t] = 1u; n_add[t] = 0u; }               // a read twice in the group: the serial kernel replays it
+        const int Dq = dup ? 0 : D;
+        const int Dmax = max(max(__builtin_amdgcn_readlane(Dq, 0), __builtin_amdgcn_readlane(Dq, 16)), max(__builtin_amdgcn_readlane(Dq, 32), __builtin_amdgcn_readlane(Dq, 48)));
+        if (sub < Dq) {
+            pkb_stage_row(nd, idj, srow[lane]);
+            const uint32_t r0 = g.rowptr[idj], r1 = g.rowptr[idj + 1];
+            sr0[lane] = r0; sr1[lane] = r1;
+#pragma unroll
+            for (int q = 0; q < PKB_SNAP_KEYS; q++) if (r0 + q < r1) sk[lane][q] = g.keys[r0 + q];
+        }
+        __syncthreads();
+        unsigned long long *mine = ad.keys + 2 * gs;
+        // pass i: rows i (pairs with j = i + 1 + sub, sub < D - 1 - i) and D - 2 - i (j = sub >= D - 1 - i) of every quarter.  Masks: bit j = pair (row, j)
+        uint32_t ES = 0u, CA = 0u;                                           // lane r: eligible | snapshot-known << 16, call | aligned << 16 of row r
+        for (int i = 0; 2 * i <= Dmax - 2; i++) {
+            const int na = Dq - 1 - i, rb = Dq - 2 - i;
+            const bool on = 2 * i <= Dq - 2;
+            const bool isA = sub < na;
+            const int r = isA ? i : rb, j = isA ? i + 1 + sub : sub;
+            const bool pair = on && sub < Dq && (isA || rb > i);
+            const unsigned long long vi = sv[qb + (pair ? r : 0)], vj2 = sv[qb + (pair ? j : 0)];
+            const int id1 = pkb_val_id(vi), ind1 = pkb_val_ind(vi), len1 = pkb_val_len(vi);
+            const int id2 = pkb_val_id(vj2), len2 = pkb_val_len(vj2);
+            const int off = ind1 - pkb_val_ind(vj2);
+            bool elig = pair && off >= 0 && !(100 * off > c.max_offset_pct * len1);
+            if (elig) {
+                const int ov = (len1 < len2 + off ? len1 : len2 + off) - off;
+                elig = ov >= c.min_overlap_area && len2 + off - len1 >= 0;
+            }
+            int snap = PKB_INF;
+            if (elig) {
+                const uint32_t r0 = sr0[qb + r], r1 = sr1[qb + r];
+                if (r1 - r0 <= (uint32_t) PKB_SNAP_KEYS) {
+                    for (uint32_t q = 0; q < r1 - r0; q++) { const unsigned long long k = sk[qb + r][q]; if (pkb_key_dst(k) == id2) snap = pkb_key_off(k); }
+                } else snap = snapshot_offset(g, id1, id2);
+            }
+            const bool call = elig && snap > off;
+            const bool ok = call && can_align_rows(srow[qb + r], srow[qb + j], len1, len2, off, c);
+            const uint32_t be = (uint32_t) (__ballot(elig) >> qb) & 0xFFFFu, bs = (uint32_t) (__ballot(snap != PKB_INF) >> qb) & 0xFFFFu;
+            const uint32_t bc = (uint32_t) (__ballot(call) >> qb) & 0xFFFFu, ba = (uint32_t) (__ballot(ok) >> qb) & 0xFFFFu;
+            const uint32_t ma = on ? ((1u << na) - 1u) : 0u;                   // lanes of row i
+            if (on && sub == i) { ES = ((be & ma) << (i + 1)) | (((bs & ma) << (i + 1)) << 16); CA = ((bc & ma) << (i + 1)) | (((ba & ma) << (i + 1)) << 16); }
+            if (on && rb > i && sub == rb) { ES = (be & ~ma) | ((bs & ~ma) << 16); CA = (bc & ~ma) | ((ba & ~ma) << 16); }
+        }
+        // the i / j loops of the reference on the masks, every quarter on its own; lane r keeps the marker row of entry r
+        uint32_t myrow = 0u;
+        int n_added = 0;
+        for (int i = Dmax - 2; i >= 0; i--) {
+            const bool on = i <= Dq - 2;
+            const uint32_t es = (uint32_t) __shfl((int) ES, qb + i), ca = (uint32_t) __shfl((int) CA, qb + i);
+            uint32_t m = on ? (es & 0xFFFFu) : 0u;
+            const uint32_t s_i = es >> 16, c_i = ca & 0xFFFFu, a_i = ca >> 16;
+            uint32_t row = 0u, addm = 0u;
+            while (__ballot(m != 0u) != 0ull) {                              // (wave-uniform: every lane stays in, the cross-lane read below needs its source active)
+                const bool act = m != 0u;
+                const int j = act ? __builtin_ctz(m) : 0;
+                const uint32_t rowj = (uint32_t) __shfl((int) myrow, qb + j);
+                if (act) {
+                    m &= m - 1u;
+                    if (!((row >> j) & 1u)) {                                // else: already reachable inside the group (:62)
+                        bool reach = true;                                   // an edge of at most this offset exists
+                        if ((c_i >> j) & 1u) {
+                            calls++;
+                            if ((a_i >> j) & 1u) addm |= 1u << j;
+                            else reach = (s_i >> j) & 1u;
+                        }
+                        if (reach) row |= (1u << j) | rowj;
+                    }
+                }
+            }
+            if (on && sub == i) myrow = row;
+            if (on && ((addm >> sub) & 1u)) {
+                const unsigned long long vi = sv[qb + i];
+                pkb_add_edge(ad, mine, n_added + __popc(addm & ((1u << sub) - 1u)), 2 * Dq, pkb_edge_key(pkb_val_id(vi), idj, pkb_val_ind(vi) - indj));
+            }
+            n_added += __popc(addm);
+        }
+        if (sub == 0 && Dq > 0) { n_add[t] = (uint32_t) (n_added < 2 * Dq ? n_added : 2 * Dq); left[t] = 0u; }
+    }
+    calls = (sub == 0) ? calls : 0ull;
+#pragma unroll
+    for (int o = 32; o >= 16; o >>= 1) calls += __shfl_xor(calls, o);
+    if (lane == 0 && calls) atomicAdd(&counters[0], calls);
+}
+
 // 2 <= D <= 7: one THREAD per group; the entries in LDS, the marker rows in one register (8 bits per row), rows staged per pair.
 // Persistent grid (a thread walks the list with the grid's stride): the call counter is updated once per wave of the GRID, not of
 // the list -- with one launch wave per 64 groups the 55 k same-address atomics were a third of the kernel's time (0.89 -> 0.6 ms per
@@ -688,13 +819,14 @@ __global__ void __launch_bounds__(64) k_pkb_groups_wave(NodesDev nd, PkbCfg c, P
 // VALU-bound; no split point between the two shapes (thread per group up to D = 1 .. 7, lanes above) beat the thread per group alone.
 constexpr int PKB_SMALL_WG = 256;
 __global__ void __launch_bounds__(PKB_SMALL_WG) k_pkb_groups_small(NodesDev nd, PkbCfg c, PkbGraph g, const uint32_t *__restrict__ heads, const uint32_t *__restrict__ hkey,
-                                                          uint32_t n_heads, const unsigned long long *__restrict__ vals, PkbAdd ad,
+                                                          const uint32_t *__restrict__ bound, const unsigned long long *__restrict__ vals, PkbAdd ad,
                                                           unsigned long long *__restrict__ counters, uint32_t *__restrict__ n_add, uint32_t *__restrict__ left) {
     __shared__ uint32_t srow[PKB_SMALL_WG][2 * PKB_ROW_WORDS + 3];           // a | 0 | b | 0 (+1: odd stride, conflict-free)
     __shared__ unsigned long long sv[PKB_SMALL_MAX][PKB_SMALL_WG];
     const int lane = (int) threadIdx.x;                                      // slot in the workgroup's LDS arrays
     unsigned long long calls = 0;
-    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n_heads; t += gridDim.x * blockDim.x) {
+    const uint32_t t_lo = bound[255 - PKB_SMALL_MAX], t_hi = bound[254];
+    for (uint32_t t = t_lo + blockIdx.x * blockDim.x + threadIdx.x; t < t_hi; t += gridDim.x * blockDim.x) {
     const int D = 255 - (int) hkey[t];
     if (D >= 2 && D <= PKB_SMALL_MAX) {
         const uint64_t gs = heads[t];
@@ -844,6 +976,10 @@ void launch_pkb_group_sizes(const unsigned long long *keys, uint64_t n, unsigned
     hipLaunchKernelGGL(k_pkb_group_sizes, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, s, keys, n, big_words, max_d, head_flag, gsize, (uint32_t) rank, (uint32_t) n_ranks);
 }
 
+void launch_pkb_class_bounds(const uint32_t *hkey, uint32_t n_heads, uint32_t *bound, hipStream_t s) {
+    hipLaunchKernelGGL(k_pkb_class_bounds, dim3(n_heads / 256 + 1), dim3(256), 0, s, hkey, n_heads, bound);
+}
+
 void launch_pkb_head_list(const uint32_t *head_flag, const uint32_t *pos, const uint32_t *gsize, uint64_t n, uint32_t *heads, uint32_t *hkey, hipStream_t s) {
     if (n == 0) return;
     hipLaunchKernelGGL(k_pkb_head_list, dim3(pkb_grid(n, 256, 8192)), dim3(256), 0, s, head_flag, pos, gsize, n, heads, hkey);
@@ -851,20 +987,25 @@ void launch_pkb_head_list(const uint32_t *head_flag, const uint32_t *pos, const 
 
 // heads / hkey: the group list in descending size (hkey = 255 - min(D, 255), ascending)
 void launch_pkb_groups(const NodesDev &nd, const PkbCfg &c, const uint32_t *rowptr, const unsigned long long *gkeys, const unsigned long long *keys,
-                       const uint32_t *heads, const uint32_t *hkey, uint32_t n_heads, unsigned long long *vals, uint64_t n, unsigned long long *marks,
+                       const uint32_t *heads, const uint32_t *hkey, const uint32_t *bound, uint32_t n_heads, unsigned long long *vals, uint64_t n, unsigned long long *marks,
                        unsigned long long *big_marks, unsigned long long *big_cursor, unsigned long long *add_keys, uint64_t add_dense, uint64_t add_cap,
-                       unsigned long long *add_overflow, unsigned long long *counters, uint32_t *n_add, uint32_t *left, int n_cu, hipStream_t s) {
+                       unsigned long long *add_overflow, unsigned long long *counters, uint32_t *n_add, uint32_t *left, int n_cu, int legacy, hipStream_t s) {
     if (n == 0 || n_heads == 0) return;
     PkbGraph g{rowptr, gkeys};
     PkbAdd ad{add_keys, add_dense, add_cap, add_overflow};
     const unsigned blocks = (n_heads + 63) / 64;
     const bool staged = nd.stride <= PKB_ROW_WORDS;
+    const unsigned cus = (unsigned) std::max(1, n_cu);
     if (staged) {
         (void) hipMemsetAsync(left, 0, (size_t) n_heads * sizeof(uint32_t), s);
-        hipLaunchKernelGGL(k_pkb_groups_wave, dim3(std::min<unsigned>(n_heads, (unsigned) std::max(1, n_cu) * 24u)), dim3(64), 0, s, nd, c, g, heads, hkey, n_heads,
-                           (const unsigned long long *) vals, ad, counters, n_add, left);
-        hipLaunchKernelGGL(k_pkb_groups_small, dim3(std::min<unsigned>((n_heads + PKB_SMALL_WG - 1) / PKB_SMALL_WG, (unsigned) std::max(1, n_cu) * 3u)), dim3(PKB_SMALL_WG), 0, s, nd, c, g,
-                           heads, hkey, n_heads, (const unsigned long long *) vals, ad, counters, n_add, left);
+        const bool quarter = !(legacy & 1);
+        // the ranges of the three shapes come from `bound` on the device: the grids are sized for the chip, not for the list
+        hipLaunchKernelGGL(k_pkb_groups_wave, dim3(std::min<unsigned>(n_heads, cus * (quarter ? 8u : 24u))), dim3(64), 0, s, nd, c, g, heads, hkey, bound,
+                           quarter ? PKB_QUARTER_MAX + 1 : PKB_SMALL_MAX + 1, (const unsigned long long *) vals, ad, counters, n_add, left);
+        if (quarter) hipLaunchKernelGGL(k_pkb_groups_quarter, dim3(std::min<unsigned>((n_heads + 3) / 4, cus * 17u)), dim3(64), 0, s, nd, c, g, heads, hkey, bound,
+                                        (const unsigned long long *) vals, ad, counters, n_add, left);
+        hipLaunchKernelGGL(k_pkb_groups_small, dim3(std::min<unsigned>((n_heads + PKB_SMALL_WG - 1) / PKB_SMALL_WG, cus * 3u)), dim3(PKB_SMALL_WG), 0, s, nd, c, g,
+                           heads, hkey, bound, (const unsigned long long *) vals, ad, counters, n_add, left);
     }
     hipLaunchKernelGGL(k_pkb_groups_serial, dim3(blocks), dim3(64), 0, s, nd, c, g, keys, heads, hkey, n_heads, staged ? 0 : 1, (const uint32_t *) left, vals, n, marks,
                        big_marks, big_cursor, ad, counters, n_add);

@@ -108,7 +108,7 @@ class PkbParams(C.Structure):
 class PkbStats(C.Structure):
     """alga_pkb_stats"""
     _fields_ = [("kmers", C.c_uint64 * 4), ("groups", C.c_uint64 * 4), ("can_align_calls", C.c_uint64 * 4),
-                ("edges_after", C.c_uint64 * 4), ("max_group", C.c_uint64), ("ms_total", C.c_double)]
+                ("edges_after", C.c_uint64 * 4), ("max_group", C.c_uint64), ("ms_total", C.c_double), ("group_hist", (C.c_uint64 * 8) * 4)]
 
 
 PROBE = {"auto": 0, "table": 1, "cluster": 2}                  # alga_probe
@@ -758,7 +758,8 @@ class Engine:
         st = PkbStats()
         self._check(self._lib.alga_pkb_last_stats(self._h, C.byref(st)))
         return dict(kmers=list(st.kmers), groups=list(st.groups), can_align_calls=list(st.can_align_calls),
-                    edges_after=list(st.edges_after), max_group=st.max_group, ms_total=st.ms_total)
+                    edges_after=list(st.edges_after), max_group=st.max_group, ms_total=st.ms_total,
+                    group_hist=[list(r) for r in st.group_hist])
 
     # ---- first simplifier step ----------------------------------------------------------------
     def cut_triangles_host(self, n_nodes, edges, max_offset_parallel_paths):

@@ -473,7 +473,8 @@ def run(args, rank, world, local_rank, dist, t_process=None):
             ps = stats["pkb"]
             ab = sum(ps["kmers"]) * 24 + sum(ps["can_align_calls"]) * 8 * W + sum(ps["edges_after"]) * 8
             out["supplement"] = {"ms": ms["supplement"], "exact_path_ms": ms_step - ms["supplement"], "kmers": ps["kmers"], "can_align_calls": ps["can_align_calls"],
-                                 "edges_after_round": ps["edges_after"], "edges_exact": int(stats["edges"]),
+                                 "edges_after_round": ps["edges_after"], "edges_exact": int(stats["edges"]), "groups": ps["groups"],
+                                 "group_hist_2_3_4_7_15_31_64_more": ps.get("group_hist"),
                                  "algorithmic_bytes": int(ab), "achieved": ab / (ms["supplement"] * 1e-3) / 1e9, "frac": ab / (ms["supplement"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                  "per_unit": "SURVEY.md section 8(d) for cfg 5: 24 B per LI k-mer + 8W B per canAlign call (+ 8 B per edge key of the graph merged per round); "
                                              "sort / merge / unique are rocPRIM, the group joins are k_pkb_groups_* (DESIGN.md section 9)"}

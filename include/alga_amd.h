@@ -447,6 +447,7 @@ typedef struct {
     uint64_t edges_after[4];    /* edges in the graph after each round                                                 */
     uint64_t max_group;
     double   ms_total;
+    uint64_t group_hist[4][8];  /* per round, groups of 2, 3, 4, 5-7, 8-15, 16-31, 32-64 and > 64 equal k-mers (this rank's)     */
 } alga_pkb_stats;
 
 /* (1 + SCALE) / (1 - SCALE) arithmetic of src/main.cpp:332-336 in float, truncating; error_rate as on the command line */

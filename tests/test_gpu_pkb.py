@@ -169,6 +169,29 @@ def test_supplement_group_shapes(eng):
     _supplement_vs_oracle(eng, reads(g3, 1200, 300, 0.02))                            # 294-nt reads: 19 words
 
 
+@pytest.mark.parametrize("G,n,seed", [(4000, 1200, 93), (2500, 1500, 94), (6000, 5000, 95)])
+def test_supplement_groups_of_8_to_16_four_per_wave(eng, G, n, seed):
+    """k-mer groups of 8 .. 16 entries go four to a wave (k_pkb_groups_quarter, round 5): against the oracle in the engine's semantics, and against
+    round 4's form of the same join (a wave per group, option pkb_legacy bit 0) down to the number of canAlign calls"""
+    rng = np.random.default_rng(seed)
+    g = rng.integers(0, 4, G, dtype=np.uint8)
+    st = rng.integers(0, G - 150 + 1, n)
+    c = g[st[:, None] + np.arange(150)[None, :]].copy()
+    m = rng.random(c.shape) < 0.02
+    c[m] = (c[m] + rng.integers(1, 4, int(m.sum()))) & 3
+    flip = rng.random(n) < 0.5
+    c[flip] = (3 - c[flip])[:, ::-1]
+    s_new = _supplement_vs_oracle(eng, c.astype(np.uint8))
+    assert s_new["group_hist"][0][4] > 20, s_new["group_hist"]               # there are groups of 8 .. 15
+    eng.set_option("pkb_legacy", 1)
+    try:
+        s_old = _supplement_vs_oracle(eng, c.astype(np.uint8))
+    finally:
+        eng.set_option("pkb_legacy", 0)
+    for k in ("kmers", "groups", "can_align_calls", "edges_after", "group_hist", "max_group"):
+        assert s_new[k] == s_old[k], k
+
+
 def test_supplement_rejects_offsets_it_cannot_represent(eng):
     """the edge merge packs (src, dst, offset) into 64 bits with 9 bits of offset: an edge outside that range is an error, not a
     silently different graph"""

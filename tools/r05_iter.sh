@@ -26,3 +26,9 @@ print("index_build_ms", d.get('index_build_ms'), "phases", d.get('phases_ms'))
 pi=d.get("pcie_inclusive",{}); print("e2e", d.get("ms_end_to_end"), d.get("end_to_end_form"), "triples", pi.get("ms_per_graph"), pi.get("phases_ms"), "compact", pi.get("compact_edges",{}).get("ms_per_graph"), pi.get("compact_edges",{}).get("phases_ms"), "pinned", pi.get("compact_edges",{}).get("pinned_node_arrays"))
 PY
 fi
+[ -f $OUT/bench_$TAG.json ] && python3 - <<PY
+import json
+d=json.loads(open('$OUT/bench_$TAG.json').read().strip().splitlines()[-1])
+if d.get("supplement"): print("supplement", {k: d["supplement"].get(k) for k in ("ms","exact_path_ms","groups","group_hist_2_3_4_7_15_31_64_more","can_align_calls","kmers")})
+PY
+exit 0
