@@ -173,8 +173,11 @@ int pkb_round(alga_engine *e, hipStream_t s, const unsigned long long **d_add, u
     st.phase = 2;
     if (nk < 2) return ALGA_OK;
     // k-mer entries are radix-sorted on this many low bits of their key (= top bits of the mixed hash) (expected places to repair: nk^2 / 2^(bits + 1) <= 2^18)
-    const int sort_bits = nk <= (1ull << 25) ? 32 : (nk <= (1ull << 29) ? 40 : 48);
-    const size_t temp = std::max(sort_u64_pairs_temp_bytes(nk, sort_bits), sort_u32_pairs_temp_bytes(nk));
+    // the engine's own sort (radix_sort.hip, round 5) takes 10 bits per pass: 30 bits while that leaves <= 2^18 places to repair (23.7 M k-mers), else 40, 50;
+    // the library's (option pkb_legacy bit 1) 8 bits per pass: 32, 40, 48
+    const bool own_sort = !(e->opt_pkb_legacy & 2);
+    const int sort_bits = own_sort ? (nk <= 23700000ull ? 30 : (nk <= (1ull << 29) ? 40 : 50)) : (nk <= (1ull << 25) ? 32 : (nk <= (1ull << 29) ? 40 : 48));
+    const size_t temp = std::max(std::max(sort_u64_pairs_temp_bytes(nk, sort_bits), rsort_u64_pairs_temp_bytes(nk)), sort_u32_pairs_temp_bytes(nk));
     if ((rc = alga_ensure(e, e->pk_fixlist, (size_t) PKB_FIX_LIST_CAP * sizeof(uint32_t)))) return rc;
     for (DevBuf *b : {&e->pk_keys, &e->pk_vals, &e->pk_keys2, &e->pk_vals2, &e->pk_marks})
         if ((rc = alga_ensure(e, *b, (nk + 1) * sizeof(unsigned long long)))) return rc;
@@ -186,8 +189,10 @@ int pkb_round(alga_engine *e, hipStream_t s, const unsigned long long **d_add, u
                      (unsigned long long *) e->pk_vals.p, s);
     if ((rc = alga_check_launch(e, "k_pkb_kmers"))) return rc;
     // equal hashes become contiguous; inside a group the group kernel orders the entries itself
-    HIP_TRY(e, sort_u64_pairs(e->sort_temp.p, temp, (const unsigned long long *) e->pk_keys.p, (unsigned long long *) e->pk_keys2.p,
-                              (const unsigned long long *) e->pk_vals.p, (unsigned long long *) e->pk_vals2.p, nk, sort_bits, s));
+    if (own_sort) HIP_TRY(e, rsort_u64_pairs(e->sort_temp.p, temp, (const unsigned long long *) e->pk_keys.p, (unsigned long long *) e->pk_keys2.p,
+                                             (const unsigned long long *) e->pk_vals.p, (unsigned long long *) e->pk_vals2.p, nk, sort_bits, s));
+    else HIP_TRY(e, sort_u64_pairs(e->sort_temp.p, temp, (const unsigned long long *) e->pk_keys.p, (unsigned long long *) e->pk_keys2.p,
+                                   (const unsigned long long *) e->pk_vals.p, (unsigned long long *) e->pk_vals2.p, nk, sort_bits, s));
     uint32_t n_heads = 0;
     uint64_t big_words = 0;
     for (int pass = 0; pass < 2; pass++) {
@@ -196,14 +201,21 @@ int pkb_round(alga_engine *e, hipStream_t s, const unsigned long long **d_add, u
                                            PKB_FIX_LIST_CAP, cnt + 9, s);
         else launch_pkb_fix_runs_loop((unsigned long long *) e->pk_keys2.p, (unsigned long long *) e->pk_vals2.p, nk, sort_bits, s);   // the list overflowed
         if ((rc = alga_check_launch(e, "k_pkb_fix_runs"))) return rc;
-        launch_pkb_group_sizes((const unsigned long long *) e->pk_keys2.p, nk, cnt + 1, cnt + 3, (uint32_t *) e->pk_flag.p, (uint32_t *) e->pk_gsz.p, st.rank, st.n_ranks, s);
-        if ((rc = alga_check_launch(e, "k_pkb_group_sizes"))) return rc;
-        launch_exclusive_scan((const uint32_t *) e->pk_flag.p, nk, (uint32_t *) e->pk_pos.p, (uint64_t *) e->scan_scratch.p, s);
-        launch_pkb_head_list((const uint32_t *) e->pk_flag.p, (const uint32_t *) e->pk_pos.p, (const uint32_t *) e->pk_gsz.p, nk, (uint32_t *) e->pk_heads.p,
-                             (uint32_t *) e->pk_hsz.p, s);
-        if ((rc = alga_check_launch(e, "k_pkb_head_list"))) return rc;
+        if (e->opt_pkb_legacy & 4) {
+            launch_pkb_group_sizes((const unsigned long long *) e->pk_keys2.p, nk, cnt + 1, cnt + 3, (uint32_t *) e->pk_flag.p, (uint32_t *) e->pk_gsz.p, st.rank, st.n_ranks, s);
+            if ((rc = alga_check_launch(e, "k_pkb_group_sizes"))) return rc;
+            launch_exclusive_scan((const uint32_t *) e->pk_flag.p, nk, (uint32_t *) e->pk_pos.p, (uint64_t *) e->scan_scratch.p, s);
+            launch_pkb_head_list((const uint32_t *) e->pk_flag.p, (const uint32_t *) e->pk_pos.p, (const uint32_t *) e->pk_gsz.p, nk, (uint32_t *) e->pk_heads.p,
+                                 (uint32_t *) e->pk_hsz.p, s);
+            if ((rc = alga_check_launch(e, "k_pkb_head_list"))) return rc;
+            HIP_TRY(e, hipMemcpyAsync(e->h_counters + 12, (uint64_t *) e->scan_scratch.p + scan_total_index(nk), sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+        } else {
+            launch_pkb_heads((const unsigned long long *) e->pk_keys2.p, nk, cnt + 1, cnt + 3, cnt + 10, (uint32_t *) e->pk_heads.p, (uint32_t *) e->pk_hsz.p,
+                             st.rank, st.n_ranks, s);
+            if ((rc = alga_check_launch(e, "k_pkb_heads"))) return rc;
+            HIP_TRY(e, hipMemcpyAsync(e->h_counters + 12, cnt + 10, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+        }
         HIP_TRY(e, hipMemcpyAsync(e->h_counters, cnt, 12 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-        HIP_TRY(e, hipMemcpyAsync(e->h_counters + 12, (uint64_t *) e->scan_scratch.p + scan_total_index(nk), sizeof(uint64_t), hipMemcpyDeviceToHost, s));
         HIP_TRY(e, hipStreamSynchronize(s));
         if (pass == 0 && e->h_counters[9] > PKB_FIX_LIST_CAP) continue;
         big_words = e->h_counters[1];

@@ -35,6 +35,9 @@ void launch_pkb_fix_runs_loop(unsigned long long *keys, unsigned long long *vals
 void launch_pkb_group_sizes(const unsigned long long *keys, uint64_t n, unsigned long long *big_words, unsigned long long *max_d, uint32_t *head_flag,
                             uint32_t *gsize, int rank, int n_ranks /* the groups of rank mix(key) mod n_ranks alone (1: all) */, hipStream_t s);
 void launch_pkb_head_list(const uint32_t *head_flag, const uint32_t *pos, const uint32_t *gsize, uint64_t n, uint32_t *heads, uint32_t *hkey, hipStream_t s);
+// group_sizes + scan + head_list in one pass (the list in no particular order; *n_heads: zeroed by the caller, the number of groups afterwards)
+void launch_pkb_heads(const unsigned long long *keys, uint64_t n, unsigned long long *big_words, unsigned long long *max_d, unsigned long long *n_heads,
+                      uint32_t *heads, uint32_t *hkey, int rank, int n_ranks, hipStream_t s);
 void launch_pkb_class_bounds(const uint32_t *hkey_sorted, uint32_t n_heads, uint32_t *bound /* 257 entries */, hipStream_t s);
 void launch_pkb_groups(const NodesDev &nd, const PkbCfg &c, const uint32_t *rowptr, const unsigned long long *gkeys, const unsigned long long *keys,
                        const uint32_t *heads, const uint32_t *hkey, const uint32_t *bound /* launch_pkb_class_bounds */, uint32_t n_heads, unsigned long long *vals, uint64_t n,

@@ -296,16 +296,30 @@ __device__ __forceinline__ void pkb_sort_run(unsigned long long *keys, unsigned 
     }
 }
 
+constexpr int PKB_FLAG_IPT = 16;                                              // entries per thread of k_pkb_fix_flag
 __global__ void __launch_bounds__(256) k_pkb_fix_flag(const unsigned long long *__restrict__ keys, uint64_t n, int bits, uint32_t *__restrict__ list,
                                                        uint32_t list_cap, unsigned long long *__restrict__ counter) {
+    // the places of a block of 4096 entries are collected in LDS and appended with ONE atomic (sorted on 30 bits, 21 M entries have 200 k such
+    // places: an atomic each on the one counter would retire at ~90 per microsecond)
+    __shared__ uint32_t s_list[256 * PKB_FLAG_IPT];
+    __shared__ uint32_t s_n, s_base;
     const unsigned long long lm = bits >= 64 ? ~0ull : ((1ull << bits) - 1ull);
-    const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0 || i >= n) return;
-    const unsigned long long k = keys[i], kp = keys[i - 1];
-    if (k != kp && (k & lm) == (kp & lm)) {
-        const unsigned long long at = atomicAdd(counter, 1ull);
-        if (at < list_cap) list[at] = (uint32_t) i;
+    if (threadIdx.x == 0) s_n = 0u;
+    __syncthreads();
+    const uint64_t base = (uint64_t) blockIdx.x * (256 * PKB_FLAG_IPT);
+#pragma unroll 4
+    for (int j = 0; j < PKB_FLAG_IPT; j++) {
+        const uint64_t i = base + (uint64_t) j * 256 + threadIdx.x;
+        if (i == 0 || i >= n) continue;
+        const unsigned long long k = keys[i], kp = keys[i - 1];
+        if (k != kp && (k & lm) == (kp & lm)) s_list[atomicAdd(&s_n, 1u)] = (uint32_t) i;
     }
+    __syncthreads();
+    const uint32_t cnt = s_n;
+    if (cnt == 0u) return;
+    if (threadIdx.x == 0) s_base = (uint32_t) min(atomicAdd(counter, (unsigned long long) cnt), (unsigned long long) list_cap);
+    __syncthreads();
+    for (uint32_t q = threadIdx.x; q < cnt; q += 256) if (s_base + q < list_cap) list[s_base + q] = s_list[q];
 }
 
 // which listed place repairs its run: the first one of the run (decided while nobody writes: bit 31 of the list entry)
@@ -470,6 +484,55 @@ __global__ void __launch_bounds__(256) k_pkb_class_bounds(const uint32_t *__rest
     const int k0 = t == 0 ? 0 : (int) hkey[t - 1] + 1;
     const int k1 = t == n_heads ? 256 : (int) hkey[t];
     for (int k = k0; k <= k1; k++) bound[k] = t;
+}
+
+// k_pkb_group_sizes + scan + k_pkb_head_list in ONE pass over the sorted keys (round 5): a block of 256 threads looks at 4096 entries, counts the
+// heads it finds, takes its place in the list with one atomic and writes (entry, 255 - min(D, 255)).  The list's order is whatever order the blocks
+// arrive in; it is sorted by size next, the additions are sorted by key at the merge: nothing downstream depends on it.
+constexpr int PKB_HEADS_IPT = 16;
+__global__ void __launch_bounds__(256) k_pkb_heads(const unsigned long long *__restrict__ keys, uint64_t n, unsigned long long *__restrict__ big_words,
+                                                    unsigned long long *__restrict__ max_d, unsigned long long *__restrict__ n_heads /* zeroed by the caller */,
+                                                    uint32_t *__restrict__ heads, uint32_t *__restrict__ hkey, uint32_t rank, uint32_t n_ranks) {
+    __shared__ uint32_t wsum[4];
+    __shared__ uint32_t s_base;
+    const uint64_t base = (uint64_t) blockIdx.x * (256 * PKB_HEADS_IPT);
+    uint32_t flags = 0u, cnt = 0u;
+    uint32_t sz[PKB_HEADS_IPT / 4] = {0u, 0u, 0u, 0u};                          // min(D, 255), a byte per entry of this thread
+#pragma unroll
+    for (int j = 0; j < PKB_HEADS_IPT; j++) {
+        const uint64_t i = base + (uint64_t) j * 256 + threadIdx.x;
+        if (i >= n) continue;
+        const unsigned long long k = keys[i];
+        const bool mine = n_ranks <= 1u || (uint32_t) (((k ^ (k >> 29)) * 0x9E3779B97F4A7C15ull) >> 40) % n_ranks == rank;
+        if (mine && (i == 0 || keys[i - 1] != k) && i + 1 < n && keys[i + 1] == k) {
+            uint64_t e = i + 2;
+            while (e < n && keys[e] == k) e++;
+            const uint64_t D = e - i;
+            flags |= 1u << j; cnt++;
+            sz[j >> 2] |= (uint32_t) (D < 255 ? D : 255) << (8 * (j & 3));
+            if (D > 64) { atomicAdd(big_words, (unsigned long long) (D * ((D + 63) / 64))); atomicMax(max_d, (unsigned long long) D); }   // rare
+        }
+    }
+    // exclusive scan of cnt over the block
+    uint32_t incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(incl, o, 64); if ((int) (threadIdx.x & 63u) >= o) incl += y; }
+    if ((threadIdx.x & 63u) == 63u) wsum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t before = 0u, total = 0u;
+#pragma unroll
+    for (int q = 0; q < 4; q++) { const uint32_t x = wsum[q]; before += (uint32_t) q < (threadIdx.x >> 6) ? x : 0u; total += x; }
+    if (total == 0u) return;
+    if (threadIdx.x == 0) s_base = (uint32_t) atomicAdd(n_heads, (unsigned long long) total);
+    __syncthreads();
+    uint32_t at = s_base + before + incl - cnt;
+#pragma unroll
+    for (int j = 0; j < PKB_HEADS_IPT; j++)
+        if ((flags >> j) & 1u) {
+            heads[at] = (uint32_t) (base + (uint64_t) j * 256 + threadIdx.x);
+            hkey[at] = 255u - ((sz[j >> 2] >> (8 * (j & 3))) & 0xFFu);
+            at++;
+        }
 }
 
 struct PkbAdd {                                                             // where a round's additions go
@@ -960,7 +1023,8 @@ void launch_pkb_kmers(const NodesDev &nd, const PkbCfg &c, const int32_t prio[4]
 void launch_pkb_fix_runs(unsigned long long *keys, unsigned long long *vals, uint64_t n, int bits, uint32_t *list, uint32_t list_cap, unsigned long long *counter,
                          hipStream_t s) {
     if (n == 0) return;
-    hipLaunchKernelGGL(k_pkb_fix_flag, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, s, (const unsigned long long *) keys, n, bits, list, list_cap, counter);
+    hipLaunchKernelGGL(k_pkb_fix_flag, dim3((unsigned) ((n + 256 * PKB_FLAG_IPT - 1) / (256 * PKB_FLAG_IPT))), dim3(256), 0, s, (const unsigned long long *) keys, n, bits,
+                       list, list_cap, counter);
     hipLaunchKernelGGL(k_pkb_fix_owner, dim3((list_cap + 63) / 64), dim3(64), 0, s, (const unsigned long long *) keys, bits, list, list_cap, (const unsigned long long *) counter);
     hipLaunchKernelGGL(k_pkb_fix_apply, dim3((list_cap + 63) / 64), dim3(64), 0, s, keys, vals, n, bits, (const uint32_t *) list, list_cap, (const unsigned long long *) counter);
 }
@@ -974,6 +1038,13 @@ void launch_pkb_group_sizes(const unsigned long long *keys, uint64_t n, unsigned
                             uint32_t *gsize, int rank, int n_ranks, hipStream_t s) {
     if (n == 0) return;
     hipLaunchKernelGGL(k_pkb_group_sizes, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, s, keys, n, big_words, max_d, head_flag, gsize, (uint32_t) rank, (uint32_t) n_ranks);
+}
+
+void launch_pkb_heads(const unsigned long long *keys, uint64_t n, unsigned long long *big_words, unsigned long long *max_d, unsigned long long *n_heads,
+                      uint32_t *heads, uint32_t *hkey, int rank, int n_ranks, hipStream_t s) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_pkb_heads, dim3((unsigned) ((n + 256 * PKB_HEADS_IPT - 1) / (256 * PKB_HEADS_IPT))), dim3(256), 0, s, keys, n, big_words, max_d, n_heads,
+                       heads, hkey, (uint32_t) rank, (uint32_t) n_ranks);
 }
 
 void launch_pkb_class_bounds(const uint32_t *hkey, uint32_t n_heads, uint32_t *bound, hipStream_t s) {

@@ -97,6 +97,10 @@ hipError_t rsort_u32_pairs(void *temp, size_t temp_bytes, const uint32_t *keys_i
 size_t     sort_u32_pairs_temp_bytes(uint64_t n);
 hipError_t sort_u32_pairs(void *temp, size_t temp_bytes, const uint32_t *keys_in, uint32_t *keys_out, const uint32_t *vals_in, uint32_t *vals_out,
                           uint64_t n, int begin_bit /* the bits below it are not looked at */, hipStream_t s, bool own_sort = true /* radix_sort.hip; false: rocPRIM */);
+size_t     rsort_u64_pairs_temp_bytes(uint64_t n);
+// radix_sort.hip: stable sort of (u64 key, u64 value) records on the key bits [0, bits), bits <= 50 (the supplement's k-mer entries)
+hipError_t rsort_u64_pairs(void *temp, size_t temp_bytes, const unsigned long long *keys_in, unsigned long long *keys_out, const unsigned long long *vals_in,
+                           unsigned long long *vals_out, uint64_t n, int bits, hipStream_t s);
 size_t     sort_u64_pairs_temp_bytes(uint64_t n, int bits);
 hipError_t sort_u64_pairs(void *temp, size_t temp_bytes, const unsigned long long *keys_in, unsigned long long *keys_out,
                           const unsigned long long *vals_in, unsigned long long *vals_out, uint64_t n, int bits, hipStream_t s);

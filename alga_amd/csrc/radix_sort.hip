@@ -50,7 +50,7 @@ int g_rs_variant = 0;                                      // tuning only (engin
 
 RsPlan rs_plan(uint64_t n, int begin_bit, int end_bit, int variant) {
     RsPlan p;
-    p.tile = variant == 1 ? 16384 : 8192;
+    p.tile = variant == 2 ? 4096 : (variant == 1 ? 16384 : 8192);          // (2: the 16-byte records of rsort_u64_pairs)
     const int RS_TILE = p.tile;
     const int total = end_bit - begin_bit;
     p.passes = (total + RS_MAX_BITS - 1) / RS_MAX_BITS;
@@ -284,6 +284,149 @@ __global__ void __launch_bounds__(THREADS) k_rs_scatter(const uint32_t *__restri
     }
 }
 
+// ---- 16-byte records: (u64 key, u64 value), sorted on the key's low bits (the k-mer entries of the supplement: pkb_kernels.hip) ---------------------
+// The same three kernels per pass; a tile is 4096 records (512 threads x 8), the staging buffer holds 8-byte words.
+constexpr int RS_IPT64 = 8;
+constexpr int RS_TILE64 = RS_THREADS * RS_IPT64;
+
+__global__ void __launch_bounds__(RS_THREADS) k_rs_hist64(const unsigned long long *__restrict__ keys, uint64_t n, int shift, int nbits, uint32_t n_tiles,
+                                                          uint32_t tiles_per_chunk, uint32_t *__restrict__ tile_pref, uint32_t *__restrict__ chunk_tot) {
+    __shared__ uint32_t h[RS_MAX_DIGITS], run[RS_MAX_DIGITS];
+    const uint32_t D = 1u << nbits, mask = D - 1u;
+    const uint32_t c = blockIdx.x, t0 = c * tiles_per_chunk, t1 = min(t0 + tiles_per_chunk, n_tiles);
+    for (uint32_t d = threadIdx.x; d < D; d += RS_THREADS) { run[d] = 0; h[d] = 0; }
+    __syncthreads();
+    unsigned long long k[RS_IPT64], kn[RS_IPT64];
+    auto fetch = [&](uint32_t t, unsigned long long *dst) {
+        const uint64_t base = (uint64_t) t * RS_TILE64;
+        if (t < t1 && base + RS_TILE64 <= n) {
+#pragma unroll
+            for (int j = 0; j < RS_IPT64; j++) dst[j] = keys[base + (uint64_t) j * RS_THREADS + threadIdx.x];
+        }
+    };
+    fetch(t0, k);
+    for (uint32_t t = t0; t < t1; t++) {
+        const uint64_t base = (uint64_t) t * RS_TILE64;
+        fetch(t + 1, kn);
+        if (base + RS_TILE64 <= n) {
+#pragma unroll
+            for (int j = 0; j < RS_IPT64; j++) atomicAdd(&h[(uint32_t) (k[j] >> shift) & mask], 1u);
+        } else {
+            for (int j = 0; j < RS_IPT64; j++) {
+                const uint64_t i = base + (uint64_t) j * RS_THREADS + threadIdx.x;
+                if (i < n) atomicAdd(&h[(uint32_t) (keys[i] >> shift) & mask], 1u);
+            }
+        }
+        __syncthreads();
+        for (uint32_t d = threadIdx.x; d < D; d += RS_THREADS) {
+            const uint32_t x = h[d], r = run[d];
+            tile_pref[(size_t) t * D + d] = r;
+            run[d] = r + x;
+            h[d] = 0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < RS_IPT64; j++) k[j] = kn[j];
+    }
+    for (uint32_t d = threadIdx.x; d < D; d += RS_THREADS) chunk_tot[(size_t) c * D + d] = run[d];
+}
+
+template <int NB>
+__global__ void __launch_bounds__(RS_THREADS) k_rs_scatter64(const unsigned long long *__restrict__ kin, const unsigned long long *__restrict__ vin,
+                                                             unsigned long long *__restrict__ kout, unsigned long long *__restrict__ vout, uint64_t n, int shift,
+                                                             int nbits, uint32_t n_tiles, uint32_t tiles_per_chunk, const uint32_t *__restrict__ tile_pref,
+                                                             const uint32_t *__restrict__ chunk_base, const uint32_t *__restrict__ digit_base) {
+    constexpr int DMAX = 1 << NB, WAVES = RS_THREADS / 64;
+    __shared__ unsigned short cnt[WAVES][DMAX];
+    __shared__ uint32_t goff[DMAX];
+    __shared__ unsigned long long stage[RS_TILE64];
+    __shared__ uint32_t wsum[WAVES];
+    const uint32_t per = (n_tiles + 7u) >> 3;
+    const uint32_t t = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+    if (t >= n_tiles) return;
+    const uint32_t D = 1u << nbits, mask = D - 1u;
+    const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    {
+        uint32_t *z = (uint32_t *) &cnt[0][0];
+        for (uint32_t i = threadIdx.x; i < WAVES * DMAX / 2; i += RS_THREADS) z[i] = 0;
+        const uint32_t c = t / tiles_per_chunk;
+        for (uint32_t d = threadIdx.x; d < D; d += RS_THREADS)
+            goff[d] = tile_pref[(size_t) t * D + d] + chunk_base[(size_t) c * D + d] + digit_base[d];
+    }
+    const uint64_t tbase = (uint64_t) t * RS_TILE64;
+    const uint32_t nv = (uint32_t) min((uint64_t) RS_TILE64, n - tbase);
+    unsigned long long k[RS_IPT64], v[RS_IPT64];
+#pragma unroll
+    for (int j = 0; j < RS_IPT64; j++) {
+        const uint32_t idx = w * (64u * RS_IPT64) + (uint32_t) j * 64u + lane;
+        const bool ok = idx < nv;
+        k[j] = ok ? kin[tbase + idx] : ~0ull;               // padding of the last tile: the largest digit, behind every item of the tile
+        v[j] = ok ? vin[tbase + idx] : 0ull;
+    }
+    __syncthreads();
+    unsigned short pos[RS_IPT64];
+#pragma unroll
+    for (int j = 0; j < RS_IPT64; j++) {
+        const uint32_t d = (uint32_t) (k[j] >> shift) & mask;
+        uint32_t plo, phi;
+        rs_match<NB>(d, plo, phi);
+        const uint32_t below = __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u));
+        const uint32_t c0 = cnt[w][d];
+        pos[j] = (unsigned short) (c0 + below);
+        if (below == 0u) cnt[w][d] = (unsigned short) (c0 + (uint32_t) (__popc(plo) + __popc(phi)));
+    }
+    __syncthreads();
+    {
+        const uint32_t d0 = 2u * threadIdx.x;
+        uint32_t a = 0, b = 0;
+        if (d0 < D) {
+#pragma unroll
+            for (int q = 0; q < WAVES; q++) {
+                uint32_t *pp = (uint32_t *) &cnt[q][d0];
+                const uint32_t x = *pp;
+                *pp = a | (b << 16);
+                a += x & 0xFFFFu; b += x >> 16;
+            }
+        }
+        const uint32_t ex = rs_block_excl_scan<WAVES>(a + b, wsum);
+        if (d0 < D) {
+#pragma unroll
+            for (int q = 0; q < WAVES; q++) {
+                uint32_t *pp = (uint32_t *) &cnt[q][d0];
+                const uint32_t x = *pp;
+                *pp = ((x & 0xFFFFu) + ex) | (((x >> 16) + ex + a) << 16);
+            }
+            goff[d0] -= ex;
+            if (d0 + 1 < D) goff[d0 + 1] -= ex + a;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < RS_IPT64; j++) {
+        const uint32_t d = (uint32_t) (k[j] >> shift) & mask;
+        pos[j] = (unsigned short) (pos[j] + cnt[w][d]);
+        stage[pos[j]] = k[j];
+    }
+    __syncthreads();
+    uint32_t ga[RS_IPT64];
+#pragma unroll
+    for (int j = 0; j < RS_IPT64; j++) {
+        const uint32_t i = (uint32_t) j * RS_THREADS + threadIdx.x;
+        const unsigned long long key = stage[i];
+        ga[j] = goff[(uint32_t) (key >> shift) & mask] + i;
+        if (i < nv) kout[ga[j]] = key;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < RS_IPT64; j++) stage[pos[j]] = v[j];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < RS_IPT64; j++) {
+        const uint32_t i = (uint32_t) j * RS_THREADS + threadIdx.x;
+        if (i < nv) vout[ga[j]] = stage[i];
+    }
+}
+
 size_t rs_align(size_t x) { return (x + 255) & ~(size_t) 255; }
 
 } // namespace
@@ -334,6 +477,44 @@ hipError_t rsort_u32_pairs(void *temp, size_t temp_bytes, const uint32_t *keys_i
         else                { if (nb <= 8) RS_SCATTER(8, 1024); else RS_SCATTER(10, 1024); }
 #undef RS_SCATTER_
 #undef RS_SCATTER
+        ki = ko; vi = vo;
+    }
+    return hipGetLastError();
+}
+
+size_t rsort_u64_pairs_temp_bytes(uint64_t n) {
+    const RsPlan p = rs_plan(n, 0, 32, 2);
+    return 2 * rs_align((size_t) (n + 4) * 8) + rs_align((size_t) p.n_tiles * RS_MAX_DIGITS * 4) + rs_align((size_t) RS_CHUNKS * RS_MAX_DIGITS * 4) +
+           2 * rs_align(RS_MAX_DIGITS * 4);
+}
+
+// stable sort of (u64 key, u64 value) records on the key bits [0, bits), 1 <= bits <= 50; the inputs are left untouched
+hipError_t rsort_u64_pairs(void *temp, size_t temp_bytes, const unsigned long long *keys_in, unsigned long long *keys_out, const unsigned long long *vals_in,
+                           unsigned long long *vals_out, uint64_t n, int bits, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    if (bits < 1 || bits > 50 || n >= (1ull << 32) - RS_TILE_MAX) return hipErrorInvalidValue;
+    if (temp_bytes < rsort_u64_pairs_temp_bytes(n)) return hipErrorInvalidValue;
+    const RsPlan p = rs_plan(n, 0, bits, 2);
+    char *at = (char *) temp;
+    unsigned long long *tk = (unsigned long long *) at; at += rs_align((size_t) (n + 4) * 8);
+    unsigned long long *tv = (unsigned long long *) at; at += rs_align((size_t) (n + 4) * 8);
+    uint32_t *tile_pref = (uint32_t *) at; at += rs_align((size_t) p.n_tiles * RS_MAX_DIGITS * 4);
+    uint32_t *chunk_tot = (uint32_t *) at; at += rs_align((size_t) RS_CHUNKS * RS_MAX_DIGITS * 4);
+    uint32_t *digit_tot = (uint32_t *) at; at += rs_align(RS_MAX_DIGITS * 4);
+    uint32_t *digit_base = (uint32_t *) at;
+    const unsigned long long *ki = keys_in, *vi = vals_in;
+    for (int i = 0; i < p.passes; i++) {
+        const bool to_out = ((p.passes - 1 - i) & 1) == 0;
+        unsigned long long *ko = to_out ? keys_out : tk, *vo = to_out ? vals_out : tv;
+        const int nb = p.bits[i], sh = p.shift[i];
+        hipLaunchKernelGGL(k_rs_hist64, dim3(p.chunks), dim3(RS_THREADS), 0, s, ki, n, sh, nb, p.n_tiles, p.tiles_per_chunk, tile_pref, chunk_tot);
+        hipLaunchKernelGGL(k_rs_scan_chunks, dim3(((1u << nb) + 63u) / 64u), dim3(RS_THREADS), 0, s, chunk_tot, p.chunks, nb, digit_tot);
+        hipLaunchKernelGGL(k_rs_scan_digits, dim3(1), dim3(RS_THREADS), 0, s, (const uint32_t *) digit_tot, nb, digit_base);
+        const dim3 grid(8u * ((p.n_tiles + 7u) / 8u));
+        if (nb <= 8) hipLaunchKernelGGL((k_rs_scatter64<8>), grid, dim3(RS_THREADS), 0, s, ki, vi, ko, vo, n, sh, nb, p.n_tiles, p.tiles_per_chunk,
+                                        (const uint32_t *) tile_pref, (const uint32_t *) chunk_tot, (const uint32_t *) digit_base);
+        else hipLaunchKernelGGL((k_rs_scatter64<10>), grid, dim3(RS_THREADS), 0, s, ki, vi, ko, vo, n, sh, nb, p.n_tiles, p.tiles_per_chunk,
+                                (const uint32_t *) tile_pref, (const uint32_t *) chunk_tot, (const uint32_t *) digit_base);
         ki = ko; vi = vo;
     }
     return hipGetLastError();

@@ -155,7 +155,7 @@ EXPORTS = ["alga_abi_version", "alga_engine_set_option", "alga_engine_create", "
            "alga_multi_create", "alga_multi_destroy", "alga_multi_last_error", "alga_multi_engine", "alga_multi_prefsuf_build_host", "alga_multi_prefsuf_build_device",
            "alga_multi_free_edges", "alga_multi_last_stats", "alga_multi_set_option", "alga_upload_twin_nodes",
            "alga_shard_index_device", "alga_shard_join_device", "alga_shard_small_keys_device", "alga_shard_resolve_device", "alga_shard_place_device",
-           "alga_shard_last_stats", "alga_sort_u32_pairs_device", "alga_multi_pkb_supplement_device", "alga_pkb_shard_begin", "alga_pkb_shard_round", "alga_pkb_shard_merge", "alga_pkb_shard_end",
+           "alga_shard_last_stats", "alga_sort_u32_pairs_device", "alga_sort_u64_pairs_device", "alga_multi_pkb_supplement_device", "alga_pkb_shard_begin", "alga_pkb_shard_round", "alga_pkb_shard_merge", "alga_pkb_shard_end",
            "alga_prefsuf_build_host_compact", "alga_download_edges_compact", "alga_free_compact_edges", "alga_host_alloc", "alga_host_free"]
 
 
@@ -237,6 +237,8 @@ def load_library():
     lib.alga_sort_records_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p,
                                              C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
     lib.alga_sort_edges_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]
+    lib.alga_sort_u64_pairs_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
+                                               C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_double)]
     lib.alga_sort_u32_pairs_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                                C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_double)]
     lib.alga_pkb_shard_begin.argtypes = [C.c_void_p, C.POINTER(_Nodes), C.POINTER(PkbParams), C.c_void_p, C.c_uint64, C.c_int32, C.c_int32, C.c_void_p]
@@ -672,6 +674,14 @@ class Engine:
         n = int(keys.shape[0])
         ko, vo, ms = C.c_void_p(), C.c_void_p(), C.c_double()
         self._check(self._lib.alga_sort_u32_pairs_device(self._h, keys.data_ptr() if n else None, vals.data_ptr() if n else None, n, int(begin_bit), int(bool(own)),
+                                                         int(repeat), C.c_void_p(stream or 0), C.byref(ko), C.byref(vo), C.byref(ms)))
+        return ko.value, vo.value, ms.value
+
+    def sort_u64_pairs_device(self, keys, vals, bits, own=True, repeat=1, stream=None):
+        """alga_sort_u64_pairs_device: (key, value) int64 tensors on this device, stable on the key bits [0, bits) -> (keys ptr, vals ptr, best ms)"""
+        n = int(keys.shape[0])
+        ko, vo, ms = C.c_void_p(), C.c_void_p(), C.c_double()
+        self._check(self._lib.alga_sort_u64_pairs_device(self._h, keys.data_ptr() if n else None, vals.data_ptr() if n else None, n, int(bits), int(bool(own)),
                                                          int(repeat), C.c_void_p(stream or 0), C.byref(ko), C.byref(vo), C.byref(ms)))
         return ko.value, vo.value, ms.value
 

@@ -414,6 +414,10 @@ int  alga_sort_records_device(alga_engine *e, const uint32_t *d_dst, const uint6
  * (valid until the next call on e); *ms_best = the fastest of `repeat` runs by HIP events. */
 int  alga_sort_u32_pairs_device(alga_engine *e, const uint32_t *d_keys, const uint32_t *d_vals, uint64_t n, int32_t begin_bit, int32_t own, int32_t repeat,
                                 void *hip_stream, const uint32_t **d_keys_sorted, const uint32_t **d_vals_sorted, double *ms_best);
+/* The (u64 key, u64 value) sort of the supplement's k-mer entries on its own (tests and tools): stable on the key bits [0, bits); own != 0: the
+ * engine's radix sort (bits <= 50), 0: rocPRIM's.  Replaces the std::sort of the reference's k-mer buckets (src/GraphCreators/GraphCreatorKmerBased.cpp:94-106). */
+int  alga_sort_u64_pairs_device(alga_engine *e, const uint64_t *d_keys, const uint64_t *d_vals, uint64_t n, int32_t bits, int32_t own, int32_t repeat,
+                                void *hip_stream, const uint64_t **d_keys_sorted, const uint64_t **d_vals_sorted, double *ms_best);
 int  alga_sort_edges_device(alga_engine *e, const alga_edge *d_edges, uint64_t n_edges, int32_t n_nodes,
                             void *hip_stream, const alga_edge **d_sorted);
 

@@ -95,3 +95,64 @@ def test_index_build_same_graph_with_either_sort(eng):
     finally:
         eng.set_option("own_sort", 1)
     assert a.shape == b.shape and (a == b).all()
+
+
+# ---- the 16-byte records of the supplement (radix_sort.hip: rsort_u64_pairs) ---------------------------------------------------------------
+
+def _check64(eng, keys_u64, bits, own=True):
+    import torch
+    n = len(keys_u64)
+    k = torch.from_numpy(keys_u64.view(np.int64)).cuda()
+    v = (torch.arange(n, dtype=torch.int64, device="cuda") << 33) | 5          # values wider than 32 bits
+    kp, vp, ms = eng.sort_u64_pairs_device(k, v, bits, own)
+    torch.cuda.synchronize()
+    if n == 0:
+        return ms
+    gk = device_view(kp, (n,), k.device, "<i8").clone()
+    gv = device_view(vp, (n,), k.device, "<i8").clone()
+    low = k & ((1 << bits) - 1) if bits < 63 else k
+    _, perm = torch.sort(low, stable=True)
+    assert torch.equal(gv, v[perm]), "values (= stable order) differ, bits %d n %d" % (bits, n)
+    assert torch.equal(gk, k[perm])
+    assert torch.equal(k, torch.from_numpy(keys_u64.view(np.int64)).cuda())
+    return ms
+
+
+@pytest.mark.parametrize("n", [0, 1, 63, 65, 4095, 4096, 4097, 100_000, 3 * 4096 * 512 + 17, (1 << 22) + 12345])
+def test_u64_records_every_size_class(eng, n):
+    rng = np.random.default_rng(n + 11)
+    keys = rng.integers(0, 1 << 63, size=n, dtype=np.uint64) * 2 + rng.integers(0, 2, size=n, dtype=np.uint64)
+    _check64(eng, keys, 30)                                # the supplement's plan at 10 M reads: 10 + 10 + 10
+    _check64(eng, keys, 40)
+
+
+@pytest.mark.parametrize("bits", [1, 7, 8, 9, 10, 11, 19, 20, 21, 29, 31, 32, 33, 41, 50])
+def test_u64_records_every_pass_plan(eng, bits):
+    rng = np.random.default_rng(300 + bits)
+    keys = rng.integers(0, 1 << 63, size=150_001, dtype=np.uint64)
+    _check64(eng, keys, bits)
+
+
+@pytest.mark.parametrize("kind", ["equal", "two", "sorted", "reversed", "one_digit_hot"])
+def test_u64_records_skewed_keys(eng, kind):
+    n = 200_000
+    rng = np.random.default_rng(6)
+    if kind == "equal":
+        keys = np.full(n, 0x123456789ABCDEF, dtype=np.uint64)
+    elif kind == "two":
+        keys = np.where(rng.random(n) < 0.5, np.uint64(0x3FFFFFFF), np.uint64(1 << 40)).astype(np.uint64)
+    elif kind == "sorted":
+        keys = np.sort(rng.integers(0, 1 << 62, size=n, dtype=np.uint64))
+    elif kind == "reversed":
+        keys = np.sort(rng.integers(0, 1 << 62, size=n, dtype=np.uint64))[::-1].copy()
+    else:
+        keys = rng.integers(0, 1 << 62, size=n, dtype=np.uint64)
+        keys[rng.random(n) < 0.9] = np.uint64(0x2AAAAAAA)
+    _check64(eng, keys, 30)
+
+
+def test_u64_records_library_path_agrees(eng):
+    rng = np.random.default_rng(8)
+    keys = rng.integers(0, 1 << 62, size=500_000, dtype=np.uint64)
+    _check64(eng, keys, 32, own=False)
+    _check64(eng, keys, 40, own=False)
