@@ -43,7 +43,7 @@ void launch_pkb_groups(const NodesDev &nd, const PkbCfg &c, const uint32_t *rowp
                        const uint32_t *heads, const uint32_t *hkey, const uint32_t *bound /* launch_pkb_class_bounds */, uint32_t n_heads, unsigned long long *vals, uint64_t n,
                        unsigned long long *marks, unsigned long long *big_marks, unsigned long long *big_cursor, unsigned long long *add_keys, uint64_t add_dense,
                        uint64_t add_cap, unsigned long long *add_overflow, unsigned long long *counters, uint32_t *n_add, uint32_t *left, int n_cu,
-                       int legacy /* bit 0: groups of 8 .. 16 through the wave kernel (round 4's form) */, hipStream_t s);
+                       int legacy /* bit 0: groups of 8 .. 16 through the wave kernel (round 4's form); bit 3: their replay inside the pair kernel */, hipStream_t s);
 void launch_pkb_gather_adds(const uint32_t *heads, const uint32_t *n_add, const uint32_t *pos, uint32_t n_heads, const unsigned long long *add_keys,
                             uint64_t add_dense, uint64_t n_dense_total, uint64_t n_ovf, unsigned long long *out, hipStream_t s);
 

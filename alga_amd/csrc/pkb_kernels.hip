@@ -417,12 +417,7 @@ __device__ __forceinline__ void pkb_stage_row(const NodesDev &nd, int id, uint32
 
 // canAlign (see can_align above) on staged rows; l1, l2 <= 16 * PKB_ROW_WORDS.  Every block the loop reads lies inside both reads
 // (32 k < 2 ov <= 2 min(l1 - off, l2)), words past a read's end are zero or masked.
-__device__ __forceinline__ bool can_align_rows(const uint32_t *a, const uint32_t *b, int l1, int l2, int off, const PkbCfg &c) {
-    if (100 * off > c.max_offset_pct * l1) return false;
-    if (off < 0) return false;
-    const int ov = (l1 < l2 + off ? l1 : l2 + off) - off;
-    if (ov < c.min_overlap_area) return false;
-    if (l2 + off - l1 < 0) return false;
+__device__ __forceinline__ bool can_align_rows_loop(const uint32_t *a, const uint32_t *b, int ov, int off, const PkbCfg &c) {
     const int bit = 2 * off, q = bit >> 5, r = bit & 31;
     const int nbits = 2 * ov;
     const int t0 = 2 * (ov - c.same_ends);
@@ -439,6 +434,36 @@ __device__ __forceinline__ bool can_align_rows(const uint32_t *a, const uint32_t
         if (lo_t < 32) tail += __popc(lo_t <= 0 ? x : (x & ~((1u << lo_t) - 1u)));
     }
     if (head != 0 || tail != 0) return false;
+    const int seq = (nbits - total) >> 1;
+    return 100 * seq >= c.min_identity_pct * ov;
+}
+
+// 32 bits of a staged row from bit `pos` on (the word behind the row is zero)
+__device__ __forceinline__ uint32_t pkb_row_bits(const uint32_t *row, int pos) { return pkb_funnel(row[pos >> 5], row[(pos >> 5) + 1], pos & 31); }
+
+// The same decision with the two end windows looked at FIRST and on their own (bits 0 .. 2 se and the last 2 se bits of the overlap: two funnel
+// shifts each), then one popcount per word of the overlap with the row word carried over: half the vector instructions of the loop above, which
+// stays for overlaps too short for the windows to be apart (never under the reference's parameters: min_overlap_area is half a read).
+__device__ __forceinline__ bool can_align_rows(const uint32_t *a, const uint32_t *b, int l1, int l2, int off, const PkbCfg &c) {
+    if (100 * off > c.max_offset_pct * l1) return false;
+    if (off < 0) return false;
+    const int ov = (l1 < l2 + off ? l1 : l2 + off) - off;
+    if (ov < c.min_overlap_area) return false;
+    if (l2 + off - l1 < 0) return false;
+    const int se = c.same_ends;
+    if (ov < 32 || se > 7 || se < 1) return can_align_rows_loop(a, b, ov, off, c);
+    const int bit = 2 * off, nbits = 2 * ov, t0 = nbits - 2 * se;
+    if (((pkb_row_bits(a, bit) ^ b[0]) & ((2u << (2 * se)) - 1u)) != 0u) return false;                     // head: bits 0 .. 2 se inclusive (LowErrorRate :43)
+    if (((pkb_row_bits(a, bit + t0) ^ pkb_row_bits(b, t0)) & ((1u << (2 * se)) - 1u)) != 0u) return false;   // tail: bits t0 .. nbits - 1
+    const int q = bit >> 5, r = bit & 31, nw = nbits >> 5, rem = nbits & 31;
+    int total = 0;
+    uint32_t lo = a[q];
+    for (int k = 0; k < nw; k++) {
+        const uint32_t hi = a[q + k + 1];
+        total += __popc(pkb_funnel(lo, hi, r) ^ b[k]);
+        lo = hi;
+    }
+    if (rem) total += __popc((pkb_funnel(lo, a[q + nw + 1], r) ^ b[nw]) & ((1u << rem) - 1u));
     const int seq = (nbits - total) >> 1;
     return 100 * seq >= c.min_identity_pct * ov;
 }
@@ -757,10 +782,14 @@ __global__ void __launch_bounds__(64) k_pkb_groups_wave(NodesDev nd, PkbCfg c, P
 // (list entry -> k-mer entries -> rows and snapshot rows -> snapshot keys), 13 us per group and wave.  Same plan as k_pkb_groups_wave -- every pair
 // speculatively, then the reference's i / j loops on bit masks -- in 16-bit masks: a pass takes row i and row D - 2 - i of each group together
 // (D - 1 - i and i + 1 pairs: D lanes), the replay runs once per wave with every quarter on its own masks (cross-lane reads stay inside a quarter).
+// REPLAY = false (the default since round 5, second step): the kernel stops after the masks -- the replay of four groups side by side cost more
+// vector instructions than everything before it (a wave executes every step of the longest of its four i / j walks) -- and leaves, per entry, its
+// row of masks in marks[] and the group's entries in sorted order in vals[]; k_pkb_quarter_replay walks them with a THREAD per group.
 constexpr int PKB_QUARTER_MAX = 16;
+template <bool REPLAY>
 __global__ void __launch_bounds__(64) k_pkb_groups_quarter(NodesDev nd, PkbCfg c, PkbGraph g, const uint32_t *__restrict__ heads, const uint32_t *__restrict__ hkey,
-                                                            const uint32_t *__restrict__ bound, const unsigned long long *__restrict__ vals, PkbAdd ad,
-                                                            unsigned long long *__restrict__ counters, uint32_t *__restrict__ n_add, uint32_t *__restrict__ left) {
+                                                            const uint32_t *__restrict__ bound, unsigned long long *__restrict__ vals, unsigned long long *__restrict__ marks,
+                                                            PkbAdd ad, unsigned long long *__restrict__ counters, uint32_t *__restrict__ n_add, uint32_t *__restrict__ left) {
     __shared__ uint32_t srow[64][PKB_ROW_WORDS + 1];
     __shared__ unsigned long long sv[64];
     __shared__ uint32_t sr0[64], sr1[64];
@@ -832,6 +861,10 @@ __global__ void __launch_bounds__(64) k_pkb_groups_quarter(NodesDev nd, PkbCfg c
             if (on && sub == i) { ES = ((be & ma) << (i + 1)) | (((bs & ma) << (i + 1)) << 16); CA = ((bc & ma) << (i + 1)) | (((ba & ma) << (i + 1)) << 16); }
             if (on && rb > i && sub == rb) { ES = (be & ~ma) | ((bs & ~ma) << 16); CA = (bc & ~ma) | ((ba & ~ma) << 16); }
         }
+        if (!REPLAY) {
+            if (sub < Dq) { marks[gs + sub] = (unsigned long long) ES | ((unsigned long long) CA << 32); vals[gs + sub] = vj; }
+            continue;
+        }
         // the i / j loops of the reference on the masks, every quarter on its own; lane r keeps the marker row of entry r
         uint32_t myrow = 0u;
         int n_added = 0;
@@ -871,6 +904,57 @@ __global__ void __launch_bounds__(64) k_pkb_groups_quarter(NodesDev nd, PkbCfg c
 #pragma unroll
     for (int o = 32; o >= 16; o >>= 1) calls += __shfl_xor(calls, o);
     if (lane == 0 && calls) atomicAdd(&counters[0], calls);
+}
+
+// the i / j loops of the reference (createAlignmentsForKmers :40-97) on the masks k_pkb_groups_quarter<false> left: one THREAD per group, the marker
+// rows of the group in a column of LDS.  marks[gs + i]: eligible | snapshot-known << 16 | call << 32 | aligned << 48 of row i (bit j = pair (i, j)).
+__global__ void __launch_bounds__(256) k_pkb_quarter_replay(const uint32_t *__restrict__ heads, const uint32_t *__restrict__ hkey, const uint32_t *__restrict__ bound,
+                                                             const unsigned long long *__restrict__ vals, const unsigned long long *__restrict__ marks, PkbAdd ad,
+                                                             unsigned long long *__restrict__ counters, uint32_t *__restrict__ n_add, uint32_t *__restrict__ left) {
+    __shared__ unsigned short srows[PKB_QUARTER_MAX][256];
+    const uint32_t t_lo = bound[255 - PKB_QUARTER_MAX], t_hi = bound[256 - (PKB_SMALL_MAX + 1)];
+    unsigned long long calls = 0;
+    for (uint32_t t = t_lo + blockIdx.x * blockDim.x + threadIdx.x; t < t_hi; t += gridDim.x * blockDim.x) {
+        if (left[t]) continue;                                               // a read twice in the group: k_pkb_groups_serial
+        const int D = 255 - (int) hkey[t];
+        const uint64_t gs = heads[t];
+        unsigned long long *mine = ad.keys + 2 * gs;
+        int n_added = 0;
+        unsigned long long mk[PKB_QUARTER_MAX - 1];                          // all rows of masks on their way at once (the walk below is a chain)
+#pragma unroll
+        for (int i = 0; i < PKB_QUARTER_MAX - 1; i++) mk[i] = i <= D - 2 ? marks[gs + i] : 0ull;
+        srows[D - 1][threadIdx.x] = 0;
+#pragma unroll
+        for (int i = PKB_QUARTER_MAX - 2; i >= 0; i--) {
+            if (i > D - 2) continue;
+            const uint32_t s_i = (uint32_t) (mk[i] >> 16) & 0xFFFFu, c_i = (uint32_t) (mk[i] >> 32) & 0xFFFFu, a_i = (uint32_t) (mk[i] >> 48);
+            uint32_t row = 0u, addm = 0u;
+            for (uint32_t m = (uint32_t) mk[i] & 0xFFFFu; m; m &= m - 1u) {
+                const int j = __builtin_ctz(m);
+                if ((row >> j) & 1u) continue;                               // already reachable inside the group (:62)
+                bool reach = true;                                           // an edge of at most this offset exists
+                if ((c_i >> j) & 1u) {
+                    calls++;
+                    if ((a_i >> j) & 1u) addm |= 1u << j;
+                    else reach = (s_i >> j) & 1u;
+                }
+                if (reach) row |= (1u << j) | srows[j][threadIdx.x];
+            }
+            srows[i][threadIdx.x] = (unsigned short) row;
+            if (addm) {
+                const unsigned long long vi = vals[gs + i];
+                for (uint32_t m = addm; m; m &= m - 1u) {
+                    const unsigned long long vj = vals[gs + __builtin_ctz(m)];
+                    pkb_add_edge(ad, mine, n_added, 2 * D, pkb_edge_key(pkb_val_id(vi), pkb_val_id(vj), pkb_val_ind(vi) - pkb_val_ind(vj)));
+                    n_added++;
+                }
+            }
+        }
+        n_add[t] = (uint32_t) (n_added < 2 * D ? n_added : 2 * D);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) calls += __shfl_xor(calls, o);
+    if ((threadIdx.x & 63u) == 0 && calls) atomicAdd(&counters[0], calls);
 }
 
 // 2 <= D <= 7: one THREAD per group; the entries in LDS, the marker rows in one register (8 bits per row), rows staged per pair.
@@ -1073,8 +1157,15 @@ void launch_pkb_groups(const NodesDev &nd, const PkbCfg &c, const uint32_t *rowp
         // the ranges of the three shapes come from `bound` on the device: the grids are sized for the chip, not for the list
         hipLaunchKernelGGL(k_pkb_groups_wave, dim3(std::min<unsigned>(n_heads, cus * (quarter ? 8u : 24u))), dim3(64), 0, s, nd, c, g, heads, hkey, bound,
                            quarter ? PKB_QUARTER_MAX + 1 : PKB_SMALL_MAX + 1, (const unsigned long long *) vals, ad, counters, n_add, left);
-        if (quarter) hipLaunchKernelGGL(k_pkb_groups_quarter, dim3(std::min<unsigned>((n_heads + 3) / 4, cus * 17u)), dim3(64), 0, s, nd, c, g, heads, hkey, bound,
-                                        (const unsigned long long *) vals, ad, counters, n_add, left);
+        if (quarter && (legacy & 8))
+            hipLaunchKernelGGL(k_pkb_groups_quarter<true>, dim3(std::min<unsigned>((n_heads + 3) / 4, cus * 17u)), dim3(64), 0, s, nd, c, g, heads, hkey, bound, vals, marks, ad,
+                               counters, n_add, left);
+        else if (quarter) {
+            hipLaunchKernelGGL(k_pkb_groups_quarter<false>, dim3(std::min<unsigned>((n_heads + 3) / 4, cus * 17u)), dim3(64), 0, s, nd, c, g, heads, hkey, bound, vals, marks, ad,
+                               counters, n_add, left);
+            hipLaunchKernelGGL(k_pkb_quarter_replay, dim3(std::min<unsigned>((n_heads + 255) / 256, cus * 8u)), dim3(256), 0, s, heads, hkey, bound,
+                               (const unsigned long long *) vals, (const unsigned long long *) marks, ad, counters, n_add, left);
+        }
         hipLaunchKernelGGL(k_pkb_groups_small, dim3(std::min<unsigned>((n_heads + PKB_SMALL_WG - 1) / PKB_SMALL_WG, cus * 3u)), dim3(PKB_SMALL_WG), 0, s, nd, c, g,
                            heads, hkey, bound, (const unsigned long long *) vals, ad, counters, n_add, left);
     }
