@@ -84,7 +84,7 @@ struct alga_engine {
     // approximate supplement (engine_pkb.hip)
     DevBuf pk_keys, pk_keys2, pk_vals, pk_vals2, pk_marks, pk_big, pk_add, pk_ekeys, pk_ekeys2, pk_flag, pk_pos, pk_edges[2], pk_rowptr, pk_deg,
            pk_mask, pk_cnt, pk_io, pk_io2, pk_tips, pk_heads, pk_g[2], pk_addk, pk_addk2, pk_merged, pk_hsz, pk_hsz2, pk_heads2, pk_nadd, pk_koff,
-           pk_gsz, pk_fixlist, pk_bounds;
+           pk_gsz, pk_fixlist, pk_bounds, pk_tiprec;
     // duplicate / prefix-read removal (engine_ingest.hip)
     DevBuf pp_rows, pp_len, pp_perm[2], pp_keys[2], pp_mark, pp_keep, pp_pos, pp_out_rows, pp_out_len, pp_out_pair, pp_tally;
     // staged host <-> HBM copies (staging.hip)

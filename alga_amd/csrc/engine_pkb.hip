@@ -151,6 +151,12 @@ int pkb_begin(alga_engine *e, const alga_nodes *dn, const alga_pkb_params *p, co
         st.nk = e->h_counters[0];
     }
     if (st.nk >= (1ull << 31)) return alga_fail(e, ALGA_ERR_CAPACITY, "more than 2^31 k-mers in the supplement; shard the input");
+    // one 128-byte record per node that takes part: its row and id now, its snapshot keys at the start of every round
+    if (st.n_tips) {
+        if ((rc = alga_ensure(e, e->pk_tiprec, pkb_tiprec_bytes(st.n_tips)))) return rc;
+        launch_pkb_tiprec_rows(nd, (const uint32_t *) e->pk_tips.p, st.n_tips, e->pk_tiprec.p, s);
+        if ((rc = alga_check_launch(e, "k_pkb_tiprec_rows"))) return rc;
+    }
     st.prio[0] = 0; st.prio[1] = 1; st.prio[2] = 2; st.prio[3] = 3;
     st.key_bits = 36 + node_bits(n);
     st.phase = 1;
@@ -185,8 +191,10 @@ int pkb_round(alga_engine *e, hipStream_t s, const unsigned long long **d_add, u
         if ((rc = alga_ensure(e, *b, (nk + 2) * sizeof(uint32_t)))) return rc;
     if ((rc = alga_ensure(e, e->sort_temp, temp))) return rc;
     if ((rc = alga_ensure(e, e->scan_scratch, scan_scratch_bytes(nk)))) return rc;
+    launch_pkb_tiprec_snap((const uint32_t *) e->pk_tips.p, n_tips, (const uint32_t *) e->pk_rowptr.p, (const unsigned long long *) e->pk_g[cur].p, e->pk_tiprec.p, s);
+    if ((rc = alga_check_launch(e, "k_pkb_tiprec_snap"))) return rc;
     launch_pkb_kmers(nd, c, st.prio, (const uint32_t *) e->pk_tips.p, (const uint32_t *) e->pk_koff.p, n_tips, sort_bits, (unsigned long long *) e->pk_keys.p,
-                     (unsigned long long *) e->pk_vals.p, s);
+                     (unsigned long long *) e->pk_vals.p, e->pk_tiprec.p, s);
     if ((rc = alga_check_launch(e, "k_pkb_kmers"))) return rc;
     // equal hashes become contiguous; inside a group the group kernel orders the entries itself
     if (own_sort) HIP_TRY(e, rsort_u64_pairs(e->sort_temp.p, temp, (const unsigned long long *) e->pk_keys.p, (unsigned long long *) e->pk_keys2.p,
@@ -242,7 +250,8 @@ int pkb_round(alga_engine *e, hipStream_t s, const unsigned long long **d_add, u
         launch_pkb_groups(nd, c, (const uint32_t *) e->pk_rowptr.p, (const unsigned long long *) e->pk_g[cur].p, (const unsigned long long *) e->pk_keys2.p,
                           (const uint32_t *) e->pk_heads2.p, (const uint32_t *) e->pk_hsz2.p, (const uint32_t *) e->pk_bounds.p, n_heads, (unsigned long long *) e->pk_vals2.p, nk,
                           (unsigned long long *) e->pk_marks.p, (unsigned long long *) e->pk_big.p, cnt + 4, (unsigned long long *) e->pk_add.p, add_dense,
-                          add_cap, cnt + 5, cnt + 6, (uint32_t *) e->pk_nadd.p, (uint32_t *) e->pk_gsz.p, e->n_cu, e->opt_pkb_legacy, s);
+                          add_cap, cnt + 5, cnt + 6, (uint32_t *) e->pk_nadd.p, (uint32_t *) e->pk_gsz.p, e->n_cu, (const uint32_t *) e->pk_tips.p, e->pk_tiprec.p,
+                          e->opt_pkb_legacy, s);
         if ((rc = alga_check_launch(e, "k_pkb_groups"))) return rc;
         launch_exclusive_scan((const uint32_t *) e->pk_nadd.p, (uint64_t) n_heads, (uint32_t *) e->pk_pos.p, (uint64_t *) e->scan_scratch.p, s);
         HIP_TRY(e, hipMemcpyAsync(e->h_counters, cnt, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));

@@ -28,7 +28,11 @@ void launch_pkb_tip_flags(const NodesDev &nd, const PkbCfg &c, const uint8_t *ma
 void launch_pkb_tip_list(const NodesDev &nd, const PkbCfg &c, const uint32_t *flag, const uint32_t *pos, uint32_t *tips, uint32_t *kcount,
                          unsigned long long *max_len, hipStream_t s);
 void launch_pkb_kmers(const NodesDev &nd, const PkbCfg &c, const int32_t prio[4], const uint32_t *tips, const uint32_t *koff, uint32_t n_tips, int sort_bits,
-                      unsigned long long *keys, unsigned long long *vals, hipStream_t s);
+                      unsigned long long *keys, unsigned long long *vals, const void *tiprec, hipStream_t s);
+// tip records (pkb_kernels.hip: PkbTipRec): row + id + first snapshot keys of every node that takes part, 128 bytes each
+size_t pkb_tiprec_bytes(uint32_t n_tips);
+void launch_pkb_tiprec_rows(const NodesDev &nd, const uint32_t *tips, uint32_t n_tips, void *tiprec, hipStream_t s);
+void launch_pkb_tiprec_snap(const uint32_t *tips, uint32_t n_tips, const uint32_t *rowptr, const unsigned long long *gkeys, void *tiprec, hipStream_t s);
 void launch_pkb_fix_runs(unsigned long long *keys, unsigned long long *vals, uint64_t n, int bits, uint32_t *list, uint32_t list_cap, unsigned long long *counter,
                          hipStream_t s);
 void launch_pkb_fix_runs_loop(unsigned long long *keys, unsigned long long *vals, uint64_t n, int bits, hipStream_t s);
@@ -43,7 +47,7 @@ void launch_pkb_groups(const NodesDev &nd, const PkbCfg &c, const uint32_t *rowp
                        const uint32_t *heads, const uint32_t *hkey, const uint32_t *bound /* launch_pkb_class_bounds */, uint32_t n_heads, unsigned long long *vals, uint64_t n,
                        unsigned long long *marks, unsigned long long *big_marks, unsigned long long *big_cursor, unsigned long long *add_keys, uint64_t add_dense,
                        uint64_t add_cap, unsigned long long *add_overflow, unsigned long long *counters, uint32_t *n_add, uint32_t *left, int n_cu,
-                       int legacy /* bit 0: groups of 8 .. 16 through the wave kernel (round 4's form); bit 3: their replay inside the pair kernel */, hipStream_t s);
+                       const uint32_t *tips, const void *tiprec, int legacy /* bit 0: groups of 8 .. 16 through the wave kernel (round 4's form); bit 3: their replay inside the pair kernel */, hipStream_t s);
 void launch_pkb_gather_adds(const uint32_t *heads, const uint32_t *n_add, const uint32_t *pos, uint32_t n_heads, const unsigned long long *add_keys,
                             uint64_t add_dense, uint64_t n_dense_total, uint64_t n_ovf, unsigned long long *out, hipStream_t s);
 

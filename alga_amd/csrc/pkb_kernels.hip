@@ -234,8 +234,9 @@ __global__ void __launch_bounds__(256) k_pkb_tip_list(NodesDev nd, PkbCfg c, con
     }
 }
 
-// A k-mer entry: key = hash, val = (4095 - indInRead) << 40 | read length << 28 | node id.  Ascending val == the order of the
-// reference inside a group (indInRead descending, read length ascending; Kmer::operator<, Kmer.cpp:58-64) with ties by node id.
+// A k-mer entry: key = hash, val = (4095 - indInRead) << 40 | read length << 28 | tip (the node's position in the dense tip list = its
+// record, PkbTipRec below; the list ascends with the node id).  Ascending val == the order of the reference inside a group (indInRead
+// descending, read length ascending; Kmer::operator<, Kmer.cpp:58-64) with ties by node id.
 constexpr unsigned long long PKB_ID_MASK = (1ull << 28) - 1;
 __device__ __forceinline__ int pkb_val_id(unsigned long long v) { return (int) (v & PKB_ID_MASK); }
 __device__ __forceinline__ int pkb_val_len(unsigned long long v) { return (int) ((v >> 28) & 0xFFFull); }
@@ -251,10 +252,20 @@ __device__ __forceinline__ int pkb_val_ind(unsigned long long v) { return 4095 -
 // from another by a sequencing error further left (1.4 M such neighbours among 21 M entries).
 constexpr unsigned long long PKB_KEY_MIX = 0x9E3779B97F4A7C15ull;
 constexpr int PKB_ROW_WORDS = 16;
+// a node that takes part, in one 128-byte line (see "Tip records" below)
+constexpr int PKB_REC_KEYS = 7;
+struct __attribute__((aligned(128))) PkbTipRec {
+    uint32_t words[PKB_ROW_WORDS];                       // the node's row (zero behind its last word)
+    uint32_t id;                                         // node id
+    uint32_t nkeys;                                      // out-edges in the round's snapshot; the first PKB_REC_KEYS of them:
+    unsigned long long keys[PKB_REC_KEYS];
+};
+static_assert(sizeof(PkbTipRec) == 128, "one record == one 128-byte line");
+
 template <bool STAGED>
 __global__ void __launch_bounds__(256) k_pkb_kmers(NodesDev nd, PkbCfg c, int4 prio4, const uint32_t *__restrict__ tips, const uint32_t *__restrict__ koff,
                                                     uint32_t n_tips, int sort_bits /* 1 .. 63 */, unsigned long long *__restrict__ keys,
-                                                    unsigned long long *__restrict__ vals) {
+                                                    unsigned long long *__restrict__ vals, const PkbTipRec *__restrict__ rec) {
     __shared__ uint64_t T[64];
     __shared__ uint32_t srow[STAGED ? 256 : 1][PKB_ROW_WORDS + 1];
     mod_table_fill(T);
@@ -263,7 +274,7 @@ __global__ void __launch_bounds__(256) k_pkb_kmers(NodesDev nd, PkbCfg c, int4 p
         const int cw = (int) (threadIdx.x & 15u);
         for (int r = (int) (threadIdx.x >> 4); r < 256; r += 16) {
             const uint32_t t = base_t + (uint32_t) r;
-            srow[r][cw] = (t < n_tips && cw < nd.stride) ? nd.words[(size_t) tips[t] * nd.stride + cw] : 0u;
+            srow[r][cw] = t < n_tips ? rec[t].words[cw] : 0u;              // (dense: the block's 256 records are 32 KB in a row)
         }
     }
     __syncthreads();
@@ -279,7 +290,7 @@ __global__ void __launch_bounds__(256) k_pkb_kmers(NodesDev nd, PkbCfg c, int4 p
     for (int j = 0; j < cnt; j++) {
         const unsigned long long m = h[j] * PKB_KEY_MIX;
         keys[base + j] = (m << sort_bits) | (m >> (64 - sort_bits));            // the product's top bits, where the sort looks
-        vals[base + j] = ((unsigned long long) (4095 - p[j]) << 40) | ((unsigned long long) (uint32_t) len << 28) | i;
+        vals[base + j] = ((unsigned long long) (4095 - p[j]) << 40) | ((unsigned long long) (uint32_t) len << 28) | t;      // t: the tip's record (ascends with the node id)
     }
 }
 
@@ -307,13 +318,16 @@ __global__ void __launch_bounds__(256) k_pkb_fix_flag(const unsigned long long *
     if (threadIdx.x == 0) s_n = 0u;
     __syncthreads();
     const uint64_t base = (uint64_t) blockIdx.x * (256 * PKB_FLAG_IPT);
-#pragma unroll 4
+    unsigned long long k[PKB_FLAG_IPT], kp[PKB_FLAG_IPT];                  // every load on its way before the first compare
+#pragma unroll
     for (int j = 0; j < PKB_FLAG_IPT; j++) {
         const uint64_t i = base + (uint64_t) j * 256 + threadIdx.x;
-        if (i == 0 || i >= n) continue;
-        const unsigned long long k = keys[i], kp = keys[i - 1];
-        if (k != kp && (k & lm) == (kp & lm)) s_list[atomicAdd(&s_n, 1u)] = (uint32_t) i;
+        const bool ok = i != 0 && i < n;
+        k[j] = ok ? keys[i] : 0ull; kp[j] = ok ? keys[i - 1] : 0ull;
     }
+#pragma unroll
+    for (int j = 0; j < PKB_FLAG_IPT; j++)
+        if (k[j] != kp[j] && (k[j] & lm) == (kp[j] & lm)) s_list[atomicAdd(&s_n, 1u)] = (uint32_t) (base + (uint64_t) j * 256 + threadIdx.x);
     __syncthreads();
     const uint32_t cnt = s_n;
     if (cnt == 0u) return;
@@ -384,7 +398,6 @@ __global__ void __launch_bounds__(256) k_pkb_fix_runs(unsigned long long *__rest
 struct PkbGraph { const uint32_t *rowptr; const unsigned long long *keys; };   // snapshot of the round's start
 constexpr int PKB_SMALL_MAX = 7;
 constexpr int PKB_WAVE_MAX = 64;
-constexpr int PKB_SNAP_KEYS = 6;
 
 __device__ __forceinline__ int snapshot_offset(const PkbGraph &g, int a, int b) {
     uint32_t lo = g.rowptr[a], hi = g.rowptr[a + 1];
@@ -396,6 +409,65 @@ __device__ __forceinline__ int snapshot_offset(const PkbGraph &g, int a, int b) 
         if (d < b) lo = mid + 1; else hi = mid;
     }
     return PKB_INF;
+}
+
+// ------------------------------------------------------------------------------------------
+// Tip records (round 5).  The group kernels used to fetch THREE isolated 128-byte lines per k-mer entry -- the node's row (64 bytes of one), its two
+// row pointers (8 bytes of another) and its snapshot keys (a third) -- and ran at the rate HBM serves isolated lines (5.7 GB per round at 10 M
+// reads).  Now every node that takes part has ONE 128-byte record: its row, its id and its first snapshot keys; a k-mer entry names the record
+// (the tip's position in the dense tip list, which ascends with the node id: the order inside a group is unchanged) instead of the node.
+// Rows longer than PKB_ROW_WORDS words are not staged at all (the serial kernel reads them through the node id).
+// ------------------------------------------------------------------------------------------
+// rows, once per supplement: four lanes per tip, sixteen bytes each (rows whose stride is not a multiple of four words: word by word)
+__global__ void __launch_bounds__(256) k_pkb_tiprec_rows(NodesDev nd, const uint32_t *__restrict__ tips, uint32_t n_tips, PkbTipRec *__restrict__ rec) {
+    const uint32_t t = (blockIdx.x * blockDim.x + threadIdx.x) >> 2, w = (threadIdx.x & 3u) * 4u;
+    if (t >= n_tips) return;
+    const uint32_t id = tips[t];
+    uint4 x = make_uint4(0u, 0u, 0u, 0u);
+    if (nd.stride <= PKB_ROW_WORDS) {
+        const uint32_t *src = nd.words + (size_t) id * nd.stride;
+        if ((nd.stride & 3) == 0) { if ((int) w < nd.stride) x = *reinterpret_cast<const uint4 *>(src + w); }
+        else {
+            if ((int) w < nd.stride) x.x = src[w];
+            if ((int) w + 1 < nd.stride) x.y = src[w + 1];
+            if ((int) w + 2 < nd.stride) x.z = src[w + 2];
+            if ((int) w + 3 < nd.stride) x.w = src[w + 3];
+        }
+    }
+    *reinterpret_cast<uint4 *>(rec[t].words + w) = x;                          // (the id goes in with the snapshot half: k_pkb_tiprec_snap)
+}
+
+// the other half of the record -- id, snapshot row size, its first keys -- once per round: four lanes per tip, sixteen bytes each, so that the
+// half-line is written WHOLE (a record whose 4-byte count alone was rewritten cost a read-modify-write in memory: 0.16 ms for 3.6 M tips)
+__global__ void __launch_bounds__(256) k_pkb_tiprec_snap(const uint32_t *__restrict__ tips, uint32_t n_tips, const uint32_t *__restrict__ rowptr,
+                                                          const unsigned long long *__restrict__ gkeys, PkbTipRec *__restrict__ rec) {
+    const uint32_t t = (blockIdx.x * blockDim.x + threadIdx.x) >> 2, q = threadIdx.x & 3u;
+    if (t >= n_tips) return;
+    const uint32_t id = tips[t], r0 = rowptr[id], r1 = rowptr[id + 1];
+    // lane q holds the 16 bytes [16 q, 16 q + 16) of the half: q = 0: id, nkeys, key 0; q > 0: keys 2 q - 1 and 2 q
+    const uint32_t ka = q == 0u ? 0u : 2u * q - 1u, kb = 2u * q;
+    const unsigned long long a = (q != 0u && r0 + ka < r1) ? gkeys[r0 + ka] : 0ull, b = r0 + kb < r1 ? gkeys[r0 + kb] : 0ull;
+    uint4 x;
+    if (q == 0u) x = make_uint4(id, r1 - r0, (uint32_t) b, (uint32_t) (b >> 32));
+    else x = make_uint4((uint32_t) a, (uint32_t) (a >> 32), (uint32_t) b, (uint32_t) (b >> 32));
+    *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(rec + t) + 64 + 16 * q) = x;
+}
+
+// neighbors[b] of node a in the round's snapshot through a's record (ra, rb: the records' positions)
+__device__ __forceinline__ int rec_offset(const PkbGraph &g, const PkbTipRec *__restrict__ rec, int ra, int id_b) {
+    const uint32_t nk = rec[ra].nkeys;
+    if (nk > (uint32_t) PKB_REC_KEYS) return snapshot_offset(g, (int) rec[ra].id, id_b);
+    int off = PKB_INF;
+    for (uint32_t q = 0; q < nk; q++) { const unsigned long long k = rec[ra].keys[q]; if (pkb_key_dst(k) == id_b) off = pkb_key_off(k); }
+    return off;
+}
+
+// a record's row into LDS: PKB_ROW_WORDS words + a zero word behind them
+__device__ __forceinline__ void pkb_stage_rec_row(const PkbTipRec *__restrict__ r, uint32_t *dst) {
+    const uint4 *src = reinterpret_cast<const uint4 *>(r->words);
+#pragma unroll
+    for (int q = 0; q < PKB_ROW_WORDS / 4; q++) { const uint4 x = src[q]; dst[4 * q] = x.x; dst[4 * q + 1] = x.y; dst[4 * q + 2] = x.z; dst[4 * q + 3] = x.w; }
+    dst[PKB_ROW_WORDS] = 0u;
 }
 
 // one row of a node into LDS: PKB_ROW_WORDS words + a zero word behind them
@@ -518,20 +590,33 @@ constexpr int PKB_HEADS_IPT = 16;
 __global__ void __launch_bounds__(256) k_pkb_heads(const unsigned long long *__restrict__ keys, uint64_t n, unsigned long long *__restrict__ big_words,
                                                     unsigned long long *__restrict__ max_d, unsigned long long *__restrict__ n_heads /* zeroed by the caller */,
                                                     uint32_t *__restrict__ heads, uint32_t *__restrict__ hkey, uint32_t rank, uint32_t n_ranks) {
+    constexpr int TILE = 256 * PKB_HEADS_IPT;
+    __shared__ unsigned long long sk[TILE + 2];                              // the block's keys, the one before and the one behind
     __shared__ uint32_t wsum[4];
     __shared__ uint32_t s_base;
-    const uint64_t base = (uint64_t) blockIdx.x * (256 * PKB_HEADS_IPT);
+    const uint64_t base = (uint64_t) blockIdx.x * TILE;
+    {
+        unsigned long long x[PKB_HEADS_IPT];
+#pragma unroll
+        for (int j = 0; j < PKB_HEADS_IPT; j++) { const uint64_t i = base + (uint64_t) j * 256 + threadIdx.x; x[j] = i < n ? keys[i] : 0ull; }
+#pragma unroll
+        for (int j = 0; j < PKB_HEADS_IPT; j++) sk[1 + j * 256 + threadIdx.x] = x[j];
+        if (threadIdx.x == 0) sk[0] = base > 0 ? keys[base - 1] : 0ull;
+        if (threadIdx.x == 1) sk[TILE + 1] = base + TILE < n ? keys[base + TILE] : 0ull;
+    }
+    __syncthreads();
     uint32_t flags = 0u, cnt = 0u;
     uint32_t sz[PKB_HEADS_IPT / 4] = {0u, 0u, 0u, 0u};                          // min(D, 255), a byte per entry of this thread
 #pragma unroll
     for (int j = 0; j < PKB_HEADS_IPT; j++) {
-        const uint64_t i = base + (uint64_t) j * 256 + threadIdx.x;
+        const uint32_t li = (uint32_t) j * 256 + threadIdx.x;                  // position in the tile
+        const uint64_t i = base + li;
         if (i >= n) continue;
-        const unsigned long long k = keys[i];
+        const unsigned long long k = sk[1 + li];
         const bool mine = n_ranks <= 1u || (uint32_t) (((k ^ (k >> 29)) * 0x9E3779B97F4A7C15ull) >> 40) % n_ranks == rank;
-        if (mine && (i == 0 || keys[i - 1] != k) && i + 1 < n && keys[i + 1] == k) {
+        if (mine && (i == 0 || sk[li] != k) && i + 1 < n && sk[2 + li] == k) {
             uint64_t e = i + 2;
-            while (e < n && keys[e] == k) e++;
+            while (e < n && (e - base <= (uint64_t) TILE ? sk[1 + (e - base)] : keys[e]) == k) e++;
             const uint64_t D = e - i;
             flags |= 1u << j; cnt++;
             sz[j >> 2] |= (uint32_t) (D < 255 ? D : 255) << (8 * (j & 3));
@@ -576,7 +661,7 @@ __device__ __forceinline__ void pkb_add_edge(const PkbAdd &ad, unsigned long lon
 __device__ __forceinline__ unsigned long long pkb_group_serial(const NodesDev &nd, const PkbCfg &c, const PkbGraph &g, const unsigned long long *__restrict__ keys,
                                                               unsigned long long *__restrict__ vals, uint64_t n, uint64_t gs, int D, unsigned long long *__restrict__ marks,
                                                               unsigned long long *__restrict__ big_marks, unsigned long long *__restrict__ big_cursor,
-                                                              const PkbAdd &ad, uint32_t *n_added) {
+                                                              const PkbAdd &ad, uint32_t *n_added, const uint32_t *__restrict__ tips) {
     if (D >= 255) {                                                          // the size key saturates: count
         uint64_t ge = gs + 1;
         while (ge < n && keys[ge] == keys[gs]) ge++;
@@ -602,12 +687,12 @@ __device__ __forceinline__ unsigned long long pkb_group_serial(const NodesDev &n
     unsigned long long calls = 0;
     for (int i = D - 2; i >= 0; i--) {
         const unsigned long long vi = v[i];
-        const int id1 = pkb_val_id(vi), ind1 = pkb_val_ind(vi), len1 = pkb_val_len(vi);
+        const int id1 = (int) tips[pkb_val_id(vi)], ind1 = pkb_val_ind(vi), len1 = pkb_val_len(vi);      // (an entry names the tip: its node id is tips[tip])
         unsigned long long *row_i = rows + (size_t) i * RW;
         for (int j = i + 1; j < D; j++) {
             const unsigned long long vj = v[j];
-            const int id2 = pkb_val_id(vj);
-            if (id1 == id2) continue;
+            if (pkb_val_id(vi) == pkb_val_id(vj)) continue;
+            const int id2 = (int) tips[pkb_val_id(vj)];
             const int off = ind1 - pkb_val_ind(vj);
             if (off < 0) continue;
             if (100 * off > c.max_offset_pct * len1) break;                  // :55
@@ -648,14 +733,14 @@ __global__ void __launch_bounds__(64) k_pkb_groups_serial(NodesDev nd, PkbCfg c,
                                                            const uint32_t *__restrict__ left /* per group: 1 = left for this kernel */,
                                                            unsigned long long *__restrict__ vals, uint64_t n, unsigned long long *__restrict__ marks,
                                                            unsigned long long *__restrict__ big_marks, unsigned long long *__restrict__ big_cursor, PkbAdd ad,
-                                                           unsigned long long *__restrict__ counters, uint32_t *__restrict__ n_add) {
+                                                           unsigned long long *__restrict__ counters, uint32_t *__restrict__ n_add, const uint32_t *__restrict__ tips) {
     unsigned long long calls = 0;
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t < n_heads) {
         const int D = 255 - (int) hkey[t];
         if (all || D > PKB_WAVE_MAX || left[t]) {
             uint32_t na = 0;
-            calls = pkb_group_serial(nd, c, g, keys, vals, n, (uint64_t) heads[t], D, marks, big_marks, big_cursor, ad, &na);
+            calls = pkb_group_serial(nd, c, g, keys, vals, n, (uint64_t) heads[t], D, marks, big_marks, big_cursor, ad, &na, tips);
             n_add[t] = na;
         }
     }
@@ -668,11 +753,12 @@ __global__ void __launch_bounds__(64) k_pkb_groups_serial(NodesDev nd, PkbCfg c,
 __global__ void __launch_bounds__(64) k_pkb_groups_wave(NodesDev nd, PkbCfg c, PkbGraph g, const uint32_t *__restrict__ heads, const uint32_t *__restrict__ hkey,
                                                          const uint32_t *__restrict__ bound, int d_lo /* sizes d_lo .. PKB_WAVE_MAX */,
                                                          const unsigned long long *__restrict__ vals, PkbAdd ad,
-                                                         unsigned long long *__restrict__ counters, uint32_t *__restrict__ n_add, uint32_t *__restrict__ left) {
+                                                         unsigned long long *__restrict__ counters, uint32_t *__restrict__ n_add, uint32_t *__restrict__ left,
+                                                         const PkbTipRec *__restrict__ rec) {
     __shared__ uint32_t srow[64][PKB_ROW_WORDS + 1];
     __shared__ unsigned long long sv[64];
-    __shared__ uint32_t sr0[64], sr1[64];                                    // snapshot row of entry i: [sr0, sr1) ...
-    __shared__ unsigned long long sk[64][PKB_SNAP_KEYS + 1];                 // ... and its first keys (all of them, usually)
+    __shared__ uint32_t sid[64], snk[64];                                    // entry i: node id, size of its snapshot row ...
+    __shared__ unsigned long long sk[64][PKB_REC_KEYS];                      // ... and its first keys (all of them, usually)
     const int lane = (int) threadIdx.x;
     unsigned long long calls = 0;
     const uint32_t t_lo = bound[255 - PKB_WAVE_MAX], t_hi = bound[256 - d_lo];
@@ -697,12 +783,14 @@ __global__ void __launch_bounds__(64) k_pkb_groups_wave(NodesDev nd, PkbCfg c, P
             if (lane == 0) { left[t] = 1u; n_add[t] = 0u; }
             continue;
         }
+        int nidj = 0;                                                        // this lane's entry: its node id
         if (lane < D) {
-            pkb_stage_row(nd, idj, srow[lane]);
-            const uint32_t r0 = g.rowptr[idj], r1 = g.rowptr[idj + 1];
-            sr0[lane] = r0; sr1[lane] = r1;
+            const PkbTipRec *r = rec + idj;                                  // the whole entry in one line: row, id, snapshot keys
+            pkb_stage_rec_row(r, srow[lane]);
+            nidj = (int) r->id;
+            sid[lane] = r->id; snk[lane] = r->nkeys;
 #pragma unroll
-            for (int q = 0; q < PKB_SNAP_KEYS; q++) if (r0 + q < r1) sk[lane][q] = g.keys[r0 + q];
+            for (int q = 0; q < PKB_REC_KEYS; q++) sk[lane][q] = r->keys[q];
         }
         __syncthreads();
         unsigned long long *mine = ad.keys + 2 * gs;
@@ -718,8 +806,8 @@ __global__ void __launch_bounds__(64) k_pkb_groups_wave(NodesDev nd, PkbCfg c, P
             while (rem >= D - 1 - i) { rem -= D - 1 - i; i++; }
             const int j = i + 1 + rem;
             const unsigned long long vi = sv[i], vj2 = sv[j];
-            const int id1 = pkb_val_id(vi), ind1 = pkb_val_ind(vi), len1 = pkb_val_len(vi);
-            const int id2 = pkb_val_id(vj2), len2 = pkb_val_len(vj2);
+            const int ind1 = pkb_val_ind(vi), len1 = pkb_val_len(vi);
+            const int id2 = (int) sid[j], len2 = pkb_val_len(vj2);
             const int off = ind1 - pkb_val_ind(vj2);
             bool elig = p < P && off >= 0 && !(100 * off > c.max_offset_pct * len1);     // the `break` of :55 is monotone in j: part of the mask
             if (elig) {
@@ -728,10 +816,10 @@ __global__ void __launch_bounds__(64) k_pkb_groups_wave(NodesDev nd, PkbCfg c, P
             }
             int snap = PKB_INF;
             if (elig) {
-                const uint32_t r0 = sr0[i], r1 = sr1[i];
-                if (r1 - r0 <= (uint32_t) PKB_SNAP_KEYS) {                       // the row is in LDS
-                    for (uint32_t q = 0; q < r1 - r0; q++) { const unsigned long long k = sk[i][q]; if (pkb_key_dst(k) == id2) snap = pkb_key_off(k); }
-                } else snap = snapshot_offset(g, id1, id2);
+                const uint32_t nk = snk[i];
+                if (nk <= (uint32_t) PKB_REC_KEYS) {                             // the row is in LDS
+                    for (uint32_t q = 0; q < nk; q++) { const unsigned long long k = sk[i][q]; if (pkb_key_dst(k) == id2) snap = pkb_key_off(k); }
+                } else snap = snapshot_offset(g, (int) sid[i], id2);
             }
             const bool call = elig && snap > off;
             const bool ok = call && can_align_rows(srow[i], srow[j], len1, len2, off, c);
@@ -767,7 +855,7 @@ __global__ void __launch_bounds__(64) k_pkb_groups_wave(NodesDev nd, PkbCfg c, P
             if (lane == i) myrow = row;
             if ((addm >> lane) & 1ull) {
                 const unsigned long long vi = sv[i];
-                pkb_add_edge(ad, mine, n_added + __popcll(addm & ((1ull << lane) - 1ull)), 2 * D, pkb_edge_key(pkb_val_id(vi), idj, pkb_val_ind(vi) - indj));
+                pkb_add_edge(ad, mine, n_added + __popcll(addm & ((1ull << lane) - 1ull)), 2 * D, pkb_edge_key((int) sid[i], nidj, pkb_val_ind(vi) - indj));
             }
             n_added += __popcll(addm);
         }
@@ -789,11 +877,12 @@ constexpr int PKB_QUARTER_MAX = 16;
 template <bool REPLAY>
 __global__ void __launch_bounds__(64) k_pkb_groups_quarter(NodesDev nd, PkbCfg c, PkbGraph g, const uint32_t *__restrict__ heads, const uint32_t *__restrict__ hkey,
                                                             const uint32_t *__restrict__ bound, unsigned long long *__restrict__ vals, unsigned long long *__restrict__ marks,
-                                                            PkbAdd ad, unsigned long long *__restrict__ counters, uint32_t *__restrict__ n_add, uint32_t *__restrict__ left) {
+                                                            PkbAdd ad, unsigned long long *__restrict__ counters, uint32_t *__restrict__ n_add, uint32_t *__restrict__ left,
+                                                            const PkbTipRec *__restrict__ rec) {
     __shared__ uint32_t srow[64][PKB_ROW_WORDS + 1];
     __shared__ unsigned long long sv[64];
-    __shared__ uint32_t sr0[64], sr1[64];
-    __shared__ unsigned long long sk[64][PKB_SNAP_KEYS + 1];
+    __shared__ uint32_t sid[64], snk[64];
+    __shared__ unsigned long long sk[64][PKB_REC_KEYS];
     const int lane = (int) threadIdx.x, sub = lane & 15, qb = lane & 48;     // qb: the quarter's first lane == its bit position in a ballot
     const uint32_t t_lo = bound[255 - PKB_QUARTER_MAX], t_hi = bound[256 - (PKB_SMALL_MAX + 1)];
     unsigned long long calls = 0;                                            // the quarter's calls, the same in its sixteen lanes
@@ -820,12 +909,14 @@ __global__ void __launch_bounds__(64) k_pkb_groups_quarter(NodesDev nd, PkbCfg c
         if (dup && sub == 0) { left[t] = 1u; n_add[t] = 0u; }               // a read twice in the group: the serial kernel replays it
         const int Dq = dup ? 0 : D;
         const int Dmax = max(max(__builtin_amdgcn_readlane(Dq, 0), __builtin_amdgcn_readlane(Dq, 16)), max(__builtin_amdgcn_readlane(Dq, 32), __builtin_amdgcn_readlane(Dq, 48)));
+        int nidj = 0;                                                        // this lane's entry: its node id
         if (sub < Dq) {
-            pkb_stage_row(nd, idj, srow[lane]);
-            const uint32_t r0 = g.rowptr[idj], r1 = g.rowptr[idj + 1];
-            sr0[lane] = r0; sr1[lane] = r1;
+            const PkbTipRec *r = rec + idj;                                  // the whole entry in one line: row, id, snapshot keys
+            pkb_stage_rec_row(r, srow[lane]);
+            nidj = (int) r->id;
+            sid[lane] = r->id; snk[lane] = r->nkeys;
 #pragma unroll
-            for (int q = 0; q < PKB_SNAP_KEYS; q++) if (r0 + q < r1) sk[lane][q] = g.keys[r0 + q];
+            for (int q = 0; q < PKB_REC_KEYS; q++) sk[lane][q] = r->keys[q];
         }
         __syncthreads();
         unsigned long long *mine = ad.keys + 2 * gs;
@@ -838,8 +929,8 @@ __global__ void __launch_bounds__(64) k_pkb_groups_quarter(NodesDev nd, PkbCfg c
             const int r = isA ? i : rb, j = isA ? i + 1 + sub : sub;
             const bool pair = on && sub < Dq && (isA || rb > i);
             const unsigned long long vi = sv[qb + (pair ? r : 0)], vj2 = sv[qb + (pair ? j : 0)];
-            const int id1 = pkb_val_id(vi), ind1 = pkb_val_ind(vi), len1 = pkb_val_len(vi);
-            const int id2 = pkb_val_id(vj2), len2 = pkb_val_len(vj2);
+            const int ind1 = pkb_val_ind(vi), len1 = pkb_val_len(vi);
+            const int id2 = (int) sid[qb + (pair ? j : 0)], len2 = pkb_val_len(vj2);
             const int off = ind1 - pkb_val_ind(vj2);
             bool elig = pair && off >= 0 && !(100 * off > c.max_offset_pct * len1);
             if (elig) {
@@ -848,10 +939,10 @@ __global__ void __launch_bounds__(64) k_pkb_groups_quarter(NodesDev nd, PkbCfg c
             }
             int snap = PKB_INF;
             if (elig) {
-                const uint32_t r0 = sr0[qb + r], r1 = sr1[qb + r];
-                if (r1 - r0 <= (uint32_t) PKB_SNAP_KEYS) {
-                    for (uint32_t q = 0; q < r1 - r0; q++) { const unsigned long long k = sk[qb + r][q]; if (pkb_key_dst(k) == id2) snap = pkb_key_off(k); }
-                } else snap = snapshot_offset(g, id1, id2);
+                const uint32_t nk = snk[qb + r];
+                if (nk <= (uint32_t) PKB_REC_KEYS) {
+                    for (uint32_t q = 0; q < nk; q++) { const unsigned long long k = sk[qb + r][q]; if (pkb_key_dst(k) == id2) snap = pkb_key_off(k); }
+                } else snap = snapshot_offset(g, (int) sid[qb + r], id2);
             }
             const bool call = elig && snap > off;
             const bool ok = call && can_align_rows(srow[qb + r], srow[qb + j], len1, len2, off, c);
@@ -862,7 +953,8 @@ __global__ void __launch_bounds__(64) k_pkb_groups_quarter(NodesDev nd, PkbCfg c
             if (on && rb > i && sub == rb) { ES = (be & ~ma) | ((bs & ~ma) << 16); CA = (bc & ~ma) | ((ba & ~ma) << 16); }
         }
         if (!REPLAY) {
-            if (sub < Dq) { marks[gs + sub] = (unsigned long long) ES | ((unsigned long long) CA << 32); vals[gs + sub] = vj; }
+            // (the sorted entries go back with the NODE id in place of the tip: the replay writes edges and reads nothing else)
+            if (sub < Dq) { marks[gs + sub] = (unsigned long long) ES | ((unsigned long long) CA << 32); vals[gs + sub] = (vj & ~PKB_ID_MASK) | (unsigned long long) (uint32_t) nidj; }
             continue;
         }
         // the i / j loops of the reference on the masks, every quarter on its own; lane r keeps the marker row of entry r
@@ -894,7 +986,7 @@ __global__ void __launch_bounds__(64) k_pkb_groups_quarter(NodesDev nd, PkbCfg c
             if (on && sub == i) myrow = row;
             if (on && ((addm >> sub) & 1u)) {
                 const unsigned long long vi = sv[qb + i];
-                pkb_add_edge(ad, mine, n_added + __popc(addm & ((1u << sub) - 1u)), 2 * Dq, pkb_edge_key(pkb_val_id(vi), idj, pkb_val_ind(vi) - indj));
+                pkb_add_edge(ad, mine, n_added + __popc(addm & ((1u << sub) - 1u)), 2 * Dq, pkb_edge_key((int) sid[qb + i], nidj, pkb_val_ind(vi) - indj));
             }
             n_added += __popc(addm);
         }
@@ -967,7 +1059,8 @@ __global__ void __launch_bounds__(256) k_pkb_quarter_replay(const uint32_t *__re
 constexpr int PKB_SMALL_WG = 256;
 __global__ void __launch_bounds__(PKB_SMALL_WG) k_pkb_groups_small(NodesDev nd, PkbCfg c, PkbGraph g, const uint32_t *__restrict__ heads, const uint32_t *__restrict__ hkey,
                                                           const uint32_t *__restrict__ bound, const unsigned long long *__restrict__ vals, PkbAdd ad,
-                                                          unsigned long long *__restrict__ counters, uint32_t *__restrict__ n_add, uint32_t *__restrict__ left) {
+                                                          unsigned long long *__restrict__ counters, uint32_t *__restrict__ n_add, uint32_t *__restrict__ left,
+                                                          const PkbTipRec *__restrict__ rec) {
     __shared__ uint32_t srow[PKB_SMALL_WG][2 * PKB_ROW_WORDS + 3];           // a | 0 | b | 0 (+1: odd stride, conflict-free)
     __shared__ unsigned long long sv[PKB_SMALL_MAX][PKB_SMALL_WG];
     const int lane = (int) threadIdx.x;                                      // slot in the workgroup's LDS arrays
@@ -995,12 +1088,12 @@ __global__ void __launch_bounds__(PKB_SMALL_WG) k_pkb_groups_small(NodesDev nd, 
             int n_added = 0;
             for (int i = D - 2; i >= 0; i--) {
                 const unsigned long long vi = sv[i][lane];
-                const int id1 = pkb_val_id(vi), ind1 = pkb_val_ind(vi), len1 = pkb_val_len(vi);
+                const int t1 = pkb_val_id(vi), ind1 = pkb_val_ind(vi), len1 = pkb_val_len(vi);       // t1, t2: the entries' records (row, node id, snapshot keys in one line)
                 bool staged = false;
                 uint32_t row_i = 0u;
                 for (int j = i + 1; j < D; j++) {
                     const unsigned long long vj = sv[j][lane];
-                    const int id2 = pkb_val_id(vj);
+                    const int t2 = pkb_val_id(vj);
                     const int off = ind1 - pkb_val_ind(vj);
                     if (off < 0) continue;
                     if (100 * off > c.max_offset_pct * len1) break;          // :55
@@ -1009,13 +1102,14 @@ __global__ void __launch_bounds__(PKB_SMALL_WG) k_pkb_groups_small(NodesDev nd, 
                     if (ov < c.min_overlap_area) continue;
                     if (len2 + off - len1 < 0) continue;
                     if ((row_i >> j) & 1u) continue;                         // already reachable inside the group (:62)
-                    int cur = snapshot_offset(g, id1, id2);                  // neighbors[id2]
+                    const int id2 = (int) rec[t2].id;
+                    int cur = rec_offset(g, rec, t1, id2);                   // neighbors[id2]
                     if (cur > off) {
                         calls++;
-                        if (!staged) { pkb_stage_row(nd, id1, ra); staged = true; }
-                        pkb_stage_row(nd, id2, rb);
+                        if (!staged) { pkb_stage_rec_row(rec + t1, ra); staged = true; }
+                        pkb_stage_rec_row(rec + t2, rb);
                         if (can_align_rows(ra, rb, len1, len2, off, c)) {    // :66
-                            pkb_add_edge(ad, mine, n_added, 2 * D, pkb_edge_key(id1, id2, off));
+                            pkb_add_edge(ad, mine, n_added, 2 * D, pkb_edge_key((int) rec[t1].id, id2, off));
                             n_added++;
                             cur = off;
                         }
@@ -1096,11 +1190,24 @@ void launch_pkb_tip_list(const NodesDev &nd, const PkbCfg &c, const uint32_t *fl
 }
 
 void launch_pkb_kmers(const NodesDev &nd, const PkbCfg &c, const int32_t prio[4], const uint32_t *tips, const uint32_t *koff, uint32_t n_tips, int sort_bits,
-                      unsigned long long *keys, unsigned long long *vals, hipStream_t s) {
+                      unsigned long long *keys, unsigned long long *vals, const void *tiprec, hipStream_t s) {
     if (n_tips == 0) return;
     const int4 pr = make_int4(prio[0], prio[1], prio[2], prio[3]);
-    if (nd.stride <= PKB_ROW_WORDS) hipLaunchKernelGGL(k_pkb_kmers<true>, dim3((n_tips + 255) / 256), dim3(256), 0, s, nd, c, pr, tips, koff, n_tips, sort_bits, keys, vals);
-    else hipLaunchKernelGGL(k_pkb_kmers<false>, dim3((n_tips + 255) / 256), dim3(256), 0, s, nd, c, pr, tips, koff, n_tips, sort_bits, keys, vals);
+    const PkbTipRec *rec = (const PkbTipRec *) tiprec;
+    if (nd.stride <= PKB_ROW_WORDS) hipLaunchKernelGGL(k_pkb_kmers<true>, dim3((n_tips + 255) / 256), dim3(256), 0, s, nd, c, pr, tips, koff, n_tips, sort_bits, keys, vals, rec);
+    else hipLaunchKernelGGL(k_pkb_kmers<false>, dim3((n_tips + 255) / 256), dim3(256), 0, s, nd, c, pr, tips, koff, n_tips, sort_bits, keys, vals, rec);
+}
+
+size_t pkb_tiprec_bytes(uint32_t n_tips) { return ((size_t) n_tips + 1) * sizeof(PkbTipRec); }
+
+void launch_pkb_tiprec_rows(const NodesDev &nd, const uint32_t *tips, uint32_t n_tips, void *tiprec, hipStream_t s) {
+    if (n_tips == 0) return;
+    hipLaunchKernelGGL(k_pkb_tiprec_rows, dim3((unsigned) (((uint64_t) n_tips * 4 + 255) / 256)), dim3(256), 0, s, nd, tips, n_tips, (PkbTipRec *) tiprec);
+}
+
+void launch_pkb_tiprec_snap(const uint32_t *tips, uint32_t n_tips, const uint32_t *rowptr, const unsigned long long *gkeys, void *tiprec, hipStream_t s) {
+    if (n_tips == 0) return;
+    hipLaunchKernelGGL(k_pkb_tiprec_snap, dim3((unsigned) (((uint64_t) n_tips * 4 + 255) / 256)), dim3(256), 0, s, tips, n_tips, rowptr, gkeys, (PkbTipRec *) tiprec);
 }
 
 // counter: zeroed by the caller; after the call *counter > list_cap means "run launch_pkb_fix_runs_loop"
@@ -1144,8 +1251,10 @@ void launch_pkb_head_list(const uint32_t *head_flag, const uint32_t *pos, const 
 void launch_pkb_groups(const NodesDev &nd, const PkbCfg &c, const uint32_t *rowptr, const unsigned long long *gkeys, const unsigned long long *keys,
                        const uint32_t *heads, const uint32_t *hkey, const uint32_t *bound, uint32_t n_heads, unsigned long long *vals, uint64_t n, unsigned long long *marks,
                        unsigned long long *big_marks, unsigned long long *big_cursor, unsigned long long *add_keys, uint64_t add_dense, uint64_t add_cap,
-                       unsigned long long *add_overflow, unsigned long long *counters, uint32_t *n_add, uint32_t *left, int n_cu, int legacy, hipStream_t s) {
+                       unsigned long long *add_overflow, unsigned long long *counters, uint32_t *n_add, uint32_t *left, int n_cu, const uint32_t *tips,
+                       const void *tiprec, int legacy, hipStream_t s) {
     if (n == 0 || n_heads == 0) return;
+    const PkbTipRec *rec = (const PkbTipRec *) tiprec;
     PkbGraph g{rowptr, gkeys};
     PkbAdd ad{add_keys, add_dense, add_cap, add_overflow};
     const unsigned blocks = (n_heads + 63) / 64;
@@ -1156,21 +1265,21 @@ void launch_pkb_groups(const NodesDev &nd, const PkbCfg &c, const uint32_t *rowp
         const bool quarter = !(legacy & 1);
         // the ranges of the three shapes come from `bound` on the device: the grids are sized for the chip, not for the list
         hipLaunchKernelGGL(k_pkb_groups_wave, dim3(std::min<unsigned>(n_heads, cus * (quarter ? 8u : 24u))), dim3(64), 0, s, nd, c, g, heads, hkey, bound,
-                           quarter ? PKB_QUARTER_MAX + 1 : PKB_SMALL_MAX + 1, (const unsigned long long *) vals, ad, counters, n_add, left);
+                           quarter ? PKB_QUARTER_MAX + 1 : PKB_SMALL_MAX + 1, (const unsigned long long *) vals, ad, counters, n_add, left, rec);
         if (quarter && (legacy & 8))
             hipLaunchKernelGGL(k_pkb_groups_quarter<true>, dim3(std::min<unsigned>((n_heads + 3) / 4, cus * 17u)), dim3(64), 0, s, nd, c, g, heads, hkey, bound, vals, marks, ad,
-                               counters, n_add, left);
+                               counters, n_add, left, rec);
         else if (quarter) {
             hipLaunchKernelGGL(k_pkb_groups_quarter<false>, dim3(std::min<unsigned>((n_heads + 3) / 4, cus * 17u)), dim3(64), 0, s, nd, c, g, heads, hkey, bound, vals, marks, ad,
-                               counters, n_add, left);
+                               counters, n_add, left, rec);
             hipLaunchKernelGGL(k_pkb_quarter_replay, dim3(std::min<unsigned>((n_heads + 255) / 256, cus * 8u)), dim3(256), 0, s, heads, hkey, bound,
                                (const unsigned long long *) vals, (const unsigned long long *) marks, ad, counters, n_add, left);
         }
         hipLaunchKernelGGL(k_pkb_groups_small, dim3(std::min<unsigned>((n_heads + PKB_SMALL_WG - 1) / PKB_SMALL_WG, cus * 3u)), dim3(PKB_SMALL_WG), 0, s, nd, c, g,
-                           heads, hkey, bound, (const unsigned long long *) vals, ad, counters, n_add, left);
+                           heads, hkey, bound, (const unsigned long long *) vals, ad, counters, n_add, left, rec);
     }
     hipLaunchKernelGGL(k_pkb_groups_serial, dim3(blocks), dim3(64), 0, s, nd, c, g, keys, heads, hkey, n_heads, staged ? 0 : 1, (const uint32_t *) left, vals, n, marks,
-                       big_marks, big_cursor, ad, counters, n_add);
+                       big_marks, big_cursor, ad, counters, n_add, tips);
 }
 
 void launch_pkb_gather_adds(const uint32_t *heads, const uint32_t *n_add, const uint32_t *pos, uint32_t n_heads, const unsigned long long *add_keys,
