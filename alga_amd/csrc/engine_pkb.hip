@@ -298,16 +298,45 @@ int pkb_merge(alga_engine *e, const unsigned long long *d_all, uint64_t A, hipSt
         if ((rc = alga_ensure(e, e->pk_merged, (E + A + 1) * sizeof(unsigned long long)))) return rc;
         if ((rc = alga_ensure(e, e->pk_g[nxt], (E + A + 1) * sizeof(unsigned long long)))) return rc;
         if ((rc = alga_ensure(e, e->sort_temp, t2))) return rc;
-        HIP_TRY(e, sort_u64_keys_bits(e->sort_temp.p, t2, d_all, (unsigned long long *) e->pk_addk2.p, A, st.key_bits, s));
+        if (A >= 1024 && !(e->opt_pkb_legacy & 16)) {     // (below: one library kernel does it)
+            const int nb = st.key_bits - 36;                                          // bits of a node id
+            const size_t t3 = rsort_u32_pairs_temp_bytes(A);
+            for (DevBuf *b : {&e->pk_heads, &e->pk_heads2, &e->pk_hsz})
+                if ((rc = alga_ensure(e, *b, (A + 16) * sizeof(uint32_t)))) return rc;
+            if ((rc = alga_ensure(e, e->sort_temp, std::max(t2, t3)))) return rc;
+            launch_pkb_src_keys(d_all, A, 32 - nb, (uint32_t *) e->pk_heads.p, s);
+            HIP_TRY(e, rsort_u32_pairs(e->sort_temp.p, std::max(t2, t3), (const uint32_t *) e->pk_heads.p, (uint32_t *) e->pk_heads2.p, nullptr, (uint32_t *) e->pk_hsz.p, A,
+                                       32 - nb, s));
+            launch_pkb_gather_keys(d_all, (const uint32_t *) e->pk_hsz.p, A, (unsigned long long *) e->pk_addk2.p, s);
+            launch_pkb_sort_src_runs((unsigned long long *) e->pk_addk2.p, A, s);
+            if ((rc = alga_check_launch(e, "k_pkb_sort_src_runs"))) return rc;
+        } else HIP_TRY(e, sort_u64_keys_bits(e->sort_temp.p, t2, d_all, (unsigned long long *) e->pk_addk2.p, A, st.key_bits, s));
         HIP_TRY(e, merge_u64(e->sort_temp.p, t2, (const unsigned long long *) e->pk_g[cur].p, E, (const unsigned long long *) e->pk_addk2.p, A,
                              (unsigned long long *) e->pk_merged.p, s));
-        HIP_TRY(e, unique_edge_keys(e->sort_temp.p, t2, (const unsigned long long *) e->pk_merged.p, (unsigned long long *) e->pk_g[nxt].p, cnt + 13, E + A, s));
-        HIP_TRY(e, hipMemcpyAsync(e->h_counters, cnt + 13, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-        HIP_TRY(e, hipStreamSynchronize(s));
-        st.E = e->h_counters[0];
-        st.cur = nxt;
-        launch_pkb_rowptr((const unsigned long long *) e->pk_g[st.cur].p, st.E, st.dn.n, (uint32_t *) e->pk_rowptr.p, s);
-        if ((rc = alga_check_launch(e, "k_pkb_rowptr"))) return rc;
+        if (e->opt_pkb_legacy & 16) {
+            HIP_TRY(e, unique_edge_keys(e->sort_temp.p, t2, (const unsigned long long *) e->pk_merged.p, (unsigned long long *) e->pk_g[nxt].p, cnt + 13, E + A, s));
+            HIP_TRY(e, hipMemcpyAsync(e->h_counters, cnt + 13, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+            HIP_TRY(e, hipStreamSynchronize(s));
+            st.E = e->h_counters[0];
+            st.cur = nxt;
+            launch_pkb_rowptr((const unsigned long long *) e->pk_g[st.cur].p, st.E, st.dn.n, (uint32_t *) e->pk_rowptr.p, s);
+            if ((rc = alga_check_launch(e, "k_pkb_rowptr"))) return rc;
+        } else {
+            // first key of every (src, dst) run: flags -> scan -> scatter; the scatter writes the new row pointers as well
+            const uint64_t M = E + A;
+            if ((rc = alga_ensure(e, e->pk_flag, (M + 2) * sizeof(uint32_t)))) return rc;
+            if ((rc = alga_ensure(e, e->pk_pos, (M + 2) * sizeof(uint32_t)))) return rc;
+            if ((rc = alga_ensure(e, e->scan_scratch, scan_scratch_bytes(M)))) return rc;
+            launch_pkb_unique_flags((const unsigned long long *) e->pk_merged.p, M, (uint32_t *) e->pk_flag.p, s);
+            launch_exclusive_scan((const uint32_t *) e->pk_flag.p, M, (uint32_t *) e->pk_pos.p, (uint64_t *) e->scan_scratch.p, s);
+            launch_pkb_unique_scatter((const unsigned long long *) e->pk_merged.p, M, (const uint32_t *) e->pk_flag.p, (const uint32_t *) e->pk_pos.p, st.dn.n,
+                                      (unsigned long long *) e->pk_g[nxt].p, (uint32_t *) e->pk_rowptr.p, s);
+            if ((rc = alga_check_launch(e, "k_pkb_unique_scatter"))) return rc;
+            HIP_TRY(e, hipMemcpyAsync(e->h_counters, (uint64_t *) e->scan_scratch.p + scan_total_index(M), sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+            HIP_TRY(e, hipStreamSynchronize(s));
+            st.E = e->h_counters[0];
+            st.cur = nxt;
+        }
     }
     e->pkb_stats.edges_after[st.round] = st.E;
     std::rotate(st.prio, st.prio + 1, st.prio + 4);                          // GraphCreatorLI.cpp:26
