@@ -194,7 +194,7 @@ int pkb_round(alga_engine *e, hipStream_t s, const unsigned long long **d_add, u
     launch_pkb_tiprec_snap((const uint32_t *) e->pk_tips.p, n_tips, (const uint32_t *) e->pk_rowptr.p, (const unsigned long long *) e->pk_g[cur].p, e->pk_tiprec.p, s);
     if ((rc = alga_check_launch(e, "k_pkb_tiprec_snap"))) return rc;
     launch_pkb_kmers(nd, c, st.prio, (const uint32_t *) e->pk_tips.p, (const uint32_t *) e->pk_koff.p, n_tips, sort_bits, (unsigned long long *) e->pk_keys.p,
-                     (unsigned long long *) e->pk_vals.p, e->pk_tiprec.p, s);
+                     (unsigned long long *) e->pk_vals.p, e->pk_tiprec.p, (e->opt_pkb_legacy & 32) != 0, s);
     if ((rc = alga_check_launch(e, "k_pkb_kmers"))) return rc;
     // equal hashes become contiguous; inside a group the group kernel orders the entries itself
     if (own_sort) HIP_TRY(e, rsort_u64_pairs(e->sort_temp.p, temp, (const unsigned long long *) e->pk_keys.p, (unsigned long long *) e->pk_keys2.p,

@@ -311,10 +311,52 @@ struct __attribute__((aligned(128))) PkbTipRec {
 };
 static_assert(sizeof(PkbTipRec) == 128, "one record == one 128-byte line");
 
+// li_kmers for k <= 48 on a staged row, the rolling value in three 32-bit words (round 5: the 128-bit form cost 37 vector instructions per start
+// position -- a quarter of them moving the upper 58 bits of zeros -- and made the k-mer kernel VALU-bound at 0.5 ms per round).  Same walk, same
+// ties (strictly smaller replaces), same interval borders; returns the k-mers written.
+__device__ __forceinline__ int li_kmers96(const uint32_t *row, int len, int k, int intervals, uint32_t pp /* prio[s] at bits 2 s */, int wave_max_len,
+                                          uint64_t *hash_out, int32_t *ind_out, const uint64_t *T) {
+    typedef unsigned __int128 u128;
+    if (k > len || intervals <= 0) return 0;
+    const int nb = 2 * k;                                                      // bits of a k-mer value
+    const uint32_t m0 = nb >= 32 ? 0xFFFFFFFFu : ((1u << nb) - 1u);
+    const uint32_t m1 = nb >= 64 ? 0xFFFFFFFFu : (nb > 32 ? ((1u << (nb - 32)) - 1u) : 0u);
+    const uint32_t m2 = nb > 64 ? ((1u << (nb - 64)) - 1u) : 0u;
+    uint32_t h0 = 0u, h1 = 0u, h2 = 0u;
+    uint32_t cur = 0u;
+    auto step = [&](int pos) {                                                 // append the digit at `pos` (pos is the same in every lane)
+        if ((pos & 15) == 0) cur = row[pos >> 4];
+        const uint32_t d = __builtin_amdgcn_ubfe(cur, (uint32_t) ((pos & 15) << 1), 2u);
+        const uint32_t dm = __builtin_amdgcn_ubfe(pp, d << 1, 2u);
+        h2 = __funnelshift_l(h1, h2, 2) & m2;
+        h1 = __funnelshift_l(h0, h1, 2) & m1;
+        h0 = ((h0 << 2) | dm) & m0;
+    };
+    for (int q = 0; q < k; q++) step(q);
+    const int il = (len - k + 1 + intervals - 1) / intervals;
+    uint32_t b0 = h0, b1 = h1, b2 = h2;
+    int best_p = 0, cnt = 0, next = il;
+    auto emit = [&]() {
+        const u128 v = ((u128) b2 << 64) | ((u128) b1 << 32) | (u128) b0;
+        hash_out[cnt] = (T != nullptr && k <= 35) ? mod_hash_u70(v, T) : mod_hash_u128(v);
+        ind_out[cnt] = best_p; cnt++;
+    };
+    for (int p = 1; p + k <= wave_max_len; p++) {
+        step(p + k - 1);
+        if (p + k <= len) {
+            const unsigned long long hl = ((unsigned long long) h1 << 32) | h0, bl = ((unsigned long long) b1 << 32) | b0;
+            if (p == next) { emit(); next += il; b0 = h0; b1 = h1; b2 = h2; best_p = p; }
+            else if (h2 < b2 || (h2 == b2 && hl < bl)) { b0 = h0; b1 = h1; b2 = h2; best_p = p; }
+        }
+    }
+    emit();
+    return cnt;
+}
+
 template <bool STAGED>
 __global__ void __launch_bounds__(256) k_pkb_kmers(NodesDev nd, PkbCfg c, int4 prio4, const uint32_t *__restrict__ tips, const uint32_t *__restrict__ koff,
                                                     uint32_t n_tips, int sort_bits /* 1 .. 63 */, unsigned long long *__restrict__ keys,
-                                                    unsigned long long *__restrict__ vals, const PkbTipRec *__restrict__ rec) {
+                                                    unsigned long long *__restrict__ vals, const PkbTipRec *__restrict__ rec, int wide /* 1: the 128-bit walk */) {
     __shared__ uint64_t T[64];
     __shared__ uint32_t srow[STAGED ? 256 : 1][PKB_ROW_WORDS + 1];
     mod_table_fill(T);
@@ -328,13 +370,23 @@ __global__ void __launch_bounds__(256) k_pkb_kmers(NodesDev nd, PkbCfg c, int4 p
     }
     __syncthreads();
     const uint32_t t = base_t + threadIdx.x;
-    if (t >= n_tips) return;
     const int prio[4] = {prio4.x, prio4.y, prio4.z, prio4.w};
     uint64_t h[PKB_MAX_INTERVALS]; int32_t p[PKB_MAX_INTERVALS];
-    const uint32_t i = tips[t];
-    const int len = nd.len[i];
-    const uint32_t *row = STAGED ? srow[threadIdx.x] : nd.words + (size_t) i * nd.stride;
-    const int cnt = li_kmers(row, len, c.li_k, c.li_intervals, prio, h, p, T);
+    const uint32_t i = t < n_tips ? tips[t] : 0u;
+    const int len = t < n_tips ? nd.len[i] : 0;
+    int cnt;
+    if (STAGED && !wide && c.li_k <= 48) {
+        int wl = len;                                                          // the longest read of the wave: every lane walks that far
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) wl = max(wl, __shfl_xor(wl, o));
+        cnt = li_kmers96(srow[threadIdx.x], len, c.li_k, c.li_intervals, (uint32_t) prio[0] | ((uint32_t) prio[1] << 2) | ((uint32_t) prio[2] << 4) | ((uint32_t) prio[3] << 6),
+                         wl, h, p, T);
+        if (t >= n_tips) return;
+    } else {
+        if (t >= n_tips) return;
+        const uint32_t *row = STAGED ? srow[threadIdx.x] : nd.words + (size_t) i * nd.stride;
+        cnt = li_kmers(row, len, c.li_k, c.li_intervals, prio, h, p, T);
+    }
     const uint32_t base = koff[t];
     for (int j = 0; j < cnt; j++) {
         const unsigned long long m = h[j] * PKB_KEY_MIX;
@@ -1259,12 +1311,12 @@ void launch_pkb_tip_list(const NodesDev &nd, const PkbCfg &c, const uint32_t *fl
 }
 
 void launch_pkb_kmers(const NodesDev &nd, const PkbCfg &c, const int32_t prio[4], const uint32_t *tips, const uint32_t *koff, uint32_t n_tips, int sort_bits,
-                      unsigned long long *keys, unsigned long long *vals, const void *tiprec, hipStream_t s) {
+                      unsigned long long *keys, unsigned long long *vals, const void *tiprec, int wide, hipStream_t s) {
     if (n_tips == 0) return;
     const int4 pr = make_int4(prio[0], prio[1], prio[2], prio[3]);
     const PkbTipRec *rec = (const PkbTipRec *) tiprec;
-    if (nd.stride <= PKB_ROW_WORDS) hipLaunchKernelGGL(k_pkb_kmers<true>, dim3((n_tips + 255) / 256), dim3(256), 0, s, nd, c, pr, tips, koff, n_tips, sort_bits, keys, vals, rec);
-    else hipLaunchKernelGGL(k_pkb_kmers<false>, dim3((n_tips + 255) / 256), dim3(256), 0, s, nd, c, pr, tips, koff, n_tips, sort_bits, keys, vals, rec);
+    if (nd.stride <= PKB_ROW_WORDS) hipLaunchKernelGGL(k_pkb_kmers<true>, dim3((n_tips + 255) / 256), dim3(256), 0, s, nd, c, pr, tips, koff, n_tips, sort_bits, keys, vals, rec, wide);
+    else hipLaunchKernelGGL(k_pkb_kmers<false>, dim3((n_tips + 255) / 256), dim3(256), 0, s, nd, c, pr, tips, koff, n_tips, sort_bits, keys, vals, rec, wide);
 }
 
 size_t pkb_tiprec_bytes(uint32_t n_tips) { return ((size_t) n_tips + 1) * sizeof(PkbTipRec); }

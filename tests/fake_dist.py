@@ -3,7 +3,6 @@ sharded driver + the real HIP backend can run as N 'ranks' inside ONE process on
 Every rank is a thread holding a FakeDist(rank); collectives rendezvous on a shared barrier."""
 import queue
 import threading
-from collections import defaultdict
 
 
 class _World:
@@ -11,7 +10,10 @@ class _World:
         self.n = n
         self.barrier = threading.Barrier(n)
         self.slots = [None] * n
-        self.mail = defaultdict(queue.Queue)        # (src, dst) -> tensors in send order (point-to-point transfers)
+        # (src, dst) -> tensors in send order (point-to-point transfers).  Every queue exists before a rank thread runs: a defaultdict made
+        # them on first touch, and a sender and a receiver touching a missing key at the same moment could each get a queue of their own -- the
+        # message went into one, the receiver waited on the other until its timeout (seen once in a full-suite run, round 5)
+        self.mail = {(s, d): queue.Queue() for s in range(n) for d in range(n)}
 
 
 class ReduceOp:

@@ -183,7 +183,7 @@ def test_supplement_groups_of_8_to_16_four_per_wave(eng, G, n, seed):
     c[flip] = (3 - c[flip])[:, ::-1]
     s_new = _supplement_vs_oracle(eng, c.astype(np.uint8))
     assert s_new["group_hist"][0][4] > 20, s_new["group_hist"]               # there are groups of 8 .. 15
-    for legacy in (1, 6, 24):                                                  # bit 0: a wave per group of 8 .. 16; bits 1, 2: the library's k-mer sort on 32 bits, the head list in three kernels; bits 3, 4: replay inside the pair kernel, the library's unique after the merge
+    for legacy in (1, 6, 56):                                                  # bit 0: a wave per group of 8 .. 16; bits 1, 2: the library's k-mer sort on 32 bits, the head list in three kernels; bits 3, 4, 5: replay inside the pair kernel, the library's unique after the merge, the 128-bit k-mer walk
         eng.set_option("pkb_legacy", legacy)
         try:
             s_old = _supplement_vs_oracle(eng, c.astype(np.uint8))
@@ -191,6 +191,43 @@ def test_supplement_groups_of_8_to_16_four_per_wave(eng, G, n, seed):
             eng.set_option("pkb_legacy", 0)
         for k in ("kmers", "groups", "can_align_calls", "edges_after", "group_hist", "max_group"):
             assert s_new[k] == s_old[k], (legacy, k)
+
+
+def test_supplement_reads_of_several_lengths(eng):
+    """reads of 110 .. 150 nt in one set: the k-mer walk of a wave runs to its longest read with every lane stopping at its own end, the interval
+    borders differ from read to read (Read::getLIKmers, src/DataStructures/Read.cpp:145-226); against the oracle, and the 96-bit walk against the 128-bit one"""
+    rng = np.random.default_rng(97)
+    G, n = 5000, 2500
+    g = rng.integers(0, 4, G, dtype=np.uint8)
+    L = rng.integers(110, 151, n)
+    st = rng.integers(0, G - 150 + 1, n)
+    rows, lens = [], []
+    for k in range(n):
+        r = g[st[k]:st[k] + L[k]].copy()
+        m = rng.random(len(r)) < 0.02
+        r[m] = (r[m] + rng.integers(1, 4, int(m.sum()))) & 3
+        for x in ((3 - r)[::-1], r):                                          # the pair (reverse complement, read): nodes 2 k, 2 k + 1
+            row = np.zeros(150, np.uint8); row[:len(x)] = x
+            rows.append(row); lens.append(len(x))
+    codes, lens = np.stack(rows), np.array(lens, dtype=np.int32)
+    words = alga_amd.pack_reads(codes, lens)
+    lo, rs = alga_amd.derive_params(float(lens.mean()))
+    pre = eng.prefsuf_host(words, lens, lo, rs)
+    kb = min(2 * lo // 3, 60)
+    op = O.pkb_params(float(lens.mean()), error_rate_percent=2)
+    p = eng.pkb_params(float(lens.mean()), 0.02, kb)
+    want, _ = O.supplement(words, lens, pre, op, kb, flags=3)
+    got = eng.pkb_supplement_host(words, lens, pre, p)
+    s_new = eng.pkb_last_stats()
+    assert len(want) > len(pre)
+    assert got.shape == want.shape and (got == want).all()
+    eng.set_option("pkb_legacy", 32)
+    try:
+        old = eng.pkb_supplement_host(words, lens, pre, p)
+        s_old = eng.pkb_last_stats()
+    finally:
+        eng.set_option("pkb_legacy", 0)
+    assert (old == got).all() and s_old["kmers"] == s_new["kmers"] and s_old["groups"] == s_new["groups"]
 
 
 def test_supplement_rejects_offsets_it_cannot_represent(eng):
