@@ -161,7 +161,7 @@ int alga_shard_join_device(alga_engine *e, const alga_nodes *nodes, const uint32
     launch_shard_desc_split(d_desc_in, n_desc, e->sh.bucket_base << shift, (uint32_t *) e->sh_dkey[0].p, (unsigned long long *) e->sh_dval[0].p, s);
     if ((rc = alga_check_launch(e, "k_shard_desc_split"))) return rc;
     HIP_TRY(e, sort_desc(e->sort_temp.p, sort_desc_temp_bytes(n_desc), (const uint32_t *) e->sh_dkey[0].p, (uint32_t *) e->sh_dkey[1].p, (const unsigned long long *) e->sh_dval[0].p,
-                         (unsigned long long *) e->sh_dval[1].p, n_desc, shift, std::min(32, shift + range_bits), s));
+                         (unsigned long long *) e->sh_dval[1].p, n_desc, shift, std::min(32, shift + range_bits), s, e->opt_own_sort != 0));
     // the groups (one per bucket) of the sorted array
     if ((rc = alga_ensure(e, e->sh_gflag, (n_desc + 2) * sizeof(uint32_t)))) return rc;
     if ((rc = alga_ensure(e, e->sh_gpos, (n_desc + 2) * sizeof(uint32_t)))) return rc;

@@ -101,6 +101,8 @@ size_t     rsort_u64_pairs_temp_bytes(uint64_t n);
 // radix_sort.hip: stable sort of (u64 key, u64 value) records on the key bits [0, bits), bits <= 50 (the supplement's k-mer entries)
 hipError_t rsort_u64_pairs(void *temp, size_t temp_bytes, const unsigned long long *keys_in, unsigned long long *keys_out, const unsigned long long *vals_in,
                            unsigned long long *vals_out, uint64_t n, int bits, hipStream_t s);
+hipError_t rsort_u32_u64(void *temp, size_t temp_bytes, const uint32_t *keys_in, uint32_t *keys_out, const unsigned long long *vals_in, unsigned long long *vals_out,
+                         uint64_t n, int begin_bit, int end_bit, hipStream_t s);          // temp: rsort_u64_pairs_temp_bytes(n)
 size_t     sort_u64_pairs_temp_bytes(uint64_t n, int bits);
 hipError_t sort_u64_pairs(void *temp, size_t temp_bytes, const unsigned long long *keys_in, unsigned long long *keys_out,
                           const unsigned long long *vals_in, unsigned long long *vals_out, uint64_t n, int bits, hipStream_t s);

@@ -22,7 +22,7 @@ void launch_shard_export_flagged(const NodesDev &nd, const PrefSufCfg &cfg, cons
 void launch_shard_desc_split(const uint32_t *in, uint64_t n, uint32_t key_base /* first key of the rank's bucket range */, uint32_t *dkey, unsigned long long *dval, hipStream_t s);
 size_t     sort_desc_temp_bytes(uint64_t n);
 hipError_t sort_desc(void *temp, size_t temp_bytes, const uint32_t *keys_in, uint32_t *keys_out, const unsigned long long *vals_in, unsigned long long *vals_out, uint64_t n,
-                     int begin_bit, int end_bit, hipStream_t s);
+                     int begin_bit, int end_bit, hipStream_t s, bool own_sort = true);
 uint64_t shard_join_record_slack(int n_cu);
 void launch_shard_groups(const uint32_t *dkey, uint64_t n_desc, int shift, uint32_t *flag, uint32_t *pos, uint32_t *gstart, uint64_t *scan_scratch, hipStream_t s);
 void launch_shard_join(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterCfg &cc, int eq, int uniform_len, const void *store, const void *dir, uint32_t bucket_base,

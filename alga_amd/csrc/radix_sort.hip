@@ -289,15 +289,16 @@ __global__ void __launch_bounds__(THREADS) k_rs_scatter(const uint32_t *__restri
 constexpr int RS_IPT64 = 8;
 constexpr int RS_TILE64 = RS_THREADS * RS_IPT64;
 
-__global__ void __launch_bounds__(RS_THREADS) k_rs_hist64(const unsigned long long *__restrict__ keys, uint64_t n, int shift, int nbits, uint32_t n_tiles,
+template <typename K>
+__global__ void __launch_bounds__(RS_THREADS) k_rs_hist64(const K *__restrict__ keys, uint64_t n, int shift, int nbits, uint32_t n_tiles,
                                                           uint32_t tiles_per_chunk, uint32_t *__restrict__ tile_pref, uint32_t *__restrict__ chunk_tot) {
     __shared__ uint32_t h[RS_MAX_DIGITS], run[RS_MAX_DIGITS];
     const uint32_t D = 1u << nbits, mask = D - 1u;
     const uint32_t c = blockIdx.x, t0 = c * tiles_per_chunk, t1 = min(t0 + tiles_per_chunk, n_tiles);
     for (uint32_t d = threadIdx.x; d < D; d += RS_THREADS) { run[d] = 0; h[d] = 0; }
     __syncthreads();
-    unsigned long long k[RS_IPT64], kn[RS_IPT64];
-    auto fetch = [&](uint32_t t, unsigned long long *dst) {
+    K k[RS_IPT64], kn[RS_IPT64];
+    auto fetch = [&](uint32_t t, K *dst) {
         const uint64_t base = (uint64_t) t * RS_TILE64;
         if (t < t1 && base + RS_TILE64 <= n) {
 #pragma unroll
@@ -331,9 +332,9 @@ __global__ void __launch_bounds__(RS_THREADS) k_rs_hist64(const unsigned long lo
     for (uint32_t d = threadIdx.x; d < D; d += RS_THREADS) chunk_tot[(size_t) c * D + d] = run[d];
 }
 
-template <int NB>
-__global__ void __launch_bounds__(RS_THREADS) k_rs_scatter64(const unsigned long long *__restrict__ kin, const unsigned long long *__restrict__ vin,
-                                                             unsigned long long *__restrict__ kout, unsigned long long *__restrict__ vout, uint64_t n, int shift,
+template <typename K, int NB>
+__global__ void __launch_bounds__(RS_THREADS) k_rs_scatter64(const K *__restrict__ kin, const unsigned long long *__restrict__ vin,
+                                                             K *__restrict__ kout, unsigned long long *__restrict__ vout, uint64_t n, int shift,
                                                              int nbits, uint32_t n_tiles, uint32_t tiles_per_chunk, const uint32_t *__restrict__ tile_pref,
                                                              const uint32_t *__restrict__ chunk_base, const uint32_t *__restrict__ digit_base) {
     constexpr int DMAX = 1 << NB, WAVES = RS_THREADS / 64;
@@ -355,12 +356,13 @@ __global__ void __launch_bounds__(RS_THREADS) k_rs_scatter64(const unsigned long
     }
     const uint64_t tbase = (uint64_t) t * RS_TILE64;
     const uint32_t nv = (uint32_t) min((uint64_t) RS_TILE64, n - tbase);
-    unsigned long long k[RS_IPT64], v[RS_IPT64];
+    K k[RS_IPT64];
+    unsigned long long v[RS_IPT64];
 #pragma unroll
     for (int j = 0; j < RS_IPT64; j++) {
         const uint32_t idx = w * (64u * RS_IPT64) + (uint32_t) j * 64u + lane;
         const bool ok = idx < nv;
-        k[j] = ok ? kin[tbase + idx] : ~0ull;               // padding of the last tile: the largest digit, behind every item of the tile
+        k[j] = ok ? kin[tbase + idx] : (K) ~(K) 0;          // padding of the last tile: the largest digit, behind every item of the tile
         v[j] = ok ? vin[tbase + idx] : 0ull;
     }
     __syncthreads();
@@ -405,14 +407,14 @@ __global__ void __launch_bounds__(RS_THREADS) k_rs_scatter64(const unsigned long
     for (int j = 0; j < RS_IPT64; j++) {
         const uint32_t d = (uint32_t) (k[j] >> shift) & mask;
         pos[j] = (unsigned short) (pos[j] + cnt[w][d]);
-        stage[pos[j]] = k[j];
+        stage[pos[j]] = (unsigned long long) k[j];
     }
     __syncthreads();
     uint32_t ga[RS_IPT64];
 #pragma unroll
     for (int j = 0; j < RS_IPT64; j++) {
         const uint32_t i = (uint32_t) j * RS_THREADS + threadIdx.x;
-        const unsigned long long key = stage[i];
+        const K key = (K) stage[i];
         ga[j] = goff[(uint32_t) (key >> shift) & mask] + i;
         if (i < nv) kout[ga[j]] = key;
     }
@@ -507,13 +509,48 @@ hipError_t rsort_u64_pairs(void *temp, size_t temp_bytes, const unsigned long lo
         const bool to_out = ((p.passes - 1 - i) & 1) == 0;
         unsigned long long *ko = to_out ? keys_out : tk, *vo = to_out ? vals_out : tv;
         const int nb = p.bits[i], sh = p.shift[i];
-        hipLaunchKernelGGL(k_rs_hist64, dim3(p.chunks), dim3(RS_THREADS), 0, s, ki, n, sh, nb, p.n_tiles, p.tiles_per_chunk, tile_pref, chunk_tot);
+        hipLaunchKernelGGL((k_rs_hist64<unsigned long long>), dim3(p.chunks), dim3(RS_THREADS), 0, s, ki, n, sh, nb, p.n_tiles, p.tiles_per_chunk, tile_pref, chunk_tot);
         hipLaunchKernelGGL(k_rs_scan_chunks, dim3(((1u << nb) + 63u) / 64u), dim3(RS_THREADS), 0, s, chunk_tot, p.chunks, nb, digit_tot);
         hipLaunchKernelGGL(k_rs_scan_digits, dim3(1), dim3(RS_THREADS), 0, s, (const uint32_t *) digit_tot, nb, digit_base);
         const dim3 grid(8u * ((p.n_tiles + 7u) / 8u));
-        if (nb <= 8) hipLaunchKernelGGL((k_rs_scatter64<8>), grid, dim3(RS_THREADS), 0, s, ki, vi, ko, vo, n, sh, nb, p.n_tiles, p.tiles_per_chunk,
+        if (nb <= 8) hipLaunchKernelGGL((k_rs_scatter64<unsigned long long, 8>), grid, dim3(RS_THREADS), 0, s, ki, vi, ko, vo, n, sh, nb, p.n_tiles, p.tiles_per_chunk,
                                         (const uint32_t *) tile_pref, (const uint32_t *) chunk_tot, (const uint32_t *) digit_base);
-        else hipLaunchKernelGGL((k_rs_scatter64<10>), grid, dim3(RS_THREADS), 0, s, ki, vi, ko, vo, n, sh, nb, p.n_tiles, p.tiles_per_chunk,
+        else hipLaunchKernelGGL((k_rs_scatter64<unsigned long long, 10>), grid, dim3(RS_THREADS), 0, s, ki, vi, ko, vo, n, sh, nb, p.n_tiles, p.tiles_per_chunk,
+                                (const uint32_t *) tile_pref, (const uint32_t *) chunk_tot, (const uint32_t *) digit_base);
+        ki = ko; vi = vo;
+    }
+    return hipGetLastError();
+}
+
+// stable sort of (u32 key, u64 value) records on the key bits [begin_bit, end_bit): the run descriptors of the bucket-sharded N-GPU build
+// (prefsuf_shard.hip) and whatever else carries eight bytes behind a 32-bit key.  temp: rsort_u64_pairs_temp_bytes(n)
+hipError_t rsort_u32_u64(void *temp, size_t temp_bytes, const uint32_t *keys_in, uint32_t *keys_out, const unsigned long long *vals_in, unsigned long long *vals_out,
+                         uint64_t n, int begin_bit, int end_bit, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    if (begin_bit < 0 || end_bit > 32 || end_bit <= begin_bit || n >= (1ull << 32) - RS_TILE_MAX) return hipErrorInvalidValue;
+    if (temp_bytes < rsort_u64_pairs_temp_bytes(n)) return hipErrorInvalidValue;
+    const RsPlan p = rs_plan(n, begin_bit, end_bit, 2);
+    char *at = (char *) temp;
+    uint32_t *tk = (uint32_t *) at; at += rs_align((size_t) (n + 4) * 8);
+    unsigned long long *tv = (unsigned long long *) at; at += rs_align((size_t) (n + 4) * 8);
+    uint32_t *tile_pref = (uint32_t *) at; at += rs_align((size_t) p.n_tiles * RS_MAX_DIGITS * 4);
+    uint32_t *chunk_tot = (uint32_t *) at; at += rs_align((size_t) RS_CHUNKS * RS_MAX_DIGITS * 4);
+    uint32_t *digit_tot = (uint32_t *) at; at += rs_align(RS_MAX_DIGITS * 4);
+    uint32_t *digit_base = (uint32_t *) at;
+    const uint32_t *ki = keys_in;
+    const unsigned long long *vi = vals_in;
+    for (int i = 0; i < p.passes; i++) {
+        const bool to_out = ((p.passes - 1 - i) & 1) == 0;
+        uint32_t *ko = to_out ? keys_out : tk;
+        unsigned long long *vo = to_out ? vals_out : tv;
+        const int nb = p.bits[i], sh = p.shift[i];
+        hipLaunchKernelGGL((k_rs_hist64<uint32_t>), dim3(p.chunks), dim3(RS_THREADS), 0, s, ki, n, sh, nb, p.n_tiles, p.tiles_per_chunk, tile_pref, chunk_tot);
+        hipLaunchKernelGGL(k_rs_scan_chunks, dim3(((1u << nb) + 63u) / 64u), dim3(RS_THREADS), 0, s, chunk_tot, p.chunks, nb, digit_tot);
+        hipLaunchKernelGGL(k_rs_scan_digits, dim3(1), dim3(RS_THREADS), 0, s, (const uint32_t *) digit_tot, nb, digit_base);
+        const dim3 grid(8u * ((p.n_tiles + 7u) / 8u));
+        if (nb <= 8) hipLaunchKernelGGL((k_rs_scatter64<uint32_t, 8>), grid, dim3(RS_THREADS), 0, s, ki, vi, ko, vo, n, sh, nb, p.n_tiles, p.tiles_per_chunk,
+                                        (const uint32_t *) tile_pref, (const uint32_t *) chunk_tot, (const uint32_t *) digit_base);
+        else hipLaunchKernelGGL((k_rs_scatter64<uint32_t, 10>), grid, dim3(RS_THREADS), 0, s, ki, vi, ko, vo, n, sh, nb, p.n_tiles, p.tiles_per_chunk,
                                 (const uint32_t *) tile_pref, (const uint32_t *) chunk_tot, (const uint32_t *) digit_base);
         ki = ko; vi = vo;
     }

@@ -97,11 +97,14 @@ hipError_t sort_u32_pairs(void *temp, size_t temp_bytes, const uint32_t *keys_in
 
 // run descriptors of the bucket-sharded N-GPU build (prefsuf_shard.hip): (u32 cluster key, u64 {source id, q | p0 | p1}) by bucket =
 // the key bits [begin_bit, end_bit) (the bits above are the same for every bucket of one rank's range)
-size_t sort_desc_temp_bytes(uint64_t n) { return sort_records_temp_bytes(n, 32); }
+size_t sort_desc_temp_bytes(uint64_t n) { return std::max(sort_records_temp_bytes(n, 32), rsort_u64_pairs_temp_bytes(n)); }
 hipError_t sort_desc(void *temp, size_t temp_bytes, const uint32_t *keys_in, uint32_t *keys_out, const unsigned long long *vals_in, unsigned long long *vals_out, uint64_t n,
-                     int begin_bit, int end_bit, hipStream_t s) {
+                     int begin_bit, int end_bit, hipStream_t s, bool own_sort) {
     if (n == 0) return hipSuccess;
-    if (n < (1ull << 22) || begin_bit < 0 || end_bit > 32 || end_bit <= begin_bit) { begin_bit = 0; end_bit = 32; }      // (small inputs: see sort_u32_pairs)
+    if (begin_bit < 0 || end_bit > 32 || end_bit <= begin_bit) { begin_bit = 0; end_bit = 32; }
+    // round 5: the engine's own radix sort (radix_sort.hip: 12-byte records through the 16-byte kernels); the library's on request (option own_sort = 0)
+    if (own_sort) return rsort_u32_u64(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, n, begin_bit, end_bit, s);
+    if (n < (1ull << 22)) { begin_bit = 0; end_bit = 32; }      // (small inputs: see sort_u32_pairs)
     return rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t) n, (unsigned) begin_bit, (unsigned) end_bit, s);
 }
 
