@@ -136,7 +136,9 @@ int pkb_begin(alga_engine *e, const alga_nodes *dn, const alga_pkb_params *p, co
     launch_pkb_tip_flags(nd, c, (const uint8_t *) e->pk_mask.p, (uint32_t *) e->pk_flag.p, s);
     if ((rc = alga_check_launch(e, "k_pkb_tip_flags"))) return rc;
     launch_exclusive_scan((const uint32_t *) e->pk_flag.p, (uint64_t) n, (uint32_t *) e->pk_pos.p, (uint64_t *) e->scan_scratch.p, s);
-    launch_pkb_tip_list(nd, c, (const uint32_t *) e->pk_flag.p, (const uint32_t *) e->pk_pos.p, (uint32_t *) e->pk_tips.p, (uint32_t *) e->pk_gsz.p, cnt + 12, s);
+    if ((rc = alga_ensure(e, e->pk_tipidx, (size_t) (n + 2) * sizeof(uint32_t)))) return rc;
+    launch_pkb_tip_list(nd, c, (const uint32_t *) e->pk_flag.p, (const uint32_t *) e->pk_pos.p, (uint32_t *) e->pk_tips.p, (uint32_t *) e->pk_gsz.p, cnt + 12,
+                        (uint32_t *) e->pk_tipidx.p, s);
     if ((rc = alga_check_launch(e, "k_pkb_tip_list"))) return rc;
     HIP_TRY(e, hipMemcpyAsync(e->h_counters, (uint64_t *) e->scan_scratch.p + scan_total_index((uint64_t) n), sizeof(uint64_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(e, hipMemcpyAsync(e->h_counters + 1, cnt + 12, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
@@ -191,8 +193,11 @@ int pkb_round(alga_engine *e, hipStream_t s, const unsigned long long **d_add, u
         if ((rc = alga_ensure(e, *b, (nk + 2) * sizeof(uint32_t)))) return rc;
     if ((rc = alga_ensure(e, e->sort_temp, temp))) return rc;
     if ((rc = alga_ensure(e, e->scan_scratch, scan_scratch_bytes(nk)))) return rc;
-    launch_pkb_tiprec_snap((const uint32_t *) e->pk_tips.p, n_tips, (const uint32_t *) e->pk_rowptr.p, (const unsigned long long *) e->pk_g[cur].p, e->pk_tiprec.p, s);
-    if ((rc = alga_check_launch(e, "k_pkb_tiprec_snap"))) return rc;
+    // the records' snapshot halves: all of them before the first round (or every round, option pkb_legacy bit 6); later the merge refreshes the rows it changed
+    if (round == 0 || (e->opt_pkb_legacy & 64)) {
+        launch_pkb_tiprec_snap((const uint32_t *) e->pk_tips.p, n_tips, (const uint32_t *) e->pk_rowptr.p, (const unsigned long long *) e->pk_g[cur].p, e->pk_tiprec.p, s);
+        if ((rc = alga_check_launch(e, "k_pkb_tiprec_snap"))) return rc;
+    }
     launch_pkb_kmers(nd, c, st.prio, (const uint32_t *) e->pk_tips.p, (const uint32_t *) e->pk_koff.p, n_tips, sort_bits, (unsigned long long *) e->pk_keys.p,
                      (unsigned long long *) e->pk_vals.p, e->pk_tiprec.p, (e->opt_pkb_legacy & 32) != 0, s);
     if ((rc = alga_check_launch(e, "k_pkb_kmers"))) return rc;
@@ -307,9 +312,8 @@ int pkb_merge(alga_engine *e, const unsigned long long *d_all, uint64_t A, hipSt
             launch_pkb_src_keys(d_all, A, 32 - nb, (uint32_t *) e->pk_heads.p, s);
             HIP_TRY(e, rsort_u32_pairs(e->sort_temp.p, std::max(t2, t3), (const uint32_t *) e->pk_heads.p, (uint32_t *) e->pk_heads2.p, nullptr, (uint32_t *) e->pk_hsz.p, A,
                                        32 - nb, s));
-            launch_pkb_gather_keys(d_all, (const uint32_t *) e->pk_hsz.p, A, (unsigned long long *) e->pk_addk2.p, s);
-            launch_pkb_sort_src_runs((unsigned long long *) e->pk_addk2.p, A, s);
-            if ((rc = alga_check_launch(e, "k_pkb_sort_src_runs"))) return rc;
+            launch_pkb_gather_sorted_runs(d_all, (const uint32_t *) e->pk_heads2.p, (const uint32_t *) e->pk_hsz.p, A, (unsigned long long *) e->pk_addk2.p, s);
+            if ((rc = alga_check_launch(e, "k_pkb_gather_sorted_runs"))) return rc;
         } else HIP_TRY(e, sort_u64_keys_bits(e->sort_temp.p, t2, d_all, (unsigned long long *) e->pk_addk2.p, A, st.key_bits, s));
         HIP_TRY(e, merge_u64(e->sort_temp.p, t2, (const unsigned long long *) e->pk_g[cur].p, E, (const unsigned long long *) e->pk_addk2.p, A,
                              (unsigned long long *) e->pk_merged.p, s));
@@ -337,6 +341,12 @@ int pkb_merge(alga_engine *e, const unsigned long long *d_all, uint64_t A, hipSt
             st.E = e->h_counters[0];
             st.cur = nxt;
         }
+    }
+    if (A && st.n_tips && !(e->opt_pkb_legacy & 64)) {
+        // the tip records of the sources that got an edge (or a smaller offset): their snapshot halves from the new graph
+        launch_pkb_tiprec_snap_srcs((const unsigned long long *) e->pk_addk2.p, A, (const uint32_t *) e->pk_tipidx.p, (const uint32_t *) e->pk_rowptr.p,
+                                    (const unsigned long long *) e->pk_g[st.cur].p, e->pk_tiprec.p, s);
+        if ((rc = alga_check_launch(e, "k_pkb_tiprec_snap_srcs"))) return rc;
     }
     e->pkb_stats.edges_after[st.round] = st.E;
     std::rotate(st.prio, st.prio + 1, st.prio + 4);                          // GraphCreatorLI.cpp:26

@@ -26,6 +26,7 @@ void launch_pkb_rowptr(const unsigned long long *keys, uint64_t E, int32_t n, ui
 void launch_pkb_src_keys(const unsigned long long *keys, uint64_t n, int shift, uint32_t *k32, hipStream_t s);
 void launch_pkb_gather_keys(const unsigned long long *keys, const uint32_t *idx, uint64_t n, unsigned long long *out, hipStream_t s);
 void launch_pkb_sort_src_runs(unsigned long long *keys, uint64_t n, hipStream_t s);
+void launch_pkb_gather_sorted_runs(const unsigned long long *keys, const uint32_t *k32_sorted, const uint32_t *idx, uint64_t n, unsigned long long *out, hipStream_t s);   // the two in one
 // first key per (src, dst) of a sorted key list: flags, then (after an exclusive scan of them into pos) the kept keys and the row pointers of the result
 void launch_pkb_unique_flags(const unsigned long long *in, uint64_t n, uint32_t *flag, hipStream_t s);
 void launch_pkb_unique_scatter(const unsigned long long *in, uint64_t n, const uint32_t *flag, const uint32_t *pos, int32_t n_nodes, unsigned long long *out,
@@ -34,12 +35,14 @@ void launch_pkb_keys_to_edges(const unsigned long long *keys, uint64_t E, alga_e
 void launch_pkb_masks(int32_t n, const uint32_t *rowptr, const unsigned long long *keys, uint64_t m, uint32_t *indeg, uint8_t *mask, hipStream_t s);
 void launch_pkb_tip_flags(const NodesDev &nd, const PkbCfg &c, const uint8_t *mask, uint32_t *flag, hipStream_t s);
 void launch_pkb_tip_list(const NodesDev &nd, const PkbCfg &c, const uint32_t *flag, const uint32_t *pos, uint32_t *tips, uint32_t *kcount,
-                         unsigned long long *max_len, hipStream_t s);
+                         unsigned long long *max_len, uint32_t *tipidx /* node -> place in tips[], ~0 if none */, hipStream_t s);
 void launch_pkb_kmers(const NodesDev &nd, const PkbCfg &c, const int32_t prio[4], const uint32_t *tips, const uint32_t *koff, uint32_t n_tips, int sort_bits,
                       unsigned long long *keys, unsigned long long *vals, const void *tiprec, int wide /* 1: round 4's 128-bit rolling value */, hipStream_t s);
 // tip records (pkb_kernels.hip: PkbTipRec): row + id + first snapshot keys of every node that takes part, 128 bytes each
 size_t pkb_tiprec_bytes(uint32_t n_tips);
 void launch_pkb_tiprec_rows(const NodesDev &nd, const uint32_t *tips, uint32_t n_tips, void *tiprec, hipStream_t s);
+void launch_pkb_tiprec_snap_srcs(const unsigned long long *sorted_adds, uint64_t n_adds, const uint32_t *tipidx, const uint32_t *rowptr, const unsigned long long *gkeys,
+                                 void *tiprec, hipStream_t s);
 void launch_pkb_tiprec_snap(const uint32_t *tips, uint32_t n_tips, const uint32_t *rowptr, const unsigned long long *gkeys, void *tiprec, hipStream_t s);
 void launch_pkb_fix_runs(unsigned long long *keys, unsigned long long *vals, uint64_t n, int bits, uint32_t *list, uint32_t list_cap, unsigned long long *counter,
                          hipStream_t s);

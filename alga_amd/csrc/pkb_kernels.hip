@@ -190,6 +190,37 @@ __global__ void __launch_bounds__(256) k_pkb_gather_keys(const unsigned long lon
     for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) out[i] = keys[idx[i]];
 }
 
+// the two kernels above in one: the thread at the first position of a src run (read off the SORTED 32-bit keys) fetches the run's keys by their
+// positions, orders them in registers (runs of up to eight keys: all but a handful) and writes them where they belong
+__global__ void __launch_bounds__(256) k_pkb_gather_sorted_runs(const unsigned long long *__restrict__ keys, const uint32_t *__restrict__ k32s, const uint32_t *__restrict__ idx,
+                                                                 uint64_t n, unsigned long long *__restrict__ out) {
+    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) {
+        const uint32_t ks = k32s[i];
+        if (i > 0 && k32s[i - 1] == ks) continue;                                // not the first key of its run
+        uint64_t e = i + 1;
+        while (e < n && k32s[e] == ks) e++;
+        const int L = (int) min(e - i, (uint64_t) 9);
+        if (L <= 8) {
+            unsigned long long k[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) k[q] = q < L ? keys[idx[i + q]] : ~0ull;
+#pragma unroll
+            for (int a = 0; a < 8; a++)                                          // odd-even transposition: eight keys, sorted after eight rounds
+#pragma unroll
+                for (int b = (a & 1); b + 1 < 8; b += 2) { const unsigned long long lo = min(k[b], k[b + 1]), hi = max(k[b], k[b + 1]); k[b] = lo; k[b + 1] = hi; }
+#pragma unroll
+            for (int q = 0; q < 8; q++) if (q < L) out[i + q] = k[q];
+        } else {
+            for (uint64_t a = i; a < e; a++) {                                    // a long run: insertion sort while gathering (nobody else touches out[i .. e))
+                const unsigned long long kx = keys[idx[a]];
+                uint64_t b = a;
+                while (b > i && out[b - 1] > kx) { out[b] = out[b - 1]; b--; }
+                out[b] = kx;
+            }
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) k_pkb_sort_src_runs(unsigned long long *__restrict__ keys, uint64_t n) {
     for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) {
         const int src = pkb_key_src(keys[i]);
@@ -261,9 +292,11 @@ __global__ void __launch_bounds__(256) k_pkb_tip_flags(NodesDev nd, PkbCfg c, co
 // tips[] and, per tip, the number of LI k-mers it yields -- a function of its length alone (the intervals that hold a start
 // position), the same in every round: the k-mer kernel writes at fixed offsets, no append counter.  max_len: longest tip.
 __global__ void __launch_bounds__(256) k_pkb_tip_list(NodesDev nd, PkbCfg c, const uint32_t *__restrict__ flag, const uint32_t *__restrict__ pos,
-                                                       uint32_t *__restrict__ tips, uint32_t *__restrict__ kcount, unsigned long long *__restrict__ max_len) {
+                                                       uint32_t *__restrict__ tips, uint32_t *__restrict__ kcount, unsigned long long *__restrict__ max_len,
+                                                       uint32_t *__restrict__ tipidx /* node -> its place in tips[], ~0: takes no part */) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     int len = 0;
+    if (i < nd.n) tipidx[i] = flag[i] ? pos[i] : 0xFFFFFFFFu;
     if (i < nd.n && flag[i]) {
         len = nd.len[i];
         const int il = (len - c.li_k + 1 + c.li_intervals - 1) / c.li_intervals;
@@ -552,6 +585,26 @@ __global__ void __launch_bounds__(256) k_pkb_tiprec_snap(const uint32_t *__restr
     if (q == 0u) x = make_uint4(id, r1 - r0, (uint32_t) b, (uint32_t) (b >> 32));
     else x = make_uint4((uint32_t) a, (uint32_t) (a >> 32), (uint32_t) b, (uint32_t) (b >> 32));
     *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(rec + t) + 64 + 16 * q) = x;
+}
+
+// ... and between the rounds only where a row changed: the sources of the round's additions (sorted keys: the first key of a source's run acts)
+__global__ void __launch_bounds__(256) k_pkb_tiprec_snap_srcs(const unsigned long long *__restrict__ adds, uint64_t n_adds, const uint32_t *__restrict__ tipidx,
+                                                               const uint32_t *__restrict__ rowptr, const unsigned long long *__restrict__ gkeys, PkbTipRec *__restrict__ rec) {
+    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n_adds; i += (uint64_t) gridDim.x * blockDim.x) {
+        const int src = pkb_key_src(adds[i]);
+        if (i > 0 && pkb_key_src(adds[i - 1]) == src) continue;
+        const uint32_t t = tipidx[src];
+        if (t == 0xFFFFFFFFu) continue;                                        // (cannot happen: only tips are sources of additions)
+        const uint32_t r0 = rowptr[src], r1 = rowptr[src + 1];
+        unsigned long long k[PKB_REC_KEYS];
+#pragma unroll
+        for (int q = 0; q < PKB_REC_KEYS; q++) k[q] = r0 + (uint32_t) q < r1 ? gkeys[r0 + q] : 0ull;
+        uint4 *h = reinterpret_cast<uint4 *>(reinterpret_cast<char *>(rec + t) + 64);       // the half-line written whole, as k_pkb_tiprec_snap does
+        h[0] = make_uint4((uint32_t) src, r1 - r0, (uint32_t) k[0], (uint32_t) (k[0] >> 32));
+        h[1] = make_uint4((uint32_t) k[1], (uint32_t) (k[1] >> 32), (uint32_t) k[2], (uint32_t) (k[2] >> 32));
+        h[2] = make_uint4((uint32_t) k[3], (uint32_t) (k[3] >> 32), (uint32_t) k[4], (uint32_t) (k[4] >> 32));
+        h[3] = make_uint4((uint32_t) k[5], (uint32_t) (k[5] >> 32), (uint32_t) k[6], (uint32_t) (k[6] >> 32));
+    }
 }
 
 // neighbors[b] of node a in the round's snapshot through a's record (ra, rb: the records' positions)
@@ -1273,6 +1326,9 @@ void launch_pkb_src_keys(const unsigned long long *keys, uint64_t n, int shift, 
 void launch_pkb_gather_keys(const unsigned long long *keys, const uint32_t *idx, uint64_t n, unsigned long long *out, hipStream_t s) {
     if (n) hipLaunchKernelGGL(k_pkb_gather_keys, dim3(pkb_grid(n, 256, 8192)), dim3(256), 0, s, keys, idx, n, out);
 }
+void launch_pkb_gather_sorted_runs(const unsigned long long *keys, const uint32_t *k32_sorted, const uint32_t *idx, uint64_t n, unsigned long long *out, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_pkb_gather_sorted_runs, dim3(pkb_grid(n, 256, 16384)), dim3(256), 0, s, keys, k32_sorted, idx, n, out);
+}
 void launch_pkb_sort_src_runs(unsigned long long *keys, uint64_t n, hipStream_t s) {
     if (n) hipLaunchKernelGGL(k_pkb_sort_src_runs, dim3(pkb_grid(n, 256, 16384)), dim3(256), 0, s, keys, n);
 }
@@ -1305,9 +1361,9 @@ void launch_pkb_tip_flags(const NodesDev &nd, const PkbCfg &c, const uint8_t *ma
 }
 
 void launch_pkb_tip_list(const NodesDev &nd, const PkbCfg &c, const uint32_t *flag, const uint32_t *pos, uint32_t *tips, uint32_t *kcount,
-                         unsigned long long *max_len, hipStream_t s) {
+                         unsigned long long *max_len, uint32_t *tipidx, hipStream_t s) {
     if (nd.n <= 0) return;
-    hipLaunchKernelGGL(k_pkb_tip_list, dim3((nd.n + 255) / 256), dim3(256), 0, s, nd, c, flag, pos, tips, kcount, max_len);
+    hipLaunchKernelGGL(k_pkb_tip_list, dim3((nd.n + 255) / 256), dim3(256), 0, s, nd, c, flag, pos, tips, kcount, max_len, tipidx);
 }
 
 void launch_pkb_kmers(const NodesDev &nd, const PkbCfg &c, const int32_t prio[4], const uint32_t *tips, const uint32_t *koff, uint32_t n_tips, int sort_bits,
@@ -1324,6 +1380,12 @@ size_t pkb_tiprec_bytes(uint32_t n_tips) { return ((size_t) n_tips + 1) * sizeof
 void launch_pkb_tiprec_rows(const NodesDev &nd, const uint32_t *tips, uint32_t n_tips, void *tiprec, hipStream_t s) {
     if (n_tips == 0) return;
     hipLaunchKernelGGL(k_pkb_tiprec_rows, dim3((unsigned) (((uint64_t) n_tips * 4 + 255) / 256)), dim3(256), 0, s, nd, tips, n_tips, (PkbTipRec *) tiprec);
+}
+
+void launch_pkb_tiprec_snap_srcs(const unsigned long long *adds, uint64_t n_adds, const uint32_t *tipidx, const uint32_t *rowptr, const unsigned long long *gkeys, void *tiprec,
+                                 hipStream_t s) {
+    if (n_adds == 0) return;
+    hipLaunchKernelGGL(k_pkb_tiprec_snap_srcs, dim3(pkb_grid(n_adds, 256, 8192)), dim3(256), 0, s, adds, n_adds, tipidx, rowptr, gkeys, (PkbTipRec *) tiprec);
 }
 
 void launch_pkb_tiprec_snap(const uint32_t *tips, uint32_t n_tips, const uint32_t *rowptr, const unsigned long long *gkeys, void *tiprec, hipStream_t s) {

@@ -120,20 +120,21 @@ __global__ void __launch_bounds__(RS_THREADS) k_rs_hist(const uint32_t *__restri
     for (uint32_t d = threadIdx.x; d < D; d += RS_THREADS) chunk_tot[(size_t) c * D + d] = run[d];
 }
 
-// chunk_tot[c][d] -> exclusive prefix over the chunks (in place); digit_tot[d] = all items with digit d.  A block per 64 digits, eight
-// groups of chunks side by side.
+// chunk_tot[c][d] -> exclusive prefix over the chunks (in place); digit_tot[d] = all items with digit d.  A block per 16 digits, 32 groups of
+// chunks side by side (a block per 64 digits with eight groups walked 64 chunks per thread, twice: 18 us of a pass that should take five)
+constexpr int RS_SC_DIGITS = 16, RS_SC_GROUPS = RS_THREADS / RS_SC_DIGITS;
 __global__ void __launch_bounds__(RS_THREADS) k_rs_scan_chunks(uint32_t *__restrict__ chunk_tot, uint32_t chunks, int nbits, uint32_t *__restrict__ digit_tot) {
-    __shared__ uint32_t gs[RS_WAVES][64];
+    __shared__ uint32_t gs[RS_SC_GROUPS][RS_SC_DIGITS];
     const uint32_t D = 1u << nbits;
-    const uint32_t g = threadIdx.x >> 6, dl = threadIdx.x & 63u, d = blockIdx.x * 64u + dl;
-    const uint32_t cpg = (chunks + RS_WAVES - 1) / RS_WAVES, c0 = g * cpg, c1 = min(c0 + cpg, chunks);
+    const uint32_t g = threadIdx.x / RS_SC_DIGITS, dl = threadIdx.x % RS_SC_DIGITS, d = blockIdx.x * RS_SC_DIGITS + dl;
+    const uint32_t cpg = (chunks + RS_SC_GROUPS - 1) / RS_SC_GROUPS, c0 = min(g * cpg, chunks), c1 = min(c0 + cpg, chunks);
     uint32_t s = 0;
     if (d < D) for (uint32_t c = c0; c < c1; c++) s += chunk_tot[(size_t) c * D + d];
     gs[g][dl] = s;
     __syncthreads();
     uint32_t base = 0, total = 0;
-#pragma unroll
-    for (int q = 0; q < RS_WAVES; q++) { const uint32_t x = gs[q][dl]; base += (uint32_t) q < g ? x : 0u; total += x; }
+#pragma unroll 8
+    for (int q = 0; q < RS_SC_GROUPS; q++) { const uint32_t x = gs[q][dl]; base += (uint32_t) q < g ? x : 0u; total += x; }
     if (d < D) {
         for (uint32_t c = c0; c < c1; c++) { const uint32_t x = chunk_tot[(size_t) c * D + d]; chunk_tot[(size_t) c * D + d] = base; base += x; }
         if (g == 0) digit_tot[d] = total;
@@ -469,7 +470,7 @@ hipError_t rsort_u32_pairs(void *temp, size_t temp_bytes, const uint32_t *keys_i
             hipLaunchKernelGGL((k_rs_hist<8192>), dim3(p.chunks), dim3(RS_THREADS), 0, s, ki, n, sh, nb, p.n_tiles, p.tiles_per_chunk, tile_pref, chunk_tot, aligned);
         else
             hipLaunchKernelGGL((k_rs_hist<16384>), dim3(p.chunks), dim3(RS_THREADS), 0, s, ki, n, sh, nb, p.n_tiles, p.tiles_per_chunk, tile_pref, chunk_tot, aligned);
-        hipLaunchKernelGGL(k_rs_scan_chunks, dim3(((1u << nb) + 63u) / 64u), dim3(RS_THREADS), 0, s, chunk_tot, p.chunks, nb, digit_tot);
+        hipLaunchKernelGGL(k_rs_scan_chunks, dim3(((1u << nb) + RS_SC_DIGITS - 1u) / RS_SC_DIGITS), dim3(RS_THREADS), 0, s, chunk_tot, p.chunks, nb, digit_tot);
         hipLaunchKernelGGL(k_rs_scan_digits, dim3(1), dim3(RS_THREADS), 0, s, (const uint32_t *) digit_tot, nb, digit_base);
         const dim3 grid(8u * ((p.n_tiles + 7u) / 8u));
 #define RS_SCATTER_(NB_, T_, I_) hipLaunchKernelGGL((k_rs_scatter<NB_, T_, I_>), grid, dim3(T_), 0, s, ki, vi, ko, vo, n, sh, nb, p.n_tiles, p.tiles_per_chunk, \
@@ -510,7 +511,7 @@ hipError_t rsort_u64_pairs(void *temp, size_t temp_bytes, const unsigned long lo
         unsigned long long *ko = to_out ? keys_out : tk, *vo = to_out ? vals_out : tv;
         const int nb = p.bits[i], sh = p.shift[i];
         hipLaunchKernelGGL((k_rs_hist64<unsigned long long>), dim3(p.chunks), dim3(RS_THREADS), 0, s, ki, n, sh, nb, p.n_tiles, p.tiles_per_chunk, tile_pref, chunk_tot);
-        hipLaunchKernelGGL(k_rs_scan_chunks, dim3(((1u << nb) + 63u) / 64u), dim3(RS_THREADS), 0, s, chunk_tot, p.chunks, nb, digit_tot);
+        hipLaunchKernelGGL(k_rs_scan_chunks, dim3(((1u << nb) + RS_SC_DIGITS - 1u) / RS_SC_DIGITS), dim3(RS_THREADS), 0, s, chunk_tot, p.chunks, nb, digit_tot);
         hipLaunchKernelGGL(k_rs_scan_digits, dim3(1), dim3(RS_THREADS), 0, s, (const uint32_t *) digit_tot, nb, digit_base);
         const dim3 grid(8u * ((p.n_tiles + 7u) / 8u));
         if (nb <= 8) hipLaunchKernelGGL((k_rs_scatter64<unsigned long long, 8>), grid, dim3(RS_THREADS), 0, s, ki, vi, ko, vo, n, sh, nb, p.n_tiles, p.tiles_per_chunk,
@@ -545,7 +546,7 @@ hipError_t rsort_u32_u64(void *temp, size_t temp_bytes, const uint32_t *keys_in,
         unsigned long long *vo = to_out ? vals_out : tv;
         const int nb = p.bits[i], sh = p.shift[i];
         hipLaunchKernelGGL((k_rs_hist64<uint32_t>), dim3(p.chunks), dim3(RS_THREADS), 0, s, ki, n, sh, nb, p.n_tiles, p.tiles_per_chunk, tile_pref, chunk_tot);
-        hipLaunchKernelGGL(k_rs_scan_chunks, dim3(((1u << nb) + 63u) / 64u), dim3(RS_THREADS), 0, s, chunk_tot, p.chunks, nb, digit_tot);
+        hipLaunchKernelGGL(k_rs_scan_chunks, dim3(((1u << nb) + RS_SC_DIGITS - 1u) / RS_SC_DIGITS), dim3(RS_THREADS), 0, s, chunk_tot, p.chunks, nb, digit_tot);
         hipLaunchKernelGGL(k_rs_scan_digits, dim3(1), dim3(RS_THREADS), 0, s, (const uint32_t *) digit_tot, nb, digit_base);
         const dim3 grid(8u * ((p.n_tiles + 7u) / 8u));
         if (nb <= 8) hipLaunchKernelGGL((k_rs_scatter64<uint32_t, 8>), grid, dim3(RS_THREADS), 0, s, ki, vi, ko, vo, n, sh, nb, p.n_tiles, p.tiles_per_chunk,

@@ -118,7 +118,8 @@ def profiled_traffic(config, src_sha):
         return {}, None
     if not ent or ent.get("src_sha256") != src_sha:
         return {}, None
-    return {k: v["read_bytes"] + v["write_bytes"] for k, v in ent["per_dispatch"].items()}, ent.get("per_step_bytes")
+    # per kernel: the bytes of ONE build (a kernel that runs several times per build -- the passes of the radix sort -- counts with all of them)
+    return {k: (v.get("bytes_per_build") or v["read_bytes"] + v["write_bytes"]) for k, v in ent["per_dispatch"].items()}, ent.get("per_step_bytes")
 
 
 def traffic_of(traffic, prefix):
@@ -434,11 +435,12 @@ def run(args, rank, world, local_rank, dist, t_process=None):
             runs_per_node = 1.0 + 2.0 * (stats["windows_probed"] / n_src - 1.0) / (min(64, lo - max(lo - 63, min(lo, 16)) + 1) + 1.0)
             nb = int(stats["table_slots"])
             rk = [("k_node_runs", ms["keys"], n * (4 * W + 4) + n * (13 + 8 * runs_per_node), "VALU-bound: ~1650 vector instructions per node"),
-                  ("rocprim radix sort of (key, id) (onesweep; >= 2^22 nodes: the 29 key bits the directory needs in 3 passes of 10, else 32 bits in 4 passes of 8)",
-                   ms["sort"], 4 * n + (3 if n >= (1 << 22) else 4) * 2 * 8 * n, "library code; bytes = histogram read + passes x (read + write) of 8-byte pairs"),
+                  ("k_rs_hist + k_rs_scan + k_rs_scatter", ms["sort"], 3 * (4 * n + 2 * 8 * n) - 4 * n,
+                   "the engine's own radix sort of (key, id) (radix_sort.hip): the 29 key bits the directory needs in 3 passes of 10; per pass 4 B (histogram) + 8 B in + 8 B out "
+                   "per pair, the first pass makes the ids up instead of reading them"),
                   ("k_tgt_gather", ms["gather"], n * (4 * W + 8 + 16 * eq), "one isolated 64-byte row per entry: 128 bytes fetched for it (not run for a build the pile path keeps)"),
                   ("k_tgt_dir", ms["dir"], 4 * n + 16 * (nb + 1), "includes the zero fill of the directory (16 B per bucket) in front of the kernel"),
-                  ("k_pile_build + k_pile_runs", ms["pile"], n * (4 * W + 8 + 16 + 16) + 64 * (n / 6.0) + n * 16 + (n / 6.0) * (128 + 48),
+                  ("k_pile_build + k_pile_runs_consensus + k_pile_own_ids", ms["pile"], n * (4 * W + 8 + 16 + 16) + 64 * (n / 6.0) + n * 16 + (n / 6.0) * (128 + 48),
                    "pile records of the key order: every node's row read once BY ID (no entry array is built for a build the pile path keeps: one isolated row per entry, "
                    "128 bytes fetched for it), its sorted (key, id) pair and a directory record, 64 B written per k-mer group (~6 entries) and a 16-byte side record per entry; "
                    "then the run list of each pile: side records read, two 64-byte run lists in and 48 bytes out per group; part of the index build"),

@@ -26,8 +26,8 @@ sys.path.insert(0, ROOT)
 
 
 def short(name):
-    name = name.split("(")[0]
-    for p in ("void alga::", "alga::"):
+    name = name.replace("(anonymous namespace)::", "").split("(")[0]
+    for p in ("void alga::", "alga::", "void ", "(anonymous namespace)::"):       # (radix_sort.hip keeps its kernels in an anonymous namespace)
         if name.startswith(p):
             name = name[len(p):]
     return name
@@ -73,7 +73,7 @@ def main():
         total += rb + wb
         if "<true" in k and k.startswith("k_probe"):                             # the statistics builds of the probes (bench.py's counted pass): not a timed kernel
             continue
-        kernels[k[:70]] = {"read_bytes": int(rb / calls), "write_bytes": int(wb / calls), "dispatches": calls,
+        kernels[k[:70]] = {"read_bytes": int(rb / calls), "write_bytes": int(wb / calls), "dispatches": calls, "bytes_per_build": int((rb + wb) / builds[0]) if builds else None,
                            "read_requests": {"128B": int(n128 / calls), "64B": int(n64 / calls), "32B": int(n32 / calls)}}
     out_path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     data = json.load(open(out_path)) if os.path.exists(out_path) else {}
