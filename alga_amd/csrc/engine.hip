@@ -250,7 +250,7 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
             }
             if (pile) {
                 launch_pile_sample(nd, cc, pp.uniform_len, (const uint32_t *) e->cl_keys[1].p, (const uint32_t *) e->cl_vals[1].p, e->cl_dir.p,
-                                   (unsigned long long *) e->cl_pile_cnt.p, e->opt_pile == 2, s);
+                                   (unsigned long long *) e->cl_pile_cnt.p, e->opt_pile >= 2 ? e->opt_pile - 1 : 0, s);
                 if ((rc = alga_check_launch(e, "k_pile_build<sample>"))) return rc;
             }
             HIP_TRY(e, launch_cluster_gather(nd, cc, pp.cluster_eq, (const uint32_t *) e->cl_keys[1].p, (const uint32_t *) e->cl_vals[1].p, (const uint32_t *) e->cl_meta.p,
@@ -343,6 +343,15 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
                                     (unsigned long long *) e->loc_second.p, (int32_t *) e->cl_defer.p, (uint32_t) n_src,
                                     piled ? (const unsigned long long *) e->cl_pile_cnt.p : nullptr, s);
                 if ((rc = alga_check_launch(e, "k_probe_stream"))) return rc;
+                if (piled) {
+                    // the MIXED form (more than one irregular bucket in 250, not more than one in 20 -- the kernels read the sample's counters themselves):
+                    // what k_pile_probe handed on goes through the stream kernel, by list, before the general kernel gets what is left
+                    if ((rc = alga_ensure(e, e->cl_defer2, (size_t) (n_src + 64) * sizeof(int32_t)))) return rc;
+                    launch_probe_stream_list(nd, cfg, cc, pp.cluster_eq, e->cl_store.p, e->cl_dir.p, e->cl_runs.p, (const uint8_t *) e->cl_nruns.p, (int32_t *) e->cl_defer.p,
+                                             (uint32_t) n_src, cnt, e->n_cu, (uint32_t *) e->outdeg.p, (unsigned long long *) e->loc_first.p,
+                                             (unsigned long long *) e->loc_second.p, (int32_t *) e->cl_defer2.p, (const unsigned long long *) e->cl_pile_cnt.p, s);
+                    if ((rc = alga_check_launch(e, "k_probe_stream (list)"))) return rc;
+                }
                 HIP_TRY(e, hipEventRecord(e->ev[EV_PAIRS], s));
                 e->pairs_timed = true;
                 launch_probe_clustered(nd, cfg, cc, pp.cluster_eq, e->cl_store.p, e->cl_dir.p, e->cl_runs.p, (const uint8_t *) e->cl_nruns.p, 0,
@@ -410,8 +419,10 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
             if (pile && pp.keys_shared != 2 && e->pile_n == nd.n) {
                 // the sample's verdict is on the host now: a build the pile path DECLINED (or one with pile_skip_gather off) did build the entry
                 // array, and a later keys_shared = 2 build of this node set may use it
-                const bool kept = e->opt_pile == 2 || e->stats.pile_irregular * (uint64_t) ALGA_PILE_IRREGULAR_ONE_IN <= e->stats.pile_buckets;
-                if (!kept || !e->opt_pile_skip_gather) e->store_n = nd.n;
+                const bool kept = e->opt_pile == 2 || e->stats.pile_irregular * (uint64_t) ALGA_PILE_DECLINE_ONE_IN <= e->stats.pile_buckets;
+                e->stats.pile_mixed = kept && e->stats.pile_irregular * (uint64_t) ALGA_PILE_IRREGULAR_ONE_IN > e->stats.pile_buckets;
+                e->stats.pile_deferred = e->stats.pile_mixed ? e->h_counters[CNT_DEFERRED_PILE] : (kept ? e->h_counters[CNT_DEFERRED] : 0);
+                if (!kept || e->stats.pile_mixed || !e->opt_pile_skip_gather) e->store_n = nd.n;      // (the entry array was built: k_tgt_gather leaves only for a build of the pure pile form)
                 e->expect_pairwise = !kept;               // (how the NEXT build's key pass is laid out -- never what it computes)
                 e->stats.pile_list_checked = 0; e->stats.pile_list_mismatch = 0;
                 if (e->opt_pile_check) {
@@ -657,7 +668,7 @@ int alga_engine_set_option(alga_engine *e, const char *name, int64_t value) {
     } else if (!strcmp(name, "cluster_pairs")) {
         e->opt_cluster_pairs = value != 0;
     } else if (!strcmp(name, "pile")) {
-        e->opt_pile = value == 2 ? 2 : (value != 0);       // (2, tests only: no sample -- the pile kernels take every build they can, however many buckets are irregular)
+        e->opt_pile = (value == 2 || value == 3) ? (int) value : (value != 0);       // (2, 3, tests only: no sample -- the pile kernels take every build they can, however many buckets are irregular; 3: in the mixed form)
     } else if (!strcmp(name, "pile_runs")) {
         e->opt_pile_runs = value != 0;
     } else if (!strcmp(name, "pile_check")) {

@@ -82,6 +82,7 @@ struct alga_engine {
     DevBuf up_len_narrow;                      // ... the lengths as they cross PCIe (one or two bytes per node), widened on the device
     DevBuf cp_deg, cp_dst, cp_off;             // compact edge list (alga_prefsuf_build_host_compact): degree bytes, neighbours, offset bytes
     // approximate supplement (engine_pkb.hip)
+    DevBuf cl_defer2;                           // mixed form of a pile-path build: the sources k_probe_stream (list mode) hands on
     DevBuf pk_keys, pk_keys2, pk_vals, pk_vals2, pk_marks, pk_big, pk_add, pk_ekeys, pk_ekeys2, pk_flag, pk_pos, pk_edges[2], pk_rowptr, pk_deg,
            pk_mask, pk_cnt, pk_io, pk_io2, pk_tips, pk_heads, pk_g[2], pk_addk, pk_addk2, pk_merged, pk_hsz, pk_hsz2, pk_heads2, pk_nadd, pk_koff,
            pk_gsz, pk_fixlist, pk_bounds, pk_tiprec, pk_tipidx;

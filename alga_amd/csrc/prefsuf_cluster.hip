@@ -66,7 +66,7 @@ __global__ void __launch_bounds__(TK_ROWS) k_node_runs(NodesDev nd, PrefSufCfg c
                                                         uint32_t *__restrict__ keys, uint32_t *__restrict__ vals, uint32_t *__restrict__ meta,
                                                         uint2 *__restrict__ runs, uint8_t *__restrict__ nruns, const int32_t *__restrict__ id_list, const unsigned long long *__restrict__ id_count,
                                                         const unsigned long long *__restrict__ only_if_declined /* null, or the pile path's sample: the kernel leaves for a build that path keeps */) {
-    if (only_if_declined && only_if_declined[1] * PILE_IRREGULAR_ONE_IN <= only_if_declined[0]) return;
+    if (only_if_declined && !pile_cnt_declines(only_if_declined)) return;
     __shared__ uint32_t s[TK_ROWS][TKW];
     // records, transposed (conflict-free): rows 0 .. NR_STACK - 1 block 1, NR_STACK the spare row that takes the stores of lanes
     // that do not push, NR_STACK + 1 .. 2 NR_STACK block 0, 2 NR_STACK + 1 its spare row
@@ -719,14 +719,24 @@ k_probe_clustered(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__res
 #define CLQ_OCC_IDORDER 5
 #endif
 constexpr int clq_occ(int eq, int kf, bool bykey) { return (eq == 4 || (eq == 3 && kf == 3)) ? 5 : (bykey ? 6 : CLQ_OCC_IDORDER); }
-template <bool STATS, int EQ, int KF, bool BYKEY>
+// LIST (round 5, the mixed form of a build the pile path keeps): the sources are the ids src_list[0 .. *src_count) -- what k_pile_probe handed
+// on, in about the order of the entry array -- rows and lengths by id; what this kernel cannot finish either goes on defer_list (a SECOND list,
+// counted in CNT_DEFERRED2).
+template <bool STATS, int EQ, int KF, bool BYKEY, bool LIST = false>
 __global__ void __launch_bounds__(PROBE_WAVES * 64, clq_occ(EQ, KF, BYKEY))
 k_probe_stream(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__restrict__ store, const uint4 *__restrict__ dir,
-               const uint2 *__restrict__ runs, const uint8_t *__restrict__ nruns, int32_t src_begin, int32_t src_end, ProbeOut o,
-               int32_t *__restrict__ defer_list, uint32_t defer_cap, const unsigned long long *__restrict__ pile_cnt) {
+               const uint2 *__restrict__ runs, const uint8_t *__restrict__ nruns, int32_t src_begin_a, int32_t src_end_a, ProbeOut o,
+               int32_t *__restrict__ defer_list, uint32_t defer_cap, const unsigned long long *__restrict__ pile_cnt,
+               const int32_t *__restrict__ src_list, const unsigned long long *__restrict__ src_count) {
+    static_assert(!(LIST && (BYKEY || STATS)), "list mode: ids from a list, no statistics build");
     // the pile kernel (prefsuf_pile.hip) was launched in front of this one and takes the build unless most buckets are irregular: the
     // same test on the same two counters, so exactly one of the two kernels does the work -- decided on the device, from this build's data
-    if (pile_cnt != nullptr && pile_cnt[1] * PILE_IRREGULAR_ONE_IN <= pile_cnt[0]) return;
+    if (!LIST && pile_cnt != nullptr && !pile_cnt_declines(pile_cnt)) return;
+    if (LIST && (pile_cnt == nullptr || !pile_cnt_mixed(pile_cnt))) return;
+    const int32_t src_begin = LIST ? 0 : src_begin_a;
+    const int32_t src_end = LIST ? (int32_t) min(*src_count, (unsigned long long) src_end_a) : src_end_a;       // (list mode: src_end_a = the list's capacity)
+    if (LIST && src_end <= 0) return;
+    constexpr int CNT_DEFER_AT = LIST ? CNT_DEFERRED2 : CNT_DEFERRED;
     constexpr int WC = 4 * EQ - 3;                         // row words of an entry
     constexpr int QW = 24;                                 // staged words per source: the row (<= 13) + the compare's slack, words 16.. stay zero
     constexpr int NS = 12;                                 // source slots: three quads
@@ -764,7 +774,7 @@ k_probe_stream(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__restri
     auto flush_defer = [&]() {                             // convergent
         if (n_defer == 0) return;
         unsigned long long base = 0;
-        if (lane == 0) base = atomicAdd(&o.counters[CNT_DEFERRED], (unsigned long long) n_defer);
+        if (lane == 0) base = atomicAdd(&o.counters[CNT_DEFER_AT], (unsigned long long) n_defer);
         base = ((unsigned long long) (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) (base >> 32)) << 32) | (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) base);
         for (int k = lane; k < n_defer; k += 64)
             if (base + (unsigned long long) k < (unsigned long long) defer_cap) defer_list[base + (unsigned long long) k] = sDefer[wave][k];
@@ -800,10 +810,24 @@ k_probe_stream(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__restri
     int a_id = 0, a_len = 0, b_id = 0, b_len = 0;
     uint32_t a_word = 0, b_word = 0, b_nrw = 0;
     uint2 b_run = make_uint2(0u, 0u);
+    // list mode: the id of a position is itself a load, and the row is fetched BY that id -- it is read one stage earlier (a_lid: the quad at
+    // posA, n_lid: the quad stage A moves to next), so that no load waits for another inside fetchA
+    auto next_pos = [&](int p) { return step <= src_end - p ? p + step : src_end; };
+    auto list_at = [&](int pos) -> int {
+        const int j = pos + g, js = j < last_src ? j : last_src;
+        return (int) min((uint32_t) src_list[js], (uint32_t) nd.n - 1u);
+    };
+    int a_lid = 0, n_lid = 0;
+    if constexpr (LIST) { a_lid = list_at(posA); n_lid = list_at(next_pos(posA)); }
     auto fetchA = [&]() {
         const int j = posA + g;
         a_valid = j < src_end;
         const int js = j < last_src ? j : last_src;
+        if constexpr (LIST) {
+            a_id = a_lid;
+            a_len = nd.len[a_lid];
+            a_word = nd.words[(size_t) a_lid * nd.stride + col];
+        } else
         if constexpr (BYKEY) {
             const uint32_t *ent = reinterpret_cast<const uint32_t *>(store) + (size_t) js * (4 * EQ);
             a_word = ent[col];
@@ -829,6 +853,7 @@ k_probe_stream(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__restri
         b_valid = adv ? a_valid : b_valid; b_id = adv ? a_id : b_id; b_len = adv ? a_len : b_len; b_word = adv ? a_word : b_word;
         posB = adv ? posA : posB;
         posA = adv ? (step <= src_end - posA ? posA + step : src_end) : posA;
+        if constexpr (LIST) { a_lid = adv ? n_lid : a_lid; n_lid = list_at(next_pos(posA)); }
         fetchB();
         fetchA();
     };
@@ -1130,7 +1155,8 @@ k_probe_stream(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__restri
         bool first = true;
         for (int q = pos0; q < src_end; q = step <= src_end - q ? q + step : src_end) {     // uniform
             const int j = q + g < src_end ? q + g : last_src;
-            const int b = BYKEY ? (int) reinterpret_cast<const uint32_t *>(store)[(size_t) j * (4 * EQ) + 4 * EQ - 3] : j;
+            const int b = BYKEY ? (int) reinterpret_cast<const uint32_t *>(store)[(size_t) j * (4 * EQ) + 4 * EQ - 3]
+                                : (LIST ? (int) min((uint32_t) src_list[j], (uint32_t) nd.n - 1u) : j);
             const bool dfr = gl == 0 && q + g < src_end && !(first && g < cur) && (run_w[(size_t) b * (2 * CL_RMAX) + 1] >> 24) != 0u;
             defer_rows(dfr, b);
             first = false;
@@ -1322,7 +1348,8 @@ void launch_probe_stream(const NodesDev &nd, const PrefSufCfg &cfg, const Cluste
          block(PROBE_WAVES * 64);
     ProbeOut o{nullptr, nullptr, 0, counters, deg, first, by_key ? 0 : src_begin, second};
     const uint4 *st = (const uint4 *) store;
-#define CLQ_LAUNCH(ST, E, K, BK) hipLaunchKernelGGL((k_probe_stream<ST, E, K, BK>), grid, block, 0, s, nd, cfg, cc, st, (const uint4 *) dir, (const uint2 *) runs, nruns, src_begin, src_end, o, defer_list, defer_cap, pile_cnt)
+#define CLQ_LAUNCH(ST, E, K, BK) hipLaunchKernelGGL((k_probe_stream<ST, E, K, BK>), grid, block, 0, s, nd, cfg, cc, st, (const uint4 *) dir, (const uint2 *) runs, nruns, src_begin, src_end, o, defer_list, defer_cap, pile_cnt, \
+                                                    (const int32_t *) nullptr, (const unsigned long long *) nullptr)
 #define CLQ_ORDER(ST, E, K) do { if (by_key) CLQ_LAUNCH(ST, E, K, true); else CLQ_LAUNCH(ST, E, K, false); } while (0)
 #define CLQ_STATS(E, K) do { if (cfg.stats) CLQ_ORDER(true, E, K); else CLQ_ORDER(false, E, K); } while (0)
     if (eq == 3 && kf == 5)      CLQ_STATS(3, 5);
@@ -1334,6 +1361,33 @@ void launch_probe_stream(const NodesDev &nd, const PrefSufCfg &cfg, const Cluste
 #undef CLQ_STATS
 #undef CLQ_ORDER
 #undef CLQ_LAUNCH
+}
+
+// The mixed form of a build the pile path keeps (prefsuf_cluster_device.h: pile_cnt_mixed): k_probe_stream over the sources k_pile_probe handed on
+// (src_list[0 .. *src_count), the count on the device); what it cannot finish goes on defer2 (counted in CNT_DEFERRED2), and k_defer_swap puts that
+// list and its count where the general kernel looks for its sources.  Both kernels leave at once for a build that is not of the mixed form.
+__global__ void __launch_bounds__(256) k_defer_swap(const unsigned long long *__restrict__ pile_cnt, unsigned long long *__restrict__ counters, const int32_t *__restrict__ list2,
+                                                     int32_t *__restrict__ list, uint32_t cap) {
+    if (!pile_cnt_mixed(pile_cnt)) return;
+    const uint64_t n2 = min(counters[CNT_DEFERRED2], (unsigned long long) cap);
+    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (uint64_t) gridDim.x * blockDim.x) list[i] = list2[i];
+    if (blockIdx.x == 0 && threadIdx.x == 0) { counters[CNT_DEFERRED_PILE] = counters[CNT_DEFERRED]; counters[CNT_DEFERRED] = n2; }
+}
+
+void launch_probe_stream_list(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterCfg &cc, int eq, const void *store, const void *dir, const void *runs, const uint8_t *nruns,
+                              int32_t *src_list, uint32_t list_cap, unsigned long long *counters, int n_cu, uint32_t *deg, unsigned long long *first,
+                              unsigned long long *second, int32_t *defer2, const unsigned long long *pile_cnt, hipStream_t s) {
+    if (eq != 3 || list_cap == 0) return;                  // (the pile path takes entries of three pieces only: pile_plan)
+    const int kf = (2 * cfg.Lmin) >> 5;
+    const int kfs = (kf == 5 || kf == 3) ? kf : 0;
+    const dim3 grid((unsigned) std::max(1, n_cu) * clq_occ(3, kfs, false)), block(PROBE_WAVES * 64);
+    ProbeOut o{nullptr, nullptr, 0, counters, deg, first, 0, second};
+#define CLQ_LIST(K) hipLaunchKernelGGL((k_probe_stream<false, 3, K, false, true>), grid, block, 0, s, nd, cfg, cc, (const uint4 *) store, (const uint4 *) dir, (const uint2 *) runs, nruns, 0, \
+                                       (int32_t) std::min<uint32_t>(list_cap, 0x7FFFFFFFu), o, defer2, list_cap, pile_cnt, (const int32_t *) src_list, (const unsigned long long *) (counters + CNT_DEFERRED))
+    if (kf == 5) CLQ_LIST(5); else if (kf == 3) CLQ_LIST(3); else CLQ_LIST(0);
+#undef CLQ_LIST
+    // the list the general kernel reads: (list2, CNT_DEFERRED2) -> (list, CNT_DEFERRED)
+    hipLaunchKernelGGL(k_defer_swap, dim3(1024), dim3(256), 0, s, pile_cnt, counters, (const int32_t *) defer2, src_list, list_cap);
 }
 
 // src_list == null: the sources are the ids src_begin .. src_end - 1; else the ids src_list[src_begin .. src_end - 1]

@@ -77,6 +77,13 @@ __device__ __forceinline__ bool same_cluster(uint32_t entry_key, uint32_t ckey, 
 // -> the entries [e0, e0 + cnt) a run {q | p0 << 8 | p1 << 16} has to look at
 // k_pile_build / k_pile_probe / k_probe_stream: more than one bucket in this many irregular and the pairwise kernels take the build (prefsuf_pile.hip)
 constexpr unsigned long long PILE_IRREGULAR_ONE_IN = ALGA_PILE_IRREGULAR_ONE_IN;      // include/alga_amd.h
+constexpr unsigned long long PILE_DECLINE_ONE_IN = ALGA_PILE_DECLINE_ONE_IN;
+// What the sample of the key order says about a build (pile_cnt = {buckets, irregular buckets}; every kernel concerned reads the same two counters,
+// so the form is decided on the device): DECLINED -- more than one bucket in PILE_DECLINE_ONE_IN irregular: the pairwise kernels take the build;
+// MIXED (round 5) -- between the two thresholds: the pile kernels take it, and the sources they hand on go through k_probe_stream (list mode; it
+// needs the entry array, so k_tgt_gather runs) before the general kernel sees what is left; else the pile kernels and the general kernel alone.
+__device__ __forceinline__ bool pile_cnt_declines(const unsigned long long *c) { return c[1] * PILE_DECLINE_ONE_IN > c[0]; }
+__device__ __forceinline__ bool pile_cnt_mixed(const unsigned long long *c) { return !pile_cnt_declines(c) && c[1] * PILE_IRREGULAR_ONE_IN > c[0]; }
 __device__ __forceinline__ void run_slice(const uint4 &rec, uint32_t run_y, uint32_t &e0, uint32_t &cnt) {
     const int q = (int) (run_y & 255u), p0 = (int) ((run_y >> 8) & 255u), p1 = (int) ((run_y >> 16) & 255u);
     int mlo = q - p1 + 1, mhi = q - p0;

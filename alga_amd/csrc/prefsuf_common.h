@@ -86,6 +86,8 @@ enum Counter {
     CNT_PILE_BUCKETS,      // pile path: non-empty buckets of the entry array / those it does not take (copied from k_pile_build's counters by k_pile_probe)
     CNT_PILE_IRREGULAR,
     CNT_PILE_OWN,          // pile path: entries that read a run list of their own (the list-driven key pass behind k_pile_runs_consensus)
+    CNT_DEFERRED2,         // mixed form: sources k_probe_stream (list mode) handed on; k_defer_swap moves that list and count to the first list's place
+    CNT_DEFERRED_PILE,     // mixed form: sources k_pile_probe handed on (CNT_DEFERRED before the swap)
     CNT_TOTAL = 24
 };
 

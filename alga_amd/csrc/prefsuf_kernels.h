@@ -76,7 +76,7 @@ bool       pile_plan(const PrefSufCfg &cfg, const ClusterCfg &cc, int eq, int un
 size_t     pile_record_bytes(uint64_t n);
 size_t     pile_table_bytes(uint32_t n_buckets);
 void       launch_pile_sample(const NodesDev &nd, const ClusterCfg &cc, int uniform_len, const uint32_t *skeys /* sorted keys */, const uint32_t *sids /* their node ids */, const void *dir,
-                              unsigned long long *pile_cnt /* of the sample: [0] buckets (raised to entries / 8), [1] irregular buckets, [2] entries */, bool no_sample, hipStream_t s);
+                              unsigned long long *pile_cnt /* of the sample: [0] buckets (raised to entries / 8), [1] irregular buckets, [2] entries */, int no_sample, hipStream_t s);
 constexpr int PILE_CNT_WORDS = 6;      // {sampled buckets, irregular ones, sampled entries, own-list ids, members checked, members whose lists differ}
 size_t     pile_own_mask_bytes(uint64_t n);
 void       launch_pile_build(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterCfg &cc, int uniform_len, const uint32_t *skeys, const uint32_t *sids, const void *dir, void *rec,
@@ -85,6 +85,10 @@ void       launch_pile_build(const NodesDev &nd, const PrefSufCfg &cfg, const Cl
 void       launch_pile_own_ids(const uint32_t *own_mask, const uint32_t *sids, uint64_t n_entries, int32_t *list, uint32_t cap, unsigned long long *pile_cnt, hipStream_t s);
 void       launch_pile_check(const void *side, uint64_t n_entries, uint32_t n_buckets, const void *tab, const void *rec2, uint32_t epoch, const void *runs, int n_nodes, int nwin,
                              unsigned long long *pile_cnt, hipStream_t s);
+// mixed form of a pile-path build: k_probe_stream over the sources on src_list (count on the device: counters[CNT_DEFERRED]), rejects to defer2, then the swap
+void       launch_probe_stream_list(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterCfg &cc, int eq, const void *store, const void *dir, const void *runs, const uint8_t *nruns,
+                                    int32_t *src_list, uint32_t list_cap, unsigned long long *counters, int n_cu, uint32_t *deg, unsigned long long *first,
+                                    unsigned long long *second, int32_t *defer2, const unsigned long long *pile_cnt, hipStream_t s);
 void       launch_pile_probe(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterCfg &cc, int uniform_len, const void *tab, uint32_t epoch, const void *rec, const void *rec2, const void *side,
                              const void *runs, unsigned long long *counters, uint32_t *deg, unsigned long long *first, unsigned long long *second, int32_t *defer_list,
                              uint32_t defer_cap, const unsigned long long *pile_cnt, int n_cu, hipStream_t s);

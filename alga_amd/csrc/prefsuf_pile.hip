@@ -66,7 +66,9 @@ constexpr int PILE_EQ = 3;                     // entry size this path takes: ro
 // kernel (every source with a run in such a bucket: eight times the buckets' share, 2 - 3.5 ms per million) cost more than the pile path saves
 // (~0.2 ms per million sources; measured: 363 M nodes of a 1 Gb genome took 252 ms this way against 160 ms through the pairwise kernels, 181 M
 // nodes of 500 Mb -- 0.27 % irregular -- 57 against 69).  Every kernel concerned reads the same two counters: decided on the device.
-__device__ __forceinline__ bool pile_declines(const unsigned long long *pile_cnt) { return pile_cnt[1] * PILE_IRREGULAR_ONE_IN > pile_cnt[0]; }
+// (round 5: between one irregular bucket in 250 and one in PILE_DECLINE_ONE_IN = 20 the pile path keeps the build in its MIXED form -- the sources
+// handed on go through k_probe_stream in list mode, ~0.3 ms per million, before the general kernel: prefsuf_cluster_device.h)
+__device__ __forceinline__ bool pile_declines(const unsigned long long *pile_cnt) { return pile_cnt_declines(pile_cnt); }
 
 // the row of node `id`, up to nine words (the pile path takes rows of that size only), straight from the node array
 __device__ __forceinline__ void load_row9(const NodesDev &nd, uint32_t id, uint32_t (&row)[9]) {
@@ -1028,11 +1030,15 @@ __global__ void k_pile_sample_close(unsigned long long *__restrict__ pile_cnt) {
 
 // The SAMPLE (k_pile_build<true> on the first 1/32 of the key order) comes before k_tgt_gather: a build the pile path keeps needs no entry
 // array -- its kernels take the rows by id -- and that kernel, like the pairwise probes, reads the two counters and leaves at once.
+__global__ void k_pile_sample_force(unsigned long long *__restrict__ pile_cnt, unsigned long long buckets, unsigned long long irregular) { pile_cnt[0] = buckets; pile_cnt[1] = irregular; }
+
 void launch_pile_sample(const NodesDev &nd, const ClusterCfg &cc, int uniform_len, const uint32_t *skeys, const uint32_t *sids, const void *dir, unsigned long long *pile_cnt,
-                        bool no_sample, hipStream_t s) {
+                        int no_sample, hipStream_t s) {
     (void) hipMemsetAsync(pile_cnt, 0, PILE_CNT_WORDS * sizeof(unsigned long long), s);
     const uint64_t n_entries = nd.n > 0 ? (uint64_t) nd.n : 0;
-    if (n_entries == 0 || no_sample) return;               // (no_sample -- tests only: the two counters stay zero and the pile kernels take the build whatever its buckets look like)
+    // (no_sample -- tests only: 1: the two counters stay zero and the pile kernels take the build whatever its buckets look like; 2: counters that say "mixed form")
+    if (no_sample == 2) hipLaunchKernelGGL(k_pile_sample_force, dim3(1), dim3(1), 0, s, pile_cnt, 100ull, 1ull);
+    if (n_entries == 0 || no_sample) return;
     const uint64_t tiles = (n_entries + PB_TILE - 1) / PB_TILE;
     const dim3 sample((unsigned) std::max<uint64_t>(1, std::min<uint64_t>(tiles, std::max<uint64_t>(64, tiles / 32)))), block(PB_THREADS);
     hipLaunchKernelGGL((k_pile_build<true>), sample, block, 0, s, nd, skeys, sids, n_entries, (const uint4 *) dir, cc, uniform_len, (uint4 *) nullptr, (uint4 *) nullptr, 0u, (uint4 *) nullptr, pile_cnt,

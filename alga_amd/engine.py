@@ -50,7 +50,7 @@ class PrefSufStats(C.Structure):
                 ("ms_keys", C.c_double), ("ms_sort", C.c_double), ("ms_gather", C.c_double), ("ms_dir", C.c_double), ("probe_rounds", C.c_uint64), ("ms_pile", C.c_double),
                 ("pile_buckets", C.c_uint64), ("pile_irregular", C.c_uint64), ("pile_list_checked", C.c_uint64), ("pile_list_mismatch", C.c_uint64),
                 ("pile_own_lists", C.c_uint64), ("host_ms_check", C.c_double), ("host_ms_upload", C.c_double), ("host_ms_build", C.c_double),
-                ("host_ms_download", C.c_double)]
+                ("host_ms_download", C.c_double), ("pile_mixed", C.c_uint64), ("pile_deferred", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
@@ -112,6 +112,7 @@ class PkbStats(C.Structure):
 
 
 PROBE = {"auto": 0, "table": 1, "cluster": 2}                  # alga_probe
+PILE_DECLINE_ONE_IN = 20                                       # ALGA_PILE_DECLINE_ONE_IN: the pile path keeps a build iff pile_irregular * this <= pile_buckets (round 5; between the two: the mixed form)
 PILE_IRREGULAR_ONE_IN = 250                                    # ALGA_PILE_IRREGULAR_ONE_IN (include/alga_amd.h): the pile path keeps a build iff pile_irregular * this <= pile_buckets
 
 class MultiStats(C.Structure):

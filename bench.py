@@ -341,7 +341,7 @@ def run(args, rank, world, local_rank, dist, t_process=None):
         # The counted pass above ran the PAIRWISE kernels (a build that collects the work counters does: they are defined by what those
         # do); the timed steps take the probe through piles where the input allows it (prefsuf_pile.hip): k_pile_probe instead of
         # k_probe_stream, and its own number of sources handed to the general kernel.
-        piled = world == 1 and s.get("pile_buckets", 0) > 0 and s.get("pile_irregular", 0) * alga_amd.engine.PILE_IRREGULAR_ONE_IN <= s.get("pile_buckets", 0) and ms["pile"] > 0
+        piled = world == 1 and s.get("pile_buckets", 0) > 0 and s.get("pile_irregular", 0) * alga_amd.engine.PILE_DECLINE_ONE_IN <= s.get("pile_buckets", 0) and ms["pile"] > 0
         first_name = "k_pile_probe" if piled else "k_probe_stream"
         deferred = int((s if piled else stats).get("deferred_sources", 0))
         two_kernels = stats.get("probe_used") == 2 and ms["probe_pairs"] > 0 and world == 1

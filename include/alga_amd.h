@@ -139,12 +139,20 @@ typedef struct {
                                      pile whose consensus gave no list -- and got it from the list-driven key pass (0: every node's list was made up front) */
     double   host_ms_check, host_ms_upload, host_ms_build, host_ms_download;   /* host entry points (alga_prefsuf_build_host*): wall time of the argument / length
                                      checks, of the upload (staging, re-stride / twin expansion included), of the build, of the download of the edges */
+    uint64_t pile_mixed;          /* 1: the pile path kept a build with more than 1 irregular bucket in ALGA_PILE_IRREGULAR_ONE_IN (but not more than 1 in
+                                     ALGA_PILE_DECLINE_ONE_IN): the sources k_pile_probe handed on went through k_probe_stream first                       */
+    uint64_t pile_deferred;       /* sources k_pile_probe handed on (deferred_sources: what reached the general kernel in the end)                          */
 } alga_prefsuf_stats;
 /* The pile path keeps a build iff  pile_irregular * ALGA_PILE_IRREGULAR_ONE_IN <= pile_buckets  (decided on the device; pile_buckets as reported: raised to
  * an eighth of the sample's entries at high coverage).  Every source with a run in an
  * irregular bucket goes to the general kernel -- eight times the buckets' share of the sources, at ~20 times the cost per source: above ~0.5 % of
  * irregular buckets the pairwise kernels are faster (reads with sequencing errors: 25 %; error-free reads of a genome of 1 Gb: 1.5 %, 250 Mb: 0.07 %). */
 #define ALGA_PILE_IRREGULAR_ONE_IN 250
+/* Round 5: above that share the pile path still keeps the build as long as  pile_irregular * ALGA_PILE_DECLINE_ONE_IN <= pile_buckets  -- the sources
+ * it hands on then go through the pairwise stream kernel (k_probe_stream over the list; the entry array is built for it) and only what that cannot
+ * finish reaches the general kernel: ~0.3 instead of ~2 ms per million sources handed on.  Beyond it (reads with sequencing errors) the pairwise
+ * kernels take the whole build as before.  alga_prefsuf_stats.pile_mixed tells which form ran. */
+#define ALGA_PILE_DECLINE_ONE_IN 20
 
 /* ---- lifetime --------------------------------------------------------------------------- */
 int         alga_abi_version(void);

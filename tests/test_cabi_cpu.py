@@ -30,6 +30,7 @@ def test_library_exports_every_declared_symbol():
     assert lib.alga_abi_version() == 7
     hdr = open(os.path.join(ROOT, "include", "alga_amd.h")).read()
     assert int(re.search(r"#define\s+ALGA_PILE_IRREGULAR_ONE_IN\s+(\d+)", hdr).group(1)) == alga_amd.engine.PILE_IRREGULAR_ONE_IN
+    assert int(re.search(r"#define\s+ALGA_PILE_DECLINE_ONE_IN\s+(\d+)", hdr).group(1)) == alga_amd.engine.PILE_DECLINE_ONE_IN
 
 
 def test_library_contains_gfx950_code_object():

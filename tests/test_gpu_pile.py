@@ -31,7 +31,9 @@ def _three_ways(eng, words, lens, lo, rs, af=None, at=None):
     # pile 2 (tests only): without the sample -- the pile kernels take the build however irregular its buckets are.  pile_runs 0: round 4's form (every
     # node its own run list, a pile's list joined from its outer members'); 1: the list from the pile's consensus, target keys only in the key pass.
     # pile_check: every node's own list as well, and every first-group member's compared with its pile's list clipped to its windows.
-    for pile, pile_runs, check in ((1, 1, 0), (2, 1, 0), (1, 0, 0), (2, 1, 1), (0, 1, 0)):
+    # pile 3 (tests only, round 5): no sample either, the build in the MIXED form -- what k_pile_probe hands on goes through k_probe_stream (list mode:
+    # the entry array is built for it), the general kernel gets what is left.
+    for pile, pile_runs, check in ((1, 1, 0), (2, 1, 0), (3, 1, 0), (3, 0, 0), (1, 0, 0), (2, 1, 1), (0, 1, 0)):
         eng.set_option("pile", pile)
         eng.set_option("pile_runs", pile_runs)
         eng.set_option("pile_check", check)
@@ -48,9 +50,14 @@ def _three_ways(eng, words, lens, lo, rs, af=None, at=None):
             assert st["pile_list_mismatch"] == 0, st
             assert (st["pile_list_checked"] > 0) == (st["ms_pile"] > 0)
             continue
+        if pile == 3:
+            if st["ms_pile"] > 0:                                            # an input the pile path takes: the mixed form ran
+                assert st["pile_mixed"] == 1 and st["pile_deferred"] >= st["deferred_sources"], st
+            continue
         if pile_runs == 0:
             assert (st["ms_pile"] > 0) == (out[1]["ms_pile"] > 0)
             continue
+        assert st["pile_mixed"] == 0 or pile == 1, st
         out[pile] = st
     assert out[0]["pile_buckets"] == 0 and out[0]["ms_pile"] == 0.0
     assert (out[2]["ms_pile"] > 0) == (out[1]["ms_pile"] > 0)       # forced or not, the same inputs are the pile path's
@@ -77,7 +84,7 @@ def test_pile_path_equals_pairwise_and_oracle(eng, length, coverage):
     lo, rs = alga_amd.derive_params(float(length - 6))
     st, E = _three_ways(eng, words, lens, lo, rs)
     assert st["probe_used"] == 2 and st["pile_buckets"] > 0, st              # the pile path ran ...
-    assert st["pile_irregular"] * alga_amd.engine.PILE_IRREGULAR_ONE_IN <= st["pile_buckets"]                   # ... and kept the build
+    assert st["pile_irregular"] * alga_amd.engine.PILE_DECLINE_ONE_IN <= st["pile_buckets"]                     # ... and kept the build
     live = int((lens > 0).sum())
     assert st["deferred_sources"] <= live // 10, (st["deferred_sources"], live)   # nearly every source finished there
     assert E > 0
@@ -132,7 +139,7 @@ def test_reads_with_errors_leave_the_build_to_the_pairwise_kernels(eng):
     words, lens = _nodes(12_000, 150, 40_000, 23, err=0.02)
     lo, rs = alga_amd.derive_params(144.0)
     st, _ = _three_ways(eng, words, lens, lo, rs)
-    assert st["pile_buckets"] > 0 and st["pile_irregular"] * alga_amd.engine.PILE_IRREGULAR_ONE_IN > st["pile_buckets"], st      # sampled, found irregular, declined on the device
+    assert st["pile_buckets"] > 0 and st["pile_irregular"] * alga_amd.engine.PILE_DECLINE_ONE_IN > st["pile_buckets"], st      # sampled, found irregular, declined on the device
 
 
 def test_inputs_the_pile_path_does_not_take(eng):
@@ -262,7 +269,7 @@ def test_a_further_piece_after_a_build_the_pile_path_declined(eng):
         n = len(lens)
         ptr, m = eng.build_range_device(dw, dl, lo, rs, 0, n)
         st = eng.last_stats()
-        assert (st["pile_irregular"] * alga_amd.engine.PILE_IRREGULAR_ONE_IN <= st["pile_buckets"]) == kept and st["pile_buckets"] > 0
+        assert (st["pile_irregular"] * alga_amd.engine.PILE_DECLINE_ONE_IN <= st["pile_buckets"]) == kept and st["pile_buckets"] > 0
         full = device_view(ptr, (m, 3), dw.device).cpu().numpy()
         assert full.shape == want.shape and (full == want).all()
         half = (n // 4) * 2
@@ -316,5 +323,5 @@ def test_declined_then_kept_then_declined(eng):
         got = eng.prefsuf_host(words, lens, lo, rs)
         st = eng.last_stats()
         assert got.shape == want.shape and (got == want).all(), err
-        kept = st["pile_irregular"] * alga_amd.engine.PILE_IRREGULAR_ONE_IN <= st["pile_buckets"]
+        kept = st["pile_irregular"] * alga_amd.engine.PILE_DECLINE_ONE_IN <= st["pile_buckets"]
         assert st["pile_buckets"] > 0 and kept == (err == 0.0)

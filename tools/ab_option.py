@@ -37,7 +37,7 @@ for rep in range(2):                                        # A B A B: drift of 
             if it:
                 for k in keys:
                     acc[k] += st[k]
-            last = {k: st[k] for k in ("deferred_sources", "pile_buckets", "pile_irregular", "pile_own_lists", "edges")}
+            last = {k: st[k] for k in ("deferred_sources", "pile_buckets", "pile_irregular", "pile_own_lists", "pile_mixed", "pile_deferred", "edges")}
         got = device_view(ptr, (m, 3), dw.device)
         if want is None:
             want = got.clone()
