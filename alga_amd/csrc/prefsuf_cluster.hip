@@ -1019,6 +1019,7 @@ k_probe_stream(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__restri
         const uint32_t v_m = (uint32_t) p | ((uint32_t) lenC << 9) | ((meta & CL_META_FROM) ? ITEM_FROM : 0u);
         uint32_t stv = 0u;                                 // status word of this lane's source after the reduction
         bool has_pred = false;
+        int n_tried2 = 0;
         if (pm != 0ull) {                                  // uniform
             uint4 v_o = make_uint4(0u, 0u, 0u, 0u);
             if (pass) {                                    // overhang: C's row from bit 2L on (see k_probe_clustered)
@@ -1049,27 +1050,51 @@ k_probe_stream(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__restri
             const uint64_t below = pass ? (occ & ((1ull << d) - 1ull)) : 0ull;
             has_pred = below != 0ull;
             const int j = has_pred ? (int) Tb[63 - __clzll((long long) below)] : lane;
-            const uint32_t Cj = bperm(id, j), mj = bperm(v_m, j);
-            Ovh<1> oj, oi;
-            oj.w[0] = bperm(v_o.x, j); oj.w[1] = bperm(v_o.y, j); oj.w[2] = bperm(v_o.z, j); oj.w[3] = bperm(v_o.w, j);
+            Ovh<1> oi;
             oi.w[0] = v_o.x; oi.w[1] = v_o.y; oi.w[2] = v_o.z; oi.w[3] = v_o.w;
             const int rho = lenC - (lenBs - d);
-            bool removed;
-            if constexpr (KF > 0) {
-                // via_ok<1> (prefsuf_device.h) with the four word masks of the overhang compare from the table in LDS
-                const int dj = (int) (mj & 511u), lenj = (int) ((mj >> 9) & 511u);
-                const int rho_j = lenj - (lenBs - dj), Lv = lenj - (d - dj);
-                const bool vok = ((mj & ITEM_FROM) != 0u) & (Cj != id) & (dj < d) & (Lv >= Lbig) & (rho_j <= rho) & ((rho_j > 0) | ((int) Cj > Bs));
-                const uint4 m4 = sMask[min(max(2 * rho_j, 0), 128)];
-                const uint32_t df = ((oi.w[0] ^ oj.w[0]) & m4.x) | ((oi.w[1] ^ oj.w[1]) & m4.y) | ((oi.w[2] ^ oj.w[2]) & m4.z) | ((oi.w[3] ^ oj.w[3]) & m4.w);
-                removed = has_pred & vok & (df == 0u);
-            } else removed = has_pred && via_ok<1>(Bs, lenBs, Lbig, Cj, mj, oj, id, d, rho, oi);
-            // not removed by the nearest predecessor although even the longest read placed there could reach C with a big overlap: undecided
-            // here -- unless that predecessor is the ONLY item before this one: nobody else can be a via, the item stands (round 4: reads with
-            // sequencing errors have few overlaps, and two whose overhangs disagree were 6 % of the sources of configs[4], all deferred)
-            const bool fail = has_pred && !removed && (below & (below - 1ull)) != 0ull && (cfg.Lcap - 1) - (d - (int) (mj & 511u)) >= Lbig;
+            // is the item on lane jj (of this lane's source, at a smaller offset) a via of this lane's item?  (convergent: cross-lane reads)
+            auto via_of = [&](int jj, bool want) -> bool {
+                const uint32_t Cj = bperm(id, jj), mjj = bperm(v_m, jj);
+                Ovh<1> oj;
+                oj.w[0] = bperm(v_o.x, jj); oj.w[1] = bperm(v_o.y, jj); oj.w[2] = bperm(v_o.z, jj); oj.w[3] = bperm(v_o.w, jj);
+                if constexpr (KF > 0) {
+                    // via_ok<1> (prefsuf_device.h) with the four word masks of the overhang compare from the table in LDS
+                    const int dj = (int) (mjj & 511u), lenj = (int) ((mjj >> 9) & 511u);
+                    const int rho_j = lenj - (lenBs - dj), Lv = lenj - (d - dj);
+                    const bool vok = ((mjj & ITEM_FROM) != 0u) & (Cj != id) & (dj < d) & (Lv >= Lbig) & (rho_j <= rho) & ((rho_j > 0) | ((int) Cj > Bs));
+                    const uint4 m4 = sMask[min(max(2 * rho_j, 0), 128)];
+                    const uint32_t df = ((oi.w[0] ^ oj.w[0]) & m4.x) | ((oi.w[1] ^ oj.w[1]) & m4.y) | ((oi.w[2] ^ oj.w[2]) & m4.z) | ((oi.w[3] ^ oj.w[3]) & m4.w);
+                    return want & vok & (df == 0u);
+                } else return want && via_ok<1>(Bs, lenBs, Lbig, Cj, mjj, oj, id, d, rho, oi);
+            };
+            bool removed = via_of(j, has_pred);
+            // (round 5) not removed by the nearest predecessor and there are others: they are tried one after the other, nearest first, as
+            // far down as a via can sit at all (an item more than Lcap - 1 - Lbig offsets before this one cannot reach it with a big overlap
+            // even at the longest read length).  Any item before this one may be its via (the all-pairs rule, prefsuf_device.h:
+            // local_reduce), so the walk decides what the nearest predecessor alone left "undecided" -- and handed to the general kernel:
+            // a read with a sequencing error in its overhang is no via of anything behind it and is itself implied by nobody; at LOW error
+            // rates most sources are clean but meet one such target among their ~11 (0.2 % substitutions at the north-star size: 33.5 M
+            // of 90.6 M sources handed on, 46 of the build's 85 ms in the general kernel).
+            const int reach = (cfg.Lcap - 1) - Lbig;         // a via sits at most this many offsets before its item
+            uint64_t cand = 0ull;
+            if (pass && has_pred && !removed) {
+                cand = below & ~(1ull << (63 - __clzll((long long) below)));                       // the nearest has been tried
+                if (d - reach > 0) cand &= ~((1ull << (d - reach)) - 1ull);                          // (d <= 63)
+            }
+            while (__ballot(cand != 0ull) != 0ull) {       // uniform
+                const bool need = cand != 0ull;
+                const int top = need ? 63 - __clzll((long long) cand) : 0;
+                const int j2 = need ? (int) Tb[top] : lane;
+                const bool r2 = via_of(j2, need);
+                removed = removed | r2;
+                cand = (need && !r2) ? cand & ~(1ull << top) : 0ull;
+                n_tried2 += need ? 1 : 0;
+            }
+            // every item that could be a via has been asked: nothing is left undecided (what still sends a source to the general kernel:
+            // two items at one offset, more than 64 entries, more than 8 runs, a flagged run list)
             const bool keep = pass && !removed;
-            if (clash || fail) atomicOr(stp, 1u);
+            if (clash) atomicOr(stp, 1u);
             if (keep) atomicAdd(stp, 0x100u);
             wave_lds_fence();
             stv = *stp;
@@ -1111,7 +1136,7 @@ k_probe_stream(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__restri
         if (STATS) {
             st_rounds++;
             const bool fin = ev && (stv & 255u) == 0u && (stv >> 8) <= 2u;      // this lane's source finishes here
-            st_slots += fin; st_raw += fin && pass; st_cmp += fin && has_pred;
+            st_slots += fin; st_raw += fin && pass; st_cmp += (fin && has_pred ? 1 : 0) + (fin ? n_tried2 : 0);
         }
         // ---- (5) the leader of a row: are its sources of quad 0 / quad 1 finished?  (status word of the round that packed them) ----
         if (gl == 0) {
