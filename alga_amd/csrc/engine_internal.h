@@ -61,7 +61,7 @@ struct alga_engine {
     int    opt_pile_check = 0;                              // option "pile_check" (tests): every node gets its own run list and every first-group member's is compared with its pile's clipped list (stats.pile_list_*)
     bool   expect_pairwise = false;                         // the pile path declined the build before this one: the next key pass makes every run list up front
     DevBuf cl_pile_own;                                     // bit j: entry j of the key order reads a run list of its own
-    int    opt_pkb_legacy = 0;                              // option "pkb_legacy" (A/B and tests): bit 0 groups of 8 .. 16 k-mers a wave each, bit 1 the library's k-mer sort, bit 2 head list in three kernels, bit 3 groups of 8 .. 16 replayed inside the pair kernel, bit 4 the library's unique + a row-pointer pass after the merge, bit 5 the k-mer walk on a 128-bit value, bit 6 every tip record's snapshot half rewritten every round
+    int    opt_pkb_legacy = 0;                              // option "pkb_legacy" (A/B and tests): bit 0 groups of 8 .. 16 k-mers a wave each, bit 1 the library's k-mer sort, bit 2 head list in three kernels, bit 3 groups of 8 .. 16 replayed inside the pair kernel, bit 4 the library's unique + a row-pointer pass after the merge, bit 5 the k-mer walk on a 128-bit value, bit 6 every tip record's snapshot half rewritten every round, bit 7 a k-mer walk per round
     int    opt_own_sort = 1;                                // option "own_sort": the (key, id) sort of the index build is the engine's own radix sort (radix_sort.hip); 0: rocPRIM's
     int    opt_test_pile_oom = 0;                           // tests only: the pile path's allocation reports out of memory (the build must continue on the pairwise kernels)
     bool   pile_timed = false;                              // EV_DIR was recorded in the last discovery (k_pile_build ran behind it)
@@ -85,7 +85,7 @@ struct alga_engine {
     DevBuf cl_defer2;                           // mixed form of a pile-path build: the sources k_probe_stream (list mode) hands on
     DevBuf pk_keys, pk_keys2, pk_vals, pk_vals2, pk_marks, pk_big, pk_add, pk_ekeys, pk_ekeys2, pk_flag, pk_pos, pk_edges[2], pk_rowptr, pk_deg,
            pk_mask, pk_cnt, pk_io, pk_io2, pk_tips, pk_heads, pk_g[2], pk_addk, pk_addk2, pk_merged, pk_hsz, pk_hsz2, pk_heads2, pk_nadd, pk_koff,
-           pk_gsz, pk_fixlist, pk_bounds, pk_tiprec, pk_tipidx;
+           pk_gsz, pk_fixlist, pk_bounds, pk_tiprec, pk_tipidx, pk_keys_all, pk_vals_all;
     // duplicate / prefix-read removal (engine_ingest.hip)
     DevBuf pp_rows, pp_len, pp_perm[2], pp_keys[2], pp_mark, pp_keep, pp_pos, pp_out_rows, pp_out_len, pp_out_pair, pp_tally;
     // staged host <-> HBM copies (staging.hip)
@@ -124,6 +124,9 @@ struct alga_engine {
         int32_t  prio[4] = {0, 1, 2, 3};
         uint64_t E = 0, nk = 0;
         uint32_t n_tips = 0;
+        bool     kmers_all = false;            // the k-mer entries of every round are in pk_keys_all / pk_vals_all (made in round 0), kmers_stride entries apart
+        size_t   kmers_stride = 0;
+        int      kmers_sort_bits = 0;
         alga_nodes dn{};
         alga::PkbCfg cfg{};
     } pkb;

@@ -198,14 +198,31 @@ int pkb_round(alga_engine *e, hipStream_t s, const unsigned long long **d_add, u
         launch_pkb_tiprec_snap((const uint32_t *) e->pk_tips.p, n_tips, (const uint32_t *) e->pk_rowptr.p, (const unsigned long long *) e->pk_g[cur].p, e->pk_tiprec.p, s);
         if ((rc = alga_check_launch(e, "k_pkb_tiprec_snap"))) return rc;
     }
-    launch_pkb_kmers(nd, c, st.prio, (const uint32_t *) e->pk_tips.p, (const uint32_t *) e->pk_koff.p, n_tips, sort_bits, (unsigned long long *) e->pk_keys.p,
-                     (unsigned long long *) e->pk_vals.p, e->pk_tiprec.p, (e->opt_pkb_legacy & 32) != 0, s);
-    if ((rc = alga_check_launch(e, "k_pkb_kmers"))) return rc;
+    // The k-mers of EVERY round in the first round's walk (the tips, their rows and the interval borders are the same; the priority rotates by one
+    // per round): one kernel for what were four.  Option pkb_legacy bit 7, or a shape that kernel does not take: a walk per round.
+    if (round == 0) st.kmers_all = false;
+    if (round == 0 && !(e->opt_pkb_legacy & (128 | 32))) {
+        const size_t stride = (size_t) nk + 1;
+        if ((rc = alga_ensure(e, e->pk_keys_all, (size_t) st.rounds * stride * sizeof(unsigned long long)))) return rc;
+        if ((rc = alga_ensure(e, e->pk_vals_all, (size_t) st.rounds * stride * sizeof(unsigned long long)))) return rc;
+        if (launch_pkb_kmers_all(nd, c, st.prio, st.rounds, (const uint32_t *) e->pk_tips.p, (const uint32_t *) e->pk_koff.p, n_tips, sort_bits,
+                                 (unsigned long long *) e->pk_keys_all.p, (unsigned long long *) e->pk_vals_all.p, stride, e->pk_tiprec.p, s)) {
+            if ((rc = alga_check_launch(e, "k_pkb_kmers_all"))) return rc;
+            st.kmers_all = true; st.kmers_stride = stride; st.kmers_sort_bits = sort_bits;
+        }
+    }
+    const unsigned long long *kin = (const unsigned long long *) e->pk_keys.p, *vin = (const unsigned long long *) e->pk_vals.p;
+    if (st.kmers_all && st.kmers_sort_bits == sort_bits && st.kmers_stride == (size_t) nk + 1) {
+        kin = (const unsigned long long *) e->pk_keys_all.p + (size_t) round * st.kmers_stride;
+        vin = (const unsigned long long *) e->pk_vals_all.p + (size_t) round * st.kmers_stride;
+    } else {
+        launch_pkb_kmers(nd, c, st.prio, (const uint32_t *) e->pk_tips.p, (const uint32_t *) e->pk_koff.p, n_tips, sort_bits, (unsigned long long *) e->pk_keys.p,
+                         (unsigned long long *) e->pk_vals.p, e->pk_tiprec.p, (e->opt_pkb_legacy & 32) != 0, s);
+        if ((rc = alga_check_launch(e, "k_pkb_kmers"))) return rc;
+    }
     // equal hashes become contiguous; inside a group the group kernel orders the entries itself
-    if (own_sort) HIP_TRY(e, rsort_u64_pairs(e->sort_temp.p, temp, (const unsigned long long *) e->pk_keys.p, (unsigned long long *) e->pk_keys2.p,
-                                             (const unsigned long long *) e->pk_vals.p, (unsigned long long *) e->pk_vals2.p, nk, sort_bits, s));
-    else HIP_TRY(e, sort_u64_pairs(e->sort_temp.p, temp, (const unsigned long long *) e->pk_keys.p, (unsigned long long *) e->pk_keys2.p,
-                                   (const unsigned long long *) e->pk_vals.p, (unsigned long long *) e->pk_vals2.p, nk, sort_bits, s));
+    if (own_sort) HIP_TRY(e, rsort_u64_pairs(e->sort_temp.p, temp, kin, (unsigned long long *) e->pk_keys2.p, vin, (unsigned long long *) e->pk_vals2.p, nk, sort_bits, s));
+    else HIP_TRY(e, sort_u64_pairs(e->sort_temp.p, temp, kin, (unsigned long long *) e->pk_keys2.p, vin, (unsigned long long *) e->pk_vals2.p, nk, sort_bits, s));
     uint32_t n_heads = 0;
     uint64_t big_words = 0;
     for (int pass = 0; pass < 2; pass++) {

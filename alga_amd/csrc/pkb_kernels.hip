@@ -428,6 +428,98 @@ __global__ void __launch_bounds__(256) k_pkb_kmers(NodesDev nd, PkbCfg c, int4 p
     }
 }
 
+// The k-mers of ALL rounds in one walk (round 5).  The rounds differ in the alphabet priority alone (GraphCreatorLI.cpp:26 rotates it by one per
+// round: round r reads prio[(s + r) & 3]), the tips and their rows are the same: one staging of the rows, one loop over the start positions with
+// R rolling values side by side -- the digit is extracted once, the interval borders are the same for every round, the loop's scalar bookkeeping
+// (a third of the per-round kernel's issue slots) is paid once.  k-mers go straight to memory when an interval closes (R x 16 buffered hashes would
+// not fit the registers).  keys / vals: R arrays `round_stride` entries apart.  Rows staged (stride <= PKB_ROW_WORDS), k <= 48.
+template <int R>
+__global__ void __launch_bounds__(256) k_pkb_kmers_all(NodesDev nd, PkbCfg c, uint32_t pp0 /* prio[s] at bits 2 s, round 0 */, int rounds, const uint32_t *__restrict__ tips,
+                                                        const uint32_t *__restrict__ koff, uint32_t n_tips, int sort_bits, unsigned long long *__restrict__ keys,
+                                                        unsigned long long *__restrict__ vals, size_t round_stride, const PkbTipRec *__restrict__ rec) {
+    typedef unsigned __int128 u128;
+    __shared__ uint64_t T[64];
+    __shared__ uint32_t srow[256][PKB_ROW_WORDS + 1];
+    mod_table_fill(T);
+    const uint32_t base_t = blockIdx.x * blockDim.x;
+    {
+        const int cw = (int) (threadIdx.x & 15u);
+        for (int r = (int) (threadIdx.x >> 4); r < 256; r += 16) {
+            const uint32_t t = base_t + (uint32_t) r;
+            srow[r][cw] = t < n_tips ? rec[t].words[cw] : 0u;
+        }
+    }
+    __syncthreads();
+    const uint32_t t = base_t + threadIdx.x;
+    const uint32_t node = t < n_tips ? tips[t] : 0u;
+    const int len = t < n_tips ? nd.len[node] : 0;
+    const int k = c.li_k, intervals = c.li_intervals;
+    const bool valid = t < n_tips && k <= len && intervals > 0;
+    int wl = len;                                                              // the longest read of the wave: every lane walks that far
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) wl = max(wl, __shfl_xor(wl, o));
+    const int nb = 2 * k;
+    const uint32_t m0 = nb >= 32 ? 0xFFFFFFFFu : ((1u << nb) - 1u);
+    const uint32_t m1 = nb >= 64 ? 0xFFFFFFFFu : (nb > 32 ? ((1u << (nb - 32)) - 1u) : 0u);
+    const uint32_t m2 = nb > 64 ? ((1u << (nb - 64)) - 1u) : 0u;
+    uint32_t pp[R], h0[R], h1[R], h2[R], b0[R], b1[R], b2[R];
+    int bp[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) { pp[r] = ((pp0 >> (2 * r)) | (pp0 << (8 - 2 * r))) & 0xFFu; h0[r] = h1[r] = h2[r] = 0u; bp[r] = 0; }
+    const uint32_t *row = srow[threadIdx.x];
+    uint32_t cur = 0u;
+    auto step = [&](int pos) {                                                 // append the digit at `pos` to every round's value (pos: the same in every lane)
+        if ((pos & 15) == 0) cur = row[pos >> 4];
+        const uint32_t d2 = __builtin_amdgcn_ubfe(cur, (uint32_t) ((pos & 15) << 1), 2u) << 1;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const uint32_t dm = __builtin_amdgcn_ubfe(pp[r], d2, 2u);
+            h2[r] = __funnelshift_l(h1[r], h2[r], 2) & m2;
+            h1[r] = __funnelshift_l(h0[r], h1[r], 2) & m1;
+            h0[r] = ((h0[r] << 2) | dm) & m0;
+        }
+    };
+    for (int q = 0; q < k; q++) step(q);
+#pragma unroll
+    for (int r = 0; r < R; r++) { b0[r] = h0[r]; b1[r] = h1[r]; b2[r] = h2[r]; }
+    const int il = valid ? (len - k + 1 + intervals - 1) / intervals : 1;
+    int cnt = 0, next = il;
+    const uint32_t kbase = valid ? koff[t] : 0u;
+    auto emit = [&]() {                                                        // the interval's k-mer of every round -> memory
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            if (r >= rounds) continue;
+            const u128 v = ((u128) b2[r] << 64) | ((u128) b1[r] << 32) | (u128) b0[r];
+            const unsigned long long hsh = k <= 35 ? mod_hash_u70(v, T) : mod_hash_u128(v);
+            const unsigned long long m = hsh * PKB_KEY_MIX;
+            const size_t at = (size_t) r * round_stride + kbase + (uint32_t) cnt;
+            keys[at] = (m << sort_bits) | (m >> (64 - sort_bits));
+            vals[at] = ((unsigned long long) (4095 - bp[r]) << 40) | ((unsigned long long) (uint32_t) len << 28) | t;
+        }
+        cnt++;
+    };
+    for (int p = 1; p + k <= wl; p++) {
+        step(p + k - 1);
+        const bool inr = valid && p + k <= len;
+        const bool border = inr && p == next;
+        if (__ballot(border) != 0ull) {                                        // uniform: an interval closes in some lane
+            if (border) {
+                emit();
+                next += il;
+#pragma unroll
+                for (int r = 0; r < R; r++) { b0[r] = h0[r]; b1[r] = h1[r]; b2[r] = h2[r]; bp[r] = p; }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const unsigned long long hl = ((unsigned long long) h1[r] << 32) | h0[r], bl = ((unsigned long long) b1[r] << 32) | b0[r];
+            const bool lt = inr & !border & ((h2[r] < b2[r]) | ((h2[r] == b2[r]) & (hl < bl)));
+            b0[r] = lt ? h0[r] : b0[r]; b1[r] = lt ? h1[r] : b1[r]; b2[r] = lt ? h2[r] : b2[r]; bp[r] = lt ? p : bp[r];
+        }
+    }
+    if (valid) emit();
+}
+
 // The k-mer entries are radix-sorted on the low `bits` bits of the key only (half the passes of a full sort).  A run of equal
 // low bits nearly always is one group; where two keys share them (n^2 / 2^(bits+1) pairs) the run is ordered by the full
 // key, so that equal hashes are contiguous for everything downstream.  k_pkb_fix_flag lists the places (one streaming pass, no
@@ -1373,6 +1465,18 @@ void launch_pkb_kmers(const NodesDev &nd, const PkbCfg &c, const int32_t prio[4]
     const PkbTipRec *rec = (const PkbTipRec *) tiprec;
     if (nd.stride <= PKB_ROW_WORDS) hipLaunchKernelGGL(k_pkb_kmers<true>, dim3((n_tips + 255) / 256), dim3(256), 0, s, nd, c, pr, tips, koff, n_tips, sort_bits, keys, vals, rec, wide);
     else hipLaunchKernelGGL(k_pkb_kmers<false>, dim3((n_tips + 255) / 256), dim3(256), 0, s, nd, c, pr, tips, koff, n_tips, sort_bits, keys, vals, rec, wide);
+}
+
+// every round's k-mers at once (round 0's priority in prio[]; the arrays of round r start r * round_stride entries in).  false: the shape is
+// not this kernel's (rows not staged, k > 48, more than four rounds) -- the caller takes launch_pkb_kmers per round
+bool launch_pkb_kmers_all(const NodesDev &nd, const PkbCfg &c, const int32_t prio[4], int rounds, const uint32_t *tips, const uint32_t *koff, uint32_t n_tips, int sort_bits,
+                          unsigned long long *keys, unsigned long long *vals, size_t round_stride, const void *tiprec, hipStream_t s) {
+    if (nd.stride > PKB_ROW_WORDS || c.li_k > 48 || rounds < 1 || rounds > 4) return false;
+    if (n_tips == 0) return true;
+    const uint32_t pp0 = (uint32_t) prio[0] | ((uint32_t) prio[1] << 2) | ((uint32_t) prio[2] << 4) | ((uint32_t) prio[3] << 6);
+    hipLaunchKernelGGL((k_pkb_kmers_all<4>), dim3((n_tips + 255) / 256), dim3(256), 0, s, nd, c, pp0, rounds, tips, koff, n_tips, sort_bits, keys, vals, round_stride,
+                       (const PkbTipRec *) tiprec);
+    return true;
 }
 
 size_t pkb_tiprec_bytes(uint32_t n_tips) { return ((size_t) n_tips + 1) * sizeof(PkbTipRec); }

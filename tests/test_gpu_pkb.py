@@ -183,7 +183,7 @@ def test_supplement_groups_of_8_to_16_four_per_wave(eng, G, n, seed):
     c[flip] = (3 - c[flip])[:, ::-1]
     s_new = _supplement_vs_oracle(eng, c.astype(np.uint8))
     assert s_new["group_hist"][0][4] > 20, s_new["group_hist"]               # there are groups of 8 .. 15
-    for legacy in (1, 6, 120):                                                  # bit 0: a wave per group of 8 .. 16; bits 1, 2: the library's k-mer sort on 32 bits, the head list in three kernels; bits 3, 4, 5: replay inside the pair kernel, the library's unique after the merge, the 128-bit k-mer walk
+    for legacy in (1, 6, 248):                                                  # bit 0: a wave per group of 8 .. 16; bits 1, 2: the library's k-mer sort on 32 bits, the head list in three kernels; bits 3, 4, 5: replay inside the pair kernel, the library's unique after the merge, the 128-bit k-mer walk
         eng.set_option("pkb_legacy", legacy)
         try:
             s_old = _supplement_vs_oracle(eng, c.astype(np.uint8))
@@ -221,13 +221,14 @@ def test_supplement_reads_of_several_lengths(eng):
     s_new = eng.pkb_last_stats()
     assert len(want) > len(pre)
     assert got.shape == want.shape and (got == want).all()
-    eng.set_option("pkb_legacy", 32)
-    try:
-        old = eng.pkb_supplement_host(words, lens, pre, p)
-        s_old = eng.pkb_last_stats()
-    finally:
-        eng.set_option("pkb_legacy", 0)
-    assert (old == got).all() and s_old["kmers"] == s_new["kmers"] and s_old["groups"] == s_new["groups"]
+    for legacy in (32, 128):                                                   # the 128-bit walk per round; the 96-bit walk per round (default: all rounds in one walk)
+        eng.set_option("pkb_legacy", legacy)
+        try:
+            old = eng.pkb_supplement_host(words, lens, pre, p)
+            s_old = eng.pkb_last_stats()
+        finally:
+            eng.set_option("pkb_legacy", 0)
+        assert (old == got).all() and s_old["kmers"] == s_new["kmers"] and s_old["groups"] == s_new["groups"] and s_old["group_hist"] == s_new["group_hist"], legacy
 
 
 def test_supplement_rejects_offsets_it_cannot_represent(eng):

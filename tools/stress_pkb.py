@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised cross-check of the approximate supplement on the GPU: this round's kernels (tip records, four groups per wave, 96-bit k-mer walk,
-one-pass head list, own sorts, merge tail) against round 4's forms of the same steps (engine option pkb_legacy = 127: every piece switched
+one-pass head list, own sorts, merge tail) against round 4's forms of the same steps (engine option pkb_legacy = 255: every piece switched
 back), which the test suite holds to the oracle.  Same graph, same work counters, on random read sets: lengths 80 .. 250 (fixed or variable),
 coverage 8 .. 300, 1 .. 4 % substitutions, tandem repeats in a third of the cases.
 usage: tools/stress_pkb.py [n_cases=100] [first_seed=5000]"""
@@ -59,7 +59,7 @@ def main():
         p = eng.pkb_params(avg, max(err, 0.011), min(2 * lo // 3, 60))
         new = eng.pkb_supplement_host(words, lens, pre, p)
         s_new = eng.pkb_last_stats()
-        eng.set_option("pkb_legacy", 127)
+        eng.set_option("pkb_legacy", 255)
         try:
             old = eng.pkb_supplement_host(words, lens, pre, p)
             s_old = eng.pkb_last_stats()
