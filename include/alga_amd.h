@@ -168,7 +168,8 @@ int         alga_engine_device_name(const alga_engine *e, char *buf, size_t bufl
  *                                (the entries of consecutive sources packed densely onto the lanes), the general kernel on what it defers
  *   "pile"                       default 1: reads of one length without masks take the probe through PILES (alga_amd/csrc/prefsuf_pile.hip): one compare
  *                                of a source against the consensus of a minimizer's targets instead of one per target; 0: always the pairwise kernels;
- *                                2 (tests only): without the sample that leaves reads with errors to the pairwise kernels
+ *                                2 (tests only): without the sample that leaves reads with errors to the pairwise kernels; 3 (tests only): without it, in
+ *                                the MIXED form (ALGA_PILE_DECLINE_ONE_IN below): what the pile kernel hands on goes through k_probe_stream by list
  *   "pile_runs"                  default 1: the run list of a pile (what its members probe with) is computed from the pile's CONSENSUS, once per pile
  *                                (k_pile_runs_consensus), and the key pass of a build the pile path keeps makes the target keys alone -- own run lists
  *                                only for the entries outside a first group and the sources handed to the general kernel; 0: round 4's form (every
@@ -184,8 +185,14 @@ int         alga_engine_device_name(const alga_engine *e, char *buf, size_t bufl
  *   "auto_reduction_per_target"  != 0: alga_prefsuf_params.reduction == AUTO resolves to PER_TARGET
  *   "shard_bucket_max"           1..4096 (default 4096): run descriptors of ONE bucket the bucket-sharded join (alga_shard_join_device) takes; a
  *                                bucket with more makes the call answer ALGA_ERR_UNSUPPORTED (tests lower it to exercise that)
- *   "own_sort"                   default 1: the (key, id) sort of the index build is the engine's own radix sort (alga_amd/csrc/radix_sort.hip: stable LSD,
- *                                wave-match ranking, XCD-contiguous tiles); 0: rocPRIM's onesweep sort (what rounds 2-4 used; kept for A/B and tests)
+ *   "own_sort"                   default 1: the (key, id) sort of the index build and the descriptor sort of the bucket-sharded form are the engine's own
+ *                                radix sort (alga_amd/csrc/radix_sort.hip: stable LSD, wave-match ranking, XCD-contiguous tiles); 0: rocPRIM's onesweep
+ *                                sort (what rounds 2-4 used; kept for A/B and tests)
+ *   "pkb_legacy"                 default 0; A/B and tests: one bit per piece of the approximate supplement that round 5 reworked, set = round 4's form of it:
+ *                                1 groups of 8..16 k-mers a wave each (now four per wave), 2 the library's sort of the k-mer entries (now the engine's),
+ *                                4 group heads in three kernels (now one), 8 the replay of the 8..16 groups inside the pair kernel, 16 the library's sort /
+ *                                unique of the additions and a row-pointer pass, 32 the k-mer walk on a 128-bit value, 64 every tip record's snapshot
+ *                                half rewritten every round, 128 a k-mer walk per round (now all rounds in one)
  *   "test_pile_oom"              tests only.  != 0: the allocation of the pile path's own buffers (~180 B per node) answers ALGA_ERR_OUT_OF_MEMORY: the build
  *                                must give them back and finish on the pairwise kernels (what a real out-of-memory there does)
  *   "test_unsorted_index"        tests only.  != 0: the CLUSTER probe's entry directory is built over UNSORTED keys; the directory pass
