@@ -135,6 +135,44 @@ def test_pile_path_on_repeats_and_tandems(eng):
     assert st["pile_buckets"] > 0
 
 
+def test_mixed_form_is_chosen_on_the_device_for_a_genome_with_repeats(eng):
+    """A genome whose repeats (a twentieth of it: 1 kb units copied with a point difference or two) make 1 - 4 % of the buckets irregular: too many for
+    the pile kernels + general kernel alone (more than 1 in ALGA_PILE_IRREGULAR_ONE_IN), too few to leave the build to the pairwise kernels (fewer
+    than 1 in ALGA_PILE_DECLINE_ONE_IN).  The SAMPLE decides, on the device: the mixed form (alga_prefsuf_stats.pile_mixed) -- the sources
+    k_pile_probe hands on go through k_probe_stream by list, the general kernel gets what is left.  Error-free reads, 30x; the list must be the one
+    the pairwise kernels give (option pile = 0), which the rest of the suite holds to the oracle."""
+    import torch
+    from alga_amd.engine import device_view
+    rng = np.random.default_rng(404)
+    G = 1_500_000
+    genome = rng.integers(0, 4, size=G).astype(np.uint8)
+    for _ in range(75):                                                       # 75 x 1 kb copied elsewhere, two point differences each
+        a, b = (int(x) for x in rng.integers(0, G - 1000, size=2))
+        unit = genome[a:a + 1000].copy()
+        pos = rng.integers(0, 1000, size=2)
+        unit[pos] = (unit[pos] + 1 + rng.integers(0, 3, size=2)) % 4
+        genome[b:b + 1000] = unit
+    words, lens = _nodes(G * 30 // 150, 150, None, 405, genome=genome)
+    lo, rs = alga_amd.derive_params(144.0)
+    dw = torch.from_numpy(np.ascontiguousarray(words).view(np.int32)).cuda()
+    dl = torch.from_numpy(lens.astype(np.int32)).cuda()
+    n = len(lens)
+    ptr, m = eng.build_range_device(dw, dl, lo, rs, 0, n)
+    st = eng.last_stats()
+    got = device_view(ptr, (m, 3), dw.device).clone()
+    assert st["probe_used"] == 2 and st["pile_buckets"] > 0 and st["ms_pile"] > 0, st
+    assert st["pile_irregular"] * alga_amd.engine.PILE_IRREGULAR_ONE_IN > st["pile_buckets"], st        # too irregular for the pure form ...
+    assert st["pile_irregular"] * alga_amd.engine.PILE_DECLINE_ONE_IN <= st["pile_buckets"], st         # ... not enough to decline
+    assert st["pile_mixed"] == 1 and 0 < st["pile_deferred"] and st["deferred_sources"] < st["pile_deferred"], st
+    eng.set_option("pile", 0)
+    try:
+        ptr, m2 = eng.build_range_device(dw, dl, lo, rs, 0, n)
+        want = device_view(ptr, (m2, 3), dw.device).clone()
+    finally:
+        eng.set_option("pile", 1)
+    assert m == m2 and torch.equal(got, want)
+
+
 def test_reads_with_errors_leave_the_build_to_the_pairwise_kernels(eng):
     words, lens = _nodes(12_000, 150, 40_000, 23, err=0.02)
     lo, rs = alga_amd.derive_params(144.0)
