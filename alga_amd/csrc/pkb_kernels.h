@@ -22,11 +22,9 @@ void launch_can_align_batch(const NodesDev &nd, const PkbCfg &c, const int32_t *
 void launch_li_kmers_slots(const NodesDev &nd, const PkbCfg &c, const int32_t prio[4], uint64_t *hash, int32_t *ind, int32_t *count, hipStream_t s);
 void launch_pkb_edge_keys(const alga_edge_dev *e, uint64_t n, unsigned long long *keys, unsigned long long *counts /* [0] bad offsets, [1] unsorted */, hipStream_t s);
 void launch_pkb_rowptr(const unsigned long long *keys, uint64_t E, int32_t n, uint32_t *rowptr, hipStream_t s);
-// the additions in key order: src << shift as a 32-bit sort key, the keys by sorted position, every run of one src put in order
+// the additions in key order: src << shift as a 32-bit sort key; then the keys by sorted position with every run of one src put in order
 void launch_pkb_src_keys(const unsigned long long *keys, uint64_t n, int shift, uint32_t *k32, hipStream_t s);
-void launch_pkb_gather_keys(const unsigned long long *keys, const uint32_t *idx, uint64_t n, unsigned long long *out, hipStream_t s);
-void launch_pkb_sort_src_runs(unsigned long long *keys, uint64_t n, hipStream_t s);
-void launch_pkb_gather_sorted_runs(const unsigned long long *keys, const uint32_t *k32_sorted, const uint32_t *idx, uint64_t n, unsigned long long *out, hipStream_t s);   // the two in one
+void launch_pkb_gather_sorted_runs(const unsigned long long *keys, const uint32_t *k32_sorted, const uint32_t *idx, uint64_t n, unsigned long long *out, hipStream_t s);
 // first key per (src, dst) of a sorted key list: flags, then (after an exclusive scan of them into pos) the kept keys and the row pointers of the result
 void launch_pkb_unique_flags(const unsigned long long *in, uint64_t n, uint32_t *flag, hipStream_t s);
 void launch_pkb_unique_scatter(const unsigned long long *in, uint64_t n, const uint32_t *flag, const uint32_t *pos, int32_t n_nodes, unsigned long long *out,

@@ -185,13 +185,8 @@ __global__ void __launch_bounds__(256) k_pkb_src_keys(const unsigned long long *
         k32[i] = (uint32_t) pkb_key_src(keys[i]) << shift;
 }
 
-__global__ void __launch_bounds__(256) k_pkb_gather_keys(const unsigned long long *__restrict__ keys, const uint32_t *__restrict__ idx, uint64_t n,
-                                                          unsigned long long *__restrict__ out) {
-    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) out[i] = keys[idx[i]];
-}
-
-// the two kernels above in one: the thread at the first position of a src run (read off the SORTED 32-bit keys) fetches the run's keys by their
-// positions, orders them in registers (runs of up to eight keys: all but a handful) and writes them where they belong
+// the thread at the first position of a src run (read off the SORTED 32-bit keys) fetches the run's keys by their positions, orders them in
+// registers (runs of up to eight keys: all but a handful) and writes them where they belong
 __global__ void __launch_bounds__(256) k_pkb_gather_sorted_runs(const unsigned long long *__restrict__ keys, const uint32_t *__restrict__ k32s, const uint32_t *__restrict__ idx,
                                                                  uint64_t n, unsigned long long *__restrict__ out) {
     for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) {
@@ -217,21 +212,6 @@ __global__ void __launch_bounds__(256) k_pkb_gather_sorted_runs(const unsigned l
                 while (b > i && out[b - 1] > kx) { out[b] = out[b - 1]; b--; }
                 out[b] = kx;
             }
-        }
-    }
-}
-
-__global__ void __launch_bounds__(256) k_pkb_sort_src_runs(unsigned long long *__restrict__ keys, uint64_t n) {
-    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) {
-        const int src = pkb_key_src(keys[i]);
-        if (i > 0 && pkb_key_src(keys[i - 1]) == src) continue;                  // not the first key of its run
-        uint64_t e = i + 1;
-        while (e < n && pkb_key_src(keys[e]) == src) e++;
-        for (uint64_t a = i + 1; a < e; a++) {                                    // insertion sort (nobody else touches this run)
-            const unsigned long long k = keys[a];
-            uint64_t b = a;
-            while (b > i && keys[b - 1] > k) { keys[b] = keys[b - 1]; b--; }
-            keys[b] = k;
         }
     }
 }
@@ -713,23 +693,6 @@ __device__ __forceinline__ void pkb_stage_rec_row(const PkbTipRec *__restrict__ 
     const uint4 *src = reinterpret_cast<const uint4 *>(r->words);
 #pragma unroll
     for (int q = 0; q < PKB_ROW_WORDS / 4; q++) { const uint4 x = src[q]; dst[4 * q] = x.x; dst[4 * q + 1] = x.y; dst[4 * q + 2] = x.z; dst[4 * q + 3] = x.w; }
-    dst[PKB_ROW_WORDS] = 0u;
-}
-
-// one row of a node into LDS: PKB_ROW_WORDS words + a zero word behind them
-__device__ __forceinline__ void pkb_stage_row(const NodesDev &nd, int id, uint32_t *dst) {
-    const uint32_t *src = nd.words + (size_t) id * nd.stride;
-    if ((nd.stride & 3) == 0) {
-#pragma unroll
-        for (int q = 0; q < PKB_ROW_WORDS / 4; q++) {
-            uint4 x = make_uint4(0u, 0u, 0u, 0u);
-            if (4 * q < nd.stride) x = *reinterpret_cast<const uint4 *>(src + 4 * q);
-            dst[4 * q] = x.x; dst[4 * q + 1] = x.y; dst[4 * q + 2] = x.z; dst[4 * q + 3] = x.w;
-        }
-    } else {
-#pragma unroll
-        for (int q = 0; q < PKB_ROW_WORDS; q++) dst[q] = q < nd.stride ? src[q] : 0u;
-    }
     dst[PKB_ROW_WORDS] = 0u;
 }
 
@@ -1415,14 +1378,8 @@ void launch_pkb_rowptr(const unsigned long long *keys, uint64_t E, int32_t n, ui
 void launch_pkb_src_keys(const unsigned long long *keys, uint64_t n, int shift, uint32_t *k32, hipStream_t s) {
     if (n) hipLaunchKernelGGL(k_pkb_src_keys, dim3(pkb_grid(n, 256, 8192)), dim3(256), 0, s, keys, n, shift, k32);
 }
-void launch_pkb_gather_keys(const unsigned long long *keys, const uint32_t *idx, uint64_t n, unsigned long long *out, hipStream_t s) {
-    if (n) hipLaunchKernelGGL(k_pkb_gather_keys, dim3(pkb_grid(n, 256, 8192)), dim3(256), 0, s, keys, idx, n, out);
-}
 void launch_pkb_gather_sorted_runs(const unsigned long long *keys, const uint32_t *k32_sorted, const uint32_t *idx, uint64_t n, unsigned long long *out, hipStream_t s) {
     if (n) hipLaunchKernelGGL(k_pkb_gather_sorted_runs, dim3(pkb_grid(n, 256, 16384)), dim3(256), 0, s, keys, k32_sorted, idx, n, out);
-}
-void launch_pkb_sort_src_runs(unsigned long long *keys, uint64_t n, hipStream_t s) {
-    if (n) hipLaunchKernelGGL(k_pkb_sort_src_runs, dim3(pkb_grid(n, 256, 16384)), dim3(256), 0, s, keys, n);
 }
 
 void launch_pkb_unique_flags(const unsigned long long *in, uint64_t n, uint32_t *flag, hipStream_t s) {
