@@ -320,8 +320,11 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
             // THIS build's data, not from an earlier build.
             if (e->opt_cluster_pairs && pp.local_sw == 1 && pp.cluster_eq <= 4) {      // (k_probe_stream: one-word offset masks, rows of up to 13 words)
                 if ((rc = alga_ensure(e, e->cl_defer, (size_t) (n_src + 64) * sizeof(int32_t)))) return rc;
-                if ((rc = alga_ensure(e, e->loc_second, (size_t) (n_src + 1) * sizeof(unsigned long long)))) return rc;
+                // (three further slots per source: k_probe_stream finishes sources with up to four standing items -- option stream_slots = 2: two, as until round 4)
+                const uint32_t slot_stride = e->opt_stream_slots >= 4 ? (uint32_t) (n_src + 1) : 0u;
+                if ((rc = alga_ensure(e, e->loc_second, (size_t) (slot_stride ? 3 : 1) * (n_src + 1) * sizeof(unsigned long long)))) return rc;
                 e->loc_second_used = true;
+                e->loc_slot_stride = slot_stride;
                 // all sources: in the order of the entry array (consecutive sources share a locus: option cluster_order); a range of
                 // ids (a rank's share, a piece): in id order
                 const bool by_key = e->opt_cluster_order != 0 && src_begin == 0 && src_end == nd.n;
@@ -341,7 +344,7 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
                 launch_probe_stream(nd, cfg, cc, pp.cluster_eq, e->cl_store.p, e->cl_dir.p, e->cl_runs.p, (const uint8_t *) e->cl_nruns.p,
                                     src_begin, src_end, by_key, cnt, e->n_cu, (uint32_t *) e->outdeg.p, (unsigned long long *) e->loc_first.p,
                                     (unsigned long long *) e->loc_second.p, (int32_t *) e->cl_defer.p, (uint32_t) n_src,
-                                    piled ? (const unsigned long long *) e->cl_pile_cnt.p : nullptr, s);
+                                    piled ? (const unsigned long long *) e->cl_pile_cnt.p : nullptr, s, slot_stride);
                 if ((rc = alga_check_launch(e, "k_probe_stream"))) return rc;
                 if (piled) {
                     // the MIXED form (more than one irregular bucket in 250, not more than one in 20 -- the kernels read the sample's counters themselves):
@@ -349,7 +352,7 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
                     if ((rc = alga_ensure(e, e->cl_defer2, (size_t) (n_src + 64) * sizeof(int32_t)))) return rc;
                     launch_probe_stream_list(nd, cfg, cc, pp.cluster_eq, e->cl_store.p, e->cl_dir.p, e->cl_runs.p, (const uint8_t *) e->cl_nruns.p, (int32_t *) e->cl_defer.p,
                                              (uint32_t) n_src, cnt, e->n_cu, (uint32_t *) e->outdeg.p, (unsigned long long *) e->loc_first.p,
-                                             (unsigned long long *) e->loc_second.p, (int32_t *) e->cl_defer2.p, (const unsigned long long *) e->cl_pile_cnt.p, s);
+                                             (unsigned long long *) e->loc_second.p, (int32_t *) e->cl_defer2.p, (const unsigned long long *) e->cl_pile_cnt.p, s, slot_stride);
                     if ((rc = alga_check_launch(e, "k_probe_stream (list)"))) return rc;
                 }
                 HIP_TRY(e, hipEventRecord(e->ev[EV_PAIRS], s));
@@ -532,7 +535,8 @@ int finalize_local(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_
     launch_local_emit(src_begin, (int32_t) n_src, (const uint32_t *) e->outdeg.p, (const unsigned long long *) e->loc_first.p,
                       e->loc_second_used ? (const unsigned long long *) e->loc_second.p : nullptr, (const uint32_t *) e->rec_dst.p, (const unsigned long long *) e->rec_val.p, n_rec, (const uint32_t *) e->out_rowptr.p,
                       (uint32_t *) e->out_cnt.p, (alga_edge_dev *) e->edges.p,
-                      e->defer_list_valid ? (const int32_t *) e->cl_defer.p : nullptr, (const unsigned long long *) e->counters.p + CNT_DEFERRED, (uint32_t) n_src, s);
+                      e->defer_list_valid ? (const int32_t *) e->cl_defer.p : nullptr, (const unsigned long long *) e->counters.p + CNT_DEFERRED, (uint32_t) n_src, s,
+                      e->loc_second_used ? e->loc_slot_stride : 0u);
     if ((rc = alga_check_launch(e, "k_local_emit"))) return rc;
     HIP_TRY(e, hipEventRecord(e->ev[EV_EMIT], s));
     uint64_t *d_total = (uint64_t *) e->scan_scratch.p + scan_total_index(n_src);
@@ -683,6 +687,8 @@ int alga_engine_set_option(alga_engine *e, const char *name, int64_t value) {
         e->opt_shard_dmax = (int) std::max<int64_t>(1, std::min<int64_t>(value, 4096));
     } else if (!strcmp(name, "rsort_variant")) {
         rsort_set_variant((int) value);                    // tuning only (process-wide): tile shape of radix_sort.hip
+    } else if (!strcmp(name, "stream_slots")) {
+        e->opt_stream_slots = value >= 4 ? 4 : 2;
     } else if (!strcmp(name, "pkb_legacy")) {
         e->opt_pkb_legacy = (int) value;
     } else if (!strcmp(name, "own_sort")) {
@@ -720,7 +726,7 @@ int alga_engine_reserve(alga_engine *e, int32_t n_nodes, int32_t max_len, int32_
         if ((rc = cluster_alloc(e, pp))) return rc;
         if (max_len - min_overlap <= 63 && eq <= 4) {
             if ((rc = alga_ensure(e, e->cl_defer, (size_t) (n + 64) * sizeof(int32_t)))) return rc;
-            if ((rc = alga_ensure(e, e->loc_second, (size_t) (n + 1) * sizeof(unsigned long long)))) return rc;
+            if ((rc = alga_ensure(e, e->loc_second, (size_t) (e->opt_stream_slots >= 4 ? 3 : 1) * (n + 1) * sizeof(unsigned long long)))) return rc;
         }
         // the pile path, should the reads turn out to have one length and no masks (what reserve assumes: it is told one length)
         if (e->opt_pile != 0 && e->opt_cluster_pairs != 0 && e->opt_cluster_order != 0 && max_len - min_overlap <= 63 && pile_plan(pp.cfg, pp.cluster, eq, max_len, false)) {

@@ -75,6 +75,8 @@ struct alga_engine {
     DevBuf cl_keys[2], cl_vals[2], cl_meta, cl_runs, cl_nruns, cl_store, cl_dir;   // clustered minimizer join: sort buffers, per-node minimizer runs, entry array, bucket directory
     DevBuf loc_second;                                      // ... the other edge of a two-edge source the pair kernel finished (clustered probe)
     bool   loc_second_used = false;                         // the last discovery wrote loc_second
+    uint32_t loc_slot_stride = 0;                           // ... with three slots per source, this many entries apart (0: one slot)
+    int    opt_stream_slots = 4;                            // option "stream_slots": standing items of a source k_probe_stream writes to slots itself (4; 2: round 4's form)
     DevBuf loc_first, loc_big_list, loc_big_items;          // source-side form: one-edge slots; second pass over repeat-rich sources
     int    big_limit = -1;                                  // largest per-wave item slice of that pass; -1 = built-in (option "local_big_max": tests)
     DevBuf edge_keys, edge_keys2, edge_vals, edge_vals2, edges_sorted, xs_dst, xs_val;

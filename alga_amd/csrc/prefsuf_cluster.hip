@@ -737,6 +737,7 @@ k_probe_stream(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__restri
     const int32_t src_end = LIST ? (int32_t) min(*src_count, (unsigned long long) src_end_a) : src_end_a;       // (list mode: src_end_a = the list's capacity)
     if (LIST && src_end <= 0) return;
     constexpr int CNT_DEFER_AT = LIST ? CNT_DEFERRED2 : CNT_DEFERRED;
+    const uint32_t max_stand = o.slot_stride ? 4u : 2u;    // standing items a source may have and still finish here: one slot in first[], the others in second[]
     constexpr int WC = 4 * EQ - 3;                         // row words of an entry
     constexpr int QW = 24;                                 // staged words per source: the row (<= 13) + the compare's slack, words 16.. stay zero
     constexpr int NS = 12;                                 // source slots: three quads
@@ -1103,52 +1104,60 @@ k_probe_stream(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__restri
                 o.deg[Bs - o.src_base] = 1u;
                 st_rec++;
             }
-            // Two items stand (a coverage gap too long for any big via; 1.7 % of the sources at 30x): the rest of local_reduce's
-            // "several stand" branch for exactly two -- the per-source cap (with one item per offset the three largest small (L, C)
-            // are the three small items at the smallest offsets) and "the same target at a smaller offset supersedes" -- and the
-            // one or two edges go to the source's two slots.
-            const bool two = keep && stv == 0x200u;
-            if (__ballot(two) != 0ull) {                   // uniform
+            // Several items stand -- a coverage gap too long for any big via (1.7 % of the sources at 30x), or, with sequencing errors, targets with
+            // an error in their overhang, which nobody implies (at 0.2 % substitutions most of what this kernel handed on: round 5) -- : the rest
+            // of local_reduce's "several stand" branch for two to `max_stand` of them: the per-source cap (with one item per offset the three
+            // largest small (L, C) are the three small items at the smallest offsets), "the same target at a smaller offset supersedes", and the
+            // edges go to the source's slots: first[], then second[] with `slot_stride` entries per further slot.
+            const uint32_t nst = stv >> 8;
+            const bool seg_multi = ev && (stv & 255u) == 0u && nst >= 2u && nst <= max_stand;        // (the same in every lane of a source)
+            if (__ballot(seg_multi) != 0ull) {             // uniform
                 uint64_t segm = 0ull;                      // the lanes of this lane's source
 #pragma unroll
                 for (int q = 0; q < 8; q++) { const uint64_t mq = __ballot(ev && s8 == q); segm = s8 == q ? mq : segm; }
-                const uint64_t km = __ballot(keep) & segm;
-                const int la = km ? __builtin_ctzll(km) : 0, lb = km ? 63 - __builtin_clzll(km) : 0;
+                const uint64_t km = __ballot(keep) & segm;                      // the standing items of this lane's source
                 const int ds0 = lenBs - cfg.rsoemo + 1;                         // first offset of a small overlap
                 const uint64_t lowm = ds0 <= 0 ? 0ull : (ds0 >= 64 ? ~0ull : ((1ull << ds0) - 1ull));
                 const bool my_kept = pass && (d < ds0 || __popcll(below & ~lowm) < 3);
-                const uint32_t Ca = bperm(id, la), Cb = bperm(id, lb);
-                const int da = (int) bperm((uint32_t) d, la), db = (int) bperm((uint32_t) d, lb);
-                const bool ka = bperm(my_kept ? 1u : 0u, la) != 0u, kb = bperm(my_kept ? 1u : 0u, lb) != 0u;
-                const bool fa = ka && (__ballot(my_kept && id == Ca && d < da) & segm) == 0ull;
-                const bool fb = kb && (__ballot(my_kept && id == Cb && d < db) & segm) == 0ull;
-                if (two) {
+                bool fin_me = false;                       // this lane's item is an edge of its source
+                uint64_t kmr = seg_multi ? km : 0ull;
+                for (int it = 0; it < 4; it++) {           // uniform: one standing item of every source per step
+                    if (__ballot(kmr != 0ull) == 0ull) break;
+                    const bool on = kmr != 0ull;
+                    const int sl = on ? __builtin_ctzll(kmr) : lane;
+                    kmr = on ? kmr & (kmr - 1ull) : 0ull;
+                    const uint32_t Cs = bperm(id, sl);
+                    const int dsl = (int) bperm((uint32_t) d, sl);
+                    const bool ks = bperm(my_kept ? 1u : 0u, sl) != 0u;
+                    const uint64_t supm = __ballot(on && my_kept && id == Cs && d < dsl) & segm;   // a kept item of the same target further left
+                    if (on && lane == sl) fin_me = ks && supm == 0ull;
+                }
+                const uint64_t F = __ballot(fin_me) & segm;
+                if (fin_me) {
+                    const int r = __popcll(F & ((1ull << lane) - 1ull));
                     const unsigned long long mine = ((unsigned long long) id << 32) | (uint32_t) d;
-                    if (lane == la && fa) { o.first[Bs - o.src_base] = mine; o.deg[Bs - o.src_base] = (fb ? 2u : 1u); st_rec++; }
-                    if (lane == lb && fb) {
-                        if (fa) o.second[Bs - o.src_base] = mine;
-                        else { o.first[Bs - o.src_base] = mine; o.deg[Bs - o.src_base] = 1u; }
-                        st_rec++;
-                    }
+                    if (r == 0) { o.first[Bs - o.src_base] = mine; o.deg[Bs - o.src_base] = (uint32_t) __popcll(F); }
+                    else o.second[(size_t) (r - 1) * o.slot_stride + (size_t) (Bs - o.src_base)] = mine;
+                    st_rec++;
                 }
             }
         }
         if (STATS) {
             st_rounds++;
-            const bool fin = ev && (stv & 255u) == 0u && (stv >> 8) <= 2u;      // this lane's source finishes here
+            const bool fin = ev && (stv & 255u) == 0u && (stv >> 8) <= max_stand;      // this lane's source finishes here
             st_slots += fin; st_raw += fin && pass; st_cmp += (fin && has_pred ? 1 : 0) + (fin ? n_tried2 : 0);
         }
         // ---- (5) the leader of a row: are its sources of quad 0 / quad 1 finished?  (status word of the round that packed them) ----
         if (gl == 0) {
             if (g >= cur && g < e) {
                 const uint32_t sv = sStat[wave][4 * b0 + g];
-                const bool ok = ((fl0 >> g) & 1u) != 0u && (sv & 255u) == 0u && (sv >> 8) <= 2u;
+                const bool ok = ((fl0 >> g) & 1u) != 0u && (sv & 255u) == 0u && (sv >> 8) <= max_stand;
                 red = ok ? red | 1u : red & ~1u;
                 if (STATS && ok) st_win += (uint64_t) ((int) sSrc[wave][4 * b0 + g].y - cfg.Lmin + 1);
             }
             if (4 + g >= cur && 4 + g < e) {
                 const uint32_t sv = sStat[wave][4 * b1 + g];
-                const bool ok = ((fl1 >> g) & 1u) != 0u && (sv & 255u) == 0u && (sv >> 8) <= 2u;
+                const bool ok = ((fl1 >> g) & 1u) != 0u && (sv & 255u) == 0u && (sv >> 8) <= max_stand;
                 red = ok ? red | 2u : red & ~2u;
                 if (STATS && ok) st_win += (uint64_t) ((int) sSrc[wave][4 * b1 + g].y - cfg.Lmin + 1);
             }
@@ -1363,7 +1372,7 @@ uint64_t cluster_record_slack(int n_cu, uint64_t n_src) { return cluster_probe_b
 void launch_probe_stream(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterCfg &cc, int eq, const void *store, const void *dir,
                          const void *runs, const uint8_t *nruns, int32_t src_begin, int32_t src_end, bool by_key, unsigned long long *counters, int n_cu,
                          uint32_t *deg, unsigned long long *first, unsigned long long *second, int32_t *defer_list, uint32_t defer_cap,
-                         const unsigned long long *pile_cnt, hipStream_t s) {
+                         const unsigned long long *pile_cnt, hipStream_t s, uint32_t slot_stride) {
     const int64_t ns = (int64_t) src_end - src_begin;
     if (ns <= 0) return;
     const uint64_t quads = ((uint64_t) ns + 3) / 4;
@@ -1372,6 +1381,7 @@ void launch_probe_stream(const NodesDev &nd, const PrefSufCfg &cfg, const Cluste
     dim3 grid((unsigned) std::max<uint64_t>(1, std::min<uint64_t>((quads + PROBE_WAVES - 1) / PROBE_WAVES, (uint64_t) std::max(1, n_cu) * clq_occ(eq <= 3 ? eq : 4, kfs, by_key)))),
          block(PROBE_WAVES * 64);
     ProbeOut o{nullptr, nullptr, 0, counters, deg, first, by_key ? 0 : src_begin, second};
+    o.slot_stride = slot_stride;
     const uint4 *st = (const uint4 *) store;
 #define CLQ_LAUNCH(ST, E, K, BK) hipLaunchKernelGGL((k_probe_stream<ST, E, K, BK>), grid, block, 0, s, nd, cfg, cc, st, (const uint4 *) dir, (const uint2 *) runs, nruns, src_begin, src_end, o, defer_list, defer_cap, pile_cnt, \
                                                     (const int32_t *) nullptr, (const unsigned long long *) nullptr)
@@ -1401,12 +1411,13 @@ __global__ void __launch_bounds__(256) k_defer_swap(const unsigned long long *__
 
 void launch_probe_stream_list(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterCfg &cc, int eq, const void *store, const void *dir, const void *runs, const uint8_t *nruns,
                               int32_t *src_list, uint32_t list_cap, unsigned long long *counters, int n_cu, uint32_t *deg, unsigned long long *first,
-                              unsigned long long *second, int32_t *defer2, const unsigned long long *pile_cnt, hipStream_t s) {
+                              unsigned long long *second, int32_t *defer2, const unsigned long long *pile_cnt, hipStream_t s, uint32_t slot_stride) {
     if (eq != 3 || list_cap == 0) return;                  // (the pile path takes entries of three pieces only: pile_plan)
     const int kf = (2 * cfg.Lmin) >> 5;
     const int kfs = (kf == 5 || kf == 3) ? kf : 0;
     const dim3 grid((unsigned) std::max(1, n_cu) * clq_occ(3, kfs, false)), block(PROBE_WAVES * 64);
     ProbeOut o{nullptr, nullptr, 0, counters, deg, first, 0, second};
+    o.slot_stride = slot_stride;
 #define CLQ_LIST(K) hipLaunchKernelGGL((k_probe_stream<false, 3, K, false, true>), grid, block, 0, s, nd, cfg, cc, (const uint4 *) store, (const uint4 *) dir, (const uint2 *) runs, nruns, 0, \
                                        (int32_t) std::min<uint32_t>(list_cap, 0x7FFFFFFFu), o, defer2, list_cap, pile_cnt, (const int32_t *) src_list, (const unsigned long long *) (counters + CNT_DEFERRED))
     if (kf == 5) CLQ_LIST(5); else if (kf == 3) CLQ_LIST(3); else CLQ_LIST(0);

@@ -39,7 +39,7 @@ uint64_t probe_record_slack(int n_cu, uint64_t n_src, bool local);
 // *record_sources_count (device), at most record_sources_cap
 void launch_local_emit(int32_t src_base, int32_t n_src, const uint32_t *deg, const unsigned long long *first, const unsigned long long *second,
                        const uint32_t *rec_dst, const unsigned long long *rec_val, uint64_t n_rec, const uint32_t *rowptr, uint32_t *cursor,
-                       alga_edge_dev *edges, const int32_t *record_sources, const unsigned long long *record_sources_count, uint32_t record_sources_cap, hipStream_t s);
+                       alga_edge_dev *edges, const int32_t *record_sources, const unsigned long long *record_sources_count, uint32_t record_sources_cap, hipStream_t s, uint32_t slot_stride = 0);
 
 // clustered minimizer join (prefsuf_cluster.hip): source-side form with one-word offset masks (max_len - Lmin <= 63)
 bool       cluster_plan(const PrefSufCfg &cfg, int max_len, uint64_t live, int bucket_log2_bias, ClusterCfg *c, int *eq);   // false: this probe does not take the input
@@ -69,7 +69,7 @@ void       launch_probe_stream(const NodesDev &nd, const PrefSufCfg &cfg, const 
                                const void *runs, const uint8_t *nruns, int32_t src_begin, int32_t src_end, bool by_key /* the range is one of entry-array positions */,
                                unsigned long long *counters, int n_cu, uint32_t *deg, unsigned long long *first, unsigned long long *second, int32_t *defer_list,
                                uint32_t defer_cap, const unsigned long long *pile_cnt /* null, or the pile kernel's two counters: leave at once where that kernel works */,
-                               hipStream_t s);
+                               hipStream_t s, uint32_t slot_stride = 0 /* != 0: second[] holds three slots per source, slot_stride entries apart */);
 // the probe through piles (prefsuf_pile.hip)
 void       launch_pile_deg(int32_t n, unsigned long long *first, uint32_t *deg, const unsigned long long *pile_cnt, hipStream_t s);
 bool       pile_plan(const PrefSufCfg &cfg, const ClusterCfg &cc, int eq, int uniform_len, bool masks);
@@ -88,7 +88,7 @@ void       launch_pile_check(const void *side, uint64_t n_entries, uint32_t n_bu
 // mixed form of a pile-path build: k_probe_stream over the sources on src_list (count on the device: counters[CNT_DEFERRED]), rejects to defer2, then the swap
 void       launch_probe_stream_list(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterCfg &cc, int eq, const void *store, const void *dir, const void *runs, const uint8_t *nruns,
                                     int32_t *src_list, uint32_t list_cap, unsigned long long *counters, int n_cu, uint32_t *deg, unsigned long long *first,
-                                    unsigned long long *second, int32_t *defer2, const unsigned long long *pile_cnt, hipStream_t s);
+                                    unsigned long long *second, int32_t *defer2, const unsigned long long *pile_cnt, hipStream_t s, uint32_t slot_stride = 0);
 void       launch_pile_probe(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterCfg &cc, int uniform_len, const void *tab, uint32_t epoch, const void *rec, const void *rec2, const void *side,
                              const void *runs, unsigned long long *counters, uint32_t *deg, unsigned long long *first, unsigned long long *second, int32_t *defer_list,
                              uint32_t defer_cap, const unsigned long long *pile_cnt, int n_cu, hipStream_t s);

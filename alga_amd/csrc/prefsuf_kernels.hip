@@ -984,9 +984,11 @@ __global__ void __launch_bounds__(256) k_keys_to_edges(const unsigned long long 
 // are in the record list and take their slot with a cursor (rows with more than one edge are ordered by k_sort_rows).
 // `second` (may be null): a source with out-degree 2 whose first slot is set has its other edge there (the pair kernel of the
 // clustered probe finishes two-edge sources in slots too); k_sort_rows orders the two.
+// slot_stride != 0 (round 5): a source with out-degree 3 or 4 whose first slot is set has its third and fourth edge in second[slot_stride + i],
+// second[2 * slot_stride + i] (k_probe_stream finishes sources with up to four standing items).
 __global__ void __launch_bounds__(256) k_local_emit_first(int32_t src_base, int32_t n_src, const uint32_t *__restrict__ deg,
                                                            const unsigned long long *__restrict__ first, const unsigned long long *__restrict__ second,
-                                                           const uint32_t *__restrict__ rowptr, alga_edge_dev *__restrict__ edges) {
+                                                           const uint32_t *__restrict__ rowptr, alga_edge_dev *__restrict__ edges, uint32_t slot_stride) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_src) return;
     const uint32_t dg = deg[i];
@@ -997,6 +999,20 @@ __global__ void __launch_bounds__(256) k_local_emit_first(int32_t src_base, int3
     e.src = src_base + i; e.dst = (int32_t) (uint32_t) (f >> 32); e.offset = (int32_t) (uint32_t) f;
     const uint32_t at = rowptr[i];
     edges[at] = e;
+    if (dg >= 3u && dg <= 4u && second != nullptr && slot_stride != 0u) {      // up to four slots: left in (dst, offset) order as well
+        unsigned long long k[4];
+        k[0] = f;
+#pragma unroll
+        for (int q = 1; q < 4; q++) k[q] = (uint32_t) q < dg ? second[(size_t) (q - 1) * slot_stride + (size_t) i] : ~0ull;       // (dst in the high half: order by (dst, offset) == by value)
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int b = (a & 1); b + 1 < 4; b += 2) { const unsigned long long lo = min(k[b], k[b + 1]), hi = max(k[b], k[b + 1]); k[b] = lo; k[b + 1] = hi; }
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if ((uint32_t) q < dg) { alga_edge_dev x; x.src = src_base + i; x.dst = (int32_t) (uint32_t) (k[q] >> 32); x.offset = (int32_t) (uint32_t) k[q]; edges[at + q] = x; }
+        return;
+    }
     if (dg == 2u && second != nullptr) {                   // both slots: left in (dst, offset) order, so that such a row needs no k_sort_rows
         const unsigned long long g = second[i];
         alga_edge_dev e2 = e;
@@ -1254,13 +1270,14 @@ void launch_probe(const NodesDev &nd, const PrefSufCfg &cfg, const unsigned long
 
 void launch_local_emit(int32_t src_base, int32_t n_src, const uint32_t *deg, const unsigned long long *first, const unsigned long long *second,
                        const uint32_t *rec_dst, const unsigned long long *rec_val, uint64_t n_rec, const uint32_t *rowptr, uint32_t *cursor,
-                       alga_edge_dev *edges, const int32_t *record_sources, const unsigned long long *record_sources_count, uint32_t record_sources_cap, hipStream_t s) {
+                       alga_edge_dev *edges, const int32_t *record_sources, const unsigned long long *record_sources_count, uint32_t record_sources_cap, hipStream_t s,
+                       uint32_t slot_stride) {
     if (n_src <= 0) return;
     // the cursors of the record rows start at zero: all of them, or those of the listed sources alone
     if (record_sources) hipLaunchKernelGGL(k_zero_cursors_list, dim3(std::min<unsigned>(grid_for((uint64_t) record_sources_cap, 256), 2048u)), dim3(256), 0, s, record_sources, record_sources_count,
                                            record_sources_cap, src_base, cursor);
     else (void) hipMemsetAsync(cursor, 0, (size_t) (n_src + 1) * sizeof(uint32_t), s);
-    hipLaunchKernelGGL(k_local_emit_first, dim3(grid_for((uint64_t) n_src, 256)), dim3(256), 0, s, src_base, n_src, deg, first, second, rowptr, edges);
+    hipLaunchKernelGGL(k_local_emit_first, dim3(grid_for((uint64_t) n_src, 256)), dim3(256), 0, s, src_base, n_src, deg, first, second, rowptr, edges, slot_stride);
     if (n_rec) {
         unsigned g = std::min<unsigned>(grid_for(n_rec, 256), 4096u);
         hipLaunchKernelGGL(k_local_emit_records, dim3(std::max(1u, g)), dim3(256), 0, s, src_base, rec_dst, rec_val, n_rec, rowptr, cursor, edges);
