@@ -320,9 +320,9 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
             // THIS build's data, not from an earlier build.
             if (e->opt_cluster_pairs && pp.local_sw == 1 && pp.cluster_eq <= 4) {      // (k_probe_stream: one-word offset masks, rows of up to 13 words)
                 if ((rc = alga_ensure(e, e->cl_defer, (size_t) (n_src + 64) * sizeof(int32_t)))) return rc;
-                // (three further slots per source: k_probe_stream finishes sources with up to four standing items -- option stream_slots = 2: two, as until round 4)
+                // (LOCAL_SLOTS_MAX - 1 further slots per source: k_probe_stream finishes sources with up to four standing items -- option stream_slots = 2: two, as until round 4)
                 const uint32_t slot_stride = e->opt_stream_slots >= 4 ? (uint32_t) (n_src + 1) : 0u;
-                if ((rc = alga_ensure(e, e->loc_second, (size_t) (slot_stride ? 3 : 1) * (n_src + 1) * sizeof(unsigned long long)))) return rc;
+                if ((rc = alga_ensure(e, e->loc_second, (size_t) (slot_stride ? LOCAL_SLOTS_MAX - 1 : 1) * (n_src + 1) * sizeof(unsigned long long)))) return rc;
                 e->loc_second_used = true;
                 e->loc_slot_stride = slot_stride;
                 // all sources: in the order of the entry array (consecutive sources share a locus: option cluster_order); a range of
@@ -726,7 +726,7 @@ int alga_engine_reserve(alga_engine *e, int32_t n_nodes, int32_t max_len, int32_
         if ((rc = cluster_alloc(e, pp))) return rc;
         if (max_len - min_overlap <= 63 && eq <= 4) {
             if ((rc = alga_ensure(e, e->cl_defer, (size_t) (n + 64) * sizeof(int32_t)))) return rc;
-            if ((rc = alga_ensure(e, e->loc_second, (size_t) (e->opt_stream_slots >= 4 ? 3 : 1) * (n + 1) * sizeof(unsigned long long)))) return rc;
+            if ((rc = alga_ensure(e, e->loc_second, (size_t) (e->opt_stream_slots >= 4 ? LOCAL_SLOTS_MAX - 1 : 1) * (n + 1) * sizeof(unsigned long long)))) return rc;
         }
         // the pile path, should the reads turn out to have one length and no masks (what reserve assumes: it is told one length)
         if (e->opt_pile != 0 && e->opt_cluster_pairs != 0 && e->opt_cluster_order != 0 && max_len - min_overlap <= 63 && pile_plan(pp.cfg, pp.cluster, eq, max_len, false)) {

@@ -737,7 +737,7 @@ k_probe_stream(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__restri
     const int32_t src_end = LIST ? (int32_t) min(*src_count, (unsigned long long) src_end_a) : src_end_a;       // (list mode: src_end_a = the list's capacity)
     if (LIST && src_end <= 0) return;
     constexpr int CNT_DEFER_AT = LIST ? CNT_DEFERRED2 : CNT_DEFERRED;
-    const uint32_t max_stand = o.slot_stride ? 4u : 2u;    // standing items a source may have and still finish here: one slot in first[], the others in second[]
+    const uint32_t max_stand = o.slot_stride ? (uint32_t) LOCAL_SLOTS_MAX : 2u;    // standing items a source may have and still finish here: one slot in first[], the others in second[]
     constexpr int WC = 4 * EQ - 3;                         // row words of an entry
     constexpr int QW = 24;                                 // staged words per source: the row (<= 13) + the compare's slack, words 16.. stay zero
     constexpr int NS = 12;                                 // source slots: three quads
@@ -1093,7 +1093,11 @@ k_probe_stream(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__restri
                 n_tried2 += need ? 1 : 0;
             }
             // every item that could be a via has been asked: nothing is left undecided (what still sends a source to the general kernel:
-            // two items at one offset, more than 64 entries, more than 8 runs, a flagged run list)
+            // two items at one offset, more than LOCAL_SLOTS_MAX standing items, more than 64 entries, more than 8 runs, a flagged run list).
+            // Tried and dropped (round 5): a second item per offset (two reads that start at one place and differ by a sequencing error: 68 % of
+            // what is still handed on at 0.2 % substitutions).  It works -- 9.5 M -> 0.14 M sources handed on -- but as tables in LDS it costs the
+            // kernel its sixth wave per SIMD (the whole build 48.3 ms instead of 49.4, error-free pairwise builds 7 ms slower), packed into one
+            // word per source it spills registers (error-free pairwise builds 20.5 -> 22.5 ms).
             const bool keep = pass && !removed;
             if (clash) atomicOr(stp, 1u);
             if (keep) atomicAdd(stp, 0x100u);
@@ -1121,7 +1125,7 @@ k_probe_stream(NodesDev nd, PrefSufCfg cfg, ClusterCfg cc, const uint4 *__restri
                 const bool my_kept = pass && (d < ds0 || __popcll(below & ~lowm) < 3);
                 bool fin_me = false;                       // this lane's item is an edge of its source
                 uint64_t kmr = seg_multi ? km : 0ull;
-                for (int it = 0; it < 4; it++) {           // uniform: one standing item of every source per step
+                for (int it = 0; it < LOCAL_SLOTS_MAX; it++) {           // uniform: one standing item of every source per step
                     if (__ballot(kmr != 0ull) == 0ull) break;
                     const bool on = kmr != 0ull;
                     const int sl = on ? __builtin_ctzll(kmr) : lane;

@@ -90,6 +90,8 @@ enum Counter {
     CNT_DEFERRED_PILE,     // mixed form: sources k_pile_probe handed on (CNT_DEFERRED before the swap)
     CNT_TOTAL = 24
 };
+constexpr int LOCAL_SLOTS_MAX = 4;                         // edges of a source k_probe_stream writes to slots itself (first[] + up to three in second[]: ProbeOut::slot_stride; eight measured no better)
+
 
 struct NodesDev {
     const uint32_t *words;

@@ -129,7 +129,7 @@ struct ProbeOut {
     unsigned long long *__restrict__ first = nullptr;
     int32_t src_base = 0;
     unsigned long long *__restrict__ second = nullptr;     // pair kernel of the clustered probe: the other edge of a two-edge source ...
-    uint32_t slot_stride = 0;                              // ... and, where != 0 (round 5), the third and fourth at second[slot_stride + i], second[2 * slot_stride + i]
+    uint32_t slot_stride = 0;                              // ... and, where != 0 (round 5), the third .. eighth at second[(k - 2) * slot_stride + i]
     // sources with more raw overlaps than a wave's LDS holds (repeats): the first pass lists them, a second pass (BIG
     // instantiation of the kernel) walks the list with the items in a global slice per wave
     int32_t *__restrict__ big_list = nullptr;

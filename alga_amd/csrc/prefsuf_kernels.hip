@@ -984,8 +984,8 @@ __global__ void __launch_bounds__(256) k_keys_to_edges(const unsigned long long 
 // are in the record list and take their slot with a cursor (rows with more than one edge are ordered by k_sort_rows).
 // `second` (may be null): a source with out-degree 2 whose first slot is set has its other edge there (the pair kernel of the
 // clustered probe finishes two-edge sources in slots too); k_sort_rows orders the two.
-// slot_stride != 0 (round 5): a source with out-degree 3 or 4 whose first slot is set has its third and fourth edge in second[slot_stride + i],
-// second[2 * slot_stride + i] (k_probe_stream finishes sources with up to four standing items).
+// slot_stride != 0 (round 5): a source with out-degree 3 .. LOCAL_SLOTS_MAX whose first slot is set has its further edges in second[(k - 2) * slot_stride + i]
+// (k_probe_stream finishes sources with up to that many standing items).
 __global__ void __launch_bounds__(256) k_local_emit_first(int32_t src_base, int32_t n_src, const uint32_t *__restrict__ deg,
                                                            const unsigned long long *__restrict__ first, const unsigned long long *__restrict__ second,
                                                            const uint32_t *__restrict__ rowptr, alga_edge_dev *__restrict__ edges, uint32_t slot_stride) {
@@ -999,17 +999,17 @@ __global__ void __launch_bounds__(256) k_local_emit_first(int32_t src_base, int3
     e.src = src_base + i; e.dst = (int32_t) (uint32_t) (f >> 32); e.offset = (int32_t) (uint32_t) f;
     const uint32_t at = rowptr[i];
     edges[at] = e;
-    if (dg >= 3u && dg <= 4u && second != nullptr && slot_stride != 0u) {      // up to four slots: left in (dst, offset) order as well
-        unsigned long long k[4];
+    if (dg >= 3u && dg <= (uint32_t) LOCAL_SLOTS_MAX && second != nullptr && slot_stride != 0u) {      // up to LOCAL_SLOTS_MAX slots: left in (dst, offset) order as well
+        unsigned long long k[LOCAL_SLOTS_MAX];
         k[0] = f;
 #pragma unroll
-        for (int q = 1; q < 4; q++) k[q] = (uint32_t) q < dg ? second[(size_t) (q - 1) * slot_stride + (size_t) i] : ~0ull;       // (dst in the high half: order by (dst, offset) == by value)
+        for (int q = 1; q < LOCAL_SLOTS_MAX; q++) k[q] = (uint32_t) q < dg ? second[(size_t) (q - 1) * slot_stride + (size_t) i] : ~0ull;   // (dst in the high half: order by (dst, offset) == by value)
 #pragma unroll
-        for (int a = 0; a < 4; a++)
+        for (int a = 0; a < LOCAL_SLOTS_MAX; a++)          // odd-even transposition
 #pragma unroll
-            for (int b = (a & 1); b + 1 < 4; b += 2) { const unsigned long long lo = min(k[b], k[b + 1]), hi = max(k[b], k[b + 1]); k[b] = lo; k[b + 1] = hi; }
+            for (int b = (a & 1); b + 1 < LOCAL_SLOTS_MAX; b += 2) { const unsigned long long lo = min(k[b], k[b + 1]), hi = max(k[b], k[b + 1]); k[b] = lo; k[b + 1] = hi; }
 #pragma unroll
-        for (int q = 0; q < 4; q++)
+        for (int q = 0; q < LOCAL_SLOTS_MAX; q++)
             if ((uint32_t) q < dg) { alga_edge_dev x; x.src = src_base + i; x.dst = (int32_t) (uint32_t) (k[q] >> 32); x.offset = (int32_t) (uint32_t) k[q]; edges[at + q] = x; }
         return;
     }
