@@ -375,10 +375,11 @@ __global__ void __launch_bounds__(256) k_pkb_kmers(NodesDev nd, PkbCfg c, int4 p
     mod_table_fill(T);
     const uint32_t base_t = blockIdx.x * blockDim.x;
     if (STAGED) {
-        const int cw = (int) (threadIdx.x & 15u);
-        for (int r = (int) (threadIdx.x >> 4); r < 256; r += 16) {
+        const int pc = (int) (threadIdx.x & 3u);                              // (dense: the block's 256 records are 32 KB in a row; 16-byte pieces)
+        for (int r = (int) (threadIdx.x >> 2); r < 256; r += 64) {
             const uint32_t t = base_t + (uint32_t) r;
-            srow[r][cw] = t < n_tips ? rec[t].words[cw] : 0u;              // (dense: the block's 256 records are 32 KB in a row)
+            const uint4 x = t < n_tips ? reinterpret_cast<const uint4 *>(rec[t].words)[pc] : make_uint4(0u, 0u, 0u, 0u);
+            srow[r][4 * pc] = x.x; srow[r][4 * pc + 1] = x.y; srow[r][4 * pc + 2] = x.z; srow[r][4 * pc + 3] = x.w;
         }
     }
     __syncthreads();
@@ -423,10 +424,11 @@ __global__ void __launch_bounds__(256) k_pkb_kmers_all(NodesDev nd, PkbCfg c, ui
     mod_table_fill(T);
     const uint32_t base_t = blockIdx.x * blockDim.x;
     {
-        const int cw = (int) (threadIdx.x & 15u);
-        for (int r = (int) (threadIdx.x >> 4); r < 256; r += 16) {
+        const int pc = (int) (threadIdx.x & 3u);                              // (the rows in 16-byte pieces: a quarter of the load instructions)
+        for (int r = (int) (threadIdx.x >> 2); r < 256; r += 64) {
             const uint32_t t = base_t + (uint32_t) r;
-            srow[r][cw] = t < n_tips ? rec[t].words[cw] : 0u;
+            const uint4 x = t < n_tips ? reinterpret_cast<const uint4 *>(rec[t].words)[pc] : make_uint4(0u, 0u, 0u, 0u);
+            srow[r][4 * pc] = x.x; srow[r][4 * pc + 1] = x.y; srow[r][4 * pc + 2] = x.z; srow[r][4 * pc + 3] = x.w;
         }
     }
     __syncthreads();
