@@ -40,7 +40,7 @@
 
 namespace alga {
 
-constexpr int PB_TILE = 512, PB_HALO = 64, PB_THREADS = PB_TILE + PB_HALO;      // buckets that START in the tile; the halo holds their tails
+constexpr int PB_TILE = 192, PB_HALO = 64, PB_THREADS = PB_TILE + PB_HALO;      // buckets that START in the tile; the halo holds their tails.  (round 5: tiles of 512 -- three big blocks per CU, every one stalled behind its row fetches at the same time -- 4.3 ms; 256: 3.9; 192: 3.5; 128: 3.6 + a slower sample)
 constexpr int PILE_SW = 13;                    // consensus words: coordinates -64 .. 143 (m_C <= 63, rows of up to 9 words)
 constexpr int PILE_MAXSUB = 4;                 // k-mer groups of one bucket (two k-mers share one of 2^26 buckets for ~12 % of the non-empty buckets at the north-star size)
 constexpr int PILE_EQ = 3;                     // entry size this path takes: rows of up to 9 words (reads of 100 - 150 bp)
@@ -84,7 +84,7 @@ __device__ __forceinline__ void load_row9(const NodesDev &nd, uint32_t id, uint3
 }
 
 template <bool SAMPLE>
-__global__ void __launch_bounds__(PB_THREADS, 3) k_pile_build(NodesDev nd, const uint32_t *__restrict__ skeys, const uint32_t *__restrict__ sids, uint64_t n_entries, const uint4 *__restrict__ dir, ClusterCfg cc, int U,
+__global__ void __launch_bounds__(PB_THREADS, 6) k_pile_build(NodesDev nd, const uint32_t *__restrict__ skeys, const uint32_t *__restrict__ sids, uint64_t n_entries, const uint4 *__restrict__ dir, ClusterCfg cc, int U,
                                                            uint4 *__restrict__ rec, uint4 *__restrict__ tab, uint32_t epoch,
                                                            uint4 *__restrict__ side, unsigned long long *__restrict__ pile_cnt, uint32_t *__restrict__ own_mask) {
     if (!SAMPLE && pile_declines(pile_cnt)) return;
