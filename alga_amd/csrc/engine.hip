@@ -604,7 +604,9 @@ static void engine_free_handles(alga_engine *e) {
     if (e->h_counters) (void) hipHostFree(e->h_counters);
     for (int i = 0; i < EV_COUNT; i++) if (e->ev[i]) (void) hipEventDestroy(e->ev[i]);
     if (e->own_stream) (void) hipStreamDestroy(e->own_stream);
-    e->h_counters = nullptr; e->own_stream = nullptr;
+    if (e->side_stream) (void) hipStreamDestroy(e->side_stream);
+    if (e->ev_side) (void) hipEventDestroy(e->ev_side);
+    e->h_counters = nullptr; e->own_stream = nullptr; e->side_stream = nullptr; e->ev_side = nullptr;
     for (int i = 0; i < EV_COUNT; i++) e->ev[i] = nullptr;
 }
 
@@ -628,9 +630,12 @@ int alga_engine_create(int hip_device, alga_engine **out) {
     }
     int rc = ALGA_OK;
     if (hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking) != hipSuccess) { e->own_stream = nullptr; rc = ALGA_ERR_HIP; }
+    if (rc == ALGA_OK && hipStreamCreateWithFlags(&e->side_stream, hipStreamNonBlocking) != hipSuccess) { e->side_stream = nullptr; rc = ALGA_ERR_HIP; }
+    if (rc == ALGA_OK && hipEventCreateWithFlags(&e->ev_side, hipEventDisableTiming) != hipSuccess) { e->ev_side = nullptr; rc = ALGA_ERR_HIP; }
     for (int i = 0; i < EV_COUNT && rc == ALGA_OK; i++)
         if (hipEventCreate(&e->ev[i]) != hipSuccess) { e->ev[i] = nullptr; rc = ALGA_ERR_HIP; }
     if (rc == ALGA_OK && hipHostMalloc((void **) &e->h_counters, (CNT_TOTAL + 2 + alga_engine::H_EXTRA) * sizeof(unsigned long long)) != hipSuccess) { e->h_counters = nullptr; rc = ALGA_ERR_OUT_OF_MEMORY; }
+    if (rc == ALGA_OK && hipHostGetDevicePointer((void **) &e->h_counters_dev, e->h_counters, 0) != hipSuccess) rc = ALGA_ERR_HIP;
     if (rc != ALGA_OK) { engine_free_handles(e); delete e; return rc; }     // nothing the failed attempt created is left behind
     *out = e;
     return ALGA_OK;
@@ -641,6 +646,7 @@ void alga_engine_destroy(alga_engine *e) {
     DeviceGuard guard;
     (void) hipSetDevice(e->device);
     if (e->own_stream) (void) hipStreamSynchronize(e->own_stream);
+    if (e->side_stream) (void) hipStreamSynchronize(e->side_stream);
     for (DevBuf *b : e->owned) alga_release(*b);           // everything alga_ensure ever allocated
     alga_release(e->up_raw);
     for (DevBuf *b : {&e->in_bytes[0], &e->in_bytes[1], &e->in_nl[0], &e->in_nl[1], &e->in_tiles, &e->in_tile_off}) alga_release(*b);

@@ -25,6 +25,8 @@ struct alga_engine {
     std::vector<DevBuf *> owned;              // the members below that hold an allocation (alga_ensure)
     int         device = -1;
     hipStream_t own_stream = nullptr;
+    hipStream_t side_stream = nullptr;         // supplement: the next round's sort beside this round's groups (pkb_presort)
+    hipEvent_t  ev_side = nullptr;             // ... its end
     std::string err;
     char        dev_name[256] = {0};
     int         n_cu = 256;
@@ -88,6 +90,8 @@ struct alga_engine {
     DevBuf pk_keys, pk_keys2, pk_vals, pk_vals2, pk_marks, pk_big, pk_add, pk_ekeys, pk_ekeys2, pk_flag, pk_pos, pk_edges[2], pk_rowptr, pk_deg,
            pk_mask, pk_cnt, pk_io, pk_io2, pk_tips, pk_heads, pk_g[2], pk_addk, pk_addk2, pk_merged, pk_hsz, pk_hsz2, pk_heads2, pk_nadd, pk_koff,
            pk_gsz, pk_fixlist, pk_bounds, pk_tiprec, pk_tipidx, pk_keys_all, pk_vals_all;
+    // the supplement's look-ahead (engine_pkb.hip: pkb_presort): the NEXT round's sorted entries and group heads, made on side_stream while this round's groups and merge run
+    DevBuf pk_keys2b, pk_vals2b, pk_headsb, pk_hszb, sort_temp2, pk_fixlist2, pk_cnt2;
     // duplicate / prefix-read removal (engine_ingest.hip)
     DevBuf pp_rows, pp_len, pp_perm[2], pp_keys[2], pp_mark, pp_keep, pp_pos, pp_out_rows, pp_out_len, pp_out_pair, pp_tally;
     // staged host <-> HBM copies (staging.hip)
@@ -126,6 +130,8 @@ struct alga_engine {
         int32_t  prio[4] = {0, 1, 2, 3};
         uint64_t E = 0, nk = 0;
         uint32_t n_tips = 0;
+        int      pre_set = 0, cur_set = 0;     // which of the two sets (engine_pkb.hip: PkbSet) the look-ahead fills / the round at hand works on
+        int      pre_round = -1;               // the round whose sort -> repair -> heads were sent ahead on side_stream (their counts: h_counters + H_PRE), -1 none
         bool     kmers_all = false;            // the k-mer entries of every round are in pk_keys_all / pk_vals_all (made in round 0), kmers_stride entries apart
         size_t   kmers_stride = 0;
         int      kmers_sort_bits = 0;
@@ -133,7 +139,8 @@ struct alga_engine {
         alga::PkbCfg cfg{};
     } pkb;
     unsigned long long *h_counters = nullptr;  // pinned, CNT_TOTAL + 2 entries + H_EXTRA more (supplement: the class bounds of a round, 257 x u32)
-    static constexpr int H_EXTRA = 132;
+    static constexpr int H_EXTRA = 132 + 16, H_PRE = alga::CNT_TOTAL + 2 + 132;       // (H_PRE: 13 counts of the look-ahead, in 64-bit words from the block's start)
+    uint32_t *h_counters_dev = nullptr;         // the same block by its device address (launch_mail writes it from a kernel)
     uint64_t    rec_cap_hint = 0, rec_cap_hint_local = 0;
     alga_prefsuf_stats stats;
     double      stats_host[2] = {0.0, 0.0};   // upload_nodes_impl: wall ms of its checks / of the upload (the host entry points copy them into stats)

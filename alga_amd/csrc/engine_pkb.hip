@@ -106,10 +106,13 @@ constexpr uint32_t PKB_FIX_LIST_CAP = 1u << 20;     // places where two hashes s
 // the additions of ALL ranks into the graph; end -- the graph as an edge list.  One GPU runs them back to back (supplement_device_impl); N ranks
 // exchange the additions between `round` and `merge` (alga_pkb_shard_*, include/alga_amd.h).  The engine's semantics make that exact: every
 // group of a round sees the graph as it was when the round started, and the merge orders by key -- the result does not depend on N.
+int pkb_drop_presort(alga_engine *e);
+
 int pkb_begin(alga_engine *e, const alga_nodes *dn, const alga_pkb_params *p, const alga_edge *d_edges_in, uint64_t m_in, int rank, int n_ranks, hipStream_t s) {
     int rc;
     auto &st = e->pkb;
     st.phase = 0;
+    if ((rc = pkb_drop_presort(e))) return rc;
     st.cfg = make_cfg(p); st.dn = *dn; st.rounds = p->rounds; st.rank = rank; st.n_ranks = n_ranks; st.round = 0;
     const NodesDev nd = nodes_dev(dn);
     const int32_t n = dn->n;
@@ -140,8 +143,12 @@ int pkb_begin(alga_engine *e, const alga_nodes *dn, const alga_pkb_params *p, co
     launch_pkb_tip_list(nd, c, (const uint32_t *) e->pk_flag.p, (const uint32_t *) e->pk_pos.p, (uint32_t *) e->pk_tips.p, (uint32_t *) e->pk_gsz.p, cnt + 12,
                         (uint32_t *) e->pk_tipidx.p, s);
     if ((rc = alga_check_launch(e, "k_pkb_tip_list"))) return rc;
-    HIP_TRY(e, hipMemcpyAsync(e->h_counters, (uint64_t *) e->scan_scratch.p + scan_total_index((uint64_t) n), sizeof(uint64_t), hipMemcpyDeviceToHost, s));
-    HIP_TRY(e, hipMemcpyAsync(e->h_counters + 1, cnt + 12, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    {
+        MailArgs m;
+        m.add((uint64_t *) e->scan_scratch.p + scan_total_index((uint64_t) n), 2, 0);
+        m.add(cnt + 12, 2, 2);
+        launch_mail(m, e->h_counters_dev, s);
+    }
     HIP_TRY(e, hipStreamSynchronize(s));
     st.n_tips = n > 0 ? (uint32_t) e->h_counters[0] : 0u;
     if (e->h_counters[1] >= 4096) return alga_fail(e, ALGA_ERR_CAPACITY, "the supplement keeps read lengths in 12 bits: a participating read has 4096 nt or more");
@@ -165,6 +172,55 @@ int pkb_begin(alga_engine *e, const alga_nodes *dn, const alga_pkb_params *p, co
     return ALGA_OK;
 }
 
+// The sorted k-mer entries of a round and its unsorted group heads exist twice: while the groups and the merge of round r work on set r's, the side stream
+// fills the other set for round r + 1 (pkb_presort).  Set 0 is what the engine had before; the head SORT's outputs (pk_heads2, pk_hsz2) exist once.
+struct PkbSet { DevBuf &keys2, &vals2, &heads, &hsz; };
+PkbSet pkb_set(alga_engine *e, int i) {
+    return i ? PkbSet{e->pk_keys2b, e->pk_vals2b, e->pk_headsb, e->pk_hszb} : PkbSet{e->pk_keys2, e->pk_vals2, e->pk_heads, e->pk_hsz};
+}
+
+// Look-ahead: sort -> repair -> heads of round `round`'s k-mer entries (they were all made in round 0: pk_keys_all) into set `set`, on the engine's SIDE
+// stream with scratch of its own, their counts through k_mail into h_counters + H_PRE, ev_side behind them.  Nothing here depends on the graph, so it runs
+// beside the groups and the merge of the round before: those are bound by isolated 128-byte reads, the sort by streaming and LDS -- and the GPU has work
+// while the host sits in the round's waits.
+int pkb_presort(alga_engine *e, int round, int set, int sort_bits) {
+    int rc;
+    auto &st = e->pkb;
+    const uint64_t nk = st.nk;
+    hipStream_t q = e->side_stream;
+    PkbSet B = pkb_set(e, set);
+    const size_t temp = rsort_u64_pairs_temp_bytes(nk);
+    for (DevBuf *b : {&B.keys2, &B.vals2})
+        if ((rc = alga_ensure(e, *b, (nk + 1) * sizeof(unsigned long long)))) return rc;
+    for (DevBuf *b : {&B.heads, &B.hsz})
+        if ((rc = alga_ensure(e, *b, (nk + 2) * sizeof(uint32_t)))) return rc;
+    if ((rc = alga_ensure(e, e->sort_temp2, temp))) return rc;
+    if ((rc = alga_ensure(e, e->pk_fixlist2, (size_t) PKB_FIX_LIST_CAP * sizeof(uint32_t)))) return rc;
+    if ((rc = alga_ensure(e, e->pk_cnt2, 16 * sizeof(unsigned long long)))) return rc;
+    unsigned long long *c2 = (unsigned long long *) e->pk_cnt2.p;
+    const unsigned long long *kin = (const unsigned long long *) e->pk_keys_all.p + (size_t) round * st.kmers_stride;
+    const unsigned long long *vin = (const unsigned long long *) e->pk_vals_all.p + (size_t) round * st.kmers_stride;
+    HIP_TRY(e, rsort_u64_pairs(e->sort_temp2.p, temp, kin, (unsigned long long *) B.keys2.p, vin, (unsigned long long *) B.vals2.p, nk, sort_bits, q));
+    HIP_TRY(e, hipMemsetAsync(c2, 0, 12 * sizeof(unsigned long long), q));
+    launch_pkb_fix_runs((unsigned long long *) B.keys2.p, (unsigned long long *) B.vals2.p, nk, sort_bits, (uint32_t *) e->pk_fixlist2.p, PKB_FIX_LIST_CAP, c2 + 9, q);
+    if ((rc = alga_check_launch(e, "k_pkb_fix_runs (look-ahead)"))) return rc;
+    launch_pkb_heads((const unsigned long long *) B.keys2.p, nk, c2 + 1, c2 + 3, c2 + 10, (uint32_t *) B.heads.p, (uint32_t *) B.hsz.p, st.rank, st.n_ranks, q);
+    if ((rc = alga_check_launch(e, "k_pkb_heads (look-ahead)"))) return rc;
+    MailArgs m;
+    m.add(c2, 24, 2 * alga_engine::H_PRE);
+    m.add(c2 + 10, 2, 2 * alga_engine::H_PRE + 24);
+    launch_mail(m, e->h_counters_dev, q);
+    HIP_TRY(e, hipEventRecord(e->ev_side, q));
+    st.pre_round = round; st.pre_set = set;
+    return ALGA_OK;
+}
+
+// a look-ahead nobody will take (a sequence given up, or begun anew): wait it out before its buffers are touched
+int pkb_drop_presort(alga_engine *e) {
+    if (e->pkb.pre_round >= 0) { e->pkb.pre_round = -1; HIP_TRY(e, hipStreamSynchronize(e->side_stream)); }
+    return ALGA_OK;
+}
+
 // the additions of this rank's groups in the round at hand: *d_add (device, unsorted edge keys), *n_add
 int pkb_round(alga_engine *e, hipStream_t s, const unsigned long long **d_add, uint64_t *n_add) {
     int rc;
@@ -184,12 +240,17 @@ int pkb_round(alga_engine *e, hipStream_t s, const unsigned long long **d_add, u
     // the engine's own sort (radix_sort.hip, round 5) takes 10 bits per pass: 30 bits while that leaves <= 2^18 places to repair (23.7 M k-mers), else 40, 50;
     // the library's (option pkb_legacy bit 1) 8 bits per pass: 32, 40, 48
     const bool own_sort = !(e->opt_pkb_legacy & 2);
+    if (st.pre_round >= 0 && st.pre_round != round && (rc = pkb_drop_presort(e))) return rc;
+    const bool have_pre = st.pre_round == round;
+    const int set = have_pre ? st.pre_set : 0;
+    st.cur_set = set;
+    PkbSet B = pkb_set(e, set);
     const int sort_bits = own_sort ? (nk <= 23700000ull ? 30 : (nk <= (1ull << 29) ? 40 : 50)) : (nk <= (1ull << 25) ? 32 : (nk <= (1ull << 29) ? 40 : 48));
     const size_t temp = std::max(std::max(sort_u64_pairs_temp_bytes(nk, sort_bits), rsort_u64_pairs_temp_bytes(nk)), sort_u32_pairs_temp_bytes(nk));
     if ((rc = alga_ensure(e, e->pk_fixlist, (size_t) PKB_FIX_LIST_CAP * sizeof(uint32_t)))) return rc;
-    for (DevBuf *b : {&e->pk_keys, &e->pk_vals, &e->pk_keys2, &e->pk_vals2, &e->pk_marks})
+    for (DevBuf *b : {&e->pk_keys, &e->pk_vals, &B.keys2, &B.vals2, &e->pk_marks})
         if ((rc = alga_ensure(e, *b, (nk + 1) * sizeof(unsigned long long)))) return rc;
-    for (DevBuf *b : {&e->pk_flag, &e->pk_pos, &e->pk_heads, &e->pk_heads2, &e->pk_hsz, &e->pk_hsz2, &e->pk_gsz, &e->pk_nadd})
+    for (DevBuf *b : {&e->pk_flag, &e->pk_pos, &B.heads, &e->pk_heads2, &B.hsz, &e->pk_hsz2, &e->pk_gsz, &e->pk_nadd})
         if ((rc = alga_ensure(e, *b, (nk + 2) * sizeof(uint32_t)))) return rc;
     if ((rc = alga_ensure(e, e->sort_temp, temp))) return rc;
     if ((rc = alga_ensure(e, e->scan_scratch, scan_scratch_bytes(nk)))) return rc;
@@ -198,6 +259,9 @@ int pkb_round(alga_engine *e, hipStream_t s, const unsigned long long **d_add, u
         launch_pkb_tiprec_snap((const uint32_t *) e->pk_tips.p, n_tips, (const uint32_t *) e->pk_rowptr.p, (const unsigned long long *) e->pk_g[cur].p, e->pk_tiprec.p, s);
         if ((rc = alga_check_launch(e, "k_pkb_tiprec_snap"))) return rc;
     }
+    const bool mail = !(e->opt_pkb_legacy & 256);            // what the host waits for, through one kernel into the pinned block (bit 8: a copy per piece)
+    // look-ahead (pkb_presort): with the engine's sort and heads kernel (option pkb_legacy bit 9: off), when every round's entries are made in round 0
+    const bool ahead_opts = own_sort && mail && !(e->opt_pkb_legacy & (4 | 512)) && e->side_stream;
     // The k-mers of EVERY round in the first round's walk (the tips, their rows and the interval borders are the same; the priority rotates by one
     // per round): one kernel for what were four.  Option pkb_legacy bit 7, or a shape that kernel does not take: a walk per round.
     if (round == 0) st.kmers_all = false;
@@ -205,58 +269,77 @@ int pkb_round(alga_engine *e, hipStream_t s, const unsigned long long **d_add, u
         const size_t stride = (size_t) nk + 1;
         if ((rc = alga_ensure(e, e->pk_keys_all, (size_t) st.rounds * stride * sizeof(unsigned long long)))) return rc;
         if ((rc = alga_ensure(e, e->pk_vals_all, (size_t) st.rounds * stride * sizeof(unsigned long long)))) return rc;
-        if (launch_pkb_kmers_all(nd, c, st.prio, st.rounds, (const uint32_t *) e->pk_tips.p, (const uint32_t *) e->pk_koff.p, n_tips, sort_bits,
+        if (launch_pkb_kmers_all(nd, c, st.prio, 0, st.rounds, (const uint32_t *) e->pk_tips.p, (const uint32_t *) e->pk_koff.p, n_tips, sort_bits,
                                  (unsigned long long *) e->pk_keys_all.p, (unsigned long long *) e->pk_vals_all.p, stride, e->pk_tiprec.p, s)) {
             if ((rc = alga_check_launch(e, "k_pkb_kmers_all"))) return rc;
             st.kmers_all = true; st.kmers_stride = stride; st.kmers_sort_bits = sort_bits;
         }
     }
-    const unsigned long long *kin = (const unsigned long long *) e->pk_keys.p, *vin = (const unsigned long long *) e->pk_vals.p;
-    if (st.kmers_all && st.kmers_sort_bits == sort_bits && st.kmers_stride == (size_t) nk + 1) {
-        kin = (const unsigned long long *) e->pk_keys_all.p + (size_t) round * st.kmers_stride;
-        vin = (const unsigned long long *) e->pk_vals_all.p + (size_t) round * st.kmers_stride;
-    } else {
-        launch_pkb_kmers(nd, c, st.prio, (const uint32_t *) e->pk_tips.p, (const uint32_t *) e->pk_koff.p, n_tips, sort_bits, (unsigned long long *) e->pk_keys.p,
-                         (unsigned long long *) e->pk_vals.p, e->pk_tiprec.p, (e->opt_pkb_legacy & 32) != 0, s);
-        if ((rc = alga_check_launch(e, "k_pkb_kmers"))) return rc;
-    }
-    // equal hashes become contiguous; inside a group the group kernel orders the entries itself
-    if (own_sort) HIP_TRY(e, rsort_u64_pairs(e->sort_temp.p, temp, kin, (unsigned long long *) e->pk_keys2.p, vin, (unsigned long long *) e->pk_vals2.p, nk, sort_bits, s));
-    else HIP_TRY(e, sort_u64_pairs(e->sort_temp.p, temp, kin, (unsigned long long *) e->pk_keys2.p, vin, (unsigned long long *) e->pk_vals2.p, nk, sort_bits, s));
+    const bool look_ahead = ahead_opts && st.kmers_all && st.kmers_sort_bits == sort_bits && st.kmers_stride == (size_t) nk + 1;
     uint32_t n_heads = 0;
     uint64_t big_words = 0;
-    for (int pass = 0; pass < 2; pass++) {
+    int first_pass = 0;
+    bool counted = false;
+    if (have_pre) {
+        // sorted, repaired and its heads listed while the round before ran; the stream at hand goes on behind that work
+        st.pre_round = -1;
+        HIP_TRY(e, hipStreamWaitEvent(s, e->ev_side, 0));
+        HIP_TRY(e, hipEventSynchronize(e->ev_side));
+        memcpy(e->h_counters, e->h_counters + alga_engine::H_PRE, 13 * sizeof(unsigned long long));
+        if (e->h_counters[9] > PKB_FIX_LIST_CAP) first_pass = 1;                  // its repair list overflowed: the loop form, here
+        else counted = true;
+    } else {
+        const unsigned long long *kin = (const unsigned long long *) e->pk_keys.p, *vin = (const unsigned long long *) e->pk_vals.p;
+        if (st.kmers_all && st.kmers_sort_bits == sort_bits && st.kmers_stride == (size_t) nk + 1) {
+            kin = (const unsigned long long *) e->pk_keys_all.p + (size_t) round * st.kmers_stride;
+            vin = (const unsigned long long *) e->pk_vals_all.p + (size_t) round * st.kmers_stride;
+        } else {
+            launch_pkb_kmers(nd, c, st.prio, (const uint32_t *) e->pk_tips.p, (const uint32_t *) e->pk_koff.p, n_tips, sort_bits, (unsigned long long *) e->pk_keys.p,
+                             (unsigned long long *) e->pk_vals.p, e->pk_tiprec.p, (e->opt_pkb_legacy & 32) != 0, s);
+            if ((rc = alga_check_launch(e, "k_pkb_kmers"))) return rc;
+        }
+        // equal hashes become contiguous; inside a group the group kernel orders the entries itself
+        if (own_sort) HIP_TRY(e, rsort_u64_pairs(e->sort_temp.p, temp, kin, (unsigned long long *) B.keys2.p, vin, (unsigned long long *) B.vals2.p, nk, sort_bits, s));
+        else HIP_TRY(e, sort_u64_pairs(e->sort_temp.p, temp, kin, (unsigned long long *) B.keys2.p, vin, (unsigned long long *) B.vals2.p, nk, sort_bits, s));
+    }
+    for (int pass = first_pass; pass < 2 && !counted; pass++) {
         HIP_TRY(e, hipMemsetAsync(cnt, 0, 12 * sizeof(unsigned long long), s));
-        if (pass == 0) launch_pkb_fix_runs((unsigned long long *) e->pk_keys2.p, (unsigned long long *) e->pk_vals2.p, nk, sort_bits, (uint32_t *) e->pk_fixlist.p,
+        if (pass == 0) launch_pkb_fix_runs((unsigned long long *) B.keys2.p, (unsigned long long *) B.vals2.p, nk, sort_bits, (uint32_t *) e->pk_fixlist.p,
                                            PKB_FIX_LIST_CAP, cnt + 9, s);
-        else launch_pkb_fix_runs_loop((unsigned long long *) e->pk_keys2.p, (unsigned long long *) e->pk_vals2.p, nk, sort_bits, s);   // the list overflowed
+        else launch_pkb_fix_runs_loop((unsigned long long *) B.keys2.p, (unsigned long long *) B.vals2.p, nk, sort_bits, s);   // the list overflowed
         if ((rc = alga_check_launch(e, "k_pkb_fix_runs"))) return rc;
         if (e->opt_pkb_legacy & 4) {
-            launch_pkb_group_sizes((const unsigned long long *) e->pk_keys2.p, nk, cnt + 1, cnt + 3, (uint32_t *) e->pk_flag.p, (uint32_t *) e->pk_gsz.p, st.rank, st.n_ranks, s);
+            launch_pkb_group_sizes((const unsigned long long *) B.keys2.p, nk, cnt + 1, cnt + 3, (uint32_t *) e->pk_flag.p, (uint32_t *) e->pk_gsz.p, st.rank, st.n_ranks, s);
             if ((rc = alga_check_launch(e, "k_pkb_group_sizes"))) return rc;
             launch_exclusive_scan((const uint32_t *) e->pk_flag.p, nk, (uint32_t *) e->pk_pos.p, (uint64_t *) e->scan_scratch.p, s);
-            launch_pkb_head_list((const uint32_t *) e->pk_flag.p, (const uint32_t *) e->pk_pos.p, (const uint32_t *) e->pk_gsz.p, nk, (uint32_t *) e->pk_heads.p,
-                                 (uint32_t *) e->pk_hsz.p, s);
+            launch_pkb_head_list((const uint32_t *) e->pk_flag.p, (const uint32_t *) e->pk_pos.p, (const uint32_t *) e->pk_gsz.p, nk, (uint32_t *) B.heads.p,
+                                 (uint32_t *) B.hsz.p, s);
             if ((rc = alga_check_launch(e, "k_pkb_head_list"))) return rc;
             HIP_TRY(e, hipMemcpyAsync(e->h_counters + 12, (uint64_t *) e->scan_scratch.p + scan_total_index(nk), sizeof(uint64_t), hipMemcpyDeviceToHost, s));
         } else {
-            launch_pkb_heads((const unsigned long long *) e->pk_keys2.p, nk, cnt + 1, cnt + 3, cnt + 10, (uint32_t *) e->pk_heads.p, (uint32_t *) e->pk_hsz.p,
+            launch_pkb_heads((const unsigned long long *) B.keys2.p, nk, cnt + 1, cnt + 3, cnt + 10, (uint32_t *) B.heads.p, (uint32_t *) B.hsz.p,
                              st.rank, st.n_ranks, s);
             if ((rc = alga_check_launch(e, "k_pkb_heads"))) return rc;
-            HIP_TRY(e, hipMemcpyAsync(e->h_counters + 12, cnt + 10, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+            if (mail) {
+                MailArgs m;
+                m.add(cnt, 24, 0);
+                m.add(cnt + 10, 2, 24);
+                launch_mail(m, e->h_counters_dev, s);
+            } else HIP_TRY(e, hipMemcpyAsync(e->h_counters + 12, cnt + 10, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
         }
-        HIP_TRY(e, hipMemcpyAsync(e->h_counters, cnt, 12 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        if (!mail || (e->opt_pkb_legacy & 4)) HIP_TRY(e, hipMemcpyAsync(e->h_counters, cnt, 12 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
         HIP_TRY(e, hipStreamSynchronize(s));
         if (pass == 0 && e->h_counters[9] > PKB_FIX_LIST_CAP) continue;
-        big_words = e->h_counters[1];
-        n_heads = (uint32_t) e->h_counters[12];
-        break;
+        counted = true;
     }
+    big_words = e->h_counters[1];
+    n_heads = (uint32_t) e->h_counters[12];
+    if (look_ahead && round + 1 < st.rounds && (rc = pkb_presort(e, round + 1, set ^ 1, sort_bits))) return rc;
     e->pkb_stats.groups[round] = n_heads;
     e->pkb_stats.max_group = std::max<uint64_t>(e->pkb_stats.max_group, e->h_counters[3]);             // exact for groups of more than 64
     if (!n_heads) return ALGA_OK;
     // groups in order of their size: the lanes of a wave replay groups of the same size
-    HIP_TRY(e, sort_u32_pairs_bits(e->sort_temp.p, temp, (const uint32_t *) e->pk_hsz.p, (uint32_t *) e->pk_hsz2.p, (const uint32_t *) e->pk_heads.p,
+    HIP_TRY(e, sort_u32_pairs_bits(e->sort_temp.p, temp, (const uint32_t *) B.hsz.p, (uint32_t *) e->pk_hsz2.p, (const uint32_t *) B.heads.p,
                                    (uint32_t *) e->pk_heads2.p, n_heads, 8, s));
     if ((rc = alga_ensure(e, e->pk_bounds, 260 * sizeof(uint32_t)))) return rc;
     launch_pkb_class_bounds((const uint32_t *) e->pk_hsz2.p, n_heads, (uint32_t *) e->pk_bounds.p, s);
@@ -269,19 +352,29 @@ int pkb_round(alga_engine *e, hipStream_t s, const unsigned long long **d_add, u
         if ((rc = alga_ensure(e, e->pk_big, (big_words + 1) * sizeof(unsigned long long)))) return rc;
         if ((rc = alga_ensure(e, e->pk_add, (add_cap + 1) * sizeof(unsigned long long)))) return rc;
         HIP_TRY(e, hipMemsetAsync(cnt + 4, 0, 4 * sizeof(unsigned long long), s));                    // big cursor, overflow, calls
-        launch_pkb_groups(nd, c, (const uint32_t *) e->pk_rowptr.p, (const unsigned long long *) e->pk_g[cur].p, (const unsigned long long *) e->pk_keys2.p,
-                          (const uint32_t *) e->pk_heads2.p, (const uint32_t *) e->pk_hsz2.p, (const uint32_t *) e->pk_bounds.p, n_heads, (unsigned long long *) e->pk_vals2.p, nk,
+        launch_pkb_groups(nd, c, (const uint32_t *) e->pk_rowptr.p, (const unsigned long long *) e->pk_g[cur].p, (const unsigned long long *) B.keys2.p,
+                          (const uint32_t *) e->pk_heads2.p, (const uint32_t *) e->pk_hsz2.p, (const uint32_t *) e->pk_bounds.p, n_heads, (unsigned long long *) B.vals2.p, nk,
                           (unsigned long long *) e->pk_marks.p, (unsigned long long *) e->pk_big.p, cnt + 4, (unsigned long long *) e->pk_add.p, add_dense,
                           add_cap, cnt + 5, cnt + 6, (uint32_t *) e->pk_nadd.p, (uint32_t *) e->pk_gsz.p, e->n_cu, (const uint32_t *) e->pk_tips.p, e->pk_tiprec.p,
                           e->opt_pkb_legacy, s);
         if ((rc = alga_check_launch(e, "k_pkb_groups"))) return rc;
         launch_exclusive_scan((const uint32_t *) e->pk_nadd.p, (uint64_t) n_heads, (uint32_t *) e->pk_pos.p, (uint64_t *) e->scan_scratch.p, s);
-        HIP_TRY(e, hipMemcpyAsync(e->h_counters, cnt, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-        HIP_TRY(e, hipMemcpyAsync(e->h_counters + 8, (uint64_t *) e->scan_scratch.p + scan_total_index((uint64_t) n_heads), sizeof(uint64_t),
-                                  hipMemcpyDeviceToHost, s));
-        HIP_TRY(e, hipMemcpyAsync(&e->h_first_hkey, e->pk_hsz2.p, sizeof(uint32_t), hipMemcpyDeviceToHost, s));    // the longest group's sort key
-        HIP_TRY(e, hipMemcpyAsync(e->h_counters + CNT_TOTAL + 2, e->pk_bounds.p, 257 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        if (mail) {
+            MailArgs m;
+            m.add(cnt, 16, 0);
+            m.add((uint64_t *) e->scan_scratch.p + scan_total_index((uint64_t) n_heads), 2, 16);
+            m.add(e->pk_bounds.p, 257, 2 * (CNT_TOTAL + 2));
+            m.add(e->pk_hsz2.p, 1, 2 * (CNT_TOTAL + 2) + 258);                                          // the longest group's sort key
+            launch_mail(m, e->h_counters_dev, s);
+        } else {
+            HIP_TRY(e, hipMemcpyAsync(e->h_counters, cnt, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+            HIP_TRY(e, hipMemcpyAsync(e->h_counters + 8, (uint64_t *) e->scan_scratch.p + scan_total_index((uint64_t) n_heads), sizeof(uint64_t),
+                                      hipMemcpyDeviceToHost, s));
+            HIP_TRY(e, hipMemcpyAsync(&e->h_first_hkey, e->pk_hsz2.p, sizeof(uint32_t), hipMemcpyDeviceToHost, s));    // the longest group's sort key
+            HIP_TRY(e, hipMemcpyAsync(e->h_counters + CNT_TOTAL + 2, e->pk_bounds.p, 257 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        }
         HIP_TRY(e, hipStreamSynchronize(s));
+        if (mail) e->h_first_hkey = ((const uint32_t *) (e->h_counters + CNT_TOTAL + 2))[258];
         if (e->h_counters[5] <= add_ovf_cap) { n_dense = e->h_counters[8]; n_ovf = e->h_counters[5]; break; }
         if (attempt == 2) return alga_fail(e, ALGA_ERR_HIP, "supplement: addition buffer kept overflowing");
         add_ovf_cap = e->h_counters[5] + 1024;
@@ -323,13 +416,14 @@ int pkb_merge(alga_engine *e, const unsigned long long *d_all, uint64_t A, hipSt
         if (A >= 1024 && !(e->opt_pkb_legacy & 16)) {     // (below: one library kernel does it)
             const int nb = st.key_bits - 36;                                          // bits of a node id
             const size_t t3 = rsort_u32_pairs_temp_bytes(A);
-            for (DevBuf *b : {&e->pk_heads, &e->pk_heads2, &e->pk_hsz})
+            PkbSet B = pkb_set(e, st.cur_set);                                          // (scratch: the round's unsorted heads are spent; the OTHER set's may be in the making)
+            for (DevBuf *b : {&B.heads, &e->pk_heads2, &B.hsz})
                 if ((rc = alga_ensure(e, *b, (A + 16) * sizeof(uint32_t)))) return rc;
             if ((rc = alga_ensure(e, e->sort_temp, std::max(t2, t3)))) return rc;
-            launch_pkb_src_keys(d_all, A, 32 - nb, (uint32_t *) e->pk_heads.p, s);
-            HIP_TRY(e, rsort_u32_pairs(e->sort_temp.p, std::max(t2, t3), (const uint32_t *) e->pk_heads.p, (uint32_t *) e->pk_heads2.p, nullptr, (uint32_t *) e->pk_hsz.p, A,
+            launch_pkb_src_keys(d_all, A, 32 - nb, (uint32_t *) B.heads.p, s);
+            HIP_TRY(e, rsort_u32_pairs(e->sort_temp.p, std::max(t2, t3), (const uint32_t *) B.heads.p, (uint32_t *) e->pk_heads2.p, nullptr, (uint32_t *) B.hsz.p, A,
                                        32 - nb, s));
-            launch_pkb_gather_sorted_runs(d_all, (const uint32_t *) e->pk_heads2.p, (const uint32_t *) e->pk_hsz.p, A, (unsigned long long *) e->pk_addk2.p, s);
+            launch_pkb_gather_sorted_runs(d_all, (const uint32_t *) e->pk_heads2.p, (const uint32_t *) B.hsz.p, A, (unsigned long long *) e->pk_addk2.p, s);
             if ((rc = alga_check_launch(e, "k_pkb_gather_sorted_runs"))) return rc;
         } else HIP_TRY(e, sort_u64_keys_bits(e->sort_temp.p, t2, d_all, (unsigned long long *) e->pk_addk2.p, A, st.key_bits, s));
         HIP_TRY(e, merge_u64(e->sort_temp.p, t2, (const unsigned long long *) e->pk_g[cur].p, E, (const unsigned long long *) e->pk_addk2.p, A,
@@ -376,6 +470,7 @@ int pkb_end(alga_engine *e, hipStream_t s, const alga_edge **d_out, uint64_t *m_
     int rc;
     auto &st = e->pkb;
     if (st.phase != 1) return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "supplement end: a round is open");
+    if ((rc = pkb_drop_presort(e))) return rc;
     if ((rc = alga_ensure(e, e->pk_edges[0], (st.E + 1) * sizeof(alga_edge_dev)))) return rc;
     launch_pkb_keys_to_edges((const unsigned long long *) e->pk_g[st.cur].p, st.E, (alga_edge_dev *) e->pk_edges[0].p, s);
     if ((rc = alga_check_launch(e, "k_pkb_keys_to_edges"))) return rc;

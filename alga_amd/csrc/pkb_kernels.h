@@ -36,7 +36,7 @@ void launch_pkb_tip_list(const NodesDev &nd, const PkbCfg &c, const uint32_t *fl
                          unsigned long long *max_len, uint32_t *tipidx /* node -> place in tips[], ~0 if none */, hipStream_t s);
 void launch_pkb_kmers(const NodesDev &nd, const PkbCfg &c, const int32_t prio[4], const uint32_t *tips, const uint32_t *koff, uint32_t n_tips, int sort_bits,
                       unsigned long long *keys, unsigned long long *vals, const void *tiprec, int wide /* 1: round 4's 128-bit rolling value */, hipStream_t s);
-bool launch_pkb_kmers_all(const NodesDev &nd, const PkbCfg &c, const int32_t prio[4] /* of round 0 */, int rounds, const uint32_t *tips, const uint32_t *koff, uint32_t n_tips,
+bool launch_pkb_kmers_all(const NodesDev &nd, const PkbCfg &c, const int32_t prio[4] /* of round 0 */, int first, int count, const uint32_t *tips, const uint32_t *koff, uint32_t n_tips,
                           int sort_bits, unsigned long long *keys, unsigned long long *vals, size_t round_stride, const void *tiprec, hipStream_t s);
 // tip records (pkb_kernels.hip: PkbTipRec): row + id + first snapshot keys of every node that takes part, 128 bytes each
 size_t pkb_tiprec_bytes(uint32_t n_tips);

@@ -1428,13 +1428,19 @@ void launch_pkb_kmers(const NodesDev &nd, const PkbCfg &c, const int32_t prio[4]
 
 // every round's k-mers at once (round 0's priority in prio[]; the arrays of round r start r * round_stride entries in).  false: the shape is
 // not this kernel's (rows not staged, k > 48, more than four rounds) -- the caller takes launch_pkb_kmers per round
-bool launch_pkb_kmers_all(const NodesDev &nd, const PkbCfg &c, const int32_t prio[4], int rounds, const uint32_t *tips, const uint32_t *koff, uint32_t n_tips, int sort_bits,
-                          unsigned long long *keys, unsigned long long *vals, size_t round_stride, const void *tiprec, hipStream_t s) {
-    if (nd.stride > PKB_ROW_WORDS || c.li_k > 48 || rounds < 1 || rounds > 4) return false;
+// rounds [first, first + count) of the sequence whose round 0 reads `prio`; keys / vals: the arrays of round 0 (round r lies r * round_stride entries on)
+bool launch_pkb_kmers_all(const NodesDev &nd, const PkbCfg &c, const int32_t prio[4], int first, int count, const uint32_t *tips, const uint32_t *koff, uint32_t n_tips,
+                          int sort_bits, unsigned long long *keys, unsigned long long *vals, size_t round_stride, const void *tiprec, hipStream_t s) {
+    if (nd.stride > PKB_ROW_WORDS || c.li_k > 48 || first < 0 || count < 1 || first + count > 4) return false;
     if (n_tips == 0) return true;
-    const uint32_t pp0 = (uint32_t) prio[0] | ((uint32_t) prio[1] << 2) | ((uint32_t) prio[2] << 4) | ((uint32_t) prio[3] << 6);
-    hipLaunchKernelGGL((k_pkb_kmers_all<4>), dim3((n_tips + 255) / 256), dim3(256), 0, s, nd, c, pp0, rounds, tips, koff, n_tips, sort_bits, keys, vals, round_stride,
-                       (const PkbTipRec *) tiprec);
+    uint32_t pp0 = (uint32_t) prio[0] | ((uint32_t) prio[1] << 2) | ((uint32_t) prio[2] << 4) | ((uint32_t) prio[3] << 6);
+    pp0 = ((pp0 >> (2 * first)) | (pp0 << (8 - 2 * first))) & 0xFFu;              // the priority of round `first`
+    keys += (size_t) first * round_stride; vals += (size_t) first * round_stride;
+    const dim3 grid((n_tips + 255) / 256), block(256);
+    const PkbTipRec *rec = (const PkbTipRec *) tiprec;
+    if (count == 1) hipLaunchKernelGGL((k_pkb_kmers_all<1>), grid, block, 0, s, nd, c, pp0, count, tips, koff, n_tips, sort_bits, keys, vals, round_stride, rec);
+    else if (count <= 3) hipLaunchKernelGGL((k_pkb_kmers_all<3>), grid, block, 0, s, nd, c, pp0, count, tips, koff, n_tips, sort_bits, keys, vals, round_stride, rec);
+    else hipLaunchKernelGGL((k_pkb_kmers_all<4>), grid, block, 0, s, nd, c, pp0, count, tips, koff, n_tips, sort_bits, keys, vals, round_stride, rec);
     return true;
 }
 

@@ -122,6 +122,15 @@ void launch_rowptr_from_sorted(const uint32_t *keys, const unsigned long long *n
 size_t   scan_scratch_bytes(uint64_t n);
 uint64_t scan_total_index(uint64_t n); // scratch[scan_total_index(n)] holds the 64-bit total after the scan
 void launch_exclusive_scan(const uint32_t *in, uint64_t n, uint32_t *out, uint64_t *scratch, hipStream_t s);
+// up to MAIL_SEGS pieces of device memory (32-bit words) -> a pinned host block through its device address (engine: h_counters), one kernel
+constexpr int MAIL_SEGS = 6;
+struct MailSeg { const uint32_t *src; uint32_t words, dst; };            // dst: word offset in the host block
+struct MailArgs {
+    MailSeg seg[MAIL_SEGS];
+    int n = 0;
+    void add(const void *src, uint32_t words, uint32_t dst_word) { seg[n].src = (const uint32_t *) src; seg[n].words = words; seg[n].dst = dst_word; n++; }
+};
+void launch_mail(const MailArgs &a, uint32_t *host_block_dev, hipStream_t s);
 
 int  reduce_targets_per_block(uint64_t n_records, uint64_t n_targets);
 void launch_gather_heads(const NodesDev &nd, const unsigned long long *seg_val, const unsigned long long *n_valid_ptr, uint64_t n_rec_max,

@@ -1319,6 +1319,17 @@ void launch_exclusive_scan(const uint32_t *in, uint64_t n, uint32_t *out, uint64
 
 uint64_t scan_total_index(uint64_t n) { return (n + SCAN_TILE - 1) / SCAN_TILE; }
 
+// The few words the host waits for at a sync point, from wherever they lie on the device, in ONE tiny kernel straight into the pinned host block
+// (a device-to-host copy per word costs a blit kernel and a PCIe round trip each, one after the other on the stream).
+__global__ void __launch_bounds__(256) k_mail(MailArgs a, uint32_t *__restrict__ dst) {
+    for (int i = 0; i < a.n; i++)
+        for (uint32_t w = threadIdx.x; w < a.seg[i].words; w += 256) dst[a.seg[i].dst + w] = a.seg[i].src[w];
+}
+
+void launch_mail(const MailArgs &a, uint32_t *host_block_dev, hipStream_t s) {
+    if (a.n > 0) hipLaunchKernelGGL(k_mail, dim3(1), dim3(256), 0, s, a, host_block_dev);
+}
+
 int reduce_targets_per_block(uint64_t n_records, uint64_t n_targets) {
     // aim at ~60 % of the LDS record capacity so that ordinary fluctuations stay on the fast path
     const double avg = n_targets ? (double) n_records / (double) n_targets : 0.0;

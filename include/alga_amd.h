@@ -195,7 +195,9 @@ int         alga_engine_device_name(const alga_engine *e, char *buf, size_t bufl
  *                                1 groups of 8..16 k-mers a wave each (now four per wave), 2 the library's sort of the k-mer entries (now the engine's),
  *                                4 group heads in three kernels (now one), 8 the replay of the 8..16 groups inside the pair kernel, 16 the library's sort /
  *                                unique of the additions and a row-pointer pass, 32 the k-mer walk on a 128-bit value, 64 every tip record's snapshot
- *                                half rewritten every round, 128 a k-mer walk per round (now all rounds in one)
+ *                                half rewritten every round, 128 a k-mer walk per round (now all rounds in one), 256 a device-to-host copy per count the
+ *                                host waits for (now one small kernel per wait writes them into the pinned block), 512 no look-ahead (now the next round's
+ *                                k-mer entries are sorted and their groups listed on a second stream beside the round's group joins and merge)
  *   "test_pile_oom"              tests only.  != 0: the allocation of the pile path's own buffers (~180 B per node) answers ALGA_ERR_OUT_OF_MEMORY: the build
  *                                must give them back and finish on the pairwise kernels (what a real out-of-memory there does)
  *   "test_unsorted_index"        tests only.  != 0: the CLUSTER probe's entry directory is built over UNSORTED keys; the directory pass

@@ -183,7 +183,8 @@ def test_supplement_groups_of_8_to_16_four_per_wave(eng, G, n, seed):
     c[flip] = (3 - c[flip])[:, ::-1]
     s_new = _supplement_vs_oracle(eng, c.astype(np.uint8))
     assert s_new["group_hist"][0][4] > 20, s_new["group_hist"]               # there are groups of 8 .. 15
-    for legacy in (1, 6, 248):                                                  # bit 0: a wave per group of 8 .. 16; bits 1, 2: the library's k-mer sort on 32 bits, the head list in three kernels; bits 3, 4, 5: replay inside the pair kernel, the library's unique after the merge, the 128-bit k-mer walk
+    for legacy in (1, 6, 248, 256, 512):                                                  # bit 0: a wave per group of 8 .. 16; bits 1, 2: the library's k-mer sort on 32 bits, the head list in three kernels; bits 3, 4, 5: replay inside the pair kernel, the library's unique after the merge, the 128-bit k-mer walk
+        # bit 8: a device-to-host copy per count the host waits for; bit 9: no look-ahead (the next round's sort beside this round's joins)
         eng.set_option("pkb_legacy", legacy)
         try:
             s_old = _supplement_vs_oracle(eng, c.astype(np.uint8))
@@ -221,7 +222,7 @@ def test_supplement_reads_of_several_lengths(eng):
     s_new = eng.pkb_last_stats()
     assert len(want) > len(pre)
     assert got.shape == want.shape and (got == want).all()
-    for legacy in (32, 128):                                                   # the 128-bit walk per round; the 96-bit walk per round (default: all rounds in one walk)
+    for legacy in (32, 128, 512):                                                   # the 128-bit walk per round; the 96-bit walk per round (default: all rounds in one walk)
         eng.set_option("pkb_legacy", legacy)
         try:
             old = eng.pkb_supplement_host(words, lens, pre, p)
@@ -229,6 +230,54 @@ def test_supplement_reads_of_several_lengths(eng):
         finally:
             eng.set_option("pkb_legacy", 0)
         assert (old == got).all() and s_old["kmers"] == s_new["kmers"] and s_old["groups"] == s_new["groups"] and s_old["group_hist"] == s_new["group_hist"], legacy
+
+
+@pytest.mark.parametrize("rounds", [1, 2, 3])
+def test_supplement_look_ahead_with_fewer_rounds_and_a_sequence_given_up(eng, rounds):
+    """The look-ahead (engine_pkb.hip: pkb_presort -- the next round's k-mer entries sorted and their groups listed on the engine's side stream while
+    this round's joins run) with 1 .. 3 rounds (the k-mer walk of all rounds is then the kernel for one or three), against the run without it (option
+    pkb_legacy bit 9) and the oracle; then a sharded sequence that is given up after its first round -- its look-ahead is in flight -- followed by a
+    full one on the same engine: the abandoned work must be waited out, not read."""
+    import torch
+    from alga_amd.engine import device_view
+    codes, lens = gen_reads.sample_reads(5000, 150, 12000, 300 + rounds, 0.02)
+    rc = (3 - codes)[:, ::-1]
+    codes = np.stack([rc, codes], axis=1).reshape(-1, 150)[:, 3:147]
+    lens = np.full(len(codes), 144, dtype=np.int32)
+    words = alga_amd.pack_reads(codes, lens)
+    pre = eng.prefsuf_host(words, lens, 82, 116)
+    p = eng.pkb_params(144.0, 0.02, 54)
+    p.rounds = rounds
+    got = eng.pkb_supplement_host(words, lens, pre, p)
+    s_new = eng.pkb_last_stats()
+    eng.set_option("pkb_legacy", 512)
+    try:
+        old = eng.pkb_supplement_host(words, lens, pre, p)
+        s_old = eng.pkb_last_stats()
+    finally:
+        eng.set_option("pkb_legacy", 0)
+    assert got.shape == old.shape and (got == old).all() and len(got) > len(pre)
+    for k in ("kmers", "groups", "can_align_calls", "edges_after", "group_hist"):
+        assert s_new[k] == s_old[k], k
+    op = O.pkb_params(144.0, error_rate_percent=2)
+    op.rounds = rounds
+    want, _ = O.supplement(words, lens, pre, op, 54, flags=3)
+    assert got.shape == want.shape and (got == want).all()
+    # a sequence given up after its first round, then a whole one
+    stride = 16
+    wide = np.zeros((len(lens), stride), dtype=np.uint32)
+    wide[:, :words.shape[1]] = words
+    dw = torch.from_numpy(wide.view(np.int32)).cuda()
+    dl = torch.from_numpy(lens).cuda()
+    d_pre = torch.from_numpy(np.ascontiguousarray(pre, dtype=np.int32)).cuda()
+    torch.cuda.synchronize()
+    p4 = eng.pkb_params(144.0, 0.02, 54)
+    eng.pkb_shard_begin(dw, dl, d_pre.data_ptr(), len(pre), p4, 0, 1)
+    eng.pkb_shard_round()                                                      # (rounds 1 .. 3 never come)
+    ptr, m = eng.pkb_supplement_device(dw, dl, d_pre.data_ptr(), len(pre), p4)
+    whole = device_view(ptr, (m, 3), dw.device).cpu().numpy()
+    ref = eng.pkb_supplement_host(words, lens, pre, p4)
+    assert whole.shape == ref.shape and (whole == ref).all()
 
 
 def test_supplement_rejects_offsets_it_cannot_represent(eng):
