@@ -165,8 +165,13 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
     e->store_timed = false;
     e->pile_timed = false;
     // the probe through piles: all sources in entry order, reads of one length without masks (prefsuf_pile.hip: pile_plan)
-    bool pile = clustered && e->opt_pile != 0 && e->opt_cluster_pairs != 0 && e->opt_cluster_order != 0 && pp.local_sw == 1 && pp.keys_shared == 0 &&
-                      src_begin == 0 && src_end == pp.nd.n && pile_plan(cfg, pp.cluster, pp.cluster_eq, pp.uniform_len, pp.nd.from != nullptr || pp.nd.to != nullptr);
+    // (a range of ids -- a rank's share of the strong-scaling N-GPU build, option pile_range: the same index, the range's side records compacted for the probe)
+    const bool all_sources = src_begin == 0 && src_end == pp.nd.n;
+    // (keys_shared = 2, a further piece of a rank's range: the piles of the build before it, where that build made them for this node set)
+    const bool pile_index_left = e->opt_pile_range != 0 && e->pile_n == pp.nd.n && e->pile_words == (const void *) pp.nd.words;
+    bool pile = clustered && e->opt_pile != 0 && e->opt_cluster_pairs != 0 && e->opt_cluster_order != 0 && pp.local_sw == 1 &&
+                      (pp.keys_shared == 0 || (pp.keys_shared == 2 && pile_index_left)) &&
+                      (all_sources || (e->opt_pile_range != 0 && src_begin >= 0 && src_end <= pp.nd.n && src_begin < src_end)) && pile_plan(cfg, pp.cluster, pp.cluster_eq, pp.uniform_len, pp.nd.from != nullptr || pp.nd.to != nullptr);
     e->loc_second_used = false;
     bool keys_only = false;                                // the key pass made no run lists (see there)
     const bool need_vals = !e->opt_own_sort || e->opt_test_unsorted_index;
@@ -197,9 +202,13 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
         if (pp.keys_shared == 2) {
             // the entry array, index, directory and runs of the previous build are still what this node set needs (a rank that
             // builds its source range in several pieces so that the gather of one piece overlaps the probe of the next)
-            if (e->store_n != nd.n || e->store_words != (const void *) nd.words || e->store_eq != pp.cluster_eq || e->store_buckets != cc.n_buckets ||
-                src_begin < e->store_run_begin || src_end > e->store_run_end)
+            // (a build the pile path kept in its pure form left no entry array and needs none: its piles serve this piece -- the kernels read the
+            // sample's verdict from the device as they did then)
+            const bool store_left = e->store_n == nd.n && e->store_words == (const void *) nd.words && e->store_eq == pp.cluster_eq && e->store_buckets == cc.n_buckets;
+            const bool piles_serve = pile && e->pile_kept_pure && e->store_buckets == cc.n_buckets && e->store_eq == pp.cluster_eq;
+            if (!(store_left || piles_serve) || src_begin < e->store_run_begin || src_end > e->store_run_end)
                 return alga_fail(e, ALGA_ERR_INVALID_ARGUMENT, "keys_shared = 2: no entry array of this node set that covers the sources is left from the previous build");
+            keys_only = pile && e->pile_keys_only;
         } else {
             int32_t run_begin = 0, run_end = nd.n;
             if (pp.keys_shared == 1) {
@@ -282,6 +291,7 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
                     launch_pile_check(e->cl_pile_succ.p, (uint64_t) nd.n, cc.n_buckets, e->cl_pile_tab.p, e->cl_pile_rec2.p, e->pile_epoch, e->cl_runs.p, nd.n, pp.uniform_len - cfg.Lmin + 1,
                                       (unsigned long long *) e->cl_pile_cnt.p, s);
                 e->pile_n = nd.n; e->pile_words = (const void *) nd.words;
+                e->pile_keys_only = keys_only; e->pile_kept_pure = false;            // (the verdict: after the probe)
                 e->pile_timed = nd.n > 0;
             }
             e->store_timed = nd.n > 0;
@@ -330,10 +340,15 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
                 const bool by_key = e->opt_cluster_order != 0 && src_begin == 0 && src_end == nd.n;
                 const bool piled = pile && e->pile_n == nd.n && e->pile_words == (const void *) nd.words;
                 if (piled) {
+                    if (!all_sources) {
+                        if ((rc = alga_ensure(e, e->cl_pile_side_r, (size_t) (n_src + 64) * 16))) return rc;
+                        if ((rc = alga_ensure(e, e->cl_pile_cursor, 64))) return rc;
+                    }
                     // k_pile_probe first; it and k_probe_stream read the same two counters k_pile_build left and exactly one of them works
                     launch_pile_probe(nd, cfg, cc, pp.uniform_len, e->cl_pile_tab.p, e->pile_epoch, e->cl_pile_rec.p, e->cl_pile_rec2.p, e->cl_pile_succ.p,
                                       e->cl_runs.p, cnt, (uint32_t *) e->outdeg.p, (unsigned long long *) e->loc_first.p, (unsigned long long *) e->loc_second.p,
-                                      (int32_t *) e->cl_defer.p, (uint32_t) n_src, (const unsigned long long *) e->cl_pile_cnt.p, e->n_cu, s);
+                                      (int32_t *) e->cl_defer.p, (uint32_t) n_src, (const unsigned long long *) e->cl_pile_cnt.p, e->n_cu, s, src_begin, src_end,
+                                      e->cl_pile_side_r.p, (unsigned long long *) e->cl_pile_cursor.p);
                     if ((rc = alga_check_launch(e, "k_pile_probe"))) return rc;
                     // the sources it handed on have no run list of their own yet (the general kernel reads it): a list-driven key pass over the
                     // defer list, whose length the device knows
@@ -352,7 +367,7 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
                     if ((rc = alga_ensure(e, e->cl_defer2, (size_t) (n_src + 64) * sizeof(int32_t)))) return rc;
                     launch_probe_stream_list(nd, cfg, cc, pp.cluster_eq, e->cl_store.p, e->cl_dir.p, e->cl_runs.p, (const uint8_t *) e->cl_nruns.p, (int32_t *) e->cl_defer.p,
                                              (uint32_t) n_src, cnt, e->n_cu, (uint32_t *) e->outdeg.p, (unsigned long long *) e->loc_first.p,
-                                             (unsigned long long *) e->loc_second.p, (int32_t *) e->cl_defer2.p, (const unsigned long long *) e->cl_pile_cnt.p, s, slot_stride);
+                                             (unsigned long long *) e->loc_second.p, (int32_t *) e->cl_defer2.p, (const unsigned long long *) e->cl_pile_cnt.p, s, slot_stride, src_begin);
                     if ((rc = alga_check_launch(e, "k_probe_stream (list)"))) return rc;
                 }
                 HIP_TRY(e, hipEventRecord(e->ev[EV_PAIRS], s));
@@ -427,6 +442,7 @@ int discover_impl(alga_engine *e, const Prepared &pp, int32_t src_begin, int32_t
                 e->stats.pile_deferred = e->stats.pile_mixed ? e->h_counters[CNT_DEFERRED_PILE] : (kept ? e->h_counters[CNT_DEFERRED] : 0);
                 if (!kept || e->stats.pile_mixed || !e->opt_pile_skip_gather) e->store_n = nd.n;      // (the entry array was built: k_tgt_gather leaves only for a build of the pure pile form)
                 e->expect_pairwise = !kept;               // (how the NEXT build's key pass is laid out -- never what it computes)
+                e->pile_kept_pure = kept && !e->stats.pile_mixed && e->opt_pile_skip_gather != 0;
                 e->stats.pile_list_checked = 0; e->stats.pile_list_mismatch = 0;
                 if (e->opt_pile_check) {
                     unsigned long long chk[2] = {0ull, 0ull};
@@ -695,6 +711,8 @@ int alga_engine_set_option(alga_engine *e, const char *name, int64_t value) {
         rsort_set_variant((int) value);                    // tuning only (process-wide): tile shape of radix_sort.hip
     } else if (!strcmp(name, "stream_slots")) {
         e->opt_stream_slots = value >= 4 ? 4 : 2;
+    } else if (!strcmp(name, "pile_range")) {
+        e->opt_pile_range = value != 0;
     } else if (!strcmp(name, "pkb_legacy")) {
         e->opt_pkb_legacy = (int) value;
     } else if (!strcmp(name, "own_sort")) {

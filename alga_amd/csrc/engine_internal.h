@@ -57,11 +57,14 @@ struct alga_engine {
     bool   warmed = false;                                  // alga_engine_reserve has run its miniature build (kernel code objects loaded)
     bool   pairs_timed = false;                             // EV_PAIRS was recorded in the last discovery
     bool   store_timed = false;                             // EV_KEYS / EV_SORT / EV_GATHER were recorded in the last discovery
+    bool   pile_keys_only = false, pile_kept_pure = false;  // of the build that made the piles at hand: its key pass made no run lists / it kept the build in the pure pile form (no entry array)
+    int    opt_pile_range = 1;                              // option "pile_range": the pile path also for a source id range (a rank's share of the N-GPU build); 0: all sources only, as until round 5
     int    opt_pile_skip_gather = 1;                        // option "pile_skip_gather": no entry array for a build the pile path keeps
     int    opt_pile = 1;                                    // option "pile": the probe through piles (prefsuf_pile.hip) where the input allows it
     int    opt_pile_runs = 1;                               // option "pile_runs": 1 = a pile's run list from its consensus (k_pile_runs_consensus; the key pass of a kept build makes target keys only), 0 = from its outer members' own lists (round 4)
     int    opt_pile_check = 0;                              // option "pile_check" (tests): every node gets its own run list and every first-group member's is compared with its pile's clipped list (stats.pile_list_*)
     bool   expect_pairwise = false;                         // the pile path declined the build before this one: the next key pass makes every run list up front
+    DevBuf cl_pile_side_r, cl_pile_cursor;                  // the side records of a source id range (k_pile_side_range), its block cursor
     DevBuf cl_pile_own;                                     // bit j: entry j of the key order reads a run list of its own
     int    opt_pkb_legacy = 0;                              // option "pkb_legacy" (A/B and tests): bit 0 groups of 8 .. 16 k-mers a wave each, bit 1 the library's k-mer sort, bit 2 head list in three kernels, bit 3 groups of 8 .. 16 replayed inside the pair kernel, bit 4 the library's unique + a row-pointer pass after the merge, bit 5 the k-mer walk on a 128-bit value, bit 6 every tip record's snapshot half rewritten every round, bit 7 a k-mer walk per round
     int    opt_own_sort = 1;                                // option "own_sort": the (key, id) sort of the index build is the engine's own radix sort (radix_sort.hip); 0: rocPRIM's
@@ -200,7 +203,7 @@ inline int alga_ensure(alga_engine *e, DevBuf &b, size_t bytes) {
 // node set that lived there -- key pass, entry array, node statistics -- may be reused by a later build (they are matched on
 // addresses and sizes, which a rewrite does not change).
 inline void alga_forget_node_set(alga_engine *e) {
-    e->keyed_n = -1; e->store_n = -1;
+    e->keyed_n = -1; e->store_n = -1; e->pile_n = -1;
     e->stat_len = nullptr; e->stat_from = nullptr; e->stat_to = nullptr;
 }
 

@@ -1427,12 +1427,12 @@ __global__ void __launch_bounds__(256) k_defer_swap(const unsigned long long *__
 
 void launch_probe_stream_list(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterCfg &cc, int eq, const void *store, const void *dir, const void *runs, const uint8_t *nruns,
                               int32_t *src_list, uint32_t list_cap, unsigned long long *counters, int n_cu, uint32_t *deg, unsigned long long *first,
-                              unsigned long long *second, int32_t *defer2, const unsigned long long *pile_cnt, hipStream_t s, uint32_t slot_stride) {
+                              unsigned long long *second, int32_t *defer2, const unsigned long long *pile_cnt, hipStream_t s, uint32_t slot_stride, int32_t src_base) {
     if (eq != 3 || list_cap == 0) return;                  // (the pile path takes entries of three pieces only: pile_plan)
     const int kf = (2 * cfg.Lmin) >> 5;
     const int kfs = (kf == 5 || kf == 3) ? kf : 0;
     const dim3 grid((unsigned) std::max(1, n_cu) * clq_occ(3, kfs, false)), block(PROBE_WAVES * 64);
-    ProbeOut o{nullptr, nullptr, 0, counters, deg, first, 0, second};
+    ProbeOut o{nullptr, nullptr, 0, counters, deg, first, src_base, second};       // (src_base: the listed ids are those of a rank's range, the slots count from its first)
     o.slot_stride = slot_stride;
 #define CLQ_LIST(K) hipLaunchKernelGGL((k_probe_stream<false, 3, K, false, true>), grid, block, 0, s, nd, cfg, cc, (const uint4 *) store, (const uint4 *) dir, (const uint2 *) runs, nruns, 0, \
                                        (int32_t) std::min<uint32_t>(list_cap, 0x7FFFFFFFu), o, defer2, list_cap, pile_cnt, (const int32_t *) src_list, (const unsigned long long *) (counters + CNT_DEFERRED))

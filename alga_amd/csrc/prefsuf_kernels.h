@@ -88,10 +88,12 @@ void       launch_pile_check(const void *side, uint64_t n_entries, uint32_t n_bu
 // mixed form of a pile-path build: k_probe_stream over the sources on src_list (count on the device: counters[CNT_DEFERRED]), rejects to defer2, then the swap
 void       launch_probe_stream_list(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterCfg &cc, int eq, const void *store, const void *dir, const void *runs, const uint8_t *nruns,
                                     int32_t *src_list, uint32_t list_cap, unsigned long long *counters, int n_cu, uint32_t *deg, unsigned long long *first,
-                                    unsigned long long *second, int32_t *defer2, const unsigned long long *pile_cnt, hipStream_t s, uint32_t slot_stride = 0);
+                                    unsigned long long *second, int32_t *defer2, const unsigned long long *pile_cnt, hipStream_t s, uint32_t slot_stride = 0,
+                                    int32_t src_base = 0 /* the slot arrays count from this id (a rank's range) */);
 void       launch_pile_probe(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterCfg &cc, int uniform_len, const void *tab, uint32_t epoch, const void *rec, const void *rec2, const void *side,
                              const void *runs, unsigned long long *counters, uint32_t *deg, unsigned long long *first, unsigned long long *second, int32_t *defer_list,
-                             uint32_t defer_cap, const unsigned long long *pile_cnt, int n_cu, hipStream_t s);
+                             uint32_t defer_cap, const unsigned long long *pile_cnt, int n_cu, hipStream_t s, int32_t src_begin, int32_t src_end,
+                             void *side_range /* a range that is not all nodes: (src_end - src_begin + 64) * 16 B of scratch */, unsigned long long *cursor /* ... and a word */);
 
 // radix_sort.hip: the engine's own stable LSD radix sort of (u32 key, u32 value) pairs on the key bits [begin_bit, 32)
 size_t     rsort_u32_pairs_temp_bytes(uint64_t n);

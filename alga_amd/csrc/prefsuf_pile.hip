@@ -591,10 +591,10 @@ constexpr int PP_LSTRIDE = 20;
 // the waves' waiting for memory -- the chain side record -> run list -> bucket records -> the targets that stand -- at four waves per SIMD
 // (five spill: 9.9 against 7.9 ms): side record and run list are read a tile ahead, the records of the next run are on their way while
 // the current one is compared (of the next two: no faster), the run loop is unrolled over the eight slots (static registers; a wave skips the slots none of its lanes uses).
-__global__ void __launch_bounds__(PP_WAVES * 64, PP_OCC) k_pile_probe(PrefSufCfg cfg, ClusterCfg cc, int U, NodesDev nd, uint64_t n_entries, int n_nodes,
+__global__ void __launch_bounds__(PP_WAVES * 64, PP_OCC) k_pile_probe(PrefSufCfg cfg, ClusterCfg cc, int U, NodesDev nd, uint64_t n_entries, uint64_t n_mine, int n_nodes,
                                                                  const uint4 *__restrict__ tab, uint32_t epoch, const uint4 *__restrict__ rec, const uint4 *__restrict__ rec2,
-                                                                 const uint4 *__restrict__ side, const uint2 *__restrict__ runs, ProbeOut o, int32_t *__restrict__ defer_list, uint32_t defer_cap,
-                                                                 const unsigned long long *__restrict__ pile_cnt) {
+                                                                 const uint4 *__restrict__ side, const uint4 *__restrict__ side_src, const uint2 *__restrict__ runs, ProbeOut o,
+                                                                 int32_t *__restrict__ defer_list, uint32_t defer_cap, const unsigned long long *__restrict__ pile_cnt) {
     // the records of the slot at hand, ONE copy per distinct bucket of the wave (the members of a pile sit side by side and want the same
     // records): PP_LSTRIDE words per record (16 used; 20: the lanes of sixteen records read conflict-free), four words of slack in front and
     // twelve behind -- a compare reads up to four words before and six behind a record, and what it finds there is masked
@@ -622,8 +622,10 @@ __global__ void __launch_bounds__(PP_WAVES * 64, PP_OCC) k_pile_probe(PrefSufCfg
         wave_lds_fence();
         n_defer = 0;
     };
-    const uint64_t n_tiles = (n_entries + PP_WAVES * 64 - 1) / (PP_WAVES * 64);
-    const uint64_t last = n_entries - 1;
+    // side_src, n_mine: the side records this launch WALKS -- side itself, all n_entries of them, or (a rank's share: k_pile_side_range's output)
+    // those of the sources of an id range; every other index (entries, group slots, the side records of TARGETS) is one of the whole entry array
+    const uint64_t n_tiles = (n_mine + PP_WAVES * 64 - 1) / (PP_WAVES * 64);
+    const uint64_t last = n_entries - 1, last_mine = n_mine - 1;
     // What a lane reads of its source is a 16-byte SIDE record (k_pile_build: id, the right neighbour in its pile, its place in the pile), a
     // tile ahead, and the run list by that id while this tile's targets are looked up.  The source's ROW is not read at all where the source is
     // a member of its home bucket's first group (94 % of them): it equals that group's consensus on its whole extent -- k_pile_build verified
@@ -631,7 +633,7 @@ __global__ void __launch_bounds__(PP_WAVES * 64, PP_OCC) k_pile_probe(PrefSufCfg
     // ~4.6 L1 misses per source; the other sources read their row from the entry array.)
     auto side_of = [&](uint64_t t) -> uint4 {              // side record of this lane's source in tile t (clamped: the last entry)
         const uint64_t j = t * (PP_WAVES * 64) + threadIdx.x;
-        uint4 v = side[j < n_entries ? j : last];
+        uint4 v = side_src[j < n_mine ? j : last_mine];
         v.x = min(v.x, (uint32_t) n_nodes - 1u);
         return v;
     };
@@ -652,7 +654,7 @@ __global__ void __launch_bounds__(PP_WAVES * 64, PP_OCC) k_pile_probe(PrefSufCfg
     }
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {      // uniform
     const uint64_t j = tile * (PP_WAVES * 64) + threadIdx.x;
-    const bool have = j < n_entries;
+    const bool have = j < n_mine;
     const uint4 my = next_side;                            // {id, right neighbour's id, its offset | m_C << 8 | group << 16 | first-group member << 31, -}
     const int Bs = (int) my.x;
     const bool first_group = (my.z >> 31) != 0u;
@@ -1082,17 +1084,69 @@ void launch_pile_check(const void *side, uint64_t n_entries, uint32_t n_buckets,
                        n_nodes, nwin, pile_cnt + 4, (const unsigned long long *) pile_cnt);
 }
 
+// A rank's share of the sources (the strong-scaling N-GPU build: every rank holds the index, the sources are dealt out by id range): the side records
+// of the entries whose id lies in [src_begin, src_end), compacted block by block -- a block of 1024 entries keeps its order, so the members of a
+// pile that fall into the range still sit side by side and share the wave's copy of their bucket's record; the order of the blocks is that of
+// their atomics (the probe's results do not depend on the order of its sources).  Every node has exactly one entry: src_end - src_begin records.
+constexpr int PSR_IPT = 4;
+__global__ void __launch_bounds__(256) k_pile_side_range(const uint4 *__restrict__ side, uint64_t n_entries, uint32_t src_begin, uint32_t src_end, uint4 *__restrict__ out,
+                                                         uint64_t out_cap, unsigned long long *__restrict__ cursor, const unsigned long long *__restrict__ pile_cnt) {
+    if (pile_declines(pile_cnt)) return;
+    __shared__ uint32_t cnt[PSR_IPT * 4];
+    __shared__ unsigned long long base;
+    const int wave = (int) (threadIdx.x >> 6);
+    const uint64_t b0 = (uint64_t) blockIdx.x * (256 * PSR_IPT);
+    uint4 v[PSR_IPT];
+    uint32_t before[PSR_IPT];
+    bool in[PSR_IPT];
+#pragma unroll
+    for (int k = 0; k < PSR_IPT; k++) {
+        const uint64_t j = b0 + (uint64_t) k * 256 + threadIdx.x;
+        v[k] = j < n_entries ? side[j] : make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);
+        in[k] = j < n_entries && v[k].x >= src_begin && v[k].x < src_end;
+        const uint64_t m = __ballot(in[k]);
+        before[k] = (uint32_t) __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, 0u));
+        if ((threadIdx.x & 63u) == 0u) cnt[k * 4 + wave] = (uint32_t) __popcll(m);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (int i = 0; i < PSR_IPT * 4; i++) tot += cnt[i];
+        base = tot ? atomicAdd(cursor, (unsigned long long) tot) : 0ull;
+    }
+    __syncthreads();
+    uint32_t run = 0;
+#pragma unroll
+    for (int k = 0; k < PSR_IPT; k++) {
+        uint32_t mine = run;
+        for (int w = 0; w < 4; w++) { if (w < wave) mine += cnt[k * 4 + w]; run += cnt[k * 4 + w]; }
+        const unsigned long long at = base + mine + before[k];
+        if (in[k] && at < out_cap) out[at] = v[k];
+    }
+}
+
+// side_range / cursor: scratch for a source range that is not all nodes (src_end - src_begin + 64 records of 16 B; one 64-bit word), else unused
 void launch_pile_probe(const NodesDev &nd, const PrefSufCfg &cfg, const ClusterCfg &cc, int uniform_len, const void *tab, uint32_t epoch, const void *rec, const void *rec2,
                        const void *side, const void *runs, unsigned long long *counters, uint32_t *deg, unsigned long long *first, unsigned long long *second,
-                       int32_t *defer_list, uint32_t defer_cap, const unsigned long long *pile_cnt, int n_cu, hipStream_t s) {
+                       int32_t *defer_list, uint32_t defer_cap, const unsigned long long *pile_cnt, int n_cu, hipStream_t s, int32_t src_begin, int32_t src_end,
+                       void *side_range, unsigned long long *cursor) {
     const uint64_t n_entries = nd.n > 0 ? (uint64_t) nd.n : 0;
-    if (n_entries == 0) return;
+    if (n_entries == 0 || src_end <= src_begin) return;
     ProbeOut o{};
-    o.counters = counters; o.deg = deg; o.first = first; o.second = second; o.src_base = 0;
-    const uint64_t tiles = (n_entries + PP_WAVES * 64 - 1) / (PP_WAVES * 64);
+    o.counters = counters; o.deg = deg; o.first = first; o.second = second; o.src_base = src_begin;
+    uint64_t n_mine = n_entries;
+    const void *side_src = side;
+    if (src_begin != 0 || src_end != nd.n) {
+        n_mine = (uint64_t) (src_end - src_begin);
+        (void) hipMemsetAsync(cursor, 0, sizeof(unsigned long long), s);
+        hipLaunchKernelGGL(k_pile_side_range, dim3((unsigned) ((n_entries + 256 * PSR_IPT - 1) / (256 * PSR_IPT))), dim3(256), 0, s, (const uint4 *) side, n_entries,
+                           (uint32_t) src_begin, (uint32_t) src_end, (uint4 *) side_range, n_mine, cursor, pile_cnt);
+        side_src = side_range;
+    }
+    const uint64_t tiles = (n_mine + PP_WAVES * 64 - 1) / (PP_WAVES * 64);
     const dim3 grid((unsigned) std::max<uint64_t>(1, std::min<uint64_t>(tiles, (uint64_t) std::max(1, n_cu) * (PP_OCC * 4 / PP_WAVES)))), block(PP_WAVES * 64);      // PP_OCC waves per SIMD, four SIMDs per CU
-    hipLaunchKernelGGL(k_pile_probe, grid, block, 0, s, cfg, cc, uniform_len, nd, n_entries, nd.n, (const uint4 *) tab, epoch, (const uint4 *) rec, (const uint4 *) rec2,
-                       (const uint4 *) side, (const uint2 *) runs, o, defer_list, defer_cap, pile_cnt);
+    hipLaunchKernelGGL(k_pile_probe, grid, block, 0, s, cfg, cc, uniform_len, nd, n_entries, n_mine, nd.n, (const uint4 *) tab, epoch, (const uint4 *) rec, (const uint4 *) rec2,
+                       (const uint4 *) side, (const uint4 *) side_src, (const uint2 *) runs, o, defer_list, defer_cap, pile_cnt);
 }
 
 void launch_pile_deg(int32_t n, unsigned long long *first, uint32_t *deg, const unsigned long long *pile_cnt, hipStream_t s) {

@@ -191,6 +191,8 @@ int         alga_engine_device_name(const alga_engine *e, char *buf, size_t bufl
  *   "stream_slots"               default 4: k_probe_stream writes the edges of a source with up to four standing items itself (slots beside the source's
  *                                first: 16 B per node more; eight measured no better); 2: two, any other source goes to the general kernel (the form until
  *                                round 4; A/B and tests)
+ *   "pile_range"                 default 1: the pile path also takes a build of a source id range (a rank's share of the strong-scaling N-GPU build: the
+ *                                index as for all sources, the range's sources compacted for k_pile_probe); 0: all sources only (until round 5; A/B and tests)
  *   "pkb_legacy"                 default 0; A/B and tests: one bit per piece of the approximate supplement that round 5 reworked, set = round 4's form of it:
  *                                1 groups of 8..16 k-mers a wave each (now four per wave), 2 the library's sort of the k-mer entries (now the engine's),
  *                                4 group heads in three kernels (now one), 8 the replay of the 8..16 groups inside the pair kernel, 16 the library's sort /

@@ -292,10 +292,11 @@ def test_out_of_memory_in_the_pile_buffers_falls_back_to_the_pairwise_kernels(en
     assert st["pile_buckets"] > 0 and st["ms_pile"] > 0
 
 
-def test_a_further_piece_after_a_build_the_pile_path_declined(eng):
-    """params.keys_shared = 2 (a further piece of the same node set reuses the entry array of the build before it): refused after a build the
-    pile path KEPT (there is no entry array), but a build it DECLINED -- reads with errors: decided on the device -- did make one and must
-    serve the next piece as it did before the pile path existed."""
+def test_a_further_piece_after_a_build_the_pile_path_kept_or_declined(eng):
+    """params.keys_shared = 2 (a further piece of the same node set reuses the index of the build before it): a build the pile path DECLINED --
+    reads with errors: decided on the device -- made an entry array and serves the next piece as before the pile path existed (ADVICE round 4);
+    one it KEPT left none and serves the piece through its piles (round 5: k_pile_probe over the piece's id range; with option pile_range 0 such a
+    piece is refused, as it was until then)."""
     import torch
     from alga_amd.engine import device_view
     lo, rs = alga_amd.derive_params(144.0)
@@ -312,13 +313,61 @@ def test_a_further_piece_after_a_build_the_pile_path_declined(eng):
         assert full.shape == want.shape and (full == want).all()
         half = (n // 4) * 2
         if kept:
-            with pytest.raises(alga_amd.AlgaError):
-                eng.build_range_device(dw, dl, lo, rs, 0, half, keys_shared=2)
-        else:
-            ptr, m = eng.build_range_device(dw, dl, lo, rs, 0, half, keys_shared=2)
+            eng.set_option("pile_range", 0)
+            try:
+                with pytest.raises(alga_amd.AlgaError):
+                    eng.build_range_device(dw, dl, lo, rs, 0, half, keys_shared=2)
+            finally:
+                eng.set_option("pile_range", 1)
+            ptr, m = eng.build_range_device(dw, dl, lo, rs, 0, n)            # (the refusal forgot nothing, but the piles are those of a build: again)
+        for a, b in ((0, half), (half, n), (half - 6, half + 10)):
+            ptr, m = eng.build_range_device(dw, dl, lo, rs, a, b, keys_shared=2)
             got = device_view(ptr, (m, 3), dw.device).cpu().numpy()
-            sel = want[want[:, 0] < half]
-            assert got.shape == sel.shape and (got == sel).all()
+            sel = want[(want[:, 0] >= a) & (want[:, 0] < b)]
+            assert got.shape == sel.shape and (got == sel).all(), (err, a, b)
+
+
+@pytest.mark.parametrize("pile,what", [(1, "sampled"), (2, "forced, pure form"), (3, "forced, mixed form")])
+def test_pile_path_for_a_rank_s_id_range(eng, pile, what):
+    """The strong-scaling N-GPU build deals the SOURCES out by id range while every rank holds the index: the pile path takes such a build too
+    (round 5: k_pile_side_range compacts the side records of the range's sources, k_pile_probe walks those).  Ranges as 2, 3 and 7 ranks would
+    get them, odd borders, a range of one twin pair and the whole: each equals the oracle's edges of those sources, the pairwise kernels' (option
+    pile 0) and the build before round 5 (option pile_range 0: pairwise for a range); on plain reads and on a genome with repeats (deferred
+    sources: the general kernel by list, in the mixed form the stream kernel first)."""
+    import torch
+    from alga_amd.engine import device_view
+    lo, rs = alga_amd.derive_params(144.0)
+    rng = np.random.default_rng(5)
+    unit = rng.integers(0, 4, 3000, dtype=np.uint8)
+    genome = np.concatenate([rng.integers(0, 4, 60_000, dtype=np.uint8), unit, rng.integers(0, 4, 20_000, dtype=np.uint8), unit, rng.integers(0, 4, 30_000, dtype=np.uint8)])
+    for words, lens in (_nodes(20_000, 150, 100_000, 41), _nodes(24_000, 150, 0, 42, genome=genome)):
+        want, _, _ = O.prefsuf(words, lens, lo, rs)
+        dw = torch.from_numpy(words.view(np.int32)).cuda()
+        dl = torch.from_numpy(lens.astype(np.int32)).cuda()
+        n = len(lens)
+        cuts = sorted({0, n} | {(n * k // w) for w in (2, 3, 7) for k in range(1, w)} | {n // 2 + 1, n // 3 - 1})
+        ranges = list(zip(cuts[:-1], cuts[1:])) + [(0, n), (n // 2, n // 2 + 2), (1, n - 1)]
+        eng.set_option("pile", pile)
+        try:
+            for a, b in ranges:
+                ptr, m = eng.build_range_device(dw, dl, lo, rs, a, b)
+                st = eng.last_stats()
+                got = device_view(ptr, (m, 3), dw.device).cpu().numpy()
+                sel = want[(want[:, 0] >= a) & (want[:, 0] < b)]
+                assert got.shape == sel.shape and (got == sel).all(), (what, a, b)
+                assert st["ms_pile"] > 0 and (pile != 1 or st["pile_buckets"] > 0), (what, a, b)       # the piles were built for the range's build (forced: no sample, no count)
+                if pile == 3:
+                    assert st["pile_mixed"] == 1, (a, b, st)
+            eng.set_option("pile_range", 0)
+            for a, b in ranges[:3]:
+                ptr, m = eng.build_range_device(dw, dl, lo, rs, a, b)
+                st = eng.last_stats()
+                got = device_view(ptr, (m, 3), dw.device).cpu().numpy()
+                sel = want[(want[:, 0] >= a) & (want[:, 0] < b)]
+                assert got.shape == sel.shape and (got == sel).all() and st["pile_buckets"] == 0, (a, b)
+        finally:
+            eng.set_option("pile", 1)
+            eng.set_option("pile_range", 1)
 
 
 @pytest.mark.parametrize("length,coverage,G", [(150, 30, 400_000), (150, 8, 300_000), (100, 40, 200_000), (150, 120, 60_000), (132, 25, 200_000)])
