@@ -355,12 +355,19 @@ void rank_main(alga_multi *m, int r, const alga_nodes *nodes_r, const alga_prefs
     const int32_t b0 = (int32_t) std::min<int64_t>(n, (int64_t) r * chunk), b1 = (int32_t) std::min<int64_t>(n, (int64_t) (r + 1) * chunk);
     double t0 = now_ms();
     // ---- 2. keys of my nodes ----
+    // (up to four ranks: no shared key pass -- every rank's build computes the target keys of all nodes itself and goes through the pile path
+    // for its id range: 16.0 / 13.9 ms of compute per rank at two / four ranks against 23.4 / 14.8 through the pairwise kernels, and no key
+    // all-gather; from five ranks on the shared key pass and the pairwise kernels: tools/emulate_rank.py)
+    const bool keys_local = N <= 4 && m->form != ALGA_MULTI_FORM_BUCKET_SHARDED;
     alga_node_keys k{};
-    int rc = alga_prefsuf_keys_device(e, nodes_r, p, b0, b1, (void *) s, &k);
-    if (rc != ALGA_OK) co.fail(rc, alga_last_error(e));
+    int rc = ALGA_OK;
+    if (!keys_local) {
+        rc = alga_prefsuf_keys_device(e, nodes_r, p, b0, b1, (void *) s, &k);
+        if (rc != ALGA_OK) co.fail(rc, alga_last_error(e));
+    }
     m->keys[(size_t) r] = k;
     Agreed ag = rendezvous(m);
-    bool shared = !ag.failed && (int64_t) N * chunk <= n + ALGA_KEY_ARRAY_SLACK;
+    bool shared = !keys_local && !ag.failed && (int64_t) N * chunk <= n + ALGA_KEY_ARRAY_SLACK;
     for (int q = 0; q < N && shared; q++) shared = m->keys[(size_t) q].eligible != 0;      // (written before the rendezvous, not touched again in this build)
     double t1 = now_ms();
     // ---- 3. share ----

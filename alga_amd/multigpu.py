@@ -617,10 +617,12 @@ def validated_runner(backend, rank, world, dist, plain=None, **fast_kw):
     form = {"form": "plain (all keys on every rank, one piece per rank)", "validated": None}
     if world <= 1:
         return plain, form
-    # two ranks: every rank computes all keys itself (5.4 ms at the north-star size) -- cheaper than the keys of half the nodes plus the
-    # all-gather of the other half over the one link between two GPUs (2.7 + 3.6 ms), and one collective less; from three ranks on the
-    # sharded key pass wins (1.5 + 1.8 ms at four)
-    kw = dict(shard_keys=world > 2, pieces=None)
+    # Up to four ranks every rank computes all keys itself: the build then goes through the PILE path on every rank (round 5: k_pile_probe over
+    # the rank's id range, include/alga_amd.h option pile_range) -- its key pass makes target keys alone (1.5 ms at the north-star size, less than
+    # the all-gather of the other ranks' keys costs), and a rank's compute is 16.0 / 13.9 ms at two / four ranks against 23.4 / 14.8 ms through the
+    # pairwise kernels (tools/emulate_rank.py).  From five ranks on the index every rank must hold (9.7 ms through the piles)
+    # outweighs the probe it saves: keys of the own nodes + all-gather, pairwise kernels (10.1 against 12.5 ms at eight).
+    kw = dict(shard_keys=world > 4, pieces=None)
     kw.update(fast_kw)
     # No exception handling around the collectives: a rank that raised alone inside a step would leave its peers in a collective it
     # never joins -- an error there ends the job (the process group's timeout sees to the peers).  Plain or fast is
@@ -633,7 +635,7 @@ def validated_runner(backend, rank, world, dist, plain=None, **fast_kw):
     t = torch.tensor([ok], dtype=torch.int64, device=backend.device)
     dist.all_reduce(t)
     if int(t.item()) == world:
-        what = "keys of own nodes + in-place key all-gather" if fast.shard_keys else "all keys on every rank"
+        what = "keys of own nodes + in-place key all-gather" if fast.shard_keys else "all keys on every rank (the rank's sources through the pile path where the build keeps it)"
         if getattr(fast, "bucket_sharded", False):
             what = "index sharded by seed bucket (%s)" % ("alga_shard_*: descriptors to the bucket's owner, per-target reduction there" if fast.form_used == "bucket_sharded"
                                                           else "DECLINED by the engine: replicated form with the gathered keys")

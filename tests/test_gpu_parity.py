@@ -622,8 +622,9 @@ def test_sharded_driver_three_ranks_one_gpu_at_a_payload_that_can_race():
 
 
 def test_validated_runner_three_ranks_one_gpu():
-    """What bench.py --gpus N times (alga_amd.multigpu.validated_runner): the sharded key pass + pieces after their graph equalled
-    the plain form's, on the real HipBackend at 1 M reads, three ranks on this GPU."""
+    """What bench.py --gpus N times (alga_amd.multigpu.validated_runner): the source range in pieces -- up to four ranks with all keys computed
+    on every rank (the pieces then go through the pile path), from five on with the sharded key pass -- after their graph equalled the plain
+    form's, on the real HipBackend at 1 M reads, three and five ranks on this GPU."""
     import torch
     from alga_amd import workload
     from alga_amd.multigpu import HipBackend, validated_runner
@@ -639,18 +640,24 @@ def test_validated_runner_three_ranks_one_gpu():
     finally:
         e0.close()
 
-    def rank_main(rank, dist):
-        e = alga_amd.Engine(0)
-        try:
-            run, form = validated_runner(HipBackend(e, dw, dl, lo, rs), rank, 3, dist)
-            assert form["form"].startswith("keys of own nodes") and run.pieces == 4 and run.shard_keys, form
-            m_r, _ = run.step()
-            assert m_r == len(want)
-            return run.edges_numpy()
-        finally:
-            e.close()
-    res = run_ranks(3, rank_main)
-    assert res[0].shape == want.shape and (res[0] == want).all()
+    for world in (3, 5):
+        def rank_main(rank, dist):
+            e = alga_amd.Engine(0)
+            try:
+                run, form = validated_runner(HipBackend(e, dw, dl, lo, rs), rank, world, dist)
+                if world <= 4:                            # every rank computes all keys: its build goes through the pile path for its id range, in pieces
+                    assert form["form"].startswith("all keys on every rank") and run.pieces == 4 and not run.shard_keys, form
+                else:
+                    assert form["form"].startswith("keys of own nodes") and run.pieces == 3 and run.shard_keys, form
+                m_r, _ = run.step()
+                assert m_r == len(want)
+                return run.edges_numpy(), e.last_stats()
+            finally:
+                e.close()
+        res = run_ranks(world, rank_main)
+        assert res[0][0].shape == want.shape and (res[0][0] == want).all()
+        # (the last piece's statistics: the piles served it at three ranks, the pairwise kernels at five)
+        assert all((st["pile_buckets"] > 0) == (world <= 4) for _, st in res), [st["pile_buckets"] for _, st in res]
 
 
 def test_bench_run_as_two_thread_ranks_equals_one_gpu():
@@ -668,7 +675,7 @@ def test_bench_run_as_two_thread_ranks_equals_one_gpu():
     assert res[1] is None
     two = res[0]
     assert two["n_gpus"] == 2 and two["config"]["edges"] == one["config"]["edges"] > 5_000_000 and two["config"]["nodes"] == one["config"]["nodes"]
-    assert two["multi_gpu_form"]["form"].startswith("all keys on every rank, 4 pieces") and "byte-identical" in two["multi_gpu_form"]["validated"]   # (two ranks: no key all-gather)
+    assert two["multi_gpu_form"]["form"].startswith("all keys on every rank") and ", 4 pieces" in two["multi_gpu_form"]["form"] and "byte-identical" in two["multi_gpu_form"]["validated"]   # (two ranks: no key all-gather; the pieces through the pile path)
     assert two["value"] > 0 and two["roofline"]["frac"] > 0 and two["scaling"] == "strong"
     plain = run_ranks(2, lambda rank, dist: bench.run(bench.parse_args(["--gpus", "2", "--multi-plain"] + common), rank, 2, 0, dist))[0]
     assert plain["config"]["edges"] == one["config"]["edges"] and plain["multi_gpu_form"]["form"].startswith("plain")

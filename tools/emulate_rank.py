@@ -66,4 +66,20 @@ for r in sorted(set([0, N - 1])):
     a = [sum(x) / len(x) for x in zip(*rows)]
     out["rank%d" % r] = {"sources": b[r + 1] - b[r], "edges": res[1], "ms_keys_own_nodes_wall": a[0], "ms_store_build": a[1], "ms_probe": a[2],
                          "ms_emit": a[3], "ms_compute_wall": a[4]}
+    # the PILE form of the same rank (round 5): every rank computes the target keys of all nodes itself (the key pass of a build the piles keep
+    # makes no run lists), builds the piles, and k_pile_probe walks the rank's id range -- one build call, no key all-gather
+    rows = []
+    for it in range(steps + 1):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = eng.build_range_device(dw, dl, lo, rs, b[r], b[r + 1], keys_shared=0)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        st = eng.last_stats()
+        if it:
+            rows.append((st["ms_seed"], st["ms_probe"], st["ms_emit"], st["ms_total"], (t1 - t0) * 1e3))
+    a = [sum(x) / len(x) for x in zip(*rows)]
+    out["rank%d_pile_form" % r] = {"sources": b[r + 1] - b[r], "edges": res[1], "ms_index": a[0], "ms_probe": a[1], "ms_emit": a[2], "ms_device": a[3],
+                                   "ms_compute_wall": a[4], "pile_buckets": st["pile_buckets"], "pile_mixed": st["pile_mixed"],
+                                   "same_edges_as_replicated_form": res[1] == out["rank%d" % r]["edges"]}
 print(json.dumps(out))
