@@ -92,10 +92,11 @@ typedef struct {
     int32_t keys_shared;      /* sharded form only.  1: the per-node keys were made by alga_prefsuf_keys_device and
                                  all-gathered by the caller; the build skips its own key pass.  2: this build follows
                                  another build of the SAME node set on this engine (nothing else in between) and reuses
-                                 its sorted entry array: only the probe of [src_begin, src_end) runs.  A previous build that
-                                 the pile path KEPT (reads of one length, no masks, all sources, the sample found the buckets
-                                 regular: option "pile") has no entry array: keys_shared = 2 after it is refused with
-                                 ALGA_ERR_INVALID_ARGUMENT; after one the pile path declined it works as before        */
+                                 its index: only the probe of [src_begin, src_end) runs.  A previous build that the pile path
+                                 KEPT (reads of one length, no masks, the sample found the buckets regular: option "pile")
+                                 has no entry array: the piece goes through its piles (k_pile_probe over the piece's ids;
+                                 with option "pile_range" 0 it is refused with ALGA_ERR_INVALID_ARGUMENT, as until round 5);
+                                 after a build the pile path declined the entry array serves the piece as before        */
     int32_t twin_rows;        /* host entry points only.  1: nodes->words holds the rows of the ODD nodes alone (row k = node 2k + 1,
                                  n / 2 rows): node 2k is the reverse complement of node 2k + 1 -- ALGA's layout (src/IO/InputReader.cpp:
                                  78-80,363-377; the duplicate removal deletes twins together, src/main.cpp:150-232) -- and its row is
@@ -318,6 +319,9 @@ int  alga_prefsuf_build_range_device(alga_engine *e, const alga_nodes *nodes, co
  *      the bucket order, builds the entry array and probes.
  *   A rank may cut step 3 into pieces (first piece keys_shared = 1, the following ones keys_shared = 2 on consecutive source
  *   sub-ranges) so that the transfer of one piece's edges overlaps the probe of the next.
+ *   Up to four ranks the drivers (engine_multi.hip, alga_amd.multigpu) skip steps 1-2: every rank's build (keys_shared = 0, its id range) computes
+ *   the target keys of all nodes itself -- the key pass of a build the PILE path keeps makes no run lists, 1.5 ms at the north-star size -- and
+ *   probes its range through the piles; the shared key pass pays from five ranks on.
  * out->eligible == 0: the CLUSTER probe does not take this input (every rank gets the same answer for the same node set and
  * options); skip steps 2-3's flag and call the build as before.  The arrays are engine-owned, valid until the next build, and
  * have room for n + ALGA_KEY_ARRAY_SLACK entries, so that equal-sized slices (ceil(n / ranks), the last one running past n) can be
