@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """The approximate supplement with option pkb_legacy at several values, on the same resident exact graph (BASELINE configs[4]'s shape by default),
 results compared edge for edge:
-  tools/ab_pkb.py [values=0,256] [n_reads=10000000] [genome=30000000] [steps=8] [err=0.02]
-prints one JSON line: per value (A B A B) the mean device time of the supplement."""
+  tools/ab_pkb.py [values=0,256] [n_reads=10000000] [genome=30000000] [steps=8] [err=0.02] [with_build=0]
+prints one JSON line: per value (A B A B) the mean device time of the supplement.  with_build 1: the exact build runs in front of every supplement,
+as in bench.py's step (its buffers and the caches are then what the supplement finds there)."""
 import json
 import os
 import sys
@@ -20,6 +21,7 @@ n_reads = int(sys.argv[2]) if len(sys.argv) > 2 else 10_000_000
 G = int(sys.argv[3]) if len(sys.argv) > 3 else 30_000_000
 steps = int(sys.argv[4]) if len(sys.argv) > 4 else 8
 err = float(sys.argv[5]) if len(sys.argv) > 5 else 0.02
+with_build = len(sys.argv) > 6 and sys.argv[6] == "1"
 wl = workload.device_build(n_reads, 150, G, 11, err=err)
 torch.cuda.synchronize()
 dw, dl, lo, rs = wl["words"], wl["lens"], wl["min_overlap"], wl["rsoemo"]
@@ -34,6 +36,8 @@ for rep in range(2):
         eng.set_option("pkb_legacy", v)
         acc = 0.0
         for it in range(steps + 1):
+            if with_build:
+                eng.prefsuf_device(dw, dl, lo, rs)
             p2, m2 = eng.pkb_supplement_device(dw, dl, exact.data_ptr(), int(exact.shape[0]), pkb)
             if it:
                 acc += eng.pkb_last_stats()["ms_total"]
