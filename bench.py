@@ -479,7 +479,7 @@ def run(args, rank, world, local_rank, dist, t_process=None):
                                  "group_hist_2_3_4_7_15_31_64_more": ps.get("group_hist"),
                                  "algorithmic_bytes": int(ab), "achieved": ab / (ms["supplement"] * 1e-3) / 1e9, "frac": ab / (ms["supplement"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                  "per_unit": "SURVEY.md section 8(d) for cfg 5: 24 B per LI k-mer + 8W B per canAlign call (+ 8 B per edge key of the graph merged per round); "
-                                             "sort / merge / unique are rocPRIM, the group joins are k_pkb_groups_* (DESIGN.md section 9)"}
+                                             "the sorts are the engine's own radix sort (radix_sort.hip), the merge of a round's additions rocPRIM's, the group joins k_pkb_groups_*; from round 1 on a round's sort runs on a second stream beside the round before (DESIGN.md section 9)"}
         if first is not None:
             first["warm_ms"] = ms_step - (ms["supplement"] if supplement else 0.0)
             first["first_over_warm"] = first["first_call_ms"] / first["warm_ms"]
