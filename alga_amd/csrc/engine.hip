@@ -717,6 +717,8 @@ int alga_engine_set_option(alga_engine *e, const char *name, int64_t value) {
         e->opt_pkb_legacy = (int) value;
     } else if (!strcmp(name, "own_sort")) {
         e->opt_own_sort = value != 0;
+    } else if (!strcmp(name, "test_presort_oom")) {
+        e->opt_test_presort_oom = value != 0;              // tests only: the supplement's look-ahead buffers answer out of memory; the rounds must go on serially
     } else if (!strcmp(name, "test_pile_oom")) {
         e->opt_test_pile_oom = value != 0;                 // tests only: the pile path's allocation answers out of memory; the build must continue on the pairwise kernels
     } else if (!strcmp(name, "test_unsorted_index")) {

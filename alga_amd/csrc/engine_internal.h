@@ -68,6 +68,7 @@ struct alga_engine {
     DevBuf cl_pile_own;                                     // bit j: entry j of the key order reads a run list of its own
     int    opt_pkb_legacy = 0;                              // option "pkb_legacy" (A/B and tests): bit 0 groups of 8 .. 16 k-mers a wave each, bit 1 the library's k-mer sort, bit 2 head list in three kernels, bit 3 groups of 8 .. 16 replayed inside the pair kernel, bit 4 the library's unique + a row-pointer pass after the merge, bit 5 the k-mer walk on a 128-bit value, bit 6 every tip record's snapshot half rewritten every round, bit 7 a k-mer walk per round
     int    opt_own_sort = 1;                                // option "own_sort": the (key, id) sort of the index build is the engine's own radix sort (radix_sort.hip); 0: rocPRIM's
+    int    opt_test_presort_oom = 0;                        // tests only: the allocation of the supplement's look-ahead buffers reports out of memory (the rounds must go on one after the other)
     int    opt_test_pile_oom = 0;                           // tests only: the pile path's allocation reports out of memory (the build must continue on the pairwise kernels)
     bool   pile_timed = false;                              // EV_DIR was recorded in the last discovery (k_pile_build ran behind it)
     DevBuf cl_pile_succ;                                    // per entry (16 B): its id, the member of its own pile that starts next to its right, its place in the pile (k_pile_probe reads this, not the entry)
@@ -134,6 +135,7 @@ struct alga_engine {
         uint64_t E = 0, nk = 0;
         uint32_t n_tips = 0;
         int      pre_set = 0, cur_set = 0;     // which of the two sets (engine_pkb.hip: PkbSet) the look-ahead fills / the round at hand works on
+        bool     no_look_ahead = false;        // the look-ahead's buffers did not fit: this sequence runs its rounds one after the other
         int      pre_round = -1;               // the round whose sort -> repair -> heads were sent ahead on side_stream (their counts: h_counters + H_PRE), -1 none
         bool     kmers_all = false;            // the k-mer entries of every round are in pk_keys_all / pk_vals_all (made in round 0), kmers_stride entries apart
         size_t   kmers_stride = 0;

@@ -113,7 +113,7 @@ int pkb_begin(alga_engine *e, const alga_nodes *dn, const alga_pkb_params *p, co
     auto &st = e->pkb;
     st.phase = 0;
     if ((rc = pkb_drop_presort(e))) return rc;
-    st.cfg = make_cfg(p); st.dn = *dn; st.rounds = p->rounds; st.rank = rank; st.n_ranks = n_ranks; st.round = 0;
+    st.cfg = make_cfg(p); st.dn = *dn; st.rounds = p->rounds; st.rank = rank; st.n_ranks = n_ranks; st.round = 0; st.no_look_ahead = false;
     const NodesDev nd = nodes_dev(dn);
     const int32_t n = dn->n;
     const PkbCfg &c = st.cfg;
@@ -190,6 +190,7 @@ int pkb_presort(alga_engine *e, int round, int set, int sort_bits) {
     hipStream_t q = e->side_stream;
     PkbSet B = pkb_set(e, set);
     const size_t temp = rsort_u64_pairs_temp_bytes(nk);
+    if (e->opt_test_presort_oom) return alga_fail(e, ALGA_ERR_OUT_OF_MEMORY, "pkb_presort (option test_presort_oom)");
     for (DevBuf *b : {&B.keys2, &B.vals2})
         if ((rc = alga_ensure(e, *b, (nk + 1) * sizeof(unsigned long long)))) return rc;
     for (DevBuf *b : {&B.heads, &B.hsz})
@@ -334,7 +335,18 @@ int pkb_round(alga_engine *e, hipStream_t s, const unsigned long long **d_add, u
     }
     big_words = e->h_counters[1];
     n_heads = (uint32_t) e->h_counters[12];
-    if (look_ahead && round + 1 < st.rounds && (rc = pkb_presort(e, round + 1, set ^ 1, sort_bits))) return rc;
+    if (look_ahead && !st.no_look_ahead && round + 1 < st.rounds && (rc = pkb_presort(e, round + 1, set ^ 1, sort_bits))) {
+        // The look-ahead wants a second set of sorted entries and sort scratch (~50 B per k-mer entry): an input that fitted without it must not fail
+        // because of it.  Its allocations come before its first launch: nothing is in flight; give the second set back, go on round by round.
+        if (rc != ALGA_ERR_OUT_OF_MEMORY) return rc;
+        (void) hipGetLastError();
+        if ((set ^ 1) == 1)                                                    // (the second set is not the one this round works on)
+            for (DevBuf *b : {&e->pk_keys2b, &e->pk_vals2b, &e->pk_headsb, &e->pk_hszb}) alga_release(*b);
+        for (DevBuf *b : {&e->sort_temp2, &e->pk_fixlist2, &e->pk_cnt2}) alga_release(*b);
+        e->err.clear();
+        st.no_look_ahead = true; st.pre_round = -1;
+        rc = ALGA_OK;
+    }
     e->pkb_stats.groups[round] = n_heads;
     e->pkb_stats.max_group = std::max<uint64_t>(e->pkb_stats.max_group, e->h_counters[3]);             // exact for groups of more than 64
     if (!n_heads) return ALGA_OK;

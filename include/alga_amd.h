@@ -201,6 +201,8 @@ int         alga_engine_device_name(const alga_engine *e, char *buf, size_t bufl
  *                                half rewritten every round, 128 a k-mer walk per round (now all rounds in one), 256 a device-to-host copy per count the
  *                                host waits for (now one small kernel per wait writes them into the pinned block), 512 no look-ahead (now the next round's
  *                                k-mer entries are sorted and their groups listed on a second stream beside the round's group joins and merge)
+ *   "test_presort_oom"           tests only.  != 0: the allocation of the supplement's look-ahead buffers (a second set of sorted k-mer entries and sort scratch,
+ *                                ~50 B per entry) answers ALGA_ERR_OUT_OF_MEMORY: the sequence must give them back and run its rounds one after the other
  *   "test_pile_oom"              tests only.  != 0: the allocation of the pile path's own buffers (~180 B per node) answers ALGA_ERR_OUT_OF_MEMORY: the build
  *                                must give them back and finish on the pairwise kernels (what a real out-of-memory there does)
  *   "test_unsorted_index"        tests only.  != 0: the CLUSTER probe's entry directory is built over UNSORTED keys; the directory pass

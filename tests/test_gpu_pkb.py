@@ -280,6 +280,30 @@ def test_supplement_look_ahead_with_fewer_rounds_and_a_sequence_given_up(eng, ro
     assert whole.shape == ref.shape and (whole == ref).all()
 
 
+def test_supplement_goes_on_serially_when_the_look_ahead_buffers_do_not_fit(eng):
+    """The look-ahead needs a second set of sorted k-mer entries and sort scratch: when their allocation fails (option test_presort_oom stands in for a
+    real out-of-memory there) the sequence gives them back and runs its rounds one after the other -- same graph, no error left behind."""
+    codes, lens = gen_reads.sample_reads(4000, 150, 9000, 77, 0.02)
+    rc = (3 - codes)[:, ::-1]
+    codes = np.stack([rc, codes], axis=1).reshape(-1, 150)[:, 3:147]
+    lens = np.full(len(codes), 144, dtype=np.int32)
+    words = alga_amd.pack_reads(codes, lens)
+    pre = eng.prefsuf_host(words, lens, 82, 116)
+    p = eng.pkb_params(144.0, 0.02, 54)
+    want = eng.pkb_supplement_host(words, lens, pre, p)
+    s_want = eng.pkb_last_stats()
+    eng.set_option("test_presort_oom", 1)
+    try:
+        got = eng.pkb_supplement_host(words, lens, pre, p)
+        s_got = eng.pkb_last_stats()
+    finally:
+        eng.set_option("test_presort_oom", 0)
+    assert got.shape == want.shape and (got == want).all() and len(got) > len(pre)
+    assert s_got["groups"] == s_want["groups"] and s_got["can_align_calls"] == s_want["can_align_calls"]
+    again = eng.pkb_supplement_host(words, lens, pre, p)                      # (and with the look-ahead again afterwards)
+    assert (again == want).all()
+
+
 def test_supplement_rejects_offsets_it_cannot_represent(eng):
     """the edge merge packs (src, dst, offset) into 64 bits with 9 bits of offset: an edge outside that range is an error, not a
     silently different graph"""
