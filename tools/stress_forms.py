@@ -97,7 +97,7 @@ def main():
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
     eng = alga_amd.Engine(0)
     used, declined, bad = 0, 0, 0
-    big = generic = clustered = piled = pile_kept = pile_forced = 0
+    big = generic = clustered = piled = pile_kept = pile_forced = ranged_builds = 0
     for seed in range(first, first + n_cases):
         words, lens, lo, rs, af, at, desc = make_case(seed)
         a = eng.prefsuf_host(words, lens, lo, rs, af, at, reduction="per_target")
@@ -148,8 +148,36 @@ def main():
             if a.shape != c.shape or not (a == c).all():
                 bad += 1
                 print("MISMATCH pile", mode, desc, a.shape, c.shape, flush=True)
-    print("cases %d: source-side used %d (all-pairs branch in %d, second pass in %d, clustered probe in %d; pile path sampled in %d, kept the build in %d, forced through it in %d), declined %d, mismatches %d" %
-          (n_cases, used, generic, big, clustered, piled, pile_kept, pile_forced, declined, bad))
+        # ... and for a rank's share (round 5): the sources dealt out by id range -- random cuts, any parity -- through the piles, pure (2) and mixed (3)
+        # form; a range is a build of its own (keys_shared 0) or a further piece of the build before it (keys_shared 2), at random
+        if PILE_DOMAIN and st["ms_pile"] > 0:
+            import torch
+            from alga_amd.engine import device_view
+            rng = np.random.default_rng(seed + 7)
+            n = len(lens)
+            stride = words.shape[1]
+            dw = torch.from_numpy(np.ascontiguousarray(words).view(np.int32).reshape(n, stride)).cuda()
+            dl = torch.from_numpy(lens.astype(np.int32)).cuda()
+            for mode in (2, 3):
+                cuts = sorted(set([0, n] + [int(x) for x in rng.integers(1, n, size=int(rng.integers(1, 5)))]))
+                eng.set_option("probe", "cluster")
+                eng.set_option("pile", mode)
+                try:
+                    parts = []
+                    for k, (lo_id, hi_id) in enumerate(zip(cuts[:-1], cuts[1:])):
+                        ks = 2 if (k > 0 and rng.random() < 0.5) else 0
+                        r = eng.build_range_device(dw, dl, lo, rs, lo_id, hi_id, keys_shared=ks)
+                        ranged_builds += 1
+                        parts.append(device_view(r[0], (r[1], 3), dw.device).cpu().numpy().astype(a.dtype))
+                finally:
+                    eng.set_option("probe", "auto")
+                    eng.set_option("pile", 1)
+                c = np.concatenate(parts) if parts else a[:0]
+                if a.shape != c.shape or not (a == c).all():
+                    bad += 1
+                    print("MISMATCH pile ranges", mode, cuts, desc, a.shape, c.shape, flush=True)
+    print("cases %d: source-side used %d (all-pairs branch in %d, second pass in %d, clustered probe in %d; pile path sampled in %d, kept the build in %d, forced through it in %d, %d builds of id ranges through it), declined %d, mismatches %d" %
+          (n_cases, used, generic, big, clustered, piled, pile_kept, pile_forced, ranged_builds, declined, bad))
     sys.exit(1 if bad else 0)
 
 
