@@ -6,6 +6,8 @@
 #   B : one rank's compute at world sizes 2 / 4 / 8 on one GPU (replicated index: tools/emulate_rank.py; bucket-sharded: tools/emulate_shard.py)
 #   C : full-size parity on THIS tree against the recorded reference dumps (sha256): 50 M reads error-free, 10 M reads with 2 % errors
 # usage: tools/final_measure_r05.sh A1|A2|B|C
+# (A1 and A2 each rewrite ONE config's entry of profiles/hbm_traffic.json on the box; run as separate gpurun calls, copy gpurun_out/r05_final/hbm_traffic.json
+#  into profiles/ after A1 and before A2 -- or regenerate an entry from the merged counter files: tools/pmc_to_traffic.py gpurun_out/prof_r05_final_<cfg> <cfg> --builds=7)
 set -u
 PART=${1:-A1}
 REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
