@@ -119,6 +119,23 @@ def test_north_star_50M_reads_properties(config, nodes, edges):
         assert _pile_kept(stp) and torch.equal(cl, pl)
         assert stp["pile_list_checked"] > n // 2 and stp["pile_list_mismatch"] == 0, stp
         del pl
+        # a rank's share through the piles at this size (round 5): the sources as three ranks get them, each range a build of
+        # its own, the second cut in two pieces (the later one reuses the piles: keys_shared 2) -- concatenated: the same list
+        if config == "cfg4_50M_150bp":
+            b = [0, (n // 3) | 1, 2 * (n // 3), n]                                          # (an odd border: ranges need not respect the twin pairs)
+            mid = (b[1] + b[2]) // 2
+            at = 0
+            for a0, a1, ks in ((b[0], b[1], 0), (b[1], mid, 0), (mid, b[2], 2), (b[2], b[3], 0)):
+                eng.set_option("probe", "auto")
+                ptr, m = eng.build_range_device(wl["words"], wl["lens"], lo, wl["rsoemo"], a0, a1, keys_shared=ks)
+                torch.cuda.synchronize()
+                stp = eng.last_stats()
+                part = device_view(ptr, (m, 3), wl["words"].device)
+                assert stp["pile_buckets"] > 0 and stp["probe_used"] == 2, stp
+                assert torch.equal(part, cl[at:at + m]), "the range [%d, %d) through the piles differs from the whole build" % (a0, a1)
+                assert m == 0 or (int(part[0, 0]) >= a0 and int(part[-1, 0]) < a1)
+                at += m
+            assert at == edges
     finally:
         eng.close()
 
